@@ -1,0 +1,37 @@
+# Builds exp_amd/libexp_amd.so (HIP, gfx950) in-tree and the CPU oracle (test infrastructure).
+#   make -j8            library + oracle
+#   make lib            library only
+HIPCC    ?= hipcc
+ARCH     ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -munsafe-fp-atomics -Wall \
+            -Rpass-analysis=kernel-resource-usage
+OBJ      := build/obj
+CSRC     := exp_amd/csrc
+SPH_LS   := 0 1 2 3 4 5 6 7 8 9 10 11 12
+
+BASE_SRC := $(filter-out $(CSRC)/sph_inst.hip,$(wildcard $(CSRC)/*.hip))
+BASE_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(BASE_SRC))
+INST_OBJ := $(foreach l,$(SPH_LS),$(OBJ)/sph_inst_L$(l).o)
+HDRS     := $(wildcard $(CSRC)/*.h) include/exp_amd.h
+
+all: lib oracle
+lib: exp_amd/libexp_amd.so
+oracle:
+	$(MAKE) -C oracle
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJ) build/log
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@ 2> build/log/$*.log || (grep -A8 -E "error" build/log/$*.log; exit 1)
+
+$(OBJ)/sph_inst_L%.o: $(CSRC)/sph_inst.hip $(HDRS)
+	@mkdir -p $(OBJ) build/log
+	$(HIPCC) $(HIPFLAGS) -DSPH_L=$* -c $< -o $@ 2> build/log/sph_inst_L$*.log || (grep -A8 -E "error" build/log/sph_inst_L$*.log; exit 1)
+
+exp_amd/libexp_amd.so: $(BASE_OBJ) $(INST_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
+
+clean:
+	rm -rf build exp_amd/libexp_amd.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

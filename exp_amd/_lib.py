@@ -1,0 +1,115 @@
+"""ctypes binding of libexp_amd.so (the C ABI declared in include/exp_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+usable, every entry point raises.  The library must be built in-tree
+(``make -j8`` or ``__graft_entry__.build()``)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_longlong, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexp_amd.so")
+
+c_double_p = POINTER(c_double)
+
+
+class ExpAmdError(RuntimeError):
+    pass
+
+
+class SphConfig(ctypes.Structure):
+    """exp_amd_sph_config (include/exp_amd.h)"""
+    _fields_ = [("lmax", c_int), ("nmax", c_int), ("numr", c_int), ("cmap", c_int),
+                ("rmap", c_double), ("scale", c_double), ("rmin", c_double), ("rmax", c_double),
+                ("xmin", c_double), ("dxi", c_double),
+                ("NO_L0", c_int), ("NO_L1", c_int), ("EVEN_L", c_int), ("EVEN_M", c_int),
+                ("M0_only", c_int), ("multistep", c_int)]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_size_t, c_void_p, c_void_p)
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "exp_amd_abi_version": (c_int, []),
+    "exp_amd_last_error": (c_char_p, [c_void_p]),
+    "exp_amd_last_global_error": (c_char_p, []),
+    "exp_amd_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "exp_amd_ctx_destroy": (None, [c_void_p]),
+    "exp_amd_ctx_synchronize": (c_int, [c_void_p]),
+    "exp_amd_ctx_stream": (c_void_p, [c_void_p]),
+    "exp_amd_comm_get_unique_id": (c_int, [c_void_p]),
+    "exp_amd_comm_init_rank": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "exp_amd_comm_set_callback": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
+    "exp_amd_comp_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "exp_amd_comp_destroy": (None, [c_void_p]),
+    "exp_amd_comp_size": (c_size_t, [c_void_p]),
+    "exp_amd_comp_upload": (c_int, [c_void_p] + [c_void_p] * 7),
+    "exp_amd_comp_upload_acc": (c_int, [c_void_p] + [c_void_p] * 4),
+    "exp_amd_comp_upload_levels": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_comp_download": (c_int, [c_void_p] + [c_void_p] * 11),
+    "exp_amd_comp_download_levels": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_comp_upload_device": (c_int, [c_void_p] + [c_void_p] * 7),
+    "exp_amd_comp_set_center": (c_int, [c_void_p, c_double_p]),
+    "exp_amd_comp_drift": (c_int, [c_void_p, c_double, c_int]),
+    "exp_amd_comp_kick": (c_int, [c_void_p, c_double, c_int]),
+    "exp_amd_comp_zero_acc": (c_int, [c_void_p, c_int]),
+    "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
+                                   c_void_p, POINTER(c_void_p)]),
+    "exp_amd_force_destroy": (None, [c_void_p]),
+    "exp_amd_force_set_level": (c_int, [c_void_p, c_int]),
+    "exp_amd_force_determine_coefficients": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_force_get_coefs": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "exp_amd_force_set_coefs": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "exp_amd_force_ncoef": (c_size_t, [c_void_p]),
+    "exp_amd_force_used": (c_int, [c_void_p, POINTER(c_longlong)]),
+    "exp_amd_force_get_acceleration": (c_int, [c_void_p, c_void_p, c_int]),
+    "exp_amd_force_multistep_reset": (c_int, [c_void_p]),
+    "exp_amd_force_compute_multistep_coefficients": (c_int, [c_void_p, c_int]),
+    "exp_amd_step_kdk": (c_int, [c_void_p, c_void_p, c_double]),
+    "exp_amd_profile_enable": (c_int, [c_void_p, c_int]),
+    "exp_amd_profile_get": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double),
+                                    POINTER(c_longlong)]),
+    "exp_amd_profile_reset": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libexp_amd.so and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExpAmdError(
+            f"{LIB_PATH} is missing: build the HIP extension first (`make -j8` at the repo "
+            "root or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "exp_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.exp_amd_last_error(ctx) if ctx else lib.exp_amd_last_global_error()
+        raise ExpAmdError(f"exp_amd error {rc}: {msg.decode() if msg else '?'}")
+
+
+def as_f64(a, n=None):
+    """Contiguous float64 view/copy + its pointer (None stays None)."""
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and arr.size != n:
+        raise ValueError(f"array of length {arr.size}, expected {n}")
+    return arr, arr.ctypes.data_as(c_void_p)

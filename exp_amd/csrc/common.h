@@ -1,0 +1,86 @@
+// Shared host-side plumbing of libexp_amd: context, device buffers, error handling,
+// per-kernel HIP-event profiling.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/exp_amd.h"
+
+#define EXPAMD_WAVE 64
+
+struct ProfileSlot {
+  const char *name;
+  double ms_total = 0.0;
+  long long launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct exp_amd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // collectives
+  void *rccl_lib = nullptr;
+  void *rccl_comm = nullptr;
+  int nranks = 1, rank = 0;
+  exp_amd_allreduce_fn ar_fn = nullptr;
+  void *ar_user = nullptr;
+  // profiling
+  bool profile = false;
+  std::vector<ProfileSlot> slots;
+  std::vector<hipEvent_t> event_pool;
+  int num_cu = 256;
+};
+
+extern thread_local std::string g_exp_amd_global_err;
+
+int expamd_fail(exp_amd_ctx *ctx, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                               \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess)                                                               \
+      return expamd_fail((ctx), EXP_AMD_ERR_HIP, "%s failed: %s (%s:%d)", #call,         \
+                         hipGetErrorString(e__), __FILE__, __LINE__);                    \
+  } while (0)
+
+// RAII-less simple device buffer (freed explicitly by owners' destructors)
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// Scoped kernel timer: records a pair of events around a launch when profiling is on.
+struct ProfScope {
+  exp_amd_ctx *ctx;
+  int slot = -1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(exp_amd_ctx *c, const char *name);
+  ~ProfScope();
+};
+
+int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

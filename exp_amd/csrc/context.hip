@@ -1,0 +1,248 @@
+// Context, error reporting, profiling and the coefficient all-reduce of libexp_amd.
+#include "common.h"
+
+#include <dlfcn.h>
+
+thread_local std::string g_exp_amd_global_err;
+
+int expamd_fail(exp_amd_ctx *ctx, int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  g_exp_amd_global_err = buf;
+  return code;
+}
+
+extern "C" int exp_amd_abi_version(void) { return 1; }
+
+extern "C" const char *exp_amd_last_error(const exp_amd_ctx *ctx)
+{
+  return ctx ? ctx->err.c_str() : g_exp_amd_global_err.c_str();
+}
+
+extern "C" const char *exp_amd_last_global_error(void) { return g_exp_amd_global_err.c_str(); }
+
+extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
+{
+  if (!out) return expamd_fail(nullptr, EXP_AMD_ERR_ARG, "ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return expamd_fail(nullptr, EXP_AMD_ERR_NODEVICE,
+                       "ctx_create: no HIP device available (%s); the BFE hot path has no "
+                       "CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return expamd_fail(nullptr, EXP_AMD_ERR_ARG, "ctx_create: device %d out of range [0,%d)",
+                       device, ndev);
+  exp_amd_ctx *ctx = new exp_amd_ctx;
+  ctx->device = device;
+  HIP_TRY(ctx, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      int rc = expamd_fail(nullptr, EXP_AMD_ERR_HIP, "hipStreamCreate failed: %s",
+                           hipGetErrorString(e));
+      delete ctx;
+      return rc;
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return EXP_AMD_OK;
+}
+
+extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->slots)
+    for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  if (ctx->rccl_comm && ctx->rccl_lib) {
+    typedef int (*destroy_fn)(void *);
+    destroy_fn d = (destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
+    if (d) d(ctx->rccl_comm);
+  }
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int exp_amd_ctx_synchronize(exp_amd_ctx *ctx)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" void *exp_amd_ctx_stream(exp_amd_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- profiling ---------------------------------------------------------------------------
+
+static hipEvent_t get_event(exp_amd_ctx *ctx)
+{
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(exp_amd_ctx *c, const char *name) : ctx(c)
+{
+  if (!ctx || !ctx->profile) return;
+  for (size_t i = 0; i < ctx->slots.size(); i++)
+    if (ctx->slots[i].name == name || !strcmp(ctx->slots[i].name, name)) { slot = (int)i; break; }
+  if (slot < 0) {
+    ProfileSlot s;
+    s.name = name;
+    ctx->slots.push_back(s);
+    slot = (int)ctx->slots.size() - 1;
+  }
+  e0 = get_event(ctx);
+  e1 = get_event(ctx);
+  (void)hipEventRecord(e0, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+  if (slot < 0) return;
+  (void)hipEventRecord(e1, ctx->stream);
+  ctx->slots[slot].pending.emplace_back(e0, e1);
+}
+
+static void drain_profile(exp_amd_ctx *ctx)
+{
+  for (auto &s : ctx->slots) {
+    for (auto &p : s.pending) {
+      (void)hipEventSynchronize(p.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+        s.ms_total += ms;
+        s.launches += 1;
+      }
+      ctx->event_pool.push_back(p.first);
+      ctx->event_pool.push_back(p.second);
+    }
+    s.pending.clear();
+  }
+}
+
+extern "C" int exp_amd_profile_enable(exp_amd_ctx *ctx, int on)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->profile = on != 0;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_profile_get(exp_amd_ctx *ctx, int idx, const char **name, double *ms_total,
+                                   long long *launches)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  drain_profile(ctx);
+  if (idx < 0 || idx >= (int)ctx->slots.size()) return EXP_AMD_ERR_ARG;
+  if (name) *name = ctx->slots[idx].name;
+  if (ms_total) *ms_total = ctx->slots[idx].ms_total;
+  if (launches) *launches = ctx->slots[idx].launches;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_profile_reset(exp_amd_ctx *ctx)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  drain_profile(ctx);
+  for (auto &s : ctx->slots) { s.ms_total = 0.0; s.launches = 0; }
+  return EXP_AMD_OK;
+}
+
+// ---- collectives ---------------------------------------------------------------------------
+// RCCL is bound lazily with dlopen so that the library loads (and single-rank runs work)
+// on hosts without it.  Only ncclAllReduce(sum, double) on the coefficient buffer is used.
+
+typedef struct { char internal[128]; } rccl_unique_id;
+typedef int (*fn_get_uid)(rccl_unique_id *);
+typedef int (*fn_init_rank)(void **, int, rccl_unique_id, int);
+typedef int (*fn_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*fn_errstr)(int);
+
+static void *open_rccl()
+{
+  static void *lib = nullptr;
+  if (lib) return lib;
+  const char *names[] = {"librccl.so.1", "librccl.so", nullptr};
+  for (int i = 0; names[i] && !lib; i++) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  return lib;
+}
+
+extern "C" int exp_amd_comm_get_unique_id(void *id128)
+{
+  void *lib = open_rccl();
+  if (!lib) return expamd_fail(nullptr, EXP_AMD_ERR_COMM, "librccl not found: %s", dlerror());
+  fn_get_uid f = (fn_get_uid)dlsym(lib, "ncclGetUniqueId");
+  if (!f) return expamd_fail(nullptr, EXP_AMD_ERR_COMM, "ncclGetUniqueId missing");
+  rccl_unique_id id;
+  int rc = f(&id);
+  if (rc) return expamd_fail(nullptr, EXP_AMD_ERR_COMM, "ncclGetUniqueId -> %d", rc);
+  memcpy(id128, &id, sizeof(id));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int nranks, int rank)
+{
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_init_rank: bad arguments");
+  void *lib = open_rccl();
+  if (!lib) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "librccl not found: %s", dlerror());
+  fn_init_rank f = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+  if (!f) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclCommInitRank missing");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rccl_unique_id id;
+  memcpy(&id, id128, sizeof(id));
+  void *comm = nullptr;
+  int rc = f(&comm, nranks, id, rank);
+  if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclCommInitRank -> %d", rc);
+  ctx->rccl_lib = lib;
+  ctx->rccl_comm = comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn fn, void *user)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->ar_fn = fn;
+  ctx->ar_user = user;
+  return EXP_AMD_OK;
+}
+
+int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count)
+{
+  if (ctx->ar_fn) {
+    ProfScope ps(ctx, "allreduce(callback)");
+    int rc = ctx->ar_fn((void *)dev, count, (void *)ctx->stream, ctx->ar_user);
+    if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "all-reduce callback returned %d", rc);
+    return EXP_AMD_OK;
+  }
+  if (ctx->rccl_comm) {
+    ProfScope ps(ctx, "ncclAllReduce(coef)");
+    fn_allreduce f = (fn_allreduce)dlsym(ctx->rccl_lib, "ncclAllReduce");
+    if (!f) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce missing");
+    // ncclDouble = 8 (ncclFloat64), ncclSum = 0
+    int rc = f(dev, dev, count, 8, 0, ctx->rccl_comm, ctx->stream);
+    if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce -> %d", rc);
+  }
+  return EXP_AMD_OK;
+}

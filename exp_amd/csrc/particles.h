@@ -1,0 +1,30 @@
+// Particle store of one Component: fp64 SoA in HBM, ordered by (level, basis cell).
+#pragma once
+#include "common.h"
+
+enum { A_X = 0, A_Y, A_Z, A_VX, A_VY, A_VZ, A_M, A_AX, A_AY, A_AZ, A_POT, A_NARR };
+
+struct exp_amd_comp {
+  exp_amd_ctx *ctx = nullptr;
+  size_t n = 0;
+  int cur = 0;                       // which buffer set holds the live data
+  DevBuf<double> arr[2][A_NARR];     // ping-pong sets (scatter target = 1-cur)
+  DevBuf<uint32_t> id[2];            // original (caller) index of each slot
+  DevBuf<uint8_t> level[2];          // multistep level of each slot
+  DevBuf<uint32_t> key;              // sort key scratch
+  DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
+  DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
+  size_t hist_cap = 0;
+  int nlevels = 1;                   // multistep + 1
+  double center[3] = {0, 0, 0};
+  const void *sorted_for = nullptr;  // force whose cell order the store currently has
+  bool acc_live = true;              // acc/pot must survive a reorder
+
+  double *a(int k) { return arr[cur][k].p; }
+  double *b(int k) { return arr[1 - cur][k].p; }
+};
+
+// Reorder the store by key[] (values < nkeys).  Keys are (level * ncell + cell); level
+// offsets are refreshed from the scanned histogram.  All work is stream-ordered.
+int expamd_comp_sort_by_key(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell_per_level,
+                            bool move_acc);

@@ -1,0 +1,474 @@
+// Particle store: upload/download, leapfrog kick/drift, counting sort by (level, cell).
+//
+// Replaces (does not translate) src/cudaComponent.cu:621-792 (AoS mirror, zeroPotAccKernel,
+// thrust level sort), src/cudaIncpos.cu:9-29 (coordDrift) and src/cudaIncvel.cu:9-41
+// (velocityKick).  Layout is fp64 SoA so that every pass streams HBM with coalesced
+// 8-byte-per-lane loads; a level is a contiguous slot range [lev_off[M], lev_off[M+1]).
+#include "particles.h"
+
+#define TPB 256
+
+struct ArrSet {
+  double *p[A_NARR];
+  uint32_t *id;
+  uint8_t *lev;
+};
+
+// ---- leapfrog -------------------------------------------------------------------------------
+
+// src/incpos.cc:15-69 : pos[k] += vel[k]*dt
+__global__ void __launch_bounds__(TPB)
+k_drift(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+        const double *__restrict__ vx, const double *__restrict__ vy,
+        const double *__restrict__ vz, const uint32_t *__restrict__ lev_off, int lo, int hi,
+        double dt)
+{
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * TPB) {
+    x[i] += vx[i] * dt;
+    y[i] += vy[i] * dt;
+    z[i] += vz[i] * dt;
+  }
+}
+
+// src/incvel.cc:15-88 : vel[k] += acc[k]*dt
+__global__ void __launch_bounds__(TPB)
+k_kick(double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+       const double *__restrict__ ax, const double *__restrict__ ay,
+       const double *__restrict__ az, const uint32_t *__restrict__ lev_off, int lo, int hi,
+       double dt)
+{
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * TPB) {
+    vx[i] += ax[i] * dt;
+    vy[i] += ay[i] * dt;
+    vz[i] += az[i] * dt;
+  }
+}
+
+// src/ComponentContainer.cc:641-665
+__global__ void __launch_bounds__(TPB)
+k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
+           double *__restrict__ pot, const uint32_t *__restrict__ lev_off, int lo, int hi)
+{
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * TPB) {
+    ax[i] = 0.0;
+    ay[i] = 0.0;
+    az[i] = 0.0;
+    pot[i] = 0.0;
+  }
+}
+
+// ---- counting sort ---------------------------------------------------------------------------
+// Keys are nearly sorted from the previous step, so a wave holds only a handful of distinct
+// keys: one atomic per distinct key per wave (match-any by ballot) instead of one per lane.
+
+__device__ inline unsigned long long lanemask_lt()
+{
+  return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_hist(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  bool valid = i < n;
+  uint32_t k = valid ? key[i] : 0xffffffffu;
+  unsigned long long remaining = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  while (remaining) {
+    int lead = __ffsll((long long)remaining) - 1;
+    uint32_t kk = __shfl(k, lead);
+    unsigned long long m = __ballot(valid && k == kk);
+    if (lane == lead) atomicAdd(&hist[kk], (uint32_t)__popcll(m));
+    remaining &= ~m;
+  }
+}
+
+// exclusive scan of hist[0..nkeys) in place (single block); hist[nkeys] = total;
+// lev_off[L] = start of key L*ncell, lev_off[nlev] = total
+__global__ void __launch_bounds__(1024)
+k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
+       uint32_t ncell, int nlev)
+{
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const uint32_t per = (nkeys + 1023u) / 1024u;
+  const uint32_t b = t * per, e = min(nkeys, b + per);
+  uint32_t s = 0;
+  for (uint32_t k = b; k < e; k++) s += hist[k];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (t >= off) ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = (t == 0) ? 0u : part[t - 1];
+  for (uint32_t k = b; k < e; k++) {
+    uint32_t c = hist[k];
+    hist[k] = run;
+    if (k % ncell == 0) lev_off[k / ncell] = run;
+    run += c;
+  }
+  if (t == 1023) {
+    hist[nkeys] = part[1023];
+    lev_off[nlev] = part[1023];
+  }
+}
+
+template <bool MOVE_ACC>
+__global__ void __launch_bounds__(TPB)
+k_scatter(const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor, size_t n, ArrSet src,
+          ArrSet dst)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  bool valid = i < n;
+  uint32_t k = valid ? key[i] : 0xffffffffu;
+  unsigned long long remaining = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  uint32_t dest = 0;
+  while (remaining) {
+    int lead = __ffsll((long long)remaining) - 1;
+    uint32_t kk = __shfl(k, lead);
+    unsigned long long m = __ballot(valid && k == kk);
+    uint32_t base = 0;
+    if (lane == lead) base = atomicAdd(&cursor[kk], (uint32_t)__popcll(m));
+    base = __shfl(base, lead);
+    if (valid && k == kk) dest = base + (uint32_t)__popcll(m & lanemask_lt());
+    remaining &= ~m;
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int a = 0; a < A_NARR; a++) {
+    if (!MOVE_ACC && a >= A_AX) break;
+    dst.p[a][dest] = src.p[a][i];
+  }
+  dst.id[dest] = src.id[i];
+  dst.lev[dest] = src.lev[i];
+}
+
+__global__ void __launch_bounds__(TPB)
+k_iota(uint32_t *__restrict__ id, size_t n)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) id[i] = (uint32_t)i;
+}
+
+// out[id[i]] = in[i]  (return to the caller's order)
+__global__ void __launch_bounds__(TPB)
+k_unpermute_f64(const double *__restrict__ in, const uint32_t *__restrict__ id, size_t n,
+                double *__restrict__ out)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[id[i]] = in[i];
+}
+
+__global__ void __launch_bounds__(TPB)
+k_unpermute_lev(const uint8_t *__restrict__ in, const uint32_t *__restrict__ id, size_t n,
+                int32_t *__restrict__ out)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[id[i]] = (int32_t)in[i];
+}
+
+// in[j] is in caller order; slot i holds caller index id[i]
+__global__ void __launch_bounds__(TPB)
+k_permute_lev(const int32_t *__restrict__ in, const uint32_t *__restrict__ id, size_t n,
+              uint8_t *__restrict__ out)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)in[id[i]];
+}
+
+__global__ void __launch_bounds__(TPB)
+k_permute_f64(const double *__restrict__ in, const uint32_t *__restrict__ id, size_t n,
+              double *__restrict__ out)
+{
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[i] = in[id[i]];
+}
+
+static ArrSet arrset(exp_amd_comp *c, int which)
+{
+  ArrSet s;
+  for (int a = 0; a < A_NARR; a++) s.p[a] = c->arr[which][a].p;
+  s.id = c->id[which].p;
+  s.lev = c->level[which].p;
+  return s;
+}
+
+static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
+{
+  size_t want = (n + TPB - 1) / TPB;
+  size_t cap = (size_t)ctx->num_cu * 8;
+  return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+int expamd_comp_sort_by_key(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  if (c->hist_cap < (size_t)nkeys + 1) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
+    c->hist_cap = (size_t)nkeys + 1;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(c->hist.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), ctx->stream));
+  unsigned g = cdiv(c->n, TPB);
+  {
+    ProfScope ps(ctx, "k_hist");
+    k_hist<<<g, TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+  }
+  {
+    ProfScope ps(ctx, "k_scan");
+    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels);
+  }
+  {
+    ProfScope ps(ctx, "k_scatter");
+    ArrSet src = arrset(c, c->cur), dst = arrset(c, 1 - c->cur);
+    if (move_acc)
+      k_scatter<true><<<g, TPB, 0, ctx->stream>>>(c->key.p, c->hist.p, c->n, src, dst);
+    else
+      k_scatter<false><<<g, TPB, 0, ctx->stream>>>(c->key.p, c->hist.p, c->n, src, dst);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  c->cur = 1 - c->cur;
+  return EXP_AMD_OK;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------
+
+extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **out)
+{
+  if (!ctx || !out) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comp_create: NULL argument");
+  if (n >= 0xffffffffull) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comp_create: n too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  exp_amd_comp *c = new exp_amd_comp;
+  c->ctx = ctx;
+  c->n = n;
+  size_t na = n ? n : 1;
+  for (int w = 0; w < 2; w++) {
+    for (int a = 0; a < A_NARR; a++) {
+      hipError_t e = c->arr[w][a].alloc(na);
+      if (e != hipSuccess) {
+        exp_amd_comp_destroy(c);
+        return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed: %s",
+                           hipGetErrorString(e));
+      }
+    }
+    if (c->id[w].alloc(na) != hipSuccess || c->level[w].alloc(na) != hipSuccess) {
+      exp_amd_comp_destroy(c);
+      return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
+    }
+  }
+  if (c->key.alloc(na) != hipSuccess || c->lev_off.alloc(64) != hipSuccess) {
+    exp_amd_comp_destroy(c);
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
+  }
+  for (int a = 0; a < A_NARR; a++)
+    HIP_TRY(ctx, hipMemsetAsync(c->arr[0][a].p, 0, na * sizeof(double), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(c->level[0].p, 0, na, ctx->stream));
+  k_iota<<<cdiv(na, TPB), TPB, 0, ctx->stream>>>(c->id[0].p, n);
+  uint32_t lo[64];
+  for (int i = 0; i < 64; i++) lo[i] = (uint32_t)n;
+  lo[0] = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(c->lev_off.p, lo, sizeof(lo), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out = c;
+  return EXP_AMD_OK;
+}
+
+extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
+{
+  if (!c) return;
+  (void)hipStreamSynchronize(c->ctx->stream);
+  for (int w = 0; w < 2; w++) {
+    for (int a = 0; a < A_NARR; a++) c->arr[w][a].release();
+    c->id[w].release();
+    c->level[w].release();
+  }
+  c->key.release();
+  c->hist.release();
+  c->lev_off.release();
+  delete c;
+}
+
+extern "C" size_t exp_amd_comp_size(const exp_amd_comp *c) { return c ? c->n : 0; }
+
+static int upload_one(exp_amd_comp *c, int a, const double *h)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (!h) {
+    HIP_TRY(ctx, hipMemsetAsync(c->a(a), 0, c->n * sizeof(double), ctx->stream));
+    return EXP_AMD_OK;
+  }
+  // caller order -> current slot order through the scratch set
+  HIP_TRY(ctx, hipMemcpyAsync(c->b(a), h, c->n * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  k_permute_f64<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->b(a), c->id[c->cur].p, c->n, c->a(a));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const double *x,
+                                   const double *y, const double *z, const double *vx,
+                                   const double *vy, const double *vz)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  const double *h[7] = {x, y, z, vx, vy, vz, mass};
+  for (int a = 0; a < 7; a++) {
+    int rc = upload_one(c, a, h[a]);
+    if (rc) return rc;
+  }
+  HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+  c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
+                                       const double *az, const double *pot)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  const double *h[4] = {ax, ay, az, pot};
+  for (int a = 0; a < 4; a++) {
+    int rc = upload_one(c, A_AX + a, h[a]);
+    if (rc) return rc;
+  }
+  HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, const double *x,
+                                          const double *y, const double *z, const double *vx,
+                                          const double *vy, const double *vz)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  const double *d[7] = {x, y, z, vx, vy, vz, mass};
+  for (int a = 0; a < 7; a++) {
+    if (!d[a]) {
+      HIP_TRY(ctx, hipMemsetAsync(c->a(a), 0, c->n * sizeof(double), ctx->stream));
+    } else {
+      k_permute_f64<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(d[a], c->id[c->cur].p, c->n,
+                                                              c->a(a));
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)
+{
+  if (!c || !level) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  int32_t *tmp = (int32_t *)c->b(A_X);   // scratch (8 B per slot >= 4 B needed)
+  HIP_TRY(ctx, hipMemcpyAsync(tmp, level, c->n * sizeof(int32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  k_permute_lev<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(tmp, c->id[c->cur].p, c->n,
+                                                          c->level[c->cur].p);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  c->sorted_for = nullptr;   // level ranges are stale until the next sort
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, double *y,
+                                     double *z, double *vx, double *vy, double *vz, double *ax,
+                                     double *ay, double *az, double *pot)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  double *h[A_NARR] = {x, y, z, vx, vy, vz, mass, ax, ay, az, pot};
+  for (int a = 0; a < A_NARR; a++) {
+    if (!h[a]) continue;
+    k_unpermute_f64<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->a(a), c->id[c->cur].p, c->n,
+                                                              c->b(a));
+    HIP_TRY(ctx, hipMemcpyAsync(h[a], c->b(a), c->n * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
+{
+  if (!c || !level) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  int32_t *tmp = (int32_t *)c->b(A_X);
+  k_unpermute_lev<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->id[c->cur].p,
+                                                            c->n, tmp);
+  HIP_TRY(ctx, hipMemcpyAsync(level, tmp, c->n * sizeof(int32_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
+{
+  if (!c || !center) return EXP_AMD_ERR_ARG;
+  for (int k = 0; k < 3; k++) c->center[k] = center[k];
+  c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
+static void level_range(const exp_amd_comp *c, int mlevel, bool upward, int *lo, int *hi)
+{
+  if (mlevel < 0) { *lo = 0; *hi = c->nlevels - 1; }
+  else if (upward) { *lo = mlevel; *hi = c->nlevels - 1; }
+  else { *lo = mlevel; *hi = mlevel; }
+  if (*lo > c->nlevels - 1) *lo = c->nlevels - 1;
+}
+
+extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  int lo, hi;
+  level_range(c, mlevel, false, &lo, &hi);
+  ProfScope ps(c->ctx, "k_drift");
+  k_drift<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
+      c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->lev_off.p, lo, hi,
+      dt);
+  HIP_TRY(c->ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  int lo, hi;
+  level_range(c, mlevel, false, &lo, &hi);
+  ProfScope ps(c->ctx, "k_kick");
+  k_kick<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
+      c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->lev_off.p, lo,
+      hi, dt);
+  HIP_TRY(c->ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  int lo, hi;
+  level_range(c, mlevel, true, &lo, &hi);
+  ProfScope ps(c->ctx, "k_zero_acc");
+  k_zero_acc<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
+      c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->lev_off.p, lo, hi);
+  HIP_TRY(c->ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}

@@ -1,0 +1,288 @@
+"""Host-side mirror of EXP's force-method interface over the C ABI.
+
+Class and method names follow the reference so that callers read the same:
+
+* ``Component``       <- ``Component`` particle accessors / CUDA mirror
+                         (``src/Component.H:738-760``, ``src/cudaComponent.cu:621-727``)
+* ``SphereSL``        <- ``Sphere : SphericalBasis : PotAccel``
+                         (``src/Sphere.cc:28-96``, ``src/PotAccel.H:173-288``)
+* ``incr_position`` / ``incr_velocity`` <- ``src/incpos.cc:72``, ``src/incvel.cc:90``
+
+Everything numeric happens in libexp_amd.so on the GPU; this file only marshals
+arguments (numpy host arrays or torch device tensors) and keeps object lifetimes.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_char_p, c_double, c_int, c_longlong, c_void_p
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import SphConfig, as_f64, check
+from .slgrid import SLGridSph
+
+
+class Context:
+    """One GPU + one HIP stream (``exp_amd_ctx``)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = c_void_p()
+        check(self.lib.exp_amd_ctx_create(int(device), c_void_p(stream) if stream else None,
+                                          byref(h)))
+        self.h = h
+        self.device = device
+        self._cb = None
+        self._children = []
+
+    # -- collectives ---------------------------------------------------------------------
+    def set_allreduce(self, fn) -> None:
+        """fn(ptr:int, count:int, stream:int) reduces `count` doubles in place (SUM)."""
+        if fn is None:
+            self._cb = None
+            check(self.lib.exp_amd_comm_set_callback(self.h, _lib.ALLREDUCE_FN(), None), self.h)
+            return
+
+        def tramp(buf, count, stream, user):
+            try:
+                fn(int(buf), int(count), int(stream or 0))
+                return 0
+            except Exception as e:  # pragma: no cover - surfaced through the C error path
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = _lib.ALLREDUCE_FN(tramp)
+        check(self.lib.exp_amd_comm_set_callback(self.h, self._cb, None), self.h)
+
+    def init_rccl(self, unique_id: bytes, nranks: int, rank: int) -> None:
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        check(self.lib.exp_amd_comm_init_rank(self.h, buf, nranks, rank), self.h)
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(128)
+        check(lib.exp_amd_comm_get_unique_id(buf))
+        return buf.raw
+
+    def synchronize(self) -> None:
+        check(self.lib.exp_amd_ctx_synchronize(self.h), self.h)
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.exp_amd_ctx_stream(self.h) or 0)
+
+    # -- profiling -----------------------------------------------------------------------
+    def profile(self, on: bool = True) -> None:
+        check(self.lib.exp_amd_profile_enable(self.h, int(on)), self.h)
+
+    def profile_reset(self) -> None:
+        check(self.lib.exp_amd_profile_reset(self.h), self.h)
+
+    def profile_report(self) -> dict:
+        out = {}
+        i = 0
+        while True:
+            name = c_char_p()
+            ms = c_double()
+            cnt = c_longlong()
+            if self.lib.exp_amd_profile_get(self.h, i, byref(name), byref(ms), byref(cnt)) != 0:
+                break
+            out[name.value.decode()] = {"ms_total": ms.value, "launches": cnt.value}
+            i += 1
+        return out
+
+    def close(self) -> None:
+        if self.h:
+            for ch in list(self._children):
+                ch.close()
+            self.lib.exp_amd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Component:
+    """Particle store of one component (fp64 SoA in HBM)."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.lib, self.n = ctx, ctx.lib, int(n)
+        h = c_void_p()
+        check(self.lib.exp_amd_comp_create(ctx.h, self.n, byref(h)), ctx.h)
+        self.h = h
+        ctx._children.append(self)
+
+    @classmethod
+    def from_arrays(cls, ctx: Context, mass, pos, vel=None) -> "Component":
+        pos = np.asarray(pos, dtype=np.float64)
+        c = cls(ctx, pos.shape[0])
+        c.upload(mass, pos, vel)
+        return c
+
+    def upload(self, mass, pos, vel=None) -> None:
+        pos = np.asarray(pos, dtype=np.float64)
+        keep = [as_f64(mass, self.n)] + [as_f64(pos[:, k], self.n) for k in range(3)]
+        if vel is not None:
+            vel = np.asarray(vel, dtype=np.float64)
+            keep += [as_f64(vel[:, k], self.n) for k in range(3)]
+        else:
+            keep += [(None, None)] * 3
+        p = [k[1] for k in keep]
+        check(self.lib.exp_amd_comp_upload(self.h, *p), self.ctx.h)
+
+    def upload_device(self, mass, x, y, z, vx=None, vy=None, vz=None) -> None:
+        """Adopt torch CUDA tensors (float64, contiguous, length n) already in HBM."""
+        ptrs = []
+        for t in (mass, x, y, z, vx, vy, vz):
+            if t is None:
+                ptrs.append(None)
+                continue
+            assert t.is_cuda and t.is_contiguous() and t.numel() == self.n and t.element_size() == 8
+            ptrs.append(c_void_p(t.data_ptr()))
+        import torch
+        torch.cuda.current_stream().synchronize()
+        check(self.lib.exp_amd_comp_upload_device(self.h, *ptrs), self.ctx.h)
+
+    def upload_acc(self, acc, pot=None) -> None:
+        acc = np.asarray(acc, dtype=np.float64)
+        keep = [as_f64(acc[:, k], self.n) for k in range(3)] + [as_f64(pot, self.n)]
+        check(self.lib.exp_amd_comp_upload_acc(self.h, *[k[1] for k in keep]), self.ctx.h)
+
+    def upload_levels(self, level) -> None:
+        lv = np.ascontiguousarray(level, dtype=np.int32)
+        assert lv.size == self.n
+        check(self.lib.exp_amd_comp_upload_levels(self.h, lv.ctypes.data_as(c_void_p)), self.ctx.h)
+
+    def download(self, fields: Sequence[str] = ("mass", "pos", "vel", "acc", "pot")) -> dict:
+        n = self.n
+        bufs = {k: np.empty(n) for k in ("mass", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az",
+                                         "pot")}
+        want = set()
+        if "mass" in fields: want |= {"mass"}
+        if "pos" in fields: want |= {"x", "y", "z"}
+        if "vel" in fields: want |= {"vx", "vy", "vz"}
+        if "acc" in fields: want |= {"ax", "ay", "az"}
+        if "pot" in fields: want |= {"pot"}
+        order = ("mass", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "pot")
+        ptrs = [bufs[k].ctypes.data_as(c_void_p) if k in want else None for k in order]
+        check(self.lib.exp_amd_comp_download(self.h, *ptrs), self.ctx.h)
+        out = {}
+        if "mass" in fields: out["mass"] = bufs["mass"]
+        if "pos" in fields: out["pos"] = np.stack([bufs["x"], bufs["y"], bufs["z"]], 1)
+        if "vel" in fields: out["vel"] = np.stack([bufs["vx"], bufs["vy"], bufs["vz"]], 1)
+        if "acc" in fields: out["acc"] = np.stack([bufs["ax"], bufs["ay"], bufs["az"]], 1)
+        if "pot" in fields: out["pot"] = bufs["pot"]
+        return out
+
+    def download_levels(self) -> np.ndarray:
+        lv = np.empty(self.n, dtype=np.int32)
+        check(self.lib.exp_amd_comp_download_levels(self.h, lv.ctypes.data_as(c_void_p)), self.ctx.h)
+        return lv
+
+    def set_center(self, center) -> None:
+        c = (c_double * 3)(*[float(v) for v in center])
+        check(self.lib.exp_amd_comp_set_center(self.h, c), self.ctx.h)
+
+    # src/incpos.cc:72, src/incvel.cc:90
+    def incr_position(self, dt: float, mlevel: int = -1) -> None:
+        check(self.lib.exp_amd_comp_drift(self.h, float(dt), int(mlevel)), self.ctx.h)
+
+    def incr_velocity(self, dt: float, mlevel: int = -1) -> None:
+        check(self.lib.exp_amd_comp_kick(self.h, float(dt), int(mlevel)), self.ctx.h)
+
+    def zero_acceleration(self, mlevel: int = 0) -> None:
+        check(self.lib.exp_amd_comp_zero_acc(self.h, int(mlevel)), self.ctx.h)
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.exp_amd_comp_destroy(self.h)
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+
+class SphereSL:
+    """``sphereSL`` force method: spherical-harmonic x Sturm-Liouville BFE."""
+
+    def __init__(self, ctx: Context, grid: SLGridSph, scale: float = 1.0,
+                 rmin: Optional[float] = None, rmax: Optional[float] = None,
+                 NO_L0=False, NO_L1=False, EVEN_L=False, EVEN_M=False, M0_only=False,
+                 multistep: int = 0):
+        self.ctx, self.lib, self.grid = ctx, ctx.lib, grid
+        # Sphere::Sphere: rmin/rmax are taken from the SL grid (src/Sphere.cc:65-67)
+        self.rmin = grid.rmin if rmin is None else rmin
+        self.rmax = grid.rmax if rmax is None else rmax
+        self.cfg = SphConfig(grid.lmax, grid.nmax, grid.numr, grid.cmap, grid.rmap, scale,
+                             self.rmin, self.rmax, grid.xmin, grid.dxi, int(NO_L0), int(NO_L1),
+                             int(EVEN_L), int(EVEN_M), int(M0_only), int(multistep))
+        keep = [as_f64(grid.xi), as_f64(grid.p0), as_f64(grid.ev), as_f64(grid.ef)]
+        h = c_void_p()
+        check(self.lib.exp_amd_sph_create(ctx.h, byref(self.cfg), *[k[1] for k in keep], byref(h)),
+              ctx.h)
+        self.h = h
+        self.lmax, self.nmax = grid.lmax, grid.nmax
+        self.nrows = (grid.lmax + 1) ** 2
+        self.multistep = multistep
+        ctx._children.append(self)
+
+    # PotAccel interface -------------------------------------------------------------------
+    def set_multistep_level(self, mlevel: int) -> None:
+        check(self.lib.exp_amd_force_set_level(self.h, int(mlevel)), self.ctx.h)
+
+    def determine_coefficients(self, comp: Component) -> None:
+        check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
+
+    def get_acceleration_and_potential(self, comp: Component, external: bool = False) -> None:
+        check(self.lib.exp_amd_force_get_acceleration(self.h, comp.h, int(external)), self.ctx.h)
+
+    def compute_multistep_coefficients(self, mdrft: int) -> None:
+        check(self.lib.exp_amd_force_compute_multistep_coefficients(self.h, int(mdrft)), self.ctx.h)
+
+    def multistep_reset(self) -> None:
+        check(self.lib.exp_amd_force_multistep_reset(self.h), self.ctx.h)
+
+    def Used(self) -> int:
+        u = c_longlong()
+        check(self.lib.exp_amd_force_used(self.h, byref(u)), self.ctx.h)
+        return int(u.value)
+
+    def get_coefs(self) -> np.ndarray:
+        out = np.empty((self.nrows, self.nmax))
+        check(self.lib.exp_amd_force_get_coefs(self.h, out.ctypes.data_as(c_void_p), out.size),
+              self.ctx.h)
+        return out
+
+    def set_coefs(self, coef) -> None:
+        c = np.ascontiguousarray(coef, dtype=np.float64)
+        assert c.size == self.nrows * self.nmax
+        check(self.lib.exp_amd_force_set_coefs(self.h, c.ctypes.data_as(c_void_p), c.size),
+              self.ctx.h)
+
+    def step_kdk(self, comp: Component, dt: float) -> None:
+        """One multistep=0 KDK step (src/step.cc:271-323), fused."""
+        check(self.lib.exp_amd_step_kdk(self.h, comp.h, float(dt)), self.ctx.h)
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.exp_amd_force_destroy(self.h)
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+
+def do_step_single(force: SphereSL, comp: Component, dt: float) -> None:
+    """Unfused multistep=0 step, call for call as ``do_step`` (src/step.cc:271-323)."""
+    comp.incr_velocity(0.5 * dt)
+    comp.incr_position(dt)
+    force.set_multistep_level(0)
+    force.determine_coefficients(comp)
+    comp.zero_acceleration(0)
+    force.get_acceleration_and_potential(comp)
+    comp.incr_velocity(0.5 * dt)

@@ -1,0 +1,168 @@
+/*
+ * exp_amd.h -- C ABI of the MI355X-native BFE hot path (libexp_amd.so).
+ *
+ * This is the drop-in boundary: plain C, opaque handles, caller-owned host buffers,
+ * library-owned device buffers, every call returns an int status (0 = ok) and never
+ * throws.  One context per GPU; calls on a context are stream-ordered on its HIP
+ * stream and must come from one host thread at a time (the same contract EXP's
+ * force methods have: one MPI rank <-> one GPU <-> one stream,
+ * src/Component.H:1054-1079).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * EXP source tree).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Real rows of spherical coefficients use the reference's order
+ * (src/SphericalBasis.cc:513-590): l=0; l=1: m0, m1 cos, m1 sin; l=2: ... ;
+ * row(l,m,cs) = l*l + (m ? 2*m-1+cs : 0), each row holding nmax doubles.
+ */
+#ifndef EXP_AMD_H
+#define EXP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXP_AMD_OK            0
+#define EXP_AMD_ERR_ARG       1   /* bad argument                                  */
+#define EXP_AMD_ERR_HIP       2   /* a HIP runtime call failed (see last_error)    */
+#define EXP_AMD_ERR_STATE     3   /* call made in the wrong state (e.g. no basis)  */
+#define EXP_AMD_ERR_NODEVICE  4   /* no HIP device / code object not loadable      */
+#define EXP_AMD_ERR_COMM      5   /* RCCL failure                                  */
+
+typedef struct exp_amd_ctx   exp_amd_ctx;    /* one per GPU                          */
+typedef struct exp_amd_comp  exp_amd_comp;   /* particle store of one Component      */
+typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylinder) */
+
+/* ---- library / context ------------------------------------------------------------ */
+
+/* ABI version of this header (bumped on any signature change). */
+int         exp_amd_abi_version(void);
+/* Static description of the last error on this context (or of the failed create). */
+const char *exp_amd_last_error(const exp_amd_ctx *ctx);
+const char *exp_amd_last_global_error(void);
+
+/* Replaces the per-rank device set-up of src/begin.cc:146-210 (one GPU per rank,
+ * one stream per component).  `stream` may be NULL (the context then creates its own
+ * non-blocking stream) or an existing hipStream_t the caller wants work ordered on. */
+int  exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out);
+void exp_amd_ctx_destroy(exp_amd_ctx *ctx);
+int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
+void *exp_amd_ctx_stream(exp_amd_ctx *ctx);
+
+/* Coefficient all-reduce across ranks.  Replaces the MPI_Allreduce calls of
+ * src/SphericalBasis.cc:864-903 and exputil/EmpCylSL.cc:4188-4222 by ONE on-stream
+ * reduction of the contiguous device coefficient buffer.
+ *   (a) native RCCL: exchange the 128-byte id out of band (MPI_Bcast / torch), then
+ *       every rank calls exp_amd_comm_init_rank;
+ *   (b) host-provided: register a callback that reduces `count` doubles in place at
+ *       device pointer `buf` on `stream` (e.g. torch.distributed.all_reduce or a
+ *       GPU-aware MPI_Allreduce).  With neither, the context is single-rank.       */
+int  exp_amd_comm_get_unique_id(void *id128);
+int  exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int nranks, int rank);
+typedef int (*exp_amd_allreduce_fn)(void *buf, size_t count, void *stream, void *user);
+int  exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn fn, void *user);
+
+/* ---- particle store ------------------------------------------------------------------
+ * Replaces the CUDA particle mirror of src/cudaComponent.cu:621-727
+ * (ParticlesToCuda / CudaToParticles) with an SoA store in HBM.  Host arrays are
+ * length n, fp64; any pointer may be NULL on upload (=> zeros) or download (=> skip).
+ * The store may physically reorder particles (cell sort); downloads always return the
+ * caller's original order.                                                           */
+int  exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **out);
+void exp_amd_comp_destroy(exp_amd_comp *c);
+size_t exp_amd_comp_size(const exp_amd_comp *c);
+int  exp_amd_comp_upload(exp_amd_comp *c, const double *mass,
+                         const double *x, const double *y, const double *z,
+                         const double *vx, const double *vy, const double *vz);
+int  exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
+                             const double *az, const double *pot);
+int  exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level);
+int  exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, double *y, double *z,
+                           double *vx, double *vy, double *vz,
+                           double *ax, double *ay, double *az, double *pot);
+int  exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level);
+/* Adopt device-resident SoA arrays (device pointers, length n) without a host trip:
+ * contents are copied device-to-device on the context stream.                      */
+int  exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass,
+                                const double *x, const double *y, const double *z,
+                                const double *vx, const double *vy, const double *vz);
+/* Expansion centre subtracted from positions (Component::Centered, src/Component.H:748-757). */
+int  exp_amd_comp_set_center(exp_amd_comp *c, const double center[3]);
+
+/* Leapfrog pieces.  Replace incr_position(dt, mlevel) (src/incpos.cc:72) and
+ * incr_velocity(dt, mlevel) (src/incvel.cc:90); mlevel < 0 means all levels.       */
+int  exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel);
+int  exp_amd_comp_kick (exp_amd_comp *c, double dt, int mlevel);
+/* Replaces the zeroing loop of ComponentContainer::compute_potential
+ * (src/ComponentContainer.cc:641-665): acc = pot = 0 for levels >= mlevel.         */
+int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
+
+/* ---- spherical force method (sphereSL) -----------------------------------------------
+ * Replaces class Sphere : SphericalBasis (src/Sphere.cc:28-96, src/SphericalBasis.cc)
+ * given the SLGridSph tables (exputil/SLGridMP2.cc: ev, ef, p0 on the xi grid).     */
+typedef struct {
+  int    lmax, nmax, numr, cmap;       /* Lmax, nmax, numr, cmap keys                  */
+  double rmap;                         /* rmapping                                     */
+  double scale;                        /* scale                                        */
+  double rmin, rmax;                   /* expansion window in unscaled r               */
+  double xmin, dxi;                    /* xi grid origin / spacing (SLGridMP2.cc:1355) */
+  int    NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;   /* src/SphericalBasis.cc:28-52       */
+  int    multistep;                    /* number of extra time-step levels (0 = none)  */
+} exp_amd_sph_config;
+
+/* xi[numr], p0[numr], ev[(lmax+1)*nmax], ef[(lmax+1)*nmax*numr] (ef(n,i) of table l) */
+int  exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cfg,
+                        const double *xi, const double *p0,
+                        const double *ev, const double *ef, exp_amd_force **out);
+void exp_amd_force_destroy(exp_amd_force *f);
+
+/* PotAccel::set_multistep_level (src/PotAccel.H:285) */
+int  exp_amd_force_set_level(exp_amd_force *f, int mlevel);
+
+/* PotAccel::determine_coefficients(Component*) (src/PotAccel.H:178-180 ->
+ * SphericalBasis::determine_coefficients_particles, src/SphericalBasis.cc:682-1002):
+ * accumulate the particles of level `mlevel` of `c` (all particles if the force has
+ * multistep == 0), reduce across ranks, leave the result on the device.             */
+int  exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c);
+
+/* Host copies of the current coefficient set, reference real-row order
+ * ((lmax+1)^2 rows x nmax).  set_coefs replaces HtoD_coefs
+ * (src/cudaSphericalBasis.cu:1437 ff.); get_coefs replaces DtoH_coefs.             */
+int  exp_amd_force_get_coefs(exp_amd_force *f, double *coef, size_t count);
+int  exp_amd_force_set_coefs(exp_amd_force *f, const double *coef, size_t count);
+size_t exp_amd_force_ncoef(const exp_amd_force *f);
+/* PotAccel::Used() (src/PotAccel.H:207): particles inside the window at the last
+ * accumulation, summed over ranks.                                                  */
+int  exp_amd_force_used(exp_amd_force *f, long long *used);
+
+/* PotAccel::get_acceleration_and_potential(Component*) (src/PotAccel.H:173 ->
+ * SphericalBasis::determine_acceleration_and_potential, src/SphericalBasis.cc:1663):
+ * acc += force, pot += potential for the particles of levels >= mlevel of `target`.
+ * `external` != 0 is SetExternal() (src/PotAccel.H:215): `target` is another
+ * component evaluated in this force's centred frame.                                */
+int  exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external);
+
+/* Multistep coefficient bookkeeping (src/SphericalBasis.cc:1231-1333, :1013-1079).  */
+int  exp_amd_force_multistep_reset(exp_amd_force *f);
+int  exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft);
+
+/* ---- fused step ------------------------------------------------------------------------
+ * One multistep=0 KDK step of a single self-gravitating component
+ * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.
+ * Same results as the unfused sequence of calls above; fewer passes over HBM.       */
+int  exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt);
+
+/* Timing of the last fused step's dominant kernels (ms, HIP events on the context
+ * stream); names are static strings.  Used by bench.py for the roofline figure.    */
+int  exp_amd_profile_enable(exp_amd_ctx *ctx, int on);
+int  exp_amd_profile_get(exp_amd_ctx *ctx, int idx, const char **name, double *ms_total,
+                         long long *launches);
+int  exp_amd_profile_reset(exp_amd_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

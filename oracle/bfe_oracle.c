@@ -1,0 +1,634 @@
+/*
+ * bfe_oracle.c -- CPU restatement of EXP's BFE hot path.  TEST INFRASTRUCTURE ONLY.
+ * See bfe_oracle.h for the scope statement ("parity unpinned", who may call this).
+ *
+ * Every function cites the reference file:line whose arithmetic it follows.  The
+ * order of floating-point operations is kept as written in the reference so that
+ * this file answers "what does EXP's CPU path compute" to the last bit it can.
+ */
+#include "bfe_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DSMALL  1.0e-16        /* src/expand.H:130              */
+#define XOFFSET 1.0e-8         /* exputil/SLGridMP2.cc:10       */
+static const double MINEPS = 3.0 * DBL_EPSILON;   /* src/Basis.cc:7 */
+
+#define P_(l, m) p[(l) * (lmax + 1) + (m)]
+#define DP_(l, m) dp[(l) * (lmax + 1) + (m)]
+
+/* src/Basis.cc:14-52 */
+void orc_legendre_R(int lmax, double x, double *p)
+{
+  double fact, somx2, pll, pl1, pl2;
+
+  P_(0, 0) = pll = 1.0;
+  if (lmax > 0) {
+    somx2 = sqrt((1.0 - x) * (1.0 + x));
+    fact = 1.0;
+    for (int m = 1; m <= lmax; m++) {
+      pll *= -fact * somx2;
+      P_(m, m) = pll;
+      fact += 2.0;
+    }
+  }
+
+  for (int m = 0; m < lmax; m++) {
+    pl2 = P_(m, m);
+    P_(m + 1, m) = pl1 = x * (2 * m + 1) * pl2;
+    for (int l = m + 2; l <= lmax; l++) {
+      P_(l, m) = pll = (x * (2 * l - 1) * pl1 - (l + m - 1) * pl2) / (l - m);
+      pl2 = pl1;
+      pl1 = pll;
+    }
+  }
+}
+
+/* src/Basis.cc:54-93 */
+void orc_dlegendre_R(int lmax, double x, double *p, double *dp)
+{
+  double somx2;
+
+  orc_legendre_R(lmax, x, p);
+
+  if (1.0 - fabs(x) < MINEPS) {
+    if (x > 0) x = 1.0 - MINEPS;
+    else       x = -(1.0 - MINEPS);
+  }
+
+  somx2 = 1.0 / (x * x - 1.0);
+  DP_(0, 0) = 0.0;
+  for (int l = 1; l <= lmax; l++) {
+    for (int m = 0; m < l; m++)
+      DP_(l, m) = somx2 * (x * l * P_(l, m) - (l + m) * P_(l - 1, m));
+    DP_(l, l) = somx2 * x * l * P_(l, l);
+  }
+}
+
+/* src/Basis.cc:95-112 */
+void orc_sinecosine_R(int mmax, double phi, double *c, double *s)
+{
+  c[0] = 1.0;
+  s[0] = 0.0;
+  if (mmax > 0) {
+    c[1] = cos(phi);
+    s[1] = sin(phi);
+    for (int m = 2; m <= mmax; m++) {
+      c[m] = 2.0 * c[1] * c[m - 1] - c[m - 2];
+      s[m] = 2.0 * c[1] * s[m - 1] - s[m - 2];
+    }
+  }
+}
+
+/* factrl(n) = n! as a double (exputil numerical-recipes style helper) */
+static double factrl(int n)
+{
+  double a = 1.0;
+  for (int i = 2; i <= n; i++) a *= (double)i;
+  return a;
+}
+
+/* src/SphericalBasis.cc:328-335 */
+void orc_factorial_table(int lmax, double *f)
+{
+  for (int l = 0; l <= lmax; l++) {
+    for (int m = 0; m <= lmax; m++) f[l * (lmax + 1) + m] = 0.0;
+    for (int m = 0; m <= l; m++) {
+      double v = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * factrl(l - m) / factrl(l + m));
+      if (m) v *= M_SQRT2;
+      f[l * (lmax + 1) + m] = v;
+    }
+  }
+}
+
+/* exputil/SLGridMP2.cc:711-727 */
+double orc_sl_r_to_xi(const orc_slgrid *g, double r)
+{
+  if (g->cmap == 1)      return (r / g->rmap - 1.0) / (r / g->rmap + 1.0);
+  else if (g->cmap == 2) return log(r);
+  return r;
+}
+
+/* exputil/SLGridMP2.cc:729-747 */
+double orc_sl_xi_to_r(const orc_slgrid *g, double xi)
+{
+  if (g->cmap == 1)      return (1.0 + xi) / (1.0 - xi) * g->rmap;
+  else if (g->cmap == 2) return exp(xi);
+  return xi;
+}
+
+/* exputil/SLGridMP2.cc:749-765 */
+double orc_sl_d_xi_to_r(const orc_slgrid *g, double xi)
+{
+  if (g->cmap == 1)      return 0.5 * (1.0 - xi) * (1.0 - xi) / g->rmap;
+  else if (g->cmap == 2) return exp(-xi);
+  return 1.0;
+}
+
+#define EF_(l, n, i) g->ef[((size_t)(l) * g->nmax + (n)) * g->numr + (i)]
+#define EV_(l, n)    g->ev[(l) * g->nmax + (n)]
+
+/* exputil/SLGridMP2.cc:872-910 (which=1: argument is a radius) */
+void orc_sl_get_pot(const orc_slgrid *g, double r, double *mat)
+{
+  double x = orc_sl_r_to_xi(g, r);
+
+  int indx = (int)((x - g->xmin) / g->dxi);
+  if (indx < 0) indx = 0;
+  if (indx > g->numr - 2) indx = g->numr - 2;
+
+  double x1 = (g->xi[indx + 1] - x) / g->dxi;
+  double x2 = (x - g->xi[indx]) / g->dxi;
+
+  for (int l = 0; l <= g->lmax; l++)
+    for (int n = 0; n < g->nmax; n++)
+      mat[l * g->nmax + n] =
+          (x1 * EF_(l, n, indx) + x2 * EF_(l, n, indx + 1)) / sqrt(EV_(l, n)) *
+          (x1 * g->p0[indx] + x2 * g->p0[indx + 1]);
+}
+
+/* exputil/SLGridMP2.cc:913-950 */
+void orc_sl_get_dens(const orc_slgrid *g, double r, double *mat)
+{
+  double x = orc_sl_r_to_xi(g, r);
+
+  int indx = (int)((x - g->xmin) / g->dxi);
+  if (indx < 0) indx = 0;
+  if (indx > g->numr - 2) indx = g->numr - 2;
+
+  double x1 = (g->xi[indx + 1] - x) / g->dxi;
+  double x2 = (x - g->xi[indx]) / g->dxi;
+
+  for (int l = 0; l <= g->lmax; l++)
+    for (int n = 0; n < g->nmax; n++)
+      mat[l * g->nmax + n] =
+          (x1 * EF_(l, n, indx) + x2 * EF_(l, n, indx + 1)) * sqrt(EV_(l, n)) *
+          (x1 * g->d0[indx] + x2 * g->d0[indx + 1]);
+}
+
+/* exputil/SLGridMP2.cc:954-989 */
+void orc_sl_get_force(const orc_slgrid *g, double r, double *mat)
+{
+  double x = orc_sl_r_to_xi(g, r);
+
+  int indx = (int)((x - g->xmin) / g->dxi);
+  if (indx < 1) indx = 1;
+  if (indx > g->numr - 2) indx = g->numr - 2;
+
+  double p = (x - g->xi[indx]) / g->dxi;
+  double fac = orc_sl_d_xi_to_r(g, x) / g->dxi;
+
+  for (int l = 0; l <= g->lmax; l++)
+    for (int n = 0; n < g->nmax; n++)
+      mat[l * g->nmax + n] =
+          fac * ((p - 0.5) * EF_(l, n, indx - 1) * g->p0[indx - 1]
+                 - 2.0 * p * EF_(l, n, indx) * g->p0[indx]
+                 + (p + 0.5) * EF_(l, n, indx + 1) * g->p0[indx + 1]) / sqrt(EV_(l, n));
+}
+
+/* scalar get_pot / get_dens with which=0 (argument already xi), used by orthoCheck:
+ * exputil/SLGridMP2.cc:767-797 and :802-830 */
+static double sl_pot_xi(const orc_slgrid *g, double x, int l, int n)
+{
+  if (g->cmap == 1) { if (x < -1.0) x = -1.0; if (x >= 1.0) x = 1.0 - XOFFSET; }
+  if (g->cmap == 2) { if (x < g->xmin) x = g->xmin; if (x > g->xmax) x = g->xmax; }
+  int indx = (int)((x - g->xmin) / g->dxi);
+  if (indx < 0) indx = 0;
+  if (indx > g->numr - 2) indx = g->numr - 2;
+  double x1 = (g->xi[indx + 1] - x) / g->dxi;
+  double x2 = (x - g->xi[indx]) / g->dxi;
+  return (x1 * EF_(l, n, indx) + x2 * EF_(l, n, indx + 1)) / sqrt(EV_(l, n)) *
+         (x1 * g->p0[indx] + x2 * g->p0[indx + 1]);
+}
+
+static double sl_dens_xi(const orc_slgrid *g, double x, int l, int n)
+{
+  if (g->cmap == 1) { if (x < -1.0) x = -1.0; if (x >= 1.0) x = 1.0 - XOFFSET; }
+  if (g->cmap == 2) { if (x < g->xmin) x = g->xmin; if (x > g->xmax) x = g->xmax; }
+  int indx = (int)((x - g->xmin) / g->dxi);
+  if (indx < 0) indx = 0;
+  if (indx > g->numr - 2) indx = g->numr - 2;
+  double x1 = (g->xi[indx + 1] - x) / g->dxi;
+  double x2 = (x - g->xi[indx]) / g->dxi;
+  return (x1 * EF_(l, n, indx) + x2 * EF_(l, n, indx + 1)) * sqrt(EV_(l, n)) *
+         (x1 * g->d0[indx] + x2 * g->d0[indx + 1]);
+}
+
+/* exputil/SLGridMP2.cc:1775-1824 */
+void orc_sl_orthocheck(const orc_slgrid *g, int num, const double *knots,
+                       const double *weights, double *ret)
+{
+  double ximin = orc_sl_r_to_xi(g, g->rmin);
+  double ximax = orc_sl_r_to_xi(g, g->rmax);
+  int nmax = g->nmax;
+
+  for (int L = 0; L <= g->lmax; L++) {
+    for (int nn = 0; nn < nmax * nmax; nn++) {
+      int n1 = nn / nmax;
+      int n2 = nn - n1 * nmax;
+      double ans = 0.0;
+      for (int i = 0; i < num; i++) {
+        double x = ximin + (ximax - ximin) * knots[i];
+        double r = orc_sl_xi_to_r(g, x);
+        ans += r * r * sl_pot_xi(g, x, L, n1) * sl_dens_xi(g, x, L, n2) /
+               orc_sl_d_xi_to_r(g, x) * (ximax - ximin) * weights[i];
+      }
+      ret[(L * nmax + n1) * nmax + n2] = -ans;
+    }
+  }
+}
+
+/* Kahan-compensated add used only in arbiter mode */
+static inline void kadd(double *s, double *c, double v)
+{
+  double y = v - *c;
+  double t = *s + y;
+  *c = (t - *s) - y;
+  *s = t;
+}
+
+/* src/SphericalBasis.cc:429-599 (determine_coefficients_thread, one thread, one
+ * level, pcavar/pcaeof/subset/mix off, sqnorm == 1 for Sphere, adb == 1)        */
+long orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
+                        const double *X, const double *Y, const double *Z,
+                        const double *M, const double *center, double *coef, int kahan)
+{
+  const double fac0 = -4.0 * M_PI;
+  const int Lmax = g->lmax, nmax = g->nmax, lmax = g->lmax;
+  const int nrows = (Lmax + 1) * (Lmax + 1);
+  long use = 0;
+
+  double *p = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *cosm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *sinm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (Lmax + 1) * nmax);
+  double *factorial = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *wk = (double *)malloc(sizeof(double) * nmax);
+  double *comp = kahan ? (double *)calloc((size_t)nrows * nmax, sizeof(double)) : NULL;
+  orc_factorial_table(Lmax, factorial);
+
+  memset(coef, 0, sizeof(double) * nrows * nmax);
+
+#define ACC(row, n, v)                                               \
+  do {                                                               \
+    if (kahan) kadd(&coef[(row) * nmax + (n)], &comp[(row) * nmax + (n)], (v)); \
+    else coef[(row) * nmax + (n)] += (v);                            \
+  } while (0)
+
+  for (long i = 0; i < nbodies; i++) {
+    double mass = M[i];
+    double xx = X[i] - center[0];
+    double yy = Y[i] - center[1];
+    double zz = Z[i] - center[2];
+
+    double r2 = (xx * xx + yy * yy + zz * zz);
+    double r = sqrt(r2) + DSMALL;
+
+    if (r >= P->rmin && r <= P->rmax) {
+      use++;
+      double costh = zz / r;
+      double phi = atan2(yy, xx);
+      double rs = r / P->scale;
+
+      orc_legendre_R(Lmax, costh, p);
+      orc_sinecosine_R(Lmax, phi, cosm, sinm);
+      orc_sl_get_pot(g, rs, potd);
+
+      for (int l = 0, loffset = 0; l <= Lmax; loffset += (2 * l + 1), l++) {
+        for (int m = 0, moffset = 0; m <= l; m++) {
+          double facL = factorial[l * (Lmax + 1) + m] * P_(l, m);
+          if (m == 0) {
+            for (int n = 0; n < nmax; n++) {
+              wk[n] = potd[l * nmax + n] * facL * mass * fac0 / 1.0;
+              ACC(loffset + moffset, n, wk[n]);
+            }
+            moffset++;
+          } else {
+            if (!P->M0_only) {
+              double fac1 = facL * cosm[m];
+              double fac2 = facL * sinm[m];
+              for (int n = 0; n < nmax; n++) {
+                wk[n] = potd[l * nmax + n] * mass * fac0 / 1.0;
+                ACC(loffset + moffset, n, wk[n] * fac1);
+                ACC(loffset + moffset + 1, n, wk[n] * fac2);
+              }
+            }
+            moffset += 2;
+          }
+        }
+      }
+    }
+  }
+#undef ACC
+
+  free(p); free(cosm); free(sinm); free(potd); free(factorial); free(wk);
+  if (comp) free(comp);
+  return use;
+}
+
+/* src/SphericalBasis.cc:1797-1813 */
+static void get_pot_coefs_safe(int l, int nmax, const double *coef, double *p, double *dp,
+                               const double *potd1, const double *dpot1)
+{
+  double pp = 0.0, dpp = 0.0;
+  for (int i = 0; i < nmax; i++) {
+    pp  += potd1[l * nmax + i] * coef[i];
+    dpp += dpot1[l * nmax + i] * coef[i];
+  }
+  *p = pp;
+  *dp = dpp;
+}
+
+/* src/SphericalBasis.cc:1476-1660 (determine_acceleration_and_potential_thread,
+ * mix off, use_external handled by the caller supplying positions + centre)      */
+void orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
+                   const double *X, const double *Y, const double *Z,
+                   const double *center, const double *expcoef,
+                   double *AX, double *AY, double *AZ, double *POT)
+{
+  const int Lmax = g->lmax, nmax = g->nmax, lmax = g->lmax;
+  const double scale = P->scale, rmax = P->rmax;
+  const double mfactor = 1.0;
+
+  double *p = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *dp = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *cosm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *sinm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (Lmax + 1) * nmax);
+  double *dpot = (double *)malloc(sizeof(double) * (Lmax + 1) * nmax);
+  double *factorial = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  orc_factorial_table(Lmax, factorial);
+#define FACT(l, m) factorial[(l) * (Lmax + 1) + (m)]
+#define COEF(row)  (expcoef + (size_t)(row) * nmax)
+
+  for (long i = 0; i < nbodies; i++) {
+    double r0 = 0.0, pp, dpp, pc, dpc, ps, dps, facp, facdp;
+    double potr, potl, pott, potp;
+
+    double xx = X[i] - center[0];
+    double yy = Y[i] - center[1];
+    double zz = Z[i] - center[2];
+
+    double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+    double costh = zz / r;
+    double rs = r / scale;
+    double phi = atan2(yy, xx);
+
+    orc_dlegendre_R(Lmax, costh, p, dp);
+    orc_sinecosine_R(Lmax, phi, cosm, sinm);
+
+    int ioff = 0;
+    if (r > rmax) {
+      ioff = 1;
+      r0 = r;
+      r = rmax;
+      rs = r / scale;
+    }
+
+    potl = potr = pott = potp = 0.0;
+
+    orc_sl_get_pot(g, rs, potd);
+    orc_sl_get_force(g, rs, dpot);
+
+    if (!P->NO_L0) {
+      get_pot_coefs_safe(0, nmax, COEF(0), &pp, &dpp, potd, dpot);
+      if (ioff) {
+        pp *= rmax / r0;
+        dpp = -pp / r0;
+      }
+      double facL = mfactor * FACT(0, 0);
+      potl = facL * pp;
+      potr = facL * dpp;
+    }
+
+    for (int l = 1, loffset = 1; l <= Lmax; loffset += (2 * l + 1), l++) {
+      if (P->NO_L1 && l == 1) continue;
+      if (P->EVEN_L && (l / 2) * 2 != l) continue;
+
+      for (int m = 0, moffset = 0; m <= l; m++) {
+        double facL = FACT(l, m) * P_(l, m) * mfactor;
+        double facD = FACT(l, m) * DP_(l, m) * mfactor;
+
+        /* NB: as in the reference these `continue`s skip the moffset update */
+        if (P->EVEN_M && (m / 2) * 2 != m) continue;
+        if (P->M0_only && m != 0) continue;
+
+        if (m == 0) {
+          get_pot_coefs_safe(l, nmax, COEF(loffset + moffset), &pp, &dpp, potd, dpot);
+          if (ioff) {
+            pp *= pow(rmax / r0, (double)(l + 1));
+            dpp = -pp / r0 * (l + 1);
+          }
+          potl += facL * pp;
+          potr += facL * dpp;
+          pott += facD * pp;
+          moffset++;
+        } else {
+          get_pot_coefs_safe(l, nmax, COEF(loffset + moffset), &pc, &dpc, potd, dpot);
+          get_pot_coefs_safe(l, nmax, COEF(loffset + moffset + 1), &ps, &dps, potd, dpot);
+          if (ioff) {
+            facp = pow(rmax / r0, (double)(l + 1));
+            facdp = -1.0 / r0 * (l + 1);
+            pc *= facp;
+            ps *= facp;
+            dpc = pc * facdp;
+            dps = ps * facdp;
+          }
+          potl += facL * (pc * cosm[m] + ps * sinm[m]);
+          potr += facL * (dpc * cosm[m] + dps * sinm[m]);
+          pott += facD * (pc * cosm[m] + ps * sinm[m]);
+          potp += facL * (-pc * sinm[m] + ps * cosm[m]) * m;
+          moffset += 2;
+        }
+      }
+    }
+
+    double fac = xx * xx + yy * yy;
+
+    potr /= scale * scale;
+    potl /= scale;
+    pott /= scale;
+    potp /= scale;
+
+    /* note: for r>rmax the reference divides by the CLAMPED r (= rmax) here */
+    AX[i] += -(potr * xx / r - pott * xx * zz / (r * r * r));
+    AY[i] += -(potr * yy / r - pott * yy * zz / (r * r * r));
+    AZ[i] += -(potr * zz / r + pott * fac / (r * r * r));
+    if (fac > DSMALL) {
+      AX[i] += potp * yy / fac;
+      AY[i] += -potp * xx / fac;
+    }
+    POT[i] += potl;
+  }
+#undef FACT
+#undef COEF
+
+  free(p); free(dp); free(cosm); free(sinm); free(potd); free(dpot); free(factorial);
+}
+
+/* src/incpos.cc:15-69 */
+void orc_drift(long n, double dt, double *x, double *y, double *z,
+               const double *vx, const double *vy, const double *vz)
+{
+  for (long i = 0; i < n; i++) {
+    x[i] += vx[i] * dt;
+    y[i] += vy[i] * dt;
+    z[i] += vz[i] * dt;
+  }
+}
+
+/* src/incvel.cc:15-88 */
+void orc_kick(long n, double dt, double *vx, double *vy, double *vz,
+              const double *ax, const double *ay, const double *az)
+{
+  for (long i = 0; i < n; i++) {
+    vx[i] += ax[i] * dt;
+    vy[i] += ay[i] * dt;
+    vz[i] += az[i] * dt;
+  }
+}
+
+/* src/step.cc:271-323 (multistep=0 block) for one self-gravitating component:
+ * incr_velocity(dt/2); incr_position(dt); compute_expansion(0);
+ * compute_potential() [zero acc/pot: src/ComponentContainer.cc:641-665, then self
+ * force :698-716]; incr_velocity(dt/2).                                           */
+void orc_sph_step(const orc_slgrid *g, const orc_sph_params *P, long n, double dt,
+                  double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                  double *ax, double *ay, double *az, double *pot,
+                  const double *mass, const double *center, double *coef)
+{
+  orc_kick(n, 0.5 * dt, vx, vy, vz, ax, ay, az);
+  orc_drift(n, dt, x, y, z, vx, vy, vz);
+  orc_sph_accumulate(g, P, n, x, y, z, mass, center, coef, 0);
+  for (long i = 0; i < n; i++) ax[i] = ay[i] = az[i] = pot[i] = 0.0;
+  orc_sph_accel(g, P, n, x, y, z, center, coef, ax, ay, az, pot);
+  orc_kick(n, 0.5 * dt, vx, vy, vz, ax, ay, az);
+}
+
+/* src/multistep.cc:630-680 */
+orc_mstep_tables *orc_mstep_create(int multistep)
+{
+  orc_mstep_tables *t = (orc_mstep_tables *)calloc(1, sizeof(*t));
+  int Mstep = 1 << multistep;
+  t->multistep = multistep;
+  t->Mstep = Mstep;
+  t->mintvl = (int *)calloc(multistep + 1, sizeof(int));
+  t->mfirst = (int *)calloc(Mstep + 1, sizeof(int));
+  t->mactive = (int *)calloc((size_t)(Mstep + 1) * (multistep + 1), sizeof(int));
+  t->dstepL = (int *)calloc((size_t)(multistep + 1) * Mstep, sizeof(int));
+  t->dstepN = (int *)calloc((size_t)(multistep + 1) * Mstep, sizeof(int));
+
+  t->mintvl[0] = Mstep;
+  for (int n = 1; n <= multistep; n++) t->mintvl[n] = t->mintvl[n - 1] / 2;
+
+  for (int M = 0; M <= multistep; M++) t->mactive[0 * (multistep + 1) + M] = 1;
+  for (int ms = 1; ms <= Mstep; ms++)
+    for (int M = 0; M <= multistep; M++)
+      if ((ms % (1 << (multistep - M))) == 0) t->mactive[ms * (multistep + 1) + M] = 1;
+
+  for (int ms = 0; ms <= Mstep; ms++)
+    for (int M = 0; M <= multistep; M++)
+      if (t->mactive[ms * (multistep + 1) + M]) { t->mfirst[ms] = M; break; }
+
+  for (int ms = 0; ms <= multistep; ms++) {
+    int rev = multistep - ms;
+    int d = 1 << ms;
+    for (int n = 0; n < Mstep; n++) {
+      t->dstepL[rev * Mstep + n] = (n / d) * d;
+      t->dstepN[rev * Mstep + n] = t->dstepL[rev * Mstep + n] + d;
+    }
+  }
+  return t;
+}
+
+void orc_mstep_free(orc_mstep_tables *t)
+{
+  if (!t) return;
+  free(t->mintvl); free(t->mfirst); free(t->mactive); free(t->dstepL); free(t->dstepN);
+  free(t);
+}
+
+void orc_mstep_export(const orc_mstep_tables *t, int *mintvl, int *mfirst,
+                      int *mactive, int *dstepL, int *dstepN)
+{
+  int ms = t->multistep, M = t->Mstep;
+  memcpy(mintvl, t->mintvl, sizeof(int) * (ms + 1));
+  memcpy(mfirst, t->mfirst, sizeof(int) * (M + 1));
+  memcpy(mactive, t->mactive, sizeof(int) * (size_t)(M + 1) * (ms + 1));
+  memcpy(dstepL, t->dstepL, sizeof(int) * (size_t)(ms + 1) * M);
+  memcpy(dstepN, t->dstepN, sizeof(int) * (size_t)(ms + 1) * M);
+}
+
+/* src/SphericalBasis.cc:1231-1333 ; src/CylEXP.cc:192-282 */
+void orc_mstep_combine(const orc_mstep_tables *t, int mdrft, long ncoef,
+                       const double *coefL, const double *coefN, double *coef)
+{
+  for (long k = 0; k < ncoef; k++) coef[k] = 0.0;
+
+  for (int M = 0; M < t->mfirst[mdrft]; M++) {
+    double numer = (double)(mdrft - t->dstepL[M * t->Mstep + mdrft]);
+    double denom = (double)(t->dstepN[M * t->Mstep + mdrft] - t->dstepL[M * t->Mstep + mdrft]);
+    double b = numer / denom;
+    double a = 1.0 - b;
+    for (long k = 0; k < ncoef; k++)
+      coef[k] += a * coefL[(size_t)M * ncoef + k] + b * coefN[(size_t)M * ncoef + k];
+  }
+  for (int M = t->mfirst[mdrft]; M <= t->multistep; M++)
+    for (long k = 0; k < ncoef; k++) coef[k] += coefN[(size_t)M * ncoef + k];
+}
+
+/* src/multistep.cc:94-196 (criteria + level rule; NoSwitch/FreezeLev off) */
+int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
+                     int shiftlevl, const double *dynfrac, double scale,
+                     const double *v, const double *a, double pot, double *dtreq)
+{
+  const double eps = 1.0e-10;
+  const double dynfracD = dynfrac[0], dynfracV = dynfrac[1], dynfracS = dynfrac[2],
+               dynfracA = dynfrac[3], dynfracP = dynfrac[4];
+  double dtr = 0.0, vtot = 0.0, atot = 0.0;
+  for (int k = 0; k < 3; k++) {
+    dtr += v[k] * a[k];
+    vtot += v[k] * v[k];
+    atot += a[k] * a[k];
+  }
+  double ptot = fabs(pot);
+  double dts, dtd, dtv, dta, dtA;
+  if (scale > 0) dts = dynfracS * scale / fabs(sqrt(vtot) + eps);
+  else           dts = 1.0 / eps;
+  dtd = dynfracD * 1.0 / sqrt(vtot + eps);
+  dtv = dynfracV * sqrt(vtot / (atot + eps));
+  dta = dynfracA * ptot / (fabs(dtr) + eps);
+  dtA = dynfracP * sqrt(ptot / (atot + eps));
+
+  /* smallest key of the std::map (dta, dtA only if > 0) */
+  double dmin = dtd;
+  if (dtv < dmin) dmin = dtv;
+  if (dts < dmin) dmin = dts;
+  if (dta > 0.0 && dta < dmin) dmin = dta;
+  if (dtA > 0.0 && dtA < dmin) dmin = dtA;
+
+  double dt = dmin > eps ? dmin : eps;
+  /* Particle::dtreq is a float (include/Particle.H:60-61): the level rule sees the
+   * float-rounded value */
+  float dtreq_f = (float)dt;
+  *dtreq = (double)dtreq_f;
+
+  unsigned plev = (unsigned)cur_level;
+  unsigned nlev = plev;
+  if (dtreq_f > dtime) nlev = 0;
+  else nlev = (unsigned)(int)floor(log(dtime / dtreq_f) / log(2.0));
+
+  if (shiftlevl) {
+    if (nlev > plev) {
+      if (nlev - plev > (unsigned)shiftlevl) nlev = plev + shiftlevl;
+    } else if (plev > nlev) {
+      if (plev - nlev > (unsigned)shiftlevl) nlev = plev - shiftlevl;
+    }
+  }
+  if (nlev > (unsigned)multistep) nlev = multistep;
+  if ((int)nlev < mfirst_mdrft) nlev = mfirst_mdrft;
+  return (int)nlev;
+}

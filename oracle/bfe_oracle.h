@@ -1,0 +1,116 @@
+/*
+ * bfe_oracle.h -- CPU restatement of EXP's BFE hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for exp_amd.  It restates, in plain scalar fp64 C, the
+ * arithmetic of the reference's CPU thread bodies (file:line citations are relative
+ * to the EXP source tree and are given on every function in bfe_oracle.c).
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors / known-answer values for
+ * coefficients or accelerations and cannot be compiled in
+ * this image (needs Eigen, yaml-cpp, HighFive, FFTW, gfortran).  The oracle is
+ * therefore pinned only by (i) line-by-line correspondence with the cited code and
+ * (ii) the analytic known-answer tests under tests/ (orthogonality, shell theorem,
+ * rotation/reflection symmetry, multipole continuity, leapfrog reversibility).
+ *
+ * Nothing under exp_amd/ may include, link or call this file.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ */
+#ifndef BFE_ORACLE_H
+#define BFE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- spherical SL grid (SLGridSph tables; include/SLGridMP2.H:28, sltableMP2.H:16-24) ---- */
+typedef struct {
+  int lmax, nmax, numr, cmap;
+  double rmin, rmax, rmap;   /* grid limits and mapping scale                 */
+  double xmin, xmax, dxi;    /* SLGridMP2.cc:1355-1382                        */
+  const double *xi;          /* [numr]                                        */
+  const double *p0;          /* [numr]  background potential                  */
+  const double *d0;          /* [numr]  4*pi*background density               */
+  const double *ev;          /* [(lmax+1)][nmax]                              */
+  const double *ef;          /* [(lmax+1)][nmax][numr]  (ef(n,i) of table l)  */
+} orc_slgrid;
+
+/* flags of SphericalBasis (src/SphericalBasis.cc:28-52) */
+typedef struct {
+  double scale;              /* "scale" key                                   */
+  double rmin, rmax;         /* expansion window (unscaled r)                 */
+  int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
+} orc_sph_params;
+
+void   orc_legendre_R (int lmax, double x, double *p);               /* p[(lmax+1)*(lmax+1)], p[l*(lmax+1)+m] */
+void   orc_dlegendre_R(int lmax, double x, double *p, double *dp);
+void   orc_sinecosine_R(int mmax, double phi, double *c, double *s);
+void   orc_factorial_table(int lmax, double *f);                     /* f[l*(lmax+1)+m] */
+
+double orc_sl_r_to_xi  (const orc_slgrid *g, double r);
+double orc_sl_xi_to_r  (const orc_slgrid *g, double xi);
+double orc_sl_d_xi_to_r(const orc_slgrid *g, double xi);
+void   orc_sl_get_pot  (const orc_slgrid *g, double r, double *mat); /* mat[(lmax+1)*nmax] */
+void   orc_sl_get_force(const orc_slgrid *g, double r, double *mat);
+void   orc_sl_get_dens (const orc_slgrid *g, double r, double *mat);
+/* orthoCheck: ret[(lmax+1)*nmax*nmax]; knots/weights = Gauss-Legendre on [0,1] */
+void   orc_sl_orthocheck(const orc_slgrid *g, int num, const double *knots,
+                         const double *weights, double *ret);
+
+/* coefficient accumulation: coef[(lmax+1)^2 * nmax] in the reference's real-row order.
+ * returns number of particles used.  kahan!=0 -> compensated summation (arbiter mode). */
+long   orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long n,
+                          const double *x, const double *y, const double *z,
+                          const double *mass, const double *center,
+                          double *coef, int kahan);
+
+/* acceleration + potential: acc{x,y,z}[i] += ..., pot[i] += ...  */
+void   orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long n,
+                     const double *x, const double *y, const double *z,
+                     const double *center, const double *coef,
+                     double *ax, double *ay, double *az, double *pot);
+
+/* leapfrog pieces (src/incpos.cc:15-69, src/incvel.cc:15-88) */
+void   orc_drift(long n, double dt, double *x, double *y, double *z,
+                 const double *vx, const double *vy, const double *vz);
+void   orc_kick (long n, double dt, double *vx, double *vy, double *vz,
+                 const double *ax, const double *ay, const double *az);
+
+/* one multistep=0 KDK step of a single self-gravitating spherical component
+ * (src/step.cc:271-323): kick/2, drift, coefficients, zero+force, kick/2.   */
+void   orc_sph_step(const orc_slgrid *g, const orc_sph_params *P, long n, double dt,
+                    double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                    double *ax, double *ay, double *az, double *pot,
+                    const double *mass, const double *center, double *coef);
+
+/* ---- multistep bookkeeping (src/multistep.cc:630-680) ---- */
+typedef struct {
+  int multistep, Mstep;
+  int *mintvl;    /* [multistep+1]            */
+  int *mfirst;    /* [Mstep+1]                */
+  int *mactive;   /* [Mstep][multistep+1]     */
+  int *dstepL;    /* [multistep+1][Mstep]     */
+  int *dstepN;    /* [multistep+1][Mstep]     */
+} orc_mstep_tables;
+
+orc_mstep_tables *orc_mstep_create(int multistep);
+void   orc_mstep_free(orc_mstep_tables *t);
+/* flat copies for ctypes: arrays sized as documented above */
+void   orc_mstep_export(const orc_mstep_tables *t, int *mintvl, int *mfirst,
+                        int *mactive, int *dstepL, int *dstepN);
+
+/* expcoef = sum_{M<mfirst[mdrft]} (a L + b N) + sum_{M>=mfirst} N
+ * (src/SphericalBasis.cc:1231-1333; src/CylEXP.cc:192-282).  coefL/coefN are
+ * [(multistep+1)][ncoef].                                                    */
+void   orc_mstep_combine(const orc_mstep_tables *t, int mdrft, long ncoef,
+                         const double *coefL, const double *coefN, double *coef);
+
+/* time-step criterion + level choice (src/multistep.cc:52-236), one particle.
+ * dynfrac = {D,V,S,A,P}; returns the new level; *dtreq receives dt.           */
+int    orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
+                        int shiftlevl, const double *dynfrac, double scale,
+                        const double *v, const double *a, double pot, double *dtreq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,195 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  Test infrastructure:
+imported only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+from numpy.polynomial import legendre as npleg
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class _SLGrid(ctypes.Structure):
+    _fields_ = [("lmax", ctypes.c_int), ("nmax", ctypes.c_int), ("numr", ctypes.c_int),
+                ("cmap", ctypes.c_int), ("rmin", ctypes.c_double), ("rmax", ctypes.c_double),
+                ("rmap", ctypes.c_double), ("xmin", ctypes.c_double), ("xmax", ctypes.c_double),
+                ("dxi", ctypes.c_double), ("xi", c_double_p), ("p0", c_double_p),
+                ("d0", c_double_p), ("ev", c_double_p), ("ef", c_double_p)]
+
+
+class _SphParams(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_double), ("rmin", ctypes.c_double), ("rmax", ctypes.c_double),
+                ("NO_L0", ctypes.c_int), ("NO_L1", ctypes.c_int), ("EVEN_L", ctypes.c_int),
+                ("EVEN_M", ctypes.c_int), ("M0_only", ctypes.c_int)]
+
+
+def build_oracle() -> str:
+    so = os.path.join(_ORACLE_DIR, "_build", "liboracle.so")
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR)
+            if f.endswith((".c", ".h"))]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = ctypes.CDLL(build_oracle())
+        L = self.lib
+        L.orc_sph_accumulate.restype = ctypes.c_long
+        L.orc_level_select.restype = ctypes.c_int
+        L.orc_mstep_create.restype = ctypes.c_void_p
+        L.orc_sl_r_to_xi.restype = ctypes.c_double
+        self._keep = []
+
+    # -- helpers ---------------------------------------------------------------------
+    def grid(self, g) -> _SLGrid:
+        arrs = [np.ascontiguousarray(getattr(g, k), dtype=np.float64)
+                for k in ("xi", "p0", "d0", "ev", "ef")]
+        self._keep.append(arrs)
+        return _SLGrid(g.lmax, g.nmax, g.numr, g.cmap, g.rmin, g.rmax, g.rmap, g.xmin, g.xmax,
+                       g.dxi, *[_dp(a) for a in arrs])
+
+    @staticmethod
+    def params(scale=1.0, rmin=0.0, rmax=1e30, NO_L0=False, NO_L1=False, EVEN_L=False,
+               EVEN_M=False, M0_only=False) -> _SphParams:
+        return _SphParams(scale, rmin, rmax, int(NO_L0), int(NO_L1), int(EVEN_L), int(EVEN_M),
+                          int(M0_only))
+
+    # -- Legendre / trig ---------------------------------------------------------------
+    def legendre(self, lmax, x):
+        p = np.zeros((lmax + 1, lmax + 1))
+        self.lib.orc_legendre_R(ctypes.c_int(lmax), ctypes.c_double(x), _dp(p))
+        return p
+
+    def dlegendre(self, lmax, x):
+        p = np.zeros((lmax + 1, lmax + 1))
+        dp = np.zeros((lmax + 1, lmax + 1))
+        self.lib.orc_dlegendre_R(ctypes.c_int(lmax), ctypes.c_double(x), _dp(p), _dp(dp))
+        return p, dp
+
+    def factorial(self, lmax):
+        f = np.zeros((lmax + 1, lmax + 1))
+        self.lib.orc_factorial_table(ctypes.c_int(lmax), _dp(f))
+        return f
+
+    # -- SL grid -----------------------------------------------------------------------
+    def get_pot(self, g, r):
+        G = self.grid(g)
+        m = np.zeros((g.lmax + 1, g.nmax))
+        self.lib.orc_sl_get_pot(ctypes.byref(G), ctypes.c_double(r), _dp(m))
+        return m
+
+    def get_force(self, g, r):
+        G = self.grid(g)
+        m = np.zeros((g.lmax + 1, g.nmax))
+        self.lib.orc_sl_get_force(ctypes.byref(G), ctypes.c_double(r), _dp(m))
+        return m
+
+    def get_dens(self, g, r):
+        G = self.grid(g)
+        m = np.zeros((g.lmax + 1, g.nmax))
+        self.lib.orc_sl_get_dens(ctypes.byref(G), ctypes.c_double(r), _dp(m))
+        return m
+
+    def orthocheck(self, g, num):
+        G = self.grid(g)
+        x, w = npleg.leggauss(num)
+        knots = np.ascontiguousarray(0.5 * (x + 1.0))
+        weights = np.ascontiguousarray(0.5 * w)
+        ret = np.zeros((g.lmax + 1, g.nmax, g.nmax))
+        self.lib.orc_sl_orthocheck(ctypes.byref(G), ctypes.c_int(num), _dp(knots), _dp(weights),
+                                   _dp(ret))
+        return ret
+
+    # -- spherical hot path ------------------------------------------------------------
+    def sph_accumulate(self, g, prm, pos, mass, center=(0.0, 0.0, 0.0), kahan=False):
+        G = self.grid(g)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        c = np.asarray(center, dtype=np.float64)
+        coef = np.zeros(((g.lmax + 1) ** 2, g.nmax))
+        used = self.lib.orc_sph_accumulate(ctypes.byref(G), ctypes.byref(prm),
+                                           ctypes.c_long(len(m)), _dp(x), _dp(y), _dp(z), _dp(m),
+                                           _dp(c), _dp(coef), ctypes.c_int(int(kahan)))
+        return coef, int(used)
+
+    def sph_accel(self, g, prm, pos, coef, center=(0.0, 0.0, 0.0)):
+        G = self.grid(g)
+        n = pos.shape[0]
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        c = np.asarray(center, dtype=np.float64)
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        ax, ay, az, pot = [np.zeros(n) for _ in range(4)]
+        self.lib.orc_sph_accel(ctypes.byref(G), ctypes.byref(prm), ctypes.c_long(n), _dp(x),
+                               _dp(y), _dp(z), _dp(c), _dp(cf), _dp(ax), _dp(ay), _dp(az),
+                               _dp(pot))
+        return np.stack([ax, ay, az], axis=1), pot
+
+    def sph_step(self, g, prm, dt, pos, vel, acc, mass, center=(0.0, 0.0, 0.0)):
+        """In-place KDK step on copies; returns (pos, vel, acc, pot, coef)."""
+        G = self.grid(g)
+        n = pos.shape[0]
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64).copy() for k in range(3)]
+        vx, vy, vz = [np.ascontiguousarray(vel[:, k], dtype=np.float64).copy() for k in range(3)]
+        ax, ay, az = [np.ascontiguousarray(acc[:, k], dtype=np.float64).copy() for k in range(3)]
+        pot = np.zeros(n)
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        c = np.asarray(center, dtype=np.float64)
+        coef = np.zeros(((g.lmax + 1) ** 2, g.nmax))
+        self.lib.orc_sph_step(ctypes.byref(G), ctypes.byref(prm), ctypes.c_long(n),
+                              ctypes.c_double(dt), _dp(x), _dp(y), _dp(z), _dp(vx), _dp(vy),
+                              _dp(vz), _dp(ax), _dp(ay), _dp(az), _dp(pot), _dp(m), _dp(c),
+                              _dp(coef))
+        return (np.stack([x, y, z], 1), np.stack([vx, vy, vz], 1), np.stack([ax, ay, az], 1),
+                pot, coef)
+
+    # -- multistep ---------------------------------------------------------------------
+    def mstep_tables(self, multistep):
+        t = ctypes.c_void_p(self.lib.orc_mstep_create(ctypes.c_int(multistep)))
+        Mstep = 1 << multistep
+        mintvl = np.zeros(multistep + 1, dtype=np.int32)
+        mfirst = np.zeros(Mstep + 1, dtype=np.int32)
+        mactive = np.zeros((Mstep + 1, multistep + 1), dtype=np.int32)
+        dstepL = np.zeros((multistep + 1, Mstep), dtype=np.int32)
+        dstepN = np.zeros((multistep + 1, Mstep), dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(c_int_p)
+        self.lib.orc_mstep_export(t, ip(mintvl), ip(mfirst), ip(mactive), ip(dstepL), ip(dstepN))
+        self.lib.orc_mstep_free(t)
+        return dict(multistep=multistep, Mstep=Mstep, mintvl=mintvl, mfirst=mfirst,
+                    mactive=mactive, dstepL=dstepL, dstepN=dstepN)
+
+    def mstep_combine(self, multistep, mdrft, coefL, coefN):
+        t = ctypes.c_void_p(self.lib.orc_mstep_create(ctypes.c_int(multistep)))
+        coefL = np.ascontiguousarray(coefL, dtype=np.float64)
+        coefN = np.ascontiguousarray(coefN, dtype=np.float64)
+        ncoef = coefL[0].size
+        out = np.zeros(ncoef)
+        self.lib.orc_mstep_combine(t, ctypes.c_int(mdrft), ctypes.c_long(ncoef), _dp(coefL),
+                                   _dp(coefN), _dp(out))
+        self.lib.orc_mstep_free(t)
+        return out.reshape(coefL[0].shape)
+
+    def level_select(self, dtime, multistep, mfirst_mdrft, cur, shiftlevl, dynfrac, scale, v, a,
+                     pot):
+        dyn = np.asarray(dynfrac, dtype=np.float64)
+        v = np.asarray(v, dtype=np.float64)
+        a = np.asarray(a, dtype=np.float64)
+        dtreq = ctypes.c_double(0.0)
+        lev = self.lib.orc_level_select(ctypes.c_double(dtime), ctypes.c_int(multistep),
+                                        ctypes.c_int(mfirst_mdrft), ctypes.c_int(cur),
+                                        ctypes.c_int(shiftlevl), _dp(dyn),
+                                        ctypes.c_double(scale), _dp(v), _dp(a),
+                                        ctypes.c_double(pot), ctypes.byref(dtreq))
+        return int(lev), dtreq.value

@@ -1,0 +1,252 @@
+"""Known-answer tests that pin the CPU oracle (the reference ships no golden numbers for
+coefficients/accelerations).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+from scipy.special import lpmv
+
+from tests.conftest import make_grid
+
+
+# ---- a1: Legendre / trig recurrences (src/Basis.cc:14-112) ---------------------------------------
+
+@pytest.mark.parametrize("x", [-0.999, -0.3, 0.0, 0.41, 0.97, 1.0])
+def test_legendre_matches_scipy(oracle, x):
+    lmax = 10
+    p = oracle.legendre(lmax, x)
+    for l in range(lmax + 1):
+        for m in range(l + 1):
+            ref = lpmv(m, l, x)        # Condon-Shortley phase included, unnormalised
+            assert p[l, m] == pytest.approx(ref, rel=1e-11, abs=1e-9)
+
+
+def test_dlegendre_finite_difference(oracle):
+    lmax, x, h = 8, 0.37, 1e-6
+    _, dp = oracle.dlegendre(lmax, x)
+    pp = oracle.legendre(lmax, x + h)
+    pm = oracle.legendre(lmax, x - h)
+    fd = (pp - pm) / (2 * h)
+    for l in range(lmax + 1):
+        for m in range(l + 1):
+            assert dp[l, m] == pytest.approx(fd[l, m], rel=2e-6, abs=1e-5)
+
+
+def test_dlegendre_pole_clamp(oracle):
+    # |x| clamped to 1 - 3 eps (src/Basis.cc:81-84): finite derivative at the pole
+    p, dp = oracle.dlegendre(6, 1.0)
+    assert np.all(np.isfinite(dp))
+    assert p[3, 0] == pytest.approx(1.0)
+
+
+def test_factorial_table(oracle):
+    f = oracle.factorial(6)
+    assert f[0, 0] == pytest.approx(math.sqrt(1.0 / (4 * math.pi)))
+    l, m = 5, 3
+    ref = math.sqrt((2 * l + 1) / (4 * math.pi) * math.factorial(l - m) / math.factorial(l + m)) * math.sqrt(2)
+    assert f[l, m] == pytest.approx(ref, rel=1e-14)
+
+
+# ---- SL tables: orthogonality (exputil/SLGridMP2.cc:1775-1824, orthoTol = 1e-2) -----------------------
+
+def test_orthocheck_plummer(oracle, plummer_s6):
+    _, g = plummer_s6
+    oc = oracle.orthocheck(g, max(g.nmax * 50, 200))
+    for l in range(g.lmax + 1):
+        assert np.abs(oc[l] - np.eye(g.nmax)).max() < 2e-3      # reference tolerance is 1e-2
+
+
+def test_orthocheck_reference_model_file(oracle):
+    """The reference's own quick test (tests/Halo/sph_basis.py): a sphereSL basis built from
+    tests/Halo/SLGridSph.model passes orthoTest (<= 1e-2).  Same data file, our SL solver."""
+    import os
+    from exp_amd.models import TableModel
+    from exp_amd.slgrid import build_slgrid
+    model = TableModel(os.path.join(os.path.dirname(__file__), "golden", "SLGridSph.model"))
+    # keys of the reference test: Lmax 4, nmax 10, numr 2000, rmapping 0.0667 (tests/Halo/sph_basis.py)
+    g = build_slgrid(model, 4, 10, numr=2000, rmin=0.0001, rmax=1.95, cmap=1, rmap=0.0667,
+                     nel=40, P=8)
+    oc = oracle.orthocheck(g, 500)
+    worst = max(np.abs(oc[l] - np.eye(10)).max() for l in range(5))
+    assert worst < 1e-2
+
+
+def test_plummer_eigenvalues_clutton_brock(plummer_s6):
+    """For a Plummer background the SL problem is the Clutton-Brock basis:
+    lambda_{nl} = (4 n (n + 2l + 2) + (2l+1)(2l+3)) / 3 on [0, inf)."""
+    _, g = plummer_s6
+    for l in range(g.lmax + 1):
+        for n in range(6):
+            ref = (4 * n * (n + 2 * l + 2) + (2 * l + 1) * (2 * l + 3)) / 3.0
+            assert g.ev[l, n] == pytest.approx(ref, rel=5e-3)
+
+
+def test_sign_convention(plummer_s6):
+    _, g = plummer_s6
+    assert np.all(g.ef[:, :, 3] > 0)        # nevsign = 4 (exputil/SLGridMP2.cc:1329-1333)
+
+
+# ---- coefficient / force known answers -----------------------------------------------------------------------
+
+def _quantile_sphere(model, n, seed=3):
+    """Equal-mass particles at mass-quantile radii (deterministic radial quadrature)."""
+    from exp_amd.models import sphere_sampling_tables
+    u_tab, r_tab, _ = sphere_sampling_tables(model, 49.0)
+    u = (np.arange(n) + 0.5) / n
+    r = np.interp(u, u_tab, r_tab)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ct = rng.uniform(-1, 1, n)
+    ph = rng.uniform(0, 2 * math.pi, n)
+    st = np.sqrt(1 - ct * ct)
+    pos = np.stack([r * st * np.cos(ph), r * st * np.sin(ph), r * ct], 1)
+    mtot = float(model.mass(r_tab[-1]) - model.mass(r_tab[0]))
+    return np.full(n, mtot / n), pos
+
+
+def test_monopole_of_background_model(oracle, plummer_s6):
+    """Particles that sample the background density: c_{00,n>0} -> 0 (biorthogonality) and the
+    l=0 reconstruction gives the Plummer force -M(r)/r^2.  Pins sign, -4pi, Y00, scale."""
+    model, g = plummer_s6
+    m, pos = _quantile_sphere(model, 40000)
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    coef, used = oracle.sph_accumulate(g, prm, pos, m)
+    assert used == len(m)
+    c0 = coef[0]
+    assert abs(c0[0]) > 0
+    assert np.abs(c0[1:]).max() < 2e-3 * abs(c0[0])
+    # force from the monopole row only
+    only0 = np.zeros_like(coef)
+    only0[0] = coef[0]
+    test = np.array([[0.3, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 3.0]])
+    acc, pot = oracle.sph_accel(g, prm, test, only0)
+    for p, a, ph in zip(test, acc, pot):
+        r = np.linalg.norm(p)
+        assert np.linalg.norm(a) == pytest.approx(float(model.mass(r)) / r ** 2, rel=5e-3)
+        assert np.dot(a, p) < 0                                 # attractive
+        assert ph == pytest.approx(float(model.pot(r)), rel=5e-3)
+
+
+def test_rotation_about_z(oracle, plummer_small):
+    """Rotating the particle set by alpha about z rotates every (cos, sin) row pair by m*alpha."""
+    model, g = plummer_small
+    from exp_amd.models import sample_sphere
+    m, pos, _ = sample_sphere(model, 500, seed=11, velocities=False)
+    pos[:, 2] *= 0.6                                            # make it non-spherical
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c0, _ = oracle.sph_accumulate(g, prm, pos, m)
+    al = 0.7
+    R = np.array([[math.cos(al), -math.sin(al), 0], [math.sin(al), math.cos(al), 0], [0, 0, 1]])
+    c1, _ = oracle.sph_accumulate(g, prm, pos @ R.T, m)
+    scale = np.abs(c0).max()
+    for l in range(g.lmax + 1):
+        assert np.allclose(c1[l * l], c0[l * l], atol=1e-12 * scale)
+        for mm in range(1, l + 1):
+            rc, rs = l * l + 2 * mm - 1, l * l + 2 * mm
+            ec = c0[rc] * math.cos(mm * al) - c0[rs] * math.sin(mm * al)
+            es = c0[rc] * math.sin(mm * al) + c0[rs] * math.cos(mm * al)
+            assert np.allclose(c1[rc], ec, atol=1e-11 * scale)
+            assert np.allclose(c1[rs], es, atol=1e-11 * scale)
+
+
+def test_z_reflection(oracle, plummer_small):
+    model, g = plummer_small
+    from exp_amd.models import sample_sphere
+    m, pos, _ = sample_sphere(model, 300, seed=5, velocities=False)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c0, _ = oracle.sph_accumulate(g, prm, pos, m)
+    c1, _ = oracle.sph_accumulate(g, prm, pos * np.array([1, 1, -1.0]), m)
+    scale = np.abs(c0).max()
+    for l in range(g.lmax + 1):
+        for mm in range(l + 1):
+            sgn = -1.0 if (l + mm) % 2 else 1.0
+            rows = [l * l] if mm == 0 else [l * l + 2 * mm - 1, l * l + 2 * mm]
+            for r in rows:
+                assert np.allclose(c1[r], sgn * c0[r], atol=1e-12 * scale)
+
+
+def test_exterior_potential_continuity(oracle, plummer_small):
+    """r > rmax uses the table at rmax times (rmax/r)^(l+1): the potential is continuous at rmax."""
+    model, g = plummer_small
+    from exp_amd.models import sample_sphere
+    m, pos, _ = sample_sphere(model, 400, seed=8, velocities=False)
+    pos[:, 0] *= 1.3
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.sph_accumulate(g, prm, pos, m)
+    d = np.array([0.3, -0.5, 0.81])
+    d /= np.linalg.norm(d)
+    eps = 1e-9
+    test = np.stack([d * g.rmax * (1 - eps), d * g.rmax * (1 + eps)])
+    _, pot = oracle.sph_accel(g, prm, test, coef)
+    assert pot[1] == pytest.approx(pot[0], rel=1e-6)
+
+
+def test_accel_is_gradient_of_potential(oracle, plummer_small):
+    """-grad(pot) = acc to the accuracy of the 3-point table derivative (pins potr/pott/potp
+    signs and the Cartesian projection of src/SphericalBasis.cc:1645-1651)."""
+    model, g = plummer_small
+    from exp_amd.models import sample_sphere
+    m, pos, _ = sample_sphere(model, 400, seed=9, velocities=False)
+    pos[:, 1] *= 0.7
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.sph_accumulate(g, prm, pos, m)
+    p0 = np.array([0.41, -0.33, 0.27])
+    h = 1e-5
+    pts = [p0]
+    for k in range(3):
+        e = np.zeros(3)
+        e[k] = h
+        pts += [p0 + e, p0 - e]
+    acc, pot = oracle.sph_accel(g, prm, np.array(pts), coef)
+    grad = np.array([(pot[1 + 2 * k] - pot[2 + 2 * k]) / (2 * h) for k in range(3)])
+    assert np.allclose(acc[0], -grad, rtol=2e-2, atol=2e-3 * np.linalg.norm(grad))
+
+
+def test_leapfrog_time_reversal(oracle, plummer_small):
+    model, g = plummer_small
+    from exp_amd.models import sample_sphere
+    m, pos, vel = sample_sphere(model, 200, seed=21)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.sph_accumulate(g, prm, pos, m)
+    acc, _ = oracle.sph_accel(g, prm, pos, coef)
+    p1, v1, a1, _, _ = oracle.sph_step(g, prm, 0.01, pos, vel, acc, m)
+    p2, v2, a2, _, _ = oracle.sph_step(g, prm, -0.01, p1, v1, a1, m)
+    assert np.allclose(p2, pos, atol=1e-13)
+    assert np.allclose(v2, vel, atol=1e-12)
+
+
+# ---- multistep bookkeeping (src/multistep.cc:630-680) ---------------------------------------------------------------
+
+def test_multistep_tables(oracle):
+    t = oracle.mstep_tables(2)
+    assert t["Mstep"] == 4
+    assert list(t["mintvl"]) == [4, 2, 1]
+    assert list(t["mfirst"]) == [0, 2, 1, 2, 0]
+    assert list(t["dstepL"][0]) == [0, 0, 0, 0] and list(t["dstepN"][0]) == [4, 4, 4, 4]
+    assert list(t["dstepL"][1]) == [0, 0, 2, 2] and list(t["dstepN"][1]) == [2, 2, 4, 4]
+    assert list(t["dstepL"][2]) == [0, 1, 2, 3] and list(t["dstepN"][2]) == [1, 2, 3, 4]
+
+
+def test_multistep_combine(oracle):
+    rng = np.random.default_rng(0)
+    L = rng.standard_normal((3, 5, 4))
+    N = rng.standard_normal((3, 5, 4))
+    # mdrft = 1 with multistep 2: mfirst = 2 -> levels 0,1 interpolated, level 2 taken whole
+    out = oracle.mstep_combine(2, 1, L, N)
+    exp = (0.75 * L[0] + 0.25 * N[0]) + (0.5 * L[1] + 0.5 * N[1]) + N[2]
+    assert np.allclose(out, exp, atol=1e-15)
+    out4 = oracle.mstep_combine(2, 4, L, N)
+    assert np.allclose(out4, N.sum(0), atol=1e-15)
+
+
+def test_level_select(oracle):
+    dyn = [1e6, 0.01, 1e6, 1e6, 1e6]          # only the velocity/acceleration criterion binds
+    v, a = [1.0, 0, 0], [0, 4.0, 0]           # dtv = 0.01*sqrt(1/16) = 0.0025
+    lev, dt = oracle.level_select(0.01, 4, 0, 0, 0, dyn, 0.0, v, a, -1.0)
+    assert dt == pytest.approx(np.float32(0.0025), rel=1e-6)
+    assert lev == 2                            # floor(log2(0.01/0.0025)) = 2
+    lev, _ = oracle.level_select(0.01, 4, 0, 0, 1, dyn, 0.0, v, a, -1.0)
+    assert lev == 1                            # shiftlevl = 1 limits the jump
+    lev, _ = oracle.level_select(0.01, 1, 0, 0, 0, dyn, 0.0, v, a, -1.0)
+    assert lev == 1                            # clamped to multistep
+    lev, _ = oracle.level_select(0.01, 4, 3, 0, 0, dyn, 0.0, v, a, -1.0)
+    assert lev == 3                            # not below mfirst[mdrft]
