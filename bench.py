@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-steps/sec (coef + force + kick-drift) of the spherical BFE
+hot path on MI355X.
+
+Workload (BASELINE.json config 5, the configuration the metric is quoted on): 1e8-particle
+truncated-NFW halo, SphericalSL lmax=10 nmax=24 (numr 2000), fp64, multistep 0.  A "step" is
+one KDK leapfrog step of every particle: kick dt/2, drift dt, cell sort, coefficient
+accumulation (+ one all-reduce of the 2904-double coefficient buffer when N > 1), force and
+potential evaluation, kick dt/2.  The total particle count is FIXED as GPUs are added (strong
+scaling): each rank owns N/world particles and the only exchange is the coefficient all-reduce.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Algorithmic HBM bytes per particle per launch of each pass (SURVEY.md section 8d accounting,
+# restated in DESIGN.md): whole step 232 B = pass A (kick/2 + drift + accumulate) 128 B +
+# pass B (force + kick/2) 104 B.
+ALGO_BYTES = {
+    "k_sph_force": 104.0,        # reads x,y,z,vx,vy,vz (48) ; writes ax,ay,az,pot,vx,vy,vz (56)
+    "k_sph_accumulate": 32.0,    # reads x,y,z,m
+    "k_kick": 72.0,
+    "k_drift": 72.0,
+    "k_scatter": 176.0,
+    "step": 232.0,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nbodies", type=float, default=1e8, help="TOTAL particle count (all ranks)")
+    ap.add_argument("--lmax", type=int, default=10)
+    ap.add_argument("--nmax", type=int, default=24)
+    ap.add_argument("--numr", type=int, default=2000)
+    ap.add_argument("--dt", type=float, default=0.002)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
+                    help="coefficient all-reduce through torch.distributed (default) or the "
+                         "library's own RCCL communicator")
+    return ap.parse_args()
+
+
+def make_halo(model, n, seed, device):
+    """n equal-mass NFW particles + Jeans-dispersion velocities, generated in HBM."""
+    import torch
+    from exp_amd.models import sphere_sampling_tables
+    u_tab, r_tab, s_tab = sphere_sampling_tables(model, 0.98 * model.rmax)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    f64 = torch.float64
+    ut = torch.tensor(u_tab, device=device, dtype=f64)
+    rt = torch.tensor(r_tab, device=device, dtype=f64)
+    sg = torch.tensor(s_tab, device=device, dtype=f64)
+    u = torch.rand(n, device=device, dtype=f64, generator=gen)
+    idx = torch.searchsorted(ut, u).clamp_(1, len(u_tab) - 1)
+    w = (u - ut[idx - 1]) / (ut[idx] - ut[idx - 1])
+    r = rt[idx - 1] + w * (rt[idx] - rt[idx - 1])
+    sig = sg[idx - 1] + w * (sg[idx] - sg[idx - 1])
+    del u, w, idx
+    ct = torch.rand(n, device=device, dtype=f64, generator=gen) * 2 - 1
+    ph = torch.rand(n, device=device, dtype=f64, generator=gen) * (2 * math.pi)
+    st = torch.sqrt(1 - ct * ct)
+    x = (r * st * torch.cos(ph)).contiguous()
+    y = (r * st * torch.sin(ph)).contiguous()
+    z = (r * ct).contiguous()
+    del ct, ph, st, r
+    vx = torch.randn(n, device=device, dtype=f64, generator=gen) * sig
+    vy = torch.randn(n, device=device, dtype=f64, generator=gen) * sig
+    vz = torch.randn(n, device=device, dtype=f64, generator=gen) * sig
+    return x, y, z, vx, vy, vz
+
+
+def cpu_baseline(grid, model, nsample, dt):
+    """The oracle (CPU restatement of EXP's CPU path, scalar, 1 thread) timed on this host on a
+    bounded sample of the same workload.  Baseline only -- see DESIGN.md."""
+    from exp_amd.models import sample_sphere
+    from tests.oracle_lib import Oracle
+    orc = Oracle()
+    m, pos, vel = sample_sphere(model, nsample, seed=777)
+    prm = orc.params(rmin=grid.rmin, rmax=grid.rmax)
+    acc = np.zeros_like(pos)
+    t0 = time.perf_counter()
+    nsteps = 0
+    p, v, a = pos, vel, acc
+    while True:
+        p, v, a, _, _ = orc.sph_step(grid, prm, dt, p, v, a, m)
+        nsteps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or nsteps >= 50:
+            break
+    return {"value": nsample * nsteps / el, "unit": "particle-steps/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{nsteps} KDK steps of {nsample} NFW particles, same basis "
+                      f"(lmax {grid.lmax}, nmax {grid.nmax}, numr {grid.numr}); "
+                      "oracle/bfe_oracle.c, scalar fp64, gcc -O2, 1 thread"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from exp_amd.models import NFWModel
+    from exp_amd.runtime import Component, Context, SphereSL
+    from exp_amd.slgrid import build_slgrid
+
+    # ---- basis tables (init; not timed) -------------------------------------------------------
+    model = NFWModel(rs=1.0, rtrunc=20.0, wtrunc=6.0, rmin=1e-3, rmax=50.0)
+    grid = build_slgrid(model, args.lmax, args.nmax, numr=args.numr, rmin=1e-3, rmax=49.5,
+                        cmap=1, rmap=1.0)
+
+    # ---- particles: static block shard of the total -----------------------------------------------
+    ntot = int(args.nbodies)
+    n0 = ntot * rank // world
+    n1 = ntot * (rank + 1) // world
+    nloc = n1 - n0
+    x, y, z, vx, vy, vz = make_halo(model, nloc, seed=23456 + rank, device=device)
+    mass = torch.full((nloc,), 1.0 / ntot, device=device, dtype=torch.float64)
+    torch.cuda.synchronize()
+
+    # the context runs on an explicit torch stream so that torch.distributed's all-reduce
+    # (issued from the coefficient callback) is ordered with the kernels
+    tstream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(tstream)
+    ctx = Context(local_rank, stream=tstream.cuda_stream)
+    comp = Component(ctx, nloc)
+    comp.upload_device(mass, x, y, z, vx, vy, vz)
+    del x, y, z, vx, vy, vz, mass
+    torch.cuda.empty_cache()
+    force = SphereSL(ctx, grid)
+
+    if world > 1:
+        if args.comm == "rccl":
+            ids = [Context.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.init_rccl(ids[0], world, rank)
+        else:
+            from exp_amd.dist import torch_allreduce_callback
+            ctx.set_allreduce(torch_allreduce_callback(device))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # initial coefficients + accelerations so that step 1 kicks with a real field
+    force.determine_coefficients(comp)
+    comp.zero_acceleration(0)
+    force.get_acceleration_and_potential(comp)
+
+    for _ in range(args.warmup):
+        force.step_kdk(comp, args.dt)
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        force.step_kdk(comp, args.dt)
+    barrier()
+    el = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile(False)
+
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        value = ntot * args.steps / el
+        ms_step = 1e3 * el / args.steps
+        # dominant kernel by measured time on this rank's stream
+        kern = {k: v for k, v in prof.items() if v["launches"] > 0}
+        dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+        roof = None
+        if dom:
+            # k_sph_accumulate is launched once per m-split per step: a "launch" here is the
+            # whole split group (ProfScope brackets the group)
+            avg_ms = kern[dom]["ms_total"] / kern[dom]["launches"]
+            algo = ALGO_BYTES.get(dom, 0.0) * nloc
+            achieved = algo / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    ent = tj.get(dom)
+                    if ent and int(ent.get("n_particles", -1)) == nloc:
+                        traffic = ent["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_particle": ALGO_BYTES.get(dom, 0.0),
+                    "step_achieved": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9,
+                    "step_frac": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernels_ms_per_step": {k: v["ms_total"] / args.steps for k, v in kern.items()}}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(grid, model, args.cpu_sample, args.dt)
+        line = {
+            "metric": "particle-steps/sec (coef+force+kick-drift)",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{ntot:.0e}-particle truncated-NFW halo, SphericalSL "
+                                   f"lmax={args.lmax} nmax={args.nmax} numr={args.numr}, "
+                                   "multistep=0, KDK step (kick/2, drift, sort, coef, force, kick/2)",
+                       "nbodies_total": ntot, "nbodies_per_gpu": nloc, "lmax": args.lmax,
+                       "nmax": args.nmax, "numr": args.numr, "dt": args.dt,
+                       "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"
+                                      f" ({args.comm})" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+    comp.close()
+    force.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -507,9 +507,9 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
     AZ[i] = az;
     POT[i] = pt;
     if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88)
-      VX[i] += ax * dt_kick;
-      VY[i] += ay * dt_kick;
-      VZ[i] += az * dt_kick;
+      VX[i] = __dadd_rn(VX[i], __dmul_rn(ax, dt_kick));
+      VY[i] = __dadd_rn(VY[i], __dmul_rn(ay, dt_kick));
+      VZ[i] = __dadd_rn(VZ[i], __dmul_rn(az, dt_kick));
     }
   }
 }

@@ -100,7 +100,7 @@ class NumericModel(SphericalModel):
         return self._Phi(np.log(np.asarray(r, dtype=np.float64)))
 
 
-def NFWModel(rs: float = 1.0, rtrunc: float = 10.0, wtrunc: float = 2.0,
+def NFWModel(rs: float = 1.0, rtrunc: float = 20.0, wtrunc: float = 6.0,
              rmin: float = 1e-3, rmax: float = 50.0, total_mass: float = 1.0) -> NumericModel:
     """NFW profile with an error-function truncation (the form used by EXP's gensph
     model headers, cf. ``tests/Halo/SLGridSph.model:1``: rtrunc / wtrunc)."""

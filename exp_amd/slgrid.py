@@ -199,6 +199,9 @@ def solve_sl_order(model: SphericalModel, l: int, nmax: int, ra: float, rb: floa
     px = r * r * f * f
     qx = (L2 * f - rho * r * r) * f
     wx = -rho * r * r * f
+    if not np.all(wx > 0.0):
+        raise ValueError("SL weight w = -rho r^2 Phi0 is not positive everywhere: the model density "
+                         "vanishes (or Phi0 >= 0) inside [rmin, rmax]")
     K, M = mesh.assemble(px / r, qx * r, wx * r)
 
     # Boundary terms (exputil/SLGridMP2.cc:1153-1164).  Weak form:

@@ -33,7 +33,7 @@ def make_grid(kind: str, lmax: int, nmax: int, numr: int = 800):
             g = build_slgrid(model, lmax, nmax, numr=numr, rmin=1e-3, rmax=49.5, cmap=1, rmap=1.0,
                              nel=32, P=8)
         elif kind == "nfw":
-            model = NFWModel(1.0, 10.0, 2.0, 1e-3, 50.0)
+            model = NFWModel(1.0, 20.0, 6.0, 1e-3, 50.0)
             g = build_slgrid(model, lmax, nmax, numr=numr, rmin=1e-3, rmax=49.5, cmap=1, rmap=1.0,
                              nel=32, P=8)
         elif kind == "plummer_log":

@@ -1,0 +1,279 @@
+"""Parity of the HIP spherical path against the CPU oracle (through the C ABI).  GPU only.
+
+Tolerances (fp64): coefficients  max|c_gpu - c_cpu| / max|c_cpu| <= 1e-10  (north_star);
+accelerations / potential  max_p |a_gpu - a_cpu| / (|a_cpu| + tiny) <= 1e-9.  The GPU path
+re-associates the n-contraction (see exp_amd/csrc/sph_kernels.h), so agreement is to rounding,
+not bitwise."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.conftest import make_grid
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-10
+ACC_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def coef_err(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def acc_err(a, b):
+    na = np.linalg.norm(a - b, axis=1)
+    nb = np.linalg.norm(b, axis=1)
+    return (na / (nb + 1e-300)).max()
+
+
+def _particles(model, n, seed, squash=0.7):
+    from exp_amd.models import sample_sphere
+    m, pos, vel = sample_sphere(model, n, seed=seed)
+    pos[:, 2] *= squash              # break spherical symmetry so every (l,m) row is exercised
+    pos[:, 0] += 0.05
+    return m, pos, vel
+
+
+def _run(ctx, g, m, pos, **kw):
+    from exp_amd.runtime import Component, SphereSL
+    f = SphereSL(ctx, g, **kw)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    coef = f.get_coefs()
+    used = f.Used()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot", "pos"))
+    c.close()
+    f.close()
+    return coef, used, out
+
+
+@pytest.mark.parametrize("kind,lmax,nmax,n", [("plummer", 6, 18, 20000), ("nfw", 6, 18, 20000),
+                                              ("plummer", 10, 24, 6000), ("plummer", 2, 10, 3000),
+                                              ("plummer", 0, 5, 1000), ("plummer", 12, 6, 2000),
+                                              ("plummer_log", 4, 8, 3000)])
+def test_coefficients_and_accel_match_oracle(ctx, oracle, kind, lmax, nmax, n):
+    model, g = make_grid(kind, lmax, nmax, 800 if lmax <= 6 else 400)
+    m, pos, _ = _particles(model, n, seed=100 + lmax)
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    c_ref, used_ref = oracle.sph_accumulate(g, prm, pos, m)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, c_ref)
+    coef, used, out = _run(ctx, g, m, pos)
+    assert used == used_ref
+    assert np.array_equal(out["pos"], pos)                 # caller order preserved
+    assert coef_err(coef, c_ref) <= COEF_TOL
+    assert acc_err(out["acc"], a_ref) <= ACC_TOL
+    assert np.abs(out["pot"] - p_ref).max() / np.abs(p_ref).max() <= ACC_TOL
+
+
+def test_edge_particles(ctx, oracle, plummer_s6):
+    """origin, z axis, inside rmin, outside rmax (multipole continuation), first/last cell."""
+    model, g = plummer_s6
+    m, pos, _ = _particles(model, 2000, seed=4)
+    extra = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.5], [0.0, 0.0, -2.0], [1e-4, 0.0, 0.0],
+                      [2e-4, 1e-4, -1e-4], [60.0, 1.0, 2.0], [0.0, 70.0, 0.0], [-80.0, 5.0, -100.0],
+                      [g.rmax * (1 - 1e-12), 0.0, 0.0], [0.0, g.rmin * (1 + 1e-9), 0.0],
+                      [1.2e-3, 0.0, 0.0], [-3.0, 0.0, 0.0], [0.0, -3.0, 0.0]])
+    pos = np.concatenate([pos, extra])
+    m = np.concatenate([m, np.full(len(extra), m[0])])
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    c_ref, used_ref = oracle.sph_accumulate(g, prm, pos, m)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, c_ref)
+    coef, used, out = _run(ctx, g, m, pos)
+    assert used == used_ref
+    assert coef_err(coef, c_ref) <= COEF_TOL
+    # the particle at the origin has |a| ~ 0/0 structure: compare absolutely there
+    scale = np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["acc"] - a_ref).max() <= 1e-9 * scale
+    assert np.abs(out["pot"] - p_ref).max() <= 1e-9 * np.abs(p_ref).max()
+
+
+@pytest.mark.parametrize("flags", [dict(NO_L0=True), dict(NO_L1=True), dict(EVEN_L=True),
+                                   dict(EVEN_M=True), dict(M0_only=True),
+                                   dict(EVEN_L=True, EVEN_M=True, NO_L1=True)])
+def test_flags(ctx, oracle, plummer_small, flags):
+    model, g = plummer_small
+    m, pos, _ = _particles(model, 3000, seed=6)
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax, **flags)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, c_ref)
+    coef, _, out = _run(ctx, g, m, pos, **flags)
+    assert coef_err(coef, c_ref) <= COEF_TOL
+    assert acc_err(out["acc"], a_ref) <= ACC_TOL
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+
+
+def test_scale_center_and_window(ctx, oracle, plummer_small):
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    m, pos, _ = _particles(model, 4000, seed=7)
+    ctr = np.array([0.3, -0.2, 0.1])
+    scale = 1.7
+    prm = oracle.params(scale=scale, rmin=0.05, rmax=20.0)
+    c_ref, used_ref = oracle.sph_accumulate(g, prm, pos, m, center=ctr)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, c_ref, center=ctr)
+    f = SphereSL(ctx, g, scale=scale, rmin=0.05, rmax=20.0)
+    c = Component.from_arrays(ctx, m, pos)
+    c.set_center(ctr)
+    f.determine_coefficients(c)
+    assert f.Used() == used_ref
+    assert coef_err(f.get_coefs(), c_ref) <= COEF_TOL
+    c.zero_acceleration()
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    assert acc_err(out["acc"], a_ref) <= ACC_TOL
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+
+
+def test_empty_and_tiny_components(ctx, oracle, plummer_small):
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    f = SphereSL(ctx, g)
+    c0 = Component(ctx, 0)
+    f.determine_coefficients(c0)
+    assert np.all(f.get_coefs() == 0.0) and f.Used() == 0
+    f.get_acceleration_and_potential(c0)
+    # one particle
+    pos = np.array([[0.3, 0.2, -0.4]])
+    m = np.array([1.0])
+    c1 = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c1)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    assert coef_err(f.get_coefs(), c_ref) <= COEF_TOL
+
+
+def test_set_coefs_roundtrip_and_external_target(ctx, oracle, plummer_small):
+    """set_coefs -> force on ANOTHER component's particles (SetExternal, src/PotAccel.H:215)."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    rng = np.random.default_rng(1)
+    coef = rng.standard_normal(((g.lmax + 1) ** 2, g.nmax))
+    f = SphereSL(ctx, g)
+    f.set_coefs(coef)
+    assert np.array_equal(f.get_coefs(), coef)
+    pos = rng.standard_normal((5000, 3)) * np.array([2.0, 1.0, 0.3])     # unsorted, disk-like
+    tgt = Component.from_arrays(ctx, np.ones(5000), pos)
+    acc0 = rng.standard_normal((5000, 3))
+    pot0 = rng.standard_normal(5000)
+    tgt.upload_acc(acc0, pot0)                                           # acc += semantics
+    f.get_acceleration_and_potential(tgt, external=True)
+    out = tgt.download(("acc", "pot"))
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, coef)
+    assert acc_err(out["acc"] - acc0, a_ref) <= 1e-8
+    assert np.abs(out["pot"] - pot0 - p_ref).max() <= 1e-9 * np.abs(p_ref).max()
+
+
+def test_leapfrog_pieces_bit_exact(ctx, oracle):
+    """incr_position / incr_velocity are single fp64 FMAs-free updates: bit-exact vs the oracle."""
+    from exp_amd.runtime import Component
+    rng = np.random.default_rng(2)
+    n = 10007
+    pos, vel, acc = rng.standard_normal((3, n, 3))
+    c = Component.from_arrays(ctx, np.ones(n), pos, vel)
+    c.upload_acc(acc, np.zeros(n))
+    c.incr_velocity(0.0125)
+    c.incr_position(0.025)
+    out = c.download(("pos", "vel"))
+    v = vel + acc * 0.0125
+    p = pos + v * 0.025
+    assert np.array_equal(out["vel"], v)
+    assert np.array_equal(out["pos"], p)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_kdk_steps_match_oracle(ctx, oracle, plummer_s6, fused):
+    from exp_amd.runtime import Component, SphereSL, do_step_single
+    model, g = plummer_s6
+    m, pos, vel = _particles(model, 8000, seed=9)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    acc, _ = oracle.sph_accel(g, prm, pos, c_ref)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(acc, np.zeros(len(m)))
+    dt = 0.01
+    p, v, a = pos, vel, acc
+    for _ in range(3):
+        p, v, a, pt, cf = oracle.sph_step(g, prm, dt, p, v, a, m)
+        if fused:
+            f.step_kdk(c, dt)
+        else:
+            do_step_single(f, c, dt)
+    out = c.download()
+    assert coef_err(f.get_coefs(), cf) <= COEF_TOL
+    assert np.abs(out["pos"] - p).max() <= 1e-12
+    assert np.abs(out["vel"] - v).max() <= 1e-10
+    assert acc_err(out["acc"], a) <= 1e-8
+    assert np.abs(out["pot"] - pt).max() <= 1e-9 * np.abs(pt).max()
+    assert np.array_equal(out["mass"], m)
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 size (1e7, S6): linearity of the accumulation in the particle set and
+    invariance to particle order -- size-independent properties, no oracle needed."""
+    import torch
+    from exp_amd.runtime import Component, SphereSL
+    model, g = make_grid("nfw", 6, 18, 2000)
+    n = 10_000_000
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    from exp_amd.models import sphere_sampling_tables
+    u_tab, r_tab, _ = sphere_sampling_tables(model, 49.0)
+    u = torch.rand(n, device="cuda", dtype=torch.float64, generator=gen)
+    ut = torch.tensor(u_tab, device="cuda")
+    rt = torch.tensor(r_tab, device="cuda")
+    idx = torch.searchsorted(ut, u).clamp(1, len(u_tab) - 1)
+    w = (u - ut[idx - 1]) / (ut[idx] - ut[idx - 1])
+    r = rt[idx - 1] + w * (rt[idx] - rt[idx - 1])
+    ct = torch.rand(n, device="cuda", dtype=torch.float64, generator=gen) * 2 - 1
+    ph = torch.rand(n, device="cuda", dtype=torch.float64, generator=gen) * 2 * math.pi
+    st = torch.sqrt(1 - ct * ct)
+    x, y, z = (r * st * torch.cos(ph)).contiguous(), (r * st * torch.sin(ph)).contiguous(), (0.8 * r * ct).contiguous()
+    mass = torch.full((n,), 1.0 / n, device="cuda", dtype=torch.float64)
+    torch.cuda.synchronize()
+    f = SphereSL(ctx, g)
+
+    def coefs(sl):
+        k = sl.stop - sl.start
+        c = Component(ctx, k)
+        c.upload_device(mass[sl].contiguous(), x[sl].contiguous(), y[sl].contiguous(),
+                        z[sl].contiguous())
+        f.determine_coefficients(c)
+        out = f.get_coefs()
+        used = f.Used()
+        c.close()
+        return out, used
+
+    c_all, u_all = coefs(slice(0, n))
+    c_a, u_a = coefs(slice(0, 3_500_000))
+    c_b, u_b = coefs(slice(3_500_000, n))
+    assert u_a + u_b == u_all
+    assert coef_err(c_a + c_b, c_all) <= COEF_TOL
+    # order invariance: a random permutation of the same particles
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    c = Component(ctx, n)
+    c.upload_device(mass, x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous())
+    f.determine_coefficients(c)
+    assert coef_err(f.get_coefs(), c_all) <= COEF_TOL
+    # the monopole force of a (nearly) spherical set obeys Newton: |a| r^2 / M(<r) ~ 1
+    c.zero_acceleration()
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pos"))
+    rr = np.linalg.norm(out["pos"], axis=1)
+    sel = (rr > 0.5) & (rr < 5.0)
+    arad = -(out["acc"][sel] * out["pos"][sel]).sum(1) / rr[sel]
+    ratio = arad * rr[sel] ** 2 / model.mass(rr[sel])
+    assert abs(np.median(ratio) - 1.0) < 0.05
+    c.close()
+    f.close()
