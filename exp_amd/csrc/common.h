@@ -83,4 +83,16 @@ struct ProfScope {
 
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
 
+// x + a*b rounded as a separate multiply and add (what the reference's scalar CPU code does).
+// hipcc contracts a*b+c to an FMA by default and HIP's __dmul_rn/__dadd_rn are plain operators;
+// the empty asm makes the product opaque so the two roundings survive.
+#if defined(__HIPCC__)
+__device__ __forceinline__ double mul_then_add(double x, double a, double b)
+{
+  double t = a * b;
+  asm volatile("" : "+v"(t));
+  return x + t;
+}
+#endif
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

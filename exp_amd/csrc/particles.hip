@@ -26,11 +26,10 @@ k_drift(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
   const size_t beg = lev_off[lo], end = lev_off[hi + 1];
   for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
        i += (size_t)gridDim.x * TPB) {
-    // separate multiply and add (no FMA contraction): bit-identical to the reference's
-    // scalar `pos += vel*dt` as compiled for baseline x86-64
-    x[i] = __dadd_rn(x[i], __dmul_rn(vx[i], dt));
-    y[i] = __dadd_rn(y[i], __dmul_rn(vy[i], dt));
-    z[i] = __dadd_rn(z[i], __dmul_rn(vz[i], dt));
+    // separate multiply and add: bit-identical to the reference's scalar `pos += vel*dt`
+    x[i] = mul_then_add(x[i], vx[i], dt);
+    y[i] = mul_then_add(y[i], vy[i], dt);
+    z[i] = mul_then_add(z[i], vz[i], dt);
   }
 }
 
@@ -44,9 +43,9 @@ k_kick(double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz
   const size_t beg = lev_off[lo], end = lev_off[hi + 1];
   for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
        i += (size_t)gridDim.x * TPB) {
-    vx[i] = __dadd_rn(vx[i], __dmul_rn(ax[i], dt));
-    vy[i] = __dadd_rn(vy[i], __dmul_rn(ay[i], dt));
-    vz[i] = __dadd_rn(vz[i], __dmul_rn(az[i], dt));
+    vx[i] = mul_then_add(vx[i], ax[i], dt);
+    vy[i] = mul_then_add(vy[i], ay[i], dt);
+    vz[i] = mul_then_add(vz[i], az[i], dt);
   }
 }
 

@@ -506,10 +506,10 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
     AY[i] = ay;
     AZ[i] = az;
     POT[i] = pt;
-    if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88)
-      VX[i] = __dadd_rn(VX[i], __dmul_rn(ax, dt_kick));
-      VY[i] = __dadd_rn(VY[i], __dmul_rn(ay, dt_kick));
-      VZ[i] = __dadd_rn(VZ[i], __dmul_rn(az, dt_kick));
+    if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
+      VX[i] = mul_then_add(VX[i], ax, dt_kick);
+      VY[i] = mul_then_add(VY[i], ay, dt_kick);
+      VZ[i] = mul_then_add(VZ[i], az, dt_kick);
     }
   }
 }

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into a small, committable summary.
+
+    python tools/summarize_profile.py gpurun_out/prof_r01a profiles/r01a
+
+Writes <out>_kernel_stats.csv (our kernels only, from rocprofv3 --kernel-trace --stats),
+<out>_traffic.json (per-kernel FETCH_SIZE/WRITE_SIZE per launch, raw and calibrated) and updates
+profiles/traffic.json (read by bench.py for roofline.traffic).
+
+HBM counter handling follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are
+collected in separate --pmc passes, are in KiB, and FETCH_SIZE under-reports wide coalesced
+streaming reads on gfx950.  The read-side scale is CALIBRATED on k_kick, whose byte count is
+known exactly (6 fp64 streams read, 3 written, 8-byte lanes like every kernel here)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+OURS = ("k_", "void k_")
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    nbodies = float(sys.argv[3]) if len(sys.argv) > 3 else 1e8
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    # ---- kernel stats -------------------------------------------------------------------
+    rows = []
+    for path in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+        for r in csv.DictReader(open(path)):
+            if r["Name"].startswith(OURS):
+                rows.append(r)
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(out + "_kernel_stats.csv", "w") as f:
+        f.write("kernel,calls,total_ms,avg_ms,min_ms,max_ms\n")
+        for r in rows:
+            f.write(f"{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs'])/1e6:.4f},"
+                    f"{float(r['AverageNs'])/1e6:.4f},{float(r['MinNs'])/1e6:.4f},"
+                    f"{float(r['MaxNs'])/1e6:.4f}\n")
+    # ---- counters -------------------------------------------------------------------------
+    traffic = defaultdict(lambda: defaultdict(list))
+    for which in ("fetch", "write"):
+        for path in glob.glob(os.path.join(src, which, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(path)):
+                if r["Kernel_Name"].startswith(OURS):
+                    traffic[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summ = {}
+    for k, d in traffic.items():
+        ent = {}
+        for c, vals in d.items():
+            # steady state: drop the first launch (first-touch / different data order)
+            v = vals[1:] if len(vals) > 2 else vals
+            ent[c + "_KiB_per_launch"] = sum(v) / len(v)
+            ent[c + "_launches"] = len(vals)
+        summ[k] = ent
+    # calibration on k_kick: reads 48 B/particle, writes 24 B/particle
+    cal_r = cal_w = None
+    if "k_kick" in summ and "FETCH_SIZE_KiB_per_launch" in summ["k_kick"]:
+        cal_r = 48.0 * nbodies / (summ["k_kick"]["FETCH_SIZE_KiB_per_launch"] * 1024.0)
+    if "k_kick" in summ and "WRITE_SIZE_KiB_per_launch" in summ["k_kick"]:
+        cal_w = 24.0 * nbodies / (summ["k_kick"]["WRITE_SIZE_KiB_per_launch"] * 1024.0)
+    for k, ent in summ.items():
+        rd = ent.get("FETCH_SIZE_KiB_per_launch")
+        wr = ent.get("WRITE_SIZE_KiB_per_launch")
+        if rd is not None and wr is not None:
+            ent["hbm_bytes_per_launch_raw"] = (rd + wr) * 1024.0
+            ent["hbm_bytes_per_launch"] = rd * 1024.0 * (cal_r or 1.0) + wr * 1024.0 * (cal_w or 1.0)
+            ent["n_particles"] = int(nbodies)
+    meta = {"read_scale_calibrated_on_k_kick": cal_r, "write_scale_calibrated_on_k_kick": cal_w,
+            "nbodies": nbodies, "source": src}
+    json.dump({"meta": meta, "kernels": summ}, open(out + "_traffic.json", "w"), indent=1)
+    # bench.py lookup table: the split accumulate launches are summed under one name
+    tj = {}
+    acc = [v for k, v in summ.items() if k.startswith("k_sph_accumulate") and "hbm_bytes_per_launch" in v]
+    if acc:
+        tj["k_sph_accumulate"] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in acc),
+                                  "n_particles": int(nbodies)}
+    for k, v in summ.items():
+        if "hbm_bytes_per_launch" in v and not k.startswith("k_sph_accumulate"):
+            base = k.split("<")[0]
+            tj[base] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "n_particles": int(nbodies)}
+    json.dump(tj, open(os.path.join(os.path.dirname(out) or ".", "traffic.json"), "w"), indent=1)
+    print(open(out + "_kernel_stats.csv").read())
+    print(json.dumps(meta))
+    for k, v in sorted(summ.items()):
+        if "hbm_bytes_per_launch" in v:
+            print(f"{k:40s} raw {v['hbm_bytes_per_launch_raw']/1e9:8.3f} GB  calibrated "
+                  f"{v['hbm_bytes_per_launch']/1e9:8.3f} GB  = {v['hbm_bytes_per_launch']/nbodies:7.1f} B/particle")
+
+
+if __name__ == "__main__":
+    main()
