@@ -24,7 +24,3 @@ struct exp_amd_comp {
   double *b(int k) { return arr[1 - cur][k].p; }
 };
 
-// Reorder the store by key[] (values < nkeys).  Keys are (level * ncell + cell); level
-// offsets are refreshed from the scanned histogram.  All work is stream-ordered.
-int expamd_comp_sort_by_key(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell_per_level,
-                            bool move_acc);

@@ -4,15 +4,9 @@
 // thrust level sort), src/cudaIncpos.cu:9-29 (coordDrift) and src/cudaIncvel.cu:9-41
 // (velocityKick).  Layout is fp64 SoA so that every pass streams HBM with coalesced
 // 8-byte-per-lane loads; a level is a contiguous slot range [lev_off[M], lev_off[M+1]).
-#include "particles.h"
+#include "sort_kernels.h"
 
 #define TPB 256
-
-struct ArrSet {
-  double *p[A_NARR];
-  uint32_t *id;
-  uint8_t *lev;
-};
 
 // ---- leapfrog -------------------------------------------------------------------------------
 
@@ -64,31 +58,7 @@ k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict_
   }
 }
 
-// ---- counting sort ---------------------------------------------------------------------------
-// Keys are nearly sorted from the previous step, so a wave holds only a handful of distinct
-// keys: one atomic per distinct key per wave (match-any by ballot) instead of one per lane.
-
-__device__ inline unsigned long long lanemask_lt()
-{
-  return (1ull << (threadIdx.x & 63)) - 1ull;
-}
-
-__global__ void __launch_bounds__(TPB)
-k_hist(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist)
-{
-  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-  bool valid = i < n;
-  uint32_t k = valid ? key[i] : 0xffffffffu;
-  unsigned long long remaining = __ballot(valid);
-  const int lane = threadIdx.x & 63;
-  while (remaining) {
-    int lead = __ffsll((long long)remaining) - 1;
-    uint32_t kk = __shfl(k, lead);
-    unsigned long long m = __ballot(valid && k == kk);
-    if (lane == lead) atomicAdd(&hist[kk], (uint32_t)__popcll(m));
-    remaining &= ~m;
-  }
-}
+// ---- counting sort (pass kernels live in sort_kernels.h) -----------------------------------
 
 // exclusive scan of hist[0..nkeys) in place (single block); hist[nkeys] = total;
 // lev_off[L] = start of key L*ncell, lev_off[nlev] = total
@@ -122,37 +92,6 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
     hist[nkeys] = part[1023];
     lev_off[nlev] = part[1023];
   }
-}
-
-template <bool MOVE_ACC>
-__global__ void __launch_bounds__(TPB)
-k_scatter(const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor, size_t n, ArrSet src,
-          ArrSet dst)
-{
-  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-  bool valid = i < n;
-  uint32_t k = valid ? key[i] : 0xffffffffu;
-  unsigned long long remaining = __ballot(valid);
-  const int lane = threadIdx.x & 63;
-  uint32_t dest = 0;
-  while (remaining) {
-    int lead = __ffsll((long long)remaining) - 1;
-    uint32_t kk = __shfl(k, lead);
-    unsigned long long m = __ballot(valid && k == kk);
-    uint32_t base = 0;
-    if (lane == lead) base = atomicAdd(&cursor[kk], (uint32_t)__popcll(m));
-    base = __shfl(base, lead);
-    if (valid && k == kk) dest = base + (uint32_t)__popcll(m & lanemask_lt());
-    remaining &= ~m;
-  }
-  if (!valid) return;
-#pragma unroll
-  for (int a = 0; a < A_NARR; a++) {
-    if (!MOVE_ACC && a >= A_AX) break;
-    dst.p[a][dest] = src.p[a][i];
-  }
-  dst.id[dest] = src.id[i];
-  dst.lev[dest] = src.lev[i];
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -196,15 +135,6 @@ k_permute_f64(const double *__restrict__ in, const uint32_t *__restrict__ id, si
   if (i < n) out[i] = in[id[i]];
 }
 
-static ArrSet arrset(exp_amd_comp *c, int which)
-{
-  ArrSet s;
-  for (int a = 0; a < A_NARR; a++) s.p[a] = c->arr[which][a].p;
-  s.id = c->id[which].p;
-  s.lev = c->level[which].p;
-  return s;
-}
-
 static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
 {
   size_t want = (n + TPB - 1) / TPB;
@@ -212,32 +142,52 @@ static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
   return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
-int expamd_comp_sort_by_key(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc)
+int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
 {
   exp_amd_ctx *ctx = c->ctx;
-  if (c->n == 0) return EXP_AMD_OK;
   if (c->hist_cap < (size_t)nkeys + 1) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
     c->hist_cap = (size_t)nkeys + 1;
   }
   HIP_TRY(ctx, hipMemsetAsync(c->hist.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), ctx->stream));
-  unsigned g = cdiv(c->n, TPB);
-  {
-    ProfScope ps(ctx, "k_hist");
-    k_hist<<<g, TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
-  }
+  return EXP_AMD_OK;
+}
+
+AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+{
+  AdvanceArgs A;
+  A.x = c->a(A_X); A.y = c->a(A_Y); A.z = c->a(A_Z);
+  A.vx = c->a(A_VX); A.vy = c->a(A_VY); A.vz = c->a(A_VZ);
+  A.ax = c->a(A_AX); A.ay = c->a(A_AY); A.az = c->a(A_AZ);
+  A.lev = c->level[c->cur].p;
+  A.dt_kick = dt_kick; A.dt_drift = dt_drift;
+  A.advance = advance ? 1 : 0;
+  return A;
+}
+
+// after k_key_hist: scan the histogram, scatter (with the same advance) into the other buffer set
+int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
+                            bool advance, double dt_kick, double dt_drift)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
   {
     ProfScope ps(ctx, "k_scan");
     k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels);
   }
   {
-    ProfScope ps(ctx, "k_scatter");
-    ArrSet src = arrset(c, c->cur), dst = arrset(c, 1 - c->cur);
+    ProfScope ps(ctx, "k_scatter_adv");
+    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    ScatterSrc S{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
+    ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
+                 c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
+                 c->level[1 - c->cur].p};
+    const unsigned g = cdiv(c->n, SORT_TILE);
     if (move_acc)
-      k_scatter<true><<<g, TPB, 0, ctx->stream>>>(c->key.p, c->hist.p, c->n, src, dst);
+      k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, c->n, c->key.p, c->hist.p);
     else
-      k_scatter<false><<<g, TPB, 0, ctx->stream>>>(c->key.p, c->hist.p, c->n, src, dst);
+      k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, c->n, c->key.p, c->hist.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   c->cur = 1 - c->cur;

@@ -1,0 +1,158 @@
+// Cell sort of the particle store, fused with the leapfrog advance.
+//
+// Two passes per step (a counting sort needs the full histogram before it can place anything):
+//   pass 1  k_key_hist    : [kick dt/2, drift dt in registers] -> key = (level, basis cell);
+//                           block-private LDS histogram over a key window, then ONE global
+//                           atomic per non-empty bin per block (the store is nearly sorted, so a
+//                           2048-particle block touches a few dozen bins at most)
+//   pass 2  k_scatter_adv : recompute the same advance (bit-identical), reserve a slot range per
+//                           (block, bin) with one global atomic, rank inside the block with LDS
+//                           atomics, write x', v', m, id, level to the sorted slot
+// Nothing is written in place by pass 1, so the advance costs no extra HBM pass.
+#pragma once
+#include "particles.h"
+
+#define SORT_TPB 256
+#define SORT_ITEMS 8
+#define SORT_TILE (SORT_TPB * SORT_ITEMS)
+#define SORT_WIN 4096          // LDS histogram window (bins) above the block's minimum key
+
+struct AdvanceArgs {
+  const double *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az;
+  const uint8_t *lev;
+  double dt_kick, dt_drift;    // 0,0 -> positions are used as they are
+  int advance;
+};
+
+__device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, double &x, double &y,
+                                            double &z, double &vx, double &vy, double &vz)
+{
+  x = A.x[i]; y = A.y[i]; z = A.z[i];
+  if (A.advance) {
+    // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
+    vx = mul_then_add(A.vx[i], A.ax[i], A.dt_kick);
+    vy = mul_then_add(A.vy[i], A.ay[i], A.dt_kick);
+    vz = mul_then_add(A.vz[i], A.az[i], A.dt_kick);
+    x = mul_then_add(x, vx, A.dt_drift);
+    y = mul_then_add(y, vy, A.dt_drift);
+    z = mul_then_add(z, vz, A.dt_drift);
+  }
+}
+
+__device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t *slot)
+{
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
+  if (threadIdx.x == 0) *slot = 0xffffffffu;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) atomicMin(slot, v);
+  __syncthreads();
+  return *slot;
+}
+
+template <class KeyFn>
+__global__ void __launch_bounds__(SORT_TPB)
+k_key_hist(KeyFn kf, AdvanceArgs A, size_t n, uint32_t *__restrict__ key_out,
+           uint32_t *__restrict__ hist)
+{
+  __shared__ uint32_t lh[SORT_WIN];
+  __shared__ uint32_t kmin_s;
+  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  uint32_t k[SORT_ITEMS];
+  uint32_t mn = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
+    k[j] = 0xffffffffu;
+    if (i < n) {
+      double x, y, z, vx, vy, vz;
+      advance_one(A, i, x, y, z, vx, vy, vz);
+      k[j] = kf(x, y, z, A.lev[i]);
+      key_out[i] = k[j];
+      mn = min(mn, k[j]);
+    }
+  }
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
+  const uint32_t kmin = block_min_u32(mn, &kmin_s);     // (also orders the zeroing)
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    if (k[j] == 0xffffffffu) continue;
+    const uint32_t d = k[j] - kmin;
+    if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
+    else atomicAdd(&hist[k[j]], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
+    const uint32_t c = lh[b];
+    if (c) atomicAdd(&hist[kmin + b], c);
+  }
+}
+
+struct ScatterDst {
+  double *x, *y, *z, *vx, *vy, *vz, *m, *ax, *ay, *az, *pot;
+  uint32_t *id;
+  uint8_t *lev;
+};
+
+struct ScatterSrc {
+  const double *m, *ax, *ay, *az, *pot;
+  const uint32_t *id;
+};
+
+template <bool MOVE_ACC>
+__global__ void __launch_bounds__(SORT_TPB)
+k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, size_t n,
+              const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor)
+{
+  __shared__ uint32_t lh[SORT_WIN];       // count, then global base of the (block, bin) range
+  __shared__ uint32_t kmin_s;
+  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  uint32_t k[SORT_ITEMS], rk[SORT_ITEMS];
+  uint32_t mn = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
+    k[j] = (i < n) ? key[i] : 0xffffffffu;
+    mn = min(mn, k[j]);
+  }
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
+  const uint32_t kmin = block_min_u32(mn, &kmin_s);
+  // rank inside (block, bin)
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    rk[j] = 0;
+    if (k[j] == 0xffffffffu) continue;
+    const uint32_t d = k[j] - kmin;
+    if (d < SORT_WIN) rk[j] = atomicAdd(&lh[d], 1u);
+  }
+  __syncthreads();
+  // reserve the global range of every non-empty bin: lh[b] <- base
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
+    const uint32_t c = lh[b];
+    if (c) lh[b] = atomicAdd(&cursor[kmin + b], c);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    if (k[j] == 0xffffffffu) continue;
+    const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
+    const uint32_t d = k[j] - kmin;
+    const uint32_t dest = (d < SORT_WIN) ? lh[d] + rk[j] : atomicAdd(&cursor[k[j]], 1u);
+    double x, y, z, vx = 0, vy = 0, vz = 0;
+    advance_one(A, i, x, y, z, vx, vy, vz);
+    if (!A.advance) { vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i]; }
+    D.x[dest] = x; D.y[dest] = y; D.z[dest] = z;
+    D.vx[dest] = vx; D.vy[dest] = vy; D.vz[dest] = vz;
+    D.m[dest] = S.m[i];
+    D.id[dest] = S.id[i];
+    D.lev[dest] = A.lev[i];
+    if (MOVE_ACC) {
+      D.ax[dest] = S.ax[i]; D.ay[dest] = S.ay[i]; D.az[dest] = S.az[i]; D.pot[dest] = S.pot[i];
+    }
+  }
+}
+
+// host helper (defined in particles.hip): scan + scatter after a k_key_hist launch
+int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
+                            bool advance, double dt_kick, double dt_drift);
+int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys);
+AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift);

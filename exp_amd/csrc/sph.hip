@@ -2,22 +2,22 @@
 // (sort key, moments -> coefficients, coefficients -> projected tables).  The per-particle
 // kernels live in sph_kernels.h and are instantiated per LMAX in sph_inst.hip.
 #include "sph_kernels.h"
+#include "sort_kernels.h"
 
 // ---- sort key -------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256)
-k_sph_key(SphDev S, const double *__restrict__ x, const double *__restrict__ y,
-          const double *__restrict__ z, const uint8_t *__restrict__ lev, size_t n,
-          uint32_t *__restrict__ key)
-{
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double xx = x[i] - S.cx, yy = y[i] - S.cy, zz = z[i] - S.cz;
-  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-  if (r > S.rmax) r = S.rmax;               // force path clamps (SphericalBasis.cc:1555-1560)
-  double xi = sph_r_to_xi(S, r / S.scale);
-  key[i] = (uint32_t)lev[i] * (uint32_t)(S.numr - 1) + (uint32_t)sph_cell(S, xi);
-}
+// key = level * (numr-1) + radial cell of get_pot/get_force (r clamped to rmax like the force path)
+struct SphKeyFn {
+  SphDev S;
+  __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
+  {
+    const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
+    double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+    if (r > S.rmax) r = S.rmax;               // src/SphericalBasis.cc:1555-1560
+    const double xi = sph_r_to_xi(S, r / S.scale);
+    return (uint32_t)lev * (uint32_t)(S.numr - 1) + (uint32_t)sph_cell(S, xi);
+  }
+};
 
 // ---- moments -> coefficients ------------------------------------------------------------------------
 // part[seg][row][n] = sum_{i in seg} E[i][l][n] W[i][row][0] + E[i+1][l][n] W[i][row][1]
@@ -205,20 +205,26 @@ static SphDev dev_for(const exp_amd_force *f, const double center[3])
   return S;
 }
 
-// (level, radial cell) order for this force's tables
-static int sph_sort(exp_amd_force *f, exp_amd_comp *c, bool move_acc)
+// (level, radial cell) order for this force's tables; with `advance` the kick dt_kick and drift
+// dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
+static int sph_sort(exp_amd_force *f, exp_amd_comp *c, bool move_acc, bool advance = false,
+                    double dt_kick = 0.0, double dt_drift = 0.0)
 {
   exp_amd_ctx *ctx = f->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   c->nlevels = f->cfg.multistep + 1;
-  SphDev S = dev_for(f, c->center);
-  {
-    ProfScope ps(ctx, "k_sph_key");
-    k_sph_key<<<cdiv(c->n, 256), 256, 0, ctx->stream>>>(S, c->a(A_X), c->a(A_Y), c->a(A_Z),
-                                                        c->level[c->cur].p, c->n, c->key.p);
-  }
   const uint32_t ncell = (uint32_t)(f->cfg.numr - 1);
-  int rc = expamd_comp_sort_by_key(c, ncell * (uint32_t)c->nlevels, ncell, move_acc);
+  const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
+  int rc = expamd_comp_prepare_hist(c, nkeys);
+  if (rc) return rc;
+  {
+    ProfScope ps(ctx, "k_key_hist");
+    SphKeyFn kf{dev_for(f, c->center)};
+    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    k_key_hist<SphKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n, c->key.p,
+                                                                              c->hist.p);
+  }
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -264,12 +270,12 @@ static int sph_accumulate(exp_amd_force *f, exp_amd_comp *c, double *d_out)
   return EXP_AMD_OK;
 }
 
-extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
+static int sph_determine_coefficients(exp_amd_force *f, exp_amd_comp *c, bool advance,
+                                      double dt_kick, double dt_drift)
 {
-  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
   exp_amd_ctx *ctx = f->ctx;
   f->home = c;
-  int rc = sph_sort(f, c, c->acc_live);
+  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift);
   if (rc) return rc;
   double *dst = f->cfg.multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef : f->d_coef.p;
   if (f->cfg.multistep) {
@@ -283,6 +289,12 @@ extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_co
   if (rc) return rc;
   f->proj_dirty = true;
   return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
+{
+  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
+  return sph_determine_coefficients(f, c, false, 0.0, 0.0);
 }
 
 static int sph_project(exp_amd_force *f)
@@ -421,10 +433,12 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
   if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "step_kdk: NULL");
   if (f->cfg.multistep) return expamd_fail(f->ctx, EXP_AMD_ERR_STATE, "step_kdk: multistep force; drive the sub-steps explicitly");
   int rc;
-  if ((rc = exp_amd_comp_kick(c, 0.5 * dt, -1))) return rc;
-  if ((rc = exp_amd_comp_drift(c, dt, -1))) return rc;
-  c->acc_live = false;               // acc/pot are recomputed below: do not carry them through the sort
-  if ((rc = exp_amd_force_determine_coefficients(f, c))) return rc;
+  // kick dt/2 + drift dt are applied inside the sort passes (no separate HBM pass); acc/pot are
+  // recomputed below, so they are not carried through the reorder
+  c->acc_live = false;
+  if (c->n == 0) {
+    if ((rc = sph_determine_coefficients(f, c, false, 0.0, 0.0))) return rc;
+  } else if ((rc = sph_determine_coefficients(f, c, true, 0.5 * dt, dt))) return rc;
   if ((rc = sph_force(f, c, 0, true, 0.5 * dt))) return rc;
   return EXP_AMD_OK;
 }

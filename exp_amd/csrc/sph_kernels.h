@@ -168,24 +168,17 @@ __device__ __forceinline__ int acc_to_wrow(int j)
 #define ACC_WAVES 4
 #define ACC_CHUNK 1024        // particles per wave (contiguous, so one or two cells per wave)
 
+// One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend).
 template <int LMAX, int MLO, int MHI>
-__global__ void __launch_bounds__(ACC_WAVES * 64)
-k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
-                 const double *__restrict__ Z, const double *__restrict__ M,
-                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ W, unsigned long long *__restrict__ used_out)
+__device__ __forceinline__ void
+sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
+                    const double *__restrict__ Z, const double *__restrict__ M, size_t cbeg,
+                    size_t cend, double *scratch, double *__restrict__ W,
+                    unsigned long long *__restrict__ used_out)
 {
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
-  __shared__ double scratch_all[ACC_WAVES][16 * FLUSH_STRIDE];
-
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  double *scratch = scratch_all[wave];
-  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  const size_t cbeg = beg + ((size_t)blockIdx.x * ACC_WAVES + wave) * ACC_CHUNK;
-  if (cbeg >= end) return;
-  const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
 
   cdp fact = (cdp)S.fact;
   const double fac0 = -4.0 * M_PI;
@@ -298,6 +291,48 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
     if (lane == 0 && used) atomicAdd(used_out, used);
   }
+}
+
+// m-range splits of the rows (keep 2 moment accumulators per real row in registers).  The waves
+// of a block take the SAME particle chunk and one split each, so the chunk is fetched from HBM
+// once and re-read from L1/L2 by the other splits.
+template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
+{
+  return LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
+}
+
+template <int LMAX>
+__global__ void __launch_bounds__(ACC_WAVES * 64)
+k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
+                 const double *__restrict__ Z, const double *__restrict__ M,
+                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
+                 double *__restrict__ W, unsigned long long *__restrict__ used_out)
+{
+  constexpr int NS = acc_nsplit<LMAX>();
+  constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;      // chunks per block
+  __shared__ double scratch_all[ACC_WAVES][16 * FLUSH_STRIDE];
+  const int wave = threadIdx.x >> 6;
+  double *scratch = scratch_all[wave];
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const int split = (NS <= ACC_WAVES) ? wave % NS : (int)(blockIdx.y * ACC_WAVES + wave);
+  const size_t chunk = (NS <= ACC_WAVES) ? (size_t)blockIdx.x * CPB + wave / NS : blockIdx.x;
+  if (split >= NS) return;
+  const size_t cbeg = beg + chunk * ACC_CHUNK;
+  if (cbeg >= end) return;
+  const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, cbeg, cend, scratch, W, used_out)
+  if constexpr (LMAX <= 4) {
+    RUN(0, LMAX);
+  } else if constexpr (LMAX <= 7) {
+    if (split == 0) RUN(0, 1); else RUN(2, LMAX);
+  } else if constexpr (LMAX <= 10) {
+    if (split == 0) RUN(0, 1); else if (split == 1) RUN(2, 3); else if (split == 2) RUN(4, 6);
+    else RUN(7, LMAX);
+  } else {
+    if (split == 0) RUN(0, 0); else if (split == 1) RUN(1, 1); else if (split == 2) RUN(2, 3);
+    else if (split == 3) RUN(4, 5); else if (split == 4) RUN(6, 8); else RUN(9, LMAX);
+  }
+#undef RUN
 }
 
 // ---- force ------------------------------------------------------------------------------------------------
