@@ -30,6 +30,14 @@ class SphConfig(ctypes.Structure):
                 ("M0_only", c_int), ("multistep", c_int)]
 
 
+class CylConfig(ctypes.Structure):
+    """exp_amd_cyl_config (include/exp_amd.h)"""
+    _fields_ = [("mmax", c_int), ("nmax", c_int), ("numx", c_int), ("numy", c_int),
+                ("cmapr", c_int), ("cmapz", c_int), ("ascale", c_double), ("hscale", c_double),
+                ("rtable", c_double), ("xmin", c_double), ("dx", c_double), ("ymin", c_double),
+                ("dy", c_double), ("rcylmax", c_double), ("EVEN_M", c_int), ("multistep", c_int)]
+
+
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_size_t, c_void_p, c_void_p)
 
 # name -> (restype, argtypes); every symbol the header declares
@@ -65,6 +73,10 @@ SIGNATURES = {
     "exp_amd_force_get_coefs": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_force_set_coefs": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_force_ncoef": (c_size_t, [c_void_p]),
+    "exp_amd_force_get_level_coefs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "exp_amd_cyl_create": (c_int, [c_void_p, POINTER(CylConfig), c_void_p, POINTER(c_void_p)]),
+    "exp_amd_cyl_get_cylmass": (c_int, [c_void_p, POINTER(c_double)]),
+    "exp_amd_cyl_set_cylmass": (c_int, [c_void_p, c_double]),
     "exp_amd_force_used": (c_int, [c_void_p, POINTER(c_longlong)]),
     "exp_amd_force_get_acceleration": (c_int, [c_void_p, c_void_p, c_int]),
     "exp_amd_force_multistep_reset": (c_int, [c_void_p]),

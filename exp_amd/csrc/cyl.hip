@@ -1,0 +1,609 @@
+// Cylindrical BFE force method (cylinder / EmpCylSL) for gfx950, from scratch.
+//
+// Reference per particle (CPU): EmpCylSL::accumulate -> get_pot (exputil/EmpCylSL.cc:4049-4146,
+// :5557-5631) bilinearly interpolates potC/potS[m][n] at the particle's (X,Y) cell for every (m,n)
+// (4 x 156 table reads at mmax 6, nmax 12); accumulated_eval (:5256-5410) interpolates six
+// tables per (m,n) (4 x 468 reads).  The interpolation is LINEAR in the four corner values of the
+// cell, so the n-sum commutes with the particle sum exactly as in the spherical case:
+//
+//   accumulate : Wn[node][j] += -4pi m trig_j(phi) c_k      node = corner k of the particle's cell,
+//                                                           trig_j = cos(m phi) | sin(m phi)
+//                cos[m][n]    = sum_node potC[m][n][node] Wn[node][cos m]          (once per step)
+//   force      : TF[node][m]  = { sum_n cos[m][n] {potC,rforceC,zforceC}[m][n][node],
+//                                 sum_n sin[m][n] {potS,rforceS,zforceS}[m][n][node] }   (once)
+//                p, fr, fz, fp from the bilinear blend of 3(2 mmax+1) node values   (per particle)
+//
+// Particles are kept sorted by (X,Y) cell, so a wave shares its four corner rows (scalar loads) and
+// its 4(2 mmax+1) moment sums stay in registers until the cell changes.
+#include "sort_kernels.h"
+#include "force.h"
+
+#include <type_traits>
+
+#define DSMALL 1.0e-16        // src/expand.H:130
+#define CYL_MAX_M 12
+
+typedef const __attribute__((address_space(4))) double *cdp;
+
+struct CylDev {
+  int mmax, nmax, numx, numy, cmapr, cmapz, EVEN_M, ntrig;
+  double ascale, hscale, rtable, xmin, dx, ymin, dy, rmax2;
+  double cx, cy, cz;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void cstatic_for(F &&f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    cstatic_for<I + 1, N>(f);
+  }
+}
+
+// exputil/EmpCylSL.cc:6446-6463
+__device__ __forceinline__ double cyl_r_to_xi(const CylDev &C, double r)
+{
+  return C.cmapr > 0 ? (r / C.ascale - 1.0) / (r / C.ascale + 1.0) : r;
+}
+
+// exputil/EmpCylSL.cc:7109-7117
+__device__ __forceinline__ double cyl_z_to_y(const CylDev &C, double z)
+{
+  if (C.cmapz == 1) return z / (fabs(z) + 2.2250738585072014e-308) * asinh(fabs(z / C.hscale));
+  if (C.cmapz == 2) return z / sqrt(z * z + C.hscale * C.hscale);
+  return z;
+}
+
+// cell and bilinear weights (exputil/EmpCylSL.cc:5567-5597 == :5280-5314), enforce_limits false
+__device__ __forceinline__ void cyl_weights(const CylDev &C, double r, double z, int &ix, int &iy,
+                                            double &c00, double &c10, double &c01, double &c11)
+{
+  const double X = (cyl_r_to_xi(C, r) - C.xmin) / C.dx;
+  const double Y = (cyl_z_to_y(C, z) - C.ymin) / C.dy;
+  ix = (int)X;
+  iy = (int)Y;
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix >= C.numx) ix = C.numx - 1;
+  if (iy >= C.numy) iy = C.numy - 1;
+  const double delx0 = (double)ix + 1.0 - X, dely0 = (double)iy + 1.0 - Y;
+  const double delx1 = X - (double)ix, dely1 = Y - (double)iy;
+  c00 = delx0 * dely0;
+  c10 = delx1 * dely0;
+  c01 = delx0 * dely1;
+  c11 = delx1 * dely1;
+}
+
+// sort key: level * (ncell+1) + cell, cell = ix*numy + iy; off-grid particles share bin ncell
+struct CylKeyFn {
+  CylDev C;
+  __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
+  {
+    const double xx = x - C.cx, yy = y - C.cy, zz = z - C.cz;
+    const double r2 = xx * xx + yy * yy;
+    const double r = sqrt(r2);
+    const uint32_t ncell = (uint32_t)(C.numx * C.numy);
+    uint32_t cell = ncell;
+    if (!(sqrt(r2 + zz * zz) / C.ascale > C.rtable)) {
+      int ix, iy;
+      double a, b, c, d;
+      cyl_weights(C, r, zz, ix, iy, a, b, c, d);
+      cell = (uint32_t)(ix * C.numy + iy);
+    }
+    return (uint32_t)lev * (ncell + 1u) + cell;
+  }
+};
+
+// ---- accumulation ----------------------------------------------------------------------------------
+
+#define CFLUSH_STRIDE 68
+#define CACC_WAVES 4
+#define CACC_CHUNK 1024
+
+// reduce NV per-lane values over the wave and atomically add value j to dst[map(j)]
+template <int NV, class MapFn>
+__device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch, double *dst,
+                                               MapFn map)
+{
+  const int lane = threadIdx.x & 63;
+  const int kk = lane >> 2, q = lane & 3;
+  cstatic_for<0, (NV + 15) / 16>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    cstatic_for<0, 16>([&](auto jc) {
+      constexpr int j = g * 16 + decltype(jc)::value;
+      if constexpr (j < NV) scratch[decltype(jc)::value * CFLUSH_STRIDE + lane] = v[j];
+    });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0;
+    if (g * 16 + kk < NV) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) s += scratch[kk * CFLUSH_STRIDE + q + 4 * e];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q == 0 && g * 16 + kk < NV && s != 0.0) unsafeAtomicAdd(dst + map(g * 16 + kk), s);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  });
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = 0.0;
+}
+
+// Wn[node][ntrig]: trig slot 0 = m0, 2m-1 = cos m, 2m = sin m
+template <int MMAX>
+__global__ void __launch_bounds__(CACC_WAVES * 64)
+k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
+                 const double *__restrict__ Z, const double *__restrict__ M,
+                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
+                 double *__restrict__ Wn, double *__restrict__ tail)
+{
+  constexpr int NT = 2 * MMAX + 1;
+  constexpr int NV = 4 * NT;
+  __shared__ double scratch_all[CACC_WAVES][16 * CFLUSH_STRIDE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *scratch = scratch_all[wave];
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const size_t cbeg = beg + ((size_t)blockIdx.x * CACC_WAVES + wave) * CACC_CHUNK;
+  if (cbeg >= end) return;
+  const size_t cend = (cbeg + CACC_CHUNK < end) ? cbeg + CACC_CHUNK : end;
+  const double norm = -4.0 * M_PI;
+  const int nyp = C.numy + 1;
+
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) acc[j] = 0.0;
+  int cur = -1;
+  double mass_used = 0.0, n_used = 0.0;
+
+  auto flush = [&](int cell) {
+    const int ix = cell / C.numy, iy = cell - ix * C.numy;
+    double *base = Wn + ((size_t)ix * nyp + iy) * NT;
+    cyl_wave_flush<NV>(acc, scratch, base, [&](int j) {
+      const int k = j / NT, t = j - k * NT;                // corner k: 0=00, 1=10, 2=01, 3=11
+      return (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT + t;
+    });
+  };
+
+  for (size_t base = cbeg; base < cend; base += 64) {
+    const size_t i = base + lane;
+    const bool valid = i < cend;
+    double xx = 1, yy = 0, zz = 0, mass = 0;
+    if (valid) {
+      xx = X[i] - C.cx;
+      yy = Y[i] - C.cy;
+      zz = Z[i] - C.cz;
+      mass = M[i];
+    }
+    // src/Cylinder.cc:853-866
+    const double r2 = xx * xx + yy * yy;
+    const double r = sqrt(r2);
+    const bool incut = valid && (r2 + zz * zz) < C.rmax2;
+    if (incut) { mass_used += mass; n_used += 1.0; }
+    // EmpCylSL::accumulate (:4062-4063)
+    const double rr = sqrt(r * r + zz * zz);
+    const bool ongrid = incut && !(rr / C.ascale > C.rtable);
+    double zc = zz;                                         // get_pot z clamp (:5563-5564)
+    if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
+    if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+    int ix, iy;
+    double c00, c10, c01, c11;
+    cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
+    const int cell = ix * C.numy + iy;
+    double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
+    if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
+    const double t0 = ongrid ? norm * mass : 0.0;
+
+    unsigned long long remaining = __ballot(ongrid);
+    while (remaining) {
+      const int lead = __ffsll((long long)remaining) - 1;
+      const int c = __shfl(cell, lead);
+      const bool sel = ongrid && cell == c;
+      if (c != cur) {
+        if (cur >= 0) flush(cur);
+        cur = c;
+      }
+      const double t = sel ? t0 : 0.0;
+      const double w0 = t * c00, w1 = t * c10, w2 = t * c01, w3 = t * c11;
+      double cm = 1.0, sm = 0.0;
+      cstatic_for<0, MMAX + 1>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m > 0) {
+          const double cn = cm * cphi - sm * sphi;          // cos(m phi), sin(m phi)
+          const double sn = sm * cphi + cm * sphi;
+          cm = cn; sm = sn;
+        }
+        const bool on = !(C.EVEN_M && (m & 1));             // get_pot skips odd m (:5601)
+        if (on) {
+          constexpr int jc = (m == 0) ? 0 : 2 * m - 1;
+          acc[0 * NT + jc] = fma(w0, cm, acc[0 * NT + jc]);
+          acc[1 * NT + jc] = fma(w1, cm, acc[1 * NT + jc]);
+          acc[2 * NT + jc] = fma(w2, cm, acc[2 * NT + jc]);
+          acc[3 * NT + jc] = fma(w3, cm, acc[3 * NT + jc]);
+          if constexpr (m > 0) {
+            acc[0 * NT + jc + 1] = fma(w0, sm, acc[0 * NT + jc + 1]);
+            acc[1 * NT + jc + 1] = fma(w1, sm, acc[1 * NT + jc + 1]);
+            acc[2 * NT + jc + 1] = fma(w2, sm, acc[2 * NT + jc + 1]);
+            acc[3 * NT + jc + 1] = fma(w3, sm, acc[3 * NT + jc + 1]);
+          }
+        }
+      });
+      remaining &= ~__ballot(sel);
+    }
+  }
+  if (cur >= 0) flush(cur);
+  for (int off = 32; off > 0; off >>= 1) {
+    mass_used += __shfl_xor(mass_used, off);
+    n_used += __shfl_xor(n_used, off);
+  }
+  if (lane == 0 && n_used > 0.0) {
+    unsafeAtomicAdd(tail + 0, mass_used);
+    unsafeAtomicAdd(tail + 1, n_used);
+  }
+}
+
+// ---- moments -> coefficients -----------------------------------------------------------------------------
+// out[cs][m][n] = sum_node tab[cs ? 3 : 0][m][n][node] * Wn[node][trig(m, cs)]
+__global__ void __launch_bounds__(256)
+k_cyl_contract(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
+               double *__restrict__ out)
+{
+  const int n = blockIdx.x, m = blockIdx.y, cs = blockIdx.z;
+  __shared__ double red[256];
+  const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
+  double s = 0.0;
+  if (!(cs == 1 && m == 0)) {
+    const int t = (m == 0) ? 0 : 2 * m - 1 + cs;
+    const double *T = tab + ((((size_t)(cs ? 3 : 0)) * (C.mmax + 1) + m) * C.nmax + n) * nnode;
+    for (size_t k = threadIdx.x; k < nnode; k += 256) s = fma(T[k], Wn[k * C.ntrig + t], s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[((size_t)cs * (C.mmax + 1) + m) * C.nmax + n] = red[0];
+}
+
+// ---- coefficients -> projected node table ----------------------------------------------------------------
+// TF[node][3*ntrig]: for m = 0: {Pc, Rc, Zc}; for m >= 1 at 3 + 6(m-1): {Pc, Rc, Zc, Ps, Rs, Zs}
+__global__ void __launch_bounds__(256)
+k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict__ coef,
+              double *__restrict__ TF)
+{
+  const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
+  const size_t node = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (node >= nnode) return;
+  const int m = blockIdx.y;
+  const int NF = 3 * C.ntrig;
+  const int q0 = (m == 0) ? 0 : 3 + 6 * (m - 1);
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  for (int kind = 0; kind < (m == 0 ? 3 : 6); kind++) {
+    const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
+    const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
+    double s = 0.0;
+    for (int n = 0; n < C.nmax; n++) s = fma(T[(size_t)n * nnode], c[n], s);
+    TF[node * NF + q0 + kind] = s;
+  }
+}
+
+// ---- force -------------------------------------------------------------------------------------------------
+
+struct CylOut { double p, fr, fz, fp; };
+
+template <int MMAX, class PT>
+__device__ __forceinline__ CylOut cyl_field(const CylDev &C, PT t00, PT t10, PT t01, PT t11,
+                                            double c00, double c10, double c01, double c11,
+                                            double cphi, double sphi)
+{
+  CylOut o{0.0, 0.0, 0.0, 0.0};
+  double cm = 1.0, sm = 0.0;
+  cstatic_for<0, MMAX + 1>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    if constexpr (m > 0) {
+      const double cn = cm * cphi - sm * sphi;
+      const double sn = sm * cphi + cm * sphi;
+      cm = cn; sm = sn;
+    }
+    const bool on = !(C.EVEN_M && (m & 1));        // exputil/EmpCylSL.cc:5318-5319
+    if (on) {
+      constexpr int q = (m == 0) ? 0 : 3 + 6 * (m - 1);
+      auto bl = [&](int k) {
+        return c00 * t00[q + k] + c10 * t10[q + k] + c01 * t01[q + k] + c11 * t11[q + k];
+      };
+      const double Pc = bl(0), Rc = bl(1), Zc = bl(2);
+      if constexpr (m == 0) {
+        o.p += Pc;
+        o.fr += Rc;
+        o.fz += Zc;
+      } else {
+        const double Ps = bl(3), Rs = bl(4), Zs = bl(5);
+        o.p += Pc * cm + Ps * sm;
+        o.fr += Rc * cm + Rs * sm;
+        o.fz += Zc * cm + Zs * sm;
+        o.fp += (Pc * sm - Ps * cm) * m;
+      }
+    }
+  });
+  return o;
+}
+
+template <int MMAX>
+__global__ void __launch_bounds__(256)
+k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
+            const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
+            int lev_hi, const double *__restrict__ TF, const double *__restrict__ cylmass_p,
+            double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
+            double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
+            double *__restrict__ VZ, double dt_kick, int assign)
+{
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const int lane = threadIdx.x & 63;
+  const size_t base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+  if (base >= end) return;
+  const size_t i = base + lane;
+  const bool valid = i < end;
+  double xx = 1, yy = 0, zz = 0;
+  if (valid) {
+    xx = X[i] - C.cx;
+    yy = Y[i] - C.cy;
+    zz = Z[i] - C.cz;
+  }
+  // src/Cylinder.cc:1357-1381
+  const double ratmin = 0.75, maxerf = 3.0;
+  const double midpt = ratmin + 0.5 * (1.0 - ratmin);
+  const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
+  double R2 = C.ascale * C.rtable;
+  R2 = R2 * R2;
+  const double r2 = xx * xx + yy * yy;
+  const double r = sqrt(r2) + DSMALL;
+  double cphi = 1.0, sphi = 0.0;
+  if (r2 > 0.0) { const double rp = sqrt(r2); cphi = xx / rp; sphi = yy / rp; }
+  const double ratio = sqrt((r2 + zz * zz) / R2);
+  double frac, cfrac;
+  if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
+  else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
+  else { cfrac = 0.0; frac = 1.0; }
+
+  // accumulated_eval (exputil/EmpCylSL.cc:5272-5314): off grid -> zeros
+  const double rr = sqrt(r * r + zz * zz);
+  const bool ongrid = valid && ratio < 1.0 && !(rr / C.ascale > C.rtable);
+  int ix, iy;
+  double c00, c10, c01, c11;
+  cyl_weights(C, r, zz, ix, iy, c00, c10, c01, c11);
+  int cell = ix * C.numy + iy;
+  const int cell_u = __builtin_amdgcn_readfirstlane(cell);
+  if (!ongrid) cell = cell_u;
+  const bool uniform = __all(cell == cell_u);
+  const int NF = 3 * (2 * MMAX + 1);
+  const int nyp = C.numy + 1;
+  CylOut o{0.0, 0.0, 0.0, 0.0};
+  if (__any(ongrid)) {
+    if (uniform) {
+      const int ux = cell_u / C.numy, uy = cell_u - ux * C.numy;
+      cdp t00 = (cdp)(TF + ((size_t)ux * nyp + uy) * NF);
+      cdp t01 = t00 + NF, t10 = t00 + (size_t)nyp * NF, t11 = t10 + NF;
+      o = cyl_field<MMAX>(C, t00, t10, t01, t11, c00, c10, c01, c11, cphi, sphi);
+    } else {
+      const double *t00 = TF + ((size_t)ix * nyp + iy) * NF;
+      const double *t01 = t00 + NF, *t10 = t00 + (size_t)nyp * NF, *t11 = t10 + NF;
+      o = cyl_field<MMAX>(C, t00, t10, t01, t11, c00, c10, c01, c11, cphi, sphi);
+    }
+  }
+  if (!valid) return;
+
+  double fx = 0.0, fy = 0.0, fz = 0.0, pa = 0.0;
+  if (ratio < 1.0) {
+    double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
+    if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
+    fx = (fr * xx / r - fp * yy / r2) * frac;      // src/Cylinder.cc:1387-1390
+    fy = (fr * yy / r + fp * xx / r2) * frac;
+    fz = fzz * frac;
+    pa = p * frac;
+  }
+  if (ratio > ratmin) {                             // monopole blend, src/Cylinder.cc:1398-1408
+    const double r3 = r2 + zz * zz;
+    const double p = -(*cylmass_p) / sqrt(r3);
+    const double fr = p / r3;
+    fx += xx * fr * cfrac;
+    fy += yy * fr * cfrac;
+    fz += zz * fr * cfrac;
+    pa += p * cfrac;
+  }
+  if (!assign) {
+    fx += AX[i];
+    fy += AY[i];
+    fz += AZ[i];
+    pa += POT[i];
+  }
+  AX[i] = fx;
+  AY[i] = fy;
+  AZ[i] = fz;
+  POT[i] = pa;
+  if (dt_kick != 0.0) {
+    VX[i] = mul_then_add(VX[i], fx, dt_kick);
+    VY[i] = mul_then_add(VY[i], fy, dt_kick);
+    VZ[i] = mul_then_add(VZ[i], fz, dt_kick);
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+
+struct CylForce : exp_amd_force {
+  exp_amd_cyl_config cfg{};
+  CylDev dev{};
+  DevBuf<double> d_tab, d_Wn, d_TF;
+  size_t nnode = 0;
+
+  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
+  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
+  void release() override { d_tab.release(); d_Wn.release(); d_TF.release(); }
+  int get_used(long long *used) override
+  {
+    double u = 0.0;
+    HIP_TRY(ctx, hipMemcpyAsync(&u, d_coef.p + ncoef + 1, sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *used = (long long)(u + 0.5);
+    return EXP_AMD_OK;
+  }
+};
+
+static CylDev cdev_for(const CylForce *f, const double center[3])
+{
+  CylDev C = f->dev;
+  C.cx = center[0]; C.cy = center[1]; C.cz = center[2];
+  return C;
+}
+
+extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
+                                  exp_amd_force **out)
+{
+  if (!ctx || !cfg || !tab || !out) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_create: NULL argument");
+  if (cfg->mmax < 0 || cfg->mmax > CYL_MAX_M || cfg->nmax < 1 || cfg->numx < 1 || cfg->numy < 1 ||
+      cfg->multistep < 0 || cfg->multistep > 16)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_create: bad mmax/nmax/numx/numy/multistep");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  CylForce *f = new CylForce;
+  f->ctx = ctx;
+  f->cfg = *cfg;
+  const int M = cfg->mmax, N = cfg->nmax;
+  f->nnode = (size_t)(cfg->numx + 1) * (cfg->numy + 1);
+  const size_t ntab = (size_t)6 * (M + 1) * N * f->nnode;
+  const int ntrig = 2 * M + 1;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(f->d_tab.alloc(ntab));
+  A(f->d_Wn.alloc(f->nnode * ntrig));
+  A(f->d_TF.alloc(f->nnode * 3 * ntrig));
+  // coefficient buffer: cos block, sin block, then {cylmass, used} riding through the all-reduce
+  if (e == hipSuccess && f->alloc_common((size_t)2 * (M + 1) * N, cfg->multistep, 2) != EXP_AMD_OK)
+    e = hipErrorOutOfMemory;
+  if (e != hipSuccess) {
+    exp_amd_force_destroy(f);
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_create: hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  HIP_TRY(ctx, hipMemcpy(f->d_tab.p, tab, ntab * sizeof(double), hipMemcpyHostToDevice));
+  CylDev &C = f->dev;
+  C.mmax = M; C.nmax = N; C.numx = cfg->numx; C.numy = cfg->numy; C.cmapr = cfg->cmapr;
+  C.cmapz = cfg->cmapz; C.EVEN_M = cfg->EVEN_M; C.ntrig = ntrig;
+  C.ascale = cfg->ascale; C.hscale = cfg->hscale; C.rtable = cfg->rtable;
+  C.xmin = cfg->xmin; C.dx = cfg->dx; C.ymin = cfg->ymin; C.dy = cfg->dy;
+  C.rmax2 = cfg->rcylmax * cfg->rcylmax * cfg->ascale * cfg->ascale;   // src/Cylinder.cc:752
+  C.cx = C.cy = C.cz = 0.0;
+  *out = f;
+  return EXP_AMD_OK;
+}
+
+#define MMAX_DISPATCH(M, CALL)                                                        \
+  switch (M) {                                                                        \
+    case 0: CALL(0); break;  case 1: CALL(1); break;  case 2: CALL(2); break;        \
+    case 3: CALL(3); break;  case 4: CALL(4); break;  case 5: CALL(5); break;        \
+    case 6: CALL(6); break;  case 7: CALL(7); break;  case 8: CALL(8); break;        \
+    case 9: CALL(9); break;  case 10: CALL(10); break; case 11: CALL(11); break;     \
+    case 12: CALL(12); break;                                                        \
+  }
+
+int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+{
+  CylForce *f = this;
+  f->home = c;
+  const CylDev C = cdev_for(f, c->center);
+  // ---- sort by (level, cell) --------------------------------------------------------------------
+  if (c->n) {
+    c->nlevels = f->multistep + 1;
+    const uint32_t ncell = (uint32_t)(cfg.numx * cfg.numy) + 1u;
+    const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
+    int rc = expamd_comp_prepare_hist(c, nkeys);
+    if (rc) return rc;
+    {
+      ProfScope ps(ctx, "k_key_hist");
+      CylKeyFn kf{C};
+      AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+      k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n,
+                                                                                c->key.p, c->hist.p);
+    }
+    rc = expamd_comp_finish_sort(c, nkeys, ncell, c->acc_live, advance, dt_kick, dt_drift);
+    if (rc) return rc;
+    c->sorted_for = f;
+  }
+  // ---- accumulate ----------------------------------------------------------------------------------
+  double *dst = f->multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef_dev : f->d_coef.p;
+  if (f->multistep)   // L <- N of this level (exputil/EmpCylSL.cc:1867 setup_accumulation swap)
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)f->mlevel * f->ncoef_dev, dst,
+                                f->ncoef_dev * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->d_Wn.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(dst + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
+  const int lo = f->multistep ? f->mlevel : 0, hi = lo;
+  if (c->n) {
+    ProfScope ps(ctx, "k_cyl_accumulate");
+    const unsigned grid = cdiv(c->n, (size_t)CACC_WAVES * CACC_CHUNK);
+#define CALL(MM)                                                                                 \
+  k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  }
+  {
+    ProfScope ps(ctx, "k_cyl_contract");
+    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2), 256, 0, ctx->stream>>>(C, f->d_tab.p,
+                                                                               f->d_Wn.p, dst);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  int rc = expamd_allreduce(ctx, dst, f->ncoef_dev);
+  if (rc) return rc;
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick)
+{
+  CylForce *f = this;
+  if (f->proj_dirty) {
+    ProfScope ps(ctx, "k_cyl_project");
+    k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(
+        f->dev, f->d_tab.p, f->d_coef.p, f->d_TF.p);
+    HIP_TRY(ctx, hipGetLastError());
+    f->proj_dirty = false;
+  }
+  if (t->n == 0) return EXP_AMD_OK;
+  const double *ctr = (external && f->home) ? f->home->center : t->center;
+  const CylDev C = cdev_for(f, ctr);
+  const int lo = (t->nlevels > 1) ? f->mlevel : 0;
+  const int hi = t->nlevels - 1;
+  {
+    ProfScope ps(ctx, "k_cyl_force");
+    const unsigned grid = cdiv(t->n, 256);
+#define CALL(MM)                                                                                  \
+  k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
+      C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_coef.p + f->ncoef, \
+      t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
+      dt_kick, assign ? 1 : 0)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  t->acc_live = true;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_cyl_get_cylmass(exp_amd_force *fb, double *mass)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f || !mass) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "get_cylmass: not a cylinder force");
+  HIP_TRY(f->ctx, hipMemcpyAsync(mass, f->d_coef.p + f->ncoef, sizeof(double), hipMemcpyDeviceToHost,
+                                 f->ctx->stream));
+  HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_cyl_set_cylmass(exp_amd_force *fb, double mass)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_cylmass: not a cylinder force");
+  HIP_TRY(f->ctx, hipMemcpyAsync(f->d_coef.p + f->ncoef, &mass, sizeof(double), hipMemcpyHostToDevice,
+                                 f->ctx->stream));
+  HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  return EXP_AMD_OK;
+}

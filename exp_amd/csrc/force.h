@@ -1,0 +1,32 @@
+// Common part of every force method (sphereSL, cylinder): coefficient buffers, multistep level
+// bookkeeping and the generic half of the C ABI (force_api.hip dispatches through the virtuals).
+#pragma once
+#include "particles.h"
+
+struct exp_amd_force {
+  exp_amd_ctx *ctx = nullptr;
+  int multistep = 0;
+  size_t ncoef = 0;                 // coefficients visible through the ABI
+  size_t ncoef_dev = 0;             // device stride of one set (ncoef + tail riding the all-reduce)
+  DevBuf<double> d_coef;            // current expansion coefficients (expcoef / accum_cos|sin)
+  DevBuf<double> d_coefN, d_coefL;  // per-level new / last sets  (src/SphericalBasis.cc:785-792)
+  DevBuf<double> d_scratch;         // >= 64 doubles of scratch for small host->device parameters
+  DevBuf<unsigned long long> d_used;
+  int mlevel = 0;
+  bool proj_dirty = true;           // projected force tables are stale w.r.t. d_coef
+  exp_amd_comp *home = nullptr;     // component whose particles define the expansion centre
+
+  virtual ~exp_amd_force() {}
+  // sort `c` into this basis' cell order (optionally applying kick+drift on the way), accumulate
+  // the particles of the current level into the coefficient set, all-reduce
+  virtual int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick,
+                                     double dt_drift) = 0;
+  // acc (+)= force, pot (+)= potential on the particles of levels >= mlevel of `t`
+  virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) = 0;
+  virtual void release() = 0;
+
+  virtual int get_used(long long *used);
+
+  int alloc_common(size_t ncoef_, int multistep_, size_t tail = 0);
+  void release_common();
+};

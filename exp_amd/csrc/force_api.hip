@@ -1,0 +1,184 @@
+// Generic half of the C ABI: everything that is the same for every force method.
+#include "force.h"
+
+#include <vector>
+
+int exp_amd_force::alloc_common(size_t ncoef_, int multistep_, size_t tail)
+{
+  ncoef = ncoef_;
+  ncoef_dev = ncoef_ + tail;
+  multistep = multistep_;
+  const int nlev = multistep + 1;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(d_coef.alloc(ncoef_dev));
+  A(d_coefN.alloc((size_t)nlev * ncoef_dev));
+  A(d_coefL.alloc((size_t)nlev * ncoef_dev));
+  A(d_scratch.alloc(256));
+  A(d_used.alloc(4));
+  if (e != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "force: hipMalloc failed: %s", hipGetErrorString(e));
+  HIP_TRY(ctx, hipMemset(d_coef.p, 0, d_coef.bytes()));
+  HIP_TRY(ctx, hipMemset(d_coefN.p, 0, d_coefN.bytes()));
+  HIP_TRY(ctx, hipMemset(d_coefL.p, 0, d_coefL.bytes()));
+  HIP_TRY(ctx, hipMemset(d_used.p, 0, d_used.bytes()));
+  return EXP_AMD_OK;
+}
+
+void exp_amd_force::release_common()
+{
+  d_coef.release(); d_coefN.release(); d_coefL.release(); d_scratch.release(); d_used.release();
+}
+
+extern "C" void exp_amd_force_destroy(exp_amd_force *f)
+{
+  if (!f) return;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  f->release();
+  f->release_common();
+  delete f;
+}
+
+extern "C" size_t exp_amd_force_ncoef(const exp_amd_force *f) { return f ? f->ncoef : 0; }
+
+extern "C" int exp_amd_force_set_level(exp_amd_force *f, int mlevel)
+{
+  if (!f || mlevel < 0 || mlevel > f->multistep)
+    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_level: level out of range");
+  f->mlevel = mlevel;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
+{
+  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
+  return f->determine_coefficients(c, false, 0.0, 0.0);
+}
+
+extern "C" int exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external)
+{
+  if (!f || !target) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_acceleration: NULL");
+  return f->accelerate(target, external, false, 0.0);
+}
+
+extern "C" int exp_amd_force_get_coefs(exp_amd_force *f, double *coef, size_t count)
+{
+  if (!f || !coef || count != f->ncoef)
+    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_coefs: bad count");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipMemcpyAsync(coef, f->d_coef.p, count * sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_set_coefs(exp_amd_force *f, const double *coef, size_t count)
+{
+  if (!f || !coef || count != f->ncoef)
+    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_coefs: bad count");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, coef, count * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_get_level_coefs(exp_amd_force *f, int level, int which, double *coef,
+                                             size_t count)
+{
+  if (!f || !coef || count != f->ncoef || level < 0 || level > f->multistep)
+    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_level_coefs: bad argument");
+  exp_amd_ctx *ctx = f->ctx;
+  const double *src = (which ? f->d_coefL.p : f->d_coefN.p) + (size_t)level * f->ncoef_dev;
+  HIP_TRY(ctx, hipMemcpyAsync(coef, src, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+int exp_amd_force::get_used(long long *used)
+{
+  unsigned long long u = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&u, d_used.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *used = (long long)u;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_used(exp_amd_force *f, long long *used)
+{
+  if (!f || !used) return EXP_AMD_ERR_ARG;
+  return f->get_used(used);
+}
+
+// ---- multistep coefficient bookkeeping -----------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int ncoef, int nlev,
+                int mfirst, const double *__restrict__ ab, double *__restrict__ out)
+{
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ncoef) return;
+  double s = 0.0;
+  // src/SphericalBasis.cc:1252-1333 ; src/CylEXP.cc:192-282
+  for (int M = 0; M < mfirst; M++)
+    s += ab[2 * M] * L[(size_t)M * ncoef + k] + ab[2 * M + 1] * N[(size_t)M * ncoef + k];
+  for (int M = mfirst; M < nlev; M++) s += N[(size_t)M * ncoef + k];
+  out[k] = s;
+}
+
+extern "C" int exp_amd_force_multistep_reset(exp_amd_force *f)
+{
+  if (!f) return EXP_AMD_ERR_ARG;
+  return EXP_AMD_OK;   // nothing to do per step for these bases (src/SphericalBasis.H multistep_reset)
+}
+
+extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft)
+{
+  if (!f) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = f->ctx;
+  const int ms = f->multistep;
+  if (ms == 0) return EXP_AMD_OK;
+  const int Mstep = 1 << ms;
+  if (mdrft < 0 || mdrft > Mstep) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "mdrft out of range");
+  // src/multistep.cc:630-680: mfirst[mdrft], dstepL/N[M][mdrft]
+  int mfirst = 0;
+  for (int M = 0; M <= ms; M++) {
+    bool active = (mdrft == 0) || (mdrft % (1 << (ms - M)) == 0);
+    if (active) { mfirst = M; break; }
+  }
+  std::vector<double> ab(2 * (ms + 1), 0.0);
+  for (int M = 0; M < mfirst; M++) {
+    const int d = 1 << (ms - M);
+    const int dL = (mdrft / d) * d, dN = dL + d;
+    const double b = (double)(mdrft - dL) / (double)(dN - dL);
+    ab[2 * M] = 1.0 - b;
+    ab[2 * M + 1] = b;
+  }
+  // tiny host->device copy on the stream (pageable memory: staged before return)
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_scratch.p, ab.data(), ab.size() * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+  k_mstep_combine<<<cdiv(f->ncoef_dev, 256), 256, 0, ctx->stream>>>(
+      f->d_coefL.p, f->d_coefN.p, (int)f->ncoef_dev, ms + 1, mfirst, f->d_scratch.p, f->d_coef.p);
+  HIP_TRY(ctx, hipGetLastError());
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+// ---- fused step -----------------------------------------------------------------------------------------------
+
+extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
+{
+  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "step_kdk: NULL");
+  if (f->multistep)
+    return expamd_fail(f->ctx, EXP_AMD_ERR_STATE,
+                       "step_kdk: multistep force; drive the sub-steps explicitly");
+  int rc;
+  // kick dt/2 + drift dt are applied inside the sort passes (no separate HBM pass); acc/pot are
+  // recomputed below, so they are not carried through the reorder
+  c->acc_live = false;
+  if (c->n == 0) {
+    if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
+  } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt))) return rc;
+  if ((rc = f->accelerate(c, 0, true, 0.5 * dt))) return rc;
+  return EXP_AMD_OK;
+}

@@ -3,6 +3,7 @@
 // kernels live in sph_kernels.h and are instantiated per LMAX in sph_inst.hip.
 #include "sph_kernels.h"
 #include "sort_kernels.h"
+#include "force.h"
 
 // ---- sort key -------------------------------------------------------------------------------------
 
@@ -55,9 +56,9 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
 }
 
 // ---- coefficients -> projected tables -----------------------------------------------------------------
+// G[i][row] = sum_n E[i][l][n] c[row][n]   (reference row order)
 __global__ void __launch_bounds__(256)
-k_sph_project(SphDev S, const double *__restrict__ coef, double *__restrict__ G,
-              double *__restrict__ H)
+k_sph_project(SphDev S, const double *__restrict__ coef, double *__restrict__ G)
 {
   const int i = blockIdx.x;
   const int stride = (S.lmax + 1) * S.nmax;
@@ -69,27 +70,52 @@ k_sph_project(SphDev S, const double *__restrict__ coef, double *__restrict__ G,
     double s = 0.0;
     for (int n = 0; n < S.nmax; n++) s = fma(e[n], c[n], s);
     G[(size_t)i * S.nrows + row] = s;
-    H[(size_t)i * S.nrows + row] = S.p0[i] * s;
+  }
+}
+
+// T4[cell][q][4] = {G0, D, Bq, Aq} (see sph_kernels.h); rowmap[q] = coefficient row feeding the
+// m-major slot q.  rowmap carries the reference's EVEN_M row quirk (src/SphericalBasis.cc:1590-1596:
+// the skipped odd-m terms do not advance moffset, so even m >= 2 read rows l*l + m-1, l*l + m).
+__global__ void __launch_bounds__(256)
+k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ rowmap,
+               double *__restrict__ T4)
+{
+  const int cell = blockIdx.x;                 // 0 .. numr-2
+  const int j = cell < 1 ? 1 : cell;
+  for (int q = threadIdx.x; q < S.nrows; q += 256) {
+    const int row = rowmap[q];
+    if (row < 0) {                             // (l,m) switched off by NO_L0/NO_L1/EVEN_L/EVEN_M/M0_only
+      double *t = T4 + ((size_t)cell * S.nrows + q) * 4;
+      t[0] = t[1] = t[2] = t[3] = 0.0;
+      continue;
+    }
+    const double g0 = G[(size_t)cell * S.nrows + row];
+    const double g1 = G[(size_t)(cell + 1) * S.nrows + row];
+    const double h0 = S.p0[j - 1] * G[(size_t)(j - 1) * S.nrows + row];
+    const double h1 = S.p0[j] * G[(size_t)j * S.nrows + row];
+    const double h2 = S.p0[j + 1] * G[(size_t)(j + 1) * S.nrows + row];
+    double *t = T4 + ((size_t)cell * S.nrows + q) * 4;
+    t[0] = g0;
+    t[1] = g1 - g0;
+    t[2] = 0.5 * (h2 - h0);
+    t[3] = (h0 - 2.0 * h1) + h2;
   }
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
 
-struct exp_amd_force {
-  exp_amd_ctx *ctx = nullptr;
-  int kind = 0;                     // 0 = sphereSL
+struct SphForce : exp_amd_force {
   exp_amd_sph_config cfg{};
   SphDev dev{};
-  DevBuf<double> d_xi, d_p0, d_E, d_fact;
-  DevBuf<double> d_W, d_part, d_G, d_H;
-  DevBuf<double> d_coef;            // expcoef
-  DevBuf<double> d_coefN, d_coefL;  // [multistep+1][ncoef]  (src/SphericalBasis.cc:785-792)
-  DevBuf<unsigned long long> d_used;
-  size_t ncoef = 0;
-  int mlevel = 0;
-  bool proj_dirty = true;
-  exp_amd_comp *home = nullptr;
-  std::vector<double> h_stage;
+  DevBuf<double> d_xi, d_p0, d_E, d_lc;
+  DevBuf<double> d_W, d_part, d_G, d_T4;
+  DevBuf<int> d_rowmap;
+  DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
+  size_t work_cap = 0;
+
+  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
+  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
+  void release() override;
 };
 
 static double factrl(int n)
@@ -112,12 +138,12 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
       cfg->multistep > 16)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_create: bad nmax/numr/cmap/multistep");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  exp_amd_force *f = new exp_amd_force;
+  SphForce *f = new SphForce;
   f->ctx = ctx;
   f->cfg = *cfg;
   const int L = cfg->lmax, nmax = cfg->nmax, numr = cfg->numr;
   const int nrows = (L + 1) * (L + 1);
-  f->ncoef = (size_t)nrows * nmax;
+  const size_t ncoef = (size_t)nrows * nmax;
 
   // E[i][l][n] = ef_l(n,i)/sqrt(ev_l[n])
   std::vector<double> E((size_t)numr * (L + 1) * nmax);
@@ -127,30 +153,58 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
       const double *src = ef + ((size_t)l * nmax + n) * numr;
       for (int i = 0; i < numr; i++) E[((size_t)i * (L + 1) + l) * nmax + n] = src[i] / s;
     }
-  // src/SphericalBasis.cc:328-335
-  std::vector<double> fact((size_t)(L + 1) * (L + 1), 0.0);
+  // factorial(l,m) of src/SphericalBasis.cc:328-335, folded into the Legendre recurrence
+  // constants {A, B, C, e} (sph_kernels.h)
+  auto fct = [](int l, int m) {
+    long double v = sqrtl((2.0L * l + 1.0L) / (4.0L * M_PIl) * (long double)factrl(l - m) /
+                          (long double)factrl(l + m));
+    if (m) v *= sqrtl(2.0L);
+    return v;
+  };
+  std::vector<double> lcv((size_t)(L + 1) * (L + 1) * 4, 0.0);
   for (int l = 0; l <= L; l++)
     for (int m = 0; m <= l; m++) {
-      double v = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * factrl(l - m) / factrl(l + m));
-      if (m) v *= M_SQRT2;
-      fact[l * (L + 1) + m] = v;
+      double *q = &lcv[((size_t)l * (L + 1) + m) * 4];
+      if (l > m) {
+        q[0] = (double)(fct(l, m) / fct(l - 1, m) * (2.0L * l - 1.0L) / (long double)(l - m));
+        q[2] = (double)((long double)(l + m) * fct(l, m) / fct(l - 1, m));
+      }
+      if (l > m + 1)
+        q[1] = (double)(fct(l, m) / fct(l - 2, m) * (long double)(l + m - 1) / (long double)(l - m));
+      if (l == m)
+        q[3] = (m == 0) ? (double)fct(0, 0)
+                        : (double)(-(2.0L * m - 1.0L) * fct(m, m) / fct(m - 1, m - 1));
+    }
+  // m-major slot -> coefficient row (with the EVEN_M quirk of the reference)
+  std::vector<int> rowmap(nrows, 0);
+  for (int m = 0; m <= L; m++)
+    for (int l = m; l <= L; l++) {
+      const int q = mmajor_row(L, l, m);
+      int rc = row_of(l, m, 0);
+      if (cfg->EVEN_M && m > 0) rc = l * l + (m - 1);
+      // terms the reference skips (src/SphericalBasis.cc:1575-1596) get zero table rows
+      bool on = true;
+      if (l == 0 && cfg->NO_L0) on = false;
+      if (l == 1 && cfg->NO_L1) on = false;
+      if (l > 0 && cfg->EVEN_L && (l & 1)) on = false;
+      if (cfg->EVEN_M && (m & 1)) on = false;
+      if (cfg->M0_only && m != 0) on = false;
+      rowmap[q] = on ? rc : -1;
+      if (m > 0) rowmap[q + 1] = on ? rc + 1 : -1;
     }
 
-  const int nlev = cfg->multistep + 1;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(f->d_xi.alloc(numr));
   A(f->d_p0.alloc(numr));
   A(f->d_E.alloc(E.size()));
-  A(f->d_fact.alloc(fact.size()));
+  A(f->d_lc.alloc(lcv.size()));
+  A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_W.alloc((size_t)(numr - 1) * nrows * 2));
-  A(f->d_part.alloc((size_t)CSEG * f->ncoef));
+  A(f->d_part.alloc((size_t)CSEG * ncoef));
   A(f->d_G.alloc((size_t)numr * nrows));
-  A(f->d_H.alloc((size_t)numr * nrows));
-  A(f->d_coef.alloc(f->ncoef));
-  A(f->d_coefN.alloc((size_t)nlev * f->ncoef));
-  A(f->d_coefL.alloc((size_t)nlev * f->ncoef));
-  A(f->d_used.alloc(1));
+  A(f->d_T4.alloc((size_t)(numr - 1) * nrows * 4));
+  if (e == hipSuccess && f->alloc_common(ncoef, cfg->multistep) != EXP_AMD_OK) e = hipErrorOutOfMemory;
   if (e != hipSuccess) {
     exp_amd_force_destroy(f);
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph_create: hipMalloc failed: %s",
@@ -159,12 +213,9 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   HIP_TRY(ctx, hipMemcpy(f->d_xi.p, xi, numr * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_p0.p, p0, numr * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_E.p, E.data(), E.size() * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemcpy(f->d_fact.p, fact.data(), fact.size() * sizeof(double),
+  HIP_TRY(ctx, hipMemcpy(f->d_lc.p, lcv.data(), lcv.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
                          hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemset(f->d_coef.p, 0, f->d_coef.bytes()));
-  HIP_TRY(ctx, hipMemset(f->d_coefN.p, 0, f->d_coefN.bytes()));
-  HIP_TRY(ctx, hipMemset(f->d_coefL.p, 0, f->d_coefL.bytes()));
-  HIP_TRY(ctx, hipMemset(f->d_used.p, 0, sizeof(unsigned long long)));
 
   SphDev &S = f->dev;
   S.lmax = L; S.nmax = nmax; S.numr = numr; S.cmap = cfg->cmap; S.nrows = nrows;
@@ -173,32 +224,19 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.cx = S.cy = S.cz = 0.0;
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
-  S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.fact = f->d_fact.p;
+  S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
   *out = f;
   return EXP_AMD_OK;
 }
 
-extern "C" void exp_amd_force_destroy(exp_amd_force *f)
+void SphForce::release()
 {
-  if (!f) return;
-  (void)hipStreamSynchronize(f->ctx->stream);
-  f->d_xi.release(); f->d_p0.release(); f->d_E.release(); f->d_fact.release();
-  f->d_W.release(); f->d_part.release(); f->d_G.release(); f->d_H.release();
-  f->d_coef.release(); f->d_coefN.release(); f->d_coefL.release(); f->d_used.release();
-  delete f;
+  d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
+  d_rowmap.release();
+  d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
 }
 
-extern "C" size_t exp_amd_force_ncoef(const exp_amd_force *f) { return f ? f->ncoef : 0; }
-
-extern "C" int exp_amd_force_set_level(exp_amd_force *f, int mlevel)
-{
-  if (!f || mlevel < 0 || mlevel > f->cfg.multistep)
-    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_level: level out of range");
-  f->mlevel = mlevel;
-  return EXP_AMD_OK;
-}
-
-static SphDev dev_for(const exp_amd_force *f, const double center[3])
+static SphDev dev_for(const SphForce *f, const double center[3])
 {
   SphDev S = f->dev;
   S.cx = center[0]; S.cy = center[1]; S.cz = center[2];
@@ -207,7 +245,7 @@ static SphDev dev_for(const exp_amd_force *f, const double center[3])
 
 // (level, radial cell) order for this force's tables; with `advance` the kick dt_kick and drift
 // dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
-static int sph_sort(exp_amd_force *f, exp_amd_comp *c, bool move_acc, bool advance = false,
+static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = false,
                     double dt_kick = 0.0, double dt_drift = 0.0)
 {
   exp_amd_ctx *ctx = f->ctx;
@@ -246,11 +284,11 @@ static const sph_force_launcher k_force_launch[SPH_MAX_L + 1] = {
     expamd_sph_force_L8, expamd_sph_force_L9, expamd_sph_force_L10, expamd_sph_force_L11,
     expamd_sph_force_L12};
 
-static int sph_accumulate(exp_amd_force *f, exp_amd_comp *c, double *d_out)
+static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
 {
   exp_amd_ctx *ctx = f->ctx;
-  const int lo = f->cfg.multistep ? f->mlevel : 0;
-  const int hi = f->cfg.multistep ? f->mlevel : 0;
+  const int lo = f->multistep ? f->mlevel : 0;
+  const int hi = f->multistep ? f->mlevel : 0;
   SphDev S = dev_for(f, c->center);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), ctx->stream));
@@ -270,10 +308,9 @@ static int sph_accumulate(exp_amd_force *f, exp_amd_comp *c, double *d_out)
   return EXP_AMD_OK;
 }
 
-static int sph_determine_coefficients(exp_amd_force *f, exp_amd_comp *c, bool advance,
-                                      double dt_kick, double dt_drift)
+int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
 {
-  exp_amd_ctx *ctx = f->ctx;
+  SphForce *f = this;
   f->home = c;
   int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift);
   if (rc) return rc;
@@ -291,26 +328,22 @@ static int sph_determine_coefficients(exp_amd_force *f, exp_amd_comp *c, bool ad
   return EXP_AMD_OK;
 }
 
-extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
-{
-  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
-  return sph_determine_coefficients(f, c, false, 0.0, 0.0);
-}
-
-static int sph_project(exp_amd_force *f)
+static int sph_project(SphForce *f)
 {
   if (!f->proj_dirty) return EXP_AMD_OK;
   exp_amd_ctx *ctx = f->ctx;
   ProfScope ps(ctx, "k_sph_project");
-  k_sph_project<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_coef.p, f->d_G.p, f->d_H.p);
+  k_sph_project<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_coef.p, f->d_G.p);
+  k_sph_project4<<<f->cfg.numr - 1, 256, 0, ctx->stream>>>(f->dev, f->d_G.p, f->d_rowmap.p,
+                                                          f->d_T4.p);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = false;
   return EXP_AMD_OK;
 }
 
-static int sph_force(exp_amd_force *f, exp_amd_comp *t, int external, bool assign, double dt_kick)
+int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick)
 {
-  exp_amd_ctx *ctx = f->ctx;
+  SphForce *f = this;
   int rc = sph_project(f);
   if (rc) return rc;
   if (t->n == 0) return EXP_AMD_OK;
@@ -321,9 +354,16 @@ static int sph_force(exp_amd_force *f, exp_amd_comp *t, int external, bool assig
   {
     ProfScope ps(ctx, "k_sph_force");
     unsigned grid = cdiv(t->n, 256);   // one 64-particle chunk per wave, no loop
-    SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_G.p, f->d_H.p,
+    const size_t need = t->n / 64 + 8;
+    if (f->work_cap < need) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, f->d_work.alloc(need + 1));
+      f->work_cap = need;
+    }
+    SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
-                   t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream};
+                   t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream,
+                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0};
     k_force_launch[f->cfg.lmax](a);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -331,114 +371,3 @@ static int sph_force(exp_amd_force *f, exp_amd_comp *t, int external, bool assig
   return EXP_AMD_OK;
 }
 
-extern "C" int exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external)
-{
-  if (!f || !target) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_acceleration: NULL");
-  return sph_force(f, target, external, false, 0.0);
-}
-
-extern "C" int exp_amd_force_get_coefs(exp_amd_force *f, double *coef, size_t count)
-{
-  if (!f || !coef || count != f->ncoef)
-    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_coefs: bad count");
-  exp_amd_ctx *ctx = f->ctx;
-  const double *src = f->d_coef.p;
-  HIP_TRY(ctx, hipMemcpyAsync(coef, src, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return EXP_AMD_OK;
-}
-
-extern "C" int exp_amd_force_set_coefs(exp_amd_force *f, const double *coef, size_t count)
-{
-  if (!f || !coef || count != f->ncoef)
-    return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_coefs: bad count");
-  exp_amd_ctx *ctx = f->ctx;
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, coef, count * sizeof(double), hipMemcpyHostToDevice,
-                              ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  f->proj_dirty = true;
-  return EXP_AMD_OK;
-}
-
-extern "C" int exp_amd_force_used(exp_amd_force *f, long long *used)
-{
-  if (!f || !used) return EXP_AMD_ERR_ARG;
-  exp_amd_ctx *ctx = f->ctx;
-  unsigned long long u = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&u, f->d_used.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  *used = (long long)u;
-  return EXP_AMD_OK;
-}
-
-// ---- multistep coefficient bookkeeping -----------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256)
-k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int ncoef, int nlev,
-                int mfirst, const double *__restrict__ ab, double *__restrict__ out)
-{
-  int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= ncoef) return;
-  double s = 0.0;
-  // src/SphericalBasis.cc:1252-1333
-  for (int M = 0; M < mfirst; M++)
-    s += ab[2 * M] * L[(size_t)M * ncoef + k] + ab[2 * M + 1] * N[(size_t)M * ncoef + k];
-  for (int M = mfirst; M < nlev; M++) s += N[(size_t)M * ncoef + k];
-  out[k] = s;
-}
-
-extern "C" int exp_amd_force_multistep_reset(exp_amd_force *f)
-{
-  if (!f) return EXP_AMD_ERR_ARG;
-  return EXP_AMD_OK;   // src/SphericalBasis.cc multistep_reset: nothing to do per step
-}
-
-extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft)
-{
-  if (!f) return EXP_AMD_ERR_ARG;
-  exp_amd_ctx *ctx = f->ctx;
-  const int ms = f->cfg.multistep;
-  if (ms == 0) return EXP_AMD_OK;
-  const int Mstep = 1 << ms;
-  if (mdrft < 0 || mdrft > Mstep) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "mdrft out of range");
-  // src/multistep.cc:630-680: mfirst[mdrft], dstepL/N[M][mdrft]
-  int mfirst = 0;
-  for (int M = 0; M <= ms; M++) {
-    bool active = (mdrft == 0) || (mdrft % (1 << (ms - M)) == 0);
-    if (active) { mfirst = M; break; }
-  }
-  std::vector<double> ab(2 * (ms + 1), 0.0);
-  for (int M = 0; M < mfirst; M++) {
-    const int d = 1 << (ms - M);
-    const int dL = (mdrft / d) * d, dN = dL + d;
-    const double b = (double)(mdrft - dL) / (double)(dN - dL);
-    ab[2 * M] = 1.0 - b;
-    ab[2 * M + 1] = b;
-  }
-  // tiny host->device copy on the stream (pageable memory: copied before return)
-  double *d_ab = f->d_part.p;   // scratch
-  HIP_TRY(ctx, hipMemcpyAsync(d_ab, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice,
-                              ctx->stream));
-  k_mstep_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
-      f->d_coefL.p, f->d_coefN.p, (int)f->ncoef, ms + 1, mfirst, d_ab, f->d_coef.p);
-  HIP_TRY(ctx, hipGetLastError());
-  f->proj_dirty = true;
-  return EXP_AMD_OK;
-}
-
-// ---- fused step -----------------------------------------------------------------------------------------------
-
-extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
-{
-  if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "step_kdk: NULL");
-  if (f->cfg.multistep) return expamd_fail(f->ctx, EXP_AMD_ERR_STATE, "step_kdk: multistep force; drive the sub-steps explicitly");
-  int rc;
-  // kick dt/2 + drift dt are applied inside the sort passes (no separate HBM pass); acc/pot are
-  // recomputed below, so they are not carried through the reorder
-  c->acc_live = false;
-  if (c->n == 0) {
-    if ((rc = sph_determine_coefficients(f, c, false, 0.0, 0.0))) return rc;
-  } else if ((rc = sph_determine_coefficients(f, c, true, 0.5 * dt, dt))) return rc;
-  if ((rc = sph_force(f, c, 0, true, 0.5 * dt))) return rc;
-  return EXP_AMD_OK;
-}

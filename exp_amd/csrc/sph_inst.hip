@@ -23,10 +23,18 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 {
   constexpr int LMAX = SPH_L;
-  const SphDev &S = a.S;
-  // FLAGS=true always: besides honouring NO_L0/.../M0_only its wave-uniform row branches keep
-  // the unrolled (l,m) nest in small basic blocks (the branch-free variant made hipcc spill).
-  k_sph_force<LMAX, true><<<a.grid, 256, 0, a.stream>>>(S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi,
-                                                        a.G, a.H, a.AX, a.AY, a.AZ, a.POT, a.VX,
-                                                        a.VY, a.VZ, a.dt_kick, a.assign);
+  if (!a.all_slow) {
+    (void)hipMemsetAsync(a.nwork, 0, sizeof(uint32_t), a.stream);
+    k_sph_force<LMAX, true><<<a.grid, 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+        a.dt_kick, a.assign, a.work, a.nwork);
+    // deferred waves: the grid is an upper bound, surplus waves leave on the count
+    k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+        a.dt_kick, a.assign, a.work, a.nwork);
+  } else {
+    k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+        a.dt_kick, a.assign, nullptr, nullptr);
+  }
 }

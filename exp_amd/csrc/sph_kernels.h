@@ -41,7 +41,7 @@ struct SphDev {
   const double *xi;      // [numr]
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
-  const double *fact;    // [(lmax+1)*(lmax+1)]  factorial(l,m), src/SphericalBasis.cc:328-335
+  const double *lc;      // [(lmax+1)*(lmax+1)][4] normalised-Legendre recurrence constants (below)
 };
 
 template <int I, int N, class F>
@@ -61,6 +61,23 @@ __host__ __device__ constexpr int acc_base(int L, int mlo, int m)
   return s;
 }
 __host__ __device__ constexpr int row_of(int l, int m, int cs) { return l * l + (m ? 2 * m - 1 + cs : 0); }
+// offset (in rows) of (l, m) in the m-major traversal order used by the projected force table
+__host__ __device__ constexpr int mmajor_row(int L, int l, int m)
+{
+  return acc_base(L, 0, m) + (m == 0 ? (l - m) : 2 * (l - m));
+}
+
+// Normalised associated Legendre functions Pt(l,m) = factorial(l,m) * P_l^m(x) (the product the
+// reference forms as facL, src/SphericalBasis.cc:521, :1586) by the same upward recurrences as
+// Basis::legendre_R (src/Basis.cc:14-52) with the normalisation folded into the constants:
+//   Pt(m,m)   = e_m * sqrt(1-x^2) * Pt(m-1,m-1)
+//   Pt(l,m)   = A(l,m) * x * Pt(l-1,m) - B(l,m) * Pt(l-2,m)
+//   dPt(l,m)  = (l * x * Pt(l,m) - C(l,m) * Pt(l-1,m)) / (x^2 - 1)          (src/Basis.cc:86-92)
+// lc[(l*(L+1)+m)*4 + {0,1,2,3}] = {A, B, C, e (only for l == m)}
+#define LC_A(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 0]
+#define LC_B(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 1]
+#define LC_C(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 2]
+#define LC_E(m)    lc[((m) * (LMAX + 1) + (m)) * 4 + 3]
 
 // ---- per-particle radial/angular coordinates --------------------------------------------------
 
@@ -180,7 +197,7 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
   constexpr int NV = 2 * NACC;
   const int lane = threadIdx.x & 63;
 
-  cdp fact = (cdp)S.fact;
+  cdp lc = (cdp)S.lc;
   const double fac0 = -4.0 * M_PI;
 
   double acc[NV];
@@ -213,11 +230,10 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
     const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
     const double t0 = inwin ? mass * fac0 * P0 : 0.0;
     if (MLO == 0 && inwin) used++;
-
     {
-      unsigned long long fp = (unsigned long long)S.fact;   // see k_sph_force: blocks LICM
-      asm volatile("" : "+s"(fp));
-      fact = (cdp)fp;
+      unsigned long long fp = (unsigned long long)S.lc;   // re-derive per iteration: blocks LICM
+      asm volatile("" : "+s"(fp));                        // of the constant loads (SGPR spills)
+      lc = (cdp)fp;
     }
     unsigned long long remaining = __ballot(inwin);
     while (remaining) {
@@ -233,48 +249,45 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
       const double a1 = sel ? t0 * x1 : 0.0;
       const double a2 = sel ? t0 * x2 : 0.0;
 
-      // Legendre (src/Basis.cc:14-52) and trig (src/Basis.cc:95-112) recurrences, m-major
       const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
-      double pmm = 1.0;
+      double pmm = LC_E(0);                              // Pt(0,0) = factorial(0,0)
       double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;   // c[m], s[m], c[m-1], s[m-1]
       static_for<0, MHI + 1>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         if constexpr (m == 1) {
-          pmm *= -1.0 * somx2;
+          pmm *= LC_E(1) * somx2;
           cm1 = 1.0; sm1 = 0.0;
           cm = cphi; sm = sphi;
         } else if constexpr (m > 1) {
-          pmm *= -(2.0 * m - 1.0) * somx2;
-          const double cn = 2.0 * cphi * cm - cm1;
+          pmm *= LC_E(m) * somx2;
+          const double cn = 2.0 * cphi * cm - cm1;       // src/Basis.cc:107-110
           const double sn = 2.0 * cphi * sm - sm1;
           cm1 = cm; sm1 = sm;
           cm = cn; sm = sn;
         }
         if constexpr (m >= MLO) {
           if (m == 0 || !S.M0_only) {
-            double pl2 = pmm, pl1 = 0.0;
-            static_for<m, LMAX + 1>([&](auto lc) {
-              constexpr int l = decltype(lc)::value;
+            // per-m weights: the four (x1|x2) x (cos|sin) moments share Pt(l,m)
+            const double a1c = a1 * cm, a2c = a2 * cm, a1s = a1 * sm, a2s = a2 * sm;
+            double pl2 = 0.0, pl1 = 0.0;
+            static_for<m, LMAX + 1>([&](auto lc_) {
+              constexpr int l = decltype(lc_)::value;
               double plm;
               if constexpr (l == m) plm = pmm;
-              else if constexpr (l == m + 1) { plm = costh * (2 * m + 1) * pl2; pl1 = plm; }
-              else {
-                plm = (costh * (2 * l - 1) * pl1 - (l + m - 1) * pl2) * (1.0 / (l - m));
-                pl2 = pl1;
-                pl1 = plm;
-              }
-              const double Yl = fact[l * (LMAX + 1) + m] * plm;
+              else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
+              else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+              pl2 = pl1;
+              pl1 = plm;
               if constexpr (m == 0) {
                 constexpr int k = acc_base(LMAX, MLO, 0) + (l - m);
-                acc[2 * k] = fma(a1, Yl, acc[2 * k]);
-                acc[2 * k + 1] = fma(a2, Yl, acc[2 * k + 1]);
+                acc[2 * k] = fma(a1, plm, acc[2 * k]);
+                acc[2 * k + 1] = fma(a2, plm, acc[2 * k + 1]);
               } else {
                 constexpr int k = acc_base(LMAX, MLO, m) + 2 * (l - m);
-                const double Yc = Yl * cm, Ys = Yl * sm;
-                acc[2 * k] = fma(a1, Yc, acc[2 * k]);
-                acc[2 * k + 1] = fma(a2, Yc, acc[2 * k + 1]);
-                acc[2 * k + 2] = fma(a1, Ys, acc[2 * k + 2]);
-                acc[2 * k + 3] = fma(a2, Ys, acc[2 * k + 3]);
+                acc[2 * k] = fma(a1c, plm, acc[2 * k]);
+                acc[2 * k + 1] = fma(a2c, plm, acc[2 * k + 1]);
+                acc[2 * k + 2] = fma(a1s, plm, acc[2 * k + 2]);
+                acc[2 * k + 3] = fma(a2s, plm, acc[2 * k + 3]);
               }
             });
           }
@@ -336,219 +349,232 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
 }
 
 // ---- force ------------------------------------------------------------------------------------------------
+//
+// Projected table T4[cell][q][4] (q = m-major row order, see mmajor_row), built once per
+// coefficient set by k_sph_project4 (sph.hip) from G[i][row] = sum_n E[i][l][n] c[row][n],
+// H = p0 * G and j = max(cell, 1):
+//     {G0, D, Bq, Aq} = {G[cell], G[cell+1]-G[cell], (H[j+1]-H[j-1])/2, H[j-1]-2H[j]+H[j+1]}
+// so that for a particle in that cell (x2, pf = its get_pot / get_force offsets):
+//     p_row  = P0   * (G0 + x2 * D)          == P0 (x1 G[cell] + x2 G[cell+1])
+//     dp_row = ffac * (Bq + pf * Aq)         == ffac ((pf-.5) H[j-1] - 2 pf H[j] + (pf+.5) H[j+1])
+// P0, ffac (and 1/(x^2-1) of the Legendre derivative) are per-particle factors applied once at
+// the end.  2 FMAs per row and field instead of 5.
 
 struct ForceOut { double potl, potr, pott, potp; };
 
-// One particle's field sums.  UNIFORM: g0.. are wave-uniform row pointers (scalar loads);
-// otherwise per-lane pointers (vector gathers).  FLAGS: honour NO_L0/NO_L1/EVEN_L/EVEN_M/M0_only
-// including the reference's moffset behaviour under EVEN_M (rows are not advanced for skipped m).
-template <int LMAX, bool FLAGS, bool UNIFORM, class PG, class PH>
+// FAST: wave-uniform cell, no exterior lane, no flag branches (disabled rows are zero in T4):
+// straight-line code whose scalar loads the scheduler can run ahead of the FMAs.
+// !FAST: per-lane table gathers, exterior continuation by per-lane selects, run-time flags.
+template <int LMAX, bool FAST, class PT>
 __device__ __forceinline__ ForceOut
-sph_field(const SphDev &S, cdp fact, double costh, double cphi, double sphi, PG g0, PG g1, PH h0,
-          PH h1, PH h2, double a1, double a2, double b0, double b1, double b2, bool ioff,
-          double rmax_over_r0, double inv_r0)
+sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double sphi, PT t4,
+          double x2, double pf, bool ioff, double rr, double kappa0)
 {
   ForceOut o{0.0, 0.0, 0.0, 0.0};
-  // src/Basis.cc:54-93
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
-  double xc = costh;
-  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-  const double dfac = 1.0 / (xc * xc - 1.0);
-
-  double pmm = 1.0;
+  double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
   static_for<0, LMAX + 1>([&](auto mc) {
     constexpr int m = decltype(mc)::value;
     if constexpr (m == 1) {
-      pmm *= -1.0 * somx2;
+      pmm *= LC_E(1) * somx2;
       cm = cphi; sm = sphi;
     } else if constexpr (m > 1) {
-      pmm *= -(2.0 * m - 1.0) * somx2;
+      pmm *= LC_E(m) * somx2;
       const double cn = 2.0 * cphi * cm - cm1;
       const double sn = 2.0 * cphi * sm - sm1;
       cm1 = cm; sm1 = sm;
       cm = cn; sm = sn;
     }
     bool m_on = true;
-    if constexpr (FLAGS) {
+    if constexpr (!FAST) {
       if (S.EVEN_M && (m & 1)) m_on = false;
       if (S.M0_only && m != 0) m_on = false;
     }
-    // (rmax/r0)^(l+1) for the exterior multipole continuation, built up with l
-    double rfac = rmax_over_r0;
-    static_for<0, m>([&](auto) { rfac *= rmax_over_r0; });
-
-    double pl2 = pmm, pl1 = 0.0;
-    static_for<m, LMAX + 1>([&](auto lc) {
-      constexpr int l = decltype(lc)::value;
-      double plm, dplm;
+    // exterior continuation (src/SphericalBasis.cc:1605-1628): (rmax/r0)^(l+1), starts at l = m
+    double rl = 1.0;
+    if constexpr (!FAST) {
+      double t = rr;
+      static_for<0, m>([&](auto) { t *= rr; });
+      rl = ioff ? t : 1.0;
+    }
+    // per-m partial sums over l: A ~ cos rows, B ~ sin rows; plain (l), radial-derivative (r),
+    // polar-derivative (t)
+    double Al = 0.0, Bl = 0.0, Ar = 0.0, Br = 0.0, At = 0.0, Bt = 0.0;
+    double pl2 = 0.0, pl1 = 0.0;
+    static_for<m, LMAX + 1>([&](auto lc_) {
+      constexpr int l = decltype(lc_)::value;
+      double plm, qlm;            // Pt(l,m) and (x^2-1) dPt(l,m)
       if constexpr (l == m) {
         plm = pmm;
-        dplm = dfac * xc * l * plm;
+        qlm = (xc * l) * plm;
       } else if constexpr (l == m + 1) {
-        plm = costh * (2 * m + 1) * pl2;
-        dplm = dfac * (xc * l * plm - (l + m) * pl2);
-        pl1 = plm;
+        plm = LC_A(l, m) * (costh * pl1);
+        qlm = (xc * l) * plm - LC_C(l, m) * pl1;
       } else {
-        plm = (costh * (2 * l - 1) * pl1 - (l + m - 1) * pl2) * (1.0 / (l - m));
-        dplm = dfac * (xc * l * plm - (l + m) * pl1);
-        pl2 = pl1;
-        pl1 = plm;
+        plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+        qlm = (xc * l) * plm - LC_C(l, m) * pl1;
       }
+      pl2 = pl1;
+      pl1 = plm;
       bool on = m_on;
-      if constexpr (FLAGS) {
+      if constexpr (!FAST) {
         if (l == 0 && S.NO_L0) on = false;
         if (l == 1 && S.NO_L1) on = false;
         if (l > 0 && S.EVEN_L && (l & 1)) on = false;
       }
       if (on) {
-        int rc = row_of(l, m, 0);
-        if constexpr (FLAGS) {
-          if (S.EVEN_M && m > 0) rc = l * l + (m - 1);
+        constexpr int q = 4 * mmajor_row(LMAX, l, m);
+        double pc = fma(x2, t4[q + 1], t4[q + 0]);
+        double dpc = fma(pf, t4[q + 3], t4[q + 2]);
+        if constexpr (!FAST) {
+          pc *= rl;
+          dpc = ioff ? (kappa0 * (l + 1)) * pc : dpc;
         }
-        const double f = fact[l * (LMAX + 1) + m];
-        const double facL = f * plm, facD = f * dplm;
-        if constexpr (m == 0) {
-          double p = a1 * g0[rc] + a2 * g1[rc];
-          double dp = b0 * h0[rc] + b1 * h1[rc] + b2 * h2[rc];
-          if (ioff) {
-            p *= rfac;
-            dp = -p * inv_r0 * (l + 1);
+        Al = fma(plm, pc, Al);
+        Ar = fma(plm, dpc, Ar);
+        At = fma(qlm, pc, At);
+        if constexpr (m > 0) {
+          double ps = fma(x2, t4[q + 5], t4[q + 4]);
+          double dps = fma(pf, t4[q + 7], t4[q + 6]);
+          if constexpr (!FAST) {
+            ps *= rl;
+            dps = ioff ? (kappa0 * (l + 1)) * ps : dps;
           }
-          o.potl += facL * p;
-          o.potr += facL * dp;
-          if constexpr (l > 0) o.pott += facD * p;
-        } else {
-          double pc = a1 * g0[rc] + a2 * g1[rc];
-          double ps = a1 * g0[rc + 1] + a2 * g1[rc + 1];
-          double dpc = b0 * h0[rc] + b1 * h1[rc] + b2 * h2[rc];
-          double dps = b0 * h0[rc + 1] + b1 * h1[rc + 1] + b2 * h2[rc + 1];
-          if (ioff) {
-            pc *= rfac;
-            ps *= rfac;
-            const double facdp = -inv_r0 * (l + 1);
-            dpc = pc * facdp;
-            dps = ps * facdp;
-          }
-          const double pcs = pc * cm + ps * sm;
-          o.potl += facL * pcs;
-          o.potr += facL * (dpc * cm + dps * sm);
-          o.pott += facD * pcs;
-          o.potp += facL * (-pc * sm + ps * cm) * m;
+          Bl = fma(plm, ps, Bl);
+          Br = fma(plm, dps, Br);
+          Bt = fma(qlm, ps, Bt);
         }
       }
-      rfac *= rmax_over_r0;
+      if constexpr (!FAST) rl *= ioff ? rr : 1.0;
     });
-    // bound the scheduling region: one m-block of rows at a time (otherwise the whole
-    // unrolled (l,m) nest is one block and register pressure explodes)
+    if constexpr (m == 0) {
+      o.potl += Al;
+      o.potr += Ar;
+      o.pott += At;
+    } else {
+      o.potl += Al * cm + Bl * sm;
+      o.potr += Ar * cm + Br * sm;
+      o.pott += At * cm + Bt * sm;
+      o.potp += (Bl * cm - Al * sm) * m;
+    }
+    // bound the scheduling region to one m-block
     __builtin_amdgcn_sched_barrier(0);
   });
   return o;
 }
 
-template <int LMAX, bool FLAGS>
+// Two launches share this body.  FAST: every wave whose lanes sit in one radial cell with no
+// exterior particle is done here; the rest push their first slot on `work` and leave.
+// !FAST: one wave per work item (or per 64-slot chunk when work == nullptr, i.e. "all waves").
+template <int LMAX, bool FAST>
 __global__ void __launch_bounds__(256)
 k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
-            int lev_hi, const double *__restrict__ G, const double *__restrict__ H,
-            double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
-            double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
-            double *__restrict__ VZ, double dt_kick, int assign)
+            int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
+            double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
+            double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
+            double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  cdp fact = (cdp)S.fact;
+  cdp lc = (cdp)S.lc;
   const int lane = threadIdx.x & 63;
   // One 64-particle chunk per wave and NO particle loop: with a loop, LICM hoists the
-  // hundreds of fp64 literals of the unrolled (l,m) nest out of it and spills them.
-  {
-    const size_t base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+  // constants of the unrolled (l,m) nest out of it and spills them.
+  size_t base;
+  if (FAST || work == nullptr) {
+    base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
     if (base >= end) return;
-    const size_t i = base + lane;
-    const bool valid = i < end;
-    double xx = 0, yy = 0, zz = 1;
-    if (valid) {
-      xx = X[i] - S.cx;
-      yy = Y[i] - S.cy;
-      zz = Z[i] - S.cz;
-    }
-    // src/SphericalBasis.cc:1545-1560
-    double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-    const double costh = zz / r;
-    double cphi, sphi;
-    phi_trig(xx, yy, cphi, sphi);
-    bool ioff = false;
-    double r0 = r;
-    if (r > S.rmax) {
-      ioff = true;
-      r = S.rmax;
-    }
-    const double rs = r / S.scale;
-    const double xi = sph_r_to_xi(S, rs);
-    int idx = sph_cell(S, xi);
-    // get_pot weights (exputil/SLGridMP2.cc:894-902)
-    const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
-    const double x2 = (xi - S.xi[idx]) / S.dxi;
-    const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
-    const double a1 = P0 * x1, a2 = P0 * x2;
-    // get_force weights (exputil/SLGridMP2.cc:971-985)
-    int jdx = idx < 1 ? 1 : idx;
-    const double pf = (xi - S.xi[jdx]) / S.dxi;
-    const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
-    const double b0 = ffac * (pf - 0.5), b1 = ffac * (-2.0 * pf), b2 = ffac * (pf + 0.5);
-
+  } else {
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= *nwork) return;
+    base = work[w];
+  }
+  const size_t i = base + lane;
+  const bool valid = i < end;
+  double xx = 0, yy = 0, zz = 1;
+  if (valid) {
+    xx = X[i] - S.cx;
+    yy = Y[i] - S.cy;
+    zz = Z[i] - S.cz;
+  }
+  // src/SphericalBasis.cc:1545-1560
+  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  const double costh = zz / r;
+  double cphi, sphi;
+  phi_trig(xx, yy, cphi, sphi);
+  bool ioff = false;
+  const double r0 = r;
+  if (r > S.rmax) {
+    ioff = true;
+    r = S.rmax;
+  }
+  const double rs = r / S.scale;
+  const double xi = sph_r_to_xi(S, rs);
+  int idx = sph_cell(S, xi);
+  // get_pot weights (exputil/SLGridMP2.cc:894-902)
+  const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
+  const double x2 = (xi - S.xi[idx]) / S.dxi;
+  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  // get_force weights (exputil/SLGridMP2.cc:971-985)
+  const int jdx = idx < 1 ? 1 : idx;
+  const double pf = (xi - S.xi[jdx]) / S.dxi;
+  const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
+  // Legendre derivative pole clamp (src/Basis.cc:81-84)
+  double xc = costh;
+  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+  const double dfac = 1.0 / (xc * xc - 1.0);
+  const size_t tq = (size_t)4 * S.nrows;
+  ForceOut o;
+  if constexpr (FAST) {
     const int idx_u = __builtin_amdgcn_readfirstlane(idx);
     if (!valid) idx = idx_u;
-    const bool uniform = __all(idx == idx_u);
-    ForceOut o;
-    const double rr = S.rmax / r0, ir0 = 1.0 / r0;
-    if (uniform) {
-      const int j_u = idx_u < 1 ? 1 : idx_u;
-      cdp g0 = (cdp)(G + (size_t)idx_u * S.nrows), g1 = (cdp)(G + (size_t)(idx_u + 1) * S.nrows);
-      cdp h0 = (cdp)(H + (size_t)(j_u - 1) * S.nrows), h1 = (cdp)(H + (size_t)j_u * S.nrows),
-          h2 = (cdp)(H + (size_t)(j_u + 1) * S.nrows);
-      o = sph_field<LMAX, FLAGS, true>(S, fact, costh, cphi, sphi, g0, g1, h0, h1, h2, a1, a2, b0,
-                                       b1, b2, ioff, rr, ir0);
-    } else {
-      const double *g0 = G + (size_t)idx * S.nrows, *g1 = g0 + S.nrows;
-      const double *h1 = H + (size_t)jdx * S.nrows, *h0 = h1 - S.nrows, *h2 = h1 + S.nrows;
-      o = sph_field<LMAX, FLAGS, false>(S, fact, costh, cphi, sphi, g0, g1, h0, h1, h2, a1, a2, b0,
-                                        b1, b2, ioff, rr, ir0);
+    const bool fast = __all(idx == idx_u) && !__any(ioff && valid);
+    if (!fast) {
+      if (lane == 0) work[atomicAdd(nwork, 1u)] = (uint32_t)base;
+      return;
     }
-    if (!valid) return;
+    cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
+    o = sph_field<LMAX, true>(S, lc, costh, xc, cphi, sphi, t4, x2, pf, false, 1.0, 0.0);
+  } else {
+    const double rr = S.rmax / r0;
+    const double kappa0 = -P0 / (r0 * ffac);     // dp = -(l+1)/r0 * p, in units of ffac
+    const double *t4 = T4 + (size_t)idx * tq;
+    o = sph_field<LMAX, false>(S, lc, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+  }
+  if (!valid) return;
 
-    // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
-    const double fac = xx * xx + yy * yy;
-    const double potr = o.potr / (S.scale * S.scale);
-    const double potl = o.potl / S.scale;
-    const double pott = o.pott / S.scale;
-    const double potp = o.potp / S.scale;
-    const double r3 = r * r * r;
-    double ax = -(potr * xx / r - pott * xx * zz / r3);
-    double ay = -(potr * yy / r - pott * yy * zz / r3);
-    double az = -(potr * zz / r + pott * fac / r3);
-    if (fac > DSMALL) {
-      ax += potp * yy / fac;
-      ay += -potp * xx / fac;
-    }
-    double pt = potl;
-    if (!assign) {
-      ax += AX[i];
-      ay += AY[i];
-      az += AZ[i];
-      pt += POT[i];
-    }
-    AX[i] = ax;
-    AY[i] = ay;
-    AZ[i] = az;
-    POT[i] = pt;
-    if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
-      VX[i] = mul_then_add(VX[i], ax, dt_kick);
-      VY[i] = mul_then_add(VY[i], ay, dt_kick);
-      VZ[i] = mul_then_add(VZ[i], az, dt_kick);
-    }
+  // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
+  const double fac = xx * xx + yy * yy;
+  const double potr = o.potr * ffac / (S.scale * S.scale);
+  const double potl = o.potl * P0 / S.scale;
+  const double pott = o.pott * (P0 * dfac) / S.scale;
+  const double potp = o.potp * P0 / S.scale;
+  const double r3 = r * r * r;
+  double ax = -(potr * xx / r - pott * xx * zz / r3);
+  double ay = -(potr * yy / r - pott * yy * zz / r3);
+  double az = -(potr * zz / r + pott * fac / r3);
+  if (fac > DSMALL) {
+    ax += potp * yy / fac;
+    ay += -potp * xx / fac;
+  }
+  double pt = potl;
+  if (!assign) {
+    ax += AX[i];
+    ay += AY[i];
+    az += AZ[i];
+    pt += POT[i];
+  }
+  AX[i] = ax;
+  AY[i] = ay;
+  AZ[i] = az;
+  POT[i] = pt;
+  if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
+    VX[i] = mul_then_add(VX[i], ax, dt_kick);
+    VY[i] = mul_then_add(VY[i], ay, dt_kick);
+    VZ[i] = mul_then_add(VZ[i], az, dt_kick);
   }
 }
-
 
 // ---- per-LMAX launchers (one translation unit per LMAX: sph_inst.hip -DSPH_L=k) -----------------
 
@@ -568,13 +594,15 @@ struct SphForceArgs {
   const double *X, *Y, *Z;
   const uint32_t *lev_off;
   int lo, hi;
-  const double *G, *H;
+  const double *T4;
   double *AX, *AY, *AZ, *POT, *VX, *VY, *VZ;
   double dt_kick;
   int assign;
   size_t n;
   unsigned grid;
   hipStream_t stream;
+  uint32_t *work, *nwork;   // slow-path work list (first slot of each deferred wave) + count
+  int all_slow;             // target is not in this force's cell order: skip the fast pass
 };
 
 typedef void (*sph_acc_launcher)(const SphAccArgs &);

@@ -1,0 +1,263 @@
+"""Empirical cylindrical basis tables (EmpCylSL EOF tables), init-time, host only.
+
+Produces what ``EmpCylSL`` holds after ``generate_eof`` (``exputil/EmpCylSL.cc:2375-2683``,
+``make_eof`` ``:2866``, ``compute_eof_grid`` ``:1454-1630``): for every azimuthal order m and
+radial order n the bilinear-interpolation tables potC, rforceC, zforceC (and the sine
+counterparts for m >= 1) on the (NUMX+1) x (NUMY+1) grid of ``setup_table`` (``:2123-2137``).
+
+Method (the reference's, re-implemented with numpy):
+1. a spherical Sturm-Liouville helper basis (lmaxfid, nmaxfid) on the exponential-sphere model of
+   ``EmpCylSL::make_sl`` / ``densR`` (``:584-700``), radii in units of ASCALE;
+2. covariance of the helper-basis potentials under the conditioning disk density
+   (``src/Cylinder.cc:315-322``) by Gauss-Legendre quadrature in (xi_r, cos theta) -- azimuthal
+   quadrature with nump = 1, so cosine and sine blocks are identical (``:2486-2490``);
+3. symmetric eigen-decomposition per m, largest-variance vectors first, sign fixed as in
+   ``eigen_problem`` (``:3577-3587``);
+4. tabulation of potential and cylindrical force components on the grid.
+
+Divergences from the reference, all init-only and irrelevant to hot-path parity (which is defined
+given the tables): eigenvectors are ordered by decreasing eigenvalue explicitly; the sine z-force
+table holds the z-force (the reference's single-process branch copies the R-force there,
+SURVEY.md section 3.7 item 5); EvenOdd splitting (ncylodd) is not applied.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Callable, Optional
+
+import numpy as np
+from numpy.polynomial import legendre as npleg
+from scipy.special import lpmv
+
+from .models import NumericModel
+from .slgrid import SLGridSph, build_slgrid
+
+KIND = {"potC": 0, "rforceC": 1, "zforceC": 2, "potS": 3, "rforceS": 4, "zforceS": 5}
+
+
+@dataclasses.dataclass
+class EmpCylGrid:
+    mmax: int
+    norder: int
+    numx: int
+    numy: int
+    cmapr: int
+    cmapz: int
+    ascale: float
+    hscale: float
+    rmin: float          # RMIN (units of ascale)
+    rmax: float          # RMAX (units of ascale)
+    rtable: float
+    xmin: float
+    xmax: float
+    dx: float
+    ymin: float
+    ymax: float
+    dy: float
+    tab: np.ndarray      # [6, mmax+1, norder, numx+1, numy+1]
+
+    def save(self, path: str) -> None:
+        np.savez_compressed(path, **{f.name: getattr(self, f.name)
+                                     for f in dataclasses.fields(self)})
+
+    @staticmethod
+    def load(path: str) -> "EmpCylGrid":
+        z = np.load(path)
+        kw = {}
+        for f in dataclasses.fields(EmpCylGrid):
+            v = z[f.name]
+            kw[f.name] = v.item() if v.ndim == 0 else np.ascontiguousarray(v, dtype=np.float64)
+        for k in ("mmax", "norder", "numx", "numy", "cmapr", "cmapz"):
+            kw[k] = int(kw[k])
+        return EmpCylGrid(**kw)
+
+
+# ---- coordinate maps (exputil/EmpCylSL.cc:6446-6491, :7109-7146) -------------------------------------
+
+def r_to_xi(r, ascale, cmapr):
+    r = np.asarray(r, dtype=np.float64)
+    return (r / ascale - 1.0) / (r / ascale + 1.0) if cmapr > 0 else r
+
+
+def xi_to_r(xi, ascale, cmapr):
+    xi = np.asarray(xi, dtype=np.float64)
+    return (1.0 + xi) / (1.0 - xi) * ascale if cmapr > 0 else xi
+
+
+def d_xi_to_r(xi, ascale, cmapr):
+    xi = np.asarray(xi, dtype=np.float64)
+    return 0.5 * (1.0 - xi) ** 2 / ascale if cmapr > 0 else np.ones_like(xi)
+
+
+def z_to_y(z, hscale, cmapz):
+    z = np.asarray(z, dtype=np.float64)
+    if cmapz == 1:
+        return np.sign(z) * np.arcsinh(np.abs(z / hscale))
+    if cmapz == 2:
+        return z / np.sqrt(z * z + hscale * hscale)
+    return z
+
+
+def y_to_z(y, hscale, cmapz):
+    y = np.asarray(y, dtype=np.float64)
+    if cmapz == 1:
+        return hscale * np.sinh(y)
+    if cmapz == 2:
+        return y * hscale / np.sqrt(1.0 - y * y)
+    return y
+
+
+# ---- vectorised SL table evaluation (exputil/SLGridMP2.cc:872-989) -----------------------------------
+
+def sl_eval(g: SLGridSph, r: np.ndarray, want_force: bool = True):
+    """potd[npts, L+1, nmax] (and dpot) of SLGridSph::get_pot / get_force at radii r."""
+    r = np.asarray(r, dtype=np.float64)
+    x = g.r_to_xi(r)
+    idx = np.clip(((x - g.xmin) / g.dxi).astype(np.int64), 0, g.numr - 2)
+    x1 = (g.xi[idx + 1] - x) / g.dxi
+    x2 = (x - g.xi[idx]) / g.dxi
+    sq = np.sqrt(g.ev)                                      # [L+1, nmax]
+    ef = g.ef                                               # [L+1, nmax, numr]
+    e0 = np.moveaxis(ef[:, :, idx], 2, 0)                   # [npts, L+1, nmax]
+    e1 = np.moveaxis(ef[:, :, idx + 1], 2, 0)
+    P0 = x1 * g.p0[idx] + x2 * g.p0[idx + 1]
+    potd = (x1[:, None, None] * e0 + x2[:, None, None] * e1) / sq[None] * P0[:, None, None]
+    if not want_force:
+        return potd, None
+    j = np.clip(((x - g.xmin) / g.dxi).astype(np.int64), 1, g.numr - 2)
+    p = (x - g.xi[j]) / g.dxi
+    if g.cmap == 1:
+        dxr = 0.5 * (1.0 - x) ** 2 / g.rmap
+    elif g.cmap == 2:
+        dxr = np.exp(-x)
+    else:
+        dxr = np.ones_like(x)
+    fac = dxr / g.dxi
+    em = np.moveaxis(ef[:, :, j - 1], 2, 0) * g.p0[j - 1][:, None, None]
+    ec = np.moveaxis(ef[:, :, j], 2, 0) * g.p0[j][:, None, None]
+    ep = np.moveaxis(ef[:, :, j + 1], 2, 0) * g.p0[j + 1][:, None, None]
+    dpot = fac[:, None, None] * ((p - 0.5)[:, None, None] * em - 2.0 * p[:, None, None] * ec +
+                                 (p + 0.5)[:, None, None] * ep) / sq[None]
+    return potd, dpot
+
+
+def _legendre_all(lmax: int, m: int, x: np.ndarray):
+    """P_l^m(x) and dP/dx for l = m..lmax (Condon-Shortley, unnormalised: src/Basis.cc:14-93)."""
+    ls = np.arange(m, lmax + 1)
+    P = np.stack([lpmv(m, l, x) for l in ls], axis=1)                      # [npts, nl]
+    xc = np.clip(x, -(1.0 - 3 * np.finfo(float).eps), 1.0 - 3 * np.finfo(float).eps)
+    somx2 = 1.0 / (xc * xc - 1.0)
+    dP = np.empty_like(P)
+    for k, l in enumerate(ls):
+        if l == m:
+            dP[:, k] = somx2 * xc * l * P[:, k]
+        else:
+            dP[:, k] = somx2 * (xc * l * P[:, k] - (l + m) * P[:, k - 1])
+    return P, dP
+
+
+def default_disk_density(acyl: float, hcyl: float, sech2: bool = False) -> Callable:
+    """src/Cylinder.cc:315-322"""
+    h = 0.5 * hcyl if sech2 else hcyl
+
+    def dens(R, z):
+        f = np.exp(-np.abs(z) / h)
+        s = 2.0 * f / (1.0 + f * f)
+        return np.exp(-R / acyl) * s * s / (4.0 * math.pi * acyl * acyl * h)
+
+    return dens
+
+
+def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 64,
+                 acyl: float = 0.01, hcyl: float = 0.002, rcylmin: float = 0.001,
+                 rcylmax: float = 20.0, lmaxfid: int = 32, nmaxfid: int = 24, numr: int = 2000,
+                 cmapr: int = 1, cmapz: int = 1, rnum: int = 200, tnum: int = 80,
+                 dens: Optional[Callable] = None) -> EmpCylGrid:
+    ASCALE, HSCALE, RMIN, RMAX = acyl, hcyl, rcylmin, rcylmax
+    pfac = 1.0 / math.sqrt(ASCALE)           # exputil/EmpCylSL.cc:173-175
+    ffac = pfac / ASCALE
+    dens = dens or default_disk_density(acyl, hcyl)
+
+    # 1. helper spherical basis on the exponential-sphere model (densR Exponential, :590-592)
+    model = NumericModel(lambda R: np.exp(-R) / (4.0 * math.pi * R), RMIN, RMAX, total_mass=None)
+    sl = build_slgrid(model, lmaxfid, nmaxfid, numr=numr, rmin=RMIN, rmax=RMAX * 0.99, cmap=1,
+                      rmap=1.0, nel=48, P=10)
+
+    # grid geometry (setup_table :2123-2137)
+    rtable = math.sqrt(0.5) * RMAX
+    XMIN = float(r_to_xi(RMIN * ASCALE, ASCALE, cmapr))
+    XMAX = float(r_to_xi(rtable * ASCALE, ASCALE, cmapr))
+    dX = (XMAX - XMIN) / numx
+    YMIN = float(z_to_y(-rtable * ASCALE, HSCALE, cmapz))
+    YMAX = float(z_to_y(rtable * ASCALE, HSCALE, cmapz))
+    dY = (YMAX - YMIN) / numy
+
+    # 2. quadrature nodes (generate_eof :2427-2454)
+    kr, wr = npleg.leggauss(rnum)
+    kr, wr = 0.5 * (kr + 1.0), 0.5 * wr
+    kt, wt = npleg.leggauss(tnum)
+    kt, wt = 0.5 * (kt + 1.0), 0.5 * wt
+    xi_q = XMIN + (XMAX - XMIN) * kr
+    rr_q = xi_to_r(xi_q, ASCALE, cmapr)                        # [rnum]
+    potd_q, _ = sl_eval(sl, rr_q / ASCALE, want_force=False)   # [rnum, L+1, nmax]
+    costh = -1.0 + 2.0 * kt                                    # [tnum]
+    dphi = 2.0 * math.pi                                       # nump = 1
+    RR, CT = np.meshgrid(rr_q, costh, indexing="ij")           # [rnum, tnum]
+    Rq = RR * np.sqrt(1.0 - CT * CT)
+    zq = RR * CT
+    jfac = (dphi * 2.0 * wt[None, :] * (XMAX - XMIN) * wr[:, None] * RR * RR /
+            d_xi_to_r(xi_q, ASCALE, cmapr)[:, None])
+    wq = (dens(Rq, zq) * jfac).reshape(-1)                     # [rnum*tnum]
+
+    # grid nodes for the tabulation (compute_eof_grid :1475-1492)
+    xg = XMIN + dX * np.arange(numx + 1)
+    yg = YMIN + dY * np.arange(numy + 1)
+    rg = xi_to_r(xg, ASCALE, cmapr)
+    zg = y_to_z(yg, HSCALE, cmapz)
+    Rg, Zg = np.meshgrid(rg, zg, indexing="ij")
+    Rg, Zg = Rg.reshape(-1), Zg.reshape(-1)
+    rrg = np.sqrt(Rg * Rg + Zg * Zg) + 1.0e-18
+    potd_g, dpot_g = sl_eval(sl, rrg / ASCALE, want_force=True)  # [npts, L+1, nmax]
+    cg = Zg / rrg
+
+    tab = np.zeros((6, mmax + 1, norder, numx + 1, numy + 1))
+    for m in range(mmax + 1):
+        nl = lmaxfid - m + 1
+        # 3. covariance: v[(l-m), ir] = pfac * P_l^m(cos) * potd(l, ir) [* 1/2 for m>0, nump = 1]
+        Pq, _ = _legendre_all(lmaxfid, m, costh)                # [tnum, nl]
+        V = (pfac * Pq[None, :, :, None] * potd_q[:, None, m:, :])  # [rnum, tnum, nl, nmax]
+        if m > 0:
+            V = 0.5 * V
+        V = V.reshape(rnum * tnum, nl * nmaxfid)                # nn = ir + NMAX*(l-m)
+        SC = (V * wq[:, None]).T @ V
+        mx = np.abs(SC).max()
+        if mx > 1e-5:
+            SC = SC / mx
+        ev, ef = np.linalg.eigh(SC)
+        order = np.argsort(ev)[::-1][:norder]
+        ef = ef[:, order]
+        nfid = min(4, ef.shape[0]) - 1
+        ef = ef * np.where(ef[nfid, :] < 0.0, -1.0, 1.0)[None, :]
+
+        # 4. tabulation
+        Pg, dPg = _legendre_all(lmaxfid, m, cg)                 # [npts, nl]
+        fac = 1.0 if m == 0 else math.sqrt(2.0)
+        potl = (fac * pfac) * Pg[:, :, None] * potd_g[:, m:, :]       # [npts, nl, nmax]
+        potr = (fac * ffac) * Pg[:, :, None] * dpot_g[:, m:, :]
+        pott = (fac * pfac) * dPg[:, :, None] * potd_g[:, m:, :]
+        frR = -(potr * (Rg / rrg)[:, None, None] - pott * (Zg * Rg / rrg ** 3)[:, None, None])
+        frZ = -(potr * (Zg / rrg)[:, None, None] + pott * (Rg * Rg / rrg ** 3)[:, None, None])
+        npts = Rg.size
+        tp = potl.reshape(npts, -1) @ ef                          # [npts, norder]
+        tr = frR.reshape(npts, -1) @ ef
+        tz = frZ.reshape(npts, -1) @ ef
+        for k, arr in ((0, tp), (1, tr), (2, tz)):
+            t = arr.T.reshape(norder, numx + 1, numy + 1)
+            tab[k, m] = t
+            if m > 0:
+                tab[k + 3, m] = t            # nump = 1: sine block == cosine block
+    return EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
+                      ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,
+                      xmin=XMIN, xmax=XMAX, dx=dX, ymin=YMIN, ymax=YMAX, dy=dY,
+                      tab=np.ascontiguousarray(tab))

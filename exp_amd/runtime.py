@@ -20,7 +20,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import SphConfig, as_f64, check
+from ._lib import CylConfig, SphConfig, as_f64, check
+from .empcyl import EmpCylGrid
 from .slgrid import SLGridSph
 
 
@@ -208,7 +209,63 @@ class Component:
                 self.ctx._children.remove(self)
 
 
-class SphereSL:
+class _Force:
+    """PotAccel-shaped methods shared by every force method (src/PotAccel.H:173-288)."""
+
+    ctx: Context
+    h: c_void_p
+
+    def set_multistep_level(self, mlevel: int) -> None:
+        check(self.lib.exp_amd_force_set_level(self.h, int(mlevel)), self.ctx.h)
+
+    def determine_coefficients(self, comp: "Component") -> None:
+        check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
+
+    def get_acceleration_and_potential(self, comp: "Component", external: bool = False) -> None:
+        check(self.lib.exp_amd_force_get_acceleration(self.h, comp.h, int(external)), self.ctx.h)
+
+    def compute_multistep_coefficients(self, mdrft: int) -> None:
+        check(self.lib.exp_amd_force_compute_multistep_coefficients(self.h, int(mdrft)), self.ctx.h)
+
+    def multistep_reset(self) -> None:
+        check(self.lib.exp_amd_force_multistep_reset(self.h), self.ctx.h)
+
+    def Used(self) -> int:
+        u = c_longlong()
+        check(self.lib.exp_amd_force_used(self.h, byref(u)), self.ctx.h)
+        return int(u.value)
+
+    def _get_flat(self, level=None, last=False) -> np.ndarray:
+        n = int(self.lib.exp_amd_force_ncoef(self.h))
+        out = np.empty(n)
+        if level is None:
+            check(self.lib.exp_amd_force_get_coefs(self.h, out.ctypes.data_as(c_void_p), n),
+                  self.ctx.h)
+        else:
+            check(self.lib.exp_amd_force_get_level_coefs(self.h, int(level), int(last),
+                                                         out.ctypes.data_as(c_void_p), n),
+                  self.ctx.h)
+        return out
+
+    def _set_flat(self, coef) -> None:
+        c = np.ascontiguousarray(coef, dtype=np.float64).reshape(-1)
+        assert c.size == int(self.lib.exp_amd_force_ncoef(self.h))
+        check(self.lib.exp_amd_force_set_coefs(self.h, c.ctypes.data_as(c_void_p), c.size),
+              self.ctx.h)
+
+    def step_kdk(self, comp: "Component", dt: float) -> None:
+        """One multistep=0 KDK step (src/step.cc:271-323), fused."""
+        check(self.lib.exp_amd_step_kdk(self.h, comp.h, float(dt)), self.ctx.h)
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.exp_amd_force_destroy(self.h)
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+
+class SphereSL(_Force):
     """``sphereSL`` force method: spherical-harmonic x Sturm-Liouville BFE."""
 
     def __init__(self, ctx: Context, grid: SLGridSph, scale: float = 1.0,
@@ -232,52 +289,52 @@ class SphereSL:
         self.multistep = multistep
         ctx._children.append(self)
 
-    # PotAccel interface -------------------------------------------------------------------
-    def set_multistep_level(self, mlevel: int) -> None:
-        check(self.lib.exp_amd_force_set_level(self.h, int(mlevel)), self.ctx.h)
-
-    def determine_coefficients(self, comp: Component) -> None:
-        check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
-
-    def get_acceleration_and_potential(self, comp: Component, external: bool = False) -> None:
-        check(self.lib.exp_amd_force_get_acceleration(self.h, comp.h, int(external)), self.ctx.h)
-
-    def compute_multistep_coefficients(self, mdrft: int) -> None:
-        check(self.lib.exp_amd_force_compute_multistep_coefficients(self.h, int(mdrft)), self.ctx.h)
-
-    def multistep_reset(self) -> None:
-        check(self.lib.exp_amd_force_multistep_reset(self.h), self.ctx.h)
-
-    def Used(self) -> int:
-        u = c_longlong()
-        check(self.lib.exp_amd_force_used(self.h, byref(u)), self.ctx.h)
-        return int(u.value)
-
-    def get_coefs(self) -> np.ndarray:
-        out = np.empty((self.nrows, self.nmax))
-        check(self.lib.exp_amd_force_get_coefs(self.h, out.ctypes.data_as(c_void_p), out.size),
-              self.ctx.h)
-        return out
+    def get_coefs(self, level=None, last=False) -> np.ndarray:
+        """(L+1)^2 x nmax, reference real-row order (src/SphericalBasis.cc:513-590)."""
+        return self._get_flat(level, last).reshape(self.nrows, self.nmax)
 
     def set_coefs(self, coef) -> None:
-        c = np.ascontiguousarray(coef, dtype=np.float64)
-        assert c.size == self.nrows * self.nmax
-        check(self.lib.exp_amd_force_set_coefs(self.h, c.ctypes.data_as(c_void_p), c.size),
-              self.ctx.h)
-
-    def step_kdk(self, comp: Component, dt: float) -> None:
-        """One multistep=0 KDK step (src/step.cc:271-323), fused."""
-        check(self.lib.exp_amd_step_kdk(self.h, comp.h, float(dt)), self.ctx.h)
-
-    def close(self) -> None:
-        if self.h:
-            self.lib.exp_amd_force_destroy(self.h)
-            self.h = None
-            if self in self.ctx._children:
-                self.ctx._children.remove(self)
+        self._set_flat(coef)
 
 
-def do_step_single(force: SphereSL, comp: Component, dt: float) -> None:
+class Cylinder(_Force):
+    """``cylinder`` force method: EmpCylSL empirical orthogonal functions (src/Cylinder.cc)."""
+
+    def __init__(self, ctx: Context, grid: EmpCylGrid, rcylmax: Optional[float] = None,
+                 EVEN_M: bool = False, multistep: int = 0):
+        self.ctx, self.lib, self.grid = ctx, ctx.lib, grid
+        rcylmax = grid.rmax if rcylmax is None else rcylmax
+        self.cfg = CylConfig(grid.mmax, grid.norder, grid.numx, grid.numy, grid.cmapr, grid.cmapz,
+                             grid.ascale, grid.hscale, grid.rtable, grid.xmin, grid.dx, grid.ymin,
+                             grid.dy, rcylmax, int(EVEN_M), int(multistep))
+        tab, ptr = as_f64(grid.tab)
+        h = c_void_p()
+        check(self.lib.exp_amd_cyl_create(ctx.h, byref(self.cfg), ptr, byref(h)), ctx.h)
+        self.h = h
+        self.mmax, self.nmax, self.multistep = grid.mmax, grid.norder, multistep
+        ctx._children.append(self)
+
+    def get_coefs(self, level=None, last=False):
+        """(accum_cos, accum_sin), each (mmax+1) x nmax (exputil/EmpCylSL.cc:4355-4550)."""
+        flat = self._get_flat(level, last).reshape(2, self.mmax + 1, self.nmax)
+        return flat[0], flat[1]
+
+    def set_coefs(self, cos, sin) -> None:
+        self._set_flat(np.stack([np.asarray(cos, dtype=np.float64),
+                                 np.asarray(sin, dtype=np.float64)]))
+
+    @property
+    def cylmass(self) -> float:
+        m = c_double()
+        check(self.lib.exp_amd_cyl_get_cylmass(self.h, byref(m)), self.ctx.h)
+        return m.value
+
+    @cylmass.setter
+    def cylmass(self, mass: float) -> None:
+        check(self.lib.exp_amd_cyl_set_cylmass(self.h, float(mass)), self.ctx.h)
+
+
+def do_step_single(force: _Force, comp: Component, dt: float) -> None:
     """Unfused multistep=0 step, call for call as ``do_step`` (src/step.cc:271-323)."""
     comp.incr_velocity(0.5 * dt)
     comp.incr_position(dt)

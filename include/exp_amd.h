@@ -134,6 +134,10 @@ int  exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c);
 int  exp_amd_force_get_coefs(exp_amd_force *f, double *coef, size_t count);
 int  exp_amd_force_set_coefs(exp_amd_force *f, const double *coef, size_t count);
 size_t exp_amd_force_ncoef(const exp_amd_force *f);
+/* Per-level coefficient sets of a multistep force: which = 0 -> expcoefN[level] (new),
+ * which = 1 -> expcoefL[level] (last)  (src/SphericalBasis.cc:785-792).              */
+int  exp_amd_force_get_level_coefs(exp_amd_force *f, int level, int which, double *coef,
+                                   size_t count);
 /* PotAccel::Used() (src/PotAccel.H:207): particles inside the window at the last
  * accumulation, summed over ranks.                                                  */
 int  exp_amd_force_used(exp_amd_force *f, long long *used);
@@ -148,6 +152,32 @@ int  exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int 
 /* Multistep coefficient bookkeeping (src/SphericalBasis.cc:1231-1333, :1013-1079).  */
 int  exp_amd_force_multistep_reset(exp_amd_force *f);
 int  exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft);
+
+/* ---- cylindrical force method (cylinder) -------------------------------------------------
+ * Replaces class Cylinder (src/Cylinder.cc) + EmpCylSL's accumulate / accumulated_eval
+ * (exputil/EmpCylSL.cc:4049-4146, :5256-5410) given the EOF tables.  Coefficients are
+ * ncoef = 2*(mmax+1)*nmax doubles: accum_cos[m][n] followed by accum_sin[m][n] (row m = 0 of the
+ * sine block is zero).                                                                       */
+typedef struct {
+  int    mmax, nmax;                   /* mmax, nmax (NORDER)                                  */
+  int    numx, numy;                   /* ncylnx, ncylny                                       */
+  int    cmapr, cmapz;                 /* cmapr, cmapz                                         */
+  double ascale, hscale;               /* acyl, hcyl                                           */
+  double rtable;                       /* Rtable = RMAX/sqrt(2)  (exputil/EmpCylSL.cc:2130)    */
+  double xmin, dx, ymin, dy;           /* grid of EmpCylSL::setup_table (:2131-2137)           */
+  double rcylmax;                      /* accumulation cut r^2+z^2 < (rcylmax*acyl)^2          */
+  int    EVEN_M;
+  int    multistep;
+} exp_amd_cyl_config;
+
+/* tab[6][mmax+1][nmax][numx+1][numy+1]: potC, rforceC, zforceC, potS, rforceS, zforceS */
+int  exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
+                        exp_amd_force **out);
+/* Mass of the particles inside the accumulation cut at the last accumulation (Cylinder's
+ * cylmass, src/Cylinder.cc:1081-1098), used for the off-grid monopole blend (:1364-1414);
+ * set_cylmass overrides it (playback / external coefficient sets).                       */
+int  exp_amd_cyl_get_cylmass(exp_amd_force *f, double *mass);
+int  exp_amd_cyl_set_cylmass(exp_amd_force *f, double mass);
 
 /* ---- fused step ------------------------------------------------------------------------
  * One multistep=0 KDK step of a single self-gravitating component

@@ -1,0 +1,242 @@
+/*
+ * cyl_oracle.c -- CPU restatement of EXP's cylindrical (EmpCylSL / Cylinder) hot path.
+ * TEST INFRASTRUCTURE ONLY; see bfe_oracle.h for the scope statement (parity unpinned).
+ *
+ * Tables are given: potC/rforceC/zforceC[m][n] and potS/rforceS/zforceS[m>=1][n] on the
+ * (NUMX+1) x (NUMY+1) grid of EmpCylSL::setup_table (exputil/EmpCylSL.cc:2123-2137), stored
+ * here as tab[kind][m][n][ix][iy] with kind 0..5 = potC, rforceC, zforceC, potS, rforceS, zforceS.
+ */
+#include "cyl_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DSMALL 1.0e-16 /* src/expand.H:130 */
+
+#define TAB(kind, m, n, ix, iy)                                                              \
+  g->tab[((((size_t)(kind) * (g->mmax + 1) + (m)) * g->norder + (n)) * (g->numx + 1) + (ix)) * \
+             (g->numy + 1) + (iy)]
+
+/* exputil/EmpCylSL.cc:6446-6463 */
+double orc_cyl_r_to_xi(const orc_cylgrid *g, double r)
+{
+  if (g->cmapr > 0) return (r / g->ascale - 1.0) / (r / g->ascale + 1.0);
+  return r;
+}
+
+/* exputil/EmpCylSL.cc:7109-7117 */
+double orc_cyl_z_to_y(const orc_cylgrid *g, double z)
+{
+  if (g->cmapz == 1) return z / (fabs(z) + DBL_MIN) * asinh(fabs(z / g->hscale));
+  else if (g->cmapz == 2) return z / sqrt(z * z + g->hscale * g->hscale);
+  return z;
+}
+
+/* cell + bilinear weights shared by get_pot (:5567-5597) and accumulated_eval (:5280-5314);
+ * enforce_limits == false (exputil/EmpCylSL.cc:56) */
+static void cyl_weights(const orc_cylgrid *g, double r, double z, int *pix, int *piy, double c[4])
+{
+  double X = (orc_cyl_r_to_xi(g, r) - g->xmin) / g->dx;
+  double Y = (orc_cyl_z_to_y(g, z) - g->ymin) / g->dy;
+  int ix = (int)X;
+  int iy = (int)Y;
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix >= g->numx) ix = g->numx - 1;
+  if (iy >= g->numy) iy = g->numy - 1;
+  double delx0 = (double)ix + 1.0 - X;
+  double dely0 = (double)iy + 1.0 - Y;
+  double delx1 = X - (double)ix;
+  double dely1 = Y - (double)iy;
+  c[0] = delx0 * dely0; /* c00 */
+  c[1] = delx1 * dely0; /* c10 */
+  c[2] = delx0 * dely1; /* c01 */
+  c[3] = delx1 * dely1; /* c11 */
+  *pix = ix;
+  *piy = iy;
+}
+
+#define INTERP(kind, m, n)                                                        \
+  (TAB(kind, m, n, ix, iy) * c[0] + TAB(kind, m, n, ix + 1, iy) * c[1] +          \
+   TAB(kind, m, n, ix, iy + 1) * c[2] + TAB(kind, m, n, ix + 1, iy + 1) * c[3])
+
+/* exputil/EmpCylSL.cc:5557-5631: Vc[m][n], Vs[m][n] */
+void orc_cyl_get_pot(const orc_cylgrid *g, double r, double z, double *Vc, double *Vs)
+{
+  if (z / g->ascale > g->rtable) z = g->rtable * g->ascale;
+  if (z / g->ascale < -g->rtable) z = -g->rtable * g->ascale;
+  int ix, iy;
+  double c[4];
+  cyl_weights(g, r, z, &ix, &iy, c);
+  const double fac = 1.0;
+  for (int mm = 0; mm <= g->mmax; mm++) {
+    if (g->EVEN_M && (mm / 2) * 2 != mm) continue;
+    for (int n = 0; n < g->norder; n++) {
+      Vc[mm * g->norder + n] = fac * INTERP(0, mm, n);
+      if (mm) Vs[mm * g->norder + n] = fac * INTERP(3, mm, n);
+    }
+  }
+}
+
+/* Cylinder::determine_coefficients_thread (src/Cylinder.cc:748-896, non-eof branch, one
+ * thread, one level) calling EmpCylSL::accumulate (exputil/EmpCylSL.cc:4049-4146).
+ * cosN[m][n], sinN[m][n] are zeroed here; returns the used count; *cylmass gets the mass
+ * of the particles that pass the Rmax2 cut (src/Cylinder.cc:866).                        */
+long orc_cyl_accumulate(const orc_cylgrid *g, long nbodies, const double *X, const double *Y,
+                        const double *Z, const double *M, const double *center, double *cosN,
+                        double *sinN, double *cylmass)
+{
+  const int nm = (g->mmax + 1) * g->norder;
+  double *vc = (double *)calloc(nm, sizeof(double));
+  double *vs = (double *)calloc(nm, sizeof(double));
+  memset(cosN, 0, sizeof(double) * nm);
+  memset(sinN, 0, sizeof(double) * nm);
+  const double Rmax2 = g->rcylmax * g->rcylmax * g->acyl * g->acyl;
+  long use = 0;
+  double mass0 = 0.0;
+  const double norm = -4.0 * M_PI;
+
+  for (long i = 0; i < nbodies; i++) {
+    double xx = X[i] - center[0];
+    double yy = Y[i] - center[1];
+    double zz = Z[i] - center[2];
+    double r2 = xx * xx + yy * yy;
+    double r = sqrt(r2);
+    double R2 = r2 + zz * zz;
+    if (R2 < Rmax2) {
+      double mas = M[i];
+      double phi = atan2(yy, xx);
+      /* EmpCylSL::accumulate */
+      double rr = sqrt(r * r + zz * zz);
+      if (!(rr / g->ascale > g->rtable)) {
+        orc_cyl_get_pot(g, r, zz, vc, vs);
+        for (int mm = 0; mm <= g->mmax; mm++) {
+          double mcos = cos(phi * mm);
+          double msin = sin(phi * mm);
+          for (int nn = 0; nn < g->norder; nn++) {
+            double hold = norm * mas * mcos * vc[mm * g->norder + nn];
+            cosN[mm * g->norder + nn] += hold;
+            if (mm > 0) {
+              hold = norm * mas * msin * vs[mm * g->norder + nn];
+              sinN[mm * g->norder + nn] += hold;
+            }
+          }
+        }
+      }
+      use++;
+      mass0 += mas;
+    }
+  }
+  *cylmass = mass0;
+  free(vc);
+  free(vs);
+  return use;
+}
+
+/* exputil/EmpCylSL.cc:5256-5410 (MMIN=0, MLIM=inf, NMIN=0, NLIM=inf) */
+void orc_cyl_accumulated_eval(const orc_cylgrid *g, const double *accum_cos,
+                              const double *accum_sin, double r, double z, double phi,
+                              double *p0, double *p, double *fr, double *fz, double *fp)
+{
+  *fr = 0.0;
+  *fz = 0.0;
+  *fp = 0.0;
+  *p = 0.0;
+  double rr = sqrt(r * r + z * z);
+  if (rr / g->ascale > g->rtable) return;
+
+  int ix, iy;
+  double c[4];
+  cyl_weights(g, r, z, &ix, &iy, c);
+
+  double ccos, ssin = 0.0, fac;
+  for (int mm = 0; mm <= g->mmax; mm++) {
+    if (g->EVEN_M && (mm / 2) * 2 != mm) continue;
+    ccos = cos(phi * mm);
+    ssin = sin(phi * mm);
+    for (int n = 0; n < g->norder; n++) {
+      fac = accum_cos[mm * g->norder + n] * ccos;
+      *p += fac * INTERP(0, mm, n);
+      *fr += fac * INTERP(1, mm, n);
+      *fz += fac * INTERP(2, mm, n);
+      fac = accum_cos[mm * g->norder + n] * ssin;
+      *fp += fac * mm * INTERP(0, mm, n);
+      if (mm) {
+        fac = accum_sin[mm * g->norder + n] * ssin;
+        *p += fac * INTERP(3, mm, n);
+        *fr += fac * INTERP(4, mm, n);
+        *fz += fac * INTERP(5, mm, n);
+        fac = -accum_sin[mm * g->norder + n] * ccos;
+        *fp += fac * mm * INTERP(3, mm, n);
+      }
+    }
+    if (mm == 0) *p0 = *p;
+  }
+}
+
+/* Cylinder::determine_acceleration_and_potential_thread (src/Cylinder.cc:1266-1446),
+ * mix off, no orientation transform: acc += frc, pot += pa.                         */
+void orc_cyl_accel(const orc_cylgrid *g, long nbodies, const double *X, const double *Y,
+                   const double *Z, const double *center, const double *accum_cos,
+                   const double *accum_sin, double cylmass, double *AX, double *AY, double *AZ,
+                   double *POT)
+{
+  const double ratmin = 0.75;
+  const double maxerf = 3.0;
+  const double midpt = ratmin + 0.5 * (1.0 - ratmin);
+  const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
+  double R2 = g->ascale * g->rtable;
+  R2 = R2 * R2;
+  const double mfactor = 1.0;
+
+  for (long i = 0; i < nbodies; i++) {
+    double xx = X[i] - center[0];
+    double yy = Y[i] - center[1];
+    double zz = Z[i] - center[2];
+    double frc[3] = {0.0, 0.0, 0.0};
+    double p, p0 = 0.0, fr, fz, fp, pa;
+
+    double r2 = xx * xx + yy * yy;
+    double r = sqrt(r2) + DSMALL;
+    double phi = atan2(yy, xx);
+    pa = 0.0;
+
+    double ratio = sqrt((r2 + zz * zz) / R2);
+    double frac, cfrac;
+    if (ratio >= 1.0) {
+      frac = 0.0;
+      cfrac = 1.0;
+    } else if (ratio > ratmin) {
+      frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth));
+      cfrac = 1.0 - frac;
+    } else {
+      cfrac = 0.0;
+      frac = 1.0;
+    }
+    cfrac *= mfactor;
+    frac *= mfactor;
+
+    if (ratio < 1.0) {
+      orc_cyl_accumulated_eval(g, accum_cos, accum_sin, r, zz, phi, &p0, &p, &fr, &fz, &fp);
+      frc[0] = (fr * xx / r - fp * yy / r2) * frac;
+      frc[1] = (fr * yy / r + fp * xx / r2) * frac;
+      frc[2] = fz * frac;
+      pa = p * frac;
+    }
+    if (ratio > ratmin) {
+      double r3 = r2 + zz * zz;
+      p = -cylmass / sqrt(r3); /* -M/r */
+      fr = p / r3;             /* -M/r^3 */
+      frc[0] += xx * fr * cfrac;
+      frc[1] += yy * fr * cfrac;
+      frc[2] += zz * fr * cfrac;
+      pa += p * cfrac;
+    }
+    POT[i] += pa;
+    AX[i] += frc[0];
+    AY[i] += frc[1];
+    AZ[i] += frc[2];
+  }
+}

@@ -1,0 +1,34 @@
+/* cyl_oracle.h -- CPU restatement of EXP's EmpCylSL/Cylinder hot path.  TEST INFRASTRUCTURE ONLY
+ * (same scope statement as bfe_oracle.h: parity unpinned; never used by exp_amd/). */
+#ifndef CYL_ORACLE_H
+#define CYL_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int mmax, norder, numx, numy, cmapr, cmapz, EVEN_M;
+  double ascale, hscale;       /* ASCALE, HSCALE (acyl, hcyl)                               */
+  double rtable;               /* Rtable = RMAX/sqrt(2)   (exputil/EmpCylSL.cc:2130)        */
+  double xmin, dx, ymin, dy;   /* grid of setup_table (:2131-2137)                          */
+  double rcylmax, acyl;        /* Cylinder's Rmax2 = (rcylmax*acyl)^2 cut (src/Cylinder.cc:752) */
+  const double *tab;           /* [6][mmax+1][norder][numx+1][numy+1]                       */
+} orc_cylgrid;
+
+double orc_cyl_r_to_xi(const orc_cylgrid *g, double r);
+double orc_cyl_z_to_y(const orc_cylgrid *g, double z);
+void   orc_cyl_get_pot(const orc_cylgrid *g, double r, double z, double *Vc, double *Vs);
+long   orc_cyl_accumulate(const orc_cylgrid *g, long n, const double *x, const double *y,
+                          const double *z, const double *mass, const double *center,
+                          double *cosN, double *sinN, double *cylmass);
+void   orc_cyl_accumulated_eval(const orc_cylgrid *g, const double *accum_cos,
+                                const double *accum_sin, double r, double z, double phi,
+                                double *p0, double *p, double *fr, double *fz, double *fp);
+void   orc_cyl_accel(const orc_cylgrid *g, long n, const double *x, const double *y,
+                     const double *z, const double *center, const double *accum_cos,
+                     const double *accum_sin, double cylmass, double *ax, double *ay, double *az,
+                     double *pot);
+#ifdef __cplusplus
+}
+#endif
+#endif

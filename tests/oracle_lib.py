@@ -34,6 +34,15 @@ class _SphParams(ctypes.Structure):
                 ("EVEN_M", ctypes.c_int), ("M0_only", ctypes.c_int)]
 
 
+class _CylGrid(ctypes.Structure):
+    _fields_ = [("mmax", ctypes.c_int), ("norder", ctypes.c_int), ("numx", ctypes.c_int),
+                ("numy", ctypes.c_int), ("cmapr", ctypes.c_int), ("cmapz", ctypes.c_int),
+                ("EVEN_M", ctypes.c_int), ("ascale", ctypes.c_double), ("hscale", ctypes.c_double),
+                ("rtable", ctypes.c_double), ("xmin", ctypes.c_double), ("dx", ctypes.c_double),
+                ("ymin", ctypes.c_double), ("dy", ctypes.c_double), ("rcylmax", ctypes.c_double),
+                ("acyl", ctypes.c_double), ("tab", c_double_p)]
+
+
 def build_oracle() -> str:
     so = os.path.join(_ORACLE_DIR, "_build", "liboracle.so")
     srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR)
@@ -154,6 +163,41 @@ class Oracle:
                               _dp(coef))
         return (np.stack([x, y, z], 1), np.stack([vx, vy, vz], 1), np.stack([ax, ay, az], 1),
                 pot, coef)
+
+    # -- cylindrical hot path ----------------------------------------------------------------
+    def cylgrid(self, g, rcylmax=None, EVEN_M=False) -> _CylGrid:
+        tab = np.ascontiguousarray(g.tab, dtype=np.float64)
+        self._keep.append(tab)
+        return _CylGrid(g.mmax, g.norder, g.numx, g.numy, g.cmapr, g.cmapz, int(EVEN_M), g.ascale,
+                        g.hscale, g.rtable, g.xmin, g.dx, g.ymin, g.dy,
+                        g.rmax if rcylmax is None else rcylmax, g.ascale, _dp(tab))
+
+    def cyl_accumulate(self, g, pos, mass, center=(0.0, 0.0, 0.0), **kw):
+        G = self.cylgrid(g, **kw)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        c = np.asarray(center, dtype=np.float64)
+        cosN = np.zeros((g.mmax + 1, g.norder))
+        sinN = np.zeros((g.mmax + 1, g.norder))
+        cylmass = ctypes.c_double(0.0)
+        self.lib.orc_cyl_accumulate.restype = ctypes.c_long
+        used = self.lib.orc_cyl_accumulate(ctypes.byref(G), ctypes.c_long(len(m)), _dp(x), _dp(y),
+                                           _dp(z), _dp(m), _dp(c), _dp(cosN), _dp(sinN),
+                                           ctypes.byref(cylmass))
+        return cosN, sinN, int(used), cylmass.value
+
+    def cyl_accel(self, g, pos, cosN, sinN, cylmass, center=(0.0, 0.0, 0.0), **kw):
+        G = self.cylgrid(g, **kw)
+        n = pos.shape[0]
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        c = np.asarray(center, dtype=np.float64)
+        cc = np.ascontiguousarray(cosN, dtype=np.float64)
+        ss = np.ascontiguousarray(sinN, dtype=np.float64)
+        ax, ay, az, pot = [np.zeros(n) for _ in range(4)]
+        self.lib.orc_cyl_accel(ctypes.byref(G), ctypes.c_long(n), _dp(x), _dp(y), _dp(z), _dp(c),
+                               _dp(cc), _dp(ss), ctypes.c_double(cylmass), _dp(ax), _dp(ay),
+                               _dp(az), _dp(pot))
+        return np.stack([ax, ay, az], axis=1), pot
 
     # -- multistep ---------------------------------------------------------------------
     def mstep_tables(self, multistep):

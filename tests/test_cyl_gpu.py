@@ -1,0 +1,150 @@
+"""Parity of the HIP cylindrical (EmpCylSL / Cylinder) path against the CPU oracle.  GPU only.
+Tolerances as in test_sph_gpu.py (fp64, re-associated sums)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-10
+ACC_TOL = 1e-9
+
+_CACHE = {}
+
+
+def cyl_grid(mmax=4, norder=6):
+    from exp_amd.empcyl import build_empcyl
+    key = (mmax, norder)
+    if key not in _CACHE:
+        _CACHE[key] = build_empcyl(mmax=mmax, norder=norder, numx=48, numy=24, lmaxfid=16,
+                                   nmaxfid=12, numr=600, rnum=60, tnum=30)
+    return _CACHE[key]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _disk(n, seed, g):
+    from exp_amd.models import sample_disk
+    m, pos, vel = sample_disk(n, seed, a=g.ascale, h=g.hscale)
+    pos[:, 0] *= 1.15            # make it non-axisymmetric so m > 0 rows are exercised
+    pos[:, 1] += 0.1 * g.ascale
+    return m, pos, vel
+
+
+def coef_err(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("mmax,norder,n", [(4, 6, 20000), (6, 12, 5000), (0, 3, 2000), (1, 2, 2000)])
+def test_cyl_coefficients_and_accel(ctx, oracle, mmax, norder, n):
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(mmax, norder)
+    m, pos, _ = _disk(n, 50 + mmax, g)
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g, pos, c_ref, s_ref, mass_ref)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert f.Used() == used_ref
+    assert f.cylmass == pytest.approx(mass_ref, rel=1e-12)
+    scale = np.abs(c_ref).max()
+    assert np.abs(cc - c_ref).max() <= COEF_TOL * scale
+    assert np.abs(ss - s_ref).max() <= COEF_TOL * scale
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    ascale = np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * ascale
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+
+
+def test_cyl_edges_offgrid_and_blend(ctx, oracle):
+    """particles beyond the grid (monopole only), in the erf blend zone, on the plane, near the axis,
+    inside RMIN (extrapolated weights), beyond rcylmax (not accumulated)."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(3000, 3, g)
+    A = g.ascale
+    Rt = g.rtable * A
+    extra = np.array([[1.2 * Rt, 0, 0], [0, 0.9 * Rt, 0.05 * Rt], [0.8 * Rt, 0.1 * Rt, 0],
+                      [0.3 * Rt, 0, 0.7 * Rt], [1e-5 * A, 2e-5 * A, 0], [0.5 * A, 0, 0],
+                      [0, -0.5 * A, 1e-9], [3 * A, 1 * A, 20 * g.hscale], [0.76 * Rt, 0, 0],
+                      [0.999 * Rt, 0, 0], [25 * A, 0, 0], [0, 0, 0.5 * Rt], [-2 * A, 0, -3 * g.hscale]])
+    pos = np.concatenate([pos, extra])
+    m = np.concatenate([m, np.full(len(extra), m[0])])
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g, pos, c_ref, s_ref, mass_ref)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert f.Used() == used_ref
+    scale = np.abs(c_ref).max()
+    assert np.abs(cc - c_ref).max() <= COEF_TOL * scale
+    assert np.abs(ss - s_ref).max() <= COEF_TOL * scale
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    ok = np.isfinite(a_ref).all(axis=1)          # x = y = 0 gives 0/0 in the reference too
+    ascale = np.linalg.norm(a_ref[ok], axis=1).max()
+    assert np.abs(out["acc"][ok] - a_ref[ok]).max() <= ACC_TOL * ascale
+    assert np.abs(out["pot"][ok] - p_ref[ok]).max() <= ACC_TOL * np.abs(p_ref[ok]).max()
+    assert np.array_equal(np.isfinite(out["acc"]).all(axis=1), ok)
+
+
+def test_cyl_even_m_and_external(ctx, oracle):
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(4000, 9, g)
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m, EVEN_M=True)
+    f = Cylinder(ctx, g, EVEN_M=True)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    scale = np.abs(c_ref).max()
+    for mm in range(0, g.mmax + 1, 2):           # odd m are unspecified under EVEN_M
+        assert np.abs(cc[mm] - c_ref[mm]).max() <= COEF_TOL * scale
+        assert np.abs(ss[mm] - s_ref[mm]).max() <= COEF_TOL * scale
+    # force on another (unsorted, halo-like) component
+    rng = np.random.default_rng(3)
+    tpos = rng.standard_normal((3000, 3)) * 5 * g.ascale
+    tgt = Component.from_arrays(ctx, np.ones(3000), tpos)
+    f.get_acceleration_and_potential(tgt, external=True)
+    out = tgt.download(("acc", "pot"))
+    a_ref, p_ref = oracle.cyl_accel(g, tpos, c_ref, s_ref, mass_ref, EVEN_M=True)
+    ascale = np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * ascale
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+
+
+def test_cyl_kdk_step(ctx, oracle):
+    """fused step == unfused sequence == oracle pieces."""
+    from exp_amd.runtime import Component, Cylinder, do_step_single
+    g = cyl_grid(4, 6)
+    m, pos, vel = _disk(5000, 13, g)
+    vel = vel + 0.01 * np.random.default_rng(1).standard_normal(vel.shape)
+    acc0 = np.zeros_like(pos)
+    dt = 1e-4
+    f = Cylinder(ctx, g)
+    c1 = Component.from_arrays(ctx, m, pos, vel)
+    c2 = Component.from_arrays(ctx, m, pos, vel)
+    f.step_kdk(c1, dt)
+    o1 = c1.download()
+    do_step_single(f, c2, dt)
+    o2 = c2.download()
+    # oracle: kick (acc0 = 0), drift, accumulate, accel, kick
+    p = pos + vel * dt
+    c_ref, s_ref, _, mass_ref = oracle.cyl_accumulate(g, p, m)
+    a_ref, p_ref = oracle.cyl_accel(g, p, c_ref, s_ref, mass_ref)
+    v = vel + a_ref * (0.5 * dt)
+    for o in (o1, o2):
+        assert np.abs(o["pos"] - p).max() <= 1e-15
+        ascale = np.linalg.norm(a_ref, axis=1).max()
+        assert np.abs(o["acc"] - a_ref).max() <= ACC_TOL * ascale
+        assert np.abs(o["vel"] - v).max() <= 1e-9 * np.abs(v).max()
