@@ -221,6 +221,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.lmax = L; S.nmax = nmax; S.numr = numr; S.cmap = cfg->cmap; S.nrows = nrows;
   S.rmap = cfg->rmap; S.scale = cfg->scale; S.rmin = cfg->rmin; S.rmax = cfg->rmax;
   S.xmin = cfg->xmin; S.dxi = cfg->dxi;
+  S.inv_dxi = 1.0 / cfg->dxi; S.inv_scale = 1.0 / cfg->scale;
   S.cx = S.cy = S.cz = 0.0;
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;

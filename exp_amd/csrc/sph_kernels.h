@@ -36,6 +36,8 @@ typedef const __attribute__((address_space(4))) double *cdp;   // constant (scal
 struct SphDev {
   int lmax, nmax, numr, cmap, nrows;
   double rmap, scale, rmin, rmax, xmin, dxi;
+  double inv_dxi, inv_scale;   // reciprocals for the interpolation WEIGHTS (the cell index keeps the
+                               // reference's exact division so that cell assignment is identical)
   double cx, cy, cz;
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
   const double *xi;      // [numr]
@@ -116,9 +118,9 @@ __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double
 {
   double R2 = xx * xx + yy * yy;
   if (R2 > 0.0) {
-    double R = sqrt(R2);
-    c = xx / R;
-    s = yy / R;
+    const double iR = 1.0 / sqrt(R2);
+    c = xx * iR;
+    s = yy * iR;
   } else {
     c = 1.0;
     s = 0.0;
@@ -206,15 +208,23 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
   int cur = -1;
   unsigned long long used = 0;
 
+  // software prefetch: the loads of chunk k+1 are in flight while chunk k is reduced
+  double nx = 0, ny = 0, nz = 0, nm = 0;
+  if (cbeg + lane < cend) {
+    nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane];
+  }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
     const bool valid = i < cend;
     double xx = 0, yy = 0, zz = 1, mass = 0;
     if (valid) {
-      xx = X[i] - S.cx;
-      yy = Y[i] - S.cy;
-      zz = Z[i] - S.cz;
-      mass = M[i];
+      xx = nx - S.cx;
+      yy = ny - S.cy;
+      zz = nz - S.cz;
+      mass = nm;
+    }
+    if (i + 64 < cend) {
+      nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
     }
     // src/SphericalBasis.cc:486-494
     const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
@@ -225,8 +235,8 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
     const double xi = sph_r_to_xi(S, r / S.scale);
     const int idx = sph_cell(S, xi);
     // exputil/SLGridMP2.cc:894-895, :901-902
-    const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
-    const double x2 = (xi - S.xi[idx]) / S.dxi;
+    const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+    const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
     const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
     const double t0 = inwin ? mass * fac0 * P0 : 0.0;
     if (MLO == 0 && inwin) used++;
@@ -513,13 +523,13 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
   const double xi = sph_r_to_xi(S, rs);
   int idx = sph_cell(S, xi);
   // get_pot weights (exputil/SLGridMP2.cc:894-902)
-  const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
-  const double x2 = (xi - S.xi[idx]) / S.dxi;
+  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
   const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
   // get_force weights (exputil/SLGridMP2.cc:971-985)
   const int jdx = idx < 1 ? 1 : idx;
-  const double pf = (xi - S.xi[jdx]) / S.dxi;
-  const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
+  const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+  const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
   // Legendre derivative pole clamp (src/Basis.cc:81-84)
   double xc = costh;
   if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
@@ -546,17 +556,19 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
 
   // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
   const double fac = xx * xx + yy * yy;
-  const double potr = o.potr * ffac / (S.scale * S.scale);
-  const double potl = o.potl * P0 / S.scale;
-  const double pott = o.pott * (P0 * dfac) / S.scale;
-  const double potp = o.potp * P0 / S.scale;
-  const double r3 = r * r * r;
-  double ax = -(potr * xx / r - pott * xx * zz / r3);
-  double ay = -(potr * yy / r - pott * yy * zz / r3);
-  double az = -(potr * zz / r + pott * fac / r3);
+  const double potr = o.potr * ffac * (S.inv_scale * S.inv_scale);
+  const double potl = o.potl * P0 * S.inv_scale;
+  const double pott = o.pott * (P0 * dfac) * S.inv_scale;
+  const double potp = o.potp * P0 * S.inv_scale;
+  const double ir = 1.0 / r, ir3 = ir * ir * ir;
+  const double pr = potr * ir, pt3 = pott * ir3;
+  double ax = -(pr * xx - pt3 * xx * zz);
+  double ay = -(pr * yy - pt3 * yy * zz);
+  double az = -(pr * zz + pt3 * fac);
   if (fac > DSMALL) {
-    ax += potp * yy / fac;
-    ay += -potp * xx / fac;
+    const double pf2 = potp / fac;
+    ax += pf2 * yy;
+    ay += -pf2 * xx;
   }
   double pt = potl;
   if (!assign) {

@@ -632,3 +632,153 @@ int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_leve
   if ((int)nlev < mfirst_mdrft) nlev = mfirst_mdrft;
   return (int)nlev;
 }
+
+/* ---- block-multistep master step for one self-gravitating spherical component ------------
+ * do_step's multistep block (src/step.cc:98-269) with ComponentContainer::compute_expansion /
+ * compute_potential (src/ComponentContainer.cc:1173-1226, :580-727) for a single component,
+ * SphericalBasis::determine_coefficients_particles' N/L swap (src/SphericalBasis.cc:785-792),
+ * compute_multistep_coefficients (:1231-1333), adjust_multistep_level (src/multistep.cc:344-627)
+ * with multistep_update / _finish (src/SphericalBasis.cc:1033-1079, :1156-1228).
+ * State carried by the caller: particle arrays, integer levels, coefN/coefL[(ms+1)][ncoef].
+ * this_step == 0 reproduces the reference's "do all levels" rule on the first sub-step.       */
+
+/* one particle's coefficient contribution (multistep_update window: r < rmax only) */
+static void sph_one_particle(const orc_slgrid *g, const orc_sph_params *P, double xx, double yy,
+                             double zz, double mass, double *val /* [(L+1)^2*nmax] */,
+                             double *p, double *cosm, double *sinm, double *potd,
+                             const double *factorial, int *inside)
+{
+  const int Lmax = g->lmax, nmax = g->nmax, lmax = g->lmax;
+  const double fac0 = -4.0 * M_PI;
+  double r2 = (xx * xx + yy * yy + zz * zz);
+  double r = sqrt(r2) + DSMALL;
+  *inside = 0;
+  if (r < P->rmax) {
+    *inside = 1;
+    double costh = zz / r;
+    double phi = atan2(yy, xx);
+    double rs = r / P->scale;
+    orc_legendre_R(Lmax, costh, p);
+    orc_sinecosine_R(Lmax, phi, cosm, sinm);
+    orc_sl_get_pot(g, rs, potd);
+    for (int l = 0, loffset = 0; l <= Lmax; loffset += (2 * l + 1), l++) {
+      for (int m = 0, moffset = 0; m <= l; m++) {
+        double facL = factorial[l * (Lmax + 1) + m] * P_(l, m);
+        if (m == 0) {
+          for (int n = 0; n < nmax; n++)
+            val[(loffset + moffset) * nmax + n] = potd[l * nmax + n] * facL * mass * fac0 / 1.0;
+          moffset++;
+        } else {
+          double fac1 = facL * cosm[m];
+          double fac2 = facL * sinm[m];
+          for (int n = 0; n < nmax; n++) {
+            val[(loffset + moffset) * nmax + n] = potd[l * nmax + n] * fac1 * mass * fac0 / 1.0;
+            val[(loffset + moffset + 1) * nmax + n] = potd[l * nmax + n] * fac2 * mass * fac0 / 1.0;
+          }
+          moffset += 2;
+        }
+      }
+    }
+  }
+}
+
+void orc_sph_multistep_step(const orc_slgrid *g, const orc_sph_params *P, int multistep,
+                            double dtime, const double *dynfrac, int shiftlevl, long n,
+                            double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                            double *ax, double *ay, double *az, double *pot, const double *mass,
+                            int *level, const double *center, double *coefN, double *coefL,
+                            int this_step, double *coef_out, long *nswitch)
+{
+  const int Lmax = g->lmax, nmax = g->nmax;
+  const long ncoef = (long)(Lmax + 1) * (Lmax + 1) * nmax;
+  orc_mstep_tables *T = orc_mstep_create(multistep);
+  const int Mstep = T->Mstep;
+  const double dt = dtime / Mstep;
+
+  double *tx = (double *)malloc(sizeof(double) * n), *ty = (double *)malloc(sizeof(double) * n),
+         *tz = (double *)malloc(sizeof(double) * n), *tm = (double *)malloc(sizeof(double) * n);
+  double *differ = (double *)malloc(sizeof(double) * (multistep + 1) * ncoef);
+  double *val = (double *)malloc(sizeof(double) * ncoef);
+  double *p = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *cosm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *sinm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (Lmax + 1) * nmax);
+  double *factorial = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *tmpc = (double *)malloc(sizeof(double) * ncoef);
+  orc_factorial_table(Lmax, factorial);
+  long switched = 0;
+
+  for (int mstep = 0; mstep < Mstep; mstep++) {
+    int mdrft = mstep;
+    for (int M = T->mfirst[mstep]; M <= multistep; M++) {
+      double DT = dt * T->mintvl[M];
+      /* incr_velocity(0.5*DT, M); incr_position(DT, M) */
+      for (long i = 0; i < n; i++)
+        if (level[i] == M) {
+          vx[i] += ax[i] * (0.5 * DT); vy[i] += ay[i] * (0.5 * DT); vz[i] += az[i] * (0.5 * DT);
+          x[i] += vx[i] * DT; y[i] += vy[i] * DT; z[i] += vz[i] * DT;
+        }
+      /* compute_expansion(M): swap N/L, accumulate level M into N[M] */
+      memcpy(coefL + (size_t)M * ncoef, coefN + (size_t)M * ncoef, sizeof(double) * ncoef);
+      long k = 0;
+      for (long i = 0; i < n; i++)
+        if (level[i] == M) { tx[k] = x[i]; ty[k] = y[i]; tz[k] = z[i]; tm[k] = mass[i]; k++; }
+      orc_sph_accumulate(g, P, k, tx, ty, tz, tm, center, coefN + (size_t)M * ncoef, 0);
+    }
+    mdrft = mstep + 1;
+    /* compute_potential(mfirst[mstep]) */
+    const int mlev = T->mfirst[mstep];
+    orc_mstep_combine(T, mdrft, ncoef, coefL, coefN, coef_out);
+    for (long i = 0; i < n; i++)
+      if (level[i] >= mlev) {
+        ax[i] = ay[i] = az[i] = pot[i] = 0.0;
+        orc_sph_accel(g, P, 1, x + i, y + i, z + i, center, coef_out, ax + i, ay + i, az + i, pot + i);
+      }
+    /* second half kick for the levels active at the next sub-step */
+    for (int M = T->mfirst[mdrft]; M <= multistep; M++) {
+      double DT = dt * T->mintvl[M];
+      for (long i = 0; i < n; i++)
+        if (level[i] == M) {
+          vx[i] += ax[i] * (0.5 * DT); vy[i] += ay[i] * (0.5 * DT); vz[i] += az[i] * (0.5 * DT);
+        }
+    }
+    /* adjust_multistep_level */
+    {
+      int first = T->mfirst[mdrft];
+      if (this_step == 0 && mstep == 0) first = 0;
+      for (int M = T->mfirst[mdrft]; M <= multistep; M++)
+        memset(differ + (size_t)M * ncoef, 0, sizeof(double) * ncoef);
+      for (int lev = first; lev <= multistep; lev++) {
+        for (long i = 0; i < n; i++) {
+          if (level[i] != lev) continue;
+          double v[3] = {vx[i], vy[i], vz[i]}, a[3] = {ax[i], ay[i], az[i]};
+          double dtreq;
+          int nlev = orc_level_select(dtime, multistep, T->mfirst[mdrft], lev, shiftlevl, dynfrac,
+                                      0.0, v, a, pot[i], &dtreq);
+          if (nlev != lev) {
+            int inside;
+            sph_one_particle(g, P, x[i] - center[0], y[i] - center[1], z[i] - center[2], mass[i],
+                             val, p, cosm, sinm, potd, factorial, &inside);
+            if (inside) {
+              /* levels below mfirst[mdrft] are never cleared/added by _begin/_finish */
+              for (long q = 0; q < ncoef; q++) {
+                if (lev >= T->mfirst[mdrft]) differ[(size_t)lev * ncoef + q] -= val[q];
+                if (nlev >= T->mfirst[mdrft]) differ[(size_t)nlev * ncoef + q] += val[q];
+              }
+            }
+            level[i] = -(nlev + 1); /* commit after the sweep so that a particle is seen once */
+            switched++;
+          }
+        }
+      }
+      for (long i = 0; i < n; i++)
+        if (level[i] < 0) level[i] = -level[i] - 1;
+      for (int M = T->mfirst[mdrft]; M <= multistep; M++)
+        for (long q = 0; q < ncoef; q++) coefN[(size_t)M * ncoef + q] += differ[(size_t)M * ncoef + q];
+    }
+  }
+  if (nswitch) *nswitch = switched;
+  orc_mstep_free(T);
+  free(tx); free(ty); free(tz); free(tm); free(differ); free(val); free(p); free(cosm); free(sinm);
+  free(potd); free(factorial); free(tmpc);
+}

@@ -110,6 +110,16 @@ int    orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_l
                         int shiftlevl, const double *dynfrac, double scale,
                         const double *v, const double *a, double pot, double *dtreq);
 
+/* One block-multistep master step (src/step.cc:98-269) of a single self-gravitating spherical
+ * component.  level[n] in/out; coefN/coefL [(multistep+1)][(lmax+1)^2*nmax] in/out; coef_out
+ * receives the last combined coefficient set; *nswitch the number of level changes.          */
+void   orc_sph_multistep_step(const orc_slgrid *g, const orc_sph_params *P, int multistep,
+                              double dtime, const double *dynfrac, int shiftlevl, long n,
+                              double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                              double *ax, double *ay, double *az, double *pot, const double *mass,
+                              int *level, const double *center, double *coefN, double *coefL,
+                              int this_step, double *coef_out, long *nswitch);
+
 #ifdef __cplusplus
 }
 #endif
