@@ -67,6 +67,7 @@ SIGNATURES = {
     "exp_amd_comp_zero_acc": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p)]),
+    "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_force_destroy": (None, [c_void_p]),
     "exp_amd_force_set_level": (c_int, [c_void_p, c_int]),
     "exp_amd_force_determine_coefficients": (c_int, [c_void_p, c_void_p]),
@@ -74,6 +75,8 @@ SIGNATURES = {
     "exp_amd_force_set_coefs": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_force_ncoef": (c_size_t, [c_void_p]),
     "exp_amd_force_get_level_coefs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "exp_amd_force_adjust_multistep_level": (c_int, [c_void_p, c_void_p, c_double, c_double_p, c_int,
+                                                     c_int, c_int, POINTER(c_longlong)]),
     "exp_amd_cyl_create": (c_int, [c_void_p, POINTER(CylConfig), c_void_p, POINTER(c_void_p)]),
     "exp_amd_cyl_get_cylmass": (c_int, [c_void_p, POINTER(c_double)]),
     "exp_amd_cyl_set_cylmass": (c_int, [c_void_p, c_double]),
@@ -82,6 +85,14 @@ SIGNATURES = {
     "exp_amd_force_multistep_reset": (c_int, [c_void_p]),
     "exp_amd_force_compute_multistep_coefficients": (c_int, [c_void_p, c_int]),
     "exp_amd_step_kdk": (c_int, [c_void_p, c_void_p, c_double]),
+    "exp_amd_sim_create": (c_int, [c_void_p, c_int, c_double, c_double_p, c_int, POINTER(c_void_p)]),
+    "exp_amd_sim_destroy": (None, [c_void_p]),
+    "exp_amd_sim_add_component": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
+    "exp_amd_sim_add_interaction": (c_int, [c_void_p, c_int, c_int]),
+    "exp_amd_sim_init": (c_int, [c_void_p]),
+    "exp_amd_sim_step": (c_int, [c_void_p, c_int]),
+    "exp_amd_sim_time": (c_double, [c_void_p]),
+    "exp_amd_sim_last_switches": (c_longlong, [c_void_p]),
     "exp_amd_profile_enable": (c_int, [c_void_p, c_int]),
     "exp_amd_profile_get": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double),
                                     POINTER(c_longlong)]),

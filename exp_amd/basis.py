@@ -1,0 +1,463 @@
+"""``pyEXP.basis``-shaped front end over the C ABI (SURVEY.md section 8 row a21 / boundary B2).
+
+Mirrors the calls of ``BasisClasses::BiorthBasis`` that ``pyEXP/BasisWrappers.cc:984-2260``
+exposes and that the reference's tests use (``tests/Halo/createCoefs.py:72-96``,
+``tests/Halo/sph_basis.py``, ``tests/Disk/cyl_basis.py``):
+
+    basis = Basis.factory(yaml_text)              # id: sphereSL | cylinder
+    coefs = basis.createFromArray(mass, pos, time=0.0, center=[0,0,0])
+    basis.initFromArray(); basis.addFromArray(m, p); coefs = basis.makeFromArray(time)
+    basis.set_coefs(coefs); acc = basis.getAccel(pos)            # [N,3]
+    basis.orthoCheck(); basis.cacheInfo(cachename)
+
+Semantics follow the pyEXP twins, not the n-body classes, where they differ
+(``expui/BiorthBasis.cc:583-665``, ``:818-926``, ``:4585-4757``): array layout rules of
+``addFromArray`` (rows vs columns, ``posvelrows``), rotation/centre applied as
+``rot @ (pos - ctr)``, NO exterior multipole continuation in ``getAccel``, complex
+(l, m>=0) x n coefficient packing of ``load_coefs`` / ``set_coefs`` (``:482-581``).
+All particle work runs on the GPU through libexp_amd.so; this file only parses the YAML keys
+(same names as the reference), builds / caches the tables and marshals arrays.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from typing import Optional
+
+import numpy as np
+import yaml
+
+from .empcyl import EmpCylGrid, build_empcyl
+from .models import TableModel
+from .runtime import Component, Context, Cylinder, SphereSL
+from .slgrid import SLGridSph, build_slgrid
+
+# expui/BiorthBasis.cc valid_keys of Spherical / SphericalSL
+SPH_KEYS = {"rmapping", "cmap", "Lmax", "dof", "npca", "npca0", "pcavar", "pcadiag", "pcavtk",
+            "subsamp", "hexp", "snr", "samplesz", "vtkfreq", "tksmooth", "tkcum", "tk_type", "nmax",
+            "modelname", "cachename", "scale", "rmin", "rmax", "numr", "nums", "N1", "N2", "NO_L0",
+            "NO_L1", "EVEN_L", "EVEN_M", "M0_ONLY", "diverge", "dfac", "dtime", "noff", "mtype"}
+CYL_KEYS = {"tk_type", "rcylmin", "rcylmax", "acyl", "hcyl", "sech2", "snr", "evcut", "nmaxfid",
+            "lmaxfid", "mmax", "mlim", "nmax", "ncylodd", "ncylnx", "ncylny", "ncylr", "ncylorder",
+            "ncylrecomp", "npca", "npca0", "nvtk", "cachename", "oldcache", "eof_file", "override",
+            "samplesz", "rnum", "pnum", "tnum", "ashift", "expcond", "ignore", "deproject", "logr",
+            "pcavar", "pcaeof", "pcavtk", "pcadiag", "subsamp", "try_cache", "density", "EVEN_M",
+            "cmap", "cmapr", "cmapz", "aratio", "hratio", "dweight", "Mfac", "HERNA", "rwidth",
+            "rfactor", "rtrunc", "rpow", "mtype", "dtype", "vflag", "self_consistent", "playback",
+            "coefCompute", "coefMaster", "pyname", "dumpbasis"}
+
+_default_ctx: Optional[Context] = None
+
+
+def _ctx() -> Context:
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.h is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+@dataclasses.dataclass
+class SphStruct:
+    """``CoefClasses::SphStruct``: complex coefficients [(L+1)(L+2)/2, nmax] (m >= 0 only)."""
+    lmax: int
+    nmax: int
+    scale: float
+    time: float
+    coefs: np.ndarray
+    ctr: np.ndarray
+    rot: np.ndarray
+    normed: bool = True
+    geometry: str = "sphere"
+
+
+@dataclasses.dataclass
+class CylStruct:
+    """``CoefClasses::CylStruct``: complex coefficients [mmax+1, nmax] = cos + i sin."""
+    mmax: int
+    nmax: int
+    time: float
+    coefs: np.ndarray
+    ctr: np.ndarray
+    rot: np.ndarray
+    geometry: str = "cylinder"
+
+
+class BiorthBasis:
+    name = ""
+
+    def __init__(self, conf: dict, ctx: Optional[Context] = None):
+        self.conf = conf
+        self.ctx = ctx or _ctx()
+        self.coefctr = np.zeros(3)
+        self.coefrot = np.eye(3)
+        self.coefret = None
+        self.coefindx = 0
+        self._ftor = None
+
+    # -- array front end (expui/BiorthBasis.cc:4585-4757) -------------------------------------------
+    def initFromArray(self, center=(0.0, 0.0, 0.0), rot=None) -> None:
+        self.coefctr = np.asarray(center, dtype=np.float64).reshape(3)
+        self.coefrot = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        self.reset_coefs()
+        self.coefindx = 0
+        self.coefret = True
+
+    def setSelector(self, ftor) -> None:
+        self._ftor = ftor
+
+    def _layout(self, p: np.ndarray, posvelrows: bool):
+        """the dimension-deduction rule of addFromArray (:4638-4655)"""
+        rows, cols = p.shape
+        if cols in (3, 6):
+            if rows not in (3, 6):
+                posvelrows = False
+        if rows in (3, 6):
+            if cols not in (3, 6):
+                posvelrows = True
+        if posvelrows:
+            if rows < 3:
+                raise RuntimeError("Basis::addFromArray: you must pass a position array with at "
+                                   f"least three rows for x, y, z.  Yours has {rows}.")
+            return p[:3].T, (p[3:6].T if rows == 6 else None)
+        if cols < 3:
+            raise RuntimeError("Basis::addFromArray: you must pass a position array with at "
+                               f"least three columns for x, y, z.  Yours has {cols}.")
+        return p[:, :3], (p[:, 3:6] if cols == 6 else None)
+
+    def addFromArray(self, m, p, roundrobin: bool = True, posvelrows: bool = False) -> None:
+        if not self.coefret:
+            raise RuntimeError("Basis::addFromArray: you must initialize coefficient accumulation "
+                               "with a call to Basis::initFromArray()")
+        m = np.asarray(m, dtype=np.float64).reshape(-1)
+        p = np.asarray(p, dtype=np.float64)
+        if p.ndim != 2:
+            p = np.stack([np.asarray(a, dtype=np.float64) for a in p])
+        pos, vel = self._layout(p, posvelrows)
+        pos = (pos - self.coefctr) @ self.coefrot.T
+        if self._ftor is not None:
+            v = np.zeros_like(pos) if vel is None else vel @ self.coefrot.T
+            keep = np.array([bool(self._ftor(m[i], pos[i], v[i], self.coefindx + i))
+                             for i in range(len(m))])
+            pos, m = pos[keep], m[keep]
+        self.coefindx += len(m)
+        self._accumulate_batch(m, pos)
+
+    def makeFromArray(self, time: float = 0.0):
+        self.make_coefs()
+        return self.load_coefs(time)
+
+    def createFromArray(self, m, p, time: float = 0.0, center=(0.0, 0.0, 0.0), rot=None,
+                        roundrobin: bool = True, posvelrows: bool = False):
+        self.initFromArray(center, rot)
+        self.addFromArray(m, p, roundrobin, posvelrows)
+        return self.makeFromArray(time)
+
+    def accumulate(self, x, y, z, mass, indx: int = 0) -> None:
+        self._accumulate_batch(np.atleast_1d(np.float64(mass)),
+                               np.array([[x, y, z]], dtype=np.float64))
+
+    def make_coefs(self) -> None:
+        """single process: the MPI reduction of expui/BiorthBasis.cc:667-709 is the device
+        all-reduce already applied per batch"""
+
+    def getAccel(self, *args) -> np.ndarray:
+        """getAccel(x, y, z) -> [3]; getAccel(xv, yv, zv) or getAccel(pos[N,3]) -> [N,3]
+        (expui/BiorthBasis.H:251-266)"""
+        if len(args) == 3:
+            x, y, z = [np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in args]
+            pos = np.stack([x, y, z], axis=1)
+            single = np.ndim(args[0]) == 0
+        else:
+            pos = np.asarray(args[0], dtype=np.float64)
+            single = False
+        pos = (pos - self.coefctr) @ self.coefrot.T
+        acc = self._accel(pos) @ self.coefrot        # rotate back: rot^T a
+        return acc[0] if single else acc
+
+
+class SphericalSL(BiorthBasis):
+    """``sphereSL`` (expui/BiorthBasis.H:503): YAML keys Lmax, nmax, numr, rmin, rmax, scale,
+    rmapping, cmap, modelname, cachename, NO_L0, NO_L1, EVEN_L, EVEN_M, M0_ONLY."""
+
+    name = "sphereSL"
+
+    def __init__(self, conf: dict, ctx: Optional[Context] = None):
+        super().__init__(conf, ctx)
+        bad = set(conf) - SPH_KEYS
+        if bad:
+            raise RuntimeError(f"Basis::Basis::Spherical: unmatched parameter(s) {sorted(bad)}")
+        self.cmap = int(conf.get("cmap", 1))
+        self.lmax = int(conf.get("Lmax", 6))
+        self.nmax = int(conf.get("nmax", 18))
+        self.rmap = float(conf.get("rmapping", 1.0))
+        self.scale = float(conf.get("scale", 1.0))
+        self.numr = int(conf.get("numr", 800))
+        model_file = conf.get("modelname", "SLGridSph.model")
+        self.cachename = conf.get("cachename", "")
+        if not self.cachename:
+            raise RuntimeError("SphericalSL requires a specified cachename in your YAML config")
+        self.model = TableModel(model_file)
+        rmin = float(conf.get("rmin", 0.0))
+        rmax = float(conf.get("rmax", np.finfo(np.float64).max))
+        if "rmin" not in conf or rmin < self.model.rmin:
+            rmin = self.model.rmin
+        if "rmax" not in conf or rmax > self.model.rmax:
+            rmax = self.model.rmax * 0.99
+        self.rmin, self.rmax = rmin, rmax
+        self.grid = self._load_or_build()
+        flags = {k: bool(conf.get(k, False)) for k in ("NO_L0", "NO_L1", "EVEN_L", "EVEN_M")}
+        flags["M0_only"] = bool(conf.get("M0_ONLY", False))
+        self.force = SphereSL(self.ctx, self.grid, scale=self.scale, rmin=rmin, rmax=rmax, **flags)
+        _lib_check = self.force.lib.exp_amd_sph_set_exterior(self.force.h, 0)   # pyEXP semantics
+        assert _lib_check == 0
+        self.nrows = (self.lmax + 1) ** 2
+        self.expcoef = np.zeros((self.nrows, self.nmax))
+        self.used = 0
+        self.orthoTest(200)
+
+    # -- tables / cache -----------------------------------------------------------------------------
+    def _cache_path(self) -> str:
+        return self.cachename if self.cachename.endswith(".npz") else self.cachename + ".npz"
+
+    def _params(self) -> dict:
+        return dict(lmax=self.lmax, nmax=self.nmax, numr=self.numr, cmap=self.cmap, rmin=self.rmin,
+                    rmax=self.rmax, rmapping=self.rmap)
+
+    def _load_or_build(self) -> SLGridSph:
+        path = self._cache_path()
+        if os.path.exists(path):
+            g = SLGridSph.load(path)
+            same = (g.lmax == self.lmax and g.nmax == self.nmax and g.numr == self.numr and
+                    g.cmap == self.cmap and abs(g.rmin - self.rmin) < 1e-12 * max(1.0, self.rmin) and
+                    abs(g.rmax - self.rmax) < 1e-12 * self.rmax and abs(g.rmap - self.rmap) < 1e-14)
+            if same:
+                return g
+        g = build_slgrid(self.model, self.lmax, self.nmax, numr=self.numr, rmin=self.rmin,
+                         rmax=self.rmax, cmap=self.cmap, rmap=self.rmap)
+        g.save(path)
+        return g
+
+    def cacheInfo(self, cachefile: Optional[str] = None) -> dict:
+        path = cachefile or self._cache_path()
+        if not path.endswith(".npz"):
+            path += ".npz"
+        g = SLGridSph.load(path)
+        return dict(geometry="sphere", lmax=g.lmax, nmax=g.nmax, numr=g.numr, cmap=g.cmap,
+                    rmin=g.rmin, rmax=g.rmax, rmapping=g.rmap)
+
+    def orthoCheck(self, num: int = 200):
+        """exputil/SLGridMP2.cc:1775-1824 on the host tables"""
+        from numpy.polynomial import legendre as npleg
+        g = self.grid
+        x, w = npleg.leggauss(num)
+        knots, weights = 0.5 * (x + 1.0), 0.5 * w
+        ximin, ximax = float(g.r_to_xi(g.rmin)), float(g.r_to_xi(g.rmax))
+        xs = ximin + (ximax - ximin) * knots
+        if g.cmap == 1:
+            xs = np.clip(xs, -1.0, 1.0 - 1e-8)
+        r = g.xi_to_r(xs)
+        idx = np.clip(((xs - g.xmin) / g.dxi).astype(np.int64), 0, g.numr - 2)
+        x1 = (g.xi[idx + 1] - xs) / g.dxi
+        x2 = (xs - g.xi[idx]) / g.dxi
+        if g.cmap == 1:
+            dxr = 0.5 * (1.0 - xs) ** 2 / g.rmap
+        elif g.cmap == 2:
+            dxr = np.exp(-xs)
+        else:
+            dxr = np.ones_like(xs)
+        P0 = x1 * g.p0[idx] + x2 * g.p0[idx + 1]
+        D0 = x1 * g.d0[idx] + x2 * g.d0[idx + 1]
+        out = []
+        for L in range(g.lmax + 1):
+            u = x1 * g.ef[L][:, idx] + x2 * g.ef[L][:, idx + 1]        # [nmax, num]
+            pot = u / np.sqrt(g.ev[L])[:, None] * P0
+            den = u * np.sqrt(g.ev[L])[:, None] * D0
+            wgt = r * r / dxr * (ximax - ximin) * weights
+            out.append(-(pot * wgt) @ den.T)
+        return out
+
+    def orthoTest(self, num: int = 200) -> None:
+        """exputil/orthoTest.cc:19-87, tolerance orthoTol = 1e-2 (exputil/libvars.cc:40)"""
+        worst = max(np.abs(m - np.eye(self.nmax)).max() for m in self.orthoCheck(num))
+        if worst > 1e-2:
+            raise RuntimeError(f"SphericalSL: orthogonality check failed, worst={worst:.3e}")
+
+    # -- coefficients ---------------------------------------------------------------------------------
+    def reset_coefs(self) -> None:
+        self.expcoef[:] = 0.0
+        self.used = 0
+
+    def _accumulate_batch(self, m, pos) -> None:
+        if len(m) == 0:
+            return
+        c = Component.from_arrays(self.ctx, m, pos)
+        self.force.determine_coefficients(c)
+        self.expcoef += self.force.get_coefs()
+        self.used += self.force.Used()
+        c.close()
+
+    def load_coefs(self, time: float = 0.0) -> SphStruct:
+        """real rows -> complex (l, m>=0) packing (expui/BiorthBasis.cc:482-517)"""
+        ldim = (self.lmax + 1) * (self.lmax + 2) // 2
+        cf = np.zeros((ldim, self.nmax), dtype=np.complex128)
+        L0 = L1 = 0
+        for l in range(self.lmax + 1):
+            for mm in range(l + 1):
+                if mm == 0:
+                    cf[L0] = self.expcoef[L1]
+                    L1 += 1
+                else:
+                    cf[L0] = self.expcoef[L1] + 1j * self.expcoef[L1 + 1]
+                    L1 += 2
+                L0 += 1
+        self.coefret = SphStruct(self.lmax, self.nmax, self.scale, time, cf, self.coefctr.copy(),
+                                 self.coefrot.copy())
+        self.force.set_coefs(self.expcoef)
+        return self.coefret
+
+    def set_coefs(self, coef: SphStruct) -> None:
+        """expui/BiorthBasis.cc:519-581"""
+        ldim = (self.lmax + 1) * (self.lmax + 2) // 2
+        if coef.coefs.shape != (ldim, self.nmax):
+            raise RuntimeError(f"Spherical::set_coefs: the basis has (lmax, nmax)=({self.lmax}, "
+                               f"{self.nmax}) and the dimensions must be (rows, cols)=({ldim}, "
+                               f"{self.nmax}). The coef structure has (rows, cols)={coef.coefs.shape}")
+        L0 = L1 = 0
+        for l in range(self.lmax + 1):
+            for mm in range(l + 1):
+                self.expcoef[L1] = coef.coefs[L0].real
+                if mm == 0:
+                    L1 += 1
+                else:
+                    self.expcoef[L1 + 1] = coef.coefs[L0].imag
+                    L1 += 2
+                L0 += 1
+        self.coefret = coef
+        self.coefctr = np.asarray(coef.ctr, dtype=np.float64) if np.size(coef.ctr) else np.zeros(3)
+        self.force.set_coefs(self.expcoef)
+
+    def _accel(self, pos: np.ndarray) -> np.ndarray:
+        c = Component.from_arrays(self.ctx, np.ones(len(pos)), pos)
+        self.force.get_acceleration_and_potential(c, external=True)
+        acc = c.download(("acc",))["acc"]
+        c.close()
+        return acc
+
+
+class Cylindrical(BiorthBasis):
+    """``cylinder`` (expui/BiorthBasis.cc Cylindrical): YAML keys acyl, hcyl, mmax, nmax, ncylnx,
+    ncylny, rcylmin, rcylmax, lmaxfid, nmaxfid, ncylr, rnum, tnum, cmapr, cmapz, cachename."""
+
+    name = "cylinder"
+
+    def __init__(self, conf: dict, ctx: Optional[Context] = None):
+        super().__init__(conf, ctx)
+        bad = set(conf) - CYL_KEYS
+        if bad:
+            raise RuntimeError(f"Basis::Basis::Cylindrical: unmatched parameter(s) {sorted(bad)}")
+        g = conf.get
+        self.acyl, self.hcyl = float(g("acyl", 0.01)), float(g("hcyl", 0.002))
+        self.mmax, self.nmax = int(g("mmax", 6)), int(g("nmax", 18))
+        self.ncylnx, self.ncylny = int(g("ncylnx", 256)), int(g("ncylny", 128))
+        self.rcylmin, self.rcylmax = float(g("rcylmin", 0.001)), float(g("rcylmax", 20.0))
+        self.lmaxfid, self.nmaxfid = int(g("lmaxfid", 72)), int(g("nmaxfid", 64))
+        self.ncylr = int(g("ncylr", 2000))
+        self.rnum, self.tnum = int(g("rnum", 200)), int(g("tnum", 80))
+        self.cmapr, self.cmapz = int(g("cmapr", g("cmap", 1))), int(g("cmapz", 1))
+        self.cachename = g("cachename", "")
+        if not self.cachename:
+            raise RuntimeError("Cylindrical requires a specified cachename in your YAML config")
+        self.grid = self._load_or_build()
+        self.force = Cylinder(self.ctx, self.grid, rcylmax=self.rcylmax,
+                              EVEN_M=bool(g("EVEN_M", False)))
+        self.cos = np.zeros((self.mmax + 1, self.nmax))
+        self.sin = np.zeros((self.mmax + 1, self.nmax))
+        self.cylmass = 0.0
+        self.used = 0
+
+    def _cache_path(self) -> str:
+        return self.cachename if self.cachename.endswith(".npz") else self.cachename + ".npz"
+
+    def _load_or_build(self) -> EmpCylGrid:
+        path = self._cache_path()
+        if os.path.exists(path):
+            gr = EmpCylGrid.load(path)
+            if (gr.mmax == self.mmax and gr.norder == self.nmax and gr.numx == self.ncylnx and
+                    gr.numy == self.ncylny and abs(gr.ascale - self.acyl) < 1e-15 and
+                    abs(gr.hscale - self.hcyl) < 1e-15 and gr.cmapr == self.cmapr and
+                    gr.cmapz == self.cmapz):
+                return gr
+        gr = build_empcyl(mmax=self.mmax, norder=self.nmax, numx=self.ncylnx, numy=self.ncylny,
+                          acyl=self.acyl, hcyl=self.hcyl, rcylmin=self.rcylmin, rcylmax=self.rcylmax,
+                          lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid, numr=self.ncylr,
+                          cmapr=self.cmapr, cmapz=self.cmapz, rnum=self.rnum, tnum=self.tnum)
+        gr.save(path)
+        return gr
+
+    def cacheInfo(self, cachefile: Optional[str] = None) -> dict:
+        path = cachefile or self._cache_path()
+        if not path.endswith(".npz"):
+            path += ".npz"
+        gr = EmpCylGrid.load(path)
+        return dict(geometry="cylinder", mmax=gr.mmax, nmax=gr.norder, numx=gr.numx, numy=gr.numy,
+                    cmapr=gr.cmapr, cmapz=gr.cmapz, rmin=gr.rmin, rmax=gr.rmax, ascl=gr.ascale,
+                    hscl=gr.hscale)
+
+    def reset_coefs(self) -> None:
+        self.cos[:] = 0.0
+        self.sin[:] = 0.0
+        self.cylmass = 0.0
+        self.used = 0
+
+    def _accumulate_batch(self, m, pos) -> None:
+        if len(m) == 0:
+            return
+        c = Component.from_arrays(self.ctx, m, pos)
+        self.force.determine_coefficients(c)
+        cc, ss = self.force.get_coefs()
+        self.cos += cc
+        self.sin += ss
+        self.cylmass += self.force.cylmass
+        self.used += self.force.Used()
+        c.close()
+
+    def load_coefs(self, time: float = 0.0) -> CylStruct:
+        self.coefret = CylStruct(self.mmax, self.nmax, time, self.cos + 1j * self.sin,
+                                 self.coefctr.copy(), self.coefrot.copy())
+        self.force.set_coefs(self.cos, self.sin)
+        self.force.cylmass = self.cylmass
+        return self.coefret
+
+    def set_coefs(self, coef: CylStruct) -> None:
+        if coef.coefs.shape != (self.mmax + 1, self.nmax):
+            raise RuntimeError("Cylindrical::set_coefs: dimension mismatch")
+        self.cos, self.sin = coef.coefs.real.copy(), coef.coefs.imag.copy()
+        self.coefret = coef
+        self.coefctr = np.asarray(coef.ctr, dtype=np.float64) if np.size(coef.ctr) else np.zeros(3)
+        self.force.set_coefs(self.cos, self.sin)
+        self.force.cylmass = self.cylmass
+
+    def _accel(self, pos: np.ndarray) -> np.ndarray:
+        c = Component.from_arrays(self.ctx, np.ones(len(pos)), pos)
+        self.force.get_acceleration_and_potential(c, external=True)
+        acc = c.download(("acc",))["acc"]
+        c.close()
+        return acc
+
+
+class Basis:
+    """``pyEXP.basis.Basis``: factory by the YAML ``id`` (expui/BasisFactory.cc:156-205)."""
+
+    @staticmethod
+    def factory(config, ctx: Optional[Context] = None) -> BiorthBasis:
+        node = yaml.safe_load(config) if isinstance(config, str) else config
+        if not isinstance(node, dict) or "id" not in node:
+            raise RuntimeError("Basis::factory: the configuration needs an 'id'")
+        params = node.get("parameters") or {}
+        name = node["id"]
+        if name == "sphereSL":
+            return SphericalSL(params, ctx)
+        if name == "cylinder":
+            return Cylindrical(params, ctx)
+        raise RuntimeError(f"Basis::factory: basis <{name}> is outside the scope of exp_amd "
+                           "(sphereSL and cylinder are built)")

@@ -242,6 +242,78 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
   }
 }
 
+// ---- multistep level change: coefficient differencing (src/CylEXP.cc:159-188) -----------------------
+// Wnd[level][node][ntrig]; window: sqrt(R^2+z^2)/ASCALE <= Rtable only.
+template <int MMAX>
+__global__ void __launch_bounds__(256)
+k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
+                   const double *__restrict__ Z, const double *__restrict__ M,
+                   const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
+                   const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
+                   double *__restrict__ Wnd)
+{
+  constexpr int NT = 2 * MMAX + 1;
+  const size_t beg = lev_off[first], end = lev_off[last + 1];
+  const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool mover = false;
+  int from = 0, to = 0;
+  if (i < end) {
+    from = lev[i];
+    to = newlev[i];
+    mover = from != to;
+  }
+  if (!__any(mover)) return;
+  double xx = 1, yy = 0, zz = 0, mass = 0;
+  if (mover) {
+    xx = X[i] - C.cx;
+    yy = Y[i] - C.cy;
+    zz = Z[i] - C.cz;
+    mass = M[i];
+  }
+  const double r2 = xx * xx + yy * yy;
+  const double r = sqrt(r2);
+  if (sqrt(r * r + zz * zz) / C.ascale > C.rtable) mover = false;
+  if (!__any(mover)) return;
+  double zc = zz;
+  if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
+  if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+  int ix, iy;
+  double cw[4];
+  cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+  double cphi = 1.0, sphi = 0.0;
+  if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
+  const double t0 = -4.0 * M_PI * mass;
+  const int nyp = C.numy + 1;
+  const size_t nnode = (size_t)(C.numx + 1) * nyp;
+  const bool sub = mover && from >= mfirst;
+  double *wto = Wnd + ((size_t)to * nnode + (size_t)ix * nyp + iy) * NT;
+  double *wfr = Wnd + ((size_t)from * nnode + (size_t)ix * nyp + iy) * NT;
+  double cm = 1.0, sm = 0.0;
+  cstatic_for<0, MMAX + 1>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    if constexpr (m > 0) {
+      const double cn = cm * cphi - sm * sphi;
+      const double sn = sm * cphi + cm * sphi;
+      cm = cn; sm = sn;
+    }
+    const bool on = mover && !(C.EVEN_M && (m & 1));
+    if (on) {
+      constexpr int jc = (m == 0) ? 0 : 2 * m - 1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
+        const double w = t0 * cw[k];
+        unsafeAtomicAdd(wto + off + jc, w * cm);
+        if (sub) unsafeAtomicAdd(wfr + off + jc, -(w * cm));
+        if constexpr (m > 0) {
+          unsafeAtomicAdd(wto + off + jc + 1, w * sm);
+          if (sub) unsafeAtomicAdd(wfr + off + jc + 1, -(w * sm));
+        }
+      }
+    }
+  });
+}
+
 // ---- moments -> coefficients -----------------------------------------------------------------------------
 // out[cs][m][n] = sum_node tab[cs ? 3 : 0][m][n][node] * Wn[node][trig(m, cs)]
 __global__ void __launch_bounds__(256)
@@ -434,11 +506,18 @@ struct CylForce : exp_amd_force {
   exp_amd_cyl_config cfg{};
   CylDev dev{};
   DevBuf<double> d_tab, d_Wn, d_TF;
+  DevBuf<double> d_Wnd, d_differ;   // multistep differencing
   size_t nnode = 0;
 
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
-  void release() override { d_tab.release(); d_Wn.release(); d_TF.release(); }
+  int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  int resort(exp_amd_comp *c) override;
+  int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift);
+  void release() override
+  {
+    d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
+  }
   int get_used(long long *used) override
   {
     double u = 0.0;
@@ -505,28 +584,84 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     case 12: CALL(12); break;                                                        \
   }
 
+int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift)
+{
+  CylForce *f = this;
+  if (c->n == 0) return EXP_AMD_OK;
+  const CylDev C = cdev_for(f, c->center);
+  c->nlevels = f->multistep + 1;
+  const uint32_t ncell = (uint32_t)(cfg.numx * cfg.numy) + 1u;
+  const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
+  int rc = expamd_comp_prepare_hist(c, nkeys);
+  if (rc) return rc;
+  {
+    ProfScope ps(ctx, "k_key_hist");
+    CylKeyFn kf{C};
+    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n, c->key.p,
+                                                                              c->hist.p);
+  }
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift);
+  if (rc) return rc;
+  c->sorted_for = f;
+  return EXP_AMD_OK;
+}
+
+int CylForce::resort(exp_amd_comp *c) { return sort(c, true, false, 0.0, 0.0); }
+
+__global__ void __launch_bounds__(256)
+k_cyl_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) dst[k] += src[k];
+}
+
+int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
+{
+  CylForce *f = this;
+  const int ms = f->multistep;
+  if (ms == 0 || c->n == 0) return EXP_AMD_OK;
+  const size_t wl = f->nnode * dev.ntrig;
+  if (f->d_Wnd.n == 0) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, f->d_Wnd.alloc(wl * (ms + 1)));
+    HIP_TRY(ctx, f->d_differ.alloc(f->ncoef_dev * (ms + 1)));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p, 0, f->d_Wnd.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p, 0, f->d_differ.bytes(), ctx->stream));
+  const CylDev C = cdev_for(f, c->center);
+  {
+    ProfScope ps(ctx, "k_cyl_mstep_update");
+    const unsigned grid = cdiv(c->n, 256);
+#define CALL(MM)                                                                              \
+  k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
+      c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wnd.p)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  }
+  for (int M = mfirst_mdrft; M <= ms; M++)
+    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2), 256, 0, ctx->stream>>>(
+        C, f->d_tab.p, f->d_Wnd.p + (size_t)M * wl, f->d_differ.p + (size_t)M * f->ncoef_dev);
+  HIP_TRY(ctx, hipGetLastError());
+  const size_t cnt = (size_t)(ms - mfirst_mdrft + 1) * f->ncoef_dev;
+  int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
+  if (rc) return rc;
+  k_cyl_add_inplace<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(
+      f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef_dev,
+      f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
 int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
 {
   CylForce *f = this;
   f->home = c;
   const CylDev C = cdev_for(f, c->center);
-  // ---- sort by (level, cell) --------------------------------------------------------------------
-  if (c->n) {
-    c->nlevels = f->multistep + 1;
-    const uint32_t ncell = (uint32_t)(cfg.numx * cfg.numy) + 1u;
-    const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
-    int rc = expamd_comp_prepare_hist(c, nkeys);
+  {
+    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift);
     if (rc) return rc;
-    {
-      ProfScope ps(ctx, "k_key_hist");
-      CylKeyFn kf{C};
-      AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-      k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n,
-                                                                                c->key.p, c->hist.p);
-    }
-    rc = expamd_comp_finish_sort(c, nkeys, ncell, c->acc_live, advance, dt_kick, dt_drift);
-    if (rc) return rc;
-    c->sorted_for = f;
   }
   // ---- accumulate ----------------------------------------------------------------------------------
   double *dst = f->multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef_dev : f->d_coef.p;

@@ -24,6 +24,12 @@ struct exp_amd_force {
   // acc (+)= force, pot (+)= potential on the particles of levels >= mlevel of `t`
   virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) = 0;
   virtual void release() = 0;
+  // multistep_update for every particle whose proposed level (c->newlev) differs from its
+  // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]
+  // (src/SphericalBasis.cc:1033-1079, :1156-1228; src/CylEXP.cc:56-188), reduced over ranks
+  virtual int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) = 0;
+  // re-establish this basis' (level, cell) order after levels changed
+  virtual int resort(exp_amd_comp *c) = 0;
 
   virtual int get_used(long long *used);
 

@@ -1,5 +1,6 @@
 // Generic half of the C ABI: everything that is the same for every force method.
 #include "force.h"
+#include "sort_kernels.h"
 
 #include <vector>
 
@@ -161,6 +162,38 @@ extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, in
       f->d_coefL.p, f->d_coefN.p, (int)f->ncoef_dev, ms + 1, mfirst, f->d_scratch.p, f->d_coef.p);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+// adjust_multistep_level (src/multistep.cc:344-627) for one component: propose levels from the
+// time-step criteria, difference the coefficient sets of the movers (multistep_update / _finish),
+// commit the levels and re-establish the (level, cell) order (reset_level_lists).
+extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_comp *c, double dtime,
+                                                    const double dynfrac[5], int shiftlevl,
+                                                    int mdrft, int first_step,
+                                                    long long *nswitch)
+{
+  if (!f || !c || !dynfrac) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "adjust_multistep_level: NULL");
+  exp_amd_ctx *ctx = f->ctx;
+  const int ms = f->multistep;
+  if (ms == 0) { if (nswitch) *nswitch = 0; return EXP_AMD_OK; }
+  const int Mstep = 1 << ms;
+  if (mdrft < 0 || mdrft > Mstep) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "mdrft out of range");
+  int mfirst = 0;                                   // src/multistep.cc:651-660
+  for (int M = 0; M <= ms; M++)
+    if (mdrft == 0 || mdrft % (1 << (ms - M)) == 0) { mfirst = M; break; }
+  const int first = first_step ? 0 : mfirst;        // src/multistep.cc:451-453
+  int rc = expamd_comp_propose_levels(c, dtime, dynfrac, shiftlevl, ms, mfirst, first);
+  if (rc) return rc;
+  if ((rc = f->multistep_update(c, first, mfirst))) return rc;
+  if ((rc = expamd_comp_commit_levels(c))) return rc;
+  if ((rc = f->resort(c))) return rc;
+  if (nswitch) {
+    unsigned long long u = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *nswitch = (long long)u;
+  }
   return EXP_AMD_OK;
 }
 

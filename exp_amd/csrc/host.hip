@@ -1,0 +1,182 @@
+// Host orchestration in C++: the step loop of EXP (do_step, src/step.cc:67-325; begin_run's
+// initial expansion, src/begin.cc:80-129; ComponentContainer::compute_expansion /
+// compute_potential, src/ComponentContainer.cc:1173-1226, :580-917) over a set of components,
+// their self-gravity force methods and the pairwise interactions, driving the device entirely
+// through the kernels of this library (no per-step host<->device particle traffic).
+#include "force.h"
+#include "sort_kernels.h"
+
+#include <vector>
+
+struct exp_amd_sim {
+  exp_amd_ctx *ctx = nullptr;
+  int multistep = 0, Mstep = 1;
+  double dtime = 0.0, tnow = 0.0;
+  double dynfrac[5] = {1000.0, 0.01, 0.01, 0.03, 0.05};   // src/global.cc:76-80 (D, V, S, A, P)
+  int shiftlevl = 0;
+  long long this_step = 0;
+  std::vector<exp_amd_comp *> comps;
+  std::vector<exp_amd_force *> forces;
+  std::vector<std::pair<int, int>> inter;                   // (source, target)
+  std::vector<int> mintvl, mfirst;
+  long long last_switch = 0;
+};
+
+extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
+                                  const double dynfrac[5], int shiftlevl, exp_amd_sim **out)
+{
+  if (!ctx || !out || multistep < 0 || multistep > 16 || !(dtime > 0.0))
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sim_create: bad argument");
+  exp_amd_sim *s = new exp_amd_sim;
+  s->ctx = ctx;
+  s->multistep = multistep;
+  s->dtime = dtime;
+  s->shiftlevl = shiftlevl;
+  if (dynfrac) for (int k = 0; k < 5; k++) s->dynfrac[k] = dynfrac[k];
+  // initialize_multistep (src/multistep.cc:630-680)
+  s->Mstep = 1 << multistep;
+  s->mintvl.resize(multistep + 1);
+  s->mintvl[0] = s->Mstep;
+  for (int n = 1; n <= multistep; n++) s->mintvl[n] = s->mintvl[n - 1] / 2;
+  s->mfirst.resize(s->Mstep + 1);
+  for (int ms = 0; ms <= s->Mstep; ms++) {
+    s->mfirst[ms] = 0;
+    for (int M = 0; M <= multistep; M++)
+      if (ms == 0 || ms % (1 << (multistep - M)) == 0) { s->mfirst[ms] = M; break; }
+  }
+  *out = s;
+  return EXP_AMD_OK;
+}
+
+extern "C" void exp_amd_sim_destroy(exp_amd_sim *s) { delete s; }
+
+extern "C" int exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_amd_force *f, int *index)
+{
+  if (!s || !c || !f) return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_add_component: NULL");
+  if (f->multistep != s->multistep)
+    return expamd_fail(s->ctx, EXP_AMD_ERR_ARG, "sim_add_component: force multistep (%d) != sim (%d)",
+                       f->multistep, s->multistep);
+  s->comps.push_back(c);
+  s->forces.push_back(f);
+  if (index) *index = (int)s->comps.size() - 1;
+  return EXP_AMD_OK;
+}
+
+// the force of component `source` also acts on component `target`
+// (Interaction list of ComponentContainer, src/ComponentContainer.cc:785-853)
+extern "C" int exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target)
+{
+  if (!s || source < 0 || target < 0 || source >= (int)s->comps.size() ||
+      target >= (int)s->comps.size() || source == target)
+    return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_add_interaction: bad index");
+  s->inter.emplace_back(source, target);
+  return EXP_AMD_OK;
+}
+
+// ComponentContainer::compute_expansion(M)
+static int compute_expansion(exp_amd_sim *s, int M)
+{
+  for (size_t k = 0; k < s->comps.size(); k++) {
+    int rc = exp_amd_force_set_level(s->forces[k], M);
+    if (rc) return rc;
+    if ((rc = s->forces[k]->determine_coefficients(s->comps[k], false, 0.0, 0.0))) return rc;
+  }
+  return EXP_AMD_OK;
+}
+
+// ComponentContainer::compute_potential(mlevel): zero, self forces, interactions
+static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft)
+{
+  int rc;
+  for (auto c : s->comps)
+    if ((rc = exp_amd_comp_zero_acc(c, mlevel))) return rc;
+  for (size_t k = 0; k < s->comps.size(); k++) {
+    exp_amd_force *f = s->forces[k];
+    if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
+    // determine_acceleration_and_potential: use_external == false branch
+    // (src/SphericalBasis.cc:1680-1685, src/Cylinder.cc:1469)
+    if (s->multistep && (rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
+    if ((rc = f->accelerate(s->comps[k], 0, false, 0.0))) return rc;
+  }
+  for (auto &pr : s->inter) {
+    exp_amd_force *f = s->forces[pr.first];
+    if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
+  }
+  return EXP_AMD_OK;
+}
+
+static int adjust_levels(exp_amd_sim *s, int mdrft, int first_step)
+{
+  s->last_switch = 0;
+  for (size_t k = 0; k < s->comps.size(); k++) {
+    long long ns = 0;
+    int rc = exp_amd_force_adjust_multistep_level(s->forces[k], s->comps[k], s->dtime, s->dynfrac,
+                                                  s->shiftlevl, mdrft, first_step, &ns);
+    if (rc) return rc;
+    s->last_switch += ns;
+  }
+  return EXP_AMD_OK;
+}
+
+// begin_run (src/begin.cc:80-129)
+extern "C" int exp_amd_sim_init(exp_amd_sim *s)
+{
+  if (!s) return EXP_AMD_ERR_ARG;
+  int rc;
+  if (s->multistep) {
+    for (int M = 0; M <= s->multistep; M++)
+      if ((rc = compute_expansion(s, M))) return rc;
+    if ((rc = compute_potential(s, 0, 0))) return rc;
+    if ((rc = adjust_levels(s, 0, 1))) return rc;
+  }
+  for (int M = 0; M <= s->multistep; M++)
+    if ((rc = compute_expansion(s, M))) return rc;
+  return compute_potential(s, 0, 0);
+}
+
+// do_step (src/step.cc:67-325)
+extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
+{
+  if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
+  int rc;
+  for (int it = 0; it < nsteps; it++) {
+    if (s->multistep) {
+      const double dt = s->dtime / s->Mstep;
+      for (int mstep = 0; mstep < s->Mstep; mstep++) {
+        for (int M = s->mfirst[mstep]; M <= s->multistep; M++) {
+          const double DT = dt * s->mintvl[M];
+          for (auto c : s->comps) {
+            if ((rc = exp_amd_comp_kick(c, 0.5 * DT, M))) return rc;
+            if ((rc = exp_amd_comp_drift(c, DT, M))) return rc;
+          }
+          if ((rc = compute_expansion(s, M))) return rc;
+        }
+        s->tnow += dt;
+        const int mdrft = mstep + 1;
+        if ((rc = compute_potential(s, s->mfirst[mstep], mdrft))) return rc;
+        for (int M = s->mfirst[mdrft]; M <= s->multistep; M++)
+          for (auto c : s->comps)
+            if ((rc = exp_amd_comp_kick(c, 0.5 * dt * s->mintvl[M], M))) return rc;
+        if ((rc = adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0))) return rc;
+      }
+    } else if (s->comps.size() == 1 && s->inter.empty()) {
+      s->tnow += s->dtime;
+      if ((rc = exp_amd_step_kdk(s->forces[0], s->comps[0], s->dtime))) return rc;
+    } else {
+      s->tnow += s->dtime;
+      for (auto c : s->comps) {
+        if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
+        if ((rc = exp_amd_comp_drift(c, s->dtime, -1))) return rc;
+      }
+      if ((rc = compute_expansion(s, 0))) return rc;
+      if ((rc = compute_potential(s, 0, 1))) return rc;
+      for (auto c : s->comps)
+        if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
+    }
+    s->this_step++;
+  }
+  return EXP_AMD_OK;
+}
+
+extern "C" double exp_amd_sim_time(const exp_amd_sim *s) { return s ? s->tnow : 0.0; }
+extern "C" long long exp_amd_sim_last_switches(const exp_amd_sim *s) { return s ? s->last_switch : 0; }

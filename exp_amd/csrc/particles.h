@@ -12,6 +12,8 @@ struct exp_amd_comp {
   DevBuf<uint32_t> id[2];            // original (caller) index of each slot
   DevBuf<uint8_t> level[2];          // multistep level of each slot
   DevBuf<uint32_t> key;              // sort key scratch
+  DevBuf<uint8_t> newlev;            // level chosen by the last adjust_multistep_level sweep
+  DevBuf<unsigned long long> nswitch; // [1] level changes counted by that sweep
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;

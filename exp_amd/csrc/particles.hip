@@ -194,6 +194,94 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
   return EXP_AMD_OK;
 }
 
+// ---- multistep level selection --------------------------------------------------------------------
+// adjust_multistep_level_thread (src/multistep.cc:52-236) for the particles of levels
+// [first, multistep]: five time-step criteria -> dtreq (rounded to float like Particle::dtreq,
+// include/Particle.H:60) -> target level.  Levels are only PROPOSED here (newlev); the force
+// method applies its coefficient differencing and the store commits + re-sorts afterwards.
+struct AdjustArgs {
+  double dtime, dynD, dynV, dynS, dynA, dynP;
+  int multistep, shiftlevl, mfirst_mdrft;
+};
+
+__global__ void __launch_bounds__(TPB)
+k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__restrict__ vy,
+                const double *__restrict__ vz, const double *__restrict__ ax,
+                const double *__restrict__ ay, const double *__restrict__ az,
+                const double *__restrict__ pot, const uint8_t *__restrict__ lev,
+                uint8_t *__restrict__ newlev, const uint32_t *__restrict__ lev_off, int first,
+                int last, size_t n, unsigned long long *__restrict__ nswitch)
+{
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned plev = lev[i];
+  unsigned nlev = plev;
+  if (i >= lev_off[first] && i < lev_off[last + 1]) {
+    const double eps = 1.0e-10;
+    const double v0 = vx[i], v1 = vy[i], v2 = vz[i], a0 = ax[i], a1 = ay[i], a2 = az[i];
+    double dtr = 0.0, vtot = 0.0, atot = 0.0;
+    dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
+    dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
+    dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
+    const double ptot = fabs(pot[i]);
+    const double dts = 1.0 / eps;                  // Particle::scale <= 0: criterion off
+    const double dtd = A.dynD * 1.0 / sqrt(vtot + eps);
+    const double dtv = A.dynV * sqrt(vtot / (atot + eps));
+    const double dta = A.dynA * ptot / (fabs(dtr) + eps);
+    const double dtA = A.dynP * sqrt(ptot / (atot + eps));
+    double dmin = dtd;
+    if (dtv < dmin) dmin = dtv;
+    if (dts < dmin) dmin = dts;
+    if (dta > 0.0 && dta < dmin) dmin = dta;
+    if (dtA > 0.0 && dtA < dmin) dmin = dtA;
+    const double dt = dmin > eps ? dmin : eps;
+    const float dtreq = (float)dt;
+    if ((double)dtreq > A.dtime) nlev = 0;
+    else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
+    if (A.shiftlevl) {
+      if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
+      else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+    }
+    if (nlev > (unsigned)A.multistep) nlev = A.multistep;
+    if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
+    if (nlev != plev) atomicAdd(nswitch, 1ull);
+  }
+  newlev[i] = (uint8_t)nlev;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) lev[i] = newlev[i];
+}
+
+int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
+                               int multistep, int mfirst_mdrft, int first)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p, 0, sizeof(unsigned long long), ctx->stream));
+  if (c->n == 0) return EXP_AMD_OK;
+  AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
+               shiftlevl, mfirst_mdrft};
+  ProfScope ps(ctx, "k_adjust_levels");
+  k_adjust_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(
+      A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, multistep, c->n, c->nswitch.p);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+int expamd_comp_commit_levels(exp_amd_comp *c)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->n == 0) return EXP_AMD_OK;
+  k_commit_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, c->n);
+  HIP_TRY(ctx, hipGetLastError());
+  c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------
 
 extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **out)
@@ -219,7 +307,8 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
       return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
     }
   }
-  if (c->key.alloc(na) != hipSuccess || c->lev_off.alloc(64) != hipSuccess) {
+  if (c->key.alloc(na) != hipSuccess || c->lev_off.alloc(64) != hipSuccess ||
+      c->newlev.alloc(na) != hipSuccess || c->nswitch.alloc(1) != hipSuccess) {
     exp_amd_comp_destroy(c);
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
   }
@@ -246,6 +335,8 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
     c->level[w].release();
   }
   c->key.release();
+  c->newlev.release();
+  c->nswitch.release();
   c->hist.release();
   c->lev_off.release();
   delete c;

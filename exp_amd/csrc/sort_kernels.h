@@ -155,4 +155,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, size_t n,
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
                             bool advance, double dt_kick, double dt_drift);
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys);
+int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
+                               int multistep, int mfirst_mdrft, int first);
+int expamd_comp_commit_levels(exp_amd_comp *c);
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift);

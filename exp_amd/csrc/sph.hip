@@ -14,7 +14,7 @@ struct SphKeyFn {
   {
     const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
     double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-    if (r > S.rmax) r = S.rmax;               // src/SphericalBasis.cc:1555-1560
+    if (r > S.rmax && !S.no_exterior) r = S.rmax;   // src/SphericalBasis.cc:1555-1560
     const double xi = sph_r_to_xi(S, r / S.scale);
     return (uint32_t)lev * (uint32_t)(S.numr - 1) + (uint32_t)sph_cell(S, xi);
   }
@@ -110,11 +110,14 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_xi, d_p0, d_E, d_lc;
   DevBuf<double> d_W, d_part, d_G, d_T4;
   DevBuf<int> d_rowmap;
+  DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
 
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
+  int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  int resort(exp_amd_comp *c) override;
   void release() override;
 };
 
@@ -225,6 +228,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.cx = S.cy = S.cz = 0.0;
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
+  S.no_exterior = 0;
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
   *out = f;
   return EXP_AMD_OK;
@@ -235,6 +239,7 @@ void SphForce::release()
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
   d_rowmap.release();
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
+  d_Wd.release(); d_differ.release();
 }
 
 static SphDev dev_for(const SphForce *f, const double center[3])
@@ -271,7 +276,8 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
 
 #define DECL_L(k)                                        \
   void expamd_sph_acc_L##k(const SphAccArgs &);          \
-  void expamd_sph_force_L##k(const SphForceArgs &);
+  void expamd_sph_force_L##k(const SphForceArgs &);  \
+  void expamd_sph_upd_L##k(const SphUpdArgs &);
 DECL_L(0) DECL_L(1) DECL_L(2) DECL_L(3) DECL_L(4) DECL_L(5) DECL_L(6)
 DECL_L(7) DECL_L(8) DECL_L(9) DECL_L(10) DECL_L(11) DECL_L(12)
 #undef DECL_L
@@ -279,6 +285,10 @@ static const sph_acc_launcher k_acc_launch[SPH_MAX_L + 1] = {
     expamd_sph_acc_L0, expamd_sph_acc_L1, expamd_sph_acc_L2,  expamd_sph_acc_L3,  expamd_sph_acc_L4,
     expamd_sph_acc_L5, expamd_sph_acc_L6, expamd_sph_acc_L7,  expamd_sph_acc_L8,  expamd_sph_acc_L9,
     expamd_sph_acc_L10, expamd_sph_acc_L11, expamd_sph_acc_L12};
+static const sph_upd_launcher k_upd_launch[SPH_MAX_L + 1] = {
+    expamd_sph_upd_L0, expamd_sph_upd_L1, expamd_sph_upd_L2,  expamd_sph_upd_L3,  expamd_sph_upd_L4,
+    expamd_sph_upd_L5, expamd_sph_upd_L6, expamd_sph_upd_L7,  expamd_sph_upd_L8,  expamd_sph_upd_L9,
+    expamd_sph_upd_L10, expamd_sph_upd_L11, expamd_sph_upd_L12};
 static const sph_force_launcher k_force_launch[SPH_MAX_L + 1] = {
     expamd_sph_force_L0, expamd_sph_force_L1, expamd_sph_force_L2,  expamd_sph_force_L3,
     expamd_sph_force_L4, expamd_sph_force_L5, expamd_sph_force_L6,  expamd_sph_force_L7,
@@ -372,3 +382,64 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   return EXP_AMD_OK;
 }
 
+
+// ---- multistep level changes ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) dst[k] += src[k];
+}
+
+int SphForce::resort(exp_amd_comp *c) { return sph_sort(this, c, true); }
+
+int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
+{
+  SphForce *f = this;
+  const int ms = f->multistep;
+  if (ms == 0 || c->n == 0) return EXP_AMD_OK;
+  const size_t wl = (size_t)(cfg.numr - 1) * dev.nrows * 2;
+  if (f->d_Wd.n == 0) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, f->d_Wd.alloc(wl * (ms + 1)));
+    HIP_TRY(ctx, f->d_differ.alloc(f->ncoef * (ms + 1)));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p, 0, f->d_Wd.bytes(), ctx->stream));
+  const SphDev S = dev_for(f, c->center);
+  {
+    ProfScope ps(ctx, "k_sph_mstep_update");
+    SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
+                 c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p, c->n, ctx->stream};
+    k_upd_launch[cfg.lmax](a);
+  }
+  // moments -> coefficient differences for the levels that _finish touches (M >= mfirst[mdrft])
+  for (int M = mfirst_mdrft; M <= ms; M++) {
+    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)M * wl,
+                                                                f->d_part.p);
+    k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
+        f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)M * f->ncoef);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M]
+  const size_t cnt = (size_t)(ms - mfirst_mdrft + 1) * f->ncoef;
+  int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef, cnt);
+  if (rc) return rc;
+  k_add_inplace<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(
+      f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef,
+      cnt);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+// Beyond rmax the n-body force continues every (l,m) term as (rmax/r)^(l+1)
+// (src/SphericalBasis.cc:1555-1560, :1605-1628); pyEXP's Spherical::computeAccel does not
+// (expui/BiorthBasis.cc:818-926: the tables are simply evaluated at r/scale).  mode 1 = n-body
+// (default), 0 = pyEXP.
+extern "C" int exp_amd_sph_set_exterior(exp_amd_force *fb, int continuation)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_exterior: not a sphereSL force");
+  f->dev.no_exterior = continuation ? 0 : 1;
+  return EXP_AMD_OK;
+}

@@ -38,3 +38,9 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
         a.dt_kick, a.assign, nullptr, nullptr);
   }
 }
+
+void CAT(expamd_sph_upd_L, SPH_L)(const SphUpdArgs &a)
+{
+  k_sph_mstep_update<SPH_L><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
+      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd);
+}

@@ -40,6 +40,7 @@ struct SphDev {
                                // reference's exact division so that cell assignment is identical)
   double cx, cy, cz;
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
+  int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
   const double *xi;      // [numr]
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
@@ -358,6 +359,101 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
 #undef RUN
 }
 
+// ---- multistep level change: coefficient differencing -----------------------------------------------------
+// For every particle whose proposed level differs from its level, add its moment contribution to
+// Wd[to] and subtract it from Wd[from] (src/SphericalBasis.cc:1156-1228; window r < rmax only).
+// Movers are a small fraction, so each mover lane issues its own fp64 atomics; waves without a
+// mover leave immediately.  Wd[level][cell][row][2].
+template <int LMAX>
+__global__ void __launch_bounds__(256)
+k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
+                   const double *__restrict__ Z, const double *__restrict__ M,
+                   const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
+                   const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
+                   double *__restrict__ Wd)
+{
+  const size_t beg = lev_off[first], end = lev_off[last + 1];
+  const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool mover = false;
+  int from = 0, to = 0;
+  if (i < end) {
+    from = lev[i];
+    to = newlev[i];
+    mover = from != to;
+  }
+  if (!__any(mover)) return;
+  double xx = 0, yy = 0, zz = 1, mass = 0;
+  if (mover) {
+    xx = X[i] - S.cx;
+    yy = Y[i] - S.cy;
+    zz = Z[i] - S.cz;
+    mass = M[i];
+  }
+  const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  if (!(r < S.rmax)) mover = false;
+  if (!__any(mover)) return;
+  cdp lc = (cdp)S.lc;
+  const double costh = zz / r;
+  double cphi, sphi;
+  phi_trig(xx, yy, cphi, sphi);
+  const double xi = sph_r_to_xi(S, r / S.scale);
+  const int idx = sph_cell(S, xi);
+  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  const double t0 = mass * (-4.0 * M_PI) * P0;
+  const double a1 = t0 * x1, a2 = t0 * x2;
+  const size_t wl = (size_t)(S.numr - 1) * S.nrows * 2;
+  double *wto = Wd + (size_t)to * wl + (size_t)idx * S.nrows * 2;
+  double *wfr = Wd + (size_t)from * wl + (size_t)idx * S.nrows * 2;
+  const bool sub = mover && from >= mfirst;       // levels below mfirst[mdrft] are not updated
+  const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  double pmm = LC_E(0);
+  double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+  static_for<0, LMAX + 1>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    if constexpr (m == 1) {
+      pmm *= LC_E(1) * somx2;
+      cm = cphi; sm = sphi;
+    } else if constexpr (m > 1) {
+      pmm *= LC_E(m) * somx2;
+      const double cn = 2.0 * cphi * cm - cm1;
+      const double sn = 2.0 * cphi * sm - sm1;
+      cm1 = cm; sm1 = sm;
+      cm = cn; sm = sn;
+    }
+    double pl2 = 0.0, pl1 = 0.0;
+    static_for<m, LMAX + 1>([&](auto lc_) {
+      constexpr int l = decltype(lc_)::value;
+      double plm;
+      if constexpr (l == m) plm = pmm;
+      else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
+      else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+      pl2 = pl1;
+      pl1 = plm;
+      constexpr int row = row_of(l, m, 0);
+      if (mover) {
+        const double yc = (m == 0) ? plm : plm * cm;
+        unsafeAtomicAdd(wto + 2 * row, a1 * yc);
+        unsafeAtomicAdd(wto + 2 * row + 1, a2 * yc);
+        if (sub) {
+          unsafeAtomicAdd(wfr + 2 * row, -(a1 * yc));
+          unsafeAtomicAdd(wfr + 2 * row + 1, -(a2 * yc));
+        }
+        if constexpr (m > 0) {
+          const double ys = plm * sm;
+          unsafeAtomicAdd(wto + 2 * row + 2, a1 * ys);
+          unsafeAtomicAdd(wto + 2 * row + 3, a2 * ys);
+          if (sub) {
+            unsafeAtomicAdd(wfr + 2 * row + 2, -(a1 * ys));
+            unsafeAtomicAdd(wfr + 2 * row + 3, -(a2 * ys));
+          }
+        }
+      }
+    });
+  });
+}
+
 // ---- force ------------------------------------------------------------------------------------------------
 //
 // Projected table T4[cell][q][4] (q = m-major row order, see mmajor_row), built once per
@@ -515,7 +611,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
   phi_trig(xx, yy, cphi, sphi);
   bool ioff = false;
   const double r0 = r;
-  if (r > S.rmax) {
+  if (r > S.rmax && !S.no_exterior) {
     ioff = true;
     r = S.rmax;
   }
@@ -617,5 +713,17 @@ struct SphForceArgs {
   int all_slow;             // target is not in this force's cell order: skip the fast pass
 };
 
+struct SphUpdArgs {
+  SphDev S;
+  const double *X, *Y, *Z, *M;
+  const uint8_t *lev, *newlev;
+  const uint32_t *lev_off;
+  int first, last, mfirst;
+  double *Wd;
+  size_t n;
+  hipStream_t stream;
+};
+
+typedef void (*sph_upd_launcher)(const SphUpdArgs &);
 typedef void (*sph_acc_launcher)(const SphAccArgs &);
 typedef void (*sph_force_launcher)(const SphForceArgs &);

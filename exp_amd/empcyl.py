@@ -143,17 +143,37 @@ def sl_eval(g: SLGridSph, r: np.ndarray, want_force: bool = True):
 
 
 def _legendre_all(lmax: int, m: int, x: np.ndarray):
-    """P_l^m(x) and dP/dx for l = m..lmax (Condon-Shortley, unnormalised: src/Basis.cc:14-93)."""
+    """Normalised associated Legendre functions of EmpCylSL::legendre_R / dlegendre_R
+    (exputil/EmpCylSL.cc:6493-6612): sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!) P_l^m(x) with the
+    Condon-Shortley phase, and their x-derivatives, for l = m..lmax."""
+    from scipy.special import gammaln
     ls = np.arange(m, lmax + 1)
-    P = np.stack([lpmv(m, l, x) for l in ls], axis=1)                      # [npts, nl]
+    lognorm = 0.5 * (np.log((2.0 * ls + 1.0) / (4.0 * math.pi)) + gammaln(ls - m + 1.0) -
+                     gammaln(ls + m + 1.0))
+    # lpmv overflows for large l, m; build the normalised functions by the stable recurrence
+    P = np.empty((x.size, ls.size))
+    u = np.sqrt(np.maximum(0.0, 1.0 - x * x))
+    pmm = np.full_like(x, math.sqrt(1.0 / (4.0 * math.pi)))
+    for k in range(1, m + 1):
+        pmm = -pmm * u * math.sqrt((2.0 * k + 1.0) / (2.0 * k))
+    P[:, 0] = pmm
+    if ls.size > 1:
+        P[:, 1] = math.sqrt(2.0 * m + 3.0) * x * pmm
+    for j in range(2, ls.size):
+        l = m + j
+        a = math.sqrt((4.0 * l * l - 1.0) / (l * l - m * m))
+        b = math.sqrt(((l - 1.0) ** 2 - m * m) / (4.0 * (l - 1.0) ** 2 - 1.0))
+        P[:, j] = a * (x * P[:, j - 1] - b * P[:, j - 2])
+    del lognorm
     xc = np.clip(x, -(1.0 - 3 * np.finfo(float).eps), 1.0 - 3 * np.finfo(float).eps)
     somx2 = 1.0 / (xc * xc - 1.0)
     dP = np.empty_like(P)
     for k, l in enumerate(ls):
         if l == m:
             dP[:, k] = somx2 * xc * l * P[:, k]
-        else:
-            dP[:, k] = somx2 * (xc * l * P[:, k] - (l + m) * P[:, k - 1])
+        else:   # exputil/EmpCylSL.cc:6604
+            dP[:, k] = somx2 * (xc * l * P[:, k] -
+                                math.sqrt((l * l - m * m) * (2.0 * l + 1.0) / (2.0 * l - 1.0)) * P[:, k - 1])
     return P, dP
 
 

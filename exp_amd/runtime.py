@@ -343,3 +343,49 @@ def do_step_single(force: _Force, comp: Component, dt: float) -> None:
     comp.zero_acceleration(0)
     force.get_acceleration_and_potential(comp)
     comp.incr_velocity(0.5 * dt)
+
+
+class Simulation:
+    """The step loop (``do_step`` src/step.cc:67-325, ``begin_run`` src/begin.cc:80-129) over
+    components, their force methods and pairwise interactions -- run by the C++ host code of
+    libexp_amd.so (``exp_amd_sim_*``)."""
+
+    def __init__(self, ctx: Context, dtime: float, multistep: int = 0, dynfrac=None,
+                 shiftlevl: int = 0):
+        self.ctx, self.lib = ctx, ctx.lib
+        dyn = None
+        if dynfrac is not None:
+            dyn = (c_double * 5)(*[float(v) for v in dynfrac])
+        h = c_void_p()
+        check(self.lib.exp_amd_sim_create(ctx.h, int(multistep), float(dtime), dyn, int(shiftlevl),
+                                          byref(h)), ctx.h)
+        self.h = h
+        self._keep = []
+
+    def add_component(self, comp: Component, force: _Force) -> int:
+        idx = c_int()
+        check(self.lib.exp_amd_sim_add_component(self.h, comp.h, force.h, byref(idx)), self.ctx.h)
+        self._keep.append((comp, force))
+        return idx.value
+
+    def add_interaction(self, source: int, target: int) -> None:
+        check(self.lib.exp_amd_sim_add_interaction(self.h, int(source), int(target)), self.ctx.h)
+
+    def init(self) -> None:
+        check(self.lib.exp_amd_sim_init(self.h), self.ctx.h)
+
+    def step(self, nsteps: int = 1) -> None:
+        check(self.lib.exp_amd_sim_step(self.h, int(nsteps)), self.ctx.h)
+
+    @property
+    def time(self) -> float:
+        return float(self.lib.exp_amd_sim_time(self.h))
+
+    @property
+    def last_switches(self) -> int:
+        return int(self.lib.exp_amd_sim_last_switches(self.h))
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.exp_amd_sim_destroy(self.h)
+            self.h = None

@@ -118,6 +118,10 @@ int  exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cfg,
                         const double *xi, const double *p0,
                         const double *ev, const double *ef, exp_amd_force **out);
 void exp_amd_force_destroy(exp_amd_force *f);
+/* continuation != 0 (default): r > rmax uses the exterior multipole continuation of the n-body
+ * force (src/SphericalBasis.cc:1555-1560, :1605-1628); 0: tables evaluated at r/scale as in
+ * pyEXP's Spherical::computeAccel (expui/BiorthBasis.cc:818-926).                          */
+int  exp_amd_sph_set_exterior(exp_amd_force *f, int continuation);
 
 /* PotAccel::set_multistep_level (src/PotAccel.H:285) */
 int  exp_amd_force_set_level(exp_amd_force *f, int mlevel);
@@ -153,6 +157,17 @@ int  exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int 
 int  exp_amd_force_multistep_reset(exp_amd_force *f);
 int  exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft);
 
+/* adjust_multistep_level() (src/multistep.cc:344-627) for one component and its force:
+ * time-step criteria (dynfrac = {dynfracD, dynfracV, dynfracS, dynfracA, dynfracP},
+ * src/global.cc:76-80) -> new levels (shiftlevl-limited, clamped to [mfirst[mdrft], multistep]);
+ * PotAccel::multistep_update_begin / multistep_update / multistep_update_finish
+ * (src/PotAccel.H:271-281) for the particles that change level; Component::reset_level_lists.
+ * first_step != 0 examines every level (src/multistep.cc:451-453).  *nswitch (may be NULL)
+ * receives the number of level changes on this rank.                                   */
+int  exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_comp *c, double dtime,
+                                          const double dynfrac[5], int shiftlevl, int mdrft,
+                                          int first_step, long long *nswitch);
+
 /* ---- cylindrical force method (cylinder) -------------------------------------------------
  * Replaces class Cylinder (src/Cylinder.cc) + EmpCylSL's accumulate / accumulated_eval
  * (exputil/EmpCylSL.cc:4049-4146, :5256-5410) given the EOF tables.  Coefficients are
@@ -184,6 +199,23 @@ int  exp_amd_cyl_set_cylmass(exp_amd_force *f, double mass);
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.
  * Same results as the unfused sequence of calls above; fewer passes over HBM.       */
 int  exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt);
+
+/* ---- step loop ---------------------------------------------------------------------------
+ * do_step (src/step.cc:67-325) and begin_run's initial expansion (src/begin.cc:80-129) over a
+ * set of components, their self-gravity force methods and pairwise interactions
+ * (ComponentContainer, src/ComponentContainer.cc:580-917, :1173-1226): the C++ host
+ * orchestration of the path.  dynfrac = {dynfracD, dynfracV, dynfracS, dynfracA, dynfracP}
+ * (NULL -> src/global.cc:76-80 defaults).                                               */
+typedef struct exp_amd_sim exp_amd_sim;
+int  exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime, const double dynfrac[5],
+                        int shiftlevl, exp_amd_sim **out);
+void exp_amd_sim_destroy(exp_amd_sim *s);
+int  exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_amd_force *f, int *index);
+int  exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target);
+int  exp_amd_sim_init(exp_amd_sim *s);
+int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
+double exp_amd_sim_time(const exp_amd_sim *s);
+long long exp_amd_sim_last_switches(const exp_amd_sim *s);
 
 /* Timing of the last fused step's dominant kernels (ms, HIP events on the context
  * stream); names are static strings.  Used by bench.py for the roofline figure.    */

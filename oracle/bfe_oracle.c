@@ -682,6 +682,55 @@ static void sph_one_particle(const orc_slgrid *g, const orc_sph_params *P, doubl
   }
 }
 
+
+/* adjust_multistep_level (src/multistep.cc:344-627) + multistep_update / _finish
+ * (src/SphericalBasis.cc:1033-1079, :1156-1228) for one spherical component              */
+static long sph_adjust_levels(const orc_slgrid *g, const orc_sph_params *P, const orc_mstep_tables *T,
+                              int multistep, double dtime, const double *dynfrac, int shiftlevl,
+                              int mdrft, int all_levels, long n, const double *x, const double *y,
+                              const double *z, const double *vx, const double *vy, const double *vz,
+                              const double *ax, const double *ay, const double *az,
+                              const double *pot, const double *mass, int *level,
+                              const double *center, double *coefN, double *differ, double *val,
+                              double *p, double *cosm, double *sinm, double *potd,
+                              const double *factorial)
+{
+  const long ncoef = (long)(g->lmax + 1) * (g->lmax + 1) * g->nmax;
+  long switched = 0;
+  int first = T->mfirst[mdrft];
+  if (all_levels) first = 0;
+  for (int M = T->mfirst[mdrft]; M <= multistep; M++)
+    memset(differ + (size_t)M * ncoef, 0, sizeof(double) * ncoef);
+  for (int lev = first; lev <= multistep; lev++) {
+    for (long i = 0; i < n; i++) {
+      if (level[i] != lev) continue;
+      double v[3] = {vx[i], vy[i], vz[i]}, a[3] = {ax[i], ay[i], az[i]};
+      double dtreq;
+      int nlev = orc_level_select(dtime, multistep, T->mfirst[mdrft], lev, shiftlevl, dynfrac, 0.0,
+                                  v, a, pot[i], &dtreq);
+      if (nlev != lev) {
+        int inside;
+        sph_one_particle(g, P, x[i] - center[0], y[i] - center[1], z[i] - center[2], mass[i], val,
+                         p, cosm, sinm, potd, factorial, &inside);
+        if (inside) {
+          /* levels below mfirst[mdrft] are never cleared/added by _begin/_finish */
+          for (long q = 0; q < ncoef; q++) {
+            if (lev >= T->mfirst[mdrft]) differ[(size_t)lev * ncoef + q] -= val[q];
+            if (nlev >= T->mfirst[mdrft]) differ[(size_t)nlev * ncoef + q] += val[q];
+          }
+        }
+        level[i] = -(nlev + 1); /* commit after the sweep so that a particle is seen once */
+        switched++;
+      }
+    }
+  }
+  for (long i = 0; i < n; i++)
+    if (level[i] < 0) level[i] = -level[i] - 1;
+  for (int M = T->mfirst[mdrft]; M <= multistep; M++)
+    for (long q = 0; q < ncoef; q++) coefN[(size_t)M * ncoef + q] += differ[(size_t)M * ncoef + q];
+  return switched;
+}
+
 void orc_sph_multistep_step(const orc_slgrid *g, const orc_sph_params *P, int multistep,
                             double dtime, const double *dynfrac, int shiftlevl, long n,
                             double *x, double *y, double *z, double *vx, double *vy, double *vz,
@@ -743,42 +792,57 @@ void orc_sph_multistep_step(const orc_slgrid *g, const orc_sph_params *P, int mu
         }
     }
     /* adjust_multistep_level */
-    {
-      int first = T->mfirst[mdrft];
-      if (this_step == 0 && mstep == 0) first = 0;
-      for (int M = T->mfirst[mdrft]; M <= multistep; M++)
-        memset(differ + (size_t)M * ncoef, 0, sizeof(double) * ncoef);
-      for (int lev = first; lev <= multistep; lev++) {
-        for (long i = 0; i < n; i++) {
-          if (level[i] != lev) continue;
-          double v[3] = {vx[i], vy[i], vz[i]}, a[3] = {ax[i], ay[i], az[i]};
-          double dtreq;
-          int nlev = orc_level_select(dtime, multistep, T->mfirst[mdrft], lev, shiftlevl, dynfrac,
-                                      0.0, v, a, pot[i], &dtreq);
-          if (nlev != lev) {
-            int inside;
-            sph_one_particle(g, P, x[i] - center[0], y[i] - center[1], z[i] - center[2], mass[i],
-                             val, p, cosm, sinm, potd, factorial, &inside);
-            if (inside) {
-              /* levels below mfirst[mdrft] are never cleared/added by _begin/_finish */
-              for (long q = 0; q < ncoef; q++) {
-                if (lev >= T->mfirst[mdrft]) differ[(size_t)lev * ncoef + q] -= val[q];
-                if (nlev >= T->mfirst[mdrft]) differ[(size_t)nlev * ncoef + q] += val[q];
-              }
-            }
-            level[i] = -(nlev + 1); /* commit after the sweep so that a particle is seen once */
-            switched++;
-          }
-        }
-      }
-      for (long i = 0; i < n; i++)
-        if (level[i] < 0) level[i] = -level[i] - 1;
-      for (int M = T->mfirst[mdrft]; M <= multistep; M++)
-        for (long q = 0; q < ncoef; q++) coefN[(size_t)M * ncoef + q] += differ[(size_t)M * ncoef + q];
-    }
+    switched += sph_adjust_levels(g, P, T, multistep, dtime, dynfrac, shiftlevl, mdrft,
+                                  (this_step == 0 && mstep == 0), n, x, y, z, vx, vy, vz, ax, ay, az,
+                                  pot, mass, level, center, coefN, differ, val, p, cosm, sinm, potd,
+                                  factorial);
   }
   if (nswitch) *nswitch = switched;
   orc_mstep_free(T);
   free(tx); free(ty); free(tz); free(tm); free(differ); free(val); free(p); free(cosm); free(sinm);
   free(potd); free(factorial); free(tmpc);
+}
+
+/* begin_run's multistep initialisation (src/begin.cc:80-129): expansion at every level, full
+ * potential, first level assignment (all levels examined), then expansion + potential again.  */
+void orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int multistep,
+                            double dtime, const double *dynfrac, int shiftlevl, long n,
+                            const double *x, const double *y, const double *z, const double *vx,
+                            const double *vy, const double *vz, double *ax, double *ay, double *az,
+                            double *pot, const double *mass, int *level, const double *center,
+                            double *coefN, double *coefL, double *coef_out)
+{
+  const int Lmax = g->lmax, nmax = g->nmax;
+  const long ncoef = (long)(Lmax + 1) * (Lmax + 1) * nmax;
+  orc_mstep_tables *T = orc_mstep_create(multistep);
+  double *tx = (double *)malloc(sizeof(double) * n), *ty = (double *)malloc(sizeof(double) * n),
+         *tz = (double *)malloc(sizeof(double) * n), *tm = (double *)malloc(sizeof(double) * n);
+  double *differ = (double *)malloc(sizeof(double) * (multistep + 1) * ncoef);
+  double *val = (double *)malloc(sizeof(double) * ncoef);
+  double *p = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  double *cosm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *sinm = (double *)malloc(sizeof(double) * (Lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (Lmax + 1) * nmax);
+  double *factorial = (double *)malloc(sizeof(double) * (Lmax + 1) * (Lmax + 1));
+  orc_factorial_table(Lmax, factorial);
+
+  for (int pass = 0; pass < 2; pass++) {
+    for (int M = 0; M <= multistep; M++) {
+      memcpy(coefL + (size_t)M * ncoef, coefN + (size_t)M * ncoef, sizeof(double) * ncoef);
+      long k = 0;
+      for (long i = 0; i < n; i++)
+        if (level[i] == M) { tx[k] = x[i]; ty[k] = y[i]; tz[k] = z[i]; tm[k] = mass[i]; k++; }
+      orc_sph_accumulate(g, P, k, tx, ty, tz, tm, center, coefN + (size_t)M * ncoef, 0);
+    }
+    orc_mstep_combine(T, 0, ncoef, coefL, coefN, coef_out);
+    for (long i = 0; i < n; i++) ax[i] = ay[i] = az[i] = pot[i] = 0.0;
+    orc_sph_accel(g, P, n, x, y, z, center, coef_out, ax, ay, az, pot);
+    if (pass == 0)
+      sph_adjust_levels(g, P, T, multistep, dtime, dynfrac, shiftlevl, 0, 1, n, x, y, z, vx, vy, vz,
+                        ax, ay, az, pot, mass, level, center, coefN, differ, val, p, cosm, sinm,
+                        potd, factorial);
+  }
+  orc_mstep_free(T);
+  free(tx); free(ty); free(tz); free(tm); free(differ); free(val); free(p); free(cosm); free(sinm);
+  free(potd); free(factorial);
 }

@@ -120,6 +120,14 @@ void   orc_sph_multistep_step(const orc_slgrid *g, const orc_sph_params *P, int 
                               int *level, const double *center, double *coefN, double *coefL,
                               int this_step, double *coef_out, long *nswitch);
 
+/* begin_run's multistep initialisation (src/begin.cc:80-129) for the same single component. */
+void   orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int multistep,
+                              double dtime, const double *dynfrac, int shiftlevl, long n,
+                              const double *x, const double *y, const double *z, const double *vx,
+                              const double *vy, const double *vz, double *ax, double *ay, double *az,
+                              double *pot, const double *mass, int *level, const double *center,
+                              double *coefN, double *coefL, double *coef_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,49 @@ class Oracle:
                                _dp(az), _dp(pot))
         return np.stack([ax, ay, az], axis=1), pot
 
+    def sph_multistep_init(self, g, prm, multistep, dtime, dynfrac, shiftlevl, pos, vel, mass,
+                           center=(0.0, 0.0, 0.0)):
+        """begin_run for one spherical component; returns a state dict."""
+        G = self.grid(g)
+        n = pos.shape[0]
+        st = {k: np.ascontiguousarray(pos[:, j], dtype=np.float64).copy()
+              for j, k in enumerate("xyz")}
+        st.update({"v" + k: np.ascontiguousarray(vel[:, j], dtype=np.float64).copy()
+                   for j, k in enumerate("xyz")})
+        for k in ("ax", "ay", "az", "pot"):
+            st[k] = np.zeros(n)
+        st["mass"] = np.ascontiguousarray(mass, dtype=np.float64)
+        st["level"] = np.zeros(n, dtype=np.int32)
+        ncoef = (g.lmax + 1) ** 2 * g.nmax
+        st["coefN"] = np.zeros((multistep + 1, ncoef))
+        st["coefL"] = np.zeros((multistep + 1, ncoef))
+        st["coef"] = np.zeros(ncoef)
+        st["center"] = np.asarray(center, dtype=np.float64)
+        st["dyn"] = np.asarray(dynfrac, dtype=np.float64)
+        st.update(multistep=multistep, dtime=dtime, shiftlevl=shiftlevl, this_step=0)
+        self.lib.orc_sph_multistep_init(
+            ctypes.byref(G), ctypes.byref(prm), ctypes.c_int(multistep), ctypes.c_double(dtime),
+            _dp(st["dyn"]), ctypes.c_int(shiftlevl), ctypes.c_long(n), _dp(st["x"]), _dp(st["y"]),
+            _dp(st["z"]), _dp(st["vx"]), _dp(st["vy"]), _dp(st["vz"]), _dp(st["ax"]), _dp(st["ay"]),
+            _dp(st["az"]), _dp(st["pot"]), _dp(st["mass"]), st["level"].ctypes.data_as(c_int_p),
+            _dp(st["center"]), _dp(st["coefN"]), _dp(st["coefL"]), _dp(st["coef"]))
+        return st
+
+    def sph_multistep_step(self, g, prm, st):
+        G = self.grid(g)
+        n = st["x"].size
+        nsw = ctypes.c_long(0)
+        self.lib.orc_sph_multistep_step(
+            ctypes.byref(G), ctypes.byref(prm), ctypes.c_int(st["multistep"]),
+            ctypes.c_double(st["dtime"]), _dp(st["dyn"]), ctypes.c_int(st["shiftlevl"]),
+            ctypes.c_long(n), _dp(st["x"]), _dp(st["y"]), _dp(st["z"]), _dp(st["vx"]), _dp(st["vy"]),
+            _dp(st["vz"]), _dp(st["ax"]), _dp(st["ay"]), _dp(st["az"]), _dp(st["pot"]),
+            _dp(st["mass"]), st["level"].ctypes.data_as(c_int_p), _dp(st["center"]),
+            _dp(st["coefN"]), _dp(st["coefL"]), ctypes.c_int(st["this_step"]), _dp(st["coef"]),
+            ctypes.byref(nsw))
+        st["this_step"] += 1
+        return int(nsw.value)
+
     # -- multistep ---------------------------------------------------------------------
     def mstep_tables(self, multistep):
         t = ctypes.c_void_p(self.lib.orc_mstep_create(ctypes.c_int(multistep)))

@@ -250,3 +250,32 @@ def test_level_select(oracle):
     assert lev == 1                            # clamped to multistep
     lev, _ = oracle.level_select(0.01, 4, 3, 0, 0, dyn, 0.0, v, a, -1.0)
     assert lev == 3                            # not below mfirst[mdrft]
+
+
+# ---- cylindrical basis known answer ----------------------------------------------------------------------------
+
+def test_cylinder_reconstructs_exponential_disk_force(oracle):
+    """EOF tables + accumulate + accumulated_eval on particles drawn from the conditioning density:
+    the in-plane radial force is that of an exponential disk, v_c^2 = 4 pi G Sigma0 a y^2 (I0K0 - I1K1)
+    (Freeman 1970, razor-thin) to within the truncation of this small basis, the finite thickness and
+    particle noise (25 %).  Pins sign, the -4pi factor, the Legendre
+    normalisation of the tables (exputil/EmpCylSL.cc:6493-6612) and pfac/ffac scaling."""
+    from scipy.special import i0, i1, k0, k1
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    a, h = 0.01, 0.001
+    g = build_empcyl(mmax=2, norder=10, numx=64, numy=32, acyl=a, hcyl=h, lmaxfid=24, nmaxfid=20,
+                     numr=1000, rnum=100, tnum=40)
+    m, pos, _ = sample_disk(40000, 5, a=a, h=h)
+    cc, ss, used, mass = oracle.cyl_accumulate(g, pos, m)
+    assert used == len(m) and mass == pytest.approx(1.0, rel=1e-9)
+    for R in (1.0 * a, 2.0 * a, 4.0 * a):
+        test = np.array([[R, 0.0, 0.0], [0.0, -R, 0.0]])
+        acc, pot = oracle.cyl_accel(g, test, cc, ss, mass)
+        y = R / (2 * a)
+        vc2 = 4 * math.pi * (1.0 / (2 * math.pi * a * a)) * a * y * y * (i0(y) * k0(y) - i1(y) * k1(y))
+        fr_ref = vc2 / R
+        assert acc[0, 0] < 0 and acc[1, 1] > 0                      # attractive
+        assert -acc[0, 0] == pytest.approx(fr_ref, rel=0.25)
+        assert acc[1, 1] == pytest.approx(fr_ref, rel=0.25)
+        assert pot[0] < 0
