@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--dt", type=float, default=0.002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="initialise the process group and run the coefficient all-reduce even at "
+                         "world size 1 (exercises the multi-GPU path on a single-GPU box)")
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
                     help="coefficient all-reduce through torch.distributed (default) or the "
                          "library's own RCCL communicator")
@@ -128,8 +131,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_comm = world > 1 or args.force_comm
+    if use_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from exp_amd.models import NFWModel
@@ -161,7 +166,7 @@ def main():
     torch.cuda.empty_cache()
     force = SphereSL(ctx, grid)
 
-    if world > 1:
+    if use_comm:
         if args.comm == "rccl":
             ids = [Context.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -171,7 +176,7 @@ def main():
             ctx.set_allreduce(torch_allreduce_callback(device))
 
     def barrier():
-        if world > 1:
+        if use_comm:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +198,7 @@ def main():
     prof = ctx.profile_report()
     ctx.profile(False)
 
-    if world > 1:
+    if use_comm:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -259,7 +264,7 @@ def main():
     comp.close()
     force.close()
     ctx.close()
-    if world > 1:
+    if use_comm:
         dist.destroy_process_group()
 
 

@@ -507,21 +507,31 @@ struct CylForce : exp_amd_force {
   CylDev dev{};
   DevBuf<double> d_tab, d_Wn, d_TF;
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
+  DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
+  bool mass_open = true;            // still within the first sub-step (tnow == resetT)
   size_t nnode = 0;
 
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
+  int multistep_reset() override
+  {
+    // Cylinder::multistep_reset: used = 0, cylmass = 0, resetT = tnow (src/Cylinder.cc:1209-1216)
+    HIP_TRY(ctx, hipMemsetAsync(d_mass.p, 0, 2 * sizeof(double), ctx->stream));
+    mass_open = true;
+    return EXP_AMD_OK;
+  }
   int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift);
   void release() override
   {
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
+    d_mass.release();
   }
   int get_used(long long *used) override
   {
     double u = 0.0;
-    HIP_TRY(ctx, hipMemcpyAsync(&u, d_coef.p + ncoef + 1, sizeof(double), hipMemcpyDeviceToHost,
+    HIP_TRY(ctx, hipMemcpyAsync(&u, d_mass.p + 1, sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *used = (long long)(u + 0.5);
@@ -556,6 +566,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   A(f->d_tab.alloc(ntab));
   A(f->d_Wn.alloc(f->nnode * ntrig));
   A(f->d_TF.alloc(f->nnode * 3 * ntrig));
+  A(f->d_mass.alloc(2));
   // coefficient buffer: cos block, sin block, then {cylmass, used} riding through the all-reduce
   if (e == hipSuccess && f->alloc_common((size_t)2 * (M + 1) * N, cfg->multistep, 2) != EXP_AMD_OK)
     e = hipErrorOutOfMemory;
@@ -564,6 +575,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_create: hipMalloc failed: %s", hipGetErrorString(e));
   }
   HIP_TRY(ctx, hipMemcpy(f->d_tab.p, tab, ntab * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemset(f->d_mass.p, 0, 2 * sizeof(double)));
   CylDev &C = f->dev;
   C.mmax = M; C.nmax = N; C.numx = cfg->numx; C.numy = cfg->numy; C.cmapr = cfg->cmapr;
   C.cmapz = cfg->cmapz; C.EVEN_M = cfg->EVEN_M; C.ntrig = ntrig;
@@ -583,6 +595,11 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     case 9: CALL(9); break;  case 10: CALL(10); break; case 11: CALL(11); break;     \
     case 12: CALL(12); break;                                                        \
   }
+
+__global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ tail, int overwrite)
+{
+  if (threadIdx.x < 2) acc[threadIdx.x] = (overwrite ? 0.0 : acc[threadIdx.x]) + tail[threadIdx.x];
+}
 
 int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift)
 {
@@ -688,6 +705,14 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   HIP_TRY(ctx, hipGetLastError());
   int rc = expamd_allreduce(ctx, dst, f->ncoef_dev);
   if (rc) return rc;
+  // used / cylmass: the reference adds the (rank-reduced) in-cut count and mass of every level
+  // accumulated while tnow == resetT, i.e. during the first sub-step of a master step
+  // (src/Cylinder.cc:1088-1099); without multistep that is simply the last accumulation
+  if (!f->multistep)
+    k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 1);
+  else if (f->mass_open)
+    k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 0);
+  HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
   return EXP_AMD_OK;
 }
@@ -702,6 +727,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     HIP_TRY(ctx, hipGetLastError());
     f->proj_dirty = false;
   }
+  f->mass_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   const double *ctr = (external && f->home) ? f->home->center : t->center;
   const CylDev C = cdev_for(f, ctr);
@@ -712,7 +738,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     const unsigned grid = cdiv(t->n, 256);
 #define CALL(MM)                                                                                  \
   k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
-      C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_coef.p + f->ncoef, \
+      C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
       t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
       dt_kick, assign ? 1 : 0)
     MMAX_DISPATCH(cfg.mmax, CALL)
@@ -727,7 +753,7 @@ extern "C" int exp_amd_cyl_get_cylmass(exp_amd_force *fb, double *mass)
 {
   CylForce *f = dynamic_cast<CylForce *>(fb);
   if (!f || !mass) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "get_cylmass: not a cylinder force");
-  HIP_TRY(f->ctx, hipMemcpyAsync(mass, f->d_coef.p + f->ncoef, sizeof(double), hipMemcpyDeviceToHost,
+  HIP_TRY(f->ctx, hipMemcpyAsync(mass, f->d_mass.p, sizeof(double), hipMemcpyDeviceToHost,
                                  f->ctx->stream));
   HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
   return EXP_AMD_OK;
@@ -737,7 +763,7 @@ extern "C" int exp_amd_cyl_set_cylmass(exp_amd_force *fb, double mass)
 {
   CylForce *f = dynamic_cast<CylForce *>(fb);
   if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_cylmass: not a cylinder force");
-  HIP_TRY(f->ctx, hipMemcpyAsync(f->d_coef.p + f->ncoef, &mass, sizeof(double), hipMemcpyHostToDevice,
+  HIP_TRY(f->ctx, hipMemcpyAsync(f->d_mass.p, &mass, sizeof(double), hipMemcpyHostToDevice,
                                  f->ctx->stream));
   HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
   return EXP_AMD_OK;

@@ -32,6 +32,8 @@ struct exp_amd_force {
   virtual int resort(exp_amd_comp *c) = 0;
 
   virtual int get_used(long long *used);
+  // PotAccel::multistep_reset (src/PotAccel.H:288): start of a master step
+  virtual int multistep_reset() { return EXP_AMD_OK; }
 
   int alloc_common(size_t ncoef_, int multistep_, size_t tail = 0);
   void release_common();

@@ -130,7 +130,7 @@ k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int 
 extern "C" int exp_amd_force_multistep_reset(exp_amd_force *f)
 {
   if (!f) return EXP_AMD_ERR_ARG;
-  return EXP_AMD_OK;   // nothing to do per step for these bases (src/SphericalBasis.H multistep_reset)
+  return f->multistep_reset();
 }
 
 extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft)

@@ -124,10 +124,12 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
   if (!s) return EXP_AMD_ERR_ARG;
   int rc;
   if (s->multistep) {
+    for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
     for (int M = 0; M <= s->multistep; M++)
       if ((rc = compute_expansion(s, M))) return rc;
     if ((rc = compute_potential(s, 0, 0))) return rc;
     if ((rc = adjust_levels(s, 0, 1))) return rc;
+    for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
   }
   for (int M = 0; M <= s->multistep; M++)
     if ((rc = compute_expansion(s, M))) return rc;
@@ -141,6 +143,8 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
   int rc;
   for (int it = 0; it < nsteps; it++) {
     if (s->multistep) {
+      // comp->multistep_reset() (src/step.cc:84)
+      for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         for (int M = s->mfirst[mstep]; M <= s->multistep; M++) {

@@ -1,0 +1,164 @@
+"""The pyEXP.basis-shaped front end, exercised the way the reference's own tests do
+(tests/Halo/sph_basis.py, tests/Halo/createCoefs.py, tests/Disk/cyl_basis.py) -- plus the numeric
+checks those tests lack.  GPU only."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# tests/Halo/createCoefs.py configuration (pcavar/subsamp dropped: variance analysis is out of scope)
+HALO_CFG = """
+---
+id : sphereSL
+parameters :
+  numr: 1000
+  rmin: 0.0001
+  rmax: 1.95
+  Lmax: 2
+  nmax: 10
+  rmapping : 0.0667
+  modelname: {model}
+  cachename: {cache}
+...
+"""
+
+
+@pytest.fixture(scope="module")
+def halo_basis(tmp_path_factory):
+    from exp_amd.basis import Basis
+    d = tmp_path_factory.mktemp("cache")
+    cfg = HALO_CFG.format(model=os.path.join(GOLD, "SLGridSph.model"),
+                          cache=str(d / "SLGridSph.cache.run0"))
+    return Basis.factory(cfg), cfg
+
+
+def test_factory_and_cache_roundtrip(halo_basis):
+    """tests/Halo/sph_basis.py: build from the reference's model file (orthoTest passes at
+    construction, otherwise the ctor raises), read the cache back."""
+    from exp_amd.basis import Basis
+    basis, cfg = halo_basis
+    info = basis.cacheInfo()
+    assert info["lmax"] == 2 and info["nmax"] == 10 and info["numr"] == 1000
+    assert info["rmapping"] == pytest.approx(0.0667)
+    again = Basis.factory(cfg)                     # second construction reads the cache
+    assert np.array_equal(again.grid.ef, basis.grid.ef)
+    oc = basis.orthoCheck(400)
+    assert max(np.abs(m - np.eye(10)).max() for m in oc) < 1e-2
+
+
+def test_unknown_key_rejected(halo_basis):
+    from exp_amd.basis import Basis
+    _, cfg = halo_basis
+    with pytest.raises(RuntimeError):
+        Basis.factory(cfg.replace("  Lmax: 2", "  Lmax: 2\n  bogus_key: 1"))
+
+
+def test_create_from_array_layouts(halo_basis, oracle):
+    """tests/Halo/createCoefs.py: lists, ndarray converted from lists, list of arrays, [3,N] array.
+    All layouts must give the same coefficients, and those must match the oracle."""
+    basis, _ = halo_basis
+    random.seed(7)
+    mass, xpos, ypos, zpos = [], [], [], []
+    for _ in range(100):
+        mass.append(0.01)
+        xpos.append(random.random() * 2.0 - 1.0)
+        ypos.append(random.random() * 2.0 - 1.0)
+        zpos.append(random.random() * 2.0 - 1.0)
+    coef1 = basis.createFromArray(mass, [xpos, ypos, zpos], time=3.0)
+    data = np.array([xpos, ypos, zpos])
+    coef2 = basis.createFromArray(np.array(mass), data, time=3.1)
+    coef3 = basis.createFromArray(np.array(mass), [np.array(xpos), np.array(ypos), np.array(zpos)],
+                                  time=3.2)
+    coef4 = basis.createFromArray(np.array(mass), data.T.copy(), time=3.3)       # [N,3]
+    assert coef1.time == 3.0 and coef1.coefs.shape == (6, 10)
+    for c in (coef2, coef3, coef4):
+        assert np.abs(c.coefs - coef1.coefs).max() <= 1e-13 * np.abs(coef1.coefs).max()
+    # numeric check against the oracle (real rows -> complex packing, expui/BiorthBasis.cc:482-517)
+    g = basis.grid
+    prm = oracle.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+    ref, used = oracle.sph_accumulate(g, prm, data.T, np.array(mass))
+    assert basis.used == used
+    packed = np.zeros((6, 10), dtype=complex)
+    L0 = L1 = 0
+    for l in range(3):
+        for m in range(l + 1):
+            if m == 0:
+                packed[L0] = ref[L1]; L1 += 1
+            else:
+                packed[L0] = ref[L1] + 1j * ref[L1 + 1]; L1 += 2
+            L0 += 1
+    assert np.abs(coef1.coefs - packed).max() <= 1e-10 * np.abs(packed).max()
+
+
+def test_center_rotation_and_incremental_accumulation(halo_basis):
+    basis, _ = halo_basis
+    rng = np.random.default_rng(3)
+    pos = rng.normal(0, 0.3, (400, 3))
+    m = np.full(400, 1.0 / 400)
+    full = basis.createFromArray(m, pos).coefs.copy()
+    # two addFromArray batches == one (expui/BiorthBasis.cc:4616-4738)
+    basis.initFromArray()
+    basis.addFromArray(m[:150], pos[:150])
+    basis.addFromArray(m[150:], pos[150:])
+    two = basis.makeFromArray(1.0).coefs
+    assert np.abs(two - full).max() <= 1e-12 * np.abs(full).max()
+    # centre: shifting the particles and the centre together changes nothing
+    ctr = np.array([0.1, -0.2, 0.05])
+    shifted = basis.createFromArray(m, pos + ctr, center=ctr).coefs
+    assert np.abs(shifted - full).max() <= 1e-10 * np.abs(full).max()
+
+
+def test_get_accel_matches_oracle_inside_rmax(halo_basis, oracle):
+    basis, _ = halo_basis
+    rng = np.random.default_rng(5)
+    pos = rng.normal(0, 0.3, (2000, 3))
+    pos[:, 2] *= 0.5
+    m = np.full(2000, 1.0 / 2000)
+    coefs = basis.createFromArray(m, pos)
+    basis.set_coefs(coefs)
+    test = rng.normal(0, 0.4, (500, 3))
+    test = test[np.linalg.norm(test, axis=1) < 0.95 * basis.rmax]
+    acc = basis.getAccel(test)
+    prm = oracle.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+    ref, _ = oracle.sph_accumulate(basis.grid, prm, pos, m)
+    a_ref, _ = oracle.sph_accel(basis.grid, prm, test, ref)
+    assert np.abs(acc - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
+    one = basis.getAccel(test[0, 0], test[0, 1], test[0, 2])
+    assert np.allclose(one, acc[0], rtol=0, atol=1e-14 * np.abs(acc[0]).max())
+
+
+def test_cylinder_basis(tmp_path):
+    """tests/Disk/cyl_basis.py shape (smaller fiducial orders so that it builds in seconds)."""
+    from exp_amd.basis import Basis
+    cfg = f"""
+---
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  mmax: 4
+  nmax: 6
+  ncylnx: 48
+  ncylny: 24
+  ncylr: 600
+  lmaxfid: 16
+  nmaxfid: 12
+  rnum: 60
+  tnum: 30
+  cachename: {tmp_path / 'eof.cache.run0'}
+...
+"""
+    basis = Basis.factory(cfg)
+    info = basis.cacheInfo()
+    assert info["mmax"] == 4 and info["nmax"] == 6 and info["numx"] == 48
+    from exp_amd.models import sample_disk
+    m, pos, _ = sample_disk(5000, 3, a=0.01, h=0.001)
+    coefs = basis.createFromArray(m, pos, time=0.5)
+    assert coefs.coefs.shape == (5, 6) and coefs.time == 0.5
+    acc = basis.getAccel(np.array([[0.02, 0.0, 0.0], [0.0, 0.03, 0.001]]))
+    assert acc[0, 0] < 0 and acc[1, 1] < 0 and np.all(np.isfinite(acc))

@@ -68,40 +68,73 @@ def test_multistep_master_steps_match_oracle(ctx, oracle):
     assert sim.time == pytest.approx(2 * dtime)
 
 
-def test_single_level_multistep_equals_multistep0(ctx):
-    """SURVEY 8c KAT (viii): if nobody leaves level 0, a multistep master step is the plain KDK
-    step (two components with mutual interactions, so compute_potential's loops are exercised)."""
+def test_two_component_multistep_level0_semantics(ctx):
+    """Two components with mutual interactions, multistep 2, nobody leaves level 0.  EXP then
+    drifts level 0 once per master step and kicks it with the force of the INTERPOLATED coefficient
+    set a L + b N at mdrft = 1 (b = 1/Mstep; src/SphericalBasis.cc:1252-1290, src/step.cc:115-231),
+    not with N alone -- so this is NOT the multistep=0 step.  Rebuild that recipe from the
+    (oracle-verified) multistep=0 pieces and compare with the C++ step driver."""
     from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
     from tests.test_cyl_gpu import _disk, cyl_grid
     g, m, pos, vel = _halo(3000, 5)
     cg = cyl_grid(4, 6)
-    pos = pos * (3.0 * cg.ascale)                    # put the halo on the disk's scale
-    vel = vel * 0.05
+    sc = 3.0 * cg.ascale
+    pos, vel = pos * sc, vel * 0.05
     dm, dpos, dvel = _disk(3000, 6, cg)
     dvel = dvel + 0.3 * np.random.default_rng(2).standard_normal(dvel.shape)   # v = 0 would force dt -> eps
-    res = {}
-    for ms in (0, 2):
-        f1 = SphereSL(ctx, g, scale=3.0 * cg.ascale, rmin=g.rmin * 3.0 * cg.ascale,
-                      rmax=g.rmax * 3.0 * cg.ascale, multistep=ms)
-        f2 = Cylinder(ctx, cg, multistep=ms)
-        c1 = Component.from_arrays(ctx, m, pos, vel)
-        c2 = Component.from_arrays(ctx, dm, dpos, dvel)
-        sim = Simulation(ctx, 1e-4, multistep=ms, dynfrac=[1e9] * 5)     # nobody wants a shorter step
-        i1 = sim.add_component(c1, f1)
-        i2 = sim.add_component(c2, f2)
-        sim.add_interaction(i1, i2)
-        sim.add_interaction(i2, i1)
-        sim.init()
-        sim.step(2)
-        res[ms] = (c1.download(), c2.download(), f1.get_coefs(), f2.get_coefs())
-        if ms:
-            assert np.all(c1.download_levels() == 0) and np.all(c2.download_levels() == 0)
-        for o in (sim, c1, c2, f1, f2):
-            o.close()
+    dt, ms = 1e-4, 2
+    kw = dict(scale=sc, rmin=g.rmin * sc, rmax=g.rmax * sc)
+
+    # ---- the driver ------------------------------------------------------------------------------
+    f1, f2 = SphereSL(ctx, g, multistep=ms, **kw), Cylinder(ctx, cg, multistep=ms)
+    c1, c2 = Component.from_arrays(ctx, m, pos, vel), Component.from_arrays(ctx, dm, dpos, dvel)
+    sim = Simulation(ctx, dt, multistep=ms, dynfrac=[1e9] * 5)       # nobody wants a shorter step
+    i1, i2 = sim.add_component(c1, f1), sim.add_component(c2, f2)
+    sim.add_interaction(i1, i2)
+    sim.add_interaction(i2, i1)
+    sim.init()
+    # the very first sub-step examines every level and lifts everybody to the top level for the
+    # rest of that master step (src/multistep.cc:451-453 with the mfirst clamp :196); take the
+    # SECOND master step, which starts from everybody back on level 0
+    sim.step(1)
+    assert np.all(c1.download_levels() == 0) and np.all(c2.download_levels() == 0)
+    s1, s2 = c1.download(), c2.download()
+    Cp1, (Cpc, Cps), mass0 = f1.get_coefs(level=0), f2.get_coefs(level=0), f2.cylmass
+    sim.step(1)
+    assert np.all(c1.download_levels() == 0) and np.all(c2.download_levels() == 0)
+    got = (c1.download(), c2.download())
+
+    # ---- the recipe from multistep=0 pieces --------------------------------------------------------
+    h1, h2 = SphereSL(ctx, g, **kw), Cylinder(ctx, cg)
+    d1 = Component.from_arrays(ctx, m, s1["pos"], s1["vel"])
+    d2 = Component.from_arrays(ctx, dm, s2["pos"], s2["vel"])
+    d1.upload_acc(s1["acc"], s1["pot"])
+    d2.upload_acc(s2["acc"], s2["pot"])
+
+    def field():
+        d1.zero_acceleration(); d2.zero_acceleration()
+        h1.get_acceleration_and_potential(d1); h2.get_acceleration_and_potential(d2)
+        h1.get_acceleration_and_potential(d2, external=True)
+        h2.get_acceleration_and_potential(d1, external=True)
+
+    for d in (d1, d2):
+        d.incr_velocity(0.5 * dt); d.incr_position(dt)
+    h1.determine_coefficients(d1); h2.determine_coefficients(d2)
+    Cn1, (Cnc, Cns) = h1.get_coefs(), h2.get_coefs()
+    b = 1.0 / (1 << ms)
+    a = 1.0 - b
+    h1.set_coefs(a * Cp1 + b * Cn1)
+    h2.set_coefs(a * Cpc + b * Cnc, a * Cps + b * Cns)
+    h2.cylmass = mass0
+    field()
+    for d in (d1, d2):
+        d.incr_velocity(0.5 * dt)
+    want = (d1.download(), d2.download())
     for k in (0, 1):
-        for key in ("pos", "vel", "acc", "pot"):
-            a, b = res[0][k][key], res[2][k][key]
-            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max()), (k, key)
+        assert np.abs(got[k]["pos"] - want[k]["pos"]).max() <= 1e-13
+        ascale = np.linalg.norm(want[k]["acc"], axis=1).max()
+        assert np.abs(got[k]["acc"] - want[k]["acc"]).max() <= 1e-9 * ascale
+        assert np.abs(got[k]["vel"] - want[k]["vel"]).max() <= 1e-9 * np.abs(want[k]["vel"]).max()
 
 
 def test_two_component_step_matches_oracle_pieces(ctx, oracle):
