@@ -21,6 +21,9 @@ import argparse
 import json
 import math
 import os
+
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
 import sys
 import time
 

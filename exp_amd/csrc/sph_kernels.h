@@ -188,7 +188,113 @@ __device__ __forceinline__ int acc_to_wrow(int j)
 #define ACC_WAVES 4
 #define ACC_CHUNK 1024        // particles per wave (contiguous, so one or two cells per wave)
 
-// One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend).
+// Per-particle inputs of the moment accumulation: everything that does not depend on (l, m).
+struct AccIn {
+  double costh, cphi, sphi, a1, a2;   // a1 = -4pi m P0 x1, a2 = -4pi m P0 x2 (0 outside the window)
+  int idx;                            // radial cell, -1 when the particle does not contribute
+};
+
+__device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, double px, double py, double pz,
+                                               double mass, bool valid)
+{
+  AccIn in;
+  double xx = 0, yy = 0, zz = 1;
+  if (valid) { xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz; }
+  // src/SphericalBasis.cc:486-494
+  const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  const bool inwin = valid && r >= S.rmin && r <= S.rmax;
+  in.costh = zz / r;
+  phi_trig(xx, yy, in.cphi, in.sphi);
+  const double xi = sph_r_to_xi(S, r / S.scale);
+  const int idx = sph_cell(S, xi);
+  // exputil/SLGridMP2.cc:894-895, :901-902
+  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  const double t0 = inwin ? mass * (-4.0 * M_PI) * P0 : 0.0;
+  in.a1 = t0 * x1;
+  in.a2 = t0 * x2;
+  in.idx = inwin ? idx : -1;
+  return in;
+}
+
+// Rows with m in [MLO, MHI] of one 64-particle group: ballot waterfall over the cells present,
+// register accumulation, LDS-transposed flush when the wave's current cell changes.
+template <int LMAX, int MLO, int MHI, int NV>
+__device__ __forceinline__ void
+sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int &cur,
+              double *scratch, double *__restrict__ W)
+{
+  {
+    unsigned long long fp = (unsigned long long)S.lc;   // re-derive per group: blocks LICM of the
+    asm volatile("" : "+s"(fp));                        // constant loads (SGPR spills)
+    lc = (cdp)fp;
+  }
+  const bool inwin = in.idx >= 0;
+  unsigned long long remaining = __ballot(inwin);
+  while (remaining) {
+    const int lead = __ffsll((long long)remaining) - 1;
+    const int c = __shfl(in.idx, lead);
+    const bool sel = inwin && in.idx == c;
+    if (c != cur) {
+      if (cur >= 0)
+        wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
+                       [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
+      cur = c;
+    }
+    const double a1 = sel ? in.a1 : 0.0;
+    const double a2 = sel ? in.a2 : 0.0;
+    const double costh = in.costh;
+    const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+    double pmm = LC_E(0);                              // Pt(0,0) = factorial(0,0)
+    double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;   // c[m], s[m], c[m-1], s[m-1]
+    static_for<0, MHI + 1>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (m == 1) {
+        pmm *= LC_E(1) * somx2;
+        cm1 = 1.0; sm1 = 0.0;
+        cm = in.cphi; sm = in.sphi;
+      } else if constexpr (m > 1) {
+        pmm *= LC_E(m) * somx2;
+        const double cn = 2.0 * in.cphi * cm - cm1;       // src/Basis.cc:107-110
+        const double sn = 2.0 * in.cphi * sm - sm1;
+        cm1 = cm; sm1 = sm;
+        cm = cn; sm = sn;
+      }
+      if constexpr (m >= MLO) {
+        if (m == 0 || !S.M0_only) {
+          // per-m weights: the four (x1|x2) x (cos|sin) moments share Pt(l,m)
+          const double a1c = a1 * cm, a2c = a2 * cm, a1s = a1 * sm, a2s = a2 * sm;
+          double pl2 = 0.0, pl1 = 0.0;
+          static_for<m, LMAX + 1>([&](auto lc_) {
+            constexpr int l = decltype(lc_)::value;
+            double plm;
+            if constexpr (l == m) plm = pmm;
+            else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
+            else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+            pl2 = pl1;
+            pl1 = plm;
+            if constexpr (m == 0) {
+              constexpr int k = acc_base(LMAX, MLO, 0) + (l - m);
+              acc[2 * k] = fma(a1, plm, acc[2 * k]);
+              acc[2 * k + 1] = fma(a2, plm, acc[2 * k + 1]);
+            } else {
+              constexpr int k = acc_base(LMAX, MLO, m) + 2 * (l - m);
+              acc[2 * k] = fma(a1c, plm, acc[2 * k]);
+              acc[2 * k + 1] = fma(a2c, plm, acc[2 * k + 1]);
+              acc[2 * k + 2] = fma(a1s, plm, acc[2 * k + 2]);
+              acc[2 * k + 3] = fma(a2s, plm, acc[2 * k + 3]);
+            }
+          });
+        }
+      }
+    });
+    remaining &= ~__ballot(sel);
+  }
+}
+
+// One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend), computing
+// the per-particle inputs itself.
 template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
@@ -199,122 +305,92 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
   const int lane = threadIdx.x & 63;
-
   cdp lc = (cdp)S.lc;
-  const double fac0 = -4.0 * M_PI;
-
   double acc[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) acc[j] = 0.0;
   int cur = -1;
   unsigned long long used = 0;
 
-  // software prefetch: the loads of chunk k+1 are in flight while chunk k is reduced
+  // software prefetch: the loads of group k+1 are in flight while group k is reduced
   double nx = 0, ny = 0, nz = 0, nm = 0;
   if (cbeg + lane < cend) {
     nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane];
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const bool valid = i < cend;
-    double xx = 0, yy = 0, zz = 1, mass = 0;
-    if (valid) {
-      xx = nx - S.cx;
-      yy = ny - S.cy;
-      zz = nz - S.cz;
-      mass = nm;
-    }
+    const AccIn in = sph_acc_input(S, nx, ny, nz, nm, i < cend);
     if (i + 64 < cend) {
       nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
     }
-    // src/SphericalBasis.cc:486-494
-    const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-    const bool inwin = valid && r >= S.rmin && r <= S.rmax;
-    const double costh = zz / r;
-    double cphi, sphi;
-    phi_trig(xx, yy, cphi, sphi);
-    const double xi = sph_r_to_xi(S, r / S.scale);
-    const int idx = sph_cell(S, xi);
-    // exputil/SLGridMP2.cc:894-895, :901-902
-    const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
-    const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
-    const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
-    const double t0 = inwin ? mass * fac0 * P0 : 0.0;
-    if (MLO == 0 && inwin) used++;
-    {
-      unsigned long long fp = (unsigned long long)S.lc;   // re-derive per iteration: blocks LICM
-      asm volatile("" : "+s"(fp));                        // of the constant loads (SGPR spills)
-      lc = (cdp)fp;
-    }
-    unsigned long long remaining = __ballot(inwin);
-    while (remaining) {
-      const int lead = __ffsll((long long)remaining) - 1;
-      const int c = __shfl(idx, lead);
-      const bool sel = inwin && idx == c;
-      if (c != cur) {
-        if (cur >= 0)
-          wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
-                         [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
-        cur = c;
-      }
-      const double a1 = sel ? t0 * x1 : 0.0;
-      const double a2 = sel ? t0 * x2 : 0.0;
-
-      const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
-      double pmm = LC_E(0);                              // Pt(0,0) = factorial(0,0)
-      double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;   // c[m], s[m], c[m-1], s[m-1]
-      static_for<0, MHI + 1>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        if constexpr (m == 1) {
-          pmm *= LC_E(1) * somx2;
-          cm1 = 1.0; sm1 = 0.0;
-          cm = cphi; sm = sphi;
-        } else if constexpr (m > 1) {
-          pmm *= LC_E(m) * somx2;
-          const double cn = 2.0 * cphi * cm - cm1;       // src/Basis.cc:107-110
-          const double sn = 2.0 * cphi * sm - sm1;
-          cm1 = cm; sm1 = sm;
-          cm = cn; sm = sn;
-        }
-        if constexpr (m >= MLO) {
-          if (m == 0 || !S.M0_only) {
-            // per-m weights: the four (x1|x2) x (cos|sin) moments share Pt(l,m)
-            const double a1c = a1 * cm, a2c = a2 * cm, a1s = a1 * sm, a2s = a2 * sm;
-            double pl2 = 0.0, pl1 = 0.0;
-            static_for<m, LMAX + 1>([&](auto lc_) {
-              constexpr int l = decltype(lc_)::value;
-              double plm;
-              if constexpr (l == m) plm = pmm;
-              else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
-              else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
-              pl2 = pl1;
-              pl1 = plm;
-              if constexpr (m == 0) {
-                constexpr int k = acc_base(LMAX, MLO, 0) + (l - m);
-                acc[2 * k] = fma(a1, plm, acc[2 * k]);
-                acc[2 * k + 1] = fma(a2, plm, acc[2 * k + 1]);
-              } else {
-                constexpr int k = acc_base(LMAX, MLO, m) + 2 * (l - m);
-                acc[2 * k] = fma(a1c, plm, acc[2 * k]);
-                acc[2 * k + 1] = fma(a2c, plm, acc[2 * k + 1]);
-                acc[2 * k + 2] = fma(a1s, plm, acc[2 * k + 2]);
-                acc[2 * k + 3] = fma(a2s, plm, acc[2 * k + 3]);
-              }
-            });
-          }
-        }
-      });
-      remaining &= ~__ballot(sel);
-    }
+    if (MLO == 0 && in.idx >= 0) used++;
+    sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
   }
   if (cur >= 0)
     wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
                    [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
   if (MLO == 0) {
-    // wave-reduce the used counter
     for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
     if (lane == 0 && used) atomicAdd(used_out, used);
   }
+}
+
+// Same rows, but the four waves of the block work on ONE chunk: each wave computes the inputs of a
+// quarter of every 256-particle tile once, shares them through LDS (double-buffered, one barrier
+// per tile) and then reduces its own m-range over the whole tile.
+struct AccShared {
+  double v[2][5][ACC_WAVES * 64];
+  int idx[2][ACC_WAVES * 64];
+};
+
+template <int LMAX, int MLO, int MHI>
+__device__ __forceinline__ void
+sph_accumulate_shared(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
+                      const double *__restrict__ Z, const double *__restrict__ M, size_t cbeg,
+                      size_t cend, double *scratch, AccShared &sh, double *__restrict__ W,
+                      unsigned long long *__restrict__ used_out)
+{
+  constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
+  constexpr int NV = 2 * NACC;
+  constexpr int TILE = ACC_WAVES * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  cdp lc = (cdp)S.lc;
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) acc[j] = 0.0;
+  int cur = -1;
+  unsigned long long used = 0;
+
+  size_t ip = cbeg + (size_t)wave * 64 + lane;
+  double nx = 0, ny = 0, nz = 0, nm = 0;
+  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+  int par = 0;
+  for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
+    {
+      const AccIn in = sph_acc_input(S, nx, ny, nz, nm, ip < cend);
+      ip += TILE;
+      if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+      if (in.idx >= 0) used++;
+      const int q = wave * 64 + lane;
+      sh.v[par][0][q] = in.costh; sh.v[par][1][q] = in.cphi; sh.v[par][2][q] = in.sphi;
+      sh.v[par][3][q] = in.a1;    sh.v[par][4][q] = in.a2;   sh.idx[par][q] = in.idx;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int sub = 0; sub < ACC_WAVES; sub++) {
+      if (tbase + (size_t)sub * 64 >= cend) break;
+      const int q = sub * 64 + lane;
+      AccIn in;
+      in.costh = sh.v[par][0][q]; in.cphi = sh.v[par][1][q]; in.sphi = sh.v[par][2][q];
+      in.a1 = sh.v[par][3][q];    in.a2 = sh.v[par][4][q];   in.idx = sh.idx[par][q];
+      sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
+    }
+  }
+  if (cur >= 0)
+    wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
+                   [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
+  for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
+  if (lane == 0 && used) atomicAdd(used_out, used);
 }
 
 // m-range splits of the rows (keep 2 moment accumulators per real row in registers).  The waves
@@ -338,6 +414,18 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const int wave = threadIdx.x >> 6;
   double *scratch = scratch_all[wave];
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  if constexpr (NS == ACC_WAVES && LMAX > 7 && LMAX <= 10) {
+    // one chunk per block, shared per-particle inputs, balanced m-ranges (31/34/26/30 rows at L=10)
+    __shared__ AccShared sh;
+    const size_t cbeg = beg + (size_t)blockIdx.x * ACC_CHUNK;
+    if (cbeg >= end) return;
+    const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, X, Y, Z, M, cbeg, cend, scratch, sh, W, used_out)
+    if (wave == 0) RUNS(0, 1); else if (wave == 1) RUNS(2, 3); else if (wave == 2) RUNS(4, 5);
+    else RUNS(6, LMAX);
+#undef RUNS
+    return;
+  }
   const int split = (NS <= ACC_WAVES) ? wave % NS : (int)(blockIdx.y * ACC_WAVES + wave);
   const size_t chunk = (NS <= ACC_WAVES) ? (size_t)blockIdx.x * CPB + wave / NS : blockIdx.x;
   if (split >= NS) return;

@@ -31,7 +31,7 @@ from numpy.polynomial import legendre as npleg
 from scipy.special import lpmv
 
 from .models import NumericModel
-from .slgrid import SLGridSph, build_slgrid
+from .slgrid import SLGridSph, build_slgrid, threadpool_limits
 
 KIND = {"potC": 0, "rforceC": 1, "zforceC": 2, "potS": 3, "rforceS": 4, "zforceS": 5}
 
@@ -242,6 +242,8 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
     cg = Zg / rrg
 
     tab = np.zeros((6, mmax + 1, norder, numx + 1, numy + 1))
+    _limit = threadpool_limits(limits=8)
+    _limit.__enter__()
     for m in range(mmax + 1):
         nl = lmaxfid - m + 1
         # 3. covariance: v[(l-m), ir] = pfac * P_l^m(cos) * potd(l, ir) [* 1/2 for m>0, nump = 1]
@@ -277,6 +279,7 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
             tab[k, m] = t
             if m > 0:
                 tab[k + 3, m] = t            # nump = 1: sine block == cosine block
+    _limit.__exit__(None, None, None)
     return EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
                       ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,
                       xmin=XMIN, xmax=XMAX, dx=dX, ymin=YMIN, ymax=YMAX, dy=dY,

@@ -32,6 +32,14 @@ from scipy.interpolate import CubicSpline
 
 from .models import SphericalModel
 
+try:                                   # keep LAPACK/BLAS from oversubscribing big hosts
+    from threadpoolctl import threadpool_limits
+except Exception:                      # pragma: no cover
+    import contextlib
+
+    def threadpool_limits(limits=None):
+        return contextlib.nullcontext()
+
 NEVSIGN = 4  # exputil/libvars.cc:38
 
 
@@ -248,6 +256,8 @@ def build_slgrid(model: SphericalModel, lmax: int, nmax: int, numr: int = 2000,
 
     ev = np.zeros((lmax + 1, nmax))
     ef = np.zeros((lmax + 1, nmax, numr))
+    _limit = threadpool_limits(limits=8)
+    _limit.__enter__()
     for l in range(lmax + 1):
         # exputil/SLGridMP2.cc:1119-1135: narrowed radial domain for large l
         Nlo, Nhi = 0, numr
@@ -265,6 +275,7 @@ def build_slgrid(model: SphericalModel, lmax: int, nmax: int, numr: int = 2000,
         sgn = np.where(u[nfid, :] < 0.0, -1.0, 1.0)
         ev[l] = lam
         ef[l, :, Nlo:Nhi] = (u * sgn[None, :]).T
+    _limit.__exit__(None, None, None)
 
     return SLGridSph(lmax=lmax, nmax=nmax, numr=numr, cmap=cmap, rmin=rmin, rmax=rmax,
                      rmap=rmap, xmin=xmin, xmax=xmax, dxi=dxi, xi=xi, r=r, p0=p0, d0=d0,

@@ -127,12 +127,17 @@ def main():
         lev_h = np.bincount(ch.download_levels(), minlength=ms + 1)
         lev_d = np.bincount(cd.download_levels(), minlength=ms + 1)
         dt = timed(lambda: sim.step(1), max(2, args.steps // 3), 1)
+        ctx.profile(True); ctx.profile_reset()
+        sim.step(1)
+        prof = {k: round(v["ms_total"], 3) for k, v in ctx.profile_report().items()}
+        ctx.profile(False)
         sub = sum(int(lev_h[M] + lev_d[M]) * (1 << M) for M in range(ms + 1))
         out.append({"config": "4: disk+halo (1e7 each), SphericalSL+EmpCylSL, multistep 4, cross forces",
                     "n": 2 * n, "ms_per_master_step": 1e3 * dt,
                     "master_step_particle_steps_per_s": 2 * n / dt,
                     "raw_particle_substeps_per_s": sub / dt,
-                    "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist()})
+                    "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist(),
+                    "kernels_ms_per_master_step": prof})
     for o in out:
         print(json.dumps(o), flush=True)
 
