@@ -522,7 +522,8 @@ struct CylForce : exp_amd_force {
     mass_open = true;
     return EXP_AMD_OK;
   }
-  int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift);
+  int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
+           int level = -1);
   void release() override
   {
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
@@ -601,7 +602,8 @@ __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ 
   if (threadIdx.x < 2) acc[threadIdx.x] = (overwrite ? 0.0 : acc[threadIdx.x]) + tail[threadIdx.x];
 }
 
-int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift)
+int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
+                   int level)
 {
   CylForce *f = this;
   if (c->n == 0) return EXP_AMD_OK;
@@ -615,10 +617,10 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n, c->key.p,
-                                                                              c->hist.p);
+    k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(
+        kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -677,7 +679,9 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   f->home = c;
   const CylDev C = cdev_for(f, c->center);
   {
-    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift);
+    const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
+                          ? f->mlevel : -1;
+    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift, level);
     if (rc) return rc;
   }
   // ---- accumulate ----------------------------------------------------------------------------------

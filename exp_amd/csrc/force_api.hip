@@ -185,14 +185,18 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   const int first = first_step ? 0 : mfirst;        // src/multistep.cc:451-453
   int rc = expamd_comp_propose_levels(c, dtime, dynfrac, shiftlevl, ms, mfirst, first);
   if (rc) return rc;
-  if ((rc = f->multistep_update(c, first, mfirst))) return rc;
-  if ((rc = expamd_comp_commit_levels(c))) return rc;
-  if ((rc = f->resort(c))) return rc;
-  if (nswitch) {
-    unsigned long long u = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *nswitch = (long long)u;
+  // one 8-byte read-back decides whether anything has to be differenced / re-ordered at all
+  unsigned long long u = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (nswitch) *nswitch = (long long)u;
+  if (ctx->nranks > 1 || ctx->ar_fn || u) {
+    // (collective: with several ranks every rank takes part even if it has no mover)
+    if ((rc = f->multistep_update(c, first, mfirst))) return rc;
+  }
+  if (u) {
+    if ((rc = expamd_comp_commit_levels(c))) return rc;
+    if ((rc = f->resort(c))) return rc;
   }
   return EXP_AMD_OK;
 }

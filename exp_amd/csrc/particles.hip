@@ -60,37 +60,57 @@ k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict_
 
 // ---- counting sort (pass kernels live in sort_kernels.h) -----------------------------------
 
-// exclusive scan of hist[0..nkeys) in place (single block); hist[nkeys] = total;
-// lev_off[L] = start of key L*ncell, lev_off[nlev] = total
+// exclusive scan of hist[0..nkeys) in place (single block, coalesced 1024-key chunks with a
+// running carry); hist[nkeys] = total; lev_off[L] = start of key L*ncell, lev_off[nlev] = total.
+// range mode (range_lo >= 0): only that level's bins [range_lo*ncell, (range_lo+1)*ncell) are
+// populated; positions start at that level's first slot and the level offsets are left alone.
 __global__ void __launch_bounds__(1024)
 k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
-       uint32_t ncell, int nlev)
+       uint32_t ncell, int nlev, int range_lo)
 {
-  __shared__ uint32_t part[1024];
-  const int t = threadIdx.x;
-  const uint32_t per = (nkeys + 1023u) / 1024u;
-  const uint32_t b = t * per, e = min(nkeys, b + per);
-  uint32_t s = 0;
-  for (uint32_t k = b; k < e; k++) s += hist[k];
-  part[t] = s;
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
+  const uint32_t k1 = (range_lo >= 0) ? k0 + ncell : nkeys;
+  if (t == 0) carry_s = (range_lo >= 0) ? lev_off[range_lo] : 0u;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (t >= off) ? part[t - off] : 0u;
+  for (uint32_t base = k0; base < k1; base += 1024u) {
+    const uint32_t k = base + t;
+    const uint32_t v = (k < k1) ? hist[k] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    part[t] += v;
+    if (wave == 0) {
+      uint32_t w = (lane < 16) ? wsum[lane] : 0u;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const uint32_t y = __shfl_up(w, off);
+        if (lane >= off) w += y;
+      }
+      if (lane < 16) wsum[lane] = w;           // inclusive prefix of the wave totals
+    }
+    __syncthreads();
+    const uint32_t carry = carry_s;
+    const uint32_t excl = carry + (wave ? wsum[wave - 1] : 0u) + (x - v);
+    if (k < k1) {
+      hist[k] = excl;
+      if (range_lo < 0 && k % ncell == 0) lev_off[k / ncell] = excl;
+    }
+    __syncthreads();
+    if (t == 0) carry_s = carry + wsum[15];
     __syncthreads();
   }
-  uint32_t run = (t == 0) ? 0u : part[t - 1];
-  for (uint32_t k = b; k < e; k++) {
-    uint32_t c = hist[k];
-    hist[k] = run;
-    if (k % ncell == 0) lev_off[k / ncell] = run;
-    run += c;
-  }
-  if (t == 1023) {
-    hist[nkeys] = part[1023];
-    lev_off[nlev] = part[1023];
+  if (t == 0) {
+    if (range_lo < 0) {
+      hist[nkeys] = carry_s;
+      lev_off[nlev] = carry_s;
+    }
   }
 }
 
@@ -167,14 +187,42 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, d
 }
 
 // after k_key_hist: scan the histogram, scatter (with the same advance) into the other buffer set
+SortRange expamd_sort_range(exp_amd_comp *c, int level)
+{
+  SortRange R;
+  R.lev_off = (level >= 0) ? c->lev_off.p : nullptr;
+  R.lo = R.hi = level < 0 ? 0 : level;
+  R.n = c->n;
+  return R;
+}
+
+// copy the slot range of one level back from the scatter target into the live buffer set
+struct CopySet {
+  double *dst[A_NARR];
+  const double *src[A_NARR];
+  uint32_t *did;
+  const uint32_t *sid;
+  int narr;
+};
+
+__global__ void __launch_bounds__(TPB)
+k_copy_range(CopySet C, const uint32_t *__restrict__ lev_off, int level)
+{
+  const size_t beg = lev_off[level], end = lev_off[level + 1];
+  const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= end) return;
+  for (int a = 0; a < C.narr; a++) C.dst[a][i] = C.src[a][i];
+  C.did[i] = C.sid[i];
+}
+
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift)
+                            bool advance, double dt_kick, double dt_drift, int level)
 {
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   {
     ProfScope ps(ctx, "k_scan");
-    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels);
+    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level);
   }
   {
     ProfScope ps(ctx, "k_scatter_adv");
@@ -184,13 +232,29 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                  c->level[1 - c->cur].p};
     const unsigned g = cdiv(c->n, SORT_TILE);
+    const SortRange R = expamd_sort_range(c, level);
     if (move_acc)
-      k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, c->n, c->key.p, c->hist.p);
+      k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     else
-      k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, c->n, c->key.p, c->hist.p);
+      k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
   }
   HIP_TRY(ctx, hipGetLastError());
-  c->cur = 1 - c->cur;
+  if (level < 0) {
+    c->cur = 1 - c->cur;
+    return EXP_AMD_OK;
+  }
+  // one level only: bring its range back (levels do not change inside a level sort, so the u8
+  // level array is already right)
+  {
+    ProfScope ps(ctx, "k_copy_range");
+    CopySet C;
+    C.narr = move_acc ? A_NARR : A_AX;
+    for (int a = 0; a < A_NARR; a++) { C.dst[a] = c->a(a); C.src[a] = c->b(a); }
+    C.did = c->id[c->cur].p;
+    C.sid = c->id[1 - c->cur].p;
+    k_copy_range<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(C, c->lev_off.p, level);
+  }
+  HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
 

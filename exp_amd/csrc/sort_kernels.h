@@ -49,14 +49,31 @@ __device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t *slot)
   return *slot;
 }
 
+// slot range handled by a sort pass: the whole store, or the levels [lo, hi] (device-resident
+// level offsets, so that no host synchronisation is needed to sort one level)
+struct SortRange {
+  const uint32_t *lev_off;   // nullptr: [0, n)
+  int lo, hi;
+  size_t n;
+};
+
+__device__ __forceinline__ void sort_range(const SortRange &R, size_t &beg, size_t &end)
+{
+  if (R.lev_off) { beg = R.lev_off[R.lo]; end = R.lev_off[R.hi + 1]; }
+  else { beg = 0; end = R.n; }
+}
+
 template <class KeyFn>
 __global__ void __launch_bounds__(SORT_TPB)
-k_key_hist(KeyFn kf, AdvanceArgs A, size_t n, uint32_t *__restrict__ key_out,
+k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
            uint32_t *__restrict__ hist)
 {
   __shared__ uint32_t lh[SORT_WIN];
   __shared__ uint32_t kmin_s;
-  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  size_t rbeg, n;
+  sort_range(R, rbeg, n);
+  const size_t base = rbeg + (size_t)blockIdx.x * SORT_TILE;
+  if (base >= n) return;
   uint32_t k[SORT_ITEMS];
   uint32_t mn = 0xffffffffu;
 #pragma unroll
@@ -100,12 +117,15 @@ struct ScatterSrc {
 
 template <bool MOVE_ACC>
 __global__ void __launch_bounds__(SORT_TPB)
-k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, size_t n,
+k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
               const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor)
 {
   __shared__ uint32_t lh[SORT_WIN];       // count, then global base of the (block, bin) range
   __shared__ uint32_t kmin_s;
-  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  size_t rbeg, n;
+  sort_range(R, rbeg, n);
+  const size_t base = rbeg + (size_t)blockIdx.x * SORT_TILE;
+  if (base >= n) return;
   uint32_t k[SORT_ITEMS], rk[SORT_ITEMS];
   uint32_t mn = 0xffffffffu;
 #pragma unroll
@@ -153,7 +173,8 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, size_t n,
 
 // host helper (defined in particles.hip): scan + scatter after a k_key_hist launch
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift);
+                            bool advance, double dt_kick, double dt_drift, int level = -1);
+SortRange expamd_sort_range(exp_amd_comp *c, int level);
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys);
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                                int multistep, int mfirst_mdrft, int first);

@@ -252,7 +252,7 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 // (level, radial cell) order for this force's tables; with `advance` the kick dt_kick and drift
 // dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
 static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = false,
-                    double dt_kick = 0.0, double dt_drift = 0.0)
+                    double dt_kick = 0.0, double dt_drift = 0.0, int level = -1)
 {
   exp_amd_ctx *ctx = f->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -265,10 +265,10 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center)};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<SphKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(kf, A, c->n, c->key.p,
-                                                                              c->hist.p);
+    k_key_hist<SphKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(
+        kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -323,7 +323,11 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
 {
   SphForce *f = this;
   f->home = c;
-  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift);
+  // multistep: only level `mlevel` has moved since the store was last put in this basis' order,
+  // so only its slot range is re-sorted
+  const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
+                        ? f->mlevel : -1;
+  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift, level);
   if (rc) return rc;
   double *dst = f->cfg.multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef : f->d_coef.p;
   if (f->cfg.multistep) {
