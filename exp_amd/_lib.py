@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_longlong, c_si
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexp_amd.so")
+LIB_PATH = os.environ.get("EXP_AMD_LIB") or os.path.join(_HERE, "libexp_amd.so")   # (override: A/B builds)
 
 c_double_p = POINTER(c_double)
 

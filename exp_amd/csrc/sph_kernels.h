@@ -566,6 +566,9 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
 {
   ForceOut o{0.0, 0.0, 0.0, 0.0};
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  double xl[LMAX + 1];                       // l * x (pole-clamped x) of the derivative recurrence
+#pragma unroll
+  for (int l = 0; l <= LMAX; l++) xl[l] = xc * l;
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
   static_for<0, LMAX + 1>([&](auto mc) {
@@ -592,56 +595,76 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
       static_for<0, m>([&](auto) { t *= rr; });
       rl = ioff ? t : 1.0;
     }
-    // per-m partial sums over l: A ~ cos rows, B ~ sin rows; plain (l), radial-derivative (r),
-    // polar-derivative (t)
-    double Al = 0.0, Bl = 0.0, Ar = 0.0, Br = 0.0, At = 0.0, Bt = 0.0;
+    // Per-m partial sums over l.  FAST: the per-particle interpolation weights are factored out of
+    // the l-sum -- with p_row = G0 + x2 D and dp_row = Bq + pf Aq,
+    //     sum_l Pt p_row = (sum_l Pt G0) + x2 (sum_l Pt D)        etc.
+    // so every FMA has exactly one scalar (table) operand and one vector operand: no SGPR->VGPR
+    // copies (a VOP3 may read one SGPR pair only) and the weights are applied once per m.
+    double Al = 0.0, Bl = 0.0, Ar = 0.0, Br = 0.0, At = 0.0, Bt = 0.0;       // !FAST accumulators
+    double Ag = 0.0, Ad = 0.0, Tg = 0.0, Td = 0.0, Rb = 0.0, Ra = 0.0;       // FAST: cos rows
+    double Bg = 0.0, Bd = 0.0, Ug = 0.0, Ud = 0.0, Sb = 0.0, Sa = 0.0;       // FAST: sin rows
     double pl2 = 0.0, pl1 = 0.0;
     static_for<m, LMAX + 1>([&](auto lc_) {
       constexpr int l = decltype(lc_)::value;
       double plm, qlm;            // Pt(l,m) and (x^2-1) dPt(l,m)
       if constexpr (l == m) {
         plm = pmm;
-        qlm = (xc * l) * plm;
+        qlm = xl[l] * plm;
       } else if constexpr (l == m + 1) {
         plm = LC_A(l, m) * (costh * pl1);
-        qlm = (xc * l) * plm - LC_C(l, m) * pl1;
+        qlm = xl[l] * plm - LC_C(l, m) * pl1;
       } else {
         plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
-        qlm = (xc * l) * plm - LC_C(l, m) * pl1;
+        qlm = xl[l] * plm - LC_C(l, m) * pl1;
       }
       pl2 = pl1;
       pl1 = plm;
-      bool on = m_on;
-      if constexpr (!FAST) {
+      constexpr int q = 4 * mmajor_row(LMAX, l, m);
+      if constexpr (FAST) {
+        Ag = fma(plm, t4[q + 0], Ag);
+        Ad = fma(plm, t4[q + 1], Ad);
+        Rb = fma(plm, t4[q + 2], Rb);
+        Ra = fma(plm, t4[q + 3], Ra);
+        Tg = fma(qlm, t4[q + 0], Tg);
+        Td = fma(qlm, t4[q + 1], Td);
+        if constexpr (m > 0) {
+          Bg = fma(plm, t4[q + 4], Bg);
+          Bd = fma(plm, t4[q + 5], Bd);
+          Sb = fma(plm, t4[q + 6], Sb);
+          Sa = fma(plm, t4[q + 7], Sa);
+          Ug = fma(qlm, t4[q + 4], Ug);
+          Ud = fma(qlm, t4[q + 5], Ud);
+        }
+      } else {
+        bool on = m_on;
         if (l == 0 && S.NO_L0) on = false;
         if (l == 1 && S.NO_L1) on = false;
         if (l > 0 && S.EVEN_L && (l & 1)) on = false;
-      }
-      if (on) {
-        constexpr int q = 4 * mmajor_row(LMAX, l, m);
-        double pc = fma(x2, t4[q + 1], t4[q + 0]);
-        double dpc = fma(pf, t4[q + 3], t4[q + 2]);
-        if constexpr (!FAST) {
+        if (on) {
+          double pc = fma(x2, t4[q + 1], t4[q + 0]);
+          double dpc = fma(pf, t4[q + 3], t4[q + 2]);
           pc *= rl;
           dpc = ioff ? (kappa0 * (l + 1)) * pc : dpc;
-        }
-        Al = fma(plm, pc, Al);
-        Ar = fma(plm, dpc, Ar);
-        At = fma(qlm, pc, At);
-        if constexpr (m > 0) {
-          double ps = fma(x2, t4[q + 5], t4[q + 4]);
-          double dps = fma(pf, t4[q + 7], t4[q + 6]);
-          if constexpr (!FAST) {
+          Al = fma(plm, pc, Al);
+          Ar = fma(plm, dpc, Ar);
+          At = fma(qlm, pc, At);
+          if constexpr (m > 0) {
+            double ps = fma(x2, t4[q + 5], t4[q + 4]);
+            double dps = fma(pf, t4[q + 7], t4[q + 6]);
             ps *= rl;
             dps = ioff ? (kappa0 * (l + 1)) * ps : dps;
+            Bl = fma(plm, ps, Bl);
+            Br = fma(plm, dps, Br);
+            Bt = fma(qlm, ps, Bt);
           }
-          Bl = fma(plm, ps, Bl);
-          Br = fma(plm, dps, Br);
-          Bt = fma(qlm, ps, Bt);
         }
+        rl *= ioff ? rr : 1.0;
       }
-      if constexpr (!FAST) rl *= ioff ? rr : 1.0;
     });
+    if constexpr (FAST) {
+      Al = fma(x2, Ad, Ag); At = fma(x2, Td, Tg); Ar = fma(pf, Ra, Rb);
+      Bl = fma(x2, Bd, Bg); Bt = fma(x2, Ud, Ug); Br = fma(pf, Sa, Sb);
+    }
     if constexpr (m == 0) {
       o.potl += Al;
       o.potr += Ar;
@@ -661,8 +684,11 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
 // Two launches share this body.  FAST: every wave whose lanes sit in one radial cell with no
 // exterior particle is done here; the rest push their first slot on `work` and leave.
 // !FAST: one wave per work item (or per 64-slot chunk when work == nullptr, i.e. "all waves").
+#ifndef SPH_FORCE_WAVES
+#define SPH_FORCE_WAVES 5      // min waves/SIMD for the fast pass: 5 beats 4 and 6 on MI355X (A/B, profiles/)
+#endif
 template <int LMAX, bool FAST>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, FAST ? SPH_FORCE_WAVES : 1)
 k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
             int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
