@@ -206,7 +206,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_W.alloc((size_t)(numr - 1) * nrows * 2));
   A(f->d_part.alloc((size_t)CSEG * ncoef));
   A(f->d_G.alloc((size_t)numr * nrows));
-  A(f->d_T4.alloc((size_t)(numr - 1) * nrows * 4));
+  A(f->d_T4.alloc((size_t)(numr - 1) * nrows * 4 + 8));   // + spare: 8-double scalar windows
   if (e == hipSuccess && f->alloc_common(ncoef, cfg->multistep) != EXP_AMD_OK) e = hipErrorOutOfMemory;
   if (e != hipSuccess) {
     exp_amd_force_destroy(f);

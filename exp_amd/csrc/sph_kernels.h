@@ -77,10 +77,47 @@ __host__ __device__ constexpr int mmajor_row(int L, int l, int m)
 //   Pt(l,m)   = A(l,m) * x * Pt(l-1,m) - B(l,m) * Pt(l-2,m)
 //   dPt(l,m)  = (l * x * Pt(l,m) - C(l,m) * Pt(l-1,m)) / (x^2 - 1)          (src/Basis.cc:86-92)
 // lc[(l*(L+1)+m)*4 + {0,1,2,3}] = {A, B, C, e (only for l == m)}
-#define LC_A(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 0]
-#define LC_B(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 1]
-#define LC_C(l, m) lc[((l) * (LMAX + 1) + (m)) * 4 + 2]
-#define LC_E(m)    lc[((m) * (LMAX + 1) + (m)) * 4 + 3]
+// The constants are pure functions of (l, m): they are evaluated at COMPILE time and become
+// literals (s_mov pairs on the scalar ALU) instead of scalar loads that the FMAs would wait for.
+//   A = sqrt((4l^2-1)/(l^2-m^2)),  B = sqrt((2l+1)(l-m-1)(l+m-1)/((2l-3)(l+m)(l-m))),
+//   C = sqrt((2l+1)(l^2-m^2)/(2l-1)),  e_m = -sqrt((2m+1) k/(2m)) (k = 2 for m = 1, else 1),
+//   e_0 = factorial(0,0) = sqrt(1/4pi)           [factorial(l,m): src/SphericalBasis.cc:328-335]
+constexpr double lc_sqrt(double x)
+{
+  if (x <= 0.0) return 0.0;
+  double r = x > 1.0 ? x : 1.0;
+  for (int i = 0; i < 200; i++) {
+    const double n = 0.5 * (r + x / r);
+    if (n == r) break;
+    r = n;
+  }
+  return r;
+}
+constexpr double lc_A(int l, int m) { return lc_sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m)); }
+constexpr double lc_B(int l, int m)
+{
+  return lc_sqrt((2.0 * l + 1.0) * (l - m - 1.0) * (l + m - 1.0) / ((2.0 * l - 3.0) * (l + m) * (l - m)));
+}
+constexpr double lc_C(int l, int m) { return lc_sqrt((2.0 * l + 1.0) * ((double)l * l - (double)m * m) / (2.0 * l - 1.0)); }
+constexpr double lc_E(int m)
+{
+  return m == 0 ? lc_sqrt(1.0 / (4.0 * 3.14159265358979323846))
+                : -lc_sqrt((2.0 * m + 1.0) * (m == 1 ? 2.0 : 1.0) / (2.0 * m));
+}
+#define LC_A(l, m) (lc_const<lc_kind_A, (l), (m)>())
+#define LC_B(l, m) (lc_const<lc_kind_B, (l), (m)>())
+#define LC_C(l, m) (lc_const<lc_kind_C, (l), (m)>())
+#define LC_E(m)    (lc_const<lc_kind_E, (m), (m)>())
+enum { lc_kind_A, lc_kind_B, lc_kind_C, lc_kind_E };
+template <int KIND, int L_, int M_>
+__host__ __device__ constexpr double lc_const()
+{
+  constexpr double v = KIND == lc_kind_A ? lc_A(L_, M_)
+                     : KIND == lc_kind_B ? lc_B(L_, M_)
+                     : KIND == lc_kind_C ? lc_C(L_, M_)
+                                         : lc_E(M_);
+  return v;
+}
 
 // ---- per-particle radial/angular coordinates --------------------------------------------------
 
@@ -681,6 +718,118 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
   return o;
 }
 
+// ---- fast path with software-pipelined scalar table loads --------------------------------------------
+// hipcc issues each (l,m) block's s_load right before its first use and waits for it at once, so
+// every one of the (L+1)(L+2)/2 blocks exposes a full scalar-cache round trip.  Here the loads are
+// written by hand (two SGPR buffers): block k+1 is requested before the FMAs of block k and only
+// waited for after them.  The inline asm follows cdna_hip_programming.md section 5.7: the asm owns its
+// waits (lgkmcnt(0), SMEM may return out of order) and every consumer is data-dependent on the
+// wait statement ("+s"), so nothing can be scheduled between a load and its wait that reads it.
+typedef double sd8 __attribute__((ext_vector_type(8)));
+typedef double sd4 __attribute__((ext_vector_type(4)));
+
+#define SLOAD8(dst, base, off_doubles) \
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(base), "n"((off_doubles) * 8))
+#define SLOAD4(dst, base, off_doubles) \
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(dst) : "s"(base), "n"((off_doubles) * 8))
+#define SWAIT8(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v))
+#define SWAIT4(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v))
+
+// m-major traversal: k-th (l,m) block, its table offset (doubles) -- all constexpr
+template <int LMAX> __host__ __device__ constexpr int blk_m(int k)
+{
+  int m = 0, base = 0;
+  while (k >= base + (LMAX - m + 1)) { base += LMAX - m + 1; m++; }
+  return m;
+}
+template <int LMAX> __host__ __device__ constexpr int blk_l(int k)
+{
+  int m = 0, base = 0;
+  while (k >= base + (LMAX - m + 1)) { base += LMAX - m + 1; m++; }
+  return m + (k - base);
+}
+
+template <int LMAX>
+__device__ __forceinline__ ForceOut
+sph_field_fast(cdp t4, double costh, double xc, double cphi, double sphi, double x2, double pf)
+{
+  constexpr int NBLK = (LMAX + 1) * (LMAX + 2) / 2;
+  ForceOut o{0.0, 0.0, 0.0, 0.0};
+  const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  const unsigned long long tb = (unsigned long long)t4;
+  double pmm = LC_E(0);
+  double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+  double Ag = 0.0, Ad = 0.0, Tg = 0.0, Td = 0.0, Rb = 0.0, Ra = 0.0;       // cos rows
+  double Bg = 0.0, Bd = 0.0, Ug = 0.0, Ud = 0.0, Sb = 0.0, Sa = 0.0;       // sin rows
+  double pl2 = 0.0, pl1 = 0.0;
+  // m = 0 rows are 4 doubles each: fetch them two rows at a time as 8-double blocks where possible
+  sd8 cur, nxt;
+  SLOAD8(cur, tb, 0);
+  SWAIT8(cur);
+  static_for<0, NBLK>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int l = blk_l<LMAX>(k), m = blk_m<LMAX>(k);
+    constexpr int q = 4 * mmajor_row(LMAX, l, m);
+    // which 8-double window holds this block, and the next one to request
+    constexpr int win = (m == 0) ? (q / 8) * 8 : q;          // m = 0: rows pair up in one window
+    constexpr bool last = (k + 1 == NBLK);
+    constexpr int l1 = last ? l : blk_l<LMAX>(k + 1), m1 = last ? m : blk_m<LMAX>(k + 1);
+    constexpr int q1 = 4 * mmajor_row(LMAX, l1, m1);
+    constexpr int win1 = (m1 == 0) ? (q1 / 8) * 8 : q1;
+    constexpr bool need = !last && win1 != win;
+    // 8-double windows may run 4 doubles past the end of the cell's rows for even row counts;
+    // T4 is allocated with one spare row per table, so the read is in bounds and unused
+    if constexpr (need) { SLOAD8(nxt, tb, win1); __builtin_amdgcn_sched_barrier(0); }
+
+    if constexpr (l == m) {            // start of an m-block
+      if constexpr (m == 1) { pmm *= LC_E(1) * somx2; cm = cphi; sm = sphi; }
+      else if constexpr (m > 1) {
+        pmm *= LC_E(m) * somx2;
+        const double cn = 2.0 * cphi * cm - cm1, sn = 2.0 * cphi * sm - sm1;
+        cm1 = cm; sm1 = sm; cm = cn; sm = sn;
+      }
+      Ag = Ad = Tg = Td = Rb = Ra = 0.0;
+      Bg = Bd = Ug = Ud = Sb = Sa = 0.0;
+      pl2 = pl1 = 0.0;
+    }
+    double plm, qlm;
+    if constexpr (l == m) { plm = pmm; qlm = (xc * l) * plm; }
+    else if constexpr (l == m + 1) { plm = LC_A(l, m) * (costh * pl1); qlm = (xc * l) * plm - LC_C(l, m) * pl1; }
+    else { plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2; qlm = (xc * l) * plm - LC_C(l, m) * pl1; }
+    pl2 = pl1;
+    pl1 = plm;
+    constexpr int o0 = q - win;        // 0 or 4 inside the window
+    Ag = fma(plm, cur[o0 + 0], Ag);
+    Ad = fma(plm, cur[o0 + 1], Ad);
+    Rb = fma(plm, cur[o0 + 2], Rb);
+    Ra = fma(plm, cur[o0 + 3], Ra);
+    Tg = fma(qlm, cur[o0 + 0], Tg);
+    Td = fma(qlm, cur[o0 + 1], Td);
+    if constexpr (m > 0) {
+      Bg = fma(plm, cur[4], Bg);
+      Bd = fma(plm, cur[5], Bd);
+      Sb = fma(plm, cur[6], Sb);
+      Sa = fma(plm, cur[7], Sa);
+      Ug = fma(qlm, cur[4], Ug);
+      Ud = fma(qlm, cur[5], Ud);
+    }
+    if constexpr (l == LMAX) {         // end of an m-block: apply the per-particle weights once
+      const double Al = fma(x2, Ad, Ag), At = fma(x2, Td, Tg), Ar = fma(pf, Ra, Rb);
+      if constexpr (m == 0) {
+        o.potl += Al; o.potr += Ar; o.pott += At;
+      } else {
+        const double Bl = fma(x2, Bd, Bg), Bt = fma(x2, Ud, Ug), Br = fma(pf, Sa, Sb);
+        o.potl += Al * cm + Bl * sm;
+        o.potr += Ar * cm + Br * sm;
+        o.pott += At * cm + Bt * sm;
+        o.potp += (Bl * cm - Al * sm) * m;
+      }
+    }
+    if constexpr (need) { __builtin_amdgcn_sched_barrier(0); SWAIT8(nxt); cur = nxt; }
+  });
+  return o;
+}
+
 // Two launches share this body.  FAST: every wave whose lanes sit in one radial cell with no
 // exterior particle is done here; the rest push their first slot on `work` and leave.
 // !FAST: one wave per work item (or per 64-slot chunk when work == nullptr, i.e. "all waves").
@@ -755,7 +904,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
       return;
     }
     cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
-    o = sph_field<LMAX, true>(S, lc, costh, xc, cphi, sphi, t4, x2, pf, false, 1.0, 0.0);
+    o = sph_field_fast<LMAX>(t4, costh, xc, cphi, sphi, x2, pf);
   } else {
     const double rr = S.rmax / r0;
     const double kappa0 = -P0 / (r0 * ffac);     // dp = -(l+1)/r0 * p, in units of ffac
