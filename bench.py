@@ -23,7 +23,7 @@ import math
 import os
 
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, "8")
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 

@@ -78,14 +78,14 @@ k_sph_project(SphDev S, const double *__restrict__ coef, double *__restrict__ G)
 // the skipped odd-m terms do not advance moffset, so even m >= 2 read rows l*l + m-1, l*l + m).
 __global__ void __launch_bounds__(256)
 k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ rowmap,
-               double *__restrict__ T4)
+               const double *__restrict__ tscale, double *__restrict__ T4)
 {
   const int cell = blockIdx.x;                 // 0 .. numr-2
   const int j = cell < 1 ? 1 : cell;
-  for (int q = threadIdx.x; q < S.nrows; q += 256) {
+  for (int q = threadIdx.x; q < S.trows; q += 256) {
     const int row = rowmap[q];
     if (row < 0) {                             // (l,m) switched off by NO_L0/NO_L1/EVEN_L/EVEN_M/M0_only
-      double *t = T4 + ((size_t)cell * S.nrows + q) * 4;
+      double *t = T4 + ((size_t)cell * S.trows + q) * 4;
       t[0] = t[1] = t[2] = t[3] = 0.0;
       continue;
     }
@@ -94,11 +94,12 @@ k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ r
     const double h0 = S.p0[j - 1] * G[(size_t)(j - 1) * S.nrows + row];
     const double h1 = S.p0[j] * G[(size_t)j * S.nrows + row];
     const double h2 = S.p0[j + 1] * G[(size_t)(j + 1) * S.nrows + row];
-    double *t = T4 + ((size_t)cell * S.nrows + q) * 4;
-    t[0] = g0;
-    t[1] = g1 - g0;
-    t[2] = 0.5 * (h2 - h0);
-    t[3] = (h0 - 2.0 * h1) + h2;
+    double *t = T4 + ((size_t)cell * S.trows + q) * 4;
+    const double sc = tscale[q];               // 1/s(l,m) of the rescaled Legendre recurrence
+    t[0] = sc * g0;
+    t[1] = sc * (g1 - g0);
+    t[2] = sc * (0.5 * (h2 - h0));
+    t[3] = sc * ((h0 - 2.0 * h1) + h2);
   }
 }
 
@@ -110,6 +111,7 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_xi, d_p0, d_E, d_lc;
   DevBuf<double> d_W, d_part, d_G, d_T4;
   DevBuf<int> d_rowmap;
+  DevBuf<double> d_tscale;
   DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
@@ -179,10 +181,11 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
                         : (double)(-(2.0L * m - 1.0L) * fct(m, m) / fct(m - 1, m - 1));
     }
   // m-major slot -> coefficient row (with the EVEN_M quirk of the reference)
-  std::vector<int> rowmap(nrows, 0);
+  std::vector<int> rowmap(t4_rows(L), -1);     // pad row (if any) stays -1 -> zeros
+  std::vector<double> tscale(t4_rows(L), 0.0);
   for (int m = 0; m <= L; m++)
     for (int l = m; l <= L; l++) {
-      const int q = mmajor_row(L, l, m);
+      const int q = t4_row(L, l, m);
       int rc = row_of(l, m, 0);
       if (cfg->EVEN_M && m > 0) rc = l * l + (m - 1);
       // terms the reference skips (src/SphericalBasis.cc:1575-1596) get zero table rows
@@ -193,7 +196,11 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
       if (cfg->EVEN_M && (m & 1)) on = false;
       if (cfg->M0_only && m != 0) on = false;
       rowmap[q] = on ? rc : -1;
-      if (m > 0) rowmap[q + 1] = on ? rc + 1 : -1;
+      tscale[q] = 1.0 / lc_s(l, m);
+      if (m > 0) {
+        rowmap[q + 1] = on ? rc + 1 : -1;
+        tscale[q + 1] = tscale[q];
+      }
     }
 
   hipError_t e = hipSuccess;
@@ -203,10 +210,11 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_E.alloc(E.size()));
   A(f->d_lc.alloc(lcv.size()));
   A(f->d_rowmap.alloc(rowmap.size()));
+  A(f->d_tscale.alloc(tscale.size()));
   A(f->d_W.alloc((size_t)(numr - 1) * nrows * 2));
   A(f->d_part.alloc((size_t)CSEG * ncoef));
   A(f->d_G.alloc((size_t)numr * nrows));
-  A(f->d_T4.alloc((size_t)(numr - 1) * nrows * 4 + 8));   // + spare: 8-double scalar windows
+  A(f->d_T4.alloc((size_t)(numr - 1) * t4_rows(L) * 4));
   if (e == hipSuccess && f->alloc_common(ncoef, cfg->multistep) != EXP_AMD_OK) e = hipErrorOutOfMemory;
   if (e != hipSuccess) {
     exp_amd_force_destroy(f);
@@ -219,12 +227,14 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   HIP_TRY(ctx, hipMemcpy(f->d_lc.p, lcv.data(), lcv.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
                          hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(f->d_tscale.p, tscale.data(), tscale.size() * sizeof(double),
+                         hipMemcpyHostToDevice));
 
   SphDev &S = f->dev;
-  S.lmax = L; S.nmax = nmax; S.numr = numr; S.cmap = cfg->cmap; S.nrows = nrows;
+  S.lmax = L; S.nmax = nmax; S.numr = numr; S.cmap = cfg->cmap; S.nrows = nrows; S.trows = t4_rows(L);
   S.rmap = cfg->rmap; S.scale = cfg->scale; S.rmin = cfg->rmin; S.rmax = cfg->rmax;
   S.xmin = cfg->xmin; S.dxi = cfg->dxi;
-  S.inv_dxi = 1.0 / cfg->dxi; S.inv_scale = 1.0 / cfg->scale;
+  S.inv_dxi = 1.0 / cfg->dxi; S.inv_scale = 1.0 / cfg->scale; S.inv_rmap = 1.0 / cfg->rmap;
   S.cx = S.cy = S.cz = 0.0;
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
@@ -238,6 +248,7 @@ void SphForce::release()
 {
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
   d_rowmap.release();
+  d_tscale.release();
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
 }
@@ -350,7 +361,7 @@ static int sph_project(SphForce *f)
   ProfScope ps(ctx, "k_sph_project");
   k_sph_project<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_coef.p, f->d_G.p);
   k_sph_project4<<<f->cfg.numr - 1, 256, 0, ctx->stream>>>(f->dev, f->d_G.p, f->d_rowmap.p,
-                                                          f->d_T4.p);
+                                                          f->d_tscale.p, f->d_T4.p);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = false;
   return EXP_AMD_OK;

@@ -35,7 +35,9 @@ typedef const __attribute__((address_space(4))) double *cdp;   // constant (scal
 
 struct SphDev {
   int lmax, nmax, numr, cmap, nrows;
+  int trows;             // rows per cell of the projected force table T4 (t4_rows below)
   double rmap, scale, rmin, rmax, xmin, dxi;
+  double inv_rmap;
   double inv_dxi, inv_scale;   // reciprocals for the interpolation WEIGHTS (the cell index keeps the
                                // reference's exact division so that cell assignment is identical)
   double cx, cy, cz;
@@ -68,6 +70,15 @@ __host__ __device__ constexpr int row_of(int l, int m, int cs) { return l * l + 
 __host__ __device__ constexpr int mmajor_row(int L, int l, int m)
 {
   return acc_base(L, 0, m) + (m == 0 ? (l - m) : 2 * (l - m));
+}
+
+// Projected force table T4: the same m-major order, plus one zero pad row after the m = 0 rows when
+// their count (L+1) is odd, so that every (cos, sin) block and the cell stride are 64-byte aligned
+// (a scalar 64-byte load that straddles two cache lines costs two scalar-cache requests).
+__host__ __device__ constexpr int t4_rows(int L) { return (L + 1) * (L + 1) + ((L + 1) & 1); }
+__host__ __device__ constexpr int t4_row(int L, int l, int m)
+{
+  return mmajor_row(L, l, m) + ((m > 0) ? ((L + 1) & 1) : 0);
 }
 
 // Normalised associated Legendre functions Pt(l,m) = factorial(l,m) * P_l^m(x) (the product the
@@ -104,17 +115,30 @@ constexpr double lc_E(int m)
   return m == 0 ? lc_sqrt(1.0 / (4.0 * 3.14159265358979323846))
                 : -lc_sqrt((2.0 * m + 1.0) * (m == 1 ? 2.0 : 1.0) / (2.0 * m));
 }
+// Force evaluation runs the l-recurrence on RESCALED functions Ph(l,m) = s(l,m) Pt(l,m) with
+// s(m,m) = s(m+1,m) = 1, s(l,m) = s(l-2,m) / B(l,m), which turns the three-term recurrence into
+//   Ph(l,m) = a(l,m) * (x Ph(l-1,m)) - Ph(l-2,m),            a = s(l) A(l) / s(l-1)
+//   (x^2-1) dPh(l,m) = l * (x Ph(l,m)) - c(l,m) * Ph(l-1,m),  c = C(l) s(l) / s(l-1)
+// (one multiply fewer per term, and x*Ph(l,m) is shared by both lines); the factor 1/s(l,m) is
+// folded into the rows of the projected force table when it is built (k_sph_project4).
+constexpr double lc_s(int l, int m) { return (l <= m + 1) ? 1.0 : lc_s(l - 2, m) / lc_B(l, m); }
+constexpr double lc_a(int l, int m) { return lc_s(l, m) * lc_A(l, m) / lc_s(l - 1, m); }
+constexpr double lc_c(int l, int m) { return lc_C(l, m) * lc_s(l, m) / lc_s(l - 1, m); }
+#define LC_a(l, m) (lc_const<lc_kind_a, (l), (m)>())
+#define LC_c(l, m) (lc_const<lc_kind_c, (l), (m)>())
 #define LC_A(l, m) (lc_const<lc_kind_A, (l), (m)>())
 #define LC_B(l, m) (lc_const<lc_kind_B, (l), (m)>())
 #define LC_C(l, m) (lc_const<lc_kind_C, (l), (m)>())
 #define LC_E(m)    (lc_const<lc_kind_E, (m), (m)>())
-enum { lc_kind_A, lc_kind_B, lc_kind_C, lc_kind_E };
+enum { lc_kind_A, lc_kind_B, lc_kind_C, lc_kind_E, lc_kind_a, lc_kind_c };
 template <int KIND, int L_, int M_>
 __host__ __device__ constexpr double lc_const()
 {
   constexpr double v = KIND == lc_kind_A ? lc_A(L_, M_)
                      : KIND == lc_kind_B ? lc_B(L_, M_)
                      : KIND == lc_kind_C ? lc_C(L_, M_)
+                     : KIND == lc_kind_a ? lc_a(L_, M_)
+                     : KIND == lc_kind_c ? lc_c(L_, M_)
                                          : lc_E(M_);
   return v;
 }
@@ -133,6 +157,20 @@ __device__ __forceinline__ double sph_r_to_xi(const SphDev &S, double r)
   if (S.cmap == 1) return (r / S.rmap - 1.0) / (r / S.rmap + 1.0);
   if (S.cmap == 2) return log(r);
   return r;
+}
+
+// the same maps with the constant divisions replaced by multiplications (fast force pass)
+__device__ __forceinline__ double sph_r_to_xi_rcp(const SphDev &S, double r)
+{
+  if (S.cmap == 1) { const double u = r * S.inv_rmap; return (u - 1.0) / (u + 1.0); }
+  if (S.cmap == 2) return log(r);
+  return r;
+}
+__device__ __forceinline__ double sph_d_xi_to_r_rcp(const SphDev &S, double xi)
+{
+  if (S.cmap == 1) return 0.5 * (1.0 - xi) * (1.0 - xi) * S.inv_rmap;
+  if (S.cmap == 2) return exp(-xi);
+  return 1.0;
 }
 
 __device__ __forceinline__ double sph_d_xi_to_r(const SphDev &S, double xi)
@@ -593,19 +631,15 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
 
 struct ForceOut { double potl, potr, pott, potp; };
 
-// FAST: wave-uniform cell, no exterior lane, no flag branches (disabled rows are zero in T4):
-// straight-line code whose scalar loads the scheduler can run ahead of the FMAs.
-// !FAST: per-lane table gathers, exterior continuation by per-lane selects, run-time flags.
-template <int LMAX, bool FAST, class PT>
+// General (slow-path) evaluation: per-lane table gathers, exterior continuation by per-lane selects,
+// run-time flags, pole-clamped x in the derivative.  Waves that the fast pass deferred come here.
+template <int LMAX, class PT>
 __device__ __forceinline__ ForceOut
-sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double sphi, PT t4,
+sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT t4,
           double x2, double pf, bool ioff, double rr, double kappa0)
 {
   ForceOut o{0.0, 0.0, 0.0, 0.0};
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
-  double xl[LMAX + 1];                       // l * x (pole-clamped x) of the derivative recurrence
-#pragma unroll
-  for (int l = 0; l <= LMAX; l++) xl[l] = xc * l;
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
   static_for<0, LMAX + 1>([&](auto mc) {
@@ -621,87 +655,53 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
       cm = cn; sm = sn;
     }
     bool m_on = true;
-    if constexpr (!FAST) {
-      if (S.EVEN_M && (m & 1)) m_on = false;
-      if (S.M0_only && m != 0) m_on = false;
-    }
+    if (S.EVEN_M && (m & 1)) m_on = false;
+    if (S.M0_only && m != 0) m_on = false;
     // exterior continuation (src/SphericalBasis.cc:1605-1628): (rmax/r0)^(l+1), starts at l = m
-    double rl = 1.0;
-    if constexpr (!FAST) {
+    double rl;
+    {
       double t = rr;
       static_for<0, m>([&](auto) { t *= rr; });
       rl = ioff ? t : 1.0;
     }
-    // Per-m partial sums over l.  FAST: the per-particle interpolation weights are factored out of
-    // the l-sum -- with p_row = G0 + x2 D and dp_row = Bq + pf Aq,
-    //     sum_l Pt p_row = (sum_l Pt G0) + x2 (sum_l Pt D)        etc.
-    // so every FMA has exactly one scalar (table) operand and one vector operand: no SGPR->VGPR
-    // copies (a VOP3 may read one SGPR pair only) and the weights are applied once per m.
-    double Al = 0.0, Bl = 0.0, Ar = 0.0, Br = 0.0, At = 0.0, Bt = 0.0;       // !FAST accumulators
-    double Ag = 0.0, Ad = 0.0, Tg = 0.0, Td = 0.0, Rb = 0.0, Ra = 0.0;       // FAST: cos rows
-    double Bg = 0.0, Bd = 0.0, Ug = 0.0, Ud = 0.0, Sb = 0.0, Sa = 0.0;       // FAST: sin rows
-    double pl2 = 0.0, pl1 = 0.0;
+    double Al = 0.0, Bl = 0.0, Ar = 0.0, Br = 0.0, At = 0.0, Bt = 0.0;
+    double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
     static_for<m, LMAX + 1>([&](auto lc_) {
       constexpr int l = decltype(lc_)::value;
-      double plm, qlm;            // Pt(l,m) and (x^2-1) dPt(l,m)
-      if constexpr (l == m) {
-        plm = pmm;
-        qlm = xl[l] * plm;
-      } else if constexpr (l == m + 1) {
-        plm = LC_A(l, m) * (costh * pl1);
-        qlm = xl[l] * plm - LC_C(l, m) * pl1;
-      } else {
-        plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
-        qlm = xl[l] * plm - LC_C(l, m) * pl1;
-      }
+      double plm, qlm;            // Ph(l,m) and (x^2-1) dPh(l,m)
+      if constexpr (l == m) plm = pmm;
+      else if constexpr (l == m + 1) plm = LC_a(l, m) * tprev;
+      else plm = fma(LC_a(l, m), tprev, -pl2);
+      tprev = costh * plm;
+      if constexpr (l == m) qlm = (xc * plm) * l;
+      else qlm = fma((double)l, xc * plm, -(LC_c(l, m) * pl1));
       pl2 = pl1;
       pl1 = plm;
-      constexpr int q = 4 * mmajor_row(LMAX, l, m);
-      if constexpr (FAST) {
-        Ag = fma(plm, t4[q + 0], Ag);
-        Ad = fma(plm, t4[q + 1], Ad);
-        Rb = fma(plm, t4[q + 2], Rb);
-        Ra = fma(plm, t4[q + 3], Ra);
-        Tg = fma(qlm, t4[q + 0], Tg);
-        Td = fma(qlm, t4[q + 1], Td);
+      constexpr int q = 4 * t4_row(LMAX, l, m);
+      bool on = m_on;
+      if (l == 0 && S.NO_L0) on = false;
+      if (l == 1 && S.NO_L1) on = false;
+      if (l > 0 && S.EVEN_L && (l & 1)) on = false;
+      if (on) {
+        double pc = fma(x2, t4[q + 1], t4[q + 0]);
+        double dpc = fma(pf, t4[q + 3], t4[q + 2]);
+        pc *= rl;
+        dpc = ioff ? (kappa0 * (l + 1)) * pc : dpc;
+        Al = fma(plm, pc, Al);
+        Ar = fma(plm, dpc, Ar);
+        At = fma(qlm, pc, At);
         if constexpr (m > 0) {
-          Bg = fma(plm, t4[q + 4], Bg);
-          Bd = fma(plm, t4[q + 5], Bd);
-          Sb = fma(plm, t4[q + 6], Sb);
-          Sa = fma(plm, t4[q + 7], Sa);
-          Ug = fma(qlm, t4[q + 4], Ug);
-          Ud = fma(qlm, t4[q + 5], Ud);
+          double ps = fma(x2, t4[q + 5], t4[q + 4]);
+          double dps = fma(pf, t4[q + 7], t4[q + 6]);
+          ps *= rl;
+          dps = ioff ? (kappa0 * (l + 1)) * ps : dps;
+          Bl = fma(plm, ps, Bl);
+          Br = fma(plm, dps, Br);
+          Bt = fma(qlm, ps, Bt);
         }
-      } else {
-        bool on = m_on;
-        if (l == 0 && S.NO_L0) on = false;
-        if (l == 1 && S.NO_L1) on = false;
-        if (l > 0 && S.EVEN_L && (l & 1)) on = false;
-        if (on) {
-          double pc = fma(x2, t4[q + 1], t4[q + 0]);
-          double dpc = fma(pf, t4[q + 3], t4[q + 2]);
-          pc *= rl;
-          dpc = ioff ? (kappa0 * (l + 1)) * pc : dpc;
-          Al = fma(plm, pc, Al);
-          Ar = fma(plm, dpc, Ar);
-          At = fma(qlm, pc, At);
-          if constexpr (m > 0) {
-            double ps = fma(x2, t4[q + 5], t4[q + 4]);
-            double dps = fma(pf, t4[q + 7], t4[q + 6]);
-            ps *= rl;
-            dps = ioff ? (kappa0 * (l + 1)) * ps : dps;
-            Bl = fma(plm, ps, Bl);
-            Br = fma(plm, dps, Br);
-            Bt = fma(qlm, ps, Bt);
-          }
-        }
-        rl *= ioff ? rr : 1.0;
       }
+      rl *= ioff ? rr : 1.0;
     });
-    if constexpr (FAST) {
-      Al = fma(x2, Ad, Ag); At = fma(x2, Td, Tg); Ar = fma(pf, Ra, Rb);
-      Bl = fma(x2, Bd, Bg); Bt = fma(x2, Ud, Ug); Br = fma(pf, Sa, Sb);
-    }
     if constexpr (m == 0) {
       o.potl += Al;
       o.potr += Ar;
@@ -726,14 +726,10 @@ sph_field(const SphDev &S, cdp lc, double costh, double xc, double cphi, double 
 // waits (lgkmcnt(0), SMEM may return out of order) and every consumer is data-dependent on the
 // wait statement ("+s"), so nothing can be scheduled between a load and its wait that reads it.
 typedef double sd8 __attribute__((ext_vector_type(8)));
-typedef double sd4 __attribute__((ext_vector_type(4)));
 
 #define SLOAD8(dst, base, off_doubles) \
   asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(base), "n"((off_doubles) * 8))
-#define SLOAD4(dst, base, off_doubles) \
-  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(dst) : "s"(base), "n"((off_doubles) * 8))
 #define SWAIT8(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v))
-#define SWAIT4(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v))
 
 // m-major traversal: k-th (l,m) block, its table offset (doubles) -- all constexpr
 template <int LMAX> __host__ __device__ constexpr int blk_m(int k)
@@ -751,34 +747,31 @@ template <int LMAX> __host__ __device__ constexpr int blk_l(int k)
 
 template <int LMAX>
 __device__ __forceinline__ ForceOut
-sph_field_fast(cdp t4, double costh, double xc, double cphi, double sphi, double x2, double pf)
+sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, double x2, double pf)
 {
   constexpr int NBLK = (LMAX + 1) * (LMAX + 2) / 2;
   ForceOut o{0.0, 0.0, 0.0, 0.0};
-  const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
   const unsigned long long tb = (unsigned long long)t4;
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
   double Ag = 0.0, Ad = 0.0, Tg = 0.0, Td = 0.0, Rb = 0.0, Ra = 0.0;       // cos rows
   double Bg = 0.0, Bd = 0.0, Ug = 0.0, Ud = 0.0, Sb = 0.0, Sa = 0.0;       // sin rows
-  double pl2 = 0.0, pl1 = 0.0;
+  double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
   // m = 0 rows are 4 doubles each: fetch them two rows at a time as 8-double blocks where possible
   sd8 cur, nxt;
-  SLOAD8(cur, tb, 0);
+  asm volatile("s_load_dwordx16 %0, %1, 0" : "=s"(cur) : "s"(tb));
   SWAIT8(cur);
   static_for<0, NBLK>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int l = blk_l<LMAX>(k), m = blk_m<LMAX>(k);
-    constexpr int q = 4 * mmajor_row(LMAX, l, m);
+    constexpr int q = 4 * t4_row(LMAX, l, m);
     // which 8-double window holds this block, and the next one to request
     constexpr int win = (m == 0) ? (q / 8) * 8 : q;          // m = 0: rows pair up in one window
     constexpr bool last = (k + 1 == NBLK);
     constexpr int l1 = last ? l : blk_l<LMAX>(k + 1), m1 = last ? m : blk_m<LMAX>(k + 1);
-    constexpr int q1 = 4 * mmajor_row(LMAX, l1, m1);
+    constexpr int q1 = 4 * t4_row(LMAX, l1, m1);
     constexpr int win1 = (m1 == 0) ? (q1 / 8) * 8 : q1;
     constexpr bool need = !last && win1 != win;
-    // 8-double windows may run 4 doubles past the end of the cell's rows for even row counts;
-    // T4 is allocated with one spare row per table, so the read is in bounds and unused
     if constexpr (need) { SLOAD8(nxt, tb, win1); __builtin_amdgcn_sched_barrier(0); }
 
     if constexpr (l == m) {            // start of an m-block
@@ -790,12 +783,15 @@ sph_field_fast(cdp t4, double costh, double xc, double cphi, double sphi, double
       }
       Ag = Ad = Tg = Td = Rb = Ra = 0.0;
       Bg = Bd = Ug = Ud = Sb = Sa = 0.0;
-      pl2 = pl1 = 0.0;
+      pl2 = pl1 = tprev = 0.0;
     }
-    double plm, qlm;
-    if constexpr (l == m) { plm = pmm; qlm = (xc * l) * plm; }
-    else if constexpr (l == m + 1) { plm = LC_A(l, m) * (costh * pl1); qlm = (xc * l) * plm - LC_C(l, m) * pl1; }
-    else { plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2; qlm = (xc * l) * plm - LC_C(l, m) * pl1; }
+    double plm, qlm;        // Ph(l,m), (x^2-1) dPh(l,m); no pole lanes here, so x == clamped x
+    if constexpr (l == m) plm = pmm;
+    else if constexpr (l == m + 1) plm = LC_a(l, m) * tprev;
+    else plm = fma(LC_a(l, m), tprev, -pl2);
+    tprev = costh * plm;
+    if constexpr (l == m) qlm = tprev * l;
+    else qlm = fma((double)l, tprev, -(LC_c(l, m) * pl1));
     pl2 = pl1;
     pl1 = plm;
     constexpr int o0 = q - win;        // 0 or 4 inside the window
@@ -803,8 +799,10 @@ sph_field_fast(cdp t4, double costh, double xc, double cphi, double sphi, double
     Ad = fma(plm, cur[o0 + 1], Ad);
     Rb = fma(plm, cur[o0 + 2], Rb);
     Ra = fma(plm, cur[o0 + 3], Ra);
-    Tg = fma(qlm, cur[o0 + 0], Tg);
-    Td = fma(qlm, cur[o0 + 1], Td);
+    if constexpr (l > 0) {       // (x^2-1) dPh(0,0) = 0
+      Tg = fma(qlm, cur[o0 + 0], Tg);
+      Td = fma(qlm, cur[o0 + 1], Td);
+    }
     if constexpr (m > 0) {
       Bg = fma(plm, cur[4], Bg);
       Bd = fma(plm, cur[5], Bd);
@@ -846,12 +844,12 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  cdp lc = (cdp)S.lc;
   const int lane = threadIdx.x & 63;
   // One 64-particle chunk per wave and NO particle loop: with a loop, LICM hoists the
   // constants of the unrolled (l,m) nest out of it and spills them.
   size_t base;
   if (FAST || work == nullptr) {
+    // (An XCD-contiguous chunk order was tried: 15% slower than the plain round-robin order.)
     base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
     if (base >= end) return;
   } else {
@@ -861,71 +859,97 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
   }
   const size_t i = base + lane;
   const bool valid = i < end;
-  double xx = 0, yy = 0, zz = 1;
+  double xx = 1, yy = 0, zz = 0;          // idle lanes: a harmless off-axis point
   if (valid) {
     xx = X[i] - S.cx;
     yy = Y[i] - S.cy;
     zz = Z[i] - S.cz;
   }
-  // src/SphericalBasis.cc:1545-1560
-  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-  const double costh = zz / r;
-  double cphi, sphi;
-  phi_trig(xx, yy, cphi, sphi);
-  bool ioff = false;
-  const double r0 = r;
-  if (r > S.rmax && !S.no_exterior) {
-    ioff = true;
-    r = S.rmax;
-  }
-  const double rs = r / S.scale;
-  const double xi = sph_r_to_xi(S, rs);
-  int idx = sph_cell(S, xi);
-  // get_pot weights (exputil/SLGridMP2.cc:894-902)
-  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
-  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
-  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
-  // get_force weights (exputil/SLGridMP2.cc:971-985)
-  const int jdx = idx < 1 ? 1 : idx;
-  const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
-  const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
-  // Legendre derivative pole clamp (src/Basis.cc:81-84)
-  double xc = costh;
-  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-  const double dfac = 1.0 / (xc * xc - 1.0);
-  const size_t tq = (size_t)4 * S.nrows;
+  const double fac = xx * xx + yy * yy;
+  const size_t tq = (size_t)4 * S.trows;
+  double r, ir, iR2, P0, ffac, dfac;
   ForceOut o;
   if constexpr (FAST) {
+    // Same quantities as the general path below with the divisions shared: one reciprocal each of
+    // r and R = sqrt(x^2+y^2) gives cos(theta), sin(theta) = R/r, cos/sin(phi), 1/(x^2-1) =
+    // -(r/R)^2 and the 1/r, 1/R^2 of the Cartesian projection (10 fp64 divisions -> 4; results
+    // agree with the reference's formulas to a few ulp).  Lanes on the polar axis, where the
+    // reference clamps x (src/Basis.cc:81-84), outside rmax, or waves spanning several radial
+    // cells are left to the general pass.
+    r = sqrt(fac + zz * zz) + DSMALL;                        // src/SphericalBasis.cc:1545-1560
+    ir = 1.0 / r;
+    const double costh = zz * ir;
+    const double R = sqrt(fac), iR = 1.0 / R;
+    iR2 = iR * iR;
+    const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
+    const bool special = (r > S.rmax && !S.no_exterior) || (1.0 - fabs(costh) < MINEPS) || !(fac > DSMALL);
+    const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
+    int idx = sph_cell(S, xi);
     const int idx_u = __builtin_amdgcn_readfirstlane(idx);
     if (!valid) idx = idx_u;
-    const bool fast = __all(idx == idx_u) && !__any(ioff && valid);
+    const bool fast = __all(idx == idx_u) && !__any(special && valid);
     if (!fast) {
       if (lane == 0) work[atomicAdd(nwork, 1u)] = (uint32_t)base;
       return;
     }
+    // get_pot / get_force weights (exputil/SLGridMP2.cc:894-902, :971-985)
+    const double x1 = (S.xi[idx_u + 1] - xi) * S.inv_dxi;
+    const double x2 = (xi - S.xi[idx_u]) * S.inv_dxi;
+    P0 = x1 * S.p0[idx_u] + x2 * S.p0[idx_u + 1];
+    const int jdx = idx_u < 1 ? 1 : idx_u;
+    const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+    ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
+    dfac = -(r * r) * iR2;
     cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
-    o = sph_field_fast<LMAX>(t4, costh, xc, cphi, sphi, x2, pf);
+    o = sph_field_fast<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
   } else {
+    // src/SphericalBasis.cc:1545-1560
+    r = sqrt(fac + zz * zz) + DSMALL;
+    const double costh = zz / r;
+    double cphi, sphi;
+    phi_trig(xx, yy, cphi, sphi);
+    bool ioff = false;
+    const double r0 = r;
+    if (r > S.rmax && !S.no_exterior) {
+      ioff = true;
+      r = S.rmax;
+    }
+    const double rs = r / S.scale;
+    const double xi = sph_r_to_xi(S, rs);
+    const int idx = sph_cell(S, xi);
+    // get_pot weights (exputil/SLGridMP2.cc:894-902)
+    const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+    const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+    P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+    // get_force weights (exputil/SLGridMP2.cc:971-985)
+    const int jdx = idx < 1 ? 1 : idx;
+    const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+    ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
+    // Legendre derivative pole clamp (src/Basis.cc:81-84)
+    double xc = costh;
+    if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+    dfac = 1.0 / (xc * xc - 1.0);
     const double rr = S.rmax / r0;
     const double kappa0 = -P0 / (r0 * ffac);     // dp = -(l+1)/r0 * p, in units of ffac
     const double *t4 = T4 + (size_t)idx * tq;
-    o = sph_field<LMAX, false>(S, lc, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+    ir = 1.0 / r;
+    iR2 = 1.0 / fac;
   }
   if (!valid) return;
 
   // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
-  const double fac = xx * xx + yy * yy;
   const double potr = o.potr * ffac * (S.inv_scale * S.inv_scale);
   const double potl = o.potl * P0 * S.inv_scale;
   const double pott = o.pott * (P0 * dfac) * S.inv_scale;
   const double potp = o.potp * P0 * S.inv_scale;
-  const double ir = 1.0 / r, ir3 = ir * ir * ir;
+  const double ir3 = ir * ir * ir;
   const double pr = potr * ir, pt3 = pott * ir3;
   double ax = -(pr * xx - pt3 * xx * zz);
   double ay = -(pr * yy - pt3 * yy * zz);
   double az = -(pr * zz + pt3 * fac);
   if (fac > DSMALL) {
-    const double pf2 = potp / fac;
+    const double pf2 = FAST ? potp * iR2 : potp / fac;
     ax += pf2 * yy;
     ay += -pf2 * xx;
   }

@@ -31,7 +31,7 @@ from numpy.polynomial import legendre as npleg
 from scipy.special import lpmv
 
 from .models import NumericModel
-from .slgrid import SLGridSph, build_slgrid, threadpool_limits
+from .slgrid import SLGridSph, build_slgrid, blas_limit
 
 KIND = {"potC": 0, "rforceC": 1, "zforceC": 2, "potS": 3, "rforceS": 4, "zforceS": 5}
 
@@ -242,7 +242,7 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
     cg = Zg / rrg
 
     tab = np.zeros((6, mmax + 1, norder, numx + 1, numy + 1))
-    _limit = threadpool_limits(limits=8)
+    _limit = blas_limit()
     _limit.__enter__()
     for m in range(mmax + 1):
         nl = lmaxfid - m + 1

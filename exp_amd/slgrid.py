@@ -40,6 +40,24 @@ except Exception:                      # pragma: no cover
     def threadpool_limits(limits=None):
         return contextlib.nullcontext()
 
+
+
+def blas_limit(cap: int = 2):
+    """Context manager capping the BLAS/LAPACK pools for the (small) table-build eigenproblems.
+    Only ever LOWERS the thread count: raising an OpenBLAS pool above the size it was initialised
+    with can crash, and hosts that expose hundreds of cores under a small CPU quota make
+    unbounded pools spin against each other."""
+    try:
+        import threadpoolctl
+        cur = [int(i.get("num_threads", 1)) for i in threadpoolctl.threadpool_info()]
+        if cur and max(cur) > cap:
+            return threadpool_limits(limits=cap)
+    except Exception:   # pragma: no cover
+        pass
+    import contextlib
+    return contextlib.nullcontext()
+
+
 NEVSIGN = 4  # exputil/libvars.cc:38
 
 
@@ -256,7 +274,7 @@ def build_slgrid(model: SphericalModel, lmax: int, nmax: int, numr: int = 2000,
 
     ev = np.zeros((lmax + 1, nmax))
     ef = np.zeros((lmax + 1, nmax, numr))
-    _limit = threadpool_limits(limits=8)
+    _limit = blas_limit()
     _limit.__enter__()
     for l in range(lmax + 1):
         # exputil/SLGridMP2.cc:1119-1135: narrowed radial domain for large l

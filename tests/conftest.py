@@ -4,7 +4,7 @@ import sys
 # some GPU boxes expose hundreds of cores under a small CPU quota: unbounded BLAS/OpenMP pools then
 # spin against each other and the (numpy-side) table builds run 20x slower
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, "8")
+    os.environ.setdefault(_v, "4")
 
 import numpy as np
 import pytest
