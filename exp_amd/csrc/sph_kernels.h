@@ -882,7 +882,9 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
     const double R = sqrt(fac), iR = 1.0 / R;
     iR2 = iR * iR;
     const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
-    const bool special = (r > S.rmax && !S.no_exterior) || (1.0 - fabs(costh) < MINEPS) || !(fac > DSMALL);
+    // theta < 1e-6: sin(theta) = R/r and the reference's sqrt((1-x)(1+x)) differ by more than the
+    // parity tolerance there (cancellation in 1-x), so those lanes take the reference's formula too
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
     int idx = sph_cell(S, xi);
     const int idx_u = __builtin_amdgcn_readfirstlane(idx);

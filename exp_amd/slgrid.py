@@ -250,12 +250,22 @@ def solve_sl_order(model: SphericalModel, l: int, nmax: int, ra: float, rb: floa
 
     Kf = K[np.ix_(free, free)]
     Mf = M[np.ix_(free, free)]
-    # Jacobi scaling tames the dynamic range of w over several decades in r
-    d = 1.0 / np.sqrt(np.diag(Mf))
+    # Solve the INVERSE pencil  M u = mu K u  (mu = 1/lambda, wanted: the nmax largest).  The weight
+    # w = -rho r^2 Phi0 spans 14+ decades for a truncated halo, so the pencil's spectrum runs from
+    # O(1) to O(1e20): reducing K u = lambda M u through a Cholesky factor of M leaves absolute
+    # errors ~ eps * 1e20 on the O(1) eigenvalues we want (observed: the l = 0 ground state, exactly
+    # 1 in theory, came out anywhere in 0.92..1.40 depending on LAPACK driver / BLAS threads).
+    # With K (SPD: p, q > 0) on the right the spectrum lies in (0, 1] and the wanted end is the
+    # accurately computed one.  Jacobi scaling by diag(K) tames the dynamic range of the shape
+    # functions over the decades in r.
+    d = 1.0 / np.sqrt(np.diag(Kf))
     Ks = Kf * d[:, None] * d[None, :]
     Ms = Mf * d[:, None] * d[None, :]
-    ev, vec = sla.eigh(Ks, Ms, subset_by_index=[0, nmax - 1])
-    vec = vec * d[:, None]
+    n = Ks.shape[0]
+    mu, vec = sla.eigh(Ms, Ks, subset_by_index=[n - nmax, n - 1])
+    mu, vec = mu[::-1], vec[:, ::-1]
+    ev = 1.0 / mu
+    vec = vec * d[:, None] / np.sqrt(mu)[None, :]        # v^T K v = 1  ->  int w u^2 dr = 1
     coef = np.zeros((mesh.ndof, nmax))
     coef[free, :] = vec
     return ev, mesh, coef

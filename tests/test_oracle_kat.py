@@ -71,6 +71,32 @@ def test_orthocheck_reference_model_file(oracle):
     assert worst < 1e-2
 
 
+@pytest.mark.parametrize("kind", ["plummer", "nfw"])
+def test_sl_ground_state_and_solver_stability(kind):
+    """The basis is built on (rho0, Phi0), so u = const solves the l = 0 problem with lambda = 1
+    exactly (exputil/SLGridMP2.cc:3647-3654 with u'' terms vanishing).  A truncated NFW weight spans
+    14 decades in r; the solver must return 1 (to discretisation error) there too, and the same
+    tables whatever the BLAS thread count (the forward pencil K u = lambda M u did neither)."""
+    import threadpoolctl
+    from exp_amd import slgrid
+    grids = []
+    for lim in (1, 4):
+        with threadpoolctl.threadpool_limits(limits=lim):
+            if kind == "nfw":
+                from exp_amd.models import NFWModel
+                model = NFWModel(1.0, 20.0, 6.0, 1e-3, 50.0)
+            else:
+                from exp_amd.models import PlummerModel
+                model = PlummerModel(1.0, 1.0, 1e-3, 50.0)
+            grids.append(slgrid.build_slgrid(model, 2, 8, numr=400, rmin=1e-3, rmax=49.5, cmap=1,
+                                             rmap=1.0, nel=32, P=8))
+    g = grids[0]
+    assert g.ev[0, 0] == pytest.approx(1.0, abs=2e-5)
+    assert np.all(np.diff(g.ev, axis=1) > 0)
+    assert np.abs(grids[0].ev - grids[1].ev).max() <= 1e-9 * np.abs(g.ev).max()
+    assert np.abs(grids[0].ef - grids[1].ef).max() <= 1e-8 * np.abs(g.ef).max()
+
+
 def test_plummer_eigenvalues_clutton_brock(plummer_s6):
     """For a Plummer background the SL problem is the Clutton-Brock basis:
     lambda_{nl} = (4 n (n + 2l + 2) + (2l+1)(2l+3)) / 3 on [0, inf)."""

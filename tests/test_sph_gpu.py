@@ -220,6 +220,45 @@ def test_kdk_steps_match_oracle(ctx, oracle, plummer_s6, fused):
     assert np.array_equal(out["mass"], m)
 
 
+@pytest.mark.parametrize("kind,lmax,nmax,numr,n", [("nfw", 6, 18, 2000, 1_500_000),
+                                                   ("nfw", 10, 24, 2000, 1_500_000),
+                                                   ("plummer", 4, 8, 400, 400_000)])
+def test_fast_pass_matches_general_pass_and_oracle(ctx, oracle, kind, lmax, nmax, numr, n):
+    """At these sizes nearly every wave is cell-uniform and takes the fast force pass (scalar table
+    loads, shared reciprocals).  The same particles evaluated as an EXTERNAL target (not in this
+    force's cell order -> general per-lane pass) and a subset on the CPU oracle must agree; so
+    must the coefficients (register accumulation over many groups per flush)."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = make_grid(kind, lmax, nmax, numr)
+    m, pos, _ = _particles(model, n, seed=21)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)                      # sorts c into f's (level, cell) order
+    coef = f.get_coefs()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)              # fast pass + deferred waves
+    out = c.download(("acc", "pot", "pos"))          # original particle order
+    tgt = Component.from_arrays(ctx, m, pos)         # never sorted by f: general pass only
+    tgt.zero_acceleration(0)
+    f.get_acceleration_and_potential(tgt, external=True)
+    gen = tgt.download(("acc", "pot"))
+    assert acc_err(out["acc"], gen["acc"]) <= ACC_TOL
+    assert np.abs(out["pot"] - gen["pot"]).max() <= 1e-10 * np.abs(gen["pot"]).max()
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    sub = np.random.default_rng(3).choice(n, 3000, replace=False)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos[sub], coef)
+    assert acc_err(out["acc"][sub], a_ref) <= ACC_TOL
+    assert np.abs(out["pot"][sub] - p_ref).max() <= 1e-10 * np.abs(p_ref).max()
+    c_ref, used = oracle.sph_accumulate(g, prm, pos[:200_000], m[:200_000])
+    c2 = Component.from_arrays(ctx, m[:200_000], pos[:200_000])
+    f.determine_coefficients(c2)
+    assert f.Used() == used
+    assert coef_err(f.get_coefs(), c_ref) <= COEF_TOL
+    for x in (c, tgt, c2):
+        x.close()
+    f.close()
+
+
 def test_full_size_properties(ctx):
     """BASELINE config 2 size (1e7, S6): linearity of the accumulation in the particle set and
     invariance to particle order -- size-independent properties, no oracle needed."""
@@ -266,7 +305,14 @@ def test_full_size_properties(ctx):
     c.upload_device(mass, x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous())
     f.determine_coefficients(c)
     assert coef_err(f.get_coefs(), c_all) <= COEF_TOL
-    # the monopole force of a (nearly) spherical set obeys Newton: |a| r^2 / M(<r) ~ 1
+    c.close()
+    # Newton: the self-consistent field of a SPHERICAL sample of the basis' own model is the
+    # model's force, |a_r| r^2 / M(<r) = 1 (sampling noise at 1e7: ~1e-4).  This is an analytic
+    # known answer for the whole chain basis -> coefficients -> force, independent of the oracle.
+    zs = (r * ct).contiguous()
+    c = Component(ctx, n)
+    c.upload_device(mass, x, y, zs)
+    f.determine_coefficients(c)
     c.zero_acceleration()
     f.get_acceleration_and_potential(c)
     out = c.download(("acc", "pos"))
@@ -274,6 +320,6 @@ def test_full_size_properties(ctx):
     sel = (rr > 0.5) & (rr < 5.0)
     arad = -(out["acc"][sel] * out["pos"][sel]).sum(1) / rr[sel]
     ratio = arad * rr[sel] ** 2 / model.mass(rr[sel])
-    assert abs(np.median(ratio) - 1.0) < 0.05
+    assert abs(np.median(ratio) - 1.0) < 2e-3
     c.close()
     f.close()
