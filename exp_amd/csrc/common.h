@@ -95,4 +95,16 @@ __device__ __forceinline__ double mul_then_add(double x, double a, double b)
 }
 #endif
 
+#if defined(__HIPCC__)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its fence
+// covers global memory), which kills any global prefetch issued before it; the accumulation
+// kernels keep next-tile loads in flight across their per-tile barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

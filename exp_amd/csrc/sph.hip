@@ -24,7 +24,8 @@ struct SphKeyFn {
 // part[seg][row][n] = sum_{i in seg} E[i][l][n] W[i][row][0] + E[i+1][l][n] W[i][row][1]
 #define CSEG 32
 __global__ void __launch_bounds__(64)
-k_sph_contract(SphDev S, const double *__restrict__ W, double *__restrict__ part)
+k_sph_contract(SphDev S, const double *__restrict__ W, const double *__restrict__ wscale,
+               double *__restrict__ part)
 {
   const int row = blockIdx.x, seg = blockIdx.y;
   int l = 0;
@@ -41,7 +42,7 @@ k_sph_contract(SphDev S, const double *__restrict__ W, double *__restrict__ part
       s = fma(S.E[(size_t)i * stride + l * S.nmax + n], w1, s);
       s = fma(S.E[(size_t)(i + 1) * stride + l * S.nmax + n], w2, s);
     }
-    part[((size_t)seg * S.nrows + row) * S.nmax + n] = s;
+    part[((size_t)seg * S.nrows + row) * S.nmax + n] = s * wscale[row];   // 1/s(l,m), see lc_s
   }
 }
 
@@ -111,7 +112,7 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_xi, d_p0, d_E, d_lc;
   DevBuf<double> d_W, d_part, d_G, d_T4;
   DevBuf<int> d_rowmap;
-  DevBuf<double> d_tscale;
+  DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
   DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
@@ -182,7 +183,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
     }
   // m-major slot -> coefficient row (with the EVEN_M quirk of the reference)
   std::vector<int> rowmap(t4_rows(L), -1);     // pad row (if any) stays -1 -> zeros
-  std::vector<double> tscale(t4_rows(L), 0.0);
+  std::vector<double> tscale(t4_rows(L), 0.0), wscale(nrows, 1.0);
   for (int m = 0; m <= L; m++)
     for (int l = m; l <= L; l++) {
       const int q = t4_row(L, l, m);
@@ -197,6 +198,8 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
       if (cfg->M0_only && m != 0) on = false;
       rowmap[q] = on ? rc : -1;
       tscale[q] = 1.0 / lc_s(l, m);
+      wscale[row_of(l, m, 0)] = tscale[q];
+      if (m > 0) wscale[row_of(l, m, 1)] = tscale[q];
       if (m > 0) {
         rowmap[q + 1] = on ? rc + 1 : -1;
         tscale[q + 1] = tscale[q];
@@ -211,6 +214,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_lc.alloc(lcv.size()));
   A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_tscale.alloc(tscale.size()));
+  A(f->d_wscale.alloc(wscale.size()));
   A(f->d_W.alloc((size_t)(numr - 1) * nrows * 2));
   A(f->d_part.alloc((size_t)CSEG * ncoef));
   A(f->d_G.alloc((size_t)numr * nrows));
@@ -229,6 +233,8 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
                          hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_tscale.p, tscale.data(), tscale.size() * sizeof(double),
                          hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(f->d_wscale.p, wscale.data(), wscale.size() * sizeof(double),
+                         hipMemcpyHostToDevice));
 
   SphDev &S = f->dev;
   S.lmax = L; S.nmax = nmax; S.numr = numr; S.cmap = cfg->cmap; S.nrows = nrows; S.trows = t4_rows(L);
@@ -239,6 +245,11 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
   S.no_exterior = 0;
+  S.xi_uniform = 1;                            // same two roundings as the device's mul_then_add
+  for (int i = 0; i < numr && S.xi_uniform; i++) {
+    volatile double t = cfg->dxi * (double)i;
+    if (xi[i] != cfg->xmin + t) S.xi_uniform = 0;
+  }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
   *out = f;
   return EXP_AMD_OK;
@@ -249,6 +260,7 @@ void SphForce::release()
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
   d_rowmap.release();
   d_tscale.release();
+  d_wscale.release();
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
 }
@@ -322,7 +334,8 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_W.p, f->d_part.p);
+    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
+                                                                f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(f->d_part.p, (int)f->ncoef,
                                                                   d_out);
   }
@@ -431,7 +444,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // moments -> coefficient differences for the levels that _finish touches (M >= mfirst[mdrft])
   for (int M = mfirst_mdrft; M <= ms; M++) {
     k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)M * wl,
-                                                                f->d_part.p);
+                                                                f->d_wscale.p, f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
         f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)M * f->ncoef);
   }

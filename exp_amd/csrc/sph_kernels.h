@@ -42,6 +42,7 @@ struct SphDev {
                                // reference's exact division so that cell assignment is identical)
   double cx, cy, cz;
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
+  int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
   const double *xi;      // [numr]
   const double *p0;      // [numr]
@@ -261,31 +262,62 @@ __device__ __forceinline__ int acc_to_wrow(int j)
 }
 
 #define ACC_WAVES 4
-#define ACC_CHUNK 1024        // particles per wave (contiguous, so one or two cells per wave)
+// Particles per block/wave chunk (contiguous, so one or two cells per wave).  Every chunk ends with
+// a flush (LDS transposes + ~60 fp64 atomics per wave) and every block pays its launch: at 1024
+// those fixed costs were 30% of the kernel, so the launcher picks up to ACC_CHUNK_MAX when the
+// component is large enough to still fill the GPU several times over.
+#define ACC_CHUNK_MIN 1024
+#define ACC_CHUNK_MAX 4096
+#define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
 
 // Per-particle inputs of the moment accumulation: everything that does not depend on (l, m).
 struct AccIn {
-  double costh, cphi, sphi, a1, a2;   // a1 = -4pi m P0 x1, a2 = -4pi m P0 x2 (0 outside the window)
-  int idx;                            // radial cell, -1 when the particle does not contribute
+  double costh, sinth, cphi, sphi, a1, a2;   // a1 = -4pi m P0 x1, a2 = -4pi m P0 x2 (0 outside the window)
+  int idx;                                   // radial cell, -1 when the particle does not contribute
 };
 
-__device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, double px, double py, double pz,
-                                               double mass, bool valid)
+// One reciprocal each of r and R = sqrt(x^2+y^2) gives cos(theta) = z/r, sin(theta) = R/r and
+// cos/sin(phi); the constant divisors (scale, rmap) are multiplied by their reciprocals.  Within
+// 1e-6 rad of the polar axis sin(theta) falls back to the reference's sqrt((1-x)(1+x)), whose
+// cancellation error exceeds the parity tolerance there.
+// p0l: the block's LDS copy of the background-potential table, or null (then S.p0 is gathered
+// from global memory).  The pointer keeps its address space so that the reads are ds_read.
+typedef const __attribute__((address_space(3))) double *ldp;
+__device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double px,
+                                               double py, double pz, double mass, bool valid)
 {
   AccIn in;
-  double xx = 0, yy = 0, zz = 1;
+  double xx = 1, yy = 0, zz = 0;
   if (valid) { xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz; }
   // src/SphericalBasis.cc:486-494
-  const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  const double R2 = xx * xx + yy * yy;
+  const double r = sqrt(R2 + zz * zz) + DSMALL;
   const bool inwin = valid && r >= S.rmin && r <= S.rmax;
-  in.costh = zz / r;
-  phi_trig(xx, yy, in.cphi, in.sphi);
-  const double xi = sph_r_to_xi(S, r / S.scale);
+  const double ir = 1.0 / r;
+  in.costh = zz * ir;
+  if (R2 > 1e-12 * (r * r)) {
+    const double R = sqrt(R2), iR = 1.0 / R;
+    in.cphi = xx * iR;
+    in.sphi = yy * iR;
+    in.sinth = R * ir;
+  } else {
+    in.costh = zz / r;
+    phi_trig(xx, yy, in.cphi, in.sphi);
+    in.sinth = sqrt((1.0 - in.costh) * (1.0 + in.costh));
+  }
+  const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
   const int idx = sph_cell(S, xi);
   // exputil/SLGridMP2.cc:894-895, :901-902
-  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
-  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
-  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  // the xi grid is uniform by construction (exputil/SLGridMP2.cc:1355-1382): recompute its nodes
+  // rather than gather them (a dependent global load in the middle of this latency-bound chain)
+  const double xlo = S.xi_uniform ? mul_then_add(S.xmin, S.dxi, (double)idx) : S.xi[idx];
+  const double xhi = S.xi_uniform ? mul_then_add(S.xmin, S.dxi, (double)(idx + 1)) : S.xi[idx + 1];
+  const double x1 = (xhi - xi) * S.inv_dxi;
+  const double x2 = (xi - xlo) * S.inv_dxi;
+  double pa, pb;
+  if (p0l) { pa = p0l[idx]; pb = p0l[idx + 1]; }
+  else { pa = S.p0[idx]; pb = S.p0[idx + 1]; }
+  const double P0 = x1 * pa + x2 * pb;
   const double t0 = inwin ? mass * (-4.0 * M_PI) * P0 : 0.0;
   in.a1 = t0 * x1;
   in.a2 = t0 * x2;
@@ -320,7 +352,7 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
     const double a1 = sel ? in.a1 : 0.0;
     const double a2 = sel ? in.a2 : 0.0;
     const double costh = in.costh;
-    const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+    const double somx2 = in.sinth;
     double pmm = LC_E(0);                              // Pt(0,0) = factorial(0,0)
     double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;   // c[m], s[m], c[m-1], s[m-1]
     static_for<0, MHI + 1>([&](auto mc) {
@@ -340,13 +372,16 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
         if (m == 0 || !S.M0_only) {
           // per-m weights: the four (x1|x2) x (cos|sin) moments share Pt(l,m)
           const double a1c = a1 * cm, a2c = a2 * cm, a1s = a1 * sm, a2s = a2 * sm;
-          double pl2 = 0.0, pl1 = 0.0;
+          // rescaled functions Ph = s(l,m) Pt (see lc_s): W holds s(l,m) x the moments and
+          // k_sph_contract divides the factor out
+          double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
           static_for<m, LMAX + 1>([&](auto lc_) {
             constexpr int l = decltype(lc_)::value;
             double plm;
             if constexpr (l == m) plm = pmm;
-            else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
-            else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+            else if constexpr (l == m + 1) plm = LC_a(l, m) * tprev;
+            else plm = fma(LC_a(l, m), tprev, -pl2);
+            if constexpr (l < LMAX) tprev = costh * plm;
             pl2 = pl1;
             pl1 = plm;
             if constexpr (m == 0) {
@@ -394,7 +429,7 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const AccIn in = sph_acc_input(S, nx, ny, nz, nm, i < cend);
+    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend);
     if (i + 64 < cend) {
       nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
     }
@@ -414,16 +449,16 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 // quarter of every 256-particle tile once, shares them through LDS (double-buffered, one barrier
 // per tile) and then reduces its own m-range over the whole tile.
 struct AccShared {
-  double v[2][5][ACC_WAVES * 64];
+  double v[2][6][ACC_WAVES * 64];
   int idx[2][ACC_WAVES * 64];
 };
 
 template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
-sph_accumulate_shared(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
-                      const double *__restrict__ Z, const double *__restrict__ M, size_t cbeg,
-                      size_t cend, double *scratch, AccShared &sh, double *__restrict__ W,
-                      unsigned long long *__restrict__ used_out)
+sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
+                      const double *__restrict__ Y, const double *__restrict__ Z,
+                      const double *__restrict__ M, size_t cbeg, size_t cend, double *scratch,
+                      AccShared &sh, double *__restrict__ W, unsigned long long *__restrict__ used_out)
 {
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
@@ -442,22 +477,26 @@ sph_accumulate_shared(const SphDev &S, const double *__restrict__ X, const doubl
   int par = 0;
   for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
     {
-      const AccIn in = sph_acc_input(S, nx, ny, nz, nm, ip < cend);
-      ip += TILE;
-      if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend);
       if (in.idx >= 0) used++;
       const int q = wave * 64 + lane;
       sh.v[par][0][q] = in.costh; sh.v[par][1][q] = in.cphi; sh.v[par][2][q] = in.sphi;
-      sh.v[par][3][q] = in.a1;    sh.v[par][4][q] = in.a2;   sh.idx[par][q] = in.idx;
+      sh.v[par][3][q] = in.a1;    sh.v[par][4][q] = in.a2;   sh.v[par][5][q] = in.sinth;
+      sh.idx[par][q] = in.idx;
     }
-    __syncthreads();
+    lds_barrier();
+    // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
+    // flight while this tile is reduced
+    ip += TILE;
+    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
 #pragma unroll 1
     for (int sub = 0; sub < ACC_WAVES; sub++) {
       if (tbase + (size_t)sub * 64 >= cend) break;
       const int q = sub * 64 + lane;
       AccIn in;
       in.costh = sh.v[par][0][q]; in.cphi = sh.v[par][1][q]; in.sphi = sh.v[par][2][q];
-      in.a1 = sh.v[par][3][q];    in.a2 = sh.v[par][4][q];   in.idx = sh.idx[par][q];
+      in.a1 = sh.v[par][3][q];    in.a2 = sh.v[par][4][q];   in.sinth = sh.v[par][5][q];
+      in.idx = sh.idx[par][q];
       sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
     }
   }
@@ -481,7 +520,7 @@ __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ W, unsigned long long *__restrict__ used_out)
+                 double *__restrict__ W, unsigned long long *__restrict__ used_out, int ACC_CHUNK)
 {
   constexpr int NS = acc_nsplit<LMAX>();
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;      // chunks per block
@@ -492,10 +531,20 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   if constexpr (NS == ACC_WAVES && LMAX > 7 && LMAX <= 10) {
     // one chunk per block, shared per-particle inputs, balanced m-ranges (31/34/26/30 rows at L=10)
     __shared__ AccShared sh;
+    // The per-particle input chain (sqrt, divisions, cell, P0 interpolation) is latency-bound and
+    // all waves of the block run it at the same time: keep the p0 table in LDS so that no global
+    // gather sits in the middle of it.
+    __shared__ double p0s[ACC_P0_LDS];
     const size_t cbeg = beg + (size_t)blockIdx.x * ACC_CHUNK;
     if (cbeg >= end) return;
     const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, X, Y, Z, M, cbeg, cend, scratch, sh, W, used_out)
+    const bool p0_in_lds = S.numr <= ACC_P0_LDS;
+    if (p0_in_lds) {
+      for (int k = threadIdx.x; k < S.numr; k += ACC_WAVES * 64) p0s[k] = S.p0[k];
+      __syncthreads();
+    }
+    ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, cbeg, cend, scratch, sh, W, used_out)
     if (wave == 0) RUNS(0, 1); else if (wave == 1) RUNS(2, 3); else if (wave == 2) RUNS(4, 5);
     else RUNS(6, LMAX);
 #undef RUNS
@@ -585,13 +634,14 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
       cm1 = cm; sm1 = sm;
       cm = cn; sm = sn;
     }
-    double pl2 = 0.0, pl1 = 0.0;
+    double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
     static_for<m, LMAX + 1>([&](auto lc_) {
       constexpr int l = decltype(lc_)::value;
-      double plm;
+      double plm;                       // rescaled Ph(l,m), as in the accumulation (same W scaling)
       if constexpr (l == m) plm = pmm;
-      else if constexpr (l == m + 1) plm = LC_A(l, m) * (costh * pl1);
-      else plm = LC_A(l, m) * (costh * pl1) - LC_B(l, m) * pl2;
+      else if constexpr (l == m + 1) plm = LC_a(l, m) * tprev;
+      else plm = fma(LC_a(l, m), tprev, -pl2);
+      tprev = costh * plm;
       pl2 = pl1;
       pl1 = plm;
       constexpr int row = row_of(l, m, 0);
