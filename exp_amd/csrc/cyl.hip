@@ -511,8 +511,10 @@ struct CylForce : exp_amd_force {
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
   size_t nnode = 0;
 
-  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
-  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
+  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
+                             bool have_keys = false) override;
+  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
+                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
   int multistep_reset() override
@@ -673,7 +675,8 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   return EXP_AMD_OK;
 }
 
-int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
+                                     bool /*have_keys: never produced by this force*/)
 {
   CylForce *f = this;
   f->home = c;
@@ -721,9 +724,11 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick)
+int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double, double,
+                         bool *prekey_done)
 {
   CylForce *f = this;
+  if (prekey_done) *prekey_done = false;
   if (f->proj_dirty) {
     ProfScope ps(ctx, "k_cyl_project");
     k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(

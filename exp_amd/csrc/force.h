@@ -20,9 +20,13 @@ struct exp_amd_force {
   // sort `c` into this basis' cell order (optionally applying kick+drift on the way), accumulate
   // the particles of the current level into the coefficient set, all-reduce
   virtual int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick,
-                                     double dt_drift) = 0;
+                                     double dt_drift, bool have_keys = false) = 0;
   // acc (+)= force, pot (+)= potential on the particles of levels >= mlevel of `t`
-  virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) = 0;
+  // nk_dtk/nk_dtd != 0 (fused step only): also write the sort key each particle will have after
+  // the NEXT step's kick(nk_dtk)+drift(nk_dtd) to t->key and count them into t->hist, so that
+  // the next step needs no key pass.  Forces that do not support it return 0 in *prekey_done.
+  virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick,
+                         double nk_dtk = 0.0, double nk_dtd = 0.0, bool *prekey_done = nullptr) = 0;
   virtual void release() = 0;
   // multistep_update for every particle whose proposed level (c->newlev) differs from its
   // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]

@@ -51,12 +51,14 @@ extern "C" int exp_amd_force_set_level(exp_amd_force *f, int mlevel)
 
 extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
 {
+  if (c) c->prekey_valid = false;
   if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
   return f->determine_coefficients(c, false, 0.0, 0.0);
 }
 
 extern "C" int exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external)
 {
+  if (target) target->prekey_valid = false;
   if (!f || !target) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_acceleration: NULL");
   return f->accelerate(target, external, false, 0.0);
 }
@@ -174,6 +176,7 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
                                                     long long *nswitch)
 {
   if (!f || !c || !dynfrac) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "adjust_multistep_level: NULL");
+  c->prekey_valid = false;
   exp_amd_ctx *ctx = f->ctx;
   const int ms = f->multistep;
   if (ms == 0) { if (nswitch) *nswitch = 0; return EXP_AMD_OK; }
@@ -213,9 +216,23 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
   // kick dt/2 + drift dt are applied inside the sort passes (no separate HBM pass); acc/pot are
   // recomputed below, so they are not carried through the reorder
   c->acc_live = false;
+  // keys + histogram left by the previous fused step's force pass for exactly this advance?
+  const bool have_keys = c->prekey_valid && c->prekey_owner == (const void *)f &&
+                         c->prekey_dtk == 0.5 * dt && c->prekey_dtd == dt &&
+                         c->prekey_center[0] == c->center[0] && c->prekey_center[1] == c->center[1] &&
+                         c->prekey_center[2] == c->center[2];
+  c->prekey_valid = false;
   if (c->n == 0) {
     if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
-  } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt))) return rc;
-  if ((rc = f->accelerate(c, 0, true, 0.5 * dt))) return rc;
+  } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys))) return rc;
+  bool done = false;
+  if ((rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done))) return rc;
+  if (done) {
+    c->prekey_valid = true;
+    c->prekey_owner = f;
+    c->prekey_dtk = 0.5 * dt;
+    c->prekey_dtd = dt;
+    for (int k = 0; k < 3; k++) c->prekey_center[k] = c->center[k];
+  }
   return EXP_AMD_OK;
 }

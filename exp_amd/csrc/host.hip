@@ -121,6 +121,7 @@ static int adjust_levels(exp_amd_sim *s, int mdrft, int first_step)
 // begin_run (src/begin.cc:80-129)
 extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 {
+  if (s) for (exp_amd_comp *c : s->comps) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!s) return EXP_AMD_ERR_ARG;
   int rc;
   if (s->multistep) {
@@ -139,6 +140,7 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 // do_step (src/step.cc:67-325)
 extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
 {
+  if (s) for (exp_amd_comp *c : s->comps) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
   int rc;
   for (int it = 0; it < nsteps; it++) {

@@ -21,6 +21,11 @@ struct exp_amd_comp {
   double center[3] = {0, 0, 0};
   const void *sorted_for = nullptr;  // force whose cell order the store currently has
   bool acc_live = true;              // acc/pot must survive a reorder
+  // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
+  // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
+  bool prekey_valid = false;
+  const void *prekey_owner = nullptr;   // force whose cells the keys are
+  double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
 
   double *a(int k) { return arr[cur][k].p; }
   double *b(int k) { return arr[1 - cur][k].p; }

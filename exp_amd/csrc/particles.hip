@@ -426,6 +426,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
                                    const double *y, const double *z, const double *vx,
                                    const double *vy, const double *vz)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   const double *h[7] = {x, y, z, vx, vy, vz, mass};
@@ -441,6 +442,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
 extern "C" int exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
                                        const double *az, const double *pot)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   const double *h[4] = {ax, ay, az, pot};
@@ -456,6 +458,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
                                           const double *y, const double *z, const double *vx,
                                           const double *vy, const double *vz)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -476,6 +479,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
 
 extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c || !level) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -524,6 +528,7 @@ extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
 
 extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c || !center) return EXP_AMD_ERR_ARG;
   for (int k = 0; k < 3; k++) c->center[k] = center[k];
   c->sorted_for = nullptr;
@@ -540,6 +545,7 @@ static void level_range(const exp_amd_comp *c, int mlevel, bool upward, int *lo,
 
 extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
@@ -554,6 +560,7 @@ extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
 
 extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
@@ -568,6 +575,7 @@ extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
 
 extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
 {
+  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;

@@ -104,6 +104,38 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
   }
 }
 
+// pass 1 when the keys already exist (written by the previous step's force pass): histogram only
+static __global__ void __launch_bounds__(SORT_TPB)
+k_hist_keys(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist)
+{
+  __shared__ uint32_t lh[SORT_WIN];
+  __shared__ uint32_t kmin_s;
+  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  if (base >= n) return;
+  uint32_t k[SORT_ITEMS];
+  uint32_t mn = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
+    k[j] = (i < n) ? key[i] : 0xffffffffu;
+    mn = min(mn, k[j]);
+  }
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
+  const uint32_t kmin = block_min_u32(mn, &kmin_s);
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++) {
+    if (k[j] == 0xffffffffu) continue;
+    const uint32_t d = k[j] - kmin;
+    if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
+    else atomicAdd(&hist[k[j]], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
+    const uint32_t c = lh[b];
+    if (c) atomicAdd(&hist[kmin + b], c);
+  }
+}
+
 struct ScatterDst {
   double *x, *y, *z, *vx, *vy, *vz, *m, *ax, *ay, *az, *pot;
   uint32_t *id;

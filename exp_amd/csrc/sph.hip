@@ -12,11 +12,7 @@ struct SphKeyFn {
   SphDev S;
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
   {
-    const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
-    double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-    if (r > S.rmax && !S.no_exterior) r = S.rmax;   // src/SphericalBasis.cc:1555-1560
-    const double xi = sph_r_to_xi(S, r / S.scale);
-    return (uint32_t)lev * (uint32_t)(S.numr - 1) + (uint32_t)sph_cell(S, xi);
+    return (uint32_t)lev * (uint32_t)(S.numr - 1) + sph_key_cell(S, x, y, z);
   }
 };
 
@@ -117,8 +113,10 @@ struct SphForce : exp_amd_force {
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
 
-  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift) override;
-  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick) override;
+  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
+                             bool have_keys = false) override;
+  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
+                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
   void release() override;
@@ -275,7 +273,8 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 // (level, radial cell) order for this force's tables; with `advance` the kick dt_kick and drift
 // dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
 static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = false,
-                    double dt_kick = 0.0, double dt_drift = 0.0, int level = -1)
+                    double dt_kick = 0.0, double dt_drift = 0.0, int level = -1,
+                    bool have_keys = false)
 {
   exp_amd_ctx *ctx = f->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -284,7 +283,12 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
   const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
   int rc = expamd_comp_prepare_hist(c, nkeys);
   if (rc) return rc;
-  {
+  if (have_keys) {
+    // c->key was filled by the previous step's force pass for exactly this advance
+    // (exp_amd_step_kdk checks that): pass 1 only counts the 4-byte keys
+    ProfScope ps(ctx, "k_hist_keys");
+    k_hist_keys<<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+  } else {
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center)};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
@@ -343,7 +347,8 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   return EXP_AMD_OK;
 }
 
-int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
+                                     bool have_keys)
 {
   SphForce *f = this;
   f->home = c;
@@ -351,7 +356,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   // so only its slot range is re-sorted
   const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                         ? f->mlevel : -1;
-  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift, level);
+  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift, level, have_keys && level < 0);
   if (rc) return rc;
   double *dst = f->cfg.multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef : f->d_coef.p;
   if (f->cfg.multistep) {
@@ -380,12 +385,18 @@ static int sph_project(SphForce *f)
   return EXP_AMD_OK;
 }
 
-int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick)
+int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk,
+                         double nk_dtd, bool *prekey_done)
 {
   SphForce *f = this;
+  if (prekey_done) *prekey_done = false;
   int rc = sph_project(f);
   if (rc) return rc;
   if (t->n == 0) return EXP_AMD_OK;
+  // next step's keys + histogram: single level, own (sorted) particles, fused half-kick only
+  const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&
+                      t->nlevels == 1 && f->cfg.multistep == 0 && t->sorted_for == f;
+
   const double *ctr = (external && f->home) ? f->home->center : t->center;
   SphDev S = dev_for(f, ctr);
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
@@ -402,11 +413,13 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream,
-                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0};
+                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0,
+                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd};
     k_force_launch[f->cfg.lmax](a);
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
+  if (prekey) *prekey_done = true;
   return EXP_AMD_OK;
 }
 

@@ -190,6 +190,29 @@ __device__ __forceinline__ int sph_cell(const SphDev &S, double xi)
   return idx;
 }
 
+// radial cell used as the sort key (r clamped to rmax like the force path, src/SphericalBasis.cc:1555-1560)
+__device__ __forceinline__ uint32_t sph_key_cell(const SphDev &S, double x, double y, double z)
+{
+  const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
+  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  if (r > S.rmax && !S.no_exterior) r = S.rmax;
+  return (uint32_t)sph_cell(S, sph_r_to_xi(S, r / S.scale));
+}
+
+// The same cell by multiplications with the stored reciprocals (one division left, in the map).
+// A key only decides where a particle is PLACED; accumulation and force recompute the cell
+// from the position, so a last-ulp difference at a cell edge costs nothing but a mixed wave.
+__device__ __forceinline__ uint32_t sph_key_cell_rcp(const SphDev &S, double x, double y, double z)
+{
+  const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
+  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  if (r > S.rmax && !S.no_exterior) r = S.rmax;
+  const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
+  int idx = (int)((xi - S.xmin) * S.inv_dxi);
+  idx = idx < 0 ? 0 : idx > S.numr - 2 ? S.numr - 2 : idx;
+  return (uint32_t)idx;
+}
+
 // cos(phi), sin(phi) for phi = atan2(y, x) without the transcendental round trip
 __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double &s)
 {
@@ -884,36 +907,30 @@ sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, dou
 #ifndef SPH_FORCE_WAVES
 #define SPH_FORCE_WAVES 5      // min waves/SIMD for the fast pass: 5 beats 4 and 6 on MI355X (A/B, profiles/)
 #endif
+#ifndef SPH_FORCE_CHUNKS
+#define SPH_FORCE_CHUNKS 1
+#endif
+// One 64-particle chunk of one wave (slots base .. base+63 of [.., end)).
 template <int LMAX, bool FAST>
-__global__ void __launch_bounds__(256, FAST ? SPH_FORCE_WAVES : 1)
-k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
-            const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
-            int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
-            double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
-            double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
-            double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork)
+__device__ __forceinline__ void
+sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
+                const double *__restrict__ Z, size_t base, size_t end, const double *__restrict__ T4,
+                double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
+                double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
+                double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ work,
+                uint32_t *__restrict__ nwork, uint32_t *__restrict__ key_out, double nk_dtk,
+                double nk_dtd)
 {
-  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   const int lane = threadIdx.x & 63;
-  // One 64-particle chunk per wave and NO particle loop: with a loop, LICM hoists the
-  // constants of the unrolled (l,m) nest out of it and spills them.
-  size_t base;
-  if (FAST || work == nullptr) {
-    // (An XCD-contiguous chunk order was tried: 15% slower than the plain round-robin order.)
-    base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
-    if (base >= end) return;
-  } else {
-    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= *nwork) return;
-    base = work[w];
-  }
   const size_t i = base + lane;
   const bool valid = i < end;
   double xx = 1, yy = 0, zz = 0;          // idle lanes: a harmless off-axis point
-  if (valid) {
-    xx = X[i] - S.cx;
-    yy = Y[i] - S.cy;
-    zz = Z[i] - S.cz;
+  double px = 0, py = 0, pz = 0;          // kept for the next-step key (a reload at the end of the
+  if (valid) {                            // wave would expose a full memory round trip)
+    px = X[i]; py = Y[i]; pz = Z[i];
+    xx = px - S.cx;
+    yy = py - S.cy;
+    zz = pz - S.cz;
   }
   const double fac = xx * xx + yy * yy;
   const size_t tq = (size_t)4 * S.trows;
@@ -1017,9 +1034,59 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
   AZ[i] = az;
   POT[i] = pt;
   if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
-    VX[i] = mul_then_add(VX[i], ax, dt_kick);
-    VY[i] = mul_then_add(VY[i], ay, dt_kick);
-    VZ[i] = mul_then_add(VZ[i], az, dt_kick);
+    const double vx = mul_then_add(VX[i], ax, dt_kick);
+    const double vy = mul_then_add(VY[i], ay, dt_kick);
+    const double vz = mul_then_add(VZ[i], az, dt_kick);
+    VX[i] = vx; VY[i] = vy; VZ[i] = vz;
+    if (key_out) {
+      // Where this particle will be after the NEXT step's kick + drift (the arithmetic of
+      // advance_one, sort_kernels.h, on the values just stored): its sort key.  The next step
+      // then histograms the 4-byte keys (k_hist_keys) instead of re-reading x, v, a (72 B).
+      // (Counting the keys here as well, one atomic per distinct key per wave, doubled this
+      // kernel's time: 5e6 atomics on ~2000 hot addresses.)
+      const double wx = mul_then_add(vx, ax, nk_dtk);
+      const double wy = mul_then_add(vy, ay, nk_dtk);
+      const double wz = mul_then_add(vz, az, nk_dtk);
+      const uint32_t key = sph_key_cell_rcp(S, mul_then_add(px, wx, nk_dtd),
+                                            mul_then_add(py, wy, nk_dtd), mul_then_add(pz, wz, nk_dtd));
+      key_out[i] = key;
+    }
+  }
+}
+
+template <int LMAX, bool FAST>
+__global__ void __launch_bounds__(256, FAST ? SPH_FORCE_WAVES : 1)
+k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
+            const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
+            int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
+            double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
+            double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
+            double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork,
+            uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd)
+{
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  if constexpr (FAST) {
+    // SPH_FORCE_CHUNKS consecutive chunks per wave (rolled loop: the literal recurrence constants
+    // are rematerialised, not hoisted) amortise the wave launch and its first-load latency.
+#pragma unroll 1
+    for (int c = 0; c < SPH_FORCE_CHUNKS; c++) {
+      const size_t base = beg + (((size_t)blockIdx.x * SPH_FORCE_CHUNKS + c) * 256 + (threadIdx.x & ~63));
+      if (base >= end) return;
+      sph_force_chunk<LMAX, true>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+                                  assign, work, nwork, key_out, nk_dtk, nk_dtd);
+    }
+  } else {
+    size_t base;
+    if (work == nullptr) {
+      base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+      if (base >= end) return;
+    } else {
+      const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+      if (w >= *nwork) return;
+      base = work[w];
+    }
+    sph_force_chunk<LMAX, false>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+                                 assign, work, nwork, key_out, nk_dtk, nk_dtd);
   }
 }
 
@@ -1050,6 +1117,8 @@ struct SphForceArgs {
   hipStream_t stream;
   uint32_t *work, *nwork;   // slow-path work list (first slot of each deferred wave) + count
   int all_slow;             // target is not in this force's cell order: skip the fast pass
+  uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
+  double nk_dtk, nk_dtd;    // ... for that step's kick and drift
 };
 
 struct SphUpdArgs {

@@ -220,6 +220,51 @@ def test_kdk_steps_match_oracle(ctx, oracle, plummer_s6, fused):
     assert np.array_equal(out["mass"], m)
 
 
+def test_fused_step_key_reuse_and_invalidation(ctx, oracle, plummer_s6):
+    """exp_amd_step_kdk lets the force pass write the NEXT step's sort keys.  They may only be
+    used when nothing touched the component in between: a changed dt, a moved centre, new
+    accelerations or an explicit kick must all fall back to the full key pass.  Every variant
+    is compared with the unfused call-for-call step sequence (and so with the oracle's step)."""
+    from exp_amd.runtime import Component, SphereSL, do_step_single
+    model, g = plummer_s6
+    m, pos, vel = _particles(model, 30000, seed=31)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    acc, _ = oracle.sph_accel(g, prm, pos, c_ref)
+
+    def run(kind):
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        c.upload_acc(acc, np.zeros(len(m)))
+        dts = [0.01, 0.01, 0.01, 0.004, 0.004, 0.01]
+        for k, dt in enumerate(dts):
+            if kind == "unfused":
+                do_step_single(f, c, dt)
+                continue
+            f.step_kdk(c, dt)
+            if kind == "touched" and k == 1:          # same state written back: keys must be dropped
+                o = c.download()
+                c2 = Component.from_arrays(ctx, o["mass"], o["pos"], o["vel"])
+                c2.upload_acc(o["acc"], o["pot"])
+                c.close()
+                c = c2
+            if kind == "touched" and k == 3:
+                c.incr_velocity(0.0)                  # a no-op kick still invalidates
+        out = c.download()
+        cf = f.get_coefs()
+        c.close()
+        f.close()
+        return out, cf
+
+    ref, cref = run("unfused")
+    for kind in ("fused", "touched"):
+        out, cf = run(kind)
+        assert coef_err(cf, cref) <= COEF_TOL
+        assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-12
+        assert np.abs(out["vel"] - ref["vel"]).max() <= 1e-10
+        assert acc_err(out["acc"], ref["acc"]) <= 1e-8
+
+
 @pytest.mark.parametrize("kind,lmax,nmax,numr,n", [("nfw", 6, 18, 2000, 1_500_000),
                                                    ("nfw", 10, 24, 2000, 1_500_000),
                                                    ("plummer", 4, 8, 400, 400_000)])
