@@ -333,7 +333,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   if (c->n) {
     ProfScope ps(ctx, "k_sph_accumulate");
     SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi,
-                 f->d_W.p, f->d_used.p, c->n, ctx->stream};
+                 f->d_W.p, f->d_used.p, c->n, ctx->stream, f->multistep ? 1 : 0};
     k_acc_launch[f->cfg.lmax](a);
   }
   {

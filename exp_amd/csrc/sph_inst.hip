@@ -17,6 +17,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   // chunk: as large as ACC_CHUNK_MAX while >= ~6 rounds of blocks remain (2 blocks x 256 CUs)
   size_t chunk = (a.n / ((size_t)CPB * 3072)) & ~(size_t)255;
   chunk = chunk < ACC_CHUNK_MIN ? ACC_CHUNK_MIN : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
+  if (a.multilevel) chunk = ACC_CHUNK_MIN;   // a sparse level must still spread over the CUs
   const unsigned nchunk = cdiv(a.n, chunk);
   dim3 grid(cdiv(nchunk, CPB), (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
   k_sph_accumulate<LMAX><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,

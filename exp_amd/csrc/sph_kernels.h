@@ -1101,6 +1101,7 @@ struct SphAccArgs {
   unsigned long long *used;
   size_t n;
   hipStream_t stream;
+  int multilevel;           // the range [lo, hi] is one level of many: its size is unknown on the host
 };
 
 struct SphForceArgs {
