@@ -343,6 +343,36 @@ class SphericalSL(BiorthBasis):
         c.close()
         return acc
 
+    # ---- field evaluation (expui/BasisFactory.cc:218-234, expui/BiorthBasis.cc:71-97, :711-958) ----
+    FIELD_LABELS = ["dens m=0", "dens m>0", "dens", "potl m=0", "potl m>0", "potl"]
+    FORCE_LABELS = {"spherical": ["rad force", "mer force", "azi force"],
+                    "cylindrical": ["rad force", "ver force", "azi force"],
+                    "cartesian": ["x force", "y force", "z force"]}
+    coordinates = "spherical"            # BasisFactory.H: default field type
+
+    def setFieldType(self, coord_type: str) -> None:
+        key = coord_type.strip().lower()
+        if key not in self.FORCE_LABELS:
+            raise RuntimeError(f"Basis: unknown coordinate type <{coord_type}>")
+        self.coordinates = key
+
+    def getFieldLabels(self, ctype: Optional[str] = None):
+        return self.FIELD_LABELS + self.FORCE_LABELS[(ctype or self.coordinates).lower()]
+
+    def __call__(self, x1, x2, x3, ctype: str = "spherical"):
+        """Fields in the requested coordinates: (r, cos theta, phi) | (R, z, phi) | (x, y, z)
+        -> the 9 values of getFieldLabels(ctype); arrays give [N, 9]."""
+        single = np.ndim(x1) == 0
+        out = self.force.fields(x1, x2, x3, ctype.lower())
+        return out[0] if single else out
+
+    def getFields(self, x, y, z):
+        """Basis::getFields -> crt_eval(x, y, z) (expui/BasisFactory.cc:231-234)."""
+        return self(x, y, z, "cartesian")
+
+    def evaluate(self, x, y, z):
+        return self.getFields(x, y, z), self.getFieldLabels("cartesian")
+
 
 class Cylindrical(BiorthBasis):
     """``cylinder`` (expui/BiorthBasis.cc Cylindrical): YAML keys acyl, hcyl, mmax, nmax, ncylnx,

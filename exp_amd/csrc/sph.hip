@@ -102,25 +102,7 @@ k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ r
 
 // ---- host side -----------------------------------------------------------------------------------------------
 
-struct SphForce : exp_amd_force {
-  exp_amd_sph_config cfg{};
-  SphDev dev{};
-  DevBuf<double> d_xi, d_p0, d_E, d_lc;
-  DevBuf<double> d_W, d_part, d_G, d_T4;
-  DevBuf<int> d_rowmap;
-  DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
-  DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
-  DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
-  size_t work_cap = 0;
-
-  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
-                             bool have_keys = false) override;
-  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
-                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
-  int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
-  int resort(exp_amd_comp *c) override;
-  void release() override;
-};
+#include "sph_force.h"
 
 static double factrl(int n)
 {
@@ -210,6 +192,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_p0.alloc(numr));
   A(f->d_E.alloc(E.size()));
   A(f->d_lc.alloc(lcv.size()));
+  A(f->d_ev.alloc((size_t)(L + 1) * nmax));
   A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_tscale.alloc(tscale.size()));
   A(f->d_wscale.alloc(wscale.size()));
@@ -227,6 +210,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   HIP_TRY(ctx, hipMemcpy(f->d_p0.p, p0, numr * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_E.p, E.data(), E.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_lc.p, lcv.data(), lcv.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(f->d_ev.p, ev, (size_t)(L + 1) * nmax * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
                          hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_tscale.p, tscale.data(), tscale.size() * sizeof(double),
@@ -258,6 +242,7 @@ void SphForce::release()
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
   d_rowmap.release();
   d_tscale.release();
+  d_ev.release(); d_d0.release(); d_Gd.release();
   d_wscale.release();
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
@@ -372,7 +357,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-static int sph_project(SphForce *f)
+int sph_project(SphForce *f)
 {
   if (!f->proj_dirty) return EXP_AMD_OK;
   exp_amd_ctx *ctx = f->ctx;

@@ -1,0 +1,180 @@
+// Field evaluation at arbitrary points for the spherical basis: the pyEXP surface
+// Spherical::sph_eval / cyl_eval / crt_eval behind getFields (expui/BiorthBasis.cc:711-816,
+// :930-958).  Not a throughput path (grids of <= 1e6 points): one lane per point, run-time loops
+// over (l, m), per-lane gathers from the projected tables
+//   G [i][row] = sum_n ef_l(n,i)/sqrt(ev_l[n]) c[row][n]     (potential / force, sph_project)
+//   Gd[i][row] = sum_n ef_l(n,i)*sqrt(ev_l[n]) c[row][n]     (density, SLGridMP2.cc:913-950)
+// so a point costs O(L^2) like the n-body force pass, not O(L^2 nmax).
+#include "sph_force.h"
+
+// Gd[i][row] = sum_n E[i][l][n] ev[l][n] c[row][n]
+__global__ void __launch_bounds__(256)
+k_sph_project_dens(SphDev S, const double *__restrict__ ev, const double *__restrict__ coef,
+                   double *__restrict__ Gd)
+{
+  const int i = blockIdx.x;
+  const int stride = (S.lmax + 1) * S.nmax;
+  for (int row = threadIdx.x; row < S.nrows; row += 256) {
+    int l = 0;
+    while ((l + 1) * (l + 1) <= row) l++;
+    const double *e = S.E + (size_t)i * stride + l * S.nmax;
+    const double *v = ev + (size_t)l * S.nmax;
+    const double *c = coef + (size_t)row * S.nmax;
+    double s = 0.0;
+    for (int n = 0; n < S.nmax; n++) s = fma(e[n] * v[n], c[n], s);
+    Gd[(size_t)i * S.nrows + row] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ Gd,
+             const double *__restrict__ d0, size_t n, const double *__restrict__ c1,
+             const double *__restrict__ c2, const double *__restrict__ c3, int coord,
+             double *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double *lc = S.lc;
+  const int L = S.lmax;
+  // ---- coordinates (cyl_eval :930-941, crt_eval :946-958) ----
+  double r, costh, phi, R = 0.0, x = 0.0, y = 0.0, z = 0.0;
+  if (coord == 0) { r = c1[i]; costh = c2[i]; phi = c3[i]; }
+  else {
+    if (coord == 1) { R = c1[i]; z = c2[i]; phi = c3[i]; }
+    else {
+      x = c1[i]; y = c2[i]; z = c3[i];
+      R = sqrt(x * x + y * y) + 1.0e-18;
+      phi = atan2(y, x);
+    }
+    r = sqrt(R * R + z * z) + 1.0e-18;
+    costh = z / r;
+  }
+  // ---- radial tables: get_dens / get_pot / get_force (exputil/SLGridMP2.cc:872-989) ----
+  const double xi = sph_r_to_xi(S, r / S.scale);
+  const int idx = sph_cell(S, xi);
+  const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
+  const double x2 = (xi - S.xi[idx]) / S.dxi;
+  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  const double D0 = x1 * d0[idx] + x2 * d0[idx + 1];
+  const int j = idx < 1 ? 1 : idx;
+  const double pf = (xi - S.xi[j]) / S.dxi;
+  const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
+  const double wa = (pf - 0.5) * S.p0[j - 1], wb = -2.0 * pf * S.p0[j], wc = (pf + 0.5) * S.p0[j + 1];
+  const double *g0 = G + (size_t)idx * S.nrows, *g1 = g0 + S.nrows;
+  const double *ga = G + (size_t)(j - 1) * S.nrows, *gb = ga + S.nrows, *gc = gb + S.nrows;
+  const double *q0 = Gd + (size_t)idx * S.nrows, *q1 = q0 + S.nrows;
+  // ---- angular part: normalised Legendre functions and their x-derivative ----
+  double xc = costh;                                   // pole clamp of the derivative (:1109-1112)
+  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+  const double dfac = 1.0 / (xc * xc - 1.0);
+  const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  double den0 = 0.0, pot0 = 0.0, potr = 0.0, den1 = 0.0, pot1 = 0.0, pott = 0.0, potp = 0.0;
+  double pmm = 0.0;
+  for (int m = 0; m <= L; m++) {
+    pmm = (m == 0) ? lc[3] : pmm * (lc[((size_t)m * (L + 1) + m) * 4 + 3] * somx2);
+    const bool m_on = !((S.M0_only && m) || (S.EVEN_M && (m & 1)));
+    const double cosm = cos(phi * m), sinm = sin(phi * m);     // direct, as sph_eval does
+    double pl2 = 0.0, pl1 = 0.0;
+    for (int l = m; l <= L; l++) {
+      const double *q = lc + ((size_t)l * (L + 1) + m) * 4;
+      double plm, dplm;
+      if (l == m) { plm = pmm; dplm = dfac * ((xc * l) * plm); }
+      else {
+        plm = (l == m + 1) ? q[0] * (costh * pl1) : q[0] * (costh * pl1) - q[1] * pl2;
+        dplm = dfac * ((xc * l) * plm - q[2] * pl1);
+      }
+      pl2 = pl1;
+      pl1 = plm;
+      bool on = m_on;
+      if (l == 0 && S.NO_L0) on = false;
+      if (l == 1 && S.NO_L1) on = false;
+      if (l > 0 && S.EVEN_L && (l & 1)) on = false;
+      if (!on) continue;
+      // coefficient row, with the reference's EVEN_M quirk (skipped odd m do not advance moffset)
+      int row = l * l + (m ? 2 * m - 1 : 0);
+      if (S.EVEN_M && m > 0) row = l * l + (m - 1);
+      const double sumP0 = P0 * (x1 * g0[row] + x2 * g1[row]);
+      const double sumR0 = D0 * (x1 * q0[row] + x2 * q1[row]);
+      const double sumD0 = ffac * (wa * ga[row] + wb * gb[row] + wc * gc[row]);
+      if (m == 0) {
+        if (l == 0) { den0 = plm * sumR0; pot0 = plm * sumP0; potr += plm * sumD0; }
+        else {
+          den1 += plm * sumR0; pot1 += plm * sumP0; potr += plm * sumD0; pott += dplm * sumP0;
+        }
+      } else {
+        const double sumP1 = P0 * (x1 * g0[row + 1] + x2 * g1[row + 1]);
+        const double sumR1 = D0 * (x1 * q0[row + 1] + x2 * q1[row + 1]);
+        const double sumD1 = ffac * (wa * ga[row + 1] + wb * gb[row + 1] + wc * gc[row + 1]);
+        den1 += plm * (sumR0 * cosm + sumR1 * sinm);
+        pot1 += plm * (sumP0 * cosm + sumP1 * sinm);
+        potr += plm * (sumD0 * cosm + sumD1 * sinm);
+        pott += dplm * (sumP0 * cosm + sumP1 * sinm);
+        potp += plm * (-sumP0 * sinm + sumP1 * cosm) * m;
+      }
+    }
+  }
+  const double sinth = sqrt(fabs(1.0 - costh * costh));
+  const double densfac = 1.0 / (S.scale * S.scale * S.scale) * 0.25 / M_PI;
+  const double potlfac = 1.0 / S.scale;
+  double v[9] = {den0 * densfac, den1 * densfac, (den0 + den1) * densfac,
+                 pot0 * potlfac, pot1 * potlfac, (pot0 + pot1) * potlfac,
+                 potr * (-potlfac) / S.scale, pott * (-potlfac) / r, potp * (-potlfac) / (r * sinth)};
+  double *o = out + 9 * i;
+  if (coord != 0) {
+    const double sth = R / r;
+    const double potR = v[6] * sth - v[7] * costh * R / r;
+    const double potz = v[6] * costh + v[7] * sth * R / r;
+    if (coord == 1) { v[6] = potR; v[7] = potz; }
+    else {
+      const double fx = potR * x / R - v[8] * y / R;
+      const double fy = potR * y / R + v[8] * x / R;
+      v[6] = fx; v[7] = fy; v[8] = potz;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) o[k] = v[k];
+}
+
+extern "C" int exp_amd_sph_set_density(exp_amd_force *fb, const double *d0)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f || !d0) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_set_density: not a spherical force / NULL");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (f->d_d0.alloc(f->cfg.numr) != hipSuccess || f->d_Gd.alloc((size_t)f->cfg.numr * f->dev.nrows) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph_set_density: hipMalloc failed");
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_d0.p, d0, f->cfg.numr * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_sph_fields(exp_amd_force *fb, size_t n, const double *c1, const double *c2,
+                                  const double *c3, int coord, double *out)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_fields: not a spherical force");
+  exp_amd_ctx *ctx = f->ctx;
+  if (n == 0) return EXP_AMD_OK;
+  if (!c1 || !c2 || !c3 || !out || coord < 0 || coord > 2)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_fields: bad argument");
+  if (!f->d_d0.p)
+    return expamd_fail(ctx, EXP_AMD_ERR_STATE, "sph_fields: call exp_amd_sph_set_density first");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = sph_project(f);
+  if (rc) return rc;
+  DevBuf<double> d_in, d_out;
+  if (d_in.alloc(3 * n) != hipSuccess || d_out.alloc(9 * n) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph_fields: hipMalloc failed");
+  const double *src[3] = {c1, c2, c3};
+  for (int k = 0; k < 3; k++)
+    HIP_TRY(ctx, hipMemcpyAsync(d_in.p + (size_t)k * n, src[k], n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  k_sph_project_dens<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_ev.p, f->d_coef.p, f->d_Gd.p);
+  k_sph_fields<<<cdiv(n, 256), 256, 0, ctx->stream>>>(f->dev, f->d_G.p, f->d_Gd.p, f->d_d0.p, n, d_in.p,
+                                                      d_in.p + n, d_in.p + 2 * n, coord, d_out.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, 9 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_in.release();
+  d_out.release();
+  return EXP_AMD_OK;
+}

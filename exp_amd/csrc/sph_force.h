@@ -1,0 +1,28 @@
+// SphForce: the spherical force object behind exp_amd_force (shared by sph.hip and sph_fields.hip).
+#pragma once
+#include "sph_kernels.h"
+#include "force.h"
+
+struct SphForce : exp_amd_force {
+  exp_amd_sph_config cfg{};
+  SphDev dev{};
+  DevBuf<double> d_xi, d_p0, d_E, d_lc;
+  DevBuf<double> d_W, d_part, d_G, d_T4;
+  DevBuf<int> d_rowmap;
+  DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
+  DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
+  DevBuf<double> d_ev, d_d0, d_Gd;  // field evaluation (pyEXP getFields): ev[l][n], d0[numr], Gd[numr][rows]
+  DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
+  size_t work_cap = 0;
+
+  int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
+                             bool have_keys = false) override;
+  int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
+                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
+  int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  int resort(exp_amd_comp *c) override;
+  void release() override;
+};
+
+
+int sph_project(SphForce *f);     // coefficients -> G / T4 tables (no-op when they are current)

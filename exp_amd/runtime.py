@@ -296,6 +296,25 @@ class SphereSL(_Force):
     def set_coefs(self, coef) -> None:
         self._set_flat(coef)
 
+    FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
+
+    def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:
+        """Fields of the current coefficient set at points -> [n, 9] = (dens m=0, dens m>0, dens,
+        potl m=0, potl m>0, potl, force x3 in the input coordinates): ``Spherical::sph_eval``
+        / ``cyl_eval`` / ``crt_eval`` (expui/BiorthBasis.cc:711-816, :930-958)."""
+        a, b, c = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (c1, c2, c3)]
+        if not (a.shape == b.shape == c.shape and a.ndim == 1):
+            raise ValueError("fields: three 1-d arrays of equal length expected")
+        if not getattr(self, "_have_density", False):
+            d0 = as_f64(self.grid.d0)
+            check(self.lib.exp_amd_sph_set_density(self.h, d0[1]), self.ctx.h)
+            self._have_density = True
+        out = np.empty((a.size, 9))
+        check(self.lib.exp_amd_sph_fields(self.h, a.size, a.ctypes.data, b.ctypes.data,
+                                          c.ctypes.data, self.FIELD_COORDS[coord],
+                                          out.ctypes.data), self.ctx.h)
+        return out
+
 
 class Cylinder(_Force):
     """``cylinder`` force method: EmpCylSL empirical orthogonal functions (src/Cylinder.cc)."""

@@ -194,6 +194,17 @@ int  exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const d
 int  exp_amd_cyl_get_cylmass(exp_amd_force *f, double *mass);
 int  exp_amd_cyl_set_cylmass(exp_amd_force *f, double mass);
 
+/* ---- field evaluation at points (pyEXP getFields) ------------------------------------------
+ * Spherical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:711-816, :930-958) for the
+ * force's current coefficient set.  coord: 0 = (r, cos theta, phi), 1 = (R, z, phi),
+ * 2 = (x, y, z); host arrays of n points; out[n][9] = {dens m=0, dens m>0, dens, potl m=0,
+ * potl m>0, potl, force x 3 in the input coordinates} (labels: BiorthBasis.cc:71-97).  The
+ * density needs SLGridSph's d0 table (4 pi rho0 on the xi grid, exputil/SLGridMP2.cc:913-950),
+ * supplied once with exp_amd_sph_set_density.                                               */
+int  exp_amd_sph_set_density(exp_amd_force *f, const double *d0 /* [numr] */);
+int  exp_amd_sph_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
+                        const double *c3, int coord, double *out /* [n][9] */);
+
 /* ---- fused step ------------------------------------------------------------------------
  * One multistep=0 KDK step of a single self-gravitating component
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.

@@ -846,3 +846,163 @@ void orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int mu
   free(tx); free(ty); free(tz); free(tm); free(differ); free(val); free(p); free(cosm); free(sinm);
   free(potd); free(factorial);
 }
+
+/* ---- pyEXP field evaluation ------------------------------------------------------------------
+ * expui/BiorthBasis.cc:711-816 (Spherical::sph_eval), :930-941 (cyl_eval), :946-958 (crt_eval);
+ * normalisation table :318-330 (lgamma form of factorial(l,m)); labels :71-97.
+ * coord: 0 = spherical input (r, cos(theta), phi), 1 = cylindrical (R, z, phi), 2 = Cartesian
+ * (x, y, z).  out[9] = {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, three force
+ * components in the input coordinate system}.  G = 1, N1..N2 = the full radial range.         */
+static void pyexp_sph_eval(const orc_slgrid *g, const orc_sph_params *P, const double *coef,
+                           const double *factorial, double r, double costh, double phi,
+                           double *dend, double *potd, double *dpot, double *legs, double *dlegs,
+                           double *out)
+{
+  const int lmax = g->lmax, nmax = g->nmax;
+  const double scale = P->scale;
+#define FC(l, m) factorial[(l) * (lmax + 1) + (m)]
+#define LG(l, m) legs[(l) * (lmax + 1) + (m)]
+#define DLG(l, m) dlegs[(l) * (lmax + 1) + (m)]
+#define CF(row, n) coef[(size_t)(row) * nmax + (n)]
+  double fac1 = FC(0, 0);
+
+  orc_sl_get_dens(g, r / scale, dend);
+  orc_sl_get_pot(g, r / scale, potd);
+  orc_sl_get_force(g, r / scale, dpot);
+
+  orc_dlegendre_R(lmax, costh, legs, dlegs);
+
+  double den0, pot0, potr;
+  double sinth = sqrt(fabs(1.0 - costh * costh));
+
+  if (P->NO_L0) {
+    den0 = 0.0;
+    pot0 = 0.0;
+    potr = 0.0;
+  } else {
+    den0 = pot0 = potr = 0.0;
+    for (int n = 0; n < nmax; n++) {
+      den0 += CF(0, n) * dend[n];
+      pot0 += CF(0, n) * potd[n];
+      potr += CF(0, n) * dpot[n];
+    }
+    den0 *= fac1;
+    pot0 *= fac1;
+    potr *= fac1;
+  }
+
+  double den1 = 0.0, pot1 = 0.0, pott = 0.0, potp = 0.0;
+
+  for (int l = 1, loffset = 1; l <= lmax; loffset += (2 * l + 1), l++) {
+    if (P->EVEN_L && l % 2) continue;
+    if (P->NO_L1 && l == 1) continue;
+
+    for (int m = 0, moffset = 0; m <= l; m++) {
+      if (P->M0_only && m) continue;
+      if (P->EVEN_M && m % 2) continue;
+
+      fac1 = FC(l, m);
+      if (m == 0) {
+        double sumR = 0.0, sumP = 0.0, sumD = 0.0;
+        for (int n = 0; n < nmax; n++) {
+          sumR += CF(loffset + moffset, n) * dend[l * nmax + n];
+          sumP += CF(loffset + moffset, n) * potd[l * nmax + n];
+          sumD += CF(loffset + moffset, n) * dpot[l * nmax + n];
+        }
+        den1 += fac1 * LG(l, m) * sumR;
+        pot1 += fac1 * LG(l, m) * sumP;
+        potr += fac1 * LG(l, m) * sumD;
+        pott += fac1 * DLG(l, m) * sumP;
+        moffset++;
+      } else {
+        double cosm = cos(phi * m);
+        double sinm = sin(phi * m);
+        double sumR0 = 0.0, sumP0 = 0.0, sumD0 = 0.0;
+        double sumR1 = 0.0, sumP1 = 0.0, sumD1 = 0.0;
+        for (int n = 0; n < nmax; n++) {
+          sumR0 += CF(loffset + moffset + 0, n) * dend[l * nmax + n];
+          sumP0 += CF(loffset + moffset + 0, n) * potd[l * nmax + n];
+          sumD0 += CF(loffset + moffset + 0, n) * dpot[l * nmax + n];
+          sumR1 += CF(loffset + moffset + 1, n) * dend[l * nmax + n];
+          sumP1 += CF(loffset + moffset + 1, n) * potd[l * nmax + n];
+          sumD1 += CF(loffset + moffset + 1, n) * dpot[l * nmax + n];
+        }
+        den1 += fac1 * LG(l, m) * (sumR0 * cosm + sumR1 * sinm);
+        pot1 += fac1 * LG(l, m) * (sumP0 * cosm + sumP1 * sinm);
+        potr += fac1 * LG(l, m) * (sumD0 * cosm + sumD1 * sinm);
+        pott += fac1 * DLG(l, m) * (sumP0 * cosm + sumP1 * sinm);
+        potp += fac1 * LG(l, m) * (-sumP0 * sinm + sumP1 * cosm) * m;
+        moffset += 2;
+      }
+    }
+  }
+
+  double densfac = 1.0 / (scale * scale * scale) * 0.25 / M_PI;
+  double potlfac = 1.0 / scale;
+
+  out[0] = den0 * densfac;
+  out[1] = den1 * densfac;
+  out[2] = (den0 + den1) * densfac;
+  out[3] = pot0 * potlfac;
+  out[4] = pot1 * potlfac;
+  out[5] = (pot0 + pot1) * potlfac;
+  out[6] = potr * (-potlfac) / scale;
+  out[7] = pott * (-potlfac) / r;
+  out[8] = potp * (-potlfac) / (r * sinth);
+#undef FC
+#undef LG
+#undef DLG
+#undef CF
+}
+
+void orc_pyexp_sph_fields(const orc_slgrid *g, const orc_sph_params *P, const double *coef, long n,
+                          const double *c1, const double *c2, const double *c3, int coord,
+                          double *out)
+{
+  const int lmax = g->lmax, nmax = g->nmax;
+  double *factorial = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *dend = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *potd = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *dpot = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *legs = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *dlegs = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  /* expui/BiorthBasis.cc:323-329 */
+  for (int l = 0; l <= lmax; l++)
+    for (int m = 0; m <= lmax; m++) {
+      double v = 0.0;
+      if (m <= l) {
+        v = sqrt((0.5 * l + 0.25) / M_PI * exp(lgamma(1.0 + l - m) - lgamma(1.0 + l + m)));
+        if (m != 0) v *= M_SQRT2;
+      }
+      factorial[l * (lmax + 1) + m] = v;
+    }
+  for (long i = 0; i < n; i++) {
+    double v[9];
+    double *o = out + 9 * i;
+    if (coord == 0) {
+      pyexp_sph_eval(g, P, coef, factorial, c1[i], c2[i], c3[i], dend, potd, dpot, legs, dlegs, o);
+      continue;
+    }
+    double R, z, phi, x = 0.0, y = 0.0;
+    if (coord == 1) { R = c1[i]; z = c2[i]; phi = c3[i]; }
+    else {                                     /* crt_eval */
+      x = c1[i]; y = c2[i]; z = c3[i];
+      R = sqrt(x * x + y * y) + 1.0e-18;
+      phi = atan2(y, x);
+    }
+    /* cyl_eval */
+    double r = sqrt(R * R + z * z) + 1.0e-18;
+    double costh = z / r, sinth = R / r;
+    pyexp_sph_eval(g, P, coef, factorial, r, costh, phi, dend, potd, dpot, legs, dlegs, v);
+    double potR = v[6] * sinth - v[7] * costh * R / r;
+    double potz = v[6] * costh + v[7] * sinth * R / r;
+    for (int k = 0; k < 6; k++) o[k] = v[k];
+    if (coord == 1) { o[6] = potR; o[7] = potz; o[8] = v[8]; }
+    else {
+      o[6] = potR * x / R - v[8] * y / R;
+      o[7] = potR * y / R + v[8] * x / R;
+      o[8] = potz;
+    }
+  }
+  free(factorial); free(dend); free(potd); free(dpot); free(legs); free(dlegs);
+}

@@ -128,6 +128,13 @@ void   orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int 
                               double *pot, const double *mass, int *level, const double *center,
                               double *coefN, double *coefL, double *coef_out);
 
+/* pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958): out[n][9] =
+ * {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, force x3 in the input coordinates};
+ * coord 0: (r, cos theta, phi), 1: (R, z, phi), 2: (x, y, z).                                  */
+void   orc_pyexp_sph_fields(const orc_slgrid *g, const orc_sph_params *P, const double *coef,
+                            long n, const double *c1, const double *c2, const double *c3,
+                            int coord, double *out);
+
 #ifdef __cplusplus
 }
 #endif

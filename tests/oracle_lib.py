@@ -134,6 +134,18 @@ class Oracle:
                                            _dp(c), _dp(coef), ctypes.c_int(int(kahan)))
         return coef, int(used)
 
+    def sph_fields(self, g, prm, coef, c1, c2, c3, coord="cartesian"):
+        """pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958) -> [n, 9]."""
+        G = self.grid(g)
+        a, b, c = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (c1, c2, c3)]
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        out = np.zeros((len(a), 9))
+        code = {"spherical": 0, "cylindrical": 1, "cartesian": 2}[coord]
+        self.lib.orc_pyexp_sph_fields(ctypes.byref(G), ctypes.byref(prm), _dp(cf),
+                                      ctypes.c_long(len(a)), _dp(a), _dp(b), _dp(c),
+                                      ctypes.c_int(code), _dp(out))
+        return out
+
     def sph_accel(self, g, prm, pos, coef, center=(0.0, 0.0, 0.0)):
         G = self.grid(g)
         n = pos.shape[0]

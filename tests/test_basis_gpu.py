@@ -132,6 +132,41 @@ def test_get_accel_matches_oracle_inside_rmax(halo_basis, oracle):
     assert np.allclose(one, acc[0], rtol=0, atol=1e-14 * np.abs(acc[0]).max())
 
 
+def test_get_fields_matches_oracle(halo_basis, oracle):
+    """getFields / __call__ in the three coordinate systems (Spherical::crt_eval, cyl_eval, sph_eval,
+    expui/BiorthBasis.cc:711-958) against the oracle's restatement; includes points beyond rmax
+    (pyEXP extrapolates the tables linearly there) and the labels of BiorthBasis.cc:71-97."""
+    basis, _ = halo_basis
+    rng = np.random.default_rng(8)
+    pos = rng.normal(0, 0.3, (3000, 3))
+    pos[:, 2] *= 0.5
+    m = np.full(3000, 1.0 / 3000)
+    basis.set_coefs(basis.createFromArray(m, pos))
+    prm = oracle.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+    coef = basis.force.get_coefs()
+    test = rng.normal(0, 0.5, (800, 3))
+    test[:5] *= 8.0                                     # a few points outside rmax
+    x, y, z = test.T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(test, axis=1)
+    for ctype, args in (("cartesian", (x, y, z)), ("cylindrical", (R, z, ph)),
+                        ("spherical", (r, z / r, ph))):
+        got = basis(*args, ctype)
+        ref = oracle.sph_fields(basis.grid, prm, coef, *args, ctype)
+        scale = np.abs(ref).max(axis=0)
+        assert np.abs(got - ref).max(axis=0).max() <= 1e-9 * scale.max()
+        assert np.all(np.abs(got - ref).max(axis=0) <= 1e-8 * scale + 1e-300)
+    f1 = basis.getFields(x[7], y[7], z[7])
+    assert f1.shape == (9,) and np.allclose(f1, basis.getFields(x, y, z)[7], rtol=0, atol=1e-13)
+    vals, labels = basis.evaluate(x[7], y[7], z[7])
+    assert labels == ["dens m=0", "dens m>0", "dens", "potl m=0", "potl m>0", "potl",
+                      "x force", "y force", "z force"]
+    assert basis.getFieldLabels("spherical")[6:] == ["rad force", "mer force", "azi force"]
+    # inside rmax the Cartesian force is the acceleration getAccel returns
+    ins = r < 0.9 * basis.rmax
+    acc = basis.getAccel(test[ins])
+    assert np.abs(basis.getFields(x, y, z)[ins, 6:9] - acc).max() <= 1e-9 * np.abs(acc).max()
+
+
 def test_cylinder_basis(tmp_path):
     """tests/Disk/cyl_basis.py shape (smaller fiducial orders so that it builds in seconds)."""
     from exp_amd.basis import Basis

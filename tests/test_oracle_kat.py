@@ -152,6 +152,45 @@ def test_monopole_of_background_model(oracle, plummer_s6):
         assert ph == pytest.approx(float(model.pot(r)), rel=5e-3)
 
 
+def test_pyexp_fields_known_answers(oracle):
+    """Spherical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:711-958).
+    (i) With only c(l=0,n=0) set, the basis being built on (rho0, Phi0) with u_00 = const, density
+    and potential are the SAME multiple K of the background model's rho0(r), Phi0(r) and the radial
+    force is -K M(r)/r^2.  (ii) Cartesian force and potential equal the n-body path's
+    acceleration and potential (src/SphericalBasis.cc:1476-1660) for the same coefficients inside
+    rmax.  (iii) The three coordinate systems are rotations of one another."""
+    model, g = make_grid("plummer", 4, 8, 400)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef = np.zeros(((g.lmax + 1) ** 2, g.nmax))
+    coef[0, 0] = 0.7
+    r = np.geomspace(0.02, 5.0, 40)      # (the tables are linear lerps: steeper falls need finer grids)
+    f = oracle.sph_fields(g, prm, coef, r, np.full_like(r, 0.3), np.full_like(r, 1.1), "spherical")
+    K = f[:, 5] / model.pot(r)
+    assert np.abs(K / K[0] - 1.0).max() < 2e-4
+    assert np.abs(f[:, 2] / model.dens(r) / K - 1.0).max() < 2e-3
+    assert np.abs(f[:, 6] / (-K * model.mass(r) / r ** 2) - 1.0).max() < 2e-3
+    assert np.abs(f[:, 7]).max() < 1e-12 and np.abs(f[:, 8]).max() < 1e-12
+    # (ii) general coefficients vs the n-body evaluation
+    rng = np.random.default_rng(12)
+    coef = rng.standard_normal(coef.shape) * 0.1
+    pos = rng.standard_normal((300, 3)) * np.array([2.0, 1.5, 0.8])
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, coef)
+    fc = oracle.sph_fields(g, prm, coef, pos[:, 0], pos[:, 1], pos[:, 2], "cartesian")
+    assert np.abs(fc[:, 6:9] - a_ref).max() <= 1e-9 * np.abs(a_ref).max()
+    assert np.abs(fc[:, 5] - p_ref).max() <= 1e-10 * np.abs(p_ref).max()
+    assert np.abs(fc[:, 0] + fc[:, 1] - fc[:, 2]).max() <= 1e-14 * np.abs(fc[:, 2]).max()
+    # (iii) cylindrical and spherical components of the same points
+    R = np.hypot(pos[:, 0], pos[:, 1]); ph = np.arctan2(pos[:, 1], pos[:, 0]); rr = np.hypot(R, pos[:, 2])
+    fy = oracle.sph_fields(g, prm, coef, R, pos[:, 2], ph, "cylindrical")
+    fs = oracle.sph_fields(g, prm, coef, rr, pos[:, 2] / rr, ph, "spherical")
+    fR = fc[:, 6] * np.cos(ph) + fc[:, 7] * np.sin(ph)
+    assert np.abs(fy[:, 6] - fR).max() <= 1e-9 * np.abs(a_ref).max()
+    assert np.abs(fy[:, 7] - fc[:, 8]).max() <= 1e-9 * np.abs(a_ref).max()
+    fr = (fc[:, 6:9] * pos).sum(1) / rr
+    assert np.abs(fs[:, 6] - fr).max() <= 1e-9 * np.abs(a_ref).max()
+    assert np.abs(fs[:, :6] - fc[:, :6]).max() <= 1e-12 * np.abs(fc[:, :6]).max()
+
+
 def test_rotation_about_z(oracle, plummer_small):
     """Rotating the particle set by alpha about z rotates every (cos, sin) row pair by m*alpha."""
     model, g = plummer_small

@@ -8,7 +8,7 @@ OBJ=build/obj_$SUF
 mkdir -p $OBJ
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics $EXTRA"
 pids=()
-for f in context particles sph cyl host force_api; do
+for f in context particles sph sph_fields cyl host force_api; do
   hipcc $FLAGS -c exp_amd/csrc/$f.hip -o $OBJ/$f.o 2>/dev/null &
   pids+=($!)
 done
