@@ -190,3 +190,46 @@ def test_two_component_step_matches_oracle_pieces(ctx, oracle):
     assert np.abs(o2["vel"] - v2).max() <= 1e-9 * np.abs(v2).max()
     assert np.abs(o1["acc"] - A1n).max() <= 1e-9 * s1
     assert np.abs(o2["acc"] - A2n).max() <= 1e-9 * s2
+
+
+def test_reference_halo_virial_check(ctx):
+    """The reference's own N-body acceptance test (tests/CMakeLists.txt expNbodyTest +
+    expNbodyCheck2TW, tests/Halo/config.yml, tests/Halo/check.py): 10000 bodies drawn from
+    tests/Halo/SLGridSph.model, sphereSL (numr 4000, Lmax 2, nmax 10, rmapping 0.0667, rmin 1e-4,
+    rmax 1.95), dtime 0.002, multistep 4, dynfracV 0.05 / dynfracA 0.03, 500 steps; the mean of
+    OUTLOG's 2T/VC column (-2 T / sum m x.a, src/OutLog.cc:494, :598; written every 10 steps) must
+    satisfy (mean - 1)^2 <= 0.003.  Same data file and keys here; the bodies come from
+    exp_amd.models.sample_sphere (isotropic Jeans dispersions) instead of utils/ICs/gensph."""
+    import os
+    from exp_amd.models import TableModel, sample_sphere
+    from exp_amd.runtime import Component, Simulation, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    model = TableModel(os.path.join(os.path.dirname(__file__), "golden", "SLGridSph.model"))
+    g = build_slgrid(model, 2, 10, numr=4000, rmin=0.0001, rmax=1.95, cmap=1, rmap=0.0667,
+                     nel=40, P=8)
+    m, pos, vel = sample_sphere(model, 10000, seed=20260101, rlim=1.95)
+    f = SphereSL(ctx, g, multistep=4)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    dyn = [1.0e32, 0.05, 1.00, 0.03, 0.05]           # D, V, S, A, P (src/global.cc:76-80 + config.yml)
+    sim = Simulation(ctx, 0.002, multistep=4, dynfrac=dyn, shiftlevl=0)
+    sim.add_component(c, f)
+    sim.init()
+
+    def ratio():
+        o = c.download()
+        ek = 0.5 * (o["mass"] * (o["vel"] ** 2).sum(1)).sum()
+        clausius = (o["mass"] * (o["pos"] * o["acc"]).sum(1)).sum()
+        return -2.0 * ek / clausius
+
+    vals = [ratio()]
+    for _ in range(50):
+        sim.step(10)
+        vals.append(ratio())
+    mean = float(np.mean(vals))
+    print(f"2T/VC: mean {mean:.5f}, std {np.std(vals):.5f}, first {vals[0]:.5f}, last {vals[-1]:.5f}")
+    assert (mean - 1.0) ** 2 <= 0.003                # the reference's criterion
+    assert abs(mean - 1.0) < 0.03 and np.std(vals) < 0.03
+    lev = np.bincount(c.download_levels(), minlength=5)
+    assert lev.sum() == 10000
+    c.close()
+    f.close()

@@ -91,9 +91,14 @@ def main():
         c, f = halo()
         f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
         dt = timed(lambda: f.step_kdk(c, 0.002), args.steps, args.warmup)
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(4):
+            f.step_kdk(c, 0.002)
+        prof = {k: round(v["ms_total"] / 4, 3) for k, v in ctx.profile_report().items()}
+        ctx.profile(False)
         out.append({"config": "2: 1e7 NFW halo, SphericalSL lmax 6 nmax 18", "n": n,
                     "ms_per_step": 1e3 * dt, "particle_steps_per_s": n / dt,
-                    "hbm_frac_232B": 232.0 * n / dt / 8e12})
+                    "hbm_frac_232B": 232.0 * n / dt / 8e12, "kernels_ms_per_step": prof})
         c.close(); f.close()
     a, h = 0.01, 0.001
     if args.only in (0, 3, 4):
@@ -107,9 +112,14 @@ def main():
         f = Cylinder(ctx, cg)
         f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
         dt = timed(lambda: f.step_kdk(c, 2e-5), args.steps, args.warmup)
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(4):
+            f.step_kdk(c, 2e-5)
+        prof = {k: round(v["ms_total"] / 4, 3) for k, v in ctx.profile_report().items()}
+        ctx.profile(False)
         out.append({"config": "3: 1e7 exponential disk, EmpCylSL mmax 6 nmax 12 (256x128 grid)",
                     "n": n, "ms_per_step": 1e3 * dt, "particle_steps_per_s": n / dt,
-                    "hbm_frac_232B": 232.0 * n / dt / 8e12})
+                    "hbm_frac_232B": 232.0 * n / dt / 8e12, "kernels_ms_per_step": prof})
         c.close(); f.close()
     if args.only in (0, 4):
         ms = 4
