@@ -264,6 +264,12 @@ def main():
                     "step_achieved": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9,
                     "step_frac": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernels_ms_per_step": {k: v["ms_total"] / args.steps for k, v in kern.items()}}
+            # The binding limit of this kernel is the fp64 vector ALU:
+            # executed flops per particle from the ISA (1024 FMA + 349 mul/add per lane at lmax 10).
+            if dom == "k_sph_force" and args.lmax == 10:
+                tf = 2397.0 * nloc / (avg_ms * 1e-3) / 1e12
+                roof["fp64_vector"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
+                                       "frac": tf / 78.6, "flops_per_particle": 2397.0}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(grid, model, args.cpu_sample, args.dt)

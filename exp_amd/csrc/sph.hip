@@ -387,7 +387,6 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   {
-    ProfScope ps(ctx, "k_sph_force");
     unsigned grid = cdiv(t->n, 256);   // one 64-particle chunk per wave, no loop
     const size_t need = t->n / 64 + 8;
     if (f->work_cap < need) {
@@ -398,7 +397,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream,
-                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0,
+                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0, ctx,
                    prekey ? t->key.p : nullptr, nk_dtk, nk_dtd};
     k_force_launch[f->cfg.lmax](a);
   }

@@ -1118,6 +1118,7 @@ struct SphForceArgs {
   hipStream_t stream;
   uint32_t *work, *nwork;   // slow-path work list (first slot of each deferred wave) + count
   int all_slow;             // target is not in this force's cell order: skip the fast pass
+  exp_amd_ctx *ctx;         // for the per-launch profiling scopes
   uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
   double nk_dtk, nk_dtd;    // ... for that step's kick and drift
 };
