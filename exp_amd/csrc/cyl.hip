@@ -98,7 +98,7 @@ struct CylKeyFn {
 
 #define CFLUSH_STRIDE 68
 #define CACC_WAVES 4
-#define CACC_CHUNK 1024
+#define CACC_CHUNK_MAX 1024   // particles per wave chunk; sparse multistep levels get shorter ones
 
 // reduce NV per-lane values over the wave and atomically add value j to dst[map(j)]
 template <int NV, class MapFn>
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(CACC_WAVES * 64)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ Wn, double *__restrict__ tail)
+                 double *__restrict__ Wn, double *__restrict__ tail, int CACC_CHUNK)
 {
   constexpr int NT = 2 * MMAX + 1;
   constexpr int NV = 4 * NT;
@@ -695,12 +695,22 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->d_Wn.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dst + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
   const int lo = f->multistep ? f->mlevel : 0, hi = lo;
-  if (c->n) {
+  size_t nrange = c->n;      // population of the accumulated level: sizes the grid and the chunks
+  if (c->n && f->multistep) {
+    int rc = expamd_comp_level_count(c, lo, hi, &nrange);
+    if (rc) return rc;
+  }
+  if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate");
-    const unsigned grid = cdiv(c->n, (size_t)CACC_WAVES * CACC_CHUNK);
+    // >= ~6 rounds of blocks (as in the spherical launcher); sparse levels pay one flush per cell
+    // change, serial within a wave, so they get short chunks and many waves
+    size_t chunk = (nrange / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
+    chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
+    if (!f->multistep) chunk = CACC_CHUNK_MAX;
+    const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
 #define CALL(MM)                                                                                 \
   k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef)
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef, (int)chunk)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }

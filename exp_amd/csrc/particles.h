@@ -21,6 +21,10 @@ struct exp_amd_comp {
   double center[3] = {0, 0, 0};
   const void *sorted_for = nullptr;  // force whose cell order the store currently has
   bool acc_live = true;              // acc/pot must survive a reorder
+  // host mirror of lev_off (refreshed lazily after a full re-sort: one small read-back), so that
+  // launches over ONE level can be sized for that level's population
+  uint32_t lev_host[66] = {0};
+  bool lev_host_valid = false;
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
   // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
   bool prekey_valid = false;
@@ -31,3 +35,5 @@ struct exp_amd_comp {
   double *b(int k) { return arr[1 - cur][k].p; }
 };
 
+// number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
+int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);

@@ -174,6 +174,20 @@ int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
   return EXP_AMD_OK;
 }
 
+int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->nlevels <= 1) { *count = c->n; return EXP_AMD_OK; }
+  if (!c->lev_host_valid) {
+    HIP_TRY(ctx, hipMemcpyAsync(c->lev_host, c->lev_off.p, (size_t)(c->nlevels + 1) * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->lev_host_valid = true;
+  }
+  *count = (size_t)c->lev_host[hi + 1] - (size_t)c->lev_host[lo];
+  return EXP_AMD_OK;
+}
+
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
 {
   AdvanceArgs A;
@@ -223,6 +237,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
   {
     ProfScope ps(ctx, "k_scan");
     k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level);
+    if (level < 0) c->lev_host_valid = false;
   }
   {
     ProfScope ps(ctx, "k_scatter_adv");
@@ -384,6 +399,7 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
   for (int i = 0; i < 64; i++) lo[i] = (uint32_t)n;
   lo[0] = 0;
   HIP_TRY(ctx, hipMemcpyAsync(c->lev_off.p, lo, sizeof(lo), hipMemcpyHostToDevice, ctx->stream));
+  c->lev_host_valid = false;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *out = c;
   return EXP_AMD_OK;

@@ -315,10 +315,15 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   SphDev S = dev_for(f, c->center);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), ctx->stream));
-  if (c->n) {
+  size_t nrange = c->n;      // particles of the level(s) accumulated: sizes the grid and the chunks
+  if (c->n && f->multistep) {
+    int rc = expamd_comp_level_count(c, lo, hi, &nrange);
+    if (rc) return rc;
+  }
+  if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
     SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi,
-                 f->d_W.p, f->d_used.p, c->n, ctx->stream, f->multistep ? 1 : 0};
+                 f->d_W.p, f->d_used.p, nrange, ctx->stream, f->multistep ? 1 : 0};
     k_acc_launch[f->cfg.lmax](a);
   }
   {

@@ -14,10 +14,12 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   constexpr int LMAX = SPH_L;
   constexpr int NS = acc_nsplit<LMAX>();
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;
-  // chunk: as large as ACC_CHUNK_MAX while >= ~6 rounds of blocks remain (2 blocks x 256 CUs)
-  size_t chunk = (a.n / ((size_t)CPB * 3072)) & ~(size_t)255;
-  chunk = chunk < ACC_CHUNK_MIN ? ACC_CHUNK_MIN : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
-  if (a.multilevel) chunk = ACC_CHUNK_MIN;   // a sparse level must still spread over the CUs
+  // chunk: as large as ACC_CHUNK_MAX while >= ~6 rounds of blocks remain (2 blocks x 256 CUs).
+  // a.n is the population of the level range, so a sparse multistep level (a few particles per
+  // cell: one flush per cell change, serial within a wave) gets short chunks and many waves.
+  size_t chunk = (a.n / ((size_t)CPB * 3072)) & ~(size_t)63;
+  const size_t cmin = a.multilevel ? 64 : ACC_CHUNK_MIN;
+  chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
   const unsigned nchunk = cdiv(a.n, chunk);
   dim3 grid(cdiv(nchunk, CPB), (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
   k_sph_accumulate<LMAX><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
