@@ -67,6 +67,7 @@ SIGNATURES = {
     "exp_amd_comp_zero_acc": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p)]),
+    "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
     "exp_amd_sph_fields": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

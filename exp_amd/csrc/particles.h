@@ -23,6 +23,7 @@ struct exp_amd_comp {
   bool acc_live = true;              // acc/pot must survive a reorder
   // host mirror of lev_off (refreshed lazily after a full re-sort: one small read-back), so that
   // launches over ONE level can be sized for that level's population
+  DevBuf<double> com_lev, com_red;   // per-level sums of m, m x, m v, m a (fix_positions) / all-reduce scratch
   uint32_t lev_host[66] = {0};
   bool lev_host_valid = false;
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one

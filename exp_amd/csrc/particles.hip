@@ -419,6 +419,8 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
   c->nswitch.release();
   c->hist.release();
   c->lev_off.release();
+  c->com_lev.release();
+  c->com_red.release();
   delete c;
 }
 
@@ -600,5 +602,91 @@ extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
   k_zero_acc<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
       c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->lev_off.p, lo, hi);
   HIP_TRY(c->ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+// ---- centre of mass / velocity / acceleration (Component::fix_positions) -----------------------------
+// src/Component.cc:3280-3351 (thread body: per-level sums of m, m x, m v, m a over the levels
+// >= mlevel), :3354-3554 (levels below mlevel keep their previous sums, all-reduce over ranks,
+// division by the total mass).  Escape/tidal bookkeeping (consp), frozen particles and the EJ
+// orientation centre are outside this path.
+#define COM_MAXLEV 16
+__global__ void __launch_bounds__(256)
+k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
+             const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
+             const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
+             const double *__restrict__ AZ, const uint8_t *__restrict__ lev, size_t n, int mlevel,
+             int nlev, double *__restrict__ out /* [nlev][10] */)
+{
+  __shared__ double acc[COM_MAXLEV][10];
+  for (int k = threadIdx.x; k < COM_MAXLEV * 10; k += 256) (&acc[0][0])[k] = 0.0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int L = nlev > 1 ? lev[i] : 0;
+    if (L < mlevel) continue;
+    const double m = M[i];
+    double v[10] = {m, m * X[i], m * Y[i], m * Z[i], m * VX[i], m * VY[i], m * VZ[i],
+                    m * AX[i], m * AY[i], m * AZ[i]};
+#pragma unroll
+    for (int k = 0; k < 10; k++) unsafeAtomicAdd(&acc[L][k], v[k]);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nlev * 10; k += 256) {
+    const double s = (&acc[0][0])[k];
+    if (s != 0.0) unsafeAtomicAdd(out + k, s);
+  }
+}
+
+extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10])
+{
+  if (!c || !out) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  const int nlev = c->nlevels;
+  if (nlev > COM_MAXLEV) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "fix_positions: more than %d levels", COM_MAXLEV);
+  if (mlevel < 0) mlevel = 0;
+  if (mlevel >= nlev) mlevel = nlev - 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!c->com_lev.p) {
+    if (c->com_lev.alloc(COM_MAXLEV * 10) != hipSuccess)
+      return expamd_fail(ctx, EXP_AMD_ERR_HIP, "fix_positions: hipMalloc failed");
+    HIP_TRY(ctx, hipMemsetAsync(c->com_lev.p, 0, c->com_lev.bytes(), ctx->stream));
+    mlevel = 0;                           // nothing cached yet
+  }
+  // zero the level sums at and above mlevel (:3363-3369), then re-accumulate them
+  HIP_TRY(ctx, hipMemsetAsync(c->com_lev.p + (size_t)mlevel * 10, 0,
+                              (size_t)(nlev - mlevel) * 10 * sizeof(double), ctx->stream));
+  if (c->n) {
+    ProfScope ps(ctx, "k_com_levels");
+    unsigned grid = cdiv(c->n, 256 * 16);
+    if (grid > 2048) grid = 2048;
+    k_com_levels<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX),
+                                               c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
+                                               c->a(A_AZ), c->level[c->cur].p, c->n, mlevel, nlev,
+                                               c->com_lev.p);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  // sum the levels on the host side of one small read-back; ranks are combined first (:3500-3503)
+  double host[COM_MAXLEV * 10];
+  if (ctx->nranks > 1 || ctx->ar_fn) {
+    // reduce a scratch copy so that the cached per-level sums stay rank-local
+    if (!c->com_red.p && c->com_red.alloc(COM_MAXLEV * 10) != hipSuccess)
+      return expamd_fail(ctx, EXP_AMD_ERR_HIP, "fix_positions: hipMalloc failed");
+    HIP_TRY(ctx, hipMemcpyAsync(c->com_red.p, c->com_lev.p, (size_t)nlev * 10 * sizeof(double),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = expamd_allreduce(ctx, c->com_red.p, (size_t)nlev * 10);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host, c->com_red.p, (size_t)nlev * 10 * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(host, c->com_lev.p, (size_t)nlev * 10 * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 10; k++) out[k] = 0.0;
+  for (int L = 0; L < nlev; L++)
+    for (int k = 0; k < 10; k++) out[k] += host[L * 10 + k];
+  if (out[0] > 0.0)                       // :3541-3545
+    for (int k = 1; k < 10; k++) out[k] /= out[0];
   return EXP_AMD_OK;
 }

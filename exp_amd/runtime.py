@@ -201,6 +201,14 @@ class Component:
     def zero_acceleration(self, mlevel: int = 0) -> None:
         check(self.lib.exp_amd_comp_zero_acc(self.h, int(mlevel)), self.ctx.h)
 
+    def fix_positions(self, mlevel: int = 0) -> dict:
+        """``Component::fix_positions`` (src/Component.cc:3280-3554): total mass and the centres
+        of mass, velocity and acceleration; levels below ``mlevel`` keep their last sums."""
+        out = (c_double * 10)()
+        check(self.lib.exp_amd_comp_fix_positions(self.h, int(mlevel), out), self.ctx.h)
+        v = np.array(out[:])
+        return {"mtot": float(v[0]), "com": v[1:4].copy(), "cov": v[4:7].copy(), "coa": v[7:10].copy()}
+
     def close(self) -> None:
         if self.h:
             self.lib.exp_amd_comp_destroy(self.h)

@@ -100,6 +100,14 @@ int  exp_amd_comp_kick (exp_amd_comp *c, double dt, int mlevel);
  * (src/ComponentContainer.cc:641-665): acc = pot = 0 for levels >= mlevel.         */
 int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
 
+/* Centre of mass / velocity / acceleration of the component: replaces Component::fix_positions
+ * (src/Component.cc:3280-3554; CUDA twin src/cudaComponent.cu:800-933) without the
+ * escape/tidal bookkeeping, frozen particles and the orientation centre.  Only the levels
+ * >= mlevel are re-summed (the others keep their previous per-level sums, as the reference
+ * does); ranks are combined with the context's all-reduce.  out = {mtot, com[3], cov[3], coa[3]}
+ * (the three vectors divided by mtot when mtot > 0).                                        */
+int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
+
 /* ---- spherical force method (sphereSL) -----------------------------------------------
  * Replaces class Sphere : SphericalBasis (src/Sphere.cc:28-96, src/SphericalBasis.cc)
  * given the SLGridSph tables (exputil/SLGridMP2.cc: ev, ef, p0 on the xi grid).     */

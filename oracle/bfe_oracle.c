@@ -1006,3 +1006,32 @@ void orc_pyexp_sph_fields(const orc_slgrid *g, const orc_sph_params *P, const do
   }
   free(factorial); free(dend); free(potd); free(dpot); free(legs); free(dlegs);
 }
+
+/* ---- Component::fix_positions ---------------------------------------------------------------
+ * src/Component.cc:3280-3351 (per-level sums over the levels >= mlevel; escape/tidal and frozen
+ * particles not modelled), :3363-3369 (only those levels are zeroed first), :3485-3503 (levels
+ * summed), :3541-3545 (division by the total mass).  lev_sums[(multistep+1)][10] carries the
+ * per-level {m, m x, m v, m a} sums between calls, as com_mas / com_lev / cov_lev / coa_lev do.  */
+void orc_fix_positions(long n, const double *mass, const double *x, const double *y, const double *z,
+                       const double *vx, const double *vy, const double *vz, const double *ax,
+                       const double *ay, const double *az, const int *level, int multistep,
+                       int mlevel, double *lev_sums, double *out)
+{
+  for (int mm = mlevel; mm <= multistep; mm++)
+    for (int k = 0; k < 10; k++) lev_sums[mm * 10 + k] = 0.0;
+  for (int mm = mlevel; mm <= multistep; mm++) {
+    double *s = lev_sums + mm * 10;
+    for (long i = 0; i < n; i++) {
+      if ((level ? level[i] : 0) != mm) continue;
+      s[0] += mass[i];
+      s[1] += mass[i] * x[i];  s[2] += mass[i] * y[i];  s[3] += mass[i] * z[i];
+      s[4] += mass[i] * vx[i]; s[5] += mass[i] * vy[i]; s[6] += mass[i] * vz[i];
+      s[7] += mass[i] * ax[i]; s[8] += mass[i] * ay[i]; s[9] += mass[i] * az[i];
+    }
+  }
+  for (int k = 0; k < 10; k++) out[k] = 0.0;
+  for (int mm = 0; mm <= multistep; mm++)
+    for (int k = 0; k < 10; k++) out[k] += lev_sums[mm * 10 + k];
+  if (out[0] > 0.0)
+    for (int k = 1; k < 10; k++) out[k] /= out[0];
+}

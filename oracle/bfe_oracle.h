@@ -128,6 +128,13 @@ void   orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int 
                               double *pot, const double *mass, int *level, const double *center,
                               double *coefN, double *coefL, double *coef_out);
 
+/* Component::fix_positions (src/Component.cc:3280-3554): out = {mtot, com, cov, coa};
+ * lev_sums[(multistep+1)][10] persists between calls (levels < mlevel are not re-summed).     */
+void   orc_fix_positions(long n, const double *mass, const double *x, const double *y,
+                         const double *z, const double *vx, const double *vy, const double *vz,
+                         const double *ax, const double *ay, const double *az, const int *level,
+                         int multistep, int mlevel, double *lev_sums, double *out);
+
 /* pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958): out[n][9] =
  * {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, force x3 in the input coordinates};
  * coord 0: (r, cos theta, phi), 1: (R, z, phi), 2: (x, y, z).                                  */

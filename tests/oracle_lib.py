@@ -134,6 +134,17 @@ class Oracle:
                                            _dp(c), _dp(coef), ctypes.c_int(int(kahan)))
         return coef, int(used)
 
+    def fix_positions(self, mass, pos, vel, acc, level, multistep, mlevel, lev_sums):
+        """src/Component.cc:3280-3554; lev_sums [(multistep+1), 10] is updated in place."""
+        cols = [np.ascontiguousarray(a[:, k], dtype=np.float64) for a in (pos, vel, acc) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        lv = np.ascontiguousarray(level, dtype=np.int32)
+        out = np.zeros(10)
+        self.lib.orc_fix_positions(ctypes.c_long(len(m)), _dp(m), *[_dp(c) for c in cols],
+                                   lv.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(multistep),
+                                   ctypes.c_int(mlevel), _dp(lev_sums), _dp(out))
+        return out
+
     def sph_fields(self, g, prm, coef, c1, c2, c3, coord="cartesian"):
         """pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958) -> [n, 9]."""
         G = self.grid(g)

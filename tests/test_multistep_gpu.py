@@ -233,3 +233,49 @@ def test_reference_halo_virial_check(ctx):
     assert lev.sum() == 10000
     c.close()
     f.close()
+
+
+def test_fix_positions_matches_oracle(ctx, oracle):
+    """Component::fix_positions (src/Component.cc:3280-3554): total mass, centre of mass, velocity and
+    acceleration; with multistep only the levels >= mlevel are re-summed, the others keep the sums of
+    the previous call (here made visibly stale by moving the particles in between)."""
+    from exp_amd.runtime import Component
+    rng = np.random.default_rng(17)
+    n, ms = 50000, 3
+    m = rng.uniform(0.5, 1.5, n) / n
+    pos, vel, acc = rng.standard_normal((3, n, 3))
+    pos += np.array([0.3, -0.1, 0.05])
+    lev = rng.integers(0, ms + 1, n).astype(np.int32)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(acc, np.zeros(n))
+    # single level
+    got = c.fix_positions(0)
+    sums = np.zeros((1, 10))
+    ref = oracle.fix_positions(m, pos, vel, acc, np.zeros(n, np.int32), 0, 0, sums)
+    vec = np.concatenate([[got["mtot"]], got["com"], got["cov"], got["coa"]])
+    assert np.abs(vec - ref).max() <= 1e-12 * np.abs(ref).max()
+    c.close()
+    # multistep: level-resolved sums with caching below mlevel
+    from exp_amd.runtime import SphereSL
+    _, g = make_grid("plummer", 4, 8, 400)
+    f = SphereSL(ctx, g, multistep=ms)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(acc, np.zeros(n))
+    c.upload_levels(lev)
+    f.set_multistep_level(0)
+    f.determine_coefficients(c)          # establishes the (level, cell) order with ms+1 levels
+    sums = np.zeros((ms + 1, 10))
+    ref0 = oracle.fix_positions(m, pos, vel, acc, lev, ms, 0, sums)
+    got0 = c.fix_positions(0)
+    vec0 = np.concatenate([[got0["mtot"]], got0["com"], got0["cov"], got0["coa"]])
+    assert np.abs(vec0 - ref0).max() <= 1e-12 * np.abs(ref0).max()
+    c.incr_position(0.25)                # x += v dt for every level
+    pos2 = pos + vel * 0.25
+    ref2 = oracle.fix_positions(m, pos2, vel, acc, lev, ms, 2, sums)   # levels 0,1 stay stale
+    got2 = c.fix_positions(2)
+    vec2 = np.concatenate([[got2["mtot"]], got2["com"], got2["cov"], got2["coa"]])
+    assert np.abs(vec2 - ref2).max() <= 1e-12 * np.abs(ref2).max()
+    fresh = oracle.fix_positions(m, pos2, vel, acc, lev, ms, 0, np.zeros((ms + 1, 10)))
+    assert np.abs(fresh[1:4] - ref2[1:4]).max() > 1e-6          # the stale levels do matter
+    c.close()
+    f.close()
