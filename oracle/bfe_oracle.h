@@ -5,12 +5,15 @@
  * arithmetic of the reference's CPU thread bodies (file:line citations are relative
  * to the EXP source tree and are given on every function in bfe_oracle.c).
  *
- * PARITY UNPINNED: the reference ships no golden vectors / known-answer values for
- * coefficients or accelerations and cannot be compiled in
- * this image (needs Eigen, yaml-cpp, HighFive, FFTW, gfortran).  The oracle is
- * therefore pinned only by (i) line-by-line correspondence with the cited code and
- * (ii) the analytic known-answer tests under tests/ (orthogonality, shell theorem,
- * rotation/reflection symmetry, multipole continuity, leapfrog reversibility).
+ * PARITY UNPINNED for coefficients and accelerations: the reference ships no golden vectors /
+ * known-answer values for them and its C++ cannot be compiled in this
+ * image (needs Eigen, yaml-cpp, HighFive, FFTW).  The oracle is therefore pinned by (i) line-by-
+ * line correspondence with the cited code, (ii) the analytic known-answer tests under tests/
+ * (orthogonality, shell theorem, rotation/reflection symmetry, multipole continuity, leapfrog
+ * reversibility, Newton's theorem at 1e7 particles), (iii) the reference's own N-body acceptance
+ * criterion (tests/Halo: mean 2T/VC) run on the device path, and (iv) for the TABLES only, the
+ * reference's own Fortran SL solver exputil/sledge.f, which does build here (flang) into
+ * oracle/_ref/ and agrees with exp_amd/slgrid.py to its tolerance (tests/test_ref_sledge.py).
  *
  * Nothing under exp_amd/ may include, link or call this file.  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
