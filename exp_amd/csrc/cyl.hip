@@ -408,7 +408,8 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
             int lev_hi, const double *__restrict__ TF, const double *__restrict__ cylmass_p,
             double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
             double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
-            double *__restrict__ VZ, double dt_kick, int assign)
+            double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ key_out,
+            double nk_dtk, double nk_dtd)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   const int lane = threadIdx.x & 63;
@@ -494,9 +495,21 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   AZ[i] = fz;
   POT[i] = pa;
   if (dt_kick != 0.0) {
-    VX[i] = mul_then_add(VX[i], fx, dt_kick);
-    VY[i] = mul_then_add(VY[i], fy, dt_kick);
-    VZ[i] = mul_then_add(VZ[i], fz, dt_kick);
+    const double vx = mul_then_add(VX[i], fx, dt_kick);
+    const double vy = mul_then_add(VY[i], fy, dt_kick);
+    const double vz = mul_then_add(VZ[i], fz, dt_kick);
+    VX[i] = vx; VY[i] = vy; VZ[i] = vz;
+    if (key_out) {
+      // the sort key this particle will have after the NEXT fused step's kick + drift (the
+      // arithmetic of advance_one on the values just stored): that step then only histograms
+      // the 4-byte keys (exp_amd_step_kdk, see sph_kernels.h for the spherical twin)
+      const double wx = mul_then_add(vx, fx, nk_dtk);
+      const double wy = mul_then_add(vy, fy, nk_dtk);
+      const double wz = mul_then_add(vz, fz, nk_dtk);
+      CylKeyFn kf{C};
+      key_out[i] = kf(mul_then_add(X[i], wx, nk_dtd), mul_then_add(Y[i], wy, nk_dtd),
+                      mul_then_add(Z[i], wz, nk_dtd), 0);
+    }
   }
 }
 
@@ -525,7 +538,7 @@ struct CylForce : exp_amd_force {
     return EXP_AMD_OK;
   }
   int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-           int level = -1);
+           int level = -1, bool have_keys = false);
   void release() override
   {
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
@@ -605,7 +618,7 @@ __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ 
 }
 
 int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-                   int level)
+                   int level, bool have_keys)
 {
   CylForce *f = this;
   if (c->n == 0) return EXP_AMD_OK;
@@ -615,7 +628,11 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
   const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
   int rc = expamd_comp_prepare_hist(c, nkeys);
   if (rc) return rc;
-  {
+  if (have_keys && level < 0) {
+    // c->key was written by the previous fused step's force pass for exactly this advance
+    ProfScope ps(ctx, "k_hist_keys");
+    k_hist_keys<<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+  } else {
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
@@ -676,7 +693,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 }
 
 int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
-                                     bool /*have_keys: never produced by this force*/)
+                                     bool have_keys)
 {
   CylForce *f = this;
   f->home = c;
@@ -684,7 +701,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                           ? f->mlevel : -1;
-    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift, level);
+    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift, level, have_keys);
     if (rc) return rc;
   }
   // ---- accumulate ----------------------------------------------------------------------------------
@@ -734,11 +751,14 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double, double,
-                         bool *prekey_done)
+int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk,
+                         double nk_dtd, bool *prekey_done)
 {
   CylForce *f = this;
   if (prekey_done) *prekey_done = false;
+  // next step's keys: single level, own (sorted) particles, fused half-kick only
+  const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&
+                      t->nlevels == 1 && f->multistep == 0 && t->sorted_for == f;
   if (f->proj_dirty) {
     ProfScope ps(ctx, "k_cyl_project");
     k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(
@@ -759,12 +779,13 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
       t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
-      dt_kick, assign ? 1 : 0)
+      dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
+  if (prekey) *prekey_done = true;
   return EXP_AMD_OK;
 }
 

@@ -148,3 +148,40 @@ def test_cyl_kdk_step(ctx, oracle):
         ascale = np.linalg.norm(a_ref, axis=1).max()
         assert np.abs(o["acc"] - a_ref).max() <= ACC_TOL * ascale
         assert np.abs(o["vel"] - v).max() <= 1e-9 * np.abs(v).max()
+
+
+def test_cyl_fused_steps_reuse_keys(ctx):
+    """Several fused steps in a row (the force pass writes the next step's sort keys) against the
+    unfused call-for-call sequence, including a dt change and an interleaved call that must
+    discard the recorded keys."""
+    from exp_amd.runtime import Component, Cylinder, do_step_single
+    g = cyl_grid(4, 6)
+    m, pos, vel = _disk(20000, 23, g)
+    vel = vel + 0.01 * np.random.default_rng(2).standard_normal(vel.shape)
+    dts = [1e-4, 1e-4, 1e-4, 4e-5, 4e-5, 1e-4]
+
+    def run(kind):
+        f = Cylinder(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        for k, dt in enumerate(dts):
+            if kind == "unfused":
+                do_step_single(f, c, dt)
+            else:
+                f.step_kdk(c, dt)
+                if kind == "touched" and k in (1, 3):
+                    c.incr_velocity(0.0)
+        out = c.download()
+        cs = f.get_coefs()
+        c.close()
+        f.close()
+        return out, cs
+
+    ref, cref = run("unfused")
+    for kind in ("fused", "touched"):
+        out, cs = run(kind)
+        assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-14
+        assert np.abs(out["vel"] - ref["vel"]).max() <= 1e-9 * np.abs(ref["vel"]).max()
+        ascale = np.linalg.norm(ref["acc"], axis=1).max()
+        assert np.abs(out["acc"] - ref["acc"]).max() <= ACC_TOL * ascale
+        for a, b in zip(cs, cref):
+            assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
