@@ -12,6 +12,7 @@ The reference cannot be built or imported in this image, 
 come from the oracle (oracle/bfe_oracle.c, oracle/cyl_oracle.c), whose correspondence with the
 reference is argued line by line there and pinned by tests/test_oracle_kat.py.  They freeze the
 oracle's answers so that any later change to oracle OR device code that moves a result is caught.
+sph_fields.npz: see make_fields() (python tests/golden/make_golden.py fields).
 SLGridSph.model is the reference's own data file (tests/Halo/SLGridSph.model), copied verbatim.
 """
 import os
@@ -77,5 +78,33 @@ def main():
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 
+def make_fields():
+    """sph_fields.npz : pyEXP field evaluation (getFields) at 60 points in the three coordinate
+    systems + a fix_positions vector, for the grid / coefficients / particles frozen in
+    sph_small.npz (which is NOT regenerated here)."""
+    from tests.golden_util import load_sph
+    orc = Oracle()
+    g, z = load_sph()
+    prm = orc.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    rng = np.random.default_rng(4242)
+    pts = rng.standard_normal((60, 3)) * np.array([2.0, 1.5, 0.8])
+    pts[:4] *= 30.0                                   # beyond rmax: pyEXP extrapolates the tables
+    x, y, zz = pts.T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(pts, axis=1)
+    crt = orc.sph_fields(g, prm, z["coef"], x, y, zz, "cartesian")
+    cyl = orc.sph_fields(g, prm, z["coef"], R, zz, ph, "cylindrical")
+    sph = orc.sph_fields(g, prm, z["coef"], r, zz / r, ph, "spherical")
+    sums = np.zeros((1, 10))
+    com = orc.fix_positions(z["mass"], z["pos"], z["vel"], z["acc"], np.zeros(len(z["mass"]), np.int32),
+                            0, 0, sums)
+    np.savez_compressed(os.path.join(HERE, "sph_fields.npz"), points=pts, crt=crt, cyl=cyl, sph=sph,
+                        fix_positions=com)
+    print("wrote sph_fields.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fields":
+        make_fields()
+    else:
+        main()
+        make_fields()

@@ -35,3 +35,21 @@ def test_arbiter_mode_agrees_with_plain_sum(oracle):
     c0, _ = oracle.sph_accumulate(g, prm, z["pos"], z["mass"])
     c1, _ = oracle.sph_accumulate(g, prm, z["pos"], z["mass"], kahan=True)
     assert np.abs(c0 - c1).max() <= 1e-14 * np.abs(c0).max()
+
+
+def test_oracle_matches_field_golden(oracle):
+    """getFields (sph_eval / cyl_eval / crt_eval) and fix_positions against the frozen vectors."""
+    import os
+    from tests.golden_util import load_sph
+    g, z = load_sph()
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "sph_fields.npz"))
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    x, y, zz = f["points"].T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(f["points"], axis=1)
+    for key, args, ctype in (("crt", (x, y, zz), "cartesian"), ("cyl", (R, zz, ph), "cylindrical"),
+                             ("sph", (r, zz / r, ph), "spherical")):
+        got = oracle.sph_fields(g, prm, z["coef"], *args, ctype)
+        assert np.abs(got - f[key]).max() <= 1e-13 * np.abs(f[key]).max()
+    com = oracle.fix_positions(z["mass"], z["pos"], z["vel"], z["acc"],
+                               np.zeros(len(z["mass"]), np.int32), 0, 0, np.zeros((1, 10)))
+    assert np.abs(com - f["fix_positions"]).max() <= 1e-15 * np.abs(f["fix_positions"]).max()

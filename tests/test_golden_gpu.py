@@ -55,3 +55,26 @@ def test_cyl_golden(ctx):
     ascale = np.linalg.norm(z["acc"][ok], axis=1).max()
     assert np.abs(out["acc"][ok] - z["acc"][ok]).max() <= 1e-9 * ascale
     assert np.abs(out["pot"][ok] - z["pot"][ok]).max() <= 1e-9 * np.abs(z["pot"][ok]).max()
+
+
+def test_sph_fields_and_fix_positions_golden(ctx):
+    """Device getFields in the three coordinate systems and fix_positions vs the frozen vectors."""
+    import os
+    from exp_amd.runtime import Component, SphereSL
+    g, z = load_sph()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sph_fields.npz"))
+    f = SphereSL(ctx, g)
+    f.set_coefs(z["coef"])
+    f.lib.exp_amd_sph_set_exterior(f.h, 0)
+    x, y, zz = gold["points"].T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(gold["points"], axis=1)
+    for key, args, ctype in (("crt", (x, y, zz), "cartesian"), ("cyl", (R, zz, ph), "cylindrical"),
+                             ("sph", (r, zz / r, ph), "spherical")):
+        got = f.fields(*args, ctype)
+        scale = np.abs(gold[key]).max(axis=0)
+        assert np.all(np.abs(got - gold[key]).max(axis=0) <= 1e-9 * scale + 1e-300)
+    c = Component.from_arrays(ctx, z["mass"], z["pos"], z["vel"])
+    c.upload_acc(z["acc"], z["pot"])
+    got = c.fix_positions(0)
+    vec = np.concatenate([[got["mtot"]], got["com"], got["cov"], got["coa"]])
+    assert np.abs(vec - gold["fix_positions"]).max() <= 1e-12 * np.abs(gold["fix_positions"]).max()
