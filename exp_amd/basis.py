@@ -373,6 +373,19 @@ class SphericalSL(BiorthBasis):
     def evaluate(self, x, y, z):
         return self.getFields(x, y, z), self.getFieldLabels("cartesian")
 
+    def getFieldsCoefs(self, x, y, z, coefs):
+        """``Basis::getFieldsCoefs`` (expui/BasisFactory.cc:236-265): the fields at one point for
+        every coefficient set of a ``Coefs`` container -> ({label: array over time}, times)."""
+        times = coefs.Times()
+        labels = self.getFieldLabels(self.coordinates)
+        ret = {s: np.zeros(len(times)) for s in labels}
+        for i, t in enumerate(times):
+            self.set_coefs(coefs.getCoefStruct(t))
+            v = self.getFields(x, y, z)          # crt_eval, as the reference does
+            for j, s in enumerate(labels):
+                ret[s][i] = v[j]
+        return ret, np.asarray(times)
+
 
 class Cylindrical(BiorthBasis):
     """``cylinder`` (expui/BiorthBasis.cc Cylindrical): YAML keys acyl, hcyl, mmax, nmax, ncylnx,

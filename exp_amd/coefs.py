@@ -1,0 +1,199 @@
+"""Coefficient sets in time: EXP's native coefficient stream format and the ``Coefs`` container.
+
+What the reference does either side of the hot path with the coefficients it produces:
+
+* ``SphericalBasis::dump_coefs(ostream&)`` (src/SphericalBasis.cc:1829-1904) appends one record per
+  dump to ``outcoef.<name>.<runtag>``: magic ``0xc0a57a2``, a YAML header (id, time, scale, nmax,
+  lmax, normed) and the doubles ordered ``[n][l][m: cos, (sin)]``; the legacy layout is the 88-byte
+  ``SphCoefHeader`` (include/coef.H:18-25) followed by the same doubles, un-normalised.
+* ``CoefClasses::SphStruct::read`` (expui/CoefStruct.cc:372-506) parses both into the complex
+  ``[(L+1)(L+2)/2, nmax]`` array (m >= 0), ``SphCoefs::readNativeCoefs`` (expui/Coefficients.cc:
+  796-838) collects them by (rounded) time, ``Coefs::interpolate`` (:183-226) blends the two
+  bracketing sets linearly -- which is what ``determine_coefficients_playback``
+  (src/SphericalBasis.cc:612-680) feeds to the force evaluation.
+
+HDF5 coefficient files (``WriteH5Coefs``) need HighFive/h5py, which this image does not have; the
+native stream format is complete for the spherical basis.  Host-side only: nothing here touches
+the device.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import BinaryIO, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .basis import SphStruct
+
+CMAGIC = 0x0C0A57A2                  # src/SphericalBasis.H:368
+_LEGACY = struct.Struct("<64sddii")  # SphCoefHeader: id[64], tnow, scale, nmax, Lmax
+
+
+def round_time(t: float) -> float:
+    """expui/BasisFactory.H roundTime / Coefficients.H: 8 decimal places."""
+    return math.floor(t * 1.0e8 + 0.5) / 1.0e8
+
+
+def real_rows_to_complex(expcoef: np.ndarray, lmax: int) -> np.ndarray:
+    """(L+1)^2 x nmax real rows (src/SphericalBasis.cc:513-590 order) -> complex (l, m>=0) rows."""
+    nmax = expcoef.shape[1]
+    out = np.zeros(((lmax + 1) * (lmax + 2) // 2, nmax), dtype=np.complex128)
+    L = off = 0
+    for l in range(lmax + 1):
+        for m in range(l + 1):
+            if m == 0:
+                out[L] = expcoef[off]
+                off += 1
+            else:
+                out[L] = expcoef[off] + 1j * expcoef[off + 1]
+                off += 2
+            L += 1
+    return out
+
+
+def complex_to_real_rows(coefs: np.ndarray, lmax: int) -> np.ndarray:
+    nmax = coefs.shape[1]
+    out = np.zeros(((lmax + 1) ** 2, nmax))
+    L = off = 0
+    for l in range(lmax + 1):
+        for m in range(l + 1):
+            out[off] = coefs[L].real
+            off += 1
+            if m:
+                out[off] = coefs[L].imag
+                off += 1
+            L += 1
+    return out
+
+
+def write_native(out: BinaryIO, c: SphStruct, force_id: str = "sphereSL") -> None:
+    """One record in the new-style native format (src/SphericalBasis.cc:1831-1879)."""
+    import yaml
+    hdr = yaml.safe_dump({"id": force_id, "time": float(c.time), "scale": float(c.scale),
+                          "nmax": int(c.nmax), "lmax": int(c.lmax), "normed": True},
+                         default_flow_style=False, sort_keys=False).encode()
+    out.write(struct.pack("<II", CMAGIC, len(hdr)))
+    out.write(hdr)
+    # [n][l][m]: cos, then sin for m > 0  == the real-row order, n-major
+    rows = complex_to_real_rows(np.asarray(c.coefs), c.lmax)
+    out.write(np.ascontiguousarray(rows.T, dtype="<f8").tobytes())
+
+
+def read_native_record(inp: BinaryIO, exp_type: bool = True) -> Optional[SphStruct]:
+    """``SphStruct::read``: returns None at end of stream."""
+    import yaml
+    head = inp.read(4)
+    if len(head) < 4:
+        return None
+    normed = False
+    if struct.unpack("<I", head)[0] == CMAGIC:
+        raw = inp.read(4)
+        if len(raw) < 4:
+            return None
+        (hsize,) = struct.unpack("<I", raw)
+        node = yaml.safe_load(inp.read(hsize).decode())
+        lmax, nmax = int(node["lmax"]), int(node["nmax"])
+        time, scale = float(node["time"]), float(node["scale"])
+        normed = bool(node.get("normed", False))
+    else:
+        rest = inp.read(_LEGACY.size - 4)
+        if len(rest) < _LEGACY.size - 4:
+            return None
+        _id, time, scale, nmax, lmax = _LEGACY.unpack(head + rest)
+    nrow = (lmax + 1) ** 2
+    buf = inp.read(8 * nrow * nmax)
+    if len(buf) < 8 * nrow * nmax:
+        return None
+    rows = np.frombuffer(buf, dtype="<f8").reshape(nmax, nrow).T.copy()
+    if exp_type and not normed:
+        # true normed coefficients from a legacy dump (expui/CoefStruct.cc:481-503); the factor of
+        # each (l, m) is applied to its own cosine and sine rows
+        off = 0
+        for l in range(lmax + 1):
+            for m in range(l + 1):
+                fac = math.sqrt((0.5 * l + 0.25) / math.pi
+                                * math.exp(math.lgamma(1.0 + l - m) - math.lgamma(1.0 + l + m)))
+                if m:
+                    fac *= math.sqrt(2.0)
+                rows[off] *= fac
+                off += 1
+                if m:
+                    rows[off] *= fac
+                    off += 1
+    return SphStruct(lmax, nmax, scale, time, real_rows_to_complex(rows, lmax), np.zeros(3),
+                     np.eye(3))
+
+
+class SphCoefs:
+    """``CoefClasses::SphCoefs``: spherical coefficient sets keyed by (rounded) time."""
+
+    geometry = "sphere"
+
+    def __init__(self, name: str = ""):
+        self.name = name
+        self.coefs: Dict[float, SphStruct] = {}
+        self.deltaT = 0.01                       # expui/Coefficients.H:133
+
+    def setDeltaT(self, dT: float) -> None:
+        self.deltaT = float(dT)
+
+    # -- container (expui/Coefficients.H) -------------------------------------------------------
+    def add(self, c: SphStruct) -> None:
+        self.coefs[round_time(c.time)] = c
+
+    def Times(self) -> List[float]:
+        return sorted(self.coefs)
+
+    def getCoefStruct(self, time: float) -> SphStruct:
+        try:
+            return self.coefs[round_time(time)]
+        except KeyError:
+            raise RuntimeError(f"SphCoefs: no coefficients at time {time}") from None
+
+    def getAllCoefs(self) -> np.ndarray:
+        """[(L+1)(L+2)/2, nmax, ntimes] complex (SphCoefs::getAllCoefs)."""
+        return np.stack([np.asarray(self.coefs[t].coefs) for t in self.Times()], axis=2)
+
+    # -- native stream files ---------------------------------------------------------------------
+    @classmethod
+    def readNativeCoefs(cls, path: str, stride: int = 1, tmin: float = -math.inf,
+                        tmax: float = math.inf, name: str = "") -> "SphCoefs":
+        """expui/Coefficients.cc:796-838"""
+        self = cls(name)
+        count = 0
+        with open(path, "rb") as f:
+            while True:
+                c = read_native_record(f)
+                if c is None:
+                    break
+                keep = count % stride == 0
+                count += 1
+                if keep and tmin <= c.time <= tmax:
+                    self.add(c)
+        return self
+
+    def writeNativeCoefs(self, path: str, append: bool = False) -> None:
+        with open(path, "ab" if append else "wb") as f:
+            for t in self.Times():
+                write_native(f, self.coefs[t])
+
+    # -- playback --------------------------------------------------------------------------------
+    def interpolate(self, time: float) -> Tuple[np.ndarray, bool]:
+        """``Coefs::interpolate`` (expui/Coefficients.cc:183-226), statement for statement: the pair
+        is (lower_bound, lower_bound + 1) -- NOT the bracketing pair when ``time`` lies strictly
+        between two stored times, where the reference extrapolates linearly from the two sets at
+        and after ``time`` -- or the last two sets at and beyond the end.  The flag is the
+        reference's off-grid test (its count of 8 tolerated attempts is not kept here)."""
+        times = self.Times()
+        if len(times) < 2:
+            raise RuntimeError("SphCoefs.interpolate: need at least two coefficient sets")
+        on_grid = not (time < times[0] - self.deltaT or time > times[-1] + self.deltaT)
+        it = int(np.searchsorted(times, time, side="left"))          # std::lower_bound
+        if it >= len(times) - 1:
+            hi, lo = len(times) - 1, len(times) - 2
+        else:
+            lo, hi = it, it + 1
+        A = (times[hi] - time) / (times[hi] - times[lo])
+        B = (time - times[lo]) / (times[hi] - times[lo])
+        return A * np.asarray(self.coefs[times[lo]].coefs) + B * np.asarray(self.coefs[times[hi]].coefs), on_grid

@@ -304,6 +304,15 @@ class SphereSL(_Force):
     def set_coefs(self, coef) -> None:
         self._set_flat(coef)
 
+    def dump_coefs(self, out, time: float = 0.0, scale: Optional[float] = None) -> None:
+        """``SphericalBasis::dump_coefs(ostream&)`` (src/SphericalBasis.cc:1829-1879): append the
+        current coefficient set to a native coefficient stream (binary file object)."""
+        from .basis import SphStruct
+        from .coefs import real_rows_to_complex, write_native
+        c = SphStruct(self.lmax, self.nmax, self.cfg.scale if scale is None else scale, time,
+                      real_rows_to_complex(self.get_coefs(), self.lmax), np.zeros(3), np.eye(3))
+        write_native(out, c)
+
     FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
 
     def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:

@@ -197,3 +197,45 @@ parameters:
     assert coefs.coefs.shape == (5, 6) and coefs.time == 0.5
     acc = basis.getAccel(np.array([[0.02, 0.0, 0.0], [0.0, 0.03, 0.001]]))
     assert acc[0, 0] < 0 and acc[1, 1] < 0 and np.all(np.isfinite(acc))
+
+
+def test_coefficient_stream_playback_and_fields_over_time(halo_basis, tmp_path):
+    """dump_coefs (native stream) of a short run -> SphCoefs.readNativeCoefs -> playback through
+    set_coefs gives back the run's own forces; getFieldsCoefs evaluates a point over time
+    (src/SphericalBasis.cc:612-680, :1829-1879; expui/BasisFactory.cc:236-265)."""
+    from exp_amd.coefs import SphCoefs, complex_to_real_rows
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component
+    basis, _ = halo_basis
+    f = basis.force
+    m, pos, vel = sample_sphere(basis.model, 20000, seed=3, rlim=1.9)
+    c = Component.from_arrays(basis.ctx, m, pos, vel)
+    path = str(tmp_path / "outcoef.halo.run0")
+    dt, accs, sets = 0.002, {}, {}
+    f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
+    with open(path, "wb") as out:
+        for k in range(4):
+            f.step_kdk(c, dt)
+            t = round((k + 1) * dt, 8)
+            f.dump_coefs(out, time=t)
+            sets[t] = f.get_coefs()
+            accs[t] = c.download(("acc", "pos"))
+    coefs = SphCoefs.readNativeCoefs(path)
+    assert coefs.Times() == sorted(sets)
+    for t in coefs.Times():
+        assert np.array_equal(complex_to_real_rows(coefs.getCoefStruct(t).coefs, basis.lmax), sets[t])
+    # playback: the stored set at time t reproduces that step's accelerations on the same positions
+    t = coefs.Times()[2]
+    basis.set_coefs(coefs.getCoefStruct(t))
+    ins = np.linalg.norm(accs[t]["pos"], axis=1) < 0.95 * basis.rmax
+    got = basis.getAccel(accs[t]["pos"][ins])
+    assert np.abs(got - accs[t]["acc"][ins]).max() <= 1e-9 * np.abs(accs[t]["acc"]).max()
+    # interpolation in time at a stored time is that set; fields of one point over all times
+    arr, ok = coefs.interpolate(t)
+    assert ok and np.allclose(arr, coefs.getCoefStruct(t).coefs, rtol=0, atol=1e-15 * np.abs(arr).max())
+    basis.setFieldType("cartesian")
+    ret, times = basis.getFieldsCoefs(0.1, -0.05, 0.02, coefs)
+    assert list(times) == coefs.Times() and set(ret) == set(basis.getFieldLabels("cartesian"))
+    basis.set_coefs(coefs.getCoefStruct(times[1]))
+    assert ret["potl"][1] == pytest.approx(basis.getFields(0.1, -0.05, 0.02)[5], rel=1e-13)
+    c.close()

@@ -1,0 +1,83 @@
+"""EXP's native coefficient stream format and the Coefs container (exp_amd/coefs.py): host-side
+data formats either side of the hot path (src/SphericalBasis.cc:1829-1904, expui/CoefStruct.cc:
+372-506, expui/Coefficients.cc:183-226, :796-838).  CPU only."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+
+def _sets(lmax=3, nmax=5, times=(0.0, 0.1, 0.2, 0.3), seed=1):
+    from exp_amd.basis import SphStruct
+    from exp_amd.coefs import SphCoefs, real_rows_to_complex
+    rng = np.random.default_rng(seed)
+    cs = SphCoefs("halo")
+    rows = {}
+    for t in times:
+        rows[t] = rng.standard_normal(((lmax + 1) ** 2, nmax))
+        cs.add(SphStruct(lmax, nmax, 0.5, t, real_rows_to_complex(rows[t], lmax), np.zeros(3), np.eye(3)))
+    return cs, rows
+
+
+def test_native_roundtrip_and_layout(tmp_path):
+    from exp_amd.coefs import CMAGIC, SphCoefs, complex_to_real_rows
+    cs, rows = _sets()
+    path = str(tmp_path / "outcoef.halo.run0")
+    cs.writeNativeCoefs(path)
+    raw = open(path, "rb").read()
+    magic, hsize = struct.unpack("<II", raw[:8])
+    assert magic == CMAGIC == 0xc0a57a2
+    import yaml
+    hdr = yaml.safe_load(raw[8:8 + hsize].decode())
+    assert hdr["lmax"] == 3 and hdr["nmax"] == 5 and hdr["normed"] is True and hdr["scale"] == 0.5
+    # the doubles are [n][row] with rows in the reference's real order (cos, sin interleaved)
+    first = np.frombuffer(raw[8 + hsize:8 + hsize + 8 * 16 * 5], dtype="<f8").reshape(5, 16)
+    assert np.array_equal(first.T, rows[0.0])
+    back = SphCoefs.readNativeCoefs(path)
+    assert back.Times() == [0.0, 0.1, 0.2, 0.3]
+    assert np.array_equal(back.getAllCoefs(), cs.getAllCoefs())
+    assert np.array_equal(complex_to_real_rows(back.getCoefStruct(0.2).coefs, 3), rows[0.2])
+    sub = SphCoefs.readNativeCoefs(path, stride=2, tmin=0.05)
+    assert sub.Times() == [0.2]
+
+
+def test_legacy_header_is_normalised(tmp_path):
+    """88-byte SphCoefHeader records (include/coef.H:18-25) hold un-normalised coefficients: the
+    reader applies sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!) [x sqrt 2 for m > 0]."""
+    from exp_amd.coefs import SphCoefs, complex_to_real_rows
+    lmax, nmax = 2, 3
+    rows = np.arange(9 * 3, dtype=np.float64).reshape(9, 3) + 1.0
+    path = str(tmp_path / "legacy.coef")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<64sddii", b"sphereSL", 1.25, 1.0, nmax, lmax))
+        f.write(np.ascontiguousarray(rows.T, dtype="<f8").tobytes())
+    c = SphCoefs.readNativeCoefs(path).getCoefStruct(1.25)
+    got = complex_to_real_rows(c.coefs, lmax)
+    off = 0
+    for l in range(lmax + 1):
+        for m in range(l + 1):
+            fac = math.sqrt((2 * l + 1) / (4 * math.pi) * math.factorial(l - m) / math.factorial(l + m))
+            if m:
+                fac *= math.sqrt(2.0)
+            for _ in range(1 if m == 0 else 2):
+                assert np.allclose(got[off], rows[off] * fac, rtol=1e-14)
+                off += 1
+
+
+def test_interpolate_follows_the_reference():
+    """Coefs::interpolate picks (lower_bound, lower_bound+1): exact at stored times, the last pair
+    at/after the end, and -- strictly between two stored times -- a linear EXTRAPOLATION from the
+    two sets at and after `time` (the reference's behaviour, expui/Coefficients.cc:199-213)."""
+    cs, _ = _sets()
+    c = {t: np.asarray(cs.getCoefStruct(t).coefs) for t in cs.Times()}
+    a, ok = cs.interpolate(0.1)
+    assert ok and np.allclose(a, c[0.1], rtol=0, atol=1e-15)
+    a, ok = cs.interpolate(0.15)
+    assert ok and np.allclose(a, 1.5 * c[0.2] - 0.5 * c[0.3], rtol=0, atol=1e-14)
+    a, ok = cs.interpolate(0.25)                    # lower_bound = last element -> (0.2, 0.3)
+    assert ok and np.allclose(a, 0.5 * c[0.2] + 0.5 * c[0.3], rtol=0, atol=1e-14)
+    a, ok = cs.interpolate(0.35)
+    assert not ok and np.allclose(a, -0.5 * c[0.2] + 1.5 * c[0.3], rtol=0, atol=1e-14)
+    with pytest.raises(RuntimeError):
+        cs.getCoefStruct(0.123)
