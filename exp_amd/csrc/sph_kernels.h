@@ -533,9 +533,19 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 // m-range splits of the rows (keep 2 moment accumulators per real row in registers).  The waves
 // of a block take the SAME particle chunk and one split each, so the chunk is fetched from HBM
 // once and re-read from L1/L2 by the other splits.
+// Shared-input path (3 <= LMAX <= 10): the four waves of a block take ONE chunk, compute the
+// per-particle inputs of a quarter of every 256-particle tile once, share them through LDS and
+// reduce one m-range each: [0,b1), [b1,b2), [b2,b3), [b3,LMAX] (rows/costs roughly balanced).
+template <int LMAX> __host__ __device__ constexpr bool acc_shared() { return LMAX >= 3 && LMAX <= 10; }
+template <int LMAX> __host__ __device__ constexpr int acc_bound(int k)
+{
+  constexpr int B[11][3] = {{1, 1, 1}, {1, 1, 1}, {1, 2, 2}, {1, 2, 3}, {1, 2, 3}, {1, 2, 3},
+                            {1, 2, 4}, {1, 2, 4}, {2, 4, 6}, {2, 4, 6}, {2, 4, 6}};
+  return B[LMAX <= 10 ? LMAX : 10][k];
+}
 template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
 {
-  return LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
+  return acc_shared<LMAX>() ? 4 : LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
 }
 
 template <int LMAX>
@@ -551,7 +561,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const int wave = threadIdx.x >> 6;
   double *scratch = scratch_all[wave];
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  if constexpr (NS == ACC_WAVES && LMAX > 7 && LMAX <= 10) {
+  if constexpr (acc_shared<LMAX>()) {
     // one chunk per block, shared per-particle inputs, balanced m-ranges (31/34/26/30 rows at L=10)
     __shared__ AccShared sh;
     // The per-particle input chain (sqrt, divisions, cell, P0 interpolation) is latency-bound and
@@ -568,11 +578,12 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
 #define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, cbeg, cend, scratch, sh, W, used_out)
-    if (wave == 0) RUNS(0, 1); else if (wave == 1) RUNS(2, 3); else if (wave == 2) RUNS(4, 5);
-    else RUNS(6, LMAX);
+    constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
+    if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
+    else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
 #undef RUNS
     return;
-  }
+  } else {
   const int split = (NS <= ACC_WAVES) ? wave % NS : (int)(blockIdx.y * ACC_WAVES + wave);
   const size_t chunk = (NS <= ACC_WAVES) ? (size_t)blockIdx.x * CPB + wave / NS : blockIdx.x;
   if (split >= NS) return;
@@ -592,6 +603,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     else if (split == 3) RUN(4, 5); else if (split == 4) RUN(6, 8); else RUN(9, LMAX);
   }
 #undef RUN
+  }
 }
 
 // ---- multistep level change: coefficient differencing -----------------------------------------------------
