@@ -218,7 +218,7 @@ int  exp_amd_sph_fields(exp_amd_force *f, size_t n, const double *c1, const doub
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.
  * Same results as the unfused sequence of calls above; fewer passes over HBM: kick and
  * drift are applied inside the cell-sort passes, the second half-kick inside the force
- * pass, which (spherical force) also records where each particle will be after the NEXT
+ * pass, which also records where each particle will be after the NEXT
  * call's kick+drift, so that consecutive calls with the same dt skip the key pass.  Any
  * other call on the component in between (upload, kick, drift, set_center, zero_acc,
  * another force, a different dt) discards that record.                                */

@@ -185,3 +185,46 @@ def test_cyl_fused_steps_reuse_keys(ctx):
         assert np.abs(out["acc"] - ref["acc"]).max() <= ACC_TOL * ascale
         for a, b in zip(cs, cref):
             assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
+
+
+def test_cyl_full_size_properties(ctx):
+    """BASELINE config 3 size (1e7 exponential-disk particles, mmax 6, nmax 12, 256 x 128 grid;
+    the helper basis of the table build is reduced -- table accuracy does not enter these
+    size-independent properties): linearity of the accumulation in the particle set (coefficients,
+    on-grid mass, used count) and invariance to particle order."""
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    from exp_amd.runtime import Component, Cylinder
+    g = build_empcyl(mmax=6, norder=12, numx=256, numy=128, acyl=0.01, hcyl=0.001, lmaxfid=16,
+                     nmaxfid=12, numr=800, rnum=100, tnum=40)
+    n = 10_000_000
+    m, pos, _ = sample_disk(n, 34567, a=g.ascale, h=g.hscale)
+    pos[:, 0] *= 1.1
+    f = Cylinder(ctx, g)
+
+    def coefs(p, w):
+        c = Component.from_arrays(ctx, w, p)
+        f.multistep_reset()
+        f.determine_coefficients(c)
+        cc, ss = f.get_coefs()
+        out = (cc, ss, f.Used(), f.cylmass)
+        c.close()
+        return out
+
+    c_all, s_all, u_all, m_all = coefs(pos, m)
+    k = 3_700_000
+    c_a, s_a, u_a, m_a = coefs(pos[:k], m[:k])
+    c_b, s_b, u_b, m_b = coefs(pos[k:], m[k:])
+    scale = np.abs(c_all).max()
+    assert u_a + u_b == u_all
+    assert abs(m_a + m_b - m_all) <= 1e-12 * m_all
+    assert np.abs(c_a + c_b - c_all).max() <= COEF_TOL * scale
+    assert np.abs(s_a + s_b - s_all).max() <= COEF_TOL * scale
+    perm = np.random.default_rng(11).permutation(n)
+    c_p, s_p, u_p, m_p = coefs(pos[perm], m[perm])
+    assert u_p == u_all and abs(m_p - m_all) <= 1e-12 * m_all
+    assert np.abs(c_p - c_all).max() <= COEF_TOL * scale
+    assert np.abs(s_p - s_all).max() <= COEF_TOL * scale
+    # the monopole coefficient of an (almost) axisymmetric disk dominates the m > 0 rows
+    assert np.abs(c_all[0]).max() > 5 * np.abs(c_all[3:]).max()
+    f.close()
