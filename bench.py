@@ -229,6 +229,18 @@ def main():
     prof = ctx.profile_report()
     ctx.profile(False)
 
+    # Full-size sanity of what was just timed (size-independent properties, no oracle): every
+    # particle is inside the expansion window by construction, a self-gravitating system's
+    # total force vanishes (sum m a: here up to the expansion's truncation), its centre of mass
+    # stays put, and the monopole coefficient of a unit-mass halo has the same sign/size at any N.
+    used = force.Used()
+    com = comp.fix_positions(0)          # all-reduced over ranks like the coefficients
+    coef00 = float(force.get_coefs()[0, 0])
+    selfcheck = {"used_rank0": int(used), "particles_rank0": int(nloc),
+                 "center_of_mass": [float(v) for v in com["com"]],
+                 "center_of_acceleration": [float(v) for v in com["coa"]],
+                 "mtot": com["mtot"], "coef_00_0": coef00}
+
     if use_comm:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,6 +307,7 @@ def main():
                                       f" ({args.comm})" if world > 1 else "single GPU"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "selfcheck": selfcheck,
         }
         print(json.dumps(line), flush=True)
 
