@@ -96,6 +96,7 @@ SIGNATURES = {
     "exp_amd_sim_step": (c_int, [c_void_p, c_int]),
     "exp_amd_sim_time": (c_double, [c_void_p]),
     "exp_amd_sim_last_switches": (c_longlong, [c_void_p]),
+    "exp_amd_sim_step_switches": (c_longlong, [c_void_p]),
     "exp_amd_profile_enable": (c_int, [c_void_p, c_int]),
     "exp_amd_profile_get": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double),
                                     POINTER(c_longlong)]),

@@ -20,6 +20,7 @@ struct exp_amd_sim {
   std::vector<std::pair<int, int>> inter;                   // (source, target)
   std::vector<int> mintvl, mfirst;
   long long last_switch = 0;
+  long long step_switch = 0;        // level changes summed over the last exp_amd_sim_step call
 };
 
 extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
@@ -114,6 +115,7 @@ static int adjust_levels(exp_amd_sim *s, int mdrft, int first_step)
                                                   s->shiftlevl, mdrft, first_step, &ns);
     if (rc) return rc;
     s->last_switch += ns;
+    s->step_switch += ns;
   }
   return EXP_AMD_OK;
 }
@@ -140,6 +142,7 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 // do_step (src/step.cc:67-325)
 extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
 {
+  if (s) s->step_switch = 0;
   if (s) for (exp_amd_comp *c : s->comps) c->prekey_valid = false;   // see exp_amd_step_kdk
   if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
   int rc;
@@ -186,3 +189,4 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
 
 extern "C" double exp_amd_sim_time(const exp_amd_sim *s) { return s ? s->tnow : 0.0; }
 extern "C" long long exp_amd_sim_last_switches(const exp_amd_sim *s) { return s ? s->last_switch : 0; }
+extern "C" long long exp_amd_sim_step_switches(const exp_amd_sim *s) { return s ? s->step_switch : 0; }

@@ -421,6 +421,11 @@ class Simulation:
     def last_switches(self) -> int:
         return int(self.lib.exp_amd_sim_last_switches(self.h))
 
+    @property
+    def step_switches(self) -> int:
+        """level changes summed over the sub-steps of the last ``step`` call"""
+        return int(self.lib.exp_amd_sim_step_switches(self.h))
+
     def close(self) -> None:
         if self.h:
             self.lib.exp_amd_sim_destroy(self.h)

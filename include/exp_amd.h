@@ -239,7 +239,8 @@ int  exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target);
 int  exp_amd_sim_init(exp_amd_sim *s);
 int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
 double exp_amd_sim_time(const exp_amd_sim *s);
-long long exp_amd_sim_last_switches(const exp_amd_sim *s);
+long long exp_amd_sim_last_switches(const exp_amd_sim *s);   /* level changes of the last adjustment */
+long long exp_amd_sim_step_switches(const exp_amd_sim *s);   /* ... summed over the last exp_amd_sim_step call */
 
 /* Timing of the last fused step's dominant kernels (ms, HIP events on the context
  * stream); names are static strings.  Used by bench.py for the roofline figure.    */

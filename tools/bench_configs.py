@@ -147,6 +147,7 @@ def main():
                     "master_step_particle_steps_per_s": 2 * n / dt,
                     "raw_particle_substeps_per_s": sub / dt,
                     "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist(),
+                    "level_switches_per_master_step": sim.step_switches,
                     "kernels_ms_per_master_step": prof})
     for o in out:
         print(json.dumps(o), flush=True)
