@@ -49,6 +49,53 @@ __device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t *slot)
   return *slot;
 }
 
+// Wave-aggregated LDS histogram updates.  The store is nearly sorted, so the 64 keys of a wave
+// are mostly equal: 64 lanes adding to ONE LDS word serialise (a 64-way same-address conflict per
+// instruction).  Instead the lanes are grouped by key with ballots and one lane per distinct key
+// adds the group's population.
+__device__ __forceinline__ void wave_hist_add(uint32_t key, bool valid, uint32_t kmin,
+                                              uint32_t *lh, uint32_t *__restrict__ hist)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long rem = __ballot(valid);
+  while (rem) {
+    const int lead = __ffsll((long long)rem) - 1;
+    const uint32_t kk = (uint32_t)__shfl((int)key, lead);
+    const unsigned long long mm = __ballot(valid && key == kk);
+    if (lane == lead) {
+      const uint32_t d = kk - kmin, cnt = (uint32_t)__popcll(mm);
+      if (d < SORT_WIN) atomicAdd(&lh[d], cnt);
+      else atomicAdd(&hist[kk], cnt);
+    }
+    rem &= ~mm;
+  }
+}
+
+// Same grouping for the scatter pass: returns the lane's rank inside its (block, bin) -- the
+// group's base from one LDS atomic plus the number of lower lanes with the same key -- or
+// 0xffffffff when the key lies outside the LDS window (ranked by a global atomic later).
+__device__ __forceinline__ uint32_t wave_rank(uint32_t key, bool valid, uint32_t kmin, uint32_t *lh)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t rk = 0xffffffffu;
+  unsigned long long rem = __ballot(valid);
+  while (rem) {
+    const int lead = __ffsll((long long)rem) - 1;
+    const uint32_t kk = (uint32_t)__shfl((int)key, lead);
+    const unsigned long long mm = __ballot(valid && key == kk);
+    const uint32_t d = kk - kmin;
+    uint32_t base = 0;
+    if (d < SORT_WIN) {
+      if (lane == lead) base = atomicAdd(&lh[d], (uint32_t)__popcll(mm));
+      base = (uint32_t)__shfl((int)base, lead);
+      if (valid && key == kk) rk = base + (uint32_t)__popcll(mm & lt);
+    }
+    rem &= ~mm;
+  }
+  return rk;
+}
+
 // slot range handled by a sort pass: the whole store, or the levels [lo, hi] (device-resident
 // level offsets, so that no host synchronisation is needed to sort one level)
 struct SortRange {
@@ -91,12 +138,7 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
   const uint32_t kmin = block_min_u32(mn, &kmin_s);     // (also orders the zeroing)
 #pragma unroll
-  for (int j = 0; j < SORT_ITEMS; j++) {
-    if (k[j] == 0xffffffffu) continue;
-    const uint32_t d = k[j] - kmin;
-    if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
-    else atomicAdd(&hist[k[j]], 1u);
-  }
+  for (int j = 0; j < SORT_ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist);
   __syncthreads();
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
     const uint32_t c = lh[b];
@@ -123,12 +165,7 @@ k_hist_keys(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ h
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
   const uint32_t kmin = block_min_u32(mn, &kmin_s);
 #pragma unroll
-  for (int j = 0; j < SORT_ITEMS; j++) {
-    if (k[j] == 0xffffffffu) continue;
-    const uint32_t d = k[j] - kmin;
-    if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
-    else atomicAdd(&hist[k[j]], 1u);
-  }
+  for (int j = 0; j < SORT_ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist);
   __syncthreads();
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
     const uint32_t c = lh[b];
@@ -170,12 +207,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
   const uint32_t kmin = block_min_u32(mn, &kmin_s);
   // rank inside (block, bin)
 #pragma unroll
-  for (int j = 0; j < SORT_ITEMS; j++) {
-    rk[j] = 0;
-    if (k[j] == 0xffffffffu) continue;
-    const uint32_t d = k[j] - kmin;
-    if (d < SORT_WIN) rk[j] = atomicAdd(&lh[d], 1u);
-  }
+  for (int j = 0; j < SORT_ITEMS; j++) rk[j] = wave_rank(k[j], k[j] != 0xffffffffu, kmin, lh);
   __syncthreads();
   // reserve the global range of every non-empty bin: lh[b] <- base
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
