@@ -631,12 +631,12 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
   if (have_keys && level < 0) {
     // c->key was written by the previous fused step's force pass for exactly this advance
     ProfScope ps(ctx, "k_hist_keys");
-    k_hist_keys<<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
   } else {
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<CylKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(
+    k_key_hist<CylKeyFn><<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
   }
   rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);

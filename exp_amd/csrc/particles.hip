@@ -246,7 +246,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                  c->level[1 - c->cur].p};
-    const unsigned g = cdiv(c->n, SORT_TILE);
+    const unsigned g = cdiv(c->n, SCAT_TILE);
     const SortRange R = expamd_sort_range(c, level);
     if (move_acc)
       k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);

@@ -272,12 +272,12 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
     // c->key was filled by the previous step's force pass for exactly this advance
     // (exp_amd_step_kdk checks that): pass 1 only counts the 4-byte keys
     ProfScope ps(ctx, "k_hist_keys");
-    k_hist_keys<<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
   } else {
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center)};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<SphKeyFn><<<cdiv(c->n, SORT_TILE), SORT_TPB, 0, ctx->stream>>>(
+    k_key_hist<SphKeyFn><<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
   }
   rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);
