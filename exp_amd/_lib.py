@@ -70,6 +70,8 @@ SIGNATURES = {
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_cyl_set_density": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_cyl_fields": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "exp_amd_sph_fields": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "exp_amd_force_destroy": (None, [c_void_p]),
     "exp_amd_force_set_level": (c_int, [c_void_p, c_int]),

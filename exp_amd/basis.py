@@ -174,6 +174,49 @@ class BiorthBasis:
         acc = self._accel(pos) @ self.coefrot        # rotate back: rot^T a
         return acc[0] if single else acc
 
+    # ---- field evaluation (expui/BasisFactory.cc:218-234, expui/BiorthBasis.cc:71-97, :711-958) ----
+    FIELD_LABELS = ["dens m=0", "dens m>0", "dens", "potl m=0", "potl m>0", "potl"]
+    FORCE_LABELS = {"spherical": ["rad force", "mer force", "azi force"],
+                    "cylindrical": ["rad force", "ver force", "azi force"],
+                    "cartesian": ["x force", "y force", "z force"]}
+    coordinates = "spherical"            # BasisFactory.H: default field type
+
+    def setFieldType(self, coord_type: str) -> None:
+        key = coord_type.strip().lower()
+        if key not in self.FORCE_LABELS:
+            raise RuntimeError(f"Basis: unknown coordinate type <{coord_type}>")
+        self.coordinates = key
+
+    def getFieldLabels(self, ctype: Optional[str] = None):
+        return self.FIELD_LABELS + self.FORCE_LABELS[(ctype or self.coordinates).lower()]
+
+    def __call__(self, x1, x2, x3, ctype: str = "spherical"):
+        """Fields in the requested coordinates: (r, cos theta, phi) | (R, z, phi) | (x, y, z)
+        -> the 9 values of getFieldLabels(ctype); arrays give [N, 9]."""
+        single = np.ndim(x1) == 0
+        out = self.force.fields(x1, x2, x3, ctype.lower())
+        return out[0] if single else out
+
+    def getFields(self, x, y, z):
+        """Basis::getFields -> crt_eval(x, y, z) (expui/BasisFactory.cc:231-234)."""
+        return self(x, y, z, "cartesian")
+
+    def evaluate(self, x, y, z):
+        return self.getFields(x, y, z), self.getFieldLabels("cartesian")
+
+    def getFieldsCoefs(self, x, y, z, coefs):
+        """``Basis::getFieldsCoefs`` (expui/BasisFactory.cc:236-265): the fields at one point for
+        every coefficient set of a ``Coefs`` container -> ({label: array over time}, times)."""
+        times = coefs.Times()
+        labels = self.getFieldLabels(self.coordinates)
+        ret = {s: np.zeros(len(times)) for s in labels}
+        for i, t in enumerate(times):
+            self.set_coefs(coefs.getCoefStruct(t))
+            v = self.getFields(x, y, z)          # crt_eval, as the reference does
+            for j, s in enumerate(labels):
+                ret[s][i] = v[j]
+        return ret, np.asarray(times)
+
 
 class SphericalSL(BiorthBasis):
     """``sphereSL`` (expui/BiorthBasis.H:503): YAML keys Lmax, nmax, numr, rmin, rmax, scale,
@@ -343,53 +386,12 @@ class SphericalSL(BiorthBasis):
         c.close()
         return acc
 
-    # ---- field evaluation (expui/BasisFactory.cc:218-234, expui/BiorthBasis.cc:71-97, :711-958) ----
-    FIELD_LABELS = ["dens m=0", "dens m>0", "dens", "potl m=0", "potl m>0", "potl"]
-    FORCE_LABELS = {"spherical": ["rad force", "mer force", "azi force"],
-                    "cylindrical": ["rad force", "ver force", "azi force"],
-                    "cartesian": ["x force", "y force", "z force"]}
-    coordinates = "spherical"            # BasisFactory.H: default field type
-
-    def setFieldType(self, coord_type: str) -> None:
-        key = coord_type.strip().lower()
-        if key not in self.FORCE_LABELS:
-            raise RuntimeError(f"Basis: unknown coordinate type <{coord_type}>")
-        self.coordinates = key
-
-    def getFieldLabels(self, ctype: Optional[str] = None):
-        return self.FIELD_LABELS + self.FORCE_LABELS[(ctype or self.coordinates).lower()]
-
-    def __call__(self, x1, x2, x3, ctype: str = "spherical"):
-        """Fields in the requested coordinates: (r, cos theta, phi) | (R, z, phi) | (x, y, z)
-        -> the 9 values of getFieldLabels(ctype); arrays give [N, 9]."""
-        single = np.ndim(x1) == 0
-        out = self.force.fields(x1, x2, x3, ctype.lower())
-        return out[0] if single else out
-
-    def getFields(self, x, y, z):
-        """Basis::getFields -> crt_eval(x, y, z) (expui/BasisFactory.cc:231-234)."""
-        return self(x, y, z, "cartesian")
-
-    def evaluate(self, x, y, z):
-        return self.getFields(x, y, z), self.getFieldLabels("cartesian")
-
-    def getFieldsCoefs(self, x, y, z, coefs):
-        """``Basis::getFieldsCoefs`` (expui/BasisFactory.cc:236-265): the fields at one point for
-        every coefficient set of a ``Coefs`` container -> ({label: array over time}, times)."""
-        times = coefs.Times()
-        labels = self.getFieldLabels(self.coordinates)
-        ret = {s: np.zeros(len(times)) for s in labels}
-        for i, t in enumerate(times):
-            self.set_coefs(coefs.getCoefStruct(t))
-            v = self.getFields(x, y, z)          # crt_eval, as the reference does
-            for j, s in enumerate(labels):
-                ret[s][i] = v[j]
-        return ret, np.asarray(times)
-
 
 class Cylindrical(BiorthBasis):
     """``cylinder`` (expui/BiorthBasis.cc Cylindrical): YAML keys acyl, hcyl, mmax, nmax, ncylnx,
     ncylny, rcylmin, rcylmax, lmaxfid, nmaxfid, ncylr, rnum, tnum, cmapr, cmapz, cachename."""
+
+    coordinates = "cylindrical"          # expui/BiorthBasis.cc:1744-1746
 
     name = "cylinder"
 

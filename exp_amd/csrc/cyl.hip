@@ -520,6 +520,7 @@ struct CylForce : exp_amd_force {
   CylDev dev{};
   DevBuf<double> d_tab, d_Wn, d_TF;
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
+  DevBuf<double> d_dens;            // densC / densS tables (field evaluation only)
   DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
   size_t nnode = 0;
@@ -543,6 +544,7 @@ struct CylForce : exp_amd_force {
   {
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
     d_mass.release();
+    d_dens.release();
   }
   int get_used(long long *used) override
   {
@@ -806,5 +808,115 @@ extern "C" int exp_amd_cyl_set_cylmass(exp_amd_force *fb, double mass)
   HIP_TRY(f->ctx, hipMemcpyAsync(f->d_mass.p, &mass, sizeof(double), hipMemcpyHostToDevice,
                                  f->ctx->stream));
   HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  return EXP_AMD_OK;
+}
+
+// ---- field evaluation at points (pyEXP getFields for the cylindrical basis) -------------------------
+// Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849) = accumulated_eval
+// (exputil/EmpCylSL.cc:5256-5410) + accumulated_dens_eval (:5413-5502) at arbitrary points.  Not a
+// throughput path: one lane per point, the (m, n) sums taken directly on the tables.
+__global__ void __launch_bounds__(256)
+k_cyl_fields(CylDev C, const double *__restrict__ tab, const double *__restrict__ dens,
+             const double *__restrict__ coef, size_t n, const double *__restrict__ c1,
+             const double *__restrict__ c2, const double *__restrict__ c3, int coord,
+             double *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double R, z, phi, x = 0.0, y = 0.0, r = 0.0;
+  if (coord == 0) {
+    r = c1[i];
+    const double cth = c2[i], sth = sqrt(1.0 - cth * cth);
+    R = r * sth; z = r * cth; phi = c3[i];
+  } else if (coord == 1) {
+    R = c1[i]; z = c2[i]; phi = c3[i];
+  } else {
+    x = c1[i]; y = c2[i]; z = c3[i];
+    R = sqrt(x * x + y * y);
+    phi = atan2(y, x);
+  }
+  double p0 = 0.0, p = 0.0, fr = 0.0, fz = 0.0, fp = 0.0, d0 = 0.0, d = 0.0;
+  if (!(sqrt(R * R + z * z) / C.ascale > C.rtable)) {
+    int ix, iy;
+    double c00, c10, c01, c11;
+    cyl_weights(C, R, z, ix, iy, c00, c10, c01, c11);
+    const size_t ny = (size_t)C.numy + 1, nnode = (size_t)(C.numx + 1) * ny;
+    const size_t n00 = (size_t)ix * ny + iy;
+    const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+    auto bl = [&](const double *T) {
+      return T[n00] * c00 + T[n00 + ny] * c10 + T[n00 + 1] * c01 + T[n00 + ny + 1] * c11;
+    };
+    for (int mm = 0; mm <= C.mmax; mm++) {
+      const double ccos = cos(phi * mm), ssin = sin(phi * mm);
+      const bool on = !(C.EVEN_M && (mm & 1));                 // accumulated_eval only (:5318)
+      for (int k = 0; k < C.nmax; k++) {
+        const size_t mk = (size_t)mm * C.nmax + k;
+        const double ac = coef[mk], as = coef[half + mk];
+        const double *Tc = tab + mk * nnode;                    // kind 0 (potC); kinds are +half*nnode apart
+        const size_t ks = half * nnode;
+        if (on) {
+          const double vp = bl(Tc), vr = bl(Tc + ks), vz = bl(Tc + 2 * ks);
+          p += ac * ccos * vp; fr += ac * ccos * vr; fz += ac * ccos * vz;
+          fp += ac * ssin * mm * vp;
+          if (mm) {
+            const double wp = bl(Tc + 3 * ks), wr = bl(Tc + 4 * ks), wz = bl(Tc + 5 * ks);
+            p += as * ssin * wp; fr += as * ssin * wr; fz += as * ssin * wz;
+            fp += -as * ccos * mm * wp;
+          }
+        }
+        d += ac * ccos * bl(dens + mk * nnode);
+        if (mm) d += as * ssin * bl(dens + (half + mk) * nnode);
+      }
+      if (mm == 0) { p0 = p; d0 = d; }
+    }
+  }
+  double *o = out + 9 * i;
+  o[0] = d0; o[1] = d - d0; o[2] = d;
+  o[3] = p0; o[4] = p - p0; o[5] = p;
+  if (coord == 0) { o[6] = fr * R / r + fz * z / R; o[7] = fr * z / r - fz * R / r; o[8] = fp; }
+  else if (coord == 1) { o[6] = fr; o[7] = fz; o[8] = fp; }
+  else { o[6] = fr * x / R - fp * y / R; o[7] = fr * y / R + fp * x / R; o[8] = fz; }
+}
+
+extern "C" int exp_amd_cyl_set_density(exp_amd_force *fb, const double *dens)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f || !dens) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_set_density: not a cylinder force / NULL");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t cnt = (size_t)2 * (f->cfg.mmax + 1) * f->cfg.nmax * f->nnode;
+  if (f->d_dens.alloc(cnt) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_set_density: hipMalloc failed");
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_dens.p, dens, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_cyl_fields(exp_amd_force *fb, size_t n, const double *c1, const double *c2,
+                                  const double *c3, int coord, double *out)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_fields: not a cylinder force");
+  exp_amd_ctx *ctx = f->ctx;
+  if (n == 0) return EXP_AMD_OK;
+  if (!c1 || !c2 || !c3 || !out || coord < 0 || coord > 2)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_fields: bad argument");
+  if (!f->d_dens.p)
+    return expamd_fail(ctx, EXP_AMD_ERR_STATE, "cyl_fields: call exp_amd_cyl_set_density first");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<double> d_in, d_out;
+  if (d_in.alloc(3 * n) != hipSuccess || d_out.alloc(9 * n) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_fields: hipMalloc failed");
+  const double *src[3] = {c1, c2, c3};
+  for (int k = 0; k < 3; k++)
+    HIP_TRY(ctx, hipMemcpyAsync(d_in.p + (size_t)k * n, src[k], n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const CylDev C = f->dev;                   // fields are evaluated about the origin, as pyEXP does
+  k_cyl_fields<<<cdiv(n, 256), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_dens.p, f->d_coef.p, n, d_in.p,
+                                                      d_in.p + n, d_in.p + 2 * n, coord, d_out.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, 9 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_in.release();
+  d_out.release();
   return EXP_AMD_OK;
 }

@@ -56,16 +56,22 @@ class EmpCylGrid:
     ymax: float
     dy: float
     tab: np.ndarray      # [6, mmax+1, norder, numx+1, numy+1]
+    # density tables densC / densS (exputil/EmpCylSL.cc:1507-1534), [2, mmax+1, norder, numx+1,
+    # numy+1]; not on the n-body path, used by the field evaluation (pyEXP getFields)
+    dens: Optional[np.ndarray] = None
 
     def save(self, path: str) -> None:
         np.savez_compressed(path, **{f.name: getattr(self, f.name)
-                                     for f in dataclasses.fields(self)})
+                                     for f in dataclasses.fields(self)
+                                     if getattr(self, f.name) is not None})
 
     @staticmethod
     def load(path: str) -> "EmpCylGrid":
         z = np.load(path)
         kw = {}
         for f in dataclasses.fields(EmpCylGrid):
+            if f.name not in z:              # caches written before the density tables existed
+                continue
             v = z[f.name]
             kw[f.name] = v.item() if v.ndim == 0 else np.ascontiguousarray(v, dtype=np.float64)
         for k in ("mmax", "norder", "numx", "numy", "cmapr", "cmapz"):
@@ -109,6 +115,19 @@ def y_to_z(y, hscale, cmapz):
 
 
 # ---- vectorised SL table evaluation (exputil/SLGridMP2.cc:872-989) -----------------------------------
+
+def sl_dens(g: SLGridSph, r: np.ndarray) -> np.ndarray:
+    """dend[npts, L+1, nmax] of SLGridSph::get_dens (exputil/SLGridMP2.cc:913-950)."""
+    r = np.asarray(r, dtype=np.float64)
+    x = g.r_to_xi(r)
+    idx = np.clip(((x - g.xmin) / g.dxi).astype(np.int64), 0, g.numr - 2)
+    x1 = (g.xi[idx + 1] - x) / g.dxi
+    x2 = (x - g.xi[idx]) / g.dxi
+    e0 = np.moveaxis(g.ef[:, :, idx], 2, 0)
+    e1 = np.moveaxis(g.ef[:, :, idx + 1], 2, 0)
+    D0 = x1 * g.d0[idx] + x2 * g.d0[idx + 1]
+    return (x1[:, None, None] * e0 + x2[:, None, None] * e1) * np.sqrt(g.ev)[None] * D0[:, None, None]
+
 
 def sl_eval(g: SLGridSph, r: np.ndarray, want_force: bool = True):
     """potd[npts, L+1, nmax] (and dpot) of SLGridSph::get_pot / get_force at radii r."""
@@ -239,9 +258,12 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
     Rg, Zg = Rg.reshape(-1), Zg.reshape(-1)
     rrg = np.sqrt(Rg * Rg + Zg * Zg) + 1.0e-18
     potd_g, dpot_g = sl_eval(sl, rrg / ASCALE, want_force=True)  # [npts, L+1, nmax]
+    dend_g = sl_dens(sl, rrg / ASCALE)
+    dfac = ffac / ASCALE                                       # exputil/EmpCylSL.cc:176
     cg = Zg / rrg
 
     tab = np.zeros((6, mmax + 1, norder, numx + 1, numy + 1))
+    dtab = np.zeros((2, mmax + 1, norder, numx + 1, numy + 1))
     _limit = blas_limit()
     _limit.__enter__()
     for m in range(mmax + 1):
@@ -279,8 +301,13 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
             tab[k, m] = t
             if m > 0:
                 tab[k + 3, m] = t            # nump = 1: sine block == cosine block
+        # density (compute_eof_grid :1507, :1518, :1534): fac * P_lm * dend * dfac / (4 pi)
+        dn = ((fac * dfac * 0.25 / math.pi) * Pg[:, :, None] * dend_g[:, m:, :]).reshape(npts, -1) @ ef
+        dtab[0, m] = dn.T.reshape(norder, numx + 1, numy + 1)
+        if m > 0:
+            dtab[1, m] = dtab[0, m]
     _limit.__exit__(None, None, None)
     return EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
                       ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,
                       xmin=XMIN, xmax=XMAX, dx=dX, ymin=YMIN, ymax=YMAX, dy=dY,
-                      tab=np.ascontiguousarray(tab))
+                      tab=np.ascontiguousarray(tab), dens=np.ascontiguousarray(dtab))

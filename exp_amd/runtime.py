@@ -369,6 +369,28 @@ class Cylinder(_Force):
     def cylmass(self, mass: float) -> None:
         check(self.lib.exp_amd_cyl_set_cylmass(self.h, float(mass)), self.ctx.h)
 
+    FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
+
+    def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:
+        """Fields of the current coefficient set at points -> [n, 9] (dens m=0, dens m>0, dens, potl
+        m=0, potl m>0, potl, force x3 in the input coordinates): ``Cylindrical::sph_eval`` /
+        ``cyl_eval`` / ``crt_eval`` (expui/BiorthBasis.cc:1749-1849)."""
+        a, b, c = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (c1, c2, c3)]
+        if not (a.shape == b.shape == c.shape and a.ndim == 1):
+            raise ValueError("fields: three 1-d arrays of equal length expected")
+        if not getattr(self, "_have_density", False):
+            if getattr(self.grid, "dens", None) is None:
+                raise RuntimeError("Cylinder.fields: the EmpCylSL grid has no density tables "
+                                   "(rebuild it with exp_amd.empcyl.build_empcyl)")
+            d = as_f64(self.grid.dens)
+            check(self.lib.exp_amd_cyl_set_density(self.h, d[1]), self.ctx.h)
+            self._have_density = True
+        out = np.empty((a.size, 9))
+        check(self.lib.exp_amd_cyl_fields(self.h, a.size, a.ctypes.data, b.ctypes.data,
+                                          c.ctypes.data, self.FIELD_COORDS[coord],
+                                          out.ctypes.data), self.ctx.h)
+        return out
+
 
 def do_step_single(force: _Force, comp: Component, dt: float) -> None:
     """Unfused multistep=0 step, call for call as ``do_step`` (src/step.cc:271-323)."""

@@ -213,6 +213,15 @@ int  exp_amd_sph_set_density(exp_amd_force *f, const double *d0 /* [numr] */);
 int  exp_amd_sph_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
                         const double *c3, int coord, double *out /* [n][9] */);
 
+/* Cylindrical twin: Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849)
+ * = EmpCylSL::accumulated_eval (exputil/EmpCylSL.cc:5256-5410) + accumulated_dens_eval
+ * (:5413-5502) for the current coefficient set; dens = densC, densS tables
+ * [2][mmax+1][norder][numx+1][numy+1] of compute_eof_grid (:1507-1534).  Same coord / out as
+ * exp_amd_sph_fields.                                                                       */
+int  exp_amd_cyl_set_density(exp_amd_force *f, const double *dens);
+int  exp_amd_cyl_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
+                        const double *c3, int coord, double *out /* [n][9] */);
+
 /* ---- fused step ------------------------------------------------------------------------
  * One multistep=0 KDK step of a single self-gravitating component
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.

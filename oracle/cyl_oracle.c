@@ -240,3 +240,81 @@ void orc_cyl_accel(const orc_cylgrid *g, long nbodies, const double *X, const do
     AZ[i] += frc[2];
   }
 }
+
+/* ---- field evaluation (pyEXP getFields for the cylindrical basis) ------------------------------
+ * EmpCylSL::accumulated_dens_eval (exputil/EmpCylSL.cc:5413-5502), MMIN=0, MLIM=NLIM=inf;
+ * dens[2][mmax+1][norder][numx+1][numy+1] = densC, densS.                                     */
+double orc_cyl_accumulated_dens_eval(const orc_cylgrid *g, const double *dens,
+                                     const double *accum_cos, const double *accum_sin, double r,
+                                     double z, double phi, double *d0)
+{
+  double ans = 0.0;
+  double rr = sqrt(r * r + z * z);
+  *d0 = 0.0;
+  if (rr / g->ascale > g->rtable) return ans;
+
+  int ix, iy;
+  double c[4];
+  cyl_weights(g, r, z, &ix, &iy, c);
+  const size_t ny = (size_t)g->numy + 1, slab = ((size_t)g->numx + 1) * ny;
+#define DTAB(cs, m, n, i, j) dens[(((size_t)(cs) * (g->mmax + 1) + (m)) * g->norder + (n)) * slab + (size_t)(i) * ny + (j)]
+#define DINTERP(cs, m, n)                                                           \
+  (DTAB(cs, m, n, ix, iy) * c[0] + DTAB(cs, m, n, ix + 1, iy) * c[1] +              \
+   DTAB(cs, m, n, ix, iy + 1) * c[2] + DTAB(cs, m, n, ix + 1, iy + 1) * c[3])
+  for (int mm = 0; mm <= g->mmax; mm++) {
+    double ccos = cos(phi * mm);
+    double ssin = sin(phi * mm);
+    for (int n = 0; n < g->norder; n++) {
+      double fac = accum_cos[mm * g->norder + n] * ccos;
+      ans += fac * DINTERP(0, mm, n);
+      if (mm) {
+        fac = accum_sin[mm * g->norder + n] * ssin;
+        ans += fac * DINTERP(1, mm, n);
+      }
+    }
+    if (mm == 0) *d0 = ans;
+  }
+#undef DINTERP
+#undef DTAB
+  return ans;
+}
+
+/* Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849), G = 1, no
+ * midplane column.  coord 0: (r, cos theta, phi), 1: (R, z, phi), 2: (x, y, z); out[n][9].     */
+void orc_pyexp_cyl_fields(const orc_cylgrid *g, const double *dens, const double *accum_cos,
+                          const double *accum_sin, long n, const double *c1, const double *c2,
+                          const double *c3, int coord, double *out)
+{
+  for (long i = 0; i < n; i++) {
+    double R, z, phi, x = 0.0, y = 0.0, r = 0.0;
+    if (coord == 0) {
+      r = c1[i];
+      double cth = c2[i], sth = sqrt(1.0 - cth * cth);
+      R = r * sth; z = r * cth; phi = c3[i];
+    } else if (coord == 1) {
+      R = c1[i]; z = c2[i]; phi = c3[i];
+    } else {
+      x = c1[i]; y = c2[i]; z = c3[i];
+      R = sqrt(x * x + y * y);
+      phi = atan2(y, x);
+    }
+    double tdens0, tdens, tpotl0 = 0.0, tpotl, tpotR, tpotz, tpotp;
+    orc_cyl_accumulated_eval(g, accum_cos, accum_sin, R, z, phi, &tpotl0, &tpotl, &tpotR, &tpotz,
+                             &tpotp);
+    tdens = orc_cyl_accumulated_dens_eval(g, dens, accum_cos, accum_sin, R, z, phi, &tdens0);
+    double *o = out + 9 * i;
+    o[0] = tdens0; o[1] = tdens - tdens0; o[2] = tdens;
+    o[3] = tpotl0; o[4] = tpotl - tpotl0; o[5] = tpotl;
+    if (coord == 0) {
+      o[6] = tpotR * R / r + tpotz * z / R;      /* as written in the reference (:1766-1767) */
+      o[7] = tpotR * z / r - tpotz * R / r;
+      o[8] = tpotp;
+    } else if (coord == 1) {
+      o[6] = tpotR; o[7] = tpotz; o[8] = tpotp;
+    } else {
+      o[6] = tpotR * x / R - tpotp * y / R;
+      o[7] = tpotR * y / R + tpotp * x / R;
+      o[8] = tpotz;
+    }
+  }
+}

@@ -28,6 +28,15 @@ void   orc_cyl_accel(const orc_cylgrid *g, long n, const double *x, const double
                      const double *z, const double *center, const double *accum_cos,
                      const double *accum_sin, double cylmass, double *ax, double *ay, double *az,
                      double *pot);
+/* field evaluation: EmpCylSL::accumulated_dens_eval (exputil/EmpCylSL.cc:5413-5502) and the pyEXP
+ * wrappers Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849);
+ * dens[2][mmax+1][norder][numx+1][numy+1] = densC, densS; out[n][9]                          */
+double orc_cyl_accumulated_dens_eval(const orc_cylgrid *g, const double *dens,
+                                     const double *accum_cos, const double *accum_sin, double r,
+                                     double z, double phi, double *d0);
+void   orc_pyexp_cyl_fields(const orc_cylgrid *g, const double *dens, const double *accum_cos,
+                            const double *accum_sin, long n, const double *c1, const double *c2,
+                            const double *c3, int coord, double *out);
 #ifdef __cplusplus
 }
 #endif

@@ -222,6 +222,20 @@ class Oracle:
                                _dp(az), _dp(pot))
         return np.stack([ax, ay, az], axis=1), pot
 
+    def cyl_fields(self, g, cosN, sinN, c1, c2, c3, coord="cartesian", **kw):
+        """pyEXP Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849)."""
+        G = self.cylgrid(g, **kw)
+        a, b, c = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (c1, c2, c3)]
+        cc = np.ascontiguousarray(cosN, dtype=np.float64)
+        ss = np.ascontiguousarray(sinN, dtype=np.float64)
+        dens = np.ascontiguousarray(g.dens, dtype=np.float64)
+        out = np.zeros((len(a), 9))
+        code = {"spherical": 0, "cylindrical": 1, "cartesian": 2}[coord]
+        self.lib.orc_pyexp_cyl_fields(ctypes.byref(G), _dp(dens), _dp(cc), _dp(ss),
+                                      ctypes.c_long(len(a)), _dp(a), _dp(b), _dp(c),
+                                      ctypes.c_int(code), _dp(out))
+        return out
+
     def sph_multistep_init(self, g, prm, multistep, dtime, dynfrac, shiftlevl, pos, vel, mass,
                            center=(0.0, 0.0, 0.0)):
         """begin_run for one spherical component; returns a state dict."""

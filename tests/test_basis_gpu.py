@@ -197,6 +197,13 @@ parameters:
     assert coefs.coefs.shape == (5, 6) and coefs.time == 0.5
     acc = basis.getAccel(np.array([[0.02, 0.0, 0.0], [0.0, 0.03, 0.001]]))
     assert acc[0, 0] < 0 and acc[1, 1] < 0 and np.all(np.isfinite(acc))
+    # field evaluation: cylindrical coordinates by default (expui/BiorthBasis.cc:1744-1746)
+    basis.set_coefs(coefs)
+    assert basis.getFieldLabels()[6:] == ["rad force", "ver force", "azi force"]
+    fld = basis.getFields(0.02, 0.0, 0.0)
+    assert fld.shape == (9,) and fld[2] > 0 and fld[5] < 0 and fld[6] == pytest.approx(acc[0, 0], rel=1e-9)
+    cyl = basis(0.02, 0.0, 0.0, "cylindrical")
+    assert cyl[6] == pytest.approx(acc[0, 0], rel=1e-9) and cyl[:6] == pytest.approx(fld[:6], rel=1e-12)
 
 
 def test_coefficient_stream_playback_and_fields_over_time(halo_basis, tmp_path):

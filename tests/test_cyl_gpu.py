@@ -228,3 +228,30 @@ def test_cyl_full_size_properties(ctx):
     # the monopole coefficient of an (almost) axisymmetric disk dominates the m > 0 rows
     assert np.abs(c_all[0]).max() > 5 * np.abs(c_all[3:]).max()
     f.close()
+
+
+def test_cyl_fields_match_oracle(ctx, oracle):
+    """Device getFields for the cylindrical basis (accumulated_eval + accumulated_dens_eval at
+    points; Cylindrical::sph_eval / cyl_eval / crt_eval, expui/BiorthBasis.cc:1749-1849) vs the
+    oracle in the three coordinate systems, with points on and off the table."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(20000, 41, g)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    rng = np.random.default_rng(5)
+    test = rng.standard_normal((600, 3)) * np.array([4 * g.ascale, 4 * g.ascale, 3 * g.hscale])
+    test[:6] *= 400.0                                  # beyond the table radius: all zeros
+    x, y, z = test.T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(test, axis=1)
+    for ctype, args in (("cartesian", (x, y, z)), ("cylindrical", (R, z, ph)),
+                        ("spherical", (r, z / r, ph))):
+        got = f.fields(*args, ctype)
+        ref = oracle.cyl_fields(g, cc, ss, *args, ctype)
+        scale = np.abs(ref).max(axis=0)
+        assert np.all(np.abs(got - ref).max(axis=0) <= 1e-9 * scale + 1e-300)
+        assert np.all(got[:6] == 0.0)
+    c.close()
+    f.close()

@@ -344,3 +344,56 @@ def test_cylinder_reconstructs_exponential_disk_force(oracle):
         assert -acc[0, 0] == pytest.approx(fr_ref, rel=0.25)
         assert acc[1, 1] == pytest.approx(fr_ref, rel=0.25)
         assert pot[0] < 0
+
+
+def test_cylinder_fields_known_answers(oracle):
+    """pyEXP Cylindrical field evaluation (expui/BiorthBasis.cc:1749-1849) with the density tables
+    of compute_eof_grid (exputil/EmpCylSL.cc:1507-1534) and accumulated_dens_eval (:5413-5502):
+    (i) the reconstructed density of an exponential-disk sample is the disk's own density
+    (positive, right scale: pins the sign, dfac and the 1/4pi of the tables) to the truncation
+    of this small basis; (ii) potential and Cartesian force equal the n-body path's
+    (accumulated_eval through Cylinder, on-grid, before the taper); (iii) the three coordinate
+    systems agree."""
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    a, h = 0.01, 0.001
+    g = build_empcyl(mmax=2, norder=10, numx=64, numy=32, acyl=a, hcyl=h, lmaxfid=24, nmaxfid=20,
+                     numr=1000, rnum=100, tnum=40)
+    assert g.dens is not None and g.dens.shape == (2, 3, 10, 65, 33)
+    m, pos, _ = sample_disk(40000, 5, a=a, h=h)
+    cc, ss, used, mass = oracle.cyl_accumulate(g, pos, m)
+    # (i) midplane density vs Sigma(R) sech^2(z/h) / (2h) ... the conditioning density of sample_disk
+    # (the helper basis cannot resolve h/a = 0.1 vertically, so the known answer is the COLUMN
+    # density Sigma(R) = M exp(-R/a) / (2 pi a^2), the quantity accumulated_midplane_eval is for)
+    zc = np.linspace(-12 * h, 12 * h, 121)
+    for R in (0.5 * a, 1.0 * a, 2.0 * a, 3.0 * a):
+        col = oracle.cyl_fields(g, cc, ss, np.full_like(zc, R), zc, np.full_like(zc, 0.3), "cylindrical")
+        mid = col[60]
+        assert mid[2] > 0 and mid[5] < 0
+        sigma = np.trapezoid(col[:, 2], zc)
+        assert sigma == pytest.approx(math.exp(-R / a) / (2 * math.pi * a * a), rel=0.2)
+        assert abs(mid[1]) < 0.2 * mid[0]                   # nearly axisymmetric: m > 0 part small
+    # (ii) against the n-body evaluation well inside the table radius (no taper, no monopole blend)
+    rng = np.random.default_rng(6)
+    test = rng.standard_normal((200, 3)) * np.array([3 * a, 3 * a, 2 * h])
+    acc, pot = oracle.cyl_accel(g, test, cc, ss, mass)
+    fc = oracle.cyl_fields(g, cc, ss, test[:, 0], test[:, 1], test[:, 2], "cartesian")
+    # potential, vertical and radial force are the n-body ones; the azimuthal term is NOT compared:
+    # crt_eval uses tpotp*y/R (expui/BiorthBasis.cc:1794-1795) where Cylinder uses fp*y/R^2
+    # (src/Cylinder.cc:1387-1390) -- both restated as written
+    Rt = np.hypot(test[:, 0], test[:, 1])
+    rad_nbody = (acc[:, 0] * test[:, 0] + acc[:, 1] * test[:, 1]) / Rt
+    rad_pyexp = (fc[:, 6] * test[:, 0] + fc[:, 7] * test[:, 1]) / Rt
+    assert np.abs(rad_pyexp - rad_nbody).max() <= 1e-9 * np.abs(acc).max()
+    assert np.abs(fc[:, 8] - acc[:, 2]).max() <= 1e-9 * np.abs(acc).max()
+    assert np.abs(fc[:, 5] - pot).max() <= 1e-10 * np.abs(pot).max()
+    # (iii) cylindrical / spherical components of the same points
+    x, y, z = test.T
+    R, ph, r = np.hypot(x, y), np.arctan2(y, x), np.linalg.norm(test, axis=1)
+    fy = oracle.cyl_fields(g, cc, ss, R, z, ph, "cylindrical")
+    fs = oracle.cyl_fields(g, cc, ss, r, z / r, ph, "spherical")
+    assert np.abs(fy[:, :6] - fc[:, :6]).max() <= 1e-12 * np.abs(fc[:, :6]).max()
+    assert np.abs(fs[:, :6] - fc[:, :6]).max() <= 1e-9 * np.abs(fc[:, :6]).max()
+    fR = fc[:, 6] * np.cos(ph) + fc[:, 7] * np.sin(ph)
+    assert np.abs(fy[:, 6] - fR).max() <= 1e-9 * np.abs(acc).max()
+    assert np.abs(fy[:, 7] - fc[:, 8]).max() <= 1e-12 * np.abs(acc).max()
