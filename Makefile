@@ -14,10 +14,19 @@ BASE_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(BASE_SRC))
 INST_OBJ := $(foreach l,$(SPH_LS),$(OBJ)/sph_inst_L$(l).o)
 HDRS     := $(wildcard $(CSRC)/*.h) include/exp_amd.h
 
-all: lib oracle
+all: lib oracle h5
 lib: exp_amd/libexp_amd.so
 oracle:
 	$(MAKE) -C oracle
+
+# host-side HDF5 basis-cache shim (no GPU code); skipped where the HDF5 C headers are absent
+HDF5_INC ?= /opt/conda/include
+HDF5_LIB ?= /opt/conda/lib
+h5:
+	@if [ -f $(HDF5_INC)/hdf5.h ]; then \
+	  gcc -O2 -fPIC -shared -I$(HDF5_INC) exp_amd/csrc_host/h5cache.c -o exp_amd/libexp_amd_h5.so \
+	      -L$(HDF5_LIB) -lhdf5 -Wl,-rpath,$(HDF5_LIB); \
+	else echo "hdf5.h not found: HDF5 cache shim not built"; fi
 
 $(OBJ)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJ) build/log
@@ -31,7 +40,7 @@ exp_amd/libexp_amd.so: $(BASE_OBJ) $(INST_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 clean:
-	rm -rf build exp_amd/libexp_amd.so
+	rm -rf build exp_amd/libexp_amd.so exp_amd/libexp_amd_h5.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle h5 clean

@@ -239,6 +239,7 @@ class SphericalSL(BiorthBasis):
         self.cachename = conf.get("cachename", "")
         if not self.cachename:
             raise RuntimeError("SphericalSL requires a specified cachename in your YAML config")
+        self.model_file = model_file
         self.model = TableModel(model_file)
         rmin = float(conf.get("rmin", 0.0))
         rmax = float(conf.get("rmax", np.finfo(np.float64).max))
@@ -267,6 +268,26 @@ class SphericalSL(BiorthBasis):
                     rmax=self.rmax, rmapping=self.rmap)
 
     def _load_or_build(self) -> SLGridSph:
+        """EXP's own HDF5 cache ``cachename`` (exputil/SLGridMP2.cc:490-696) is read when it exists
+        and matches -- a basis built by EXP drives the kernels as it is -- and written after a
+        build; where the HDF5 shim is unavailable an ``.npz`` twin is used instead."""
+        from . import h5cache
+        if h5cache.available():
+            if os.path.exists(self.cachename):
+                try:
+                    return h5cache.read_slgrid_cache(
+                        self.cachename, self.model,
+                        check=dict(lmax=self.lmax, nmax=self.nmax, numr=self.numr, cmap=self.cmap,
+                                   rmin=float(self.rmin), rmax=float(self.rmax),
+                                   rmapping=float(self.rmap)))
+                except RuntimeError:
+                    pass                                  # the reference rebuilds on any mismatch
+            g = build_slgrid(self.model, self.lmax, self.nmax, numr=self.numr, rmin=self.rmin,
+                             rmax=self.rmax, cmap=self.cmap, rmap=self.rmap)
+            if os.path.exists(self.cachename):            # :631-648 back up, then write afresh
+                os.replace(self.cachename, self.cachename + ".bak")
+            h5cache.write_slgrid_cache(self.cachename, g, self.model_file)
+            return g
         path = self._cache_path()
         if os.path.exists(path):
             g = SLGridSph.load(path)
@@ -281,7 +302,15 @@ class SphericalSL(BiorthBasis):
         return g
 
     def cacheInfo(self, cachefile: Optional[str] = None) -> dict:
-        path = cachefile or self._cache_path()
+        """``SLGridSph::cacheInfo`` (the header of the cache file)."""
+        from . import h5cache
+        path = cachefile or self.cachename
+        if h5cache.available() and os.path.exists(path):
+            h = h5cache.read_slgrid_header(path)
+            return dict(geometry=h["geometry"], forceID=h["forceID"], model=h["model"],
+                        lmax=h["lmax"], nmax=h["nmax"], numr=h["numr"], cmap=h["cmap"],
+                        rmin=h["rmin"], rmax=h["rmax"], rmapping=h["rmapping"],
+                        diverge=h["diverge"], dfac=h["dfac"])
         if not path.endswith(".npz"):
             path += ".npz"
         g = SLGridSph.load(path)
