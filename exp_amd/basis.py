@@ -452,7 +452,32 @@ class Cylindrical(BiorthBasis):
     def _cache_path(self) -> str:
         return self.cachename if self.cachename.endswith(".npz") else self.cachename + ".npz"
 
+    def _build(self) -> EmpCylGrid:
+        return build_empcyl(mmax=self.mmax, norder=self.nmax, numx=self.ncylnx, numy=self.ncylny,
+                            acyl=self.acyl, hcyl=self.hcyl, rcylmin=self.rcylmin,
+                            rcylmax=self.rcylmax, lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid,
+                            numr=self.ncylr, cmapr=self.cmapr, cmapz=self.cmapz, rnum=self.rnum,
+                            tnum=self.tnum)
+
     def _load_or_build(self) -> EmpCylGrid:
+        """EXP's own HDF5 cache ``cachename`` (exputil/EmpCylSL.cc:7378-7640) when the HDF5 shim is
+        available -- read if it matches, else rebuilt and written --, an ``.npz`` twin otherwise."""
+        from . import h5cache
+        if h5cache.available():
+            if os.path.exists(self.cachename):
+                try:
+                    return h5cache.read_empcyl_cache(
+                        self.cachename,
+                        check=dict(mmax=self.mmax, nmax=self.nmax, numx=self.ncylnx, numy=self.ncylny,
+                                   lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid, cmapr=self.cmapr,
+                                   cmapz=self.cmapz, rmin=float(self.rcylmin),
+                                   rmax=float(self.rcylmax), ascl=float(self.acyl),
+                                   hscl=float(self.hcyl)))
+                except RuntimeError:
+                    pass                                  # the reference rebuilds on any mismatch
+            gr = self._build()
+            h5cache.write_empcyl_cache(self.cachename, gr, self.lmaxfid, self.nmaxfid)
+            return gr
         path = self._cache_path()
         if os.path.exists(path):
             gr = EmpCylGrid.load(path)
@@ -469,7 +494,13 @@ class Cylindrical(BiorthBasis):
         return gr
 
     def cacheInfo(self, cachefile: Optional[str] = None) -> dict:
-        path = cachefile or self._cache_path()
+        from . import h5cache
+        path = cachefile or self.cachename
+        if h5cache.available() and os.path.exists(path):
+            h = h5cache.read_empcyl_header(path)
+            return {k: h[k] for k in ("geometry", "forceID", "model", "mmax", "nmax", "numx", "numy",
+                                      "lmaxfid", "nmaxfid", "neven", "nodd", "cmapr", "cmapz",
+                                      "rmin", "rmax", "ascl", "hscl", "cmass")}
         if not path.endswith(".npz"):
             path += ".npz"
         gr = EmpCylGrid.load(path)

@@ -248,3 +248,143 @@ int exp_h5_slgrid_read_tables(const char *path, int lmax, int nmax, int numr, do
   H5Fclose(f);
   return rc;
 }
+
+/* ---- EmpCylSL cache ------------------------------------------------------------------------------
+ * EmpCylSL::WriteH5Cache / ReadH5Cache (exputil/EmpCylSL.cc:7378-7460, :7486-7640): root attributes
+ * geometry = "cylinder", forceID = "Cylinder", Version = "1.0", model (e.g. "Exponential"), mmax,
+ * numx, numy, nmax (= NORDER), lmaxfid, nmaxfid, neven, nodd, cmapr, cmapz (int), rmin, rmax, ascl,
+ * hscl, cmass (double); groups Cosine/<m>/<n> with potC, rforceC, zforceC, densC and (m >= 1)
+ * Sine/<m>/<n> with potS, rforceS, zforceS, densS, each a [numx+1][numy+1] matrix.
+ * tab[6][mmax+1][norder][numx+1][numy+1] = potC, rforceC, zforceC, potS, rforceS, zforceS;
+ * dens[2][mmax+1][norder][numx+1][numy+1] = densC, densS.                                       */
+typedef struct {
+  char geometry[64], forceID[64], version[32], model[128];
+  int mmax, numx, numy, nmax, lmaxfid, nmaxfid, neven, nodd, cmapr, cmapz;
+  double rmin, rmax, ascl, hscl, cmass;
+} exp_h5_cyl_hdr;
+
+int exp_h5_cyl_write(const char *path, const exp_h5_cyl_hdr *h, const double *tab, const double *dens)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= put_str(f, "geometry", "cylinder");
+  rc |= put_str(f, "forceID", "Cylinder");
+  rc |= put_str(f, "Version", h->version[0] ? h->version : "1.0");
+  rc |= put_str(f, "model", h->model);
+  rc |= put_int(f, "mmax", h->mmax);
+  rc |= put_int(f, "numx", h->numx);
+  rc |= put_int(f, "numy", h->numy);
+  rc |= put_int(f, "nmax", h->nmax);
+  rc |= put_int(f, "lmaxfid", h->lmaxfid);
+  rc |= put_int(f, "nmaxfid", h->nmaxfid);
+  rc |= put_int(f, "neven", h->neven);
+  rc |= put_int(f, "nodd", h->nodd);
+  rc |= put_int(f, "cmapr", h->cmapr);
+  rc |= put_int(f, "cmapz", h->cmapz);
+  rc |= put_dbl(f, "rmin", h->rmin);
+  rc |= put_dbl(f, "rmax", h->rmax);
+  rc |= put_dbl(f, "ascl", h->ascl);
+  rc |= put_dbl(f, "hscl", h->hscl);
+  rc |= put_dbl(f, "cmass", h->cmass);
+  const size_t nnode = (size_t)(h->numx + 1) * (h->numy + 1);
+  const size_t kind = (size_t)(h->mmax + 1) * h->nmax * nnode;
+  hsize_t d2[2] = {(hsize_t)h->numx + 1, (hsize_t)h->numy + 1};
+  static const char *cn[4] = {"potC", "rforceC", "zforceC", "densC"};
+  static const char *sn[4] = {"potS", "rforceS", "zforceS", "densS"};
+  for (int cs = 0; cs < 2 && rc == 0; cs++) {
+    hid_t top = H5Gcreate2(f, cs ? "Sine" : "Cosine", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (top < 0) { rc = -1; break; }
+    for (int m = cs; m <= h->mmax && rc == 0; m++) {
+      char nm[32];
+      snprintf(nm, sizeof nm, "%d", m);
+      hid_t gm = H5Gcreate2(top, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+      for (int n = 0; n < h->nmax && rc == 0; n++) {
+        snprintf(nm, sizeof nm, "%d", n);
+        hid_t gn = H5Gcreate2(gm, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        const size_t off = ((size_t)m * h->nmax + n) * nnode;
+        for (int k = 0; k < 3; k++)
+          rc |= put_array(gn, cs ? sn[k] : cn[k], 2, d2, tab + (size_t)(3 * cs + k) * kind + off);
+        rc |= put_array(gn, cs ? sn[3] : cn[3], 2, d2, dens + (size_t)cs * kind + off);
+        H5Gclose(gn);
+      }
+      H5Gclose(gm);
+    }
+    H5Gclose(top);
+  }
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+int exp_h5_cyl_read_header(const char *path, exp_h5_cyl_hdr *h)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  memset(h, 0, sizeof *h);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= get_str(f, "geometry", h->geometry, sizeof h->geometry);
+  rc |= get_str(f, "forceID", h->forceID, sizeof h->forceID);
+  get_str(f, "Version", h->version, sizeof h->version);
+  rc |= get_str(f, "model", h->model, sizeof h->model);
+  rc |= get_int(f, "mmax", &h->mmax);
+  rc |= get_int(f, "numx", &h->numx);
+  rc |= get_int(f, "numy", &h->numy);
+  rc |= get_int(f, "nmax", &h->nmax);
+  rc |= get_int(f, "lmaxfid", &h->lmaxfid);
+  rc |= get_int(f, "nmaxfid", &h->nmaxfid);
+  rc |= get_int(f, "neven", &h->neven);
+  rc |= get_int(f, "nodd", &h->nodd);
+  rc |= get_int(f, "cmapr", &h->cmapr);
+  rc |= get_int(f, "cmapz", &h->cmapz);
+  rc |= get_dbl(f, "rmin", &h->rmin);
+  rc |= get_dbl(f, "rmax", &h->rmax);
+  rc |= get_dbl(f, "ascl", &h->ascl);
+  rc |= get_dbl(f, "hscl", &h->hscl);
+  rc |= get_dbl(f, "cmass", &h->cmass);
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+static int get_matrix(hid_t f, const char *name, int nx1, int ny1, double *dst)
+{
+  hid_t d = H5Dopen2(f, name, H5P_DEFAULT);
+  if (d < 0) return -1;
+  hid_t s = H5Dget_space(d);
+  hsize_t dims[2] = {0, 0};
+  int rc = 0;
+  if (H5Sget_simple_extent_ndims(s) != 2) rc = -1;
+  else H5Sget_simple_extent_dims(s, dims, NULL);
+  if (rc == 0 && (dims[0] != (hsize_t)nx1 || dims[1] != (hsize_t)ny1)) rc = -1;
+  if (rc == 0 && H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, dst) < 0) rc = -1;
+  H5Sclose(s);
+  H5Dclose(d);
+  return rc;
+}
+
+int exp_h5_cyl_read_tables(const char *path, int mmax, int nmax, int numx, int numy, double *tab,
+                           double *dens)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  const size_t nnode = (size_t)(numx + 1) * (numy + 1);
+  const size_t kind = (size_t)(mmax + 1) * nmax * nnode;
+  static const char *cn[4] = {"potC", "rforceC", "zforceC", "densC"};
+  static const char *sn[4] = {"potS", "rforceS", "zforceS", "densS"};
+  int rc = 0;
+  for (int cs = 0; cs < 2 && rc == 0; cs++)
+    for (int m = cs; m <= mmax && rc == 0; m++)
+      for (int n = 0; n < nmax && rc == 0; n++) {
+        const size_t off = ((size_t)m * nmax + n) * nnode;
+        char nm[96];
+        for (int k = 0; k < 4 && rc == 0; k++) {
+          snprintf(nm, sizeof nm, "%s/%d/%d/%s", cs ? "Sine" : "Cosine", m, n, cs ? sn[k] : cn[k]);
+          double *dst = (k < 3) ? tab + (size_t)(3 * cs + k) * kind + off : dens + (size_t)cs * kind + off;
+          rc |= get_matrix(f, nm, numx + 1, numy + 1, dst);
+        }
+      }
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}

@@ -105,3 +105,81 @@ def read_slgrid_cache(path: str, model, check: Optional[dict] = None) -> SLGridS
     return SLGridSph(lmax=lmax, nmax=nmax, numr=numr, cmap=h["cmap"], rmin=h["rmin"], rmax=h["rmax"],
                      rmap=h["rmapping"], xmin=xmin, xmax=xmax, dxi=dxi, xi=xi, r=r, p0=p0, d0=d0,
                      ev=ev, ef=ef)
+
+
+# ---- EmpCylSL cache (exputil/EmpCylSL.cc:7378-7460, :7486-7640) -----------------------------------
+
+class _CylHdr(ctypes.Structure):
+    _fields_ = [("geometry", ctypes.c_char * 64), ("forceID", ctypes.c_char * 64),
+                ("version", ctypes.c_char * 32), ("model", ctypes.c_char * 128),
+                ("mmax", ctypes.c_int), ("numx", ctypes.c_int), ("numy", ctypes.c_int),
+                ("nmax", ctypes.c_int), ("lmaxfid", ctypes.c_int), ("nmaxfid", ctypes.c_int),
+                ("neven", ctypes.c_int), ("nodd", ctypes.c_int), ("cmapr", ctypes.c_int),
+                ("cmapz", ctypes.c_int), ("rmin", ctypes.c_double), ("rmax", ctypes.c_double),
+                ("ascl", ctypes.c_double), ("hscl", ctypes.c_double), ("cmass", ctypes.c_double)]
+
+
+def write_empcyl_cache(path: str, g, lmaxfid: int, nmaxfid: int, model: str = "Exponential",
+                       neven: Optional[int] = None, nodd: int = 0, cmass: float = 0.0) -> None:
+    """``EmpCylSL::WriteH5Cache``: ``g`` is an ``exp_amd.empcyl.EmpCylGrid`` WITH density tables."""
+    if g.dens is None:
+        raise RuntimeError("write_empcyl_cache: the grid has no density tables")
+    h = _CylHdr()
+    h.version, h.model = b"1.0", model.encode()
+    h.mmax, h.numx, h.numy, h.nmax = g.mmax, g.numx, g.numy, g.norder
+    h.lmaxfid, h.nmaxfid = int(lmaxfid), int(nmaxfid)
+    h.neven, h.nodd = (g.norder - nodd if neven is None else int(neven)), int(nodd)
+    h.cmapr, h.cmapz = g.cmapr, g.cmapz
+    h.rmin, h.rmax, h.ascl, h.hscl, h.cmass = g.rmin, g.rmax, g.ascale, g.hscale, float(cmass)
+    tab = np.ascontiguousarray(g.tab, dtype=np.float64)
+    dens = np.ascontiguousarray(g.dens, dtype=np.float64)
+    lib = _load()
+    lib.exp_h5_cyl_write.restype = ctypes.c_int
+    if lib.exp_h5_cyl_write(path.encode(), ctypes.byref(h), tab.ctypes.data_as(ctypes.c_void_p),
+                            dens.ctypes.data_as(ctypes.c_void_p)):
+        raise RuntimeError(f"write_empcyl_cache: HDF5 error writing <{path}>")
+
+
+def read_empcyl_header(path: str) -> dict:
+    h = _CylHdr()
+    lib = _load()
+    lib.exp_h5_cyl_read_header.restype = ctypes.c_int
+    if lib.exp_h5_cyl_read_header(path.encode(), ctypes.byref(h)):
+        raise RuntimeError(f"read_empcyl_header: <{path}> is not a readable EmpCylSL cache")
+    out = {k: getattr(h, k) for k, _ in _CylHdr._fields_}
+    for k in ("geometry", "forceID", "version", "model"):
+        out[k] = out[k].decode()
+    return out
+
+
+def read_empcyl_cache(path: str, check: Optional[dict] = None):
+    """``EmpCylSL::ReadH5Cache``: an ``EmpCylGrid`` with the file's tables; the grid geometry
+    (Rtable, XMIN.., YMIN.., ``setup_table`` exputil/EmpCylSL.cc:2123-2137) follows from the header."""
+    from .empcyl import EmpCylGrid, r_to_xi, z_to_y
+    h = read_empcyl_header(path)
+    if h["geometry"] != "cylinder" or h["forceID"] != "Cylinder":
+        raise RuntimeError(f"<{path}>: geometry/forceID = {h['geometry']}/{h['forceID']}")
+    for k, v in (check or {}).items():
+        have = h[k]
+        bad = (abs(have - v) >= 1.0e-16) if isinstance(v, float) else (have != v)
+        if bad:
+            raise RuntimeError(f"<{path}>: parameter {k}: wanted {v} found {have}")
+    mmax, nmax, numx, numy = h["mmax"], h["nmax"], h["numx"], h["numy"]
+    tab = np.zeros((6, mmax + 1, nmax, numx + 1, numy + 1))
+    dens = np.zeros((2, mmax + 1, nmax, numx + 1, numy + 1))
+    lib = _load()
+    lib.exp_h5_cyl_read_tables.restype = ctypes.c_int
+    if lib.exp_h5_cyl_read_tables(path.encode(), mmax, nmax, numx, numy,
+                                  tab.ctypes.data_as(ctypes.c_void_p),
+                                  dens.ctypes.data_as(ctypes.c_void_p)):
+        raise RuntimeError(f"<{path}>: Cosine|Sine/<m>/<n> tables missing or of the wrong shape")
+    A, H = h["ascl"], h["hscl"]
+    rtable = math.sqrt(0.5) * h["rmax"]
+    xmin = float(r_to_xi(h["rmin"] * A, A, h["cmapr"]))
+    xmax = float(r_to_xi(rtable * A, A, h["cmapr"]))
+    ymin = float(z_to_y(-rtable * A, H, h["cmapz"]))
+    ymax = float(z_to_y(rtable * A, H, h["cmapz"]))
+    return EmpCylGrid(mmax=mmax, norder=nmax, numx=numx, numy=numy, cmapr=h["cmapr"], cmapz=h["cmapz"],
+                      ascale=A, hscale=H, rmin=h["rmin"], rmax=h["rmax"], rtable=rtable, xmin=xmin,
+                      xmax=xmax, dx=(xmax - xmin) / numx, ymin=ymin, ymax=ymax, dy=(ymax - ymin) / numy,
+                      tab=tab, dens=dens)

@@ -62,3 +62,28 @@ def test_old_matrix_layout_is_transposed(h5, tmp_path):
                                               ev.ctypes.data_as(ctypes.c_void_p),
                                               ef.ctypes.data_as(ctypes.c_void_p))
     assert rc != 0
+
+
+def test_empcyl_cache_roundtrip(h5, tmp_path):
+    """EmpCylSL::WriteH5Cache / ReadH5Cache layout (exputil/EmpCylSL.cc:7378-7640)."""
+    from exp_amd.empcyl import build_empcyl
+    g = build_empcyl(mmax=2, norder=3, numx=16, numy=8, lmaxfid=8, nmaxfid=6, numr=300, rnum=40, tnum=20)
+    path = str(tmp_path / ".eof.cache.run0")
+    h5.write_empcyl_cache(path, g, lmaxfid=8, nmaxfid=6, cmass=0.25)
+    hdr = h5.read_empcyl_header(path)
+    assert hdr["geometry"] == "cylinder" and hdr["forceID"] == "Cylinder" and hdr["model"] == "Exponential"
+    assert (hdr["mmax"], hdr["numx"], hdr["numy"], hdr["nmax"], hdr["lmaxfid"], hdr["nmaxfid"]) == (2, 16, 8, 3, 8, 6)
+    assert hdr["ascl"] == g.ascale and hdr["hscl"] == g.hscale and hdr["cmass"] == 0.25
+    back = h5.read_empcyl_cache(path, check={"mmax": 2, "nmax": 3, "ascl": g.ascale})
+    assert np.array_equal(back.tab[:3], g.tab[:3])                       # cosine tables, all m
+    assert np.array_equal(back.tab[3:, 1:], g.tab[3:, 1:])               # sine tables exist for m >= 1
+    assert np.all(back.tab[3:, 0] == 0.0)
+    assert np.array_equal(back.dens[0], g.dens[0]) and np.array_equal(back.dens[1, 1:], g.dens[1, 1:])
+    for k in ("rtable", "xmin", "xmax", "dx", "ymin", "ymax", "dy"):
+        assert getattr(back, k) == pytest.approx(getattr(g, k), rel=1e-15), k
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        txt = subprocess.run([h5dump, "-H", path], capture_output=True, text=True).stdout
+        assert 'GROUP "Cosine"' in txt and 'GROUP "Sine"' in txt and 'DATASET "densC"' in txt
+        assert "DATASPACE  SIMPLE { ( 17, 9 ) / ( 17, 9 ) }" in txt
+        assert txt.count('DATASET "potS"') == 2 * 3 and txt.count('DATASET "potC"') == 3 * 3
