@@ -12,9 +12,9 @@ What the reference does either side of the hot path with the coefficients it pro
   bracketing sets linearly -- which is what ``determine_coefficients_playback``
   (src/SphericalBasis.cc:612-680) feeds to the force evaluation.
 
-HDF5 coefficient files (``WriteH5Coefs``) need HighFive/h5py, which this image does not have; the
-native stream format is complete for the spherical basis.  Host-side only: nothing here touches
-the device.
+HDF5 coefficient files (``WriteH5Coefs`` / the reading constructor) go through the libhdf5 C shim
+(``exp_amd/csrc_host/h5cache.c``); this image has no h5py/HighFive.  Host-side only: nothing here
+touches the device.
 """
 from __future__ import annotations
 
@@ -197,3 +197,67 @@ class SphCoefs:
         A = (times[hi] - time) / (times[hi] - times[lo])
         B = (time - times[lo]) / (times[hi] - times[lo])
         return A * np.asarray(self.coefs[times[lo]].coefs) + B * np.asarray(self.coefs[times[hi]].coefs), on_grid
+
+    # -- HDF5 coefficient files (pyEXP's default format) -------------------------------------------
+    def WriteH5Coefs(self, path: str, config: str = "", force_id: str = "sphereSL") -> None:
+        """``Coefs::WriteH5Coefs`` + ``SphCoefs::WriteH5Params/WriteH5Times`` (expui/Coefficients.cc:
+        3100-3163, :841-853, :907-944) through the HDF5 C shim (``exp_amd.h5cache``)."""
+        import ctypes
+        from . import h5cache
+        times = self.Times()
+        if not times:
+            raise RuntimeError("Coefs::WriteH5Coefs: we have NO coefficient sets")
+        first = self.coefs[times[0]]
+        lmax, nmax = first.lmax, first.nmax
+        ldim = (lmax + 1) * (lmax + 2) // 2
+        data = np.zeros((len(times), ldim, nmax, 2))
+        ctr = np.zeros((len(times), 3))
+        rot = np.zeros((len(times), 3, 3))
+        for k, t in enumerate(times):
+            c = self.coefs[t]
+            data[k, :, :, 0], data[k, :, :, 1] = np.real(c.coefs), np.imag(c.coefs)
+            ctr[k] = np.asarray(c.ctr, dtype=np.float64).reshape(3) if np.size(c.ctr) == 3 else 0.0
+            rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
+        tarr = np.array([self.coefs[t].time for t in times])
+        lib = h5cache._load()
+        lib.exp_h5_sphcoef_write.restype = ctypes.c_int
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = lib.exp_h5_sphcoef_write(path.encode(), self.name.encode(), config.encode(),
+                                      force_id.encode(), lmax, nmax, ctypes.c_double(first.scale),
+                                      len(times), vp(tarr), vp(ctr), vp(rot), vp(data))
+        if rc:
+            raise RuntimeError(f"WriteH5Coefs: HDF5 error writing <{path}>")
+
+    @classmethod
+    def readH5Coefs(cls, path: str, stride: int = 1, tmin: float = -math.inf,
+                    tmax: float = math.inf) -> "SphCoefs":
+        """The reading constructor ``SphCoefs(HighFive::File&, stride, Tmin, Tmax)``
+        (expui/Coefficients.cc:228-330)."""
+        import ctypes
+        from . import h5cache
+        lib = h5cache._load()
+        lib.exp_h5_sphcoef_info.restype = ctypes.c_int
+        lib.exp_h5_sphcoef_read.restype = ctypes.c_int
+        lmax, nmax, count, hasv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        scale = ctypes.c_double()
+        name, fid, geo = (ctypes.create_string_buffer(256) for _ in range(3))
+        if lib.exp_h5_sphcoef_info(path.encode(), ctypes.byref(lmax), ctypes.byref(nmax),
+                                   ctypes.byref(scale), ctypes.byref(count), name, 256, fid, 256,
+                                   geo, 256, ctypes.byref(hasv)):
+            raise RuntimeError(f"readH5Coefs: <{path}> is not a readable coefficient file")
+        if geo.value.decode() != "sphere":
+            raise RuntimeError(f"readH5Coefs: geometry <{geo.value.decode()}> is not spherical")
+        L, N, C = lmax.value, nmax.value, count.value
+        ldim = (L + 1) * (L + 2) // 2
+        times, ctr, rot = np.zeros(C), np.zeros((C, 3)), np.zeros((C, 3, 3))
+        data = np.zeros((C, ldim, N, 2))
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if lib.exp_h5_sphcoef_read(path.encode(), C, L, N, vp(times), vp(ctr), vp(rot), vp(data)):
+            raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
+        self = cls(name.value.decode())
+        for k in range(0, C, stride):
+            if times[k] < tmin or times[k] > tmax:
+                continue
+            self.add(SphStruct(L, N, scale.value, float(times[k]), data[k, :, :, 0] + 1j * data[k, :, :, 1],
+                               ctr[k].copy(), rot[k].copy()))
+        return self

@@ -388,3 +388,153 @@ int exp_h5_cyl_read_tables(const char *path, int mmax, int nmax, int numx, int n
   H5Fclose(f);
   return rc ? -1 : 0;
 }
+
+/* ---- spherical coefficient files -------------------------------------------------------------------
+ * Coefs::WriteH5Coefs (expui/Coefficients.cc:3100-3163), SphCoefs::WriteH5Params (:841-853),
+ * SphCoefs::WriteH5Times (:907-944) and the reading constructor (:228-330): root attributes
+ * CoefficientOutputVersion = "1.0" (Coefficients.H:95), geometry = "sphere", name, config, lmax,
+ * nmax (int), scale (double), forceID; dataset "count" (unsigned); group snapshots/%08d with the
+ * attributes Time (double), Center (double[3]), Rotation (double[3][3]) and the dataset
+ * "coefficients" [(L+1)(L+2)/2][nmax] of std::complex<double> (HighFive's compound {r, i}).
+ * The optional "Units" dataset is not written (the reader takes it only if present, :171-181).
+ * coefs[ntimes][ldim][nmax][2] = (re, im).                                                      */
+static hid_t complex_type(void)
+{
+  hid_t t = H5Tcreate(H5T_COMPOUND, 16);
+  H5Tinsert(t, "r", 0, H5T_NATIVE_DOUBLE);
+  H5Tinsert(t, "i", 8, H5T_NATIVE_DOUBLE);
+  return t;
+}
+
+static int put_dbl_array_attr(hid_t loc, const char *name, int rank, const hsize_t *dims, const double *v)
+{
+  hid_t s = H5Screate_simple(rank, dims, NULL);
+  hid_t a = H5Acreate2(loc, name, H5T_NATIVE_DOUBLE, s, H5P_DEFAULT, H5P_DEFAULT);
+  int rc = (a < 0) ? -1 : (H5Awrite(a, H5T_NATIVE_DOUBLE, v) < 0 ? -1 : 0);
+  if (a >= 0) H5Aclose(a);
+  H5Sclose(s);
+  return rc;
+}
+
+int exp_h5_sphcoef_write(const char *path, const char *name, const char *config, const char *forceID,
+                         int lmax, int nmax, double scale, int ntimes, const double *times,
+                         const double *centers, const double *rots, const double *coefs)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= put_str(f, "CoefficientOutputVersion", "1.0");
+  rc |= put_str(f, "geometry", "sphere");
+  rc |= put_str(f, "name", name);
+  rc |= put_str(f, "config", config);
+  rc |= put_int(f, "lmax", lmax);
+  rc |= put_int(f, "nmax", nmax);
+  rc |= put_dbl(f, "scale", scale);
+  rc |= put_str(f, "forceID", forceID);
+  {
+    unsigned count = (unsigned)ntimes;
+    hid_t s = H5Screate(H5S_SCALAR);
+    hid_t d = H5Dcreate2(f, "count", H5T_NATIVE_UINT, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (d < 0 || H5Dwrite(d, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
+    if (d >= 0) H5Dclose(d);
+    H5Sclose(s);
+  }
+  hid_t snaps = H5Gcreate2(f, "snapshots", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  hid_t ct = complex_type();
+  const int ldim = (lmax + 1) * (lmax + 2) / 2;
+  for (int k = 0; k < ntimes && rc == 0 && snaps >= 0; k++) {
+    char nm[16];
+    snprintf(nm, sizeof nm, "%08d", k);
+    hid_t g = H5Gcreate2(snaps, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (g < 0) { rc = -1; break; }
+    rc |= put_dbl(g, "Time", times[k]);
+    hsize_t d3[1] = {3}, d33[2] = {3, 3};
+    rc |= put_dbl_array_attr(g, "Center", 1, d3, centers + 3 * k);
+    rc |= put_dbl_array_attr(g, "Rotation", 2, d33, rots + 9 * k);
+    hsize_t dc[2] = {(hsize_t)ldim, (hsize_t)nmax};
+    hid_t s = H5Screate_simple(2, dc, NULL);
+    hid_t d = H5Dcreate2(g, "coefficients", ct, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (d < 0 || H5Dwrite(d, ct, H5S_ALL, H5S_ALL, H5P_DEFAULT, coefs + (size_t)k * ldim * nmax * 2) < 0) rc = -1;
+    if (d >= 0) H5Dclose(d);
+    H5Sclose(s);
+    H5Gclose(g);
+  }
+  H5Tclose(ct);
+  if (snaps >= 0) H5Gclose(snaps); else rc = -1;
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+int exp_h5_sphcoef_info(const char *path, int *lmax, int *nmax, double *scale, int *count,
+                        char *name, int name_cap, char *forceID, int id_cap, char *geometry,
+                        int geo_cap, int *has_version)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= get_int(f, "lmax", lmax);
+  rc |= get_int(f, "nmax", nmax);
+  rc |= get_dbl(f, "scale", scale);
+  get_str(f, "name", name, (size_t)name_cap);
+  get_str(f, "forceID", forceID, (size_t)id_cap);
+  rc |= get_str(f, "geometry", geometry, (size_t)geo_cap);
+  *has_version = H5Aexists(f, "CoefficientOutputVersion") > 0;
+  unsigned c = 0;
+  hid_t d = H5Dopen2(f, "count", H5P_DEFAULT);
+  if (d < 0 || H5Dread(d, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &c) < 0) rc = -1;
+  if (d >= 0) H5Dclose(d);
+  *count = (int)c;
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+int exp_h5_sphcoef_read(const char *path, int count, int lmax, int nmax, double *times,
+                        double *centers, double *rots, double *coefs)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  hid_t ct = complex_type();
+  const int ldim = (lmax + 1) * (lmax + 2) / 2;
+  int rc = 0;
+  for (int k = 0; k < count && rc == 0; k++) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "snapshots/%08d", k);
+    hid_t g = H5Gopen2(f, nm, H5P_DEFAULT);
+    if (g < 0) { rc = -1; break; }
+    rc |= get_dbl(g, "Time", times + k);
+    double *c3 = centers + 3 * k, *r9 = rots + 9 * k;
+    c3[0] = c3[1] = c3[2] = 0.0;
+    for (int q = 0; q < 9; q++) r9[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    if (H5Aexists(g, "Center") > 0) {
+      hid_t a = H5Aopen(g, "Center", H5P_DEFAULT);
+      hid_t s = H5Aget_space(a);
+      if (H5Sget_simple_extent_npoints(s) == 3) H5Aread(a, H5T_NATIVE_DOUBLE, c3);
+      H5Sclose(s); H5Aclose(a);
+    }
+    if (H5Aexists(g, "Rotation") > 0) {
+      hid_t a = H5Aopen(g, "Rotation", H5P_DEFAULT);
+      hid_t s = H5Aget_space(a);
+      if (H5Sget_simple_extent_npoints(s) == 9) H5Aread(a, H5T_NATIVE_DOUBLE, r9);
+      H5Sclose(s); H5Aclose(a);
+    }
+    hid_t d = H5Dopen2(g, "coefficients", H5P_DEFAULT);
+    if (d < 0) rc = -1;
+    else {
+      hid_t s = H5Dget_space(d);
+      hsize_t dims[2] = {0, 0};
+      if (H5Sget_simple_extent_ndims(s) != 2) rc = -1;
+      else H5Sget_simple_extent_dims(s, dims, NULL);
+      if (rc == 0 && (dims[0] != (hsize_t)ldim || dims[1] != (hsize_t)nmax)) rc = -1;
+      if (rc == 0 && H5Dread(d, ct, H5S_ALL, H5S_ALL, H5P_DEFAULT, coefs + (size_t)k * ldim * nmax * 2) < 0) rc = -1;
+      H5Sclose(s);
+      H5Dclose(d);
+    }
+    H5Gclose(g);
+  }
+  H5Tclose(ct);
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}

@@ -87,3 +87,30 @@ def test_empcyl_cache_roundtrip(h5, tmp_path):
         assert 'GROUP "Cosine"' in txt and 'GROUP "Sine"' in txt and 'DATASET "densC"' in txt
         assert "DATASPACE  SIMPLE { ( 17, 9 ) / ( 17, 9 ) }" in txt
         assert txt.count('DATASET "potS"') == 2 * 3 and txt.count('DATASET "potC"') == 3 * 3
+
+
+def test_sph_coefficient_file_roundtrip(h5, tmp_path):
+    """pyEXP's HDF5 coefficient file layout (expui/Coefficients.cc:228-330, :841-944, :3100-3163)."""
+    from exp_amd.basis import SphStruct
+    from exp_amd.coefs import SphCoefs
+    rng = np.random.default_rng(3)
+    cs = SphCoefs("dark halo")
+    for k, t in enumerate((0.0, 0.02, 0.04)):
+        cf = rng.standard_normal((10, 5)) + 1j * rng.standard_normal((10, 5))
+        cs.add(SphStruct(3, 5, 0.7, t, cf, np.array([0.1 * k, 0.0, -0.2]), np.eye(3) * (1 + k)))
+    path = str(tmp_path / "outcoef.halo.run0.h5")
+    cs.WriteH5Coefs(path, config="id: sphereSL")
+    back = SphCoefs.readH5Coefs(path)
+    assert back.name == "dark halo" and back.Times() == cs.Times()
+    for t in cs.Times():
+        a, b = cs.getCoefStruct(t), back.getCoefStruct(t)
+        assert np.array_equal(a.coefs, b.coefs) and np.array_equal(a.ctr, b.ctr) and np.array_equal(a.rot, b.rot)
+        assert (b.lmax, b.nmax, b.scale, b.time) == (3, 5, 0.7, t)
+    assert SphCoefs.readH5Coefs(path, stride=2).Times() == [0.0, 0.04]
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        txt = subprocess.run([h5dump, "-H", path], capture_output=True, text=True).stdout
+        assert 'GROUP "snapshots"' in txt and 'GROUP "00000002"' in txt and 'DATASET "count"' in txt
+        assert 'H5T_IEEE_F64LE "r"' in txt and 'H5T_IEEE_F64LE "i"' in txt
+        assert "DATASPACE  SIMPLE { ( 10, 5 ) / ( 10, 5 ) }" in txt
+        assert 'ATTRIBUTE "CoefficientOutputVersion"' in txt and 'ATTRIBUTE "Rotation"' in txt
