@@ -24,7 +24,7 @@ from typing import BinaryIO, Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .basis import SphStruct
+from .basis import CylStruct, SphStruct
 
 CMAGIC = 0x0C0A57A2                  # src/SphericalBasis.H:368
 _LEGACY = struct.Struct("<64sddii")  # SphCoefHeader: id[64], tnow, scale, nmax, Lmax
@@ -261,3 +261,105 @@ class SphCoefs:
             self.add(SphStruct(L, N, scale.value, float(times[k]), data[k, :, :, 0] + 1j * data[k, :, :, 1],
                                ctr[k].copy(), rot[k].copy()))
         return self
+
+
+# ---- cylindrical basis -----------------------------------------------------------------------------
+CMAGIC_CYL = 0x0C0A57A3              # expui/CoefStruct.cc:270 (EmpCylSL::dump_coefs_binary)
+_LEGACY_CYL = struct.Struct("<dii")  # CylCoefHeader: time, mmax, nmax (include/coef.H)
+
+
+def write_native_cyl(out: BinaryIO, c: CylStruct) -> None:
+    """``EmpCylSL::dump_coefs_binary`` (exputil/EmpCylSL.cc:5868-5920), new-style header: magic, YAML
+    {time, mmax, nmax}, then per m the cosine row and (m > 0) the sine row."""
+    import yaml
+    hdr = yaml.safe_dump({"time": float(c.time), "mmax": int(c.mmax), "nmax": int(c.nmax)},
+                         default_flow_style=False, sort_keys=False).encode()
+    out.write(struct.pack("<II", CMAGIC_CYL, len(hdr)))
+    out.write(hdr)
+    cf = np.asarray(c.coefs)
+    for m in range(c.mmax + 1):
+        out.write(np.ascontiguousarray(cf[m].real, dtype="<f8").tobytes())
+        if m:
+            out.write(np.ascontiguousarray(cf[m].imag, dtype="<f8").tobytes())
+
+
+def read_native_cyl_record(inp: BinaryIO) -> Optional[CylStruct]:
+    """``CylStruct::read`` (expui/CoefStruct.cc:258-370): new-style or 16-byte legacy header."""
+    import yaml
+    head = inp.read(4)
+    if len(head) < 4:
+        return None
+    if struct.unpack("<I", head)[0] == CMAGIC_CYL:
+        raw = inp.read(4)
+        if len(raw) < 4:
+            return None
+        node = yaml.safe_load(inp.read(struct.unpack("<I", raw)[0]).decode())
+        time, mmax, nmax = float(node["time"]), int(node["mmax"]), int(node["nmax"])
+    else:
+        rest = inp.read(_LEGACY_CYL.size - 4)
+        if len(rest) < _LEGACY_CYL.size - 4:
+            return None
+        time, mmax, nmax = _LEGACY_CYL.unpack(head + rest)
+    nrow = 2 * mmax + 1
+    buf = inp.read(8 * nrow * nmax)
+    if len(buf) < 8 * nrow * nmax:
+        return None
+    rows = np.frombuffer(buf, dtype="<f8").reshape(nrow, nmax)
+    cf = np.zeros((mmax + 1, nmax), dtype=np.complex128)
+    k = 0
+    for m in range(mmax + 1):
+        cf[m] = rows[k]
+        k += 1
+        if m:
+            cf[m] = cf[m] + 1j * rows[k]
+            k += 1
+    return CylStruct(mmax, nmax, time, cf, np.zeros(3), np.eye(3))
+
+
+class CylCoefs:
+    """``CoefClasses::CylCoefs``: cylindrical coefficient sets keyed by (rounded) time."""
+
+    geometry = "cylinder"
+
+    def __init__(self, name: str = ""):
+        self.name = name
+        self.coefs: Dict[float, CylStruct] = {}
+        self.deltaT = 0.01
+
+    def add(self, c: CylStruct) -> None:
+        self.coefs[round_time(c.time)] = c
+
+    def Times(self) -> List[float]:
+        return sorted(self.coefs)
+
+    def getCoefStruct(self, time: float) -> CylStruct:
+        try:
+            return self.coefs[round_time(time)]
+        except KeyError:
+            raise RuntimeError(f"CylCoefs: no coefficients at time {time}") from None
+
+    def getAllCoefs(self) -> np.ndarray:
+        return np.stack([np.asarray(self.coefs[t].coefs) for t in self.Times()], axis=2)
+
+    @classmethod
+    def readNativeCoefs(cls, path: str, stride: int = 1, tmin: float = -math.inf,
+                        tmax: float = math.inf, name: str = "") -> "CylCoefs":
+        self = cls(name)
+        count = 0
+        with open(path, "rb") as f:
+            while True:
+                c = read_native_cyl_record(f)
+                if c is None:
+                    break
+                keep = count % stride == 0
+                count += 1
+                if keep and tmin <= c.time <= tmax:
+                    self.add(c)
+        return self
+
+    def writeNativeCoefs(self, path: str, append: bool = False) -> None:
+        with open(path, "ab" if append else "wb") as f:
+            for t in self.Times():
+                write_native_cyl(f, self.coefs[t])
+
+    interpolate = SphCoefs.interpolate          # Coefs::interpolate is geometry-independent

@@ -369,6 +369,15 @@ class Cylinder(_Force):
     def cylmass(self, mass: float) -> None:
         check(self.lib.exp_amd_cyl_set_cylmass(self.h, float(mass)), self.ctx.h)
 
+    def dump_coefs_binary(self, out, time: float = 0.0) -> None:
+        """``EmpCylSL::dump_coefs_binary`` (exputil/EmpCylSL.cc:5868-5920): append the current
+        coefficient set to a native coefficient stream (binary file object)."""
+        from .basis import CylStruct
+        from .coefs import write_native_cyl
+        cc, ss = self.get_coefs()
+        write_native_cyl(out, CylStruct(self.grid.mmax, self.grid.norder, time, cc + 1j * ss,
+                                        np.zeros(3), np.eye(3)))
+
     FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
 
     def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:

@@ -81,3 +81,37 @@ def test_interpolate_follows_the_reference():
     assert not ok and np.allclose(a, -0.5 * c[0.2] + 1.5 * c[0.3], rtol=0, atol=1e-14)
     with pytest.raises(RuntimeError):
         cs.getCoefStruct(0.123)
+
+
+def test_cylinder_native_stream(tmp_path):
+    """EmpCylSL::dump_coefs_binary / CylStruct::read (exputil/EmpCylSL.cc:5868-5920,
+    expui/CoefStruct.cc:258-370): magic 0xc0a57a3, YAML {time, mmax, nmax}, rows cos(m), sin(m>0);
+    16-byte legacy header accepted."""
+    from exp_amd.basis import CylStruct
+    from exp_amd.coefs import CMAGIC_CYL, CylCoefs
+    rng = np.random.default_rng(2)
+    cs = CylCoefs("disk")
+    for t in (0.0, 0.5, 1.0):
+        cf = rng.standard_normal((4, 6)) + 1j * rng.standard_normal((4, 6))
+        cf[0] = cf[0].real
+        cs.add(CylStruct(3, 6, t, cf, np.zeros(3), np.eye(3)))
+    path = str(tmp_path / "outcoef.disk.run0")
+    cs.writeNativeCoefs(path)
+    raw = open(path, "rb").read()
+    assert struct.unpack("<I", raw[:4])[0] == CMAGIC_CYL == 0xc0a57a3
+    back = CylCoefs.readNativeCoefs(path)
+    assert back.Times() == [0.0, 0.5, 1.0]
+    assert np.array_equal(back.getAllCoefs(), cs.getAllCoefs())
+    a, ok = back.interpolate(0.5)
+    assert ok and np.allclose(a, cs.getCoefStruct(0.5).coefs, rtol=0, atol=1e-15)
+    # legacy header
+    leg = str(tmp_path / "legacy.cyl")
+    c = cs.getCoefStruct(0.5)
+    with open(leg, "wb") as f:
+        f.write(struct.pack("<dii", 0.5, 3, 6))
+        for m in range(4):
+            f.write(np.ascontiguousarray(c.coefs[m].real).tobytes())
+            if m:
+                f.write(np.ascontiguousarray(c.coefs[m].imag).tobytes())
+    got = CylCoefs.readNativeCoefs(leg).getCoefStruct(0.5)
+    assert np.array_equal(got.coefs, c.coefs)
