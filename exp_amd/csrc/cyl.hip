@@ -409,7 +409,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
             double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
             double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
             double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ key_out,
-            double nk_dtk, double nk_dtd)
+            double nk_dtk, double nk_dtd, int store_v)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   const int lane = threadIdx.x & 63;
@@ -498,7 +498,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     const double vx = mul_then_add(VX[i], fx, dt_kick);
     const double vy = mul_then_add(VY[i], fy, dt_kick);
     const double vz = mul_then_add(VZ[i], fz, dt_kick);
-    VX[i] = vx; VY[i] = vy; VZ[i] = vz;
+    if (store_v) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // else: deferred (exp_amd_comp::pending_kick)
     if (key_out) {
       // the sort key this particle will have after the NEXT fused step's kick + drift (the
       // arithmetic of advance_one on the values just stored): that step then only histograms
@@ -528,7 +528,7 @@ struct CylForce : exp_amd_force {
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
                              bool have_keys = false) override;
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
-                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
+                 double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
   int multistep_reset() override
@@ -754,7 +754,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
 }
 
 int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk,
-                         double nk_dtd, bool *prekey_done)
+                         double nk_dtd, bool *prekey_done, bool defer_kick)
 {
   CylForce *f = this;
   if (prekey_done) *prekey_done = false;
@@ -781,13 +781,15 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
       t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
-      dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd)
+      dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd,                        \
+      (defer_kick && dt_kick != 0.0) ? 0 : 1)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
   if (prekey) *prekey_done = true;
+  if (defer_kick && dt_kick != 0.0) t->pending_kick = dt_kick;
   return EXP_AMD_OK;
 }
 

@@ -25,8 +25,11 @@ struct exp_amd_force {
   // nk_dtk/nk_dtd != 0 (fused step only): also write the sort key each particle will have after
   // the NEXT step's kick(nk_dtk)+drift(nk_dtd) to t->key and count them into t->hist, so that
   // the next step needs no key pass.  Forces that do not support it return 0 in *prekey_done.
+  // defer_kick (fused step only): do not store v += a*dt_kick; remember it in t->pending_kick (the
+  // next fused step's scatter pass, or expamd_comp_touch, applies it as its own rounding step).
   virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick,
-                         double nk_dtk = 0.0, double nk_dtd = 0.0, bool *prekey_done = nullptr) = 0;
+                         double nk_dtk = 0.0, double nk_dtd = 0.0, bool *prekey_done = nullptr,
+                         bool defer_kick = false) = 0;
   virtual void release() = 0;
   // multistep_update for every particle whose proposed level (c->newlev) differs from its
   // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]

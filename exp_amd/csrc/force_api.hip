@@ -51,14 +51,14 @@ extern "C" int exp_amd_force_set_level(exp_amd_force *f, int mlevel)
 
 extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
 {
-  if (c) c->prekey_valid = false;
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
   return f->determine_coefficients(c, false, 0.0, 0.0);
 }
 
 extern "C" int exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external)
 {
-  if (target) target->prekey_valid = false;
+  if (target) { int rc_ = expamd_comp_touch(target); if (rc_) return rc_; }
   if (!f || !target) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "get_acceleration: NULL");
   return f->accelerate(target, external, false, 0.0);
 }
@@ -176,7 +176,7 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
                                                     long long *nswitch)
 {
   if (!f || !c || !dynfrac) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "adjust_multistep_level: NULL");
-  c->prekey_valid = false;
+  { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   exp_amd_ctx *ctx = f->ctx;
   const int ms = f->multistep;
   if (ms == 0) { if (nswitch) *nswitch = 0; return EXP_AMD_OK; }
@@ -226,7 +226,9 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
     if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
   } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys))) return rc;
   bool done = false;
-  if ((rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done))) return rc;
+  // the closing half-kick is deferred: the next fused step's scatter pass applies it (as its own
+  // rounding step) together with its opening half-kick; any other call applies it first
+  if ((rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done, /*defer_kick=*/c->n > 0))) return rc;
   if (done) {
     c->prekey_valid = true;
     c->prekey_owner = f;

@@ -123,7 +123,7 @@ static int adjust_levels(exp_amd_sim *s, int mdrft, int first_step)
 // begin_run (src/begin.cc:80-129)
 extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 {
-  if (s) for (exp_amd_comp *c : s->comps) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (s) for (exp_amd_comp *c : s->comps) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!s) return EXP_AMD_ERR_ARG;
   int rc;
   if (s->multistep) {
@@ -143,7 +143,7 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
 {
   if (s) s->step_switch = 0;
-  if (s) for (exp_amd_comp *c : s->comps) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (s) for (exp_amd_comp *c : s->comps) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
   int rc;
   for (int it = 0; it < nsteps; it++) {

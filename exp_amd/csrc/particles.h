@@ -29,6 +29,10 @@ struct exp_amd_comp {
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
   // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
   bool prekey_valid = false;
+  // The last half-kick of a fused step is NOT applied by its force pass (that would cost a read and
+  // a write of v there); it is remembered here and applied, as its own rounding step, inside the
+  // next fused step's scatter pass -- or by expamd_comp_touch() before anything else looks.
+  double pending_kick = 0.0;
   const void *prekey_owner = nullptr;   // force whose cells the keys are
   double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
 
@@ -38,3 +42,10 @@ struct exp_amd_comp {
 
 // number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
 int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);
+
+// An outside call is about to read or change the component: apply the deferred half-kick of the
+// last fused step (if any) and drop the keys it recorded for the next one.
+int expamd_comp_touch(exp_amd_comp *c);
+// ... only the first half (a read-only call: the recorded keys stay valid, they were computed from
+// the kicked velocity)
+int expamd_comp_apply_pending(exp_amd_comp *c);

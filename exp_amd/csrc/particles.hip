@@ -188,6 +188,27 @@ int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count)
   return EXP_AMD_OK;
 }
 
+int expamd_comp_touch(exp_amd_comp *c)
+{
+  c->prekey_valid = false;
+  return expamd_comp_apply_pending(c);
+}
+
+int expamd_comp_apply_pending(exp_amd_comp *c)
+{
+  if (c->pending_kick != 0.0 && c->n) {
+    const double dt = c->pending_kick;
+    c->pending_kick = 0.0;
+    ProfScope ps(c->ctx, "k_kick");
+    k_kick<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
+        c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->lev_off.p, 0,
+        c->nlevels - 1, dt);
+    HIP_TRY(c->ctx, hipGetLastError());
+  }
+  c->pending_kick = 0.0;
+  return EXP_AMD_OK;
+}
+
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
 {
   AdvanceArgs A;
@@ -196,6 +217,7 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, d
   A.ax = c->a(A_AX); A.ay = c->a(A_AY); A.az = c->a(A_AZ);
   A.lev = c->level[c->cur].p;
   A.dt_kick = dt_kick; A.dt_drift = dt_drift;
+  A.dt_kick0 = advance ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
   A.advance = advance ? 1 : 0;
   return A;
 }
@@ -254,6 +276,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
       k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
   }
   HIP_TRY(ctx, hipGetLastError());
+  if (advance) c->pending_kick = 0.0;      // the scatter applied it ahead of its own kick
   if (level < 0) {
     c->cur = 1 - c->cur;
     return EXP_AMD_OK;
@@ -444,7 +467,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
                                    const double *y, const double *z, const double *vx,
                                    const double *vy, const double *vz)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   const double *h[7] = {x, y, z, vx, vy, vz, mass};
@@ -460,7 +483,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
 extern "C" int exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
                                        const double *az, const double *pot)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   const double *h[4] = {ax, ay, az, pot};
@@ -476,7 +499,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
                                           const double *y, const double *z, const double *vx,
                                           const double *vy, const double *vz)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -497,7 +520,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
 
 extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c || !level) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -516,6 +539,7 @@ extern "C" int exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, d
                                      double *ay, double *az, double *pot)
 {
   if (!c) return EXP_AMD_ERR_ARG;
+  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   double *h[A_NARR] = {x, y, z, vx, vy, vz, mass, ax, ay, az, pot};
@@ -546,7 +570,7 @@ extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
 
 extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c || !center) return EXP_AMD_ERR_ARG;
   for (int k = 0; k < 3; k++) c->center[k] = center[k];
   c->sorted_for = nullptr;
@@ -563,7 +587,7 @@ static void level_range(const exp_amd_comp *c, int mlevel, bool upward, int *lo,
 
 extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
@@ -578,7 +602,7 @@ extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
 
 extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
@@ -593,7 +617,7 @@ extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
 
 extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
 {
-  if (c) c->prekey_valid = false;   // see exp_amd_step_kdk
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
@@ -657,6 +681,7 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
   if (mlevel < 0) mlevel = 0;
   if (mlevel >= nlev) mlevel = nlev - 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
   if (!c->com_lev.p) {
     if (c->com_lev.alloc(COM_MAXLEV * 10) != hipSuccess)
       return expamd_fail(ctx, EXP_AMD_ERR_HIP, "fix_positions: hipMalloc failed");

@@ -30,6 +30,7 @@ struct AdvanceArgs {
   const double *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az;
   const uint8_t *lev;
   double dt_kick, dt_drift;    // 0,0 -> positions are used as they are
+  double dt_kick0;             // deferred half-kick of the previous fused step, applied first (0: none)
   int advance;
 };
 
@@ -39,9 +40,16 @@ __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, doub
   x = A.x[i]; y = A.y[i]; z = A.z[i];
   if (A.advance) {
     // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
-    vx = mul_then_add(A.vx[i], A.ax[i], A.dt_kick);
-    vy = mul_then_add(A.vy[i], A.ay[i], A.dt_kick);
-    vz = mul_then_add(A.vz[i], A.az[i], A.dt_kick);
+    const double ax = A.ax[i], ay = A.ay[i], az = A.az[i];
+    vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
+    if (A.dt_kick0 != 0.0) {       // its own rounding step, exactly as the separate kick would be
+      vx = mul_then_add(vx, ax, A.dt_kick0);
+      vy = mul_then_add(vy, ay, A.dt_kick0);
+      vz = mul_then_add(vz, az, A.dt_kick0);
+    }
+    vx = mul_then_add(vx, ax, A.dt_kick);
+    vy = mul_then_add(vy, ay, A.dt_kick);
+    vz = mul_then_add(vz, az, A.dt_kick);
     x = mul_then_add(x, vx, A.dt_drift);
     y = mul_then_add(y, vy, A.dt_drift);
     z = mul_then_add(z, vz, A.dt_drift);

@@ -376,7 +376,7 @@ int sph_project(SphForce *f)
 }
 
 int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk,
-                         double nk_dtd, bool *prekey_done)
+                         double nk_dtd, bool *prekey_done, bool defer_kick)
 {
   SphForce *f = this;
   if (prekey_done) *prekey_done = false;
@@ -403,12 +403,13 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream,
                    f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0, ctx,
-                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd};
+                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1};
     k_force_launch[f->cfg.lmax](a);
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
   if (prekey) *prekey_done = true;
+  if (defer_kick && dt_kick != 0.0) t->pending_kick = dt_kick;
   return EXP_AMD_OK;
 }
 

@@ -18,7 +18,7 @@ struct SphForce : exp_amd_force {
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
                              bool have_keys = false) override;
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
-                 double nk_dtd = 0.0, bool *prekey_done = nullptr) override;
+                 double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
   void release() override;

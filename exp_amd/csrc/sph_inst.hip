@@ -35,18 +35,18 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
       ProfScope ps(a.ctx, "k_sph_force");
       k_sph_force<LMAX, true><<<cdiv(a.grid, SPH_FORCE_CHUNKS), 256, 0, a.stream>>>(
           a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-          a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd);
+          a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
     }
     // deferred waves: the grid is an upper bound, surplus waves leave on the count
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-        a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd);
+        a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
   } else {
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-        a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd);
+        a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
   }
 }
 

@@ -931,7 +931,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
                 double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
                 double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ work,
                 uint32_t *__restrict__ nwork, uint32_t *__restrict__ key_out, double nk_dtk,
-                double nk_dtd)
+                double nk_dtd, int store_v)
 {
   const int lane = threadIdx.x & 63;
   const size_t i = base + lane;
@@ -1049,7 +1049,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double vx = mul_then_add(VX[i], ax, dt_kick);
     const double vy = mul_then_add(VY[i], ay, dt_kick);
     const double vz = mul_then_add(VZ[i], az, dt_kick);
-    VX[i] = vx; VY[i] = vy; VZ[i] = vz;
+    if (store_v) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // else: deferred (exp_amd_comp::pending_kick)
     if (key_out) {
       // Where this particle will be after the NEXT step's kick + drift (the arithmetic of
       // advance_one, sort_kernels.h, on the values just stored): its sort key.  The next step
@@ -1074,7 +1074,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
             double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
             double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork,
-            uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd)
+            uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if constexpr (FAST) {
@@ -1085,7 +1085,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
       const size_t base = beg + (((size_t)blockIdx.x * SPH_FORCE_CHUNKS + c) * 256 + (threadIdx.x & ~63));
       if (base >= end) return;
       sph_force_chunk<LMAX, true>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
-                                  assign, work, nwork, key_out, nk_dtk, nk_dtd);
+                                  assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v);
     }
   } else {
     size_t base;
@@ -1098,7 +1098,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
       base = work[w];
     }
     sph_force_chunk<LMAX, false>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
-                                 assign, work, nwork, key_out, nk_dtk, nk_dtd);
+                                 assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v);
   }
 }
 
@@ -1133,6 +1133,7 @@ struct SphForceArgs {
   exp_amd_ctx *ctx;         // for the per-launch profiling scopes
   uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
   double nk_dtk, nk_dtd;    // ... for that step's kick and drift
+  int store_v;              // 0: the half-kick is deferred, v is left as it is
 };
 
 struct SphUpdArgs {

@@ -226,8 +226,9 @@ int  exp_amd_cyl_fields(exp_amd_force *f, size_t n, const double *c1, const doub
  * One multistep=0 KDK step of a single self-gravitating component
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.
  * Same results as the unfused sequence of calls above; fewer passes over HBM: kick and
- * drift are applied inside the cell-sort passes, the second half-kick inside the force
- * pass, which also records where each particle will be after the NEXT
+ * drift are applied inside the cell-sort passes; the closing half-kick is deferred (applied,
+ * as its own rounding step, by the next fused step's scatter pass, or before any other call
+ * reads or changes the component); the force pass also records where each particle will be after the NEXT
  * call's kick+drift, so that consecutive calls with the same dt skip the key pass.  Any
  * other call on the component in between (upload, kick, drift, set_center, zero_acc,
  * another force, a different dt) discards that record.                                */
