@@ -304,6 +304,61 @@ class SphereSL(_Force):
     def set_coefs(self, coef) -> None:
         self._set_flat(coef)
 
+    # -- playback (the `playback` / `coefCompute` keys, src/SphericalBasis.cc:155-213) ---------------
+    def set_playback(self, coefs, dtime: float, coef_compute: bool = False) -> None:
+        """Drive the force from a stored coefficient series instead of the particles: ``coefs`` is
+        a ``SphCoefs`` (native stream or HDF5 file read by exp_amd.coefs) or a path to one.  The
+        constructor's checks are the reference's: lmax and nmax must match the basis (``:179-195``),
+        the off-grid tolerance is twice the time step (``:177``)."""
+        from .coefs import SphCoefs
+        if isinstance(coefs, (str, bytes)):
+            path = coefs.decode() if isinstance(coefs, bytes) else coefs
+            with open(path, "rb") as f:
+                magic = f.read(8)
+            coefs = (SphCoefs.readH5Coefs(path) if magic.startswith(b"\x89HDF")
+                     else SphCoefs.readNativeCoefs(path))
+        first = coefs.getCoefStruct(coefs.Times()[0])
+        if first.nmax != self.nmax:
+            raise RuntimeError(f"SphericalBasis: nmax for playback [{first.nmax}] does not match "
+                               f"specification [{self.nmax}]")
+        if first.lmax != self.lmax:
+            raise RuntimeError(f"SphericalBasis: Lmax for playback [{first.lmax}] does not match "
+                               f"specification [{self.lmax}]")
+        coefs.setDeltaT(2.0 * dtime)
+        self.playback, self.play_back, self.play_cnew = coefs, True, bool(coef_compute)
+        self.lastPlayTime, self.expcoefP, self.stop_signal = -np.inf, None, 0
+
+    def determine_coefficients(self, comp: "Component", tnow: Optional[float] = None) -> None:
+        """``SphericalBasis::determine_coefficients`` (src/SphericalBasis.cc:600-608): from the
+        particles, or -- in playback -- from the coefficient series at ``tnow`` (``:610-680``: one
+        interpolation per new time, complex (l, m>=0) rows unpacked into the real-row order), plus
+        the particles when ``coefCompute`` is set."""
+        if not getattr(self, "play_back", False):
+            return super().determine_coefficients(comp)
+        if tnow is None:
+            raise ValueError("playback: determine_coefficients needs the current time")
+        if tnow > self.lastPlayTime:
+            from .coefs import complex_to_real_rows
+            self.lastPlayTime = tnow
+            mat, ok = self.playback.interpolate(tnow)
+            if not ok:
+                self.stop_signal = 1
+            self.expcoefP = complex_to_real_rows(mat, self.lmax)
+        if self.play_cnew:
+            super().determine_coefficients(comp)
+
+    def get_acceleration_and_potential(self, comp: "Component", external: bool = False) -> None:
+        """Force pass; in playback the played-back set is swapped in for the evaluation and the
+        particle-derived one (``coefCompute``) restored after it (src/SphericalBasis.cc:1676-1678,
+        :1752-1754)."""
+        if not getattr(self, "play_back", False) or self.expcoefP is None:
+            return super().get_acceleration_and_potential(comp, external)
+        keep = self._get_flat() if self.play_cnew else None
+        self._set_flat(self.expcoefP)
+        super().get_acceleration_and_potential(comp, external)
+        if keep is not None:
+            self._set_flat(keep)
+
     def dump_coefs(self, out, time: float = 0.0, scale: Optional[float] = None) -> None:
         """``SphericalBasis::dump_coefs(ostream&)`` (src/SphericalBasis.cc:1829-1879): append the
         current coefficient set to a native coefficient stream (binary file object)."""
@@ -401,12 +456,17 @@ class Cylinder(_Force):
         return out
 
 
-def do_step_single(force: _Force, comp: Component, dt: float) -> None:
-    """Unfused multistep=0 step, call for call as ``do_step`` (src/step.cc:271-323)."""
+def do_step_single(force: _Force, comp: Component, dt: float, tnow: Optional[float] = None) -> None:
+    """Unfused multistep=0 step, call for call as ``do_step`` (src/step.cc:271-323).  ``tnow`` is
+    the reference's global of that name while the step runs -- the END-of-step time (``tnow +=
+    dtime`` comes first, ``:274``) -- and is what a force in playback mode is evaluated at."""
     comp.incr_velocity(0.5 * dt)
     comp.incr_position(dt)
     force.set_multistep_level(0)
-    force.determine_coefficients(comp)
+    if getattr(force, "play_back", False):
+        force.determine_coefficients(comp, tnow)
+    else:
+        force.determine_coefficients(comp)
     comp.zero_acceleration(0)
     force.get_acceleration_and_potential(comp)
     comp.incr_velocity(0.5 * dt)

@@ -246,3 +246,66 @@ def test_coefficient_stream_playback_and_fields_over_time(halo_basis, tmp_path):
     basis.set_coefs(coefs.getCoefStruct(times[1]))
     assert ret["potl"][1] == pytest.approx(basis.getFields(0.1, -0.05, 0.02)[5], rel=1e-13)
     c.close()
+
+
+def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
+    """`playback` key of the n-body force (src/SphericalBasis.cc:155-213, :600-680, :1676-1754):
+    a live run writes its coefficient stream (native and HDF5); re-running the same initial
+    conditions with the force in playback mode -- coefficients from the file, no accumulation --
+    gives the same trajectory, bit for bit at the stored times (interpolation weights 1 and 0).
+    With coefCompute the particle-derived set is also produced and survives the force call."""
+    from exp_amd.coefs import SphCoefs, round_time
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, do_step_single
+    basis, _ = halo_basis
+    f = basis.force
+    m, pos, vel = sample_sphere(basis.model, 20000, seed=11, rlim=1.9)
+    dt, nstep = 0.002, 4
+
+    def run(playback):
+        c = Component.from_arrays(basis.ctx, m, pos, vel)
+        f.play_back = False
+        f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
+        if playback is not None:
+            f.set_playback(playback[0], dt, coef_compute=playback[1])
+        rec, sets = SphCoefs("halo"), []
+        for k in range(nstep):
+            do_step_single(f, c, dt, tnow=round_time((k + 1) * dt))
+            sets.append(f.get_coefs())
+            if playback is None:
+                import io
+                from exp_amd.coefs import read_native_record
+                buf = io.BytesIO(); f.dump_coefs(buf, time=round_time((k + 1) * dt)); buf.seek(0)
+                rec.add(read_native_record(buf))
+        out = c.download(("pos", "vel", "acc"))
+        c.close()
+        f.play_back = False
+        return out, rec, sets
+
+    live, rec, live_sets = run(None)
+    native, h5 = str(tmp_path / "outcoef.halo"), str(tmp_path / "outcoef.halo.h5")
+    rec.writeNativeCoefs(native)
+    rec.WriteH5Coefs(h5)
+    for src in (rec, native, h5):
+        got, _, _ = run((src, False))
+        for k in ("pos", "vel", "acc"):
+            assert np.array_equal(got[k], live[k]), (type(src), k)
+    assert f.stop_signal == 0
+    got, _, sets = run((rec, True))                      # coefCompute: both sets exist
+    assert np.array_equal(got["pos"], live["pos"])
+    assert np.array_equal(sets[-1], live_sets[-1])        # particle-derived set restored after the force
+    # a basis mismatch is refused the way the constructor refuses it
+    bad = SphCoefs("bad")
+    st = rec.getCoefStruct(rec.Times()[0])
+    import copy
+    st2 = copy.copy(st); st2.nmax = st.nmax + 1
+    bad.add(st2)
+    with pytest.raises(RuntimeError, match="nmax for playback"):
+        f.set_playback(bad, dt)
+    # beyond the stored range (by more than 2 dtime) the stop signal is raised
+    f.set_playback(rec, dt)
+    c = Component.from_arrays(basis.ctx, m, pos, vel)
+    f.determine_coefficients(c, tnow=nstep * dt + 5 * dt)
+    assert f.stop_signal == 1
+    f.play_back = False
+    c.close()
