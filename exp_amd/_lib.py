@@ -7,7 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_longlong, c_size_t, c_void_p
+from ctypes import (POINTER, c_char_p, c_double, c_int, c_int32, c_longlong, c_size_t, c_uint,
+                    c_void_p)
 
 import numpy as np
 
@@ -68,6 +69,14 @@ SIGNATURES = {
     "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p)]),
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
+    "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
+                                      POINTER(c_void_p)]),
+    "exp_amd_orient_destroy": (None, [c_void_p]),
+    "exp_amd_orient_set_center": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_orient_set_cenvel": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_orient_set_linear": (c_int, [c_void_p]),
+    "exp_amd_orient_accumulate": (c_int, [c_void_p, c_double, c_double, c_void_p]),
+    "exp_amd_orient_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
     "exp_amd_cyl_set_density": (c_int, [c_void_p, c_void_p]),

@@ -1,0 +1,439 @@
+// Orientation / expansion-centre estimator: replaces class Orient (src/Orient.cc:38-790, Orient.H)
+// with its O(N) part on the device.  What the reference does per call (accumulate, :420-747):
+//   1. energy of every particle, E = pot [+ v^2/2 with KE]             (accumulate_cpu :325-417)
+//   2. keep the `many`+1 most bound; Ecurr = the (many+1)-th lowest energy (or the highest when the
+//      component holds no more than `many` particles)                     (:452-483)
+//   3. over the particles with E < Ecurr: sum m (x - centre) x v, m x, m  (:485-555)
+//   4. push (time, L/M) and (time, R/M) on two short histories and take a damped linear
+//      least-squares extrapolation of each as the new axis / centre      (:557-700)
+// Steps 1-3 are a selection problem over N doubles.  The reference sorts 200000-particle bunches of
+// 64-byte records with thrust and walks a std::set on the host (src/cudaOrient.cu:109-199); here
+// the energies become order-preserving 64-bit keys (8 B/particle, written once), the k-th smallest
+// is found EXACTLY by a six-pass most-significant-digit radix select (12-bit digits, LDS
+// histograms, wave-aggregated updates, one small all-reduce of the 4096 bins per pass when the
+// component is sharded over ranks -- so the threshold is the global one, where the reference's
+// per-rank many/numprocs trimming is only approximately that), and one streaming pass forms the
+// sums.  Step 4 is a few dozen flops on the host, restated statement for statement including the
+// reference's use of the CENTRE history length in the AXIS regression (:583).
+// Not carried over: the log file and its restart (:84-330), the PseudoAccel helper (naccel), the
+// EXTERNAL flag (this store has no separate external potential) and keep == 0, whose code path in
+// the reference indexes its 3-vectors out of range (:741-744).
+#include "particles.h"
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <array>
+#include <new>
+
+namespace {
+
+constexpr int ORI_BITS = 12, ORI_BINS = 1 << ORI_BITS, ORI_TPB = 256, ORI_ITEMS = 8;
+constexpr int ORI_TILE = ORI_TPB * ORI_ITEMS;
+enum { ORI_AXIS = 1, ORI_CENTER = 2 };          // Orient::OrientFlags  (src/Orient.H:129)
+enum { ORI_DIAG = 1, ORI_KE = 2, ORI_EXTERNAL = 4 };   // Orient::ControlFlags (:132)
+
+// device-resident selection state
+struct OriState {
+  unsigned long long prefix;     // digits chosen so far (most significant first)
+  unsigned long long krem;       // rank still to descend inside the chosen prefix
+  unsigned long long total;      // particles over all ranks
+  unsigned long long pad;
+};
+
+// order-preserving map of a double onto an unsigned 64-bit integer (-0 is folded onto +0 first)
+__device__ __forceinline__ unsigned long long ord_key(double e)
+{
+  e = e + 0.0;
+  const unsigned long long u = (unsigned long long)__double_as_longlong(e);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ void __launch_bounds__(ORI_TPB)
+k_orient_keys(const double *__restrict__ POT, const double *__restrict__ VX,
+              const double *__restrict__ VY, const double *__restrict__ VZ, size_t n, int ke,
+              unsigned long long *__restrict__ key)
+{
+  const size_t i = (size_t)blockIdx.x * ORI_TPB + threadIdx.x;
+  if (i >= n) return;
+  double e = POT[i];
+  if (ke) {                      // v2 += vel[k]*vel[k]; energy += 0.5*v2 -- each product rounded (:352-359)
+    double v2 = mul_then_add(0.0, VX[i], VX[i]);
+    v2 = mul_then_add(v2, VY[i], VY[i]);
+    v2 = mul_then_add(v2, VZ[i], VZ[i]);
+    e = mul_then_add(e, 0.5, v2);
+  }
+  key[i] = ord_key(e);
+}
+
+// one radix-select pass: histogram of the digit at `shift` over the keys whose higher bits equal
+// the prefix chosen so far.  The bins are doubles so that the context's all-reduce can sum them.
+__global__ void __launch_bounds__(ORI_TPB)
+k_orient_hist(const unsigned long long *__restrict__ key, size_t n, const OriState *__restrict__ st,
+              int pass, int shift, int bits, double *__restrict__ hist)
+{
+  __shared__ uint32_t lh[ORI_BINS];
+  for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) lh[b] = 0;
+  __syncthreads();
+  const unsigned long long prefix = st->prefix;
+  const unsigned mask = (1u << bits) - 1u;
+  const int lane = threadIdx.x & 63;
+  const size_t base = (size_t)blockIdx.x * ORI_TILE;
+#pragma unroll
+  for (int j = 0; j < ORI_ITEMS; j++) {
+    const size_t i = base + (size_t)j * ORI_TPB + threadIdx.x;
+    bool valid = i < n;
+    unsigned digit = 0;
+    if (valid) {
+      const unsigned long long k = key[i];
+      valid = pass == 0 || (k >> ((shift + bits) & 63)) == prefix;
+      digit = (unsigned)(k >> shift) & mask;
+    }
+    // energies cluster: group the lanes of a wave by digit, one LDS add per distinct digit
+    unsigned long long rem = __ballot(valid);
+    while (rem) {
+      const int lead = __ffsll((long long)rem) - 1;
+      const unsigned dd = (unsigned)__shfl((int)digit, lead);
+      const unsigned long long mm = __ballot(valid && digit == dd);
+      if (lane == lead) atomicAdd(&lh[dd], (uint32_t)__popcll(mm));
+      rem &= ~mm;
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) {
+    const uint32_t c = lh[b];
+    if (c) unsafeAtomicAdd(&hist[b], (double)c);
+  }
+}
+
+// descend one digit: find the bin that holds rank krem, clear the histogram for the next pass
+__global__ void __launch_bounds__(64)
+k_orient_pick(double *__restrict__ hist, OriState *__restrict__ st, int pass, int bits,
+              unsigned long long many)
+{
+  __shared__ unsigned long long cum[64], sub[64], s_run, s_krem;
+  __shared__ int s_blk;
+  const int nb = 1 << bits, per = nb >= 64 ? nb / 64 : 1, nblk = nb / per;
+  const int t = threadIdx.x;
+  unsigned long long mine = 0;
+  if (t < nblk)
+    for (int b = t * per; b < (t + 1) * per; b++) mine += (unsigned long long)hist[b];
+  cum[t] = mine;
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long krem = st->krem;
+    if (pass == 0) {             // ee.size() <= many ? ee.back() : ee[many]   (:474-478)
+      unsigned long long tot = 0;
+      for (int k = 0; k < nblk; k++) tot += cum[k];
+      st->total = tot;
+      krem = tot == 0 ? 0 : (tot <= many ? tot - 1 : many);
+      st->prefix = 0;
+    }
+    unsigned long long run = 0;
+    int blk = 0;
+    for (; blk < nblk - 1; blk++) {
+      if (krem < run + cum[blk]) break;
+      run += cum[blk];
+    }
+    s_blk = blk; s_run = run; s_krem = krem;
+  }
+  __syncthreads();
+  if (t < per) sub[t] = (unsigned long long)hist[s_blk * per + t];
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long run = s_run;
+    int b = 0;
+    for (; b < per - 1; b++) {
+      if (s_krem < run + sub[b]) break;
+      run += sub[b];
+    }
+    st->krem = s_krem - run;
+    st->prefix = (st->prefix << bits) | (unsigned long long)(s_blk * per + b);
+  }
+  __syncthreads();
+  for (int b = t; b < ORI_BINS; b += 64) hist[b] = 0.0;
+}
+
+// sums over the particles more bound than the threshold key: {count, M, L[3], R[3]}
+__global__ void __launch_bounds__(ORI_TPB)
+k_orient_sums(const unsigned long long *__restrict__ key, const double *__restrict__ M,
+              const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+              const double *__restrict__ VX, const double *__restrict__ VY,
+              const double *__restrict__ VZ, size_t n, const OriState *__restrict__ st,
+              double cx, double cy, double cz, double *__restrict__ out)
+{
+  __shared__ double acc[8];
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0.0;
+  __syncthreads();
+  const unsigned long long thr = st->prefix;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * ORI_TPB;
+  for (size_t i = (size_t)blockIdx.x * ORI_TPB + threadIdx.x; i < n; i += stride) {
+    if (key[i] >= thr) continue;                     // i->E < Ecurr   (:489)
+    const double m = M[i], x = X[i], y = Y[i], z = Z[i], vx = VX[i], vy = VY[i], vz = VZ[i];
+    const double px = x - cx, py = y - cy, pz = z - cz;
+    v[0] += 1.0;
+    v[1] += m;
+    v[2] += m * (py * vz - pz * vy);                 // t.L (:378-380)
+    v[3] += m * (pz * vx - px * vz);
+    v[4] += m * (px * vy - py * vx);
+    v[5] += m * x;                                   // t.R (:382-384)
+    v[6] += m * y;
+    v[7] += m * z;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    double t = v[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if ((threadIdx.x & 63) == 0 && t != 0.0) unsafeAtomicAdd(&acc[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && acc[threadIdx.x] != 0.0) unsafeAtomicAdd(out + threadIdx.x, acc[threadIdx.x]);
+}
+
+typedef std::array<double, 3> V3;
+typedef std::pair<double, V3> DV;
+
+// return_euler_slater (exputil/euler_slater.cc:46-76), row-major 3x3; body != 0 transposes
+void euler_slater(double phi, double theta, double psi, int body, double *o)
+{
+  const double sph = sin(phi), cph = cos(phi), sth = sin(theta), cth = cos(theta), sps = sin(psi),
+               cps = cos(psi);
+  double e[9] = {-sps * sph + cth * cph * cps, sps * cph + cth * sph * cps, cps * sth,
+                 -cps * sph - cth * cph * sps, cps * cph - cth * sph * sps, -sps * sth,
+                 -sth * cph, -sth * sph, cth};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) o[3 * i + j] = body ? e[3 * j + i] : e[3 * i + j];
+}
+
+}  // namespace
+
+struct exp_amd_orient {
+  exp_amd_ctx *ctx = nullptr;
+  int keep = 0, many = 0;
+  unsigned oflags = 0, cflags = 0;
+  double deltaT = 0, damp = 1;
+  bool linear = false;
+  V3 center{{0, 0, 0}}, center0{{0, 0, 0}}, cenvel0{{0, 0, 0}}, axis{{0, 0, 1}};
+  V3 axis1{{0, 0, 0}}, center1{{0, 0, 0}};
+  std::deque<DV> sumsA, sumsC;
+  double lasttime = -1.7976931348623157e308;
+  double body[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, orig[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  long long used = 0;
+  double Ecurr = 0, sigA = 0, sigC = 0, sigCz = 0, mtot = 0;
+  DevBuf<unsigned long long> keys;
+  DevBuf<double> hist, sums;
+  DevBuf<OriState> state;
+};
+
+extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsigned oflags,
+                                     unsigned cflags, double deltaT, double damp,
+                                     exp_amd_orient **out)
+{
+  if (!ctx || !out) return EXP_AMD_ERR_ARG;
+  if (keep < 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: keep must be >= 1 (the keep == 0 "
+                                   "branch of the reference indexes out of range, src/Orient.cc:741-744)");
+  if (want < 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: target number must be >= 1");
+  if (cflags & ORI_EXTERNAL)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: EXTERNAL (potext) is not kept by this particle store");
+  exp_amd_orient *o = new (std::nothrow) exp_amd_orient;
+  if (!o) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: out of memory");
+  o->ctx = ctx; o->keep = keep; o->many = want; o->oflags = oflags; o->cflags = cflags;
+  o->deltaT = deltaT; o->damp = damp;
+  if (hipSetDevice(ctx->device) != hipSuccess || o->hist.alloc(ORI_BINS) != hipSuccess ||
+      o->sums.alloc(8) != hipSuccess || o->state.alloc(1) != hipSuccess) {
+    delete o;
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc failed");
+  }
+  *out = o;
+  return EXP_AMD_OK;
+}
+
+extern "C" void exp_amd_orient_destroy(exp_amd_orient *o)
+{
+  if (!o) return;
+  o->keys.release(); o->hist.release(); o->sums.release(); o->state.release();
+  delete o;
+}
+
+// Orient::set_center / set_cenvel / set_linear (src/Orient.H:143-160)
+extern "C" int exp_amd_orient_set_center(exp_amd_orient *o, const double c[3])
+{
+  if (!o || !c) return EXP_AMD_ERR_ARG;
+  for (int k = 0; k < 3; k++) o->center[k] = o->center0[k] = c[k];
+  return EXP_AMD_OK;
+}
+extern "C" int exp_amd_orient_set_cenvel(exp_amd_orient *o, const double v[3])
+{
+  if (!o || !v) return EXP_AMD_ERR_ARG;
+  for (int k = 0; k < 3; k++) o->cenvel0[k] = v[k];
+  return EXP_AMD_OK;
+}
+extern "C" int exp_amd_orient_set_linear(exp_amd_orient *o)
+{
+  if (!o) return EXP_AMD_ERR_ARG;
+  o->linear = true;
+  return EXP_AMD_OK;
+}
+
+// steps 1-3 on the device: Ecurr, used, mtot, sum L, sum R (all ranks combined)
+static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], double *Ecurr)
+{
+  exp_amd_ctx *ctx = o->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  const size_t n = c->n;
+  if (o->keys.n < n && o->keys.alloc(n) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc of %zu keys failed", n);
+  HIP_TRY(ctx, hipMemsetAsync(o->hist.p, 0, o->hist.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(o->sums.p, 0, o->sums.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(o->state.p, 0, sizeof(OriState), ctx->stream));
+  const bool multi = ctx->nranks > 1 || ctx->ar_fn;
+  {
+    ProfScope ps(ctx, "k_orient_select");
+    if (n)
+      k_orient_keys<<<cdiv(n, ORI_TPB), ORI_TPB, 0, ctx->stream>>>(
+          c->a(A_POT), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n, (o->cflags & ORI_KE) ? 1 : 0, o->keys.p);
+    static const int shift[6] = {52, 40, 28, 16, 4, 0}, bits[6] = {12, 12, 12, 12, 12, 4};
+    for (int p = 0; p < 6; p++) {
+      if (n)
+        k_orient_hist<<<cdiv(n, ORI_TILE), ORI_TPB, 0, ctx->stream>>>(o->keys.p, n, o->state.p, p,
+                                                                      shift[p], bits[p], o->hist.p);
+      if (multi) { int rc = expamd_allreduce(ctx, o->hist.p, ORI_BINS); if (rc) return rc; }
+      k_orient_pick<<<1, 64, 0, ctx->stream>>>(o->hist.p, o->state.p, p, bits[p],
+                                               (unsigned long long)o->many);
+    }
+    if (n) {
+      unsigned grid = cdiv(n, ORI_TPB * 16);
+      if (grid > 2048) grid = 2048;
+      k_orient_sums<<<grid, ORI_TPB, 0, ctx->stream>>>(o->keys.p, c->a(A_M), c->a(A_X), c->a(A_Y),
+                                                       c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n,
+                                                       o->state.p, o->center[0], o->center[1],
+                                                       o->center[2], o->sums.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (multi) { int rc = expamd_allreduce(ctx, o->sums.p, 8); if (rc) return rc; }
+  OriState st;
+  HIP_TRY(ctx, hipMemcpyAsync(res, o->sums.p, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&st, o->state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long u = st.prefix;                  // undo ord_key
+  u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+  double e;
+  memcpy(&e, &u, sizeof(e));
+  *Ecurr = st.total ? e : 0.0;
+  return EXP_AMD_OK;
+}
+
+// damped least-squares extrapolation of a (time, vector) history (:576-604, :620-676).  N is passed
+// in because the AXIS branch of the reference uses the CENTRE history's length.
+static void regress(const std::deque<DV> &h, int N, double damp, double time, V3 &val, double &sig,
+                    double *sigz)
+{
+  double sumX = 0, sumX2 = 0;
+  V3 sumY{{0, 0, 0}}, sumXY{{0, 0, 0}};
+  for (const DV &j : h) {
+    const double x = j.first;
+    sumX += x;
+    sumX2 += x * x;
+    for (int k = 0; k < 3; k++) { sumY[k] += j.second[k]; sumXY[k] += j.second[k] * x; }
+  }
+  V3 slope, icpt;
+  const double den = sumX2 * N - sumX * sumX;
+  for (int k = 0; k < 3; k++) {
+    slope[k] = (sumXY[k] * N - sumX * sumY[k]) / den;
+    icpt[k] = (sumX2 * sumY[k] - sumX * sumXY[k]) / den;
+  }
+  const double tt = damp * time + (1.0 - damp) * h.front().first;
+  for (int k = 0; k < 3; k++) val[k] = icpt[k] + slope[k] * tt;
+  sig = 0.0;
+  if (sigz) *sigz = 0.0;
+  int i = 0;
+  for (const DV &j : h) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) {
+      const double d = j.second[k] - icpt[k] - slope[k] * j.first;
+      s += d * d;
+      if (k == 2 && sigz) *sigz += d * d;
+    }
+    sig += s;
+    i++;
+  }
+  sig /= i;
+  if (sigz) *sigz /= i;
+}
+
+// Orient::accumulate(time, c) (src/Orient.cc:420-747); dtime is the reference's global time step
+// (centre drift `center0 += cenvel0*dtime`, :433, :716)
+extern "C" int exp_amd_orient_accumulate(exp_amd_orient *o, double time, double dtime, exp_amd_comp *c)
+{
+  if (!o || !c) return EXP_AMD_ERR_ARG;
+  if (fabs(o->lasttime - time) < 1.0e-12) return EXP_AMD_OK;      // no duplicate entry (:423)
+  if (time - o->deltaT - o->lasttime < 0.0) return EXP_AMD_OK;    // spaced by deltaT (:425)
+  o->lasttime = time;
+  if (o->linear) {
+    o->center = o->center0;
+    for (int k = 0; k < 3; k++) o->center0[k] += o->cenvel0[k] * dtime;
+    return EXP_AMD_OK;
+  }
+  double r[8];
+  int rc = orient_select(o, c, r, &o->Ecurr);
+  if (rc) return rc;
+  o->used = (long long)r[0];
+  o->mtot = r[1];
+  for (int k = 0; k < 3; k++) { o->axis1[k] = r[2 + k]; o->center1[k] = r[5 + k]; }
+  if (o->mtot > 0.0) {
+    for (int k = 0; k < 3; k++) { o->axis1[k] /= o->mtot; o->center1[k] /= o->mtot; }
+    if (o->oflags & ORI_AXIS) o->sumsA.push_back(DV(time, o->axis1));
+    if (o->oflags & ORI_CENTER) o->sumsC.push_back(DV(time, o->center1));
+  }
+  if ((int)o->sumsA.size() > o->keep + 1) {
+    o->sumsA.pop_front();
+    regress(o->sumsA, (int)o->sumsC.size(), o->damp, time, o->axis, o->sigA, nullptr);
+    const double phi = atan2(o->axis[1], o->axis[0]);
+    const double theta = -acos(o->axis[2] / sqrt(o->axis[0] * o->axis[0] + o->axis[1] * o->axis[1] +
+                                                 o->axis[2] * o->axis[2]));
+    euler_slater(phi, theta, 0.0, 0, o->body);
+    euler_slater(phi, theta, 0.0, 1, o->orig);
+  }
+  if (o->sumsC.size() > 1) {
+    if ((int)o->sumsC.size() > o->keep + 1) o->sumsC.pop_front();
+    regress(o->sumsC, (int)o->sumsC.size(), o->damp, time, o->center, o->sigC, &o->sigCz);
+  }
+  if (o->keep > 1) {
+    if (o->sumsC.size() > 1) {
+      double factor = (double)((int)o->sumsC.size() - o->keep) / o->keep;
+      factor = factor * factor;
+      for (int k = 0; k < 3; k++) o->center[k] = o->center0[k] * factor + o->center[k] * (1.0 - factor);
+    } else
+      o->center = o->center0;
+  } else
+    o->center = o->center1;
+  for (int k = 0; k < 3; k++) o->center0[k] += o->cenvel0[k] * dtime;
+  return EXP_AMD_OK;
+}
+
+// currentCenter / currentAxis / transformBody / transformOrig and the diagnostics of logEntry
+// (src/Orient.H:166-194, src/Orient.cc:749-783): stats = {Ecurr, used, sigA, sigC, sigCz, mtot,
+// axis1[3], center1[3], center0[3]}
+extern "C" int exp_amd_orient_get(const exp_amd_orient *o, double center[3], double axis[3],
+                                  double body[9], double orig[9], double stats[15])
+{
+  if (!o) return EXP_AMD_ERR_ARG;
+  for (int k = 0; k < 3; k++) {
+    if (center) center[k] = o->center[k];
+    if (axis) axis[k] = o->axis[k];
+  }
+  for (int k = 0; k < 9; k++) {
+    if (body) body[k] = o->body[k];
+    if (orig) orig[k] = o->orig[k];
+  }
+  if (stats) {
+    stats[0] = o->Ecurr; stats[1] = (double)o->used; stats[2] = o->sigA; stats[3] = o->sigC;
+    stats[4] = o->sigCz; stats[5] = o->mtot;
+    for (int k = 0; k < 3; k++) {
+      stats[6 + k] = o->axis1[k]; stats[9 + k] = o->center1[k]; stats[12 + k] = o->center0[k];
+    }
+  }
+  return EXP_AMD_OK;
+}

@@ -217,6 +217,92 @@ class Component:
                 self.ctx._children.remove(self)
 
 
+class Orient:
+    """``Orient`` (src/Orient.H:31-204): the most-bound-particle estimator of a component's
+    expansion centre and symmetry axis.  Constructor arguments are the reference's
+    (number_to_keep, target, orient flags, control flags, dT, damping); the log file, its restart
+    and the pseudo-acceleration helper are not carried over."""
+
+    AXIS, CENTER = 1, 2                     # Orient::OrientFlags
+    DIAG, KE, EXTERNAL = 1, 2, 4            # Orient::ControlFlags
+
+    def __init__(self, ctx: Context, number_to_keep: int, target: int, orient_flags: int,
+                 control_flags: int = 0, dT: float = 0.0, damping: float = 1.0):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = c_void_p()
+        check(self.lib.exp_amd_orient_create(ctx.h, int(number_to_keep), int(target),
+                                             int(orient_flags), int(control_flags), float(dT),
+                                             float(damping), byref(h)), ctx.h)
+        self.h = h
+        ctx._children.append(self)
+
+    def set_center(self, x: float, y: float, z: float) -> None:
+        v = (c_double * 3)(x, y, z)
+        check(self.lib.exp_amd_orient_set_center(self.h, v), self.ctx.h)
+
+    def set_cenvel(self, u: float, v: float, w: float) -> None:
+        a = (c_double * 3)(u, v, w)
+        check(self.lib.exp_amd_orient_set_cenvel(self.h, a), self.ctx.h)
+
+    def set_linear(self) -> None:
+        check(self.lib.exp_amd_orient_set_linear(self.h), self.ctx.h)
+
+    def accumulate(self, time: float, comp: "Component", dtime: float = 0.0) -> None:
+        """``Orient::accumulate(time, c)`` (src/Orient.cc:420-747); ``dtime`` is the reference's
+        global time step (drift of the user-specified centre)."""
+        check(self.lib.exp_amd_orient_accumulate(self.h, float(time), float(dtime), comp.h),
+              self.ctx.h)
+
+    def _get(self):
+        c, a, b, o, s = ((c_double * 3)(), (c_double * 3)(), (c_double * 9)(), (c_double * 9)(),
+                         (c_double * 15)())
+        check(self.lib.exp_amd_orient_get(self.h, c, a, b, o, s), self.ctx.h)
+        return (np.array(c[:]), np.array(a[:]), np.array(b[:]).reshape(3, 3),
+                np.array(o[:]).reshape(3, 3), np.array(s[:]))
+
+    def currentCenter(self) -> np.ndarray:
+        return self._get()[0]
+
+    def currentAxis(self) -> np.ndarray:
+        return self._get()[1]
+
+    def transformBody(self) -> np.ndarray:
+        return self._get()[2]
+
+    def transformOrig(self) -> np.ndarray:
+        return self._get()[3]
+
+    def currentE(self) -> float:
+        return float(self._get()[4][0])
+
+    def currentUsed(self) -> int:
+        return int(self._get()[4][1])
+
+    def currentAxisVar(self) -> float:
+        return float(self._get()[4][2])
+
+    def currentCenterVar(self) -> float:
+        return float(self._get()[4][3])
+
+    def currentCenterVarZ(self) -> float:
+        return float(self._get()[4][4])
+
+    def state(self) -> dict:
+        """The quantities ``Orient::logEntry`` writes (src/Orient.cc:749-783)."""
+        c, a, b, o, s = self._get()
+        return {"center": c, "axis": a, "body": b, "orig": o, "Ecurr": float(s[0]),
+                "used": int(s[1]), "sigA": float(s[2]), "sigC": float(s[3]), "sigCz": float(s[4]),
+                "mtot": float(s[5]), "axis1": s[6:9].copy(), "center1": s[9:12].copy(),
+                "center0": s[12:15].copy()}
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.exp_amd_orient_destroy(self.h)
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+
 class _Force:
     """PotAccel-shaped methods shared by every force method (src/PotAccel.H:173-288)."""
 

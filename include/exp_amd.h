@@ -108,6 +108,31 @@ int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
  * (the three vectors divided by mtot when mtot > 0).                                        */
 int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
 
+/* ---- orientation / expansion-centre estimator ("EJ") ----------------------------------------
+ * Replaces class Orient (src/Orient.H:31-204, src/Orient.cc:38-790; CUDA twin
+ * src/cudaOrient.cu:109-199), created by Component::initialize with (nEJkeep, nEJwant, EJ flags,
+ * EJkinE, EJdT, EJdamp) (src/Component.cc:1323-1370) and consulted by Component::fix_positions
+ * (:3569-3582) and the cylinder force (src/Cylinder.cc:799, :1352).
+ *   oflags: 1 = AXIS, 2 = CENTER (Orient::OrientFlags);  cflags: 2 = KE (Orient::ControlFlags; DIAG
+ *   is ignored, EXTERNAL is refused: no separate external potential is stored).  keep >= 1.
+ * accumulate(time, dtime, c) is Orient::accumulate(time, c) with the global time step passed in:
+ * the `want` most bound particles (E = pot [+ v^2/2]) are selected on the device -- exactly, over
+ * all ranks of the context -- and their mass-weighted position and angular momentum about the
+ * current centre enter the damped least-squares histories; calls closer than deltaT are skipped.
+ * get: centre, axis, the body/original rotations (row-major 3x3, return_euler_slater
+ * exputil/euler_slater.cc:46) and stats = {Ecurr, used, sigA, sigC, sigCz, mtot, axis1[3],
+ * center1[3], center0[3]}; any output pointer may be NULL.                                    */
+typedef struct exp_amd_orient exp_amd_orient;
+int  exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsigned oflags, unsigned cflags,
+                           double deltaT, double damp, exp_amd_orient **out);
+void exp_amd_orient_destroy(exp_amd_orient *o);
+int  exp_amd_orient_set_center(exp_amd_orient *o, const double center[3]);   /* Orient::set_center */
+int  exp_amd_orient_set_cenvel(exp_amd_orient *o, const double vel[3]);      /* Orient::set_cenvel */
+int  exp_amd_orient_set_linear(exp_amd_orient *o);                           /* Orient::set_linear */
+int  exp_amd_orient_accumulate(exp_amd_orient *o, double time, double dtime, exp_amd_comp *c);
+int  exp_amd_orient_get(const exp_amd_orient *o, double center[3], double axis[3], double body[9],
+                        double orig[9], double stats[15]);
+
 /* ---- spherical force method (sphereSL) -----------------------------------------------
  * Replaces class Sphere : SphericalBasis (src/Sphere.cc:28-96, src/SphericalBasis.cc)
  * given the SLGridSph tables (exputil/SLGridMP2.cc: ev, ef, p0 on the xi grid).     */

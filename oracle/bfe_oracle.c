@@ -1035,3 +1035,151 @@ void orc_fix_positions(long n, const double *mass, const double *x, const double
   if (out[0] > 0.0)
     for (int k = 1; k < 10; k++) out[k] /= out[0];
 }
+
+/* ---- Orient ------------------------------------------------------------------------------------
+ * return_euler_slater (exputil/euler_slater.cc:46-76); row-major, BODY != 0 transposes.         */
+void orc_euler_slater(double phi, double theta, double psi, int body, double *o)
+{
+  double sph = sin(phi), cph = cos(phi), sth = sin(theta), cth = cos(theta), sps = sin(psi),
+         cps = cos(psi);
+  double e[3][3];
+  e[0][0] = -sps * sph + cth * cph * cps; e[0][1] = sps * cph + cth * sph * cps; e[0][2] = cps * sth;
+  e[1][0] = -cps * sph - cth * cph * sps; e[1][1] = cps * cph - cth * sph * sps; e[1][2] = -sps * sth;
+  e[2][0] = -sth * cph;                   e[2][1] = -sth * sph;                  e[2][2] = cth;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) o[3 * i + j] = body ? e[j][i] : e[i][j];
+}
+
+/* Orient::Orient (src/Orient.cc:38-80) */
+void orc_orient_init(orc_orient *o, int keep, int many, unsigned oflags, unsigned cflags,
+                     double deltaT, double damp)
+{
+  memset(o, 0, sizeof(*o));
+  o->keep = keep; o->many = many; o->oflags = oflags; o->cflags = cflags;
+  o->deltaT = deltaT; o->damp = damp;
+  o->lasttime = -DBL_MAX;
+  o->axis[2] = 1.0;
+  for (int k = 0; k < 3; k++) o->body[4 * k] = o->orig[4 * k] = 1.0;
+}
+
+typedef struct { double E, M, L[3], R[3]; } orc_el3;
+
+/* the linear least-squares blocks (:576-604 axis, :620-676 centre); N as the reference passes it */
+static void orc_orient_regress(int n, const double *t, double (*v)[3], int N, double damp,
+                               double time, double *val, double *sig, double *sigz)
+{
+  double sumX = 0, sumX2 = 0, sumY[3] = {0, 0, 0}, sumXY[3] = {0, 0, 0}, slope[3], icpt[3];
+  for (int j = 0; j < n; j++) {
+    double x = t[j];
+    sumX += x;
+    sumX2 += x * x;
+    for (int k = 0; k < 3; k++) { sumY[k] += v[j][k]; sumXY[k] += v[j][k] * x; }
+  }
+  for (int k = 0; k < 3; k++) {
+    slope[k] = (sumXY[k] * N - sumX * sumY[k]) / (sumX2 * N - sumX * sumX);
+    icpt[k] = (sumX2 * sumY[k] - sumX * sumXY[k]) / (sumX2 * N - sumX * sumX);
+    val[k] = icpt[k] + slope[k] * (damp * time + (1.0 - damp) * t[0]);
+  }
+  *sig = 0.0;
+  if (sigz) *sigz = 0.0;
+  for (int j = 0; j < n; j++) {
+    for (int k = 0; k < 3; k++) {
+      double d = v[j][k] - icpt[k] - slope[k] * t[j];
+      *sig += d * d;
+      if (k == 2 && sigz) *sigz += d * d;
+    }
+  }
+  *sig /= n;
+  if (sigz) *sigz /= n;
+}
+
+static void orc_hist_pop(int *n, double *t, double (*v)[3])
+{
+  for (int j = 1; j < *n; j++) { t[j - 1] = t[j]; memcpy(v[j - 1], v[j], sizeof(v[0])); }
+  (*n)--;
+}
+
+/* Orient::accumulate (src/Orient.cc:420-747) with accumulate_cpu (:325-417) inlined; numprocs = 1.
+ * The std::set ordered on E alone is restated as a sorted array that, like the set, refuses a
+ * second entry of equal energy and never holds more than many+1 entries.                        */
+void orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, const double *mass,
+                           const double *x, const double *y, const double *z, const double *vx,
+                           const double *vy, const double *vz, const double *pot)
+{
+  if (fabs(o->lasttime - time) < 1.0e-12) return;
+  if (time - o->deltaT - o->lasttime < 0.0) return;
+  o->lasttime = time;
+  if (o->linear) {
+    for (int k = 0; k < 3; k++) { o->center[k] = o->center0[k]; o->center0[k] += o->cenvel0[k] * dtime; }
+    return;
+  }
+  long tkeep = o->many, size = 0;
+  orc_el3 *angm = (orc_el3 *)malloc((size_t)(tkeep + 2) * sizeof(orc_el3));
+  for (long i = 0; i < n; i++) {
+    double pos[3] = {x[i], y[i], z[i]}, vel[3] = {vx[i], vy[i], vz[i]}, psa[3], v2 = 0.0;
+    for (int k = 0; k < 3; k++) { psa[k] = pos[k] - o->center[k]; v2 += vel[k] * vel[k]; }
+    double energy = pot[i];
+    if (o->cflags & 2u) energy += 0.5 * v2;
+    int test1 = size <= tkeep, test2 = 1;
+    if (size) test2 = energy < angm[size - 1].E;
+    if (!(test1 || test2)) continue;
+    orc_el3 t;
+    t.E = energy; t.M = mass[i];
+    t.L[0] = mass[i] * (psa[1] * vel[2] - psa[2] * vel[1]);
+    t.L[1] = mass[i] * (psa[2] * vel[0] - psa[0] * vel[2]);
+    t.L[2] = mass[i] * (psa[0] * vel[1] - psa[1] * vel[0]);
+    for (int k = 0; k < 3; k++) t.R[k] = mass[i] * pos[k];
+    if (test2 && !test1) size--;                       /* erase the largest energy */
+    long lo = 0, hi = size;                            /* lower bound on E          */
+    while (lo < hi) { long mid = (lo + hi) / 2; if (angm[mid].E < energy) lo = mid + 1; else hi = mid; }
+    if (lo < size && !(energy < angm[lo].E)) continue; /* equal key: set::insert is a no-op */
+    memmove(angm + lo + 1, angm + lo, (size_t)(size - lo) * sizeof(orc_el3));
+    angm[lo] = t;
+    size++;
+  }
+  /* ee = the stored energies, already sorted (:452-478) */
+  if (size) o->Ecurr = (size <= o->many) ? angm[size - 1].E : angm[o->many].E;
+  double mtot = 0.0;
+  long cnum = 0;
+  for (int k = 0; k < 3; k++) o->axis1[k] = o->center1[k] = 0.0;
+  for (long i = 0; i < size && angm[i].E < o->Ecurr; i++) {
+    for (int k = 0; k < 3; k++) { o->axis1[k] += angm[i].L[k]; o->center1[k] += angm[i].R[k]; }
+    mtot += angm[i].M;
+    cnum++;
+  }
+  free(angm);
+  o->used = cnum;
+  o->mtot = mtot;
+  if (mtot > 0.0) {
+    for (int k = 0; k < 3; k++) { o->axis1[k] /= mtot; o->center1[k] /= mtot; }
+    if ((o->oflags & 1u) && o->nA < ORC_ORIENT_HIST) {
+      o->tA[o->nA] = time; memcpy(o->vA[o->nA], o->axis1, sizeof(o->axis1)); o->nA++;
+    }
+    if ((o->oflags & 2u) && o->nC < ORC_ORIENT_HIST) {
+      o->tC[o->nC] = time; memcpy(o->vC[o->nC], o->center1, sizeof(o->center1)); o->nC++;
+    }
+  }
+  if (o->nA > o->keep + 1) {
+    orc_hist_pop(&o->nA, o->tA, o->vA);
+    orc_orient_regress(o->nA, o->tA, o->vA, o->nC /* sic, :583 */, o->damp, time, o->axis, &o->sigA, 0);
+    double phi = atan2(o->axis[1], o->axis[0]);
+    double theta = -acos(o->axis[2] / sqrt(o->axis[0] * o->axis[0] + o->axis[1] * o->axis[1] +
+                                           o->axis[2] * o->axis[2]));
+    orc_euler_slater(phi, theta, 0.0, 0, o->body);
+    orc_euler_slater(phi, theta, 0.0, 1, o->orig);
+  }
+  if (o->nC > 1) {
+    if (o->nC > o->keep + 1) orc_hist_pop(&o->nC, o->tC, o->vC);
+    orc_orient_regress(o->nC, o->tC, o->vC, o->nC, o->damp, time, o->center, &o->sigC, &o->sigCz);
+  }
+  if (o->keep > 1) {
+    if (o->nC > 1) {
+      double factor = (double)(o->nC - o->keep) / o->keep;
+      factor = factor * factor;
+      for (int k = 0; k < 3; k++) o->center[k] = o->center0[k] * factor + o->center[k] * (1.0 - factor);
+    } else
+      for (int k = 0; k < 3; k++) o->center[k] = o->center0[k];
+  } else
+    for (int k = 0; k < 3; k++) o->center[k] = o->center1[k];
+  for (int k = 0; k < 3; k++) o->center0[k] += o->cenvel0[k] * dtime;
+}

@@ -138,6 +138,29 @@ void   orc_fix_positions(long n, const double *mass, const double *x, const doub
                          const double *ax, const double *ay, const double *az, const int *level,
                          int multistep, int mlevel, double *lev_sums, double *out);
 
+/* ---- Orient (src/Orient.H, src/Orient.cc) -------------------------------------------------- */
+#define ORC_ORIENT_HIST 64
+typedef struct {
+  int keep, many;
+  unsigned oflags, cflags;        /* AXIS=1, CENTER=2;  DIAG=1, KE=2, EXTERNAL=4            */
+  double deltaT, damp;
+  int linear;
+  double center[3], center0[3], cenvel0[3], axis[3], axis1[3], center1[3];
+  double body[9], orig[9];        /* row-major                                              */
+  double lasttime, Ecurr, sigA, sigC, sigCz, mtot;
+  long used;
+  int nA, nC;                     /* history lengths (sumsA, sumsC)                         */
+  double tA[ORC_ORIENT_HIST], vA[ORC_ORIENT_HIST][3], tC[ORC_ORIENT_HIST], vC[ORC_ORIENT_HIST][3];
+} orc_orient;
+/* Orient::Orient (src/Orient.cc:38-80) without the log-file restart */
+void   orc_orient_init(orc_orient *o, int keep, int many, unsigned oflags, unsigned cflags,
+                       double deltaT, double damp);
+/* Orient::accumulate + accumulate_cpu (src/Orient.cc:325-747), one process */
+void   orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, const double *mass,
+                             const double *x, const double *y, const double *z, const double *vx,
+                             const double *vy, const double *vz, const double *pot);
+void   orc_euler_slater(double phi, double theta, double psi, int body, double *out9);
+
 /* pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958): out[n][9] =
  * {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, force x3 in the input coordinates};
  * coord 0: (r, cos theta, phi), 1: (R, z, phi), 2: (x, y, z).                                  */

@@ -52,6 +52,27 @@ def build_oracle() -> str:
     return so
 
 
+ORC_ORIENT_HIST = 64
+
+
+class OrcOrient(ctypes.Structure):
+    """orc_orient (oracle/bfe_oracle.h)."""
+    _fields_ = [("keep", ctypes.c_int), ("many", ctypes.c_int), ("oflags", ctypes.c_uint),
+                ("cflags", ctypes.c_uint), ("deltaT", ctypes.c_double), ("damp", ctypes.c_double),
+                ("linear", ctypes.c_int),
+                ("center", ctypes.c_double * 3), ("center0", ctypes.c_double * 3),
+                ("cenvel0", ctypes.c_double * 3), ("axis", ctypes.c_double * 3),
+                ("axis1", ctypes.c_double * 3), ("center1", ctypes.c_double * 3),
+                ("body", ctypes.c_double * 9), ("orig", ctypes.c_double * 9),
+                ("lasttime", ctypes.c_double), ("Ecurr", ctypes.c_double), ("sigA", ctypes.c_double),
+                ("sigC", ctypes.c_double), ("sigCz", ctypes.c_double), ("mtot", ctypes.c_double),
+                ("used", ctypes.c_long), ("nA", ctypes.c_int), ("nC", ctypes.c_int),
+                ("tA", ctypes.c_double * ORC_ORIENT_HIST),
+                ("vA", (ctypes.c_double * 3) * ORC_ORIENT_HIST),
+                ("tC", ctypes.c_double * ORC_ORIENT_HIST),
+                ("vC", (ctypes.c_double * 3) * ORC_ORIENT_HIST)]
+
+
 class Oracle:
     def __init__(self):
         self.lib = ctypes.CDLL(build_oracle())
@@ -144,6 +165,27 @@ class Oracle:
                                    lv.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(multistep),
                                    ctypes.c_int(mlevel), _dp(lev_sums), _dp(out))
         return out
+
+    def orient(self, keep, many, oflags, cflags=0, deltaT=0.0, damp=1.0):
+        """A fresh ``orc_orient`` (src/Orient.cc:38-80)."""
+        o = OrcOrient()
+        self.lib.orc_orient_init(ctypes.byref(o), int(keep), int(many), ctypes.c_uint(oflags),
+                                 ctypes.c_uint(cflags), ctypes.c_double(deltaT), ctypes.c_double(damp))
+        return o
+
+    def orient_accumulate(self, o, time, dtime, mass, pos, vel, pot):
+        """src/Orient.cc:325-747 (one process)."""
+        cols = [np.ascontiguousarray(a[:, k], dtype=np.float64) for a in (pos, vel) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        p = np.ascontiguousarray(pot, dtype=np.float64)
+        self.lib.orc_orient_accumulate(ctypes.byref(o), ctypes.c_double(time), ctypes.c_double(dtime),
+                                       ctypes.c_long(len(m)), _dp(m), *[_dp(c) for c in cols], _dp(p))
+
+    def euler_slater(self, phi, theta, psi, body):
+        out = np.zeros(9)
+        self.lib.orc_euler_slater(ctypes.c_double(phi), ctypes.c_double(theta), ctypes.c_double(psi),
+                                  ctypes.c_int(body), _dp(out))
+        return out.reshape(3, 3)
 
     def sph_fields(self, g, prm, coef, c1, c2, c3, coord="cartesian"):
         """pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958) -> [n, 9]."""

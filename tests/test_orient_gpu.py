@@ -1,0 +1,136 @@
+"""Device Orient (exp_amd/csrc/orient.hip) against the oracle's restatement of src/Orient.cc over
+a run: the energy threshold (exact radix select) must be the SAME double, the number of particles
+used the same integer, centre / axis / rotations equal to round-off.  GPU only."""
+import numpy as np
+import pytest
+
+from tests.conftest import make_grid
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _compare(o, ref, tol=1e-12):
+    st = o.state()
+    assert st["Ecurr"] == ref.Ecurr                                   # bit for bit
+    assert st["used"] == ref.used
+    assert st["mtot"] == pytest.approx(ref.mtot, rel=1e-13)
+    for k in ("center", "axis", "axis1", "center1", "center0"):
+        r = np.array(getattr(ref, k)[:])
+        assert np.abs(st[k] - r).max() <= tol * max(1.0, np.abs(r).max()), k
+    assert np.abs(st["body"] - np.array(ref.body[:]).reshape(3, 3)).max() <= 1e-10
+    assert np.abs(st["orig"] - np.array(ref.orig[:]).reshape(3, 3)).max() <= 1e-10
+    for k, r in (("sigA", ref.sigA), ("sigC", ref.sigC), ("sigCz", ref.sigCz)):
+        assert st[k] == pytest.approx(r, rel=1e-6, abs=1e-24), k
+
+
+@pytest.mark.parametrize("ke", [False, True])
+def test_orient_follows_the_oracle_over_a_run(ctx, oracle, ke):
+    """A drifting, slightly rotating halo stepped with the fused KDK step (so the closing half kick
+    is still pending when Orient reads the velocities): every call agrees with the oracle fed the
+    downloaded state."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Orient, SphereSL
+    model, g = make_grid("plummer", 4, 8, 400)
+    n = 30000
+    m, pos, vel = sample_sphere(model, n, seed=41)
+    pos = pos + np.array([0.2, -0.1, 0.05])
+    vel = vel + np.array([0.3, 0.1, -0.2]) + 0.2 * np.cross([0.0, 0.3, 1.0], pos)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.set_center([0.2, -0.1, 0.05])
+    f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
+    keep, many, dt = 3, 2000, 0.02
+    cfl = Orient.KE if ke else 0
+    o = Orient(ctx, keep, many, Orient.AXIS | Orient.CENTER, cfl, dT=0.0, damping=0.7)
+    ref = oracle.orient(keep, many, 3, cfl, 0.0, 0.7)
+    for k in range(8):
+        t = k * dt
+        o.accumulate(t, c, dt)
+        d = c.download(("mass", "pos", "vel", "pot"))
+        oracle.orient_accumulate(ref, t, dt, d["mass"], d["pos"], d["vel"], d["pot"])
+        _compare(o, ref)
+        assert o.currentUsed() == many and o.currentE() == ref.Ecurr
+        # the component's expansion centre follows the estimate (Component::fix_positions :3569-3582)
+        c.set_center(o.currentCenter() if k else [0.2, -0.1, 0.05])
+        f.step_kdk(c, dt)
+    assert ref.nA == keep + 1 and ref.nC == keep + 1                 # regression branches exercised
+    assert np.abs(o.transformBody() @ o.transformOrig() - np.eye(3)).max() < 1e-13
+    o.close(); c.close(); f.close()
+
+
+def test_orient_small_component_duplicates_and_modes(ctx, oracle):
+    from exp_amd.runtime import Component, Orient
+    rng = np.random.default_rng(3)
+    n = 777
+    m = rng.uniform(0.5, 1.5, n) / n
+    pos, vel = rng.standard_normal((2, n, 3))
+    pot = -1.0 / np.sqrt(0.1 + (pos ** 2).sum(axis=1))
+    pot[::7] = 0.0                                                      # +0 / -0 and exact ties at the top
+    pot[7::14] = -0.0
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(np.zeros((n, 3)), pot)
+    # fewer particles than wanted: the threshold is the highest energy, which is excluded (:474-489)
+    for many in (5000, n, n - 1, 1):
+        o = Orient(ctx, 1, many, Orient.CENTER)
+        ref = oracle.orient(1, many, 2)
+        o.accumulate(0.0, c)
+        oracle.orient_accumulate(ref, 0.0, 0.0, m, pos, vel, pot)
+        st = o.state()
+        assert st["Ecurr"] == ref.Ecurr and st["used"] == ref.used
+        assert np.abs(st["center"] - np.array(ref.center[:])).max() <= 1e-13
+        o.close()
+    # spacing by dT and the linear mode
+    o = Orient(ctx, 2, 50, Orient.CENTER, dT=0.5)
+    o.accumulate(0.0, c); e0 = o.state()
+    c.incr_position(1.0)
+    o.accumulate(0.3, c)
+    assert np.array_equal(o.state()["center1"], e0["center1"])          # ignored: too soon
+    o.accumulate(0.5, c)
+    assert not np.array_equal(o.state()["center1"], e0["center1"])
+    o.close()
+    o = Orient(ctx, 2, 50, Orient.CENTER)
+    o.set_center(1.0, 2.0, 3.0); o.set_cenvel(0.5, 0.0, -0.5); o.set_linear()
+    o.accumulate(0.0, c, 0.2)
+    st = o.state()
+    assert list(st["center"]) == [1.0, 2.0, 3.0] and list(st["center0"]) == [1.1, 2.0, 2.9]
+    o.close()
+    # refused configurations
+    with pytest.raises(RuntimeError, match="keep"):
+        Orient(ctx, 0, 50, Orient.CENTER)
+    with pytest.raises(RuntimeError, match="EXTERNAL"):
+        Orient(ctx, 2, 50, Orient.CENTER, Orient.EXTERNAL)
+    c.close()
+
+
+def test_orient_selection_at_scale(ctx):
+    """2e7 particles: the radix select returns exactly numpy's (many+1)-th smallest energy and the
+    sums match a float64 numpy reduction."""
+    from exp_amd.runtime import Component, Orient
+    rng = np.random.default_rng(8)
+    n, many = 20_000_000, 100_000
+    pos = rng.standard_normal((n, 3)) * 0.5
+    vel = rng.standard_normal((n, 3)) * 0.3
+    m = np.full(n, 1.0 / n)
+    pot = -1.0 / np.sqrt(0.05 + (pos ** 2).sum(axis=1))
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(np.zeros((1, 3)).repeat(n, axis=0), pot)
+    o = Orient(ctx, 1, many, Orient.AXIS | Orient.CENTER, Orient.KE)
+    o.accumulate(0.0, c)
+    st = o.state()
+    E = pot + 0.5 * ((vel[:, 0] * vel[:, 0] + vel[:, 1] * vel[:, 1]) + vel[:, 2] * vel[:, 2])
+    Ecurr = np.partition(E, many)[many]
+    sel = E < Ecurr
+    assert st["Ecurr"] == Ecurr and st["used"] == int(sel.sum()) == many
+    assert st["mtot"] == pytest.approx(m[sel].sum(), rel=1e-12)
+    assert np.abs(st["center1"] - (m[sel, None] * pos[sel]).sum(axis=0) / m[sel].sum()).max() < 1e-12
+    L = (m[sel, None] * np.cross(pos[sel], vel[sel])).sum(axis=0) / m[sel].sum()
+    assert np.abs(st["axis1"] - L).max() < 1e-12
+    o.close(); c.close()
