@@ -6,6 +6,7 @@
 #include "force.h"
 #include "sort_kernels.h"
 
+#include <cmath>
 #include <vector>
 
 struct exp_amd_sim {
@@ -21,6 +22,11 @@ struct exp_amd_sim {
   std::vector<int> mintvl, mfirst;
   long long last_switch = 0;
   long long step_switch = 0;        // level changes summed over the last exp_amd_sim_step call
+  // EJ centre (Component::orient, EJdryrun; global centerlevl, src/global.cc:68)
+  std::vector<exp_amd_orient *> orients;
+  std::vector<int> ej_dryrun;
+  int centerlevl = -1;
+  bool gottapot = false;
 };
 
 extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
@@ -59,6 +65,8 @@ extern "C" int exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_am
                        f->multistep, s->multistep);
   s->comps.push_back(c);
   s->forces.push_back(f);
+  s->orients.push_back(nullptr);
+  s->ej_dryrun.push_back(0);
   if (index) *index = (int)s->comps.size() - 1;
   return EXP_AMD_OK;
 }
@@ -74,6 +82,46 @@ extern "C" int exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int targe
   return EXP_AMD_OK;
 }
 
+// Attach an Orient to a component (Component::initialize, src/Component.cc:1323-1370: the EJ keys);
+// centerlevl < 0 selects multistep/2 (src/ComponentContainer.cc:42-45).
+extern "C" int exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dryrun,
+                                      int centerlevl)
+{
+  if (!s || index < 0 || index >= (int)s->comps.size())
+    return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_set_orient: bad index");
+  s->orients[index] = o;
+  s->ej_dryrun[index] = dryrun;
+  s->centerlevl = centerlevl < 0 ? s->multistep / 2 : (centerlevl > s->multistep ? s->multistep : centerlevl);
+  return EXP_AMD_OK;
+}
+
+// The centre part of ComponentContainer::compute_potential (src/ComponentContainer.cc:955-959) for
+// the components that carry an Orient: Component::fix_positions zeroes the centre and adds the
+// estimator's current one unless it holds a NaN (src/Component.cc:3357, :3569-3582), THEN the
+// estimator takes in the present state (ComponentContainer::fix_positions :1386-1389, only once
+// potentials exist) -- so the expansion centre lags the estimate by one call, as in the reference.
+static int fix_centers(exp_amd_sim *s, int mstep)
+{
+  bool any = false;
+  for (auto o : s->orients) any = any || o;
+  if (!any) return EXP_AMD_OK;
+  const int cl = s->centerlevl < 0 ? s->multistep / 2 : s->centerlevl;
+  const bool active = mstep == 0 || mstep % (1 << (s->multistep - cl)) == 0;     // mactive[mstep][centerlevl]
+  if (!active) return EXP_AMD_OK;
+  for (size_t k = 0; k < s->comps.size(); k++) {
+    exp_amd_orient *o = s->orients[k];
+    if (!o) continue;
+    double ctr[3], axis[3], center[3] = {0.0, 0.0, 0.0};
+    int rc = exp_amd_orient_get(o, ctr, axis, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (!s->ej_dryrun[k] && !(std::isnan(ctr[0]) || std::isnan(ctr[1]) || std::isnan(ctr[2])))
+      for (int i = 0; i < 3; i++) center[i] += ctr[i];
+    if ((rc = exp_amd_comp_set_center(s->comps[k], center))) return rc;
+    if (s->gottapot && (rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;
+  }
+  return EXP_AMD_OK;
+}
+
 // ComponentContainer::compute_expansion(M)
 static int compute_expansion(exp_amd_sim *s, int M)
 {
@@ -86,9 +134,10 @@ static int compute_expansion(exp_amd_sim *s, int M)
 }
 
 // ComponentContainer::compute_potential(mlevel): zero, self forces, interactions
-static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft)
+static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft, int mstep)
 {
   int rc;
+  if ((rc = fix_centers(s, mstep))) return rc;
   for (auto c : s->comps)
     if ((rc = exp_amd_comp_zero_acc(c, mlevel))) return rc;
   for (size_t k = 0; k < s->comps.size(); k++) {
@@ -103,6 +152,7 @@ static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft)
     exp_amd_force *f = s->forces[pr.first];
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
   }
+  s->gottapot = true;
   return EXP_AMD_OK;
 }
 
@@ -130,13 +180,13 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
     for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
     for (int M = 0; M <= s->multistep; M++)
       if ((rc = compute_expansion(s, M))) return rc;
-    if ((rc = compute_potential(s, 0, 0))) return rc;
+    if ((rc = compute_potential(s, 0, 0, 0))) return rc;
     if ((rc = adjust_levels(s, 0, 1))) return rc;
     for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
   }
   for (int M = 0; M <= s->multistep; M++)
     if ((rc = compute_expansion(s, M))) return rc;
-  return compute_potential(s, 0, 0);
+  return compute_potential(s, 0, 0, 0);
 }
 
 // do_step (src/step.cc:67-325)
@@ -162,13 +212,13 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         }
         s->tnow += dt;
         const int mdrft = mstep + 1;
-        if ((rc = compute_potential(s, s->mfirst[mstep], mdrft))) return rc;
+        if ((rc = compute_potential(s, s->mfirst[mstep], mdrft, mstep))) return rc;
         for (int M = s->mfirst[mdrft]; M <= s->multistep; M++)
           for (auto c : s->comps)
             if ((rc = exp_amd_comp_kick(c, 0.5 * dt * s->mintvl[M], M))) return rc;
         if ((rc = adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0))) return rc;
       }
-    } else if (s->comps.size() == 1 && s->inter.empty()) {
+    } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
       s->tnow += s->dtime;
       if ((rc = exp_amd_step_kdk(s->forces[0], s->comps[0], s->dtime))) return rc;
     } else {
@@ -178,7 +228,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if ((rc = exp_amd_comp_drift(c, s->dtime, -1))) return rc;
       }
       if ((rc = compute_expansion(s, 0))) return rc;
-      if ((rc = compute_potential(s, 0, 1))) return rc;
+      if ((rc = compute_potential(s, 0, 1, 0))) return rc;
       for (auto c : s->comps)
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
     }

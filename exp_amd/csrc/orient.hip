@@ -153,17 +153,18 @@ k_orient_pick(double *__restrict__ hist, OriState *__restrict__ st, int pass, in
   for (int b = t; b < ORI_BINS; b += 64) hist[b] = 0.0;
 }
 
-// sums over the particles more bound than the threshold key: {count, M, L[3], R[3]}
+// sums over the particles more bound than the threshold key: {count, M, L[3], R[3]}.  No atomics:
+// the expansion centre feeds back into the run, so the sums are formed in a fixed order (lane
+// strides, wave shuffles, waves in order, blocks in order) and repeat bit for bit.
+constexpr int ORI_SUM_BLOCKS = 1024;
 __global__ void __launch_bounds__(ORI_TPB)
 k_orient_sums(const unsigned long long *__restrict__ key, const double *__restrict__ M,
               const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
               const double *__restrict__ VX, const double *__restrict__ VY,
               const double *__restrict__ VZ, size_t n, const OriState *__restrict__ st,
-              double cx, double cy, double cz, double *__restrict__ out)
+              double cx, double cy, double cz, double *__restrict__ part /* [gridDim.x][8] */)
 {
-  __shared__ double acc[8];
-  if (threadIdx.x < 8) acc[threadIdx.x] = 0.0;
-  __syncthreads();
+  __shared__ double wsum[ORI_TPB / 64][8];
   const unsigned long long thr = st->prefix;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const size_t stride = (size_t)gridDim.x * ORI_TPB;
@@ -184,10 +185,25 @@ k_orient_sums(const unsigned long long *__restrict__ key, const double *__restri
   for (int k = 0; k < 8; k++) {
     double t = v[k];
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    if ((threadIdx.x & 63) == 0 && t != 0.0) unsafeAtomicAdd(&acc[k], t);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][k] = t;
   }
   __syncthreads();
-  if (threadIdx.x < 8 && acc[threadIdx.x] != 0.0) unsafeAtomicAdd(out + threadIdx.x, acc[threadIdx.x]);
+  if (threadIdx.x < 8) {
+    double t = 0.0;
+    for (int w = 0; w < ORI_TPB / 64; w++) t += wsum[w][threadIdx.x];
+    part[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_orient_final(const double *__restrict__ part, int nblk, double *__restrict__ out)
+{
+  // lane = (block residue, value): 8 groups of 8 values; fixed-order strided sums, then shuffles
+  const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
+  double t = 0.0;
+  for (int b = g; b < nblk; b += 8) t += part[(size_t)b * 8 + k];
+  for (int off = 8; off < 64; off <<= 1) t += __shfl_xor(t, off);
+  if (g == 0) out[k] = t;
 }
 
 typedef std::array<double, 3> V3;
@@ -221,7 +237,7 @@ struct exp_amd_orient {
   long long used = 0;
   double Ecurr = 0, sigA = 0, sigC = 0, sigCz = 0, mtot = 0;
   DevBuf<unsigned long long> keys;
-  DevBuf<double> hist, sums;
+  DevBuf<double> hist, sums, part;
   DevBuf<OriState> state;
 };
 
@@ -240,7 +256,8 @@ extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsig
   o->ctx = ctx; o->keep = keep; o->many = want; o->oflags = oflags; o->cflags = cflags;
   o->deltaT = deltaT; o->damp = damp;
   if (hipSetDevice(ctx->device) != hipSuccess || o->hist.alloc(ORI_BINS) != hipSuccess ||
-      o->sums.alloc(8) != hipSuccess || o->state.alloc(1) != hipSuccess) {
+      o->sums.alloc(8) != hipSuccess || o->state.alloc(1) != hipSuccess ||
+      o->part.alloc((size_t)ORI_SUM_BLOCKS * 8) != hipSuccess) {
     delete o;
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc failed");
   }
@@ -251,7 +268,7 @@ extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsig
 extern "C" void exp_amd_orient_destroy(exp_amd_orient *o)
 {
   if (!o) return;
-  o->keys.release(); o->hist.release(); o->sums.release(); o->state.release();
+  o->keys.release(); o->hist.release(); o->sums.release(); o->state.release(); o->part.release();
   delete o;
 }
 
@@ -304,11 +321,12 @@ static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], doub
     }
     if (n) {
       unsigned grid = cdiv(n, ORI_TPB * 16);
-      if (grid > 2048) grid = 2048;
+      if (grid > (unsigned)ORI_SUM_BLOCKS) grid = ORI_SUM_BLOCKS;
       k_orient_sums<<<grid, ORI_TPB, 0, ctx->stream>>>(o->keys.p, c->a(A_M), c->a(A_X), c->a(A_Y),
                                                        c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n,
                                                        o->state.p, o->center[0], o->center[1],
-                                                       o->center[2], o->sums.p);
+                                                       o->center[2], o->part.p);
+      k_orient_final<<<1, 64, 0, ctx->stream>>>(o->part.p, (int)grid, o->sums.p);
     }
     HIP_TRY(ctx, hipGetLastError());
   }

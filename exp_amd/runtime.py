@@ -581,6 +581,12 @@ class Simulation:
         self._keep.append((comp, force))
         return idx.value
 
+    def set_orient(self, index: int, orient: "Orient", dryrun: bool = False, centerlevl: int = -1) -> None:
+        """The EJ keys of a component (src/Component.cc:1323-1370): the expansion centre follows the
+        estimator, which is fed at every force evaluation of level ``centerlevl``."""
+        check(self.lib.exp_amd_sim_set_orient(self.h, int(index), orient.h if orient else None,
+                                              int(dryrun), int(centerlevl)), self.ctx.h)
+
     def add_interaction(self, source: int, target: int) -> None:
         check(self.lib.exp_amd_sim_add_interaction(self.h, int(source), int(target)), self.ctx.h)
 

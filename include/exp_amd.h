@@ -271,6 +271,13 @@ int  exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime, const dou
 void exp_amd_sim_destroy(exp_amd_sim *s);
 int  exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_amd_force *f, int *index);
 int  exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target);
+/* Give component `index` an orientation estimator (the EJ keys of Component, src/Component.cc:1323-
+ * 1370): whenever level `centerlevl` (< 0: multistep/2, src/ComponentContainer.cc:42-45) is active,
+ * the force evaluation first sets the component's expansion centre to the estimator's current
+ * centre (not with dryrun != 0; Component::fix_positions :3357, :3569-3582) and then lets the
+ * estimator take in the present state (ComponentContainer::fix_positions :1386-1389).  The axis is
+ * estimated but not applied.  The sim does not own the estimator.                               */
+int  exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dryrun, int centerlevl);
 int  exp_amd_sim_init(exp_amd_sim *s);
 int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
 double exp_amd_sim_time(const exp_amd_sim *s);

@@ -134,3 +134,66 @@ def test_orient_selection_at_scale(ctx):
     L = (m[sel, None] * np.cross(pos[sel], vel[sel])).sum(axis=0) / m[sel].sum()
     assert np.abs(st["axis1"] - L).max() < 1e-12
     o.close(); c.close()
+
+
+def test_simulation_follows_the_orient_centre(ctx):
+    """The step loop with an estimator attached (exp_amd_sim_set_orient) against the same sequence
+    spelled out call by call: centre := estimator's current centre, estimator takes in the state
+    (only once potentials exist), then the force -- src/ComponentContainer.cc:955-959, :1386-1389,
+    src/Component.cc:3357, :3569-3582."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Orient, Simulation, SphereSL
+    model, g = make_grid("plummer", 4, 8, 400)
+    n, dt, nstep = 20000, 0.02, 5
+    m, pos, vel = sample_sphere(model, n, seed=43)
+    pos = pos + np.array([0.3, 0.0, -0.1])
+    vel = vel + np.array([0.5, -0.25, 0.125])
+
+    def mk():
+        return SphereSL(ctx, g), Component.from_arrays(ctx, m, pos, vel), \
+            Orient(ctx, 2, 1500, Orient.CENTER, Orient.KE, dT=0.0, damping=1.0)
+
+    f, c, o = mk()
+    sim = Simulation(ctx, dt)
+    sim.add_component(c, f)
+    sim.set_orient(0, o)
+    sim.init()
+    sim.step(nstep)
+    got = c.download(("pos", "vel", "acc", "pot"))
+    got_state = o.state()
+    sim.close(); o.close(); c.close(); f.close()
+
+    f, c, o = mk()
+    centers = []
+
+    def potential(tnow, gottapot):
+        ctr = o.currentCenter()
+        c.set_center(ctr if not np.isnan(ctr).any() else np.zeros(3))
+        centers.append(ctr.copy())
+        if gottapot:
+            o.accumulate(tnow, c, dt)
+        c.zero_acceleration(0)
+        f.get_acceleration_and_potential(c)
+
+    f.set_multistep_level(0)
+    f.determine_coefficients(c)
+    potential(0.0, False)
+    t = 0.0
+    for k in range(nstep):
+        t += dt
+        c.incr_velocity(0.5 * dt); c.incr_position(dt)
+        f.determine_coefficients(c)
+        potential(t, True)
+        c.incr_velocity(0.5 * dt)
+    ref = c.download(("pos", "vel", "acc", "pot"))
+    for k in ref:       # round-off only: the coefficient sums are order-dependent at the last bit
+        assert np.abs(got[k] - ref[k]).max() <= 1e-10 * np.abs(ref[k]).max(), k
+    st = o.state()
+    assert got_state["Ecurr"] == pytest.approx(st["Ecurr"], rel=1e-12)
+    assert np.abs(got_state["center"] - st["center"]).max() < 1e-12
+    # the centre did move with the halo, one call behind the estimate
+    # (keep = 2 with a full history mixes in a quarter of center0 = 0, src/Orient.cc:695-699)
+    assert np.abs(centers[-1] - (np.array([0.3, 0.0, -0.1]) + np.array([0.5, -0.25, 0.125]) * (t - dt))).max() < 0.1
+    assert centers[-1][0] > 0.25
+    assert np.array_equal(centers[0], np.zeros(3)) and np.array_equal(centers[1], np.zeros(3))
+    o.close(); c.close(); f.close()
