@@ -71,6 +71,8 @@ SIGNATURES = {
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
     "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
                                       POINTER(c_void_p)]),
+    "exp_amd_comp_set_orientation": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_orient_flags": (c_uint, [c_void_p]),
     "exp_amd_orient_destroy": (None, [c_void_p]),
     "exp_amd_sim_set_orient": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int]),
     "exp_amd_orient_set_center": (c_int, [c_void_p, c_void_p]),

@@ -29,7 +29,24 @@ struct CylDev {
   int mmax, nmax, numx, numy, cmapr, cmapz, EVEN_M, ntrig;
   double ascale, hscale, rtable, xmin, dx, ymin, dy, rmax2;
   double cx, cy, cz;
+  // Orient::transformBody of the component the basis belongs to (src/Cylinder.cc:799, :1352);
+  // forces go back through its transpose, transformOrig (:1418)
+  int use_rot;
+  double rot[9];
 };
+
+// centred, then rotated into the body frame
+__device__ __forceinline__ void cyl_local(const CylDev &C, double x, double y, double z, double &xx,
+                                          double &yy, double &zz)
+{
+  xx = x - C.cx; yy = y - C.cy; zz = z - C.cz;
+  if (C.use_rot) {
+    const double a = xx, b = yy, c = zz;
+    xx = C.rot[0] * a + C.rot[1] * b + C.rot[2] * c;
+    yy = C.rot[3] * a + C.rot[4] * b + C.rot[5] * c;
+    zz = C.rot[6] * a + C.rot[7] * b + C.rot[8] * c;
+  }
+}
 
 template <int I, int N, class F>
 __device__ __forceinline__ void cstatic_for(F &&f)
@@ -79,7 +96,8 @@ struct CylKeyFn {
   CylDev C;
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
   {
-    const double xx = x - C.cx, yy = y - C.cy, zz = z - C.cz;
+    double xx, yy, zz;
+    cyl_local(C, x, y, z, xx, yy, zz);
     const double r2 = xx * xx + yy * yy;
     const double r = sqrt(r2);
     const uint32_t ncell = (uint32_t)(C.numx * C.numy);
@@ -170,9 +188,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     const bool valid = i < cend;
     double xx = 1, yy = 0, zz = 0, mass = 0;
     if (valid) {
-      xx = X[i] - C.cx;
-      yy = Y[i] - C.cy;
-      zz = Z[i] - C.cz;
+      cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
       mass = M[i];
     }
     // src/Cylinder.cc:853-866
@@ -265,9 +281,7 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   if (!__any(mover)) return;
   double xx = 1, yy = 0, zz = 0, mass = 0;
   if (mover) {
-    xx = X[i] - C.cx;
-    yy = Y[i] - C.cy;
-    zz = Z[i] - C.cz;
+    cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
     mass = M[i];
   }
   const double r2 = xx * xx + yy * yy;
@@ -419,9 +433,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   const bool valid = i < end;
   double xx = 1, yy = 0, zz = 0;
   if (valid) {
-    xx = X[i] - C.cx;
-    yy = Y[i] - C.cy;
-    zz = Z[i] - C.cz;
+    cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
   }
   // src/Cylinder.cc:1357-1381
   const double ratmin = 0.75, maxerf = 3.0;
@@ -483,6 +495,12 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     fy += yy * fr * cfrac;
     fz += zz * fr * cfrac;
     pa += p * cfrac;
+  }
+  if (C.use_rot) {                                  // frc = transformOrig * frc (src/Cylinder.cc:1417-1418)
+    const double a = fx, b = fy, c = fz;
+    fx = C.rot[0] * a + C.rot[3] * b + C.rot[6] * c;
+    fy = C.rot[1] * a + C.rot[4] * b + C.rot[7] * c;
+    fz = C.rot[2] * a + C.rot[5] * b + C.rot[8] * c;
   }
   if (!assign) {
     fx += AX[i];
@@ -557,10 +575,12 @@ struct CylForce : exp_amd_force {
   }
 };
 
-static CylDev cdev_for(const CylForce *f, const double center[3])
+static CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
 {
   CylDev C = f->dev;
-  C.cx = center[0]; C.cy = center[1]; C.cz = center[2];
+  C.cx = c->center[0]; C.cy = c->center[1]; C.cz = c->center[2];
+  C.use_rot = c->use_rot ? 1 : 0;
+  for (int k = 0; k < 9; k++) C.rot[k] = c->rot[k];
   return C;
 }
 
@@ -624,7 +644,7 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
 {
   CylForce *f = this;
   if (c->n == 0) return EXP_AMD_OK;
-  const CylDev C = cdev_for(f, c->center);
+  const CylDev C = cdev_for(f, c);
   c->nlevels = f->multistep + 1;
   const uint32_t ncell = (uint32_t)(cfg.numx * cfg.numy) + 1u;
   const uint32_t nkeys = ncell * (uint32_t)c->nlevels;
@@ -669,7 +689,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   }
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p, 0, f->d_Wnd.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p, 0, f->d_differ.bytes(), ctx->stream));
-  const CylDev C = cdev_for(f, c->center);
+  const CylDev C = cdev_for(f, c);
   {
     ProfScope ps(ctx, "k_cyl_mstep_update");
     const unsigned grid = cdiv(c->n, 256);
@@ -699,7 +719,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
 {
   CylForce *f = this;
   f->home = c;
-  const CylDev C = cdev_for(f, c->center);
+  const CylDev C = cdev_for(f, c);
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                           ? f->mlevel : -1;
@@ -770,8 +790,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   }
   f->mass_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
-  const double *ctr = (external && f->home) ? f->home->center : t->center;
-  const CylDev C = cdev_for(f, ctr);
+  const CylDev C = cdev_for(f, (external && f->home) ? f->home : t);
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   {

@@ -111,12 +111,18 @@ static int fix_centers(exp_amd_sim *s, int mstep)
   for (size_t k = 0; k < s->comps.size(); k++) {
     exp_amd_orient *o = s->orients[k];
     if (!o) continue;
-    double ctr[3], axis[3], center[3] = {0.0, 0.0, 0.0};
-    int rc = exp_amd_orient_get(o, ctr, axis, nullptr, nullptr, nullptr);
+    double ctr[3], center[3] = {0.0, 0.0, 0.0};
+    int rc = exp_amd_orient_get(o, ctr, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    if (!s->ej_dryrun[k] && !(std::isnan(ctr[0]) || std::isnan(ctr[1]) || std::isnan(ctr[2])))
+    if (!s->ej_dryrun[k] && (exp_amd_orient_flags(o) & 2u) &&            // EJ & Orient::CENTER
+        !(std::isnan(ctr[0]) || std::isnan(ctr[1]) || std::isnan(ctr[2])))
       for (int i = 0; i < 3; i++) center[i] += ctr[i];
     if ((rc = exp_amd_comp_set_center(s->comps[k], center))) return rc;
+    if (!s->ej_dryrun[k] && (exp_amd_orient_flags(o) & 1u)) {            // EJ & Orient::AXIS
+      double body[9];
+      if ((rc = exp_amd_orient_get(o, nullptr, nullptr, body, nullptr, nullptr))) return rc;
+      if ((rc = exp_amd_comp_set_orientation(s->comps[k], body))) return rc;
+    }
     if (s->gottapot && (rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;
   }
   return EXP_AMD_OK;

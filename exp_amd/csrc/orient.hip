@@ -431,6 +431,8 @@ extern "C" int exp_amd_orient_accumulate(exp_amd_orient *o, double time, double 
   return EXP_AMD_OK;
 }
 
+extern "C" unsigned exp_amd_orient_flags(const exp_amd_orient *o) { return o ? o->oflags : 0u; }
+
 // currentCenter / currentAxis / transformBody / transformOrig and the diagnostics of logEntry
 // (src/Orient.H:166-194, src/Orient.cc:749-783): stats = {Ecurr, used, sigA, sigC, sigCz, mtot,
 // axis1[3], center1[3], center0[3]}

@@ -19,6 +19,8 @@ struct exp_amd_comp {
   size_t hist_cap = 0;
   int nlevels = 1;                   // multistep + 1
   double center[3] = {0, 0, 0};
+  bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
+  double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const void *sorted_for = nullptr;  // force whose cell order the store currently has
   bool acc_live = true;              // acc/pot must survive a reorder
   // host mirror of lev_off (refreshed lazily after a full re-sort: one small read-back), so that

@@ -577,6 +577,16 @@ extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
   return EXP_AMD_OK;
 }
 
+extern "C" int exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9])
+{
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (!c) return EXP_AMD_ERR_ARG;
+  c->use_rot = body != nullptr;
+  for (int k = 0; k < 9; k++) c->rot[k] = body ? body[k] : (k % 4 == 0 ? 1.0 : 0.0);
+  c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
 static void level_range(const exp_amd_comp *c, int mlevel, bool upward, int *lo, int *hi)
 {
   if (mlevel < 0) { *lo = 0; *hi = c->nlevels - 1; }

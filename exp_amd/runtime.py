@@ -192,6 +192,15 @@ class Component:
         check(self.lib.exp_amd_comp_set_center(self.h, c), self.ctx.h)
 
     # src/incpos.cc:72, src/incvel.cc:90
+    def set_orientation(self, body=None) -> None:
+        """Body-frame rotation of the component (``Orient::transformBody``), used by the cylindrical
+        force method after centring (src/Cylinder.cc:799, :1352, :1418); ``None`` removes it."""
+        if body is None:
+            check(self.lib.exp_amd_comp_set_orientation(self.h, None), self.ctx.h)
+        else:
+            b = np.ascontiguousarray(body, dtype=np.float64).reshape(9)
+            check(self.lib.exp_amd_comp_set_orientation(self.h, b.ctypes.data_as(c_void_p)), self.ctx.h)
+
     def incr_position(self, dt: float, mlevel: int = -1) -> None:
         check(self.lib.exp_amd_comp_drift(self.h, float(dt), int(mlevel)), self.ctx.h)
 

@@ -91,6 +91,11 @@ int  exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass,
                                 const double *vx, const double *vy, const double *vz);
 /* Expansion centre subtracted from positions (Component::Centered, src/Component.H:748-757). */
 int  exp_amd_comp_set_center(exp_amd_comp *c, const double center[3]);
+/* Body-frame rotation applied after centring by the cylindrical force method (row-major 3x3 =
+ * Orient::transformBody; positions go in as body * (x - centre), forces come back through the
+ * transpose, transformOrig: src/Cylinder.cc:799-800, :1352-1353, :1417-1418).  NULL = none.
+ * The spherical method ignores it, as Sphere does.                                            */
+int  exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9]);
 
 /* Leapfrog pieces.  Replace incr_position(dt, mlevel) (src/incpos.cc:72) and
  * incr_velocity(dt, mlevel) (src/incvel.cc:90); mlevel < 0 means all levels.       */
@@ -130,6 +135,7 @@ int  exp_amd_orient_set_center(exp_amd_orient *o, const double center[3]);   /* 
 int  exp_amd_orient_set_cenvel(exp_amd_orient *o, const double vel[3]);      /* Orient::set_cenvel */
 int  exp_amd_orient_set_linear(exp_amd_orient *o);                           /* Orient::set_linear */
 int  exp_amd_orient_accumulate(exp_amd_orient *o, double time, double dtime, exp_amd_comp *c);
+unsigned exp_amd_orient_flags(const exp_amd_orient *o);                     /* the orient flags */
 int  exp_amd_orient_get(const exp_amd_orient *o, double center[3], double axis[3], double body[9],
                         double orig[9], double stats[15]);
 
@@ -275,8 +281,9 @@ int  exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target);
  * 1370): whenever level `centerlevl` (< 0: multistep/2, src/ComponentContainer.cc:42-45) is active,
  * the force evaluation first sets the component's expansion centre to the estimator's current
  * centre (not with dryrun != 0; Component::fix_positions :3357, :3569-3582) and then lets the
- * estimator take in the present state (ComponentContainer::fix_positions :1386-1389).  The axis is
- * estimated but not applied.  The sim does not own the estimator.                               */
+ * estimator take in the present state (ComponentContainer::fix_positions :1386-1389).  With the AXIS
+ * flag the body rotation is handed to the component too (used by the cylindrical method).  The
+ * sim does not own the estimator.                               */
 int  exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dryrun, int centerlevl);
 int  exp_amd_sim_init(exp_amd_sim *s);
 int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
