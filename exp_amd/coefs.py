@@ -363,3 +363,71 @@ class CylCoefs:
                 write_native_cyl(f, self.coefs[t])
 
     interpolate = SphCoefs.interpolate          # Coefs::interpolate is geometry-independent
+
+    def setDeltaT(self, dT: float) -> None:
+        self.deltaT = float(dT)
+
+    # -- HDF5 coefficient files --------------------------------------------------------------------
+    def WriteH5Coefs(self, path: str, config: str = "", force_id: str = "cylinder") -> None:
+        """``Coefs::WriteH5Coefs`` + ``CylCoefs::WriteH5Params/WriteH5Times`` (expui/Coefficients.cc:
+        3100-3163, :1323-1332, :1375-1405): attributes mmax / nmax / forceID, one (mmax+1) x nmax
+        complex ``coefficients`` dataset with Time / Center / Rotation per snapshot."""
+        import ctypes
+        from . import h5cache
+        times = self.Times()
+        if not times:
+            raise RuntimeError("Coefs::WriteH5Coefs: we have NO coefficient sets")
+        first = self.coefs[times[0]]
+        mmax, nmax = first.mmax, first.nmax
+        data = np.zeros((len(times), mmax + 1, nmax, 2))
+        ctr = np.zeros((len(times), 3))
+        rot = np.zeros((len(times), 3, 3))
+        for k, t in enumerate(times):
+            c = self.coefs[t]
+            data[k, :, :, 0], data[k, :, :, 1] = np.real(c.coefs), np.imag(c.coefs)
+            ctr[k] = np.asarray(c.ctr, dtype=np.float64).reshape(3) if np.size(c.ctr) == 3 else 0.0
+            rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
+        tarr = np.array([self.coefs[t].time for t in times])
+        lib = h5cache._load()
+        lib.exp_h5_cylcoef_write.restype = ctypes.c_int
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if lib.exp_h5_cylcoef_write(path.encode(), self.name.encode(), config.encode(),
+                                    force_id.encode(), mmax, nmax, len(times), vp(tarr), vp(ctr),
+                                    vp(rot), vp(data)):
+            raise RuntimeError(f"WriteH5Coefs: HDF5 error writing <{path}>")
+
+    @classmethod
+    def readH5Coefs(cls, path: str, stride: int = 1, tmin: float = -math.inf,
+                    tmax: float = math.inf) -> "CylCoefs":
+        """The reading constructor ``CylCoefs(HighFive::File&, stride, Tmin, Tmax)``
+        (expui/Coefficients.cc:1075-1176), files written with CoefficientOutputVersion (the legacy
+        transposed storage, ``H5back``, is refused); the m = 0 row is forced real as there (:1157)."""
+        import ctypes
+        from . import h5cache
+        lib = h5cache._load()
+        lib.exp_h5_cylcoef_info.restype = ctypes.c_int
+        lib.exp_h5_cylcoef_read.restype = ctypes.c_int
+        mmax, nmax, count, hasv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        name, fid, geo = (ctypes.create_string_buffer(256) for _ in range(3))
+        if lib.exp_h5_cylcoef_info(path.encode(), ctypes.byref(mmax), ctypes.byref(nmax),
+                                   ctypes.byref(count), name, 256, fid, 256, geo, 256,
+                                   ctypes.byref(hasv)):
+            raise RuntimeError(f"readH5Coefs: <{path}> is not a readable cylindrical coefficient file")
+        if geo.value.decode() != "cylinder":
+            raise RuntimeError(f"readH5Coefs: geometry <{geo.value.decode()}> is not cylindrical")
+        if not hasv.value:
+            raise RuntimeError("readH5Coefs: legacy (pre-CoefficientOutputVersion) storage order is not supported")
+        M, N, C = mmax.value, nmax.value, count.value
+        times, ctr, rot = np.zeros(C), np.zeros((C, 3)), np.zeros((C, 3, 3))
+        data = np.zeros((C, M + 1, N, 2))
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if lib.exp_h5_cylcoef_read(path.encode(), C, M, N, vp(times), vp(ctr), vp(rot), vp(data)):
+            raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
+        self = cls(name.value.decode())
+        for k in range(0, C, stride):
+            if times[k] < tmin or times[k] > tmax:
+                continue
+            cf = data[k, :, :, 0] + 1j * data[k, :, :, 1]
+            cf[0] = cf[0].real
+            self.add(CylStruct(M, N, float(times[k]), cf, ctr[k].copy(), rot[k].copy()))
+        return self

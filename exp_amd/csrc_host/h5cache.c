@@ -416,21 +416,25 @@ static int put_dbl_array_attr(hid_t loc, const char *name, int rank, const hsize
   return rc;
 }
 
-int exp_h5_sphcoef_write(const char *path, const char *name, const char *config, const char *forceID,
-                         int lmax, int nmax, double scale, int ntimes, const double *times,
-                         const double *centers, const double *rots, const double *coefs)
+/* Coefs::WriteH5Coefs (expui/Coefficients.cc:3100-3163) with the per-geometry WriteH5Params /
+ * WriteH5Times: sphere (:841-853, :907-944: lmax, nmax, scale; (l, m>=0) rows) and cylinder
+ * (:1323-1332, :1375-1405: mmax, nmax; m rows).  `ldim` is the number of complex rows.            */
+static int coef_write(const char *path, const char *geometry, const char *name, const char *config,
+                      const char *forceID, const char *key1, int val1, int nmax, int has_scale,
+                      double scale, int ldim, int ntimes, const double *times, const double *centers,
+                      const double *rots, const double *coefs)
 {
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
   hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   if (f < 0) return -1;
   int rc = 0;
   rc |= put_str(f, "CoefficientOutputVersion", "1.0");
-  rc |= put_str(f, "geometry", "sphere");
+  rc |= put_str(f, "geometry", geometry);
   rc |= put_str(f, "name", name);
   rc |= put_str(f, "config", config);
-  rc |= put_int(f, "lmax", lmax);
+  rc |= put_int(f, key1, val1);
   rc |= put_int(f, "nmax", nmax);
-  rc |= put_dbl(f, "scale", scale);
+  if (has_scale) rc |= put_dbl(f, "scale", scale);
   rc |= put_str(f, "forceID", forceID);
   {
     unsigned count = (unsigned)ntimes;
@@ -442,7 +446,6 @@ int exp_h5_sphcoef_write(const char *path, const char *name, const char *config,
   }
   hid_t snaps = H5Gcreate2(f, "snapshots", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
   hid_t ct = complex_type();
-  const int ldim = (lmax + 1) * (lmax + 2) / 2;
   for (int k = 0; k < ntimes && rc == 0 && snaps >= 0; k++) {
     char nm[16];
     snprintf(nm, sizeof nm, "%08d", k);
@@ -462,6 +465,45 @@ int exp_h5_sphcoef_write(const char *path, const char *name, const char *config,
   }
   H5Tclose(ct);
   if (snaps >= 0) H5Gclose(snaps); else rc = -1;
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+int exp_h5_sphcoef_write(const char *path, const char *name, const char *config, const char *forceID,
+                         int lmax, int nmax, double scale, int ntimes, const double *times,
+                         const double *centers, const double *rots, const double *coefs)
+{
+  return coef_write(path, "sphere", name, config, forceID, "lmax", lmax, nmax, 1, scale,
+                    (lmax + 1) * (lmax + 2) / 2, ntimes, times, centers, rots, coefs);
+}
+
+int exp_h5_cylcoef_write(const char *path, const char *name, const char *config, const char *forceID,
+                         int mmax, int nmax, int ntimes, const double *times, const double *centers,
+                         const double *rots, const double *coefs)
+{
+  return coef_write(path, "cylinder", name, config, forceID, "mmax", mmax, nmax, 0, 0.0, mmax + 1,
+                    ntimes, times, centers, rots, coefs);
+}
+
+/* header of a cylindrical coefficient file: CylCoefs(HighFive::File&, ...) (expui/Coefficients.cc:1075-1095) */
+int exp_h5_cylcoef_info(const char *path, int *mmax, int *nmax, int *count, char *name, int name_cap,
+                        char *forceID, int id_cap, char *geometry, int geo_cap, int *has_version)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= get_int(f, "mmax", mmax);
+  rc |= get_int(f, "nmax", nmax);
+  get_str(f, "name", name, (size_t)name_cap);
+  get_str(f, "forceID", forceID, (size_t)id_cap);
+  rc |= get_str(f, "geometry", geometry, (size_t)geo_cap);
+  *has_version = H5Aexists(f, "CoefficientOutputVersion") > 0;
+  unsigned c = 0;
+  hid_t d = H5Dopen2(f, "count", H5P_DEFAULT);
+  if (d < 0 || H5Dread(d, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &c) < 0) rc = -1;
+  if (d >= 0) H5Dclose(d);
+  *count = (int)c;
   H5Fclose(f);
   return rc ? -1 : 0;
 }
@@ -490,14 +532,29 @@ int exp_h5_sphcoef_info(const char *path, int *lmax, int *nmax, double *scale, i
   return rc ? -1 : 0;
 }
 
+static int coef_read(const char *path, int count, int ldim, int nmax, double *times, double *centers,
+                     double *rots, double *coefs);
+
 int exp_h5_sphcoef_read(const char *path, int count, int lmax, int nmax, double *times,
                         double *centers, double *rots, double *coefs)
+{
+  return coef_read(path, count, (lmax + 1) * (lmax + 2) / 2, nmax, times, centers, rots, coefs);
+}
+
+/* the snapshots of a cylindrical file, (mmax+1) x nmax complex each (expui/Coefficients.cc:1100-1170) */
+int exp_h5_cylcoef_read(const char *path, int count, int mmax, int nmax, double *times,
+                        double *centers, double *rots, double *coefs)
+{
+  return coef_read(path, count, mmax + 1, nmax, times, centers, rots, coefs);
+}
+
+static int coef_read(const char *path, int count, int ldim, int nmax, double *times, double *centers,
+                     double *rots, double *coefs)
 {
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
   if (f < 0) return -1;
   hid_t ct = complex_type();
-  const int ldim = (lmax + 1) * (lmax + 2) / 2;
   int rc = 0;
   for (int k = 0; k < count && rc == 0; k++) {
     char nm[64];

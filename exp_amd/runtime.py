@@ -321,11 +321,66 @@ class _Force:
     def set_multistep_level(self, mlevel: int) -> None:
         check(self.lib.exp_amd_force_set_level(self.h, int(mlevel)), self.ctx.h)
 
-    def determine_coefficients(self, comp: "Component") -> None:
-        check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
+    # -- playback (the `playback` / `coefCompute` keys: src/SphericalBasis.cc:155-213, src/Cylinder.cc:
+    #    560-618) -------------------------------------------------------------------------------------
+    play_back = False
+
+    def set_playback(self, coefs, dtime: float, coef_compute: bool = False) -> None:
+        """Drive the force from a stored coefficient series instead of the particles: ``coefs`` is a
+        ``SphCoefs`` / ``CylCoefs`` (exp_amd.coefs) or a path to a native stream or HDF5 file.  The
+        checks are the reference's: the basis orders must match, the off-grid tolerance is twice the
+        time step."""
+        if isinstance(coefs, (str, bytes)):
+            path = coefs.decode() if isinstance(coefs, bytes) else coefs
+            with open(path, "rb") as f:
+                magic = f.read(8)
+            coefs = self._pb_open(path, magic.startswith(b"\x89HDF"))
+        self._pb_check(coefs.getCoefStruct(coefs.Times()[0]))
+        coefs.setDeltaT(2.0 * dtime)
+        self.playback, self.play_back, self.play_cnew = coefs, True, bool(coef_compute)
+        self.lastPlayTime, self.expcoefP, self.stop_signal = -np.inf, None, 0
+        self._pb_started = False
+
+    def _pb_first(self, comp: "Component") -> None:
+        pass
+
+    def _pb_before_force(self) -> None:
+        pass
+
+    def determine_coefficients(self, comp: "Component", tnow: Optional[float] = None) -> None:
+        """``determine_coefficients`` (src/SphericalBasis.cc:600-608, src/Cylinder.cc:898-906): from the
+        particles, or -- in playback -- from the coefficient series at ``tnow`` (one interpolation
+        per new time, ``:610-680`` / ``:908-946``), plus the particles when ``coefCompute`` is set."""
+        if not self.play_back:
+            check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
+            return
+        if tnow is None:
+            raise ValueError("playback: determine_coefficients needs the current time")
+        if not self._pb_started:
+            self._pb_first(comp)
+            self._pb_started = True
+        if tnow > self.lastPlayTime:
+            self.lastPlayTime = tnow
+            mat, ok = self.playback.interpolate(tnow)
+            if not ok:
+                self.stop_signal = 1
+            self.expcoefP = self._pb_unpack(mat)
+        if self.play_cnew:
+            check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
 
     def get_acceleration_and_potential(self, comp: "Component", external: bool = False) -> None:
+        """Force pass; in playback the played-back set is swapped in for the evaluation and the
+        particle-derived one (``coefCompute``) restored after it (src/SphericalBasis.cc:1676-1678,
+        :1752-1754; src/Cylinder.cc:1462-1465, :1533-1536)."""
+        if not self.play_back or self.expcoefP is None:
+            check(self.lib.exp_amd_force_get_acceleration(self.h, comp.h, int(external)), self.ctx.h)
+            return
+        keep = self._get_flat() if self.play_cnew else None
+        self._set_flat(self.expcoefP)
+        self._pb_before_force()
         check(self.lib.exp_amd_force_get_acceleration(self.h, comp.h, int(external)), self.ctx.h)
+        if keep is not None:
+            self._set_flat(keep)
 
     def compute_multistep_coefficients(self, mdrft: int) -> None:
         check(self.lib.exp_amd_force_compute_multistep_coefficients(self.h, int(mdrft)), self.ctx.h)
@@ -399,60 +454,23 @@ class SphereSL(_Force):
     def set_coefs(self, coef) -> None:
         self._set_flat(coef)
 
-    # -- playback (the `playback` / `coefCompute` keys, src/SphericalBasis.cc:155-213) ---------------
-    def set_playback(self, coefs, dtime: float, coef_compute: bool = False) -> None:
-        """Drive the force from a stored coefficient series instead of the particles: ``coefs`` is
-        a ``SphCoefs`` (native stream or HDF5 file read by exp_amd.coefs) or a path to one.  The
-        constructor's checks are the reference's: lmax and nmax must match the basis (``:179-195``),
-        the off-grid tolerance is twice the time step (``:177``)."""
+    # -- playback hooks (src/SphericalBasis.cc:155-213, :610-680) ----------------------------------
+    def _pb_open(self, path: str, h5: bool):
         from .coefs import SphCoefs
-        if isinstance(coefs, (str, bytes)):
-            path = coefs.decode() if isinstance(coefs, bytes) else coefs
-            with open(path, "rb") as f:
-                magic = f.read(8)
-            coefs = (SphCoefs.readH5Coefs(path) if magic.startswith(b"\x89HDF")
-                     else SphCoefs.readNativeCoefs(path))
-        first = coefs.getCoefStruct(coefs.Times()[0])
+        return SphCoefs.readH5Coefs(path) if h5 else SphCoefs.readNativeCoefs(path)
+
+    def _pb_check(self, first) -> None:
         if first.nmax != self.nmax:
             raise RuntimeError(f"SphericalBasis: nmax for playback [{first.nmax}] does not match "
                                f"specification [{self.nmax}]")
         if first.lmax != self.lmax:
             raise RuntimeError(f"SphericalBasis: Lmax for playback [{first.lmax}] does not match "
                                f"specification [{self.lmax}]")
-        coefs.setDeltaT(2.0 * dtime)
-        self.playback, self.play_back, self.play_cnew = coefs, True, bool(coef_compute)
-        self.lastPlayTime, self.expcoefP, self.stop_signal = -np.inf, None, 0
 
-    def determine_coefficients(self, comp: "Component", tnow: Optional[float] = None) -> None:
-        """``SphericalBasis::determine_coefficients`` (src/SphericalBasis.cc:600-608): from the
-        particles, or -- in playback -- from the coefficient series at ``tnow`` (``:610-680``: one
-        interpolation per new time, complex (l, m>=0) rows unpacked into the real-row order), plus
-        the particles when ``coefCompute`` is set."""
-        if not getattr(self, "play_back", False):
-            return super().determine_coefficients(comp)
-        if tnow is None:
-            raise ValueError("playback: determine_coefficients needs the current time")
-        if tnow > self.lastPlayTime:
-            from .coefs import complex_to_real_rows
-            self.lastPlayTime = tnow
-            mat, ok = self.playback.interpolate(tnow)
-            if not ok:
-                self.stop_signal = 1
-            self.expcoefP = complex_to_real_rows(mat, self.lmax)
-        if self.play_cnew:
-            super().determine_coefficients(comp)
-
-    def get_acceleration_and_potential(self, comp: "Component", external: bool = False) -> None:
-        """Force pass; in playback the played-back set is swapped in for the evaluation and the
-        particle-derived one (``coefCompute``) restored after it (src/SphericalBasis.cc:1676-1678,
-        :1752-1754)."""
-        if not getattr(self, "play_back", False) or self.expcoefP is None:
-            return super().get_acceleration_and_potential(comp, external)
-        keep = self._get_flat() if self.play_cnew else None
-        self._set_flat(self.expcoefP)
-        super().get_acceleration_and_potential(comp, external)
-        if keep is not None:
-            self._set_flat(keep)
+    def _pb_unpack(self, mat) -> np.ndarray:
+        """complex (l, m>=0) rows -> the real-row order of expcoef (:640-651)"""
+        from .coefs import complex_to_real_rows
+        return complex_to_real_rows(mat, self.lmax)
 
     def dump_coefs(self, out, time: float = 0.0, scale: Optional[float] = None) -> None:
         """``SphericalBasis::dump_coefs(ostream&)`` (src/SphericalBasis.cc:1829-1879): append the
@@ -508,6 +526,31 @@ class Cylinder(_Force):
     def set_coefs(self, cos, sin) -> None:
         self._set_flat(np.stack([np.asarray(cos, dtype=np.float64),
                                  np.asarray(sin, dtype=np.float64)]))
+
+    # -- playback hooks (src/Cylinder.cc:560-618, :908-946, :1825-1860) ----------------------------
+    def _pb_open(self, path: str, h5: bool):
+        from .coefs import CylCoefs
+        return CylCoefs.readH5Coefs(path) if h5 else CylCoefs.readNativeCoefs(path)
+
+    def _pb_check(self, first) -> None:
+        if first.nmax != self.nmax:
+            raise RuntimeError(f"Cylinder: nmax for playback [{first.nmax}] does not match "
+                               f"specification [{self.nmax}]")
+        if first.mmax != self.mmax:
+            raise RuntimeError(f"Cylinder: mmax for playback [{first.mmax}] does not match "
+                               f"specification [{self.mmax}]")
+
+    def _pb_unpack(self, mat) -> np.ndarray:
+        return np.stack([np.real(mat), np.imag(mat)])
+
+    def _pb_first(self, comp: "Component") -> None:
+        """``Cylinder::compute_grid_mass`` (:1825-1860): mass and count inside rcylmax, once, from the
+        particles -- here as the by-product of one accumulation pass."""
+        check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
+        self._pb_cylmass = self.cylmass
+
+    def _pb_before_force(self) -> None:
+        self.cylmass = self._pb_cylmass
 
     @property
     def cylmass(self) -> float:

@@ -320,3 +320,55 @@ def test_cyl_body_rotation_and_centre(ctx, oracle):
     assert abs(abs(axis @ B[2]) - 1.0) < 1e-3          # the disc's spin axis is the body z axis, B^T e_z
     assert np.abs(o.transformBody() @ axis - np.array([0, 0, 1.0])).max() < 1e-12
     sim.close(); o.close(); c.close(); f.close()
+
+
+def test_cyl_nbody_playback(ctx, tmp_path):
+    """`playback` key of the cylinder force (src/Cylinder.cc:560-618, :898-946, :1462-1465, :1533-1536,
+    :1825-1860): a live run's coefficient stream (native and HDF5) drives a second run of the same
+    initial conditions to the same trajectory; the in-cut mass comes from one pass over the
+    particles (compute_grid_mass), here identical to the live value because nothing leaves rcylmax."""
+    import io
+    from exp_amd.coefs import CylCoefs, read_native_cyl_record, round_time
+    from exp_amd.runtime import Component, Cylinder, do_step_single
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(10000, 91, g)
+    vel = 3.0 * np.cross([0.0, 0.0, 1.0], pos)
+    dt, nstep = 1e-5, 4
+    f = Cylinder(ctx, g)
+
+    def run(src):
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.play_back = False
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        if src is not None:
+            f.set_playback(src, dt)
+        rec = CylCoefs("disk")
+        for k in range(nstep):
+            t = round_time((k + 1) * dt)
+            do_step_single(f, c, dt, tnow=t)
+            if src is None:
+                buf = io.BytesIO(); f.dump_coefs_binary(buf, time=t); buf.seek(0)
+                rec.add(read_native_cyl_record(buf))
+        out = c.download(("pos", "vel", "acc", "pot"))
+        c.close()
+        f.play_back = False
+        return out, rec
+
+    live, rec = run(None)
+    assert rec.Times() == [round_time((k + 1) * dt) for k in range(nstep)]
+    native, h5 = str(tmp_path / "outcoef.disk"), str(tmp_path / "outcoef.disk.h5")
+    rec.writeNativeCoefs(native)
+    rec.WriteH5Coefs(h5)
+    for src in (rec, native, h5):
+        got, _ = run(src)
+        for k in live:
+            assert np.abs(got[k] - live[k]).max() <= 1e-10 * np.abs(live[k]).max(), (type(src), k)
+    assert f.stop_signal == 0
+    bad = CylCoefs("bad")
+    import copy
+    st = copy.copy(rec.getCoefStruct(rec.Times()[0])); st.mmax += 1
+    bad.add(st)
+    with pytest.raises(RuntimeError, match="mmax for playback"):
+        f.set_playback(bad, dt)
+    f.play_back = False
+    f.close()

@@ -114,3 +114,35 @@ def test_sph_coefficient_file_roundtrip(h5, tmp_path):
         assert 'H5T_IEEE_F64LE "r"' in txt and 'H5T_IEEE_F64LE "i"' in txt
         assert "DATASPACE  SIMPLE { ( 10, 5 ) / ( 10, 5 ) }" in txt
         assert 'ATTRIBUTE "CoefficientOutputVersion"' in txt and 'ATTRIBUTE "Rotation"' in txt
+
+
+def test_cyl_coefficient_file_roundtrip(h5, tmp_path):
+    """Cylindrical HDF5 coefficient files (expui/Coefficients.cc:1075-1176, :1323-1405): attributes
+    mmax / nmax / forceID / geometry "cylinder", (mmax+1) x nmax complex snapshots; the m = 0 row
+    comes back real; a spherical file is refused by the cylindrical reader and vice versa."""
+    from exp_amd.basis import CylStruct
+    from exp_amd.coefs import CylCoefs, SphCoefs
+    rng = np.random.default_rng(4)
+    cs = CylCoefs("star disk")
+    for k, t in enumerate((0.0, 0.01, 0.02, 0.03)):
+        cf = rng.standard_normal((5, 7)) + 1j * rng.standard_normal((5, 7))
+        cf[0] = cf[0].real
+        cs.add(CylStruct(4, 7, t, cf, np.array([0.0, 0.1 * k, 0.0]), np.eye(3)))
+    path = str(tmp_path / "outcoef.disk.run0.h5")
+    cs.WriteH5Coefs(path, config="id: cylinder")
+    back = CylCoefs.readH5Coefs(path)
+    assert back.name == "star disk" and back.Times() == cs.Times()
+    for t in cs.Times():
+        a, b = cs.getCoefStruct(t), back.getCoefStruct(t)
+        assert np.array_equal(a.coefs, b.coefs) and np.array_equal(a.ctr, b.ctr) and np.array_equal(a.rot, b.rot)
+        assert (b.mmax, b.nmax, b.time) == (4, 7, t)
+    assert CylCoefs.readH5Coefs(path, tmin=0.005, tmax=0.025).Times() == [0.01, 0.02]
+    a, ok = back.interpolate(0.02)
+    assert ok and np.allclose(a, cs.getCoefStruct(0.02).coefs, rtol=0, atol=1e-15)
+    with pytest.raises(RuntimeError):
+        SphCoefs.readH5Coefs(path)
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        txt = subprocess.run([h5dump, "-H", path], capture_output=True, text=True).stdout
+        assert 'ATTRIBUTE "mmax"' in txt and 'ATTRIBUTE "lmax"' not in txt and 'ATTRIBUTE "scale"' not in txt
+        assert "DATASPACE  SIMPLE { ( 5, 7 ) / ( 5, 7 ) }" in txt and 'GROUP "00000003"' in txt
