@@ -39,7 +39,15 @@ struct exp_amd_ctx {
   std::vector<ProfileSlot> slots;
   std::vector<hipEvent_t> event_pool;
   int num_cu = 256;
+  // second stream of the split fused step: the HBM-bound sort passes of one half of a component run
+  // here while the VALU-bound accumulate / force passes of the other half run on `stream`
+  long long split_min = 0;           // components at least this large take the split step (<= 0: never;
+                                     // off by default: +1.5 % at 1e8 on MI355X)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_forced[2] = {nullptr, nullptr};
 };
+// lazily creates ctx->aux and the four events
+int expamd_ctx_aux(exp_amd_ctx *ctx);
 
 extern thread_local std::string g_exp_amd_global_err;
 
@@ -77,7 +85,8 @@ struct ProfScope {
   exp_amd_ctx *ctx;
   int slot = -1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  ProfScope(exp_amd_ctx *c, const char *name);
+  hipStream_t st = nullptr;
+  ProfScope(exp_amd_ctx *c, const char *name, hipStream_t on = nullptr);
   ~ProfScope();
 };
 

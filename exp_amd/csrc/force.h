@@ -30,6 +30,14 @@ struct exp_amd_force {
   virtual int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick,
                          double nk_dtk = 0.0, double nk_dtd = 0.0, bool *prekey_done = nullptr,
                          bool defer_kick = false) = 0;
+  // exp_amd_step_kdk on a large single-level component: the same step with the particle store in
+  // two independently sorted halves, the sort passes of one half overlapping the accumulate /
+  // force passes of the other on a second stream.  *handled = false: not supported / not worth it.
+  virtual int fused_step_split(exp_amd_comp *, double, bool, bool *handled)
+  {
+    *handled = false;
+    return EXP_AMD_OK;
+  }
   virtual void release() = 0;
   // multistep_update for every particle whose proposed level (c->newlev) differs from its
   // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]

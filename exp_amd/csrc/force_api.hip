@@ -222,15 +222,22 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
                          c->prekey_center[0] == c->center[0] && c->prekey_center[1] == c->center[1] &&
                          c->prekey_center[2] == c->center[2];
   c->prekey_valid = false;
+  {
+    bool handled = false;
+    if ((rc = f->fused_step_split(c, dt, have_keys && c->prekey_split, &handled))) return rc;
+    if (handled) return EXP_AMD_OK;
+  }
+  const bool have_keys_whole = have_keys && !c->prekey_split;
   if (c->n == 0) {
     if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
-  } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys))) return rc;
+  } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys_whole))) return rc;
   bool done = false;
   // the closing half-kick is deferred: the next fused step's scatter pass applies it (as its own
   // rounding step) together with its opening half-kick; any other call applies it first
   if ((rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done, /*defer_kick=*/c->n > 0))) return rc;
   if (done) {
     c->prekey_valid = true;
+    c->prekey_split = false;
     c->prekey_owner = f;
     c->prekey_dtk = 0.5 * dt;
     c->prekey_dtd = dt;

@@ -38,9 +38,21 @@ struct exp_amd_comp {
   const void *prekey_owner = nullptr;   // force whose cells the keys are
   double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
 
+  // Split fused step (exp_amd_step_kdk on large single-level components): the slots [0, half) and
+  // [half, n) are two independently cell-sorted halves; half_off = {0, half, n} on the device plays
+  // lev_off for the kernels, keys of the second half carry +ncell.  Any full sort ends the mode.
+  bool split = false, prekey_split = false;
+  size_t half = 0;
+  DevBuf<uint32_t> half_off;
+
   double *a(int k) { return arr[cur][k].p; }
   double *b(int k) { return arr[1 - cur][k].p; }
 };
+
+// exclusive scan of the key histogram (range_lo >= 0: only the bins of that level / half, starting
+// at lev_off[range_lo]; lev_off is then left alone)
+void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                        uint32_t ncell, int nlev, int range_lo);
 
 // number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
 int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);

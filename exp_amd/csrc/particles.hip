@@ -162,6 +162,12 @@ static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
   return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
+void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                        uint32_t ncell, int nlev, int range_lo)
+{
+  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo);
+}
+
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
 {
   exp_amd_ctx *ctx = c->ctx;
@@ -278,6 +284,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
   HIP_TRY(ctx, hipGetLastError());
   if (advance) c->pending_kick = 0.0;      // the scatter applied it ahead of its own kick
   if (level < 0) {
+    c->split = false;                      // one global order again
     c->cur = 1 - c->cur;
     return EXP_AMD_OK;
   }
@@ -442,6 +449,7 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
   c->nswitch.release();
   c->hist.release();
   c->lev_off.release();
+  c->half_off.release();
   c->com_lev.release();
   c->com_red.release();
   delete c;

@@ -12,7 +12,7 @@ struct SphKeyFn {
   SphDev S;
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
   {
-    return (uint32_t)lev * (uint32_t)(S.numr - 1) + sph_key_cell(S, x, y, z);
+    return (uint32_t)lev * (uint32_t)(S.numr - 1) + sph_key_cell(S, x, y, z) + S.key_add;
   }
 };
 
@@ -413,6 +413,142 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   return EXP_AMD_OK;
 }
 
+
+// ---- split fused step -------------------------------------------------------------------------------------------
+// One KDK step (src/step.cc:271-323) of a single-level component whose slots [0, half) and
+// [half, n) are kept as two independently cell-sorted halves.  Per half h the chain is
+//   force_{n-1}(h) -> count keys(h) -> scan(h) -> scatter+advance(h) -> accumulate(h)
+// and the two chains only meet at the coefficient sum.  The sort passes are HBM-bound, the
+// accumulate and force passes fp64-VALU-bound, so they are issued on two streams in an order that
+// pairs unlike kernels:        main:  F(0)   F(1)      Acc(0)    Acc(1)  contract  project | F(0) ...
+//                              aux :         sort(0)   sort(1)                            |
+// (sort(0) of step n+1 runs under F(1) of step n, sort(1) under Acc(0)); events carry the per-half
+// dependencies.  Results differ from the unsplit step only in the order of the coefficient sums.
+
+int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled)
+{
+  SphForce *f = this;
+  *handled = false;
+  if (f->cfg.multistep || ctx->split_min <= 0 || c->n < (size_t)ctx->split_min || c->n >= 0x7fffffffu)
+    return EXP_AMD_OK;
+  int rc = expamd_ctx_aux(ctx);
+  if (rc) return rc;
+  hipStream_t V = ctx->stream, H = ctx->aux;
+  const uint32_t ncell = (uint32_t)(f->cfg.numr - 1);
+  const uint32_t nkeys = 2u * ncell;
+  const double dt_kick = 0.5 * dt;
+  f->home = c;
+  if (!c->split) {
+    // enter the mode: fix the halves (block-aligned boundary), nothing is known about the order
+    HIP_TRY(ctx, hipStreamSynchronize(V));
+    c->half = (c->n / 2) & ~(size_t)1023;
+    if (!c->half_off.p) HIP_TRY(ctx, c->half_off.alloc(4));
+    const uint32_t ho[4] = {0u, (uint32_t)c->half, (uint32_t)c->n, 0u}, lo1[2] = {0u, (uint32_t)c->n};
+    HIP_TRY(ctx, hipMemcpy(c->half_off.p, ho, sizeof(ho), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(c->lev_off.p, lo1, sizeof(lo1), hipMemcpyHostToDevice));
+    if (c->hist_cap < (size_t)nkeys + 1) {
+      HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
+      c->hist_cap = (size_t)nkeys + 1;
+    }
+    c->nlevels = 1;
+    c->lev_host_valid = false;
+    have_keys = false;
+    // main-stream work issued so far (uploads, an unsplit force pass) precedes both chains
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[0], V));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[1], V));
+  }
+  if (c->hist_cap < (size_t)nkeys + 1) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "split step: histogram too small");
+  const size_t beg[2] = {0, c->half}, len[2] = {c->half, c->n - c->half};
+
+  // ---- aux stream: the two sort chains (reading the live set, writing the other one)
+  const AdvanceArgs A = expamd_advance_args(c, true, dt_kick, dt);
+  const ScatterSrc Ssrc{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
+  const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
+                        c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
+                        c->level[1 - c->cur].p};
+  for (int h = 0; h < 2; h++) {
+    HIP_TRY(ctx, hipStreamWaitEvent(H, ctx->ev_forced[h], 0));
+    const SortRange R{c->half_off.p, h, h, c->n};
+    HIP_TRY(ctx, hipMemsetAsync(c->hist.p + (size_t)h * ncell, 0, ((size_t)ncell + (h ? 1 : 0)) * sizeof(uint32_t), H));
+    if (have_keys) {
+      ProfScope ps(ctx, "k_hist_keys", H);
+      k_hist_keys<<<cdiv(len[h], HIST_TILE), SORT_TPB, 0, H>>>(c->key.p + beg[h], len[h], c->hist.p);
+    } else {
+      ProfScope ps(ctx, "k_key_hist", H);
+      SphDev S = dev_for(f, c->center);
+      S.key_add = (uint32_t)h * ncell;
+      k_key_hist<SphKeyFn><<<cdiv(len[h], HIST_TILE), SORT_TPB, 0, H>>>(SphKeyFn{S}, A, R, c->key.p, c->hist.p);
+    }
+    {
+      ProfScope ps(ctx, "k_scan", H);
+      expamd_launch_scan(H, c->hist.p, nkeys, c->half_off.p, ncell, 2, h);
+    }
+    {
+      ProfScope ps(ctx, "k_scatter_adv", H);
+      k_scatter_adv<false><<<cdiv(len[h], SCAT_TILE), SORT_TPB, 0, H>>>(A, Ssrc, Sdst, R, c->key.p, c->hist.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sorted[h], H));
+  }
+  c->pending_kick = 0.0;
+  c->cur = 1 - c->cur;
+  c->split = true;
+  c->sorted_for = f;
+  c->acc_live = false;
+
+  // ---- main stream: accumulate the halves as they arrive, reduce, project, force
+  SphDev S = dev_for(f, c->center);
+  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), V));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), V));
+  for (int h = 0; h < 2; h++) {
+    HIP_TRY(ctx, hipStreamWaitEvent(V, ctx->ev_sorted[h], 0));
+    if (!len[h]) continue;
+    ProfScope ps(ctx, "k_sph_accumulate");
+    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->half_off.p, h, h,
+                 f->d_W.p, f->d_used.p, len[h], V, 0};
+    k_acc_launch[f->cfg.lmax](a);
+  }
+  {
+    ProfScope ps(ctx, "k_sph_contract");
+    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
+    k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, V>>>(f->d_part.p, (int)f->ncoef, f->d_coef.p);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = expamd_allreduce(ctx, f->d_coef.p, f->ncoef))) return rc;
+  f->proj_dirty = true;
+  if ((rc = sph_project(f))) return rc;
+  {
+    const size_t need = c->n / 64 + 8;
+    if (f->work_cap < need) {
+      HIP_TRY(ctx, hipStreamSynchronize(V));
+      HIP_TRY(ctx, f->d_work.alloc(need + 1));
+      f->work_cap = need;
+    }
+  }
+  for (int h = 0; h < 2; h++) {
+    if (len[h]) {
+      SphDev Sh = S;
+      Sh.key_add = (uint32_t)h * ncell;
+      SphForceArgs a{Sh, c->a(A_X), c->a(A_Y), c->a(A_Z), c->half_off.p, h, h, f->d_T4.p,
+                     c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->a(A_VX), c->a(A_VY),
+                     c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,
+                     f->d_work.p, f->d_work.p + f->work_cap, 0, ctx, c->key.p, dt_kick, dt, 0};
+      k_force_launch[f->cfg.lmax](a);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[h], V));
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  c->acc_live = true;
+  c->pending_kick = dt_kick;
+  c->prekey_valid = true;
+  c->prekey_split = true;
+  c->prekey_owner = f;
+  c->prekey_dtk = dt_kick;
+  c->prekey_dtd = dt;
+  for (int k = 0; k < 3; k++) c->prekey_center[k] = c->center[k];
+  *handled = true;
+  return EXP_AMD_OK;
+}
 
 // ---- multistep level changes ------------------------------------------------------------------------------------
 

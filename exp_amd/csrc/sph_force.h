@@ -21,6 +21,7 @@ struct SphForce : exp_amd_force {
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int resort(exp_amd_comp *c) override;
+  int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;
 };
 

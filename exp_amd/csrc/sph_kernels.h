@@ -44,6 +44,7 @@ struct SphDev {
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
   int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
+  uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   const double *xi;      // [numr]
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
@@ -1061,7 +1062,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
       const double wz = mul_then_add(vz, az, nk_dtk);
       const uint32_t key = sph_key_cell_rcp(S, mul_then_add(px, wx, nk_dtd),
                                             mul_then_add(py, wy, nk_dtd), mul_then_add(pz, wz, nk_dtd));
-      key_out[i] = key;
+      key_out[i] = key + S.key_add;
     }
   }
 }

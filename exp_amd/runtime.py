@@ -69,6 +69,10 @@ class Context:
         check(lib.exp_amd_comm_get_unique_id(buf))
         return buf.raw
 
+    def set_split_min(self, nmin: int) -> None:
+        """Smallest component the fused step handles as two overlapped halves (<= 0: never)."""
+        check(self.lib.exp_amd_ctx_set_split_min(self.h, int(nmin)), self.h)
+
     def synchronize(self) -> None:
         check(self.lib.exp_amd_ctx_synchronize(self.h), self.h)
 

@@ -50,6 +50,13 @@ const char *exp_amd_last_global_error(void);
 int  exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out);
 void exp_amd_ctx_destroy(exp_amd_ctx *ctx);
 int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
+/* Tuning knob of exp_amd_step_kdk: single-level components of at least `nmin` particles are stepped
+ * as two independently cell-sorted halves so that the HBM-bound sort passes of one half overlap the
+ * VALU-bound accumulate / force passes of the other on a second HIP stream (same results up to the
+ * order of the coefficient sums).  nmin <= 0 (the default) turns it off; EXP_AMD_SPLIT_MIN sets the
+ * default.  Measured on MI355X at 1e8 particles: 12.33 -> 12.12 ms per step only, because the
+ * co-running kernels slow each other down (force 5.6 -> 7.1 ms, accumulate 2.9 -> 4.5 ms).        */
+int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
 void *exp_amd_ctx_stream(exp_amd_ctx *ctx);
 
 /* Coefficient all-reduce across ranks.  Replaces the MPI_Allreduce calls of

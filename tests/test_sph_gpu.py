@@ -265,6 +265,57 @@ def test_fused_step_key_reuse_and_invalidation(ctx, oracle, plummer_s6):
         assert acc_err(out["acc"], ref["acc"]) <= 1e-8
 
 
+def test_split_fused_step_matches_the_unfused_sequence(ctx, oracle, plummer_s6):
+    """The split fused step (two independently sorted halves, sort passes on a second stream
+    overlapping accumulate / force) against the call-for-call step: same trajectory up to the order
+    of the coefficient sums -- through key reuse, a dt change, a moved centre, an intervening
+    download, an intervening unfused step (one global sort, then back into the split mode) and an
+    odd particle count (halves of different length, ragged last block)."""
+    from exp_amd.runtime import Component, SphereSL, do_step_single
+    model, g = plummer_s6
+    n = 70001
+    m, pos, vel = _particles(model, n, seed=37)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    acc, _ = oracle.sph_accel(g, prm, pos, c_ref)
+    dts = [0.01, 0.01, 0.01, 0.004, 0.004, 0.01, 0.01, 0.01]
+
+    def run(split):
+        ctx.set_split_min(1000 if split else 0)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        c.upload_acc(acc, np.zeros(n))
+        mid = None
+        for k, dt in enumerate(dts):
+            if split and k == 5:
+                do_step_single(f, c, dt)              # full sort: leaves the split mode
+            elif split:
+                f.step_kdk(c, dt)
+            else:
+                do_step_single(f, c, dt)
+            if k == 1:
+                mid = c.download(("pos", "vel"))       # applies the pending kick, keys stay
+            if k == 2:
+                c.set_center([0.01, -0.02, 0.005])     # keys dropped
+        out = c.download()
+        cf = f.get_coefs()
+        used = f.Used()
+        c.close(); f.close()
+        ctx.set_split_min(0)
+        return out, cf, mid, used
+
+    ref, cref, mref, uref = run(False)
+    out, cf, mid, used = run(True)
+    assert used == uref
+    assert coef_err(cf, cref) <= COEF_TOL
+    for k in ("pos", "vel"):
+        assert np.abs(mid[k] - mref[k]).max() <= 1e-11, k
+    assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-11
+    assert np.abs(out["vel"] - ref["vel"]).max() <= 1e-9
+    assert acc_err(out["acc"], ref["acc"]) <= 1e-8
+    assert np.array_equal(out["mass"], ref["mass"])           # the id permutation survives both halves
+
+
 @pytest.mark.parametrize("kind,lmax,nmax,numr,n", [("nfw", 6, 18, 2000, 1_500_000),
                                                    ("nfw", 10, 24, 2000, 1_500_000),
                                                    ("plummer", 4, 8, 400, 400_000)])
