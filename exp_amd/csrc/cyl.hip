@@ -296,36 +296,62 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
   double cphi = 1.0, sphi = 0.0;
   if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
-  const double t0 = -4.0 * M_PI * mass;
+  const double t0 = mover ? -4.0 * M_PI * mass : 0.0;
   const int nyp = C.numy + 1;
   const size_t nnode = (size_t)(C.numx + 1) * nyp;
-  const bool sub = mover && from >= mfirst;
-  double *wto = Wnd + ((size_t)to * nnode + (size_t)ix * nyp + iy) * NT;
-  double *wfr = Wnd + ((size_t)from * nnode + (size_t)ix * nyp + iy) * NT;
-  double cm = 1.0, sm = 0.0;
-  cstatic_for<0, MMAX + 1>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    if constexpr (m > 0) {
-      const double cn = cm * cphi - sm * sphi;
-      const double sn = sm * cphi + cm * sphi;
-      cm = cn; sm = sn;
-    }
-    const bool on = mover && !(C.EVEN_M && (m & 1));
-    if (on) {
+  // cos / sin (m phi) of this lane
+  double cmv[MMAX + 1], smv[MMAX + 1];
+  cmv[0] = 1.0; smv[0] = 0.0;
+#pragma unroll
+  for (int m = 1; m <= MMAX; m++) {
+    cmv[m] = cmv[m - 1] * cphi - smv[m - 1] * sphi;
+    smv[m] = smv[m - 1] * cphi + cmv[m - 1] * sphi;
+  }
+  // The store is ordered by (level, cell), so the movers of a wave share a handful of (cell, from,
+  // to) keys: one lane per key adds the key's wave-reduced contribution.  (One atomic per mover and
+  // value -- up to 64 lanes on the same word -- made the sweep that lifts a whole level 11 ms long.)
+  const int lane = threadIdx.x & 63;
+  const uint32_t mkey = mover ? (((uint32_t)(ix * nyp + iy) << 10) | ((uint32_t)from << 5) | (uint32_t)to)
+                              : 0xffffffffu;
+  unsigned long long rem = __ballot(mover);
+  while (rem) {
+    const int lead = __ffsll((long long)rem) - 1;
+    const uint32_t kk = (uint32_t)__shfl((int)mkey, lead);
+    const unsigned long long mm = __ballot(mover && mkey == kk);
+    rem &= ~mm;
+    const bool in = (mm >> lane) & 1ull;
+    const bool many = __popcll(mm) > 1;
+    const int gto = (int)(kk & 31u), gfrom = (int)((kk >> 5) & 31u);
+    const size_t gnode = (size_t)(kk >> 10);
+    const bool sub = gfrom >= mfirst;
+    double *wto = Wnd + ((size_t)gto * nnode + gnode) * NT;
+    double *wfr = Wnd + ((size_t)gfrom * nnode + gnode) * NT;
+    cstatic_for<0, MMAX + 1>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if (C.EVEN_M && (m & 1)) return;
       constexpr int jc = (m == 0) ? 0 : 2 * m - 1;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
-        const double w = t0 * cw[k];
-        unsafeAtomicAdd(wto + off + jc, w * cm);
-        if (sub) unsafeAtomicAdd(wfr + off + jc, -(w * cm));
-        if constexpr (m > 0) {
-          unsafeAtomicAdd(wto + off + jc + 1, w * sm);
-          if (sub) unsafeAtomicAdd(wfr + off + jc + 1, -(w * sm));
+        const double w = in ? t0 * cw[k] : 0.0;
+        double vc = w * cmv[m], vs = w * smv[m];
+        if (many) {
+          for (int o = 32; o > 0; o >>= 1) {
+            vc += __shfl_xor(vc, o);
+            if constexpr (m > 0) vs += __shfl_xor(vs, o);
+          }
+        }
+        if (lane == lead) {
+          unsafeAtomicAdd(wto + off + jc, vc);
+          if (sub) unsafeAtomicAdd(wfr + off + jc, -vc);
+          if constexpr (m > 0) {
+            unsafeAtomicAdd(wto + off + jc + 1, vs);
+            if (sub) unsafeAtomicAdd(wfr + off + jc + 1, -vs);
+          }
         }
       }
-    }
-  });
+    });
+  }
 }
 
 // ---- moments -> coefficients -----------------------------------------------------------------------------
