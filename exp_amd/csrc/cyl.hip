@@ -574,7 +574,7 @@ struct CylForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
-  int resort(exp_amd_comp *c) override;
+  int resort(exp_amd_comp *c, int first = 0) override;
   int multistep_reset() override
   {
     // Cylinder::multistep_reset: used = 0, cylmass = 0, resetT = tnow (src/Cylinder.cc:1209-1216)
@@ -583,7 +583,7 @@ struct CylForce : exp_amd_force {
     return EXP_AMD_OK;
   }
   int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-           int level = -1, bool have_keys = false);
+           int level = -1, bool have_keys = false, int level_hi = -1);
   void release() override
   {
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
@@ -666,7 +666,7 @@ __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ 
 }
 
 int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-                   int level, bool have_keys)
+                   int level, bool have_keys, int level_hi)
 {
   CylForce *f = this;
   if (c->n == 0) return EXP_AMD_OK;
@@ -681,19 +681,27 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
     ProfScope ps(ctx, "k_hist_keys");
     k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
   } else {
+    size_t nr = c->n;          // a level range is sized for its own population
+    if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
+    if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<CylKeyFn><<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
-        kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
+    k_key_hist<CylKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
+        kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level, level_hi);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
 }
 
-int CylForce::resort(exp_amd_comp *c) { return sort(c, true, false, 0.0, 0.0); }
+int CylForce::resort(exp_amd_comp *c, int first)
+{
+  if (first > 0 && c->nlevels == multistep + 1)      // (the caller vouches for the order below `first`)
+    return sort(c, true, false, 0.0, 0.0, first, false, multistep);
+  return sort(c, true, false, 0.0, 0.0);
+}
 
 __global__ void __launch_bounds__(256)
 k_cyl_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size_t n)

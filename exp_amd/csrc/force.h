@@ -44,7 +44,8 @@ struct exp_amd_force {
   // (src/SphericalBasis.cc:1033-1079, :1156-1228; src/CylEXP.cc:56-188), reduced over ranks
   virtual int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) = 0;
   // re-establish this basis' (level, cell) order after levels changed
-  virtual int resort(exp_amd_comp *c) = 0;
+  // (only levels >= first can have changed: their slot range alone is re-ordered)
+  virtual int resort(exp_amd_comp *c, int first = 0) = 0;
 
   virtual int get_used(long long *used);
   // PotAccel::multistep_reset (src/PotAccel.H:288): start of a master step

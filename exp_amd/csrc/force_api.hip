@@ -198,8 +198,11 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
     if ((rc = f->multistep_update(c, first, mfirst))) return rc;
   }
   if (u) {
+    // only slots of levels >= first can have changed level; if the store was in this force's order
+    // the rest of it still is, and only that slot range is re-ordered
+    const bool ordered = c->sorted_for == (const void *)f && c->nlevels == ms + 1;
     if ((rc = expamd_comp_commit_levels(c))) return rc;
-    if ((rc = f->resort(c))) return rc;
+    if ((rc = f->resort(c, ordered ? first : 0))) return rc;
   }
   return EXP_AMD_OK;
 }

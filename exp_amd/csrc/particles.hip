@@ -66,13 +66,13 @@ k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict_
 // populated; positions start at that level's first slot and the level offsets are left alone.
 __global__ void __launch_bounds__(1024)
 k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
-       uint32_t ncell, int nlev, int range_lo)
+       uint32_t ncell, int nlev, int range_lo, int range_hi)
 {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
-  const uint32_t k1 = (range_lo >= 0) ? k0 + ncell : nkeys;
+  const uint32_t k1 = (range_lo >= 0) ? (uint32_t)(range_hi + 1) * ncell : nkeys;
   if (t == 0) carry_s = (range_lo >= 0) ? lev_off[range_lo] : 0u;
   __syncthreads();
   for (uint32_t base = k0; base < k1; base += 1024u) {
@@ -100,7 +100,8 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
     const uint32_t excl = carry + (wave ? wsum[wave - 1] : 0u) + (x - v);
     if (k < k1) {
       hist[k] = excl;
-      if (range_lo < 0 && k % ncell == 0) lev_off[k / ncell] = excl;
+      // (a range of several levels re-partitions its slots: the inner level starts move)
+      if ((range_lo < 0 || range_hi > range_lo) && k % ncell == 0) lev_off[k / ncell] = excl;
     }
     __syncthreads();
     if (t == 0) carry_s = carry + wsum[15];
@@ -165,7 +166,7 @@ static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
 void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
                         uint32_t ncell, int nlev, int range_lo)
 {
-  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo);
+  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_lo);
 }
 
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
@@ -229,11 +230,12 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, d
 }
 
 // after k_key_hist: scan the histogram, scatter (with the same advance) into the other buffer set
-SortRange expamd_sort_range(exp_amd_comp *c, int level)
+SortRange expamd_sort_range(exp_amd_comp *c, int level, int level_hi)
 {
   SortRange R;
   R.lev_off = (level >= 0) ? c->lev_off.p : nullptr;
   R.lo = R.hi = level < 0 ? 0 : level;
+  if (level >= 0 && level_hi > level) R.hi = level_hi;
   R.n = c->n;
   return R;
 }
@@ -248,24 +250,32 @@ struct CopySet {
 };
 
 __global__ void __launch_bounds__(TPB)
-k_copy_range(CopySet C, const uint32_t *__restrict__ lev_off, int level)
+k_copy_range(CopySet C, const uint32_t *__restrict__ lev_off, int level, int level_hi,
+             uint8_t *__restrict__ dlev, const uint8_t *__restrict__ slev)
 {
-  const size_t beg = lev_off[level], end = lev_off[level + 1];
+  const size_t beg = lev_off[level], end = lev_off[level_hi + 1];
   const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= end) return;
   for (int a = 0; a < C.narr; a++) C.dst[a][i] = C.src[a][i];
   C.did[i] = C.sid[i];
+  if (dlev) dlev[i] = slev[i];          // several levels: the level of a slot may have changed
 }
 
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift, int level)
+                            bool advance, double dt_kick, double dt_drift, int level, int level_hi)
 {
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
+  if (level < 0 || level_hi < level) level_hi = level;
+  // launches over a level range are sized for its population (host mirror of lev_off), not for n:
+  // the upper levels are small and are sorted every sub-step
+  size_t nr = c->n;
+  if (level >= 0) { int rc_ = expamd_comp_level_count(c, level, level_hi, &nr); if (rc_) return rc_; }
+  if (nr == 0) return EXP_AMD_OK;
   {
     ProfScope ps(ctx, "k_scan");
-    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level);
-    if (level < 0) c->lev_host_valid = false;
+    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level, level_hi);
+    if (level < 0 || level_hi > level) c->lev_host_valid = false;
   }
   {
     ProfScope ps(ctx, "k_scatter_adv");
@@ -274,8 +284,8 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                  c->level[1 - c->cur].p};
-    const unsigned g = cdiv(c->n, SCAT_TILE);
-    const SortRange R = expamd_sort_range(c, level);
+    const unsigned g = cdiv(nr, SCAT_TILE);
+    const SortRange R = expamd_sort_range(c, level, level_hi);
     if (move_acc)
       k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     else
@@ -297,7 +307,10 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     for (int a = 0; a < A_NARR; a++) { C.dst[a] = c->a(a); C.src[a] = c->b(a); }
     C.did = c->id[c->cur].p;
     C.sid = c->id[1 - c->cur].p;
-    k_copy_range<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(C, c->lev_off.p, level);
+    const bool many = level_hi > level;
+    k_copy_range<<<cdiv(nr, TPB), TPB, 0, ctx->stream>>>(
+        C, c->lev_off.p, level, level_hi, many ? c->level[c->cur].p : nullptr,
+        many ? c->level[1 - c->cur].p : nullptr);
   }
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;

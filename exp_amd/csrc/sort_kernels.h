@@ -254,8 +254,10 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
 
 // host helper (defined in particles.hip): scan + scatter after a k_key_hist launch
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift, int level = -1);
-SortRange expamd_sort_range(exp_amd_comp *c, int level);
+                            bool advance, double dt_kick, double dt_drift, int level = -1,
+                            int level_hi = -1);
+// level < 0: all slots; else the slots of levels [level, max(level, level_hi)]
+SortRange expamd_sort_range(exp_amd_comp *c, int level, int level_hi = -1);
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys);
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                                int multistep, int mfirst_mdrft, int first);

@@ -259,7 +259,7 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 // dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
 static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = false,
                     double dt_kick = 0.0, double dt_drift = 0.0, int level = -1,
-                    bool have_keys = false)
+                    bool have_keys = false, int level_hi = -1)
 {
   exp_amd_ctx *ctx = f->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -274,13 +274,16 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
     ProfScope ps(ctx, "k_hist_keys");
     k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
   } else {
+    size_t nr = c->n;          // a level range is sized for its own population
+    if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
+    if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center)};
     AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
-    k_key_hist<SphKeyFn><<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
-        kf, A, expamd_sort_range(c, level), c->key.p, c->hist.p);
+    k_key_hist<SphKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
+        kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level, level_hi);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -559,7 +562,13 @@ k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size_t n
   if (k < n) dst[k] += src[k];
 }
 
-int SphForce::resort(exp_amd_comp *c) { return sph_sort(this, c, true); }
+int SphForce::resort(exp_amd_comp *c, int first)
+{
+  // levels below `first` were not examined (src/multistep.cc:451-453): their slots stay as they are
+  if (first > 0 && c->nlevels == multistep + 1)      // (the caller vouches for the order below `first`)
+    return sph_sort(this, c, true, false, 0.0, 0.0, first, false, multistep);
+  return sph_sort(this, c, true);
+}
 
 int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 {
