@@ -41,6 +41,7 @@ struct exp_amd_ctx {
   int num_cu = 256;
   // second stream of the split fused step: the HBM-bound sort passes of one half of a component run
   // here while the VALU-bound accumulate / force passes of the other half run on `stream`
+  std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
   hipStream_t aux = nullptr;

@@ -601,13 +601,18 @@ struct CylForce : exp_amd_force {
   }
 };
 
-static CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
+static CylDev cdev_frame(const CylForce *f, const double *center, bool use_rot, const double *rot)
 {
   CylDev C = f->dev;
-  C.cx = c->center[0]; C.cy = c->center[1]; C.cz = c->center[2];
-  C.use_rot = c->use_rot ? 1 : 0;
-  for (int k = 0; k < 9; k++) C.rot[k] = c->rot[k];
+  C.cx = center[0]; C.cy = center[1]; C.cz = center[2];
+  C.use_rot = use_rot ? 1 : 0;
+  for (int k = 0; k < 9; k++) C.rot[k] = rot[k];
   return C;
+}
+
+static CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
+{
+  return cdev_frame(f, c->center, c->use_rot, c->rot);
 }
 
 extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
@@ -753,6 +758,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
 {
   CylForce *f = this;
   f->home = c;
+  f->home_gone = false;
   const CylDev C = cdev_for(f, c);
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
@@ -824,7 +830,9 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   }
   f->mass_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
-  const CylDev C = cdev_for(f, (external && f->home) ? f->home : t);
+  // external target: positions go into the frame of the component the expansion was built from
+  const CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
+                   : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   {

@@ -15,6 +15,12 @@ struct exp_amd_force {
   int mlevel = 0;
   bool proj_dirty = true;           // projected force tables are stale w.r.t. d_coef
   exp_amd_comp *home = nullptr;     // component whose particles define the expansion centre
+  // ... and what it looked like when it was destroyed while this force still pointed at it (pyEXP
+  // builds its coefficients from temporary components): frame of the expansion for external targets
+  bool home_gone = false;
+  double home_center[3] = {0, 0, 0}, home_rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  bool home_use_rot = false;
+  void forget_home(const exp_amd_comp *c);
 
   virtual ~exp_amd_force() {}
   // sort `c` into this basis' cell order (optionally applying kick+drift on the way), accumulate

@@ -4,8 +4,24 @@
 
 #include <vector>
 
+void exp_amd_force::forget_home(const exp_amd_comp *c)
+{
+  if (home != c) return;
+  for (int k = 0; k < 3; k++) home_center[k] = c->center[k];
+  for (int k = 0; k < 9; k++) home_rot[k] = c->rot[k];
+  home_use_rot = c->use_rot;
+  home_gone = true;
+  home = nullptr;
+}
+
+void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c)
+{
+  for (exp_amd_force *f : ctx->forces) f->forget_home(c);
+}
+
 int exp_amd_force::alloc_common(size_t ncoef_, int multistep_, size_t tail)
 {
+  if (ctx) ctx->forces.push_back(this);
   ncoef = ncoef_;
   ncoef_dev = ncoef_ + tail;
   multistep = multistep_;
@@ -34,6 +50,11 @@ extern "C" void exp_amd_force_destroy(exp_amd_force *f)
 {
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
+  {
+    auto &v = f->ctx->forces;
+    for (size_t k = 0; k < v.size(); k++)
+      if (v[k] == f) { v.erase(v.begin() + k); break; }
+  }
   f->release();
   f->release_common();
   delete f;

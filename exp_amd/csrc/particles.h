@@ -18,6 +18,7 @@ struct exp_amd_comp {
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
   int nlevels = 1;                   // multistep + 1
+  bool levels_zero = true;           // no slot has ever been given a level > 0 (both level arrays are 0)
   double center[3] = {0, 0, 0};
   bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
   double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -53,6 +54,9 @@ struct exp_amd_comp {
 // at lev_off[range_lo]; lev_off is then left alone)
 void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
                         uint32_t ncell, int nlev, int range_lo);
+
+// a component is about to be destroyed: forces that use it as their expansion frame keep a copy
+void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);
 
 // number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
 int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);

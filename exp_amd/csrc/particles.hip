@@ -283,7 +283,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     ScatterSrc S{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
     ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
-                 c->level[1 - c->cur].p};
+                 c->levels_zero ? nullptr : c->level[1 - c->cur].p};
     const unsigned g = cdiv(nr, SCAT_TILE);
     const SortRange R = expamd_sort_range(c, level, level_hi);
     if (move_acc)
@@ -398,6 +398,7 @@ int expamd_comp_commit_levels(exp_amd_comp *c)
 {
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
+  c->levels_zero = false;
   k_commit_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, c->n);
   HIP_TRY(ctx, hipGetLastError());
   c->sorted_for = nullptr;
@@ -437,6 +438,7 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
   for (int a = 0; a < A_NARR; a++)
     HIP_TRY(ctx, hipMemsetAsync(c->arr[0][a].p, 0, na * sizeof(double), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(c->level[0].p, 0, na, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(c->level[1].p, 0, na, ctx->stream));   // (levels_zero: never written then)
   k_iota<<<cdiv(na, TPB), TPB, 0, ctx->stream>>>(c->id[0].p, n);
   uint32_t lo[64];
   for (int i = 0; i < 64; i++) lo[i] = (uint32_t)n;
@@ -451,7 +453,9 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
 extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
 {
   if (!c) return;
+  if (c->ctx->aux) (void)hipStreamSynchronize(c->ctx->aux);
   (void)hipStreamSynchronize(c->ctx->stream);
+  expamd_forget_component(c->ctx, c);
   for (int w = 0; w < 2; w++) {
     for (int a = 0; a < A_NARR; a++) c->arr[w][a].release();
     c->id[w].release();
@@ -545,6 +549,7 @@ extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)
   if (!c || !level) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
+  c->levels_zero = false;
   int32_t *tmp = (int32_t *)c->b(A_X);   // scratch (8 B per slot >= 4 B needed)
   HIP_TRY(ctx, hipMemcpyAsync(tmp, level, c->n * sizeof(int32_t), hipMemcpyHostToDevice,
                               ctx->stream));

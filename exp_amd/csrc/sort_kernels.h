@@ -245,7 +245,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
     D.vx[dest] = vx; D.vy[dest] = vy; D.vz[dest] = vz;
     D.m[dest] = S.m[i];
     D.id[dest] = S.id[i];
-    D.lev[dest] = A.lev[i];
+    if (D.lev) D.lev[dest] = A.lev[i];     // nullptr: every level is 0 and stays 0 (single-level runs)
     if (MOVE_ACC) {
       D.ax[dest] = S.ax[i]; D.ay[dest] = S.ay[i]; D.az[dest] = S.az[i]; D.pot[dest] = S.pot[i];
     }

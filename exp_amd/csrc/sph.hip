@@ -345,6 +345,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
 {
   SphForce *f = this;
   f->home = c;
+  f->home_gone = false;
   // multistep: only level `mlevel` has moved since the store was last put in this basis' order,
   // so only its slot range is re-sorted
   const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
@@ -390,7 +391,8 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&
                       t->nlevels == 1 && f->cfg.multistep == 0 && t->sorted_for == f;
 
-  const double *ctr = (external && f->home) ? f->home->center : t->center;
+  // external target: positions go into the frame of the component the expansion was built from
+  const double *ctr = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
   SphDev S = dev_for(f, ctr);
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
@@ -441,6 +443,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   const uint32_t nkeys = 2u * ncell;
   const double dt_kick = 0.5 * dt;
   f->home = c;
+  f->home_gone = false;
   if (!c->split) {
     // enter the mode: fix the halves (block-aligned boundary), nothing is known about the order
     HIP_TRY(ctx, hipStreamSynchronize(V));
@@ -468,7 +471,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   const ScatterSrc Ssrc{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
   const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                         c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
-                        c->level[1 - c->cur].p};
+                        c->levels_zero ? nullptr : c->level[1 - c->cur].p};
   for (int h = 0; h < 2; h++) {
     HIP_TRY(ctx, hipStreamWaitEvent(H, ctx->ev_forced[h], 0));
     const SortRange R{c->half_off.p, h, h, c->n};

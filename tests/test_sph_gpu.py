@@ -175,6 +175,37 @@ def test_set_coefs_roundtrip_and_external_target(ctx, oracle, plummer_small):
     assert np.abs(out["pot"] - pot0 - p_ref).max() <= 1e-9 * np.abs(p_ref).max()
 
 
+def test_external_target_after_the_source_component_is_gone(ctx, oracle, plummer_small):
+    """An external target is evaluated in the frame (centre) of the component the expansion was
+    built from (use_external: src/SphericalBasis.cc:1509-1520).  pyEXP-style callers build the
+    coefficients from a temporary component and free it: the force must keep that frame, not a
+    pointer into freed memory (it once did: garbage accelerations whenever the allocator reused it)."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    m, pos, _ = _particles(model, 8000, seed=5)
+    ctr = np.array([0.4, -0.3, 0.2])
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    tpos = np.random.default_rng(2).standard_normal((3000, 3)) + ctr
+    a_ref, _ = oracle.sph_accel(g, prm, tpos, c_ref, center=ctr)
+    f = SphereSL(ctx, g)
+    src = Component.from_arrays(ctx, m, pos + ctr)
+    src.set_center(ctr)
+    f.determine_coefficients(src)
+    assert coef_err(f.get_coefs(), c_ref) <= COEF_TOL
+    src.close()
+    junk = [Component.from_arrays(ctx, np.full(k, np.nan), np.full((k, 3), np.nan)) for k in (7, 8000, 123)]
+    for rep in range(3):
+        tgt = Component.from_arrays(ctx, np.ones(3000), tpos)          # its own centre is the origin
+        f.get_acceleration_and_potential(tgt, external=True)
+        out = tgt.download(("acc",))
+        tgt.close()
+        assert acc_err(out["acc"], a_ref) <= 1e-8
+    for j in junk:
+        j.close()
+    f.close()
+
+
 def test_leapfrog_pieces_bit_exact(ctx, oracle):
     """incr_position / incr_velocity are single fp64 FMAs-free updates: bit-exact vs the oracle."""
     from exp_amd.runtime import Component
