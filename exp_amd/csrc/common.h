@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,8 @@ struct exp_amd_ctx {
   int num_cu = 256;
   // second stream of the split fused step: the HBM-bound sort passes of one half of a component run
   // here while the VALU-bound accumulate / force passes of the other half run on `stream`
+  unsigned long long force_epoch = 0;           // bumped when a force dies: sort keys recorded for "the force
+                                                // at this address" must not outlive it
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
@@ -63,6 +66,12 @@ int expamd_fail(exp_amd_ctx *ctx, int code, const char *fmt, ...);
   } while (0)
 
 // RAII-less simple device buffer (freed explicitly by owners' destructors)
+inline bool expamd_poison()
+{
+  static const bool on = getenv("EXP_AMD_POISON") && atoi(getenv("EXP_AMD_POISON")) != 0;
+  return on;
+}
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -71,7 +80,14 @@ struct DevBuf {
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void **)&p, count * sizeof(T));
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    // EXP_AMD_POISON=1 (tests): fresh device memory reads as NaN / 0xff..., so that anything which
+    // relies on hipMalloc handing out zeros shows up
+    if (e == hipSuccess && expamd_poison()) {
+      e = hipMemset(p, 0xff, count * sizeof(T));       // (null stream: not ordered with ours)
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    return e;
   }
   void release() {
     if (p) (void)hipFree(p);

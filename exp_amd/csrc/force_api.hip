@@ -50,6 +50,7 @@ extern "C" void exp_amd_force_destroy(exp_amd_force *f)
 {
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
+  f->ctx->force_epoch++;
   {
     auto &v = f->ctx->forces;
     for (size_t k = 0; k < v.size(); k++)
@@ -242,6 +243,7 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
   c->acc_live = false;
   // keys + histogram left by the previous fused step's force pass for exactly this advance?
   const bool have_keys = c->prekey_valid && c->prekey_owner == (const void *)f &&
+                         c->prekey_epoch == f->ctx->force_epoch &&
                          c->prekey_dtk == 0.5 * dt && c->prekey_dtd == dt &&
                          c->prekey_center[0] == c->center[0] && c->prekey_center[1] == c->center[1] &&
                          c->prekey_center[2] == c->center[2];
@@ -263,6 +265,7 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
     c->prekey_valid = true;
     c->prekey_split = false;
     c->prekey_owner = f;
+    c->prekey_epoch = f->ctx->force_epoch;
     c->prekey_dtk = 0.5 * dt;
     c->prekey_dtd = dt;
     for (int k = 0; k < 3; k++) c->prekey_center[k] = c->center[k];

@@ -37,6 +37,7 @@ struct exp_amd_comp {
   // next fused step's scatter pass -- or by expamd_comp_touch() before anything else looks.
   double pending_kick = 0.0;
   const void *prekey_owner = nullptr;   // force whose cells the keys are
+  unsigned long long prekey_epoch = 0;  // ctx->force_epoch when they were written
   double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
 
   // Split fused step (exp_amd_step_kdk on large single-level components): the slots [0, half) and

@@ -549,6 +549,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   c->prekey_valid = true;
   c->prekey_split = true;
   c->prekey_owner = f;
+  c->prekey_epoch = ctx->force_epoch;
   c->prekey_dtk = dt_kick;
   c->prekey_dtd = dt;
   for (int k = 0; k < 3; k++) c->prekey_center[k] = c->center[k];
