@@ -74,6 +74,9 @@ SIGNATURES = {
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_comp_set_orientation": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_flags": (c_uint, [c_void_p]),
+    "exp_amd_orient_set_naccel": (c_int, [c_void_p, c_int]),
+    "exp_amd_orient_accel": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "exp_amd_comp_set_pseudo_accel": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_orient_destroy": (None, [c_void_p]),
     "exp_amd_sim_set_orient": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int]),
     "exp_amd_orient_set_center": (c_int, [c_void_p, c_void_p]),

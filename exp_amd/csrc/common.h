@@ -112,6 +112,31 @@ int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
 // x + a*b rounded as a separate multiply and add (what the reference's scalar CPU code does).
 // hipcc contracts a*b+c to an FMA by default and HIP's __dmul_rn/__dadd_rn are plain operators;
 // the empty asm makes the product opaque so the two roundings survive.
+// Component::getPseudoAccel (src/Component.cc:4407-4427): the acceleration of the component's
+// non-inertial frame that Component::AddAcc subtracts from every force it is handed
+// (src/Component.H:914-921): the centre's acceleration (EJ & CENTER) and the Coriolis, Euler and
+// centrifugal terms of the rotating axis (EJ & AXIS), from the stored position and velocity.
+struct PseudoDev {
+  int center, axis;
+  double a[3], om[3], dom[3];
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void pseudo_accel(const PseudoDev &P, double x, double y, double z, double vx,
+                                             double vy, double vz, double &px, double &py, double &pz)
+{
+  px = py = pz = 0.0;
+  if (P.center) { px += P.a[0]; py += P.a[1]; pz += P.a[2]; }
+  if (P.axis) {
+    // 2 omega x V + domega/dt x P + omega x (omega x P)
+    const double ox = P.om[0], oy = P.om[1], oz = P.om[2];
+    const double wx = oy * z - oz * y, wy = oz * x - ox * z, wz = ox * y - oy * x;     // omega x P
+    px += 2.0 * (oy * vz - oz * vy) + (P.dom[1] * z - P.dom[2] * y) + (oy * wz - oz * wy);
+    py += 2.0 * (oz * vx - ox * vz) + (P.dom[2] * x - P.dom[0] * z) + (oz * wx - ox * wz);
+    pz += 2.0 * (ox * vy - oy * vx) + (P.dom[0] * y - P.dom[1] * x) + (ox * wy - oy * wx);
+  }
+}
+#endif
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ double mul_then_add(double x, double a, double b)
 {

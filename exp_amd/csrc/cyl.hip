@@ -33,6 +33,7 @@ struct CylDev {
   // forces go back through its transpose, transformOrig (:1418)
   int use_rot;
   double rot[9];
+  PseudoDev ps;     // frame acceleration of the TARGET component (force pass only)
 };
 
 // centred, then rotated into the body frame
@@ -528,6 +529,12 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     fy = C.rot[1] * a + C.rot[4] * b + C.rot[7] * c;
     fz = C.rot[2] * a + C.rot[5] * b + C.rot[8] * c;
   }
+  if (C.ps.center | C.ps.axis) {        // acc += val - pseudo (Component::AddAcc, src/Component.H:914-921)
+    double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+    if (C.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+    pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
+    fx -= qx; fy -= qy; fz -= qz;
+  }
   if (!assign) {
     fx += AX[i];
     fy += AY[i];
@@ -831,8 +838,9 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   f->mass_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   // external target: positions go into the frame of the component the expansion was built from
-  const CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
-                   : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
+  CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
+             : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
+  C.ps = t->pseudo;
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   {

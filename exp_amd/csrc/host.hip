@@ -123,6 +123,13 @@ static int fix_centers(exp_amd_sim *s, int mstep)
       if ((rc = exp_amd_orient_get(o, nullptr, nullptr, body, nullptr, nullptr))) return rc;
       if ((rc = exp_amd_comp_set_orientation(s->comps[k], body))) return rc;
     }
+    if (!s->ej_dryrun[k]) {       // std::tie(accel, omega, domdt) = orient->currentAccel() (src/Component.cc:3571)
+      double acc[3], om[3], dom[3];
+      const unsigned fl = exp_amd_orient_flags(o);
+      if ((rc = exp_amd_orient_accel(o, acc, om, dom))) return rc;
+      if ((rc = exp_amd_comp_set_pseudo_accel(s->comps[k], (fl & 2u) ? acc : nullptr, (fl & 1u) ? om : nullptr,
+                                              (fl & 1u) ? dom : nullptr))) return rc;
+    }
     if (s->gottapot && (rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;
   }
   return EXP_AMD_OK;

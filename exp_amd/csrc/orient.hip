@@ -15,13 +15,16 @@
 // per-rank many/numprocs trimming is only approximately that), and one streaming pass forms the
 // sums.  Step 4 is a few dozen flops on the host, restated statement for statement including the
 // reference's use of the CENTRE history length in the AXIS regression (:583).
-// Not carried over: the log file and its restart (:84-330), the PseudoAccel helper (naccel), the
+// The PseudoAccel helper (include/PseudoAccel.H: quadratic least squares over the last Naccel
+// (time, centre, axis) triples -> frame acceleration, angular velocity and its rate) rides along.
+// Not carried over: the log file and its restart (:84-330), the
 // EXTERNAL flag (this store has no separate external potential) and keep == 0, whose code path in
 // the reference indexes its 3-vectors out of range (:741-744).
 #include "particles.h"
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <vector>
 #include <array>
 #include <new>
 
@@ -223,8 +226,40 @@ void euler_slater(double phi, double theta, double psi, int body, double *o)
 
 }  // namespace
 
+// QuadLS (include/QuadLS.H:17-53): y = a x^2 + b x + c by least squares
+static void quadls(const std::vector<double> &x, const std::vector<double> &y, double &a, double &b,
+                   double &c)
+{
+  a = b = c = 0.0;
+  const size_t n = x.size();
+  if (n != y.size() || n == 0) return;
+  double sumx = 0, sumy = 0, sumxy = 0, sumx2y = 0, sumx2 = 0, sumx3 = 0, sumx4 = 0;
+  for (size_t i = 0; i < n; i++) {
+    sumx += x[i];
+    sumy += y[i];
+    sumx2 += x[i] * x[i];
+    sumxy += x[i] * y[i];
+    sumx2y += x[i] * x[i] * y[i];
+    sumx3 += x[i] * x[i] * x[i];
+    sumx4 += x[i] * x[i] * x[i] * x[i];
+  }
+  const double Sxx = sumx2 - sumx * sumx / n, Sxy = sumxy - sumx * sumy / n;
+  const double Sxx2 = sumx3 - sumx * sumx2 / n, Sx2y = sumx2y - sumx2 * sumy / n;
+  const double Sx2x2 = sumx4 - sumx2 * sumx2 / n;
+  const double denom = Sxx * Sx2x2 - Sxx2 * Sxx2;
+  if (fabs(denom) > 0.0) {
+    a = (Sx2y * Sxx - Sxy * Sxx2) / denom;
+    b = (Sxy * Sx2x2 - Sx2y * Sxx2) / denom;
+    c = (sumy - sumx2 * a - sumx * b) / n;
+  }
+}
+
 struct exp_amd_orient {
   exp_amd_ctx *ctx = nullptr;
+  // PseudoAccel (include/PseudoAccel.H): queue of {t, centre, axis}, the last estimates
+  unsigned naccel = 0;
+  std::deque<std::array<double, 7>> aq;
+  double ps_accel[3] = {0, 0, 0}, ps_omega[3] = {0, 0, 0}, ps_domdt[3] = {0, 0, 0};
   int keep = 0, many = 0;
   unsigned oflags = 0, cflags = 0;
   double deltaT = 0, damp = 1;
@@ -427,7 +462,63 @@ extern "C" int exp_amd_orient_accumulate(exp_amd_orient *o, double time, double 
       o->center = o->center0;
   } else
     o->center = o->center1;
+  // pseudo-acceleration estimator (:709-713)
+  if (o->naccel) {
+    o->aq.push_back({time, o->center1[0], o->center1[1], o->center1[2], o->axis1[0], o->axis1[1], o->axis1[2]});
+    if (o->aq.size() > o->naccel) o->aq.pop_front();
+  }
   for (int k = 0; k < 3; k++) o->center0[k] += o->cenvel0[k] * dtime;
+  return EXP_AMD_OK;
+}
+
+// Orient's Naccel constructor argument: length of the PseudoAccel queue (0: none)
+extern "C" int exp_amd_orient_set_naccel(exp_amd_orient *o, int naccel)
+{
+  if (!o || naccel < 0) return EXP_AMD_ERR_ARG;
+  o->naccel = (unsigned)naccel;
+  o->aq.clear();
+  return EXP_AMD_OK;
+}
+
+// Orient::currentAccel() = PseudoAccel::operator() (include/PseudoAccel.H:45-91): centre
+// acceleration 2a of the quadratic fits (CENTER), omega = n x dn/dt and its rate n x d2n/dt2 from
+// the fits of the axis evaluated at the last time (AXIS); only once the queue is full, the last
+// values persist otherwise.
+extern "C" int exp_amd_orient_accel(exp_amd_orient *o, double accel[3], double omega[3], double domdt[3])
+{
+  if (!o) return EXP_AMD_ERR_ARG;
+  const bool CEN = o->oflags & ORI_CENTER, AX = o->oflags & ORI_AXIS;
+  if (o->naccel && (CEN || AX) && o->aq.size() == o->naccel) {
+    std::vector<double> t, v[6];
+    for (auto &e : o->aq) {
+      t.push_back(e[0]);
+      for (int k = 0; k < 6; k++) v[k].push_back(e[1 + k]);
+    }
+    double a, b, c;
+    if (CEN)
+      for (int k = 0; k < 3; k++) { quadls(t, v[k], a, b, c); o->ps_accel[k] = 2.0 * a; }
+    if (AX) {
+      const double T = t.back();
+      double n[3], dn[3], d2n[3];
+      for (int k = 0; k < 3; k++) {
+        quadls(t, v[3 + k], a, b, c);
+        n[k] = a * T * T + b * T + c;
+        dn[k] = 2.0 * a * T + b;
+        d2n[k] = 2.0 * a;
+      }
+      o->ps_omega[0] = n[1] * dn[2] - n[2] * dn[1];
+      o->ps_omega[1] = n[2] * dn[0] - n[0] * dn[2];
+      o->ps_omega[2] = n[0] * dn[1] - n[1] * dn[0];
+      o->ps_domdt[0] = n[1] * d2n[2] - n[2] * d2n[1];
+      o->ps_domdt[1] = n[2] * d2n[0] - n[0] * d2n[2];
+      o->ps_domdt[2] = n[0] * d2n[1] - n[1] * d2n[0];
+    }
+  }
+  for (int k = 0; k < 3; k++) {
+    if (accel) accel[k] = o->ps_accel[k];
+    if (omega) omega[k] = o->ps_omega[k];
+    if (domdt) domdt[k] = o->ps_domdt[k];
+  }
   return EXP_AMD_OK;
 }
 

@@ -22,6 +22,7 @@ struct exp_amd_comp {
   double center[3] = {0, 0, 0};
   bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
   double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  PseudoDev pseudo = {0, 0, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // frame acceleration subtracted by the forces
   const void *sorted_for = nullptr;  // force whose cell order the store currently has
   bool acc_live = true;              // acc/pot must survive a reorder
   // host mirror of lev_off (refreshed lazily after a full re-sort: one small read-back), so that

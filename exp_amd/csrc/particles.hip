@@ -613,6 +613,21 @@ extern "C" int exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9
   return EXP_AMD_OK;
 }
 
+extern "C" int exp_amd_comp_set_pseudo_accel(exp_amd_comp *c, const double accel[3], const double omega[3],
+                                             const double domdt[3])
+{
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (!c) return EXP_AMD_ERR_ARG;
+  c->pseudo.center = accel != nullptr;
+  c->pseudo.axis = omega != nullptr && domdt != nullptr;
+  for (int k = 0; k < 3; k++) {
+    c->pseudo.a[k] = accel ? accel[k] : 0.0;
+    c->pseudo.om[k] = c->pseudo.axis ? omega[k] : 0.0;
+    c->pseudo.dom[k] = c->pseudo.axis ? domdt[k] : 0.0;
+  }
+  return EXP_AMD_OK;
+}
+
 static void level_range(const exp_amd_comp *c, int mlevel, bool upward, int *lo, int *hi)
 {
   if (mlevel < 0) { *lo = 0; *hi = c->nlevels - 1; }

@@ -394,6 +394,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   // external target: positions go into the frame of the component the expansion was built from
   const double *ctr = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
   SphDev S = dev_for(f, ctr);
+  S.ps = t->pseudo;                    // Component::AddAcc of the TARGET (src/Component.H:914-921)
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   {
@@ -535,6 +536,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     if (len[h]) {
       SphDev Sh = S;
       Sh.key_add = (uint32_t)h * ncell;
+      Sh.ps = c->pseudo;
       SphForceArgs a{Sh, c->a(A_X), c->a(A_Y), c->a(A_Z), c->half_off.p, h, h, f->d_T4.p,
                      c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->a(A_VX), c->a(A_VY),
                      c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,

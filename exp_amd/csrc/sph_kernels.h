@@ -45,6 +45,7 @@ struct SphDev {
   int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
+  PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
   const double *xi;      // [numr]
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
@@ -1034,6 +1035,12 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double pf2 = FAST ? potp * iR2 : potp / fac;
     ax += pf2 * yy;
     ay += -pf2 * xx;
+  }
+  if (S.ps.center | S.ps.axis) {      // acc += val - pseudo (Component::AddAcc, src/Component.H:914-921)
+    double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+    if (S.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+    pseudo_accel(S.ps, px, py, pz, ux, uy, uz, qx, qy, qz);
+    ax -= qx; ay -= qy; az -= qz;
   }
   double pt = potl;
   if (!assign) {

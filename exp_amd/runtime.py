@@ -205,6 +205,14 @@ class Component:
             b = np.ascontiguousarray(body, dtype=np.float64).reshape(9)
             check(self.lib.exp_amd_comp_set_orientation(self.h, b.ctypes.data_as(c_void_p)), self.ctx.h)
 
+    def set_pseudo_accel(self, accel=None, omega=None, domdt=None) -> None:
+        """Frame acceleration subtracted by every force applied to this component
+        (``Component::AddAcc`` / ``getPseudoAccel``, src/Component.H:914-921, src/Component.cc:4407-4427)."""
+        arrs = [None if v is None else np.ascontiguousarray(v, dtype=np.float64).reshape(3)
+                for v in (accel, omega, domdt)]
+        ptr = [None if a is None else a.ctypes.data_as(c_void_p) for a in arrs]
+        check(self.lib.exp_amd_comp_set_pseudo_accel(self.h, *ptr), self.ctx.h)
+
     def incr_position(self, dt: float, mlevel: int = -1) -> None:
         check(self.lib.exp_amd_comp_drift(self.h, float(dt), int(mlevel)), self.ctx.h)
 
@@ -259,6 +267,16 @@ class Orient:
 
     def set_linear(self) -> None:
         check(self.lib.exp_amd_orient_set_linear(self.h), self.ctx.h)
+
+    def set_naccel(self, naccel: int) -> None:
+        """The ``Naccel`` constructor argument: length of the pseudo-acceleration queue."""
+        check(self.lib.exp_amd_orient_set_naccel(self.h, int(naccel)), self.ctx.h)
+
+    def currentAccel(self):
+        """``Orient::currentAccel`` -> (accel, omega, domdt) (include/PseudoAccel.H:45-91)."""
+        a, o, d = (c_double * 3)(), (c_double * 3)(), (c_double * 3)()
+        check(self.lib.exp_amd_orient_accel(self.h, a, o, d), self.ctx.h)
+        return np.array(a[:]), np.array(o[:]), np.array(d[:])
 
     def accumulate(self, time: float, comp: "Component", dtime: float = 0.0) -> None:
         """``Orient::accumulate(time, c)`` (src/Orient.cc:420-747); ``dtime`` is the reference's

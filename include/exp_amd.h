@@ -103,6 +103,13 @@ int  exp_amd_comp_set_center(exp_amd_comp *c, const double center[3]);
  * transpose, transformOrig: src/Cylinder.cc:799-800, :1352-1353, :1417-1418).  NULL = none.
  * The spherical method ignores it, as Sphere does.                                            */
 int  exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9]);
+/* Acceleration of the component's non-inertial frame, subtracted by every force applied to its
+ * particles (Component::AddAcc -> getPseudoAccel, src/Component.H:914-921, src/Component.cc:4407-4427):
+ * accel (the EJ centre's acceleration; NULL: none) plus, when omega and domdt are both given, the
+ * Coriolis, Euler and centrifugal terms 2 omega x v + domdt x x + omega x (omega x x) of the
+ * rotating axis frame, from the stored position and velocity.                                  */
+int  exp_amd_comp_set_pseudo_accel(exp_amd_comp *c, const double accel[3], const double omega[3],
+                                   const double domdt[3]);
 
 /* Leapfrog pieces.  Replace incr_position(dt, mlevel) (src/incpos.cc:72) and
  * incr_velocity(dt, mlevel) (src/incvel.cc:90); mlevel < 0 means all levels.       */
@@ -143,6 +150,12 @@ int  exp_amd_orient_set_cenvel(exp_amd_orient *o, const double vel[3]);      /* 
 int  exp_amd_orient_set_linear(exp_amd_orient *o);                           /* Orient::set_linear */
 int  exp_amd_orient_accumulate(exp_amd_orient *o, double time, double dtime, exp_amd_comp *c);
 unsigned exp_amd_orient_flags(const exp_amd_orient *o);                     /* the orient flags */
+/* The pseudo-acceleration helper of Orient (Naccel constructor argument, include/PseudoAccel.H):
+ * quadratic least squares over the last `naccel` (time, centre, axis) estimates; accel = centre
+ * acceleration (CENTER), omega / domdt = angular velocity of the axis and its rate (AXIS).  The step
+ * loop hands them to the component (exp_amd_comp_set_pseudo_accel) together with the centre.    */
+int  exp_amd_orient_set_naccel(exp_amd_orient *o, int naccel);
+int  exp_amd_orient_accel(exp_amd_orient *o, double accel[3], double omega[3], double domdt[3]);
 int  exp_amd_orient_get(const exp_amd_orient *o, double center[3], double axis[3], double body[9],
                         double orig[9], double stats[15]);
 

@@ -1183,3 +1183,79 @@ void orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, con
     for (int k = 0; k < 3; k++) o->center[k] = o->center1[k];
   for (int k = 0; k < 3; k++) o->center0[k] += o->cenvel0[k] * dtime;
 }
+
+/* QuadLS::fit (include/QuadLS.H:17-53) */
+void orc_quadls(int n, const double *x, const double *y, double *out)
+{
+  out[0] = out[1] = out[2] = 0.0;
+  if (n <= 0) return;
+  double sumx = 0, sumy = 0, sumxy = 0, sumx2y = 0, sumx2 = 0, sumx3 = 0, sumx4 = 0;
+  for (int i = 0; i < n; i++) {
+    sumx += x[i];
+    sumy += y[i];
+    sumx2 += x[i] * x[i];
+    sumxy += x[i] * y[i];
+    sumx2y += x[i] * x[i] * y[i];
+    sumx3 += x[i] * x[i] * x[i];
+    sumx4 += x[i] * x[i] * x[i] * x[i];
+  }
+  double Sxx = sumx2 - sumx * sumx / n, Sxy = sumxy - sumx * sumy / n;
+  double Sxx2 = sumx3 - sumx * sumx2 / n, Sx2y = sumx2y - sumx2 * sumy / n;
+  double Sx2x2 = sumx4 - sumx2 * sumx2 / n;
+  double denom = Sxx * Sx2x2 - Sxx2 * Sxx2;
+  if (fabs(denom) > 0.0) {
+    out[0] = (Sx2y * Sxx - Sxy * Sxx2) / denom;
+    out[1] = (Sxy * Sx2x2 - Sx2y * Sxx2) / denom;
+    out[2] = (sumy - sumx2 * out[0] - sumx * out[1]) / n;
+  }
+}
+
+/* PseudoAccel::operator() (include/PseudoAccel.H:45-91), queue full */
+void orc_pseudo_accel_fit(int n, const double *rows, double *accel, double *omega, double *domdt)
+{
+  double *t = (double *)malloc(sizeof(double) * n), *v = (double *)malloc(sizeof(double) * n), q[3];
+  for (int i = 0; i < n; i++) t[i] = rows[7 * i];
+  for (int k = 0; k < 3; k++) {
+    for (int i = 0; i < n; i++) v[i] = rows[7 * i + 1 + k];
+    orc_quadls(n, t, v, q);
+    accel[k] = 2.0 * q[0];
+  }
+  double T = t[n - 1], nn[3], dn[3], d2n[3];
+  for (int k = 0; k < 3; k++) {
+    for (int i = 0; i < n; i++) v[i] = rows[7 * i + 4 + k];
+    orc_quadls(n, t, v, q);
+    nn[k] = q[0] * T * T + q[1] * T + q[2];
+    dn[k] = 2.0 * q[0] * T + q[1];
+    d2n[k] = 2.0 * q[0];
+  }
+  omega[0] = nn[1] * dn[2] - nn[2] * dn[1];
+  omega[1] = nn[2] * dn[0] - nn[0] * dn[2];
+  omega[2] = nn[0] * dn[1] - nn[1] * dn[0];
+  domdt[0] = nn[1] * d2n[2] - nn[2] * d2n[1];
+  domdt[1] = nn[2] * d2n[0] - nn[0] * d2n[2];
+  domdt[2] = nn[0] * d2n[1] - nn[1] * d2n[0];
+  free(t); free(v);
+}
+
+static void orc_cross(const double *a, const double *b, double *c)
+{
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* Component::getPseudoAccel (src/Component.cc:4407-4427) */
+void orc_get_pseudo_accel(int center, int axis, const double *accel, const double *omega,
+                          const double *domdt, const double *pos, const double *vel, double *out)
+{
+  out[0] = out[1] = out[2] = 0.0;
+  if (center) for (int k = 0; k < 3; k++) out[k] += accel[k];
+  if (axis) {
+    double a[3], b[3], c[3], d[3];
+    orc_cross(omega, vel, a);
+    orc_cross(domdt, pos, b);
+    orc_cross(omega, pos, c);
+    orc_cross(omega, c, d);
+    for (int k = 0; k < 3; k++) out[k] += 2.0 * a[k] + b[k] + d[k];
+  }
+}

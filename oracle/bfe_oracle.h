@@ -160,6 +160,14 @@ void   orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, c
                              const double *x, const double *y, const double *z, const double *vx,
                              const double *vy, const double *vz, const double *pot);
 void   orc_euler_slater(double phi, double theta, double psi, int body, double *out9);
+/* QuadLS (include/QuadLS.H:17-53): y = a x^2 + b x + c; out = {a, b, c} */
+void   orc_quadls(int n, const double *x, const double *y, double *out3);
+/* PseudoAccel::operator() (include/PseudoAccel.H:45-91) on a full queue of n rows {t, c[3], a[3]}:
+ * accel = 2a of the centre fits, omega = n x dn/dt, domdt = n x d2n/dt2 at the last time */
+void   orc_pseudo_accel_fit(int n, const double *rows7, double *accel, double *omega, double *domdt);
+/* Component::getPseudoAccel (src/Component.cc:4407-4427) */
+void   orc_get_pseudo_accel(int center, int axis, const double *accel, const double *omega,
+                            const double *domdt, const double *pos, const double *vel, double *out3);
 
 /* pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958): out[n][9] =
  * {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, force x3 in the input coordinates};

@@ -181,6 +181,31 @@ class Oracle:
         self.lib.orc_orient_accumulate(ctypes.byref(o), ctypes.c_double(time), ctypes.c_double(dtime),
                                        ctypes.c_long(len(m)), _dp(m), *[_dp(c) for c in cols], _dp(p))
 
+    def quadls(self, x, y):
+        x, y = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y)]
+        out = np.zeros(3)
+        self.lib.orc_quadls(ctypes.c_int(len(x)), _dp(x), _dp(y), _dp(out))
+        return out
+
+    def pseudo_accel_fit(self, rows):
+        """rows [n, 7] = {t, centre, axis} -> (accel, omega, domdt) (include/PseudoAccel.H:45-91)."""
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        a, o, d = np.zeros(3), np.zeros(3), np.zeros(3)
+        self.lib.orc_pseudo_accel_fit(ctypes.c_int(len(r)), _dp(r), _dp(a), _dp(o), _dp(d))
+        return a, o, d
+
+    def get_pseudo_accel(self, center, axis, accel, omega, domdt, pos, vel):
+        """src/Component.cc:4407-4427 for every row of pos / vel."""
+        out = np.zeros_like(pos)
+        a, o, d = [np.ascontiguousarray(v, dtype=np.float64) for v in (accel, omega, domdt)]
+        for i in range(len(pos)):
+            p, v, q = (np.ascontiguousarray(pos[i], dtype=np.float64),
+                       np.ascontiguousarray(vel[i], dtype=np.float64), np.zeros(3))
+            self.lib.orc_get_pseudo_accel(ctypes.c_int(center), ctypes.c_int(axis), _dp(a), _dp(o), _dp(d),
+                                          _dp(p), _dp(v), _dp(q))
+            out[i] = q
+        return out
+
     def euler_slater(self, phi, theta, psi, body):
         out = np.zeros(9)
         self.lib.orc_euler_slater(ctypes.c_double(phi), ctypes.c_double(theta), ctypes.c_double(psi),

@@ -119,3 +119,32 @@ def test_spacing_and_linear_mode(oracle):
     o.cenvel0[:] = (0.5, 0.0, -0.5)
     oracle.orient_accumulate(o, 0.0, 0.2, m, pos, vel, pot)
     assert list(o.center[:]) == [1.0, 2.0, 3.0] and list(o.center0[:]) == [1.1, 2.0, 2.9]
+
+
+def test_quadls_and_pseudo_accel_known_answers(oracle):
+    """QuadLS / PseudoAccel (include/QuadLS.H, include/PseudoAccel.H): exact on quadratics; a centre
+    on c0 + u t + g t^2 / 2 has acceleration g; an axis turning at rate w about z gives omega = w z
+    (to the order of the quadratic fit) and getPseudoAccel is 2 w x v + dw/dt x x + w x (w x x)."""
+    t = np.linspace(0.3, 1.7, 9)
+    a, b, c = -0.7, 2.5, 0.125
+    assert np.allclose(oracle.quadls(t, a * t * t + b * t + c), [a, b, c], rtol=0, atol=1e-11)
+    assert np.allclose(oracle.quadls(t, a * t * t + b * t + c), np.polyfit(t, a * t * t + b * t + c, 2), atol=1e-10)
+    c0, u, g = np.array([0.1, -0.2, 0.3]), np.array([1.0, 0.5, -0.25]), np.array([0.02, -0.04, 0.06])
+    w = 0.05
+    rows = np.zeros((9, 7))
+    rows[:, 0] = t
+    rows[:, 1:4] = c0 + np.outer(t, u) + 0.5 * np.outer(t * t, g)
+    tilt = 0.3
+    rows[:, 4:7] = np.stack([np.sin(tilt) * np.cos(w * t), np.sin(tilt) * np.sin(w * t),
+                             np.full_like(t, np.cos(tilt))], axis=1)
+    acc, om, dom = oracle.pseudo_accel_fit(rows)
+    assert np.allclose(acc, g, rtol=0, atol=1e-10)
+    # n x dn/dt = w sin(tilt) (-cos(tilt) cos, -cos(tilt) sin, sin(tilt)) at the last time
+    T = t[-1]
+    want = w * np.sin(tilt) * np.array([-np.cos(tilt) * np.cos(w * T), -np.cos(tilt) * np.sin(w * T), np.sin(tilt)])
+    assert np.allclose(om, want, rtol=0, atol=2e-5)
+    pos, vel = np.random.default_rng(1).standard_normal((2, 5, 3))
+    got = oracle.get_pseudo_accel(1, 1, acc, om, dom, pos, vel)
+    ref = acc + 2 * np.cross(om, vel) + np.cross(dom, pos) + np.cross(om, np.cross(om, pos))
+    assert np.allclose(got, ref, rtol=0, atol=1e-15)
+    assert np.array_equal(oracle.get_pseudo_accel(0, 0, acc, om, dom, pos, vel), np.zeros((5, 3)))

@@ -197,3 +197,119 @@ def test_simulation_follows_the_orient_centre(ctx):
     assert centers[-1][0] > 0.25
     assert np.array_equal(centers[0], np.zeros(3)) and np.array_equal(centers[1], np.zeros(3))
     o.close(); c.close(); f.close()
+
+
+def test_pseudo_acceleration_of_the_component_frame(ctx, oracle):
+    """Component::AddAcc subtracts getPseudoAccel(pos, vel) from every force it is handed
+    (src/Component.H:914-921, src/Component.cc:4407-4427).  With the frame acceleration set on the
+    component, every force pass -- unfused, external target, fused step, cylinder -- gives the plain
+    force minus the oracle's pseudo-acceleration of the stored position and velocity."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Cylinder, SphereSL
+    from tests.test_cyl_gpu import cyl_grid, _disk
+    model, g = make_grid("plummer", 4, 8, 400)
+    n = 20000
+    m, pos, vel = sample_sphere(model, n, seed=47)
+    acc0, om, dom = np.array([0.3, -0.2, 0.1]), np.array([0.02, -0.05, 0.4]), np.array([0.01, 0.03, -0.02])
+    f = SphereSL(ctx, g)
+
+    def force(setter, fused=False, external=False):
+        c = Component.from_arrays(ctx, m, pos, vel)
+        src = c
+        if external:                                   # coefficients from another component
+            src = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(src)
+        setter(c)
+        if fused:
+            c.zero_acceleration(0)
+            f.get_acceleration_and_potential(c)        # a(0) for the opening kick
+            f.step_kdk(c, 0.01)
+        else:
+            c.zero_acceleration(0)
+            f.get_acceleration_and_potential(c, external=external)
+        out = c.download(("pos", "vel", "acc"))
+        c.close()
+        if external:
+            src.close()
+        return out
+
+    for external in (False, True):
+        plain = force(lambda c: None, external=external)
+        for cen, ax in ((True, False), (False, True), (True, True)):
+            got = force(lambda c: c.set_pseudo_accel(acc0 if cen else None, om if ax else None,
+                                                     dom if ax else None), external=external)
+            ps = oracle.get_pseudo_accel(int(cen), int(ax), acc0, om, dom, pos, vel)
+            assert np.abs(got["acc"] - (plain["acc"] - ps)).max() <= 1e-12 * np.abs(plain["acc"]).max()
+    # fused step: the closing force is the plain force at the new position minus the pseudo term of
+    # the position and (half-kicked) velocity the force pass saw
+    got = force(lambda c: c.set_pseudo_accel(acc0, om, dom), fused=True)
+    c = Component.from_arrays(ctx, m, got["pos"], got["vel"])
+    f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+    plain_acc = c.download(("acc",))["acc"]
+    c.close()
+    vhalf = got["vel"] - 0.005 * got["acc"]            # undo the closing half-kick
+    ps = oracle.get_pseudo_accel(1, 1, acc0, om, dom, got["pos"], vhalf)
+    assert np.abs(got["acc"] - (plain_acc - ps)).max() <= 1e-9 * np.abs(plain_acc).max()
+    f.close()
+    # cylinder
+    gc = cyl_grid(4, 6)
+    md, pd, _ = _disk(10000, 93, gc)
+    vd = 3.0 * np.cross([0.0, 0.0, 1.0], pd)
+    fc = Cylinder(ctx, gc)
+    outs = []
+    for on in (False, True):
+        c = Component.from_arrays(ctx, md, pd, vd)
+        fc.determine_coefficients(c)
+        if on:
+            c.set_pseudo_accel(acc0, om, dom)
+        c.zero_acceleration(0)
+        fc.get_acceleration_and_potential(c)
+        outs.append(c.download(("acc",))["acc"])
+        c.close()
+    ps = oracle.get_pseudo_accel(1, 1, acc0, om, dom, pd, vd)
+    assert np.abs(outs[1] - (outs[0] - ps)).max() <= 1e-12 * np.abs(outs[0]).max()
+    fc.close()
+
+
+def test_orient_pseudo_accel_estimates_and_step_loop(ctx, oracle):
+    """Orient's Naccel helper against the oracle's PseudoAccel fed the same (time, centre, axis)
+    estimates, and the step loop handing the centre acceleration to the component."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Orient, Simulation, SphereSL
+    model, g = make_grid("plummer", 4, 8, 400)
+    n, dt, nacc = 20000, 0.02, 5
+    m, pos, vel = sample_sphere(model, n, seed=53)
+    vel = vel + np.array([0.4, -0.2, 0.1])
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    o = Orient(ctx, 2, 2000, Orient.AXIS | Orient.CENTER, Orient.KE)
+    o.set_naccel(nacc)
+    f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+    rows = []
+    for k in range(8):
+        o.accumulate(k * dt, c, dt)
+        st = o.state()
+        rows.append([k * dt, *st["center1"], *st["axis1"]])
+        acc, om, dom = o.currentAccel()
+        if len(rows) >= nacc:
+            ra, ro, rd = oracle.pseudo_accel_fit(np.array(rows[-nacc:]))
+            assert np.allclose(acc, ra, rtol=0, atol=1e-9 * max(1.0, np.abs(ra).max()))
+            assert np.allclose(om, ro, rtol=0, atol=1e-9) and np.allclose(dom, rd, rtol=0, atol=1e-8)
+        else:
+            assert not acc.any() and not om.any() and not dom.any()      # queue not full yet
+        f.step_kdk(c, dt)
+    o.close(); c.close()
+    # step loop: the estimate reaches the component (no crash, finite, small for a coasting halo)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    o = Orient(ctx, 2, 2000, Orient.CENTER, Orient.KE)
+    o.set_naccel(4)
+    sim = Simulation(ctx, dt)
+    sim.add_component(c, f)
+    sim.set_orient(0, o)
+    sim.init()
+    sim.step(8)
+    acc, _, _ = o.currentAccel()
+    assert np.isfinite(acc).all() and acc.any()      # (4 noisy centres 0.02 apart: not a small number)
+    out = c.download(("acc",))["acc"]
+    assert np.isfinite(out).all()
+    sim.close(); o.close(); c.close(); f.close()
