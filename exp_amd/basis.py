@@ -258,6 +258,11 @@ class SphericalSL(BiorthBasis):
         self.expcoef = np.zeros((self.nrows, self.nmax))
         self.used = 0
         self.orthoTest(200)
+        # coefficient covariance by sub-sampling (expui/BiorthBasis.cc:271-274, :335)
+        self.pcavar = bool(conf.get("pcavar", False))
+        self.sampT = max(1, int(conf.get("subsamp", 100)))
+        if self.pcavar:
+            self.enableCoefCovariance(True, self.sampT)
 
     # -- tables / cache -----------------------------------------------------------------------------
     def _cache_path(self) -> str:
@@ -358,6 +363,8 @@ class SphericalSL(BiorthBasis):
     def reset_coefs(self) -> None:
         self.expcoef[:] = 0.0
         self.used = 0
+        if getattr(self, "pcavar", False):                   # zero_covariance (:478)
+            self.force.cov_reset()
 
     def _accumulate_batch(self, m, pos) -> None:
         if len(m) == 0:
@@ -365,8 +372,29 @@ class SphericalSL(BiorthBasis):
         c = Component.from_arrays(self.ctx, m, pos)
         self.force.determine_coefficients(c)
         self.expcoef += self.force.get_coefs()
+        if getattr(self, "pcavar", False):                   # the pcavar block of accumulate (:613-660)
+            self.force.cov_accumulate(c, self.used)
         self.used += self.force.Used()
         c.close()
+
+    # -- covariance by sub-sampling (expui/BiorthBasis.H:425-470) -------------------------------------
+    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100) -> None:
+        """``enableCoefCovariance(pcavar, sampT)``: (re)initialise the sub-sample means and covariances
+        (init_covariance, expui/BiorthBasis.cc:342-365); the HDF5 covariance store is not carried over."""
+        self.pcavar, self.sampT = bool(pcavar), max(1, int(sampT))
+        self.force.cov_enable(self.sampT if self.pcavar else 0)
+
+    def getCovarSamples(self):
+        """(sampleCounts, sampleMasses), one entry per sub-sample."""
+        d = self.force.cov_get()
+        return d["counts"], d["masses"]
+
+    def getCoefCovariance(self):
+        """[T][lm] -> (mean vector [nmax] complex, covariance matrix [nmax, nmax] complex), lm the
+        (l, m >= 0) index of the coefficient packing (``Spherical::getCoefCovariance``)."""
+        d = self.force.cov_get()
+        return [[(d["mean"][t, lm].copy(), d["covr"][t, lm].astype(np.complex128))
+                 for lm in range(d["mean"].shape[1])] for t in range(self.sampT)]
 
     def load_coefs(self, time: float = 0.0) -> SphStruct:
         """real rows -> complex (l, m>=0) packing (expui/BiorthBasis.cc:482-517)"""

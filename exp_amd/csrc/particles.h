@@ -57,6 +57,11 @@ struct exp_amd_comp {
 void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
                         uint32_t ncell, int nlev, int range_lo);
 
+// ... of all nkeys bins: hist[k] <- exclusive prefix, hist[nkeys] <- total, lev_off[j] <- start of
+// level j (bins j*ncell ...), lev_off[nlev] <- total
+void expamd_launch_scan_full(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                             uint32_t ncell, int nlev);
+
 // a component is about to be destroyed: forces that use it as their expansion frame keep a copy
 void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);
 

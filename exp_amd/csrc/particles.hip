@@ -169,6 +169,12 @@ void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t
   k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_lo);
 }
 
+void expamd_launch_scan_full(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                             uint32_t ncell, int nlev)
+{
+  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, -1, -1);
+}
+
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
 {
   exp_amd_ctx *ctx = c->ctx;

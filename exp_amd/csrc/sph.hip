@@ -244,6 +244,7 @@ void SphForce::release()
   d_tscale.release();
   d_ev.release(); d_d0.release(); d_Gd.release();
   d_wscale.release();
+  expamd_sph_cov_release(this);
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
 }

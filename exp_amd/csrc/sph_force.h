@@ -12,6 +12,7 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
   DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
   DevBuf<double> d_ev, d_d0, d_Gd;  // field evaluation (pyEXP getFields): ev[l][n], d0[numr], Gd[numr][rows]
+  void *cov = nullptr;              // sub-sample covariance state (sph_cov.hip), analysis only
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
 
@@ -26,4 +27,5 @@ struct SphForce : exp_amd_force {
 };
 
 
+void expamd_sph_cov_release(SphForce *f);
 int sph_project(SphForce *f);     // coefficients -> G / T4 tables (no-op when they are current)

@@ -503,6 +503,29 @@ class SphereSL(_Force):
                       real_rows_to_complex(self.get_coefs(), self.lmax), np.zeros(3), np.eye(3))
         write_native(out, c)
 
+    # -- coefficient covariance by sub-sampling (pyEXP pcavar; expui/BiorthBasis.cc:583-665) ---------
+    def cov_enable(self, sampT: int) -> None:
+        check(self.lib.exp_amd_sph_cov_enable(self.h, int(sampT)), self.ctx.h)
+        self._cov_T = int(sampT)
+
+    def cov_reset(self) -> None:
+        check(self.lib.exp_amd_sph_cov_reset(self.h), self.ctx.h)
+
+    def cov_accumulate(self, comp: "Component", used_before: int = 0) -> int:
+        """File the particles of ``comp`` (caller order) under their sub-samples; returns the number
+        inside the expansion window."""
+        acc = c_longlong()
+        check(self.lib.exp_amd_sph_cov_accumulate(self.h, comp.h, int(used_before), byref(acc)), self.ctx.h)
+        return int(acc.value)
+
+    def cov_get(self) -> dict:
+        T, ltot = self._cov_T, (self.lmax + 1) * (self.lmax + 2) // 2
+        counts = np.zeros(T, dtype=np.int64)
+        masses, mean, covr = np.zeros(T), np.zeros((T, ltot, self.nmax, 2)), np.zeros((T, ltot, self.nmax, self.nmax))
+        check(self.lib.exp_amd_sph_cov_get(self.h, counts.ctypes.data, masses.ctypes.data, mean.ctypes.data,
+                                           covr.ctypes.data), self.ctx.h)
+        return {"counts": counts, "masses": masses, "mean": mean[..., 0] + 1j * mean[..., 1], "covr": covr}
+
     FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
 
     def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:

@@ -264,6 +264,19 @@ int  exp_amd_sph_set_density(exp_amd_force *f, const double *d0 /* [numr] */);
 int  exp_amd_sph_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
                         const double *c3, int coord, double *out /* [n][9] */);
 
+/* Coefficient covariance by sub-sampling (pyEXP: the `pcavar` / `subsamp` keys, enableCoefCovariance,
+ * getCoefCovariance, getCovarSamples; Spherical::accumulate expui/BiorthBasis.cc:583-665, :342-378,
+ * expui/BiorthBasis.H:425-470).  enable(sampT) allocates and zeroes (sampT <= 0 frees); accumulate
+ * files every particle of `c` inside the expansion window, in the CALLER's order, under sub-sample
+ * (used_before + its running count) % sampT and adds its g and g g^dagger; get returns
+ * counts[sampT], masses[sampT], mean[sampT][(L+1)(L+2)/2][nmax][2] (re, im) and
+ * covr[sampT][(L+1)(L+2)/2][nmax][nmax] (real: the phase cancels).                              */
+int  exp_amd_sph_cov_enable(exp_amd_force *f, int sampT);
+int  exp_amd_sph_cov_reset(exp_amd_force *f);
+int  exp_amd_sph_cov_accumulate(exp_amd_force *f, exp_amd_comp *c, long long used_before,
+                                long long *accepted);
+int  exp_amd_sph_cov_get(exp_amd_force *f, long long *counts, double *masses, double *mean, double *covr);
+
 /* Cylindrical twin: Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849)
  * = EmpCylSL::accumulated_eval (exputil/EmpCylSL.cc:5256-5410) + accumulated_dens_eval
  * (:5413-5502) for the current coefficient set; dens = densC, densS tables

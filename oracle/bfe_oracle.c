@@ -1259,3 +1259,54 @@ void orc_get_pseudo_accel(int center, int axis, const double *accel, const doubl
     for (int k = 0; k < 3; k++) out[k] += 2.0 * a[k] + b[k] + d[k];
   }
 }
+
+/* Spherical::accumulate with pcavar (expui/BiorthBasis.cc:583-665): window r < rmin or r > rmax
+ * -> skip, dsmall 1e-20, used++ then T = used % sampT, g = exp(i m phi) potd.row(l) fac norm,
+ * meanV[T][L] += g mass, covrV[T][L] += g g^dagger mass.                                        */
+long orc_pyexp_sph_covariance(const orc_slgrid *g, const orc_sph_params *P, long n,
+                              const double *X, const double *Y, const double *Z, const double *M,
+                              int sampT, long used0, long *counts, double *masses, double *mean,
+                              double *covr)
+{
+  const int lmax = g->lmax, nmax = g->nmax;
+  const double norm = -4.0 * M_PI, dsmall = 1.0e-20;
+  double *factorial = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *p = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *gr = (double *)malloc(sizeof(double) * nmax), *gi = (double *)malloc(sizeof(double) * nmax);
+  orc_factorial_table(lmax, factorial);
+  long used = used0, accepted = 0;
+  for (long i = 0; i < n; i++) {
+    double x = X[i], y = Y[i], z = Z[i], mass = M[i];
+    double r2 = x * x + y * y + z * z;
+    double r = sqrt(r2) + dsmall;
+    double costh = z / r, phi = atan2(y, x), rs = r / P->scale;
+    if (r < P->rmin || r > P->rmax) continue;
+    used++; accepted++;
+    orc_sl_get_pot(g, rs, potd);
+    orc_legendre_R(lmax, costh, p);
+    int T = (int)(used % sampT);
+    counts[T] += 1;
+    masses[T] += mass;
+    for (int l = 0, L = 0; l <= lmax; l++) {
+      for (int m = 0; m <= l; m++, L++) {
+        double fac = factorial[l * (lmax + 1) + m] * P_(l, m);
+        double c = cos(m * phi), s = sin(m * phi);
+        for (int k = 0; k < nmax; k++) {
+          double v = potd[l * nmax + k] * fac * norm;
+          gr[k] = c * v;
+          gi[k] = s * v;
+        }
+        double *mv = mean + (((size_t)T * ((lmax + 1) * (lmax + 2) / 2) + L) * nmax) * 2;
+        double *cv = covr + ((size_t)T * ((lmax + 1) * (lmax + 2) / 2) + L) * nmax * nmax;
+        for (int k = 0; k < nmax; k++) {
+          mv[2 * k] += gr[k] * mass;
+          mv[2 * k + 1] += gi[k] * mass;
+          for (int k2 = 0; k2 < nmax; k2++) cv[k * nmax + k2] += (gr[k] * gr[k2] + gi[k] * gi[k2]) * mass;
+        }
+      }
+    }
+  }
+  free(factorial); free(potd); free(p); free(gr); free(gi);
+  return accepted;
+}

@@ -161,6 +161,15 @@ void   orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, c
                              const double *vy, const double *vz, const double *pot);
 void   orc_euler_slater(double phi, double theta, double psi, int body, double *out9);
 /* QuadLS (include/QuadLS.H:17-53): y = a x^2 + b x + c; out = {a, b, c} */
+/* pyEXP coefficient covariance by sub-sampling: Spherical::accumulate with pcavar
+ * (expui/BiorthBasis.cc:583-665).  used0 = accepted particles before this call; per sub-sample
+ * T = used % sampT: counts[T], masses[T], mean[T][lm][n] (re, im) and covr[T][lm][n][n2] (the real
+ * part of g g^dagger mass; its imaginary part is identically zero).  Accumulates; returns the
+ * number of accepted particles. */
+long   orc_pyexp_sph_covariance(const orc_slgrid *g, const orc_sph_params *P, long n,
+                                const double *x, const double *y, const double *z, const double *mass,
+                                int sampT, long used0, long *counts, double *masses, double *mean,
+                                double *covr);
 void   orc_quadls(int n, const double *x, const double *y, double *out3);
 /* PseudoAccel::operator() (include/PseudoAccel.H:45-91) on a full queue of n rows {t, c[3], a[3]}:
  * accel = 2a of the centre fits, omega = n x dn/dt, domdt = n x d2n/dt2 at the last time */

@@ -181,6 +181,27 @@ class Oracle:
         self.lib.orc_orient_accumulate(ctypes.byref(o), ctypes.c_double(time), ctypes.c_double(dtime),
                                        ctypes.c_long(len(m)), _dp(m), *[_dp(c) for c in cols], _dp(p))
 
+    def pyexp_sph_covariance(self, g, prm, pos, mass, sampT, used0=0, acc=None):
+        """Spherical::accumulate with pcavar (expui/BiorthBasis.cc:583-665) -> dict(counts, masses,
+        mean [T, ltot, nmax] complex, covr [T, ltot, nmax, nmax] real, used); ``acc`` continues one."""
+        G = self.grid(g)
+        ltot = (g.lmax + 1) * (g.lmax + 2) // 2
+        if acc is None:
+            acc = {"counts": np.zeros(sampT, dtype=np.int64), "masses": np.zeros(sampT),
+                   "mean2": np.zeros((sampT, ltot, g.nmax, 2)), "covr": np.zeros((sampT, ltot, g.nmax, g.nmax)),
+                   "used": int(used0)}
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        self.lib.orc_pyexp_sph_covariance.restype = ctypes.c_long
+        n = self.lib.orc_pyexp_sph_covariance(ctypes.byref(G), ctypes.byref(prm), ctypes.c_long(len(m)),
+                                              _dp(x), _dp(y), _dp(z), _dp(m), ctypes.c_int(sampT),
+                                              ctypes.c_long(acc["used"]),
+                                              acc["counts"].ctypes.data_as(ctypes.c_void_p),
+                                              _dp(acc["masses"]), _dp(acc["mean2"]), _dp(acc["covr"]))
+        acc["used"] += int(n)
+        acc["mean"] = acc["mean2"][..., 0] + 1j * acc["mean2"][..., 1]
+        return acc
+
     def quadls(self, x, y):
         x, y = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y)]
         out = np.zeros(3)

@@ -311,3 +311,40 @@ def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
     assert f.stop_signal == 1
     f.play_back = False
     c.close()
+
+
+def test_coefficient_covariance_by_subsampling(halo_basis, oracle):
+    """pyEXP's pcavar / subsamp (tests/Halo/createCoefs.py asks for them): sub-sample counts, masses,
+    mean vectors and covariance matrices of Spherical::accumulate (expui/BiorthBasis.cc:583-665)
+    against the oracle's restatement, over two addFromArray batches (the sub-sample index follows
+    the running count of accepted particles in the caller's order); the means add up to the
+    coefficients; reset_coefs zeroes everything."""
+    basis, _ = halo_basis
+    rng = np.random.default_rng(21)
+    n, sampT = 6000, 9
+    pos = rng.normal(0, 0.4, (n, 3))
+    pos[::50] *= 20.0                                   # some outside rmax: not counted, not ranked
+    m = rng.uniform(0.5, 1.5, n) / n
+    basis.enableCoefCovariance(True, sampT)
+    basis.initFromArray()
+    basis.addFromArray(m[:2500], pos[:2500])
+    basis.addFromArray(m[2500:], pos[2500:])
+    coef = basis.makeFromArray(time=1.0)
+    prm = oracle.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+    ref = oracle.pyexp_sph_covariance(basis.grid, prm, pos, m, sampT)
+    counts, masses = basis.getCovarSamples()
+    assert np.array_equal(counts, ref["counts"]) and counts.sum() == basis.used == ref["used"]
+    assert np.allclose(masses, ref["masses"], rtol=1e-13, atol=0)
+    cov = basis.getCoefCovariance()
+    assert len(cov) == sampT and len(cov[0]) == (basis.lmax + 1) * (basis.lmax + 2) // 2
+    mean = np.array([[cov[t][lm][0] for lm in range(len(cov[0]))] for t in range(sampT)])
+    covr = np.array([[cov[t][lm][1] for lm in range(len(cov[0]))] for t in range(sampT)])
+    assert np.abs(mean - ref["mean"]).max() <= 1e-10 * np.abs(ref["mean"]).max()
+    assert np.abs(covr.real - ref["covr"]).max() <= 1e-10 * np.abs(ref["covr"]).max() and not covr.imag.any()
+    assert np.abs(mean.sum(axis=0) - coef.coefs).max() <= 1e-10 * np.abs(coef.coefs).max()
+    basis.reset_coefs()
+    counts, masses = basis.getCovarSamples()
+    assert not counts.any() and not masses.any() and not np.array(basis.getCoefCovariance()[0][0][1]).any()
+    basis.enableCoefCovariance(False)
+    with pytest.raises(RuntimeError, match="covariance not enabled"):
+        basis.force.cov_get()
