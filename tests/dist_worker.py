@@ -1,0 +1,63 @@
+"""Worker of tests/test_dist_gpu.py: one rank of a 2-process run that SHARES one GPU.  The data-path
+collective (one all-reduce of a small device buffer) goes host-staged through gloo, so that two
+ranks can sit on the same device (RCCL refuses that); everything else is the production path."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    import torch
+    import torch.distributed as dist
+    from exp_amd.dist import shard_range
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, Orient, SphereSL
+    from tests.conftest import make_grid
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def host_staged_allreduce(ptr, count, stream):
+        buf = np.empty(count)
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream)) == 0
+        assert hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), count * 8, 2) == 0
+        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), buf.ctypes.data_as(ctypes.c_void_p), count * 8, 1) == 0
+
+    model, g = make_grid("plummer", 4, 8, 400)
+    n = 40001
+    m, pos, vel = sample_sphere(model, n, seed=61)
+    pos = pos + np.array([0.1, 0.0, -0.05])
+    n0, n1 = shard_range(n, rank, world)
+    ctx = Context(0)
+    if world > 1:
+        ctx.set_allreduce(host_staged_allreduce)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m[n0:n1], pos[n0:n1], vel[n0:n1])
+    f.determine_coefficients(c)
+    coef0 = f.get_coefs()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    o = Orient(ctx, 1, 3000, Orient.CENTER | Orient.AXIS, Orient.KE)
+    o.accumulate(0.0, c)                      # global radix select: histograms all-reduced per pass
+    st = o.state()
+    for _ in range(3):
+        f.step_kdk(c, 0.01)
+    com = c.fix_positions(0)
+    d = c.download(("pos", "vel", "acc", "pot"))
+    np.savez(out, coef0=coef0, coef=f.get_coefs(), used=f.Used(), n0=n0, n1=n1, Ecurr=st["Ecurr"],
+             oused=st["used"], center1=st["center1"], axis1=st["axis1"], com=com["com"], mtot=com["mtot"],
+             **d)
+    o.close(); c.close(); f.close(); ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""SURVEY section 8e on real kernels: two processes, each with its block of the particles, ONE
+all-reduce of the coefficient buffer per accumulation (and of the small histogram / sum buffers of
+Orient and fix_positions), must reproduce the single-process run -- coefficients, the used count,
+the trajectories after three fused steps, the global energy threshold of the orientation estimator
+and the centre of mass.  Both ranks share the one GPU of the test box; the collective is host-staged
+through gloo (tests/dist_worker.py) because RCCL refuses two ranks on one device.  GPU only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, tmp_path, port):
+    outs = [str(tmp_path / f"w{world}_r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r),
+                               str(world), str(port), outs[r]], cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
+    port = 29500 + (os.getpid() % 400)
+    one = _run(1, tmp_path, port)[0]
+    two = _run(2, tmp_path, port)
+    assert two[0]["n0"] == 0 and two[0]["n1"] == two[1]["n0"] and two[1]["n1"] == one["n1"]
+    scale = np.abs(one["coef0"]).max()
+    for r in two:
+        # every rank holds the FULL coefficient set after the all-reduce
+        assert np.abs(r["coef0"] - one["coef0"]).max() <= 1e-12 * scale
+        assert np.abs(r["coef"] - one["coef"]).max() <= 1e-10 * scale
+        # the energy threshold of the most-bound selection is the GLOBAL one (the potentials differ
+        # from the single-rank run by the rounding of the coefficient sums, hence not bit for bit)
+        assert float(r["Ecurr"]) == pytest.approx(float(one["Ecurr"]), rel=1e-12) and r["oused"] == one["oused"]
+        assert np.abs(r["center1"] - one["center1"]).max() <= 1e-12
+        assert np.abs(r["axis1"] - one["axis1"]).max() <= 1e-12 * max(1.0, np.abs(one["axis1"]).max())
+        assert r["mtot"] == pytest.approx(float(one["mtot"]), rel=1e-13)
+        assert np.abs(r["com"] - one["com"]).max() <= 1e-13
+    assert int(two[0]["used"]) + int(two[1]["used"]) == int(one["used"])
+    for k in ("pos", "vel", "acc", "pot"):
+        both = np.concatenate([two[0][k], two[1][k]])
+        assert np.abs(both - one[k]).max() <= 1e-10 * np.abs(one[k]).max(), k
