@@ -54,7 +54,21 @@ def main():
     np.savez(out, coef0=coef0, coef=f.get_coefs(), used=f.Used(), n0=n0, n1=n1, Ecurr=st["Ecurr"],
              oused=st["used"], center1=st["center1"], axis1=st["axis1"], com=com["com"], mtot=com["mtot"],
              **d)
-    o.close(); c.close(); f.close(); ctx.close()
+    o.close(); c.close(); f.close()
+    # block multistep over the ranks: per-level coefficient sets, level-change differencing (its
+    # packed all-reduce runs on every rank whether or not it has movers), re-sorts
+    from exp_amd.runtime import Simulation
+    ms, dtime = 2, 0.04
+    f = SphereSL(ctx, g, multistep=ms)
+    c = Component.from_arrays(ctx, m[n0:n1], pos[n0:n1], vel[n0:n1])
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=[1000.0, 0.01, 0.01, 0.03, 0.05], shiftlevl=0)
+    sim.add_component(c, f)
+    sim.init()
+    sim.step(2)
+    d2 = c.download(("pos", "vel", "acc"))
+    lev = c.download_levels()
+    np.savez(out.replace(".npz", "_ms.npz"), coef=f.get_coefs(), lev=lev, **d2)
+    sim.close(); c.close(); f.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

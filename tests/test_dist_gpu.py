@@ -25,13 +25,13 @@ def _run(world, tmp_path, port):
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
-    return [np.load(o) for o in outs]
+    return [np.load(o) for o in outs], [np.load(o.replace(".npz", "_ms.npz")) for o in outs]
 
 
 def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
     port = 29500 + (os.getpid() % 400)
-    one = _run(1, tmp_path, port)[0]
-    two = _run(2, tmp_path, port)
+    (one,), (one_ms,) = _run(1, tmp_path, port)
+    two, two_ms = _run(2, tmp_path, port)
     assert two[0]["n0"] == 0 and two[0]["n1"] == two[1]["n0"] and two[1]["n1"] == one["n1"]
     scale = np.abs(one["coef0"]).max()
     for r in two:
@@ -49,3 +49,12 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
     for k in ("pos", "vel", "acc", "pot"):
         both = np.concatenate([two[0][k], two[1][k]])
         assert np.abs(both - one[k]).max() <= 1e-10 * np.abs(one[k]).max(), k
+    # multistep (2 levels above the base, two master steps): same levels, same trajectories
+    lev = np.concatenate([two_ms[0]["lev"], two_ms[1]["lev"]])
+    assert (lev != one_ms["lev"]).mean() < 1e-3 and one_ms["lev"].max() > 0      # (a borderline dt may flip)
+    for r in two_ms:
+        assert np.abs(r["coef"] - one_ms["coef"]).max() <= 1e-8 * np.abs(one_ms["coef"]).max()
+    same = lev == one_ms["lev"]
+    for k in ("pos", "vel"):
+        both = np.concatenate([two_ms[0][k], two_ms[1][k]])
+        assert np.abs(both - one_ms[k])[same].max() <= 1e-8 * np.abs(one_ms[k]).max(), k
