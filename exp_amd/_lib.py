@@ -86,6 +86,10 @@ SIGNATURES = {
     "exp_amd_orient_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_cyl_cov_enable": (c_int, [c_void_p, c_int]),
+    "exp_amd_cyl_cov_reset": (c_int, [c_void_p]),
+    "exp_amd_cyl_cov_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]),
+    "exp_amd_cyl_cov_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_sph_cov_enable": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_cov_reset": (c_int, [c_void_p]),
     "exp_amd_sph_cov_accumulate": (c_int, [c_void_p, c_void_p, c_longlong, POINTER(c_longlong)]),

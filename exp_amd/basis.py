@@ -134,13 +134,14 @@ class BiorthBasis:
             p = np.stack([np.asarray(a, dtype=np.float64) for a in p])
         pos, vel = self._layout(p, posvelrows)
         pos = (pos - self.coefctr) @ self.coefrot.T
+        seq = np.arange(len(m), dtype=np.uint32)      # the index accumulate() is handed (:4616-4738)
         if self._ftor is not None:
             v = np.zeros_like(pos) if vel is None else vel @ self.coefrot.T
             keep = np.array([bool(self._ftor(m[i], pos[i], v[i], self.coefindx + i))
                              for i in range(len(m))])
-            pos, m = pos[keep], m[keep]
+            pos, m, seq = pos[keep], m[keep], seq[keep]
         self.coefindx += len(m)
-        self._accumulate_batch(m, pos)
+        self._accumulate_batch(m, pos, seq)
 
     def makeFromArray(self, time: float = 0.0):
         self.make_coefs()
@@ -154,7 +155,7 @@ class BiorthBasis:
 
     def accumulate(self, x, y, z, mass, indx: int = 0) -> None:
         self._accumulate_batch(np.atleast_1d(np.float64(mass)),
-                               np.array([[x, y, z]], dtype=np.float64))
+                               np.array([[x, y, z]], dtype=np.float64), np.array([indx], dtype=np.uint32))
 
     def make_coefs(self) -> None:
         """single process: the MPI reduction of expui/BiorthBasis.cc:667-709 is the device
@@ -366,7 +367,7 @@ class SphericalSL(BiorthBasis):
         if getattr(self, "pcavar", False):                   # zero_covariance (:478)
             self.force.cov_reset()
 
-    def _accumulate_batch(self, m, pos) -> None:
+    def _accumulate_batch(self, m, pos, seq=None) -> None:
         if len(m) == 0:
             return
         c = Component.from_arrays(self.ctx, m, pos)
@@ -541,8 +542,10 @@ class Cylindrical(BiorthBasis):
         self.sin[:] = 0.0
         self.cylmass = 0.0
         self.used = 0
+        if getattr(self, "pcavar", False):                   # setup_accumulation zeroes VC / MV too
+            self.force.cov_reset()
 
-    def _accumulate_batch(self, m, pos) -> None:
+    def _accumulate_batch(self, m, pos, seq=None) -> None:
         if len(m) == 0:
             return
         c = Component.from_arrays(self.ctx, m, pos)
@@ -552,7 +555,24 @@ class Cylindrical(BiorthBasis):
         self.sin += ss
         self.cylmass += self.force.cylmass
         self.used += self.force.Used()
+        if getattr(self, "pcavar", False):                   # sl->accumulate(..., indx, 0, 0, pcavar)
+            self.force.cov_accumulate(c, seq)
         c.close()
+
+    # -- covariance by sub-sampling (expui/BiorthBasis.H:1120-1145; exputil/EmpCylSL.cc:4974-5015) ---
+    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100) -> None:
+        self.pcavar, self.sampT = bool(pcavar), max(1, int(sampT))
+        self.force.cov_enable(self.sampT if self.pcavar else 0)
+
+    def getCovarSamples(self):
+        d = self.force.cov_get()
+        return d["counts"], d["masses"]
+
+    def getCoefCovariance(self):
+        """(VC [sampT, mmax+1, nmax], MV [sampT, mmax+1, nmax, nmax]), complex, as
+        ``EmpCylSL::getCoefCovariance`` returns them."""
+        d = self.force.cov_get()
+        return d["mean"], d["covr"]
 
     def load_coefs(self, time: float = 0.0) -> CylStruct:
         self.coefret = CylStruct(self.mmax, self.nmax, time, self.cos + 1j * self.sin,

@@ -572,6 +572,13 @@ struct CylForce : exp_amd_force {
   DevBuf<double> d_tab, d_Wn, d_TF;
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
   DevBuf<double> d_dens;            // densC / densS tables (field evaluation only)
+  // sub-sample covariance (pyEXP pcavar, analysis only): node moments U[T][node][ntrig], cell
+  // moments Q[T][cell][10], counts / masses [T], results
+  int cov_T = 0;
+  DevBuf<double> cov_U, cov_Q, cov_mass, cov_vc, cov_mv;
+  DevBuf<unsigned long long> cov_cnt, cov_used;
+  DevBuf<uint32_t> cov_seq;
+  size_t cov_seq_cap = 0;
   DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
   size_t nnode = 0;
@@ -593,6 +600,8 @@ struct CylForce : exp_amd_force {
            int level = -1, bool have_keys = false, int level_hi = -1);
   void release() override
   {
+    cov_U.release(); cov_Q.release(); cov_mass.release(); cov_vc.release(); cov_mv.release();
+    cov_cnt.release(); cov_used.release(); cov_seq.release();
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
     d_mass.release();
     d_dens.release();
@@ -989,5 +998,251 @@ extern "C" int exp_amd_cyl_fields(exp_amd_force *fb, size_t n, const double *c1,
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   d_in.release();
   d_out.release();
+  return EXP_AMD_OK;
+}
+
+// ---- sub-sample covariance of the coefficients (pyEXP) ------------------------------------------------------
+// The `covar` branch of EmpCylSL::accumulate (exputil/EmpCylSL.cc:4049-4146) behind
+// Cylindrical::accumulate (expui/BiorthBasis.cc:1851-1857): per particle on the grid, sub-sample
+// whch = seq % sampT, vec = norm [(Vc cos + Vs sin) + i (Vc sin - Vs cos)] (m = 0: Vs = 0),
+// VC[whch][m] += mass vec, MV[whch][m] += mass vec vec^dagger.  Vc, Vs are bilinear in the four
+// node values of the particle's cell with weights c_k, so with u_k = c_k cos, w_k = c_k sin
+//   sum mass vec            = norm sum_node [U TC + W TS] + i norm sum_node [W TC - U TS]
+//   sum mass vec vec^dagger = norm^2 sum_cell sum_kk' Q_kk' [TC_k TC_k' + TS_k TS_k' + i (TC_k TS_k' - TS_k TC_k')]
+// (the azimuthal phase cancels: u_k u_k' + w_k w_k' = c_k c_k', u_k w_k' - w_k u_k' = 0), i.e. per
+// sub-sample the node moments U, W of the coefficient pass plus TEN cell moments Q_kk' = sum mass
+// c_k c_k' that do not even depend on m; two contractions with the tables finish the job.
+__global__ void __launch_bounds__(256)
+k_cyl_cov_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
+                     const double *__restrict__ Z, const double *__restrict__ M,
+                     const uint32_t *__restrict__ id, const uint32_t *__restrict__ seq, size_t n,
+                     int sampT, double *__restrict__ U, double *__restrict__ Q,
+                     unsigned long long *__restrict__ cnt, double *__restrict__ msum,
+                     unsigned long long *__restrict__ used)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double xx, yy, zz;
+  cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
+  const double r2 = xx * xx + yy * yy, r = sqrt(r2);
+  if (sqrt(r * r + zz * zz) / C.ascale > C.rtable) return;            // EmpCylSL.cc:4062-4063
+  const double mass = M[i];
+  const uint32_t sq = seq ? seq[id[i]] : id[i];
+  const int T = (int)(sq % (uint32_t)sampT);
+  atomicAdd(&cnt[T], 1ull);
+  atomicAdd(used, 1ull);
+  unsafeAtomicAdd(&msum[T], mass);
+  double zc = zz;                                                     // get_pot z clamp (:5563-5564)
+  if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
+  if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+  int ix, iy;
+  double cw[4];
+  cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+  const double phi = atan2(yy, xx);
+  const int nyp = C.numy + 1, NT = C.ntrig;
+  const size_t nnode = (size_t)(C.numx + 1) * nyp;
+  double *u0 = U + ((size_t)T * nnode + (size_t)ix * nyp + iy) * NT;
+  for (int m = 0; m <= C.mmax; m++) {
+    double sn, cs;
+    sincos((double)m * phi, &sn, &cs);                                // cos(phi*mm), sin(phi*mm) (:4081-4082)
+    const int jc = (m == 0) ? 0 : 2 * m - 1;
+    for (int k = 0; k < 4; k++) {
+      double *u = u0 + (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
+      unsafeAtomicAdd(u + jc, mass * cw[k] * cs);
+      if (m) unsafeAtomicAdd(u + jc + 1, mass * cw[k] * sn);
+    }
+  }
+  double *q = Q + ((size_t)T * C.numx * C.numy + (size_t)ix * C.numy + iy) * 10;
+  int p = 0;
+  for (int k = 0; k < 4; k++)
+    for (int k2 = k; k2 < 4; k2++) unsafeAtomicAdd(q + p++, mass * cw[k] * cw[k2]);
+}
+
+// VC[T][m][n] (re, im): one block per (n, m, T), reduction over the nodes
+__global__ void __launch_bounds__(256)
+k_cyl_cov_mean(CylDev C, const double *__restrict__ tab, const double *__restrict__ U,
+               double *__restrict__ vc)
+{
+  const int n = blockIdx.x, m = blockIdx.y, T = blockIdx.z;
+  __shared__ double red[2][256];
+  const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
+  const double *TC = tab + (((size_t)0 * (C.mmax + 1) + m) * C.nmax + n) * nnode;
+  const double *TS = tab + (((size_t)3 * (C.mmax + 1) + m) * C.nmax + n) * nnode;
+  const double *u = U + (size_t)T * nnode * C.ntrig;
+  const int jc = (m == 0) ? 0 : 2 * m - 1;
+  double re = 0.0, im = 0.0;
+  for (size_t k = threadIdx.x; k < nnode; k += 256) {
+    const double uc = u[k * C.ntrig + jc];
+    if (m == 0) { re = fma(uc, TC[k], re); continue; }
+    const double us = u[k * C.ntrig + jc + 1];
+    re += uc * TC[k] + us * TS[k];
+    im += us * TC[k] - uc * TS[k];
+  }
+  red[0][threadIdx.x] = re; red[1][threadIdx.x] = im;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double norm = -4.0 * M_PI;
+    double *o = vc + (((size_t)T * (C.mmax + 1) + m) * C.nmax + n) * 2;
+    o[0] = norm * red[0][0];
+    o[1] = norm * red[1][0];
+  }
+}
+
+// MV[T][m][n][o] (re, im): one block per (m, T); the corner table values of a cell are staged in LDS
+#define CYL_COV_MAXN 32
+__global__ void __launch_bounds__(256)
+k_cyl_cov_mv(CylDev C, const double *__restrict__ tab, const double *__restrict__ Q,
+             double *__restrict__ mv)
+{
+  const int m = blockIdx.x, T = blockIdx.y, N = C.nmax;
+  __shared__ double tc[4][CYL_COV_MAXN], ts[4][CYL_COV_MAXN], qs[10];
+  const int nyp = C.numy + 1;
+  const size_t nnode = (size_t)(C.numx + 1) * nyp, ncell = (size_t)C.numx * C.numy;
+  const int npair = N * N;
+  double are[4] = {0, 0, 0, 0}, aim[4] = {0, 0, 0, 0};               // N <= 32: <= 4 pairs per thread
+  for (size_t cell = 0; cell < ncell; cell++) {
+    const double *q = Q + ((size_t)T * ncell + cell) * 10;
+    if (q[0] == 0.0 && q[4] == 0.0 && q[7] == 0.0 && q[9] == 0.0) continue;   // no mass in the cell
+    __syncthreads();
+    const int ix = (int)(cell / C.numy), iy = (int)(cell - (size_t)ix * C.numy);
+    if (threadIdx.x < 10) qs[threadIdx.x] = q[threadIdx.x];
+    for (int t = threadIdx.x; t < 8 * N; t += 256) {
+      const int k = (t / N) & 3, cs = t / (4 * N), n = t % N;
+      const size_t node = (size_t)(ix + (k & 1)) * nyp + iy + ((k & 2) ? 1 : 0);
+      const double v = (cs && m == 0) ? 0.0
+                       : tab[((((size_t)(cs ? 3 : 0)) * (C.mmax + 1) + m) * N + n) * nnode + node];
+      if (cs) ts[k][n] = v; else tc[k][n] = v;
+    }
+    __syncthreads();
+    for (int j = 0, p = threadIdx.x; p < npair; p += 256, j++) {
+      const int n = p / N, o = p - n * N;
+      double re = 0.0, im = 0.0;
+      int qi = 0;
+      for (int k = 0; k < 4; k++)
+        for (int k2 = k; k2 < 4; k2++, qi++) {
+          const double w = qs[qi];
+          re += w * (tc[k][n] * tc[k2][o] + ts[k][n] * ts[k2][o]);
+          im += w * (tc[k][n] * ts[k2][o] - ts[k][n] * tc[k2][o]);
+          if (k2 != k) {                                             // the (k2, k) term of the double sum
+            re += w * (tc[k2][n] * tc[k][o] + ts[k2][n] * ts[k][o]);
+            im += w * (tc[k2][n] * ts[k][o] - ts[k2][n] * tc[k][o]);
+          }
+        }
+      are[j] += re; aim[j] += im;
+    }
+  }
+  const double norm2 = 16.0 * M_PI * M_PI;
+  for (int j = 0, p = threadIdx.x; p < npair; p += 256, j++) {
+    double *o = mv + ((((size_t)T * (C.mmax + 1) + m) * npair) + p) * 2;
+    o[0] = norm2 * are[j];
+    o[1] = norm2 * aim[j];
+  }
+}
+
+static CylForce *as_cyl(exp_amd_force *fb) { return dynamic_cast<CylForce *>(fb); }
+
+// enableCoefCovariance -> setSampT / set_covar (expui/BiorthBasis.H:1132-1145)
+extern "C" int exp_amd_cyl_cov_enable(exp_amd_force *fb, int sampT)
+{
+  CylForce *f = as_cyl(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_cov_enable: not a cylinder force");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  f->cov_U.release(); f->cov_Q.release(); f->cov_mass.release(); f->cov_vc.release(); f->cov_mv.release();
+  f->cov_cnt.release(); f->cov_used.release();
+  f->cov_T = 0;
+  if (sampT <= 0) return EXP_AMD_OK;
+  if (f->cfg.nmax > CYL_COV_MAXN) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_cov_enable: nmax > %d", CYL_COV_MAXN);
+  const CylDev &C = f->dev;
+  const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1), ncell = (size_t)C.numx * C.numy;
+  const size_t M1 = C.mmax + 1, N = C.nmax;
+  if (f->cov_U.alloc((size_t)sampT * nnode * C.ntrig) != hipSuccess ||
+      f->cov_Q.alloc((size_t)sampT * ncell * 10) != hipSuccess || f->cov_mass.alloc(sampT) != hipSuccess ||
+      f->cov_cnt.alloc(sampT) != hipSuccess || f->cov_used.alloc(1) != hipSuccess ||
+      f->cov_vc.alloc((size_t)sampT * M1 * N * 2) != hipSuccess ||
+      f->cov_mv.alloc((size_t)sampT * M1 * N * N * 2) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_cov_enable: hipMalloc failed");
+  f->cov_T = sampT;
+  HIP_TRY(ctx, hipMemset(f->cov_U.p, 0, f->cov_U.bytes()));
+  HIP_TRY(ctx, hipMemset(f->cov_Q.p, 0, f->cov_Q.bytes()));
+  HIP_TRY(ctx, hipMemset(f->cov_mass.p, 0, f->cov_mass.bytes()));
+  HIP_TRY(ctx, hipMemset(f->cov_cnt.p, 0, f->cov_cnt.bytes()));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_cyl_cov_reset(exp_amd_force *fb)
+{
+  CylForce *f = as_cyl(fb);
+  if (!f || !f->cov_T) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cyl_cov_reset: covariance not enabled");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipMemsetAsync(f->cov_U.p, 0, f->cov_U.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->cov_Q.p, 0, f->cov_Q.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->cov_mass.p, 0, f->cov_mass.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->cov_cnt.p, 0, f->cov_cnt.bytes(), ctx->stream));
+  return EXP_AMD_OK;
+}
+
+// seq[n] (caller order; NULL: 0 .. n-1) is the `seq` argument of EmpCylSL::accumulate
+extern "C" int exp_amd_cyl_cov_accumulate(exp_amd_force *fb, exp_amd_comp *c, const uint32_t *seq,
+                                          long long *on_grid)
+{
+  CylForce *f = as_cyl(fb);
+  if (!f || !c || !f->cov_T) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cyl_cov_accumulate: covariance not enabled");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  if (on_grid) *on_grid = 0;
+  if (c->n == 0) return EXP_AMD_OK;
+  if (seq) {
+    if (f->cov_seq_cap < c->n) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (f->cov_seq.alloc(c->n) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_cov_accumulate: hipMalloc failed");
+      f->cov_seq_cap = c->n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(f->cov_seq.p, seq, c->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(f->cov_used.p, 0, sizeof(unsigned long long), ctx->stream));
+  const CylDev C = cdev_for(f, c);
+  {
+    ProfScope ps(ctx, "k_cyl_covariance");
+    k_cyl_cov_accumulate<<<cdiv(c->n, 256), 256, 0, ctx->stream>>>(
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->id[c->cur].p, seq ? f->cov_seq.p : nullptr, c->n,
+        f->cov_T, f->cov_U.p, f->cov_Q.p, f->cov_cnt.p, f->cov_mass.p, f->cov_used.p);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  unsigned long long u = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&u, f->cov_used.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (on_grid) *on_grid = (long long)u;
+  return EXP_AMD_OK;
+}
+
+// EmpCylSL::getCovarSamples / getCoefCovariance (exputil/EmpCylSL.cc:4974-5015): counts[sampT],
+// masses[sampT], VC[sampT][mmax+1][nmax][2], MV[sampT][mmax+1][nmax][nmax][2]; any may be NULL
+extern "C" int exp_amd_cyl_cov_get(exp_amd_force *fb, long long *counts, double *masses, double *vc, double *mv)
+{
+  CylForce *f = as_cyl(fb);
+  if (!f || !f->cov_T) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cyl_cov_get: covariance not enabled");
+  exp_amd_ctx *ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const CylDev &C = f->dev;
+  k_cyl_cov_mean<<<dim3(C.nmax, C.mmax + 1, f->cov_T), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->cov_U.p, f->cov_vc.p);
+  k_cyl_cov_mv<<<dim3(C.mmax + 1, f->cov_T), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->cov_Q.p, f->cov_mv.p);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<unsigned long long> cnt(f->cov_T);
+  if (counts) HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), f->cov_cnt.p, f->cov_cnt.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+  if (masses) HIP_TRY(ctx, hipMemcpyAsync(masses, f->cov_mass.p, f->cov_mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+  if (vc) HIP_TRY(ctx, hipMemcpyAsync(vc, f->cov_vc.p, f->cov_vc.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+  if (mv) HIP_TRY(ctx, hipMemcpyAsync(mv, f->cov_mv.p, f->cov_mv.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (counts) for (int t = 0; t < f->cov_T; t++) counts[t] = (long long)cnt[t];
   return EXP_AMD_OK;
 }

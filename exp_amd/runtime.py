@@ -607,6 +607,35 @@ class Cylinder(_Force):
     def cylmass(self, mass: float) -> None:
         check(self.lib.exp_amd_cyl_set_cylmass(self.h, float(mass)), self.ctx.h)
 
+    # -- sub-sample covariance (pyEXP; the `covar` branch of EmpCylSL::accumulate) --------------------
+    def cov_enable(self, sampT: int) -> None:
+        check(self.lib.exp_amd_cyl_cov_enable(self.h, int(sampT)), self.ctx.h)
+        self._cov_T = int(sampT)
+
+    def cov_reset(self) -> None:
+        check(self.lib.exp_amd_cyl_cov_reset(self.h), self.ctx.h)
+
+    def cov_accumulate(self, comp: "Component", seq=None) -> int:
+        """File the on-grid particles of ``comp`` under sub-sample ``seq % sampT`` (``seq``: the running
+        index EmpCylSL::accumulate is handed, caller order; default 0 .. n-1)."""
+        acc = c_longlong()
+        ptr = None
+        if seq is not None:
+            sq = np.ascontiguousarray(seq, dtype=np.uint32)
+            assert sq.size == comp.n
+            ptr = sq.ctypes.data_as(c_void_p)
+        check(self.lib.exp_amd_cyl_cov_accumulate(self.h, comp.h, ptr, byref(acc)), self.ctx.h)
+        return int(acc.value)
+
+    def cov_get(self) -> dict:
+        T, M1, N = self._cov_T, self.mmax + 1, self.nmax
+        counts = np.zeros(T, dtype=np.int64)
+        masses, vc, mv = np.zeros(T), np.zeros((T, M1, N, 2)), np.zeros((T, M1, N, N, 2))
+        check(self.lib.exp_amd_cyl_cov_get(self.h, counts.ctypes.data, masses.ctypes.data, vc.ctypes.data,
+                                           mv.ctypes.data), self.ctx.h)
+        return {"counts": counts, "masses": masses, "mean": vc[..., 0] + 1j * vc[..., 1],
+                "covr": mv[..., 0] + 1j * mv[..., 1]}
+
     def dump_coefs_binary(self, out, time: float = 0.0) -> None:
         """``EmpCylSL::dump_coefs_binary`` (exputil/EmpCylSL.cc:5868-5920): append the current
         coefficient set to a native coefficient stream (binary file object)."""

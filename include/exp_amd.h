@@ -286,6 +286,17 @@ int  exp_amd_cyl_set_density(exp_amd_force *f, const double *dens);
 int  exp_amd_cyl_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
                         const double *c3, int coord, double *out /* [n][9] */);
 
+/* Sub-sample covariance of the cylindrical coefficients (pyEXP: Cylindrical::enableCoefCovariance,
+ * getCoefCovariance, getCovarSamples; the `covar` branch of EmpCylSL::accumulate, exputil/EmpCylSL.cc:
+ * 4049-4146, :4554-4575, :4974-5015).  accumulate files every particle of `c` that lies on the grid
+ * under sub-sample seq % sampT, seq[] (caller order; NULL: the caller index) being the `seq` argument
+ * of EmpCylSL::accumulate; get returns counts[sampT], masses[sampT], VC[sampT][mmax+1][nmax][2] and
+ * MV[sampT][mmax+1][nmax][nmax][2] (re, im).                                                      */
+int  exp_amd_cyl_cov_enable(exp_amd_force *f, int sampT);
+int  exp_amd_cyl_cov_reset(exp_amd_force *f);
+int  exp_amd_cyl_cov_accumulate(exp_amd_force *f, exp_amd_comp *c, const uint32_t *seq, long long *on_grid);
+int  exp_amd_cyl_cov_get(exp_amd_force *f, long long *counts, double *masses, double *vc, double *mv);
+
 /* ---- fused step ------------------------------------------------------------------------
  * One multistep=0 KDK step of a single self-gravitating component
  * (src/step.cc:271-323): kick dt/2, drift dt, coefficients, zero + force, kick dt/2.

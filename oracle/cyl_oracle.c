@@ -318,3 +318,47 @@ void orc_pyexp_cyl_fields(const orc_cylgrid *g, const double *dens, const double
     }
   }
 }
+
+/* EmpCylSL::accumulate, `compute and covar` (exputil/EmpCylSL.cc:4049-4146): vec = (vC cos + vS sin)
+ * + i (vC sin - vS cos) with vC = norm Vc(m,:), vS = norm Vs(m,:) (zero for m = 0);
+ * VC[whch][m] += mass vec, MV[whch][m] += mass vec vec^dagger.                                    */
+long orc_cyl_covariance(const orc_cylgrid *g, long n, const double *X, const double *Y,
+                        const double *Z, const double *M, const long *seq, int sampT, long *numbT,
+                        double *massT, double *VC, double *MV)
+{
+  const int nm = (g->mmax + 1) * g->norder, N = g->norder;
+  double *vc = (double *)calloc(nm, sizeof(double)), *vs = (double *)calloc(nm, sizeof(double));
+  double *re = (double *)malloc(sizeof(double) * N), *im = (double *)malloc(sizeof(double) * N);
+  const double norm = -4.0 * M_PI;
+  long used = 0;
+  for (long i = 0; i < n; i++) {
+    double r = sqrt(X[i] * X[i] + Y[i] * Y[i]), z = Z[i], phi = atan2(Y[i], X[i]), mass = M[i];
+    double rr = sqrt(r * r + z * z);
+    if (rr / g->ascale > g->rtable) continue;
+    used++;
+    long whch = (seq ? seq[i] : i) % sampT;
+    numbT[whch] += 1;
+    massT[whch] += mass;
+    orc_cyl_get_pot(g, r, z, vc, vs);
+    for (int mm = 0; mm <= g->mmax; mm++) {
+      double mcos = cos(phi * mm), msin = sin(phi * mm);
+      for (int k = 0; k < N; k++) {
+        double vC = vc[mm * N + k] * norm, vS = mm ? vs[mm * N + k] * norm : 0.0;
+        re[k] = vC * mcos + vS * msin;
+        im[k] = vC * msin - vS * mcos;
+      }
+      double *v = VC + (((size_t)whch * (g->mmax + 1) + mm) * N) * 2;
+      double *mv = MV + (((size_t)whch * (g->mmax + 1) + mm) * N * N) * 2;
+      for (int k = 0; k < N; k++) {
+        v[2 * k] += mass * re[k];
+        v[2 * k + 1] += mass * im[k];
+        for (int o = 0; o < N; o++) {          /* vec vec^dagger (k, o) = vec_k conj(vec_o) */
+          mv[2 * (k * N + o)] += mass * (re[k] * re[o] + im[k] * im[o]);
+          mv[2 * (k * N + o) + 1] += mass * (im[k] * re[o] - re[k] * im[o]);
+        }
+      }
+    }
+  }
+  free(vc); free(vs); free(re); free(im);
+  return used;
+}

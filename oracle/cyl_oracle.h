@@ -37,6 +37,14 @@ double orc_cyl_accumulated_dens_eval(const orc_cylgrid *g, const double *dens,
 void   orc_pyexp_cyl_fields(const orc_cylgrid *g, const double *dens, const double *accum_cos,
                             const double *accum_sin, long n, const double *c1, const double *c2,
                             const double *c3, int coord, double *out);
+/* Sub-sample covariance of the cylindrical coefficients: the `covar` branch of EmpCylSL::accumulate
+ * (exputil/EmpCylSL.cc:4049-4146) as pyEXP drives it (Cylindrical::accumulate, expui/BiorthBasis.cc:
+ * 1851-1857): particles on the grid only, whch = seq % sampT (seq NULL: the particle's index),
+ * numbT/massT[sampT], VC[sampT][mmax+1][norder][2], MV[sampT][mmax+1][norder][norder][2] (re, im).
+ * Accumulates into the outputs; returns the number of particles on the grid.                    */
+long   orc_cyl_covariance(const orc_cylgrid *g, long n, const double *x, const double *y,
+                          const double *z, const double *mass, const long *seq, int sampT,
+                          long *numbT, double *massT, double *VC, double *MV);
 #ifdef __cplusplus
 }
 #endif

@@ -297,6 +297,27 @@ class Oracle:
                                            ctypes.byref(cylmass))
         return cosN, sinN, int(used), cylmass.value
 
+    def cyl_covariance(self, g, pos, mass, sampT, seq=None, acc=None, **kw):
+        """The `covar` branch of EmpCylSL::accumulate (exputil/EmpCylSL.cc:4049-4146) -> dict(counts,
+        masses, mean [T, mmax+1, norder] complex, covr [T, mmax+1, norder, norder] complex, used)."""
+        G = self.cylgrid(g, **kw)
+        if acc is None:
+            acc = {"counts": np.zeros(sampT, dtype=np.int64), "masses": np.zeros(sampT),
+                   "vc2": np.zeros((sampT, g.mmax + 1, g.norder, 2)),
+                   "mv2": np.zeros((sampT, g.mmax + 1, g.norder, g.norder, 2)), "used": 0}
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        sq = None if seq is None else np.ascontiguousarray(seq, dtype=np.int64)
+        self.lib.orc_cyl_covariance.restype = ctypes.c_long
+        n = self.lib.orc_cyl_covariance(ctypes.byref(G), ctypes.c_long(len(m)), _dp(x), _dp(y), _dp(z), _dp(m),
+                                        None if sq is None else sq.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_int(sampT), acc["counts"].ctypes.data_as(ctypes.c_void_p),
+                                        _dp(acc["masses"]), _dp(acc["vc2"]), _dp(acc["mv2"]))
+        acc["used"] += int(n)
+        acc["mean"] = acc["vc2"][..., 0] + 1j * acc["vc2"][..., 1]
+        acc["covr"] = acc["mv2"][..., 0] + 1j * acc["mv2"][..., 1]
+        return acc
+
     def cyl_accel(self, g, pos, cosN, sinN, cylmass, center=(0.0, 0.0, 0.0), **kw):
         G = self.cylgrid(g, **kw)
         n = pos.shape[0]

@@ -204,6 +204,14 @@ parameters:
     assert fld.shape == (9,) and fld[2] > 0 and fld[5] < 0 and fld[6] == pytest.approx(acc[0, 0], rel=1e-9)
     cyl = basis(0.02, 0.0, 0.0, "cylindrical")
     assert cyl[6] == pytest.approx(acc[0, 0], rel=1e-9) and cyl[:6] == pytest.approx(fld[:6], rel=1e-12)
+    # sub-sample covariance through the basis object (enableCoefCovariance / getCoefCovariance)
+    basis.enableCoefCovariance(True, 5)
+    basis.createFromArray(m, pos, time=0.6)
+    counts, masses = basis.getCovarSamples()
+    assert counts.sum() <= 5000 and counts.min() > 0 and masses.sum() == pytest.approx(m.sum(), rel=1e-3)
+    VC, MV = basis.getCoefCovariance()
+    assert VC.shape == (5, 5, 6) and MV.shape == (5, 5, 6, 6)
+    assert np.all(np.real(np.einsum("tmnn->tmn", MV)) >= 0.0)
 
 
 def test_coefficient_stream_playback_and_fields_over_time(halo_basis, tmp_path):

@@ -372,3 +372,66 @@ def test_cyl_nbody_playback(ctx, tmp_path):
         f.set_playback(bad, dt)
     f.play_back = False
     f.close()
+
+
+def test_cyl_subsample_covariance(ctx, oracle):
+    """The `covar` branch of EmpCylSL::accumulate behind pyEXP's Cylindrical (exputil/EmpCylSL.cc:
+    4049-4146, :4974-5015): per sub-sample seq % sampT the counts, masses, mean vectors VC and
+    Hermitian covariance matrices MV against the oracle's per-particle restatement -- here from
+    hoisted moments (node moments + ten cell moments, the azimuthal phase cancels in vec vec^dagger).
+    Off-grid particles are not counted; a caller-supplied seq (selection functor) is honoured;
+    the means add up to the coefficients."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    n, sampT = 12000, 7
+    m, pos, _ = _disk(n, 97, g)
+    pos[::40] *= 400.0                                   # well off the grid
+    f = Cylinder(ctx, g)
+    f.cov_enable(sampT)
+    c = Component.from_arrays(ctx, m, pos)
+    used = f.cov_accumulate(c)
+    ref = oracle.cyl_covariance(g, pos, m, sampT)
+    got = f.cov_get()
+    assert used == ref["used"] < n
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.allclose(got["masses"], ref["masses"], rtol=1e-13, atol=0)
+    assert np.abs(got["mean"] - ref["mean"]).max() <= 1e-10 * np.abs(ref["mean"]).max()
+    assert np.abs(got["covr"] - ref["covr"]).max() <= 1e-10 * np.abs(ref["covr"]).max()
+    # (the sine tables of this basis equal the cosine tables, so the imaginary part cancels to round-off)
+    assert np.abs(got["covr"] - np.conj(np.swapaxes(got["covr"], -1, -2))).max() <= 1e-12 * np.abs(got["covr"]).max()
+    # sum over sub-samples of VC = accum_cos + accum_sin + i (cross terms): its real part for m = 0
+    # is the m = 0 cosine coefficient row
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert np.abs(got["mean"].sum(axis=0)[0].real - cc[0]).max() <= 1e-10 * np.abs(cc).max()
+    assert np.abs(got["mean"].sum(axis=0)[0].imag).max() == 0.0
+    # a second batch with an explicit seq continues the accumulation
+    seq = np.arange(n, dtype=np.uint32)[::-1].copy()
+    f.cov_accumulate(c, seq)
+    ref = oracle.cyl_covariance(g, pos, m, sampT, seq=seq, acc=ref)
+    got = f.cov_get()
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.abs(got["covr"] - ref["covr"]).max() <= 1e-10 * np.abs(ref["covr"]).max()
+    f.cov_reset()
+    z = f.cov_get()
+    assert not z["counts"].any() and not z["covr"].any() and not z["mean"].any()
+    f.cov_enable(0)
+    with pytest.raises(RuntimeError, match="covariance not enabled"):
+        f.cov_get()
+    f.close()
+    # sine tables that differ from the cosine ones: MV becomes genuinely complex (its imaginary
+    # part tests the cross terms TC_k TS_k' - TS_k TC_k')
+    import copy
+    g2 = copy.copy(g)
+    g2.tab = g.tab.copy()
+    rng = np.random.default_rng(5)
+    g2.tab[3] = g.tab[0] * (1.0 + 0.5 * rng.standard_normal(g.tab[0].shape))
+    f2 = Cylinder(ctx, g2)
+    f2.cov_enable(sampT)
+    f2.cov_accumulate(c)
+    ref2 = oracle.cyl_covariance(g2, pos, m, sampT)
+    got2 = f2.cov_get()
+    assert np.abs(ref2["covr"].imag).max() > 1e-3 * np.abs(ref2["covr"]).max()
+    assert np.abs(got2["mean"] - ref2["mean"]).max() <= 1e-10 * np.abs(ref2["mean"]).max()
+    assert np.abs(got2["covr"] - ref2["covr"]).max() <= 1e-10 * np.abs(ref2["covr"]).max()
+    c.close(); f2.close()
