@@ -326,6 +326,32 @@ class Orient:
                 "mtot": float(s[5]), "axis1": s[6:9].copy(), "center1": s[9:12].copy(),
                 "center0": s[12:15].copy()}
 
+    # -- log file (src/Orient.cc:238-291 header, :749-783 logEntry); the restart from it is not kept --
+    LOG_COLUMNS = ["Time", "E_curr", "Used", "X-axis(reg)", "Y-axis(reg)", "Z-axis(reg)", "X-axis(cur)",
+                   "Y-axis(cur)", "Z-axis(cur)", "X-center(anl)", "Y-center(anl)", "Z-center(anl)",
+                   "X-center(reg)", "Y-center(reg)", "Z-center(reg)", "X-center(cur)", "Y-center(cur)",
+                   "Z-center(cur)", "X-com(cur)", "Y-com(cur)", "Z-com(cur)", "X-com(dif)", "Y-com(dif)",
+                   "Z-com(dif)", "X-accel", "Y-accel", "Z-accel", "Omega_X", "Omega_Y", "Omega_Z",
+                   "dOmega/dt_X", "dOmega/dt_Y", "dOmega/dt_Z"]
+
+    def logHeader(self, path: str) -> None:
+        """The two header lines the constructor writes to a fresh log file (15-character columns)."""
+        with open(path, "w") as f:
+            f.write("".join(("# " if k == 0 else "| ") .__add__(c).ljust(15) for k, c in enumerate(self.LOG_COLUMNS)) + "\n")
+            f.write("".join(("# " if k == 0 else "| ") + str(k + 1).ljust(13, "-") for k in range(33)) + "\n")
+
+    def logEntry(self, time: float, path: str, com=(0.0, 0.0, 0.0), com0=(0.0, 0.0, 0.0)) -> None:
+        """``Orient::logEntry(time, c)``: one row of 33 columns -- time, Ecurr, used, axis, axis1,
+        centre, centre0, centre1, the component's com and com0, pseudo-acceleration, omega, domega/dt
+        (column order of the reference's own writer, whose header labels columns 10-15 the other way)."""
+        st = self.state()
+        acc, om, dom = self.currentAccel()
+        vals = [time, st["Ecurr"], st["used"], *st["axis"], *st["axis1"], *st["center"], *st["center0"],
+                *st["center1"], *com, *com0, *acc, *om, *dom]
+        with open(path, "a") as f:
+            f.write("".join(f"{v:>15.6g}" if not isinstance(v, (int, np.integer)) else f"{int(v):>15d}"
+                            for v in vals) + "\n")
+
     def close(self) -> None:
         if self.h:
             self.lib.exp_amd_orient_destroy(self.h)

@@ -1,6 +1,8 @@
 """Device Orient (exp_amd/csrc/orient.hip) against the oracle's restatement of src/Orient.cc over
 a run: the energy threshold (exact radix select) must be the SAME double, the number of particles
 used the same integer, centre / axis / rotations equal to round-off.  GPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -298,6 +300,18 @@ def test_orient_pseudo_accel_estimates_and_step_loop(ctx, oracle):
         else:
             assert not acc.any() and not om.any() and not dom.any()      # queue not full yet
         f.step_kdk(c, dt)
+    # log file in the reference's 33-column layout
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        log = os.path.join(d, "halo.orient.run0")
+        o.logHeader(log)
+        o.logEntry(7 * dt, log, com=(0.1, 0.2, 0.3))
+        lines = open(log).read().splitlines()
+        assert len(lines) == 3 and lines[0].startswith("# Time") and lines[0].count("|") == 32
+        row = [float(v) for v in lines[2].split()]
+        st = o.state()
+        assert len(row) == 33 and row[0] == pytest.approx(7 * dt) and row[2] == st["used"]
+        assert row[9:12] == pytest.approx(list(st["center"]), rel=1e-5, abs=1e-12) and row[18:21] == [0.1, 0.2, 0.3]
     o.close(); c.close()
     # step loop: the estimate reaches the component (no crash, finite, small for a coasting halo)
     c = Component.from_arrays(ctx, m, pos, vel)
