@@ -150,6 +150,17 @@ def cpu_baseline(grid, model, nsample, dt):
                       "oracle/bfe_oracle.c, scalar fp64, gcc -O2"}
 
 
+def _flush_c_stdio():
+    """RCCL prints a banner through C stdio; on a pipe it would only come out at exit -- after the
+    JSON line, and from every rank under torchrun.  Push it out now."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
     import torch
@@ -219,6 +230,7 @@ def main():
     for _ in range(args.warmup):
         force.step_kdk(comp, args.dt)
     barrier()
+    _flush_c_stdio()            # (every rank: the communicator exists by now)
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
@@ -309,6 +321,7 @@ def main():
             "cpu_baseline": cpu,
             "selfcheck": selfcheck,
         }
+        _flush_c_stdio()        # the JSON line is the last thing on stdout
         print(json.dumps(line), flush=True)
 
     comp.close()
