@@ -164,7 +164,7 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
 }
 
 // pass 1 when the keys already exist (written by the previous step's force pass): histogram only
-static __global__ void __launch_bounds__(SORT_TPB)
+[[maybe_unused]] static __global__ void __launch_bounds__(SORT_TPB)
 k_hist_keys(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist)
 {
   __shared__ uint32_t lh[SORT_WIN];

@@ -641,7 +641,6 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
   if (!(r < S.rmax)) mover = false;
   if (!__any(mover)) return;
-  cdp lc = (cdp)S.lc;
   const double costh = zz / r;
   double cphi, sphi;
   phi_trig(xx, yy, cphi, sphi);
