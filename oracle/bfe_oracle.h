@@ -170,6 +170,20 @@ long   orc_pyexp_sph_covariance(const orc_slgrid *g, const orc_sph_params *P, lo
                                 const double *x, const double *y, const double *z, const double *mass,
                                 int sampT, long used0, long *counts, double *masses, double *mean,
                                 double *covr);
+/* ---- tuned CPU baseline (tuned_cpu.c): the same arithmetic with the n-dependence hoisted out of
+ * the particle loops (moments + contraction, projected table), an upper bound for what a CPU can
+ * do with this algorithm; baseline infrastructure only ------------------------------------------ */
+typedef struct orc_tuned orc_tuned;
+orc_tuned *orc_tuned_create(const orc_slgrid *g);
+void   orc_tuned_free(orc_tuned *t);
+long   orc_tuned_moments(const orc_slgrid *g, const orc_tuned *t, const orc_sph_params *P, long n,
+                         const double *x, const double *y, const double *z, const double *mass,
+                         const double *center, double *W /* [(numr-1)][(lmax+1)^2][2], += */);
+void   orc_tuned_contract(const orc_slgrid *g, const orc_tuned *t, const double *W, double *coef);
+void   orc_tuned_project(const orc_slgrid *g, const orc_tuned *t, const double *coef, double *G);
+void   orc_tuned_accel(const orc_slgrid *g, const orc_tuned *t, const orc_sph_params *P, long n,
+                       const double *x, const double *y, const double *z, const double *center,
+                       const double *G, double *ax, double *ay, double *az, double *pot);
 void   orc_quadls(int n, const double *x, const double *y, double *out3);
 /* PseudoAccel::operator() (include/PseudoAccel.H:45-91) on a full queue of n rows {t, c[3], a[3]}:
  * accel = 2a of the centre fits, omega = n x dn/dt, domdt = n x d2n/dt2 at the last time */

@@ -202,6 +202,40 @@ class Oracle:
         acc["mean"] = acc["mean2"][..., 0] + 1j * acc["mean2"][..., 1]
         return acc
 
+    # -- tuned CPU baseline (oracle/tuned_cpu.c) ------------------------------------------------------
+    def tuned(self, g):
+        self.lib.orc_tuned_create.restype = ctypes.c_void_p
+        return ctypes.c_void_p(self.lib.orc_tuned_create(ctypes.byref(self.grid(g))))
+
+    def tuned_moments(self, g, t, prm, pos, mass, W, center=(0.0, 0.0, 0.0)):
+        """W [(numr-1), nrows, 2] += moments of these particles; returns the number used."""
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        c = np.asarray(center, dtype=np.float64)
+        self.lib.orc_tuned_moments.restype = ctypes.c_long
+        return int(self.lib.orc_tuned_moments(ctypes.byref(self.grid(g)), t, ctypes.byref(prm),
+                                              ctypes.c_long(len(m)), _dp(x), _dp(y), _dp(z), _dp(m), _dp(c), _dp(W)))
+
+    def tuned_contract(self, g, t, W):
+        coef = np.zeros(((g.lmax + 1) ** 2, g.nmax))
+        self.lib.orc_tuned_contract(ctypes.byref(self.grid(g)), t, _dp(W), _dp(coef))
+        return coef
+
+    def tuned_project(self, g, t, coef):
+        G = np.zeros((g.numr, (g.lmax + 1) ** 2))
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        self.lib.orc_tuned_project(ctypes.byref(self.grid(g)), t, _dp(cf), _dp(G))
+        return G
+
+    def tuned_accel(self, g, t, prm, pos, G, center=(0.0, 0.0, 0.0)):
+        n = pos.shape[0]
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        c = np.asarray(center, dtype=np.float64)
+        ax, ay, az, pot = [np.zeros(n) for _ in range(4)]
+        self.lib.orc_tuned_accel(ctypes.byref(self.grid(g)), t, ctypes.byref(prm), ctypes.c_long(n), _dp(x),
+                                 _dp(y), _dp(z), _dp(c), _dp(G), _dp(ax), _dp(ay), _dp(az), _dp(pot))
+        return np.stack([ax, ay, az], axis=1), pot
+
     def quadls(self, x, y):
         x, y = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y)]
         out = np.zeros(3)

@@ -397,3 +397,25 @@ def test_cylinder_fields_known_answers(oracle):
     fR = fc[:, 6] * np.cos(ph) + fc[:, 7] * np.sin(ph)
     assert np.abs(fy[:, 6] - fR).max() <= 1e-9 * np.abs(acc).max()
     assert np.abs(fy[:, 7] - fc[:, 8]).max() <= 1e-12 * np.abs(acc).max()
+
+
+def test_tuned_cpu_baseline_equals_the_oracle(oracle):
+    """oracle/tuned_cpu.c (the hoisted CPU statement timed as the 'tuned CPU' baseline) gives the
+    oracle's coefficients and accelerations to round-off, flags and the r > rmax branch included."""
+    from exp_amd.models import sample_sphere
+    model, g = make_grid("plummer", 6, 10, 400)
+    m, pos, _ = sample_sphere(model, 4000, seed=9)
+    pos[:30] *= 30.0                                    # beyond rmax: multipole continuation
+    pos[:, 2] *= 0.8
+    t = oracle.tuned(g)
+    for kw in ({}, {"NO_L0": 1}, {"NO_L1": 1, "EVEN_L": 1}, {"EVEN_M": 1}, {"M0_only": 1}):
+        prm = oracle.params(rmin=g.rmin, rmax=g.rmax, **kw)
+        coef, used = oracle.sph_accumulate(g, prm, pos, m)
+        W = np.zeros((g.numr - 1, (g.lmax + 1) ** 2, 2))
+        assert oracle.tuned_moments(g, t, prm, pos, m, W) == used
+        c2 = oracle.tuned_contract(g, t, W)
+        assert np.abs(c2 - coef).max() <= 1e-12 * np.abs(coef).max()
+        acc, pot = oracle.sph_accel(g, prm, pos, coef)
+        a2, p2 = oracle.tuned_accel(g, t, prm, pos, oracle.tuned_project(g, t, coef))
+        assert np.abs(a2 - acc).max() <= 1e-11 * np.abs(acc).max(), kw
+        assert np.abs(p2 - pot).max() <= 1e-11 * np.abs(pot).max(), kw
