@@ -192,6 +192,10 @@ def cpu_baseline(grid, model, nsample, dt):
                       "oracle/bfe_oracle.c, scalar fp64, gcc -O2"}
 
 
+# BASELINE.json's metric, verbatim
+METRIC = "particle-steps/sec (coef+force+kick-drift), 1e8 SphericalSL halo, 1/2/4/8 GPU"
+
+
 def _flush_c_stdio():
     """RCCL prints a banner through C stdio; on a pipe it would only come out at exit -- after the
     JSON line, and from every rank under torchrun.  Push it out now."""
@@ -340,7 +344,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(grid, model, args.cpu_sample, args.dt)
         line = {
-            "metric": "particle-steps/sec (coef+force+kick-drift)",
+            "metric": METRIC,
             "value": value,
             "unit": "particle-steps/s",
             "n_gpus": world,
