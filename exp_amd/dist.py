@@ -32,8 +32,12 @@ def torch_allreduce_callback(device=None, group=None):
     import torch
     import torch.distributed as dist
 
+    views = {}          # (ptr, count) -> tensor view: the buffers are long-lived, wrap each once
+
     def fn(ptr: int, count: int, stream: int) -> None:
-        t = torch.as_tensor(_DevPtr(ptr, count), device=device)
+        t = views.get((ptr, count))
+        if t is None:
+            t = views[(ptr, count)] = torch.as_tensor(_DevPtr(ptr, count), device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return fn
