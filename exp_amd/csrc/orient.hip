@@ -9,8 +9,9 @@
 // Steps 1-3 are a selection problem over N doubles.  The reference sorts 200000-particle bunches of
 // 64-byte records with thrust and walks a std::set on the host (src/cudaOrient.cu:109-199); here
 // the energies become order-preserving 64-bit keys (8 B/particle, written once), the k-th smallest
-// is found EXACTLY by a six-pass most-significant-digit radix select (12-bit digits, LDS
-// histograms, wave-aggregated updates, one small all-reduce of the 4096 bins per pass when the
+// is found EXACTLY by a most-significant-digit radix select (12-bit digits, LDS histograms with
+// wave-aggregated updates; the first digit is counted while the keys are formed, after the second
+// the few keys that still share the threshold's prefix are copied out and finish the select, one small all-reduce of the 4096 bins per pass when the
 // component is sharded over ranks -- so the threshold is the global one, where the reference's
 // per-rank many/numprocs trimming is only approximately that), and one streaming pass forms the
 // sums.  Step 4 is a few dozen flops on the host, restated statement for statement including the
@@ -51,54 +52,107 @@ __device__ __forceinline__ unsigned long long ord_key(double e)
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+// energies cluster: group the lanes of a wave by digit, one LDS add per distinct digit
+__device__ __forceinline__ void ori_hist_add(uint32_t *lh, unsigned digit, bool valid)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long rem = __ballot(valid);
+  while (rem) {
+    const int lead = __ffsll((long long)rem) - 1;
+    const unsigned dd = (unsigned)__shfl((int)digit, lead);
+    const unsigned long long mm = __ballot(valid && digit == dd);
+    if (lane == lead) atomicAdd(&lh[dd], (uint32_t)__popcll(mm));
+    rem &= ~mm;
+  }
+}
+
+// energies -> keys, and the histogram of their most significant digit in the same pass
 __global__ void __launch_bounds__(ORI_TPB)
 k_orient_keys(const double *__restrict__ POT, const double *__restrict__ VX,
               const double *__restrict__ VY, const double *__restrict__ VZ, size_t n, int ke,
-              unsigned long long *__restrict__ key)
-{
-  const size_t i = (size_t)blockIdx.x * ORI_TPB + threadIdx.x;
-  if (i >= n) return;
-  double e = POT[i];
-  if (ke) {                      // v2 += vel[k]*vel[k]; energy += 0.5*v2 -- each product rounded (:352-359)
-    double v2 = mul_then_add(0.0, VX[i], VX[i]);
-    v2 = mul_then_add(v2, VY[i], VY[i]);
-    v2 = mul_then_add(v2, VZ[i], VZ[i]);
-    e = mul_then_add(e, 0.5, v2);
-  }
-  key[i] = ord_key(e);
-}
-
-// one radix-select pass: histogram of the digit at `shift` over the keys whose higher bits equal
-// the prefix chosen so far.  The bins are doubles so that the context's all-reduce can sum them.
-__global__ void __launch_bounds__(ORI_TPB)
-k_orient_hist(const unsigned long long *__restrict__ key, size_t n, const OriState *__restrict__ st,
-              int pass, int shift, int bits, double *__restrict__ hist)
+              unsigned long long *__restrict__ key, double *__restrict__ hist)
 {
   __shared__ uint32_t lh[ORI_BINS];
   for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) lh[b] = 0;
   __syncthreads();
+  for (size_t base = (size_t)blockIdx.x * ORI_TILE; base < n; base += (size_t)gridDim.x * ORI_TILE) {
+#pragma unroll
+    for (int j = 0; j < ORI_ITEMS; j++) {
+      const size_t i = base + (size_t)j * ORI_TPB + threadIdx.x;
+      const bool valid = i < n;
+      unsigned long long k = 0;
+      if (valid) {
+        double e = POT[i];
+        if (ke) {                  // v2 += vel[k]*vel[k]; energy += 0.5*v2 -- each product rounded (:352-359)
+          double v2 = mul_then_add(0.0, VX[i], VX[i]);
+          v2 = mul_then_add(v2, VY[i], VY[i]);
+          v2 = mul_then_add(v2, VZ[i], VZ[i]);
+          e = mul_then_add(e, 0.5, v2);
+        }
+        k = ord_key(e);
+        key[i] = k;
+      }
+      ori_hist_add(lh, (unsigned)(k >> 52), valid);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) {
+    const uint32_t c = lh[b];
+    if (c) unsafeAtomicAdd(&hist[b], (double)c);
+  }
+}
+
+// after two digits (24 bits) the bin that holds the threshold is small: copy its keys out, the
+// remaining 40 bits are resolved on that short list
+__global__ void __launch_bounds__(ORI_TPB)
+k_orient_compact(const unsigned long long *__restrict__ key, size_t n, const OriState *__restrict__ st,
+                 unsigned long long *__restrict__ cand, unsigned long long *__restrict__ ncand)
+{
+  const unsigned long long prefix = st->prefix;         // 24 bits
+  const int lane = threadIdx.x & 63;
+  for (size_t base = (size_t)blockIdx.x * ORI_TILE; base < n; base += (size_t)gridDim.x * ORI_TILE) {
+#pragma unroll
+    for (int j = 0; j < ORI_ITEMS; j++) {
+      const size_t i = base + (size_t)j * ORI_TPB + threadIdx.x;
+      unsigned long long k = 0;
+      bool hit = false;
+      if (i < n) { k = key[i]; hit = (k >> 40) == prefix; }
+      const unsigned long long mm = __ballot(hit);
+      if (!mm) continue;
+      unsigned long long base_slot = 0;
+      const int lead = __ffsll((long long)mm) - 1;
+      if (lane == lead) base_slot = atomicAdd(ncand, (unsigned long long)__popcll(mm));
+      base_slot = (unsigned long long)__shfl((long long)base_slot, lead);
+      if (hit) cand[base_slot + (unsigned long long)__popcll(mm & ((1ull << lane) - 1ull))] = k;
+    }
+  }
+}
+
+// one radix-select pass: histogram of the digit at `shift` over the keys whose higher bits equal
+// the prefix chosen so far.  The bins are doubles so that the context's all-reduce can sum them.
+// (n_dev != nullptr: the keys are the compacted candidates, their number lives on the device)
+__global__ void __launch_bounds__(ORI_TPB)
+k_orient_hist(const unsigned long long *__restrict__ key, size_t n, const unsigned long long *__restrict__ n_dev,
+              const OriState *__restrict__ st, int pass, int shift, int bits, double *__restrict__ hist)
+{
+  __shared__ uint32_t lh[ORI_BINS];
+  for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) lh[b] = 0;
+  __syncthreads();
+  if (n_dev) { const size_t nd = (size_t)*n_dev; if (nd < n) n = nd; }
   const unsigned long long prefix = st->prefix;
   const unsigned mask = (1u << bits) - 1u;
-  const int lane = threadIdx.x & 63;
-  const size_t base = (size_t)blockIdx.x * ORI_TILE;
+  for (size_t base = (size_t)blockIdx.x * ORI_TILE; base < n; base += (size_t)gridDim.x * ORI_TILE) {
 #pragma unroll
-  for (int j = 0; j < ORI_ITEMS; j++) {
-    const size_t i = base + (size_t)j * ORI_TPB + threadIdx.x;
-    bool valid = i < n;
-    unsigned digit = 0;
-    if (valid) {
-      const unsigned long long k = key[i];
-      valid = pass == 0 || (k >> ((shift + bits) & 63)) == prefix;
-      digit = (unsigned)(k >> shift) & mask;
-    }
-    // energies cluster: group the lanes of a wave by digit, one LDS add per distinct digit
-    unsigned long long rem = __ballot(valid);
-    while (rem) {
-      const int lead = __ffsll((long long)rem) - 1;
-      const unsigned dd = (unsigned)__shfl((int)digit, lead);
-      const unsigned long long mm = __ballot(valid && digit == dd);
-      if (lane == lead) atomicAdd(&lh[dd], (uint32_t)__popcll(mm));
-      rem &= ~mm;
+    for (int j = 0; j < ORI_ITEMS; j++) {
+      const size_t i = base + (size_t)j * ORI_TPB + threadIdx.x;
+      bool valid = i < n;
+      unsigned digit = 0;
+      if (valid) {
+        const unsigned long long k = key[i];
+        valid = pass == 0 || (k >> ((shift + bits) & 63)) == prefix;
+        digit = (unsigned)(k >> shift) & mask;
+      }
+      ori_hist_add(lh, digit, valid);
     }
   }
   __syncthreads();
@@ -271,7 +325,7 @@ struct exp_amd_orient {
   double body[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, orig[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   long long used = 0;
   double Ecurr = 0, sigA = 0, sigC = 0, sigCz = 0, mtot = 0;
-  DevBuf<unsigned long long> keys;
+  DevBuf<unsigned long long> keys, cand, ncand;   // all keys; those sharing the threshold's first 24 bits
   DevBuf<double> hist, sums, part;
   DevBuf<OriState> state;
 };
@@ -292,7 +346,7 @@ extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsig
   o->deltaT = deltaT; o->damp = damp;
   if (hipSetDevice(ctx->device) != hipSuccess || o->hist.alloc(ORI_BINS) != hipSuccess ||
       o->sums.alloc(8) != hipSuccess || o->state.alloc(1) != hipSuccess ||
-      o->part.alloc((size_t)ORI_SUM_BLOCKS * 8) != hipSuccess) {
+      o->part.alloc((size_t)ORI_SUM_BLOCKS * 8) != hipSuccess || o->ncand.alloc(1) != hipSuccess) {
     delete o;
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc failed");
   }
@@ -303,7 +357,8 @@ extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsig
 extern "C" void exp_amd_orient_destroy(exp_amd_orient *o)
 {
   if (!o) return;
-  o->keys.release(); o->hist.release(); o->sums.release(); o->state.release(); o->part.release();
+  o->keys.release(); o->cand.release(); o->ncand.release(); o->hist.release(); o->sums.release();
+  o->state.release(); o->part.release();
   delete o;
 }
 
@@ -334,22 +389,33 @@ static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], doub
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
   const size_t n = c->n;
-  if (o->keys.n < n && o->keys.alloc(n) != hipSuccess)
+  if (o->keys.n < n && (o->keys.alloc(n) != hipSuccess || o->cand.alloc(n) != hipSuccess))
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc of %zu keys failed", n);
+  HIP_TRY(ctx, hipMemsetAsync(o->ncand.p, 0, sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(o->hist.p, 0, o->hist.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(o->sums.p, 0, o->sums.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(o->state.p, 0, sizeof(OriState), ctx->stream));
   const bool multi = ctx->nranks > 1 || ctx->ar_fn;
   {
     ProfScope ps(ctx, "k_orient_select");
-    if (n)
-      k_orient_keys<<<cdiv(n, ORI_TPB), ORI_TPB, 0, ctx->stream>>>(
-          c->a(A_POT), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n, (o->cflags & ORI_KE) ? 1 : 0, o->keys.p);
     static const int shift[6] = {52, 40, 28, 16, 4, 0}, bits[6] = {12, 12, 12, 12, 12, 4};
+    const unsigned gbig = (unsigned)(cdiv(n, ORI_TILE) < 4096 ? cdiv(n, ORI_TILE) : 4096);
     for (int p = 0; p < 6; p++) {
-      if (n)
-        k_orient_hist<<<cdiv(n, ORI_TILE), ORI_TPB, 0, ctx->stream>>>(o->keys.p, n, o->state.p, p,
-                                                                      shift[p], bits[p], o->hist.p);
+      if (n) {
+        if (p == 0)            // keys + first digit in one pass over pot, v
+          k_orient_keys<<<gbig, ORI_TPB, 0, ctx->stream>>>(c->a(A_POT), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n,
+                                                         (o->cflags & ORI_KE) ? 1 : 0, o->keys.p, o->hist.p);
+        else if (p == 1)
+          k_orient_hist<<<gbig, ORI_TPB, 0, ctx->stream>>>(o->keys.p, n, nullptr, o->state.p, p, shift[p],
+                                                         bits[p], o->hist.p);
+        else {                 // digits 3..6 on the compacted candidates (this rank's share)
+          if (p == 2)
+            k_orient_compact<<<gbig, ORI_TPB, 0, ctx->stream>>>(o->keys.p, n, o->state.p, o->cand.p,
+                                                              o->ncand.p);
+          k_orient_hist<<<256, ORI_TPB, 0, ctx->stream>>>(o->cand.p, n, o->ncand.p, o->state.p, p, shift[p],
+                                                         bits[p], o->hist.p);
+        }
+      }
       if (multi) { int rc = expamd_allreduce(ctx, o->hist.p, ORI_BINS); if (rc) return rc; }
       k_orient_pick<<<1, 64, 0, ctx->stream>>>(o->hist.p, o->state.p, p, bits[p],
                                                (unsigned long long)o->many);
