@@ -13,6 +13,7 @@ come from the oracle (oracle/bfe_oracle.c, oracle/cyl_oracle.c), whose correspon
 reference is argued line by line there and pinned by tests/test_oracle_kat.py.  They freeze the
 oracle's answers so that any later change to oracle OR device code that moves a result is caught.
 sph_fields.npz: see make_fields() (python tests/golden/make_golden.py fields).
+extras.npz    : see make_extras() (python tests/golden/make_golden.py extras).
 SLGridSph.model is the reference's own data file (tests/Halo/SLGridSph.model), copied verbatim.
 """
 import os
@@ -102,9 +103,40 @@ def make_fields():
     print("wrote sph_fields.npz")
 
 
+def make_extras():
+    """extras.npz : Orient (three calls: selection, histories, regression, rotations), the pseudo-
+    acceleration fit, and the sub-sample covariances of both bases, for the particles / tables frozen
+    in sph_small.npz and cyl_small.npz (NOT regenerated here)."""
+    from tests.golden_util import load_cyl, load_sph
+    orc = Oracle()
+    g, z = load_sph()
+    prm = orc.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    o = orc.orient(2, 120, 3, 2, 0.0, 0.8)
+    rows, states = [], []
+    pos, vel = z["pos"].copy(), z["vel"].copy()
+    for k in range(4):
+        orc.orient_accumulate(o, 0.1 * k, 0.1, z["mass"], pos, vel, z["pot"])
+        states.append([o.Ecurr, o.used, *o.center[:], *o.axis[:], *o.center1[:], *o.axis1[:], o.sigC, o.sigA])
+        rows.append([0.1 * k, *o.center1[:], *o.axis1[:]])
+        pos = pos + 0.1 * vel
+    acc, om, dom = orc.pseudo_accel_fit(np.array(rows))
+    cov = orc.pyexp_sph_covariance(g, prm, z["pos"], z["mass"], 5)
+    cg, cz = load_cyl()
+    ccov = orc.cyl_covariance(cg, cz["pos"], cz["mass"], 4)
+    np.savez_compressed(os.path.join(HERE, "extras.npz"), orient_states=np.array(states),
+                        orient_body=np.array(o.body[:]), pseudo=np.concatenate([acc, om, dom]),
+                        sph_cov_counts=cov["counts"], sph_cov_masses=cov["masses"], sph_cov_mean=cov["mean"],
+                        sph_cov_covr=cov["covr"], cyl_cov_counts=ccov["counts"], cyl_cov_mean=ccov["mean"],
+                        cyl_cov_covr=ccov["covr"])
+    print("wrote extras.npz")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fields":
         make_fields()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extras":
+        make_extras()
     else:
         main()
         make_fields()
+        make_extras()

@@ -53,3 +53,31 @@ def test_oracle_matches_field_golden(oracle):
     com = oracle.fix_positions(z["mass"], z["pos"], z["vel"], z["acc"],
                                np.zeros(len(z["mass"]), np.int32), 0, 0, np.zeros((1, 10)))
     assert np.abs(com - f["fix_positions"]).max() <= 1e-15 * np.abs(f["fix_positions"]).max()
+
+
+def test_oracle_matches_extras_golden(oracle):
+    """Orient, the pseudo-acceleration fit and the sub-sample covariances against the frozen vectors
+    (tests/golden/extras.npz, make_golden.py extras)."""
+    import os
+    from tests.golden_util import load_cyl, load_sph
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "extras.npz"))
+    g, z = load_sph()
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    o = oracle.orient(2, 120, 3, 2, 0.0, 0.8)
+    rows, pos = [], z["pos"].copy()
+    for k in range(4):
+        oracle.orient_accumulate(o, 0.1 * k, 0.1, z["mass"], pos, z["vel"], z["pot"])
+        got = np.array([o.Ecurr, o.used, *o.center[:], *o.axis[:], *o.center1[:], *o.axis1[:], o.sigC, o.sigA])
+        assert np.allclose(got, f["orient_states"][k], rtol=1e-13, atol=1e-300), k
+        rows.append([0.1 * k, *o.center1[:], *o.axis1[:]])
+        pos = pos + 0.1 * z["vel"]
+    assert np.allclose(np.array(o.body[:]), f["orient_body"], rtol=0, atol=1e-15)
+    acc, om, dom = oracle.pseudo_accel_fit(np.array(rows))
+    assert np.allclose(np.concatenate([acc, om, dom]), f["pseudo"], rtol=1e-10, atol=1e-300)
+    cov = oracle.pyexp_sph_covariance(g, prm, z["pos"], z["mass"], 5)
+    assert np.array_equal(cov["counts"], f["sph_cov_counts"]) and np.array_equal(cov["masses"], f["sph_cov_masses"])
+    assert np.array_equal(cov["mean"], f["sph_cov_mean"]) and np.array_equal(cov["covr"], f["sph_cov_covr"])
+    cg, cz = load_cyl()
+    ccov = oracle.cyl_covariance(cg, cz["pos"], cz["mass"], 4)
+    assert np.array_equal(ccov["counts"], f["cyl_cov_counts"])
+    assert np.array_equal(ccov["mean"], f["cyl_cov_mean"]) and np.array_equal(ccov["covr"], f["cyl_cov_covr"])

@@ -78,3 +78,53 @@ def test_sph_fields_and_fix_positions_golden(ctx):
     got = c.fix_positions(0)
     vec = np.concatenate([[got["mtot"]], got["com"], got["cov"], got["coa"]])
     assert np.abs(vec - gold["fix_positions"]).max() <= 1e-12 * np.abs(gold["fix_positions"]).max()
+
+
+def test_extras_golden(ctx):
+    """Orient (selection, histories, rotations), its pseudo-acceleration fit and the sub-sample
+    covariances of both bases against tests/golden/extras.npz -- no oracle code at run time."""
+    import os
+    from exp_amd.runtime import Component, Cylinder, Orient, SphereSL
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "extras.npz"))
+    g, z = load_sph()
+    pos = z["pos"].copy()
+    o = Orient(ctx, 2, 120, Orient.AXIS | Orient.CENTER, Orient.KE, dT=0.0, damping=0.8)
+    o.set_naccel(4)
+    for k in range(4):
+        c = Component.from_arrays(ctx, z["mass"], pos, z["vel"])
+        c.upload_acc(np.zeros_like(pos), z["pot"])
+        o.accumulate(0.1 * k, c, 0.1)
+        c.close()
+        st = o.state()
+        got = np.array([st["Ecurr"], st["used"], *st["center"], *st["axis"], *st["center1"], *st["axis1"],
+                        st["sigC"], st["sigA"]])
+        ref = f["orient_states"][k]
+        assert got[0] == ref[0] and got[1] == ref[1]                      # threshold energy, count: exact
+        assert np.allclose(got[2:14], ref[2:14], rtol=0, atol=1e-12 * np.abs(ref[2:14]).max())
+        assert np.allclose(got[14:], ref[14:], rtol=1e-6, atol=1e-24)
+        pos = pos + 0.1 * z["vel"]
+    assert np.abs(o.transformBody().reshape(9) - f["orient_body"]).max() <= 1e-10
+    acc, om, dom = o.currentAccel()
+    assert np.allclose(np.concatenate([acc, om, dom]), f["pseudo"], rtol=1e-7, atol=1e-9 * np.abs(f["pseudo"]).max())
+    o.close()
+    fs = SphereSL(ctx, g)
+    fs.cov_enable(5)
+    c = Component.from_arrays(ctx, z["mass"], z["pos"])
+    fs.cov_accumulate(c, 0)
+    d = fs.cov_get()
+    c.close()
+    assert np.array_equal(d["counts"], f["sph_cov_counts"])
+    assert np.abs(d["mean"] - f["sph_cov_mean"]).max() <= 1e-10 * np.abs(f["sph_cov_mean"]).max()
+    assert np.abs(d["covr"] - f["sph_cov_covr"]).max() <= 1e-10 * np.abs(f["sph_cov_covr"]).max()
+    fs.close()
+    cg, cz = load_cyl()
+    fc = Cylinder(ctx, cg)
+    fc.cov_enable(4)
+    c = Component.from_arrays(ctx, cz["mass"], cz["pos"])
+    fc.cov_accumulate(c)
+    d = fc.cov_get()
+    c.close()
+    assert np.array_equal(d["counts"], f["cyl_cov_counts"])
+    assert np.abs(d["mean"] - f["cyl_cov_mean"]).max() <= 1e-10 * np.abs(f["cyl_cov_mean"]).max()
+    assert np.abs(d["covr"] - f["cyl_cov_covr"]).max() <= 1e-10 * np.abs(f["cyl_cov_covr"]).max()
+    fc.close()
