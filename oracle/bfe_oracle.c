@@ -683,6 +683,20 @@ static void sph_one_particle(const orc_slgrid *g, const orc_sph_params *P, doubl
 }
 
 
+/* public form of the above for the multi-component step loop (nbody_oracle.c): val[(L+1)^2*nmax] gets
+ * the particle's contribution; returns 1 when r < rmax (SphericalBasis::multistep_update,
+ * src/SphericalBasis.cc:1156-1228) */
+int orc_sph_multistep_update(const orc_slgrid *g, const orc_sph_params *P, double xx, double yy,
+                             double zz, double mass, double *val)
+{
+  const int L1 = g->lmax + 1;
+  double p[L1 * L1], cosm[L1], sinm[L1], potd[L1 * g->nmax], factorial[L1 * L1];
+  int inside = 0;
+  orc_factorial_table(g->lmax, factorial);
+  sph_one_particle(g, P, xx, yy, zz, mass, val, p, cosm, sinm, potd, factorial, &inside);
+  return inside;
+}
+
 /* adjust_multistep_level (src/multistep.cc:344-627) + multistep_update / _finish
  * (src/SphericalBasis.cc:1033-1079, :1156-1228) for one spherical component              */
 static long sph_adjust_levels(const orc_slgrid *g, const orc_sph_params *P, const orc_mstep_tables *T,

@@ -131,6 +131,11 @@ void   orc_sph_multistep_init(const orc_slgrid *g, const orc_sph_params *P, int 
                               double *pot, const double *mass, int *level, const double *center,
                               double *coefN, double *coefL, double *coef_out);
 
+/* SphericalBasis::multistep_update (src/SphericalBasis.cc:1156-1228) for one particle given in the
+ * centred frame: val[(lmax+1)^2*nmax]; returns 1 when the particle is inside the window r < rmax. */
+int    orc_sph_multistep_update(const orc_slgrid *g, const orc_sph_params *P, double xx, double yy,
+                                double zz, double mass, double *val);
+
 /* Component::fix_positions (src/Component.cc:3280-3554): out = {mtot, com, cov, coa};
  * lev_sums[(multistep+1)][10] persists between calls (levels < mlevel are not re-summed).     */
 void   orc_fix_positions(long n, const double *mass, const double *x, const double *y,

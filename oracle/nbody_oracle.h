@@ -1,0 +1,71 @@
+/* nbody_oracle.h -- CPU restatement of EXP's block-multistep step loop over SEVERAL components with
+ * mutual interactions (BASELINE config 4: disk + halo, multistep > 0).  TEST INFRASTRUCTURE ONLY
+ * (same scope statement as bfe_oracle.h: parity unpinned; never used by exp_amd/).
+ *
+ * Follows: do_step (src/step.cc:67-325), begin_run (src/begin.cc:80-129),
+ * ComponentContainer::compute_expansion / compute_potential / multistep_reset
+ * (src/ComponentContainer.cc:1173-1241, :580-917), adjust_multistep_level (src/multistep.cc:344-627)
+ * with the thread body (:52-236), SphericalBasis's N/L swap, multistep_update / _finish and
+ * compute_multistep_coefficients (src/SphericalBasis.cc:785-792, :1033-1079, :1156-1333), the
+ * cylinder's twins (src/Cylinder.cc:946-1199, :1752-1795; src/CylEXP.cc:45-282;
+ * exputil/EmpCylSL.cc:1867-2030 setup_accumulation).
+ */
+#ifndef NBODY_ORACLE_H
+#define NBODY_ORACLE_H
+
+#include "bfe_oracle.h"
+#include "cyl_oracle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int kind;                   /* 0 = sphereSL (sg, sp), 1 = cylinder (cg)                        */
+  const orc_slgrid *sg;
+  const orc_sph_params *sp;
+  const orc_cylgrid *cg;
+  long n;
+  double *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az, *pot;
+  const double *mass;
+  int *level;                 /* Particle::level                                                 */
+  double center[3];           /* Component::center (Local | Centered)                            */
+  long ncoef;                 /* sph: (L+1)^2 nmax real rows; cyl: cos[m][n] then sin[m][n]      */
+  double *coefN, *coefL;      /* [(multistep+1)][ncoef]  expcoefN/L, cosN/sinN, cosL/sinL        */
+  double *coef;               /* [ncoef] the combined set of the last force evaluation           */
+  double cylmass;             /* Cylinder::cylmass                                               */
+  long used;                  /* PotAccel::used                                                  */
+  double resetT;              /* Cylinder::resetT                                                */
+} orc_nbody_comp;
+
+typedef struct {
+  int ncomp;
+  orc_nbody_comp *comp;
+  int ninter;
+  const int *inter;           /* ninter pairs (source, target): source's force acts on target    */
+  int multistep;
+  double dtime;
+  double dynfrac[5];          /* D, V, S, A, P (src/global.cc:76-80)                             */
+  int shiftlevl;
+  long this_step;
+  double tnow;
+} orc_nbody;
+
+/* begin_run's initial expansion, potential and level assignment (src/begin.cc:80-129) */
+void orc_nbody_init(orc_nbody *S);
+void orc_nbody_init_pass0(orc_nbody *S);   /* its first half (test hook) */
+/* one do_step (src/step.cc:67-325); nswitch[ncomp] (may be NULL) receives the level changes of
+ * each component summed over the sub-steps                                                     */
+void orc_nbody_step(orc_nbody *S, long *nswitch);
+
+/* CylEXP::multistep_update (src/CylEXP.cc:159-188) for one particle given in the cylinder's centred
+ * frame: val[2*(mmax+1)*norder] (cos block, sin block) receives `hold`; returns 0 when the particle
+ * is off the grid (nothing to add).  Called by Cylinder::multistep_update (src/Cylinder.cc:1752-1773),
+ * which applies neither the rcylmax cut nor the body rotation.                                  */
+int orc_cyl_multistep_update(const orc_cylgrid *g, double xx, double yy, double zz, double mass,
+                             double *val, double *vc, double *vs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

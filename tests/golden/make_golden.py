@@ -14,6 +14,7 @@ reference is argued line by line there and pinned by tests/test_oracle_kat.py.  
 oracle's answers so that any later change to oracle OR device code that moves a result is caught.
 sph_fields.npz: see make_fields() (python tests/golden/make_golden.py fields).
 extras.npz    : see make_extras() (python tests/golden/make_golden.py extras).
+config4_small.npz: see make_config4() (python tests/golden/make_golden.py config4).
 SLGridSph.model is the reference's own data file (tests/Halo/SLGridSph.model), copied verbatim.
 """
 import os
@@ -131,8 +132,28 @@ def make_extras():
     print("wrote extras.npz")
 
 
+def make_config4():
+    """config4_small.npz : BASELINE config 4 at test size -- inputs (600 + 600 bodies on the tables of
+    sph_small.npz / cyl_small.npz, which are NOT regenerated here) and the n-body oracle's state after
+    begin_run and after two multistep-4 master steps (oracle/nbody_oracle.c)."""
+    from tests import config4_util as c4
+    orc = Oracle()
+    inp = c4.config4_inputs()
+    nb0, _ = c4.oracle_run(orc, inp, nsteps=0)
+    init = {"init_" + k: v for k, v in c4.snapshot(nb0, [0, 0]).items()}
+    nb, nsw = c4.oracle_run(orc, inp)
+    snap = c4.snapshot(nb, nsw)
+    print("levels halo", np.bincount(snap["halo_level"], minlength=5), "disk",
+          np.bincount(snap["disk_level"], minlength=5), "switches", nsw)
+    np.savez_compressed(os.path.join(HERE, "config4_small.npz"), multistep=c4.MULTISTEP, dtime=c4.DTIME,
+                        dynfrac=np.array(c4.DYN), nsteps=c4.NSTEPS, **inp, **init, **snap)
+    print("wrote config4_small.npz")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "fields":
+    if len(sys.argv) > 1 and sys.argv[1] == "config4":
+        make_config4()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fields":
         make_fields()
     elif len(sys.argv) > 1 and sys.argv[1] == "extras":
         make_extras()
@@ -140,3 +161,4 @@ if __name__ == "__main__":
         main()
         make_fields()
         make_extras()
+        make_config4()

@@ -73,6 +73,111 @@ class OrcOrient(ctypes.Structure):
                 ("vC", (ctypes.c_double * 3) * ORC_ORIENT_HIST)]
 
 
+class _NBodyComp(ctypes.Structure):
+    """orc_nbody_comp (oracle/nbody_oracle.h)."""
+    _fields_ = [("kind", ctypes.c_int), ("sg", ctypes.POINTER(_SLGrid)), ("sp", ctypes.POINTER(_SphParams)),
+                ("cg", ctypes.POINTER(_CylGrid)), ("n", ctypes.c_long)] + \
+               [(k, c_double_p) for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "pot", "mass")] + \
+               [("level", c_int_p), ("center", ctypes.c_double * 3), ("ncoef", ctypes.c_long),
+                ("coefN", c_double_p), ("coefL", c_double_p), ("coef", c_double_p),
+                ("cylmass", ctypes.c_double), ("used", ctypes.c_long), ("resetT", ctypes.c_double)]
+
+
+class _NBody(ctypes.Structure):
+    """orc_nbody (oracle/nbody_oracle.h)."""
+    _fields_ = [("ncomp", ctypes.c_int), ("comp", ctypes.POINTER(_NBodyComp)), ("ninter", ctypes.c_int),
+                ("inter", c_int_p), ("multistep", ctypes.c_int), ("dtime", ctypes.c_double),
+                ("dynfrac", ctypes.c_double * 5), ("shiftlevl", ctypes.c_int), ("this_step", ctypes.c_long),
+                ("tnow", ctypes.c_double)]
+
+
+class NBodyOracle:
+    """The multi-component block-multistep step loop of oracle/nbody_oracle.c (do_step, begin_run,
+    ComponentContainer, adjust_multistep_level).  Components are added with ``add_sphere`` /
+    ``add_cylinder``; the state arrays live in ``self.state[k]`` (numpy, updated in place)."""
+
+    def __init__(self, oracle, multistep, dtime, dynfrac, shiftlevl=0):
+        self.orc, self.lib = oracle, oracle.lib
+        self.multistep, self.dtime, self.shiftlevl = int(multistep), float(dtime), int(shiftlevl)
+        self.dyn = [float(v) for v in dynfrac]
+        self.state, self._grids, self.inter = [], [], []
+        self.S = None
+
+    def _add(self, kind, grid_struct, prm, ncoef, mass, pos, vel, center):
+        n = len(mass)
+        st = {k: np.ascontiguousarray(pos[:, j], dtype=np.float64).copy() for j, k in enumerate("xyz")}
+        st.update({"v" + k: np.ascontiguousarray(vel[:, j], dtype=np.float64).copy() for j, k in enumerate("xyz")})
+        for k in ("ax", "ay", "az", "pot"):
+            st[k] = np.zeros(n)
+        st["mass"] = np.ascontiguousarray(mass, dtype=np.float64).copy()
+        st["level"] = np.zeros(n, dtype=np.int32)
+        st["coefN"] = np.zeros((self.multistep + 1, ncoef))
+        st["coefL"] = np.zeros((self.multistep + 1, ncoef))
+        st["coef"] = np.zeros(ncoef)
+        st.update(kind=kind, ncoef=ncoef, center=np.asarray(center, dtype=np.float64), n=n)
+        self.state.append(st)
+        self._grids.append((grid_struct, prm))
+        return len(self.state) - 1
+
+    def add_sphere(self, g, prm, mass, pos, vel, center=(0.0, 0.0, 0.0)):
+        return self._add(0, self.orc.grid(g), prm, (g.lmax + 1) ** 2 * g.nmax, mass, pos, vel, center)
+
+    def add_cylinder(self, g, mass, pos, vel, center=(0.0, 0.0, 0.0), **kw):
+        return self._add(1, self.orc.cylgrid(g, **kw), None, 2 * (g.mmax + 1) * g.norder, mass, pos, vel, center)
+
+    def add_interaction(self, source, target):
+        self.inter.append((int(source), int(target)))
+
+    def _build(self):
+        nc = len(self.state)
+        self._comps = (_NBodyComp * nc)()
+        for k, st in enumerate(self.state):
+            c = self._comps[k]
+            G, prm = self._grids[k]
+            c.kind = st["kind"]
+            if st["kind"] == 0:
+                c.sg, c.sp = ctypes.pointer(G), ctypes.pointer(prm)
+            else:
+                c.cg = ctypes.pointer(G)
+            c.n = st["n"]
+            for key in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "pot", "mass"):
+                setattr(c, key, _dp(st[key]))
+            c.level = st["level"].ctypes.data_as(c_int_p)
+            for j in range(3):
+                c.center[j] = st["center"][j]
+            c.ncoef = st["ncoef"]
+            c.coefN, c.coefL, c.coef = _dp(st["coefN"]), _dp(st["coefL"]), _dp(st["coef"])
+        self._inter = np.ascontiguousarray(np.array(self.inter, dtype=np.int32).reshape(-1))
+        S = _NBody()
+        S.ncomp, S.comp = nc, self._comps
+        S.ninter = len(self.inter)
+        S.inter = self._inter.ctypes.data_as(c_int_p) if len(self.inter) else None
+        S.multistep, S.dtime, S.shiftlevl = self.multistep, self.dtime, self.shiftlevl
+        for j in range(5):
+            S.dynfrac[j] = self.dyn[j]
+        self.S = S
+
+    def init(self, pass0_only=False):
+        self._build()
+        (self.lib.orc_nbody_init_pass0 if pass0_only else self.lib.orc_nbody_init)(ctypes.byref(self.S))
+
+    def step(self):
+        """One master step; returns the level changes per component."""
+        nsw = (ctypes.c_long * len(self.state))()
+        self.lib.orc_nbody_step(ctypes.byref(self.S), nsw)
+        return [int(v) for v in nsw]
+
+    def cylmass(self, k):
+        return float(self._comps[k].cylmass)
+
+    def used(self, k):
+        return int(self._comps[k].used)
+
+    @property
+    def time(self):
+        return float(self.S.tnow)
+
+
 class Oracle:
     def __init__(self):
         self.lib = ctypes.CDLL(build_oracle())

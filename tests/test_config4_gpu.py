@@ -1,0 +1,111 @@
+"""BASELINE config 4 (disk + halo, SphericalSL + EmpCylSL, multistep 4, both self forces and both
+cross forces, level changes in BOTH components) on the device against the n-body oracle
+(oracle/nbody_oracle.c: do_step src/step.cc:98-269, ComponentContainer::compute_potential
+src/ComponentContainer.cc:698-853, adjust_multistep_level src/multistep.cc:344-627, CylEXP's
+multistep_update / _finish / compute_multistep_coefficients src/CylEXP.cc:56-282) and against the
+frozen golden vector tests/golden/config4_small.npz.  GPU only.
+
+Bars: levels bit-exact after begin_run and after every master step; every per-level coefficient set
+(expcoefN/L, cosN/L, sinN/L) within 1e-10 of the largest coefficient; positions 1e-11 absolute,
+velocities / accelerations / potentials 1e-9 relative to their largest value."""
+import numpy as np
+import pytest
+
+from tests import config4_util as c4
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _device_run(ctx, z, multistep, dtime, dyn):
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    g, cg = c4.grids()
+    f1 = SphereSL(ctx, g, multistep=multistep, **c4.sph_window(g, float(z["scale"])))
+    f2 = Cylinder(ctx, cg, multistep=multistep)
+    c1 = Component.from_arrays(ctx, z["halo_mass"], z["halo_pos"], z["halo_vel"])
+    c2 = Component.from_arrays(ctx, z["disk_mass"], z["disk_pos"], z["disk_vel"])
+    sim = Simulation(ctx, dtime, multistep=multistep, dynfrac=dyn, shiftlevl=0)
+    i1, i2 = sim.add_component(c1, f1), sim.add_component(c2, f2)
+    sim.add_interaction(i1, i2)
+    sim.add_interaction(i2, i1)
+    sim.init()
+    return sim, (f1, f2), (c1, c2)
+
+
+def _compare(tag, forces, comps, want, multistep):
+    """`want(name, key)` returns the oracle's array."""
+    for name, f, c in zip(("halo", "disk"), forces, comps):
+        lev = c.download_levels()
+        ref = want(name, "level")
+        assert np.array_equal(lev, ref), (tag, name, int((lev != ref).sum()))
+        out = c.download()
+        p = np.stack([want(name, k) for k in "xyz"], 1)
+        v = np.stack([want(name, "v" + k) for k in "xyz"], 1)
+        a = np.stack([want(name, "a" + k) for k in "xyz"], 1)
+        assert np.abs(out["pos"] - p).max() <= 1e-11, (tag, name)
+        assert np.abs(out["vel"] - v).max() <= 1e-9 * np.abs(v).max(), (tag, name)
+        assert np.abs(out["acc"] - a).max() <= 1e-9 * np.linalg.norm(a, axis=1).max(), (tag, name)
+        assert np.abs(out["pot"] - want(name, "pot")).max() <= 1e-9 * np.abs(want(name, "pot")).max(), (tag, name)
+        cN, cL = want(name, "coefN"), want(name, "coefL")
+        cmax = np.abs(cN).max()
+        for M in range(multistep + 1):
+            if name == "halo":
+                gn = f.get_coefs(level=M).reshape(-1)
+                gl = f.get_coefs(level=M, last=True).reshape(-1)
+            else:
+                gn = np.concatenate([x.reshape(-1) for x in f.get_coefs(level=M)])
+                gl = np.concatenate([x.reshape(-1) for x in f.get_coefs(level=M, last=True)])
+            assert np.abs(gn - cN[M]).max() <= 1e-10 * cmax, (tag, name, M, "N")
+            assert np.abs(gl - cL[M]).max() <= 1e-10 * cmax, (tag, name, M, "L")
+
+
+def test_config4_against_the_nbody_oracle(ctx, oracle):
+    z = c4.load_golden()
+    ms, dtime, dyn = c4.MULTISTEP, c4.DTIME, c4.DYN
+    nb, _ = c4.oracle_run(oracle, z, nsteps=0)
+    sim, forces, comps = _device_run(ctx, z, ms, dtime, dyn)
+
+    def want(name, key):
+        return nb.state[0 if name == "halo" else 1][key]
+
+    _compare("init", forces, comps, want, ms)
+    assert forces[1].cylmass == pytest.approx(nb.cylmass(1), rel=1e-12)
+    total = [0, 0]
+    for k in range(c4.NSTEPS + 1):                       # one master step more than the golden file holds
+        nsw = nb.step()
+        total = [a + b for a, b in zip(total, nsw)]
+        sim.step(1)
+        assert sim.step_switches == sum(nsw), (k, sim.step_switches, nsw)
+        _compare(f"step{k}", forces, comps, want, ms)
+        assert forces[1].cylmass == pytest.approx(nb.cylmass(1), rel=1e-12)
+        assert forces[0].Used() == nb.used(0) and forces[1].Used() == nb.used(1)
+        # the combined sets of the last force evaluation
+        assert np.abs(forces[0].get_coefs().reshape(-1) - want("halo", "coef")).max() <= \
+            1e-10 * np.abs(want("halo", "coef")).max()
+        gc = np.concatenate([x.reshape(-1) for x in forces[1].get_coefs()])
+        assert np.abs(gc - want("disk", "coef")).max() <= 1e-10 * np.abs(want("disk", "coef")).max()
+    # the run really is config 4: level changes in both components, >= 4 populated levels each
+    assert min(total) > 0
+    for name in ("halo", "disk"):
+        assert (np.bincount(want(name, "level"), minlength=ms + 1) >= 30).sum() >= 4
+    assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
+
+
+def test_config4_against_the_golden_file(ctx):
+    """No oracle at run time: the committed vector (inputs + state after begin_run and after two
+    master steps) alone."""
+    z = c4.load_golden()
+    ms = int(z["multistep"])
+    sim, forces, comps = _device_run(ctx, z, ms, float(z["dtime"]), list(z["dynfrac"]))
+    _compare("init", forces, comps, lambda name, key: z[f"init_{name}_{key}"], ms)
+    sim.step(int(z["nsteps"]))
+    _compare("golden", forces, comps, lambda name, key: z[f"{name}_{key}"], ms)
+    assert forces[1].cylmass == pytest.approx(float(z["disk_cylmass"]), rel=1e-12)
+    assert sim.step_switches == int(np.sum(z["nswitch"]))
