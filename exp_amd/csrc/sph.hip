@@ -318,7 +318,11 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   const int hi = f->multistep ? f->mlevel : 0;
   SphDev S = dev_for(f, c->center);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), ctx->stream));
+  // used: multistep = 0 counts the last accumulation; a multistep force adds up the levels of the
+  // first sub-step (see SphForce::used_open)
+  unsigned long long *used_p = f->d_used.p + ((f->multistep && !f->used_open) ? 1 : 0);
+  if (!(f->multistep && f->used_open))
+    HIP_TRY(ctx, hipMemsetAsync(used_p, 0, sizeof(unsigned long long), ctx->stream));
   size_t nrange = c->n;      // particles of the level(s) accumulated: sizes the grid and the chunks
   if (c->n && f->multistep) {
     int rc = expamd_comp_level_count(c, lo, hi, &nrange);
@@ -327,7 +331,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
     SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi,
-                 f->d_W.p, f->d_used.p, nrange, ctx->stream, f->multistep ? 1 : 0};
+                 f->d_W.p, used_p, nrange, ctx->stream, f->multistep ? 1 : 0};
     k_acc_launch[f->cfg.lmax](a);
   }
   {
@@ -387,6 +391,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   if (prekey_done) *prekey_done = false;
   int rc = sph_project(f);
   if (rc) return rc;
+  f->used_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   // next step's keys + histogram: single level, own (sorted) particles, fused half-kick only
   const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&

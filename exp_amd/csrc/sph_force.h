@@ -15,6 +15,16 @@ struct SphForce : exp_amd_force {
   void *cov = nullptr;              // sub-sample covariance state (sph_cov.hip), analysis only
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
+  // PotAccel::used of a multistep run: the counts of every level accumulated while tnow == resetT,
+  // i.e. during the first sub-step of a master step (src/SphericalBasis.cc:796, :860-862, :1004-1010);
+  // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
+  bool used_open = true;
+  int multistep_reset() override
+  {
+    HIP_TRY(ctx, hipMemsetAsync(d_used.p, 0, sizeof(unsigned long long), ctx->stream));
+    used_open = true;
+    return EXP_AMD_OK;
+  }
 
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
                              bool have_keys = false) override;
