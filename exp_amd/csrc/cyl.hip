@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(CACC_WAVES * 64)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ Wn, double *__restrict__ tail, int CACC_CHUNK)
+                 double *__restrict__ Wn, double *__restrict__ tail, int CACC_CHUNK,
+                 const uint8_t *__restrict__ LEV /* non-null: Wn[level][node][ntrig], several levels */)
 {
   constexpr int NT = 2 * MMAX + 1;
   constexpr int NV = 4 * NT;
@@ -175,9 +176,12 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
   int cur = -1;
   double mass_used = 0.0, n_used = 0.0;
 
-  auto flush = [&](int cell) {
+  const int ncellT = C.numx * C.numy;
+  const size_t wlev = (size_t)(C.numx + 1) * nyp * NT;
+  auto flush = [&](int key) {
+    const int L = key / ncellT, cell = key - L * ncellT;       // (L = 0 in single-level launches)
     const int ix = cell / C.numy, iy = cell - ix * C.numy;
-    double *base = Wn + ((size_t)ix * nyp + iy) * NT;
+    double *base = Wn + (size_t)L * wlev + ((size_t)ix * nyp + iy) * NT;
     cyl_wave_flush<NV>(acc, scratch, base, [&](int j) {
       const int k = j / NT, t = j - k * NT;                // corner k: 0=00, 1=10, 2=01, 3=11
       return (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT + t;
@@ -188,9 +192,11 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     const size_t i = base + lane;
     const bool valid = i < cend;
     double xx = 1, yy = 0, zz = 0, mass = 0;
+    int lvl = 0;
     if (valid) {
       cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
       mass = M[i];
+      if (LEV) lvl = LEV[i];
     }
     // src/Cylinder.cc:853-866
     const double r2 = xx * xx + yy * yy;
@@ -206,7 +212,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     int ix, iy;
     double c00, c10, c01, c11;
     cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
-    const int cell = ix * C.numy + iy;
+    const int cell = ix * C.numy + iy + lvl * ncellT;
     double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
     if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
     const double t0 = ongrid ? norm * mass : 0.0;
@@ -359,11 +365,13 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 // out[cs][m][n] = sum_node tab[cs ? 3 : 0][m][n][node] * Wn[node][trig(m, cs)]
 __global__ void __launch_bounds__(256)
 k_cyl_contract(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
-               double *__restrict__ out)
+               double *__restrict__ out, size_t ostride = 0)
 {
-  const int n = blockIdx.x, m = blockIdx.y, cs = blockIdx.z;
+  const int n = blockIdx.x, m = blockIdx.y, cs = blockIdx.z & 1, L = blockIdx.z >> 1;   // L: level of a multi-level launch
   __shared__ double red[256];
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
+  Wn += (size_t)L * nnode * C.ntrig;
+  out += (size_t)L * ostride;
   double s = 0.0;
   if (!(cs == 1 && m == 0)) {
     const int t = (m == 0) ? 0 : 2 * m - 1 + cs;
@@ -588,6 +596,7 @@ struct CylForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
   int resort(exp_amd_comp *c, int first = 0) override;
   int multistep_reset() override
   {
@@ -596,8 +605,8 @@ struct CylForce : exp_amd_force {
     mass_open = true;
     return EXP_AMD_OK;
   }
-  int sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-           int level = -1, bool have_keys = false, int level_hi = -1);
+  int sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level = -1, bool have_keys = false,
+           int level_hi = -1);
   void release() override
   {
     cov_U.release(); cov_Q.release(); cov_mass.release(); cov_vc.release(); cov_mv.release();
@@ -649,7 +658,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(f->d_tab.alloc(ntab));
-  A(f->d_Wn.alloc(f->nnode * ntrig));
+  A(f->d_Wn.alloc((size_t)(cfg->multistep + 1) * f->nnode * ntrig));   // one moment buffer per level
   A(f->d_TF.alloc(f->nnode * 3 * ntrig));
   A(f->d_mass.alloc(2));
   // coefficient buffer: cos block, sin block, then {cylmass, used} riding through the all-reduce
@@ -686,8 +695,8 @@ __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ 
   if (threadIdx.x < 2) acc[threadIdx.x] = (overwrite ? 0.0 : acc[threadIdx.x]) + tail[threadIdx.x];
 }
 
-int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick, double dt_drift,
-                   int level, bool have_keys, int level_hi)
+int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level, bool have_keys,
+                   int level_hi)
 {
   CylForce *f = this;
   if (c->n == 0) return EXP_AMD_OK;
@@ -707,11 +716,11 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
     if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C};
-    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    AdvanceArgs A = expamd_advance_args(c, adv);
     k_key_hist<CylKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level, level_hi);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, adv, level, level_hi);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -720,8 +729,8 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, bool advance, double dt_kick,
 int CylForce::resort(exp_amd_comp *c, int first)
 {
   if (first > 0 && c->nlevels == multistep + 1)      // (the caller vouches for the order below `first`)
-    return sort(c, true, false, 0.0, 0.0, first, false, multistep);
-  return sort(c, true, false, 0.0, 0.0);
+    return sort(c, true, AdvSpec(), first, false, multistep);
+  return sort(c, true, AdvSpec());
 }
 
 __global__ void __launch_bounds__(256)
@@ -735,19 +744,25 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 {
   CylForce *f = this;
   const int ms = f->multistep;
-  if (ms == 0 || c->n == 0) return EXP_AMD_OK;
+  if (ms == 0) return EXP_AMD_OK;
   const size_t wl = f->nnode * dev.ntrig;
   if (f->d_Wnd.n == 0) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, f->d_Wnd.alloc(wl * (ms + 1)));
     HIP_TRY(ctx, f->d_differ.alloc(f->ncoef_dev * (ms + 1)));
   }
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p, 0, f->d_Wnd.bytes(), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p, 0, f->d_differ.bytes(), ctx->stream));
+  // the levels that multistep_update_begin clears and _finish adds (M >= mfirst[mdrft],
+  // src/CylEXP.cc:45-157); a rank without particles still takes part in the reduction
+  const int nl = ms - mfirst_mdrft + 1;
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p + (size_t)mfirst_mdrft * wl, 0, (size_t)nl * wl * sizeof(double), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, 0,
+                              (size_t)nl * f->ncoef_dev * sizeof(double), ctx->stream));
   const CylDev C = cdev_for(f, c);
-  {
+  size_t nr = 0;
+  if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
+  if (nr) {
     ProfScope ps(ctx, "k_cyl_mstep_update");
-    const unsigned grid = cdiv(c->n, 256);
+    const unsigned grid = cdiv(nr, 256);
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
@@ -755,11 +770,11 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
-  for (int M = mfirst_mdrft; M <= ms; M++)
-    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2), 256, 0, ctx->stream>>>(
-        C, f->d_tab.p, f->d_Wnd.p + (size_t)M * wl, f->d_differ.p + (size_t)M * f->ncoef_dev);
+  k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2 * nl), 256, 0, ctx->stream>>>(
+      C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl,
+      f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, f->ncoef_dev);
   HIP_TRY(ctx, hipGetLastError());
-  const size_t cnt = (size_t)(ms - mfirst_mdrft + 1) * f->ncoef_dev;
+  const size_t cnt = (size_t)nl * f->ncoef_dev;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
   if (rc) return rc;
   k_cyl_add_inplace<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(
@@ -779,7 +794,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                           ? f->mlevel : -1;
-    int rc = sort(c, c->acc_live, advance, dt_kick, dt_drift, level, have_keys);
+    int rc = sort(c, c->acc_live, AdvSpec::step(advance, dt_kick, dt_drift), level, have_keys);
     if (rc) return rc;
   }
   // ---- accumulate ----------------------------------------------------------------------------------
@@ -787,7 +802,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   if (f->multistep)   // L <- N of this level (exputil/EmpCylSL.cc:1867 setup_accumulation swap)
     HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)f->mlevel * f->ncoef_dev, dst,
                                 f->ncoef_dev * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->d_Wn.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->nnode * dev.ntrig * sizeof(double), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dst + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
   const int lo = f->multistep ? f->mlevel : 0, hi = lo;
   size_t nrange = c->n;      // population of the accumulated level: sizes the grid and the chunks
@@ -805,7 +820,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
 #define CALL(MM)                                                                                 \
   k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef, (int)chunk)
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef, (int)chunk, nullptr)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
@@ -824,6 +839,66 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 1);
   else if (f->mass_open)
     k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 0);
+  HIP_TRY(ctx, hipGetLastError());
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
+{
+  CylForce *f = this;
+  const int ms = f->multistep;
+  if (lo < 0 || lo > ms) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "substep_expansion: level out of range");
+  f->home = c;
+  f->home_gone = false;
+  const int nact = ms - lo + 1;
+  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
+  int rc;
+  if (c->n) {
+    const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
+    const bool full = lo == 0 || !ordered;
+    uint32_t keep[66];
+    const bool had = c->lev_host_valid && ordered;
+    if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
+    rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, ms);
+    if (rc) return rc;
+    if (had) {
+      for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
+      c->lev_host_valid = true;
+    }
+  }
+  const CylDev C = cdev_for(f, c);
+  // setup_accumulation(M) of every active level: L <- N, N <- 0 (exputil/EmpCylSL.cc:2010-2030)
+  double *dst = f->d_coefN.p + (size_t)lo * f->ncoef_dev;
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)lo * f->ncoef_dev, dst,
+                              (size_t)nact * f->ncoef_dev * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  const size_t wl = f->nnode * dev.ntrig;
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
+  // {in-cut mass, count} of the whole launch ride in the tail of the FIRST active level's set (the
+  // other tails are zero): one number per sub-step is all Cylinder keeps (src/Cylinder.cc:1081-1099)
+  HIP_TRY(ctx, hipMemsetAsync(dst, 0, (size_t)nact * f->ncoef_dev * sizeof(double), ctx->stream));
+  size_t nrange = 0;
+  if (c->n && (rc = expamd_comp_level_count(c, lo, ms, &nrange))) return rc;
+  if (nrange) {
+    ProfScope ps(ctx, "k_cyl_accumulate");
+    size_t chunk = (nrange / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
+    chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
+    const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
+#define CALL(MM)                                                                                 \
+  k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, f->d_Wn.p, dst + f->ncoef, \
+      (int)chunk, c->level[c->cur].p)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  }
+  {
+    ProfScope ps(ctx, "k_cyl_contract");
+    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2 * nact), 256, 0, ctx->stream>>>(
+        C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, dst, f->ncoef_dev);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;
+  if (f->mass_open) k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 0);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
   return EXP_AMD_OK;
@@ -852,9 +927,12 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   C.ps = t->pseudo;
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
+  size_t nr = t->n;                    // population of the level range: sizes the launch
+  if (t->nlevels > 1) { int rc_ = expamd_comp_level_count(t, lo, hi, &nr); if (rc_) return rc_; }
+  if (nr == 0) { t->acc_live = true; return EXP_AMD_OK; }
   {
     ProfScope ps(ctx, "k_cyl_force");
-    const unsigned grid = cdiv(t->n, 256);
+    const unsigned grid = cdiv(nr, 256);
 #define CALL(MM)                                                                                  \
   k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \

@@ -53,6 +53,18 @@ struct exp_amd_force {
   // (only levels >= first can have changed: their slot range alone is re-ordered)
   virtual int resort(exp_amd_comp *c, int first = 0) = 0;
 
+  // First half of a block-multistep sub-step for the ACTIVE levels [lo, multistep] of `c` (the active
+  // levels of a sub-step are always a suffix, src/multistep.cc:651-660) in one sweep instead of one
+  // pass per level: per level M kick DT(M)/2 and drift DT(M), DT(M) = dt_min 2^(multistep-M), fused
+  // into ONE cell sort of that slot range (src/step.cc:115-160: incr_velocity, incr_position), then
+  // for every active level the N/L swap and the accumulation of levlist[M] into expcoefN[M]
+  // (compute_expansion(M), src/ComponentContainer.cc:1173-1226) from one launch over the range with
+  // per-level moment buffers, one contraction and ONE all-reduce of the contiguous level block.
+  // The levels are disjoint particle sets and each level's accumulation reads only its own
+  // particles, so the reference's level-by-level order gives the same sums.  dt_min <= 0: no advance
+  // (begin_run's expansion of every level).
+  virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min) = 0;
+
   virtual int get_used(long long *used);
   // PotAccel::multistep_reset (src/PotAccel.H:288): start of a master step
   virtual int multistep_reset() { return EXP_AMD_OK; }

@@ -27,6 +27,8 @@ struct exp_amd_sim {
   std::vector<int> ej_dryrun;
   int centerlevl = -1;
   bool gottapot = false;
+  unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
+  size_t pinned_cap = 0;                  // (components it has room for)
 };
 
 extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
@@ -55,7 +57,12 @@ extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
   return EXP_AMD_OK;
 }
 
-extern "C" void exp_amd_sim_destroy(exp_amd_sim *s) { delete s; }
+extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
+{
+  if (!s) return;
+  if (s->pinned) (void)hipHostFree(s->pinned);
+  delete s;
+}
 
 extern "C" int exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_amd_force *f, int *index)
 {
@@ -169,16 +176,97 @@ static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft, int mstep)
   return EXP_AMD_OK;
 }
 
-static int adjust_levels(exp_amd_sim *s, int mdrft, int first_step)
+// ---- block multistep, level-fused ------------------------------------------------------------------
+// The active levels of a sub-step are a suffix [mfirst[mstep], multistep] of the level list, i.e. ONE
+// contiguous slot range of the (level, cell)-ordered store, so every phase of do_step's sub-step
+// (src/step.cc:115-231) is issued once per component over that range instead of once per level, and
+// the host looks at the device once per sub-step (the level changes of all components).
+
+// first half: for M = mfirst[mstep] .. multistep: incr_velocity(DT(M)/2, M); incr_position(DT(M), M);
+// compute_expansion(M)  (src/step.cc:126-160)
+static int substep_expansion(exp_amd_sim *s, int lo, double dt_min)
 {
-  s->last_switch = 0;
   for (size_t k = 0; k < s->comps.size(); k++) {
-    long long ns = 0;
-    int rc = exp_amd_force_adjust_multistep_level(s->forces[k], s->comps[k], s->dtime, s->dynfrac,
-                                                  s->shiftlevl, mdrft, first_step, &ns);
+    int rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min);
     if (rc) return rc;
-    s->last_switch += ns;
-    s->step_switch += ns;
+  }
+  return EXP_AMD_OK;
+}
+
+// ComponentContainer::compute_potential(mlevel): the self force of a component is evaluated first
+// and ASSIGNS acc / pot of its levels >= mlevel (the reference zeroes them and adds, src/
+// ComponentContainer.cc:641-716: same values, one pass less); the interactions then add.
+static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep)
+{
+  int rc;
+  if ((rc = fix_centers(s, mstep))) return rc;
+  for (size_t k = 0; k < s->comps.size(); k++) {
+    exp_amd_force *f = s->forces[k];
+    if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
+    if ((rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
+    if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
+  }
+  for (auto &pr : s->inter) {
+    exp_amd_force *f = s->forces[pr.first];
+    if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
+  }
+  s->gottapot = true;
+  return EXP_AMD_OK;
+}
+
+// second half: incr_velocity(dt*mintvl[M]/2, M) for M >= mfirst[mdrft] (src/step.cc:198-203; not in
+// begin_run) fused with adjust_multistep_level() (src/multistep.cc:344-627) for every component:
+// time-step criteria -> proposed levels, one read-back of {changes, new level populations} for all
+// components, then multistep_update / _finish, the commit and the re-ordering of the examined slots.
+static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool kick)
+{
+  exp_amd_ctx *ctx = s->ctx;
+  const int ms = s->multistep;
+  const int mf = s->mfirst[mdrft];
+  const int first = first_step ? 0 : mf;            // src/multistep.cc:451-453
+  const size_t nc = s->comps.size();
+  const double dt_min = s->dtime / s->Mstep;
+  if (s->pinned_cap < nc) {
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    s->pinned = nullptr;
+    HIP_TRY(ctx, hipHostMalloc((void **)&s->pinned, nc * 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    s->pinned_cap = nc;
+  }
+  int rc;
+  for (size_t k = 0; k < nc; k++) {
+    if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
+                                      kick ? mf : ms + 1, first, dt_min))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, s->comps[k]->nswitch.p, 32 * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  s->last_switch = 0;
+  for (size_t k = 0; k < nc; k++) {
+    exp_amd_comp *c = s->comps[k];
+    exp_amd_force *f = s->forces[k];
+    const unsigned long long *res = s->pinned + k * 32;
+    const unsigned long long u = res[0];
+    s->last_switch += (long long)u;
+    s->step_switch += (long long)u;
+    // (collective: with several ranks every rank takes part even if it has no mover)
+    if (ctx->nranks > 1 || ctx->ar_fn || u)
+      if ((rc = f->multistep_update(c, first, mf))) return rc;
+    if (u) {
+      const bool ordered = c->sorted_for == (const void *)f && c->nlevels == ms + 1;
+      const bool mirror = ordered && c->lev_host_valid;
+      uint32_t off[66];
+      if (mirror) {
+        // new level offsets: the levels below `first` were not examined, the proposals fill the rest
+        for (int L = 0; L <= first; L++) off[L] = c->lev_host[L];
+        for (int L = first; L <= ms; L++) off[L + 1] = off[L] + (uint32_t)res[1 + L];
+      }
+      if ((rc = expamd_comp_commit_levels(c, mirror ? (size_t)c->lev_host[first] : 0))) return rc;
+      if ((rc = f->resort(c, ordered ? first : 0))) return rc;
+      if (mirror) {
+        for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];
+        c->lev_host_valid = true;
+      }
+    }
   }
   return EXP_AMD_OK;
 }
@@ -191,14 +279,15 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
   int rc;
   if (s->multistep) {
     for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
-    for (int M = 0; M <= s->multistep; M++)
-      if ((rc = compute_expansion(s, M))) return rc;
-    if ((rc = compute_potential(s, 0, 0, 0))) return rc;
-    if ((rc = adjust_levels(s, 0, 1))) return rc;
+    // for (M = 0 .. multistep) compute_expansion(M): every level, nothing advanced
+    if ((rc = substep_expansion(s, 0, 0.0))) return rc;
+    if ((rc = compute_potential_ms(s, 0, 0, 0))) return rc;
+    if ((rc = kick_adjust_levels(s, 0, 1, false))) return rc;
     for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
+    if ((rc = substep_expansion(s, 0, 0.0))) return rc;
+    return compute_potential_ms(s, 0, 0, 0);
   }
-  for (int M = 0; M <= s->multistep; M++)
-    if ((rc = compute_expansion(s, M))) return rc;
+  if ((rc = compute_expansion(s, 0))) return rc;
   return compute_potential(s, 0, 0, 0);
 }
 
@@ -215,21 +304,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
-        for (int M = s->mfirst[mstep]; M <= s->multistep; M++) {
-          const double DT = dt * s->mintvl[M];
-          for (auto c : s->comps) {
-            if ((rc = exp_amd_comp_kick(c, 0.5 * DT, M))) return rc;
-            if ((rc = exp_amd_comp_drift(c, DT, M))) return rc;
-          }
-          if ((rc = compute_expansion(s, M))) return rc;
-        }
+        if ((rc = substep_expansion(s, s->mfirst[mstep], dt))) return rc;
         s->tnow += dt;
         const int mdrft = mstep + 1;
-        if ((rc = compute_potential(s, s->mfirst[mstep], mdrft, mstep))) return rc;
-        for (int M = s->mfirst[mdrft]; M <= s->multistep; M++)
-          for (auto c : s->comps)
-            if ((rc = exp_amd_comp_kick(c, 0.5 * dt * s->mintvl[M], M))) return rc;
-        if ((rc = adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0))) return rc;
+        if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep))) return rc;
+        if ((rc = kick_adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0, true))) return rc;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
       s->tnow += s->dtime;

@@ -2,6 +2,19 @@
 #pragma once
 #include "common.h"
 
+// How a sort pass advances the particles on the way (sort_kernels.h: advance_one).
+//   mode 0: not at all;  1: kick dt_kick, drift dt_drift (fused single-level step);
+//   2: the first half of a block-multistep sub-step, per level M: kick DT(M)/2, drift DT(M),
+//      DT(M) = dt_min * 2^(multistep - M)  (src/step.cc:115-160)
+struct AdvSpec {
+  int mode = 0;
+  double dt_kick = 0.0, dt_drift = 0.0, dt_min = 0.0;
+  int multistep = 0;
+  static AdvSpec none() { return AdvSpec{}; }
+  static AdvSpec step(bool on, double dtk, double dtd) { AdvSpec a; a.mode = on ? 1 : 0; a.dt_kick = dtk; a.dt_drift = dtd; return a; }
+  static AdvSpec levels(double dt_min_, int ms) { AdvSpec a; a.mode = 2; a.dt_min = dt_min_; a.multistep = ms; return a; }
+};
+
 enum { A_X = 0, A_Y, A_Z, A_VX, A_VY, A_VZ, A_M, A_AX, A_AY, A_AZ, A_POT, A_NARR };
 
 struct exp_amd_comp {

@@ -232,16 +232,18 @@ int expamd_comp_apply_pending(exp_amd_comp *c)
   return EXP_AMD_OK;
 }
 
-AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv)
 {
   AdvanceArgs A;
   A.x = c->a(A_X); A.y = c->a(A_Y); A.z = c->a(A_Z);
   A.vx = c->a(A_VX); A.vy = c->a(A_VY); A.vz = c->a(A_VZ);
   A.ax = c->a(A_AX); A.ay = c->a(A_AY); A.az = c->a(A_AZ);
   A.lev = c->level[c->cur].p;
-  A.dt_kick = dt_kick; A.dt_drift = dt_drift;
-  A.dt_kick0 = advance ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
-  A.advance = advance ? 1 : 0;
+  A.dt_kick = adv.dt_kick; A.dt_drift = adv.dt_drift;
+  A.dt_kick0 = adv.mode ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
+  A.advance = adv.mode;
+  A.multistep = adv.multistep;
+  A.dt_min = adv.dt_min;
   return A;
 }
 
@@ -278,8 +280,9 @@ k_copy_range(CopySet C, const uint32_t *__restrict__ lev_off, int level, int lev
 }
 
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift, int level, int level_hi)
+                            const AdvSpec &adv, int level, int level_hi)
 {
+  const bool advance = adv.mode != 0;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   if (level < 0 || level_hi < level) level_hi = level;
@@ -295,7 +298,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
   }
   {
     ProfScope ps(ctx, "k_scatter_adv");
-    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    AdvanceArgs A = expamd_advance_args(c, adv);
     ScatterSrc S{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
     ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
@@ -388,10 +391,92 @@ k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__res
 }
 
 __global__ void __launch_bounds__(TPB)
-k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, size_t n)
+k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, size_t beg, size_t n)
 {
-  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i < n) lev[i] = newlev[i];
+}
+
+// The second half of a block-multistep sub-step in one pass over the slots of the levels that take
+// part: incr_velocity(0.5*dt*mintvl[M], M) for M >= kick_lo (src/step.cc:198-203) and, on the kicked
+// velocities, adjust_multistep_level's sweep over the levels >= first (src/multistep.cc:52-236), as
+// k_adjust_levels above.  out[0] += level changes; out[1 + L] += particles proposed for level L
+// among those examined (the host derives the new level offsets from them without a second
+// read-back).  kick_lo > last: no kick (begin_run's first assignment).
+#define KA_ITEMS 8       // 256-slot tiles per block (the counters leave a block as one atomic per value)
+__global__ void __launch_bounds__(TPB)
+k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+              const double *__restrict__ ax, const double *__restrict__ ay,
+              const double *__restrict__ az, const double *__restrict__ pot,
+              const uint8_t *__restrict__ lev, uint8_t *__restrict__ newlev,
+              const uint32_t *__restrict__ lev_off, int kick_lo, int first, int last, double dt_min,
+              unsigned long long *__restrict__ out)
+{
+  __shared__ unsigned int cnt[32];
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int lo = kick_lo < first ? kick_lo : first;
+  const size_t beg = lev_off[lo], end = lev_off[last + 1], ebeg = lev_off[first];
+  const int lane = threadIdx.x & 63;
+  for (int it = 0; it < KA_ITEMS; it++) {
+    const size_t i = beg + ((size_t)blockIdx.x * KA_ITEMS + it) * TPB + threadIdx.x;
+    if (i - threadIdx.x >= end) break;          // (block-uniform)
+    const bool valid = i < end;
+    unsigned plev = 0, nlev = 0;
+    bool examined = false;
+    if (valid) {
+      plev = lev[i];
+      nlev = plev;
+      double v0 = vx[i], v1 = vy[i], v2 = vz[i];
+      const double a0 = ax[i], a1 = ay[i], a2 = az[i];
+      if ((int)plev >= kick_lo) {
+        const double dtk = 0.5 * level_dt(dt_min, A.multistep, (int)plev);
+        v0 = mul_then_add(v0, a0, dtk);
+        v1 = mul_then_add(v1, a1, dtk);
+        v2 = mul_then_add(v2, a2, dtk);
+        vx[i] = v0; vy[i] = v1; vz[i] = v2;
+      }
+      examined = i >= ebeg;
+      if (examined) {
+        const double eps = 1.0e-10;
+        double dtr = 0.0, vtot = 0.0, atot = 0.0;
+        dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
+        dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
+        dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
+        const double ptot = fabs(pot[i]);
+        const double dts = 1.0 / eps;                  // Particle::scale <= 0: criterion off
+        const double dtd = A.dynD * 1.0 / sqrt(vtot + eps);
+        const double dtv = A.dynV * sqrt(vtot / (atot + eps));
+        const double dta = A.dynA * ptot / (fabs(dtr) + eps);
+        const double dtA = A.dynP * sqrt(ptot / (atot + eps));
+        double dmin = dtd;
+        if (dtv < dmin) dmin = dtv;
+        if (dts < dmin) dmin = dts;
+        if (dta > 0.0 && dta < dmin) dmin = dta;
+        if (dtA > 0.0 && dtA < dmin) dmin = dtA;
+        const double dt = dmin > eps ? dmin : eps;
+        const float dtreq = (float)dt;
+        if ((double)dtreq > A.dtime) nlev = 0;
+        else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
+        if (A.shiftlevl) {
+          if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
+          else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+        }
+        if (nlev > (unsigned)A.multistep) nlev = A.multistep;
+        if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
+        newlev[i] = (uint8_t)nlev;
+      }
+    }
+    // wave-aggregated counters in LDS: one add per wave and value
+    const unsigned long long sw = __ballot(examined && nlev != plev);
+    if (lane == 0 && sw) atomicAdd(&cnt[0], (unsigned)__popcll(sw));
+    for (int L = A.mfirst_mdrft; L <= A.multistep; L++) {
+      const unsigned long long mm = __ballot(examined && (int)nlev == L);
+      if (lane == 0 && mm) atomicAdd(&cnt[1 + L], (unsigned)__popcll(mm));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && cnt[threadIdx.x]) atomicAdd(out + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
 }
 
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
@@ -410,14 +495,36 @@ int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfr
   return EXP_AMD_OK;
 }
 
-int expamd_comp_commit_levels(exp_amd_comp *c)
+int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg)
 {
   exp_amd_ctx *ctx = c->ctx;
-  if (c->n == 0) return EXP_AMD_OK;
+  if (c->n == 0 || beg >= c->n) return EXP_AMD_OK;
   c->levels_zero = false;
-  k_commit_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, c->n);
+  k_commit_levels<<<cdiv(c->n - beg, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, beg, c->n);
   HIP_TRY(ctx, hipGetLastError());
   c->sorted_for = nullptr;
+  return EXP_AMD_OK;
+}
+
+// launches k_kick_adjust; results land in c->nswitch (u64[1 + levels], zeroed here)
+int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
+                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p, 0, c->nswitch.bytes(), ctx->stream));
+  if (c->n == 0) return EXP_AMD_OK;
+  const int lo = kick_lo < first ? kick_lo : first;
+  size_t nr = 0;
+  int rc = expamd_comp_level_count(c, lo, multistep, &nr);
+  if (rc) return rc;
+  if (nr == 0) return EXP_AMD_OK;
+  AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
+               shiftlevl, mfirst_mdrft};
+  ProfScope ps(ctx, "k_kick_adjust");
+  k_kick_adjust<<<cdiv(nr, (size_t)TPB * KA_ITEMS), TPB, 0, ctx->stream>>>(
+      A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, c->nswitch.p);
+  HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
 
@@ -447,7 +554,7 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
     }
   }
   if (c->key.alloc(na) != hipSuccess || c->lev_off.alloc(64) != hipSuccess ||
-      c->newlev.alloc(na) != hipSuccess || c->nswitch.alloc(1) != hipSuccess) {
+      c->newlev.alloc(na) != hipSuccess || c->nswitch.alloc(32) != hipSuccess) {
     exp_amd_comp_destroy(c);
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
   }

@@ -31,8 +31,18 @@ struct AdvanceArgs {
   const uint8_t *lev;
   double dt_kick, dt_drift;    // 0,0 -> positions are used as they are
   double dt_kick0;             // deferred half-kick of the previous fused step, applied first (0: none)
-  int advance;
+  int advance;                 // 0: none; 1: dt_kick / dt_drift; 2: per-level steps of a block-multistep
+                               // sub-step: drift DT(M) = dt_min * 2^(multistep - M), kick DT(M)/2
+                               // (src/step.cc:115-160: dt*mintvl[M]; exact power-of-two scalings)
+  int multistep;
+  double dt_min;
 };
+
+// the block-multistep time step of level `lev` (src/multistep.cc:640-646: mintvl[M] = Mstep >> M)
+__device__ __forceinline__ double level_dt(double dt_min, int multistep, int lev)
+{
+  return dt_min * (double)(1u << (multistep - lev));
+}
 
 __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, double &x, double &y,
                                             double &z, double &vx, double &vy, double &vz)
@@ -42,17 +52,22 @@ __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, doub
     // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
     const double ax = A.ax[i], ay = A.ay[i], az = A.az[i];
     vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
+    double dtk = A.dt_kick, dtd = A.dt_drift;
+    if (A.advance == 2) {
+      dtd = level_dt(A.dt_min, A.multistep, A.lev[i]);
+      dtk = 0.5 * dtd;
+    }
     if (A.dt_kick0 != 0.0) {       // its own rounding step, exactly as the separate kick would be
       vx = mul_then_add(vx, ax, A.dt_kick0);
       vy = mul_then_add(vy, ay, A.dt_kick0);
       vz = mul_then_add(vz, az, A.dt_kick0);
     }
-    vx = mul_then_add(vx, ax, A.dt_kick);
-    vy = mul_then_add(vy, ay, A.dt_kick);
-    vz = mul_then_add(vz, az, A.dt_kick);
-    x = mul_then_add(x, vx, A.dt_drift);
-    y = mul_then_add(y, vy, A.dt_drift);
-    z = mul_then_add(z, vz, A.dt_drift);
+    vx = mul_then_add(vx, ax, dtk);
+    vy = mul_then_add(vy, ay, dtk);
+    vz = mul_then_add(vz, az, dtk);
+    x = mul_then_add(x, vx, dtd);
+    y = mul_then_add(y, vy, dtd);
+    z = mul_then_add(z, vz, dtd);
   }
 }
 
@@ -254,12 +269,13 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
 
 // host helper (defined in particles.hip): scan + scatter after a k_key_hist launch
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
-                            bool advance, double dt_kick, double dt_drift, int level = -1,
-                            int level_hi = -1);
+                            const AdvSpec &adv, int level = -1, int level_hi = -1);
 // level < 0: all slots; else the slots of levels [level, max(level, level_hi)]
 SortRange expamd_sort_range(exp_amd_comp *c, int level, int level_hi = -1);
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys);
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                                int multistep, int mfirst_mdrft, int first);
-int expamd_comp_commit_levels(exp_amd_comp *c);
-AdvanceArgs expamd_advance_args(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift);
+int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg = 0);
+int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
+                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min);
+AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv);

@@ -27,6 +27,9 @@ k_sph_contract(SphDev S, const double *__restrict__ W, const double *__restrict_
   int l = 0;
   while ((l + 1) * (l + 1) <= row) l++;
   const int ncell = S.numr - 1;
+  // blockIdx.z: one moment buffer / partial set per level (multi-level launches)
+  W += (size_t)blockIdx.z * ncell * S.nrows * 2;
+  part += (size_t)blockIdx.z * CSEG * S.nrows * S.nmax;
   const int per = (ncell + CSEG - 1) / CSEG;
   const int i0 = seg * per, i1 = min(ncell, i0 + per);
   const int stride = (S.lmax + 1) * S.nmax;
@@ -47,6 +50,8 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
 {
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
+  part += (size_t)blockIdx.y * CSEG * ncoef;      // blockIdx.y: level (multi-level launches)
+  coef += (size_t)blockIdx.y * ncoef;
   double s = 0.0;
   for (int seg = 0; seg < CSEG; seg++) s += part[(size_t)seg * ncoef + k];
   coef[k] = s;
@@ -196,8 +201,9 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_tscale.alloc(tscale.size()));
   A(f->d_wscale.alloc(wscale.size()));
-  A(f->d_W.alloc((size_t)(numr - 1) * nrows * 2));
-  A(f->d_part.alloc((size_t)CSEG * ncoef));
+  // one moment buffer and one set of contraction partials per level (substep_expansion)
+  A(f->d_W.alloc((size_t)(cfg->multistep + 1) * (numr - 1) * nrows * 2));
+  A(f->d_part.alloc((size_t)(cfg->multistep + 1) * CSEG * ncoef));
   A(f->d_G.alloc((size_t)numr * nrows));
   A(f->d_T4.alloc((size_t)(numr - 1) * t4_rows(L) * 4));
   if (e == hipSuccess && f->alloc_common(ncoef, cfg->multistep) != EXP_AMD_OK) e = hipErrorOutOfMemory;
@@ -258,9 +264,8 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 
 // (level, radial cell) order for this force's tables; with `advance` the kick dt_kick and drift
 // dt_drift of the leapfrog are applied on the way (src/step.cc:279-288)
-static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = false,
-                    double dt_kick = 0.0, double dt_drift = 0.0, int level = -1,
-                    bool have_keys = false, int level_hi = -1)
+static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &adv = AdvSpec(),
+                    int level = -1, bool have_keys = false, int level_hi = -1)
 {
   exp_amd_ctx *ctx = f->ctx;
   if (c->n == 0) return EXP_AMD_OK;
@@ -280,11 +285,11 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, bool advance = 
     if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center)};
-    AdvanceArgs A = expamd_advance_args(c, advance, dt_kick, dt_drift);
+    AdvanceArgs A = expamd_advance_args(c, adv);
     k_key_hist<SphKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }
-  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, advance, dt_kick, dt_drift, level, level_hi);
+  rc = expamd_comp_finish_sort(c, nkeys, ncell, move_acc, adv, level, level_hi);
   if (rc) return rc;
   c->sorted_for = f;
   return EXP_AMD_OK;
@@ -317,7 +322,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   const int lo = f->multistep ? f->mlevel : 0;
   const int hi = f->multistep ? f->mlevel : 0;
   SphDev S = dev_for(f, c->center);
-  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), ctx->stream));
   // used: multistep = 0 counts the last accumulation; a multistep force adds up the levels of the
   // first sub-step (see SphForce::used_open)
   unsigned long long *used_p = f->d_used.p + ((f->multistep && !f->used_open) ? 1 : 0);
@@ -355,7 +360,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   // so only its slot range is re-sorted
   const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                         ? f->mlevel : -1;
-  int rc = sph_sort(f, c, c->acc_live, advance, dt_kick, dt_drift, level, have_keys && level < 0);
+  int rc = sph_sort(f, c, c->acc_live, AdvSpec::step(advance, dt_kick, dt_drift), level, have_keys && level < 0);
   if (rc) return rc;
   double *dst = f->cfg.multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef : f->d_coef.p;
   if (f->cfg.multistep) {
@@ -367,6 +372,62 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   if (rc) return rc;
   rc = expamd_allreduce(ctx, dst, f->ncoef);
   if (rc) return rc;
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
+{
+  SphForce *f = this;
+  const int ms = f->multistep;
+  if (lo < 0 || lo > ms) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "substep_expansion: level out of range");
+  f->home = c;
+  f->home_gone = false;
+  const int nact = ms - lo + 1;
+  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
+  int rc;
+  if (c->n) {
+    // one sort of the active slot range with the per-level kick + drift applied on the way; the whole
+    // store when the level partition is not this basis' yet.  acc / pot of the active levels are
+    // rewritten by the force evaluation that follows (compute_potential(mfirst[mstep])), so they are
+    // not carried through the reorder -- unless a full re-partition also moves inactive levels.
+    const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
+    const bool full = lo == 0 || !ordered;
+    uint32_t keep[66];
+    const bool had = c->lev_host_valid && ordered;
+    if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
+    rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, ms);
+    if (rc) return rc;
+    if (had) {     // an advance changes no level population: the host mirror stays what it was
+      for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
+      c->lev_host_valid = true;
+    }
+  }
+  // N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)lo * f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef,
+                              (size_t)nact * f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  const SphDev S = dev_for(f, c->center);
+  const size_t wl = (size_t)(cfg.numr - 1) * S.nrows * 2;
+  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
+  unsigned long long *used_p = f->d_used.p + (f->used_open ? 0 : 1);
+  if (!f->used_open) HIP_TRY(ctx, hipMemsetAsync(used_p, 0, sizeof(unsigned long long), ctx->stream));
+  size_t nrange = 0;
+  if (c->n && (rc = expamd_comp_level_count(c, lo, ms, &nrange))) return rc;
+  if (nrange) {
+    ProfScope ps(ctx, "k_sph_accumulate");
+    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms,
+                 f->d_W.p, used_p, nrange, ctx->stream, 1, c->level[c->cur].p};
+    k_acc_launch[cfg.lmax](a);
+  }
+  {
+    ProfScope ps(ctx, "k_sph_contract");
+    k_sph_contract<<<dim3(S.nrows, CSEG, nact), 64, 0, ctx->stream>>>(
+        S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p);
+    k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nact), 256, 0, ctx->stream>>>(
+        f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = expamd_allreduce(ctx, f->d_coefN.p + (size_t)lo * f->ncoef, (size_t)nact * f->ncoef))) return rc;
   f->proj_dirty = true;
   return EXP_AMD_OK;
 }
@@ -403,8 +464,11 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   S.ps = t->pseudo;                    // Component::AddAcc of the TARGET (src/Component.H:914-921)
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
+  size_t nr = t->n;                    // population of the level range: sizes the launch
+  if (t->nlevels > 1 && (rc = expamd_comp_level_count(t, lo, hi, &nr))) return rc;
+  if (nr == 0) { t->acc_live = true; return EXP_AMD_OK; }
   {
-    unsigned grid = cdiv(t->n, 256);   // one 64-particle chunk per wave, no loop
+    unsigned grid = cdiv(nr, 256);     // one 64-particle chunk per wave, no loop
     const size_t need = t->n / 64 + 8;
     if (f->work_cap < need) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -413,7 +477,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     }
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
-                   t->a(A_VZ), dt_kick, assign ? 1 : 0, t->n, grid, ctx->stream,
+                   t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
                    f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0, ctx,
                    prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1};
     k_force_launch[f->cfg.lmax](a);
@@ -474,7 +538,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   const size_t beg[2] = {0, c->half}, len[2] = {c->half, c->n - c->half};
 
   // ---- aux stream: the two sort chains (reading the live set, writing the other one)
-  const AdvanceArgs A = expamd_advance_args(c, true, dt_kick, dt);
+  const AdvanceArgs A = expamd_advance_args(c, AdvSpec::step(true, dt_kick, dt));
   const ScatterSrc Ssrc{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
   const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
                         c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
@@ -511,7 +575,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
 
   // ---- main stream: accumulate the halves as they arrive, reduce, project, force
   SphDev S = dev_for(f, c->center);
-  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), V));
+  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), V));
   HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), V));
   for (int h = 0; h < 2; h++) {
     HIP_TRY(ctx, hipStreamWaitEvent(V, ctx->ev_sorted[h], 0));
@@ -578,7 +642,7 @@ int SphForce::resort(exp_amd_comp *c, int first)
 {
   // levels below `first` were not examined (src/multistep.cc:451-453): their slots stay as they are
   if (first > 0 && c->nlevels == multistep + 1)      // (the caller vouches for the order below `first`)
-    return sph_sort(this, c, true, false, 0.0, 0.0, first, false, multistep);
+    return sph_sort(this, c, true, AdvSpec(), first, false, multistep);
   return sph_sort(this, c, true);
 }
 
@@ -586,31 +650,34 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 {
   SphForce *f = this;
   const int ms = f->multistep;
-  if (ms == 0 || c->n == 0) return EXP_AMD_OK;
+  if (ms == 0) return EXP_AMD_OK;
   const size_t wl = (size_t)(cfg.numr - 1) * dev.nrows * 2;
   if (f->d_Wd.n == 0) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, f->d_Wd.alloc(wl * (ms + 1)));
     HIP_TRY(ctx, f->d_differ.alloc(f->ncoef * (ms + 1)));
   }
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p, 0, f->d_Wd.bytes(), ctx->stream));
+  // the difference matrices of the levels that _begin clears and _finish adds (M >= mfirst[mdrft],
+  // src/SphericalBasis.cc:1013-1079); a rank without particles still takes part in the reduction
+  const int nl = ms - mfirst_mdrft + 1;
+  HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p + (size_t)mfirst_mdrft * wl, 0, (size_t)nl * wl * sizeof(double), ctx->stream));
   const SphDev S = dev_for(f, c->center);
-  {
+  size_t nr = 0;
+  if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
+  if (nr) {
     ProfScope ps(ctx, "k_sph_mstep_update");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
-                 c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p, c->n, ctx->stream};
+                 c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p, nr, ctx->stream};
     k_upd_launch[cfg.lmax](a);
   }
-  // moments -> coefficient differences for the levels that _finish touches (M >= mfirst[mdrft])
-  for (int M = mfirst_mdrft; M <= ms; M++) {
-    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)M * wl,
-                                                                f->d_wscale.p, f->d_part.p);
-    k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
-        f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)M * f->ncoef);
-  }
+  // moments -> coefficient differences, all levels in one launch
+  k_sph_contract<<<dim3(S.nrows, CSEG, nl), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
+                                                                  f->d_wscale.p, f->d_part.p);
+  k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nl), 256, 0, ctx->stream>>>(
+      f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef);
   HIP_TRY(ctx, hipGetLastError());
   // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M]
-  const size_t cnt = (size_t)(ms - mfirst_mdrft + 1) * f->ncoef;
+  const size_t cnt = (size_t)nl * f->ncoef;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef, cnt);
   if (rc) return rc;
   k_add_inplace<<<cdiv(cnt, 256), 256, 0, ctx->stream>>>(

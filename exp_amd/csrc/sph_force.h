@@ -31,6 +31,7 @@ struct SphForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
   int resort(exp_amd_comp *c, int first = 0) override;
   int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;

@@ -23,7 +23,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   const unsigned nchunk = cdiv(a.n, chunk);
   dim3 grid(cdiv(nchunk, CPB), (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
   k_sph_accumulate<LMAX><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
-                                                                a.lo, a.hi, a.W, a.used, (int)chunk);
+                                                                a.lo, a.hi, a.W, a.used, (int)chunk, a.lev);
 }
 
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)

@@ -308,8 +308,11 @@ struct AccIn {
 // p0l: the block's LDS copy of the background-potential table, or null (then S.p0 is gathered
 // from global memory).  The pointer keeps its address space so that the reads are ds_read.
 typedef const __attribute__((address_space(3))) double *ldp;
+// cell_add: level * (numr-1) when several levels are accumulated in one launch (the moment buffer is
+// then W[level][cell][row][2] and the wave's "current cell" the combined index), else 0.
 __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double px,
-                                               double py, double pz, double mass, bool valid)
+                                               double py, double pz, double mass, bool valid,
+                                               int cell_add = 0)
 {
   AccIn in;
   double xx = 1, yy = 0, zz = 0;
@@ -346,7 +349,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   const double t0 = inwin ? mass * (-4.0 * M_PI) * P0 : 0.0;
   in.a1 = t0 * x1;
   in.a2 = t0 * x2;
-  in.idx = inwin ? idx : -1;
+  in.idx = inwin ? idx + cell_add : -1;
   return in;
 }
 
@@ -433,10 +436,12 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
 template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
-                    const double *__restrict__ Z, const double *__restrict__ M, size_t cbeg,
+                    const double *__restrict__ Z, const double *__restrict__ M,
+                    const uint8_t *__restrict__ LEV, size_t cbeg,
                     size_t cend, double *scratch, double *__restrict__ W,
                     unsigned long long *__restrict__ used_out)
 {
+  const int ncl = S.numr - 1;
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
   const int lane = threadIdx.x & 63;
@@ -449,14 +454,17 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 
   // software prefetch: the loads of group k+1 are in flight while group k is reduced
   double nx = 0, ny = 0, nz = 0, nm = 0;
+  int nl = 0;
   if (cbeg + lane < cend) {
     nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane];
+    if (LEV) nl = LEV[cbeg + lane];
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend);
+    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend, nl * ncl);
     if (i + 64 < cend) {
       nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
+      if (LEV) nl = LEV[i + 64];
     }
     if (MLO == 0 && in.idx >= 0) used++;
     sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
@@ -482,9 +490,11 @@ template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
 sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
                       const double *__restrict__ Y, const double *__restrict__ Z,
-                      const double *__restrict__ M, size_t cbeg, size_t cend, double *scratch,
+                      const double *__restrict__ M, const uint8_t *__restrict__ LEV, size_t cbeg,
+                      size_t cend, double *scratch,
                       AccShared &sh, double *__restrict__ W, unsigned long long *__restrict__ used_out)
 {
+  const int ncl = S.numr - 1;
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
   constexpr int TILE = ACC_WAVES * 64;
@@ -498,11 +508,12 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 
   size_t ip = cbeg + (size_t)wave * 64 + lane;
   double nx = 0, ny = 0, nz = 0, nm = 0;
-  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+  int nl = 0;
+  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; if (LEV) nl = LEV[ip]; }
   int par = 0;
   for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
     {
-      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend);
+      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend, nl * ncl);
       if (in.idx >= 0) used++;
       const int q = wave * 64 + lane;
       sh.v[par][0][q] = in.costh; sh.v[par][1][q] = in.cphi; sh.v[par][2][q] = in.sphi;
@@ -513,7 +524,7 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced
     ip += TILE;
-    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; if (LEV) nl = LEV[ip]; }
 #pragma unroll 1
     for (int sub = 0; sub < ACC_WAVES; sub++) {
       if (tbase + (size_t)sub * 64 >= cend) break;
@@ -555,7 +566,8 @@ __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ W, unsigned long long *__restrict__ used_out, int ACC_CHUNK)
+                 double *__restrict__ W, unsigned long long *__restrict__ used_out, int ACC_CHUNK,
+                 const uint8_t *__restrict__ LEV /* non-null: W[level][cell][row][2], several levels */)
 {
   constexpr int NS = acc_nsplit<LMAX>();
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;      // chunks per block
@@ -579,7 +591,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
       __syncthreads();
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, cbeg, cend, scratch, sh, W, used_out)
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, LEV, cbeg, cend, scratch, sh, W, used_out)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
     if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
     else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
@@ -592,7 +604,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const size_t cbeg = beg + chunk * ACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, cbeg, cend, scratch, W, used_out)
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, LEV, cbeg, cend, scratch, W, used_out)
   if constexpr (LMAX <= 4) {
     RUN(0, LMAX);
   } else if constexpr (LMAX <= 7) {
@@ -1121,6 +1133,7 @@ struct SphAccArgs {
   size_t n;
   hipStream_t stream;
   int multilevel;           // the range [lo, hi] is one level of many: its size is unknown on the host
+  const uint8_t *lev = nullptr;   // non-null: several levels in one launch, W[level][cell][row][2]
 };
 
 struct SphForceArgs {
