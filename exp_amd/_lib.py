@@ -72,6 +72,7 @@ SIGNATURES = {
     "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
                                       POINTER(c_void_p)]),
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
+    "exp_amd_ctx_set_dense_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_comp_set_orientation": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_flags": (c_uint, [c_void_p]),
     "exp_amd_orient_set_naccel": (c_int, [c_void_p, c_int]),

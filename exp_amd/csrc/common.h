@@ -47,6 +47,8 @@ struct exp_amd_ctx {
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
+  long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
+                                     // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;
   hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_forced[2] = {nullptr, nullptr};
 };

@@ -42,6 +42,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   exp_amd_ctx *ctx = new exp_amd_ctx;
   ctx->device = device;
   if (const char *e = getenv("EXP_AMD_SPLIT_MIN")) ctx->split_min = atoll(e);
+  if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
   HIP_TRY(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -81,6 +82,13 @@ extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C" int exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->dense_min = nmin;
+  return EXP_AMD_OK;
 }
 
 extern "C" int exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin)

@@ -95,8 +95,10 @@ __device__ __forceinline__ void cyl_weights(const CylDev &C, double r, double z,
 // sort key: level * (ncell+1) + cell, cell = ix*numy + iy; off-grid particles share bin ncell
 struct CylKeyFn {
   CylDev C;
+  uint32_t sparse_mask;      // levels that are not cell-sorted: all their particles share bin 0
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
   {
+    if ((sparse_mask >> lev) & 1u) return (uint32_t)lev * ((uint32_t)(C.numx * C.numy) + 1u);
     double xx, yy, zz;
     cyl_local(C, x, y, z, xx, yy, zz);
     const double r2 = xx * xx + yy * yy;
@@ -114,6 +116,16 @@ struct CylKeyFn {
 };
 
 // ---- accumulation ----------------------------------------------------------------------------------
+
+// Work split of an accumulation launch over several time-step levels: the blocks [bstart[j],
+// bstart[j+1]) take level lo + j in chunks of chunk[j] particles per wave (no chunk crosses a level,
+// every level gets a chunk size that suits its own population).  nlev = 1: the classic launch.
+#define LEVCHUNK_MAX 17
+struct LevChunks {
+  int lo, nlev;
+  unsigned bstart[LEVCHUNK_MAX + 1];
+  int chunk[LEVCHUNK_MAX];
+};
 
 #define CFLUSH_STRIDE 68
 #define CACC_WAVES 4
@@ -154,17 +166,24 @@ template <int MMAX>
 __global__ void __launch_bounds__(CACC_WAVES * 64)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
-                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ Wn, double *__restrict__ tail, int CACC_CHUNK,
-                 const uint8_t *__restrict__ LEV /* non-null: Wn[level][node][ntrig], several levels */)
+                 const uint32_t *__restrict__ lev_off, LevChunks LC,
+                 double *__restrict__ Wn, double *__restrict__ tail,
+                 int multilevel /* Wn[level][node][ntrig] */)
 {
+  // which level this block works on, and with which chunk size (block-uniform: scalar loop)
+  int lj = 0;
+  while (lj + 1 < LC.nlev && blockIdx.x >= LC.bstart[lj + 1]) lj++;
+  const int lev_lo = LC.lo + lj, lev_hi = lev_lo;
+  const int CACC_CHUNK = LC.chunk[lj];
+  const unsigned bx = blockIdx.x - LC.bstart[lj];
+  const int lvl = multilevel ? lev_lo : 0;
   constexpr int NT = 2 * MMAX + 1;
   constexpr int NV = 4 * NT;
   __shared__ double scratch_all[CACC_WAVES][16 * CFLUSH_STRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *scratch = scratch_all[wave];
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  const size_t cbeg = beg + ((size_t)blockIdx.x * CACC_WAVES + wave) * CACC_CHUNK;
+  const size_t cbeg = beg + ((size_t)bx * CACC_WAVES + wave) * CACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + CACC_CHUNK < end) ? cbeg + CACC_CHUNK : end;
   const double norm = -4.0 * M_PI;
@@ -192,11 +211,9 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     const size_t i = base + lane;
     const bool valid = i < cend;
     double xx = 1, yy = 0, zz = 0, mass = 0;
-    int lvl = 0;
     if (valid) {
       cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
       mass = M[i];
-      if (LEV) lvl = LEV[i];
     }
     // src/Cylinder.cc:853-866
     const double r2 = xx * xx + yy * yy;
@@ -273,8 +290,11 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
                    const double *__restrict__ Z, const double *__restrict__ M,
                    const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
                    const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
-                   double *__restrict__ Wnd)
+                   double *__restrict__ Wnd, int plain, double *__restrict__ tail)
 {
+  // plain != 0: every particle of the range adds its contribution to Wnd[its level] -- the accumulation
+  // of SPARSE multistep levels, which are not cell-sorted (Cylinder's rcylmax cut, the in-cut mass /
+  // count and EmpCylSL::accumulate's grid window, src/Cylinder.cc:853-866, exputil/EmpCylSL.cc:4062)
   constexpr int NT = 2 * MMAX + 1;
   const size_t beg = lev_off[first], end = lev_off[last + 1];
   const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -282,8 +302,8 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   int from = 0, to = 0;
   if (i < end) {
     from = lev[i];
-    to = newlev[i];
-    mover = from != to;
+    to = plain ? from : newlev[i];
+    mover = plain || from != to;
   }
   if (!__any(mover)) return;
   double xx = 1, yy = 0, zz = 0, mass = 0;
@@ -293,6 +313,13 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   }
   const double r2 = xx * xx + yy * yy;
   const double r = sqrt(r2);
+  if (plain) {
+    const bool incut = mover && (r2 + zz * zz) < C.rmax2;
+    double mu = incut ? mass : 0.0, nu = incut ? 1.0 : 0.0;
+    for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
+    if ((threadIdx.x & 63) == 0 && nu > 0.0) { unsafeAtomicAdd(tail + 0, mu); unsafeAtomicAdd(tail + 1, nu); }
+    mover = incut;
+  }
   if (sqrt(r * r + zz * zz) / C.ascale > C.rtable) mover = false;
   if (!__any(mover)) return;
   double zc = zz;
@@ -330,7 +357,7 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
     const bool many = __popcll(mm) > 1;
     const int gto = (int)(kk & 31u), gfrom = (int)((kk >> 5) & 31u);
     const size_t gnode = (size_t)(kk >> 10);
-    const bool sub = gfrom >= mfirst;
+    const bool sub = !plain && gfrom >= mfirst;
     double *wto = Wnd + ((size_t)gto * nnode + gnode) * NT;
     double *wfr = Wnd + ((size_t)gfrom * nnode + gnode) * NT;
     cstatic_for<0, MMAX + 1>([&](auto mc) {
@@ -565,7 +592,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
       const double wx = mul_then_add(vx, fx, nk_dtk);
       const double wy = mul_then_add(vy, fy, nk_dtk);
       const double wz = mul_then_add(vz, fz, nk_dtk);
-      CylKeyFn kf{C};
+      CylKeyFn kf{C, 0u};
       key_out[i] = kf(mul_then_add(X[i], wx, nk_dtd), mul_then_add(Y[i], wy, nk_dtd),
                       mul_then_add(Z[i], wz, nk_dtd), 0);
     }
@@ -597,6 +624,7 @@ struct CylForce : exp_amd_force {
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
+  long long sparse_threshold() const override { return 3000000LL / (4 * dev.ntrig); }
   int resort(exp_amd_comp *c, int first = 0) override;
   int multistep_reset() override
   {
@@ -715,7 +743,7 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
     if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
-    CylKeyFn kf{C};
+    CylKeyFn kf{C, c->sparse_mask};
     AdvanceArgs A = expamd_advance_args(c, adv);
     k_key_hist<CylKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
@@ -766,7 +794,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
-      c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wnd.p)
+      c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wnd.p, 0, nullptr)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
@@ -794,6 +822,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                           ? f->mlevel : -1;
+    if (level >= 0) c->sparse_mask &= ~(1u << level); else c->sparse_mask = 0;   // this call cell-sorts what it touches
     int rc = sort(c, c->acc_live, AdvSpec::step(advance, dt_kick, dt_drift), level, have_keys);
     if (rc) return rc;
   }
@@ -818,9 +847,11 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
     if (!f->multistep) chunk = CACC_CHUNK_MAX;
     const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
+    LevChunks LC;
+    LC.lo = lo; LC.nlev = 1; LC.bstart[0] = 0; LC.bstart[1] = grid; LC.chunk[0] = (int)chunk;
 #define CALL(MM)                                                                                 \
   k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi, f->d_Wn.p, dst + f->ncoef, (int)chunk, nullptr)
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
@@ -854,18 +885,25 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   const int nact = ms - lo + 1;
   const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
   int rc;
+  // dense levels (cell-sorted) of the active suffix end at dmax; the levels above it are sparse
+  int dmax = lo - 1;
+  for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dmax = L;
+  const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
+  const bool full = lo == 0 || !ordered;
+  if (full) dmax = ms;
   if (c->n) {
-    const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
-    const bool full = lo == 0 || !ordered;
     uint32_t keep[66];
     const bool had = c->lev_host_valid && ordered;
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
-    rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, ms);
-    if (rc) return rc;
+    if (dmax >= lo) {
+      rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
+      if (rc) return rc;
+    }
     if (had) {
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
     }
+    if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
   const CylDev C = cdev_for(f, c);
   // setup_accumulation(M) of every active level: L <- N, N <- 0 (exputil/EmpCylSL.cc:2010-2030)
@@ -877,17 +915,41 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   // {in-cut mass, count} of the whole launch ride in the tail of the FIRST active level's set (the
   // other tails are zero): one number per sub-step is all Cylinder keeps (src/Cylinder.cc:1081-1099)
   HIP_TRY(ctx, hipMemsetAsync(dst, 0, (size_t)nact * f->ncoef_dev * sizeof(double), ctx->stream));
+  int dacc = lo - 1;                    // last level the cell-ordered kernel takes
+  for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
   size_t nrange = 0;
-  if (c->n && (rc = expamd_comp_level_count(c, lo, ms, &nrange))) return rc;
+  if (c->n && dacc >= lo && (rc = expamd_comp_level_count(c, lo, dacc, &nrange))) return rc;
   if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate");
-    size_t chunk = (nrange / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
-    chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
-    const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
+    // per level: >= ~6 rounds of blocks; sparse levels pay one flush per cell change, serial within
+    // a wave, so they get short chunks and many waves
+    LevChunks LC;
+    LC.lo = lo; LC.nlev = dacc - lo + 1;
+    unsigned grid = 0;
+    for (int L = lo; L <= dacc; L++) {
+      const size_t nl = (size_t)c->lev_host[L + 1] - c->lev_host[L];
+      size_t chunk = (nl / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
+      chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
+      LC.bstart[L - lo] = grid;
+      LC.chunk[L - lo] = (int)chunk;
+      grid += cdiv(nl, (size_t)CACC_WAVES * chunk);
+    }
+    LC.bstart[LC.nlev] = grid;
 #define CALL(MM)                                                                                 \
   k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, f->d_Wn.p, dst + f->ncoef, \
-      (int)chunk, c->level[c->cur].p)
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  }
+  nrange = 0;
+  if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
+  if (nrange) {
+    ProfScope ps(ctx, "k_cyl_accumulate_sparse");
+    const unsigned grid = cdiv(nrange, 256);
+#define CALL(MM)                                                                              \
+  k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
+      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,              \
+      c->lev_off.p, dacc + 1, ms, 0, f->d_Wn.p, 1, dst + f->ncoef)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }

@@ -65,6 +65,12 @@ struct exp_amd_force {
   // (begin_run's expansion of every level).
   virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min) = 0;
 
+  // Level population below which a multistep level is left un-cell-sorted (see exp_amd_comp::
+  // sparse_mask).  Sorting a level costs ~100 us of small launches per sub-step; accumulating one
+  // particle by atomics costs `values per particle` fp64 atomics at ~3e10/s on MI355X, so the two meet
+  // near 3e6 / values particles.  ctx->dense_min >= 0 overrides.
+  virtual long long sparse_threshold() const { return 0; }
+
   virtual int get_used(long long *used);
   // PotAccel::multistep_reset (src/PotAccel.H:288): start of a master step
   virtual int multistep_reset() { return EXP_AMD_OK; }

@@ -261,6 +261,11 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
         for (int L = first; L <= ms; L++) off[L + 1] = off[L] + (uint32_t)res[1 + L];
       }
       if ((rc = expamd_comp_commit_levels(c, mirror ? (size_t)c->lev_host[first] : 0))) return rc;
+      if (mirror) {
+        // the populations the re-ordering is about to establish decide which levels stay cell-sorted
+        for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];
+        expamd_comp_update_sparse(c, first, ctx->dense_min >= 0 ? ctx->dense_min : f->sparse_threshold());
+      } else c->sparse_mask = 0;
       if ((rc = f->resort(c, ordered ? first : 0))) return rc;
       if (mirror) {
         for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];

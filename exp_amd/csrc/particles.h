@@ -43,6 +43,12 @@ struct exp_amd_comp {
   DevBuf<double> com_lev, com_red;   // per-level sums of m, m x, m v, m a (fix_positions) / all-reduce scratch
   uint32_t lev_host[66] = {0};
   bool lev_host_valid = false;
+  // Block multistep: levels with fewer particles than the force method's sparse_threshold() are kept level-contiguous but
+  // NOT cell-sorted (bit L set).  A sparse level has about one particle per basis cell, so the cell
+  // order buys nothing there: it is advanced in place, accumulated with per-particle atomics and its
+  // forces take the gather path.  Set by the step driver from the level populations; any per-level
+  // call of the plain API clears the bit of the level it sorts.
+  uint32_t sparse_mask = 0;
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
   // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
   bool prekey_valid = false;
@@ -77,6 +83,11 @@ void expamd_launch_scan_full(hipStream_t st, uint32_t *hist, uint32_t nkeys, uin
 
 // a component is about to be destroyed: forces that use it as their expansion frame keep a copy
 void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);
+
+// recompute sparse_mask for the levels >= first from the (valid) host mirror of the level offsets
+void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh);
+// kick DT(M)/2 + drift DT(M) in place for the levels [lo, hi] (no reorder): sparse levels
+int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep);
 
 // number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
 int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);

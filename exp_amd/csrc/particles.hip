@@ -43,6 +43,29 @@ k_kick(double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz
   }
 }
 
+// first half of a block-multistep sub-step, in place: incr_velocity(DT(M)/2, M); incr_position(DT(M), M)
+// for the slots of levels [lo, hi] (src/step.cc:126-148), DT(M) = dt_min 2^(multistep - M)
+__global__ void __launch_bounds__(TPB)
+k_advance_levels(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                 double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                 const double *__restrict__ ax, const double *__restrict__ ay,
+                 const double *__restrict__ az, const uint8_t *__restrict__ lev,
+                 const uint32_t *__restrict__ lev_off, int lo, int hi, double dt_min, int multistep)
+{
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
+       i += (size_t)gridDim.x * TPB) {
+    const double dtd = level_dt(dt_min, multistep, lev[i]), dtk = 0.5 * dtd;
+    const double u = mul_then_add(vx[i], ax[i], dtk);
+    const double v = mul_then_add(vy[i], ay[i], dtk);
+    const double w = mul_then_add(vz[i], az[i], dtk);
+    vx[i] = u; vy[i] = v; vz[i] = w;
+    x[i] = mul_then_add(x[i], u, dtd);
+    y[i] = mul_then_add(y[i], v, dtd);
+    z[i] = mul_then_add(z[i], w, dtd);
+  }
+}
+
 // src/ComponentContainer.cc:641-665
 __global__ void __launch_bounds__(TPB)
 k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
@@ -208,6 +231,30 @@ int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count)
     c->lev_host_valid = true;
   }
   *count = (size_t)c->lev_host[hi + 1] - (size_t)c->lev_host[lo];
+  return EXP_AMD_OK;
+}
+
+void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh)
+{
+  if (!c->lev_host_valid || c->nlevels <= 1) { c->sparse_mask = 0; return; }
+  for (int L = first; L < c->nlevels; L++) {
+    const uint32_t cnt = c->lev_host[L + 1] - c->lev_host[L];
+    if ((long long)cnt < thresh) c->sparse_mask |= (1u << L);
+    else c->sparse_mask &= ~(1u << L);
+  }
+}
+
+int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep)
+{
+  size_t nr = 0;
+  int rc = expamd_comp_level_count(c, lo, hi, &nr);
+  if (rc) return rc;
+  if (nr == 0) return EXP_AMD_OK;
+  ProfScope ps(c->ctx, "k_advance_levels");
+  k_advance_levels<<<stream_grid(c->ctx, nr), TPB, 0, c->ctx->stream>>>(
+      c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
+      c->a(A_AZ), c->level[c->cur].p, c->lev_off.p, lo, hi, dt_min, multistep);
+  HIP_TRY(c->ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
 

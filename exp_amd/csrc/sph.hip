@@ -10,9 +10,11 @@
 // key = level * (numr-1) + radial cell of get_pot/get_force (r clamped to rmax like the force path)
 struct SphKeyFn {
   SphDev S;
+  uint32_t sparse_mask;      // levels that are not cell-sorted: all their particles share bin 0
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
   {
-    return (uint32_t)lev * (uint32_t)(S.numr - 1) + sph_key_cell(S, x, y, z) + S.key_add;
+    const uint32_t cell = ((sparse_mask >> lev) & 1u) ? 0u : sph_key_cell(S, x, y, z);
+    return (uint32_t)lev * (uint32_t)(S.numr - 1) + cell + S.key_add;
   }
 };
 
@@ -284,7 +286,7 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
     if (nr == 0) return EXP_AMD_OK;
     ProfScope ps(ctx, "k_key_hist");
-    SphKeyFn kf{dev_for(f, c->center)};
+    SphKeyFn kf{dev_for(f, c->center), c->sparse_mask};
     AdvanceArgs A = expamd_advance_args(c, adv);
     k_key_hist<SphKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
@@ -360,6 +362,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   // so only its slot range is re-sorted
   const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                         ? f->mlevel : -1;
+  if (level >= 0) c->sparse_mask &= ~(1u << level); else c->sparse_mask = 0;   // this call cell-sorts what it touches
   int rc = sph_sort(f, c, c->acc_live, AdvSpec::step(advance, dt_kick, dt_drift), level, have_keys && level < 0);
   if (rc) return rc;
   double *dst = f->cfg.multistep ? f->d_coefN.p + (size_t)f->mlevel * f->ncoef : f->d_coef.p;
@@ -386,22 +389,31 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   const int nact = ms - lo + 1;
   const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
   int rc;
+  // dense levels (cell-sorted) of the active suffix end at dmax; the levels above it are sparse
+  int dmax = lo - 1;
+  for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dmax = L;
+  const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
+  const bool full = lo == 0 || !ordered;
+  if (full) dmax = ms;                  // a full re-partition passes over everything anyway
   if (c->n) {
-    // one sort of the active slot range with the per-level kick + drift applied on the way; the whole
-    // store when the level partition is not this basis' yet.  acc / pot of the active levels are
-    // rewritten by the force evaluation that follows (compute_potential(mfirst[mstep])), so they are
-    // not carried through the reorder -- unless a full re-partition also moves inactive levels.
-    const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
-    const bool full = lo == 0 || !ordered;
+    // one sort of the dense part of the active slot range with the per-level kick + drift applied on
+    // the way; the whole store when the level partition is not this basis' yet.  acc / pot of the
+    // active levels are rewritten by the force evaluation that follows (compute_potential(mfirst[
+    // mstep])), so they are not carried through the reorder -- unless a full re-partition also moves
+    // inactive levels.
     uint32_t keep[66];
     const bool had = c->lev_host_valid && ordered;
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
-    rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, ms);
-    if (rc) return rc;
+    if (dmax >= lo) {
+      rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
+      if (rc) return rc;
+    }
     if (had) {     // an advance changes no level population: the host mirror stays what it was
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
     }
+    // sparse levels above: advanced in place
+    if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
   // N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
   HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)lo * f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef,
@@ -411,13 +423,26 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
   unsigned long long *used_p = f->d_used.p + (f->used_open ? 0 : 1);
   if (!f->used_open) HIP_TRY(ctx, hipMemsetAsync(used_p, 0, sizeof(unsigned long long), ctx->stream));
+  // the sparse levels inside a full re-partition are level-contiguous but unordered as well
+  int dacc = lo - 1;                    // last level the cell-ordered kernel takes
+  for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
   size_t nrange = 0;
-  if (c->n && (rc = expamd_comp_level_count(c, lo, ms, &nrange))) return rc;
+  if (c->n && dacc >= lo && (rc = expamd_comp_level_count(c, lo, dacc, &nrange))) return rc;
   if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
-    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms,
-                 f->d_W.p, used_p, nrange, ctx->stream, 1, c->level[c->cur].p};
+    uint32_t counts[LEVCHUNK_MAX];
+    for (int L = lo; L <= dacc; L++) counts[L - lo] = c->lev_host[L + 1] - c->lev_host[L];
+    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, dacc,
+                 f->d_W.p, used_p, nrange, ctx->stream, 1, counts, 1};
     k_acc_launch[cfg.lmax](a);
+  }
+  nrange = 0;
+  if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
+  if (nrange) {
+    ProfScope ps(ctx, "k_sph_accumulate_sparse");
+    SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,
+                 c->lev_off.p, dacc + 1, ms, 0, f->d_W.p, nrange, ctx->stream, 1, used_p};
+    k_upd_launch[cfg.lmax](a);
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
@@ -467,6 +492,9 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   size_t nr = t->n;                    // population of the level range: sizes the launch
   if (t->nlevels > 1 && (rc = expamd_comp_level_count(t, lo, hi, &nr))) return rc;
   if (nr == 0) { t->acc_live = true; return EXP_AMD_OK; }
+  // a range of sparse (not cell-sorted) levels only: no wave would pass the fast pass' uniformity test
+  bool all_sparse = t->nlevels > 1 && t->sorted_for == f;
+  for (int L = lo; L <= hi && all_sparse; L++) if (!((t->sparse_mask >> L) & 1u)) all_sparse = false;
   {
     unsigned grid = cdiv(nr, 256);     // one 64-particle chunk per wave, no loop
     const size_t need = t->n / 64 + 8;
@@ -478,7 +506,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
-                   f->d_work.p, f->d_work.p + f->work_cap, t->sorted_for != f ? 1 : 0, ctx,
+                   f->d_work.p, f->d_work.p + f->work_cap, (t->sorted_for != f || all_sparse) ? 1 : 0, ctx,
                    prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1};
     k_force_launch[f->cfg.lmax](a);
   }
@@ -554,7 +582,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
       ProfScope ps(ctx, "k_key_hist", H);
       SphDev S = dev_for(f, c->center);
       S.key_add = (uint32_t)h * ncell;
-      k_key_hist<SphKeyFn><<<cdiv(len[h], HIST_TILE), SORT_TPB, 0, H>>>(SphKeyFn{S}, A, R, c->key.p, c->hist.p);
+      k_key_hist<SphKeyFn><<<cdiv(len[h], HIST_TILE), SORT_TPB, 0, H>>>(SphKeyFn{S, 0u}, A, R, c->key.p, c->hist.p);
     }
     {
       ProfScope ps(ctx, "k_scan", H);

@@ -32,6 +32,7 @@ struct SphForce : exp_amd_force {
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
+  long long sparse_threshold() const override { return 3000000LL / (2 * dev.nrows); }
   int resort(exp_amd_comp *c, int first = 0) override;
   int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;

@@ -15,15 +15,26 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   constexpr int NS = acc_nsplit<LMAX>();
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;
   // chunk: as large as ACC_CHUNK_MAX while >= ~6 rounds of blocks remain (2 blocks x 256 CUs).
-  // a.n is the population of the level range, so a sparse multistep level (a few particles per
-  // cell: one flush per cell change, serial within a wave) gets short chunks and many waves.
-  size_t chunk = (a.n / ((size_t)CPB * 3072)) & ~(size_t)63;
-  const size_t cmin = a.multilevel ? 64 : ACC_CHUNK_MIN;
-  chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
-  const unsigned nchunk = cdiv(a.n, chunk);
-  dim3 grid(cdiv(nchunk, CPB), (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
+  // Per level: a sparse multistep level (a few particles per cell: one flush per cell change,
+  // serial within a wave) gets short chunks and many waves.
+  LevChunks LC;
+  LC.lo = a.lo;
+  LC.nlev = a.hi - a.lo + 1;
+  unsigned nb = 0;
+  for (int j = 0; j < LC.nlev; j++) {
+    const size_t n = a.counts ? a.counts[j] : a.n;
+    size_t chunk = (n / ((size_t)CPB * 3072)) & ~(size_t)63;
+    const size_t cmin = a.multilevel ? 64 : ACC_CHUNK_MIN;
+    chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
+    LC.bstart[j] = nb;
+    LC.chunk[j] = (int)chunk;
+    nb += cdiv(cdiv(n, chunk), CPB);
+  }
+  LC.bstart[LC.nlev] = nb;
+  if (nb == 0) return;
+  dim3 grid(nb, (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
   k_sph_accumulate<LMAX><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
-                                                                a.lo, a.hi, a.W, a.used, (int)chunk, a.lev);
+                                                                LC, a.W, a.used, a.wlevels);
 }
 
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
@@ -53,5 +64,5 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 void CAT(expamd_sph_upd_L, SPH_L)(const SphUpdArgs &a)
 {
   k_sph_mstep_update<SPH_L><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
-      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd);
+      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used);
 }

@@ -286,6 +286,16 @@ __device__ __forceinline__ int acc_to_wrow(int j)
   return row_of(l, m, cs) * 2 + s;
 }
 
+// Work split of an accumulation launch over several time-step levels: the blocks [bstart[j],
+// bstart[j+1]) take level lo + j in chunks of chunk[j] particles (no chunk crosses a level, and
+// every level gets a chunk size that suits its own population).  nlev = 1: the classic launch.
+#define LEVCHUNK_MAX 17
+struct LevChunks {
+  int lo, nlev;
+  unsigned bstart[LEVCHUNK_MAX + 1];
+  int chunk[LEVCHUNK_MAX];
+};
+
 #define ACC_WAVES 4
 // Particles per block/wave chunk (contiguous, so one or two cells per wave).  Every chunk ends with
 // a flush (LDS transposes + ~60 fp64 atomics per wave) and every block pays its launch: at 1024
@@ -437,11 +447,10 @@ template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                     const double *__restrict__ Z, const double *__restrict__ M,
-                    const uint8_t *__restrict__ LEV, size_t cbeg,
+                    int cell_add, size_t cbeg,
                     size_t cend, double *scratch, double *__restrict__ W,
                     unsigned long long *__restrict__ used_out)
 {
-  const int ncl = S.numr - 1;
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
   const int lane = threadIdx.x & 63;
@@ -454,17 +463,14 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 
   // software prefetch: the loads of group k+1 are in flight while group k is reduced
   double nx = 0, ny = 0, nz = 0, nm = 0;
-  int nl = 0;
   if (cbeg + lane < cend) {
     nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane];
-    if (LEV) nl = LEV[cbeg + lane];
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend, nl * ncl);
+    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend, cell_add);
     if (i + 64 < cend) {
       nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
-      if (LEV) nl = LEV[i + 64];
     }
     if (MLO == 0 && in.idx >= 0) used++;
     sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
@@ -490,11 +496,10 @@ template <int LMAX, int MLO, int MHI>
 __device__ __forceinline__ void
 sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
                       const double *__restrict__ Y, const double *__restrict__ Z,
-                      const double *__restrict__ M, const uint8_t *__restrict__ LEV, size_t cbeg,
+                      const double *__restrict__ M, int cell_add, size_t cbeg,
                       size_t cend, double *scratch,
                       AccShared &sh, double *__restrict__ W, unsigned long long *__restrict__ used_out)
 {
-  const int ncl = S.numr - 1;
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
   constexpr int TILE = ACC_WAVES * 64;
@@ -508,12 +513,11 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 
   size_t ip = cbeg + (size_t)wave * 64 + lane;
   double nx = 0, ny = 0, nz = 0, nm = 0;
-  int nl = 0;
-  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; if (LEV) nl = LEV[ip]; }
+  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
   int par = 0;
   for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
     {
-      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend, nl * ncl);
+      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend, cell_add);
       if (in.idx >= 0) used++;
       const int q = wave * 64 + lane;
       sh.v[par][0][q] = in.costh; sh.v[par][1][q] = in.cphi; sh.v[par][2][q] = in.sphi;
@@ -524,7 +528,7 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced
     ip += TILE;
-    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; if (LEV) nl = LEV[ip]; }
+    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
 #pragma unroll 1
     for (int sub = 0; sub < ACC_WAVES; sub++) {
       if (tbase + (size_t)sub * 64 >= cend) break;
@@ -565,11 +569,18 @@ template <int LMAX>
 __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
-                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
-                 double *__restrict__ W, unsigned long long *__restrict__ used_out, int ACC_CHUNK,
-                 const uint8_t *__restrict__ LEV /* non-null: W[level][cell][row][2], several levels */)
+                 const uint32_t *__restrict__ lev_off, LevChunks LC,
+                 double *__restrict__ W, unsigned long long *__restrict__ used_out,
+                 int multilevel /* W[level][cell][row][2] */)
 {
   constexpr int NS = acc_nsplit<LMAX>();
+  // which level this block works on, and with which chunk size (block-uniform: scalar loop)
+  int lj = 0;
+  while (lj + 1 < LC.nlev && blockIdx.x >= LC.bstart[lj + 1]) lj++;
+  const int lev_lo = LC.lo + lj, lev_hi = lev_lo;
+  const int ACC_CHUNK = LC.chunk[lj];
+  const unsigned bx = blockIdx.x - LC.bstart[lj];
+  const int cell_add = multilevel ? lev_lo * (S.numr - 1) : 0;
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;      // chunks per block
   __shared__ double scratch_all[ACC_WAVES][16 * FLUSH_STRIDE];
   const int wave = threadIdx.x >> 6;
@@ -582,7 +593,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     // all waves of the block run it at the same time: keep the p0 table in LDS so that no global
     // gather sits in the middle of it.
     __shared__ double p0s[ACC_P0_LDS];
-    const size_t cbeg = beg + (size_t)blockIdx.x * ACC_CHUNK;
+    const size_t cbeg = beg + (size_t)bx * ACC_CHUNK;
     if (cbeg >= end) return;
     const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
     const bool p0_in_lds = S.numr <= ACC_P0_LDS;
@@ -591,7 +602,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
       __syncthreads();
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, LEV, cbeg, cend, scratch, sh, W, used_out)
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
     if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
     else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
@@ -599,12 +610,12 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     return;
   } else {
   const int split = (NS <= ACC_WAVES) ? wave % NS : (int)(blockIdx.y * ACC_WAVES + wave);
-  const size_t chunk = (NS <= ACC_WAVES) ? (size_t)blockIdx.x * CPB + wave / NS : blockIdx.x;
+  const size_t chunk = (NS <= ACC_WAVES) ? (size_t)bx * CPB + wave / NS : bx;
   if (split >= NS) return;
   const size_t cbeg = beg + chunk * ACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, LEV, cbeg, cend, scratch, W, used_out)
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out)
   if constexpr (LMAX <= 4) {
     RUN(0, LMAX);
   } else if constexpr (LMAX <= 7) {
@@ -620,18 +631,21 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   }
 }
 
-// ---- multistep level change: coefficient differencing -----------------------------------------------------
-// For every particle whose proposed level differs from its level, add its moment contribution to
-// Wd[to] and subtract it from Wd[from] (src/SphericalBasis.cc:1156-1228; window r < rmax only).
-// Movers are a small fraction, so each mover lane issues its own fp64 atomics; waves without a
-// mover leave immediately.  Wd[level][cell][row][2].
+// ---- per-particle atomic moments: level-change differencing and sparse levels ----------------------------
+// differencing (plain == 0): for every particle whose proposed level differs from its level, add its
+// moment contribution to Wd[to] and subtract it from Wd[from] (src/SphericalBasis.cc:1156-1228;
+// window r < rmax only).  plain != 0: every particle of the range adds its contribution to
+// Wd[its level] -- the accumulation of SPARSE multistep levels, which are not cell-sorted (window
+// rmin <= r <= rmax and the used count of determine_coefficients_thread, src/SphericalBasis.cc:
+// 486-494).  Each contributing lane issues its own fp64 atomics; waves without one leave at once.
+// Wd[level][cell][row][2].
 template <int LMAX>
 __global__ void __launch_bounds__(256)
 k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                    const double *__restrict__ Z, const double *__restrict__ M,
                    const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
                    const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
-                   double *__restrict__ Wd)
+                   double *__restrict__ Wd, int plain, unsigned long long *__restrict__ used_out)
 {
   const size_t beg = lev_off[first], end = lev_off[last + 1];
   const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -639,8 +653,8 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
   int from = 0, to = 0;
   if (i < end) {
     from = lev[i];
-    to = newlev[i];
-    mover = from != to;
+    to = plain ? from : newlev[i];
+    mover = plain || from != to;
   }
   if (!__any(mover)) return;
   double xx = 0, yy = 0, zz = 1, mass = 0;
@@ -651,7 +665,11 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
     mass = M[i];
   }
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
-  if (!(r < S.rmax)) mover = false;
+  if (plain) {
+    if (!(r >= S.rmin && r <= S.rmax)) mover = false;
+    const unsigned long long in = __ballot(mover);
+    if ((threadIdx.x & 63) == 0 && in) atomicAdd(used_out, (unsigned long long)__popcll(in));
+  } else if (!(r < S.rmax)) mover = false;
   if (!__any(mover)) return;
   const double costh = zz / r;
   double cphi, sphi;
@@ -666,7 +684,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
   const size_t wl = (size_t)(S.numr - 1) * S.nrows * 2;
   double *wto = Wd + (size_t)to * wl + (size_t)idx * S.nrows * 2;
   double *wfr = Wd + (size_t)from * wl + (size_t)idx * S.nrows * 2;
-  const bool sub = mover && from >= mfirst;       // levels below mfirst[mdrft] are not updated
+  const bool sub = !plain && mover && from >= mfirst;       // levels below mfirst[mdrft] are not updated
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
@@ -1127,13 +1145,14 @@ struct SphAccArgs {
   SphDev S;
   const double *X, *Y, *Z, *M;
   const uint32_t *lev_off;
-  int lo, hi;
+  int lo, hi;               // levels lo..hi, each with its own chunking (hi == lo: the classic launch)
   double *W;
   unsigned long long *used;
-  size_t n;
+  size_t n;                 // population of level lo when hi == lo ...
   hipStream_t stream;
-  int multilevel;           // the range [lo, hi] is one level of many: its size is unknown on the host
-  const uint8_t *lev = nullptr;   // non-null: several levels in one launch, W[level][cell][row][2]
+  int multilevel;           // the range is one level of many (short chunks allowed)
+  const uint32_t *counts = nullptr;   // ... else counts[j] = population of level lo + j
+  int wlevels = 0;          // 1: W[level][cell][row][2] (one moment buffer per level)
 };
 
 struct SphForceArgs {
@@ -1165,6 +1184,8 @@ struct SphUpdArgs {
   double *Wd;
   size_t n;
   hipStream_t stream;
+  int plain = 0;                        // 1: accumulate every particle of the range into Wd[its level]
+  unsigned long long *used = nullptr;   // ... and count those inside the window
 };
 
 typedef void (*sph_upd_launcher)(const SphUpdArgs &);

@@ -69,6 +69,10 @@ class Context:
         check(lib.exp_amd_comm_get_unique_id(buf))
         return buf.raw
 
+    def set_dense_min(self, nmin: int) -> None:
+        """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
+        check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)
+
     def set_split_min(self, nmin: int) -> None:
         """Smallest component the fused step handles as two overlapped halves (<= 0: never)."""
         check(self.lib.exp_amd_ctx_set_split_min(self.h, int(nmin)), self.h)

@@ -57,6 +57,14 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
  * default.  Measured on MI355X at 1e8 particles: 12.33 -> 12.12 ms per step only, because the
  * co-running kernels slow each other down (force 5.6 -> 7.1 ms, accumulate 2.9 -> 4.5 ms).        */
 int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
+/* Tuning knob of the block-multistep step loop (exp_amd_sim_step): time-step levels holding fewer
+ * than `nmin` particles are kept level-contiguous but not cell-sorted -- advanced in place,
+ * accumulated with per-particle atomics, forces by the gather path -- because a sparse level has
+ * about one particle per basis cell and the cell order buys nothing.  Same results up to the order
+ * of the sums.  nmin < 0 (the default; EXP_AMD_DENSE_MIN overrides): each force method's own
+ * break-even (about 3e6 / moments per particle: ~30000 for lmax 6, ~58000 for mmax 6);
+ * 0: every level is cell-sorted.                                                                  */
+int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
 void *exp_amd_ctx_stream(exp_amd_ctx *ctx);
 
 /* Coefficient all-reduce across ranks.  Replaces the MPI_Allreduce calls of

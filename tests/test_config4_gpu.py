@@ -66,7 +66,12 @@ def _compare(tag, forces, comps, want, multistep):
             assert np.abs(gl - cL[M]).max() <= 1e-10 * cmax, (tag, name, M, "L")
 
 
-def test_config4_against_the_nbody_oracle(ctx, oracle):
+@pytest.mark.parametrize("dense_min", [-1, 0, 100])
+def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min):
+    """dense_min: the level population below which a level is kept unsorted (runtime.Context.
+    set_dense_min): the default (-1) makes every level of this small run sparse, 0 makes all of them
+    cell-sorted, 100 mixes the two paths."""
+    ctx.set_dense_min(dense_min)
     z = c4.load_golden()
     ms, dtime, dyn = c4.MULTISTEP, c4.DTIME, c4.DYN
     nb, _ = c4.oracle_run(oracle, z, nsteps=0)
@@ -96,6 +101,7 @@ def test_config4_against_the_nbody_oracle(ctx, oracle):
     for name in ("halo", "disk"):
         assert (np.bincount(want(name, "level"), minlength=ms + 1) >= 30).sum() >= 4
     assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
+    ctx.set_dense_min(-1)
 
 
 def test_config4_against_the_golden_file(ctx):
