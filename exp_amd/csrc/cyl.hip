@@ -348,6 +348,41 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   const uint32_t mkey = mover ? (((uint32_t)(ix * nyp + iy) << 10) | ((uint32_t)from << 5) | (uint32_t)to)
                               : 0xffffffffu;
   unsigned long long rem = __ballot(mover);
+  // Movers that do not share keys (an un-cell-sorted sparse level, or a few scattered level changes)
+  // are served in parallel instead: every lane adds its own values.  The grouped loop below would
+  // spend one serial round per key on them.
+  {
+    // (a mover is compared with the previous MOVER of the wave, non-movers in between do not count)
+    const unsigned long long below = rem & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+    const int prev = below ? 63 - __clzll((long long)below) : lane;
+    const uint32_t up = (uint32_t)__shfl((int)mkey, prev);
+    const int npair = __popcll(__ballot(mover && below && mkey == up));
+    if (2 * npair < __popcll(rem)) {
+      if (mover) {
+        const bool sub = !plain && from >= mfirst;
+        double *wto = Wnd + ((size_t)to * nnode + (size_t)(ix * nyp + iy)) * NT;
+        double *wfr = Wnd + ((size_t)from * nnode + (size_t)(ix * nyp + iy)) * NT;
+        cstatic_for<0, MMAX + 1>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          if (C.EVEN_M && (m & 1)) return;
+          constexpr int jc = (m == 0) ? 0 : 2 * m - 1;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
+            const double w = t0 * cw[k];
+            const double vc = w * cmv[m], vs = w * smv[m];
+            unsafeAtomicAdd(wto + off + jc, vc);
+            if (sub) unsafeAtomicAdd(wfr + off + jc, -vc);
+            if constexpr (m > 0) {
+              unsafeAtomicAdd(wto + off + jc + 1, vs);
+              if (sub) unsafeAtomicAdd(wfr + off + jc + 1, -vs);
+            }
+          }
+        });
+      }
+      return;
+    }
+  }
   while (rem) {
     const int lead = __ffsll((long long)rem) - 1;
     const uint32_t kk = (uint32_t)__shfl((int)mkey, lead);
@@ -392,13 +427,14 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 // out[cs][m][n] = sum_node tab[cs ? 3 : 0][m][n][node] * Wn[node][trig(m, cs)]
 __global__ void __launch_bounds__(256)
 k_cyl_contract(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
-               double *__restrict__ out, size_t ostride = 0)
+               double *__restrict__ out, size_t ostride = 0, double *__restrict__ last = nullptr)
 {
   const int n = blockIdx.x, m = blockIdx.y, cs = blockIdx.z & 1, L = blockIdx.z >> 1;   // L: level of a multi-level launch
   __shared__ double red[256];
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
   Wn += (size_t)L * nnode * C.ntrig;
   out += (size_t)L * ostride;
+  if (last) last += (size_t)L * ostride;     // setup_accumulation's swap on the way: last <- out, out <- new
   double s = 0.0;
   if (!(cs == 1 && m == 0)) {
     const int t = (m == 0) ? 0 : 2 * m - 1 + cs;
@@ -411,7 +447,11 @@ k_cyl_contract(CylDev C, const double *__restrict__ tab, const double *__restric
     if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[((size_t)cs * (C.mmax + 1) + m) * C.nmax + n] = red[0];
+  if (threadIdx.x == 0) {
+    const size_t o = ((size_t)cs * (C.mmax + 1) + m) * C.nmax + n;
+    if (last) last[o] = out[o];
+    out[o] = red[0];
+  }
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
@@ -616,6 +656,7 @@ struct CylForce : exp_amd_force {
   size_t cov_seq_cap = 0;
   DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
+  bool tails_clean = false;         // the {mass, count} tails of all expcoefN sets are zero (substep_expansion keeps them so)
   size_t nnode = 0;
 
   int determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
@@ -721,6 +762,16 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
 __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ tail, int overwrite)
 {
   if (threadIdx.x < 2) acc[threadIdx.x] = (overwrite ? 0.0 : acc[threadIdx.x]) + tail[threadIdx.x];
+}
+
+// step-driver form: {in-cut mass, count} of the sub-step are added while the master step's first
+// sub-step is open, and the tail is left zero for the next accumulation either way
+__global__ void k_cyl_mass_take(double *__restrict__ acc, double *__restrict__ tail, int open)
+{
+  if (threadIdx.x < 2) {
+    if (open) acc[threadIdx.x] += tail[threadIdx.x];
+    tail[threadIdx.x] = 0.0;
+  }
 }
 
 int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level, bool have_keys,
@@ -833,6 +884,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
                                 f->ncoef_dev * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->nnode * dev.ntrig * sizeof(double), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dst + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
+  f->tails_clean = false;
   const int lo = f->multistep ? f->mlevel : 0, hi = lo;
   size_t nrange = c->n;      // population of the accumulated level: sizes the grid and the chunks
   if (c->n && f->multistep) {
@@ -893,7 +945,8 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   if (full) dmax = ms;
   if (c->n) {
     uint32_t keep[66];
-    const bool had = c->lev_host_valid && ordered;
+    const bool had = c->lev_host_valid && (ordered || c->partition_stale);
+    c->partition_stale = false;         // (a stale partition implies lo == 0: the full sort below settles it)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
     if (dmax >= lo) {
       rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
@@ -906,15 +959,17 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
   const CylDev C = cdev_for(f, c);
-  // setup_accumulation(M) of every active level: L <- N, N <- 0 (exputil/EmpCylSL.cc:2010-2030)
   double *dst = f->d_coefN.p + (size_t)lo * f->ncoef_dev;
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)lo * f->ncoef_dev, dst,
-                              (size_t)nact * f->ncoef_dev * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   const size_t wl = f->nnode * dev.ntrig;
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
   // {in-cut mass, count} of the whole launch ride in the tail of the FIRST active level's set (the
-  // other tails are zero): one number per sub-step is all Cylinder keeps (src/Cylinder.cc:1081-1099)
-  HIP_TRY(ctx, hipMemsetAsync(dst, 0, (size_t)nact * f->ncoef_dev * sizeof(double), ctx->stream));
+  // other tails are zero): one number per sub-step is all Cylinder keeps (src/Cylinder.cc:1081-1099).
+  // k_cyl_mass_take leaves the tail zero again; only the plain per-level API can have dirtied one.
+  if (!f->tails_clean) {
+    for (int L = 0; L <= ms; L++)
+      HIP_TRY(ctx, hipMemsetAsync(f->d_coefN.p + (size_t)L * f->ncoef_dev + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
+    f->tails_clean = true;
+  }
   int dacc = lo - 1;                    // last level the cell-ordered kernel takes
   for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
   size_t nrange = 0;
@@ -955,12 +1010,14 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
+    // ... with setup_accumulation(M)'s swap of every active level: L <- N, N <- new
+    // (exputil/EmpCylSL.cc:2010-2030)
     k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2 * nact), 256, 0, ctx->stream>>>(
-        C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, dst, f->ncoef_dev);
+        C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, dst, f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
   if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;
-  if (f->mass_open) k_cyl_mass<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, 0);
+  k_cyl_mass_take<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, f->mass_open ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
   return EXP_AMD_OK;

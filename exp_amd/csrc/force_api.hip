@@ -137,10 +137,13 @@ extern "C" int exp_amd_force_used(exp_amd_force *f, long long *used)
 
 // ---- multistep coefficient bookkeeping -----------------------------------------------------------------------
 
+struct CombineW { double ab[2 * 17]; };      // interpolation weights (a, b) of the levels below mfirst
+
 __global__ void __launch_bounds__(256)
 k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int ncoef, int nlev,
-                int mfirst, const double *__restrict__ ab, double *__restrict__ out)
+                int mfirst, CombineW W, double *__restrict__ out)
 {
+  const double *ab = W.ab;
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
   double s = 0.0;
@@ -171,7 +174,9 @@ extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, in
     bool active = (mdrft == 0) || (mdrft % (1 << (ms - M)) == 0);
     if (active) { mfirst = M; break; }
   }
-  std::vector<double> ab(2 * (ms + 1), 0.0);
+  CombineW W;
+  double *ab = W.ab;
+  for (int k = 0; k < 2 * 17; k++) ab[k] = 0.0;
   for (int M = 0; M < mfirst; M++) {
     const int d = 1 << (ms - M);
     const int dL = (mdrft / d) * d, dN = dL + d;
@@ -179,11 +184,8 @@ extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, in
     ab[2 * M] = 1.0 - b;
     ab[2 * M + 1] = b;
   }
-  // tiny host->device copy on the stream (pageable memory: staged before return)
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_scratch.p, ab.data(), ab.size() * sizeof(double),
-                              hipMemcpyHostToDevice, ctx->stream));
   k_mstep_combine<<<cdiv(f->ncoef_dev, 256), 256, 0, ctx->stream>>>(
-      f->d_coefL.p, f->d_coefN.p, (int)f->ncoef_dev, ms + 1, mfirst, f->d_scratch.p, f->d_coef.p);
+      f->d_coefL.p, f->d_coefN.p, (int)f->ncoef_dev, ms + 1, mfirst, W, f->d_coef.p);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
   return EXP_AMD_OK;
@@ -212,7 +214,7 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   if (rc) return rc;
   // one 8-byte read-back decides whether anything has to be differenced / re-ordered at all
   unsigned long long u = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p + 64, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (nswitch) *nswitch = (long long)u;
   if (ctx->nranks > 1 || ctx->ar_fn || u) {

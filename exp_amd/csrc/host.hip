@@ -234,9 +234,10 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
   }
   int rc;
   for (size_t k = 0; k < nc; k++) {
+    const unsigned long long *res = nullptr;
     if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
-                                      kick ? mf : ms + 1, first, dt_min))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, s->comps[k]->nswitch.p, 32 * sizeof(unsigned long long),
+                                      kick ? mf : ms + 1, first, dt_min, &res))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, res, 32 * sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -266,6 +267,12 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
         for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];
         expamd_comp_update_sparse(c, first, ctx->dense_min >= 0 ? ctx->dense_min : f->sparse_threshold());
       } else c->sparse_mask = 0;
+      if (mirror && first == 0 && mdrft == s->Mstep) {
+        // end of a master step: the next one opens with a full advance sort of every level
+        // (substep_expansion(0)), which re-partitions by the committed levels in the same pass
+        c->partition_stale = true;
+        continue;
+      }
       if ((rc = f->resort(c, ordered ? first : 0))) return rc;
       if (mirror) {
         for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];
@@ -300,7 +307,11 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
 extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
 {
   if (s) s->step_switch = 0;
-  if (s) for (exp_amd_comp *c : s->comps) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (s) for (exp_amd_comp *c : s->comps) {
+    // (a level partition left stale by the previous master step is this loop's own business)
+    int rc_ = s->multistep ? expamd_comp_touch_keep_partition(c) : expamd_comp_touch(c);
+    if (rc_) return rc_;
+  }
   if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
   int rc;
   for (int it = 0; it < nsteps; it++) {

@@ -26,7 +26,8 @@ struct exp_amd_comp {
   DevBuf<uint8_t> level[2];          // multistep level of each slot
   DevBuf<uint32_t> key;              // sort key scratch
   DevBuf<uint8_t> newlev;            // level chosen by the last adjust_multistep_level sweep
-  DevBuf<unsigned long long> nswitch; // [1] level changes counted by that sweep
+  DevBuf<unsigned long long> nswitch; // counters of the level sweeps: two alternating sets [32] + one word
+  int nsw_flip = 0;
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
@@ -49,6 +50,11 @@ struct exp_amd_comp {
   // forces take the gather path.  Set by the step driver from the level populations; any per-level
   // call of the plain API clears the bit of the level it sorts.
   uint32_t sparse_mask = 0;
+  // Levels were committed at the end of a master step but the slots not yet re-partitioned: the step
+  // driver lets the next master step's first (full) advance sort do it in the same pass.  lev_host
+  // already holds the offsets that sort will establish; any other entry point re-partitions first
+  // (expamd_comp_touch).
+  bool partition_stale = false;
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
   // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
   bool prekey_valid = false;
@@ -95,6 +101,8 @@ int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);
 // An outside call is about to read or change the component: apply the deferred half-kick of the
 // last fused step (if any) and drop the keys it recorded for the next one.
 int expamd_comp_touch(exp_amd_comp *c);
+// ... without resolving a stale level partition (the step driver's own entry)
+int expamd_comp_touch_keep_partition(exp_amd_comp *c);
 // ... only the first half (a read-only call: the recorded keys stay valid, they were computed from
 // the kicked velocity)
 int expamd_comp_apply_pending(exp_amd_comp *c);

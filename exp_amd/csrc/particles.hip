@@ -100,7 +100,7 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
   __syncthreads();
   // eight consecutive bins per thread and pass: the passes are barrier-latency bound (the cylinder's
   // 5 x 33025 bins took 200 us at one bin per thread)
-  constexpr uint32_t SI = 8;
+  constexpr uint32_t SI = 32;
   for (uint32_t base = k0; base < k1; base += 1024u * SI) {
     const uint32_t kb = base + (uint32_t)t * SI;
     uint32_t v[SI], s = 0;
@@ -258,7 +258,44 @@ int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, i
   return EXP_AMD_OK;
 }
 
+// sort key of a force-independent re-partition: the level alone
+struct LevelKeyFn {
+  __device__ __forceinline__ uint32_t operator()(double, double, double, uint8_t lev) const { return lev; }
+};
+
+static int partition_by_level(exp_amd_comp *c)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  c->partition_stale = false;
+  if (c->n == 0) return EXP_AMD_OK;
+  const uint32_t nkeys = (uint32_t)c->nlevels;
+  int rc = expamd_comp_prepare_hist(c, nkeys);
+  if (rc) return rc;
+  uint32_t keep[66];
+  const bool had = c->lev_host_valid;
+  for (int k = 0; k <= c->nlevels; k++) keep[k] = c->lev_host[k];
+  {
+    ProfScope ps(ctx, "k_key_hist");
+    AdvanceArgs A = expamd_advance_args(c, AdvSpec());
+    k_key_hist<LevelKeyFn><<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
+        LevelKeyFn{}, A, expamd_sort_range(c, -1, -1), c->key.p, c->hist.p);
+  }
+  rc = expamd_comp_finish_sort(c, nkeys, 1u, true, AdvSpec(), -1, -1);
+  if (rc) return rc;
+  if (had) { for (int k = 0; k <= c->nlevels; k++) c->lev_host[k] = keep[k]; c->lev_host_valid = true; }
+  c->sorted_for = nullptr;
+  c->sparse_mask = 0;
+  return EXP_AMD_OK;
+}
+
 int expamd_comp_touch(exp_amd_comp *c)
+{
+  c->prekey_valid = false;
+  if (c->partition_stale) { int rc = partition_by_level(c); if (rc) return rc; }
+  return expamd_comp_apply_pending(c);
+}
+
+int expamd_comp_touch_keep_partition(exp_amd_comp *c)
 {
   c->prekey_valid = false;
   return expamd_comp_apply_pending(c);
@@ -457,8 +494,10 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
               const double *__restrict__ az, const double *__restrict__ pot,
               const uint8_t *__restrict__ lev, uint8_t *__restrict__ newlev,
               const uint32_t *__restrict__ lev_off, int kick_lo, int first, int last, double dt_min,
-              unsigned long long *__restrict__ out)
+              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next)
 {
+  // two counter sets are used alternately: this launch leaves the other one clean for the next
+  if (blockIdx.x == 0 && threadIdx.x < 32) out_next[threadIdx.x] = 0ull;
   __shared__ unsigned int cnt[32];
   if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -530,14 +569,15 @@ int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfr
                                int multistep, int mfirst_mdrft, int first)
 {
   exp_amd_ctx *ctx = c->ctx;
-  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p, 0, sizeof(unsigned long long), ctx->stream));
+  // (the counter of this entry point is nswitch[64]; [0, 64) are the step driver's two counter sets)
+  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p + 64, 0, sizeof(unsigned long long), ctx->stream));
   if (c->n == 0) return EXP_AMD_OK;
   AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
                shiftlevl, mfirst_mdrft};
   ProfScope ps(ctx, "k_adjust_levels");
   k_adjust_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(
       A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, multistep, c->n, c->nswitch.p);
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, multistep, c->n, c->nswitch.p + 64);
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
@@ -553,25 +593,27 @@ int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg)
   return EXP_AMD_OK;
 }
 
-// launches k_kick_adjust; results land in c->nswitch (u64[1 + levels], zeroed here)
+// launches k_kick_adjust; *result receives the device address of this launch's counter set
+// (u64[32]: level changes, then the proposals per level)
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
-                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min)
+                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
+                            const unsigned long long **result)
 {
   exp_amd_ctx *ctx = c->ctx;
-  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p, 0, c->nswitch.bytes(), ctx->stream));
-  if (c->n == 0) return EXP_AMD_OK;
+  unsigned long long *out = c->nswitch.p + 32 * c->nsw_flip, *nxt = c->nswitch.p + 32 * (1 - c->nsw_flip);
+  *result = out;
   const int lo = kick_lo < first ? kick_lo : first;
   size_t nr = 0;
-  int rc = expamd_comp_level_count(c, lo, multistep, &nr);
-  if (rc) return rc;
-  if (nr == 0) return EXP_AMD_OK;
+  if (c->n) { int rc = expamd_comp_level_count(c, lo, multistep, &nr); if (rc) return rc; }
+  if (nr == 0) return EXP_AMD_OK;        // (the set stays clean and is used again)
   AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
                shiftlevl, mfirst_mdrft};
   ProfScope ps(ctx, "k_kick_adjust");
   k_kick_adjust<<<cdiv(nr, (size_t)TPB * KA_ITEMS), TPB, 0, ctx->stream>>>(
       A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, c->nswitch.p);
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt);
   HIP_TRY(ctx, hipGetLastError());
+  c->nsw_flip ^= 1;
   return EXP_AMD_OK;
 }
 
@@ -601,12 +643,13 @@ extern "C" int exp_amd_comp_create(exp_amd_ctx *ctx, size_t n, exp_amd_comp **ou
     }
   }
   if (c->key.alloc(na) != hipSuccess || c->lev_off.alloc(64) != hipSuccess ||
-      c->newlev.alloc(na) != hipSuccess || c->nswitch.alloc(32) != hipSuccess) {
+      c->newlev.alloc(na) != hipSuccess || c->nswitch.alloc(72) != hipSuccess) {
     exp_amd_comp_destroy(c);
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_create: hipMalloc failed");
   }
   for (int a = 0; a < A_NARR; a++)
     HIP_TRY(ctx, hipMemsetAsync(c->arr[0][a].p, 0, na * sizeof(double), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(c->nswitch.p, 0, c->nswitch.bytes(), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(c->level[0].p, 0, na, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(c->level[1].p, 0, na, ctx->stream));   // (levels_zero: never written then)
   k_iota<<<cdiv(na, TPB), TPB, 0, ctx->stream>>>(c->id[0].p, n);

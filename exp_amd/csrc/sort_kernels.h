@@ -277,5 +277,6 @@ int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfr
                                int multistep, int mfirst_mdrft, int first);
 int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg = 0);
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
-                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min);
+                            int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
+                            const unsigned long long **result);
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv);

@@ -21,9 +21,11 @@ struct SphKeyFn {
 // ---- moments -> coefficients ------------------------------------------------------------------------
 // part[seg][row][n] = sum_{i in seg} E[i][l][n] W[i][row][0] + E[i+1][l][n] W[i][row][1]
 #define CSEG 32
+// clear != 0: the moments are zeroed once they have been read (each (cell, row) pair is read by exactly
+// one block), so that the next accumulation finds a clean buffer without a separate memset pass
 __global__ void __launch_bounds__(64)
-k_sph_contract(SphDev S, const double *__restrict__ W, const double *__restrict__ wscale,
-               double *__restrict__ part)
+k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wscale,
+               double *__restrict__ part, int clear = 0)
 {
   const int row = blockIdx.x, seg = blockIdx.y;
   int l = 0;
@@ -45,10 +47,20 @@ k_sph_contract(SphDev S, const double *__restrict__ W, const double *__restrict_
     }
     part[((size_t)seg * S.nrows + row) * S.nmax + n] = s * wscale[row];   // 1/s(l,m), see lc_s
   }
+  if (clear) {
+    __syncthreads();
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 64) {
+      W[((size_t)i * S.nrows + row) * 2] = 0.0;
+      W[((size_t)i * S.nrows + row) * 2 + 1] = 0.0;
+    }
+  }
 }
 
+// last != nullptr: the N/L swap of determine_coefficients (src/SphericalBasis.cc:785-792) on the way,
+// last <- coef (the previous set of this level), coef <- new
 __global__ void __launch_bounds__(256)
-k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__ coef)
+k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__ coef,
+                double *__restrict__ last = nullptr)
 {
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
@@ -56,6 +68,7 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
   coef += (size_t)blockIdx.y * ncoef;
   double s = 0.0;
   for (int seg = 0; seg < CSEG; seg++) s += part[(size_t)seg * ncoef + k];
+  if (last) last[(size_t)blockIdx.y * ncoef + k] = coef[k];
   coef[k] = s;
 }
 
@@ -325,6 +338,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   const int hi = f->multistep ? f->mlevel : 0;
   SphDev S = dev_for(f, c->center);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), ctx->stream));
+  f->w_clean = false;
   // used: multistep = 0 counts the last accumulation; a multistep force adds up the levels of the
   // first sub-step (see SphForce::used_open)
   unsigned long long *used_p = f->d_used.p + ((f->multistep && !f->used_open) ? 1 : 0);
@@ -402,7 +416,8 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // mstep])), so they are not carried through the reorder -- unless a full re-partition also moves
     // inactive levels.
     uint32_t keep[66];
-    const bool had = c->lev_host_valid && ordered;
+    const bool had = c->lev_host_valid && (ordered || c->partition_stale);
+    c->partition_stale = false;         // (a stale partition implies lo == 0: the full sort below settles it)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
     if (dmax >= lo) {
       rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
@@ -415,14 +430,16 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // sparse levels above: advanced in place
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
-  // N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_coefL.p + (size_t)lo * f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef,
-                              (size_t)nact * f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   const SphDev S = dev_for(f, c->center);
   const size_t wl = (size_t)(cfg.numr - 1) * S.nrows * 2;
-  HIP_TRY(ctx, hipMemsetAsync(f->d_W.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
+  // the per-level moment buffers are left clean by the contraction that consumes them (below); only
+  // a buffer the plain per-level API may have used (level 0's) is cleared here
+  if (!f->w_clean) {
+    HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, f->d_W.bytes(), ctx->stream));
+    f->w_clean = true;
+  }
+  // counts accumulated after the first sub-step are not kept (SphForce::used_open): d_used[1] is a sink
   unsigned long long *used_p = f->d_used.p + (f->used_open ? 0 : 1);
-  if (!f->used_open) HIP_TRY(ctx, hipMemsetAsync(used_p, 0, sizeof(unsigned long long), ctx->stream));
   // the sparse levels inside a full re-partition are level-contiguous but unordered as well
   int dacc = lo - 1;                    // last level the cell-ordered kernel takes
   for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
@@ -447,9 +464,10 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   {
     ProfScope ps(ctx, "k_sph_contract");
     k_sph_contract<<<dim3(S.nrows, CSEG, nact), 64, 0, ctx->stream>>>(
-        S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p);
+        S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
+    // ... with the N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
     k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nact), 256, 0, ctx->stream>>>(
-        f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef);
+        f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef, f->d_coefL.p + (size_t)lo * f->ncoef);
   }
   HIP_TRY(ctx, hipGetLastError());
   if ((rc = expamd_allreduce(ctx, f->d_coefN.p + (size_t)lo * f->ncoef, (size_t)nact * f->ncoef))) return rc;
@@ -500,15 +518,20 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     const size_t need = t->n / 64 + 8;
     if (f->work_cap < need) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx, f->d_work.alloc(need + 1));
+      HIP_TRY(ctx, f->d_work.alloc(need + 2));          // work list + two counters (used alternately)
+      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + need, 0, 2 * sizeof(uint32_t), ctx->stream));
       f->work_cap = need;
+      f->work_flip = 0;
     }
+    const bool slow = t->sorted_for != f || all_sparse;
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
-                   f->d_work.p, f->d_work.p + f->work_cap, (t->sorted_for != f || all_sparse) ? 1 : 0, ctx,
-                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1};
+                   f->d_work.p, f->d_work.p + f->work_cap + f->work_flip, slow ? 1 : 0, ctx,
+                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1,
+                   f->d_work.p + f->work_cap + (1 - f->work_flip)};
     k_force_launch[f->cfg.lmax](a);
+    if (!slow) f->work_flip ^= 1;
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
@@ -604,6 +627,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   // ---- main stream: accumulate the halves as they arrive, reduce, project, force
   SphDev S = dev_for(f, c->center);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), V));
+  f->w_clean = false;
   HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), V));
   for (int h = 0; h < 2; h++) {
     HIP_TRY(ctx, hipStreamWaitEvent(V, ctx->ev_sorted[h], 0));
@@ -626,8 +650,10 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     const size_t need = c->n / 64 + 8;
     if (f->work_cap < need) {
       HIP_TRY(ctx, hipStreamSynchronize(V));
-      HIP_TRY(ctx, f->d_work.alloc(need + 1));
+      HIP_TRY(ctx, f->d_work.alloc(need + 2));
+      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + need, 0, 2 * sizeof(uint32_t), V));
       f->work_cap = need;
+      f->work_flip = 0;
     }
   }
   for (int h = 0; h < 2; h++) {
@@ -638,8 +664,10 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
       SphForceArgs a{Sh, c->a(A_X), c->a(A_Y), c->a(A_Z), c->half_off.p, h, h, f->d_T4.p,
                      c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->a(A_VX), c->a(A_VY),
                      c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,
-                     f->d_work.p, f->d_work.p + f->work_cap, 0, ctx, c->key.p, dt_kick, dt, 0};
+                     f->d_work.p, f->d_work.p + f->work_cap + f->work_flip, 0, ctx, c->key.p, dt_kick, dt, 0,
+                     f->d_work.p + f->work_cap + (1 - f->work_flip)};
       k_force_launch[f->cfg.lmax](a);
+      f->work_flip ^= 1;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[h], V));
   }
@@ -688,7 +716,10 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // the difference matrices of the levels that _begin clears and _finish adds (M >= mfirst[mdrft],
   // src/SphericalBasis.cc:1013-1079); a rank without particles still takes part in the reduction
   const int nl = ms - mfirst_mdrft + 1;
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p + (size_t)mfirst_mdrft * wl, 0, (size_t)nl * wl * sizeof(double), ctx->stream));
+  if (!f->wd_clean) {      // (afterwards the contraction below leaves what it consumed zeroed)
+    HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p, 0, f->d_Wd.bytes(), ctx->stream));
+    f->wd_clean = true;
+  }
   const SphDev S = dev_for(f, c->center);
   size_t nr = 0;
   if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
@@ -700,7 +731,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   }
   // moments -> coefficient differences, all levels in one launch
   k_sph_contract<<<dim3(S.nrows, CSEG, nl), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
-                                                                  f->d_wscale.p, f->d_part.p);
+                                                                  f->d_wscale.p, f->d_part.p, /*clear=*/1);
   k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nl), 256, 0, ctx->stream>>>(
       f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef);
   HIP_TRY(ctx, hipGetLastError());

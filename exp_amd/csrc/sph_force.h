@@ -15,10 +15,13 @@ struct SphForce : exp_amd_force {
   void *cov = nullptr;              // sub-sample covariance state (sph_cov.hip), analysis only
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
+  int work_flip = 0;                // which of the two work-list counters the next fast pass counts into
   // PotAccel::used of a multistep run: the counts of every level accumulated while tnow == resetT,
   // i.e. during the first sub-step of a master step (src/SphericalBasis.cc:796, :860-862, :1004-1010);
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
   bool used_open = true;
+  bool wd_clean = false;            // ... and of d_Wd (multistep_update)
+  bool w_clean = false;             // every per-level moment buffer of d_W is zero (substep_expansion keeps it so)
   int multistep_reset() override
   {
     HIP_TRY(ctx, hipMemsetAsync(d_used.p, 0, sizeof(unsigned long long), ctx->stream));
@@ -32,7 +35,9 @@ struct SphForce : exp_amd_force {
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
-  long long sparse_threshold() const override { return 3000000LL / (2 * dev.nrows); }
+  // (the spherical basis has few cells, numr - 1: a level stays worth sorting down to a few particles
+  // per cell, and per-particle atomics on so few addresses contend)
+  long long sparse_threshold() const override { return 4LL * (cfg.numr - 1); }
   int resort(exp_amd_comp *c, int first = 0) override;
   int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;

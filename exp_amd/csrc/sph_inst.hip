@@ -41,23 +41,24 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 {
   constexpr int LMAX = SPH_L;
   if (!a.all_slow) {
-    (void)hipMemsetAsync(a.nwork, 0, sizeof(uint32_t), a.stream);
+    // a.nwork[0..1]: two work-list counters used alternately; the general pass of launch k clears the
+    // one launch k+1 will count into (no memset between the launches)
     {
       ProfScope ps(a.ctx, "k_sph_force");
       k_sph_force<LMAX, true><<<cdiv(a.grid, SPH_FORCE_CHUNKS), 256, 0, a.stream>>>(
           a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-          a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
+          a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
     }
     // deferred waves: the grid is an upper bound, surplus waves leave on the count
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-        a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
+        a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next);
   } else {
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-        a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v);
+        a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
   }
 }
 

@@ -1111,8 +1111,10 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
             double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
             double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork,
-            uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v)
+            uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v,
+            uint32_t *__restrict__ nwork_clear /* counter of the NEXT launch pair: zeroed here */)
 {
+  if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if constexpr (FAST) {
     // SPH_FORCE_CHUNKS consecutive chunks per wave (rolled loop: the literal recurrence constants
@@ -1173,6 +1175,7 @@ struct SphForceArgs {
   uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
   double nk_dtk, nk_dtd;    // ... for that step's kick and drift
   int store_v;              // 0: the half-kick is deferred, v is left as it is
+  uint32_t *nwork_next = nullptr;   // the counter the next launch will use (cleared by this one's general pass)
 };
 
 struct SphUpdArgs {
