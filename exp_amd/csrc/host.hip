@@ -29,7 +29,66 @@ struct exp_amd_sim {
   bool gottapot = false;
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
+  // Two-stream sub-steps: everything that touches the particles of component k is issued on stream
+  // k & 1 (the context's stream / its auxiliary stream).  The small launches of a sub-step are
+  // latency-bound, so the two components' chains fill each other's gaps.  Events carry the cross
+  // dependencies: ev_self[k] = force method k has projected its tables and applied its self force;
+  // ev_used[k] = the last use of force method k's tables by a cross force on the other stream.
+  bool overlap = false;
+  hipStream_t main_stream = nullptr;
+  std::vector<hipEvent_t> ev_self, ev_used;
+  std::vector<char> used_pending;
+  hipEvent_t ev_join = nullptr;
 };
+
+// issue on component k's stream for the lifetime of the object
+struct StreamOf {
+  exp_amd_ctx *ctx;
+  hipStream_t saved;
+  StreamOf(exp_amd_sim *s, size_t k) : ctx(s->ctx), saved(s->ctx->stream)
+  {
+    if (s->overlap) ctx->stream = (k & 1) ? ctx->aux : s->main_stream;
+  }
+  ~StreamOf() { ctx->stream = saved; }
+};
+
+static int overlap_begin(exp_amd_sim *s)
+{
+  exp_amd_ctx *ctx = s->ctx;
+  bool any_orient = false;
+  for (auto o : s->orients) any_orient = any_orient || o;
+  const char *env = getenv("EXP_AMD_SIM_OVERLAP");
+  s->overlap = s->multistep > 0 && s->comps.size() >= 2 && !any_orient && !ctx->ar_fn &&
+               !(env && atoi(env) == 0);     // (a host-provided all-reduce callback owns its stream)
+  if (!s->overlap) return EXP_AMD_OK;
+  int rc = expamd_ctx_aux(ctx);
+  if (rc) return rc;
+  s->main_stream = ctx->stream;
+  while (s->ev_self.size() < s->comps.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    s->ev_self.push_back(a);
+    s->ev_used.push_back(b);
+    s->used_pending.push_back(0);
+  }
+  if (!s->ev_join) HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  // whatever was issued on the context's stream so far precedes the auxiliary stream's work
+  HIP_TRY(ctx, hipEventRecord(s->ev_join, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, s->ev_join, 0));
+  return EXP_AMD_OK;
+}
+
+static int overlap_end(exp_amd_sim *s)
+{
+  if (!s->overlap) return EXP_AMD_OK;
+  exp_amd_ctx *ctx = s->ctx;
+  HIP_TRY(ctx, hipEventRecord(s->ev_join, ctx->aux));
+  HIP_TRY(ctx, hipStreamWaitEvent(s->main_stream, s->ev_join, 0));
+  for (auto &u : s->used_pending) u = 0;       // (main now follows everything)
+  s->overlap = false;
+  return EXP_AMD_OK;
+}
 
 extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
                                   const double dynfrac[5], int shiftlevl, exp_amd_sim **out)
@@ -61,6 +120,9 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
 {
   if (!s) return;
   if (s->pinned) (void)hipHostFree(s->pinned);
+  for (auto e : s->ev_self) (void)hipEventDestroy(e);
+  for (auto e : s->ev_used) (void)hipEventDestroy(e);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
 
@@ -182,12 +244,26 @@ static int compute_potential(exp_amd_sim *s, int mlevel, int mdrft, int mstep)
 // (src/step.cc:115-231) is issued once per component over that range instead of once per level, and
 // the host looks at the device once per sub-step (the level changes of all components).
 
+// force method k's coefficient sets / tables / in-cut mass are about to change on the current stream:
+// the cross forces that read them on the other stream come first
+static int wait_used(exp_amd_sim *s, size_t k)
+{
+  if (s->overlap && s->used_pending[k]) {
+    HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[k], 0));
+    s->used_pending[k] = 0;
+  }
+  return EXP_AMD_OK;
+}
+
 // first half: for M = mfirst[mstep] .. multistep: incr_velocity(DT(M)/2, M); incr_position(DT(M), M);
 // compute_expansion(M)  (src/step.cc:126-160)
 static int substep_expansion(exp_amd_sim *s, int lo, double dt_min)
 {
   for (size_t k = 0; k < s->comps.size(); k++) {
-    int rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min);
+    StreamOf on(s, k);
+    int rc = wait_used(s, k);
+    if (rc) return rc;
+    rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min);
     if (rc) return rc;
   }
   return EXP_AMD_OK;
@@ -201,14 +277,27 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
   int rc;
   if ((rc = fix_centers(s, mstep))) return rc;
   for (size_t k = 0; k < s->comps.size(); k++) {
+    StreamOf on(s, k);
     exp_amd_force *f = s->forces[k];
     if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
     if ((rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
     if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
+    if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
   }
   for (auto &pr : s->inter) {
+    StreamOf on(s, (size_t)pr.second);            // the target's particles: the target's stream
     exp_amd_force *f = s->forces[pr.first];
+    const bool foreign = s->overlap && ((pr.first ^ pr.second) & 1);
+    if (foreign) {
+      // the source's projected tables (and the scratch of its force pass) must be ready and free
+      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_self[pr.first], 0));
+      if (s->used_pending[pr.first]) HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[pr.first], 0));
+    }
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
+    if (foreign) {
+      HIP_TRY(s->ctx, hipEventRecord(s->ev_used[pr.first], s->ctx->stream));
+      s->used_pending[pr.first] = 1;
+    }
   }
   s->gottapot = true;
   return EXP_AMD_OK;
@@ -234,15 +323,18 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
   }
   int rc;
   for (size_t k = 0; k < nc; k++) {
+    StreamOf on(s, k);
     const unsigned long long *res = nullptr;
     if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
                                       kick ? mf : ms + 1, first, dt_min, &res))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, res, 32 * sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, ctx->stream));
   }
+  if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   s->last_switch = 0;
   for (size_t k = 0; k < nc; k++) {
+    StreamOf on(s, k);
     exp_amd_comp *c = s->comps[k];
     exp_amd_force *f = s->forces[k];
     const unsigned long long *res = s->pinned + k * 32;
@@ -290,14 +382,16 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
   if (!s) return EXP_AMD_ERR_ARG;
   int rc;
   if (s->multistep) {
-    for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
+    if ((rc = overlap_begin(s))) return rc;
+    for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
     // for (M = 0 .. multistep) compute_expansion(M): every level, nothing advanced
     if ((rc = substep_expansion(s, 0, 0.0))) return rc;
     if ((rc = compute_potential_ms(s, 0, 0, 0))) return rc;
     if ((rc = kick_adjust_levels(s, 0, 1, false))) return rc;
-    for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
+    for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
     if ((rc = substep_expansion(s, 0, 0.0))) return rc;
-    return compute_potential_ms(s, 0, 0, 0);
+    if ((rc = compute_potential_ms(s, 0, 0, 0))) return rc;
+    return overlap_end(s);
   }
   if ((rc = compute_expansion(s, 0))) return rc;
   return compute_potential(s, 0, 0, 0);
@@ -314,10 +408,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
   }
   if (!s || nsteps < 0) return EXP_AMD_ERR_ARG;
   int rc;
+  if ((rc = overlap_begin(s))) return rc;
   for (int it = 0; it < nsteps; it++) {
     if (s->multistep) {
       // comp->multistep_reset() (src/step.cc:84)
-      for (auto f : s->forces) if ((rc = f->multistep_reset())) return rc;
+      for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt))) return rc;
@@ -342,7 +437,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
     }
     s->this_step++;
   }
-  return EXP_AMD_OK;
+  return overlap_end(s);
 }
 
 extern "C" double exp_amd_sim_time(const exp_amd_sim *s) { return s ? s->tnow : 0.0; }
