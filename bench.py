@@ -34,17 +34,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TF = 78.6   # MI355X fp64 vector (non-matrix) peak, datasheet; ubench: ~73 (tools/dbg/ubench_dp.hip)
 # Algorithmic HBM bytes per particle per launch of each pass (SURVEY.md section 8d accounting,
 # restated in DESIGN.md): whole step 232 B = pass A (kick/2 + drift + accumulate) 128 B +
-# pass B (force + kick/2) 104 B.
+# pass B (force + kick/2) 104 B.  `roofline.achieved` uses these contract figures.
 ALGO_BYTES = {
     "k_sph_force": 104.0,        # reads x,y,z,vx,vy,vz (48) ; writes ax,ay,az,pot,vx,vy,vz (56)
+    "k_cyl_force": 104.0,
     "k_sph_accumulate": 32.0,    # reads x,y,z,m
+    "k_cyl_accumulate": 32.0,
     "k_kick": 72.0,
     "k_drift": 72.0,
-    "k_scatter": 176.0,
+    "k_scatter_adv": 148.0,      # reads x,v,a,m,id (84 + 4) ; writes x,v,m,id (60): kick + drift inside the sort
     "step": 232.0,
 }
+# What the kernels of the FUSED step themselves move: the closing half-kick's
+# v store is deferred into the next scatter pass, so the force pass reads x,y,z,vx,vy,vz (48) and
+# writes ax,ay,az,pot (32) + the 4-byte sort key of the next step = 84 B; measured 85 B (PMC).
+OWN_BYTES = {"k_sph_force": 84.0, "k_cyl_force": 84.0}
+# fp64 operations executed per particle (FMA = 2), static count of the unrolled fast paths
+# (tools/isa_count.py on the gfx950 assembly)
+EXEC_FLOPS = {("k_sph_force", 10): 2585.0, ("k_sph_force", 6): 1374.0, ("k_cyl_force", 6): 950.0,
+              ("k_sph_accumulate", 10): 1100.0, ("k_sph_accumulate", 6): 640.0, ("k_cyl_accumulate", 6): 350.0}
+# reference formulation, SURVEY.md section 8d: flops per particle-step
+REF_FLOPS = {"S6": 7800.0, "S10": 22600.0, "C6": 6200.0}
 
 
 def parse_args():
@@ -58,6 +71,10 @@ def parse_args():
     ap.add_argument("--numr", type=int, default=2000)
     ap.add_argument("--dt", type=float, default=0.002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the secondary BASELINE configurations (2: 1e7 S6 halo, 3: 1e7 C6 disk, "
+                         "4: disk + halo, multistep 4) measured after the headline on rank 0 at N = 1")
+    ap.add_argument("--other-n", type=float, default=1e7, help="particles per component of those")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--force-comm", action="store_true",
                     help="initialise the process group and run the coefficient all-reduce even at "
@@ -190,6 +207,148 @@ def cpu_baseline(grid, model, nsample, dt):
                       f"slices, per-thread coefficient sums) and {s1} steps of {nsample} on 1 "
                       f"thread; same basis (lmax {grid.lmax}, nmax {grid.nmax}, numr {grid.numr}); "
                       "oracle/bfe_oracle.c, scalar fp64, gcc -O2"}
+
+
+# ---- secondary configurations (BASELINE.json configs 2-4): parity-test workloads, reported as extras ----
+
+def make_disk(n, a, h, seed, device, vscale):
+    """n exponential-disk particles (Sigma ~ exp(-R/a), sech^2(z/h): the reference's conditioning
+    density, src/Cylinder.cc:315-322) on roughly circular orbits, generated in HBM."""
+    import torch
+    gen = torch.Generator(device=device).manual_seed(seed)
+    f64 = torch.float64
+    x = torch.linspace(0.0, 12.0, 16384, device=device, dtype=f64)
+    cdf = 1.0 - (1.0 + x) * torch.exp(-x)
+    cdf = cdf / cdf[-1]
+    u = torch.rand(n, device=device, dtype=f64, generator=gen)
+    idx = torch.searchsorted(cdf, u).clamp_(1, 16383)
+    w = (u - cdf[idx - 1]) / (cdf[idx] - cdf[idx - 1])
+    R = a * (x[idx - 1] + w * (x[idx] - x[idx - 1]))
+    ph = torch.rand(n, device=device, dtype=f64, generator=gen) * (2 * math.pi)
+    uz = torch.rand(n, device=device, dtype=f64, generator=gen).clamp_(1e-12, 1 - 1e-12)
+    z = h * torch.atanh(2 * uz - 1)
+    X, Y = (R * torch.cos(ph)).contiguous(), (R * torch.sin(ph)).contiguous()
+    # roughly circular orbits + dispersion so that the cell order really changes every step
+    vc = vscale * torch.sqrt(R / (R + a))
+    vx = (-vc * torch.sin(ph) + 0.1 * vscale * torch.randn(n, device=device, dtype=f64, generator=gen)).contiguous()
+    vy = (vc * torch.cos(ph) + 0.1 * vscale * torch.randn(n, device=device, dtype=f64, generator=gen)).contiguous()
+    vz = (0.05 * vscale * torch.randn(n, device=device, dtype=f64, generator=gen)).contiguous()
+    return X, Y, z.contiguous(), vx, vy, vz
+
+
+def _timed(fn, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _kernel_fracs(prof, nsteps, n, basis, lmax):
+    """per-kernel ms/step + the dominant kernel's algorithmic-byte and executed-fp64 fractions"""
+    kern = {k: v["ms_total"] / nsteps for k, v in prof.items() if v["launches"] > 0}
+    dom = max(kern, key=kern.get)
+    out = {"kernels_ms_per_step": {k: round(v, 4) for k, v in kern.items()}, "dominant_kernel": dom}
+    t = kern[dom] * 1e-3
+    if dom in ALGO_BYTES:
+        out["dominant_hbm_frac_algorithmic"] = ALGO_BYTES[dom] * n / t / 1e9 / HBM_PEAK_GBS
+    if dom in OWN_BYTES:
+        out["dominant_hbm_frac_own_bytes"] = OWN_BYTES[dom] * n / t / 1e9 / HBM_PEAK_GBS
+    fl = EXEC_FLOPS.get((dom, lmax))
+    if fl:
+        out["dominant_fp64_frac_executed"] = fl * n / t / 1e12 / FP64_VECTOR_PEAK_TF
+        out["dominant_executed_flops_per_particle"] = fl
+    out["reference_flops_per_particle_step"] = REF_FLOPS[basis]
+    return out
+
+
+def other_configs(ctx, device, n, which=(2, 3, 4), steps=30):
+    """BASELINE.json configs 2-4 on one GPU: one dict each."""
+    import torch
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import NFWModel
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    model = NFWModel(rs=1.0, rtrunc=20.0, wtrunc=6.0, rmin=1e-3, rmax=50.0)
+    grid = build_slgrid(model, 6, 18, numr=2000, rmin=1e-3, rmax=49.5, cmap=1, rmap=1.0)
+
+    def halo(scale=1.0, vfac=1.0, mult=0):
+        x, y, z, vx, vy, vz = make_halo(model, n, 23456, device)
+        mass = torch.full((n,), 1.0 / n, device=device, dtype=torch.float64)
+        c = Component(ctx, n)
+        c.upload_device(mass, (x * scale).contiguous(), (y * scale).contiguous(), (z * scale).contiguous(),
+                        (vx * vfac).contiguous(), (vy * vfac).contiguous(), (vz * vfac).contiguous())
+        f = SphereSL(ctx, grid, scale=scale, rmin=grid.rmin * scale, rmax=grid.rmax * scale, multistep=mult)
+        return c, f
+
+    def fused(c, f, dt, basis, lmax, label):
+        f.determine_coefficients(c); c.zero_acceleration(); f.get_acceleration_and_potential(c)
+        el = _timed(lambda: f.step_kdk(c, dt), steps, 3)
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(4):
+            f.step_kdk(c, dt)
+        prof = ctx.profile_report()
+        ctx.profile(False)
+        o = {"config": label, "n": n, "ms_per_step": 1e3 * el, "particle_steps_per_s": n / el,
+             "step_hbm_frac_232B": ALGO_BYTES["step"] * n / el / 1e9 / HBM_PEAK_GBS}
+        o.update(_kernel_fracs(prof, 4, n, basis, lmax))
+        c.close(); f.close()
+        return o
+
+    out = []
+    if 2 in which:
+        c, f = halo()
+        out.append(fused(c, f, 0.002, "S6", 6, "2: NFW halo, SphericalSL lmax 6 nmax 18, fused KDK step"))
+    a, h = 0.01, 0.001
+    cg = None
+    if 3 in which or 4 in which:
+        cg = build_empcyl(mmax=6, norder=12, numx=256, numy=128, acyl=a, hcyl=h, lmaxfid=32,
+                          nmaxfid=24, numr=2000, rnum=200, tnum=80)
+    if 3 in which:
+        X, Y, Z, vx, vy, vz = make_disk(n, a, h, 34567, device, vscale=7.0)
+        mass = torch.full((n,), 1.0 / n, device=device, dtype=torch.float64)
+        c = Component(ctx, n)
+        c.upload_device(mass, X, Y, Z, vx, vy, vz)
+        out.append(fused(c, Cylinder(ctx, cg), 2e-5, "C6", 6,
+                         "3: exponential disk, EmpCylSL mmax 6 nmax 12 (256x128 grid), fused KDK step"))
+    if 4 in which:
+        ms = 4
+        ch, fh = halo(scale=0.1, vfac=math.sqrt(10.0), mult=ms)      # a / rs = 0.1
+        X, Y, Z, vx, vy, vz = make_disk(n, a, h, 34567, device, vscale=7.0)
+        mass = torch.full((n,), 0.1 / n, device=device, dtype=torch.float64)
+        cd = Component(ctx, n)
+        cd.upload_device(mass, X, Y, Z, vx, vy, vz)
+        fd = Cylinder(ctx, cg, multistep=ms)
+        sim = Simulation(ctx, 4e-4, multistep=ms)
+        i1, i2 = sim.add_component(ch, fh), sim.add_component(cd, fd)
+        sim.add_interaction(i1, i2)
+        sim.add_interaction(i2, i1)
+        sim.init()
+        el = _timed(lambda: sim.step(1), max(3, steps // 5), 2)
+        lev_h = np.bincount(ch.download_levels(), minlength=ms + 1)
+        lev_d = np.bincount(cd.download_levels(), minlength=ms + 1)
+        ctx.profile(True); ctx.profile_reset()
+        sim.step(1)
+        prof = {k: round(v["ms_total"], 3) for k, v in ctx.profile_report().items() if v["launches"] > 0}
+        ctx.profile(False)
+        sub = sum(int(lev_h[M] + lev_d[M]) * (1 << M) for M in range(ms + 1))
+        # algorithmic bytes per particle-sub-step: 232 (its own step) + 32 (acc / pot read-modify-write
+        # of the cross force applied to it), SURVEY.md section 8d
+        out.append({"config": "4: disk + halo, SphericalSL lmax 6 nmax 18 + EmpCylSL mmax 6 nmax 12, "
+                              "multistep 4, both self and both cross forces (C++ step driver)",
+                    "n": 2 * n, "ms_per_master_step": 1e3 * el,
+                    "master_step_particle_steps_per_s": 2 * n / el,
+                    "raw_particle_substeps_per_s": sub / el,
+                    "substeps_hbm_frac_264B": 264.0 * sub / el / 1e9 / HBM_PEAK_GBS,
+                    "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist(),
+                    "level_switches_last_master_step": sim.step_switches,
+                    "kernels_ms_per_master_step": prof})
+        sim.close(); ch.close(); cd.close(); fh.close(); fd.close()
+    return out
 
 
 # BASELINE.json's metric, verbatim
@@ -329,20 +488,39 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                      "separate passes, of this command (tools/profile.sh)" if traffic else None,
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_particle": ALGO_BYTES.get(dom, 0.0),
                     "step_achieved": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9,
                     "step_frac": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernels_ms_per_step": {k: v["ms_total"] / args.steps for k, v in kern.items()}}
-            # The binding limit of this kernel is the fp64 vector ALU:
-            # executed flops per particle from the ISA (1024 FMA + 349 mul/add per lane at lmax 10).
-            if dom == "k_sph_force" and args.lmax == 10:
-                tf = 2397.0 * nloc / (avg_ms * 1e-3) / 1e12
-                roof["fp64_vector"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
-                                       "frac": tf / 78.6, "flops_per_particle": 2397.0}
+            # what the kernel itself moves in the fused step (the contract's figure counts the v store
+            # of the closing half-kick, which lives in the next scatter pass here)
+            if dom in OWN_BYTES:
+                own = OWN_BYTES[dom] * nloc / (avg_ms * 1e-3) / 1e9
+                roof["kernel_own_bytes_per_particle"] = OWN_BYTES[dom]
+                roof["kernel_own_achieved"] = own
+                roof["kernel_own_frac"] = own / HBM_PEAK_GBS
+            # The binding limit of this kernel is the fp64 vector ALU: executed
+            # flops per particle from the ISA (tools/isa_count.py).
+            fl = EXEC_FLOPS.get((dom, args.lmax))
+            if fl:
+                tf = fl * nloc / (avg_ms * 1e-3) / 1e12
+                roof["binding_limit"] = "fp64_vector"
+                roof["fp64_vector"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": tf / FP64_VECTOR_PEAK_TF, "flops_per_particle": fl}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(grid, model, args.cpu_sample, args.dt)
+        others = None
+        if not args.no_other_configs and world == 1:
+            # free the headline's 19 GB first; these are extras, a failure must not lose the line
+            comp.close(); force.close()
+            try:
+                others = other_configs(ctx, device, int(args.other_n))
+            except Exception as e:      # pragma: no cover
+                others = [{"error": repr(e)}]
         line = {
             "metric": METRIC,
             "value": value,
@@ -366,11 +544,12 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "selfcheck": selfcheck,
+            "other_configs": others,
         }
         _flush_c_stdio()        # the JSON line is the last thing on stdout
         print(json.dumps(line), flush=True)
 
-    comp.close()
+    comp.close()           # (idempotent)
     force.close()
     ctx.close()
     if use_comm:
