@@ -49,6 +49,9 @@ struct exp_amd_comp {
   // order buys nothing there: it is advanced in place, accumulated with per-particle atomics and its
   // forces take the gather path.  Set by the step driver from the level populations; any per-level
   // call of the plain API clears the bit of the level it sorts.
+  // Every particle has the same mass (found at upload): BOTH buffer sets then hold the constant in their
+  // mass arrays and the scatter passes leave the mass stream alone (16 of their 148 B per particle).
+  bool uniform_mass = false;
   uint32_t sparse_mask = 0;
   // Levels were committed at the end of a master step but the slots not yet re-partitioned: the step
   // driver lets the next master step's first (full) advance sort do it in the same pass.  lev_host

@@ -384,7 +384,8 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     ProfScope ps(ctx, "k_scatter_adv");
     AdvanceArgs A = expamd_advance_args(c, adv);
     ScatterSrc S{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
-    ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
+    ScatterDst D{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ),
+                 c->uniform_mass ? nullptr : c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                  c->levels_zero ? nullptr : c->level[1 - c->cur].p};
     const unsigned g = cdiv(nr, SCAT_TILE);
@@ -687,6 +688,54 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
 
 extern "C" size_t exp_amd_comp_size(const exp_amd_comp *c) { return c ? c->n : 0; }
 
+// min / max of a device array (two atomics per block on the order-preserving bit patterns)
+__global__ void __launch_bounds__(TPB)
+k_minmax(const double *__restrict__ v, size_t n, double *__restrict__ out /* {min, max}, preset */)
+{
+  double lo = 1.0e300, hi = -1.0e300;
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) {
+    const double x = v[i];
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double a = __shfl_xor(lo, off), b = __shfl_xor(hi, off);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    // masses are >= 0: their IEEE bit patterns order like unsigned integers
+    atomicMin((unsigned long long *)out, (unsigned long long)__double_as_longlong(lo < 0.0 ? 0.0 : lo));
+    atomicMax((unsigned long long *)(out + 1), (unsigned long long)__double_as_longlong(hi < 0.0 ? 0.0 : hi));
+  }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_fill_f64(double *__restrict__ v, size_t n, double x)
+{
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) v[i] = x;
+}
+
+// after the mass array was (re)written: is it one value?  Then the other buffer set gets it too.
+static int detect_uniform_mass(exp_amd_comp *c)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  c->uniform_mass = false;
+  if (c->n == 0) return EXP_AMD_OK;
+  double init[2] = {1.0e300, 0.0}, got[2];
+  double *scr = (double *)(c->nswitch.p + 66);   // two spare words of the counter block
+  HIP_TRY(ctx, hipMemcpyAsync(scr, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  k_minmax<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->a(A_M), c->n, scr);
+  HIP_TRY(ctx, hipMemcpyAsync(got, scr, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (got[0] == got[1] && got[0] >= 0.0) {
+    k_fill_f64<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->b(A_M), c->n, got[0]);
+    HIP_TRY(ctx, hipGetLastError());
+    c->uniform_mass = true;
+  }
+  return EXP_AMD_OK;
+}
+
 static int upload_one(exp_amd_comp *c, int a, const double *h)
 {
   exp_amd_ctx *ctx = c->ctx;
@@ -715,7 +764,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
   }
   HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
   c->sorted_for = nullptr;
-  return EXP_AMD_OK;
+  return detect_uniform_mass(c);
 }
 
 extern "C" int exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
@@ -753,7 +802,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   c->sorted_for = nullptr;
-  return EXP_AMD_OK;
+  return detect_uniform_mass(c);
 }
 
 extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)

@@ -258,7 +258,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
     if (!A.advance) { vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i]; }
     D.x[dest] = x; D.y[dest] = y; D.z[dest] = z;
     D.vx[dest] = vx; D.vy[dest] = vy; D.vz[dest] = vz;
-    D.m[dest] = S.m[i];
+    if (D.m) D.m[dest] = S.m[i];            // nullptr: uniform mass, both buffer sets hold it already
     D.id[dest] = S.id[i];
     if (D.lev) D.lev[dest] = A.lev[i];     // nullptr: every level is 0 and stays 0 (single-level runs)
     if (MOVE_ACC) {

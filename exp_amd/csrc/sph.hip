@@ -591,7 +591,8 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   // ---- aux stream: the two sort chains (reading the live set, writing the other one)
   const AdvanceArgs A = expamd_advance_args(c, AdvSpec::step(true, dt_kick, dt));
   const ScatterSrc Ssrc{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
-  const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ), c->b(A_M),
+  const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ),
+                        c->uniform_mass ? nullptr : c->b(A_M),
                         c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                         c->levels_zero ? nullptr : c->level[1 - c->cur].p};
   for (int h = 0; h < 2; h++) {
