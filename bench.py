@@ -79,9 +79,10 @@ def parse_args():
     ap.add_argument("--force-comm", action="store_true",
                     help="initialise the process group and run the coefficient all-reduce even at "
                          "world size 1 (exercises the multi-GPU path on a single-GPU box)")
-    ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
-                    help="coefficient all-reduce through torch.distributed (default) or the "
-                         "library's own RCCL communicator")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="coefficient all-reduce through the library's own RCCL communicator on the "
+                         "compute stream (default; falls back to torch.distributed if its self-check "
+                         "fails) or through a torch.distributed callback")
     return ap.parse_args()
 
 
@@ -413,14 +414,34 @@ def main():
     torch.cuda.empty_cache()
     force = SphereSL(ctx, grid)
 
+    comm_used = "none"
     if use_comm:
+        comm_used = None
         if args.comm == "rccl":
-            ids = [Context.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.init_rccl(ids[0], world, rank)
-        else:
+            # the library's own communicator: id from rank 0 through the process group, then a
+            # known-answer all-reduce (every rank contributes rank + 1) before it is trusted
+            try:
+                ids = [Context.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.init_rccl(ids[0], world, rank)
+                with torch.cuda.stream(tstream):
+                    probe = torch.full((64,), float(rank + 1), device=device, dtype=torch.float64)
+                    ctx.allreduce(probe.data_ptr(), probe.numel())
+                    tstream.synchronize()
+                ok = bool((probe == world * (world + 1) / 2.0).all().item())
+            except Exception as e:          # pragma: no cover
+                print(f"[bench] rank {rank}: native RCCL communicator failed ({e!r})", file=sys.stderr)
+                ok = False
+            flag = torch.tensor([1 if ok else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm_used = "rccl (library communicator, ncclAllReduce on the compute stream)"
+            elif rank == 0:
+                print("[bench] falling back to the torch.distributed all-reduce callback", file=sys.stderr)
+        if comm_used is None:
             from exp_amd.dist import torch_allreduce_callback
             ctx.set_allreduce(torch_allreduce_callback(device))
+            comm_used = "torch.distributed all-reduce callback" + (" (fallback)" if args.comm == "rccl" else "")
 
     def barrier():
         if use_comm:
@@ -540,7 +561,9 @@ def main():
                        "nbodies_total": ntot, "nbodies_per_gpu": nloc, "lmax": args.lmax,
                        "nmax": args.nmax, "numr": args.numr, "dt": args.dt,
                        "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"
-                                      f" ({args.comm})" if world > 1 else "single GPU"},
+                                      if world > 1 else "single GPU",
+                       # which all-reduce really ran, the rank count it saw and how often it was issued
+                       "comm": {"path": comm_used, **ctx.comm_info()}},
             "roofline": roof,
             "cpu_baseline": cpu,
             "selfcheck": selfcheck,

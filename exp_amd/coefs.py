@@ -107,8 +107,15 @@ def read_native_record(inp: BinaryIO, exp_type: bool = True) -> Optional[SphStru
         return None
     rows = np.frombuffer(buf, dtype="<f8").reshape(nmax, nrow).T.copy()
     if exp_type and not normed:
-        # true normed coefficients from a legacy dump (expui/CoefStruct.cc:481-503); the factor of
-        # each (l, m) is applied to its own cosine and sine rows
+        # True normed coefficients from a legacy dump.  This is a CORRECTED reading of the reference's
+        # legacy branch (expui/CoefStruct.cc:481-503), not a statement-for-statement port: there the
+        # running index k walks the rows of the COMPLEX (l, m >= 0) x nmax array but is advanced twice
+        # for m > 0 (as if cosine and sine were separate rows), so the factors land on the wrong rows
+        # for l >= 1 and run past the array; and the header's scale is ignored.  Here the factor of
+        # each (l, m) multiplies its own cosine and sine REAL rows and scale is taken from the header.
+        # Legacy files therefore do not round-trip identically to pyEXP; new-style ("normed") records,
+        # which every current EXP writes, are unaffected.  Pinned by tests/test_coefs_cpu.py::
+        # test_legacy_header_is_normalised.
         off = 0
         for l in range(lmax + 1):
             for m in range(l + 1):

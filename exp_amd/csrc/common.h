@@ -32,6 +32,8 @@ struct exp_amd_ctx {
   // collectives
   void *rccl_lib = nullptr;
   void *rccl_comm = nullptr;
+  void *rccl_allreduce = nullptr;    // ncclAllReduce, resolved once at exp_amd_comm_init_rank
+  unsigned long long ar_calls = 0;   // all-reduces issued so far (either path)
   int nranks = 1, rank = 0;
   exp_amd_allreduce_fn ar_fn = nullptr;
   void *ar_user = nullptr;

@@ -249,6 +249,9 @@ extern "C" int exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int n
   void *comm = nullptr;
   int rc = f(&comm, nranks, id, rank);
   if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclCommInitRank -> %d", rc);
+  void *ar = dlsym(lib, "ncclAllReduce");
+  if (!ar) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce missing");
+  ctx->rccl_allreduce = ar;
   ctx->rccl_lib = lib;
   ctx->rccl_comm = comm;
   ctx->nranks = nranks;
@@ -270,15 +273,36 @@ int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count)
     ProfScope ps(ctx, "allreduce(callback)");
     int rc = ctx->ar_fn((void *)dev, count, (void *)ctx->stream, ctx->ar_user);
     if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "all-reduce callback returned %d", rc);
+    ctx->ar_calls++;
     return EXP_AMD_OK;
   }
   if (ctx->rccl_comm) {
     ProfScope ps(ctx, "ncclAllReduce(coef)");
-    fn_allreduce f = (fn_allreduce)dlsym(ctx->rccl_lib, "ncclAllReduce");
-    if (!f) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce missing");
-    // ncclDouble = 8 (ncclFloat64), ncclSum = 0
+    fn_allreduce f = (fn_allreduce)ctx->rccl_allreduce;
+    // ncclDouble = 8 (ncclFloat64), ncclSum = 0  (rccl.h:448, :467)
     int rc = f(dev, dev, count, 8, 0, ctx->rccl_comm, ctx->stream);
     if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce -> %d", rc);
+    ctx->ar_calls++;
   }
   return EXP_AMD_OK;
+}
+
+// which all-reduce the context uses: kind 0 = none (single rank), 1 = the library's RCCL
+// communicator, 2 = host-provided callback; calls = all-reduces issued so far
+extern "C" int exp_amd_comm_info(exp_amd_ctx *ctx, int *kind, int *nranks, int *rank, long long *calls)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  if (kind) *kind = ctx->ar_fn ? 2 : ctx->rccl_comm ? 1 : 0;
+  if (nranks) *nranks = ctx->nranks;
+  if (rank) *rank = ctx->rank;
+  if (calls) *calls = (long long)ctx->ar_calls;
+  return EXP_AMD_OK;
+}
+
+// in-place sum of `count` doubles at device pointer `dev` over the ranks, on the context's stream:
+// the collective the force methods use, exposed so that a host can check the communicator it set up
+extern "C" int exp_amd_comm_allreduce(exp_amd_ctx *ctx, void *dev, size_t count)
+{
+  if (!ctx || !dev) return EXP_AMD_ERR_ARG;
+  return expamd_allreduce(ctx, (double *)dev, count);
 }

@@ -58,8 +58,9 @@ static int overlap_begin(exp_amd_sim *s)
   bool any_orient = false;
   for (auto o : s->orients) any_orient = any_orient || o;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
+  // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   s->overlap = s->multistep > 0 && s->comps.size() >= 2 && !any_orient && !ctx->ar_fn &&
-               !(env && atoi(env) == 0);     // (a host-provided all-reduce callback owns its stream)
+               ctx->nranks == 1 && !ctx->rccl_comm && !(env && atoi(env) == 0);
   if (!s->overlap) return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);
   if (rc) return rc;
@@ -192,11 +193,14 @@ static int fix_centers(exp_amd_sim *s, int mstep)
       if ((rc = exp_amd_orient_get(o, nullptr, nullptr, body, nullptr, nullptr))) return rc;
       if ((rc = exp_amd_comp_set_orientation(s->comps[k], body))) return rc;
     }
-    if (!s->ej_dryrun[k]) {       // std::tie(accel, omega, domdt) = orient->currentAccel() (src/Component.cc:3571)
+    // std::tie(accel, omega, domdt) = orient->currentAccel() sits inside `if ((EJ & CENTER) &&
+    // !EJdryrun)` (src/Component.cc:3569-3571): with AXIS alone the three stay zero and
+    // getPseudoAccel returns nothing; with CENTER the rotating-frame terms join when AXIS is set too
+    if (!s->ej_dryrun[k] && (exp_amd_orient_flags(o) & 2u)) {
       double acc[3], om[3], dom[3];
       const unsigned fl = exp_amd_orient_flags(o);
       if ((rc = exp_amd_orient_accel(o, acc, om, dom))) return rc;
-      if ((rc = exp_amd_comp_set_pseudo_accel(s->comps[k], (fl & 2u) ? acc : nullptr, (fl & 1u) ? om : nullptr,
+      if ((rc = exp_amd_comp_set_pseudo_accel(s->comps[k], acc, (fl & 1u) ? om : nullptr,
                                               (fl & 1u) ? dom : nullptr))) return rc;
     }
     if (s->gottapot && (rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;

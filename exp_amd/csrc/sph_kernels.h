@@ -1065,11 +1065,15 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     ax += pf2 * yy;
     ay += -pf2 * xx;
   }
-  if (S.ps.center | S.ps.axis) {      // acc += val - pseudo (Component::AddAcc, src/Component.H:914-921)
+  if (S.ps.center | S.ps.axis) {
+    // Component::AddAcc(i, j, val) is acc[j] += val - pseudo[j] on EVERY call (src/Component.H:914-921)
+    // and the reference's thread body calls it for x, y, z and, when fac > DSMALL, for x and y once
+    // more (the potp term, src/SphericalBasis.cc:1645-1651): x and y lose the frame term twice.
     double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
     if (S.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
     pseudo_accel(S.ps, px, py, pz, ux, uy, uz, qx, qy, qz);
     ax -= qx; ay -= qy; az -= qz;
+    if (fac > DSMALL) { ax -= qx; ay -= qy; }
   }
   double pt = potl;
   if (!assign) {

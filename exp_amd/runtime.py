@@ -69,6 +69,18 @@ class Context:
         check(lib.exp_amd_comm_get_unique_id(buf))
         return buf.raw
 
+    def comm_info(self) -> dict:
+        """Which coefficient all-reduce this context uses and how often it ran."""
+        from ctypes import c_longlong
+        kind, nr, rk, calls = c_int(), c_int(), c_int(), c_longlong()
+        check(self.lib.exp_amd_comm_info(self.h, byref(kind), byref(nr), byref(rk), byref(calls)), self.h)
+        return {"kind": ("none", "rccl", "callback")[kind.value], "nranks": nr.value, "rank": rk.value,
+                "allreduce_calls": int(calls.value)}
+
+    def allreduce(self, device_ptr: int, count: int) -> None:
+        """In-place sum over ranks of ``count`` doubles at a device pointer, on the context's stream."""
+        check(self.lib.exp_amd_comm_allreduce(self.h, c_void_p(int(device_ptr)), int(count)), self.h)
+
     def set_dense_min(self, nmin: int) -> None:
         """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
         check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)

@@ -79,6 +79,14 @@ int  exp_amd_comm_get_unique_id(void *id128);
 int  exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int nranks, int rank);
 typedef int (*exp_amd_allreduce_fn)(void *buf, size_t count, void *stream, void *user);
 int  exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn fn, void *user);
+/* Which reduction the context uses -- kind 0: none (single rank), 1: the library's RCCL communicator,
+ * 2: the host's callback -- with the rank count / rank it was given and the number of all-reduces
+ * issued so far; any output pointer may be NULL.                                                */
+int  exp_amd_comm_info(exp_amd_ctx *ctx, int *kind, int *nranks, int *rank, long long *calls);
+/* The collective itself: in-place sum over the ranks of `count` doubles at DEVICE pointer `buf`, on
+ * the context's stream (what replaces MPI_Allreduce, src/SphericalBasis.cc:864-903), so that a host
+ * can verify the communicator it has just set up.                                               */
+int  exp_amd_comm_allreduce(exp_amd_ctx *ctx, void *buf, size_t count);
 
 /* ---- particle store ------------------------------------------------------------------
  * Replaces the CUDA particle mirror of src/cudaComponent.cu:621-727

@@ -344,10 +344,15 @@ static void get_pot_coefs_safe(int l, int nmax, const double *coef, double *p, d
 
 /* src/SphericalBasis.cc:1476-1660 (determine_acceleration_and_potential_thread,
  * mix off, use_external handled by the caller supplying positions + centre)      */
-void orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
-                   const double *X, const double *Y, const double *Z,
-                   const double *center, const double *expcoef,
-                   double *AX, double *AY, double *AZ, double *POT)
+/* PS (may be NULL): per-particle pseudo-acceleration [n][3] of the target component's frame,
+ * Component::getPseudoAccel(pos, vel) (src/Component.cc:4407-4427).  Component::AddAcc(i, j, val) does
+ * acc[j] += val - pseudo[j] on EVERY call (src/Component.H:914-921), and the thread body makes five
+ * of them (:1645-1651): x, y, z, and x, y once more for the potp term when fac > DSMALL.  So with EJ
+ * on, the reference subtracts the x and y components TWICE; restated as written.                */
+static void sph_accel_addacc(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
+                             const double *X, const double *Y, const double *Z,
+                             const double *center, const double *expcoef, const double *PS,
+                             double *AX, double *AY, double *AZ, double *POT)
 {
   const int Lmax = g->lmax, nmax = g->nmax, lmax = g->lmax;
   const double scale = P->scale, rmax = P->rmax;
@@ -454,12 +459,13 @@ void orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
     potp /= scale;
 
     /* note: for r>rmax the reference divides by the CLAMPED r (= rmax) here */
-    AX[i] += -(potr * xx / r - pott * xx * zz / (r * r * r));
-    AY[i] += -(potr * yy / r - pott * yy * zz / (r * r * r));
-    AZ[i] += -(potr * zz / r + pott * fac / (r * r * r));
+    const double ps0 = PS ? PS[3 * i] : 0.0, ps1 = PS ? PS[3 * i + 1] : 0.0, ps2 = PS ? PS[3 * i + 2] : 0.0;
+    AX[i] += -(potr * xx / r - pott * xx * zz / (r * r * r)) - ps0;
+    AY[i] += -(potr * yy / r - pott * yy * zz / (r * r * r)) - ps1;
+    AZ[i] += -(potr * zz / r + pott * fac / (r * r * r)) - ps2;
     if (fac > DSMALL) {
-      AX[i] += potp * yy / fac;
-      AY[i] += -potp * xx / fac;
+      AX[i] += potp * yy / fac - ps0;
+      AY[i] += -potp * xx / fac - ps1;
     }
     POT[i] += potl;
   }
@@ -467,6 +473,22 @@ void orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
 #undef COEF
 
   free(p); free(dp); free(cosm); free(sinm); free(potd); free(dpot); free(factorial);
+}
+
+void orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
+                   const double *X, const double *Y, const double *Z,
+                   const double *center, const double *expcoef,
+                   double *AX, double *AY, double *AZ, double *POT)
+{
+  sph_accel_addacc(g, P, nbodies, X, Y, Z, center, expcoef, NULL, AX, AY, AZ, POT);
+}
+
+void orc_sph_accel_pseudo(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
+                          const double *X, const double *Y, const double *Z,
+                          const double *center, const double *expcoef, const double *pseudo,
+                          double *AX, double *AY, double *AZ, double *POT)
+{
+  sph_accel_addacc(g, P, nbodies, X, Y, Z, center, expcoef, pseudo, AX, AY, AZ, POT);
 }
 
 /* src/incpos.cc:15-69 */

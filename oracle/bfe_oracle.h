@@ -72,6 +72,14 @@ void   orc_sph_accel(const orc_slgrid *g, const orc_sph_params *P, long n,
                      const double *center, const double *coef,
                      double *ax, double *ay, double *az, double *pot);
 
+/* ... with the target component's frame pseudo-acceleration pseudo[n][3] (Component::getPseudoAccel)
+ * subtracted by every Component::AddAcc call the thread body makes (src/Component.H:914-921,
+ * src/SphericalBasis.cc:1645-1651): once for z, TWICE for x and y when x^2 + y^2 > DSMALL. */
+void   orc_sph_accel_pseudo(const orc_slgrid *g, const orc_sph_params *P, long n,
+                            const double *x, const double *y, const double *z,
+                            const double *center, const double *coef, const double *pseudo,
+                            double *ax, double *ay, double *az, double *pot);
+
 /* leapfrog pieces (src/incpos.cc:15-69, src/incvel.cc:15-88) */
 void   orc_drift(long n, double dt, double *x, double *y, double *z,
                  const double *vx, const double *vy, const double *vz);

@@ -396,6 +396,20 @@ class Oracle:
                                _dp(pot))
         return np.stack([ax, ay, az], axis=1), pot
 
+    def sph_accel_pseudo(self, g, prm, pos, coef, pseudo, center=(0.0, 0.0, 0.0)):
+        """orc_sph_accel with Component::AddAcc's pseudo-acceleration (one row per particle) subtracted
+        on each of the reference's five AddAcc calls (src/SphericalBasis.cc:1645-1651)."""
+        G = self.grid(g)
+        n = pos.shape[0]
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        c = np.asarray(center, dtype=np.float64)
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        ps = np.ascontiguousarray(pseudo, dtype=np.float64)
+        ax, ay, az, pot = [np.zeros(n) for _ in range(4)]
+        self.lib.orc_sph_accel_pseudo(ctypes.byref(G), ctypes.byref(prm), ctypes.c_long(n), _dp(x), _dp(y),
+                                      _dp(z), _dp(c), _dp(cf), _dp(ps), _dp(ax), _dp(ay), _dp(az), _dp(pot))
+        return np.stack([ax, ay, az], axis=1), pot
+
     def sph_step(self, g, prm, dt, pos, vel, acc, mass, center=(0.0, 0.0, 0.0)):
         """In-place KDK step on copies; returns (pos, vel, acc, pot, coef)."""
         G = self.grid(g)

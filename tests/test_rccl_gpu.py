@@ -1,0 +1,66 @@
+"""The library's own RCCL communicator (exp_amd_comm_get_unique_id / exp_amd_comm_init_rank,
+exp_amd/csrc/context.hip): the ONE on-stream ncclAllReduce of the coefficient buffer that replaces the
+(L+1)^2 MPI_Allreduce calls of src/SphericalBasis.cc:864-903 and the two of
+exputil/EmpCylSL.cc:4188-4222.  RCCL accepts a one-rank communicator, so the path -- symbol binding,
+communicator, the collective on the compute stream inside accumulate / fused step / the multistep
+driver -- runs on the single GPU of the test box; the sum over one rank must leave every result
+bit-identical to the run without a communicator.  GPU only."""
+import numpy as np
+import pytest
+
+from tests.conftest import make_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(with_rccl):
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, Simulation, SphereSL
+    ctx = Context(0)
+    if with_rccl:
+        ctx.init_rccl(Context.rccl_unique_id(), 1, 0)
+        info = ctx.comm_info()
+        assert info["kind"] == "rccl" and info["nranks"] == 1 and info["rank"] == 0
+    else:
+        assert ctx.comm_info()["kind"] == "none"
+    model, g = make_grid("plummer", 4, 8, 400)
+    m, pos, vel = sample_sphere(model, 30000, seed=5)
+    out = {}
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    f.determine_coefficients(c)
+    out["coef"] = f.get_coefs().copy()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    for _ in range(3):
+        f.step_kdk(c, 0.01)
+    out["step"] = c.download()
+    n_single = ctx.comm_info()["allreduce_calls"]
+    c.close(); f.close()
+    # block multistep: the per-sub-step level block and the level-change differences are reduced too
+    f = SphereSL(ctx, g, multistep=2)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    sim = Simulation(ctx, 0.05, multistep=2)
+    sim.add_component(c, f)
+    sim.init()
+    sim.step(2)
+    out["ms"] = c.download()
+    out["lev"] = c.download_levels()
+    out["calls"] = (n_single, ctx.comm_info()["allreduce_calls"])
+    sim.close(); c.close(); f.close(); ctx.close()
+    return out
+
+
+def test_native_rccl_communicator_one_rank():
+    ref = _run(False)
+    got = _run(True)
+    assert ref["calls"] == (0, 0)
+    # accumulate + 3 fused steps = 4 reductions; the multistep run adds one per sub-step and one per
+    # level sweep with changes
+    assert got["calls"][0] == 4 and got["calls"][1] > got["calls"][0] + 2 * 4
+    assert np.array_equal(got["coef"], ref["coef"]) or \
+        np.abs(got["coef"] - ref["coef"]).max() <= 1e-13 * np.abs(ref["coef"]).max()   # (atomics: not bitwise)
+    for key in ("step", "ms"):
+        for k in ("pos", "vel", "acc", "pot"):
+            assert np.abs(got[key][k] - ref[key][k]).max() <= 1e-10 * np.abs(ref[key][k]).max(), (key, k)
+    assert (got["lev"] != ref["lev"]).mean() < 1e-3 and ref["lev"].max() > 0
