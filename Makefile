@@ -14,7 +14,7 @@ BASE_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(BASE_SRC))
 INST_OBJ := $(foreach l,$(SPH_LS),$(OBJ)/sph_inst_L$(l).o)
 HDRS     := $(wildcard $(CSRC)/*.h) include/exp_amd.h
 
-all: lib oracle h5
+all: lib oracle h5 adaptor
 lib: exp_amd/libexp_amd.so
 oracle:
 	$(MAKE) -C oracle
@@ -39,8 +39,15 @@ $(OBJ)/sph_inst_L%.o: $(CSRC)/sph_inst.hip $(HDRS)
 exp_amd/libexp_amd.so: $(BASE_OBJ) $(INST_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
+# the C++ adaptor (include/exp_amd_potaccel.hpp) and its no-Python test, built with g++ against the C ABI
+adaptor: build/test_potaccel
+build/test_potaccel: tests/cpp/test_potaccel.cpp include/exp_amd_potaccel.hpp include/exp_amd.h exp_amd/libexp_amd.so
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude $< -o $@ -Lexp_amd -lexp_amd \
+	    -Wl,-rpath,'$$ORIGIN/../exp_amd' -Wl,-rpath-link,/opt/rocm/lib
+
 clean:
 	rm -rf build exp_amd/libexp_amd.so exp_amd/libexp_amd_h5.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle h5 clean
+.PHONY: all lib oracle h5 adaptor clean

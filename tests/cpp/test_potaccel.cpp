@@ -1,0 +1,211 @@
+// Drives the C++ adaptor (include/exp_amd_potaccel.hpp) the way EXP's step loop drives a PotAccel --
+// no Python in the process: a multistep=0 KDK step (do_step, src/step.cc:271-323) and begin_run + one
+// block-multistep master step (src/begin.cc:80-129, src/step.cc:98-269) of a sphereSL component,
+// checked against the oracle's results stored in tests/golden/adaptor_case.bin
+// (tests/golden/make_adaptor_case.py).  Build and run: see tests/test_adaptor_gpu.py / Makefile.
+//
+//   test_potaccel <path to adaptor_case.bin>      exit code 0 = all checks passed
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "exp_amd_potaccel.hpp"
+
+using exp_amd::ComponentView;
+
+// a Component reduced to what the adaptor asks of it
+struct VecComponent : ComponentView {
+  std::vector<double> m, x, y, z, vx, vy, vz, ax, ay, az, pot;
+  std::vector<std::int32_t> level;
+  explicit VecComponent(std::size_t n)
+      : m(n), x(n), y(n), z(n), vx(n), vy(n), vz(n), ax(n, 0.0), ay(n, 0.0), az(n, 0.0), pot(n, 0.0), level(n, 0) {}
+  std::size_t Number() const override { return m.size(); }
+  void gather(double *M, double *X, double *Y, double *Z, double *VX, double *VY, double *VZ, double *AX,
+              double *AY, double *AZ, double *POT, std::int32_t *LEV) const override
+  {
+    auto cp = [&](double *dst, const std::vector<double> &src) { if (dst) std::memcpy(dst, src.data(), src.size() * sizeof(double)); };
+    cp(M, m); cp(X, x); cp(Y, y); cp(Z, z); cp(VX, vx); cp(VY, vy); cp(VZ, vz); cp(AX, ax); cp(AY, ay); cp(AZ, az); cp(POT, pot);
+    if (LEV) std::memcpy(LEV, level.data(), level.size() * sizeof(std::int32_t));
+  }
+  void scatter(const double *X, const double *Y, const double *Z, const double *VX, const double *VY,
+               const double *VZ, const double *AX, const double *AY, const double *AZ, const double *POT,
+               const std::int32_t *LEV) override
+  {
+    auto cp = [&](std::vector<double> &dst, const double *src) { if (src) std::memcpy(dst.data(), src, dst.size() * sizeof(double)); };
+    cp(x, X); cp(y, Y); cp(z, Z); cp(vx, VX); cp(vy, VY); cp(vz, VZ); cp(ax, AX); cp(ay, AY); cp(az, AZ); cp(pot, POT);
+    if (LEV) std::memcpy(level.data(), LEV, level.size() * sizeof(std::int32_t));
+  }
+};
+
+static std::vector<double> rd(std::ifstream &f, std::size_t n)
+{
+  std::vector<double> v(n);
+  f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * sizeof(double)));
+  return v;
+}
+
+static int failures = 0;
+static void expect(const char *what, double err, double tol)
+{
+  const bool ok = err <= tol;
+  std::printf("%-44s err %.3e  tol %.1e  %s\n", what, err, tol, ok ? "ok" : "FAIL");
+  if (!ok) failures++;
+}
+static double maxabs(const std::vector<double> &a) { double s = 0; for (double v : a) s = std::fmax(s, std::fabs(v)); return s; }
+static double maxdiff3(const std::vector<double> &a, const std::vector<double> &b, const std::vector<double> &c,
+                       const std::vector<double> &ref /* [n][3] */)
+{
+  double s = 0;
+  for (std::size_t i = 0; i < a.size(); i++) {
+    s = std::fmax(s, std::fabs(a[i] - ref[3 * i]));
+    s = std::fmax(s, std::fabs(b[i] - ref[3 * i + 1]));
+    s = std::fmax(s, std::fabs(c[i] - ref[3 * i + 2]));
+  }
+  return s;
+}
+static double maxdiff(const std::vector<double> &a, const std::vector<double> &ref)
+{
+  double s = 0;
+  for (std::size_t i = 0; i < a.size(); i++) s = std::fmax(s, std::fabs(a[i] - ref[i]));
+  return s;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) { std::fprintf(stderr, "usage: %s adaptor_case.bin\n", argv[0]); return 2; }
+  std::ifstream f(argv[1], std::ios::binary);
+  char magic[8];
+  f.read(magic, 8);
+  if (!f || std::memcmp(magic, "EXPAMD01", 8) != 0) { std::fprintf(stderr, "bad fixture\n"); return 2; }
+  std::int32_t hd[6];
+  f.read(reinterpret_cast<char *>(hd), sizeof(hd));
+  const int lmax = hd[0], nmax = hd[1], numr = hd[2], cmap = hd[3], n = hd[4], ms = hd[5];
+  double sc[8], dyn[5];
+  f.read(reinterpret_cast<char *>(sc), sizeof(sc));
+  f.read(reinterpret_cast<char *>(dyn), sizeof(dyn));
+  long long nsw_ref = 0, used_ref = 0;
+  f.read(reinterpret_cast<char *>(&nsw_ref), sizeof(nsw_ref));
+  f.read(reinterpret_cast<char *>(&used_ref), sizeof(used_ref));
+  const double rmap = sc[0], scale = sc[1], rmin = sc[2], rmax = sc[3], xmin = sc[4], dxi = sc[5], dt = sc[6], dtime = sc[7];
+  const std::size_t ncoef = (std::size_t)(lmax + 1) * (lmax + 1) * nmax;
+  auto xi = rd(f, numr), p0 = rd(f, numr), ev = rd(f, (std::size_t)(lmax + 1) * nmax),
+       ef = rd(f, (std::size_t)(lmax + 1) * nmax * numr), mass = rd(f, n), pos = rd(f, 3 * (std::size_t)n),
+       vel = rd(f, 3 * (std::size_t)n), coef0 = rd(f, ncoef), acc0 = rd(f, 3 * (std::size_t)n), pot0 = rd(f, n),
+       spos = rd(f, 3 * (std::size_t)n), svel = rd(f, 3 * (std::size_t)n), sacc = rd(f, 3 * (std::size_t)n),
+       spot = rd(f, n), scoef = rd(f, ncoef);
+  std::vector<std::int32_t> mlev(n);
+  f.read(reinterpret_cast<char *>(mlev.data()), (std::streamsize)(n * sizeof(std::int32_t)));
+  auto mpos = rd(f, 3 * (std::size_t)n), mvel = rd(f, 3 * (std::size_t)n), macc = rd(f, 3 * (std::size_t)n), mcoef = rd(f, ncoef);
+  if (!f) { std::fprintf(stderr, "short fixture\n"); return 2; }
+
+  auto fresh = [&]() {
+    VecComponent c((std::size_t)n);
+    for (int i = 0; i < n; i++) {
+      c.m[i] = mass[i];
+      c.x[i] = pos[3 * i]; c.y[i] = pos[3 * i + 1]; c.z[i] = pos[3 * i + 2];
+      c.vx[i] = vel[3 * i]; c.vy[i] = vel[3 * i + 1]; c.vz[i] = vel[3 * i + 2];
+    }
+    return c;
+  };
+  try {
+    exp_amd::Context ctx(0);
+    // ---- multistep = 0: initial field, then do_step's KDK block (src/step.cc:271-323) ---------------
+    {
+      VecComponent comp = fresh();
+      exp_amd::Mirror mirror(ctx);
+      exp_amd_sph_config cfg{lmax, nmax, numr, cmap, rmap, scale, rmin, rmax, xmin, dxi, 0, 0, 0, 0, 0, 0};
+      exp_amd::SphereAMD force(ctx, mirror, &comp, cfg, xi.data(), p0.data(), ev.data(), ef.data());
+      // begin_run: compute_expansion(0); compute_potential(0)
+      force.set_multistep_level(0);
+      force.determine_coefficients(&comp);
+      exp_amd::zero_acceleration(ctx, mirror, &comp, 0);
+      force.get_acceleration_and_potential(&comp);
+      mirror.download(&comp);
+      const double cmax = maxabs(coef0), amax = maxabs(acc0);
+      expect("coefficients (begin_run)", maxdiff(force.get_coefs(), coef0), 1e-10 * cmax);
+      expect("accelerations (begin_run)", maxdiff3(comp.ax, comp.ay, comp.az, acc0), 1e-9 * amax);
+      expect("potential (begin_run)", maxdiff(comp.pot, pot0), 1e-9 * maxabs(pot0));
+      // do_step
+      exp_amd::incr_velocity(ctx, mirror, &comp, 0.5 * dt);
+      exp_amd::incr_position(ctx, mirror, &comp, dt);
+      force.set_multistep_level(0);
+      force.determine_coefficients(&comp);
+      exp_amd::zero_acceleration(ctx, mirror, &comp, 0);
+      force.get_acceleration_and_potential(&comp);
+      exp_amd::incr_velocity(ctx, mirror, &comp, 0.5 * dt);
+      mirror.download(&comp);
+      expect("positions after one KDK step", maxdiff3(comp.x, comp.y, comp.z, spos), 1e-12);
+      expect("velocities after one KDK step", maxdiff3(comp.vx, comp.vy, comp.vz, svel), 1e-9 * maxabs(svel));
+      expect("accelerations after one KDK step", maxdiff3(comp.ax, comp.ay, comp.az, sacc), 1e-9 * maxabs(sacc));
+      expect("potential after one KDK step", maxdiff(comp.pot, spot), 1e-9 * maxabs(spot));
+      expect("coefficients after one KDK step", maxdiff(force.get_coefs(), scoef), 1e-10 * maxabs(scoef));
+      (void)used_ref;      // (the stored count is that of the INITIAL accumulation; one particle may cross rmax in the step)
+      expect("PotAccel::Used()", std::fabs((double)(force.Used() - used_ref)), 1.0);
+    }
+    // ---- block multistep: begin_run + one master step, call for call as the reference's loop ---------
+    {
+      VecComponent comp = fresh();
+      exp_amd::Mirror mirror(ctx);
+      exp_amd_sph_config cfg{lmax, nmax, numr, cmap, rmap, scale, rmin, rmax, xmin, dxi, 0, 0, 0, 0, 0, ms};
+      exp_amd::SphereAMD force(ctx, mirror, &comp, cfg, xi.data(), p0.data(), ev.data(), ef.data());
+      const int Mstep = 1 << ms;
+      std::vector<int> mintvl(ms + 1), mfirst(Mstep + 1, 0);            // src/multistep.cc:630-680
+      mintvl[0] = Mstep;
+      for (int k = 1; k <= ms; k++) mintvl[k] = mintvl[k - 1] / 2;
+      for (int s = 0; s <= Mstep; s++)
+        for (int M = 0; M <= ms; M++)
+          if (s == 0 || s % (1 << (ms - M)) == 0) { mfirst[s] = M; break; }
+      auto compute_expansion = [&](int M) { force.set_multistep_level((unsigned)M); force.determine_coefficients(&comp); };
+      auto compute_potential = [&](int mlevel, int mdrft) {
+        exp_amd::zero_acceleration(ctx, mirror, &comp, mlevel);
+        force.set_multistep_level((unsigned)mlevel);
+        force.set_mdrft(mdrft);
+        force.get_acceleration_and_potential(&comp);
+      };
+      long long nswitch = 0;
+      // begin_run (src/begin.cc:80-129)
+      force.multistep_reset();
+      for (int M = 0; M <= ms; M++) compute_expansion(M);
+      compute_potential(0, 0);
+      force.multistep_update_begin();
+      force.multistep_update_device(&comp, dtime, dyn, 0, 0, true);
+      force.multistep_update_finish();
+      force.multistep_reset();
+      for (int M = 0; M <= ms; M++) compute_expansion(M);
+      compute_potential(0, 0);
+      // do_step (src/step.cc:98-269)
+      force.multistep_reset();
+      const double dts = dtime / Mstep;
+      for (int mstep = 0; mstep < Mstep; mstep++) {
+        for (int M = mfirst[mstep]; M <= ms; M++) {
+          const double DT = dts * mintvl[M];
+          exp_amd::incr_velocity(ctx, mirror, &comp, 0.5 * DT, M);
+          exp_amd::incr_position(ctx, mirror, &comp, DT, M);
+          compute_expansion(M);
+        }
+        const int mdrft = mstep + 1;
+        compute_potential(mfirst[mstep], mdrft);
+        for (int M = mfirst[mdrft]; M <= ms; M++) exp_amd::incr_velocity(ctx, mirror, &comp, 0.5 * dts * mintvl[M], M);
+        force.multistep_update_begin();
+        nswitch += force.multistep_update_device(&comp, dtime, dyn, 0, mdrft, mstep == 0);
+        force.multistep_update_finish();
+      }
+      mirror.download(&comp);
+      int nlev = 0;
+      for (int i = 0; i < n; i++) nlev += comp.level[i] != mlev[i];
+      expect("multistep: levels (mismatches)", (double)nlev, 0.0);
+      expect("multistep: level changes", std::fabs((double)(nswitch - nsw_ref)), 0.0);
+      expect("multistep: positions", maxdiff3(comp.x, comp.y, comp.z, mpos), 1e-11);
+      expect("multistep: velocities", maxdiff3(comp.vx, comp.vy, comp.vz, mvel), 1e-9 * maxabs(mvel));
+      expect("multistep: accelerations", maxdiff3(comp.ax, comp.ay, comp.az, macc), 1e-8 * maxabs(macc));
+      expect("multistep: combined coefficients", maxdiff(force.get_coefs(), mcoef), 1e-10 * maxabs(mcoef));
+    }
+  } catch (const exp_amd::Error &e) {
+    std::fprintf(stderr, "exp_amd::Error: %s\n", e.what());
+    return 3;
+  }
+  std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,39 @@
+"""The C++ adaptor include/exp_amd_potaccel.hpp (PotAccel's method names over the C ABI, SURVEY
+section 8b) driven by a g++-built program with no Python in the process: begin_run + one KDK step at
+multistep 0 (src/step.cc:271-323) and begin_run + one block-multistep master step (src/step.cc:98-269)
+of a sphereSL component, against the oracle's results frozen in tests/golden/adaptor_case.bin.
+The CPU half checks that the adaptor compiles and links against nothing but the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "test_potaccel")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "adaptor"], cwd=ROOT)
+    assert os.path.exists(EXE)
+
+
+def test_adaptor_builds_against_the_c_abi_only():
+    _build()
+    # the header includes nothing but the C ABI and the standard library
+    txt = open(os.path.join(ROOT, "include", "exp_amd_potaccel.hpp")).read()
+    incs = [l.split()[1] for l in txt.splitlines() if l.startswith("#include")]
+    assert all(i.startswith("<") or i == '"exp_amd.h"' for i in incs), incs
+    # ... and the program links the product library, not the oracle
+    out = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
+    assert "libexp_amd.so" in out and "oracle" not in out
+
+
+@pytest.mark.gpu
+def test_adaptor_drives_kdk_and_multistep_without_python():
+    if not os.path.exists(EXE):
+        _build()
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "adaptor_case.bin")], capture_output=True,
+                       text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and r.stdout.count(" ok") >= 15
