@@ -255,6 +255,20 @@ class SphericalSL(BiorthBasis):
         self.force = SphereSL(self.ctx, self.grid, scale=self.scale, rmin=rmin, rmax=rmax, **flags)
         _lib_check = self.force.lib.exp_amd_sph_set_exterior(self.force.h, 0)   # pyEXP semantics
         assert _lib_check == 0
+        # N1, N2: the radial window of the l >= 1 sums in computeAccel / sph_eval
+        # (expui/BiorthBasis.cc:761, :780, :876, :894; the l = 0 term takes every n).  The reference
+        # reads both keys with `.as<bool>()` (:264-265), so the only values a YAML file can give them
+        # are booleans, stored as 0 / 1; anything else makes yaml-cpp throw, and is refused here too.
+        self.N1, self.N2 = 0, np.iinfo(np.int32).max
+        for key in ("N1", "N2"):
+            if key in conf:
+                v = conf[key]
+                if isinstance(v, str) and v.strip().lower() in ("true", "yes", "on", "y", "false", "no", "off", "n"):
+                    v = v.strip().lower() in ("true", "yes", "on", "y")
+                if not isinstance(v, bool) and v not in (0, 1):
+                    raise RuntimeError(f"Basis::Basis::Spherical: {key} is read as a boolean by the reference "
+                                       f"(expui/BiorthBasis.cc:264-265); <{conf[key]}> does not convert")
+                setattr(self, key, int(bool(v)))
         self.nrows = (self.lmax + 1) ** 2
         self.expcoef = np.zeros((self.nrows, self.nmax))
         self.used = 0
@@ -367,10 +381,15 @@ class SphericalSL(BiorthBasis):
         if getattr(self, "pcavar", False):                   # zero_covariance (:478)
             self.force.cov_reset()
 
+    def _dsmall(self, v: float) -> None:
+        from ._lib import check
+        check(self.force.lib.exp_amd_sph_set_dsmall(self.force.h, float(v)), self.ctx.h)
+
     def _accumulate_batch(self, m, pos, seq=None) -> None:
         if len(m) == 0:
             return
         c = Component.from_arrays(self.ctx, m, pos)
+        self._dsmall(1.0e-20)                                # Spherical::accumulate (:588)
         self.force.determine_coefficients(c)
         self.expcoef += self.force.get_coefs()
         if getattr(self, "pcavar", False):                   # the pcavar block of accumulate (:613-660)
@@ -413,8 +432,19 @@ class SphericalSL(BiorthBasis):
                 L0 += 1
         self.coefret = SphStruct(self.lmax, self.nmax, self.scale, time, cf, self.coefctr.copy(),
                                  self.coefrot.copy())
-        self.force.set_coefs(self.expcoef)
+        self.force.set_coefs(self._windowed(self.expcoef))
         return self.coefret
+
+    def _windowed(self, expcoef: np.ndarray) -> np.ndarray:
+        """The coefficient set the EVALUATIONS see: rows of l >= 1 restricted to n in
+        [max(0, N1), min(nmax-1, N2)]; the monopole row keeps every n, as in the reference."""
+        lo, hi = max(0, self.N1), min(self.nmax - 1, self.N2)
+        if lo == 0 and hi == self.nmax - 1:
+            return expcoef
+        w = expcoef.copy()
+        w[1:, :lo] = 0.0
+        w[1:, hi + 1:] = 0.0
+        return w
 
     def set_coefs(self, coef: SphStruct) -> None:
         """expui/BiorthBasis.cc:519-581"""
@@ -435,10 +465,16 @@ class SphericalSL(BiorthBasis):
                 L0 += 1
         self.coefret = coef
         self.coefctr = np.asarray(coef.ctr, dtype=np.float64) if np.size(coef.ctr) else np.zeros(3)
-        self.force.set_coefs(self.expcoef)
+        self.force.set_coefs(self._windowed(self.expcoef))
 
     def _accel(self, pos: np.ndarray) -> np.ndarray:
+        """``Spherical::computeAccel`` (expui/BiorthBasis.cc:818-926): the tables at r/scale whatever r
+        is (no exterior continuation: exp_amd_sph_set_exterior(0)).  One deliberate difference: ON the
+        polar axis the reference divides the azimuthal term by x^2 + y^2 = 0 and returns NaN in x and
+        y; the device guards that term (x^2 + y^2 > 1e-16, as the n-body force does) and returns the
+        finite limit."""
         c = Component.from_arrays(self.ctx, np.ones(len(pos)), pos)
+        self._dsmall(1.0e-18)                                # Spherical::computeAccel (:824-825)
         self.force.get_acceleration_and_potential(c, external=True)
         acc = c.download(("acc",))["acc"]
         c.close()
@@ -591,11 +627,12 @@ class Cylindrical(BiorthBasis):
         self.force.cylmass = self.cylmass
 
     def _accel(self, pos: np.ndarray) -> np.ndarray:
-        c = Component.from_arrays(self.ctx, np.ones(len(pos)), pos)
-        self.force.get_acceleration_and_potential(c, external=True)
-        acc = c.download(("acc",))["acc"]
-        c.close()
-        return acc
+        """``Cylindrical::computeAccel`` (expui/BiorthBasis.cc:1804-1821): ``accumulated_eval``
+        projected on x, y, z -- no taper, no monopole continuation beyond the table (those belong to
+        the n-body ``Cylinder``, src/Cylinder.cc:1364-1414): the force columns of crt_eval."""
+        if len(pos) == 0:
+            return np.zeros((0, 3))
+        return self.force.fields(pos[:, 0], pos[:, 1], pos[:, 2], "cartesian")[:, 6:9].copy()
 
 
 class Basis:

@@ -248,6 +248,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
   S.no_exterior = 0;
+  S.dsmall = DSMALL;
   S.xi_uniform = 1;                            // same two roundings as the device's mul_then_add
   for (int i = 0; i < numr && S.xi_uniform; i++) {
     volatile double t = cfg->dxi * (double)i;
@@ -751,6 +752,18 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 // (src/SphericalBasis.cc:1555-1560, :1605-1628); pyEXP's Spherical::computeAccel does not
 // (expui/BiorthBasis.cc:818-926: the tables are simply evaluated at r/scale).  mode 1 = n-body
 // (default), 0 = pyEXP.
+// The small number added to r before any division: src/expand.H:130 DSMALL = 1e-16 in the n-body code
+// (the default); pyEXP's Spherical::accumulate uses 1e-20 and computeAccel 1e-18 (expui/BiorthBasis.cc:
+// 588, :824-825).  It only matters at the origin and ON the polar axis, where cos(theta) = z / (|z| +
+// dsmall) is or is not exactly 1: sin(theta) = 2.6e-8 against 0.
+extern "C" int exp_amd_sph_set_dsmall(exp_amd_force *fb, double dsmall)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f || !(dsmall >= 0.0)) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_dsmall: not a sphereSL force");
+  f->dev.dsmall = dsmall;
+  return EXP_AMD_OK;
+}
+
 extern "C" int exp_amd_sph_set_exterior(exp_amd_force *fb, int continuation)
 {
   SphForce *f = dynamic_cast<SphForce *>(fb);

@@ -44,6 +44,7 @@ struct SphDev {
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
   int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
+  double dsmall;         // added to r (src/expand.H:130: 1e-16; pyEXP: 1e-20 accumulating, 1e-18 evaluating)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
   const double *xi;      // [numr]
@@ -329,7 +330,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   if (valid) { xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz; }
   // src/SphericalBasis.cc:486-494
   const double R2 = xx * xx + yy * yy;
-  const double r = sqrt(R2 + zz * zz) + DSMALL;
+  const double r = sqrt(R2 + zz * zz) + S.dsmall;
   const bool inwin = valid && r >= S.rmin && r <= S.rmax;
   const double ir = 1.0 / r;
   in.costh = zz * ir;
@@ -986,7 +987,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     // agree with the reference's formulas to a few ulp).  Lanes on the polar axis, where the
     // reference clamps x (src/Basis.cc:81-84), outside rmax, or waves spanning several radial
     // cells are left to the general pass.
-    r = sqrt(fac + zz * zz) + DSMALL;                        // src/SphericalBasis.cc:1545-1560
+    r = sqrt(fac + zz * zz) + S.dsmall;                      // src/SphericalBasis.cc:1545-1560
     ir = 1.0 / r;
     const double costh = zz * ir;
     const double R = sqrt(fac), iR = 1.0 / R;
@@ -1016,7 +1017,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     o = sph_field_fast<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
   } else {
     // src/SphericalBasis.cc:1545-1560
-    r = sqrt(fac + zz * zz) + DSMALL;
+    r = sqrt(fac + zz * zz) + S.dsmall;
     const double costh = zz / r;
     double cphi, sphi;
     phi_trig(xx, yy, cphi, sphi);

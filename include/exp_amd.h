@@ -197,6 +197,10 @@ void exp_amd_force_destroy(exp_amd_force *f);
  * force (src/SphericalBasis.cc:1555-1560, :1605-1628); 0: tables evaluated at r/scale as in
  * pyEXP's Spherical::computeAccel (expui/BiorthBasis.cc:818-926).                          */
 int  exp_amd_sph_set_exterior(exp_amd_force *f, int continuation);
+/* The small number added to r before any division: 1e-16 (DSMALL, src/expand.H:130) by default, as in
+ * the n-body code; pyEXP's Spherical::accumulate adds 1e-20 and computeAccel 1e-18
+ * (expui/BiorthBasis.cc:588, :824-825).  Only the origin and the polar axis can tell them apart.  */
+int  exp_amd_sph_set_dsmall(exp_amd_force *f, double dsmall);
 
 /* PotAccel::set_multistep_level (src/PotAccel.H:285) */
 int  exp_amd_force_set_level(exp_amd_force *f, int mlevel);

@@ -928,6 +928,9 @@ static void pyexp_sph_eval(const orc_slgrid *g, const orc_sph_params *P, const d
   }
 
   double den1 = 0.0, pot1 = 0.0, pott = 0.0, potp = 0.0;
+  /* the radial window of the l >= 1 sums (:761, :780); the l = 0 term above takes every n */
+  const int nlo = P->N1 > 0 ? P->N1 : 0;
+  const int nhi = (P->N2 >= 0 && P->N2 < nmax - 1) ? P->N2 : nmax - 1;
 
   for (int l = 1, loffset = 1; l <= lmax; loffset += (2 * l + 1), l++) {
     if (P->EVEN_L && l % 2) continue;
@@ -940,7 +943,7 @@ static void pyexp_sph_eval(const orc_slgrid *g, const orc_sph_params *P, const d
       fac1 = FC(l, m);
       if (m == 0) {
         double sumR = 0.0, sumP = 0.0, sumD = 0.0;
-        for (int n = 0; n < nmax; n++) {
+        for (int n = nlo; n <= nhi; n++) {
           sumR += CF(loffset + moffset, n) * dend[l * nmax + n];
           sumP += CF(loffset + moffset, n) * potd[l * nmax + n];
           sumD += CF(loffset + moffset, n) * dpot[l * nmax + n];
@@ -955,7 +958,7 @@ static void pyexp_sph_eval(const orc_slgrid *g, const orc_sph_params *P, const d
         double sinm = sin(phi * m);
         double sumR0 = 0.0, sumP0 = 0.0, sumD0 = 0.0;
         double sumR1 = 0.0, sumP1 = 0.0, sumD1 = 0.0;
-        for (int n = 0; n < nmax; n++) {
+        for (int n = nlo; n <= nhi; n++) {
           sumR0 += CF(loffset + moffset + 0, n) * dend[l * nmax + n];
           sumP0 += CF(loffset + moffset + 0, n) * potd[l * nmax + n];
           sumD0 += CF(loffset + moffset + 0, n) * dpot[l * nmax + n];
@@ -989,6 +992,173 @@ static void pyexp_sph_eval(const orc_slgrid *g, const orc_sph_params *P, const d
 #undef LG
 #undef DLG
 #undef CF
+}
+
+/* expui/BiorthBasis.cc:323-329: factorial(l, m) in the lgamma form pyEXP uses */
+static void pyexp_factorial(int lmax, double *factorial)
+{
+  for (int l = 0; l <= lmax; l++)
+    for (int m = 0; m <= lmax; m++) {
+      double v = 0.0;
+      if (m <= l) {
+        v = sqrt((0.5 * l + 0.25) / M_PI * exp(lgamma(1.0 + l - m) - lgamma(1.0 + l + m)));
+        if (m != 0) v *= M_SQRT2;
+      }
+      factorial[l * (lmax + 1) + m] = v;
+    }
+}
+
+/* Spherical::accumulate (expui/BiorthBasis.cc:583-665), the coefficient part */
+long orc_pyexp_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodies, const double *X,
+                              const double *Y, const double *Z, const double *M, double *expcoef)
+{
+  const int lmax = g->lmax, nmax = g->nmax;
+  double *factorial = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *legs = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  pyexp_factorial(lmax, factorial);
+  long used = 0;
+  const double norm = -4.0 * M_PI;
+  const double dsmall = 1.0e-20;
+  for (long i = 0; i < nbodies; i++) {
+    double x = X[i], y = Y[i], z = Z[i], mass = M[i];
+    double fac, fac1, fac2, fac4;
+    double r2 = (x * x + y * y + z * z);
+    double r = sqrt(r2) + dsmall;
+    double costh = z / r;
+    double phi = atan2(y, x);
+    double rs = r / P->scale;
+
+    if (r < P->rmin || r > P->rmax) continue;
+
+    used++;
+    orc_sl_get_pot(g, rs, potd);
+    orc_legendre_R(lmax, costh, legs);
+
+    for (int l = 0, loffset = 0; l <= lmax; loffset += (2 * l + 1), l++) {
+      for (int m = 0, moffset = 0; m <= l; m++) {
+        fac = factorial[l * (lmax + 1) + m] * legs[l * (lmax + 1) + m];
+        if (m == 0) {
+          for (int n = 0; n < nmax; n++) {
+            fac4 = potd[l * nmax + n] * fac;
+            expcoef[(size_t)(loffset + moffset) * nmax + n] += fac4 * norm * mass;
+          }
+          moffset++;
+        } else {
+          fac1 = fac * cos(phi * m);
+          fac2 = fac * sin(phi * m);
+          for (int n = 0; n < nmax; n++) {
+            fac4 = potd[l * nmax + n];
+            expcoef[(size_t)(loffset + moffset) * nmax + n] += fac1 * fac4 * norm * mass;
+            expcoef[(size_t)(loffset + moffset + 1) * nmax + n] += fac2 * fac4 * norm * mass;
+          }
+          moffset += 2;
+        }
+      }
+    }
+  }
+  free(factorial); free(potd); free(legs);
+  return used;
+}
+
+/* Spherical::computeAccel (expui/BiorthBasis.cc:818-926), G = 1 */
+void orc_pyexp_sph_accel(const orc_slgrid *g, const orc_sph_params *P, const double *expcoef, long nbodies,
+                         const double *X, const double *Y, const double *Z, double *acc)
+{
+  const int lmax = g->lmax, nmax = g->nmax;
+  const double scale = P->scale;
+  double *factorial = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *potd = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *dpot = (double *)malloc(sizeof(double) * (lmax + 1) * nmax);
+  double *legs = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  double *dlegs = (double *)malloc(sizeof(double) * (lmax + 1) * (lmax + 1));
+  pyexp_factorial(lmax, factorial);
+  const int nlo = P->N1 > 0 ? P->N1 : 0;
+  const int nhi = (P->N2 >= 0 && P->N2 < nmax - 1) ? P->N2 : nmax - 1;
+#define FC(l, m) factorial[(l) * (lmax + 1) + (m)]
+#define LG(l, m) legs[(l) * (lmax + 1) + (m)]
+#define DLG(l, m) dlegs[(l) * (lmax + 1) + (m)]
+#define CF(row, n) expcoef[(size_t)(row) * nmax + (n)]
+  for (long i = 0; i < nbodies; i++) {
+    double x = X[i], y = Y[i], z = Z[i];
+    double R2 = x * x + y * y;
+    double r2 = R2 + z * z;
+    double R = sqrt(x * x + y * y) + 1.0e-18;
+    double r = sqrt(r2) + 1.0e-18;
+    double costh = z / r;
+    double sinth = R / r;
+    double phi = atan2(y, x);
+
+    double fac1 = FC(0, 0);
+    orc_sl_get_pot(g, r / scale, potd);
+    orc_sl_get_force(g, r / scale, dpot);
+    orc_dlegendre_R(lmax, costh, legs, dlegs);
+
+    double pot0, potr;
+    if (P->NO_L0) {
+      pot0 = 0.0;
+      potr = 0.0;
+    } else {
+      pot0 = potr = 0.0;
+      for (int n = 0; n < nmax; n++) {          /* expcoef.row(0).dot(...): every n */
+        pot0 += CF(0, n) * potd[n];
+        potr += CF(0, n) * dpot[n];
+      }
+      pot0 *= fac1;
+      potr *= fac1;
+    }
+    (void)pot0;
+    double pot1 = 0.0, pott = 0.0, potp = 0.0;
+    for (int l = 1, loffset = 1; l <= lmax; loffset += (2 * l + 1), l++) {
+      if (P->EVEN_L && l % 2) continue;
+      if (P->NO_L1 && l == 1) continue;
+      for (int m = 0, moffset = 0; m <= l; m++) {
+        if (P->M0_only && m) continue;
+        if (P->EVEN_M && m % 2) continue;
+        fac1 = FC(l, m);
+        if (m == 0) {
+          double sumP = 0.0, sumD = 0.0;
+          for (int n = nlo; n <= nhi; n++) {
+            sumP += CF(loffset + moffset, n) * potd[l * nmax + n];
+            sumD += CF(loffset + moffset, n) * dpot[l * nmax + n];
+          }
+          pot1 += fac1 * LG(l, m) * sumP;
+          potr += fac1 * LG(l, m) * sumD;
+          pott += fac1 * DLG(l, m) * sumP;
+          moffset++;
+        } else {
+          double cosm = cos(phi * m);
+          double sinm = sin(phi * m);
+          double sumP0 = 0.0, sumD0 = 0.0, sumP1 = 0.0, sumD1 = 0.0;
+          for (int n = nlo; n <= nhi; n++) {
+            sumP0 += CF(loffset + moffset + 0, n) * potd[l * nmax + n];
+            sumD0 += CF(loffset + moffset + 0, n) * dpot[l * nmax + n];
+            sumP1 += CF(loffset + moffset + 1, n) * potd[l * nmax + n];
+            sumD1 += CF(loffset + moffset + 1, n) * dpot[l * nmax + n];
+          }
+          pot1 += fac1 * LG(l, m) * (sumP0 * cosm + sumP1 * sinm);
+          potr += fac1 * LG(l, m) * (sumD0 * cosm + sumD1 * sinm);
+          pott += fac1 * DLG(l, m) * (sumP0 * cosm + sumP1 * sinm);
+          potp += fac1 * LG(l, m) * (-sumP0 * sinm + sumP1 * cosm) * m;
+          moffset += 2;
+        }
+      }
+    }
+    (void)pot1;
+    double potlfac = 1.0 / scale;
+    potr *= (-potlfac) / scale;
+    pott *= (-potlfac);
+    potp *= (-potlfac);
+    /* transform to Cartesian components; R2 is the unguarded x^2 + y^2 (:917-919) */
+    acc[3 * i + 0] = (potr - pott * costh / r) * x / r - potp * y / R2;
+    acc[3 * i + 1] = (potr - pott * costh / r) * y / r + potp * x / R2;
+    acc[3 * i + 2] = potr * costh + pott * sinth * sinth / r;
+  }
+#undef FC
+#undef LG
+#undef DLG
+#undef CF
+  free(factorial); free(potd); free(dpot); free(legs); free(dlegs);
 }
 
 void orc_pyexp_sph_fields(const orc_slgrid *g, const orc_sph_params *P, const double *coef, long n,

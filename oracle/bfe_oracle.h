@@ -42,6 +42,8 @@ typedef struct {
   double scale;              /* "scale" key                                   */
   double rmin, rmax;         /* expansion window (unscaled r)                 */
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
+  int N1, N2;                /* pyEXP only: radial window of the l >= 1 sums in sph_eval / computeAccel
+                                (expui/BiorthBasis.cc:761, :876); N2 < 0 means no upper limit    */
 } orc_sph_params;
 
 void   orc_legendre_R (int lmax, double x, double *p);               /* p[(lmax+1)*(lmax+1)], p[l*(lmax+1)+m] */
@@ -208,6 +210,16 @@ void   orc_get_pseudo_accel(int center, int axis, const double *accel, const dou
 /* pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958): out[n][9] =
  * {dens m=0, dens m>0, dens, potl m=0, potl m>0, potl, force x3 in the input coordinates};
  * coord 0: (r, cos theta, phi), 1: (R, z, phi), 2: (x, y, z).                                  */
+/* pyEXP-literal twins of the n-body thread bodies.  Spherical::accumulate (expui/BiorthBasis.cc:583-665:
+ * dsmall 1e-20, particles with r < rmin or r > rmax skipped, cos(m phi) / sin(m phi) evaluated
+ * directly): coef[(lmax+1)^2][nmax] +=, returns the number used.  Spherical::computeAccel (:818-926:
+ * 1e-18 added to R and r, tables evaluated at r/scale whatever r is, the l = 0 term summed over ALL n
+ * and the l >= 1 terms over N1..N2, the azimuthal term divided by the unguarded x^2 + y^2): acc[n][3]. */
+long   orc_pyexp_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long n, const double *x,
+                                const double *y, const double *z, const double *mass, double *coef);
+void   orc_pyexp_sph_accel(const orc_slgrid *g, const orc_sph_params *P, const double *coef, long n,
+                           const double *x, const double *y, const double *z, double *acc);
+
 void   orc_pyexp_sph_fields(const orc_slgrid *g, const orc_sph_params *P, const double *coef,
                             long n, const double *c1, const double *c2, const double *c3,
                             int coord, double *out);

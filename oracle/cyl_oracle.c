@@ -362,3 +362,53 @@ long orc_cyl_covariance(const orc_cylgrid *g, long n, const double *X, const dou
   free(vc); free(vs); free(re); free(im);
   return used;
 }
+
+/* Cylindrical::accumulate (expui/BiorthBasis.cc:1851-1857) -> EmpCylSL::accumulate
+ * (exputil/EmpCylSL.cc:4049-4146), compute = false */
+long orc_pyexp_cyl_accumulate(const orc_cylgrid *g, long n, const double *X, const double *Y,
+                              const double *Z, const double *M, double *cosN, double *sinN)
+{
+  const int nm = (g->mmax + 1) * g->norder;
+  double *vc = (double *)calloc(nm, sizeof(double)), *vs = (double *)calloc(nm, sizeof(double));
+  const double norm = -4.0 * M_PI;
+  long howmany = 0;
+  for (long i = 0; i < n; i++) {
+    double R = sqrt(X[i] * X[i] + Y[i] * Y[i]);
+    double phi = atan2(Y[i], X[i]);
+    double z = Z[i], mass = M[i];
+    double rr = sqrt(R * R + z * z);
+    if (rr / g->ascale > g->rtable) continue;
+    howmany++;
+    orc_cyl_get_pot(g, R, z, vc, vs);
+    for (int mm = 0; mm <= g->mmax; mm++) {
+      double mcos = cos(phi * mm);
+      double msin = sin(phi * mm);
+      for (int nn = 0; nn < g->norder; nn++) {
+        double hold = norm * mass * mcos * vc[mm * g->norder + nn];
+        cosN[mm * g->norder + nn] += hold;
+        if (mm > 0) {
+          hold = norm * mass * msin * vs[mm * g->norder + nn];
+          sinN[mm * g->norder + nn] += hold;
+        }
+      }
+    }
+  }
+  free(vc); free(vs);
+  return howmany;
+}
+
+/* Cylindrical::computeAccel (expui/BiorthBasis.cc:1804-1821) */
+void orc_pyexp_cyl_accel(const orc_cylgrid *g, const double *accum_cos, const double *accum_sin,
+                         long n, const double *X, const double *Y, const double *Z, double *acc)
+{
+  for (long i = 0; i < n; i++) {
+    double x = X[i], y = Y[i], z = Z[i];
+    double R = sqrt(x * x + y * y);
+    double phi = atan2(y, x);
+    double tpotl0 = 0.0, tpotl, tpotR, tpotz, tpotp;
+    orc_cyl_accumulated_eval(g, accum_cos, accum_sin, R, z, phi, &tpotl0, &tpotl, &tpotR, &tpotz, &tpotp);
+    acc[3 * i + 0] = tpotR * x / R - tpotp * y / R;
+    acc[3 * i + 1] = tpotR * y / R + tpotp * x / R;
+    acc[3 * i + 2] = tpotz;
+  }
+}

@@ -37,6 +37,14 @@ double orc_cyl_accumulated_dens_eval(const orc_cylgrid *g, const double *dens,
 void   orc_pyexp_cyl_fields(const orc_cylgrid *g, const double *dens, const double *accum_cos,
                             const double *accum_sin, long n, const double *c1, const double *c2,
                             const double *c3, int coord, double *out);
+/* pyEXP-literal twins.  Cylindrical::accumulate (expui/BiorthBasis.cc:1851-1857) = EmpCylSL::accumulate
+ * on (R, z, phi): no rcylmax cut, only the table window; cosN/sinN +=, returns the number on the grid.
+ * Cylindrical::computeAccel (:1804-1821) = accumulated_eval projected with the unguarded x/R, y/R:
+ * no taper, no monopole continuation; acc[n][3], G = 1.                                           */
+long   orc_pyexp_cyl_accumulate(const orc_cylgrid *g, long n, const double *x, const double *y,
+                                const double *z, const double *mass, double *cosN, double *sinN);
+void   orc_pyexp_cyl_accel(const orc_cylgrid *g, const double *accum_cos, const double *accum_sin,
+                           long n, const double *x, const double *y, const double *z, double *acc);
 /* Sub-sample covariance of the cylindrical coefficients: the `covar` branch of EmpCylSL::accumulate
  * (exputil/EmpCylSL.cc:4049-4146) as pyEXP drives it (Cylindrical::accumulate, expui/BiorthBasis.cc:
  * 1851-1857): particles on the grid only, whch = seq % sampT (seq NULL: the particle's index),

@@ -31,7 +31,8 @@ class _SLGrid(ctypes.Structure):
 class _SphParams(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_double), ("rmin", ctypes.c_double), ("rmax", ctypes.c_double),
                 ("NO_L0", ctypes.c_int), ("NO_L1", ctypes.c_int), ("EVEN_L", ctypes.c_int),
-                ("EVEN_M", ctypes.c_int), ("M0_only", ctypes.c_int)]
+                ("EVEN_M", ctypes.c_int), ("M0_only", ctypes.c_int), ("N1", ctypes.c_int),
+                ("N2", ctypes.c_int)]
 
 
 class _CylGrid(ctypes.Structure):
@@ -198,9 +199,10 @@ class Oracle:
 
     @staticmethod
     def params(scale=1.0, rmin=0.0, rmax=1e30, NO_L0=False, NO_L1=False, EVEN_L=False,
-               EVEN_M=False, M0_only=False) -> _SphParams:
+               EVEN_M=False, M0_only=False, N1=0, N2=-1) -> _SphParams:
+        """N1, N2: pyEXP's radial window of the l >= 1 sums (N2 < 0: no upper limit)."""
         return _SphParams(scale, rmin, rmax, int(NO_L0), int(NO_L1), int(EVEN_L), int(EVEN_M),
-                          int(M0_only))
+                          int(M0_only), int(N1), int(N2))
 
     # -- Legendre / trig ---------------------------------------------------------------
     def legendre(self, lmax, x):
@@ -371,6 +373,46 @@ class Oracle:
         self.lib.orc_euler_slater(ctypes.c_double(phi), ctypes.c_double(theta), ctypes.c_double(psi),
                                   ctypes.c_int(body), _dp(out))
         return out.reshape(3, 3)
+
+    # -- pyEXP-literal twins (expui/BiorthBasis.cc:583-665, :818-926, :1804-1857) ---------------------
+    def pyexp_sph_accumulate(self, g, prm, pos, mass):
+        G = self.grid(g)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        coef = np.zeros(((g.lmax + 1) ** 2, g.nmax))
+        self.lib.orc_pyexp_sph_accumulate.restype = ctypes.c_long
+        used = self.lib.orc_pyexp_sph_accumulate(ctypes.byref(G), ctypes.byref(prm), ctypes.c_long(len(m)),
+                                                 _dp(x), _dp(y), _dp(z), _dp(m), _dp(coef))
+        return coef, int(used)
+
+    def pyexp_sph_accel(self, g, prm, coef, pos):
+        G = self.grid(g)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        acc = np.zeros((len(x), 3))
+        with np.errstate(all="ignore"):
+            self.lib.orc_pyexp_sph_accel(ctypes.byref(G), ctypes.byref(prm), _dp(cf), ctypes.c_long(len(x)),
+                                         _dp(x), _dp(y), _dp(z), _dp(acc))
+        return acc
+
+    def pyexp_cyl_accumulate(self, g, pos, mass, **kw):
+        G = self.cylgrid(g, **kw)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        cosN, sinN = np.zeros((g.mmax + 1, g.norder)), np.zeros((g.mmax + 1, g.norder))
+        self.lib.orc_pyexp_cyl_accumulate.restype = ctypes.c_long
+        n = self.lib.orc_pyexp_cyl_accumulate(ctypes.byref(G), ctypes.c_long(len(m)), _dp(x), _dp(y), _dp(z),
+                                              _dp(m), _dp(cosN), _dp(sinN))
+        return cosN, sinN, int(n)
+
+    def pyexp_cyl_accel(self, g, cosN, sinN, pos, **kw):
+        G = self.cylgrid(g, **kw)
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        cc, ss = [np.ascontiguousarray(a, dtype=np.float64) for a in (cosN, sinN)]
+        acc = np.zeros((len(x), 3))
+        self.lib.orc_pyexp_cyl_accel(ctypes.byref(G), _dp(cc), _dp(ss), ctypes.c_long(len(x)), _dp(x), _dp(y),
+                                     _dp(z), _dp(acc))
+        return acc
 
     def sph_fields(self, g, prm, coef, c1, c2, c3, coord="cartesian"):
         """pyEXP field evaluation (expui/BiorthBasis.cc:711-816, :930-958) -> [n, 9]."""

@@ -132,6 +132,87 @@ def test_get_accel_matches_oracle_inside_rmax(halo_basis, oracle):
     assert np.allclose(one, acc[0], rtol=0, atol=1e-14 * np.abs(acc[0]).max())
 
 
+def test_accumulate_and_get_accel_against_the_pyexp_literal_oracle(halo_basis, oracle):
+    """``Spherical::accumulate`` / ``computeAccel`` restated literally (oracle/bfe_oracle.c:
+    orc_pyexp_sph_accumulate / orc_pyexp_sph_accel; expui/BiorthBasis.cc:583-665, :818-926): particles
+    outside [rmin, rmax] are skipped, dsmall 1e-20 / 1e-18, tables evaluated at r/scale inside rmin and
+    beyond rmax alike (no exterior continuation), the azimuthal term over the unguarded x^2 + y^2."""
+    basis, _ = halo_basis
+    rng = np.random.default_rng(11)
+    pos = rng.normal(0, 0.35, (3000, 3))
+    pos[:40] *= 12.0                                   # beyond rmax = 1.95: skipped by accumulate
+    pos[40:50] *= 1e-5                                 # inside rmin = 1e-4: skipped too
+    m = rng.uniform(0.5, 1.5, 3000) / 3000
+    coefs = basis.createFromArray(m, pos)
+    prm = oracle.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+    ref, used = oracle.pyexp_sph_accumulate(basis.grid, prm, pos, m)
+    r = np.linalg.norm(pos, axis=1)
+    assert used == basis.used == int(((r >= basis.rmin) & (r <= basis.rmax)).sum()) < 3000
+    assert np.abs(basis.expcoef - ref).max() <= 1e-10 * np.abs(ref).max()
+    basis.set_coefs(coefs)
+    # evaluation points: bulk, inside rmin, beyond rmax, a hair off the polar axis
+    test = np.concatenate([rng.normal(0, 0.5, (300, 3)),
+                           rng.normal(0, 3e-5, (20, 3)),
+                           rng.normal(0, 4.0, (40, 3)),
+                           np.array([[4e-4, 0.0, 0.4], [0.0, -9e-4, -0.9], [1e-3, 1e-3, 1.2]])])   # theta ~ 1e-3
+    a_ref = oracle.pyexp_sph_accel(basis.grid, prm, ref, test)
+    acc = basis.getAccel(test)
+    rt = np.linalg.norm(test, axis=1)
+    assert (rt < basis.rmin).sum() >= 5 and (rt > basis.rmax).sum() >= 10
+    scale = np.linalg.norm(a_ref, axis=1)
+    assert np.all(np.isfinite(a_ref))
+    assert (np.linalg.norm(acc - a_ref, axis=1) <= 1e-9 * np.maximum(scale, scale.max() * 1e-6)).all()
+    # A hair off the axis (theta ~ 1e-7) the transverse components are ill-conditioned in the reference
+    # itself: sqrt((1-x)(1+x)) with x = z/r rounded amplifies one ulp of x by 1/(1-|x|) ~ 1e13, so even
+    # its own 1e-18 versus the n-body 1e-16 added to r moves them by 1e-3.  z is well conditioned.
+    hair = np.array([[1e-7, 0.0, 0.4], [0.0, -3e-8, -0.9]])
+    lit, got = oracle.pyexp_sph_accel(basis.grid, prm, ref, hair), basis.getAccel(hair)
+    assert np.abs(got[:, 2] - lit[:, 2]).max() <= 1e-9 * np.abs(lit[:, 2]).max()
+    assert np.abs(got[:, :2] - lit[:, :2]).max() <= 2e-2 * np.abs(lit[:, :2]).max()
+    # ON the axis the reference computes potp * y / (x^2 + y^2) = 0/0: NaN in x and y.  The device
+    # guards the azimuthal term and returns the finite limit; z agrees.
+    axis = np.array([[0.0, 0.0, 0.7], [0.0, 0.0, -0.3]])
+    lit = oracle.pyexp_sph_accel(basis.grid, prm, ref, axis)
+    assert np.isnan(lit[:, :2]).all() and np.isfinite(lit[:, 2]).all()
+    got = basis.getAccel(axis)
+    near = basis.getAccel(axis + np.array([1e-9, 0.0, 0.0]))
+    assert np.all(np.isfinite(got)) and np.abs(got[:, 2] - lit[:, 2]).max() <= 1e-9 * np.abs(lit[:, 2]).max()
+    assert np.abs(got - near).max() <= 1e-6 * np.abs(near).max()
+
+
+def test_radial_window_keys_N1_N2(halo_basis, oracle, tmp_path):
+    """N1 / N2 restrict the l >= 1 sums of computeAccel / sph_eval to n in [N1, N2] while the monopole
+    keeps every n (expui/BiorthBasis.cc:841-849 vs :876, :894).  The reference reads both keys with
+    ``.as<bool>()`` (:264-265): ``true`` means 1, anything that is not a boolean does not convert."""
+    from exp_amd.basis import Basis
+    basis, cfg = halo_basis
+    cfgw = cfg.replace("  Lmax: 2", "  Lmax: 2\n  N1: true\n  N2: true")
+    cfgw = cfgw.replace(cfgw.split("cachename: ")[1].split()[0], str(tmp_path / "SLGridSph.cache.win"))
+    win = Basis.factory(cfgw)
+    assert (win.N1, win.N2) == (1, 1)
+    rng = np.random.default_rng(13)
+    pos = rng.normal(0, 0.3, (2000, 3)) * np.array([1.0, 0.8, 0.5])
+    m = np.full(2000, 1.0 / 2000)
+    coefs = win.createFromArray(m, pos)
+    full_c = basis.createFromArray(m, pos).coefs                       # accumulation is not windowed
+    assert np.abs(coefs.coefs - full_c).max() <= 1e-13 * np.abs(full_c).max()
+    win.set_coefs(coefs)
+    test = rng.normal(0, 0.4, (200, 3))
+    prm = oracle.params(scale=1.0, rmin=win.rmin, rmax=win.rmax, N1=1, N2=1)
+    ref, _ = oracle.pyexp_sph_accumulate(win.grid, prm, pos, m)
+    a_ref = oracle.pyexp_sph_accel(win.grid, prm, ref, test)
+    acc = win.getAccel(test)
+    assert np.abs(acc - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
+    full = oracle.pyexp_sph_accel(win.grid, oracle.params(scale=1.0, rmin=win.rmin, rmax=win.rmax), ref, test)
+    assert np.abs(full - a_ref).max() > 1e-3 * np.linalg.norm(a_ref, axis=1).max()   # the window matters
+    # the same window in the field evaluation
+    f_ref = oracle.sph_fields(win.grid, prm, ref, test[:, 0], test[:, 1], test[:, 2], "cartesian")
+    f_got = win.getFields(test[:, 0], test[:, 1], test[:, 2])
+    assert np.abs(f_got[:, 3:] - f_ref[:, 3:]).max() <= 1e-9 * np.abs(f_ref[:, 3:]).max()
+    with pytest.raises(RuntimeError):
+        Basis.factory(cfgw.replace("N1: true", "N1: 5"))
+
+
 def test_get_fields_matches_oracle(halo_basis, oracle):
     """getFields / __call__ in the three coordinate systems (Spherical::crt_eval, cyl_eval, sph_eval,
     expui/BiorthBasis.cc:711-958) against the oracle's restatement; includes points beyond rmax
@@ -197,6 +278,23 @@ parameters:
     assert coefs.coefs.shape == (5, 6) and coefs.time == 0.5
     acc = basis.getAccel(np.array([[0.02, 0.0, 0.0], [0.0, 0.03, 0.001]]))
     assert acc[0, 0] < 0 and acc[1, 1] < 0 and np.all(np.isfinite(acc))
+    # Cylindrical::accumulate / computeAccel restated literally (oracle/cyl_oracle.c:
+    # orc_pyexp_cyl_accumulate / orc_pyexp_cyl_accel; expui/BiorthBasis.cc:1804-1857): the table
+    # window only, accumulated_eval projected on x, y, z -- no taper, nothing beyond the table
+    from tests.oracle_lib import Oracle
+    orc = Oracle()
+    cc, ss, ongrid = orc.pyexp_cyl_accumulate(basis.grid, pos, m)
+    assert np.abs(coefs.coefs.real - cc).max() <= 1e-10 * np.abs(cc).max()
+    assert np.abs(coefs.coefs.imag - ss).max() <= 1e-10 * np.abs(cc).max()
+    rng = np.random.default_rng(8)
+    Rt = basis.grid.rtable * basis.grid.ascale
+    test = np.concatenate([rng.normal(0, 0.03, (300, 3)) * np.array([1.0, 1.0, 0.1]),
+                           np.array([[1.2 * Rt, 0.0, 0.0], [0.0, 0.9 * Rt, 0.3 * Rt], [1e-8, 0.0, 0.001],
+                                     [0.7 * Rt, 0.1 * Rt, 0.0]])])
+    a_ref = orc.pyexp_cyl_accel(basis.grid, cc, ss, test)
+    a_got = basis.getAccel(test)
+    assert np.all(a_ref[-4] == 0.0)                       # beyond the table: accumulated_eval returns zeros
+    assert np.abs(a_got - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
     # field evaluation: cylindrical coordinates by default (expui/BiorthBasis.cc:1744-1746)
     basis.set_coefs(coefs)
     assert basis.getFieldLabels()[6:] == ["rad force", "ver force", "azi force"]
