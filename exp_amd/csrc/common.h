@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -49,6 +50,7 @@ struct exp_amd_ctx {
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
+  bool deterministic = false;        // order-independent (bit-reproducible) coefficient sums, exp_amd_ctx_set_deterministic
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;
@@ -161,5 +163,16 @@ __device__ __forceinline__ void lds_barrier()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 #endif
+
+// Deterministic accumulation (acc_add<true>, sph_kernels.h): the constant C = 1.5 * 2^(52+e) whose grid
+// 2^e keeps every partial sum of a launch exact, given an upper bound of the sum of |contributions|:
+// bound < 2^ex, e = ex - 50 => single terms < 2^(51+e), partial sums < 2^(53+e).  0 when off.
+static inline double expamd_det_constant(bool on, double bound)
+{
+  if (!on || !(bound > 0.0)) return 0.0;
+  int ex = 0;
+  (void)frexp(bound, &ex);
+  return ldexp(1.5, 52 + ex - 50);
+}
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -34,6 +34,8 @@ struct CylDev {
   int use_rot;
   double rot[9];
   PseudoDev ps;     // frame acceleration of the TARGET component (force pass only)
+  // deterministic mode: rounding-grid constants of the moment terms / of the in-cut mass (0: off)
+  double detC, detCm;
 };
 
 // centred, then rotated into the body frame
@@ -131,6 +133,21 @@ struct LevChunks {
 #define CACC_WAVES 4
 #define CACC_CHUNK_MAX 1024   // particles per wave chunk; sparse multistep levels get shorter ones
 
+// Deterministic (order-independent) accumulation, as in sph_kernels.h: every term is rounded to a fixed
+// absolute grid 2^e first, (w*p + C) - C with C = 1.5 * 2^(52+e), so that all later additions are exact.
+template <bool DET>
+__device__ __forceinline__ void cacc_add(double &a, double w, double p, double C)
+{
+  if constexpr (DET) {
+    double t = fma(w, p, C);
+    t -= C;
+    a += t;
+  } else {
+    a = fma(w, p, a);
+  }
+}
+__device__ __forceinline__ double cdet_round(double v, double C) { return C != 0.0 ? (v + C) - C : v; }
+
 // reduce NV per-lane values over the wave and atomically add value j to dst[map(j)]
 template <int NV, class MapFn>
 __device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch, double *dst,
@@ -162,7 +179,7 @@ __device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch,
 }
 
 // Wn[node][ntrig]: trig slot 0 = m0, 2m-1 = cos m, 2m = sin m
-template <int MMAX>
+template <int MMAX, bool DET>
 __global__ void __launch_bounds__(CACC_WAVES * 64)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
@@ -219,7 +236,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     const double r2 = xx * xx + yy * yy;
     const double r = sqrt(r2);
     const bool incut = valid && (r2 + zz * zz) < C.rmax2;
-    if (incut) { mass_used += mass; n_used += 1.0; }
+    if (incut) { mass_used += cdet_round(mass, C.detCm); n_used += 1.0; }
     // EmpCylSL::accumulate (:4062-4063)
     const double rr = sqrt(r * r + zz * zz);
     const bool ongrid = incut && !(rr / C.ascale > C.rtable);
@@ -256,15 +273,15 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
         const bool on = !(C.EVEN_M && (m & 1));             // get_pot skips odd m (:5601)
         if (on) {
           constexpr int jc = (m == 0) ? 0 : 2 * m - 1;
-          acc[0 * NT + jc] = fma(w0, cm, acc[0 * NT + jc]);
-          acc[1 * NT + jc] = fma(w1, cm, acc[1 * NT + jc]);
-          acc[2 * NT + jc] = fma(w2, cm, acc[2 * NT + jc]);
-          acc[3 * NT + jc] = fma(w3, cm, acc[3 * NT + jc]);
+          cacc_add<DET>(acc[0 * NT + jc], w0, cm, C.detC);
+          cacc_add<DET>(acc[1 * NT + jc], w1, cm, C.detC);
+          cacc_add<DET>(acc[2 * NT + jc], w2, cm, C.detC);
+          cacc_add<DET>(acc[3 * NT + jc], w3, cm, C.detC);
           if constexpr (m > 0) {
-            acc[0 * NT + jc + 1] = fma(w0, sm, acc[0 * NT + jc + 1]);
-            acc[1 * NT + jc + 1] = fma(w1, sm, acc[1 * NT + jc + 1]);
-            acc[2 * NT + jc + 1] = fma(w2, sm, acc[2 * NT + jc + 1]);
-            acc[3 * NT + jc + 1] = fma(w3, sm, acc[3 * NT + jc + 1]);
+            cacc_add<DET>(acc[0 * NT + jc + 1], w0, sm, C.detC);
+            cacc_add<DET>(acc[1 * NT + jc + 1], w1, sm, C.detC);
+            cacc_add<DET>(acc[2 * NT + jc + 1], w2, sm, C.detC);
+            cacc_add<DET>(acc[3 * NT + jc + 1], w3, sm, C.detC);
           }
         }
       });
@@ -315,7 +332,7 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   const double r = sqrt(r2);
   if (plain) {
     const bool incut = mover && (r2 + zz * zz) < C.rmax2;
-    double mu = incut ? mass : 0.0, nu = incut ? 1.0 : 0.0;
+    double mu = incut ? cdet_round(mass, C.detCm) : 0.0, nu = incut ? 1.0 : 0.0;
     for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
     if ((threadIdx.x & 63) == 0 && nu > 0.0) { unsafeAtomicAdd(tail + 0, mu); unsafeAtomicAdd(tail + 1, nu); }
     mover = incut;
@@ -370,7 +387,7 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
           for (int k = 0; k < 4; k++) {
             const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
             const double w = t0 * cw[k];
-            const double vc = w * cmv[m], vs = w * smv[m];
+            const double vc = cdet_round(w * cmv[m], C.detC), vs = cdet_round(w * smv[m], C.detC);
             unsafeAtomicAdd(wto + off + jc, vc);
             if (sub) unsafeAtomicAdd(wfr + off + jc, -vc);
             if constexpr (m > 0) {
@@ -403,7 +420,7 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
       for (int k = 0; k < 4; k++) {
         const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
         const double w = in ? t0 * cw[k] : 0.0;
-        double vc = w * cmv[m], vs = w * smv[m];
+        double vc = cdet_round(w * cmv[m], C.detC), vs = cdet_round(w * smv[m], C.detC);
         if (many) {
           for (int o = 32; o > 0; o >>= 1) {
             vc += __shfl_xor(vc, o);
@@ -709,6 +726,17 @@ static CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
   return cdev_frame(f, c->center, c->use_rot, c->rot);
 }
 
+// ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding
+// grids that keep every partial sum of this component exact (|-4 pi m c_k trig| <= 4 pi |m| x 2 for the
+// bilinear weights; the in-cut mass itself)
+static CylDev cdev_acc(const CylForce *f, const exp_amd_comp *c)
+{
+  CylDev C = cdev_for(f, c);
+  C.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * 4.0 * M_PI * 2.0);
+  C.detCm = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum);
+  return C;
+}
+
 extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
                                   exp_amd_force **out)
 {
@@ -836,7 +864,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p + (size_t)mfirst_mdrft * wl, 0, (size_t)nl * wl * sizeof(double), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, 0,
                               (size_t)nl * f->ncoef_dev * sizeof(double), ctx->stream));
-  const CylDev C = cdev_for(f, c);
+  const CylDev C = cdev_acc(f, c);
   size_t nr = 0;
   if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
   if (nr) {
@@ -869,7 +897,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   CylForce *f = this;
   f->home = c;
   f->home_gone = false;
-  const CylDev C = cdev_for(f, c);
+  const CylDev C = cdev_acc(f, c);
   {
     const int level = (f->multistep && c->sorted_for == f && c->nlevels == f->multistep + 1)
                           ? f->mlevel : -1;
@@ -902,8 +930,12 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     LevChunks LC;
     LC.lo = lo; LC.nlev = 1; LC.bstart[0] = 0; LC.bstart[1] = grid; LC.chunk[0] = (int)chunk;
 #define CALL(MM)                                                                                 \
-  k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0)
+  if (C.detC != 0.0)                                                                             \
+    k_cyl_accumulate<MM, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                       \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0); \
+  else                                                                                           \
+    k_cyl_accumulate<MM, false><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                      \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
@@ -958,7 +990,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     }
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
-  const CylDev C = cdev_for(f, c);
+  const CylDev C = cdev_acc(f, c);
   double *dst = f->d_coefN.p + (size_t)lo * f->ncoef_dev;
   const size_t wl = f->nnode * dev.ntrig;
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
@@ -991,8 +1023,12 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     }
     LC.bstart[LC.nlev] = grid;
 #define CALL(MM)                                                                                 \
-  k_cyl_accumulate<MM><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                               \
-      C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1)
+  if (C.detC != 0.0)                                                                             \
+    k_cyl_accumulate<MM, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                       \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1); \
+  else                                                                                           \
+    k_cyl_accumulate<MM, false><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                      \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }

@@ -710,6 +710,16 @@ k_minmax(const double *__restrict__ v, size_t n, double *__restrict__ out /* {mi
   }
 }
 
+// sum |v| (an upper bound is all that is needed: plain fp atomics)
+__global__ void __launch_bounds__(TPB)
+k_abs_sum(const double *__restrict__ v, size_t n, double *__restrict__ out)
+{
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) s += fabs(v[i]);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(out, s);
+}
+
 __global__ void __launch_bounds__(TPB)
 k_fill_f64(double *__restrict__ v, size_t n, double x)
 {
@@ -721,13 +731,16 @@ static int detect_uniform_mass(exp_amd_comp *c)
 {
   exp_amd_ctx *ctx = c->ctx;
   c->uniform_mass = false;
+  c->mass_abs_sum = 0.0;
   if (c->n == 0) return EXP_AMD_OK;
-  double init[2] = {1.0e300, 0.0}, got[2];
-  double *scr = (double *)(c->nswitch.p + 66);   // two spare words of the counter block
+  double init[3] = {1.0e300, 0.0, 0.0}, got[3];
+  double *scr = (double *)(c->nswitch.p + 66);   // three spare words of the counter block
   HIP_TRY(ctx, hipMemcpyAsync(scr, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
   k_minmax<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->a(A_M), c->n, scr);
+  k_abs_sum<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->a(A_M), c->n, scr + 2);
   HIP_TRY(ctx, hipMemcpyAsync(got, scr, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  c->mass_abs_sum = got[2] * (1.0 + 1e-9);         // (the fp sum itself is only known to rounding)
   if (got[0] == got[1] && got[0] >= 0.0) {
     k_fill_f64<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->b(A_M), c->n, got[0]);
     HIP_TRY(ctx, hipGetLastError());

@@ -255,6 +255,29 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
     if (xi[i] != cfg->xmin + t) S.xi_uniform = 0;
   }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
+  S.detC = 0.0;
+  {
+    // bound of a unit-mass particle's moment contribution |4 pi P0 x_k Ph(l,m)(cos theta) trig|, for the
+    // rounding grid of the deterministic mode: max |p0| on the grid x max |Ph| on a fine cos(theta) grid
+    double p0max = 0.0, phmax = 0.0;
+    for (int i = 0; i < numr; i++) p0max = fmax(p0max, fabs(p0[i]));
+    std::vector<double> ph((size_t)(L + 1) * (L + 1), 0.0);
+    for (int k = 0; k <= 4000; k++) {
+      const double x = -1.0 + k / 2000.0, sx = sqrt(fmax(0.0, (1.0 - x) * (1.0 + x)));
+      double pmm = lc_E(0);
+      for (int m = 0; m <= L; m++) {
+        if (m > 0) pmm *= lc_E(m) * sx;
+        double pl2 = 0.0, pl1 = 0.0;
+        for (int l = m; l <= L; l++) {
+          const double plm = (l == m) ? pmm : (l == m + 1) ? lc_a(l, m) * x * pl1 : lc_a(l, m) * x * pl1 - pl2;
+          pl2 = pl1;
+          pl1 = plm;
+          phmax = fmax(phmax, fabs(plm));
+        }
+      }
+    }
+    f->term_max = 4.0 * M_PI * p0max * phmax * 2.0;
+  }
   *out = f;
   return EXP_AMD_OK;
 }
@@ -275,6 +298,15 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 {
   SphDev S = f->dev;
   S.cx = center[0]; S.cy = center[1]; S.cz = center[2];
+  return S;
+}
+
+// ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding
+// grid that keeps every partial sum of this component exact (common.h: expamd_det_constant)
+static SphDev dev_acc(const SphForce *f, const exp_amd_comp *c)
+{
+  SphDev S = dev_for(f, c->center);
+  S.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * f->term_max);
   return S;
 }
 
@@ -337,7 +369,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   exp_amd_ctx *ctx = f->ctx;
   const int lo = f->multistep ? f->mlevel : 0;
   const int hi = f->multistep ? f->mlevel : 0;
-  SphDev S = dev_for(f, c->center);
+  SphDev S = dev_acc(f, c);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), ctx->stream));
   f->w_clean = false;
   // used: multistep = 0 counts the last accumulation; a multistep force adds up the levels of the
@@ -431,7 +463,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // sparse levels above: advanced in place
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
-  const SphDev S = dev_for(f, c->center);
+  const SphDev S = dev_acc(f, c);
   const size_t wl = (size_t)(cfg.numr - 1) * S.nrows * 2;
   // the per-level moment buffers are left clean by the contraction that consumes them (below); only
   // a buffer the plain per-level API may have used (level 0's) is cleared here
@@ -519,18 +551,25 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     const size_t need = t->n / 64 + 8;
     if (f->work_cap < need) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx, f->d_work.alloc(need + 2));          // work list + two counters (used alternately)
-      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + need, 0, 2 * sizeof(uint32_t), ctx->stream));
+      HIP_TRY(ctx, f->d_work.alloc(SPH_WORK_STRIDE * need + 2));   // work list + two counters (used alternately)
+      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + SPH_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), ctx->stream));
       f->work_cap = need;
       f->work_flip = 0;
     }
-    const bool slow = t->sorted_for != f || all_sparse;
+    // Waterfall fast pass: every lane gets the uniform-wave arithmetic whatever its neighbours are --
+    // what the deterministic mode needs (the path a particle takes must not depend on the slot it
+    // landed in).  (Tried for targets in ANOTHER basis' cell order too: a wave of disk particles spans
+    // too many radial cells, 4.5 ms against 2.8 ms by gathers in config 4.)
+    const bool foreign = t->sorted_for != f;
+    const bool wfall = ctx->deterministic;
+    const bool slow = !wfall && (foreign || all_sparse);
+    uint32_t *cnt = f->d_work.p + SPH_WORK_STRIDE * f->work_cap;
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
-                   f->d_work.p, f->d_work.p + f->work_cap + f->work_flip, slow ? 1 : 0, ctx,
+                   f->d_work.p, cnt + f->work_flip, slow ? 1 : 0, ctx,
                    prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1,
-                   f->d_work.p + f->work_cap + (1 - f->work_flip)};
+                   cnt + (1 - f->work_flip), wfall ? 1 : 0};
     k_force_launch[f->cfg.lmax](a);
     if (!slow) f->work_flip ^= 1;
   }
@@ -627,7 +666,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   c->acc_live = false;
 
   // ---- main stream: accumulate the halves as they arrive, reduce, project, force
-  SphDev S = dev_for(f, c->center);
+  SphDev S = dev_acc(f, c);
   HIP_TRY(ctx, hipMemsetAsync(f->d_W.p, 0, (size_t)(f->cfg.numr - 1) * S.nrows * 2 * sizeof(double), V));
   f->w_clean = false;
   HIP_TRY(ctx, hipMemsetAsync(f->d_used.p, 0, sizeof(unsigned long long), V));
@@ -652,8 +691,8 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     const size_t need = c->n / 64 + 8;
     if (f->work_cap < need) {
       HIP_TRY(ctx, hipStreamSynchronize(V));
-      HIP_TRY(ctx, f->d_work.alloc(need + 2));
-      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + need, 0, 2 * sizeof(uint32_t), V));
+      HIP_TRY(ctx, f->d_work.alloc(SPH_WORK_STRIDE * need + 2));
+      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + SPH_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), V));
       f->work_cap = need;
       f->work_flip = 0;
     }
@@ -666,8 +705,8 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
       SphForceArgs a{Sh, c->a(A_X), c->a(A_Y), c->a(A_Z), c->half_off.p, h, h, f->d_T4.p,
                      c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->a(A_VX), c->a(A_VY),
                      c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,
-                     f->d_work.p, f->d_work.p + f->work_cap + f->work_flip, 0, ctx, c->key.p, dt_kick, dt, 0,
-                     f->d_work.p + f->work_cap + (1 - f->work_flip)};
+                     f->d_work.p, f->d_work.p + SPH_WORK_STRIDE * f->work_cap + f->work_flip, 0, ctx, c->key.p, dt_kick, dt, 0,
+                     f->d_work.p + SPH_WORK_STRIDE * f->work_cap + (1 - f->work_flip), ctx->deterministic ? 1 : 0};
       k_force_launch[f->cfg.lmax](a);
       f->work_flip ^= 1;
     }
@@ -722,7 +761,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     HIP_TRY(ctx, hipMemsetAsync(f->d_Wd.p, 0, f->d_Wd.bytes(), ctx->stream));
     f->wd_clean = true;
   }
-  const SphDev S = dev_for(f, c->center);
+  const SphDev S = dev_acc(f, c);
   size_t nr = 0;
   if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
   if (nr) {

@@ -15,6 +15,7 @@ struct SphForce : exp_amd_force {
   void *cov = nullptr;              // sub-sample covariance state (sph_cov.hip), analysis only
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)
   size_t work_cap = 0;
+  double term_max = 0.0;            // max |P0| x max |Ph(l,m)| x 4 pi x 2: bound of one unit-mass contribution
   int work_flip = 0;                // which of the two work-list counters the next fast pass counts into
   // PotAccel::used of a multistep run: the counts of every level accumulated while tnow == resetT,
   // i.e. during the first sub-step of a master step (src/SphericalBasis.cc:796, :860-862, :1004-1010);

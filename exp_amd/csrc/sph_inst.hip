@@ -33,8 +33,12 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   LC.bstart[LC.nlev] = nb;
   if (nb == 0) return;
   dim3 grid(nb, (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
-  k_sph_accumulate<LMAX><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
-                                                                LC, a.W, a.used, a.wlevels);
+  if (a.S.detC != 0.0)      // deterministic mode (exp_amd_ctx_set_deterministic): order-independent sums
+    k_sph_accumulate<LMAX, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                        LC, a.W, a.used, a.wlevels);
+  else
+    k_sph_accumulate<LMAX, false><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                         LC, a.W, a.used, a.wlevels);
 }
 
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
@@ -45,18 +49,23 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
     // one launch k+1 will count into (no memset between the launches)
     {
       ProfScope ps(a.ctx, "k_sph_force");
-      k_sph_force<LMAX, true><<<cdiv(a.grid, SPH_FORCE_CHUNKS), 256, 0, a.stream>>>(
-          a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-          a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
+      if (a.waterfall)
+        k_sph_force<LMAX, 2><<<cdiv(a.grid, SPH_FORCE_CHUNKS), 256, 0, a.stream>>>(
+            a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+            a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
+      else
+        k_sph_force<LMAX, 1><<<cdiv(a.grid, SPH_FORCE_CHUNKS), 256, 0, a.stream>>>(
+            a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+            a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
     }
-    // deferred waves: the grid is an upper bound, surplus waves leave on the count
+    // deferred waves / lanes: the grid is an upper bound, surplus waves leave on the count
     ProfScope ps(a.ctx, "k_sph_force_general");
-    k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
+    k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
         a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next);
   } else {
     ProfScope ps(a.ctx, "k_sph_force_general");
-    k_sph_force<LMAX, false><<<a.grid, 256, 0, a.stream>>>(
+    k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
         a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
   }

@@ -44,6 +44,8 @@ struct SphDev {
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
   int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
+  double detC;           // deterministic mode: 1.5 * 2^(52+e), every contribution is rounded to the grid 2^e
+                         // before it is added (acc_add below); 0: off
   double dsmall;         // added to r (src/expand.H:130: 1e-16; pyEXP: 1e-20 accumulating, 1e-18 evaluating)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
@@ -364,9 +366,29 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   return in;
 }
 
+// Deterministic (order-independent) accumulation: with DET every contribution w*p is first rounded
+// to a fixed absolute grid 2^e -- (w*p + C) - C with C = 1.5 * 2^(52+e), one FMA and one subtraction,
+// both exact after the FMA's rounding -- chosen by the host so that every partial sum of the launch
+// stays below 2^53 * 2^e.  All later additions (registers, the LDS-transposed wave reduction, the fp64
+// atomics on W) are then EXACT, hence associative: the sums no longer depend on the order the
+// particles happen to sit in, and a run is bit-reproducible.  Costs two more VALU ops per term.
+template <bool DET>
+__device__ __forceinline__ void acc_add(double &a, double w, double p, double C)
+{
+  if constexpr (DET) {
+    double t = fma(w, p, C);
+    t -= C;
+    a += t;
+  } else {
+    a = fma(w, p, a);
+  }
+}
+// ... for a value about to be added by an atomic
+__device__ __forceinline__ double det_round(double v, double C) { return C != 0.0 ? (v + C) - C : v; }
+
 // Rows with m in [MLO, MHI] of one 64-particle group: ballot waterfall over the cells present,
 // register accumulation, LDS-transposed flush when the wave's current cell changes.
-template <int LMAX, int MLO, int MHI, int NV>
+template <int LMAX, int MLO, int MHI, int NV, bool DET>
 __device__ __forceinline__ void
 sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int &cur,
               double *scratch, double *__restrict__ W)
@@ -425,14 +447,14 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
             pl1 = plm;
             if constexpr (m == 0) {
               constexpr int k = acc_base(LMAX, MLO, 0) + (l - m);
-              acc[2 * k] = fma(a1, plm, acc[2 * k]);
-              acc[2 * k + 1] = fma(a2, plm, acc[2 * k + 1]);
+              acc_add<DET>(acc[2 * k], a1, plm, S.detC);
+              acc_add<DET>(acc[2 * k + 1], a2, plm, S.detC);
             } else {
               constexpr int k = acc_base(LMAX, MLO, m) + 2 * (l - m);
-              acc[2 * k] = fma(a1c, plm, acc[2 * k]);
-              acc[2 * k + 1] = fma(a2c, plm, acc[2 * k + 1]);
-              acc[2 * k + 2] = fma(a1s, plm, acc[2 * k + 2]);
-              acc[2 * k + 3] = fma(a2s, plm, acc[2 * k + 3]);
+              acc_add<DET>(acc[2 * k], a1c, plm, S.detC);
+              acc_add<DET>(acc[2 * k + 1], a2c, plm, S.detC);
+              acc_add<DET>(acc[2 * k + 2], a1s, plm, S.detC);
+              acc_add<DET>(acc[2 * k + 3], a2s, plm, S.detC);
             }
           });
         }
@@ -444,7 +466,7 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
 
 // One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend), computing
 // the per-particle inputs itself.
-template <int LMAX, int MLO, int MHI>
+template <int LMAX, int MLO, int MHI, bool DET>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                     const double *__restrict__ Z, const double *__restrict__ M,
@@ -474,7 +496,7 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
       nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
     }
     if (MLO == 0 && in.idx >= 0) used++;
-    sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
+    sph_acc_group<LMAX, MLO, MHI, NV, DET>(S, lc, in, acc, cur, scratch, W);
   }
   if (cur >= 0)
     wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
@@ -493,7 +515,7 @@ struct AccShared {
   int idx[2][ACC_WAVES * 64];
 };
 
-template <int LMAX, int MLO, int MHI>
+template <int LMAX, int MLO, int MHI, bool DET>
 __device__ __forceinline__ void
 sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
                       const double *__restrict__ Y, const double *__restrict__ Z,
@@ -538,7 +560,7 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
       in.costh = sh.v[par][0][q]; in.cphi = sh.v[par][1][q]; in.sphi = sh.v[par][2][q];
       in.a1 = sh.v[par][3][q];    in.a2 = sh.v[par][4][q];   in.sinth = sh.v[par][5][q];
       in.idx = sh.idx[par][q];
-      sph_acc_group<LMAX, MLO, MHI, NV>(S, lc, in, acc, cur, scratch, W);
+      sph_acc_group<LMAX, MLO, MHI, NV, DET>(S, lc, in, acc, cur, scratch, W);
     }
   }
   if (cur >= 0)
@@ -566,7 +588,7 @@ template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
   return acc_shared<LMAX>() ? 4 : LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
 }
 
-template <int LMAX>
+template <int LMAX, bool DET>
 __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
@@ -603,7 +625,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
       __syncthreads();
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out)
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
     if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
     else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
@@ -616,7 +638,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const size_t cbeg = beg + chunk * ACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out)
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI, DET>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out)
   if constexpr (LMAX <= 4) {
     RUN(0, LMAX);
   } else if constexpr (LMAX <= 7) {
@@ -714,19 +736,21 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
       constexpr int row = row_of(l, m, 0);
       if (mover) {
         const double yc = (m == 0) ? plm : plm * cm;
-        unsafeAtomicAdd(wto + 2 * row, a1 * yc);
-        unsafeAtomicAdd(wto + 2 * row + 1, a2 * yc);
+        const double v1 = det_round(a1 * yc, S.detC), v2 = det_round(a2 * yc, S.detC);
+        unsafeAtomicAdd(wto + 2 * row, v1);
+        unsafeAtomicAdd(wto + 2 * row + 1, v2);
         if (sub) {
-          unsafeAtomicAdd(wfr + 2 * row, -(a1 * yc));
-          unsafeAtomicAdd(wfr + 2 * row + 1, -(a2 * yc));
+          unsafeAtomicAdd(wfr + 2 * row, -v1);
+          unsafeAtomicAdd(wfr + 2 * row + 1, -v2);
         }
         if constexpr (m > 0) {
           const double ys = plm * sm;
-          unsafeAtomicAdd(wto + 2 * row + 2, a1 * ys);
-          unsafeAtomicAdd(wto + 2 * row + 3, a2 * ys);
+          const double u1 = det_round(a1 * ys, S.detC), u2 = det_round(a2 * ys, S.detC);
+          unsafeAtomicAdd(wto + 2 * row + 2, u1);
+          unsafeAtomicAdd(wto + 2 * row + 3, u2);
           if (sub) {
-            unsafeAtomicAdd(wfr + 2 * row + 2, -(a1 * ys));
-            unsafeAtomicAdd(wfr + 2 * row + 3, -(a2 * ys));
+            unsafeAtomicAdd(wfr + 2 * row + 2, -u1);
+            unsafeAtomicAdd(wfr + 2 * row + 3, -u2);
           }
         }
       }
@@ -945,6 +969,20 @@ sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, dou
   return o;
 }
 
+// out-of-line copy for the waterfall loop of MODE 2: inlined into a loop, the (l, m) recurrence literals
+// are hoisted out of it as loop invariants -- several hundred SGPRs, i.e. a kernel that lives in scratch
+template <int LMAX>
+__device__ __noinline__ ForceOut
+sph_field_fast_call(cdp t4, double costh, double somx2, double cphi, double sphi, double x2, double pf)
+{
+  // (arguments of a real call arrive in vector registers: the wave-uniform table address goes back
+  // to scalar registers for the s_load pipeline)
+  const unsigned long long a = (unsigned long long)t4;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return sph_field_fast<LMAX>((cdp)(((unsigned long long)hi << 32) | lo), costh, somx2, cphi, sphi, x2, pf);
+}
+
 // Two launches share this body.  FAST: every wave whose lanes sit in one radial cell with no
 // exterior particle is done here; the rest push their first slot on `work` and leave.
 // !FAST: one wave per work item (or per 64-slot chunk when work == nullptr, i.e. "all waves").
@@ -955,7 +993,16 @@ sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, dou
 #define SPH_FORCE_CHUNKS 1
 #endif
 // One 64-particle chunk of one wave (slots base .. base+63 of [.., end)).
-template <int LMAX, bool FAST>
+// MODE 0: general evaluation of the lanes in `lanemask`.  MODE 1: the fast pass (a wave either is
+// cell-uniform and done here, or is deferred whole).  MODE 2: the fast pass as a WATERFALL -- the
+// wave's distinct radial cells are served one after the other by the same scalar-table code, so
+// every non-special lane gets exactly the arithmetic it would get in a uniform wave whatever its
+// neighbours are (deterministic mode), and targets that are not in this basis' cell order but
+// still local in radius (another component's particles) avoid the gather path; only the special
+// lanes (polar axis, exterior) go to the general pass, by lane mask.
+// Work-list entries are three words: first slot, lane mask low / high.
+#define SPH_WORK_STRIDE 3
+template <int LMAX, int MODE>
 __device__ __forceinline__ void
 sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                 const double *__restrict__ Z, size_t base, size_t end, const double *__restrict__ T4,
@@ -963,11 +1010,12 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
                 double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
                 double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ work,
                 uint32_t *__restrict__ nwork, uint32_t *__restrict__ key_out, double nk_dtk,
-                double nk_dtd, int store_v)
+                double nk_dtd, int store_v, unsigned long long lanemask = ~0ull)
 {
+  constexpr bool FAST = MODE != 0;
   const int lane = threadIdx.x & 63;
   const size_t i = base + lane;
-  const bool valid = i < end;
+  bool valid = i < end && ((lanemask >> lane) & 1ull);
   double xx = 1, yy = 0, zz = 0;          // idle lanes: a harmless off-axis point
   double px = 0, py = 0, pz = 0;          // kept for the next-step key (a reload at the end of the
   if (valid) {                            // wave would expose a full memory round trip)
@@ -998,23 +1046,58 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
     int idx = sph_cell(S, xi);
-    const int idx_u = __builtin_amdgcn_readfirstlane(idx);
-    if (!valid) idx = idx_u;
-    const bool fast = __all(idx == idx_u) && !__any(special && valid);
-    if (!fast) {
-      if (lane == 0) work[atomicAdd(nwork, 1u)] = (uint32_t)base;
-      return;
-    }
-    // get_pot / get_force weights (exputil/SLGridMP2.cc:894-902, :971-985)
-    const double x1 = (S.xi[idx_u + 1] - xi) * S.inv_dxi;
-    const double x2 = (xi - S.xi[idx_u]) * S.inv_dxi;
-    P0 = x1 * S.p0[idx_u] + x2 * S.p0[idx_u + 1];
-    const int jdx = idx_u < 1 ? 1 : idx_u;
-    const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
     ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
     dfac = -(r * r) * iR2;
-    cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
-    o = sph_field_fast<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
+    if constexpr (MODE == 1) {
+      const int idx_u = __builtin_amdgcn_readfirstlane(idx);
+      if (!valid) idx = idx_u;
+      const bool fast = __all(idx == idx_u) && !__any(special && valid);
+      if (!fast) {
+        if (lane == 0) {
+          const uint32_t w = atomicAdd(nwork, 1u);
+          work[SPH_WORK_STRIDE * w] = (uint32_t)base;
+          work[SPH_WORK_STRIDE * w + 1] = 0xffffffffu;
+          work[SPH_WORK_STRIDE * w + 2] = 0xffffffffu;
+        }
+        return;
+      }
+      // get_pot / get_force weights (exputil/SLGridMP2.cc:894-902, :971-985)
+      const double x1 = (S.xi[idx_u + 1] - xi) * S.inv_dxi;
+      const double x2 = (xi - S.xi[idx_u]) * S.inv_dxi;
+      P0 = x1 * S.p0[idx_u] + x2 * S.p0[idx_u + 1];
+      const int jdx = idx_u < 1 ? 1 : idx_u;
+      const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+      cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
+      o = sph_field_fast<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
+    } else {
+      // the same weights from the lane's own cell (gathers of the small xi / p0 tables: same operands,
+      // same operations as above)
+      const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+      const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+      P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+      const int jdx = idx < 1 ? 1 : idx;
+      const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+      const unsigned long long sp = __ballot(valid && special);
+      if (sp && lane == 0) {              // the special lanes of this chunk: general pass, by lane mask
+        const uint32_t w = atomicAdd(nwork, 1u);
+        work[SPH_WORK_STRIDE * w] = (uint32_t)base;
+        work[SPH_WORK_STRIDE * w + 1] = (uint32_t)sp;
+        work[SPH_WORK_STRIDE * w + 2] = (uint32_t)(sp >> 32);
+      }
+      if (special) valid = false;
+      unsigned long long todo = __ballot(valid);
+      o = ForceOut{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+      while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int idx_u = __builtin_amdgcn_readfirstlane(__shfl(idx, lead));
+        const bool sel = valid && idx == idx_u;
+        cdp t4 = (cdp)(T4 + (size_t)idx_u * tq);
+        const ForceOut q = sph_field_fast_call<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
+        if (sel) o = q;
+        todo &= ~__ballot(sel);
+      }
+    }
   } else {
     // src/SphericalBasis.cc:1545-1560
     r = sqrt(fac + zz * zz) + S.dsmall;
@@ -1108,8 +1191,8 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
   }
 }
 
-template <int LMAX, bool FAST>
-__global__ void __launch_bounds__(256, FAST ? SPH_FORCE_WAVES : 1)
+template <int LMAX, int MODE>
+__global__ void __launch_bounds__(256, MODE == 1 ? SPH_FORCE_WAVES : MODE == 2 ? 2 : 1)
 k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
             int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
@@ -1121,28 +1204,31 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
 {
   if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
-  if constexpr (FAST) {
+  if constexpr (MODE != 0) {
     // SPH_FORCE_CHUNKS consecutive chunks per wave (rolled loop: the literal recurrence constants
     // are rematerialised, not hoisted) amortise the wave launch and its first-load latency.
 #pragma unroll 1
     for (int c = 0; c < SPH_FORCE_CHUNKS; c++) {
       const size_t base = beg + (((size_t)blockIdx.x * SPH_FORCE_CHUNKS + c) * 256 + (threadIdx.x & ~63));
       if (base >= end) return;
-      sph_force_chunk<LMAX, true>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+      sph_force_chunk<LMAX, MODE>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
                                   assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v);
     }
   } else {
     size_t base;
+    unsigned long long mask = ~0ull;
     if (work == nullptr) {
       base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
       if (base >= end) return;
     } else {
       const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
       if (w >= *nwork) return;
-      base = work[w];
+      base = work[SPH_WORK_STRIDE * w];
+      mask = (unsigned long long)work[SPH_WORK_STRIDE * w + 1] |
+             ((unsigned long long)work[SPH_WORK_STRIDE * w + 2] << 32);
     }
-    sph_force_chunk<LMAX, false>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
-                                 assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v);
+    sph_force_chunk<LMAX, 0>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+                             assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v, mask);
   }
 }
 
@@ -1175,12 +1261,13 @@ struct SphForceArgs {
   unsigned grid;
   hipStream_t stream;
   uint32_t *work, *nwork;   // slow-path work list (first slot of each deferred wave) + count
-  int all_slow;             // target is not in this force's cell order: skip the fast pass
+  int all_slow;             // skip the fast pass (every wave takes the general evaluation)
   exp_amd_ctx *ctx;         // for the per-launch profiling scopes
   uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
   double nk_dtk, nk_dtd;    // ... for that step's kick and drift
   int store_v;              // 0: the half-kick is deferred, v is left as it is
   uint32_t *nwork_next = nullptr;   // the counter the next launch will use (cleared by this one's general pass)
+  int waterfall = 0;        // fast pass as a waterfall over each wave's radial cells (MODE 2)
 };
 
 struct SphUpdArgs {

@@ -81,6 +81,10 @@ class Context:
         """In-place sum over ranks of ``count`` doubles at a device pointer, on the context's stream."""
         check(self.lib.exp_amd_comm_allreduce(self.h, c_void_p(int(device_ptr)), int(count)), self.h)
 
+    def set_deterministic(self, on: bool = True) -> None:
+        """Order-independent coefficient sums: runs become bit-reproducible (include/exp_amd.h)."""
+        check(self.lib.exp_amd_ctx_set_deterministic(self.h, int(bool(on))), self.h)
+
     def set_dense_min(self, nmin: int) -> None:
         """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
         check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)

@@ -57,6 +57,15 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
  * default.  Measured on MI355X at 1e8 particles: 12.33 -> 12.12 ms per step only, because the
  * co-running kernels slow each other down (force 5.6 -> 7.1 ms, accumulate 2.9 -> 4.5 ms).        */
 int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
+/* Deterministic mode (off by default; EXP_AMD_DETERMINISTIC sets the default).  The coefficient sums
+ * are reductions over millions of particles by fp64 atomics in whatever order the hardware serves
+ * them, so two runs agree to rounding (~1e-15), not bit for bit -- like the reference's thread and MPI
+ * reduction order.  With `on`, every particle's contribution is first rounded to a fixed absolute
+ * grid 2^e chosen from a bound of the sum (4 pi x sum|m| x max|table|), fine enough to stay far below
+ * the 1e-10 coefficient tolerance; all additions are then exact, hence independent of their order,
+ * and a run is bit-reproducible on a given number of ranks.  Costs two extra fp64 operations per
+ * accumulated term (~1.5x the accumulation kernels, ~10 % of a step).                             */
+int  exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on);
 /* Tuning knob of the block-multistep step loop (exp_amd_sim_step): time-step levels holding fewer
  * than `nmin` particles are kept level-contiguous but not cell-sorted -- advanced in place,
  * accumulated with per-particle atomics, forces by the gather path -- because a sparse level has
