@@ -398,11 +398,32 @@ class SphericalSL(BiorthBasis):
         c.close()
 
     # -- covariance by sub-sampling (expui/BiorthBasis.H:425-470) -------------------------------------
-    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100) -> None:
-        """``enableCoefCovariance(pcavar, sampT)``: (re)initialise the sub-sample means and covariances
-        (init_covariance, expui/BiorthBasis.cc:342-365); the HDF5 covariance store is not carried over."""
+    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100, ftype: bool = False,
+                             covr_tot: bool = True, covar: bool = True) -> None:
+        """``enableCoefCovariance(pcavar, sampT, ftype, covr_tot, covar)`` (expui/BiorthBasis.H:467-482):
+        (re)initialise the sub-sample means and covariances (init_covariance, expui/BiorthBasis.cc:342-365)
+        and the HDF5 store's flags: summed covariance only (covr_tot), full matrices or diagonals (covar);
+        32-bit storage (ftype) is not written by this build."""
         self.pcavar, self.sampT = bool(pcavar), max(1, int(sampT))
+        self._covar_flags = (bool(covr_tot), bool(covar))
+        if ftype:
+            raise RuntimeError("enableCoefCovariance: 32-bit covariance storage (ftype) is not supported")
         self.force.cov_enable(self.sampT if self.pcavar else 0)
+
+    def writeCoefCovariance(self, compname: str, runtag: str, time: float = 0.0) -> str:
+        """``Spherical::writeCoefCovariance`` (expui/BiorthBasis.H:433-463) -> ``SubsampleCovariance::
+        writeCoefCovariance`` (expui/Covariance.cc:283-417): create or extend ``coefcovar.<compname>.
+        <runtag>.h5`` with the current sub-sample counts, masses, means and covariances."""
+        if not getattr(self, "pcavar", False):
+            raise RuntimeError("Spherical::writeCoefCovariance: covariance storage not initialized")
+        from . import h5cache
+        d = self.force.cov_get()
+        fname = f"coefcovar.{compname}.{runtag}.h5"
+        summed, covar = getattr(self, "_covar_flags", (True, True))
+        h5cache.covar_append(fname, "SphereSL", 0, (self.lmax, self.nmax), (self.scale, self.rmin, self.rmax),
+                             time, d["counts"], d["masses"], d["mean"], d["covr"].astype(np.complex128),
+                             summed=summed, covar=covar)
+        return fname
 
     def getCovarSamples(self):
         """(sampleCounts, sampleMasses), one entry per sub-sample."""
@@ -596,9 +617,28 @@ class Cylindrical(BiorthBasis):
         c.close()
 
     # -- covariance by sub-sampling (expui/BiorthBasis.H:1120-1145; exputil/EmpCylSL.cc:4974-5015) ---
-    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100) -> None:
+    def enableCoefCovariance(self, pcavar: bool, sampT: int = 100, ftype: bool = False,
+                             covr_tot: bool = True, covar: bool = True) -> None:
+        """expui/BiorthBasis.H:1133-1148"""
         self.pcavar, self.sampT = bool(pcavar), max(1, int(sampT))
+        self._covar_flags = (bool(covr_tot), bool(covar))
+        if ftype:
+            raise RuntimeError("enableCoefCovariance: 32-bit covariance storage (ftype) is not supported")
         self.force.cov_enable(self.sampT if self.pcavar else 0)
+
+    def writeCoefCovariance(self, compname: str, runtag: str, time: float = 0.0) -> str:
+        """``Cylindrical::writeCoefCovariance`` (expui/BiorthBasis.H:1120-1131); parameters of
+        ``Cylindrical::writeCovarH5Params`` (expui/BiorthBasis.cc:5201-5210)."""
+        if not getattr(self, "pcavar", False):
+            raise RuntimeError("Cylindrical::writeCoefCovariance: covariance storage not initialized")
+        from . import h5cache
+        d = self.force.cov_get()
+        fname = f"coefcovar.{compname}.{runtag}.h5"
+        summed, covar = getattr(self, "_covar_flags", (True, True))
+        h5cache.covar_append(fname, "Cylindrical", 1, (self.mmax, self.nmax),
+                             (self.rcylmin, self.rcylmax, self.acyl, float(self.conf.get("bias", 1.0)), self.hcyl),
+                             time, d["counts"], d["masses"], d["mean"], d["covr"], summed=summed, covar=covar)
+        return fname
 
     def getCovarSamples(self):
         d = self.force.cov_get()

@@ -17,6 +17,7 @@
  * (exp_amd/libexp_amd_h5.so); no HighFive, no C++.
  */
 #include <hdf5.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -592,6 +593,219 @@ static int coef_read(const char *path, int count, int ldim, int nmax, double *ti
     H5Gclose(g);
   }
   H5Tclose(ct);
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+/* ---- coefficient covariance store ----------------------------------------------------------------
+ * SubsampleCovariance::writeCoefCovariance / extendCoefCovariance / writeCovarH5
+ * (expui/Covariance.cc:17-417; include/Covariance.H) with the per-basis parameters of
+ * Spherical::writeCovarH5Params / Cylindrical::writeCovarH5Params (expui/BiorthBasis.cc:5192-5210),
+ * file version "1.1", FloatSize 8.  Root: attributes CovarianceFileVersion, BasisID, FloatSize and
+ * the basis parameters; dataset `count` (unsigned); group snapshots/%08d with attributes Time
+ * (rounded to 1e-8), sampleSize, angularSize, rankSize and the datasets sampleCounts (int),
+ * sampleMasses, coefficients_real / _imag [T*ltot*nmax] and either covariance_real_total / _imag_total
+ * [ltot*nmax(nmax+1)/2] (summed over the sub-samples, upper triangles, the default) or covariance_real /
+ * _imag per sub-sample (upper triangles if `covar`, else diagonals).  Eigen vectors are stored by
+ * HighFive as [n][1] datasets, chunked, shuffled and deflated (level 5) as the reference does.
+ *   kind 0: sphere    ipar = {lmax, nmax},  dpar = {scale, rmin, rmax}
+ *   kind 1: cylinder  ipar = {mmax, nmax},  dpar = {rcylmin, rcylmax, acyl, bias, hcyl}
+ * mean[T][ltot][nmax][2], covr[T][ltot][nmax][nmax][2] (re, im); covr may be NULL (no covariance). */
+static int put_uint(hid_t loc, const char *name, unsigned v)
+{
+  hid_t s = H5Screate(H5S_SCALAR);
+  hid_t a = H5Acreate2(loc, name, H5T_NATIVE_UINT, s, H5P_DEFAULT, H5P_DEFAULT);
+  int rc = (a < 0) ? -1 : (H5Awrite(a, H5T_NATIVE_UINT, &v) < 0 ? -1 : 0);
+  if (a >= 0) H5Aclose(a);
+  H5Sclose(s);
+  return rc;
+}
+
+static int put_vec(hid_t loc, const char *name, hid_t type, size_t n, const void *data)
+{
+  hsize_t dims[2] = {(hsize_t)n, 1}, chunk[2] = {(hsize_t)(n < 1048576 ? (n ? n : 1) : 1048576), 1};
+  hid_t s = H5Screate_simple(2, dims, NULL);
+  hid_t p = H5Pcreate(H5P_DATASET_CREATE);
+  if (n) {
+    H5Pset_chunk(p, 2, chunk);
+    H5Pset_shuffle(p);
+    H5Pset_deflate(p, 5);
+  }
+  hid_t d = H5Dcreate2(loc, name, type, s, H5P_DEFAULT, p, H5P_DEFAULT);
+  int rc = (d < 0) ? -1 : (H5Dwrite(d, type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0 ? -1 : 0);
+  if (d >= 0) H5Dclose(d);
+  H5Pclose(p);
+  H5Sclose(s);
+  return rc;
+}
+
+static double covar_round_time(double t) { return floor(t * 1.0e8 + 0.5) / 1.0e8; }
+
+int exp_h5_covar_append(const char *path, const char *basisID, int kind, const int *ipar, const double *dpar,
+                        int summed, int covar, double time, int sampT, int ltot, int nmax, const int *counts,
+                        const double *masses, const double *mean, const double *covr)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  if (summed) covar = 1;                                   /* expui/Covariance.cc:14 */
+  long total = 0;
+  for (int t = 0; t < sampT; t++) total += counts[t];
+  if (total == 0) return 1;                                /* "no data": nothing is written (:309-312) */
+  int rc = 0;
+  unsigned count = 0;
+  hid_t f = -1, snaps = -1, cd = -1;
+  htri_t isf = H5Fis_hdf5(path);
+  if (isf > 0) f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+  if (f >= 0 && H5Aexists(f, "CovarianceFileVersion") > 0) {          /* extendCoefCovariance */
+    cd = H5Dopen2(f, "count", H5P_DEFAULT);
+    if (cd < 0 || H5Dread(cd, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
+    snaps = H5Gopen2(f, "snapshots", H5P_DEFAULT);
+  } else {
+    if (f >= 0) H5Fclose(f);
+    f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    if (f < 0) return -1;
+    rc |= put_str(f, "CovarianceFileVersion", "1.1");
+    rc |= put_str(f, "BasisID", basisID);
+    rc |= put_int(f, "FloatSize", 8);
+    if (kind == 0) {
+      rc |= put_int(f, "lmax", ipar[0]); rc |= put_int(f, "nmax", ipar[1]);
+      rc |= put_dbl(f, "scale", dpar[0]); rc |= put_dbl(f, "rmin", dpar[1]); rc |= put_dbl(f, "rmax", dpar[2]);
+    } else {
+      rc |= put_int(f, "mmax", ipar[0]); rc |= put_int(f, "nmax", ipar[1]);
+      rc |= put_dbl(f, "rcylmin", dpar[0]); rc |= put_dbl(f, "rcylmax", dpar[1]); rc |= put_dbl(f, "acyl", dpar[2]);
+      rc |= put_dbl(f, "bias", dpar[3]); rc |= put_dbl(f, "hcyl", dpar[4]);
+    }
+    hid_t s = H5Screate(H5S_SCALAR);
+    cd = H5Dcreate2(f, "count", H5T_NATIVE_UINT, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    H5Sclose(s);
+    snaps = H5Gcreate2(f, "snapshots", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  }
+  if (snaps < 0 || cd < 0) rc = -1;
+  if (rc == 0) {
+    char nm[16];
+    snprintf(nm, sizeof nm, "%08u", count);
+    hid_t g = H5Gcreate2(snaps, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (g < 0) rc = -1;
+    else {
+      rc |= put_dbl(g, "Time", covar_round_time(time));
+      rc |= put_vec(g, "sampleCounts", H5T_NATIVE_INT, (size_t)sampT, counts);
+      rc |= put_vec(g, "sampleMasses", H5T_NATIVE_DOUBLE, (size_t)sampT, masses);
+      rc |= put_uint(g, "sampleSize", (unsigned)sampT);
+      rc |= put_uint(g, "angularSize", (unsigned)ltot);
+      rc |= put_uint(g, "rankSize", (unsigned)nmax);
+      const size_t nc = (size_t)sampT * ltot * nmax;
+      double *re = (double *)malloc(sizeof(double) * (nc ? nc : 1)), *im = (double *)malloc(sizeof(double) * (nc ? nc : 1));
+      for (size_t c = 0; c < nc; c++) { re[c] = mean[2 * c]; im[c] = mean[2 * c + 1]; }
+      rc |= put_vec(g, "coefficients_real", H5T_NATIVE_DOUBLE, nc, re);
+      rc |= put_vec(g, "coefficients_imag", H5T_NATIVE_DOUBLE, nc, im);
+      free(re); free(im);
+      if (covr) {
+        const size_t diag = covar ? (size_t)nmax * (nmax + 1) / 2 : (size_t)nmax;
+        const size_t nv = (size_t)ltot * diag * (summed ? 1 : (size_t)sampT);
+        re = (double *)calloc(nv ? nv : 1, sizeof(double));
+        im = (double *)calloc(nv ? nv : 1, sizeof(double));
+        for (int T = 0; T < sampT; T++) {
+          size_t c = summed ? 0 : (size_t)T * ltot * diag;
+          for (int l = 0; l < ltot; l++)
+            for (int n1 = 0; n1 < nmax; n1++) {
+              const double *row = covr + ((((size_t)T * ltot + l) * nmax + n1) * nmax) * 2;
+              if (covar) {
+                for (int n2 = n1; n2 < nmax; n2++, c++) { re[c] += row[2 * n2]; im[c] += row[2 * n2 + 1]; }
+              } else {
+                re[c] = row[2 * n1]; im[c] = row[2 * n1 + 1]; c++;
+              }
+            }
+        }
+        rc |= put_vec(g, summed ? "covariance_real_total" : "covariance_real", H5T_NATIVE_DOUBLE, nv, re);
+        rc |= put_vec(g, summed ? "covariance_imag_total" : "covariance_imag", H5T_NATIVE_DOUBLE, nv, im);
+        free(re); free(im);
+      }
+      H5Gclose(g);
+      count++;
+      if (H5Dwrite(cd, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
+    }
+  }
+  if (cd >= 0) H5Dclose(cd);
+  if (snaps >= 0) H5Gclose(snaps);
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+/* header of a covariance file: BasisID, version, the number of snapshots and the sizes of snapshot 0 */
+int exp_h5_covar_info(const char *path, char *basisID, int cap, char *version, int vcap, int *floatsize,
+                      int *count, int *sampT, int *ltot, int *nmax, int *summed, int *has_covar, int *full)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  rc |= get_str(f, "CovarianceFileVersion", version, (size_t)vcap);
+  rc |= get_str(f, "BasisID", basisID, (size_t)cap);
+  rc |= get_int(f, "FloatSize", floatsize);
+  unsigned cnt = 0;
+  hid_t cd = H5Dopen2(f, "count", H5P_DEFAULT);
+  if (cd < 0 || H5Dread(cd, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &cnt) < 0) rc = -1;
+  if (cd >= 0) H5Dclose(cd);
+  *count = (int)cnt;
+  *sampT = *ltot = *nmax = *summed = *has_covar = *full = 0;
+  if (rc == 0 && cnt > 0) {
+    hid_t g = H5Gopen2(f, "snapshots/00000000", H5P_DEFAULT);
+    if (g < 0) rc = -1;
+    else {
+      rc |= get_int(g, "sampleSize", sampT); rc |= get_int(g, "angularSize", ltot); rc |= get_int(g, "rankSize", nmax);
+      *summed = H5Lexists(g, "covariance_real_total", H5P_DEFAULT) > 0;
+      *has_covar = *summed || H5Lexists(g, "covariance_real", H5P_DEFAULT) > 0;
+      if (*has_covar) {
+        hid_t d = H5Dopen2(g, *summed ? "covariance_real_total" : "covariance_real", H5P_DEFAULT);
+        hid_t s = H5Dget_space(d);
+        const hssize_t npts = H5Sget_simple_extent_npoints(s);
+        const hssize_t tri = (hssize_t)(*ltot) * (*nmax) * (*nmax + 1) / 2 * (*summed ? 1 : *sampT);
+        *full = npts == tri;
+        H5Sclose(s); H5Dclose(d);
+      }
+      H5Gclose(g);
+    }
+  }
+  H5Fclose(f);
+  return rc ? -1 : 0;
+}
+
+static int get_vec(hid_t g, const char *name, hid_t type, void *out)
+{
+  hid_t d = H5Dopen2(g, name, H5P_DEFAULT);
+  if (d < 0) return -1;
+  int rc = H5Dread(d, type, H5S_ALL, H5S_ALL, H5P_DEFAULT, out) < 0 ? -1 : 0;
+  H5Dclose(d);
+  return rc;
+}
+
+/* snapshot `index`: time, counts[T], masses[T], mean[T][ltot][nmax][2] and the covariance vectors as stored
+ * (cre / cim: ltot * diag * (summed ? 1 : T) values; may be NULL) */
+int exp_h5_covar_read(const char *path, int index, int sampT, int ltot, int nmax, int summed, double *time,
+                      int *counts, double *masses, double *mean, double *cre, double *cim)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  char nm[32];
+  snprintf(nm, sizeof nm, "snapshots/%08d", index);
+  hid_t g = H5Gopen2(f, nm, H5P_DEFAULT);
+  int rc = g < 0 ? -1 : 0;
+  if (rc == 0) {
+    rc |= get_dbl(g, "Time", time);
+    rc |= get_vec(g, "sampleCounts", H5T_NATIVE_INT, counts);
+    rc |= get_vec(g, "sampleMasses", H5T_NATIVE_DOUBLE, masses);
+    const size_t nc = (size_t)sampT * ltot * nmax;
+    double *re = (double *)malloc(sizeof(double) * (nc ? nc : 1)), *im = (double *)malloc(sizeof(double) * (nc ? nc : 1));
+    rc |= get_vec(g, "coefficients_real", H5T_NATIVE_DOUBLE, re);
+    rc |= get_vec(g, "coefficients_imag", H5T_NATIVE_DOUBLE, im);
+    for (size_t c = 0; c < nc && rc == 0; c++) { mean[2 * c] = re[c]; mean[2 * c + 1] = im[c]; }
+    free(re); free(im);
+    if (cre && cim) {
+      rc |= get_vec(g, summed ? "covariance_real_total" : "covariance_real", H5T_NATIVE_DOUBLE, cre);
+      rc |= get_vec(g, summed ? "covariance_imag_total" : "covariance_imag", H5T_NATIVE_DOUBLE, cim);
+    }
+    H5Gclose(g);
+  }
   H5Fclose(f);
   return rc ? -1 : 0;
 }

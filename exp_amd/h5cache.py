@@ -183,3 +183,100 @@ def read_empcyl_cache(path: str, check: Optional[dict] = None):
                       ascale=A, hscale=H, rmin=h["rmin"], rmax=h["rmax"], rtable=rtable, xmin=xmin,
                       xmax=xmax, dx=(xmax - xmin) / numx, ymin=ymin, ymax=ymax, dy=(ymax - ymin) / numy,
                       tab=tab, dens=dens)
+
+
+# ---- coefficient covariance store (expui/Covariance.cc, include/Covariance.H) --------------------------
+
+def covar_append(path: str, basis_id: str, kind: int, ipar, dpar, time: float, counts, masses, mean, covr=None,
+                 summed: bool = True, covar: bool = True) -> bool:
+    """``SubsampleCovariance::writeCoefCovariance(fname, elem, time)``: create the file (version "1.1",
+    FloatSize 8) or append one snapshot to it.  mean [T, ltot, nmax] complex, covr [T, ltot, nmax, nmax]
+    complex or None; summed / covar as the constructor flags (expui/Covariance.cc:9-15).  Returns False
+    when there is no data (nothing written, as the reference)."""
+    lib = _load()
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    masses = np.ascontiguousarray(masses, dtype=np.float64)
+    mean = np.asarray(mean, dtype=np.complex128)
+    T, ltot, nmax = mean.shape
+    m2 = np.ascontiguousarray(np.stack([mean.real, mean.imag], -1))
+    c2 = None
+    if covr is not None:
+        covr = np.asarray(covr, dtype=np.complex128)
+        c2 = np.ascontiguousarray(np.stack([covr.real, covr.imag], -1))
+    ip = (ctypes.c_int * 2)(*[int(v) for v in ipar])
+    dp = (ctypes.c_double * 5)(*([float(v) for v in dpar] + [0.0] * (5 - len(dpar))))
+    lib.exp_h5_covar_append.restype = ctypes.c_int
+    rc = lib.exp_h5_covar_append(path.encode(), basis_id.encode(), int(kind), ip, dp, int(summed), int(covar),
+                                 ctypes.c_double(time), int(T), int(ltot), int(nmax),
+                                 counts.ctypes.data_as(ctypes.c_void_p), masses.ctypes.data_as(ctypes.c_void_p),
+                                 m2.ctypes.data_as(ctypes.c_void_p),
+                                 None if c2 is None else c2.ctypes.data_as(ctypes.c_void_p))
+    if rc < 0:
+        raise RuntimeError(f"SubsampleCovariance::writeCoefCovariance: cannot write <{path}>")
+    return rc == 0
+
+
+class SubsampleCovariance:
+    """``BasisClasses::SubsampleCovariance(filename, stride)`` (expui/Covariance.cc:419-700): reads a
+    covariance file back; ``Times()``, ``getCoefCovariance(time)`` -> (counts, masses, mean [T, ltot,
+    nmax], covr [T, ltot, nmax, nmax]).  A summed file gives every sub-sample the total divided by the
+    number of sub-samples, as the reference's reader does (:685-695)."""
+
+    def __init__(self, filename: str, stride: int = 1):
+        lib = _load()
+        bid, ver = ctypes.create_string_buffer(64), ctypes.create_string_buffer(32)
+        iv = [ctypes.c_int() for _ in range(8)]
+        lib.exp_h5_covar_info.restype = ctypes.c_int
+        if lib.exp_h5_covar_info(filename.encode(), bid, 64, ver, 32, *[ctypes.byref(v) for v in iv]):
+            raise RuntimeError(f"SubsampleCovariance: cannot read <{filename}>")
+        self.BasisID, version = bid.value.decode(), ver.value.decode()
+        if version == "1.0":
+            raise RuntimeError("SubsampleCovariance: this is an early alpha test version. Please remake your files")
+        if version != "1.1":
+            raise RuntimeError(f"SubsampleCovariance: unsupported file version, {version}")
+        fsz, count, T, ltot, nmax, summed, has_cov, full = [v.value for v in iv]
+        if fsz != 8:
+            raise RuntimeError(f"SubsampleCovariance: float size {fsz} is not supported by this reader")
+        self.summed, self.times, self._data = bool(summed), [], {}
+        diag = nmax * (nmax + 1) // 2 if full else nmax
+        lib.exp_h5_covar_read.restype = ctypes.c_int
+        for k in range(0, count, max(1, int(stride))):
+            t = ctypes.c_double()
+            counts, masses = np.zeros(T, dtype=np.int32), np.zeros(T)
+            mean = np.zeros((T, ltot, nmax, 2))
+            nv = ltot * diag * (1 if summed else T)
+            cre, cim = (np.zeros(nv), np.zeros(nv)) if has_cov else (None, None)
+            if lib.exp_h5_covar_read(filename.encode(), k, T, ltot, nmax, int(summed), ctypes.byref(t),
+                                     counts.ctypes.data_as(ctypes.c_void_p), masses.ctypes.data_as(ctypes.c_void_p),
+                                     mean.ctypes.data_as(ctypes.c_void_p),
+                                     None if cre is None else cre.ctypes.data_as(ctypes.c_void_p),
+                                     None if cim is None else cim.ctypes.data_as(ctypes.c_void_p)):
+                raise RuntimeError(f"SubsampleCovariance: cannot read snapshot {k} of <{filename}>")
+            covr = None
+            if has_cov:
+                flat = (cre + 1j * cim).reshape((1 if summed else T), ltot, diag)
+                covr = np.zeros((flat.shape[0], ltot, nmax, nmax), dtype=np.complex128)
+                if full:                              # upper triangles; the reference's reader copies them
+                    iu = np.triu_indices(nmax)        # into the lower ones unconjugated (:663-666)
+                    covr[:, :, iu[0], iu[1]] = flat
+                    lower = np.swapaxes(covr, 2, 3).copy()
+                    idx = np.arange(nmax)
+                    lower[:, :, idx, idx] = 0.0
+                    covr = covr + lower
+                else:
+                    idx = np.arange(nmax)
+                    covr[:, :, idx, idx] = flat
+                if summed:
+                    covr = np.repeat(covr / T, T, axis=0)
+            tt = float(np.floor(t.value * 1e8 + 0.5) / 1e8)
+            self.times.append(tt)
+            self._data[tt] = (counts, masses, mean[..., 0] + 1j * mean[..., 1], covr)
+
+    def Times(self):
+        return list(self.times)
+
+    def getCoefCovariance(self, time: float):
+        key = float(np.floor(time * 1e8 + 0.5) / 1e8)
+        if key not in self._data:
+            raise RuntimeError("SubsampleCovariance::getCoefCovariance: time not found")
+        return self._data[key]

@@ -419,7 +419,7 @@ def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
     c.close()
 
 
-def test_coefficient_covariance_by_subsampling(halo_basis, oracle):
+def test_coefficient_covariance_by_subsampling(halo_basis, oracle, tmp_path, monkeypatch):
     """pyEXP's pcavar / subsamp (tests/Halo/createCoefs.py asks for them): sub-sample counts, masses,
     mean vectors and covariance matrices of Spherical::accumulate (expui/BiorthBasis.cc:583-665)
     against the oracle's restatement, over two addFromArray batches (the sub-sample index follows
@@ -448,6 +448,18 @@ def test_coefficient_covariance_by_subsampling(halo_basis, oracle):
     assert np.abs(mean - ref["mean"]).max() <= 1e-10 * np.abs(ref["mean"]).max()
     assert np.abs(covr.real - ref["covr"]).max() <= 1e-10 * np.abs(ref["covr"]).max() and not covr.imag.any()
     assert np.abs(mean.sum(axis=0) - coef.coefs).max() <= 1e-10 * np.abs(coef.coefs).max()
+    # the HDF5 covariance store (expui/BiorthBasis.H:433-463 -> expui/Covariance.cc): written in the
+    # working directory as coefcovar.<compname>.<runtag>.h5, extended by the next call, read back
+    from exp_amd import h5cache
+    if h5cache.available():
+        monkeypatch.chdir(tmp_path)
+        fname = basis.writeCoefCovariance("halo", "run0", 1.0)
+        assert fname == "coefcovar.halo.run0.h5" and basis.writeCoefCovariance("halo", "run0", 2.0) == fname
+        rd = h5cache.SubsampleCovariance(fname)
+        assert rd.BasisID == "SphereSL" and rd.Times() == [1.0, 2.0] and rd.summed
+        c, mm, mu, cv = rd.getCoefCovariance(2.0)
+        assert np.array_equal(c, counts) and np.array_equal(mm, masses) and np.array_equal(mu, mean)
+        assert np.abs(cv[0] - covr.sum(0) / sampT).max() <= 1e-13 * np.abs(covr).max()     # summed, split T ways
     basis.reset_coefs()
     counts, masses = basis.getCovarSamples()
     assert not counts.any() and not masses.any() and not np.array(basis.getCoefCovariance()[0][0][1]).any()

@@ -146,3 +146,53 @@ def test_cyl_coefficient_file_roundtrip(h5, tmp_path):
         txt = subprocess.run([h5dump, "-H", path], capture_output=True, text=True).stdout
         assert 'ATTRIBUTE "mmax"' in txt and 'ATTRIBUTE "lmax"' not in txt and 'ATTRIBUTE "scale"' not in txt
         assert "DATASPACE  SIMPLE { ( 5, 7 ) / ( 5, 7 ) }" in txt and 'GROUP "00000003"' in txt
+
+
+def test_covariance_store_roundtrip_and_layout(h5, tmp_path):
+    """``SubsampleCovariance`` files (expui/Covariance.cc, include/Covariance.H; written by
+    ``Spherical::writeCoefCovariance``, expui/BiorthBasis.H:433-463): create, extend, read back --
+    summed upper triangles (the default), per-sample upper triangles, per-sample diagonals; the
+    structure the reference's reader walks is checked with h5dump."""
+    rng = np.random.default_rng(5)
+    T, ltot, nmax = 4, 6, 5
+    counts = rng.integers(5, 50, T).astype(np.int32)
+    masses = rng.uniform(0.1, 1.0, T)
+    mean = rng.standard_normal((T, ltot, nmax)) + 1j * rng.standard_normal((T, ltot, nmax))
+    a = rng.standard_normal((T, ltot, nmax, nmax)) + 1j * rng.standard_normal((T, ltot, nmax, nmax))
+    covr = a + np.conj(np.swapaxes(a, 2, 3))               # Hermitian like g g^dagger sums
+    iu = np.triu_indices(nmax)
+    for summed, covar, tag in ((True, True, "sum"), (False, True, "full"), (False, False, "diag")):
+        path = str(tmp_path / f"coefcovar.halo.{tag}.h5")
+        assert h5.covar_append(path, "SphereSL", 0, (2, nmax), (1.0, 1e-4, 1.95), 0.1234567891, counts, masses,
+                               mean, covr, summed=summed, covar=covar)
+        assert h5.covar_append(path, "SphereSL", 0, (2, nmax), (1.0, 1e-4, 1.95), 0.5, counts, masses, 2 * mean,
+                               2 * covr, summed=summed, covar=covar)        # extendCoefCovariance
+        # nothing to write: no file is touched, False comes back
+        assert not h5.covar_append(path, "SphereSL", 0, (2, nmax), (1.0, 1e-4, 1.95), 0.9, 0 * counts, masses,
+                                   mean, covr, summed=summed, covar=covar)
+        rd = h5.SubsampleCovariance(path)
+        assert rd.BasisID == "SphereSL" and rd.Times() == [0.12345679, 0.5]          # times rounded to 1e-8
+        c, m, mu, cv = rd.getCoefCovariance(0.12345679)
+        assert np.array_equal(c, counts) and np.array_equal(m, masses) and np.array_equal(mu, mean)
+        want = np.zeros_like(covr)
+        if covar:
+            src = covr.sum(0, keepdims=True) / T if summed else covr
+            src = np.repeat(src, T, axis=0) if summed else src
+            want[:, :, iu[0], iu[1]] = src[:, :, iu[0], iu[1]]
+            want[:, :, iu[1], iu[0]] = src[:, :, iu[0], iu[1]]              # the reader's unconjugated mirror
+        else:
+            idx = np.arange(nmax)
+            want[:, :, idx, idx] = covr[:, :, idx, idx]
+        assert np.abs(cv - want).max() <= 1e-14 * np.abs(want).max()
+        assert np.array_equal(rd.getCoefCovariance(0.5)[2], 2 * mean)
+        with pytest.raises(RuntimeError):
+            rd.getCoefCovariance(0.7)
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        txt = subprocess.run([h5dump, "-H", str(tmp_path / "coefcovar.halo.sum.h5")], capture_output=True, text=True).stdout
+        for s in ('ATTRIBUTE "CovarianceFileVersion"', 'ATTRIBUTE "BasisID"', 'ATTRIBUTE "FloatSize"', 'ATTRIBUTE "lmax"',
+                  'ATTRIBUTE "rmax"', 'DATASET "count"', 'GROUP "snapshots"', 'GROUP "00000001"', 'ATTRIBUTE "Time"',
+                  'ATTRIBUTE "sampleSize"', 'ATTRIBUTE "angularSize"', 'ATTRIBUTE "rankSize"', 'DATASET "sampleCounts"',
+                  'DATASET "coefficients_real"', 'DATASET "covariance_imag_total"'):
+            assert s in txt, s
+        assert f"( {ltot * nmax * (nmax + 1) // 2}, 1 )" in txt           # summed upper triangles, [n][1]
