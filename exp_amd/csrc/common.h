@@ -114,6 +114,7 @@ struct ProfScope {
 };
 
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
+bool expamd_orient_has_log(const exp_amd_orient *o);     // orient.hip: a log file is open
 
 // x + a*b rounded as a separate multiply and add (what the reference's scalar CPU code does).
 // hipcc contracts a*b+c to an FMA by default and HIP's __dmul_rn/__dadd_rn are plain operators;

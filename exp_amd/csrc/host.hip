@@ -27,6 +27,7 @@ struct exp_amd_sim {
   std::vector<int> ej_dryrun;
   int centerlevl = -1;
   bool gottapot = false;
+  bool restart = false;            // the global `restart` (src/global.cc): the estimators take in the first state too
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
   // Two-stream sub-steps: everything that touches the particles of component k is issued on stream
@@ -154,6 +155,13 @@ extern "C" int exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int targe
 
 // Attach an Orient to a component (Component::initialize, src/Component.cc:1323-1370: the EJ keys);
 // centerlevl < 0 selects multistep/2 (src/ComponentContainer.cc:42-45).
+extern "C" int exp_amd_sim_set_restart(exp_amd_sim *s, int on)
+{
+  if (!s) return EXP_AMD_ERR_ARG;
+  s->restart = on != 0;
+  return EXP_AMD_OK;
+}
+
 extern "C" int exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dryrun,
                                       int centerlevl)
 {
@@ -203,7 +211,14 @@ static int fix_centers(exp_amd_sim *s, int mstep)
       if ((rc = exp_amd_comp_set_pseudo_accel(s->comps[k], acc, (fl & 1u) ? om : nullptr,
                                               (fl & 1u) ? dom : nullptr))) return rc;
     }
-    if (s->gottapot && (rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;
+    if (s->gottapot || s->restart) {                                       // (:1386-1389)
+      if ((rc = exp_amd_orient_accumulate(o, s->tnow, s->dtime, s->comps[k]))) return rc;
+      if (expamd_orient_has_log(o)) {                                      // Orient::logEntry(tnow, c)
+        double cm[10];
+        if ((rc = exp_amd_comp_fix_positions(s->comps[k], 0, cm))) return rc;
+        if ((rc = exp_amd_orient_log_entry(o, s->tnow, cm + 1, nullptr))) return rc;
+      }
+    }
   }
   return EXP_AMD_OK;
 }

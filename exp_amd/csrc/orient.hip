@@ -18,8 +18,8 @@
 // reference's use of the CENTRE history length in the AXIS regression (:583).
 // The PseudoAccel helper (include/PseudoAccel.H: quadratic least squares over the last Naccel
 // (time, centre, axis) triples -> frame acceleration, angular velocity and its rate) rides along.
-// Not carried over: the log file and its restart (:84-330), the
-// EXTERNAL flag (this store has no separate external potential) and keep == 0, whose code path in
+// The log file and the restart from it (:84-335, :742-785) are at the end of this file.
+// Not carried over: the EXTERNAL flag (this store has no separate external potential) and keep == 0, whose code path in
 // the reference indexes its 3-vectors out of range (:741-744).
 #include "particles.h"
 #include <cmath>
@@ -28,6 +28,11 @@
 #include <vector>
 #include <array>
 #include <new>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <string>
 
 namespace {
 
@@ -328,6 +333,7 @@ struct exp_amd_orient {
   DevBuf<unsigned long long> keys, cand, ncand;   // all keys; those sharing the threshold's first 24 bits
   DevBuf<double> hist, sums, part;
   DevBuf<OriState> state;
+  std::string logfile;                            // Orient's Logfile argument (empty: no log)
 };
 
 extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsigned oflags,
@@ -612,5 +618,200 @@ extern "C" int exp_amd_orient_get(const exp_amd_orient *o, double center[3], dou
       stats[6 + k] = o->axis1[k]; stats[9 + k] = o->center1[k]; stats[12 + k] = o->center0[k];
     }
   }
+  return EXP_AMD_OK;
+}
+
+// ---- the log file and the restart from it (src/Orient.cc:84-335 constructor, :742-785 logEntry) ----
+// One row per logEntry call, 33 columns of width 15 in the stream's default format (6 significant
+// digits): time, Ecurr, used, axis, axis1, centre, centre0, centre1, com, com0, pseudo-acceleration,
+// omega, domega/dt.  (The header labels columns 10-15 "anl" then "reg"; the rows hold the regression
+// centre first, then the analytic one -- both as the reference writes them.)
+static const char *const ORI_LOG_LABELS[33] = {
+    "Time", "E_curr", "Used", "X-axis(reg)", "Y-axis(reg)", "Z-axis(reg)", "X-axis(cur)", "Y-axis(cur)",
+    "Z-axis(cur)", "X-center(anl)", "Y-center(anl)", "Z-center(anl)", "X-center(reg)", "Y-center(reg)",
+    "Z-center(reg)", "X-center(cur)", "Y-center(cur)", "Z-center(cur)", "X-com(cur)", "Y-com(cur)",
+    "Z-com(cur)", "X-com(dif)", "Y-com(dif)", "Z-com(dif)", "X-accel", "Y-accel", "Z-accel", "Omega_X",
+    "Omega_Y", "Omega_Z", "dOmega/dt_X", "dOmega/dt_Y", "dOmega/dt_Z"};
+
+// What root learns from the old log and every rank then holds (the reference broadcasts Ecurr, axis,
+// centre, centre0 and the two histories, :205-230; the pseudo-acceleration queue travels here too so
+// that the ranks stay identical).
+struct OriRestart {
+  double in_ok = 0, Ecurr = 0;
+  V3 axis{{0, 0, 1}}, center{{0, 0, 0}}, center0{{0, 0, 0}}, axis1{{0, 0, 0}}, center1{{0, 0, 0}};
+  std::deque<DV> sumsA, sumsC;
+  std::deque<std::array<double, 7>> aq;
+  long long rows = 0;
+};
+
+// Root's pass over the old log (:88-199): move it to <logfile>.bak, copy every data row up to the
+// current time into a fresh <logfile> (comment rows are dropped, as there), and rebuild the state
+// from the rows copied.  Returns 0, or a message.
+static const char *orient_read_log(exp_amd_orient *o, bool restart, double tnow, double dtime, int Mstep,
+                                   bool queue_center1, OriRestart &R)
+{
+  {
+    std::ifstream probe(o->logfile.c_str());
+    if (!probe) {
+      // no previous log: write the two header rows (:236-284)
+      std::ofstream out(o->logfile.c_str());
+      if (!out) return "Orient: error opening log file";
+      out.setf(std::ios::left);
+      for (int k = 0; k < 33; k++) out << std::setw(15) << (std::string(k ? "| " : "# ") + ORI_LOG_LABELS[k]);
+      out << std::endl;
+      out.fill('-');
+      for (int k = 0; k < 33; k++) out << (k ? "| " : "# ") << std::setw(13) << k + 1;
+      out << std::endl;
+      return nullptr;
+    }
+  }
+  const std::string backup = o->logfile + ".bak";
+  if (std::rename(o->logfile.c_str(), backup.c_str())) return "Orient: error making backup file";
+  std::ofstream out(o->logfile.c_str());
+  if (!out) return "Orient: error opening new log file for writing";
+  std::ifstream in(backup.c_str());
+  if (!in) return "Orient: error opening original log file for reading";
+  R.in_ok = 1;
+  R.Ecurr = o->Ecurr; R.axis = o->axis; R.center = o->center; R.center0 = o->center0;
+  R.axis1 = o->axis1; R.center1 = o->center1;
+  std::string row;
+  while (in && restart) {
+    std::getline(in, row);
+    if (in.fail() || in.eof()) break;              // a last row without its newline is not taken (:134)
+    if (!row.empty() && row[0] == '#') continue;
+    std::istringstream line(row);
+    double time = 0;
+    line >> time;
+    if (tnow + 0.1 * dtime / Mstep < time) break;  // read until the current time is reached (:146)
+    out << row << "\n";
+    long long tused;
+    line >> R.Ecurr >> tused;
+    for (int k = 0; k < 3; k++) line >> R.axis[k];
+    for (int k = 0; k < 3; k++) line >> R.axis1[k];
+    for (int k = 0; k < 3; k++) line >> R.center[k];
+    for (int k = 0; k < 3; k++) line >> R.center0[k];
+    for (int k = 0; k < 3; k++) line >> R.center1[k];
+    R.rows++;
+    if (o->oflags & ORI_AXIS) {
+      R.sumsA.push_back(DV(time, R.axis1));
+      if ((int)R.sumsA.size() > o->keep) R.sumsA.pop_front();
+    }
+    if (o->oflags & ORI_CENTER) {
+      R.sumsC.push_back(DV(time, R.center1));
+      if ((int)R.sumsC.size() > o->keep) R.sumsC.pop_front();
+    }
+    // com, com0, pseudo-acceleration: three triples read into the same vector, the last one stays
+    // (:174-186); a row that ends early feeds nothing to the queue
+    double pseudo[3] = {0, 0, 0};
+    bool all = true;
+    for (int i = 0; i < 3; i++) {
+      if (line.eof()) { all = false; break; }
+      for (int k = 0; k < 3; k++) line >> pseudo[k];
+    }
+    if (all && o->naccel) {
+      // The reference queues (time, pseudo, axis1) here -- the logged ACCELERATION in the slot that
+      // accumulate() fills with centre1 (:711) -- so its fits straddle two different quantities until
+      // the queue has turned over.  Restated as is unless the caller asks for centre1.
+      const double *cq = queue_center1 ? R.center1.data() : pseudo;
+      R.aq.push_back({time, cq[0], cq[1], cq[2], R.axis1[0], R.axis1[1], R.axis1[2]});
+      if (R.aq.size() > o->naccel) R.aq.pop_front();
+    }
+  }
+  return nullptr;
+}
+
+bool expamd_orient_has_log(const exp_amd_orient *o) { return o && !o->logfile.empty(); }
+
+/* Orient's Logfile constructor argument and the restart block of the constructor. */
+extern "C" int exp_amd_orient_open_log(exp_amd_orient *o, const char *logfile, unsigned flags, double tnow,
+                                       double dtime, int Mstep, long long *rows)
+{
+  if (!o || !logfile || !*logfile || Mstep < 1) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = o->ctx;
+  o->logfile = logfile;
+  OriRestart R;
+  const bool multi = ctx->nranks > 1 || ctx->ar_fn;
+  const char *msg = nullptr;
+  if (ctx->rank == 0) msg = orient_read_log(o, flags & 1u, tnow, dtime, Mstep, flags & 2u, R);
+  if (multi) {
+    // root's state to every rank: one sum over a vector the others leave at zero
+    const size_t K = (size_t)o->keep, Q = o->naccel, NV = 21 + 8 * K + 7 * Q;
+    std::vector<double> v(NV, 0.0);
+    if (ctx->rank == 0) {
+      size_t i = 0;
+      v[i++] = msg ? -1.0 : R.in_ok; v[i++] = R.Ecurr;
+      for (const V3 *a : {&R.axis, &R.center, &R.center0, &R.axis1, &R.center1})
+        for (int k = 0; k < 3; k++) v[i++] = (*a)[k];
+      v[i++] = (double)R.sumsA.size(); v[i++] = (double)R.sumsC.size(); v[i++] = (double)R.aq.size();
+      v[i++] = (double)R.rows;
+      for (size_t j = 0; j < R.sumsA.size(); j++) { v[21 + 4 * j] = R.sumsA[j].first; for (int k = 0; k < 3; k++) v[22 + 4 * j + k] = R.sumsA[j].second[k]; }
+      for (size_t j = 0; j < R.sumsC.size(); j++) { v[21 + 4 * (K + j)] = R.sumsC[j].first; for (int k = 0; k < 3; k++) v[22 + 4 * (K + j) + k] = R.sumsC[j].second[k]; }
+      for (size_t j = 0; j < R.aq.size(); j++) for (int k = 0; k < 7; k++) v[21 + 8 * K + 7 * j + k] = R.aq[j][k];
+    }
+    DevBuf<double> d;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (d.alloc(NV) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d.p, v.data(), NV * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    int rc = e == hipSuccess ? expamd_allreduce(ctx, d.p, NV) : EXP_AMD_ERR_HIP;
+    if (!rc) e = hipMemcpyAsync(v.data(), d.p, NV * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (rc) return rc;
+    if (e != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: restart broadcast failed");
+    if (ctx->rank != 0) {
+      if (v[0] < 0) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: root could not open its log file");
+      size_t i = 1;
+      R.in_ok = v[0]; R.Ecurr = v[i++];
+      for (V3 *a : {&R.axis, &R.center, &R.center0, &R.axis1, &R.center1})
+        for (int k = 0; k < 3; k++) (*a)[k] = v[i++];
+      const size_t nA = (size_t)v[i++], nC = (size_t)v[i++], nQ = (size_t)v[i++];
+      R.rows = (long long)v[i++];
+      for (size_t j = 0; j < nA; j++) R.sumsA.push_back(DV(v[21 + 4 * j], V3{{v[22 + 4 * j], v[23 + 4 * j], v[24 + 4 * j]}}));
+      for (size_t j = 0; j < nC; j++) R.sumsC.push_back(DV(v[21 + 4 * (K + j)], V3{{v[22 + 4 * (K + j)], v[23 + 4 * (K + j)], v[24 + 4 * (K + j)]}}));
+      for (size_t j = 0; j < nQ; j++) {
+        std::array<double, 7> q;
+        for (int k = 0; k < 7; k++) q[k] = v[21 + 8 * K + 7 * j + k];
+        R.aq.push_back(q);
+      }
+    }
+  }
+  if (msg) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "%s <%s>", msg, logfile);
+  if (rows) *rows = R.rows;
+  if (R.in_ok != 0) {
+    o->Ecurr = R.Ecurr; o->axis = R.axis; o->center = R.center; o->center0 = R.center0;
+    o->axis1 = R.axis1; o->center1 = R.center1;
+    o->sumsA = R.sumsA; o->sumsC = R.sumsC;
+    if (o->naccel) o->aq = R.aq;
+    if (o->oflags & ORI_AXIS) {                   // (:325-335)
+      const double phi = atan2(o->axis[1], o->axis[0]);
+      const double theta = -acos(o->axis[2] / sqrt(o->axis[0] * o->axis[0] + o->axis[1] * o->axis[1] +
+                                                   o->axis[2] * o->axis[2]));
+      euler_slater(phi, theta, 0.0, 0, o->body);
+      euler_slater(phi, theta, 0.0, 1, o->orig);
+    }
+  }
+  return EXP_AMD_OK;
+}
+
+/* Orient::logEntry(time, c) (:742-785): root appends one row; com / com0 are the component's. */
+extern "C" int exp_amd_orient_log_entry(exp_amd_orient *o, double time, const double com[3], const double com0[3])
+{
+  if (!o) return EXP_AMD_ERR_ARG;
+  if (o->logfile.empty()) return expamd_fail(o->ctx, EXP_AMD_ERR_ARG, "Orient: no log file is open");
+  double a[3], w[3], dw[3];
+  int rc = exp_amd_orient_accel(o, a, w, dw);      // the queue is evaluated on every rank, written by root
+  if (rc) return rc;
+  if (o->ctx->rank) return EXP_AMD_OK;
+  std::ofstream outl(o->logfile.c_str(), std::ios::app);
+  if (!outl) return EXP_AMD_OK;                    // the reference skips the row silently
+  const double zero[3] = {0, 0, 0};
+  if (!com) com = zero;
+  if (!com0) com0 = zero;
+  outl << std::setw(15) << time << std::setw(15) << o->Ecurr << std::setw(15) << o->used;
+  const double *cols[10] = {o->axis.data(), o->axis1.data(), o->center.data(), o->center0.data(),
+                            o->center1.data(), com, com0, a, w, dw};
+  for (const double *t : cols)
+    for (int k = 0; k < 3; k++) outl << std::setw(15) << t[k];
+  outl << std::endl;
   return EXP_AMD_OK;
 }

@@ -261,8 +261,8 @@ class Component:
 class Orient:
     """``Orient`` (src/Orient.H:31-204): the most-bound-particle estimator of a component's
     expansion centre and symmetry axis.  Constructor arguments are the reference's
-    (number_to_keep, target, orient flags, control flags, dT, damping); the log file, its restart
-    and the pseudo-acceleration helper are not carried over."""
+    (number_to_keep, target, orient flags, control flags, dT, damping); ``Naccel`` is ``set_naccel``
+    and ``Logfile`` with its restart is ``openLog``."""
 
     AXIS, CENTER = 1, 2                     # Orient::OrientFlags
     DIAG, KE, EXTERNAL = 1, 2, 4            # Orient::ControlFlags
@@ -346,7 +346,7 @@ class Orient:
                 "mtot": float(s[5]), "axis1": s[6:9].copy(), "center1": s[9:12].copy(),
                 "center0": s[12:15].copy()}
 
-    # -- log file (src/Orient.cc:238-291 header, :749-783 logEntry); the restart from it is not kept --
+    # -- log file and the restart from it (src/Orient.cc:84-335 constructor, :742-785 logEntry) --
     LOG_COLUMNS = ["Time", "E_curr", "Used", "X-axis(reg)", "Y-axis(reg)", "Z-axis(reg)", "X-axis(cur)",
                    "Y-axis(cur)", "Z-axis(cur)", "X-center(anl)", "Y-center(anl)", "Z-center(anl)",
                    "X-center(reg)", "Y-center(reg)", "Z-center(reg)", "X-center(cur)", "Y-center(cur)",
@@ -354,23 +354,35 @@ class Orient:
                    "Z-com(dif)", "X-accel", "Y-accel", "Z-accel", "Omega_X", "Omega_Y", "Omega_Z",
                    "dOmega/dt_X", "dOmega/dt_Y", "dOmega/dt_Z"]
 
-    def logHeader(self, path: str) -> None:
-        """The two header lines the constructor writes to a fresh log file (15-character columns)."""
-        with open(path, "w") as f:
-            f.write("".join(("# " if k == 0 else "| ") .__add__(c).ljust(15) for k, c in enumerate(self.LOG_COLUMNS)) + "\n")
-            f.write("".join(("# " if k == 0 else "| ") + str(k + 1).ljust(13, "-") for k in range(33)) + "\n")
+    def openLog(self, path: str, restart: bool = False, tnow: float = 0.0, dtime: float = 0.0,
+                Mstep: int = 1, queue_center1: bool = False) -> int:
+        """The ``Logfile`` constructor argument and the constructor's restart block: a missing file
+        gets the two header rows; an existing one is moved to ``<path>.bak`` and -- with the global
+        ``restart`` -- its rows up to ``tnow + 0.1*dtime/Mstep`` are copied back and rebuild the
+        estimator's state (include/exp_amd.h).  Call after ``set_naccel``.  Returns the rows taken."""
+        from ctypes import c_longlong
+        rows = c_longlong(0)
+        flags = (1 if restart else 0) | (2 if queue_center1 else 0)
+        check(self.lib.exp_amd_orient_open_log(self.h, str(path).encode(), flags, float(tnow),
+                                               float(dtime), int(Mstep), byref(rows)), self.ctx.h)
+        self._log = str(path)
+        return int(rows.value)
 
-    def logEntry(self, time: float, path: str, com=(0.0, 0.0, 0.0), com0=(0.0, 0.0, 0.0)) -> None:
+    def logHeader(self, path: str) -> None:
+        """A fresh log file at ``path`` (any file already there is dropped first)."""
+        import os
+        if os.path.exists(path):
+            os.remove(path)
+        self.openLog(path)
+
+    def logEntry(self, time: float, path: str = None, com=(0.0, 0.0, 0.0), com0=(0.0, 0.0, 0.0)) -> None:
         """``Orient::logEntry(time, c)``: one row of 33 columns -- time, Ecurr, used, axis, axis1,
         centre, centre0, centre1, the component's com and com0, pseudo-acceleration, omega, domega/dt
         (column order of the reference's own writer, whose header labels columns 10-15 the other way)."""
-        st = self.state()
-        acc, om, dom = self.currentAccel()
-        vals = [time, st["Ecurr"], st["used"], *st["axis"], *st["axis1"], *st["center"], *st["center0"],
-                *st["center1"], *com, *com0, *acc, *om, *dom]
-        with open(path, "a") as f:
-            f.write("".join(f"{v:>15.6g}" if not isinstance(v, (int, np.integer)) else f"{int(v):>15d}"
-                            for v in vals) + "\n")
+        if path is not None and path != getattr(self, "_log", None):
+            raise ValueError("Orient.logEntry: rows go to the file given to openLog / logHeader")
+        a, b = (c_double * 3)(*com), (c_double * 3)(*com0)
+        check(self.lib.exp_amd_orient_log_entry(self.h, float(time), a, b), self.ctx.h)
 
     def close(self) -> None:
         if self.h:
@@ -758,6 +770,10 @@ class Simulation:
         estimator, which is fed at every force evaluation of level ``centerlevl``."""
         check(self.lib.exp_amd_sim_set_orient(self.h, int(index), orient.h if orient else None,
                                               int(dryrun), int(centerlevl)), self.ctx.h)
+
+    def set_restart(self, on: bool = True) -> None:
+        """The global ``restart``: the estimators take in the first force evaluation's state too."""
+        check(self.lib.exp_amd_sim_set_restart(self.h, int(bool(on))), self.ctx.h)
 
     def add_interaction(self, source: int, target: int) -> None:
         check(self.lib.exp_amd_sim_add_interaction(self.h, int(source), int(target)), self.ctx.h)

@@ -183,6 +183,23 @@ int  exp_amd_orient_set_naccel(exp_amd_orient *o, int naccel);
 int  exp_amd_orient_accel(exp_amd_orient *o, double accel[3], double omega[3], double domdt[3]);
 int  exp_amd_orient_get(const exp_amd_orient *o, double center[3], double axis[3], double body[9],
                         double orig[9], double stats[15]);
+/* Orient's Logfile constructor argument with the restart block of the constructor
+ * (src/Orient.cc:84-335).  Call after create / set_naccel.  Rank 0 does the file work:
+ *   - no file: the two header rows are written (:236-284);
+ *   - a file: it is moved to <logfile>.bak and, with flags & 1 (the global `restart`), its data rows
+ *     up to tnow + 0.1*dtime/Mstep are copied into a fresh <logfile> and rebuild Ecurr, axis, centre,
+ *     centre0, the last `keep` (time, axis1) / (time, centre1) pairs of the two histories, the
+ *     pseudo-acceleration queue and the body/orig rotations; the state then goes to every rank.
+ * The reference queues the row's logged pseudo-ACCELERATION where accumulate() queues centre1
+ * (:185 vs :711); that is reproduced unless flags & 2 asks for centre1.  *rows (may be NULL) = data
+ * rows taken.  Values come back with the 6 significant digits the log holds.
+ * log_entry is Orient::logEntry(time, c) (:742-785): one 33-column row appended by rank 0 -- time,
+ * Ecurr, used, axis, axis1, centre, centre0, centre1, com, com0 (NULL: zeros), pseudo-acceleration,
+ * omega, domega/dt.  A sim whose estimator has a log open writes the row itself after each
+ * accumulate (src/ComponentContainer.cc:1386-1389).                                          */
+int  exp_amd_orient_open_log(exp_amd_orient *o, const char *logfile, unsigned flags, double tnow,
+                             double dtime, int Mstep, long long *rows);
+int  exp_amd_orient_log_entry(exp_amd_orient *o, double time, const double com[3], const double com0[3]);
 
 /* ---- spherical force method (sphereSL) -----------------------------------------------
  * Replaces class Sphere : SphericalBasis (src/Sphere.cc:28-96, src/SphericalBasis.cc)
@@ -358,6 +375,9 @@ int  exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int target);
  * flag the body rotation is handed to the component too (used by the cylindrical method).  The
  * sim does not own the estimator.                               */
 int  exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dryrun, int centerlevl);
+/* The global `restart` (src/global.cc): the estimators take in the state of the first force
+ * evaluation too, where a fresh run waits for potentials (src/ComponentContainer.cc:1386).   */
+int  exp_amd_sim_set_restart(exp_amd_sim *s, int on);
 int  exp_amd_sim_init(exp_amd_sim *s);
 int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
 double exp_amd_sim_time(const exp_amd_sim *s);

@@ -10,6 +10,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1266,6 +1267,144 @@ void orc_orient_init(orc_orient *o, int keep, int many, unsigned oflags, unsigne
   o->lasttime = -DBL_MAX;
   o->axis[2] = 1.0;
   for (int k = 0; k < 3; k++) o->body[4 * k] = o->orig[4 * k] = 1.0;
+}
+
+/* one whitespace-separated number of a log row, as `line >> x` takes it: *p advances past the
+ * token; *eof is set once the scan touches the end of the row (an istringstream's eofbit)        */
+static double orc_row_number(const char **p, int *eof)
+{
+  char *e;
+  while (**p == ' ' || **p == '\t') (*p)++;
+  if (!**p) { *eof = 1; return 0.0; }
+  double v = strtod(*p, &e);
+  *p = e;
+  if (!*e) *eof = 1;
+  return v;
+}
+
+/* The restart block of Orient::Orient (src/Orient.cc:84-335), one process: a missing log gets its
+ * two header rows (:236-284); an existing one moves to <logfile>.bak and -- with `restart` -- its
+ * data rows up to tnow + 0.1*dtime/Mstep are copied into a fresh <logfile> and rebuild Ecurr, axis,
+ * axis1, centre, centre0, centre1, the last `keep` entries of the two histories and body/orig.
+ * queue7[naccel][7] / *nq receive what the reference hands its PseudoAccel: (time, the row's logged
+ * pseudo-acceleration, axis1) (:174-186).  Returns the rows taken, -1 on a file error.            */
+long orc_orient_restart(orc_orient *o, const char *logfile, int restart, double tnow, double dtime,
+                        int Mstep, int naccel, double *queue7, int *nq)
+{
+  static const char *lab[33] = {
+      "Time", "E_curr", "Used", "X-axis(reg)", "Y-axis(reg)", "Z-axis(reg)", "X-axis(cur)", "Y-axis(cur)",
+      "Z-axis(cur)", "X-center(anl)", "Y-center(anl)", "Z-center(anl)", "X-center(reg)", "Y-center(reg)",
+      "Z-center(reg)", "X-center(cur)", "Y-center(cur)", "Z-center(cur)", "X-com(cur)", "Y-com(cur)",
+      "Z-com(cur)", "X-com(dif)", "Y-com(dif)", "Z-com(dif)", "X-accel", "Y-accel", "Z-accel", "Omega_X",
+      "Omega_Y", "Omega_Z", "dOmega/dt_X", "dOmega/dt_Y", "dOmega/dt_Z"};
+  if (nq) *nq = 0;
+  FILE *in = fopen(logfile, "r");
+  if (!in) {
+    FILE *out = fopen(logfile, "w");
+    if (!out) return -1;
+    for (int k = 0; k < 33; k++) {
+      char cell[32];
+      snprintf(cell, sizeof cell, "%s%s", k ? "| " : "# ", lab[k]);
+      fprintf(out, "%-15s", cell);
+    }
+    fputc('\n', out);
+    for (int k = 0; k < 33; k++) {
+      char num[16];
+      int w = snprintf(num, sizeof num, "%d", k + 1);
+      fputs(k ? "| " : "# ", out);
+      fputs(num, out);
+      for (; w < 13; w++) fputc('-', out);
+    }
+    fputc('\n', out);
+    fclose(out);
+    return 0;
+  }
+  fclose(in);
+  size_t L = strlen(logfile);
+  char *bak = (char *)malloc(L + 5);
+  memcpy(bak, logfile, L);
+  memcpy(bak + L, ".bak", 5);
+  if (rename(logfile, bak)) { free(bak); return -1; }
+  FILE *out = fopen(logfile, "w");
+  in = fopen(bak, "r");
+  free(bak);
+  if (!out || !in) { if (out) fclose(out); if (in) fclose(in); return -1; }
+  long rows = 0;
+  char *row = (char *)malloc(16384);
+  while (restart && fgets(row, 16384, in)) {
+    size_t n = strlen(row);
+    if (!n || row[n - 1] != '\n') break;           /* a last row without its newline is not taken */
+    row[n - 1] = 0;
+    if (row[0] == '#') continue;
+    const char *p = row;
+    int eof = 0;
+    double time = orc_row_number(&p, &eof);
+    if (tnow + 0.1 * dtime / Mstep < time) break;
+    fprintf(out, "%s\n", row);
+    o->Ecurr = orc_row_number(&p, &eof);
+    (void)orc_row_number(&p, &eof);                /* tused */
+    for (int k = 0; k < 3; k++) o->axis[k] = orc_row_number(&p, &eof);
+    for (int k = 0; k < 3; k++) o->axis1[k] = orc_row_number(&p, &eof);
+    for (int k = 0; k < 3; k++) o->center[k] = orc_row_number(&p, &eof);
+    for (int k = 0; k < 3; k++) o->center0[k] = orc_row_number(&p, &eof);
+    for (int k = 0; k < 3; k++) o->center1[k] = orc_row_number(&p, &eof);
+    rows++;
+    if (o->oflags & 1u) {
+      if (o->nA == o->keep) {                      /* push_back, then pop_front beyond keep */
+        memmove(o->tA, o->tA + 1, (size_t)(o->nA - 1) * sizeof(double));
+        memmove(o->vA, o->vA + 1, (size_t)(o->nA - 1) * sizeof(o->vA[0]));
+        o->nA--;
+      }
+      o->tA[o->nA] = time;
+      memcpy(o->vA[o->nA++], o->axis1, sizeof(o->axis1));
+    }
+    if (o->oflags & 2u) {
+      if (o->nC == o->keep) {
+        memmove(o->tC, o->tC + 1, (size_t)(o->nC - 1) * sizeof(double));
+        memmove(o->vC, o->vC + 1, (size_t)(o->nC - 1) * sizeof(o->vC[0]));
+        o->nC--;
+      }
+      o->tC[o->nC] = time;
+      memcpy(o->vC[o->nC++], o->center1, sizeof(o->center1));
+    }
+    double pseudo[3] = {0, 0, 0};
+    int all = 1;
+    for (int i = 0; i < 3; i++) {
+      if (eof) { all = 0; break; }
+      for (int k = 0; k < 3; k++) pseudo[k] = orc_row_number(&p, &eof);
+    }
+    if (all && naccel > 0 && queue7 && nq) {
+      if (*nq == naccel) { memmove(queue7, queue7 + 7, (size_t)(naccel - 1) * 7 * sizeof(double)); (*nq)--; }
+      double *q = queue7 + 7 * (*nq)++;
+      q[0] = time;
+      for (int k = 0; k < 3; k++) { q[1 + k] = pseudo[k]; q[4 + k] = o->axis1[k]; }
+    }
+  }
+  free(row);
+  fclose(in);
+  fclose(out);
+  if (o->oflags & 1u) {                            /* (:325-335) */
+    double phi = atan2(o->axis[1], o->axis[0]);
+    double theta = -acos(o->axis[2] / sqrt(o->axis[0] * o->axis[0] + o->axis[1] * o->axis[1] + o->axis[2] * o->axis[2]));
+    orc_euler_slater(phi, theta, 0.0, 0, o->body);
+    orc_euler_slater(phi, theta, 0.0, 1, o->orig);
+  }
+  return rows;
+}
+
+/* Orient::logEntry (src/Orient.cc:742-785): setw(15) in the stream's default format is %15.6g */
+int orc_orient_log_entry(const orc_orient *o, const char *logfile, double time, const double *com,
+                         const double *com0, const double *accel, const double *omega, const double *domdt)
+{
+  FILE *f = fopen(logfile, "a");
+  if (!f) return -1;
+  const double *cols[10] = {o->axis, o->axis1, o->center, o->center0, o->center1, com, com0, accel, omega, domdt};
+  fprintf(f, "%15.6g%15.6g%15ld", time, o->Ecurr, o->used);
+  for (int c = 0; c < 10; c++)
+    for (int k = 0; k < 3; k++) fprintf(f, "%15.6g", cols[c][k]);
+  fputc('\n', f);
+  fclose(f);
+  return 0;
 }
 
 typedef struct { double E, M, L[3], R[3]; } orc_el3;

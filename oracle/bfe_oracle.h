@@ -167,13 +167,18 @@ typedef struct {
   int nA, nC;                     /* history lengths (sumsA, sumsC)                         */
   double tA[ORC_ORIENT_HIST], vA[ORC_ORIENT_HIST][3], tC[ORC_ORIENT_HIST], vC[ORC_ORIENT_HIST][3];
 } orc_orient;
-/* Orient::Orient (src/Orient.cc:38-80) without the log-file restart */
+/* Orient::Orient (src/Orient.cc:38-80); the log-file restart is orc_orient_restart */
 void   orc_orient_init(orc_orient *o, int keep, int many, unsigned oflags, unsigned cflags,
                        double deltaT, double damp);
 /* Orient::accumulate + accumulate_cpu (src/Orient.cc:325-747), one process */
 void   orc_orient_accumulate(orc_orient *o, double time, double dtime, long n, const double *mass,
                              const double *x, const double *y, const double *z, const double *vx,
                              const double *vy, const double *vz, const double *pot);
+/* the log file: the restart block of the constructor (src/Orient.cc:84-335) and logEntry (:742-785) */
+long   orc_orient_restart(orc_orient *o, const char *logfile, int restart, double tnow, double dtime,
+                          int Mstep, int naccel, double *queue7, int *nq);
+int    orc_orient_log_entry(const orc_orient *o, const char *logfile, double time, const double *com,
+                            const double *com0, const double *accel, const double *omega, const double *domdt);
 void   orc_euler_slater(double phi, double theta, double psi, int body, double *out9);
 /* QuadLS (include/QuadLS.H:17-53): y = a x^2 + b x + c; out = {a, b, c} */
 /* pyEXP coefficient covariance by sub-sampling: Spherical::accumulate with pcavar

@@ -280,6 +280,24 @@ class Oracle:
                                  ctypes.c_uint(cflags), ctypes.c_double(deltaT), ctypes.c_double(damp))
         return o
 
+    def orient_restart(self, o, logfile, restart, tnow, dtime, Mstep, naccel=0):
+        """The restart block of the constructor (src/Orient.cc:84-335) -> (rows, queue [nq, 7])."""
+        q = np.zeros((max(naccel, 1), 7))
+        nq = ctypes.c_int(0)
+        self.lib.orc_orient_restart.restype = ctypes.c_long
+        rows = self.lib.orc_orient_restart(ctypes.byref(o), str(logfile).encode(), ctypes.c_int(int(restart)),
+                                           ctypes.c_double(tnow), ctypes.c_double(dtime), ctypes.c_int(Mstep),
+                                           ctypes.c_int(naccel), _dp(q), ctypes.byref(nq))
+        return int(rows), q[:nq.value].copy()
+
+    def orient_log_entry(self, o, logfile, time, com=(0, 0, 0), com0=(0, 0, 0), accel=(0, 0, 0),
+                         omega=(0, 0, 0), domdt=(0, 0, 0)):
+        """``Orient::logEntry`` (src/Orient.cc:742-785)."""
+        v = [np.ascontiguousarray(a, dtype=np.float64) for a in (com, com0, accel, omega, domdt)]
+        rc = self.lib.orc_orient_log_entry(ctypes.byref(o), str(logfile).encode(), ctypes.c_double(time),
+                                           *[_dp(a) for a in v])
+        assert rc == 0
+
     def orient_accumulate(self, o, time, dtime, mass, pos, vel, pot):
         """src/Orient.cc:325-747 (one process)."""
         cols = [np.ascontiguousarray(a[:, k], dtype=np.float64) for a in (pos, vel) for k in range(3)]

@@ -109,3 +109,46 @@ def test_config4_small_golden(oracle):
             ref = z[f"{name}_{key}"]
             assert np.abs(snap[f"{name}_{key}"] - ref).max() <= 1e-13 * np.abs(ref).max(), (name, key)
     assert snap["disk_cylmass"] == float(z["disk_cylmass"])
+
+
+def test_orient_log_restart_oracle(tmp_path):
+    """The oracle's restatement of Orient's log (src/Orient.cc:84-335, :742-785) on a hand-made run:
+    header layout, the row format (33 columns of width 15), the time cut, the `keep` newest history
+    entries, the untouched backup and the rule that a row which ends early feeds no queue entry."""
+    import numpy as np
+    from tests.oracle_lib import Oracle
+    orc = Oracle()
+    log = str(tmp_path / "disk.orient.run1")
+    o = orc.orient(3, 100, 3)
+    assert orc.orient_restart(o, log, True, 0.0, 0.01, 1)[0] == 0
+    head = open(log).read().splitlines()
+    assert len(head) == 2 and len(head[0]) == 33 * 15 and head[0][:15] == "# Time".ljust(15)
+    assert head[1].startswith("# 1------------| 2------------") and head[1].endswith("| 33-----------")
+    rng = np.random.default_rng(5)
+    rowsv = []
+    for k in range(6):
+        o.Ecurr = -1.0 - 0.1 * k
+        o.used = 90 + k
+        for name in ("axis", "axis1", "center", "center0", "center1"):
+            v = rng.normal(size=3)
+            for j in range(3):
+                getattr(o, name)[j] = v[j]
+        acc = rng.normal(size=3)
+        orc.orient_log_entry(o, log, 0.01 * k, com=(0.1, 0.2, 0.3), accel=acc)
+        rowsv.append((0.01 * k, acc))
+    text = open(log).read().splitlines()
+    assert all(len(r) == 33 * 15 for r in text[2:])
+    with open(log, "a") as f:                       # a short (18-column) row as older logs have them
+        f.write("".join(f"{v:>15.6g}" for v in [0.06, -2.0, 50] + list(range(15))) + "\n")
+    o2 = orc.orient(3, 100, 3)
+    rows, q = orc.orient_restart(o2, log, True, 0.06, 0.01, 2, naccel=4)
+    assert rows == 7 and o2.nA == 3 and o2.nC == 3 and list(o2.tA[:3]) == [0.04, 0.05, 0.06]
+    assert list(o2.center1[:]) == [12.0, 13.0, 14.0] and o2.Ecurr == -2.0
+    tab = np.array([r.split() for r in text[2:]], dtype=float)
+    assert q.shape == (4, 7) and np.array_equal(q[:, 0], tab[2:6, 0]) and np.array_equal(q[:, 1:4], tab[2:6, 24:27])
+    assert open(log + ".bak").read().splitlines()[:8] == text and len(open(log).read().splitlines()) == 7
+    # the cut: rows later than tnow + 0.1 dtime/Mstep stay behind
+    o3 = orc.orient(3, 100, 2)
+    rows, _ = orc.orient_restart(o3, log, True, 0.0204, 0.01, 2)
+    assert rows == 3 and o3.nA == 0 and o3.nC == 3
+    assert np.allclose(np.array(o3.body[:]).reshape(3, 3), np.eye(3))    # CENTER only: no rotation

@@ -337,3 +337,86 @@ def test_orient_pseudo_accel_estimates_and_step_loop(ctx, oracle):
     out = c.download(("acc",))["acc"]
     assert np.isfinite(out).all()
     sim.close(); o.close(); c.close(); f.close()
+
+
+def test_orient_restart_from_its_log(ctx, oracle, tmp_path):
+    """The restart block of the constructor (src/Orient.cc:84-335): a run writes its log through
+    Orient::logEntry, a second estimator re-reads it up to the restart time.  The device estimator
+    and the oracle's restatement must (a) write the same header bytes, (b) copy the same rows into the
+    fresh log and leave the old one as <log>.bak, (c) hold the same state after the restart -- the
+    values are the log's 6-digit ones, so (c) is exact -- and (d) continue the run alike."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Orient, SphereSL
+    model, g = make_grid("plummer", 4, 8, 400)
+    n, dt, keep, many, nacc = 20000, 0.02, 3, 1500, 4
+    m, pos, vel = sample_sphere(model, n, seed=77)
+    pos = pos + np.array([0.1, 0.05, -0.02])
+    vel = vel + np.array([0.2, -0.3, 0.1]) + 0.2 * np.cross([0.1, 0.2, 1.0], pos)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+    log, rlog = str(tmp_path / "halo.orient.run0"), str(tmp_path / "ref.orient.run0")
+    o = Orient(ctx, keep, many, Orient.AXIS | Orient.CENTER, Orient.KE, dT=0.0, damping=0.8)
+    o.set_naccel(nacc)
+    assert o.openLog(log) == 0
+    ref = oracle.orient(keep, many, 3, Orient.KE, 0.0, 0.8)
+    assert oracle.orient_restart(ref, rlog, True, 0.0, dt, 1)[0] == 0
+    assert open(log, "rb").read() == open(rlog, "rb").read()          # (a) the two header rows
+    states = []
+    for k in range(9):
+        t = k * dt
+        o.accumulate(t, c, dt)
+        o.logEntry(t, com=(0.01 * k, 0.0, -0.02))
+        states.append(c.download(("mass", "pos", "vel", "pot")))
+        f.step_kdk(c, dt)
+    full = open(log).read().splitlines()
+    assert len(full) == 2 + 9 and all(len(r.split()) == 33 for r in full[2:])
+    # the oracle restarts from a copy of the same file
+    open(rlog, "w").write(open(log).read())
+    tnow = 6 * dt
+    o2 = Orient(ctx, keep, many, Orient.AXIS | Orient.CENTER, Orient.KE, dT=0.0, damping=0.8)
+    o2.set_naccel(nacc)
+    rows = o2.openLog(log, restart=True, tnow=tnow, dtime=dt, Mstep=1)
+    rrows, rq = oracle.orient_restart(ref, rlog, True, tnow, dt, 1, naccel=nacc)
+    assert rows == rrows == 7                                           # rows 0..6, the cut is t <= tnow + 0.1 dt
+    assert open(log, "rb").read() == open(rlog, "rb").read()          # (b)
+    assert open(log).read().splitlines() == full[2:9]
+    assert open(log + ".bak").read().splitlines() == full
+    st = o2.state()
+    for k in ("center", "axis", "axis1", "center1", "center0"):         # (c)
+        assert np.array_equal(st[k], np.array(getattr(ref, k)[:])), k
+    assert st["Ecurr"] == ref.Ecurr
+    assert np.abs(st["body"] - np.array(ref.body[:]).reshape(3, 3)).max() <= 1e-15
+    last = np.array(full[8].split(), dtype=float)
+    assert np.array_equal(st["center"], last[9:12]) and np.array_equal(st["axis1"], last[6:9])
+    # the queue holds (time, logged pseudo-acceleration, axis1) of the last `nacc` rows, as the
+    # reference's does (:174-186); with queue_center1 the centre estimate instead
+    tab = np.array([r.split() for r in full[2:9]], dtype=float)
+    assert np.array_equal(rq, np.hstack([tab[-nacc:, 0:1], tab[-nacc:, 24:27], tab[-nacc:, 6:9]]))
+    acc, om, dom = o2.currentAccel()
+    ra, ro, rd = oracle.pseudo_accel_fit(rq)
+    assert np.allclose(acc, ra, rtol=0, atol=1e-9 * max(1.0, np.abs(ra).max()))
+    assert np.allclose(om, ro, rtol=0, atol=1e-9) and np.allclose(dom, rd, rtol=0, atol=1e-7)
+    # (d) both continue from the restored histories with the run's next states
+    for k in (7, 8):
+        d = states[k]
+        cc = Component.from_arrays(ctx, d["mass"], d["pos"], d["vel"])
+        cc.upload_acc(np.zeros_like(d["pos"]), d["pot"])
+        oracle.orient_accumulate(ref, k * dt, dt, d["mass"], d["pos"], d["vel"], d["pot"])
+        o2.accumulate(k * dt, cc, dt)
+        _compare(o2, ref)
+        cc.close()
+    # no restart: the old log is set aside and nothing is read back (:128 `while (in && restart)`)
+    o3 = Orient(ctx, keep, many, Orient.AXIS | Orient.CENTER, Orient.KE)
+    assert o3.openLog(log, restart=False, tnow=tnow, dtime=dt) == 0
+    assert open(log).read() == "" and np.array_equal(o3.currentAxis(), [0.0, 0.0, 1.0])
+    # queue_center1: the evident intention
+    open(log, "w").write("\n".join(full) + "\n")
+    o4 = Orient(ctx, keep, many, Orient.AXIS | Orient.CENTER, Orient.KE)
+    o4.set_naccel(nacc)
+    assert o4.openLog(log, restart=True, tnow=tnow, dtime=dt, queue_center1=True) == 7
+    a4, _, _ = o4.currentAccel()
+    r4, _, _ = oracle.pseudo_accel_fit(np.hstack([tab[-nacc:, 0:1], tab[-nacc:, 15:18], tab[-nacc:, 6:9]]))
+    assert np.allclose(a4, r4, rtol=0, atol=1e-7 * max(1.0, np.abs(r4).max()))
+    for x in (o, o2, o3, o4, c):
+        x.close()
