@@ -2,7 +2,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_cfg4
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/tools/bench_configs.py --only 4 --steps 3 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/tools/bench_configs.py --only 4 --steps 6 > $OUT/log.txt 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 rows=[]
@@ -21,4 +21,5 @@ for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1]))[:14]:
     v2=sorted(v)
     print(f"{k[:40]:40s} n={len(v):5d} total={sum(v)/1e3:8.2f} ms  median={v2[len(v2)//2]:8.1f} us  p90={v2[int(len(v2)*0.9)]:8.1f}  max={v2[-1]:8.1f}")
 PY
+python3 $REPO/tools/trace_cfg4.py $OUT
 find $OUT -name "*.csv" -size +5M -delete

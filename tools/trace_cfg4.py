@@ -23,13 +23,22 @@ def main():
     rows.sort(key=lambda r: r[1])
     adj = [i for i, r in enumerate(rows) if r[0].startswith("k_kick_adjust")]
     per = ncomp * (1 << ms)
-    # the last complete master step ends with the last adjust launch of the trace
-    a, b = adj[-per - ncomp], adj[-ncomp]
+    # one complete steady master step: the one before the last (the last one runs into the bench's
+    # final downloads); a master step ends with its last sub-step's adjust launches
+    back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    a, b = adj[-(back + 1) * per - ncomp], adj[-back * per - ncomp]
     seg = rows[a:b]
     span = (seg[-1][2] - seg[0][1]) / 1e6
-    busy = sum(e - s for _, s, e in seg) / 1e6
-    print(f"{os.path.basename(f)}: master step span {span:.2f} ms, busy {busy:.2f} ms ({busy / span:.3f}), "
-          f"{len(seg)} launches")
+    ksum = sum(e - s for _, s, e in seg) / 1e6
+    # GPU-busy time = the UNION of the kernel intervals (two streams overlap, so the plain sum of the
+    # durations can exceed the span)
+    busy, hi = 0.0, seg[0][1]
+    for _, s, e in seg:
+        if e > hi:
+            busy += (e - max(s, hi)) / 1e6
+            hi = e
+    print(f"{os.path.basename(f)}: master step span {span:.2f} ms, GPU busy (union of kernel intervals) "
+          f"{busy:.2f} ms = {busy / span:.3f}, kernel time summed {ksum:.2f} ms, {len(seg)} launches")
     tot, cnt = collections.Counter(), collections.Counter()
     for k, s, e in seg:
         tot[k] += (e - s) / 1e6
@@ -37,10 +46,12 @@ def main():
     for k, v in tot.most_common(24):
         print(f"  {k[:44]:44s} n={cnt[k]:4d} {v:7.3f} ms")
     gaps = collections.Counter()
-    for (k0, s0, e0), (k1, s1, e1) in zip(seg[:-1], seg[1:]):
-        g = (s1 - e0) / 1e6
-        if g > 0:
-            gaps[k0[:30] + " -> " + k1[:30]] += g
+    hi, klast = seg[0][2], seg[0][0]
+    for k1, s1, e1 in seg[1:]:
+        if s1 > hi:
+            gaps[klast[:30] + " -> " + k1[:30]] += (s1 - hi) / 1e6
+        if e1 > hi:
+            hi, klast = e1, k1
     print(f"  idle {span - busy:.2f} ms; largest gap classes:")
     for k, v in gaps.most_common(8):
         print(f"    {k:64s} {v:6.3f} ms")
