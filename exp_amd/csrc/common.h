@@ -154,6 +154,93 @@ __device__ __forceinline__ double mul_then_add(double x, double a, double b)
 #endif
 
 #if defined(__HIPCC__)
+// sqrt(t) and ~1/sqrt(t) together, for the squared radii of a model (positive, far from the
+// denormal and overflow ranges: no argument scaling; t == 0 is lifted to 1e-300).  The root follows
+// the compiler's own fp64 expansion -- v_rsq_f64 seed, one coupled Newton step, two residual
+// corrections -- so g is the same correctly rounded value `sqrt` returns; y = 1/sqrt(t) to about an
+// ulp falls out of the same iteration.  11 VALU operations where sqrt followed by an IEEE division
+// costs about 34.
+__device__ __forceinline__ void sqrt_rsqrt(double t, double &g, double &y)
+{
+#ifdef EXPAMD_EXACT_DIV        // A/B switch (tools/build_variant*.sh): the library sqrt and IEEE divisions
+  g = sqrt(t); y = 1.0 / g; return;
+#endif
+  t = fmax(t, 1e-300);
+  const double y0 = __builtin_amdgcn_rsq(t);
+  double g0 = t * y0, h = 0.5 * y0;
+  const double r0 = fma(-h, g0, 0.5);
+  g0 = fma(g0, r0, g0);
+  h = fma(h, r0, h);
+  double d = fma(-g0, g0, t);
+  g0 = fma(d, h, g0);
+  d = fma(-g0, g0, t);
+  g = fma(d, h, g0);
+  y = h + h;
+}
+// 1/v from an estimate y of it (one Newton step: the error is squared)
+__device__ __forceinline__ double rcp_refine(double v, double y)
+{
+#ifdef EXPAMD_EXACT_DIV
+  return 1.0 / v;
+#endif
+  const double e = fma(-v, y, 1.0);
+  return fma(y, e, y);
+}
+// a / b to about an ulp for b in the normal range: v_rcp_f64 seed, two Newton steps, one residual
+// correction of the quotient (8 VALU operations instead of the 11-13 of the IEEE sequence)
+__device__ __forceinline__ double div_fast(double a, double b)
+{
+#ifdef EXPAMD_EXACT_DIV
+  return a / b;
+#endif
+  double y = __builtin_amdgcn_rcp(b);
+  y = rcp_refine(b, y);
+  y = rcp_refine(b, y);
+  const double q = a * y;
+  return fma(fma(-b, q, a), y, q);
+}
+// asinh(u) for u >= 0 to a few ulp, as log1p(u + u^2 / (1 + sqrt(1 + u^2))) with the logarithm
+// written out: 1 + t = 2^k m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m - 1)/(m + 1)) by its
+// series (|z| <= 0.172: ten terms), the rounding error of 1 + t carried along.  About 65 VALU
+// operations; the library asinh (extended-precision logarithm inside) costs several times that and
+// sits on every particle of the cylinder's accumulate and force passes (EmpCylSL::z_to_y with
+// cmapz = 1, exputil/EmpCylSL.cc:7109-7117).
+__device__ __forceinline__ double asinh_pos(double u)
+{
+#ifdef EXPAMD_EXACT_DIV
+  return asinh(u);
+#endif
+  const double u2 = u * u;
+  double s, is;
+  sqrt_rsqrt(1.0 + u2, s, is);
+  const double t = u + div_fast(u2, 1.0 + s);
+  const double f = 1.0 + t;
+  const double c = t - (f - 1.0);                     // f + c == 1 + t
+  int k = __builtin_amdgcn_frexp_exp(f);              // f = mant 2^k, mant in [1/2, 1)
+  double m = __builtin_amdgcn_frexp_mant(f);
+  const int up = m < 0.70710678118654752 ? 1 : 0;
+  m = ldexp(m, up);
+  k -= up;
+  const double z = div_fast(m - 1.0, m + 1.0);
+  const double w = z * z;
+  double q = 1.0 / 19.0;
+  q = fma(q, w, 1.0 / 17.0);
+  q = fma(q, w, 1.0 / 15.0);
+  q = fma(q, w, 1.0 / 13.0);
+  q = fma(q, w, 1.0 / 11.0);
+  q = fma(q, w, 1.0 / 9.0);
+  q = fma(q, w, 1.0 / 7.0);
+  q = fma(q, w, 1.0 / 5.0);
+  q = fma(q, w, 1.0 / 3.0);
+  const double z2 = z + z;
+  const double kd = (double)k;
+  // ln 2 in two pieces (the high one has 21 trailing zero bits: kd * hi is exact)
+  const double lo = fma(kd, 1.90821492927058770002e-10, c * __builtin_amdgcn_rcp(f));
+  return fma(kd, 6.93147180369123816490e-01, z2 + fma(z2 * w, q, lo));
+}
+#endif
+
+#if defined(__HIPCC__)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its fence
 // covers global memory), which kills any global prefetch issued before it; the accumulation
 // kernels keep next-tile loads in flight across their per-tile barrier.

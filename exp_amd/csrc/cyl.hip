@@ -28,6 +28,10 @@ typedef const __attribute__((address_space(4))) double *cdp;
 struct CylDev {
   int mmax, nmax, numx, numy, cmapr, cmapz, EVEN_M, ntrig;
   double ascale, hscale, rtable, xmin, dx, ymin, dy, rmax2;
+  // reciprocals and products of the above, so that the per-particle code multiplies where the
+  // reference divides by a constant (last-ulp differences only; the bilinear blend is continuous
+  // across cell edges): 1/ascale, 1/hscale, 1/dx, 1/dy, rtable*ascale
+  double inv_ascale, inv_hscale, inv_dx, inv_dy, rtab_abs, inv_rtab_abs;
   double cx, cy, cz;
   // Orient::transformBody of the component the basis belongs to (src/Cylinder.cc:799, :1352);
   // forces go back through its transpose, transformOrig (:1418)
@@ -63,14 +67,19 @@ __device__ __forceinline__ void cstatic_for(F &&f)
 // exputil/EmpCylSL.cc:6446-6463
 __device__ __forceinline__ double cyl_r_to_xi(const CylDev &C, double r)
 {
-  return C.cmapr > 0 ? (r / C.ascale - 1.0) / (r / C.ascale + 1.0) : r;
+  if (C.cmapr > 0) { const double u = r * C.inv_ascale; return div_fast(u - 1.0, u + 1.0); }
+  return r;
 }
 
 // exputil/EmpCylSL.cc:7109-7117
 __device__ __forceinline__ double cyl_z_to_y(const CylDev &C, double z)
 {
-  if (C.cmapz == 1) return z / (fabs(z) + 2.2250738585072014e-308) * asinh(fabs(z / C.hscale));
-  if (C.cmapz == 2) return z / sqrt(z * z + C.hscale * C.hscale);
+  if (C.cmapz == 1) return copysign(asinh_pos(fabs(z) * C.inv_hscale), z);     // sign(z) asinh|z/h|
+  if (C.cmapz == 2) {
+    double g, y;
+    sqrt_rsqrt(z * z + C.hscale * C.hscale, g, y);
+    return z * y;
+  }
   return z;
 }
 
@@ -78,8 +87,8 @@ __device__ __forceinline__ double cyl_z_to_y(const CylDev &C, double z)
 __device__ __forceinline__ void cyl_weights(const CylDev &C, double r, double z, int &ix, int &iy,
                                             double &c00, double &c10, double &c01, double &c11)
 {
-  const double X = (cyl_r_to_xi(C, r) - C.xmin) / C.dx;
-  const double Y = (cyl_z_to_y(C, z) - C.ymin) / C.dy;
+  const double X = (cyl_r_to_xi(C, r) - C.xmin) * C.inv_dx;
+  const double Y = (cyl_z_to_y(C, z) - C.ymin) * C.inv_dy;
   ix = (int)X;
   iy = (int)Y;
   if (ix < 0) ix = 0;
@@ -104,10 +113,12 @@ struct CylKeyFn {
     double xx, yy, zz;
     cyl_local(C, x, y, z, xx, yy, zz);
     const double r2 = xx * xx + yy * yy;
-    const double r = sqrt(r2);
+    double r, ir_, r3, ir3_;
+    sqrt_rsqrt(r2, r, ir_);
+    sqrt_rsqrt(r2 + zz * zz, r3, ir3_);
     const uint32_t ncell = (uint32_t)(C.numx * C.numy);
     uint32_t cell = ncell;
-    if (!(sqrt(r2 + zz * zz) / C.ascale > C.rtable)) {
+    if (!(r3 > C.rtab_abs)) {
       int ix, iy;
       double a, b, c, d;
       cyl_weights(C, r, zz, ix, iy, a, b, c, d);
@@ -224,37 +235,43 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     });
   };
 
+  // software prefetch: the loads of group k+1 are in flight while group k is reduced (at two waves
+  // per SIMD nothing else hides an HBM round trip)
+  double nx = 0, ny = 0, nz = 0, nm = 0;
+  if (cbeg + lane < cend) { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane]; }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
     const bool valid = i < cend;
     double xx = 1, yy = 0, zz = 0, mass = 0;
     if (valid) {
-      cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
-      mass = M[i];
+      cyl_local(C, nx, ny, nz, xx, yy, zz);
+      mass = nm;
     }
+    if (i + 64 < cend) { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64]; }
     // src/Cylinder.cc:853-866
     const double r2 = xx * xx + yy * yy;
-    const double r = sqrt(r2);
+    double r, ir, rr, irr;
+    sqrt_rsqrt(r2, r, ir);
     const bool incut = valid && (r2 + zz * zz) < C.rmax2;
     if (incut) { mass_used += cdet_round(mass, C.detCm); n_used += 1.0; }
     // EmpCylSL::accumulate (:4062-4063)
-    const double rr = sqrt(r * r + zz * zz);
-    const bool ongrid = incut && !(rr / C.ascale > C.rtable);
+    sqrt_rsqrt(r2 + zz * zz, rr, irr);
+    const bool ongrid = incut && !(rr > C.rtab_abs);
     double zc = zz;                                         // get_pot z clamp (:5563-5564)
-    if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
-    if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+    if (zc > C.rtab_abs) zc = C.rtab_abs;
+    if (zc < -C.rtab_abs) zc = -C.rtab_abs;
     int ix, iy;
     double c00, c10, c01, c11;
     cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
     const int cell = ix * C.numy + iy + lvl * ncellT;
     double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
-    if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
+    if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
     const double t0 = ongrid ? norm * mass : 0.0;
 
     unsigned long long remaining = __ballot(ongrid);
     while (remaining) {
       const int lead = __ffsll((long long)remaining) - 1;
-      const int c = __shfl(cell, lead);
+      const int c = __builtin_amdgcn_readlane(cell, lead);
       const bool sel = ongrid && cell == c;
       if (c != cur) {
         if (cur >= 0) flush(cur);
@@ -329,7 +346,8 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
     mass = M[i];
   }
   const double r2 = xx * xx + yy * yy;
-  const double r = sqrt(r2);
+  double r, ir;
+  sqrt_rsqrt(r2, r, ir);
   if (plain) {
     const bool incut = mover && (r2 + zz * zz) < C.rmax2;
     double mu = incut ? cdet_round(mass, C.detCm) : 0.0, nu = incut ? 1.0 : 0.0;
@@ -337,16 +355,16 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
     if ((threadIdx.x & 63) == 0 && nu > 0.0) { unsafeAtomicAdd(tail + 0, mu); unsafeAtomicAdd(tail + 1, nu); }
     mover = incut;
   }
-  if (sqrt(r * r + zz * zz) / C.ascale > C.rtable) mover = false;
+  if (sqrt(r2 + zz * zz) > C.rtab_abs) mover = false;
   if (!__any(mover)) return;
   double zc = zz;
-  if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
-  if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+  if (zc > C.rtab_abs) zc = C.rtab_abs;
+  if (zc < -C.rtab_abs) zc = -C.rtab_abs;
   int ix, iy;
   double cw[4];
   cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
   double cphi = 1.0, sphi = 0.0;
-  if (r2 > 0.0) { cphi = xx / r; sphi = yy / r; }
+  if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
   const double t0 = mover ? -4.0 * M_PI * mass : 0.0;
   const int nyp = C.numy + 1;
   const size_t nnode = (size_t)(C.numx + 1) * nyp;
@@ -558,21 +576,21 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   const double ratmin = 0.75, maxerf = 3.0;
   const double midpt = ratmin + 0.5 * (1.0 - ratmin);
   const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
-  double R2 = C.ascale * C.rtable;
-  R2 = R2 * R2;
   const double r2 = xx * xx + yy * yy;
-  const double r = sqrt(r2) + DSMALL;
+  double rp, irp, r3s, ir3s;                  // sqrt(x^2+y^2), sqrt(x^2+y^2+z^2) and their reciprocals
+  sqrt_rsqrt(r2, rp, irp);
+  sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
+  const double r = rp + DSMALL;
   double cphi = 1.0, sphi = 0.0;
-  if (r2 > 0.0) { const double rp = sqrt(r2); cphi = xx / rp; sphi = yy / rp; }
-  const double ratio = sqrt((r2 + zz * zz) / R2);
+  if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+  const double ratio = r3s * C.inv_rtab_abs;              // sqrt((r^2 + z^2) / (ascale rtable)^2)
   double frac, cfrac;
   if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
   else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
   else { cfrac = 0.0; frac = 1.0; }
 
   // accumulated_eval (exputil/EmpCylSL.cc:5272-5314): off grid -> zeros
-  const double rr = sqrt(r * r + zz * zz);
-  const bool ongrid = valid && ratio < 1.0 && !(rr / C.ascale > C.rtable);
+  const bool ongrid = valid && ratio < 1.0 && !(r3s > C.rtab_abs);
   int ix, iy;
   double c00, c10, c01, c11;
   cyl_weights(C, r, zz, ix, iy, c00, c10, c01, c11);
@@ -601,15 +619,16 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   if (ratio < 1.0) {
     double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
     if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
-    fx = (fr * xx / r - fp * yy / r2) * frac;      // src/Cylinder.cc:1387-1390
-    fy = (fr * yy / r + fp * xx / r2) * frac;
+    // (1/r2 is infinite on the axis: the reference's fp*yy/r2 is 0/0 = NaN there, and so is this)
+    const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+    fx = (fr * xx * ir - fp * yy * ir2) * frac;    // src/Cylinder.cc:1387-1390
+    fy = (fr * yy * ir + fp * xx * ir2) * frac;
     fz = fzz * frac;
     pa = p * frac;
   }
   if (ratio > ratmin) {                             // monopole blend, src/Cylinder.cc:1398-1408
-    const double r3 = r2 + zz * zz;
-    const double p = -(*cylmass_p) / sqrt(r3);
-    const double fr = p / r3;
+    const double p = -(*cylmass_p) * ir3s;          // -M / sqrt(r^2 + z^2)
+    const double fr = p * (ir3s * ir3s);
     fx += xx * fr * cfrac;
     fy += yy * fr * cfrac;
     fz += zz * fr * cfrac;
@@ -771,7 +790,10 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   C.mmax = M; C.nmax = N; C.numx = cfg->numx; C.numy = cfg->numy; C.cmapr = cfg->cmapr;
   C.cmapz = cfg->cmapz; C.EVEN_M = cfg->EVEN_M; C.ntrig = ntrig;
   C.ascale = cfg->ascale; C.hscale = cfg->hscale; C.rtable = cfg->rtable;
+  C.inv_ascale = 1.0 / cfg->ascale; C.inv_hscale = 1.0 / cfg->hscale;
+  C.rtab_abs = cfg->rtable * cfg->ascale; C.inv_rtab_abs = 1.0 / C.rtab_abs;
   C.xmin = cfg->xmin; C.dx = cfg->dx; C.ymin = cfg->ymin; C.dy = cfg->dy;
+  C.inv_dx = 1.0 / cfg->dx; C.inv_dy = 1.0 / cfg->dy;
   C.rmax2 = cfg->rcylmax * cfg->rcylmax * cfg->ascale * cfg->ascale;   // src/Cylinder.cc:752
   C.cx = C.cy = C.cz = 0.0;
   *out = f;
@@ -1149,7 +1171,7 @@ k_cyl_fields(CylDev C, const double *__restrict__ tab, const double *__restrict_
     phi = atan2(y, x);
   }
   double p0 = 0.0, p = 0.0, fr = 0.0, fz = 0.0, fp = 0.0, d0 = 0.0, d = 0.0;
-  if (!(sqrt(R * R + z * z) / C.ascale > C.rtable)) {
+  if (!(sqrt(R * R + z * z) > C.rtab_abs)) {
     int ix, iy;
     double c00, c10, c01, c11;
     cyl_weights(C, R, z, ix, iy, c00, c10, c01, c11);
@@ -1258,7 +1280,7 @@ k_cyl_cov_accumulate(CylDev C, const double *__restrict__ X, const double *__res
   double xx, yy, zz;
   cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
   const double r2 = xx * xx + yy * yy, r = sqrt(r2);
-  if (sqrt(r * r + zz * zz) / C.ascale > C.rtable) return;            // EmpCylSL.cc:4062-4063
+  if (sqrt(r * r + zz * zz) > C.rtab_abs) return;                     // EmpCylSL.cc:4062-4063
   const double mass = M[i];
   const uint32_t sq = seq ? seq[id[i]] : id[i];
   const int T = (int)(sq % (uint32_t)sampT);
@@ -1266,8 +1288,8 @@ k_cyl_cov_accumulate(CylDev C, const double *__restrict__ X, const double *__res
   atomicAdd(used, 1ull);
   unsafeAtomicAdd(&msum[T], mass);
   double zc = zz;                                                     // get_pot z clamp (:5563-5564)
-  if (zc / C.ascale > C.rtable) zc = C.rtable * C.ascale;
-  if (zc / C.ascale < -C.rtable) zc = -C.rtable * C.ascale;
+  if (zc > C.rtab_abs) zc = C.rtab_abs;
+  if (zc < -C.rtab_abs) zc = -C.rtab_abs;
   int ix, iy;
   double cw[4];
   cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);

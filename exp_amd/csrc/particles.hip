@@ -100,7 +100,7 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
   __syncthreads();
   // eight consecutive bins per thread and pass: the passes are barrier-latency bound (the cylinder's
   // 5 x 33025 bins took 200 us at one bin per thread)
-  constexpr uint32_t SI = 32;
+  constexpr uint32_t SI = 33;     // (1024 x 33 covers the cylinder's 256 x 128 + 1 bins of one level in ONE pass)
   for (uint32_t base = k0; base < k1; base += 1024u * SI) {
     const uint32_t kb = base + (uint32_t)t * SI;
     uint32_t v[SI], s = 0;

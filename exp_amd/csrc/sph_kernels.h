@@ -168,7 +168,7 @@ __device__ __forceinline__ double sph_r_to_xi(const SphDev &S, double r)
 // the same maps with the constant divisions replaced by multiplications (fast force pass)
 __device__ __forceinline__ double sph_r_to_xi_rcp(const SphDev &S, double r)
 {
-  if (S.cmap == 1) { const double u = r * S.inv_rmap; return (u - 1.0) / (u + 1.0); }
+  if (S.cmap == 1) { const double u = r * S.inv_rmap; return div_fast(u - 1.0, u + 1.0); }
   if (S.cmap == 2) return log(r);
   return r;
 }
@@ -210,7 +210,9 @@ __device__ __forceinline__ uint32_t sph_key_cell(const SphDev &S, double x, doub
 __device__ __forceinline__ uint32_t sph_key_cell_rcp(const SphDev &S, double x, double y, double z)
 {
   const double xx = x - S.cx, yy = y - S.cy, zz = z - S.cz;
-  double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  double r, ir_;
+  sqrt_rsqrt(xx * xx + yy * yy + zz * zz, r, ir_);
+  r += DSMALL;
   if (r > S.rmax && !S.no_exterior) r = S.rmax;
   const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
   int idx = (int)((xi - S.xmin) * S.inv_dxi);
@@ -332,12 +334,15 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   if (valid) { xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz; }
   // src/SphericalBasis.cc:486-494
   const double R2 = xx * xx + yy * yy;
-  const double r = sqrt(R2 + zz * zz) + S.dsmall;
+  double g, y;
+  sqrt_rsqrt(R2 + zz * zz, g, y);
+  const double r = g + S.dsmall;
   const bool inwin = valid && r >= S.rmin && r <= S.rmax;
-  const double ir = 1.0 / r;
+  const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
   if (R2 > 1e-12 * (r * r)) {
-    const double R = sqrt(R2), iR = 1.0 / R;
+    double R, iR;
+    sqrt_rsqrt(R2, R, iR);
     in.cphi = xx * iR;
     in.sphi = yy * iR;
     in.sinth = R * ir;
@@ -402,7 +407,7 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
   unsigned long long remaining = __ballot(inwin);
   while (remaining) {
     const int lead = __ffsll((long long)remaining) - 1;
-    const int c = __shfl(in.idx, lead);
+    const int c = __builtin_amdgcn_readlane(in.idx, lead);   // (scalar: the flush test below is a scalar branch)
     const bool sel = inwin && in.idx == c;
     if (c != cur) {
       if (cur >= 0)
@@ -1035,10 +1040,12 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     // agree with the reference's formulas to a few ulp).  Lanes on the polar axis, where the
     // reference clamps x (src/Basis.cc:81-84), outside rmax, or waves spanning several radial
     // cells are left to the general pass.
-    r = sqrt(fac + zz * zz) + S.dsmall;                      // src/SphericalBasis.cc:1545-1560
-    ir = 1.0 / r;
+    double g, y, R, iR;
+    sqrt_rsqrt(fac + zz * zz, g, y);
+    r = g + S.dsmall;                                        // src/SphericalBasis.cc:1545-1560
+    ir = rcp_refine(r, y);
     const double costh = zz * ir;
-    const double R = sqrt(fac), iR = 1.0 / R;
+    sqrt_rsqrt(fac, R, iR);
     iR2 = iR * iR;
     const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
     // theta < 1e-6: sin(theta) = R/r and the reference's sqrt((1-x)(1+x)) differ by more than the
