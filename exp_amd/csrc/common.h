@@ -54,6 +54,7 @@ struct exp_amd_ctx {
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;
+  struct ScanSums { uint32_t *p = nullptr; size_t n = 0; hipError_t alloc(size_t c) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void **)&p, c * sizeof(uint32_t)); if (e == hipSuccess) n = c; return e; } } scan_sums[2];   // chunk totals of multi-chunk scans, one per stream (particles.hip)
   hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_forced[2] = {nullptr, nullptr};
 };
 // lazily creates ctx->aux and the four events

@@ -81,6 +81,7 @@ extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
     (void)hipStreamDestroy(ctx->aux);
     for (int k = 0; k < 2; k++) { (void)hipEventDestroy(ctx->ev_sorted[k]); (void)hipEventDestroy(ctx->ev_forced[k]); }
   }
+  for (auto &ss : ctx->scan_sums) if (ss.p) (void)hipFree(ss.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -460,33 +460,76 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 
 // ---- moments -> coefficients -----------------------------------------------------------------------------
 // out[cs][m][n] = sum_node tab[cs ? 3 : 0][m][n][node] * Wn[node][trig(m, cs)]
+// Two stages.  Stage 1: block (trig slot t, node segment, level) keeps the sums of ALL n in registers,
+// so a moment Wn[node][t] -- stride ntrig, one cache line each -- is fetched once per (t, node) and
+// not once per (t, n, node) as a block per coefficient would (that variant moved 330 MB through L2
+// for 45 MB of tables: 70 us per contraction at 256 x 128).  Stage 2 adds the segments in a fixed
+// order (same bits every run) and does setup_accumulation's swap on the way.
+#define CYL_CSEG 24
+#define CYL_CNB 12                 // n per register block
 __global__ void __launch_bounds__(256)
-k_cyl_contract(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
-               double *__restrict__ out, size_t ostride = 0, double *__restrict__ last = nullptr)
+k_cyl_contract_part(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
+                    double *__restrict__ part /* [level][CYL_CSEG][ncoef] */)
 {
-  const int n = blockIdx.x, m = blockIdx.y, cs = blockIdx.z & 1, L = blockIdx.z >> 1;   // L: level of a multi-level launch
-  __shared__ double red[256];
+  const int t = blockIdx.x, seg = blockIdx.y, L = blockIdx.z;
+  const int m = (t + 1) >> 1, cs = t ? ((t + 1) & 1) : 0;
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
+  const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   Wn += (size_t)L * nnode * C.ntrig;
-  out += (size_t)L * ostride;
-  if (last) last += (size_t)L * ostride;     // setup_accumulation's swap on the way: last <- out, out <- new
-  double s = 0.0;
-  if (!(cs == 1 && m == 0)) {
-    const int t = (m == 0) ? 0 : 2 * m - 1 + cs;
-    const double *T = tab + ((((size_t)(cs ? 3 : 0)) * (C.mmax + 1) + m) * C.nmax + n) * nnode;
-    for (size_t k = threadIdx.x; k < nnode; k += 256) s = fma(T[k], Wn[k * C.ntrig + t], s);
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+  const size_t k0 = nnode * seg / CYL_CSEG, k1 = nnode * (seg + 1) / CYL_CSEG;
+  const double *T0 = tab + ((((size_t)(cs ? 3 : 0)) * (C.mmax + 1) + m) * C.nmax) * nnode;
+  double *out = part + ((size_t)L * CYL_CSEG + seg) * ncoef + ((size_t)cs * (C.mmax + 1) + m) * C.nmax;
+  __shared__ double red[4][CYL_CNB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int nb = 0; nb < C.nmax; nb += CYL_CNB) {
+    double s[CYL_CNB];
+#pragma unroll
+    for (int j = 0; j < CYL_CNB; j++) s[j] = 0.0;
+    for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
+      const double w = Wn[k * C.ntrig + t];
+#pragma unroll
+      for (int j = 0; j < CYL_CNB; j++)
+        if (nb + j < C.nmax) s[j] = fma(T0[(size_t)(nb + j) * nnode + k], w, s[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CYL_CNB; j++) {
+      for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_xor(s[j], off);
+      if (lane == 0) red[wave][j] = s[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < CYL_CNB && nb + (int)threadIdx.x < C.nmax)
+      out[nb + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const size_t o = ((size_t)cs * (C.mmax + 1) + m) * C.nmax + n;
-    if (last) last[o] = out[o];
-    out[o] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict__ out, size_t ostride,
+                   double *__restrict__ last)
+{
+  const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int L = blockIdx.y;                   // level of a multi-level launch
+  if (o >= ncoef) return;
+  const bool none = o >= ncoef / 2 && o < ncoef / 2 + (size_t)C.nmax;      // (sin, m = 0): no such row
+  double s = 0.0;
+  if (!none)
+    for (int seg = 0; seg < CYL_CSEG; seg++) s += part[((size_t)L * CYL_CSEG + seg) * ncoef + o];
+  out += (size_t)L * ostride;
+  if (last) {                                 // setup_accumulation's swap on the way: last <- out, out <- new
+    last += (size_t)L * ostride;
+    last[o] = out[o];
   }
+  out[o] = s;
+}
+
+// both stages; nl levels starting at Wn / out / last
+static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, const double *Wn, double *part,
+                         double *out, int nl = 1, size_t ostride = 0, double *last = nullptr)
+{
+  const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
+  k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part);
+  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last);
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
@@ -505,9 +548,17 @@ k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict
   for (int kind = 0; kind < (m == 0 ? 3 : 6); kind++) {
     const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
     const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
-    double s = 0.0;
-    for (int n = 0; n < C.nmax; n++) s = fma(T[(size_t)n * nnode], c[n], s);
-    TF[node * NF + q0 + kind] = s;
+    // four independent chains: the nmax table loads of a row are all in flight together
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int n = 0;
+    for (; n + 3 < C.nmax; n += 4) {
+      const double t0 = T[(size_t)n * nnode], t1 = T[(size_t)(n + 1) * nnode];
+      const double t2 = T[(size_t)(n + 2) * nnode], t3 = T[(size_t)(n + 3) * nnode];
+      s0 = fma(t0, c[n], s0); s1 = fma(t1, c[n + 1], s1);
+      s2 = fma(t2, c[n + 2], s2); s3 = fma(t3, c[n + 3], s3);
+    }
+    for (; n < C.nmax; n++) s0 = fma(T[(size_t)n * nnode], c[n], s0);
+    TF[node * NF + q0 + kind] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -681,6 +732,7 @@ struct CylForce : exp_amd_force {
   exp_amd_cyl_config cfg{};
   CylDev dev{};
   DevBuf<double> d_tab, d_Wn, d_TF;
+  DevBuf<double> d_cpart;           // stage-1 sums of the contraction: [level][CYL_CSEG][ncoef]
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
   DevBuf<double> d_dens;            // densC / densS tables (field evaluation only)
   // sub-sample covariance (pyEXP pcavar, analysis only): node moments U[T][node][ntrig], cell
@@ -716,7 +768,7 @@ struct CylForce : exp_amd_force {
   {
     cov_U.release(); cov_Q.release(); cov_mass.release(); cov_vc.release(); cov_mv.release();
     cov_cnt.release(); cov_used.release(); cov_seq.release();
-    d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release();
+    d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release(); d_cpart.release();
     d_mass.release();
     d_dens.release();
   }
@@ -776,6 +828,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   A(f->d_tab.alloc(ntab));
   A(f->d_Wn.alloc((size_t)(cfg->multistep + 1) * f->nnode * ntrig));   // one moment buffer per level
   A(f->d_TF.alloc(f->nnode * 3 * ntrig));
+  A(f->d_cpart.alloc((size_t)(cfg->multistep + 1) * CYL_CSEG * 2 * (M + 1) * N));
   A(f->d_mass.alloc(2));
   // coefficient buffer: cos block, sin block, then {cylmass, used} riding through the all-reduce
   if (e == hipSuccess && f->alloc_common((size_t)2 * (M + 1) * N, cfg->multistep, 2) != EXP_AMD_OK)
@@ -899,9 +952,8 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
-  k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2 * nl), 256, 0, ctx->stream>>>(
-      C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl,
-      f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, f->ncoef_dev);
+  cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl, f->d_cpart.p,
+               f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev);
   HIP_TRY(ctx, hipGetLastError());
   const size_t cnt = (size_t)nl * f->ncoef_dev;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
@@ -963,8 +1015,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
-    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2), 256, 0, ctx->stream>>>(C, f->d_tab.p,
-                                                                               f->d_Wn.p, dst);
+    cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p, f->d_cpart.p, dst);
   }
   HIP_TRY(ctx, hipGetLastError());
   int rc = expamd_allreduce(ctx, dst, f->ncoef_dev);
@@ -1070,8 +1121,8 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     ProfScope ps(ctx, "k_cyl_contract");
     // ... with setup_accumulation(M)'s swap of every active level: L <- N, N <- new
     // (exputil/EmpCylSL.cc:2010-2030)
-    k_cyl_contract<<<dim3(cfg.nmax, cfg.mmax + 1, 2 * nact), 256, 0, ctx->stream>>>(
-        C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, dst, f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev);
+    cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, f->d_cpart.p, dst, nact,
+                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
   if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;

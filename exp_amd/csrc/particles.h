@@ -84,13 +84,13 @@ struct exp_amd_comp {
 
 // exclusive scan of the key histogram (range_lo >= 0: only the bins of that level / half, starting
 // at lev_off[range_lo]; lev_off is then left alone)
-void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
-                        uint32_t ncell, int nlev, int range_lo);
+int expamd_launch_scan(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                       uint32_t ncell, int nlev, int range_lo);
 
 // ... of all nkeys bins: hist[k] <- exclusive prefix, hist[nkeys] <- total, lev_off[j] <- start of
 // level j (bins j*ncell ...), lev_off[nlev] <- total
-void expamd_launch_scan_full(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
-                             uint32_t ncell, int nlev);
+int expamd_launch_scan_full(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                            uint32_t ncell, int nlev);
 
 // a component is about to be destroyed: forces that use it as their expansion frame keep a copy
 void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);

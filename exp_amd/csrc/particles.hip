@@ -83,69 +83,111 @@ k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict_
 
 // ---- counting sort (pass kernels live in sort_kernels.h) -----------------------------------
 
-// exclusive scan of hist[0..nkeys) in place (single block, coalesced 8192-key chunks with a
-// running carry); hist[nkeys] = total; lev_off[L] = start of key L*ncell, lev_off[nlev] = total.
-// range mode (range_lo >= 0): only that level's bins [range_lo*ncell, (range_lo+1)*ncell) are
-// populated; positions start at that level's first slot and the level offsets are left alone.
+// exclusive scan of hist[0..nkeys) in place; hist[nkeys] = total; lev_off[L] = start of key L*ncell,
+// lev_off[nlev] = total.  range mode (range_lo >= 0): only the bins of the levels range_lo..range_hi
+// are populated; positions start at lev_off[range_lo] and the level offsets outside are left alone.
+// One block per chunk of 1024 x SCAN_SI bins; with several chunks k_scan_sums first leaves every
+// chunk's total in `sums` and block b starts from the sum of the totals before it (the single-block
+// loop this replaces took 18 us per chunk in sequence: 90 us for the cylinder's 5 x 32769 bins).
+#define SCAN_SI 33u     // (1024 x 33 covers the 256 x 128 + 1 bins of one cylinder level in ONE chunk)
+
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t x, uint32_t *wsum /* [16] */, uint32_t &total)
+{
+  // inclusive scan of one value per thread over a 1024-thread block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = (lane < 16) ? wsum[lane] : 0u;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t y = __shfl_up(w, off);
+      if (lane >= off) w += y;
+    }
+    if (lane < 16) wsum[lane] = w;           // inclusive prefix of the wave totals
+  }
+  __syncthreads();
+  total = wsum[15];
+  return x + (wave ? wsum[wave - 1] : 0u);
+}
+
 __global__ void __launch_bounds__(1024)
-k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
-       uint32_t ncell, int nlev, int range_lo, int range_hi)
+k_scan_sums(const uint32_t *__restrict__ hist, uint32_t k0, uint32_t k1, uint32_t *__restrict__ sums)
 {
   __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t base = k0 + blockIdx.x * 1024u * SCAN_SI, top = min(k1, base + 1024u * SCAN_SI);
+  uint32_t s = 0;
+  for (uint32_t k = base + threadIdx.x; k < top; k += 1024u) s += hist[k];
+  uint32_t total;
+  (void)block_scan_1024(s, wsum, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
+       uint32_t ncell, int nlev, int range_lo, int range_hi, const uint32_t *__restrict__ sums)
+{
+  __shared__ uint32_t wsum[16];
+  const int t = threadIdx.x;
   const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
   const uint32_t k1 = (range_lo >= 0) ? (uint32_t)(range_hi + 1) * ncell : nkeys;
-  if (t == 0) carry_s = (range_lo >= 0) ? lev_off[range_lo] : 0u;
-  __syncthreads();
-  // eight consecutive bins per thread and pass: the passes are barrier-latency bound (the cylinder's
-  // 5 x 33025 bins took 200 us at one bin per thread)
-  constexpr uint32_t SI = 33;     // (1024 x 33 covers the cylinder's 256 x 128 + 1 bins of one level in ONE pass)
-  for (uint32_t base = k0; base < k1; base += 1024u * SI) {
-    const uint32_t kb = base + (uint32_t)t * SI;
-    uint32_t v[SI], s = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < SI; j++) { v[j] = (kb + j < k1) ? hist[kb + j] : 0u; s += v[j]; }
-    uint32_t x = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t y = __shfl_up(x, off);
-      if (lane >= off) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    if (wave == 0) {
-      uint32_t w = (lane < 16) ? wsum[lane] : 0u;
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        const uint32_t y = __shfl_up(w, off);
-        if (lane >= off) w += y;
-      }
-      if (lane < 16) wsum[lane] = w;           // inclusive prefix of the wave totals
-    }
-    __syncthreads();
-    const uint32_t carry = carry_s;
-    uint32_t excl = carry + (wave ? wsum[wave - 1] : 0u) + (x - s);
-#pragma unroll
-    for (uint32_t j = 0; j < SI; j++) {
-      const uint32_t k = kb + j;
-      if (k < k1) {
-        hist[k] = excl;
-        // (a range of several levels re-partitions its slots: the inner level starts move)
-        if ((range_lo < 0 || range_hi > range_lo) && k % ncell == 0) lev_off[k / ncell] = excl;
-      }
-      excl += v[j];
-    }
-    __syncthreads();
-    if (t == 0) carry_s = carry + wsum[15];
+  uint32_t carry = (range_lo >= 0) ? lev_off[range_lo] : 0u;
+  if (blockIdx.x) {                          // the chunks before this one
+    uint32_t p = 0, tot;
+    for (uint32_t j = t; j < blockIdx.x; j += 1024u) p += sums[j];
+    (void)block_scan_1024(p, wsum, tot);
+    carry += tot;
     __syncthreads();
   }
-  if (t == 0) {
-    if (range_lo < 0) {
-      hist[nkeys] = carry_s;
-      lev_off[nlev] = carry_s;
+  // SCAN_SI consecutive bins per thread: the pass is barrier-latency bound (the cylinder's bins took
+  // 200 us at one bin per thread)
+  const uint32_t kb = k0 + blockIdx.x * 1024u * SCAN_SI + (uint32_t)t * SCAN_SI;
+  uint32_t v[SCAN_SI], s = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_SI; j++) { v[j] = (kb + j < k1) ? hist[kb + j] : 0u; s += v[j]; }
+  uint32_t total;
+  const uint32_t incl = block_scan_1024(s, wsum, total);
+  uint32_t excl = carry + (incl - s);
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_SI; j++) {
+    const uint32_t k = kb + j;
+    if (k < k1) {
+      hist[k] = excl;
+      // (a range of several levels re-partitions its slots: the inner level starts move)
+      if ((range_lo < 0 || range_hi > range_lo) && k % ncell == 0) lev_off[k / ncell] = excl;
     }
+    excl += v[j];
   }
+  if (t == 0 && range_lo < 0 && blockIdx.x + 1 == gridDim.x) {
+    hist[nkeys] = carry + total;
+    lev_off[nlev] = carry + total;
+  }
+}
+
+// chunk totals of multi-chunk scans: one small buffer per context (grown on demand)
+static int scan_launch(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                       uint32_t ncell, int nlev, int range_lo, int range_hi)
+{
+  const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
+  const uint32_t k1 = (range_lo >= 0) ? (uint32_t)(range_hi + 1) * ncell : nkeys;
+  const uint32_t P = k1 > k0 ? (k1 - k0 + 1024u * SCAN_SI - 1u) / (1024u * SCAN_SI) : 1u;
+  auto &SS = ctx->scan_sums[(ctx->aux && st == ctx->aux) ? 1 : 0];
+  if (P > 1u) {
+    if (SS.n < P) {
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      if (SS.alloc((size_t)P + 64) != hipSuccess)
+        return expamd_fail(ctx, EXP_AMD_ERR_HIP, "scan: hipMalloc failed");
+    }
+    k_scan_sums<<<P, 1024, 0, st>>>(hist, k0, k1, SS.p);
+  }
+  k_scan<<<P, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_hi, P > 1u ? SS.p : nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -196,16 +238,16 @@ static unsigned stream_grid(exp_amd_ctx *ctx, size_t n)
   return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
-void expamd_launch_scan(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
-                        uint32_t ncell, int nlev, int range_lo)
+int expamd_launch_scan(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                       uint32_t ncell, int nlev, int range_lo)
 {
-  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_lo);
+  return scan_launch(ctx, st, hist, nkeys, lev_off, ncell, nlev, range_lo, range_lo);
 }
 
-void expamd_launch_scan_full(hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
-                             uint32_t ncell, int nlev)
+int expamd_launch_scan_full(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_t nkeys, uint32_t *lev_off,
+                            uint32_t ncell, int nlev)
 {
-  k_scan<<<1, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, -1, -1);
+  return scan_launch(ctx, st, hist, nkeys, lev_off, ncell, nlev, -1, -1);
 }
 
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
@@ -377,7 +419,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
   if (nr == 0) return EXP_AMD_OK;
   {
     ProfScope ps(ctx, "k_scan");
-    k_scan<<<1, 1024, 0, ctx->stream>>>(c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level, level_hi);
+    { int rc_ = scan_launch(ctx, ctx->stream, c->hist.p, nkeys, c->lev_off.p, ncell, c->nlevels, level, level_hi); if (rc_) return rc_; }
     if (level < 0 || level_hi > level) c->lev_host_valid = false;
   }
   {

@@ -650,7 +650,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     }
     {
       ProfScope ps(ctx, "k_scan", H);
-      expamd_launch_scan(H, c->hist.p, nkeys, c->half_off.p, ncell, 2, h);
+      { int rc_ = expamd_launch_scan(ctx, H, c->hist.p, nkeys, c->half_off.p, ncell, 2, h); if (rc_) return rc_; }
     }
     {
       ProfScope ps(ctx, "k_scatter_adv", H);

@@ -225,7 +225,7 @@ extern "C" int exp_amd_sph_cov_accumulate(exp_amd_force *fb, exp_amd_comp *comp,
   k_cov_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(S, comp->a(A_X), comp->a(A_Y), comp->a(A_Z), id, n,
                                                     c->flags.p);
   // exclusive scan in place; one "level" of n+1 bins so that only tot[0] / tot[1] are written
-  expamd_launch_scan_full(ctx->stream, c->flags.p, (uint32_t)n, c->tot.p, (uint32_t)n + 1u, 1);
+  { int rc_ = expamd_launch_scan_full(ctx, ctx->stream, c->flags.p, (uint32_t)n, c->tot.p, (uint32_t)n + 1u, 1); if (rc_) return rc_; }
   k_cov_accumulate<<<cdiv(n, 256), 256, 0, ctx->stream>>>(
       S, comp->a(A_X), comp->a(A_Y), comp->a(A_Z), comp->a(A_M), id, n, c->flags.p, c->fac.p, c->sampT,
       (unsigned long long)used_before, c->mom.p, c->counts.p, c->masses.p);
