@@ -54,7 +54,9 @@ ALGO_BYTES = {
 OWN_BYTES = {"k_sph_force": 84.0, "k_cyl_force": 84.0}
 # fp64 operations executed per particle (FMA = 2), static count of the unrolled fast paths
 # (tools/isa_count.py on the gfx950 assembly)
-EXEC_FLOPS = {("k_sph_force", 10): 2585.0, ("k_sph_force", 6): 1374.0, ("k_cyl_force", 6): 950.0,
+# (k_cyl_force: its static count of 1427 holds both table paths -- scalar rows for a cell-uniform wave,
+# per-lane gathers otherwise, ~400 flops each -- and the erf taper; a wave executes one of them: ~820)
+EXEC_FLOPS = {("k_sph_force", 10): 2579.0, ("k_sph_force", 6): 1368.0, ("k_cyl_force", 6): 820.0,
               ("k_sph_accumulate", 10): 1100.0, ("k_sph_accumulate", 6): 640.0, ("k_cyl_accumulate", 6): 350.0}
 # reference formulation, SURVEY.md section 8d: flops per particle-step
 REF_FLOPS = {"S6": 7800.0, "S10": 22600.0, "C6": 6200.0}

@@ -40,6 +40,7 @@ struct CylDev {
   PseudoDev ps;     // frame acceleration of the TARGET component (force pass only)
   // deterministic mode: rounding-grid constants of the moment terms / of the in-cut mass (0: off)
   double detC, detCm;
+  double umass;     // != 0: every particle of the component has this mass (accumulate does not read the stream)
 };
 
 // centred, then rotated into the body frame
@@ -142,6 +143,9 @@ struct LevChunks {
 
 #define CFLUSH_STRIDE 68
 #define CACC_WAVES 4
+#ifndef CACC_OCC
+#define CACC_OCC 2          // waves per SIMD asked of the compiler
+#endif
 #define CACC_CHUNK_MAX 1024   // particles per wave chunk; sparse multistep levels get shorter ones
 
 // Deterministic (order-independent) accumulation, as in sph_kernels.h: every term is rounded to a fixed
@@ -191,7 +195,7 @@ __device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch,
 
 // Wn[node][ntrig]: trig slot 0 = m0, 2m-1 = cos m, 2m = sin m
 template <int MMAX, bool DET>
-__global__ void __launch_bounds__(CACC_WAVES * 64)
+__global__ void __launch_bounds__(CACC_WAVES * 64, CACC_OCC)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, LevChunks LC,
@@ -235,10 +239,11 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     });
   };
 
-  // software prefetch: the loads of group k+1 are in flight while group k is reduced (at two waves
-  // per SIMD nothing else hides an HBM round trip)
+  // software prefetch: the loads of group k+1 are in flight while group k is reduced (two groups ahead
+  // measured the same: the waves wait on their own dependent fp64 chains, not on these loads)
   double nx = 0, ny = 0, nz = 0, nm = 0;
-  if (cbeg + lane < cend) { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane]; }
+  const bool um = C.umass != 0.0;
+  if (cbeg + lane < cend) { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? C.umass : M[cbeg + lane]; }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
     const bool valid = i < cend;
@@ -247,7 +252,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
       cyl_local(C, nx, ny, nz, xx, yy, zz);
       mass = nm;
     }
-    if (i + 64 < cend) { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64]; }
+    if (i + 64 < cend) { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? C.umass : M[i + 64]; }
     // src/Cylinder.cc:853-866
     const double r2 = xx * xx + yy * yy;
     double r, ir, rr, irr;
@@ -805,6 +810,7 @@ static CylDev cdev_acc(const CylForce *f, const exp_amd_comp *c)
   CylDev C = cdev_for(f, c);
   C.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * 4.0 * M_PI * 2.0);
   C.detCm = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum);
+  C.umass = c->uniform_mass ? c->mass_value : 0.0;
   return C;
 }
 
@@ -847,6 +853,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   C.rtab_abs = cfg->rtable * cfg->ascale; C.inv_rtab_abs = 1.0 / C.rtab_abs;
   C.xmin = cfg->xmin; C.dx = cfg->dx; C.ymin = cfg->ymin; C.dy = cfg->dy;
   C.inv_dx = 1.0 / cfg->dx; C.inv_dy = 1.0 / cfg->dy;
+  C.umass = 0.0;
   C.rmax2 = cfg->rcylmax * cfg->rcylmax * cfg->ascale * cfg->ascale;   // src/Cylinder.cc:752
   C.cx = C.cy = C.cz = 0.0;
   *out = f;

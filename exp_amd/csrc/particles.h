@@ -52,6 +52,7 @@ struct exp_amd_comp {
   // Every particle has the same mass (found at upload): BOTH buffer sets then hold the constant in their
   // mass arrays and the scatter passes leave the mass stream alone (16 of their 148 B per particle).
   bool uniform_mass = false;
+  double mass_value = 0.0;           // ... that one value
   double mass_abs_sum = 0.0;          // sum |m| over this rank's particles (found at upload): bound of the
                                       // coefficient sums for the deterministic mode's rounding grid
   uint32_t sparse_mask = 0;

@@ -786,7 +786,8 @@ static int detect_uniform_mass(exp_amd_comp *c)
   if (got[0] == got[1] && got[0] >= 0.0) {
     k_fill_f64<<<stream_grid(ctx, c->n), TPB, 0, ctx->stream>>>(c->b(A_M), c->n, got[0]);
     HIP_TRY(ctx, hipGetLastError());
-    c->uniform_mass = true;
+    c->uniform_mass = got[0] > 0.0;      // (a component of massless tracers keeps its stream)
+    c->mass_value = got[0];
   }
   return EXP_AMD_OK;
 }

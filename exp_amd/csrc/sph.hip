@@ -256,6 +256,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
   S.detC = 0.0;
+  S.umass = 0.0;
   {
     // bound of a unit-mass particle's moment contribution |4 pi P0 x_k Ph(l,m)(cos theta) trig|, for the
     // rounding grid of the deterministic mode: max |p0| on the grid x max |Ph| on a fine cos(theta) grid
@@ -307,6 +308,7 @@ static SphDev dev_acc(const SphForce *f, const exp_amd_comp *c)
 {
   SphDev S = dev_for(f, c->center);
   S.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * f->term_max);
+  S.umass = c->uniform_mass ? c->mass_value : 0.0;
   return S;
 }
 

@@ -46,6 +46,7 @@ struct SphDev {
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
   double detC;           // deterministic mode: 1.5 * 2^(52+e), every contribution is rounded to the grid 2^e
                          // before it is added (acc_add below); 0: off
+  double umass;          // != 0: every particle of the component has this mass (the mass stream is not read)
   double dsmall;         // added to r (src/expand.H:130: 1e-16; pyEXP: 1e-20 accumulating, 1e-18 evaluating)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
@@ -491,14 +492,15 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 
   // software prefetch: the loads of group k+1 are in flight while group k is reduced
   double nx = 0, ny = 0, nz = 0, nm = 0;
+  const bool um = S.umass != 0.0;
   if (cbeg + lane < cend) {
-    nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = M[cbeg + lane];
+    nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? S.umass : M[cbeg + lane];
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
     const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend, cell_add);
     if (i + 64 < cend) {
-      nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = M[i + 64];
+      nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? S.umass : M[i + 64];
     }
     if (MLO == 0 && in.idx >= 0) used++;
     sph_acc_group<LMAX, MLO, MHI, NV, DET>(S, lc, in, acc, cur, scratch, W);
@@ -541,7 +543,8 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 
   size_t ip = cbeg + (size_t)wave * 64 + lane;
   double nx = 0, ny = 0, nz = 0, nm = 0;
-  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+  const bool um = S.umass != 0.0;
+  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
   int par = 0;
   for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
     {
@@ -556,7 +559,7 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced
     ip += TILE;
-    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = M[ip]; }
+    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
 #pragma unroll 1
     for (int sub = 0; sub < ACC_WAVES; sub++) {
       if (tbase + (size_t)sub * 64 >= cend) break;

@@ -257,6 +257,44 @@ def test_cyl_fields_match_oracle(ctx, oracle):
     f.close()
 
 
+def test_cyl_mapping_at_extreme_heights_and_radii(ctx, oracle):
+    """The device evaluates EmpCylSL's coordinate maps with its own short sequences (asinh for cmapz = 1,
+    sqrt / reciprocal square root, divisions; exp_amd/csrc/common.h) where the reference calls libm and
+    divides (exputil/EmpCylSL.cc:6446-6463, :7109-7117).  Fields at heights from 1e-12 to the table edge
+    and radii from 1e-9 to the table edge pin them against the oracle's libm: 1e-10 of the field scale."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(20000, 43, g)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    Rt = g.rtable * g.ascale
+    zs = np.concatenate([[0.0], g.hscale * 10.0 ** np.arange(-12.0, 2.01, 0.5), [0.3 * Rt, 0.69 * Rt]])
+    zs = np.concatenate([zs, -zs[1:]])
+    Rs = np.concatenate([g.ascale * 10.0 ** np.arange(-9.0, 0.01, 0.75), [0.2 * Rt, 0.7 * Rt]])
+    R, z = [a.ravel() for a in np.meshgrid(Rs, zs)]
+    keep = np.hypot(R, z) < 0.99 * Rt
+    R, z = R[keep], z[keep]
+    ph = np.linspace(0.1, 6.0, R.size)
+    got = f.fields(R, z, ph, "cylindrical")
+    ref = oracle.cyl_fields(g, cc, ss, R, z, ph, "cylindrical")
+    scale = np.abs(ref).max(axis=0)
+    assert np.all(np.abs(got - ref).max(axis=0) <= 1e-10 * scale + 1e-300)
+    # and through the n-body force pass (its own prologue / epilogue reciprocals)
+    pts = np.stack([R * np.cos(ph), R * np.sin(ph), z], axis=1)
+    c_ref, s_ref, _, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g, pts, c_ref, s_ref, mass_ref)
+    t = Component.from_arrays(ctx, np.full(len(pts), 1e-9), pts)
+    t.zero_acceleration(0)
+    f.get_acceleration_and_potential(t, external=True)
+    out = t.download(("acc", "pot"))
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    for o in (t, c, f):
+        o.close()
+
+
 def test_cyl_body_rotation_and_centre(ctx, oracle):
     """Orient::transformBody on the cylinder path (src/Cylinder.cc:799-800, :1352-1353, :1417-1418):
     with a body rotation B and centre c on the component, a tilted, shifted disc x = B^T y + c gives

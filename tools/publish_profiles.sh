@@ -1,0 +1,14 @@
+#!/bin/bash
+# ON THE DEV BOX, after `gpurun -- bash tools/dbg/prof_r02.sh <tag>`: condense gpurun_out/ into the
+# committed summaries profiles/<round>_*  (round = tag without its trailing letter, e.g. r02c -> r02).
+#   tools/publish_profiles.sh r02c
+set -e
+cd "$(dirname "$0")/.."
+TAG=$1; RND=${TAG%[a-z]}
+python3 tools/summarize_profile.py gpurun_out/prof_$TAG profiles/$RND > /dev/null
+cp gpurun_out/pmc_${TAG}_all.txt profiles/${RND}_pmc.txt
+sed -i "1i # rocprofv3 --pmc passes over 'python bench.py --steps 3 --warmup 1' (1e8 NFW, S10), one counter set per pass (tools/pmc_multi.sh); per-launch means, first launch dropped" profiles/${RND}_pmc.txt
+python3 tools/summarize_cfg.py gpurun_out/prof_${TAG}_cfg3 profiles/${RND}_cfg3 > /dev/null
+python3 tools/summarize_cfg.py --cfg4 gpurun_out/prof_cfg4 profiles/${RND}_cfg4 > /dev/null
+grep "^{" gpurun_out/prof_$TAG/stats.log | tail -1 > profiles/${RND}_bench_under_rocprof.json
+ls -la profiles/${RND}_*
