@@ -5,7 +5,7 @@ cd "$REPO"
 for v in "$@"; do
   if [ "$v" = base ]; then unset EXP_AMD_LIB; else export EXP_AMD_LIB=$REPO/exp_amd/libexp_amd_$v.so; fi
   echo "== $v"
-  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-sustained 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs "$@" > "$OUT/log.txt" 2>&1
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-sustained "$@" > "$OUT/log.txt" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
