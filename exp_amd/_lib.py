@@ -76,6 +76,7 @@ SIGNATURES = {
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_dense_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_deterministic": (c_int, [c_void_p, c_int]),
+    "exp_amd_ctx_set_prekick": (c_int, [c_void_p, c_int]),
     "exp_amd_comp_set_orientation": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_flags": (c_uint, [c_void_p]),
     "exp_amd_orient_set_naccel": (c_int, [c_void_p, c_int]),

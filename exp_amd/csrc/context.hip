@@ -44,6 +44,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   if (const char *e = getenv("EXP_AMD_SPLIT_MIN")) ctx->split_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_DETERMINISTIC")) ctx->deterministic = atoi(e) != 0;
+  if (const char *e = getenv("EXP_AMD_PREKICK")) ctx->prekick = atoi(e) != 0;
   HIP_TRY(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -84,6 +85,13 @@ extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
   for (auto &ss : ctx->scan_sums) if (ss.p) (void)hipFree(ss.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C" int exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->prekick = on != 0;
+  return EXP_AMD_OK;
 }
 
 extern "C" int exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on)

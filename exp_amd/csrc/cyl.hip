@@ -716,7 +716,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     const double vx = mul_then_add(VX[i], fx, dt_kick);
     const double vy = mul_then_add(VY[i], fy, dt_kick);
     const double vz = mul_then_add(VZ[i], fz, dt_kick);
-    if (store_v) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // else: deferred (exp_amd_comp::pending_kick)
+    if (store_v == 1) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // 0: deferred (exp_amd_comp::pending_kick)
     if (key_out) {
       // the sort key this particle will have after the NEXT fused step's kick + drift (the
       // arithmetic of advance_one on the values just stored): that step then only histograms
@@ -724,6 +724,8 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
       const double wx = mul_then_add(vx, fx, nk_dtk);
       const double wy = mul_then_add(vy, fy, nk_dtk);
       const double wz = mul_then_add(vz, fz, nk_dtk);
+      // store_v == 2: velocities stored with the next step's opening half-kick applied (sph_kernels.h)
+      if (store_v == 2) { VX[i] = wx; VY[i] = wy; VZ[i] = wz; }
       CylKeyFn kf{C, 0u};
       key_out[i] = kf(mul_then_add(X[i], wx, nk_dtd), mul_then_add(Y[i], wy, nk_dtd),
                       mul_then_add(Z[i], wz, nk_dtd), 0);
@@ -1147,6 +1149,9 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   // next step's keys: single level, own (sorted) particles, fused half-kick only
   const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&
                       t->nlevels == 1 && f->multistep == 0 && t->sorted_for == f;
+  // closing half-kick: stored (1), deferred (0), or stored with the next opening half-kick (2); see sph.hip
+  const bool deferred = defer_kick && dt_kick != 0.0;
+  const int sv = !deferred ? 1 : (prekey && nk_dtk != 0.0 && ctx->prekick) ? 2 : 0;
   if (f->proj_dirty) {
     ProfScope ps(ctx, "k_cyl_project");
     k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(
@@ -1173,14 +1178,14 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
       t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
       dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd,                        \
-      (defer_kick && dt_kick != 0.0) ? 0 : 1)
+      sv)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
   if (prekey) *prekey_done = true;
-  if (defer_kick && dt_kick != 0.0) t->pending_kick = dt_kick;
+  if (deferred) t->pending_kick = sv == 2 ? -nk_dtk : dt_kick;
   return EXP_AMD_OK;
 }
 

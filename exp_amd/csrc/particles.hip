@@ -214,6 +214,15 @@ k_unpermute_lev(const uint8_t *__restrict__ in, const uint32_t *__restrict__ id,
   if (i < n) out[id[i]] = (int32_t)in[i];
 }
 
+// out[id[i]] = v[i] + a[i] * dt (two roundings, as k_kick)
+__global__ void __launch_bounds__(TPB)
+k_unpermute_kicked(const double *__restrict__ v, const double *__restrict__ a, double dt,
+                   const uint32_t *__restrict__ id, size_t n, double *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[id[i]] = mul_then_add(v[i], a[i], dt);
+}
+
 // in[j] is in caller order; slot i holds caller index id[i]
 __global__ void __launch_bounds__(TPB)
 k_permute_lev(const int32_t *__restrict__ in, const uint32_t *__restrict__ id, size_t n,
@@ -367,6 +376,10 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv)
   A.lev = c->level[c->cur].p;
   A.dt_kick = adv.dt_kick; A.dt_drift = adv.dt_drift;
   A.dt_kick0 = adv.mode ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
+  // ... or the opposite: that force pass stored the velocities with THIS opening half-kick applied already
+  // (pending_kick == -dt_kick, set together with the step's sort keys): nothing left to kick
+  A.nokick = (adv.mode == 1 && c->pending_kick != 0.0 && c->pending_kick == -adv.dt_kick) ? 1 : 0;
+  if (A.nokick) A.dt_kick0 = 0.0;
   A.advance = adv.mode;
   A.multistep = adv.multistep;
   A.dt_min = adv.dt_min;
@@ -883,12 +896,22 @@ extern "C" int exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, d
                                      double *ay, double *az, double *pot)
 {
   if (!c) return EXP_AMD_ERR_ARG;
-  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  // A fused step leaves the velocities either short of their closing half-kick (pending_kick > 0: applied
+  // now, exactly the operation the next step would have done first) or AHEAD by the next step's opening
+  // half-kick (pending_kick < 0).  The second state is left as it is -- undoing and redoing a rounded
+  // operation would move the trajectory by an ulp just because someone looked -- and the velocities go
+  // out through v + a * pending_kick.
+  const double back = c->pending_kick < 0.0 ? c->pending_kick : 0.0;
+  if (back == 0.0) { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   double *h[A_NARR] = {x, y, z, vx, vy, vz, mass, ax, ay, az, pot};
   for (int a = 0; a < A_NARR; a++) {
     if (!h[a]) continue;
+    if (back != 0.0 && a >= A_VX && a <= A_VZ)
+      k_unpermute_kicked<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->a(a), c->a(A_AX + (a - A_VX)), back,
+                                                                   c->id[c->cur].p, c->n, c->b(a));
+    else
     k_unpermute_f64<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->a(a), c->id[c->cur].p, c->n,
                                                               c->b(a));
     HIP_TRY(ctx, hipMemcpyAsync(h[a], c->b(a), c->n * sizeof(double), hipMemcpyDeviceToHost,

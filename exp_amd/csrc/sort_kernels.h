@@ -36,6 +36,9 @@ struct AdvanceArgs {
                                // (src/step.cc:115-160: dt*mintvl[M]; exact power-of-two scalings)
   int multistep;
   double dt_min;
+  int nokick;                  // 1: the stored velocities already hold this step's opening half-kick (the last
+                               // fused force pass stored v + a dt_close + a dt_open, exp_amd_comp::pending_kick
+                               // == -dt_kick): drift only, the acceleration stream is not read
 };
 
 // the block-multistep time step of level `lev` (src/multistep.cc:640-646: mintvl[M] = Mstep >> M)
@@ -50,21 +53,23 @@ __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, doub
   x = A.x[i]; y = A.y[i]; z = A.z[i];
   if (A.advance) {
     // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
-    const double ax = A.ax[i], ay = A.ay[i], az = A.az[i];
     vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
     double dtk = A.dt_kick, dtd = A.dt_drift;
     if (A.advance == 2) {
       dtd = level_dt(A.dt_min, A.multistep, A.lev[i]);
       dtk = 0.5 * dtd;
     }
-    if (A.dt_kick0 != 0.0) {       // its own rounding step, exactly as the separate kick would be
-      vx = mul_then_add(vx, ax, A.dt_kick0);
-      vy = mul_then_add(vy, ay, A.dt_kick0);
-      vz = mul_then_add(vz, az, A.dt_kick0);
+    if (!A.nokick) {
+      const double ax = A.ax[i], ay = A.ay[i], az = A.az[i];
+      if (A.dt_kick0 != 0.0) {       // its own rounding step, exactly as the separate kick would be
+        vx = mul_then_add(vx, ax, A.dt_kick0);
+        vy = mul_then_add(vy, ay, A.dt_kick0);
+        vz = mul_then_add(vz, az, A.dt_kick0);
+      }
+      vx = mul_then_add(vx, ax, dtk);
+      vy = mul_then_add(vy, ay, dtk);
+      vz = mul_then_add(vz, az, dtk);
     }
-    vx = mul_then_add(vx, ax, dtk);
-    vy = mul_then_add(vy, ay, dtk);
-    vz = mul_then_add(vz, az, dtk);
     x = mul_then_add(x, vx, dtd);
     y = mul_then_add(y, vy, dtd);
     z = mul_then_add(z, vz, dtd);

@@ -540,6 +540,10 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   const double *ctr = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
   SphDev S = dev_for(f, ctr);
   S.ps = t->pseudo;                    // Component::AddAcc of the TARGET (src/Component.H:914-921)
+  // closing half-kick: stored (1), left to the next scatter pass (0), or -- when that pass is known,
+  // i.e. its keys are produced here -- stored together with its opening half-kick (2)
+  const bool deferred = defer_kick && dt_kick != 0.0;
+  const int sv = !deferred ? 1 : (prekey && nk_dtk != 0.0 && ctx->prekick) ? 2 : 0;
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   size_t nr = t->n;                    // population of the level range: sizes the launch
@@ -570,7 +574,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
                    f->d_work.p, cnt + f->work_flip, slow ? 1 : 0, ctx,
-                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, (defer_kick && dt_kick != 0.0) ? 0 : 1,
+                   prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, sv,
                    cnt + (1 - f->work_flip), wfall ? 1 : 0};
     k_force_launch[f->cfg.lmax](a);
     if (!slow) f->work_flip ^= 1;
@@ -578,7 +582,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
   if (prekey) *prekey_done = true;
-  if (defer_kick && dt_kick != 0.0) t->pending_kick = dt_kick;
+  if (deferred) t->pending_kick = sv == 2 ? -nk_dtk : dt_kick;
   return EXP_AMD_OK;
 }
 

@@ -1186,7 +1186,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double vx = mul_then_add(VX[i], ax, dt_kick);
     const double vy = mul_then_add(VY[i], ay, dt_kick);
     const double vz = mul_then_add(VZ[i], az, dt_kick);
-    if (store_v) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // else: deferred (exp_amd_comp::pending_kick)
+    if (store_v == 1) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // 0: deferred (exp_amd_comp::pending_kick)
     if (key_out) {
       // Where this particle will be after the NEXT step's kick + drift (the arithmetic of
       // advance_one, sort_kernels.h, on the values just stored): its sort key.  The next step
@@ -1196,6 +1196,10 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
       const double wx = mul_then_add(vx, ax, nk_dtk);
       const double wy = mul_then_add(vy, ay, nk_dtk);
       const double wz = mul_then_add(vz, az, nk_dtk);
+      // store_v == 2: the velocities go out WITH the next step's opening half-kick (the same two
+      // rounding steps that step's scatter pass would take), so that pass only drifts and never
+      // reads the accelerations (24 B/particle); pending_kick = -nk_dtk tells everyone else
+      if (store_v == 2) { VX[i] = wx; VY[i] = wy; VZ[i] = wz; }
       const uint32_t key = sph_key_cell_rcp(S, mul_then_add(px, wx, nk_dtd),
                                             mul_then_add(py, wy, nk_dtd), mul_then_add(pz, wz, nk_dtd));
       key_out[i] = key + S.key_add;
@@ -1277,7 +1281,8 @@ struct SphForceArgs {
   exp_amd_ctx *ctx;         // for the per-launch profiling scopes
   uint32_t *key_out;        // next step's sort keys (nullptr: not wanted)
   double nk_dtk, nk_dtd;    // ... for that step's kick and drift
-  int store_v;              // 0: the half-kick is deferred, v is left as it is
+  int store_v;              // 0: the half-kick is deferred, v is left as it is; 1: v + a dt_kick; 2: that plus the
+                            // next step's opening half-kick (needs key_out)
   uint32_t *nwork_next = nullptr;   // the counter the next launch will use (cleared by this one's general pass)
   int waterfall = 0;        // fast pass as a waterfall over each wave's radial cells (MODE 2)
 };

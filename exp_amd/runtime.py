@@ -85,6 +85,10 @@ class Context:
         """Order-independent coefficient sums: runs become bit-reproducible (include/exp_amd.h)."""
         check(self.lib.exp_amd_ctx_set_deterministic(self.h, int(bool(on))), self.h)
 
+    def set_prekick(self, on: bool = True) -> None:
+        """Fused steps store velocities with the next opening half-kick applied (include/exp_amd.h)."""
+        check(self.lib.exp_amd_ctx_set_prekick(self.h, int(bool(on))), self.h)
+
     def set_dense_min(self, nmin: int) -> None:
         """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
         check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)

@@ -177,8 +177,12 @@ def test_cyl_fused_steps_reuse_keys(ctx):
         return out, cs
 
     ref, cref = run("unfused")
-    for kind in ("fused", "touched"):
-        out, cs = run(kind)
+    for kind in ("fused", "touched", "prekick", "prekick-touched"):
+        # (prekick: velocities stored with the next opening half-kick applied, exp_amd_ctx_set_prekick;
+        # the dt changes and the interleaved calls make it take that half-kick back)
+        ctx.set_prekick(kind.startswith("prekick"))
+        out, cs = run("touched" if kind.endswith("touched") else "fused")
+        ctx.set_prekick(False)
         assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-14
         assert np.abs(out["vel"] - ref["vel"]).max() <= 1e-9 * np.abs(ref["vel"]).max()
         ascale = np.linalg.norm(ref["acc"], axis=1).max()

@@ -433,3 +433,55 @@ def test_full_size_properties(ctx):
     assert abs(np.median(ratio) - 1.0) < 2e-3
     c.close()
     f.close()
+
+
+def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6):
+    """The fused step stores velocities with the next step's opening half-kick already applied
+    (exp_amd_ctx_set_prekick, include/exp_amd.h) so that the reordering pass does not read the accelerations.
+    (a) positions are bit-identical to the run that leaves the closing half-kick to the next pass, velocities
+    on the way out agree to an ulp; (b) a download in the middle of a run does not move the trajectory by a
+    single bit; (c) a step with another dt, or any other consumer of the velocities, takes the half-kick back
+    first: the oracle's KDK sequence to the usual tolerance."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_s6
+    from exp_amd.models import sample_sphere
+    m, pos, vel = sample_sphere(model, 20011, seed=91)
+    # (bit-for-bit statements need the order-independent coefficient sums: atomics alone reorder)
+    ctx.set_deterministic(True)
+    f = SphereSL(ctx, g)
+    dt = 0.01
+
+    def run(prekick, look_at=(), steps=6, dts=None):
+        ctx.set_prekick(prekick)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        seen = []
+        for k in range(steps):
+            f.step_kdk(c, dts[k] if dts else dt)
+            if k in look_at:
+                seen.append(c.download(("pos", "vel")))
+        out = c.download(("pos", "vel", "acc"))
+        c.close()
+        ctx.set_prekick(False)
+        return out, seen
+
+    on, _ = run(True)
+    off, _ = run(False)
+    assert np.array_equal(on["pos"], off["pos"]) and np.array_equal(on["acc"], off["acc"])      # (a)
+    ulp = np.spacing(np.abs(off["vel"]) + np.abs(off["acc"]) * dt)
+    assert np.all(np.abs(on["vel"] - off["vel"]) <= ulp)
+    looked, seen = run(True, look_at=(2, 3))                                                      # (b)
+    assert np.array_equal(looked["pos"], on["pos"]) and np.array_equal(looked["vel"], on["vel"])
+    assert len(seen) == 2 and np.isfinite(seen[0]["vel"]).all()
+    # (c) changing dt from step to step: every change takes the half-kick back and redoes it
+    dts = [0.01, 0.01, 0.004, 0.004, 0.02, 0.01]
+    var, _ = run(True, dts=dts)
+    orc_prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    p, v, a = pos.copy(), vel.copy(), None
+    _, _, a, _, _ = oracle.sph_step(g, orc_prm, 0.0, p, v, np.zeros_like(p), m)
+    for d in dts:
+        p, v, a, _, _ = oracle.sph_step(g, orc_prm, d, p, v, a, m)
+    assert np.abs(var["pos"] - p).max() <= 1e-12
+    assert np.abs(var["vel"] - v).max() <= 1e-10
+    f.close()
+    ctx.set_deterministic(False)
