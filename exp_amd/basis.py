@@ -21,6 +21,7 @@ All particle work runs on the GPU through libexp_amd.so; this file only parses t
 from __future__ import annotations
 
 import dataclasses
+import math
 import os
 from typing import Optional
 
@@ -320,6 +321,33 @@ class SphericalSL(BiorthBasis):
                          rmax=self.rmax, cmap=self.cmap, rmap=self.rmap)
         g.save(path)
         return g
+
+    # -- index helpers of the pybind layer (pyEXP/BasisWrappers.cc:2065-2110) ---------------------------
+    def getLmax(self) -> int:
+        return self.lmax
+
+    def getNmax(self) -> int:
+        return self.nmax
+
+    def I(self, l: int, m: int, n: int = 0) -> int:
+        """Packing index of the coefficient (l, m, n): (lmax+1)(lmax+2)/2 * n + l(l+1)/2 + m."""
+        if l < 0:
+            raise RuntimeError("l must be greater than 0")
+        if m < 0:
+            raise RuntimeError("m must be greater than 0")
+        if n < 0:
+            raise RuntimeError("n must be greater than 0")
+        if abs(m) > l:
+            raise RuntimeError("m must be less than or equal to l")
+        return (self.lmax + 1) * (self.lmax + 2) // 2 * n + l * (l + 1) // 2 + m
+
+    def invI(self, I: int):
+        """(l, m, n) of a packing index (the inverse of ``I``)."""
+        ltot = (self.lmax + 1) * (self.lmax + 2) // 2
+        n = I // ltot
+        L = I - n * ltot
+        l = int(math.floor(0.5 * (-1.0 + math.sqrt(1.0 + 8.0 * L))))
+        return l, L - l * (l + 1) // 2, n
 
     def cacheInfo(self, cachefile: Optional[str] = None) -> dict:
         """``SLGridSph::cacheInfo`` (the header of the cache file)."""
@@ -691,3 +719,11 @@ class Basis:
             return Cylindrical(params, ctx)
         raise RuntimeError(f"Basis::factory: basis <{name}> is outside the scope of exp_amd "
                            "(sphereSL and cylinder are built)")
+
+
+def CovarianceReader(filename: str, stride: int = 1):
+    """``pyEXP.basis.CovarianceReader(filename, stride=1)`` (pyEXP/BasisWrappers.cc:3173-3215): the reader of
+    the ``coefcovar.<name>.<runtag>.h5`` files ``writeCoefCovariance`` produces; ``Times()``,
+    ``getCoefCovariance(time)`` -> (counts, masses, means, covariances)."""
+    from .h5cache import SubsampleCovariance
+    return SubsampleCovariance(filename, stride)

@@ -26,6 +26,8 @@ import numpy as np
 
 from .basis import CylStruct, SphStruct
 
+builtins_max, builtins_min = max, min      # (Power's arguments are called min / max, as in the reference)
+
 CMAGIC = 0x0C0A57A2                  # src/SphericalBasis.H:368
 _LEGACY = struct.Struct("<64sddii")  # SphCoefHeader: id[64], tnow, scale, nmax, Lmax
 
@@ -132,18 +134,232 @@ def read_native_record(inp: BinaryIO, exp_type: bool = True) -> Optional[SphStru
                      np.eye(3))
 
 
-class SphCoefs:
-    """``CoefClasses::SphCoefs``: spherical coefficient sets keyed by (rounded) time."""
+class Coefs:
+    """``CoefClasses::Coefs`` (expui/Coefficients.H:31-290): what the containers of every geometry share
+    -- the mnemonic name, the time-keyed map, ``factory`` / ``makecoefs`` / ``addcoef``, deep copies,
+    comparison, per-harmonic power, and the HDF5 write / extend pair.  ``SphCoefs`` and ``CylCoefs`` add
+    their geometry's shapes."""
 
-    geometry = "sphere"
+    geometry = ""
+    _what = "Coefs"
 
-    def __init__(self, name: str = ""):
+    def __init__(self, name="", verbose: bool = False):
+        # pyEXP constructs ``SphCoefs(verbose: bool = False)`` (pyEXP/CoefWrappers.cc:1546); the mnemonic
+        # name is set with setName.  A string here is the name, a bool the verbosity.
+        if isinstance(name, bool):
+            name, verbose = "", name
         self.name = name
-        self.coefs: Dict[float, SphStruct] = {}
+        self.verbose = bool(verbose)
+        self.coefs: Dict[float, object] = {}
         self.deltaT = 0.01                       # expui/Coefficients.H:133
 
     def setDeltaT(self, dT: float) -> None:
         self.deltaT = float(dT)
+
+    # expui/Coefficients.H:222-228
+    def getGeometry(self) -> str:
+        return self.geometry
+
+    def getName(self) -> str:
+        return self.name
+
+    def setName(self, newname: str) -> None:
+        self.name = str(newname)
+
+    def clear(self) -> None:
+        self.coefs.clear()
+
+    def zerodata(self) -> None:
+        """``Coefs::zerodata``: every stored set keeps its shape and time, its values become zero."""
+        for c in self.coefs.values():
+            c.coefs = np.zeros_like(np.asarray(c.coefs))
+
+    def deepcopy(self):
+        """``SphCoefs::deepcopy`` / ``CylCoefs::deepcopy`` (expui/Coefficients.cc:337-377): new container,
+        new structures, same fields."""
+        import copy
+        ret = type(self)(self.name)
+        ret.deltaT = self.deltaT
+        for t, c in self.coefs.items():
+            ret.coefs[t] = copy.deepcopy(c)
+        return ret
+
+    # -- values at one time (``__call__`` is the pybind operator, pyEXP/CoefWrappers.cc:1559, :1634) --
+    def getMatrix(self, time: float) -> np.ndarray:
+        """``getMatrix(time)``: the complex [rows, nmax] array, EMPTY (0 x 0) when the time is not there
+        (expui/Coefficients.cc:683-696)."""
+        c = self.coefs.get(round_time(time))
+        return np.zeros((0, 0), dtype=np.complex128) if c is None else np.asarray(c.coefs, dtype=np.complex128)
+
+    __call__ = getMatrix
+
+    def getData(self, time: float) -> np.ndarray:
+        """``getData(time)``: the same values flattened in the reference's (column-major) storage order."""
+        return self.getMatrix(time).reshape(-1, order="F")
+
+    def setMatrix(self, time: float, mat) -> None:
+        """``setMatrix(time, mat)``: replace the values of an EXISTING time (expui/Coefficients.cc:713-725)."""
+        c = self.coefs.get(round_time(time))
+        if c is None:
+            raise RuntimeError(f"{self._what}::setMatrix: requested time={time} not found")
+        mat = np.asarray(mat, dtype=np.complex128)
+        if mat.shape != np.shape(c.coefs):
+            raise RuntimeError(f"{self._what}::setMatrix: shape {mat.shape} does not match {np.shape(c.coefs)}")
+        c.coefs = mat.copy()
+
+    def setData(self, time: float, dat) -> None:
+        c = self.coefs.get(round_time(time))
+        if c is None:
+            raise RuntimeError(f"{self._what}::setData: requested time={time} not found")
+        c.coefs = np.asarray(dat, dtype=np.complex128).reshape(np.shape(c.coefs), order="F").copy()
+
+    def CompareStanzas(self, check: "Coefs") -> bool:
+        """``CompareStanzas`` (expui/Coefficients.cc:979-1031, :3056-3100): same times, same orders, same
+        values -- exact comparison, as there."""
+        if type(check) is not type(self):
+            return False
+        ret = True
+        for t in self.coefs:
+            if t not in check.coefs:
+                print(f"Can't find Time={t}")
+                ret = False
+        if not ret:
+            print("Times in other coeffcients are:", *check.Times())
+            return False
+        for t, c in self.coefs.items():
+            o = check.coefs[t]
+            if (c.nmax != o.nmax or c.time != o.time or getattr(c, "lmax", None) != getattr(o, "lmax", None)
+                    or getattr(c, "mmax", None) != getattr(o, "mmax", None)):
+                return False
+        for t, c in self.coefs.items():
+            if not np.array_equal(np.asarray(c.coefs), np.asarray(check.coefs[t].coefs)):
+                return False
+        return True
+
+    # -- construction from files and single structures ------------------------------------------------
+    @staticmethod
+    def factory(file: str, stride: int = 1, tmin: float = -math.inf, tmax: float = math.inf) -> "Coefs":
+        """``Coefs::factory`` (expui/Coefficients.cc:2911-3018): HDF5 first -- the ``geometry`` attribute
+        picks the class --, then EXP's native streams by their magic number (0xc0a57a2 sphere, 0xc0a57a3
+        cylinder; anything else is a legacy spherical stream or an ascii table, which this mirror does not
+        carry)."""
+        import os
+        from . import h5cache
+        geo = None
+        try:
+            geo = h5cache.coef_geometry(file)
+        except Exception:
+            geo = None
+        if geo is not None:
+            if geo == "sphere":
+                return SphCoefs.readH5Coefs(file, stride, tmin, tmax)
+            if geo == "cylinder":
+                return CylCoefs.readH5Coefs(file, stride, tmin, tmax)
+            raise RuntimeError("Coefs::factory: unknown H5 coefficient file geometry: " + geo)
+        if not os.path.exists(file):
+            raise RuntimeError("Coefs::factory: file <" + file + "> does not exist")
+        with open(file, "rb") as f:
+            head = f.read(4)
+        magic = struct.unpack("<I", head)[0] if len(head) == 4 else 0
+        if magic == CMAGIC_CYL:
+            return CylCoefs.readNativeCoefs(file, stride, tmin, tmax)
+        # (the reference sends every other magic to TableData; a legacy spherical stream starts with its
+        # 64-character id instead and is read by SphCoefs there only when asked for explicitly)
+        return SphCoefs.readNativeCoefs(file, stride, tmin, tmax)
+
+    @staticmethod
+    def makecoefs(coef, name: str = "") -> "Coefs":
+        """``Coefs::makecoefs`` (expui/Coefficients.cc:3020-3043): an empty container of the structure's
+        geometry."""
+        if isinstance(coef, SphStruct):
+            return SphCoefs(name)
+        if isinstance(coef, CylStruct):
+            return CylCoefs(name)
+        raise RuntimeError("Coefs::makecoefs: cannot deduce coefficient file type")
+
+    @staticmethod
+    def addcoef(coefs: Optional["Coefs"], coef) -> "Coefs":
+        """``Coefs::addcoef`` (:3046-3054)."""
+        ret = coefs if coefs is not None else Coefs.makecoefs(coef)
+        ret.add(coef)
+        return ret
+
+    # -- HDF5: extend an existing file (expui/Coefficients.cc:3165-3204) -------------------------------
+    def _h5_arrays(self):
+        times = self.Times()
+        first = self.coefs[times[0]]
+        rows = np.shape(first.coefs)[0]
+        data = np.zeros((len(times), rows, first.nmax, 2))
+        ctr = np.zeros((len(times), 3))
+        rot = np.zeros((len(times), 3, 3))
+        for k, t in enumerate(times):
+            c = self.coefs[t]
+            data[k, :, :, 0], data[k, :, :, 1] = np.real(c.coefs), np.imag(c.coefs)
+            ctr[k] = np.asarray(c.ctr, dtype=np.float64).reshape(3) if np.size(c.ctr) == 3 else 0.0
+            rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
+        tarr = np.array([self.coefs[t].time for t in times])
+        return tarr, ctr, rot, data, rows, first.nmax
+
+    def ExtendH5Coefs(self, path: str) -> None:
+        """``Coefs::ExtendH5Coefs``: the stored sets are appended to an existing file after
+        ``CheckH5Params`` (orders, scale to 1e-8, forceID: :855-905, :1334-1373); the snapshot numbering
+        continues at the file's ``count``."""
+        import ctypes
+        from . import h5cache
+        if not self.Times():
+            return
+        if not self._check_h5_params(path):
+            raise RuntimeError("Coefs::ExtendH5Coefs: H5 parameter check failed, aborting extension")
+        tarr, ctr, rot, data, rows, nmax = self._h5_arrays()
+        lib = h5cache._load()
+        lib.exp_h5_coef_extend.restype = ctypes.c_int
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if lib.exp_h5_coef_extend(path.encode(), rows, nmax, len(tarr), vp(tarr), vp(ctr), vp(rot), vp(data)):
+            raise RuntimeError(f"ExtendH5Coefs: HDF5 error extending <{path}>")
+
+
+class SphCoefs(Coefs):
+    """``CoefClasses::SphCoefs``: spherical coefficient sets keyed by (rounded) time."""
+
+    geometry = "sphere"
+    _what = "SphCoefs"
+
+    def Power(self, min: int = 0, max: int = 2 ** 31 - 1) -> np.ndarray:
+        """``SphCoefs::Power`` (expui/Coefficients.cc:1033-1060): [ntimes, lmax + 1], the sum over m and over
+        the radial orders min <= n < max of |c|^2."""
+        times = self.Times()
+        if not times:
+            return np.zeros((0, 0))
+        first = self.coefs[times[0]]
+        lo, hi = builtins_max(0, min), builtins_min(first.nmax, max)
+        out = np.zeros((len(times), first.lmax + 1))
+        for T, t in enumerate(times):
+            a2 = np.abs(np.asarray(self.coefs[t].coefs)[:, lo:hi]) ** 2
+            L = 0
+            for l in range(first.lmax + 1):
+                out[T, l] = a2[L:L + l + 1].sum()
+                L += l + 1
+        return out
+
+    def _check_h5_params(self, path: str) -> bool:
+        import ctypes
+        from . import h5cache
+        lib = h5cache._load()
+        lib.exp_h5_sphcoef_info.restype = ctypes.c_int
+        lmax, nmax, count, hasv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        scale = ctypes.c_double()
+        name, fid, geo = (ctypes.create_string_buffer(256) for _ in range(3))
+        if lib.exp_h5_sphcoef_info(path.encode(), ctypes.byref(lmax), ctypes.byref(nmax), ctypes.byref(scale),
+                                   ctypes.byref(count), name, 256, fid, 256, geo, 256, ctypes.byref(hasv)):
+            return False
+        first = self.coefs[self.Times()[0]]
+        ok = lmax.value == first.lmax and nmax.value == first.nmax
+        s0, s1 = float(first.scale), scale.value
+        if abs(s0 - s1) > 1.0e-8 * builtins_max(abs(s0), abs(s1)):
+            ok = False
+        if fid.value.decode() != getattr(self, "_force_id", "sphereSL"):
+            ok = False
+        return ok
 
     # -- container (expui/Coefficients.H) -------------------------------------------------------
     def add(self, c: SphStruct) -> None:
@@ -226,6 +442,7 @@ class SphCoefs:
             ctr[k] = np.asarray(c.ctr, dtype=np.float64).reshape(3) if np.size(c.ctr) == 3 else 0.0
             rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
         tarr = np.array([self.coefs[t].time for t in times])
+        self._force_id = force_id
         lib = h5cache._load()
         lib.exp_h5_sphcoef_write.restype = ctypes.c_int
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
@@ -262,6 +479,7 @@ class SphCoefs:
         if lib.exp_h5_sphcoef_read(path.encode(), C, L, N, vp(times), vp(ctr), vp(rot), vp(data)):
             raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
         self = cls(name.value.decode())
+        self._force_id = fid.value.decode()
         for k in range(0, C, stride):
             if times[k] < tmin or times[k] > tmax:
                 continue
@@ -323,15 +541,52 @@ def read_native_cyl_record(inp: BinaryIO) -> Optional[CylStruct]:
     return CylStruct(mmax, nmax, time, cf, np.zeros(3), np.eye(3))
 
 
-class CylCoefs:
+class CylCoefs(Coefs):
     """``CoefClasses::CylCoefs``: cylindrical coefficient sets keyed by (rounded) time."""
 
     geometry = "cylinder"
+    _what = "CylCoefs"
 
-    def __init__(self, name: str = ""):
-        self.name = name
-        self.coefs: Dict[float, CylStruct] = {}
-        self.deltaT = 0.01
+    def Power(self, min: int = 0, max: int = 2 ** 31 - 1) -> np.ndarray:
+        """``CylCoefs::Power`` (expui/Coefficients.cc:1442-1470): [ntimes, mmax + 1]."""
+        times = self.Times()
+        if not times:
+            return np.zeros((0, 0))
+        first = self.coefs[times[0]]
+        lo, hi = builtins_max(0, min), builtins_min(first.nmax, max)
+        return np.stack([(np.abs(np.asarray(self.coefs[t].coefs)[:, lo:hi]) ** 2).sum(axis=1) for t in times])
+
+    def EvenOddPower(self, nodd: int = -1, min: int = 0, max: int = 2 ** 31 - 1):
+        """``CylCoefs::EvenOddPower`` (:1472-1537): the radial orders split at nmax - nodd into the
+        vertically even and odd families; ``nodd`` must be given (this mirror keeps no YAML config to take
+        ``ncylodd`` from)."""
+        times = self.Times()
+        if not times:
+            return np.zeros((0, 0)), np.zeros((0, 0))
+        if nodd < 0:
+            raise RuntimeError("CylCoefs::EvenOddPower: ncylodd is not in the YAML config stanza.  Please "
+                               "specify this explicitly as the first argument to EvenOddPower()")
+        first = self.coefs[times[0]]
+        cut = first.nmax - nodd
+        ev = np.stack([(np.abs(np.asarray(self.coefs[t].coefs)[:, builtins_max(0, min):builtins_min(cut, max)]) ** 2).sum(axis=1)
+                       for t in times])
+        od = np.stack([(np.abs(np.asarray(self.coefs[t].coefs)[:, builtins_max(cut, min):builtins_min(first.nmax, max)]) ** 2).sum(axis=1)
+                       for t in times])
+        return ev, od
+
+    def _check_h5_params(self, path: str) -> bool:
+        import ctypes
+        from . import h5cache
+        lib = h5cache._load()
+        lib.exp_h5_cylcoef_info.restype = ctypes.c_int
+        mmax, nmax, count, hasv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        name, fid, geo = (ctypes.create_string_buffer(256) for _ in range(3))
+        if lib.exp_h5_cylcoef_info(path.encode(), ctypes.byref(mmax), ctypes.byref(nmax), ctypes.byref(count),
+                                   name, 256, fid, 256, geo, 256, ctypes.byref(hasv)):
+            return False
+        first = self.coefs[self.Times()[0]]
+        return (mmax.value == first.mmax and nmax.value == first.nmax
+                and fid.value.decode() == getattr(self, "_force_id", "cylinder"))
 
     def add(self, c: CylStruct) -> None:
         self.coefs[round_time(c.time)] = c
@@ -395,6 +650,7 @@ class CylCoefs:
             ctr[k] = np.asarray(c.ctr, dtype=np.float64).reshape(3) if np.size(c.ctr) == 3 else 0.0
             rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
         tarr = np.array([self.coefs[t].time for t in times])
+        self._force_id = force_id
         lib = h5cache._load()
         lib.exp_h5_cylcoef_write.restype = ctypes.c_int
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
@@ -431,6 +687,7 @@ class CylCoefs:
         if lib.exp_h5_cylcoef_read(path.encode(), C, M, N, vp(times), vp(ctr), vp(rot), vp(data)):
             raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
         self = cls(name.value.decode())
+        self._force_id = fid.value.decode()
         for k in range(0, C, stride):
             if times[k] < tmin or times[k] > tmax:
                 continue

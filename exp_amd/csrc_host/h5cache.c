@@ -423,33 +423,40 @@ static int put_dbl_array_attr(hid_t loc, const char *name, int rank, const hsize
 static int coef_write(const char *path, const char *geometry, const char *name, const char *config,
                       const char *forceID, const char *key1, int val1, int nmax, int has_scale,
                       double scale, int ldim, int ntimes, const double *times, const double *centers,
-                      const double *rots, const double *coefs)
+                      const double *rots, const double *coefs, int extend)
 {
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
-  hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  /* extend != 0: Coefs::ExtendH5Coefs (expui/Coefficients.cc:3165-3204) -- open read-write, continue
+   * the snapshot numbering at the stored count, update the count (the parameter check,
+   * CheckH5Params, is the caller's) */
+  hid_t f = extend ? H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT)
+                   : H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   if (f < 0) return -1;
   int rc = 0;
-  rc |= put_str(f, "CoefficientOutputVersion", "1.0");
-  rc |= put_str(f, "geometry", geometry);
-  rc |= put_str(f, "name", name);
-  rc |= put_str(f, "config", config);
-  rc |= put_int(f, key1, val1);
-  rc |= put_int(f, "nmax", nmax);
-  if (has_scale) rc |= put_dbl(f, "scale", scale);
-  rc |= put_str(f, "forceID", forceID);
-  {
-    unsigned count = (unsigned)ntimes;
+  unsigned first = 0;
+  hid_t cnt = -1;
+  if (!extend) {
+    rc |= put_str(f, "CoefficientOutputVersion", "1.0");
+    rc |= put_str(f, "geometry", geometry);
+    rc |= put_str(f, "name", name);
+    rc |= put_str(f, "config", config);
+    rc |= put_int(f, key1, val1);
+    rc |= put_int(f, "nmax", nmax);
+    if (has_scale) rc |= put_dbl(f, "scale", scale);
+    rc |= put_str(f, "forceID", forceID);
     hid_t s = H5Screate(H5S_SCALAR);
-    hid_t d = H5Dcreate2(f, "count", H5T_NATIVE_UINT, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    if (d < 0 || H5Dwrite(d, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
-    if (d >= 0) H5Dclose(d);
+    cnt = H5Dcreate2(f, "count", H5T_NATIVE_UINT, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     H5Sclose(s);
+  } else {
+    cnt = H5Dopen2(f, "count", H5P_DEFAULT);
+    if (cnt < 0 || H5Dread(cnt, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &first) < 0) rc = -1;
   }
-  hid_t snaps = H5Gcreate2(f, "snapshots", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  hid_t snaps = extend ? H5Gopen2(f, "snapshots", H5P_DEFAULT)
+                       : H5Gcreate2(f, "snapshots", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
   hid_t ct = complex_type();
   for (int k = 0; k < ntimes && rc == 0 && snaps >= 0; k++) {
     char nm[16];
-    snprintf(nm, sizeof nm, "%08d", k);
+    snprintf(nm, sizeof nm, "%08u", first + (unsigned)k);
     hid_t g = H5Gcreate2(snaps, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     if (g < 0) { rc = -1; break; }
     rc |= put_dbl(g, "Time", times[k]);
@@ -466,6 +473,12 @@ static int coef_write(const char *path, const char *geometry, const char *name, 
   }
   H5Tclose(ct);
   if (snaps >= 0) H5Gclose(snaps); else rc = -1;
+  if (cnt >= 0) {
+    const unsigned count = first + (unsigned)ntimes;
+    if (rc == 0 && H5Dwrite(cnt, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
+    H5Dclose(cnt);
+  } else
+    rc = -1;
   H5Fclose(f);
   return rc ? -1 : 0;
 }
@@ -475,7 +488,14 @@ int exp_h5_sphcoef_write(const char *path, const char *name, const char *config,
                          const double *centers, const double *rots, const double *coefs)
 {
   return coef_write(path, "sphere", name, config, forceID, "lmax", lmax, nmax, 1, scale,
-                    (lmax + 1) * (lmax + 2) / 2, ntimes, times, centers, rots, coefs);
+                    (lmax + 1) * (lmax + 2) / 2, ntimes, times, centers, rots, coefs, 0);
+}
+
+/* Coefs::ExtendH5Coefs for either geometry: ldim complex rows per snapshot */
+int exp_h5_coef_extend(const char *path, int ldim, int nmax, int ntimes, const double *times,
+                       const double *centers, const double *rots, const double *coefs)
+{
+  return coef_write(path, "", "", "", "", "", 0, nmax, 0, 0.0, ldim, ntimes, times, centers, rots, coefs, 1);
 }
 
 int exp_h5_cylcoef_write(const char *path, const char *name, const char *config, const char *forceID,
@@ -483,7 +503,19 @@ int exp_h5_cylcoef_write(const char *path, const char *name, const char *config,
                          const double *rots, const double *coefs)
 {
   return coef_write(path, "cylinder", name, config, forceID, "mmax", mmax, nmax, 0, 0.0, mmax + 1,
-                    ntimes, times, centers, rots, coefs);
+                    ntimes, times, centers, rots, coefs, 0);
+}
+
+/* Coefs::factory's first question (expui/Coefficients.cc:2917-2931): is this an HDF5 file with a
+ * `geometry` attribute?  0 and the string, or -1.                                                */
+int exp_h5_coef_geometry(const char *path, char *geometry, int cap)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = get_str(f, "geometry", geometry, (size_t)cap);
+  H5Fclose(f);
+  return rc ? -1 : 0;
 }
 
 /* header of a cylindrical coefficient file: CylCoefs(HighFive::File&, ...) (expui/Coefficients.cc:1075-1095) */

@@ -216,6 +216,17 @@ def covar_append(path: str, basis_id: str, kind: int, ipar, dpar, time: float, c
     return rc == 0
 
 
+def coef_geometry(path: str):
+    """The ``geometry`` attribute of an HDF5 coefficient file, or None when ``path`` is not one
+    (``Coefs::factory``, expui/Coefficients.cc:2917-2931)."""
+    lib = _load()
+    buf = ctypes.create_string_buffer(64)
+    lib.exp_h5_coef_geometry.restype = ctypes.c_int
+    if lib.exp_h5_coef_geometry(str(path).encode(), buf, 64):
+        return None
+    return buf.value.decode()
+
+
 class SubsampleCovariance:
     """``BasisClasses::SubsampleCovariance(filename, stride)`` (expui/Covariance.cc:419-700): reads a
     covariance file back; ``Times()``, ``getCoefCovariance(time)`` -> (counts, masses, mean [T, ltot,

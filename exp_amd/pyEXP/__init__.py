@@ -1,0 +1,14 @@
+"""``import exp_amd.pyEXP as pyEXP``: the two pyEXP sub-modules this path covers, under their names.
+
+    pyEXP.basis.Basis.factory(yaml) / SphericalSL / Cylindrical / CovarianceReader
+    pyEXP.coefs.Coefs.factory(file) / SphCoefs / CylCoefs / SphStruct / CylStruct
+
+so that a script written against the reference's Python module (tests/Halo/createCoefs.py,
+tests/Halo/changeCoefs.py, tests/Disk/cyl_basis.py) runs with the import line changed.  Everything else
+of pyEXP (field generators, mSSA, particle readers, utilities) is outside this repository's scope and
+raises on access."""
+from . import basis, coefs
+
+
+def __getattr__(name):
+    raise AttributeError(f"exp_amd.pyEXP has no sub-module <{name}>: only basis and coefs are in scope")

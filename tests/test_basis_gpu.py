@@ -466,3 +466,77 @@ def test_coefficient_covariance_by_subsampling(halo_basis, oracle, tmp_path, mon
     basis.enableCoefCovariance(False)
     with pytest.raises(RuntimeError, match="covariance not enabled"):
         basis.force.cov_get()
+
+
+def test_reference_script_sequences_through_the_pyexp_namespace(tmp_path, monkeypatch):
+    """The call sequences of the reference's pyEXP scripts, through ``import exp_amd.pyEXP as pyEXP``:
+    tests/Halo/createCoefs.py (pcavar / subsamp basis, enableCoefCovariance, SphCoefs(True), four
+    createFromArray layouts into the container, writeCoefCovariance, CovarianceReader),
+    tests/Halo/readCoefs.py (Coefs.factory on a native stream, getAllCoefs, getName) and
+    tests/Halo/changeCoefs.py (invI over the packing index, zeroing the odd orders with setMatrix, the
+    zero test on getAllCoefs)."""
+    import exp_amd.pyEXP as pyEXP
+    monkeypatch.chdir(tmp_path)
+    config = HALO_CFG.format(model=os.path.join(GOLD, "SLGridSph.model"), cache="SLGridSph.cache.run0")
+    config = config.replace("  rmapping : 0.0667", "  rmapping : 0.0667\n  pcavar : true\n  subsamp : 10")
+    basis = pyEXP.basis.Basis.factory(config)
+    basis.enableCoefCovariance(True, 100)
+    coefs = pyEXP.coefs.SphCoefs(True)
+    random.seed(11)
+    mass, xpos, ypos, zpos = [], [], [], []
+    for _ in range(100):
+        mass.append(0.01)
+        xpos.append(random.random() * 2.0 - 1.0)
+        ypos.append(random.random() * 2.0 - 1.0)
+        zpos.append(random.random() * 2.0 - 1.0)
+    coef1 = basis.createFromArray(mass, [xpos, ypos, zpos], time=3.0)
+    coefs.add(coef1)
+    basis.writeCoefCovariance("halo", "test_covar", coef1.time)
+    testcovar = pyEXP.basis.CovarianceReader("coefcovar.halo.test_covar.h5")
+    counts, masses, means, covr = testcovar.getCoefCovariance(coef1.time)
+    assert testcovar.Times() == [3.0] and int(np.sum(counts)) == basis.used and np.sum(masses) == pytest.approx(basis.used * 0.01)
+    assert means.shape[1:] == (6, 10) and covr.shape[1:] == (6, 10, 10)
+    mass = np.array(mass)
+    data = np.array([xpos, ypos, zpos])
+    coefs.add(basis.createFromArray(mass, data, time=3.1))
+    rng = np.random.default_rng(5)
+    mass = np.ones(100) * 1.0e-02
+    xyz = [rng.normal(0.0, 1.0, 100) for _ in range(3)]
+    coefs.add(basis.createFromArray(mass, xyz, time=3.2))
+    coefs.add(basis.createFromArray(mass, np.array(xyz), time=3.3))
+    assert coefs.Times() == [3.0, 3.1, 3.2, 3.3]
+    # readCoefs.py: a native stream as the n-body code leaves it, through the factory
+    coefs.setName("halo")
+    coefs.writeNativeCoefs("outcoef.halo.run0")
+    back = pyEXP.coefs.Coefs.factory("outcoef.halo.run0")
+    data = back.getAllCoefs()
+    assert data.shape == (6, 10, 4) and back.getGeometry() == "sphere" and isinstance(back.getName(), str)
+    assert coefs.CompareStanzas(back)
+    # changeCoefs.py: zero every odd (l, m) through setMatrix, then look again
+    times = back.Times()
+    for k in range(data.shape[0]):
+        l, m, _ = basis.invI(k)
+        assert basis.I(l, m) == k
+        if l % 2 != 0 or m % 2 != 0:
+            data[k, :, :] *= 0.0
+    for i in range(data.shape[2]):
+        back.setMatrix(times[i], data[:, :, i])
+    data1 = back.getAllCoefs()
+    odd = [k for k in range(data1.shape[0]) if basis.invI(k)[0] % 2 or basis.invI(k)[1] % 2]
+    assert len(odd) == 3 and np.abs(data1[odd]).max() == 0.0 and np.abs(data1).max() > 0.0
+    with pytest.raises(RuntimeError, match="requested time"):
+        back.setMatrix(9.0, data[:, :, 0])
+    # the HDF5 pair and the per-harmonic power
+    back.WriteH5Coefs("halo.h5")
+    more = pyEXP.coefs.SphCoefs()
+    more.add(basis.createFromArray(mass, xyz, time=3.4))
+    more._force_id = "sphereSL"
+    more.ExtendH5Coefs("halo.h5")
+    allc = pyEXP.coefs.Coefs.factory("halo.h5")
+    assert allc.Times() == [3.0, 3.1, 3.2, 3.3, 3.4] and allc.Power().shape == (5, 3)
+    assert np.allclose(allc.Power()[0], [np.sum(np.abs(data1[0, :, 0]) ** 2), 0.0,
+                                         np.sum(np.abs(data1[[3, 5], :, 0]) ** 2)])
+    bad = pyEXP.coefs.SphCoefs()
+    bad.add(pyEXP.coefs.SphStruct(3, 10, 1.0, 3.5, np.zeros((10, 10), complex), np.zeros(3), np.eye(3)))
+    with pytest.raises(RuntimeError, match="parameter check failed"):
+        bad.ExtendH5Coefs("halo.h5")

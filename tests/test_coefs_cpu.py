@@ -115,3 +115,81 @@ def test_cylinder_native_stream(tmp_path):
                 f.write(np.ascontiguousarray(c.coefs[m].imag).tobytes())
     got = CylCoefs.readNativeCoefs(leg).getCoefStruct(0.5)
     assert np.array_equal(got.coefs, c.coefs)
+
+
+def test_coefs_container_surface(tmp_path):
+    """``CoefClasses::Coefs`` beyond add / Times (expui/Coefficients.H, expui/Coefficients.cc): factory by file
+    type, makecoefs / addcoef, the pybind ``__call__``, setMatrix / setData on existing times only, deepcopy
+    and zerodata, CompareStanzas, Power / EvenOddPower, ExtendH5Coefs with its parameter check."""
+    from exp_amd.basis import CylStruct, SphStruct
+    from exp_amd.coefs import Coefs, CylCoefs, SphCoefs
+    rng = np.random.default_rng(4)
+
+    def S(t, L=3, N=5):
+        r = (L + 1) * (L + 2) // 2
+        cf = rng.normal(size=(r, N)) + 1j * rng.normal(size=(r, N))
+        for l in range(L + 1):
+            cf[l * (l + 1) // 2] = cf[l * (l + 1) // 2].real          # m = 0 rows carry no sine part
+        return SphStruct(L, N, 0.5, t, cf, np.zeros(3), np.eye(3))
+
+    def C(t, M=4, N=6):
+        cf = rng.normal(size=(M + 1, N)) + 1j * rng.normal(size=(M + 1, N))
+        cf[0] = cf[0].real
+        return CylStruct(M, N, t, cf, np.zeros(3), np.eye(3))
+
+    sph = cyl = None
+    for t in (0.0, 0.1, 0.2):
+        sph, cyl = Coefs.addcoef(sph, S(t)), Coefs.addcoef(cyl, C(t))
+    assert isinstance(sph, SphCoefs) and isinstance(cyl, CylCoefs)
+    assert sph.getGeometry() == "sphere" and cyl.getGeometry() == "cylinder"
+    with pytest.raises(RuntimeError):
+        Coefs.makecoefs(object())
+    # values at a time: the matrix, or an EMPTY one (expui/Coefficients.cc:683-696)
+    assert sph(0.1).shape == (10, 5) and sph(0.15).shape == (0, 0)
+    assert np.array_equal(sph.getData(0.1), sph(0.1).reshape(-1, order="F"))
+    m = sph(0.1) * 2.0
+    sph.setMatrix(0.1, m)
+    assert np.array_equal(sph(0.1), m)
+    sph.setData(0.1, (m * 0.5).reshape(-1, order="F"))
+    assert np.array_equal(sph(0.1), m * 0.5)
+    for fn in (sph.setMatrix, sph.setData):
+        with pytest.raises(RuntimeError, match="not found"):
+            fn(0.7, m)
+    # power: |c|^2 summed over m and the radial window
+    P = sph.Power(1, 4)
+    a2 = np.abs(sph(0.0)[:, 1:4]) ** 2
+    assert P.shape == (3, 4) and np.allclose(P[0], [a2[0].sum(), a2[1:3].sum(), a2[3:6].sum(), a2[6:10].sum()])
+    assert np.allclose(cyl.Power()[2], (np.abs(cyl(0.2)) ** 2).sum(axis=1))
+    ev, od = cyl.EvenOddPower(2)
+    assert np.allclose(ev + od, cyl.Power()) and np.allclose(od[1], (np.abs(cyl(0.1)[:, 4:]) ** 2).sum(axis=1))
+    with pytest.raises(RuntimeError, match="ncylodd"):
+        cyl.EvenOddPower()
+    # copies
+    cp = sph.deepcopy()
+    assert sph.CompareStanzas(cp) and cp.coefs[0.0] is not sph.coefs[0.0]
+    cp.zerodata()
+    assert np.abs(cp.getAllCoefs()).max() == 0.0 and not sph.CompareStanzas(cp) and cp.Times() == sph.Times()
+    cp.clear()
+    assert cp.Times() == [] and cp.Power().shape == (0, 0)
+    # files: factory picks the class from the HDF5 geometry attribute or the native magic number
+    for obj, tag in ((sph, "s"), (cyl, "c")):
+        obj.setName("comp" + tag)
+        h5, nat = str(tmp_path / (tag + ".h5")), str(tmp_path / (tag + ".native"))
+        obj.WriteH5Coefs(h5)
+        obj.writeNativeCoefs(nat)
+        for path in (h5, nat):
+            back = Coefs.factory(path)
+            assert type(back) is type(obj) and back.Times() == obj.Times()
+            assert np.abs(back.getAllCoefs() - obj.getAllCoefs()).max() <= 1e-15
+        assert Coefs.factory(h5).getName() == "comp" + tag
+        ext = type(obj)()
+        ext.add(S(0.3) if tag == "s" else C(0.3))
+        ext.ExtendH5Coefs(h5)                     # (a fresh container assumes the default forceID)
+        assert Coefs.factory(h5).Times() == [0.0, 0.1, 0.2, 0.3]
+        assert Coefs.factory(h5, stride=2).Times() == [0.0, 0.2] and Coefs.factory(h5, tmin=0.05, tmax=0.25).Times() == [0.1, 0.2]
+        wrong = type(obj)()
+        wrong.add(S(0.4, L=2) if tag == "s" else C(0.4, M=3))
+        with pytest.raises(RuntimeError, match="parameter check failed"):
+            wrong.ExtendH5Coefs(h5)
+    with pytest.raises(RuntimeError, match="does not exist"):
+        Coefs.factory(str(tmp_path / "nothing"))
