@@ -203,8 +203,17 @@ def cpu_baseline(grid, model, nsample, dt):
     # tuned CPU mode: the device path's hoisting on the same threads
     mt, post, velt = sample_sphere(model, big * 4, seed=779)
     vt, st = _cpu_steps_tuned(orc, grid, prm, dt, mt, post, velt, nthreads, 6.0, 50)
+    # what the process may actually use: affinity mask, cgroup CPU quota (a container's "64 CPUs" are often
+    # a fraction of that in quota: the threaded rate then scales with the quota, not with the thread count)
+    host = {"affinity_cpus": ncpu, "os_cpu_count": os.cpu_count()}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            host["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+            break
+        except OSError:
+            pass
     return {"value": max(vn, v1), "unit": "particle-steps/s", "cores": nthreads if vn >= v1 else 1,
-            "kind": "port", "value_1thread": v1,
+            "kind": "port", "value_1thread": v1, "thread_speedup": vn / v1 if v1 > 0 else None, "host": host,
             "tuned": {"value": vt, "cores": nthreads, "steps": st, "particles": big * 4,
                       "what": "oracle/tuned_cpu.c: cell moments + contraction, projected force table "
                               "(the device algorithm on CPU threads), gcc -O3"},

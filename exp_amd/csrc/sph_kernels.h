@@ -1002,6 +1002,9 @@ sph_field_fast_call(cdp t4, double costh, double somx2, double cphi, double sphi
 #ifndef SPH_FORCE_CHUNKS
 #define SPH_FORCE_CHUNKS 1
 #endif
+#ifndef SPH_T4_PREFETCH
+#define SPH_T4_PREFETCH 2     // cells ahead whose table rows a fast-pass wave pulls into L2 (0: off)
+#endif
 // One 64-particle chunk of one wave (slots base .. base+63 of [.., end)).
 // MODE 0: general evaluation of the lanes in `lanemask`.  MODE 1: the fast pass (a wave either is
 // cell-uniform and done here, or is deferred whole).  MODE 2: the fast pass as a WATERFALL -- the
@@ -1037,6 +1040,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
   const double fac = xx * xx + yy * yy;
   const size_t tq = (size_t)4 * S.trows;
   double r, ir, iR2, P0, ffac, dfac;
+  [[maybe_unused]] double t4_sink = 0.0;      // destination of the table prefetch of the fast pass
   ForceOut o;
   if constexpr (FAST) {
     // Same quantities as the general path below with the divisions shared: one reciprocal each of
@@ -1073,6 +1077,23 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
         }
         return;
       }
+#if SPH_T4_PREFETCH
+      {
+        // Warm this XCD's L2 with the table rows of the cell SPH_T4_PREFETCH ahead.  The whole table (7.7 MB
+        // at S10) does not fit the 4 MB L2 of an XCD, so the first waves to reach a new cell would take each
+        // of their 61 scalar 64-byte loads from HBM, one behind the other (the s_load pipeline is one block
+        // deep); at 5e8 particles, where those front waves are five times rarer, the same kernel runs 9 %
+        // faster per particle.  One vector load per wave, a cache line per lane, result never used.
+        int pc = idx_u + SPH_T4_PREFETCH;
+        pc = pc > S.numr - 2 ? S.numr - 2 : pc;
+        const double *pp = T4 + (size_t)pc * tq + (size_t)lane * 8;
+        // (the load is asynchronous and the compiler does not know it: the destination registers stay
+        // reserved until the end of the wave -- see the matching fake use below -- or the data would land in
+        // whatever had been given those registers in the meantime)
+        if ((size_t)lane * 8 < tq)
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t4_sink) : "v"(pp) : "memory");
+      }
+#endif
       // get_pot / get_force weights (exputil/SLGridMP2.cc:894-902, :971-985)
       const double x1 = (S.xi[idx_u + 1] - xi) * S.inv_dxi;
       const double x2 = (xi - S.xi[idx_u]) * S.inv_dxi;
@@ -1205,6 +1226,9 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
       key_out[i] = key + S.key_add;
     }
   }
+#if SPH_T4_PREFETCH
+  if constexpr (MODE == 1) asm volatile("" : : "v"(t4_sink));     // keeps the prefetch's registers out of circulation
+#endif
 }
 
 template <int LMAX, int MODE>
