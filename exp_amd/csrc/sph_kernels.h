@@ -911,6 +911,8 @@ sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, dou
   // m = 0 rows are 4 doubles each: fetch them two rows at a time as 8-double blocks where possible
   sd8 cur, nxt;
   asm volatile("s_load_dwordx16 %0, %1, 0" : "=s"(cur) : "s"(tb));
+  // (touching all 61 lines of the cell with scalar loads up front -- a scalar-cache warm-up for the first waves
+  // of a cell on a CU pair -- measured neutral once the rows are L2-resident: the prefetch in k_sph_force)
   SWAIT8(cur);
   static_for<0, NBLK>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
