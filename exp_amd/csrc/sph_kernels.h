@@ -1120,6 +1120,15 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
         work[SPH_WORK_STRIDE * w + 2] = (uint32_t)(sp >> 32);
       }
       if (special) valid = false;
+#if SPH_T4_PREFETCH
+      {                       // the same L2 warm-up as in the fast pass, from the first lane's cell
+        int pc = __builtin_amdgcn_readfirstlane(idx) + SPH_T4_PREFETCH;
+        pc = pc > S.numr - 2 ? S.numr - 2 : pc;
+        const double *pp = T4 + (size_t)pc * tq + (size_t)lane * 8;
+        if ((size_t)lane * 8 < tq)
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t4_sink) : "v"(pp) : "memory");
+      }
+#endif
       unsigned long long todo = __ballot(valid);
       o = ForceOut{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
@@ -1229,7 +1238,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     }
   }
 #if SPH_T4_PREFETCH
-  if constexpr (MODE == 1) asm volatile("" : : "v"(t4_sink));     // keeps the prefetch's registers out of circulation
+  if constexpr (MODE != 0) asm volatile("" : : "v"(t4_sink));     // keeps the prefetch's registers out of circulation
 #endif
 }
 
