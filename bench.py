@@ -45,13 +45,15 @@ ALGO_BYTES = {
     "k_cyl_accumulate": 32.0,
     "k_kick": 72.0,
     "k_drift": 72.0,
-    "k_scatter_adv": 148.0,      # reads x,v,a,m,id (84 + 4) ; writes x,v,m,id (60): kick + drift inside the sort
+    "k_scatter_adv": 148.0,      # contract accounting: reads x,v,a,m,id (84 + 4) ; writes x,v,m,id (60); the pass itself
+                                 # moves 112 (no a: prekick; no m: equal-mass component)
     "step": 232.0,
 }
-# What the kernels of the FUSED step themselves move: the closing half-kick's
-# v store is deferred into the next scatter pass, so the force pass reads x,y,z,vx,vy,vz (48) and
-# writes ax,ay,az,pot (32) + the 4-byte sort key of the next step = 84 B; measured 85 B (PMC).
-OWN_BYTES = {"k_sph_force": 84.0, "k_cyl_force": 84.0}
+# What the kernels of the FUSED step themselves move: the force pass reads x,y,z,vx,vy,vz
+# (48) and writes ax,ay,az,pot (32), the velocities with both half-kicks of the step boundary applied (24:
+# exp_amd_ctx_set_prekick, so that the reordering pass does not read the accelerations) and the 4-byte sort key of
+# the next step = 108 B, i.e. the contract's 104 + the key.
+OWN_BYTES = {"k_sph_force": 108.0, "k_cyl_force": 108.0}
 # fp64 operations executed per particle (FMA = 2), static count of the unrolled fast paths
 # (tools/isa_count.py on the gfx950 assembly)
 # (k_cyl_force: its static count of 1427 holds both table paths -- scalar rows for a cell-uniform wave,

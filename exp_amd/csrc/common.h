@@ -50,8 +50,8 @@ struct exp_amd_ctx {
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
-  bool prekick = false;              // opt-in: the fused step stores velocities with the NEXT step's opening half-kick
-                                     // applied (exp_amd_ctx_set_prekick, EXP_AMD_PREKICK=1; measured +1 %)
+  bool prekick = true;               // the fused step stores velocities with the NEXT step's opening half-kick applied
+                                     // (exp_amd_ctx_set_prekick; EXP_AMD_PREKICK=0 sets the default off)
   bool deterministic = false;        // order-independent (bit-reproducible) coefficient sums, exp_amd_ctx_set_deterministic
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)

@@ -58,16 +58,16 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
  * co-running kernels slow each other down (force 5.6 -> 7.1 ms, accumulate 2.9 -> 4.5 ms).        */
 int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
 /* The fused KDK step (exp_amd_step_kdk) ends with a force pass that knows the next step: it writes that
- * step's sort keys.  With prekick on (opt-in; EXP_AMD_PREKICK=1 sets the default) the same pass stores the
+ * step's sort keys.  With prekick on (the default; EXP_AMD_PREKICK=0 turns it off) the same pass stores the
  * velocities with BOTH half-kicks around the step boundary applied -- v + a dt/2 (closing), then + a dt/2
  * (opening), two rounding steps as src/incvel.cc:15-88 would take them -- so that the next step's
  * reordering pass only drifts and never reads the accelerations (24 B per particle-step less).  The
  * trajectory is bit-identical to the sequence kick, kick, drift.  Anything that reads velocities at the
  * step boundary sees v - a dt/2 formed on the way out (exp_amd_comp_download: non-destructively, within
  * one ulp of the closing-kick value) or after the opening half-kick has been taken back (every other
- * consumer; a following step_kdk with another dt included).  Off (default): the closing half-kick is left
- * to the next reordering pass, which then reads the accelerations.  Measured at 1e8 / S10: the reordering
- * pass 2.85 -> 2.30 ms, the force pass 5.60 -> 6.07 ms for its three extra stores, the step 1 % faster.  */
+ * consumer; a following step_kdk with another dt included).  Off: the closing half-kick is left to the
+ * next reordering pass, which then reads the accelerations.  Measured at 1e8 / S10: the reordering pass
+ * 2.94 -> 2.44 ms, the force pass 4.82 -> 5.01 ms for its three extra stores, the step 2 % faster.       */
 int  exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on);
 /* Deterministic mode (off by default; EXP_AMD_DETERMINISTIC sets the default).  The coefficient sums
  * are reductions over millions of particles by fp64 atomics in whatever order the hardware serves
