@@ -6,6 +6,9 @@
 #error "compile with -DSPH_L=<lmax>"
 #endif
 
+#ifndef ACC_BLOCKS_TARGET
+#define ACC_BLOCKS_TARGET 3072     // blocks a large launch is cut into (ACC_CHUNK_MAX permitting)
+#endif
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 
@@ -23,7 +26,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   unsigned nb = 0;
   for (int j = 0; j < LC.nlev; j++) {
     const size_t n = a.counts ? a.counts[j] : a.n;
-    size_t chunk = (n / ((size_t)CPB * 3072)) & ~(size_t)63;
+    size_t chunk = (n / ((size_t)CPB * ACC_BLOCKS_TARGET)) & ~(size_t)63;
     const size_t cmin = a.multilevel ? 64 : ACC_CHUNK_MIN;
     chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
     LC.bstart[j] = nb;

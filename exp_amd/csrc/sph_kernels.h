@@ -308,7 +308,9 @@ struct LevChunks {
 // those fixed costs were 30% of the kernel, so the launcher picks up to ACC_CHUNK_MAX when the
 // component is large enough to still fill the GPU several times over.
 #define ACC_CHUNK_MIN 1024
+#ifndef ACC_CHUNK_MAX
 #define ACC_CHUNK_MAX 4096
+#endif
 #define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
 
 // Per-particle inputs of the moment accumulation: everything that does not depend on (l, m).
