@@ -524,6 +524,7 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 struct AccShared {
   double v[2][6][ACC_WAVES * 64];
   int idx[2][ACC_WAVES * 64];
+  unsigned long long used[ACC_WAVES];      // in-window counts of the four quarters, handed over at the last tile
 };
 
 template <int LMAX, int MLO, int MHI, bool DET>
@@ -559,7 +560,18 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
       sh.v[par][3][q] = in.a1;    sh.v[par][4][q] = in.a2;   sh.v[par][5][q] = in.sinth;
       sh.idx[par][q] = in.idx;
     }
+    // the in-window count leaves the block as ONE atomic, issued here at the last tile's barrier (four
+    // same-address atomics per block right before the waves end kept their registers waiting for the acks)
+    const bool last_tile = tbase + TILE >= cend;
+    if (last_tile) {
+      for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
+      if (lane == 0) sh.used[wave] = used;
+    }
     lds_barrier();
+    if (last_tile && wave == 0 && lane == 0) {
+      const unsigned long long tot = (sh.used[0] + sh.used[1]) + (sh.used[2] + sh.used[3]);
+      if (tot) atomicAdd(used_out, tot);
+    }
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced
     ip += TILE;
@@ -578,8 +590,6 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
   if (cur >= 0)
     wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
                    [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
-  for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
-  if (lane == 0 && used) atomicAdd(used_out, used);
 }
 
 // m-range splits of the rows (keep 2 moment accumulators per real row in registers).  The waves
