@@ -23,7 +23,7 @@ struct SphKeyFn {
 #define CSEG 32
 // clear != 0: the moments are zeroed once they have been read (each (cell, row) pair is read by exactly
 // one block), so that the next accumulation finds a clean buffer without a separate memset pass
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wscale,
                double *__restrict__ part, int clear = 0)
 {
@@ -37,19 +37,32 @@ k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wsca
   const int per = (ncell + CSEG - 1) / CSEG;
   const int i0 = seg * per, i1 = min(ncell, i0 + per);
   const int stride = (S.lmax + 1) * S.nmax;
-  for (int n = threadIdx.x; n < S.nmax; n += 64) {
+  // 32 radial orders x 8 cell slots per pass: the segment's cells are walked 8 at a time (a block per
+  // (row, segment) of 64 threads, 24 of them busy for 63 dependent iterations, took 29 us -- the longest
+  // of the fixed per-step kernels of a strong-scaled run); the slots are added in a fixed order
+  __shared__ double red[8][32];
+  const int nn = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  for (int n0 = 0; n0 < S.nmax; n0 += 32) {
+    const int n = n0 + nn;
     double s = 0.0;
-    for (int i = i0; i < i1; i++) {
-      const double w1 = W[((size_t)i * S.nrows + row) * 2];
-      const double w2 = W[((size_t)i * S.nrows + row) * 2 + 1];
-      s = fma(S.E[(size_t)i * stride + l * S.nmax + n], w1, s);
-      s = fma(S.E[(size_t)(i + 1) * stride + l * S.nmax + n], w2, s);
+    if (n < S.nmax)
+      for (int i = i0 + slot; i < i1; i += 8) {
+        const double w1 = W[((size_t)i * S.nrows + row) * 2];
+        const double w2 = W[((size_t)i * S.nrows + row) * 2 + 1];
+        s = fma(S.E[(size_t)i * stride + l * S.nmax + n], w1, s);
+        s = fma(S.E[(size_t)(i + 1) * stride + l * S.nmax + n], w2, s);
+      }
+    red[slot][nn] = s;
+    __syncthreads();
+    if (slot == 0 && n < S.nmax) {
+      const double t = ((red[0][nn] + red[1][nn]) + (red[2][nn] + red[3][nn])) +
+                       ((red[4][nn] + red[5][nn]) + (red[6][nn] + red[7][nn]));
+      part[((size_t)seg * S.nrows + row) * S.nmax + n] = t * wscale[row];   // 1/s(l,m), see lc_s
     }
-    part[((size_t)seg * S.nrows + row) * S.nmax + n] = s * wscale[row];   // 1/s(l,m), see lc_s
+    __syncthreads();
   }
   if (clear) {
-    __syncthreads();
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += 64) {
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
       W[((size_t)i * S.nrows + row) * 2] = 0.0;
       W[((size_t)i * S.nrows + row) * 2 + 1] = 0.0;
     }
@@ -392,7 +405,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
+    k_sph_contract<<<dim3(S.nrows, CSEG), 256, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
                                                                 f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(f->d_part.p, (int)f->ncoef,
                                                                   d_out);
@@ -498,7 +511,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG, nact), 64, 0, ctx->stream>>>(
+    k_sph_contract<<<dim3(S.nrows, CSEG, nact), 256, 0, ctx->stream>>>(
         S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
     // ... with the N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
     k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nact), 256, 0, ctx->stream>>>(
@@ -686,7 +699,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG), 64, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
+    k_sph_contract<<<dim3(S.nrows, CSEG), 256, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, V>>>(f->d_part.p, (int)f->ncoef, f->d_coef.p);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -777,7 +790,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     k_upd_launch[cfg.lmax](a);
   }
   // moments -> coefficient differences, all levels in one launch
-  k_sph_contract<<<dim3(S.nrows, CSEG, nl), 64, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
+  k_sph_contract<<<dim3(S.nrows, CSEG, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
                                                                   f->d_wscale.p, f->d_part.p, /*clear=*/1);
   k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nl), 256, 0, ctx->stream>>>(
       f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef);
