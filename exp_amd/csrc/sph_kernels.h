@@ -1266,6 +1266,11 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             uint32_t *__restrict__ nwork_clear /* counter of the NEXT launch pair: zeroed here */)
 {
   if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
+  if constexpr (MODE == 0) {
+    // the general pass is launched over every POSSIBLE work item and nearly all of its waves have none:
+    // they leave on the count alone, before the level offsets (two more dependent round trips) are read
+    if (work != nullptr && (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) >= *nwork) return;
+  }
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if constexpr (MODE != 0) {
     // SPH_FORCE_CHUNKS consecutive chunks per wave (rolled loop: the literal recurrence constants
