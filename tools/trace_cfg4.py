@@ -26,6 +26,26 @@ def main():
     # one complete steady master step: the one before the last (the last one runs into the bench's
     # final downloads); a master step ends with its last sub-step's adjust launches
     back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+
+    def union_busy(seg):
+        busy, hi = 0.0, seg[0][1]
+        for _, s_, e_ in seg:
+            if e_ > hi:
+                busy += (e_ - max(s_, hi)) / 1e6
+                hi = e_
+        return busy
+
+    # every complete master step of the trace (the first ones still carry begin_run's level changes)
+    k, tot_sp, tot_bz, cnt = 1, 0.0, 0.0, 0
+    while (k + 1) * per + ncomp <= len(adj):
+        sg = rows[adj[-(k + 1) * per - ncomp]:adj[-k * per - ncomp]]
+        sp = (sg[-1][2] - sg[0][1]) / 1e6
+        print(f"master step -{k}: span {sp:6.2f} ms, GPU busy {union_busy(sg) / sp:.3f}, {len(sg)} launches")
+        if k <= 6:
+            tot_sp += sp; tot_bz += union_busy(sg); cnt += 1
+        k += 1
+    if cnt:
+        print(f"last {cnt} master steps: mean span {tot_sp / cnt:.2f} ms, GPU busy {tot_bz / tot_sp:.3f}")
     a, b = adj[-(back + 1) * per - ncomp], adj[-back * per - ncomp]
     seg = rows[a:b]
     span = (seg[-1][2] - seg[0][1]) / 1e6
