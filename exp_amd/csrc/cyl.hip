@@ -193,6 +193,16 @@ __device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch,
   for (int j = 0; j < NV; j++) v[j] = 0.0;
 }
 
+// Profiling aid (tools/dbg/cyl_timing.py; tools/build_variant_cyl.sh timing -DEXPT_TIMING): s_memtime counters of
+// the phases of a 64-particle group in k_cyl_accumulate -- waiting for outstanding memory operations at its
+// top, the per-particle inputs, the moment sums, the flushes and the time until everything outstanding is
+// back after one -- summed over all waves.
+#ifdef EXPT_TIMING
+__device__ unsigned long long g_dbg_t[8];
+extern "C" int exp_amd_debug_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_t), sizeof(g_dbg_t)); }
+extern "C" int exp_amd_debug_zero() { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_t), z, sizeof(z)); }
+#define TSTAMP() __builtin_readcyclecounter()
+#endif
 // Wn[node][ntrig]: trig slot 0 = m0, 2m-1 = cos m, 2m = sin m
 template <int MMAX, bool DET>
 __global__ void __launch_bounds__(CACC_WAVES * 64, CACC_OCC)
@@ -244,10 +254,19 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
   double nx = 0, ny = 0, nz = 0, nm = 0;
   const bool um = C.umass != 0.0;
   if (cbeg + lane < cend) { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? C.umass : M[cbeg + lane]; }
+#ifdef EXPT_TIMING
+  unsigned long long t_load = 0, t_prep = 0, t_red = 0, t_fl = 0, t_fld = 0, t_nfl = 0, t_all0 = TSTAMP();
+#endif
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
     const bool valid = i < cend;
     double xx = 1, yy = 0, zz = 0, mass = 0;
+#ifdef EXPT_TIMING
+    const unsigned long long ta = TSTAMP();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tb = TSTAMP();
+    t_load += tb - ta;
+#endif
     if (valid) {
       cyl_local(C, nx, ny, nz, xx, yy, zz);
       mass = nm;
@@ -272,6 +291,11 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
     if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
     const double t0 = ongrid ? norm * mass : 0.0;
+#ifdef EXPT_TIMING
+    asm volatile("" :: "v"(t0), "v"(c00), "v"(c11), "v"(cphi), "v"(sphi));
+    const unsigned long long tc = TSTAMP();
+    t_prep += tc - tb;
+#endif
 
     unsigned long long remaining = __ballot(ongrid);
     while (remaining) {
@@ -279,7 +303,15 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
       const int c = __builtin_amdgcn_readlane(cell, lead);
       const bool sel = ongrid && cell == c;
       if (c != cur) {
+#ifdef EXPT_TIMING
+        const unsigned long long tf0 = TSTAMP();
+        if (cur >= 0) { flush(cur); t_nfl++; }
+        const unsigned long long tf1 = TSTAMP();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the flush's atomics AND the prefetched loads)
+        t_fl += tf1 - tf0; t_fld += TSTAMP() - tf1;
+#else
         if (cur >= 0) flush(cur);
+#endif
         cur = c;
       }
       const double t = sel ? t0 : 0.0;
@@ -309,7 +341,18 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
       });
       remaining &= ~__ballot(sel);
     }
+#ifdef EXPT_TIMING
+    t_red += TSTAMP() - tc;
+#endif
   }
+#ifdef EXPT_TIMING
+  if (lane == 0) {
+    atomicAdd(&g_dbg_t[0], t_load); atomicAdd(&g_dbg_t[1], t_prep); atomicAdd(&g_dbg_t[2], t_red);
+    atomicAdd(&g_dbg_t[3], TSTAMP() - t_all0); atomicAdd(&g_dbg_t[4], 1ull + (t_nfl << 32));
+    atomicAdd(&g_dbg_t[5], (unsigned long long)((cend - cbeg + 63) / 64));
+    atomicAdd(&g_dbg_t[6], t_fl); atomicAdd(&g_dbg_t[7], t_fld);
+  }
+#endif
   if (cur >= 0) flush(cur);
   for (int off = 32; off > 0; off >>= 1) {
     mass_used += __shfl_xor(mass_used, off);
