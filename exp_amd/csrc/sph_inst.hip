@@ -9,6 +9,11 @@
 #ifndef ACC_BLOCKS_TARGET
 #define ACC_BLOCKS_TARGET 3072     // blocks a large launch is cut into (ACC_CHUNK_MAX permitting)
 #endif
+#ifdef EXPT_TIMING
+__device__ unsigned long long g_dbg_s[16];
+extern "C" int exp_amd_debug_sph_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_s), sizeof(g_dbg_s)); }
+extern "C" int exp_amd_debug_sph_zero() { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_s), z, sizeof(z)); }
+#endif
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 

@@ -551,7 +551,16 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
   const bool um = S.umass != 0.0;
   if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
   int par = 0;
+#ifdef EXPT_TIMING
+  unsigned long long t_load = 0, t_in = 0, t_bar = 0, t_red = 0, t_all0 = __builtin_readcyclecounter();
+#endif
   for (size_t tbase = cbeg; tbase < cend; tbase += TILE, par ^= 1) {
+#ifdef EXPT_TIMING
+    const unsigned long long ta = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tb = __builtin_readcyclecounter();
+    t_load += tb - ta;
+#endif
     {
       const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend, cell_add);
       if (in.idx >= 0) used++;
@@ -567,7 +576,16 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
       for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off);
       if (lane == 0) sh.used[wave] = used;
     }
+#ifdef EXPT_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tc = __builtin_readcyclecounter();
+    t_in += tc - tb;
+#endif
     lds_barrier();
+#ifdef EXPT_TIMING
+    const unsigned long long td = __builtin_readcyclecounter();
+    t_bar += td - tc;
+#endif
     if (last_tile && wave == 0 && lane == 0) {
       const unsigned long long tot = (sh.used[0] + sh.used[1]) + (sh.used[2] + sh.used[3]);
       if (tot) atomicAdd(used_out, tot);
@@ -586,7 +604,19 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
       in.idx = sh.idx[par][q];
       sph_acc_group<LMAX, MLO, MHI, NV, DET>(S, lc, in, acc, cur, scratch, W);
     }
+#ifdef EXPT_TIMING
+    t_red += __builtin_readcyclecounter() - td;
+#endif
   }
+#ifdef EXPT_TIMING
+  if (lane == 0) {
+    extern __device__ unsigned long long g_dbg_s[16];
+    const int o = MLO == 0 ? 0 : 8;         // the first m-range and the others apart
+    atomicAdd(&g_dbg_s[o + 0], t_load); atomicAdd(&g_dbg_s[o + 1], t_in); atomicAdd(&g_dbg_s[o + 2], t_bar);
+    atomicAdd(&g_dbg_s[o + 3], t_red); atomicAdd(&g_dbg_s[o + 4], __builtin_readcyclecounter() - t_all0);
+    atomicAdd(&g_dbg_s[o + 5], 1ull); atomicAdd(&g_dbg_s[o + 6], (unsigned long long)((cend - cbeg + TILE - 1) / TILE));
+  }
+#endif
   if (cur >= 0)
     wave_flush<NV>(acc, scratch, W + (size_t)cur * S.nrows * 2,
                    [](int j) { return acc_to_wrow<LMAX, MLO, MHI>(j); });
