@@ -115,3 +115,62 @@ def test_config4_against_the_golden_file(ctx):
     _compare("golden", forces, comps, lambda name, key: z[f"{name}_{key}"], ms)
     assert forces[1].cylmass == pytest.approx(float(z["disk_cylmass"]), rel=1e-12)
     assert sim.step_switches == int(np.sum(z["nswitch"]))
+
+
+def test_config4_full_size_level_sets_add_up(ctx):
+    """BASELINE config 4 at its full size (1e7 halo + 1e7 disk particles, SphericalSL lmax 6 nmax 18 and
+    EmpCylSL mmax 6 nmax 12 on the 256 x 128 grid -- the helper basis of the table build reduced, table
+    accuracy does not enter --, multistep 4, both cross forces), through a size-independent identity of the
+    block-multistep bookkeeping instead of the oracle: at the end of a master step every level has been
+    accumulated at the new time, and every particle that changed level on the way has had its contribution
+    moved with it (multistep_update, src/SphericalBasis.cc:1156-1228, src/CylEXP.cc:159-188) -- so the SUM of
+    the per-level coefficient sets must equal a from-scratch, single-level accumulation of the final
+    positions.  Sparse levels, deferred partition, level-fused sub-steps and the differencing all have to be
+    right for that.  Plus: the combined set is that sum, level populations add up, several levels are in use."""
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import NFWModel, sample_disk, sample_sphere
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    n, ms, a, h = 10_000_000, 4, 0.01, 0.001
+    model = NFWModel(rs=1.0, rtrunc=20.0, wtrunc=6.0, rmin=1e-3, rmax=50.0)
+    g = build_slgrid(model, 6, 18, numr=2000, rmin=1e-3, rmax=49.5, cmap=1, rmap=1.0)
+    cg = build_empcyl(mmax=6, norder=12, numx=256, numy=128, acyl=a, hcyl=h, lmaxfid=16, nmaxfid=12,
+                      numr=800, rnum=100, tnum=40)
+    scale = 0.1                                   # disk scale length / halo scale radius, as in bench.py
+    hm, hpos, hvel = sample_sphere(model, n, seed=23)
+    hpos, hvel = hpos * scale, hvel * np.sqrt(1.0 / scale)
+    dm, dpos, dvel = sample_disk(n, 29, a=a, h=h, mass=0.1)
+    dvel = dvel + 0.3 * np.random.default_rng(3).standard_normal(dvel.shape)
+    kw = dict(scale=scale, rmin=g.rmin * scale, rmax=g.rmax * scale)
+    f1, f2 = SphereSL(ctx, g, multistep=ms, **kw), Cylinder(ctx, cg, multistep=ms)
+    c1, c2 = Component.from_arrays(ctx, hm, hpos, hvel), Component.from_arrays(ctx, dm, dpos, dvel)
+    del hpos, hvel, dpos, dvel
+    sim = Simulation(ctx, 4e-4, multistep=ms)
+    i1, i2 = sim.add_component(c1, f1), sim.add_component(c2, f2)
+    sim.add_interaction(i1, i2)
+    sim.add_interaction(i2, i1)
+    sim.init()
+    sim.step(2)
+    assert sim.step_switches > 0
+    for c, f, fresh in ((c1, f1, lambda: SphereSL(ctx, g, **kw)), (c2, f2, lambda: Cylinder(ctx, cg))):
+        lev = c.download_levels()
+        pop = np.bincount(lev, minlength=ms + 1)
+        assert pop.sum() == n and lev.max() <= ms and (pop > 0).sum() >= 3, pop
+        flat = lambda x: np.ravel(x) if isinstance(x, np.ndarray) else np.concatenate([np.ravel(y) for y in x])
+        total = np.sum([flat(f.get_coefs(level=M)) for M in range(ms + 1)], axis=0)
+        comb = flat(f.get_coefs())
+        cmax = np.abs(total).max()
+        assert np.abs(comb - total).max() <= 1e-12 * cmax
+        out = c.download(("mass", "pos"))
+        ff = fresh()
+        cc = Component.from_arrays(ctx, out["mass"], out["pos"])
+        ff.determine_coefficients(cc)
+        ref = flat(ff.get_coefs())
+        assert np.abs(total - ref).max() <= 1e-9 * cmax, (type(f).__name__, np.abs(total - ref).max() / cmax)
+        # Used() of a multistep force counts the first sub-step's accumulations (src/SphericalBasis.cc:797, 861),
+        # i.e. the positions one master step earlier: the same up to the few particles that crossed rmax since
+        assert abs(f.Used() - ff.Used()) <= 100
+        cc.close(); ff.close()
+    sim.close()
+    for o in (c1, c2, f1, f2):
+        o.close()
