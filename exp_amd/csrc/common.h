@@ -53,6 +53,9 @@ struct exp_amd_ctx {
   bool prekick = true;               // the fused step stores velocities with the NEXT step's opening half-kick applied
                                      // (exp_amd_ctx_set_prekick; EXP_AMD_PREKICK=0 sets the default off)
   bool deterministic = false;        // order-independent (bit-reproducible) coefficient sums, exp_amd_ctx_set_deterministic
+  long long mover_list_min = 2048;   // block multistep: from this many level changes in a sweep on, the differencing goes
+                                     // through the accumulation kernel over a list of the movers instead of per-particle
+                                     // atomics (EXP_AMD_MOVER_LIST_MIN; < 0: never)
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;

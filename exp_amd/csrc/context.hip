@@ -43,6 +43,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   ctx->device = device;
   if (const char *e = getenv("EXP_AMD_SPLIT_MIN")) ctx->split_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
+  if (const char *e = getenv("EXP_AMD_MOVER_LIST_MIN")) ctx->mover_list_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_DETERMINISTIC")) ctx->deterministic = atoi(e) != 0;
   if (const char *e = getenv("EXP_AMD_PREKICK")) ctx->prekick = atoi(e) != 0;
   HIP_TRY(ctx, hipSetDevice(device));
@@ -105,6 +106,13 @@ extern "C" int exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin)
 {
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->dense_min = nmin;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin)
+{
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->mover_list_min = nmin;
   return EXP_AMD_OK;
 }
 

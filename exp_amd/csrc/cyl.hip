@@ -203,14 +203,39 @@ extern "C" int exp_amd_debug_read(unsigned long long *out) { return (int)hipMemc
 extern "C" int exp_amd_debug_zero() { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_t), z, sizeof(z)); }
 #define TSTAMP() __builtin_readcyclecounter()
 #endif
+// LIST mode: the level-change differencing of MANY movers (multistep_update, src/CylEXP.cc:159-188) through this
+// kernel.  The particles are taken through a list of mover slots (k_mover_list: slot order, i.e. by (level, cell)
+// where the store is cell-sorted) and blockIdx.z selects what a launch slice adds: z = 0 subtracts every mover
+// from Wn[its level] (levels >= mfirst only), z = 1 + T adds the movers whose proposed level is T to Wn[T].  Runs
+// of equal (level, cell) are summed in registers as in the plain accumulation; window: on the table only.
+struct CylAccList {
+  const uint32_t *list;
+  const uint8_t *lev, *newlev;
+  int mfirst;
+};
+__device__ __forceinline__ void cyl_list_fetch(const CylAccList &al, const double *__restrict__ X,
+                                               const double *__restrict__ Y, const double *__restrict__ Z,
+                                               const double *__restrict__ M, double umass, size_t ip,
+                                               double &x, double &y, double &z, double &m, int &lv)
+{
+  const uint32_t j = al.list[ip];
+  const int fr = al.lev[j], to = al.newlev[j];
+  const int slice = blockIdx.z;
+  if (slice == 0) lv = fr >= al.mfirst ? fr : -1;
+  else lv = (to == slice - 1) ? to : -1;
+  x = X[j]; y = Y[j]; z = Z[j];
+  const double mm = umass != 0.0 ? umass : M[j];
+  m = slice == 0 ? -mm : mm;
+}
+
 // Wn[node][ntrig]: trig slot 0 = m0, 2m-1 = cos m, 2m = sin m
-template <int MMAX, bool DET>
+template <int MMAX, bool DET, bool LIST = false>
 __global__ void __launch_bounds__(CACC_WAVES * 64, CACC_OCC)
 k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, LevChunks LC,
                  double *__restrict__ Wn, double *__restrict__ tail,
-                 int multilevel /* Wn[level][node][ntrig] */)
+                 int multilevel /* Wn[level][node][ntrig] */, CylAccList al = CylAccList{})
 {
   // which level this block works on, and with which chunk size (block-uniform: scalar loop)
   int lj = 0;
@@ -252,14 +277,19 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
   // software prefetch: the loads of group k+1 are in flight while group k is reduced (two groups ahead
   // measured the same: the waves wait on their own dependent fp64 chains, not on these loads)
   double nx = 0, ny = 0, nz = 0, nm = 0;
+  int nlv = lvl;                            // LIST: per entry (< 0: not in this slice)
   const bool um = C.umass != 0.0;
-  if (cbeg + lane < cend) { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? C.umass : M[cbeg + lane]; }
+  if (cbeg + lane < cend) {
+    if constexpr (LIST) cyl_list_fetch(al, X, Y, Z, M, C.umass, cbeg + lane, nx, ny, nz, nm, nlv);
+    else { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? C.umass : M[cbeg + lane]; }
+  }
 #ifdef EXPT_TIMING
   unsigned long long t_load = 0, t_prep = 0, t_red = 0, t_fl = 0, t_fld = 0, t_nfl = 0, t_all0 = TSTAMP();
 #endif
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const bool valid = i < cend;
+    const bool valid = LIST ? (i < cend && nlv >= 0) : i < cend;
+    const int plv = LIST ? nlv : lvl;
     double xx = 1, yy = 0, zz = 0, mass = 0;
 #ifdef EXPT_TIMING
     const unsigned long long ta = TSTAMP();
@@ -271,13 +301,16 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
       cyl_local(C, nx, ny, nz, xx, yy, zz);
       mass = nm;
     }
-    if (i + 64 < cend) { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? C.umass : M[i + 64]; }
-    // src/Cylinder.cc:853-866
+    if (i + 64 < cend) {
+      if constexpr (LIST) cyl_list_fetch(al, X, Y, Z, M, C.umass, i + 64, nx, ny, nz, nm, nlv);
+      else { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? C.umass : M[i + 64]; }
+    }
+    // src/Cylinder.cc:853-866 (the differencing has no rcylmax cut and counts nothing: src/CylEXP.cc:159-188)
     const double r2 = xx * xx + yy * yy;
     double r, ir, rr, irr;
     sqrt_rsqrt(r2, r, ir);
-    const bool incut = valid && (r2 + zz * zz) < C.rmax2;
-    if (incut) { mass_used += cdet_round(mass, C.detCm); n_used += 1.0; }
+    const bool incut = LIST ? valid : (valid && (r2 + zz * zz) < C.rmax2);
+    if (!LIST && incut) { mass_used += cdet_round(mass, C.detCm); n_used += 1.0; }
     // EmpCylSL::accumulate (:4062-4063)
     sqrt_rsqrt(r2 + zz * zz, rr, irr);
     const bool ongrid = incut && !(rr > C.rtab_abs);
@@ -287,7 +320,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     int ix, iy;
     double c00, c10, c01, c11;
     cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
-    const int cell = ix * C.numy + iy + lvl * ncellT;
+    const int cell = ix * C.numy + iy + plv * ncellT;
     double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
     if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
     const double t0 = ongrid ? norm * mass : 0.0;
@@ -372,17 +405,27 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
                    const double *__restrict__ Z, const double *__restrict__ M,
                    const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
                    const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
-                   double *__restrict__ Wnd, int plain, double *__restrict__ tail)
+                   double *__restrict__ Wnd, int plain, double *__restrict__ tail,
+                   const uint32_t *__restrict__ list = nullptr /* slots of the movers (k_mover_list; lev_off = {0, count}) */,
+                   unsigned spread = 1)
 {
   // plain != 0: every particle of the range adds its contribution to Wnd[its level] -- the accumulation
   // of SPARSE multistep levels, which are not cell-sorted (Cylinder's rcylmax cut, the in-cut mass /
   // count and EmpCylSL::accumulate's grid window, src/Cylinder.cc:853-866, exputil/EmpCylSL.cc:4062)
   constexpr int NT = 2 * MMAX + 1;
-  const size_t beg = lev_off[first], end = lev_off[last + 1];
-  const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t i = 0;
+  bool have = false;
+  if (list) {
+    // few movers: one per `spread` lanes, so that their (serial, latency-bound) atomics come from more waves
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, g = t / spread;
+    if (t % spread == 0 && g < lev_off[1]) { i = list[g]; have = true; }
+  } else {
+    i = lev_off[first] + (size_t)blockIdx.x * 256 + threadIdx.x;
+    have = i < lev_off[last + 1];
+  }
   bool mover = false;
   int from = 0, to = 0;
-  if (i < end) {
+  if (have) {
     from = lev[i];
     to = plain ? from : newlev[i];
     mover = plain || from != to;
@@ -996,13 +1039,43 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   const CylDev C = cdev_acc(f, c);
   size_t nr = 0;
   if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
-  if (nr) {
+  // the step driver knows how many particles change level (c->mover_hint): their slots are compacted first
+  // (k_mover_list, 16 slots per thread), so that the differencing launches over the movers, not over the range
+  const bool listed = nr && c->mover_hint >= 0;
+  if (listed && c->mover_hint > 0) { int rc_ = expamd_comp_mover_list(c, first, ms, (size_t)c->mover_hint); if (rc_) return rc_; }
+  if (listed && c->mover_hint == 0) {
+    // nothing moved on this rank (it only takes part in the reduction)
+  } else if (listed && ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min) {
+    // many movers: through the accumulation kernel (CylAccList)
     ProfScope ps(ctx, "k_cyl_mstep_update");
-    const unsigned grid = cdiv(nr, 256);
+    const size_t nm = (size_t)c->mover_hint;
+    LevChunks LC;
+    LC.lo = 0; LC.nlev = 1;
+    size_t chunk = (nm / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
+    chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
+    LC.bstart[0] = 0;
+    LC.chunk[0] = (int)chunk;
+    LC.bstart[1] = cdiv(nm, (size_t)CACC_WAVES * chunk);
+    const dim3 grid(LC.bstart[1], 1, ms + 2);
+    const CylAccList al{c->mover_list.p, c->level[c->cur].p, c->newlev.p, mfirst_mdrft};
+#define CALL(MM)                                                                                 \
+  if (C.detC != 0.0)                                                                             \
+    k_cyl_accumulate<MM, true, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                 \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt.p, LC, f->d_Wnd.p, nullptr, 1, al); \
+  else                                                                                           \
+    k_cyl_accumulate<MM, false, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt.p, LC, f->d_Wnd.p, nullptr, 1, al)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+  } else if (nr) {
+    ProfScope ps(ctx, "k_cyl_mstep_update");
+    const unsigned spread = listed ? expamd_mover_spread((size_t)c->mover_hint) : 1u;
+    const unsigned grid = cdiv(listed ? (size_t)c->mover_hint * spread : nr, 256);
+    const uint32_t *lo_ = listed ? c->mover_cnt.p : c->lev_off.p, *li_ = listed ? c->mover_list.p : nullptr;
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
-      c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wnd.p, 0, nullptr)
+      lo_, first, ms, mfirst_mdrft, f->d_Wnd.p, 0, nullptr, li_, spread)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }

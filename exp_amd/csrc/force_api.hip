@@ -219,7 +219,10 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   if (nswitch) *nswitch = (long long)u;
   if (ctx->nranks > 1 || ctx->ar_fn || u) {
     // (collective: with several ranks every rank takes part even if it has no mover)
-    if ((rc = f->multistep_update(c, first, mfirst))) return rc;
+    c->mover_hint = (long long)u;
+    rc = f->multistep_update(c, first, mfirst);
+    c->mover_hint = -1;
+    if (rc) return rc;
   }
   if (u) {
     // only slots of levels >= first can have changed level; if the store was in this force's order

@@ -361,8 +361,10 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     s->last_switch += (long long)u;
     s->step_switch += (long long)u;
     // (collective: with several ranks every rank takes part even if it has no mover)
+    c->mover_hint = (long long)u;
     if (ctx->nranks > 1 || ctx->ar_fn || u)
       if ((rc = f->multistep_update(c, first, mf))) return rc;
+    c->mover_hint = -1;
     if (u) {
       const bool ordered = c->sorted_for == (const void *)f && c->nlevels == ms + 1;
       const bool mirror = ordered && c->lev_host_valid;

@@ -28,6 +28,10 @@ struct exp_amd_comp {
   DevBuf<uint8_t> newlev;            // level chosen by the last adjust_multistep_level sweep
   DevBuf<unsigned long long> nswitch; // counters of the level sweeps: two alternating sets [32] + one word
   int nsw_flip = 0;
+  // Level-change differencing of many movers (force methods' multistep_update): the step driver leaves the number of
+  // level changes of the last sweep here (< 0: unknown), expamd_comp_mover_list compacts their slots
+  long long mover_hint = -1;
+  DevBuf<uint32_t> mover_list, mover_cnt;     // slots of the movers; {0, how many}: plays lev_off for the kernels
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
@@ -100,6 +104,17 @@ void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);
 void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh);
 // kick DT(M)/2 + drift DT(M) in place for the levels [lo, hi] (no reorder): sparse levels
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep);
+
+// slots of the particles of levels [first, last] whose proposed level (newlev) differs from their level, in slot order
+// within blocks of 256 slots: c->mover_list, c->mover_cnt = {0, count}; capacity = the expected count
+int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected);
+// lanes per mover of the per-mover atomics kernels: enough waves (~2048) to hide the atomics' latency
+inline unsigned expamd_mover_spread(size_t movers)
+{
+  unsigned s = 1;
+  while (s < 16 && movers * s < 131072) s <<= 1;
+  return s;
+}
 
 // number of particles in levels [lo, hi] (refreshes the host mirror of lev_off when stale)
 int expamd_comp_level_count(exp_amd_comp *c, int lo, int hi, size_t *count);

@@ -649,6 +649,76 @@ int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg)
   return EXP_AMD_OK;
 }
 
+// Compaction of the movers (level != proposed level) of the slot range of levels [first, last].  Order-preserving
+// inside a block of 256 x ML_ITEMS slots (per-thread bit masks + a block-level prefix); the blocks claim their stretch
+// of the list with one atomic, in any order -- long stretches, so that where movers are dense (the case this list is
+// for) a 64-entry group of the consumer still sees the (level, cell) runs of the store.  cnt = {0, count}.
+#define ML_ITEMS 16
+__global__ void __launch_bounds__(256)
+k_mover_list(const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
+             const uint32_t *__restrict__ lev_off, int first, int last, uint32_t *__restrict__ list,
+             uint32_t cap, uint32_t *__restrict__ cnt)
+{
+  __shared__ uint32_t wsum[4], base;
+  const size_t beg = lev_off[first], end = lev_off[last + 1];
+  const size_t abeg = beg & ~(size_t)(ML_ITEMS - 1);          // 16-byte aligned reads
+  const size_t s0 = abeg + ((size_t)blockIdx.x * 256 + threadIdx.x) * ML_ITEMS;
+  uint32_t mask = 0;                                           // bit k: slot s0 + k is a mover
+  if (s0 >= beg && s0 + ML_ITEMS <= end) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(lev + s0), b = *reinterpret_cast<const uint4 *>(newlev + s0);
+    const uint32_t d[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+#pragma unroll
+    for (int k = 0; k < ML_ITEMS; k++) if ((d[k >> 2] >> (8 * (k & 3))) & 0xffu) mask |= 1u << k;
+  } else if (s0 < end) {
+    for (int k = 0; k < ML_ITEMS; k++) {
+      const size_t i = s0 + k;
+      if (i >= beg && i < end && lev[i] != newlev[i]) mask |= 1u << k;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t mine = (uint32_t)__popc(mask);
+  uint32_t incl = mine;                                        // inclusive prefix over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    base = tot ? atomicAdd(cnt + 1, tot) : 0u;
+  }
+  __syncthreads();
+  if (mask) {
+    uint32_t o = base + incl - mine;
+    for (int w = 0; w < wave; w++) o += wsum[w];
+    for (uint32_t m = mask; m; m &= m - 1u) {
+      if (o < cap) list[o] = (uint32_t)(s0 + (size_t)(__ffs((int)m) - 1));
+      o++;
+    }
+  }
+}
+
+int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->mover_cnt.n == 0) HIP_TRY(ctx, c->mover_cnt.alloc(2));
+  if (c->mover_list.n < expected) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->mover_list.release();
+    HIP_TRY(ctx, c->mover_list.alloc(expected + expected / 4 + 1024));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(c->mover_cnt.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+  size_t nr = 0;
+  if (c->n) { int rc = expamd_comp_level_count(c, first, last, &nr); if (rc) return rc; }
+  if (nr == 0) return EXP_AMD_OK;
+  k_mover_list<<<cdiv(nr + ML_ITEMS, (size_t)256 * ML_ITEMS), 256, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, last,
+                                                               c->mover_list.p, (uint32_t)c->mover_list.n, c->mover_cnt.p);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
 // launches k_kick_adjust; *result receives the device address of this launch's counter set
 // (u64[32]: level changes, then the proposals per level)
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,

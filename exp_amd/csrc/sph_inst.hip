@@ -41,6 +41,17 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   LC.bstart[LC.nlev] = nb;
   if (nb == 0) return;
   dim3 grid(nb, (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
+  if (a.list) {             // level-change differencing through the list of movers
+    grid.z = a.nslices;
+    const AccList al{a.list, a.lev, a.newlev, a.mfirst, a.S.numr - 1};
+    if (a.S.detC != 0.0)
+      k_sph_accumulate<LMAX, true, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                              LC, a.W, a.used, a.wlevels, al);
+    else
+      k_sph_accumulate<LMAX, false, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                               LC, a.W, a.used, a.wlevels, al);
+    return;
+  }
   if (a.S.detC != 0.0)      // deterministic mode (exp_amd_ctx_set_deterministic): order-independent sums
     k_sph_accumulate<LMAX, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
                                                                         LC, a.W, a.used, a.wlevels);
@@ -81,6 +92,7 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 
 void CAT(expamd_sph_upd_L, SPH_L)(const SphUpdArgs &a)
 {
-  k_sph_mstep_update<SPH_L><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
-      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used);
+  k_sph_mstep_update<SPH_L><<<cdiv(a.n * a.spread, 256), 256, 0, a.stream>>>(
+      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used, a.list,
+      a.spread);
 }

@@ -313,6 +313,35 @@ struct LevChunks {
 #endif
 #define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
 
+// LIST mode of the accumulation kernel: the level-change differencing of MANY movers (multistep_update,
+// src/SphericalBasis.cc:1156-1228).  The particles are taken through a list of mover slots (k_mover_list: in
+// slot order, i.e. by (level, cell) where the store is cell-sorted) and blockIdx.z selects what a launch slice
+// adds: z = 0 subtracts every mover from W[its level] (levels >= mfirst only), z = 1 + T adds the movers whose
+// proposed level is T to W[T].  Within a slice the runs of equal (level, cell) accumulate in registers exactly as
+// in the plain accumulation -- one flush per run instead of 4 (L+1)^2 same-address atomics per mover.
+struct AccList {
+  const uint32_t *list;
+  const uint8_t *lev, *newlev;
+  int mfirst, numr1;            // numr1 = numr - 1: cells per level of W
+};
+// one list entry: position, signed mass and the level offset of its W cell (ca < 0: not in this slice)
+__device__ __forceinline__ void acc_list_fetch(const AccList &al, const double *__restrict__ X,
+                                               const double *__restrict__ Y, const double *__restrict__ Z,
+                                               const double *__restrict__ M, double umass, size_t ip,
+                                               double &x, double &y, double &z, double &m, int &ca)
+{
+  const uint32_t j = al.list[ip];
+  const int fr = al.lev[j], to = al.newlev[j];
+  const int slice = blockIdx.z;
+  int lv;
+  if (slice == 0) lv = fr >= al.mfirst ? fr : -1;
+  else lv = (to == slice - 1) ? to : -1;
+  ca = lv < 0 ? -1 : lv * al.numr1;
+  x = X[j]; y = Y[j]; z = Z[j];
+  const double mm = umass != 0.0 ? umass : M[j];
+  m = slice == 0 ? -mm : mm;
+}
+
 // Per-particle inputs of the moment accumulation: everything that does not depend on (l, m).
 struct AccIn {
   double costh, sinth, cphi, sphi, a1, a2;   // a1 = -4pi m P0 x1, a2 = -4pi m P0 x2 (0 outside the window)
@@ -328,6 +357,8 @@ struct AccIn {
 typedef const __attribute__((address_space(3))) double *ldp;
 // cell_add: level * (numr-1) when several levels are accumulated in one launch (the moment buffer is
 // then W[level][cell][row][2] and the wave's "current cell" the combined index), else 0.
+// UPD: the window of the differencing, r < rmax (src/SphericalBasis.cc:1183), instead of rmin <= r <= rmax.
+template <bool UPD = false>
 __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double px,
                                                double py, double pz, double mass, bool valid,
                                                int cell_add = 0)
@@ -340,7 +371,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   double g, y;
   sqrt_rsqrt(R2 + zz * zz, g, y);
   const double r = g + S.dsmall;
-  const bool inwin = valid && r >= S.rmin && r <= S.rmax;
+  const bool inwin = UPD ? (valid && r < S.rmax) : (valid && r >= S.rmin && r <= S.rmax);
   const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
   if (R2 > 1e-12 * (r * r)) {
@@ -476,13 +507,13 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
 
 // One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend), computing
 // the per-particle inputs itself.
-template <int LMAX, int MLO, int MHI, bool DET>
+template <int LMAX, int MLO, int MHI, bool DET, bool LIST>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                     const double *__restrict__ Z, const double *__restrict__ M,
                     int cell_add, size_t cbeg,
                     size_t cend, double *scratch, double *__restrict__ W,
-                    unsigned long long *__restrict__ used_out)
+                    unsigned long long *__restrict__ used_out, const AccList &al)
 {
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
@@ -496,15 +527,19 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
 
   // software prefetch: the loads of group k+1 are in flight while group k is reduced
   double nx = 0, ny = 0, nz = 0, nm = 0;
+  int nca = cell_add;                       // LIST: per entry (< 0: not in this slice)
   const bool um = S.umass != 0.0;
   if (cbeg + lane < cend) {
-    nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? S.umass : M[cbeg + lane];
+    if constexpr (LIST) acc_list_fetch(al, X, Y, Z, M, S.umass, cbeg + lane, nx, ny, nz, nm, nca);
+    else { nx = X[cbeg + lane]; ny = Y[cbeg + lane]; nz = Z[cbeg + lane]; nm = um ? S.umass : M[cbeg + lane]; }
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const AccIn in = sph_acc_input(S, (ldp) nullptr, nx, ny, nz, nm, i < cend, cell_add);
+    const AccIn in = sph_acc_input<LIST>(S, (ldp) nullptr, nx, ny, nz, nm, LIST ? (i < cend && nca >= 0) : i < cend,
+                                         LIST ? nca : cell_add);
     if (i + 64 < cend) {
-      nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? S.umass : M[i + 64];
+      if constexpr (LIST) acc_list_fetch(al, X, Y, Z, M, S.umass, i + 64, nx, ny, nz, nm, nca);
+      else { nx = X[i + 64]; ny = Y[i + 64]; nz = Z[i + 64]; nm = um ? S.umass : M[i + 64]; }
     }
     if (MLO == 0 && in.idx >= 0) used++;
     sph_acc_group<LMAX, MLO, MHI, NV, DET>(S, lc, in, acc, cur, scratch, W);
@@ -527,13 +562,14 @@ struct AccShared {
   unsigned long long used[ACC_WAVES];      // in-window counts of the four quarters, handed over at the last tile
 };
 
-template <int LMAX, int MLO, int MHI, bool DET>
+template <int LMAX, int MLO, int MHI, bool DET, bool LIST>
 __device__ __forceinline__ void
 sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
                       const double *__restrict__ Y, const double *__restrict__ Z,
                       const double *__restrict__ M, int cell_add, size_t cbeg,
                       size_t cend, double *scratch,
-                      AccShared &sh, double *__restrict__ W, unsigned long long *__restrict__ used_out)
+                      AccShared &sh, double *__restrict__ W, unsigned long long *__restrict__ used_out,
+                      const AccList &al)
 {
   constexpr int NACC = acc_base(LMAX, MLO, MHI + 1);
   constexpr int NV = 2 * NACC;
@@ -548,8 +584,12 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 
   size_t ip = cbeg + (size_t)wave * 64 + lane;
   double nx = 0, ny = 0, nz = 0, nm = 0;
+  int nca = cell_add;                       // LIST: per entry (< 0: not in this slice)
   const bool um = S.umass != 0.0;
-  if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
+  if (ip < cend) {
+    if constexpr (LIST) acc_list_fetch(al, X, Y, Z, M, S.umass, ip, nx, ny, nz, nm, nca);
+    else { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
+  }
   int par = 0;
 #ifdef EXPT_TIMING
   unsigned long long t_load = 0, t_in = 0, t_bar = 0, t_red = 0, t_all0 = __builtin_readcyclecounter();
@@ -562,7 +602,8 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     t_load += tb - ta;
 #endif
     {
-      const AccIn in = sph_acc_input(S, p0t, nx, ny, nz, nm, ip < cend, cell_add);
+      const AccIn in = sph_acc_input<LIST>(S, p0t, nx, ny, nz, nm, LIST ? (ip < cend && nca >= 0) : ip < cend,
+                                           LIST ? nca : cell_add);
       if (in.idx >= 0) used++;
       const int q = wave * 64 + lane;
       sh.v[par][0][q] = in.costh; sh.v[par][1][q] = in.cphi; sh.v[par][2][q] = in.sphi;
@@ -593,7 +634,10 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced
     ip += TILE;
-    if (ip < cend) { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
+    if (ip < cend) {
+      if constexpr (LIST) acc_list_fetch(al, X, Y, Z, M, S.umass, ip, nx, ny, nz, nm, nca);
+      else { nx = X[ip]; ny = Y[ip]; nz = Z[ip]; nm = um ? S.umass : M[ip]; }
+    }
 #pragma unroll 1
     for (int sub = 0; sub < ACC_WAVES; sub++) {
       if (tbase + (size_t)sub * 64 >= cend) break;
@@ -640,13 +684,13 @@ template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
   return acc_shared<LMAX>() ? 4 : LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
 }
 
-template <int LMAX, bool DET>
+template <int LMAX, bool DET, bool LIST = false>
 __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
                  const uint32_t *__restrict__ lev_off, LevChunks LC,
                  double *__restrict__ W, unsigned long long *__restrict__ used_out,
-                 int multilevel /* W[level][cell][row][2] */)
+                 int multilevel /* W[level][cell][row][2] */, AccList al = AccList{})
 {
   constexpr int NS = acc_nsplit<LMAX>();
   // which level this block works on, and with which chunk size (block-uniform: scalar loop)
@@ -677,7 +721,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
       __syncthreads();
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out)
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET, LIST>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out, al)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
     if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
     else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
@@ -690,7 +734,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const size_t cbeg = beg + chunk * ACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI, DET>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out)
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI, DET, LIST>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out, al)
   if constexpr (LMAX <= 4) {
     RUN(0, LMAX);
   } else if constexpr (LMAX <= 7) {
@@ -720,13 +764,23 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
                    const double *__restrict__ Z, const double *__restrict__ M,
                    const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
                    const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
-                   double *__restrict__ Wd, int plain, unsigned long long *__restrict__ used_out)
+                   double *__restrict__ Wd, int plain, unsigned long long *__restrict__ used_out,
+                   const uint32_t *__restrict__ list /* slots of the movers (k_mover_list; lev_off = {0, count}) or null */,
+                   unsigned spread)
 {
-  const size_t beg = lev_off[first], end = lev_off[last + 1];
-  const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t i = 0;
+  bool have = false;
+  if (list) {
+    // few movers: one per `spread` lanes, so that their (serial, latency-bound) atomics come from more waves
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, g = t / spread;
+    if (t % spread == 0 && g < lev_off[1]) { i = list[g]; have = true; }
+  } else {
+    i = lev_off[first] + (size_t)blockIdx.x * 256 + threadIdx.x;
+    have = i < lev_off[last + 1];
+  }
   bool mover = false;
   int from = 0, to = 0;
-  if (i < end) {
+  if (have) {
     from = lev[i];
     to = plain ? from : newlev[i];
     mover = plain || from != to;
@@ -1344,6 +1398,10 @@ struct SphAccArgs {
   int multilevel;           // the range is one level of many (short chunks allowed)
   const uint32_t *counts = nullptr;   // ... else counts[j] = population of level lo + j
   int wlevels = 0;          // 1: W[level][cell][row][2] (one moment buffer per level)
+  // LIST mode (level-change differencing of many movers): lev_off -> {0, list length}, n = the host's count
+  const uint32_t *list = nullptr;
+  const uint8_t *lev = nullptr, *newlev = nullptr;
+  int mfirst = 0, nslices = 1;        // nslices = multistep + 2 (AccList)
 };
 
 struct SphForceArgs {
@@ -1380,6 +1438,8 @@ struct SphUpdArgs {
   hipStream_t stream;
   int plain = 0;                        // 1: accumulate every particle of the range into Wd[its level]
   unsigned long long *used = nullptr;   // ... and count those inside the window
+  const uint32_t *list = nullptr;       // slots of the movers: lev_off = {0, count}, n = the expected count
+  unsigned spread = 1;                  // ... one mover per `spread` lanes
 };
 
 typedef void (*sph_upd_launcher)(const SphUpdArgs &);

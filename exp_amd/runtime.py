@@ -93,6 +93,11 @@ class Context:
         """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
         check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)
 
+    def set_mover_list_min(self, nmin: int) -> None:
+        """Block multistep: from this many level changes in a sweep on, the coefficient differencing runs the list of
+        movers through the accumulation kernels instead of per-particle atomics (0: always, < 0: never)."""
+        check(self.lib.exp_amd_ctx_set_mover_list_min(self.h, int(nmin)), self.h)
+
     def set_split_min(self, nmin: int) -> None:
         """Smallest component the fused step handles as two overlapped halves (<= 0: never)."""
         check(self.lib.exp_amd_ctx_set_split_min(self.h, int(nmin)), self.h)

@@ -86,6 +86,14 @@ int  exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on);
  * break-even (about 3e6 / moments per particle: ~30000 for lmax 6, ~58000 for mmax 6);
  * 0: every level is cell-sorted.                                                                  */
 int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
+/* Second knob of the same loop: how the coefficient sets are differenced when particles change level
+ * (multistep_update, src/SphericalBasis.cc:1156-1228, src/CylEXP.cc:159-188).  The slots of the movers of a
+ * sweep are compacted into a list; below `nmin` movers each adds and subtracts its own contribution with
+ * fp64 atomics, from `nmin` on the list goes through the accumulation kernels, which sum runs of equal
+ * (level, cell) in registers (the first sweeps of a run move several per cent of a component at once).
+ * Same results up to rounding (each way is order-independent in deterministic mode).  Default 2048
+ * (EXP_AMD_MOVER_LIST_MIN overrides); 0: always the accumulation kernels; < 0: never.                */
+int  exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin);
 void *exp_amd_ctx_stream(exp_amd_ctx *ctx);
 
 /* Coefficient all-reduce across ranks.  Replaces the MPI_Allreduce calls of

@@ -66,12 +66,15 @@ def _compare(tag, forces, comps, want, multistep):
             assert np.abs(gl - cL[M]).max() <= 1e-10 * cmax, (tag, name, M, "L")
 
 
-@pytest.mark.parametrize("dense_min", [-1, 0, 100])
-def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min):
+@pytest.mark.parametrize("dense_min,list_min", [(-1, 2048), (0, 2048), (100, 2048), (0, 0), (100, 0), (-1, 16)])
+def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min):
     """dense_min: the level population below which a level is kept unsorted (runtime.Context.
     set_dense_min): the default (-1) makes every level of this small run sparse, 0 makes all of them
-    cell-sorted, 100 mixes the two paths."""
+    cell-sorted, 100 mixes the two paths.  list_min: the number of level changes in a sweep from which the
+    differencing runs the list of movers through the accumulation kernels (set_mover_list_min; 2048 = the
+    default: per-mover atomics throughout this small run, 0: always the accumulation kernels, 16: both)."""
     ctx.set_dense_min(dense_min)
+    ctx.set_mover_list_min(list_min)
     z = c4.load_golden()
     ms, dtime, dyn = c4.MULTISTEP, c4.DTIME, c4.DYN
     nb, _ = c4.oracle_run(oracle, z, nsteps=0)
@@ -102,6 +105,7 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min):
         assert (np.bincount(want(name, "level"), minlength=ms + 1) >= 30).sum() >= 4
     assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
     ctx.set_dense_min(-1)
+    ctx.set_mover_list_min(2048)
 
 
 def test_config4_against_the_golden_file(ctx):

@@ -1,7 +1,7 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_cfg4
-mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+OUT=$REPO/gpurun_out/prof_cfg4${1:+_$1}
+rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/tools/bench_configs.py --only 4 --steps 40 > $OUT/log.txt 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
