@@ -212,6 +212,7 @@ struct CylAccList {
   const uint32_t *list;
   const uint8_t *lev, *newlev;
   int mfirst;
+  int per_level;                // 1: one adding slice per proposed level (z = 1 + T); 0: ONE adding slice (z = 1)
 };
 __device__ __forceinline__ void cyl_list_fetch(const CylAccList &al, const double *__restrict__ X,
                                                const double *__restrict__ Y, const double *__restrict__ Z,
@@ -222,7 +223,7 @@ __device__ __forceinline__ void cyl_list_fetch(const CylAccList &al, const doubl
   const int fr = al.lev[j], to = al.newlev[j];
   const int slice = blockIdx.z;
   if (slice == 0) lv = fr >= al.mfirst ? fr : -1;
-  else lv = (to == slice - 1) ? to : -1;
+  else lv = (!al.per_level || to == slice - 1) ? to : -1;
   x = X[j]; y = Y[j]; z = Z[j];
   const double mm = umass != 0.0 ? umass : M[j];
   m = slice == 0 ? -mm : mm;
@@ -1056,8 +1057,9 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     LC.bstart[0] = 0;
     LC.chunk[0] = (int)chunk;
     LC.bstart[1] = cdiv(nm, (size_t)CACC_WAVES * chunk);
-    const dim3 grid(LC.bstart[1], 1, ms + 2);
-    const CylAccList al{c->mover_list.p, c->level[c->cur].p, c->newlev.p, mfirst_mdrft};
+    const int per_level = c->mover_hint >= ctx->mover_slices_min ? 1 : 0;
+    const dim3 grid(LC.bstart[1], 1, per_level ? ms + 2 : 2);
+    const CylAccList al{c->mover_list.p, c->level[c->cur].p, c->newlev.p, mfirst_mdrft, per_level};
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
     k_cyl_accumulate<MM, true, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                 \

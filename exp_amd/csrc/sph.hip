@@ -379,6 +379,25 @@ static const sph_force_launcher k_force_launch[SPH_MAX_L + 1] = {
     expamd_sph_force_L8, expamd_sph_force_L9, expamd_sph_force_L10, expamd_sph_force_L11,
     expamd_sph_force_L12};
 
+// staging buffers of the per-particle atomic path (k_sph_mstep_update<L, true> + k_mstep_apply) for up to
+// SPH_STAGE_MAX particles; beyond that the launch keeps its own atomics
+static int sph_stage(SphForce *f, size_t np, SphUpdArgs &a)
+{
+  exp_amd_ctx *ctx = f->ctx;
+  if (np == 0 || np > SPH_STAGE_MAX) return EXP_AMD_OK;
+  const size_t nval = (size_t)f->dev.nrows * 2;
+  if (f->d_stage.n < np * nval) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    f->d_stage.release(); f->d_stage_keys.release();
+    const size_t cap = np < 4096 ? 4096 : np + np / 2;
+    HIP_TRY(ctx, f->d_stage.alloc(cap * nval));
+    HIP_TRY(ctx, f->d_stage_keys.alloc(cap * 2));
+  }
+  a.stage = f->d_stage.p;
+  a.keys = reinterpret_cast<int2 *>(f->d_stage_keys.p);
+  return EXP_AMD_OK;
+}
+
 static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
 {
   exp_amd_ctx *ctx = f->ctx;
@@ -507,6 +526,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     ProfScope ps(ctx, "k_sph_accumulate_sparse");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,
                  c->lev_off.p, dacc + 1, ms, 0, f->d_W.p, nrange, ctx->stream, 1, used_p};
+    if ((rc = sph_stage(f, nrange, a))) return rc;
     k_upd_launch[cfg.lmax](a);
   }
   {
@@ -800,14 +820,19 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     a.lev = c->level[c->cur].p;
     a.newlev = c->newlev.p;
     a.mfirst = mfirst_mdrft;
-    a.nslices = ms + 2;
+    a.nslices = c->mover_hint >= ctx->mover_slices_min ? ms + 2 : 2;
     k_acc_launch[cfg.lmax](a);
   } else if (nr) {
     ProfScope ps(ctx, "k_sph_mstep_update");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
                  listed ? c->mover_cnt.p : c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p,
                  listed ? (size_t)c->mover_hint : nr, ctx->stream};
-    if (listed) { a.list = c->mover_list.p; a.spread = expamd_mover_spread((size_t)c->mover_hint); }
+    if (listed) {
+      a.list = c->mover_list.p;
+      // few movers: staged (values by plain stores, then one lane per value: see k_sph_mstep_update)
+      int rc_ = sph_stage(f, (size_t)c->mover_hint, a);
+      if (rc_) return rc_;
+    }
     k_upd_launch[cfg.lmax](a);
   }
   // moments -> coefficient differences, all levels in one launch

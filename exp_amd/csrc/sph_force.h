@@ -3,6 +3,7 @@
 #include "sph_kernels.h"
 #include "force.h"
 
+#define SPH_STAGE_MAX 65536          // movers up to which the per-mover differencing is staged
 struct SphForce : exp_amd_force {
   exp_amd_sph_config cfg{};
   SphDev dev{};
@@ -11,6 +12,8 @@ struct SphForce : exp_amd_force {
   DevBuf<int> d_rowmap;
   DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
   DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level
+  DevBuf<double> d_stage;            // staged differencing of few movers: values [mover][nrows][2] ...
+  DevBuf<int> d_stage_keys;          // ... and their two W offsets (k_sph_mstep_update<L, true>, k_mstep_apply)
   DevBuf<double> d_ev, d_d0, d_Gd;  // field evaluation (pyEXP getFields): ev[l][n], d0[numr], Gd[numr][rows]
   void *cov = nullptr;              // sub-sample covariance state (sph_cov.hip), analysis only
   DevBuf<uint32_t> d_work;          // slow-path work list of the force pass + count (last slot)

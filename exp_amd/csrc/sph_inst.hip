@@ -43,7 +43,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   dim3 grid(nb, (NS > ACC_WAVES) ? cdiv(NS, ACC_WAVES) : 1);
   if (a.list) {             // level-change differencing through the list of movers
     grid.z = a.nslices;
-    const AccList al{a.list, a.lev, a.newlev, a.mfirst, a.S.numr - 1};
+    const AccList al{a.list, a.lev, a.newlev, a.mfirst, a.S.numr - 1, a.nslices > 2 ? 1 : 0};
     if (a.S.detC != 0.0)
       k_sph_accumulate<LMAX, true, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
                                                                               LC, a.W, a.used, a.wlevels, al);
@@ -92,7 +92,15 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 
 void CAT(expamd_sph_upd_L, SPH_L)(const SphUpdArgs &a)
 {
-  k_sph_mstep_update<SPH_L><<<cdiv(a.n * a.spread, 256), 256, 0, a.stream>>>(
-      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used, a.list,
-      a.spread);
+  if (a.stage) {
+    k_sph_mstep_update<SPH_L, true><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used, a.list,
+        a.stage, a.keys);
+    const int nval = a.S.nrows * 2;
+    k_mstep_apply<><<<cdiv(a.n * (size_t)nval, 256), 256, 0, a.stream>>>(a.stage, a.keys, a.list ? a.lev_off : nullptr,
+                                                                        (uint32_t)a.n, nval, a.Wd);
+    return;
+  }
+  k_sph_mstep_update<SPH_L><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
+      a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used, a.list);
 }

@@ -323,6 +323,8 @@ struct AccList {
   const uint32_t *list;
   const uint8_t *lev, *newlev;
   int mfirst, numr1;            // numr1 = numr - 1: cells per level of W
+  int per_level;                // 1: one adding slice per proposed level (z = 1 + T); 0: ONE adding slice (z = 1) whose
+                                // runs are the runs of equal (proposed level, cell) -- fewer passes, more flushes
 };
 // one list entry: position, signed mass and the level offset of its W cell (ca < 0: not in this slice)
 __device__ __forceinline__ void acc_list_fetch(const AccList &al, const double *__restrict__ X,
@@ -335,7 +337,7 @@ __device__ __forceinline__ void acc_list_fetch(const AccList &al, const double *
   const int slice = blockIdx.z;
   int lv;
   if (slice == 0) lv = fr >= al.mfirst ? fr : -1;
-  else lv = (to == slice - 1) ? to : -1;
+  else lv = (!al.per_level || to == slice - 1) ? to : -1;
   ca = lv < 0 ? -1 : lv * al.numr1;
   x = X[j]; y = Y[j]; z = Z[j];
   const double mm = umass != 0.0 ? umass : M[j];
@@ -715,7 +717,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     const size_t cbeg = beg + (size_t)bx * ACC_CHUNK;
     if (cbeg >= end) return;
     const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-    const bool p0_in_lds = S.numr <= ACC_P0_LDS;
+    const bool p0_in_lds = !LIST && S.numr <= ACC_P0_LDS;     // (short LIST launches: not worth the fill)
     if (p0_in_lds) {
       for (int k = threadIdx.x; k < S.numr; k += ACC_WAVES * 64) p0s[k] = S.p0[k];
       __syncthreads();
@@ -758,7 +760,11 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
 // rmin <= r <= rmax and the used count of determine_coefficients_thread, src/SphericalBasis.cc:
 // 486-494).  Each contributing lane issues its own fp64 atomics; waves without one leave at once.
 // Wd[level][cell][row][2].
-template <int LMAX>
+// STAGED (few movers, through the list): an atomic INSTRUCTION costs a wave ~65 ns whatever its lane count
+// (tools/dbg/atomic_chain.hip), so a wave of this kernel with a handful of movers spends 50 us on its
+// 8 (L+1)^2 of them.  Staged, the lanes write their values to stage[mover][row][2] with plain stores and their
+// two W offsets to keys[mover]; k_mstep_apply then adds them with one lane per VALUE (64 values an instruction).
+template <int LMAX, bool STAGED = false>
 __global__ void __launch_bounds__(256)
 k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                    const double *__restrict__ Z, const double *__restrict__ M,
@@ -766,14 +772,13 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
                    const uint32_t *__restrict__ lev_off, int first, int last, int mfirst,
                    double *__restrict__ Wd, int plain, unsigned long long *__restrict__ used_out,
                    const uint32_t *__restrict__ list /* slots of the movers (k_mover_list; lev_off = {0, count}) or null */,
-                   unsigned spread)
+                   double *__restrict__ stage = nullptr, int2 *__restrict__ keys = nullptr)
 {
   size_t i = 0;
   bool have = false;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;      // list entry, or offset in the slot range
   if (list) {
-    // few movers: one per `spread` lanes, so that their (serial, latency-bound) atomics come from more waves
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, g = t / spread;
-    if (t % spread == 0 && g < lev_off[1]) { i = list[g]; have = true; }
+    if (g < lev_off[1]) { i = list[g]; have = true; }
   } else {
     i = lev_off[first] + (size_t)blockIdx.x * 256 + threadIdx.x;
     have = i < lev_off[last + 1];
@@ -799,6 +804,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
     const unsigned long long in = __ballot(mover);
     if ((threadIdx.x & 63) == 0 && in) atomicAdd(used_out, (unsigned long long)__popcll(in));
   } else if (!(r < S.rmax)) mover = false;
+  if constexpr (STAGED) { if (have && !mover) keys[g] = make_int2(-1, -1); }      // (g: list entry, or offset in the range)
   if (!__any(mover)) return;
   const double costh = zz / r;
   double cphi, sphi;
@@ -814,6 +820,14 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
   double *wto = Wd + (size_t)to * wl + (size_t)idx * S.nrows * 2;
   double *wfr = Wd + (size_t)from * wl + (size_t)idx * S.nrows * 2;
   const bool sub = !plain && mover && from >= mfirst;       // levels below mfirst[mdrft] are not updated
+  [[maybe_unused]] double *st = nullptr;
+  if constexpr (STAGED) {
+    if (mover) {
+      keys[g] = make_int2((int)((size_t)to * wl + (size_t)idx * S.nrows * 2),
+                          sub ? (int)((size_t)from * wl + (size_t)idx * S.nrows * 2) : -1);
+      st = stage + g * (size_t)(S.nrows * 2);
+    }
+  }
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
@@ -840,6 +854,16 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
       pl2 = pl1;
       pl1 = plm;
       constexpr int row = row_of(l, m, 0);
+      if constexpr (STAGED) {
+        if (mover) {
+          const double yc = (m == 0) ? plm : plm * cm;
+          *reinterpret_cast<double2 *>(st + 2 * row) = make_double2(det_round(a1 * yc, S.detC), det_round(a2 * yc, S.detC));
+          if constexpr (m > 0) {
+            const double ys = plm * sm;
+            *reinterpret_cast<double2 *>(st + 2 * row + 2) = make_double2(det_round(a1 * ys, S.detC), det_round(a2 * ys, S.detC));
+          }
+        }
+      } else
       if (mover) {
         const double yc = (m == 0) ? plm : plm * cm;
         const double v1 = det_round(a1 * yc, S.detC), v2 = det_round(a2 * yc, S.detC);
@@ -862,6 +886,25 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
       }
     });
   });
+}
+
+// second half of the staged differencing: one lane per (mover, value); keys[mover] = {offset of its cell in
+// W[to], in W[from] or -1}, values as stored by k_sph_mstep_update<L, true>
+template <int UNUSED = 0>            // (a template only for its linkage: this header is in every sph_inst unit)
+__global__ void __launch_bounds__(256)
+k_mstep_apply(const double *__restrict__ stage, const int2 *__restrict__ keys, const uint32_t *__restrict__ cnt,
+              uint32_t nfixed /* entries when cnt is null */, int nval, double *__restrict__ Wd)
+{
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t g = t / (size_t)nval;
+  if (g >= (cnt ? cnt[1] : nfixed)) return;
+  const int r = (int)(t - g * (size_t)nval);
+  const int2 k = keys[g];
+  if (k.x < 0) return;
+  const double v = stage[t];
+  if (v == 0.0) return;
+  unsafeAtomicAdd(Wd + (size_t)k.x + r, v);
+  if (k.y >= 0) unsafeAtomicAdd(Wd + (size_t)k.y + r, -v);
 }
 
 // ---- force ------------------------------------------------------------------------------------------------
@@ -1401,7 +1444,7 @@ struct SphAccArgs {
   // LIST mode (level-change differencing of many movers): lev_off -> {0, list length}, n = the host's count
   const uint32_t *list = nullptr;
   const uint8_t *lev = nullptr, *newlev = nullptr;
-  int mfirst = 0, nslices = 1;        // nslices = multistep + 2 (AccList)
+  int mfirst = 0, nslices = 1;        // nslices = multistep + 2 (AccList::per_level) or 2
 };
 
 struct SphForceArgs {
@@ -1439,7 +1482,8 @@ struct SphUpdArgs {
   int plain = 0;                        // 1: accumulate every particle of the range into Wd[its level]
   unsigned long long *used = nullptr;   // ... and count those inside the window
   const uint32_t *list = nullptr;       // slots of the movers: lev_off = {0, count}, n = the expected count
-  unsigned spread = 1;                  // ... one mover per `spread` lanes
+  double *stage = nullptr;              // ... staged: values [mover][nrows][2] and W offsets, applied by k_mstep_apply
+  int2 *keys = nullptr;
 };
 
 typedef void (*sph_upd_launcher)(const SphUpdArgs &);
