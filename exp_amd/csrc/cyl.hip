@@ -560,8 +560,9 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 #define CYL_CSEG 24
 #define CYL_CNB 12                 // n per register block
 __global__ void __launch_bounds__(256)
-k_cyl_contract_part(CylDev C, const double *__restrict__ tab, const double *__restrict__ Wn,
-                    double *__restrict__ part /* [level][CYL_CSEG][ncoef] */)
+k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict__ Wn,
+                    double *__restrict__ part /* [level][CYL_CSEG][ncoef] */,
+                    int clear /* leave the moments zero behind (each is read by exactly one block) */)
 {
   const int t = blockIdx.x, seg = blockIdx.y, L = blockIdx.z;
   const int m = (t + 1) >> 1, cs = t ? ((t + 1) & 1) : 0;
@@ -577,8 +578,10 @@ k_cyl_contract_part(CylDev C, const double *__restrict__ tab, const double *__re
     double s[CYL_CNB];
 #pragma unroll
     for (int j = 0; j < CYL_CNB; j++) s[j] = 0.0;
+    const bool wipe = clear && nb + CYL_CNB >= C.nmax;
     for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
       const double w = Wn[k * C.ntrig + t];
+      if (wipe && w != 0.0) Wn[k * C.ntrig + t] = 0.0;
 #pragma unroll
       for (int j = 0; j < CYL_CNB; j++)
         if (nb + j < C.nmax) s[j] = fma(T0[(size_t)(nb + j) * nnode + k], w, s[j]);
@@ -616,11 +619,11 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
 }
 
 // both stages; nl levels starting at Wn / out / last
-static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, const double *Wn, double *part,
-                         double *out, int nl = 1, size_t ostride = 0, double *last = nullptr)
+static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, double *Wn, double *part,
+                         double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
-  k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part);
+  k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
   k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last);
 }
 
@@ -840,6 +843,8 @@ struct CylForce : exp_amd_force {
   size_t cov_seq_cap = 0;
   DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
+  bool wn_clean = false;            // every per-level moment buffer of d_Wn is zero (substep_expansion's contraction keeps it so)
+  bool wnd_clean = false;           // ... and d_Wnd, d_differ's tails (multistep_update)
   bool tails_clean = false;         // the {mass, count} tails of all expcoefN sets are zero (substep_expansion keeps them so)
   size_t nnode = 0;
 
@@ -1034,9 +1039,14 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // the levels that multistep_update_begin clears and _finish adds (M >= mfirst[mdrft],
   // src/CylEXP.cc:45-157); a rank without particles still takes part in the reduction
   const int nl = ms - mfirst_mdrft + 1;
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p + (size_t)mfirst_mdrft * wl, 0, (size_t)nl * wl * sizeof(double), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, 0,
-                              (size_t)nl * f->ncoef_dev * sizeof(double), ctx->stream));
+  // (the contraction below leaves the moments it consumed zeroed -- proposed levels are >= mfirst[mdrft],
+  // src/multistep.cc:196, so nothing else is ever written -- and overwrites every coefficient of d_differ; the
+  // {mass, count} tails of d_differ are never written at all)
+  if (!f->wnd_clean) {
+    HIP_TRY(ctx, hipMemsetAsync(f->d_Wnd.p, 0, f->d_Wnd.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(f->d_differ.p, 0, f->d_differ.bytes(), ctx->stream));
+    f->wnd_clean = true;
+  }
   const CylDev C = cdev_acc(f, c);
   size_t nr = 0;
   if (c->n) { int rc_ = expamd_comp_level_count(c, first, ms, &nr); if (rc_) return rc_; }
@@ -1063,17 +1073,17 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
     k_cyl_accumulate<MM, true, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                 \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt.p, LC, f->d_Wnd.p, nullptr, 1, al); \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt, LC, f->d_Wnd.p, nullptr, 1, al); \
   else                                                                                           \
     k_cyl_accumulate<MM, false, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt.p, LC, f->d_Wnd.p, nullptr, 1, al)
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt, LC, f->d_Wnd.p, nullptr, 1, al)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   } else if (nr) {
     ProfScope ps(ctx, "k_cyl_mstep_update");
     const unsigned spread = listed ? expamd_mover_spread((size_t)c->mover_hint) : 1u;
     const unsigned grid = cdiv(listed ? (size_t)c->mover_hint * spread : nr, 256);
-    const uint32_t *lo_ = listed ? c->mover_cnt.p : c->lev_off.p, *li_ = listed ? c->mover_list.p : nullptr;
+    const uint32_t *lo_ = listed ? c->mover_cnt : c->lev_off.p, *li_ = listed ? c->mover_list.p : nullptr;
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
@@ -1082,7 +1092,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 #undef CALL
   }
   cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl, f->d_cpart.p,
-               f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev);
+               f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev, nullptr, /*clear=*/1);
   HIP_TRY(ctx, hipGetLastError());
   const size_t cnt = (size_t)nl * f->ncoef_dev;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
@@ -1116,6 +1126,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->nnode * dev.ntrig * sizeof(double), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dst + f->ncoef, 0, 2 * sizeof(double), ctx->stream));
   f->tails_clean = false;
+  f->wn_clean = false;
   const int lo = f->multistep ? f->mlevel : 0, hi = lo;
   size_t nrange = c->n;      // population of the accumulated level: sizes the grid and the chunks
   if (c->n && f->multistep) {
@@ -1195,7 +1206,12 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   const CylDev C = cdev_acc(f, c);
   double *dst = f->d_coefN.p + (size_t)lo * f->ncoef_dev;
   const size_t wl = f->nnode * dev.ntrig;
-  HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p + (size_t)lo * wl, 0, (size_t)nact * wl * sizeof(double), ctx->stream));
+  // the per-level moment buffers are left clean by the contraction that consumes them (below); only the plain
+  // per-level API can have dirtied one
+  if (!f->wn_clean) {
+    HIP_TRY(ctx, hipMemsetAsync(f->d_Wn.p, 0, f->d_Wn.bytes(), ctx->stream));
+    f->wn_clean = true;
+  }
   // {in-cut mass, count} of the whole launch ride in the tail of the FIRST active level's set (the
   // other tails are zero): one number per sub-step is all Cylinder keeps (src/Cylinder.cc:1081-1099).
   // k_cyl_mass_take leaves the tail zero again; only the plain per-level API can have dirtied one.
@@ -1251,7 +1267,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // ... with setup_accumulation(M)'s swap of every active level: L <- N, N <- new
     // (exputil/EmpCylSL.cc:2010-2030)
     cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, f->d_cpart.p, dst, nact,
-                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev);
+                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1);
   }
   HIP_TRY(ctx, hipGetLastError());
   if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;

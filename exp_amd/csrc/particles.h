@@ -31,7 +31,9 @@ struct exp_amd_comp {
   // Level-change differencing of many movers (force methods' multistep_update): the step driver leaves the number of
   // level changes of the last sweep here (< 0: unknown), expamd_comp_mover_list compacts their slots
   long long mover_hint = -1;
-  DevBuf<uint32_t> mover_list, mover_cnt;     // slots of the movers; {0, how many}: plays lev_off for the kernels
+  DevBuf<uint32_t> mover_list, mover_cnt_buf; // slots of the movers; two {0, how many} pairs used alternately
+  uint32_t *mover_cnt = nullptr;              // the pair of the last compaction: plays lev_off for the kernels
+  int mover_flip = 0;
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;

@@ -657,9 +657,10 @@ int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg)
 __global__ void __launch_bounds__(256)
 k_mover_list(const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
              const uint32_t *__restrict__ lev_off, int first, int last, uint32_t *__restrict__ list,
-             uint32_t cap, uint32_t *__restrict__ cnt)
+             uint32_t cap, uint32_t *__restrict__ cnt, uint32_t *__restrict__ cnt_next /* the NEXT call's pair: zeroed here */)
 {
   __shared__ uint32_t wsum[4], base;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cnt_next[0] = 0u; cnt_next[1] = 0u; }
   const size_t beg = lev_off[first], end = lev_off[last + 1];
   const size_t abeg = beg & ~(size_t)(ML_ITEMS - 1);          // 16-byte aligned reads
   const size_t s0 = abeg + ((size_t)blockIdx.x * 256 + threadIdx.x) * ML_ITEMS;
@@ -703,18 +704,25 @@ k_mover_list(const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev
 int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected)
 {
   exp_amd_ctx *ctx = c->ctx;
-  if (c->mover_cnt.n == 0) HIP_TRY(ctx, c->mover_cnt.alloc(2));
+  // two {0, count} pairs used alternately: a call clears the pair the next one will count into (no memset in between)
+  if (c->mover_cnt_buf.n == 0) {
+    HIP_TRY(ctx, c->mover_cnt_buf.alloc(4));
+    HIP_TRY(ctx, hipMemsetAsync(c->mover_cnt_buf.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    c->mover_flip = 0;
+  }
   if (c->mover_list.n < expected) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     c->mover_list.release();
     HIP_TRY(ctx, c->mover_list.alloc(expected + expected / 4 + 1024));
   }
-  HIP_TRY(ctx, hipMemsetAsync(c->mover_cnt.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+  uint32_t *cnt = c->mover_cnt_buf.p + 2 * c->mover_flip, *nxt = c->mover_cnt_buf.p + 2 * (1 - c->mover_flip);
+  c->mover_cnt = cnt;
   size_t nr = 0;
   if (c->n) { int rc = expamd_comp_level_count(c, first, last, &nr); if (rc) return rc; }
-  if (nr == 0) return EXP_AMD_OK;
+  if (nr == 0) return EXP_AMD_OK;      // (the pair stays clean and is used again)
   k_mover_list<<<cdiv(nr + ML_ITEMS, (size_t)256 * ML_ITEMS), 256, 0, ctx->stream>>>(c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, last,
-                                                               c->mover_list.p, (uint32_t)c->mover_list.n, c->mover_cnt.p);
+                                                               c->mover_list.p, (uint32_t)c->mover_list.n, cnt, nxt);
+  c->mover_flip ^= 1;
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }

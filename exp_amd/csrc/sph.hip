@@ -814,7 +814,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     // registers, where the per-particle path sends 4 (L+1)^2 atomics per mover to a handful of addresses (4 % of 1e7
     // particles leaving level 0 in the first sweep: 140 ms that way, 1-3 ms this way)
     ProfScope ps(ctx, "k_sph_mstep_update");
-    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt.p, 0, 0, f->d_Wd.p, f->d_used.p + 1,
+    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt, 0, 0, f->d_Wd.p, f->d_used.p + 1,
                  (size_t)c->mover_hint, ctx->stream, 1, nullptr, 1};
     a.list = c->mover_list.p;
     a.lev = c->level[c->cur].p;
@@ -825,7 +825,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   } else if (nr) {
     ProfScope ps(ctx, "k_sph_mstep_update");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
-                 listed ? c->mover_cnt.p : c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p,
+                 listed ? c->mover_cnt : c->lev_off.p, first, ms, mfirst_mdrft, f->d_Wd.p,
                  listed ? (size_t)c->mover_hint : nr, ctx->stream};
     if (listed) {
       a.list = c->mover_list.p;
