@@ -5,6 +5,14 @@
 set -e
 cd "$(dirname "$0")/.."
 TAG=$1; RND=${TAG%[a-z]}
+# gpurun MERGES a call's files into gpurun_out/: a tag used before leaves its old traces beside the new ones and the
+# summaries would average both.  Keep only what the newest stats run (and anything within 30 minutes of it) wrote.
+NEWEST=$(ls -t gpurun_out/prof_$TAG/stats.log gpurun_out/prof_$TAG/stats/*/*.csv 2>/dev/null | head -1)
+if [ -n "$NEWEST" ]; then
+  REF=$(mktemp); touch -d "$(date -r "$NEWEST" '+%Y-%m-%d %H:%M:%S') 30 minutes ago" "$REF"
+  find gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_cfg3 gpurun_out/prof_cfg4 gpurun_out/pmc_${TAG}_* -type f ! -newer "$REF" -delete 2>/dev/null || true
+  rm -f "$REF"
+fi
 python3 tools/summarize_profile.py gpurun_out/prof_$TAG profiles/$RND > /dev/null
 cp gpurun_out/pmc_${TAG}_all.txt profiles/${RND}_pmc.txt
 sed -i "1i # rocprofv3 --pmc passes over 'python bench.py --steps 3 --warmup 1' (1e8 NFW, S10), one counter set per pass (tools/pmc_multi.sh); per-launch means, first launch dropped" profiles/${RND}_pmc.txt
