@@ -28,6 +28,7 @@ struct exp_amd_sim {
   int centerlevl = -1;
   bool gottapot = false;
   bool restart = false;            // the global `restart` (src/global.cc): the estimators take in the first state too
+  bool defer_resort = true;               // EXP_AMD_SIM_DEFER_RESORT=0: re-order right after every sweep with level changes
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
   // Two-stream sub-steps: everything that touches the particles of component k is issued on stream
@@ -58,6 +59,7 @@ static int overlap_begin(exp_amd_sim *s)
   exp_amd_ctx *ctx = s->ctx;
   bool any_orient = false;
   for (auto o : s->orients) any_orient = any_orient || o;
+  if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   s->overlap = s->multistep > 0 && s->comps.size() >= 2 && !any_orient && !ctx->ar_fn &&
@@ -380,10 +382,15 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
         for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];
         expamd_comp_update_sparse(c, first, ctx->dense_min >= 0 ? ctx->dense_min : f->sparse_threshold());
       } else c->sparse_mask = 0;
-      if (mirror && first == 0 && mdrft == s->Mstep) {
-        // end of a master step: the next one opens with a full advance sort of every level
-        // (substep_expansion(0)), which re-partitions by the committed levels in the same pass
+      // The next sub-step advances the levels >= mfirst[its mstep] = mfirst[mdrft] (0 after the last sweep of a
+      // master step) -- the levels this sweep examined, unless it was the first of the run (first = 0 then): its
+      // advance sort re-partitions them by the committed levels in the same pass (substep_expansion), so the
+      // re-ordering is not done twice.
+      const int next_lo = mdrft == s->Mstep ? 0 : s->mfirst[mdrft];
+      if (mirror && s->defer_resort && next_lo == first) {
         c->partition_stale = true;
+        c->stale_lo = first;
+        c->stale_for = (const void *)f;
         continue;
       }
       if ((rc = f->resort(c, ordered ? first : 0))) return rc;

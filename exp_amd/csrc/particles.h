@@ -67,6 +67,11 @@ struct exp_amd_comp {
   // already holds the offsets that sort will establish; any other entry point re-partitions first
   // (expamd_comp_touch).
   bool partition_stale = false;
+  // ... more generally after ANY sweep whose examined levels [stale_lo, multistep] are exactly what the next
+  // sub-step advances: that sub-step's advance sort re-partitions them in the same pass (stale_for: the force
+  // method whose cell order the slots below stale_lo -- and, up to the level changes, above -- still have)
+  int stale_lo = 0;
+  const void *stale_for = nullptr;
   // Sort keys + histogram of the NEXT fused step, produced by the force pass of the last one
   // (exp_amd_step_kdk): valid only while nothing else has touched the component since.
   bool prekey_valid = false;

@@ -473,9 +473,12 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   // dense levels (cell-sorted) of the active suffix end at dmax; the levels above it are sparse
   int dmax = lo - 1;
   for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dmax = L;
-  const bool ordered = c->sorted_for == f && c->nlevels == ms + 1;
+  // a sweep left its level changes to this sort (exp_amd_comp::partition_stale): the whole active range is
+  // re-partitioned, sparse levels included (they are advanced by the sort then, not in place)
+  const bool stale_ok = c->partition_stale && c->stale_for == (const void *)f && c->nlevels == ms + 1 && c->stale_lo >= lo;
+  const bool ordered = (c->sorted_for == f && c->nlevels == ms + 1) || stale_ok;
   const bool full = lo == 0 || !ordered;
-  if (full) dmax = ms;                  // a full re-partition passes over everything anyway
+  if (full || stale_ok) dmax = ms;                  // a full re-partition passes over everything anyway
   if (c->n) {
     // one sort of the dense part of the active slot range with the per-level kick + drift applied on
     // the way; the whole store when the level partition is not this basis' yet.  acc / pot of the
@@ -484,7 +487,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // inactive levels.
     uint32_t keep[66];
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
-    c->partition_stale = false;         // (a stale partition implies lo == 0: the full sort below settles it)
+    c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
     if (dmax >= lo) {
       rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
