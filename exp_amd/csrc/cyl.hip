@@ -557,7 +557,9 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 // not once per (t, n, node) as a block per coefficient would (that variant moved 330 MB through L2
 // for 45 MB of tables: 70 us per contraction at 256 x 128).  Stage 2 adds the segments in a fixed
 // order (same bits every run) and does setup_accumulation's swap on the way.
-#define CYL_CSEG 24
+#ifndef CYL_CSEG
+#define CYL_CSEG 48          // node segments of stage 1 (24: 312 blocks, too few to pull the 45 MB table at HBM rate: 50 -> 36 us)
+#endif
 #define CYL_CNB 12                 // n per register block
 __global__ void __launch_bounds__(256)
 k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict__ Wn,
