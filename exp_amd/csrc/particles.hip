@@ -144,24 +144,40 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
     carry += tot;
     __syncthreads();
   }
-  // SCAN_SI consecutive bins per thread: the pass is barrier-latency bound (the cylinder's bins took
-  // 200 us at one bin per thread)
-  const uint32_t kb = k0 + blockIdx.x * 1024u * SCAN_SI + (uint32_t)t * SCAN_SI;
+  // SCAN_SI consecutive bins per thread (the pass is barrier-latency bound: the cylinder's bins took 200 us at one
+  // bin per thread), staged through LDS so that the global loads and stores are coalesced: element j * 1024 + t in
+  // pass j; a thread's own run of SCAN_SI words starts at word t * SCAN_SI -- an odd stride, no bank conflicts.
+  __shared__ uint32_t stage[1024u * SCAN_SI];
+  const uint32_t cb = k0 + blockIdx.x * 1024u * SCAN_SI;           // first bin of this chunk
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_SI; j++) {
+    const uint32_t e = j * 1024u + (uint32_t)t;
+    stage[e] = (cb + e < k1) ? hist[cb + e] : 0u;
+  }
+  __syncthreads();
   uint32_t v[SCAN_SI], s = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < SCAN_SI; j++) { v[j] = (kb + j < k1) ? hist[kb + j] : 0u; s += v[j]; }
+  for (uint32_t j = 0; j < SCAN_SI; j++) { v[j] = stage[(uint32_t)t * SCAN_SI + j]; s += v[j]; }
   uint32_t total;
   const uint32_t incl = block_scan_1024(s, wsum, total);
   uint32_t excl = carry + (incl - s);
+  // (a range of several levels re-partitions its slots: the inner level starts move)  next level boundary at or
+  // after this thread's first bin -- one division here instead of a modulo per bin
+  const uint32_t kb = cb + (uint32_t)t * SCAN_SI;
+  const bool offs = range_lo < 0 || range_hi > range_lo;
+  uint32_t lvl = (kb + ncell - 1u) / ncell, kbnd = lvl * ncell;
 #pragma unroll
   for (uint32_t j = 0; j < SCAN_SI; j++) {
     const uint32_t k = kb + j;
-    if (k < k1) {
-      hist[k] = excl;
-      // (a range of several levels re-partitions its slots: the inner level starts move)
-      if ((range_lo < 0 || range_hi > range_lo) && k % ncell == 0) lev_off[k / ncell] = excl;
-    }
+    stage[(uint32_t)t * SCAN_SI + j] = excl;
+    if (offs && k == kbnd && k < k1) { lev_off[lvl] = excl; lvl++; kbnd += ncell; }
     excl += v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_SI; j++) {
+    const uint32_t e = j * 1024u + (uint32_t)t;
+    if (cb + e < k1) hist[cb + e] = stage[e];
   }
   if (t == 0 && range_lo < 0 && blockIdx.x + 1 == gridDim.x) {
     hist[nkeys] = carry + total;
