@@ -602,7 +602,7 @@ k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict
 
 __global__ void __launch_bounds__(256)
 k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict__ out, size_t ostride,
-                   double *__restrict__ last)
+                   double *__restrict__ last, double *__restrict__ add_to /* += the new set as well, or null */)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -618,15 +618,17 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
     last[o] = out[o];
   }
   out[o] = s;
+  if (add_to) add_to[(size_t)L * ostride + o] += s;
 }
 
 // both stages; nl levels starting at Wn / out / last
 static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, double *Wn, double *part,
-                         double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0)
+                         double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0,
+                         double *add_to = nullptr)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
-  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last);
+  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to);
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
@@ -1093,9 +1095,13 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
+  // (expcoefN += differ in the summing kernel itself when this rank is alone: no all-reduce in between)
+  const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;
   cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl, f->d_cpart.p,
-               f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev, nullptr, /*clear=*/1);
+               f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev, nullptr, /*clear=*/1,
+               alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef_dev : nullptr);
   HIP_TRY(ctx, hipGetLastError());
+  if (alone) return EXP_AMD_OK;
   const size_t cnt = (size_t)nl * f->ncoef_dev;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, cnt);
   if (rc) return rc;

@@ -71,9 +71,11 @@ k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wsca
 
 // last != nullptr: the N/L swap of determine_coefficients (src/SphericalBasis.cc:785-792) on the way,
 // last <- coef (the previous set of this level), coef <- new
+// add_to != nullptr: add_to += the new set as well (the differencing of a single rank: expcoefN += differ with no
+// all-reduce in between)
 __global__ void __launch_bounds__(256)
 k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__ coef,
-                double *__restrict__ last = nullptr)
+                double *__restrict__ last = nullptr, double *__restrict__ add_to = nullptr)
 {
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
@@ -83,6 +85,7 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
   for (int seg = 0; seg < CSEG; seg++) s += part[(size_t)seg * ncoef + k];
   if (last) last[(size_t)blockIdx.y * ncoef + k] = coef[k];
   coef[k] = s;
+  if (add_to) add_to[(size_t)blockIdx.y * ncoef + k] += s;
 }
 
 // ---- coefficients -> projected tables -----------------------------------------------------------------
@@ -841,10 +844,14 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // moments -> coefficient differences, all levels in one launch
   k_sph_contract<<<dim3(S.nrows, CSEG, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
                                                                   f->d_wscale.p, f->d_part.p, /*clear=*/1);
+  // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M] -- in the summing kernel
+  // itself when this rank is alone
+  const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;
   k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nl), 256, 0, ctx->stream>>>(
-      f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef);
+      f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef, nullptr,
+      alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef : nullptr);
   HIP_TRY(ctx, hipGetLastError());
-  // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M]
+  if (alone) return EXP_AMD_OK;
   const size_t cnt = (size_t)nl * f->ncoef;
   int rc = expamd_allreduce(ctx, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef, cnt);
   if (rc) return rc;
