@@ -57,6 +57,8 @@ struct exp_amd_ctx {
                                      // through the accumulation kernel over a list of the movers instead of per-particle
                                      // atomics (EXP_AMD_MOVER_LIST_MIN; < 0: never)
   long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (EXP_AMD_MOVER_SLICES_MIN)
+  long long stage_max = 1 << 20;     // particles up to which the per-particle atomic paths are staged (values by plain stores,
+                                     // one lane per value for the atomics): 8 (L+1)^2 bytes each (EXP_AMD_STAGE_MAX)
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;

@@ -147,6 +147,7 @@ struct LevChunks {
 #define CACC_OCC 2          // waves per SIMD asked of the compiler
 #endif
 #define CACC_CHUNK_MAX 1024   // particles per wave chunk; sparse multistep levels get shorter ones
+#define CACC_THICK_MIN 1000000u   // level population from which a multistep level is accumulated apart from thinner ones
 
 // Deterministic (order-independent) accumulation, as in sph_kernels.h: every term is rounded to a fixed
 // absolute grid 2^e first, (w*p + C) - C with C = 1.5 * 2^(52+e), so that all later additions are exact.
@@ -1238,19 +1239,27 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate");
     // per level: >= ~6 rounds of blocks; sparse levels pay one flush per cell change, serial within
-    // a wave, so they get short chunks and many waves
-    LevChunks LC;
-    LC.lo = lo; LC.nlev = dacc - lo + 1;
-    unsigned grid = 0;
-    for (int L = lo; L <= dacc; L++) {
-      const size_t nl = (size_t)c->lev_host[L + 1] - c->lev_host[L];
-      size_t chunk = (nl / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
-      chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
-      LC.bstart[L - lo] = grid;
-      LC.chunk[L - lo] = (int)chunk;
-      grid += cdiv(nl, (size_t)CACC_WAVES * chunk);
-    }
-    LC.bstart[LC.nlev] = grid;
+    // a wave, so they get short chunks and many waves.  Thickly and thinly populated levels go in SEPARATE
+    // launches (consecutive levels of one kind together): mixed in one launch they took twice the time of the
+    // two apart (measured for the sphere's twin, SphForce::substep_expansion).
+    for (int L0 = lo; L0 <= dacc;) {
+      auto pop = [&](int L) { return (size_t)c->lev_host[L + 1] - c->lev_host[L]; };
+      const bool thick = pop(L0) >= CACC_THICK_MIN;
+      int L1 = L0;
+      while (L1 + 1 <= dacc && (pop(L1 + 1) >= CACC_THICK_MIN) == thick) L1++;
+      LevChunks LC;
+      LC.lo = L0; LC.nlev = L1 - L0 + 1;
+      unsigned grid = 0;
+      for (int L = L0; L <= L1; L++) {
+        const size_t nl = pop(L);
+        size_t chunk = (nl / ((size_t)CACC_WAVES * 3072)) & ~(size_t)63;
+        chunk = chunk < 64 ? 64 : chunk > CACC_CHUNK_MAX ? CACC_CHUNK_MAX : chunk;
+        LC.bstart[L - L0] = grid;
+        LC.chunk[L - L0] = (int)chunk;
+        grid += cdiv(nl, (size_t)CACC_WAVES * chunk);
+      }
+      LC.bstart[LC.nlev] = grid;
+      if (grid) {
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
     k_cyl_accumulate<MM, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                       \
@@ -1258,8 +1267,11 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   else                                                                                           \
     k_cyl_accumulate<MM, false><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                      \
         C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1)
-    MMAX_DISPATCH(cfg.mmax, CALL)
+        MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+      }
+      L0 = L1 + 1;
+    }
   }
   nrange = 0;
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;

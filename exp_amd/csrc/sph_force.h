@@ -3,7 +3,6 @@
 #include "sph_kernels.h"
 #include "force.h"
 
-#define SPH_STAGE_MAX 65536          // movers up to which the per-mover differencing is staged
 struct SphForce : exp_amd_force {
   exp_amd_sph_config cfg{};
   SphDev dev{};
