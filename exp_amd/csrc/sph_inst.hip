@@ -32,10 +32,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   for (int j = 0; j < LC.nlev; j++) {
     const size_t n = a.counts ? a.counts[j] : a.n;
     size_t chunk = (n / ((size_t)CPB * ACC_BLOCKS_TARGET)) & ~(size_t)63;
-#ifndef ACC_ML_CHUNK_MIN
-#define ACC_ML_CHUNK_MIN 64
-#endif
-    const size_t cmin = a.multilevel ? ACC_ML_CHUNK_MIN : ACC_CHUNK_MIN;
+    const size_t cmin = ACC_CHUNK_MIN;
     chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
     LC.bstart[j] = nb;
     LC.chunk[j] = (int)chunk;

@@ -306,8 +306,11 @@ struct LevChunks {
 // Particles per block/wave chunk (contiguous, so one or two cells per wave).  Every chunk ends with
 // a flush (LDS transposes + ~60 fp64 atomics per wave) and every block pays its launch: at 1024
 // those fixed costs were 30% of the kernel, so the launcher picks up to ACC_CHUNK_MAX when the
-// component is large enough to still fill the GPU several times over.
-#define ACC_CHUNK_MIN 1024
+// component is large enough to still fill the GPU several times over.  SMALL components (a snapshot of 1e4-1e6
+// particles through pyEXP, a thin multistep level) get chunks down to one 64-particle group: what they pay is one
+// serial flush per cell change within a wave, and the GPU is not even full (2e4 particles: 550 us at 1024 per
+// chunk, 67 us at 64; 1e6: 150 -> 87 us).
+#define ACC_CHUNK_MIN 64
 #ifndef ACC_CHUNK_MAX
 #define ACC_CHUNK_MAX 4096
 #endif
