@@ -315,6 +315,9 @@ struct LevChunks {
 #define ACC_CHUNK_MAX 4096
 #endif
 #define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
+#ifndef ACC_P0_FILL_MIN
+#define ACC_P0_FILL_MIN 512    // ... for chunks longer than this
+#endif
 
 // LIST mode of the accumulation kernel: the level-change differencing of MANY movers (multistep_update,
 // src/SphericalBasis.cc:1156-1228).  The particles are taken through a list of mover slots (k_mover_list: in
@@ -720,7 +723,9 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     const size_t cbeg = beg + (size_t)bx * ACC_CHUNK;
     if (cbeg >= end) return;
     const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-    const bool p0_in_lds = !LIST && S.numr <= ACC_P0_LDS;     // (short LIST launches: not worth the fill)
+    // (short chunks -- LIST launches, thin multistep levels, small components -- are not worth the fill: the table
+    // is numr doubles, the chunk may be 64 particles)
+    const bool p0_in_lds = !LIST && S.numr <= ACC_P0_LDS && ACC_CHUNK > ACC_P0_FILL_MIN;
     if (p0_in_lds) {
       for (int k = threadIdx.x; k < S.numr; k += ACC_WAVES * 64) p0s[k] = S.p0[k];
       __syncthreads();
