@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
 for n in 1.25e7 2.5e7 5e7; do
   echo "== nbodies $n"
-  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --nbodies $n --force-comm 2>/dev/null | python -c "
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-sustained --nbodies $n --force-comm 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
