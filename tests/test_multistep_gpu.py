@@ -279,3 +279,44 @@ def test_fix_positions_matches_oracle(ctx, oracle):
     assert np.abs(fresh[1:4] - ref2[1:4]).max() > 1e-6          # the stale levels do matter
     c.close()
     f.close()
+
+
+def test_unsorted_levels_of_many_particles_take_the_staged_path(ctx, oracle):
+    """A multistep run whose levels are ALL kept un-sorted (set_dense_min above every population): 2e5 particles per
+    sweep go through the per-particle atomic path -- staged: values by plain stores, then one lane per value
+    (k_sph_mstep_update<L, true> + k_mstep_apply; before round 2's last changes the cap was 65 536 particles, beyond
+    which every lane issued its own 8 (L+1)^2 atomics).  The per-level sets after two master steps must add up to a
+    from-scratch accumulation of the final positions by the cell-sorted kernel, and that one agrees with the oracle."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Simulation, SphereSL
+    model, g = make_grid("nfw", 6, 18, 2000)
+    n, ms = 200_000, 3
+    m, pos, vel = sample_sphere(model, n, seed=77)
+    ctx.set_dense_min(10**9)
+    try:
+        f = SphereSL(ctx, g, multistep=ms)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        sim = Simulation(ctx, 2e-3, multistep=ms)
+        sim.add_component(c, f)
+        sim.init()
+        sim.step(2)
+        lev = np.bincount(c.download_levels(), minlength=ms + 1)
+        assert (lev > 0).sum() >= 2 and lev.sum() == n
+        total = np.sum([f.get_coefs(level=M) for M in range(ms + 1)], axis=0)
+        out = c.download(("mass", "pos"))
+    finally:
+        ctx.set_dense_min(-1)
+    ff = SphereSL(ctx, g)
+    cc = Component.from_arrays(ctx, out["mass"], out["pos"])
+    ff.determine_coefficients(cc)
+    ref = ff.get_coefs()
+    assert np.abs(total - ref).max() <= 1e-11 * np.abs(ref).max()
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, used = oracle.sph_accumulate(g, prm, out["pos"][:50_000], out["mass"][:50_000])
+    c2 = Component.from_arrays(ctx, out["mass"][:50_000], out["pos"][:50_000])
+    ff.determine_coefficients(c2)
+    assert ff.Used() == used
+    assert np.abs(ff.get_coefs() - c_ref).max() <= 1e-10 * np.abs(c_ref).max()
+    for x in (c, cc, c2, f, ff):
+        x.close()
+    sim.close()
