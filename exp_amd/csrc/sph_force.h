@@ -40,7 +40,13 @@ struct SphForce : exp_amd_force {
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
   // (the spherical basis has few cells, numr - 1: a level stays worth sorting down to a few particles
   // per cell, and per-particle atomics on so few addresses contend)
-  long long sparse_threshold() const override { return 4LL * (cfg.numr - 1); }
+  // (break-even of the un-sorted treatment -- staged per-particle accumulation + gather forces, no sort -- against the
+  // cell-sorted one, measured at S6 and S10 with tools/dbg/acc_staged.py: about 5e6 / (values per particle))
+  long long sparse_threshold() const override
+  {
+    const long long a = 4LL * (cfg.numr - 1), b = 5000000LL / (2LL * (cfg.lmax + 1) * (cfg.lmax + 1));
+    return a > b ? a : b;
+  }
   int resort(exp_amd_comp *c, int first = 0) override;
   int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;

@@ -83,7 +83,7 @@ int  exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on);
  * accumulated with per-particle atomics, forces by the gather path -- because a sparse level has
  * about one particle per basis cell and the cell order buys nothing.  Same results up to the order
  * of the sums.  nmin < 0 (the default; EXP_AMD_DENSE_MIN overrides): each force method's own
- * break-even (about 3e6 / moments per particle: ~30000 for lmax 6, ~58000 for mmax 6);
+ * break-even (about 3e6-5e6 / moments per particle: ~51000 for lmax 6, ~20000 for lmax 10, ~58000 for mmax 6);
  * 0: every level is cell-sorted.                                                                  */
 int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
 /* Second knob of the same loop: how the coefficient sets are differenced when particles change level
