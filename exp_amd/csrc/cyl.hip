@@ -165,33 +165,34 @@ __device__ __forceinline__ void cacc_add(double &a, double w, double p, double C
 __device__ __forceinline__ double cdet_round(double v, double C) { return C != 0.0 ? (v + C) - C : v; }
 
 // reduce NV per-lane values over the wave and atomically add value j to dst[map(j)]
-template <int NV, class MapFn>
+// (CNT < NV: only the first CNT values -- they alone are reduced, added and zeroed)
+template <int NV, int CNT = NV, class MapFn>
 __device__ __forceinline__ void cyl_wave_flush(double (&v)[NV], double *scratch, double *dst,
                                                MapFn map)
 {
   const int lane = threadIdx.x & 63;
   const int kk = lane >> 2, q = lane & 3;
-  cstatic_for<0, (NV + 15) / 16>([&](auto gc) {
+  cstatic_for<0, (CNT + 15) / 16>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     cstatic_for<0, 16>([&](auto jc) {
       constexpr int j = g * 16 + decltype(jc)::value;
-      if constexpr (j < NV) scratch[decltype(jc)::value * CFLUSH_STRIDE + lane] = v[j];
+      if constexpr (j < CNT) scratch[decltype(jc)::value * CFLUSH_STRIDE + lane] = v[j];
     });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double s = 0.0;
-    if (g * 16 + kk < NV) {
+    if (g * 16 + kk < CNT) {
 #pragma unroll
       for (int e = 0; e < 16; e++) s += scratch[kk * CFLUSH_STRIDE + q + 4 * e];
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    if (q == 0 && g * 16 + kk < NV && s != 0.0) unsafeAtomicAdd(dst + map(g * 16 + kk), s);
+    if (q == 0 && g * 16 + kk < CNT && s != 0.0) unsafeAtomicAdd(dst + map(g * 16 + kk), s);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   });
 #pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = 0.0;
+  for (int j = 0; j < CNT; j++) v[j] = 0.0;
 }
 
 // Profiling aid (tools/dbg/cyl_timing.py; tools/build_variant_cyl.sh timing -DEXPT_TIMING): s_memtime counters of
@@ -266,14 +267,24 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
 
   const int ncellT = C.numx * C.numy;
   const size_t wlev = (size_t)(C.numx + 1) * nyp * NT;
-  auto flush = [&](int key) {
+  // next == key + 1 inside one column of cells (same ix, next iy; the particles are in cell order, so that is the usual
+  // change): the two upper corners of the old cell ARE the two lower corners of the new one -- only the lower two
+  // (corners 00, 10: the first 2 NT sums) are reduced and added, the upper two move down and keep accumulating.  Half
+  // the work per cell change; on a thick disk (a hundred particles per cell) the flushes were 58 % of this kernel.
+  auto flush = [&](int key, int next) {
     const int L = key / ncellT, cell = key - L * ncellT;       // (L = 0 in single-level launches)
     const int ix = cell / C.numy, iy = cell - ix * C.numy;
     double *base = Wn + (size_t)L * wlev + ((size_t)ix * nyp + iy) * NT;
-    cyl_wave_flush<NV>(acc, scratch, base, [&](int j) {
+    auto map = [&](int j) {
       const int k = j / NT, t = j - k * NT;                // corner k: 0=00, 1=10, 2=01, 3=11
       return (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT + t;
-    });
+    };
+    if (next == key + 1 && iy + 1 < C.numy) {
+      cyl_wave_flush<NV, 2 * NT>(acc, scratch, base, map);
+#pragma unroll
+      for (int j = 0; j < 2 * NT; j++) { acc[j] = acc[2 * NT + j]; acc[2 * NT + j] = 0.0; }
+    } else
+      cyl_wave_flush<NV>(acc, scratch, base, map);
   };
 
   // software prefetch: the loads of group k+1 are in flight while group k is reduced (two groups ahead
@@ -340,12 +351,12 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
       if (c != cur) {
 #ifdef EXPT_TIMING
         const unsigned long long tf0 = TSTAMP();
-        if (cur >= 0) { flush(cur); t_nfl++; }
+        if (cur >= 0) { flush(cur, c); t_nfl++; }
         const unsigned long long tf1 = TSTAMP();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the flush's atomics AND the prefetched loads)
         t_fl += tf1 - tf0; t_fld += TSTAMP() - tf1;
 #else
-        if (cur >= 0) flush(cur);
+        if (cur >= 0) flush(cur, c);
 #endif
         cur = c;
       }
@@ -388,7 +399,7 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     atomicAdd(&g_dbg_t[6], t_fl); atomicAdd(&g_dbg_t[7], t_fld);
   }
 #endif
-  if (cur >= 0) flush(cur);
+  if (cur >= 0) flush(cur, -1);
   for (int off = 32; off > 0; off >>= 1) {
     mass_used += __shfl_xor(mass_used, off);
     n_used += __shfl_xor(n_used, off);
