@@ -107,6 +107,10 @@ SIGNATURES = {
     "exp_amd_cyl_set_density": (c_int, [c_void_p, c_void_p]),
     "exp_amd_cyl_fields": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "exp_amd_sph_fields": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "exp_amd_sph_basis": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "exp_amd_sph_window_mass": (c_int, [c_void_p, c_void_p, POINTER(c_double)]),
+    "exp_amd_cyl_basis": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "exp_amd_cyl_orthocheck": (c_int, [c_void_p, c_void_p]),
     "exp_amd_force_destroy": (None, [c_void_p]),
     "exp_amd_force_set_level": (c_int, [c_void_p, c_int]),
     "exp_amd_force_determine_coefficients": (c_int, [c_void_p, c_void_p]),

@@ -94,6 +94,9 @@ class BiorthBasis:
         self.coefret = None
         self.coefindx = 0
         self._ftor = None
+        self.pseudo = np.zeros(3)
+        self.totalMass = 0.0
+        self.t_accel, self.p_accel = np.zeros(0), np.zeros((0, 3))
 
     # -- array front end (expui/BiorthBasis.cc:4585-4757) -------------------------------------------
     def initFromArray(self, center=(0.0, 0.0, 0.0), rot=None) -> None:
@@ -105,6 +108,107 @@ class BiorthBasis:
 
     def setSelector(self, ftor) -> None:
         self._ftor = ftor
+
+    def clrSelector(self) -> None:
+        """``Basis::clrSelector`` (expui/BasisFactory.H:281; pyEXP/BasisWrappers.cc:1144)."""
+        self._ftor = None
+
+    # -- non-inertial frame (expui/BasisFactory.H:160-178, :286-310; expui/BasisFactory.cc:286-404) ---------
+    Naccel = 0
+
+    def setInertial(self) -> None:
+        """``Basis::setInertial``: back to an inertial frame, the pseudo-acceleration is zero."""
+        self.Naccel = 0
+        self.pseudo = np.zeros(3)
+
+    def usingNonInertial(self) -> bool:
+        return self.Naccel > 0
+
+    def setNonInertial(self, N: int, times_or_orient, pos=None) -> None:
+        """``Basis::setNonInertial(N, times, pos)`` -- the expansion centre's track, one row per time --
+        or ``setNonInertial(N, orient_file)`` -- the track read from an Orient log (src/Orient.cc:742-785):
+        rows that do not start with ``#``, time in the first column, and, after two more columns, eight
+        triples of which the LAST one read is kept as the position (the reference's loop reads all eight
+        into the same vector, expui/BasisFactory.cc:329-337: with the current 33-column log that is the
+        pseudo-acceleration triple; restated, not repaired)."""
+        if isinstance(times_or_orient, (str, bytes, os.PathLike)) and pos is None:
+            path = os.fspath(times_or_orient)
+            if not os.path.exists(path):
+                raise RuntimeError("Cannot open Orient file with centering data: " + str(path))
+            times, centers = [], []
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("#"):
+                        continue
+                    tok = line.split()
+                    if len(tok) < 3 + 24:                # the row must hold all eight triples
+                        continue
+                    times.append(float(tok[0]))
+                    centers.append([float(v) for v in tok[3 + 21:3 + 24]])
+            t, p = np.array(times), np.array(centers).reshape(-1, 3)
+        else:
+            t = np.asarray(times_or_orient, dtype=np.float64).reshape(-1)
+            p = np.asarray(pos, dtype=np.float64)
+            if t.size < 1:
+                raise RuntimeError("Basis: setNonInertial: no times in time array")
+            if p.ndim != 2 or t.size != p.shape[0]:
+                raise RuntimeError("Basis::setNonInertial: size mismatch in time and position arrays")
+        self.Naccel, self.t_accel, self.p_accel = int(N), t, p
+
+    @staticmethod
+    def _quadls_a(x, y) -> float:
+        """leading coefficient of ``QuadLS`` (include/QuadLS.H:17-53), sums taken in the reference's order"""
+        n = len(x)
+        if n == 0:
+            return 0.0
+        sumx = sumy = sumxy = sumx2y = sumx2 = sumx3 = sumx4 = 0.0
+        for xi, yi in zip(x, y):
+            sumx += xi; sumy += yi; sumx2 += xi * xi; sumxy += xi * yi
+            sumx2y += xi * xi * yi; sumx3 += xi * xi * xi; sumx4 += xi * xi * xi * xi
+        Sxx, Sxy = sumx2 - sumx * sumx / n, sumxy - sumx * sumy / n
+        Sxx2, Sx2y = sumx3 - sumx * sumx2 / n, sumx2y - sumx2 * sumy / n
+        Sx2x2 = sumx4 - sumx2 * sumx2 / n
+        denom = Sxx * Sx2x2 - Sxx2 * Sxx2
+        return (Sx2y * Sxx - Sxy * Sxx2) / denom if abs(denom) > 0.0 else 0.0
+
+    def currentAccel(self, time: float) -> np.ndarray:
+        """``Basis::currentAccel`` (expui/BasisFactory.cc:358-401): twice the leading coefficient of a
+        quadratic least-squares fit to ~Naccel track points around ``time``."""
+        t, n = self.t_accel, len(self.t_accel)
+        if n < 2 or time < t[0] - 0.5 * (t[1] - t[0]) or time > t[n - 1] + 0.5 * (t[n - 1] - t[n - 2]):
+            raise RuntimeError(f"Basis::currentAccel: {time} is outside the range of the non-inertial DB "
+                               f"[{t[0]}, {t[n - 1]}]")
+        imax = int(np.searchsorted(t, time, side="left"))
+        imax = min(n - 1, imax + self.Naccel // 2)
+        imin = max(imax - self.Naccel, 0)
+        tt = [float(v) for v in t[imin:imax + 1]]
+        return np.array([2.0 * self._quadls_a(tt, [float(v) for v in self.p_accel[imin:imax + 1, k]])
+                         for k in range(3)])
+
+    def setNonInertialAccel(self, time: float) -> None:
+        """``Basis::setNonInertialAccel`` (expui/BasisFactory.H:297-300)."""
+        if self.Naccel > 0:
+            self.pseudo = self.currentAccel(time)
+
+    def getCenter(self) -> np.ndarray:
+        return self.coefctr
+
+    def getRotation(self) -> np.ndarray:
+        return self.coefrot
+
+    def getCoefficients(self):
+        return self.coefret
+
+    def getMass(self) -> float:
+        """``BiorthBasis::getMass`` (expui/BiorthBasis.H:189): the mass accumulated on the grid."""
+        return float(self.totalMass)
+
+    def setCovarH5Compress(self, level: int, chunksize: int, shuffle: bool, szip: bool = False) -> None:
+        """``Basis::setCovarH5Compress`` (expui/BasisFactory.H:351-358)."""
+        if not getattr(self, "pcavar", False):
+            raise RuntimeError("Basis::setCovarH5Compress: covariance storage not initialized")
+        from . import h5cache
+        h5cache.covar_set_compress(level, chunksize, shuffle, szip)
 
     def _layout(self, p: np.ndarray, posvelrows: bool):
         """the dimension-deduction rule of addFromArray (:4638-4655)"""
@@ -169,12 +273,22 @@ class BiorthBasis:
             x, y, z = [np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in args]
             pos = np.stack([x, y, z], axis=1)
             single = np.ndim(args[0]) == 0
+            if not (x.shape == y.shape == z.shape):
+                raise RuntimeError("BiorthBasis::getAccel: x, y, z vectors must be of the same size")
         else:
             pos = np.asarray(args[0], dtype=np.float64)
             single = False
-        pos = (pos - self.coefctr) @ self.coefrot.T
-        acc = self._accel(pos) @ self.coefrot        # rotate back: rot^T a
+            if pos.ndim != 2 or pos.shape[1] != 3:
+                raise RuntimeError("BiorthBasis::getAccel: input array must have 3 columns")
+        # "in centered coordinate system" (expui/BiorthBasis.H:219-266): computeAccel takes the point as it
+        # is; centre and rotation are the caller's business (AccelFunc::evalaccel applies them, :4760-4790)
+        acc = self._accel(np.ascontiguousarray(pos))
         return acc[0] if single else acc
+
+    def getAccelArray(self, x, y, z) -> np.ndarray:
+        """``getAccelArray(x, y, z)`` (pyEXP/BasisWrappers.cc:1616): the three-vector overload of getAccel
+        under a name of its own -> [N, 3]."""
+        return self.getAccel(np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(z))
 
     # ---- field evaluation (expui/BasisFactory.cc:218-234, expui/BiorthBasis.cc:71-97, :711-958) ----
     FIELD_LABELS = ["dens m=0", "dens m>0", "dens", "potl m=0", "potl m>0", "potl"]
@@ -188,6 +302,10 @@ class BiorthBasis:
         if key not in self.FORCE_LABELS:
             raise RuntimeError(f"Basis: unknown coordinate type <{coord_type}>")
         self.coordinates = key
+
+    def getFieldType(self) -> str:
+        """``Basis::getFieldType`` (expui/BasisFactory.H:242; coordLabels, expui/BasisFactory.cc:16-20)."""
+        return self.coordinates.capitalize()
 
     def getFieldLabels(self, ctype: Optional[str] = None):
         return self.FIELD_LABELS + self.FORCE_LABELS[(ctype or self.coordinates).lower()]
@@ -406,6 +524,7 @@ class SphericalSL(BiorthBasis):
     def reset_coefs(self) -> None:
         self.expcoef[:] = 0.0
         self.used = 0
+        self.totalMass = 0.0                                 # (:475)
         if getattr(self, "pcavar", False):                   # zero_covariance (:478)
             self.force.cov_reset()
 
@@ -423,7 +542,106 @@ class SphericalSL(BiorthBasis):
         if getattr(self, "pcavar", False):                   # the pcavar block of accumulate (:613-660)
             self.force.cov_accumulate(c, self.used)
         self.used += self.force.Used()
+        self.totalMass += self.force.window_mass(c)          # totalMass += mass (:607)
         c.close()
+
+    # -- the basis functions on a grid (expui/BiorthBasis.cc:960-993; pyEXP/BasisWrappers.cc:2142) -------
+    def getBasis(self, logxmin: float = -3.0, logxmax: float = 0.5, numgrid: int = 2000):
+        """``SphericalSL::getBasis(logxmin, logxmax, numgrid)`` -> ``ret[l][n]`` = dict of ``potential``,
+        ``density``, ``rforce`` arrays on the grid r_i = 10^(logxmin + i (logxmax - logxmin)/(numgrid-1))."""
+        dx = (logxmax - logxmin) / (numgrid - 1)
+        r = np.array([math.pow(10.0, logxmin + dx * i) for i in range(numgrid)])
+        t = self.force.basis(r)                              # [3, L+1, nmax, numgrid]
+        return [[{"potential": t[0, l, n].copy(), "density": t[1, l, n].copy(), "rforce": t[2, l, n].copy()}
+                 for n in range(self.nmax)] for l in range(self.lmax + 1)]
+
+    # -- coefficients of a function by quadrature (expui/BiorthBasis.cc:5230-5458) -------------------------
+    @staticmethod
+    def _call_on_points(func, x, y, z, *extra):
+        """func(x, y, z[, time]) at arrays of points: one vectorised call when the callable takes arrays
+        (and returns one value per point), else point by point as pybind11 would call it."""
+        try:
+            v = np.asarray(func(x, y, z, *extra), dtype=np.float64)
+            if v.shape == x.shape:
+                return v
+        except Exception:
+            pass
+        return np.array([float(func(float(a), float(b), float(c), *extra)) for a, b, c in zip(x, y, z)])
+
+    def _quadrature_points(self, params, who):
+        """The knots^3 product rule of makeFromFunction / computeQuadrature: Gauss-Legendre in the mapped
+        radius xi in [xi(rmin), xi(rmax)] and in cos(theta), uniform in phi -> (x, y, z, weight)."""
+        rmapping = float(params.get("rmapping", self.rmap))
+        knots = int(params.get("knots", 200))
+        r_to_x = lambda r: (r / rmapping - 1.0) / (r / rmapping + 1.0)
+        ximin, ximax = r_to_x(self.rmin), r_to_x(self.rmax)
+        for v, msg in ((ximin, "x<=-1"), (ximax, "x<=-1")):
+            if v <= -1.0:
+                raise RuntimeError(f"BiorthBasis::{who}: {msg}")
+        for v in (ximin, ximax):
+            if v >= 1.0:
+                raise RuntimeError(f"BiorthBasis::{who}: x>=+1")
+        xk, wk = np.polynomial.legendre.leggauss(knots)      # LegeQuad: knots and weights on [0, 1]
+        xk, wk = 0.5 * (xk + 1.0), 0.5 * wk
+        xx = ximin + (ximax - ximin) * xk
+        rr = (1.0 + xx) / (1.0 - xx) * rmapping
+        dxr = 0.5 * (1.0 - xx) * (1.0 - xx) / rmapping
+        costh = -1.0 + 2.0 * xk
+        sinth = np.sqrt(np.abs(1.0 - costh * costh))
+        phi = 2.0 * math.pi / knots * np.arange(knots)
+        R, T, P = np.meshgrid(np.arange(knots), np.arange(knots), np.arange(knots), indexing="ij")
+        R, T, P = R.ravel(), T.ravel(), P.ravel()
+        x = rr[R] * sinth[T] * np.cos(phi[P])
+        y = rr[R] * sinth[T] * np.sin(phi[P])
+        z = rr[R] * costh[T]
+        w = (ximax - ximin) * rr[R] * rr[R] / dxr[R] * 2.0 * wk[R] * wk[T] * 2.0 * math.pi / knots
+        return x, y, z, w
+
+    def makeFromFunction(self, func, params=None, time: float = 0.0, potential: bool = False) -> SphStruct:
+        """``Spherical::makeFromFunction(func, params, time, potential)`` (expui/BiorthBasis.cc:5230-5362;
+        pyEXP/BasisWrappers.cc:1464): the expansion of a density (``potential`` False: against the potential
+        functions) or of a potential (True: against the density functions) given as a callable
+        ``func(x, y, z, time)``, by the knots^3 product rule (``params``: knots, default 200; rmapping).
+        The quadrature points go through the SAME accumulation kernels as particles do, each carrying its
+        weight as a mass: mat(l, n) = sum_p w_p f(p) factorial(l,m) P_lm e^{i m phi} phi_ln(r_p) -- no -4 pi,
+        tables at r itself.  Nothing of the basis' own coefficient state is touched."""
+        params = dict(params or {})
+        x, y, z, w = self._quadrature_points(params, "makeFromFunction")
+        fval = self._call_on_points(func, x, y, z, time) * w
+        force = self._quadrature_force(potential)
+        c = Component.from_arrays(self.ctx, fval / (-4.0 * math.pi), np.stack([x, y, z], 1))
+        force.determine_coefficients(c)
+        rows = force.get_coefs()
+        c.close()
+        from .coefs import real_rows_to_complex
+        return SphStruct(self.lmax, self.nmax, self.scale, time, real_rows_to_complex(rows, self.lmax),
+                         np.zeros(3), np.eye(3))
+
+    def _quadrature_force(self, potential: bool) -> SphereSL:
+        """A force object over the same tables with scale 1, no flags and no r offset (get_pot(r) as it is);
+        for ``potential`` the density functions ef sqrt(ev) d0 in the place of ef / sqrt(ev) p0
+        (SLGridSph::get_dens, exputil/SLGridMP2.cc:913-950)."""
+        key = "_qforce_dens" if potential else "_qforce_pot"
+        f = getattr(self, key, None)
+        if f is None:
+            g = self.grid
+            if potential:
+                import copy
+                g = copy.copy(self.grid)
+                g.ef = self.grid.ef * self.grid.ev[:, :, None]       # (ef ev) / sqrt(ev) = ef sqrt(ev)
+                g.p0 = np.asarray(self.grid.d0, dtype=np.float64).copy()
+            f = SphereSL(self.ctx, g, scale=1.0, rmin=self.rmin, rmax=self.rmax)
+            from ._lib import check
+            check(f.lib.exp_amd_sph_set_dsmall(f.h, 0.0), self.ctx.h)
+            setattr(self, key, f)
+        return f
+
+    def computeQuadrature(self, func, params=None) -> float:
+        """``Spherical::computeQuadrature(func, params)`` (expui/BiorthBasis.cc:5364-5457;
+        pyEXP/BasisWrappers.cc:1496): the integral of ``func(x, y, z)`` over rmin <= r <= rmax by the
+        same product rule -- the check of a makeFromFunction input (no basis function is involved)."""
+        x, y, z, w = self._quadrature_points(dict(params or {}), "computeQuadrature")
+        return float(np.sum(self._call_on_points(func, x, y, z) * w))
 
     # -- covariance by sub-sampling (expui/BiorthBasis.H:425-470) -------------------------------------
     def enableCoefCovariance(self, pcavar: bool, sampT: int = 100, ftype: bool = False,
@@ -644,6 +862,113 @@ class Cylindrical(BiorthBasis):
             self.force.cov_accumulate(c, seq)
         c.close()
 
+    def getMass(self) -> float:
+        """``getMass``: the reference's Cylindrical never updates ``totalMass`` (its accumulate hands the
+        particle straight to EmpCylSL, expui/BiorthBasis.cc:1851-1857; the member is not even initialised);
+        what a caller wants from "the mass on the grid" is EmpCylSL's own count, cylmass -- returned here."""
+        return float(self.cylmass)
+
+    def _fields_ready(self):
+        self.force.fields(np.zeros(1), np.zeros(1), np.zeros(1), "cylindrical")     # uploads the density tables
+
+    # -- the basis functions on a grid (expui/BiorthBasis.cc:1930-1974; pyEXP/BasisWrappers.cc:1811) --------
+    def getBasis(self, xmin: float = 0.0, xmax: float = 1.0, numR: int = 40, zmin: float = -0.1,
+                 zmax: float = 0.1, numZ: int = 40, linear: bool = True):
+        """``Cylindrical::getBasis(xmin, xmax, numR, zmin, zmax, numZ, linear)`` -> ``ret[m][n]`` = dict of
+        ``potential``, ``density``, ``rforce``, ``zforce`` [numR, numZ] arrays (R = 10^x when not linear):
+        ``EmpCylSL::get_all`` at phi = 0 with the force's current cylmass beyond the table."""
+        delR = (xmax - xmin) / max(numR - 1, 1)
+        delZ = (zmax - zmin) / max(numZ - 1, 1)
+        R = np.array([xmin + delR * i for i in range(numR)])
+        if not linear:
+            R = np.array([math.pow(10.0, v) for v in R])
+        Z = np.array([zmin + delZ * j for j in range(numZ)])
+        RR, ZZ = np.meshgrid(R, Z, indexing="ij")
+        self._fields_ready()
+        t = self.force.basis(RR.ravel(), ZZ.ravel()).reshape(4, self.mmax + 1, self.nmax, numR, numZ)
+        keys = ("potential", "density", "rforce", "zforce")
+        return [[{k: t[j, m, n].copy() for j, k in enumerate(keys)} for n in range(self.nmax)]
+                for m in range(self.mmax + 1)]
+
+    def orthoCheck(self, knots: int = 40):
+        """``Cylindrical::orthoCheck`` (expui/BiorthBasis.H:1105-1109 -> EmpCylSL::orthoCheck,
+        exputil/EmpCylSL.cc:7199-7260; pyEXP/BasisWrappers.cc:1854) -> one [nmax, nmax] matrix per m (the
+        ``knots`` argument is ignored by the reference too: the integral runs over the table grid)."""
+        self._fields_ready()
+        return [m for m in self.force.orthocheck()]
+
+    # -- coefficients of a function by quadrature (expui/BiorthBasis.cc:5459-5630) -------------------------
+    def _quadrature_points(self, params):
+        """knots^3 product rule over the table's own box: Gauss-Legendre in X = xi(R) and Y = y(z), uniform
+        in phi (expui/BiorthBasis.cc:5474-5530) -> (x, y, z, weight)."""
+        g = self.grid
+        knots = int(params.get("knots", 200))
+        A, H, Rtab = g.ascale, g.hscale, g.rtable
+        r_to_xi = (lambda r: (r / A - 1.0) / (r / A + 1.0)) if g.cmapr > 0 else (lambda r: r)
+        if g.cmapz == 1:
+            z_to_y = lambda z: math.copysign(math.asinh(abs(z / H)), z)
+            y_to_z, d_y_to_z = (lambda y: H * np.sinh(y)), (lambda y: H * np.cosh(y))
+        elif g.cmapz == 2:
+            z_to_y = lambda z: z / math.sqrt(z * z + H * H)
+            y_to_z, d_y_to_z = (lambda y: y * H / np.sqrt(1.0 - y * y)), (lambda y: H * (1.0 - y * y) ** -1.5)
+        else:
+            z_to_y, y_to_z, d_y_to_z = (lambda z: z), (lambda y: y), (lambda y: np.ones_like(y))
+        xmin, xmax = r_to_xi(g.rmin * A), r_to_xi(Rtab * A)
+        ymin, ymax = z_to_y(-Rtab * A), z_to_y(Rtab * A)
+        xk, wk = np.polynomial.legendre.leggauss(knots)
+        xk, wk = 0.5 * (xk + 1.0), 0.5 * wk
+        xx, yy = xmin + (xmax - xmin) * xk, ymin + (ymax - ymin) * xk
+        if g.cmapr > 0:
+            Rk, dxr = (1.0 + xx) / (1.0 - xx) * A, 0.5 * (1.0 - xx) * (1.0 - xx) / A
+        else:
+            Rk, dxr = xx, np.ones_like(xx)
+        zk, dyz = y_to_z(yy), d_y_to_z(yy)
+        phi = 2.0 * math.pi / knots * np.arange(knots)
+        I, J, K = np.meshgrid(np.arange(knots), np.arange(knots), np.arange(knots), indexing="ij")
+        I, J, K = I.ravel(), J.ravel(), K.ravel()
+        x, y, z = Rk[I] * np.cos(phi[K]), Rk[I] * np.sin(phi[K]), zk[J]
+        w = (xmax - xmin) * (ymax - ymin) * wk[I] * wk[J] * 2.0 * math.pi / knots * Rk[I] / dxr[I] * dyz[J]
+        return x, y, z, w
+
+    _call_on_points = staticmethod(SphericalSL._call_on_points)
+
+    def makeFromFunction(self, func, params=None, time: float = 0.0, potential: bool = False) -> CylStruct:
+        """``Cylindrical::makeFromFunction`` (expui/BiorthBasis.cc:5459-5556): mat(m, n) = sum_p w_p f(p)
+        [potC cos(m phi) + i potS sin(m phi)] (densC / densS with ``potential``), the quadrature points
+        taken through the accumulation kernels with their weights as masses.  The box corners lie outside
+        the sphere EmpCylSL::accumulate cuts at but inside getPotSC's R <= Rtable: the transient force
+        object's cut radius is widened to hold the whole box."""
+        x, y, z, w = self._quadrature_points(dict(params or {}))
+        fval = self._call_on_points(func, x, y, z, time) * w
+        force = self._quadrature_force(potential)
+        c = Component.from_arrays(self.ctx, fval / (-4.0 * math.pi), np.stack([x, y, z], 1))
+        force.determine_coefficients(c)
+        cc, ss = force.get_coefs()
+        c.close()
+        return CylStruct(self.mmax, self.nmax, time, cc + 1j * ss, np.zeros(3), np.eye(3))
+
+    def _quadrature_force(self, potential: bool) -> Cylinder:
+        key = "_qforce_dens" if potential else "_qforce_pot"
+        f = getattr(self, key, None)
+        if f is None:
+            import copy
+            g = copy.copy(self.grid)
+            g.rtable = self.grid.rtable * 1.5                  # sphere around the (R, z) box of the tables
+            if potential:
+                if getattr(self.grid, "dens", None) is None:
+                    raise RuntimeError("Cylindrical.makeFromFunction: the EmpCylSL grid has no density tables")
+                tab = np.array(self.grid.tab, dtype=np.float64, copy=True)
+                tab[0], tab[3] = self.grid.dens[0], self.grid.dens[1]       # potC <- densC, potS <- densS
+                g.tab = tab
+            f = Cylinder(self.ctx, g, rcylmax=1.0e30)
+            setattr(self, key, f)
+        return f
+
+    def computeQuadrature(self, func, params=None) -> float:
+        """``Cylindrical::computeQuadrature`` (expui/BiorthBasis.cc:5558-5630)."""
+        x, y, z, w = self._quadrature_points(dict(params or {}))
+        return float(np.sum(self._call_on_points(func, x, y, z) * w))
+
     # -- covariance by sub-sampling (expui/BiorthBasis.H:1120-1145; exputil/EmpCylSL.cc:4974-5015) ---
     def enableCoefCovariance(self, pcavar: bool, sampT: int = 100, ftype: bool = False,
                              covr_tot: bool = True, covar: bool = True) -> None:
@@ -727,3 +1052,157 @@ def CovarianceReader(filename: str, stride: int = 1):
     ``getCoefCovariance(time)`` -> (counts, masses, means, covariances)."""
     from .h5cache import SubsampleCovariance
     return SubsampleCovariance(filename, stride)
+
+
+# ---- orbit integration in a time-dependent expansion (expui/BiorthBasis.H:1511-1599, expui/BiorthBasis.cc:
+#      4759-5195; pyEXP/BasisWrappers.cc:3050-3170) -------------------------------------------------------------
+
+class AccelFunc:
+    """``BasisClasses::AccelFunc``: the acceleration of a (basis, coefficient container) pair at a time.
+    A derived class provides ``evalcoefs(t, mod)``, which installs the coefficients for time ``t`` in the
+    basis; ``F(t, ps, accel, mod)`` -- the callable IntegrateOrbits is handed -- then adds the field of that
+    model at the phase-space points ``ps`` [n, 6] to ``accel`` [n, 3]."""
+
+    def evalcoefs(self, t: float, mod) -> None:          # pragma: no cover - interface
+        raise NotImplementedError("AccelFunc::evalcoefs is pure virtual")
+
+    def evalaccel(self, ps: np.ndarray, accel: np.ndarray, mod) -> np.ndarray:
+        """``AccelFunc::evalaccel`` (expui/BiorthBasis.cc:4759-4816): points into the expansion frame
+        (minus the centre -- zero in a non-inertial frame --, then the rotation), ``getFields`` there, the
+        three force columns added to ``accel`` minus the frame's pseudo-acceleration."""
+        basis = mod[0]
+        ctr = np.zeros(3) if basis.usingNonInertial() else np.asarray(basis.getCenter(), dtype=np.float64)
+        rot = np.asarray(basis.getRotation(), dtype=np.float64)
+        pp = (np.asarray(ps, dtype=np.float64)[:, :3] - ctr) @ rot.T
+        v = np.atleast_2d(basis.getFields(pp[:, 0].copy(), pp[:, 1].copy(), pp[:, 2].copy()))
+        accel += v[:, 6:9] - basis.pseudo
+        return accel
+
+    def F(self, t: float, ps: np.ndarray, accel: np.ndarray, mod) -> np.ndarray:
+        self.evalcoefs(t, mod)
+        return self.evalaccel(ps, accel, mod)
+
+    __call__ = F
+
+
+def _bracket(times, t, who):
+    """the (it1, it2, a, b) of AllTimeAccel::evalcoefs / SingleTimeAccel (expui/BiorthBasis.cc:4833-4851)"""
+    if t < times[0] or t > times[-1]:
+        raise RuntimeError(f"Basis::OneAccel: time t={t} is out of bounds: [{times[0]}, {times[-1]}]")
+    i2 = int(np.searchsorted(times, t, side="left"))
+    i1 = i2
+    if i2 == len(times):
+        raise RuntimeError(f"Basis::{who}::evalcoefs: time t={t} out of bounds")
+    if i2 == 0:
+        i2 += 1
+    else:
+        i1 -= 1
+    a = (times[i2] - t) / (times[i2] - times[i1])
+    b = (t - times[i1]) / (times[i2] - times[i1])
+    return times[i1], times[i2], a, b
+
+
+class AllTimeAccel(AccelFunc):
+    """``AllTimeAccel``: coefficients linearly interpolated in time between the two stored sets around ``t``;
+    centre interpolated likewise, rotation interpolated and projected back onto the rotations by its
+    polar decomposition (U V^T of the SVD); the pseudo-acceleration of a non-inertial frame updated."""
+
+    def evalcoefs(self, t: float, mod) -> None:
+        import copy
+        basis, coefs = mod[0], mod[1]
+        t1, t2, a, b = _bracket(coefs.Times(), t, "AllTimeAccel")
+        A, B = coefs.getCoefStruct(t1), coefs.getCoefStruct(t2)
+        new = copy.deepcopy(A)
+        new.time = t
+        new.coefs = a * np.asarray(A.coefs) + b * np.asarray(B.coefs)
+        new.ctr = a * np.asarray(A.ctr, dtype=np.float64) + b * np.asarray(B.ctr, dtype=np.float64)
+        U, _, Vt = np.linalg.svd(a * np.asarray(A.rot, dtype=np.float64) + b * np.asarray(B.rot, dtype=np.float64))
+        new.rot = U @ Vt
+        basis.set_coefs(new)
+        basis.coefrot = new.rot
+        basis.setNonInertialAccel(t)
+
+
+class SingleTimeAccel(AccelFunc):
+    """``SingleTimeAccel(t, mod)``: every model's coefficients interpolated to the ONE time ``t`` at
+    construction; ``evalcoefs`` then leaves them alone (a frozen potential)."""
+
+    def __init__(self, t: float, mod):
+        import copy
+        for basis, coefs in [(m[0], m[1]) for m in mod]:
+            t1, t2, a, b = _bracket(coefs.Times(), t, "SingleTimeAccel")
+            A, B = coefs.getCoefStruct(t1), coefs.getCoefStruct(t2)
+            new = copy.deepcopy(A)
+            new.time = t
+            new.coefs = a * np.asarray(A.coefs) + b * np.asarray(B.coefs)
+            if np.size(A.ctr) and np.size(B.ctr):
+                new.ctr = a * np.asarray(A.ctr, dtype=np.float64) + b * np.asarray(B.ctr, dtype=np.float64)
+            basis.set_coefs(new)
+
+    def evalcoefs(self, t: float, mod) -> None:
+        pass
+
+
+def _one_step(t, h, ps, accel, bfe, F):
+    """``OneStep`` (expui/BiorthBasis.cc:4936-5055), its leap-frog branch: drift h/2, kick h with the
+    field at time t, drift h/2."""
+    ps[:, :3] += ps[:, 3:6] * (0.5 * h)
+    accel[:] = 0.0
+    for mod in bfe:
+        F(t, ps, accel, mod)
+    ps[:, 3:6] += accel * h
+    ps[:, :3] += ps[:, 3:6] * (0.5 * h)
+    return t + h, ps
+
+
+def IntegrateOrbits(tinit: float, tfinal: float, h: float, ps, bfe, F, nout: int = 0):
+    """``pyEXP.basis.IntegrateOrbits(tinit, tfinal, h, ps, bfe, F, nout)`` (expui/BiorthBasis.cc:5056-5195):
+    leap-frog orbits of the phase-space points ``ps`` [n, 6] in the fields of the models ``bfe`` = list of
+    (basis, coefs) -- evaluated on the GPU through ``getFields`` -- from ``tinit`` to ``tfinal`` in steps of
+    about ``h`` (re-fitted to land on ``tfinal``), every ``stride``-th state kept so that ``nout`` states
+    come back.  Returns (times [nout], states [n, 6, nout] float32)."""
+    ps = np.array(ps, dtype=np.float64)
+    if ps.ndim != 2 or ps.shape[1] != 6:
+        cols = ps.shape[1] if ps.ndim == 2 else ps.shape[-1]
+        raise RuntimeError("IntegrateOrbits: phase space array should be n x 6 where n is the number of "
+                           f"particles.  You specified {cols} columns")
+    rows = ps.shape[0]
+    accel = np.zeros((rows, 3))
+    if tfinal == tinit:
+        raise RuntimeError("BasisClasses::IntegrateOrbits: tinit cannot be equal to tfinal")
+    if h < 0.0 and tfinal > tinit:
+        raise RuntimeError("BasisClasses::IntegrateOrbits: tfinal must be smaller than tinit when step size "
+                           "is negative")
+    if h > 0.0 and tfinal < tinit:
+        raise RuntimeError("BasisClasses::IntegrateOrbits: tfinal must be larger than tinit when step size "
+                           "is positive")
+    if (tfinal - tinit) / h > float(np.iinfo(np.int32).max):
+        print("BasisClasses::IntegrateOrbits: step size is too small or time interval is too large.")
+        return np.zeros(0), np.zeros((0, 0, 0), dtype=np.float32)
+    numT = max(2, int(math.ceil((tfinal - tinit) / h + 0.5)))
+    stride = 1
+    if nout > 0:
+        nout = max(2, int(nout))
+        stride = int(math.ceil(numT / nout))
+        numT = (nout - 1) * stride + 1
+    else:
+        nout = numT
+    h = (tfinal - tinit) / (numT - 1)
+    ret = np.zeros((rows, 6, nout), dtype=np.float32)
+    times = np.zeros(nout)
+    times[0] = tinit
+    ret[:, :, 0] = ps
+    sgn = (0 < h) - (h < 0)
+    tnow, s, cnt = tinit, 0, 1
+    while s < numT:                         # `while (s++ < numT)`: numT passes, s = 1 .. numT inside
+        s += 1
+        if (tfinal - tnow) * sgn < h * sgn:
+            h = tfinal - tnow
+        tnow, ps = _one_step(tnow, h, ps, accel, bfe, F)
+        if cnt < nout and s % stride == 0:
+            times[cnt] = tnow
+            ret[:, :, cnt] = ps
+            cnt += 1
+    times[nout - 1] = tnow
+    ret[:, :, nout - 1] = ps
+    return times, ret

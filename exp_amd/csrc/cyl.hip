@@ -1734,3 +1734,134 @@ extern "C" int exp_amd_cyl_cov_get(exp_amd_force *fb, long long *counts, double 
   if (counts) for (int t = 0; t < f->cov_T; t++) counts[t] = (long long)cnt[t];
   return EXP_AMD_OK;
 }
+
+// ---- the basis functions themselves on an (R, z) grid (pyEXP getBasis) and their orthogonality ----------------
+// Cylindrical::getBasis (expui/BiorthBasis.cc:1930-1974) calls EmpCylSL::get_all(m, n, R, z, phi = 0, ...)
+// (exputil/EmpCylSL.cc:5635-5800) for every (m, n): at phi = 0 only the cosine tables contribute; beyond the
+// table radius the monopole -cylmass/r and its radial / vertical force.  One lane per point, blockIdx.y = m*nmax+n;
+// out[4][mmax+1][nmax][npts] = potential, density, rforce, zforce.
+__global__ void __launch_bounds__(256)
+k_cyl_basis(CylDev C, const double *__restrict__ tab, const double *__restrict__ dens, double cylmass, size_t n,
+            const double *__restrict__ Rv, const double *__restrict__ Zv, double *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int mk = blockIdx.y;
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const size_t plane = half * n;
+  double *o = out + (size_t)mk * n + i;
+  const double r = Rv[i];
+  double z = Zv[i];
+  const double rr = sqrt(r * r + z * z);
+  if (rr * C.inv_ascale > C.rtable) {                                  // :5653-5659
+    const double p = -cylmass / (rr + 1.0e-16);
+    o[0] = p; o[plane] = 0.0;
+    o[2 * plane] = p * r / (rr + 1.0e-16) / (rr + 1.0e-16);
+    o[3 * plane] = p * z / (rr + 1.0e-16) / (rr + 1.0e-16);
+    return;
+  }
+  if (z * C.inv_ascale > C.rtable) z = C.rtab_abs;                     // :5661-5662
+  if (z * C.inv_ascale < -C.rtable) z = -C.rtab_abs;
+  int ix, iy;
+  double c00, c10, c01, c11;
+  cyl_weights(C, r, z, ix, iy, c00, c10, c01, c11);
+  const size_t ny = (size_t)C.numy + 1, nnode = (size_t)(C.numx + 1) * ny;
+  const size_t n00 = (size_t)ix * ny + iy;
+  auto bl = [&](const double *T) {
+    return T[n00] * c00 + T[n00 + ny] * c10 + T[n00 + 1] * c01 + T[n00 + ny + 1] * c11;
+  };
+  const double *Tc = tab + (size_t)mk * nnode;
+  const size_t ks = half * nnode;
+  o[0] = bl(Tc);
+  o[plane] = bl(dens + (size_t)mk * nnode);
+  o[2 * plane] = bl(Tc + ks);
+  o[3 * plane] = bl(Tc + 2 * ks);
+}
+
+extern "C" int exp_amd_cyl_basis(exp_amd_force *fb, size_t n, const double *R, const double *z, double *out)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_basis: not a cylinder force");
+  exp_amd_ctx *ctx = f->ctx;
+  if (n == 0) return EXP_AMD_OK;
+  if (!R || !z || !out) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_basis: NULL argument");
+  if (!f->d_dens.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "cyl_basis: call exp_amd_cyl_set_density first");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t half = (size_t)(f->cfg.mmax + 1) * f->cfg.nmax;
+  DevBuf<double> d_in, d_out;
+  if (d_in.alloc(2 * n) != hipSuccess || d_out.alloc(4 * half * n) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_basis: hipMalloc failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_in.p, R, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_in.p + n, z, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  double cylmass = 0.0;
+  HIP_TRY(ctx, hipMemcpyAsync(&cylmass, f->d_mass.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  k_cyl_basis<<<dim3(cdiv(n, 256), (unsigned)half), 256, 0, ctx->stream>>>(f->dev, f->d_tab.p, f->d_dens.p, cylmass, n,
+                                                                           d_in.p, d_in.p + n, d_out.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, 4 * half * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_in.release();
+  d_out.release();
+  return EXP_AMD_OK;
+}
+
+// EmpCylSL::orthoCheck (exputil/EmpCylSL.cc:7199-7260) behind pyEXP's Cylindrical.orthoCheck: trapezoidal
+// integral of pot x dens over the (X, Y) table grid with the gravitational-energy normalisation; cosine and
+// sine parts of m > 0 combined as sqrt((C^2 + S^2)/2).  (As written the reference halves the weight of row
+// iy == NUMX, not NUMY: restated.)  One block per (m, n1, n2).
+__global__ void __launch_bounds__(256)
+k_cyl_orthocheck(CylDev C, const double *__restrict__ tab, const double *__restrict__ dens, double *__restrict__ out)
+{
+  const int n2 = blockIdx.x % C.nmax, n1 = (blockIdx.x / C.nmax) % C.nmax, mm = blockIdx.x / (C.nmax * C.nmax);
+  const size_t ny = (size_t)C.numy + 1, nnode = (size_t)(C.numx + 1) * ny;
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const double *pC = tab + ((size_t)mm * C.nmax + n1) * nnode;
+  const double *pS = tab + (3 * half + (size_t)mm * C.nmax + n1) * nnode;
+  const double *dC = dens + ((size_t)mm * C.nmax + n2) * nnode;
+  const double *dS = dens + (half + (size_t)mm * C.nmax + n2) * nnode;
+  double fac = -4.0 * M_PI * (2.0 * M_PI) * C.dx * C.dy;
+  if (mm) fac *= 0.5;
+  double sc = 0.0, ss = 0.0;
+  for (size_t q = threadIdx.x; q < nnode; q += 256) {
+    const int ix = (int)(q / ny), iy = (int)(q % ny);
+    const double x = C.xmin + C.dx * ix, y = C.ymin + C.dy * iy;
+    const double r = (C.cmapr > 0) ? (1.0 + x) / (1.0 - x) * C.ascale : x;
+    const double dxr = (C.cmapr > 0) ? 0.5 * (1.0 - x) * (1.0 - x) / C.ascale : 1.0;
+    double dyz = 1.0;
+    if (C.cmapz == 1) dyz = C.hscale * cosh(y);
+    else if (C.cmapz == 2) dyz = C.hscale * pow(1.0 - y * y, -1.5);
+    const double fx = (ix == 0 || ix == C.numx) ? 0.5 : 1.0;
+    const double fy = (iy == 0 || iy == C.numx) ? 0.5 : 1.0;
+    const double jac = fac * r / dxr * dyz * fx * fy;
+    sc += jac * pC[q] * dC[q];
+    if (mm) ss += jac * pS[q] * dS[q];
+  }
+  __shared__ double red[2][4];
+  for (int o = 32; o > 0; o >>= 1) { sc += __shfl_down(sc, o); ss += __shfl_down(ss, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sc; red[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    out[blockIdx.x] = mm == 0 ? a : sqrt(0.5 * (a * a + b * b));
+  }
+}
+
+extern "C" int exp_amd_cyl_orthocheck(exp_amd_force *fb, double *out)
+{
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f || !out) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_orthocheck: not a cylinder force / NULL");
+  exp_amd_ctx *ctx = f->ctx;
+  if (!f->d_dens.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "cyl_orthocheck: call exp_amd_cyl_set_density first");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t cnt = (size_t)(f->cfg.mmax + 1) * f->cfg.nmax * f->cfg.nmax;
+  DevBuf<double> d_out;
+  if (d_out.alloc(cnt) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_orthocheck: hipMalloc failed");
+  k_cyl_orthocheck<<<(unsigned)cnt, 256, 0, ctx->stream>>>(f->dev, f->d_tab.p, f->d_dens.p, d_out.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_out.release();
+  return EXP_AMD_OK;
+}

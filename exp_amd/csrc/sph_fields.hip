@@ -178,3 +178,101 @@ extern "C" int exp_amd_sph_fields(exp_amd_force *fb, size_t n, const double *c1,
   d_out.release();
   return EXP_AMD_OK;
 }
+
+// ---- the basis functions themselves on a radial grid (pyEXP getBasis) ---------------------------------
+// SphericalSL::getBasis (expui/BiorthBasis.cc:960-993) tabulates SLGridSph::get_pot / get_dens /
+// get_force (exputil/SLGridMP2.cc:872-989) of every (l, n) -- at r itself, not r/scale -- and returns
+// the force with its sign changed.  One lane per radius, blockIdx.y = l * nmax + n.
+__global__ void __launch_bounds__(256)
+k_sph_basis(SphDev S, const double *__restrict__ ev, const double *__restrict__ d0, size_t n,
+            const double *__restrict__ r, double *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ln = blockIdx.y;                                  // l * nmax + n
+  const int stride = (S.lmax + 1) * S.nmax;
+  const double xi = sph_r_to_xi(S, r[i]);
+  const int idx = sph_cell(S, xi);
+  const double x1 = (S.xi[idx + 1] - xi) / S.dxi;
+  const double x2 = (xi - S.xi[idx]) / S.dxi;
+  const double u = x1 * S.E[(size_t)idx * stride + ln] + x2 * S.E[(size_t)(idx + 1) * stride + ln];
+  const int j = idx < 1 ? 1 : idx;
+  const double pf = (xi - S.xi[j]) / S.dxi;
+  const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
+  const double frc = ffac * ((pf - 0.5) * S.E[(size_t)(j - 1) * stride + ln] * S.p0[j - 1]
+                             - 2.0 * pf * S.E[(size_t)j * stride + ln] * S.p0[j]
+                             + (pf + 0.5) * S.E[(size_t)(j + 1) * stride + ln] * S.p0[j + 1]);
+  const size_t plane = (size_t)stride * n;
+  double *o = out + (size_t)ln * n + i;
+  o[0] = u * (x1 * S.p0[idx] + x2 * S.p0[idx + 1]);                       // potential
+  o[plane] = u * ev[ln] * (x1 * d0[idx] + x2 * d0[idx + 1]);              // density: ef sqrt(ev) d0 = E ev d0
+  o[2 * plane] = -frc;                                                    // radial force
+}
+
+extern "C" int exp_amd_sph_basis(exp_amd_force *fb, size_t n, const double *r, double *out)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_basis: not a spherical force");
+  exp_amd_ctx *ctx = f->ctx;
+  if (n == 0) return EXP_AMD_OK;
+  if (!r || !out) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_basis: NULL argument");
+  if (!f->d_d0.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "sph_basis: call exp_amd_sph_set_density first");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t ln = (size_t)(f->cfg.lmax + 1) * f->cfg.nmax;
+  DevBuf<double> d_r, d_out;
+  if (d_r.alloc(n) != hipSuccess || d_out.alloc(3 * ln * n) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph_basis: hipMalloc failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_r.p, r, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  k_sph_basis<<<dim3(cdiv(n, 256), (unsigned)ln), 256, 0, ctx->stream>>>(f->dev, f->d_ev.p, f->d_d0.p, n, d_r.p, d_out.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, 3 * ln * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_r.release();
+  d_out.release();
+  return EXP_AMD_OK;
+}
+
+// ---- mass inside the expansion window (pyEXP getMass) --------------------------------------------------
+// Spherical::accumulate adds a particle's mass to totalMass when rmin <= r <= rmax, r = sqrt(r^2) + dsmall
+// (expui/BiorthBasis.cc:596-607); BiorthBasis::getMass returns it (expui/BiorthBasis.H:189).
+__global__ void __launch_bounds__(256)
+k_sph_window_mass(SphDev S, size_t n, const double *__restrict__ x, const double *__restrict__ y,
+                  const double *__restrict__ z, const double *__restrict__ m, double *__restrict__ out)
+{
+  __shared__ double part[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double xx = x[i] - S.cx, yy = y[i] - S.cy, zz = z[i] - S.cz;
+    const double r = sqrt(xx * xx + yy * yy + zz * zz) + S.dsmall;
+    if (!(r < S.rmin || r > S.rmax)) s += S.umass != 0.0 ? S.umass : m[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int exp_amd_sph_window_mass(exp_amd_force *fb, exp_amd_comp *c, double *mass)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f || !c || !mass)
+    return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_window_mass: not a spherical force / NULL");
+  exp_amd_ctx *ctx = f->ctx;
+  if (c->ctx != ctx) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_window_mass: component of another context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *mass = 0.0;                                  // (positions and masses only: a pending half-kick does not matter)
+  if (c->n == 0) return EXP_AMD_OK;
+  DevBuf<double> d_s;
+  if (d_s.alloc(1) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph_window_mass: hipMalloc failed");
+  HIP_TRY(ctx, hipMemsetAsync(d_s.p, 0, sizeof(double), ctx->stream));
+  SphDev S = f->dev;
+  S.cx = c->center[0]; S.cy = c->center[1]; S.cz = c->center[2];
+  S.umass = c->uniform_mass ? c->mass_value : 0.0;
+  const unsigned nb = (unsigned)(cdiv(c->n, 256) < 2048 ? cdiv(c->n, 256) : 2048);
+  k_sph_window_mass<<<nb, 256, 0, ctx->stream>>>(S, c->n, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), d_s.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(mass, d_s.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  d_s.release();
+  return EXP_AMD_OK;
+}

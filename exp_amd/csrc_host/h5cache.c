@@ -17,6 +17,7 @@
  * (exp_amd/libexp_amd_h5.so); no HighFive, no C++.
  */
 #include <hdf5.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -653,15 +654,30 @@ static int put_uint(hid_t loc, const char *name, unsigned v)
   return rc;
 }
 
+/* SubsampleCovariance::setCovarH5Compress(level, chunksize, shuffle, szip) (include/Covariance.H:147-153;
+ * defaults :60-63 of the class: level 5, chunk 1024*1024, shuffle on): level 0 = no filters, contiguous.
+ * szip is refused (the HDF5 library of this image has no szip encoder).                                  */
+static unsigned g_covar_level = 5, g_covar_chunk = 1048576;
+static int g_covar_shuffle = 1;
+
+int exp_h5_covar_set_compress(unsigned level, unsigned chunksize, int shuffle, int szip)
+{
+  if (szip || level > 9 || chunksize == 0) return -1;
+  g_covar_level = level;
+  g_covar_chunk = chunksize;
+  g_covar_shuffle = shuffle ? 1 : 0;
+  return 0;
+}
+
 static int put_vec(hid_t loc, const char *name, hid_t type, size_t n, const void *data)
 {
-  hsize_t dims[2] = {(hsize_t)n, 1}, chunk[2] = {(hsize_t)(n < 1048576 ? (n ? n : 1) : 1048576), 1};
+  hsize_t dims[2] = {(hsize_t)n, 1}, chunk[2] = {(hsize_t)(n < g_covar_chunk ? (n ? n : 1) : g_covar_chunk), 1};
   hid_t s = H5Screate_simple(2, dims, NULL);
   hid_t p = H5Pcreate(H5P_DATASET_CREATE);
-  if (n) {
+  if (n && g_covar_level) {
     H5Pset_chunk(p, 2, chunk);
-    H5Pset_shuffle(p);
-    H5Pset_deflate(p, 5);
+    if (g_covar_shuffle) H5Pset_shuffle(p);
+    H5Pset_deflate(p, g_covar_level);
   }
   hid_t d = H5Dcreate2(loc, name, type, s, H5P_DEFAULT, p, H5P_DEFAULT);
   int rc = (d < 0) ? -1 : (H5Dwrite(d, type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0 ? -1 : 0);
@@ -685,16 +701,27 @@ int exp_h5_covar_append(const char *path, const char *basisID, int kind, const i
   int rc = 0;
   unsigned count = 0;
   hid_t f = -1, snaps = -1, cd = -1;
+  /* expui/Covariance.cc:283-417: the file is opened ReadWrite | Create.  An existing HDF5 file WITHOUT the
+   * version attribute gets the attributes and groups added to it (nothing of it is dropped); a path that
+   * exists and is not HDF5 is an error, never truncated.                                               */
   htri_t isf = H5Fis_hdf5(path);
-  if (isf > 0) f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+  if (isf > 0) {
+    f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+    if (f < 0) return -1;
+  } else if (access(path, F_OK) == 0) {
+    return -2;                                             /* exists, not HDF5 */
+  }
   if (f >= 0 && H5Aexists(f, "CovarianceFileVersion") > 0) {          /* extendCoefCovariance */
     cd = H5Dopen2(f, "count", H5P_DEFAULT);
     if (cd < 0 || H5Dread(cd, H5T_NATIVE_UINT, H5S_ALL, H5S_ALL, H5P_DEFAULT, &count) < 0) rc = -1;
     snaps = H5Gopen2(f, "snapshots", H5P_DEFAULT);
   } else {
-    if (f >= 0) H5Fclose(f);
-    f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    if (f < 0) f = H5Fcreate(path, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT);
     if (f < 0) return -1;
+    if (H5Lexists(f, "count", H5P_DEFAULT) > 0 || H5Lexists(f, "snapshots", H5P_DEFAULT) > 0) {
+      H5Fclose(f);
+      return -2;                                           /* a foreign file that already uses these names */
+    }
     rc |= put_str(f, "CovarianceFileVersion", "1.1");
     rc |= put_str(f, "BasisID", basisID);
     rc |= put_int(f, "FloatSize", 8);

@@ -211,9 +211,23 @@ def covar_append(path: str, basis_id: str, kind: int, ipar, dpar, time: float, c
                                  counts.ctypes.data_as(ctypes.c_void_p), masses.ctypes.data_as(ctypes.c_void_p),
                                  m2.ctypes.data_as(ctypes.c_void_p),
                                  None if c2 is None else c2.ctypes.data_as(ctypes.c_void_p))
+    if rc == -2:
+        raise RuntimeError(f"SubsampleCovariance::writeCoefCovariance: <{path}> exists and is not a covariance "
+                           "file (not HDF5, or an HDF5 file with its own `count` / `snapshots`): left untouched")
     if rc < 0:
         raise RuntimeError(f"SubsampleCovariance::writeCoefCovariance: cannot write <{path}>")
     return rc == 0
+
+
+def covar_set_compress(level: int, chunksize: int, shuffle: bool, szip: bool = False) -> None:
+    """``SubsampleCovariance::setCovarH5Compress`` (include/Covariance.H:147-153): deflate level (0: none),
+    chunk size and shuffle filter of the datasets ``covar_append`` writes from now on."""
+    lib = _load()
+    lib.exp_h5_covar_set_compress.restype = ctypes.c_int
+    if lib.exp_h5_covar_set_compress(ctypes.c_uint(int(level)), ctypes.c_uint(int(chunksize)), int(bool(shuffle)),
+                                     int(bool(szip))):
+        raise RuntimeError("setCovarH5Compress: level must be 0..9, chunksize > 0, and szip is not available "
+                           "in this HDF5 build")
 
 
 def coef_geometry(path: str):

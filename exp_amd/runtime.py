@@ -593,6 +593,28 @@ class SphereSL(_Force):
                                            covr.ctypes.data), self.ctx.h)
         return {"counts": counts, "masses": masses, "mean": mean[..., 0] + 1j * mean[..., 1], "covr": covr}
 
+    def _need_density(self) -> None:
+        if not getattr(self, "_have_density", False):
+            d0 = as_f64(self.grid.d0)
+            check(self.lib.exp_amd_sph_set_density(self.h, d0[1]), self.ctx.h)
+            self._have_density = True
+
+    def basis(self, r) -> np.ndarray:
+        """``SphericalSL::getBasis``'s tables at the radii ``r`` -> [3, lmax+1, nmax, len(r)] = potential,
+        density, radial force of every (l, n) (expui/BiorthBasis.cc:960-993)."""
+        r = np.ascontiguousarray(np.atleast_1d(r), dtype=np.float64)
+        self._need_density()
+        out = np.empty((3, self.lmax + 1, self.nmax, r.size))
+        check(self.lib.exp_amd_sph_basis(self.h, r.size, r.ctypes.data, out.ctypes.data), self.ctx.h)
+        return out
+
+    def window_mass(self, comp: "Component") -> float:
+        """Mass of the particles of ``comp`` with rmin <= r <= rmax (``totalMass`` of
+        Spherical::accumulate, expui/BiorthBasis.cc:596-607)."""
+        m = c_double()
+        check(self.lib.exp_amd_sph_window_mass(self.h, comp.h, byref(m)), self.ctx.h)
+        return m.value
+
     FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
 
     def fields(self, c1, c2, c3, coord: str = "cartesian") -> np.ndarray:
@@ -702,6 +724,22 @@ class Cylinder(_Force):
                                            mv.ctypes.data), self.ctx.h)
         return {"counts": counts, "masses": masses, "mean": vc[..., 0] + 1j * vc[..., 1],
                 "covr": mv[..., 0] + 1j * mv[..., 1]}
+
+    def basis(self, R, z) -> np.ndarray:
+        """``Cylindrical::getBasis``'s tables at the points (R, z) -> [4, mmax+1, nmax, npts] = potential,
+        density, radial force, vertical force of every (m, n) at phi = 0 (``EmpCylSL::get_all``)."""
+        R = np.ascontiguousarray(np.atleast_1d(R), dtype=np.float64)
+        z = np.ascontiguousarray(np.atleast_1d(z), dtype=np.float64)
+        assert R.shape == z.shape
+        out = np.empty((4, self.mmax + 1, self.nmax, R.size))
+        check(self.lib.exp_amd_cyl_basis(self.h, R.size, R.ctypes.data, z.ctypes.data, out.ctypes.data), self.ctx.h)
+        return out
+
+    def orthocheck(self) -> np.ndarray:
+        """``EmpCylSL::orthoCheck`` (exputil/EmpCylSL.cc:7199-7260) -> [mmax+1, nmax, nmax]."""
+        out = np.empty((self.mmax + 1, self.nmax, self.nmax))
+        check(self.lib.exp_amd_cyl_orthocheck(self.h, out.ctypes.data), self.ctx.h)
+        return out
 
     def dump_coefs_binary(self, out, time: float = 0.0) -> None:
         """``EmpCylSL::dump_coefs_binary`` (exputil/EmpCylSL.cc:5868-5920): append the current

@@ -352,6 +352,25 @@ int  exp_amd_cyl_set_density(exp_amd_force *f, const double *dens);
 int  exp_amd_cyl_fields(exp_amd_force *f, size_t n, const double *c1, const double *c2,
                         const double *c3, int coord, double *out /* [n][9] */);
 
+/* ---- the basis functions themselves (pyEXP getBasis / orthoCheck / getMass) ------------------------
+ * SphericalSL::getBasis (expui/BiorthBasis.cc:960-993; pyEXP/BasisWrappers.cc:2142): SLGridSph::get_pot /
+ * get_dens / get_force (exputil/SLGridMP2.cc:872-989) of every (l, n) at n host radii r[] -- taken as they
+ * are, not divided by `scale` --; out[3][lmax+1][nmax][n] = potential, density, radial force (= -get_force).
+ * Needs exp_amd_sph_set_density.                                                                       */
+int  exp_amd_sph_basis(exp_amd_force *f, size_t n, const double *r, double *out);
+/* Mass of the particles of `c` inside the expansion window rmin <= r <= rmax, r = sqrt(r^2) + dsmall: what
+ * Spherical::accumulate adds to totalMass (expui/BiorthBasis.cc:596-607) and BiorthBasis::getMass returns
+ * (expui/BiorthBasis.H:189; pyEXP/BasisWrappers.cc:1729).                                              */
+int  exp_amd_sph_window_mass(exp_amd_force *f, exp_amd_comp *c, double *mass);
+/* Cylindrical::getBasis (expui/BiorthBasis.cc:1930-1974; pyEXP/BasisWrappers.cc:1811): EmpCylSL::get_all(m, n,
+ * R, z, phi = 0) (exputil/EmpCylSL.cc:5635-5800) of every (m, n) at n host points -- the cosine tables'
+ * bilinear blend on the grid, the monopole of cylmass beyond the table radius;
+ * out[4][mmax+1][nmax][n] = potential, density, radial force, vertical force.  Needs exp_amd_cyl_set_density. */
+int  exp_amd_cyl_basis(exp_amd_force *f, size_t n, const double *R, const double *z, double *out);
+/* EmpCylSL::orthoCheck (exputil/EmpCylSL.cc:7199-7260) behind Cylindrical.orthoCheck (pyEXP/BasisWrappers.cc:
+ * 1854): the pot x dens overlap integrals on the table grid; out[mmax+1][nmax][nmax].                    */
+int  exp_amd_cyl_orthocheck(exp_amd_force *f, double *out);
+
 /* Sub-sample covariance of the cylindrical coefficients (pyEXP: Cylindrical::enableCoefCovariance,
  * getCoefCovariance, getCovarSamples; the `covar` branch of EmpCylSL::accumulate, exputil/EmpCylSL.cc:
  * 4049-4146, :4554-4575, :4974-5015).  accumulate files every particle of `c` that lies on the grid

@@ -639,3 +639,90 @@ class Oracle:
                                         ctypes.c_double(scale), _dp(v), _dp(a),
                                         ctypes.c_double(pot), ctypes.byref(dtreq))
         return int(lev), dtreq.value
+
+    # -- pyEXP.basis beyond accumulate / getAccel / getFields (oracle/pyexp_oracle.c) ----------------------------
+    @staticmethod
+    def legequad(knots):
+        """LegeQuad(knots): Gauss-Legendre knots and weights on [0, 1]."""
+        x, w = npleg.leggauss(knots)
+        return np.ascontiguousarray(0.5 * (x + 1.0)), np.ascontiguousarray(0.5 * w)
+
+    def pyexp_sph_get_basis(self, g, logxmin, logxmax, numgrid):
+        out = np.zeros((3, g.lmax + 1, g.nmax, numgrid))
+        self.lib.orc_pyexp_sph_get_basis(ctypes.byref(self.grid(g)), ctypes.c_double(logxmin), ctypes.c_double(logxmax),
+                                         ctypes.c_int(numgrid), _dp(out))
+        return out
+
+    def pyexp_sph_quad_points(self, rmin, rmax, rmapping, knots):
+        k, w = self.legequad(knots)
+        xyz = np.zeros((knots ** 3, 3))
+        self.lib.orc_pyexp_sph_quad_points(ctypes.c_double(rmin), ctypes.c_double(rmax), ctypes.c_double(rmapping),
+                                           ctypes.c_int(knots), _dp(k), _dp(w), _dp(xyz))
+        return xyz
+
+    def pyexp_sph_make_from_function(self, g, rmin, rmax, rmapping, knots, fv, potential=False):
+        k, w = self.legequad(knots)
+        fv = np.ascontiguousarray(fv, dtype=np.float64)
+        assert fv.size == knots ** 3
+        mat = np.zeros(((g.lmax + 1) * (g.lmax + 2) // 2, g.nmax, 2))
+        self.lib.orc_pyexp_sph_make_from_function(ctypes.byref(self.grid(g)), ctypes.c_double(rmin), ctypes.c_double(rmax),
+                                                  ctypes.c_double(rmapping), ctypes.c_int(knots), _dp(k), _dp(w), _dp(fv),
+                                                  ctypes.c_int(int(potential)), _dp(mat))
+        return mat[..., 0] + 1j * mat[..., 1]
+
+    def pyexp_sph_compute_quadrature(self, rmin, rmax, rmapping, knots, fv):
+        k, w = self.legequad(knots)
+        fv = np.ascontiguousarray(fv, dtype=np.float64)
+        self.lib.orc_pyexp_sph_compute_quadrature.restype = ctypes.c_double
+        return float(self.lib.orc_pyexp_sph_compute_quadrature(ctypes.c_double(rmin), ctypes.c_double(rmax),
+                                                               ctypes.c_double(rmapping), ctypes.c_int(knots), _dp(k),
+                                                               _dp(w), _dp(fv)))
+
+    def _cyl_dens(self, g):
+        d = np.ascontiguousarray(g.dens, dtype=np.float64)
+        self._keep.append(d)
+        return d
+
+    def cyl_get_all(self, g, cylmass, mm, nn, R, z, phi, **kw):
+        out = np.zeros(5)
+        self.lib.orc_cyl_get_all(ctypes.byref(self.cylgrid(g, **kw)), _dp(self._cyl_dens(g)), ctypes.c_double(cylmass),
+                                 ctypes.c_int(mm), ctypes.c_int(nn), ctypes.c_double(R), ctypes.c_double(z),
+                                 ctypes.c_double(phi), _dp(out))
+        return out
+
+    def pyexp_cyl_get_basis(self, g, cylmass, xmin, xmax, numR, zmin, zmax, numZ, linear=True, **kw):
+        out = np.zeros((4, g.mmax + 1, g.norder, numR, numZ))
+        self.lib.orc_pyexp_cyl_get_basis(ctypes.byref(self.cylgrid(g, **kw)), _dp(self._cyl_dens(g)),
+                                         ctypes.c_double(cylmass), ctypes.c_double(xmin), ctypes.c_double(xmax),
+                                         ctypes.c_int(numR), ctypes.c_double(zmin), ctypes.c_double(zmax),
+                                         ctypes.c_int(numZ), ctypes.c_int(int(linear)), _dp(out))
+        return out
+
+    def cyl_orthocheck(self, g, **kw):
+        out = np.zeros((g.mmax + 1, g.norder, g.norder))
+        self.lib.orc_cyl_orthocheck(ctypes.byref(self.cylgrid(g, **kw)), _dp(self._cyl_dens(g)), _dp(out))
+        return out
+
+    def pyexp_cyl_quad_points(self, g, rmin, knots, **kw):
+        k, _ = self.legequad(knots)
+        xyz = np.zeros((knots ** 3, 3))
+        self.lib.orc_pyexp_cyl_quad_points(ctypes.byref(self.cylgrid(g, **kw)), ctypes.c_double(rmin), ctypes.c_int(knots),
+                                           _dp(k), _dp(xyz))
+        return xyz
+
+    def pyexp_cyl_make_from_function(self, g, rmin, knots, fv, potential=False, **kw):
+        k, w = self.legequad(knots)
+        fv = np.ascontiguousarray(fv, dtype=np.float64)
+        assert fv.size == knots ** 3
+        mat = np.zeros((g.mmax + 1, g.norder, 2))
+        self.lib.orc_pyexp_cyl_make_from_function(ctypes.byref(self.cylgrid(g, **kw)), _dp(self._cyl_dens(g)),
+                                                  ctypes.c_double(rmin), ctypes.c_int(knots), _dp(k), _dp(w), _dp(fv),
+                                                  ctypes.c_int(int(potential)), _dp(mat))
+        return mat[..., 0] + 1j * mat[..., 1]
+
+    def pyexp_cyl_compute_quadrature(self, g, rmin, knots, fv, **kw):
+        k, w = self.legequad(knots)
+        fv = np.ascontiguousarray(fv, dtype=np.float64)
+        self.lib.orc_pyexp_cyl_compute_quadrature.restype = ctypes.c_double
+        return float(self.lib.orc_pyexp_cyl_compute_quadrature(ctypes.byref(self.cylgrid(g, **kw)), ctypes.c_double(rmin),
+                                                               ctypes.c_int(knots), _dp(k), _dp(w), _dp(fv)))

@@ -419,3 +419,154 @@ def test_tuned_cpu_baseline_equals_the_oracle(oracle):
         a2, p2 = oracle.tuned_accel(g, t, prm, pos, oracle.tuned_project(g, t, coef))
         assert np.abs(a2 - acc).max() <= 1e-11 * np.abs(acc).max(), kw
         assert np.abs(p2 - pot).max() <= 1e-11 * np.abs(pot).max(), kw
+
+
+# ---- exact l > 0 known answers (SURVEY 8c iii-v for every l, not only the monopole) ----------------------------
+
+KAT_MODES = [(1, 0, 0), (1, 1, 1), (2, 1, 0), (2, 2, 1), (3, 3, 0), (4, 2, 1), (5, 4, 0), (6, 0, 0), (6, 6, 1)]
+
+
+def multipole_errors(case, coef, accel_fn):
+    """Per mode: (max |Phi - exact| / max |exact|, pointwise relative errors of Phi, of the acceleration)
+    of the field of that mode's coefficient ROW ALONE, evaluated by `accel_fn(points, coef)`."""
+    from tests.kat_multipole import row_of
+    pts = case.test_points()
+    out = []
+    for k, md in enumerate(case.modes):
+        only = np.zeros_like(coef)
+        only[row_of(*md)] = coef[row_of(*md)]
+        acc, pot = accel_fn(pts, only)
+        epot, eacc = case.exact_mode(k, pts)
+        out.append((np.abs(pot - epot).max() / np.abs(epot).max(), np.abs(pot - epot) / np.abs(epot),
+                    np.linalg.norm(acc - eacc, axis=1) / np.linalg.norm(eacc, axis=1)))
+    return out
+
+
+def check_multipole_errors(errs, modes):
+    """The bars of the l > 0 known answer at nmax >= 12, numr 800 (set by the n-truncation and the
+    table's linear interpolation; measured: 6e-6 .. 2.5e-5 of the maximum, pointwise 1e-6 .. 2e-4 for
+    r <= 3, <= 8e-3 at r = 8, <= 2e-2 at 0.98 rmax and beyond rmax)."""
+    for (emax, epot, eacc), md in zip(errs, modes):
+        assert emax < 1e-4, (md, emax)
+        assert epot[:5].max() < 1e-3 and eacc[:5].max() < 1e-3, (md, epot, eacc)       # r = 0.2 .. 3
+        assert epot[5:].max() < 5e-2 and eacc[5:].max() < 5e-2, (md, epot, eacc)       # r = 8, 0.98 b, 1.5 b, 4 b
+
+
+def test_multipole_known_answers_for_every_l(oracle):
+    """A density made of single solid harmonics l = 1..6 (cos and sin rows, m = 0..l) on a smooth radial
+    profile, laid down as an exact product quadrature: (i) only the excited rows of the coefficient array
+    are non-zero -- to 1e-14: pins the row order l^2 + 2m-1+cs and the cos/sin assignment; (ii) the field
+    of each row alone, evaluated by the n-body force path (src/SphericalBasis.cc:1476-1660), is the
+    classical multipole solution of that density, inside, near and BEYOND rmax -- pins factorial(l,m),
+    the sqrt(2), the Condon-Shortley sign, -4 pi and the normalisation of every l's radial functions
+    jointly (:328-335, :519-566) against an answer that contains none of them; (iii) the error falls
+    with nmax (n-truncation), then saturates at the table's interpolation error."""
+    from tests.kat_multipole import MultipoleCase, row_of
+    errs = {}
+    for nmax in (6, 12):
+        model, g = make_grid("plummer", 6, nmax, 800)
+        case = MultipoleCase(model, g, KAT_MODES)
+        prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+        coef, used = oracle.sph_accumulate(g, prm, case.pos, case.mass)
+        assert used == len(case.mass)
+        rows = [row_of(*md) for md in KAT_MODES]
+        quiet = np.delete(coef, rows, axis=0)
+        assert np.abs(quiet).max() < 1e-13 * np.abs(coef).max()
+        errs[nmax] = multipole_errors(case, coef, lambda p, c: oracle.sph_accel(g, prm, p, c))
+    check_multipole_errors(errs[12], KAT_MODES)
+    for (e6, _, _), (e12, _, _), md in zip(errs[6], errs[12], KAT_MODES):
+        assert e12 < 0.2 * e6, (md, e6, e12)
+
+
+def test_multipole_known_answer_pyexp_twin(oracle):
+    """The same known answer through the pyEXP twins (Spherical::accumulate, expui/BiorthBasis.cc:583-665,
+    and the field evaluation :711-816): their lgamma-form factorial(l,m) and direct cos(m phi) obey it too
+    (potential; and the Cartesian force inside rmax -- computeAccel has no exterior branch)."""
+    from tests.kat_multipole import MultipoleCase, row_of
+    model, g = make_grid("plummer", 6, 12, 800)
+    case = MultipoleCase(model, g, KAT_MODES)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.pyexp_sph_accumulate(g, prm, case.pos, case.mass)
+    pts = case.test_points()[:7]
+    for k, md in enumerate(KAT_MODES):
+        only = np.zeros_like(coef)
+        only[row_of(*md)] = coef[row_of(*md)]
+        f = oracle.sph_fields(g, prm, only, pts[:, 0], pts[:, 1], pts[:, 2], "cartesian")
+        epot, eacc = case.exact_mode(k, pts)
+        assert np.abs(f[:, 5] - epot).max() < 1e-4 * np.abs(epot).max(), md
+        rel = np.linalg.norm(f[:, 6:9] - eacc, axis=1) / np.linalg.norm(eacc, axis=1)
+        assert rel[:5].max() < 1e-3 and rel.max() < 5e-2, (md, rel)
+
+
+def poisson_residuals(g, get_pot, get_force, get_dens, r1, r2):
+    """Integral form of the radial Poisson equation of every (l, n) basis pair on [r1, r2]:
+        r2^2 phi'(r2) - r1^2 phi'(r1) - l(l+1) int phi dr  =  int dens r^2 dr
+    (the pyEXP density carries 1/4pi in its prefactor, expui/BiorthBasis.cc:806, so that 4 pi rho = dens).
+    Returns the worst |lhs - rhs| / (sum of the magnitudes of the terms) over (l, n)."""
+    xg, wg = np.polynomial.legendre.leggauss(8)
+    edges = np.geomspace(r1, r2, 400)
+    lo, hi = edges[:-1], edges[1:]
+    rr = (0.5 * (lo + hi)[:, None] + 0.5 * (hi - lo)[:, None] * xg[None, :]).ravel()
+    ww = (0.5 * (hi - lo)[:, None] * wg[None, :]).ravel()
+    P, D = get_pot(rr), get_dens(rr)                       # [nr, L+1, nmax]
+    f1, f2 = get_force(np.array([r1]))[0], get_force(np.array([r2]))[0]
+    worst = 0.0
+    for l in range(g.lmax + 1):
+        ip = (P[:, l, :] * ww[:, None]).sum(0)
+        lhs = r2 * r2 * f2[l] - r1 * r1 * f1[l] - l * (l + 1) * ip
+        rhs = (D[:, l, :] * (rr * rr * ww)[:, None]).sum(0)
+        scale = np.abs(r2 * r2 * f2[l]) + np.abs(r1 * r1 * f1[l]) + l * (l + 1) * np.abs(ip)
+        worst = max(worst, float((np.abs(lhs - rhs) / scale).max()))
+    return worst
+
+
+@pytest.mark.parametrize("kind", ["plummer", "nfw"])
+def test_poisson_consistency_for_every_l(oracle, kind):
+    """SURVEY 8c-v for l > 0: potential, radial force and density tables (SLGridSph::get_pot / get_force /
+    get_dens, exputil/SLGridMP2.cc:872-989) of every (l, n) satisfy Poisson's equation in integral form --
+    pins the sign, the 4 pi and the sqrt(ev) placement of the density against the potential and the
+    3-point force rule against both.  Tolerance: the O(dxi^2) of the lerped tables (measured <= 2e-3 on
+    Plummer, <= 4e-3 on the truncated NFW at numr 800)."""
+    model, g = make_grid(kind, 6, 12, 800)
+    tab = lambda fn: (lambda rr: np.array([fn(g, float(r)) for r in rr]))
+    for r1, r2 in ((0.05, 0.4), (0.3, 2.0), (1.0, 10.0)):
+        w = poisson_residuals(g, tab(oracle.get_pot), tab(oracle.get_force), tab(oracle.get_dens), r1, r2)
+        assert w < 8e-3, (kind, r1, r2, w)
+
+
+def test_make_from_function_twin_agrees_with_the_particle_path(oracle):
+    """oracle/pyexp_oracle.c's Spherical::makeFromFunction (expui/BiorthBasis.cc:5230-5362) against the
+    particle accumulation: for the same density, c_accumulate = -4 pi x mat_makeFromFunction (the function
+    form carries no -4 pi), the quadrature particles of tests/kat_multipole.py on one side, the reference's
+    knots^3 product rule on the other.  computeQuadrature returns the density's mass."""
+    from tests.kat_multipole import MultipoleCase, harmonic
+    model, g = make_grid("plummer", 4, 8, 400)
+    modes = [(1, 1, 0), (2, 0, 0), (3, 2, 1), (4, 4, 0)]
+    case = MultipoleCase(model, g, modes, monopole=True)
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.pyexp_sph_accumulate(g, prm, case.pos, case.mass)
+    knots = 48
+
+    def rho(p):
+        r = np.linalg.norm(p, axis=1)
+        ct, ph = p[:, 2] / r, np.arctan2(p[:, 1], p[:, 0])
+        out = model.dens(r)
+        for (l, m, cs), e in zip(modes, case.eps):
+            out = out + e * case.shape(l, r) * harmonic(l, m, cs, ct, ph)
+        return out
+
+    xyz = oracle.pyexp_sph_quad_points(g.rmin, g.rmax, g.rmap, knots)
+    fv = rho(xyz)
+    mat = oracle.pyexp_sph_make_from_function(g, g.rmin, g.rmax, g.rmap, knots, fv, False)
+    L0 = L1 = 0
+    packed = np.zeros_like(mat)
+    for l in range(g.lmax + 1):
+        for m in range(l + 1):
+            if m == 0:
+                packed[L0] = coef[L1]; L1 += 1
+            else:
+                packed[L0] = coef[L1] + 1j * coef[L1 + 1]; L1 += 2
+            L0 += 1
+    assert np.abs(packed - (-4.0 * math.pi) * mat).max() < 2e-4 * np.abs(packed).max()
+    mass = oracle.pyexp_sph_compute_quadrature(g.rmin, g.rmax, g.rmap, knots, fv)
+    assert mass == pytest.approx(case.mass.sum(), rel=1e-4)
