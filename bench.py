@@ -69,7 +69,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nbodies", type=float, default=1e8, help="TOTAL particle count (all ranks)")
+    ap.add_argument("--nbodies", type=float, default=1e8,
+                    help="particle count: the TOTAL over all ranks with --scaling strong (default), PER GPU with "
+                         "--scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: --nbodies particles in total, N/world per GPU (BASELINE config 5: 1e8 sharded); "
+                         "weak: --nbodies particles on EVERY GPU (SURVEY 8d config 5 asks for both curves; the "
+                         "8-GPU share of the strong run is `--scaling weak --nbodies 1.25e7`)")
     ap.add_argument("--lmax", type=int, default=10)
     ap.add_argument("--nmax", type=int, default=24)
     ap.add_argument("--numr", type=int, default=2000)
@@ -184,18 +190,54 @@ def _cpu_steps_tuned(orc, grid, prm, dt, m, pos, vel, nthreads, budget_s, max_st
     return n * nsteps / el, nsteps
 
 
-def cpu_baseline(grid, model, nsample, dt):
-    """The oracle (CPU restatement of EXP's CPU path, scalar fp64) timed on this host on a bounded
-    sample of the same workload: once on 1 thread, once on all the cores this process may use,
-    sliced the way the reference slices particles over its pthreads.  Baseline only -- DESIGN.md."""
-    from exp_amd.models import sample_sphere
-    from tests.oracle_lib import Oracle
-    orc = Oracle()
+def host_cpus():
+    """What this process may really use: min(affinity mask, cgroup CPU quota) -- a container that shows hundreds
+    of CPUs often owns a fraction of them in quota, and a threaded rate scales with the quota -- and the CPU model."""
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:      # pragma: no cover
         ncpu = os.cpu_count() or 1
-    nthreads = max(1, min(ncpu, 64))
+    host = {"affinity_cpus": ncpu, "os_cpu_count": os.cpu_count()}
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().strip()
+        host["cgroup_cpu.max"] = txt
+        a, b = txt.split()
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            host["cgroup_cfs_quota_us"] = q
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    host["cgroup_quota_cpus"] = quota
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                host["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = ncpu if quota is None else max(1, min(ncpu, int(math.floor(quota + 1e-9))))
+    host["usable_cpus"] = max(1, min(usable, 64))
+    return host
+
+
+def cpu_baseline(grid, model, nsample, dt):
+    """The oracle (CPU restatement of EXP's CPU path, scalar fp64) timed on this host on a bounded
+    sample of the same workload: once on 1 thread, once on all the cores this process may use (its
+    affinity mask capped by the cgroup CPU quota), sliced the way the reference slices particles over its
+    pthreads; then the device algorithm on those threads (`tuned`) and the reference's DATA STRUCTURE around
+    the same arithmetic (`reference_structure`).  Baseline only -- DESIGN.md."""
+    from exp_amd.models import sample_sphere
+    from tests.oracle_lib import Oracle
+    orc = Oracle()
+    host = host_cpus()
+    nthreads = host["usable_cpus"]
     prm = orc.params(rmin=grid.rmin, rmax=grid.rmax)
     m, pos, vel = sample_sphere(model, nsample, seed=777)
     v1, s1 = _cpu_steps(orc, grid, prm, dt, m, pos, vel, 1, 6.0, 50)
@@ -205,17 +247,30 @@ def cpu_baseline(grid, model, nsample, dt):
     # tuned CPU mode: the device path's hoisting on the same threads
     mt, post, velt = sample_sphere(model, big * 4, seed=779)
     vt, st = _cpu_steps_tuned(orc, grid, prm, dt, mt, post, velt, nthreads, 6.0, 50)
-    # what the process may actually use: affinity mask, cgroup CPU quota (a container's "64 CPUs" are often
-    # a fraction of that in quota: the threaded rate then scales with the quota, not with the thread count)
-    host = {"affinity_cpus": ncpu, "os_cpu_count": os.cpu_count()}
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            host["cgroup_" + os.path.basename(path)] = open(path).read().strip()
-            break
-        except OSError:
-            pass
+    # reference-structure mode (oracle/refstruct_cpu.c): hash map of individually allocated
+    # particles, level list of keys, five separate pthread-forked passes per step -- at N = 1e5 and 1e6
+    refstruct = {}
+    for nref in (100_000, 1_000_000):
+        mr, pr, vr = sample_sphere(model, nref, seed=780)
+        rs = orc.refstruct(mr, pr, vr)
+        G = orc.grid(grid)
+        orc.refstruct_field(rs, grid, prm, nthreads)
+        t0, ns = time.perf_counter(), 0
+        while True:
+            orc.refstruct_step(rs, grid, prm, dt, nthreads, G)
+            ns += 1
+            el = time.perf_counter() - t0
+            if el > 4.0 or ns >= 50:
+                break
+        orc.refstruct_free(rs)
+        refstruct[f"N={nref:.0e}"] = {"value": nref * ns / el, "steps": ns, "seconds": el}
     return {"value": max(vn, v1), "unit": "particle-steps/s", "cores": nthreads if vn >= v1 else 1,
             "kind": "port", "value_1thread": v1, "thread_speedup": vn / v1 if v1 > 0 else None, "host": host,
+            "reference_structure": {**refstruct, "cores": nthreads,
+                                    "what": "oracle/refstruct_cpu.c: the same arithmetic behind EXP's data structure -- "
+                                            "unordered_map-style hash of ~200-byte particle objects, level list of keys, "
+                                            "Mass/Pos/AddAcc lookups per access, five pthread-forked passes per step "
+                                            "(kick, drift, coefficients, force, kick); a restatement, not a build of EXP"},
             "tuned": {"value": vt, "cores": nthreads, "steps": st, "particles": big * 4,
                       "what": "oracle/tuned_cpu.c: cell moments + contraction, projected force table "
                               "(the device algorithm on CPU threads), gcc -O3"},
@@ -451,10 +506,14 @@ def main():
                         cmap=1, rmap=1.0)
 
     # ---- particles: static block shard of the total -----------------------------------------------
-    ntot = int(args.nbodies)
-    n0 = ntot * rank // world
-    n1 = ntot * (rank + 1) // world
-    nloc = n1 - n0
+    if args.scaling == "weak":
+        nloc = int(args.nbodies)
+        ntot = nloc * world
+    else:
+        ntot = int(args.nbodies)
+        n0 = ntot * rank // world
+        n1 = ntot * (rank + 1) // world
+        nloc = n1 - n0
     x, y, z, vx, vy, vz = make_halo(model, nloc, seed=23456 + rank, device=device)
     mass = torch.full((nloc,), 1.0 / ntot, device=device, dtype=torch.float64)
     torch.cuda.synchronize()
@@ -515,13 +574,23 @@ def main():
     _flush_c_stdio()            # (every rank: the communicator exists by now)
     ctx.profile(True)
     ctx.profile_reset()
+    # per-step device times: one event per step boundary on the context's stream (SURVEY 8d timing protocol:
+    # the median of these is reported beside the mean of the wall-clock region that `value` is)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(tstream)
+    for k in range(args.steps):
         force.step_kdk(comp, args.dt)
+        marks[k + 1].record(tstream)
     barrier()
     el = time.perf_counter() - t0
     prof = ctx.profile_report()
     ctx.profile(False)
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    step_times = {"median_ms": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
+                  0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+                  "min_ms": step_ms[0], "max_ms": step_ms[-1],
+                  "what": "hipEvent time of each of the K timed steps on the context's stream (per-kernel events on)"}
 
     # A second, longer region (>= 2 s of steps, no per-kernel events): `value` stays the K steps the
     # contract asks for; this shows that the rate holds when the region is not a quarter of a second.
@@ -580,10 +649,15 @@ def main():
                         traffic = ent["hbm_bytes_per_launch"]
                 except Exception:
                     traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # achieved / peak / unit / frac are the contract's HBM accounting (algorithmic bytes over the kernel's
+            # time: `frac_of`); `bound` is DERIVED below: the roof the kernel sits closest to, i.e. the larger of
+            # the HBM fraction and the executed-fp64 fraction (= `binding_limit`)
+            roof = {"bound": "hbm", "frac_of": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                      "separate passes, of this command (tools/profile.sh)" if traffic else None,
+                    "traffic_source": "REPLAYED from profiles/traffic.json, not measured in this run: rocprofv3 --pmc "
+                                      "FETCH_SIZE / WRITE_SIZE, separate passes, of this same command on an earlier box "
+                                      "(tools/profile.sh; a process cannot read those counters about itself)"
+                                      if traffic else None,
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_particle": ALGO_BYTES.get(dom, 0.0),
                     "step_achieved": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9,
@@ -601,9 +675,11 @@ def main():
             fl = EXEC_FLOPS.get((dom, args.lmax))
             if fl:
                 tf = fl * nloc / (avg_ms * 1e-3) / 1e12
-                roof["binding_limit"] = "fp64_vector"
                 roof["fp64_vector"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": tf / FP64_VECTOR_PEAK_TF, "flops_per_particle": fl}
+                own_frac = roof.get("kernel_own_frac", roof["frac"])
+                roof["binding_limit"] = "fp64_vector" if tf / FP64_VECTOR_PEAK_TF > max(own_frac, roof["frac"]) else "hbm"
+                roof["bound"] = roof["binding_limit"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(grid, model, args.cpu_sample, args.dt)
@@ -623,8 +699,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "step_times": step_times,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

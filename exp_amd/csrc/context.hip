@@ -330,6 +330,6 @@ extern "C" int exp_amd_comm_info(exp_amd_ctx *ctx, int *kind, int *nranks, int *
 // the collective the force methods use, exposed so that a host can check the communicator it set up
 extern "C" int exp_amd_comm_allreduce(exp_amd_ctx *ctx, void *dev, size_t count)
 {
-  if (!ctx || !dev) return EXP_AMD_ERR_ARG;
+  if (!ctx || !dev) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_allreduce: NULL argument");
   return expamd_allreduce(ctx, (double *)dev, count);
 }

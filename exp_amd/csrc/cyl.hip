@@ -1200,7 +1200,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   f->home = c;
   f->home_gone = false;
   const int nact = ms - lo + 1;
-  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
+  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms, lo) : AdvSpec();
   int rc;
   // dense levels (cell-sorted) of the active suffix end at dmax; the levels above it are sparse
   int dmax = lo - 1;
@@ -1686,7 +1686,7 @@ extern "C" int exp_amd_cyl_cov_accumulate(exp_amd_force *fb, exp_amd_comp *c, co
   if (!f || !c || !f->cov_T) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cyl_cov_accumulate: covariance not enabled");
   exp_amd_ctx *ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  // (positions and masses only: whatever half-kick the velocities are owed or ahead by does not matter here)
   if (on_grid) *on_grid = 0;
   if (c->n == 0) return EXP_AMD_OK;
   if (seq) {

@@ -62,7 +62,10 @@ static int overlap_begin(exp_amd_sim *s)
   if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
-  s->overlap = s->multistep > 0 && s->comps.size() >= 2 && !any_orient && !ctx->ar_fn &&
+  // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
+  // followed across the streams by ONE pair of events -- with a third component the cross forces of one
+  // source on two targets would run on both streams at once and share the scratch of its force pass)
+  s->overlap = s->multistep > 0 && s->comps.size() == 2 && !any_orient && !ctx->ar_fn &&
                ctx->nranks == 1 && !ctx->rccl_comm && !(env && atoi(env) == 0);
   if (!s->overlap) return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);

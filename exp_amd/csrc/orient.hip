@@ -74,9 +74,12 @@ __device__ __forceinline__ void ori_hist_add(uint32_t *lh, unsigned digit, bool 
 // energies -> keys, and the histogram of their most significant digit in the same pass
 __global__ void __launch_bounds__(ORI_TPB)
 k_orient_keys(const double *__restrict__ POT, const double *__restrict__ VX,
-              const double *__restrict__ VY, const double *__restrict__ VZ, size_t n, int ke,
+              const double *__restrict__ VY, const double *__restrict__ VZ, const double *__restrict__ AX,
+              const double *__restrict__ AY, const double *__restrict__ AZ, double back, size_t n, int ke,
               unsigned long long *__restrict__ key, double *__restrict__ hist)
 {
+  // back != 0: the stored velocities carry the next step's opening half-kick (exp_amd_comp::pending_kick < 0);
+  // the velocity of the step boundary is v + a * back, formed here and never stored (expamd_comp_velocity_view)
   __shared__ uint32_t lh[ORI_BINS];
   for (int b = threadIdx.x; b < ORI_BINS; b += ORI_TPB) lh[b] = 0;
   __syncthreads();
@@ -89,9 +92,13 @@ k_orient_keys(const double *__restrict__ POT, const double *__restrict__ VX,
       if (valid) {
         double e = POT[i];
         if (ke) {                  // v2 += vel[k]*vel[k]; energy += 0.5*v2 -- each product rounded (:352-359)
-          double v2 = mul_then_add(0.0, VX[i], VX[i]);
-          v2 = mul_then_add(v2, VY[i], VY[i]);
-          v2 = mul_then_add(v2, VZ[i], VZ[i]);
+          double vx = VX[i], vy = VY[i], vz = VZ[i];
+          if (back != 0.0) {
+            vx = mul_then_add(vx, AX[i], back); vy = mul_then_add(vy, AY[i], back); vz = mul_then_add(vz, AZ[i], back);
+          }
+          double v2 = mul_then_add(0.0, vx, vx);
+          v2 = mul_then_add(v2, vy, vy);
+          v2 = mul_then_add(v2, vz, vz);
           e = mul_then_add(e, 0.5, v2);
         }
         k = ord_key(e);
@@ -223,7 +230,8 @@ __global__ void __launch_bounds__(ORI_TPB)
 k_orient_sums(const unsigned long long *__restrict__ key, const double *__restrict__ M,
               const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
               const double *__restrict__ VX, const double *__restrict__ VY,
-              const double *__restrict__ VZ, size_t n, const OriState *__restrict__ st,
+              const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
+              const double *__restrict__ AZ, double back, size_t n, const OriState *__restrict__ st,
               double cx, double cy, double cz, double *__restrict__ part /* [gridDim.x][8] */)
 {
   __shared__ double wsum[ORI_TPB / 64][8];
@@ -232,7 +240,11 @@ k_orient_sums(const unsigned long long *__restrict__ key, const double *__restri
   const size_t stride = (size_t)gridDim.x * ORI_TPB;
   for (size_t i = (size_t)blockIdx.x * ORI_TPB + threadIdx.x; i < n; i += stride) {
     if (key[i] >= thr) continue;                     // i->E < Ecurr   (:489)
-    const double m = M[i], x = X[i], y = Y[i], z = Z[i], vx = VX[i], vy = VY[i], vz = VZ[i];
+    const double m = M[i], x = X[i], y = Y[i], z = Z[i];
+    double vx = VX[i], vy = VY[i], vz = VZ[i];
+    if (back != 0.0) {
+      vx = mul_then_add(vx, AX[i], back); vy = mul_then_add(vy, AY[i], back); vz = mul_then_add(vz, AZ[i], back);
+    }
     const double px = x - cx, py = y - cy, pz = z - cz;
     v[0] += 1.0;
     v[1] += m;
@@ -393,7 +405,8 @@ static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], doub
 {
   exp_amd_ctx *ctx = o->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  double back = 0.0;                    // read-only view of the step-boundary velocities: the store is not touched
+  { int rc_ = expamd_comp_velocity_view(c, &back); if (rc_) return rc_; }
   const size_t n = c->n;
   if (o->keys.n < n && (o->keys.alloc(n) != hipSuccess || o->cand.alloc(n) != hipSuccess))
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "Orient: hipMalloc of %zu keys failed", n);
@@ -409,7 +422,8 @@ static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], doub
     for (int p = 0; p < 6; p++) {
       if (n) {
         if (p == 0)            // keys + first digit in one pass over pot, v
-          k_orient_keys<<<gbig, ORI_TPB, 0, ctx->stream>>>(c->a(A_POT), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n,
+          k_orient_keys<<<gbig, ORI_TPB, 0, ctx->stream>>>(c->a(A_POT), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX),
+                                                         c->a(A_AY), c->a(A_AZ), back, n,
                                                          (o->cflags & ORI_KE) ? 1 : 0, o->keys.p, o->hist.p);
         else if (p == 1)
           k_orient_hist<<<gbig, ORI_TPB, 0, ctx->stream>>>(o->keys.p, n, nullptr, o->state.p, p, shift[p],
@@ -430,8 +444,8 @@ static int orient_select(exp_amd_orient *o, exp_amd_comp *c, double res[8], doub
       unsigned grid = cdiv(n, ORI_TPB * 16);
       if (grid > (unsigned)ORI_SUM_BLOCKS) grid = ORI_SUM_BLOCKS;
       k_orient_sums<<<grid, ORI_TPB, 0, ctx->stream>>>(o->keys.p, c->a(A_M), c->a(A_X), c->a(A_Y),
-                                                       c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), n,
-                                                       o->state.p, o->center[0], o->center[1],
+                                                       c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX),
+                                                       c->a(A_AY), c->a(A_AZ), back, n, o->state.p, o->center[0], o->center[1],
                                                        o->center[2], o->part.p);
       k_orient_final<<<1, 64, 0, ctx->stream>>>(o->part.p, (int)grid, o->sums.p);
     }

@@ -10,9 +10,11 @@ struct AdvSpec {
   int mode = 0;
   double dt_kick = 0.0, dt_drift = 0.0, dt_min = 0.0;
   int multistep = 0;
+  int lev_lo = 0;        // mode 2: levels below are passed through unadvanced (a full re-partition of a sub-step
+                         // whose active levels start at lev_lo also moves the inactive ones)
   static AdvSpec none() { return AdvSpec{}; }
   static AdvSpec step(bool on, double dtk, double dtd) { AdvSpec a; a.mode = on ? 1 : 0; a.dt_kick = dtk; a.dt_drift = dtd; return a; }
-  static AdvSpec levels(double dt_min_, int ms) { AdvSpec a; a.mode = 2; a.dt_min = dt_min_; a.multistep = ms; return a; }
+  static AdvSpec levels(double dt_min_, int ms, int lo = 0) { AdvSpec a; a.mode = 2; a.dt_min = dt_min_; a.multistep = ms; a.lev_lo = lo; return a; }
 };
 
 enum { A_X = 0, A_Y, A_Z, A_VX, A_VY, A_VZ, A_M, A_AX, A_AY, A_AZ, A_POT, A_NARR };
@@ -134,3 +136,6 @@ int expamd_comp_touch_keep_partition(exp_amd_comp *c);
 // ... only the first half (a read-only call: the recorded keys stay valid, they were computed from
 // the kicked velocity)
 int expamd_comp_apply_pending(exp_amd_comp *c);
+// ... a read-only look at the step-boundary velocities that does not change the stored state: *back = 0 (velocities
+// are current, a closing half-kick owed has been applied) or the (negative) dt with which v + a * dt is the value
+int expamd_comp_velocity_view(exp_amd_comp *c, double *back);

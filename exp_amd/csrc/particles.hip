@@ -368,6 +368,18 @@ int expamd_comp_touch_keep_partition(exp_amd_comp *c)
   return expamd_comp_apply_pending(c);
 }
 
+// A read-only consumer of the step-boundary velocities (fix_positions, Orient::accumulate): a closing half-kick
+// still owed (pending_kick > 0) is applied -- exactly the operation the next step would do first --, velocities
+// that are AHEAD by the next opening half-kick (pending_kick < 0, prekick) stay as they are and the caller forms
+// v + a * (*back) on the fly, as exp_amd_comp_download does: un-kicking and re-kicking a rounded operation would
+// move the trajectory by an ulp just because a diagnostic looked.  The keys recorded for the next step stay valid.
+int expamd_comp_velocity_view(exp_amd_comp *c, double *back)
+{
+  *back = c->pending_kick < 0.0 ? c->pending_kick : 0.0;
+  if (*back != 0.0) return EXP_AMD_OK;
+  return expamd_comp_apply_pending(c);
+}
+
 int expamd_comp_apply_pending(exp_amd_comp *c)
 {
   if (c->pending_kick != 0.0 && c->n) {
@@ -398,6 +410,7 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv)
   if (A.nokick) A.dt_kick0 = 0.0;
   A.advance = adv.mode;
   A.multistep = adv.multistep;
+  A.lev_lo = adv.lev_lo;
   A.dt_min = adv.dt_min;
   return A;
 }
@@ -971,7 +984,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
 extern "C" int exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
-  if (!c || !level) return EXP_AMD_ERR_ARG;
+  if (!c || !level) return expamd_fail(c ? c->ctx : nullptr, EXP_AMD_ERR_ARG, "comp_upload_levels: NULL argument");
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
   c->levels_zero = false;
@@ -1075,6 +1088,8 @@ extern "C" int exp_amd_comp_drift(exp_amd_comp *c, double dt, int mlevel)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
+  if (mlevel >= c->nlevels)
+    return expamd_fail(c->ctx, EXP_AMD_ERR_ARG, "comp_drift: level %d beyond the component's %d level(s)", mlevel, c->nlevels);
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
   level_range(c, mlevel, false, &lo, &hi);
@@ -1090,6 +1105,8 @@ extern "C" int exp_amd_comp_kick(exp_amd_comp *c, double dt, int mlevel)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
+  if (mlevel >= c->nlevels)
+    return expamd_fail(c->ctx, EXP_AMD_ERR_ARG, "comp_kick: level %d beyond the component's %d level(s)", mlevel, c->nlevels);
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
   level_range(c, mlevel, false, &lo, &hi);
@@ -1125,7 +1142,7 @@ __global__ void __launch_bounds__(256)
 k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
              const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
              const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
-             const double *__restrict__ AZ, const uint8_t *__restrict__ lev, size_t n, int mlevel,
+             const double *__restrict__ AZ, double back, const uint8_t *__restrict__ lev, size_t n, int mlevel,
              int nlev, double *__restrict__ out /* [nlev][10] */)
 {
   __shared__ double acc[COM_MAXLEV][10];
@@ -1141,8 +1158,13 @@ k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const d
       const double m = M[i];
       v[0] += m;
       v[1] = fma(m, X[i], v[1]);  v[2] = fma(m, Y[i], v[2]);  v[3] = fma(m, Z[i], v[3]);
-      v[4] = fma(m, VX[i], v[4]); v[5] = fma(m, VY[i], v[5]); v[6] = fma(m, VZ[i], v[6]);
-      v[7] = fma(m, AX[i], v[7]); v[8] = fma(m, AY[i], v[8]); v[9] = fma(m, AZ[i], v[9]);
+      const double ax = AX[i], ay = AY[i], az = AZ[i];
+      double vx = VX[i], vy = VY[i], vz = VZ[i];
+      if (back != 0.0) {        // prekicked store: the step-boundary velocity, formed on the fly (expamd_comp_velocity_view)
+        vx = mul_then_add(vx, ax, back); vy = mul_then_add(vy, ay, back); vz = mul_then_add(vz, az, back);
+      }
+      v[4] = fma(m, vx, v[4]); v[5] = fma(m, vy, v[5]); v[6] = fma(m, vz, v[6]);
+      v[7] = fma(m, ax, v[7]); v[8] = fma(m, ay, v[8]); v[9] = fma(m, az, v[9]);
     }
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -1167,7 +1189,8 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
   if (mlevel < 0) mlevel = 0;
   if (mlevel >= nlev) mlevel = nlev - 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  { int rc_ = expamd_comp_apply_pending(c); if (rc_) return rc_; }
+  double back = 0.0;
+  { int rc_ = expamd_comp_velocity_view(c, &back); if (rc_) return rc_; }
   if (!c->com_lev.p) {
     if (c->com_lev.alloc(COM_MAXLEV * 10) != hipSuccess)
       return expamd_fail(ctx, EXP_AMD_ERR_HIP, "fix_positions: hipMalloc failed");
@@ -1183,7 +1206,7 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
     if (grid > 2048) grid = 2048;
     k_com_levels<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX),
                                                c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
-                                               c->a(A_AZ), c->level[c->cur].p, c->n, mlevel, nlev,
+                                               c->a(A_AZ), back, c->level[c->cur].p, c->n, mlevel, nlev,
                                                c->com_lev.p);
     HIP_TRY(ctx, hipGetLastError());
   }

@@ -35,6 +35,7 @@ struct AdvanceArgs {
                                // sub-step: drift DT(M) = dt_min * 2^(multistep - M), kick DT(M)/2
                                // (src/step.cc:115-160: dt*mintvl[M]; exact power-of-two scalings)
   int multistep;
+  int lev_lo;                  // advance == 2: particles of levels below are not advanced (inactive in this sub-step)
   double dt_min;
   int nokick;                  // 1: the stored velocities already hold this step's opening half-kick (the last
                                // fused force pass stored v + a dt_close + a dt_open, exp_amd_comp::pending_kick
@@ -51,6 +52,10 @@ __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, doub
                                             double &z, double &vx, double &vy, double &vz)
 {
   x = A.x[i]; y = A.y[i]; z = A.z[i];
+  if (A.advance == 2 && (int)A.lev[i] < A.lev_lo) {       // inactive level: carried through as it is
+    vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
+    return;
+  }
   if (A.advance) {
     // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
     vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];

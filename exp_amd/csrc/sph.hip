@@ -473,7 +473,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
   f->home = c;
   f->home_gone = false;
   const int nact = ms - lo + 1;
-  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms) : AdvSpec();
+  const AdvSpec adv = dt_min > 0.0 ? AdvSpec::levels(dt_min, ms, lo) : AdvSpec();
   int rc;
   // dense levels (cell-sorted) of the active suffix end at dmax; the levels above it are sparse
   int dmax = lo - 1;

@@ -209,7 +209,7 @@ extern "C" int exp_amd_sph_cov_accumulate(exp_amd_force *fb, exp_amd_comp *comp,
   SphCov *c = cov_of(f);
   exp_amd_ctx *ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  { int rc_ = expamd_comp_apply_pending(comp); if (rc_) return rc_; }
+  // (positions and masses only: whatever half-kick the velocities are owed or ahead by does not matter here)
   const size_t n = comp->n;
   if (accepted) *accepted = 0;
   if (n == 0) return EXP_AMD_OK;

@@ -64,8 +64,10 @@ int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
  * reordering pass only drifts and never reads the accelerations (24 B per particle-step less).  The
  * trajectory is bit-identical to the sequence kick, kick, drift.  Anything that reads velocities at the
  * step boundary sees v - a dt/2 formed on the way out (exp_amd_comp_download: non-destructively, within
- * one ulp of the closing-kick value) or after the opening half-kick has been taken back (every other
- * consumer; a following step_kdk with another dt included).  Off: the closing half-kick is left to the
+ * one ulp of the closing-kick value; exp_amd_comp_fix_positions and exp_amd_orient_accumulate read the
+ * same way: a diagnostic between two steps does not move the trajectory by a bit) or after the opening
+ * half-kick has been taken back (every call that CHANGES the component; a following step_kdk with
+ * another dt included).  Off: the closing half-kick is left to the
  * next reordering pass, which then reads the accelerations.  Measured at 1e8 / S10: the reordering pass
  * 2.94 -> 2.44 ms, the force pass 4.82 -> 5.01 ms for its three extra stores, the step 2 % faster.       */
 int  exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on);

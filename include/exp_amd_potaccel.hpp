@@ -22,7 +22,9 @@
 #define EXP_AMD_POTACCEL_HPP
 
 #include <cstdint>
+#include <cstdio>
 #include <map>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -98,9 +100,21 @@ public:
   exp_amd_comp *upload(ComponentView *c)
   {
     const std::size_t n = c->Number();
-    exp_amd_comp *&d = dev_[c];
-    if (d && exp_amd_comp_size(d) != n) { exp_amd_comp_destroy(d); d = nullptr; }
-    if (!d) check(exp_amd_comp_create(ctx_.get(), n, &d), ctx_.get());
+    auto it = dev_.find(c);
+    bool fresh = false;
+    if (it != dev_.end() && exp_amd_comp_size(it->second) != n) {
+      exp_amd_comp_destroy(it->second);
+      dev_.erase(it);
+      it = dev_.end();
+    }
+    if (it == dev_.end()) {
+      // (no map entry is left behind when the creation throws: dev() must never hand out a null store)
+      exp_amd_comp *nd = nullptr;
+      check(exp_amd_comp_create(ctx_.get(), n, &nd), ctx_.get());
+      it = dev_.emplace(c, nd).first;
+      fresh = true;
+    }
+    exp_amd_comp *d = it->second;
     std::vector<double> v[11];
     for (auto &a : v) a.resize(n ? n : 1);
     std::vector<std::int32_t> lev(n ? n : 1);
@@ -109,7 +123,9 @@ public:
     check(exp_amd_comp_upload(d, v[0].data(), v[1].data(), v[2].data(), v[3].data(), v[4].data(), v[5].data(),
                               v[6].data()), ctx_.get());
     check(exp_amd_comp_upload_acc(d, v[7].data(), v[8].data(), v[9].data(), v[10].data()), ctx_.get());
-    bool any = false;
+    // a store that already exists may hold levels from an earlier upload: they are replaced even when every host
+    // level has gone back to zero; only a fresh store (all zero by construction) can skip an all-zero upload
+    bool any = !fresh;
     for (std::size_t i = 0; i < n && !any; i++) any = lev[i] != 0;
     if (any) check(exp_amd_comp_upload_levels(d, lev.data()), ctx_.get());
     double ctr[3];
@@ -221,6 +237,26 @@ public:
     return c;
   }
   void set_coefs(const std::vector<double> &c) { check(exp_amd_force_set_coefs(force_, c.data(), c.size()), ctx_.get()); }
+
+  // PotAccel::dump_coefs(ostream&) (src/PotAccel.H:224): one record of the native coefficient stream at time tnow
+  virtual void dump_coefs(std::ostream &out, double tnow) = 0;
+
+protected:
+  // magic number + YAML header of a new-style record (NewCoefs; src/SphericalBasis.cc:1831-1861,
+  // exputil/EmpCylSL.cc:5870-5898): `cmagic` (0xc0a57a2 for the sphere, src/SphericalBasis.H:368; 0xc0a57a3 for the cylinder, include/EmpCylSL.H:222), the header's byte count, the header
+  static void write_header(std::ostream &out, unsigned int cmagic, const std::string &yaml)
+  {
+    const unsigned int hsize = (unsigned int)yaml.size();
+    out.write(reinterpret_cast<const char *>(&cmagic), sizeof(unsigned int));
+    out.write(reinterpret_cast<const char *>(&hsize), sizeof(unsigned int));
+    out.write(yaml.data(), hsize);
+  }
+  static std::string num(double v)
+  {
+    char b[40];
+    std::snprintf(b, sizeof b, "%.17g", v);
+    return b;
+  }
 };
 
 // sphereSL: class Sphere : SphericalBasis (src/Sphere.cc:28-96) given SLGridSph's tables
@@ -234,7 +270,24 @@ public:
       : PotAccelAMD(ctx, mirror, c0, cfg.multistep)
   {
     check(exp_amd_sph_create(ctx.get(), &cfg, xi, p0, ev, ef, &force_), ctx.get());
+    lmax_ = cfg.lmax; nmax_ = cfg.nmax; scale_ = cfg.scale;
   }
+  // SphericalBasis::dump_coefs (src/SphericalBasis.cc:1829-1879): header {id, time, scale, nmax, lmax, normed},
+  // then for every radial order the real rows in (l, m; cos, sin) order -- the row order of the device buffer
+  void dump_coefs(std::ostream &out, double tnow) override
+  {
+    write_header(out, 0xc0a57a2u, "id: sphereSL\ntime: " + num(tnow) + "\nscale: " + num(scale_) + "\nnmax: " +
+                          std::to_string(nmax_) + "\nlmax: " + std::to_string(lmax_) + "\nnormed: true");
+    const std::vector<double> c = get_coefs();               // [(lmax+1)^2][nmax]
+    const int nrows = (lmax_ + 1) * (lmax_ + 1);
+    for (int ir = 0; ir < nmax_; ir++)
+      for (int row = 0; row < nrows; row++)
+        out.write(reinterpret_cast<const char *>(&c[(std::size_t)row * nmax_ + ir]), sizeof(double));
+  }
+
+private:
+  int lmax_ = 0, nmax_ = 0;
+  double scale_ = 1.0;
 };
 
 // cylinder: class Cylinder (src/Cylinder.cc) given EmpCylSL's tables
@@ -245,7 +298,25 @@ public:
       : PotAccelAMD(ctx, mirror, c0, cfg.multistep)
   {
     check(exp_amd_cyl_create(ctx.get(), &cfg, tab, &force_), ctx.get());
+    mmax_ = cfg.mmax; nmax_ = cfg.nmax;
   }
+  // Cylinder::dump_coefs -> EmpCylSL::dump_coefs_binary (src/Cylinder.cc:1618-1621, exputil/EmpCylSL.cc:5868-5920):
+  // header {time, mmax, nmax}, then per m the cosine row and, for m > 0, the sine row
+  void dump_coefs(std::ostream &out, double tnow) override
+  {
+    write_header(out, 0xc0a57a3u, "time: " + num(tnow) + "\nmmax: " + std::to_string(mmax_) + "\nnmax: " + std::to_string(nmax_));
+    const std::vector<double> c = get_coefs();               // [2][mmax+1][nmax]: cos block, sin block
+    const std::size_t half = (std::size_t)(mmax_ + 1) * nmax_;
+    for (int mm = 0; mm <= mmax_; mm++) {
+      out.write(reinterpret_cast<const char *>(&c[(std::size_t)mm * nmax_]), sizeof(double) * nmax_);
+      if (mm) out.write(reinterpret_cast<const char *>(&c[half + (std::size_t)mm * nmax_]), sizeof(double) * nmax_);
+    }
+  }
+
+private:
+  int mmax_ = 0, nmax_ = 0;
+
+public:
   double cylmass()
   {
     double m = 0.0;

@@ -4,11 +4,12 @@
 // checked against the oracle's results stored in tests/golden/adaptor_case.bin
 // (tests/golden/make_adaptor_case.py).  Build and run: see tests/test_adaptor_gpu.py / Makefile.
 //
-//   test_potaccel <path to adaptor_case.bin>      exit code 0 = all checks passed
+//   test_potaccel <path to adaptor_case.bin> [file for dump_coefs]     exit code 0 = all checks passed
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <string>
 #include <vector>
 
 #include "exp_amd_potaccel.hpp"
@@ -143,6 +144,71 @@ int main(int argc, char **argv)
       expect("coefficients after one KDK step", maxdiff(force.get_coefs(), scoef), 1e-10 * maxabs(scoef));
       (void)used_ref;      // (the stored count is that of the INITIAL accumulation; one particle may cross rmax in the step)
       expect("PotAccel::Used()", std::fabs((double)(force.Used() - used_ref)), 1.0);
+      // PotAccel::dump_coefs(ostream&) (src/PotAccel.H:224, src/SphericalBasis.cc:1829-1879): one native record;
+      // read back here field by field, and by exp_amd.coefs.SphCoefs.readNativeCoefs in tests/test_adaptor_gpu.py
+      if (argc > 2) {
+        std::ofstream out(argv[2], std::ios::binary);
+        force.dump_coefs(out, 0.125);
+        force.dump_coefs(out, 0.25);
+        out.close();
+        std::ifstream in(argv[2], std::ios::binary);
+        unsigned int mg = 0, hs = 0;
+        in.read(reinterpret_cast<char *>(&mg), 4);
+        in.read(reinterpret_cast<char *>(&hs), 4);
+        std::string hdr(hs, ' ');
+        in.read(&hdr[0], hs);
+        std::vector<double> rec(ncoef);
+        in.read(reinterpret_cast<char *>(rec.data()), (std::streamsize)(ncoef * sizeof(double)));
+        const std::vector<double> cf = force.get_coefs();
+        double worst = 0;
+        const int nrows = (lmax + 1) * (lmax + 1);
+        for (int ir = 0; ir < nmax; ir++)
+          for (int row = 0; row < nrows; row++)
+            worst = std::fmax(worst, std::fabs(rec[(std::size_t)ir * nrows + row] - cf[(std::size_t)row * nmax + ir]));
+        expect("dump_coefs: magic", mg == 0xc0a57a2u ? 0.0 : 1.0, 0.0);
+        expect("dump_coefs: header names the force id", hdr.find("id: sphereSL") == 0 && hdr.find("normed: true") != std::string::npos ? 0.0 : 1.0, 0.0);
+        expect("dump_coefs: record = coefficients, n-major", worst, 0.0);
+      }
+    }
+    // ---- error paths of the C ABI: documented status codes and exp_amd_last_error, nothing thrown, nothing lost ----
+    {
+      exp_amd_ctx *c = ctx.get();
+      auto code = [&](const char *what, int rc, int want) {
+        const char *msg = exp_amd_last_error(c);
+        const bool ok = rc == want && (want == EXP_AMD_OK || (msg && msg[0]));
+        std::printf("%-44s rc %d (want %d) %s  %s\n", what, rc, want, ok ? "ok" : "FAIL", want ? (msg ? msg : "(null)") : "");
+        if (!ok) failures++;
+      };
+      exp_amd_comp *comp = nullptr;
+      exp_amd_force *force = nullptr;
+      exp_amd_sph_config cfg{lmax, nmax, numr, cmap, rmap, scale, rmin, rmax, xmin, dxi, 0, 0, 0, 0, 0, 0};
+      code("comp_create(NULL out)", exp_amd_comp_create(c, 10, nullptr), EXP_AMD_ERR_ARG);
+      code("sph_create(NULL tables)", exp_amd_sph_create(c, &cfg, nullptr, p0.data(), ev.data(), ef.data(), &force), EXP_AMD_ERR_ARG);
+      exp_amd_sph_config bad = cfg;
+      bad.lmax = 99;
+      code("sph_create(lmax out of range)", exp_amd_sph_create(c, &bad, xi.data(), p0.data(), ev.data(), ef.data(), &force), EXP_AMD_ERR_ARG);
+      bad = cfg;
+      bad.numr = 1;
+      code("sph_create(numr < 3)", exp_amd_sph_create(c, &bad, xi.data(), p0.data(), ev.data(), ef.data(), &force), EXP_AMD_ERR_ARG);
+      code("sph_create (good)", exp_amd_sph_create(c, &cfg, xi.data(), p0.data(), ev.data(), ef.data(), &force), EXP_AMD_OK);
+      code("comp_create (good)", exp_amd_comp_create(c, (std::size_t)n, &comp), EXP_AMD_OK);
+      code("determine_coefficients(NULL component)", exp_amd_force_determine_coefficients(force, nullptr), EXP_AMD_ERR_ARG);
+      code("determine_coefficients(NULL force)", exp_amd_force_determine_coefficients(nullptr, comp), EXP_AMD_ERR_ARG);
+      std::vector<double> buf(ncoef + 7);
+      code("get_coefs(ncoef mismatch)", exp_amd_force_get_coefs(force, buf.data(), ncoef + 7), EXP_AMD_ERR_ARG);
+      code("set_coefs(ncoef mismatch)", exp_amd_force_set_coefs(force, buf.data(), ncoef - 1), EXP_AMD_ERR_ARG);
+      code("set_level(beyond multistep)", exp_amd_force_set_level(force, 3), EXP_AMD_ERR_ARG);
+      code("get_level_coefs(level out of range)", exp_amd_force_get_level_coefs(force, 5, 0, buf.data(), ncoef), EXP_AMD_ERR_ARG);
+      code("comp_kick(level out of range)", exp_amd_comp_kick(comp, 0.1, 40), EXP_AMD_ERR_ARG);
+      code("sph_fields before set_density", exp_amd_sph_fields(force, 1, buf.data(), buf.data(), buf.data(), 2, buf.data()), EXP_AMD_ERR_STATE);
+      code("comm_init_rank(rank >= nranks)", exp_amd_comm_init_rank(c, buf.data(), 2, 5), EXP_AMD_ERR_ARG);
+      code("comm_init_rank(nranks < 1)", exp_amd_comm_init_rank(c, buf.data(), 0, 0), EXP_AMD_ERR_ARG);
+      // a failed call leaves the objects usable
+      code("determine_coefficients after the failures", exp_amd_force_determine_coefficients(force, comp), EXP_AMD_OK);
+      exp_amd_force_destroy(force);
+      exp_amd_comp_destroy(comp);
+      exp_amd_force_destroy(nullptr);       // destroying NULL is a no-op
+      exp_amd_comp_destroy(nullptr);
     }
     // ---- block multistep: begin_run + one master step, call for call as the reference's loop ---------
     {

@@ -726,3 +726,32 @@ class Oracle:
         self.lib.orc_pyexp_cyl_compute_quadrature.restype = ctypes.c_double
         return float(self.lib.orc_pyexp_cyl_compute_quadrature(ctypes.byref(self.cylgrid(g, **kw)), ctypes.c_double(rmin),
                                                                ctypes.c_int(knots), _dp(k), _dp(w), _dp(fv)))
+
+    # -- CPU baseline in the reference's data structure (oracle/refstruct_cpu.c) --------------------------------
+    def refstruct(self, mass, pos, vel):
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        v = np.ascontiguousarray(vel, dtype=np.float64)
+        self.lib.orc_refstruct_create.restype = ctypes.c_void_p
+        return ctypes.c_void_p(self.lib.orc_refstruct_create(ctypes.c_long(len(m)), _dp(m), _dp(p), _dp(v)))
+
+    def refstruct_field(self, rs, g, prm, nthreads):
+        self.lib.orc_refstruct_field.restype = ctypes.c_long
+        return int(self.lib.orc_refstruct_field(rs, ctypes.byref(self.grid(g)), ctypes.byref(prm), ctypes.c_int(nthreads)))
+
+    def refstruct_step(self, rs, g, prm, dt, nthreads, G=None):
+        self.lib.orc_refstruct_step.restype = ctypes.c_long
+        return int(self.lib.orc_refstruct_step(rs, ctypes.byref(G if G is not None else self.grid(g)), ctypes.byref(prm),
+                                               ctypes.c_double(dt), ctypes.c_int(nthreads)))
+
+    def refstruct_get(self, rs, n, ncoef=None):
+        pos, vel, acc, pot = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n)
+        self.lib.orc_refstruct_get(rs, _dp(pos), _dp(vel), _dp(acc), _dp(pot))
+        out = {"pos": pos, "vel": vel, "acc": acc, "pot": pot}
+        if ncoef:
+            self.lib.orc_refstruct_coef.restype = c_double_p
+            out["coef"] = np.ctypeslib.as_array(self.lib.orc_refstruct_coef(rs), shape=(ncoef,)).copy()
+        return out
+
+    def refstruct_free(self, rs):
+        self.lib.orc_refstruct_free(rs)

@@ -6,6 +6,7 @@ The CPU half checks that the adaptor compiles and links against nothing but the 
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,11 +30,19 @@ def test_adaptor_builds_against_the_c_abi_only():
 
 
 @pytest.mark.gpu
-def test_adaptor_drives_kdk_and_multistep_without_python():
-    if not os.path.exists(EXE):
+def test_adaptor_drives_kdk_and_multistep_without_python(tmp_path):
+    """... plus PotAccel::dump_coefs(ostream&) from the C++ side (the record is read back HERE by the coefficient
+    reader, exp_amd.coefs) and the error paths of the C ABI (status codes + exp_amd_last_error)."""
+    if not os.path.exists(EXE):          # (the snapshot sent to the GPU box carries the built program)
         _build()
-    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "adaptor_case.bin")], capture_output=True,
-                       text=True, timeout=600)
-    print(r.stdout[-3000:], r.stderr[-2000:])
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "ALL PASSED" in r.stdout and r.stdout.count(" ok") >= 15
+    dump = tmp_path / "outcoef.halo.run0"
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "adaptor_case.bin"), str(dump)],
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-6000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and r.stdout.count(" ok") >= 35 and "FAIL" not in r.stdout
+    from exp_amd.coefs import SphCoefs
+    cf = SphCoefs.readNativeCoefs(str(dump))
+    assert cf.Times() == [0.125, 0.25]
+    a, b = cf.getCoefStruct(0.125), cf.getCoefStruct(0.25)
+    assert a.coefs.shape == b.coefs.shape and np.array_equal(a.coefs, b.coefs) and np.abs(a.coefs).max() > 0

@@ -178,3 +178,68 @@ def test_config4_full_size_level_sets_add_up(ctx):
     sim.close()
     for o in (c1, c2, f1, f2):
         o.close()
+
+
+def test_three_components_deterministic_multistep(ctx, oracle):
+    """Three components (halo, disk, a second spherical component) with the halo's force acting on BOTH others
+    and both acting back on the halo, block multistep, deterministic mode: the cross forces of ONE source on two
+    targets must not run on two streams at once (they share the scratch of its force pass; the two-stream
+    sub-steps are for exactly two components, exp_amd/csrc/host.hip:overlap_begin).  Against the n-body
+    oracle to the usual bars, and two runs bit for bit."""
+    from exp_amd.models import PlummerModel, sample_sphere
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    from tests.oracle_lib import NBodyOracle
+    z = c4.load_golden()
+    ms, dtime, dyn = c4.MULTISTEP, c4.DTIME, c4.DYN
+    g, cg = c4.grids()
+    sc = float(z["scale"])
+    win = c4.sph_window(g, sc)
+    bm, bpos, bvel = sample_sphere(PlummerModel(1.0, 1.0, 1e-3, 50.0), 400, seed=77, rlim=30.0)
+    bm, bpos, bvel = bm * 0.3, bpos * (0.5 * sc), bvel / np.sqrt(0.5 * sc) * np.sqrt(0.3)
+    parts = [(z["halo_mass"], z["halo_pos"], z["halo_vel"]), (z["disk_mass"], z["disk_pos"], z["disk_vel"]),
+             (bm, bpos, bvel)]
+    inter = [(0, 1), (0, 2), (1, 0), (2, 0), (2, 1)]
+
+    nb = NBodyOracle(oracle, ms, dtime, dyn)
+    nb.add_sphere(g, oracle.params(**win), *parts[0])
+    nb.add_cylinder(cg, *parts[1])
+    nb.add_sphere(g, oracle.params(**win), *parts[2])
+    for a, b in inter:
+        nb.add_interaction(a, b)
+    nb.init()
+    nsw = [nb.step() for _ in range(2)]
+    assert sum(sum(v) for v in nsw) > 0
+
+    def device():
+        forces = [SphereSL(ctx, g, multistep=ms, **win), Cylinder(ctx, cg, multistep=ms),
+                  SphereSL(ctx, g, multistep=ms, **win)]
+        comps = [Component.from_arrays(ctx, *p) for p in parts]
+        sim = Simulation(ctx, dtime, multistep=ms, dynfrac=dyn, shiftlevl=0)
+        for c, f in zip(comps, forces):
+            sim.add_component(c, f)
+        for a, b in inter:
+            sim.add_interaction(a, b)
+        sim.init()
+        sim.step(2)
+        out = [(c.download(), c.download_levels()) for c in comps]
+        sim.close()
+        for o in comps + forces:
+            o.close()
+        return out
+
+    ctx.set_deterministic(True)
+    try:
+        first, second = device(), device()
+    finally:
+        ctx.set_deterministic(False)
+    for k, ((o, lev), (o2, lev2)) in enumerate(zip(first, second)):
+        st = nb.state[k]
+        assert np.array_equal(lev, st["level"]), k
+        p = np.stack([st[q] for q in "xyz"], 1)
+        a = np.stack([st["a" + q] for q in "xyz"], 1)
+        assert np.abs(o["pos"] - p).max() <= 1e-11, k
+        assert np.abs(o["acc"] - a).max() <= 1e-9 * np.linalg.norm(a, axis=1).max(), k
+        assert np.abs(o["pot"] - st["pot"]).max() <= 1e-9 * np.abs(st["pot"]).max(), k
+        for key in ("pos", "vel", "acc", "pot"):
+            assert np.array_equal(o[key], o2[key]), (k, key)          # bit for bit, run to run
+        assert np.array_equal(lev, lev2)

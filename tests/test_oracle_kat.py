@@ -570,3 +570,29 @@ def test_make_from_function_twin_agrees_with_the_particle_path(oracle):
     assert np.abs(packed - (-4.0 * math.pi) * mat).max() < 2e-4 * np.abs(packed).max()
     mass = oracle.pyexp_sph_compute_quadrature(g.rmin, g.rmax, g.rmap, knots, fv)
     assert mass == pytest.approx(case.mass.sum(), rel=1e-4)
+
+
+def test_reference_structure_baseline_equals_the_oracle(oracle, plummer_small):
+    """oracle/refstruct_cpu.c (hash map of individually allocated particles, level list of keys, five separate
+    threaded passes: the `reference-structure` CPU baseline of bench.py) produces the array
+    oracle's KDK steps to the rounding of its chunk and thread sums."""
+    from exp_amd.models import sample_sphere
+    model, g = plummer_small
+    m, pos, vel = sample_sphere(model, 1500, seed=31)
+    pos[:, 2] *= 0.8
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    ncoef = (g.lmax + 1) ** 2 * g.nmax
+    p, v, a = pos.copy(), vel.copy(), None
+    _, _, a, pt, cf = oracle.sph_step(g, prm, 0.0, p, v, np.zeros_like(p), m)
+    for _ in range(3):
+        p, v, a, pt, cf = oracle.sph_step(g, prm, 0.01, p, v, a, m)
+    for nthreads in (1, 3):
+        tol = 1e-13          # (chunks of 256 particles and thread slices are summed apart: rounding only)
+        rs = oracle.refstruct(m, pos, vel)
+        assert oracle.refstruct_field(rs, g, prm, nthreads) == len(m)
+        for _ in range(3):
+            oracle.refstruct_step(rs, g, prm, 0.01, nthreads)
+        out = oracle.refstruct_get(rs, len(m), ncoef)
+        oracle.refstruct_free(rs)
+        for key, ref in (("pos", p), ("vel", v), ("acc", a), ("pot", pt), ("coef", cf.reshape(-1))):
+            assert np.abs(out[key] - ref).max() <= tol * np.abs(ref).max(), (nthreads, key)

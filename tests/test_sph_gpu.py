@@ -453,15 +453,22 @@ def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6
     f = SphereSL(ctx, g)
     dt = 0.01
 
-    def run(prekick, look_at=(), steps=6, dts=None):
+    def run(prekick, look_at=(), steps=6, dts=None, diag_at=()):
+        from exp_amd.runtime import Orient
         ctx.set_prekick(prekick)
         c = Component.from_arrays(ctx, m, pos, vel)
         f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
         seen = []
+        ori = Orient(ctx, 4, 500, Orient.CENTER | Orient.AXIS, Orient.KE) if diag_at else None
         for k in range(steps):
             f.step_kdk(c, dts[k] if dts else dt)
             if k in look_at:
                 seen.append(c.download(("pos", "vel")))
+            if k in diag_at:            # read-only diagnostics between steps (they read the velocities)
+                seen.append(c.fix_positions())
+                ori.accumulate(0.01 * (k + 1), c)
+        if ori:
+            ori.close()
         out = c.download(("pos", "vel", "acc"))
         c.close()
         ctx.set_prekick(os.environ.get("EXP_AMD_PREKICK", "1") != "0")
@@ -475,6 +482,15 @@ def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6
     looked, seen = run(True, look_at=(2, 3))                                                      # (b)
     assert np.array_equal(looked["pos"], on["pos"]) and np.array_equal(looked["vel"], on["vel"])
     assert len(seen) == 2 and np.isfinite(seen[0]["vel"]).all()
+    # ... and neither do fix_positions / Orient::accumulate between steps: they see v - a dt/2 formed on the way,
+    # the stored state and the keys of the next step stay as they are (step / diagnostic / step == step / step)
+    diag, cm = run(True, diag_at=(1, 2, 4))
+    for k in ("pos", "vel", "acc"):
+        assert np.array_equal(diag[k], on[k]), k
+    plain, cm_off = run(False, diag_at=(1, 2, 4))             # the same diagnostics on closing-kick velocities
+    for a, b in zip(cm, cm_off):
+        # (block sums meet in atomics: equal to rounding, not bit for bit)
+        assert np.allclose(a["cov"], b["cov"], rtol=0, atol=1e-14) and np.allclose(a["com"], b["com"], rtol=0, atol=1e-14)
     # (c) changing dt from step to step: every change takes the half-kick back and redoes it
     dts = [0.01, 0.01, 0.004, 0.004, 0.02, 0.01]
     var, _ = run(True, dts=dts)
