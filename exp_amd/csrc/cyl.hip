@@ -146,8 +146,11 @@ struct LevChunks {
 #ifndef CACC_OCC
 #define CACC_OCC 2          // waves per SIMD asked of the compiler
 #endif
+#ifndef CACC_CHUNK_MAX
 #define CACC_CHUNK_MAX 1024   // particles per wave chunk; sparse multistep levels get shorter ones
+#endif
 #define CACC_THICK_MIN 1000000u   // level population from which a multistep level is accumulated apart from thinner ones
+#define CYL_TAILS 128             // slot pairs the {in-cut mass, count} tallies of an accumulation launch are spread over
 
 // Deterministic (order-independent) accumulation, as in sph_kernels.h: every term is rounded to a fixed
 // absolute grid 2^e first, (w*p + C) - C with C = 1.5 * 2^(52+e), so that all later additions are exact.
@@ -404,10 +407,242 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     mass_used += __shfl_xor(mass_used, off);
     n_used += __shfl_xor(n_used, off);
   }
+  // {in-cut mass, count}: into one of CYL_TAILS slot pairs (summed and cleared by the contraction that follows).  Two
+  // addresses for every wave of the launch serialise in the memory-side atomic unit at ~12 ns each: at 1e7 particles
+  // the 19 532 atomics of the 9766 waves took 0.12 of this kernel's 0.32 ms -- as long as everything else it does.
   if (lane == 0 && n_used > 0.0) {
-    unsafeAtomicAdd(tail + 0, mass_used);
-    unsafeAtomicAdd(tail + 1, n_used);
+    double *tp = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+    unsafeAtomicAdd(tp + 0, mass_used);
+    unsafeAtomicAdd(tp + 1, n_used);
   }
+}
+
+// ---- the same accumulation with the moment sums spread over the LANES of the wave ("slot" formulation) ---------
+// k_cyl_accumulate keeps its 4 NT moment sums (52 doubles at mmax 6) in the registers of every lane and reduces them
+// over the wave on each cell change; at two waves per SIMD that kernel issues in a third of its cycles and waits for
+// memory in the rest.  Here a particle's contribution -- the rank-one product w_k trig_t, w_k = -4 pi m c_k (corner k),
+// trig_t = cos | sin(m phi) -- is formed by the lane that OWNS the pair (cos m, sin m): lane = 8 sub + m
+// (m <= MMAX <= 7 active), eight accumulators per lane (4 corners x {cos, sin}), the eight sub-groups taking every
+// eighth particle of the 64-particle group.  The particle lanes leave w[4] and the trig pairs in LDS (one pass of the
+// recurrences per particle), the owner lanes read them back (one 32-byte and one 16-byte broadcast read per particle and
+// lane).  What that buys: no 52-register accumulator file (~100 VGPRs instead of ~230: three to four waves per SIMD and
+// particle loads two groups ahead), and a cell change costs one 8-way LDS sum + ONE atomic instruction.
+#ifndef CYL_SLOT_OCC
+#define CYL_SLOT_OCC 3
+#endif
+#ifndef CSLOT_EXPT
+#define CSLOT_EXPT 0
+#endif
+#define CSLOT_TSTRIDE 65          // trig rows [m][65] pairs: 1040 B apart, i.e. 4 banks per row for the 16-byte reads
+
+template <int MMAX, bool DET, bool LIST = false>
+__global__ void __launch_bounds__(CACC_WAVES * 64, CYL_SLOT_OCC)
+k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
+                      const double *__restrict__ Z, const double *__restrict__ M,
+                      const uint32_t *__restrict__ lev_off, LevChunks LC,
+                      double *__restrict__ Wn, double *__restrict__ tail,
+                      int multilevel /* Wn[level][node][ntrig] */, CylAccList al = CylAccList{})
+{
+  static_assert(MMAX <= 7, "slot formulation: one lane per azimuthal order, eight per sub-group");
+  int lj = 0;
+  while (lj + 1 < LC.nlev && blockIdx.x >= LC.bstart[lj + 1]) lj++;
+  const int lev_lo = LC.lo + lj, lev_hi = lev_lo;
+  const int CACC_CHUNK = LC.chunk[lj];
+  const unsigned bx = blockIdx.x - LC.bstart[lj];
+  const int lvl = multilevel ? lev_lo : 0;
+  constexpr int NT = 2 * MMAX + 1;
+  // per wave: w[64][4] (2 KB), trig pairs [MMAX+1][65][2], flush scratch [64][4] (2 KB)
+  constexpr int WB = 64 * 4, TB = (MMAX + 1) * CSLOT_TSTRIDE * 2, SB = 64 * 4;
+  __shared__ __attribute__((aligned(16))) double lds_all[CACC_WAVES][WB + TB + SB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *wbuf = lds_all[wave], *tbuf = wbuf + WB, *sbuf = tbuf + TB;
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const size_t cbeg = beg + ((size_t)bx * CACC_WAVES + wave) * CACC_CHUNK;
+  if (cbeg >= end) return;
+  const size_t cend = (cbeg + CACC_CHUNK < end) ? cbeg + CACC_CHUNK : end;
+  const double norm = -4.0 * M_PI;
+  const int nyp = C.numy + 1;
+  const int sub = lane >> 3, om = lane & 7;            // owner role: sub-group, azimuthal order
+  const bool owner = om <= MMAX && !(C.EVEN_M && (om & 1));
+  const int orow = om <= MMAX ? om : 0;                // (idle lanes read row 0 and accumulate nothing)
+  // trig row of m = 0: (1, 0) for every particle, once
+  tbuf[(0 * CSLOT_TSTRIDE + lane) * 2 + 0] = 1.0;
+  tbuf[(0 * CSLOT_TSTRIDE + lane) * 2 + 1] = 0.0;
+
+  double a00 = 0, a01 = 0, a10 = 0, a11 = 0, a20 = 0, a21 = 0, a30 = 0, a31 = 0;    // a<corner><cos|sin>
+  int cur = -1;
+  double mass_used = 0.0, n_used = 0.0;
+  const int ncellT = C.numx * C.numy;
+  const size_t wlev = (size_t)(C.numx + 1) * nyp * NT;
+
+  // sum the eight sub-groups' values of two corners (k0, k0 + 1) and add them to the node table: lanes j < 4 (MMAX+1),
+  // j = 4 m + q, q = 2 (corner - k0) + cs
+  auto flush_pair = [&](double *base, int k0, double v0, double v1, double v2, double v3) {
+    double *mine = sbuf + lane * 4;
+    mine[0] = v0; mine[1] = v1; mine[2] = v2; mine[3] = v3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 4 * (MMAX + 1)) {
+      const int m = lane >> 2, q = lane & 3;
+      double s = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) s += sbuf[(g * 8 + m) * 4 + q];
+      const int k = k0 + (q >> 1), cs = q & 1;
+      if (s != 0.0 && !(m == 0 && cs)) {
+        const int t = m == 0 ? 0 : 2 * m - 1 + cs;
+        unsafeAtomicAdd(base + (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT + t, s);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto flush = [&](int key, int next) {
+    const int L = key / ncellT, cell = key - L * ncellT;
+    const int ix = cell / C.numy, iy = cell - ix * C.numy;
+    double *base = Wn + (size_t)L * wlev + ((size_t)ix * nyp + iy) * NT;
+    flush_pair(base, 0, a00, a01, a10, a11);
+    if (next == key + 1 && iy + 1 < C.numy) {           // next cell of the column: the upper corners move down
+      a00 = a20; a01 = a21; a10 = a30; a11 = a31;
+    } else {
+      flush_pair(base, 2, a20, a21, a30, a31);
+      a00 = a01 = a10 = a11 = 0.0;
+    }
+    a20 = a21 = a30 = a31 = 0.0;
+  };
+
+  // particle loads two groups ahead
+  double nx[2] = {0, 0}, ny[2] = {0, 0}, nz[2] = {0, 0}, nm[2] = {0, 0};
+  int nlv[2] = {lvl, lvl};
+  const bool um = C.umass != 0.0;
+  auto fetch = [&](size_t i, int slot) {
+    if (i < cend) {
+      if constexpr (LIST) cyl_list_fetch(al, X, Y, Z, M, C.umass, i, nx[slot], ny[slot], nz[slot], nm[slot], nlv[slot]);
+      else { nx[slot] = X[i]; ny[slot] = Y[i]; nz[slot] = Z[i]; nm[slot] = um ? C.umass : M[i]; }
+    }
+  };
+  fetch(cbeg + lane, 0);
+  fetch(cbeg + 64 + lane, 1);
+  int slot = 0;
+  for (size_t base = cbeg; base < cend; base += 64, slot ^= 1) {
+    const size_t i = base + lane;
+    const bool valid = LIST ? (i < cend && nlv[slot] >= 0) : i < cend;
+    const int plv = LIST ? nlv[slot] : lvl;
+    double xx = 1, yy = 0, zz = 0, mass = 0;
+    if (valid) {
+      cyl_local(C, nx[slot], ny[slot], nz[slot], xx, yy, zz);
+      mass = nm[slot];
+    }
+    fetch(i + 128, slot);
+#if CSLOT_EXPT == 1 || CSLOT_EXPT == 5        // timing experiment: the particle stream alone
+    mass_used += xx + yy + zz + mass; n_used += 1.0;
+    continue;
+#endif
+    const double r2 = xx * xx + yy * yy;
+    double r, ir, rr, irr;
+    sqrt_rsqrt(r2, r, ir);
+    const bool incut = LIST ? valid : (valid && (r2 + zz * zz) < C.rmax2);
+    if (!LIST && incut) { mass_used += cdet_round(mass, C.detCm); n_used += 1.0; }
+    sqrt_rsqrt(r2 + zz * zz, rr, irr);
+    const bool ongrid = incut && !(rr > C.rtab_abs);
+    double zc = zz;
+    if (zc > C.rtab_abs) zc = C.rtab_abs;
+    if (zc < -C.rtab_abs) zc = -C.rtab_abs;
+    int ix, iy;
+    double c00, c10, c01, c11;
+    cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
+    const int cell = ix * C.numy + iy + plv * ncellT;
+    double cphi = 1.0, sphi = 0.0;
+    if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+    const double t0 = ongrid ? norm * mass : 0.0;
+#if CSLOT_EXPT == 2        // timing experiment: stream + per-particle inputs, no LDS, no sums
+    mass_used += t0 * (c00 + c10 + c01 + c11) + cphi + sphi + (double)cell; continue;
+#endif
+    // this particle's row of the two LDS tables
+    {
+      double *w = wbuf + lane * 4;
+      w[0] = t0 * c00; w[1] = t0 * c10; w[2] = t0 * c01; w[3] = t0 * c11;
+      double cm = 1.0, sm = 0.0;
+      cstatic_for<1, MMAX + 1>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const double cn = cm * cphi - sm * sphi;
+        const double sn = sm * cphi + cm * sphi;
+        cm = cn; sm = sn;
+        tbuf[(m * CSLOT_TSTRIDE + lane) * 2 + 0] = cm;
+        tbuf[(m * CSLOT_TSTRIDE + lane) * 2 + 1] = sm;
+      });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    unsigned long long remaining = __ballot(ongrid);
+    while (remaining) {
+      const int lead = __ffsll((long long)remaining) - 1;
+      const int c = __builtin_amdgcn_readlane(cell, lead);
+      const unsigned long long mask = __ballot(ongrid && cell == c);
+      if (c != cur) {
+#if CSLOT_EXPT != 3        // (3: timing experiment without the flushes)
+        if (cur >= 0) flush(cur, c);
+#endif
+        cur = c;
+      }
+      // owner pass over the particles of `mask`: iterations ia .. ib of eight particles each; the first and the last
+      // (and every one when the run has holes: an un-sorted LIST slice) take the trig pair through the mask
+      const int pa = lead, pb = 63 - __clzll((long long)mask);
+      const bool holes = __popcll(mask) != pb - pa + 1;
+      const unsigned long long ms = mask >> sub;                       // bit 8 i: particle 8 i + sub
+      for (int it = pa >> 3; it <= (pb >> 3); it++) {
+        const int p = it * 8 + sub;
+        const double *w = wbuf + p * 4;
+        const double w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        double tc = tbuf[(orow * CSLOT_TSTRIDE + p) * 2 + 0], tsn = tbuf[(orow * CSLOT_TSTRIDE + p) * 2 + 1];
+        if (holes || it == (pa >> 3) || it == (pb >> 3)) {
+          const bool in = (ms >> (8 * it)) & 1ull;
+          tc = in ? tc : 0.0;
+          tsn = in ? tsn : 0.0;
+        }
+        if (owner) {
+          cacc_add<DET>(a00, w0, tc, C.detC); cacc_add<DET>(a01, w0, tsn, C.detC);
+          cacc_add<DET>(a10, w1, tc, C.detC); cacc_add<DET>(a11, w1, tsn, C.detC);
+          cacc_add<DET>(a20, w2, tc, C.detC); cacc_add<DET>(a21, w2, tsn, C.detC);
+          cacc_add<DET>(a30, w3, tc, C.detC); cacc_add<DET>(a31, w3, tsn, C.detC);
+        }
+      }
+      remaining &= ~mask;
+    }
+    // (the next group's rows are written only after every read above has been consumed: same wave, program order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (cur >= 0) flush(cur, -1);
+  for (int off = 32; off > 0; off >>= 1) {
+    mass_used += __shfl_xor(mass_used, off);
+    n_used += __shfl_xor(n_used, off);
+  }
+#if CSLOT_EXPT < 4
+  if (lane == 0 && n_used > 0.0) {          // (see k_cyl_accumulate: CYL_TAILS slot pairs, not one)
+    double *tp = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+    unsafeAtomicAdd(tp + 0, mass_used);
+    unsafeAtomicAdd(tp + 1, n_used);
+  }
+#endif
+}
+
+// which formulation an accumulation launch uses: the slot kernel for mmax <= 7 (CYL_ACC_SLOT=0 builds the register
+// formulation everywhere)
+#ifndef CYL_ACC_SLOT
+#define CYL_ACC_SLOT 1
+#endif
+template <int MMAX, bool DET, bool LIST = false>
+static void cyl_acc_launch(unsigned gx, unsigned gz, hipStream_t st, const CylDev &C, const double *X, const double *Y,
+                           const double *Z, const double *M, const uint32_t *lev_off, const LevChunks &LC, double *Wn,
+                           double *tail, int multilevel, const CylAccList &al = CylAccList{})
+{
+  if constexpr (CYL_ACC_SLOT && MMAX <= 7)
+    k_cyl_accumulate_slot<MMAX, DET, LIST><<<dim3(gx, 1, gz), CACC_WAVES * 64, 0, st>>>(C, X, Y, Z, M, lev_off, LC, Wn,
+                                                                                       tail, multilevel, al);
+  else
+    k_cyl_accumulate<MMAX, DET, LIST><<<dim3(gx, 1, gz), CACC_WAVES * 64, 0, st>>>(C, X, Y, Z, M, lev_off, LC, Wn, tail,
+                                                                                  multilevel, al);
 }
 
 // ---- multistep level change: coefficient differencing (src/CylEXP.cc:159-188) -----------------------
@@ -614,11 +849,18 @@ k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict
 
 __global__ void __launch_bounds__(256)
 k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict__ out, size_t ostride,
-                   double *__restrict__ last, double *__restrict__ add_to /* += the new set as well, or null */)
+                   double *__restrict__ last, double *__restrict__ add_to /* += the new set as well, or null */,
+                   double *__restrict__ tailpart /* [CYL_TAILS][2] of the accumulation launches, or null */)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int L = blockIdx.y;                   // level of a multi-level launch
+  // the accumulation's {in-cut mass, count} slots -> the tail of the FIRST set of the launch (out + ncoef), slots cleared
+  if (tailpart && blockIdx.x == 0 && L == 0 && threadIdx.x < 2) {
+    double t = 0.0;
+    for (int j = 0; j < CYL_TAILS; j++) { t += tailpart[2 * j + threadIdx.x]; tailpart[2 * j + threadIdx.x] = 0.0; }
+    out[ncoef + threadIdx.x] += t;
+  }
   if (o >= ncoef) return;
   const bool none = o >= ncoef / 2 && o < ncoef / 2 + (size_t)C.nmax;      // (sin, m = 0): no such row
   double s = 0.0;
@@ -636,11 +878,11 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
 // both stages; nl levels starting at Wn / out / last
 static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, double *Wn, double *part,
                          double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0,
-                         double *add_to = nullptr)
+                         double *add_to = nullptr, double *tailpart = nullptr)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
-  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to);
+  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to, tailpart);
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
@@ -858,6 +1100,7 @@ struct CylForce : exp_amd_force {
   DevBuf<uint32_t> cov_seq;
   size_t cov_seq_cap = 0;
   DevBuf<double> d_mass;            // {cylmass, used}: in-cut mass / count of the current master step
+  DevBuf<double> d_tailpart;        // [CYL_TAILS][2]: the same tallies of ONE accumulation launch, spread over slots
   bool mass_open = true;            // still within the first sub-step (tnow == resetT)
   bool wn_clean = false;            // every per-level moment buffer of d_Wn is zero (substep_expansion's contraction keeps it so)
   bool wnd_clean = false;           // ... and d_Wnd, d_differ's tails (multistep_update)
@@ -887,6 +1130,7 @@ struct CylForce : exp_amd_force {
     cov_cnt.release(); cov_used.release(); cov_seq.release();
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release(); d_cpart.release();
     d_mass.release();
+    d_tailpart.release();
     d_dens.release();
   }
   int get_used(long long *used) override
@@ -948,6 +1192,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   A(f->d_TF.alloc(f->nnode * 3 * ntrig));
   A(f->d_cpart.alloc((size_t)(cfg->multistep + 1) * CYL_CSEG * 2 * (M + 1) * N));
   A(f->d_mass.alloc(2));
+  A(f->d_tailpart.alloc(2 * CYL_TAILS));
   // coefficient buffer: cos block, sin block, then {cylmass, used} riding through the all-reduce
   if (e == hipSuccess && f->alloc_common((size_t)2 * (M + 1) * N, cfg->multistep, 2) != EXP_AMD_OK)
     e = hipErrorOutOfMemory;
@@ -957,6 +1202,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   }
   HIP_TRY(ctx, hipMemcpy(f->d_tab.p, tab, ntab * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemset(f->d_mass.p, 0, 2 * sizeof(double)));
+  HIP_TRY(ctx, hipMemset(f->d_tailpart.p, 0, 2 * CYL_TAILS * sizeof(double)));
   CylDev &C = f->dev;
   C.mmax = M; C.nmax = N; C.numx = cfg->numx; C.numy = cfg->numy; C.cmapr = cfg->cmapr;
   C.cmapz = cfg->cmapz; C.EVEN_M = cfg->EVEN_M; C.ntrig = ntrig;
@@ -1088,10 +1334,10 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     const CylAccList al{c->mover_list.p, c->level[c->cur].p, c->newlev.p, mfirst_mdrft, per_level};
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
-    k_cyl_accumulate<MM, true, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                 \
+    cyl_acc_launch<MM, true, true>(grid.x, grid.z, ctx->stream,                                  \
         C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt, LC, f->d_Wnd.p, nullptr, 1, al); \
   else                                                                                           \
-    k_cyl_accumulate<MM, false, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                \
+    cyl_acc_launch<MM, false, true>(grid.x, grid.z, ctx->stream,                                 \
         C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_cnt, LC, f->d_Wnd.p, nullptr, 1, al)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
@@ -1165,17 +1411,17 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     LC.lo = lo; LC.nlev = 1; LC.bstart[0] = 0; LC.bstart[1] = grid; LC.chunk[0] = (int)chunk;
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
-    k_cyl_accumulate<MM, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                       \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0); \
+    cyl_acc_launch<MM, true>(grid, 1, ctx->stream,                                               \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, f->d_tailpart.p, 0); \
   else                                                                                           \
-    k_cyl_accumulate<MM, false><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                      \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 0)
+    cyl_acc_launch<MM, false>(grid, 1, ctx->stream,                                              \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, f->d_tailpart.p, 0)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
-    cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p, f->d_cpart.p, dst);
+    cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p, f->d_cpart.p, dst, 1, 0, nullptr, 0, nullptr, f->d_tailpart.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   int rc = expamd_allreduce(ctx, dst, f->ncoef_dev);
@@ -1273,11 +1519,11 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
       if (grid) {
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
-    k_cyl_accumulate<MM, true><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                       \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1); \
+    cyl_acc_launch<MM, true>(grid, 1, ctx->stream,                                               \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, f->d_tailpart.p, 1); \
   else                                                                                           \
-    k_cyl_accumulate<MM, false><<<grid, CACC_WAVES * 64, 0, ctx->stream>>>(                      \
-        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, dst + f->ncoef, 1)
+    cyl_acc_launch<MM, false>(grid, 1, ctx->stream,                                              \
+        C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, f->d_tailpart.p, 1)
         MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
       }
@@ -1301,7 +1547,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     // ... with setup_accumulation(M)'s swap of every active level: L <- N, N <- new
     // (exputil/EmpCylSL.cc:2010-2030)
     cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, f->d_cpart.p, dst, nact,
-                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1);
+                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1, nullptr, f->d_tailpart.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;
