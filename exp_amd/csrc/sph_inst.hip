@@ -82,6 +82,15 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
     k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
         a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next);
+  } else if (a.stage_rows > 0 && a.dt_kick == 0.0 && !a.key_out) {
+    // a target that is not in this basis' cell order (another component: interactions), no fused kick: the general
+    // evaluation with the rows of each block's cell range staged in LDS
+    ProfScope ps(a.ctx, "k_sph_force_staged");
+    const int tq = 4 * a.S.trows;
+    const int tqs = tq + ((2 - tq % 16) + 16) % 16;
+    k_sph_force_staged<LMAX><<<a.grid, 256, (size_t)a.stage_rows * tqs * sizeof(double), a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ, a.assign,
+        a.stage_rows, tqs);
   } else {
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(

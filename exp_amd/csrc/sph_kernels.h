@@ -1164,6 +1164,77 @@ sph_field_fast_call(cdp t4, double costh, double somx2, double cphi, double sphi
 // lanes (polar axis, exterior) go to the general pass, by lane mask.
 // Work-list entries are three words: first slot, lane mask low / high.
 #define SPH_WORK_STRIDE 3
+// The Cartesian projection and the stores of one particle's field (src/SphericalBasis.cc:1636-1652), with the fused
+// half-kick and the next step's sort key of the fused step: shared by every evaluation path.
+template <bool FAST>
+__device__ __forceinline__ void
+sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double yy, double zz, double px, double py,
+                 double pz, double fac, double ir, double iR2, double P0, double ffac, double dfac,
+                 double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
+                 double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ, double dt_kick, int assign,
+                 uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v)
+{
+  // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
+  const double potr = o.potr * ffac * (S.inv_scale * S.inv_scale);
+  const double potl = o.potl * P0 * S.inv_scale;
+  const double pott = o.pott * (P0 * dfac) * S.inv_scale;
+  const double potp = o.potp * P0 * S.inv_scale;
+  const double ir3 = ir * ir * ir;
+  const double pr = potr * ir, pt3 = pott * ir3;
+  double ax = -(pr * xx - pt3 * xx * zz);
+  double ay = -(pr * yy - pt3 * yy * zz);
+  double az = -(pr * zz + pt3 * fac);
+  if (fac > DSMALL) {
+    const double pf2 = FAST ? potp * iR2 : potp / fac;
+    ax += pf2 * yy;
+    ay += -pf2 * xx;
+  }
+  if (S.ps.center | S.ps.axis) {
+    // Component::AddAcc(i, j, val) is acc[j] += val - pseudo[j] on EVERY call (src/Component.H:914-921)
+    // and the reference's thread body calls it for x, y, z and, when fac > DSMALL, for x and y once
+    // more (the potp term, src/SphericalBasis.cc:1645-1651): x and y lose the frame term twice.
+    double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+    if (S.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+    pseudo_accel(S.ps, px, py, pz, ux, uy, uz, qx, qy, qz);
+    ax -= qx; ay -= qy; az -= qz;
+    if (fac > DSMALL) { ax -= qx; ay -= qy; }
+  }
+  double pt = potl;
+  if (!assign) {
+    ax += AX[i];
+    ay += AY[i];
+    az += AZ[i];
+    pt += POT[i];
+  }
+  AX[i] = ax;
+  AY[i] = ay;
+  AZ[i] = az;
+  POT[i] = pt;
+  if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
+    const double vx = mul_then_add(VX[i], ax, dt_kick);
+    const double vy = mul_then_add(VY[i], ay, dt_kick);
+    const double vz = mul_then_add(VZ[i], az, dt_kick);
+    if (store_v == 1) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // 0: deferred (exp_amd_comp::pending_kick)
+    if (key_out) {
+      // Where this particle will be after the NEXT step's kick + drift (the arithmetic of
+      // advance_one, sort_kernels.h, on the values just stored): its sort key.  The next step
+      // then histograms the 4-byte keys (k_hist_keys) instead of re-reading x, v, a (72 B).
+      // (Counting the keys here as well, one atomic per distinct key per wave, doubled this
+      // kernel's time: 5e6 atomics on ~2000 hot addresses.)
+      const double wx = mul_then_add(vx, ax, nk_dtk);
+      const double wy = mul_then_add(vy, ay, nk_dtk);
+      const double wz = mul_then_add(vz, az, nk_dtk);
+      // store_v == 2: the velocities go out WITH the next step's opening half-kick (the same two
+      // rounding steps that step's scatter pass would take), so that pass only drifts and never
+      // reads the accelerations (24 B/particle); pending_kick = -nk_dtk tells everyone else
+      if (store_v == 2) { VX[i] = wx; VY[i] = wy; VZ[i] = wz; }
+      const uint32_t key = sph_key_cell_rcp(S, mul_then_add(px, wx, nk_dtd),
+                                            mul_then_add(py, wy, nk_dtd), mul_then_add(pz, wz, nk_dtd));
+      key_out[i] = key + S.key_add;
+    }
+  }
+}
+
 template <int LMAX, int MODE>
 __device__ __forceinline__ void
 sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
@@ -1324,66 +1395,8 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     iR2 = 1.0 / fac;
   }
   if (!valid) return;
-
-  // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
-  const double potr = o.potr * ffac * (S.inv_scale * S.inv_scale);
-  const double potl = o.potl * P0 * S.inv_scale;
-  const double pott = o.pott * (P0 * dfac) * S.inv_scale;
-  const double potp = o.potp * P0 * S.inv_scale;
-  const double ir3 = ir * ir * ir;
-  const double pr = potr * ir, pt3 = pott * ir3;
-  double ax = -(pr * xx - pt3 * xx * zz);
-  double ay = -(pr * yy - pt3 * yy * zz);
-  double az = -(pr * zz + pt3 * fac);
-  if (fac > DSMALL) {
-    const double pf2 = FAST ? potp * iR2 : potp / fac;
-    ax += pf2 * yy;
-    ay += -pf2 * xx;
-  }
-  if (S.ps.center | S.ps.axis) {
-    // Component::AddAcc(i, j, val) is acc[j] += val - pseudo[j] on EVERY call (src/Component.H:914-921)
-    // and the reference's thread body calls it for x, y, z and, when fac > DSMALL, for x and y once
-    // more (the potp term, src/SphericalBasis.cc:1645-1651): x and y lose the frame term twice.
-    double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
-    if (S.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
-    pseudo_accel(S.ps, px, py, pz, ux, uy, uz, qx, qy, qz);
-    ax -= qx; ay -= qy; az -= qz;
-    if (fac > DSMALL) { ax -= qx; ay -= qy; }
-  }
-  double pt = potl;
-  if (!assign) {
-    ax += AX[i];
-    ay += AY[i];
-    az += AZ[i];
-    pt += POT[i];
-  }
-  AX[i] = ax;
-  AY[i] = ay;
-  AZ[i] = az;
-  POT[i] = pt;
-  if (dt_kick != 0.0) {   // fused second half-kick (src/incvel.cc:15-88), mul then add
-    const double vx = mul_then_add(VX[i], ax, dt_kick);
-    const double vy = mul_then_add(VY[i], ay, dt_kick);
-    const double vz = mul_then_add(VZ[i], az, dt_kick);
-    if (store_v == 1) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }   // 0: deferred (exp_amd_comp::pending_kick)
-    if (key_out) {
-      // Where this particle will be after the NEXT step's kick + drift (the arithmetic of
-      // advance_one, sort_kernels.h, on the values just stored): its sort key.  The next step
-      // then histograms the 4-byte keys (k_hist_keys) instead of re-reading x, v, a (72 B).
-      // (Counting the keys here as well, one atomic per distinct key per wave, doubled this
-      // kernel's time: 5e6 atomics on ~2000 hot addresses.)
-      const double wx = mul_then_add(vx, ax, nk_dtk);
-      const double wy = mul_then_add(vy, ay, nk_dtk);
-      const double wz = mul_then_add(vz, az, nk_dtk);
-      // store_v == 2: the velocities go out WITH the next step's opening half-kick (the same two
-      // rounding steps that step's scatter pass would take), so that pass only drifts and never
-      // reads the accelerations (24 B/particle); pending_kick = -nk_dtk tells everyone else
-      if (store_v == 2) { VX[i] = wx; VY[i] = wy; VZ[i] = wz; }
-      const uint32_t key = sph_key_cell_rcp(S, mul_then_add(px, wx, nk_dtd),
-                                            mul_then_add(py, wy, nk_dtd), mul_then_add(pz, wz, nk_dtd));
-      key_out[i] = key + S.key_add;
-    }
-  }
+  sph_force_finish<FAST>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
+                         dt_kick, assign, key_out, nk_dtk, nk_dtd, store_v);
 #if SPH_T4_PREFETCH
   if constexpr (MODE != 0) asm volatile("" : : "v"(t4_sink));     // keeps the prefetch's registers out of circulation
 #endif
@@ -1435,6 +1448,94 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
   }
 }
 
+// ---- general evaluation with the table rows of the block's cells staged in LDS ----------------------------------
+// The forces of this basis on ANOTHER component's particles (interactions, src/ComponentContainer.cc:785-853) cannot
+// take the fast pass: the target is in its own basis' cell order, a wave spans several radial cells of this one, and
+// the general pass above pays ~100 dependent per-lane gathers from global memory per wave for its table rows (the
+// largest single launch of a two-component master step).  But a block's 256 consecutive target particles are still
+// LOCAL in radius (a disk in (R, z)-cell order: ~8 cells of the halo's radial grid), so the block copies the rows of
+// its cell range [cmin, cmax] into LDS once -- coalesced -- and every lane reads its own cell's rows from there (same
+// operands, same operations as sph_field on global rows: bit-identical results).  Blocks whose range does not fit
+// (nstage rows) keep the global gathers.  tqs: LDS row stride in doubles (tq padded to 2 mod 16: consecutive cells
+// start four banks apart).
+typedef const __attribute__((address_space(3))) double *ldsp;
+
+template <int LMAX>
+__global__ void __launch_bounds__(256, 2)
+k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
+                   const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
+                   const double *__restrict__ T4, double *__restrict__ AX, double *__restrict__ AY,
+                   double *__restrict__ AZ, double *__restrict__ POT, double *__restrict__ VX,
+                   double *__restrict__ VY, double *__restrict__ VZ, int assign, int nstage, int tqs)
+{
+  extern __shared__ __attribute__((aligned(16))) double stage[];
+  __shared__ int s_min, s_max;
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const size_t base0 = beg + (size_t)blockIdx.x * 256;
+  if (base0 >= end) return;
+  if (threadIdx.x == 0) { s_min = 0x7fffffff; s_max = -1; }
+  const int lane = threadIdx.x & 63;
+  const size_t i = base0 + threadIdx.x;
+  const bool valid = i < end;
+  double xx = 1, yy = 0, zz = 0, px = 0, py = 0, pz = 0;
+  if (valid) {
+    px = X[i]; py = Y[i]; pz = Z[i];
+    xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz;
+  }
+  // the general path's prologue (sph_force_chunk<LMAX, 0>), statement for statement
+  const double fac = xx * xx + yy * yy;
+  const size_t tq = (size_t)4 * S.trows;
+  double r = sqrt(fac + zz * zz) + S.dsmall;
+  const double costh = zz / r;
+  double cphi, sphi;
+  phi_trig(xx, yy, cphi, sphi);
+  bool ioff = false;
+  const double r0 = r;
+  if (r > S.rmax && !S.no_exterior) { ioff = true; r = S.rmax; }
+  const double rs = r / S.scale;
+  const double xi = sph_r_to_xi(S, rs);
+  const int idx = sph_cell(S, xi);
+  const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+  const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+  const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+  const int jdx = idx < 1 ? 1 : idx;
+  const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+  const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
+  double xc = costh;
+  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+  const double dfac = 1.0 / (xc * xc - 1.0);
+  const double rr = S.rmax / r0;
+  const double kappa0 = -P0 / (r0 * ffac);
+  // the block's range of cells
+  int lo = valid ? idx : 0x7fffffff, hi = valid ? idx : -1;
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off));
+    hi = max(hi, __shfl_xor(hi, off));
+  }
+  __syncthreads();
+  if (lane == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+  __syncthreads();
+  const int cmin = s_min, span = s_max - cmin + 1;
+  ForceOut o;
+  if (span <= nstage) {                         // block-uniform
+    const double *src = T4 + (size_t)cmin * tq;
+    const int total = span * (int)tq;
+    for (int t = threadIdx.x; t < total; t += 256) {
+      const int c = t / (int)tq, k = t - c * (int)tq;
+      stage[c * tqs + k] = src[t];
+    }
+    __syncthreads();
+    ldsp t4 = (ldsp)stage + (size_t)((valid ? idx : cmin) - cmin) * tqs;
+    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+  } else {
+    const double *t4 = T4 + (size_t)idx * tq;
+    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+  }
+  if (!valid) return;
+  sph_force_finish<false>(S, o, i, xx, yy, zz, px, py, pz, fac, 1.0 / r, 1.0 / fac, P0, ffac, dfac, AX, AY, AZ, POT, VX,
+                          VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
+}
+
 // ---- per-LMAX launchers (one translation unit per LMAX: sph_inst.hip -DSPH_L=k) -----------------
 
 struct SphAccArgs {
@@ -1476,6 +1577,7 @@ struct SphForceArgs {
                             // next step's opening half-kick (needs key_out)
   uint32_t *nwork_next = nullptr;   // the counter the next launch will use (cleared by this one's general pass)
   int waterfall = 0;        // fast pass as a waterfall over each wave's radial cells (MODE 2)
+  int stage_rows = 0;       // all_slow launches: cells whose table rows a block stages in LDS (0: global gathers)
 };
 
 struct SphUpdArgs {
