@@ -84,6 +84,10 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the secondary BASELINE configurations (2: 1e7 S6 halo, 3: 1e7 C6 disk, "
                          "4: disk + halo, multistep 4) measured after the headline on rank 0 at N = 1")
+    ap.add_argument("--graph", action="store_true",
+                    help="time the K steps as ONE call of exp_amd_step_kdk_n (pairs of steady-state steps replayed from a "
+                         "HIP graph, the RCCL all-reduce included) instead of K calls of exp_amd_step_kdk; per-kernel "
+                         "events are off then (roofline.avg_launch_ms comes from a second, eager region)")
     ap.add_argument("--no-sustained", action="store_true",
                     help="skip the extra >= 2 s timed region reported as `sustained`")
     ap.add_argument("--other-n", type=float, default=1e7, help="particles per component of those")
@@ -572,6 +576,21 @@ def main():
         force.step_kdk(comp, args.dt)
     barrier()
     _flush_c_stdio()            # (every rank: the communicator exists by now)
+    graph_region = None
+    if args.graph:
+        # the K steps as one call, replayed from the graph of a pair of steps (no per-kernel events: they cannot be
+        # captured); the eager region below then only supplies the per-kernel breakdown
+        force.step_kdk_n(comp, args.dt, 4)          # capture + one replay, untimed
+        barrier()
+        tg = time.perf_counter()
+        force.step_kdk_n(comp, args.dt, args.steps)
+        barrier()
+        eg = time.perf_counter() - tg
+        if use_comm:
+            tgt = torch.tensor([eg], device=device, dtype=torch.float64)
+            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+            eg = float(tgt.item())
+        graph_region = {"steps": args.steps, "seconds": eg, "ms_per_step": 1e3 * eg / args.steps}
     ctx.profile(True)
     ctx.profile_reset()
     # per-step device times: one event per step boundary on the context's stream (SURVEY 8d timing protocol:
@@ -599,8 +618,11 @@ def main():
         ns = max(args.steps, int(math.ceil(2.0 / max(el / args.steps, 1e-6))))
         barrier()
         t1 = time.perf_counter()
-        for _ in range(ns):
-            force.step_kdk(comp, args.dt)
+        if args.graph:
+            force.step_kdk_n(comp, args.dt, ns)
+        else:
+            for _ in range(ns):
+                force.step_kdk(comp, args.dt)
         barrier()
         es = time.perf_counter() - t1
         if use_comm:
@@ -627,6 +649,8 @@ def main():
         el = float(t.item())
 
     if rank == 0:
+        if graph_region:                # --graph: the timed region is the replayed one
+            el_eager, el = el, graph_region["seconds"]
         value = ntot * args.steps / el
         ms_step = 1e3 * el / args.steps
         # dominant kernel by measured time on this rank's stream
@@ -700,6 +724,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "step_times": step_times,
+            "stepping": ("exp_amd_step_kdk_n: pairs of steps replayed from a HIP graph (eager region with per-kernel "
+                         f"events: {1e3 * el_eager / args.steps:.4f} ms/step)") if graph_region else
+                        "exp_amd_step_kdk per step (eager launches, per-kernel events on)",
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

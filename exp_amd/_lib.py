@@ -128,6 +128,7 @@ SIGNATURES = {
     "exp_amd_force_multistep_reset": (c_int, [c_void_p]),
     "exp_amd_force_compute_multistep_coefficients": (c_int, [c_void_p, c_int]),
     "exp_amd_step_kdk": (c_int, [c_void_p, c_void_p, c_double]),
+    "exp_amd_step_kdk_n": (c_int, [c_void_p, c_void_p, c_double, c_int]),
     "exp_amd_sim_create": (c_int, [c_void_p, c_int, c_double, c_double_p, c_int, POINTER(c_void_p)]),
     "exp_amd_sim_destroy": (None, [c_void_p]),
     "exp_amd_sim_add_component": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int)]),

@@ -71,6 +71,20 @@ struct exp_amd_force {
   // near 3e6 / values particles.  ctx->dense_min >= 0 overrides.
   virtual long long sparse_threshold() const { return 0; }
 
+  // Host-side state of this force that alternates from one fused step to the next (the spherical method's two
+  // work-list counters): part of the key under which exp_amd_step_kdk_n replays a captured pair of steps
+  virtual int step_parity() const { return 0; }
+  // the graph of TWO consecutive fused steps of (this, one component, one dt) and the host state it was captured in
+  struct StepGraph {
+    hipGraphExec_t exec = nullptr;
+    const exp_amd_comp *comp = nullptr;
+    double dt = 0.0, center[3] = {0, 0, 0}, pending = 0.0;
+    size_t n = 0;
+    int cur = -1, parity = -1, prekick = -1, det = -1;
+    unsigned long long epoch = 0;
+    bool refused = false;          // capture failed once for this pair: eager from then on
+  } step_graph;
+
   virtual int get_used(long long *used);
   // PotAccel::multistep_reset (src/PotAccel.H:288): start of a master step
   virtual int multistep_reset() { return EXP_AMD_OK; }

@@ -16,7 +16,13 @@ void exp_amd_force::forget_home(const exp_amd_comp *c)
 
 void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c)
 {
-  for (exp_amd_force *f : ctx->forces) f->forget_home(c);
+  for (exp_amd_force *f : ctx->forces) {
+    f->forget_home(c);
+    if (f->step_graph.comp == c) {            // a graph of steps of this component: its buffers are about to go
+      if (f->step_graph.exec) (void)hipGraphExecDestroy(f->step_graph.exec);
+      f->step_graph = exp_amd_force::StepGraph{};
+    }
+  }
 }
 
 int exp_amd_force::alloc_common(size_t ncoef_, int multistep_, size_t tail)
@@ -50,6 +56,8 @@ extern "C" void exp_amd_force_destroy(exp_amd_force *f)
 {
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->step_graph.exec) (void)hipGraphExecDestroy(f->step_graph.exec);
+  f->step_graph.exec = nullptr;
   f->ctx->force_epoch++;
   {
     auto &v = f->ctx->forces;
@@ -274,6 +282,96 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
     c->prekey_dtk = 0.5 * dt;
     c->prekey_dtd = dt;
     for (int k = 0; k < 3; k++) c->prekey_center[k] = c->center[k];
+  }
+  return EXP_AMD_OK;
+}
+
+// ---- several fused steps, pairs of them replayed from a HIP graph ------------------------------------------------
+// A fused step is ~12 launches (histogram, scan, scatter, memsets, accumulate, contraction, all-reduce, projection,
+// two force passes); at 1e8 particles they hide behind 10 ms of kernels, at an 8-GPU share (1.25e7 per GPU, 1.4 ms per
+// step) the gaps between them are 3-4 % of the step.  In steady state -- same dt, same centre, the force pass of step k
+// has written the keys of step k+1 -- the host-side state of a step alternates with period two (the ping-pong buffer
+// set of the store, the two work-list counters of the force pass): TWO consecutive steps captured once on the context's
+// stream return the host to the state they started from, and the instantiated graph is replayed for every further
+// pair, the RCCL all-reduce included (a host callback cannot be captured: such contexts step eagerly).  Anything that
+// does not match the captured state -- another dt, a moved centre, an intervening call -- drops the graph.
+static bool step_state_matches(const exp_amd_force *f, const exp_amd_comp *c, double dt)
+{
+  const exp_amd_force::StepGraph &g = f->step_graph;
+  return g.exec && g.comp == c && g.dt == dt && g.n == c->n && g.cur == c->cur && g.parity == f->step_parity() &&
+         g.prekick == (int)f->ctx->prekick && g.det == (int)f->ctx->deterministic && g.epoch == f->ctx->force_epoch &&
+         g.pending == c->pending_kick && g.center[0] == c->center[0] && g.center[1] == c->center[1] &&
+         g.center[2] == c->center[2];
+}
+
+static void step_graph_drop(exp_amd_force *f)
+{
+  if (f->step_graph.exec) (void)hipGraphExecDestroy(f->step_graph.exec);
+  f->step_graph.exec = nullptr;
+}
+
+// the next step would take the key-reusing fast path of exp_amd_step_kdk (its steady state)
+static bool step_is_steady(const exp_amd_force *f, const exp_amd_comp *c, double dt)
+{
+  return c->n > 0 && !f->multistep && c->prekey_valid && !c->prekey_split && !c->split &&
+         c->prekey_owner == (const void *)f && c->prekey_epoch == f->ctx->force_epoch && c->prekey_dtk == 0.5 * dt &&
+         c->prekey_dtd == dt && c->prekey_center[0] == c->center[0] && c->prekey_center[1] == c->center[1] &&
+         c->prekey_center[2] == c->center[2] && c->sorted_for == (const void *)f && c->nlevels == 1;
+}
+
+extern "C" int exp_amd_step_kdk_n(exp_amd_force *f, exp_amd_comp *c, double dt, int nsteps)
+{
+  if (!f || !c || nsteps < 0) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "step_kdk_n: bad argument");
+  exp_amd_ctx *ctx = f->ctx;
+  static const bool graphs_on = !(getenv("EXP_AMD_STEP_GRAPH") && atoi(getenv("EXP_AMD_STEP_GRAPH")) == 0);
+  int rc, done = 0;
+  while (done < nsteps) {
+    const bool can = graphs_on && nsteps - done >= 2 && !ctx->profile && !ctx->ar_fn && ctx->split_min <= 0 &&
+                     !f->step_graph.refused && step_is_steady(f, c, dt);
+    if (!can) {
+      if ((rc = exp_amd_step_kdk(f, c, dt))) return rc;
+      done++;
+      continue;
+    }
+    if (!step_state_matches(f, c, dt)) {
+      // capture two steps from this state; the host code of the steps runs as usual, its launches are recorded
+      step_graph_drop(f);
+      exp_amd_force::StepGraph g;
+      g.comp = c; g.dt = dt; g.n = c->n; g.cur = c->cur; g.parity = f->step_parity();
+      g.prekick = (int)ctx->prekick; g.det = (int)ctx->deterministic; g.epoch = ctx->force_epoch;
+      g.pending = c->pending_kick;
+      for (int k = 0; k < 3; k++) g.center[k] = c->center[k];
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+      int r1 = EXP_AMD_OK, r2 = EXP_AMD_OK;
+      if (e == hipSuccess) {
+        r1 = exp_amd_step_kdk(f, c, dt);
+        if (!r1) r2 = exp_amd_step_kdk(f, c, dt);
+        e = hipStreamEndCapture(ctx->stream, &graph);
+      }
+      // two steps bring the host back to where it was (period two), whether or not the capture worked
+      const bool back = g.cur == c->cur && g.parity == f->step_parity() && g.pending == c->pending_kick &&
+                        step_is_steady(f, c, dt);
+      if (e == hipSuccess && !r1 && !r2 && graph && back)
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+      else if (e == hipSuccess)
+        e = hipErrorUnknown;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess || !g.exec) {
+        (void)hipGetLastError();
+        f->step_graph.refused = true;        // eager from now on; nothing was executed, the two steps are still to do
+        if (!back) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "step_kdk_n: the captured steps left the host state changed");
+        continue;
+      }
+      f->step_graph = g;
+      HIP_TRY(ctx, hipGraphLaunch(f->step_graph.exec, ctx->stream));      // (its all-reduces were counted while capturing)
+      done += 2;
+      continue;
+    }
+    HIP_TRY(ctx, hipGraphLaunch(f->step_graph.exec, ctx->stream));
+    ctx->ar_calls += ctx->rccl_comm ? 2 : 0;
+    done += 2;
   }
   return EXP_AMD_OK;
 }

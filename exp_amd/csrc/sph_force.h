@@ -25,6 +25,7 @@ struct SphForce : exp_amd_force {
   bool used_open = true;
   bool wd_clean = false;            // ... and of d_Wd (multistep_update)
   bool w_clean = false;             // every per-level moment buffer of d_W is zero (substep_expansion keeps it so)
+  int step_parity() const override { return work_flip; }
   int multistep_reset() override
   {
     HIP_TRY(ctx, hipMemsetAsync(d_used.p, 0, sizeof(unsigned long long), ctx->stream));

@@ -504,6 +504,11 @@ class _Force:
         """One multistep=0 KDK step (src/step.cc:271-323), fused."""
         check(self.lib.exp_amd_step_kdk(self.h, comp.h, float(dt)), self.ctx.h)
 
+    def step_kdk_n(self, comp: "Component", dt: float, nsteps: int) -> None:
+        """``nsteps`` fused KDK steps; pairs of steady-state steps are replayed from a HIP graph
+        (include/exp_amd.h: exp_amd_step_kdk_n).  Same results as ``nsteps`` calls of ``step_kdk``."""
+        check(self.lib.exp_amd_step_kdk_n(self.h, comp.h, float(dt), int(nsteps)), self.ctx.h)
+
     def close(self) -> None:
         if self.h:
             self.lib.exp_amd_force_destroy(self.h)

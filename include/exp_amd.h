@@ -395,6 +395,14 @@ int  exp_amd_cyl_cov_get(exp_amd_force *f, long long *counts, double *masses, do
  * other call on the component in between (upload, kick, drift, set_center, zero_acc,
  * another force, a different dt) discards that record.                                */
 int  exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt);
+/* `nsteps` such steps (the do_step loop of src/expand.cc:423-470 at multistep 0 for one component).  Once
+ * the steps are in their steady state -- same dt, same centre, the force pass of each step has written the
+ * sort keys of the next -- PAIRS of steps are captured once in a HIP graph on the context's stream (the
+ * host-side state of a step alternates with period two) and replayed, the RCCL all-reduce of
+ * exp_amd_comm_init_rank included: bit-identical to nsteps calls of exp_amd_step_kdk, without the ~12
+ * launch gaps per step (3-4 % of a step at 1.25e7 particles per GPU).  A host all-reduce callback, the
+ * profiler (exp_amd_profile_enable), the split step or EXP_AMD_STEP_GRAPH=0 keep every step eager.      */
+int  exp_amd_step_kdk_n(exp_amd_force *f, exp_amd_comp *c, double dt, int nsteps);
 
 /* ---- step loop ---------------------------------------------------------------------------
  * do_step (src/step.cc:67-325) and begin_run's initial expansion (src/begin.cc:80-129) over a

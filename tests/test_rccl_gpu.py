@@ -64,3 +64,73 @@ def test_native_rccl_communicator_one_rank():
         for k in ("pos", "vel", "acc", "pot"):
             assert np.abs(got[key][k] - ref[key][k]).max() <= 1e-10 * np.abs(ref[key][k]).max(), (key, k)
     assert (got["lev"] != ref["lev"]).mean() < 1e-3 and ref["lev"].max() > 0
+
+
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_graph_replay_of_fused_steps_is_bit_identical(with_rccl):
+    """exp_amd_step_kdk_n replays PAIRS of steady-state fused steps from a HIP graph captured on the context's
+    stream -- with a communicator, the ncclAllReduce of the coefficient buffer is a node of that graph.  In
+    deterministic mode (order-independent sums) the replayed run must equal the eager one bit for bit: odd and
+    even step counts, a diagnostic in the middle, a change of dt (the graph is dropped and captured again),
+    and the all-reduce count must be what eager stepping gives."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, SphereSL
+    model, g = make_grid("plummer", 4, 8, 400)
+    m, pos, vel = sample_sphere(model, 40000, seed=15)
+
+    def run(graph):
+        ctx = Context(0)
+        if with_rccl:
+            ctx.init_rccl(Context.rccl_unique_id(), 1, 0)
+        ctx.set_deterministic(True)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+
+        def steps(k, dt):
+            if graph:
+                f.step_kdk_n(c, dt, k)
+            else:
+                for _ in range(k):
+                    f.step_kdk(c, dt)
+
+        steps(7, 0.01)
+        mid = c.fix_positions()                    # a read-only diagnostic: the keys of the next step stay valid
+        steps(6, 0.01)
+        steps(5, 0.004)                            # another dt: captured anew
+        steps(1, 0.004)
+        out = c.download()
+        out["coef"] = f.get_coefs().copy()
+        out["calls"] = ctx.comm_info()["allreduce_calls"]
+        out["mid"] = mid["com"]
+        c.close(); f.close(); ctx.close()
+        return out
+
+    eager, replay = run(False), run(True)
+    for k in ("pos", "vel", "acc", "pot", "coef"):
+        assert np.array_equal(eager[k], replay[k]), k
+    assert eager["calls"] == replay["calls"] == (20 if with_rccl else 0)
+
+
+def test_graph_replay_without_deterministic_mode():
+    """... and in the default mode (atomics in arrival order) to rounding; EXP_AMD_STEP_GRAPH is honoured."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, SphereSL
+    model, g = make_grid("plummer", 6, 10, 400)
+    m, pos, vel = sample_sphere(model, 200000, seed=16)
+    outs = []
+    for graph in (False, True):
+        ctx = Context(0)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        if graph:
+            f.step_kdk_n(c, 0.005, 12)
+        else:
+            for _ in range(12):
+                f.step_kdk(c, 0.005)
+        outs.append(c.download())
+        c.close(); f.close(); ctx.close()
+    for k in ("pos", "vel"):
+        assert np.abs(outs[0][k] - outs[1][k]).max() <= 1e-11 * np.abs(outs[0][k]).max(), k
+    assert np.abs(outs[0]["acc"] - outs[1]["acc"]).max() <= 1e-9 * np.abs(outs[0]["acc"]).max()
