@@ -691,7 +691,10 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
     const bool incut = mover && (r2 + zz * zz) < C.rmax2;
     double mu = incut ? cdet_round(mass, C.detCm) : 0.0, nu = incut ? 1.0 : 0.0;
     for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
-    if ((threadIdx.x & 63) == 0 && nu > 0.0) { unsafeAtomicAdd(tail + 0, mu); unsafeAtomicAdd(tail + 1, nu); }
+    if ((threadIdx.x & 63) == 0 && nu > 0.0) {        // (slot pairs, folded by the contraction: see k_cyl_accumulate)
+      double *tp = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+      unsafeAtomicAdd(tp + 0, mu); unsafeAtomicAdd(tp + 1, nu);
+    }
     mover = incut;
   }
   if (sqrt(r2 + zz * zz) > C.rtab_abs) mover = false;
@@ -1538,7 +1541,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,              \
-      c->lev_off.p, dacc + 1, ms, 0, f->d_Wn.p, 1, dst + f->ncoef)
+      c->lev_off.p, dacc + 1, ms, 0, f->d_Wn.p, 1, f->d_tailpart.p)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
   }

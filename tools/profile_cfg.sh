@@ -15,7 +15,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
 i=0
 for CTRS in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+            "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM" \
+            "TCC_EA0_ATOMIC_sum TCC_EA0_ATOMIC_LEVEL_sum" "TCC_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/sq$i" -- $CMD > "$OUT/sq$i.log" 2>&1
 done
