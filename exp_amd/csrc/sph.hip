@@ -631,13 +631,13 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
                    cnt + (1 - f->work_flip), wfall ? 1 : 0};
     if (slow && foreign) {
       // another component's particles: local in radius though not in this basis' cell order -- the rows of each
-      // block's cell range go through LDS (k_sph_force_staged).  About 28 KB per block, so that LDS does not hold the
-      // kernel below the three blocks per CU its registers allow: 16 rows at lmax 6 (measured on 1e7 disk particles in
-      // (R, z)-cell order, tools/dbg/cross_force.py: global gathers 0.97 ms, 4 / 8 / 16 / 32 rows 0.81 / 0.61 / 0.56 /
-      // 0.70 ms), 7 at lmax 10
+      // block's cell range go through LDS (k_sph_force_staged), about 40 KB per block (three blocks per CU, as many as
+      // its registers allow).  Measured on 1e7 disk particles in (R, z)-cell order (tools/dbg/cross_force.py,
+      // profiles/r03_cross_force_staging.txt): lmax 6: global gathers 0.98 ms, 8 / 16 / 24 rows 0.57 / 0.51 / 0.48 ms;
+      // lmax 10: 2.21 ms, 4 / 7 / 12 rows 1.72 / 1.32 / 1.08 ms
       const int tq = 4 * S.trows, tqs = tq + ((2 - tq % 16) + 16) % 16;
-      int rows = (int)(28672 / ((size_t)tqs * sizeof(double)));
-      a.stage_rows = rows > 16 ? 16 : rows < 4 ? 4 : rows;
+      int rows = (int)(40960 / ((size_t)tqs * sizeof(double)));
+      a.stage_rows = rows > 24 ? 24 : rows < 4 ? 4 : rows;
       if (const char *e = getenv("EXP_AMD_STAGE_ROWS")) a.stage_rows = atoi(e);
     }
     k_force_launch[f->cfg.lmax](a);

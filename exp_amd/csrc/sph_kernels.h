@@ -1128,6 +1128,79 @@ sph_field_fast(cdp t4, double costh, double somx2, double cphi, double sphi, dou
   return o;
 }
 
+// The fast pass' arithmetic with the rows behind a PER-LANE pointer (LDS-staged rows of k_sph_force_staged, or global
+// memory): the same factored sums, recurrences and operation order as sph_field_fast -- results are bit-identical to
+// it for the same cell -- without the scalar-load pipeline.
+template <int LMAX, class PT>
+__device__ __forceinline__ ForceOut
+sph_field_fast_ptr(PT t4, double costh, double somx2, double cphi, double sphi, double x2, double pf)
+{
+  constexpr int NBLK = (LMAX + 1) * (LMAX + 2) / 2;
+  ForceOut o{0.0, 0.0, 0.0, 0.0};
+  double pmm = LC_E(0);
+  double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+  double Ag = 0.0, Ad = 0.0, Tg = 0.0, Td = 0.0, Rb = 0.0, Ra = 0.0;
+  double Bg = 0.0, Bd = 0.0, Ug = 0.0, Ud = 0.0, Sb = 0.0, Sa = 0.0;
+  double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
+  static_for<0, NBLK>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int l = blk_l<LMAX>(k), m = blk_m<LMAX>(k);
+    constexpr int q = 4 * t4_row(LMAX, l, m);
+    if constexpr (l == m) {
+      if constexpr (m == 1) { pmm *= LC_E(1) * somx2; cm = cphi; sm = sphi; }
+      else if constexpr (m > 1) {
+        pmm *= LC_E(m) * somx2;
+        const double cn = 2.0 * cphi * cm - cm1, sn = 2.0 * cphi * sm - sm1;
+        cm1 = cm; sm1 = sm; cm = cn; sm = sn;
+      }
+      Ag = Ad = Tg = Td = Rb = Ra = 0.0;
+      Bg = Bd = Ug = Ud = Sb = Sa = 0.0;
+      pl2 = pl1 = tprev = 0.0;
+    }
+    double plm, qlm;
+    if constexpr (l == m) plm = pmm;
+    else if constexpr (l == m + 1) plm = LC_a(l, m) * tprev;
+    else plm = fma(LC_a(l, m), tprev, -pl2);
+    tprev = costh * plm;
+    if constexpr (l == m) qlm = tprev * l;
+    else qlm = fma((double)l, tprev, -(LC_c(l, m) * pl1));
+    pl2 = pl1;
+    pl1 = plm;
+    const double g0 = t4[q + 0], g1 = t4[q + 1], g2 = t4[q + 2], g3 = t4[q + 3];
+    Ag = fma(plm, g0, Ag);
+    Ad = fma(plm, g1, Ad);
+    Rb = fma(plm, g2, Rb);
+    Ra = fma(plm, g3, Ra);
+    if constexpr (l > 0) {
+      Tg = fma(qlm, g0, Tg);
+      Td = fma(qlm, g1, Td);
+    }
+    if constexpr (m > 0) {
+      const double h0 = t4[q + 4], h1 = t4[q + 5], h2 = t4[q + 6], h3 = t4[q + 7];
+      Bg = fma(plm, h0, Bg);
+      Bd = fma(plm, h1, Bd);
+      Sb = fma(plm, h2, Sb);
+      Sa = fma(plm, h3, Sa);
+      Ug = fma(qlm, h0, Ug);
+      Ud = fma(qlm, h1, Ud);
+    }
+    if constexpr (l == LMAX) {
+      const double Al = fma(x2, Ad, Ag), At = fma(x2, Td, Tg), Ar = fma(pf, Ra, Rb);
+      if constexpr (m == 0) {
+        o.potl += Al; o.potr += Ar; o.pott += At;
+      } else {
+        const double Bl = fma(x2, Bd, Bg), Bt = fma(x2, Ud, Ug), Br = fma(pf, Sa, Sb);
+        o.potl += Al * cm + Bl * sm;
+        o.potr += Ar * cm + Br * sm;
+        o.pott += At * cm + Bt * sm;
+        o.potp += (Bl * cm - Al * sm) * m;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  });
+  return o;
+}
+
 // out-of-line copy for the waterfall loop of MODE 2: inlined into a loop, the (l, m) recurrence literals
 // are hoisted out of it as loop invariants -- several hundred SGPRs, i.e. a kernel that lives in scratch
 template <int LMAX>
@@ -1454,9 +1527,11 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
 // the general pass above pays ~100 dependent per-lane gathers from global memory per wave for its table rows (the
 // largest single launch of a two-component master step).  But a block's 256 consecutive target particles are still
 // LOCAL in radius (a disk in (R, z)-cell order: ~8 cells of the halo's radial grid), so the block copies the rows of
-// its cell range [cmin, cmax] into LDS once -- coalesced -- and every lane reads its own cell's rows from there (same
-// operands, same operations as sph_field on global rows: bit-identical results).  Blocks whose range does not fit
-// (nstage rows) keep the global gathers.  tqs: LDS row stride in doubles (tq padded to 2 mod 16: consecutive cells
+// its cell range [cmin, cmax] into LDS once -- coalesced -- and every lane reads its own cell's rows from there, with
+// the FAST pass' arithmetic (shared reciprocals, factored weights: half the instructions of the general evaluation;
+// the same operations as a cell-uniform wave of the fast pass performs, so a particle gets the bits it would get
+// there).  Lanes on the polar axis or beyond rmax take the general evaluation on global rows; blocks whose range
+// does not fit (nstage rows) read their rows from global memory with the same arithmetic.  tqs: LDS row stride in doubles (tq padded to 2 mod 16: consecutive cells
 // start four banks apart).
 typedef const __attribute__((address_space(3))) double *ldsp;
 
@@ -1482,42 +1557,41 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
     px = X[i]; py = Y[i]; pz = Z[i];
     xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz;
   }
-  // the general path's prologue (sph_force_chunk<LMAX, 0>), statement for statement
   const double fac = xx * xx + yy * yy;
   const size_t tq = (size_t)4 * S.trows;
-  double r = sqrt(fac + zz * zz) + S.dsmall;
-  const double costh = zz / r;
-  double cphi, sphi;
-  phi_trig(xx, yy, cphi, sphi);
-  bool ioff = false;
-  const double r0 = r;
-  if (r > S.rmax && !S.no_exterior) { ioff = true; r = S.rmax; }
-  const double rs = r / S.scale;
-  const double xi = sph_r_to_xi(S, rs);
+  // the fast pass' prologue (sph_force_chunk<LMAX, 1>): shared reciprocals, cell, weights
+  double g, y, R, iR;
+  sqrt_rsqrt(fac + zz * zz, g, y);
+  const double r = g + S.dsmall;
+  const double ir = rcp_refine(r, y);
+  const double costh = zz * ir;
+  sqrt_rsqrt(fac, R, iR);
+  const double iR2 = iR * iR;
+  const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
+  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
+  const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
   const int idx = sph_cell(S, xi);
+  const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
+  const double dfac = -(r * r) * iR2;
   const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
   const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
   const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
   const int jdx = idx < 1 ? 1 : idx;
   const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
-  const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
-  double xc = costh;
-  if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-  const double dfac = 1.0 / (xc * xc - 1.0);
-  const double rr = S.rmax / r0;
-  const double kappa0 = -P0 / (r0 * ffac);
-  // the block's range of cells
-  int lo = valid ? idx : 0x7fffffff, hi = valid ? idx : -1;
+  const bool regular = valid && !special;
+  // the block's range of cells (regular lanes only: the special ones -- polar axis, beyond rmax -- take the general
+  // evaluation on global rows below)
+  int lo = regular ? idx : 0x7fffffff, hi = regular ? idx : -1;
   for (int off = 32; off > 0; off >>= 1) {
     lo = min(lo, __shfl_xor(lo, off));
     hi = max(hi, __shfl_xor(hi, off));
   }
   __syncthreads();
-  if (lane == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+  if (lane == 0 && hi >= 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
   __syncthreads();
   const int cmin = s_min, span = s_max - cmin + 1;
-  ForceOut o;
-  if (span <= nstage) {                         // block-uniform
+  ForceOut o{0.0, 0.0, 0.0, 0.0};
+  if (span >= 1 && span <= nstage) {            // block-uniform
     const double *src = T4 + (size_t)cmin * tq;
     const int total = span * (int)tq;
     for (int t = threadIdx.x; t < total; t += 256) {
@@ -1525,15 +1599,43 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
       stage[c * tqs + k] = src[t];
     }
     __syncthreads();
-    ldsp t4 = (ldsp)stage + (size_t)((valid ? idx : cmin) - cmin) * tqs;
-    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
-  } else {
-    const double *t4 = T4 + (size_t)idx * tq;
-    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+    ldsp t4 = (ldsp)stage + (size_t)((regular ? idx : cmin) - cmin) * tqs;
+    o = sph_field_fast_ptr<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
+  } else if (span >= 1) {
+    const double *t4 = T4 + (size_t)(regular ? idx : cmin) * tq;
+    o = sph_field_fast_ptr<LMAX>(t4, costh, sinth, cphi, sphi, x2, pf);
   }
-  if (!valid) return;
-  sph_force_finish<false>(S, o, i, xx, yy, zz, px, py, pz, fac, 1.0 / r, 1.0 / fac, P0, ffac, dfac, AX, AY, AZ, POT, VX,
-                          VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
+  if (regular)
+    sph_force_finish<true>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
+                           0.0, assign, nullptr, 0.0, 0.0, 1);
+  if (__any(valid && special)) {
+    // the general path (sph_force_chunk<LMAX, 0>), statement for statement, for the special lanes
+    double rg = sqrt(fac + zz * zz) + S.dsmall;
+    const double costh_g = zz / rg;
+    double cphi_g, sphi_g;
+    phi_trig(xx, yy, cphi_g, sphi_g);
+    bool ioff = false;
+    const double r0 = rg;
+    if (rg > S.rmax && !S.no_exterior) { ioff = true; rg = S.rmax; }
+    const double xig = sph_r_to_xi(S, rg / S.scale);
+    const int idg = sph_cell(S, xig);
+    const double y1 = (S.xi[idg + 1] - xig) * S.inv_dxi;
+    const double y2 = (xig - S.xi[idg]) * S.inv_dxi;
+    const double P0g = y1 * S.p0[idg] + y2 * S.p0[idg + 1];
+    const int jdg = idg < 1 ? 1 : idg;
+    const double pfg = (xig - S.xi[jdg]) * S.inv_dxi;
+    const double ffacg = sph_d_xi_to_r(S, xig) * S.inv_dxi;
+    double xc = costh_g;
+    if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+    const double dfacg = 1.0 / (xc * xc - 1.0);
+    const double rr = S.rmax / r0;
+    const double kappa0 = -P0g / (r0 * ffacg);
+    const double *t4 = T4 + (size_t)idg * tq;
+    const ForceOut og = sph_field<LMAX>(S, costh_g, xc, cphi_g, sphi_g, t4, y2, pfg, ioff, rr, kappa0);
+    if (valid && special)
+      sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, fac, 1.0 / rg, 1.0 / fac, P0g, ffacg, dfacg, AX, AY, AZ,
+                              POT, VX, VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
+  }
 }
 
 // ---- per-LMAX launchers (one translation unit per LMAX: sph_inst.hip -DSPH_L=k) -----------------
