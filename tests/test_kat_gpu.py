@@ -188,3 +188,37 @@ def test_headline_size_properties(ctx):
     assert np.abs(cf[0, 1:]).max() < 2e-3 * abs(cf[0, 0])
     c.close()
     f.close()
+
+
+def test_cylinder_poisson_consistency_through_getbasis(ctx, tmp_path):
+    """pyEXP's Cylindrical.getBasis (expui/BiorthBasis.cc:1930-1974 -> EmpCylSL::get_all) on the device tables:
+    potential, density, radial and vertical force of every (m, n) satisfy Poisson's equation in integral form
+    (tests/test_oracle_kat.py::cyl_poisson_residual) -- the device's bilinear blend of the four table kinds, on a
+    grid that is not the tables' own."""
+    from exp_amd.basis import Basis
+    from tests.test_oracle_kat import cyl_poisson_residual
+    basis = Basis.factory(f"""
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  mmax: 2
+  nmax: 5
+  ncylnx: 96
+  ncylny: 48
+  ncylr: 1000
+  lmaxfid: 24
+  nmaxfid: 20
+  rnum: 100
+  tnum: 40
+  cachename: {tmp_path / 'eof.cache.kat'}
+""", ctx)
+    for (R1, R2, z1, z2) in ((0.004, 0.03, -0.002, 0.002), (0.01, 0.05, -0.004, 0.001)):
+        nR, nZ = 160, 120
+        t = basis.getBasis(R1, R2, nR, z1, z2, nZ, True)
+        R, z = np.linspace(R1, R2, nR), np.linspace(z1, z2, nZ)
+        for m in range(3):
+            for n in range(5):
+                b = t[m][n]
+                res = cyl_poisson_residual(R, z, b["potential"], b["rforce"], b["zforce"], b["density"], m)
+                assert res < 2e-2, (R1, R2, m, n, res)

@@ -596,3 +596,61 @@ def test_reference_structure_baseline_equals_the_oracle(oracle, plummer_small):
         oracle.refstruct_free(rs)
         for key, ref in (("pos", p), ("vel", v), ("acc", a), ("pot", pt), ("coef", cf.reshape(-1))):
             assert np.abs(out[key] - ref).max() <= tol * np.abs(ref).max(), (nthreads, key)
+
+
+def cyl_poisson_residual(R, z, P, FR, FZ, D, m):
+    """Integral form of Poisson's equation for one cylindrical basis function Phi(R, z) cos(m phi) over the
+    rectangle spanned by the sample lines R[], z[] (values on the product grid, trapezoidal rule):
+        -[R F_R] dz  -  [F_z] R dR  -  m^2 int int Phi / R  =  4 pi int int rho R        (F = -grad Phi)
+    Returns |lhs - rhs| / (sum of the magnitudes of the terms)."""
+    tr = np.trapezoid
+    t1 = -(R[-1] * tr(FR[-1], z) - R[0] * tr(FR[0], z))
+    t2 = -(tr(R * FZ[:, -1], R) - tr(R * FZ[:, 0], R))
+    t3 = -m * m * tr(tr(P / R[:, None], z, axis=1), R)
+    rhs = 4.0 * math.pi * tr(tr(D * R[:, None], z, axis=1), R)
+    return abs(t1 + t2 + t3 - rhs) / (abs(t1) + abs(t2) + abs(t3) + abs(rhs))
+
+
+def test_empcyl_tables_satisfy_poisson():
+    """The EOF tables of exp_amd.empcyl (potC, rforceC, zforceC and the density tables of compute_eof_grid,
+    exputil/EmpCylSL.cc:1454-1534) are not pinned by any reference-built file; this holds them to Poisson's
+    equation for every (m, n), m = 0..2 -- the sign and pfac / ffac / dfac scalings of the three kinds, the
+    1/4pi of the density and the m^2 / R^2 term -- on three rectangles of the table's own node grid.
+    Tolerance: the trapezoidal rule on a 96 x 48 grid (measured <= 5e-3; 2e-3 at 128 x 64)."""
+    from exp_amd.empcyl import build_empcyl
+    g = build_empcyl(mmax=2, norder=6, numx=96, numy=48, acyl=0.01, hcyl=0.001, lmaxfid=24, nmaxfid=20,
+                     numr=1000, rnum=100, tnum=40)
+    x = g.xmin + g.dx * np.arange(g.numx + 1)
+    y = g.ymin + g.dy * np.arange(g.numy + 1)
+    R = (1.0 + x) / (1.0 - x) * g.ascale
+    z = g.hscale * np.sinh(y)
+    for i1, i2, j1, j2 in ((8, 45, 9, 39), (4, 30, 21, 27), (12, 50, 14, 34)):
+        for m in range(g.mmax + 1):
+            for n in range(g.norder):
+                sl = (slice(i1, i2 + 1), slice(j1, j2 + 1))
+                res = cyl_poisson_residual(R[i1:i2 + 1], z[j1:j2 + 1], g.tab[0, m, n][sl], g.tab[1, m, n][sl],
+                                           g.tab[2, m, n][sl], g.dens[0, m, n][sl], m)
+                assert res < 2e-2, (i1, i2, j1, j2, m, n, res)
+
+
+def test_cylinder_rotation_about_z(oracle):
+    """Rotating the particle set by alpha about z rotates every (cos, sin) coefficient pair of EmpCylSL::accumulate
+    (exputil/EmpCylSL.cc:4049-4146) by m alpha: pins the cos / sin assignment and the sign of the sine rows."""
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    g = build_empcyl(mmax=3, norder=4, numx=32, numy=16, acyl=0.01, hcyl=0.001, lmaxfid=16, nmaxfid=12,
+                     numr=600, rnum=60, tnum=30)
+    m, pos, _ = sample_disk(3000, 12, a=0.01, h=0.001)
+    pos[:, 0] *= 1.3                                            # not axisymmetric
+    c0, s0, _, _ = oracle.cyl_accumulate(g, pos, m)
+    al = 0.6
+    Rz = np.array([[math.cos(al), -math.sin(al), 0], [math.sin(al), math.cos(al), 0], [0, 0, 1]])
+    c1, s1, _, _ = oracle.cyl_accumulate(g, pos @ Rz.T, m)
+    scale = np.abs(c0).max()
+    for mm in range(g.mmax + 1):
+        ec = c0[mm] * math.cos(mm * al) - s0[mm] * math.sin(mm * al)
+        es = c0[mm] * math.sin(mm * al) + s0[mm] * math.cos(mm * al)
+        assert np.allclose(c1[mm], ec, atol=1e-10 * scale)
+        if mm:
+            assert np.allclose(s1[mm], es, atol=1e-10 * scale)
+    assert np.abs(s0[1:]).max() > 1e-3 * scale and np.abs(c0[2]).max() > 1e-3 * scale
