@@ -878,6 +878,37 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
   if (add_to) add_to[(size_t)L * ostride + o] += s;
 }
 
+// The block-multistep sub-step's form for a rank that is alone: the segment sums of every active level with
+// setup_accumulation's swap, the {in-cut mass, count} slots of the accumulation folded straight into the master step's
+// tally (k_cyl_mass_take: while its first sub-step is open; the sets' tails stay zero), THEN the combined set of
+// CylEXP::compute_multistep_coefficients (src/CylEXP.cc:192-282) -- what k_cyl_contract_sum + k_cyl_mass_take +
+// k_mstep_combine do, in one launch instead of three.
+__global__ void __launch_bounds__(256)
+k_cyl_sum_combine(CylDev C, const double *__restrict__ part, double *__restrict__ N, double *__restrict__ Lset,
+                  size_t stride, int lo, int nact, int nlev, int mfirst, CombineW W, double *__restrict__ out,
+                  double *__restrict__ tailpart, double *__restrict__ mass_acc, int open)
+{
+  const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    double t = 0.0;
+    for (int j = 0; j < CYL_TAILS; j++) { t += tailpart[2 * j + threadIdx.x]; tailpart[2 * j + threadIdx.x] = 0.0; }
+    if (open) mass_acc[threadIdx.x] += t;
+    out[ncoef + threadIdx.x] = 0.0;
+  }
+  if (o >= ncoef) return;
+  const bool none = o >= ncoef / 2 && o < ncoef / 2 + (size_t)C.nmax;      // (sin, m = 0): no such row
+  for (int j = 0; j < nact; j++) {
+    double s = 0.0;
+    if (!none)
+      for (int seg = 0; seg < CYL_CSEG; seg++) s += part[((size_t)j * CYL_CSEG + seg) * ncoef + o];
+    const size_t q = (size_t)(lo + j) * stride + o;
+    Lset[q] = N[q];
+    N[q] = s;
+  }
+  out[o] = expamd_combine_one(Lset, N, stride, nlev, mfirst, W.ab, o);
+}
+
 // both stages; nl levels starting at Wn / out / last
 static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, double *Wn, double *part,
                          double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0,
@@ -1115,7 +1146,7 @@ struct CylForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
-  int substep_expansion(exp_amd_comp *c, int lo, double dt_min) override;
+  int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1) override;
   long long sparse_threshold() const override { return 3000000LL / (4 * dev.ntrig); }
   int resort(exp_amd_comp *c, int first = 0) override;
   int multistep_reset() override
@@ -1441,7 +1472,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
+int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine)
 {
   CylForce *f = this;
   const int ms = f->multistep;
@@ -1549,10 +1580,25 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     ProfScope ps(ctx, "k_cyl_contract");
     // ... with setup_accumulation(M)'s swap of every active level: L <- N, N <- new
     // (exputil/EmpCylSL.cc:2010-2030)
+    if (mdrft_combine >= 0) {
+      int mfc = 0;
+      CombineW Wc;
+      expamd_combine_weights(ms, mdrft_combine, &mfc, &Wc);
+      k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nact), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl,
+                                                                                 f->d_cpart.p, /*clear=*/1);
+      k_cyl_sum_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
+          C, f->d_cpart.p, f->d_coefN.p, f->d_coefL.p, f->ncoef_dev, lo, nact, ms + 1, mfc, Wc, f->d_coef.p,
+          f->d_tailpart.p, f->d_mass.p, f->mass_open ? 1 : 0);
+      HIP_TRY(ctx, hipGetLastError());
+      f->combined_mdrft = mdrft_combine;
+      f->proj_dirty = true;
+      return EXP_AMD_OK;
+    }
     cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, f->d_cpart.p, dst, nact,
                  f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1, nullptr, f->d_tailpart.p);
   }
   HIP_TRY(ctx, hipGetLastError());
+  f->combined_mdrft = -1;
   if ((rc = expamd_allreduce(ctx, dst, (size_t)nact * f->ncoef_dev))) return rc;
   k_cyl_mass_take<<<1, 64, 0, ctx->stream>>>(f->d_mass.p, dst + f->ncoef, f->mass_open ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());

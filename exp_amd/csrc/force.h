@@ -3,6 +3,36 @@
 #pragma once
 #include "particles.h"
 
+// compute_multistep_coefficients (src/SphericalBasis.cc:1252-1333, src/CylEXP.cc:192-282): the interpolation weights
+// (a, b) of the levels below mfirst[mdrft] and the combination itself, shared by the stand-alone kernel of force_api.hip
+// and the fused per-level-sums + combination kernels of the two force methods
+struct CombineW { double ab[2 * 17]; };
+inline void expamd_combine_weights(int ms, int mdrft, int *mfirst, CombineW *W)
+{
+  int mf = 0;                                   // src/multistep.cc:630-680: mfirst[mdrft], dstepL/N[M][mdrft]
+  for (int M = 0; M <= ms; M++)
+    if (mdrft == 0 || mdrft % (1 << (ms - M)) == 0) { mf = M; break; }
+  for (int k = 0; k < 2 * 17; k++) W->ab[k] = 0.0;
+  for (int M = 0; M < mf; M++) {
+    const int d = 1 << (ms - M);
+    const int dL = (mdrft / d) * d, dN = dL + d;
+    const double b = (double)(mdrft - dL) / (double)(dN - dL);
+    W->ab[2 * M] = 1.0 - b;
+    W->ab[2 * M + 1] = b;
+  }
+  *mfirst = mf;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ double expamd_combine_one(const double *__restrict__ L, const double *__restrict__ N,
+                                                     size_t stride, int nlev, int mfirst, const double *ab, size_t k)
+{
+  double s = 0.0;
+  for (int M = 0; M < mfirst; M++) s += ab[2 * M] * L[(size_t)M * stride + k] + ab[2 * M + 1] * N[(size_t)M * stride + k];
+  for (int M = mfirst; M < nlev; M++) s += N[(size_t)M * stride + k];
+  return s;
+}
+#endif
+
 struct exp_amd_force {
   exp_amd_ctx *ctx = nullptr;
   int multistep = 0;
@@ -63,7 +93,11 @@ struct exp_amd_force {
   // The levels are disjoint particle sets and each level's accumulation reads only its own
   // particles, so the reference's level-by-level order gives the same sums.  dt_min <= 0: no advance
   // (begin_run's expansion of every level).
-  virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min) = 0;
+  // mdrft_combine >= 0 (a single rank only: no all-reduce sits between the two): the kernel that sums the per-level
+  // sets also forms the combined set of compute_multistep_coefficients(mdrft_combine) -- one link less in the chain of
+  // dependent launches of a sub-step; `combined_mdrft` then says so until the sets change again
+  virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1) = 0;
+  int combined_mdrft = -1;
 
   // Level population below which a multistep level is left un-cell-sorted (see exp_amd_comp::
   // sparse_mask).  Sorting a level costs ~100 us of small launches per sub-step; accumulating one

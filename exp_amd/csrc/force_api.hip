@@ -145,8 +145,6 @@ extern "C" int exp_amd_force_used(exp_amd_force *f, long long *used)
 
 // ---- multistep coefficient bookkeeping -----------------------------------------------------------------------
 
-struct CombineW { double ab[2 * 17]; };      // interpolation weights (a, b) of the levels below mfirst
-
 __global__ void __launch_bounds__(256)
 k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int ncoef, int nlev,
                 int mfirst, CombineW W, double *__restrict__ out)
@@ -154,11 +152,8 @@ k_mstep_combine(const double *__restrict__ L, const double *__restrict__ N, int 
   const double *ab = W.ab;
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
-  double s = 0.0;
   // src/SphericalBasis.cc:1252-1333 ; src/CylEXP.cc:192-282
-  for (int M = 0; M < mfirst; M++)
-    s += ab[2 * M] * L[(size_t)M * ncoef + k] + ab[2 * M + 1] * N[(size_t)M * ncoef + k];
-  for (int M = mfirst; M < nlev; M++) s += N[(size_t)M * ncoef + k];
+  const double s = expamd_combine_one(L, N, (size_t)ncoef, nlev, mfirst, ab, (size_t)k);
   out[k] = s;
 }
 
@@ -176,26 +171,14 @@ extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, in
   if (ms == 0) return EXP_AMD_OK;
   const int Mstep = 1 << ms;
   if (mdrft < 0 || mdrft > Mstep) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "mdrft out of range");
-  // src/multistep.cc:630-680: mfirst[mdrft], dstepL/N[M][mdrft]
   int mfirst = 0;
-  for (int M = 0; M <= ms; M++) {
-    bool active = (mdrft == 0) || (mdrft % (1 << (ms - M)) == 0);
-    if (active) { mfirst = M; break; }
-  }
   CombineW W;
-  double *ab = W.ab;
-  for (int k = 0; k < 2 * 17; k++) ab[k] = 0.0;
-  for (int M = 0; M < mfirst; M++) {
-    const int d = 1 << (ms - M);
-    const int dL = (mdrft / d) * d, dN = dL + d;
-    const double b = (double)(mdrft - dL) / (double)(dN - dL);
-    ab[2 * M] = 1.0 - b;
-    ab[2 * M + 1] = b;
-  }
+  expamd_combine_weights(ms, mdrft, &mfirst, &W);
   k_mstep_combine<<<cdiv(f->ncoef_dev, 256), 256, 0, ctx->stream>>>(
       f->d_coefL.p, f->d_coefN.p, (int)f->ncoef_dev, ms + 1, mfirst, W, f->d_coef.p);
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = true;
+  f->combined_mdrft = -1;
   return EXP_AMD_OK;
 }
 

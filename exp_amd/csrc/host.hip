@@ -281,13 +281,16 @@ static int wait_used(exp_amd_sim *s, size_t k)
 
 // first half: for M = mfirst[mstep] .. multistep: incr_velocity(DT(M)/2, M); incr_position(DT(M), M);
 // compute_expansion(M)  (src/step.cc:126-160)
-static int substep_expansion(exp_amd_sim *s, int lo, double dt_min)
+static int substep_expansion(exp_amd_sim *s, int lo, double dt_min, int mdrft)
 {
+  // (alone: the combined coefficient set of the force evaluation that follows is formed by the same kernel that sums
+  // the per-level sets; with several ranks the all-reduce of the level block sits between the two)
+  const bool alone = s->ctx->nranks <= 1 && !s->ctx->ar_fn && !s->ctx->rccl_comm;
   for (size_t k = 0; k < s->comps.size(); k++) {
     StreamOf on(s, k);
     int rc = wait_used(s, k);
     if (rc) return rc;
-    rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min);
+    rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1);
     if (rc) return rc;
   }
   return EXP_AMD_OK;
@@ -304,7 +307,8 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     StreamOf on(s, k);
     exp_amd_force *f = s->forces[k];
     if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
-    if ((rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
+    if (f->combined_mdrft != mdrft && (rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
+    f->combined_mdrft = -1;
     if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
     if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
   }
@@ -416,11 +420,11 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
     if ((rc = overlap_begin(s))) return rc;
     for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
     // for (M = 0 .. multistep) compute_expansion(M): every level, nothing advanced
-    if ((rc = substep_expansion(s, 0, 0.0))) return rc;
+    if ((rc = substep_expansion(s, 0, 0.0, 0))) return rc;
     if ((rc = compute_potential_ms(s, 0, 0, 0))) return rc;
     if ((rc = kick_adjust_levels(s, 0, 1, false))) return rc;
     for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
-    if ((rc = substep_expansion(s, 0, 0.0))) return rc;
+    if ((rc = substep_expansion(s, 0, 0.0, 0))) return rc;
     if ((rc = compute_potential_ms(s, 0, 0, 0))) return rc;
     return overlap_end(s);
   }
@@ -446,9 +450,9 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
-        if ((rc = substep_expansion(s, s->mfirst[mstep], dt))) return rc;
-        s->tnow += dt;
         const int mdrft = mstep + 1;
+        if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
+        s->tnow += dt;
         if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep))) return rc;
         if ((rc = kick_adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0, true))) return rc;
       }

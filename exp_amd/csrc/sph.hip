@@ -88,6 +88,26 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
   if (add_to) add_to[(size_t)blockIdx.y * ncoef + k] += s;
 }
 
+// The block-multistep sub-step's form for a rank that is alone: every active level's segment sums with the N/L swap
+// (as above), THEN the combined set of compute_multistep_coefficients (src/SphericalBasis.cc:1252-1333) in the same
+// thread -- the same operations in the same order as k_sph_sum_parts + k_mstep_combine, one launch less in the chain.
+__global__ void __launch_bounds__(256)
+k_sph_sum_combine(const double *__restrict__ part, int ncoef, double *__restrict__ N, double *__restrict__ L, int lo,
+                  int nact, int nlev, int mfirst, CombineW W, double *__restrict__ out)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ncoef) return;
+  for (int j = 0; j < nact; j++) {
+    const double *p = part + (size_t)j * CSEG * ncoef;
+    double s = 0.0;
+    for (int seg = 0; seg < CSEG; seg++) s += p[(size_t)seg * ncoef + k];
+    const size_t o = (size_t)(lo + j) * ncoef + k;
+    L[o] = N[o];
+    N[o] = s;
+  }
+  out[k] = expamd_combine_one(L, N, (size_t)ncoef, nlev, mfirst, W.ab, (size_t)k);
+}
+
 // ---- coefficients -> projected tables -----------------------------------------------------------------
 // G[i][row] = sum_n E[i][l][n] c[row][n]   (reference row order)
 __global__ void __launch_bounds__(256)
@@ -465,7 +485,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
+int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine)
 {
   SphForce *f = this;
   const int ms = f->multistep;
@@ -554,11 +574,20 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min)
     k_sph_contract<<<dim3(S.nrows, CSEG, nact), 256, 0, ctx->stream>>>(
         S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
     // ... with the N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
+    if (mdrft_combine >= 0) {
+      int mfc = 0;
+      CombineW Wc;
+      expamd_combine_weights(ms, mdrft_combine, &mfc, &Wc);
+      k_sph_sum_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
+          f->d_part.p, (int)f->ncoef, f->d_coefN.p, f->d_coefL.p, lo, nact, ms + 1, mfc, Wc, f->d_coef.p);
+    } else
     k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nact), 256, 0, ctx->stream>>>(
         f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef, f->d_coefL.p + (size_t)lo * f->ncoef);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if ((rc = expamd_allreduce(ctx, f->d_coefN.p + (size_t)lo * f->ncoef, (size_t)nact * f->ncoef))) return rc;
+  f->combined_mdrft = mdrft_combine;
+  if (mdrft_combine < 0 &&
+      (rc = expamd_allreduce(ctx, f->d_coefN.p + (size_t)lo * f->ncoef, (size_t)nact * f->ncoef))) return rc;
   f->proj_dirty = true;
   return EXP_AMD_OK;
 }
