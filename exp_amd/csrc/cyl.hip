@@ -833,7 +833,10 @@ k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict
     const bool wipe = clear && nb + CYL_CNB >= C.nmax;
     for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
       const double w = Wn[k * C.ntrig + t];
-      if (wipe && w != 0.0) Wn[k * C.ntrig + t] = 0.0;
+      // a node without mass adds nothing (fma(T, 0, s) == s): its table column is not fetched -- the moments of a thinly
+      // populated multistep level are almost all zero, and its contraction then reads the 3 MB of moments, not the 45 MB table
+      if (w == 0.0) continue;
+      if (wipe) Wn[k * C.ntrig + t] = 0.0;
 #pragma unroll
       for (int j = 0; j < CYL_CNB; j++)
         if (nb + j < C.nmax) s[j] = fma(T0[(size_t)(nb + j) * nnode + k], w, s[j]);
@@ -850,6 +853,22 @@ k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict
   }
 }
 
+// the accumulation launches' {in-cut mass, count} slot pairs, summed by the first wave of a block in a fixed order
+// (two slots a lane, then a butterfly) and cleared; every lane of that wave returns the two sums.  A single thread
+// walking the 128 slots took 10 us -- as long as everything else the small sub-steps' contraction does.
+__device__ __forceinline__ void cyl_tail_fold(double *__restrict__ tailpart, double &t0, double &t1)
+{
+  static_assert(CYL_TAILS == 128, "two slot pairs a lane");
+  const int lane = threadIdx.x & 63;
+  double2 *tp = reinterpret_cast<double2 *>(tailpart);
+  const double2 a = tp[lane], b = tp[lane + 64];
+  tp[lane] = make_double2(0.0, 0.0);
+  tp[lane + 64] = make_double2(0.0, 0.0);
+  t0 = a.x + b.x;
+  t1 = a.y + b.y;
+  for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_xor(t0, off); t1 += __shfl_xor(t1, off); }
+}
+
 __global__ void __launch_bounds__(256)
 k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict__ out, size_t ostride,
                    double *__restrict__ last, double *__restrict__ add_to /* += the new set as well, or null */,
@@ -859,10 +878,10 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int L = blockIdx.y;                   // level of a multi-level launch
   // the accumulation's {in-cut mass, count} slots -> the tail of the FIRST set of the launch (out + ncoef), slots cleared
-  if (tailpart && blockIdx.x == 0 && L == 0 && threadIdx.x < 2) {
-    double t = 0.0;
-    for (int j = 0; j < CYL_TAILS; j++) { t += tailpart[2 * j + threadIdx.x]; tailpart[2 * j + threadIdx.x] = 0.0; }
-    out[ncoef + threadIdx.x] += t;
+  if (tailpart && blockIdx.x == 0 && L == 0 && threadIdx.x < 64) {
+    double t0, t1;
+    cyl_tail_fold(tailpart, t0, t1);
+    if (threadIdx.x < 2) out[ncoef + threadIdx.x] += threadIdx.x ? t1 : t0;
   }
   if (o >= ncoef) return;
   const bool none = o >= ncoef / 2 && o < ncoef / 2 + (size_t)C.nmax;      // (sin, m = 0): no such row
@@ -890,11 +909,13 @@ k_cyl_sum_combine(CylDev C, const double *__restrict__ part, double *__restrict_
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    double t = 0.0;
-    for (int j = 0; j < CYL_TAILS; j++) { t += tailpart[2 * j + threadIdx.x]; tailpart[2 * j + threadIdx.x] = 0.0; }
-    if (open) mass_acc[threadIdx.x] += t;
-    out[ncoef + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double t0, t1;
+    cyl_tail_fold(tailpart, t0, t1);
+    if (threadIdx.x < 2) {
+      if (open) mass_acc[threadIdx.x] += threadIdx.x ? t1 : t0;
+      out[ncoef + threadIdx.x] = 0.0;
+    }
   }
   if (o >= ncoef) return;
   const bool none = o >= ncoef / 2 && o < ncoef / 2 + (size_t)C.nmax;      // (sin, m = 0): no such row
@@ -935,17 +956,22 @@ k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict
   for (int kind = 0; kind < (m == 0 ? 3 : 6); kind++) {
     const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
     const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
-    // four independent chains: the nmax table loads of a row are all in flight together
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int n = 0;
-    for (; n + 3 < C.nmax; n += 4) {
-      const double t0 = T[(size_t)n * nnode], t1 = T[(size_t)(n + 1) * nnode];
-      const double t2 = T[(size_t)(n + 2) * nnode], t3 = T[(size_t)(n + 3) * nnode];
-      s0 = fma(t0, c[n], s0); s1 = fma(t1, c[n + 1], s1);
-      s2 = fma(t2, c[n + 2], s2); s3 = fma(t3, c[n + 3], s3);
+    // four chains (orders n = j mod 4 below the last multiple of four, the rest on chain 0); the table loads of twelve
+    // orders are issued before the first of them is used: the kernel is bound by the loads it keeps in flight
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nq = C.nmax & ~3;
+    for (int nb = 0; nb < C.nmax; nb += 12) {
+      double t[12];
+#pragma unroll
+      for (int j = 0; j < 12; j++) t[j] = nb + j < C.nmax ? T[(size_t)(nb + j) * nnode] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        const int n = nb + j;
+        if (n < nq) a[j & 3] = fma(t[j], c[n], a[j & 3]);
+        else if (n < C.nmax) a[0] = fma(t[j], c[n], a[0]);
+      }
     }
-    for (; n < C.nmax; n++) s0 = fma(T[(size_t)n * nnode], c[n], s0);
-    TF[node * NF + q0 + kind] = (s0 + s1) + (s2 + s3);
+    TF[node * NF + q0 + kind] = (a[0] + a[1]) + (a[2] + a[3]);
   }
 }
 

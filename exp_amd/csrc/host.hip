@@ -3,6 +3,7 @@
 // compute_potential, src/ComponentContainer.cc:1173-1226, :580-917) over a set of components,
 // their self-gravity force methods and the pairwise interactions, driving the device entirely
 // through the kernels of this library (no per-step host<->device particle traffic).
+#include <chrono>
 #include "force.h"
 #include "sort_kernels.h"
 
@@ -41,7 +42,17 @@ struct exp_amd_sim {
   std::vector<hipEvent_t> ev_self, ev_used;
   std::vector<char> used_pending;
   hipEvent_t ev_join = nullptr;
+  // EXP_AMD_HOST_TIMING=1: where the HOST spends a master step (seconds; printed by exp_amd_sim_destroy) -- issuing the
+  // launches of the three phases, waiting for the read-back, and the level-change phase behind it
+  bool host_timing = false;
+  double ht[5] = {0, 0, 0, 0, 0};
+  long long ht_steps = 0;
 };
+
+static inline double host_now()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // issue on component k's stream for the lifetime of the object
 struct StreamOf {
@@ -60,6 +71,7 @@ static int overlap_begin(exp_amd_sim *s)
   bool any_orient = false;
   for (auto o : s->orients) any_orient = any_orient || o;
   if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
+  if (const char *e = getenv("EXP_AMD_HOST_TIMING")) s->host_timing = atoi(e) != 0;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
@@ -126,6 +138,10 @@ extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
 extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
 {
   if (!s) return;
+  if (s->host_timing && s->ht_steps)
+    fprintf(stderr, "[exp_amd host timing] per master step over %lld: issue expansion %.3f ms, issue forces %.3f ms, issue kick/adjust "
+            "%.3f ms, wait for the read-back %.3f ms, level changes %.3f ms\n", s->ht_steps, 1e3 * s->ht[0] / s->ht_steps,
+            1e3 * s->ht[1] / s->ht_steps, 1e3 * s->ht[2] / s->ht_steps, 1e3 * s->ht[3] / s->ht_steps, 1e3 * s->ht[4] / s->ht_steps);
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
@@ -350,6 +366,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     s->pinned_cap = nc;
   }
   int rc;
+  const double th0 = s->host_timing ? host_now() : 0.0;
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
     const unsigned long long *res = nullptr;
@@ -358,8 +375,14 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, res, 32 * sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, ctx->stream));
   }
+  const double th1 = s->host_timing ? host_now() : 0.0;
   if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double th2 = s->host_timing ? host_now() : 0.0;
+  struct HtClose {
+    exp_amd_sim *s; double a, b, c;
+    ~HtClose() { if (s->host_timing) { s->ht[2] += b - a; s->ht[3] += c - b; s->ht[4] += host_now() - c; } }
+  } htc{s, th0, th1, th2};
   s->last_switch = 0;
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
@@ -451,9 +474,12 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         const int mdrft = mstep + 1;
+        const double th0 = s->host_timing ? host_now() : 0.0;
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
         s->tnow += dt;
+        const double th1 = s->host_timing ? host_now() : 0.0;
         if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep))) return rc;
+        if (s->host_timing) { s->ht[0] += th1 - th0; s->ht[1] += host_now() - th1; }
         if ((rc = kick_adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0, true))) return rc;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
@@ -471,6 +497,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
     }
     s->this_step++;
+    if (s->multistep) s->ht_steps++;
   }
   return overlap_end(s);
 }

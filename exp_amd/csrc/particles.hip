@@ -572,14 +572,15 @@ k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, s
 // k_adjust_levels above.  out[0] += level changes; out[1 + L] += particles proposed for level L
 // among those examined (the host derives the new level offsets from them without a second
 // read-back).  kick_lo > last: no kick (begin_run's first assignment).
-#define KA_ITEMS 8       // 256-slot tiles per block (the counters leave a block as one atomic per value)
+#define KA_ITEMS 8       // 256-slot tiles per block at most (the counters leave a block as one atomic per value); the
+                         // short ranges of the upper levels take one tile per block: a block's tiles run one after the other
 __global__ void __launch_bounds__(TPB)
 k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
               const double *__restrict__ ax, const double *__restrict__ ay,
               const double *__restrict__ az, const double *__restrict__ pot,
               const uint8_t *__restrict__ lev, uint8_t *__restrict__ newlev,
               const uint32_t *__restrict__ lev_off, int kick_lo, int first, int last, double dt_min,
-              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next)
+              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next, int items)
 {
   // two counter sets are used alternately: this launch leaves the other one clean for the next
   if (blockIdx.x == 0 && threadIdx.x < 32) out_next[threadIdx.x] = 0ull;
@@ -589,8 +590,8 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
   const int lo = kick_lo < first ? kick_lo : first;
   const size_t beg = lev_off[lo], end = lev_off[last + 1], ebeg = lev_off[first];
   const int lane = threadIdx.x & 63;
-  for (int it = 0; it < KA_ITEMS; it++) {
-    const size_t i = beg + ((size_t)blockIdx.x * KA_ITEMS + it) * TPB + threadIdx.x;
+  for (int it = 0; it < items; it++) {
+    const size_t i = beg + ((size_t)blockIdx.x * items + it) * TPB + threadIdx.x;
     if (i - threadIdx.x >= end) break;          // (block-uniform)
     const bool valid = i < end;
     unsigned plev = 0, nlev = 0;
@@ -772,9 +773,11 @@ int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[
   AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
                shiftlevl, mfirst_mdrft};
   ProfScope ps(ctx, "k_kick_adjust");
-  k_kick_adjust<<<cdiv(nr, (size_t)TPB * KA_ITEMS), TPB, 0, ctx->stream>>>(
+  const size_t tiles = cdiv(nr, (size_t)TPB);
+  const int items = tiles >= 4096 * KA_ITEMS ? KA_ITEMS : (int)(tiles / 4096 > 1 ? tiles / 4096 : 1);
+  k_kick_adjust<<<cdiv(tiles, (size_t)items), TPB, 0, ctx->stream>>>(
       A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt);
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items);
   HIP_TRY(ctx, hipGetLastError());
   c->nsw_flip ^= 1;
   return EXP_AMD_OK;

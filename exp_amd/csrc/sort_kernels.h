@@ -104,6 +104,16 @@ __device__ __forceinline__ void wave_hist_add(uint32_t key, bool valid, uint32_t
     const int lead = __ffsll((long long)rem) - 1;
     const uint32_t kk = (uint32_t)__shfl((int)key, lead);
     const unsigned long long mm = __ballot(valid && key == kk);
+    // A thinly populated multistep level has a different key in almost every lane: a group that is a small part of
+    // what is left means ~64 rounds of this loop -- the lanes left then add for themselves, few of them to one word.
+    if (__popcll(mm) * 8 < __popcll(rem)) {
+      if ((rem >> lane) & 1ull) {
+        const uint32_t d = key - kmin;
+        if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
+        else atomicAdd(&hist[key], 1u);
+      }
+      return;
+    }
     if (lane == lead) {
       const uint32_t d = kk - kmin, cnt = (uint32_t)__popcll(mm);
       if (d < SORT_WIN) atomicAdd(&lh[d], cnt);
@@ -126,6 +136,13 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t key, bool valid, uint32_t
     const int lead = __ffsll((long long)rem) - 1;
     const uint32_t kk = (uint32_t)__shfl((int)key, lead);
     const unsigned long long mm = __ballot(valid && key == kk);
+    if (__popcll(mm) * 8 < __popcll(rem)) {           // (see wave_hist_add: every lane left takes its own rank)
+      if ((rem >> lane) & 1ull) {
+        const uint32_t dl = key - kmin;
+        if (dl < SORT_WIN) rk = atomicAdd(&lh[dl], 1u);
+      }
+      return rk;
+    }
     const uint32_t d = kk - kmin;
     uint32_t base = 0;
     if (d < SORT_WIN) {

@@ -46,11 +46,23 @@ k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wsca
     const int n = n0 + nn;
     double s = 0.0;
     if (n < S.nmax)
-      for (int i = i0 + slot; i < i1; i += 8) {
-        const double w1 = W[((size_t)i * S.nrows + row) * 2];
-        const double w2 = W[((size_t)i * S.nrows + row) * 2 + 1];
-        s = fma(S.E[(size_t)i * stride + l * S.nmax + n], w1, s);
-        s = fma(S.E[(size_t)(i + 1) * stride + l * S.nmax + n], w2, s);
+      // (eight cells' loads are issued before the first is used: the kernel is a chain of load latencies otherwise)
+      for (int ib = i0 + slot; ib < i1; ib += 64) {
+        double w1[8], w2[8], e1[8], e2[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = ib + 8 * j;
+          const bool in = i < i1;
+          w1[j] = in ? W[((size_t)i * S.nrows + row) * 2] : 0.0;
+          w2[j] = in ? W[((size_t)i * S.nrows + row) * 2 + 1] : 0.0;
+          e1[j] = in ? S.E[(size_t)i * stride + l * S.nmax + n] : 0.0;
+          e2[j] = in ? S.E[(size_t)(i + 1) * stride + l * S.nmax + n] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          s = fma(e1[j], w1[j], s);
+          s = fma(e2[j], w2[j], s);
+        }
       }
     red[slot][nn] = s;
     __syncthreads();
