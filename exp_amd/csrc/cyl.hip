@@ -15,6 +15,7 @@
 //
 // Particles are kept sorted by (X,Y) cell, so a wave shares its four corner rows (scalar loads) and
 // its 4(2 mmax+1) moment sums stay in registers until the cell changes.
+#include <cstring>
 #include "sort_kernels.h"
 #include "force.h"
 
@@ -811,12 +812,15 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
 #define CYL_CSEG 48          // node segments of stage 1 (24: 312 blocks, too few to pull the 45 MB table at HBM rate: 50 -> 36 us)
 #endif
 #define CYL_CNB 12                 // n per register block
+static_assert(CYL_CSEG % 8 == 0, "the block -> XCD mapping of k_cyl_contract_part");
 __global__ void __launch_bounds__(256)
 k_cyl_contract_part(CylDev C, const double *__restrict__ tab, double *__restrict__ Wn,
                     double *__restrict__ part /* [level][CYL_CSEG][ncoef] */,
                     int clear /* leave the moments zero behind (each is read by exactly one block) */)
 {
-  const int t = blockIdx.x, seg = blockIdx.y, L = blockIdx.z;
+  // (segment fastest: the ntrig blocks that read the same lines of Wn -- stride ntrig -- get block ids that differ by a
+  // multiple of CYL_CSEG, a multiple of 8, i.e. they share an XCD and its L2)
+  const int seg = blockIdx.x, t = blockIdx.y, L = blockIdx.z;
   const int m = (t + 1) >> 1, cs = t ? ((t + 1) & 1) : 0;
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
@@ -936,15 +940,19 @@ static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, dou
                          double *add_to = nullptr, double *tailpart = nullptr)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
-  k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
+  k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
   k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to, tailpart);
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
 // TF[node][3*ntrig]: for m = 0: {Pc, Rc, Zc}; for m >= 1 at 3 + 6(m-1): {Pc, Rc, Zc, Ps, Rs, Zs}
+// twin != 0: the sine tables are bit for bit the cosine tables (the usual case: an EOF basis conditioned on an
+// axisymmetric density has SC == SS, exputil/EmpCylSL.cc:2556-2760; CylForce checks it when the tables arrive).  The
+// cosine and sine rows of a harmonic are then formed from ONE fetch of each table value -- same products, same sums,
+// half the 133 MB (256 x 128, mmax 6, nmax 12) that bound this kernel.
 __global__ void __launch_bounds__(256)
 k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict__ coef,
-              double *__restrict__ TF)
+              double *__restrict__ TF, int twin)
 {
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
   const size_t node = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -953,6 +961,28 @@ k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict
   const int NF = 3 * C.ntrig;
   const int q0 = (m == 0) ? 0 : 3 + 6 * (m - 1);
   const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  if (twin && m > 0) {
+    const int nq = C.nmax & ~3;
+    for (int kind = 0; kind < 3; kind++) {
+      const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
+      const double *cc = coef + (size_t)m * C.nmax, *cs = cc + half;
+      double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int nb = 0; nb < C.nmax; nb += 12) {
+        double t[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) t[j] = nb + j < C.nmax ? T[(size_t)(nb + j) * nnode] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+          const int n = nb + j;
+          if (n < nq) { a[j & 3] = fma(t[j], cc[n], a[j & 3]); b[j & 3] = fma(t[j], cs[n], b[j & 3]); }
+          else if (n < C.nmax) { a[0] = fma(t[j], cc[n], a[0]); b[0] = fma(t[j], cs[n], b[0]); }
+        }
+      }
+      TF[node * NF + q0 + kind] = (a[0] + a[1]) + (a[2] + a[3]);
+      TF[node * NF + q0 + kind + 3] = (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    return;
+  }
   for (int kind = 0; kind < (m == 0 ? 3 : 6); kind++) {
     const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
     const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
@@ -1149,6 +1179,7 @@ struct CylForce : exp_amd_force {
   exp_amd_cyl_config cfg{};
   CylDev dev{};
   DevBuf<double> d_tab, d_Wn, d_TF;
+  bool tab_twin = false;            // the three sine tables equal the three cosine tables bit for bit (m >= 1)
   DevBuf<double> d_cpart;           // stage-1 sums of the contraction: [level][CYL_CSEG][ncoef]
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
   DevBuf<double> d_dens;            // densC / densS tables (field evaluation only)
@@ -1261,6 +1292,14 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_create: hipMalloc failed: %s", hipGetErrorString(e));
   }
   HIP_TRY(ctx, hipMemcpy(f->d_tab.p, tab, ntab * sizeof(double), hipMemcpyHostToDevice));
+  {
+    // tab[kind][m][n][node], kinds 0-2 cosine {potential, radial, vertical force}, 3-5 sine: compare the m >= 1 parts
+    const size_t per_kind = (size_t)(M + 1) * N * f->nnode, skip = (size_t)N * f->nnode;
+    f->tab_twin = M >= 1;
+    if (const char *ev = getenv("EXP_AMD_CYL_TWIN")) if (atoi(ev) == 0) f->tab_twin = false;
+    for (int k = 0; k < 3 && f->tab_twin; k++)
+      f->tab_twin = memcmp(tab + k * per_kind + skip, tab + (k + 3) * per_kind + skip, (per_kind - skip) * sizeof(double)) == 0;
+  }
   HIP_TRY(ctx, hipMemset(f->d_mass.p, 0, 2 * sizeof(double)));
   HIP_TRY(ctx, hipMemset(f->d_tailpart.p, 0, 2 * CYL_TAILS * sizeof(double)));
   CylDev &C = f->dev;
@@ -1610,7 +1649,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       int mfc = 0;
       CombineW Wc;
       expamd_combine_weights(ms, mdrft_combine, &mfc, &Wc);
-      k_cyl_contract_part<<<dim3(C.ntrig, CYL_CSEG, nact), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl,
+      k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nact), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl,
                                                                                  f->d_cpart.p, /*clear=*/1);
       k_cyl_sum_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
           C, f->d_cpart.p, f->d_coefN.p, f->d_coefL.p, f->ncoef_dev, lo, nact, ms + 1, mfc, Wc, f->d_coef.p,
@@ -1646,7 +1685,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   if (f->proj_dirty) {
     ProfScope ps(ctx, "k_cyl_project");
     k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(
-        f->dev, f->d_tab.p, f->d_coef.p, f->d_TF.p);
+        f->dev, f->d_tab.p, f->d_coef.p, f->d_TF.p, f->tab_twin ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     f->proj_dirty = false;
   }

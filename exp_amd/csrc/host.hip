@@ -46,6 +46,7 @@ struct exp_amd_sim {
   // launches of the three phases, waiting for the read-back, and the level-change phase behind it
   bool host_timing = false;
   double ht[5] = {0, 0, 0, 0, 0};
+  double ht_lo[17] = {0};           // wall time of the sub-steps by their lowest active level
   long long ht_steps = 0;
 };
 
@@ -71,7 +72,8 @@ static int overlap_begin(exp_amd_sim *s)
   bool any_orient = false;
   for (auto o : s->orients) any_orient = any_orient || o;
   if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
-  if (const char *e = getenv("EXP_AMD_HOST_TIMING")) s->host_timing = atoi(e) != 0;
+  // (EXP_AMD_HOST_TIMING=k: from master step k-1 on -- k = 9 skips the eight in which the level populations settle)
+  if (const char *e = getenv("EXP_AMD_HOST_TIMING")) s->host_timing = atoi(e) != 0 && s->this_step >= atoi(e) - 1;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
@@ -142,6 +144,10 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
     fprintf(stderr, "[exp_amd host timing] per master step over %lld: issue expansion %.3f ms, issue forces %.3f ms, issue kick/adjust "
             "%.3f ms, wait for the read-back %.3f ms, level changes %.3f ms\n", s->ht_steps, 1e3 * s->ht[0] / s->ht_steps,
             1e3 * s->ht[1] / s->ht_steps, 1e3 * s->ht[2] / s->ht_steps, 1e3 * s->ht[3] / s->ht_steps, 1e3 * s->ht[4] / s->ht_steps);
+  if (s->host_timing && s->ht_steps)
+    for (int L = 0; L <= s->multistep; L++)
+      fprintf(stderr, "[exp_amd host timing]   sub-steps with lowest active level %d: %.3f ms per master step (%d of them)\n", L,
+              1e3 * s->ht_lo[L] / s->ht_steps, L == 0 ? 1 : 1 << (L - 1));
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
@@ -480,7 +486,9 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         const double th1 = s->host_timing ? host_now() : 0.0;
         if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep))) return rc;
         if (s->host_timing) { s->ht[0] += th1 - th0; s->ht[1] += host_now() - th1; }
+        const int lo_now = s->mfirst[mstep];
         if ((rc = kick_adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0, true))) return rc;
+        if (s->host_timing) s->ht_lo[lo_now] += host_now() - th0;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
       s->tnow += s->dtime;
@@ -497,7 +505,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
     }
     s->this_step++;
-    if (s->multistep) s->ht_steps++;
+    if (s->multistep && s->host_timing) s->ht_steps++;
   }
   return overlap_end(s);
 }

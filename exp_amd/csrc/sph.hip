@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256)
 k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wscale,
                double *__restrict__ part, int clear = 0)
 {
-  const int row = blockIdx.x, seg = blockIdx.y;
+  // (segment fastest: the nrows blocks that read the same lines of W share an XCD -- CSEG is a multiple of 8)
+  const int seg = blockIdx.x, row = blockIdx.y;
   int l = 0;
   while ((l + 1) * (l + 1) <= row) l++;
   const int ncell = S.numr - 1;
@@ -461,7 +462,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG), 256, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
+    k_sph_contract<<<dim3(CSEG, S.nrows), 256, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
                                                                 f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(f->d_part.p, (int)f->ncoef,
                                                                   d_out);
@@ -583,7 +584,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG, nact), 256, 0, ctx->stream>>>(
+    k_sph_contract<<<dim3(CSEG, S.nrows, nact), 256, 0, ctx->stream>>>(
         S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
     // ... with the N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
     if (mdrft_combine >= 0) {
@@ -791,7 +792,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(S.nrows, CSEG), 256, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
+    k_sph_contract<<<dim3(CSEG, S.nrows), 256, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, V>>>(f->d_part.p, (int)f->ncoef, f->d_coef.p);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -908,7 +909,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     k_upd_launch[cfg.lmax](a);
   }
   // moments -> coefficient differences, all levels in one launch
-  k_sph_contract<<<dim3(S.nrows, CSEG, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
+  k_sph_contract<<<dim3(CSEG, S.nrows, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
                                                                   f->d_wscale.p, f->d_part.p, /*clear=*/1);
   // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M] -- in the summing kernel
   // itself when this rank is alone

@@ -32,7 +32,8 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   for (int j = 0; j < LC.nlev; j++) {
     const size_t n = a.counts ? a.counts[j] : a.n;
     size_t chunk = (n / ((size_t)CPB * ACC_BLOCKS_TARGET)) & ~(size_t)63;
-    const size_t cmin = ACC_CHUNK_MIN;
+    static const size_t cmin_env = [] { const char *e = getenv("EXP_AMD_ACC_CHUNK_MIN"); return e ? (size_t)atoi(e) & ~(size_t)63 : (size_t)0; }();
+    const size_t cmin = cmin_env ? cmin_env : ACC_CHUNK_MIN;
     chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
     LC.bstart[j] = nb;
     LC.chunk[j] = (int)chunk;
