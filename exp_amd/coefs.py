@@ -152,6 +152,73 @@ class Coefs:
         self.verbose = bool(verbose)
         self.coefs: Dict[float, object] = {}
         self.deltaT = 0.01                       # expui/Coefficients.H:133
+        self.units: List[Tuple[str, str, float]] = [("G", "none", 1.0)]      # expui/Coefficients.H:121
+
+    # -- unit metadata (expui/Coefficients.cc:74-149; the "Units" dataset of the HDF5 files) -------
+    def setUnits(self, name, unit: Optional[str] = None, value: Optional[float] = None) -> None:
+        """``setUnits(name, unit, value)`` or ``setUnits([(name, unit, value), ...])``: type and unit go through the
+        validator and are stored under their canonical spellings; a type that is already there is updated."""
+        from .units import UnitValidator
+        if unit is None and value is None and not isinstance(name, str):
+            for n, u, v in name:
+                self.setUnits(n, u, v)
+            return
+        ok, cname, cunit = UnitValidator()(str(name), str(unit))
+        if not ok:
+            raise RuntimeError(f"Coefs::setUnits: Warning, type '{name}' with unit '{unit}' is incompatible or not recognized.")
+        val = float(np.float32(value))                     # (Unit::value is a float)
+        for k, (n, _, _) in enumerate(self.units):
+            if n == cname:
+                self.units[k] = (cname, cunit[:15], val)
+                return
+        self.units.append((cname[:15], cunit[:15], val))
+
+    def removeUnits(self, name: str) -> None:
+        self.units = [u for u in self.units if u[0] != name]
+
+    def getUnits(self) -> List[Tuple[str, str, float]]:
+        return list(self.units)
+
+    def getGravConstant(self) -> float:
+        for n, _, v in self.units:
+            if n == "G":
+                return v
+        return 1.0
+
+    def getAllowedUnitTypes(self) -> List[str]:
+        from .units import UnitValidator
+        return UnitValidator.getAllowedTypes()
+
+    def getAllowedTypeAliases(self, type: str) -> List[str]:
+        from .units import UnitValidator
+        return UnitValidator.getAllowedTypeAliases(type)
+
+    def getAllowedUnitNames(self, type: str) -> List[str]:
+        from .units import UnitValidator
+        return UnitValidator.getAllowedUnits(type)
+
+    def _units_for_h5(self):
+        """``Coefs::WriteH5Units`` (expui/Coefficients.cc:152-169): spherical and cylindrical sets must carry four
+        units -- (length, mass, time, G) or (length, mass, velocity, G) -- or the write is refused; the records are
+        {char name[16], char unit[16], float value}."""
+        if len(self.units) != 4:
+            raise RuntimeError("---- Coefs::WriteH5Units: Warning, expected 4 units: (length, mass, time, G) or (length, mass, "
+                               f"velocity, G), etc. I found {len(self.units)} units instead.  Please  provide a consistent unit set.")
+        rec = np.zeros(len(self.units), dtype=[("name", "S16"), ("unit", "S16"), ("value", "<f4")])
+        for k, (n, u, v) in enumerate(self.units):
+            rec[k] = (n.encode()[:15], u.encode()[:15], v)
+        return rec
+
+    def _read_units_h5(self, path: str) -> None:
+        """``Coefs::ReadH5Units`` (expui/Coefficients.cc:171-182): taken over when the file has the dataset."""
+        import ctypes
+        from . import h5cache
+        lib = h5cache._load()
+        lib.exp_h5_coef_read_units.restype = ctypes.c_int
+        rec = np.zeros(16, dtype=[("name", "S16"), ("unit", "S16"), ("value", "<f4")])
+        n = ctypes.c_int(0)
+        if lib.exp_h5_coef_read_units(path.encode(), 16, rec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)) == 0 and n.value >= 0:
+            self.units = [(r["name"].decode(), r["unit"].decode(), float(r["value"])) for r in rec[:n.value]]
 
     def setDeltaT(self, dT: float) -> None:
         self.deltaT = float(dT)
@@ -180,6 +247,7 @@ class Coefs:
         import copy
         ret = type(self)(self.name)
         ret.deltaT = self.deltaT
+        ret.units = list(self.units)
         for t, c in self.coefs.items():
             ret.coefs[t] = copy.deepcopy(c)
         return ret
@@ -443,7 +511,9 @@ class SphCoefs(Coefs):
             rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
         tarr = np.array([self.coefs[t].time for t in times])
         self._force_id = force_id
+        urec = self._units_for_h5()
         lib = h5cache._load()
+        lib.exp_h5_coef_set_units(len(urec), urec.ctypes.data_as(ctypes.c_void_p))
         lib.exp_h5_sphcoef_write.restype = ctypes.c_int
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         rc = lib.exp_h5_sphcoef_write(path.encode(), self.name.encode(), config.encode(),
@@ -479,6 +549,7 @@ class SphCoefs(Coefs):
         if lib.exp_h5_sphcoef_read(path.encode(), C, L, N, vp(times), vp(ctr), vp(rot), vp(data)):
             raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
         self = cls(name.value.decode())
+        self._read_units_h5(path)
         self._force_id = fid.value.decode()
         for k in range(0, C, stride):
             if times[k] < tmin or times[k] > tmax:
@@ -651,7 +722,9 @@ class CylCoefs(Coefs):
             rot[k] = np.asarray(c.rot, dtype=np.float64).reshape(3, 3) if np.size(c.rot) == 9 else np.eye(3)
         tarr = np.array([self.coefs[t].time for t in times])
         self._force_id = force_id
+        urec = self._units_for_h5()
         lib = h5cache._load()
+        lib.exp_h5_coef_set_units(len(urec), urec.ctypes.data_as(ctypes.c_void_p))
         lib.exp_h5_cylcoef_write.restype = ctypes.c_int
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         if lib.exp_h5_cylcoef_write(path.encode(), self.name.encode(), config.encode(),
@@ -687,6 +760,7 @@ class CylCoefs(Coefs):
         if lib.exp_h5_cylcoef_read(path.encode(), C, M, N, vp(times), vp(ctr), vp(rot), vp(data)):
             raise RuntimeError(f"readH5Coefs: <{path}>: snapshots missing or of the wrong shape")
         self = cls(name.value.decode())
+        self._read_units_h5(path)
         self._force_id = fid.value.decode()
         for k in range(0, C, stride):
             if times[k] < tmin or times[k] > tmax:

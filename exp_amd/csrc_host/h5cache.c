@@ -16,6 +16,7 @@
  * here the header is returned to the caller.  Built only where hdf5.h is available
  * (exp_amd/libexp_amd_h5.so); no HighFive, no C++.
  */
+#include <stddef.h>
 #include <hdf5.h>
 #include <unistd.h>
 #include <math.h>
@@ -421,6 +422,74 @@ static int put_dbl_array_attr(hid_t loc, const char *name, int rank, const hsize
 /* Coefs::WriteH5Coefs (expui/Coefficients.cc:3100-3163) with the per-geometry WriteH5Params /
  * WriteH5Times: sphere (:841-853, :907-944: lmax, nmax, scale; (l, m>=0) rows) and cylinder
  * (:1323-1332, :1375-1405: mmax, nmax; m rows).  `ldim` is the number of complex rows.            */
+/* Coefs::WriteH5Units / ReadH5Units (expui/Coefficients.cc:20-30, :152-182): dataset "Units", one compound record
+ * {char name[16]; char unit[16]; float value;} per unit (HighFive: AtomicType<char[16]> = a 16-byte UTF-8 string).
+ * The records for the next coefficient file are handed over with exp_h5_coef_set_units. */
+typedef struct { char name[16]; char unit[16]; float value; } exp_h5_unit;
+static exp_h5_unit g_units[16];
+static int g_nunits = 0;
+
+int exp_h5_coef_set_units(int n, const void *records /* n x 36 bytes */)
+{
+  if (n < 0 || n > 16) return -1;
+  memcpy(g_units, records, (size_t)n * sizeof(exp_h5_unit));
+  g_nunits = n;
+  return 0;
+}
+
+static hid_t unit_type(void)
+{
+  hid_t st = H5Tcopy(H5T_C_S1);
+  H5Tset_size(st, 16);
+  H5Tset_cset(st, H5T_CSET_UTF8);
+  hid_t ct = H5Tcreate(H5T_COMPOUND, sizeof(exp_h5_unit));
+  H5Tinsert(ct, "name", offsetof(exp_h5_unit, name), st);
+  H5Tinsert(ct, "unit", offsetof(exp_h5_unit, unit), st);
+  H5Tinsert(ct, "value", offsetof(exp_h5_unit, value), H5T_NATIVE_FLOAT);
+  H5Tclose(st);
+  return ct;
+}
+
+static int put_units(hid_t f)
+{
+  hsize_t dims[1] = {(hsize_t)g_nunits};
+  hid_t ct = unit_type(), sp = H5Screate_simple(1, dims, NULL);
+  hid_t d = H5Dcreate2(f, "Units", ct, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  int rc = 0;
+  if (d < 0 || (g_nunits && H5Dwrite(d, ct, H5S_ALL, H5S_ALL, H5P_DEFAULT, g_units) < 0)) rc = -1;
+  if (d >= 0) H5Dclose(d);
+  H5Sclose(sp);
+  H5Tclose(ct);
+  return rc;
+}
+
+/* *n = -1 when the file has no "Units" dataset (older files: the reader keeps its default) */
+int exp_h5_coef_read_units(const char *path, int cap, void *records, int *n)
+{
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+  *n = -1;
+  hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (f < 0) return -1;
+  int rc = 0;
+  if (H5Lexists(f, "Units", H5P_DEFAULT) > 0) {
+    hid_t d = H5Dopen2(f, "Units", H5P_DEFAULT);
+    hid_t sp = d >= 0 ? H5Dget_space(d) : -1;
+    hsize_t dims[1] = {0};
+    if (sp >= 0 && H5Sget_simple_extent_ndims(sp) == 1) H5Sget_simple_extent_dims(sp, dims, NULL);
+    if (d < 0 || (int)dims[0] > cap) rc = -1;
+    else {
+      hid_t ct = unit_type();
+      if (dims[0] && H5Dread(d, ct, H5S_ALL, H5S_ALL, H5P_DEFAULT, records) < 0) rc = -1;
+      else *n = (int)dims[0];
+      H5Tclose(ct);
+    }
+    if (sp >= 0) H5Sclose(sp);
+    if (d >= 0) H5Dclose(d);
+  }
+  H5Fclose(f);
+  return rc;
+}
+
 static int coef_write(const char *path, const char *geometry, const char *name, const char *config,
                       const char *forceID, const char *key1, int val1, int nmax, int has_scale,
                       double scale, int ldim, int ntimes, const double *times, const double *centers,
@@ -441,6 +510,7 @@ static int coef_write(const char *path, const char *geometry, const char *name, 
     rc |= put_str(f, "geometry", geometry);
     rc |= put_str(f, "name", name);
     rc |= put_str(f, "config", config);
+    rc |= put_units(f);
     rc |= put_int(f, key1, val1);
     rc |= put_int(f, "nmax", nmax);
     if (has_scale) rc |= put_dbl(f, "scale", scale);

@@ -392,6 +392,7 @@ def test_nbody_playback_reproduces_the_live_run(halo_basis, tmp_path):
     live, rec, live_sets = run(None)
     native, h5 = str(tmp_path / "outcoef.halo"), str(tmp_path / "outcoef.halo.h5")
     rec.writeNativeCoefs(native)
+    rec.setUnits([("length", "kpc", 1.0), ("mass", "Msun", 1.0e10), ("time", "Gyr", 1.0), ("G", "mixed", 43007.1)])        # (four units or the write is refused, expui/Coefficients.cc:152-160)
     rec.WriteH5Coefs(h5)
     for src in (rec, native, h5):
         got, _, _ = run((src, False))
@@ -527,6 +528,7 @@ def test_reference_script_sequences_through_the_pyexp_namespace(tmp_path, monkey
     with pytest.raises(RuntimeError, match="requested time"):
         back.setMatrix(9.0, data[:, :, 0])
     # the HDF5 pair and the per-harmonic power
+    back.setUnits([("length", "kpc", 1.0), ("mass", "Msun", 1.0e10), ("time", "Gyr", 1.0), ("G", "mixed", 43007.1)])
     back.WriteH5Coefs("halo.h5")
     more = pyEXP.coefs.SphCoefs()
     more.add(basis.createFromArray(mass, xyz, time=3.4))

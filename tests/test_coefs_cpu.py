@@ -175,6 +175,7 @@ def test_coefs_container_surface(tmp_path):
     for obj, tag in ((sph, "s"), (cyl, "c")):
         obj.setName("comp" + tag)
         h5, nat = str(tmp_path / (tag + ".h5")), str(tmp_path / (tag + ".native"))
+        obj.setUnits([("length", "kpc", 1.0), ("mass", "Msun", 1.0e10), ("time", "Gyr", 1.0), ("G", "mixed", 43007.1)])
         obj.WriteH5Coefs(h5)
         obj.writeNativeCoefs(nat)
         for path in (h5, nat):

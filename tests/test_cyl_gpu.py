@@ -402,6 +402,7 @@ def test_cyl_nbody_playback(ctx, tmp_path):
     assert rec.Times() == [round_time((k + 1) * dt) for k in range(nstep)]
     native, h5 = str(tmp_path / "outcoef.disk"), str(tmp_path / "outcoef.disk.h5")
     rec.writeNativeCoefs(native)
+    rec.setUnits([("length", "kpc", 1.0), ("mass", "Msun", 1.0e10), ("time", "Gyr", 1.0), ("G", "mixed", 43007.1)])
     rec.WriteH5Coefs(h5)
     for src in (rec, native, h5):
         got, _ = run(src)

@@ -99,9 +99,22 @@ def test_sph_coefficient_file_roundtrip(h5, tmp_path):
         cf = rng.standard_normal((10, 5)) + 1j * rng.standard_normal((10, 5))
         cs.add(SphStruct(3, 5, 0.7, t, cf, np.array([0.1 * k, 0.0, -0.2]), np.eye(3) * (1 + k)))
     path = str(tmp_path / "outcoef.halo.run0.h5")
+    with pytest.raises(RuntimeError, match="expected 4 units"):          # Coefs::WriteH5Units (expui/Coefficients.cc:152-160)
+        cs.WriteH5Coefs(path, config="id: sphereSL")
+    with pytest.raises(RuntimeError, match="incompatible or not recognized"):
+        cs.setUnits("length", "furlong", 1.0)
+    cs.setUnits("Len", "kiloparsec", 1.0)                   # aliases are stored under the canonical spellings
+    cs.setUnits([("M", "solar_mass", 1.0e10), ("t", "Gyr", 1.0)])
+    cs.setUnits("G", "mixed", 43007.1)                      # (an update of the default entry, not a fifth unit)
+    assert cs.getUnits() == [("G", "mixed", float(np.float32(43007.1))), ("length", "kpc", 1.0), ("mass", "Msun", 1.0e10),
+                             ("time", "Gyr", 1.0)]
+    assert cs.getGravConstant() == float(np.float32(43007.1))
+    assert "kpc" in cs.getAllowedUnitNames("length") and cs.getAllowedTypeAliases("mass") == ["M", "Mass", "m", "mass"]
+    assert cs.getAllowedUnitTypes() == ["mass", "length", "time", "velocity", "G"]
     cs.WriteH5Coefs(path, config="id: sphereSL")
     back = SphCoefs.readH5Coefs(path)
     assert back.name == "dark halo" and back.Times() == cs.Times()
+    assert back.getUnits() == cs.getUnits()                 # Coefs::ReadH5Units
     for t in cs.Times():
         a, b = cs.getCoefStruct(t), back.getCoefStruct(t)
         assert np.array_equal(a.coefs, b.coefs) and np.array_equal(a.ctr, b.ctr) and np.array_equal(a.rot, b.rot)
@@ -129,9 +142,13 @@ def test_cyl_coefficient_file_roundtrip(h5, tmp_path):
         cf[0] = cf[0].real
         cs.add(CylStruct(4, 7, t, cf, np.array([0.0, 0.1 * k, 0.0]), np.eye(3)))
     path = str(tmp_path / "outcoef.disk.run0.h5")
+    cs.setUnits([("length", "kpc", 1.0), ("mass", "Msun", 1.0e10), ("time", "Gyr", 1.0), ("G", "mixed", 43007.1)])
+    cs.removeUnits("time")
+    cs.setUnits("velocity", "km/s", 1.0)                    # (length, mass, velocity, G) is the other accepted set
     cs.WriteH5Coefs(path, config="id: cylinder")
     back = CylCoefs.readH5Coefs(path)
     assert back.name == "star disk" and back.Times() == cs.Times()
+    assert back.getUnits() == cs.getUnits() and [u[0] for u in back.getUnits()] == ["G", "length", "mass", "velocity"]
     for t in cs.Times():
         a, b = cs.getCoefStruct(t), back.getCoefStruct(t)
         assert np.array_equal(a.coefs, b.coefs) and np.array_equal(a.ctr, b.ctr) and np.array_equal(a.rot, b.rot)
