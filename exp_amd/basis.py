@@ -310,6 +310,16 @@ class BiorthBasis:
     def getFieldLabels(self, ctype: Optional[str] = None):
         return self.FIELD_LABELS + self.FORCE_LABELS[(ctype or self.coordinates).lower()]
 
+    # midplane evaluation (expui/BasisFactory.H:127-131, :283-288): only a disk basis acts on it
+    midplane = False
+    colh = 4.0
+
+    def setMidplane(self, value: bool) -> None:
+        self.midplane = bool(value)
+
+    def setColumnHeight(self, value: float) -> None:
+        self.colh = float(value)
+
     def __call__(self, x1, x2, x3, ctype: str = "spherical"):
         """Fields in the requested coordinates: (r, cos theta, phi) | (R, z, phi) | (x, y, z)
         -> the 9 values of getFieldLabels(ctype); arrays give [N, 9]."""
@@ -780,6 +790,46 @@ class Cylindrical(BiorthBasis):
         self.sin = np.zeros((self.mmax + 1, self.nmax))
         self.cylmass = 0.0
         self.used = 0
+
+    def getFieldLabels(self, ctype: Optional[str] = None):
+        """... with "midplane" behind the cylindrical forces while midplane evaluation is on
+        (expui/BiorthBasis.cc:79-84; the reference adds the label for every basis but only ``Cylindrical::cyl_eval``
+        returns the value)."""
+        labels = super().getFieldLabels(ctype)
+        if self.midplane and (ctype or self.coordinates).lower() == "cylindrical":
+            labels = labels + ["midplane"]
+        return labels
+
+    def __call__(self, x1, x2, x3, ctype: str = "spherical"):
+        """``Cylindrical::cyl_eval`` (expui/BiorthBasis.cc:1823-1849): with midplane evaluation on, a tenth value --
+        the height of the density peak in the column |z| <= colh * hcyl above (R, phi):
+        ``EmpCylSL::accumulated_midplane_eval`` (exputil/EmpCylSL.cc:5506-5554; 40 samples, the peak sample refined by
+        the parabola through its neighbours, the peak DENSITY when it sits at an end of the column).  The 40 columns
+        of all points are one launch of the fields kernel."""
+        out = super().__call__(x1, x2, x3, ctype)
+        if not (self.midplane and ctype.lower() == "cylindrical"):
+            return out
+        single = np.ndim(x1) == 0
+        R, phi = np.atleast_1d(np.asarray(x1, np.float64)), np.atleast_1d(np.asarray(x3, np.float64))
+        num = 40
+        zmin, zmax = -self.colh * self.hcyl, self.colh * self.hcyl
+        dz = (zmax - zmin) / (num - 1)
+        zk = zmin + dz * np.arange(num)
+        dens = self.force.fields(np.repeat(R, num), np.tile(zk, R.size), np.repeat(phi, num), "cylindrical")[:, 2]
+        dens = dens.reshape(R.size, num)
+        kp = np.argmax(dens, axis=1)                      # (first maximum: the reference's scan keeps it on ties)
+        rows = np.arange(R.size)
+        pval = dens[rows, kp]
+        inner = (kp > 0) & (kp < num - 1)
+        km, kq = np.clip(kp - 1, 0, num - 1), np.clip(kp + 1, 0, num - 1)
+        f0, f1, f2 = dens[rows, km], dens[rows, kp], dens[rows, kq]
+        z0 = zmin + dz * kp
+        denom = f0 - 2.0 * f1 + f2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            quad = ((2 * z0 + dz) * f0 * 0.5 - 2 * z0 * f1 + (2 * z0 - dz) * f2 * 0.5) / denom
+        height = np.where(inner, np.where(np.abs(denom) < 1.0e-16, z0, quad), pval)
+        full = np.concatenate([np.atleast_2d(out), height[:, None]], axis=1)
+        return full[0] if single else full
 
     def _cache_path(self) -> str:
         return self.cachename if self.cachename.endswith(".npz") else self.cachename + ".npz"

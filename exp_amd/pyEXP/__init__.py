@@ -1,14 +1,15 @@
-"""``import exp_amd.pyEXP as pyEXP``: the two pyEXP sub-modules this path covers, under their names.
+"""``import exp_amd.pyEXP as pyEXP``: the pyEXP sub-modules this path covers, under their names.
 
     pyEXP.basis.Basis.factory(yaml) / SphericalSL / Cylindrical / CovarianceReader
     pyEXP.coefs.Coefs.factory(file) / SphCoefs / CylCoefs / SphStruct / CylStruct
+    pyEXP.field.FieldGenerator(times, lower, upper, gridsize) / (times, mesh)
 
 so that a script written against the reference's Python module (tests/Halo/createCoefs.py,
 tests/Halo/changeCoefs.py, tests/Disk/cyl_basis.py) runs with the import line changed.  Everything else
-of pyEXP (field generators, mSSA, particle readers, utilities) is outside this repository's scope and
+of pyEXP (mSSA, particle readers and the particle histograms of the field generator, utilities) is outside this repository's scope and
 raises on access."""
-from . import basis, coefs
+from . import basis, coefs, field
 
 
 def __getattr__(name):
-    raise AttributeError(f"exp_amd.pyEXP has no sub-module <{name}>: only basis and coefs are in scope")
+    raise AttributeError(f"exp_amd.pyEXP has no sub-module <{name}>: only basis, coefs and field are in scope")
