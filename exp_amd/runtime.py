@@ -575,6 +575,27 @@ class SphereSL(_Force):
                       real_rows_to_complex(self.get_coefs(), self.lmax), np.zeros(3), np.eye(3))
         write_native(out, c)
 
+    def dump_coefs_h5(self, file: str, time: float = 0.0, name: str = "", config: str = "", center=None,
+                      rotation=None, scale: Optional[float] = None) -> None:
+        """``SphericalBasis::dump_coefs_h5`` (src/SphericalBasis.cc:1909-1975; called by ``OutCoef``): the current set as
+        one snapshot of pyEXP's HDF5 coefficient file -- appended (``ExtendH5Coefs``) when ``file`` exists, else a new
+        file with the component's name, the configuration and the default units {length, mass, time: none} beside the
+        container's own G."""
+        import os
+        from .basis import SphStruct
+        from .coefs import SphCoefs, real_rows_to_complex
+        cur = SphStruct(self.lmax, self.nmax, self.cfg.scale if scale is None else scale, time,
+                        real_rows_to_complex(self.get_coefs(), self.lmax),
+                        np.zeros(3) if center is None else np.asarray(center, np.float64),
+                        np.eye(3) if rotation is None else np.asarray(rotation, np.float64))
+        cs = SphCoefs(name)
+        cs.add(cur)
+        if os.path.exists(file):
+            cs.ExtendH5Coefs(file)
+        else:
+            cs.setUnits([("length", "none", 1.0), ("mass", "none", 1.0), ("time", "none", 1.0)])
+            cs.WriteH5Coefs(file, config=config)
+
     # -- coefficient covariance by sub-sampling (pyEXP pcavar; expui/BiorthBasis.cc:583-665) ---------
     def cov_enable(self, sampT: int) -> None:
         check(self.lib.exp_amd_sph_cov_enable(self.h, int(sampT)), self.ctx.h)
@@ -754,6 +775,27 @@ class Cylinder(_Force):
         cc, ss = self.get_coefs()
         write_native_cyl(out, CylStruct(self.grid.mmax, self.grid.norder, time, cc + 1j * ss,
                                         np.zeros(3), np.eye(3)))
+
+    def dump_coefs_h5(self, file: str, time: float = 0.0, name: str = "", config: str = "", center=None,
+                      rotation=None) -> None:
+        """``Cylinder::dump_coefs_h5`` (src/Cylinder.cc:1625-1690): as the sphere's -- extend an existing file, else
+        create it with the name, the configuration and the default units."""
+        import os
+        from .basis import CylStruct
+        from .coefs import CylCoefs
+        cc, ss = self.get_coefs()
+        cf = cc + 1j * ss
+        cf[0] = cc[0]                                    # (m = 0 has no sine part)
+        cur = CylStruct(self.grid.mmax, self.grid.norder, time, cf,
+                        np.zeros(3) if center is None else np.asarray(center, np.float64),
+                        np.eye(3) if rotation is None else np.asarray(rotation, np.float64))
+        cs = CylCoefs(name)
+        cs.add(cur)
+        if os.path.exists(file):
+            cs.ExtendH5Coefs(file)
+        else:
+            cs.setUnits([("length", "none", 1.0), ("mass", "none", 1.0), ("time", "none", 1.0)])
+            cs.WriteH5Coefs(file, config=config)
 
     FIELD_COORDS = {"spherical": 0, "cylindrical": 1, "cartesian": 2}
 

@@ -542,3 +542,51 @@ def test_reference_script_sequences_through_the_pyexp_namespace(tmp_path, monkey
     bad.add(pyEXP.coefs.SphStruct(3, 10, 1.0, 3.5, np.zeros((10, 10), complex), np.zeros(3), np.eye(3)))
     with pytest.raises(RuntimeError, match="parameter check failed"):
         bad.ExtendH5Coefs("halo.h5")
+
+
+def test_dump_coefs_h5_creates_then_extends(tmp_path):
+    """``SphericalBasis::dump_coefs_h5`` / ``Cylinder::dump_coefs_h5`` as ``OutCoef`` calls them (src/OutCoef.cc:135,
+    src/SphericalBasis.cc:1909-1975, src/Cylinder.cc:1625-1690): the first call creates the file with the component's
+    name, the configuration and the default units, later calls append snapshots; what comes back are the
+    coefficient sets the force method held at each call."""
+    from exp_amd import h5cache
+    if not h5cache.available():
+        pytest.skip("HDF5 shim not built")
+    from exp_amd.coefs import Coefs, complex_to_real_rows
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, Cylinder, SphereSL
+    from tests.conftest import make_grid
+    from tests.test_cyl_gpu import _disk, cyl_grid
+    ctx = Context(0)
+    model, g = make_grid("plummer", 3, 6, 300)
+    m, pos, vel = sample_sphere(model, 20000, seed=11)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    path = str(tmp_path / "outcoef.halo.h5")
+    sets = []
+    for k in range(3):
+        f.determine_coefficients(c)
+        sets.append(f.get_coefs().copy())
+        f.dump_coefs_h5(path, time=0.01 * k, name="dark halo", config="id: sphereSL", center=[0.1, 0.0, -0.2])
+        c.incr_position(0.05)
+    back = Coefs.factory(path)
+    assert back.getName() == "dark halo" and back.Times() == [0.0, 0.01, 0.02] and back.getGeometry() == "sphere"
+    assert back.getUnits() == [("G", "none", 1.0), ("length", "none", 1.0), ("mass", "none", 1.0), ("time", "none", 1.0)]
+    for k, t in enumerate(back.Times()):
+        st = back.getCoefStruct(t)
+        assert np.array_equal(complex_to_real_rows(st.coefs, 3), sets[k]) and np.array_equal(st.ctr, [0.1, 0.0, -0.2])
+    c.close(); f.close()
+    gc = cyl_grid(3, 5)
+    md, pd, _ = _disk(20000, 7, gc)
+    fc = Cylinder(ctx, gc)
+    cd = Component.from_arrays(ctx, md, pd)
+    pathc = str(tmp_path / "outcoef.disk.h5")
+    for k in range(2):
+        fc.determine_coefficients(cd)
+        fc.dump_coefs_h5(pathc, time=0.5 * k, name="star disk")
+    cc, ss = fc.get_coefs()
+    backc = Coefs.factory(pathc)
+    assert backc.getGeometry() == "cylinder" and backc.Times() == [0.0, 0.5] and len(backc.getUnits()) == 4
+    st = backc.getCoefStruct(0.5)
+    assert np.array_equal(st.coefs.real, cc) and np.array_equal(st.coefs.imag[1:], ss[1:]) and np.all(st.coefs.imag[0] == 0)
+    cd.close(); fc.close(); ctx.close()
