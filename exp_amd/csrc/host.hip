@@ -47,6 +47,9 @@ struct exp_amd_sim {
   bool host_timing = false;
   double ht[5] = {0, 0, 0, 0, 0};
   double ht_lo[17] = {0};           // wall time of the sub-steps by their lowest active level
+  double ht_dev[17][2] = {{0}};     // device time from the start of a sub-step to the end of each stream's sweep
+  hipEvent_t ht_ev0 = nullptr, ht_ev1[2] = {nullptr, nullptr};
+  int ht_lo_now = 0;
   long long ht_steps = 0;
 };
 
@@ -146,9 +149,11 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
             1e3 * s->ht[1] / s->ht_steps, 1e3 * s->ht[2] / s->ht_steps, 1e3 * s->ht[3] / s->ht_steps, 1e3 * s->ht[4] / s->ht_steps);
   if (s->host_timing && s->ht_steps)
     for (int L = 0; L <= s->multistep; L++)
-      fprintf(stderr, "[exp_amd host timing]   sub-steps with lowest active level %d: %.3f ms per master step (%d of them)\n", L,
-              1e3 * s->ht_lo[L] / s->ht_steps, L == 0 ? 1 : 1 << (L - 1));
+      fprintf(stderr, "[exp_amd host timing]   sub-steps with lowest active level %d: %.3f ms per master step (%d of them); device time "
+              "to the end of the sweep on stream 0 / 1: %.3f / %.3f ms\n", L, 1e3 * s->ht_lo[L] / s->ht_steps, L == 0 ? 1 : 1 << (L - 1),
+              1e3 * s->ht_dev[L][0] / s->ht_steps, 1e3 * s->ht_dev[L][1] / s->ht_steps);
   if (s->pinned) (void)hipHostFree(s->pinned);
+  if (s->ht_ev0) { (void)hipEventDestroy(s->ht_ev0); (void)hipEventDestroy(s->ht_ev1[0]); (void)hipEventDestroy(s->ht_ev1[1]); }
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
@@ -380,11 +385,17 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
                                       kick ? mf : ms + 1, first, dt_min, &res))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, res, 32 * sizeof(unsigned long long),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (s->host_timing && s->overlap && s->ht_ev0 && kick && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
   }
   const double th1 = s->host_timing ? host_now() : 0.0;
   if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const double th2 = s->host_timing ? host_now() : 0.0;
+  if (s->host_timing && s->overlap && s->ht_ev0 && kick && nc == 2)
+    for (int k = 0; k < 2; k++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ht_ev0, s->ht_ev1[k]) == hipSuccess) s->ht_dev[s->ht_lo_now][k] += 1e-3 * ms;
+    }
   struct HtClose {
     exp_amd_sim *s; double a, b, c;
     ~HtClose() { if (s->host_timing) { s->ht[2] += b - a; s->ht[3] += c - b; s->ht[4] += host_now() - c; } }
@@ -481,6 +492,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         const int mdrft = mstep + 1;
         const double th0 = s->host_timing ? host_now() : 0.0;
+        if (s->host_timing && s->overlap) {
+          if (!s->ht_ev0) { (void)hipEventCreate(&s->ht_ev0); (void)hipEventCreate(&s->ht_ev1[0]); (void)hipEventCreate(&s->ht_ev1[1]); }
+          (void)hipEventRecord(s->ht_ev0, s->main_stream);
+          s->ht_lo_now = s->mfirst[mstep];
+        }
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
         s->tnow += dt;
         const double th1 = s->host_timing ? host_now() : 0.0;
