@@ -402,8 +402,9 @@ def other_configs(ctx, device, n, which=(2, 3, 4), steps=30, min_seconds=0.0):
     a, h = 0.01, 0.001
     cg = None
     if 3 in which or 4 in which:
+        # (C6 of SURVEY section 8d: ncylodd 4-6 -- eight vertically symmetric and four antisymmetric functions per m)
         cg = build_empcyl(mmax=6, norder=12, numx=256, numy=128, acyl=a, hcyl=h, lmaxfid=32,
-                          nmaxfid=24, numr=2000, rnum=200, tnum=80)
+                          nmaxfid=24, numr=2000, rnum=200, tnum=80, nodd=4)
     if 3 in which:
         X, Y, Z, vx, vy, vz = make_disk(n, a, h, 34567, device, vscale=7.0)
         mass = torch.full((n,), 1.0 / n, device=device, dtype=torch.float64)

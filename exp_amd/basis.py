@@ -780,6 +780,9 @@ class Cylindrical(BiorthBasis):
         self.ncylr = int(g("ncylr", 2000))
         self.rnum, self.tnum = int(g("rnum", 200)), int(g("tnum", 80))
         self.cmapr, self.cmapz = int(g("cmapr", g("cmap", 1))), int(g("cmapz", 1))
+        # the number of vertically antisymmetric functions per m (expui/BiorthBasis.cc:1389, :1470; EmpCylSL's constructor
+        # keeps the even / odd split only for 0 <= ncylodd <= nmax, exputil/EmpCylSL.cc:178-185)
+        self.ncylodd = int(g("ncylodd", 9))
         self.cachename = g("cachename", "")
         if not self.cachename:
             raise RuntimeError("Cylindrical requires a specified cachename in your YAML config")
@@ -839,7 +842,11 @@ class Cylindrical(BiorthBasis):
                             acyl=self.acyl, hcyl=self.hcyl, rcylmin=self.rcylmin,
                             rcylmax=self.rcylmax, lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid,
                             numr=self.ncylr, cmapr=self.cmapr, cmapz=self.cmapz, rnum=self.rnum,
-                            tnum=self.tnum)
+                            tnum=self.tnum, nodd=self.ncylodd)
+
+    def _even_odd(self):
+        """(neven, nodd) as the cache records them (exputil/EmpCylSL.cc:98-99, :182-184): zeros without the split"""
+        return (self.nmax - self.ncylodd, self.ncylodd) if 0 <= self.ncylodd <= self.nmax else (0, 0)
 
     def _load_or_build(self) -> EmpCylGrid:
         """EXP's own HDF5 cache ``cachename`` (exputil/EmpCylSL.cc:7378-7640) when the HDF5 shim is
@@ -854,11 +861,12 @@ class Cylindrical(BiorthBasis):
                                    lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid, cmapr=self.cmapr,
                                    cmapz=self.cmapz, rmin=float(self.rcylmin),
                                    rmax=float(self.rcylmax), ascl=float(self.acyl),
-                                   hscl=float(self.hcyl)))
+                                   hscl=float(self.hcyl), neven=self._even_odd()[0], nodd=self._even_odd()[1]))
                 except RuntimeError:
                     pass                                  # the reference rebuilds on any mismatch
             gr = self._build()
-            h5cache.write_empcyl_cache(self.cachename, gr, self.lmaxfid, self.nmaxfid)
+            h5cache.write_empcyl_cache(self.cachename, gr, self.lmaxfid, self.nmaxfid, neven=self._even_odd()[0],
+                                       nodd=self._even_odd()[1])
             return gr
         path = self._cache_path()
         if os.path.exists(path):
@@ -868,10 +876,7 @@ class Cylindrical(BiorthBasis):
                     abs(gr.hscale - self.hcyl) < 1e-15 and gr.cmapr == self.cmapr and
                     gr.cmapz == self.cmapz):
                 return gr
-        gr = build_empcyl(mmax=self.mmax, norder=self.nmax, numx=self.ncylnx, numy=self.ncylny,
-                          acyl=self.acyl, hcyl=self.hcyl, rcylmin=self.rcylmin, rcylmax=self.rcylmax,
-                          lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid, numr=self.ncylr,
-                          cmapr=self.cmapr, cmapz=self.cmapz, rnum=self.rnum, tnum=self.tnum)
+        gr = self._build()
         gr.save(path)
         return gr
 

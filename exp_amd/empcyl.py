@@ -18,7 +18,8 @@ Method (the reference's, re-implemented with numpy):
 Divergences from the reference, all init-only and irrelevant to hot-path parity (which is defined
 given the tables): eigenvectors are ordered by decreasing eigenvalue explicitly; the sine z-force
 table holds the z-force (the reference's single-process branch copies the R-force there,
-SURVEY.md section 3.7 item 5); EvenOdd splitting (ncylodd) is not applied.
+SURVEY.md section 3.7 item 5).  The split into vertically symmetric and antisymmetric functions (``ncylodd``) is the
+``nodd`` argument of ``build_empcyl``.
 """
 from __future__ import annotations
 
@@ -212,8 +213,14 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
                  acyl: float = 0.01, hcyl: float = 0.002, rcylmin: float = 0.001,
                  rcylmax: float = 20.0, lmaxfid: int = 32, nmaxfid: int = 24, numr: int = 2000,
                  cmapr: int = 1, cmapz: int = 1, rnum: int = 200, tnum: int = 80,
-                 dens: Optional[Callable] = None) -> EmpCylGrid:
+                 dens: Optional[Callable] = None, nodd: Optional[int] = None) -> EmpCylGrid:
+    """``nodd`` (the reference's ``ncylodd``; EmpCylSL's constructor argument, exputil/EmpCylSL.cc:178-185): with
+    0 <= nodd <= norder the functions are chosen by vertical parity -- the norder - nodd largest-variance combinations
+    of the helper functions with l + m even (symmetric about the plane) first, then the nodd largest-variance ones with
+    l + m odd (``lE`` / ``lO``, ``SCe`` / ``SCo``, :2250-2268, :2743-2858; tabulated even first, :1680-1760).  None or out
+    of range: the norder largest-variance combinations whatever their parity."""
     ASCALE, HSCALE, RMIN, RMAX = acyl, hcyl, rcylmin, rcylmax
+    even_odd = nodd is not None and 0 <= nodd <= norder
     pfac = 1.0 / math.sqrt(ASCALE)           # exputil/EmpCylSL.cc:173-175
     ffac = pfac / ASCALE
     dens = dens or default_disk_density(acyl, hcyl)
@@ -278,11 +285,29 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
         mx = np.abs(SC).max()
         if mx > 1e-5:
             SC = SC / mx
-        ev, ef = np.linalg.eigh(SC)
-        order = np.argsort(ev)[::-1][:norder]
-        ef = ef[:, order]
-        nfid = min(4, ef.shape[0]) - 1
-        ef = ef * np.where(ef[nfid, :] < 0.0, -1.0, 1.0)[None, :]
+        def top(mat, k):
+            mx_ = np.abs(mat).max()
+            if mx_ > 1e-5:
+                mat = mat / mx_
+            w, v = np.linalg.eigh(mat)
+            v = v[:, np.argsort(w)[::-1][:k]]
+            nf = min(4, v.shape[0]) - 1
+            return v * np.where(v[nf, :] < 0.0, -1.0, 1.0)[None, :]
+
+        if even_odd:
+            # columns nn = ir + NMAX * (l - m): the two parities do not mix under a density symmetric about the plane, and
+            # each is decomposed in its own index space nn' = ir + NMAX * il (il counts the l of that parity)
+            lpar = np.repeat((np.arange(m, lmaxfid + 1) + m) % 2, nmaxfid)          # 0: l + m even
+            ce, co = np.flatnonzero(lpar == 0), np.flatnonzero(lpar == 1)
+            ef = np.zeros((nl * nmaxfid, norder))
+            ne = norder - nodd
+            ve = top(SC[np.ix_(ce, ce)], ne)
+            ef[ce, :ve.shape[1]] = ve
+            if nodd and co.size:
+                vo = top(SC[np.ix_(co, co)], nodd)
+                ef[co, ne:ne + vo.shape[1]] = vo
+        else:
+            ef = top(SC, norder)
 
         # 4. tabulation
         Pg, dPg = _legendre_all(lmaxfid, m, cg)                 # [npts, nl]

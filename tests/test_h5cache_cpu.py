@@ -213,3 +213,35 @@ def test_covariance_store_roundtrip_and_layout(h5, tmp_path):
                   'DATASET "coefficients_real"', 'DATASET "covariance_imag_total"'):
             assert s in txt, s
         assert f"( {ltot * nmax * (nmax + 1) // 2}, 1 )" in txt           # summed upper triangles, [n][1]
+
+
+def test_even_odd_function_split_of_the_disk_basis():
+    """``ncylodd`` (EmpCylSL's constructor argument ``nodd``, exputil/EmpCylSL.cc:178-185; pyEXP's default 9,
+    expui/BiorthBasis.cc:1389; the n-body default nmax/4, src/Cylinder.cc:553-555): norder - nodd vertically symmetric
+    functions first, then nodd antisymmetric ones (compute_eof_grid, :1680-1760), each the largest-variance
+    combinations within its parity; out of range = no split.  The symmetric functions of a split basis are the
+    symmetric functions of the plain one, in the same order."""
+    from exp_amd.empcyl import build_empcyl
+    kw = dict(mmax=2, norder=8, numx=32, numy=16, acyl=0.01, hcyl=0.001, lmaxfid=16, nmaxfid=12, numr=400, rnum=40, tnum=24)
+    plain, split, out_of_range = build_empcyl(**kw), build_empcyl(nodd=3, **kw), build_empcyl(nodd=9, **kw)
+
+    def parity(g, m, n):           # +1: symmetric about the plane
+        a = g.tab[0, m, n]
+        return 1 if np.abs(a - a[:, ::-1]).max() < np.abs(a + a[:, ::-1]).max() else -1
+
+    assert np.array_equal(out_of_range.tab, plain.tab)
+    for m in range(3):
+        assert [parity(split, m, n) for n in range(8)] == [1] * 5 + [-1] * 3
+        ev = [n for n in range(8) if parity(plain, m, n) == 1][:5]
+        for k, n in enumerate(ev):
+            for kind in (0, 1, 2):
+                ref = plain.tab[kind, m, n]
+                assert np.abs(split.tab[kind, m, k] - ref).max() <= 1e-12 * np.abs(ref).max()
+        # the z-force of a symmetric potential is antisymmetric, and the other way round
+        assert np.abs(split.tab[2, m, 0] + split.tab[2, m, 0][:, ::-1]).max() <= 1e-12 * np.abs(split.tab[2, m, 0]).max()
+        assert np.abs(split.tab[2, m, 7] - split.tab[2, m, 7][:, ::-1]).max() <= 1e-12 * np.abs(split.tab[2, m, 7]).max()
+    # biorthogonality survives the selection: density x potential of different functions integrates to ~0
+    # (checked on the device by Cylindrical.orthoCheck; here only that the split functions are not degenerate)
+    for m in range(3):
+        flat = split.tab[0, m].reshape(8, -1)
+        assert np.linalg.matrix_rank(flat) == 8
