@@ -784,6 +784,12 @@ class Cylindrical(BiorthBasis):
         # keeps the even / odd split only for 0 <= ncylodd <= nmax, exputil/EmpCylSL.cc:178-185)
         self.ncylodd = int(g("ncylodd", 9))
         self.cachename = g("cachename", "")
+        if "eof_file" in conf:                   # the deprecated spelling wins when both are given (:1471-1472, :1517-1526)
+            print("Cylinder: parameter 'eof_file' is deprecated. and will be removed in a future release. Please use "
+                  "'cachename' instead.")
+            self.cachename = str(conf["eof_file"])
+        if "density" in conf:
+            print("Cylindrical: parameter 'density' is deprecated. The density field will be computed regardless.")
         if not self.cachename:
             raise RuntimeError("Cylindrical requires a specified cachename in your YAML config")
         self.grid = self._load_or_build()

@@ -590,3 +590,51 @@ def test_dump_coefs_h5_creates_then_extends(tmp_path):
     st = backc.getCoefStruct(0.5)
     assert np.array_equal(st.coefs.real, cc) and np.array_equal(st.coefs.imag[1:], ss[1:]) and np.all(st.coefs.imag[0] == 0)
     cd.close(); fc.close(); ctx.close()
+
+
+def test_reference_disk_script_configuration(tmp_path, capsys):
+    """tests/Disk/cyl_basis.py: its parameter set as it stands (the deprecated ``eof_file`` and ``density`` keys, ``ncylodd: 3``,
+    ``pnum: 0``, ``ashift``, ``vflag``, ``logr``, ``ignore``) builds a basis and ``cacheInfo(<file>)`` reads the cache back --
+    five vertically symmetric and three antisymmetric functions per m are recorded in it."""
+    from exp_amd.basis import Basis
+    cache = tmp_path / ".eof.cache.run0t"
+    cfg = f"""
+---
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  lmaxfid: 20
+  nmaxfid: 20
+  mmax: 6
+  nmax: 8
+  ncylnx: 128
+  ncylny: 64
+  ncylodd: 3
+  rnum: 32
+  pnum: 0
+  tnum: 16
+  ashift: 0.5
+  vflag: 16
+  logr: false
+  density: true
+  eof_file: {cache}
+  ignore: true
+...
+"""
+    disk_basis = Basis.factory(cfg)
+    out = capsys.readouterr().out
+    assert "'eof_file' is deprecated" in out and "'density' is deprecated" in out
+    node_cyl = disk_basis.cacheInfo(str(cache))
+    assert (node_cyl["mmax"], node_cyl["nmax"], node_cyl["numx"], node_cyl["numy"]) == (6, 8, 128, 64)
+    assert (node_cyl["lmaxfid"], node_cyl["nmaxfid"], node_cyl["neven"], node_cyl["nodd"]) == (20, 20, 5, 3)
+    oc = disk_basis.orthoCheck()
+    assert max(np.abs(np.asarray(m) - np.eye(8)).max() for m in oc) < 0.05
+    # functions 5..7 change sign across the plane: a particle pair mirrored in z excites none of them
+    pos = np.array([[0.02, 0.01, 0.0007], [0.02, 0.01, -0.0007]])
+    cs = disk_basis.createFromArray(np.array([0.5, 0.5]), pos)
+    c = np.abs(cs.coefs)
+    assert c[:, 5:].max() <= 1e-12 * c[:, :5].max()
+    # ... and a single particle above the plane does excite them
+    one = np.abs(disk_basis.createFromArray(np.array([1.0]), pos[:1]).coefs)
+    assert one[:, 5:].max() > 1e-3 * one[:, :5].max()
