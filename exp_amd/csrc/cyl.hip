@@ -1203,7 +1203,7 @@ struct CylForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
-  int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1) override;
+  int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1, int phase = 0) override;
   long long sparse_threshold() const override { return 3000000LL / (4 * dev.ntrig); }
   int resort(exp_amd_comp *c, int first = 0) override;
   int multistep_reset() override
@@ -1537,7 +1537,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine)
+int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine, int phase)
 {
   CylForce *f = this;
   const int ms = f->multistep;
@@ -1556,7 +1556,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   const bool ordered = (c->sorted_for == f && c->nlevels == ms + 1) || stale_ok;
   const bool full = lo == 0 || !ordered;
   if (full || stale_ok) dmax = ms;
-  if (c->n) {
+  if (c->n && phase != 2) {
     uint32_t keep[66];
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
     c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
@@ -1571,6 +1571,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     }
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
+  if (phase == 1) return EXP_AMD_OK;
   const CylDev C = cdev_acc(f, c);
   double *dst = f->d_coefN.p + (size_t)lo * f->ncoef_dev;
   const size_t wl = f->nnode * dev.ntrig;

@@ -96,7 +96,10 @@ struct exp_amd_force {
   // mdrft_combine >= 0 (a single rank only: no all-reduce sits between the two): the kernel that sums the per-level
   // sets also forms the combined set of compute_multistep_coefficients(mdrft_combine) -- one link less in the chain of
   // dependent launches of a sub-step; `combined_mdrft` then says so until the sets change again
-  virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1) = 0;
+  // phase: 0 = the whole first half; 1 = only the kick + drift (the advance sort / in-place advance), 2 = only the
+  // accumulation behind it -- the step driver issues phase 1 of every component before phase 2 of any, so that the second
+  // stream is not idle while the host issues the first component's chain
+  virtual int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1, int phase = 0) = 0;
   int combined_mdrft = -1;
 
   // Level population below which a multistep level is left un-cell-sorted (see exp_amd_comp::

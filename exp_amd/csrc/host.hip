@@ -49,13 +49,26 @@ struct exp_amd_sim {
   double ht_lo[17] = {0};           // wall time of the sub-steps by their lowest active level
   double ht_dev[17][2] = {{0}};     // device time from the start of a sub-step to the end of each stream's sweep
   hipEvent_t ht_ev0 = nullptr, ht_ev1[2] = {nullptr, nullptr};
+  // EXP_AMD_HOST_TIMING_MARKS=1: three more timing events per stream and sub-step (after the expansion, the self force,
+  // the cross force) -- each costs the stream ~5 us, so the totals grow, but the order of things shows
+  bool ht_marks = false;
+  hipEvent_t ht_mk[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  double ht_mkt[17][2][3] = {{{0}}};
   int ht_lo_now = 0;
   long long ht_steps = 0;
 };
 
+static inline void ht_mark(exp_amd_sim *s, size_t k, int which);
 static inline double host_now()
 {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static inline void ht_mark(exp_amd_sim *s, size_t k, int which)
+{
+  if (!s->host_timing || !s->ht_marks || !s->overlap || !s->ht_ev0 || k >= 2) return;
+  if (!s->ht_mk[k][which]) (void)hipEventCreate(&s->ht_mk[k][which]);
+  (void)hipEventRecord(s->ht_mk[k][which], s->ctx->stream);
 }
 
 // issue on component k's stream for the lifetime of the object
@@ -77,6 +90,7 @@ static int overlap_begin(exp_amd_sim *s)
   if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
   // (EXP_AMD_HOST_TIMING=k: from master step k-1 on -- k = 9 skips the eight in which the level populations settle)
   if (const char *e = getenv("EXP_AMD_HOST_TIMING")) s->host_timing = atoi(e) != 0 && s->this_step >= atoi(e) - 1;
+  if (const char *e = getenv("EXP_AMD_HOST_TIMING_MARKS")) s->ht_marks = atoi(e) != 0;
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
@@ -152,8 +166,17 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
       fprintf(stderr, "[exp_amd host timing]   sub-steps with lowest active level %d: %.3f ms per master step (%d of them); device time "
               "to the end of the sweep on stream 0 / 1: %.3f / %.3f ms\n", L, 1e3 * s->ht_lo[L] / s->ht_steps, L == 0 ? 1 : 1 << (L - 1),
               1e3 * s->ht_dev[L][0] / s->ht_steps, 1e3 * s->ht_dev[L][1] / s->ht_steps);
+  if (s->host_timing && s->ht_marks && s->ht_steps)
+    for (int L = 0; L <= s->multistep; L++) {
+      const double n = (double)s->ht_steps * (L == 0 ? 1 : 1 << (L - 1)) * 1e-6;
+      fprintf(stderr, "[exp_amd host timing]   level %d, us per sub-step from its start: stream 0 expansion %.0f self %.0f cross %.0f end %.0f | "
+              "stream 1 expansion %.0f self %.0f cross %.0f end %.0f\n", L, s->ht_mkt[L][0][0] / n, s->ht_mkt[L][0][1] / n,
+              s->ht_mkt[L][0][2] / n, s->ht_dev[L][0] / n, s->ht_mkt[L][1][0] / n, s->ht_mkt[L][1][1] / n, s->ht_mkt[L][1][2] / n,
+              s->ht_dev[L][1] / n);
+    }
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->ht_ev0) { (void)hipEventDestroy(s->ht_ev0); (void)hipEventDestroy(s->ht_ev1[0]); (void)hipEventDestroy(s->ht_ev1[1]); }
+  for (auto &row : s->ht_mk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
@@ -313,13 +336,18 @@ static int substep_expansion(exp_amd_sim *s, int lo, double dt_min, int mdrft)
   // (alone: the combined coefficient set of the force evaluation that follows is formed by the same kernel that sums
   // the per-level sets; with several ranks the all-reduce of the level block sits between the two)
   const bool alone = s->ctx->nranks <= 1 && !s->ctx->ar_fn && !s->ctx->rccl_comm;
-  for (size_t k = 0; k < s->comps.size(); k++) {
-    StreamOf on(s, k);
-    int rc = wait_used(s, k);
-    if (rc) return rc;
-    rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1);
-    if (rc) return rc;
-  }
+  static const bool split = [] { const char *e = getenv("EXP_AMD_SIM_SPLIT_ISSUE"); return !e || atoi(e) != 0; }();
+  // two streams: the advance of every component is issued before the accumulation of any -- the host needs ~25 us for
+  // the launches of one component's first half, and the other stream would have nothing to do meanwhile
+  for (int phase = (s->overlap && split) ? 1 : 0; phase <= ((s->overlap && split) ? 2 : 0); phase++)
+    for (size_t k = 0; k < s->comps.size(); k++) {
+      StreamOf on(s, k);
+      int rc = phase == 2 ? 0 : wait_used(s, k);
+      if (rc) return rc;
+      rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1, phase);
+      if (rc) return rc;
+      if (phase != 1) ht_mark(s, k, 0);
+    }
   return EXP_AMD_OK;
 }
 
@@ -338,6 +366,7 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     f->combined_mdrft = -1;
     if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
     if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
+    ht_mark(s, k, 1);
   }
   for (auto &pr : s->inter) {
     StreamOf on(s, (size_t)pr.second);            // the target's particles: the target's stream
@@ -349,10 +378,16 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
       if (s->used_pending[pr.first]) HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[pr.first], 0));
     }
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
-    if (foreign) {
+    // (the tables this cross force reads are next written by the source's stream in the NEXT sub-step's first half, and
+    // every path there leads through a join of the two streams: the read-back of kick_adjust_levels synchronises both, and
+    // begin_run / the end of a step call end in overlap_end.  An event per cross force for it cost each stream ~5 us a
+    // sub-step, tools/dbg/launch_gap.hip; EXP_AMD_SIM_USED_EVENTS=1 records them again)
+    static const bool used_ev = [] { const char *e = getenv("EXP_AMD_SIM_USED_EVENTS"); return e && atoi(e) != 0; }();
+    if (foreign && used_ev) {
       HIP_TRY(s->ctx, hipEventRecord(s->ev_used[pr.first], s->ctx->stream));
       s->used_pending[pr.first] = 1;
     }
+    ht_mark(s, (size_t)pr.second, 2);
   }
   s->gottapot = true;
   return EXP_AMD_OK;
@@ -395,6 +430,9 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     for (int k = 0; k < 2; k++) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, s->ht_ev0, s->ht_ev1[k]) == hipSuccess) s->ht_dev[s->ht_lo_now][k] += 1e-3 * ms;
+      for (int w = 0; w < 3 && s->ht_marks; w++)
+        if (s->ht_mk[k][w] && hipEventElapsedTime(&ms, s->ht_ev0, s->ht_mk[k][w]) == hipSuccess)
+          s->ht_mkt[s->ht_lo_now][k][w] += 1e-3 * ms;
     }
   struct HtClose {
     exp_amd_sim *s; double a, b, c;

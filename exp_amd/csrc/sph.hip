@@ -498,7 +498,7 @@ int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   return EXP_AMD_OK;
 }
 
-int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine)
+int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine, int phase)
 {
   SphForce *f = this;
   const int ms = f->multistep;
@@ -517,7 +517,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   const bool ordered = (c->sorted_for == f && c->nlevels == ms + 1) || stale_ok;
   const bool full = lo == 0 || !ordered;
   if (full || stale_ok) dmax = ms;                  // a full re-partition passes over everything anyway
-  if (c->n) {
+  if (c->n && phase != 2) {
     // one sort of the dense part of the active slot range with the per-level kick + drift applied on
     // the way; the whole store when the level partition is not this basis' yet.  acc / pot of the
     // active levels are rewritten by the force evaluation that follows (compute_potential(mfirst[
@@ -538,6 +538,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     // sparse levels above: advanced in place
     if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
   }
+  if (phase == 1) return EXP_AMD_OK;
   const SphDev S = dev_acc(f, c);
   const size_t wl = (size_t)(cfg.numr - 1) * S.nrows * 2;
   // the per-level moment buffers are left clean by the contraction that consumes them (below); only

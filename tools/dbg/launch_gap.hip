@@ -83,5 +83,33 @@ int main()
     }
     printf("%-64s %.2f us per hop\n", "hops between two streams through events", 1e3 * best / (2 * N));
   }
+  // what a small device-to-host copy costs the stream: kernel, 256-byte copy into page-locked memory, next kernel
+  {
+    void *h; CK(hipHostMalloc(&h, 4096));
+    auto chain = [&](const char *name, int variant) -> int {
+      double *hd = nullptr;
+      CK(hipHostGetDevicePointer((void **)&hd, h, 0));
+      float best = 1e9;
+      for (int rep = 0; rep < 3; rep++) {
+        CK(hipDeviceSynchronize());
+        k_block<<<1, 64, 0, s1>>>(d, 300000);
+        CK(hipEventRecord(e0, s1));
+        for (int i = 0; i < N; i++) {
+          k_tiny<<<1, 256, 0, s1>>>(d, 256);
+          if (variant == 0) CK(hipMemcpyAsync(h, d, 256, hipMemcpyDeviceToHost, s1));
+          else if (variant == 1) CK(hipMemcpyAsync(d + 65536, d, 256, hipMemcpyDeviceToDevice, s1));
+          else k_tiny<<<1, 32, 0, s1>>>(hd, 32);
+        }
+        CK(hipEventRecord(e1, s1));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+      }
+      printf("%-64s %.2f us per pair\n", name, 1e3 * best / N);
+      return 0;
+    };
+    chain("kernel + 256-byte copy to page-locked host memory", 0);
+    chain("kernel + 256-byte device-to-device copy", 1);
+    chain("kernel + a kernel writing 256 bytes of page-locked host memory", 2);
+  }
   return 0;
 }
