@@ -480,3 +480,52 @@ def test_cyl_subsample_covariance(ctx, oracle):
     assert np.abs(got2["mean"] - ref2["mean"]).max() <= 1e-10 * np.abs(ref2["mean"]).max()
     assert np.abs(got2["covr"] - ref2["covr"]).max() <= 1e-10 * np.abs(ref2["covr"]).max()
     c.close(); f2.close()
+
+
+def test_sine_tables_that_differ_from_the_cosine_tables(ctx, oracle, monkeypatch):
+    """The projection fetches each table value once for the cosine and the sine row of a harmonic when the two sets of
+    tables are the same bits (``CylForce::tab_twin``, the usual case and that of every other test basis).  Here the sine
+    tables are perturbed -- an EOF basis conditioned on a non-axisymmetric density has SC != SS (exputil/EmpCylSL.cc:
+    2556-2760) -- so the separate fetch is what runs: coefficients, accelerations and potential against the oracle; and
+    with the shared fetch switched off (EXP_AMD_CYL_TWIN=0) a twin basis gives the same bits as with it on."""
+    import copy
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    m, pos, _ = _disk(20000, 77, g)
+    g2 = copy.copy(g)
+    rng = np.random.default_rng(12)
+    g2.tab = g.tab.copy()
+    for k in (3, 4, 5):
+        g2.tab[k] = g.tab[k] * (1.0 + 0.3 * rng.standard_normal(g.tab[k].shape))
+    g2.tab[3:, 0] = 0.0                                     # (no sine functions at m = 0)
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g2, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g2, pos, c_ref, s_ref, mass_ref)
+    f = Cylinder(ctx, g2)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    scale = np.abs(c_ref).max()
+    assert np.abs(cc - c_ref).max() <= COEF_TOL * scale and np.abs(ss - s_ref).max() <= COEF_TOL * scale
+    assert np.abs(ss[1:]).max() > 1e-3 * scale
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    # ... and the perturbation matters: the twin basis gives another field
+    a_twin, _ = oracle.cyl_accel(g, pos, *oracle.cyl_accumulate(g, pos, m)[:2], mass_ref)
+    assert np.abs(a_twin - a_ref).max() > 1e-3 * np.linalg.norm(a_ref, axis=1).max()
+    c.close(); f.close()
+    res = []
+    ctx.set_deterministic(True)                             # (order-independent sums: the two accumulations agree bit for bit)
+    for twin in ("1", "0"):
+        monkeypatch.setenv("EXP_AMD_CYL_TWIN", twin)
+        f = Cylinder(ctx, g)
+        c = Component.from_arrays(ctx, m, pos)
+        f.determine_coefficients(c)
+        c.zero_acceleration(0)
+        f.get_acceleration_and_potential(c)
+        res.append(c.download(("acc", "pot")))
+        c.close(); f.close()
+    ctx.set_deterministic(False)
+    assert np.array_equal(res[0]["acc"], res[1]["acc"]) and np.array_equal(res[0]["pot"], res[1]["pot"])
