@@ -392,6 +392,26 @@ class SphCoefs(Coefs):
     geometry = "sphere"
     _what = "SphCoefs"
 
+    def makeKeys(self, subkey=()) -> List[List[int]]:
+        """``SphCoefs::makeKeys`` (expui/Coefficients.cc:750-792): every key [l, m, n] under a leading sub-key -- ``[]``: all,
+        ``[l]``: all (m, n) of that l, ``[l, m]``: all n; l is clamped to Lmax, m to l; nothing without stored sets."""
+        if not self.coefs:
+            return []
+        first = self.coefs[self.Times()[0]]
+        Lmax, Nmax = first.lmax, first.nmax
+        k = [int(v) for v in subkey]
+        if len(k) > 2:
+            raise RuntimeError("SphCoefs::makeKeys: the subkey must have rank 0, 1 or 2")
+        if k:
+            k[0] = min(max(k[0], 0), Lmax)
+        if len(k) > 1:
+            k[1] = min(max(k[1], 0), k[0])
+        if not k:
+            return [[l, m, n] for l in range(Lmax + 1) for m in range(l + 1) for n in range(Nmax)]
+        if len(k) == 1:
+            return [[k[0], m, n] for m in range(k[0] + 1) for n in range(Nmax)]
+        return [[k[0], k[1], n] for n in range(Nmax)]
+
     def Power(self, min: int = 0, max: int = 2 ** 31 - 1) -> np.ndarray:
         """``SphCoefs::Power`` (expui/Coefficients.cc:1033-1060): [ntimes, lmax + 1], the sum over m and over
         the radial orders min <= n < max of |c|^2."""
@@ -617,6 +637,20 @@ class CylCoefs(Coefs):
 
     geometry = "cylinder"
     _what = "CylCoefs"
+
+    def makeKeys(self, subkey=()) -> List[List[int]]:
+        """``CylCoefs::makeKeys`` (expui/Coefficients.cc:1257-1287): every key [m, n], or those of one m (clamped to Mmax)."""
+        if not self.coefs:
+            return []
+        first = self.coefs[self.Times()[0]]
+        Mmax, Nmax = first.mmax, first.nmax
+        k = [int(v) for v in subkey]
+        if len(k) > 1:
+            raise RuntimeError("CylCoefs::makeKeys: the subkey must have rank 1")
+        if not k:
+            return [[m, n] for m in range(Mmax + 1) for n in range(Nmax)]
+        m = min(max(k[0], 0), Mmax)
+        return [[m, n] for n in range(Nmax)]
 
     def Power(self, min: int = 0, max: int = 2 ** 31 - 1) -> np.ndarray:
         """``CylCoefs::Power`` (expui/Coefficients.cc:1442-1470): [ntimes, mmax + 1]."""

@@ -155,6 +155,15 @@ def test_coefs_container_surface(tmp_path):
     for fn in (sph.setMatrix, sph.setData):
         with pytest.raises(RuntimeError, match="not found"):
             fn(0.7, m)
+    # makeKeys (expui/Coefficients.cc:750-792, :1257-1287): the keys under a leading sub-key, clamped to the orders
+    assert SphCoefs("x").makeKeys() == [] and len(sph.makeKeys()) == 10 * 5 and sph.makeKeys()[:2] == [[0, 0, 0], [0, 0, 1]]
+    assert sph.makeKeys([2]) == [[2, m, n] for m in range(3) for n in range(5)]
+    assert sph.makeKeys([9, 7]) == [[3, 3, n] for n in range(5)]                       # l -> Lmax, m -> l
+    assert cyl.makeKeys() == [[m, n] for m in range(5) for n in range(6)] and cyl.makeKeys([11]) == [[4, n] for n in range(6)]
+    with pytest.raises(RuntimeError, match="rank 0, 1 or 2"):
+        sph.makeKeys([1, 1, 1])
+    with pytest.raises(RuntimeError, match="rank 1"):
+        cyl.makeKeys([1, 1])
     # power: |c|^2 summed over m and the radial window
     P = sph.Power(1, 4)
     a2 = np.abs(sph(0.0)[:, 1:4]) ** 2
