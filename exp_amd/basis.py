@@ -57,30 +57,130 @@ def _ctx() -> Context:
     return _default_ctx
 
 
+class _CoefStructAPI:
+    """What pyEXP exposes of ``CoefClasses::CoefStruct`` (expui/CoefStruct.H:18-113; pyEXP/CoefWrappers.cc:720-960):
+    the time / centre / orientation accessors, the flat data store (the matrix in column-major order, as Eigen maps
+    it), ``deepcopy``, and the gravitational constant a set carries when no container owns it."""
+
+    G = 1.0
+    _owner = None                     # the Coefs container that holds the set (CoefStruct::C), or None
+
+    @property
+    def center(self):
+        return self.ctr
+
+    @property
+    def orient(self):
+        return self.rot
+
+    def deepcopy(self):
+        """new arrays, same owner (CoefStruct::copyfields copies the pointer to the container, expui/CoefStruct.cc:24-34)"""
+        import copy
+        owner, self._owner = self._owner, None
+        try:
+            ret = copy.deepcopy(self)
+        finally:
+            self._owner = owner
+        ret._owner = owner
+        return ret
+
+    def zerodata(self) -> None:
+        self.coefs = np.zeros_like(np.asarray(self.coefs))
+
+    def getCoefTime(self) -> float:
+        return self.time
+
+    def setCoefTime(self, tval: float) -> None:
+        self.time = float(tval)
+
+    def getCoefCenter(self) -> np.ndarray:
+        return self.ctr
+
+    def setCoefCenter(self, mat) -> None:
+        self.ctr = np.asarray(mat, dtype=np.float64).reshape(3).copy()
+
+    def getCoefRotation(self) -> np.ndarray:
+        return self.rot
+
+    def setCoefRotation(self, mat) -> None:
+        self.rot = np.asarray(mat, dtype=np.float64).reshape(3, 3).copy()
+
+    def getCoefs(self) -> np.ndarray:
+        return np.asarray(self.coefs, dtype=np.complex128).reshape(-1, order="F")
+
+    def setCoefs(self, mat=None):
+        """``setCoefs(vector)`` replaces the store (sizes must agree); ``setCoefs()`` hands out the coefficient array
+        itself for in-place changes (the reference returns an Eigen::Ref to the store)."""
+        if mat is None:
+            self.coefs = np.ascontiguousarray(self.coefs, dtype=np.complex128)
+            return self.coefs
+        v = np.asarray(mat, dtype=np.complex128).reshape(-1)
+        cur = np.asarray(self.coefs)
+        if v.size != cur.size:
+            raise ValueError("CoefStruct::setCoefs: coefficient vector size does not match")
+        self.coefs = v.reshape(cur.shape, order="F").copy()
+        return None
+
+    def setGravConstant(self, G: float) -> None:
+        self.G = float(G)
+
+    def getGravConstant(self) -> float:
+        return self._owner.getGravConstant() if self._owner is not None else self.G
+
+
 @dataclasses.dataclass
-class SphStruct:
+class SphStruct(_CoefStructAPI):
     """``CoefClasses::SphStruct``: complex coefficients [(L+1)(L+2)/2, nmax] (m >= 0 only)."""
-    lmax: int
-    nmax: int
-    scale: float
-    time: float
-    coefs: np.ndarray
-    ctr: np.ndarray
-    rot: np.ndarray
+    lmax: int = 0
+    nmax: int = 0
+    scale: float = 1.0
+    time: float = 0.0
+    coefs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((0, 0), dtype=np.complex128))
+    ctr: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(3))
+    rot: np.ndarray = dataclasses.field(default_factory=lambda: np.eye(3))
     normed: bool = True
     geometry: str = "sphere"
 
+    def create(self) -> None:
+        """``SphStruct::create`` (expui/CoefStruct.cc:43-49): zeroed storage for the orders that are set."""
+        if self.nmax <= 0:
+            raise RuntimeError("SphStruct::create: nmax must be >0")
+        self.coefs = np.zeros(((self.lmax + 1) * (self.lmax + 2) // 2, self.nmax), dtype=np.complex128)
+
+    def assign(self, mat, lmax: int, nmax: int) -> None:
+        """``SphStruct::assign`` (expui/CoefStruct.H:158-164)."""
+        mat = np.asarray(mat, dtype=np.complex128)
+        self.lmax, self.nmax = int(lmax), int(nmax)
+        rows = (self.lmax + 1) * (self.lmax + 2) // 2
+        if mat.shape != (rows, self.nmax):
+            raise ValueError(f"SphStruct::assign: matrix of shape {mat.shape}, expected {(rows, self.nmax)}")
+        self.coefs = mat.copy()
+
 
 @dataclasses.dataclass
-class CylStruct:
+class CylStruct(_CoefStructAPI):
     """``CoefClasses::CylStruct``: complex coefficients [mmax+1, nmax] = cos + i sin."""
-    mmax: int
-    nmax: int
-    time: float
-    coefs: np.ndarray
-    ctr: np.ndarray
-    rot: np.ndarray
+    mmax: int = 0
+    nmax: int = 0
+    time: float = 0.0
+    coefs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((0, 0), dtype=np.complex128))
+    ctr: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(3))
+    rot: np.ndarray = dataclasses.field(default_factory=lambda: np.eye(3))
     geometry: str = "cylinder"
+
+    def create(self) -> None:
+        """``CylStruct::create`` (expui/CoefStruct.cc:35-41)."""
+        if self.nmax <= 0:
+            raise RuntimeError("CylStruct::create: nmax must be >0")
+        self.coefs = np.zeros((self.mmax + 1, self.nmax), dtype=np.complex128)
+
+    def assign(self, mat, mmax: int, nmax: int) -> None:
+        """``CylStruct::assign`` (expui/CoefStruct.H:204-210)."""
+        mat = np.asarray(mat, dtype=np.complex128)
+        self.mmax, self.nmax = int(mmax), int(nmax)
+        if mat.shape != (self.mmax + 1, self.nmax):
+            raise ValueError(f"CylStruct::assign: matrix of shape {mat.shape}, expected {(self.mmax + 1, self.nmax)}")
+        self.coefs = mat.copy()
 
 
 class BiorthBasis:
@@ -1173,7 +1273,7 @@ class AllTimeAccel(AccelFunc):
         basis, coefs = mod[0], mod[1]
         t1, t2, a, b = _bracket(coefs.Times(), t, "AllTimeAccel")
         A, B = coefs.getCoefStruct(t1), coefs.getCoefStruct(t2)
-        new = copy.deepcopy(A)
+        new = A.deepcopy()
         new.time = t
         new.coefs = a * np.asarray(A.coefs) + b * np.asarray(B.coefs)
         new.ctr = a * np.asarray(A.ctr, dtype=np.float64) + b * np.asarray(B.ctr, dtype=np.float64)
@@ -1193,7 +1293,7 @@ class SingleTimeAccel(AccelFunc):
         for basis, coefs in [(m[0], m[1]) for m in mod]:
             t1, t2, a, b = _bracket(coefs.Times(), t, "SingleTimeAccel")
             A, B = coefs.getCoefStruct(t1), coefs.getCoefStruct(t2)
-            new = copy.deepcopy(A)
+            new = A.deepcopy()
             new.time = t
             new.coefs = a * np.asarray(A.coefs) + b * np.asarray(B.coefs)
             if np.size(A.ctr) and np.size(B.ctr):

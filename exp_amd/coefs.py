@@ -249,7 +249,8 @@ class Coefs:
         ret.deltaT = self.deltaT
         ret.units = list(self.units)
         for t, c in self.coefs.items():
-            ret.coefs[t] = copy.deepcopy(c)
+            ret.coefs[t] = c.deepcopy() if hasattr(c, "deepcopy") else copy.deepcopy(c)
+            ret.coefs[t]._owner = ret
         return ret
 
     # -- values at one time (``__call__`` is the pybind operator, pyEXP/CoefWrappers.cc:1559, :1634) --
@@ -451,6 +452,7 @@ class SphCoefs(Coefs):
 
     # -- container (expui/Coefficients.H) -------------------------------------------------------
     def add(self, c: SphStruct) -> None:
+        c._owner = self                      # CoefStruct::setOwner: the set reports the container's G from now on
         self.coefs[round_time(c.time)] = c
 
     def Times(self) -> List[float]:
@@ -694,6 +696,7 @@ class CylCoefs(Coefs):
                 and fid.value.decode() == getattr(self, "_force_id", "cylinder"))
 
     def add(self, c: CylStruct) -> None:
+        c._owner = self
         self.coefs[round_time(c.time)] = c
 
     def Times(self) -> List[float]:

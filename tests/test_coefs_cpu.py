@@ -203,3 +203,55 @@ def test_coefs_container_surface(tmp_path):
             wrong.ExtendH5Coefs(h5)
     with pytest.raises(RuntimeError, match="does not exist"):
         Coefs.factory(str(tmp_path / "nothing"))
+
+
+def test_coefstruct_surface():
+    """``CoefStruct`` / ``SphStruct`` / ``CylStruct`` as pyEXP exposes them (pyEXP/CoefWrappers.cc:720-1000; expui/CoefStruct.H):
+    default construction, assign / create, the flat column-major store, in-place access, time / centre / orientation,
+    deep copies, and the gravitational constant of a free set against that of its container."""
+    from exp_amd.basis import CylStruct, SphStruct
+    from exp_amd.coefs import SphCoefs
+    rng = np.random.default_rng(9)
+    s = SphStruct()
+    assert (s.lmax, s.nmax, s.scale, s.geometry, s.time) == (0, 0, 1.0, "sphere", 0.0)
+    with pytest.raises(RuntimeError, match="nmax must be >0"):
+        s.create()
+    mat = rng.normal(size=(6, 4)) + 1j * rng.normal(size=(6, 4))
+    s.assign(mat, 2, 4)
+    assert (s.lmax, s.nmax) == (2, 4) and np.array_equal(s.coefs, mat)
+    assert np.array_equal(s.getCoefs(), mat.reshape(-1, order="F"))                 # Eigen's column-major store
+    with pytest.raises(ValueError, match="size does not match"):
+        s.setCoefs(np.zeros(5))
+    s.setCoefs(2.0 * s.getCoefs())
+    assert np.array_equal(s.coefs, 2.0 * mat)
+    ref = s.setCoefs()                                       # read-write access: changes land in the structure
+    ref[1, 2] = 7.0 - 1.0j
+    assert s.coefs[1, 2] == 7.0 - 1.0j
+    s.setCoefTime(0.75); s.setCoefCenter([0.1, 0.2, 0.3]); s.setCoefRotation(2.0 * np.eye(3))
+    assert s.getCoefTime() == 0.75 and s.time == 0.75 and np.array_equal(s.center, [0.1, 0.2, 0.3])
+    assert np.array_equal(s.getCoefCenter(), s.center) and np.array_equal(s.orient, 2.0 * np.eye(3))
+    assert np.array_equal(s.getCoefRotation(), s.orient)
+    c = s.deepcopy()
+    c.coefs[0, 0] = 0.0
+    assert s.coefs[0, 0] != 0.0 and c.time == 0.75
+    s.zerodata()
+    assert not s.coefs.any() and s.coefs.shape == (6, 4)
+    z = SphStruct(lmax=1, nmax=3)
+    z.create()
+    assert z.coefs.shape == (3, 3) and not z.coefs.any()
+    # G: the structure's own value until a container owns it (expui/CoefStruct.cc:16-22)
+    z.setGravConstant(4.3)
+    assert z.getGravConstant() == 4.3
+    cs = SphCoefs("x")
+    cs.setUnits("G", "mixed", 43007.1)
+    cs.add(z)
+    assert z.getGravConstant() == cs.getGravConstant() == float(np.float32(43007.1))
+    y = CylStruct()
+    assert (y.mmax, y.nmax, y.geometry) == (0, 0, "cylinder")
+    m2 = rng.normal(size=(3, 5)) + 1j * rng.normal(size=(3, 5))
+    y.assign(m2, 2, 5)
+    assert np.array_equal(y.getCoefs(), m2.reshape(-1, order="F"))
+    with pytest.raises(ValueError):
+        y.assign(m2, 3, 5)
+    with pytest.raises(RuntimeError, match="nmax must be >0"):
+        CylStruct().create()
