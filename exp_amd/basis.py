@@ -883,6 +883,20 @@ class Cylindrical(BiorthBasis):
         # the number of vertically antisymmetric functions per m (expui/BiorthBasis.cc:1389, :1470; EmpCylSL's constructor
         # keeps the even / odd split only for 0 <= ncylodd <= nmax, exputil/EmpCylSL.cc:178-185)
         self.ncylodd = int(g("ncylodd", 9))
+        # the conditioning of the basis (expui/BiorthBasis.cc:1397-1440, :1475-1495, :1543): azimuthal knots, the shift of the
+        # m >= 1 targets along x, the functional form of the target disk and its parameters
+        self.pnum = max(1, int(g("pnum", 1)))
+        self.ashift = float(g("ashift", 0.0))
+        self.sech2 = bool(g("sech2", False))
+        self.dtype = str(g("dtype", "exponential")).lower()
+        if self.dtype not in ("constant", "gaussian", "mn", "exponential", "doubleexpon", "diskbulge", "python"):
+            raise RuntimeError("Cylindrical::initialize: invalid DiskType")
+        if self.dtype == "python":
+            raise RuntimeError("Cylindrical: dtype 'python' (a user density through pyname) is not supported: pass the "
+                               "callable to exp_amd.empcyl.build_empcyl(dens=...) and hand the cache to the basis")
+        self.aratio, self.hratio = float(g("aratio", 1.0)), float(g("hratio", 1.0))
+        self.dweight, self.Mfac, self.HERNA = float(g("dweight", 1.0)), float(g("Mfac", 1.0)), float(g("HERNA", 0.10))
+        self.rwidth, self.rtrunc = float(g("rwidth", 0.0)), float(g("rtrunc", 0.1))
         self.cachename = g("cachename", "")
         if "eof_file" in conf:                   # the deprecated spelling wins when both are given (:1471-1472, :1517-1526)
             print("Cylinder: parameter 'eof_file' is deprecated. and will be removed in a future release. Please use "
@@ -948,7 +962,51 @@ class Cylindrical(BiorthBasis):
                             acyl=self.acyl, hcyl=self.hcyl, rcylmin=self.rcylmin,
                             rcylmax=self.rcylmax, lmaxfid=self.lmaxfid, nmaxfid=self.nmaxfid,
                             numr=self.ncylr, cmapr=self.cmapr, cmapz=self.cmapz, rnum=self.rnum,
-                            tnum=self.tnum, nodd=self.ncylodd)
+                            tnum=self.tnum, nodd=self.ncylodd, pnum=self.pnum, ashift=self.ashift,
+                            dens=self.DiskDens)
+
+    def DiskDens(self, R, z, phi=0.0):
+        """``Cylindrical::DiskDens`` (expui/BiorthBasis.cc:1265-1341): the target density the basis is conditioned on, by
+        ``dtype``; numpy arrays in, arrays out."""
+        R, z = np.asarray(R, dtype=np.float64), np.asarray(z, dtype=np.float64)
+        a, h0 = self.acyl, self.hcyl
+        pi = math.pi
+
+        def sech2_of(zz, h):                       # 1 / cosh^2 without overflow
+            f = np.exp(-np.abs(zz) / h)
+            sq = 2.0 * f / (1.0 + f * f)
+            return sq * sq
+
+        if self.dtype == "constant":
+            ans = np.where((R < a) & (np.abs(z) < h0), 1.0 / (2.0 * h0 * pi * a * a), 0.0)
+        elif self.dtype == "gaussian":
+            ans = np.where(np.abs(z) < h0, 1.0 / (2.0 * h0 * 2.0 * pi * a * a) * np.exp(-R * R / (2.0 * a * a)), 0.0)
+        elif self.dtype == "mn":
+            Z2 = z * z + h0 * h0
+            Z = np.sqrt(Z2)
+            Q2 = (a + Z) * (a + Z)
+            ans = 0.25 * h0 * h0 / pi * (a * R * R + (a + 3.0 * Z) * Q2) / ((R * R + Q2) ** 2.5 * Z * Z2)
+        elif self.dtype == "doubleexpon":
+            a1, a2, h1, h2 = a, a * self.aratio, h0, h0 * self.hratio
+            w1, w2 = 1.0 / (1.0 + self.dweight), self.dweight / (1.0 + self.dweight)
+            if self.sech2:
+                h1, h2 = 0.5 * h1, 0.5 * h2
+            ans = (w1 * np.exp(-R / a1) * sech2_of(z, h1) / (4.0 * pi * a1 * a1 * h1) +
+                   w2 * np.exp(-R / a2) * sech2_of(z, h2) / (4.0 * pi * a2 * a2 * h2))
+        elif self.dtype == "diskbulge":
+            h = 0.5 * h0 if self.sech2 else h0
+            rr = np.sqrt(R * R + z * z)
+            w1, w2, as_ = self.Mfac, 1.0 - self.Mfac, self.HERNA
+            with np.errstate(divide="ignore", invalid="ignore"):
+                bulge = w2 * as_ ** 4 / (2.0 * pi * rr) * (rr + as_) ** -3.0 if w2 != 0.0 else 0.0
+            ans = w1 * np.exp(-R / a) * sech2_of(z, h) / (4.0 * pi * a * a * h) + bulge
+        else:                                      # exponential
+            h = 0.5 * h0 if self.sech2 else h0
+            ans = np.exp(-R / a) * sech2_of(z, h) / (4.0 * pi * a * a * h)
+        if self.rwidth > 0.0:
+            from scipy.special import erf
+            ans = ans * erf((self.rtrunc - R) / self.rwidth)
+        return ans
 
     def _even_odd(self):
         """(neven, nodd) as the cache records them (exputil/EmpCylSL.cc:98-99, :182-184): zeros without the split"""

@@ -213,14 +213,22 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
                  acyl: float = 0.01, hcyl: float = 0.002, rcylmin: float = 0.001,
                  rcylmax: float = 20.0, lmaxfid: int = 32, nmaxfid: int = 24, numr: int = 2000,
                  cmapr: int = 1, cmapz: int = 1, rnum: int = 200, tnum: int = 80,
-                 dens: Optional[Callable] = None, nodd: Optional[int] = None) -> EmpCylGrid:
+                 dens: Optional[Callable] = None, nodd: Optional[int] = None, pnum: int = 1,
+                 ashift: float = 0.0) -> EmpCylGrid:
     """``nodd`` (the reference's ``ncylodd``; EmpCylSL's constructor argument, exputil/EmpCylSL.cc:178-185): with
     0 <= nodd <= norder the functions are chosen by vertical parity -- the norder - nodd largest-variance combinations
     of the helper functions with l + m even (symmetric about the plane) first, then the nodd largest-variance ones with
     l + m odd (``lE`` / ``lO``, ``SCe`` / ``SCo``, :2250-2268, :2743-2858; tabulated even first, :1680-1760).  None or out
-    of range: the norder largest-variance combinations whatever their parity."""
+    of range: the norder largest-variance combinations whatever their parity.
+
+    ``pnum`` azimuthal knots (at least one, src/Cylinder.cc:168, expui/BiorthBasis.cc:1543) and ``ashift``: with more than
+    one knot the covariance of the cosine and of the sine functions of an m >= 1 are integrated separately under a
+    conditioning density folded into [-pi/m, pi/m] and shifted by ashift * acyl along x (``dcond``, src/Cylinder.cc:
+    325-348, expui/BiorthBasis.cc:1345-1366; ``generate_eof``, exputil/EmpCylSL.cc:2455-2500) -- the sine tables then
+    differ from the cosine tables.  One knot: the azimuthal average, sine tables = cosine tables."""
     ASCALE, HSCALE, RMIN, RMAX = acyl, hcyl, rcylmin, rcylmax
     even_odd = nodd is not None and 0 <= nodd <= norder
+    nump = max(1, int(pnum))
     pfac = 1.0 / math.sqrt(ASCALE)           # exputil/EmpCylSL.cc:173-175
     ffac = pfac / ASCALE
     dens = dens or default_disk_density(acyl, hcyl)
@@ -248,13 +256,21 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
     rr_q = xi_to_r(xi_q, ASCALE, cmapr)                        # [rnum]
     potd_q, _ = sl_eval(sl, rr_q / ASCALE, want_force=False)   # [rnum, L+1, nmax]
     costh = -1.0 + 2.0 * kt                                    # [tnum]
-    dphi = 2.0 * math.pi                                       # nump = 1
+    dphi = 2.0 * math.pi / nump
     RR, CT = np.meshgrid(rr_q, costh, indexing="ij")           # [rnum, tnum]
     Rq = RR * np.sqrt(1.0 - CT * CT)
     zq = RR * CT
     jfac = (dphi * 2.0 * wt[None, :] * (XMAX - XMIN) * wr[:, None] * RR * RR /
             d_xi_to_r(xi_q, ASCALE, cmapr)[:, None])
-    wq = (dens(Rq, zq) * jfac).reshape(-1)                     # [rnum*tnum]
+    wq = (dens(Rq, zq) * jfac).reshape(-1)                     # [rnum*tnum]: the unshifted density (m = 0, or one knot)
+
+    def dcond(phi, M):
+        """the conditioning density of harmonic M >= 1 at azimuth phi, times jfac"""
+        dmult = math.pi / M
+        phiS = phi + dmult * int((2.0 * math.pi - phi) / dmult) if phi > math.pi else phi - dmult * int(phi / dmult)
+        x = Rq * math.cos(phiS) - ashift * acyl
+        y = Rq * math.sin(phiS)
+        return (dens(np.sqrt(x * x + y * y), zq) * jfac).reshape(-1)
 
     # grid nodes for the tabulation (compute_eof_grid :1475-1492)
     xg = XMIN + dX * np.arange(numx + 1)
@@ -278,13 +294,21 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
         # 3. covariance: v[(l-m), ir] = pfac * P_l^m(cos) * potd(l, ir) [* 1/2 for m>0, nump = 1]
         Pq, _ = _legendre_all(lmaxfid, m, costh)                # [tnum, nl]
         V = (pfac * Pq[None, :, :, None] * potd_q[:, None, m:, :])  # [rnum, tnum, nl, nmax]
-        if m > 0:
-            V = 0.5 * V
         V = V.reshape(rnum * tnum, nl * nmaxfid)                # nn = ir + NMAX*(l-m)
-        SC = (V * wq[:, None]).T @ V
-        mx = np.abs(SC).max()
-        if mx > 1e-5:
-            SC = SC / mx
+        SS = None
+        if m == 0:
+            SC = (V * (wq * nump)[:, None]).T @ V               # (every knot adds the same)
+        elif nump == 1:
+            SC = 0.25 * ((V * wq[:, None]).T @ V)               # facC = facS = V / 2
+        else:
+            SC = np.zeros((V.shape[1], V.shape[1]))
+            SS = np.zeros_like(SC)
+            for qp in range(nump):
+                phi = dphi * qp
+                w = dcond(phi, m)
+                VW = (V * w[:, None]).T @ V
+                SC += math.cos(m * phi) ** 2 * VW
+                SS += math.sin(m * phi) ** 2 * VW
         def top(mat, k):
             mx_ = np.abs(mat).max()
             if mx_ > 1e-5:
@@ -294,20 +318,24 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
             nf = min(4, v.shape[0]) - 1
             return v * np.where(v[nf, :] < 0.0, -1.0, 1.0)[None, :]
 
-        if even_odd:
+        def functions(mat):
+            if not even_odd:
+                return top(mat, norder)
             # columns nn = ir + NMAX * (l - m): the two parities do not mix under a density symmetric about the plane, and
             # each is decomposed in its own index space nn' = ir + NMAX * il (il counts the l of that parity)
             lpar = np.repeat((np.arange(m, lmaxfid + 1) + m) % 2, nmaxfid)          # 0: l + m even
             ce, co = np.flatnonzero(lpar == 0), np.flatnonzero(lpar == 1)
-            ef = np.zeros((nl * nmaxfid, norder))
+            out = np.zeros((nl * nmaxfid, norder))
             ne = norder - nodd
-            ve = top(SC[np.ix_(ce, ce)], ne)
-            ef[ce, :ve.shape[1]] = ve
+            ve = top(mat[np.ix_(ce, ce)], ne)
+            out[ce, :ve.shape[1]] = ve
             if nodd and co.size:
-                vo = top(SC[np.ix_(co, co)], nodd)
-                ef[co, ne:ne + vo.shape[1]] = vo
-        else:
-            ef = top(SC, norder)
+                vo = top(mat[np.ix_(co, co)], nodd)
+                out[co, ne:ne + vo.shape[1]] = vo
+            return out
+
+        ef = functions(SC)
+        efS = functions(SS) if SS is not None else ef             # one knot: the sine functions ARE the cosine functions
 
         # 4. tabulation
         Pg, dPg = _legendre_all(lmaxfid, m, cg)                 # [npts, nl]
@@ -318,19 +346,14 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
         frR = -(potr * (Rg / rrg)[:, None, None] - pott * (Zg * Rg / rrg ** 3)[:, None, None])
         frZ = -(potr * (Zg / rrg)[:, None, None] + pott * (Rg * Rg / rrg ** 3)[:, None, None])
         npts = Rg.size
-        tp = potl.reshape(npts, -1) @ ef                          # [npts, norder]
-        tr = frR.reshape(npts, -1) @ ef
-        tz = frZ.reshape(npts, -1) @ ef
-        for k, arr in ((0, tp), (1, tr), (2, tz)):
-            t = arr.T.reshape(norder, numx + 1, numy + 1)
-            tab[k, m] = t
-            if m > 0:
-                tab[k + 3, m] = t            # nump = 1: sine block == cosine block
-        # density (compute_eof_grid :1507, :1518, :1534): fac * P_lm * dend * dfac / (4 pi)
-        dn = ((fac * dfac * 0.25 / math.pi) * Pg[:, :, None] * dend_g[:, m:, :]).reshape(npts, -1) @ ef
-        dtab[0, m] = dn.T.reshape(norder, numx + 1, numy + 1)
-        if m > 0:
-            dtab[1, m] = dtab[0, m]
+        dnb = ((fac * dfac * 0.25 / math.pi) * Pg[:, :, None] * dend_g[:, m:, :]).reshape(npts, -1)
+        for off, vec in ((0, ef), (3, efS)):
+            if off and m == 0:
+                continue
+            for k, arr in ((0, potl), (1, frR), (2, frZ)):
+                tab[k + off, m] = (arr.reshape(npts, -1) @ vec).T.reshape(norder, numx + 1, numy + 1)
+            # density (compute_eof_grid :1507, :1518, :1534): fac * P_lm * dend * dfac / (4 pi)
+            dtab[off // 3, m] = (dnb @ vec).T.reshape(norder, numx + 1, numy + 1)
     _limit.__exit__(None, None, None)
     return EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
                       ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,

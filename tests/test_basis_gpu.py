@@ -638,3 +638,55 @@ parameters:
     # ... and a single particle above the plane does excite them
     one = np.abs(disk_basis.createFromArray(np.array([1.0]), pos[:1]).coefs)
     assert one[:, 5:].max() > 1e-3 * one[:, :5].max()
+
+
+def test_cylindrical_conditioning_options(tmp_path):
+    """The keys that shape the conditioning of the disk basis (expui/BiorthBasis.cc:1265-1366, :1397-1440): ``pnum`` knots with a
+    shifted target (``ashift``) give sine functions of their own -- the projection then fetches both table sets --, ``sech2``
+    and ``dtype: doubleexpon`` change the target; every variant stays biorthogonal and its coefficients and accelerations
+    match the literal pyEXP twin of the oracle on the tables it produced."""
+    from exp_amd.basis import Basis
+    from exp_amd.models import sample_disk
+    from tests.oracle_lib import Oracle
+    orc = Oracle()
+    base = """
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  mmax: 3
+  nmax: 6
+  ncylodd: 2
+  ncylnx: 40
+  ncylny: 20
+  ncylr: 500
+  lmaxfid: 14
+  nmaxfid: 10
+  rnum: 40
+  tnum: 24
+"""
+    m, pos, _ = sample_disk(4000, 5, a=0.01, h=0.001)
+    pos[:, 0] += 0.004                                        # an off-centre disk: odd m are excited
+    test = np.random.default_rng(3).normal(0, 0.02, (200, 3)) * np.array([1.0, 1.0, 0.1])
+    tabs = {}
+    for tag, extra in (("plain", ""), ("shift", "  pnum: 6\n  ashift: 0.6\n"), ("sech2", "  sech2: true\n"),
+                       ("double", "  dtype: doubleexpon\n  aratio: 2.5\n  hratio: 0.5\n  dweight: 0.7\n")):
+        basis = Basis.factory(base + extra + f"  cachename: {tmp_path / ('eof.' + tag)}\n")
+        tabs[tag] = basis.grid.tab.copy()
+        oc = basis.orthoCheck()
+        assert max(np.abs(np.asarray(q) - np.eye(6)).max() for q in oc) < 0.2, tag        # (a 40 x 20 grid: coarse)
+        cs = basis.createFromArray(m, pos)
+        cc, ss, _ = orc.pyexp_cyl_accumulate(basis.grid, pos, m)
+        assert np.abs(cs.coefs.real - cc).max() <= 1e-10 * np.abs(cc).max(), tag
+        assert np.abs(cs.coefs.imag - ss).max() <= 1e-10 * np.abs(cc).max(), tag
+        a_ref = orc.pyexp_cyl_accel(basis.grid, cc, ss, test)
+        assert np.abs(basis.getAccel(test) - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max(), tag
+        assert basis.force.lib is not None
+    t = tabs["plain"]
+    assert np.array_equal(t[3:, 1:], t[:3, 1:])
+    s = tabs["shift"]
+    assert np.abs(s[3:, 1:] - s[:3, 1:]).max() > 0.02 * np.abs(s[:3]).max()
+    for tag in ("sech2", "double"):
+        assert np.abs(tabs[tag][:3] - t[:3]).max() > 1e-3 * np.abs(t[:3]).max(), tag
+    with pytest.raises(RuntimeError, match="invalid DiskType"):
+        Basis.factory(base + f"  dtype: toomre\n  cachename: {tmp_path / 'eof.bad'}\n")

@@ -245,3 +245,24 @@ def test_even_odd_function_split_of_the_disk_basis():
     for m in range(3):
         flat = split.tab[0, m].reshape(8, -1)
         assert np.linalg.matrix_rank(flat) == 8
+
+
+def test_azimuthal_knots_and_shifted_conditioning_of_the_disk_basis():
+    """``pnum`` / ``ashift`` (generate_eof's phi quadrature and ``dcond``, exputil/EmpCylSL.cc:2455-2500, src/Cylinder.cc:325-348):
+    several knots without a shift reproduce the one-knot basis (an axisymmetric target weights cos^2 and sin^2 alike);
+    with a shift the sine functions of m >= 1 part from the cosine functions while m = 0 -- never shifted -- stays put."""
+    from exp_amd.empcyl import build_empcyl
+    kw = dict(mmax=2, norder=6, numx=24, numy=12, acyl=0.01, hcyl=0.001, lmaxfid=12, nmaxfid=10, numr=300, rnum=30, tnum=20)
+    one = build_empcyl(**kw)
+    assert np.array_equal(one.tab[3:, 1:], one.tab[:3, 1:])
+    many = build_empcyl(pnum=8, **kw)
+    scale = np.abs(one.tab[:3]).max()
+    assert np.abs(many.tab[:3] - one.tab[:3]).max() <= 1e-10 * scale
+    assert np.abs(many.tab[3:, 1:] - many.tab[:3, 1:]).max() <= 1e-10 * scale
+    shifted = build_empcyl(pnum=8, ashift=0.5, **kw)
+    assert np.array_equal(shifted.tab[:3, 0], one.tab[:3, 0]) and np.all(shifted.tab[3:, 0] == 0.0)
+    assert np.abs(shifted.tab[3:, 1:] - shifted.tab[:3, 1:]).max() > 0.05 * scale
+    assert np.abs(shifted.tab[:3, 1:] - one.tab[:3, 1:]).max() > 0.01 * scale
+    assert np.isfinite(shifted.tab).all() and np.isfinite(shifted.dens).all()
+    # pnum below one is one (src/Cylinder.cc:168)
+    assert np.array_equal(build_empcyl(pnum=0, **kw).tab, one.tab)
