@@ -894,6 +894,11 @@ class Cylindrical(BiorthBasis):
         if self.dtype == "python":
             raise RuntimeError("Cylindrical: dtype 'python' (a user density through pyname) is not supported: pass the "
                                "callable to exp_amd.empcyl.build_empcyl(dens=...) and hand the cache to the basis")
+        for key, why in (("deproject", "the deprojected helper basis (EmpCylSL::create_deprojection)"),
+                         ("logr", "the logarithmic radial grid of the helper model (EmpCylSL::logarithmic)")):
+            if bool(g(key, False)):
+                raise RuntimeError(f"Cylindrical: '{key}: true' is not supported here -- {why} would give another basis than "
+                                   "the one this build makes; drop the key or supply the reference's cache file")
         self.aratio, self.hratio = float(g("aratio", 1.0)), float(g("hratio", 1.0))
         self.dweight, self.Mfac, self.HERNA = float(g("dweight", 1.0)), float(g("Mfac", 1.0)), float(g("HERNA", 0.10))
         self.rwidth, self.rtrunc = float(g("rwidth", 0.0)), float(g("rtrunc", 0.1))
