@@ -503,3 +503,58 @@ def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6
     assert np.abs(var["vel"] - v).max() <= 1e-10
     f.close()
     ctx.set_deterministic(False)
+
+
+def test_extrapolation_inside_rmin_with_the_logarithmic_map(ctx, oracle):
+    """Found by the randomised campaign (tools/dbg/fuzz_parity.py): with cmap = 2 a radius well inside rmin is extrapolated
+    over hundreds of cells (p = (xi - xi[1]) / dxi = -244 at rmin / 6 for numr 1500), and the reference's three-term radial
+    derivative (p - 1/2) H[0] - 2 p H[1] + (p + 1/2) H[2] (exputil/SLGridMP2.cc:954-989) cancels to ~1e-6 of its terms for
+    l = 0 (a Plummer core: the potential is flat there, the radial force a small difference of large numbers).  The device
+    evaluates the same quadratic as B + p A on the n-contracted table -- algebraically equal, rounded elsewhere.  Against
+    50-digit arithmetic on the oracle's own tables and coefficients NEITHER is exact to the parity tolerance there
+    (reference 1e-6, device 1e-5 of the particle's own, small, force; 1e-7 of the largest force in the set): a conditioning
+    limit of the extrapolation, not a difference of formulas -- at r >= 0.98 rmin (|p| < 4) the two agree to the usual
+    1e-9.  (cmap = 1 compresses r -> 0 to p > -3: no such regime.  EXP places rmin inside every particle.)"""
+    import mpmath as mp
+    from exp_amd.models import PlummerModel, sample_sphere
+    from exp_amd.runtime import Component, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    model = PlummerModel(1.0, 1.0, 1e-3, 50.0)
+    g = build_slgrid(model, 0, 7, numr=1500, rmin=1e-3, rmax=49.5, cmap=2, rmap=1.0, nel=24, P=6)
+    m, pos, _ = sample_sphere(model, 2000, seed=5)
+    probes = np.array([[1e-4, -1e-4, 1e-4], [0.98e-3 / np.sqrt(3)] * 3, [3e-4, 0.0, 0.0]])
+    pos[:3] = probes
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.sph_accumulate(g, prm, pos, m)
+    a_ref, _ = oracle.sph_accel(g, prm, pos, coef)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.set_coefs(coef)
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    a_dev = c.download(("acc",))["acc"]
+    c.close(); f.close()
+    # everything but the probes, and the probe at 0.98 rmin: the usual bar
+    scale = np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(a_dev[3:] - a_ref[3:]).max() <= 1e-9 * scale
+    assert np.abs(a_dev[1] - a_ref[1]).max() <= 1e-9 * scale
+    mp.mp.dps = 50
+    for k in (0, 2):
+        r = float(np.linalg.norm(pos[k]))
+        x = np.log(r)
+        p = (x - g.xi[1]) / g.dxi
+        assert p < -100.0
+        # the l = 0 radial sum in the reference's order (float64) and exactly
+        terms = [(p - 0.5) * g.ef[0, n, 0] * g.p0[0] - 2.0 * p * g.ef[0, n, 1] * g.p0[1] + (p + 0.5) * g.ef[0, n, 2] * g.p0[2]
+                 for n in range(g.nmax)]
+        s_ref = sum(t / np.sqrt(g.ev[0, n]) * coef[0, n] for n, t in enumerate(terms))
+        s_mp = sum(((mp.mpf(p) - mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 0]) * mp.mpf(g.p0[0]) - 2 * mp.mpf(p) * mp.mpf(g.ef[0, n, 1]) * mp.mpf(g.p0[1])
+                    + (mp.mpf(p) + mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 2]) * mp.mpf(g.p0[2])) / mp.sqrt(mp.mpf(g.ev[0, n])) * mp.mpf(coef[0, n])
+                   for n in range(g.nmax))
+        ref_err = abs(float((mp.mpf(s_ref) - s_mp) / s_mp))
+        assert ref_err > 1e-9                                 # the reference's own arithmetic is off by more than the parity bar
+        ar, ad = np.linalg.norm(a_ref[k]), np.linalg.norm(a_dev[k])
+        a_exact = ar * float(s_mp / mp.mpf(s_ref))            # (the radial force is this sum times factors both sides share)
+        e_ref, e_dev = abs(ar - a_exact) / ar, abs(ad - a_exact) / ar
+        assert e_dev <= 1e-3, (e_dev, e_ref)                  # bounded: a conditioning effect, not a formula difference
+        assert np.abs(a_dev[k] - a_ref[k]).max() <= 1e-6 * scale      # (1.2e-7 of the largest force in the set at rmin / 6)
