@@ -1,0 +1,116 @@
+"""Randomised block-multistep campaign (GPU): the C++ step driver against the n-body oracle (oracle/nbody_oracle.c) over
+random level counts, time steps, time-step criteria, component sizes, interaction lists, sparse-level thresholds and
+differencing routes; levels bit for bit, states and per-level coefficient sets to the tolerances of
+tests/test_config4_gpu.py.  One line per trial; a level mismatch of a handful of particles is a time-step criterion
+within rounding of a power-of-two boundary (reported as `edge`), anything else is a failure.
+
+    python tools/dbg/fuzz_multistep.py [trials=30] [seed=1]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+
+import tests.config4_util as c4
+from exp_amd.runtime import Component, Context, Cylinder, Simulation, SphereSL
+from tests.oracle_lib import NBodyOracle, Oracle
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc = Oracle()
+ctx = Context(0)
+g, cg = c4.grids()
+
+
+def one(t, rng):
+    ms = int(rng.integers(1, 5))
+    dtime = c4.DTIME * float(rng.choice([0.3, 1.0, 2.5]))
+    dyn = list(c4.DYN)
+    dyn[1] *= float(rng.choice([0.5, 1.0, 2.0]))
+    dyn[3] *= float(rng.choice([0.5, 1.0, 3.0]))
+    nh, nd = int(rng.choice([1, 130, 600, 2500])), int(rng.choice([1, 130, 600, 2500]))
+    inp = c4.config4_inputs(n_halo=nh, n_disk=nd)
+    which = rng.choice(["both", "halo", "disk"], p=[0.7, 0.15, 0.15])
+    inter = rng.choice(["both", "one", "none"], p=[0.6, 0.2, 0.2]) if which == "both" else "none"
+    dense_min, list_min = int(rng.choice([-1, 0, 50, 500])), int(rng.choice([0, 16, 2048]))
+    nsteps = int(rng.integers(1, 4))
+    sc = float(inp["scale"])
+    prm = orc.params(**c4.sph_window(g, sc))
+    nb = NBodyOracle(orc, ms, dtime, dyn)
+    ctx.set_dense_min(dense_min)
+    ctx.set_mover_list_min(list_min)
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=dyn, shiftlevl=0)
+    forces, comps, names, ids_o, ids_d = [], [], [], [], []
+    if which in ("both", "halo"):
+        ids_o.append(nb.add_sphere(g, prm, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"]))
+        f = SphereSL(ctx, g, multistep=ms, **c4.sph_window(g, sc))
+        c = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+        ids_d.append(sim.add_component(c, f)); forces.append(f); comps.append(c); names.append("halo")
+    if which in ("both", "disk"):
+        ids_o.append(nb.add_cylinder(cg, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"]))
+        f = Cylinder(ctx, cg, multistep=ms)
+        c = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+        ids_d.append(sim.add_component(c, f)); forces.append(f); comps.append(c); names.append("disk")
+    if inter in ("both", "one"):
+        nb.add_interaction(ids_o[0], ids_o[1]); sim.add_interaction(ids_d[0], ids_d[1])
+    if inter == "both":
+        nb.add_interaction(ids_o[1], ids_o[0]); sim.add_interaction(ids_d[1], ids_d[0])
+    nb.init()
+    sim.init()
+    status, detail = "ok", ""
+    switches = 0
+    for k in range(nsteps + 1):
+        if k:
+            nsw = nb.step()
+            sim.step(1)
+            switches += int(sum(nsw))
+            if sim.step_switches != sum(nsw):
+                status, detail = "STATE", f"step {k}: {sim.step_switches} level changes, oracle {sum(nsw)}"
+                break
+        for j, (name, f, c) in enumerate(zip(names, forces, comps)):
+            s = nb.state[j]
+            lev = c.download_levels()
+            nbad = int((lev != s["level"]).sum())
+            if nbad:
+                status, detail = ("edge" if nbad <= 3 else "LEVELS"), f"step {k} {name}: {nbad} levels differ"
+                break
+            out = c.download()
+            p = np.stack([s[q] for q in "xyz"], 1)
+            v = np.stack([s["v" + q] for q in "xyz"], 1)
+            a = np.stack([s["a" + q] for q in "xyz"], 1)
+            e = [np.abs(out["pos"] - p).max() / 1e-11, np.abs(out["vel"] - v).max() / (1e-9 * max(np.abs(v).max(), 1e-300)),
+                 np.abs(out["acc"] - a).max() / (1e-9 * max(np.linalg.norm(a, axis=1).max(), 1e-300)),
+                 np.abs(out["pot"] - s["pot"]).max() / (1e-9 * max(np.abs(s["pot"]).max(), 1e-300))]
+            cmax = max(np.abs(s["coefN"]).max(), 1e-300)
+            for M in range(ms + 1):
+                gn = f.get_coefs(level=M)
+                gn = gn.reshape(-1) if name == "halo" else np.concatenate([x.reshape(-1) for x in gn])
+                e.append(np.abs(gn - s["coefN"][M]).max() / (1e-10 * cmax))
+            if max(e) > 1.0 or not np.isfinite(max(e)):
+                status, detail = "STATE", f"step {k} {name}: worst ratio to tolerance {max(e):.2g} ({np.round(e, 2).tolist()})"
+                break
+        if status != "ok":
+            break
+    print(f"{t:3d} ms {ms} dtime {dtime:.2e} n {nh}/{nd} {which} inter {inter} dense_min {dense_min} list_min {list_min} steps {nsteps}: "
+          f"{status} {detail} [{switches} level changes, populated levels "
+          f"{[int((np.bincount(st['level'], minlength=ms + 1) > 0).sum()) for st in nb.state]}]", flush=True)
+    global total_switches
+    total_switches += switches
+    sim.close()
+    for c in comps:
+        c.close()
+    for f in forces:
+        f.close()
+    return status
+
+
+t0 = time.time()
+total_switches = 0
+tally = {"ok": 0, "edge": 0, "LEVELS": 0, "STATE": 0}
+for t in range(trials):
+    tally[one(t, np.random.default_rng([seed0, t]))] += 1
+ctx.set_dense_min(-1)
+ctx.set_mover_list_min(2048)
+print(f"{trials} trials: {tally}, {total_switches} level changes in all, {time.time() - t0:.0f} s")
+sys.exit(1 if tally["LEVELS"] or tally["STATE"] else 0)
