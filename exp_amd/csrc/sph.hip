@@ -262,6 +262,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_E.alloc(E.size()));
   A(f->d_lc.alloc(lcv.size()));
   A(f->d_ev.alloc((size_t)(L + 1) * nmax));
+  A(f->d_litef.alloc((size_t)6 * (L + 1) * nmax));
   A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_tscale.alloc(tscale.size()));
   A(f->d_wscale.alloc(wscale.size()));
@@ -281,6 +282,17 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   HIP_TRY(ctx, hipMemcpy(f->d_E.p, E.data(), E.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_lc.p, lcv.data(), lcv.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_ev.p, ev, (size_t)(L + 1) * nmax * sizeof(double), hipMemcpyHostToDevice));
+  {
+    // lit_ef[edge][k][l][n] = ef_l(n, node): nodes 0, 1, 2 (edge 0) and numr-3, numr-2, numr-1 (edge 1), undivided
+    std::vector<double> le((size_t)6 * (L + 1) * nmax);
+    for (int edge = 0; edge < 2; edge++)
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l <= L; l++)
+          for (int n = 0; n < nmax; n++)
+            le[(((size_t)edge * 3 + k) * (L + 1) + l) * nmax + n] =
+                ef[((size_t)l * nmax + n) * numr + (edge ? numr - 3 + k : k)];
+    HIP_TRY(ctx, hipMemcpy(f->d_litef.p, le.data(), le.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
                          hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_tscale.p, tscale.data(), tscale.size() * sizeof(double),
@@ -304,6 +316,18 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
     if (xi[i] != cfg->xmin + t) S.xi_uniform = 0;
   }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
+  // the literal radial derivative (sph_dp_lit): more than four cells outside the first / last force stencil -- which
+  // only the logarithmic map can reach (cmap 1 maps r -> 0 to within three cells of xmin; an unmapped grid is left alone)
+  S.lit_ef = f->d_litef.p; S.lit_ev = f->d_ev.p; S.lit_coef = f->d_coef.p;
+  S.lit_rowmap = f->d_rowmap.p; S.lit_tscale = f->d_tscale.p;
+  const bool lit_on = cfg->cmap == 2 && !getenv("EXP_AMD_NO_LITERAL");
+  f->lit_on = lit_on;
+  S.lit_list = nullptr;             // (sized to the target by accelerate())
+  S.lit_cap = 0;
+  S.lit_lo = lit_on ? -4.0 : -1.0e300;
+  S.lit_hi = lit_on ? 5.0 : 1.0e300;
+  S.lit_xlo = lit_on ? xi[1] - 4.0 * cfg->dxi : -1.0e300;
+  S.lit_xhi = lit_on ? xi[numr - 2] + 5.0 * cfg->dxi : 1.0e300;
   S.detC = 0.0;
   S.umass = 0.0;
   {
@@ -334,7 +358,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
 
 void SphForce::release()
 {
-  d_xi.release(); d_p0.release(); d_E.release(); d_lc.release();
+  d_xi.release(); d_p0.release(); d_E.release(); d_lc.release(); d_litef.release(); d_litlist.release();
   d_rowmap.release();
   d_tscale.release();
   d_ev.release(); d_d0.release(); d_Gd.release();
@@ -666,6 +690,17 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     const bool wfall = ctx->deterministic;
     const bool slow = !wfall && (foreign || all_sparse);
     uint32_t *cnt = f->d_work.p + SPH_WORK_STRIDE * f->work_cap;
+    if (f->lit_on) {
+      // room for every particle of this evaluation (a few ever land there: 4 bytes each beside the store's 186)
+      if (f->d_litlist.n < nr + 1) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        f->d_litlist.release();
+        if (f->d_litlist.alloc(nr + 1) != hipSuccess)
+          return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sph accelerate: hipMalloc of the literal-pass list failed");
+      }
+      S.lit_list = f->d_litlist.p;
+      S.lit_cap = (uint32_t)nr;
+    }
     SphForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_T4.p,
                    t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY),
                    t->a(A_VZ), dt_kick, assign ? 1 : 0, nr, grid, ctx->stream,
@@ -709,7 +744,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
 {
   SphForce *f = this;
   *handled = false;
-  if (f->cfg.multistep || ctx->split_min <= 0 || c->n < (size_t)ctx->split_min || c->n >= 0x7fffffffu)
+  if (f->cfg.multistep || ctx->split_min <= 0 || c->n < (size_t)ctx->split_min || c->n >= 0x7fffffffu || f->lit_on)
     return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);
   if (rc) return rc;

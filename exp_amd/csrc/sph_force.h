@@ -7,6 +7,9 @@ struct SphForce : exp_amd_force {
   exp_amd_sph_config cfg{};
   SphDev dev{};
   DevBuf<double> d_xi, d_p0, d_E, d_lc;
+  DevBuf<double> d_litef;           // raw eigenfunctions at the first and last force stencil (SphDev::lit_ef)
+  DevBuf<uint32_t> d_litlist;       // [1 + capacity]: slots left to the literal pass (SphDev::lit_list), cmap 2 only
+  bool lit_on = false;
   DevBuf<double> d_W, d_part, d_G, d_T4;
   DevBuf<int> d_rowmap;
   DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row

@@ -64,6 +64,23 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 {
   constexpr int LMAX = SPH_L;
+  // the logarithmic map only: the passes below leave the particles far outside the table on a list (SphDev::lit_list),
+  // the literal pass at the end takes them
+  struct LitPass {
+    const SphForceArgs &a;
+    explicit LitPass(const SphForceArgs &a_) : a(a_)
+    {
+      if (a.S.lit_list) (void)hipMemsetAsync(a.S.lit_list, 0, sizeof(uint32_t), a.stream);
+    }
+    ~LitPass()
+    {
+      if (!a.S.lit_list) return;
+      ProfScope ps(a.ctx, "k_sph_force_literal");
+      k_sph_force<LMAX, 3><<<64, 256, 0, a.stream>>>(
+          a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+          a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
+    }
+  } lit_pass(a);
   if (!a.all_slow) {
     // a.nwork[0..1]: two work-list counters used alternately; the general pass of launch k clears the
     // one launch k+1 will count into (no memset between the launches)

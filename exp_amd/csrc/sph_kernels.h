@@ -54,6 +54,21 @@ struct SphDev {
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
   const double *lc;      // [(lmax+1)*(lmax+1)][4] normalised-Legendre recurrence constants (below)
+  // Far extrapolation beyond the table (possible with the logarithmic map only: hundreds of cells inside rmin, or outside
+  // rmax in the pyEXP mode): the three-term radial derivative is then a small difference of large numbers and only the
+  // reference's own operation order reproduces its value (sph_dp_lit below).  lit_lo / lit_hi: the force offset pf
+  // below / above which a lane takes that evaluation (-/+ huge: never); lit_ef[edge][k][l][n]: the RAW eigenfunctions
+  // at the three nodes of the first (edge 0) and of the last (edge 1) force stencil; lit_ev[l][n]; lit_coef: the
+  // coefficient set the projected table was made from; lit_rowmap / lit_tscale: row and Legendre scale of a table slot.
+  double lit_lo, lit_hi;
+  double lit_xlo, lit_xhi;     // the same bounds in xi (the fast passes hand such lanes to the general pass)
+  const double *lit_ef, *lit_ev, *lit_coef, *lit_tscale;
+  const int *lit_rowmap;
+  // the evaluation passes do not carry that code (its calls would put scratch under every wave they launch): they
+  // append such a particle's slot to lit_list (lit_list[0] = count, entries from 1; lit_cap of them) and leave it to
+  // the literal pass (k_sph_force<LMAX, 3>) that follows
+  uint32_t *lit_list;
+  uint32_t lit_cap;
 };
 
 template <int I, int N, class F>
@@ -929,14 +944,49 @@ k_mstep_apply(const double *__restrict__ stage, const int2 *__restrict__ keys, c
 
 struct ForceOut { double potl, potr, pott, potp; };
 
+// The radial-derivative sum of one table slot, literally as the reference forms it: dpot(l, n) of SLGridSph::get_force
+// (exputil/SLGridMP2.cc:954-989: ((p - 1/2) ef[j-1] p0[j-1] - 2 p ef[j] p0[j] + (p + 1/2) ef[j+1] p0[j+1]) / sqrt(ev), each
+// product rounded on its own, no fused multiply-add), contracted with the coefficient row in ascending n
+// (get_pot_coefs_safe, src/SphericalBasis.cc).  The common factor d_xi_to_r / dxi stays outside (it multiplies the finished
+// sum here as everywhere on the device, a rounding of the RESULT, not of the cancelling terms).  Rare lanes only.
+__device__ __noinline__ double sph_dp_lit(const SphDev &S, int slot, int l, double p)
+{
+  const int row = S.lit_rowmap[slot];
+  if (row < 0) return 0.0;
+  const int edge = p < 0.0 ? 0 : 1;
+  const int j = edge ? S.numr - 2 : 1;
+  const size_t ln = (size_t)(S.lmax + 1) * S.nmax;
+  const double *e0 = S.lit_ef + ((size_t)edge * 3 + 0) * ln + (size_t)l * S.nmax;
+  const double *e1 = e0 + ln, *e2 = e1 + ln;
+  const double *c = S.lit_coef + (size_t)row * S.nmax;
+  const double pa = S.p0[j - 1], pb = S.p0[j], pc = S.p0[j + 1];
+  const double wm = p - 0.5, wp = p + 0.5, w2 = 2.0 * p;
+  double dp = 0.0;
+  for (int n = 0; n < S.nmax; n++) {
+    double a = wm * e0[n], b = w2 * e1[n], cc = wp * e2[n];
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(cc));          // (the products are rounded before the next factor joins)
+    a *= pa; b *= pb; cc *= pc;
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(cc));
+    double x = a - b;
+    asm volatile("" : "+v"(x));
+    x += cc;
+    const double d = x / sqrt(S.lit_ev[l * S.nmax + n]);
+    dp = mul_then_add(dp, d, c[n]);
+  }
+  return S.lit_tscale[slot] * dp;
+}
+
 // General (slow-path) evaluation: per-lane table gathers, exterior continuation by per-lane selects,
 // run-time flags, pole-clamped x in the derivative.  Waves that the fast pass deferred come here.
-template <int LMAX, class PT>
+template <int LMAX, class PT, bool LIT = false>
 __device__ __forceinline__ ForceOut
 sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT t4,
-          double x2, double pf, bool ioff, double rr, double kappa0)
+          double x2, double pf, bool ioff, double rr, double kappa0, double pf_lit = 0.0)
 {
   ForceOut o{0.0, 0.0, 0.0, 0.0};
+  // LIT: the instantiation for lanes far outside the table (sph_field_lit below); pf_lit: their force offset by the
+  // reference's own division
+  [[maybe_unused]] const bool lit = LIT && !ioff && (pf_lit < S.lit_lo || pf_lit > S.lit_hi);
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
@@ -983,6 +1033,7 @@ sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT
       if (on) {
         double pc = fma(x2, t4[q + 1], t4[q + 0]);
         double dpc = fma(pf, t4[q + 3], t4[q + 2]);
+        if constexpr (LIT) { if (lit) dpc = sph_dp_lit(S, q / 4, l, pf_lit); }
         pc *= rl;
         dpc = ioff ? (kappa0 * (l + 1)) * pc : dpc;
         Al = fma(plm, pc, Al);
@@ -991,6 +1042,7 @@ sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT
         if constexpr (m > 0) {
           double ps = fma(x2, t4[q + 5], t4[q + 4]);
           double dps = fma(pf, t4[q + 7], t4[q + 6]);
+          if constexpr (LIT) { if (lit) dps = sph_dp_lit(S, q / 4 + 1, l, pf_lit); }
           ps *= rl;
           dps = ioff ? (kappa0 * (l + 1)) * ps : dps;
           Bl = fma(plm, ps, Bl);
@@ -1318,10 +1370,12 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
                 uint32_t *__restrict__ nwork, uint32_t *__restrict__ key_out, double nk_dtk,
                 double nk_dtd, int store_v, unsigned long long lanemask = ~0ull)
 {
-  constexpr bool FAST = MODE != 0;
+  constexpr bool FAST = MODE != 0 && MODE != 3;
   const int lane = threadIdx.x & 63;
-  const size_t i = base + lane;
+  // MODE 3 (the literal pass): base / end index the list of slots the evaluation passes left behind
+  size_t i = base + lane;
   bool valid = i < end && ((lanemask >> lane) & 1ull);
+  if constexpr (MODE == 3) i = valid ? S.lit_list[1 + i] : 0;
   double xx = 1, yy = 0, zz = 0;          // idle lanes: a harmless off-axis point
   double px = 0, py = 0, pz = 0;          // kept for the next-step key (a reload at the end of the
   if (valid) {                            // wave would expose a full memory round trip)
@@ -1352,8 +1406,11 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
     // theta < 1e-6: sin(theta) = R/r and the reference's sqrt((1-x)(1+x)) differ by more than the
     // parity tolerance there (cancellation in 1-x), so those lanes take the reference's formula too
-    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
+    // (far outside the table -- the logarithmic map only -- the radial derivative takes the reference's literal
+    // evaluation in the general pass: sph_dp_lit)
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL) ||
+                         xi < S.lit_xlo || xi > S.lit_xhi;
     int idx = sph_cell(S, xi);
     ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
     dfac = -(r * r) * iR2;
@@ -1463,7 +1520,17 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double rr = S.rmax / r0;
     const double kappa0 = -P0 / (r0 * ffac);     // dp = -(l+1)/r0 * p, in units of ffac
     const double *t4 = T4 + (size_t)idx * tq;
-    o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+    if constexpr (MODE == 3) {
+      o = sph_field<LMAX, const double *, true>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0,
+                                                (xi - S.xi[jdx]) / S.dxi);
+    } else {
+      o = sph_field<LMAX>(S, costh, xc, cphi, sphi, t4, x2, pf, ioff, rr, kappa0);
+      // far outside the table: the literal pass takes the particle (sph_dp_lit)
+      if (valid && !ioff && (pf < S.lit_lo || pf > S.lit_hi)) {
+        const uint32_t k = atomicAdd(S.lit_list, 1u);
+        if (k < S.lit_cap) { S.lit_list[1 + k] = (uint32_t)i; valid = false; }
+      }
+    }
     ir = 1.0 / r;
     iR2 = 1.0 / fac;
   }
@@ -1487,6 +1554,14 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             uint32_t *__restrict__ nwork_clear /* counter of the NEXT launch pair: zeroed here */)
 {
   if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
+  if constexpr (MODE == 3) {
+    // the literal pass: a fixed small grid walks the list (its length is only known on the device)
+    const size_t n = S.lit_list[0] < S.lit_cap ? S.lit_list[0] : S.lit_cap;
+    for (size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n; base += (size_t)gridDim.x * 256)
+      sph_force_chunk<LMAX, 3>(S, X, Y, Z, base, n, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, nullptr, nullptr,
+                               key_out, nk_dtk, nk_dtd, store_v);
+    return;
+  }
   if constexpr (MODE == 0) {
     // the general pass is launched over every POSSIBLE work item and nearly all of its waves have none:
     // they leave on the count alone, before the level offsets (two more dependent round trips) are read
@@ -1568,8 +1643,9 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
   sqrt_rsqrt(fac, R, iR);
   const double iR2 = iR * iR;
   const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
-  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
   const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
+  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL) ||
+                       xi < S.lit_xlo || xi > S.lit_xhi;
   const int idx = sph_cell(S, xi);
   const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
   const double dfac = -(r * r) * iR2;
@@ -1632,7 +1708,12 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
     const double kappa0 = -P0g / (r0 * ffacg);
     const double *t4 = T4 + (size_t)idg * tq;
     const ForceOut og = sph_field<LMAX>(S, costh_g, xc, cphi_g, sphi_g, t4, y2, pfg, ioff, rr, kappa0);
-    if (valid && special)
+    bool mine = valid && special;
+    if (mine && !ioff && (pfg < S.lit_lo || pfg > S.lit_hi)) {       // far outside the table: the literal pass takes it
+      const uint32_t k = atomicAdd(S.lit_list, 1u);
+      if (k < S.lit_cap) { S.lit_list[1 + k] = (uint32_t)i; mine = false; }
+    }
+    if (mine)
       sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, fac, 1.0 / rg, 1.0 / fac, P0g, ffacg, dfacg, AX, AY, AZ,
                               POT, VX, VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
   }

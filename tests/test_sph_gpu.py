@@ -505,56 +505,87 @@ def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6
     ctx.set_deterministic(False)
 
 
-def test_extrapolation_inside_rmin_with_the_logarithmic_map(ctx, oracle):
+def test_extrapolation_inside_rmin_with_the_logarithmic_map(ctx, oracle, monkeypatch):
     """Found by the randomised campaign (tools/dbg/fuzz_parity.py): with cmap = 2 a radius well inside rmin is extrapolated
     over hundreds of cells (p = (xi - xi[1]) / dxi = -244 at rmin / 6 for numr 1500), and the reference's three-term radial
     derivative (p - 1/2) H[0] - 2 p H[1] + (p + 1/2) H[2] (exputil/SLGridMP2.cc:954-989) cancels to ~1e-6 of its terms for
-    l = 0 (a Plummer core: the potential is flat there, the radial force a small difference of large numbers).  The device
-    evaluates the same quadratic as B + p A on the n-contracted table -- algebraically equal, rounded elsewhere.  Against
-    50-digit arithmetic on the oracle's own tables and coefficients NEITHER is exact to the parity tolerance there
-    (reference 1e-6, device 1e-5 of the particle's own, small, force; 1e-7 of the largest force in the set): a conditioning
-    limit of the extrapolation, not a difference of formulas -- at r >= 0.98 rmin (|p| < 4) the two agree to the usual
-    1e-9.  (cmap = 1 compresses r -> 0 to p > -3: no such regime.  EXP places rmin inside every particle.)"""
+    l = 0 (a Plummer core: the potential is flat there, the radial force a small difference of large numbers).  Against
+    50-digit arithmetic on the oracle's own tables and coefficients the reference's value is itself off by more than the
+    parity tolerance there, so only ITS operation order reproduces it: lanes more than four cells outside the force
+    stencil take the literal per-(l, n) evaluation (sph_dp_lit, sph_kernels.h) -- 1e-9 again; with that switched off
+    (EXP_AMD_NO_LITERAL) the factored table form B + p A, algebraically equal, lands 1e-8 ... 1e-5 of the particle's force away (by basis).
+    (cmap = 1 compresses r -> 0 to p > -3: no such regime.)"""
     import mpmath as mp
     from exp_amd.models import PlummerModel, sample_sphere
     from exp_amd.runtime import Component, SphereSL
     from exp_amd.slgrid import build_slgrid
     model = PlummerModel(1.0, 1.0, 1e-3, 50.0)
-    g = build_slgrid(model, 0, 7, numr=1500, rmin=1e-3, rmax=49.5, cmap=2, rmap=1.0, nel=24, P=6)
+    g = build_slgrid(model, 2, 7, numr=1500, rmin=1e-3, rmax=49.5, cmap=2, rmap=1.0, nel=24, P=6)
     m, pos, _ = sample_sphere(model, 2000, seed=5)
-    probes = np.array([[1e-4, -1e-4, 1e-4], [0.98e-3 / np.sqrt(3)] * 3, [3e-4, 0.0, 0.0]])
-    pos[:3] = probes
+    pos[:, 2] *= 0.7
+    probes = np.array([[1e-4, -1e-4, 1e-4], [0.98e-3 / np.sqrt(3)] * 3, [3e-4, 0.0, 0.0], [2e-5, 1e-5, -4e-5]])
+    pos[:4] = probes
     prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
     coef, _ = oracle.sph_accumulate(g, prm, pos, m)
-    a_ref, _ = oracle.sph_accel(g, prm, pos, coef)
-    f = SphereSL(ctx, g)
-    c = Component.from_arrays(ctx, m, pos)
-    f.set_coefs(coef)
-    c.zero_acceleration(0)
-    f.get_acceleration_and_potential(c)
-    a_dev = c.download(("acc",))["acc"]
-    c.close(); f.close()
-    # everything but the probes, and the probe at 0.98 rmin: the usual bar
-    scale = np.linalg.norm(a_ref, axis=1).max()
-    assert np.abs(a_dev[3:] - a_ref[3:]).max() <= 1e-9 * scale
-    assert np.abs(a_dev[1] - a_ref[1]).max() <= 1e-9 * scale
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, coef)
+
+    def device():
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos)
+        f.set_coefs(coef)
+        c.zero_acceleration(0)
+        f.get_acceleration_and_potential(c)
+        out = c.download(("acc", "pot"))
+        c.close(); f.close()
+        return out
+
+    out = device()
+    own = np.linalg.norm(a_ref, axis=1)
+    assert (np.linalg.norm(out["acc"] - a_ref, axis=1) / own).max() <= ACC_TOL          # every particle, the probes included
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    monkeypatch.setenv("EXP_AMD_NO_LITERAL", "1")
+    off = device()
+    monkeypatch.delenv("EXP_AMD_NO_LITERAL")
+    rel = np.linalg.norm(off["acc"] - a_ref, axis=1) / own
+    assert rel[4:].max() <= ACC_TOL and rel[1] <= ACC_TOL                               # 0.98 rmin and outwards: no difference
+    assert rel[[0, 2, 3]].max() > 5 * ACC_TOL and rel[[0, 2, 3]].max() < 1e-3          # deep inside: the factored form drifts
+    # the reference's own value against exact arithmetic on the same tables (the l = 0 radial sum of probe 0)
     mp.mp.dps = 50
-    for k in (0, 2):
-        r = float(np.linalg.norm(pos[k]))
-        x = np.log(r)
-        p = (x - g.xi[1]) / g.dxi
-        assert p < -100.0
-        # the l = 0 radial sum in the reference's order (float64) and exactly
-        terms = [(p - 0.5) * g.ef[0, n, 0] * g.p0[0] - 2.0 * p * g.ef[0, n, 1] * g.p0[1] + (p + 0.5) * g.ef[0, n, 2] * g.p0[2]
-                 for n in range(g.nmax)]
-        s_ref = sum(t / np.sqrt(g.ev[0, n]) * coef[0, n] for n, t in enumerate(terms))
-        s_mp = sum(((mp.mpf(p) - mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 0]) * mp.mpf(g.p0[0]) - 2 * mp.mpf(p) * mp.mpf(g.ef[0, n, 1]) * mp.mpf(g.p0[1])
-                    + (mp.mpf(p) + mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 2]) * mp.mpf(g.p0[2])) / mp.sqrt(mp.mpf(g.ev[0, n])) * mp.mpf(coef[0, n])
-                   for n in range(g.nmax))
-        ref_err = abs(float((mp.mpf(s_ref) - s_mp) / s_mp))
-        assert ref_err > 1e-9                                 # the reference's own arithmetic is off by more than the parity bar
-        ar, ad = np.linalg.norm(a_ref[k]), np.linalg.norm(a_dev[k])
-        a_exact = ar * float(s_mp / mp.mpf(s_ref))            # (the radial force is this sum times factors both sides share)
-        e_ref, e_dev = abs(ar - a_exact) / ar, abs(ad - a_exact) / ar
-        assert e_dev <= 1e-3, (e_dev, e_ref)                  # bounded: a conditioning effect, not a formula difference
-        assert np.abs(a_dev[k] - a_ref[k]).max() <= 1e-6 * scale      # (1.2e-7 of the largest force in the set at rmin / 6)
+    x = np.log(float(np.linalg.norm(pos[0])))
+    p = (x - g.xi[1]) / g.dxi
+    assert p < -100.0
+    terms = [(p - 0.5) * g.ef[0, n, 0] * g.p0[0] - 2.0 * p * g.ef[0, n, 1] * g.p0[1] + (p + 0.5) * g.ef[0, n, 2] * g.p0[2]
+             for n in range(g.nmax)]
+    s_ref = sum(t / np.sqrt(g.ev[0, n]) * coef[0, n] for n, t in enumerate(terms))
+    s_mp = sum(((mp.mpf(p) - mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 0]) * mp.mpf(g.p0[0]) - 2 * mp.mpf(p) * mp.mpf(g.ef[0, n, 1]) * mp.mpf(g.p0[1])
+                + (mp.mpf(p) + mp.mpf(0.5)) * mp.mpf(g.ef[0, n, 2]) * mp.mpf(g.p0[2])) / mp.sqrt(mp.mpf(g.ev[0, n])) * mp.mpf(coef[0, n])
+               for n in range(g.nmax))
+    assert abs(float((mp.mpf(s_ref) - s_mp) / s_mp)) > 1e-9
+
+
+def test_pyexp_extrapolation_beyond_rmax_with_the_logarithmic_map(ctx, oracle):
+    """The other end: pyEXP's computeAccel has no exterior branch (expui/BiorthBasis.cc:818-926), so beyond rmax the tables
+    are extrapolated outwards -- with cmap = 2 over many cells again; the same literal evaluation keeps the device on
+    the literal pyEXP twin of the oracle."""
+    from exp_amd.models import PlummerModel, sample_sphere
+    from exp_amd.runtime import Component, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    model = PlummerModel(1.0, 1.0, 1e-3, 50.0)
+    g = build_slgrid(model, 3, 6, numr=800, rmin=1e-3, rmax=49.5, cmap=2, rmap=1.0, nel=24, P=6)
+    m, pos, _ = sample_sphere(model, 1500, seed=8)
+    pos[:, 0] += 0.05
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    coef, _ = oracle.pyexp_sph_accumulate(g, prm, pos, m)
+    test = np.concatenate([pos[:300], np.array([[70.0, 5.0, -3.0], [0.0, 120.0, 40.0], [-300.0, 10.0, 10.0], [49.6, 0.0, 0.1]])])
+    a_ref = oracle.pyexp_sph_accel(g, prm, coef, test)
+    f = SphereSL(ctx, g)
+    assert f.lib.exp_amd_sph_set_exterior(f.h, 0) == 0
+    assert f.lib.exp_amd_sph_set_dsmall(f.h, 1.0e-18) == 0                 # Spherical::computeAccel (expui/BiorthBasis.cc:824-825)
+    f.set_coefs(coef)
+    c = Component.from_arrays(ctx, np.full(len(test), 1.0), test)
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c, external=True)
+    acc = c.download(("acc",))["acc"]
+    c.close(); f.close()
+    own = np.linalg.norm(a_ref, axis=1)
+    assert (np.linalg.norm(acc - a_ref, axis=1) / own).max() <= ACC_TOL

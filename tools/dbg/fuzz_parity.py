@@ -63,12 +63,6 @@ def nasty_sphere(rng, model, g, scale, rmin, rmax, ctr):
                np.array([rmin, 0, 0]), np.array([rmin * (1 - 1e-12), 0, 0]), np.array([3 * rmax, rmax, -5 * rmax]),
                np.array([1e-9 * scale, 1e-9 * scale, scale]), np.array([scale, 0, 1e-200]), np.array([-scale, 1e-17, 0]),
                pos[0] - ctr, pos[0] - ctr, np.array([1e-4, -1e-4, 1e-4]) * scale]
-    if g.cmap == 2:
-        # With the logarithmic map a radius well inside rmin is extrapolated over hundreds of cells (p = -244 at rmin / 6,
-        # numr 1500): the reference's three-term derivative (exputil/SLGridMP2.cc:954-989) then cancels to ~6e-7 of its
-        # l = 0 terms, the device's factored form to ~1.4e-7 (measured against 50-digit arithmetic) -- neither is the
-        # other to 1e-9 there.  Such points stay within 2 % of rmin here; tests/test_sph_gpu.py holds the documented case.
-        special = [v if not (0 < np.linalg.norm(v) < 0.98 * rmin) else v * (0.98 * rmin / np.linalg.norm(v)) for v in special]
     for j, i in enumerate(idx):
         pos[i] = special[j] + ctr
     if n > 3 and rng.random() < 0.5:
