@@ -60,6 +60,7 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
   const double pf = (xi - S.xi[j]) / S.dxi;
   const double ffac = sph_d_xi_to_r(S, xi) / S.dxi;
   const double wa = (pf - 0.5) * S.p0[j - 1], wb = -2.0 * pf * S.p0[j], wc = (pf + 0.5) * S.p0[j + 1];
+  const bool lit = pf < S.lit_lo || pf > S.lit_hi;
   const double *g0 = G + (size_t)idx * S.nrows, *g1 = g0 + S.nrows;
   const double *ga = G + (size_t)(j - 1) * S.nrows, *gb = ga + S.nrows, *gc = gb + S.nrows;
   const double *q0 = Gd + (size_t)idx * S.nrows, *q1 = q0 + S.nrows;
@@ -95,7 +96,9 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
       if (S.EVEN_M && m > 0) row = l * l + (m - 1);
       const double sumP0 = P0 * (x1 * g0[row] + x2 * g1[row]);
       const double sumR0 = D0 * (x1 * q0[row] + x2 * q1[row]);
-      const double sumD0 = ffac * (wa * ga[row] + wb * gb[row] + wc * gc[row]);
+      // (far outside the table -- the logarithmic map only -- the radial derivative is formed term by term as the
+      // reference does: sph_dp_lit_row, sph_kernels.h)
+      const double sumD0 = ffac * (lit ? sph_dp_lit_row(S, row, l, pf) : wa * ga[row] + wb * gb[row] + wc * gc[row]);
       if (m == 0) {
         if (l == 0) { den0 = plm * sumR0; pot0 = plm * sumP0; potr += plm * sumD0; }
         else {
@@ -104,7 +107,8 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
       } else {
         const double sumP1 = P0 * (x1 * g0[row + 1] + x2 * g1[row + 1]);
         const double sumR1 = D0 * (x1 * q0[row + 1] + x2 * q1[row + 1]);
-        const double sumD1 = ffac * (wa * ga[row + 1] + wb * gb[row + 1] + wc * gc[row + 1]);
+        const double sumD1 = ffac * (lit ? sph_dp_lit_row(S, row + 1, l, pf)
+                                         : wa * ga[row + 1] + wb * gb[row + 1] + wc * gc[row + 1]);
         den1 += plm * (sumR0 * cosm + sumR1 * sinm);
         pot1 += plm * (sumP0 * cosm + sumP1 * sinm);
         potr += plm * (sumD0 * cosm + sumD1 * sinm);

@@ -949,10 +949,8 @@ struct ForceOut { double potl, potr, pott, potp; };
 // product rounded on its own, no fused multiply-add), contracted with the coefficient row in ascending n
 // (get_pot_coefs_safe, src/SphericalBasis.cc).  The common factor d_xi_to_r / dxi stays outside (it multiplies the finished
 // sum here as everywhere on the device, a rounding of the RESULT, not of the cancelling terms).  Rare lanes only.
-__device__ __noinline__ double sph_dp_lit(const SphDev &S, int slot, int l, double p)
+__device__ __noinline__ double sph_dp_lit_row(const SphDev &S, int row, int l, double p)
 {
-  const int row = S.lit_rowmap[slot];
-  if (row < 0) return 0.0;
   const int edge = p < 0.0 ? 0 : 1;
   const int j = edge ? S.numr - 2 : 1;
   const size_t ln = (size_t)(S.lmax + 1) * S.nmax;
@@ -973,7 +971,13 @@ __device__ __noinline__ double sph_dp_lit(const SphDev &S, int slot, int l, doub
     const double d = x / sqrt(S.lit_ev[l * S.nmax + n]);
     dp = mul_then_add(dp, d, c[n]);
   }
-  return S.lit_tscale[slot] * dp;
+  return dp;
+}
+// ... for a slot of the projected table (its coefficient row and the scale of the rescaled Legendre functions)
+__device__ __forceinline__ double sph_dp_lit(const SphDev &S, int slot, int l, double p)
+{
+  const int row = S.lit_rowmap[slot];
+  return row < 0 ? 0.0 : S.lit_tscale[slot] * sph_dp_lit_row(S, row, l, p);
 }
 
 // General (slow-path) evaluation: per-lane table gathers, exterior continuation by per-lane selects,

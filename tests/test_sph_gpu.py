@@ -586,6 +586,14 @@ def test_pyexp_extrapolation_beyond_rmax_with_the_logarithmic_map(ctx, oracle):
     c.zero_acceleration(0)
     f.get_acceleration_and_potential(c, external=True)
     acc = c.download(("acc",))["acc"]
-    c.close(); f.close()
     own = np.linalg.norm(a_ref, axis=1)
     assert (np.linalg.norm(acc - a_ref, axis=1) / own).max() <= ACC_TOL
+    # getFields (Spherical::crt_eval / sph_eval) at points far inside rmin and far outside rmax: every column per point
+    far = np.array([[1e-4, -1e-4, 1e-4], [3e-4, 0.0, 0.0], [2e-5, 1e-5, -4e-5], [0.1, 0.2, 0.3], [70.0, 5.0, -3.0],
+                    [0.0, 120.0, 40.0], [-300.0, 10.0, 10.0]])
+    x, y, z = far.T
+    r = np.linalg.norm(far, axis=1)
+    for ctype, args in (("cartesian", (x, y, z)), ("spherical", (r, z / r, np.arctan2(y, x)))):
+        got, ref = f.fields(*args, ctype), oracle.sph_fields(g, prm, coef, *args, ctype)
+        assert (np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= ACC_TOL, ctype
+    c.close(); f.close()
