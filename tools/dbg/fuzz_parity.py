@@ -89,9 +89,28 @@ def trial_sph(t, rng):
     c.zero_acceleration(0)
     f.get_acceleration_and_potential(c)
     out = c.download(("acc", "pot", "pos"))
+    # pyEXP's field evaluation of the same coefficient set at (some of) the same points, in a random coordinate type
+    sub = rng.choice(len(m), min(len(m), 300), replace=False)
+    q = pos[sub] - ctr
+    ctype = str(rng.choice(["cartesian", "cylindrical", "spherical"]))
+    if ctype == "cartesian":
+        args = (q[:, 0], q[:, 1], q[:, 2])
+    elif ctype == "cylindrical":
+        args = (np.hypot(q[:, 0], q[:, 1]), q[:, 2], np.arctan2(q[:, 1], q[:, 0]))
+    else:
+        rq = np.linalg.norm(q, axis=1)
+        with np.errstate(all="ignore"):
+            args = (rq, np.where(rq > 0, q[:, 2] / rq, 0.0), np.arctan2(q[:, 1], q[:, 0]))
+    f.set_coefs(c_ref)
+    with np.errstate(all="ignore"):
+        fg, fr = f.fields(*args, ctype), orc.sph_fields(g, prm, c_ref, *args, ctype)
+    finf = np.isfinite(fr).all(axis=1)
+    fsc = np.abs(fr[finf]).max(axis=0) if finf.any() else np.ones(9)
+    e_f = (np.abs(fg[finf] - fr[finf]).max(axis=0) / np.maximum(fsc, 1e-300)).max() if finf.any() else 0.0
+    same_f = np.array_equal(np.isfinite(fg).all(axis=1), finf)
     c.close(); f.close()
     cs = max(np.abs(c_ref).max(), 1e-300)
-    ok = used == used_ref and np.array_equal(out["pos"], pos)
+    ok = used == used_ref and np.array_equal(out["pos"], pos) and same_f and e_f <= ACC_TOL
     e_c = np.abs(coef - c_ref).max() / cs
     fin = np.isfinite(a_ref).all(axis=1) & np.isfinite(p_ref)
     same_nan = np.array_equal(np.isfinite(out["acc"]).all(axis=1) & np.isfinite(out["pot"]), fin)
@@ -101,6 +120,7 @@ def trial_sph(t, rng):
     e_p = np.abs(out["pot"][fin] - p_ref[fin]).max() / psc if fin.any() else 0.0
     ok = ok and same_nan and e_c <= COEF_TOL and e_a <= ACC_TOL and e_p <= ACC_TOL
     print(f"sph {t:3d} {key} scale {scale} flags {[k for k, v in flags.items() if v]} n {len(m)}: coef {e_c:.1e} acc {e_a:.1e} pot {e_p:.1e} "
+          f"fields[{ctype[:3]}] {e_f:.1e}{'' if same_f else ' NAN-PATTERN'} "
           f"used {used}/{used_ref} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok and fin.any():
         d = np.abs(out["acc"] - a_ref).max(axis=1)
