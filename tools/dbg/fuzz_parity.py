@@ -26,6 +26,16 @@ COEF_TOL, ACC_TOL = 1e-10, 1e-9
 _sl, _cy = {}, {}
 
 
+def field_err(got, ref):
+    """density, potential and force columns each against the largest value of THEIR group over the points (a column that is
+    identically zero -- the azimuthal force on the axis -- has no scale of its own)"""
+    e = 0.0
+    for a, b in ((0, 3), (3, 6), (6, 9)):
+        sc = max(np.abs(ref[:, a:b]).max(), 1e-300)
+        e = max(e, np.abs(got[:, a:b] - ref[:, a:b]).max() / sc)
+    return e
+
+
 def sl_grid(rng):
     kind = rng.choice(["plummer", "nfw"])
     lmax, nmax = int(rng.integers(0, 13)), int(rng.integers(1, 21))
@@ -105,8 +115,7 @@ def trial_sph(t, rng):
     with np.errstate(all="ignore"):
         fg, fr = f.fields(*args, ctype), orc.sph_fields(g, prm, c_ref, *args, ctype)
     finf = np.isfinite(fr).all(axis=1)
-    fsc = np.abs(fr[finf]).max(axis=0) if finf.any() else np.ones(9)
-    e_f = (np.abs(fg[finf] - fr[finf]).max(axis=0) / np.maximum(fsc, 1e-300)).max() if finf.any() else 0.0
+    e_f = field_err(fg[finf], fr[finf]) if finf.any() else 0.0
     same_f = np.array_equal(np.isfinite(fg).all(axis=1), finf)
     c.close(); f.close()
     cs = max(np.abs(c_ref).max(), 1e-300)
@@ -159,6 +168,24 @@ def trial_cyl(t, rng):
     c.zero_acceleration(0)
     f.get_acceleration_and_potential(c)
     out = c.download(("acc", "pot"))
+    # pyEXP's field evaluation (accumulated_eval + accumulated_dens_eval) at some of the points, random coordinate type
+    sub = rng.choice(n, min(n, 300), replace=False)
+    q = pos[sub]
+    ctype = str(rng.choice(["cartesian", "cylindrical", "spherical"]))
+    if ctype == "cartesian":
+        args = (q[:, 0], q[:, 1], q[:, 2])
+    elif ctype == "cylindrical":
+        args = (np.hypot(q[:, 0], q[:, 1]), q[:, 2], np.arctan2(q[:, 1], q[:, 0]))
+    else:
+        rq = np.linalg.norm(q, axis=1)
+        with np.errstate(all="ignore"):
+            args = (rq, np.where(rq > 0, q[:, 2] / rq, 0.0), np.arctan2(q[:, 1], q[:, 0]))
+    f.set_coefs(c_ref, s_ref)
+    with np.errstate(all="ignore"):
+        fg, fr = f.fields(*args, ctype), orc.cyl_fields(g, c_ref, s_ref, *args, ctype, **kw)
+    finf = np.isfinite(fr).all(axis=1)
+    e_f = field_err(fg[finf], fr[finf]) if finf.any() else 0.0
+    same_f = np.array_equal(np.isfinite(fg).all(axis=1), finf)
     c.close(); f.close()
     # (a lone particle in the plane and a basis of vertically antisymmetric functions: every coefficient is 0 in the oracle and
     # a rounding of the maps on the device -- the scale is what the particle COULD have contributed)
@@ -171,8 +198,9 @@ def trial_cyl(t, rng):
     e_a = np.abs(out["acc"][fin] - a_ref[fin]).max() / asc if fin.any() else 0.0
     e_p = np.abs(out["pot"][fin] - p_ref[fin]).max() / psc if fin.any() else 0.0
     ok = (used == used_ref and abs(cm - mass_ref) <= 1e-12 * max(abs(mass_ref), 1e-300) and same_nan and e_c <= COEF_TOL
-          and e_a <= ACC_TOL and e_p <= ACC_TOL)
-    print(f"cyl {t:3d} {key} EVEN_M {even_m} n {n}: coef {e_c:.1e} acc {e_a:.1e} pot {e_p:.1e} used {used}/{used_ref} "
+          and e_a <= ACC_TOL and e_p <= ACC_TOL and same_f and e_f <= ACC_TOL)
+    print(f"cyl {t:3d} {key} EVEN_M {even_m} n {n}: coef {e_c:.1e} acc {e_a:.1e} pot {e_p:.1e} fields[{ctype[:3]}] {e_f:.1e}"
+          f"{'' if same_f else ' NAN-PATTERN'} used {used}/{used_ref} "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
     return ok
 
