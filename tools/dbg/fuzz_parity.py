@@ -26,13 +26,15 @@ COEF_TOL, ACC_TOL = 1e-10, 1e-9
 _sl, _cy = {}, {}
 
 
-def field_err(got, ref):
+def field_err(got, ref, floor=0.0):
     """density, potential and force columns each against the largest value of THEIR group over the points (a column that is
     identically zero -- the azimuthal force on the axis -- has no scale of its own)"""
     e = 0.0
     for a, b in ((0, 3), (3, 6), (6, 9)):
-        sc = np.abs(ref[:, a:b]).max()
-        if sc < 1e-250:          # (coefficients that vanish identically: an all-antisymmetric basis and a particle in the plane)
+        # (floor: what the particles COULD have contributed -- an all-antisymmetric basis and a particle in the plane leave
+        # coefficients, and fields, that are rounding noise around zero on both sides)
+        sc = max(np.abs(ref[:, a:b]).max(), floor)
+        if sc < 1e-250:
             continue
         e = max(e, np.abs(got[:, a:b] - ref[:, a:b]).max() / sc)
     return e
@@ -186,7 +188,7 @@ def trial_cyl(t, rng):
     with np.errstate(all="ignore"):
         fg, fr = f.fields(*args, ctype), orc.cyl_fields(g, c_ref, s_ref, *args, ctype, **kw)
     finf = np.isfinite(fr).all(axis=1)
-    e_f = field_err(fg[finf], fr[finf]) if finf.any() else 0.0
+    e_f = field_err(fg[finf], fr[finf], 1e-6 * np.abs(m).sum() * np.abs(g.tab[0]).max() ** 2) if finf.any() else 0.0
     same_f = np.array_equal(np.isfinite(fg).all(axis=1), finf)
     c.close(); f.close()
     # (a lone particle in the plane and a basis of vertically antisymmetric functions: every coefficient is 0 in the oracle and
