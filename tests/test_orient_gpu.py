@@ -75,7 +75,9 @@ def test_orient_small_component_duplicates_and_modes(ctx, oracle):
     m = rng.uniform(0.5, 1.5, n) / n
     pos, vel = rng.standard_normal((2, n, 3))
     pot = -1.0 / np.sqrt(0.1 + (pos ** 2).sum(axis=1))
-    pot[::7] = 0.0                                                      # +0 / -0 and exact ties at the top
+    # +0 / -0 and exact ties AT THE TOP: both sides exclude the threshold energy.  (Exact ties BELOW it are a documented
+    # deviation, DESIGN.md section 2: the reference's std::set keeps one particle per energy.)
+    pot[::7] = 0.0
     pot[7::14] = -0.0
     c = Component.from_arrays(ctx, m, pos, vel)
     c.upload_acc(np.zeros((n, 3)), pot)
