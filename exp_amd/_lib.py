@@ -94,6 +94,7 @@ SIGNATURES = {
     "exp_amd_orient_accumulate": (c_int, [c_void_p, c_double, c_double, c_void_p]),
     "exp_amd_orient_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
+    "exp_amd_sph_set_accumulate_all_m": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_dsmall": (c_int, [c_void_p, c_double]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
     "exp_amd_cyl_cov_enable": (c_int, [c_void_p, c_int]),

@@ -484,6 +484,10 @@ class SphericalSL(BiorthBasis):
         self.force = SphereSL(self.ctx, self.grid, scale=self.scale, rmin=rmin, rmax=rmax, **flags)
         _lib_check = self.force.lib.exp_amd_sph_set_exterior(self.force.h, 0)   # pyEXP semantics
         assert _lib_check == 0
+        # Spherical::accumulate applies none of the flags (expui/BiorthBasis.cc:583-665): with M0_ONLY the coefficients
+        # it returns still hold every m, only the evaluation drops them
+        _lib_check = self.force.lib.exp_amd_sph_set_accumulate_all_m(self.force.h, 1)
+        assert _lib_check == 0
         # N1, N2: the radial window of the l >= 1 sums in computeAccel / sph_eval
         # (expui/BiorthBasis.cc:761, :780, :876, :894; the l = 0 term takes every n).  The reference
         # reads both keys with `.as<bool>()` (:264-265), so the only values a YAML file can give them

@@ -308,6 +308,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.cx = S.cy = S.cz = 0.0;
   S.NO_L0 = cfg->NO_L0; S.NO_L1 = cfg->NO_L1; S.EVEN_L = cfg->EVEN_L; S.EVEN_M = cfg->EVEN_M;
   S.M0_only = cfg->M0_only;
+  S.M0_acc = cfg->M0_only;
   S.no_exterior = 0;
   S.dsmall = DSMALL;
   S.xi_uniform = 1;                            // same two roundings as the device's mul_then_add
@@ -978,6 +979,14 @@ extern "C" int exp_amd_sph_set_dsmall(exp_amd_force *fb, double dsmall)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f || !(dsmall >= 0.0)) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_dsmall: not a sphereSL force");
   f->dev.dsmall = dsmall;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_sph_set_accumulate_all_m(exp_amd_force *fb, int all_m)
+{
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_accumulate_all_m: not a sphereSL force");
+  f->dev.M0_acc = all_m ? 0 : f->dev.M0_only;
   return EXP_AMD_OK;
 }
 

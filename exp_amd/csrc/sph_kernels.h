@@ -42,6 +42,7 @@ struct SphDev {
                                // reference's exact division so that cell assignment is identical)
   double cx, cy, cz;
   int NO_L0, NO_L1, EVEN_L, EVEN_M, M0_only;
+  int M0_acc;            // accumulation skips m > 0 (the n-body M0_only, src/SphericalBasis.cc:550; pyEXP's accumulate keeps every m)
   int xi_uniform;        // 1: xi[i] == xmin + dxi*i bit for bit (checked at create): no table gather
   int no_exterior;       // 1: no r>rmax multipole continuation (pyEXP computeAccel semantics)
   double detC;           // deterministic mode: 1.5 * 2^(52+e), every contribution is rounded to the grid 2^e
@@ -494,7 +495,7 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
         cm = cn; sm = sn;
       }
       if constexpr (m >= MLO) {
-        if (m == 0 || !S.M0_only) {
+        if (m == 0 || !S.M0_acc) {
           // per-m weights: the four (x1|x2) x (cos|sin) moments share Pt(l,m)
           const double a1c = a1 * cm, a2c = a2 * cm, a1s = a1 * sm, a2s = a2 * sm;
           // rescaled functions Ph = s(l,m) Pt (see lc_s): W holds s(l,m) x the moments and

@@ -245,6 +245,10 @@ void exp_amd_force_destroy(exp_amd_force *f);
  * force (src/SphericalBasis.cc:1555-1560, :1605-1628); 0: tables evaluated at r/scale as in
  * pyEXP's Spherical::computeAccel (expui/BiorthBasis.cc:818-926).                          */
 int  exp_amd_sph_set_exterior(exp_amd_force *f, int continuation);
+/* M0_only in the accumulation: the n-body code skips the m > 0 sums altogether (src/SphericalBasis.cc:550), pyEXP's
+ * Spherical::accumulate applies no flag at all (expui/BiorthBasis.cc:583-665: the coefficients it returns hold every m;
+ * only the evaluation drops them, :851).  all_m = 1 selects the latter; the default is the former.                */
+int  exp_amd_sph_set_accumulate_all_m(exp_amd_force *f, int all_m);
 /* The small number added to r before any division: 1e-16 (DSMALL, src/expand.H:130) by default, as in
  * the n-body code; pyEXP's Spherical::accumulate adds 1e-20 and computeAccel 1e-18
  * (expui/BiorthBasis.cc:588, :824-825).  Only the origin and the polar axis can tell them apart.  */

@@ -180,6 +180,44 @@ def test_accumulate_and_get_accel_against_the_pyexp_literal_oracle(halo_basis, o
     assert np.abs(got - near).max() <= 1e-6 * np.abs(near).max()
 
 
+def test_m0_only_is_an_evaluation_flag_in_pyexp(halo_basis, oracle, tmp_path):
+    """``Spherical::accumulate`` applies none of the flags (expui/BiorthBasis.cc:583-665): with M0_ONLY the coefficient
+    structure it returns still holds every m and only the evaluation drops m > 0 (:851).  The n-body force skips the
+    m > 0 sums in the accumulation itself (src/SphericalBasis.cc:550): ``exp_amd_sph_set_accumulate_all_m`` selects
+    between the two, and the basis object asks for pyEXP's (found by tools/dbg/fuzz_pyexp.py)."""
+    from exp_amd.basis import Basis
+    from exp_amd.runtime import Component, SphereSL
+    basis, cfg = halo_basis
+    cfg0 = cfg.replace("  Lmax: 2", "  Lmax: 2\n  M0_ONLY: true")
+    cfg0 = cfg0.replace(cfg0.split("cachename: ")[1].split()[0], str(tmp_path / "SLGridSph.cache.m0"))
+    b0 = Basis.factory(cfg0)
+    rng = np.random.default_rng(17)
+    pos = rng.normal(0, 0.3, (2000, 3)) * np.array([1.0, 0.7, 0.4])
+    m = np.full(2000, 1.0 / 2000)
+    c0, call = b0.createFromArray(m, pos), basis.createFromArray(m, pos)
+    assert np.abs(c0.coefs[4]).max() > 1e-3 * np.abs(c0.coefs[0]).max()          # (l, m) = (2, 1): not dropped
+    assert np.abs(c0.coefs - call.coefs).max() <= 1e-13 * np.abs(call.coefs).max()
+    prm = oracle.params(scale=1.0, rmin=b0.rmin, rmax=b0.rmax, M0_only=True)
+    ref, _ = oracle.pyexp_sph_accumulate(b0.grid, prm, pos, m)
+    assert np.abs(b0.expcoef - ref).max() <= 1e-10 * np.abs(ref).max()
+    b0.set_coefs(c0)
+    test = rng.normal(0, 0.4, (100, 3))
+    a_ref = oracle.pyexp_sph_accel(b0.grid, prm, ref, test)
+    assert np.abs(b0.getAccel(test) - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
+    basis.set_coefs(call)
+    assert np.abs(basis.getAccel(test) - a_ref).max() > 1e-3 * np.linalg.norm(a_ref, axis=1).max()   # the flag matters
+    # the n-body force of the same flag leaves the m > 0 rows at zero
+    f = SphereSL(b0.ctx, b0.grid, rmin=b0.rmin, rmax=b0.rmax, M0_only=True)
+    c = Component.from_arrays(b0.ctx, m, pos)
+    f.determine_coefficients(c)
+    nb = f.get_coefs()
+    assert np.all(nb[[2, 3, 5, 6, 7, 8]] == 0.0) and np.abs(nb[4]).max() > 0
+    assert f.lib.exp_amd_sph_set_accumulate_all_m(f.h, 1) == 0
+    f.determine_coefficients(c)
+    assert np.abs(f.get_coefs()[5]).max() > 0
+    c.close(); f.close()
+
+
 def test_radial_window_keys_N1_N2(halo_basis, oracle, tmp_path):
     """N1 / N2 restrict the l >= 1 sums of computeAccel / sph_eval to n in [N1, N2] while the monopole
     keeps every n (expui/BiorthBasis.cc:841-849 vs :876, :894).  The reference reads both keys with
