@@ -358,6 +358,35 @@ class BiorthBasis:
         self.addFromArray(m, p, roundrobin, posvelrows)
         return self.makeFromArray(time)
 
+    def createFromReader(self, reader, center=(0.0, 0.0, 0.0), rot=None):
+        """``BiorthBasis::createFromReader(reader, ctr, rot)`` (expui/BiorthBasis.cc:4517-4581; pyEXP/BasisWrappers.cc:
+        1287): the coefficients of the particles a ``ParticleReader`` (``exp_amd.reader``) delivers -- its selected type,
+        this rank's share -- at ``rot (x - ctr)``, stamped with the reader's time.  The selector functor sees the
+        transformed position, the rotated velocity and the particle's own index; ``accumulate`` is handed that index too
+        (the sub-sample of the covariance is chosen from it).  The reference walks the particles one at a time; here
+        they go to the device in batches."""
+        ctr = np.asarray(center, dtype=np.float64).reshape(3)
+        R = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        self.coefctr, self.coefrot = ctr, R
+        self.reset_coefs()
+        a = reader.arrays()
+        n, step = len(a["mass"]), 1 << 24
+        for lo in range(0, max(n, 1), step):
+            sl = slice(lo, min(lo + step, n))
+            m = np.ascontiguousarray(a["mass"][sl], dtype=np.float64)
+            pos = (np.asarray(a["pos"][sl], dtype=np.float64) - ctr) @ R.T
+            seq = np.asarray(a["indx"][sl]).astype(np.uint32)
+            if self._ftor is not None:
+                v = np.asarray(a["vel"][sl], dtype=np.float64) @ R.T
+                idx = a["indx"][sl]
+                keep = np.array([bool(self._ftor(m[i], pos[i], v[i], int(idx[i]))) for i in range(len(m))], dtype=bool)
+                m, pos, seq = m[keep], pos[keep], seq[keep]
+            self._accumulate_batch(m, pos, seq)
+        self.make_coefs()
+        cs = self.load_coefs(reader.CurrentTime())
+        cs.ctr, cs.rot = ctr.copy(), R.copy()
+        return cs
+
     def accumulate(self, x, y, z, mass, indx: int = 0) -> None:
         self._accumulate_batch(np.atleast_1d(np.float64(mass)),
                                np.array([[x, y, z]], dtype=np.float64), np.array([indx], dtype=np.uint32))

@@ -7,8 +7,10 @@ of a frame go to the device in ONE ``exp_amd_sph_fields`` / ``exp_amd_cyl_fields
 arrays), in the basis' own coordinate type exactly as the reference converts them (``r + 1e-18``, ``R + 1e-18``).
 Results are float32 like the reference's ``Eigen::MatrixXf`` / ``VectorXf`` / ``Tensor<float, 3>``.
 
-The three particle histograms (``histo2d``, ``histo1d``, ``histo1dlog``) take a ``ParticleReader`` and never touch a
-basis: they are outside this package's path and not provided."""
+The three particle histograms (``histo2d``, ``histo1d``, ``histo1dlog``) take a ``ParticleReader`` (``exp_amd.reader``);
+their float accumulators are filled one particle at a time in reader order (``exp_amd_host_binsum_f32``), which is what
+the result depends on in the last bits.  With several ranks each reads its share and the float sums are added, as the
+reference's MPI_Reduce(MPI_FLOAT, MPI_SUM) does."""
 from __future__ import annotations
 
 import os
@@ -104,6 +106,123 @@ class FieldGenerator:
             self.grid = [int(v) for v in gridsize]
         self.midplane = False
         self.colheight = 4.0
+
+    # -- particle histograms (expui/FieldGenerator.cc:776-1009; pyEXP/FieldWrappers.cc:273-350) --
+    @staticmethod
+    def _binsum(bins: np.ndarray, vals: np.ndarray, nbins: int) -> np.ndarray:
+        from ._lib import load
+        import ctypes
+        lib = load()
+        out = np.zeros(nbins, dtype=np.float32)
+        b = np.ascontiguousarray(bins, dtype=np.int32)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        rc = lib.exp_amd_host_binsum_f32(len(b), b.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p),
+                                         int(nbins), out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError("FieldGenerator: exp_amd_host_binsum_f32 failed")
+        return out
+
+    @staticmethod
+    def _reduce_f32(a: np.ndarray) -> np.ndarray:
+        """MPI_Reduce(MPI_FLOAT, MPI_SUM) to the root: every rank gets the sum here"""
+        try:
+            import torch
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                t = torch.from_numpy(np.ascontiguousarray(a))
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.all_reduce(t)
+                return t.cpu().numpy()
+        except ImportError:
+            pass
+        return a
+
+    def histogram2d(self, reader, center=(0.0, 0.0, 0.0)) -> Dict[str, np.ndarray]:
+        """Surface density of the reader's particles on the generator's grid, projected along each axis whose two
+        others have a positive grid size: {"xy": [g0, g1], "xz": [g0, g2], "yz": [g1, g2]}, float32."""
+        if self.grid is None:
+            raise RuntimeError("FieldGenerator::histogram2d: no grid was given to the constructor")
+        a = reader.arrays()
+        ctr = np.asarray(center, dtype=np.float64).reshape(3)
+        pmin, pmax, grid = np.array(self.pmin), np.array(self.pmax), self.grid
+        dl = np.array([(pmax[k] - pmin[k]) / grid[k] if grid[k] > 0 else 0.0 for k in range(3)])
+        pp = a["pos"].astype(np.float64) - ctr
+        bb = (pp >= pmin) & (pp < pmax) & (dl > 0.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            idx = np.floor((pp - pmin) / np.where(dl > 0.0, dl, 1.0))
+        idx = np.where(np.isfinite(idx), idx, -1).astype(np.int64)
+        ret = {}
+        for key, (i, j) in (("xy", (0, 1)), ("xz", (0, 2)), ("yz", (1, 2))):
+            if not (grid[i] > 0 and grid[j] > 0):
+                continue
+            fac = 1.0 / (dl[i] * dl[j])
+            ok = bb[:, i] & bb[:, j] & (idx[:, i] >= 0) & (idx[:, i] < grid[i]) & (idx[:, j] >= 0) & (idx[:, j] < grid[j])
+            flat = np.where(ok, idx[:, i] * grid[j] + idx[:, j], -1)
+            ret[key] = self._reduce_f32(self._binsum(flat, a["mass"] * fac, grid[i] * grid[j])).reshape(grid[i], grid[j])
+        return ret
+
+    def histogram1d(self, reader, rmax: float, nbins: int, proj: str, center=(0.0, 0.0, 0.0)) -> np.ndarray:
+        """Density in ``nbins`` linear bins out to ``rmax``: cylindrical rings of the plane ``proj`` in ("xy", "xz", "yz"),
+        spherical shells for "r".  Any other string leaves the reference's projection variable unset (its error is
+        built and dropped, :871-876); it is refused here."""
+        axes = {"xy": (0, 1), "xz": (0, 2), "yz": (1, 2), "r": (0, 1, 2)}
+        if proj not in axes:
+            raise RuntimeError(f'FieldGenerator::histogram1d: error parsing projection <{proj}>.  Must be one of '
+                               '"xy", "xz", "yz, "r".')
+        a = reader.arrays()
+        ctr = np.asarray(center, dtype=np.float64).reshape(3)
+        dl = float(rmax) / nbins
+        pp = a["pos"].astype(np.float64) - ctr
+        rad = np.zeros(len(pp))
+        for k in axes[proj]:                                  # summed in the order k = 0, 1, 2
+            rad = rad + pp[:, k] * pp[:, k]
+        q = np.floor(np.sqrt(rad) / dl)
+        bins = np.where(np.isfinite(q) & (q >= 0) & (q < nbins), q, -1).astype(np.int64)
+        ret = self._reduce_f32(self._binsum(bins, a["mass"].astype(np.float64), nbins))
+        i = np.arange(nbins)
+        pi = 3.14159265358979323846
+        if proj == "r":
+            ret = (ret.astype(np.float64) / (4.0 * pi / 3.0 * dl * dl * dl * (3 * i * (i + 1) + 1))).astype(np.float32)
+        else:
+            ret = (ret.astype(np.float64) / (pi * dl * dl * (2 * i + 1))).astype(np.float32)
+        return ret
+
+    def histo1dlog(self, reader, rmin: float, rmax: float, nbins: int, center=(0.0, 0.0, 0.0)):
+        """Spherical shells, logarithmic in radius -> (bin-centre radii, density, velocity dispersion), float32."""
+        if rmin <= 0.0:
+            raise RuntimeError("FieldGenerator::histo1dlog: rmin must be > 0.0")
+        if rmax <= rmin:
+            raise RuntimeError("FieldGenerator::histo1dlog: rmax must be > rmin")
+        import math
+        a = reader.arrays()
+        ctr = np.asarray(center, dtype=np.float64).reshape(3)
+        lrmin, lrmax = math.log(rmin), math.log(rmax)
+        dl = (lrmax - lrmin) / nbins
+        pp = a["pos"].astype(np.float64) - ctr
+        r2 = (pp[:, 0] * pp[:, 0] + pp[:, 1] * pp[:, 1]) + pp[:, 2] * pp[:, 2]
+        with np.errstate(divide="ignore"):
+            q = np.floor((np.log(np.sqrt(r2)) - lrmin) / dl)
+        bins = np.where(np.isfinite(q) & (q >= 0) & (q < nbins), q, -1).astype(np.int64)
+        m, v = a["mass"].astype(np.float64), a["vel"].astype(np.float64)
+        ret = self._reduce_f32(self._binsum(bins, m, nbins))
+        vc1 = np.stack([self._reduce_f32(self._binsum(bins, m * v[:, k], nbins)) for k in range(3)], axis=1)
+        vc2 = np.stack([self._reduce_f32(self._binsum(bins, m * v[:, k] * v[:, k], nbins)) for k in range(3)], axis=1)
+        i = np.arange(nbins)
+        rf = 4.0 * 3.14159265358979323846 / 3.0 * (math.exp(3.0 * dl) - 1.0)
+        rad = np.exp(lrmin + dl * (0.5 + i)).astype(np.float32)
+        has = ret > 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c1 = (vc1 / ret[:, None]).astype(np.float32)                      # float / float
+            c2 = (vc2 / ret[:, None]).astype(np.float32)
+            sig = np.zeros(nbins)
+            for k in range(3):
+                sig = sig + (c2[:, k] - c1[:, k] * c1[:, k]).astype(np.float64)   # double += float - float * float
+            dens = (ret.astype(np.float64) / (np.exp(3.0 * (lrmin + dl * i)) * rf)).astype(np.float32)
+            vel = np.sqrt(np.abs(sig)).astype(np.float32)
+        return rad, np.where(has, dens, np.float32(0)), np.where(has, vel, np.float32(0))
+
+    histo2d, histo1d = histogram2d, histogram1d               # the names pyEXP binds (pyEXP/FieldWrappers.cc:273, :295)
 
     # -- expui/FieldGenerator.H:150-156 --
     def setMidplane(self, value: bool) -> None:

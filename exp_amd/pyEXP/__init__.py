@@ -3,13 +3,13 @@
     pyEXP.basis.Basis.factory(yaml) / SphericalSL / Cylindrical / CovarianceReader
     pyEXP.coefs.Coefs.factory(file) / SphCoefs / CylCoefs / SphStruct / CylStruct
     pyEXP.field.FieldGenerator(times, lower, upper, gridsize) / (times, mesh)
+    pyEXP.read.ParticleReader.createReader(type, files) / PSPout / PSPspl / PSPhdf5 / GadgetNative / GadgetHDF5 / Tipsy
 
 so that a script written against the reference's Python module (tests/Halo/createCoefs.py,
 tests/Halo/changeCoefs.py, tests/Disk/cyl_basis.py) runs with the import line changed.  Everything else
-of pyEXP (mSSA, particle readers and the particle histograms of the field generator, utilities) is outside this repository's scope and
-raises on access."""
-from . import basis, coefs, field
+of pyEXP (mSSA, utilities) is outside this repository's scope and raises on access."""
+from . import basis, coefs, field, read
 
 
 def __getattr__(name):
-    raise AttributeError(f"exp_amd.pyEXP has no sub-module <{name}>: only basis, coefs and field are in scope")
+    raise AttributeError(f"exp_amd.pyEXP has no sub-module <{name}>: only basis, coefs, field and read are in scope")

@@ -437,6 +437,11 @@ double exp_amd_sim_time(const exp_amd_sim *s);
 long long exp_amd_sim_last_switches(const exp_amd_sim *s);   /* level changes of the last adjustment */
 long long exp_amd_sim_step_switches(const exp_amd_sim *s);   /* ... summed over the last exp_amd_sim_step call */
 
+/* Host-only: out[bin[i]] += val[i] (float accumulator, double addend, the particles in the order given; bins outside
+ * [0, nbins) are skipped) -- the arithmetic of FieldGenerator::histogram2d / histogram1d / histo1dlog
+ * (expui/FieldGenerator.cc:776-1009), whose float sums depend on the order of the particles.              */
+int  exp_amd_host_binsum_f32(long long n, const int *bin, const double *val, int nbins, float *out);
+
 /* Timing of the last fused step's dominant kernels (ms, HIP events on the context
  * stream); names are static strings.  Used by bench.py for the roofline figure.    */
 int  exp_amd_profile_enable(exp_amd_ctx *ctx, int on);

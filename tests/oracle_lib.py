@@ -361,6 +361,85 @@ class Oracle:
                                  _dp(y), _dp(z), _dp(c), _dp(G), _dp(ax), _dp(ay), _dp(az), _dp(pot))
         return np.stack([ax, ay, az], axis=1), pot
 
+    # -- phase-space files and particle histograms (oracle/psp_oracle.c) ------------------------------------
+    def psp_write(self, path, time, comps, real4=False):
+        """comps: dicts with info (str), indexing (bool), mass, pos, vel, pot and optionally potext, indx, iattrib,
+        dattrib -- Component::write_binary per component (src/Component.cc:2385-2454)."""
+        n = [len(c["mass"]) for c in comps]
+        def two_d(c, key, k, dtype):
+            a = np.asarray(c[key], dtype=dtype) if c.get(key) is not None else np.zeros((k, 0), dtype=dtype)
+            return a.reshape(k, a.size // k if k else (a.shape[1] if a.ndim == 2 else 0))
+        ia = [two_d(c, "iattrib", k, np.int32) for c, k in zip(comps, n)]
+        da = [two_d(c, "dattrib", k, np.float64) for c, k in zip(comps, n)]
+        cat = lambda key, w: np.ascontiguousarray(np.concatenate(
+            [np.asarray(c.get(key, np.zeros((k,) + w)), dtype=np.float64).reshape((k,) + w) for c, k in zip(comps, n)]))
+        mass, pos, vel, pot, potext = cat("mass", ()), cat("pos", (3,)), cat("vel", (3,)), cat("pot", ()), cat("potext", ())
+        indx = np.ascontiguousarray(np.concatenate(
+            [np.asarray(c["indx"], dtype=np.uint64) if c.get("indx") is not None else np.arange(1, k + 1, dtype=np.uint64)
+             for c, k in zip(comps, n)]))
+        iav = np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in ia])) if ia else np.zeros(0, np.int32)
+        dav = np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in da])) if da else np.zeros(0)
+        arr_i = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])
+        infos = (ctypes.c_char_p * len(comps))(*[(c["info"] if c["info"].endswith("\n") else c["info"] + "\n").encode() for c in comps])
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = self.lib.orc_psp_write(str(path).encode(), ctypes.c_double(time), len(comps), arr_i(n),
+                                    arr_i([a.shape[1] for a in ia]), arr_i([a.shape[1] for a in da]), infos,
+                                    arr_i([int(bool(c.get("indexing", False))) for c in comps]), int(bool(real4)),
+                                    vp(indx), vp(mass), vp(pos), vp(vel), vp(pot), vp(potext), vp(iav), vp(dav))
+        assert rc == 0
+
+    def psp_read(self, path, indexing, numprocs=1, myid=0):
+        """PSPout constructor + firstParticle / nextParticle of every stanza -> (time, ntot, [dict per stanza])."""
+        class Stanza(ctypes.Structure):
+            _fields_ = [("nbod", ctypes.c_int), ("niatr", ctypes.c_int), ("ndatr", ctypes.c_int), ("ninfochar", ctypes.c_int),
+                        ("r_size", ctypes.c_ulong), ("index_size", ctypes.c_ulong), ("pspos", ctypes.c_long),
+                        ("info", ctypes.c_char * 8192)]
+        st = (Stanza * 16)()
+        time, ntot = ctypes.c_double(), ctypes.c_int()
+        idx = (ctypes.c_int * 16)(*([int(bool(v)) for v in indexing] + [0] * (16 - len(indexing))))
+        found = self.lib.orc_psp_scan(str(path).encode(), ctypes.byref(time), ctypes.byref(ntot), 16, st, idx)
+        assert found >= 0, found
+        out = []
+        self.lib.orc_psp_read.restype = ctypes.c_long
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        for k in range(found):
+            s = st[k]
+            n = s.nbod
+            indx, mass, pos, vel, pot = np.zeros(n, np.uint64), np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n)
+            ia, da = np.zeros((n, s.niatr), np.int32), np.zeros((n, s.ndatr))
+            got = self.lib.orc_psp_read(str(path).encode(), ctypes.byref(s), int(numprocs), int(myid), vp(indx), vp(mass),
+                                        vp(pos), vp(vel), vp(pot), vp(ia), vp(da))
+            out.append({"nbod": n, "niatr": s.niatr, "ndatr": s.ndatr, "r_size": int(s.r_size), "info": s.info.split(b"\0")[0].decode(),
+                        "indx": indx[:got], "mass": mass[:got], "pos": pos[:got], "vel": vel[:got], "pot": pot[:got],
+                        "iattrib": ia[:got], "dattrib": da[:got]})
+        return time.value, ntot.value, out
+
+    def histo2d(self, mass, pos, ctr, pmin, pmax, grid):
+        m, p = np.ascontiguousarray(mass, dtype=np.float64), np.ascontiguousarray(pos, dtype=np.float64)
+        g = [int(v) for v in grid]
+        out = [np.zeros((max(g[a], 0), max(g[b], 0)), dtype=np.float32) for a, b in ((0, 1), (0, 2), (1, 2))]
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.lib.orc_histo2d(ctypes.c_long(len(m)), _dp(m), _dp(p), _dp(np.asarray(ctr, dtype=np.float64)),
+                             _dp(np.asarray(pmin, dtype=np.float64)), _dp(np.asarray(pmax, dtype=np.float64)),
+                             (ctypes.c_int * 3)(*g), vp(out[0]), vp(out[1]), vp(out[2]))
+        return {k: o for k, o, (a, b) in zip(("xy", "xz", "yz"), out, ((0, 1), (0, 2), (1, 2))) if g[a] > 0 and g[b] > 0}
+
+    def histo1d(self, mass, pos, ctr, rmax, nbins, proj):
+        m, p = np.ascontiguousarray(mass, dtype=np.float64), np.ascontiguousarray(pos, dtype=np.float64)
+        out = np.zeros(nbins, dtype=np.float32)
+        self.lib.orc_histo1d(ctypes.c_long(len(m)), _dp(m), _dp(p), _dp(np.asarray(ctr, dtype=np.float64)),
+                             ctypes.c_double(rmax), int(nbins), {"xy": 0, "xz": 1, "yz": 2, "r": 3}[proj],
+                             out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def histo1dlog(self, mass, pos, vel, ctr, rmin, rmax, nbins):
+        m, p, v = [np.ascontiguousarray(a, dtype=np.float64) for a in (mass, pos, vel)]
+        out = [np.zeros(nbins, dtype=np.float32) for _ in range(3)]
+        self.lib.orc_histo1dlog(ctypes.c_long(len(m)), _dp(m), _dp(p), _dp(v), _dp(np.asarray(ctr, dtype=np.float64)),
+                                ctypes.c_double(rmin), ctypes.c_double(rmax), int(nbins),
+                                *[o.ctypes.data_as(ctypes.c_void_p) for o in out])
+        return tuple(out)
+
     def quadls(self, x, y):
         x, y = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y)]
         out = np.zeros(3)
