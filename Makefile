@@ -24,7 +24,7 @@ HDF5_INC ?= /opt/conda/include
 HDF5_LIB ?= /opt/conda/lib
 h5:
 	@if [ -f $(HDF5_INC)/hdf5.h ]; then \
-	  gcc -O2 -fPIC -shared -I$(HDF5_INC) exp_amd/csrc_host/h5cache.c -o exp_amd/libexp_amd_h5.so \
+	  gcc -O2 -fPIC -shared -Wall -I$(HDF5_INC) exp_amd/csrc_host/h5cache.c exp_amd/csrc_host/h5part.c -o exp_amd/libexp_amd_h5.so \
 	      -L$(HDF5_LIB) -lhdf5 -Wl,-rpath,$(HDF5_LIB); \
 	else echo "hdf5.h not found: HDF5 cache shim not built"; fi
 
