@@ -65,12 +65,14 @@ SIGNATURES = {
     "exp_amd_comp_download_levels": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_upload_device": (c_int, [c_void_p] + [c_void_p] * 7),
     "exp_amd_comp_set_center": (c_int, [c_void_p, c_double_p]),
+    "exp_amd_comp_get_center": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_drift": (c_int, [c_void_p, c_double, c_int]),
     "exp_amd_comp_kick": (c_int, [c_void_p, c_double, c_int]),
     "exp_amd_comp_zero_acc": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p)]),
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
+    "exp_amd_comp_log_sums": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
                                       POINTER(c_void_p)]),
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),

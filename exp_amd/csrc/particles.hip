@@ -1054,6 +1054,13 @@ extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
   return EXP_AMD_OK;
 }
 
+extern "C" int exp_amd_comp_get_center(const exp_amd_comp *c, double center[3])
+{
+  if (!c || !center) return EXP_AMD_ERR_ARG;
+  for (int k = 0; k < 3; k++) center[k] = c->center[k];
+  return EXP_AMD_OK;
+}
+
 extern "C" int exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9])
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
@@ -1181,6 +1188,78 @@ k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const d
     const double s = (&acc[0][0])[k];
     if (s != 0.0) unsafeAtomicAdd(out + k, s);
   }
+}
+
+// ---- the run log's sums (OutLog::Run, src/OutLog.cc:392-446) ------------------------------------------
+// Per component: mass, m x, m v, angular momentum, kinetic energy, 0.5 m pot, the Clausius virial m x.a -- over every
+// particle (no frozen particles in this store), positions and velocities as stored (com_system off: Local = Inertial).
+// Velocities are the step-boundary ones (expamd_comp_velocity_view), as at the reference's call after the second kick.
+__global__ void __launch_bounds__(256)
+k_log_sums(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
+           const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
+           const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
+           const double *__restrict__ AZ, const double *__restrict__ P, double back, size_t n,
+           double *__restrict__ out /* [13] */)
+{
+  __shared__ double acc[13];
+  if (threadIdx.x < 13) acc[threadIdx.x] = 0.0;
+  __syncthreads();
+  double v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const double m = M[i], x = X[i], y = Y[i], z = Z[i];
+    const double ax = AX[i], ay = AY[i], az = AZ[i];
+    double vx = VX[i], vy = VY[i], vz = VZ[i];
+    if (back != 0.0) { vx = mul_then_add(vx, ax, back); vy = mul_then_add(vy, ay, back); vz = mul_then_add(vz, az, back); }
+    v[0] += m;
+    v[1] += m * x;  v[2] += m * y;  v[3] += m * z;
+    v[4] += m * vx; v[5] += m * vy; v[6] += m * vz;
+    v[7] += m * (y * vz - z * vy);
+    v[8] += m * (z * vx - x * vz);
+    v[9] += m * (x * vy - y * vx);
+    v[10] += 0.5 * m * (vx * vx + vy * vy + vz * vz);
+    v[11] += 0.5 * m * P[i];
+    v[12] += m * (x * ax + y * ay + z * az);
+  }
+#pragma unroll
+  for (int k = 0; k < 13; k++) {
+    double t = v[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if ((threadIdx.x & 63) == 0 && t != 0.0) unsafeAtomicAdd(&acc[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < 13 && acc[threadIdx.x] != 0.0) unsafeAtomicAdd(out + threadIdx.x, acc[threadIdx.x]);
+}
+
+extern "C" int exp_amd_comp_log_sums(exp_amd_comp *c, double out[14])
+{
+  if (!c || !out) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double back = 0.0;
+  { int rc_ = expamd_comp_velocity_view(c, &back); if (rc_) return rc_; }
+  if (!c->com_red.p && c->com_red.alloc(COM_MAXLEV * 10) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "log_sums: hipMalloc failed");
+  HIP_TRY(ctx, hipMemsetAsync(c->com_red.p, 0, 14 * sizeof(double), ctx->stream));
+  if (c->n) {
+    ProfScope ps(ctx, "k_log_sums");
+    unsigned grid = cdiv(c->n, 256 * 16);
+    if (grid > 2048) grid = 2048;
+    k_log_sums<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY),
+                                             c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), back, c->n,
+                                             c->com_red.p);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  // the reference's MPI_Reduce of each sum (:448-478); the body count travels as the fourteenth double
+  double nb = (double)c->n;
+  HIP_TRY(ctx, hipMemcpyAsync(c->com_red.p + 13, &nb, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->nranks > 1 || ctx->ar_fn) {
+    int rc = expamd_allreduce(ctx, c->com_red.p, 14);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(out, c->com_red.p, 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
 }
 
 extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10])

@@ -224,6 +224,13 @@ class Component:
         c = (c_double * 3)(*[float(v) for v in center])
         check(self.lib.exp_amd_comp_set_center(self.h, c), self.ctx.h)
 
+    @property
+    def center(self) -> np.ndarray:
+        """``Component::center`` as it stands (the caller's, or the orientation estimator's inside a sim)."""
+        c = (c_double * 3)()
+        check(self.lib.exp_amd_comp_get_center(self.h, c), self.ctx.h)
+        return np.array(c[:])
+
     # src/incpos.cc:72, src/incvel.cc:90
     def set_orientation(self, body=None) -> None:
         """Body-frame rotation of the component (``Orient::transformBody``), used by the cylindrical
@@ -258,6 +265,14 @@ class Component:
         check(self.lib.exp_amd_comp_fix_positions(self.h, int(mlevel), out), self.ctx.h)
         v = np.array(out[:])
         return {"mtot": float(v[0]), "com": v[1:4].copy(), "cov": v[4:7].copy(), "coa": v[7:10].copy()}
+
+    def log_sums(self) -> dict:
+        """The sums ``OutLog::Run`` forms over a component (src/OutLog.cc:392-478), on the device."""
+        out = (c_double * 14)()
+        check(self.lib.exp_amd_comp_log_sums(self.h, out), self.ctx.h)
+        v = np.array(out[:])
+        return {"mtot": float(v[0]), "com": v[1:4].copy(), "cov": v[4:7].copy(), "angm": v[7:10].copy(),
+                "ektot": float(v[10]), "eptot": float(v[11]), "clausius": float(v[12]), "nbodies": int(round(v[13]))}
 
     def close(self) -> None:
         if self.h:

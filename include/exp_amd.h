@@ -145,6 +145,9 @@ int  exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass,
                                 const double *vx, const double *vy, const double *vz);
 /* Expansion centre subtracted from positions (Component::Centered, src/Component.H:748-757). */
 int  exp_amd_comp_set_center(exp_amd_comp *c, const double center[3]);
+/* Component::center as it stands (set by the caller or by the orientation estimator of a sim; the C(x), C(y), C(z)
+ * columns of the run log, src/OutLog.cc:444) */
+int  exp_amd_comp_get_center(const exp_amd_comp *c, double center[3]);
 /* Body-frame rotation applied after centring by the cylindrical force method (row-major 3x3 =
  * Orient::transformBody; positions go in as body * (x - centre), forces come back through the
  * transpose, transformOrig: src/Cylinder.cc:799-800, :1352-1353, :1417-1418).  NULL = none.
@@ -173,6 +176,11 @@ int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
  * does); ranks are combined with the context's all-reduce.  out = {mtot, com[3], cov[3], coa[3]}
  * (the three vectors divided by mtot when mtot > 0).                                        */
 int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
+/* The per-component sums of the run log (OutLog::Run, src/OutLog.cc:392-478): out = {mass, m x [3], m v [3], angular
+ * momentum [3], kinetic energy, 0.5 m pot, Clausius virial m x.a, number of bodies}, reduced over the ranks; every
+ * particle counts (no frozen particles in this store), positions and velocities as stored (com_system off), velocities at
+ * the step boundary.                                                                                              */
+int  exp_amd_comp_log_sums(exp_amd_comp *c, double out[14]);
 
 /* ---- orientation / expansion-centre estimator ("EJ") ----------------------------------------
  * Replaces class Orient (src/Orient.H:31-204, src/Orient.cc:38-790; CUDA twin

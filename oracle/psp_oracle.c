@@ -15,6 +15,7 @@
  *                            stride numprocs)
  *   orc_histo2d/1d/1dlog     FieldGenerator::histogram2d / histogram1d / histo1dlog (expui/FieldGenerator.cc:776-1009):
  *                            float accumulators, one particle at a time, in reader order
+ *   orc_outlog_sums/_row     the particle loop and the data row of OutLog::Run (src/OutLog.cc:392-446, :480-590)
  */
 #include <math.h>
 #include <stdio.h>
@@ -276,4 +277,96 @@ void orc_histo1dlog(long n, const double *mass, const double *pos, const double 
     }
   }
   free(vc1); free(vc2);
+}
+
+/* The particle loop of OutLog::Run (src/OutLog.cc:392-446) for one component with com_system off and no frozen
+ * particle: out = {mtot, com[3], cov[3], angm[3], ektot, eptot, clausius} (sums, not yet divided) */
+void orc_outlog_sums(long n, const double *mass, const double *pos, const double *vel, const double *acc,
+                     const double *pot, double *out)
+{
+  double mtot1 = 0.0, com1[3] = {0, 0, 0}, cov1[3] = {0, 0, 0}, angm1[3] = {0, 0, 0};
+  double ektot1 = 0.0, eptot1 = 0.0, clausius1 = 0.0;
+  for (long i = 0; i < n; i++) {
+    const double m = mass[i];
+    const double *posL = pos + 3 * i, *velL = vel + 3 * i;
+    mtot1 += m;
+    for (int k = 0; k < 3; k++) {
+      com1[k] += m * posL[k];
+      cov1[k] += m * velL[k];
+    }
+    angm1[0] += m * (posL[1] * velL[2] - posL[2] * velL[1]);
+    angm1[1] += m * (posL[2] * velL[0] - posL[0] * velL[2]);
+    angm1[2] += m * (posL[0] * velL[1] - posL[1] * velL[0]);
+    eptot1 += 0.5 * m * pot[i];
+    for (int k = 0; k < 3; k++) {
+      ektot1 += 0.5 * m * velL[k] * velL[k];
+      clausius1 += m * posL[k] * acc[3 * i + k];
+    }
+  }
+  out[0] = mtot1;
+  for (int k = 0; k < 3; k++) { out[1 + k] = com1[k]; out[4 + k] = cov1[k]; out[7 + k] = angm1[k]; }
+  out[10] = ektot1; out[11] = eptot1; out[12] = clausius1;
+}
+
+/* The data row of OutLog::Run (src/OutLog.cc:480-590) written with the C library's %*.*e -- the same characters as
+ * `out << std::scientific << setprecision(p) << setw(w)`.  sums: [ncomp][13] as above, nbodies, used, ctr [ncomp][3]. */
+int orc_outlog_row(char *buf, int cap, double tnow, int ncomp, const double *sums, const int *nbodies, const int *used,
+                   const double *ctr, double wtime, int precision)
+{
+  const int cwid = 10 + precision;
+  int o = 0;
+#define PUT_D(v) o += snprintf(buf + o, (size_t)(cap - o), "%s%*.*e", o ? "|" : "", cwid, precision, (double)(v))
+#define PUT_I(v) o += snprintf(buf + o, (size_t)(cap - o), "|%*d", cwid, (int)(v))
+  PUT_D(tnow);
+  double mtot0 = 0.0;
+  for (int i = 0; i < ncomp; i++) mtot0 += sums[13 * i];
+  PUT_D(mtot0);
+  int nbodies0 = 0;
+  for (int i = 0; i < ncomp; i++) nbodies0 += nbodies[i];
+  PUT_I(nbodies0);
+  double com0[3] = {0, 0, 0}, cov0[3] = {0, 0, 0}, angm0[3] = {0, 0, 0};
+  for (int i = 0; i < ncomp; i++)
+    for (int j = 0; j < 3; j++) { com0[j] += sums[13 * i + 1 + j]; cov0[j] += sums[13 * i + 4 + j]; angm0[j] += sums[13 * i + 7 + j]; }
+  for (int j = 0; j < 3; j++) PUT_D(mtot0 > 0.0 ? com0[j] / mtot0 : 0.0);
+  for (int j = 0; j < 3; j++) PUT_D(mtot0 > 0.0 ? cov0[j] / mtot0 : 0.0);
+  for (int j = 0; j < 3; j++) PUT_D(angm0[j]);
+  double ektot0 = 0.0, eptot0 = 0.0, clausius0 = 0.0;
+  for (int i = 0; i < ncomp; i++) ektot0 += sums[13 * i + 10];
+  PUT_D(ektot0);
+  for (int i = 0; i < ncomp; i++) eptot0 += sums[13 * i + 11] + 0.0;
+  PUT_D(eptot0);
+  for (int i = 0; i < ncomp; i++) clausius0 += sums[13 * i + 12];
+  PUT_D(clausius0);
+  PUT_D(ektot0 + clausius0);
+  PUT_D(clausius0 != 0.0 ? -2.0 * ektot0 / clausius0 : 0.0);
+  PUT_D(wtime);
+  int usedT = 0;
+  for (int i = 0; i < ncomp; i++) usedT += used[i];
+  PUT_I(usedT);
+  for (int i = 0; i < ncomp; i++) {
+    const double *s = sums + 13 * i;
+    PUT_D(s[0]);
+    PUT_I(nbodies[i]);
+    for (int j = 0; j < 3; j++) PUT_D(s[0] > 0.0 ? s[1 + j] / s[0] : 0.0);
+    for (int j = 0; j < 3; j++) PUT_D(s[0] > 0.0 ? s[4 + j] / s[0] : 0.0);
+    for (int j = 0; j < 3; j++) PUT_D(s[7 + j]);
+    for (int j = 0; j < 3; j++) PUT_D(ctr[3 * i + j]);
+    double vbar2 = 0.0;
+    if (s[0] > 0.0) {
+      for (int j = 0; j < 3; j++) vbar2 += s[4 + j] * s[4 + j];
+      vbar2 /= s[0] * s[0];
+    }
+    double ek = s[10];
+    if (nbodies[i] > 1) ek -= 0.5 * s[0] * vbar2;
+    PUT_D(ek);
+    PUT_D(s[11] + 0.0);
+    PUT_D(s[12]);
+    PUT_D(ek + s[12]);
+    PUT_D(s[12] != 0.0 ? -2.0 * ek / s[12] : 0.0);
+    PUT_I(used[i]);
+  }
+  o += snprintf(buf + o, (size_t)(cap - o), "\n");
+#undef PUT_D
+#undef PUT_I
+  return o;
 }

@@ -440,6 +440,24 @@ class Oracle:
                                 *[o.ctypes.data_as(ctypes.c_void_p) for o in out])
         return tuple(out)
 
+    def outlog_sums(self, mass, pos, vel, acc, pot):
+        """The particle loop of OutLog::Run for one component (src/OutLog.cc:392-446) -> the dict Component.log_sums gives."""
+        m, p, v, a, ph = [np.ascontiguousarray(x, dtype=np.float64) for x in (mass, pos, vel, acc, pot)]
+        out = np.zeros(13)
+        self.lib.orc_outlog_sums(ctypes.c_long(len(m)), _dp(m), _dp(p), _dp(v), _dp(a), _dp(ph), _dp(out))
+        return {"mtot": out[0], "com": out[1:4].copy(), "cov": out[4:7].copy(), "angm": out[7:10].copy(),
+                "ektot": out[10], "eptot": out[11], "clausius": out[12], "nbodies": len(m)}
+
+    def outlog_row(self, tnow, sums, centers, used, wtime, precision=10):
+        flat = np.ascontiguousarray(np.array([[s["mtot"], *s["com"], *s["cov"], *s["angm"], s["ektot"], s["eptot"], s["clausius"]]
+                                              for s in sums], dtype=np.float64))
+        n = len(sums)
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.lib.orc_outlog_row(buf, len(buf), ctypes.c_double(tnow), n, _dp(flat),
+                                (ctypes.c_int * n)(*[int(s["nbodies"]) for s in sums]), (ctypes.c_int * n)(*[int(u) for u in used]),
+                                _dp(np.ascontiguousarray(centers, dtype=np.float64)), ctypes.c_double(wtime), int(precision))
+        return buf.value.decode()
+
     def quadls(self, x, y):
         x, y = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y)]
         out = np.zeros(3)
