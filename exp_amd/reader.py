@@ -859,12 +859,20 @@ class Tipsy(ParticleReader):
 # ---------------------------------------------------------------------------------------------------------------
 # writers
 # ---------------------------------------------------------------------------------------------------------------
+def _two_d(a, n: int, dtype):
+    """attribute array -> [n, k] (k kept for an empty component handed a (0, k) array), or None"""
+    if a is None:
+        return None
+    a = np.asarray(a, dtype=dtype)
+    k = a.shape[1] if a.ndim == 2 else (a.size // n if n else 0)
+    return a.reshape(n, k) if k else None
+
+
 def _write_records(out, r_size: int, indexing: bool, indx, mass, pos, vel, pot, iattrib=None, dattrib=None) -> None:
     """Particle::writeBinary for a whole component (exputil/Particle.cc:333-388): doubles are narrowed to float with
     static_cast when rsize is 4."""
     n = len(mass)
-    ia = None if iattrib is None or np.size(iattrib) == 0 else np.asarray(iattrib).reshape(n, -1)
-    da = None if dattrib is None or np.size(dattrib) == 0 else np.asarray(dattrib).reshape(n, -1)
+    ia, da = _two_d(iattrib, n, np.int32), _two_d(dattrib, n, np.float64)
     dt = psp_record_dtype(r_size, indexing, 0 if ia is None else ia.shape[1], 0 if da is None else da.shape[1])
     rec = np.zeros(n, dtype=dt)
     if indexing:
@@ -896,9 +904,9 @@ def _component_block(comp: dict, real4: bool):
     if not isinstance(info, (bytes, bytearray)):
         info = (info if info.endswith("\n") else info + "\n").encode()
     ninfo = max(DEFAULT_INFO_SIZE, len(info))                   # grown when the stanza is longer (:2399-2408)
-    ia, da = comp.get("iattrib"), comp.get("dattrib")
-    niatr = 0 if ia is None or np.size(ia) == 0 else np.asarray(ia).reshape(n, -1).shape[1]
-    ndatr = 0 if da is None or np.size(da) == 0 else np.asarray(da).reshape(n, -1).shape[1]
+    ia, da = _two_d(comp.get("iattrib"), n, np.int32), _two_d(comp.get("dattrib"), n, np.float64)
+    niatr = 0 if ia is None else ia.shape[1]
+    ndatr = 0 if da is None else da.shape[1]
     import yaml
     try:
         conf = yaml.safe_load(info.decode())
@@ -962,8 +970,7 @@ def write_spl(master: str, time: float, comps: Sequence[dict], nparts: int = 2, 
                     part.write(struct.pack("<I", edges[k + 1] - edges[k]))
                     _write_records(part, r_size, indexing, None if indx is None else np.asarray(indx)[s],
                                    np.asarray(mass)[s], np.asarray(pos)[s], np.asarray(vel)[s], np.asarray(pot)[s],
-                                   None if ia is None else np.asarray(ia).reshape(n, -1)[s],
-                                   None if da is None else np.asarray(da).reshape(n, -1)[s])
+                                   None if ia is None else ia[s], None if da is None else da[s])
                 written.append(os.path.join(outdir, name))
     return written
 

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .reader import GADGET_TYPES, PSP, ParticleReader, _Gadget
+from .reader import GADGET_TYPES, PSP, ParticleReader, _Gadget, _two_d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
@@ -311,8 +311,8 @@ def write_psp_hdf5(path: str, time: float, comps: Sequence[dict], real4: bool = 
         attr("/Config", "PSPstyle", "i", [0 if gadget4 else 1], scalar=True)
         attr("/Config", "NTYPES", "i", [len(comps)], scalar=True)
         attr("/Config", "DOUBLEPRECISION", "i", [dp], scalar=True)
-        nia = [0 if c.get("iattrib") is None else np.asarray(c["iattrib"]).reshape(len(c["mass"]), -1).shape[1] for c in comps]
-        nda = [0 if c.get("dattrib") is None else np.asarray(c["dattrib"]).reshape(len(c["mass"]), -1).shape[1] for c in comps]
+        nia = [0 if _two_d(c.get("iattrib"), len(c["mass"]), np.int32) is None else _two_d(c["iattrib"], len(c["mass"]), np.int32).shape[1] for c in comps]
+        nda = [0 if _two_d(c.get("dattrib"), len(c["mass"]), np.float64) is None else _two_d(c["dattrib"], len(c["mass"]), np.float64).shape[1] for c in comps]
         attr("/Config", "Niattrib", "i", nia)
         attr("/Config", "Ndattrib", "i", nda)
         lib.exp_h5p_group(p, b"/Parameters")
@@ -333,8 +333,9 @@ def write_psp_hdf5(path: str, time: float, comps: Sequence[dict], real4: bool = 
         pex = np.asarray(c["potext"]) if c.get("potext") is not None else zeros
         vel = np.asarray(c["vel"]) if c.get("vel") is not None else np.zeros((n, 3))
         idx = np.asarray(c["indx"]) if c.get("indx") is not None else np.arange(1, n + 1)
-        ia = None if c.get("iattrib") is None else np.ascontiguousarray(np.asarray(c["iattrib"]).reshape(n, -1), dtype=np.int32)
-        da = None if c.get("dattrib") is None else np.ascontiguousarray(np.asarray(c["dattrib"]).reshape(n, -1), dtype=np.float64)
+        ia, da = _two_d(c.get("iattrib"), n, np.int32), _two_d(c.get("dattrib"), n, np.float64)
+        ia = None if ia is None else np.ascontiguousarray(ia)
+        da = None if da is None else np.ascontiguousarray(da)
         if gadget4:
             if masses[k] == 0.0:
                 dset(grp + "/Masses", real, c["mass"])

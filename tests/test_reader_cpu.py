@@ -155,6 +155,21 @@ def test_split_psp_round_trip(tmp_path, oracle):
                 assert np.array_equal(v, b.arrays()[k]), (name, k)
 
 
+def test_empty_component_with_attributes(oracle, tmp_path):
+    """nbod = 0 with niatr / ndatr > 0: the header still states the attribute counts (found by tools/dbg/fuzz_reader.py)."""
+    rng = np.random.default_rng(4)
+    comps = [_comp(rng, "dark", 0, True, 2, 3), _comp(rng, "star", 5, False, 1, 0)]
+    a, b, m = tmp_path / "OUT.a", tmp_path / "OUT.b", tmp_path / "SPL.e"
+    R.write_psp(str(a), 0.0, comps)
+    oracle.psp_write(b, 0.0, comps)
+    assert a.read_bytes() == b.read_bytes()
+    R.write_spl(str(m), 0.0, comps, nparts=3)
+    rd = R.PSPspl([str(m)])
+    assert (rd.stanzas[0].nbod, rd.stanzas[0].niatr, rd.stanzas[0].ndatr) == (0, 2, 3) and len(rd.arrays()["mass"]) == 0
+    rd.SelectType("star")
+    assert np.array_equal(rd.arrays()["iattrib"], comps[1]["iattrib"])
+
+
 def test_psp_copy_as_the_reference_writes_it(tmp_path):
     """PSP::writePSP (exputil/ParticleReader.cc:1883-1930) writes float records whatever ``real4`` says: the real4 copy
     of a double file reads back as the float narrowing of the original."""
