@@ -60,3 +60,77 @@ def test_two_rank_gloo_allreduce_matches_single_rank():
         assert p.exitcode == 0
     for rank, n0, n1, err in res:
         assert err < 1e-13, (rank, err)
+
+
+def _reader_worker(rank, world, port, path, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from exp_amd import reader as R
+    from exp_amd.field import FieldGenerator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rd = R.ParticleReader.createReader("PSPout", [path])
+    assert (rd.numprocs, rd.myid) == (world, rank)            # ParticleReader() asks the process group as the reference asks MPI
+    rd.SelectType("dark")
+    mine = rd.arrays()["indx"].astype(np.int64)
+    # every particle on exactly one rank, dealt round-robin
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(mine)]))
+    buf = [torch.zeros(int(s), dtype=torch.int64) for s in sizes]
+    pad = torch.from_numpy(mine)
+    if len({int(s) for s in sizes}) == 1:
+        dist.all_gather(buf, pad)
+    else:                                                      # ragged shares: gather padded
+        big = max(int(s) for s in sizes)
+        bufp = [torch.zeros(big, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(bufp, torch.nn.functional.pad(pad, (0, big - len(mine))))
+        buf = [b[: int(s)] for b, s in zip(bufp, sizes)]
+    # the histogram: each rank bins its share in float, the float sums are added (MPI_Reduce(MPI_FLOAT, MPI_SUM))
+    fg = FieldGenerator([0.0], [-1, -1, -1], [1, 1, 1], [8, 8, 0])
+    got = fg.histo1d(rd, 2.0, 12, "r")
+    parts = []
+    for r in range(world):
+        solo = R.PSPout([path])
+        solo.numprocs, solo.myid = world, r
+        solo.SelectType("dark")
+        one = FieldGenerator([0.0], [-1, -1, -1], [1, 1, 1], [8, 8, 0])
+        one._reduce_f32 = staticmethod(lambda a: a)
+        a = solo.arrays()
+        rad = np.sqrt((a["pos"] ** 2).sum(axis=1))
+        bins = np.where(np.floor(rad / (2.0 / 12)) < 12, np.floor(rad / (2.0 / 12)), -1).astype(np.int64)
+        parts.append(one._binsum(bins, a["mass"], 12))
+    q.put((rank, [b.numpy().tolist() for b in buf], got.tolist(), [p.tolist() for p in parts]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_a_phase_space_file(tmp_path):
+    """The readers deal a file over the ranks of the process group as the reference deals it over MPI ranks, and the
+    particle histograms add the ranks' float sums (world_size 2, gloo; the float accumulation is the C-ABI's host loop)."""
+    import torch.multiprocessing as mp
+    from exp_amd import reader as R
+    if not os.path.exists(os.path.join(ROOT, "exp_amd", "libexp_amd.so")):
+        pytest.skip("exp_amd/libexp_amd.so not built")
+    rng = np.random.default_rng(3)
+    n = 1001
+    comp = dict(info=R.component_info("dark", "sphereSL", {}, {"indexing": True}), mass=rng.uniform(1, 2, n) / n,
+                pos=rng.normal(0, 0.6, (n, 3)), vel=rng.normal(size=(n, 3)), indx=(rng.permutation(n) + 1).astype(np.uint64))
+    path = str(tmp_path / "OUT.shared")
+    R.write_psp(path, 0.0, [comp])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_reader_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shares, got, parts in res:
+        assert shares[0] == comp["indx"][0::2].tolist() and shares[1] == comp["indx"][1::2].tolist()
+        want = (np.array(parts[0], dtype=np.float32) + np.array(parts[1], dtype=np.float32))
+        i = np.arange(12)
+        want = (want.astype(np.float64) / (4.0 * 3.14159265358979323846 / 3.0 * (2.0 / 12) ** 3 * (3 * i * (i + 1) + 1))).astype(np.float32)
+        assert np.array_equal(np.array(got, dtype=np.float32), want) and want.sum() > 0
