@@ -216,6 +216,8 @@ class ParticleReader:
         m, pos, vel = a["mass"].astype(np.float64), a["pos"].astype(np.float64), a["vel"].astype(np.float64)
         mtot = m.sum()
         rows = {}
+        if len(m) == 0:
+            return
         for tag, x in (("p", pos), ("v", vel)):
             med = []
             for k in range(3):
@@ -378,6 +380,8 @@ def _parse_info(st: PSPstanza, allow_old: bool) -> Optional[str]:
         conf = None
     if conf is not None:
         cconf, fconf = conf.get("parameters"), conf.get("force")
+        if "name" not in conf:
+            raise RuntimeError("Error parsing component config: the stanza has no <name>")
         st.name = str(conf["name"])
         st.id = str(fconf["id"]) if isinstance(fconf, dict) else "<undefined>"
         st.cparam = _flow(cconf)
@@ -484,7 +488,7 @@ class PSP(ParticleReader):
                              ("nbod", s.nbod), ("niatr", s.niatr), ("ndatr", s.ndatr), ("rsize", s.r_size)):
                 out.write(f" {key} :: ".rjust(20) + f"{val}\n")
             out.write("-" * 60 + "\n")
-            if stats:
+            if stats and len(self.arrays()["mass"]):
                 a = self.arrays()
                 n = self.stanzas[self._cur].nbod
                 mid = min(int(math.floor(0.5 * n + 0.5)), len(a["mass"]) - 1)   # (the reference indexes one past the end for n = 1)
@@ -526,7 +530,6 @@ class PSPout(PSP):
             if len(raw) < 16:
                 raise RuntimeError(f"Could not read master header for <{self.file}>")
             self.time, self.ntot, self.ncomp = struct.unpack("<dii", raw)
-            size = os.fstat(f.fileno()).st_size
             for _ in range(self.ncomp):
                 st = PSPstanza()
                 raw = f.read(8)
@@ -539,17 +542,18 @@ class PSPout(PSP):
                 msg = _parse_info(st, allow_old=True)
                 if msg and verbose:
                     print(msg, end="")
-                skip = st.nbod * (st.index_size + 8 * st.r_size + st.niatr * 4 + st.ndatr * st.r_size)
-                if st.pspos + skip > size:
-                    print(f"IO error: can't find next header for time={_g(self.time)} . . . quit reading <{self.file}>")
-                    break
-                f.seek(skip, os.SEEK_CUR)
+                # (seeking past the end of a truncated file does not fail, there or here: the stanza is kept, the NEXT read
+                # -- of a magic number here, of the particles in _load -- is what fails)
+                f.seek(st.nbod * (st.index_size + 8 * st.r_size + st.niatr * 4 + st.ndatr * st.r_size), os.SEEK_CUR)
                 self.stanzas.append(st)
 
     def _load(self) -> Dict[str, np.ndarray]:
         st = self.stanzas[self._cur]
         dt = self._dtype(st)
-        rec = np.memmap(self.file, dtype=dt, mode="r", offset=st.pspos, shape=(st.nbod,)) if st.nbod else np.zeros(0, dt)
+        try:
+            rec = np.memmap(self.file, dtype=dt, mode="r", offset=st.pspos, shape=(st.nbod,)) if st.nbod else np.zeros(0, dt)
+        except (ValueError, OSError) as e:                     # shorter than its header says
+            raise RuntimeError(f"PSPout: <{self.file}> ends inside component <{st.name}>") from e
         mine = np.array(rec[self.myid::self.numprocs])       # stagger by myid, stride numprocs (:1689-1735)
         return self._finish(st, mine, self.myid)
 
@@ -740,14 +744,13 @@ class GadgetNative(_Gadget):
             pos = block("<f4", 3, "position")
             vel = block("<f4", 3, "velocity")
             ids = block("<i4", 1, "id")
-            with_mass = any(npart[k] > 0 and h["mass"][k] == 0 for k in range(6))
+            # (the mass block exists when some populated type has a zero table entry, and holds those types only)
             if h["mass"][self.ptype] == 0 and n:
                 b1, = struct.unpack("<i", f.read(4))
                 f.seek(sum(npart[k] for k in range(self.ptype) if h["mass"][k] == 0) * 4, os.SEEK_CUR)
                 mass = np.fromfile(f, dtype="<f4", count=n).astype(np.float64)
             else:
                 mass = np.full(n, float(h["mass"][self.ptype]))
-            del with_mass
         s = slice(self.myid, None, self.numprocs)
         return {"mass": mass[s], "pos": pos[s].astype(np.float64), "vel": vel[s].astype(np.float64),
                 "indx": ids[s].astype(np.int64).astype(np.uint64)}     # `indx = temp` (int -> unsigned long: sign-extended)

@@ -390,3 +390,36 @@ def test_histograms_cpu_parts_match_the_oracle(oracle, tmp_path):
         fg.histo1d(rd, 1.0, 4, "zz")
     with pytest.raises(RuntimeError):
         fg.histo1dlog(rd, 0.0, 1.0, 4)
+
+
+def test_truncated_and_malformed_files_fail_loudly(tmp_path):
+    rng = np.random.default_rng(8)
+    comps = [_comp(rng, "dark", 50, False, 0, 0), _comp(rng, "star", 20, False, 0, 0)]
+    path = tmp_path / "OUT.t"
+    R.write_psp(str(path), 0.0, comps)
+    raw = path.read_bytes()
+    (tmp_path / "cut1").write_bytes(raw[: len(raw) - 100])          # inside the last component's particles
+    rd = R.PSPout([str(tmp_path / "cut1")])
+    assert rd.GetTypes() == ["dark", "star"]
+    rd.SelectType("dark")
+    assert len(rd.arrays()["mass"]) == 50
+    rd.SelectType("star")
+    with pytest.raises(RuntimeError, match="ends inside"):
+        rd.arrays()
+    (tmp_path / "cut2").write_bytes(raw[: 16 + 8 + 16 + 1024 + 50 * 64 + 4])   # inside the second magic
+    with pytest.raises(RuntimeError, match="magic"):
+        R.PSPout([str(tmp_path / "cut2")])
+    (tmp_path / "cut3").write_bytes(raw[:10])
+    with pytest.raises(RuntimeError, match="master header"):
+        R.PSPout([str(tmp_path / "cut3")])
+    with pytest.raises(RuntimeError):
+        R.PSPout([str(tmp_path / "nonexistent")])
+    bad = dict(comps[0], info="parameters: {indexing: false}\n")    # YAML without a name
+    R.write_psp(str(tmp_path / "noname"), 0.0, [bad])
+    with pytest.raises(RuntimeError, match="name"):
+        R.PSPout([str(tmp_path / "noname")])
+    # an empty stanza prints its summary without statistics
+    R.write_psp(str(tmp_path / "empty"), 0.0, [_comp(rng, "gas", 0, False, 0, 0)])
+    out = io.StringIO()
+    R.PSPout([str(tmp_path / "empty")]).PrintSummary(stats=True, out=out)
+    assert "nbod :: 0" in out.getvalue() and "Position" not in out.getvalue()
