@@ -4,7 +4,7 @@ differencing routes; levels bit for bit, states and per-level coefficient sets t
 tests/test_config4_gpu.py.  One line per trial; a level mismatch of a handful of particles is a time-step criterion
 within rounding of a power-of-two boundary (reported as `edge`), anything else is a failure.
 
-    python tools/dbg/fuzz_multistep.py [trials=30] [seed=1]"""
+    python tests/fuzz/fuzz_multistep.py [trials=30] [seed=1]"""
 import os
 import sys
 import time

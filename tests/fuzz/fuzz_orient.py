@@ -2,7 +2,7 @@
 restatement of src/Orient.cc over random particle sets (sizes from 1 to 1e5, ties and signed zeros in the binding
 energies), `keep`, `many`, flags, the kinetic-energy mode, spacing and damping, several calls in a row with the
 component moved in between.  The energy threshold must be the same double, the count the same integer, centre / axis /
-rotations equal to round-off.    python tools/dbg/fuzz_orient.py [trials=60] [seed=1]"""
+rotations equal to round-off.    python tests/fuzz/fuzz_orient.py [trials=60] [seed=1]"""
 import os
 import sys
 import time

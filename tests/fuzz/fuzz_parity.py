@@ -3,7 +3,7 @@ centres and ADVERSARIAL particle sets (origin, polar axis, exactly on the window
 duplicates, zero masses, one particle, a handful) for both force methods, single level.  Every trial prints one line;
 exit code 1 on the first mismatch with the seed that reproduces it.
 
-    python tools/dbg/fuzz_parity.py [trials=60] [seed=1] [sph|cyl|both]"""
+    python tests/fuzz/fuzz_parity.py [trials=60] [seed=1] [sph|cyl|both]"""
 import os
 import sys
 import time
@@ -217,6 +217,6 @@ for t in range(trials):
             rng = np.random.default_rng([seed0, t, 0 if kind == "sph" else 1])
             if not fn(t, rng):
                 bad += 1
-                print(f"  reproduce: python tools/dbg/fuzz_parity.py {t + 1} {seed0} {kind}   (trial {t})", flush=True)
+                print(f"  reproduce: python tests/fuzz/fuzz_parity.py {t + 1} {seed0} {kind}   (trial {t})", flush=True)
 print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -2,7 +2,7 @@
 orders, grids, maps, windows (N1 / N2), flags and vertical-parity splits; `createFromArray` with a random centre, rotation,
 array layout (posvelrows, extra velocity columns) against the literal pyEXP twins of the oracle (accumulate at the
 transformed positions); `getAccel` and `getFields` at points inside and far outside the tables; `set_coefs` round trip of
-the returned structure.    python tools/dbg/fuzz_pyexp.py [trials=40] [seed=1]"""
+the returned structure.    python tests/fuzz/fuzz_pyexp.py [trials=40] [seed=1]"""
 import os
 import sys
 import tempfile

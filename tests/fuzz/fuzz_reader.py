@@ -2,7 +2,7 @@
 and real attributes, indexed or not, names with spaces, info stanzas around the 1024-byte limit), both precisions, 1-5
 ranks.  Per trial: `write_psp` must be byte-identical to the oracle's writer; `PSPout` on the oracle's file must give the
 oracle reader's arrays for every rank; `write_spl` -> `PSPspl` and `write_psp_hdf5` -> `PSPhdf5` (both layouts) must give
-what `PSPout` gives.    python tools/dbg/fuzz_reader.py [trials=200] [seed=1]"""
+what `PSPout` gives.    python tests/fuzz/fuzz_reader.py [trials=200] [seed=1]"""
 import os
 import sys
 import tempfile

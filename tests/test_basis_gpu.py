@@ -184,7 +184,7 @@ def test_m0_only_is_an_evaluation_flag_in_pyexp(halo_basis, oracle, tmp_path):
     """``Spherical::accumulate`` applies none of the flags (expui/BiorthBasis.cc:583-665): with M0_ONLY the coefficient
     structure it returns still holds every m and only the evaluation drops m > 0 (:851).  The n-body force skips the
     m > 0 sums in the accumulation itself (src/SphericalBasis.cc:550): ``exp_amd_sph_set_accumulate_all_m`` selects
-    between the two, and the basis object asks for pyEXP's (found by tools/dbg/fuzz_pyexp.py)."""
+    between the two, and the basis object asks for pyEXP's (found by tests/fuzz/fuzz_pyexp.py)."""
     from exp_amd.basis import Basis
     from exp_amd.runtime import Component, SphereSL
     basis, cfg = halo_basis

@@ -156,7 +156,7 @@ def test_split_psp_round_trip(tmp_path, oracle):
 
 
 def test_empty_component_with_attributes(oracle, tmp_path):
-    """nbod = 0 with niatr / ndatr > 0: the header still states the attribute counts (found by tools/dbg/fuzz_reader.py)."""
+    """nbod = 0 with niatr / ndatr > 0: the header still states the attribute counts (found by tests/fuzz/fuzz_reader.py)."""
     rng = np.random.default_rng(4)
     comps = [_comp(rng, "dark", 0, True, 2, 3), _comp(rng, "star", 5, False, 1, 0)]
     a, b, m = tmp_path / "OUT.a", tmp_path / "OUT.b", tmp_path / "SPL.e"

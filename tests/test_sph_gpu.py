@@ -506,7 +506,7 @@ def test_prekicked_velocities_leave_the_trajectory_alone(ctx, oracle, plummer_s6
 
 
 def test_extrapolation_inside_rmin_with_the_logarithmic_map(ctx, oracle, monkeypatch):
-    """Found by the randomised campaign (tools/dbg/fuzz_parity.py): with cmap = 2 a radius well inside rmin is extrapolated
+    """Found by the randomised campaign (tests/fuzz/fuzz_parity.py): with cmap = 2 a radius well inside rmin is extrapolated
     over hundreds of cells (p = (xi - xi[1]) / dxi = -244 at rmin / 6 for numr 1500), and the reference's three-term radial
     derivative (p - 1/2) H[0] - 2 p H[1] + (p + 1/2) H[2] (exputil/SLGridMP2.cc:954-989) cancels to ~1e-6 of its terms for
     l = 0 (a Plummer core: the potential is flat there, the radial force a small difference of large numbers).  Against
