@@ -777,8 +777,20 @@ class Tipsy(ParticleReader):
     particles, the last one the remainder (``ios_psize``); the index of a native file's particle is its position in
     its group + 1, a Bonsai file carries its own."""
 
+    class TipsyType:
+        """the enum pyEXP exports (pyEXP/ParticleReaderWrappers.cc:563-567; ``export_values``: also ``Tipsy.native`` ...)"""
+        native, xdr, bonsai1, bonsai = "native", "xdr", "bonsai1", "bonsai"
+
+    native, xdr, bonsai = TipsyType.native, TipsyType.xdr, TipsyType.bonsai
+
     def __init__(self, files, ttype: str = "native", verbose: bool = False):
         super().__init__()
+        if ttype == "xdr":
+            # (a reference build without RPC/XDR falls back to the native reader for this type, :2117-2121; refusing is
+            # the safer reading of a request for XDR data)
+            raise RuntimeError("Tipsy: this build does not have RPC/XDR support; use Tipsy native format")
+        if ttype not in ("native", "bonsai", "bonsai1"):
+            raise RuntimeError(f"Tipsy: unknown file type <{ttype}>")
         self.files = [files] if isinstance(files, str) else list(files)
         if not isinstance(files, str) and len(self.files) == 1:
             scan = self.scanDirectory(self.files[0])
