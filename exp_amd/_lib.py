@@ -98,6 +98,8 @@ SIGNATURES = {
     "exp_amd_sph_set_exterior": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_accumulate_all_m": (c_int, [c_void_p, c_int]),
     "exp_amd_host_binsum_f32": (c_int, [ctypes.c_longlong, c_void_p, c_void_p, c_int, c_void_p]),
+    "exp_amd_host_psp_unpack": (c_int, [ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exp_amd_sph_set_dsmall": (c_int, [c_void_p, c_double]),
     "exp_amd_sph_set_density": (c_int, [c_void_p, c_void_p]),
     "exp_amd_cyl_cov_enable": (c_int, [c_void_p, c_int]),

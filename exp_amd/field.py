@@ -125,17 +125,15 @@ class FieldGenerator:
     @staticmethod
     def _reduce_f32(a: np.ndarray) -> np.ndarray:
         """MPI_Reduce(MPI_FLOAT, MPI_SUM) to the root: every rank gets the sum here"""
-        try:
+        import sys
+        dist = sys.modules.get("torch.distributed")           # (only a process that made a group has it; no import here)
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             import torch
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                t = torch.from_numpy(np.ascontiguousarray(a))
-                if dist.get_backend() == "nccl":
-                    t = t.cuda()
-                dist.all_reduce(t)
-                return t.cpu().numpy()
-        except ImportError:
-            pass
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t)
+            return t.cpu().numpy()
         return a
 
     def histogram2d(self, reader, center=(0.0, 0.0, 0.0)) -> Dict[str, np.ndarray]:

@@ -28,6 +28,7 @@ Writers: ``write_psp`` (the OUT file of OutPSN / OutCHKPT), ``write_spl`` (OutPS
 ``read_bodies_ascii`` (the body file a component starts from: src/Component.cc:1462-1560, exputil/Particle.cc:469-526)."""
 from __future__ import annotations
 
+import ctypes
 import io
 import math
 import os
@@ -62,13 +63,31 @@ class Particle:
 
 def _ranks():
     """(numprocs, myid): ParticleReader() asks MPI (include/ParticleReader.H:50-62); here the process group."""
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+    dist = sys.modules.get("torch.distributed")               # (a process with a group has imported it; no import here:
+    try:                                                       # the first `import torch` of a process takes seconds)
+        if dist is not None and dist.is_available() and dist.is_initialized():
             return dist.get_world_size(), dist.get_rank()
     except Exception:
         pass
     return 1, 0
+
+
+_hostlib = False
+
+
+def _host_lib():
+    """libexp_amd.so for its host-side record unpacking (exp_amd_host_psp_unpack); None when it is not built -- the
+    files are then unpacked by numpy, same values, a tenth of the rate"""
+    global _hostlib
+    if _hostlib is False:
+        try:
+            from ._lib import load
+            _hostlib = load()
+            if not hasattr(_hostlib, "exp_amd_host_psp_unpack"):
+                _hostlib = None
+        except Exception:
+            _hostlib = None
+    return _hostlib
 
 
 class P2Quantile:
@@ -463,15 +482,58 @@ class PSP(ParticleReader):
         return psp_record_dtype(st.r_size, st.index_size > 0, st.niatr, st.ndatr)
 
     def _finish(self, st: PSPstanza, rec: np.ndarray, first: int) -> Dict[str, np.ndarray]:
-        """records of this rank (global sequence numbers first, first + numprocs, ...) -> double arrays"""
-        seq = first + self.numprocs * np.arange(len(rec), dtype=np.uint64)
-        out = {"mass": rec["mass"].astype(np.float64), "pos": rec["pos"].astype(np.float64),
-               "vel": rec["vel"].astype(np.float64), "pot": rec["pot"].astype(np.float64),
-               "indx": rec["indx"].astype(np.uint64) if st.index_size else seq}      # indx = pcount otherwise (:283)
+        """records of this rank (global sequence numbers first, first + numprocs, ...) -> double arrays.  The fields are
+        taken out of the packed records one scalar column at a time (a strided 1-D copy each): numpy's copy of a
+        sub-array field out of a packed structured array runs at a fifth of that rate."""
+        n = len(rec)
+        seq = first + self.numprocs * np.arange(n, dtype=np.uint64)
+        lib = _host_lib()
+        if lib is not None and n:
+            # rec may be a strided view of the file's records (this rank's share): the byte distance between them is the stride
+            base = rec if rec.flags.c_contiguous or rec.strides[0] % rec.dtype.itemsize == 0 else np.ascontiguousarray(rec)
+            indx = np.empty(n, np.uint64) if st.index_size else seq
+            mass, pos, vel, pot = np.empty(n), np.empty((n, 3)), np.empty((n, 3)), np.empty(n)
+            ia = np.empty((n, st.niatr), np.int32) if st.niatr else None
+            da = np.empty((n, st.ndatr)) if st.ndatr else None
+            vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            rc = lib.exp_amd_host_psp_unpack(n, ctypes.c_void_p(base.__array_interface__["data"][0]), int(base.strides[0]),
+                                             int(st.r_size), int(bool(st.index_size)), int(st.niatr), int(st.ndatr),
+                                             vp(indx) if st.index_size else None, vp(mass), vp(pos), vp(vel), vp(pot), vp(ia), vp(da))
+            if rc != 0:
+                raise RuntimeError(f"PSP: exp_amd_host_psp_unpack failed ({rc})")
+            out = {"mass": mass, "pos": pos, "vel": vel, "pot": pot, "indx": indx}
+            if ia is not None:
+                out["iattrib"] = ia
+            if da is not None:
+                out["dattrib"] = da
+            return out
+        rec = np.ascontiguousarray(rec)
+        dt, raw, size = rec.dtype, rec.view(np.uint8).reshape(-1), rec.dtype.itemsize
+
+        def column(name, k, width, out_dtype):
+            base, off = dt.fields[name][0].base, dt.fields[name][1]
+            out = np.empty((n, width) if width > 1 or k is None else n, dtype=out_dtype)
+            for j in range(width):
+                col = np.ndarray(shape=(n,), dtype=base, buffer=raw, offset=off + j * base.itemsize, strides=(size,))
+                if out.ndim == 2:
+                    out[:, j] = col
+                else:
+                    out[:] = col
+            return out
+        if n == 0:
+            out = {"mass": np.zeros(0), "pos": np.zeros((0, 3)), "vel": np.zeros((0, 3)), "pot": np.zeros(0), "indx": seq}
+            if st.niatr:
+                out["iattrib"] = np.zeros((0, st.niatr), np.int32)
+            if st.ndatr:
+                out["dattrib"] = np.zeros((0, st.ndatr))
+            return out
+        out = {"mass": column("mass", 0, 1, np.float64), "pos": column("pos", None, 3, np.float64),
+               "vel": column("vel", None, 3, np.float64), "pot": column("pot", 0, 1, np.float64),
+               "indx": column("indx", 0, 1, np.uint64) if st.index_size else seq}      # indx = pcount otherwise (:283)
         if st.niatr:
-            out["iattrib"] = rec["iattrib"].astype(np.int32)
+            out["iattrib"] = column("iattrib", None, st.niatr, np.int32)
         if st.ndatr:
-            out["dattrib"] = rec["dattrib"].astype(np.float64)
+            out["dattrib"] = column("dattrib", None, st.ndatr, np.float64)
         return out
 
     def PrintSummary(self, stats: bool = True, timeonly: bool = False, out=None) -> None:
@@ -554,8 +616,7 @@ class PSPout(PSP):
             rec = np.memmap(self.file, dtype=dt, mode="r", offset=st.pspos, shape=(st.nbod,)) if st.nbod else np.zeros(0, dt)
         except (ValueError, OSError) as e:                     # shorter than its header says
             raise RuntimeError(f"PSPout: <{self.file}> ends inside component <{st.name}>") from e
-        mine = np.array(rec[self.myid::self.numprocs])       # stagger by myid, stride numprocs (:1689-1735)
-        return self._finish(st, mine, self.myid)
+        return self._finish(st, rec[self.myid::self.numprocs], self.myid)   # stagger by myid, stride numprocs (:1689-1735)
 
 
 class PSPspl(PSP):

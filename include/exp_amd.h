@@ -450,6 +450,14 @@ long long exp_amd_sim_step_switches(const exp_amd_sim *s);   /* ... summed over 
  * (expui/FieldGenerator.cc:776-1009), whose float sums depend on the order of the particles.              */
 int  exp_amd_host_binsum_f32(long long n, const int *bin, const double *val, int nbins, float *out);
 
+/* Host-only: n packed particle records of a PSP file (exputil/Particle.cc:333-388; PParticle::read,
+ * include/ParticleReader.H:276-315), `rec_size` bytes apart -- [unsigned long indx]? real mass, pos[3], vel[3], pot;
+ * int iattrib[niatr]; real dattrib[ndatr], real = float (r_size 4) or double (8) -- into separate arrays, reals
+ * widened to double (what a reader hands to exp_amd_comp_upload).                                              */
+int  exp_amd_host_psp_unpack(long long n, const void *rec, long long rec_size, int r_size, int indexed, int niatr,
+                             int ndatr, unsigned long long *indx, double *mass, double *pos, double *vel, double *pot,
+                             int *iattrib, double *dattrib);
+
 /* Timing of the last fused step's dominant kernels (ms, HIP events on the context
  * stream); names are static strings.  Used by bench.py for the roofline figure.    */
 int  exp_amd_profile_enable(exp_amd_ctx *ctx, int on);
