@@ -57,6 +57,16 @@ def _ctx() -> Context:
     return _default_ctx
 
 
+
+def _legequad(n: int):
+    """``LegeQuad(n)`` (include/gaussQ.H:104-108, exputil/gaussQ.cc -> Jacobi.c): the Gauss-Legendre knots and weights on
+    [0, 1] of makeFromFunction / computeQuadrature.  The reference finds them by Newton iteration on the Jacobi
+    polynomials and lists them in descending order; these are the same numbers to 4e-15 (tests/test_ref_util.py against
+    the reference's own gaussQ.cc), ascending -- the quadrature sums do not depend on the order."""
+    x, w = np.polynomial.legendre.leggauss(int(n))
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
 class _CoefStructAPI:
     """What pyEXP exposes of ``CoefClasses::CoefStruct`` (expui/CoefStruct.H:18-113; pyEXP/CoefWrappers.cc:720-960):
     the time / centre / orientation accessors, the flat data store (the matrix in column-major order, as Eigen maps
@@ -724,8 +734,7 @@ class SphericalSL(BiorthBasis):
         for v in (ximin, ximax):
             if v >= 1.0:
                 raise RuntimeError(f"BiorthBasis::{who}: x>=+1")
-        xk, wk = np.polynomial.legendre.leggauss(knots)      # LegeQuad: knots and weights on [0, 1]
-        xk, wk = 0.5 * (xk + 1.0), 0.5 * wk
+        xk, wk = _legequad(knots)
         xx = ximin + (ximax - ximin) * xk
         rr = (1.0 + xx) / (1.0 - xx) * rmapping
         dxr = 0.5 * (1.0 - xx) * (1.0 - xx) / rmapping
@@ -1172,8 +1181,7 @@ class Cylindrical(BiorthBasis):
             z_to_y, y_to_z, d_y_to_z = (lambda z: z), (lambda y: y), (lambda y: np.ones_like(y))
         xmin, xmax = r_to_xi(g.rmin * A), r_to_xi(Rtab * A)
         ymin, ymax = z_to_y(-Rtab * A), z_to_y(Rtab * A)
-        xk, wk = np.polynomial.legendre.leggauss(knots)
-        xk, wk = 0.5 * (xk + 1.0), 0.5 * wk
+        xk, wk = _legequad(knots)
         xx, yy = xmin + (xmax - xmin) * xk, ymin + (ymax - ymin) * xk
         if g.cmapr > 0:
             Rk, dxr = (1.0 + xx) / (1.0 - xx) * A, 0.5 * (1.0 - xx) * (1.0 - xx) / A

@@ -19,13 +19,19 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 
+def _nan(v: float) -> str:
+    """a NaN as the C library prints it: with its sign (0/0 on x86 is the NEGATIVE quiet NaN: a one-point axis of a grid
+    reads `-nan` in the reference's files); Python's % drops it"""
+    return "-nan" if np.signbit(v) else "nan"
+
+
 def _fmt_general(v: float) -> str:
     """operator<< of a float with the stream's default flags (6 significant digits, %g)."""
-    return "%g" % float(v)
+    return _nan(v) if v != v else "%g" % float(v)
 
 
 def _fmt_sci8(v: float) -> str:
-    return "%.8e" % float(v)
+    return _nan(v) if v != v else "%.8e" % float(v)
 
 
 class _VtrGrid:

@@ -2,10 +2,11 @@
  * psp_oracle.c -- TEST INFRASTRUCTURE ONLY (see bfe_oracle.h): CPU restatement of the reference's phase-space file
  * format and of the particle histograms that read it.  Only tests/ may call it.
  *
- * The reference code these follow needs MPI, yaml-cpp and HighFive to compile (include/libvars.H:8 pulls mpi.h into
- * exputil/Particle.cc; exputil/ParticleReader.cc:12-19), none of which this image has, so it cannot be built into
- * oracle/_ref: the format is restated here statement by statement and pinned by tests/test_ref_pspformat.py, which
- * checks the order, widths and constants against the reference's SOURCE TEXT where /root/reference exists.
+ * The reference's READERS (exputil/ParticleReader.cc) need yaml-cpp and HighFive, which this image lacks, so their logic
+ * is restated here statement by statement.  The RECORD code (exputil/Particle.cc, exputil/header.cc, include/tipsy.H) does
+ * compile -- it needs only <mpi.h>, present under /opt/conda -- into oracle/_ref/libref_particle.so, and
+ * tests/test_ref_particle.py checks this restatement's writer byte for byte against it; tests/test_ref_pspformat.py
+ * checks order, widths and constants against the reference's SOURCE TEXT as well.
  *
  *   orc_psp_write            OutPSN::Run (src/OutPSN.cc:141-169) -> Component::write_binary (src/Component.cc:2385-2454)
  *                            -> ComponentHeader::write (exputil/header.cc:7-19), Particle::writeBinary

@@ -1,7 +1,8 @@
 """The phase-space file format of exp_amd/reader.py and oracle/psp_oracle.c against the reference's SOURCE TEXT.
 
-The reference's reader and writer cannot be compiled here (exputil/Particle.cc pulls mpi.h through include/libvars.H,
-exputil/ParticleReader.cc needs yaml-cpp and HighFive), so what CAN be pinned on the reference side is pinned: the ORDER
+The reference's readers cannot be compiled here (exputil/ParticleReader.cc needs yaml-cpp and HighFive) and its
+output classes neither (src/*.cc need Eigen and yaml-cpp); the record code that CAN be is pinned byte for byte in
+tests/test_ref_particle.py.  What this file adds is the part only the source text can give: the ORDER
 and WIDTH of the stream writes of `Particle::writeBinary`, `ComponentHeader::write`, `Component::write_binary` and
 `Component::write_binary_header`, the stream reads of `PParticle::read`, the members of `MasterHeader`, the magic
 constants and the reader names -- each extracted from the function body where it lies and compared with the record layout

@@ -1,0 +1,105 @@
+"""Two more files of the REFERENCE compiled where they lie (oracle/_ref/libref_util.so, oracle/ref/Makefile):
+exputil/gaussQ.cc -- the Gauss-Legendre rule of makeFromFunction / computeQuadrature -- and exputil/VtkGrid.cc -- the
+rectilinear-grid writer behind FieldGenerator::file_slices / file_volumes in a build without VTK.  CPU only; skipped where
+neither the reference tree nor a prebuilt library exists."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libref_util.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(LIB) and os.path.exists("/root/reference/exputil/gaussQ.cc"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref")], check=False)
+    if not os.path.exists(LIB):
+        pytest.skip("no oracle/_ref/libref_util.so (built where /root/reference exists)")
+    return ctypes.CDLL(LIB)
+
+
+def test_legendre_rule_is_the_references(ref, oracle):
+    """LegeQuad(n) (Jacobi rule with alpha = beta = 0 on [0, 1], found by Newton iteration) against the knots and weights
+    the oracle and the product use for the same rule: the same set to 4e-15 (the reference lists them in DESCENDING
+    order; the quadrature sums do not depend on it), weights summing to 1, polynomials of degree 2n - 1 integrated exactly."""
+    from exp_amd import basis as B
+    for n in (1, 2, 3, 8, 20, 40, 100, 200):
+        k, w = np.zeros(n), np.zeros(n)
+        assert ref.ref_legequad(n, k.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p)) == 0
+        ko, wo = oracle.legequad(n)
+        order = np.argsort(k)
+        assert np.abs(k[order] - ko).max() <= 4e-15 and np.abs(w[order] - wo).max() <= 4e-15 * max(1.0, 1.0 / n) + 1e-17
+        assert abs(w.sum() - 1.0) <= 1e-14
+        kp, wp = B._legequad(n)
+        assert np.array_equal(kp, ko) and np.array_equal(wp, wo)
+        p = min(2 * n - 1, 25)
+        assert abs((w * k ** p).sum() - 1.0 / (p + 1)) <= 1e-14
+
+
+def test_vtr_files_are_the_references_bytes(ref, tmp_path):
+    """exputil/VtkGrid.cc (no VTK) against exp_amd.field._VtrGrid: the same file, byte for byte, for a slice (nz = 1 with a
+    degenerate z range), a volume, field names with `<` and `>`, values across the float range."""
+    from exp_amd.field import _VtrGrid
+    rng = np.random.default_rng(2)
+    cases = [(7, 5, 1, (-1.0, 1.0, -0.5, 0.5, 0.0, 0.0), ["dens", "potl m>0", "x force"]),
+             (4, 3, 6, (0.1, 2.3, -4.0, 4.0, 1e-3, 2e-3), ["dens m=0", "a<b", "rad force", "potl"]),
+             (1, 1, 1, (0.0, 0.0, 0.0, 0.0, 0.0, 0.0), ["single"]),
+             (2, 9, 2, (-1e5, 1e5, -1e-5, 1e-5, 3.0, 5.0), ["big"])]
+    for c, (nx, ny, nz, bounds, names) in enumerate(cases):
+        n = nx * ny * nz
+        data = rng.normal(size=(len(names), n)) * 10.0 ** rng.integers(-12, 12, (len(names), 1))
+        data[0, : min(n, 3)] = [0.0, -0.0, 1.0][: min(n, 3)]
+        a, b = str(tmp_path / f"ref_{c}"), str(tmp_path / f"mine_{c}")
+        arr = (ctypes.c_char_p * len(names))(*[s.encode() for s in names])
+        flat = np.ascontiguousarray(data)
+        rc = ref.ref_vtk_write(a.encode(), nx, ny, nz, (ctypes.c_double * 6)(*bounds), len(names), arr,
+                               flat.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        g = _VtrGrid(nx, ny, nz, *bounds)
+        for name, v in zip(names, data):
+            g.Add(v, name)
+        g.Write(b)
+        assert open(a + ".vtr", "rb").read() == open(b + ".vtr", "rb").read(), (c, names)
+
+
+def test_unit_tables_are_the_references(ref):
+    """expui/UnitValidator.cc compiled in place against exp_amd.units: every (type alias, unit name) pair the product
+    accepts gives the same canonical pair there, the reference accepts nothing more (its own lists of types, aliases and
+    units are walked), and junk is refused by both."""
+    from exp_amd import units as U
+    if not hasattr(ref, "ref_unit_check"):
+        pytest.skip("oracle/_ref/libref_util.so predates ref_unit_check")
+    mine = U.UnitValidator()
+
+    def check(t, u):
+        a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+        ok = ref.ref_unit_check(t.encode(), u.encode(), a, b, 128)
+        return bool(ok), a.value.decode(), b.value.decode()
+
+    def lst(which, t=""):
+        out = ctypes.create_string_buffer(1 << 14)
+        assert ref.ref_unit_list(which, t.encode(), out, len(out)) == 0
+        return [s for s in out.value.decode().split("\n") if s != "" or False]
+    # everything the product's tables hold
+    for alias, canon in U._TYPES.items():
+        for unit in U._UNITS[canon]:
+            assert check(alias, unit) == mine(alias, unit), (alias, unit)
+    # everything the reference's tables hold
+    types = lst(0)
+    assert sorted(types) == sorted(mine.getAllowedTypes())
+    for t in types:
+        aliases = lst(1, t)
+        assert sorted(aliases) == sorted(mine.getAllowedTypeAliases(t)), t
+        units = lst(2, t)
+        assert sorted(u for u in units) == sorted(u for u in mine.getAllowedUnits(t) if u != ""), t
+        for a in aliases:
+            for u in units:
+                assert check(a, u) == mine(a, u), (a, u)
+    for t, u in (("length", "furlong"), ("colour", "kpc"), ("", ""), ("G", "kpc"), ("velocity", "None")):
+        assert check(t, u) == mine(t, u), (t, u)
+    assert check("G", "") == mine("G", "") == (True, "G", "none")
+    assert check("vel", "cm/s") == (True, "velocity", "cmm/s")          # the typo of the reference's table, kept
