@@ -382,6 +382,23 @@ def _flow(node) -> str:
     return yaml.dump(node, default_flow_style=True, width=1 << 20).strip()
 
 
+def _string_tok(text: str, delim: str, count: int) -> List[str]:
+    """``StringTok<string> tokens(text); trim_copy(tokens(delim))`` ``count`` times (include/StringTok.H,
+    exputil/Sutils.cc): like strtok, a token starts at the first character that is NOT a delimiter, so empty fields are
+    skipped, and once the text is used up every further token is empty"""
+    out, pos = [], 0
+    for _ in range(count):
+        token = ""
+        if pos is not None:
+            first = next((i for i in range(pos, len(text)) if text[i] not in delim), None)
+            if first is not None:
+                end = next((i for i in range(first, len(text)) if text[i] in delim), None)
+                token = text[first:end] if end is not None else text[first:]
+                pos = None if end is None or end + 1 >= len(text) else end + 1
+        out.append(token.strip(" \t\n\r\f\v"))
+    return out
+
+
 def _parse_info(st: PSPstanza, allow_old: bool) -> Optional[str]:
     """The stanza's info string -> name, id, cparam, fparam, index_size (exputil/ParticleReader.cc:1346-1439)."""
     import yaml
@@ -408,7 +425,7 @@ def _parse_info(st: PSPstanza, allow_old: bool) -> Optional[str]:
         st.index_size = 8 if isinstance(cconf, dict) and bool(cconf.get("indexing", False)) else 0
         return err
     # old style: name : id : cparam : fparam, "indexing=1" in cparam (:1405-1437)
-    tok = [t.strip() for t in text.split(":")] + [""] * 4
+    tok = _string_tok(text, ":", 4)
     st.name, st.id, st.cparam, st.fparam = tok[0], tok[1], tok[2], tok[3]
     st.index_size = 0
     p1 = st.cparam.find("indexing")

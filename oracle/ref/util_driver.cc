@@ -69,3 +69,17 @@ extern "C" int ref_unit_list(int which, const char *type, char *out, int cap)
     return 0;
   } catch (std::exception &) { out[0] = 0; return -1; }
 }
+
+// The old-style PSP info string as PSPout::PSPout takes it apart (exputil/ParticleReader.cc:1405-1412):
+// StringTok<string> tokens(info); name = trim_copy(tokens(":")); id, cparam, fparam likewise (include/StringTok.H,
+// exputil/Sutils.cc)
+#include "StringTok.H"
+#include "Sutils.H"
+
+extern "C" void ref_old_info(const char *info, char *out4, int cap)
+{
+  StringTok<std::string> tokens(info);
+  std::string s;
+  for (int k = 0; k < 4; k++) { s += trim_copy(tokens(":")); s += '\n'; }
+  strncpy(out4, s.c_str(), cap - 1); out4[cap - 1] = 0;
+}

@@ -103,3 +103,17 @@ def test_unit_tables_are_the_references(ref):
         assert check(t, u) == mine(t, u), (t, u)
     assert check("G", "") == mine("G", "") == (True, "G", "none")
     assert check("vel", "cm/s") == (True, "velocity", "cmm/s")          # the typo of the reference's table, kept
+
+
+def test_old_style_info_tokens_are_the_references(ref):
+    """StringTok + trim_copy of the reference (include/StringTok.H, exputil/Sutils.cc) against reader._string_tok: empty
+    fields are skipped (a token starts at the first non-delimiter), missing ones are empty, white space is trimmed."""
+    from exp_amd.reader import _string_tok
+    if not hasattr(ref, "ref_old_info"):
+        pytest.skip("oracle/_ref/libref_util.so predates ref_old_info")
+    for text in ("halo : sphereSL : nlevel=1, indexing=1 : Lmax=2, nmax=10", "a:b:c:d:e:f", "a::b:::c", ":lead:x", "only",
+                 "", "::::", " spaced  :\ttabs\t: x=1 ,y=2 :", "a:b", "trail:", "x:y:z:", "name :id: c :f \n"):
+        out = ctypes.create_string_buffer(4096)
+        ref.ref_old_info(text.encode(), out, 4096)
+        want = out.value.decode().split("\n")[:4]
+        assert _string_tok(text, ":", 4) == want, (text, want)
