@@ -14,7 +14,7 @@ reference's MPI_Reduce(MPI_FLOAT, MPI_SUM) does."""
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional, Sequence
+from typing import Dict, Sequence
 
 import numpy as np
 
