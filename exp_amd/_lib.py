@@ -59,6 +59,7 @@ SIGNATURES = {
     "exp_amd_comp_destroy": (None, [c_void_p]),
     "exp_amd_comp_size": (c_size_t, [c_void_p]),
     "exp_amd_comp_upload": (c_int, [c_void_p] + [c_void_p] * 7),
+    "exp_amd_comp_upload_frame": (c_int, [c_void_p] + [c_void_p] * 7 + [c_int, c_void_p, c_void_p]),
     "exp_amd_comp_upload_acc": (c_int, [c_void_p] + [c_void_p] * 4),
     "exp_amd_comp_upload_levels": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_download": (c_int, [c_void_p] + [c_void_p] * 11),

@@ -348,13 +348,17 @@ class BiorthBasis:
         if p.ndim != 2:
             p = np.stack([np.asarray(a, dtype=np.float64) for a in p])
         pos, vel = self._layout(p, posvelrows)
-        pos = (pos - self.coefctr) @ self.coefrot.T
         seq = np.arange(len(m), dtype=np.uint32)      # the index accumulate() is handed (:4616-4738)
-        if self._ftor is not None:
-            v = np.zeros_like(pos) if vel is None else vel @ self.coefrot.T
-            keep = np.array([bool(self._ftor(m[i], pos[i], v[i], self.coefindx + i))
-                             for i in range(len(m))])
-            pos, m, seq = pos[keep], m[keep], seq[keep]
+        if self._ftor is None:
+            # the expansion frame rot (x - ctr) is applied on the device as the particles are uploaded
+            self.coefindx += len(m)
+            self._accumulate_batch(m, pos, seq, frame=(self.coefctr, self.coefrot))
+            return
+        pos = (pos - self.coefctr) @ self.coefrot.T
+        v = np.zeros_like(pos) if vel is None else vel @ self.coefrot.T
+        keep = np.array([bool(self._ftor(m[i], pos[i], v[i], self.coefindx + i))
+                         for i in range(len(m))])
+        pos, m, seq = pos[keep], m[keep], seq[keep]
         self.coefindx += len(m)
         self._accumulate_batch(m, pos, seq)
 
@@ -384,8 +388,11 @@ class BiorthBasis:
         for lo in range(0, max(n, 1), step):
             sl = slice(lo, min(lo + step, n))
             m = np.ascontiguousarray(a["mass"][sl], dtype=np.float64)
-            pos = (np.asarray(a["pos"][sl], dtype=np.float64) - ctr) @ R.T
             seq = np.asarray(a["indx"][sl]).astype(np.uint32)
+            if self._ftor is None:
+                self._accumulate_batch(m, np.asarray(a["pos"][sl], dtype=np.float64), seq, frame=(ctr, R))
+                continue
+            pos = (np.asarray(a["pos"][sl], dtype=np.float64) - ctr) @ R.T
             if self._ftor is not None:
                 v = np.asarray(a["vel"][sl], dtype=np.float64) @ R.T
                 idx = a["indx"][sl]
@@ -685,10 +692,10 @@ class SphericalSL(BiorthBasis):
         from ._lib import check
         check(self.force.lib.exp_amd_sph_set_dsmall(self.force.h, float(v)), self.ctx.h)
 
-    def _accumulate_batch(self, m, pos, seq=None) -> None:
+    def _accumulate_batch(self, m, pos, seq=None, frame=None) -> None:
         if len(m) == 0:
             return
-        c = Component.from_arrays(self.ctx, m, pos)
+        c = Component.from_arrays(self.ctx, m, pos) if frame is None else Component.from_frame(self.ctx, m, pos, None, *frame)
         self._dsmall(1.0e-20)                                # Spherical::accumulate (:588)
         self.force.determine_coefficients(c)
         self.expcoef += self.force.get_coefs()
@@ -1114,10 +1121,10 @@ class Cylindrical(BiorthBasis):
         if getattr(self, "pcavar", False):                   # setup_accumulation zeroes VC / MV too
             self.force.cov_reset()
 
-    def _accumulate_batch(self, m, pos, seq=None) -> None:
+    def _accumulate_batch(self, m, pos, seq=None, frame=None) -> None:
         if len(m) == 0:
             return
-        c = Component.from_arrays(self.ctx, m, pos)
+        c = Component.from_arrays(self.ctx, m, pos) if frame is None else Component.from_frame(self.ctx, m, pos, None, *frame)
         self.force.determine_coefficients(c)
         cc, ss = self.force.get_coefs()
         self.cos += cc

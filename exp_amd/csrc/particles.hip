@@ -946,6 +946,81 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
   return detect_uniform_mass(c);
 }
 
+// ---- upload of positions as the caller holds them, with the expansion frame applied on the device ----------
+// Basis::addFromArray / createFromReader (expui/BiorthBasis.cc:4616-4738, :4555-4562): every position becomes
+// rot (x - ctr) before it is accumulated.  The caller's array is [n][3] (stride 3: x, y, z interleaved) or three
+// columns (stride 1); it is copied as it lies into the scratch set and taken apart, shifted and rotated by one pass
+// (numpy needs 0.17 s for the same on 1e7 particles: strided column copies and a [n,3] x [3,3] product).
+struct Frame { double c[3], r[9]; int shift, rotate; };
+
+__global__ void __launch_bounds__(TPB)
+k_upload_frame(const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2, int stride,
+               Frame F, const uint32_t *__restrict__ id, size_t n, double *__restrict__ X, double *__restrict__ Y,
+               double *__restrict__ Z)
+{
+  const size_t s = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (s >= n) return;
+  const size_t i = id[s];
+  double p[3];
+  if (stride == 1) { p[0] = b0[i]; p[1] = b1[i]; p[2] = b2[i]; }
+  else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                     // element 3 i + k of the array that lies across the three buffers
+      const size_t f = 3 * i + k;
+      p[k] = f < n ? b0[f] : (f < 2 * n ? b1[f - n] : b2[f - 2 * n]);
+    }
+  }
+  if (F.shift) { p[0] -= F.c[0]; p[1] -= F.c[1]; p[2] -= F.c[2]; }
+  if (F.rotate) {
+    const double a = p[0], b = p[1], c = p[2];
+    p[0] = F.r[0] * a + F.r[1] * b + F.r[2] * c;
+    p[1] = F.r[3] * a + F.r[4] * b + F.r[5] * c;
+    p[2] = F.r[6] * a + F.r[7] * b + F.r[8] * c;
+  }
+  X[s] = p[0]; Y[s] = p[1]; Z[s] = p[2];
+}
+
+static int upload_frame3(exp_amd_comp *c, int a0, const double *x, const double *y, const double *z, int stride,
+                         const Frame &F)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  const size_t n = c->n, bytes = n * sizeof(double);
+  const double *src[3] = {x, stride == 1 ? y : x + n, stride == 1 ? z : x + 2 * n};
+  for (int k = 0; k < 3; k++)
+    HIP_TRY(ctx, hipMemcpyAsync(c->b(a0 + k), src[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+  k_upload_frame<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(c->b(a0), c->b(a0 + 1), c->b(a0 + 2), stride, F, c->id[c->cur].p, n,
+                                                       c->a(a0), c->a(a0 + 1), c->a(a0 + 2));
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_upload_frame(exp_amd_comp *c, const double *mass, const double *x, const double *y,
+                                         const double *z, const double *vx, const double *vy, const double *vz,
+                                         int stride, const double center[3], const double rot[9])
+{
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (!c || !x || (stride != 1 && stride != 3) || (stride == 1 && (!y || !z)) || (stride == 1 && vx && (!vy || !vz)))
+    return EXP_AMD_ERR_ARG;
+  if (c->n == 0) return EXP_AMD_OK;
+  exp_amd_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Frame F{};
+  for (int k = 0; k < 3; k++) { F.c[k] = center ? center[k] : 0.0; if (F.c[k] != 0.0) F.shift = 1; }
+  for (int k = 0; k < 9; k++) { F.r[k] = rot ? rot[k] : (k % 4 == 0 ? 1.0 : 0.0); if (F.r[k] != (k % 4 == 0 ? 1.0 : 0.0)) F.rotate = 1; }
+  int rc = upload_frame3(c, A_X, x, y, z, stride, F);
+  if (rc) return rc;
+  if (vx) {                                            // velocities are rotated, not shifted (:4566-4568)
+    Frame V = F;
+    V.shift = 0;
+    if ((rc = upload_frame3(c, A_VX, vx, vy, vz, stride, V))) return rc;
+  } else
+    for (int a = A_VX; a <= A_VZ; a++) HIP_TRY(ctx, hipMemsetAsync(c->a(a), 0, c->n * sizeof(double), ctx->stream));
+  if ((rc = upload_one(c, A_M, mass))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  c->sorted_for = nullptr;
+  return detect_uniform_mass(c);
+}
+
 extern "C" int exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
                                        const double *az, const double *pot)
 {

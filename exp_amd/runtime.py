@@ -160,6 +160,40 @@ class Component:
         c.upload(mass, pos, vel)
         return c
 
+    @classmethod
+    def from_frame(cls, ctx: Context, mass, pos, vel=None, center=None, rot=None) -> "Component":
+        """Particles as the caller holds them ([n, 3], C- or Fortran-ordered), taken into the expansion frame
+        ``rot (x - center)`` on the device (``exp_amd_comp_upload_frame``): no host-side column copies, no host product."""
+        pos = np.asarray(pos, dtype=np.float64)
+        c = cls(ctx, pos.shape[0])
+        c.upload_frame(mass, pos, vel, center, rot)
+        return c
+
+    def upload_frame(self, mass, pos, vel=None, center=None, rot=None) -> None:
+        def parts(a):
+            """-> (x, y, z pointers, stride, keep-alive)"""
+            if a is None:
+                return (None, None, None), 1, None
+            a = np.asarray(a, dtype=np.float64)
+            assert a.shape == (self.n, 3)
+            if a.T.flags.c_contiguous and self.n > 1:           # three contiguous columns (a [3, n] array seen as [n, 3])
+                return tuple(a[:, k].ctypes.data_as(c_void_p) for k in range(3)), 1, a
+            a = np.ascontiguousarray(a)
+            return (a.ctypes.data_as(c_void_p), None, None), 3, a
+        (x, y, z), stride, keep_p = parts(pos)
+        (vx, vy, vz), vstride, keep_v = parts(vel)
+        if vel is not None and vstride != stride:               # one stride per call: make the velocities match
+            v = np.asarray(vel, dtype=np.float64)
+            keep_v = np.ascontiguousarray(v) if stride == 3 else np.asfortranarray(v)
+            (vx, vy, vz), vstride, keep_v = parts(keep_v)
+        m = as_f64(mass, self.n)
+        ctr = None if center is None else np.ascontiguousarray(center, dtype=np.float64).reshape(3)
+        R = None if rot is None else np.ascontiguousarray(rot, dtype=np.float64).reshape(9)
+        check(self.lib.exp_amd_comp_upload_frame(self.h, m[1], x, y, z, vx, vy, vz, int(stride),
+                                                 None if ctr is None else ctr.ctypes.data_as(c_void_p),
+                                                 None if R is None else R.ctypes.data_as(c_void_p)), self.ctx.h)
+        del keep_p, keep_v
+
     def upload(self, mass, pos, vel=None) -> None:
         pos = np.asarray(pos, dtype=np.float64)
         keep = [as_f64(mass, self.n)] + [as_f64(pos[:, k], self.n) for k in range(3)]

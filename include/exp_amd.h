@@ -131,6 +131,13 @@ size_t exp_amd_comp_size(const exp_amd_comp *c);
 int  exp_amd_comp_upload(exp_amd_comp *c, const double *mass,
                          const double *x, const double *y, const double *z,
                          const double *vx, const double *vy, const double *vz);
+/* Positions (and velocities) as the caller holds them -- three columns (stride 1) or one [n][3] array (stride 3, passed as
+ * x; y and z ignored) -- with the expansion frame of Basis::addFromArray / createFromReader applied on the device:
+ * x' = rot (x - center), v' = rot v (expui/BiorthBasis.cc:4555-4568, :4616-4738); center / rot may be NULL (no shift / no
+ * rotation; rot is row-major).  Saves the caller the strided column copies and the [n,3] x [3,3] product.           */
+int  exp_amd_comp_upload_frame(exp_amd_comp *c, const double *mass, const double *x, const double *y, const double *z,
+                               const double *vx, const double *vy, const double *vz, int stride,
+                               const double center[3], const double rot[9]);
 int  exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
                              const double *az, const double *pot);
 int  exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level);

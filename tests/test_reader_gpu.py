@@ -180,3 +180,35 @@ def test_component_restart_from_a_phase_space_file(snapshot, tmp_path):
         assert np.array_equal(b[k], out[k])
     assert np.array_equal(b["indx"], halo["indx"]) and np.allclose(b["pos"], halo["pos"] + 0.01 * halo["vel"], rtol=0, atol=1e-15)
     c.close()
+
+
+def test_upload_frame_is_the_host_transform():
+    """exp_amd_comp_upload_frame: positions as the caller holds them ([n, 3] C-ordered = stride 3, or the [n, 3] view of a
+    [3, n] array = three columns) taken into rot (x - ctr) on the device, velocities rotated only -- against the numpy
+    expression addFromArray used to evaluate on the host, to a few ulps; no frame = the bits of the input."""
+    from exp_amd.runtime import Component, Context
+    ctx = Context(0)
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 3, 1000, 4097):
+        pos, vel, m = rng.normal(size=(n, 3)), rng.normal(size=(n, 3)), rng.uniform(1, 2, n)
+        ctr, rot = rng.normal(0, 0.1, 3), _rot(rng)
+        for p, v in ((pos, vel), (np.ascontiguousarray(pos.T).T, np.ascontiguousarray(vel.T).T), (pos, np.ascontiguousarray(vel.T).T),
+                     (pos[::-1][::-1], None)):
+            c = Component.from_frame(ctx, m, p, v, ctr, rot)
+            out = c.download(("mass", "pos", "vel"))
+            want = (pos - ctr) @ rot.T
+            assert np.abs(out["pos"] - want).max() <= 8e-16 * max(1.0, np.abs(want).max())
+            if v is not None:
+                assert np.abs(out["vel"] - vel @ rot.T).max() <= 8e-16 * max(1.0, np.abs(vel).max() * 2)
+            else:
+                assert not np.any(out["vel"])
+            assert np.array_equal(out["mass"], m)
+            c.close()
+            c = Component.from_frame(ctx, m, p, v)                    # no frame: nothing is computed
+            out = c.download(("pos", "vel"))
+            assert np.array_equal(out["pos"], pos) and (v is None or np.array_equal(out["vel"], vel))
+            c.close()
+        c = Component.from_frame(ctx, m, pos, None, ctr, None)        # shift only
+        assert np.array_equal(c.download(("pos",))["pos"], pos - ctr)
+        c.close()
+    ctx.close()
