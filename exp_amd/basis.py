@@ -899,7 +899,7 @@ class SphericalSL(BiorthBasis):
         polar axis the reference divides the azimuthal term by x^2 + y^2 = 0 and returns NaN in x and
         y; the device guards that term (x^2 + y^2 > 1e-16, as the n-body force does) and returns the
         finite limit."""
-        c = Component.from_arrays(self.ctx, np.ones(len(pos)), pos)
+        c = Component.from_frame(self.ctx, np.ones(len(pos)), pos)   # (no frame: the [n, 3] array goes up as it lies)
         self._dsmall(1.0e-18)                                # Spherical::computeAccel (:824-825)
         self.force.get_acceleration_and_potential(c, external=True)
         acc = c.download(("acc",))["acc"]

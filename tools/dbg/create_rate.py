@@ -34,3 +34,17 @@ for label, p in (("[N,3]", pos), ("[3,N]", np.ascontiguousarray(pos.T))):
     print(f"{label}: {dt:.3f} s = {n / dt:.2e} particles/s")
 cProfile.run("basis.createFromArray(m, pos)", "/tmp/create.prof")
 pstats.Stats("/tmp/create.prof").sort_stats("cumtime").print_stats(14)
+
+# ---- the evaluation side: getAccel and getFields on many points
+basis.set_coefs(basis.createFromArray(m, pos))
+for k in (1_000_000, 10_000_000):
+    q = pos[:k]
+    basis.getAccel(q[:1000])
+    t = time.time(); acc = basis.getAccel(q); dt = time.time() - t
+    print(f"getAccel {k:.0e} points: {dt:.3f} s = {k / dt:.2e} points/s")
+x, y, z = np.ascontiguousarray(pos[:1_000_000].T)
+basis.getFields(x[:10], y[:10], z[:10])
+t = time.time(); f = basis.getFields(x, y, z); dt = time.time() - t
+print(f"getFields 1e6 points: {dt:.3f} s = {1e6 / dt:.2e} points/s")
+cProfile.run("basis.getAccel(pos)", "/tmp/acc.prof")
+pstats.Stats("/tmp/acc.prof").sort_stats("cumtime").print_stats(12)
