@@ -64,6 +64,14 @@ def test_null_handles_and_bad_arguments(env):
         ("sim multistep", lambda: lib.exp_amd_sim_create(ctx.h, 40, 0.1, None, 0, byref(c_void_p())), ERR_ARG),
         ("comp_create NULL", lambda: lib.exp_amd_comp_create(ctx.h, 10, None), ERR_ARG),
         ("upload_levels NULL", lambda: lib.exp_amd_comp_upload_levels(c.h, None), ERR_ARG),
+        ("upload_frame NULL comp", lambda: lib.exp_amd_comp_upload_frame(None, p, p, p, p, None, None, None, 1, None, None), ERR_ARG),
+        ("upload_frame NULL x", lambda: lib.exp_amd_comp_upload_frame(c.h, p, None, p, p, None, None, None, 1, None, None), ERR_ARG),
+        ("upload_frame stride", lambda: lib.exp_amd_comp_upload_frame(c.h, p, p, p, p, None, None, None, 2, None, None), ERR_ARG),
+        ("upload_frame columns", lambda: lib.exp_amd_comp_upload_frame(c.h, p, p, None, p, None, None, None, 1, None, None), ERR_ARG),
+        ("log_sums NULL", lambda: lib.exp_amd_comp_log_sums(c.h, None), ERR_ARG),
+        ("log_sums NULL comp", lambda: lib.exp_amd_comp_log_sums(None, p), ERR_ARG),
+        ("get_center NULL", lambda: lib.exp_amd_comp_get_center(c.h, None), ERR_ARG),
+        ("all_m on a NULL force", lambda: lib.exp_amd_sph_set_accumulate_all_m(None, 1), ERR_ARG),
     ]
     for name, call, want in cases:
         rc = call()
