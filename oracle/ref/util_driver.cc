@@ -2,6 +2,7 @@
 //   exputil/gaussQ.cc   LegeQuad: the Gauss-Legendre knots and weights on [0, 1] of makeFromFunction / computeQuadrature
 //                       (expui/BiorthBasis.cc:5230-5458)
 //   expui/UnitValidator.cc  the unit type / name alias tables of Coefs::setUnits (expui/Coefficients.cc:61)
+//   include/KDtree.H    the k-nearest-neighbour search of Utility::getDensityCenter (expui/Centering.cc)
 //   exputil/VtkGrid.cc  the rectilinear-grid writer of a build without the VTK library: FieldGenerator::file_slices /
 //                       file_volumes (expui/FieldGenerator.cc:512-564, 725-774)
 // Test infrastructure only (tests/test_ref_util.py).
@@ -82,4 +83,31 @@ extern "C" void ref_old_info(const char *info, char *out4, int cap)
   std::string s;
   for (int k = 0; k < 4; k++) { s += trim_copy(tokens(":")); s += '\n'; }
   strncpy(out4, s.c_str(), cap - 1); out4[cap - 1] = 0;
+}
+
+// include/KDtree.H: the k-nearest-neighbour density of getDensityCenter (expui/Centering.cc:66-96), one value per point:
+// nearestN(points[i], Ndens) -> (summed mass of the neighbours, the point itself among them) / (4 pi/3 r_N^3) / total mass
+#include <iostream>
+#include <cmath>
+#include "KDtree.H"
+
+extern "C" int ref_kd_density(int n, const double *pos, const double *mass, int Ndens, double *density)
+{
+  using point3 = KDtree::point<double, 3>;
+  using tree3 = KDtree::kdtree<double, 3>;
+  try {
+    std::vector<point3> points;
+    double KDmass = 0.0;
+    for (int i = 0; i < n; i++) {
+      KDmass += mass[i];
+      points.push_back(point3({pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}, mass[i]));
+    }
+    tree3 tree(points.begin(), points.end());
+    for (int i = 0; i < n; i++) {
+      auto ret = tree.nearestN(points[i], Ndens);
+      double volume = 4.0 * M_PI / 3.0 * std::pow(std::get<2>(ret), 3.0);
+      density[i] = (volume > 0.0 && KDmass > 0.0) ? std::get<1>(ret) / volume / KDmass : 0.0;
+    }
+    return 0;
+  } catch (std::exception &) { return -1; }
 }

@@ -117,3 +117,47 @@ def test_old_style_info_tokens_are_the_references(ref):
         ref.ref_old_info(text.encode(), out, 4096)
         want = out.value.decode().split("\n")[:4]
         assert _string_tok(text, ":", 4) == want, (text, want)
+
+
+def test_knn_density_is_the_references_kdtree(ref, tmp_path):
+    """include/KDtree.H (nearestN) compiled in place, driven as Utility::getDensityCenter drives it, against
+    exp_amd.util.knn_density (scipy's exact k-nearest search): the same density at every point -- the point itself is one
+    of its neighbours -- and, through the formula of expui/Centering.cc:66-160, the same centre; then the function on a
+    reader: an off-centre Plummer sphere is found to a few per cent of its scale, the Nsort variant too."""
+    from exp_amd import reader as R, util as U
+    if not hasattr(ref, "ref_kd_density"):
+        pytest.skip("oracle/_ref/libref_util.so predates ref_kd_density")
+    rng = np.random.default_rng(17)
+    for n, nd in ((40, 8), (500, 32), (3000, 16), (20, 32)):
+        pos = rng.normal(size=(n, 3)) * np.array([1.0, 0.5, 2.0]) + np.array([0.3, -0.1, 0.2])
+        mass = rng.uniform(0.5, 1.5, n)
+        want = np.zeros(n)
+        assert ref.ref_kd_density(n, np.ascontiguousarray(pos).ctypes.data_as(ctypes.c_void_p),
+                                  mass.ctypes.data_as(ctypes.c_void_p), nd, want.ctypes.data_as(ctypes.c_void_p)) == 0
+        got, ok = U.knn_density(pos, mass, np.arange(n), nd)
+        assert ok.all() and np.abs(got - want).max() <= 1e-12 * want.max()
+        ctr_ref = (want[:, None] * pos).sum(axis=0) / want.sum()
+        path = str(tmp_path / f"OUT.{n}")
+        R.write_psp(path, 0.0, [dict(info=R.component_info("dark", "sphereSL", {}, {}), mass=mass, pos=pos)])
+        rd = R.PSPout([path])
+        assert np.allclose(U.getDensityCenter(rd, 1, 0, nd), ctr_ref, rtol=0, atol=1e-12)
+        top = np.argsort(want)[-5:]
+        assert np.allclose(U.getDensityCenter(rd, 1, 5, nd), (want[top, None] * pos[top]).sum(axis=0) / want[top].sum(), rtol=0, atol=1e-12)
+        com = (mass[:, None] * pos).sum(axis=0) / mass.sum()
+        assert np.allclose(U.getCenterOfMass(rd), com, rtol=0, atol=1e-14)
+    # a Plummer sphere (a = 1) displaced to (2, -1, 0.5) with a 20 % uniform background
+    n = 6000
+    r = 1.0 / np.sqrt(rng.uniform(0, 1, n) ** (-2.0 / 3.0) - 1.0)
+    u = rng.normal(size=(n, 3))
+    pos = r[:, None] * u / np.linalg.norm(u, axis=1)[:, None] + np.array([2.0, -1.0, 0.5])
+    pos = np.concatenate([pos, rng.uniform(-20, 20, (n // 5, 3))])
+    path = str(tmp_path / "OUT.plummer")
+    R.write_psp(path, 0.0, [dict(info=R.component_info("dark", "sphereSL", {}, {}), mass=np.full(len(pos), 1.0 / len(pos)), pos=pos)])
+    rd = R.PSPout([path])
+    c = np.array(U.getDensityCenter(rd, stride=2, Ndens=32, seed=1))
+    assert np.linalg.norm(c - [2.0, -1.0, 0.5]) < 0.1
+    assert np.linalg.norm(np.array(U.getDensityCenter(rd, stride=1, Nsort=200, Ndens=16)) - [2.0, -1.0, 0.5]) < 0.1
+    assert np.linalg.norm(np.array(U.getCenterOfMass(rd)) - [2.0, -1.0, 0.5]) > 0.15          # the background pulls the mean
+    seen = []
+    U.particleIterator(rd, lambda m, p, v, i: seen.append((m, p, i)))
+    assert len(seen) == len(pos) and seen[3][2] == 3 and seen[3][1] == pos[3].tolist()
