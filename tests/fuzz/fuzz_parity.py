@@ -28,9 +28,10 @@ _sl, _cy = {}, {}
 
 def field_err(got, ref, floor=0.0):
     """density, potential and force columns each against the largest value of THEIR group over the points (a column that is
-    identically zero -- the azimuthal force on the axis -- has no scale of its own)"""
+    identically zero -- the azimuthal force on the axis -- has no scale of its own); `floor`: one number or one per group"""
     e = 0.0
-    for a, b in ((0, 3), (3, 6), (6, 9)):
+    floors = floor if isinstance(floor, tuple) else (floor, floor, floor)
+    for (a, b), floor in zip(((0, 3), (3, 6), (6, 9)), floors):
         # (floor: what the particles COULD have contributed -- an all-antisymmetric basis and a particle in the plane leave
         # coefficients, and fields, that are rounding noise around zero on both sides)
         sc = max(np.abs(ref[:, a:b]).max(), floor)
@@ -188,8 +189,19 @@ def trial_cyl(t, rng):
     with np.errstate(all="ignore"):
         fg, fr = f.fields(*args, ctype), orc.cyl_fields(g, c_ref, s_ref, *args, ctype, **kw)
     finf = np.isfinite(fr).all(axis=1)
-    e_f = field_err(fg[finf], fr[finf], 1e-6 * np.abs(m).sum() * np.abs(g.tab[0]).max() ** 2) if finf.any() else 0.0
+    # (floors: a thousandth of what a coefficient of the size the particles could produce gives through the largest entry of
+    # the density, potential and force tables -- a lone particle at the origin, evaluated at the origin, has a force that
+    # vanishes by symmetry and is interpolation rounding, 1e-16 of that scale, on both sides)
+    unit = 1e-3 * np.abs(m).sum() * np.abs(g.tab[0]).max()
+    floors = (unit * np.abs(g.dens).max(), unit * np.abs(g.tab[0]).max(), unit * max(np.abs(g.tab[1]).max(), np.abs(g.tab[2]).max()))
+    e_f = field_err(fg[finf], fr[finf], floors) if finf.any() else 0.0
     same_f = np.array_equal(np.isfinite(fg).all(axis=1), finf)
+    if e_f > ACC_TOL:
+        for a_, b_ in ((0, 3), (3, 6), (6, 9)):
+            d_ = np.abs(fg[finf][:, a_:b_] - fr[finf][:, a_:b_])
+            k_ = np.unravel_index(np.argmax(d_), d_.shape)
+            print(f"    cols {a_}:{b_} worst |d| {d_.max():.3e} at args {[float(v[finf][k_[0]]) for v in args]} col {a_ + k_[1]} ref "
+                  f"{fr[finf][k_[0], a_ + k_[1]]:.6e} got {fg[finf][k_[0], a_ + k_[1]]:.6e} group max {np.abs(fr[finf][:, a_:b_]).max():.3e}")
     c.close(); f.close()
     # (a lone particle in the plane and a basis of vertically antisymmetric functions: every coefficient is 0 in the oracle and
     # a rounding of the maps on the device -- the scale is what the particle COULD have contributed)
