@@ -4,6 +4,11 @@ centre, kinetic and potential energy, the Clausius virial, their sum and the vir
 step and the number of particles the force used.  The reference's own N-body acceptance test reads it
 (tests/Halo/check.py: the mean of column 17, 2T/VC, within 5.5 % of 1).
 
+One column differs for runs with component interactions: this particle store adds the potential of a cross force to
+``pot`` (it keeps no separate ``potext``), so a component's PE is 0.5 m (pot_self + pot_cross) where the reference writes
+0.5 m pot_self + m pot_cross (src/OutLog.cc:424-425, :520, :573); the single-component log -- the one the reference's
+test reads -- and every other column are unaffected.
+
 The sums over the particles are the device's (``exp_amd_comp_log_sums``); the file is the reference's, character for
 character: a six-line header, then ``setw(10 + precision)`` columns in scientific notation joined by ``|``."""
 from __future__ import annotations
