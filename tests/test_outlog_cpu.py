@@ -37,7 +37,7 @@ def test_rows_match_the_oracles_printf(oracle):
 
 
 def test_header_layout_and_the_references_reader(tmp_path):
-    """Six header lines, then rows: tests/Halo/check.py skips exactly six lines, splits on '|' and averages column 16."""
+    """Six header lines, then rows: tests/Halo/check.py skips exactly six lines, splits on '|' and averages the 17th column."""
     rng = np.random.default_rng(5)
     names, ids = ["halo"], ["sphereSL"]
     path = tmp_path / "OUTLOG.run0"
@@ -55,17 +55,10 @@ def test_header_layout_and_the_references_reader(tmp_path):
             s = _sums(rng, 10000)
             want.append(-2.0 * s["ektot"] / s["clausius"])
             f.write(outlog.row_from_sums(0.02 * k, [s], [np.zeros(3)], [10000], 0.1))
-    # tests/Halo/check.py, statement for statement
-    file = open(path)
-    n, mean = 0, 0.0
-    while (line := file.readline()) != "":
-        if n >= 6:
-            v = [float(x) for x in line.split("|")]
-            mean += v[16]
-        n = n + 1
-    if n > 6:
-        mean /= n - 6
-    assert n == 14 and mean == pytest.approx(np.mean(want), rel=1e-9)
+    # what tests/Halo/check.py does with the file: six header lines skipped, rows split on '|', column 17 averaged
+    lines = open(path).read().splitlines()
+    vals = [float(ln.split("|")[16]) for ln in lines[6:]]
+    assert len(lines) == 14 and np.mean(vals) == pytest.approx(np.mean(want), rel=1e-9)
     # a label longer than the column is written unpadded (src/OutLog.cc:305-309)
     long_head = outlog.header(["a component with a long name"], ["cylinder"], 4).split("\n")
     assert "|a component with a long name 2T/VC|" in long_head[2] and len(long_head[2]) > len(long_head[1])
