@@ -1,0 +1,136 @@
+"""Randomised campaign for the sub-sample covariance of both bases through the pyEXP surface (GPU): random orders, sample
+counts (1 ... more than there are particles), particle numbers, one or several addFromArray batches, particles outside the
+window / off the grid, and -- through a phase-space file with its own index column -- createFromReader, whose particle
+indices choose the sub-sample of the cylinder (EmpCylSL::accumulate takes seq = p->indx) while the sphere goes by the running
+count of accepted particles.  Counts must be the same integers, masses / means / covariances agree to 1e-10.
+    python tests/fuzz/fuzz_covariance.py [trials=40] [seed=1]"""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+
+from exp_amd import reader as R
+from exp_amd.basis import Basis
+from tests.oracle_lib import Oracle
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc = Oracle()
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+tmp = tempfile.mkdtemp(prefix="fuzz_cov_")
+_sph, _cyl = {}, {}
+
+
+def sph_basis(rng):
+    key = (int(rng.integers(0, 5)), int(rng.integers(1, 9)))
+    if key not in _sph:
+        _sph[key] = Basis.factory(f"""
+id : sphereSL
+parameters :
+  numr: 400
+  rmin: 0.0001
+  rmax: 1.95
+  Lmax: {key[0]}
+  nmax: {key[1]}
+  rmapping : 0.0667
+  modelname: {os.path.join(GOLD, 'SLGridSph.model')}
+  cachename: {os.path.join(tmp, 'sl.%d_%d' % key)}
+""")
+    return key, _sph[key]
+
+
+def cyl_basis(rng):
+    key = (int(rng.integers(0, 4)), int(rng.integers(1, 5)))
+    if key not in _cyl:
+        _cyl[key] = Basis.factory(f"""
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  mmax: {key[0]}
+  nmax: {key[1]}
+  ncylodd: {key[1] // 2}
+  ncylnx: 24
+  ncylny: 12
+  ncylr: 400
+  lmaxfid: {max(10, key[0] + 6)}
+  nmaxfid: 8
+  rnum: 30
+  tnum: 20
+  cachename: {os.path.join(tmp, 'eof.%d_%d' % key)}
+""")
+    return key, _cyl[key]
+
+
+def rel(a, b):
+    s = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / s
+
+
+def one(t, rng):
+    sphere = bool(rng.random() < 0.5)
+    key, basis = sph_basis(rng) if sphere else cyl_basis(rng)
+    n = int(rng.choice([1, 7, 64, 500, 3000]))
+    sampT = int(rng.choice([1, 2, 5, 16, 100, 2 * n + 1]))
+    if sphere:
+        pos = rng.normal(0, 0.4, (n, 3))
+        pos[::17] *= 30.0
+    else:
+        pos = np.stack([rng.normal(0, 0.02, n), rng.normal(0, 0.02, n), rng.normal(0, 0.002, n)], axis=1)
+        pos[::13] *= 200.0
+    m = rng.uniform(0.5, 1.5, n) / n
+    how = str(rng.choice(["array", "batches", "reader"]))
+    basis.enableCoefCovariance(True, sampT)
+    seq = None
+    if how == "array":
+        basis.createFromArray(m, pos)
+    elif how == "batches":
+        cuts = np.sort(rng.integers(0, n + 1, 2))
+        basis.initFromArray()
+        for a, b in ((0, cuts[0]), (cuts[0], cuts[1]), (cuts[1], n)):
+            basis.addFromArray(m[a:b], pos[a:b])
+        basis.makeFromArray(0.0)
+        # (the cylinder's sub-sample index restarts with every batch: addFromArray hands accumulate the index within the
+        # batch; the sphere's follows the running count of accepted particles)
+        seq = np.concatenate([np.arange(b - a) for a, b in ((0, cuts[0]), (cuts[0], cuts[1]), (cuts[1], n))])
+    else:
+        indx = rng.integers(1, 10 * n + 10, n).astype(np.uint64)
+        path = os.path.join(tmp, f"OUT.{t}")
+        R.write_psp(path, 0.0, [dict(info=R.component_info("c", "x", {}, {"indexing": True}), mass=m, pos=pos, indx=indx)])
+        rd = R.PSPout([path])
+        basis.createFromReader(rd)
+        os.remove(path)
+        seq = indx.astype(np.int64)
+    bad = []
+    if sphere:
+        prm = orc.params(scale=1.0, rmin=basis.rmin, rmax=basis.rmax)
+        ref = orc.pyexp_sph_covariance(basis.grid, prm, pos, m, sampT)
+        counts, masses = basis.getCovarSamples()
+        cov = basis.getCoefCovariance()
+        mean = np.array([[cov[k][lm][0] for lm in range(len(cov[0]))] for k in range(sampT)])
+        covr = np.array([[cov[k][lm][1] for lm in range(len(cov[0]))] for k in range(sampT)])
+        errs = (rel(masses, ref["masses"]), rel(mean, ref["mean"]), rel(covr.real, ref["covr"]))
+    else:
+        ref = orc.cyl_covariance(basis.grid, pos, m, sampT, seq=seq)
+        counts, masses = basis.getCovarSamples()
+        mean, covr = basis.getCoefCovariance()
+        floor = 1e-3 * m.sum() * np.abs(basis.grid.tab[0]).max()
+        errs = (rel(masses, ref["masses"]), np.abs(mean - ref["mean"]).max() / max(np.abs(ref["mean"]).max(), floor),
+                np.abs(covr - ref["covr"]).max() / max(np.abs(ref["covr"]).max(), floor * floor / max(m.sum(), 1e-300)))
+    if not np.array_equal(counts, ref["counts"]):
+        bad.append(f"counts {counts[:6].tolist()} vs {ref['counts'][:6].tolist()}")
+    if max(errs) > 1e-10 or not np.isfinite(max(errs)):
+        bad.append(f"masses / mean / covr {['%.1e' % e for e in errs]}")
+    basis.enableCoefCovariance(False)
+    print(f"{t:3d} {'sph' if sphere else 'cyl'} {key} n {n} sampT {sampT} {how}: used {int(counts.sum())} "
+          f"{'ok' if not bad else 'MISMATCH ' + '; '.join(bad)}", flush=True)
+    return not bad
+
+
+t0 = time.time()
+bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
+print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
