@@ -68,7 +68,17 @@ def one(t, rng):
         if peek == 1:
             c.fix_positions(0)
         elif peek == 2:
-            c.log_sums()
+            # the run log's sums see the step-boundary state whatever the store holds (pre-kicked or with its closing
+            # half-kick still deferred)
+            s = nb.state[0]
+            ls = c.log_sums()
+            ref = orc.outlog_sums(s["mass"] if "mass" in s else m, np.stack([s[q] for q in "xyz"], 1), np.stack([s["v" + q] for q in "xyz"], 1),
+                                  np.stack([s["a" + q] for q in "xyz"], 1), s["pot"])
+            for key_ in ("ektot", "eptot", "clausius", "mtot"):
+                if abs(ls[key_] - ref[key_]) > 1e-9 * max(abs(ref[key_]), 1e-300):
+                    status, detail = "MISMATCH", f"log_sums {key_} {ls[key_]!r} vs {ref[key_]!r} after {hist}"
+            if np.abs(ls["angm"] - ref["angm"]).max() > 1e-9 * max(np.abs(m).sum() * np.abs(pos).max() * max(np.abs(vel).max(), 1e-300), 1e-300):
+                status, detail = "MISMATCH", f"log_sums angm after {hist}"
         elif peek == 3:
             f.get_coefs()
         if peek == 4 or k >= nsteps:
