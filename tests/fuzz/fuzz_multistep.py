@@ -62,6 +62,15 @@ def one(t, rng):
     switches = 0
     for k in range(nsteps + 1):
         if k:
+            # read-only calls between master steps must not change the trajectory
+            for c_ in comps:
+                peek = int(rng.integers(0, 4))
+                if peek == 1:
+                    c_.fix_positions(0)
+                elif peek == 2:
+                    c_.log_sums()
+                elif peek == 3:
+                    c_.download_levels()
             nsw = nb.step()
             sim.step(1)
             switches += int(sum(nsw))
