@@ -1207,6 +1207,10 @@ extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c) return EXP_AMD_ERR_ARG;
+  // (as kick and drift: a level the store has not been partitioned into is refused, not clamped -- clamping zeroed
+  // EVERY particle of a store that only had its levels uploaded; found by tests/fuzz/fuzz_store.py)
+  if (mlevel > 0 && mlevel >= c->nlevels)
+    return expamd_fail(c->ctx, EXP_AMD_ERR_ARG, "comp_zero_acc: level %d beyond the component's %d level(s)", mlevel, c->nlevels);
   if (c->n == 0) return EXP_AMD_OK;
   int lo, hi;
   level_range(c, mlevel, true, &lo, &hi);

@@ -140,6 +140,11 @@ int  exp_amd_comp_upload_frame(exp_amd_comp *c, const double *mass, const double
                                const double center[3], const double rot[9]);
 int  exp_amd_comp_upload_acc(exp_amd_comp *c, const double *ax, const double *ay,
                              const double *az, const double *pot);
+/* Per-particle multistep levels (Particle::level).  The store keeps its particles PARTITIONED by level -- the
+ * counterpart of Component::levlist -- and level-specific calls (kick, drift, zero_acc with mlevel >= 0) work on those
+ * ranges: uploaded levels take effect for them at the next accumulation of a multistep force on this component, which
+ * re-partitions the store (every driver accumulates before it advances); until a multistep force has done so the store
+ * has one level, and a call for a level beyond it is refused with EXP_AMD_ERR_ARG.                                 */
 int  exp_amd_comp_upload_levels(exp_amd_comp *c, const int32_t *level);
 int  exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, double *y, double *z,
                            double *vx, double *vy, double *vz,

@@ -51,6 +51,7 @@ def test_null_handles_and_bad_arguments(env):
         ("level_coefs", lambda: lib.exp_amd_force_get_level_coefs(f.h, 2, 0, p, ncoef), ERR_ARG),
         ("kick level", lambda: lib.exp_amd_comp_kick(c.h, 0.1, 3), ERR_ARG),
         ("drift level", lambda: lib.exp_amd_comp_drift(c.h, 0.1, 3), ERR_ARG),
+        ("zero level", lambda: lib.exp_amd_comp_zero_acc(c.h, 3), ERR_ARG),
         ("fields before density", lambda: lib.exp_amd_sph_fields(f.h, 1, p, p, p, 2, p), ERR_STATE),
         ("basis before density", lambda: lib.exp_amd_sph_basis(f.h, 1, p, p), ERR_STATE),
         ("fields coord", lambda: (lib.exp_amd_sph_set_density(f.h, np.ascontiguousarray(g.d0).ctypes.data_as(c_void_p)),
