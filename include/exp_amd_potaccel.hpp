@@ -337,6 +337,17 @@ inline void incr_velocity(Context &ctx, Mirror &m, ComponentView *c, double dt, 
 {
   check(exp_amd_comp_kick(m.dev(c), dt, mlevel), ctx.get());
 }
+// OutLog::Run's particle loop (src/OutLog.cc:392-478; with CUDA the reference copies the particles back first, :377-385):
+// {mass, m x [3], m v [3], angular momentum [3], kinetic energy, 0.5 m pot, Clausius virial, number of bodies}, already
+// reduced over the ranks -- what a device-resident OutLog divides and prints
+struct LogSums { double v[14]; };
+inline LogSums log_sums(Context &ctx, Mirror &m, ComponentView *c)
+{
+  LogSums s{};
+  check(exp_amd_comp_log_sums(m.dev(c), s.v), ctx.get());
+  return s;
+}
+
 inline void zero_acceleration(Context &ctx, Mirror &m, ComponentView *c, int mlevel = 0)
 {
   check(exp_amd_comp_zero_acc(m.dev(c), mlevel), ctx.get());

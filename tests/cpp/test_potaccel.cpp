@@ -142,6 +142,20 @@ int main(int argc, char **argv)
       expect("accelerations after one KDK step", maxdiff3(comp.ax, comp.ay, comp.az, sacc), 1e-9 * maxabs(sacc));
       expect("potential after one KDK step", maxdiff(comp.pot, spot), 1e-9 * maxabs(spot));
       expect("coefficients after one KDK step", maxdiff(force.get_coefs(), scoef), 1e-10 * maxabs(scoef));
+      {
+        // the run log's sums on the device (OutLog::Run's particle loop) against the same loop over the downloaded state
+        const exp_amd::LogSums ls = exp_amd::log_sums(ctx, mirror, &comp);
+        double mt = 0.0, ek = 0.0, vc = 0.0;
+        for (size_t i = 0; i < comp.m.size(); i++) {
+          mt += comp.m[i];
+          ek += 0.5 * comp.m[i] * (comp.vx[i] * comp.vx[i] + comp.vy[i] * comp.vy[i] + comp.vz[i] * comp.vz[i]);
+          vc += comp.m[i] * (comp.x[i] * comp.ax[i] + comp.y[i] * comp.ay[i] + comp.z[i] * comp.az[i]);
+        }
+        expect("log sums: mass", std::fabs(ls.v[0] - mt), 1e-12 * mt);
+        expect("log sums: kinetic energy", std::fabs(ls.v[10] - ek), 1e-11 * ek);
+        expect("log sums: Clausius virial", std::fabs(ls.v[12] - vc), 1e-11 * std::fabs(vc));
+        expect("log sums: bodies", std::fabs(ls.v[13] - (double)comp.m.size()), 0.0);
+      }
       (void)used_ref;      // (the stored count is that of the INITIAL accumulation; one particle may cross rmax in the step)
       expect("PotAccel::Used()", std::fabs((double)(force.Used() - used_ref)), 1.0);
       // PotAccel::dump_coefs(ostream&) (src/PotAccel.H:224, src/SphericalBasis.cc:1829-1879): one native record;
