@@ -13,6 +13,19 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <atomic>
+
+// Library-wide mutation counter: bumped by every (re)allocation or release of device memory and by every call that
+// changes what a step's kernels are launched WITH (force settings, tables, uploads, frame, any outside call on a
+// component).  A HIP graph of fused steps bakes those pointers and values in as kernel arguments; it is replayed only
+// while the counter still has the value it had when the graph was captured (exp_amd_step_kdk_n).
+inline std::atomic<unsigned long long> &expamd_mutation_counter()
+{
+  static std::atomic<unsigned long long> n{0};
+  return n;
+}
+inline void expamd_mutated() { expamd_mutation_counter().fetch_add(1, std::memory_order_relaxed); }
+
 
 #include "../../include/exp_amd.h"
 
@@ -62,7 +75,7 @@ struct exp_amd_ctx {
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;
-  struct ScanSums { uint32_t *p = nullptr; size_t n = 0; hipError_t alloc(size_t c) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void **)&p, c * sizeof(uint32_t)); if (e == hipSuccess) n = c; return e; } } scan_sums[2];   // chunk totals of multi-chunk scans, one per stream (particles.hip)
+  struct ScanSums { uint32_t *p = nullptr; size_t n = 0; hipError_t alloc(size_t c) { expamd_mutated(); if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void **)&p, c * sizeof(uint32_t)); if (e == hipSuccess) n = c; return e; } } scan_sums[2];   // chunk totals of multi-chunk scans, one per stream (particles.hip)
   hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_forced[2] = {nullptr, nullptr};
 };
 // lazily creates ctx->aux and the four events
@@ -93,6 +106,7 @@ struct DevBuf {
   size_t n = 0;
   hipError_t alloc(size_t count) {
     release();
+    expamd_mutated();
     n = count;
     if (count == 0) return hipSuccess;
     hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
@@ -105,7 +119,7 @@ struct DevBuf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) { (void)hipFree(p); expamd_mutated(); }
     p = nullptr;
     n = 0;
   }

@@ -92,6 +92,7 @@ extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
 
 extern "C" int exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->prekick = on != 0;
   return EXP_AMD_OK;
@@ -99,6 +100,7 @@ extern "C" int exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on)
 
 extern "C" int exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->deterministic = on != 0;
   return EXP_AMD_OK;
@@ -106,6 +108,7 @@ extern "C" int exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on)
 
 extern "C" int exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->dense_min = nmin;
   return EXP_AMD_OK;
@@ -113,6 +116,7 @@ extern "C" int exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin)
 
 extern "C" int exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->mover_list_min = nmin;
   return EXP_AMD_OK;
@@ -120,6 +124,7 @@ extern "C" int exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin)
 
 extern "C" int exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->split_min = nmin;
   return EXP_AMD_OK;
@@ -264,6 +269,7 @@ extern "C" int exp_amd_comm_get_unique_id(void *id128)
 
 extern "C" int exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int nranks, int rank)
 {
+  expamd_mutated();
   if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_init_rank: bad arguments");
   void *lib = open_rccl();
@@ -288,6 +294,7 @@ extern "C" int exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int n
 
 extern "C" int exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn fn, void *user)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->ar_fn = fn;
   ctx->ar_user = user;

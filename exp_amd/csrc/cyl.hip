@@ -1732,6 +1732,7 @@ extern "C" int exp_amd_cyl_get_cylmass(exp_amd_force *fb, double *mass)
 
 extern "C" int exp_amd_cyl_set_cylmass(exp_amd_force *fb, double mass)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   CylForce *f = dynamic_cast<CylForce *>(fb);
   if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_cylmass: not a cylinder force");
   HIP_TRY(f->ctx, hipMemcpyAsync(f->d_mass.p, &mass, sizeof(double), hipMemcpyHostToDevice,
@@ -1809,6 +1810,7 @@ k_cyl_fields(CylDev C, const double *__restrict__ tab, const double *__restrict_
 
 extern "C" int exp_amd_cyl_set_density(exp_amd_force *fb, const double *dens)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   CylForce *f = dynamic_cast<CylForce *>(fb);
   if (!f || !dens) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "cyl_set_density: not a cylinder force / NULL");
   exp_amd_ctx *ctx = f->ctx;

@@ -119,6 +119,7 @@ struct exp_amd_force {
     size_t n = 0;
     int cur = -1, parity = -1, prekick = -1, det = -1;
     unsigned long long epoch = 0;
+    unsigned long long mutation = 0; // expamd_mutation_counter() right after the capture (common.h)
     bool refused = false;          // capture failed once for this pair: eager from then on
   } step_graph;
 

@@ -106,6 +106,7 @@ extern "C" int exp_amd_force_get_coefs(exp_amd_force *f, double *coef, size_t co
 
 extern "C" int exp_amd_force_set_coefs(exp_amd_force *f, const double *coef, size_t count)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!f || !coef || count != f->ncoef)
     return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_coefs: bad count");
   exp_amd_ctx *ctx = f->ctx;
@@ -281,7 +282,7 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
 static bool step_state_matches(const exp_amd_force *f, const exp_amd_comp *c, double dt)
 {
   const exp_amd_force::StepGraph &g = f->step_graph;
-  return g.exec && g.comp == c && g.dt == dt && g.n == c->n && g.cur == c->cur && g.parity == f->step_parity() &&
+  return g.exec && g.mutation == expamd_mutation_counter().load(std::memory_order_relaxed) && g.comp == c && g.dt == dt && g.n == c->n && g.cur == c->cur && g.parity == f->step_parity() &&
          g.prekick == (int)f->ctx->prekick && g.det == (int)f->ctx->deterministic && g.epoch == f->ctx->force_epoch &&
          g.pending == c->pending_kick && g.center[0] == c->center[0] && g.center[1] == c->center[1] &&
          g.center[2] == c->center[2];
@@ -360,6 +361,7 @@ extern "C" int exp_amd_step_kdk_n(exp_amd_force *f, exp_amd_comp *c, double dt, 
         done += 2;
         continue;
       }
+      g.mutation = expamd_mutation_counter().load(std::memory_order_relaxed);
       f->step_graph = g;
       HIP_TRY(ctx, hipGraphLaunch(f->step_graph.exec, ctx->stream));      // (its all-reduces were counted while capturing)
       done += 2;

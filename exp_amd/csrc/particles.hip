@@ -357,6 +357,7 @@ static int partition_by_level(exp_amd_comp *c)
 
 int expamd_comp_touch(exp_amd_comp *c)
 {
+  expamd_mutated();
   c->prekey_valid = false;
   if (c->partition_stale) { int rc = partition_by_level(c); if (rc) return rc; }
   return expamd_comp_apply_pending(c);
@@ -364,6 +365,7 @@ int expamd_comp_touch(exp_amd_comp *c)
 
 int expamd_comp_touch_keep_partition(exp_amd_comp *c)
 {
+  expamd_mutated();
   c->prekey_valid = false;
   return expamd_comp_apply_pending(c);
 }

@@ -976,6 +976,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
 // dsmall) is or is not exactly 1: sin(theta) = 2.6e-8 against 0.
 extern "C" int exp_amd_sph_set_dsmall(exp_amd_force *fb, double dsmall)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f || !(dsmall >= 0.0)) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_dsmall: not a sphereSL force");
   f->dev.dsmall = dsmall;
@@ -984,6 +985,7 @@ extern "C" int exp_amd_sph_set_dsmall(exp_amd_force *fb, double dsmall)
 
 extern "C" int exp_amd_sph_set_accumulate_all_m(exp_amd_force *fb, int all_m)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_accumulate_all_m: not a sphereSL force");
   f->dev.M0_acc = all_m ? 0 : f->dev.M0_only;
@@ -992,6 +994,7 @@ extern "C" int exp_amd_sph_set_accumulate_all_m(exp_amd_force *fb, int all_m)
 
 extern "C" int exp_amd_sph_set_exterior(exp_amd_force *fb, int continuation)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_exterior: not a sphereSL force");
   f->dev.no_exterior = continuation ? 0 : 1;

@@ -141,6 +141,7 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
 
 extern "C" int exp_amd_sph_set_density(exp_amd_force *fb, const double *d0)
 {
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f || !d0) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_set_density: not a spherical force / NULL");
   exp_amd_ctx *ctx = f->ctx;

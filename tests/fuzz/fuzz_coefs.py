@@ -15,8 +15,9 @@ import numpy as np
 from exp_amd import coefs as C
 from exp_amd.basis import CylStruct, SphStruct
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_cpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 200
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
 tmp = tempfile.mkdtemp(prefix="fuzz_coefs_")
 UNITS = (("mass", "Msun", 1e10), ("length", "kpc", 1.0), ("time", "Myr", 1.0), ("G", "mixed", 4.3e-6))
 
@@ -119,7 +120,12 @@ def one(t, rng):
     return not bad
 
 
-t0 = time.time()
-bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def main():
+    t0 = time.time()
+    bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
+    print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,8 +16,9 @@ from exp_amd import reader as R
 from exp_amd.basis import Basis
 from tests.oracle_lib import Oracle
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_gpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 40
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
 orc = Oracle()
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 tmp = tempfile.mkdtemp(prefix="fuzz_cov_")
@@ -130,7 +131,12 @@ def one(t, rng):
     return not bad
 
 
-t0 = time.time()
-bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def main():
+    t0 = time.time()
+    bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
+    print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,9 @@ import tests.config4_util as c4
 from exp_amd.runtime import Component, Context, Cylinder, SphereSL
 from tests.oracle_lib import NBodyOracle, Oracle
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_gpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 60
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
 orc = Oracle()
 ctx = Context(0)
 g, cg = c4.grids()
@@ -101,8 +102,13 @@ def one(t, rng):
     return status == "ok"
 
 
-t0 = time.time()
-bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
-ctx.set_prekick(True)
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def main():
+    t0 = time.time()
+    bad = sum(0 if one(t, np.random.default_rng([seed0, t])) else 1 for t in range(trials))
+    ctx.set_prekick(True)
+    print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

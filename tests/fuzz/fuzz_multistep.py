@@ -16,8 +16,9 @@ import tests.config4_util as c4
 from exp_amd.runtime import Component, Context, Cylinder, Simulation, SphereSL
 from tests.oracle_lib import NBodyOracle, Oracle
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_gpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 30
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
 orc = Oracle()
 ctx = Context(0)
 g, cg = c4.grids()
@@ -114,12 +115,21 @@ def one(t, rng):
     return status
 
 
-t0 = time.time()
 total_switches = 0
-tally = {"ok": 0, "edge": 0, "LEVELS": 0, "STATE": 0}
-for t in range(trials):
-    tally[one(t, np.random.default_rng([seed0, t]))] += 1
-ctx.set_dense_min(-1)
-ctx.set_mover_list_min(2048)
-print(f"{trials} trials: {tally}, {total_switches} level changes in all, {time.time() - t0:.0f} s")
-sys.exit(1 if tally["LEVELS"] or tally["STATE"] else 0)
+
+
+def main():
+    global total_switches
+    total_switches = 0
+    t0 = time.time()
+    tally = {"ok": 0, "edge": 0, "LEVELS": 0, "STATE": 0}
+    for t in range(trials):
+        tally[one(t, np.random.default_rng([seed0, t]))] += 1
+    ctx.set_dense_min(-1)
+    ctx.set_mover_list_min(2048)
+    print(f"{trials} trials: {tally}, {total_switches} level changes in all, {time.time() - t0:.0f} s")
+    sys.exit(1 if tally["LEVELS"] or tally["STATE"] else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,9 +17,10 @@ from exp_amd.runtime import Component, Context, Cylinder, SphereSL
 from exp_amd.slgrid import build_slgrid
 from tests.oracle_lib import Oracle
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-which = sys.argv[3] if len(sys.argv) > 3 else "both"
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_gpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 60
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
+which = _argv[3] if len(_argv) > 3 else "both"
 orc = Oracle()
 ctx = Context(0)
 COEF_TOL, ACC_TOL = 1e-10, 1e-9
@@ -221,14 +222,19 @@ def trial_cyl(t, rng):
     return ok
 
 
-t0 = time.time()
-bad = 0
-for t in range(trials):
-    for kind, fn in (("sph", trial_sph), ("cyl", trial_cyl)):
-        if which in (kind, "both"):
-            rng = np.random.default_rng([seed0, t, 0 if kind == "sph" else 1])
-            if not fn(t, rng):
-                bad += 1
-                print(f"  reproduce: python tests/fuzz/fuzz_parity.py {t + 1} {seed0} {kind}   (trial {t})", flush=True)
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def main():
+    t0 = time.time()
+    bad = 0
+    for t in range(trials):
+        for kind, fn in (("sph", trial_sph), ("cyl", trial_cyl)):
+            if which in (kind, "both"):
+                rng = np.random.default_rng([seed0, t, 0 if kind == "sph" else 1])
+                if not fn(t, rng):
+                    bad += 1
+                    print(f"  reproduce: python tests/fuzz/fuzz_parity.py {t + 1} {seed0} {kind}   (trial {t})", flush=True)
+    print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,9 @@ import numpy as np
 from exp_amd.basis import Basis
 from tests.oracle_lib import Oracle
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_argv = sys.argv if __name__ == "__main__" else [""]   # imported by tests/test_fuzz_gpu.py: defaults
+trials = int(_argv[1]) if len(_argv) > 1 else 40
+seed0 = int(_argv[2]) if len(_argv) > 2 else 1
 orc = Oracle()
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 tmp = tempfile.mkdtemp(prefix="fuzz_pyexp_")
@@ -189,11 +190,16 @@ def trial_cyl(t, rng):
     return ok
 
 
-t0 = time.time()
-bad = 0
-for t in range(trials):
-    for kind, fn in (("sph", trial_sph), ("cyl", trial_cyl)):
-        if not fn(t, np.random.default_rng([seed0, t, 0 if kind == "sph" else 1])):
-            bad += 1
-print(f"{trials} trials of each basis, {bad} mismatches, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def main():
+    t0 = time.time()
+    bad = 0
+    for t in range(trials):
+        for kind, fn in (("sph", trial_sph), ("cyl", trial_cyl)):
+            if not fn(t, np.random.default_rng([seed0, t, 0 if kind == "sph" else 1])):
+                bad += 1
+    print(f"{trials} trials of each basis, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""A bounded, fixed-seed slice of every randomised campaign of tests/fuzz/ inside `pytest -m gpu`, so that the run the
+driver makes -- not only the builder's hand-run logs under profiles/ -- vouches for them.  Each test imports the campaign's
+own trial function and replays trials 0..N-1 of seed 1 (the first N lines of the committed campaign logs); tolerances are
+the campaigns' own: coefficients 1e-10, accelerations / potentials / fields 1e-9 (BASELINE.json north_star), integer and
+level results bit for bit.  The full campaigns stay hand-run: `python tests/fuzz/fuzz_*.py [trials] [seed]`."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 1
+
+
+def _campaign(name):
+    return importlib.import_module("tests.fuzz." + name)
+
+
+def test_fuzz_parity_slice():
+    """both force methods against the oracle over random bases, windows, flags, centres, adversarial particle sets"""
+    m = _campaign("fuzz_parity")
+    bad = []
+    for t in range(30):
+        for k, (kind, fn) in enumerate((("sph", m.trial_sph), ("cyl", m.trial_cyl))):
+            if not fn(t, np.random.default_rng([SEED, t, k])):
+                bad.append((kind, t))
+    assert not bad, f"fuzz_parity mismatches (kind, trial) at seed {SEED}: {bad}"
+
+
+def test_fuzz_multistep_slice():
+    """the C++ block-multistep driver against the n-body oracle: levels bit for bit, states, per-level sets"""
+    m = _campaign("fuzz_multistep")
+    try:
+        res = [m.one(t, np.random.default_rng([SEED, t])) for t in range(60)]
+    finally:
+        m.ctx.set_dense_min(-1)
+        m.ctx.set_mover_list_min(2048)
+    bad = [(t, r) for t, r in enumerate(res) if r in ("LEVELS", "STATE")]
+    assert not bad, f"fuzz_multistep failures (trial, kind) at seed {SEED}: {bad}"
+    assert res.count("edge") <= 2, "more than a couple of power-of-two boundary cases: not rounding"
+    assert m.total_switches > 0, "no level change in the whole slice: the campaign is not exercising the sweep"
+
+
+def test_fuzz_kdk_slice():
+    """the fused single-level step and its HIP-graph replay against the n-body oracle"""
+    m = _campaign("fuzz_kdk")
+    try:
+        bad = [t for t in range(40) if not m.one(t, np.random.default_rng([SEED, t]))]
+    finally:
+        m.ctx.set_prekick(True)
+    assert not bad, f"fuzz_kdk mismatches at seed {SEED}: trials {bad}"
+
+
+def test_fuzz_pyexp_slice():
+    """Basis.factory / createFromArray / getAccel / getFields against the literal pyEXP twins"""
+    m = _campaign("fuzz_pyexp")
+    bad = []
+    for t in range(30):
+        for k, (kind, fn) in enumerate((("sph", m.trial_sph), ("cyl", m.trial_cyl))):
+            if not fn(t, np.random.default_rng([SEED, t, k])):
+                bad.append((kind, t))
+    assert not bad, f"fuzz_pyexp mismatches (kind, trial) at seed {SEED}: {bad}"
+
+
+def test_fuzz_covariance_slice():
+    """sub-sample covariance of both bases through arrays, batches and a reader"""
+    m = _campaign("fuzz_covariance")
+    bad = [t for t in range(40) if not m.one(t, np.random.default_rng([SEED, t]))]
+    assert not bad, f"fuzz_covariance mismatches at seed {SEED}: trials {bad}"
+
+
+def test_fuzz_orient_slice():
+    """the centre / orientation estimator against the oracle's restatement of src/Orient.cc"""
+    m = _campaign("fuzz_orient")
+    bad = [t for t in range(30) if not m.one(t, np.random.default_rng([SEED, t]))]
+    assert not bad, f"fuzz_orient mismatches at seed {SEED}: trials {bad}"
+
+
+def test_fuzz_store_slice():
+    """random call sequences on the particle store against a numpy model, bit for bit"""
+    m = _campaign("fuzz_store")
+    bad = [t for t in range(100) if not m.one(t, np.random.default_rng([SEED, t]))]
+    assert not bad, f"fuzz_store mismatches at seed {SEED}: trials {bad}"

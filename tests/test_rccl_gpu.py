@@ -138,3 +138,64 @@ def test_graph_replay_without_deterministic_mode():
     for k in ("pos", "vel"):
         assert np.abs(outs[0][k] - outs[1][k]).max() <= 1e-11 * np.abs(outs[0][k]).max(), k
     assert np.abs(outs[0]["acc"] - outs[1]["acc"]).max() <= 1e-9 * np.abs(outs[0]["acc"]).max()
+
+
+def test_graph_replay_sees_changes_made_between_calls():
+    """A captured pair of fused steps bakes in kernel ARGUMENTS the replay key of round 3 did not cover: the force's
+    settings (exterior continuation, dsmall, M0 accumulation), the component's frame (body rotation, pseudo-acceleration,
+    the mass array a re-upload replaces) and the scratch pointers an outside force pass on a larger target re-allocates.
+    Every such call now bumps the library's mutation counter (common.h) and the graph is captured afresh; replayed and
+    eager runs must stay bit-identical through each of them, with 0 and 2 eager steps in between (an even number of
+    eager steps used to bring `cur` and the parity back to the captured values)."""
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, Context, SphereSL
+    from exp_amd._lib import check
+    model, g = make_grid("plummer", 4, 8, 400)
+    m, pos, vel = sample_sphere(model, 30000, seed=21)
+    pos[:40] *= 80.0 / np.linalg.norm(pos[:40], axis=1)[:, None]      # beyond rmax: the exterior continuation matters
+    m2, pos2, _ = sample_sphere(model, 90000, seed=22)
+    th = 0.3
+    body = np.array([[np.cos(th), np.sin(th), 0.0], [-np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+
+    def run(graph):
+        ctx = Context(0)
+        ctx.set_deterministic(True)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        big = Component.from_arrays(ctx, m2, pos2)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+
+        def steps(k, dt=0.01, eager=False):
+            if graph and not eager:
+                f.step_kdk_n(c, dt, k)
+            else:
+                for _ in range(k):
+                    f.step_kdk(c, dt)
+
+        steps(6)
+        check(ctx.lib.exp_amd_sph_set_exterior(f.h, 0), ctx.h)          # case 1: a force setting, no eager step between
+        steps(4)
+        check(ctx.lib.exp_amd_sph_set_dsmall(f.h, 1e-18), ctx.h)
+        steps(4)
+        c.set_pseudo_accel([1e-3, -2e-3, 5e-4])                         # case 2: the frame, two eager steps between
+        steps(2, eager=True)
+        steps(4)
+        c.set_orientation(body)
+        steps(2, eager=True)
+        steps(4)
+        st = c.download(("mass", "pos", "vel"))                         # ... a re-upload with other masses
+        c.upload(st["mass"] * 1.25, st["pos"], st["vel"])
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        steps(2, eager=True)
+        steps(4)
+        f.get_acceleration_and_potential(big, external=True)            # case 3: scratch of the force pass re-allocated
+        steps(2, eager=True)
+        steps(5)
+        out = c.download()
+        out["coef"] = f.get_coefs().copy()
+        big.close(); c.close(); f.close(); ctx.close()
+        return out
+
+    eager, replay = run(False), run(True)
+    for k in ("pos", "vel", "acc", "pot", "coef"):
+        assert np.array_equal(eager[k], replay[k]), k
