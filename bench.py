@@ -454,7 +454,9 @@ def other_configs(ctx, device, n, which=(2, 3, 4), steps=30, min_seconds=0.0):
         lev_d = np.bincount(cd.download_levels(), minlength=ms + 1)
         ctx.profile(True); ctx.profile_reset()
         sim.step(1)
-        prof = {k: round(v["ms_total"], 3) for k, v in ctx.profile_report().items() if v["launches"] > 0}
+        rep_ = ctx.profile_report()
+        prof = {k: round(v["ms_total"], 3) for k, v in rep_.items() if v["launches"] > 0}
+        prof_n = {k: int(v["launches"]) for k, v in rep_.items() if v["launches"] > 0}
         ctx.profile(False)
         sub = sum(int(lev_h[M] + lev_d[M]) * (1 << M) for M in range(ms + 1))
         # algorithmic bytes per particle-sub-step: 232 (its own step) + 32 (acc / pot read-modify-write
@@ -468,7 +470,7 @@ def other_configs(ctx, device, n, which=(2, 3, 4), steps=30, min_seconds=0.0):
                     "substeps_hbm_frac_264B": 264.0 * sub / el / 1e9 / HBM_PEAK_GBS,
                     "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist(),
                     "level_switches_last_master_step": sim.step_switches,
-                    "kernels_ms_per_master_step": prof})
+                    "kernels_ms_per_master_step": prof, "kernel_scopes_per_master_step": prof_n})
         sim.close(); ch.close(); cd.close(); fh.close(); fd.close()
     return out
 

@@ -78,6 +78,7 @@ SIGNATURES = {
                                       POINTER(c_void_p)]),
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_dense_min": (c_int, [c_void_p, c_longlong]),
+    "exp_amd_ctx_set_thin_max": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_mover_list_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_deterministic": (c_int, [c_void_p, c_int]),
     "exp_amd_ctx_set_prekick": (c_int, [c_void_p, c_int]),

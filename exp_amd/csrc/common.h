@@ -72,6 +72,10 @@ struct exp_amd_ctx {
   long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (EXP_AMD_MOVER_SLICES_MIN)
   long long stage_max = 1 << 20;     // particles up to which the per-particle atomic paths are staged (values by plain stores,
                                      // one lane per value for the atomics): 8 (L+1)^2 bytes each (EXP_AMD_STAGE_MAX)
+  long long thin_max = 4096;         // block multistep: an active slot range of at most this many particles, all of it in sparse
+                                     // levels, is accumulated and evaluated straight from the basis tables (k_*_acc_thin,
+                                     // k_*_force_thin: no moments, no contraction, no projected table); 0: never
+                                     // (exp_amd_ctx_set_thin_max; EXP_AMD_THIN_MAX sets the default)
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
                                      // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
   hipStream_t aux = nullptr;

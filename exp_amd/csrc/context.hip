@@ -43,6 +43,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   ctx->device = device;
   if (const char *e = getenv("EXP_AMD_SPLIT_MIN")) ctx->split_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
+  if (const char *e = getenv("EXP_AMD_THIN_MAX")) ctx->thin_max = atoll(e);
   if (const char *e = getenv("EXP_AMD_MOVER_LIST_MIN")) ctx->mover_list_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_MOVER_SLICES_MIN")) ctx->mover_slices_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_STAGE_MAX")) ctx->stage_max = atoll(e);
@@ -111,6 +112,14 @@ extern "C" int exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin)
   expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->dense_min = nmin;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax)
+{
+  expamd_mutated();
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->thin_max = nmax < 0 ? 0 : nmax;
   return EXP_AMD_OK;
 }
 

@@ -874,9 +874,10 @@ __device__ __forceinline__ void cyl_tail_fold(double *__restrict__ tailpart, dou
 }
 
 __global__ void __launch_bounds__(256)
-k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict__ out, size_t ostride,
+k_cyl_contract_sum(CylDev C, double *__restrict__ part, double *__restrict__ out, size_t ostride,
                    double *__restrict__ last, double *__restrict__ add_to /* += the new set as well, or null */,
-                   double *__restrict__ tailpart /* [CYL_TAILS][2] of the accumulation launches, or null */)
+                   double *__restrict__ tailpart /* [CYL_TAILS][2] of the accumulation launches, or null */,
+                   int clear = 0 /* leave the partial sums zero behind (the thin accumulation adds to them) */)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -892,6 +893,7 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
   double s = 0.0;
   if (!none)
     for (int seg = 0; seg < CYL_CSEG; seg++) s += part[((size_t)L * CYL_CSEG + seg) * ncoef + o];
+  if (clear) for (int seg = 0; seg < CYL_CSEG; seg++) part[((size_t)L * CYL_CSEG + seg) * ncoef + o] = 0.0;
   out += (size_t)L * ostride;
   if (last) {                                 // setup_accumulation's swap on the way: last <- out, out <- new
     last += (size_t)L * ostride;
@@ -907,9 +909,9 @@ k_cyl_contract_sum(CylDev C, const double *__restrict__ part, double *__restrict
 // CylEXP::compute_multistep_coefficients (src/CylEXP.cc:192-282) -- what k_cyl_contract_sum + k_cyl_mass_take +
 // k_mstep_combine do, in one launch instead of three.
 __global__ void __launch_bounds__(256)
-k_cyl_sum_combine(CylDev C, const double *__restrict__ part, double *__restrict__ N, double *__restrict__ Lset,
+k_cyl_sum_combine(CylDev C, double *__restrict__ part, double *__restrict__ N, double *__restrict__ Lset,
                   size_t stride, int lo, int nact, int nlev, int mfirst, CombineW W, double *__restrict__ out,
-                  double *__restrict__ tailpart, double *__restrict__ mass_acc, int open)
+                  double *__restrict__ tailpart, double *__restrict__ mass_acc, int open, int clear = 0)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
   const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -927,6 +929,7 @@ k_cyl_sum_combine(CylDev C, const double *__restrict__ part, double *__restrict_
     double s = 0.0;
     if (!none)
       for (int seg = 0; seg < CYL_CSEG; seg++) s += part[((size_t)j * CYL_CSEG + seg) * ncoef + o];
+    if (clear) for (int seg = 0; seg < CYL_CSEG; seg++) part[((size_t)j * CYL_CSEG + seg) * ncoef + o] = 0.0;
     const size_t q = (size_t)(lo + j) * stride + o;
     Lset[q] = N[q];
     N[q] = s;
@@ -935,13 +938,14 @@ k_cyl_sum_combine(CylDev C, const double *__restrict__ part, double *__restrict_
 }
 
 // both stages; nl levels starting at Wn / out / last
+// thin: stage 1 has been done by k_cyl_acc_thin (its sums ADDED to `part`, which stage 2 then leaves zero)
 static void cyl_contract(hipStream_t st, const CylDev &C, const double *tab, double *Wn, double *part,
                          double *out, int nl = 1, size_t ostride = 0, double *last = nullptr, int clear = 0,
-                         double *add_to = nullptr, double *tailpart = nullptr)
+                         double *add_to = nullptr, double *tailpart = nullptr, bool thin = false)
 {
   const size_t ncoef = (size_t)2 * (C.mmax + 1) * C.nmax;
-  k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
-  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to, tailpart);
+  if (!thin) k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nl), 256, 0, st>>>(C, tab, Wn, part, clear);
+  k_cyl_contract_sum<<<dim3(cdiv(ncoef, 256), nl), 256, 0, st>>>(C, part, out, ostride, last, add_to, tailpart, (thin || clear) ? 1 : 0);
 }
 
 // ---- coefficients -> projected node table ----------------------------------------------------------------
@@ -1173,6 +1177,316 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   }
 }
 
+// ---- thin active sets: straight from the basis tables ---------------------------------------------------------------
+// The cylinder's twin of sph_kernels.h's k_sph_acc_thin / k_sph_force_thin (see there for the why): the few active
+// particles of an upper time-step level are accumulated and evaluated per particle, as EmpCylSL::accumulate and
+// accumulated_eval do (exputil/EmpCylSL.cc:4049-4146, :5256-5410), with the block as the unit of parallelism -- no node
+// moments, no contraction over 33 000 nodes, no projection of the 66 MB table set.  The tables are read through a
+// NODE-MAJOR copy tabT[node][kind][m][n] (a particle's four corner nodes are four contiguous 2-4 KB stretches; the
+// [kind][m][n][node] layout of the sweep kernels would cost one cache line per (kind, m, n, corner pair)).
+//   k_cyl_acc_thin  : part[level][seg][cs][m][n] += sum_corners (-4 pi mass c_k trig_m) tab[pot cos|sin][m][n][node_k],
+//                     the layout k_cyl_contract_part leaves, finished by k_cyl_contract_sum / k_cyl_sum_combine;
+//   k_cyl_force_thin: TF rows of the particle's four corner nodes projected into LDS (the sums of k_cyl_project, same
+//                     four chains), then cyl_field and Cylinder's taper / monopole blend exactly as in k_cyl_force.
+__global__ void __launch_bounds__(256)
+k_cyl_transpose(const double *__restrict__ tab, double *__restrict__ tabT, size_t nnode, int per_node /* nk (mmax+1) nmax */)
+{
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;            // index into tabT
+  if (o >= nnode * (size_t)per_node) return;
+  const size_t node = o / per_node, k = o - node * per_node;
+  tabT[o] = tab[k * nnode + node];
+}
+
+// sum_n T[n] c[n] in the four chains of k_cyl_project: orders n = j mod 4 below the last multiple of four, the rest on
+// chain 0; the table values twelve at a time, all loads of a batch issued before the first is used
+template <class CP>
+__device__ __forceinline__ double cyl_chain4(const double *__restrict__ T, CP c, int nmax)
+{
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  const int nq = nmax & ~3;
+  for (int nb = 0; nb < nmax; nb += 12) {
+    double t[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) t[j] = nb + j < nmax ? T[nb + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      const int n = nb + j;
+      if (n < nq) a[j & 3] = fma(t[j], c[n], a[j & 3]);
+      else if (n < nmax) a[0] = fma(t[j], c[n], a[0]);
+    }
+  }
+  return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+// ... the cosine and the sine row of a harmonic from ONE fetch of each table value (the sine tables being bit for bit the
+// cosine tables: k_cyl_project's twin branch)
+template <class CP>
+__device__ __forceinline__ void cyl_chain4_pair(const double *__restrict__ T, CP cc, CP cs, int nmax, double &ra, double &rb)
+{
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  const int nq = nmax & ~3;
+  for (int nb = 0; nb < nmax; nb += 12) {
+    double t[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) t[j] = nb + j < nmax ? T[nb + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      const int n = nb + j;
+      if (n < nq) { a[j & 3] = fma(t[j], cc[n], a[j & 3]); b[j & 3] = fma(t[j], cs[n], b[j & 3]); }
+      else if (n < nmax) { a[0] = fma(t[j], cc[n], a[0]); b[0] = fma(t[j], cs[n], b[0]); }
+    }
+  }
+  ra = (a[0] + a[1]) + (a[2] + a[3]);
+  rb = (b[0] + b[1]) + (b[2] + b[3]);
+}
+
+#define CYL_THIN_TP_MAX 64
+
+template <int MMAX>
+__global__ void __launch_bounds__(256)
+k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi, const double *__restrict__ tabT, int nk,
+                 const double *__restrict__ coef, const double *__restrict__ cylmass_p, double *__restrict__ AX,
+                 double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT, double *__restrict__ VX,
+                 double *__restrict__ VY, double *__restrict__ VZ, int assign, int tp)
+{
+  extern __shared__ __attribute__((aligned(16))) double cthin_lds[];
+  __shared__ int s_node[CYL_THIN_TP_MAX];
+  constexpr int NT = 2 * MMAX + 1, NF = 3 * NT, NFS = NF + 1;       // (row stride 40 doubles: lanes 16 banks apart)
+  const int half = (C.mmax + 1) * C.nmax;
+  double *s_coef = cthin_lds;                                       // cos block, sin block
+  double *stage = cthin_lds + 2 * half;                             // [tp][PS]: four corner rows of NFS doubles each
+  constexpr int PS = 4 * NFS + 2;                                   // (particle stride = 4 banks mod 64: no conflicts)
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  if (beg + (size_t)blockIdx.x * tp >= end) return;
+  for (int k = threadIdx.x; k < 2 * half; k += 256) s_coef[k] = coef[k];
+  const int t = threadIdx.x;
+  const int nyp = C.numy + 1;
+  const size_t per_node = (size_t)nk * half;
+  for (size_t base = beg + (size_t)blockIdx.x * tp; base < end; base += (size_t)gridDim.x * tp) {
+    // ---- the prologue of k_cyl_force, one particle per lane of the first wave
+    const size_t i = base + t;
+    const bool valid = t < tp && i < end;
+    double xx = 1, yy = 0, zz = 0;
+    if (valid) cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
+    const double ratmin = 0.75, maxerf = 3.0;                       // src/Cylinder.cc:1357-1381
+    const double midpt = ratmin + 0.5 * (1.0 - ratmin);
+    const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
+    const double r2 = xx * xx + yy * yy;
+    double rp, irp, r3s, ir3s;
+    sqrt_rsqrt(r2, rp, irp);
+    sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
+    const double r = rp + DSMALL;
+    double cphi = 1.0, sphi = 0.0;
+    if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+    const double ratio = r3s * C.inv_rtab_abs;
+    double frac, cfrac;
+    if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
+    else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
+    else { cfrac = 0.0; frac = 1.0; }
+    const bool ongrid = valid && ratio < 1.0 && !(r3s > C.rtab_abs);
+    int ix, iy;
+    double c00, c10, c01, c11;
+    cyl_weights(C, r, zz, ix, iy, c00, c10, c01, c11);
+    if (t < CYL_THIN_TP_MAX) s_node[t] = ongrid ? ix * nyp + iy : -1;
+    __syncthreads();
+    // ---- TF rows of the four corner nodes of every on-grid particle: item = (particle, corner, kind, m)
+    const int per_p = 4 * 3 * (C.mmax + 1);
+    for (int it = threadIdx.x; it < tp * per_p; it += 256) {
+      const int p = it / per_p;
+      int rest = it - p * per_p;
+      const int node0 = s_node[p];
+      if (node0 < 0) continue;
+      const int k = rest / (3 * (C.mmax + 1));
+      rest -= k * 3 * (C.mmax + 1);
+      const int kind = rest / (C.mmax + 1), m = rest - kind * (C.mmax + 1);
+      const size_t node = (size_t)node0 + ((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0);     // 00, 10, 01, 11
+      const double *T = tabT + node * per_node + ((size_t)kind * (C.mmax + 1) + m) * C.nmax;
+      const double *cc = s_coef + (size_t)m * C.nmax, *cs = cc + half;
+      double *o = stage + (size_t)p * PS + (size_t)k * NFS + ((m == 0) ? 0 : 3 + 6 * (m - 1));
+      if (m == 0) o[kind] = cyl_chain4(T, cc, C.nmax);
+      else if (nk == 3) cyl_chain4_pair(T, cc, cs, C.nmax, o[kind], o[kind + 3]);    // (sine tables == cosine tables)
+      else {
+        o[kind] = cyl_chain4(T, cc, C.nmax);
+        o[kind + 3] = cyl_chain4(T + (size_t)3 * half, cs, C.nmax);                   // the sine tables: kinds 3-5
+      }
+    }
+    __syncthreads();
+    if (valid) {
+      CylOut o{0.0, 0.0, 0.0, 0.0};
+      if (ongrid) {
+        const double *t00 = stage + (size_t)t * PS;
+        const double *t10 = t00 + NFS, *t01 = t00 + 2 * NFS, *t11 = t00 + 3 * NFS;
+        o = cyl_field<MMAX>(C, t00, t10, t01, t11, c00, c10, c01, c11, cphi, sphi);
+      }
+      // ---- the tail of k_cyl_force (src/Cylinder.cc:1387-1418), no fused kick
+      double fx = 0.0, fy = 0.0, fz = 0.0, pa = 0.0;
+      if (ratio < 1.0) {
+        double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
+        if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
+        const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+        fx = (fr * xx * ir - fp * yy * ir2) * frac;
+        fy = (fr * yy * ir + fp * xx * ir2) * frac;
+        fz = fzz * frac;
+        pa = p * frac;
+      }
+      if (ratio > ratmin) {
+        const double p = -(*cylmass_p) * ir3s;
+        const double fr = p * (ir3s * ir3s);
+        fx += xx * fr * cfrac;
+        fy += yy * fr * cfrac;
+        fz += zz * fr * cfrac;
+        pa += p * cfrac;
+      }
+      if (C.use_rot) {
+        const double a = fx, b = fy, c = fz;
+        fx = C.rot[0] * a + C.rot[3] * b + C.rot[6] * c;
+        fy = C.rot[1] * a + C.rot[4] * b + C.rot[7] * c;
+        fz = C.rot[2] * a + C.rot[5] * b + C.rot[8] * c;
+      }
+      if (C.ps.center | C.ps.axis) {
+        double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+        if (C.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+        pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
+        fx -= qx; fy -= qy; fz -= qz;
+      }
+      if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
+      AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
+    }
+    __syncthreads();
+  }
+}
+
+// Accumulation of a thin, level-contiguous slot range into part[level - lo][seg][ncoef] (zero on entry; consumed and
+// cleared by k_cyl_contract_sum / k_cyl_sum_combine with clear = 1).  Cuts, window and weights are those of the sparse
+// accumulation (k_cyl_mstep_update with plain = 1): Cylinder's rcylmax cut with its {mass, count} tally, the grid window
+// of EmpCylSL::accumulate, z clamped to the table.
+template <int MMAX>
+__global__ void __launch_bounds__(256)
+k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+               const double *__restrict__ M, const uint32_t *__restrict__ lev_off, int lo, int hi,
+               const double *__restrict__ tabT, int nk, double *__restrict__ part, double *__restrict__ tail, int tpa)
+{
+  extern __shared__ __attribute__((aligned(16))) double cthin_lds[];
+  constexpr int NT = 2 * MMAX + 1;
+  __shared__ int s_node[CYL_THIN_TP_MAX], s_lev[CYL_THIN_TP_MAX];
+  __shared__ double s_cw[CYL_THIN_TP_MAX][4], s_trig[CYL_THIN_TP_MAX][NT + 1];
+  const int half = (C.mmax + 1) * C.nmax, ncoef = 2 * half;
+  const int nset = nk == 3 ? 1 : 2;                                 // potential tables: one (cos == sin) or two
+  double *pe = cthin_lds;                                           // [tpa][nset][half]: sum_k c_k tab[pot][m][n][node_k]
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  const int seg = blockIdx.x % CYL_CSEG;
+  const int t = threadIdx.x;
+  const int nyp = C.numy + 1;
+  const size_t per_node = (size_t)nk * half;
+  for (size_t base = beg + (size_t)blockIdx.x * tpa; base < end; base += (size_t)gridDim.x * tpa) {
+    const int np = (int)((end - base) < (size_t)tpa ? (end - base) : (size_t)tpa);
+    if (t < 64) {                                                   // (the whole first wave: the tally is wave-reduced)
+      const size_t i = base + t;
+      const bool valid = t < tpa && i < end;
+      double xx = 1, yy = 0, zz = 0, mass = 0;
+      if (valid) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = M[i]; }
+      const double r2 = xx * xx + yy * yy;
+      double r, ir;
+      sqrt_rsqrt(r2, r, ir);
+      const bool incut = valid && (r2 + zz * zz) < C.rmax2;
+      double mu = incut ? mass : 0.0, nu = incut ? 1.0 : 0.0;
+      for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
+      if (t == 0 && nu > 0.0) {
+        double *tp_ = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+        unsafeAtomicAdd(tp_ + 0, mu); unsafeAtomicAdd(tp_ + 1, nu);
+      }
+      const bool on = incut && !(sqrt(r2 + zz * zz) > C.rtab_abs);
+      double zc = zz;
+      if (zc > C.rtab_abs) zc = C.rtab_abs;
+      if (zc < -C.rtab_abs) zc = -C.rtab_abs;
+      int ix, iy;
+      double cw[4];
+      cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+      double cphi = 1.0, sphi = 0.0;
+      if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      const double t0 = on ? -4.0 * M_PI * mass : 0.0;
+      if (t < tpa) {
+        int lv = lo;
+        while (lv < hi && i >= lev_off[lv + 1]) lv++;
+        s_node[t] = on ? ix * nyp + iy : -1;
+        s_lev[t] = lv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_cw[t][k] = cw[k];
+        double cm = 1.0, sm = 0.0;
+        s_trig[t][0] = t0;
+#pragma unroll
+        for (int m = 1; m <= MMAX; m++) {
+          const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi;
+          cm = cn; sm = sn;
+          const bool m_on = !(C.EVEN_M && (m & 1));
+          s_trig[t][2 * m - 1] = m_on ? t0 * cm : 0.0;
+          s_trig[t][2 * m] = m_on ? t0 * sm : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    for (int it0 = threadIdx.x; it0 < np * nset * half; it0 += 3 * 256) {     // (three items = twelve loads in flight)
+      double tv[3][4];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int it = it0 + u * 256;
+        tv[u][0] = tv[u][1] = tv[u][2] = tv[u][3] = 0.0;
+        if (it < np * nset * half) {
+          const int p = it / (nset * half);
+          const int rest = it - p * nset * half;
+          const int set = rest / half, mn = rest - set * half;
+          const int node0 = s_node[p];
+          if (node0 >= 0) {
+            const double *T = tabT + (size_t)node0 * per_node + (size_t)(set ? 3 : 0) * half + mn;
+            tv[u][0] = T[0]; tv[u][1] = T[(size_t)nyp * per_node]; tv[u][2] = T[per_node]; tv[u][3] = T[(size_t)(nyp + 1) * per_node];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int it = it0 + u * 256;
+        if (it < np * nset * half) {
+          const int p = it / (nset * half);
+          pe[it] = s_cw[p][0] * tv[u][0] + s_cw[p][1] * tv[u][1] + s_cw[p][2] * tv[u][2] + s_cw[p][3] * tv[u][3];
+        }
+      }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < ncoef; o += 256) {
+      const int cs = o / half, mn = o - cs * half, m = mn / C.nmax;
+      if (cs && m == 0) continue;                                  // (sin, m = 0): no such row
+      const int jt = m == 0 ? 0 : 2 * m - 1 + cs;
+      const int set = (cs && nset == 2) ? 1 : 0;
+      double acc = 0.0;
+      int cur = s_lev[0];
+      for (int p0 = 0; p0 < np; p0 += 8) {                 // (eight particles' LDS reads issued before their fmas)
+        double tt_[8], pp_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const bool in = p0 + u < np;
+          tt_[u] = in ? s_trig[p0 + u][jt] : 0.0;
+          pp_[u] = in ? pe[((size_t)(p0 + u) * nset + set) * half + mn] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (p0 + u < np) {
+            const int lv = s_lev[p0 + u];
+            if (lv != cur) {
+              if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)(cur - lo) * CYL_CSEG + seg) * ncoef + o, acc);
+              acc = 0.0;
+              cur = lv;
+            }
+            acc = fma(tt_[u], pp_[u], acc);
+          }
+        }
+      }
+      if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)(cur - lo) * CYL_CSEG + seg) * ncoef + o, acc);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 
 struct CylForce : exp_amd_force {
@@ -1181,6 +1495,10 @@ struct CylForce : exp_amd_force {
   DevBuf<double> d_tab, d_Wn, d_TF;
   bool tab_twin = false;            // the three sine tables equal the three cosine tables bit for bit (m >= 1)
   DevBuf<double> d_cpart;           // stage-1 sums of the contraction: [level][CYL_CSEG][ncoef]
+  bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)
+  DevBuf<double> d_tabT;            // node-major copy tabT[node][kind][m][n] for the thin path (made on first use)
+  int tabT_nk = 0;                  // kinds it holds: 3 (sine tables == cosine tables) or 6
+  int ensure_tabT();
   DevBuf<double> d_Wnd, d_differ;   // multistep differencing
   DevBuf<double> d_dens;            // densC / densS tables (field evaluation only)
   // sub-sample covariance (pyEXP pcavar, analysis only): node moments U[T][node][ntrig], cell
@@ -1220,6 +1538,7 @@ struct CylForce : exp_amd_force {
     cov_U.release(); cov_Q.release(); cov_mass.release(); cov_vc.release(); cov_mv.release();
     cov_cnt.release(); cov_used.release(); cov_seq.release();
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release(); d_cpart.release();
+    d_tabT.release();
     d_mass.release();
     d_tailpart.release();
     d_dens.release();
@@ -1325,6 +1644,65 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     case 9: CALL(9); break;  case 10: CALL(10); break; case 11: CALL(11); break;     \
     case 12: CALL(12); break;                                                        \
   }
+
+int CylForce::ensure_tabT()
+{
+  if (d_tabT.p) return EXP_AMD_OK;
+  const size_t half = (size_t)(cfg.mmax + 1) * cfg.nmax;
+  tabT_nk = tab_twin ? 3 : 6;
+  const int per_node = (int)(tabT_nk * half);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (d_tabT.alloc(nnode * (size_t)per_node) != hipSuccess)
+    return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cylinder: hipMalloc of the node-major table copy failed");
+  k_cyl_transpose<<<cdiv(nnode * (size_t)per_node, 256), 256, 0, ctx->stream>>>(d_tab.p, d_tabT.p, nnode, per_node);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+// tile sizes of the thin kernels: what fits the LDS
+template <int MM>
+static void cyl_thin_force_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
+                                  const uint32_t *lev_off, int lo, int hi, const double *tabT, int nk, const double *coef,
+                                  const double *mass, double *AX, double *AY, double *AZ, double *POT, double *VX, double *VY,
+                                  double *VZ, int assign)
+{
+  static const int tp0 = [] { const char *e = getenv("EXP_AMD_THIN_TP"); return e ? atoi(e) : 4; }();
+  const int tp = tp0 < 1 ? 1 : tp0 > 64 ? 64 : tp0;      // (small tiles: see the spherical launcher)
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const size_t lds = (2 * half + (size_t)tp * (4 * (3 * (2 * MM + 1) + 1) + 2)) * sizeof(double);
+  size_t grid = cdiv(n, (size_t)tp);
+  if (grid > 16384) grid = 16384;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_force_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_cyl_force_thin<MM><<<(unsigned)grid, 256, lds, st>>>(C, X, Y, Z, lev_off, lo, hi, tabT, nk, coef, mass, AX, AY, AZ, POT, VX,
+                                                         VY, VZ, assign, tp);
+}
+
+template <int MM>
+static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
+                                const double *M, const uint32_t *lev_off, int lo, int hi, const double *tabT, int nk,
+                                double *part, double *tail)
+{
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const int nset = nk == 3 ? 1 : 2;
+  static const int tpa0 = [] { const char *e = getenv("EXP_AMD_THIN_TPA"); return e ? atoi(e) : 8; }();
+  int tpa = tpa0 < 1 ? 1 : tpa0 > 64 ? 64 : tpa0;
+  while (tpa > 4 && (size_t)tpa * nset * half * sizeof(double) > 96 * 1024) tpa >>= 1;
+  size_t grid = cdiv(n, (size_t)tpa);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_acc_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_cyl_acc_thin<MM><<<(unsigned)grid, 256, (size_t)tpa * nset * half * sizeof(double), st>>>(C, X, Y, Z, M, lev_off, lo, hi, tabT,
+                                                                                                 nk, part, tail, tpa);
+}
 
 __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ tail, int overwrite)
 {
@@ -1520,6 +1898,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
+    f->cpart_clean = false;
     cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p, f->d_cpart.p, dst, 1, 0, nullptr, 0, nullptr, f->d_tailpart.p);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -1632,7 +2011,24 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   }
   nrange = 0;
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
-  if (nrange) {
+  // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
+  // (k_cyl_acc_thin), no node moments and no pass over the nodes
+  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0;
+  if (thin) {
+    if ((rc = ensure_tabT())) return rc;
+    if (!f->cpart_clean) {
+      HIP_TRY(ctx, hipMemsetAsync(f->d_cpart.p, 0, f->d_cpart.bytes(), ctx->stream));
+      f->cpart_clean = true;
+    }
+    if (nrange) {
+      ProfScope ps(ctx, "k_cyl_acc_thin");
+#define CALL(MM)                                                                                         \
+  cyl_thin_acc_launch<MM>(ctx->stream, nrange, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, \
+                          f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p)
+      MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+    }
+  } else if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate_sparse");
     const unsigned grid = cdiv(nrange, 256);
 #define CALL(MM)                                                                              \
@@ -1650,18 +2046,20 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       int mfc = 0;
       CombineW Wc;
       expamd_combine_weights(ms, mdrft_combine, &mfc, &Wc);
-      k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nact), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl,
-                                                                                 f->d_cpart.p, /*clear=*/1);
+      if (!thin)
+        k_cyl_contract_part<<<dim3(CYL_CSEG, C.ntrig, nact), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl,
+                                                                                   f->d_cpart.p, /*clear=*/1);
+      // (the stage-1 sums are left zero by the kernel that reads them, table path or thin: no memset in between)
       k_cyl_sum_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
           C, f->d_cpart.p, f->d_coefN.p, f->d_coefL.p, f->ncoef_dev, lo, nact, ms + 1, mfc, Wc, f->d_coef.p,
-          f->d_tailpart.p, f->d_mass.p, f->mass_open ? 1 : 0);
+          f->d_tailpart.p, f->d_mass.p, f->mass_open ? 1 : 0, /*clear=*/1);
       HIP_TRY(ctx, hipGetLastError());
       f->combined_mdrft = mdrft_combine;
       f->proj_dirty = true;
       return EXP_AMD_OK;
     }
     cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wn.p + (size_t)lo * wl, f->d_cpart.p, dst, nact,
-                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1, nullptr, f->d_tailpart.p);
+                 f->ncoef_dev, f->d_coefL.p + (size_t)lo * f->ncoef_dev, /*clear=*/1, nullptr, f->d_tailpart.p, thin);
   }
   HIP_TRY(ctx, hipGetLastError());
   f->combined_mdrft = -1;
@@ -1683,6 +2081,36 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   // closing half-kick: stored (1), deferred (0), or stored with the next opening half-kick (2); see sph.hip
   const bool deferred = defer_kick && dt_kick != 0.0;
   const int sv = !deferred ? 1 : (prekey && nk_dtk != 0.0 && ctx->prekick) ? 2 : 0;
+  // a thin target range (a block-multistep sub-step's few active particles, ours or another component's) is evaluated
+  // straight from the coefficient set (k_cyl_force_thin): the projected node table is not needed and stays stale
+  bool thin = false;
+  size_t nthin = 0;
+  if (f->multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !ctx->deterministic &&
+      ctx->thin_max > 0) {
+    int rc_ = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin);
+    if (rc_) return rc_;
+    thin = (long long)nthin <= ctx->thin_max;
+  }
+  if (thin) {
+    int rc_ = ensure_tabT();
+    if (rc_) return rc_;
+    f->mass_open = false;
+    if (nthin) {
+      ProfScope ps(ctx, "k_cyl_force_thin");
+      CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
+                 : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
+      C.ps = t->pseudo;
+#define CALL(MM)                                                                                          \
+  cyl_thin_force_launch<MM>(ctx->stream, nthin, C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel,      \
+                            t->nlevels - 1, f->d_tabT.p, f->tabT_nk, f->d_coef.p, f->d_mass.p, t->a(A_AX), t->a(A_AY), \
+                            t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ), assign ? 1 : 0)
+      MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    t->acc_live = true;
+    return EXP_AMD_OK;
+  }
   if (f->proj_dirty) {
     ProfScope ps(ctx, "k_cyl_project");
     k_cyl_project<<<dim3(cdiv(f->nnode, 256), cfg.mmax + 1), 256, 0, ctx->stream>>>(

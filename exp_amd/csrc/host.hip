@@ -354,7 +354,10 @@ static int substep_expansion(exp_amd_sim *s, int lo, double dt_min, int mdrft)
 // ComponentContainer::compute_potential(mlevel): the self force of a component is evaluated first
 // and ASSIGNS acc / pot of its levels >= mlevel (the reference zeroes them and adds, src/
 // ComponentContainer.cc:641-716: same values, one pass less); the interactions then add.
-static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep)
+// join_follows: the sweep behind this force evaluation ends in a read-back that synchronises both streams; false for the
+// sweeps that cannot move anything (kick_adjust_levels): the cross forces then leave their 'tables used' events, so that
+// the NEXT sub-step's first half on the other stream waits for them before it rewrites those tables.
+static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep, bool join_follows = true)
 {
   int rc;
   if ((rc = fix_centers(s, mstep))) return rc;
@@ -383,7 +386,7 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     // begin_run / the end of a step call end in overlap_end.  An event per cross force for it cost each stream ~5 us a
     // sub-step, tools/dbg/launch_gap.hip; EXP_AMD_SIM_USED_EVENTS=1 records them again)
     static const bool used_ev = [] { const char *e = getenv("EXP_AMD_SIM_USED_EVENTS"); return e && atoi(e) != 0; }();
-    if (foreign && used_ev) {
+    if (foreign && (used_ev || !join_follows)) {
       HIP_TRY(s->ctx, hipEventRecord(s->ev_used[pr.first], s->ctx->stream));
       s->used_pending[pr.first] = 1;
     }
@@ -391,6 +394,16 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
   }
   s->gottapot = true;
   return EXP_AMD_OK;
+}
+
+// A sweep that examines the TOP level only cannot move anything: the proposals of adjust_multistep_level are clamped to
+// [mfirst[mdrft], multistep] (src/multistep.cc:188-196: `nlev = std::max<int>(nlev, mfirst[mdrft])` after the cap at multistep), and for odd
+// mdrft that interval is the single level `multistep` its particles are already on.  Half the sweeps of a master step
+// are of this kind: they reduce to the closing kick, with no counters, no read-back and no wait.
+static bool sweep_is_noop(const exp_amd_sim *s, int mdrft, int first_step)
+{
+  static const bool on = [] { const char *e = getenv("EXP_AMD_SIM_SKIP_NOOP_SWEEPS"); return !e || atoi(e) != 0; }();
+  return on && s->multistep > 0 && !first_step && s->mfirst[mdrft] == s->multistep;
 }
 
 // second half: incr_velocity(dt*mintvl[M]/2, M) for M >= mfirst[mdrft] (src/step.cc:198-203; not in
@@ -412,6 +425,21 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     s->pinned_cap = nc;
   }
   int rc;
+  // (sweep_is_noop: the closing kick alone -- the host goes straight on to the next sub-step's launches; the streams stay
+  // ordered among themselves, nothing is differenced, committed or re-ordered because nothing changed)
+  if (kick && sweep_is_noop(s, mdrft, first_step)) {
+    const double th0 = s->host_timing ? host_now() : 0.0;
+    for (size_t k = 0; k < nc; k++) {
+      StreamOf on(s, k);
+      const unsigned long long *res = nullptr;
+      if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf, mf, /*first=*/ms + 1,
+                                        dt_min, &res))) return rc;
+      if (s->host_timing && s->overlap && s->ht_ev0 && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
+    }
+    s->last_switch = 0;
+    if (s->host_timing) s->ht[2] += host_now() - th0;
+    return EXP_AMD_OK;
+  }
   const double th0 = s->host_timing ? host_now() : 0.0;
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
@@ -538,10 +566,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
         s->tnow += dt;
         const double th1 = s->host_timing ? host_now() : 0.0;
-        if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep))) return rc;
+        const int first_step = (s->this_step == 0 && mstep == 0) ? 1 : 0;
+        if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep, !sweep_is_noop(s, mdrft, first_step)))) return rc;
         if (s->host_timing) { s->ht[0] += th1 - th0; s->ht[1] += host_now() - th1; }
         const int lo_now = s->mfirst[mstep];
-        if ((rc = kick_adjust_levels(s, mdrft, (s->this_step == 0 && mstep == 0) ? 1 : 0, true))) return rc;
+        if ((rc = kick_adjust_levels(s, mdrft, first_step, true))) return rc;
         if (s->host_timing) s->ht_lo[lo_now] += host_now() - th0;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {

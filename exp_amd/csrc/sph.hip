@@ -20,7 +20,7 @@ struct SphKeyFn {
 
 // ---- moments -> coefficients ------------------------------------------------------------------------
 // part[seg][row][n] = sum_{i in seg} E[i][l][n] W[i][row][0] + E[i+1][l][n] W[i][row][1]
-#define CSEG 32
+// (CSEG, the number of segments: sph_kernels.h)
 // clear != 0: the moments are zeroed once they have been read (each (cell, row) pair is read by exactly
 // one block), so that the next accumulation finds a clean buffer without a separate memset pass
 __global__ void __launch_bounds__(256)
@@ -86,9 +86,10 @@ k_sph_contract(SphDev S, double *__restrict__ W, const double *__restrict__ wsca
 // last <- coef (the previous set of this level), coef <- new
 // add_to != nullptr: add_to += the new set as well (the differencing of a single rank: expcoefN += differ with no
 // all-reduce in between)
+// clear != 0: the partial sums are left zero behind (what the thin accumulation, which ADDS to them, starts from)
 __global__ void __launch_bounds__(256)
-k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__ coef,
-                double *__restrict__ last = nullptr, double *__restrict__ add_to = nullptr)
+k_sph_sum_parts(double *__restrict__ part, int ncoef, double *__restrict__ coef,
+                double *__restrict__ last = nullptr, double *__restrict__ add_to = nullptr, int clear = 0)
 {
   int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
@@ -96,6 +97,7 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
   coef += (size_t)blockIdx.y * ncoef;
   double s = 0.0;
   for (int seg = 0; seg < CSEG; seg++) s += part[(size_t)seg * ncoef + k];
+  if (clear) for (int seg = 0; seg < CSEG; seg++) part[(size_t)seg * ncoef + k] = 0.0;
   if (last) last[(size_t)blockIdx.y * ncoef + k] = coef[k];
   coef[k] = s;
   if (add_to) add_to[(size_t)blockIdx.y * ncoef + k] += s;
@@ -105,15 +107,16 @@ k_sph_sum_parts(const double *__restrict__ part, int ncoef, double *__restrict__
 // (as above), THEN the combined set of compute_multistep_coefficients (src/SphericalBasis.cc:1252-1333) in the same
 // thread -- the same operations in the same order as k_sph_sum_parts + k_mstep_combine, one launch less in the chain.
 __global__ void __launch_bounds__(256)
-k_sph_sum_combine(const double *__restrict__ part, int ncoef, double *__restrict__ N, double *__restrict__ L, int lo,
-                  int nact, int nlev, int mfirst, CombineW W, double *__restrict__ out)
+k_sph_sum_combine(double *__restrict__ part, int ncoef, double *__restrict__ N, double *__restrict__ L, int lo,
+                  int nact, int nlev, int mfirst, CombineW W, double *__restrict__ out, int clear = 0)
 {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= ncoef) return;
   for (int j = 0; j < nact; j++) {
-    const double *p = part + (size_t)j * CSEG * ncoef;
+    double *p = part + (size_t)j * CSEG * ncoef;
     double s = 0.0;
     for (int seg = 0; seg < CSEG; seg++) s += p[(size_t)seg * ncoef + k];
+    if (clear) for (int seg = 0; seg < CSEG; seg++) p[(size_t)seg * ncoef + k] = 0.0;
     const size_t o = (size_t)(lo + j) * ncoef + k;
     L[o] = N[o];
     N[o] = s;
@@ -129,13 +132,10 @@ k_sph_project(SphDev S, const double *__restrict__ coef, double *__restrict__ G)
   const int i = blockIdx.x;
   const int stride = (S.lmax + 1) * S.nmax;
   for (int row = threadIdx.x; row < S.nrows; row += 256) {
-    int l = 0;
-    while ((l + 1) * (l + 1) <= row) l++;
+    const int l = sph_l_of_row(row);
     const double *e = S.E + (size_t)i * stride + l * S.nmax;
     const double *c = coef + (size_t)row * S.nmax;
-    double s = 0.0;
-    for (int n = 0; n < S.nmax; n++) s = fma(e[n], c[n], s);
-    G[(size_t)i * S.nrows + row] = s;
+    G[(size_t)i * S.nrows + row] = sph_G_row(e, c, S.nmax);
   }
 }
 
@@ -161,11 +161,8 @@ k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ r
     const double h1 = S.p0[j] * G[(size_t)j * S.nrows + row];
     const double h2 = S.p0[j + 1] * G[(size_t)(j + 1) * S.nrows + row];
     double *t = T4 + ((size_t)cell * S.trows + q) * 4;
-    const double sc = tscale[q];               // 1/s(l,m) of the rescaled Legendre recurrence
-    t[0] = sc * g0;
-    t[1] = sc * (g1 - g0);
-    t[2] = sc * (0.5 * (h2 - h0));
-    t[3] = sc * ((h0 - 2.0 * h1) + h2);
+    // (tscale: 1/s(l,m) of the rescaled Legendre recurrence)
+    sph_t4_entry(tscale[q], g0, g1, h0, h1, h2, t[0], t[1], t[2], t[3]);
   }
 }
 
@@ -422,7 +419,9 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
 #define DECL_L(k)                                        \
   void expamd_sph_acc_L##k(const SphAccArgs &);          \
   void expamd_sph_force_L##k(const SphForceArgs &);  \
-  void expamd_sph_upd_L##k(const SphUpdArgs &);
+  void expamd_sph_upd_L##k(const SphUpdArgs &);         \
+  void expamd_sph_thin_force_L##k(const SphThinForceArgs &); \
+  void expamd_sph_thin_acc_L##k(const SphThinAccArgs &);
 DECL_L(0) DECL_L(1) DECL_L(2) DECL_L(3) DECL_L(4) DECL_L(5) DECL_L(6)
 DECL_L(7) DECL_L(8) DECL_L(9) DECL_L(10) DECL_L(11) DECL_L(12)
 #undef DECL_L
@@ -434,6 +433,16 @@ static const sph_upd_launcher k_upd_launch[SPH_MAX_L + 1] = {
     expamd_sph_upd_L0, expamd_sph_upd_L1, expamd_sph_upd_L2,  expamd_sph_upd_L3,  expamd_sph_upd_L4,
     expamd_sph_upd_L5, expamd_sph_upd_L6, expamd_sph_upd_L7,  expamd_sph_upd_L8,  expamd_sph_upd_L9,
     expamd_sph_upd_L10, expamd_sph_upd_L11, expamd_sph_upd_L12};
+static const sph_thin_force_launcher k_thin_force_launch[SPH_MAX_L + 1] = {
+    expamd_sph_thin_force_L0, expamd_sph_thin_force_L1, expamd_sph_thin_force_L2,  expamd_sph_thin_force_L3,
+    expamd_sph_thin_force_L4, expamd_sph_thin_force_L5, expamd_sph_thin_force_L6,  expamd_sph_thin_force_L7,
+    expamd_sph_thin_force_L8, expamd_sph_thin_force_L9, expamd_sph_thin_force_L10, expamd_sph_thin_force_L11,
+    expamd_sph_thin_force_L12};
+static const sph_thin_acc_launcher k_thin_acc_launch[SPH_MAX_L + 1] = {
+    expamd_sph_thin_acc_L0, expamd_sph_thin_acc_L1, expamd_sph_thin_acc_L2,  expamd_sph_thin_acc_L3,
+    expamd_sph_thin_acc_L4, expamd_sph_thin_acc_L5, expamd_sph_thin_acc_L6,  expamd_sph_thin_acc_L7,
+    expamd_sph_thin_acc_L8, expamd_sph_thin_acc_L9, expamd_sph_thin_acc_L10, expamd_sph_thin_acc_L11,
+    expamd_sph_thin_acc_L12};
 static const sph_force_launcher k_force_launch[SPH_MAX_L + 1] = {
     expamd_sph_force_L0, expamd_sph_force_L1, expamd_sph_force_L2,  expamd_sph_force_L3,
     expamd_sph_force_L4, expamd_sph_force_L5, expamd_sph_force_L6,  expamd_sph_force_L7,
@@ -489,6 +498,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
     ProfScope ps(ctx, "k_sph_contract");
     k_sph_contract<<<dim3(CSEG, S.nrows), 256, 0, ctx->stream>>>(S, f->d_W.p, f->d_wscale.p,
                                                                 f->d_part.p);
+    f->part_clean = false;
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(f->d_part.p, (int)f->ncoef,
                                                                   d_out);
   }
@@ -601,7 +611,22 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   }
   nrange = 0;
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
-  if (nrange) {
+  // the whole active range is sparse and thin: straight from the basis tables into the contraction's partial sums
+  // (k_sph_acc_thin), no moments and no contraction (the deterministic mode keeps the moment path: its rounding grid
+  // is that of the moment terms)
+  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic;
+  if (thin) {
+    if (!f->part_clean) {
+      HIP_TRY(ctx, hipMemsetAsync(f->d_part.p, 0, f->d_part.bytes(), ctx->stream));
+      f->part_clean = true;
+    }
+    if (nrange) {
+      ProfScope ps(ctx, "k_sph_acc_thin");
+      SphThinAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, f->d_wscale.p, f->d_part.p,
+                       used_p, nrange, ctx->stream};
+      k_thin_acc_launch[cfg.lmax](a);
+    }
+  } else if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate_sparse");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,
                  c->lev_off.p, dacc + 1, ms, 0, f->d_W.p, nrange, ctx->stream, 1, used_p};
@@ -610,18 +635,22 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
-    k_sph_contract<<<dim3(CSEG, S.nrows, nact), 256, 0, ctx->stream>>>(
-        S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
+    if (!thin)
+      k_sph_contract<<<dim3(CSEG, S.nrows, nact), 256, 0, ctx->stream>>>(
+          S, f->d_W.p + (size_t)lo * wl, f->d_wscale.p, f->d_part.p, /*clear=*/1);
     // ... with the N/L swap of every active level (src/SphericalBasis.cc:785-792): L <- N, N <- new
+    // (the summing kernels leave the partial sums they read ZERO: what the thin accumulation, which adds to them, starts
+    // from -- no memset between a table-path sub-step and a thin one)
     if (mdrft_combine >= 0) {
       int mfc = 0;
       CombineW Wc;
       expamd_combine_weights(ms, mdrft_combine, &mfc, &Wc);
       k_sph_sum_combine<<<cdiv(f->ncoef, 256), 256, 0, ctx->stream>>>(
-          f->d_part.p, (int)f->ncoef, f->d_coefN.p, f->d_coefL.p, lo, nact, ms + 1, mfc, Wc, f->d_coef.p);
+          f->d_part.p, (int)f->ncoef, f->d_coefN.p, f->d_coefL.p, lo, nact, ms + 1, mfc, Wc, f->d_coef.p, /*clear=*/1);
     } else
     k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nact), 256, 0, ctx->stream>>>(
-        f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef, f->d_coefL.p + (size_t)lo * f->ncoef);
+        f->d_part.p, (int)f->ncoef, f->d_coefN.p + (size_t)lo * f->ncoef, f->d_coefL.p + (size_t)lo * f->ncoef, nullptr,
+        /*clear=*/1);
   }
   HIP_TRY(ctx, hipGetLastError());
   f->combined_mdrft = mdrft_combine;
@@ -649,10 +678,34 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
 {
   SphForce *f = this;
   if (prekey_done) *prekey_done = false;
-  int rc = sph_project(f);
-  if (rc) return rc;
+  int rc;
+  // A thin target range (a block-multistep sub-step's few active particles, ours or another component's) is evaluated
+  // straight from the coefficient set (k_sph_force_thin): the projected table is not needed and stays stale.
+  bool thin = false;
+  size_t nthin = 0;
+  if (f->cfg.multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !f->lit_on &&
+      !ctx->deterministic && ctx->thin_max > 0) {
+    if ((rc = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin))) return rc;
+    thin = (long long)nthin <= ctx->thin_max;
+  }
+  if (!thin && (rc = sph_project(f))) return rc;
   f->used_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
+  if (thin) {
+    if (nthin) {
+      ProfScope ps(ctx, "k_sph_force_thin");
+      const double *ctr_ = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
+      SphDev S = dev_for(f, ctr_);
+      S.ps = t->pseudo;
+      SphThinForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1, f->d_coef.p,
+                         f->d_rowmap.p, f->d_tscale.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX),
+                         t->a(A_VY), t->a(A_VZ), assign ? 1 : 0, nthin, ctx->stream};
+      k_thin_force_launch[f->cfg.lmax](a);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    t->acc_live = true;
+    return EXP_AMD_OK;
+  }
   // next step's keys + histogram: single level, own (sorted) particles, fused half-kick only
   const bool prekey = prekey_done && nk_dtd != 0.0 && dt_kick != 0.0 && !external &&
                       t->nlevels == 1 && f->cfg.multistep == 0 && t->sorted_for == f;
@@ -830,6 +883,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
   {
     ProfScope ps(ctx, "k_sph_contract");
     k_sph_contract<<<dim3(CSEG, S.nrows), 256, 0, V>>>(S, f->d_W.p, f->d_wscale.p, f->d_part.p);
+    f->part_clean = false;
     k_sph_sum_parts<<<cdiv(f->ncoef, 256), 256, 0, V>>>(f->d_part.p, (int)f->ncoef, f->d_coef.p);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -953,7 +1007,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;
   k_sph_sum_parts<<<dim3(cdiv(f->ncoef, 256), nl), 256, 0, ctx->stream>>>(
       f->d_part.p, (int)f->ncoef, f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef, nullptr,
-      alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef : nullptr);
+      alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef : nullptr, /*clear=*/1);
   HIP_TRY(ctx, hipGetLastError());
   if (alone) return EXP_AMD_OK;
   const size_t cnt = (size_t)nl * f->ncoef;

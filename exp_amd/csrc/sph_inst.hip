@@ -131,3 +131,52 @@ void CAT(expamd_sph_upd_L, SPH_L)(const SphUpdArgs &a)
   k_sph_mstep_update<SPH_L><<<cdiv(a.n, 256), 256, 0, a.stream>>>(
       a.S, a.X, a.Y, a.Z, a.M, a.lev, a.newlev, a.lev_off, a.first, a.last, a.mfirst, a.Wd, a.plain, a.used, a.list);
 }
+
+// thin active sets (sph_kernels.h): tile sizes from what fits the LDS next to the coefficient set / the products
+void CAT(expamd_sph_thin_force_L, SPH_L)(const SphThinForceArgs &a)
+{
+  constexpr int LMAX = SPH_L;
+  const int tq = 4 * a.S.trows;
+  const int tqs = tq + ((2 - tq % 16) + 16) % 16;
+  const size_t ncoef = ((size_t)a.S.nrows * a.S.nmax + 1) & ~(size_t)1;
+  const size_t lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
+  // (small tiles: a thin range is a few hundred to a few thousand particles and the GPU has a thousand SIMDs -- what
+  // counts is the length of a block's chain of dependent phases, not the number of blocks)
+  static const int tp0 = [] { const char *e = getenv("EXP_AMD_THIN_TP"); return e ? atoi(e) : 4; }();
+  int tp = tp0 < 1 ? 1 : tp0 > 64 ? 64 : tp0;
+  while (tp > 4 && (ncoef + (size_t)tp * (tqs + 3 * lsn)) * sizeof(double) > 100 * 1024) tp >>= 1;
+  const size_t lds = (ncoef + (size_t)tp * (tqs + 3 * lsn)) * sizeof(double);
+  size_t grid = cdiv(a.n, (size_t)tp);
+  if (grid > 16384) grid = 16384;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_force_thin<LMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_sph_force_thin<LMAX><<<(unsigned)grid, 256, lds, a.stream>>>(
+      a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.coef, a.rowmap, a.tscale, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+      a.assign, tp, tqs);
+}
+
+void CAT(expamd_sph_thin_acc_L, SPH_L)(const SphThinAccArgs &a)
+{
+  constexpr int LMAX = SPH_L;
+  const size_t nrows = (size_t)a.S.nrows, lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
+  static const int tpa0 = [] { const char *e = getenv("EXP_AMD_THIN_TPA"); return e ? atoi(e) : 8; }();
+  int tpa = tpa0 < 1 ? 1 : tpa0 > 64 ? 64 : tpa0;
+  auto need = [&](int t) { return ((((size_t)t * nrows + 1) & ~(size_t)1) + (size_t)t * lsn) * sizeof(double); };
+  while (tpa > 4 && need(tpa) > 96 * 1024) tpa >>= 1;
+  size_t grid = cdiv(a.n, (size_t)tpa);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_acc_thin<LMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_sph_acc_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off, a.lo, a.hi, a.wscale,
+                                                                    a.part, a.used, tpa);
+}

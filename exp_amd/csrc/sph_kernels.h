@@ -1724,6 +1724,319 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
   }
 }
 
+// ---- thin active sets: straight from the basis tables ---------------------------------------------------------------
+// The upper time-step levels of a block-multistep run hold a few hundred to a few thousand particles and are stepped
+// 2^level times per master step.  For them the table formulation above is all fixed cost: the contraction reads every
+// cell's moments, the projection rebuilds all numr rows of T4, and the evaluation of 2000 particles by 32 waves is one
+// long chain of gathers -- ~25 launches of 5-35 us for particles that need microseconds of arithmetic.  These two
+// kernels do what the reference's thread bodies do (src/SphericalBasis.cc:429-599, :1476-1660): per particle, straight
+// from E[i][l][n] and the coefficient set, with the block as the unit of parallelism:
+//   k_sph_acc_thin  : part[level][seg][row][n] += s(l,m)^-1 Yh_row(p) (a1 E[i][l][n] + a2 E[i+1][l][n])   (a1, a2 as in
+//                     sph_acc_input: -4 pi m P0 x1|x2), in the layout k_sph_contract leaves its partial sums in, so the
+//                     same k_sph_sum_parts / k_sph_sum_combine finish the job (N/L swap, combined set);
+//   k_sph_force_thin: the rows of T4 for THE CELLS ITS PARTICLES SIT IN are projected into LDS by the whole block (the
+//                     arithmetic of k_sph_project + k_sph_project4 through the shared sph_G_row / sph_t4_entry: the same
+//                     bits as the global table would hold), then evaluated by the staged kernel's code.
+// No moments, no contraction, no projection launch, no global T4: exp_amd_force::proj_dirty simply stays set.
+#ifndef CSEG
+#define CSEG 32                // segments of the contraction's partial sums (sph.hip)
+#endif
+
+__host__ __device__ __forceinline__ int sph_l_of_row(int row)
+{
+  int l = 0;
+  while ((l + 1) * (l + 1) <= row) l++;
+  return l;
+}
+
+// G[i][row] = sum_n E[i][l][n] c[row][n], ascending n, one fma per term (k_sph_project and k_sph_force_thin)
+template <class CP>
+__device__ __forceinline__ double sph_G_row(const double *__restrict__ e, CP c, int nmax)
+{
+  double s = 0.0;
+  for (int n = 0; n < nmax; n++) s = fma(e[n], c[n], s);
+  return s;
+}
+
+// one slot of T4 from G at the cell's two nodes and H = p0 G at the three nodes of the force stencil
+// (k_sph_project4 and k_sph_force_thin)
+__device__ __forceinline__ void sph_t4_entry(double sc, double g0, double g1, double h0, double h1, double h2,
+                                             double &t0, double &t1, double &t2, double &t3)
+{
+  t0 = sc * g0;
+  t1 = sc * (g1 - g0);
+  t2 = sc * (0.5 * (h2 - h0));
+  t3 = sc * ((h0 - 2.0 * h1) + h2);
+}
+
+#define SPH_THIN_TP_MAX 64      // particles per tile: the first wave of the block owns them
+
+template <int LMAX>
+__global__ void __launch_bounds__(256)
+k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
+                 const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
+                 const double *__restrict__ coef, const int *__restrict__ rowmap, const double *__restrict__ tscale,
+                 double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
+                 double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ, int assign, int tp, int tqs)
+{
+  extern __shared__ __attribute__((aligned(16))) double thin_lds[];
+  __shared__ int s_cell[SPH_THIN_TP_MAX];
+  const int ncoef = S.nrows * S.nmax;
+  const int lsn = (S.lmax + 1) * S.nmax;
+  double *s_coef = thin_lds;                                  // [nrows][nmax]
+  double *stage = thin_lds + ((ncoef + 1) & ~1);              // [tp][tqs]: the T4 rows of each particle's cell
+  double *s_E = stage + (size_t)tp * tqs;                     // [tp][3][lsn]: E at the three nodes of its force stencil
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  if (beg + (size_t)blockIdx.x * tp >= end) return;
+  for (int k = threadIdx.x; k < ncoef; k += 256) s_coef[k] = coef[k];
+  const int t = threadIdx.x;
+  for (size_t base = beg + (size_t)blockIdx.x * tp; base < end; base += (size_t)gridDim.x * tp) {
+    // ---- the prologue of k_sph_force_staged, one particle per lane of the first wave
+    const size_t i = base + t;
+    const bool valid = t < tp && i < end;
+    double xx = 1, yy = 0, zz = 0, px = 0, py = 0, pz = 0;
+    if (valid) {
+      px = X[i]; py = Y[i]; pz = Z[i];
+      xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz;
+    }
+    const double fac = xx * xx + yy * yy;
+    double g, y, R, iR;
+    sqrt_rsqrt(fac + zz * zz, g, y);
+    const double r = g + S.dsmall;
+    const double ir = rcp_refine(r, y);
+    const double costh = zz * ir;
+    sqrt_rsqrt(fac, R, iR);
+    const double iR2 = iR * iR;
+    const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
+    const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
+    const int idx = sph_cell(S, xi);
+    const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
+    const double dfac = -(r * r) * iR2;
+    const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
+    const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
+    const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
+    const int jdx = idx < 1 ? 1 : idx;
+    const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
+    const bool regular = valid && !special;
+    // the general evaluation's own radius and cell for the special lanes (sph_force_chunk<LMAX, 0>)
+    double rg = sqrt(fac + zz * zz) + S.dsmall;
+    const double r0 = rg;
+    bool ioff = false;
+    if (rg > S.rmax && !S.no_exterior) { ioff = true; rg = S.rmax; }
+    const double xig = sph_r_to_xi(S, rg / S.scale);
+    const int idg = sph_cell(S, xig);
+    if (t < SPH_THIN_TP_MAX) s_cell[t] = !valid ? -1 : regular ? idx : idg;
+    __syncthreads();
+    // ---- E[j-1 .. j+1][l][n] of every particle's stencil: one contiguous stretch of 3 lsn doubles each, copied with
+    // four loads in flight per thread (a dependent load per term of the sums below is what this kernel would
+    // otherwise consist of)
+    {
+      const int e3 = 3 * lsn, total = tp * e3;
+      for (int it0 = threadIdx.x; it0 < total; it0 += 4 * 256) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int it = it0 + u * 256;
+          v[u] = 0.0;
+          if (it < total) {
+            const int p = it / e3, cell = s_cell[p];
+            if (cell >= 0) v[u] = S.E[(size_t)((cell < 1 ? 1 : cell) - 1) * lsn + (it - p * e3)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (it0 + u * 256 < total) s_E[it0 + u * 256] = v[u];
+      }
+    }
+    __syncthreads();
+    // ---- the T4 rows of those cells, projected by the whole block: slot q of particle p
+    for (int it = threadIdx.x; it < tp * S.trows; it += 256) {
+      const int p = it / S.trows, q = it - p * S.trows;
+      const int cell = s_cell[p];
+      if (cell < 0) continue;
+      double *o = stage + (size_t)p * tqs + 4 * q;
+      const int row = rowmap[q];
+      if (row < 0) { o[0] = o[1] = o[2] = o[3] = 0.0; continue; }
+      const int l = sph_l_of_row(row);
+      const int j = cell < 1 ? 1 : cell;                   // force stencil j-1, j, j+1 (k_sph_project4)
+      const double *e = s_E + (size_t)p * 3 * lsn + l * S.nmax;
+      const double *c = s_coef + (size_t)row * S.nmax;
+      // (sph_G_row for the three nodes at once, six orders' LDS reads issued before their fmas: same terms, same order)
+      double ga = 0.0, gb = 0.0, gc = 0.0;
+      for (int n0 = 0; n0 < S.nmax; n0 += 6) {
+        double cv[6], ea[6], eb[6], ec[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const bool in = n0 + u < S.nmax;
+          cv[u] = in ? c[n0 + u] : 0.0;
+          ea[u] = in ? e[n0 + u] : 0.0;
+          eb[u] = in ? e[lsn + n0 + u] : 0.0;
+          ec[u] = in ? e[2 * lsn + n0 + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+          if (n0 + u < S.nmax) { ga = fma(ea[u], cv[u], ga); gb = fma(eb[u], cv[u], gb); gc = fma(ec[u], cv[u], gc); }
+      }
+      const double g0 = cell < 1 ? ga : gb, g1 = cell < 1 ? gb : gc;      // G[cell], G[cell + 1]
+      const double h0 = S.p0[j - 1] * ga, h1 = S.p0[j] * gb, h2 = S.p0[j + 1] * gc;
+      sph_t4_entry(tscale[q], g0, g1, h0, h1, h2, o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // ---- evaluation: the fast pass' arithmetic on the lane's own rows; polar axis / beyond rmax: the general one
+    if (t < tp) {
+      if (regular) {
+        const ForceOut o = sph_field_fast_ptr<LMAX>((ldsp)(stage + (size_t)t * tqs), costh, sinth, cphi, sphi, x2, pf);
+        sph_force_finish<true>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
+                               0.0, assign, nullptr, 0.0, 0.0, 1);
+      }
+      if (__any(valid && special)) {
+        const double costh_g = zz / r0;
+        double cphi_g, sphi_g;
+        phi_trig(xx, yy, cphi_g, sphi_g);
+        const double y1 = (S.xi[idg + 1] - xig) * S.inv_dxi;
+        const double y2 = (xig - S.xi[idg]) * S.inv_dxi;
+        const double P0g = y1 * S.p0[idg] + y2 * S.p0[idg + 1];
+        const int jdg = idg < 1 ? 1 : idg;
+        const double pfg = (xig - S.xi[jdg]) * S.inv_dxi;
+        const double ffacg = sph_d_xi_to_r(S, xig) * S.inv_dxi;
+        double xc = costh_g;
+        if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
+        const double dfacg = 1.0 / (xc * xc - 1.0);
+        const double rr = S.rmax / r0;
+        const double kappa0 = -P0g / (r0 * ffacg);
+        const double *t4 = stage + (size_t)t * tqs;
+        const ForceOut og = sph_field<LMAX>(S, costh_g, xc, cphi_g, sphi_g, t4, y2, pfg, ioff, rr, kappa0);
+        if (valid && special)
+          sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, fac, 1.0 / rg, 1.0 / fac, P0g, ffacg, dfacg, AX, AY,
+                                  AZ, POT, VX, VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Accumulation of a thin slot range [lev_off[lo], lev_off[hi + 1]) -- level-contiguous, in no cell order -- into
+// part[level - lo][seg][row][n] (seg = blockIdx.x mod CSEG; the buffer must be zero on entry and is consumed AND cleared
+// by k_sph_sum_parts / k_sph_sum_combine with clear = 1).  Window, inputs and the rescaled Legendre recurrence are those
+// of the dense kernel (sph_acc_input, sph_acc_group); tpa particles per tile.
+template <int LMAX>
+__global__ void __launch_bounds__(256)
+k_sph_acc_thin(SphDev S, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+               const double *__restrict__ M, const uint32_t *__restrict__ lev_off, int lo, int hi,
+               const double *__restrict__ wscale, double *__restrict__ part, unsigned long long *__restrict__ used_out,
+               int tpa)
+{
+  extern __shared__ __attribute__((aligned(16))) double thin_lds[];
+  __shared__ int s_idx[SPH_THIN_TP_MAX], s_lev[SPH_THIN_TP_MAX];
+  __shared__ double s_a1[SPH_THIN_TP_MAX], s_a2[SPH_THIN_TP_MAX];
+  const int nrows = S.nrows, lsn = (S.lmax + 1) * S.nmax, ncoef = nrows * S.nmax;
+  double *yv = thin_lds;                                      // [tpa][nrows]: Yh_row of each particle
+  double *pe = thin_lds + (((size_t)tpa * nrows + 1) & ~(size_t)1);   // [tpa][lsn]: a1 E[i] + a2 E[i+1]
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  const int seg = blockIdx.x % CSEG;
+  const int t = threadIdx.x;
+  const bool um = S.umass != 0.0;
+  for (size_t base = beg + (size_t)blockIdx.x * tpa; base < end; base += (size_t)gridDim.x * tpa) {
+    const int np = (int)((end - base) < (size_t)tpa ? (end - base) : (size_t)tpa);
+    if (t < tpa) {
+      const size_t i = base + t;
+      const bool valid = i < end;
+      double x = 0, y = 0, z = 0, m = 0;
+      if (valid) { x = X[i]; y = Y[i]; z = Z[i]; m = um ? S.umass : M[i]; }
+      const AccIn in = sph_acc_input<false>(S, (ldp) nullptr, x, y, z, m, valid);
+      int lv = lo;
+      while (lv < hi && i >= lev_off[lv + 1]) lv++;
+      s_idx[t] = in.idx; s_lev[t] = lv; s_a1[t] = in.a1; s_a2[t] = in.a2;
+      double *yr = yv + (size_t)t * nrows;
+      const bool on = in.idx >= 0;
+      double pmm = LC_E(0);
+      double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+      static_for<0, LMAX + 1>([&](auto mc) {
+        constexpr int m_ = decltype(mc)::value;
+        if constexpr (m_ == 1) {
+          pmm *= LC_E(1) * in.sinth;
+          cm = in.cphi; sm = in.sphi;
+        } else if constexpr (m_ > 1) {
+          pmm *= LC_E(m_) * in.sinth;
+          const double cn = 2.0 * in.cphi * cm - cm1;
+          const double sn = 2.0 * in.cphi * sm - sm1;
+          cm1 = cm; sm1 = sm;
+          cm = cn; sm = sn;
+        }
+        const bool m_on = on && (m_ == 0 || !S.M0_acc);
+        double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
+        static_for<m_, LMAX + 1>([&](auto lc_) {
+          constexpr int l = decltype(lc_)::value;
+          double plm;
+          if constexpr (l == m_) plm = pmm;
+          else if constexpr (l == m_ + 1) plm = LC_a(l, m_) * tprev;
+          else plm = fma(LC_a(l, m_), tprev, -pl2);
+          tprev = in.costh * plm;
+          pl2 = pl1;
+          pl1 = plm;
+          constexpr int row = row_of(l, m_, 0);
+          if constexpr (m_ == 0) yr[row] = m_on ? plm : 0.0;
+          else { yr[row] = m_on ? plm * cm : 0.0; yr[row + 1] = m_on ? plm * sm : 0.0; }
+        });
+      });
+    }
+    __syncthreads();
+    for (int it0 = threadIdx.x; it0 < np * lsn; it0 += 4 * 256) {         // (four pairs of loads in flight per thread)
+      double ea[4], eb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int it = it0 + u * 256;
+        ea[u] = eb[u] = 0.0;
+        if (it < np * lsn) {
+          const int p = it / lsn, idx = s_idx[p];
+          if (idx >= 0) { ea[u] = S.E[(size_t)idx * lsn + (it - p * lsn)]; eb[u] = S.E[(size_t)(idx + 1) * lsn + (it - p * lsn)]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int it = it0 + u * 256;
+        if (it < np * lsn) { const int p = it / lsn; pe[it] = fma(s_a2[p], eb[u], s_a1[p] * ea[u]); }
+      }
+    }
+    if (threadIdx.x == 0) {
+      unsigned long long u = 0;
+      for (int p = 0; p < np; p++) u += s_idx[p] >= 0 ? 1u : 0u;
+      if (u) atomicAdd(used_out, u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncoef; k += 256) {
+      const int row = k / S.nmax, n = k - row * S.nmax;
+      const int ln = sph_l_of_row(row) * S.nmax + n;
+      const double ws = wscale[row];
+      double acc = 0.0;
+      int cur = s_lev[0];
+      for (int p0 = 0; p0 < np; p0 += 8) {                 // (eight particles' LDS reads issued before their fmas)
+        double yy_[8], pp_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const bool in = p0 + u < np;
+          yy_[u] = in ? yv[(size_t)(p0 + u) * nrows + row] : 0.0;
+          pp_[u] = in ? pe[(size_t)(p0 + u) * lsn + ln] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (p0 + u < np) {
+            const int lv = s_lev[p0 + u];
+            if (lv != cur) {
+              if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)(cur - lo) * CSEG + seg) * ncoef + k, acc * ws);
+              acc = 0.0;
+              cur = lv;
+            }
+            acc = fma(yy_[u], pp_[u], acc);
+          }
+        }
+      }
+      if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)(cur - lo) * CSEG + seg) * ncoef + k, acc * ws);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- per-LMAX launchers (one translation unit per LMAX: sph_inst.hip -DSPH_L=k) -----------------
 
 struct SphAccArgs {
@@ -1784,6 +2097,32 @@ struct SphUpdArgs {
   int2 *keys = nullptr;
 };
 
+struct SphThinForceArgs {
+  SphDev S;
+  const double *X, *Y, *Z;
+  const uint32_t *lev_off;
+  int lo, hi;
+  const double *coef;       // the coefficient set evaluated (expcoef), [nrows][nmax]
+  const int *rowmap;
+  const double *tscale;
+  double *AX, *AY, *AZ, *POT, *VX, *VY, *VZ;
+  int assign;
+  size_t n;                 // population of the range (sizes the grid; the kernel strides over whatever is there)
+  hipStream_t stream;
+};
+struct SphThinAccArgs {
+  SphDev S;
+  const double *X, *Y, *Z, *M;
+  const uint32_t *lev_off;
+  int lo, hi;
+  const double *wscale;
+  double *part;
+  unsigned long long *used;
+  size_t n;
+  hipStream_t stream;
+};
+typedef void (*sph_thin_force_launcher)(const SphThinForceArgs &);
+typedef void (*sph_thin_acc_launcher)(const SphThinAccArgs &);
 typedef void (*sph_upd_launcher)(const SphUpdArgs &);
 typedef void (*sph_acc_launcher)(const SphAccArgs &);
 typedef void (*sph_force_launcher)(const SphForceArgs &);

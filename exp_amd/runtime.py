@@ -93,6 +93,11 @@ class Context:
         """Block multistep: levels with fewer particles than this are not cell-sorted (0: all are)."""
         check(self.lib.exp_amd_ctx_set_dense_min(self.h, int(nmin)), self.h)
 
+    def set_thin_max(self, nmax: int) -> None:
+        """Block multistep: active slot ranges of at most this many particles (all in sparse levels) are accumulated and
+        evaluated straight from the basis tables, without moments or a projected table (0: never)."""
+        check(self.lib.exp_amd_ctx_set_thin_max(self.h, int(nmax)), self.h)
+
     def set_mover_list_min(self, nmin: int) -> None:
         """Block multistep: from this many level changes in a sweep on, the coefficient differencing runs the list of
         movers through the accumulation kernels instead of per-particle atomics (0: always, < 0: never)."""

@@ -88,6 +88,17 @@ int  exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on);
  * break-even (about 3e6-5e6 / moments per particle: ~51000 for lmax 6, ~20000 for lmax 10, ~58000 for mmax 6);
  * 0: every level is cell-sorted.                                                                  */
 int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
+/* ... and what happens to a sub-step whose ACTIVE particles are few (the upper levels of a settled run: hundreds to
+ * thousands of particles, stepped 2^level times per master step): when every active level of a component is sparse
+ * and together they hold at most `nmax` particles, their coefficients are accumulated and the forces on them are
+ * evaluated straight from the basis tables, particle by particle -- the reference's own formulation
+ * (src/SphericalBasis.cc:429-599, :1476-1660; exputil/EmpCylSL.cc:4049-4146, :5256-5410) -- instead of through cell
+ * moments and a projected table whose fixed costs (contraction over every cell, projection of every table row) dwarf
+ * the particles' own work.  Any force evaluation on at most `nmax` target particles (a cross force on another
+ * component's thin active set included) takes the same route.  Same results up to the order of the sums.
+ * Default 4096 (EXP_AMD_THIN_MAX overrides; the direct kernels cost ~5 ns per particle and kernel against the table
+ * path's ~100 us of fixed costs per sub-step and component); 0: never.                                            */
+int  exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax);
 /* Second knob of the same loop: how the coefficient sets are differenced when particles change level
  * (multistep_update, src/SphericalBasis.cc:1156-1228, src/CylEXP.cc:159-188).  The slots of the movers of a
  * sweep are compacted into a list; below `nmin` movers each adds and subtracts its own contribution with

@@ -36,11 +36,13 @@ def one(t, rng):
     inter = rng.choice(["both", "one", "none"], p=[0.6, 0.2, 0.2]) if which == "both" else "none"
     dense_min, list_min = int(rng.choice([-1, 0, 50, 500])), int(rng.choice([0, 16, 2048]))
     nsteps = int(rng.integers(1, 4))
+    thin_max = int(rng.choice([0, 30, 400, 16384]))           # (drawn last: the earlier draws of a (seed, trial) stay what they were)
     sc = float(inp["scale"])
     prm = orc.params(**c4.sph_window(g, sc))
     nb = NBodyOracle(orc, ms, dtime, dyn)
     ctx.set_dense_min(dense_min)
     ctx.set_mover_list_min(list_min)
+    ctx.set_thin_max(thin_max)
     sim = Simulation(ctx, dtime, multistep=ms, dynfrac=dyn, shiftlevl=0)
     forces, comps, names, ids_o, ids_d = [], [], [], [], []
     if which in ("both", "halo"):
@@ -102,7 +104,7 @@ def one(t, rng):
                 break
         if status != "ok":
             break
-    print(f"{t:3d} ms {ms} dtime {dtime:.2e} n {nh}/{nd} {which} inter {inter} dense_min {dense_min} list_min {list_min} steps {nsteps}: "
+    print(f"{t:3d} ms {ms} dtime {dtime:.2e} n {nh}/{nd} {which} inter {inter} dense_min {dense_min} list_min {list_min} thin_max {thin_max} steps {nsteps}: "
           f"{status} {detail} [{switches} level changes, populated levels "
           f"{[int((np.bincount(st['level'], minlength=ms + 1) > 0).sum()) for st in nb.state]}]", flush=True)
     global total_switches
@@ -127,6 +129,7 @@ def main():
         tally[one(t, np.random.default_rng([seed0, t]))] += 1
     ctx.set_dense_min(-1)
     ctx.set_mover_list_min(2048)
+    ctx.set_thin_max(16384)
     print(f"{trials} trials: {tally}, {total_switches} level changes in all, {time.time() - t0:.0f} s")
     sys.exit(1 if tally["LEVELS"] or tally["STATE"] else 0)
 

@@ -66,15 +66,22 @@ def _compare(tag, forces, comps, want, multistep):
             assert np.abs(gl - cL[M]).max() <= 1e-10 * cmax, (tag, name, M, "L")
 
 
-@pytest.mark.parametrize("dense_min,list_min", [(-1, 2048), (0, 2048), (100, 2048), (0, 0), (100, 0), (-1, 16)])
-def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min):
-    """dense_min: the level population below which a level is kept unsorted (runtime.Context.
+@pytest.mark.parametrize("dense_min,list_min,thin_max", [
+    (-1, 2048, 16384), (0, 2048, 16384), (100, 2048, 16384), (0, 0, 16384), (100, 0, 0), (-1, 16, 0), (-1, 2048, 0),
+    (100, 2048, 40), (-1, 16, 300)])
+def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin_max):
+    """thin_max: the size of an active slot range up to which it is accumulated and evaluated straight from the basis
+    tables (runtime.Context.set_thin_max; 16384 = the default: with dense_min -1 EVERY sub-step of this small run takes
+    the direct kernels of both bases -- k_sph_acc_thin / k_sph_force_thin, k_cyl_acc_thin / k_cyl_force_thin -- for the
+    self forces and both cross forces; 0: never, the moment / projected-table path alone; 40 and 300: the two mixed, by
+    sub-step).  dense_min: the level population below which a level is kept unsorted (runtime.Context.
     set_dense_min): the default (-1) makes every level of this small run sparse, 0 makes all of them
     cell-sorted, 100 mixes the two paths.  list_min: the number of level changes in a sweep from which the
     differencing runs the list of movers through the accumulation kernels (set_mover_list_min; 2048 = the
     default: per-mover atomics throughout this small run, 0: always the accumulation kernels, 16: both)."""
     ctx.set_dense_min(dense_min)
     ctx.set_mover_list_min(list_min)
+    ctx.set_thin_max(thin_max)
     z = c4.load_golden()
     ms, dtime, dyn = c4.MULTISTEP, c4.DTIME, c4.DYN
     nb, _ = c4.oracle_run(oracle, z, nsteps=0)
@@ -106,6 +113,7 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min):
     assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
     ctx.set_dense_min(-1)
     ctx.set_mover_list_min(2048)
+    ctx.set_thin_max(16384)
 
 
 def test_config4_against_the_golden_file(ctx):
