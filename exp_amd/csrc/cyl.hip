@@ -22,7 +22,8 @@
 #include <type_traits>
 
 #define DSMALL 1.0e-16        // src/expand.H:130
-#define CYL_MAX_M 12
+#define CYL_MAX_M 12            // azimuthal orders with unrolled kernels; above: k_cyl_moments_gen / k_cyl_force_gen
+#define CYL_GEN_MAX_M 64        // ... up to this order
 
 typedef const __attribute__((address_space(4))) double *cdp;
 
@@ -1487,6 +1488,197 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
   }
 }
 
+// ---- any azimuthal order: run-time loops over m ------------------------------------------------------------------
+// The kernels above are instantiated for mmax <= CYL_MAX_M; the reference takes any `mmax` (src/Cylinder.cc:473,
+// exputil/EmpCylSL.cc:343-420).  Above CYL_MAX_M (and, for tests, at any order with EXP_AMD_CYL_GENERIC=1) every
+// per-particle pass goes through these two plain kernels -- one particle per lane, node moments by atomics, node rows by
+// gathers -- with the same cuts, windows and operations as k_cyl_mstep_update (differencing, plain accumulation) and
+// k_cyl_force.  The contraction and projection kernels never depended on the order.
+__global__ void __launch_bounds__(256)
+k_cyl_moments_gen(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                  const double *__restrict__ M, const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev,
+                  const uint32_t *__restrict__ lev_off, int first, int last, int mfirst, double *__restrict__ Wnd,
+                  int plain /* 1: every particle into Wnd[its level]; 2: ... into Wnd[wlevel] (single-level buffers) */,
+                  int wlevel, double *__restrict__ tail, const uint32_t *__restrict__ list)
+{
+  const int NT = C.ntrig;
+  size_t i = 0;
+  bool have = false;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (list) {
+    if (g < lev_off[1]) { i = list[g]; have = true; }
+  } else {
+    i = lev_off[first] + g;
+    have = i < lev_off[last + 1];
+  }
+  bool mover = false;
+  int from = 0, to = 0;
+  if (have) {
+    from = plain == 2 ? wlevel : lev[i];
+    to = plain ? from : newlev[i];
+    mover = plain || from != to;
+  }
+  if (!__any(mover)) return;
+  double xx = 1, yy = 0, zz = 0, mass = 0;
+  if (mover) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = C.umass != 0.0 ? C.umass : M[i]; }
+  const double r2 = xx * xx + yy * yy;
+  double r, ir;
+  sqrt_rsqrt(r2, r, ir);
+  if (plain) {
+    const bool incut = mover && (r2 + zz * zz) < C.rmax2;
+    double mu = incut ? cdet_round(mass, C.detCm) : 0.0, nu = incut ? 1.0 : 0.0;
+    for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
+    if ((threadIdx.x & 63) == 0 && nu > 0.0 && tail) {
+      double *tp = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+      unsafeAtomicAdd(tp + 0, mu); unsafeAtomicAdd(tp + 1, nu);
+    }
+    mover = incut;
+  }
+  if (sqrt(r2 + zz * zz) > C.rtab_abs) mover = false;
+  if (!__any(mover)) return;
+  double zc = zz;
+  if (zc > C.rtab_abs) zc = C.rtab_abs;
+  if (zc < -C.rtab_abs) zc = -C.rtab_abs;
+  int ix, iy;
+  double cw[4];
+  cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+  double cphi = 1.0, sphi = 0.0;
+  if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+  const double t0 = mover ? -4.0 * M_PI * mass : 0.0;
+  const int nyp = C.numy + 1;
+  const size_t nnode = (size_t)(C.numx + 1) * nyp;
+  if (!mover) return;
+  const bool sub = !plain && from >= mfirst;
+  double *wto = Wnd + ((size_t)to * nnode + (size_t)(ix * nyp + iy)) * NT;
+  double *wfr = Wnd + ((size_t)from * nnode + (size_t)(ix * nyp + iy)) * NT;
+  double cm = 1.0, sm = 0.0;
+  for (int m = 0; m <= C.mmax; m++) {
+    if (m > 0) {
+      const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi;
+      cm = cn; sm = sn;
+    }
+    if (C.EVEN_M && (m & 1)) continue;
+    const int jc = (m == 0) ? 0 : 2 * m - 1;
+    for (int k = 0; k < 4; k++) {
+      const size_t off = (size_t)(((k & 1) ? nyp : 0) + ((k & 2) ? 1 : 0)) * NT;
+      const double w = t0 * cw[k];
+      const double vc = cdet_round(w * cm, C.detC), vs = cdet_round(w * sm, C.detC);
+      unsafeAtomicAdd(wto + off + jc, vc);
+      if (sub) unsafeAtomicAdd(wfr + off + jc, -vc);
+      if (m > 0) {
+        unsafeAtomicAdd(wto + off + jc + 1, vs);
+        if (sub) unsafeAtomicAdd(wfr + off + jc + 1, -vs);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_cyl_force_gen(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi, const double *__restrict__ TF,
+                const double *__restrict__ cylmass_p, double *__restrict__ AX, double *__restrict__ AY,
+                double *__restrict__ AZ, double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
+                double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ key_out, double nk_dtk,
+                double nk_dtd, int store_v)
+{
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  const size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= end) return;
+  double xx, yy, zz;
+  cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
+  const double ratmin = 0.75, maxerf = 3.0;                         // src/Cylinder.cc:1357-1381
+  const double midpt = ratmin + 0.5 * (1.0 - ratmin);
+  const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
+  const double r2 = xx * xx + yy * yy;
+  double rp, irp, r3s, ir3s;
+  sqrt_rsqrt(r2, rp, irp);
+  sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
+  const double r = rp + DSMALL;
+  double cphi = 1.0, sphi = 0.0;
+  if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+  const double ratio = r3s * C.inv_rtab_abs;
+  double frac, cfrac;
+  if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
+  else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
+  else { cfrac = 0.0; frac = 1.0; }
+  const bool ongrid = ratio < 1.0 && !(r3s > C.rtab_abs);
+  int ix, iy;
+  double c00, c10, c01, c11;
+  cyl_weights(C, r, zz, ix, iy, c00, c10, c01, c11);
+  const int NF = 3 * C.ntrig, nyp = C.numy + 1;
+  CylOut o{0.0, 0.0, 0.0, 0.0};
+  if (ongrid) {
+    // cyl_field with a run-time m loop (exputil/EmpCylSL.cc:5318-5400)
+    const double *t00 = TF + ((size_t)ix * nyp + iy) * NF;
+    const double *t01 = t00 + NF, *t10 = t00 + (size_t)nyp * NF, *t11 = t10 + NF;
+    double cm = 1.0, sm = 0.0;
+    for (int m = 0; m <= C.mmax; m++) {
+      if (m > 0) {
+        const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi;
+        cm = cn; sm = sn;
+      }
+      if (C.EVEN_M && (m & 1)) continue;
+      const int q = (m == 0) ? 0 : 3 + 6 * (m - 1);
+      auto bl = [&](int k) { return c00 * t00[q + k] + c10 * t10[q + k] + c01 * t01[q + k] + c11 * t11[q + k]; };
+      const double Pc = bl(0), Rc = bl(1), Zc = bl(2);
+      if (m == 0) { o.p += Pc; o.fr += Rc; o.fz += Zc; }
+      else {
+        const double Ps = bl(3), Rs = bl(4), Zs = bl(5);
+        o.p += Pc * cm + Ps * sm;
+        o.fr += Rc * cm + Rs * sm;
+        o.fz += Zc * cm + Zs * sm;
+        o.fp += (Pc * sm - Ps * cm) * m;
+      }
+    }
+  }
+  double fx = 0.0, fy = 0.0, fz = 0.0, pa = 0.0;
+  if (ratio < 1.0) {
+    double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
+    if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
+    const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+    fx = (fr * xx * ir - fp * yy * ir2) * frac;                     // src/Cylinder.cc:1387-1390
+    fy = (fr * yy * ir + fp * xx * ir2) * frac;
+    fz = fzz * frac;
+    pa = p * frac;
+  }
+  if (ratio > ratmin) {                                             // monopole blend, src/Cylinder.cc:1398-1408
+    const double p = -(*cylmass_p) * ir3s;
+    const double fr = p * (ir3s * ir3s);
+    fx += xx * fr * cfrac;
+    fy += yy * fr * cfrac;
+    fz += zz * fr * cfrac;
+    pa += p * cfrac;
+  }
+  if (C.use_rot) {
+    const double a = fx, b = fy, c = fz;
+    fx = C.rot[0] * a + C.rot[3] * b + C.rot[6] * c;
+    fy = C.rot[1] * a + C.rot[4] * b + C.rot[7] * c;
+    fz = C.rot[2] * a + C.rot[5] * b + C.rot[8] * c;
+  }
+  if (C.ps.center | C.ps.axis) {
+    double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+    if (C.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+    pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
+    fx -= qx; fy -= qy; fz -= qz;
+  }
+  if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
+  AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
+  if (dt_kick != 0.0) {
+    const double vx = mul_then_add(VX[i], fx, dt_kick);
+    const double vy = mul_then_add(VY[i], fy, dt_kick);
+    const double vz = mul_then_add(VZ[i], fz, dt_kick);
+    if (store_v == 1) { VX[i] = vx; VY[i] = vy; VZ[i] = vz; }
+    if (key_out) {
+      const double wx = mul_then_add(vx, fx, nk_dtk);
+      const double wy = mul_then_add(vy, fy, nk_dtk);
+      const double wz = mul_then_add(vz, fz, nk_dtk);
+      if (store_v == 2) { VX[i] = wx; VY[i] = wy; VZ[i] = wz; }
+      CylKeyFn kf{C, 0u};
+      key_out[i] = kf(mul_then_add(X[i], wx, nk_dtd), mul_then_add(Y[i], wy, nk_dtd), mul_then_add(Z[i], wz, nk_dtd), 0);
+    }
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 
 struct CylForce : exp_amd_force {
@@ -1495,6 +1687,7 @@ struct CylForce : exp_amd_force {
   DevBuf<double> d_tab, d_Wn, d_TF;
   bool tab_twin = false;            // the three sine tables equal the three cosine tables bit for bit (m >= 1)
   DevBuf<double> d_cpart;           // stage-1 sums of the contraction: [level][CYL_CSEG][ncoef]
+  bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
   bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)
   DevBuf<double> d_tabT;            // node-major copy tabT[node][kind][m][n] for the thin path (made on first use)
   int tabT_nk = 0;                  // kinds it holds: 3 (sine tables == cosine tables) or 6
@@ -1584,7 +1777,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
                                   exp_amd_force **out)
 {
   if (!ctx || !cfg || !tab || !out) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_create: NULL argument");
-  if (cfg->mmax < 0 || cfg->mmax > CYL_MAX_M || cfg->nmax < 1 || cfg->numx < 1 || cfg->numy < 1 ||
+  if (cfg->mmax < 0 || cfg->mmax > CYL_GEN_MAX_M || cfg->nmax < 1 || cfg->numx < 1 || cfg->numy < 1 ||
       cfg->multistep < 0 || cfg->multistep > 16)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cyl_create: bad mmax/nmax/numx/numy/multistep");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1619,6 +1812,8 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
     for (int k = 0; k < 3 && f->tab_twin; k++)
       f->tab_twin = memcmp(tab + k * per_kind + skip, tab + (k + 3) * per_kind + skip, (per_kind - skip) * sizeof(double)) == 0;
   }
+  f->generic = M > CYL_MAX_M;
+  if (const char *eg = getenv("EXP_AMD_CYL_GENERIC")) if (atoi(eg) != 0) f->generic = true;
   HIP_TRY(ctx, hipMemset(f->d_mass.p, 0, 2 * sizeof(double)));
   HIP_TRY(ctx, hipMemset(f->d_tailpart.p, 0, 2 * CYL_TAILS * sizeof(double)));
   CylDev &C = f->dev;
@@ -1795,7 +1990,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   if (listed && c->mover_hint > 0) { int rc_ = expamd_comp_mover_list(c, first, ms, (size_t)c->mover_hint); if (rc_) return rc_; }
   if (listed && c->mover_hint == 0) {
     // nothing moved on this rank (it only takes part in the reduction)
-  } else if (listed && ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min) {
+  } else if (listed && ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min && !f->generic) {
     // many movers: through the accumulation kernel (CylAccList)
     ProfScope ps(ctx, "k_cyl_mstep_update");
     const size_t nm = (size_t)c->mover_hint;
@@ -1823,12 +2018,18 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     const unsigned spread = listed ? expamd_mover_spread((size_t)c->mover_hint) : 1u;
     const unsigned grid = cdiv(listed ? (size_t)c->mover_hint * spread : nr, 256);
     const uint32_t *lo_ = listed ? c->mover_cnt : c->lev_off.p, *li_ = listed ? c->mover_list.p : nullptr;
+    if (f->generic)
+      k_cyl_moments_gen<<<cdiv(listed ? (size_t)c->mover_hint : nr, 256), 256, 0, ctx->stream>>>(
+          C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p, lo_, first, ms, mfirst_mdrft,
+          f->d_Wnd.p, 0, 0, nullptr, li_);
+    else {
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,          \
       lo_, first, ms, mfirst_mdrft, f->d_Wnd.p, 0, nullptr, li_, spread)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+    }
   }
   // (expcoefN += differ in the summing kernel itself when this rank is alone: no all-reduce in between)
   const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;
@@ -1886,6 +2087,11 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
     const unsigned grid = cdiv(nrange, (size_t)CACC_WAVES * chunk);
     LevChunks LC;
     LC.lo = lo; LC.nlev = 1; LC.bstart[0] = 0; LC.bstart[1] = grid; LC.chunk[0] = (int)chunk;
+    if (f->generic)        // (one moment buffer, whatever the level: plain = 2)
+      k_cyl_moments_gen<<<cdiv(nrange, 256), 256, 0, ctx->stream>>>(
+          C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), nullptr, nullptr, c->lev_off.p, lo, hi, 0, f->d_Wn.p, 2, 0,
+          f->d_tailpart.p, nullptr);
+    else {
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
     cyl_acc_launch<MM, true>(grid, 1, ctx->stream,                                               \
@@ -1895,6 +2101,7 @@ int CylForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_ki
         C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, LC, f->d_Wn.p, f->d_tailpart.p, 0)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+    }
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
@@ -1995,7 +2202,13 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
         grid += cdiv(nl, (size_t)CACC_WAVES * chunk);
       }
       LC.bstart[LC.nlev] = grid;
-      if (grid) {
+      if (grid && f->generic) {
+        size_t np_ = 0;
+        for (int L = L0; L <= L1; L++) np_ += pop(L);
+        k_cyl_moments_gen<<<cdiv(np_, 256), 256, 0, ctx->stream>>>(
+            C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr, c->lev_off.p, L0, L1, 0, f->d_Wn.p, 1,
+            0, f->d_tailpart.p, nullptr);
+      } else if (grid) {
 #define CALL(MM)                                                                                 \
   if (C.detC != 0.0)                                                                             \
     cyl_acc_launch<MM, true>(grid, 1, ctx->stream,                                               \
@@ -2013,7 +2226,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
   // (k_cyl_acc_thin), no node moments and no pass over the nodes
-  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0;
+  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0 && !f->generic;
   if (thin) {
     if ((rc = ensure_tabT())) return rc;
     if (!f->cpart_clean) {
@@ -2031,12 +2244,18 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   } else if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate_sparse");
     const unsigned grid = cdiv(nrange, 256);
+    if (f->generic)
+      k_cyl_moments_gen<<<grid, 256, 0, ctx->stream>>>(
+          C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr, c->lev_off.p, dacc + 1, ms, 0, f->d_Wn.p,
+          1, 0, f->d_tailpart.p, nullptr);
+    else {
 #define CALL(MM)                                                                              \
   k_cyl_mstep_update<MM><<<grid, 256, 0, ctx->stream>>>(                                      \
       C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,              \
       c->lev_off.p, dacc + 1, ms, 0, f->d_Wn.p, 1, f->d_tailpart.p)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+    }
   }
   {
     ProfScope ps(ctx, "k_cyl_contract");
@@ -2086,7 +2305,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   bool thin = false;
   size_t nthin = 0;
   if (f->multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !ctx->deterministic &&
-      ctx->thin_max > 0) {
+      ctx->thin_max > 0 && !f->generic) {
     int rc_ = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin);
     if (rc_) return rc_;
     thin = (long long)nthin <= ctx->thin_max;
@@ -2132,6 +2351,12 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   {
     ProfScope ps(ctx, "k_cyl_force");
     const unsigned grid = cdiv(nr, 256);
+    if (f->generic)
+      k_cyl_force_gen<<<grid, 256, 0, ctx->stream>>>(
+          C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ),
+          t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ), dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk,
+          nk_dtd, sv);
+    else {
 #define CALL(MM)                                                                                  \
   k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
@@ -2140,6 +2365,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       sv)
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   t->acc_live = true;
@@ -2375,17 +2601,23 @@ k_cyl_cov_mean(CylDev C, const double *__restrict__ tab, const double *__restric
 }
 
 // MV[T][m][n][o] (re, im): one block per (m, T); the corner table values of a cell are staged in LDS
-#define CYL_COV_MAXN 32
+// blockIdx.z: a stretch of 1024 (n, o) pairs, four per thread (any nmax)
+#define CYL_COV_MAXN 512
 __global__ void __launch_bounds__(256)
 k_cyl_cov_mv(CylDev C, const double *__restrict__ tab, const double *__restrict__ Q,
              double *__restrict__ mv)
 {
   const int m = blockIdx.x, T = blockIdx.y, N = C.nmax;
-  __shared__ double tc[4][CYL_COV_MAXN], ts[4][CYL_COV_MAXN], qs[10];
+  extern __shared__ double cov_lds[];                                // tc[4][N] | ts[4][N]
+  __shared__ double qs[10];
+  double *tc_ = cov_lds, *ts_ = cov_lds + 4 * N;
+#define tc(k, n) tc_[(k) * N + (n)]
+#define ts(k, n) ts_[(k) * N + (n)]
   const int nyp = C.numy + 1;
   const size_t nnode = (size_t)(C.numx + 1) * nyp, ncell = (size_t)C.numx * C.numy;
   const int npair = N * N;
-  double are[4] = {0, 0, 0, 0}, aim[4] = {0, 0, 0, 0};               // N <= 32: <= 4 pairs per thread
+  const int p0 = blockIdx.z * 1024, p1 = min(npair, p0 + 1024);
+  double are[4] = {0, 0, 0, 0}, aim[4] = {0, 0, 0, 0};
   for (size_t cell = 0; cell < ncell; cell++) {
     const double *q = Q + ((size_t)T * ncell + cell) * 10;
     if (q[0] == 0.0 && q[4] == 0.0 && q[7] == 0.0 && q[9] == 0.0) continue;   // no mass in the cell
@@ -2397,32 +2629,34 @@ k_cyl_cov_mv(CylDev C, const double *__restrict__ tab, const double *__restrict_
       const size_t node = (size_t)(ix + (k & 1)) * nyp + iy + ((k & 2) ? 1 : 0);
       const double v = (cs && m == 0) ? 0.0
                        : tab[((((size_t)(cs ? 3 : 0)) * (C.mmax + 1) + m) * N + n) * nnode + node];
-      if (cs) ts[k][n] = v; else tc[k][n] = v;
+      if (cs) ts(k, n) = v; else tc(k, n) = v;
     }
     __syncthreads();
-    for (int j = 0, p = threadIdx.x; p < npair; p += 256, j++) {
+    for (int j = 0, p = p0 + threadIdx.x; p < p1; p += 256, j++) {
       const int n = p / N, o = p - n * N;
       double re = 0.0, im = 0.0;
       int qi = 0;
       for (int k = 0; k < 4; k++)
         for (int k2 = k; k2 < 4; k2++, qi++) {
           const double w = qs[qi];
-          re += w * (tc[k][n] * tc[k2][o] + ts[k][n] * ts[k2][o]);
-          im += w * (tc[k][n] * ts[k2][o] - ts[k][n] * tc[k2][o]);
+          re += w * (tc(k, n) * tc(k2, o) + ts(k, n) * ts(k2, o));
+          im += w * (tc(k, n) * ts(k2, o) - ts(k, n) * tc(k2, o));
           if (k2 != k) {                                             // the (k2, k) term of the double sum
-            re += w * (tc[k2][n] * tc[k][o] + ts[k2][n] * ts[k][o]);
-            im += w * (tc[k2][n] * ts[k][o] - ts[k2][n] * tc[k][o]);
+            re += w * (tc(k2, n) * tc(k, o) + ts(k2, n) * ts(k, o));
+            im += w * (tc(k2, n) * ts(k, o) - ts(k2, n) * tc(k, o));
           }
         }
       are[j] += re; aim[j] += im;
     }
   }
   const double norm2 = 16.0 * M_PI * M_PI;
-  for (int j = 0, p = threadIdx.x; p < npair; p += 256, j++) {
+  for (int j = 0, p = p0 + threadIdx.x; p < p1; p += 256, j++) {
     double *o = mv + ((((size_t)T * (C.mmax + 1) + m) * npair) + p) * 2;
     o[0] = norm2 * are[j];
     o[1] = norm2 * aim[j];
   }
+#undef tc
+#undef ts
 }
 
 static CylForce *as_cyl(exp_amd_force *fb) { return dynamic_cast<CylForce *>(fb); }
@@ -2514,7 +2748,8 @@ extern "C" int exp_amd_cyl_cov_get(exp_amd_force *fb, long long *counts, double 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const CylDev &C = f->dev;
   k_cyl_cov_mean<<<dim3(C.nmax, C.mmax + 1, f->cov_T), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->cov_U.p, f->cov_vc.p);
-  k_cyl_cov_mv<<<dim3(C.mmax + 1, f->cov_T), 256, 0, ctx->stream>>>(C, f->d_tab.p, f->cov_Q.p, f->cov_mv.p);
+  k_cyl_cov_mv<<<dim3(C.mmax + 1, f->cov_T, cdiv((size_t)C.nmax * C.nmax, 1024)), 256, 8 * (size_t)C.nmax * sizeof(double),
+                 ctx->stream>>>(C, f->d_tab.p, f->cov_Q.p, f->cov_mv.p);
   HIP_TRY(ctx, hipGetLastError());
   std::vector<unsigned long long> cnt(f->cov_T);
   if (counts) HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), f->cov_cnt.p, f->cov_cnt.bytes(), hipMemcpyDeviceToHost, ctx->stream));

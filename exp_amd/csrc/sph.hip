@@ -183,9 +183,9 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
 {
   if (!ctx || !cfg || !xi || !p0 || !ev || !ef || !out)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_create: NULL argument");
-  if (cfg->lmax < 0 || cfg->lmax > SPH_MAX_L)
+  if (cfg->lmax < 0 || cfg->lmax > SPH_GEN_MAX_L)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_create: lmax=%d outside [0,%d]", cfg->lmax,
-                       SPH_MAX_L);
+                       SPH_GEN_MAX_L);
   if (cfg->nmax < 1 || cfg->numr < 3 || cfg->cmap < 0 || cfg->cmap > 2 || cfg->multistep < 0 ||
       cfg->multistep > 16)
     return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_create: bad nmax/numr/cmap/multistep");
@@ -260,6 +260,20 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   A(f->d_lc.alloc(lcv.size()));
   A(f->d_ev.alloc((size_t)(L + 1) * nmax));
   A(f->d_litef.alloc((size_t)6 * (L + 1) * nmax));
+  // the rescaled recurrence as data, for the any-order kernels (sph_gen.hip): the same constexpr functions whose
+  // values the unrolled kernels fold into literals
+  std::vector<double> gen_ac((size_t)(L + 1) * (L + 1) * 2, 0.0), gen_e(L + 1, 0.0);
+  for (int m = 0; m <= L; m++) {
+    gen_e[m] = lc_E(m);
+    for (int l = m + 1; l <= L; l++) {
+      gen_ac[((size_t)l * (L + 1) + m) * 2] = lc_a(l, m);
+      gen_ac[((size_t)l * (L + 1) + m) * 2 + 1] = lc_c(l, m);
+    }
+  }
+  A(f->d_gen_ac.alloc(gen_ac.size()));
+  A(f->d_gen_e.alloc(gen_e.size()));
+  f->generic = L > SPH_MAX_L;
+  if (const char *eg = getenv("EXP_AMD_SPH_GENERIC")) if (atoi(eg) != 0) f->generic = true;
   A(f->d_rowmap.alloc(rowmap.size()));
   A(f->d_tscale.alloc(tscale.size()));
   A(f->d_wscale.alloc(wscale.size()));
@@ -290,6 +304,8 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
                 ef[((size_t)l * nmax + n) * numr + (edge ? numr - 3 + k : k)];
     HIP_TRY(ctx, hipMemcpy(f->d_litef.p, le.data(), le.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  HIP_TRY(ctx, hipMemcpy(f->d_gen_ac.p, gen_ac.data(), gen_ac.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(f->d_gen_e.p, gen_e.data(), gen_e.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
                          hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_tscale.p, tscale.data(), tscale.size() * sizeof(double),
@@ -314,6 +330,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
     if (xi[i] != cfg->xmin + t) S.xi_uniform = 0;
   }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
+  S.gen_ac = f->d_gen_ac.p; S.gen_e = f->d_gen_e.p;
   // the literal radial derivative (sph_dp_lit): more than four cells outside the first / last force stencil -- which
   // only the logarithmic map can reach (cmap 1 maps r -> 0 to within three cells of xmin; an unmapped grid is left alone)
   S.lit_ef = f->d_litef.p; S.lit_ev = f->d_ev.p; S.lit_coef = f->d_coef.p;
@@ -357,6 +374,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
 void SphForce::release()
 {
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release(); d_litef.release(); d_litlist.release();
+  d_gen_ac.release(); d_gen_e.release();
   d_rowmap.release();
   d_tscale.release();
   d_ev.release(); d_d0.release(); d_Gd.release();
@@ -425,11 +443,14 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
 DECL_L(0) DECL_L(1) DECL_L(2) DECL_L(3) DECL_L(4) DECL_L(5) DECL_L(6)
 DECL_L(7) DECL_L(8) DECL_L(9) DECL_L(10) DECL_L(11) DECL_L(12)
 #undef DECL_L
-static const sph_acc_launcher k_acc_launch[SPH_MAX_L + 1] = {
+void expamd_sph_acc_gen(const SphAccArgs &);          // any order (sph_gen.hip)
+void expamd_sph_upd_gen(const SphUpdArgs &);
+void expamd_sph_force_gen(const SphForceArgs &);
+static const sph_acc_launcher k_acc_launch_tab[SPH_MAX_L + 1] = {
     expamd_sph_acc_L0, expamd_sph_acc_L1, expamd_sph_acc_L2,  expamd_sph_acc_L3,  expamd_sph_acc_L4,
     expamd_sph_acc_L5, expamd_sph_acc_L6, expamd_sph_acc_L7,  expamd_sph_acc_L8,  expamd_sph_acc_L9,
     expamd_sph_acc_L10, expamd_sph_acc_L11, expamd_sph_acc_L12};
-static const sph_upd_launcher k_upd_launch[SPH_MAX_L + 1] = {
+static const sph_upd_launcher k_upd_launch_tab[SPH_MAX_L + 1] = {
     expamd_sph_upd_L0, expamd_sph_upd_L1, expamd_sph_upd_L2,  expamd_sph_upd_L3,  expamd_sph_upd_L4,
     expamd_sph_upd_L5, expamd_sph_upd_L6, expamd_sph_upd_L7,  expamd_sph_upd_L8,  expamd_sph_upd_L9,
     expamd_sph_upd_L10, expamd_sph_upd_L11, expamd_sph_upd_L12};
@@ -443,11 +464,25 @@ static const sph_thin_acc_launcher k_thin_acc_launch[SPH_MAX_L + 1] = {
     expamd_sph_thin_acc_L4, expamd_sph_thin_acc_L5, expamd_sph_thin_acc_L6,  expamd_sph_thin_acc_L7,
     expamd_sph_thin_acc_L8, expamd_sph_thin_acc_L9, expamd_sph_thin_acc_L10, expamd_sph_thin_acc_L11,
     expamd_sph_thin_acc_L12};
-static const sph_force_launcher k_force_launch[SPH_MAX_L + 1] = {
+static const sph_force_launcher k_force_launch_tab[SPH_MAX_L + 1] = {
     expamd_sph_force_L0, expamd_sph_force_L1, expamd_sph_force_L2,  expamd_sph_force_L3,
     expamd_sph_force_L4, expamd_sph_force_L5, expamd_sph_force_L6,  expamd_sph_force_L7,
     expamd_sph_force_L8, expamd_sph_force_L9, expamd_sph_force_L10, expamd_sph_force_L11,
     expamd_sph_force_L12};
+
+// the unrolled kernels of this order, or the any-order ones
+static void sph_launch_acc(const SphForce *f, const SphAccArgs &a)
+{
+  if (f->generic) expamd_sph_acc_gen(a); else k_acc_launch_tab[f->cfg.lmax](a);
+}
+static void sph_launch_upd(const SphForce *f, const SphUpdArgs &a)
+{
+  if (f->generic) expamd_sph_upd_gen(a); else k_upd_launch_tab[f->cfg.lmax](a);
+}
+static void sph_launch_force(const SphForce *f, const SphForceArgs &a)
+{
+  if (f->generic) expamd_sph_force_gen(a); else k_force_launch_tab[f->cfg.lmax](a);
+}
 
 // staging buffers of the per-particle atomic path (k_sph_mstep_update<L, true> + k_mstep_apply) for up to
 // ctx->stage_max particles; beyond that the launch keeps its own atomics
@@ -492,7 +527,7 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
     ProfScope ps(ctx, "k_sph_accumulate");
     SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi,
                  f->d_W.p, used_p, nrange, ctx->stream, f->multistep ? 1 : 0};
-    k_acc_launch[f->cfg.lmax](a);
+    sph_launch_acc(f, a);
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
@@ -604,7 +639,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       if (nr) {
         SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, L0, L1,
                      f->d_W.p, used_p, nr, ctx->stream, 1, counts + (L0 - lo), 1};
-        k_acc_launch[cfg.lmax](a);
+        sph_launch_acc(f, a);
       }
       L0 = L1 + 1;
     }
@@ -614,7 +649,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's partial sums
   // (k_sph_acc_thin), no moments and no contraction (the deterministic mode keeps the moment path: its rounding grid
   // is that of the moment terms)
-  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic;
+  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic && !f->generic;
   if (thin) {
     if (!f->part_clean) {
       HIP_TRY(ctx, hipMemsetAsync(f->d_part.p, 0, f->d_part.bytes(), ctx->stream));
@@ -631,7 +666,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, nullptr,
                  c->lev_off.p, dacc + 1, ms, 0, f->d_W.p, nrange, ctx->stream, 1, used_p};
     if ((rc = sph_stage(f, nrange, a))) return rc;
-    k_upd_launch[cfg.lmax](a);
+    sph_launch_upd(f, a);
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
@@ -683,7 +718,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   // straight from the coefficient set (k_sph_force_thin): the projected table is not needed and stays stale.
   bool thin = false;
   size_t nthin = 0;
-  if (f->cfg.multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !f->lit_on &&
+  if (f->cfg.multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !f->lit_on && !f->generic &&
       !ctx->deterministic && ctx->thin_max > 0) {
     if ((rc = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin))) return rc;
     thin = (long long)nthin <= ctx->thin_max;
@@ -772,7 +807,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       a.stage_rows = rows > 24 ? 24 : rows < 4 ? 4 : rows;
       if (const char *e = getenv("EXP_AMD_STAGE_ROWS")) a.stage_rows = atoi(e);
     }
-    k_force_launch[f->cfg.lmax](a);
+    sph_launch_force(f, a);
     if (!slow) f->work_flip ^= 1;
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -878,7 +913,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     ProfScope ps(ctx, "k_sph_accumulate");
     SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->half_off.p, h, h,
                  f->d_W.p, f->d_used.p, len[h], V, 0};
-    k_acc_launch[f->cfg.lmax](a);
+    sph_launch_acc(f, a);
   }
   {
     ProfScope ps(ctx, "k_sph_contract");
@@ -910,7 +945,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
                      c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,
                      f->d_work.p, f->d_work.p + SPH_WORK_STRIDE * f->work_cap + f->work_flip, 0, ctx, c->key.p, dt_kick, dt, 0,
                      f->d_work.p + SPH_WORK_STRIDE * f->work_cap + (1 - f->work_flip), ctx->deterministic ? 1 : 0};
-      k_force_launch[f->cfg.lmax](a);
+      sph_launch_force(f, a);
       f->work_flip ^= 1;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[h], V));
@@ -985,7 +1020,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     a.newlev = c->newlev.p;
     a.mfirst = mfirst_mdrft;
     a.nslices = c->mover_hint >= ctx->mover_slices_min ? ms + 2 : 2;
-    k_acc_launch[cfg.lmax](a);
+    sph_launch_acc(f, a);
   } else if (nr) {
     ProfScope ps(ctx, "k_sph_mstep_update");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
@@ -997,7 +1032,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
       int rc_ = sph_stage(f, (size_t)c->mover_hint, a);
       if (rc_) return rc_;
     }
-    k_upd_launch[cfg.lmax](a);
+    sph_launch_upd(f, a);
   }
   // moments -> coefficient differences, all levels in one launch
   k_sph_contract<<<dim3(CSEG, S.nrows, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,

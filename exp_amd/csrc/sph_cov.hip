@@ -109,8 +109,11 @@ k_cov_contract(SphDev S, const double *__restrict__ mom, double *__restrict__ me
   while ((l + 1) * (l + 2) / 2 <= lm) l++;
   const int ncell = S.numr - 1, stride = (L + 1) * nmax;
   const int npair = nmax * nmax;
-  // up to ceil(nmax^2/256) pairs and ceil(2 nmax/256) mean entries per thread (nmax <= 64)
-  double cacc[16], macc = 0.0;
+  // blockIdx.z: a stretch of 4096 (n, n2) pairs, sixteen per thread (any nmax: the reference takes what the YAML gives,
+  // expui/BiorthBasis.cc:342-378); the 2 nmax mean entries ride with the first stretch, up to four per thread
+  const int p0 = blockIdx.z * 4096, p1 = min(npair, p0 + 4096);
+  const bool do_mean = blockIdx.z == 0;
+  double cacc[16], macc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k < 16; k++) cacc[k] = 0.0;
   const double *w0 = mom + (((size_t)T * ncell) * ltot + lm) * COV_NMOM;
   for (int i = 0; i < ncell; i++) {
@@ -118,17 +121,20 @@ k_cov_contract(SphDev S, const double *__restrict__ mom, double *__restrict__ me
     const double a = w[4], b = w[5], c = w[6];
     if (a == 0.0 && b == 0.0 && c == 0.0 && w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) continue;
     const double *e0 = S.E + (size_t)i * stride + l * nmax, *e1 = e0 + stride;
-    if ((int)threadIdx.x < 2 * nmax) {
-      const int n = threadIdx.x >> 1, ri = threadIdx.x & 1;       // re / im
-      macc += w[ri] * e0[n] + w[2 + ri] * e1[n];
-    }
-    for (int k = 0, p = threadIdx.x; p < npair; p += 256, k++) {
+    if (do_mean)
+      for (int j = 0, t = threadIdx.x; t < 2 * nmax && j < 4; t += 256, j++) {
+        const int n = t >> 1, ri = t & 1;                           // re / im
+        macc[j] += w[ri] * e0[n] + w[2 + ri] * e1[n];
+      }
+    for (int k = 0, p = p0 + threadIdx.x; p < p1; p += 256, k++) {
       const int n = p / nmax, n2 = p - n * nmax;
       cacc[k] += a * e0[n] * e0[n2] + b * (e0[n] * e1[n2] + e1[n] * e0[n2]) + c * e1[n] * e1[n2];
     }
   }
-  if ((int)threadIdx.x < 2 * nmax) mean[((size_t)T * ltot + lm) * nmax * 2 + threadIdx.x] = macc;
-  for (int k = 0, p = threadIdx.x; p < npair; p += 256, k++)
+  if (do_mean)
+    for (int j = 0, t = threadIdx.x; t < 2 * nmax && j < 4; t += 256, j++)
+      mean[((size_t)T * ltot + lm) * nmax * 2 + t] = macc[j];
+  for (int k = 0, p = p0 + threadIdx.x; p < p1; p += 256, k++)
     covr[((size_t)T * ltot + lm) * npair + p] = cacc[k];
 }
 
@@ -157,7 +163,7 @@ extern "C" int exp_amd_sph_cov_enable(exp_amd_force *fb, int sampT)
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   expamd_sph_cov_release(f);
   if (sampT <= 0) return EXP_AMD_OK;
-  if (f->cfg.nmax > 64) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cov_enable: nmax > 64 not supported");
+  if (f->cfg.nmax > 512) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "cov_enable: nmax > 512 not supported");
   SphCov *c = new SphCov;
   f->cov = c;
   c->sampT = sampT;
@@ -249,7 +255,8 @@ extern "C" int exp_amd_sph_cov_get(exp_amd_force *fb, long long *counts, double 
   exp_amd_ctx *ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int L = f->cfg.lmax, ltot = (L + 1) * (L + 2) / 2;
-  k_cov_contract<<<dim3(ltot, c->sampT), 256, 0, ctx->stream>>>(f->dev, c->mom.p, c->mean.p, c->covr.p);
+  k_cov_contract<<<dim3(ltot, c->sampT, cdiv((size_t)f->cfg.nmax * f->cfg.nmax, 4096)), 256, 0, ctx->stream>>>(
+      f->dev, c->mom.p, c->mean.p, c->covr.p);
   HIP_TRY(ctx, hipGetLastError());
   std::vector<unsigned long long> cnt(c->sampT);
   if (counts) HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), c->counts.p, c->counts.bytes(), hipMemcpyDeviceToHost, ctx->stream));

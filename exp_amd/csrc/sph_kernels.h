@@ -31,7 +31,8 @@
 
 typedef const __attribute__((address_space(4))) double *cdp;   // constant (scalar-loadable)
 
-#define SPH_MAX_L 12
+#define SPH_MAX_L 12            // orders with unrolled kernels (sph_inst.hip); above: the run-time loops of sph_gen.hip
+#define SPH_GEN_MAX_L 64        // ... up to this order
 
 struct SphDev {
   int lmax, nmax, numr, cmap, nrows;
@@ -55,6 +56,8 @@ struct SphDev {
   const double *p0;      // [numr]
   const double *E;       // [numr][lmax+1][nmax]
   const double *lc;      // [(lmax+1)*(lmax+1)][4] normalised-Legendre recurrence constants (below)
+  const double *gen_ac;  // [(lmax+1)*(lmax+1)][2]: a(l,m), c(l,m) of the RESCALED recurrence (lc_a, lc_c) as run-time
+  const double *gen_e;   // [lmax+1]: e_m (lc_E) -- data for the any-order kernels of sph_gen.hip
   // Far extrapolation beyond the table (possible with the logarithmic map only: hundreds of cells inside rmin, or outside
   // rmax in the pyEXP mode): the three-term radial derivative is then a small difference of large numbers and only the
   // reference's own operation order reproduces its value (sph_dp_lit below).  lit_lo / lit_hi: the force offset pf

@@ -14,8 +14,39 @@ import numpy as np
 
 
 def shard_range(ntot: int, rank: int, world: int) -> Tuple[int, int]:
-    """Static block partition [n0, n1) of ntot particles (every rank within one of equal)."""
+    """Static BLOCK partition [n0, n1) of ntot particles (every rank within one of equal).
+
+    Balanced in particle count only: on an input ordered by radius or binding energy (what the reference's `gensph`
+    writes) the blocks are radial shells, and under block multistep the deep time-step levels all land on the rank
+    that holds the centre.  Use it for single-level runs and for inputs in random order; `shard_indices` /
+    `shard_by_level` below are what a multistep run wants (each GPU owns ~N/world of EVERY level).
+    """
     return ntot * rank // world, ntot * (rank + 1) // world
+
+
+def shard_indices(ntot: int, rank: int, world: int) -> np.ndarray:
+    """STRIDED partition: rank r owns the particles r, r + world, r + 2 world, ... (every rank within one of equal).
+
+    Whatever varies smoothly along the input order -- radius, energy, hence the time-step level a particle will be
+    given -- is dealt evenly to all ranks, so every rank holds ~1/world of every level and the sub-steps of a block-
+    multistep run cost every GPU the same; the reference reaches the same end with its rate-weighted `load_balance`
+    (src/Component.cc:3780, :3868).  The caller index of a rank's k-th particle is rank + k * world (downloads come back
+    in that order)."""
+    return np.arange(rank, ntot, world, dtype=np.int64)
+
+
+def shard_by_level(levels, rank: int, world: int) -> np.ndarray:
+    """EXACT level balance for a known level assignment (e.g. the one `begin_run` produced, or a restart file's): within
+    each level, in input order, the k-th particle goes to rank k mod world (rotated per level so that the remainders
+    do not pile up on rank 0).  Every rank's population of every level is within one of N_level / world.  Returns the
+    sorted caller indices owned by `rank`."""
+    lev = np.asarray(levels)
+    order = np.argsort(lev, kind="stable")                     # level-major, input order within a level
+    counts = np.bincount(lev.astype(np.int64)) if len(lev) else np.zeros(0, dtype=np.int64)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else np.zeros(0, dtype=np.int64)
+    k = np.arange(len(lev)) - np.repeat(start, counts)         # position of each sorted entry within its level
+    owner = (k + np.repeat(np.arange(len(counts)), counts)) % world
+    return np.sort(order[owner == rank])
 
 
 class _DevPtr:

@@ -68,6 +68,23 @@ def main():
     d2 = c.download(("pos", "vel", "acc"))
     lev = c.download_levels()
     np.savez(out.replace(".npz", "_ms.npz"), coef=f.get_coefs(), lev=lev, **d2)
+    sim.close(); c.close(); f.close()
+    # the same run on a RADIUS-ORDERED input (what the reference's gensph writes) with the level-balanced strided
+    # partition (exp_amd.dist.shard_indices): every rank must hold ~1/world of every time-step level
+    from exp_amd.dist import shard_indices
+    order = np.argsort(np.linalg.norm(pos, axis=1), kind="stable")
+    mr, pr, vr = m[order], pos[order], vel[order]
+    idx = shard_indices(n, rank, world)
+    ms, dtime = 3, 0.04
+    f = SphereSL(ctx, g, multistep=ms)
+    c = Component.from_arrays(ctx, mr[idx], pr[idx], vr[idx])
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=[1000.0, 0.01, 0.01, 0.03, 0.05], shiftlevl=0)
+    sim.add_component(c, f)
+    sim.init()
+    lev0 = c.download_levels()
+    sim.step(1)
+    d3 = c.download(("pos", "vel"))
+    np.savez(out.replace(".npz", "_bal.npz"), idx=idx, lev0=lev0, lev=c.download_levels(), coef=f.get_coefs(), **d3)
     sim.close(); c.close(); f.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -46,6 +46,32 @@ def test_shard_ranges_cover():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_level_balanced_shards():
+    """shard_indices / shard_by_level: disjoint, covering, and every rank within one of N_level / world in every level."""
+    from exp_amd.dist import shard_by_level, shard_indices
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 10, 1001):
+        for w in (1, 2, 3, 8):
+            parts = [shard_indices(n, r, w) for r in range(w)]
+            allidx = np.sort(np.concatenate(parts)) if n else np.zeros(0, dtype=np.int64)
+            assert np.array_equal(allidx, np.arange(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+    # radius-ordered levels (deep levels first): the block partition is badly skewed, the two others are not
+    n, w = 20000, 8
+    lev = np.sort(rng.choice(5, size=n, p=[0.02, 0.05, 0.13, 0.3, 0.5]))[::-1].copy()      # level 4 ... 0 along the input
+    full = np.bincount(lev, minlength=5)
+    parts = [shard_by_level(lev, r, w) for r in range(w)]
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(n))
+    for r in range(w):
+        mine = np.bincount(lev[parts[r]], minlength=5)
+        assert np.all(np.abs(mine - full / w) < 1.0 + 1e-9), (r, mine, full)
+        strided = np.bincount(lev[shard_indices(n, r, w)], minlength=5)
+        assert np.all(np.abs(strided - full / w) <= 1.0 + 1e-9)
+    from exp_amd.dist import shard_range
+    n0, n1 = shard_range(n, 0, w)
+    assert np.bincount(lev[n0:n1], minlength=5)[4] == n1 - n0 > 2 * full[4] / w          # (the control)
+    assert len(shard_by_level(np.zeros(0, dtype=np.int32), 0, 2)) == 0
+
+
 def test_two_rank_gloo_allreduce_matches_single_rank():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

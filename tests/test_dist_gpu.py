@@ -25,13 +25,14 @@ def _run(world, tmp_path, port):
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
-    return [np.load(o) for o in outs], [np.load(o.replace(".npz", "_ms.npz")) for o in outs]
+    return ([np.load(o) for o in outs], [np.load(o.replace(".npz", "_ms.npz")) for o in outs],
+            [np.load(o.replace(".npz", "_bal.npz")) for o in outs])
 
 
 def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
     port = 29500 + (os.getpid() % 400)
-    (one,), (one_ms,) = _run(1, tmp_path, port)
-    two, two_ms = _run(2, tmp_path, port)
+    (one,), (one_ms,), (one_bal,) = _run(1, tmp_path, port)
+    two, two_ms, two_bal = _run(2, tmp_path, port)
     assert two[0]["n0"] == 0 and two[0]["n1"] == two[1]["n0"] and two[1]["n1"] == one["n1"]
     scale = np.abs(one["coef0"]).max()
     for r in two:
@@ -58,3 +59,28 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
     for k in ("pos", "vel"):
         both = np.concatenate([two_ms[0][k], two_ms[1][k]])
         assert np.abs(both - one_ms[k])[same].max() <= 1e-8 * np.abs(one_ms[k]).max(), k
+
+    # ---- level-balanced partition (each GPU owns ~N/world of EVERY level; the reference gets there
+    # with load_balance, src/Component.cc:3780, :3868): radius-ordered input, strided shards
+    ms = 3
+    full = np.bincount(one_bal["lev0"], minlength=ms + 1)
+    assert (full >= 400).sum() >= 3, full                                # the run populates several levels
+    for r in two_bal:
+        mine = np.bincount(r["lev0"], minlength=ms + 1)
+        for L in range(ms + 1):
+            if full[L] >= 400:
+                assert abs(mine[L] - full[L] / 2) <= 0.05 * full[L] / 2, (L, mine, full)
+    # (control: the BLOCK partition of the same input puts the deep levels on the rank that holds the centre)
+    half = len(one_bal["lev0"]) // 2
+    blk = np.bincount(one_bal["lev0"][:half], minlength=ms + 1)
+    deep = max(L for L in range(ms + 1) if full[L] >= 400)
+    assert blk[deep] > 0.65 * full[deep]                              # (measured 0.76; balanced would be 0.50)
+    # ... and the sharded run is the single-rank run: levels after begin_run and one master step, trajectories
+    lev0 = np.empty_like(one_bal["lev0"]); lev1 = np.empty_like(one_bal["lev"])
+    posb = np.empty_like(one_bal["pos"])
+    for r in two_bal:
+        lev0[r["idx"]] = r["lev0"]; lev1[r["idx"]] = r["lev"]; posb[r["idx"]] = r["pos"]
+        assert np.abs(r["coef"] - one_bal["coef"]).max() <= 1e-8 * np.abs(one_bal["coef"]).max()
+    assert (lev0 != one_bal["lev0"]).mean() < 1e-3 and (lev1 != one_bal["lev"]).mean() < 2e-3
+    same = (lev0 == one_bal["lev0"]) & (lev1 == one_bal["lev"])
+    assert np.abs(posb - one_bal["pos"])[same].max() <= 1e-8 * np.abs(one_bal["pos"]).max()
