@@ -1488,6 +1488,234 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
   }
 }
 
+// ---- thin active sets, second formulation (round 4; any azimuthal order) ----------------------------------------------
+// k_cyl_force_wave: one WAVE per particle.  The lanes own the items (corner k, kind, m) of accumulated_eval's sums: each
+// forms its node-row entries sum_n tab[kind][m][n][node_k] {cos, sin}[m][n] (the sums of k_cyl_project, from the node-major
+// table copy), weights them with its corner weight and cos / sin(m phi), and the four field sums are reduced over the
+// wave; lane 0 applies Cylinder's taper / monopole blend (the tail of k_cyl_force).  No LDS, no barrier.
+__global__ void __launch_bounds__(256)
+k_cyl_force_wave(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                 const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi, const double *__restrict__ tabT, int nk,
+                 const double *__restrict__ coef, const double *__restrict__ cylmass_p, double *__restrict__ AX,
+                 double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT, double *__restrict__ VX,
+                 double *__restrict__ VY, double *__restrict__ VZ, int assign)
+{
+  const int lane = threadIdx.x & 63;
+  const int M1 = C.mmax + 1, half = M1 * C.nmax, nyp = C.numy + 1;
+  const size_t per_node = (size_t)nk * half;
+  const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+  for (size_t i = beg + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < end; i += (size_t)gridDim.x * 4) {
+    double xx, yy, zz;
+    cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
+    const double ratmin = 0.75, maxerf = 3.0;                       // src/Cylinder.cc:1357-1381
+    const double midpt = ratmin + 0.5 * (1.0 - ratmin);
+    const double rsmth = 0.5 * (1.0 - ratmin) / maxerf;
+    const double r2 = xx * xx + yy * yy;
+    double rp, irp, r3s, ir3s;
+    sqrt_rsqrt(r2, rp, irp);
+    sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
+    const double r = rp + DSMALL;
+    double cphi = 1.0, sphi = 0.0;
+    if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+    const double ratio = r3s * C.inv_rtab_abs;
+    const bool ongrid = ratio < 1.0 && !(r3s > C.rtab_abs);
+    double op = 0.0, ofr = 0.0, ofz = 0.0, ofp = 0.0;
+    if (ongrid) {                                                   // (wave-uniform)
+      int ix, iy;
+      double cw[4];
+      cyl_weights(C, r, zz, ix, iy, cw[0], cw[2], cw[1], cw[3]);    // (c00, c10, c01, c11) -> k = 0: 00, 1: 01, 2: 10, 3: 11
+      const size_t node0 = (size_t)ix * nyp + iy;
+      for (int it = lane; it < 12 * M1; it += 64) {
+        const int k = it / (3 * M1), rest = it - k * 3 * M1;
+        const int kind = rest / M1, m = rest - kind * M1;
+        if (C.EVEN_M && (m & 1)) continue;
+        const size_t node = node0 + ((k & 2) ? nyp : 0) + (k & 1);
+        const double *T = tabT + node * per_node + ((size_t)kind * M1 + m) * C.nmax;
+        const double *cc = coef + (size_t)m * C.nmax, *cs = cc + half;
+        double a, b = 0.0;
+        if (m == 0) a = cyl_chain4(T, cc, C.nmax);
+        else if (nk == 3) cyl_chain4_pair(T, cc, cs, C.nmax, a, b);
+        else { a = cyl_chain4(T, cc, C.nmax); b = cyl_chain4(T + (size_t)3 * half, cs, C.nmax); }
+        double cm = 1.0, sm = 0.0;
+        for (int q = 0; q < m; q++) { const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi; cm = cn; sm = sn; }
+        const double w = k == 0 ? cw[0] : k == 1 ? cw[1] : k == 2 ? cw[2] : cw[3];
+        const double v = w * (a * cm + b * sm);
+        if (kind == 0) { op += v; ofp += w * (a * sm - b * cm) * m; }
+        else if (kind == 1) ofr += v;
+        else ofz += v;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        op += __shfl_xor(op, off); ofr += __shfl_xor(ofr, off);
+        ofz += __shfl_xor(ofz, off); ofp += __shfl_xor(ofp, off);
+      }
+    }
+    if (lane != 0) continue;
+    double frac, cfrac;
+    if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
+    else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
+    else { cfrac = 0.0; frac = 1.0; }
+    double fx = 0.0, fy = 0.0, fz = 0.0, pa = 0.0;
+    if (ratio < 1.0) {
+      const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+      fx = (ofr * xx * ir - ofp * yy * ir2) * frac;                 // src/Cylinder.cc:1387-1390
+      fy = (ofr * yy * ir + ofp * xx * ir2) * frac;
+      fz = ofz * frac;
+      pa = op * frac;
+    }
+    if (ratio > ratmin) {                                           // monopole blend, src/Cylinder.cc:1398-1408
+      const double p = -(*cylmass_p) * ir3s;
+      const double fr = p * (ir3s * ir3s);
+      fx += xx * fr * cfrac; fy += yy * fr * cfrac; fz += zz * fr * cfrac;
+      pa += p * cfrac;
+    }
+    if (C.use_rot) {
+      const double a = fx, b = fy, c = fz;
+      fx = C.rot[0] * a + C.rot[3] * b + C.rot[6] * c;
+      fy = C.rot[1] * a + C.rot[4] * b + C.rot[7] * c;
+      fz = C.rot[2] * a + C.rot[5] * b + C.rot[8] * c;
+    }
+    if (C.ps.center | C.ps.axis) {
+      double qx, qy, qz, ux = 0.0, uy = 0.0, uz = 0.0;
+      if (C.ps.axis) { ux = VX[i]; uy = VY[i]; uz = VZ[i]; }
+      pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
+      fx -= qx; fy -= qy; fz -= qz;
+    }
+    if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
+    AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
+  }
+}
+
+// k_cyl_acc_tile: tiles of up to 64 particles.  Lane t of the first wave prepares particle t (cuts, window, corner weights,
+// -4 pi m cos / sin(m phi): k_cyl_mstep_update with plain = 1); the block blends the potential tables at the four
+// corners, pe[p][set][m][n], with coalesced reads of the node-major copy; each thread owns coefficients (cs, m, n) and
+// sums over the tile's runs of equal level, one atomic per run into part[level - lo][seg][ncoef].
+#define CYL_TILE_MAX 64
+__global__ void __launch_bounds__(256)
+k_cyl_acc_tile(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+               const double *__restrict__ M, const uint32_t *__restrict__ lev_off, int lo, int hi,
+               const double *__restrict__ tabT, int nk, double *__restrict__ part, double *__restrict__ tail, int tile)
+{
+  extern __shared__ __attribute__((aligned(16))) double ctile_lds[];
+  __shared__ int s_node[CYL_TILE_MAX], s_run_beg[20], s_run_lev[20], s_nrun;
+  __shared__ double s_cw[CYL_TILE_MAX][4];
+  const int NT = C.ntrig, tst = NT | 1;
+  const int M1 = C.mmax + 1, half = M1 * C.nmax, ncoef = 2 * half, nyp = C.numy + 1;
+  const int nset = nk == 3 ? 1 : 2;
+  double *trig = ctile_lds;                                         // [tile][tst]: -4 pi m {1, cos phi, sin phi, cos 2 phi, ...}
+  double *pe = ctile_lds + (((size_t)tile * tst + 1) & ~(size_t)1);         // [tile][nset][half]
+  const size_t per_node = (size_t)nk * half;
+  const size_t beg = lev_off[lo], end = lev_off[hi + 1];
+  const int seg = blockIdx.x % CYL_CSEG;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (size_t base = beg + (size_t)blockIdx.x * tile; base < end; base += (size_t)gridDim.x * tile) {
+    const int np = (int)((end - base) < (size_t)tile ? (end - base) : (size_t)tile);
+    if (wave == 0) {
+      const size_t i = base + lane;
+      const bool valid = lane < np;
+      double xx = 1, yy = 0, zz = 0, mass = 0;
+      if (valid) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = C.umass != 0.0 ? C.umass : M[i]; }
+      const double r2 = xx * xx + yy * yy;
+      double r, ir;
+      sqrt_rsqrt(r2, r, ir);
+      const bool incut = valid && (r2 + zz * zz) < C.rmax2;
+      double mu = incut ? mass : 0.0, nu = incut ? 1.0 : 0.0;
+      for (int off = 32; off > 0; off >>= 1) { mu += __shfl_xor(mu, off); nu += __shfl_xor(nu, off); }
+      if (lane == 0 && nu > 0.0) {
+        double *tp_ = tail + 2 * (blockIdx.x & (CYL_TAILS - 1));
+        unsafeAtomicAdd(tp_ + 0, mu); unsafeAtomicAdd(tp_ + 1, nu);
+      }
+      const bool on = incut && !(sqrt(r2 + zz * zz) > C.rtab_abs);
+      double zc = zz;
+      if (zc > C.rtab_abs) zc = C.rtab_abs;
+      if (zc < -C.rtab_abs) zc = -C.rtab_abs;
+      int ix, iy;
+      double cw[4];
+      cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+      double cphi = 1.0, sphi = 0.0;
+      if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      const double t0 = on ? -4.0 * M_PI * mass : 0.0;
+      int lv = lo;
+      while (lv < hi && i >= lev_off[lv + 1]) lv++;
+      if (!valid) lv = -1;
+      const int prev = __shfl_up(lv, 1);
+      const bool start = valid && (lane == 0 || lv != prev);
+      const unsigned long long starts = __ballot(start);
+      if (start) {
+        const int rr_ = __popcll(starts & ((1ull << lane) - 1ull));
+        if (rr_ < 20) { s_run_beg[rr_] = lane; s_run_lev[rr_] = lv; }
+      }
+      if (lane == 0) s_nrun = min(20, (int)__popcll(starts));
+      if (lane < tile) {
+        s_node[lane] = on ? ix * nyp + iy : -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_cw[lane][k] = cw[k];
+        double *tr = trig + (size_t)lane * tst;
+        double cm = 1.0, sm = 0.0;
+        tr[0] = t0;
+        for (int m = 1; m <= C.mmax; m++) {
+          const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi;
+          cm = cn; sm = sn;
+          const bool m_on = !(C.EVEN_M && (m & 1));
+          tr[2 * m - 1] = m_on ? t0 * cm : 0.0;
+          tr[2 * m] = m_on ? t0 * sm : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    // pe: wave w takes particles w, w + 4, ...; two at a time: eight table loads per lane in flight
+    for (int p0 = wave * 2; p0 < np; p0 += 8) {
+      for (int e0 = lane; e0 < nset * half; e0 += 64) {
+        const int set = e0 / half, mn = e0 - set * half;
+        double tv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int p = p0 + u;
+          tv[u][0] = tv[u][1] = tv[u][2] = tv[u][3] = 0.0;
+          if (p < np) {
+            const int node0 = s_node[p];
+            if (node0 >= 0) {
+              const double *T = tabT + (size_t)node0 * per_node + (size_t)(set ? 3 : 0) * half + mn;
+              tv[u][0] = T[0]; tv[u][1] = T[(size_t)nyp * per_node]; tv[u][2] = T[per_node]; tv[u][3] = T[(size_t)(nyp + 1) * per_node];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int p = p0 + u;
+          if (p < np)
+            pe[((size_t)p * nset + set) * half + mn] =
+                s_cw[p][0] * tv[u][0] + s_cw[p][1] * tv[u][1] + s_cw[p][2] * tv[u][2] + s_cw[p][3] * tv[u][3];
+        }
+      }
+    }
+    __syncthreads();
+    const int nrun = s_nrun;
+    for (int o = t; o < ncoef; o += 256) {
+      const int cs = o / half, mn = o - cs * half, m = mn / C.nmax;
+      if (cs && m == 0) continue;                                  // (sin, m = 0): no such row
+      const int jt = m == 0 ? 0 : 2 * m - 1 + cs;
+      const int set = (cs && nset == 2) ? 1 : 0;
+      for (int r = 0; r < nrun; r++) {
+        const int pb = s_run_beg[r], pe_ = r + 1 < nrun ? s_run_beg[r + 1] : np;
+        double acc = 0.0;
+        for (int p0 = pb; p0 < pe_; p0 += 8) {
+          double tt_[8], pp_[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const bool in = p0 + u < pe_;
+            tt_[u] = in ? trig[(size_t)(p0 + u) * tst + jt] : 0.0;
+            pp_[u] = in ? pe[((size_t)(p0 + u) * nset + set) * half + mn] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc = fma(tt_[u], pp_[u], acc);
+        }
+        if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)(s_run_lev[r] - lo) * CYL_CSEG + seg) * ncoef + o, acc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- any azimuthal order: run-time loops over m ------------------------------------------------------------------
 // The kernels above are instantiated for mmax <= CYL_MAX_M; the reference takes any `mmax` (src/Cylinder.cc:473,
 // exputil/EmpCylSL.cc:343-420).  Above CYL_MAX_M (and, for tests, at any order with EXP_AMD_CYL_GENERIC=1) every
@@ -1899,6 +2127,46 @@ static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const
                                                                                                  nk, part, tail, tpa);
 }
 
+static int cyl_thin_version()
+{
+  static const int v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+// second formulation of the thin kernels (any order): one wave per particle / 64-particle tiles
+static void cyl_wave_force_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
+                                  const uint32_t *lev_off, int lo, int hi, const double *tabT, int nk, const double *coef,
+                                  const double *mass, double *AX, double *AY, double *AZ, double *POT, double *VX, double *VY,
+                                  double *VZ, int assign)
+{
+  size_t grid = cdiv(n, 4);
+  if (grid > 16384) grid = 16384;
+  if (grid == 0) return;
+  k_cyl_force_wave<<<(unsigned)grid, 256, 0, st>>>(C, X, Y, Z, lev_off, lo, hi, tabT, nk, coef, mass, AX, AY, AZ, POT, VX, VY, VZ,
+                                                   assign);
+}
+
+static void cyl_tile_acc_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
+                                const double *M, const uint32_t *lev_off, int lo, int hi, const double *tabT, int nk,
+                                double *part, double *tail)
+{
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const int nset = nk == 3 ? 1 : 2;
+  static const int tile0 = [] { const char *e = getenv("EXP_AMD_THIN_TILE"); return e ? atoi(e) : 64; }();
+  int tile = tile0 < 4 ? 4 : tile0 > CYL_TILE_MAX ? CYL_TILE_MAX : tile0;
+  auto need = [&](int t) { return ((((size_t)t * (C.ntrig | 1) + 1) & ~(size_t)1) + (size_t)t * nset * half) * sizeof(double); };
+  while (tile > 4 && need(tile) > 120 * 1024) tile >>= 1;
+  size_t grid = cdiv(n, (size_t)tile);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_acc_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_cyl_acc_tile<<<(unsigned)grid, 256, need(tile), st>>>(C, X, Y, Z, M, lev_off, lo, hi, tabT, nk, part, tail, tile);
+}
+
 __global__ void k_cyl_mass(double *__restrict__ acc, const double *__restrict__ tail, int overwrite)
 {
   if (threadIdx.x < 2) acc[threadIdx.x] = (overwrite ? 0.0 : acc[threadIdx.x]) + tail[threadIdx.x];
@@ -2226,7 +2494,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
   // (k_cyl_acc_thin), no node moments and no pass over the nodes
-  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0 && !f->generic;
+  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0;
   if (thin) {
     if ((rc = ensure_tabT())) return rc;
     if (!f->cpart_clean) {
@@ -2235,11 +2503,16 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     }
     if (nrange) {
       ProfScope ps(ctx, "k_cyl_acc_thin");
+      if (cyl_thin_version() != 1 || f->generic)
+        cyl_tile_acc_launch(ctx->stream, nrange, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms,
+                            f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p);
+      else {
 #define CALL(MM)                                                                                         \
   cyl_thin_acc_launch<MM>(ctx->stream, nrange, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, \
                           f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p)
       MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+      }
     }
   } else if (nrange) {
     ProfScope ps(ctx, "k_cyl_accumulate_sparse");
@@ -2305,7 +2578,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   bool thin = false;
   size_t nthin = 0;
   if (f->multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !ctx->deterministic &&
-      ctx->thin_max > 0 && !f->generic) {
+      ctx->thin_max > 0) {
     int rc_ = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin);
     if (rc_) return rc_;
     thin = (long long)nthin <= ctx->thin_max;
@@ -2319,12 +2592,18 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
                  : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
       C.ps = t->pseudo;
+      if (cyl_thin_version() != 1 || f->generic)
+        cyl_wave_force_launch(ctx->stream, nthin, C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1,
+                              f->d_tabT.p, f->tabT_nk, f->d_coef.p, f->d_mass.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT),
+                              t->a(A_VX), t->a(A_VY), t->a(A_VZ), assign ? 1 : 0);
+      else {
 #define CALL(MM)                                                                                          \
   cyl_thin_force_launch<MM>(ctx->stream, nthin, C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel,      \
                             t->nlevels - 1, f->d_tabT.p, f->tabT_nk, f->d_coef.p, f->d_mass.p, t->a(A_AX), t->a(A_AY), \
                             t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ), assign ? 1 : 0)
       MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+      }
       HIP_TRY(ctx, hipGetLastError());
     }
     t->acc_live = true;

@@ -38,7 +38,7 @@ int exp_amd_force::alloc_common(size_t ncoef_, int multistep_, size_t tail)
   A(d_coefN.alloc((size_t)nlev * ncoef_dev));
   A(d_coefL.alloc((size_t)nlev * ncoef_dev));
   A(d_scratch.alloc(256));
-  A(d_used.alloc(4));
+  A(d_used.alloc(8 + 8 * 128));      // [0], [1]: the counts; the rest: slots of the EXPT_USED_SPREAD A/B build
   if (e != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "force: hipMalloc failed: %s", hipGetErrorString(e));
   HIP_TRY(ctx, hipMemset(d_coef.p, 0, d_coef.bytes()));
   HIP_TRY(ctx, hipMemset(d_coefN.p, 0, d_coefN.bytes()));

@@ -270,6 +270,14 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
       gen_ac[((size_t)l * (L + 1) + m) * 2 + 1] = lc_c(l, m);
     }
   }
+  std::vector<unsigned char> gen_slot((size_t)t4_rows(L) * 2, 0);
+  for (int m = 0; m <= L; m++)
+    for (int l = m; l <= L; l++) {
+      const int q = t4_row(L, l, m);
+      gen_slot[2 * q] = (unsigned char)l; gen_slot[2 * q + 1] = (unsigned char)m;
+      if (m > 0) { gen_slot[2 * q + 2] = (unsigned char)l; gen_slot[2 * q + 3] = (unsigned char)(m | 0x80); }
+    }
+  A(f->d_gen_slot.alloc(gen_slot.size()));
   A(f->d_gen_ac.alloc(gen_ac.size()));
   A(f->d_gen_e.alloc(gen_e.size()));
   f->generic = L > SPH_MAX_L;
@@ -304,6 +312,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
                 ef[((size_t)l * nmax + n) * numr + (edge ? numr - 3 + k : k)];
     HIP_TRY(ctx, hipMemcpy(f->d_litef.p, le.data(), le.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  HIP_TRY(ctx, hipMemcpy(f->d_gen_slot.p, gen_slot.data(), gen_slot.size(), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_gen_ac.p, gen_ac.data(), gen_ac.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_gen_e.p, gen_e.data(), gen_e.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(f->d_rowmap.p, rowmap.data(), rowmap.size() * sizeof(int),
@@ -330,7 +339,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
     if (xi[i] != cfg->xmin + t) S.xi_uniform = 0;
   }
   S.xi = f->d_xi.p; S.p0 = f->d_p0.p; S.E = f->d_E.p; S.lc = f->d_lc.p;
-  S.gen_ac = f->d_gen_ac.p; S.gen_e = f->d_gen_e.p;
+  S.gen_ac = f->d_gen_ac.p; S.gen_e = f->d_gen_e.p; S.gen_slot = f->d_gen_slot.p;
   // the literal radial derivative (sph_dp_lit): more than four cells outside the first / last force stencil -- which
   // only the logarithmic map can reach (cmap 1 maps r -> 0 to within three cells of xmin; an unmapped grid is left alone)
   S.lit_ef = f->d_litef.p; S.lit_ev = f->d_ev.p; S.lit_coef = f->d_coef.p;
@@ -374,7 +383,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
 void SphForce::release()
 {
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release(); d_litef.release(); d_litlist.release();
-  d_gen_ac.release(); d_gen_e.release();
+  d_gen_ac.release(); d_gen_e.release(); d_gen_slot.release();
   d_rowmap.release();
   d_tscale.release();
   d_ev.release(); d_d0.release(); d_Gd.release();
@@ -446,6 +455,8 @@ DECL_L(7) DECL_L(8) DECL_L(9) DECL_L(10) DECL_L(11) DECL_L(12)
 void expamd_sph_acc_gen(const SphAccArgs &);          // any order (sph_gen.hip)
 void expamd_sph_upd_gen(const SphUpdArgs &);
 void expamd_sph_force_gen(const SphForceArgs &);
+void expamd_sph_thin_force_gen(const SphThinForceArgs &);   // one wave per particle (k_sph_force_wave)
+void expamd_sph_thin_acc_gen(const SphThinAccArgs &);        // 64-particle tiles (k_sph_acc_tile)
 static const sph_acc_launcher k_acc_launch_tab[SPH_MAX_L + 1] = {
     expamd_sph_acc_L0, expamd_sph_acc_L1, expamd_sph_acc_L2,  expamd_sph_acc_L3,  expamd_sph_acc_L4,
     expamd_sph_acc_L5, expamd_sph_acc_L6, expamd_sph_acc_L7,  expamd_sph_acc_L8,  expamd_sph_acc_L9,
@@ -649,7 +660,8 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's partial sums
   // (k_sph_acc_thin), no moments and no contraction (the deterministic mode keeps the moment path: its rounding grid
   // is that of the moment terms)
-  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic && !f->generic;
+  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic &&
+                    f->ncoef <= 4096;
   if (thin) {
     if (!f->part_clean) {
       HIP_TRY(ctx, hipMemsetAsync(f->d_part.p, 0, f->d_part.bytes(), ctx->stream));
@@ -659,7 +671,8 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       ProfScope ps(ctx, "k_sph_acc_thin");
       SphThinAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, f->d_wscale.p, f->d_part.p,
                        used_p, nrange, ctx->stream};
-      k_thin_acc_launch[cfg.lmax](a);
+      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
+      if (thin_v == 1 && !f->generic) k_thin_acc_launch[cfg.lmax](a); else expamd_sph_thin_acc_gen(a);
     }
   } else if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate_sparse");
@@ -718,8 +731,8 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   // straight from the coefficient set (k_sph_force_thin): the projected table is not needed and stays stale.
   bool thin = false;
   size_t nthin = 0;
-  if (f->cfg.multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !f->lit_on && !f->generic &&
-      !ctx->deterministic && ctx->thin_max > 0) {
+  if (f->cfg.multistep > 0 && t->n && t->nlevels > 1 && dt_kick == 0.0 && !prekey_done && !ctx->deterministic &&
+      ctx->thin_max > 0) {
     if ((rc = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin))) return rc;
     thin = (long long)nthin <= ctx->thin_max;
   }
@@ -735,7 +748,8 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       SphThinForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1, f->d_coef.p,
                          f->d_rowmap.p, f->d_tscale.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX),
                          t->a(A_VY), t->a(A_VZ), assign ? 1 : 0, nthin, ctx->stream};
-      k_thin_force_launch[f->cfg.lmax](a);
+      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
+      if (thin_v == 1 && !f->generic) k_thin_force_launch[f->cfg.lmax](a); else expamd_sph_thin_force_gen(a);
       HIP_TRY(ctx, hipGetLastError());
     }
     t->acc_live = true;

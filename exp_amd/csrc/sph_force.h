@@ -10,6 +10,7 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_litef;           // raw eigenfunctions at the first and last force stencil (SphDev::lit_ef)
   DevBuf<uint32_t> d_litlist;       // [1 + capacity]: slots left to the literal pass (SphDev::lit_list), cmap 2 only
   bool lit_on = false;
+  DevBuf<unsigned char> d_gen_slot; // (l, m | sine flag) of the projected table's slots (SphDev::gen_slot)
   DevBuf<double> d_gen_ac, d_gen_e; // run-time recurrence constants of the any-order kernels (SphDev::gen_ac, gen_e)
   bool generic = false;             // lmax > SPH_MAX_L (or EXP_AMD_SPH_GENERIC=1): every per-particle pass through sph_gen.hip
   DevBuf<double> d_W, d_part, d_G, d_T4;

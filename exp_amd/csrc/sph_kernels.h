@@ -58,6 +58,7 @@ struct SphDev {
   const double *lc;      // [(lmax+1)*(lmax+1)][4] normalised-Legendre recurrence constants (below)
   const double *gen_ac;  // [(lmax+1)*(lmax+1)][2]: a(l,m), c(l,m) of the RESCALED recurrence (lc_a, lc_c) as run-time
   const double *gen_e;   // [lmax+1]: e_m (lc_E) -- data for the any-order kernels of sph_gen.hip
+  const unsigned char *gen_slot;   // [trows][2]: l, m | (sine row ? 0x80 : 0) of every slot of the projected table
   // Far extrapolation beyond the table (possible with the logarithmic map only: hundreds of cells inside rmin, or outside
   // rmax in the pyEXP mode): the three-term radial derivative is then a small difference of large numbers and only the
   // reference's own operation order reproduces its value (sph_dp_lit below).  lit_lo / lit_hi: the force offset pf
@@ -656,7 +657,16 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 #endif
     if (last_tile && wave == 0 && lane == 0) {
       const unsigned long long tot = (sh.used[0] + sh.used[1]) + (sh.used[2] + sh.used[3]);
+      // (A/B builds of round 4, tools/build_variant_l10.sh: EXPT_NO_USED drops the block's one same-address atomic,
+      // EXPT_USED_SPREAD sends it to one of 128 slots -- both measured NEUTRAL on the 1e8 headline, DESIGN.md section 5:
+      // 24 414 atomics in 2.9 ms are one every 120 ns, a tenth of what the atomic unit serves)
+#if defined(EXPT_NO_USED)
+      (void)tot;
+#elif defined(EXPT_USED_SPREAD)
+      if (tot) atomicAdd(used_out + 8 + 8 * (blockIdx.x & 127), tot);
+#else
       if (tot) atomicAdd(used_out, tot);
+#endif
     }
     // next tile's particles: requested AFTER the barrier (no load is outstanding at it) and in
     // flight while this tile is reduced

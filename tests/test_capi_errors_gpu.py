@@ -90,13 +90,13 @@ def test_bad_basis_configurations_are_refused(env):
     arr = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(c_void_p)
     good = dict(lmax=g.lmax, nmax=g.nmax, numr=g.numr, cmap=g.cmap, rmap=g.rmap, scale=1.0, rmin=g.rmin, rmax=g.rmax,
                 xmin=g.xmin, dxi=g.dxi, NO_L0=0, NO_L1=0, EVEN_L=0, EVEN_M=0, M0_only=0, multistep=0)
-    for key, val in (("lmax", -1), ("lmax", 64), ("nmax", 0), ("numr", 2), ("cmap", 5), ("multistep", 30)):
+    for key, val in (("lmax", -1), ("lmax", 65), ("nmax", 0), ("numr", 2), ("cmap", 5), ("multistep", 30)):
         cfg = SphConfig(**{**good, key: val})
         out = c_void_p()
         rc = lib.exp_amd_sph_create(ctx.h, byref(cfg), arr(g.xi), arr(g.p0), arr(g.ev), arr(g.ef), byref(out))
         assert rc == ERR_ARG and not out.value, (key, val, rc)
         assert key in _msg(lib, ctx) or "sph_create" in _msg(lib, ctx)
-    ccfg = CylConfig(mmax=40, nmax=4, numx=8, numy=8, cmapr=1, cmapz=1, ascale=0.01, hscale=0.001, rtable=1.0,
+    ccfg = CylConfig(mmax=65, nmax=4, numx=8, numy=8, cmapr=1, cmapz=1, ascale=0.01, hscale=0.001, rtable=1.0,
                      xmin=0.0, dx=0.1, ymin=0.0, dy=0.1, rcylmax=20.0, EVEN_M=0, multistep=0)
     out = c_void_p()
     assert lib.exp_amd_cyl_create(ctx.h, byref(ccfg), arr(np.zeros(8)), byref(out)) == ERR_ARG and not out.value
