@@ -1051,7 +1051,14 @@ __device__ __forceinline__ CylOut cyl_field(const CylDev &C, PT t00, PT t10, PT 
   return o;
 }
 
-template <int MMAX>
+// TAIL == false: the launch over the slot range.  Lanes inside 0.75 of the table radius (no taper, no monopole: almost
+// every particle of the component the basis belongs to) are finished here; a wave with lanes beyond leaves its first slot
+// and their mask on `work` and the tail launch (TAIL == true: one wave per work item, the same body with the erf taper
+// and the monopole blend of src/Cylinder.cc:1357-1408) finishes those.  The split keeps erf -- a long routine that put
+// 68 bytes of scratch under every wave -- out of the kernel that does the bulk of the work; a lane's arithmetic is the
+// same in either kernel (frac = 1, cfrac = 0 multiply exactly).
+#define CYL_WORK_STRIDE 3
+template <int MMAX, bool TAIL>
 __global__ void __launch_bounds__(256)
 k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
@@ -1059,14 +1066,32 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
             double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
             double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
             double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ key_out,
-            double nk_dtk, double nk_dtd, int store_v)
+            double nk_dtk, double nk_dtd, int store_v, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork,
+            uint32_t *__restrict__ nwork_clear /* the counter of the NEXT launch pair: zeroed by the tail launch */)
 {
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   const int lane = threadIdx.x & 63;
-  const size_t base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
-  if (base >= end) return;
+  size_t base;
+  unsigned long long mask = ~0ull;
+  if constexpr (TAIL) {
+    if (work == nullptr) {
+      // the whole range in this kernel alone: ANOTHER component's particles (a halo around the disk: most of them beyond
+      // the table radius, every wave would go through the list)
+      base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+      if (base >= end) return;
+    } else {
+      if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
+      const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+      if (w >= *nwork) return;
+      base = work[CYL_WORK_STRIDE * w];
+      mask = (unsigned long long)work[CYL_WORK_STRIDE * w + 1] | ((unsigned long long)work[CYL_WORK_STRIDE * w + 2] << 32);
+    }
+  } else {
+    base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+    if (base >= end) return;
+  }
   const size_t i = base + lane;
-  const bool valid = i < end;
+  bool valid = i < end && ((mask >> lane) & 1ull);
   double xx = 1, yy = 0, zz = 0;
   if (valid) {
     cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
@@ -1083,10 +1108,24 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   double cphi = 1.0, sphi = 0.0;
   if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
   const double ratio = r3s * C.inv_rtab_abs;              // sqrt((r^2 + z^2) / (ascale rtable)^2)
-  double frac, cfrac;
-  if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
-  else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
-  else { cfrac = 0.0; frac = 1.0; }
+  double frac = 1.0, cfrac = 0.0;
+  if constexpr (TAIL) {
+    if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
+    else if (ratio > ratmin) { frac = 0.5 * (1.0 - erf((ratio - midpt) / rsmth)); cfrac = 1.0 - frac; }
+    else { cfrac = 0.0; frac = 1.0; }
+  } else {
+    // beyond 0.75 of the table radius: the tail launch's business
+    const unsigned long long far = __ballot(valid && ratio > ratmin);
+    if (far) {
+      if (lane == 0) {
+        const uint32_t w = atomicAdd(nwork, 1u);
+        work[CYL_WORK_STRIDE * w] = (uint32_t)base;
+        work[CYL_WORK_STRIDE * w + 1] = (uint32_t)far;
+        work[CYL_WORK_STRIDE * w + 2] = (uint32_t)(far >> 32);
+      }
+      if ((far >> lane) & 1ull) valid = false;
+    }
+  }
 
   // accumulated_eval (exputil/EmpCylSL.cc:5272-5314): off grid -> zeros
   const bool ongrid = valid && ratio < 1.0 && !(r3s > C.rtab_abs);
@@ -1096,7 +1135,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   int cell = ix * C.numy + iy;
   const int cell_u = __builtin_amdgcn_readfirstlane(cell);
   if (!ongrid) cell = cell_u;
-  const bool uniform = __all(cell == cell_u);
+  const bool uniform = (!TAIL || work == nullptr) && __all(cell == cell_u);
   const int NF = 3 * (2 * MMAX + 1);
   const int nyp = C.numy + 1;
   CylOut o{0.0, 0.0, 0.0, 0.0};
@@ -1127,13 +1166,15 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     fz = fzz * frac;
     pa = p * frac;
   }
-  if (ratio > ratmin) {                             // monopole blend, src/Cylinder.cc:1398-1408
-    const double p = -(*cylmass_p) * ir3s;          // -M / sqrt(r^2 + z^2)
-    const double fr = p * (ir3s * ir3s);
-    fx += xx * fr * cfrac;
-    fy += yy * fr * cfrac;
-    fz += zz * fr * cfrac;
-    pa += p * cfrac;
+  if constexpr (TAIL) {
+    if (ratio > ratmin) {                             // monopole blend, src/Cylinder.cc:1398-1408
+      const double p = -(*cylmass_p) * ir3s;          // -M / sqrt(r^2 + z^2)
+      const double fr = p * (ir3s * ir3s);
+      fx += xx * fr * cfrac;
+      fy += yy * fr * cfrac;
+      fz += zz * fr * cfrac;
+      pa += p * cfrac;
+    }
   }
   if (C.use_rot) {                                  // frc = transformOrig * frc (src/Cylinder.cc:1417-1418)
     const double a = fx, b = fy, c = fz;
@@ -1915,6 +1956,10 @@ struct CylForce : exp_amd_force {
   DevBuf<double> d_tab, d_Wn, d_TF;
   bool tab_twin = false;            // the three sine tables equal the three cosine tables bit for bit (m >= 1)
   DevBuf<double> d_cpart;           // stage-1 sums of the contraction: [level][CYL_CSEG][ncoef]
+  DevBuf<uint32_t> d_work;          // work list of the force pass' tail launch (lanes beyond 0.75 of the table radius)
+  size_t work_cap = 0;              // ... in waves; the two counters behind it are used alternately
+  int work_flip = 0;
+  int step_parity() const override { return work_flip; }
   bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
   bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)
   DevBuf<double> d_tabT;            // node-major copy tabT[node][kind][m][n] for the thin path (made on first use)
@@ -1959,7 +2004,7 @@ struct CylForce : exp_amd_force {
     cov_U.release(); cov_Q.release(); cov_mass.release(); cov_vc.release(); cov_mv.release();
     cov_cnt.release(); cov_used.release(); cov_seq.release();
     d_tab.release(); d_Wn.release(); d_TF.release(); d_Wnd.release(); d_differ.release(); d_cpart.release();
-    d_tabT.release();
+    d_tabT.release(); d_work.release();
     d_mass.release();
     d_tailpart.release();
     d_dens.release();
@@ -2636,14 +2681,40 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
           t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ), dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk,
           nk_dtd, sv);
     else {
+      // main launch + tail launch (beyond 0.75 of the table radius); the work list holds one entry per wave at most
+      const size_t need = t->n / 64 + 8;
+      if (f->work_cap < need) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, f->d_work.alloc(CYL_WORK_STRIDE * need + 2));
+        HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + CYL_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), ctx->stream));
+        f->work_cap = need;
+        f->work_flip = 0;
+      }
+      uint32_t *cnt = f->d_work.p + CYL_WORK_STRIDE * f->work_cap;
+      if (external) {
 #define CALL(MM)                                                                                  \
-  k_cyl_force<MM><<<grid, 256, 0, ctx->stream>>>(                                                 \
+  k_cyl_force<MM, true><<<grid, 256, 0, ctx->stream>>>(                                           \
+      C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
+      t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
+      dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd, sv, nullptr, nullptr, nullptr)
+      MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
+      } else {
+#define CALL(MM)                                                                                  \
+  k_cyl_force<MM, false><<<grid, 256, 0, ctx->stream>>>(                                          \
       C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
       t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
       dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd,                        \
-      sv)
+      sv, f->d_work.p, cnt + f->work_flip, nullptr);                                               \
+  k_cyl_force<MM, true><<<grid, 256, 0, ctx->stream>>>(                                           \
+      C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, lo, hi, f->d_TF.p, f->d_mass.p, \
+      t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX), t->a(A_VY), t->a(A_VZ),        \
+      dt_kick, assign ? 1 : 0, prekey ? t->key.p : nullptr, nk_dtk, nk_dtd,                        \
+      sv, f->d_work.p, cnt + f->work_flip, cnt + (1 - f->work_flip))
     MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
+      f->work_flip ^= 1;
+      }
     }
   }
   HIP_TRY(ctx, hipGetLastError());
