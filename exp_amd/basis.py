@@ -385,10 +385,23 @@ class BiorthBasis:
         self.reset_coefs()
         a = reader.arrays()
         n, step = len(a["mass"]), 1 << 24
-        for lo in range(0, max(n, 1), step):
-            sl = slice(lo, min(lo + step, n))
+        # every batch ends in one all-reduce of the coefficient buffer: all ranks must issue the same number of them
+        # (shares that straddle a multiple of 2^24 differently would hang or mis-sum) -- empty batches take part
+        nbatch = max(1, -(-n // step))
+        import sys as _sys
+        _dist = _sys.modules.get("torch.distributed")
+        if _dist is not None and _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
+            box = [None] * _dist.get_world_size()
+            _dist.all_gather_object(box, nbatch)
+            nbatch = max(box)
+        sampT = int(getattr(self, "sampT", 0) or 0)
+        for lo in range(0, nbatch * step, step):
+            sl = slice(min(lo, n), min(lo + step, n))
             m = np.ascontiguousarray(a["mass"][sl], dtype=np.float64)
-            seq = np.asarray(a["indx"][sl]).astype(np.uint32)
+            # the particle's own index picks the cylinder's sub-sample (seq % sampT with an unsigned long index in the
+            # reference, exputil/EmpCylSL.cc:4062-4075): reduced BEFORE the 32-bit cast so that indices >= 2^32 agree
+            idx64 = np.asarray(a["indx"][sl]).astype(np.uint64)
+            seq = (idx64 % np.uint64(sampT) if sampT > 1 else idx64 & np.uint64(0xffffffff)).astype(np.uint32)
             if self._ftor is None:
                 self._accumulate_batch(m, np.asarray(a["pos"][sl], dtype=np.float64), seq, frame=(ctr, R))
                 continue

@@ -2249,6 +2249,10 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level
     ProfScope ps(ctx, "k_key_hist");
     CylKeyFn kf{C, c->sparse_mask};
     AdvanceArgs A = expamd_advance_args(c, adv);
+    if (nr <= HIST_SHORT_MAX)
+      k_key_hist<CylKeyFn, HIST_ITEMS_SHORT><<<cdiv(nr, SORT_TPB * HIST_ITEMS_SHORT), SORT_TPB, 0, ctx->stream>>>(
+          kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
+    else
     k_key_hist<CylKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }

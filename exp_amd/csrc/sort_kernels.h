@@ -169,7 +169,12 @@ __device__ __forceinline__ void sort_range(const SortRange &R, size_t &beg, size
   else { beg = 0; end = R.n; }
 }
 
-template <class KeyFn>
+// ITEMS: slots per thread.  HIST_ITEMS for the bulk passes; the short ranges of a block-multistep sub-step (a few thousand to
+// a few ten thousand slots, sorted sixteen times per master step) take HIST_ITEMS_SHORT: sixteen keys per thread one after
+// the other -- each a square root and a division or more -- made a 13 000-slot pass of four blocks 35 us long
+#define HIST_ITEMS_SHORT 2
+#define HIST_SHORT_MAX 65536       // slots up to which a range counts as short
+template <class KeyFn, int ITEMS = HIST_ITEMS>
 __global__ void __launch_bounds__(SORT_TPB)
 k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
            uint32_t *__restrict__ hist)
@@ -178,12 +183,12 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
   __shared__ uint32_t kmin_s;
   size_t rbeg, n;
   sort_range(R, rbeg, n);
-  const size_t base = rbeg + (size_t)blockIdx.x * HIST_TILE;
+  const size_t base = rbeg + (size_t)blockIdx.x * (SORT_TPB * ITEMS);
   if (base >= n) return;
-  uint32_t k[HIST_ITEMS];
+  uint32_t k[ITEMS];
   uint32_t mn = 0xffffffffu;
 #pragma unroll
-  for (int j = 0; j < HIST_ITEMS; j++) {
+  for (int j = 0; j < ITEMS; j++) {
     const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
     k[j] = 0xffffffffu;
     if (i < n) {
@@ -197,7 +202,7 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
   const uint32_t kmin = block_min_u32(mn, &kmin_s);     // (also orders the zeroing)
 #pragma unroll
-  for (int j = 0; j < HIST_ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist);
+  for (int j = 0; j < ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist);
   __syncthreads();
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
     const uint32_t c = lh[b];

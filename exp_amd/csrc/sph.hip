@@ -434,6 +434,10 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
     ProfScope ps(ctx, "k_key_hist");
     SphKeyFn kf{dev_for(f, c->center), c->sparse_mask};
     AdvanceArgs A = expamd_advance_args(c, adv);
+    if (nr <= HIST_SHORT_MAX)
+      k_key_hist<SphKeyFn, HIST_ITEMS_SHORT><<<cdiv(nr, SORT_TPB * HIST_ITEMS_SHORT), SORT_TPB, 0, ctx->stream>>>(
+          kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
+    else
     k_key_hist<SphKeyFn><<<cdiv(nr, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(
         kf, A, expamd_sort_range(c, level, level_hi), c->key.p, c->hist.p);
   }

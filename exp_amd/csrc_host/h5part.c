@@ -32,6 +32,7 @@ static void quiet(void) { H5Eset_auto2(H5E_DEFAULT, NULL, NULL); }
 /* 1: the link exists, 0: it does not, <0: the file cannot be opened */
 int exp_h5p_exists(const char *path, const char *obj)
 {
+  if (!path || !obj || !obj[0]) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -39,7 +40,7 @@ int exp_h5p_exists(const char *path, const char *obj)
   char buf[1024];
   strncpy(buf, obj, sizeof(buf) - 1); buf[sizeof(buf) - 1] = '\0';
   int ok = 1;
-  for (char *p = buf + 1; ok && (p = strchr(p, '/')); p++) {
+  for (char *p = buf[0] ? buf + 1 : buf; ok && (p = strchr(p, '/')); p++) {
     *p = '\0';
     if (H5Lexists(f, buf, H5P_DEFAULT) <= 0) ok = 0;
     *p = '/';
@@ -52,6 +53,7 @@ int exp_h5p_exists(const char *path, const char *obj)
 /* numeric attribute (scalar or 1-D, any integer or float type) -> doubles */
 int exp_h5p_attr_f64(const char *path, const char *obj, const char *name, double *out, int cap, int *n)
 {
+  if (!path || !obj || !name || !out || !n || cap < 0) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -76,6 +78,7 @@ int exp_h5p_attr_f64(const char *path, const char *obj, const char *name, double
 /* string attribute, scalar or 1-D, variable- or fixed-length: element `index` -> out; *count = number of elements */
 int exp_h5p_attr_str(const char *path, const char *obj, const char *name, int index, char *out, int cap, int *count)
 {
+  if (!path || !obj || !name || !count || (cap > 0 && !out) || cap < 0) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   out[0] = '\0';
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
@@ -126,6 +129,7 @@ int exp_h5p_attr_str(const char *path, const char *obj, const char *name, int in
 
 int exp_h5p_dset_shape(const char *path, const char *dset, int *rank, long long *dims, long long *storage)
 {
+  if (!path || !dset || !rank || !dims) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -164,6 +168,7 @@ static hid_t mem_type(char kind)
 /* the whole dataset converted to `kind` */
 int exp_h5p_dset_read(const char *path, const char *dset, char kind, void *out)
 {
+  if (!path || !dset || !out) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t mt = mem_type(kind);
   if (mt < 0) return -5;
@@ -259,6 +264,7 @@ int exp_h5p_particles_read(const char *path, const char *dset, int real4, long l
 /* ---- writing ---- */
 int exp_h5p_create(const char *path)
 {
+  if (!path) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -268,6 +274,7 @@ int exp_h5p_create(const char *path)
 
 int exp_h5p_group(const char *path, const char *group)
 {
+  if (!path || !group || !group[0]) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -281,6 +288,7 @@ int exp_h5p_group(const char *path, const char *group)
 /* n < 0: scalar; otherwise a 1-D attribute of n elements.  The file type is the native type, as HighFive / H5:: write it. */
 int exp_h5p_attr_write(const char *path, const char *obj, const char *name, char kind, int n, const void *data)
 {
+  if (!path || !obj || !name || n < -1 || (n != 0 && !data)) return -9;   /* n = -1: a scalar */     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t mt = mem_type(kind);
   if (mt < 0) return -5;
@@ -301,6 +309,7 @@ int exp_h5p_attr_write(const char *path, const char *obj, const char *name, char
 
 int exp_h5p_attr_write_str(const char *path, const char *obj, const char *name, int n, const char *const *vals)
 {
+  if (!path || !obj || !name || n < -1 || (n != 0 && !vals)) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
   if (f < 0) return -1;
@@ -342,6 +351,7 @@ static hid_t creation_props(int rank, const hsize_t *dims, int chunk, int deflat
 int exp_h5p_dset_write(const char *path, const char *dset, char kind, int rank, const long long *dims, const void *data,
                        int chunk, int deflate, int shuffle)
 {
+  if (!path || !dset || rank < 0 || (rank > 0 && !dims) || !data) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   hid_t mt = mem_type(kind);
   if (mt < 0 || rank < 1 || rank > 4) return -5;

@@ -93,6 +93,15 @@ def header(names: Sequence[str], ids: Sequence[str], precision: int = 10) -> str
     return out
 
 
+_ATOF = __import__("re").compile(r"^[ \t]*([+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
+
+
+def _atof(tok: str) -> float:
+    """C's atof: the longest leading numeric prefix, 0.0 when there is none (`1.5|` -> 1.5, `abc` -> 0.0)"""
+    m = _ATOF.match(tok)
+    return float(m.group(1)) if m else 0.0
+
+
 class OutLog:
     """``OutLog(filename | outdir + runtag, nint, precision)``; ``run(n, tnow, last)`` appends a row when ``n % nint == 0``
     (or ``last``).  Components are registered with their name, force id, particle store and force (for ``Used()``)."""
@@ -118,20 +127,20 @@ class OutLog:
         backup = self.filename + ".bak"
         os.replace(self.filename, backup)
         with open(backup) as src, open(self.filename, "w") as out:
+            # std::getline semantics (src/OutLog.cc:271-287): a last row WITHOUT a trailing newline is still a row (characters
+            # were extracted, only eofbit is set); the empty fragment behind a trailing newline is not
             lines = src.read().split("\n")
+            if lines and lines[-1] == "":
+                lines.pop()
             k = 0
-            while k < len(lines) - 1:
+            while k < len(lines):
                 out.write(lines[k] + "\n")
                 k += 1
                 if any(ch in lines[k - 1] for ch in "Time"):   # find_first_of("Time"): ANY of the four letters
                     break
-            while k < len(lines) - 1:
-                tok = lines[k].split(" ")
-                tok = [t for t in tok if t]
-                try:
-                    ttim = float(tok[0].split("|")[0]) if tok else 0.0
-                except ValueError:
-                    ttim = 0.0                                  # atof of a non-number
+            while k < len(lines):
+                tok = [t for t in lines[k].split(" ") if t]
+                ttim = _atof(tok[0]) if tok else 0.0
                 if tnow < ttim:
                     break
                 out.write(lines[k] + "\n")

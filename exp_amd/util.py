@@ -66,6 +66,15 @@ def getDensityCenter(reader, stride: int = 1, Nsort: int = 0, Ndens: int = 32, s
         raise RuntimeError("tree is empty")                   # kdtree::nearestN on an empty tree (include/KDtree.H:349)
     samples = np.arange(nbods)
     if stride > 1:
+        # every rank evaluates the whole estimate on the gathered particle set: they must draw the SAME sample (the
+        # reference splits one loop over the ranks and combines, expui/Centering.cc); an unseeded draw is rank 0's
+        if seed is None:
+            import sys
+            dist = sys.modules.get("torch.distributed")
+            box = [int(np.random.SeedSequence().entropy % (1 << 63))]
+            if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast_object_list(box, src=0)
+            seed = box[0]
         samples = np.random.default_rng(seed).permutation(nbods)[: nbods // stride]
     dens, ok = knn_density(pos, mass, samples, Ndens)
     samples, dens = samples[ok], dens[ok]
