@@ -563,6 +563,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
           (void)hipEventRecord(s->ht_ev0, s->main_stream);
           s->ht_lo_now = s->mfirst[mstep];
         }
+        // EXP_AMD_SIM_SERIAL0=1 (experiment): the first sub-step -- every particle of every component moves: bandwidth-
+        // and issue-bound kernels that gain nothing from sharing the GPU -- on ONE stream; the small sub-steps keep two
+        static const bool serial0 = [] { const char *e = getenv("EXP_AMD_SIM_SERIAL0"); return e && atoi(e) != 0; }();
+        const bool was_overlap = s->overlap;
+        if (serial0 && mstep == 0 && was_overlap && (rc = overlap_end(s))) return rc;
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
         s->tnow += dt;
         const double th1 = s->host_timing ? host_now() : 0.0;
@@ -571,6 +576,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if (s->host_timing) { s->ht[0] += th1 - th0; s->ht[1] += host_now() - th1; }
         const int lo_now = s->mfirst[mstep];
         if ((rc = kick_adjust_levels(s, mdrft, first_step, true))) return rc;
+        if (serial0 && mstep == 0 && was_overlap && (rc = overlap_begin(s))) return rc;
         if (s->host_timing) s->ht_lo[lo_now] += host_now() - th0;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
