@@ -2124,6 +2124,9 @@ int CylForce::ensure_tabT()
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cylinder: hipMalloc of the node-major table copy failed");
   k_cyl_transpose<<<cdiv(nnode * (size_t)per_node, 256), 256, 0, ctx->stream>>>(d_tab.p, d_tabT.p, nnode, per_node);
   HIP_TRY(ctx, hipGetLastError());
+  // (made once; finished before anything else is issued: the step driver reads it from BOTH of its streams -- the
+  // self expansion on the component's own, a cross force on the target's -- and only this stream is ordered behind it)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return EXP_AMD_OK;
 }
 
