@@ -1301,7 +1301,8 @@ k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restric
   constexpr int PS = 4 * NFS + 2;                                   // (particle stride = 4 banks mod 64: no conflicts)
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if (beg + (size_t)blockIdx.x * tp >= end) return;
-  for (int k = threadIdx.x; k < 2 * half; k += 256) s_coef[k] = coef[k];
+  const int NTH = blockDim.x;                 // 256, or 64 for ranges of thousands (see k_sph_force_thin)
+  for (int k = threadIdx.x; k < 2 * half; k += NTH) s_coef[k] = coef[k];
   const int t = threadIdx.x;
   const int nyp = C.numy + 1;
   const size_t per_node = (size_t)nk * half;
@@ -1334,7 +1335,7 @@ k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restric
     __syncthreads();
     // ---- TF rows of the four corner nodes of every on-grid particle: item = (particle, corner, kind, m)
     const int per_p = 4 * 3 * (C.mmax + 1);
-    for (int it = threadIdx.x; it < tp * per_p; it += 256) {
+    for (int it = threadIdx.x; it < tp * per_p; it += NTH) {
       const int p = it / per_p;
       int rest = it - p * per_p;
       const int node0 = s_node[p];
@@ -2149,7 +2150,9 @@ static void cyl_thin_force_launch(hipStream_t st, size_t n, const CylDev &C, con
     return true;
   }();
   (void)big;
-  k_cyl_force_thin<MM><<<(unsigned)grid, 256, lds, st>>>(C, X, Y, Z, lev_off, lo, hi, tabT, nk, coef, mass, AX, AY, AZ, POT, VX,
+  static const int nt0 = [] { const char *e = getenv("EXP_AMD_THIN_NT"); return e ? atoi(e) : 0; }();
+  const int nt = nt0 ? nt0 : 256;
+  k_cyl_force_thin<MM><<<(unsigned)grid, nt, lds, st>>>(C, X, Y, Z, lev_off, lo, hi, tabT, nk, coef, mass, AX, AY, AZ, POT, VX,
                                                          VY, VZ, assign, tp);
 }
 

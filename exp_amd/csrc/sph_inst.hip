@@ -155,7 +155,9 @@ void CAT(expamd_sph_thin_force_L, SPH_L)(const SphThinForceArgs &a)
     return true;
   }();
   (void)big;
-  k_sph_force_thin<LMAX><<<(unsigned)grid, 256, lds, a.stream>>>(
+  static const int nt0 = [] { const char *e = getenv("EXP_AMD_THIN_NT"); return e ? atoi(e) : 0; }();
+  const int nt = nt0 ? nt0 : 256;       // (64-thread blocks -- four times as many resident -- measured SLOWER at 2e3 and 1.3e4 particles)
+  k_sph_force_thin<LMAX><<<(unsigned)grid, nt, lds, a.stream>>>(
       a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.coef, a.rowmap, a.tscale, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
       a.assign, tp, tqs);
 }

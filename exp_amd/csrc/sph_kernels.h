@@ -1801,7 +1801,10 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
   double *s_E = stage + (size_t)tp * tqs;                     // [tp][3][lsn]: E at the three nodes of its force stencil
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if (beg + (size_t)blockIdx.x * tp >= end) return;
-  for (int k = threadIdx.x; k < ncoef; k += 256) s_coef[k] = coef[k];
+  // (blockDim.x threads, 256 by default; EXP_AMD_THIN_NT=64 -- the 232 VGPRs
+  // allow two waves per SIMD, i.e. two 256-thread blocks per CU but eight 64-thread ones)
+  const int NT = blockDim.x;
+  for (int k = threadIdx.x; k < ncoef; k += NT) s_coef[k] = coef[k];
   const int t = threadIdx.x;
   for (size_t base = beg + (size_t)blockIdx.x * tp; base < end; base += (size_t)gridDim.x * tp) {
     // ---- the prologue of k_sph_force_staged, one particle per lane of the first wave
@@ -1846,11 +1849,11 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
     // otherwise consist of)
     {
       const int e3 = 3 * lsn, total = tp * e3;
-      for (int it0 = threadIdx.x; it0 < total; it0 += 4 * 256) {
+      for (int it0 = threadIdx.x; it0 < total; it0 += 4 * NT) {
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int it = it0 + u * 256;
+          const int it = it0 + u * NT;
           v[u] = 0.0;
           if (it < total) {
             const int p = it / e3, cell = s_cell[p];
@@ -1858,12 +1861,12 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (it0 + u * 256 < total) s_E[it0 + u * 256] = v[u];
+        for (int u = 0; u < 4; u++) if (it0 + u * NT < total) s_E[it0 + u * NT] = v[u];
       }
     }
     __syncthreads();
     // ---- the T4 rows of those cells, projected by the whole block: slot q of particle p
-    for (int it = threadIdx.x; it < tp * S.trows; it += 256) {
+    for (int it = threadIdx.x; it < tp * S.trows; it += NT) {
       const int p = it / S.trows, q = it - p * S.trows;
       const int cell = s_cell[p];
       if (cell < 0) continue;
