@@ -86,14 +86,20 @@ k_zero_acc(double *__restrict__ ax, double *__restrict__ ay, double *__restrict_
 // exclusive scan of hist[0..nkeys) in place; hist[nkeys] = total; lev_off[L] = start of key L*ncell,
 // lev_off[nlev] = total.  range mode (range_lo >= 0): only the bins of the levels range_lo..range_hi
 // are populated; positions start at lev_off[range_lo] and the level offsets outside are left alone.
-// One block per chunk of 1024 x SCAN_SI bins; with several chunks k_scan_sums first leaves every
+// One block per chunk of SCAN_TPB x SCAN_SI bins; with several chunks k_scan_sums first leaves every
 // chunk's total in `sums` and block b starts from the sum of the totals before it (the single-block
 // loop this replaces took 18 us per chunk in sequence: 90 us for the cylinder's 5 x 32769 bins).
-#define SCAN_SI 33u     // (1024 x 33 covers the 256 x 128 + 1 bins of one cylinder level in ONE chunk)
+// SCAN_TPB = 256 (round 4; was 1024 threads with 135 KB of LDS a block): in the first sub-step of a two-component master
+// step these small launches sit between the other stream's full-size passes, and a workgroup that needs sixteen free wave
+// slots and most of a CU's LDS at once waited 100 us (sphere, one block) and 260 us (cylinder, five) for a CU to drain;
+// four waves and 34 KB find room at once.
+#define SCAN_TPB 256u
+#define SCAN_NW (SCAN_TPB / 64u)
+#define SCAN_SI 33u     // bins per thread (odd: a thread's run of words in the LDS stage starts on its own bank)
 
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t x, uint32_t *wsum /* [16] */, uint32_t &total)
+__device__ __forceinline__ uint32_t block_scan_tpb(uint32_t x, uint32_t *wsum /* [SCAN_NW] */, uint32_t &total)
 {
-  // inclusive scan of one value per thread over a 1024-thread block
+  // inclusive scan of one value per thread over a SCAN_TPB-thread block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -103,55 +109,55 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t x, uint32_t *wsum /
   if (lane == 63) wsum[wave] = x;
   __syncthreads();
   if (wave == 0) {
-    uint32_t w = (lane < 16) ? wsum[lane] : 0u;
+    uint32_t w = (lane < (int)SCAN_NW) ? wsum[lane] : 0u;
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
+    for (int off = 1; off < (int)SCAN_NW; off <<= 1) {
       const uint32_t y = __shfl_up(w, off);
       if (lane >= off) w += y;
     }
-    if (lane < 16) wsum[lane] = w;           // inclusive prefix of the wave totals
+    if (lane < (int)SCAN_NW) wsum[lane] = w;           // inclusive prefix of the wave totals
   }
   __syncthreads();
-  total = wsum[15];
+  total = wsum[SCAN_NW - 1];
   return x + (wave ? wsum[wave - 1] : 0u);
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(SCAN_TPB)
 k_scan_sums(const uint32_t *__restrict__ hist, uint32_t k0, uint32_t k1, uint32_t *__restrict__ sums)
 {
-  __shared__ uint32_t wsum[16];
-  const uint32_t base = k0 + blockIdx.x * 1024u * SCAN_SI, top = min(k1, base + 1024u * SCAN_SI);
+  __shared__ uint32_t wsum[SCAN_NW];
+  const uint32_t base = k0 + blockIdx.x * SCAN_TPB * SCAN_SI, top = min(k1, base + SCAN_TPB * SCAN_SI);
   uint32_t s = 0;
-  for (uint32_t k = base + threadIdx.x; k < top; k += 1024u) s += hist[k];
+  for (uint32_t k = base + threadIdx.x; k < top; k += SCAN_TPB) s += hist[k];
   uint32_t total;
-  (void)block_scan_1024(s, wsum, total);
+  (void)block_scan_tpb(s, wsum, total);
   if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(SCAN_TPB)
 k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_off,
        uint32_t ncell, int nlev, int range_lo, int range_hi, const uint32_t *__restrict__ sums)
 {
-  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t wsum[SCAN_NW];
   const int t = threadIdx.x;
   const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
   const uint32_t k1 = (range_lo >= 0) ? (uint32_t)(range_hi + 1) * ncell : nkeys;
   uint32_t carry = (range_lo >= 0) ? lev_off[range_lo] : 0u;
   if (blockIdx.x) {                          // the chunks before this one
     uint32_t p = 0, tot;
-    for (uint32_t j = t; j < blockIdx.x; j += 1024u) p += sums[j];
-    (void)block_scan_1024(p, wsum, tot);
+    for (uint32_t j = t; j < blockIdx.x; j += SCAN_TPB) p += sums[j];
+    (void)block_scan_tpb(p, wsum, tot);
     carry += tot;
     __syncthreads();
   }
   // SCAN_SI consecutive bins per thread (the pass is barrier-latency bound: the cylinder's bins took 200 us at one
-  // bin per thread), staged through LDS so that the global loads and stores are coalesced: element j * 1024 + t in
+  // bin per thread), staged through LDS so that the global loads and stores are coalesced: element j * SCAN_TPB + t in
   // pass j; a thread's own run of SCAN_SI words starts at word t * SCAN_SI -- an odd stride, no bank conflicts.
-  __shared__ uint32_t stage[1024u * SCAN_SI];
-  const uint32_t cb = k0 + blockIdx.x * 1024u * SCAN_SI;           // first bin of this chunk
+  __shared__ uint32_t stage[SCAN_TPB * SCAN_SI];
+  const uint32_t cb = k0 + blockIdx.x * SCAN_TPB * SCAN_SI;           // first bin of this chunk
 #pragma unroll
   for (uint32_t j = 0; j < SCAN_SI; j++) {
-    const uint32_t e = j * 1024u + (uint32_t)t;
+    const uint32_t e = j * SCAN_TPB + (uint32_t)t;
     stage[e] = (cb + e < k1) ? hist[cb + e] : 0u;
   }
   __syncthreads();
@@ -159,7 +165,7 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
 #pragma unroll
   for (uint32_t j = 0; j < SCAN_SI; j++) { v[j] = stage[(uint32_t)t * SCAN_SI + j]; s += v[j]; }
   uint32_t total;
-  const uint32_t incl = block_scan_1024(s, wsum, total);
+  const uint32_t incl = block_scan_tpb(s, wsum, total);
   uint32_t excl = carry + (incl - s);
   // (a range of several levels re-partitions its slots: the inner level starts move)  next level boundary at or
   // after this thread's first bin -- one division here instead of a modulo per bin
@@ -176,7 +182,7 @@ k_scan(uint32_t *__restrict__ hist, uint32_t nkeys, uint32_t *__restrict__ lev_o
   __syncthreads();
 #pragma unroll
   for (uint32_t j = 0; j < SCAN_SI; j++) {
-    const uint32_t e = j * 1024u + (uint32_t)t;
+    const uint32_t e = j * SCAN_TPB + (uint32_t)t;
     if (cb + e < k1) hist[cb + e] = stage[e];
   }
   if (t == 0 && range_lo < 0 && blockIdx.x + 1 == gridDim.x) {
@@ -191,7 +197,7 @@ static int scan_launch(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_
 {
   const uint32_t k0 = (range_lo >= 0) ? (uint32_t)range_lo * ncell : 0u;
   const uint32_t k1 = (range_lo >= 0) ? (uint32_t)(range_hi + 1) * ncell : nkeys;
-  const uint32_t P = k1 > k0 ? (k1 - k0 + 1024u * SCAN_SI - 1u) / (1024u * SCAN_SI) : 1u;
+  const uint32_t P = k1 > k0 ? (k1 - k0 + SCAN_TPB * SCAN_SI - 1u) / (SCAN_TPB * SCAN_SI) : 1u;
   auto &SS = ctx->scan_sums[(ctx->aux && st == ctx->aux) ? 1 : 0];
   if (P > 1u) {
     if (SS.n < P) {
@@ -199,9 +205,9 @@ static int scan_launch(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, uint32_
       if (SS.alloc((size_t)P + 64) != hipSuccess)
         return expamd_fail(ctx, EXP_AMD_ERR_HIP, "scan: hipMalloc failed");
     }
-    k_scan_sums<<<P, 1024, 0, st>>>(hist, k0, k1, SS.p);
+    k_scan_sums<<<P, SCAN_TPB, 0, st>>>(hist, k0, k1, SS.p);
   }
-  k_scan<<<P, 1024, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_hi, P > 1u ? SS.p : nullptr);
+  k_scan<<<P, SCAN_TPB, 0, st>>>(hist, nkeys, lev_off, ncell, nlev, range_lo, range_hi, P > 1u ? SS.p : nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
