@@ -71,7 +71,7 @@ def _compare(tag, forces, comps, want, multistep):
     (100, 2048, 40), (-1, 16, 300)])
 def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin_max):
     """thin_max: the size of an active slot range up to which it is accumulated and evaluated straight from the basis
-    tables (runtime.Context.set_thin_max; 16384 = the default: with dense_min -1 EVERY sub-step of this small run takes
+    tables (runtime.Context.set_thin_max; 4096 = the default; 16384 here: with dense_min -1 EVERY sub-step of this small run takes
     the direct kernels of both bases -- k_sph_acc_thin / k_sph_force_thin, k_cyl_acc_thin / k_cyl_force_thin -- for the
     self forces and both cross forces; 0: never, the moment / projected-table path alone; 40 and 300: the two mixed, by
     sub-step).  dense_min: the level population below which a level is kept unsorted (runtime.Context.
@@ -113,7 +113,7 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin
     assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
     ctx.set_dense_min(-1)
     ctx.set_mover_list_min(2048)
-    ctx.set_thin_max(16384)
+    ctx.set_thin_max(4096)
 
 
 def test_config4_against_the_golden_file(ctx):
@@ -251,3 +251,35 @@ def test_three_components_deterministic_multistep(ctx, oracle):
         for key in ("pos", "vel", "acc", "pot"):
             assert np.array_equal(o[key], o2[key]), (k, key)          # bit for bit, run to run
         assert np.array_equal(lev, lev2)
+
+
+@pytest.mark.parametrize("thin_v", ["1", "2"])
+def test_thin_kernels_reproduce_the_table_path(ctx, monkeypatch, thin_v):
+    """The direct kernels of thin active sets (k_*_acc_thin, k_*_force_thin; EXP_AMD_THIN_V=2: their any-order formulation)
+    against the moment / projected-table path ON THE DEVICE: the same run with thin_max 0 and 16384 -- levels identical,
+    per-level sets, trajectories and accelerations to 1e-12 (the force kernels project the very rows the table would hold;
+    the sums differ in order only).  The bars against the oracle (1e-10 / 1e-9) are the parametrised test above."""
+    monkeypatch.setenv("EXP_AMD_THIN_V", thin_v)
+    z = c4.load_golden()
+    ms = int(z["multistep"])
+    runs = []
+    for tm in (0, 16384):
+        ctx.set_thin_max(tm)
+        sim, forces, comps = _device_run(ctx, z, ms, float(z["dtime"]), list(z["dynfrac"]))
+        sim.step(2)
+        out = []
+        for f, c in zip(forces, comps):
+            sets = [f.get_coefs(level=M) for M in range(ms + 1)]
+            sets = [np.concatenate([np.asarray(x).reshape(-1) for x in (s if isinstance(s, tuple) else (s,))]) for s in sets]
+            out.append((c.download_levels(), c.download(), np.stack(sets)))
+        runs.append(out)
+        sim.close()
+        for o in list(forces) + list(comps):
+            o.close()
+    ctx.set_thin_max(4096)
+    for (l0, d0, s0), (l1, d1, s1) in zip(*runs):
+        assert np.array_equal(l0, l1)
+        assert np.abs(s0 - s1).max() <= 1e-12 * np.abs(s0).max()
+        assert np.abs(d0["pos"] - d1["pos"]).max() <= 1e-13
+        for k in ("vel", "acc", "pot"):
+            assert np.abs(d0[k] - d1[k]).max() <= 1e-11 * np.abs(d0[k]).max(), k

@@ -35,7 +35,7 @@ def test_fuzz_multistep_slice():
     finally:
         m.ctx.set_dense_min(-1)
         m.ctx.set_mover_list_min(2048)
-        m.ctx.set_thin_max(16384)
+        m.ctx.set_thin_max(4096)
     bad = [(t, r) for t, r in enumerate(res) if r in ("LEVELS", "STATE")]
     assert not bad, f"fuzz_multistep failures (trial, kind) at seed {SEED}: {bad}"
     assert res.count("edge") <= 2, "more than a couple of power-of-two boundary cases: not rounding"
