@@ -712,8 +712,11 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
 template <int LMAX> __host__ __device__ constexpr bool acc_shared() { return LMAX >= 3 && LMAX <= 10; }
 template <int LMAX> __host__ __device__ constexpr int acc_bound(int k)
 {
+#ifndef ACC_B10
+#define ACC_B10 {2, 4, 6}
+#endif
   constexpr int B[11][3] = {{1, 1, 1}, {1, 1, 1}, {1, 2, 2}, {1, 2, 3}, {1, 2, 3}, {1, 2, 3},
-                            {1, 2, 4}, {1, 2, 4}, {2, 4, 6}, {2, 4, 6}, {2, 4, 6}};
+                            {1, 2, 4}, {1, 2, 4}, {2, 4, 6}, {2, 4, 6}, ACC_B10};
   return B[LMAX <= 10 ? LMAX : 10][k];
 }
 template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
@@ -762,8 +765,12 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
 #define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET, LIST>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out, al)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
-    if (wave == 0) RUNS(0, b1 - 1); else if (wave == 1) RUNS(b1, b2 - 1);
-    else if (wave == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
+    // (two A/B experiments of round 4, profiles/r04_accumulate_split_ab.txt: other m-splits -- a 36-row wave costs the
+    // second wave per SIMD, 4.5-6.3 ms --, and odd blocks taking the ranges in reverse order so that a SIMD's two waves
+    // would be one light and one heavy range: neutral, 3.03 against 3.01 ms)
+    const int role = wave;
+    if (role == 0) RUNS(0, b1 - 1); else if (role == 1) RUNS(b1, b2 - 1);
+    else if (role == 2) RUNS(b2, b3 - 1); else RUNS(b3, LMAX);
 #undef RUNS
     return;
   } else {
