@@ -39,6 +39,8 @@ struct exp_amd_comp {
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
+  size_t hist_clean = 0;       // leading entries of `hist` known to be zero (a range sort's last kernel leaves the bins it
+                               // used clean again: the next sort needs no memset)
   int nlevels = 1;                   // multistep + 1
   bool levels_zero = true;           // no slot has ever been given a level > 0 (both level arrays are 0)
   double center[3] = {0, 0, 0};

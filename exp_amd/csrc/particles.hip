@@ -288,8 +288,11 @@ int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
     c->hist_cap = (size_t)nkeys + 1;
+    c->hist_clean = 0;
   }
-  HIP_TRY(ctx, hipMemsetAsync(c->hist.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), ctx->stream));
+  if (c->hist_clean < (size_t)nkeys + 1)
+    HIP_TRY(ctx, hipMemsetAsync(c->hist.p, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), ctx->stream));
+  c->hist_clean = 0;           // (about to be counted into)
   return EXP_AMD_OK;
 }
 
@@ -443,10 +446,14 @@ struct CopySet {
   int narr;
 };
 
+// hist[hz0, hz1): the histogram bins this range sort used (offsets by now), zeroed on the way: the next sort of this
+// component then starts from a clean histogram without a memset (exp_amd_comp::hist_clean)
 __global__ void __launch_bounds__(TPB)
 k_copy_range(CopySet C, const uint32_t *__restrict__ lev_off, int level, int level_hi,
-             uint8_t *__restrict__ dlev, const uint8_t *__restrict__ slev)
+             uint8_t *__restrict__ dlev, const uint8_t *__restrict__ slev, uint32_t *__restrict__ hist, uint32_t hz0,
+             uint32_t hz1)
 {
+  for (size_t k = hz0 + (size_t)blockIdx.x * TPB + threadIdx.x; k < hz1; k += (size_t)gridDim.x * TPB) hist[k] = 0u;
   const size_t beg = lev_off[level], end = lev_off[level_hi + 1];
   const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= end) return;
@@ -504,9 +511,12 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     C.did = c->id[c->cur].p;
     C.sid = c->id[1 - c->cur].p;
     const bool many = level_hi > level;
+    // (range mode of the scan: only the bins of levels level..level_hi were populated, the rest is still zero)
+    const uint32_t hz0 = (uint32_t)level * ncell, hz1 = (uint32_t)(level_hi + 1) * ncell;
     k_copy_range<<<cdiv(nr, TPB), TPB, 0, ctx->stream>>>(
         C, c->lev_off.p, level, level_hi, many ? c->level[c->cur].p : nullptr,
-        many ? c->level[1 - c->cur].p : nullptr);
+        many ? c->level[1 - c->cur].p : nullptr, c->hist.p, hz0, hz1);
+    c->hist_clean = (size_t)nkeys + 1;
   }
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;

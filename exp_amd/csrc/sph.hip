@@ -873,6 +873,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
       HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
       c->hist_cap = (size_t)nkeys + 1;
     }
+    c->hist_clean = 0;
     c->nlevels = 1;
     c->lev_host_valid = false;
     have_keys = false;
@@ -881,6 +882,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_forced[1], V));
   }
   if (c->hist_cap < (size_t)nkeys + 1) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "split step: histogram too small");
+  c->hist_clean = 0;                 // (this path counts into the histogram with its own memsets)
   const size_t beg[2] = {0, c->half}, len[2] = {c->half, c->n - c->half};
 
   // ---- aux stream: the two sort chains (reading the live set, writing the other one)
