@@ -267,7 +267,10 @@ typedef struct {
   int    multistep;                    /* number of extra time-step levels (0 = none)  */
 } exp_amd_sph_config;
 
-/* xi[numr], p0[numr], ev[(lmax+1)*nmax], ef[(lmax+1)*nmax*numr] (ef(n,i) of table l) */
+/* xi[numr], p0[numr], ev[(lmax+1)*nmax], ef[(lmax+1)*nmax*numr] (ef(n,i) of table l).
+ * lmax: any order the reference's YAML may ask for (src/Sphere.cc:28-96), 0 <= lmax <= 64; up to 12 the per-particle
+ * kernels are unrolled at compile time, above that run-time-loop kernels take over (slower, same results;
+ * EXP_AMD_SPH_GENERIC=1 selects them at any order).  EXP_AMD_ERR_ARG outside that range.           */
 int  exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cfg,
                         const double *xi, const double *p0,
                         const double *ev, const double *ef, exp_amd_force **out);
@@ -347,7 +350,9 @@ typedef struct {
   int    multistep;
 } exp_amd_cyl_config;
 
-/* tab[6][mmax+1][nmax][numx+1][numy+1]: potC, rforceC, zforceC, potS, rforceS, zforceS */
+/* tab[6][mmax+1][nmax][numx+1][numy+1]: potC, rforceC, zforceC, potS, rforceS, zforceS.
+ * mmax: 0 <= mmax <= 64 (src/Cylinder.cc:473); unrolled kernels up to 12, run-time-loop kernels above
+ * (EXP_AMD_CYL_GENERIC=1: at any order).                                                            */
 int  exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
                         exp_amd_force **out);
 /* Mass of the particles inside the accumulation cut at the last accumulation (Cylinder's
