@@ -149,14 +149,17 @@ def test_generic_cylinder_kernels_reproduce_the_unrolled_ones(ctx, monkeypatch):
     assert np.abs(o0["pos"] - o1["pos"]).max() <= 1e-13
 
 
-def test_block_multistep_above_the_unrolled_range(ctx, oracle):
+@pytest.mark.parametrize("lmax,nmax,mmax,norder", [(13, 4, 13, 3), (10, 24, 6, 12)])
+def test_block_multistep_above_the_unrolled_range(ctx, oracle, lmax, nmax, mmax, norder):
     """The C++ step driver with both bases on the any-order kernels (lmax 13, mmax 13), two components, cross forces,
-    level changes: against the n-body oracle, bars of tests/test_config4_gpu.py."""
+    level changes: against the n-body oracle, bars of tests/test_config4_gpu.py.  Second case: the headline's orders
+    (lmax 10, nmax 24; mmax 6, nmax 12) -- unrolled kernels, but coefficient sets and projected rows large enough that
+    the thin kernels' tiles need more than 64 KB of LDS."""
     from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
     from tests import config4_util as c4
     from tests.oracle_lib import NBodyOracle
-    model, g = make_grid("plummer", 13, 4, 300)
-    cg = _cyl_grid(13, 3)
+    model, g = make_grid("plummer", lmax, nmax, 300)
+    cg = _cyl_grid(mmax, norder)
     inp = c4.config4_inputs(n_halo=700, n_disk=500)
     ms, dtime, dyn = 3, c4.DTIME, list(c4.DYN)
     sc = float(inp["scale"])
