@@ -753,7 +753,11 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
                          f->d_rowmap.p, f->d_tscale.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX),
                          t->a(A_VY), t->a(A_VZ), assign ? 1 : 0, nthin, ctx->stream};
       static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
-      if (thin_v == 1 && !f->generic) k_thin_force_launch[f->cfg.lmax](a); else expamd_sph_thin_force_gen(a);
+      // (the tiled kernel keeps the coefficient set and four particles' rows in LDS: where that does not fit -- very large
+      // nmax -- the one-wave-per-particle kernel, which uses none, takes over)
+      const size_t tq_ = 4 * (size_t)f->dev.trows + 16, lsn_ = (size_t)(f->cfg.lmax + 1) * f->cfg.nmax;
+      const bool fits = (f->ncoef + 2 + 4 * (tq_ + 3 * lsn_)) * sizeof(double) <= 120 * 1024;
+      if (thin_v == 1 && !f->generic && fits) k_thin_force_launch[f->cfg.lmax](a); else expamd_sph_thin_force_gen(a);
       HIP_TRY(ctx, hipGetLastError());
     }
     t->acc_live = true;
