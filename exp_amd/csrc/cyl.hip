@@ -1530,6 +1530,120 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
   }
 }
 
+// Level-change differencing of FEW movers (multistep_update, src/CylEXP.cc:45-157), direct: tiles over the mover list;
+// a mover adds its contribution to the set of its proposed level and takes it out of its level's set (levels >= mfirst
+// only).  Window of k_cyl_mstep_update with plain = 0: the grid window, z clamped to the table, no rcylmax cut, no tally.
+// Sums into part[level - mfirst][seg][ncoef] (zero on entry), finished by k_cyl_contract_sum (add_to = expcoefN).
+template <int MMAX>
+__global__ void __launch_bounds__(256)
+k_cyl_diff_thin(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                const double *__restrict__ M, const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, int mfirst, int nlev_out,
+                const double *__restrict__ tabT, int nk, double *__restrict__ part)
+{
+  extern __shared__ __attribute__((aligned(16))) double cthin_lds[];
+  constexpr int NT = 2 * MMAX + 1;
+  constexpr int TPA = 8;
+  __shared__ int s_node[TPA], s_from[TPA], s_to[TPA];
+  __shared__ double s_cw[TPA][4], s_trig[TPA][NT + 1];
+  const int half = (C.mmax + 1) * C.nmax, ncoef = 2 * half;
+  const int nset = nk == 3 ? 1 : 2;
+  double *pe = cthin_lds;                                           // [TPA][nset][half]
+  const size_t count = cnt[1];
+  const int seg = blockIdx.x % CYL_CSEG;
+  const int t = threadIdx.x;
+  const int nyp = C.numy + 1;
+  const size_t per_node = (size_t)nk * half;
+  for (size_t base = (size_t)blockIdx.x * TPA; base < count; base += (size_t)gridDim.x * TPA) {
+    const int np = (int)((count - base) < (size_t)TPA ? (count - base) : (size_t)TPA);
+    if (t < TPA) {
+      const bool valid = t < np;
+      double xx = 1, yy = 0, zz = 0, mass = 0;
+      int from = -1, to = -1;
+      if (valid) {
+        const uint32_t i = list[base + t];
+        cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
+        mass = M[i];
+        from = lev[i]; to = newlev[i];
+      }
+      const double r2 = xx * xx + yy * yy;
+      double r, ir;
+      sqrt_rsqrt(r2, r, ir);
+      const bool on = valid && !(sqrt(r2 + zz * zz) > C.rtab_abs);
+      double zc = zz;
+      if (zc > C.rtab_abs) zc = C.rtab_abs;
+      if (zc < -C.rtab_abs) zc = -C.rtab_abs;
+      int ix, iy;
+      double cw[4];
+      cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
+      double cphi = 1.0, sphi = 0.0;
+      if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      const double t0 = on ? -4.0 * M_PI * mass : 0.0;
+      s_node[t] = on ? ix * nyp + iy : -1;
+      s_to[t] = on ? to : -1;
+      s_from[t] = (on && from >= mfirst) ? from : -1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) s_cw[t][k] = cw[k];
+      double cm = 1.0, sm = 0.0;
+      s_trig[t][0] = t0;
+#pragma unroll
+      for (int m = 1; m <= MMAX; m++) {
+        const double cn = cm * cphi - sm * sphi, sn = sm * cphi + cm * sphi;
+        cm = cn; sm = sn;
+        const bool m_on = !(C.EVEN_M && (m & 1));
+        s_trig[t][2 * m - 1] = m_on ? t0 * cm : 0.0;
+        s_trig[t][2 * m] = m_on ? t0 * sm : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int it0 = threadIdx.x; it0 < np * nset * half; it0 += 3 * 256) {
+      double tv[3][4];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int it = it0 + u * 256;
+        tv[u][0] = tv[u][1] = tv[u][2] = tv[u][3] = 0.0;
+        if (it < np * nset * half) {
+          const int p = it / (nset * half);
+          const int rest = it - p * nset * half;
+          const int set = rest / half, mn = rest - set * half;
+          const int node0 = s_node[p];
+          if (node0 >= 0) {
+            const double *T = tabT + (size_t)node0 * per_node + (size_t)(set ? 3 : 0) * half + mn;
+            tv[u][0] = T[0]; tv[u][1] = T[(size_t)nyp * per_node]; tv[u][2] = T[per_node]; tv[u][3] = T[(size_t)(nyp + 1) * per_node];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int it = it0 + u * 256;
+        if (it < np * nset * half) {
+          const int p = it / (nset * half);
+          pe[it] = s_cw[p][0] * tv[u][0] + s_cw[p][1] * tv[u][1] + s_cw[p][2] * tv[u][2] + s_cw[p][3] * tv[u][3];
+        }
+      }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < ncoef; o += 256) {
+      const int cs = o / half, mn = o - cs * half, m = mn / C.nmax;
+      if (cs && m == 0) continue;                                  // (sin, m = 0): no such row
+      const int jt = m == 0 ? 0 : 2 * m - 1 + cs;
+      const int set = (cs && nset == 2) ? 1 : 0;
+      double v[TPA];
+#pragma unroll
+      for (int p = 0; p < TPA; p++) v[p] = p < np ? s_trig[p][jt] * pe[((size_t)p * nset + set) * half + mn] : 0.0;
+      for (int L = 0; L < nlev_out; L++) {
+        const int level = mfirst + L;
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < TPA; p++)
+          if (p < np) acc += (s_to[p] == level ? v[p] : 0.0) - (s_from[p] == level ? v[p] : 0.0);
+        if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)L * CYL_CSEG + seg) * ncoef + o, acc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- thin active sets, second formulation (round 4; any azimuthal order) ----------------------------------------------
 // k_cyl_force_wave: one WAVE per particle.  The lanes own the items (corner k, kind, m) of accumulated_eval's sums: each
 // forms its node-row entries sum_n tab[kind][m][n][node_k] {cos, sin}[m][n] (the sums of k_cyl_project, from the node-major
@@ -2178,6 +2292,25 @@ static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const
                                                                                                  nk, part, tail, tpa);
 }
 
+template <int MM>
+static void cyl_thin_diff_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
+                                 const double *M, const uint32_t *list, const uint32_t *cnt, const uint8_t *lev,
+                                 const uint8_t *newlev, int mfirst, int nl, const double *tabT, int nk, double *part)
+{
+  const size_t half = (size_t)(C.mmax + 1) * C.nmax;
+  const int nset = nk == 3 ? 1 : 2;
+  size_t grid = cdiv(n, (size_t)8);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_diff_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_cyl_diff_thin<MM><<<(unsigned)grid, 256, (size_t)8 * nset * half * sizeof(double), st>>>(C, X, Y, Z, M, list, cnt, lev, newlev,
+                                                                                              mfirst, nl, tabT, nk, part);
+}
+
 static int cyl_thin_version()
 {
   static const int v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
@@ -2311,8 +2444,27 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // (k_mover_list, 16 slots per thread), so that the differencing launches over the movers, not over the range
   const bool listed = nr && c->mover_hint >= 0;
   if (listed && c->mover_hint > 0) { int rc_ = expamd_comp_mover_list(c, first, ms, (size_t)c->mover_hint); if (rc_) return rc_; }
+  static const bool thin_diff_on = [] { const char *e = getenv("EXP_AMD_THIN_DIFF"); return !e || atoi(e) != 0; }();
+  const bool few = listed && c->mover_hint > 0 && !(ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min);
+  const bool thin_diff = few && thin_diff_on && ctx->thin_max > 0 && c->mover_hint <= ctx->thin_max && !ctx->deterministic &&
+                         !f->generic && (size_t)8 * 2 * (cfg.mmax + 1) * cfg.nmax * sizeof(double) <= 96 * 1024;
   if (listed && c->mover_hint == 0) {
     // nothing moved on this rank (it only takes part in the reduction)
+  } else if (thin_diff) {
+    // few movers, straight from the basis tables into the contraction's stage-1 sums (k_cyl_diff_thin): no node moments,
+    // no pass over the nodes of every level
+    ProfScope ps(ctx, "k_cyl_diff_thin");
+    { int rc_ = ensure_tabT(); if (rc_) return rc_; }
+    if (!f->cpart_clean) {
+      HIP_TRY(ctx, hipMemsetAsync(f->d_cpart.p, 0, f->d_cpart.bytes(), ctx->stream));
+      f->cpart_clean = true;
+    }
+#define CALL(MM)                                                                                                   \
+  cyl_thin_diff_launch<MM>(ctx->stream, (size_t)c->mover_hint, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M),      \
+                           c->mover_list.p, c->mover_cnt, c->level[c->cur].p, c->newlev.p, mfirst_mdrft, nl,      \
+                           f->d_tabT.p, f->tabT_nk, f->d_cpart.p)
+    MMAX_DISPATCH(cfg.mmax, CALL)
+#undef CALL
   } else if (listed && ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min && !f->generic) {
     // many movers: through the accumulation kernel (CylAccList)
     ProfScope ps(ctx, "k_cyl_mstep_update");
@@ -2358,7 +2510,7 @@ int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;
   cyl_contract(ctx->stream, C, f->d_tab.p, f->d_Wnd.p + (size_t)mfirst_mdrft * wl, f->d_cpart.p,
                f->d_differ.p + (size_t)mfirst_mdrft * f->ncoef_dev, nl, f->ncoef_dev, nullptr, /*clear=*/1,
-               alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef_dev : nullptr);
+               alone ? f->d_coefN.p + (size_t)mfirst_mdrft * f->ncoef_dev : nullptr, nullptr, thin_diff);
   HIP_TRY(ctx, hipGetLastError());
   if (alone) return EXP_AMD_OK;
   const size_t cnt = (size_t)nl * f->ncoef_dev;
@@ -2470,6 +2622,10 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
     c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
+    // (a closing half-kick still owed rides along with the pass that advances its levels)
+    if (c->pending_kick != 0.0 && (!adv.mode || dmax >= lo) &&
+        (rc = adv.mode ? expamd_comp_settle_pending(c, lo, dmax, true) : expamd_comp_settle_pending(c, 0, ms, false)))
+      return rc;
     if (dmax >= lo) {
       rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
       if (rc) return rc;

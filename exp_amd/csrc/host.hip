@@ -8,6 +8,7 @@
 #include "sort_kernels.h"
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 struct exp_amd_sim {
@@ -32,6 +33,10 @@ struct exp_amd_sim {
   bool defer_resort = true;               // EXP_AMD_SIM_DEFER_RESORT=0: re-order right after every sweep with level changes
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
+  unsigned long long *pinned_dev = nullptr;   // the device's address of it (k_kick_adjust's last block writes there)
+  unsigned long long pub_seq = 0;         // sequence number of the counters last handed over that way
+  bool publish = true;                    // EXP_AMD_SIM_PUBLISH=0: copy + stream wait instead
+  bool sweep_lists = true;                // EXP_AMD_SIM_SWEEP_LISTS=0: the movers are compacted by a pass of their own
   // Two-stream sub-steps: everything that touches the particles of component k is issued on stream
   // k & 1 (the context's stream / its auxiliary stream).  The small launches of a sub-step are
   // latency-bound, so the two components' chains fill each other's gaps.  Events carry the cross
@@ -421,18 +426,36 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
   if (s->pinned_cap < nc) {
     if (s->pinned) (void)hipHostFree(s->pinned);
     s->pinned = nullptr;
-    HIP_TRY(ctx, hipHostMalloc((void **)&s->pinned, nc * 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    // (40 words a component: 32 counters, the sequence number, padding; coherent = visible to the polling host while
+    // the stream runs on)
+    HIP_TRY(ctx, hipHostMalloc((void **)&s->pinned, nc * 40 * sizeof(unsigned long long),
+                               hipHostMallocMapped | hipHostMallocCoherent));
+    memset(s->pinned, 0, nc * 40 * sizeof(unsigned long long));
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&s->pinned_dev, s->pinned, 0));
     s->pinned_cap = nc;
+    static const bool pub = [] { const char *e = getenv("EXP_AMD_SIM_PUBLISH"); return !e || atoi(e) != 0; }();
+    s->publish = pub;
+    static const bool sl = [] { const char *e = getenv("EXP_AMD_SIM_SWEEP_LISTS"); return !e || atoi(e) != 0; }();
+    s->sweep_lists = sl;
   }
+  const bool publish = s->publish && !s->host_timing;
   int rc;
   // (sweep_is_noop: the closing kick alone -- the host goes straight on to the next sub-step's launches; the streams stay
   // ordered among themselves, nothing is differenced, committed or re-ordered because nothing changed)
   if (kick && sweep_is_noop(s, mdrft, first_step)) {
     const double th0 = s->host_timing ? host_now() : 0.0;
+    static const bool fold = [] { const char *e = getenv("EXP_AMD_SIM_FOLD_KICK"); return !e || atoi(e) != 0; }();
     for (size_t k = 0; k < nc; k++) {
       StreamOf on(s, k);
+      exp_amd_comp *c = s->comps[k];
+      // ... and the closing kick itself -- of the top level alone, DT(multistep)/2 = dt_min/2 -- is left to the advance
+      // of the next sub-step, which applies it first, as its own rounding step (exp_amd_comp::pending_kick / pending_lo)
+      if (fold && c->nlevels == ms + 1 && c->pending_kick == 0.0) {
+        if (c->n) { c->pending_kick = 0.5 * dt_min; c->pending_lo = ms; }
+        continue;
+      }
       const unsigned long long *res = nullptr;
-      if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf, mf, /*first=*/ms + 1,
+      if ((rc = expamd_comp_kick_adjust(c, s->dtime, s->dynfrac, s->shiftlevl, ms, mf, mf, /*first=*/ms + 1,
                                         dt_min, &res))) return rc;
       if (s->host_timing && s->overlap && s->ht_ev0 && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
     }
@@ -441,18 +464,55 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     return EXP_AMD_OK;
   }
   const double th0 = s->host_timing ? host_now() : 0.0;
+  std::vector<unsigned long long> want(nc, 0ull);
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
     const unsigned long long *res = nullptr;
+    bool launched = false;
+    if (((++s->pub_seq) & 0xffffffull) == 0) ++s->pub_seq;       // (the tag of a word never written)
+    const unsigned long long seq = s->pub_seq & 0xffffffull;
     if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
-                                      kick ? mf : ms + 1, first, dt_min, &res))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 32, res, 32 * sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, ctx->stream));
+                                      kick ? mf : ms + 1, first, dt_min, &res, publish ? s->pinned_dev + k * 40 : nullptr,
+                                      seq, &launched, s->sweep_lists))) return rc;
+    if (publish) {
+      if (launched) want[k] = seq;
+      else memset(s->pinned + k * 40, 0, 32 * sizeof(unsigned long long));      // (nothing in the range: no counts)
+    } else
+      HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 40, res, 32 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx->stream));
     if (s->host_timing && s->overlap && s->ht_ev0 && kick && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
   }
   const double th1 = s->host_timing ? host_now() : 0.0;
-  if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (publish) {
+    // poll the tags; the streams themselves are asked now and then, so that a failed launch ends the wait
+    for (size_t k = 0; k < nc; k++) {
+      if (!want[k]) continue;
+      unsigned long long *w = s->pinned + k * 40;
+      unsigned long spins = 0;
+      auto all_there = [&] {
+        for (int q = 0; q < 32; q++) if ((__atomic_load_n(w + q, __ATOMIC_RELAXED) >> 40) != want[k]) return false;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return true;
+      };
+      while (!all_there()) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {
+          StreamOf on(s, k);
+          const hipError_t e = hipStreamQuery(ctx->stream);
+          if (e == hipSuccess) {                 // (everything ran: the words are there, or never will be)
+            if (all_there()) break;
+            return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: the level counters did not arrive");
+          }
+          if (e != hipErrorNotReady) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: %s", hipGetErrorString(e));
+        }
+      }
+    }
+    for (size_t k = 0; k < nc; k++)
+      if (want[k]) for (int q = 0; q < 32; q++) s->pinned[k * 40 + q] &= 0xffffffffffull;
+  } else {
+    if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   const double th2 = s->host_timing ? host_now() : 0.0;
   if (s->host_timing && s->overlap && s->ht_ev0 && kick && nc == 2)
     for (int k = 0; k < 2; k++) {
@@ -471,7 +531,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     StreamOf on(s, k);
     exp_amd_comp *c = s->comps[k];
     exp_amd_force *f = s->forces[k];
-    const unsigned long long *res = s->pinned + k * 32;
+    const unsigned long long *res = s->pinned + k * 40;
     const unsigned long long u = res[0];
     s->last_switch += (long long)u;
     s->step_switch += (long long)u;
@@ -480,6 +540,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     if (ctx->nranks > 1 || ctx->ar_fn || u)
       if ((rc = f->multistep_update(c, first, mf))) return rc;
     c->mover_hint = -1;
+    c->mover_list_built = false;
     if (u) {
       const bool ordered = c->sorted_for == (const void *)f && c->nlevels == ms + 1;
       const bool mirror = ordered && c->lev_host_valid;

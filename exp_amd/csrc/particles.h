@@ -36,6 +36,7 @@ struct exp_amd_comp {
   DevBuf<uint32_t> mover_list, mover_cnt_buf; // slots of the movers; two {0, how many} pairs used alternately
   uint32_t *mover_cnt = nullptr;              // the pair of the last compaction: plays lev_off for the kernels
   int mover_flip = 0;
+  bool mover_list_built = false;              // k_kick_adjust has compacted the last sweep's movers itself
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
@@ -83,6 +84,8 @@ struct exp_amd_comp {
   // a write of v there); it is remembered here and applied, as its own rounding step, inside the
   // next fused step's scatter pass -- or by expamd_comp_touch() before anything else looks.
   double pending_kick = 0.0;
+  int pending_lo = 0;                   // ... owed by the levels >= this only (the closing kick of a block-multistep sweep that
+                                        // could not move anything: folded into the next sub-step's advance)
   const void *prekey_owner = nullptr;   // force whose cells the keys are
   unsigned long long prekey_epoch = 0;  // ctx->force_epoch when they were written
   double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
@@ -115,6 +118,7 @@ void expamd_forget_component(exp_amd_ctx *ctx, const exp_amd_comp *c);
 void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh);
 // kick DT(M)/2 + drift DT(M) in place for the levels [lo, hi] (no reorder): sparse levels
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep);
+int expamd_comp_settle_pending(exp_amd_comp *c, int lo, int hi, bool advancing);
 
 // slots of the particles of levels [first, last] whose proposed level (newlev) differs from their level, in slot order
 // within blocks of 256 slots: c->mover_list, c->mover_cnt = {0, count}; capacity = the expected count

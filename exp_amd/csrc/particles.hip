@@ -50,15 +50,24 @@ k_advance_levels(double *__restrict__ x, double *__restrict__ y, double *__restr
                  double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
                  const double *__restrict__ ax, const double *__restrict__ ay,
                  const double *__restrict__ az, const uint8_t *__restrict__ lev,
-                 const uint32_t *__restrict__ lev_off, int lo, int hi, double dt_min, int multistep)
+                 const uint32_t *__restrict__ lev_off, int lo, int hi, double dt_min, int multistep,
+                 double dt_kick0 /* a closing half-kick still owed by the levels >= kick0_lo: applied first */, int kick0_lo)
 {
   const size_t beg = lev_off[lo], end = lev_off[hi + 1];
   for (size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x; i < end;
        i += (size_t)gridDim.x * TPB) {
-    const double dtd = level_dt(dt_min, multistep, lev[i]), dtk = 0.5 * dtd;
-    const double u = mul_then_add(vx[i], ax[i], dtk);
-    const double v = mul_then_add(vy[i], ay[i], dtk);
-    const double w = mul_then_add(vz[i], az[i], dtk);
+    const int L = lev[i];
+    const double dtd = level_dt(dt_min, multistep, L), dtk = 0.5 * dtd;
+    double u = vx[i], v = vy[i], w = vz[i];
+    const double a0 = ax[i], a1 = ay[i], a2 = az[i];
+    if (dt_kick0 != 0.0 && L >= kick0_lo) {
+      u = mul_then_add(u, a0, dt_kick0);
+      v = mul_then_add(v, a1, dt_kick0);
+      w = mul_then_add(w, a2, dt_kick0);
+    }
+    u = mul_then_add(u, a0, dtk);
+    v = mul_then_add(v, a1, dtk);
+    w = mul_then_add(w, a2, dtk);
     vx[i] = u; vy[i] = v; vz[i] = w;
     x[i] = mul_then_add(x[i], u, dtd);
     y[i] = mul_then_add(y[i], v, dtd);
@@ -320,16 +329,38 @@ void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh)
   }
 }
 
+// before a pass that advances the levels [lo, hi] with the half-kick owed folded in: it must hold all of the owing
+// levels [pending_lo, top] or none of them -- otherwise the kick is applied now, by a launch of its own
+int expamd_comp_settle_pending(exp_amd_comp *c, int lo, int hi, bool advancing)
+{
+  if (c->pending_kick == 0.0) return EXP_AMD_OK;
+  const int top = c->nlevels - 1;
+  const bool all = lo <= c->pending_lo && hi >= top, none = hi < c->pending_lo;
+  if (advancing && (all || none)) return EXP_AMD_OK;
+  if (!advancing && none) return EXP_AMD_OK;
+  return expamd_comp_apply_pending(c);
+}
+
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep)
 {
   size_t nr = 0;
   int rc = expamd_comp_level_count(c, lo, hi, &nr);
   if (rc) return rc;
+  // a closing half-kick still owed (pending_kick, levels >= pending_lo): taken along when this range holds all of those
+  // levels, left alone when it holds none of them, applied by a launch of its own otherwise
+  double k0 = 0.0;
+  int k0lo = 0;
+  bool settle = false;
+  if (c->pending_kick != 0.0) {
+    if (lo <= c->pending_lo && hi >= c->nlevels - 1) { k0 = c->pending_kick; k0lo = c->pending_lo; settle = true; }
+    else if (hi >= c->pending_lo && (rc = expamd_comp_apply_pending(c))) return rc;
+  }
+  if (settle) { c->pending_kick = 0.0; c->pending_lo = 0; }
   if (nr == 0) return EXP_AMD_OK;
   ProfScope ps(c->ctx, "k_advance_levels");
   k_advance_levels<<<stream_grid(c->ctx, nr), TPB, 0, c->ctx->stream>>>(
       c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
-      c->a(A_AZ), c->level[c->cur].p, c->lev_off.p, lo, hi, dt_min, multistep);
+      c->a(A_AZ), c->level[c->cur].p, c->lev_off.p, lo, hi, dt_min, multistep, k0, k0lo);
   HIP_TRY(c->ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
@@ -395,14 +426,17 @@ int expamd_comp_apply_pending(exp_amd_comp *c)
 {
   if (c->pending_kick != 0.0 && c->n) {
     const double dt = c->pending_kick;
+    const int lo = c->pending_lo < c->nlevels ? c->pending_lo : 0;
     c->pending_kick = 0.0;
+    c->pending_lo = 0;
     ProfScope ps(c->ctx, "k_kick");
     k_kick<<<stream_grid(c->ctx, c->n), TPB, 0, c->ctx->stream>>>(
-        c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->lev_off.p, 0,
+        c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->lev_off.p, lo,
         c->nlevels - 1, dt);
     HIP_TRY(c->ctx, hipGetLastError());
   }
   c->pending_kick = 0.0;
+  c->pending_lo = 0;
   return EXP_AMD_OK;
 }
 
@@ -415,6 +449,7 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv)
   A.lev = c->level[c->cur].p;
   A.dt_kick = adv.dt_kick; A.dt_drift = adv.dt_drift;
   A.dt_kick0 = adv.mode ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
+  A.kick0_lo = c->pending_lo;
   // ... or the opposite: that force pass stored the velocities with THIS opening half-kick applied already
   // (pending_kick == -dt_kick, set together with the step's sort keys): nothing left to kick
   A.nokick = (adv.mode == 1 && c->pending_kick != 0.0 && c->pending_kick == -adv.dt_kick) ? 1 : 0;
@@ -495,7 +530,13 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
       k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (advance) c->pending_kick = 0.0;      // the scatter applied it ahead of its own kick
+  // the scatter applied the half-kick still owed ahead of its own kick (a range sort: to the levels it holds -- callers
+  // see to it that those are all of the owing levels or none, expamd_comp_settle_pending)
+  if (advance && (level < 0 || c->pending_lo == 0 ||
+                  (level <= c->pending_lo && (level_hi > level ? level_hi : level) >= c->nlevels - 1))) {
+    c->pending_kick = 0.0;
+    c->pending_lo = 0;
+  }
   if (level < 0) {
     c->split = false;                      // one global order again
     c->cur = 1 - c->cur;
@@ -598,12 +639,20 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
               const double *__restrict__ az, const double *__restrict__ pot,
               const uint8_t *__restrict__ lev, uint8_t *__restrict__ newlev,
               const uint32_t *__restrict__ lev_off, int kick_lo, int first, int last, double dt_min,
-              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next, int items)
+              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next, int items,
+              unsigned int *__restrict__ ticket = nullptr, unsigned long long *__restrict__ host_out = nullptr,
+              unsigned long long seq = 0ull,
+              uint32_t *__restrict__ list = nullptr /* the movers' slots are compacted here as well (k_mover_list's job) */,
+              uint32_t *__restrict__ lcnt = nullptr, uint32_t *__restrict__ lcnt_next = nullptr)
 {
   // two counter sets are used alternately: this launch leaves the other one clean for the next
   if (blockIdx.x == 0 && threadIdx.x < 32) out_next[threadIdx.x] = 0ull;
+  if (list && blockIdx.x == 0 && threadIdx.x == 0) { lcnt_next[0] = 0u; lcnt_next[1] = 0u; }
   __shared__ unsigned int cnt[32];
+  __shared__ uint32_t s_ml[KA_ITEMS * TPB];      // the block's movers: one claim of the list per block
+  __shared__ unsigned int s_mln, s_mlbase;
   if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_mln = 0;
   __syncthreads();
   const int lo = kick_lo < first ? kick_lo : first;
   const size_t beg = lev_off[lo], end = lev_off[last + 1], ebeg = lev_off[first];
@@ -660,12 +709,45 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
     // wave-aggregated counters in LDS: one add per wave and value
     const unsigned long long sw = __ballot(examined && nlev != plev);
     if (lane == 0 && sw) atomicAdd(&cnt[0], (unsigned)__popcll(sw));
+    if (list && sw) {                           // (wave-uniform)
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(&s_mln, (unsigned)__popcll(sw));
+      base = (unsigned int)__shfl((int)base, 0);
+      if ((sw >> lane) & 1ull) s_ml[base + __popcll(sw & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
     for (int L = A.mfirst_mdrft; L <= A.multistep; L++) {
       const unsigned long long mm = __ballot(examined && (int)nlev == L);
       if (lane == 0 && mm) atomicAdd(&cnt[1 + L], (unsigned)__popcll(mm));
     }
   }
   __syncthreads();
+  if (list && s_mln) {                          // (block-uniform)
+    if (threadIdx.x == 0) s_mlbase = atomicAdd(lcnt + 1, s_mln);
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < s_mln; k += TPB) list[s_mlbase + k] = s_ml[k];
+  }
+  // host_out: the LAST block to finish hands the 32 counters to the host itself -- page-locked, host-coherent words, each
+  // tagged with the sweep's sequence number, which the step driver polls (no copy launch behind the kernel, no stream
+  // wait).  The counters are only ever touched by device-scope atomics, performed at the memory side: the adds RETURN
+  // (so they are done before the ticket is drawn) and the last block reads them with atomics too -- no fence, whose
+  // agent-scope form writes the whole L2 back on this multi-die part.
+  if (host_out) {
+    __shared__ unsigned int s_last;
+    unsigned long long got = 0ull;
+    if (threadIdx.x < 32 && cnt[threadIdx.x]) got = atomicAdd(out + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
+    // (the barrier's wait covers the returns of this wave's adds)
+    asm volatile("" ::"v"(got));
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x < 32) {
+      const unsigned long long v = atomicAdd(out + threadIdx.x, 0ull);
+      __hip_atomic_store(host_out + threadIdx.x, (seq << 40) | (v & 0xffffffffffull), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) atomicExch(ticket, 0u);
+    }
+    return;
+  }
   if (threadIdx.x < 32 && cnt[threadIdx.x]) atomicAdd(out + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
 }
 
@@ -752,6 +834,7 @@ k_mover_list(const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev
 int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected)
 {
   exp_amd_ctx *ctx = c->ctx;
+  if (c->mover_list_built) return EXP_AMD_OK;      // (k_kick_adjust did it: c->mover_cnt is its pair)
   // two {0, count} pairs used alternately: a call clears the pair the next one will count into (no memset in between)
   if (c->mover_cnt_buf.n == 0) {
     HIP_TRY(ctx, c->mover_cnt_buf.alloc(4));
@@ -779,24 +862,50 @@ int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected
 // (u64[32]: level changes, then the proposals per level)
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                             int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
-                            const unsigned long long **result)
+                            const unsigned long long **result, unsigned long long *host_out, unsigned long long seq,
+                            bool *launched, bool build_list)
 {
   exp_amd_ctx *ctx = c->ctx;
   unsigned long long *out = c->nswitch.p + 32 * c->nsw_flip, *nxt = c->nswitch.p + 32 * (1 - c->nsw_flip);
   *result = out;
+  if (launched) *launched = false;
   const int lo = kick_lo < first ? kick_lo : first;
   size_t nr = 0;
   if (c->n) { int rc = expamd_comp_level_count(c, lo, multistep, &nr); if (rc) return rc; }
   if (nr == 0) return EXP_AMD_OK;        // (the set stays clean and is used again)
   AdjustArgs A{dtime, dynfrac[0], dynfrac[1], dynfrac[2], dynfrac[3], dynfrac[4], multistep,
                shiftlevl, mfirst_mdrft};
+  // build_list: the slots of the movers are compacted by the sweep itself (room for every examined slot)
+  uint32_t *lcnt = nullptr, *lnxt = nullptr;
+  c->mover_list_built = false;
+  if (build_list && first <= multistep) {
+    size_t ne = 0;
+    { int rc = expamd_comp_level_count(c, first, multistep, &ne); if (rc) return rc; }
+    if (c->mover_cnt_buf.n == 0) {
+      HIP_TRY(ctx, c->mover_cnt_buf.alloc(4));
+      HIP_TRY(ctx, hipMemsetAsync(c->mover_cnt_buf.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+      c->mover_flip = 0;
+    }
+    if (c->mover_list.n < ne) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      c->mover_list.release();
+      HIP_TRY(ctx, c->mover_list.alloc(c->n > ne ? c->n : ne));
+    }
+    lcnt = c->mover_cnt_buf.p + 2 * c->mover_flip;
+    lnxt = c->mover_cnt_buf.p + 2 * (1 - c->mover_flip);
+    c->mover_cnt = lcnt;
+    c->mover_flip ^= 1;
+    c->mover_list_built = true;
+  }
   ProfScope ps(ctx, "k_kick_adjust");
   const size_t tiles = cdiv(nr, (size_t)TPB);
   const int items = tiles >= 4096 * KA_ITEMS ? KA_ITEMS : (int)(tiles / 4096 > 1 ? tiles / 4096 : 1);
   k_kick_adjust<<<cdiv(tiles, (size_t)items), TPB, 0, ctx->stream>>>(
       A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items);
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items,
+      (unsigned int *)(c->nswitch.p + 70), host_out, seq, lcnt ? c->mover_list.p : nullptr, lcnt, lnxt);
   HIP_TRY(ctx, hipGetLastError());
+  if (launched) *launched = true;
   c->nsw_flip ^= 1;
   return EXP_AMD_OK;
 }

@@ -31,6 +31,7 @@ struct AdvanceArgs {
   const uint8_t *lev;
   double dt_kick, dt_drift;    // 0,0 -> positions are used as they are
   double dt_kick0;             // deferred half-kick of the previous fused step, applied first (0: none)
+  int kick0_lo;                // ... to the particles of levels >= this (exp_amd_comp::pending_lo; 0: all, levels not read)
   int advance;                 // 0: none; 1: dt_kick / dt_drift; 2: per-level steps of a block-multistep
                                // sub-step: drift DT(M) = dt_min * 2^(multistep - M), kick DT(M)/2
                                // (src/step.cc:115-160: dt*mintvl[M]; exact power-of-two scalings)
@@ -66,7 +67,7 @@ __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, doub
     }
     if (!A.nokick) {
       const double ax = A.ax[i], ay = A.ay[i], az = A.az[i];
-      if (A.dt_kick0 != 0.0) {       // its own rounding step, exactly as the separate kick would be
+      if (A.dt_kick0 != 0.0 && (A.kick0_lo == 0 || (int)A.lev[i] >= A.kick0_lo)) {   // its own rounding step, as the separate kick
         vx = mul_then_add(vx, ax, A.dt_kick0);
         vy = mul_then_add(vy, ay, A.dt_kick0);
         vz = mul_then_add(vz, az, A.dt_kick0);
@@ -310,5 +311,8 @@ int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfr
 int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg = 0);
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                             int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
-                            const unsigned long long **result);
+                            const unsigned long long **result, unsigned long long *host_out = nullptr,
+                            unsigned long long seq = 0ull, bool *launched = nullptr, bool build_list = false);
+// (host_out: device address of 33 page-locked, host-coherent words -- the counters and, behind them, `seq` once they
+// are all there: k_kick_adjust's last block writes them itself)
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv);

@@ -452,7 +452,8 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
   void expamd_sph_force_L##k(const SphForceArgs &);  \
   void expamd_sph_upd_L##k(const SphUpdArgs &);         \
   void expamd_sph_thin_force_L##k(const SphThinForceArgs &); \
-  void expamd_sph_thin_acc_L##k(const SphThinAccArgs &);
+  void expamd_sph_thin_acc_L##k(const SphThinAccArgs &); \
+  void expamd_sph_thin_diff_L##k(const SphThinDiffArgs &);
 DECL_L(0) DECL_L(1) DECL_L(2) DECL_L(3) DECL_L(4) DECL_L(5) DECL_L(6)
 DECL_L(7) DECL_L(8) DECL_L(9) DECL_L(10) DECL_L(11) DECL_L(12)
 #undef DECL_L
@@ -474,6 +475,11 @@ static const sph_thin_force_launcher k_thin_force_launch[SPH_MAX_L + 1] = {
     expamd_sph_thin_force_L4, expamd_sph_thin_force_L5, expamd_sph_thin_force_L6,  expamd_sph_thin_force_L7,
     expamd_sph_thin_force_L8, expamd_sph_thin_force_L9, expamd_sph_thin_force_L10, expamd_sph_thin_force_L11,
     expamd_sph_thin_force_L12};
+static const sph_thin_diff_launcher k_thin_diff_launch[SPH_MAX_L + 1] = {
+    expamd_sph_thin_diff_L0, expamd_sph_thin_diff_L1, expamd_sph_thin_diff_L2,  expamd_sph_thin_diff_L3,
+    expamd_sph_thin_diff_L4, expamd_sph_thin_diff_L5, expamd_sph_thin_diff_L6,  expamd_sph_thin_diff_L7,
+    expamd_sph_thin_diff_L8, expamd_sph_thin_diff_L9, expamd_sph_thin_diff_L10, expamd_sph_thin_diff_L11,
+    expamd_sph_thin_diff_L12};
 static const sph_thin_acc_launcher k_thin_acc_launch[SPH_MAX_L + 1] = {
     expamd_sph_thin_acc_L0, expamd_sph_thin_acc_L1, expamd_sph_thin_acc_L2,  expamd_sph_thin_acc_L3,
     expamd_sph_thin_acc_L4, expamd_sph_thin_acc_L5, expamd_sph_thin_acc_L6,  expamd_sph_thin_acc_L7,
@@ -612,6 +618,10 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
     c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
+    // (a closing half-kick still owed rides along with the pass that advances its levels)
+    if (c->pending_kick != 0.0 && (!adv.mode || dmax >= lo) &&
+        (rc = adv.mode ? expamd_comp_settle_pending(c, lo, dmax, true) : expamd_comp_settle_pending(c, 0, ms, false)))
+      return rc;
     if (dmax >= lo) {
       rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
       if (rc) return rc;
@@ -1030,6 +1040,11 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // (k_mover_list, 16 slots per thread), so that the differencing launches over the movers, not over the range
   const bool listed = nr && c->mover_hint >= 0;
   if (listed && c->mover_hint > 0) { int rc_ = expamd_comp_mover_list(c, first, ms, (size_t)c->mover_hint); if (rc_) return rc_; }
+  static const bool thin_diff_on = [] { const char *e = getenv("EXP_AMD_THIN_DIFF"); return !e || atoi(e) != 0; }();
+  const bool few = listed && c->mover_hint > 0 && !(ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min);
+  const bool thin_diff = few && thin_diff_on && ctx->thin_max > 0 && c->mover_hint <= ctx->thin_max && !ctx->deterministic &&
+                         !f->generic && f->ncoef <= 4096;
+  // (no mover anywhere in the thin case: the moments were not touched, the partial sums are zero)
   if (listed && c->mover_hint == 0) {
     // nothing moved on this rank (it only takes part in the reduction)
   } else if (listed && ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min) {
@@ -1045,6 +1060,18 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     a.mfirst = mfirst_mdrft;
     a.nslices = c->mover_hint >= ctx->mover_slices_min ? ms + 2 : 2;
     sph_launch_acc(f, a);
+  } else if (thin_diff) {
+    // few movers, straight from the basis tables into the contraction's partial sums (k_sph_diff_thin): no staging, no
+    // moments, no contraction over the cells of every level
+    ProfScope ps(ctx, "k_sph_diff_thin");
+    if (!f->part_clean) {
+      HIP_TRY(ctx, hipMemsetAsync(f->d_part.p, 0, f->d_part.bytes(), ctx->stream));
+      f->part_clean = true;
+    }
+    SphThinDiffArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->mover_list.p, c->mover_cnt,
+                      c->level[c->cur].p, c->newlev.p, mfirst_mdrft, nl, f->d_wscale.p, f->d_part.p,
+                      (size_t)c->mover_hint, ctx->stream};
+    k_thin_diff_launch[cfg.lmax](a);
   } else if (nr) {
     ProfScope ps(ctx, "k_sph_mstep_update");
     SphUpdArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->level[c->cur].p, c->newlev.p,
@@ -1059,8 +1086,9 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
     sph_launch_upd(f, a);
   }
   // moments -> coefficient differences, all levels in one launch
-  k_sph_contract<<<dim3(CSEG, S.nrows, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
-                                                                  f->d_wscale.p, f->d_part.p, /*clear=*/1);
+  if (!thin_diff)
+    k_sph_contract<<<dim3(CSEG, S.nrows, nl), 256, 0, ctx->stream>>>(S, f->d_Wd.p + (size_t)mfirst_mdrft * wl,
+                                                                    f->d_wscale.p, f->d_part.p, /*clear=*/1);
   // one packed all-reduce (src/SphericalBasis.cc:1063-1064), then expcoefN[M] += differ[M] -- in the summing kernel
   // itself when this rank is alone
   const bool alone = ctx->nranks <= 1 && !ctx->ar_fn;

@@ -182,3 +182,23 @@ void CAT(expamd_sph_thin_acc_L, SPH_L)(const SphThinAccArgs &a)
   k_sph_acc_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off, a.lo, a.hi, a.wscale,
                                                                     a.part, a.used, tpa);
 }
+
+void CAT(expamd_sph_thin_diff_L, SPH_L)(const SphThinDiffArgs &a)
+{
+  constexpr int LMAX = SPH_L;
+  const size_t nrows = (size_t)a.S.nrows, lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
+  int tpa = 8;
+  auto need = [&](int t) { return ((((size_t)t * nrows + 1) & ~(size_t)1) + (size_t)t * lsn) * sizeof(double); };
+  while (tpa > 4 && need(tpa) > 96 * 1024) tpa >>= 1;
+  size_t grid = cdiv(a.n, (size_t)tpa);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) return;
+  static const bool big = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_diff_thin<LMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)big;
+  k_sph_diff_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.list, a.cnt, a.lev, a.newlev,
+                                                                     a.mfirst, a.nlev_out, a.wscale, a.part, tpa);
+}

@@ -2060,6 +2060,114 @@ k_sph_acc_thin(SphDev S, const double *__restrict__ X, const double *__restrict_
   }
 }
 
+// Level-change differencing of FEW movers (multistep_update, src/SphericalBasis.cc:1156-1228), direct: the tiles run
+// over the list of movers (k_mover_list); a mover adds its contribution to the set of its proposed level and takes it
+// out of its level's set (levels >= mfirst only).  The sums go to part[level - mfirst][seg][row][n] -- one atomic per
+// (tile, level, coefficient) -- and k_sph_sum_parts adds them to expcoefN (clear = 1).  Replaces the staged moment path
+// (k_sph_mstep_update<L, true> + k_mstep_apply + a contraction over every cell of every level: three launches, 30 us).
+template <int LMAX>
+__global__ void __launch_bounds__(256)
+k_sph_diff_thin(SphDev S, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                const double *__restrict__ M, const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                const uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, int mfirst, int nlev_out,
+                const double *__restrict__ wscale, double *__restrict__ part, int tpa)
+{
+  extern __shared__ __attribute__((aligned(16))) double thin_lds[];
+  __shared__ int s_idx[SPH_THIN_TP_MAX], s_from[SPH_THIN_TP_MAX], s_to[SPH_THIN_TP_MAX];
+  __shared__ double s_a1[SPH_THIN_TP_MAX], s_a2[SPH_THIN_TP_MAX];
+  const int nrows = S.nrows, lsn = (S.lmax + 1) * S.nmax, ncoef = nrows * S.nmax;
+  double *yv = thin_lds;
+  double *pe = thin_lds + (((size_t)tpa * nrows + 1) & ~(size_t)1);
+  const size_t count = cnt[1];
+  const int seg = blockIdx.x % CSEG;
+  const int t = threadIdx.x;
+  const bool um = S.umass != 0.0;
+  for (size_t base = (size_t)blockIdx.x * tpa; base < count; base += (size_t)gridDim.x * tpa) {
+    const int np = (int)((count - base) < (size_t)tpa ? (count - base) : (size_t)tpa);
+    if (t < tpa) {
+      const bool valid = t < np;
+      double x = 0, y = 0, z = 0, m = 0;
+      int from = -1, to = -1;
+      if (valid) {
+        const uint32_t i = list[base + t];
+        x = X[i]; y = Y[i]; z = Z[i]; m = um ? S.umass : M[i];
+        from = lev[i]; to = newlev[i];
+      }
+      const AccIn in = sph_acc_input<true>(S, (ldp) nullptr, x, y, z, m, valid);      // (window r < rmax, :1183)
+      const bool on = in.idx >= 0;
+      s_idx[t] = in.idx; s_a1[t] = in.a1; s_a2[t] = in.a2;
+      s_to[t] = on ? to : -1;
+      s_from[t] = (on && from >= mfirst) ? from : -1;          // levels below mfirst[mdrft] are not updated
+      double *yr = yv + (size_t)t * nrows;
+      double pmm = LC_E(0);
+      double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+      static_for<0, LMAX + 1>([&](auto mc) {
+        constexpr int m_ = decltype(mc)::value;
+        if constexpr (m_ == 1) {
+          pmm *= LC_E(1) * in.sinth;
+          cm = in.cphi; sm = in.sphi;
+        } else if constexpr (m_ > 1) {
+          pmm *= LC_E(m_) * in.sinth;
+          const double cn = 2.0 * in.cphi * cm - cm1;
+          const double sn = 2.0 * in.cphi * sm - sm1;
+          cm1 = cm; sm1 = sm;
+          cm = cn; sm = sn;
+        }
+        double pl2 = 0.0, pl1 = 0.0, tprev = 0.0;
+        static_for<m_, LMAX + 1>([&](auto lc_) {
+          constexpr int l = decltype(lc_)::value;
+          double plm;
+          if constexpr (l == m_) plm = pmm;
+          else if constexpr (l == m_ + 1) plm = LC_a(l, m_) * tprev;
+          else plm = fma(LC_a(l, m_), tprev, -pl2);
+          tprev = in.costh * plm;
+          pl2 = pl1;
+          pl1 = plm;
+          constexpr int row = row_of(l, m_, 0);
+          if constexpr (m_ == 0) yr[row] = on ? plm : 0.0;
+          else { yr[row] = on ? plm * cm : 0.0; yr[row + 1] = on ? plm * sm : 0.0; }
+        });
+      });
+    }
+    __syncthreads();
+    for (int it0 = threadIdx.x; it0 < np * lsn; it0 += 4 * 256) {
+      double ea[4], eb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int it = it0 + u * 256;
+        ea[u] = eb[u] = 0.0;
+        if (it < np * lsn) {
+          const int p = it / lsn, idx = s_idx[p];
+          if (idx >= 0) { ea[u] = S.E[(size_t)idx * lsn + (it - p * lsn)]; eb[u] = S.E[(size_t)(idx + 1) * lsn + (it - p * lsn)]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int it = it0 + u * 256;
+        if (it < np * lsn) { const int p = it / lsn; pe[it] = fma(s_a2[p], eb[u], s_a1[p] * ea[u]); }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncoef; k += 256) {
+      const int row = k / S.nmax, n = k - row * S.nmax;
+      const int ln = sph_l_of_row(row) * S.nmax + n;
+      const double ws = wscale[row];
+      double v[8];                   // this coefficient's term of each mover (tpa <= 8)
+#pragma unroll
+      for (int p = 0; p < 8; p++) v[p] = p < np ? yv[(size_t)p * nrows + row] * pe[(size_t)p * lsn + ln] : 0.0;
+      for (int L = 0; L < nlev_out; L++) {
+        const int level = mfirst + L;
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+          if (p < np) acc += (s_to[p] == level ? v[p] : 0.0) - (s_from[p] == level ? v[p] : 0.0);
+        if (acc != 0.0) unsafeAtomicAdd(part + ((size_t)L * CSEG + seg) * ncoef + k, acc * ws);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- per-LMAX launchers (one translation unit per LMAX: sph_inst.hip -DSPH_L=k) -----------------
 
 struct SphAccArgs {
@@ -2144,6 +2252,18 @@ struct SphThinAccArgs {
   size_t n;
   hipStream_t stream;
 };
+struct SphThinDiffArgs {
+  SphDev S;
+  const double *X, *Y, *Z, *M;
+  const uint32_t *list, *cnt;       // slots of the movers, {0, count}
+  const uint8_t *lev, *newlev;
+  int mfirst, nlev_out;
+  const double *wscale;
+  double *part;
+  size_t n;                         // the host's count of movers (sizes the grid)
+  hipStream_t stream;
+};
+typedef void (*sph_thin_diff_launcher)(const SphThinDiffArgs &);
 typedef void (*sph_thin_force_launcher)(const SphThinForceArgs &);
 typedef void (*sph_thin_acc_launcher)(const SphThinAccArgs &);
 typedef void (*sph_upd_launcher)(const SphUpdArgs &);
