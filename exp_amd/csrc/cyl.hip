@@ -17,6 +17,7 @@
 // its 4(2 mmax+1) moment sums stay in registers until the cell changes.
 #include <cstring>
 #include "sort_kernels.h"
+#include "thin_adv.h"
 #include "force.h"
 
 #include <type_traits>
@@ -1408,7 +1409,8 @@ template <int MMAX>
 __global__ void __launch_bounds__(256)
 k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
                const double *__restrict__ M, const uint32_t *__restrict__ lev_off, int lo, int hi,
-               const double *__restrict__ tabT, int nk, double *__restrict__ part, double *__restrict__ tail, int tpa)
+               const double *__restrict__ tabT, int nk, double *__restrict__ part, double *__restrict__ tail, int tpa,
+               ThinAdv adv)
 {
   extern __shared__ __attribute__((aligned(16))) double cthin_lds[];
   constexpr int NT = 2 * MMAX + 1;
@@ -1428,7 +1430,12 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
       const size_t i = base + t;
       const bool valid = t < tpa && i < end;
       double xx = 1, yy = 0, zz = 0, mass = 0;
-      if (valid) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = M[i]; }
+      if (valid) {
+        double px, py, pz;
+        if (adv.on) thin_advance(adv, i, px, py, pz); else { px = X[i]; py = Y[i]; pz = Z[i]; }
+        cyl_local(C, px, py, pz, xx, yy, zz);
+        mass = M[i];
+      }
       const double r2 = xx * xx + yy * yy;
       double r, ir;
       sqrt_rsqrt(r2, r, ir);
@@ -2076,6 +2083,8 @@ struct CylForce : exp_amd_force {
   int work_flip = 0;
   int step_parity() const override { return work_flip; }
   bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
+  bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_cyl_acc_thin
+  double adv_dt_min = 0.0;
   bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)
   DevBuf<double> d_tabT;            // node-major copy tabT[node][kind][m][n] for the thin path (made on first use)
   int tabT_nk = 0;                  // kinds it holds: 3 (sine tables == cosine tables) or 6
@@ -2273,7 +2282,7 @@ static void cyl_thin_force_launch(hipStream_t st, size_t n, const CylDev &C, con
 template <int MM>
 static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const double *X, const double *Y, const double *Z,
                                 const double *M, const uint32_t *lev_off, int lo, int hi, const double *tabT, int nk,
-                                double *part, double *tail)
+                                double *part, double *tail, const ThinAdv &adv)
 {
   const size_t half = (size_t)(C.mmax + 1) * C.nmax;
   const int nset = nk == 3 ? 1 : 2;
@@ -2289,7 +2298,7 @@ static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const
   }();
   (void)big;
   k_cyl_acc_thin<MM><<<(unsigned)grid, 256, (size_t)tpa * nset * half * sizeof(double), st>>>(C, X, Y, Z, M, lev_off, lo, hi, tabT,
-                                                                                                 nk, part, tail, tpa);
+                                                                                                 nk, part, tail, tpa, adv);
 }
 
 template <int MM>
@@ -2634,7 +2643,18 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
     }
-    if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
+    // (... by the thin accumulation kernel itself when that is what follows: thin_adv.h)
+    if (dmax < ms && adv.mode) {
+      size_t nall = 0;
+      if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
+      static const bool fuse_on = [] { const char *e = getenv("EXP_AMD_THIN_ADVANCE"); return !e || atoi(e) != 0; }();
+      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max &&
+                        !ctx->deterministic && cyl_thin_version() == 1 && !f->generic;
+      if (fuse) {
+        f->adv_owed = true;
+        f->adv_dt_min = dt_min;
+      } else if ((rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
+    }
   }
   if (phase == 1) return EXP_AMD_OK;
   const CylDev C = cdev_acc(f, c);
@@ -2706,6 +2726,11 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
   // (k_cyl_acc_thin), no node moments and no pass over the nodes
   const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0;
+  // (the advance that kernel was to perform, should it not run after all)
+  if (f->adv_owed && !(thin && nrange)) {
+    f->adv_owed = false;
+    if ((rc = expamd_comp_advance_levels(c, lo, ms, f->adv_dt_min, ms))) return rc;
+  }
   if (thin) {
     if ((rc = ensure_tabT())) return rc;
     if (!f->cpart_clean) {
@@ -2714,13 +2739,22 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     }
     if (nrange) {
       ProfScope ps(ctx, "k_cyl_acc_thin");
+      ThinAdv tadv{};
+      if (f->adv_owed) {
+        f->adv_owed = false;
+        double k0 = 0.0;
+        int k0lo = 0;
+        if ((rc = expamd_comp_take_pending(c, lo, ms, &k0, &k0lo))) return rc;
+        tadv = ThinAdv{c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ),
+                       c->level[c->cur].p, f->adv_dt_min, ms, k0, k0lo, 1};
+      }
       if (cyl_thin_version() != 1 || f->generic)
         cyl_tile_acc_launch(ctx->stream, nrange, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms,
                             f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p);
       else {
 #define CALL(MM)                                                                                         \
   cyl_thin_acc_launch<MM>(ctx->stream, nrange, C, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, \
-                          f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p)
+                          f->d_tabT.p, f->tabT_nk, f->d_cpart.p, f->d_tailpart.p, tadv)
       MMAX_DISPATCH(cfg.mmax, CALL)
 #undef CALL
       }

@@ -119,6 +119,7 @@ void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh);
 // kick DT(M)/2 + drift DT(M) in place for the levels [lo, hi] (no reorder): sparse levels
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep);
 int expamd_comp_settle_pending(exp_amd_comp *c, int lo, int hi, bool advancing);
+int expamd_comp_take_pending(exp_amd_comp *c, int lo, int hi, double *k0, int *k0lo);
 
 // slots of the particles of levels [first, last] whose proposed level (newlev) differs from their level, in slot order
 // within blocks of 256 slots: c->mover_list, c->mover_cnt = {0, count}; capacity = the expected count

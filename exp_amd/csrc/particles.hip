@@ -341,21 +341,33 @@ int expamd_comp_settle_pending(exp_amd_comp *c, int lo, int hi, bool advancing)
   return expamd_comp_apply_pending(c);
 }
 
+// a pass that advances the levels [lo, hi] in place: a closing half-kick still owed (pending_kick, levels >= pending_lo)
+// is taken along -- *k0 / *k0lo, settled here -- when the range holds all of the owing levels, left alone when it holds
+// none of them, applied by a launch of its own otherwise
+int expamd_comp_take_pending(exp_amd_comp *c, int lo, int hi, double *k0, int *k0lo)
+{
+  *k0 = 0.0;
+  *k0lo = 0;
+  if (c->pending_kick == 0.0) return EXP_AMD_OK;
+  if (lo <= c->pending_lo && hi >= c->nlevels - 1) {
+    *k0 = c->pending_kick;
+    *k0lo = c->pending_lo;
+    c->pending_kick = 0.0;
+    c->pending_lo = 0;
+    return EXP_AMD_OK;
+  }
+  if (hi >= c->pending_lo) return expamd_comp_apply_pending(c);
+  return EXP_AMD_OK;
+}
+
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep)
 {
   size_t nr = 0;
   int rc = expamd_comp_level_count(c, lo, hi, &nr);
   if (rc) return rc;
-  // a closing half-kick still owed (pending_kick, levels >= pending_lo): taken along when this range holds all of those
-  // levels, left alone when it holds none of them, applied by a launch of its own otherwise
   double k0 = 0.0;
   int k0lo = 0;
-  bool settle = false;
-  if (c->pending_kick != 0.0) {
-    if (lo <= c->pending_lo && hi >= c->nlevels - 1) { k0 = c->pending_kick; k0lo = c->pending_lo; settle = true; }
-    else if (hi >= c->pending_lo && (rc = expamd_comp_apply_pending(c))) return rc;
-  }
-  if (settle) { c->pending_kick = 0.0; c->pending_lo = 0; }
+  if ((rc = expamd_comp_take_pending(c, lo, hi, &k0, &k0lo))) return rc;
   if (nr == 0) return EXP_AMD_OK;
   ProfScope ps(c->ctx, "k_advance_levels");
   k_advance_levels<<<stream_grid(c->ctx, nr), TPB, 0, c->ctx->stream>>>(

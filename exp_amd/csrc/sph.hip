@@ -630,8 +630,20 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
     }
-    // sparse levels above: advanced in place
-    if (dmax < ms && adv.mode && (rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
+    // sparse levels above: advanced in place -- by the thin accumulation kernel itself when that is what follows (the
+    // whole active range sparse and thin: thin_adv.h), which then needs no launch for it
+    if (dmax < ms && adv.mode) {
+      size_t nall = 0;
+      if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
+      static const bool fuse_on = [] { const char *e = getenv("EXP_AMD_THIN_ADVANCE"); return !e || atoi(e) != 0; }();
+      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
+      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max &&
+                        !ctx->deterministic && f->ncoef <= 4096 && thin_v == 1 && !f->generic;
+      if (fuse) {
+        f->adv_owed = true;
+        f->adv_dt_min = dt_min;
+      } else if ((rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
+    }
   }
   if (phase == 1) return EXP_AMD_OK;
   const SphDev S = dev_acc(f, c);
@@ -676,6 +688,11 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // is that of the moment terms)
   const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic &&
                     f->ncoef <= 4096;
+  // (the advance this kernel was to perform, should it not run after all)
+  if (f->adv_owed && !(thin && nrange)) {
+    f->adv_owed = false;
+    if ((rc = expamd_comp_advance_levels(c, lo, ms, f->adv_dt_min, ms))) return rc;
+  }
   if (thin) {
     if (!f->part_clean) {
       HIP_TRY(ctx, hipMemsetAsync(f->d_part.p, 0, f->d_part.bytes(), ctx->stream));
@@ -685,6 +702,14 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       ProfScope ps(ctx, "k_sph_acc_thin");
       SphThinAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, ms, f->d_wscale.p, f->d_part.p,
                        used_p, nrange, ctx->stream};
+      if (f->adv_owed) {
+        f->adv_owed = false;
+        double k0 = 0.0;
+        int k0lo = 0;
+        if ((rc = expamd_comp_take_pending(c, lo, ms, &k0, &k0lo))) return rc;
+        a.adv = ThinAdv{c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ),
+                        c->level[c->cur].p, f->adv_dt_min, ms, k0, k0lo, 1};
+      }
       static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
       if (thin_v == 1 && !f->generic) k_thin_acc_launch[cfg.lmax](a); else expamd_sph_thin_acc_gen(a);
     }

@@ -30,6 +30,8 @@ struct SphForce : exp_amd_force {
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
   bool used_open = true;
   bool wd_clean = false;            // ... and of d_Wd (multistep_update)
+  bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_sph_acc_thin
+  double adv_dt_min = 0.0;
   bool part_clean = false;          // d_part is all zero (what the thin accumulation adds to; its summing kernels keep it so)
   bool w_clean = false;             // every per-level moment buffer of d_W is zero (substep_expansion keeps it so)
   int step_parity() const override { return work_flip; }

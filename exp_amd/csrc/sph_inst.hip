@@ -180,7 +180,7 @@ void CAT(expamd_sph_thin_acc_L, SPH_L)(const SphThinAccArgs &a)
   }();
   (void)big;
   k_sph_acc_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off, a.lo, a.hi, a.wscale,
-                                                                    a.part, a.used, tpa);
+                                                                    a.part, a.used, tpa, a.adv);
 }
 
 void CAT(expamd_sph_thin_diff_L, SPH_L)(const SphThinDiffArgs &a)

@@ -22,6 +22,7 @@
 // waterfall (accumulate) or per-lane row gathers (force); any particle order is correct.
 #pragma once
 #include "particles.h"
+#include "thin_adv.h"
 
 #include <type_traits>
 #include <utility>
@@ -1947,7 +1948,7 @@ __global__ void __launch_bounds__(256)
 k_sph_acc_thin(SphDev S, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
                const double *__restrict__ M, const uint32_t *__restrict__ lev_off, int lo, int hi,
                const double *__restrict__ wscale, double *__restrict__ part, unsigned long long *__restrict__ used_out,
-               int tpa)
+               int tpa, ThinAdv adv)
 {
   extern __shared__ __attribute__((aligned(16))) double thin_lds[];
   __shared__ int s_idx[SPH_THIN_TP_MAX], s_lev[SPH_THIN_TP_MAX];
@@ -1965,7 +1966,10 @@ k_sph_acc_thin(SphDev S, const double *__restrict__ X, const double *__restrict_
       const size_t i = base + t;
       const bool valid = i < end;
       double x = 0, y = 0, z = 0, m = 0;
-      if (valid) { x = X[i]; y = Y[i]; z = Z[i]; m = um ? S.umass : M[i]; }
+      if (valid) {
+        if (adv.on) thin_advance(adv, i, x, y, z); else { x = X[i]; y = Y[i]; z = Z[i]; }
+        m = um ? S.umass : M[i];
+      }
       const AccIn in = sph_acc_input<false>(S, (ldp) nullptr, x, y, z, m, valid);
       int lv = lo;
       while (lv < hi && i >= lev_off[lv + 1]) lv++;
@@ -2251,6 +2255,7 @@ struct SphThinAccArgs {
   unsigned long long *used;
   size_t n;
   hipStream_t stream;
+  ThinAdv adv;                      // (k_sph_acc_thin only: the advance of the range folded in)
 };
 struct SphThinDiffArgs {
   SphDev S;

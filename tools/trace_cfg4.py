@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 kernel trace of tools/bench_configs.py --only 4: the last complete master step
-(16 sub-steps, delimited by the k_kick_adjust launches of the first component): span, GPU-busy
+(16 sub-steps, delimited by the long k_kick_adjust launches of the sweep over all levels): span, GPU-busy
 fraction, per-kernel totals, launch count, and where the idle gaps are.
 
     python tools/trace_cfg4.py gpurun_out/prof_cfg4 [ncomp=2] [multistep=4]"""
@@ -21,8 +21,12 @@ def main():
         rows.append((r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Start_Timestamp"]),
                      int(r["End_Timestamp"])))
     rows.sort(key=lambda r: r[1])
-    adj = [i for i, r in enumerate(rows) if r[0].startswith("k_kick_adjust")]
-    per = ncomp * (1 << ms)
+    # master steps end with the sweep over ALL levels: the long k_kick_adjust launches, one per component (the sweeps
+    # of the sub-steps in between are short, and the ones that cannot move anything are not launched at all)
+    adj_all = [i for i, r in enumerate(rows) if r[0].startswith("k_kick_adjust")]
+    dmax = max(rows[i][2] - rows[i][1] for i in adj_all)
+    adj = [i for i in adj_all if rows[i][2] - rows[i][1] >= 0.4 * dmax]
+    per = ncomp
     # one complete steady master step: the one before the last (the last one runs into the bench's
     # final downloads); a master step ends with its last sub-step's adjust launches
     back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
