@@ -45,6 +45,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_THIN_MAX")) ctx->thin_max = atoll(e);
   if (const char *e = getenv("EXP_AMD_MOVER_LIST_MIN")) ctx->mover_list_min = atoll(e);
+  if (const char *e = getenv("EXP_AMD_THIN_ACC_SCALE")) ctx->thin_acc_scale = atoll(e) > 0 ? atoll(e) : 1;
   if (const char *e = getenv("EXP_AMD_MOVER_SLICES_MIN")) ctx->mover_slices_min = atoll(e);
   if (const char *e = getenv("EXP_AMD_STAGE_MAX")) ctx->stage_max = atoll(e);
   if (const char *e = getenv("EXP_AMD_DETERMINISTIC")) ctx->deterministic = atoi(e) != 0;

@@ -2629,6 +2629,8 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   if (c->n && phase != 2) {
     uint32_t keep[66];
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
+    // a commit left to this sort: it must be the sort of exactly the slots the sweep examined
+    if (c->commit_pending && !(stale_ok && c->stale_lo == lo && dmax >= lo) && (rc = expamd_comp_flush_commit(c))) return rc;
     c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
     // (a closing half-kick still owed rides along with the pass that advances its levels)
@@ -2639,6 +2641,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
       if (rc) return rc;
     }
+    c->commit_pending = false;          // (the scatter stored the proposed levels)
     if (had) {
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
@@ -2648,13 +2651,15 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       size_t nall = 0;
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       static const bool fuse_on = [] { const char *e = getenv("EXP_AMD_THIN_ADVANCE"); return !e || atoi(e) != 0; }();
-      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max &&
+      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
                         !ctx->deterministic && cyl_thin_version() == 1 && !f->generic;
       if (fuse) {
         f->adv_owed = true;
         f->adv_dt_min = dt_min;
       } else if ((rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
     }
+    // (a half-kick owed by levels of the advanced range that no pass took along: that range was empty)
+    if (c->pending_kick != 0.0 && adv.mode && !f->adv_owed && lo <= c->pending_lo) { c->pending_kick = 0.0; c->pending_lo = 0; }
   }
   if (phase == 1) return EXP_AMD_OK;
   const CylDev C = cdev_acc(f, c);
@@ -2725,7 +2730,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
   // (k_cyl_acc_thin), no node moments and no pass over the nodes
-  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max && !ctx->deterministic && ctx->thin_max > 0;
+  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max * ctx->thin_acc_scale && !ctx->deterministic && ctx->thin_max > 0;
   // (the advance that kernel was to perform, should it not run after all)
   if (f->adv_owed && !(thin && nrange)) {
     f->adv_owed = false;

@@ -451,7 +451,11 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
       // ... and the closing kick itself -- of the top level alone, DT(multistep)/2 = dt_min/2 -- is left to the advance
       // of the next sub-step, which applies it first, as its own rounding step (exp_amd_comp::pending_kick / pending_lo)
       if (fold && c->nlevels == ms + 1 && c->pending_kick == 0.0) {
-        if (c->n) { c->pending_kick = 0.5 * dt_min; c->pending_lo = ms; }
+        // (an EMPTY top level owes nothing -- and must not: the next real sweep may move particles there, which would
+        // then be kicked for a step they never took)
+        size_t ntop = 0;
+        if (c->n && (rc = expamd_comp_level_count(c, ms, ms, &ntop))) return rc;
+        if (ntop) { c->pending_kick = 0.5 * dt_min; c->pending_lo = ms; }
         continue;
       }
       const unsigned long long *res = nullptr;
@@ -550,7 +554,17 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
         for (int L = 0; L <= first; L++) off[L] = c->lev_host[L];
         for (int L = first; L <= ms; L++) off[L + 1] = off[L] + (uint32_t)res[1 + L];
       }
-      if ((rc = expamd_comp_commit_levels(c, mirror ? (size_t)c->lev_host[first] : 0))) return rc;
+      // (the commit itself is left to the sort that settles the partition when that is the next thing to touch these
+      // slots -- see below: it reads the proposed levels where they are, exp_amd_comp::commit_pending)
+      const int next_lo_ = mdrft == s->Mstep ? 0 : s->mfirst[mdrft];
+      static const bool fuse_commit = [] { const char *e = getenv("EXP_AMD_SIM_FUSE_COMMIT"); return !e || atoi(e) != 0; }();
+      const bool put_off = fuse_commit && mirror && s->defer_resort && next_lo_ == first && c->n > 0;
+      if (put_off) {
+        c->commit_pending = true;
+        c->commit_beg = (size_t)c->lev_host[first];
+        c->levels_zero = false;
+        c->sorted_for = nullptr;
+      } else if ((rc = expamd_comp_commit_levels(c, mirror ? (size_t)c->lev_host[first] : 0))) return rc;
       if (mirror) {
         // the populations the re-ordering is about to establish decide which levels stay cell-sorted
         for (int L = 0; L <= ms + 1; L++) c->lev_host[L] = off[L];

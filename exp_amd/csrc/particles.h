@@ -71,6 +71,8 @@ struct exp_amd_comp {
   // driver lets the next master step's first (full) advance sort do it in the same pass.  lev_host
   // already holds the offsets that sort will establish; any other entry point re-partitions first
   // (expamd_comp_touch).
+  bool commit_pending = false;          // (with partition_stale) the proposed levels of the slots >= commit_beg are still
+  size_t commit_beg = 0;                // in newlev: the sort that settles the partition reads them there and stores them
   bool partition_stale = false;
   // ... more generally after ANY sweep whose examined levels [stale_lo, multistep] are exactly what the next
   // sub-step advances: that sub-step's advance sort re-partitions them in the same pass (stale_for: the force
@@ -119,6 +121,7 @@ void expamd_comp_update_sparse(exp_amd_comp *c, int first, long long thresh);
 // kick DT(M)/2 + drift DT(M) in place for the levels [lo, hi] (no reorder): sparse levels
 int expamd_comp_advance_levels(exp_amd_comp *c, int lo, int hi, double dt_min, int multistep);
 int expamd_comp_settle_pending(exp_amd_comp *c, int lo, int hi, bool advancing);
+int expamd_comp_flush_commit(exp_amd_comp *c);       // a commit left to the next sort (commit_pending) is done now
 int expamd_comp_take_pending(exp_amd_comp *c, int lo, int hi, double *k0, int *k0lo);
 
 // slots of the particles of levels [first, last] whose proposed level (newlev) differs from their level, in slot order

@@ -407,10 +407,21 @@ static int partition_by_level(exp_amd_comp *c)
   return EXP_AMD_OK;
 }
 
+int expamd_comp_flush_commit(exp_amd_comp *c)
+{
+  if (!c->commit_pending) return EXP_AMD_OK;
+  c->commit_pending = false;
+  const void *sf = c->sorted_for;
+  int rc = expamd_comp_commit_levels(c, c->commit_beg);
+  c->sorted_for = sf;                    // (it was cleared when the commit was put off)
+  return rc;
+}
+
 int expamd_comp_touch(exp_amd_comp *c)
 {
   expamd_mutated();
   c->prekey_valid = false;
+  if (c->commit_pending) { int rc = expamd_comp_flush_commit(c); if (rc) return rc; }
   if (c->partition_stale) { int rc = partition_by_level(c); if (rc) return rc; }
   return expamd_comp_apply_pending(c);
 }
@@ -429,6 +440,7 @@ int expamd_comp_touch_keep_partition(exp_amd_comp *c)
 // move the trajectory by an ulp just because a diagnostic looked.  The keys recorded for the next step stay valid.
 int expamd_comp_velocity_view(exp_amd_comp *c, double *back)
 {
+  { int rc_ = expamd_comp_flush_commit(c); if (rc_) return rc_; }      // (these consumers read the level array too)
   *back = c->pending_kick < 0.0 ? c->pending_kick : 0.0;
   if (*back != 0.0) return EXP_AMD_OK;
   return expamd_comp_apply_pending(c);
@@ -458,7 +470,8 @@ AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv)
   A.x = c->a(A_X); A.y = c->a(A_Y); A.z = c->a(A_Z);
   A.vx = c->a(A_VX); A.vy = c->a(A_VY); A.vz = c->a(A_VZ);
   A.ax = c->a(A_AX); A.ay = c->a(A_AY); A.az = c->a(A_AZ);
-  A.lev = c->level[c->cur].p;
+  A.lev = c->commit_pending ? c->newlev.p : c->level[c->cur].p;     // (the caller has checked that the pass stays within
+                                                                      // the slots the last sweep examined)
   A.dt_kick = adv.dt_kick; A.dt_drift = adv.dt_drift;
   A.dt_kick0 = adv.mode ? c->pending_kick : 0.0;     // deferred half-kick of the last fused step
   A.kick0_lo = c->pending_lo;
@@ -563,7 +576,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
     for (int a = 0; a < A_NARR; a++) { C.dst[a] = c->a(a); C.src[a] = c->b(a); }
     C.did = c->id[c->cur].p;
     C.sid = c->id[1 - c->cur].p;
-    const bool many = level_hi > level;
+    const bool many = level_hi > level || c->commit_pending;
     // (range mode of the scan: only the bins of levels level..level_hi were populated, the rest is still zero)
     const uint32_t hz0 = (uint32_t)level * ncell, hz1 = (uint32_t)(level_hi + 1) * ncell;
     k_copy_range<<<cdiv(nr, TPB), TPB, 0, ctx->stream>>>(
@@ -1250,6 +1263,7 @@ extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
   if (!c || !level) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
+  { int rc_ = expamd_comp_flush_commit(c); if (rc_) return rc_; }
   int32_t *tmp = (int32_t *)c->b(A_X);
   k_unpermute_lev<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->id[c->cur].p,
                                                             c->n, tmp);

@@ -166,6 +166,36 @@ k_sph_project4(SphDev S, const double *__restrict__ G, const int *__restrict__ r
   }
 }
 
+// Both steps in one launch: the block of a cell forms G at the three nodes its T4 rows need (the cell's two and the
+// force stencil's: {cell-1, cell, cell+1}, {0, 1, 2} for cell 0) into LDS -- the same sums, sph_G_row -- and builds the
+// rows from there; G itself (field evaluation, sph_fields.hip) is written on the way, node `cell` by block `cell`, the
+// last node by the last block.  gs: 3 nrows doubles of dynamic LDS.
+__global__ void __launch_bounds__(256)
+k_sph_project_both(SphDev S, const double *__restrict__ coef, const int *__restrict__ rowmap,
+                   const double *__restrict__ tscale, double *__restrict__ G, double *__restrict__ T4)
+{
+  extern __shared__ __attribute__((aligned(16))) double gs[];
+  const int cell = blockIdx.x;                 // 0 .. numr-2
+  const int j = cell < 1 ? 1 : cell, b = j - 1;
+  const int stride = (S.lmax + 1) * S.nmax;
+  for (int it = threadIdx.x; it < 3 * S.nrows; it += 256) {
+    const int k = it / S.nrows, row = it - k * S.nrows, node = b + k;
+    const int l = sph_l_of_row(row);
+    const double g = sph_G_row(S.E + (size_t)node * stride + l * S.nmax, coef + (size_t)row * S.nmax, S.nmax);
+    gs[it] = g;
+    if (node == cell || (cell == S.numr - 2 && node == S.numr - 1)) G[(size_t)node * S.nrows + row] = g;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < S.trows; q += 256) {
+    const int row = rowmap[q];
+    double *t = T4 + ((size_t)cell * S.trows + q) * 4;
+    if (row < 0) { t[0] = t[1] = t[2] = t[3] = 0.0; continue; }
+    const double g0 = gs[(cell - b) * S.nrows + row], g1 = gs[(cell + 1 - b) * S.nrows + row];
+    const double h0 = S.p0[j - 1] * gs[row], h1 = S.p0[j] * gs[S.nrows + row], h2 = S.p0[j + 1] * gs[2 * S.nrows + row];
+    sph_t4_entry(tscale[q], g0, g1, h0, h1, h2, t[0], t[1], t[2], t[3]);
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 
 #include "sph_force.h"
@@ -616,6 +646,8 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     // inactive levels.
     uint32_t keep[66];
     const bool had = c->lev_host_valid && (ordered || c->partition_stale);
+    // a commit left to this sort: it must be the sort of exactly the slots the sweep examined
+    if (c->commit_pending && !(stale_ok && c->stale_lo == lo && dmax >= lo) && (rc = expamd_comp_flush_commit(c))) return rc;
     c->partition_stale = false;         // (the sort below settles it: the active range, or everything)
     if (had) for (int k = 0; k <= ms + 1; k++) keep[k] = c->lev_host[k];
     // (a closing half-kick still owed rides along with the pass that advances its levels)
@@ -626,6 +658,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
       if (rc) return rc;
     }
+    c->commit_pending = false;          // (the scatter stored the proposed levels)
     if (had) {     // an advance changes no level population: the host mirror stays what it was
       for (int k = 0; k <= ms + 1; k++) c->lev_host[k] = keep[k];
       c->lev_host_valid = true;
@@ -637,13 +670,15 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       static const bool fuse_on = [] { const char *e = getenv("EXP_AMD_THIN_ADVANCE"); return !e || atoi(e) != 0; }();
       static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
-      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max &&
+      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
                         !ctx->deterministic && f->ncoef <= 4096 && thin_v == 1 && !f->generic;
       if (fuse) {
         f->adv_owed = true;
         f->adv_dt_min = dt_min;
       } else if ((rc = expamd_comp_advance_levels(c, dmax + 1, ms, dt_min, ms))) return rc;
     }
+    // (a half-kick owed by levels of the advanced range that no pass took along: that range was empty)
+    if (c->pending_kick != 0.0 && adv.mode && !f->adv_owed && lo <= c->pending_lo) { c->pending_kick = 0.0; c->pending_lo = 0; }
   }
   if (phase == 1) return EXP_AMD_OK;
   const SphDev S = dev_acc(f, c);
@@ -686,7 +721,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's partial sums
   // (k_sph_acc_thin), no moments and no contraction (the deterministic mode keeps the moment path: its rounding grid
   // is that of the moment terms)
-  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max && !ctx->deterministic &&
+  const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max * ctx->thin_acc_scale && !ctx->deterministic &&
                     f->ncoef <= 4096;
   // (the advance this kernel was to perform, should it not run after all)
   if (f->adv_owed && !(thin && nrange)) {
@@ -752,9 +787,16 @@ int sph_project(SphForce *f)
   if (!f->proj_dirty) return EXP_AMD_OK;
   exp_amd_ctx *ctx = f->ctx;
   ProfScope ps(ctx, "k_sph_project");
-  k_sph_project<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_coef.p, f->d_G.p);
-  k_sph_project4<<<f->cfg.numr - 1, 256, 0, ctx->stream>>>(f->dev, f->d_G.p, f->d_rowmap.p,
-                                                          f->d_tscale.p, f->d_T4.p);
+  static const bool both = [] { const char *e = getenv("EXP_AMD_SPH_PROJECT_BOTH"); return !e || atoi(e) != 0; }();
+  const size_t lds = (size_t)3 * f->dev.nrows * sizeof(double);
+  if (both && lds <= 48 * 1024 && f->cfg.numr >= 3)
+    k_sph_project_both<<<f->cfg.numr - 1, 256, lds, ctx->stream>>>(f->dev, f->d_coef.p, f->d_rowmap.p, f->d_tscale.p,
+                                                                   f->d_G.p, f->d_T4.p);
+  else {
+    k_sph_project<<<f->cfg.numr, 256, 0, ctx->stream>>>(f->dev, f->d_coef.p, f->d_G.p);
+    k_sph_project4<<<f->cfg.numr - 1, 256, 0, ctx->stream>>>(f->dev, f->d_G.p, f->d_rowmap.p,
+                                                            f->d_tscale.p, f->d_T4.p);
+  }
   HIP_TRY(ctx, hipGetLastError());
   f->proj_dirty = false;
   return EXP_AMD_OK;

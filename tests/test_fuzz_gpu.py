@@ -42,6 +42,25 @@ def test_fuzz_multistep_slice():
     assert m.total_switches > 0, "no level change in the whole slice: the campaign is not exercising the sweep"
 
 
+# (seed, trial) pairs of tests/fuzz/fuzz_multistep.py that once failed: kept as regressions
+MULTISTEP_REPLAYS = [
+    (61, 386),   # an EMPTY top level at a sweep that cannot move anything, populated by the next sweep: the closing kick folded
+                 # into the next advance (exp_amd_comp::pending_kick) must not be owed by particles that arrive later
+]
+
+
+@pytest.mark.parametrize("seed,trial", MULTISTEP_REPLAYS)
+def test_fuzz_multistep_replays(seed, trial):
+    m = _campaign("fuzz_multistep")
+    try:
+        res = m.one(trial, np.random.default_rng([seed, trial]))
+    finally:
+        m.ctx.set_dense_min(-1)
+        m.ctx.set_mover_list_min(2048)
+        m.ctx.set_thin_max(4096)
+    assert res in ("ok", "edge"), f"fuzz_multistep seed {seed} trial {trial}: {res}"
+
+
 def test_fuzz_kdk_slice():
     """the fused single-level step and its HIP-graph replay against the n-body oracle"""
     m = _campaign("fuzz_kdk")
