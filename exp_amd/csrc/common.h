@@ -72,7 +72,9 @@ struct exp_amd_ctx {
   long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (EXP_AMD_MOVER_SLICES_MIN)
   long long stage_max = 1 << 20;     // particles up to which the per-particle atomic paths are staged (values by plain stores,
                                      // one lane per value for the atomics): 8 (L+1)^2 bytes each (EXP_AMD_STAGE_MAX)
-  long long thin_acc_scale = 1;      // ... times this for the accumulation side alone (EXP_AMD_THIN_ACC_SCALE: experiment)
+  long long thin_acc_scale = 4;      // ... times this for the accumulation side alone (the direct kernel replaces three launches
+                                     // there; config 4, 13e3 particles in the halo's levels >= 2: 6.05 -> 5.93 ms per master step;
+                                     // EXP_AMD_THIN_ACC_SCALE)
   long long thin_max = 4096;         // block multistep: an active slot range of at most this many particles, all of it in sparse
                                      // levels, is accumulated and evaluated straight from the basis tables (k_*_acc_thin,
                                      // k_*_force_thin: no moments, no contraction, no projected table); 0: never

@@ -97,7 +97,9 @@ int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
  * the particles' own work.  Any force evaluation on at most `nmax` target particles (a cross force on another
  * component's thin active set included) takes the same route.  Same results up to the order of the sums.
  * Default 4096 (EXP_AMD_THIN_MAX overrides; the direct kernels cost ~5 ns per particle and kernel against the table
- * path's ~100 us of fixed costs per sub-step and component); 0: never.                                            */
+ * path's ~100 us of fixed costs per sub-step and component); 0: never.  The ACCUMULATION side alone takes the direct
+ * route up to 4 x nmax particles (one launch there against three; EXP_AMD_THIN_ACC_SCALE), and the level-change
+ * differencing of at most nmax movers does too.                                                                   */
 int  exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax);
 /* Second knob of the same loop: how the coefficient sets are differenced when particles change level
  * (multistep_update, src/SphericalBasis.cc:1156-1228, src/CylEXP.cc:159-188).  The slots of the movers of a
