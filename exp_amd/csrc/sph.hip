@@ -789,7 +789,9 @@ int sph_project(SphForce *f)
   ProfScope ps(ctx, "k_sph_project");
   static const bool both = [] { const char *e = getenv("EXP_AMD_SPH_PROJECT_BOTH"); return !e || atoi(e) != 0; }();
   const size_t lds = (size_t)3 * f->dev.nrows * sizeof(double);
-  if (both && lds <= 48 * 1024 && f->cfg.numr >= 3)
+  // (one launch where a block's three nodes' rows fit one round of its threads -- lmax <= 8; above, the threefold sums
+  // cost more than the launch saved: lmax 10, nmax 24: 35 us against 11 + 5)
+  if (both && 3 * f->dev.nrows <= 256 && lds <= 48 * 1024 && f->cfg.numr >= 3)
     k_sph_project_both<<<f->cfg.numr - 1, 256, lds, ctx->stream>>>(f->dev, f->d_coef.p, f->d_rowmap.p, f->d_tscale.p,
                                                                    f->d_G.p, f->d_T4.p);
   else {
