@@ -66,7 +66,7 @@ struct exp_amd_ctx {
   bool prekick = true;               // the fused step stores velocities with the NEXT step's opening half-kick applied
                                      // (exp_amd_ctx_set_prekick; EXP_AMD_PREKICK=0 sets the default off)
   bool deterministic = false;        // order-independent (bit-reproducible) coefficient sums, exp_amd_ctx_set_deterministic
-  long long mover_list_min = 2048;   // block multistep: from this many level changes in a sweep on, the differencing goes
+  long long mover_list_min = 8192;   // block multistep: from this many level changes in a sweep on, the differencing goes
                                      // through the accumulation kernel over a list of the movers instead of per-particle
                                      // atomics (EXP_AMD_MOVER_LIST_MIN; < 0: never)
   long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (EXP_AMD_MOVER_SLICES_MIN)
@@ -75,7 +75,7 @@ struct exp_amd_ctx {
   long long thin_acc_scale = 4;      // ... times this for the accumulation side alone (the direct kernel replaces three launches
                                      // there; config 4, 13e3 particles in the halo's levels >= 2: 6.05 -> 5.93 ms per master step;
                                      // EXP_AMD_THIN_ACC_SCALE)
-  long long thin_max = 4096;         // block multistep: an active slot range of at most this many particles, all of it in sparse
+  long long thin_max = 8192;         // block multistep: an active slot range of at most this many particles, all of it in sparse
                                      // levels, is accumulated and evaluated straight from the basis tables (k_*_acc_thin,
                                      // k_*_force_thin: no moments, no contraction, no projected table); 0: never
                                      // (exp_amd_ctx_set_thin_max; EXP_AMD_THIN_MAX sets the default)

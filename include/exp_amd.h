@@ -96,17 +96,18 @@ int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
  * moments and a projected table whose fixed costs (contraction over every cell, projection of every table row) dwarf
  * the particles' own work.  Any force evaluation on at most `nmax` target particles (a cross force on another
  * component's thin active set included) takes the same route.  Same results up to the order of the sums.
- * Default 4096 (EXP_AMD_THIN_MAX overrides; the direct kernels cost ~5 ns per particle and kernel against the table
+ * Default 8192 (EXP_AMD_THIN_MAX overrides; the direct kernels cost ~5 ns per particle and kernel against the table
  * path's ~100 us of fixed costs per sub-step and component); 0: never.  The ACCUMULATION side alone takes the direct
  * route up to 4 x nmax particles (one launch there against three; EXP_AMD_THIN_ACC_SCALE), and the level-change
  * differencing of at most nmax movers does too.                                                                   */
 int  exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax);
 /* Second knob of the same loop: how the coefficient sets are differenced when particles change level
  * (multistep_update, src/SphericalBasis.cc:1156-1228, src/CylEXP.cc:159-188).  The slots of the movers of a
- * sweep are compacted into a list; below `nmin` movers each adds and subtracts its own contribution with
- * fp64 atomics, from `nmin` on the list goes through the accumulation kernels, which sum runs of equal
+ * sweep are compacted into a list; below `nmin` movers each adds and subtracts its own contribution (straight
+ * from the basis tables up to thin_max of them, through staged fp64 atomics above), from `nmin` on the list goes
+ * through the accumulation kernels, which sum runs of equal
  * (level, cell) in registers (the first sweeps of a run move several per cent of a component at once).
- * Same results up to rounding (each way is order-independent in deterministic mode).  Default 2048
+ * Same results up to rounding (each way is order-independent in deterministic mode).  Default 8192
  * (EXP_AMD_MOVER_LIST_MIN overrides); 0: always the accumulation kernels; < 0: never.                */
 int  exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin);
 void *exp_amd_ctx_stream(exp_amd_ctx *ctx);

@@ -128,8 +128,8 @@ def main():
     for t in range(trials):
         tally[one(t, np.random.default_rng([seed0, t]))] += 1
     ctx.set_dense_min(-1)
-    ctx.set_mover_list_min(2048)
-    ctx.set_thin_max(4096)
+    ctx.set_mover_list_min(8192)
+    ctx.set_thin_max(8192)
     print(f"{trials} trials: {tally}, {total_switches} level changes in all, {time.time() - t0:.0f} s")
     sys.exit(1 if tally["LEVELS"] or tally["STATE"] else 0)
 

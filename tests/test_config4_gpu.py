@@ -71,7 +71,7 @@ def _compare(tag, forces, comps, want, multistep):
     (100, 2048, 40), (-1, 16, 300)])
 def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin_max):
     """thin_max: the size of an active slot range up to which it is accumulated and evaluated straight from the basis
-    tables (runtime.Context.set_thin_max; 4096 = the default; 16384 here: with dense_min -1 EVERY sub-step of this small run takes
+    tables (runtime.Context.set_thin_max; 8192 = the default; 16384 here: with dense_min -1 EVERY sub-step of this small run takes
     the direct kernels of both bases -- k_sph_acc_thin / k_sph_force_thin, k_cyl_acc_thin / k_cyl_force_thin -- for the
     self forces and both cross forces; 0: never, the moment / projected-table path alone; 40 and 300: the two mixed, by
     sub-step).  dense_min: the level population below which a level is kept unsorted (runtime.Context.
@@ -112,8 +112,8 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin
         assert (np.bincount(want(name, "level"), minlength=ms + 1) >= 30).sum() >= 4
     assert sim.time == pytest.approx((c4.NSTEPS + 1) * dtime)
     ctx.set_dense_min(-1)
-    ctx.set_mover_list_min(2048)
-    ctx.set_thin_max(4096)
+    ctx.set_mover_list_min(8192)
+    ctx.set_thin_max(8192)
 
 
 def test_config4_against_the_golden_file(ctx):
@@ -276,7 +276,7 @@ def test_thin_kernels_reproduce_the_table_path(ctx, monkeypatch, thin_v):
         sim.close()
         for o in list(forces) + list(comps):
             o.close()
-    ctx.set_thin_max(4096)
+    ctx.set_thin_max(8192)
     for (l0, d0, s0), (l1, d1, s1) in zip(*runs):
         assert np.array_equal(l0, l1)
         assert np.abs(s0 - s1).max() <= 1e-12 * np.abs(s0).max()

@@ -34,8 +34,8 @@ def test_fuzz_multistep_slice():
         res = [m.one(t, np.random.default_rng([SEED, t])) for t in range(60)]
     finally:
         m.ctx.set_dense_min(-1)
-        m.ctx.set_mover_list_min(2048)
-        m.ctx.set_thin_max(4096)
+        m.ctx.set_mover_list_min(8192)
+        m.ctx.set_thin_max(8192)
     bad = [(t, r) for t, r in enumerate(res) if r in ("LEVELS", "STATE")]
     assert not bad, f"fuzz_multistep failures (trial, kind) at seed {SEED}: {bad}"
     assert res.count("edge") <= 2, "more than a couple of power-of-two boundary cases: not rounding"
@@ -56,8 +56,8 @@ def test_fuzz_multistep_replays(seed, trial):
         res = m.one(trial, np.random.default_rng([seed, trial]))
     finally:
         m.ctx.set_dense_min(-1)
-        m.ctx.set_mover_list_min(2048)
-        m.ctx.set_thin_max(4096)
+        m.ctx.set_mover_list_min(8192)
+        m.ctx.set_thin_max(8192)
     assert res in ("ok", "edge"), f"fuzz_multistep seed {seed} trial {trial}: {res}"
 
 
