@@ -2083,6 +2083,7 @@ struct CylForce : exp_amd_force {
   int work_flip = 0;
   int step_parity() const override { return work_flip; }
   bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
+  bool external_shares_no_scratch() const override { return !ctx->deterministic; }
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_cyl_acc_thin
   double adv_dt_min = 0.0;
   bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)
@@ -2836,6 +2837,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   if (thin) {
     int rc_ = ensure_tabT();
     if (rc_) return rc_;
+    if (!external && f->ev_tables) HIP_TRY(ctx, hipEventRecord(f->ev_tables, ctx->stream));
     f->mass_open = false;
     if (nthin) {
       ProfScope ps(ctx, "k_cyl_force_thin");
@@ -2866,6 +2868,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     HIP_TRY(ctx, hipGetLastError());
     f->proj_dirty = false;
   }
+  if (!external && f->ev_tables) HIP_TRY(ctx, hipEventRecord(f->ev_tables, ctx->stream));
   f->mass_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   // external target: positions go into the frame of the component the expansion was built from
@@ -2888,7 +2891,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     else {
       // main launch + tail launch (beyond 0.75 of the table radius); the work list holds one entry per wave at most
       const size_t need = t->n / 64 + 8;
-      if (f->work_cap < need) {
+      if (f->work_cap < need && !(external && f->work_cap > 0)) {      // (an external launch uses no list)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, f->d_work.alloc(CYL_WORK_STRIDE * need + 2));
         HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + CYL_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), ctx->stream));

@@ -44,7 +44,10 @@ struct exp_amd_sim {
   // ev_used[k] = the last use of force method k's tables by a cross force on the other stream.
   bool overlap = false;
   hipStream_t main_stream = nullptr;
-  std::vector<hipEvent_t> ev_self, ev_used;
+  std::vector<hipEvent_t> ev_self, ev_used, ev_tab;     // (ev_tab[k]: tables of force method k final, its self force not yet run)
+  bool early_cross = false;         // EXP_AMD_SIM_EARLY_CROSS=1 (experiment): cross forces wait for the source's tables only, not
+                                    // for its self force -- measured neutral on config 4 (5.93 against 5.90 ms: the two
+                                    // kernels then run side by side and slow each other by what the earlier start gains)
   std::vector<char> used_pending;
   hipEvent_t ev_join = nullptr;
   // EXP_AMD_HOST_TIMING=1: where the HOST spends a master step (seconds; printed by exp_amd_sim_destroy) -- issuing the
@@ -114,7 +117,11 @@ static int overlap_begin(exp_amd_sim *s)
     s->ev_self.push_back(a);
     s->ev_used.push_back(b);
     s->used_pending.push_back(0);
+    hipEvent_t c_;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&c_, hipEventDisableTiming));
+    s->ev_tab.push_back(c_);
   }
+  if (const char *e = getenv("EXP_AMD_SIM_EARLY_CROSS")) s->early_cross = atoi(e) != 0;
   if (!s->ev_join) HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   // whatever was issued on the context's stream so far precedes the auxiliary stream's work
   HIP_TRY(ctx, hipEventRecord(s->ev_join, ctx->stream));
@@ -183,6 +190,7 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
   if (s->ht_ev0) { (void)hipEventDestroy(s->ht_ev0); (void)hipEventDestroy(s->ht_ev1[0]); (void)hipEventDestroy(s->ht_ev1[1]); }
   for (auto &row : s->ht_mk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
+  for (auto e : s->ev_tab) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
@@ -366,13 +374,20 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
 {
   int rc;
   if ((rc = fix_centers(s, mstep))) return rc;
+  std::vector<char> early(s->comps.size(), 0);
   for (size_t k = 0; k < s->comps.size(); k++) {
     StreamOf on(s, k);
     exp_amd_force *f = s->forces[k];
     if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
     if (f->combined_mdrft != mdrft && (rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
     f->combined_mdrft = -1;
-    if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
+    // (two streams: the cross force of this basis on the other component needs its coefficient set and tables, not its
+    // self force -- which the call below records an event ahead of, where the external call shares no scratch with it)
+    early[k] = s->overlap && s->early_cross && f->external_shares_no_scratch();
+    f->ev_tables = early[k] ? s->ev_tab[k] : nullptr;
+    rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0);
+    f->ev_tables = nullptr;
+    if (rc) return rc;
     if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
     ht_mark(s, k, 1);
   }
@@ -382,7 +397,7 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     const bool foreign = s->overlap && ((pr.first ^ pr.second) & 1);
     if (foreign) {
       // the source's projected tables (and the scratch of its force pass) must be ready and free
-      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_self[pr.first], 0));
+      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, early[pr.first] ? s->ev_tab[pr.first] : s->ev_self[pr.first], 0));
       if (s->used_pending[pr.first]) HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[pr.first], 0));
     }
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;

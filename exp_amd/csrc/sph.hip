@@ -820,6 +820,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     thin = (long long)nthin <= ctx->thin_max;
   }
   if (!thin && (rc = sph_project(f))) return rc;
+  if (!external && f->ev_tables) HIP_TRY(ctx, hipEventRecord(f->ev_tables, ctx->stream));
   f->used_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   if (thin) {
@@ -865,7 +866,10 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   {
     unsigned grid = cdiv(nr, 256);     // one 64-particle chunk per wave, no loop
     const size_t need = t->n / 64 + 8;
-    if (f->work_cap < need) {
+    // (the work list belongs to the fast pass: the staged / gather evaluation of foreign or all-sparse targets has none --
+    // and must not re-allocate it under a self force that runs on the other stream, exp_amd_force::ev_tables)
+    const bool listless = !ctx->deterministic && (t->sorted_for != f || all_sparse);
+    if (f->work_cap < need && !(listless && f->work_cap > 0)) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       HIP_TRY(ctx, f->d_work.alloc(SPH_WORK_STRIDE * need + 2));   // work list + two counters (used alternately)
       HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + SPH_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), ctx->stream));

@@ -30,6 +30,7 @@ struct SphForce : exp_amd_force {
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
   bool used_open = true;
   bool wd_clean = false;            // ... and of d_Wd (multistep_update)
+  bool external_shares_no_scratch() const override { return !lit_on && !generic && !ctx->deterministic; }
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_sph_acc_thin
   double adv_dt_min = 0.0;
   bool part_clean = false;          // d_part is all zero (what the thin accumulation adds to; its summing kernels keep it so)
