@@ -77,8 +77,8 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin
     sub-step).  dense_min: the level population below which a level is kept unsorted (runtime.Context.
     set_dense_min): the default (-1) makes every level of this small run sparse, 0 makes all of them
     cell-sorted, 100 mixes the two paths.  list_min: the number of level changes in a sweep from which the
-    differencing runs the list of movers through the accumulation kernels (set_mover_list_min; 2048 = the
-    default: per-mover atomics throughout this small run, 0: always the accumulation kernels, 16: both)."""
+    differencing runs the list of movers through the accumulation kernels (set_mover_list_min; 8192 = the
+    default; at 2048: per-mover atomics throughout this small run, 0: always the accumulation kernels, 16: both)."""
     ctx.set_dense_min(dense_min)
     ctx.set_mover_list_min(list_min)
     ctx.set_thin_max(thin_max)
@@ -114,6 +114,17 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin
     ctx.set_dense_min(-1)
     ctx.set_mover_list_min(8192)
     ctx.set_thin_max(8192)
+
+
+def test_config4_with_early_cross_forces(ctx, oracle, monkeypatch):
+    """EXP_AMD_SIM_EARLY_CROSS=1 (read when a step driver starts its two streams): the cross forces start from the
+    source's tables-ready event, beside its self force, instead of behind it.  Off by default (measured neutral,
+    profiles/r04_cfg4_ab.txt); same results to the order of two additions."""
+    monkeypatch.setenv("EXP_AMD_SIM_EARLY_CROSS", "1")
+    try:
+        test_config4_against_the_nbody_oracle(ctx, oracle, 100, 8192, 40)
+    finally:
+        monkeypatch.delenv("EXP_AMD_SIM_EARLY_CROSS")
 
 
 def test_config4_against_the_golden_file(ctx):
