@@ -421,6 +421,9 @@ void SphForce::release()
   expamd_sph_cov_release(this);
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
+  if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
+  if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+  if (ev_side) { (void)hipEventDestroy(ev_side); ev_side = nullptr; }
 }
 
 static SphDev dev_for(const SphForce *f, const double center[3])
@@ -695,6 +698,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   int dacc = lo - 1;                    // last level the cell-ordered kernel takes
   for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
   size_t nrange = 0;
+  bool side_pending = false;            // a launch on f->side is under way: the contraction waits for it
   if (c->n && dacc >= lo && (rc = expamd_comp_level_count(c, lo, dacc, &nrange))) return rc;
   if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
@@ -703,17 +707,43 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     // Thickly and thinly populated levels go in SEPARATE launches (consecutive levels of one kind together): measured
     // on config 4, level 0 (9.6e6 particles, 3072-particle chunks) with levels 1-2 (2.5e5 + 1.2e5, 64-particle
     // chunks) in one launch takes 970 us, level 0 alone 240 us and the thin levels together 190 us.
+    // EXP_AMD_ACC_SIDE=1 (experiment): the thin ones BESIDE the thick one, on a stream of the force method's own
+    // (different moment buffers; the contraction below waits for it).  Measured neutral on config 4 (6.06 against 6.07 ms
+    // per master step, profiles/r04_cfg4_ab.txt): the first sub-step is bound by the GPU's throughput, not by its chains.
+    static const bool side_on = [] { const char *e = getenv("EXP_AMD_ACC_SIDE"); return e && atoi(e) != 0; }();
+    bool forked = false;
+    int ngroups = 0;
     for (int L0 = lo; L0 <= dacc;) {
       const bool thick = counts[L0 - lo] >= ACC_THICK_MIN;
       int L1 = L0;
       size_t nr = counts[L0 - lo];
       while (L1 + 1 <= dacc && (counts[L1 + 1 - lo] >= ACC_THICK_MIN) == thick) { L1++; nr += counts[L1 - lo]; }
       if (nr) {
+        hipStream_t st = ctx->stream;
+        if (side_on && ngroups > 0 && !ctx->deterministic) {
+          if (!f->side) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming));
+          }
+          if (!forked) {
+            // (what the first launch waited for -- the sort, the cleared moments -- this one waits for too)
+            HIP_TRY(ctx, hipEventRecord(f->ev_fork, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(f->side, f->ev_fork, 0));
+            forked = true;
+          }
+          st = f->side;
+        }
         SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, L0, L1,
-                     f->d_W.p, used_p, nr, ctx->stream, 1, counts + (L0 - lo), 1};
+                     f->d_W.p, used_p, nr, st, 1, counts + (L0 - lo), 1};
         sph_launch_acc(f, a);
+        ngroups++;
       }
       L0 = L1 + 1;
+    }
+    if (forked) {
+      HIP_TRY(ctx, hipEventRecord(f->ev_side, f->side));
+      side_pending = true;
     }
   }
   nrange = 0;
@@ -755,6 +785,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     if ((rc = sph_stage(f, nrange, a))) return rc;
     sph_launch_upd(f, a);
   }
+  if (side_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, f->ev_side, 0));
   {
     ProfScope ps(ctx, "k_sph_contract");
     if (!thin)
