@@ -481,6 +481,16 @@ def other_configs(ctx, device, n, which=(2, 3, 4), steps=30, min_seconds=0.0):
             el = tot / nm
         lev_h = np.bincount(ch.download_levels(), minlength=ms + 1)
         lev_d = np.bincount(cd.download_levels(), minlength=ms + 1)
+        # ... and once more, further along the same run: the populations of the upper levels keep thinning for a few dozen
+        # master steps (level 1 of the halo: 2.5e5 particles at step 14, 8e4 at step 48), which is where a long run lives
+        later = None
+        if min_seconds > 0.0:
+            nlate = 20
+            el_late = _timed(lambda: sim.step(1), nlate, 40 - settle - nper if 40 - settle - nper > 0 else 0)
+            later = {"ms_per_master_step": 1e3 * el_late, "timed_master_steps": nlate,
+                     "untimed_master_steps_before": max(40, settle + nper),
+                     "levels_halo": np.bincount(ch.download_levels(), minlength=ms + 1).tolist(),
+                     "levels_disk": np.bincount(cd.download_levels(), minlength=ms + 1).tolist()}
         ctx.profile(True); ctx.profile_reset()
         sim.step(1)
         rep_ = ctx.profile_report()
@@ -498,6 +508,7 @@ def other_configs(ctx, device, n, which=(2, 3, 4), steps=30, min_seconds=0.0):
                     "raw_particle_substeps_per_s": sub / el,
                     "substeps_hbm_frac_264B": 264.0 * sub / el / 1e9 / HBM_PEAK_GBS,
                     "levels_halo": lev_h.tolist(), "levels_disk": lev_d.tolist(),
+                    "later_in_the_run": later,
                     "level_switches_last_master_step": sim.step_switches,
                     "kernels_ms_per_master_step": prof, "kernel_scopes_per_master_step": prof_n})
         sim.close(); ch.close(); cd.close(); fh.close(); fd.close()
