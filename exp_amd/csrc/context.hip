@@ -1,5 +1,6 @@
 // Context, error reporting, profiling and the coefficient all-reduce of libexp_amd.
 #include "common.h"
+#include <chrono>
 
 #include <dlfcn.h>
 
@@ -179,6 +180,13 @@ static hipEvent_t get_event(exp_amd_ctx *ctx)
 
 ProfScope::ProfScope(exp_amd_ctx *c, const char *name, hipStream_t on) : ctx(c)
 {
+  // EXP_AMD_HOST_DELAY_NS=n (experiment): the host idles n ns in front of every kernel scope -- how much of a run's time
+  // follows the host's issue rate (tools/dbg/ab_cfg4_env.sh; profiles/r04_cfg4_ab.txt)
+  static const long delay_ns = [] { const char *e = getenv("EXP_AMD_HOST_DELAY_NS"); return e ? atol(e) : 0L; }();
+  if (delay_ns > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() < delay_ns) {}
+  }
   if (!ctx || !ctx->profile) return;
   st = on ? on : ctx->stream;
   for (size_t i = 0; i < ctx->slots.size(); i++)
