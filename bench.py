@@ -96,6 +96,12 @@ def parse_args():
     ap.add_argument("--force-comm", action="store_true",
                     help="initialise the process group and run the coefficient all-reduce even at "
                          "world size 1 (exercises the multi-GPU path on a single-GPU box)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="dress rehearsal of the N > 1 launch on a ONE-GPU box: every rank uses device 0, the process "
+                         "group is gloo, and the coefficient all-reduce is host-staged through it (RCCL refuses two ranks "
+                         "on one device).  Sharding, the communicator vote and its fallback, the MAX-reduce of the timings "
+                         "and the rank-0-only JSON line are the production code; the rate it prints is NOT a scaling "
+                         "measurement (the ranks time-share one GPU) and the line says so")
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
                     help="coefficient all-reduce through the library's own RCCL communicator on the "
                          "compute stream (default; falls back to torch.distributed if its self-check "
@@ -540,13 +546,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    rehearse = bool(args.rehearse_shared_gpu)
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_comm = world > 1 or args.force_comm
+    # tensors handed to torch.distributed (the vote, the MAX of the timings): on the device for RCCL, on the host for gloo
+    cdev = torch.device("cpu") if rehearse else device
     if use_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def reduce_max(v):
+        """MAX over the ranks of one host number (the timed regions)"""
+        if not use_comm:
+            return float(v)
+        t_ = torch.tensor([v], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
 
     from exp_amd.models import NFWModel
     from exp_amd.runtime import Component, Context, SphereSL
@@ -561,12 +582,17 @@ def main():
     if args.scaling == "weak":
         nloc = int(args.nbodies)
         ntot = nloc * world
+        x, y, z, vx, vy, vz = make_halo(model, nloc, seed=23456 + rank, device=device)
     else:
+        # strong scaling: ONE particle set whatever the rank count -- every rank draws the whole set from the same seed
+        # and keeps its block, so that an N-rank run is the 1-rank run sharded (selfcheck.coef_00_0 agrees to rounding)
         ntot = int(args.nbodies)
         n0 = ntot * rank // world
         n1 = ntot * (rank + 1) // world
         nloc = n1 - n0
-    x, y, z, vx, vy, vz = make_halo(model, nloc, seed=23456 + rank, device=device)
+        full = make_halo(model, ntot, seed=23456, device=device)
+        x, y, z, vx, vy, vz = full if world == 1 else tuple(a[n0:n1].clone() for a in full)
+        del full
     mass = torch.full((nloc,), 1.0 / ntot, device=device, dtype=torch.float64)
     torch.cuda.synchronize()
 
@@ -574,7 +600,7 @@ def main():
     # (issued from the coefficient callback) is ordered with the kernels
     tstream = torch.cuda.Stream(device)
     torch.cuda.set_stream(tstream)
-    ctx = Context(local_rank, stream=tstream.cuda_stream)
+    ctx = Context(dev_index, stream=tstream.cuda_stream)
     comp = Component(ctx, nloc)
     comp.upload_device(mass, x, y, z, vx, vy, vz)
     del x, y, z, vx, vy, vz, mass
@@ -582,33 +608,52 @@ def main():
     force = SphereSL(ctx, grid)
 
     comm_used = "none"
+    comm_note = None
     if use_comm:
         comm_used = None
         if args.comm == "rccl":
             # the library's own communicator: id from rank 0 through the process group, then a
             # known-answer all-reduce (every rank contributes rank + 1) before it is trusted
-            try:
-                ids = [Context.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                ctx.init_rccl(ids[0], world, rank)
-                with torch.cuda.stream(tstream):
-                    probe = torch.full((64,), float(rank + 1), device=device, dtype=torch.float64)
-                    ctx.allreduce(probe.data_ptr(), probe.numel())
-                    tstream.synchronize()
-                ok = bool((probe == world * (world + 1) / 2.0).all().item())
-            except Exception as e:          # pragma: no cover
-                print(f"[bench] rank {rank}: native RCCL communicator failed ({e!r})", file=sys.stderr)
-                ok = False
-            flag = torch.tensor([1 if ok else 0], device=device)
+            ok = False
+            if rehearse and world > 1:
+                # RCCL refuses two ranks on one device: not attempted; every rank votes "failed", which takes the
+                # same vote + fallback path a real failure takes
+                comm_note = "native RCCL communicator not attempted (ranks share device 0): voted down"
+            else:
+                try:
+                    ids = [Context.rccl_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    ctx.init_rccl(ids[0], world, rank)
+                    with torch.cuda.stream(tstream):
+                        probe = torch.full((64,), float(rank + 1), device=device, dtype=torch.float64)
+                        ctx.allreduce(probe.data_ptr(), probe.numel())
+                        tstream.synchronize()
+                    ok = bool((probe == world * (world + 1) / 2.0).all().item())
+                except Exception as e:          # pragma: no cover
+                    print(f"[bench] rank {rank}: native RCCL communicator failed ({e!r})", file=sys.stderr)
+                    ok = False
+                # test hook: EXP_AMD_BENCH_FAIL_RCCL = "all" or a rank number makes that rank vote "failed" AFTER the
+                # (collective) set-up, so that the fallback below can be exercised where RCCL works
+                forced = os.environ.get("EXP_AMD_BENCH_FAIL_RCCL")
+                if forced and (forced == "all" or forced == str(rank)):
+                    ok = False
+                    comm_note = f"native RCCL communicator voted down by EXP_AMD_BENCH_FAIL_RCCL={forced}"
+            flag = torch.tensor([1 if ok else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 comm_used = "rccl (library communicator, ncclAllReduce on the compute stream)"
             elif rank == 0:
-                print("[bench] falling back to the torch.distributed all-reduce callback", file=sys.stderr)
+                print("[bench] falling back to the all-reduce callback", file=sys.stderr)
         if comm_used is None:
-            from exp_amd.dist import torch_allreduce_callback
-            ctx.set_allreduce(torch_allreduce_callback(device))
-            comm_used = "torch.distributed all-reduce callback" + (" (fallback)" if args.comm == "rccl" else "")
+            fb = " (fallback)" if args.comm == "rccl" else ""
+            if rehearse:
+                from exp_amd.dist import host_staged_allreduce_callback
+                ctx.set_allreduce(host_staged_allreduce_callback(), world, rank)
+                comm_used = "host-staged all-reduce callback through gloo (rehearsal on a shared GPU)" + fb
+            else:
+                from exp_amd.dist import torch_allreduce_callback
+                ctx.set_allreduce(torch_allreduce_callback(device), world, rank)
+                comm_used = "torch.distributed all-reduce callback" + fb
 
     def barrier():
         if use_comm:
@@ -633,11 +678,7 @@ def main():
         tg = time.perf_counter()
         force.step_kdk_n(comp, args.dt, args.steps)
         barrier()
-        eg = time.perf_counter() - tg
-        if use_comm:
-            tgt = torch.tensor([eg], device=device, dtype=torch.float64)
-            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
-            eg = float(tgt.item())
+        eg = reduce_max(time.perf_counter() - tg)
         graph_region = {"steps": args.steps, "seconds": eg, "ms_per_step": 1e3 * eg / args.steps}
     ctx.profile(True)
     ctx.profile_reset()
@@ -672,11 +713,7 @@ def main():
             for _ in range(ns):
                 force.step_kdk(comp, args.dt)
         barrier()
-        es = time.perf_counter() - t1
-        if use_comm:
-            ts = torch.tensor([es], device=device, dtype=torch.float64)
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            es = float(ts.item())
+        es = reduce_max(time.perf_counter() - t1)
         sustained = {"steps": ns, "seconds": es, "ms_per_step": 1e3 * es / ns, "value": ntot * ns / es}
 
     # Full-size sanity of what was just timed (size-independent properties, no oracle): every
@@ -691,10 +728,7 @@ def main():
                  "center_of_acceleration": [float(v) for v in com["coa"]],
                  "mtot": com["mtot"], "coef_00_0": coef00}
 
-    if use_comm:
-        t = torch.tensor([el], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = reduce_max(el)
 
     if rank == 0:
         if graph_region:                # --graph: the timed region is the replayed one
@@ -792,7 +826,9 @@ def main():
                        "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"
                                       if world > 1 else "single GPU",
                        # which all-reduce really ran, the rank count it saw and how often it was issued
-                       "comm": {"path": comm_used, **ctx.comm_info()}},
+                       "comm": {"path": comm_used, "note": comm_note, **ctx.comm_info()},
+                       "rehearsal": ("ranks time-share ONE GPU (gloo process group, host-staged all-reduce): a dress "
+                                     "rehearsal of the launch, not a scaling measurement") if rehearse else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "selfcheck": selfcheck,

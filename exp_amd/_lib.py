@@ -53,6 +53,7 @@ SIGNATURES = {
     "exp_amd_comm_get_unique_id": (c_int, [c_void_p]),
     "exp_amd_comm_init_rank": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "exp_amd_comm_set_callback": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
+    "exp_amd_comm_set_world": (c_int, [c_void_p, c_int, c_int]),
     "exp_amd_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_longlong)]),
     "exp_amd_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_comp_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),

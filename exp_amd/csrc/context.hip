@@ -319,8 +319,25 @@ extern "C" int exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn 
   return EXP_AMD_OK;
 }
 
+// the world a host-provided callback reduces over (exp_amd_comm_init_rank states its own)
+extern "C" int exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank)
+{
+  expamd_mutated();
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks)
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_set_world: bad arguments");
+  if (ctx->rccl_comm && (nranks != ctx->nranks || rank != ctx->rank))
+    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_set_world: (%d, %d) contradicts the RCCL communicator's (%d, %d)",
+                       nranks, rank, ctx->nranks, ctx->rank);
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return EXP_AMD_OK;
+}
+
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count)
 {
+  if (ctx->nranks > 1 && !ctx->ar_fn && !ctx->rccl_comm)
+    return expamd_fail(ctx, EXP_AMD_ERR_COMM, "all-reduce over %d ranks asked for, but the context has neither an RCCL "
+                       "communicator nor a callback", ctx->nranks);
   if (ctx->ar_fn) {
     ProfScope ps(ctx, "allreduce(callback)");
     int rc = ctx->ar_fn((void *)dev, count, (void *)ctx->stream, ctx->ar_user);

@@ -74,6 +74,30 @@ def torch_allreduce_callback(device=None, group=None):
     return fn
 
 
+def host_staged_allreduce_callback(group=None):
+    """Callback for Context.set_allreduce that stages the buffer through the host: stream sync, D2H copy, a
+    torch.distributed all-reduce of the host array (gloo, or whatever backend `group` has), H2D copy.  For ranks that
+    SHARE a device (RCCL refuses that: test boxes, rehearsals of a multi-rank launch on one GPU) and for hosts whose
+    only collective is a CPU one.  Costs two synchronous copies per reduction; not a production path."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def fn(ptr: int, count: int, stream: int) -> None:
+        buf = np.empty(count)
+        if hip.hipStreamSynchronize(ctypes.c_void_p(stream)) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
+        if hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(count * 8), 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+        if hip.hipMemcpy(ctypes.c_void_p(ptr), buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(count * 8), 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    return fn
+
+
 def allreduce_coefs_(coef: np.ndarray, group=None) -> np.ndarray:
     """Host-array flavour (gloo / CPU tests, or host-staged MPI-style callers): in place."""
     import torch

@@ -39,8 +39,11 @@ class Context:
         self._children = []
 
     # -- collectives ---------------------------------------------------------------------
-    def set_allreduce(self, fn) -> None:
-        """fn(ptr:int, count:int, stream:int) reduces `count` doubles in place (SUM)."""
+    def set_allreduce(self, fn, nranks: Optional[int] = None, rank: int = 0) -> None:
+        """fn(ptr:int, count:int, stream:int) reduces `count` doubles in place (SUM) over `nranks` ranks (the size
+        and rank of the host's communicator, ``exp_amd_comm_set_world``: what ``comm_info`` reports; optional)."""
+        if nranks is not None:
+            check(self.lib.exp_amd_comm_set_world(self.h, int(nranks), int(rank)), self.h)
         if fn is None:
             self._cb = None
             check(self.lib.exp_amd_comm_set_callback(self.h, _lib.ALLREDUCE_FN(), None), self.h)

@@ -124,6 +124,11 @@ int  exp_amd_comm_get_unique_id(void *id128);
 int  exp_amd_comm_init_rank(exp_amd_ctx *ctx, const void *id128, int nranks, int rank);
 typedef int (*exp_amd_allreduce_fn)(void *buf, size_t count, void *stream, void *user);
 int  exp_amd_comm_set_callback(exp_amd_ctx *ctx, exp_amd_allreduce_fn fn, void *user);
+/* The world the callback of (b) reduces over (MPI_Comm_size / MPI_Comm_rank of the host's communicator): what
+ * exp_amd_comm_info then reports, and what rank-dependent host logic above the ABI may read back.  (a) sets both
+ * itself; contradicting it is EXP_AMD_ERR_ARG.  A context told nranks > 1 that has neither a communicator nor a
+ * callback fails its first reduction with EXP_AMD_ERR_COMM instead of silently keeping rank-local sums.          */
+int  exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank);
 /* Which reduction the context uses -- kind 0: none (single rank), 1: the library's RCCL communicator,
  * 2: the host's callback -- with the rank count / rank it was given and the number of all-reduces
  * issued so far; any output pointer may be NULL.                                                */

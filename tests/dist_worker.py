@@ -1,7 +1,6 @@
 """Worker of tests/test_dist_gpu.py: one rank of a 2-process run that SHARES one GPU.  The data-path
 collective (one all-reduce of a small device buffer) goes host-staged through gloo, so that two
 ranks can sit on the same device (RCCL refuses that); everything else is the production path."""
-import ctypes
 import os
 import sys
 
@@ -15,21 +14,12 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     import torch
     import torch.distributed as dist
-    from exp_amd.dist import shard_range
+    from exp_amd.dist import host_staged_allreduce_callback, shard_range
     from exp_amd.models import sample_sphere
     from exp_amd.runtime import Component, Context, Orient, SphereSL
     from tests.conftest import make_grid
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    hip = ctypes.CDLL("libamdhip64.so")
-
-    def host_staged_allreduce(ptr, count, stream):
-        buf = np.empty(count)
-        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream)) == 0
-        assert hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), count * 8, 2) == 0
-        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
-        assert hip.hipMemcpy(ctypes.c_void_p(ptr), buf.ctypes.data_as(ctypes.c_void_p), count * 8, 1) == 0
-
     model, g = make_grid("plummer", 4, 8, 400)
     n = 40001
     m, pos, vel = sample_sphere(model, n, seed=61)
@@ -37,7 +27,7 @@ def main():
     n0, n1 = shard_range(n, rank, world)
     ctx = Context(0)
     if world > 1:
-        ctx.set_allreduce(host_staged_allreduce)
+        ctx.set_allreduce(host_staged_allreduce_callback(), world, rank)
     f = SphereSL(ctx, g)
     c = Component.from_arrays(ctx, m[n0:n1], pos[n0:n1], vel[n0:n1])
     f.determine_coefficients(c)
