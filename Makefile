@@ -5,6 +5,11 @@ HIPCC    ?= hipcc
 ARCH     ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -munsafe-fp-atomics -Wall \
             -Rpass-analysis=kernel-resource-usage
+# make EXPERIMENTAL=1: the tuning / A-B switches of the development rounds become environment variables again
+# (EXPAMD_EXPT in exp_amd/csrc/common.h); the default build compiles them to their defaults
+ifeq ($(EXPERIMENTAL),1)
+HIPFLAGS += -DEXP_AMD_EXPERIMENTAL
+endif
 OBJ      := build/obj
 CSRC     := exp_amd/csrc
 SPH_LS   := 0 1 2 3 4 5 6 7 8 9 10 11 12

@@ -29,6 +29,16 @@ inline void expamd_mutated() { expamd_mutation_counter().fetch_add(1, std::memor
 
 #include "../../include/exp_amd.h"
 
+// Run-time switches.  The default build reads only the few environment variables documented in include/exp_amd.h
+// ("Environment"); the tuning and A/B switches of the development rounds are compile-time constants -- unless the library
+// is built with -DEXP_AMD_EXPERIMENTAL (make EXPERIMENTAL=1), which turns each EXPAMD_EXPT(name, default) back into an
+// environment variable read once.
+#ifdef EXP_AMD_EXPERIMENTAL
+#define EXPAMD_EXPT(name, dflt) ([&] { static const long long v_ = [&] { const char *e_ = getenv(name); return e_ ? atoll(e_) : (long long)(dflt); }(); return v_; }())
+#else
+#define EXPAMD_EXPT(name, dflt) ((long long)(dflt))
+#endif
+
 #define EXPAMD_WAVE 64
 
 struct ProfileSlot {

@@ -42,15 +42,10 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
                        device, ndev);
   exp_amd_ctx *ctx = new exp_amd_ctx;
   ctx->device = device;
-  if (const char *e = getenv("EXP_AMD_SPLIT_MIN")) ctx->split_min = atoll(e);
-  if (const char *e = getenv("EXP_AMD_DENSE_MIN")) ctx->dense_min = atoll(e);
-  if (const char *e = getenv("EXP_AMD_THIN_MAX")) ctx->thin_max = atoll(e);
-  if (const char *e = getenv("EXP_AMD_MOVER_LIST_MIN")) ctx->mover_list_min = atoll(e);
-  if (const char *e = getenv("EXP_AMD_THIN_ACC_SCALE")) ctx->thin_acc_scale = atoll(e) > 0 ? atoll(e) : 1;
-  if (const char *e = getenv("EXP_AMD_MOVER_SLICES_MIN")) ctx->mover_slices_min = atoll(e);
-  if (const char *e = getenv("EXP_AMD_STAGE_MAX")) ctx->stage_max = atoll(e);
-  if (const char *e = getenv("EXP_AMD_DETERMINISTIC")) ctx->deterministic = atoi(e) != 0;
-  if (const char *e = getenv("EXP_AMD_PREKICK")) ctx->prekick = atoi(e) != 0;
+  // (tuning constants of the block-multistep engine without a setter of their own)
+  ctx->thin_acc_scale = EXPAMD_EXPT("EXP_AMD_THIN_ACC_SCALE", ctx->thin_acc_scale) > 0 ? EXPAMD_EXPT("EXP_AMD_THIN_ACC_SCALE", ctx->thin_acc_scale) : 1;
+  ctx->mover_slices_min = EXPAMD_EXPT("EXP_AMD_MOVER_SLICES_MIN", ctx->mover_slices_min);
+  ctx->stage_max = EXPAMD_EXPT("EXP_AMD_STAGE_MAX", ctx->stage_max);
   HIP_TRY(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -180,13 +175,6 @@ static hipEvent_t get_event(exp_amd_ctx *ctx)
 
 ProfScope::ProfScope(exp_amd_ctx *c, const char *name, hipStream_t on) : ctx(c)
 {
-  // EXP_AMD_HOST_DELAY_NS=n (experiment): the host idles n ns in front of every kernel scope -- how much of a run's time
-  // follows the host's issue rate (tools/dbg/ab_cfg4_env.sh; profiles/r04_cfg4_ab.txt)
-  static const long delay_ns = [] { const char *e = getenv("EXP_AMD_HOST_DELAY_NS"); return e ? atol(e) : 0L; }();
-  if (delay_ns > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() < delay_ns) {}
-  }
   if (!ctx || !ctx->profile) return;
   st = on ? on : ctx->stream;
   for (size_t i = 0; i < ctx->slots.size(); i++)

@@ -44,11 +44,6 @@ struct exp_amd_force {
   DevBuf<unsigned long long> d_used;
   int mlevel = 0;
   bool proj_dirty = true;           // projected force tables are stale w.r.t. d_coef
-  // (step driver, two streams) recorded by the SELF call of accelerate() once coefficient set and projected tables are
-  // final, ahead of the self force itself: a cross force of this basis on the other stream starts from there
-  hipEvent_t ev_tables = nullptr;
-  // ... which takes an external call that touches none of the scratch the self force uses (work lists, literal list)
-  virtual bool external_shares_no_scratch() const { return false; }
   exp_amd_comp *home = nullptr;     // component whose particles define the expansion centre
   // ... and what it looked like when it was destroyed while this force still pointed at it (pyEXP
   // builds its coefficients from temporary components): frame of the expansion for external targets

@@ -30,13 +30,10 @@ struct exp_amd_sim {
   int centerlevl = -1;
   bool gottapot = false;
   bool restart = false;            // the global `restart` (src/global.cc): the estimators take in the first state too
-  bool defer_resort = true;               // EXP_AMD_SIM_DEFER_RESORT=0: re-order right after every sweep with level changes
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
   unsigned long long *pinned_dev = nullptr;   // the device's address of it (k_kick_adjust's last block writes there)
   unsigned long long pub_seq = 0;         // sequence number of the counters last handed over that way
-  bool publish = true;                    // EXP_AMD_SIM_PUBLISH=0: copy + stream wait instead
-  bool sweep_lists = true;                // EXP_AMD_SIM_SWEEP_LISTS=0: the movers are compacted by a pass of their own
   // Two-stream sub-steps: everything that touches the particles of component k is issued on stream
   // k & 1 (the context's stream / its auxiliary stream).  The small launches of a sub-step are
   // latency-bound, so the two components' chains fill each other's gaps.  Events carry the cross
@@ -44,39 +41,14 @@ struct exp_amd_sim {
   // ev_used[k] = the last use of force method k's tables by a cross force on the other stream.
   bool overlap = false;
   hipStream_t main_stream = nullptr;
-  std::vector<hipEvent_t> ev_self, ev_used, ev_tab;     // (ev_tab[k]: tables of force method k final, its self force not yet run)
-  bool early_cross = false;         // EXP_AMD_SIM_EARLY_CROSS=1 (experiment): cross forces wait for the source's tables only, not
-                                    // for its self force -- measured neutral on config 4 (5.93 against 5.90 ms: the two
-                                    // kernels then run side by side and slow each other by what the earlier start gains)
+  std::vector<hipEvent_t> ev_self, ev_used;
   std::vector<char> used_pending;
   hipEvent_t ev_join = nullptr;
-  // EXP_AMD_HOST_TIMING=1: where the HOST spends a master step (seconds; printed by exp_amd_sim_destroy) -- issuing the
-  // launches of the three phases, waiting for the read-back, and the level-change phase behind it
-  bool host_timing = false;
-  double ht[5] = {0, 0, 0, 0, 0};
-  double ht_lo[17] = {0};           // wall time of the sub-steps by their lowest active level
-  double ht_dev[17][2] = {{0}};     // device time from the start of a sub-step to the end of each stream's sweep
-  hipEvent_t ht_ev0 = nullptr, ht_ev1[2] = {nullptr, nullptr};
-  // EXP_AMD_HOST_TIMING_MARKS=1: three more timing events per stream and sub-step (after the expansion, the self force,
-  // the cross force) -- each costs the stream ~5 us, so the totals grow, but the order of things shows
-  bool ht_marks = false;
-  hipEvent_t ht_mk[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  double ht_mkt[17][2][3] = {{{0}}};
-  int ht_lo_now = 0;
-  long long ht_steps = 0;
 };
 
-static inline void ht_mark(exp_amd_sim *s, size_t k, int which);
 static inline double host_now()
 {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-static inline void ht_mark(exp_amd_sim *s, size_t k, int which)
-{
-  if (!s->host_timing || !s->ht_marks || !s->overlap || !s->ht_ev0 || k >= 2) return;
-  if (!s->ht_mk[k][which]) (void)hipEventCreate(&s->ht_mk[k][which]);
-  (void)hipEventRecord(s->ht_mk[k][which], s->ctx->stream);
 }
 
 // issue on component k's stream for the lifetime of the object
@@ -95,10 +67,7 @@ static int overlap_begin(exp_amd_sim *s)
   exp_amd_ctx *ctx = s->ctx;
   bool any_orient = false;
   for (auto o : s->orients) any_orient = any_orient || o;
-  if (const char *e = getenv("EXP_AMD_SIM_DEFER_RESORT")) s->defer_resort = atoi(e) != 0;
-  // (EXP_AMD_HOST_TIMING=k: from master step k-1 on -- k = 9 skips the eight in which the level populations settle)
-  if (const char *e = getenv("EXP_AMD_HOST_TIMING")) s->host_timing = atoi(e) != 0 && s->this_step >= atoi(e) - 1;
-  if (const char *e = getenv("EXP_AMD_HOST_TIMING_MARKS")) s->ht_marks = atoi(e) != 0;
+  // EXP_AMD_SIM_OVERLAP=0 (include/exp_amd.h, environment): both components on the context's one stream
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
@@ -117,11 +86,7 @@ static int overlap_begin(exp_amd_sim *s)
     s->ev_self.push_back(a);
     s->ev_used.push_back(b);
     s->used_pending.push_back(0);
-    hipEvent_t c_;
-    HIP_TRY(ctx, hipEventCreateWithFlags(&c_, hipEventDisableTiming));
-    s->ev_tab.push_back(c_);
   }
-  if (const char *e = getenv("EXP_AMD_SIM_EARLY_CROSS")) s->early_cross = atoi(e) != 0;
   if (!s->ev_join) HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   // whatever was issued on the context's stream so far precedes the auxiliary stream's work
   HIP_TRY(ctx, hipEventRecord(s->ev_join, ctx->stream));
@@ -169,28 +134,8 @@ extern "C" int exp_amd_sim_create(exp_amd_ctx *ctx, int multistep, double dtime,
 extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
 {
   if (!s) return;
-  if (s->host_timing && s->ht_steps)
-    fprintf(stderr, "[exp_amd host timing] per master step over %lld: issue expansion %.3f ms, issue forces %.3f ms, issue kick/adjust "
-            "%.3f ms, wait for the read-back %.3f ms, level changes %.3f ms\n", s->ht_steps, 1e3 * s->ht[0] / s->ht_steps,
-            1e3 * s->ht[1] / s->ht_steps, 1e3 * s->ht[2] / s->ht_steps, 1e3 * s->ht[3] / s->ht_steps, 1e3 * s->ht[4] / s->ht_steps);
-  if (s->host_timing && s->ht_steps)
-    for (int L = 0; L <= s->multistep; L++)
-      fprintf(stderr, "[exp_amd host timing]   sub-steps with lowest active level %d: %.3f ms per master step (%d of them); device time "
-              "to the end of the sweep on stream 0 / 1: %.3f / %.3f ms\n", L, 1e3 * s->ht_lo[L] / s->ht_steps, L == 0 ? 1 : 1 << (L - 1),
-              1e3 * s->ht_dev[L][0] / s->ht_steps, 1e3 * s->ht_dev[L][1] / s->ht_steps);
-  if (s->host_timing && s->ht_marks && s->ht_steps)
-    for (int L = 0; L <= s->multistep; L++) {
-      const double n = (double)s->ht_steps * (L == 0 ? 1 : 1 << (L - 1)) * 1e-6;
-      fprintf(stderr, "[exp_amd host timing]   level %d, us per sub-step from its start: stream 0 expansion %.0f self %.0f cross %.0f end %.0f | "
-              "stream 1 expansion %.0f self %.0f cross %.0f end %.0f\n", L, s->ht_mkt[L][0][0] / n, s->ht_mkt[L][0][1] / n,
-              s->ht_mkt[L][0][2] / n, s->ht_dev[L][0] / n, s->ht_mkt[L][1][0] / n, s->ht_mkt[L][1][1] / n, s->ht_mkt[L][1][2] / n,
-              s->ht_dev[L][1] / n);
-    }
   if (s->pinned) (void)hipHostFree(s->pinned);
-  if (s->ht_ev0) { (void)hipEventDestroy(s->ht_ev0); (void)hipEventDestroy(s->ht_ev1[0]); (void)hipEventDestroy(s->ht_ev1[1]); }
-  for (auto &row : s->ht_mk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
-  for (auto e : s->ev_tab) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
@@ -349,17 +294,15 @@ static int substep_expansion(exp_amd_sim *s, int lo, double dt_min, int mdrft)
   // (alone: the combined coefficient set of the force evaluation that follows is formed by the same kernel that sums
   // the per-level sets; with several ranks the all-reduce of the level block sits between the two)
   const bool alone = s->ctx->nranks <= 1 && !s->ctx->ar_fn && !s->ctx->rccl_comm;
-  static const bool split = [] { const char *e = getenv("EXP_AMD_SIM_SPLIT_ISSUE"); return !e || atoi(e) != 0; }();
   // two streams: the advance of every component is issued before the accumulation of any -- the host needs ~25 us for
   // the launches of one component's first half, and the other stream would have nothing to do meanwhile
-  for (int phase = (s->overlap && split) ? 1 : 0; phase <= ((s->overlap && split) ? 2 : 0); phase++)
+  for (int phase = s->overlap ? 1 : 0; phase <= (s->overlap ? 2 : 0); phase++)
     for (size_t k = 0; k < s->comps.size(); k++) {
       StreamOf on(s, k);
       int rc = phase == 2 ? 0 : wait_used(s, k);
       if (rc) return rc;
       rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1, phase);
       if (rc) return rc;
-      if (phase != 1) ht_mark(s, k, 0);
     }
   return EXP_AMD_OK;
 }
@@ -374,22 +317,14 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
 {
   int rc;
   if ((rc = fix_centers(s, mstep))) return rc;
-  std::vector<char> early(s->comps.size(), 0);
   for (size_t k = 0; k < s->comps.size(); k++) {
     StreamOf on(s, k);
     exp_amd_force *f = s->forces[k];
     if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
     if (f->combined_mdrft != mdrft && (rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
     f->combined_mdrft = -1;
-    // (two streams: the cross force of this basis on the other component needs its coefficient set and tables, not its
-    // self force -- which the call below records an event ahead of, where the external call shares no scratch with it)
-    early[k] = s->overlap && s->early_cross && f->external_shares_no_scratch();
-    f->ev_tables = early[k] ? s->ev_tab[k] : nullptr;
-    rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0);
-    f->ev_tables = nullptr;
-    if (rc) return rc;
+    if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
     if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
-    ht_mark(s, k, 1);
   }
   for (auto &pr : s->inter) {
     StreamOf on(s, (size_t)pr.second);            // the target's particles: the target's stream
@@ -397,20 +332,18 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     const bool foreign = s->overlap && ((pr.first ^ pr.second) & 1);
     if (foreign) {
       // the source's projected tables (and the scratch of its force pass) must be ready and free
-      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, early[pr.first] ? s->ev_tab[pr.first] : s->ev_self[pr.first], 0));
+      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_self[pr.first], 0));
       if (s->used_pending[pr.first]) HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[pr.first], 0));
     }
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;
     // (the tables this cross force reads are next written by the source's stream in the NEXT sub-step's first half, and
     // every path there leads through a join of the two streams: the read-back of kick_adjust_levels synchronises both, and
     // begin_run / the end of a step call end in overlap_end.  An event per cross force for it cost each stream ~5 us a
-    // sub-step, tools/dbg/launch_gap.hip; EXP_AMD_SIM_USED_EVENTS=1 records them again)
-    static const bool used_ev = [] { const char *e = getenv("EXP_AMD_SIM_USED_EVENTS"); return e && atoi(e) != 0; }();
-    if (foreign && (used_ev || !join_follows)) {
+    // sub-step, tools/dbg/launch_gap.hip: they are recorded only where no join follows)
+    if (foreign && !join_follows) {
       HIP_TRY(s->ctx, hipEventRecord(s->ev_used[pr.first], s->ctx->stream));
       s->used_pending[pr.first] = 1;
     }
-    ht_mark(s, (size_t)pr.second, 2);
   }
   s->gottapot = true;
   return EXP_AMD_OK;
@@ -422,8 +355,7 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
 // are of this kind: they reduce to the closing kick, with no counters, no read-back and no wait.
 static bool sweep_is_noop(const exp_amd_sim *s, int mdrft, int first_step)
 {
-  static const bool on = [] { const char *e = getenv("EXP_AMD_SIM_SKIP_NOOP_SWEEPS"); return !e || atoi(e) != 0; }();
-  return on && s->multistep > 0 && !first_step && s->mfirst[mdrft] == s->multistep;
+  return s->multistep > 0 && !first_step && s->mfirst[mdrft] == s->multistep;
 }
 
 // second half: incr_velocity(dt*mintvl[M]/2, M) for M >= mfirst[mdrft] (src/step.cc:198-203; not in
@@ -448,24 +380,17 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     memset(s->pinned, 0, nc * 40 * sizeof(unsigned long long));
     HIP_TRY(ctx, hipHostGetDevicePointer((void **)&s->pinned_dev, s->pinned, 0));
     s->pinned_cap = nc;
-    static const bool pub = [] { const char *e = getenv("EXP_AMD_SIM_PUBLISH"); return !e || atoi(e) != 0; }();
-    s->publish = pub;
-    static const bool sl = [] { const char *e = getenv("EXP_AMD_SIM_SWEEP_LISTS"); return !e || atoi(e) != 0; }();
-    s->sweep_lists = sl;
   }
-  const bool publish = s->publish && !s->host_timing;
   int rc;
   // (sweep_is_noop: the closing kick alone -- the host goes straight on to the next sub-step's launches; the streams stay
   // ordered among themselves, nothing is differenced, committed or re-ordered because nothing changed)
   if (kick && sweep_is_noop(s, mdrft, first_step)) {
-    const double th0 = s->host_timing ? host_now() : 0.0;
-    static const bool fold = [] { const char *e = getenv("EXP_AMD_SIM_FOLD_KICK"); return !e || atoi(e) != 0; }();
     for (size_t k = 0; k < nc; k++) {
       StreamOf on(s, k);
       exp_amd_comp *c = s->comps[k];
       // ... and the closing kick itself -- of the top level alone, DT(multistep)/2 = dt_min/2 -- is left to the advance
       // of the next sub-step, which applies it first, as its own rounding step (exp_amd_comp::pending_kick / pending_lo)
-      if (fold && c->nlevels == ms + 1 && c->pending_kick == 0.0) {
+      if (c->nlevels == ms + 1 && c->pending_kick == 0.0) {
         // (an EMPTY top level owes nothing -- and must not: the next real sweep may move particles there, which would
         // then be kicked for a step they never took)
         size_t ntop = 0;
@@ -476,13 +401,10 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
       const unsigned long long *res = nullptr;
       if ((rc = expamd_comp_kick_adjust(c, s->dtime, s->dynfrac, s->shiftlevl, ms, mf, mf, /*first=*/ms + 1,
                                         dt_min, &res))) return rc;
-      if (s->host_timing && s->overlap && s->ht_ev0 && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
     }
     s->last_switch = 0;
-    if (s->host_timing) s->ht[2] += host_now() - th0;
     return EXP_AMD_OK;
   }
-  const double th0 = s->host_timing ? host_now() : 0.0;
   std::vector<unsigned long long> want(nc, 0ull);
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
@@ -491,60 +413,45 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     if (((++s->pub_seq) & 0xffffffull) == 0) ++s->pub_seq;       // (the tag of a word never written)
     const unsigned long long seq = s->pub_seq & 0xffffffull;
     if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
-                                      kick ? mf : ms + 1, first, dt_min, &res, publish ? s->pinned_dev + k * 40 : nullptr,
-                                      seq, &launched, s->sweep_lists))) return rc;
-    if (publish) {
-      if (launched) want[k] = seq;
-      else memset(s->pinned + k * 40, 0, 32 * sizeof(unsigned long long));      // (nothing in the range: no counts)
-    } else
-      HIP_TRY(ctx, hipMemcpyAsync(s->pinned + k * 40, res, 32 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    if (s->host_timing && s->overlap && s->ht_ev0 && kick && k < 2) (void)hipEventRecord(s->ht_ev1[k], ctx->stream);
+                                      kick ? mf : ms + 1, first, dt_min, &res, s->pinned_dev + k * 40, seq, &launched, /*build_list=*/true))) return rc;
+    if (launched) want[k] = seq;
+    else {
+      // nothing in the examined range: no counts, and no sweep on this component's stream to wait for -- but this
+      // function IS the join of the two streams that compute_potential_ms(join_follows = true) relies on (the cross
+      // forces before it left no 'tables used' events), so the stream itself is waited for; it is all but idle
+      memset(s->pinned + k * 40, 0, 32 * sizeof(unsigned long long));
+      if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
-  const double th1 = s->host_timing ? host_now() : 0.0;
-  if (publish) {
-    // poll the tags; the streams themselves are asked now and then, so that a failed launch ends the wait
-    for (size_t k = 0; k < nc; k++) {
-      if (!want[k]) continue;
-      unsigned long long *w = s->pinned + k * 40;
-      unsigned long spins = 0;
-      auto all_there = [&] {
-        for (int q = 0; q < 32; q++) if ((__atomic_load_n(w + q, __ATOMIC_RELAXED) >> 40) != want[k]) return false;
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        return true;
-      };
-      while (!all_there()) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0) {
-          StreamOf on(s, k);
-          const hipError_t e = hipStreamQuery(ctx->stream);
-          if (e == hipSuccess) {                 // (everything ran: the words are there, or never will be)
-            if (all_there()) break;
-            return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: the level counters did not arrive");
-          }
-          if (e != hipErrorNotReady) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: %s", hipGetErrorString(e));
-        }
+  // poll the tags; the streams themselves are asked every ~100 us, so that a failed launch ends the wait
+  for (size_t k = 0; k < nc; k++) {
+    if (!want[k]) continue;
+    unsigned long long *w = s->pinned + k * 40;
+    auto all_there = [&] {
+      for (int q = 0; q < 32; q++) if ((__atomic_load_n(w + q, __ATOMIC_RELAXED) >> 40) != want[k]) return false;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return true;
+    };
+    double t_query = host_now() + 100e-6;
+    while (!all_there()) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#elif defined(__aarch64__)
+      asm volatile("yield");
+#endif
+      if (host_now() < t_query) continue;
+      t_query = host_now() + 100e-6;
+      StreamOf on(s, k);
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) {                 // (everything ran: the words are there, or never will be)
+        if (all_there()) break;
+        return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: the level counters did not arrive");
       }
+      if (e != hipErrorNotReady) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "sim_step: %s", hipGetErrorString(e));
     }
-    for (size_t k = 0; k < nc; k++)
-      if (want[k]) for (int q = 0; q < 32; q++) s->pinned[k * 40 + q] &= 0xffffffffffull;
-  } else {
-    if (s->overlap) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  const double th2 = s->host_timing ? host_now() : 0.0;
-  if (s->host_timing && s->overlap && s->ht_ev0 && kick && nc == 2)
-    for (int k = 0; k < 2; k++) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, s->ht_ev0, s->ht_ev1[k]) == hipSuccess) s->ht_dev[s->ht_lo_now][k] += 1e-3 * ms;
-      for (int w = 0; w < 3 && s->ht_marks; w++)
-        if (s->ht_mk[k][w] && hipEventElapsedTime(&ms, s->ht_ev0, s->ht_mk[k][w]) == hipSuccess)
-          s->ht_mkt[s->ht_lo_now][k][w] += 1e-3 * ms;
-    }
-  struct HtClose {
-    exp_amd_sim *s; double a, b, c;
-    ~HtClose() { if (s->host_timing) { s->ht[2] += b - a; s->ht[3] += c - b; s->ht[4] += host_now() - c; } }
-  } htc{s, th0, th1, th2};
+  for (size_t k = 0; k < nc; k++)
+    if (want[k]) for (int q = 0; q < 32; q++) s->pinned[k * 40 + q] &= 0xffffffffffull;
   s->last_switch = 0;
   for (size_t k = 0; k < nc; k++) {
     StreamOf on(s, k);
@@ -572,8 +479,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
       // (the commit itself is left to the sort that settles the partition when that is the next thing to touch these
       // slots -- see below: it reads the proposed levels where they are, exp_amd_comp::commit_pending)
       const int next_lo_ = mdrft == s->Mstep ? 0 : s->mfirst[mdrft];
-      static const bool fuse_commit = [] { const char *e = getenv("EXP_AMD_SIM_FUSE_COMMIT"); return !e || atoi(e) != 0; }();
-      const bool put_off = fuse_commit && mirror && s->defer_resort && next_lo_ == first && c->n > 0;
+      const bool put_off = mirror && next_lo_ == first && c->n > 0;
       if (put_off) {
         c->commit_pending = true;
         c->commit_beg = (size_t)c->lev_host[first];
@@ -590,7 +496,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
       // advance sort re-partitions them by the committed levels in the same pass (substep_expansion), so the
       // re-ordering is not done twice.
       const int next_lo = mdrft == s->Mstep ? 0 : s->mfirst[mdrft];
-      if (mirror && s->defer_resort && next_lo == first) {
+      if (mirror && next_lo == first) {
         c->partition_stale = true;
         c->stale_lo = first;
         c->stale_for = (const void *)f;
@@ -647,27 +553,11 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         const int mdrft = mstep + 1;
-        const double th0 = s->host_timing ? host_now() : 0.0;
-        if (s->host_timing && s->overlap) {
-          if (!s->ht_ev0) { (void)hipEventCreate(&s->ht_ev0); (void)hipEventCreate(&s->ht_ev1[0]); (void)hipEventCreate(&s->ht_ev1[1]); }
-          (void)hipEventRecord(s->ht_ev0, s->main_stream);
-          s->ht_lo_now = s->mfirst[mstep];
-        }
-        // EXP_AMD_SIM_SERIAL0=1 (experiment): the first sub-step -- every particle of every component moves: bandwidth-
-        // and issue-bound kernels that gain nothing from sharing the GPU -- on ONE stream; the small sub-steps keep two
-        static const bool serial0 = [] { const char *e = getenv("EXP_AMD_SIM_SERIAL0"); return e && atoi(e) != 0; }();
-        const bool was_overlap = s->overlap;
-        if (serial0 && mstep == 0 && was_overlap && (rc = overlap_end(s))) return rc;
         if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
         s->tnow += dt;
-        const double th1 = s->host_timing ? host_now() : 0.0;
         const int first_step = (s->this_step == 0 && mstep == 0) ? 1 : 0;
         if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep, !sweep_is_noop(s, mdrft, first_step)))) return rc;
-        if (s->host_timing) { s->ht[0] += th1 - th0; s->ht[1] += host_now() - th1; }
-        const int lo_now = s->mfirst[mstep];
         if ((rc = kick_adjust_levels(s, mdrft, first_step, true))) return rc;
-        if (serial0 && mstep == 0 && was_overlap && (rc = overlap_begin(s))) return rc;
-        if (s->host_timing) s->ht_lo[lo_now] += host_now() - th0;
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
       s->tnow += s->dtime;
@@ -684,7 +574,6 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
     }
     s->this_step++;
-    if (s->multistep && s->host_timing) s->ht_steps++;
   }
   return overlap_end(s);
 }

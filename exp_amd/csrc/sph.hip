@@ -421,9 +421,6 @@ void SphForce::release()
   expamd_sph_cov_release(this);
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
   d_Wd.release(); d_differ.release();
-  if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
-  if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
-  if (ev_side) { (void)hipEventDestroy(ev_side); ev_side = nullptr; }
 }
 
 static SphDev dev_for(const SphForce *f, const double center[3])
@@ -671,10 +668,9 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     if (dmax < ms && adv.mode) {
       size_t nall = 0;
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
-      static const bool fuse_on = [] { const char *e = getenv("EXP_AMD_THIN_ADVANCE"); return !e || atoi(e) != 0; }();
-      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
+      const bool fuse_on = EXPAMD_EXPT("EXP_AMD_THIN_ADVANCE", 1) != 0;
       const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
-                        !ctx->deterministic && f->ncoef <= 4096 && thin_v == 1 && !f->generic;
+                        !ctx->deterministic && f->ncoef <= 4096 && !f->generic;
       if (fuse) {
         f->adv_owed = true;
         f->adv_dt_min = dt_min;
@@ -698,7 +694,6 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   int dacc = lo - 1;                    // last level the cell-ordered kernel takes
   for (int L = lo; L <= ms; L++) if (!((c->sparse_mask >> L) & 1u)) dacc = L;
   size_t nrange = 0;
-  bool side_pending = false;            // a launch on f->side is under way: the contraction waits for it
   if (c->n && dacc >= lo && (rc = expamd_comp_level_count(c, lo, dacc, &nrange))) return rc;
   if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
@@ -707,43 +702,17 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     // Thickly and thinly populated levels go in SEPARATE launches (consecutive levels of one kind together): measured
     // on config 4, level 0 (9.6e6 particles, 3072-particle chunks) with levels 1-2 (2.5e5 + 1.2e5, 64-particle
     // chunks) in one launch takes 970 us, level 0 alone 240 us and the thin levels together 190 us.
-    // EXP_AMD_ACC_SIDE=1 (experiment): the thin ones BESIDE the thick one, on a stream of the force method's own
-    // (different moment buffers; the contraction below waits for it).  Measured neutral on config 4 (6.06 against 6.07 ms
-    // per master step, profiles/r04_cfg4_ab.txt): the first sub-step is bound by the GPU's throughput, not by its chains.
-    static const bool side_on = [] { const char *e = getenv("EXP_AMD_ACC_SIDE"); return e && atoi(e) != 0; }();
-    bool forked = false;
-    int ngroups = 0;
     for (int L0 = lo; L0 <= dacc;) {
       const bool thick = counts[L0 - lo] >= ACC_THICK_MIN;
       int L1 = L0;
       size_t nr = counts[L0 - lo];
       while (L1 + 1 <= dacc && (counts[L1 + 1 - lo] >= ACC_THICK_MIN) == thick) { L1++; nr += counts[L1 - lo]; }
       if (nr) {
-        hipStream_t st = ctx->stream;
-        if (side_on && ngroups > 0 && !ctx->deterministic) {
-          if (!f->side) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming));
-          }
-          if (!forked) {
-            // (what the first launch waited for -- the sort, the cleared moments -- this one waits for too)
-            HIP_TRY(ctx, hipEventRecord(f->ev_fork, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(f->side, f->ev_fork, 0));
-            forked = true;
-          }
-          st = f->side;
-        }
         SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, L0, L1,
-                     f->d_W.p, used_p, nr, st, 1, counts + (L0 - lo), 1};
+                     f->d_W.p, used_p, nr, ctx->stream, 1, counts + (L0 - lo), 1};
         sph_launch_acc(f, a);
-        ngroups++;
       }
       L0 = L1 + 1;
-    }
-    if (forked) {
-      HIP_TRY(ctx, hipEventRecord(f->ev_side, f->side));
-      side_pending = true;
     }
   }
   nrange = 0;
@@ -775,8 +744,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
         a.adv = ThinAdv{c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ),
                         c->level[c->cur].p, f->adv_dt_min, ms, k0, k0lo, 1};
       }
-      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
-      if (thin_v == 1 && !f->generic) k_thin_acc_launch[cfg.lmax](a); else expamd_sph_thin_acc_gen(a);
+      if (!f->generic) k_thin_acc_launch[cfg.lmax](a); else expamd_sph_thin_acc_gen(a);
     }
   } else if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate_sparse");
@@ -785,7 +753,6 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
     if ((rc = sph_stage(f, nrange, a))) return rc;
     sph_launch_upd(f, a);
   }
-  if (side_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, f->ev_side, 0));
   {
     ProfScope ps(ctx, "k_sph_contract");
     if (!thin)
@@ -818,7 +785,7 @@ int sph_project(SphForce *f)
   if (!f->proj_dirty) return EXP_AMD_OK;
   exp_amd_ctx *ctx = f->ctx;
   ProfScope ps(ctx, "k_sph_project");
-  static const bool both = [] { const char *e = getenv("EXP_AMD_SPH_PROJECT_BOTH"); return !e || atoi(e) != 0; }();
+  const bool both = EXPAMD_EXPT("EXP_AMD_SPH_PROJECT_BOTH", 1) != 0;
   const size_t lds = (size_t)3 * f->dev.nrows * sizeof(double);
   // (one launch where a block's three nodes' rows fit one round of its threads -- lmax <= 8; above, the threefold sums
   // cost more than the launch saved: lmax 10, nmax 24: 35 us against 11 + 5)
@@ -851,7 +818,6 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     thin = (long long)nthin <= ctx->thin_max;
   }
   if (!thin && (rc = sph_project(f))) return rc;
-  if (!external && f->ev_tables) HIP_TRY(ctx, hipEventRecord(f->ev_tables, ctx->stream));
   f->used_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
   if (thin) {
@@ -863,12 +829,11 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       SphThinForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1, f->d_coef.p,
                          f->d_rowmap.p, f->d_tscale.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX),
                          t->a(A_VY), t->a(A_VZ), assign ? 1 : 0, nthin, ctx->stream};
-      static const int thin_v = [] { const char *e = getenv("EXP_AMD_THIN_V"); return e ? atoi(e) : 1; }();
       // (the tiled kernel keeps the coefficient set and four particles' rows in LDS: where that does not fit -- very large
       // nmax -- the one-wave-per-particle kernel, which uses none, takes over)
       const size_t tq_ = 4 * (size_t)f->dev.trows + 16, lsn_ = (size_t)(f->cfg.lmax + 1) * f->cfg.nmax;
       const bool fits = (f->ncoef + 2 + 4 * (tq_ + 3 * lsn_)) * sizeof(double) <= 120 * 1024;
-      if (thin_v == 1 && !f->generic && fits) k_thin_force_launch[f->cfg.lmax](a); else expamd_sph_thin_force_gen(a);
+      if (!f->generic && fits) k_thin_force_launch[f->cfg.lmax](a); else expamd_sph_thin_force_gen(a);
       HIP_TRY(ctx, hipGetLastError());
     }
     t->acc_live = true;
@@ -898,7 +863,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     unsigned grid = cdiv(nr, 256);     // one 64-particle chunk per wave, no loop
     const size_t need = t->n / 64 + 8;
     // (the work list belongs to the fast pass: the staged / gather evaluation of foreign or all-sparse targets has none --
-    // and must not re-allocate it under a self force that runs on the other stream, exp_amd_force::ev_tables)
+    // and must not re-allocate it under a self force that runs on the other stream)
     const bool listless = !ctx->deterministic && (t->sorted_for != f || all_sparse);
     if (f->work_cap < need && !(listless && f->work_cap > 0)) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -941,7 +906,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       const int tq = 4 * S.trows, tqs = tq + ((2 - tq % 16) + 16) % 16;
       int rows = (int)(40960 / ((size_t)tqs * sizeof(double)));
       a.stage_rows = rows > 24 ? 24 : rows < 4 ? 4 : rows;
-      if (const char *e = getenv("EXP_AMD_STAGE_ROWS")) a.stage_rows = atoi(e);
+      a.stage_rows = (int)EXPAMD_EXPT("EXP_AMD_STAGE_ROWS", a.stage_rows);
     }
     sph_launch_force(f, a);
     if (!slow) f->work_flip ^= 1;
@@ -1144,7 +1109,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   // (k_mover_list, 16 slots per thread), so that the differencing launches over the movers, not over the range
   const bool listed = nr && c->mover_hint >= 0;
   if (listed && c->mover_hint > 0) { int rc_ = expamd_comp_mover_list(c, first, ms, (size_t)c->mover_hint); if (rc_) return rc_; }
-  static const bool thin_diff_on = [] { const char *e = getenv("EXP_AMD_THIN_DIFF"); return !e || atoi(e) != 0; }();
+  const bool thin_diff_on = EXPAMD_EXPT("EXP_AMD_THIN_DIFF", 1) != 0;
   const bool few = listed && c->mover_hint > 0 && !(ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min);
   const bool thin_diff = few && thin_diff_on && ctx->thin_max > 0 && c->mover_hint <= ctx->thin_max && !ctx->deterministic &&
                          !f->generic && f->ncoef <= 4096;

@@ -30,11 +30,6 @@ struct SphForce : exp_amd_force {
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
   bool used_open = true;
   bool wd_clean = false;            // ... and of d_Wd (multistep_update)
-  bool external_shares_no_scratch() const override { return !lit_on && !generic && !ctx->deterministic; }
-  // block multistep: the accumulation launches of the thinly populated dense levels (latency-bound: 64-particle chunks)
-  // run on a stream of their own beside the launch of the thick ones (issue-bound); the contraction waits for both
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_side = nullptr;
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_sph_acc_thin
   double adv_dt_min = 0.0;
   bool part_clean = false;          // d_part is all zero (what the thin accumulation adds to; its summing kernels keep it so)

@@ -579,7 +579,7 @@ void expamd_sph_thin_acc_gen(const SphThinAccArgs &a)
 {
   if (a.n == 0) return;
   const size_t nrows = (size_t)a.S.nrows, lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
-  static const int tile0 = [] { const char *e = getenv("EXP_AMD_THIN_TILE"); return e ? atoi(e) : 64; }();
+  const int tile0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_TILE", 64);
   int tile = tile0 < 4 ? 4 : tile0 > SPH_TILE_MAX ? SPH_TILE_MAX : tile0;
   auto need = [&](int t) { return ((((size_t)t * (nrows | 1) + 1) & ~(size_t)1) + (size_t)t * lsn) * sizeof(double); };
   while (tile > 4 && need(tile) > 120 * 1024) tile >>= 1;

@@ -32,7 +32,7 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   for (int j = 0; j < LC.nlev; j++) {
     const size_t n = a.counts ? a.counts[j] : a.n;
     size_t chunk = (n / ((size_t)CPB * ACC_BLOCKS_TARGET)) & ~(size_t)63;
-    static const size_t cmin_env = [] { const char *e = getenv("EXP_AMD_ACC_CHUNK_MIN"); return e ? (size_t)atoi(e) & ~(size_t)63 : (size_t)0; }();
+    const size_t cmin_env = (size_t)EXPAMD_EXPT("EXP_AMD_ACC_CHUNK_MIN", 0) & ~(size_t)63;
     const size_t cmin = cmin_env ? cmin_env : ACC_CHUNK_MIN;
     chunk = chunk < cmin ? cmin : chunk > ACC_CHUNK_MAX ? ACC_CHUNK_MAX : chunk;
     LC.bstart[j] = nb;
@@ -142,7 +142,7 @@ void CAT(expamd_sph_thin_force_L, SPH_L)(const SphThinForceArgs &a)
   const size_t lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
   // (small tiles: a thin range is a few hundred to a few thousand particles and the GPU has a thousand SIMDs -- what
   // counts is the length of a block's chain of dependent phases, not the number of blocks)
-  static const int tp0 = [] { const char *e = getenv("EXP_AMD_THIN_TP"); return e ? atoi(e) : 4; }();
+  const int tp0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_TP", 4);
   int tp = tp0 < 1 ? 1 : tp0 > 64 ? 64 : tp0;
   while (tp > 4 && (ncoef + (size_t)tp * (tqs + 3 * lsn)) * sizeof(double) > 100 * 1024) tp >>= 1;
   const size_t lds = (ncoef + (size_t)tp * (tqs + 3 * lsn)) * sizeof(double);
@@ -155,7 +155,7 @@ void CAT(expamd_sph_thin_force_L, SPH_L)(const SphThinForceArgs &a)
     return true;
   }();
   (void)big;
-  static const int nt0 = [] { const char *e = getenv("EXP_AMD_THIN_NT"); return e ? atoi(e) : 0; }();
+  const int nt0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_NT", 0);
   const int nt = nt0 ? nt0 : 256;       // (64-thread blocks -- four times as many resident -- measured SLOWER at 2e3 and 1.3e4 particles)
   k_sph_force_thin<LMAX><<<(unsigned)grid, nt, lds, a.stream>>>(
       a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.coef, a.rowmap, a.tscale, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
@@ -166,7 +166,7 @@ void CAT(expamd_sph_thin_acc_L, SPH_L)(const SphThinAccArgs &a)
 {
   constexpr int LMAX = SPH_L;
   const size_t nrows = (size_t)a.S.nrows, lsn = (size_t)(a.S.lmax + 1) * a.S.nmax;
-  static const int tpa0 = [] { const char *e = getenv("EXP_AMD_THIN_TPA"); return e ? atoi(e) : 8; }();
+  const int tpa0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_TPA", 8);
   int tpa = tpa0 < 1 ? 1 : tpa0 > 64 ? 64 : tpa0;
   auto need = [&](int t) { return ((((size_t)t * nrows + 1) & ~(size_t)1) + (size_t)t * lsn) * sizeof(double); };
   while (tpa > 4 && need(tpa) > 96 * 1024) tpa >>= 1;

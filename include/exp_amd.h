@@ -38,6 +38,23 @@ typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylin
 
 /* ---- library / context ------------------------------------------------------------ */
 
+/* Environment.  The library reads SEVEN environment variables, each once, where the object it concerns is created; none
+ * is needed for correct results, everything a host would want to set at run time has a setter below.
+ *   EXP_AMD_SPH_GENERIC=1 / EXP_AMD_CYL_GENERIC=1   (exp_amd_sph_create / exp_amd_cyl_create) every per-particle pass of
+ *       that force through the any-order (run-time loop) kernels, which orders above 12 always take
+ *       (tests/test_generic_order_gpu.py);
+ *   EXP_AMD_NO_LITERAL=1    (exp_amd_sph_create, logarithmic radial map only) particles far outside the table keep the
+ *       factored radial derivative instead of the reference's literal term-by-term form (tests/test_sph_gpu.py);
+ *   EXP_AMD_CYL_TWIN=0      (exp_amd_cyl_create) the sine tables are fetched even where they equal the cosine tables bit
+ *       for bit (tests/test_cyl_gpu.py);
+ *   EXP_AMD_SIM_OVERLAP=0   (exp_amd_sim_init / exp_amd_sim_step) the two-component block-multistep driver keeps both
+ *       components on the context's one stream (tests/test_config4_gpu.py);
+ *   EXP_AMD_STEP_GRAPH=0    (exp_amd_step_kdk_n) never capture: every step eager (tests/test_rccl_gpu.py);
+ *   EXP_AMD_POISON=1        (every device allocation) fresh device memory reads as NaN patterns (tests/test_poison_gpu.py).
+ * The tuning and A/B switches of the development rounds (tile sizes, launch reductions that can be undone, ...) are
+ * compile-time constants of the default build; `make EXPERIMENTAL=1` (-DEXP_AMD_EXPERIMENTAL) turns each
+ * EXPAMD_EXPT("NAME", default) of exp_amd/csrc/ back into an environment variable for A/B runs.                       */
+
 /* ABI version of this header (bumped on any signature change). */
 int         exp_amd_abi_version(void);
 /* Static description of the last error on this context (or of the failed create). */
@@ -53,12 +70,12 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
 /* Tuning knob of exp_amd_step_kdk: single-level components of at least `nmin` particles are stepped
  * as two independently cell-sorted halves so that the HBM-bound sort passes of one half overlap the
  * VALU-bound accumulate / force passes of the other on a second HIP stream (same results up to the
- * order of the coefficient sums).  nmin <= 0 (the default) turns it off; EXP_AMD_SPLIT_MIN sets the
- * default.  Measured on MI355X at 1e8 particles: 12.33 -> 12.12 ms per step only, because the
+ * order of the coefficient sums).  nmin <= 0 (the default) turns it off.
+ * Measured on MI355X at 1e8 particles: 12.33 -> 12.12 ms per step only, because the
  * co-running kernels slow each other down (force 5.6 -> 7.1 ms, accumulate 2.9 -> 4.5 ms).        */
 int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
 /* The fused KDK step (exp_amd_step_kdk) ends with a force pass that knows the next step: it writes that
- * step's sort keys.  With prekick on (the default; EXP_AMD_PREKICK=0 turns it off) the same pass stores the
+ * step's sort keys.  With prekick on (the default) the same pass stores the
  * velocities with BOTH half-kicks around the step boundary applied -- v + a dt/2 (closing), then + a dt/2
  * (opening), two rounding steps as src/incvel.cc:15-88 would take them -- so that the next step's
  * reordering pass only drifts and never reads the accelerations (24 B per particle-step less).  The
@@ -71,7 +88,7 @@ int  exp_amd_ctx_set_split_min(exp_amd_ctx *ctx, long long nmin);
  * next reordering pass, which then reads the accelerations.  Measured at 1e8 / S10: the reordering pass
  * 2.94 -> 2.44 ms, the force pass 4.82 -> 5.01 ms for its three extra stores, the step 2 % faster.       */
 int  exp_amd_ctx_set_prekick(exp_amd_ctx *ctx, int on);
-/* Deterministic mode (off by default; EXP_AMD_DETERMINISTIC sets the default).  The coefficient sums
+/* Deterministic mode (off by default).  The coefficient sums
  * are reductions over millions of particles by fp64 atomics in whatever order the hardware serves
  * them, so two runs agree to rounding (~1e-15), not bit for bit -- like the reference's thread and MPI
  * reduction order.  With `on`, every particle's contribution is first rounded to a fixed absolute
@@ -84,7 +101,7 @@ int  exp_amd_ctx_set_deterministic(exp_amd_ctx *ctx, int on);
  * than `nmin` particles are kept level-contiguous but not cell-sorted -- advanced in place,
  * accumulated with per-particle atomics, forces by the gather path -- because a sparse level has
  * about one particle per basis cell and the cell order buys nothing.  Same results up to the order
- * of the sums.  nmin < 0 (the default; EXP_AMD_DENSE_MIN overrides): each force method's own
+ * of the sums.  nmin < 0 (the default): each force method's own
  * break-even (about 3e6-5e6 / moments per particle: ~51000 for lmax 6, ~20000 for lmax 10, ~58000 for mmax 6);
  * 0: every level is cell-sorted.                                                                  */
 int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
@@ -96,9 +113,9 @@ int  exp_amd_ctx_set_dense_min(exp_amd_ctx *ctx, long long nmin);
  * moments and a projected table whose fixed costs (contraction over every cell, projection of every table row) dwarf
  * the particles' own work.  Any force evaluation on at most `nmax` target particles (a cross force on another
  * component's thin active set included) takes the same route.  Same results up to the order of the sums.
- * Default 8192 (EXP_AMD_THIN_MAX overrides; the direct kernels cost ~5 ns per particle and kernel against the table
+ * Default 8192 (the direct kernels cost ~5 ns per particle and kernel against the table
  * path's ~100 us of fixed costs per sub-step and component); 0: never.  The ACCUMULATION side alone takes the direct
- * route up to 4 x nmax particles (one launch there against three; EXP_AMD_THIN_ACC_SCALE), and the level-change
+ * route up to 4 x nmax particles (one launch there against three), and the level-change
  * differencing of at most nmax movers does too.                                                                   */
 int  exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax);
 /* Second knob of the same loop: how the coefficient sets are differenced when particles change level
@@ -107,8 +124,8 @@ int  exp_amd_ctx_set_thin_max(exp_amd_ctx *ctx, long long nmax);
  * from the basis tables up to thin_max of them, through staged fp64 atomics above), from `nmin` on the list goes
  * through the accumulation kernels, which sum runs of equal
  * (level, cell) in registers (the first sweeps of a run move several per cent of a component at once).
- * Same results up to rounding (each way is order-independent in deterministic mode).  Default 8192
- * (EXP_AMD_MOVER_LIST_MIN overrides); 0: always the accumulation kernels; < 0: never.                */
+ * Same results up to rounding (each way is order-independent in deterministic mode).  Default 8192;
+ * 0: always the accumulation kernels; < 0: never.                */
 int  exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin);
 void *exp_amd_ctx_stream(exp_amd_ctx *ctx);
 

@@ -116,15 +116,14 @@ def test_config4_against_the_nbody_oracle(ctx, oracle, dense_min, list_min, thin
     ctx.set_thin_max(8192)
 
 
-def test_config4_with_early_cross_forces(ctx, oracle, monkeypatch):
-    """EXP_AMD_SIM_EARLY_CROSS=1 (read when a step driver starts its two streams): the cross forces start from the
-    source's tables-ready event, beside its self force, instead of behind it.  Off by default (measured neutral,
-    profiles/r04_cfg4_ab.txt); same results to the order of two additions."""
-    monkeypatch.setenv("EXP_AMD_SIM_EARLY_CROSS", "1")
+def test_config4_on_one_stream(ctx, oracle, monkeypatch):
+    """EXP_AMD_SIM_OVERLAP=0 (read when a step driver starts a call): both components' chains on the context's one stream
+    instead of one stream each -- the schedule a run with more than one rank or an Orient takes anyway.  Same bars."""
+    monkeypatch.setenv("EXP_AMD_SIM_OVERLAP", "0")
     try:
         test_config4_against_the_nbody_oracle(ctx, oracle, 100, 8192, 40)
     finally:
-        monkeypatch.delenv("EXP_AMD_SIM_EARLY_CROSS")
+        monkeypatch.delenv("EXP_AMD_SIM_OVERLAP")
 
 
 def test_config4_against_the_golden_file(ctx):
@@ -266,11 +265,14 @@ def test_three_components_deterministic_multistep(ctx, oracle):
 
 @pytest.mark.parametrize("thin_v", ["1", "2"])
 def test_thin_kernels_reproduce_the_table_path(ctx, monkeypatch, thin_v):
-    """The direct kernels of thin active sets (k_*_acc_thin, k_*_force_thin; EXP_AMD_THIN_V=2: their any-order formulation)
+    """The direct kernels of thin active sets (k_*_acc_thin, k_*_force_thin; "2": their any-order formulation, which the
+    run-time-order kernels use -- selected here by EXP_AMD_SPH_GENERIC / EXP_AMD_CYL_GENERIC, read when a force is created)
     against the moment / projected-table path ON THE DEVICE: the same run with thin_max 0 and 16384 -- levels identical,
     per-level sets, trajectories and accelerations to 1e-12 (the force kernels project the very rows the table would hold;
     the sums differ in order only).  The bars against the oracle (1e-10 / 1e-9) are the parametrised test above."""
-    monkeypatch.setenv("EXP_AMD_THIN_V", thin_v)
+    if thin_v == "2":
+        monkeypatch.setenv("EXP_AMD_SPH_GENERIC", "1")
+        monkeypatch.setenv("EXP_AMD_CYL_GENERIC", "1")
     z = c4.load_golden()
     ms = int(z["multistep"])
     runs = []

@@ -61,23 +61,6 @@ def test_fuzz_multistep_replays(seed, trial):
     assert res in ("ok", "edge"), f"fuzz_multistep seed {seed} trial {trial}: {res}"
 
 
-def test_fuzz_multistep_with_the_separate_launches():
-    """The launch reductions of the step driver each have a switch that restores the separate launch (INTEGRATION.md;
-    read once per process): a slice of the campaign in a process of its own with all of them off."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    for k in ("EXP_AMD_SIM_PUBLISH", "EXP_AMD_SIM_SWEEP_LISTS", "EXP_AMD_SIM_FOLD_KICK", "EXP_AMD_SIM_FUSE_COMMIT",
-              "EXP_AMD_SPH_PROJECT_BOTH", "EXP_AMD_THIN_DIFF", "EXP_AMD_THIN_ADVANCE", "EXP_AMD_SIM_SKIP_NOOP_SWEEPS"):
-        env[k] = "0"
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_multistep.py"), "40", "3"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "'LEVELS': 0, 'STATE': 0" in r.stdout, r.stdout[-500:]
-
-
 def test_fuzz_kdk_slice():
     """the fused single-level step and its HIP-graph replay against the n-body oracle"""
     m = _campaign("fuzz_kdk")
