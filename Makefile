@@ -45,10 +45,14 @@ exp_amd/libexp_amd.so: $(BASE_OBJ) $(INST_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 # the C++ adaptor (include/exp_amd_potaccel.hpp) and its no-Python test, built with g++ against the C ABI
-adaptor: build/test_potaccel
-build/test_potaccel: tests/cpp/test_potaccel.cpp include/exp_amd_potaccel.hpp include/exp_amd.h exp_amd/libexp_amd.so
+adaptor: build/test_potaccel build/test_potaccel2
+build/test_potaccel%: tests/cpp/test_potaccel%.cpp tests/cpp/potaccel_test_util.hpp include/exp_amd_potaccel.hpp include/exp_amd.h exp_amd/libexp_amd.so
 	@mkdir -p build
-	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude $< -o $@ -Lexp_amd -lexp_amd \
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude -Itests/cpp $< -o $@ -Lexp_amd -lexp_amd \
+	    -Wl,-rpath,'$$ORIGIN/../exp_amd' -Wl,-rpath-link,/opt/rocm/lib
+build/test_potaccel: tests/cpp/test_potaccel.cpp tests/cpp/potaccel_test_util.hpp include/exp_amd_potaccel.hpp include/exp_amd.h exp_amd/libexp_amd.so
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude -Itests/cpp $< -o $@ -Lexp_amd -lexp_amd \
 	    -Wl,-rpath,'$$ORIGIN/../exp_amd' -Wl,-rpath-link,/opt/rocm/lib
 
 clean:

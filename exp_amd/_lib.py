@@ -54,6 +54,15 @@ SIGNATURES = {
     "exp_amd_comm_init_rank": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "exp_amd_comm_set_callback": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
     "exp_amd_comm_set_world": (c_int, [c_void_p, c_int, c_int]),
+    "exp_amd_comp_set_rtrunc": (c_int, [c_void_p, c_double, c_void_p]),
+    "exp_amd_force_set_mass_scale": (c_int, [c_void_p, c_double]),
+    "exp_amd_force_set_self_consistent": (c_int, [c_void_p, c_int]),
+    "exp_amd_force_set_initializing": (c_int, [c_void_p, c_int]),
+    "exp_amd_force_coefs_frozen": (c_int, [c_void_p]),
+    "exp_amd_sph_set_fix_l0": (c_int, [c_void_p, c_int]),
+    "exp_amd_cyl_set_mlim": (c_int, [c_void_p, c_int]),
+    "exp_amd_sim_set_adiabatic": (c_int, [c_void_p, c_int, c_double, c_double, c_double]),
+    "exp_amd_sim_set_time": (c_int, [c_void_p, c_double]),
     "exp_amd_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_longlong)]),
     "exp_amd_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_comp_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),

@@ -658,34 +658,8 @@ class SphericalSL(BiorthBasis):
 
     def orthoCheck(self, num: int = 200):
         """exputil/SLGridMP2.cc:1775-1824 on the host tables"""
-        from numpy.polynomial import legendre as npleg
-        g = self.grid
-        x, w = npleg.leggauss(num)
-        knots, weights = 0.5 * (x + 1.0), 0.5 * w
-        ximin, ximax = float(g.r_to_xi(g.rmin)), float(g.r_to_xi(g.rmax))
-        xs = ximin + (ximax - ximin) * knots
-        if g.cmap == 1:
-            xs = np.clip(xs, -1.0, 1.0 - 1e-8)
-        r = g.xi_to_r(xs)
-        idx = np.clip(((xs - g.xmin) / g.dxi).astype(np.int64), 0, g.numr - 2)
-        x1 = (g.xi[idx + 1] - xs) / g.dxi
-        x2 = (xs - g.xi[idx]) / g.dxi
-        if g.cmap == 1:
-            dxr = 0.5 * (1.0 - xs) ** 2 / g.rmap
-        elif g.cmap == 2:
-            dxr = np.exp(-xs)
-        else:
-            dxr = np.ones_like(xs)
-        P0 = x1 * g.p0[idx] + x2 * g.p0[idx + 1]
-        D0 = x1 * g.d0[idx] + x2 * g.d0[idx + 1]
-        out = []
-        for L in range(g.lmax + 1):
-            u = x1 * g.ef[L][:, idx] + x2 * g.ef[L][:, idx + 1]        # [nmax, num]
-            pot = u / np.sqrt(g.ev[L])[:, None] * P0
-            den = u * np.sqrt(g.ev[L])[:, None] * D0
-            wgt = r * r / dxr * (ximax - ximin) * weights
-            out.append(-(pot * wgt) @ den.T)
-        return out
+        from .slgrid import orthocheck
+        return orthocheck(self.grid, num)
 
     def orthoTest(self, num: int = 200) -> None:
         """exputil/orthoTest.cc:19-87, tolerance orthoTol = 1e-2 (exputil/libvars.cc:40)"""
@@ -974,8 +948,10 @@ class Cylindrical(BiorthBasis):
         if not self.cachename:
             raise RuntimeError("Cylindrical requires a specified cachename in your YAML config")
         self.grid = self._load_or_build()
+        # mlim (expui/BiorthBasis.cc:1384, :1466, :1620: `if (mlim>=0) sl->set_mlim(mlim)`): harmonics above it take no part
+        self.mlim = int(g("mlim", np.iinfo(np.int32).max))
         self.force = Cylinder(self.ctx, self.grid, rcylmax=self.rcylmax,
-                              EVEN_M=bool(g("EVEN_M", False)))
+                              EVEN_M=bool(g("EVEN_M", False)), mlim=self.mlim)
         self.cos = np.zeros((self.mmax + 1, self.nmax))
         self.sin = np.zeros((self.mmax + 1, self.nmax))
         self.cylmass = 0.0

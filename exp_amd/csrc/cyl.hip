@@ -56,6 +56,8 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   C.xmin = cfg->xmin; C.dx = cfg->dx; C.ymin = cfg->ymin; C.dy = cfg->dy;
   C.inv_dx = 1.0 / cfg->dx; C.inv_dy = 1.0 / cfg->dy;
   C.umass = 0.0;
+  C.mscale = 1.0;
+  C.frz = 0;
   C.rmax2 = cfg->rcylmax * cfg->rcylmax * cfg->ascale * cfg->ascale;   // src/Cylinder.cc:752
   C.cx = C.cy = C.cz = 0.0;
   *out = f;
@@ -471,7 +473,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       size_t nall = 0;
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       const bool fuse_on = EXPAMD_EXPT("EXP_AMD_THIN_ADVANCE", 1) != 0;
-      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
+      const bool fuse = fuse_on && !f->frozen() && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
                         !ctx->deterministic && !f->generic;
       if (fuse) {
         f->adv_owed = true;
@@ -662,6 +664,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
                  : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
       C.ps = t->pseudo;
+      cdev_freeze(C, t);
       if (f->generic)
         cyl_wave_force_launch(ctx->stream, nthin, C, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1,
                               f->d_tabT.p, f->tabT_nk, f->d_coef.p, f->d_mass.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT),
@@ -692,6 +695,7 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   CylDev C = !external ? cdev_for(f, t) : f->home ? cdev_for(f, f->home)
              : f->home_gone ? cdev_frame(f, f->home_center, f->home_use_rot, f->home_rot) : cdev_for(f, t);
   C.ps = t->pseudo;
+  cdev_freeze(C, t);
   const int lo = (t->nlevels > 1) ? f->mlevel : 0;
   const int hi = t->nlevels - 1;
   size_t nr = t->n;                    // population of the level range: sizes the launch
@@ -746,6 +750,39 @@ int CylForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   t->acc_live = true;
   if (prekey) *prekey_done = true;
   if (deferred) t->pending_kick = sv == 2 ? -nk_dtk : dt_kick;
+  return EXP_AMD_OK;
+}
+
+// The "mlim" key (src/Cylinder.cc:40, :225 -> EmpCylSL::set_mlim; pyEXP: expui/BiorthBasis.cc:1466, :1620): harmonics
+// m > mlim take no part -- EmpCylSL::get_pot fills Vc / Vs up to min(MLIM, MMAX) only (exputil/EmpCylSL.cc:5602) and
+// accumulated_eval / accumulated_dens_eval sum up to it (:5317, :5465).  Here the TABLES of m > mlim are zeroed on the
+// device: every pass -- accumulation, differencing, projection, the direct kernels, fields -- then drops those harmonics
+// with no change to a kernel, and the coefficients of m > mlim come out as zero (the reference leaves the rows of Vc it
+// never fills as they were allocated, :4078: unspecified there, zero here).  Can only be lowered once set.
+extern "C" int exp_amd_cyl_set_mlim(exp_amd_force *fb, int mlim)
+{
+  expamd_mutated();
+  CylForce *f = dynamic_cast<CylForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_mlim: not a cylinder force");
+  if (mlim < 0) return expamd_fail(f->ctx, EXP_AMD_ERR_ARG, "set_mlim: mlim must be >= 0 (the key's -1 means: do not call)");
+  const int M = f->cfg.mmax, N = f->cfg.nmax;
+  if (mlim >= M) return EXP_AMD_OK;                                  // min(MLIM, MMAX)
+  if (f->mlim >= 0 && mlim > f->mlim)
+    return expamd_fail(f->ctx, EXP_AMD_ERR_STATE, "set_mlim: the tables above m = %d are already dropped", f->mlim);
+  exp_amd_ctx *ctx = f->ctx;
+  const size_t per_m = (size_t)N * f->nnode, per_kind = (size_t)(M + 1) * per_m;
+  for (int k = 0; k < 6; k++)
+    HIP_TRY(ctx, hipMemsetAsync(f->d_tab.p + k * per_kind + (size_t)(mlim + 1) * per_m, 0,
+                                (size_t)(M - mlim) * per_m * sizeof(double), ctx->stream));
+  if (f->d_dens.n)
+    for (int k = 0; k < 2; k++)
+      HIP_TRY(ctx, hipMemsetAsync(f->d_dens.p + k * per_kind + (size_t)(mlim + 1) * per_m, 0,
+                                  (size_t)(M - mlim) * per_m * sizeof(double), ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  f->d_tabT.release();                        // (the node-major copy of the thin path is remade from the new tables)
+  f->tabT_nk = 0;
+  f->mlim = mlim;
+  f->proj_dirty = true;
   return EXP_AMD_OK;
 }
 

@@ -30,7 +30,24 @@ struct CylDev {
   // deterministic mode: rounding-grid constants of the moment terms / of the in-cut mass (0: off)
   double detC, detCm;
   double umass;     // != 0: every particle of the component has this mass (accumulate does not read the stream)
+  double mscale;    // Component::Adiabatic() of the basis' component at the time of the call: multiplies every mass the
+                    // accumulation and the differencing read (src/Cylinder.cc:834, :1758; exp_amd_force_set_mass_scale)
+  // Component::freeze (src/Component.cc:4194-4202) of the component whose particles the launch walks (the source of an
+  // accumulation, the TARGET of a force pass: src/Cylinder.cc:788, :842, :1329, :1756).  frz == 0: rtrunc not set
+  int frz;
+  double frz_c0[3], frz_c[3], frz_r2;
 };
+
+// Component::freeze, in the reference's operation order: r2 = sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2
+__device__ __forceinline__ bool cyl_frozen(const CylDev &C, double px, double py, double pz)
+{
+  if (!C.frz) return false;
+  const double dx = (px - C.frz_c0[0]) - C.frz_c[0], dy = (py - C.frz_c0[1]) - C.frz_c[1], dz = (pz - C.frz_c0[2]) - C.frz_c[2];
+  double r2 = dx * dx;
+  r2 = mul_then_add(r2, dy, dy);
+  r2 = mul_then_add(r2, dz, dz);
+  return r2 > C.frz_r2;
+}
 
 // centred, then rotated into the body frame
 __device__ __forceinline__ void cyl_local(const CylDev &C, double x, double y, double z, double &xx,
@@ -43,6 +60,16 @@ __device__ __forceinline__ void cyl_local(const CylDev &C, double x, double y, d
     yy = C.rot[3] * a + C.rot[4] * b + C.rot[5] * c;
     zz = C.rot[6] * a + C.rot[7] * b + C.rot[8] * c;
   }
+}
+
+// ... for the passes that ADD particle contributions: a frozen particle (Component::freeze) is sent far off the grid and
+// outside the rcylmax cut, where the pass neither counts nor adds it -- the `continue` of src/Cylinder.cc:842, the
+// `return` of :1756
+__device__ __forceinline__ void cyl_local_acc(const CylDev &C, double x, double y, double z, double &xx,
+                                              double &yy, double &zz)
+{
+  cyl_local(C, x, y, z, xx, yy, zz);
+  if (C.frz && cyl_frozen(C, x, y, z)) { xx = 1.0e150; yy = 0.0; zz = 0.0; }
 }
 
 template <int I, int N, class F>

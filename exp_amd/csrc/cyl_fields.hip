@@ -80,6 +80,12 @@ extern "C" int exp_amd_cyl_set_density(exp_amd_force *fb, const double *dens)
   if (f->d_dens.alloc(cnt) != hipSuccess)
     return expamd_fail(ctx, EXP_AMD_ERR_HIP, "cyl_set_density: hipMalloc failed");
   HIP_TRY(ctx, hipMemcpyAsync(f->d_dens.p, dens, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (f->mlim >= 0 && f->mlim < f->cfg.mmax) {         // accumulated_dens_eval sums up to MLIM (exputil/EmpCylSL.cc:5465)
+    const size_t per_m = (size_t)f->cfg.nmax * f->nnode, per_kind = (size_t)(f->cfg.mmax + 1) * per_m;
+    for (int k = 0; k < 2; k++)
+      HIP_TRY(ctx, hipMemsetAsync(f->d_dens.p + k * per_kind + (size_t)(f->mlim + 1) * per_m, 0,
+                                  (size_t)(f->cfg.mmax - f->mlim) * per_m * sizeof(double), ctx->stream));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return EXP_AMD_OK;
 }

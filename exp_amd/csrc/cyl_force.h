@@ -13,6 +13,7 @@ struct CylForce : exp_amd_force {
   size_t work_cap = 0;              // ... in waves; the two counters behind it are used alternately
   int work_flip = 0;
   int step_parity() const override { return work_flip; }
+  int mlim = -1;                    // the "mlim" key (exp_amd_cyl_set_mlim): harmonics above it are dropped; < 0: none
   bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_cyl_acc_thin
   double adv_dt_min = 0.0;
@@ -89,6 +90,14 @@ static inline CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
   return cdev_frame(f, c->center, c->use_rot, c->rot);
 }
 
+// Component::freeze of the component whose particles a launch walks (the source of an accumulation, the target of a force)
+static inline void cdev_freeze(CylDev &C, const exp_amd_comp *c)
+{
+  C.frz = c->freeze_on ? 1 : 0;
+  for (int k = 0; k < 3; k++) { C.frz_c0[k] = c->com0[k]; C.frz_c[k] = c->center[k]; }
+  C.frz_r2 = c->rtrunc * c->rtrunc;
+}
+
 // ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding
 // grids that keep every partial sum of this component exact (|-4 pi m c_k trig| <= 4 pi |m| x 2 for the
 // bilinear weights; the in-cut mass itself)
@@ -98,6 +107,8 @@ static inline CylDev cdev_acc(const CylForce *f, const exp_amd_comp *c)
   C.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * 4.0 * M_PI * 2.0);
   C.detCm = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum);
   C.umass = c->uniform_mass ? c->mass_value : 0.0;
+  C.mscale = f->mass_scale;
+  cdev_freeze(C, c);
   return C;
 }
 

@@ -203,8 +203,8 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     t_load += tb - ta;
 #endif
     if (valid) {
-      cyl_local(C, nx, ny, nz, xx, yy, zz);
-      mass = nm;
+      cyl_local_acc(C, nx, ny, nz, xx, yy, zz);
+      mass = nm * C.mscale;
     }
     if (i + 64 < cend) {
       if constexpr (LIST) cyl_list_fetch(al, X, Y, Z, M, C.umass, i + 64, nx, ny, nz, nm, nlv);
@@ -418,8 +418,8 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
     const int plv = LIST ? nlv[slot] : lvl;
     double xx = 1, yy = 0, zz = 0, mass = 0;
     if (valid) {
-      cyl_local(C, nx[slot], ny[slot], nz[slot], xx, yy, zz);
-      mass = nm[slot];
+      cyl_local_acc(C, nx[slot], ny[slot], nz[slot], xx, yy, zz);
+      mass = nm[slot] * C.mscale;
     }
     fetch(i + 128, slot);
 #if CSLOT_EXPT == 1 || CSLOT_EXPT == 5        // timing experiment: the particle stream alone
@@ -570,8 +570,8 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   if (!__any(mover)) return;
   double xx = 1, yy = 0, zz = 0, mass = 0;
   if (mover) {
-    cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
-    mass = M[i];
+    cyl_local_acc(C, X[i], Y[i], Z[i], xx, yy, zz);
+    mass = M[i] * C.mscale;
   }
   const double r2 = xx * xx + yy * yy;
   double r, ir;
@@ -1075,6 +1075,8 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
     fx -= qx; fy -= qy; fz -= qz;
   }
+  // (a frozen target particle is skipped by the thread body, src/Cylinder.cc:1329: nothing is added)
+  if (C.frz && cyl_frozen(C, X[i], Y[i], Z[i])) { fx = fy = fz = 0.0; pa = 0.0; }
   if (!assign) {
     fx += AX[i];
     fy += AY[i];
@@ -1280,6 +1282,7 @@ k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restric
         pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
         fx -= qx; fy -= qy; fz -= qz;
       }
+      if (C.frz && cyl_frozen(C, X[i], Y[i], Z[i])) { fx = fy = fz = 0.0; pa = 0.0; }
       if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
       AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
     }
@@ -1319,8 +1322,8 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
       if (valid) {
         double px, py, pz;
         if (adv.on) thin_advance(adv, i, px, py, pz); else { px = X[i]; py = Y[i]; pz = Z[i]; }
-        cyl_local(C, px, py, pz, xx, yy, zz);
-        mass = M[i];
+        cyl_local_acc(C, px, py, pz, xx, yy, zz);
+        mass = M[i] * C.mscale;
       }
       const double r2 = xx * xx + yy * yy;
       double r, ir;
@@ -1455,8 +1458,8 @@ k_cyl_diff_thin(CylDev C, const double *__restrict__ X, const double *__restrict
       int from = -1, to = -1;
       if (valid) {
         const uint32_t i = list[base + t];
-        cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz);
-        mass = M[i];
+        cyl_local_acc(C, X[i], Y[i], Z[i], xx, yy, zz);
+        mass = M[i] * C.mscale;
         from = lev[i]; to = newlev[i];
       }
       const double r2 = xx * xx + yy * yy;
@@ -1629,6 +1632,7 @@ k_cyl_force_wave(CylDev C, const double *__restrict__ X, const double *__restric
       pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
       fx -= qx; fy -= qy; fz -= qz;
     }
+    if (C.frz && cyl_frozen(C, X[i], Y[i], Z[i])) { fx = fy = fz = 0.0; pa = 0.0; }
     if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
     AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
   }
@@ -1662,7 +1666,7 @@ k_cyl_acc_tile(CylDev C, const double *__restrict__ X, const double *__restrict_
       const size_t i = base + lane;
       const bool valid = lane < np;
       double xx = 1, yy = 0, zz = 0, mass = 0;
-      if (valid) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = C.umass != 0.0 ? C.umass : M[i]; }
+      if (valid) { cyl_local_acc(C, X[i], Y[i], Z[i], xx, yy, zz); mass = (C.umass != 0.0 ? C.umass : M[i]) * C.mscale; }
       const double r2 = xx * xx + yy * yy;
       double r, ir;
       sqrt_rsqrt(r2, r, ir);
@@ -1797,7 +1801,7 @@ k_cyl_moments_gen(CylDev C, const double *__restrict__ X, const double *__restri
   }
   if (!__any(mover)) return;
   double xx = 1, yy = 0, zz = 0, mass = 0;
-  if (mover) { cyl_local(C, X[i], Y[i], Z[i], xx, yy, zz); mass = C.umass != 0.0 ? C.umass : M[i]; }
+  if (mover) { cyl_local_acc(C, X[i], Y[i], Z[i], xx, yy, zz); mass = (C.umass != 0.0 ? C.umass : M[i]) * C.mscale; }
   const double r2 = xx * xx + yy * yy;
   double r, ir;
   sqrt_rsqrt(r2, r, ir);
@@ -1938,6 +1942,7 @@ k_cyl_force_gen(CylDev C, const double *__restrict__ X, const double *__restrict
     pseudo_accel(C.ps, X[i], Y[i], Z[i], ux, uy, uz, qx, qy, qz);
     fx -= qx; fy -= qy; fz -= qz;
   }
+  if (C.frz && cyl_frozen(C, X[i], Y[i], Z[i])) { fx = fy = fz = 0.0; pa = 0.0; }
   if (!assign) { fx += AX[i]; fy += AY[i]; fz += AZ[i]; pa += POT[i]; }
   AX[i] = fx; AY[i] = fy; AZ[i] = fz; POT[i] = pa;
   if (dt_kick != 0.0) {

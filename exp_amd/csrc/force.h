@@ -43,6 +43,14 @@ struct exp_amd_force {
   DevBuf<double> d_scratch;         // >= 64 doubles of scratch for small host->device parameters
   DevBuf<unsigned long long> d_used;
   int mlevel = 0;
+  // Component::Adiabatic() of the component the basis belongs to, as the host evaluated it for the CURRENT time
+  // (src/Component.cc:4214-4220; exp_amd_force_set_mass_scale): multiplies every mass the accumulation and the
+  // level-change differencing read (src/SphericalBasis.cc:441, :471, :1161; src/Cylinder.cc:834, :1758)
+  double mass_scale = 1.0;
+  // "self_consistent: false" (src/SphericalBasis.cc:114-117, :694; src/Cylinder.cc:557, :959, :1755): once the first
+  // evaluation is done and begin_run is over (`initializing`) the coefficients stay what they are: frozen()
+  bool self_consistent = true, firstime_coef = true, initializing = false;
+  bool frozen() const { return !self_consistent && !firstime_coef && !initializing; }
   bool proj_dirty = true;           // projected force tables are stale w.r.t. d_coef
   exp_amd_comp *home = nullptr;     // component whose particles define the expansion centre
   // ... and what it looked like when it was destroyed while this force still pointed at it (pyEXP

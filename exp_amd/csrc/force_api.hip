@@ -79,11 +79,44 @@ extern "C" int exp_amd_force_set_level(exp_amd_force *f, int mlevel)
   return EXP_AMD_OK;
 }
 
+// Component::Adiabatic() of the basis' component at the current time (src/Component.cc:4214-4220), evaluated by the host
+extern "C" int exp_amd_force_set_mass_scale(exp_amd_force *f, double adb)
+{
+  expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
+  if (!f || !(adb >= 0.0)) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "set_mass_scale: factor must be >= 0");
+  f->mass_scale = adb;
+  return EXP_AMD_OK;
+}
+
+// the "self_consistent" key (src/SphericalBasis.cc:114-117, src/Cylinder.cc:557-558) and the global `initializing`
+// (src/begin.cc:80, :129) it is tested with
+extern "C" int exp_amd_force_set_self_consistent(exp_amd_force *f, int on)
+{
+  expamd_mutated();
+  if (!f) return EXP_AMD_ERR_ARG;
+  f->self_consistent = on != 0;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_set_initializing(exp_amd_force *f, int on)
+{
+  expamd_mutated();
+  if (!f) return EXP_AMD_ERR_ARG;
+  f->initializing = on != 0;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_force_coefs_frozen(const exp_amd_force *f) { return f && f->frozen() ? 1 : 0; }
+
 extern "C" int exp_amd_force_determine_coefficients(exp_amd_force *f, exp_amd_comp *c)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!f || !c) return expamd_fail(f ? f->ctx : nullptr, EXP_AMD_ERR_ARG, "determine_coefficients: NULL");
-  return f->determine_coefficients(c, false, 0.0, 0.0);
+  // "Return if we should leave the coefficients fixed" (src/SphericalBasis.cc:694, src/Cylinder.cc:959)
+  if (f->frozen()) return EXP_AMD_OK;
+  const int rc = f->determine_coefficients(c, false, 0.0, 0.0);
+  if (rc == EXP_AMD_OK) f->firstime_coef = false;                  // (:1001, :1198)
+  return rc;
 }
 
 extern "C" int exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external)
@@ -172,6 +205,9 @@ extern "C" int exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, in
   if (ms == 0) return EXP_AMD_OK;
   const int Mstep = 1 << ms;
   if (mdrft < 0 || mdrft > Mstep) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "mdrft out of range");
+  // `if (multistep && (self_consistent || initializing)) compute_multistep_coefficients()`
+  // (src/SphericalBasis.cc:1682, src/Cylinder.cc:1469)
+  if (!f->self_consistent && !f->initializing) return EXP_AMD_OK;
   int mfirst = 0;
   CombineW W;
   expamd_combine_weights(ms, mdrft, &mfirst, &W);
@@ -209,7 +245,9 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   HIP_TRY(ctx, hipMemcpyAsync(&u, c->nswitch.p + 64, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (nswitch) *nswitch = (long long)u;
-  if (ctx->nranks > 1 || ctx->ar_fn || u) {
+  // (not self-consistent: Cylinder::multistep_update returns at once, src/Cylinder.cc:1755; the sphere's differencing
+  // only feeds level sets that nothing reads again once compute_multistep_coefficients is no longer called)
+  if ((ctx->nranks > 1 || ctx->ar_fn || u) && f->self_consistent) {
     // (collective: with several ranks every rank takes part even if it has no mover)
     c->mover_hint = (long long)u;
     rc = f->multistep_update(c, first, mfirst);
@@ -235,6 +273,14 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
     return expamd_fail(f->ctx, EXP_AMD_ERR_STATE,
                        "step_kdk: multistep force; drive the sub-steps explicitly");
   int rc;
+  if (f->frozen()) {
+    // coefficients held fixed ("self_consistent: false" after the first evaluation): the step is kick, drift, force,
+    // kick with the set as it is -- nothing to fuse the advance into
+    if ((rc = exp_amd_comp_kick(c, 0.5 * dt, -1)) || (rc = exp_amd_comp_drift(c, dt, -1))) return rc;
+    if ((rc = exp_amd_comp_zero_acc(c, 0))) return rc;
+    if ((rc = f->accelerate(c, 0, false, 0.0))) return rc;
+    return exp_amd_comp_kick(c, 0.5 * dt, -1);
+  }
   // kick dt/2 + drift dt are applied inside the sort passes (no separate HBM pass); acc/pot are
   // recomputed below, so they are not carried through the reorder
   c->acc_live = false;
@@ -258,6 +304,7 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
   // the closing half-kick is deferred: the next fused step's scatter pass applies it (as its own
   // rounding step) together with its opening half-kick; any other call applies it first
   if ((rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done, /*defer_kick=*/c->n > 0))) return rc;
+  f->firstime_coef = false;
   if (done) {
     c->prekey_valid = true;
     c->prekey_split = false;

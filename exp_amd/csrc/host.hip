@@ -39,6 +39,10 @@ struct exp_amd_sim {
   // latency-bound, so the two components' chains fill each other's gaps.  Events carry the cross
   // dependencies: ev_self[k] = force method k has projected its tables and applied its self force;
   // ev_used[k] = the last use of force method k's tables by a cross force on the other stream.
+  // Component::Adiabatic (the ton / toff / twid keys, src/Component.cc:1040-1055, :4214-4220) per component: the driver
+  // evaluates it at tnow before every accumulation and differencing (exp_amd_sim_set_adiabatic)
+  struct Adiabatic { bool on = false; double ton = -1.0e20, toff = 1.0e20, twid = 0.1; };
+  std::vector<Adiabatic> adb;
   bool overlap = false;
   hipStream_t main_stream = nullptr;
   std::vector<hipEvent_t> ev_self, ev_used;
@@ -49,6 +53,13 @@ struct exp_amd_sim {
 static inline double host_now()
 {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// double Component::Adiabatic() (src/Component.cc:4214-4220) at the driver's tnow -> the force's mass factor
+static void set_mass_scale(exp_amd_sim *s, size_t k)
+{
+  const exp_amd_sim::Adiabatic &a = s->adb[k];
+  s->forces[k]->mass_scale = !a.on ? 1.0 : 0.25 * (1.0 + erf((s->tnow - a.ton) / a.twid)) * (1.0 + erf((a.toff - s->tnow) / a.twid));
 }
 
 // issue on component k's stream for the lifetime of the object
@@ -151,6 +162,7 @@ extern "C" int exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_am
   s->forces.push_back(f);
   s->orients.push_back(nullptr);
   s->ej_dryrun.push_back(0);
+  s->adb.emplace_back();
   if (index) *index = (int)s->comps.size() - 1;
   return EXP_AMD_OK;
 }
@@ -163,6 +175,24 @@ extern "C" int exp_amd_sim_add_interaction(exp_amd_sim *s, int source, int targe
       target >= (int)s->comps.size() || source == target)
     return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_add_interaction: bad index");
   s->inter.emplace_back(source, target);
+  return EXP_AMD_OK;
+}
+
+// The component's adiabatic turn-on / turn-off (keys ton, toff, twid of a component, src/Component.cc:1040-1055): from now
+// on the driver multiplies the masses its force method accumulates and differences by Component::Adiabatic() at tnow
+extern "C" int exp_amd_sim_set_adiabatic(exp_amd_sim *s, int index, double ton, double toff, double twid)
+{
+  if (!s || index < 0 || index >= (int)s->comps.size() || !(twid > 0.0))
+    return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_set_adiabatic: bad index or width");
+  s->adb[index].on = true;
+  s->adb[index].ton = ton; s->adb[index].toff = toff; s->adb[index].twid = twid;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_sim_set_time(exp_amd_sim *s, double tnow)
+{
+  if (!s) return EXP_AMD_ERR_ARG;
+  s->tnow = tnow;
   return EXP_AMD_OK;
 }
 
@@ -242,7 +272,10 @@ static int compute_expansion(exp_amd_sim *s, int M)
   for (size_t k = 0; k < s->comps.size(); k++) {
     int rc = exp_amd_force_set_level(s->forces[k], M);
     if (rc) return rc;
+    if (s->forces[k]->frozen()) continue;                      // "self_consistent: false" after begin_run
+    set_mass_scale(s, k);
     if ((rc = s->forces[k]->determine_coefficients(s->comps[k], false, 0.0, 0.0))) return rc;
+    s->forces[k]->firstime_coef = false;
   }
   return EXP_AMD_OK;
 }
@@ -301,8 +334,13 @@ static int substep_expansion(exp_amd_sim *s, int lo, double dt_min, int mdrft)
       StreamOf on(s, k);
       int rc = phase == 2 ? 0 : wait_used(s, k);
       if (rc) return rc;
-      rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1, phase);
+      // coefficients held fixed ("self_consistent: false" once begin_run is over): the advance alone
+      const bool frz = s->forces[k]->frozen();
+      if (frz && phase == 2) continue;
+      set_mass_scale(s, k);
+      rc = s->forces[k]->substep_expansion(s->comps[k], lo, dt_min, alone ? mdrft : -1, frz ? 1 : phase);
       if (rc) return rc;
+      if (!frz && phase != 1) s->forces[k]->firstime_coef = false;
     }
   return EXP_AMD_OK;
 }
@@ -463,8 +501,12 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     s->step_switch += (long long)u;
     // (collective: with several ranks every rank takes part even if it has no mover)
     c->mover_hint = (long long)u;
-    if (ctx->nranks > 1 || ctx->ar_fn || u)
+    // (not self-consistent: Cylinder::multistep_update returns at once, src/Cylinder.cc:1755; the sphere's only feeds
+    // level sets that nothing reads again)
+    if ((ctx->nranks > 1 || ctx->ar_fn || u) && f->self_consistent) {
+      set_mass_scale(s, k);                                    // (tnow is the END of the sub-step here, as in the reference)
       if ((rc = f->multistep_update(c, first, mf))) return rc;
+    }
     c->mover_hint = -1;
     c->mover_list_built = false;
     if (u) {
@@ -518,6 +560,12 @@ extern "C" int exp_amd_sim_init(exp_amd_sim *s)
   if (s) for (exp_amd_comp *c : s->comps) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!s) return EXP_AMD_ERR_ARG;
   int rc;
+  // `initializing = true` ... `= false` around begin_run's expansions (src/begin.cc:80, :129)
+  struct Init {
+    exp_amd_sim *s;
+    Init(exp_amd_sim *s_) : s(s_) { for (auto f : s->forces) f->initializing = true; }
+    ~Init() { for (auto f : s->forces) f->initializing = false; }
+  } init_scope(s);
   if (s->multistep) {
     if ((rc = overlap_begin(s))) return rc;
     for (size_t k = 0; k < s->forces.size(); k++) { StreamOf on(s, k); if ((rc = wait_used(s, k)) || (rc = s->forces[k]->multistep_reset())) return rc; }

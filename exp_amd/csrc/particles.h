@@ -45,6 +45,11 @@ struct exp_amd_comp {
   int nlevels = 1;                   // multistep + 1
   bool levels_zero = true;           // no slot has ever been given a level > 0 (both level arrays are 0)
   double center[3] = {0, 0, 0};
+  // Component::rtrunc / com0 of Component::freeze (src/Component.cc:213, :4194-4202): a particle with
+  // |pos - com0 - center| > rtrunc takes no part in any force method's accumulation, differencing or force pass
+  // (exp_amd_comp_set_rtrunc; freeze_on == false: the default rtrunc of 1e20)
+  bool freeze_on = false;
+  double rtrunc = 1.0e20, com0[3] = {0, 0, 0};
   bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
   double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   PseudoDev pseudo = {0, 0, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // frame acceleration subtracted by the forces

@@ -1282,6 +1282,17 @@ extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
   return EXP_AMD_OK;
 }
 
+// Component::rtrunc and com0 (the "rtrunc" key of a component, src/Component.cc:69, :1023)
+extern "C" int exp_amd_comp_set_rtrunc(exp_amd_comp *c, double rtrunc, const double com0[3])
+{
+  if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (!c || !(rtrunc > 0.0)) return expamd_fail(c ? c->ctx : nullptr, EXP_AMD_ERR_ARG, "comp_set_rtrunc: rtrunc must be positive");
+  c->rtrunc = rtrunc;
+  for (int k = 0; k < 3; k++) c->com0[k] = com0 ? com0[k] : 0.0;
+  c->freeze_on = rtrunc < 1.0e20;
+  return EXP_AMD_OK;
+}
+
 extern "C" int exp_amd_comp_get_center(const exp_amd_comp *c, double center[3])
 {
   if (!c || !center) return EXP_AMD_ERR_ARG;

@@ -384,6 +384,8 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.lit_xhi = lit_on ? xi[numr - 2] + 5.0 * cfg->dxi : 1.0e300;
   S.detC = 0.0;
   S.umass = 0.0;
+  S.fac0 = -4.0 * M_PI;
+  S.frz = 0;
   {
     // bound of a unit-mass particle's moment contribution |4 pi P0 x_k Ph(l,m)(cos theta) trig|, for the
     // rounding grid of the deterministic mode: max |p0| on the grid x max |Ph| on a fine cos(theta) grid
@@ -414,6 +416,7 @@ void SphForce::release()
 {
   d_xi.release(); d_p0.release(); d_E.release(); d_lc.release(); d_litef.release(); d_litlist.release();
   d_gen_ac.release(); d_gen_e.release(); d_gen_slot.release();
+  d_c0.release();
   d_rowmap.release();
   d_tscale.release();
   d_ev.release(); d_d0.release(); d_Gd.release();
@@ -430,6 +433,14 @@ static SphDev dev_for(const SphForce *f, const double center[3])
   return S;
 }
 
+// Component::freeze of the component whose particles a launch walks (the source of an accumulation, the target of a force)
+static void dev_freeze(SphDev &S, const exp_amd_comp *c)
+{
+  S.frz = c->freeze_on ? 1 : 0;
+  for (int k = 0; k < 3; k++) { S.frz_c0[k] = c->com0[k]; S.frz_c[k] = c->center[k]; }
+  S.frz_r2 = c->rtrunc * c->rtrunc;
+}
+
 // ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding
 // grid that keeps every partial sum of this component exact (common.h: expamd_det_constant)
 static SphDev dev_acc(const SphForce *f, const exp_amd_comp *c)
@@ -437,6 +448,8 @@ static SphDev dev_acc(const SphForce *f, const exp_amd_comp *c)
   SphDev S = dev_for(f, c->center);
   S.detC = expamd_det_constant(f->ctx->deterministic, c->mass_abs_sum * f->term_max);
   S.umass = c->uniform_mass ? c->mass_value : 0.0;
+  S.fac0 = -4.0 * M_PI * f->mass_scale;
+  dev_freeze(S, c);
   return S;
 }
 
@@ -669,7 +682,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       size_t nall = 0;
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       const bool fuse_on = EXPAMD_EXPT("EXP_AMD_THIN_ADVANCE", 1) != 0;
-      const bool fuse = fuse_on && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
+      const bool fuse = fuse_on && !f->frozen() && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
                         !ctx->deterministic && f->ncoef <= 4096 && !f->generic;
       if (fuse) {
         f->adv_owed = true;
@@ -817,6 +830,18 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     if ((rc = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin))) return rc;
     thin = (long long)nthin <= ctx->thin_max;
   }
+  if (f->fix_l0) {
+    // "Save the monopole coefficients on the first evaluation / Copy the saved coefficients to the active array"
+    // (src/SphericalBasis.cc:1689-1694; outside the use_external test: self and external calls alike)
+    const size_t nb = (size_t)f->cfg.nmax * sizeof(double);
+    if (!f->have_c0) {
+      HIP_TRY(ctx, hipMemcpyAsync(f->d_c0.p, f->d_coef.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+      f->have_c0 = true;
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, f->d_c0.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+      f->proj_dirty = true;
+    }
+  }
   if (!thin && (rc = sph_project(f))) return rc;
   f->used_open = false;          // tnow has moved past resetT once forces are evaluated
   if (t->n == 0) return EXP_AMD_OK;
@@ -826,6 +851,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       const double *ctr_ = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
       SphDev S = dev_for(f, ctr_);
       S.ps = t->pseudo;
+      dev_freeze(S, t);
       SphThinForceArgs a{S, t->a(A_X), t->a(A_Y), t->a(A_Z), t->lev_off.p, f->mlevel, t->nlevels - 1, f->d_coef.p,
                          f->d_rowmap.p, f->d_tscale.p, t->a(A_AX), t->a(A_AY), t->a(A_AZ), t->a(A_POT), t->a(A_VX),
                          t->a(A_VY), t->a(A_VZ), assign ? 1 : 0, nthin, ctx->stream};
@@ -847,6 +873,7 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   const double *ctr = !external ? t->center : f->home ? f->home->center : f->home_gone ? f->home_center : t->center;
   SphDev S = dev_for(f, ctr);
   S.ps = t->pseudo;                    // Component::AddAcc of the TARGET (src/Component.H:914-921)
+  dev_freeze(S, t);
   // closing half-kick: stored (1), left to the next scatter pass (0), or -- when that pass is known,
   // i.e. its keys are produced here -- stored together with its opening half-kick (2)
   const bool deferred = defer_kick && dt_kick != 0.0;
@@ -1043,6 +1070,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
       SphDev Sh = S;
       Sh.key_add = (uint32_t)h * ncell;
       Sh.ps = c->pseudo;
+      dev_freeze(Sh, c);
       SphForceArgs a{Sh, c->a(A_X), c->a(A_Y), c->a(A_Z), c->half_off.p, h, h, f->d_T4.p,
                      c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->a(A_VX), c->a(A_VY),
                      c->a(A_VZ), dt_kick, 1, len[h], (unsigned)cdiv(len[h], 256), V,
@@ -1199,6 +1227,19 @@ extern "C" int exp_amd_sph_set_accumulate_all_m(exp_amd_force *fb, int all_m)
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_accumulate_all_m: not a sphereSL force");
   f->dev.M0_acc = all_m ? 0 : f->dev.M0_only;
+  return EXP_AMD_OK;
+}
+
+// FIX_L0 (src/SphericalBasis.cc:119): on -> the next force evaluation saves the l = 0 row; off -> forgotten
+extern "C" int exp_amd_sph_set_fix_l0(exp_amd_force *fb, int on)
+{
+  expamd_mutated();
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_fix_l0: not a spherical force");
+  if (on && !f->d_c0.p && f->d_c0.alloc((size_t)f->cfg.nmax) != hipSuccess)
+    return expamd_fail(f->ctx, EXP_AMD_ERR_HIP, "set_fix_l0: hipMalloc failed");
+  f->fix_l0 = on != 0;
+  f->have_c0 = false;
   return EXP_AMD_OK;
 }
 

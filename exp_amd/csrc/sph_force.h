@@ -10,6 +10,10 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_litef;           // raw eigenfunctions at the first and last force stencil (SphDev::lit_ef)
   DevBuf<uint32_t> d_litlist;       // [1 + capacity]: slots left to the literal pass (SphDev::lit_list), cmap 2 only
   bool lit_on = false;
+  // FIX_L0 (src/SphericalBasis.cc:34, :1689-1694): the monopole row of the coefficient set is saved at the first force
+  // evaluation and copied back into the active set at every later one (exp_amd_sph_set_fix_l0)
+  bool fix_l0 = false, have_c0 = false;
+  DevBuf<double> d_c0;              // [nmax]
   DevBuf<unsigned char> d_gen_slot; // (l, m | sine flag) of the projected table's slots (SphDev::gen_slot)
   DevBuf<double> d_gen_ac, d_gen_e; // run-time recurrence constants of the any-order kernels (SphDev::gen_ac, gen_e)
   bool generic = false;             // lmax > SPH_MAX_L (or EXP_AMD_SPH_GENERIC=1): every per-particle pass through sph_gen.hip

@@ -106,7 +106,10 @@ k_sph_upd_gen(SphDev S, const double *__restrict__ X, const double *__restrict__
   }
   if (!__any(mover)) return;
   double xx = 0, yy = 0, zz = 1, mass = 0;
-  if (mover) { xx = X[i] - S.cx; yy = Y[i] - S.cy; zz = Z[i] - S.cz; mass = M[i]; }
+  if (mover) {
+    xx = X[i] - S.cx; yy = Y[i] - S.cy; zz = Z[i] - S.cz; mass = M[i];
+    if (S.frz && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;
+  }
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
   if (plain) {
     if (!(r >= S.rmin && r <= S.rmax)) mover = false;
@@ -122,7 +125,7 @@ k_sph_upd_gen(SphDev S, const double *__restrict__ X, const double *__restrict__
   const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
   const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
   const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
-  const double t0 = mass * (-4.0 * M_PI) * P0;
+  const double t0 = mass * S.fac0 * P0;
   const double a1 = t0 * x1, a2 = t0 * x2;
   const size_t wl = (size_t)(S.numr - 1) * S.nrows * 2;
   double *wto = Wd + (size_t)to * wl + (size_t)idx * S.nrows * 2;

@@ -50,6 +50,13 @@ struct SphDev {
   double detC;           // deterministic mode: 1.5 * 2^(52+e), every contribution is rounded to the grid 2^e
                          // before it is added (acc_add below); 0: off
   double umass;          // != 0: every particle of the component has this mass (the mass stream is not read)
+  double fac0;           // -4 pi x Component::Adiabatic() of the basis' component at the time of the accumulation
+                         // (src/SphericalBasis.cc:433, :441, :471; exp_amd_force_set_mass_scale): what a mass is multiplied by
+  // Component::freeze (src/Component.cc:4194-4202) of the component whose particles the launch walks -- the source in an
+  // accumulation, the TARGET in a force pass: beyond rtrunc of com0 + center a particle neither contributes nor is
+  // accelerated (src/SphericalBasis.cc:468, :1159, :1521).  frz == 0: rtrunc not set (the default, 1e20)
+  int frz;
+  double frz_c0[3], frz_c[3], frz_r2;
   double dsmall;         // added to r (src/expand.H:130: 1e-16; pyEXP: 1e-20 accumulating, 1e-18 evaluating)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
@@ -256,6 +263,17 @@ __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double
   }
 }
 
+// Component::freeze, in the reference's operation order: r2 = sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2
+__device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py, double pz)
+{
+  if (!S.frz) return false;
+  const double dx = (px - S.frz_c0[0]) - S.frz_c[0], dy = (py - S.frz_c0[1]) - S.frz_c[1], dz = (pz - S.frz_c0[2]) - S.frz_c[2];
+  double r2 = dx * dx;
+  r2 = mul_then_add(r2, dy, dy);
+  r2 = mul_then_add(r2, dz, dz);
+  return r2 > S.frz_r2;
+}
+
 // ---- accumulation ----------------------------------------------------------------------------------
 
 #define FLUSH_STRIDE 68      // doubles per scratch row: conflict-free for the 4x16 read pattern
@@ -400,7 +418,8 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   double g, y;
   sqrt_rsqrt(R2 + zz * zz, g, y);
   const double r = g + S.dsmall;
-  const bool inwin = UPD ? (valid && r < S.rmax) : (valid && r >= S.rmin && r <= S.rmax);
+  bool inwin = UPD ? (valid && r < S.rmax) : (valid && r >= S.rmin && r <= S.rmax);
+  if (S.frz) inwin = inwin && !sph_frozen(S, px, py, pz);
   const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
   if (R2 > 1e-12 * (r * r)) {
@@ -427,7 +446,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   if (p0l) { pa = p0l[idx]; pb = p0l[idx + 1]; }
   else { pa = S.p0[idx]; pb = S.p0[idx + 1]; }
   const double P0 = x1 * pa + x2 * pb;
-  const double t0 = inwin ? mass * (-4.0 * M_PI) * P0 : 0.0;
+  const double t0 = inwin ? mass * S.fac0 * P0 : 0.0;
   in.a1 = t0 * x1;
   in.a2 = t0 * x2;
   in.idx = inwin ? idx + cell_add : -1;
@@ -842,6 +861,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
     yy = Y[i] - S.cy;
     zz = Z[i] - S.cz;
     mass = M[i];
+    if (S.frz && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;     // (:468, :1159: before anything else)
   }
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
   if (plain) {
@@ -859,7 +879,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
   const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
   const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
   const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
-  const double t0 = mass * (-4.0 * M_PI) * P0;
+  const double t0 = mass * S.fac0 * P0;
   const double a1 = t0 * x1, a2 = t0 * x2;
   const size_t wl = (size_t)(S.numr - 1) * S.nrows * 2;
   double *wto = Wd + (size_t)to * wl + (size_t)idx * S.nrows * 2;
@@ -1351,6 +1371,9 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
     if (fac > DSMALL) { ax -= qx; ay -= qy; }
   }
   double pt = potl;
+  // a frozen target particle is skipped by the thread body (src/SphericalBasis.cc:1521): nothing is added, the frame
+  // term neither; the fused half-kick below still applies whatever other forces left in acc
+  if (S.frz && sph_frozen(S, px, py, pz)) { ax = ay = az = 0.0; pt = 0.0; }
   if (!assign) {
     ax += AX[i];
     ay += AY[i];

@@ -262,6 +262,27 @@ class Component:
         check(self.lib.exp_amd_comp_download_levels(self.h, lv.ctypes.data_as(c_void_p)), self.ctx.h)
         return lv
 
+    def set_rtrunc(self, rtrunc: float, com0=None) -> None:
+        """The component's ``rtrunc`` key with the ``com0`` it is measured from (src/Component.cc:69, :213, :1023):
+        ``Component::freeze`` (:4194-4202) -- a particle with |pos - com0 - center| > rtrunc takes no part in any force
+        method's accumulation, level-change differencing or force pass."""
+        c0 = None if com0 is None else as_f64(np.asarray(com0, dtype=np.float64).reshape(3))
+        check(self.lib.exp_amd_comp_set_rtrunc(self.h, float(rtrunc), c0[1] if c0 else None), self.ctx.h)
+        self.rtrunc = float(rtrunc)
+
+    # Component::Adiabatic() (src/Component.cc:4214-4220; keys ton, toff, twid :1040-1055)
+    adiabatic = None
+
+    def set_adiabatic(self, ton: float = -1.0e20, toff: float = 1.0e20, twid: float = 0.1) -> None:
+        self.adiabatic = (float(ton), float(toff), float(twid))
+
+    def Adiabatic(self, tnow: float) -> float:
+        if self.adiabatic is None:
+            return 1.0
+        import math
+        ton, toff, twid = self.adiabatic
+        return 0.25 * (1.0 + math.erf((tnow - ton) / twid)) * (1.0 + math.erf((toff - tnow) / twid))
+
     def set_center(self, center) -> None:
         c = (c_double * 3)(*[float(v) for v in center])
         check(self.lib.exp_amd_comp_set_center(self.h, c), self.ctx.h)
@@ -487,16 +508,48 @@ class _Force:
         self.lastPlayTime, self.expcoefP, self.stop_signal = -np.inf, None, 0
         self._pb_started = False
 
+    _pending_playback = None
+
+    def start_playback(self, dtime: float) -> None:
+        """The ``playback`` / ``coefCompute`` keys taken by ``from_config``, now that the run's time step is known."""
+        if self._pending_playback is None:
+            raise ValueError("start_playback: no playback key was given")
+        path, cc = self._pending_playback
+        self.set_playback(path, dtime, cc)
+        self._pending_playback = None
+
     def _pb_first(self, comp: "Component") -> None:
         pass
 
     def _pb_before_force(self) -> None:
         pass
 
+    def set_mass_scale(self, adb: float) -> None:
+        """``component->Adiabatic()`` as evaluated for the current time: every mass the accumulation and the level-change
+        differencing read is multiplied by it (src/SphericalBasis.cc:441, :471, :1161; src/Cylinder.cc:834, :1758)."""
+        check(self.lib.exp_amd_force_set_mass_scale(self.h, float(adb)), self.ctx.h)
+
+    def set_self_consistent(self, on: bool) -> None:
+        """The ``self_consistent`` key (include/exp_amd.h: exp_amd_force_set_self_consistent)."""
+        check(self.lib.exp_amd_force_set_self_consistent(self.h, int(bool(on))), self.ctx.h)
+
+    def set_initializing(self, on: bool) -> None:
+        """The global ``initializing`` of begin_run (src/begin.cc:80, :129) for hosts that drive the calls themselves."""
+        check(self.lib.exp_amd_force_set_initializing(self.h, int(bool(on))), self.ctx.h)
+
+    @property
+    def coefs_frozen(self) -> bool:
+        return bool(self.lib.exp_amd_force_coefs_frozen(self.h))
+
     def determine_coefficients(self, comp: "Component", tnow: Optional[float] = None) -> None:
         """``determine_coefficients`` (src/SphericalBasis.cc:600-608, src/Cylinder.cc:898-906): from the
         particles, or -- in playback -- from the coefficient series at ``tnow`` (one interpolation
-        per new time, ``:610-680`` / ``:908-946``), plus the particles when ``coefCompute`` is set."""
+        per new time, ``:610-680`` / ``:908-946``), plus the particles when ``coefCompute`` is set.
+        A component with an adiabatic turn-on (``Component.set_adiabatic``) needs ``tnow`` too."""
+        if comp.adiabatic is not None:
+            if tnow is None:
+                raise ValueError("determine_coefficients: the component has ton / toff / twid set: pass tnow")
+            self.set_mass_scale(comp.Adiabatic(tnow))
         if not self.play_back:
             check(self.lib.exp_amd_force_determine_coefficients(self.h, comp.h), self.ctx.h)
             return
@@ -580,7 +633,7 @@ class SphereSL(_Force):
     def __init__(self, ctx: Context, grid: SLGridSph, scale: float = 1.0,
                  rmin: Optional[float] = None, rmax: Optional[float] = None,
                  NO_L0=False, NO_L1=False, EVEN_L=False, EVEN_M=False, M0_only=False,
-                 multistep: int = 0):
+                 multistep: int = 0, self_consistent: bool = True, FIX_L0: bool = False):
         self.ctx, self.lib, self.grid = ctx, ctx.lib, grid
         # Sphere::Sphere: rmin/rmax are taken from the SL grid (src/Sphere.cc:65-67)
         self.rmin = grid.rmin if rmin is None else rmin
@@ -597,6 +650,22 @@ class SphereSL(_Force):
         self.nrows = (grid.lmax + 1) ** 2
         self.multistep = multistep
         ctx._children.append(self)
+        if not self_consistent:
+            self.set_self_consistent(False)
+        if FIX_L0:
+            self.set_fix_l0(True)
+
+    @classmethod
+    def from_config(cls, ctx: Context, grid: SLGridSph, conf: dict, multistep: int = 0) -> "SphereSL":
+        """From the reference's YAML keys (``SphericalBasis::valid_keys``, src/SphericalBasis.cc:30-52): every key is
+        honoured or refused, none dropped (exp_amd/config.py)."""
+        from .config import sphere_from_config
+        return sphere_from_config(cls, ctx, grid, conf, multistep)
+
+    def set_fix_l0(self, on: bool = True) -> None:
+        """``FIX_L0`` (src/SphericalBasis.cc:1689-1694): the l = 0 row is saved at the next force evaluation and copied
+        back into the active set at every later one."""
+        check(self.lib.exp_amd_sph_set_fix_l0(self.h, int(bool(on))), self.ctx.h)
 
     def get_coefs(self, level=None, last=False) -> np.ndarray:
         """(L+1)^2 x nmax, reference real-row order (src/SphericalBasis.cc:513-590)."""
@@ -722,7 +791,7 @@ class Cylinder(_Force):
     """``cylinder`` force method: EmpCylSL empirical orthogonal functions (src/Cylinder.cc)."""
 
     def __init__(self, ctx: Context, grid: EmpCylGrid, rcylmax: Optional[float] = None,
-                 EVEN_M: bool = False, multistep: int = 0):
+                 EVEN_M: bool = False, multistep: int = 0, self_consistent: bool = True, mlim: int = -1):
         self.ctx, self.lib, self.grid = ctx, ctx.lib, grid
         rcylmax = grid.rmax if rcylmax is None else rcylmax
         self.cfg = CylConfig(grid.mmax, grid.norder, grid.numx, grid.numy, grid.cmapr, grid.cmapz,
@@ -734,6 +803,24 @@ class Cylinder(_Force):
         self.h = h
         self.mmax, self.nmax, self.multistep = grid.mmax, grid.norder, multistep
         ctx._children.append(self)
+        if not self_consistent:
+            self.set_self_consistent(False)
+        self.mlim = -1
+        if mlim is not None and mlim >= 0:             # `if (mlim>=0) ortho->set_mlim(mlim)` (src/Cylinder.cc:225)
+            self.set_mlim(mlim)
+
+    @classmethod
+    def from_config(cls, ctx: Context, conf: dict, multistep: int = 0, grid: Optional[EmpCylGrid] = None) -> "Cylinder":
+        """From the reference's YAML keys (``Cylinder::valid_keys``, src/Cylinder.cc:24-80): every key is honoured or
+        refused, none dropped (exp_amd/config.py).  ``grid`` None: the EOF tables are built from the keys."""
+        from .config import cylinder_from_config
+        return cylinder_from_config(cls, ctx, conf, multistep, grid)
+
+    def set_mlim(self, mlim: int) -> None:
+        """The ``mlim`` key (src/Cylinder.cc:225 -> EmpCylSL::set_mlim): harmonics m > mlim take no part in accumulation or
+        evaluation (exputil/EmpCylSL.cc:5602, :5317, :5465); their coefficients read back as zero."""
+        check(self.lib.exp_amd_cyl_set_mlim(self.h, int(mlim)), self.ctx.h)
+        self.mlim = min(int(mlim), self.mmax)
 
     def get_coefs(self, level=None, last=False):
         """(accum_cos, accum_sin), each (mmax+1) x nmax (exputil/EmpCylSL.cc:4355-4550)."""
@@ -884,7 +971,7 @@ def do_step_single(force: _Force, comp: Component, dt: float, tnow: Optional[flo
     comp.incr_velocity(0.5 * dt)
     comp.incr_position(dt)
     force.set_multistep_level(0)
-    if getattr(force, "play_back", False):
+    if getattr(force, "play_back", False) or comp.adiabatic is not None:
         force.determine_coefficients(comp, tnow)
     else:
         force.determine_coefficients(comp)
@@ -915,6 +1002,14 @@ class Simulation:
         check(self.lib.exp_amd_sim_add_component(self.h, comp.h, force.h, byref(idx)), self.ctx.h)
         self._keep.append((comp, force))
         return idx.value
+
+    def set_adiabatic(self, index: int, ton: float = -1.0e20, toff: float = 1.0e20, twid: float = 0.1) -> None:
+        """The ton / toff / twid keys of component ``index``: the driver multiplies the masses its force method reads by
+        Component::Adiabatic() at the driver's time (include/exp_amd.h: exp_amd_sim_set_adiabatic)."""
+        check(self.lib.exp_amd_sim_set_adiabatic(self.h, int(index), float(ton), float(toff), float(twid)), self.ctx.h)
+
+    def set_time(self, tnow: float) -> None:
+        check(self.lib.exp_amd_sim_set_time(self.h, float(tnow)), self.ctx.h)
 
     def set_orient(self, index: int, orient: "Orient", dryrun: bool = False, centerlevl: int = -1) -> None:
         """The EJ keys of a component (src/Component.cc:1323-1370): the expansion centre follows the

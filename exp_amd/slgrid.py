@@ -308,3 +308,40 @@ def build_slgrid(model: SphericalModel, lmax: int, nmax: int, numr: int = 2000,
     return SLGridSph(lmax=lmax, nmax=nmax, numr=numr, cmap=cmap, rmin=rmin, rmax=rmax,
                      rmap=rmap, xmin=xmin, xmax=xmax, dxi=dxi, xi=xi, r=r, p0=p0, d0=d0,
                      ev=np.ascontiguousarray(ev), ef=np.ascontiguousarray(ef))
+
+
+def orthocheck(g: "SLGridSph", num: int = 200):
+    """``SLGridSph::orthoCheck`` (exputil/SLGridMP2.cc:1775-1824) on the host tables: one nmax x nmax matrix per l,
+    the identity for a biorthonormal basis."""
+    from numpy.polynomial import legendre as npleg
+    x, w = npleg.leggauss(num)
+    knots, weights = 0.5 * (x + 1.0), 0.5 * w
+    ximin, ximax = float(g.r_to_xi(g.rmin)), float(g.r_to_xi(g.rmax))
+    xs = ximin + (ximax - ximin) * knots
+    if g.cmap == 1:
+        xs = np.clip(xs, -1.0, 1.0 - 1e-8)
+    r = g.xi_to_r(xs)
+    idx = np.clip(((xs - g.xmin) / g.dxi).astype(np.int64), 0, g.numr - 2)
+    x1 = (g.xi[idx + 1] - xs) / g.dxi
+    x2 = (xs - g.xi[idx]) / g.dxi
+    if g.cmap == 1:
+        dxr = 0.5 * (1.0 - xs) ** 2 / g.rmap
+    elif g.cmap == 2:
+        dxr = np.exp(-xs)
+    else:
+        dxr = np.ones_like(xs)
+    P0 = x1 * g.p0[idx] + x2 * g.p0[idx + 1]
+    D0 = x1 * g.d0[idx] + x2 * g.d0[idx + 1]
+    out = []
+    for L in range(g.lmax + 1):
+        u = x1 * g.ef[L][:, idx] + x2 * g.ef[L][:, idx + 1]        # [nmax, num]
+        pot = u / np.sqrt(g.ev[L])[:, None] * P0
+        den = u * np.sqrt(g.ev[L])[:, None] * D0
+        wgt = r * r / dxr * (ximax - ximin) * weights
+        out.append(-(pot * wgt) @ den.T)
+    return out
+
+
+def orthocheck_max(g: "SLGridSph", num: int = 200) -> float:
+    """worst deviation from the identity (what exputil/orthoTest.cc:19-87 holds against orthoTol = 1e-2)"""
+    return float(max(np.abs(m - np.eye(g.nmax)).max() for m in orthocheck(g, num)))

@@ -201,6 +201,14 @@ int  exp_amd_comp_get_center(const exp_amd_comp *c, double center[3]);
  * transpose, transformOrig: src/Cylinder.cc:799-800, :1352-1353, :1417-1418).  NULL = none.
  * The spherical method ignores it, as Sphere does.                                            */
 int  exp_amd_comp_set_orientation(exp_amd_comp *c, const double body[9]);
+/* Component::rtrunc with the com0 it is measured from (the "rtrunc" key of a component, src/Component.cc:69, :213,
+ * :1023): Component::freeze(i) (:4194-4202) is |pos - com0 - center|^2 > rtrunc^2 with `center` the one of
+ * exp_amd_comp_set_center.  A frozen particle takes no part in ANY force method's accumulation, level-change differencing
+ * or force pass (src/SphericalBasis.cc:468, :1159, :1521; src/Cylinder.cc:788, :842, :1329, :1756): nothing is added to its
+ * acc / pot -- not even the frame's pseudo-acceleration -- while kicks and drifts still move it.  The test is made
+ * with the positions of the moment of each call, in the reference's operation order.  com0 NULL = zeros; rtrunc >= 1e20
+ * (the reference's default) switches the test off.                                                                  */
+int  exp_amd_comp_set_rtrunc(exp_amd_comp *c, double rtrunc, const double com0[3]);
 /* Acceleration of the component's non-inertial frame, subtracted by every force applied to its
  * particles (Component::AddAcc -> getPseudoAccel, src/Component.H:914-921, src/Component.cc:4407-4427):
  * accel (the EJ centre's acceleration; NULL: none) plus, when omega and domdt are both given, the
@@ -304,6 +312,9 @@ void exp_amd_force_destroy(exp_amd_force *f);
  * force (src/SphericalBasis.cc:1555-1560, :1605-1628); 0: tables evaluated at r/scale as in
  * pyEXP's Spherical::computeAccel (expui/BiorthBasis.cc:818-926).                          */
 int  exp_amd_sph_set_exterior(exp_amd_force *f, int continuation);
+/* FIX_L0 (src/SphericalBasis.cc:34, :119, :1689-1694): with on != 0 the next force evaluation saves the l = 0 row of the
+ * coefficient set (nmax values) and every later one -- self or external -- copies it back into the active set first.  */
+int  exp_amd_sph_set_fix_l0(exp_amd_force *f, int on);
 /* M0_only in the accumulation: the n-body code skips the m > 0 sums altogether (src/SphericalBasis.cc:550), pyEXP's
  * Spherical::accumulate applies no flag at all (expui/BiorthBasis.cc:583-665: the coefficients it returns hold every m;
  * only the evaluation drops them, :851).  all_m = 1 selects the latter; the default is the former.                */
@@ -343,6 +354,23 @@ int  exp_amd_force_used(exp_amd_force *f, long long *used);
  * component evaluated in this force's centred frame.                                */
 int  exp_amd_force_get_acceleration(exp_amd_force *f, exp_amd_comp *target, int external);
 
+/* Component::Adiabatic() (src/Component.cc:4214-4220: 0.25 (1 + erf((tnow - ton)/twid)) (1 + erf((toff - tnow)/twid)), the
+ * keys ton / toff / twid of the component the basis belongs to) as the host has evaluated it for the current time: every
+ * mass read by the accumulation and by the level-change differencing is multiplied by it (src/SphericalBasis.cc:441,
+ * :471, :1161; src/Cylinder.cc:834, :1758 -- the cylinder's in-cut mass tally included, :864).  1 by default.  The step
+ * driver does this itself for components given to exp_amd_sim_set_adiabatic.                                        */
+int  exp_amd_force_set_mass_scale(exp_amd_force *f, double adiabatic);
+/* The "self_consistent" key (src/SphericalBasis.cc:33, :114-117; src/Cylinder.cc:76, :557-558).  With on = 0 the
+ * coefficients are held fixed once the FIRST determine_coefficients call has completed and the host is not
+ * `initializing` (the global of src/begin.cc:80-129, mirrored by exp_amd_force_set_initializing; exp_amd_sim_init sets
+ * it around its own work): exp_amd_force_determine_coefficients returns at once (src/SphericalBasis.cc:694,
+ * src/Cylinder.cc:959), exp_amd_force_compute_multistep_coefficients leaves the combined set alone (:1682, :1469), the
+ * level changes are not differenced (src/Cylinder.cc:1755), exp_amd_step_kdk and the step driver only advance the
+ * particles and evaluate the force of the set as it is.  exp_amd_force_coefs_frozen tells whether that point is reached. */
+int  exp_amd_force_set_self_consistent(exp_amd_force *f, int on);
+int  exp_amd_force_set_initializing(exp_amd_force *f, int on);
+int  exp_amd_force_coefs_frozen(const exp_amd_force *f);
+
 /* Multistep coefficient bookkeeping (src/SphericalBasis.cc:1231-1333, :1013-1079).  */
 int  exp_amd_force_multistep_reset(exp_amd_force *f);
 int  exp_amd_force_compute_multistep_coefficients(exp_amd_force *f, int mdrft);
@@ -380,6 +408,13 @@ typedef struct {
  * (EXP_AMD_CYL_GENERIC=1: at any order).                                                            */
 int  exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
                         exp_amd_force **out);
+/* The "mlim" key (src/Cylinder.cc:40, :225 -> EmpCylSL::set_mlim; pyEXP: expui/BiorthBasis.cc:1466, :1620): harmonics
+ * m > mlim take no part -- EmpCylSL::get_pot fills Vc / Vs up to min(MLIM, MMAX) (exputil/EmpCylSL.cc:5602), so nothing
+ * is accumulated there, and accumulated_eval / accumulated_dens_eval sum up to it (:5317, :5465).  The coefficients of
+ * m > mlim read back as zero (the reference leaves them unspecified: rows of Vc it never fills, :4078).  mlim >= mmax
+ * changes nothing; mlim < 0 is EXP_AMD_ERR_ARG (the key's default -1 means "do not call"); once set it can only be
+ * lowered (EXP_AMD_ERR_STATE otherwise: the tables above it are gone from the device).                              */
+int  exp_amd_cyl_set_mlim(exp_amd_force *f, int mlim);
 /* Mass of the particles inside the accumulation cut at the last accumulation (Cylinder's
  * cylmass, src/Cylinder.cc:1081-1098), used for the off-grid monopole blend (:1364-1414);
  * set_cylmass overrides it (playback / external coefficient sets).                       */
@@ -492,6 +527,12 @@ int  exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dr
 /* The global `restart` (src/global.cc): the estimators take in the state of the first force
  * evaluation too, where a fresh run waits for potentials (src/ComponentContainer.cc:1386).   */
 int  exp_amd_sim_set_restart(exp_amd_sim *s, int on);
+/* The adiabatic turn-on / turn-off of component `index` (its keys ton, toff, twid; src/Component.cc:1040-1055): the driver
+ * evaluates Component::Adiabatic() at its tnow before every accumulation (the time at the START of the sub-step, as
+ * do_step has it, src/step.cc:126-160) and before every level-change differencing (the time at its end) and hands it to
+ * the component's force method (exp_amd_force_set_mass_scale).  exp_amd_sim_set_time sets tnow (a restart).          */
+int  exp_amd_sim_set_adiabatic(exp_amd_sim *s, int index, double ton, double toff, double twid);
+int  exp_amd_sim_set_time(exp_amd_sim *s, double tnow);
 int  exp_amd_sim_init(exp_amd_sim *s);
 int  exp_amd_sim_step(exp_amd_sim *s, int nsteps);
 double exp_amd_sim_time(const exp_amd_sim *s);

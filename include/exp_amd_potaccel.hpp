@@ -61,6 +61,12 @@ struct ComponentView {
                        const double *pot, const std::int32_t *level) = 0;
   // Component::center (Local | Centered positions subtract it, src/Component.H:748-757)
   virtual void center(double c[3]) const { c[0] = c[1] = c[2] = 0.0; }
+  // Component::rtrunc and com0 (src/Component.cc:213, :4194-4202): beyond rtrunc of com0 + center a particle is frozen
+  // -- no force method accumulates it, differences it or accelerates it.  1e20 (the reference's default): never
+  virtual double rtrunc() const { return 1.0e20; }
+  virtual void com0(double c[3]) const { c[0] = c[1] = c[2] = 0.0; }
+  // double Component::Adiabatic() (src/Component.cc:4214-4220) at the caller's current tnow; 1 without ton / toff
+  virtual double Adiabatic() const { return 1.0; }
 };
 
 // One GPU / one stream / one rank, as in EXP (src/Component.H:1054-1079).
@@ -80,6 +86,12 @@ public:
   static void unique_id(void *id128) { check(exp_amd_comm_get_unique_id(id128), nullptr); }
   void init_comm(const void *id128, int nranks, int rank) { check(exp_amd_comm_init_rank(h_, id128, nranks, rank), h_); }
   void set_allreduce(exp_amd_allreduce_fn fn, void *user) { check(exp_amd_comm_set_callback(h_, fn, user), h_); }
+  // ... with numprocs / myid of the communicator the callback reduces over
+  void set_allreduce(exp_amd_allreduce_fn fn, void *user, int nranks, int rank)
+  {
+    check(exp_amd_comm_set_world(h_, nranks, rank), h_);
+    check(exp_amd_comm_set_callback(h_, fn, user), h_);
+  }
 };
 
 // Device stores of the Components a force method has met: ParticlesToCuda on first use,
@@ -131,6 +143,11 @@ public:
     double ctr[3];
     c->center(ctr);
     check(exp_amd_comp_set_center(d, ctr), ctx_.get());
+    if (c->rtrunc() < 1.0e20) {                       // Component::freeze (src/Component.cc:4194-4202)
+      double c0[3];
+      c->com0(c0);
+      check(exp_amd_comp_set_rtrunc(d, c->rtrunc(), c0), ctx_.get());
+    }
     return d;
   }
 
@@ -192,8 +209,17 @@ public:
   void determine_coefficients(ComponentView *c) { cC_ = c; determine_coefficients(); }   // :179-180
   void determine_coefficients()                                                     // :178
   {
+    // `double adb = component->Adiabatic();` (src/SphericalBasis.cc:441, src/Cylinder.cc:834): the OWNER's, at this tnow
+    check(exp_amd_force_set_mass_scale(force_, component_->Adiabatic()), ctx_.get());
+    // (with "self_consistent: false" the library returns at once after the first completed call unless `initializing`,
+    // src/SphericalBasis.cc:694, src/Cylinder.cc:959)
     check(exp_amd_force_determine_coefficients(force_, mirror_.dev(cC_)), ctx_.get());
   }
+  // the "self_consistent" key (src/SphericalBasis.cc:114-117, src/Cylinder.cc:557-558) and EXP's global `initializing`
+  // (src/begin.cc:80, :129), which begin_run sets around its expansions
+  void set_self_consistent(bool on) { check(exp_amd_force_set_self_consistent(force_, on ? 1 : 0), ctx_.get()); }
+  void set_initializing(bool on) { check(exp_amd_force_set_initializing(force_, on ? 1 : 0), ctx_.get()); }
+  bool coefs_frozen() const { return exp_amd_force_coefs_frozen(force_) != 0; }
   // src/SphericalBasis.cc:381, :1663-1777 / src/Cylinder.cc:1448-1500: the self call recombines the
   // per-level coefficient sets first (use_external == false branch)
   void get_acceleration_and_potential(ComponentView *c)                             // :173
@@ -215,6 +241,8 @@ public:
                                     int mdrft, bool first_step)
   {
     long long nswitch = 0;
+    // `double mass = c->Mass(i) * component->Adiabatic();` (src/SphericalBasis.cc:1161, src/Cylinder.cc:1758)
+    check(exp_amd_force_set_mass_scale(force_, component_->Adiabatic()), ctx_.get());
     check(exp_amd_force_adjust_multistep_level(force_, mirror_.dev(c), dtime, dynfrac, shiftlevl, mdrft,
                                                first_step ? 1 : 0, &nswitch), ctx_.get());
     return nswitch;
@@ -285,6 +313,9 @@ public:
         out.write(reinterpret_cast<const char *>(&c[(std::size_t)row * nmax_ + ir]), sizeof(double));
   }
 
+  // FIX_L0 (src/SphericalBasis.cc:119, :1689-1694)
+  void set_fix_l0(bool on) { check(exp_amd_sph_set_fix_l0(force_, on ? 1 : 0), ctx_.get()); }
+
 private:
   int lmax_ = 0, nmax_ = 0;
   double scale_ = 1.0;
@@ -317,6 +348,8 @@ private:
   int mmax_ = 0, nmax_ = 0;
 
 public:
+  // the "mlim" key: `if (mlim>=0) ortho->set_mlim(mlim);` (src/Cylinder.cc:225)
+  void set_mlim(int mlim) { if (mlim >= 0) check(exp_amd_cyl_set_mlim(force_, mlim), ctx_.get()); }
   double cylmass()
   {
     double m = 0.0;

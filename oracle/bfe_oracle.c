@@ -242,6 +242,35 @@ void orc_sl_orthocheck(const orc_slgrid *g, int num, const double *knots,
   }
 }
 
+/* ---- per-call options (bfe_oracle.h) ---- */
+static _Thread_local orc_call_opts g_opts = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1};
+void orc_set_call_opts(const orc_call_opts *o)
+{
+  if (o) g_opts = *o;
+  else { orc_call_opts d = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1}; g_opts = d; }
+}
+double orc_opt_adb(void) { return g_opts.adb; }
+int orc_opt_mlim(int mmax) { return (g_opts.mlim >= 0 && g_opts.mlim < mmax) ? g_opts.mlim : mmax; }
+/* bool Component::freeze(unsigned indx) (src/Component.cc:4194-4202) */
+int orc_opt_frozen(double x, double y, double z)
+{
+  if (!g_opts.frz) return 0;
+  const double pos[3] = {x, y, z};
+  double r2 = 0.0;
+  for (int i = 0; i < 3; i++) r2 +=
+                                (pos[i] - g_opts.com0[i] - g_opts.fcenter[i]) *
+                                (pos[i] - g_opts.com0[i] - g_opts.fcenter[i]);
+  if (r2 > g_opts.rtrunc * g_opts.rtrunc) return 1;
+  else return 0;
+}
+/* double Component::Adiabatic() (src/Component.cc:4214-4220), `adiabatic` true */
+double orc_adiabatic(double tnow, double ton, double toff, double twid)
+{
+  return 0.25 *
+    ( 1.0 + erf((tnow - ton )/twid) ) *
+    ( 1.0 + erf((toff - tnow)/twid) ) ;
+}
+
 /* Kahan-compensated add used only in arbiter mode */
 static inline void kadd(double *s, double *c, double v)
 {
@@ -252,7 +281,7 @@ static inline void kadd(double *s, double *c, double v)
 }
 
 /* src/SphericalBasis.cc:429-599 (determine_coefficients_thread, one thread, one
- * level, pcavar/pcaeof/subset/mix off, sqnorm == 1 for Sphere, adb == 1)        */
+ * level, pcavar/pcaeof/subset/mix off, sqnorm == 1 for Sphere; adb and freeze: orc_set_call_opts) */
 long orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodies,
                         const double *X, const double *Y, const double *Z,
                         const double *M, const double *center, double *coef, int kahan)
@@ -279,8 +308,10 @@ long orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodi
     else coef[(row) * nmax + (n)] += (v);                            \
   } while (0)
 
+  const double adb = orc_opt_adb();                                   /* :441 */
   for (long i = 0; i < nbodies; i++) {
-    double mass = M[i];
+    if (orc_opt_frozen(X[i], Y[i], Z[i])) continue;                   /* :468 */
+    double mass = M[i] * adb;                                         /* :471 */
     double xx = X[i] - center[0];
     double yy = Y[i] - center[1];
     double zz = Z[i] - center[2];
@@ -374,6 +405,7 @@ static void sph_accel_addacc(const orc_slgrid *g, const orc_sph_params *P, long 
     double r0 = 0.0, pp, dpp, pc, dpc, ps, dps, facp, facdp;
     double potr, potl, pott, potp;
 
+    if (orc_opt_frozen(X[i], Y[i], Z[i])) continue;                   /* :1521 (cC->freeze: the TARGET component's) */
     double xx = X[i] - center[0];
     double yy = Y[i] - center[1];
     double zz = Z[i] - center[2];

@@ -46,6 +46,29 @@ typedef struct {
                                 (expui/BiorthBasis.cc:761, :876); N2 < 0 means no upper limit    */
 } orc_sph_params;
 
+/* ---- options of the n-body thread bodies that default to "off" (the reference's Component / Basis keys rtrunc, ton /
+ * toff / twid, mlim).  They are per-CALL state of the calling thread: set before a call of an accumulate / accel /
+ * multistep_update function of this library, cleared (NULL) after it.
+ *   adb      Component::Adiabatic() of the basis' component (src/Component.cc:4214-4220): `mass = Mass(indx) * adb`
+ *            (src/SphericalBasis.cc:441, :471, :1161; src/Cylinder.cc:834, :1758)
+ *   frz      Component::freeze(indx) (src/Component.cc:4194-4202) of the component whose particles the call walks:
+ *            sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2  ->  `continue` (src/SphericalBasis.cc:468, :1521;
+ *            src/Cylinder.cc:842, :1329) / `return` (src/SphericalBasis.cc:1159, src/Cylinder.cc:1756)
+ *   mlim     EmpCylSL::MLIM (set_mlim, include/EmpCylSL.H:567): get_pot, accumulated_eval and accumulated_dens_eval
+ *            loop to min(MLIM, MMAX) (exputil/EmpCylSL.cc:5602, :5317, :5465); < 0: no limit                      */
+typedef struct {
+  double adb;
+  int    frz;
+  double rtrunc, com0[3], fcenter[3];
+  int    mlim;
+} orc_call_opts;
+void   orc_set_call_opts(const orc_call_opts *o);      /* NULL: the defaults (adb 1, no freeze, no mlim) */
+double orc_opt_adb(void);
+int    orc_opt_mlim(int mmax);                         /* min(MLIM, MMAX) */
+int    orc_opt_frozen(double x, double y, double z);   /* Component::freeze of the position (component coordinates) */
+/* Component::Adiabatic() (src/Component.cc:4214-4220) */
+double orc_adiabatic(double tnow, double ton, double toff, double twid);
+
 void   orc_legendre_R (int lmax, double x, double *p);               /* p[(lmax+1)*(lmax+1)], p[l*(lmax+1)+m] */
 void   orc_dlegendre_R(int lmax, double x, double *p, double *dp);
 void   orc_sinecosine_R(int mmax, double phi, double *c, double *s);

@@ -7,6 +7,7 @@
  * here as tab[kind][m][n][ix][iy] with kind 0..5 = potC, rforceC, zforceC, potS, rforceS, zforceS.
  */
 #include "cyl_oracle.h"
+#include "bfe_oracle.h"      /* the per-call options (orc_opt_*) */
 
 #include <float.h>
 #include <math.h>
@@ -71,7 +72,7 @@ void orc_cyl_get_pot(const orc_cylgrid *g, double r, double z, double *Vc, doubl
   double c[4];
   cyl_weights(g, r, z, &ix, &iy, c);
   const double fac = 1.0;
-  for (int mm = 0; mm <= g->mmax; mm++) {
+  for (int mm = 0; mm <= orc_opt_mlim(g->mmax); mm++) {             /* :5602: min(MLIM, MMAX) */
     if (g->EVEN_M && (mm / 2) * 2 != mm) continue;
     for (int n = 0; n < g->norder; n++) {
       Vc[mm * g->norder + n] = fac * INTERP(0, mm, n);
@@ -98,7 +99,9 @@ long orc_cyl_accumulate(const orc_cylgrid *g, long nbodies, const double *X, con
   double mass0 = 0.0;
   const double norm = -4.0 * M_PI;
 
+  const double adb = orc_opt_adb();                                   /* src/Cylinder.cc:834 */
   for (long i = 0; i < nbodies; i++) {
+    if (orc_opt_frozen(X[i], Y[i], Z[i])) continue;                   /* :842 */
     double xx = X[i] - center[0];
     double yy = Y[i] - center[1];
     double zz = Z[i] - center[2];
@@ -106,7 +109,7 @@ long orc_cyl_accumulate(const orc_cylgrid *g, long nbodies, const double *X, con
     double r = sqrt(r2);
     double R2 = r2 + zz * zz;
     if (R2 < Rmax2) {
-      double mas = M[i];
+      double mas = M[i] * adb;
       double phi = atan2(yy, xx);
       /* EmpCylSL::accumulate */
       double rr = sqrt(r * r + zz * zz);
@@ -135,7 +138,7 @@ long orc_cyl_accumulate(const orc_cylgrid *g, long nbodies, const double *X, con
   return use;
 }
 
-/* exputil/EmpCylSL.cc:5256-5410 (MMIN=0, MLIM=inf, NMIN=0, NLIM=inf) */
+/* exputil/EmpCylSL.cc:5256-5410 (MMIN=0, NMIN=0, NLIM=inf; MLIM: orc_set_call_opts) */
 void orc_cyl_accumulated_eval(const orc_cylgrid *g, const double *accum_cos,
                               const double *accum_sin, double r, double z, double phi,
                               double *p0, double *p, double *fr, double *fz, double *fp)
@@ -152,7 +155,7 @@ void orc_cyl_accumulated_eval(const orc_cylgrid *g, const double *accum_cos,
   cyl_weights(g, r, z, &ix, &iy, c);
 
   double ccos, ssin = 0.0, fac;
-  for (int mm = 0; mm <= g->mmax; mm++) {
+  for (int mm = 0; mm <= orc_opt_mlim(g->mmax); mm++) {             /* :5317 */
     if (g->EVEN_M && (mm / 2) * 2 != mm) continue;
     ccos = cos(phi * mm);
     ssin = sin(phi * mm);
@@ -192,6 +195,7 @@ void orc_cyl_accel(const orc_cylgrid *g, long nbodies, const double *X, const do
   const double mfactor = 1.0;
 
   for (long i = 0; i < nbodies; i++) {
+    if (orc_opt_frozen(X[i], Y[i], Z[i])) continue;                   /* src/Cylinder.cc:1329 (cC->freeze: the TARGET's) */
     double xx = X[i] - center[0];
     double yy = Y[i] - center[1];
     double zz = Z[i] - center[2];
@@ -261,7 +265,7 @@ double orc_cyl_accumulated_dens_eval(const orc_cylgrid *g, const double *dens,
 #define DINTERP(cs, m, n)                                                           \
   (DTAB(cs, m, n, ix, iy) * c[0] + DTAB(cs, m, n, ix + 1, iy) * c[1] +              \
    DTAB(cs, m, n, ix, iy + 1) * c[2] + DTAB(cs, m, n, ix + 1, iy + 1) * c[3])
-  for (int mm = 0; mm <= g->mmax; mm++) {
+  for (int mm = 0; mm <= orc_opt_mlim(g->mmax); mm++) {             /* :5465 */
     double ccos = cos(phi * mm);
     double ssin = sin(phi * mm);
     for (int n = 0; n < g->norder; n++) {

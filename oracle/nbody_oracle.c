@@ -46,6 +46,27 @@ int orc_cyl_multistep_update(const orc_cylgrid *g, double xx, double yy, double 
 
 /* ---- helpers ------------------------------------------------------------------------------------- */
 
+/* the per-call options (bfe_oracle.h) of a call that walks the particles of `walked` with the force method of `basis`:
+ * adb = basis' component->Adiabatic() at tnow, freeze = walked->freeze(), mlim = the basis' */
+static void call_opts(const orc_nbody *S, const orc_nbody_comp *basis, const orc_nbody_comp *walked)
+{
+  orc_call_opts o = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1};
+  if (basis->adiabatic) o.adb = orc_adiabatic(S->tnow, basis->ton, basis->toff, basis->twid);
+  if (walked->has_rtrunc) {
+    o.frz = 1;
+    o.rtrunc = walked->rtrunc;
+    for (int k = 0; k < 3; k++) { o.com0[k] = walked->com0[k]; o.fcenter[k] = walked->center[k]; }
+  }
+  if (basis->has_mlim) o.mlim = basis->mlim;
+  orc_set_call_opts(&o);
+}
+
+/* `if (!self_consistent && !firstime_coef && !initializing) return;` (src/SphericalBasis.cc:694, src/Cylinder.cc:959) */
+static int coefs_fixed(const orc_nbody *S, const orc_nbody_comp *c)
+{
+  return c->not_self_consistent && c->coef_calls > 0 && !S->initializing;
+}
+
 typedef struct {
   double *tx, *ty, *tz, *tm;     /* gathered level lists */
   double *val, *differ, *vc, *vs;
@@ -105,8 +126,10 @@ static void compute_expansion(orc_nbody *S, int M, nb_work *w)
 {
   for (int k = 0; k < S->ncomp; k++) {
     orc_nbody_comp *c = &S->comp[k];
+    if (coefs_fixed(S, c)) continue;              /* (the return precedes the N/L swap) */
     double *N = c->coefN + (size_t)M * c->ncoef, *L = c->coefL + (size_t)M * c->ncoef;
     memcpy(L, N, sizeof(double) * c->ncoef);      /* after the swap, L holds the old N */
+    call_opts(S, c, c);
     long cnt = 0;
     for (long i = 0; i < c->n; i++)
       if (c->level[i] == M) {
@@ -129,12 +152,17 @@ static void compute_expansion(orc_nbody *S, int M, nb_work *w)
       if (S->multistep == 0) { c->used = use; c->cylmass = cm; }
       else if (S->tnow == c->resetT) { c->used += use; c->cylmass += cm; }
     }
+    orc_set_call_opts(NULL);
+    c->coef_calls++;                              /* firstime_coef = false (:1001, :1198) */
   }
 }
 
 /* compute_multistep_coefficients (src/SphericalBasis.cc:1231-1333; src/CylEXP.cc:192-282) */
 static void combine(const orc_nbody *S, const orc_mstep_tables *T, orc_nbody_comp *c, int mdrft)
 {
+  /* `if (multistep && (self_consistent || initializing)) compute_multistep_coefficients();`
+   * (src/SphericalBasis.cc:1682, src/Cylinder.cc:1469); with multistep = 0 the set that is not re-made is the one copied */
+  if (S->multistep && c->not_self_consistent && !S->initializing) return;
   if (S->multistep == 0) {
     memcpy(c->coef, c->coefN, sizeof(double) * c->ncoef);
     return;
@@ -143,8 +171,14 @@ static void combine(const orc_nbody *S, const orc_mstep_tables *T, orc_nbody_com
 }
 
 /* one force method applied to the particles of `t` with level >= mlevel */
-static void apply_force(const orc_nbody_comp *src, orc_nbody_comp *t, int mlevel)
+static void apply_force(const orc_nbody *S, orc_nbody_comp *src, orc_nbody_comp *t, int mlevel)
 {
+  if (src->kind == 0 && src->fix_l0) {            /* src/SphericalBasis.cc:1689-1694 (self and external calls alike) */
+    const int nmax = src->sg->nmax;
+    if (!src->have_c0) { memcpy(src->C0, src->coef, sizeof(double) * nmax); src->have_c0 = 1; }
+    else memcpy(src->coef, src->C0, sizeof(double) * nmax);
+  }
+  call_opts(S, src, t);
   for (long i = 0; i < t->n; i++) {
     if (t->level[i] < mlevel) continue;
     if (src->kind == 0)
@@ -156,6 +190,7 @@ static void apply_force(const orc_nbody_comp *src, orc_nbody_comp *t, int mlevel
                     src->coef + half, src->cylmass, t->ax + i, t->ay + i, t->az + i, t->pot + i);
     }
   }
+  orc_set_call_opts(NULL);
 }
 
 /* ComponentContainer::compute_potential(mlevel) (src/ComponentContainer.cc:580-917): per component
@@ -171,10 +206,10 @@ static void compute_potential(orc_nbody *S, const orc_mstep_tables *T, int mleve
     for (long i = 0; i < c->n; i++)
       if (c->level[i] >= mlevel) c->ax[i] = c->ay[i] = c->az[i] = c->pot[i] = 0.0;
     combine(S, T, c, mdrft);
-    apply_force(c, c, mlevel);
+    apply_force(S, c, c, mlevel);
   }
   for (int q = 0; q < S->ninter; q++)
-    apply_force(&S->comp[S->inter[2 * q]], &S->comp[S->inter[2 * q + 1]], mlevel);
+    apply_force(S, &S->comp[S->inter[2 * q]], &S->comp[S->inter[2 * q + 1]], mlevel);
 }
 
 /* adjust_multistep_level (src/multistep.cc:344-627): multistep_update_begin for every component,
@@ -203,8 +238,15 @@ static void adjust_levels(orc_nbody *S, const orc_mstep_tables *T, int mdrft, in
         if (nlev == lev) continue;
         double xx = c->x[i] - c->center[0], yy = c->y[i] - c->center[1], zz = c->z[i] - c->center[2];
         int inside;
-        if (c->kind == 0) inside = orc_sph_multistep_update(c->sg, c->sp, xx, yy, zz, c->mass[i], w->val);
-        else              inside = orc_cyl_multistep_update(c->cg, xx, yy, zz, c->mass[i], w->val, w->vc, w->vs);
+        /* `if (c->freeze(i)) return; double mass = c->Mass(i) * component->Adiabatic();` (src/SphericalBasis.cc:
+         * 1159-1161, src/Cylinder.cc:1756-1758); the cylinder alone tests self_consistent first (:1755) */
+        call_opts(S, c, c);
+        const double mas = c->mass[i] * orc_opt_adb();
+        if (orc_opt_frozen(c->x[i], c->y[i], c->z[i])) inside = 0;
+        else if (c->kind == 0) inside = orc_sph_multistep_update(c->sg, c->sp, xx, yy, zz, mas, w->val);
+        else if (c->not_self_consistent) inside = 0;
+        else              inside = orc_cyl_multistep_update(c->cg, xx, yy, zz, mas, w->val, w->vc, w->vs);
+        orc_set_call_opts(NULL);
         if (inside)
           for (long q = 0; q < nc; q++) {
             /* differ[from] -= val; differ[to] += val; only M >= mfirst[mdrft] is cleared by
@@ -234,10 +276,12 @@ void orc_nbody_init_pass0(orc_nbody *S)
   nb_work w;
   work_alloc(&w, S);
   S->this_step = 0;
+  S->initializing = 1;
   multistep_reset(S);
   for (int M = 0; M <= ms; M++) compute_expansion(S, M, &w);
   compute_potential(S, T, 0, 0);
   adjust_levels(S, T, 0, 1, &w, NULL);
+  S->initializing = 0;
   work_free(&w);
   orc_mstep_free(T);
 }
@@ -249,6 +293,7 @@ void orc_nbody_init(orc_nbody *S)
   nb_work w;
   work_alloc(&w, S);
   S->this_step = 0;
+  S->initializing = 1;                                        /* src/begin.cc:80 */
   if (ms) {
     multistep_reset(S);
     for (int M = 0; M <= ms; M++) compute_expansion(S, M, &w);
@@ -258,6 +303,7 @@ void orc_nbody_init(orc_nbody *S)
   if (ms) multistep_reset(S);
   for (int M = 0; M <= ms; M++) compute_expansion(S, M, &w);
   compute_potential(S, T, 0, 0);
+  S->initializing = 0;                                        /* :129 */
   work_free(&w);
   orc_mstep_free(T);
 }

@@ -36,6 +36,17 @@ typedef struct {
   double cylmass;             /* Cylinder::cylmass                                               */
   long used;                  /* PotAccel::used                                                  */
   double resetT;              /* Cylinder::resetT                                                */
+  /* ---- keys that default to "off" (all zero = the defaults) ------------------------------------ */
+  int has_rtrunc;             /* Component::rtrunc set (src/Component.cc:1023); freeze(): :4194-4202 */
+  double rtrunc, com0[3];
+  int adiabatic;              /* ton / toff / twid given (src/Component.cc:1040-1055): Adiabatic() :4214-4220 */
+  double ton, toff, twid;
+  int not_self_consistent;    /* "self_consistent: false" (src/SphericalBasis.cc:114-117, src/Cylinder.cc:557) */
+  int coef_calls;             /* !firstime_coef once > 0 (src/SphericalBasis.cc:1001, src/Cylinder.cc:1198) */
+  int fix_l0, have_c0;        /* FIX_L0 (src/SphericalBasis.cc:1689-1694); C0 = the saved l = 0 row [nmax]    */
+  double *C0;
+  int mlim;                   /* the cylinder's "mlim" key when has_mlim (src/Cylinder.cc:225)                */
+  int has_mlim;
 } orc_nbody_comp;
 
 typedef struct {
@@ -49,6 +60,7 @@ typedef struct {
   int shiftlevl;
   long this_step;
   double tnow;
+  int initializing;           /* the global of src/begin.cc:80, :129 (set by orc_nbody_init itself)  */
 } orc_nbody;
 
 /* begin_run's initial expansion, potential and level assignment (src/begin.cc:80-129) */

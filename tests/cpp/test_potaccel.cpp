@@ -14,64 +14,7 @@
 
 #include "exp_amd_potaccel.hpp"
 
-using exp_amd::ComponentView;
-
-// a Component reduced to what the adaptor asks of it
-struct VecComponent : ComponentView {
-  std::vector<double> m, x, y, z, vx, vy, vz, ax, ay, az, pot;
-  std::vector<std::int32_t> level;
-  explicit VecComponent(std::size_t n)
-      : m(n), x(n), y(n), z(n), vx(n), vy(n), vz(n), ax(n, 0.0), ay(n, 0.0), az(n, 0.0), pot(n, 0.0), level(n, 0) {}
-  std::size_t Number() const override { return m.size(); }
-  void gather(double *M, double *X, double *Y, double *Z, double *VX, double *VY, double *VZ, double *AX,
-              double *AY, double *AZ, double *POT, std::int32_t *LEV) const override
-  {
-    auto cp = [&](double *dst, const std::vector<double> &src) { if (dst) std::memcpy(dst, src.data(), src.size() * sizeof(double)); };
-    cp(M, m); cp(X, x); cp(Y, y); cp(Z, z); cp(VX, vx); cp(VY, vy); cp(VZ, vz); cp(AX, ax); cp(AY, ay); cp(AZ, az); cp(POT, pot);
-    if (LEV) std::memcpy(LEV, level.data(), level.size() * sizeof(std::int32_t));
-  }
-  void scatter(const double *X, const double *Y, const double *Z, const double *VX, const double *VY,
-               const double *VZ, const double *AX, const double *AY, const double *AZ, const double *POT,
-               const std::int32_t *LEV) override
-  {
-    auto cp = [&](std::vector<double> &dst, const double *src) { if (src) std::memcpy(dst.data(), src, dst.size() * sizeof(double)); };
-    cp(x, X); cp(y, Y); cp(z, Z); cp(vx, VX); cp(vy, VY); cp(vz, VZ); cp(ax, AX); cp(ay, AY); cp(az, AZ); cp(pot, POT);
-    if (LEV) std::memcpy(level.data(), LEV, level.size() * sizeof(std::int32_t));
-  }
-};
-
-static std::vector<double> rd(std::ifstream &f, std::size_t n)
-{
-  std::vector<double> v(n);
-  f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * sizeof(double)));
-  return v;
-}
-
-static int failures = 0;
-static void expect(const char *what, double err, double tol)
-{
-  const bool ok = err <= tol;
-  std::printf("%-44s err %.3e  tol %.1e  %s\n", what, err, tol, ok ? "ok" : "FAIL");
-  if (!ok) failures++;
-}
-static double maxabs(const std::vector<double> &a) { double s = 0; for (double v : a) s = std::fmax(s, std::fabs(v)); return s; }
-static double maxdiff3(const std::vector<double> &a, const std::vector<double> &b, const std::vector<double> &c,
-                       const std::vector<double> &ref /* [n][3] */)
-{
-  double s = 0;
-  for (std::size_t i = 0; i < a.size(); i++) {
-    s = std::fmax(s, std::fabs(a[i] - ref[3 * i]));
-    s = std::fmax(s, std::fabs(b[i] - ref[3 * i + 1]));
-    s = std::fmax(s, std::fabs(c[i] - ref[3 * i + 2]));
-  }
-  return s;
-}
-static double maxdiff(const std::vector<double> &a, const std::vector<double> &ref)
-{
-  double s = 0;
-  for (std::size_t i = 0; i < a.size(); i++) s = std::fmax(s, std::fabs(a[i] - ref[i]));
-  return s;
-}
+#include "potaccel_test_util.hpp"
 
 int main(int argc, char **argv)
 {

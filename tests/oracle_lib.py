@@ -81,7 +81,13 @@ class _NBodyComp(ctypes.Structure):
                [(k, c_double_p) for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "pot", "mass")] + \
                [("level", c_int_p), ("center", ctypes.c_double * 3), ("ncoef", ctypes.c_long),
                 ("coefN", c_double_p), ("coefL", c_double_p), ("coef", c_double_p),
-                ("cylmass", ctypes.c_double), ("used", ctypes.c_long), ("resetT", ctypes.c_double)]
+                ("cylmass", ctypes.c_double), ("used", ctypes.c_long), ("resetT", ctypes.c_double),
+                # the keys that default to "off" (oracle/nbody_oracle.h)
+                ("has_rtrunc", ctypes.c_int), ("rtrunc", ctypes.c_double), ("com0", ctypes.c_double * 3),
+                ("adiabatic", ctypes.c_int), ("ton", ctypes.c_double), ("toff", ctypes.c_double),
+                ("twid", ctypes.c_double), ("not_self_consistent", ctypes.c_int), ("coef_calls", ctypes.c_int),
+                ("fix_l0", ctypes.c_int), ("have_c0", ctypes.c_int), ("C0", c_double_p),
+                ("mlim", ctypes.c_int), ("has_mlim", ctypes.c_int)]
 
 
 class _NBody(ctypes.Structure):
@@ -89,7 +95,7 @@ class _NBody(ctypes.Structure):
     _fields_ = [("ncomp", ctypes.c_int), ("comp", ctypes.POINTER(_NBodyComp)), ("ninter", ctypes.c_int),
                 ("inter", c_int_p), ("multistep", ctypes.c_int), ("dtime", ctypes.c_double),
                 ("dynfrac", ctypes.c_double * 5), ("shiftlevl", ctypes.c_int), ("this_step", ctypes.c_long),
-                ("tnow", ctypes.c_double)]
+                ("tnow", ctypes.c_double), ("initializing", ctypes.c_int)]
 
 
 class NBodyOracle:
@@ -129,6 +135,13 @@ class NBodyOracle:
     def add_interaction(self, source, target):
         self.inter.append((int(source), int(target)))
 
+    def set_options(self, k, rtrunc=None, com0=(0.0, 0.0, 0.0), adiabatic=None, self_consistent=True, fix_l0=False,
+                    mlim=None):
+        """The keys of component ``k`` that default to off (oracle/nbody_oracle.h): ``rtrunc`` (+ ``com0``),
+        ``adiabatic = (ton, toff, twid)``, ``self_consistent``, ``FIX_L0`` (sphere), ``mlim`` (cylinder)."""
+        self.state[k]["options"] = dict(rtrunc=rtrunc, com0=tuple(com0), adiabatic=adiabatic,
+                                        self_consistent=self_consistent, fix_l0=fix_l0, mlim=mlim)
+
     def _build(self):
         nc = len(self.state)
         self._comps = (_NBodyComp * nc)()
@@ -148,6 +161,21 @@ class NBodyOracle:
                 c.center[j] = st["center"][j]
             c.ncoef = st["ncoef"]
             c.coefN, c.coefL, c.coef = _dp(st["coefN"]), _dp(st["coefL"]), _dp(st["coef"])
+            o = st.get("options")
+            if o:
+                if o["rtrunc"] is not None:
+                    c.has_rtrunc, c.rtrunc = 1, float(o["rtrunc"])
+                    for j in range(3):
+                        c.com0[j] = o["com0"][j]
+                if o["adiabatic"] is not None:
+                    c.adiabatic = 1
+                    c.ton, c.toff, c.twid = (float(v) for v in o["adiabatic"])
+                c.not_self_consistent = 0 if o["self_consistent"] else 1
+                if o["fix_l0"]:
+                    st["C0"] = np.zeros(G.nmax)
+                    c.fix_l0, c.C0 = 1, _dp(st["C0"])
+                if o["mlim"] is not None:
+                    c.has_mlim, c.mlim = 1, int(o["mlim"])
         self._inter = np.ascontiguousarray(np.array(self.inter, dtype=np.int32).reshape(-1))
         S = _NBody()
         S.ncomp, S.comp = nc, self._comps
@@ -179,10 +207,34 @@ class NBodyOracle:
         return float(self.S.tnow)
 
 
+class _CallOpts(ctypes.Structure):
+    """orc_call_opts (oracle/bfe_oracle.h)"""
+    _fields_ = [("adb", ctypes.c_double), ("frz", ctypes.c_int), ("rtrunc", ctypes.c_double),
+                ("com0", ctypes.c_double * 3), ("fcenter", ctypes.c_double * 3), ("mlim", ctypes.c_int)]
+
+
 class Oracle:
+    def call_opts(self, adb=1.0, rtrunc=None, com0=(0.0, 0.0, 0.0), fcenter=(0.0, 0.0, 0.0), mlim=None):
+        """Context manager: the per-call options of the thread bodies (Adiabatic factor, Component::freeze of the
+        component walked, the cylinder's mlim) for the oracle calls made inside the ``with`` block."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            o = _CallOpts(float(adb), 0 if rtrunc is None else 1, 1e20 if rtrunc is None else float(rtrunc),
+                          (ctypes.c_double * 3)(*com0), (ctypes.c_double * 3)(*fcenter), -1 if mlim is None else int(mlim))
+            self.lib.orc_set_call_opts(ctypes.byref(o))
+            try:
+                yield
+            finally:
+                self.lib.orc_set_call_opts(None)
+        return cm()
+
     def __init__(self):
         self.lib = ctypes.CDLL(build_oracle())
         L = self.lib
+        L.orc_adiabatic.restype = ctypes.c_double
+        L.orc_adiabatic.argtypes = [ctypes.c_double] * 4
         L.orc_sph_accumulate.restype = ctypes.c_long
         L.orc_level_select.restype = ctypes.c_int
         L.orc_mstep_create.restype = ctypes.c_void_p

@@ -11,11 +11,12 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "build", "test_potaccel")
+EXE2 = os.path.join(ROOT, "build", "test_potaccel2")
 
 
 def _build():
     subprocess.check_call(["make", "-s", "adaptor"], cwd=ROOT)
-    assert os.path.exists(EXE)
+    assert os.path.exists(EXE) and os.path.exists(EXE2)
 
 
 def test_adaptor_builds_against_the_c_abi_only():
@@ -25,8 +26,9 @@ def test_adaptor_builds_against_the_c_abi_only():
     incs = [l.split()[1] for l in txt.splitlines() if l.startswith("#include")]
     assert all(i.startswith("<") or i == '"exp_amd.h"' for i in incs), incs
     # ... and the program links the product library, not the oracle
-    out = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
-    assert "libexp_amd.so" in out and "oracle" not in out
+    for exe in (EXE, EXE2):
+        out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        assert "libexp_amd.so" in out and "oracle" not in out
 
 
 @pytest.mark.gpu
@@ -46,3 +48,20 @@ def test_adaptor_drives_kdk_and_multistep_without_python(tmp_path):
     assert cf.Times() == [0.125, 0.25]
     a, b = cf.getCoefStruct(0.125), cf.getCoefStruct(0.25)
     assert a.coefs.shape == b.coefs.shape and np.array_equal(a.coefs, b.coefs) and np.abs(a.coefs).max() > 0
+
+
+@pytest.mark.gpu
+def test_adaptor_two_components_cross_forces_and_option_keys():
+    """tests/cpp/test_potaccel2.cpp: a sphereSL halo and a cylinder disk, self forces and both cross forces through
+    SetExternal() / ClearExternal() as ComponentContainer::compute_potential makes the calls
+    (src/ComponentContainer.cc:698-822), begin_run + one block-multistep master step, against oracle/nbody_oracle.c's
+    results frozen in tests/golden/adaptor_case2.bin -- the plain run, then with rtrunc / com0, ton / toff / twid,
+    FIX_L0 and mlim, then with self_consistent: false on both (and a frozen outer disk)."""
+    if not os.path.exists(EXE2):
+        _build()
+    r = subprocess.run([EXE2, os.path.join(ROOT, "tests", "golden", "adaptor_case2.bin")], capture_output=True, text=True,
+                       timeout=600)
+    print(r.stdout[-9000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-9000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and r.stdout.count(" ok") >= 60 and "FAIL" not in r.stdout
+    assert r.stdout.count("---- scenario") == 3

@@ -1,0 +1,202 @@
+"""Every YAML key of the two n-body force methods is either honoured or refused -- none is accepted and dropped.
+
+Walks ``SphericalBasis::valid_keys`` (src/SphericalBasis.cc:30-52) and ``Cylinder::valid_keys`` (src/Cylinder.cc:24-80)
+through ``SphereSL.from_config`` / ``Cylinder.from_config`` (exp_amd/config.py) and the pyEXP key sets through
+``Basis.factory``: for each key, a value that asks for something either changes what the device computes (checked
+against the oracle or against the object's state) or raises.  The CPU half pins the two key tuples to the reference's own
+lists where /root/reference is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from exp_amd.config import CYLINDER_KEYS, SPHERICALBASIS_KEYS
+from tests.golden_util import load_cyl
+
+REF = "/root/reference/src"
+
+
+def _ref_keys(path, cls):
+    txt = open(path).read()
+    m = re.search(cls + r"::valid_keys = \{(.*?)\};", txt, re.S)
+    return re.findall(r'"([^"]+)"', m.group(1))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_key_tuples_are_the_references_lists():
+    assert list(SPHERICALBASIS_KEYS) == _ref_keys(os.path.join(REF, "SphericalBasis.cc"), "SphericalBasis")
+    assert list(CYLINDER_KEYS) == _ref_keys(os.path.join(REF, "Cylinder.cc"), "Cylinder")
+
+
+def test_pyexp_key_sets_hold_the_option_keys():
+    from exp_amd.basis import CYL_KEYS, SPH_KEYS
+    assert "mlim" in CYL_KEYS and "self_consistent" in CYL_KEYS and {"NO_L0", "EVEN_M", "M0_ONLY"} <= SPH_KEYS
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+# key -> (a value that ASKS for something, "honoured" | "refused").  The honoured ones are checked for their effect in
+# the test bodies below and in tests/test_options_gpu.py / test_sph_gpu.py / test_cyl_gpu.py.
+SPH_WALK = {
+    "scale": (2.0, "honoured"), "rmin": (0.4, "honoured"), "rmax": (10.0, "honoured"),
+    "self_consistent": (False, "honoured"), "FIX_L0": (True, "honoured"), "NO_L0": (True, "honoured"),
+    "NO_L1": (True, "honoured"), "EVEN_L": (True, "honoured"), "EVEN_M": (True, "honoured"), "M0_ONLY": (True, "honoured"),
+    "NOISE": (True, "refused"), "noiseN": (1e-3, "honoured"),         # (read only with NOISE, which is refused)
+    "noise_model_file": ("x.model", "honoured"), "seedN": (7, "honoured"),
+    "ssfrac": (0.5, "refused"), "playback": ("PLAYBACK_FILE", "honoured"), "coefCompute": (True, "refused"),   # (alone)
+    "coefMaster": (False, "honoured"), "orthocheck": (True, "honoured"), "subsampleFloat": (True, "refused"),
+    "totalCovar": (True, "refused"), "fullCovar": (True, "refused"),
+}
+
+
+@pytest.mark.gpu
+def test_every_sphericalbasis_key_is_honoured_or_refused(ctx, oracle, plummer_small, tmp_path):
+    from exp_amd.models import sample_sphere
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    assert set(SPH_WALK) == set(SPHERICALBASIS_KEYS)
+    m, pos, _ = sample_sphere(model, 3000, seed=2)
+    pos[:, 2] *= 0.8
+    base = SphereSL.from_config(ctx, g, {})
+    cb = Component.from_arrays(ctx, m, pos)
+    base.determine_coefficients(cb)
+    cb.zero_acceleration(0)
+    base.get_acceleration_and_potential(cb)
+    c_base, a_base = base.get_coefs(), cb.download(("acc",))["acc"]
+    with pytest.raises(ValueError, match="unmatched"):
+        SphereSL.from_config(ctx, g, {"Lmax": 4})                  # (a key of Sphere, not of SphericalBasis)
+    for key in SPHERICALBASIS_KEYS:
+        val, what = SPH_WALK[key]
+        if key == "playback":
+            continue                                               # below
+        if what == "refused":
+            with pytest.raises(ValueError):
+                SphereSL.from_config(ctx, g, {key: val})
+            continue
+        f = SphereSL.from_config(ctx, g, {key: val})
+        c = Component.from_arrays(ctx, m, pos)
+        f.determine_coefficients(c)
+        c.zero_acceleration(0)
+        f.get_acceleration_and_potential(c)
+        coef, acc = f.get_coefs(), c.download(("acc",))["acc"]
+        if key in ("scale", "rmin", "rmax", "NO_L0", "NO_L1", "EVEN_L", "EVEN_M", "M0_ONLY"):
+            prm = oracle.params(**{"scale": 1.0, "rmin": g.rmin, "rmax": g.rmax,
+                                   **({key.replace("M0_ONLY", "M0_only"): val})})
+            c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+            a_ref, _ = oracle.sph_accel(g, prm, pos, c_ref)
+            assert np.abs(coef - c_ref).max() <= 1e-10 * np.abs(c_ref).max(), key
+            assert np.abs(acc - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max(), key
+            assert np.abs(acc - a_base).max() > 1e-6 * np.abs(a_base).max(), key          # ... and it matters
+        elif key == "self_consistent":
+            assert f.coefs_frozen
+        elif key == "FIX_L0":
+            c.incr_position(0.1)
+            f.determine_coefficients(c)
+            c.zero_acceleration(0)
+            f.get_acceleration_and_potential(c)
+            assert np.array_equal(f.get_coefs()[0], coef[0]) and not np.array_equal(f.get_coefs()[1], coef[1])
+        elif key == "orthocheck":
+            assert 0.0 <= f.orthocheck_worst < 1e-2
+        else:                                                      # read only with NOISE / which rank writes the file
+            assert key in ("noiseN", "noise_model_file", "seedN", "coefMaster")
+            assert np.abs(coef - c_base).max() <= 1e-12 * np.abs(c_base).max()      # (same sums, atomics in arrival order)
+        c.close(); f.close()
+    # playback: the key names a coefficient file; from_config takes it, start_playback opens it once dtime is known
+    out = tmp_path / "outcoef.halo.test"
+    with open(out, "wb") as fh:
+        base.dump_coefs(fh, time=0.0)
+        base.dump_coefs(fh, time=1.0)
+    f = SphereSL.from_config(ctx, g, {"playback": str(out), "coefCompute": True})
+    f.start_playback(0.01)
+    assert f.play_back and f.play_cnew
+    f.determine_coefficients(cb, 0.5)
+    cb.zero_acceleration(0)
+    f.get_acceleration_and_potential(cb)
+    assert np.abs(cb.download(("acc",))["acc"] - a_base).max() <= 1e-9 * np.abs(a_base).max()
+    for o in (f, base, cb):
+        o.close()
+
+
+CYL_TABLE = dict(mmax=2, nmax=3, ncylnx=16, ncylny=8)
+CYL_WALK = {
+    # how the tables are made: honoured by building them (grid=None) or checked against the grid handed in
+    **{k: (None, "table") for k in ("rcylmin", "rcylmax", "acyl", "hcyl", "nmaxfid", "lmaxfid", "mmax", "ncylnx", "ncylny",
+                                    "ncylr", "nmax", "ncylodd", "rnum", "pnum", "tnum", "ashift", "cmap", "cmapr", "cmapz")},
+    "mlim": (1, "honoured"), "EVEN_M": (True, "honoured"), "self_consistent": (False, "honoured"),
+    "playback": ("PLAYBACK_FILE", "honoured"), "coefCompute": (True, "refused"), "coefMaster": (False, "honoured"),
+    "vflag": (3, "honoured"), "density": (True, "honoured"), "override": (True, "honoured"), "try_cache": (False, "honoured"),
+    "sech2": (True, "honoured"), "expcond": (True, "honoured"), "precond": (True, "honoured"),
+    "tk_type": ("Hall", "refused"), "bias": (2.0, "refused"), "hexp": (2.0, "refused"), "snr": (3.0, "refused"),
+    "evcut": (0.5, "refused"), "ncylrecomp": (10, "refused"), "npca": (50, "refused"), "npca0": (10, "refused"),
+    "nvtk": (5, "refused"), "cachename": ("eof.cache", "refused"), "eof_file": ("eof.cache", "refused"),
+    "samplesz": (4, "refused"), "logr": (True, "refused"), "pcavar": (True, "refused"), "pcaeof": (True, "refused"),
+    "pcavtk": (True, "refused"), "pcadiag": (True, "refused"), "subsamp": (True, "refused"), "nint": (5, "refused"),
+    "mtype": ("Gaussian", "refused"), "ppower": (5.0, "refused"), "pyname": ("dens.py", "refused"),
+    "dumpbasis": (True, "refused"), "fullCovar": (True, "refused"), "totalCovar": (True, "refused"),
+}
+
+
+@pytest.mark.gpu
+def test_every_cylinder_key_is_honoured_or_refused(ctx, oracle):
+    from exp_amd.models import sample_disk
+    from exp_amd.runtime import Component, Cylinder
+    assert set(CYL_WALK) == set(CYLINDER_KEYS)
+    cg, _ = load_cyl()
+    m, pos, _ = sample_disk(4000, 9, a=cg.ascale, h=cg.hscale, mass=1.0)
+    pos[:, 0] *= 1.3
+    with pytest.raises(ValueError, match="unmatched"):
+        Cylinder.from_config(ctx, {"Lmax": 4}, grid=cg)
+    table_ok = dict(mmax=cg.mmax, nmax=cg.norder, ncylnx=cg.numx, ncylny=cg.numy, acyl=cg.ascale, hcyl=cg.hscale,
+                    rcylmin=cg.rmin, rcylmax=cg.rmax, cmapr=cg.cmapr, cmap=cg.cmapr, cmapz=cg.cmapz)
+    for key in CYLINDER_KEYS:
+        val, what = CYL_WALK[key]
+        if key == "playback":
+            continue
+        if what == "table":
+            if key in table_ok:
+                f = Cylinder.from_config(ctx, {key: table_ok[key]}, grid=cg)       # agrees with the tables: taken
+                f.close()
+                wrong = table_ok[key] * 2 if key not in ("cmapr", "cmap", "cmapz") else table_ok[key] + 1
+                with pytest.raises(ValueError, match="contradicts"):
+                    Cylinder.from_config(ctx, {key: wrong}, grid=cg)
+            else:                                                  # how the tables were MADE: not recorded by a grid
+                with pytest.raises(ValueError, match="MADE"):
+                    Cylinder.from_config(ctx, {key: 12}, grid=cg)
+            continue
+        if what == "refused":
+            with pytest.raises(ValueError):
+                Cylinder.from_config(ctx, {key: val}, grid=None if key in ("cachename", "eof_file") else cg)
+            continue
+        f = Cylinder.from_config(ctx, {key: val}, grid=cg)
+        c = Component.from_arrays(ctx, m, pos)
+        f.determine_coefficients(c)
+        gc, gs = f.get_coefs()
+        if key == "mlim":
+            with oracle.call_opts(mlim=val):
+                cc, ss, _, _ = oracle.cyl_accumulate(cg, pos, m)
+            assert np.abs(gc - cc).max() <= 1e-10 * np.abs(cc).max() and np.all(gc[val + 1:] == 0.0)
+        elif key == "EVEN_M":
+            cc, ss, _, _ = oracle.cyl_accumulate(cg, pos, m, EVEN_M=True)
+            assert np.abs(gc[::2] - cc[::2]).max() <= 1e-10 * np.abs(cc).max()
+        elif key == "self_consistent":
+            assert f.coefs_frozen
+        else:                  # cache policy, deprecated no-ops, verbosity, the defaults of the conditioning: no effect
+            cc, ss, _, _ = oracle.cyl_accumulate(cg, pos, m)
+            assert np.abs(gc - cc).max() <= 1e-10 * np.abs(cc).max(), key
+        c.close(); f.close()
+    # the defaults of features that are not built ask for nothing and are taken
+    f = Cylinder.from_config(ctx, dict(pcavar=False, logr=False, nint=0, ncylrecomp=-1, precond=True, mtype="Exponential",
+                                       bias=1.0, tk_type="Null", samplesz=1, nvtk=1, evcut=-1.0), grid=cg)
+    f.close()
+    # grid=None: the tables are built from the keys (small orders so that it takes seconds)
+    f = Cylinder.from_config(ctx, dict(mmax=2, nmax=4, ncylnx=24, ncylny=12, ncylr=400, lmaxfid=10, nmaxfid=8, rnum=40,
+                                       tnum=20, ncylodd=1, acyl=0.01, hcyl=0.001, mlim=1))
+    assert (f.mmax, f.nmax, f.mlim) == (2, 4, 1) and f.grid.numx == 24
+    f.close()

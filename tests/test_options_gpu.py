@@ -1,0 +1,336 @@
+"""The keys of the two force methods that default to "off", against the oracle (SURVEY.md section 8, rows a6 / a9 / a10 /
+a13 / a15 -- the option branches inside the cited line ranges):
+
+* ``rtrunc`` / ``com0`` -- ``Component::freeze`` (src/Component.cc:4194-4202; call sites src/SphericalBasis.cc:468, :1159,
+  :1521; src/Cylinder.cc:842, :1329, :1756);
+* ``ton`` / ``toff`` / ``twid`` -- ``Component::Adiabatic`` (src/Component.cc:4214-4220; :441, :471, :1161 / :834, :1758);
+* ``self_consistent: false`` (src/SphericalBasis.cc:694, :1682; src/Cylinder.cc:959, :1469, :1755);
+* ``FIX_L0`` (src/SphericalBasis.cc:1689-1694);
+* ``mlim`` (src/Cylinder.cc:225; exputil/EmpCylSL.cc:5317, :5465, :5602).
+
+Bars as everywhere: coefficients 1e-10 of the largest, accelerations / potentials 1e-9.  GPU only."""
+import numpy as np
+import pytest
+
+from tests import config4_util as c4
+from tests.golden_util import load_cyl
+from tests.oracle_lib import NBodyOracle
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL, ACC_TOL = 1e-10, 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from exp_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _halo(model, n, seed):
+    from exp_amd.models import sample_sphere
+    m, pos, vel = sample_sphere(model, n, seed=seed)
+    pos[:, 2] *= 0.7
+    pos[:, 0] += 0.05
+    m = m * (1.0 + 0.3 * np.sin(np.arange(n)))            # unequal masses: the mass stream is read
+    return m, pos, vel
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("lmax,nmax,n", [(4, 8, 6000), (6, 18, 20000), (10, 24, 5000)])
+def test_sphere_freeze_and_adiabatic_against_the_oracle(ctx, oracle, lmax, nmax, n):
+    """accumulation and self force with a truncation radius that freezes ~a third of the particles about a shifted
+    com0 + centre, and an adiabatic factor"""
+    from exp_amd.runtime import Component, SphereSL
+    from tests.conftest import make_grid
+    model, g = make_grid("plummer", lmax, nmax, 400 if lmax != 6 else 800)
+    m, pos, _ = _halo(model, n, 11 + lmax)
+    center, com0, rtrunc, adb = np.array([0.02, -0.01, 0.03]), np.array([0.1, 0.05, -0.02]), 1.1, 0.3721
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    with oracle.call_opts(adb=adb, rtrunc=rtrunc, com0=com0, fcenter=center):
+        c_ref, used_ref = oracle.sph_accumulate(g, prm, pos, m, center=center)
+    with oracle.call_opts(rtrunc=rtrunc, com0=com0, fcenter=center):
+        a_ref, p_ref = oracle.sph_accel(g, prm, pos, c_ref, center=center)
+    frozen = np.linalg.norm(pos - com0 - center, axis=1) > rtrunc
+    assert 0.15 * n < frozen.sum() < 0.7 * n
+    assert np.all(a_ref[frozen] == 0.0) and np.all(p_ref[frozen] == 0.0)
+
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    c.set_center(center)
+    c.set_rtrunc(rtrunc, com0)
+    f.set_mass_scale(adb)
+    f.determine_coefficients(c)
+    assert f.Used() == used_ref
+    assert _rel(f.get_coefs(), c_ref) <= COEF_TOL
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    assert np.all(out["acc"][frozen] == 0.0) and np.all(out["pot"][frozen] == 0.0)
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    # ... the same through one fused KDK step: frozen particles are kicked with zero acceleration, i.e. drift freely
+    c2 = Component.from_arrays(ctx, m, pos, np.full_like(pos, 0.01))
+    c2.set_center(center)
+    c2.set_rtrunc(rtrunc, com0)
+    f.determine_coefficients(c2)
+    c2.zero_acceleration(0)
+    f.get_acceleration_and_potential(c2)
+    f.step_kdk(c2, 1e-3)
+    o2 = c2.download(("pos", "vel", "acc"))
+    p1 = pos + 0.01 * 1e-3
+    still = frozen & (np.linalg.norm(p1 - com0 - center, axis=1) > rtrunc)
+    assert still.sum() > 0.1 * n
+    assert np.abs(o2["pos"][still] - p1[still]).max() <= 1e-15 and np.all(o2["vel"][still] == 0.01)
+    assert np.all(o2["acc"][still] == 0.0)
+    for o in (c, c2, f):
+        o.close()
+
+
+def test_sphere_external_target_is_frozen_by_its_own_rtrunc(ctx, oracle, plummer_small):
+    """SetExternal: the TARGET's freeze (cC->freeze, src/SphericalBasis.cc:1521) with the target's own com0 + centre, while
+    the positions go into the source's frame"""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    m, pos, _ = _halo(model, 4000, 5)
+    mt, post, _ = _halo(model, 3000, 6)
+    post = post * 1.3 + np.array([0.3, 0.0, -0.1])
+    src_center, tgt_center, com0, rtrunc = np.array([0.05, 0.0, 0.0]), np.array([0.3, 0.0, -0.1]), np.array([0.0, 0.1, 0.0]), 1.5
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m, center=src_center)
+    with oracle.call_opts(rtrunc=rtrunc, com0=com0, fcenter=tgt_center):
+        a_ref, p_ref = oracle.sph_accel(g, prm, post, c_ref, center=src_center)
+    f = SphereSL(ctx, g)
+    cs, ct = Component.from_arrays(ctx, m, pos), Component.from_arrays(ctx, mt, post)
+    cs.set_center(src_center)
+    ct.set_center(tgt_center)
+    ct.set_rtrunc(rtrunc, com0)
+    f.determine_coefficients(cs)
+    ct.zero_acceleration(0)
+    f.get_acceleration_and_potential(ct, external=True)
+    out = ct.download(("acc", "pot"))
+    frozen = np.linalg.norm(post - com0 - tgt_center, axis=1) > rtrunc
+    assert 100 < frozen.sum() < 2900 and np.all(out["acc"][frozen] == 0.0)
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    for o in (cs, ct, f):
+        o.close()
+
+
+@pytest.mark.parametrize("mlim", [None, 1, 0])
+def test_cylinder_freeze_adiabatic_and_mlim_against_the_oracle(ctx, oracle, mlim):
+    from exp_amd.models import sample_disk
+    from exp_amd.runtime import Component, Cylinder
+    cg, _ = load_cyl()
+    n = 20000
+    m, pos, _ = sample_disk(n, 17, a=cg.ascale, h=cg.hscale, mass=1.0)
+    m = m * (1.0 + 0.4 * np.cos(np.arange(n)))
+    pos[:, 0] *= 1.2
+    pos[::7] *= 40.0                                          # some beyond 0.75 of the table radius: taper + monopole
+    center, com0, rtrunc, adb = np.array([1e-3, -5e-4, 2e-4]), np.array([2e-3, 0.0, 1e-3]), 0.025, 0.61
+    with oracle.call_opts(adb=adb, rtrunc=rtrunc, com0=com0, fcenter=center, mlim=mlim):
+        cc, ss, used_ref, cm_ref = oracle.cyl_accumulate(cg, pos, m, center=center)
+        a_ref, p_ref = oracle.cyl_accel(cg, pos, cc, ss, cm_ref, center=center)
+    frozen = np.linalg.norm(pos - com0 - center, axis=1) > rtrunc
+    assert 0.1 * n < frozen.sum() < 0.8 * n
+    f = Cylinder(ctx, cg, mlim=-1 if mlim is None else mlim)
+    c = Component.from_arrays(ctx, m, pos)
+    c.set_center(center)
+    c.set_rtrunc(rtrunc, com0)
+    f.set_mass_scale(adb)
+    f.determine_coefficients(c)
+    gc, gs = f.get_coefs()
+    scale = max(np.abs(cc).max(), np.abs(ss).max())
+    assert f.Used() == used_ref
+    assert f.cylmass == pytest.approx(cm_ref, rel=1e-12)
+    assert np.abs(gc - cc).max() <= COEF_TOL * scale and np.abs(gs - ss).max() <= COEF_TOL * scale
+    if mlim is not None:
+        assert np.all(gc[mlim + 1:] == 0.0) and np.all(gs[mlim + 1:] == 0.0) and np.abs(gc[:mlim + 1]).max() > 0
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    assert np.all(out["acc"][frozen] == 0.0) and np.all(out["pot"][frozen] == 0.0)
+    assert np.abs(out["acc"] - a_ref).max() <= ACC_TOL * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    c.close(); f.close()
+
+
+def test_mlim_refusals(ctx):
+    from exp_amd.runtime import Cylinder
+    cg, _ = load_cyl()
+    f = Cylinder(ctx, cg, mlim=1)
+    f.set_mlim(0)                                              # lowering is fine
+    with pytest.raises(RuntimeError, match="already dropped"):
+        f.set_mlim(1)
+    with pytest.raises(RuntimeError, match="must be >= 0"):
+        f.set_mlim(-3)
+    f.set_mlim(cg.mmax + 5)                                   # min(MLIM, MMAX): nothing to do
+    f.close()
+
+
+def test_pyexp_cylindrical_honours_mlim(oracle, tmp_path):
+    """``mlim`` in the YAML of ``Basis.factory`` (expui/BiorthBasis.cc:1466, :1620: `if (mlim>=0) sl->set_mlim(mlim)`) used
+    to be accepted and dropped: coefficients and accelerations against the literal pyEXP twins of the oracle with MLIM"""
+    from exp_amd.basis import Basis
+    from exp_amd.models import sample_disk
+    cfg = f"""
+---
+id: cylinder
+parameters:
+  acyl: 0.01
+  hcyl: 0.001
+  mmax: 4
+  nmax: 6
+  mlim: 2
+  ncylnx: 48
+  ncylny: 24
+  ncylr: 600
+  lmaxfid: 16
+  nmaxfid: 12
+  rnum: 60
+  tnum: 30
+  cachename: {tmp_path / 'eof.cache.mlim'}
+...
+"""
+    basis = Basis.factory(cfg)
+    m, pos, _ = sample_disk(5000, 3, a=0.01, h=0.001)
+    pos[:, 0] *= 1.25
+    coefs = basis.createFromArray(m, pos, time=0.0)
+    with oracle.call_opts(mlim=2):
+        cc, ss, _ = oracle.pyexp_cyl_accumulate(basis.grid, pos, m)
+        rng = np.random.default_rng(8)
+        test = rng.normal(0, 0.03, (300, 3)) * np.array([1.0, 1.0, 0.1])
+        a_ref = oracle.pyexp_cyl_accel(basis.grid, cc, ss, test)
+    assert np.all(coefs.coefs[3:] == 0.0) and np.abs(coefs.coefs[:3]).max() > 0
+    assert np.abs(coefs.coefs.real[:3] - cc[:3]).max() <= 1e-10 * np.abs(cc).max()
+    assert np.abs(coefs.coefs.imag[:3] - ss[:3]).max() <= 1e-10 * np.abs(cc).max()
+    a_got = basis.getAccel(test)
+    assert np.abs(a_got - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
+    # ... and it matters: the unrestricted evaluation of the same coefficients differs
+    a_all = oracle.pyexp_cyl_accel(basis.grid, *oracle.pyexp_cyl_accumulate(basis.grid, pos, m)[:2], test)
+    assert np.abs(a_all - a_ref).max() > 1e-6 * np.linalg.norm(a_ref, axis=1).max()
+
+
+def _driver_run(ctx, inp, opts_h, opts_d, ms, dtime, nsteps):
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    g, cg = c4.grids()
+    sc = float(inp["scale"])
+    ch = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    cd = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    fh = SphereSL(ctx, g, multistep=ms, self_consistent=opts_h.get("self_consistent", True), FIX_L0=opts_h.get("fix_l0", False),
+                  **c4.sph_window(g, sc))
+    fd = Cylinder(ctx, cg, multistep=ms, self_consistent=opts_d.get("self_consistent", True),
+                  mlim=opts_d["mlim"] if opts_d.get("mlim") is not None else -1)
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=c4.DYN)
+    ih, idk = sim.add_component(ch, fh), sim.add_component(cd, fd)
+    sim.add_interaction(ih, idk)
+    sim.add_interaction(idk, ih)
+    for c, o, k in ((ch, opts_h, ih), (cd, opts_d, idk)):
+        if o.get("rtrunc") is not None:
+            c.set_rtrunc(o["rtrunc"], o.get("com0"))
+        if o.get("adiabatic") is not None:
+            sim.set_adiabatic(k, *o["adiabatic"])
+    sim.init()
+    sim.step(nsteps)
+    return sim, (fh, fd), (ch, cd)
+
+
+SCENARIOS = [
+    (dict(rtrunc=0.35, com0=(0.004, -0.003, 0.002), fix_l0=True), dict(adiabatic=(7.5e-5, 1.0e20, 1.5e-4), mlim=1)),
+    (dict(self_consistent=False), dict(rtrunc=0.03, self_consistent=False)),
+    (dict(adiabatic=(1.0e-4, 4.0e-4, 1.0e-4), rtrunc=0.6), dict(rtrunc=0.05, com0=(0.001, 0.0, 0.0), adiabatic=(0.0, 1.0e20, 3.0e-4))),
+]
+
+
+@pytest.mark.parametrize("scen", range(len(SCENARIOS)))
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_step_driver_with_the_option_keys_against_the_nbody_oracle(ctx, oracle, monkeypatch, scen, overlap):
+    """the C++ step driver (exp_amd_sim_*: both schedules) on the disk + halo miniature with the keys switched on: levels
+    bit for bit, trajectories, accelerations, combined coefficient sets, cylmass against oracle/nbody_oracle.c"""
+    monkeypatch.setenv("EXP_AMD_SIM_OVERLAP", overlap)
+    oh, od = SCENARIOS[scen]
+    ms, dtime, nsteps = 2, 1.5e-4, 2
+    inp = c4.config4_inputs(n_halo=500, n_disk=500)
+    g, cg = c4.grids()
+    prm = oracle.params(**c4.sph_window(g, float(inp["scale"])))
+    nb = NBodyOracle(oracle, ms, dtime, c4.DYN)
+    i1 = nb.add_sphere(g, prm, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    i2 = nb.add_cylinder(cg, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    nb.add_interaction(i1, i2)
+    nb.add_interaction(i2, i1)
+    nb.set_options(i1, **oh)
+    nb.set_options(i2, **od)
+    nb.init()
+    nsw = [0, 0]
+    for _ in range(nsteps):
+        nsw = [a + b for a, b in zip(nsw, nb.step())]
+    sim, forces, comps = _driver_run(ctx, inp, oh, od, ms, dtime, nsteps)
+    assert sum(nsw) > 0
+    for k, (f, c) in enumerate(zip(forces, comps)):
+        st = nb.state[k]
+        o = c.download()
+        assert np.array_equal(c.download_levels(), st["level"]), k
+        p = np.stack([st[q] for q in "xyz"], 1)
+        v = np.stack([st["v" + q] for q in "xyz"], 1)
+        a = np.stack([st["a" + q] for q in "xyz"], 1)
+        assert np.abs(o["pos"] - p).max() <= 1e-11, k
+        assert np.abs(o["vel"] - v).max() <= 1e-9 * np.abs(v).max(), k
+        assert np.abs(o["acc"] - a).max() <= 1e-8 * np.linalg.norm(a, axis=1).max(), k
+        assert np.abs(o["pot"] - st["pot"]).max() <= 1e-8 * np.abs(st["pot"]).max(), k
+        gc = f.get_coefs()
+        gc = np.concatenate([np.asarray(x).reshape(-1) for x in (gc if isinstance(gc, tuple) else (gc,))])
+        assert np.abs(gc - st["coef"]).max() <= 1e-10 * np.abs(st["coef"]).max(), k
+    assert forces[1].cylmass == pytest.approx(nb.cylmass(1), rel=1e-12, abs=1e-300)
+    if not oh.get("self_consistent", True):
+        assert forces[0].coefs_frozen and forces[1].coefs_frozen
+    sim.close()
+    for o in list(forces) + list(comps):
+        o.close()
+
+
+def test_self_consistent_false_and_fix_l0_at_the_call_level(ctx, oracle, plummer_small):
+    """the PotAccel calls themselves: determine_coefficients returns at once after the first completed call unless
+    `initializing`; FIX_L0 saves the monopole row at the first evaluation and restores it at every later one"""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    m, pos, vel = _halo(model, 5000, 21)
+    prm = oracle.params(scale=1.0, rmin=g.rmin, rmax=g.rmax)
+    f = SphereSL(ctx, g, self_consistent=False, FIX_L0=True)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    assert not f.coefs_frozen
+    f.determine_coefficients(c)                                # the first call always runs (firstime_coef)
+    c0 = f.get_coefs()
+    c_ref, _ = oracle.sph_accumulate(g, prm, pos, m)
+    assert _rel(c0, c_ref) <= COEF_TOL and f.coefs_frozen
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)                        # FIX_L0: C0 saved here
+    a0 = c.download(("acc",))["acc"]
+    c.incr_position(0.05)
+    f.determine_coefficients(c)                                # frozen: nothing happens
+    assert np.array_equal(f.get_coefs(), c0)
+    f.set_initializing(True)
+    f.determine_coefficients(c)                                # begin_run may still re-make them
+    f.set_initializing(False)
+    moved = c.download(("pos",))["pos"]
+    c1_ref, _ = oracle.sph_accumulate(g, prm, moved, m)
+    assert _rel(f.get_coefs(), c1_ref) <= COEF_TOL and not np.array_equal(f.get_coefs(), c0)
+    # the next force evaluation puts the saved monopole row back (and only that row)
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    now = f.get_coefs()
+    assert np.array_equal(now[0], c0[0]) and np.array_equal(now[1:], f.get_coefs()[1:])
+    want = c1_ref.copy()
+    want[0] = c_ref[0]
+    a_ref, _ = oracle.sph_accel(g, prm, moved, want)
+    got = c.download(("acc",))["acc"]
+    assert np.abs(got - a_ref).max() <= 1e-9 * np.linalg.norm(a_ref, axis=1).max()
+    assert np.abs(got - a0).max() > 0
+    # a fused step with the coefficients held fixed: kick, drift, force of the same set, kick
+    f.step_kdk(c, 1e-3)
+    assert np.array_equal(f.get_coefs(), now)
+    c.close(); f.close()
