@@ -64,6 +64,8 @@ SIGNATURES = {
     "exp_amd_sim_set_adiabatic": (c_int, [c_void_p, c_int, c_double, c_double, c_double]),
     "exp_amd_sim_set_time": (c_int, [c_void_p, c_double]),
     "exp_amd_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_longlong)]),
+    "exp_amd_comm_streams": (c_int, [c_void_p]),
+    "exp_amd_comm_allreduce_max": (c_int, [c_void_p, POINTER(c_double)]),
     "exp_amd_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t]),
     "exp_amd_comp_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "exp_amd_comp_destroy": (None, [c_void_p]),

@@ -388,12 +388,23 @@ class BiorthBasis:
         # every batch ends in one all-reduce of the coefficient buffer: all ranks must issue the same number of them
         # (shares that straddle a multiple of 2^24 differently would hang or mis-sum) -- empty batches take part
         nbatch = max(1, -(-n // step))
-        import sys as _sys
-        _dist = _sys.modules.get("torch.distributed")
-        if _dist is not None and _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
-            box = [None] * _dist.get_world_size()
-            _dist.all_gather_object(box, nbatch)
-            nbatch = max(box)
+        # ... agreed on the transport the coefficient all-reduce itself uses (the library's RCCL communicator or the
+        # host's callback), so that hosts without a torch process group are covered too
+        info = self.ctx.comm_info()
+        if info["kind"] != "none":
+            if info["kind"] == "callback" and info["nranks"] <= 1:
+                import sys as _sys
+                _dist = _sys.modules.get("torch.distributed")
+                if _dist is not None and _dist.is_available() and _dist.is_initialized():
+                    if _dist.get_world_size() > 1:
+                        box = [None] * _dist.get_world_size()
+                        _dist.all_gather_object(box, nbatch)
+                        nbatch = max(box)
+                else:
+                    raise RuntimeError("createFromReader: the context reduces through a callback but does not know its "
+                                       "world: Context.set_allreduce(fn, nranks, rank)")
+            else:
+                nbatch = int(self.ctx.allreduce_max(nbatch))
         sampT = int(getattr(self, "sampT", 0) or 0)
         for lo in range(0, nbatch * step, step):
             sl = slice(min(lo, n), min(lo + step, n))

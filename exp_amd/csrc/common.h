@@ -56,6 +56,9 @@ struct exp_amd_ctx {
   // collectives
   void *rccl_lib = nullptr;
   void *rccl_comm = nullptr;
+  void *rccl_comm2 = nullptr;        // a second communicator (ncclCommSplit of the first) for collectives issued on `aux`: the
+                                     // two-stream schedule of the step driver keeps one communicator per stream
+  bool rccl_comm2_tried = false;
   void *rccl_allreduce = nullptr;    // ncclAllReduce, resolved once at exp_amd_comm_init_rank
   unsigned long long ar_calls = 0;   // all-reduces issued so far (either path)
   int nranks = 1, rank = 0;
@@ -154,6 +157,9 @@ struct ProfScope {
 };
 
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
+// true when collectives may be issued on ctx->aux as well as on ctx->stream: a single rank, a host callback (it is
+// handed the stream), or an RCCL communicator that could be split into a second one
+bool expamd_comm_two_streams(exp_amd_ctx *ctx);
 bool expamd_orient_has_log(const exp_amd_orient *o);     // orient.hip: a log file is open
 
 // x + a*b rounded as a separate multiply and add (what the reference's scalar CPU code does).

@@ -76,6 +76,7 @@ extern "C" void exp_amd_ctx_destroy(exp_amd_ctx *ctx)
   if (ctx->rccl_comm && ctx->rccl_lib) {
     typedef int (*destroy_fn)(void *);
     destroy_fn d = (destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
+    if (d && ctx->rccl_comm2) d(ctx->rccl_comm2);
     if (d) d(ctx->rccl_comm);
   }
   if (ctx->aux) {
@@ -321,6 +322,25 @@ extern "C" int exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank)
   return EXP_AMD_OK;
 }
 
+// The step driver runs two components' chains on two streams (host.hip).  Collectives of one RCCL communicator are
+// ordered among themselves whatever stream they are given, so the second stream gets a communicator of its own: the first
+// one split with every rank in the same colour (ncclCommSplit, RCCL >= 2.18).  Each rank issues the collectives of each
+// communicator in the same order -- the driver's launch order does not depend on the data -- which is what NCCL asks of
+// concurrently used communicators.  No split available: one stream, as before.
+typedef int (*fn_comm_split)(void *, int, int, void **, void *);
+bool expamd_comm_two_streams(exp_amd_ctx *ctx)
+{
+  if (ctx->ar_fn) return true;                       // (the callback is told the stream)
+  if (!ctx->rccl_comm) return ctx->nranks <= 1;
+  if (!ctx->rccl_comm2 && !ctx->rccl_comm2_tried) {
+    ctx->rccl_comm2_tried = true;
+    fn_comm_split f = ctx->rccl_lib ? (fn_comm_split)dlsym(ctx->rccl_lib, "ncclCommSplit") : nullptr;
+    void *c2 = nullptr;
+    if (f && f(ctx->rccl_comm, 0, ctx->rank, &c2, nullptr) == 0) ctx->rccl_comm2 = c2;
+  }
+  return ctx->rccl_comm2 != nullptr;
+}
+
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count)
 {
   if (ctx->nranks > 1 && !ctx->ar_fn && !ctx->rccl_comm)
@@ -337,12 +357,47 @@ int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count)
     ProfScope ps(ctx, "ncclAllReduce(coef)");
     fn_allreduce f = (fn_allreduce)ctx->rccl_allreduce;
     // ncclDouble = 8 (ncclFloat64), ncclSum = 0  (rccl.h:448, :467)
-    int rc = f(dev, dev, count, 8, 0, ctx->rccl_comm, ctx->stream);
+    void *comm = (ctx->aux && ctx->stream == ctx->aux && ctx->rccl_comm2) ? ctx->rccl_comm2 : ctx->rccl_comm;
+    int rc = f(dev, dev, count, 8, 0, comm, ctx->stream);
     if (rc) return expamd_fail(ctx, EXP_AMD_ERR_COMM, "ncclAllReduce -> %d", rc);
     ctx->ar_calls++;
   }
   return EXP_AMD_OK;
 }
+
+// MAX over the ranks of one host number, on the transport the coefficient all-reduce uses (a SUM of one-hot slots): what
+// rank-dependent host logic needs to agree on a count -- e.g. the number of batches, each ending in one all-reduce, that
+// every rank must issue alike
+extern "C" int exp_amd_comm_allreduce_max(exp_amd_ctx *ctx, double *value)
+{
+  if (!ctx || !value) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comm_allreduce_max: NULL argument");
+  if (!ctx->ar_fn && !ctx->rccl_comm) return EXP_AMD_OK;                  // single rank
+  if (ctx->nranks <= 1 && ctx->ar_fn)
+    return expamd_fail(ctx, EXP_AMD_ERR_COMM, "comm_allreduce_max: the context has an all-reduce callback but was not told "
+                       "its world (exp_amd_comm_set_world)");
+  const int nr = ctx->nranks;
+  std::vector<double> h((size_t)nr, 0.0);
+  h[(size_t)ctx->rank] = *value;
+  DevBuf<double> d;
+  HIP_TRY(ctx, d.alloc((size_t)nr));
+  HIP_TRY(ctx, hipMemcpyAsync(d.p, h.data(), nr * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = expamd_allreduce(ctx, d.p, (size_t)nr);
+  if (rc == EXP_AMD_OK) {
+    hipError_t e = hipMemcpyAsync(h.data(), d.p, nr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = expamd_fail(ctx, EXP_AMD_ERR_HIP, "comm_allreduce_max: %s", hipGetErrorString(e));
+  }
+  d.release();
+  if (rc) return rc;
+  double m = h[0];
+  for (int k = 1; k < nr; k++) m = h[k] > m ? h[k] : m;
+  *value = m;
+  return EXP_AMD_OK;
+}
+
+// on how many streams the context can reduce at once: 2 = the step driver keeps its two-stream schedule with this transport
+// (a single rank, a host callback, or an RCCL communicator with a split twin), 1 = one stream
+extern "C" int exp_amd_comm_streams(exp_amd_ctx *ctx) { return ctx && expamd_comm_two_streams(ctx) ? 2 : 1; }
 
 // which all-reduce the context uses: kind 0 = none (single rank), 1 = the library's RCCL
 // communicator, 2 = host-provided callback; calls = all-reduces issued so far

@@ -474,7 +474,7 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       const bool fuse_on = EXPAMD_EXPT("EXP_AMD_THIN_ADVANCE", 1) != 0;
       const bool fuse = fuse_on && !f->frozen() && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
-                        !ctx->deterministic && !f->generic;
+                        !ctx->deterministic && !f->generic && f->thin_lds_ok();
       if (fuse) {
         f->adv_owed = true;
         f->adv_dt_min = dt_min;
@@ -552,7 +552,8 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   if (c->n && dacc < ms && (rc = expamd_comp_level_count(c, dacc + 1, ms, &nrange))) return rc;
   // the whole active range is sparse and thin: straight from the basis tables into the contraction's stage-1 sums
   // (k_cyl_acc_thin), no node moments and no pass over the nodes
-  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max * ctx->thin_acc_scale && !ctx->deterministic && ctx->thin_max > 0;
+  const bool thin = dacc < lo && (long long)nrange <= ctx->thin_max * ctx->thin_acc_scale && !ctx->deterministic && ctx->thin_max > 0 &&
+                    (f->generic || f->thin_lds_ok());
   // (the advance that kernel was to perform, should it not run after all)
   if (f->adv_owed && !(thin && nrange)) {
     f->adv_owed = false;

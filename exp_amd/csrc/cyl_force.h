@@ -15,6 +15,9 @@ struct CylForce : exp_amd_force {
   int step_parity() const override { return work_flip; }
   int mlim = -1;                    // the "mlim" key (exp_amd_cyl_set_mlim): harmonics above it are dropped; < 0: none
   bool generic = false;             // mmax > CYL_MAX_M (or EXP_AMD_CYL_GENERIC=1): the run-time-order kernels throughout
+  // k_cyl_acc_thin keeps the table blends of at least four particles in LDS (one or two sets of (mmax+1) nmax values
+  // each): beyond 120 KB the moment path takes the work
+  bool thin_lds_ok() const { return (size_t)4 * 2 * (cfg.mmax + 1) * cfg.nmax * sizeof(double) <= 120 * 1024; }
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_cyl_acc_thin
   double adv_dt_min = 0.0;
   bool cpart_clean = false;         // ... all zero (what k_cyl_acc_thin adds to; its summing kernels keep them so)

@@ -80,12 +80,14 @@ static int overlap_begin(exp_amd_sim *s)
   for (auto o : s->orients) any_orient = any_orient || o;
   // EXP_AMD_SIM_OVERLAP=0 (include/exp_amd.h, environment): both components on the context's one stream
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
-  // (single rank only: a communicator's collectives stay on ONE stream, in one order on every rank)
+  // (several ranks: each stream needs a transport of its own -- a host callback is handed the stream; the library's RCCL
+  // communicator is split into a second one for the auxiliary stream, expamd_comm_two_streams -- and every rank issues
+  // the collectives of each stream in the same order: the launch order below does not depend on the data)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
   // followed across the streams by ONE pair of events -- with a third component the cross forces of one
   // source on two targets would run on both streams at once and share the scratch of its force pass)
-  s->overlap = s->multistep > 0 && s->comps.size() == 2 && !any_orient && !ctx->ar_fn &&
-               ctx->nranks == 1 && !ctx->rccl_comm && !(env && atoi(env) == 0);
+  s->overlap = s->multistep > 0 && s->comps.size() == 2 && !any_orient && !(env && atoi(env) == 0) &&
+               expamd_comm_two_streams(ctx);
   if (!s->overlap) return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);
   if (rc) return rc;

@@ -683,7 +683,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
       if ((rc = expamd_comp_level_count(c, lo, ms, &nall))) return rc;
       const bool fuse_on = EXPAMD_EXPT("EXP_AMD_THIN_ADVANCE", 1) != 0;
       const bool fuse = fuse_on && !f->frozen() && dmax < lo && adv.mode == 2 && nall > 0 && ctx->thin_max > 0 && (long long)nall <= ctx->thin_max * ctx->thin_acc_scale &&
-                        !ctx->deterministic && f->ncoef <= 4096 && !f->generic;
+                        !ctx->deterministic && f->ncoef <= 4096 && !f->generic && f->thin_lds_ok();
       if (fuse) {
         f->adv_owed = true;
         f->adv_dt_min = dt_min;
@@ -734,7 +734,7 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
   // (k_sph_acc_thin), no moments and no contraction (the deterministic mode keeps the moment path: its rounding grid
   // is that of the moment terms)
   const bool thin = dacc < lo && ctx->thin_max > 0 && (long long)nrange <= ctx->thin_max * ctx->thin_acc_scale && !ctx->deterministic &&
-                    f->ncoef <= 4096;
+                    f->ncoef <= 4096 && (f->generic || f->thin_lds_ok());
   // (the advance this kernel was to perform, should it not run after all)
   if (f->adv_owed && !(thin && nrange)) {
     f->adv_owed = false;
@@ -1140,7 +1140,7 @@ int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
   const bool thin_diff_on = EXPAMD_EXPT("EXP_AMD_THIN_DIFF", 1) != 0;
   const bool few = listed && c->mover_hint > 0 && !(ctx->mover_list_min >= 0 && c->mover_hint >= ctx->mover_list_min);
   const bool thin_diff = few && thin_diff_on && ctx->thin_max > 0 && c->mover_hint <= ctx->thin_max && !ctx->deterministic &&
-                         !f->generic && f->ncoef <= 4096;
+                         !f->generic && f->ncoef <= 4096 && f->thin_lds_ok();
   // (no mover anywhere in the thin case: the moments were not touched, the partial sums are zero)
   if (listed && c->mover_hint == 0) {
     // nothing moved on this rank (it only takes part in the reduction)

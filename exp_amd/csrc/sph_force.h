@@ -34,6 +34,13 @@ struct SphForce : exp_amd_force {
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations
   bool used_open = true;
   bool wd_clean = false;            // ... and of d_Wd (multistep_update)
+  // the tiled direct kernels (k_sph_acc_thin / k_sph_diff_thin) keep the harmonics and table blends of at least four
+  // particles in LDS: where that does not fit (a small lmax with a very large nmax) the moment path takes the work
+  bool thin_lds_ok() const
+  {
+    const size_t nrows = (size_t)(cfg.lmax + 1) * (cfg.lmax + 1), lsn = (size_t)(cfg.lmax + 1) * cfg.nmax;
+    return ((((size_t)4 * nrows + 1) & ~(size_t)1) + (size_t)4 * lsn) * sizeof(double) <= 120 * 1024;
+  }
   bool adv_owed = false;            // substep_expansion: the advance of the active range is left to k_sph_acc_thin
   double adv_dt_min = 0.0;
   bool part_clean = false;          // d_part is all zero (what the thin accumulation adds to; its summing kernels keep it so)

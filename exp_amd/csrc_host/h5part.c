@@ -78,7 +78,7 @@ int exp_h5p_attr_f64(const char *path, const char *obj, const char *name, double
 /* string attribute, scalar or 1-D, variable- or fixed-length: element `index` -> out; *count = number of elements */
 int exp_h5p_attr_str(const char *path, const char *obj, const char *name, int index, char *out, int cap, int *count)
 {
-  if (!path || !obj || !name || !count || (cap > 0 && !out) || cap < 0) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
+  if (!path || !obj || !name || !count || !out || cap < 1) return -9;     /* (C-ABI entry point: arguments are checked before anything is touched) */
   quiet();
   out[0] = '\0';
   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);

@@ -59,17 +59,26 @@ class _DevPtr:
 
 def torch_allreduce_callback(device=None, group=None):
     """Callback for Context.set_allreduce: SUM-reduce the device coefficient buffer in place with
-    torch.distributed (RCCL).  The context must run on torch's current stream."""
+    torch.distributed (RCCL) ON THE STREAM IT IS HANDED -- the context's own, or the auxiliary stream of the two-stream
+    step driver -- which is made torch's current stream for the call when it is not already."""
     import torch
     import torch.distributed as dist
 
     views = {}          # (ptr, count) -> tensor view: the buffers are long-lived, wrap each once
+    streams = {}        # raw stream -> torch.cuda.ExternalStream
 
     def fn(ptr: int, count: int, stream: int) -> None:
         t = views.get((ptr, count))
         if t is None:
             t = views[(ptr, count)] = torch.as_tensor(_DevPtr(ptr, count), device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if stream and stream != torch.cuda.current_stream(device).cuda_stream:
+            ext = streams.get(stream)
+            if ext is None:
+                ext = streams[stream] = torch.cuda.ExternalStream(stream, device=device)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return fn
 

@@ -78,11 +78,17 @@ class Context:
         kind, nr, rk, calls = c_int(), c_int(), c_int(), c_longlong()
         check(self.lib.exp_amd_comm_info(self.h, byref(kind), byref(nr), byref(rk), byref(calls)), self.h)
         return {"kind": ("none", "rccl", "callback")[kind.value], "nranks": nr.value, "rank": rk.value,
-                "allreduce_calls": int(calls.value)}
+                "allreduce_calls": int(calls.value), "streams": int(self.lib.exp_amd_comm_streams(self.h))}
 
     def allreduce(self, device_ptr: int, count: int) -> None:
         """In-place sum over ranks of ``count`` doubles at a device pointer, on the context's stream."""
         check(self.lib.exp_amd_comm_allreduce(self.h, c_void_p(int(device_ptr)), int(count)), self.h)
+
+    def allreduce_max(self, value: float) -> float:
+        """MAX over the ranks of one host number, on the context's own transport (``exp_amd_comm_allreduce_max``)."""
+        v = c_double(float(value))
+        check(self.lib.exp_amd_comm_allreduce_max(self.h, byref(v)), self.h)
+        return float(v.value)
 
     def set_deterministic(self, on: bool = True) -> None:
         """Order-independent coefficient sums: runs become bit-reproducible (include/exp_amd.h)."""

@@ -150,6 +150,15 @@ int  exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank);
  * 2: the host's callback -- with the rank count / rank it was given and the number of all-reduces
  * issued so far; any output pointer may be NULL.                                                */
 int  exp_amd_comm_info(exp_amd_ctx *ctx, int *kind, int *nranks, int *rank, long long *calls);
+/* 2 when the context can reduce on two streams at once -- a single rank, a host callback (it is handed the stream), or an
+ * RCCL communicator that could be split into a second one for the auxiliary stream (ncclCommSplit) -- and the
+ * two-component step driver therefore keeps its two-stream schedule with several ranks; 1 otherwise.            */
+int  exp_amd_comm_streams(exp_amd_ctx *ctx);
+/* MAX over the ranks of one HOST number through the same transport (a sum of one-hot slots): for host logic that must
+ * agree on a count before it issues collectives (e.g. how many batches a reader is cut into, each ending in one
+ * all-reduce).  Single-rank contexts return at once; a callback context that was never told its world is
+ * EXP_AMD_ERR_COMM.                                                                             */
+int  exp_amd_comm_allreduce_max(exp_amd_ctx *ctx, double *value);
 /* The collective itself: in-place sum over the ranks of `count` doubles at DEVICE pointer `buf`, on
  * the context's stream (what replaces MPI_Allreduce, src/SphericalBasis.cc:864-903), so that a host
  * can verify the communicator it has just set up.                                               */

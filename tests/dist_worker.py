@@ -75,7 +75,39 @@ def main():
     sim.step(1)
     d3 = c.download(("pos", "vel"))
     np.savez(out.replace(".npz", "_bal.npz"), idx=idx, lev0=lev0, lev=c.download_levels(), coef=f.get_coefs(), **d3)
-    sim.close(); c.close(); f.close(); ctx.close()
+    sim.close(); c.close(); f.close()
+    # ---- the two-component run (BASELINE config 4 in miniature: sphereSL halo + cylinder disk, both self forces and both
+    # cross forces, block multistep) with BOTH components sharded over the ranks by shard_indices: every rank holds ~1/world of
+    # every level of each; the cylinder's cos / sin sets and its in-cut mass ride one all-reduce (exputil/EmpCylSL.cc:
+    # 4355-4550 uses two, src/Cylinder.cc:1081-1098 two more).  With a callback the step driver keeps its two-stream
+    # schedule (the callback is handed each stream); EXP_AMD_SIM_OVERLAP=0 in the environment runs the one-stream one.
+    from exp_amd.runtime import Cylinder
+    from tests import config4_util as c4
+    inp = c4.config4_inputs(n_halo=600, n_disk=600)
+    gs, cg = c4.grids()
+    ms, dtime = 3, 2.5e-4
+    ih, idk = shard_indices(600, rank, world), shard_indices(600, rank, world)
+    fh = SphereSL(ctx, gs, multistep=ms, **c4.sph_window(gs, float(inp["scale"])))
+    fd = Cylinder(ctx, cg, multistep=ms)
+    ch = Component.from_arrays(ctx, inp["halo_mass"][ih], inp["halo_pos"][ih], inp["halo_vel"][ih])
+    cd = Component.from_arrays(ctx, inp["disk_mass"][idk], inp["disk_pos"][idk], inp["disk_vel"][idk])
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=c4.DYN, shiftlevl=0)
+    k1, k2 = sim.add_component(ch, fh), sim.add_component(cd, fd)
+    sim.add_interaction(k1, k2)
+    sim.add_interaction(k2, k1)
+    sim.init()
+    lev0 = (ch.download_levels(), cd.download_levels())
+    sim.step(2)
+    dh, dd = ch.download(("pos", "vel", "acc", "pot")), cd.download(("pos", "vel", "acc", "pot"))
+    gc = fd.get_coefs()
+    np.savez(out.replace(".npz", "_c4.npz"), ih=ih, idk=idk, lev0_h=lev0[0], lev0_d=lev0[1], lev_h=ch.download_levels(),
+             lev_d=cd.download_levels(), coef_h=fh.get_coefs(), coef_dc=gc[0], coef_ds=gc[1], cylmass=fd.cylmass,
+             used_h=fh.Used(), used_d=fd.Used(), switches=sim.step_switches, calls=ctx.comm_info()["allreduce_calls"],
+             **{"h_" + k: v for k, v in dh.items()}, **{"d_" + k: v for k, v in dd.items()})
+    sim.close()
+    for o in (ch, cd, fh, fd):
+        o.close()
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -16,15 +16,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, tmp_path, port):
-    outs = [str(tmp_path / f"w{world}_r{r}.npz") for r in range(world)]
+def _run(world, tmp_path, port, env=None, tag=""):
+    outs = [str(tmp_path / f"w{world}{tag}_r{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r),
-                               str(world), str(port), outs[r]], cwd=ROOT,
+                               str(world), str(port), outs[r]], cwd=ROOT, env=dict(os.environ, **(env or {})),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
+    _run.c4 = [np.load(o.replace(".npz", "_c4.npz")) for o in outs]
     return ([np.load(o) for o in outs], [np.load(o.replace(".npz", "_ms.npz")) for o in outs],
             [np.load(o.replace(".npz", "_bal.npz")) for o in outs])
 
@@ -84,3 +85,49 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_run(tmp_path):
     assert (lev0 != one_bal["lev0"]).mean() < 1e-3 and (lev1 != one_bal["lev"]).mean() < 2e-3
     same = (lev0 == one_bal["lev0"]) & (lev1 == one_bal["lev"])
     assert np.abs(posb - one_bal["pos"])[same].max() <= 1e-8 * np.abs(one_bal["pos"]).max()
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_sharded_two_component_run_reproduces_the_single_rank_run(tmp_path, overlap):
+    """Cylinder + sphere, both cross forces, block multistep 3, each component sharded over two ranks by shard_indices
+    (tests/dist_worker.py): the cylinder's cos / sin sets and in-cut mass, the halo's sets and both used counts are
+    all-reduced; levels after begin_run and after two master steps, trajectories, accelerations and the combined sets must
+    be the single-rank run's.  overlap = 1: the step driver keeps its two-stream schedule with several ranks (the callback
+    is handed each stream); 0: the one-stream schedule (EXP_AMD_SIM_OVERLAP=0)."""
+    env = {"EXP_AMD_SIM_OVERLAP": overlap}
+    port = 29900 + (os.getpid() % 400) + (7 if overlap == "0" else 0)
+    _run(1, tmp_path, port, env, tag="o" + overlap)
+    (one,) = _run.c4
+    _run(2, tmp_path, port, env, tag="o" + overlap)
+    two = _run.c4
+    assert int(one["switches"]) > 0 and int(two[0]["calls"]) > 0 and int(one["calls"]) == 0
+    for name, key in (("h", "ih"), ("d", "idk")):
+        n = len(one["lev_" + name])
+        full = {k: np.empty_like(one[k]) for k in (f"lev0_{name}", f"lev_{name}", f"{name}_pos", f"{name}_vel", f"{name}_acc",
+                                                    f"{name}_pot")}
+        seen = np.zeros(n, dtype=bool)
+        for r in two:
+            idx = r[key]
+            seen[idx] = True
+            for k in full:
+                full[k][idx] = r[k]
+        assert seen.all()
+        # every rank holds about half of every populated level
+        pop = np.bincount(one["lev_" + name], minlength=4)
+        for r in two:
+            mine = np.bincount(r["lev_" + name], minlength=4)
+            assert all(abs(mine[L] - pop[L] / 2) <= max(6, 0.2 * pop[L]) for L in range(4)), (name, mine, pop)
+        assert np.array_equal(full[f"lev0_{name}"], one[f"lev0_{name}"]), name
+        same = full[f"lev_{name}"] == one[f"lev_{name}"]
+        assert same.mean() > 0.995, name                     # (a borderline time step may flip on the rounding of the sums)
+        assert np.abs(full[f"{name}_pos"] - one[f"{name}_pos"])[same].max() <= 1e-10
+        for k in ("vel", "acc", "pot"):
+            a, b = full[f"{name}_{k}"][same], one[f"{name}_{k}"][same]
+            assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), (name, k)
+    for r in two:
+        for k in ("coef_h", "coef_dc", "coef_ds"):
+            assert np.abs(r[k] - one[k]).max() <= 1e-8 * np.abs(one[k]).max(), k
+        assert float(r["cylmass"]) == pytest.approx(float(one["cylmass"]), rel=1e-12)
+    # (the sphere's used count is this rank's; the cylinder's rides the all-reduce with its in-cut mass)
+    assert int(two[0]["used_h"]) + int(two[1]["used_h"]) == int(one["used_h"])
+    assert int(two[0]["used_d"]) in (int(one["used_d"]), int(one["used_d"]) - int(two[1]["used_d"]))

@@ -199,3 +199,46 @@ def test_graph_replay_sees_changes_made_between_calls():
     eager, replay = run(False), run(True)
     for k in ("pos", "vel", "acc", "pot", "coef"):
         assert np.array_equal(eager[k], replay[k]), k
+
+
+def _two_component_run(with_rccl):
+    """the disk + halo miniature through the step driver (two streams)"""
+    from exp_amd.runtime import Component, Context, Cylinder, Simulation, SphereSL
+    from tests import config4_util as c4
+    ctx = Context(0)
+    if with_rccl:
+        ctx.init_rccl(Context.rccl_unique_id(), 1, 0)
+        assert ctx.comm_info()["streams"] == 2          # ncclCommSplit gave the auxiliary stream its own communicator
+    inp = c4.config4_inputs(n_halo=500, n_disk=500)
+    g, cg = c4.grids()
+    fh = SphereSL(ctx, g, multistep=3, **c4.sph_window(g, float(inp["scale"])))
+    fd = Cylinder(ctx, cg, multistep=3)
+    ch = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    cd = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    sim = Simulation(ctx, 2.5e-4, multistep=3, dynfrac=c4.DYN)
+    k1, k2 = sim.add_component(ch, fh), sim.add_component(cd, fd)
+    sim.add_interaction(k1, k2)
+    sim.add_interaction(k2, k1)
+    sim.init()
+    sim.step(2)
+    out = dict(h=ch.download(), d=cd.download(), lh=ch.download_levels(), ld=cd.download_levels(),
+               calls=ctx.comm_info()["allreduce_calls"], switches=sim.step_switches)
+    sim.close()
+    for o in (ch, cd, fh, fd):
+        o.close()
+    ctx.close()
+    return out
+
+
+def test_two_stream_step_driver_with_a_communicator_per_stream():
+    """With an RCCL communicator the two-component step driver keeps its two-stream schedule: the auxiliary stream's
+    collectives go through a second communicator split from the first (exp_amd/csrc/context.hip:
+    expamd_comm_two_streams).  One rank: the sums over one rank leave every result what it is without a communicator, to
+    the order of the atomics."""
+    ref, got = _two_component_run(False), _two_component_run(True)
+    assert ref["calls"] == 0 and got["calls"] > 2 * 2 * 8 and ref["switches"] > 0
+    assert np.array_equal(ref["lh"], got["lh"]) and np.array_equal(ref["ld"], got["ld"])
+    for comp in ("h", "d"):
+        assert np.abs(ref[comp]["pos"] - got[comp]["pos"]).max() <= 1e-12
+        for k in ("vel", "acc", "pot"):
+            assert np.abs(ref[comp][k] - got[comp][k]).max() <= 1e-10 * np.abs(ref[comp][k]).max(), (comp, k)
