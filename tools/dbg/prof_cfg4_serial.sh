@@ -1,11 +1,11 @@
 #!/bin/bash
 # config 4 on ONE stream (EXP_AMD_SIM_OVERLAP=0) under rocprofv3: every kernel's own duration, nothing beside it
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_cfg4_serial
+OUT=$REPO/gpurun_out/prof_cfg4_serial$TAG       # TAG=_x ./prof_cfg4_serial.sh --xlist-min -1: extra arguments go to bench_configs.py
 rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 export EXP_AMD_SIM_OVERLAP=0
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/tools/bench_configs.py --only 4 --steps 30 > $OUT/log.txt 2>&1
-python3 - $OUT <<'PY'
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/tools/bench_configs.py --only 4 --steps 30 "$@" > $OUT/log.txt 2>&1
+python3 - $OUT > $OUT/serial.txt <<'PY'
 import csv, glob, sys
 rows=[]
 for p in glob.glob(sys.argv[1]+"/*/*_kernel_trace.csv"):
