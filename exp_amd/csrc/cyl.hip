@@ -57,7 +57,7 @@ extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cf
   C.inv_dx = 1.0 / cfg->dx; C.inv_dy = 1.0 / cfg->dy;
   C.umass = 0.0;
   C.mscale = 1.0;
-  C.frz = 0;
+  C.frz = nullptr;
   C.rmax2 = cfg->rcylmax * cfg->rcylmax * cfg->ascale * cfg->ascale;   // src/Cylinder.cc:752
   C.cx = C.cy = C.cz = 0.0;
   *out = f;

@@ -33,20 +33,21 @@ struct CylDev {
   double mscale;    // Component::Adiabatic() of the basis' component at the time of the call: multiplies every mass the
                     // accumulation and the differencing read (src/Cylinder.cc:834, :1758; exp_amd_force_set_mass_scale)
   // Component::freeze (src/Component.cc:4194-4202) of the component whose particles the launch walks (the source of an
-  // accumulation, the TARGET of a force pass: src/Cylinder.cc:788, :842, :1329, :1756).  frz == 0: rtrunc not set
-  int frz;
-  double frz_c0[3], frz_c[3], frz_r2;
+  // accumulation, the TARGET of a force pass: src/Cylinder.cc:788, :842, :1329, :1756): {com0[3], center[3], rtrunc^2} in
+  // device memory (exp_amd_comp::d_frz; behind a pointer: see SphDev), nullptr: rtrunc not set
+  const double *frz;
 };
 
 // Component::freeze, in the reference's operation order: r2 = sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2
 __device__ __forceinline__ bool cyl_frozen(const CylDev &C, double px, double py, double pz)
 {
   if (!C.frz) return false;
-  const double dx = (px - C.frz_c0[0]) - C.frz_c[0], dy = (py - C.frz_c0[1]) - C.frz_c[1], dz = (pz - C.frz_c0[2]) - C.frz_c[2];
+  const double *F = C.frz;
+  const double dx = (px - F[0]) - F[3], dy = (py - F[1]) - F[4], dz = (pz - F[2]) - F[5];
   double r2 = dx * dx;
   r2 = mul_then_add(r2, dy, dy);
   r2 = mul_then_add(r2, dz, dz);
-  return r2 > C.frz_r2;
+  return r2 > F[6];
 }
 
 // centred, then rotated into the body frame

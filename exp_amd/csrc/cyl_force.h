@@ -96,9 +96,7 @@ static inline CylDev cdev_for(const CylForce *f, const exp_amd_comp *c)
 // Component::freeze of the component whose particles a launch walks (the source of an accumulation, the target of a force)
 static inline void cdev_freeze(CylDev &C, const exp_amd_comp *c)
 {
-  C.frz = c->freeze_on ? 1 : 0;
-  for (int k = 0; k < 3; k++) { C.frz_c0[k] = c->com0[k]; C.frz_c[k] = c->center[k]; }
-  C.frz_r2 = c->rtrunc * c->rtrunc;
+  C.frz = expamd_comp_frz(c);
 }
 
 // ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding

@@ -50,6 +50,9 @@ struct exp_amd_comp {
   // (exp_amd_comp_set_rtrunc; freeze_on == false: the default rtrunc of 1e20)
   bool freeze_on = false;
   double rtrunc = 1.0e20, com0[3] = {0, 0, 0};
+  DevBuf<double> d_frz;                         // {com0[3], center[3], rtrunc^2} for the kernels (expamd_comp_frz)
+  double frz_host[7] = {0, 0, 0, 0, 0, 0, 0};
+  bool frz_valid = false;
   bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
   double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   PseudoDev pseudo = {0, 0, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // frame acceleration subtracted by the forces
@@ -154,3 +157,7 @@ int expamd_comp_apply_pending(exp_amd_comp *c);
 // ... a read-only look at the step-boundary velocities that does not change the stored state: *back = 0 (velocities
 // are current, a closing half-kick owed has been applied) or the (negative) dt with which v + a * dt is the value
 int expamd_comp_velocity_view(exp_amd_comp *c, double *back);
+
+// device copy of the freeze parameters of `c` ({com0, center, rtrunc^2}; nullptr when rtrunc is not set), kept current by
+// exp_amd_comp_set_rtrunc / exp_amd_comp_set_center
+const double *expamd_comp_frz(const exp_amd_comp *c);

@@ -992,6 +992,7 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
     c->id[w].release();
     c->level[w].release();
   }
+  c->d_frz.release();
   c->key.release();
   c->newlev.release();
   c->nswitch.release();
@@ -1273,12 +1274,31 @@ extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
   return EXP_AMD_OK;
 }
 
+static int comp_frz_refresh(exp_amd_comp *c);
 extern "C" int exp_amd_comp_set_center(exp_amd_comp *c, const double center[3])
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
   if (!c || !center) return EXP_AMD_ERR_ARG;
   for (int k = 0; k < 3; k++) c->center[k] = center[k];
   c->sorted_for = nullptr;
+  return comp_frz_refresh(c);
+}
+
+const double *expamd_comp_frz(const exp_amd_comp *c) { return c->freeze_on ? c->d_frz.p : nullptr; }
+
+// {com0, center, rtrunc^2} of Component::freeze to the device (called by the two setters that change them: rare -- the key is
+// set once, the centre moves with an orientation estimator; ordered with every stream by being synchronous)
+static int comp_frz_refresh(exp_amd_comp *c)
+{
+  if (!c->freeze_on) return EXP_AMD_OK;
+  exp_amd_ctx *ctx = c->ctx;
+  const double want[7] = {c->com0[0], c->com0[1], c->com0[2], c->center[0], c->center[1], c->center[2], c->rtrunc * c->rtrunc};
+  if (!c->d_frz.p) HIP_TRY(ctx, c->d_frz.alloc(8));
+  if (c->frz_valid && memcmp(want, c->frz_host, sizeof(want)) == 0) return EXP_AMD_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(c->d_frz.p, want, sizeof(want), hipMemcpyHostToDevice));
+  memcpy(c->frz_host, want, sizeof(want));
+  c->frz_valid = true;
   return EXP_AMD_OK;
 }
 
@@ -1290,7 +1310,7 @@ extern "C" int exp_amd_comp_set_rtrunc(exp_amd_comp *c, double rtrunc, const dou
   c->rtrunc = rtrunc;
   for (int k = 0; k < 3; k++) c->com0[k] = com0 ? com0[k] : 0.0;
   c->freeze_on = rtrunc < 1.0e20;
-  return EXP_AMD_OK;
+  return comp_frz_refresh(c);
 }
 
 extern "C" int exp_amd_comp_get_center(const exp_amd_comp *c, double center[3])

@@ -26,6 +26,20 @@
 #define SCAT_TILE (SORT_TPB * SCAT_ITEMS)
 #define SORT_WIN 4096          // LDS histogram window (bins) above the block's minimum key
 
+// A/B switch of the scatter pass (tools/build_variant_tu.sh <suffix> particles "-DSCAT_NT=n"): bit 0 = non-temporal stores of
+// the scattered streams, bit 1 = non-temporal loads of the streams read once.  profiles/r05_scatter_ab.txt
+#ifndef SCAT_NT
+#define SCAT_NT 0
+#endif
+template <class T> __device__ __forceinline__ void scat_store(T *p, T v)
+{
+  if constexpr ((SCAT_NT & 1) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <class T> __device__ __forceinline__ T scat_load(const T *p)
+{
+  if constexpr ((SCAT_NT & 2) != 0) return __builtin_nontemporal_load(p); else return *p;
+}
+
 struct AdvanceArgs {
   const double *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az;
   const uint8_t *lev;
@@ -52,14 +66,14 @@ __device__ __forceinline__ double level_dt(double dt_min, int multistep, int lev
 __device__ __forceinline__ void advance_one(const AdvanceArgs &A, size_t i, double &x, double &y,
                                             double &z, double &vx, double &vy, double &vz)
 {
-  x = A.x[i]; y = A.y[i]; z = A.z[i];
+  x = scat_load(A.x + i); y = scat_load(A.y + i); z = scat_load(A.z + i);
   if (A.advance == 2 && (int)A.lev[i] < A.lev_lo) {       // inactive level: carried through as it is
     vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
     return;
   }
   if (A.advance) {
     // src/incvel.cc:15-88 then src/incpos.cc:15-69, same roundings as k_kick / k_drift
-    vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i];
+    vx = scat_load(A.vx + i); vy = scat_load(A.vy + i); vz = scat_load(A.vz + i);
     double dtk = A.dt_kick, dtd = A.dt_drift;
     if (A.advance == 2) {
       dtd = level_dt(A.dt_min, A.multistep, A.lev[i]);
@@ -289,10 +303,10 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
     double x, y, z, vx = 0, vy = 0, vz = 0;
     advance_one(A, i, x, y, z, vx, vy, vz);
     if (!A.advance) { vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i]; }
-    D.x[dest] = x; D.y[dest] = y; D.z[dest] = z;
-    D.vx[dest] = vx; D.vy[dest] = vy; D.vz[dest] = vz;
+    scat_store(D.x + dest, x); scat_store(D.y + dest, y); scat_store(D.z + dest, z);
+    scat_store(D.vx + dest, vx); scat_store(D.vy + dest, vy); scat_store(D.vz + dest, vz);
     if (D.m) D.m[dest] = S.m[i];            // nullptr: uniform mass, both buffer sets hold it already
-    D.id[dest] = S.id[i];
+    scat_store(D.id + dest, scat_load(S.id + i));
     if (D.lev) D.lev[dest] = A.lev[i];     // nullptr: every level is 0 and stays 0 (single-level runs)
     if (MOVE_ACC) {
       D.ax[dest] = S.ax[i]; D.ay[dest] = S.ay[i]; D.az[dest] = S.az[i]; D.pot[dest] = S.pot[i];

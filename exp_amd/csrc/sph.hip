@@ -385,7 +385,7 @@ extern "C" int exp_amd_sph_create(exp_amd_ctx *ctx, const exp_amd_sph_config *cf
   S.detC = 0.0;
   S.umass = 0.0;
   S.fac0 = -4.0 * M_PI;
-  S.frz = 0;
+  S.frz = nullptr;
   {
     // bound of a unit-mass particle's moment contribution |4 pi P0 x_k Ph(l,m)(cos theta) trig|, for the
     // rounding grid of the deterministic mode: max |p0| on the grid x max |Ph| on a fine cos(theta) grid
@@ -436,9 +436,7 @@ static SphDev dev_for(const SphForce *f, const double center[3])
 // Component::freeze of the component whose particles a launch walks (the source of an accumulation, the target of a force)
 static void dev_freeze(SphDev &S, const exp_amd_comp *c)
 {
-  S.frz = c->freeze_on ? 1 : 0;
-  for (int k = 0; k < 3; k++) { S.frz_c0[k] = c->com0[k]; S.frz_c[k] = c->center[k]; }
-  S.frz_r2 = c->rtrunc * c->rtrunc;
+  S.frz = expamd_comp_frz(c);
 }
 
 // ... for the passes that ADD particle contributions: with the deterministic mode on, the rounding

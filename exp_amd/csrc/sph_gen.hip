@@ -108,7 +108,7 @@ k_sph_upd_gen(SphDev S, const double *__restrict__ X, const double *__restrict__
   double xx = 0, yy = 0, zz = 1, mass = 0;
   if (mover) {
     xx = X[i] - S.cx; yy = Y[i] - S.cy; zz = Z[i] - S.cz; mass = M[i];
-    if (S.frz && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;
+    if (SPH_FRZ_ON(S) && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;
   }
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
   if (plain) {

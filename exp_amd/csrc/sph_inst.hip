@@ -56,11 +56,17 @@ void CAT(expamd_sph_acc_L, SPH_L)(const SphAccArgs &a)
   if (a.S.detC != 0.0)      // deterministic mode (exp_amd_ctx_set_deterministic): order-independent sums
     k_sph_accumulate<LMAX, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
                                                                         LC, a.W, a.used, a.wlevels);
+  else if (a.S.frz)         // rtrunc set (Component::freeze): the instantiation that carries the test
+    k_sph_accumulate<LMAX, false, false, true><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                                     LC, a.W, a.used, a.wlevels);
   else
-    k_sph_accumulate<LMAX, false><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
-                                                                         LC, a.W, a.used, a.wlevels);
+    k_sph_accumulate<LMAX, false, false, false><<<grid, ACC_WAVES * 64, 0, a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off,
+                                                                                      LC, a.W, a.used, a.wlevels);
 }
 
+#ifndef SPH_GENERAL_GRID
+#define SPH_GENERAL_GRID 4096u      // blocks of the general pass behind a fast pass (4 work items each per round)
+#endif
 void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
 {
   constexpr int LMAX = SPH_L;
@@ -95,9 +101,10 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
             a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
             a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
     }
-    // deferred waves / lanes: the grid is an upper bound, surplus waves leave on the count
+    // deferred waves / lanes: a fixed grid walks the work list (its length is only known on the device)
     ProfScope ps(a.ctx, "k_sph_force_general");
-    k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(
+    const unsigned ggrid = a.grid < SPH_GENERAL_GRID ? a.grid : SPH_GENERAL_GRID;
+    k_sph_force<LMAX, 0><<<ggrid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
         a.dt_kick, a.assign, a.work, a.nwork, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next);
   } else if (a.stage_rows > 0 && a.dt_kick == 0.0 && !a.key_out) {

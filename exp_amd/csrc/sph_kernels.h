@@ -54,9 +54,11 @@ struct SphDev {
                          // (src/SphericalBasis.cc:433, :441, :471; exp_amd_force_set_mass_scale): what a mass is multiplied by
   // Component::freeze (src/Component.cc:4194-4202) of the component whose particles the launch walks -- the source in an
   // accumulation, the TARGET in a force pass: beyond rtrunc of com0 + center a particle neither contributes nor is
-  // accelerated (src/SphericalBasis.cc:468, :1159, :1521).  frz == 0: rtrunc not set (the default, 1e20)
-  int frz;
-  double frz_c0[3], frz_c[3], frz_r2;
+  // accelerated (src/SphericalBasis.cc:468, :1159, :1521).  frz: {com0[3], center[3], rtrunc^2} in device memory (the
+  // component's, exp_amd_comp::d_frz), or nullptr: rtrunc not set (the default, 1e20).  Behind a pointer because this struct
+  // is a kernel argument held in scalar registers: seven more doubles there cost the accumulation 11 % in spills with the
+  // option OFF (profiles/r05_freeze_ab.txt)
+  const double *frz;
   double dsmall;         // added to r (src/expand.H:130: 1e-16; pyEXP: 1e-20 accumulating, 1e-18 evaluating)
   uint32_t key_add;      // added to every sort key produced (second half of a split store: +ncell)
   PseudoDev ps;          // frame acceleration of the TARGET component (force pass only)
@@ -266,12 +268,17 @@ __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double
 // Component::freeze, in the reference's operation order: r2 = sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2
 __device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py, double pz)
 {
+#ifdef EXPAMD_NO_FREEZE      // A/B build: what the option's code costs the passes when it is off (profiles/r05_freeze_ab.txt)
+  return false;
+#endif
+#define SPH_FRZ_ON(S) ((S).frz != nullptr)
   if (!S.frz) return false;
-  const double dx = (px - S.frz_c0[0]) - S.frz_c[0], dy = (py - S.frz_c0[1]) - S.frz_c[1], dz = (pz - S.frz_c0[2]) - S.frz_c[2];
+  const double *F = S.frz;
+  const double dx = (px - F[0]) - F[3], dy = (py - F[1]) - F[4], dz = (pz - F[2]) - F[5];
   double r2 = dx * dx;
   r2 = mul_then_add(r2, dy, dy);
   r2 = mul_then_add(r2, dz, dz);
-  return r2 > S.frz_r2;
+  return r2 > F[6];
 }
 
 // ---- accumulation ----------------------------------------------------------------------------------
@@ -405,7 +412,9 @@ typedef const __attribute__((address_space(3))) double *ldp;
 // cell_add: level * (numr-1) when several levels are accumulated in one launch (the moment buffer is
 // then W[level][cell][row][2] and the wave's "current cell" the combined index), else 0.
 // UPD: the window of the differencing, r < rmax (src/SphericalBasis.cc:1183), instead of rmin <= r <= rmax.
-template <bool UPD = false>
+// MAYFRZ = false: an instantiation without the Component::freeze test (the launcher picks it when rtrunc is not set: even
+// behind a scalar branch the test's code costs the dense accumulation 3 %, profiles/r05_freeze_ab.txt)
+template <bool UPD = false, bool MAYFRZ = true>
 __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double px,
                                                double py, double pz, double mass, bool valid,
                                                int cell_add = 0)
@@ -419,7 +428,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   sqrt_rsqrt(R2 + zz * zz, g, y);
   const double r = g + S.dsmall;
   bool inwin = UPD ? (valid && r < S.rmax) : (valid && r >= S.rmin && r <= S.rmax);
-  if (S.frz) inwin = inwin && !sph_frozen(S, px, py, pz);
+  if constexpr (MAYFRZ) { if (SPH_FRZ_ON(S)) inwin = inwin && !sph_frozen(S, px, py, pz); }
   const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
   if (R2 > 1e-12 * (r * r)) {
@@ -555,7 +564,7 @@ sph_acc_group(const SphDev &S, cdp &lc, const AccIn &in, double (&acc)[NV], int 
 
 // One wave accumulates the rows with m in [MLO, MHI] over the particle chunk [cbeg, cend), computing
 // the per-particle inputs itself.
-template <int LMAX, int MLO, int MHI, bool DET, bool LIST>
+template <int LMAX, int MLO, int MHI, bool DET, bool LIST, bool MAYFRZ = true>
 __device__ __forceinline__ void
 sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                     const double *__restrict__ Z, const double *__restrict__ M,
@@ -583,7 +592,7 @@ sph_accumulate_wave(const SphDev &S, const double *__restrict__ X, const double 
   }
   for (size_t base = cbeg; base < cend; base += 64) {
     const size_t i = base + lane;
-    const AccIn in = sph_acc_input<LIST>(S, (ldp) nullptr, nx, ny, nz, nm, LIST ? (i < cend && nca >= 0) : i < cend,
+    const AccIn in = sph_acc_input<LIST, MAYFRZ>(S, (ldp) nullptr, nx, ny, nz, nm, LIST ? (i < cend && nca >= 0) : i < cend,
                                          LIST ? nca : cell_add);
     if (i + 64 < cend) {
       if constexpr (LIST) acc_list_fetch(al, X, Y, Z, M, S.umass, i + 64, nx, ny, nz, nm, nca);
@@ -610,7 +619,7 @@ struct AccShared {
   unsigned long long used[ACC_WAVES];      // in-window counts of the four quarters, handed over at the last tile
 };
 
-template <int LMAX, int MLO, int MHI, bool DET, bool LIST>
+template <int LMAX, int MLO, int MHI, bool DET, bool LIST, bool MAYFRZ = true>
 __device__ __forceinline__ void
 sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
                       const double *__restrict__ Y, const double *__restrict__ Z,
@@ -650,7 +659,7 @@ sph_accumulate_shared(const SphDev &S, ldp p0t, const double *__restrict__ X,
     t_load += tb - ta;
 #endif
     {
-      const AccIn in = sph_acc_input<LIST>(S, p0t, nx, ny, nz, nm, LIST ? (ip < cend && nca >= 0) : ip < cend,
+      const AccIn in = sph_acc_input<LIST, MAYFRZ>(S, p0t, nx, ny, nz, nm, LIST ? (ip < cend && nca >= 0) : ip < cend,
                                            LIST ? nca : cell_add);
       if (in.idx >= 0) used++;
       const int q = wave * 64 + lane;
@@ -744,7 +753,7 @@ template <int LMAX> __host__ __device__ constexpr int acc_nsplit()
   return acc_shared<LMAX>() ? 4 : LMAX <= 4 ? 1 : LMAX <= 7 ? 2 : LMAX <= 10 ? 4 : 6;
 }
 
-template <int LMAX, bool DET, bool LIST = false>
+template <int LMAX, bool DET, bool LIST = false, bool MAYFRZ = true>
 __global__ void __launch_bounds__(ACC_WAVES * 64)
 k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                  const double *__restrict__ Z, const double *__restrict__ M,
@@ -783,7 +792,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
       __syncthreads();
     }
     ldp p0t = p0_in_lds ? (ldp)p0s : (ldp) nullptr;
-#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET, LIST>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out, al)
+#define RUNS(LO, HI) sph_accumulate_shared<LMAX, LO, HI, DET, LIST, MAYFRZ>(S, p0t, X, Y, Z, M, cell_add, cbeg, cend, scratch, sh, W, used_out, al)
     constexpr int b1 = acc_bound<LMAX>(0), b2 = acc_bound<LMAX>(1), b3 = acc_bound<LMAX>(2);
     // (two A/B experiments of round 4, profiles/r04_accumulate_split_ab.txt: other m-splits -- a 36-row wave costs the
     // second wave per SIMD, 4.5-6.3 ms --, and odd blocks taking the ranges in reverse order so that a SIMD's two waves
@@ -800,7 +809,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const size_t cbeg = beg + chunk * ACC_CHUNK;
   if (cbeg >= end) return;
   const size_t cend = (cbeg + ACC_CHUNK < end) ? cbeg + ACC_CHUNK : end;
-#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI, DET, LIST>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out, al)
+#define RUN(LO, HI) sph_accumulate_wave<LMAX, LO, HI, DET, LIST, MAYFRZ>(S, X, Y, Z, M, cell_add, cbeg, cend, scratch, W, used_out, al)
   if constexpr (LMAX <= 4) {
     RUN(0, LMAX);
   } else if constexpr (LMAX <= 7) {
@@ -861,7 +870,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
     yy = Y[i] - S.cy;
     zz = Z[i] - S.cz;
     mass = M[i];
-    if (S.frz && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;     // (:468, :1159: before anything else)
+    if (SPH_FRZ_ON(S) && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;     // (:468, :1159: before anything else)
   }
   const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
   if (plain) {
@@ -1373,7 +1382,7 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
   double pt = potl;
   // a frozen target particle is skipped by the thread body (src/SphericalBasis.cc:1521): nothing is added, the frame
   // term neither; the fused half-kick below still applies whatever other forces left in acc
-  if (S.frz && sph_frozen(S, px, py, pz)) { ax = ay = az = 0.0; pt = 0.0; }
+  if (SPH_FRZ_ON(S) && sph_frozen(S, px, py, pz)) { ax = ay = az = 0.0; pt = 0.0; }
   if (!assign) {
     ax += AX[i];
     ay += AY[i];
@@ -1612,9 +1621,20 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
     return;
   }
   if constexpr (MODE == 0) {
-    // the general pass is launched over every POSSIBLE work item and nearly all of its waves have none:
-    // they leave on the count alone, before the level offsets (two more dependent round trips) are read
-    if (work != nullptr && (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) >= *nwork) return;
+    // the general pass behind a fast pass: how many work items there are is only known on the device, so a FIXED grid
+    // walks the list (a grid over every possible item is ~4e5 blocks at 1e8 particles that find nothing and leave: 0.1 ms)
+    if (work != nullptr) {
+      const size_t nw = *nwork;
+      const size_t end_ = lev_off[lev_hi + 1];
+      for (size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += (size_t)gridDim.x * 4) {
+        const size_t base = work[SPH_WORK_STRIDE * w];
+        const unsigned long long mask = (unsigned long long)work[SPH_WORK_STRIDE * w + 1] |
+                                        ((unsigned long long)work[SPH_WORK_STRIDE * w + 2] << 32);
+        sph_force_chunk<LMAX, 0>(S, X, Y, Z, base, end_, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, work, nwork,
+                                 key_out, nk_dtk, nk_dtd, store_v, mask);
+      }
+      return;
+    }
   }
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
   if constexpr (MODE != 0) {
@@ -1628,20 +1648,10 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
                                   assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v);
     }
   } else {
-    size_t base;
-    unsigned long long mask = ~0ull;
-    if (work == nullptr) {
-      base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
-      if (base >= end) return;
-    } else {
-      const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-      if (w >= *nwork) return;
-      base = work[SPH_WORK_STRIDE * w];
-      mask = (unsigned long long)work[SPH_WORK_STRIDE * w + 1] |
-             ((unsigned long long)work[SPH_WORK_STRIDE * w + 2] << 32);
-    }
+    const size_t base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+    if (base >= end) return;
     sph_force_chunk<LMAX, 0>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
-                             assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v, mask);
+                             assign, work, nwork, key_out, nk_dtk, nk_dtd, store_v, ~0ull);
   }
 }
 
