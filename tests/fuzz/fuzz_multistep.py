@@ -24,6 +24,18 @@ ctx = Context(0)
 g, cg = c4.grids()
 
 
+def _apply(nb, io, sim, idd, comp, o):
+    """the option keys of one component on both sides"""
+    if not o:
+        return
+    nb.set_options(io, rtrunc=o.get("rtrunc"), com0=o.get("com0", (0.0, 0.0, 0.0)), adiabatic=o.get("adiabatic"),
+                   self_consistent=o.get("self_consistent", True), fix_l0=o.get("fix_l0", False), mlim=o.get("mlim"))
+    if o.get("rtrunc") is not None:
+        comp.set_rtrunc(o["rtrunc"], o.get("com0"))
+    if o.get("adiabatic") is not None:
+        sim.set_adiabatic(idd, *o["adiabatic"])
+
+
 def one(t, rng):
     ms = int(rng.integers(1, 5))
     dtime = c4.DTIME * float(rng.choice([0.3, 1.0, 2.5]))
@@ -37,6 +49,22 @@ def one(t, rng):
     dense_min, list_min = int(rng.choice([-1, 0, 50, 500])), int(rng.choice([0, 16, 2048]))
     nsteps = int(rng.integers(1, 4))
     thin_max = int(rng.choice([0, 30, 400, 16384]))           # (drawn last: the earlier draws of a (seed, trial) stay what they were)
+    # round 5, drawn after everything else: the keys that default to off -- rtrunc / com0 (Component::freeze), ton / toff /
+    # twid (Adiabatic), self_consistent: false, FIX_L0 (sphere), mlim (cylinder) -- on half of the trials
+    oh, od = {}, {}
+    if rng.random() < 0.5:
+        for o, kind in ((oh, "halo"), (od, "disk")):
+            if rng.random() < 0.5:
+                o["rtrunc"] = float(rng.choice([0.02, 0.05, 0.3] if kind == "disk" else [0.05, 0.3, 1.0]))
+                o["com0"] = tuple(float(v) for v in rng.normal(0.0, 0.003, 3))
+            if rng.random() < 0.4:
+                o["adiabatic"] = (float(rng.uniform(-1.0, 2.0)) * dtime, float(rng.choice([1e20, 2.5 * dtime])), float(rng.uniform(0.3, 2.0)) * dtime)
+            if rng.random() < 0.25:
+                o["self_consistent"] = False
+        if rng.random() < 0.3:
+            oh["fix_l0"] = True
+        if rng.random() < 0.4:
+            od["mlim"] = int(rng.integers(0, cg.mmax + 1))
     sc = float(inp["scale"])
     prm = orc.params(**c4.sph_window(g, sc))
     nb = NBodyOracle(orc, ms, dtime, dyn)
@@ -47,14 +75,18 @@ def one(t, rng):
     forces, comps, names, ids_o, ids_d = [], [], [], [], []
     if which in ("both", "halo"):
         ids_o.append(nb.add_sphere(g, prm, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"]))
-        f = SphereSL(ctx, g, multistep=ms, **c4.sph_window(g, sc))
+        f = SphereSL(ctx, g, multistep=ms, self_consistent=oh.get("self_consistent", True), FIX_L0=oh.get("fix_l0", False),
+                     **c4.sph_window(g, sc))
         c = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
         ids_d.append(sim.add_component(c, f)); forces.append(f); comps.append(c); names.append("halo")
+        _apply(nb, ids_o[-1], sim, ids_d[-1], c, oh)
     if which in ("both", "disk"):
         ids_o.append(nb.add_cylinder(cg, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"]))
-        f = Cylinder(ctx, cg, multistep=ms)
+        f = Cylinder(ctx, cg, multistep=ms, self_consistent=od.get("self_consistent", True),
+                     mlim=od["mlim"] if "mlim" in od else -1)
         c = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
         ids_d.append(sim.add_component(c, f)); forces.append(f); comps.append(c); names.append("disk")
+        _apply(nb, ids_o[-1], sim, ids_d[-1], c, od)
     if inter in ("both", "one"):
         nb.add_interaction(ids_o[0], ids_o[1]); sim.add_interaction(ids_d[0], ids_d[1])
     if inter == "both":
@@ -95,17 +127,23 @@ def one(t, rng):
                  np.abs(out["acc"] - a).max() / (1e-9 * max(np.linalg.norm(a, axis=1).max(), 1e-300)),
                  np.abs(out["pot"] - s["pot"]).max() / (1e-9 * max(np.abs(s["pot"]).max(), 1e-300))]
             cmax = max(np.abs(s["coefN"]).max(), 1e-300)
+            frozen_set = not (oh if name == "halo" else od).get("self_consistent", True)
             for M in range(ms + 1):
+                if frozen_set:      # (the per-level sets are dead once the coefficients are held fixed: the reference's sphere
+                    break           #  still differences into them, its cylinder does not, nothing reads them; the COMBINED set is compared)
                 gn = f.get_coefs(level=M)
                 gn = gn.reshape(-1) if name == "halo" else np.concatenate([x.reshape(-1) for x in gn])
                 e.append(np.abs(gn - s["coefN"][M]).max() / (1e-10 * cmax))
+            gc = f.get_coefs()
+            gc = gc.reshape(-1) if name == "halo" else np.concatenate([x.reshape(-1) for x in gc])
+            e.append(np.abs(gc - s["coef"]).max() / (1e-10 * max(np.abs(s["coef"]).max(), 1e-300)))
             if max(e) > 1.0 or not np.isfinite(max(e)):
                 status, detail = "STATE", f"step {k} {name}: worst ratio to tolerance {max(e):.2g} ({np.round(e, 2).tolist()})"
                 break
         if status != "ok":
             break
     print(f"{t:3d} ms {ms} dtime {dtime:.2e} n {nh}/{nd} {which} inter {inter} dense_min {dense_min} list_min {list_min} thin_max {thin_max} steps {nsteps}: "
-          f"{status} {detail} [{switches} level changes, populated levels "
+          f"{'opts ' + str(oh) + ' ' + str(od) + ' ' if (oh or od) else ''}{status} {detail} [{switches} level changes, populated levels "
           f"{[int((np.bincount(st['level'], minlength=ms + 1) > 0).sum()) for st in nb.state]}]", flush=True)
     global total_switches
     total_switches += switches
