@@ -191,6 +191,17 @@ __device__ __forceinline__ void pseudo_accel(const PseudoDev &P, double x, doubl
 #endif
 
 #if defined(__HIPCC__)
+// cos(phi), sin(phi) of phi = atan2(y, x) for x = y = 0 -- a particle exactly on the axis -- as the reference's libm sees
+// them: atan2(+-0, +0) = +-0, atan2(+-0, -0) = +-pi (cos = -1, sin = +-1.22e-16: sin of the double next to pi).  The
+// sign of a zero x is the sign of the odd-m terms there (src/SphericalBasis.cc:1548, src/Cylinder.cc:1333; they do not
+// vanish on the axis: the sphere's P_l^1 sees |cos(theta)| = 1 - 1 ulp, the disk's tables are extrapolated below rmin).
+__device__ __forceinline__ void atan2_trig_zero(double xx, double yy, double &c, double &s)
+{
+  const bool neg = __builtin_signbit(xx);
+  c = neg ? -1.0 : 1.0;
+  s = neg ? __builtin_copysign(1.2246467991473532e-16, yy) : yy;
+}
+
 __device__ __forceinline__ double mul_then_add(double x, double a, double b)
 {
   double t = a * b;

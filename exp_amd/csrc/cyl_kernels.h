@@ -226,8 +226,9 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
     double c00, c10, c01, c11;
     cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
     const int cell = ix * C.numy + iy + plv * ncellT;
-    double cphi = 1.0, sphi = 0.0;                          // phi = atan2(y, x)
+    double cphi, sphi;                          // phi = atan2(y, x)
     if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+    else atan2_trig_zero(xx, yy, cphi, sphi);
     const double t0 = ongrid ? norm * mass : 0.0;
 #ifdef EXPT_TIMING
     asm volatile("" :: "v"(t0), "v"(c00), "v"(c11), "v"(cphi), "v"(sphi));
@@ -440,8 +441,9 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
     double c00, c10, c01, c11;
     cyl_weights(C, r, zc, ix, iy, c00, c10, c01, c11);
     const int cell = ix * C.numy + iy + plv * ncellT;
-    double cphi = 1.0, sphi = 0.0;
+    double cphi, sphi;
     if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+    else atan2_trig_zero(xx, yy, cphi, sphi);
     const double t0 = ongrid ? norm * mass : 0.0;
 #if CSLOT_EXPT == 2        // timing experiment: stream + per-particle inputs, no LDS, no sums
     mass_used += t0 * (c00 + c10 + c01 + c11) + cphi + sphi + (double)cell; continue;
@@ -594,8 +596,9 @@ k_cyl_mstep_update(CylDev C, const double *__restrict__ X, const double *__restr
   int ix, iy;
   double cw[4];
   cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
-  double cphi = 1.0, sphi = 0.0;
+  double cphi, sphi;
   if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+  else atan2_trig_zero(xx, yy, cphi, sphi);
   const double t0 = mover ? -4.0 * M_PI * mass : 0.0;
   const int nyp = C.numy + 1;
   const size_t nnode = (size_t)(C.numx + 1) * nyp;
@@ -992,8 +995,9 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
   sqrt_rsqrt(r2, rp, irp);
   sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
   const double r = rp + DSMALL;
-  double cphi = 1.0, sphi = 0.0;
+  double cphi, sphi;
   if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+  else atan2_trig_zero(xx, yy, cphi, sphi);
   const double ratio = r3s * C.inv_rtab_abs;              // sqrt((r^2 + z^2) / (ascale rtable)^2)
   double frac = 1.0, cfrac = 0.0;
   if constexpr (TAIL) {
@@ -1209,8 +1213,9 @@ k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restric
     sqrt_rsqrt(r2, rp, irp);
     sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
     const double r = rp + DSMALL;
-    double cphi = 1.0, sphi = 0.0;
+    double cphi, sphi;
     if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+    else atan2_trig_zero(xx, yy, cphi, sphi);
     const double ratio = r3s * C.inv_rtab_abs;
     double frac, cfrac;
     if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }
@@ -1342,8 +1347,9 @@ k_cyl_acc_thin(CylDev C, const double *__restrict__ X, const double *__restrict_
       int ix, iy;
       double cw[4];
       cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
-      double cphi = 1.0, sphi = 0.0;
+      double cphi, sphi;
       if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      else atan2_trig_zero(xx, yy, cphi, sphi);
       const double t0 = on ? -4.0 * M_PI * mass : 0.0;
       if (t < tpa) {
         int lv = lo;
@@ -1472,8 +1478,9 @@ k_cyl_diff_thin(CylDev C, const double *__restrict__ X, const double *__restrict
       int ix, iy;
       double cw[4];
       cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
-      double cphi = 1.0, sphi = 0.0;
+      double cphi, sphi;
       if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      else atan2_trig_zero(xx, yy, cphi, sphi);
       const double t0 = on ? -4.0 * M_PI * mass : 0.0;
       s_node[t] = on ? ix * nyp + iy : -1;
       s_to[t] = on ? to : -1;
@@ -1567,8 +1574,9 @@ k_cyl_force_wave(CylDev C, const double *__restrict__ X, const double *__restric
     sqrt_rsqrt(r2, rp, irp);
     sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
     const double r = rp + DSMALL;
-    double cphi = 1.0, sphi = 0.0;
+    double cphi, sphi;
     if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+    else atan2_trig_zero(xx, yy, cphi, sphi);
     const double ratio = r3s * C.inv_rtab_abs;
     const bool ongrid = ratio < 1.0 && !(r3s > C.rtab_abs);
     double op = 0.0, ofr = 0.0, ofz = 0.0, ofp = 0.0;
@@ -1684,8 +1692,9 @@ k_cyl_acc_tile(CylDev C, const double *__restrict__ X, const double *__restrict_
       int ix, iy;
       double cw[4];
       cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
-      double cphi = 1.0, sphi = 0.0;
+      double cphi, sphi;
       if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+      else atan2_trig_zero(xx, yy, cphi, sphi);
       const double t0 = on ? -4.0 * M_PI * mass : 0.0;
       int lv = lo;
       while (lv < hi && i >= lev_off[lv + 1]) lv++;
@@ -1823,8 +1832,9 @@ k_cyl_moments_gen(CylDev C, const double *__restrict__ X, const double *__restri
   int ix, iy;
   double cw[4];
   cyl_weights(C, r, zc, ix, iy, cw[0], cw[1], cw[2], cw[3]);
-  double cphi = 1.0, sphi = 0.0;
+  double cphi, sphi;
   if (r2 > 0.0) { cphi = xx * ir; sphi = yy * ir; }
+  else atan2_trig_zero(xx, yy, cphi, sphi);
   const double t0 = mover ? -4.0 * M_PI * mass : 0.0;
   const int nyp = C.numy + 1;
   const size_t nnode = (size_t)(C.numx + 1) * nyp;
@@ -1875,8 +1885,9 @@ k_cyl_force_gen(CylDev C, const double *__restrict__ X, const double *__restrict
   sqrt_rsqrt(r2, rp, irp);
   sqrt_rsqrt(r2 + zz * zz, r3s, ir3s);
   const double r = rp + DSMALL;
-  double cphi = 1.0, sphi = 0.0;
+  double cphi, sphi;
   if (r2 > 0.0) { cphi = xx * irp; sphi = yy * irp; }
+  else atan2_trig_zero(xx, yy, cphi, sphi);
   const double ratio = r3s * C.inv_rtab_abs;
   double frac, cfrac;
   if (ratio >= 1.0) { frac = 0.0; cfrac = 1.0; }

@@ -422,7 +422,7 @@ void SphForce::release()
   d_ev.release(); d_d0.release(); d_Gd.release();
   d_wscale.release();
   expamd_sph_cov_release(this);
-  d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release();
+  d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release(); d_xwork.release();
   d_Wd.release(); d_differ.release();
 }
 
@@ -932,6 +932,19 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
       int rows = (int)(40960 / ((size_t)tqs * sizeof(double)));
       a.stage_rows = rows > 24 ? 24 : rows < 4 ? 4 : rows;
       a.stage_rows = (int)EXPAMD_EXPT("EXP_AMD_STAGE_ROWS", a.stage_rows);
+      // the lanes that kernel leaves to the general pass (polar axis, beyond rmax): a wave and its lane mask per entry
+      if (f->xwork_cap < need) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, f->d_xwork.alloc(SPH_WORK_STRIDE * need + 2));
+        HIP_TRY(ctx, hipMemsetAsync(f->d_xwork.p + SPH_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), ctx->stream));
+        f->xwork_cap = need;
+        f->xwork_flip = 0;
+      }
+      uint32_t *xcnt = f->d_xwork.p + SPH_WORK_STRIDE * f->xwork_cap;
+      a.work = f->d_xwork.p;
+      a.nwork = xcnt + f->xwork_flip;
+      a.nwork_next = xcnt + (1 - f->xwork_flip);
+      if (a.stage_rows > 0 && dt_kick == 0.0 && !prekey) f->xwork_flip ^= 1;      // (the launcher's own condition for that kernel)
     }
     sph_launch_force(f, a);
     if (!slow) f->work_flip ^= 1;

@@ -43,10 +43,10 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
     if (coord == 1) { R = c1[i]; z = c2[i]; phi = c3[i]; }
     else {
       x = c1[i]; y = c2[i]; z = c3[i];
-      R = sqrt(x * x + y * y) + 1.0e-18;
-      phi = atan2(y, x);
-    }
-    r = sqrt(R * R + z * z) + 1.0e-18;
+      R = sqrt(sq_sum2_lit(x, y)) + 1.0e-18;           // (every product rounded on its own, as the reference's compiler
+      phi = atan2(y, x);                                //  forms them: near the polar axis an ulp of r decides cos(theta),
+    }                                                   //  see sq_sum2_lit, sph_kernels.h)
+    r = sqrt(sq_sum2_lit(R, z)) + 1.0e-18;
     costh = z / r;
   }
   // ---- radial tables: get_dens / get_pot / get_force (exputil/SLGridMP2.cc:872-989) ----
@@ -67,8 +67,10 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
   // ---- angular part: normalised Legendre functions and their x-derivative ----
   double xc = costh;                                   // pole clamp of the derivative (:1109-1112)
   if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-  const double dfac = 1.0 / (xc * xc - 1.0);
+  const double dfac = 1.0 / sq_add_lit(-1.0, xc);
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  const bool polar = 1.0 - fabs(costh) < SPH_POLAR_FAC;         // the m = 0 derivative by the reference's own recurrence
+  double lp1 = 0.0, lp2 = 0.0;                                  // (leg0_lit_step, sph_kernels.h)
   double den0 = 0.0, pot0 = 0.0, potr = 0.0, den1 = 0.0, pot1 = 0.0, pott = 0.0, potp = 0.0;
   double pmm = 0.0;
   for (int m = 0; m <= L; m++) {
@@ -83,6 +85,11 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
       else {
         plm = (l == m + 1) ? q[0] * (costh * pl1) : q[0] * (costh * pl1) - q[1] * pl2;
         dplm = dfac * ((xc * l) * plm - q[2] * pl1);
+      }
+      if (m == 0 && polar) {
+        double ql;
+        leg0_lit_step(l, costh, xc, lp1, lp2, ql);
+        dplm = dfac * (ql * (plm / lp1));
       }
       pl2 = pl1;
       pl1 = plm;
@@ -117,7 +124,9 @@ k_sph_fields(SphDev S, const double *__restrict__ G, const double *__restrict__ 
       }
     }
   }
-  const double sinth = sqrt(fabs(1.0 - costh * costh));
+  double cc = costh * costh;
+  asm volatile("" : "+v"(cc));                          // (rounded before the subtraction, expui/BiorthBasis.cc:726)
+  const double sinth = sqrt(fabs(1.0 - cc));
   const double densfac = 1.0 / (S.scale * S.scale * S.scale) * 0.25 / M_PI;
   const double potlfac = 1.0 / S.scale;
   double v[9] = {den0 * densfac, den1 * densfac, (den0 + den1) * densfac,

@@ -29,6 +29,11 @@ struct SphForce : exp_amd_force {
   size_t work_cap = 0;
   double term_max = 0.0;            // max |P0| x max |Ph(l,m)| x 4 pi x 2: bound of one unit-mass contribution
   int work_flip = 0;                // which of the two work-list counters the next fast pass counts into
+  // ... the same for the staged evaluation of ANOTHER component's particles (its special lanes): a list of its own, because
+  // that launch may run on the target's stream beside this force's self evaluation
+  DevBuf<uint32_t> d_xwork;
+  size_t xwork_cap = 0;
+  int xwork_flip = 0;
   // PotAccel::used of a multistep run: the counts of every level accumulated while tnow == resetT,
   // i.e. during the first sub-step of a master step (src/SphericalBasis.cc:796, :860-862, :1004-1010);
   // d_used[0] is what Used() reports, d_used[1] takes the counts of the later accumulations

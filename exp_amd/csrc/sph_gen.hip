@@ -110,7 +110,7 @@ k_sph_upd_gen(SphDev S, const double *__restrict__ X, const double *__restrict__
     xx = X[i] - S.cx; yy = Y[i] - S.cy; zz = Z[i] - S.cz; mass = M[i];
     if (SPH_FRZ_ON(S) && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;
   }
-  const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  const double r = sqrt(sq_add_lit(sq_sum2_lit(xx, yy), zz)) + DSMALL;       // (every product rounded on its own: sq_sum2_lit)
   if (plain) {
     if (!(r >= S.rmin && r <= S.rmax)) mover = false;
     const unsigned long long in = __ballot(mover);
@@ -180,6 +180,8 @@ sph_field_gen(const SphDev &S, double costh, double xc, double cphi, double sphi
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
   double pmm = S.gen_e[0];
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
+  const bool clamped = 1.0 - fabs(costh) < SPH_POLAR_FAC;      // (see leg0_lit_step, sph_kernels.h)
+  double lp1 = 0.0, lp2 = 0.0;
   int qb = 0;                                          // first slot of this m (gen_t4_base)
   for (int m = 0; m <= L; m++) {
     if (m == 1) { pmm *= S.gen_e[1] * somx2; cm = cphi; sm = sphi; }
@@ -206,6 +208,11 @@ sph_field_gen(const SphDev &S, double costh, double xc, double cphi, double sphi
       tprev = costh * plm;
       if (l == m) qlm = (xc * plm) * l;
       else qlm = fma((double)l, xc * plm, -(ac[1] * pl1));
+      if (m == 0 && clamped) {          // (leg0_lit_step, sph_kernels.h: the reference's own m = 0 recurrence near the poles)
+        double ql;
+        leg0_lit_step(l, costh, xc, lp1, lp2, ql);
+        qlm = ql * (plm / lp1);
+      }
       pl2 = pl1;
       pl1 = plm;
       const int slot = qb + (m == 0 ? (l - m) : 2 * (l - m));
@@ -262,8 +269,8 @@ k_sph_force_gen(SphDev S, const double *__restrict__ X, const double *__restrict
   // sph_force_chunk<LMAX, 0>, statement for statement (src/SphericalBasis.cc:1545-1560)
   const double px = X[i], py = Y[i], pz = Z[i];
   const double xx = px - S.cx, yy = py - S.cy, zz = pz - S.cz;
-  const double fac = xx * xx + yy * yy;
-  double r = sqrt(fac + zz * zz) + S.dsmall;
+  const double fac = sq_sum2_lit(xx, yy);           // (no fused multiply-add: see sq_sum2_lit)
+  double r = sqrt(sq_add_lit(fac, zz)) + S.dsmall;
   const double costh = zz / r;
   double cphi, sphi;
   phi_trig(xx, yy, cphi, sphi);
@@ -281,7 +288,7 @@ k_sph_force_gen(SphDev S, const double *__restrict__ X, const double *__restrict
   const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
   double xc = costh;
   if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-  const double dfac = 1.0 / (xc * xc - 1.0);
+  const double dfac = 1.0 / sq_add_lit(-1.0, xc);
   const double rr = S.rmax / r0;
   const double kappa0 = -P0 / (r0 * ffac);
   const double *t4 = T4 + (size_t)idx * 4 * S.trows;
@@ -344,8 +351,8 @@ k_sph_force_wave(SphDev S, const double *__restrict__ X, const double *__restric
     // ---- sph_force_chunk<LMAX, 0>'s prologue, the same for every lane
     const double px = X[i], py = Y[i], pz = Z[i];
     const double xx = px - S.cx, yy = py - S.cy, zz = pz - S.cz;
-    const double fac = xx * xx + yy * yy;
-    double r = sqrt(fac + zz * zz) + S.dsmall;
+    const double fac = sq_sum2_lit(xx, yy);
+    double r = sqrt(sq_add_lit(fac, zz)) + S.dsmall;
     const double costh = zz / r;
     double cphi, sphi;
     phi_trig(xx, yy, cphi, sphi);
@@ -362,7 +369,7 @@ k_sph_force_wave(SphDev S, const double *__restrict__ X, const double *__restric
     const double ffac = sph_d_xi_to_r(S, xi) * S.inv_dxi;
     double xc = costh;
     if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-    const double dfac = 1.0 / (xc * xc - 1.0);
+    const double dfac = 1.0 / sq_add_lit(-1.0, xc);
     const double rr = S.rmax / r0;
     const double kappa0 = -P0 / (r0 * ffac);
     const double pf_lit = (xi - S.xi[jdx]) / S.dxi;
@@ -412,6 +419,11 @@ k_sph_force_wave(SphDev S, const double *__restrict__ X, const double *__restric
         plm = (k == m + 1) ? ac[0] * tprev : fma(ac[0], tprev, -pl2);
         tprev = costh * plm;
         qlm = fma((double)k, xc * plm, -(ac[1] * pl1));
+      }
+      if (m == 0 && 1.0 - fabs(costh) < SPH_POLAR_FAC) {      // (leg0_lit_step: the reference's own m = 0 recurrence near the poles)
+        double lp1 = 0.0, lp2 = 0.0, ql = 0.0;
+        for (int k = 0; k <= l; k++) leg0_lit_step(k, costh, xc, lp1, lp2, ql);
+        qlm = ql * (plm / lp1);
       }
       double rl = 1.0;
       if (ioff) { rl = rr; for (int k = 0; k < l; k++) rl *= rr; }      // (rmax / r0)^(l + 1)

@@ -115,7 +115,12 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
     const int tqs = tq + ((2 - tq % 16) + 16) % 16;
     k_sph_force_staged<LMAX><<<a.grid, 256, (size_t)a.stage_rows * tqs * sizeof(double), a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ, a.assign,
-        a.stage_rows, tqs);
+        a.stage_rows, tqs, a.work, a.nwork);
+    // ... and its special lanes (a.work: this evaluation's own list, sph.hip)
+    const unsigned ggrid = a.grid < 256u ? a.grid : 256u;
+    k_sph_force<LMAX, 0><<<ggrid, 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+        0.0, a.assign, a.work, a.nwork, nullptr, 0.0, 0.0, 1, a.nwork_next);
   } else {
     ProfScope ps(a.ctx, "k_sph_force_general");
     k_sph_force<LMAX, 0><<<a.grid, 256, 0, a.stream>>>(

@@ -255,14 +255,16 @@ __device__ __forceinline__ uint32_t sph_key_cell_rcp(const SphDev &S, double x, 
 __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double &s)
 {
   double R2 = xx * xx + yy * yy;
-  if (R2 > 0.0) {
-    const double iR = 1.0 / sqrt(R2);
-    c = xx * iR;
-    s = yy * iR;
-  } else {
-    c = 1.0;
-    s = 0.0;
+  if (!(R2 > 0.0)) {
+    // x^2 + y^2 underflowed, or the particle is exactly on the axis
+    const double ax = fabs(xx), ay = fabs(yy), mx = ax > ay ? ax : ay;
+    if (!(mx > 0.0)) { atan2_trig_zero(xx, yy, c, s); return; }
+    xx /= mx; yy /= mx;
+    R2 = xx * xx + yy * yy;
   }
+  const double iR = 1.0 / sqrt(R2);
+  c = xx * iR;
+  s = yy * iR;
 }
 
 // Component::freeze, in the reference's operation order: r2 = sum_k (pos[k] - com0[k] - center[k])^2 > rtrunc^2
@@ -280,6 +282,28 @@ __device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py
   r2 = mul_then_add(r2, dz, dz);
   return r2 > F[6];
 }
+
+// xx^2 + yy^2 and (xx^2 + yy^2) + zz^2 as the reference's compiler forms them (src/SphericalBasis.cc:1545, :1630): every
+// product rounded on its own, no fused multiply-add.  For the general force pass: a lane within ~1e-7 rad of the polar
+// axis has 1 - |cos(theta)| of a few ulp, its Legendre functions of order m >= 1 go with the square root of that, and one
+// ulp of r^2 decides whether it is two, three or four of them (+-18 % in the tangential force of such a lane).
+__device__ __forceinline__ double sq_sum2_lit(double a, double b)
+{
+  double p = a * a, q = b * b;
+  asm volatile("" : "+v"(p), "+v"(q));
+  return p + q;
+}
+__device__ __forceinline__ double sq_add_lit(double s, double c)
+{
+  double q = c * c;
+  asm volatile("" : "+v"(q));
+  return s + q;
+}
+
+// sin^2(theta) below which the accumulation forms cos(theta), sin(theta) as the reference does (a lane-level branch)
+#ifndef SPH_POLAR_ACC
+#define SPH_POLAR_ACC 1.0e-4
+#endif
 
 // ---- accumulation ----------------------------------------------------------------------------------
 
@@ -431,14 +455,17 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   if constexpr (MAYFRZ) { if (SPH_FRZ_ON(S)) inwin = inwin && !sph_frozen(S, px, py, pz); }
   const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
-  if (R2 > 1e-12 * (r * r)) {
+  if (R2 > SPH_POLAR_ACC * (r * r)) {
     double R, iR;
     sqrt_rsqrt(R2, R, iR);
     in.cphi = xx * iR;
     in.sphi = yy * iR;
     in.sinth = R * ir;
   } else {
-    in.costh = zz / r;
+    // near the axis the reference's sin(theta) = sqrt((1 - x)(1 + x)) from the rounded x = z/r carries a relative error
+    // of ~1e-14 / theta^2 into the m >= 1 functions (see SPH_POLAR_FAC): its own operations, r^2 formed without fused
+    // multiply-adds (src/SphericalBasis.cc:486-490, src/Basis.cc:22)
+    in.costh = zz / (sqrt(sq_add_lit(sq_sum2_lit(xx, yy), zz)) + S.dsmall);
     phi_trig(xx, yy, in.cphi, in.sphi);
     in.sinth = sqrt((1.0 - in.costh) * (1.0 + in.costh));
   }
@@ -872,7 +899,7 @@ k_sph_mstep_update(SphDev S, const double *__restrict__ X, const double *__restr
     mass = M[i];
     if (SPH_FRZ_ON(S) && sph_frozen(S, X[i], Y[i], Z[i])) mover = false;     // (:468, :1159: before anything else)
   }
-  const double r = sqrt(xx * xx + yy * yy + zz * zz) + DSMALL;
+  const double r = sqrt(sq_add_lit(sq_sum2_lit(xx, yy), zz)) + DSMALL;       // (every product rounded on its own: sq_sum2_lit)
   if (plain) {
     if (!(r >= S.rmin && r <= S.rmax)) mover = false;
     const unsigned long long in = __ballot(mover);
@@ -995,6 +1022,26 @@ k_mstep_apply(const double *__restrict__ stage, const int2 *__restrict__ keys, c
 
 struct ForceOut { double potl, potr, pott, potp; };
 
+// sin^2(theta) below which a lane takes the general evaluation.  The fast arithmetic forms sin(theta) = R/r, good to an
+// ulp; the reference forms sqrt((1 - x)(1 + x)) from the rounded x = z/r, whose relative error is ~5.5e-17 / theta^2
+// -- and its m >= 1 terms carry that into the tangential force of a lane near the axis (measured against a CPU restatement of the reference:
+// 1.7e-3 at theta = 1e-6, 5e-5 at 1e-5, 6e-9 at 1e-3, 8e-11 at 1e-2).  Parity is with the reference's value, rounding
+// noise included, so these lanes -- 5e-6 of an isotropic set -- go where its own formula is used.
+#ifndef SPH_POLAR_FAC
+#define SPH_POLAR_FAC 1.0e-5
+#endif
+// ... and sin^2(theta) below which a lane of the FAST evaluation takes the reference's cos(theta), sin(theta) and
+// 1/(x*x - 1) instead of the accurate ones (x = z/r by a true division from the literally formed r, the square root of
+// (1 - x)(1 + x), the product x*x rounded before the subtraction): between the two thresholds that is all that separates
+// the fast arithmetic from the reference's (measured, the accurate values against the reference's: up to 3e-9 of the
+// acceleration at theta = 3e-3, 8e-11 at 1e-2; with these: 1e-13) -- the m = 0 cancellation and the clamp that the
+// general pass reproduces only matter further in.  Sending these lanes (5e-5 of an isotropic set, one wave in 300) to
+// the general pass instead costs the 1e8-particle step 0.13 ms (profiles/r05_polar_ab.txt); this costs nothing
+// measurable: a wave-uniform branch that one wave in 300 takes.
+#ifndef SPH_POLAR_FAST
+#define SPH_POLAR_FAST 1.0e-4
+#endif
+
 // The radial-derivative sum of one table slot, literally as the reference forms it: dpot(l, n) of SLGridSph::get_force
 // (exputil/SLGridMP2.cc:954-989: ((p - 1/2) ef[j-1] p0[j-1] - 2 p ef[j] p0[j] + (p + 1/2) ef[j+1] p0[j+1]) / sqrt(ev), each
 // product rounded on its own, no fused multiply-add), contracted with the coefficient row in ascending n
@@ -1031,6 +1078,37 @@ __device__ __forceinline__ double sph_dp_lit(const SphDev &S, int slot, int l, d
   return row < 0 ? 0.0 : S.lit_tscale[slot] * sph_dp_lit_row(S, row, l, p);
 }
 
+// One degree of the reference's own m = 0 Legendre recurrences (src/Basis.cc:71-92: p(l,0), then x*l*p(l,0) - l*p(l-1,0)
+// with the pole-clamped x), every operation rounded on its own.  For lanes near the poles (1 - |x| < SPH_POLAR_FAC: they
+// are all in the general pass): there |p(l,0)| is within theta^2 of 1, the difference is O(theta^2) with a rounding
+// error of an ulp of p -- 1e-16 / theta^2 of it, 1e-8 at theta = 1e-4, all of it under the clamp -- and WHICH error
+// depends on the exact rounding sequence; the rescaled recurrence of sph_field has another.  Measured against the
+// reference's arithmetic before: 4e-9 of such a lane's tangential force at theta = 1e-4, 1e-8 at 1e-7.
+__device__ __forceinline__ void leg0_lit_step(int l, double x, double xc, double &lp1, double &lp2, double &q)
+{
+#pragma clang fp contract(off)
+  double p;
+  if (l == 0) { p = 1.0; q = 0.0; }
+  else if (l == 1) { p = x * 1 * lp1; q = xc * l * p - l * lp1; }
+  else { p = (x * (2 * l - 1) * lp1 - (l - 1) * lp2) / l; q = xc * l * p - l * lp1; }
+  lp2 = lp1;
+  lp1 = p;
+}
+
+// (SPH_POLAR_FAST) the reference's angular inputs for the near-polar lanes of a fast evaluation
+__device__ __forceinline__ void sph_polar_faithful(const SphDev &S, double xx, double yy, double zz, double fac, double r,
+                                                   bool regular, double &costh, double &sinth, double &dfac)
+{
+  const bool polarish = regular && !(fac > SPH_POLAR_FAST * (r * r));
+  if (__any(polarish)) {
+    const double rl = sqrt(sq_add_lit(sq_sum2_lit(xx, yy), zz)) + S.dsmall;      // src/SphericalBasis.cc:1545
+    const double xr = zz / rl;
+    const double sr = sqrt((1.0 - xr) * (1.0 + xr));                              // src/Basis.cc:62
+    const double dr = 1.0 / sq_add_lit(-1.0, xr);                                 // src/Basis.cc:86
+    if (polarish) { costh = xr; sinth = sr; dfac = dr; }
+  }
+}
+
 // General (slow-path) evaluation: per-lane table gathers, exterior continuation by per-lane selects,
 // run-time flags, pole-clamped x in the derivative.  Waves that the fast pass deferred come here.
 template <int LMAX, class PT, bool LIT = false>
@@ -1043,6 +1121,8 @@ sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT
   // reference's own division
   [[maybe_unused]] const bool lit = LIT && !ioff && (pf_lit < S.lit_lo || pf_lit > S.lit_hi);
   const double somx2 = sqrt((1.0 - costh) * (1.0 + costh));
+  const bool clamped = 1.0 - fabs(costh) < SPH_POLAR_FAC;      // (see leg0_lit_step)
+  [[maybe_unused]] double lp1 = 0.0, lp2 = 0.0;
   double pmm = LC_E(0);
   double cm = 1.0, sm = 0.0, cm1 = 1.0, sm1 = 0.0;
   static_for<0, LMAX + 1>([&](auto mc) {
@@ -1078,6 +1158,13 @@ sph_field(const SphDev &S, double costh, double xc, double cphi, double sphi, PT
       tprev = costh * plm;
       if constexpr (l == m) qlm = (xc * plm) * l;
       else qlm = fma((double)l, xc * plm, -(LC_c(l, m) * pl1));
+      if constexpr (m == 0) {
+        if (clamped) {                  // (plm / lp1: this function's scale of Ph(l,0) against the reference's P_l)
+          double ql;
+          leg0_lit_step(l, costh, xc, lp1, lp2, ql);
+          qlm = ql * (plm / lp1);
+        }
+      }
       pl2 = pl1;
       pl1 = plm;
       constexpr int q = 4 * t4_row(LMAX, l, m);
@@ -1364,7 +1451,11 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
   double ax = -(pr * xx - pt3 * xx * zz);
   double ay = -(pr * yy - pt3 * yy * zz);
   double az = -(pr * zz + pt3 * fac);
-  if (fac > DSMALL) {
+  // (the n-body thread body adds the azimuthal term `if (fac > DSMALL)`, src/SphericalBasis.cc:1647; pyEXP's
+  // Spherical::computeAccel -- the no_exterior mode -- adds potp*y/R2 always, expui/BiorthBasis.cc:918-919, and within
+  // 1e-8 of the axis that term is of order one: P_l^1 / sin(theta).  On the axis itself it is 0/0 there; not added here.)
+  const double fac_floor = S.no_exterior ? 0.0 : DSMALL;
+  if (fac > fac_floor) {
     const double pf2 = FAST ? potp * iR2 : potp / fac;
     ax += pf2 * yy;
     ay += -pf2 * xx;
@@ -1442,7 +1533,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     yy = py - S.cy;
     zz = pz - S.cz;
   }
-  const double fac = xx * xx + yy * yy;
+  double fac = xx * xx + yy * yy;
   const size_t tq = (size_t)4 * S.trows;
   double r, ir, iR2, P0, ffac, dfac;
   [[maybe_unused]] double t4_sink = 0.0;      // destination of the table prefetch of the fast pass
@@ -1458,20 +1549,22 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     sqrt_rsqrt(fac + zz * zz, g, y);
     r = g + S.dsmall;                                        // src/SphericalBasis.cc:1545-1560
     ir = rcp_refine(r, y);
-    const double costh = zz * ir;
+    double costh = zz * ir;
     sqrt_rsqrt(fac, R, iR);
     iR2 = iR * iR;
-    const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
-    // theta < 1e-6: sin(theta) = R/r and the reference's sqrt((1-x)(1+x)) differ by more than the
+    const double cphi = xx * iR, sphi = yy * iR;
+    double sinth = R * ir;
+    // sin^2(theta) < SPH_POLAR_FAC: sin(theta) = R/r and the reference's sqrt((1-x)(1+x)) differ by more than the
     // parity tolerance there (cancellation in 1-x), so those lanes take the reference's formula too
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
     // (far outside the table -- the logarithmic map only -- the radial derivative takes the reference's literal
     // evaluation in the general pass: sph_dp_lit)
-    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL) ||
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) ||
                          xi < S.lit_xlo || xi > S.lit_xhi;
     int idx = sph_cell(S, xi);
     ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
     dfac = -(r * r) * iR2;
+    sph_polar_faithful(S, xx, yy, zz, fac, r, valid && !special, costh, sinth, dfac);
     if constexpr (MODE == 1) {
       const int idx_u = __builtin_amdgcn_readfirstlane(idx);
       if (!valid) idx = idx_u;
@@ -1550,7 +1643,8 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     }
   } else {
     // src/SphericalBasis.cc:1545-1560
-    r = sqrt(fac + zz * zz) + S.dsmall;
+    fac = sq_sum2_lit(xx, yy);
+    r = sqrt(sq_add_lit(fac, zz)) + S.dsmall;
     const double costh = zz / r;
     double cphi, sphi;
     phi_trig(xx, yy, cphi, sphi);
@@ -1574,7 +1668,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     // Legendre derivative pole clamp (src/Basis.cc:81-84)
     double xc = costh;
     if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-    dfac = 1.0 / (xc * xc - 1.0);
+    dfac = 1.0 / sq_add_lit(-1.0, xc);
     const double rr = S.rmax / r0;
     const double kappa0 = -P0 / (r0 * ffac);     // dp = -(l+1)/r0 * p, in units of ffac
     const double *t4 = T4 + (size_t)idx * tq;
@@ -1664,18 +1758,22 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
 // its cell range [cmin, cmax] into LDS once -- coalesced -- and every lane reads its own cell's rows from there, with
 // the FAST pass' arithmetic (shared reciprocals, factored weights: half the instructions of the general evaluation;
 // the same operations as a cell-uniform wave of the fast pass performs, so a particle gets the bits it would get
-// there).  Lanes on the polar axis or beyond rmax take the general evaluation on global rows; blocks whose range
+// there).  Lanes on the polar axis or beyond rmax are left on a work list for the general pass; blocks whose range
 // does not fit (nstage rows) read their rows from global memory with the same arithmetic.  tqs: LDS row stride in doubles (tq padded to 2 mod 16: consecutive cells
 // start four banks apart).
 typedef const __attribute__((address_space(3))) double *ldsp;
 
+#ifndef STAGED_MINB
+#define STAGED_MINB 2          // (A/B: tools/build_variant_tu.sh <suffix> sph_inst_L6 "-DSTAGED_MINB=5")
+#endif
 template <int LMAX>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, STAGED_MINB)
 k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
                    const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo, int lev_hi,
                    const double *__restrict__ T4, double *__restrict__ AX, double *__restrict__ AY,
                    double *__restrict__ AZ, double *__restrict__ POT, double *__restrict__ VX,
-                   double *__restrict__ VY, double *__restrict__ VZ, int assign, int nstage, int tqs)
+                   double *__restrict__ VY, double *__restrict__ VZ, int assign, int nstage, int tqs,
+                   uint32_t *__restrict__ work, uint32_t *__restrict__ nwork)
 {
   extern __shared__ __attribute__((aligned(16))) double stage[];
   __shared__ int s_min, s_max;
@@ -1698,22 +1796,24 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
   sqrt_rsqrt(fac + zz * zz, g, y);
   const double r = g + S.dsmall;
   const double ir = rcp_refine(r, y);
-  const double costh = zz * ir;
+  double costh = zz * ir;
   sqrt_rsqrt(fac, R, iR);
   const double iR2 = iR * iR;
-  const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
+  const double cphi = xx * iR, sphi = yy * iR;
+  double sinth = R * ir;
   const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
-  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL) ||
+  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) ||
                        xi < S.lit_xlo || xi > S.lit_xhi;
   const int idx = sph_cell(S, xi);
   const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
-  const double dfac = -(r * r) * iR2;
+  double dfac = -(r * r) * iR2;
   const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
   const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
   const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
   const int jdx = idx < 1 ? 1 : idx;
   const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
   const bool regular = valid && !special;
+  sph_polar_faithful(S, xx, yy, zz, fac, r, regular, costh, sinth, dfac);
   // the block's range of cells (regular lanes only: the special ones -- polar axis, beyond rmax -- take the general
   // evaluation on global rows below)
   int lo = regular ? idx : 0x7fffffff, hi = regular ? idx : -1;
@@ -1743,38 +1843,14 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
   if (regular)
     sph_force_finish<true>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
                            0.0, assign, nullptr, 0.0, 0.0, 1);
-  if (__any(valid && special)) {
-    // the general path (sph_force_chunk<LMAX, 0>), statement for statement, for the special lanes
-    double rg = sqrt(fac + zz * zz) + S.dsmall;
-    const double costh_g = zz / rg;
-    double cphi_g, sphi_g;
-    phi_trig(xx, yy, cphi_g, sphi_g);
-    bool ioff = false;
-    const double r0 = rg;
-    if (rg > S.rmax && !S.no_exterior) { ioff = true; rg = S.rmax; }
-    const double xig = sph_r_to_xi(S, rg / S.scale);
-    const int idg = sph_cell(S, xig);
-    const double y1 = (S.xi[idg + 1] - xig) * S.inv_dxi;
-    const double y2 = (xig - S.xi[idg]) * S.inv_dxi;
-    const double P0g = y1 * S.p0[idg] + y2 * S.p0[idg + 1];
-    const int jdg = idg < 1 ? 1 : idg;
-    const double pfg = (xig - S.xi[jdg]) * S.inv_dxi;
-    const double ffacg = sph_d_xi_to_r(S, xig) * S.inv_dxi;
-    double xc = costh_g;
-    if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-    const double dfacg = 1.0 / (xc * xc - 1.0);
-    const double rr = S.rmax / r0;
-    const double kappa0 = -P0g / (r0 * ffacg);
-    const double *t4 = T4 + (size_t)idg * tq;
-    const ForceOut og = sph_field<LMAX>(S, costh_g, xc, cphi_g, sphi_g, t4, y2, pfg, ioff, rr, kappa0);
-    bool mine = valid && special;
-    if (mine && !ioff && (pfg < S.lit_lo || pfg > S.lit_hi)) {       // far outside the table: the literal pass takes it
-      const uint32_t k = atomicAdd(S.lit_list, 1u);
-      if (k < S.lit_cap) { S.lit_list[1 + k] = (uint32_t)i; mine = false; }
-    }
-    if (mine)
-      sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, fac, 1.0 / rg, 1.0 / fac, P0g, ffacg, dfacg, AX, AY, AZ,
-                              POT, VX, VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
+  // the special lanes of this wave: the general pass that follows (k_sph_force<LMAX, 0> on the work list), by lane mask
+  // -- kept inline, that evaluation cost this kernel a third of its registers (159 against 126 at lmax 6, 217 at lmax 10)
+  const unsigned long long sp = __ballot(valid && special);
+  if (sp && lane == 0) {
+    const uint32_t w = atomicAdd(nwork, 1u);
+    work[SPH_WORK_STRIDE * w] = (uint32_t)(base0 + (threadIdx.x & ~63u));
+    work[SPH_WORK_STRIDE * w + 1] = (uint32_t)sp;
+    work[SPH_WORK_STRIDE * w + 2] = (uint32_t)(sp >> 32);
   }
 }
 
@@ -1861,23 +1937,26 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
     sqrt_rsqrt(fac + zz * zz, g, y);
     const double r = g + S.dsmall;
     const double ir = rcp_refine(r, y);
-    const double costh = zz * ir;
+    double costh = zz * ir;
     sqrt_rsqrt(fac, R, iR);
     const double iR2 = iR * iR;
-    const double cphi = xx * iR, sphi = yy * iR, sinth = R * ir;
+    const double cphi = xx * iR, sphi = yy * iR;
+    double sinth = R * ir;
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
-    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > 1e-12 * (r * r)) || !(fac > DSMALL);
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL);
     const int idx = sph_cell(S, xi);
     const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
-    const double dfac = -(r * r) * iR2;
+    double dfac = -(r * r) * iR2;
     const double x1 = (S.xi[idx + 1] - xi) * S.inv_dxi;
     const double x2 = (xi - S.xi[idx]) * S.inv_dxi;
     const double P0 = x1 * S.p0[idx] + x2 * S.p0[idx + 1];
     const int jdx = idx < 1 ? 1 : idx;
     const double pf = (xi - S.xi[jdx]) * S.inv_dxi;
     const bool regular = valid && !special;
+    sph_polar_faithful(S, xx, yy, zz, fac, r, regular, costh, sinth, dfac);
     // the general evaluation's own radius and cell for the special lanes (sph_force_chunk<LMAX, 0>)
-    double rg = sqrt(fac + zz * zz) + S.dsmall;
+    const double facg = sq_sum2_lit(xx, yy);
+    double rg = sqrt(sq_add_lit(facg, zz)) + S.dsmall;
     const double r0 = rg;
     bool ioff = false;
     if (rg > S.rmax && !S.no_exterior) { ioff = true; rg = S.rmax; }
@@ -1958,13 +2037,13 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
         const double ffacg = sph_d_xi_to_r(S, xig) * S.inv_dxi;
         double xc = costh_g;
         if (1.0 - fabs(xc) < MINEPS) xc = (xc > 0) ? 1.0 - MINEPS : -(1.0 - MINEPS);
-        const double dfacg = 1.0 / (xc * xc - 1.0);
+        const double dfacg = 1.0 / sq_add_lit(-1.0, xc);
         const double rr = S.rmax / r0;
         const double kappa0 = -P0g / (r0 * ffacg);
         const double *t4 = stage + (size_t)t * tqs;
         const ForceOut og = sph_field<LMAX>(S, costh_g, xc, cphi_g, sphi_g, t4, y2, pfg, ioff, rr, kappa0);
         if (valid && special)
-          sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, fac, 1.0 / rg, 1.0 / fac, P0g, ffacg, dfacg, AX, AY,
+          sph_force_finish<false>(S, og, i, xx, yy, zz, px, py, pz, facg, 1.0 / rg, 1.0 / facg, P0g, ffacg, dfacg, AX, AY,
                                   AZ, POT, VX, VY, VZ, 0.0, assign, nullptr, 0.0, 0.0, 1);
       }
     }

@@ -72,18 +72,25 @@ def nasty_sphere(rng, model, g, scale, rmin, rmax, ctr):
     pos[:, 2] *= rng.uniform(0.2, 1.5)
     pos[:, 0] += rng.uniform(-0.2, 0.2) * scale
     m = m * rng.uniform(0.1, 3.0, n)
-    k = min(n, 16)
+    # (near the polar axis the reference's arithmetic is ill-conditioned and parity is with ITS values: a ladder of polar
+    # angles from 1e-9 to 1e-2 about either pole, and the axis itself with a negative zero x -- phi = pi there)
+    ladder = []
+    for _ in range(8):
+        th, ph, rr = 10.0 ** rng.uniform(-9, -2), rng.uniform(0, 2 * np.pi), scale * np.exp(rng.uniform(np.log(0.02), np.log(5.0)))
+        ladder.append(np.array([rr * np.sin(th) * np.cos(ph), rr * np.sin(th) * np.sin(ph), rng.choice([-1.0, 1.0]) * rr * np.cos(th)]))
+    ladder += [np.array([-0.0, 0.0, 0.4 * scale]), np.array([-0.0, -0.0, -0.7 * scale])]
+    k = min(n, 26)
     idx = rng.choice(n, k, replace=False)
-    special = [np.zeros(3), np.array([0, 0, 0.3 * scale]), np.array([0, 0, -2.0 * scale]), np.array([1e-300, 0, 0]),
+    special = ladder + [np.zeros(3), np.array([0, 0, 0.3 * scale]), np.array([0, 0, -2.0 * scale]), np.array([1e-300, 0, 0]),
                np.array([rmax, 0, 0]), np.array([0, rmax * (1 - 1e-15), 0]), np.array([0, 0, rmax * (1 + 1e-15)]),
                np.array([rmin, 0, 0]), np.array([rmin * (1 - 1e-12), 0, 0]), np.array([3 * rmax, rmax, -5 * rmax]),
                np.array([1e-9 * scale, 1e-9 * scale, scale]), np.array([scale, 0, 1e-200]), np.array([-scale, 1e-17, 0]),
                pos[0] - ctr, pos[0] - ctr, np.array([1e-4, -1e-4, 1e-4]) * scale]
     for j, i in enumerate(idx):
-        pos[i] = special[j] + ctr
+        pos[i] = special[j] + ctr if ctr.any() else special[j]         # (-0 + 0 would be +0)
     if n > 3 and rng.random() < 0.5:
         m[rng.choice(n, 2, replace=False)] = 0.0
-    return m, pos
+    return m, pos, idx[:min(k, 8)]          # (the slots of the polar ladder)
 
 
 def trial_sph(t, rng):
@@ -93,7 +100,7 @@ def trial_sph(t, rng):
     rmax = g.rmax * scale * float(rng.choice([1.0, 1.0, 0.2]))
     flags = {k: bool(rng.random() < 0.2) for k in ("NO_L0", "NO_L1", "EVEN_L", "EVEN_M", "M0_only")}
     ctr = rng.normal(0, 0.3, 3) * scale if rng.random() < 0.5 else np.zeros(3)
-    m, pos = nasty_sphere(rng, model, g, scale, rmin, rmax, ctr)
+    m, pos, lad = nasty_sphere(rng, model, g, scale, rmin, rmax, ctr)
     prm = orc.params(scale=scale, rmin=rmin, rmax=rmax, **flags)
     c_ref, used_ref = orc.sph_accumulate(g, prm, pos, m, center=ctr)
     a_ref, p_ref = orc.sph_accel(g, prm, pos, c_ref, center=ctr)
@@ -133,8 +140,11 @@ def trial_sph(t, rng):
     psc = max(np.abs(p_ref[fin]).max() if fin.any() else 0.0, 1e-300)
     e_a = np.abs(out["acc"][fin] - a_ref[fin]).max() / asc if fin.any() else 0.0
     e_p = np.abs(out["pot"][fin] - p_ref[fin]).max() / psc if fin.any() else 0.0
-    ok = ok and same_nan and e_c <= COEF_TOL and e_a <= ACC_TOL and e_p <= ACC_TOL
-    print(f"sph {t:3d} {key} scale {scale} flags {[k for k, v in flags.items() if v]} n {len(m)}: coef {e_c:.1e} acc {e_a:.1e} pot {e_p:.1e} "
+    # ... and the particles of the polar ladder each against its OWN acceleration (floored at 1e-3 of the largest)
+    lf = lad[fin[lad]]
+    e_o = (np.linalg.norm(out["acc"][lf] - a_ref[lf], axis=1) / np.maximum(np.linalg.norm(a_ref[lf], axis=1), 1e-3 * asc)).max() if len(lf) else 0.0
+    ok = ok and same_nan and e_c <= COEF_TOL and e_a <= ACC_TOL and e_p <= ACC_TOL and e_o <= ACC_TOL
+    print(f"sph {t:3d} {key} scale {scale} flags {[k for k, v in flags.items() if v]} n {len(m)}: coef {e_c:.1e} acc {e_a:.1e} own {e_o:.1e} pot {e_p:.1e} "
           f"fields[{ctype[:3]}] {e_f:.1e}{'' if same_f else ' NAN-PATTERN'} "
           f"used {used}/{used_ref} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok and fin.any():
@@ -156,7 +166,8 @@ def trial_cyl(t, rng):
     z = 2 * H * np.arctanh(rng.uniform(-0.999, 0.999, n)) * rng.uniform(0.3, 3.0)
     pos = np.stack([R * np.cos(ph), R * np.sin(ph), z], axis=1)
     Rt = g.rtable * A
-    special = [np.zeros(3), np.array([0, 0, H]), np.array([1e-300, 0, 0]), np.array([A, 0, 0.0]), np.array([Rt * 0.999999, 0, 0]),
+    special = [np.array([-0.0, 0.0, -0.6 * H]), np.array([-0.0, -0.0, 0.2 * H]),       # (on the axis, phi = +-pi: IEEE atan2)
+               np.zeros(3), np.array([0, 0, H]), np.array([1e-300, 0, 0]), np.array([A, 0, 0.0]), np.array([Rt * 0.999999, 0, 0]),
                np.array([Rt * 1.000001, 0, 0]), np.array([0, 0.3 * Rt, 0.69 * Rt]), np.array([0.1 * Rt, 0, -0.71 * Rt]),
                np.array([5 * Rt, Rt, 0]), np.array([g.rmin * A * 0.5, 0, 0]), np.array([A, 1e-17, 1e-200]), np.array([-A, 0, -H])]
     for j, i in enumerate(rng.choice(n, min(n, len(special)), replace=False)):

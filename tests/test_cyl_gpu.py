@@ -100,6 +100,37 @@ def test_cyl_edges_offgrid_and_blend(ctx, oracle):
     assert np.array_equal(np.isfinite(out["acc"]).all(axis=1), ok)
 
 
+def test_cyl_axis_signed_zero(ctx, oracle):
+    """A particle exactly on the axis: phi = atan2(+-0, +-0) is 0 or +-pi by the SIGN of the zero x (src/Cylinder.cc:834;
+    IEEE atan2), and the odd-m functions do not vanish there -- the tables are extrapolated below RMIN -- so that sign is
+    the sign of its odd-m contributions.  Only such particles, every (m, n) against its own size; the potential too (the
+    reference's forces there are 0/0)."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    A, H = g.ascale, g.hscale
+    pos = np.array([[-0.0, 0.0, 0.3 * H], [0.0, -0.0, -0.5 * H], [-0.0, -0.0, 1.1 * H], [0.0, 0.0, 0.2 * H],
+                    [-0.0, 0.0, -2.0 * H]])
+    m = np.array([1.0, 0.7, 1.3, 0.9, 1.1])
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    assert np.abs(c_ref[1]).max() > 1e-6 * np.abs(c_ref[0]).max()       # (the odd-m terms are there)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert f.Used() == used_ref
+    for got, ref in ((cc, c_ref), (ss, s_ref)):
+        assert np.abs(got - ref).max() <= COEF_TOL * np.abs(c_ref).max()
+        big = np.abs(ref) > 1e-12 * np.abs(c_ref).max()
+        assert (np.abs(got - ref)[big] <= 1e-9 * np.abs(ref)[big]).all()
+    _, p_ref = oracle.cyl_accel(g, pos, c_ref, s_ref, mass_ref)
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("pot",))
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    c.close()
+    f.close()
+
+
 def test_cyl_even_m_and_external(ctx, oracle):
     from exp_amd.runtime import Component, Cylinder
     g = cyl_grid(4, 6)

@@ -177,6 +177,95 @@ def test_set_coefs_roundtrip_and_external_target(ctx, oracle, plummer_small):
     assert np.abs(out["pot"] - pot0 - p_ref).max() <= 1e-9 * np.abs(p_ref).max()
 
 
+def _polar_ladder(g, n, rng):
+    """positions at polar angles from 1e-9 to 1e-2 (both poles), on the axis, at the centre, beyond rmax, and regular"""
+    thetas = np.array([0.0, 1e-9, 1e-8, 1e-7, 1e-6, 3e-6, 1e-5, 1e-4, 1e-3, 3e-3, 1e-2, -1.0, -2.0])
+    cat = np.arange(n) % len(thetas)
+    r = np.exp(rng.uniform(np.log(g.rmin * 3), np.log(g.rmax * 0.5), n))
+    th = thetas[cat] * rng.uniform(0.5, 1.5, n)
+    reg = cat >= len(thetas) - 2                                          # the last two classes: anywhere on the sphere
+    th[reg] = np.arccos(rng.uniform(-1.0, 1.0, reg.sum()))
+    ph = rng.uniform(0.0, 2.0 * np.pi, n)
+    sgn = np.where(rng.uniform(size=n) < 0.5, -1.0, 1.0)
+    pos = np.stack([r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), sgn * r * np.cos(th)], 1)
+    k = np.arange(n)
+    ext = k % 41 == 7
+    pos[ext] *= (g.rmax * 3.0 / r[ext])[:, None]                          # exterior
+    pos[k % 1999 == 11] = 0.0                                            # the centre itself
+    return pos
+
+
+@pytest.mark.parametrize("kind,lmax,nmax,numr", [("plummer", 4, 8, 400), ("nfw", 6, 18, 2000), ("plummer_log", 4, 8, 3000)])
+@pytest.mark.parametrize("external", [True, False])
+def test_polar_axis_lanes(ctx, oracle, kind, lmax, nmax, numr, external):
+    """Near the polar axis the reference's own arithmetic is ill-conditioned -- sqrt((1-x)(1+x)) and 1/(x*x-1) from the
+    rounded x = z/r, the m = 0 derivative as a difference of two numbers within theta^2 of each other, the clamp of
+    src/Basis.cc:81-84 -- and parity is with ITS values: lanes with sin^2(theta) < 1e-5 take the general pass, which forms
+    r^2, x*x - 1 and the m = 0 recurrence operation for operation (sph_kernels.h: SPH_POLAR_FAC, leg0_lit_step).  Before,
+    a lane at theta = 1e-6 was off by 1.7e-3 of its tangential force.  external: another component's particles go
+    through k_sph_force_staged, whose special lanes are left on a work list for the general pass behind it; otherwise
+    the component's own fast pass defers them.  Per-particle relative error, acc += semantics."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = make_grid(kind, lmax, nmax, numr)
+    rng = np.random.default_rng(77)
+    coef = rng.standard_normal(((g.lmax + 1) ** 2, g.nmax)) * 1e-2
+    f = SphereSL(ctx, g)
+    n = 13 * 600
+    pos = _polar_ladder(g, n, rng)
+    tgt = Component.from_arrays(ctx, np.ones(n), pos)
+    if not external:
+        f.determine_coefficients(tgt)                                    # the component's own cell order
+    f.set_coefs(coef)
+    acc0 = rng.standard_normal((n, 3)) * 1e-3
+    pot0 = rng.standard_normal(n) * 1e-3
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    a_ref, p_ref = oracle.sph_accel(g, prm, pos, coef)
+    scale = np.maximum(np.abs(a_ref).max(1), 1e-3 * np.abs(a_ref).max())
+    outs = []
+    for rep in range(2):                                                 # (twice: the two work-list counters alternate)
+        tgt.upload_acc(acc0, pot0)
+        f.get_acceleration_and_potential(tgt, external=external)
+        outs.append(tgt.download(("acc", "pot")))
+    out = outs[0]
+    assert np.isfinite(out["acc"]).all() and np.isfinite(out["pot"]).all()
+    err = np.abs(out["acc"] - acc0 - a_ref).max(1) / scale
+    assert err.max() <= 1e-9, (err.argmax(), pos[err.argmax()])
+    assert np.abs(out["pot"] - pot0 - p_ref).max() <= 1e-10 * np.abs(p_ref).max()
+    assert np.array_equal(outs[1]["acc"], out["acc"]) and np.array_equal(outs[1]["pot"], out["pot"])
+    tgt.close()
+    f.close()
+
+
+@pytest.mark.parametrize("theta", [0.0, 1e-9, 3e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2])
+def test_polar_axis_coefficients(ctx, oracle, plummer_small, theta):
+    """The same near the axis for the accumulation (src/SphericalBasis.cc:486-561): the m >= 1 functions of a particle at
+    polar angle theta go with sin(theta)^m, which the reference forms from the rounded cos(theta).  A few particles at
+    that angle only, so that nothing else hides their share; every coefficient row against its own size."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_small
+    rng = np.random.default_rng(int(theta * 1e9) + 5)
+    n = 5
+    r = np.exp(rng.uniform(np.log(0.05), np.log(5.0), n))
+    th = theta * rng.uniform(0.5, 1.5, n)
+    ph = rng.uniform(0.0, 2.0 * np.pi, n)
+    sgn = np.where(rng.uniform(size=n) < 0.5, -1.0, 1.0)
+    pos = np.stack([r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), sgn * r * np.cos(th)], 1)
+    m = rng.uniform(0.5, 1.5, n)
+    f = SphereSL(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    got = f.get_coefs()
+    prm = oracle.params(rmin=g.rmin, rmax=g.rmax)
+    c_ref, used = oracle.sph_accumulate(g, prm, pos, m)
+    assert f.Used() == used
+    assert coef_err(got, c_ref) <= COEF_TOL
+    rows = np.abs(c_ref).max(1)
+    big = rows > 1e-30
+    assert (np.abs(got - c_ref).max(1)[big] <= 1e-9 * rows[big]).all()
+    c.close()
+    f.close()
+
+
 def test_external_target_after_the_source_component_is_gone(ctx, oracle, plummer_small):
     """An external target is evaluated in the frame (centre) of the component the expansion was
     built from (use_external: src/SphericalBasis.cc:1509-1520).  pyEXP-style callers build the
