@@ -593,6 +593,20 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
 // [first, multistep]: five time-step criteria -> dtreq (rounded to float like Particle::dtreq,
 // include/Particle.H:60) -> target level.  Levels are only PROPOSED here (newlev); the force
 // method applies its coefficient differencing and the store commits + re-sorts afterwards.
+// v.a, v.v and a.a of the time-step criteria as the reference's compiler forms them (src/multistep.cc:100-108): every
+// product rounded on its own, added in the order of k.  v.a of a near-circular orbit is what is left of terms a
+// thousand to a million times larger; a fused multiply-add leaves a different residue, and the criterion built on it
+// (dta) decides a level where it is the smallest.
+__device__ __forceinline__ void level_sums_lit(double v0, double v1, double v2, double a0, double a1, double a2,
+                                               double &dtr, double &vtot, double &atot)
+{
+#pragma clang fp contract(off)
+  dtr = 0.0; vtot = 0.0; atot = 0.0;
+  dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
+  dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
+  dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
+}
+
 struct AdjustArgs {
   double dtime, dynD, dynV, dynS, dynA, dynP;
   int multistep, shiftlevl, mfirst_mdrft;
@@ -613,10 +627,8 @@ k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__res
   if (i >= lev_off[first] && i < lev_off[last + 1]) {
     const double eps = 1.0e-10;
     const double v0 = vx[i], v1 = vy[i], v2 = vz[i], a0 = ax[i], a1 = ay[i], a2 = az[i];
-    double dtr = 0.0, vtot = 0.0, atot = 0.0;
-    dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
-    dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
-    dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
+    double dtr, vtot, atot;
+    level_sums_lit(v0, v1, v2, a0, a1, a2, dtr, vtot, atot);
     const double ptot = fabs(pot[i]);
     const double dts = 1.0 / eps;                  // Particle::scale <= 0: criterion off
     const double dtd = A.dynD * 1.0 / sqrt(vtot + eps);
@@ -703,10 +715,8 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
       examined = i >= ebeg;
       if (examined) {
         const double eps = 1.0e-10;
-        double dtr = 0.0, vtot = 0.0, atot = 0.0;
-        dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
-        dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
-        dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
+        double dtr, vtot, atot;
+        level_sums_lit(v0, v1, v2, a0, a1, a2, dtr, vtot, atot);
         const double ptot = fabs(pot[i]);
         const double dts = 1.0 / eps;                  // Particle::scale <= 0: criterion off
         const double dtd = A.dynD * 1.0 / sqrt(vtot + eps);
