@@ -82,6 +82,14 @@ __device__ __forceinline__ void cstatic_for(F &&f)
   }
 }
 
+// 1 / r for r = sqrt(x^2 + y^2) + DSMALL (src/Cylinder.cc:1359) from irp ~ 1 / sqrt(x^2 + y^2): one Newton step squares
+// the relative difference DSMALL / R between the two, which is below an ulp only from R ~ 1e-8 outwards; within 1e-9 of the
+// axis the division itself (before: 1e-4 of the radial force's projection at R = 1e-14)
+__device__ __forceinline__ double cyl_inv_r(double r, double irp, double r2)
+{
+  return r2 > 1.0e-18 ? rcp_refine(r, irp) : 1.0 / r;
+}
+
 // exputil/EmpCylSL.cc:6446-6463
 __device__ __forceinline__ double cyl_r_to_xi(const CylDev &C, double r)
 {

@@ -1051,7 +1051,7 @@ k_cyl_force(CylDev C, const double *__restrict__ X, const double *__restrict__ Y
     double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
     if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
     // (1/r2 is infinite on the axis: the reference's fp*yy/r2 is 0/0 = NaN there, and so is this)
-    const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+    const double ir = cyl_inv_r(r, irp, r2), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
     fx = (fr * xx * ir - fp * yy * ir2) * frac;    // src/Cylinder.cc:1387-1390
     fy = (fr * yy * ir + fp * xx * ir2) * frac;
     fz = fzz * frac;
@@ -1261,7 +1261,7 @@ k_cyl_force_thin(CylDev C, const double *__restrict__ X, const double *__restric
       if (ratio < 1.0) {
         double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
         if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
-        const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+        const double ir = cyl_inv_r(r, irp, r2), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
         fx = (fr * xx * ir - fp * yy * ir2) * frac;
         fy = (fr * yy * ir + fp * xx * ir2) * frac;
         fz = fzz * frac;
@@ -1616,7 +1616,7 @@ k_cyl_force_wave(CylDev C, const double *__restrict__ X, const double *__restric
     else { cfrac = 0.0; frac = 1.0; }
     double fx = 0.0, fy = 0.0, fz = 0.0, pa = 0.0;
     if (ratio < 1.0) {
-      const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+      const double ir = cyl_inv_r(r, irp, r2), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
       fx = (ofr * xx * ir - ofp * yy * ir2) * frac;                 // src/Cylinder.cc:1387-1390
       fy = (ofr * yy * ir + ofp * xx * ir2) * frac;
       fz = ofz * frac;
@@ -1927,7 +1927,7 @@ k_cyl_force_gen(CylDev C, const double *__restrict__ X, const double *__restrict
   if (ratio < 1.0) {
     double p = 0.0, fr = 0.0, fzz = 0.0, fp = 0.0;
     if (ongrid) { p = o.p; fr = o.fr; fzz = o.fz; fp = o.fp; }
-    const double ir = rcp_refine(r, irp), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
+    const double ir = cyl_inv_r(r, irp, r2), ir2 = r2 > 0.0 ? irp * irp : __builtin_inf();
     fx = (fr * xx * ir - fp * yy * ir2) * frac;                     // src/Cylinder.cc:1387-1390
     fy = (fr * yy * ir + fp * xx * ir2) * frac;
     fz = fzz * frac;

@@ -170,8 +170,15 @@ def trial_cyl(t, rng):
                np.zeros(3), np.array([0, 0, H]), np.array([1e-300, 0, 0]), np.array([A, 0, 0.0]), np.array([Rt * 0.999999, 0, 0]),
                np.array([Rt * 1.000001, 0, 0]), np.array([0, 0.3 * Rt, 0.69 * Rt]), np.array([0.1 * Rt, 0, -0.71 * Rt]),
                np.array([5 * Rt, Rt, 0]), np.array([g.rmin * A * 0.5, 0, 0]), np.array([A, 1e-17, 1e-200]), np.array([-A, 0, -H])]
-    for j, i in enumerate(rng.choice(n, min(n, len(special)), replace=False)):
+    # (a ladder of distances from the axis, 1e-12 a to 1e-3 a: the force is projected with 1/R and 1/R^2 there)
+    for _ in range(8):
+        Rr, pp = A * 10.0 ** rng.uniform(-12, -3), rng.uniform(0, 2 * np.pi)
+        special.append(np.array([Rr * np.cos(pp), Rr * np.sin(pp), H * rng.normal(0, 1.5)]))
+    nlad = min(n, len(special))
+    lad = rng.choice(n, nlad, replace=False)
+    for j, i in enumerate(lad):
         pos[i] = special[j]
+    lad = lad[12:] if nlad > 12 else lad[:0]                    # (the slots of that ladder)
     m = np.full(n, 1.0 / n) * rng.uniform(0.1, 3.0, n)
     even_m = bool(rng.random() < 0.2)
     kw = dict(EVEN_M=even_m) if even_m else {}
@@ -225,9 +232,11 @@ def trial_cyl(t, rng):
     psc = max(np.abs(p_ref[fin]).max() if fin.any() else 0.0, 1e-300)
     e_a = np.abs(out["acc"][fin] - a_ref[fin]).max() / asc if fin.any() else 0.0
     e_p = np.abs(out["pot"][fin] - p_ref[fin]).max() / psc if fin.any() else 0.0
+    lf = lad[fin[lad]]
+    e_o = (np.linalg.norm(out["acc"][lf] - a_ref[lf], axis=1) / np.maximum(np.linalg.norm(a_ref[lf], axis=1), 1e-3 * asc)).max() if len(lf) else 0.0
     ok = (used == used_ref and abs(cm - mass_ref) <= 1e-12 * max(abs(mass_ref), 1e-300) and same_nan and e_c <= COEF_TOL
-          and e_a <= ACC_TOL and e_p <= ACC_TOL and same_f and e_f <= ACC_TOL)
-    print(f"cyl {t:3d} {key} EVEN_M {even_m} n {n}: coef {e_c:.1e} acc {e_a:.1e} pot {e_p:.1e} fields[{ctype[:3]}] {e_f:.1e}"
+          and e_a <= ACC_TOL and e_p <= ACC_TOL and same_f and e_f <= ACC_TOL and e_o <= ACC_TOL)
+    print(f"cyl {t:3d} {key} EVEN_M {even_m} n {n}: coef {e_c:.1e} acc {e_a:.1e} own {e_o:.1e} pot {e_p:.1e} fields[{ctype[:3]}] {e_f:.1e}"
           f"{'' if same_f else ' NAN-PATTERN'} used {used}/{used_ref} "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
     return ok

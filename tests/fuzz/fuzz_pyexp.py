@@ -177,14 +177,20 @@ def trial_cyl(t, rng):
     cmax = max(np.abs(cc).max(), floor)
     e_c = max(np.abs(cs.coefs.real - cc).max(), np.abs(cs.coefs.imag - ss).max()) / cmax
     Rt = basis.grid.rtable * A
+    # (a ladder of distances from the axis, 1e-12 a to 1e-3 a: the force is projected with 1/R and 1/R^2 there)
+    lad = []
+    for _ in range(10):
+        Rr, ph = A * 10.0 ** rng.uniform(-12, -3), rng.uniform(0, 2 * np.pi)
+        lad.append([Rr * np.cos(ph), Rr * np.sin(ph), H * rng.normal(0, 1.5)])
     test = np.concatenate([np.random.default_rng(t).normal(0, 0.03, (200, 3)) * np.array([1, 1, 0.1]),
-                           np.array([[1.2 * Rt, 0, 0], [0, 0.9 * Rt, 0.3 * Rt], [1e-8, 0, 0.001]])])
+                           np.array([[1.2 * Rt, 0, 0], [0, 0.9 * Rt, 0.3 * Rt], [1e-8, 0, 0.001]]), np.array(lad)])
     basis.set_coefs(cs)
     a_ref = orc.pyexp_cyl_accel(basis.grid, cc, ss, test)
     acc = basis.getAccel(test)
     fin = np.isfinite(a_ref).all(axis=1)
     asc = max(np.linalg.norm(a_ref[fin], axis=1).max(), 1e-3 * m.sum() * np.abs(basis.grid.tab[1]).max())
     e_a = np.abs(acc[fin] - a_ref[fin]).max() / asc
+    e_a = max(e_a, 0.1 * (np.linalg.norm(acc[fin] - a_ref[fin], axis=1) / np.maximum(np.linalg.norm(a_ref[fin], axis=1), 1e-2 * asc)).max())
     same = np.array_equal(np.isfinite(acc).all(axis=1), fin)
     x, y, z = test.T
     with np.errstate(all="ignore"):

@@ -131,6 +131,40 @@ def test_cyl_axis_signed_zero(ctx, oracle):
     f.close()
 
 
+def test_cyl_near_axis_ladder(ctx, oracle):
+    """Distances from the axis from 1e-3 a down to 1e-14 a: the force is projected with x / r, r = sqrt(x^2 + y^2) + 1e-16
+    (src/Cylinder.cc:1359, :1387-1388) -- the 1e-16 is 1 % of r at the bottom of the ladder, and a reciprocal refined from
+    1 / sqrt(x^2 + y^2) no longer gives 1 / r there (before: 1e-4 of the projection at R = 1e-14 a).  Every particle against
+    its own acceleration."""
+    from exp_amd.runtime import Component, Cylinder
+    g = cyl_grid(4, 6)
+    A, H = g.ascale, g.hscale
+    rng = np.random.default_rng(12)
+    m0, pos0, _ = _disk(2000, 7, g)
+    k = np.arange(12 * 8)
+    R = A * 10.0 ** (-3.0 - (k % 12))
+    ph = rng.uniform(0, 2 * np.pi, len(k))
+    lad = np.stack([R * np.cos(ph), R * np.sin(ph), H * rng.normal(0, 1.0, len(k))], 1)
+    pos = np.concatenate([pos0, lad])
+    m = np.concatenate([m0, np.full(len(k), m0[0])])
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g, pos, c_ref, s_ref, mass_ref)
+    f = Cylinder(ctx, g)
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert np.abs(cc - c_ref).max() <= COEF_TOL * np.abs(c_ref).max()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    own = np.linalg.norm(a_ref, axis=1)
+    err = np.linalg.norm(out["acc"] - a_ref, axis=1) / np.maximum(own, 1e-3 * own.max())
+    assert err.max() <= ACC_TOL, (err.argmax(), pos[err.argmax()])
+    assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
+    c.close()
+    f.close()
+
+
 def test_cyl_even_m_and_external(ctx, oracle):
     from exp_amd.runtime import Component, Cylinder
     g = cyl_grid(4, 6)
