@@ -304,6 +304,12 @@ __device__ __forceinline__ double sq_add_lit(double s, double c)
 #ifndef SPH_POLAR_ACC
 #define SPH_POLAR_ACC 1.0e-4
 #endif
+// The radius, in units of the reference's r = sqrt(x^2 + y^2 + z^2) + DSMALL offset (1e-16; pyEXP 1e-18), below which
+// a lane takes the general pass: the fast arithmetic forms sin(theta) = R/r and 1/(x*x - 1) = -r^2/R^2 from the true R, the
+// reference from x = z/r with the OFFSET r -- a relative difference of 2 DSMALL / r in every m >= 1 and every theta-derivative
+// term (1.5e-8 of the acceleration at r = 1.3e-8: a particle the block-multistep campaign placed there left on a
+// different trajectory).  1e-11 at this radius; nothing of a realistic set is inside it (rmin is 1e-3 of the scale).
+#define SPH_TINY_R 1.0e11
 
 // ---- accumulation ----------------------------------------------------------------------------------
 
@@ -455,7 +461,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
   if constexpr (MAYFRZ) { if (SPH_FRZ_ON(S)) inwin = inwin && !sph_frozen(S, px, py, pz); }
   const double ir = rcp_refine(r, y);
   in.costh = zz * ir;
-  if (R2 > SPH_POLAR_ACC * (r * r)) {
+  if (R2 > SPH_POLAR_ACC * (r * r) && !(r < SPH_TINY_R * S.dsmall)) {
     double R, iR;
     sqrt_rsqrt(R2, R, iR);
     in.cphi = xx * iR;
@@ -1559,7 +1565,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
     // (far outside the table -- the logarithmic map only -- the radial derivative takes the reference's literal
     // evaluation in the general pass: sph_dp_lit)
-    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) ||
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) || r < SPH_TINY_R * S.dsmall ||
                          xi < S.lit_xlo || xi > S.lit_xhi;
     int idx = sph_cell(S, xi);
     ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
@@ -1802,7 +1808,7 @@ k_sph_force_staged(SphDev S, const double *__restrict__ X, const double *__restr
   const double cphi = xx * iR, sphi = yy * iR;
   double sinth = R * ir;
   const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
-  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) ||
+  const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) || r < SPH_TINY_R * S.dsmall ||
                        xi < S.lit_xlo || xi > S.lit_xhi;
   const int idx = sph_cell(S, xi);
   const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
@@ -1943,7 +1949,7 @@ k_sph_force_thin(SphDev S, const double *__restrict__ X, const double *__restric
     const double cphi = xx * iR, sphi = yy * iR;
     double sinth = R * ir;
     const double xi = sph_r_to_xi_rcp(S, r * S.inv_scale);
-    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL);
+    const bool special = (r > S.rmax && !S.no_exterior) || !(fac > SPH_POLAR_FAC * (r * r)) || !(fac > DSMALL) || r < SPH_TINY_R * S.dsmall;
     const int idx = sph_cell(S, xi);
     const double ffac = sph_d_xi_to_r_rcp(S, xi) * S.inv_dxi;
     double dfac = -(r * r) * iR2;

@@ -66,6 +66,27 @@ def one(t, rng):
         if rng.random() < 0.4:
             od["mlim"] = int(rng.integers(0, cg.mmax + 1))
     sc = float(inp["scale"])
+    # round 5, drawn after the option keys: on a third of the trials a few particles sit where the reference's arithmetic is
+    # ill-conditioned -- a ladder of polar angles and of radii towards the centre in the halo, of distances from the axis in
+    # the disk -- and a few start at rest (v.a = 0, v.v = 0 in the time-step criteria)
+    if rng.random() < 0.33:
+        hp, hv, dp, dv = (inp[k].copy() for k in ("halo_pos", "halo_vel", "disk_pos", "disk_vel"))
+        for i in range(min(len(hp), 8)):
+            th, ph, rr = 10.0 ** rng.uniform(-9, -2), rng.uniform(0, 2 * np.pi), sc * np.exp(rng.uniform(np.log(0.05), np.log(3.0)))
+            hp[i] = [rr * np.sin(th) * np.cos(ph), rr * np.sin(th) * np.sin(ph), rng.choice([-1.0, 1.0]) * rr * np.cos(th)]
+        for i in range(8, min(len(hp), 12)):
+            u = rng.normal(0, 1, 3)
+            hp[i] = u / np.linalg.norm(u) * sc * 10.0 ** rng.uniform(-12, -3)
+        for i in range(12, min(len(hp), 15)):
+            hv[i] = 0.0
+        # (not in a disk of one: the azimuthal force of a particle on ITSELF cancels exactly, Pc sin(m phi) - Ps cos(m phi)
+        # with (Pc, Ps) ~ (cos, sin)(m phi), and what rounding leaves of it is divided by R: 1e-8 of the force at R = 1e-13)
+        for i in range(min(len(dp), 6) if len(dp) >= 100 else 0):
+            Rr, ph = 0.01 * 10.0 ** rng.uniform(-12, -3), rng.uniform(0, 2 * np.pi)
+            dp[i] = [Rr * np.cos(ph), Rr * np.sin(ph), 0.001 * rng.normal(0, 1.0)]
+        for i in range(6, min(len(dp), 8)):
+            dv[i] = 0.0
+        inp = dict(inp, halo_pos=hp, halo_vel=hv, disk_pos=dp, disk_vel=dv)
     prm = orc.params(**c4.sph_window(g, sc))
     nb = NBodyOracle(orc, ms, dtime, dyn)
     ctx.set_dense_min(dense_min)
@@ -123,7 +144,10 @@ def one(t, rng):
             p = np.stack([s[q] for q in "xyz"], 1)
             v = np.stack([s["v" + q] for q in "xyz"], 1)
             a = np.stack([s["a" + q] for q in "xyz"], 1)
-            e = [np.abs(out["pos"] - p).max() / 1e-11, np.abs(out["vel"] - v).max() / (1e-9 * max(np.abs(v).max(), 1e-300)),
+            # (positions: 1e-11 of the box, or of the distance a particle has been flung to -- one that starts 1e-13 from the
+            # centre of an l >= 1 expansion sees a gradient ~ 1/r and leaves at 1e6, in the reference as here)
+            e = [(np.abs(out["pos"] - p).max(1) / (1e-11 * np.maximum(1.0, np.abs(p).max(1)))).max(),
+                 np.abs(out["vel"] - v).max() / (1e-9 * max(np.abs(v).max(), 1e-300)),
                  np.abs(out["acc"] - a).max() / (1e-9 * max(np.linalg.norm(a, axis=1).max(), 1e-300)),
                  np.abs(out["pot"] - s["pot"]).max() / (1e-9 * max(np.abs(s["pot"]).max(), 1e-300))]
             cmax = max(np.abs(s["coefN"]).max(), 1e-300)
@@ -139,6 +163,11 @@ def one(t, rng):
             e.append(np.abs(gc - s["coef"]).max() / (1e-10 * max(np.abs(s["coef"]).max(), 1e-300)))
             if max(e) > 1.0 or not np.isfinite(max(e)):
                 status, detail = "STATE", f"step {k} {name}: worst ratio to tolerance {max(e):.2g} ({np.round(e, 2).tolist()})"
+                if os.environ.get("FUZZ_VERBOSE"):
+                    ip, ia = int(np.abs(out["pos"] - p).max(1).argmax()), int(np.abs(out["acc"] - a).max(1).argmax())
+                    o0 = inp["halo_pos" if name == "halo" else "disk_pos"]
+                    detail += (f"\n    pos: particle {ip} started at {o0[ip]} now {out['pos'][ip]} oracle {p[ip]} vel {out['vel'][ip]} / {v[ip]} level {lev[ip]}"
+                               f"\n    acc: particle {ia} started at {o0[ia]} acc {out['acc'][ia]} oracle {a[ia]} pos {out['pos'][ia]}")
                 break
         if status != "ok":
             break
