@@ -24,6 +24,9 @@ import os
 
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "4")
+# (several ranks on one node: the host driver of this pool supports dmabuf IPC only -- without this RCCL's and torch's
+# buffer sharing between processes fails with `hipIpcGetMemHandle: invalid argument`; set before anything touches HIP)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import time
 
