@@ -849,14 +849,22 @@ __global__ void __launch_bounds__(256)
 k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict__ coef,
               double *__restrict__ TF, int twin)
 {
+  // The block's values go out through LDS: a thread's own stores would be six 8-byte writes 312 bytes apart from its
+  // neighbours' (NF doubles a node) -- 64 sectors touched per store instruction; node by node, the six doubles of a
+  // harmonic are contiguous (33 -> 24 us at 257 x 129 nodes, mmax 6, nmax 12.  One wave per harmonic and 64 nodes per
+  // block, so that whole node rows leave contiguously, was slower: 36 us).
+  __shared__ double tile[256 * 6];
   const size_t nnode = (size_t)(C.numx + 1) * (C.numy + 1);
-  const size_t node = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (node >= nnode) return;
+  const size_t node0 = (size_t)blockIdx.x * 256;
+  const size_t node = node0 + threadIdx.x;
+  const bool in = node < nnode;
   const int m = blockIdx.y;
   const int NF = 3 * C.ntrig;
   const int q0 = (m == 0) ? 0 : 3 + 6 * (m - 1);
+  const int nk = (m == 0) ? 3 : 6;
   const size_t half = (size_t)(C.mmax + 1) * C.nmax;
-  if (twin && m > 0) {
+  double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (in && twin && m > 0) {
     const int nq = C.nmax & ~3;
     for (int kind = 0; kind < 3; kind++) {
       const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
@@ -873,30 +881,38 @@ k_cyl_project(CylDev C, const double *__restrict__ tab, const double *__restrict
           else if (n < C.nmax) { a[0] = fma(t[j], cc[n], a[0]); b[0] = fma(t[j], cs[n], b[0]); }
         }
       }
-      TF[node * NF + q0 + kind] = (a[0] + a[1]) + (a[2] + a[3]);
-      TF[node * NF + q0 + kind + 3] = (b[0] + b[1]) + (b[2] + b[3]);
+      v[kind] = (a[0] + a[1]) + (a[2] + a[3]);
+      v[kind + 3] = (b[0] + b[1]) + (b[2] + b[3]);
     }
-    return;
-  }
-  for (int kind = 0; kind < (m == 0 ? 3 : 6); kind++) {
-    const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
-    const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
-    // four chains (orders n = j mod 4 below the last multiple of four, the rest on chain 0); the table loads of twelve
-    // orders are issued before the first of them is used: the kernel is bound by the loads it keeps in flight
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    const int nq = C.nmax & ~3;
-    for (int nb = 0; nb < C.nmax; nb += 12) {
-      double t[12];
+  } else if (in) {
+    for (int kind = 0; kind < nk; kind++) {
+      const double *T = tab + (((size_t)kind * (C.mmax + 1) + m) * C.nmax) * nnode + node;
+      const double *c = coef + (kind >= 3 ? half : 0) + (size_t)m * C.nmax;
+      // four chains (orders n = j mod 4 below the last multiple of four, the rest on chain 0); the table loads of twelve
+      // orders are issued before the first of them is used: the kernel is bound by the loads it keeps in flight
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      const int nq = C.nmax & ~3;
+      for (int nb = 0; nb < C.nmax; nb += 12) {
+        double t[12];
 #pragma unroll
-      for (int j = 0; j < 12; j++) t[j] = nb + j < C.nmax ? T[(size_t)(nb + j) * nnode] : 0.0;
+        for (int j = 0; j < 12; j++) t[j] = nb + j < C.nmax ? T[(size_t)(nb + j) * nnode] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; j++) {
-        const int n = nb + j;
-        if (n < nq) a[j & 3] = fma(t[j], c[n], a[j & 3]);
-        else if (n < C.nmax) a[0] = fma(t[j], c[n], a[0]);
+        for (int j = 0; j < 12; j++) {
+          const int n = nb + j;
+          if (n < nq) a[j & 3] = fma(t[j], c[n], a[j & 3]);
+          else if (n < C.nmax) a[0] = fma(t[j], c[n], a[0]);
+        }
       }
+      v[kind] = (a[0] + a[1]) + (a[2] + a[3]);
     }
-    TF[node * NF + q0 + kind] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) if (k < nk) tile[threadIdx.x * nk + k] = v[k];
+  __syncthreads();
+  const int nvalid = nnode - node0 < 256 ? (int)(nnode - node0) : 256;
+  for (int e = threadIdx.x; e < nvalid * nk; e += 256) {
+    const int nd = e / nk, k = e - nd * nk;
+    TF[(node0 + nd) * NF + q0 + k] = tile[e];
   }
 }
 
