@@ -195,8 +195,17 @@ __device__ __forceinline__ void pseudo_accel(const PseudoDev &P, double x, doubl
 // them: atan2(+-0, +0) = +-0, atan2(+-0, -0) = +-pi (cos = -1, sin = +-1.22e-16: sin of the double next to pi).  The
 // sign of a zero x is the sign of the odd-m terms there (src/SphericalBasis.cc:1548, src/Cylinder.cc:1333; they do not
 // vanish on the axis: the sphere's P_l^1 sees |cos(theta)| = 1 - 1 ulp, the disk's tables are extrapolated below rmin).
+// (x*x + y*y can also be zero by UNDERFLOW -- components below 1e-162 --: those are rescaled and take the ordinary route)
 __device__ __forceinline__ void atan2_trig_zero(double xx, double yy, double &c, double &s)
 {
+  const double ax = __builtin_fabs(xx), ay = __builtin_fabs(yy), mx = ax > ay ? ax : ay;
+  if (mx > 0.0) {
+    const double u = xx / mx, v = yy / mx;
+    const double iR = 1.0 / __builtin_sqrt(u * u + v * v);
+    c = u * iR;
+    s = v * iR;
+    return;
+  }
   const bool neg = __builtin_signbit(xx);
   c = neg ? -1.0 : 1.0;
   s = neg ? __builtin_copysign(1.2246467991473532e-16, yy) : yy;

@@ -254,14 +254,8 @@ __device__ __forceinline__ uint32_t sph_key_cell_rcp(const SphDev &S, double x, 
 // cos(phi), sin(phi) for phi = atan2(y, x) without the transcendental round trip
 __device__ __forceinline__ void phi_trig(double xx, double yy, double &c, double &s)
 {
-  double R2 = xx * xx + yy * yy;
-  if (!(R2 > 0.0)) {
-    // x^2 + y^2 underflowed, or the particle is exactly on the axis
-    const double ax = fabs(xx), ay = fabs(yy), mx = ax > ay ? ax : ay;
-    if (!(mx > 0.0)) { atan2_trig_zero(xx, yy, c, s); return; }
-    xx /= mx; yy /= mx;
-    R2 = xx * xx + yy * yy;
-  }
+  const double R2 = xx * xx + yy * yy;
+  if (!(R2 > 0.0)) { atan2_trig_zero(xx, yy, c, s); return; }     // exactly on the axis, or x^2 + y^2 underflowed
   const double iR = 1.0 / sqrt(R2);
   c = xx * iR;
   s = yy * iR;
