@@ -52,6 +52,9 @@ struct exp_amd_force {
   bool self_consistent = true, firstime_coef = true, initializing = false;
   bool frozen() const { return !self_consistent && !firstime_coef && !initializing; }
   bool proj_dirty = true;           // projected force tables are stale w.r.t. d_coef
+  // accelerate() itself writes d_coef before it evaluates (the sphere's FIX_L0 copies, src/SphericalBasis.cc:1689-1694): a
+  // cross force on the other stream must then stay ordered behind the self force (host.hip: ev_coef / ev_self)
+  bool accel_writes_coef = false;
   exp_amd_comp *home = nullptr;     // component whose particles define the expansion centre
   // ... and what it looked like when it was destroyed while this force still pointed at it (pyEXP
   // builds its coefficients from temporary components): frame of the expansion for external targets

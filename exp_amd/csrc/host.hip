@@ -38,6 +38,8 @@ struct exp_amd_sim {
   // k & 1 (the context's stream / its auxiliary stream).  The small launches of a sub-step are
   // latency-bound, so the two components' chains fill each other's gaps.  Events carry the cross
   // dependencies: ev_self[k] = force method k has projected its tables and applied its self force;
+  // ev_coef[k] = its combined coefficient set is complete (all a THIN cross force reads: it then need not sit out the
+  // source's self force and the latency of an event that has only just been recorded);
   // ev_used[k] = the last use of force method k's tables by a cross force on the other stream.
   // Component::Adiabatic (the ton / toff / twid keys, src/Component.cc:1040-1055, :4214-4220) per component: the driver
   // evaluates it at tnow before every accumulation and differencing (exp_amd_sim_set_adiabatic)
@@ -45,7 +47,7 @@ struct exp_amd_sim {
   std::vector<Adiabatic> adb;
   bool overlap = false;
   hipStream_t main_stream = nullptr;
-  std::vector<hipEvent_t> ev_self, ev_used;
+  std::vector<hipEvent_t> ev_self, ev_used, ev_coef;
   std::vector<char> used_pending;
   hipEvent_t ev_join = nullptr;
 };
@@ -93,11 +95,13 @@ static int overlap_begin(exp_amd_sim *s)
   if (rc) return rc;
   s->main_stream = ctx->stream;
   while (s->ev_self.size() < s->comps.size()) {
-    hipEvent_t a, b;
+    hipEvent_t a, b, c;
     HIP_TRY(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&c, hipEventDisableTiming));
     s->ev_self.push_back(a);
     s->ev_used.push_back(b);
+    s->ev_coef.push_back(c);
     s->used_pending.push_back(0);
   }
   if (!s->ev_join) HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
@@ -150,6 +154,7 @@ extern "C" void exp_amd_sim_destroy(exp_amd_sim *s)
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->ev_self) (void)hipEventDestroy(e);
   for (auto e : s->ev_used) (void)hipEventDestroy(e);
+  for (auto e : s->ev_coef) (void)hipEventDestroy(e);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
@@ -363,6 +368,7 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     if ((rc = exp_amd_force_set_level(f, mlevel))) return rc;
     if (f->combined_mdrft != mdrft && (rc = exp_amd_force_compute_multistep_coefficients(f, mdrft))) return rc;
     f->combined_mdrft = -1;
+    if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_coef[k], s->ctx->stream));
     if ((rc = f->accelerate(s->comps[k], 0, /*assign=*/true, 0.0))) return rc;
     if (s->overlap) HIP_TRY(s->ctx, hipEventRecord(s->ev_self[k], s->ctx->stream));
   }
@@ -371,8 +377,20 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
     exp_amd_force *f = s->forces[pr.first];
     const bool foreign = s->overlap && ((pr.first ^ pr.second) & 1);
     if (foreign) {
-      // the source's projected tables (and the scratch of its force pass) must be ready and free
-      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_self[pr.first], 0));
+      // the source's projected tables (and the scratch of its force pass) must be ready and free -- or, for a target range
+      // the force method evaluates straight from its coefficient set (the same test as in its accelerate()), that set
+      exp_amd_comp *t = s->comps[pr.second];
+      bool thin = f->multistep > 0 && t->n && t->nlevels > 1 && !s->ctx->deterministic && s->ctx->thin_max > 0 &&
+                  !f->accel_writes_coef;
+      if (thin) {
+        size_t nthin = 0;
+        if ((rc = expamd_comp_level_count(t, mlevel, t->nlevels - 1, &nthin))) return rc;
+        thin = (long long)nthin <= s->ctx->thin_max;
+      }
+      // (... and a table-path evaluation projects the tables ITSELF, on this stream, when the source's self force -- issued
+      // above -- left them stale, i.e. was thin: the coefficient set is all it waits for then, too)
+      const bool early = thin || (f->proj_dirty && !f->accel_writes_coef);
+      HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, early ? s->ev_coef[pr.first] : s->ev_self[pr.first], 0));
       if (s->used_pending[pr.first]) HIP_TRY(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_used[pr.first], 0));
     }
     if ((rc = f->accelerate(s->comps[pr.second], 1, false, 0.0))) return rc;

@@ -1250,6 +1250,7 @@ extern "C" int exp_amd_sph_set_fix_l0(exp_amd_force *fb, int on)
   if (on && !f->d_c0.p && f->d_c0.alloc((size_t)f->cfg.nmax) != hipSuccess)
     return expamd_fail(f->ctx, EXP_AMD_ERR_HIP, "set_fix_l0: hipMalloc failed");
   f->fix_l0 = on != 0;
+  f->accel_writes_coef = f->fix_l0;
   f->have_c0 = false;
   return EXP_AMD_OK;
 }
