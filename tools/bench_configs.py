@@ -31,6 +31,8 @@ def main():
     ts = torch.cuda.Stream(device)
     torch.cuda.set_stream(ts)
     ctx = Context(0, stream=ts.cuda_stream)
+    if os.environ.get("BENCH_THIN_MAX"):                     # (A/B of exp_amd_ctx_set_thin_max; default 8192)
+        ctx.set_thin_max(int(os.environ["BENCH_THIN_MAX"]))
     which = (args.only,) if args.only else (2, 3, 4)
     for o in other_configs(ctx, device, int(args.n), which, args.steps):
         print(json.dumps(o), flush=True)
