@@ -19,8 +19,11 @@
 // The PseudoAccel helper (include/PseudoAccel.H: quadratic least squares over the last Naccel
 // (time, centre, axis) triples -> frame acceleration, angular velocity and its rate) rides along.
 // The log file and the restart from it (:84-335, :742-785) are at the end of this file.
-// Not carried over: the EXTERNAL flag (this store has no separate external potential) and keep == 0, whose code path in
-// the reference indexes its 3-vectors out of range (:741-744).
+// The EXTERNAL flag (`energy += p->potext`, :377) is accepted and adds nothing: Particle::potext only ever receives the
+// potential of the External force plug-ins (Component::AddPotExt: src/HaloBulge.cc, externalShock.cc, tidalField.cc), which
+// are outside this build; the cross forces between components add to `pot` in the reference as here
+// (src/SphericalBasis.cc:1652, src/Cylinder.cc:1416).  Not carried over: keep == 0, whose code path in the reference
+// indexes its 3-vectors out of range (:741-744).
 #include "particles.h"
 #include <cmath>
 #include <cstring>
@@ -356,8 +359,6 @@ extern "C" int exp_amd_orient_create(exp_amd_ctx *ctx, int keep, int want, unsig
   if (keep < 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: keep must be >= 1 (the keep == 0 "
                                    "branch of the reference indexes out of range, src/Orient.cc:741-744)");
   if (want < 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: target number must be >= 1");
-  if (cflags & ORI_EXTERNAL)
-    return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: EXTERNAL (potext) is not kept by this particle store");
   exp_amd_orient *o = new (std::nothrow) exp_amd_orient;
   if (!o) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "Orient: out of memory");
   o->ctx = ctx; o->keep = keep; o->many = want; o->oflags = oflags; o->cflags = cflags;

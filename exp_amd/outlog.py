@@ -4,10 +4,10 @@ centre, kinetic and potential energy, the Clausius virial, their sum and the vir
 step and the number of particles the force used.  The reference's own N-body acceptance test reads it
 (tests/Halo/check.py: the mean of column 17, 2T/VC, within 5.5 % of 1).
 
-One column differs for runs with component interactions: this particle store adds the potential of a cross force to
-``pot`` (it keeps no separate ``potext``), so a component's PE is 0.5 m (pot_self + pot_cross) where the reference writes
-0.5 m pot_self + m pot_cross (src/OutLog.cc:424-425, :520, :573); the single-component log -- the one the reference's
-test reads -- and every other column are unaffected.
+PE is 0.5 m pot + m potext (src/OutLog.cc:490-491, :589, :642).  The cross forces between components add to ``pot`` in
+the reference as here (``Component::AddPot``, src/SphericalBasis.cc:1652, src/Cylinder.cc:1416); ``potext`` only ever
+receives the External force plug-ins (``AddPotExt``), which are outside this build: it is zero, and the store keeps no
+array for it.
 
 The sums over the particles are the device's (``exp_amd_comp_log_sums``); the file is the reference's, character for
 character: a six-line header, then ``setw(10 + precision)`` columns in scientific notation joined by ``|``."""

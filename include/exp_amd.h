@@ -253,7 +253,9 @@ int  exp_amd_comp_log_sums(exp_amd_comp *c, double out[14]);
  * EJkinE, EJdT, EJdamp) (src/Component.cc:1323-1370) and consulted by Component::fix_positions
  * (:3569-3582) and the cylinder force (src/Cylinder.cc:799, :1352).
  *   oflags: 1 = AXIS, 2 = CENTER (Orient::OrientFlags);  cflags: 2 = KE (Orient::ControlFlags; DIAG
- *   is ignored, EXTERNAL is refused: no separate external potential is stored).  keep >= 1.
+ *   is ignored; 4 = EXTERNAL is accepted and adds nothing: Particle::potext only holds the potential of the External
+ *   force plug-ins, which are outside this build -- cross forces between components add to pot, src/SphericalBasis.cc:
+ *   1652, src/Cylinder.cc:1416).  keep >= 1.
  * accumulate(time, dtime, c) is Orient::accumulate(time, c) with the global time step passed in:
  * the `want` most bound particles (E = pot [+ v^2/2]) are selected on the device -- exactly, over
  * all ranks of the context -- and their mass-weighted position and angular momentum about the

@@ -109,8 +109,14 @@ def test_orient_small_component_duplicates_and_modes(ctx, oracle):
     # refused configurations
     with pytest.raises(RuntimeError, match="keep"):
         Orient(ctx, 0, 50, Orient.CENTER)
-    with pytest.raises(RuntimeError, match="EXTERNAL"):
-        Orient(ctx, 2, 50, Orient.CENTER, Orient.EXTERNAL)
+    # EXTERNAL (energy += potext, src/Orient.cc:377) is accepted: potext only ever holds the External plug-ins' potential
+    # (out of scope: zero), so the state is the one without the flag
+    o1 = Orient(ctx, 2, 50, Orient.CENTER, Orient.KE | Orient.EXTERNAL)
+    o2 = Orient(ctx, 2, 50, Orient.CENTER, Orient.KE)
+    o1.accumulate(0.0, c, 0.2); o2.accumulate(0.0, c, 0.2)
+    s1, s2 = o1.state(), o2.state()
+    assert all(np.array_equal(np.asarray(s1[k]), np.asarray(s2[k])) for k in s2)
+    o1.close(); o2.close()
     c.close()
 
 
