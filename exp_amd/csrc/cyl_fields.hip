@@ -17,13 +17,13 @@ k_cyl_fields(CylDev C, const double *__restrict__ tab, const double *__restrict_
   double R, z, phi, x = 0.0, y = 0.0, r = 0.0;
   if (coord == 0) {
     r = c1[i];
-    const double cth = c2[i], sth = sqrt(1.0 - cth * cth);
+    const double cth = c2[i], sth = sqrt(-sq_add_lit(-1.0, cth));     // 1 - cth*cth, the product rounded first (expui/BiorthBasis.cc:1753)
     R = r * sth; z = r * cth; phi = c3[i];
   } else if (coord == 1) {
     R = c1[i]; z = c2[i]; phi = c3[i];
   } else {
     x = c1[i]; y = c2[i]; z = c3[i];
-    R = sqrt(x * x + y * y);
+    R = sqrt(sq_sum2_lit(x, y));                                       // (:1780; no fused multiply-add: sq_sum2_lit, common.h)
     phi = atan2(y, x);
   }
   double p0 = 0.0, p = 0.0, fr = 0.0, fz = 0.0, fp = 0.0, d0 = 0.0, d = 0.0;

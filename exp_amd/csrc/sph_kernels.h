@@ -277,23 +277,6 @@ __device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py
   return r2 > F[6];
 }
 
-// xx^2 + yy^2 and (xx^2 + yy^2) + zz^2 as the reference's compiler forms them (src/SphericalBasis.cc:1545, :1630): every
-// product rounded on its own, no fused multiply-add.  For the general force pass: a lane within ~1e-7 rad of the polar
-// axis has 1 - |cos(theta)| of a few ulp, its Legendre functions of order m >= 1 go with the square root of that, and one
-// ulp of r^2 decides whether it is two, three or four of them (+-18 % in the tangential force of such a lane).
-__device__ __forceinline__ double sq_sum2_lit(double a, double b)
-{
-  double p = a * a, q = b * b;
-  asm volatile("" : "+v"(p), "+v"(q));
-  return p + q;
-}
-__device__ __forceinline__ double sq_add_lit(double s, double c)
-{
-  double q = c * c;
-  asm volatile("" : "+v"(q));
-  return s + q;
-}
-
 // sin^2(theta) below which the accumulation forms cos(theta), sin(theta) as the reference does (a lane-level branch)
 #ifndef SPH_POLAR_ACC
 #define SPH_POLAR_ACC 1.0e-4

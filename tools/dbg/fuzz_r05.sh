@@ -5,7 +5,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/fuzz_r05
 mkdir -p $OUT; cd $REPO
-python3 tests/fuzz/fuzz_multistep.py 1500 97 > $OUT/multistep.txt 2>&1; tail -1 $OUT/multistep.txt
+python3 tests/fuzz/fuzz_multistep.py 1500 ${SEED0:-97} > $OUT/multistep.txt 2>&1; tail -1 $OUT/multistep.txt
 EXP_AMD_SPH_GENERIC=1 EXP_AMD_CYL_GENERIC=1 python3 tests/fuzz/fuzz_multistep.py 400 101 > $OUT/multistep_generic.txt 2>&1; tail -1 $OUT/multistep_generic.txt
 EXP_AMD_SIM_OVERLAP=0 python3 tests/fuzz/fuzz_multistep.py 400 103 > $OUT/multistep_one_stream.txt 2>&1; tail -1 $OUT/multistep_one_stream.txt
 python3 tests/fuzz/fuzz_parity.py 300 107 both > $OUT/parity.txt 2>&1; tail -1 $OUT/parity.txt
