@@ -1415,18 +1415,30 @@ extern "C" int exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel)
   return EXP_AMD_OK;
 }
 
+// Component::freeze (src/Component.cc:4194-4202) for the sums below: frz = {com0[3], center[3], rtrunc^2} on the device
+// (exp_amd_comp::d_frz), nullptr when rtrunc is not set; the reference's operation order
+__device__ __forceinline__ bool comp_frozen(const double *__restrict__ F, double px, double py, double pz)
+{
+  if (!F) return false;
+  const double dx = (px - F[0]) - F[3], dy = (py - F[1]) - F[4], dz = (pz - F[2]) - F[5];
+  double r2 = dx * dx;
+  r2 = mul_then_add(r2, dy, dy);
+  r2 = mul_then_add(r2, dz, dz);
+  return r2 > F[6];
+}
+
 // ---- centre of mass / velocity / acceleration (Component::fix_positions) -----------------------------
 // src/Component.cc:3280-3351 (thread body: per-level sums of m, m x, m v, m a over the levels
 // >= mlevel), :3354-3554 (levels below mlevel keep their previous sums, all-reduce over ranks,
-// division by the total mass).  Escape/tidal bookkeeping (consp), frozen particles and the EJ
-// orientation centre are outside this path.
+// division by the total mass).  A frozen particle (beyond rtrunc, :3336) is skipped.  Escape/tidal bookkeeping (consp)
+// and the EJ orientation centre are outside this path.
 #define COM_MAXLEV 16
 __global__ void __launch_bounds__(256)
 k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
              const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
              const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
              const double *__restrict__ AZ, double back, const uint8_t *__restrict__ lev, size_t n, int mlevel,
-             int nlev, double *__restrict__ out /* [nlev][10] */)
+             int nlev, double *__restrict__ out /* [nlev][10] */, const double *__restrict__ frz)
 {
   __shared__ double acc[COM_MAXLEV][10];
   for (int k = threadIdx.x; k < COM_MAXLEV * 10; k += 256) (&acc[0][0])[k] = 0.0;
@@ -1438,9 +1450,10 @@ k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const d
     double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
       if (nlev > 1 && lev[i] != L) continue;
-      const double m = M[i];
+      const double m = M[i], px = X[i], py = Y[i], pz = Z[i];
+      if (comp_frozen(frz, px, py, pz)) continue;
       v[0] += m;
-      v[1] = fma(m, X[i], v[1]);  v[2] = fma(m, Y[i], v[2]);  v[3] = fma(m, Z[i], v[3]);
+      v[1] = fma(m, px, v[1]);  v[2] = fma(m, py, v[2]);  v[3] = fma(m, pz, v[3]);
       const double ax = AX[i], ay = AY[i], az = AZ[i];
       double vx = VX[i], vy = VY[i], vz = VZ[i];
       if (back != 0.0) {        // prekicked store: the step-boundary velocity, formed on the fly (expamd_comp_velocity_view)
@@ -1465,14 +1478,14 @@ k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const d
 
 // ---- the run log's sums (OutLog::Run, src/OutLog.cc:392-446) ------------------------------------------
 // Per component: mass, m x, m v, angular momentum, kinetic energy, 0.5 m pot, the Clausius virial m x.a -- over every
-// particle (no frozen particles in this store), positions and velocities as stored (com_system off: Local = Inertial).
+// particle that is not frozen (beyond rtrunc, src/OutLog.cc:460), positions and velocities as stored (com_system off: Local = Inertial).
 // Velocities are the step-boundary ones (expamd_comp_velocity_view), as at the reference's call after the second kick.
 __global__ void __launch_bounds__(256)
 k_log_sums(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
            const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
            const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
            const double *__restrict__ AZ, const double *__restrict__ P, double back, size_t n,
-           double *__restrict__ out /* [13] */)
+           double *__restrict__ out /* [13] */, const double *__restrict__ frz)
 {
   __shared__ double acc[13];
   if (threadIdx.x < 13) acc[threadIdx.x] = 0.0;
@@ -1481,6 +1494,7 @@ k_log_sums(const double *__restrict__ M, const double *__restrict__ X, const dou
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const double m = M[i], x = X[i], y = Y[i], z = Z[i];
+    if (comp_frozen(frz, x, y, z)) continue;
     const double ax = AX[i], ay = AY[i], az = AZ[i];
     double vx = VX[i], vy = VY[i], vz = VZ[i];
     if (back != 0.0) { vx = mul_then_add(vx, ax, back); vy = mul_then_add(vy, ay, back); vz = mul_then_add(vz, az, back); }
@@ -1520,7 +1534,7 @@ extern "C" int exp_amd_comp_log_sums(exp_amd_comp *c, double out[14])
     if (grid > 2048) grid = 2048;
     k_log_sums<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX), c->a(A_VY),
                                              c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), back, c->n,
-                                             c->com_red.p);
+                                             c->com_red.p, expamd_comp_frz(c));
     HIP_TRY(ctx, hipGetLastError());
   }
   // the reference's MPI_Reduce of each sum (:448-478); the body count travels as the fourteenth double
@@ -1562,7 +1576,7 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
     k_com_levels<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX),
                                                c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
                                                c->a(A_AZ), back, c->level[c->cur].p, c->n, mlevel, nlev,
-                                               c->com_lev.p);
+                                               c->com_lev.p, expamd_comp_frz(c));
     HIP_TRY(ctx, hipGetLastError());
   }
   // sum the levels on the host side of one small read-back; ranks are combined first (:3500-3503)

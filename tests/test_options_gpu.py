@@ -160,6 +160,46 @@ def test_cylinder_freeze_adiabatic_and_mlim_against_the_oracle(ctx, oracle, mlim
     c.close(); f.close()
 
 
+def test_frozen_particles_are_left_out_of_the_centre_and_log_sums(ctx):
+    """``if (c->freeze(n)) continue;`` also sits in Component::fix_positions (src/Component.cc:3336) and in OutLog's sums
+    (src/OutLog.cc:460): total mass, centres of mass / velocity / acceleration, angular momentum, energies and the virial
+    are over the particles inside rtrunc of com0 + center.  Against numpy with the reference's test."""
+    from exp_amd.runtime import Component
+    rng = np.random.default_rng(23)
+    n = 40000
+    m = rng.uniform(0.5, 1.5, n) / n
+    pos, vel, acc = rng.standard_normal((3, n, 3))
+    pot = rng.standard_normal(n)
+    com0, ctr, rtrunc = np.array([0.2, -0.1, 0.05]), np.array([-0.05, 0.1, 0.0]), 1.3
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(acc, pot)
+    c.set_center(ctr)
+    c.set_rtrunc(rtrunc, com0)
+    d = pos - com0 - ctr
+    keep = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]) <= rtrunc * rtrunc
+    assert 0.2 * n < keep.sum() < 0.8 * n
+    mk = m[keep]
+    got = c.fix_positions(0)
+    mt = mk.sum()
+    assert abs(got["mtot"] - mt) <= 1e-13 * mt
+    for key, arr in (("com", pos), ("cov", vel), ("coa", acc)):
+        ref = (mk[:, None] * arr[keep]).sum(0) / mt
+        assert np.abs(got[key] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-3), key
+    lg = c.log_sums()
+    assert abs(lg["mtot"] - mt) <= 1e-13 * mt and lg["nbodies"] == n
+    p, v, a = pos[keep], vel[keep], acc[keep]
+    ref = {"com": (mk[:, None] * p).sum(0), "cov": (mk[:, None] * v).sum(0), "angm": (mk[:, None] * np.cross(p, v)).sum(0)}
+    for key in ref:
+        assert np.abs(lg[key] - ref[key]).max() <= 1e-12 * max(np.abs(ref[key]).max(), 1e-3), key
+    assert abs(lg["ektot"] - (0.5 * mk * (v * v).sum(1)).sum()) <= 1e-12 * lg["ektot"]
+    assert abs(lg["eptot"] - (0.5 * mk * pot[keep]).sum()) <= 1e-12 * max(abs(lg["eptot"]), 1e-3)
+    assert abs(lg["clausius"] - (mk * (p * a).sum(1)).sum()) <= 1e-12 * max(abs(lg["clausius"]), 1e-3)
+    # rtrunc back at its default: everything counts again
+    c.set_rtrunc(1.0e20, com0)
+    assert abs(c.fix_positions(0)["mtot"] - m.sum()) <= 1e-13 * m.sum()
+    c.close()
+
+
 def test_mlim_refusals(ctx):
     from exp_amd.runtime import Cylinder
     cg, _ = load_cyl()
