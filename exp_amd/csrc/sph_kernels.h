@@ -285,8 +285,9 @@ __device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py
 // a lane takes the general pass: the fast arithmetic forms sin(theta) = R/r and 1/(x*x - 1) = -r^2/R^2 from the true R, the
 // reference from x = z/r with the OFFSET r -- a relative difference of 2 DSMALL / r in every m >= 1 and every theta-derivative
 // term (1.5e-8 of the acceleration at r = 1.3e-8: a particle the block-multistep campaign placed there left on a
-// different trajectory).  1e-11 at this radius; nothing of a realistic set is inside it (rmin is 1e-3 of the scale).
-#define SPH_TINY_R 1.0e11
+// different trajectory).  2e-12 at this radius (r = 1e-4 with the n-body offset); a handful of particles of a realistic set
+// are inside it (rmin is 1e-3 of the scale).
+#define SPH_TINY_R 1.0e12
 
 // ---- accumulation ----------------------------------------------------------------------------------
 
