@@ -195,7 +195,8 @@ def _polar_ladder(g, n, rng):
     return pos
 
 
-@pytest.mark.parametrize("kind,lmax,nmax,numr", [("plummer", 4, 8, 400), ("nfw", 6, 18, 2000), ("plummer_log", 4, 8, 3000)])
+@pytest.mark.parametrize("kind,lmax,nmax,numr", [("plummer", 4, 8, 400), ("nfw", 6, 18, 2000), ("plummer_log", 4, 8, 3000),
+                                                 ("plummer", 14, 4, 300)])      # (lmax 14: the any-order kernels)
 @pytest.mark.parametrize("external", [True, False])
 def test_polar_axis_lanes(ctx, oracle, kind, lmax, nmax, numr, external):
     """Near the polar axis the reference's own arithmetic is ill-conditioned -- sqrt((1-x)(1+x)) and 1/(x*x-1) from the
