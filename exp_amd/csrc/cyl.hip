@@ -3,6 +3,7 @@
 // cyl_kernels.h, the analysis entry points (fields, covariance, basis functions) in cyl_fields.hip.
 #include "cyl_kernels.h"
 #include "cyl_force.h"
+#include "kick_adjust.h"
 
 extern "C" int exp_amd_cyl_create(exp_amd_ctx *ctx, const exp_amd_cyl_config *cfg, const double *tab,
                                   exp_amd_force **out)
@@ -211,7 +212,9 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level
   if (have_keys && level < 0) {
     // c->key was written by the previous fused step's force pass for exactly this advance
     ProfScope ps(ctx, "k_hist_keys");
-    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+    // (a block-multistep run: the closing sweep's full keys; those of the levels that are not cell-sorted collapse here)
+    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p,
+                                                                    f->multistep ? c->sparse_mask : 0u, ncell);
   } else {
     size_t nr = c->n;          // a level range is sized for its own population
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
@@ -244,6 +247,15 @@ k_cyl_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size
 {
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k < n) dst[k] += src[k];
+}
+
+bool CylForce::prekey_launcher(exp_amd_comp *c, ka_launch_fn *fn, void **self)
+{
+  if (multistep == 0 || c->n == 0 || c->n >= 0x7fffffffu) return false;
+  ka_C = cdev_for(this, c);
+  *fn = [](void *p, const KaLaunch &L) { ka_launch_with(L, CylKeyFn{static_cast<CylForce *>(p)->ka_C, 0u}); };
+  *self = this;
+  return true;
 }
 
 int CylForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)
@@ -460,7 +472,9 @@ int CylForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
         (rc = adv.mode ? expamd_comp_settle_pending(c, lo, dmax, true) : expamd_comp_settle_pending(c, 0, ms, false)))
       return rc;
     if (dmax >= lo) {
-      rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
+      // (sub-step 0 of a master step: the sweep that closed the last one wrote these keys, k_kick_adjust / kick_adjust.h)
+      const bool keys_there = full && lo == 0 && adv.mode == 2 && expamd_comp_mprekey_ok(c, f, adv.dt_min);
+      rc = sort(c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, keys_there, dmax);
       if (rc) return rc;
     }
     c->commit_pending = false;          // (the scatter stored the proposed levels)

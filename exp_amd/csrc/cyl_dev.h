@@ -131,6 +131,7 @@ __device__ __forceinline__ void cyl_weights(const CylDev &C, double r, double z,
 
 // sort key: level * (ncell+1) + cell, cell = ix*numy + iy; off-grid particles share bin ncell
 struct CylKeyFn {
+  static constexpr bool on = true;     // (k_kick_adjust: writes keys, kick_adjust.h)
   CylDev C;
   uint32_t sparse_mask;      // levels that are not cell-sorted: all their particles share bin 0
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const

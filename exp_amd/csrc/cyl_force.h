@@ -46,6 +46,8 @@ struct CylForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  bool prekey_launcher(exp_amd_comp *c, ka_launch_fn *fn, void **self) override;
+  CylDev ka_C;
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1, int phase = 0) override;
   long long sparse_threshold() const override { return 3000000LL / (4 * dev.ntrig); }
   int resort(exp_amd_comp *c, int first = 0) override;

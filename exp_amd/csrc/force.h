@@ -33,6 +33,9 @@ __device__ __forceinline__ double expamd_combine_one(const double *__restrict__ 
 }
 #endif
 
+struct KaLaunch;                                        // kick_adjust.h
+typedef void (*ka_launch_fn)(void *self, const KaLaunch &L);
+
 struct exp_amd_force {
   exp_amd_ctx *ctx = nullptr;
   int multistep = 0;
@@ -90,6 +93,9 @@ struct exp_amd_force {
   // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]
   // (src/SphericalBasis.cc:1033-1079, :1156-1228; src/CylEXP.cc:56-188), reduced over ranks
   virtual int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) = 0;
+  // a launcher of k_kick_adjust that also writes component c's sort keys for sub-step 0 of the next master step (this
+  // force's cells, full keys: the sort collapses those of sparse levels); false: not offered (any-order bases, ...)
+  virtual bool prekey_launcher(exp_amd_comp *, ka_launch_fn *, void **) { return false; }
   // re-establish this basis' (level, cell) order after levels changed
   // (only levels >= first can have changed: their slot range alone is re-ordered)
   virtual int resort(exp_amd_comp *c, int first = 0) = 0;

@@ -470,8 +470,26 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     bool launched = false;
     if (((++s->pub_seq) & 0xffffffull) == 0) ++s->pub_seq;       // (the tag of a word never written)
     const unsigned long long seq = s->pub_seq & 0xffffffull;
-    if ((rc = expamd_comp_kick_adjust(s->comps[k], s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
-                                      kick ? mf : ms + 1, first, dt_min, &res, s->pinned_dev + k * 40, seq, &launched, /*build_list=*/true))) return rc;
+    // The sweep that closes a master step examines every slot and is followed by sub-step 0 of the next one, in which every
+    // level is advanced: it writes that sub-step's sort keys on the way (the force method's instantiation of the kernel,
+    // kick_adjust.h), and the sort counts those instead of reading x, v, a once more (73 B a slot against 4 + 28 here).
+    exp_amd_comp *ck = s->comps[k];
+    exp_amd_force *fk = s->forces[k];
+    ka_launch_fn kfn = nullptr;
+    void *kself = nullptr;
+    const bool closing = kick && !first_step && mdrft == s->Mstep && first == 0 && !s->orients[k] && ck->nlevels == ms + 1 &&
+                         ck->pending_kick == 0.0 && EXPAMD_EXPT("EXP_AMD_MS_PREKEY", 1) != 0;
+    if (closing && !fk->prekey_launcher(ck, &kfn, &kself)) kfn = nullptr;
+    if ((rc = expamd_comp_kick_adjust(ck, s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
+                                      kick ? mf : ms + 1, first, dt_min, &res, s->pinned_dev + k * 40, seq, &launched, /*build_list=*/true,
+                                      kfn, kself))) return rc;
+    if (kfn && launched && ck->mprekey_n == ck->n) {
+      ck->mprekey_valid = true;
+      ck->mprekey_owner = (const void *)fk;
+      ck->mprekey_epoch = ctx->force_epoch;
+      ck->mprekey_dt_min = dt_min;
+      for (int q = 0; q < 3; q++) ck->mprekey_center[q] = ck->center[q];
+    }
     if (launched) want[k] = seq;
     else {
       // nothing in the examined range: no counts, and no sweep on this component's stream to wait for -- but this

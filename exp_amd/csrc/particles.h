@@ -99,6 +99,14 @@ struct exp_amd_comp {
   const void *prekey_owner = nullptr;   // force whose cells the keys are
   unsigned long long prekey_epoch = 0;  // ctx->force_epoch when they were written
   double prekey_dtk = 0, prekey_dtd = 0, prekey_center[3] = {0, 0, 0};
+  // ... and for a block-multistep run: the sweep that closed a master step (k_kick_adjust with the force's key function)
+  // left in `key` the (level, cell) keys of sub-step 0 of the NEXT one -- for this force (owner, epoch), this smallest
+  // step, this centre, this many particles; any call that touches the store drops them (expamd_comp_touch)
+  bool mprekey_valid = false;
+  const void *mprekey_owner = nullptr;
+  unsigned long long mprekey_epoch = 0;
+  double mprekey_dt_min = 0, mprekey_center[3] = {0, 0, 0};
+  size_t mprekey_n = 0;
 
   // Split fused step (exp_amd_step_kdk on large single-level components): the slots [0, half) and
   // [half, n) are two independently cell-sorted halves; half_off = {0, half, n} on the device plays

@@ -5,6 +5,7 @@
 // (velocityKick).  Layout is fp64 SoA so that every pass streams HBM with coalesced
 // 8-byte-per-lane loads; a level is a contiguous slot range [lev_off[M], lev_off[M+1]).
 #include "sort_kernels.h"
+#include "kick_adjust.h"
 
 #define TPB 256
 
@@ -293,6 +294,7 @@ int expamd_launch_scan_full(exp_amd_ctx *ctx, hipStream_t st, uint32_t *hist, ui
 int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
 {
   exp_amd_ctx *ctx = c->ctx;
+  c->mprekey_valid = false;            // (every sort uses the key array and moves slots: a caller that has such keys asked first)
   if (c->hist_cap < (size_t)nkeys + 1) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
@@ -417,10 +419,18 @@ int expamd_comp_flush_commit(exp_amd_comp *c)
   return rc;
 }
 
+bool expamd_comp_mprekey_ok(const exp_amd_comp *c, const void *owner, double dt_min)
+{
+  return c->mprekey_valid && c->mprekey_owner == owner && c->mprekey_epoch == c->ctx->force_epoch && c->mprekey_dt_min == dt_min &&
+         c->mprekey_n == c->n && c->mprekey_center[0] == c->center[0] && c->mprekey_center[1] == c->center[1] &&
+         c->mprekey_center[2] == c->center[2] && c->pending_kick == 0.0;
+}
+
 int expamd_comp_touch(exp_amd_comp *c)
 {
   expamd_mutated();
   c->prekey_valid = false;
+  c->mprekey_valid = false;
   if (c->commit_pending) { int rc = expamd_comp_flush_commit(c); if (rc) return rc; }
   if (c->partition_stale) { int rc = partition_by_level(c); if (rc) return rc; }
   return expamd_comp_apply_pending(c);
@@ -593,25 +603,6 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
 // [first, multistep]: five time-step criteria -> dtreq (rounded to float like Particle::dtreq,
 // include/Particle.H:60) -> target level.  Levels are only PROPOSED here (newlev); the force
 // method applies its coefficient differencing and the store commits + re-sorts afterwards.
-// v.a, v.v and a.a of the time-step criteria as the reference's compiler forms them (src/multistep.cc:100-108): every
-// product rounded on its own, added in the order of k.  v.a of a near-circular orbit is what is left of terms a
-// thousand to a million times larger; a fused multiply-add leaves a different residue, and the criterion built on it
-// (dta) decides a level where it is the smallest.
-__device__ __forceinline__ void level_sums_lit(double v0, double v1, double v2, double a0, double a1, double a2,
-                                               double &dtr, double &vtot, double &atot)
-{
-#pragma clang fp contract(off)
-  dtr = 0.0; vtot = 0.0; atot = 0.0;
-  dtr += v0 * a0; vtot += v0 * v0; atot += a0 * a0;
-  dtr += v1 * a1; vtot += v1 * v1; atot += a1 * a1;
-  dtr += v2 * a2; vtot += v2 * v2; atot += a2 * a2;
-}
-
-struct AdjustArgs {
-  double dtime, dynD, dynV, dynS, dynA, dynP;
-  int multistep, shiftlevl, mfirst_mdrft;
-};
-
 __global__ void __launch_bounds__(TPB)
 k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__restrict__ vy,
                 const double *__restrict__ vz, const double *__restrict__ ax,
@@ -660,130 +651,6 @@ k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, s
 {
   const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i < n) lev[i] = newlev[i];
-}
-
-// The second half of a block-multistep sub-step in one pass over the slots of the levels that take
-// part: incr_velocity(0.5*dt*mintvl[M], M) for M >= kick_lo (src/step.cc:198-203) and, on the kicked
-// velocities, adjust_multistep_level's sweep over the levels >= first (src/multistep.cc:52-236), as
-// k_adjust_levels above.  out[0] += level changes; out[1 + L] += particles proposed for level L
-// among those examined (the host derives the new level offsets from them without a second
-// read-back).  kick_lo > last: no kick (begin_run's first assignment).
-#define KA_ITEMS 8       // 256-slot tiles per block at most (the counters leave a block as one atomic per value); the
-                         // short ranges of the upper levels take one tile per block: a block's tiles run one after the other
-__global__ void __launch_bounds__(TPB)
-k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
-              const double *__restrict__ ax, const double *__restrict__ ay,
-              const double *__restrict__ az, const double *__restrict__ pot,
-              const uint8_t *__restrict__ lev, uint8_t *__restrict__ newlev,
-              const uint32_t *__restrict__ lev_off, int kick_lo, int first, int last, double dt_min,
-              unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_next, int items,
-              unsigned int *__restrict__ ticket = nullptr, unsigned long long *__restrict__ host_out = nullptr,
-              unsigned long long seq = 0ull,
-              uint32_t *__restrict__ list = nullptr /* the movers' slots are compacted here as well (k_mover_list's job) */,
-              uint32_t *__restrict__ lcnt = nullptr, uint32_t *__restrict__ lcnt_next = nullptr)
-{
-  // two counter sets are used alternately: this launch leaves the other one clean for the next
-  if (blockIdx.x == 0 && threadIdx.x < 32) out_next[threadIdx.x] = 0ull;
-  if (list && blockIdx.x == 0 && threadIdx.x == 0) { lcnt_next[0] = 0u; lcnt_next[1] = 0u; }
-  __shared__ unsigned int cnt[32];
-  __shared__ uint32_t s_ml[KA_ITEMS * TPB];      // the block's movers: one claim of the list per block
-  __shared__ unsigned int s_mln, s_mlbase;
-  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) s_mln = 0;
-  __syncthreads();
-  const int lo = kick_lo < first ? kick_lo : first;
-  const size_t beg = lev_off[lo], end = lev_off[last + 1], ebeg = lev_off[first];
-  const int lane = threadIdx.x & 63;
-  for (int it = 0; it < items; it++) {
-    const size_t i = beg + ((size_t)blockIdx.x * items + it) * TPB + threadIdx.x;
-    if (i - threadIdx.x >= end) break;          // (block-uniform)
-    const bool valid = i < end;
-    unsigned plev = 0, nlev = 0;
-    bool examined = false;
-    if (valid) {
-      plev = lev[i];
-      nlev = plev;
-      double v0 = vx[i], v1 = vy[i], v2 = vz[i];
-      const double a0 = ax[i], a1 = ay[i], a2 = az[i];
-      if ((int)plev >= kick_lo) {
-        const double dtk = 0.5 * level_dt(dt_min, A.multistep, (int)plev);
-        v0 = mul_then_add(v0, a0, dtk);
-        v1 = mul_then_add(v1, a1, dtk);
-        v2 = mul_then_add(v2, a2, dtk);
-        vx[i] = v0; vy[i] = v1; vz[i] = v2;
-      }
-      examined = i >= ebeg;
-      if (examined) {
-        const double eps = 1.0e-10;
-        double dtr, vtot, atot;
-        level_sums_lit(v0, v1, v2, a0, a1, a2, dtr, vtot, atot);
-        const double ptot = fabs(pot[i]);
-        const double dts = 1.0 / eps;                  // Particle::scale <= 0: criterion off
-        const double dtd = A.dynD * 1.0 / sqrt(vtot + eps);
-        const double dtv = A.dynV * sqrt(vtot / (atot + eps));
-        const double dta = A.dynA * ptot / (fabs(dtr) + eps);
-        const double dtA = A.dynP * sqrt(ptot / (atot + eps));
-        double dmin = dtd;
-        if (dtv < dmin) dmin = dtv;
-        if (dts < dmin) dmin = dts;
-        if (dta > 0.0 && dta < dmin) dmin = dta;
-        if (dtA > 0.0 && dtA < dmin) dmin = dtA;
-        const double dt = dmin > eps ? dmin : eps;
-        const float dtreq = (float)dt;
-        if ((double)dtreq > A.dtime) nlev = 0;
-        else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
-        if (A.shiftlevl) {
-          if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
-          else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
-        }
-        if (nlev > (unsigned)A.multistep) nlev = A.multistep;
-        if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
-        newlev[i] = (uint8_t)nlev;
-      }
-    }
-    // wave-aggregated counters in LDS: one add per wave and value
-    const unsigned long long sw = __ballot(examined && nlev != plev);
-    if (lane == 0 && sw) atomicAdd(&cnt[0], (unsigned)__popcll(sw));
-    if (list && sw) {                           // (wave-uniform)
-      unsigned int base = 0;
-      if (lane == 0) base = atomicAdd(&s_mln, (unsigned)__popcll(sw));
-      base = (unsigned int)__shfl((int)base, 0);
-      if ((sw >> lane) & 1ull) s_ml[base + __popcll(sw & ((1ull << lane) - 1ull))] = (uint32_t)i;
-    }
-    for (int L = A.mfirst_mdrft; L <= A.multistep; L++) {
-      const unsigned long long mm = __ballot(examined && (int)nlev == L);
-      if (lane == 0 && mm) atomicAdd(&cnt[1 + L], (unsigned)__popcll(mm));
-    }
-  }
-  __syncthreads();
-  if (list && s_mln) {                          // (block-uniform)
-    if (threadIdx.x == 0) s_mlbase = atomicAdd(lcnt + 1, s_mln);
-    __syncthreads();
-    for (unsigned int k = threadIdx.x; k < s_mln; k += TPB) list[s_mlbase + k] = s_ml[k];
-  }
-  // host_out: the LAST block to finish hands the 32 counters to the host itself -- page-locked, host-coherent words, each
-  // tagged with the sweep's sequence number, which the step driver polls (no copy launch behind the kernel, no stream
-  // wait).  The counters are only ever touched by device-scope atomics, performed at the memory side: the adds RETURN
-  // (so they are done before the ticket is drawn) and the last block reads them with atomics too -- no fence, whose
-  // agent-scope form writes the whole L2 back on this multi-die part.
-  if (host_out) {
-    __shared__ unsigned int s_last;
-    unsigned long long got = 0ull;
-    if (threadIdx.x < 32 && cnt[threadIdx.x]) got = atomicAdd(out + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
-    // (the barrier's wait covers the returns of this wave's adds)
-    asm volatile("" ::"v"(got));
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last && threadIdx.x < 32) {
-      const unsigned long long v = atomicAdd(out + threadIdx.x, 0ull);
-      __hip_atomic_store(host_out + threadIdx.x, (seq << 40) | (v & 0xffffffffffull), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-      if (threadIdx.x == 0) atomicExch(ticket, 0u);
-    }
-    return;
-  }
-  if (threadIdx.x < 32 && cnt[threadIdx.x]) atomicAdd(out + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
 }
 
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
@@ -898,7 +765,7 @@ int expamd_comp_mover_list(exp_amd_comp *c, int first, int last, size_t expected
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                             int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
                             const unsigned long long **result, unsigned long long *host_out, unsigned long long seq,
-                            bool *launched, bool build_list)
+                            bool *launched, bool build_list, void (*key_launch)(void *, const KaLaunch &), void *key_self)
 {
   exp_amd_ctx *ctx = c->ctx;
   unsigned long long *out = c->nswitch.p + 32 * c->nsw_flip, *nxt = c->nswitch.p + 32 * (1 - c->nsw_flip);
@@ -933,13 +800,19 @@ int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[
     c->mover_list_built = true;
   }
   ProfScope ps(ctx, "k_kick_adjust");
-  const size_t tiles = cdiv(nr, (size_t)TPB);
+  const size_t tiles = cdiv(nr, (size_t)KA_TPB);
   const int items = tiles >= 4096 * KA_ITEMS ? KA_ITEMS : (int)(tiles / 4096 > 1 ? tiles / 4096 : 1);
-  k_kick_adjust<<<cdiv(tiles, (size_t)items), TPB, 0, ctx->stream>>>(
-      A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items,
-      (unsigned int *)(c->nswitch.p + 70), host_out, seq, lcnt ? c->mover_list.p : nullptr, lcnt, lnxt);
+  KaLaunch L{cdiv(tiles, (size_t)items), ctx->stream, A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ),
+             c->a(A_POT), c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items,
+             (unsigned int *)(c->nswitch.p + 70), host_out, seq, lcnt ? c->mover_list.p : nullptr, lcnt, lnxt,
+             KaKeyArgs{c->a(A_X), c->a(A_Y), c->a(A_Z), c->key.p}};
+  c->mprekey_valid = false;
+  // (key_launch: the sweep that closes a master step, every slot examined: the force method's instantiation writes the
+  // next sub-step's sort keys on the way -- host.hip, kick_adjust.h)
+  if (key_launch && lo == 0 && first == 0 && nr == c->n) key_launch(key_self, L);
+  else { key_launch = nullptr; ka_launch_with(L, KaNoKey()); }
   HIP_TRY(ctx, hipGetLastError());
+  c->mprekey_n = key_launch ? c->n : 0;        // (the caller completes the record: owner, step, centre)
   if (launched) *launched = true;
   c->nsw_flip ^= 1;
   return EXP_AMD_OK;

@@ -226,8 +226,10 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
 }
 
 // pass 1 when the keys already exist (written by the previous step's force pass): histogram only
+// sparse_mask != 0 (keys a block-multistep sweep left, kick_adjust.h: full (level, cell) keys): the keys of the levels that
+// are not cell-sorted are collapsed to the level's first bin -- level = key / stride -- and stored back for the scatter pass
 [[maybe_unused]] static __global__ void __launch_bounds__(SORT_TPB)
-k_hist_keys(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist)
+k_hist_keys(uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t sparse_mask = 0u, uint32_t stride = 1u)
 {
   __shared__ uint32_t lh[SORT_WIN];
   __shared__ uint32_t kmin_s;
@@ -239,6 +241,10 @@ k_hist_keys(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ h
   for (int j = 0; j < HIST_ITEMS; j++) {
     const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
     k[j] = (i < n) ? key[i] : 0xffffffffu;
+    if (sparse_mask && i < n) {
+      const uint32_t lv = k[j] / stride;
+      if ((sparse_mask >> lv) & 1u) { k[j] = lv * stride; key[i] = k[j]; }
+    }
     mn = min(mn, k[j]);
   }
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
@@ -314,6 +320,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
   }
 }
 
+struct KaLaunch;
 // host helper (defined in particles.hip): scan + scatter after a k_key_hist launch
 int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, bool move_acc,
                             const AdvSpec &adv, int level = -1, int level_hi = -1);
@@ -326,7 +333,11 @@ int expamd_comp_commit_levels(exp_amd_comp *c, size_t beg = 0);
 int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
                             int multistep, int mfirst_mdrft, int kick_lo, int first, double dt_min,
                             const unsigned long long **result, unsigned long long *host_out = nullptr,
-                            unsigned long long seq = 0ull, bool *launched = nullptr, bool build_list = false);
+                            unsigned long long seq = 0ull, bool *launched = nullptr, bool build_list = false,
+                            void (*key_launch)(void *, const struct KaLaunch &) = nullptr, void *key_self = nullptr);
 // (host_out: device address of 33 page-locked, host-coherent words -- the counters and, behind them, `seq` once they
 // are all there: k_kick_adjust's last block writes them itself)
 AdvanceArgs expamd_advance_args(exp_amd_comp *c, const AdvSpec &adv);
+// the keys a closing sweep left for sub-step 0 (exp_amd_comp::mprekey_*) are this force's, for this smallest step, and nothing
+// has touched the store since
+bool expamd_comp_mprekey_ok(const exp_amd_comp *c, const void *owner, double dt_min);

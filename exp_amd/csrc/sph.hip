@@ -9,6 +9,7 @@
 
 // key = level * (numr-1) + radial cell of get_pot/get_force (r clamped to rmax like the force path)
 struct SphKeyFn {
+  static constexpr bool on = true;     // (k_kick_adjust: writes keys, kick_adjust.h)
   SphDev S;
   uint32_t sparse_mask;      // levels that are not cell-sorted: all their particles share bin 0
   __device__ __forceinline__ uint32_t operator()(double x, double y, double z, uint8_t lev) const
@@ -199,6 +200,7 @@ k_sph_project_both(SphDev S, const double *__restrict__ coef, const int *__restr
 // ---- host side -----------------------------------------------------------------------------------------------
 
 #include "sph_force.h"
+#include "kick_adjust.h"
 
 static double factrl(int n)
 {
@@ -467,7 +469,10 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
     // c->key was filled by the previous step's force pass for exactly this advance
     // (exp_amd_step_kdk checks that): pass 1 only counts the 4-byte keys
     ProfScope ps(ctx, "k_hist_keys");
-    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p);
+    // (a block-multistep run: the keys the closing sweep left are full (level, cell) keys, those of the levels that are
+    // not cell-sorted collapse to the level's first bin here)
+    k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p,
+                                                                    f->cfg.multistep ? c->sparse_mask : 0u, ncell);
   } else {
     size_t nr = c->n;          // a level range is sized for its own population
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
@@ -666,7 +671,9 @@ int SphForce::substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrf
         (rc = adv.mode ? expamd_comp_settle_pending(c, lo, dmax, true) : expamd_comp_settle_pending(c, 0, ms, false)))
       return rc;
     if (dmax >= lo) {
-      rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, false, dmax);
+      // (sub-step 0 of a master step: the sweep that closed the last one wrote these keys, k_kick_adjust / kick_adjust.h)
+      const bool keys_there = full && lo == 0 && adv.mode == 2 && expamd_comp_mprekey_ok(c, f, adv.dt_min);
+      rc = sph_sort(f, c, /*move_acc=*/full && lo > 0, adv, full ? -1 : lo, keys_there, dmax);
       if (rc) return rc;
     }
     c->commit_pending = false;          // (the scatter stored the proposed levels)
@@ -1121,6 +1128,15 @@ int SphForce::resort(exp_amd_comp *c, int first)
   if (first > 0 && c->nlevels == multistep + 1)      // (the caller vouches for the order below `first`)
     return sph_sort(this, c, true, AdvSpec(), first, false, multistep);
   return sph_sort(this, c, true);
+}
+
+bool SphForce::prekey_launcher(exp_amd_comp *c, ka_launch_fn *fn, void **self)
+{
+  if (cfg.multistep == 0 || c->n == 0 || c->n >= 0x7fffffffu) return false;
+  ka_S = dev_for(this, c->center);
+  *fn = [](void *p, const KaLaunch &L) { ka_launch_with(L, SphKeyFn{static_cast<SphForce *>(p)->ka_S, 0u}); };
+  *self = this;
+  return true;
 }
 
 int SphForce::multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft)

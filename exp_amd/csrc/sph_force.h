@@ -63,6 +63,8 @@ struct SphForce : exp_amd_force {
   int accelerate(exp_amd_comp *t, int external, bool assign, double dt_kick, double nk_dtk = 0.0,
                  double nk_dtd = 0.0, bool *prekey_done = nullptr, bool defer_kick = false) override;
   int multistep_update(exp_amd_comp *c, int first, int mfirst_mdrft) override;
+  bool prekey_launcher(exp_amd_comp *c, ka_launch_fn *fn, void **self) override;
+  SphDev ka_S;                      // ... the frame its key function was given (the component's centre at the sweep)
   int substep_expansion(exp_amd_comp *c, int lo, double dt_min, int mdrft_combine = -1, int phase = 0) override;
   // (the spherical basis has few cells, numr - 1: a level stays worth sorting down to a few particles
   // per cell, and per-particle atomics on so few addresses contend)

@@ -296,3 +296,34 @@ def test_thin_kernels_reproduce_the_table_path(ctx, monkeypatch, thin_v):
         assert np.abs(d0["pos"] - d1["pos"]).max() <= 1e-13
         for k in ("vel", "acc", "pot"):
             assert np.abs(d0[k] - d1[k]).max() <= 1e-11 * np.abs(d0[k]).max(), k
+
+
+def test_keys_of_the_closing_sweep_are_dropped_when_the_store_is_touched(ctx):
+    """The sweep that closes a master step leaves the sort keys of the next one's sub-step 0 (k_kick_adjust with the force's
+    key function); they are this force's, for this smallest step and this centre, and any call that touches the store
+    drops them.  Three runs from the same state: master steps one after the other; the accelerations uploaded again as they
+    are (touches the store, changes nothing) between them; the centre moved and moved back between them.  Same levels, same state."""
+    from exp_amd.runtime import Component
+    z = c4.config4_inputs(n_halo=2000, n_disk=2000)
+    outs = []
+    for mode in ("plain", "touch", "center"):
+        sim, fs, cs = _device_run(ctx, z, c4.MULTISTEP, c4.DTIME, c4.DYN)
+        for k in range(3):
+            sim.step(1)
+            if mode == "touch":
+                for c in cs:
+                    st = c.download(("acc", "pot"))
+                    c.upload_acc(st["acc"], st["pot"])
+            elif mode == "center":
+                for c in cs:
+                    c.set_center(np.array([1e-3, -2e-3, 5e-4]))
+                    c.set_center(np.zeros(3))
+        outs.append([(c.download_levels(), c.download()) for c in cs])
+        sim.close()
+        for x in cs + fs:
+            x.close()
+    for other in outs[1:]:
+        for (lev0, st0), (lev1, st1) in zip(outs[0], other):
+            assert np.array_equal(lev0, lev1)
+            for key in ("pos", "vel", "acc"):
+                assert np.abs(st0[key] - st1[key]).max() <= 1e-10 * max(np.abs(st0[key]).max(), 1e-300), key
