@@ -71,13 +71,17 @@ def one(t, rng):
     # the disk -- and a few start at rest (v.a = 0, v.v = 0 in the time-step criteria)
     if rng.random() < 0.33:
         hp, hv, dp, dv = (inp[k].copy() for k in ("halo_pos", "halo_vel", "disk_pos", "disk_vel"))
-        for i in range(min(len(hp), 8)):
+        # (not in a halo of a few particles: one that sits 1e-4 from the centre IS the expansion, and the 1e-11 its position is
+        # held to is 1e-7 of its radius -- the field every other particle feels then differs by more than the bars allow,
+        # seed 307 trial 862)
+        nhl = len(hp) if len(hp) >= 100 else 0
+        for i in range(min(nhl, 8)):
             th, ph, rr = 10.0 ** rng.uniform(-9, -2), rng.uniform(0, 2 * np.pi), sc * np.exp(rng.uniform(np.log(0.05), np.log(3.0)))
             hp[i] = [rr * np.sin(th) * np.cos(ph), rr * np.sin(th) * np.sin(ph), rng.choice([-1.0, 1.0]) * rr * np.cos(th)]
-        for i in range(8, min(len(hp), 12)):
+        for i in range(8, min(nhl, 12)):
             u = rng.normal(0, 1, 3)
             hp[i] = u / np.linalg.norm(u) * sc * 10.0 ** rng.uniform(-12, -3)
-        for i in range(12, min(len(hp), 15)):
+        for i in range(12, min(nhl, 15)):
             hv[i] = 0.0
         # (not in a disk of one: the azimuthal force of a particle on ITSELF cancels exactly, Pc sin(m phi) - Ps cos(m phi)
         # with (Pc, Ps) ~ (cos, sin)(m phi), and what rounding leaves of it is divided by R: 1e-8 of the force at R = 1e-13)
@@ -166,6 +170,18 @@ def one(t, rng):
                 if os.environ.get("FUZZ_VERBOSE"):
                     ip, ia = int(np.abs(out["pos"] - p).max(1).argmax()), int(np.abs(out["acc"] - a).max(1).argmax())
                     o0 = inp["halo_pos" if name == "halo" else "disk_pos"]
+                    if name == "disk" and which == "both" and os.environ.get("FUZZ_VERBOSE") == "2":
+                        # (which of the two forces on the disk differs: the halo's coefficient set on the disk's positions,
+                        # oracle against device, as an external target)
+                        hc = forces[0].get_coefs()
+                        a_o, p_o = orc.sph_accel(g, prm, p, hc)
+                        tmp = Component.from_arrays(ctx, np.ones(len(p)), p)
+                        tmp.zero_acceleration(0)
+                        forces[0].get_acceleration_and_potential(tmp, external=True)
+                        a_d = tmp.download(("acc",))["acc"]
+                        tmp.close()
+                        dd = np.abs(a_d - a_o).max(1)
+                        detail += f"\n    halo-on-disk alone: worst |dev - oracle| {dd.max():.3e} at particle {int(dd.argmax())} (|a| {np.linalg.norm(a_o[int(dd.argmax())]):.3e}); at particle {ia}: {dd[ia]:.3e} of {np.linalg.norm(a_o[ia]):.3e}"
                     detail += (f"\n    pos: particle {ip} started at {o0[ip]} now {out['pos'][ip]} oracle {p[ip]} vel {out['vel'][ip]} / {v[ip]} level {lev[ip]}"
                                f"\n    acc: particle {ia} started at {o0[ia]} acc {out['acc'][ia]} oracle {a[ia]} pos {out['pos'][ia]}")
                 break
