@@ -188,7 +188,10 @@ __device__ __forceinline__ void sort_range(const SortRange &R, size_t &beg, size
 // a few ten thousand slots, sorted sixteen times per master step) take HIST_ITEMS_SHORT: sixteen keys per thread one after
 // the other -- each a square root and a division or more -- made a 13 000-slot pass of four blocks 35 us long
 #define HIST_ITEMS_SHORT 2
-#define HIST_SHORT_MAX 65536       // slots up to which a range counts as short
+#ifndef HIST_SHORT_MAX
+#define HIST_SHORT_MAX 1048576     // slots up to which a range counts as short (65536 until round 5: a level range of 8e4 - 3e5 slots
+                                   // then ran sixteen slots a thread on 20 - 80 blocks, 40 us where 10 do: config 4 -0.09 ms)
+#endif
 template <class KeyFn, int ITEMS = HIST_ITEMS>
 __global__ void __launch_bounds__(SORT_TPB)
 k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
