@@ -557,12 +557,21 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
                  c->uniform_mass ? nullptr : c->b(A_M),
                  c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                  c->levels_zero ? nullptr : c->level[1 - c->cur].p};
-    const unsigned g = cdiv(nr, SCAT_TILE);
     const SortRange R = expamd_sort_range(c, level, level_hi);
+    if (nr <= SCAT_SHORT_MAX && level >= 0) {
+      // (a level range of a sub-step: one slot a thread -- four times the blocks for a pass that is all latency there)
+      const unsigned g = cdiv(nr, (size_t)SORT_TPB * SCAT_ITEMS_SHORT);
+      if (move_acc)
+        k_scatter_adv<true, SCAT_ITEMS_SHORT><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
+      else
+        k_scatter_adv<false, SCAT_ITEMS_SHORT><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
+    } else {
+    const unsigned g = cdiv(nr, SCAT_TILE);
     if (move_acc)
       k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     else
       k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   // the scatter applied the half-kick still owed ahead of its own kick (a range sort: to the levels it holds -- callers

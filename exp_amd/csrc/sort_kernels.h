@@ -272,21 +272,27 @@ struct ScatterSrc {
   const uint32_t *id;
 };
 
-template <bool MOVE_ACC>
+// (ITEMS: slots per thread; SCAT_ITEMS_SHORT for the level ranges of a block-multistep sub-step, as HIST_ITEMS_SHORT above)
+#define SCAT_ITEMS_SHORT 1
+#ifndef SCAT_SHORT_MAX
+#define SCAT_SHORT_MAX 1048576
+#endif
+template <bool MOVE_ACC, int ITEMS = SCAT_ITEMS>
 __global__ void __launch_bounds__(SORT_TPB)
 k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
               const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor)
 {
+  constexpr int SCAT_ITEMS_ = ITEMS;
   __shared__ uint32_t lh[SORT_WIN];       // count, then global base of the (block, bin) range
   __shared__ uint32_t kmin_s;
   size_t rbeg, n;
   sort_range(R, rbeg, n);
-  const size_t base = rbeg + (size_t)blockIdx.x * SCAT_TILE;
+  const size_t base = rbeg + (size_t)blockIdx.x * (SORT_TPB * SCAT_ITEMS_);
   if (base >= n) return;
-  uint32_t k[SCAT_ITEMS], rk[SCAT_ITEMS];
+  uint32_t k[SCAT_ITEMS_], rk[SCAT_ITEMS_];
   uint32_t mn = 0xffffffffu;
 #pragma unroll
-  for (int j = 0; j < SCAT_ITEMS; j++) {
+  for (int j = 0; j < SCAT_ITEMS_; j++) {
     const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
     k[j] = (i < n) ? key[i] : 0xffffffffu;
     mn = min(mn, k[j]);
@@ -295,7 +301,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
   const uint32_t kmin = block_min_u32(mn, &kmin_s);
   // rank inside (block, bin)
 #pragma unroll
-  for (int j = 0; j < SCAT_ITEMS; j++) rk[j] = wave_rank(k[j], k[j] != 0xffffffffu, kmin, lh);
+  for (int j = 0; j < SCAT_ITEMS_; j++) rk[j] = wave_rank(k[j], k[j] != 0xffffffffu, kmin, lh);
   __syncthreads();
   // reserve the global range of every non-empty bin: lh[b] <- base
   for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
@@ -304,7 +310,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < SCAT_ITEMS; j++) {
+  for (int j = 0; j < SCAT_ITEMS_; j++) {
     if (k[j] == 0xffffffffu) continue;
     const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
     const uint32_t d = k[j] - kmin;
