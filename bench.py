@@ -85,6 +85,12 @@ def parse_args():
     ap.add_argument("--numr", type=int, default=2000)
     ap.add_argument("--dt", type=float, default=0.002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of this same "
+                         "command, FETCH_SIZE and WRITE_SIZE, about a minute together); it is also skipped with "
+                         "--no-cpu-baseline (the quick runs of the A/B and profiling tools), with several ranks, and "
+                         "when this process itself runs under a profiler.  The line then carries the figure of "
+                         "profiles/traffic.json and says so")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the secondary BASELINE configurations (2: 1e7 S6 halo, 3: 1e7 C6 disk, "
                          "4: disk + halo, multistep 4) measured after the headline on rank 0 at N = 1")
@@ -323,6 +329,78 @@ def cpu_baseline(grid, model, nsample, dt):
 
 
 # ---- secondary configurations (BASELINE.json configs 2-4): parity-test workloads, reported as extras ----
+
+def live_traffic(args, dom, nloc, budget_s=300.0):
+    """HBM bytes per launch of kernel `dom`, from the PMC counters of THIS box: two child runs of this same command under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two do not fit one, MI355X_MICROARCH.md
+    counter table), each with --kernel-trace only.  A process cannot read these counters about itself, and the profiler
+    must start the program (its preloaded library initialises the GPU first), so the passes are children: `python3
+    bench.py` directly behind `--`, started with subprocess (never exec'd).  Corrections as the guide's HBM section
+    prescribes: both counters are KiB; on gfx950 FETCH_SIZE tallies a wide coalesced read at half its bytes, so the
+    read side is doubled (the calibration of tools/summarize_profile.py on k_kick's known byte count gives 2.0000);
+    WRITE_SIZE is exact.  The first launch of a kernel is dropped (first touch); template variants that run once per
+    step each (the fast and the general pass of k_sph_force) are summed, as in profiles/traffic.json.
+    Returns (bytes_per_launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="exp_amd_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+             "--no-cpu-baseline", "--no-other-configs", "--no-sustained", "--no-live-traffic",
+             "--nbodies", repr(float(args.nbodies)), "--lmax", str(args.lmax), "--nmax", str(args.nmax),
+             "--numr", str(args.numr), "--dt", repr(float(args.dt))]
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 20.0:
+                return None, "time budget of the counter passes used up"
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=left)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s: exit code %d" % (ctr, r.returncode)
+            vals = {}
+            for path in glob.glob(os.path.join(out, "*", "*_counter_collection.csv")):
+                for row in csv.DictReader(open(path)):
+                    name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    if name.split("<")[0] == dom and row["Counter_Name"] == ctr:
+                        vals.setdefault(name, []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for %s" % (ctr, dom)
+            per[ctr] = vals
+        top = max(len(v) for v in per["FETCH_SIZE"].values())
+        total = 0.0
+        parts = {}
+        for ctr, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            for name, v in per[ctr].items():
+                if len(v) != top:
+                    continue              # a one-off variant (e.g. the initial full pass), not the steady-state one
+                steady = v[1:] if len(v) > 2 else v
+                b = sum(steady) / len(steady) * 1024.0 * scale
+                parts.setdefault(name, {})[ctr] = b
+                total += b
+        note = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate child passes of this "
+                "command (--steps 4 --warmup 2, %d launches each, first dropped), KiB -> bytes, FETCH_SIZE x 2 (gfx950 "
+                "tallies wide coalesced reads at half their bytes), WRITE_SIZE as it is; %.0f s for both passes"
+                % (top, time.perf_counter() - t0))
+        return total, {"note": note, "per_variant_bytes": parts, "n_particles": int(nloc)}
+    except subprocess.TimeoutExpired:
+        return None, "a counter pass ran into its time budget"
+    except Exception as e:          # the line must come out whatever the profiler does
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
 
 def make_disk(n, a, h, seed, device, vscale):
     """n exponential-disk particles (Sigma ~ exp(-R/a), sech^2(z/h): the reference's conditioning
@@ -758,15 +836,25 @@ def main():
                         traffic = ent["hbm_bytes_per_launch"]
                 except Exception:
                     traffic = None
+            traffic_src = ("REPLAYED from profiles/traffic.json, not measured in this run: rocprofv3 --pmc "
+                           "FETCH_SIZE / WRITE_SIZE, separate passes, of this same command on an earlier box "
+                           "(tools/profile.sh)") if traffic else None
+            traffic_extra = None
+            if world == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
+                replayed = traffic
+                lt, info = live_traffic(args, dom, nloc)
+                if lt is not None:
+                    traffic, traffic_src = lt, info["note"]
+                    traffic_extra = {"per_variant_bytes": info["per_variant_bytes"],
+                                     "replayed_from_profiles_traffic_json": replayed}
+                else:
+                    traffic_src = "%s; the live counter passes did not run: %s" % (traffic_src, info)
             # achieved / peak / unit / frac are the contract's HBM accounting (algorithmic bytes over the kernel's
             # time: `frac_of`); `bound` is DERIVED below: the roof the kernel sits closest to, i.e. the larger of
             # the HBM fraction and the executed-fp64 fraction (= `binding_limit`)
             roof = {"bound": "hbm", "frac_of": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": "REPLAYED from profiles/traffic.json, not measured in this run: rocprofv3 --pmc "
-                                      "FETCH_SIZE / WRITE_SIZE, separate passes, of this same command on an earlier box "
-                                      "(tools/profile.sh; a process cannot read those counters about itself)"
-                                      if traffic else None,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_particle": ALGO_BYTES.get(dom, 0.0),
                     "step_achieved": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9,
@@ -776,6 +864,9 @@ def main():
                     "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
                     "step_frac_of_measured_peak": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_MEASURED_GBS,
                     "kernels_ms_per_step": {k: v["ms_total"] / args.steps for k, v in kern.items()}}
+            if traffic_extra:
+                roof["traffic_detail"] = traffic_extra
+                roof["traffic_over_algorithmic"] = traffic / algo if algo else None
             # what the kernel itself moves in the fused step (the contract's figure counts the v store
             # of the closing half-kick, which lives in the next scatter pass here)
             if dom in OWN_BYTES:
