@@ -291,31 +291,47 @@ __device__ __forceinline__ bool sph_frozen(const SphDev &S, double px, double py
 
 // ---- accumulation ----------------------------------------------------------------------------------
 
-#define FLUSH_STRIDE 68      // doubles per scratch row: conflict-free for the 4x16 read pattern
+// Rows (accumulators) a flush transposes through the wave's LDS scratch at a time: 16 (64 lanes = 16 accumulators x 4
+// lanes, each adding 16 of the 64 per-lane values), 8 (x 8 lanes x 8 values) or 4 (x 16 x 4).  Fewer rows = less LDS
+// (4 waves x FLUSH_ROWS x FLUSH_STRIDE doubles) for more rounds.  FLUSH_STRIDE: doubles per scratch row, conflict-free
+// for the read pattern of a half-wave (rows 8 / 16 / 32 banks apart).
+#ifndef FLUSH_ROWS
+#define FLUSH_ROWS 16
+#endif
+#if FLUSH_ROWS == 16
+#define FLUSH_STRIDE 68
+#elif FLUSH_ROWS == 8
+#define FLUSH_STRIDE 72
+#elif FLUSH_ROWS == 4
+#define FLUSH_STRIDE 80
+#else
+#error "FLUSH_ROWS: 16, 8 or 4"
+#endif
 
 // Reduce NV per-lane values over the wave and atomically add them to dst[map(j)].
-// scratch: wave-private LDS, 16*FLUSH_STRIDE doubles.
+// scratch: wave-private LDS, FLUSH_ROWS*FLUSH_STRIDE doubles.
 template <int NV, class MapFn>
 __device__ __forceinline__ void wave_flush(double (&v)[NV], double *scratch, double *dst, MapFn map)
 {
+  constexpr int R = FLUSH_ROWS, P = 64 / R;       // P lanes per accumulator, each adds R values
   const int lane = threadIdx.x & 63;
-  const int kk = lane >> 2, q = lane & 3;
-  static_for<0, (NV + 15) / 16>([&](auto gc) {
+  const int kk = lane / P, q = lane % P;
+  static_for<0, (NV + R - 1) / R>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
-    static_for<0, 16>([&](auto jc) {
-      constexpr int j = g * 16 + decltype(jc)::value;
+    static_for<0, R>([&](auto jc) {
+      constexpr int j = g * R + decltype(jc)::value;
       if constexpr (j < NV) scratch[decltype(jc)::value * FLUSH_STRIDE + lane] = v[j];
     });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double s = 0.0;
-    if (g * 16 + kk < NV) {
+    if (g * R + kk < NV) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) s += scratch[kk * FLUSH_STRIDE + q + 4 * e];
+      for (int e = 0; e < R; e++) s += scratch[kk * FLUSH_STRIDE + q + P * e];
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (q == 0 && g * 16 + kk < NV && s != 0.0) unsafeAtomicAdd(dst + map(g * 16 + kk), s);
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1) s += __shfl_xor(s, off);
+    if (q == 0 && g * R + kk < NV && s != 0.0) unsafeAtomicAdd(dst + map(g * R + kk), s);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   });
@@ -368,7 +384,9 @@ struct LevChunks {
 #ifndef ACC_CHUNK_MAX
 #define ACC_CHUNK_MAX 4096
 #endif
+#ifndef ACC_P0_LDS
 #define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
+#endif
 #ifndef ACC_P0_FILL_MIN
 #define ACC_P0_FILL_MIN 512    // ... for chunks longer than this
 #endif
@@ -781,7 +799,7 @@ k_sph_accumulate(SphDev S, const double *__restrict__ X, const double *__restric
   const unsigned bx = blockIdx.x - LC.bstart[lj];
   const int cell_add = multilevel ? lev_lo * (S.numr - 1) : 0;
   constexpr int CPB = (ACC_WAVES >= NS) ? ACC_WAVES / NS : 1;      // chunks per block
-  __shared__ double scratch_all[ACC_WAVES][16 * FLUSH_STRIDE];
+  __shared__ double scratch_all[ACC_WAVES][FLUSH_ROWS * FLUSH_STRIDE];
   const int wave = threadIdx.x >> 6;
   double *scratch = scratch_all[wave];
   const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
