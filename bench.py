@@ -330,6 +330,37 @@ def cpu_baseline(grid, model, nsample, dt):
 
 # ---- secondary configurations (BASELINE.json configs 2-4): parity-test workloads, reported as extras ----
 
+def _counter_rows(out_dir, ctr, dom):
+    """{kernel variant: [counter value of each launch]} of kernel `dom` from a rocprofv3 --pmc output directory."""
+    import csv
+    import glob
+    vals = {}
+    for path in glob.glob(os.path.join(out_dir, "*", "*_counter_collection.csv")):
+        for row in csv.DictReader(open(path)):
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if name.split("<")[0] == dom and row["Counter_Name"] == ctr:
+                vals.setdefault(name, []).append(float(row["Counter_Value"]))
+    return vals
+
+
+def _traffic_from_counters(per):
+    """HBM bytes per launch from {"FETCH_SIZE": {variant: [KiB per launch]}, "WRITE_SIZE": {...}}: the variants that run
+    once per step (the most launches; a one-off variant such as an initial full pass is left out), first launch dropped,
+    KiB -> bytes, the read side doubled (gfx950, MI355X_MICROARCH.md HBM section).  -> (total, per variant, launches)."""
+    top = max(len(v) for v in per["FETCH_SIZE"].values())
+    total = 0.0
+    parts = {}
+    for ctr, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        for name, v in per[ctr].items():
+            if len(v) != top:
+                continue
+            steady = v[1:] if len(v) > 2 else v
+            b = sum(steady) / len(steady) * 1024.0 * scale
+            parts.setdefault(name, {})[ctr] = b
+            total += b
+    return total, parts, top
+
+
 def live_traffic(args, dom, nloc, budget_s=300.0):
     """HBM bytes per launch of kernel `dom`, from the PMC counters of THIS box: two child runs of this same command under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two do not fit one, MI355X_MICROARCH.md
@@ -341,8 +372,6 @@ def live_traffic(args, dom, nloc, budget_s=300.0):
     WRITE_SIZE is exact.  The first launch of a kernel is dropped (first touch); template variants that run once per
     step each (the fast and the general pass of k_sph_force) are summed, as in profiles/traffic.json.
     Returns (bytes_per_launch or None, note)."""
-    import csv
-    import glob
     import shutil
     import subprocess
     import tempfile
@@ -369,26 +398,11 @@ def live_traffic(args, dom, nloc, budget_s=300.0):
                                timeout=left)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s: exit code %d" % (ctr, r.returncode)
-            vals = {}
-            for path in glob.glob(os.path.join(out, "*", "*_counter_collection.csv")):
-                for row in csv.DictReader(open(path)):
-                    name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                    if name.split("<")[0] == dom and row["Counter_Name"] == ctr:
-                        vals.setdefault(name, []).append(float(row["Counter_Value"]))
+            vals = _counter_rows(out, ctr, dom)
             if not vals:
                 return None, "no %s rows for %s" % (ctr, dom)
             per[ctr] = vals
-        top = max(len(v) for v in per["FETCH_SIZE"].values())
-        total = 0.0
-        parts = {}
-        for ctr, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-            for name, v in per[ctr].items():
-                if len(v) != top:
-                    continue              # a one-off variant (e.g. the initial full pass), not the steady-state one
-                steady = v[1:] if len(v) > 2 else v
-                b = sum(steady) / len(steady) * 1024.0 * scale
-                parts.setdefault(name, {})[ctr] = b
-                total += b
+        total, parts, top = _traffic_from_counters(per)
         note = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate child passes of this "
                 "command (--steps 4 --warmup 2, %d launches each, first dropped), KiB -> bytes, FETCH_SIZE x 2 (gfx950 "
                 "tallies wide coalesced reads at half their bytes), WRITE_SIZE as it is; %.0f s for both passes"
