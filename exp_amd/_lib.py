@@ -85,6 +85,9 @@ SIGNATURES = {
     "exp_amd_sph_create": (c_int, [c_void_p, POINTER(SphConfig), c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p)]),
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
+    "exp_amd_comp_set_consp": (c_int, [c_void_p, c_int, c_double]),
+    "exp_amd_comp_get_escaped": (c_int, [c_void_p, c_void_p]),
+    "exp_amd_comp_set_escaped": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_log_sums": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
                                       POINTER(c_void_p)]),

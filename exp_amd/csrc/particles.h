@@ -53,6 +53,13 @@ struct exp_amd_comp {
   DevBuf<double> d_frz;                         // {com0[3], center[3], rtrunc^2} for the kernels (expamd_comp_frz)
   double frz_host[7] = {0, 0, 0, 0, 0, 0, 0};
   bool frz_valid = false;
+  // Component::consp / tidal / rcom (src/Component.cc:214-216, :998-1000, :1024): the escape bookkeeping of fix_positions
+  // (:3317-3334) -- a particle beyond rcom of com0 + center is flagged once and left out of the centre-of-mass sums from
+  // then on.  d_escaped: iattrib[tidal] of every particle, indexed by its id (the caller's index; ids travel with the
+  // slots through every sort, the flags stay where they are).  exp_amd_comp_set_consp
+  bool consp_on = false;
+  double rcom = 1.0e20;
+  DevBuf<uint8_t> d_escaped;
   bool use_rot = false;                    // body-frame rotation (Orient::transformBody), cylinder only
   double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   PseudoDev pseudo = {0, 0, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // frame acceleration subtracted by the forces

@@ -885,6 +885,7 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
     c->level[w].release();
   }
   c->d_frz.release();
+  c->d_escaped.release();
   c->key.release();
   c->newlev.release();
   c->nswitch.release();
@@ -1312,15 +1313,19 @@ __device__ __forceinline__ bool comp_frozen(const double *__restrict__ F, double
 // ---- centre of mass / velocity / acceleration (Component::fix_positions) -----------------------------
 // src/Component.cc:3280-3351 (thread body: per-level sums of m, m x, m v, m a over the levels
 // >= mlevel), :3354-3554 (levels below mlevel keep their previous sums, all-reduce over ranks,
-// division by the total mass).  A frozen particle (beyond rtrunc, :3336) is skipped.  Escape/tidal bookkeeping (consp)
-// and the EJ orientation centre are outside this path.
+// division by the total mass).  A frozen particle (beyond rtrunc, :3336) is skipped; with consp on (exp_amd_comp_set_consp)
+// so is an escaped one, flagged here the first time it is found beyond rcom (:3317-3334).  The EJ orientation centre is
+// orient.hip's.
 #define COM_MAXLEV 16
+// Component::escape_com (src/Component.cc:4204-4212): {com0[3], center[3], rcom^2}, the layout comp_frozen reads
+struct EscapeArgs { double v[7]; };
 __global__ void __launch_bounds__(256)
 k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const double *__restrict__ Y,
              const double *__restrict__ Z, const double *__restrict__ VX, const double *__restrict__ VY,
              const double *__restrict__ VZ, const double *__restrict__ AX, const double *__restrict__ AY,
              const double *__restrict__ AZ, double back, const uint8_t *__restrict__ lev, size_t n, int mlevel,
-             int nlev, double *__restrict__ out /* [nlev][10] */, const double *__restrict__ frz)
+             int nlev, double *__restrict__ out /* [nlev][10] */, const double *__restrict__ frz,
+             const uint32_t *__restrict__ id, uint8_t *__restrict__ escaped /* by id; nullptr: consp off */, EscapeArgs E)
 {
   __shared__ double acc[COM_MAXLEV][10];
   for (int k = threadIdx.x; k < COM_MAXLEV * 10; k += 256) (&acc[0][0])[k] = 0.0;
@@ -1333,6 +1338,12 @@ k_com_levels(const double *__restrict__ M, const double *__restrict__ X, const d
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
       if (nlev > 1 && lev[i] != L) continue;
       const double m = M[i], px = X[i], py = Y[i], pz = Z[i];
+      if (escaped) {            // src/Component.cc:3317-3334 (every slot is examined by exactly one thread, once)
+        const uint32_t pid = id[i];
+        const uint8_t fl = escaped[pid];
+        if (!fl && comp_frozen(E.v, px, py, pz)) { escaped[pid] = 1; continue; }
+        if (fl == 1) continue;
+      }
       if (comp_frozen(frz, px, py, pz)) continue;
       v[0] += m;
       v[1] = fma(m, px, v[1]);  v[2] = fma(m, py, v[2]);  v[3] = fma(m, pz, v[3]);
@@ -1431,6 +1442,52 @@ extern "C" int exp_amd_comp_log_sums(exp_amd_comp *c, double out[14])
   return EXP_AMD_OK;
 }
 
+// Component::consp / tidal / rcom (src/Component.cc:998-1000, :1024): the flags start at zero (iattrib as the body file gave
+// them: exp_amd_comp_set_escaped), one byte per particle id
+extern "C" int exp_amd_comp_set_consp(exp_amd_comp *c, int on, double rcom)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (on && !(rcom > 0.0)) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comp_set_consp: rcom must be positive");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (on && !c->d_escaped.p && c->n) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->d_escaped.alloc(c->n) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_set_consp: hipMalloc failed");
+    HIP_TRY(ctx, hipMemsetAsync(c->d_escaped.p, 0, c->n, ctx->stream));
+  }
+  c->consp_on = on != 0;
+  if (on) c->rcom = rcom;
+  // (the cached per-level sums were formed under the other rule)
+  if (c->com_lev.p) HIP_TRY(ctx, hipMemsetAsync(c->com_lev.p, 0, c->com_lev.bytes(), ctx->stream));
+  return EXP_AMD_OK;
+}
+
+// iattrib[tidal] of every particle, in the caller's order (0 / 1): read back, or set (a restart: the body file's column)
+extern "C" int exp_amd_comp_get_escaped(exp_amd_comp *c, unsigned char *flags)
+{
+  if (!c || !flags) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (!c->d_escaped.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "comp_get_escaped: consp was never switched on (exp_amd_comp_set_consp)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, c->d_escaped.p, c->n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_comp_set_escaped(exp_amd_comp *c, const unsigned char *flags)
+{
+  if (!c || !flags) return EXP_AMD_ERR_ARG;
+  exp_amd_ctx *ctx = c->ctx;
+  if (!c->d_escaped.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "comp_set_escaped: consp was never switched on (exp_amd_comp_set_consp)");
+  for (size_t i = 0; i < c->n; i++)
+    if (flags[i] > 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comp_set_escaped: flag %zu is %d (0 or 1)", i, (int)flags[i]);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(c->d_escaped.p, flags, c->n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (c->com_lev.p) HIP_TRY(ctx, hipMemsetAsync(c->com_lev.p, 0, c->com_lev.bytes(), ctx->stream));
+  return EXP_AMD_OK;
+}
+
 extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10])
 {
   if (!c || !out) return EXP_AMD_ERR_ARG;
@@ -1451,6 +1508,9 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
   // zero the level sums at and above mlevel (:3363-3369), then re-accumulate them
   HIP_TRY(ctx, hipMemsetAsync(c->com_lev.p + (size_t)mlevel * 10, 0,
                               (size_t)(nlev - mlevel) * 10 * sizeof(double), ctx->stream));
+  EscapeArgs E;
+  for (int k = 0; k < 3; k++) { E.v[k] = c->com0[k]; E.v[3 + k] = c->center[k]; }
+  E.v[6] = c->rcom * c->rcom;
   if (c->n) {
     ProfScope ps(ctx, "k_com_levels");
     unsigned grid = cdiv(c->n, 256 * 16);
@@ -1458,7 +1518,8 @@ extern "C" int exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double ou
     k_com_levels<<<grid, 256, 0, ctx->stream>>>(c->a(A_M), c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_VX),
                                                c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY),
                                                c->a(A_AZ), back, c->level[c->cur].p, c->n, mlevel, nlev,
-                                               c->com_lev.p, expamd_comp_frz(c));
+                                               c->com_lev.p, expamd_comp_frz(c), c->id[c->cur].p,
+                                               c->consp_on ? c->d_escaped.p : nullptr, E);
     HIP_TRY(ctx, hipGetLastError());
   }
   // sum the levels on the host side of one small read-back; ranks are combined first (:3500-3503)

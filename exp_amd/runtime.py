@@ -276,6 +276,24 @@ class Component:
         check(self.lib.exp_amd_comp_set_rtrunc(self.h, float(rtrunc), c0[1] if c0 else None), self.ctx.h)
         self.rtrunc = float(rtrunc)
 
+    def set_consp(self, rcom: float, on: bool = True) -> None:
+        """The component keys ``tidal`` (switches ``consp`` on, src/Component.cc:998-1000) and ``rcom`` (:1024): from now on
+        ``fix_positions`` flags a particle beyond ``rcom`` of com0 + center (``escape_com``, :4204-4212) and leaves it out of
+        the centre-of-mass sums for good (:3317-3334).  ``escaped()`` is the attribute column ``iattrib[tidal]``."""
+        check(self.lib.exp_amd_comp_set_consp(self.h, int(bool(on)), float(rcom)), self.ctx.h)
+        self.rcom = float(rcom)
+
+    def escaped(self) -> np.ndarray:
+        fl = np.empty(self.n, dtype=np.uint8)
+        check(self.lib.exp_amd_comp_get_escaped(self.h, fl.ctypes.data_as(c_void_p)), self.ctx.h)
+        return fl
+
+    def set_escaped(self, flags) -> None:
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        if fl.shape != (self.n,):
+            raise ValueError("set_escaped: one flag per particle")
+        check(self.lib.exp_amd_comp_set_escaped(self.h, fl.ctypes.data_as(c_void_p)), self.ctx.h)
+
     # Component::Adiabatic() (src/Component.cc:4214-4220; keys ton, toff, twid :1040-1055)
     adiabatic = None
 

@@ -235,12 +235,22 @@ int  exp_amd_comp_kick (exp_amd_comp *c, double dt, int mlevel);
 int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
 
 /* Centre of mass / velocity / acceleration of the component: replaces Component::fix_positions
- * (src/Component.cc:3280-3554; CUDA twin src/cudaComponent.cu:800-933) without the
- * escape/tidal bookkeeping, frozen particles and the orientation centre.  Only the levels
+ * (src/Component.cc:3280-3554; CUDA twin src/cudaComponent.cu:800-933) without the orientation centre (that is
+ * exp_amd_orient_*); frozen particles (exp_amd_comp_set_rtrunc) and, with exp_amd_comp_set_consp, escaped ones are left
+ * out as in the thread body (:3317-3336).  com_system is off in this scope (no comE / covE sums).  Only the levels
  * >= mlevel are re-summed (the others keep their previous per-level sums, as the reference
  * does); ranks are combined with the context's all-reduce.  out = {mtot, com[3], cov[3], coa[3]}
  * (the three vectors divided by mtot when mtot > 0).                                        */
 int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
+/* The escape bookkeeping of Component::fix_positions: the component keys "tidal" (which switches `consp` on and names the
+ * integer attribute that holds the flag, src/Component.cc:998-1000) and "rcom" (:1024).  With it on, fix_positions flags a
+ * particle of the examined levels that is beyond rcom of com0 + center (Component::escape_com, :4204-4212; com0 is the one of
+ * exp_amd_comp_set_rtrunc, zeros by default) -- iattrib[tidal] = 1 -- and leaves it out of the sums from then on (:3317-3334).
+ * The flags live on the device, one byte per particle in the caller's order; they start at zero.  get / set: the attribute
+ * column as a body file holds it (a restart sets it before the first step).  on = 0 switches the test off and keeps the flags. */
+int  exp_amd_comp_set_consp(exp_amd_comp *c, int on, double rcom);
+int  exp_amd_comp_get_escaped(exp_amd_comp *c, unsigned char *flags /* [n] */);
+int  exp_amd_comp_set_escaped(exp_amd_comp *c, const unsigned char *flags /* [n], 0 or 1 */);
 /* The per-component sums of the run log (OutLog::Run, src/OutLog.cc:392-478): out = {mass, m x [3], m v [3], angular
  * momentum [3], kinetic energy, 0.5 m pot, Clausius virial m x.a, number of bodies}, reduced over the ranks; every
  * particle counts (no frozen particles in this store), positions and velocities as stored (com_system off), velocities at

@@ -1275,6 +1275,55 @@ void orc_fix_positions(long n, const double *mass, const double *x, const double
     for (int k = 1; k < 10; k++) out[k] /= out[0];
 }
 
+/* The same with the two per-particle tests of the thread body (src/Component.cc:3317-3336):
+ *   consp (the component's "tidal" key, :998-1000) -- a particle beyond rcom of com0 + center (escape_com, :4204-4212) that is
+ *   not yet flagged gets iattr = 1 and is left out; a flagged particle is left out from then on (iattr: iattrib[tidal],
+ *   in/out, NULL = consp off).  Only the particles of the levels >= mlevel are examined.  com_system is off in this scope, so
+ *   the comE / covE sums of :3322-3329 and the com0 update of :3520-3537 are not formed;
+ *   freeze (:3336, :4194-4202) -- a particle beyond rtrunc of com0 + center is left out (rtrunc >= 1e20: off).
+ * Products are rounded before they are added (the reference's translation unit is compiled without contraction).       */
+static int orc_beyond(const double *com0, const double *center, double rad, double px, double py, double pz)
+{
+  const double p[3] = {px, py, pz};
+  double r2 = 0.0;
+  for (int i = 0; i < 3; i++) {
+    volatile double t = (p[i] - com0[i] - center[i]) * (p[i] - com0[i] - center[i]);
+    r2 += t;
+  }
+  volatile double lim = rad * rad;
+  return r2 > lim;
+}
+
+void orc_fix_positions_opts(long n, const double *mass, const double *x, const double *y, const double *z,
+                            const double *vx, const double *vy, const double *vz, const double *ax,
+                            const double *ay, const double *az, const int *level, int multistep,
+                            int mlevel, const double *com0, const double *center, double rcom, int *iattr,
+                            double rtrunc, double *lev_sums, double *out)
+{
+  for (int mm = mlevel; mm <= multistep; mm++)
+    for (int k = 0; k < 10; k++) lev_sums[mm * 10 + k] = 0.0;
+  for (int mm = mlevel; mm <= multistep; mm++) {
+    double *s = lev_sums + mm * 10;
+    for (long i = 0; i < n; i++) {
+      if ((level ? level[i] : 0) != mm) continue;
+      if (iattr) {
+        if (orc_beyond(com0, center, rcom, x[i], y[i], z[i]) && iattr[i] == 0) { iattr[i] = 1; continue; }
+        if (iattr[i] == 1) continue;
+      }
+      if (rtrunc < 1.0e20 && orc_beyond(com0, center, rtrunc, x[i], y[i], z[i])) continue;
+      s[0] += mass[i];
+      s[1] += mass[i] * x[i];  s[2] += mass[i] * y[i];  s[3] += mass[i] * z[i];
+      s[4] += mass[i] * vx[i]; s[5] += mass[i] * vy[i]; s[6] += mass[i] * vz[i];
+      s[7] += mass[i] * ax[i]; s[8] += mass[i] * ay[i]; s[9] += mass[i] * az[i];
+    }
+  }
+  for (int k = 0; k < 10; k++) out[k] = 0.0;
+  for (int mm = 0; mm <= multistep; mm++)
+    for (int k = 0; k < 10; k++) out[k] += lev_sums[mm * 10 + k];
+  if (out[0] > 0.0)
+    for (int k = 1; k < 10; k++) out[k] /= out[0];
+}
+
 /* ---- Orient ------------------------------------------------------------------------------------
  * return_euler_slater (exputil/euler_slater.cc:46-76); row-major, BODY != 0 transposes.         */
 void orc_euler_slater(double phi, double theta, double psi, int body, double *o)

@@ -176,6 +176,14 @@ void   orc_fix_positions(long n, const double *mass, const double *x, const doub
                          const double *ax, const double *ay, const double *az, const int *level,
                          int multistep, int mlevel, double *lev_sums, double *out);
 
+/* ... with the escape bookkeeping (consp / tidal / rcom, src/Component.cc:3317-3334, :4204-4212; iattr [n] in/out, NULL: off)
+ * and the freeze test (:3336, :4194-4202; rtrunc >= 1e20: off) of the thread body.                                      */
+void   orc_fix_positions_opts(long n, const double *mass, const double *x, const double *y,
+                              const double *z, const double *vx, const double *vy, const double *vz,
+                              const double *ax, const double *ay, const double *az, const int *level,
+                              int multistep, int mlevel, const double *com0, const double *center,
+                              double rcom, int *iattr, double rtrunc, double *lev_sums, double *out);
+
 /* ---- Orient (src/Orient.H, src/Orient.cc) -------------------------------------------------- */
 #define ORC_ORIENT_HIST 64
 typedef struct {

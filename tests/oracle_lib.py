@@ -325,6 +325,25 @@ class Oracle:
                                    ctypes.c_int(mlevel), _dp(lev_sums), _dp(out))
         return out
 
+    def fix_positions_opts(self, mass, pos, vel, acc, level, multistep, mlevel, lev_sums, com0, center, rcom=None,
+                           iattr=None, rtrunc=1.0e20):
+        """src/Component.cc:3280-3554 with the escape (consp / tidal / rcom: ``iattr`` int32 [n], updated in place) and
+        freeze tests of the thread body (:3317-3336)."""
+        cols = [np.ascontiguousarray(a[:, k], dtype=np.float64) for a in (pos, vel, acc) for k in range(3)]
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        lv = np.ascontiguousarray(level, dtype=np.int32)
+        c0 = np.ascontiguousarray(com0, dtype=np.float64)
+        ce = np.ascontiguousarray(center, dtype=np.float64)
+        out = np.zeros(10)
+        if iattr is not None:
+            assert iattr.dtype == np.int32 and iattr.flags.c_contiguous
+        self.lib.orc_fix_positions_opts(ctypes.c_long(len(m)), _dp(m), *[_dp(c) for c in cols],
+                                        lv.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(multistep), ctypes.c_int(mlevel),
+                                        _dp(c0), _dp(ce), ctypes.c_double(rcom if rcom is not None else 1.0e20),
+                                        iattr.ctypes.data_as(ctypes.c_void_p) if iattr is not None else None,
+                                        ctypes.c_double(rtrunc), _dp(lev_sums), _dp(out))
+        return out
+
     def orient(self, keep, many, oflags, cflags=0, deltaT=0.0, damp=1.0):
         """A fresh ``orc_orient`` (src/Orient.cc:38-80)."""
         o = OrcOrient()

@@ -320,3 +320,76 @@ def test_unsorted_levels_of_many_particles_take_the_staged_path(ctx, oracle):
     for x in (c, cc, c2, f, ff):
         x.close()
     sim.close()
+
+
+@pytest.mark.gpu
+def test_fix_positions_escape_bookkeeping_matches_oracle(ctx, oracle):
+    """The component keys ``tidal`` / ``rcom`` (src/Component.cc:998-1000, :1024): ``consp``.  Component::fix_positions flags a
+    particle of the examined levels that is beyond rcom of com0 + center (escape_com, :4204-4212) -- iattrib[tidal] = 1 --
+    and leaves it out of the sums from then on, whether it comes back inside or not (:3317-3334); together with the freeze
+    test behind it (:3336).  Several calls in a row with the particles moved, the levels re-sorted and a level cut (mlevel 2:
+    the lower levels are neither examined nor re-summed), flags and sums against the oracle; then the flags as a restart
+    would set them."""
+    from exp_amd.runtime import Component, SphereSL
+    rng = np.random.default_rng(29)
+    n, ms = 60000, 3
+    m = rng.uniform(0.5, 1.5, n) / n
+    pos, vel, acc = rng.standard_normal((3, n, 3))
+    lev = rng.integers(0, ms + 1, n).astype(np.int32)
+    com0, ctr, rcom, rtrunc = np.array([0.1, -0.2, 0.05]), np.array([-0.05, 0.1, 0.0]), 1.6, 2.2
+    _, g = make_grid("plummer", 4, 8, 400)
+    f = SphereSL(ctx, g, multistep=ms)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.upload_acc(acc, np.zeros(n))
+    c.upload_levels(lev)
+    c.set_center(ctr)
+    c.set_rtrunc(rtrunc, com0)
+    f.set_multistep_level(0)
+    f.determine_coefficients(c)          # (level, cell) order: slots no longer in the caller's order
+    with pytest.raises(RuntimeError):
+        c.escaped()                      # consp was never switched on
+    c.set_consp(rcom)
+    assert not c.escaped().any()
+    iattr = np.zeros(n, np.int32)
+    sums = np.zeros((ms + 1, 10))
+
+    def check(p, mlevel):
+        ref = oracle.fix_positions_opts(m, p, vel, acc, lev, ms, mlevel, sums, com0, ctr, rcom, iattr, rtrunc)
+        got = c.fix_positions(mlevel)
+        vec = np.concatenate([[got["mtot"]], got["com"], got["cov"], got["coa"]])
+        assert np.abs(vec - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.array_equal(c.escaped().astype(np.int32), iattr)
+
+    check(pos, 0)
+    n1 = int(iattr.sum())
+    assert 0.05 * n < n1 < 0.6 * n
+    c.incr_position(0.5)                 # some come back inside (they stay flagged), others leave
+    p2 = pos + vel * 0.5
+    check(p2, 2)                         # only levels 2, 3 examined: the new escapers of levels 0, 1 are not flagged yet
+    n2 = int(iattr.sum())
+    late = (lev < 2) & oracle_beyond(p2, com0, ctr, rcom) & (iattr == 0)
+    assert n2 > n1 and late.sum() > 100          # ... and these wait for a call that examines their levels
+    f.determine_coefficients(c)          # a re-sort in between: the flags follow the particles, not the slots
+    check(p2, 0)
+    assert int(iattr.sum()) > n2
+    c.incr_position(-0.5)                # everything back where it started: the flagged ones stay out
+    check(pos, 0)
+    # a restart: the attribute column of a body file
+    fl = (rng.random(n) < 0.3).astype(np.uint8)
+    c.set_escaped(fl)
+    iattr[:] = fl
+    sums[:] = 0.0
+    check(pos, 0)
+    with pytest.raises(RuntimeError):
+        c.set_escaped(np.full(n, 2, np.uint8))
+    # switched off: every particle inside rtrunc counts again, the flags are kept
+    c.set_consp(rcom, on=False)
+    keep = ~oracle_beyond(pos, com0, ctr, rtrunc)
+    assert abs(c.fix_positions(0)["mtot"] - m[keep].sum()) <= 1e-13
+    assert np.array_equal(c.escaped().astype(np.int32), iattr)
+    c.close(); f.close()
+
+
+def oracle_beyond(pos, com0, ctr, rad):
+    d = pos - com0 - ctr
+    return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]) > rad * rad
