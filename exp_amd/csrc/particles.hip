@@ -1467,6 +1467,7 @@ extern "C" int exp_amd_comp_get_escaped(exp_amd_comp *c, unsigned char *flags)
 {
   if (!c || !flags) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
+  if (!c->n && c->consp_on) return EXP_AMD_OK;
   if (!c->d_escaped.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "comp_get_escaped: consp was never switched on (exp_amd_comp_set_consp)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(flags, c->d_escaped.p, c->n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1478,6 +1479,7 @@ extern "C" int exp_amd_comp_set_escaped(exp_amd_comp *c, const unsigned char *fl
 {
   if (!c || !flags) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
+  if (!c->n && c->consp_on) return EXP_AMD_OK;
   if (!c->d_escaped.p) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "comp_set_escaped: consp was never switched on (exp_amd_comp_set_consp)");
   for (size_t i = 0; i < c->n; i++)
     if (flags[i] > 1) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "comp_set_escaped: flag %zu is %d (0 or 1)", i, (int)flags[i]);

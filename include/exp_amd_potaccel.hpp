@@ -65,6 +65,11 @@ struct ComponentView {
   // -- no force method accumulates it, differences it or accelerates it.  1e20 (the reference's default): never
   virtual double rtrunc() const { return 1.0e20; }
   virtual void com0(double c[3]) const { c[0] = c[1] = c[2] = 0.0; }
+  // Component::tidal / rcom (src/Component.cc:998-1000, :1024): tidal >= 0 switches `consp` on -- Component::fix_positions
+  // (exp_amd_comp_fix_positions) flags a particle beyond rcom of com0 + center in iattrib[tidal] and leaves it out of the
+  // centre-of-mass sums from then on (:3317-3334); exp_amd_comp_get_escaped / _set_escaped are that attribute column
+  virtual int tidal() const { return -1; }
+  virtual double rcom() const { return 1.0e20; }
   // double Component::Adiabatic() (src/Component.cc:4214-4220) at the caller's current tnow; 1 without ton / toff
   virtual double Adiabatic() const { return 1.0; }
 };
@@ -143,11 +148,12 @@ public:
     double ctr[3];
     c->center(ctr);
     check(exp_amd_comp_set_center(d, ctr), ctx_.get());
-    if (c->rtrunc() < 1.0e20) {                       // Component::freeze (src/Component.cc:4194-4202)
+    if (c->rtrunc() < 1.0e20 || c->tidal() >= 0) {    // Component::freeze / escape_com (src/Component.cc:4194-4212): com0
       double c0[3];
       c->com0(c0);
       check(exp_amd_comp_set_rtrunc(d, c->rtrunc(), c0), ctx_.get());
     }
+    if (c->tidal() >= 0) check(exp_amd_comp_set_consp(d, 1, c->rcom()), ctx_.get());
     return d;
   }
 
