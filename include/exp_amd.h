@@ -252,9 +252,9 @@ int  exp_amd_comp_set_consp(exp_amd_comp *c, int on, double rcom);
 int  exp_amd_comp_get_escaped(exp_amd_comp *c, unsigned char *flags /* [n] */);
 int  exp_amd_comp_set_escaped(exp_amd_comp *c, const unsigned char *flags /* [n], 0 or 1 */);
 /* The per-component sums of the run log (OutLog::Run, src/OutLog.cc:392-478): out = {mass, m x [3], m v [3], angular
- * momentum [3], kinetic energy, 0.5 m pot, Clausius virial m x.a, number of bodies}, reduced over the ranks; every
- * particle counts (no frozen particles in this store), positions and velocities as stored (com_system off), velocities at
- * the step boundary.                                                                                              */
+ * momentum [3], kinetic energy, 0.5 m pot, Clausius virial m x.a, number of bodies}, reduced over the ranks; a frozen
+ * particle (beyond rtrunc, exp_amd_comp_set_rtrunc) is left out of the sums as in src/OutLog.cc:460 and still counted in the
+ * number of bodies; positions and velocities as stored (com_system off), velocities at the step boundary.              */
 int  exp_amd_comp_log_sums(exp_amd_comp *c, double out[14]);
 
 /* ---- orientation / expansion-centre estimator ("EJ") ----------------------------------------
