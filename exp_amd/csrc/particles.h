@@ -40,6 +40,8 @@ struct exp_amd_comp {
   DevBuf<uint32_t> hist;             // histogram / cursors [nkeys+1]
   DevBuf<uint32_t> lev_off;          // [maxlev+2] start slot of every level (device)
   size_t hist_cap = 0;
+  uint32_t sort_win = 0;       // LDS window of the NEXT full sort's passes (0: SORT_WIN); set by the force method's sort function
+                               // for that one sort (SORT_WIN_DENSE: sort_kernels.h), taken and cleared by expamd_comp_finish_sort
   size_t hist_clean = 0;       // leading entries of `hist` known to be zero (a range sort's last kernel leaves the bins it
                                // used clean again: the next sort needs no memset)
   int nlevels = 1;                   // multistep + 1

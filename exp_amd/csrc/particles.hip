@@ -295,6 +295,7 @@ int expamd_comp_prepare_hist(exp_amd_comp *c, uint32_t nkeys)
 {
   exp_amd_ctx *ctx = c->ctx;
   c->mprekey_valid = false;            // (every sort uses the key array and moves slots: a caller that has such keys asked first)
+  c->sort_win = 0;                     // (the force method's sort function sets it after this call, for its own sort)
   if (c->hist_cap < (size_t)nkeys + 1) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, c->hist.alloc((size_t)nkeys + 1));
@@ -567,11 +568,13 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
         k_scatter_adv<false, SCAT_ITEMS_SHORT><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     } else {
     const unsigned g = cdiv(nr, SCAT_TILE);
+    const uint32_t win = (level < 0 && c->sort_win) ? c->sort_win : (uint32_t)SORT_WIN;
     if (move_acc)
-      k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
+      k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
     else
-      k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
+      k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
     }
+    c->sort_win = 0;
   }
   HIP_TRY(ctx, hipGetLastError());
   // the scatter applied the half-kick still owed ahead of its own kick (a range sort: to the levels it holds -- callers

@@ -24,7 +24,16 @@
 #endif
 #define HIST_TILE (SORT_TPB * HIST_ITEMS)
 #define SCAT_TILE (SORT_TPB * SCAT_ITEMS)
+#ifndef SORT_WIN
 #define SORT_WIN 4096          // LDS histogram window (bins) above the block's minimum key
+#endif
+// ... and the part of it a pass zeroes, counts into and walks for a DENSE ONE-LEVEL store of a force method with one-dimensional
+// cells (the sphere's fused step: a 1024-slot tile of 1e8 particles over 2000 cells touches two or three bins, and walking 4096 of
+// them twice is most of the tile's LDS work): k_hist_keys 0.19 -> 0.17 ms, k_scatter_adv 2.10 -> 2.05 ms at 1e8
+// (profiles/r05_sort_win_ab.txt).  Keys beyond the window take the global atomics either way.  Level ranges of a multistep store
+// keep the full window (their keys jump by ncell at a level boundary: config 4 +0.9 ms at 512 bins, +2 ms at 256).
+#define SORT_WIN_DENSE 256
+#define SORT_DENSE_MIN 64       // particles per cell from which a one-level store counts as dense
 
 // A/B switch of the scatter pass (tools/build_variant_tu.sh <suffix> particles "-DSCAT_NT=n"): bit 0 = non-temporal stores of
 // the scattered streams, bit 1 = non-temporal loads of the streams read once.  profiles/r05_scatter_ab.txt
@@ -111,7 +120,7 @@ __device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t *slot)
 // instruction).  Instead the lanes are grouped by key with ballots and one lane per distinct key
 // adds the group's population.
 __device__ __forceinline__ void wave_hist_add(uint32_t key, bool valid, uint32_t kmin,
-                                              uint32_t *lh, uint32_t *__restrict__ hist)
+                                              uint32_t *lh, uint32_t *__restrict__ hist, uint32_t win = SORT_WIN)
 {
   const int lane = threadIdx.x & 63;
   unsigned long long rem = __ballot(valid);
@@ -124,14 +133,14 @@ __device__ __forceinline__ void wave_hist_add(uint32_t key, bool valid, uint32_t
     if (__popcll(mm) * 8 < __popcll(rem)) {
       if ((rem >> lane) & 1ull) {
         const uint32_t d = key - kmin;
-        if (d < SORT_WIN) atomicAdd(&lh[d], 1u);
+        if (d < win) atomicAdd(&lh[d], 1u);
         else atomicAdd(&hist[key], 1u);
       }
       return;
     }
     if (lane == lead) {
       const uint32_t d = kk - kmin, cnt = (uint32_t)__popcll(mm);
-      if (d < SORT_WIN) atomicAdd(&lh[d], cnt);
+      if (d < win) atomicAdd(&lh[d], cnt);
       else atomicAdd(&hist[kk], cnt);
     }
     rem &= ~mm;
@@ -141,7 +150,7 @@ __device__ __forceinline__ void wave_hist_add(uint32_t key, bool valid, uint32_t
 // Same grouping for the scatter pass: returns the lane's rank inside its (block, bin) -- the
 // group's base from one LDS atomic plus the number of lower lanes with the same key -- or
 // 0xffffffff when the key lies outside the LDS window (ranked by a global atomic later).
-__device__ __forceinline__ uint32_t wave_rank(uint32_t key, bool valid, uint32_t kmin, uint32_t *lh)
+__device__ __forceinline__ uint32_t wave_rank(uint32_t key, bool valid, uint32_t kmin, uint32_t *lh, uint32_t win = SORT_WIN)
 {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -154,13 +163,13 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t key, bool valid, uint32_t
     if (__popcll(mm) * 8 < __popcll(rem)) {           // (see wave_hist_add: every lane left takes its own rank)
       if ((rem >> lane) & 1ull) {
         const uint32_t dl = key - kmin;
-        if (dl < SORT_WIN) rk = atomicAdd(&lh[dl], 1u);
+        if (dl < win) rk = atomicAdd(&lh[dl], 1u);
       }
       return rk;
     }
     const uint32_t d = kk - kmin;
     uint32_t base = 0;
-    if (d < SORT_WIN) {
+    if (d < win) {
       if (lane == lead) base = atomicAdd(&lh[d], (uint32_t)__popcll(mm));
       base = (uint32_t)__shfl((int)base, lead);
       if (valid && key == kk) rk = base + (uint32_t)__popcll(mm & lt);
@@ -232,7 +241,8 @@ k_key_hist(KeyFn kf, AdvanceArgs A, SortRange R, uint32_t *__restrict__ key_out,
 // sparse_mask != 0 (keys a block-multistep sweep left, kick_adjust.h: full (level, cell) keys): the keys of the levels that
 // are not cell-sorted are collapsed to the level's first bin -- level = key / stride -- and stored back for the scatter pass
 [[maybe_unused]] static __global__ void __launch_bounds__(SORT_TPB)
-k_hist_keys(uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t sparse_mask = 0u, uint32_t stride = 1u)
+k_hist_keys(uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t sparse_mask = 0u, uint32_t stride = 1u,
+            uint32_t win = SORT_WIN /* bins of the LDS window in use (<= SORT_WIN): SORT_WIN_DENSE for a dense one-level store */)
 {
   __shared__ uint32_t lh[SORT_WIN];
   __shared__ uint32_t kmin_s;
@@ -250,12 +260,12 @@ k_hist_keys(uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, u
     }
     mn = min(mn, k[j]);
   }
-  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
+  for (int b = threadIdx.x; b < (int)win; b += SORT_TPB) lh[b] = 0;
   const uint32_t kmin = block_min_u32(mn, &kmin_s);
 #pragma unroll
-  for (int j = 0; j < HIST_ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist);
+  for (int j = 0; j < HIST_ITEMS; j++) wave_hist_add(k[j], k[j] != 0xffffffffu, kmin, lh, hist, win);
   __syncthreads();
-  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
+  for (int b = threadIdx.x; b < (int)win; b += SORT_TPB) {
     const uint32_t c = lh[b];
     if (c) atomicAdd(&hist[kmin + b], c);
   }
@@ -280,7 +290,7 @@ struct ScatterSrc {
 template <bool MOVE_ACC, int ITEMS = SCAT_ITEMS>
 __global__ void __launch_bounds__(SORT_TPB)
 k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
-              const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor)
+              const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor, uint32_t win = SORT_WIN /* as k_hist_keys */)
 {
   constexpr int SCAT_ITEMS_ = ITEMS;
   __shared__ uint32_t lh[SORT_WIN];       // count, then global base of the (block, bin) range
@@ -297,14 +307,14 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
     k[j] = (i < n) ? key[i] : 0xffffffffu;
     mn = min(mn, k[j]);
   }
-  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) lh[b] = 0;
+  for (int b = threadIdx.x; b < (int)win; b += SORT_TPB) lh[b] = 0;
   const uint32_t kmin = block_min_u32(mn, &kmin_s);
   // rank inside (block, bin)
 #pragma unroll
-  for (int j = 0; j < SCAT_ITEMS_; j++) rk[j] = wave_rank(k[j], k[j] != 0xffffffffu, kmin, lh);
+  for (int j = 0; j < SCAT_ITEMS_; j++) rk[j] = wave_rank(k[j], k[j] != 0xffffffffu, kmin, lh, win);
   __syncthreads();
   // reserve the global range of every non-empty bin: lh[b] <- base
-  for (int b = threadIdx.x; b < SORT_WIN; b += SORT_TPB) {
+  for (int b = threadIdx.x; b < (int)win; b += SORT_TPB) {
     const uint32_t c = lh[b];
     if (c) lh[b] = atomicAdd(&cursor[kmin + b], c);
   }
@@ -314,7 +324,7 @@ k_scatter_adv(AdvanceArgs A, ScatterSrc S, ScatterDst D, SortRange R,
     if (k[j] == 0xffffffffu) continue;
     const size_t i = base + (size_t)j * SORT_TPB + threadIdx.x;
     const uint32_t d = k[j] - kmin;
-    const uint32_t dest = (d < SORT_WIN) ? lh[d] + rk[j] : atomicAdd(&cursor[k[j]], 1u);
+    const uint32_t dest = (d < win) ? lh[d] + rk[j] : atomicAdd(&cursor[k[j]], 1u);
     double x, y, z, vx = 0, vy = 0, vz = 0;
     advance_one(A, i, x, y, z, vx, vy, vz);
     if (!A.advance) { vx = A.vx[i]; vy = A.vy[i]; vz = A.vz[i]; }

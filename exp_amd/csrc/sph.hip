@@ -471,8 +471,11 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
     ProfScope ps(ctx, "k_hist_keys");
     // (a block-multistep run: the keys the closing sweep left are full (level, cell) keys, those of the levels that are
     // not cell-sorted collapse to the level's first bin here)
+    // (a dense one-level store: a tile's keys are two or three neighbouring cells -- the short LDS window, sort_kernels.h)
+    c->sort_win = (c->nlevels == 1 && level < 0 && c->n >= (size_t)SORT_DENSE_MIN * ncell) ? SORT_WIN_DENSE : 0;
     k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p,
-                                                                    f->cfg.multistep ? c->sparse_mask : 0u, ncell);
+                                                                    f->cfg.multistep ? c->sparse_mask : 0u, ncell,
+                                                                    c->sort_win ? c->sort_win : (uint32_t)SORT_WIN);
   } else {
     size_t nr = c->n;          // a level range is sized for its own population
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;
