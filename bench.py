@@ -394,10 +394,22 @@ def live_traffic(args, dom, nloc, budget_s=300.0):
                 return None, "time budget of the counter passes used up"
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                               timeout=left)
-            if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s: exit code %d" % (ctr, r.returncode)
+            # (a session of its own: on a timeout the profiler AND the program it started are ended, by process group --
+            # never by a pattern)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s: exit code %d" % (ctr, rc)
             vals = _counter_rows(out, ctr, dom)
             if not vals:
                 return None, "no %s rows for %s" % (ctr, dom)
