@@ -86,6 +86,7 @@ SIGNATURES = {
                                    c_void_p, POINTER(c_void_p)]),
     "exp_amd_comp_fix_positions": (c_int, [c_void_p, c_int, c_void_p]),
     "exp_amd_comp_set_consp": (c_int, [c_void_p, c_int, c_double]),
+    "exp_amd_comp_set_level_policy": (c_int, [c_void_p, c_int, c_int, c_int]),
     "exp_amd_comp_get_escaped": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_set_escaped": (c_int, [c_void_p, c_void_p]),
     "exp_amd_comp_log_sums": (c_int, [c_void_p, c_void_p]),

@@ -238,6 +238,9 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   for (int M = 0; M <= ms; M++)
     if (mdrft == 0 || mdrft % (1 << (ms - M)) == 0) { mfirst = M; break; }
   const int first = first_step ? 0 : mfirst;        // src/multistep.cc:451-453
+  // `if (not firstCall and c->FreezeLev()) apply = false;` (src/multistep.cc:158, :534): nothing is proposed, nothing moves
+  // (firstCall = this_step == 0 and mdrft == 0, begin_run's call; first_step alone is the "do all levels" rule of :453)
+  if (c->freeze_levels && !(first_step && mdrft == 0)) { if (nswitch) *nswitch = 0; return EXP_AMD_OK; }
   int rc = expamd_comp_propose_levels(c, dtime, dynfrac, shiftlevl, ms, mfirst, first);
   if (rc) return rc;
   // one 8-byte read-back decides whether anything has to be differenced / re-ordered at all

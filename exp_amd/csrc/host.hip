@@ -477,11 +477,16 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     exp_amd_force *fk = s->forces[k];
     ka_launch_fn kfn = nullptr;
     void *kself = nullptr;
-    const bool closing = kick && !first_step && mdrft == s->Mstep && first == 0 && !s->orients[k] && ck->nlevels == ms + 1 &&
+    // "freezeL" (Component::FreezeLev, src/multistep.cc:158, :534): after the first call this component's sweep examines no
+    // level -- the closing kick alone, counters of zero
+    // (firstCall = this_step == 0 and mdrft == 0: begin_run's assignment; the first sub-step of the run examines every level
+    // too -- first_step -- but is not the first call)
+    const int first_k = (ck->freeze_levels && !(first_step && mdrft == 0)) ? ms + 1 : first;
+    const bool closing = kick && !first_step && mdrft == s->Mstep && first_k == 0 && !s->orients[k] && ck->nlevels == ms + 1 &&
                          ck->pending_kick == 0.0 && EXPAMD_EXPT("EXP_AMD_MS_PREKEY", 1) != 0;
     if (closing && !fk->prekey_launcher(ck, &kfn, &kself)) kfn = nullptr;
     if ((rc = expamd_comp_kick_adjust(ck, s->dtime, s->dynfrac, s->shiftlevl, ms, mf,
-                                      kick ? mf : ms + 1, first, dt_min, &res, s->pinned_dev + k * 40, seq, &launched, /*build_list=*/true,
+                                      kick ? mf : ms + 1, first_k, dt_min, &res, s->pinned_dev + k * 40, seq, &launched, /*build_list=*/true,
                                       kfn, kself))) return rc;
     if (kfn && launched && ck->mprekey_n == ck->n) {
       ck->mprekey_valid = true;

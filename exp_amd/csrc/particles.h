@@ -55,6 +55,11 @@ struct exp_amd_comp {
   DevBuf<double> d_frz;                         // {com0[3], center[3], rtrunc^2} for the kernels (expamd_comp_frz)
   double frz_host[7] = {0, 0, 0, 0, 0, 0, 0};
   bool frz_valid = false;
+  // Component::freezeLev (the component key "freezeL", src/Component.cc:255, :1037): levels are assigned on the first call of
+  // adjust_multistep_level only (src/multistep.cc:158, :534: `if (not firstCall and c->FreezeLev()) apply = false;`).
+  // "noswitch" (:253, level changes at the end of a master step only, from the smallest time step seen during it) is not
+  // built: exp_amd_comp_set_level_policy refuses it
+  bool freeze_levels = false;
   // Component::consp / tidal / rcom (src/Component.cc:214-216, :998-1000, :1024): the escape bookkeeping of fix_positions
   // (:3317-3334) -- a particle beyond rcom of com0 + center is flagged once and left out of the centre-of-mass sums from
   // then on.  d_escaped: iattrib[tidal] of every particle, indexed by its id (the caller's index; ids travel with the

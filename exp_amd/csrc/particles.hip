@@ -1445,6 +1445,20 @@ extern "C" int exp_amd_comp_log_sums(exp_amd_comp *c, double out[14])
   return EXP_AMD_OK;
 }
 
+// The component keys "noswitch", "freezeL", "dtreset" (src/Component.cc:253-255, :1036-1038), read by adjust_multistep_level's
+// thread body (src/multistep.cc:136-158) and its device twin's caller (:528-534)
+extern "C" int exp_amd_comp_set_level_policy(exp_amd_comp *c, int noswitch, int freeze_levels, int dtreset)
+{
+  if (!c) return EXP_AMD_ERR_ARG;
+  (void)dtreset;               // (only read with noswitch on)
+  if (noswitch)
+    return expamd_fail(c->ctx, EXP_AMD_ERR_ARG, "comp_set_level_policy: 'noswitch: true' is not supported by this build -- level "
+                       "changes at the end of a master step only, from the smallest time step a particle asked for during it "
+                       "(Particle::dtreq kept between sweeps, src/multistep.cc:136-147), are not built");
+  c->freeze_levels = freeze_levels != 0;
+  return EXP_AMD_OK;
+}
+
 // Component::consp / tidal / rcom (src/Component.cc:998-1000, :1024): the flags start at zero (iattrib as the body file gave
 // them: exp_amd_comp_set_escaped), one byte per particle id
 extern "C" int exp_amd_comp_set_consp(exp_amd_comp *c, int on, double rcom)

@@ -276,6 +276,14 @@ class Component:
         check(self.lib.exp_amd_comp_set_rtrunc(self.h, float(rtrunc), c0[1] if c0 else None), self.ctx.h)
         self.rtrunc = float(rtrunc)
 
+    def set_level_policy(self, noswitch: bool = False, freeze_levels: bool = False, dtreset: bool = True) -> None:
+        """The component keys ``noswitch``, ``freezeL``, ``dtreset`` (src/Component.cc:253-255, :1036-1038) that
+        ``adjust_multistep_level`` reads (src/multistep.cc:136-158, :528-534).  ``freezeL``: levels are assigned on the first
+        call only.  ``noswitch: true`` is refused by name (the per-particle ``dtreq`` minimum over a master step is not
+        built); ``dtreset`` is only read with it."""
+        check(self.lib.exp_amd_comp_set_level_policy(self.h, int(bool(noswitch)), int(bool(freeze_levels)), int(bool(dtreset))),
+              self.ctx.h)
+
     def set_consp(self, rcom: float, on: bool = True) -> None:
         """The component keys ``tidal`` (switches ``consp`` on, src/Component.cc:998-1000) and ``rcom`` (:1024): from now on
         ``fix_positions`` flags a particle beyond ``rcom`` of com0 + center (``escape_com``, :4204-4212) and leaves it out of

@@ -242,6 +242,13 @@ int  exp_amd_comp_zero_acc(exp_amd_comp *c, int mlevel);
  * does); ranks are combined with the context's all-reduce.  out = {mtot, com[3], cov[3], coa[3]}
  * (the three vectors divided by mtot when mtot > 0).                                        */
 int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
+/* The component keys "noswitch", "freezeL", "dtreset" (src/Component.cc:253-255, :1036-1038), read by
+ * adjust_multistep_level (src/multistep.cc:136-158, :528-534).  freeze_levels: levels are assigned on the first call only
+ * (`if (not firstCall and c->FreezeLev()) apply = false;`) -- exp_amd_force_adjust_multistep_level and the step driver's
+ * sweeps then move nothing of this component.  noswitch != 0 (level changes at the end of a master step only, from the
+ * smallest time step a particle asked for during it: Particle::dtreq kept between sweeps) is NOT built and is refused
+ * with EXP_AMD_ERR_ARG; dtreset is only read with it.                                                                  */
+int  exp_amd_comp_set_level_policy(exp_amd_comp *c, int noswitch, int freeze_levels, int dtreset);
 /* The escape bookkeeping of Component::fix_positions: the component keys "tidal" (which switches `consp` on and names the
  * integer attribute that holds the flag, src/Component.cc:998-1000) and "rcom" (:1024).  With it on, fix_positions flags a
  * particle of the examined levels that is beyond rcom of com0 + center (Component::escape_com, :4204-4212; com0 is the one of

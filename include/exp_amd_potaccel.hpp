@@ -70,6 +70,12 @@ struct ComponentView {
   // centre-of-mass sums from then on (:3317-3334); exp_amd_comp_get_escaped / _set_escaped are that attribute column
   virtual int tidal() const { return -1; }
   virtual double rcom() const { return 1.0e20; }
+  // Component::NoSwitch / FreezeLev / DTreset (keys noswitch, freezeL, dtreset; src/Component.cc:253-255): read by
+  // adjust_multistep_level (src/multistep.cc:136-158).  FreezeLev is honoured; NoSwitch() == true is refused when the
+  // component is uploaded (exp_amd_comp_set_level_policy says why)
+  virtual bool NoSwitch() const { return false; }
+  virtual bool FreezeLev() const { return false; }
+  virtual bool DTreset() const { return true; }
   // double Component::Adiabatic() (src/Component.cc:4214-4220) at the caller's current tnow; 1 without ton / toff
   virtual double Adiabatic() const { return 1.0; }
 };
@@ -154,6 +160,8 @@ public:
       check(exp_amd_comp_set_rtrunc(d, c->rtrunc(), c0), ctx_.get());
     }
     if (c->tidal() >= 0) check(exp_amd_comp_set_consp(d, 1, c->rcom()), ctx_.get());
+    if (c->NoSwitch() || c->FreezeLev())
+      check(exp_amd_comp_set_level_policy(d, c->NoSwitch() ? 1 : 0, c->FreezeLev() ? 1 : 0, c->DTreset() ? 1 : 0), ctx_.get());
     return d;
   }
 

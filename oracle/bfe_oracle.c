@@ -635,7 +635,7 @@ void orc_mstep_combine(const orc_mstep_tables *t, int mdrft, long ncoef,
     for (long k = 0; k < ncoef; k++) coef[k] += coefN[(size_t)M * ncoef + k];
 }
 
-/* src/multistep.cc:94-196 (criteria + level rule; NoSwitch/FreezeLev off) */
+/* src/multistep.cc:94-196 (criteria + level rule; NoSwitch off; FreezeLev is the caller's: nbody_oracle.c adjust_levels) */
 int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
                      int shiftlevl, const double *dynfrac, double scale,
                      const double *v, const double *a, double pot, double *dtreq)

@@ -228,7 +228,10 @@ static void adjust_levels(orc_nbody *S, const orc_mstep_tables *T, int mdrft, in
     const long nc = c->ncoef;
     for (int M = mf; M <= ms; M++) memset(w->differ + (size_t)M * nc, 0, sizeof(double) * nc);
     long switched = 0;
-    for (int lev = first; lev <= ms; lev++) {
+    /* `if (not firstCall and c->FreezeLev()) apply = false;` (src/multistep.cc:158): no level is proposed, nothing moves */
+    /* (firstCall = this_step == 0 and mdrft == 0: begin_run's call; the first sub-step of the run also does all levels, :453) */
+    const int frozen_levels = c->freeze_lev && !(all_levels && mdrft == 0);
+    for (int lev = first; lev <= ms && !frozen_levels; lev++) {
       for (long i = 0; i < c->n; i++) {
         if (c->level[i] != lev) continue;
         double v[3] = {c->vx[i], c->vy[i], c->vz[i]}, a[3] = {c->ax[i], c->ay[i], c->az[i]};

@@ -47,6 +47,8 @@ typedef struct {
   double *C0;
   int mlim;                   /* the cylinder's "mlim" key when has_mlim (src/Cylinder.cc:225)                */
   int has_mlim;
+  int freeze_lev;             /* "freezeL" (Component::FreezeLev, src/Component.cc:255, :1037): levels are assigned on the first
+                                 call of adjust_multistep_level only (src/multistep.cc:158, :534)               */
 } orc_nbody_comp;
 
 typedef struct {

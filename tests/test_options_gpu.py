@@ -275,6 +275,8 @@ def _driver_run(ctx, inp, opts_h, opts_d, ms, dtime, nsteps):
             c.set_rtrunc(o["rtrunc"], o.get("com0"))
         if o.get("adiabatic") is not None:
             sim.set_adiabatic(k, *o["adiabatic"])
+        if o.get("freeze_levels"):
+            c.set_level_policy(freeze_levels=True)
     sim.init()
     sim.step(nsteps)
     return sim, (fh, fd), (ch, cd)
@@ -284,6 +286,9 @@ SCENARIOS = [
     (dict(rtrunc=0.35, com0=(0.004, -0.003, 0.002), fix_l0=True), dict(adiabatic=(7.5e-5, 1.0e20, 1.5e-4), mlim=1)),
     (dict(self_consistent=False), dict(rtrunc=0.03, self_consistent=False)),
     (dict(adiabatic=(1.0e-4, 4.0e-4, 1.0e-4), rtrunc=0.6), dict(rtrunc=0.05, com0=(0.001, 0.0, 0.0), adiabatic=(0.0, 1.0e20, 3.0e-4))),
+    # "freezeL" (Component::FreezeLev, src/multistep.cc:158, :534): the disk keeps the levels of its first assignment, the halo moves on
+    (dict(), dict(freeze_levels=True)),
+    (dict(freeze_levels=True, rtrunc=0.6), dict(freeze_levels=True)),
 ]
 
 
@@ -310,8 +315,10 @@ def test_step_driver_with_the_option_keys_against_the_nbody_oracle(ctx, oracle, 
     for _ in range(nsteps):
         nsw = [a + b for a, b in zip(nsw, nb.step())]
     sim, forces, comps = _driver_run(ctx, inp, oh, od, ms, dtime, nsteps)
-    assert sum(nsw) > 0
+    assert sum(nsw) > 0 or (oh.get("freeze_levels") and od.get("freeze_levels"))
     for k, (f, c) in enumerate(zip(forces, comps)):
+        if (oh, od)[k].get("freeze_levels"):
+            assert nsw[k] == 0 and len(np.unique(nb.state[k]["level"])) > 1      # levels assigned once, never moved
         st = nb.state[k]
         o = c.download()
         assert np.array_equal(c.download_levels(), st["level"]), k
@@ -373,4 +380,45 @@ def test_self_consistent_false_and_fix_l0_at_the_call_level(ctx, oracle, plummer
     # a fused step with the coefficients held fixed: kick, drift, force of the same set, kick
     f.step_kdk(c, 1e-3)
     assert np.array_equal(f.get_coefs(), now)
+    c.close(); f.close()
+
+
+def test_level_policy_keys_through_the_c_abi(ctx):
+    """The component keys noswitch / freezeL / dtreset (src/Component.cc:253-255): ``freezeL`` makes the per-call
+    adjust_multistep_level (exp_amd_force_adjust_multistep_level, what the C++ adaptor calls) a no-op after the first call
+    (src/multistep.cc:158: firstCall = this_step == 0 and mdrft == 0) and leaves it alone on that call; ``noswitch: true`` is
+    refused by name."""
+    import ctypes
+    from exp_amd.runtime import Component, SphereSL
+    from tests.conftest import make_grid
+    rng = np.random.default_rng(3)
+    n, ms = 20000, 3
+    _, g = make_grid("plummer", 4, 8, 400)
+    m = np.full(n, 1.0 / n)
+    pos = rng.standard_normal((n, 3)) * 0.5
+    vel = rng.standard_normal((n, 3)) * 0.3
+    f = SphereSL(ctx, g, multistep=ms)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    with pytest.raises(RuntimeError, match="noswitch"):
+        c.set_level_policy(noswitch=True)
+    c.set_level_policy(freeze_levels=True, dtreset=False)
+    f.set_multistep_level(0)
+    f.determine_coefficients(c)                  # (the store in this force's order, ms + 1 levels)
+    c.upload_acc(rng.standard_normal((n, 3)), -np.abs(rng.standard_normal(n)) - 0.5)
+    dyn = (ctypes.c_double * 5)(1e20, 0.02, 1e20, 0.05, 0.05)
+    nsw = ctypes.c_longlong(-1)
+
+    def adjust(mdrft, first_step):
+        rc = c.lib.exp_amd_force_adjust_multistep_level(f.h, c.h, 0.05, dyn, 0, mdrft, first_step, ctypes.byref(nsw))
+        assert rc == 0
+        return int(nsw.value)
+
+    assert adjust(0, 1) > 0                      # begin_run's call: the one assignment
+    lev = c.download_levels()
+    assert len(np.unique(lev)) > 1
+    c.incr_velocity(0.3)                          # other velocities: every criterion changes
+    assert adjust(1, 1) == 0 and adjust(8, 0) == 0
+    assert np.array_equal(c.download_levels(), lev)
+    c.set_level_policy(freeze_levels=False)
+    assert adjust(8, 0) > 0                      # ... and with the key off the same call moves particles
     c.close(); f.close()
