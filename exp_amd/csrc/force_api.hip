@@ -241,6 +241,9 @@ extern "C" int exp_amd_force_adjust_multistep_level(exp_amd_force *f, exp_amd_co
   // `if (not firstCall and c->FreezeLev()) apply = false;` (src/multistep.cc:158, :534): nothing is proposed, nothing moves
   // (firstCall = this_step == 0 and mdrft == 0, begin_run's call; first_step alone is the "do all levels" rule of :453)
   if (c->freeze_levels && !(first_step && mdrft == 0)) { if (nswitch) *nswitch = 0; return EXP_AMD_OK; }
+  // "noswitch" (src/multistep.cc:136-147): mstep = mdrft - 1 at do_step's call (src/step.cc:188, :221)
+  c->ns_reset = ((c->dtreset && mdrft == 1) || (first_step && mdrft == 0)) ? 1 : 0;
+  c->ns_apply = (mdrft == Mstep || (first_step && mdrft == 0)) ? 1 : 0;
   int rc = expamd_comp_propose_levels(c, dtime, dynfrac, shiftlevl, ms, mfirst, first);
   if (rc) return rc;
   // one 8-byte read-back decides whether anything has to be differenced / re-ordered at all

@@ -413,6 +413,8 @@ static int compute_potential_ms(exp_amd_sim *s, int mlevel, int mdrft, int mstep
 // are of this kind: they reduce to the closing kick, with no counters, no read-back and no wait.
 static bool sweep_is_noop(const exp_amd_sim *s, int mdrft, int first_step)
 {
+  // (a "noswitch" component: every sweep takes its particles' time steps into Particle::dtreq, whether it can move them or not)
+  for (const exp_amd_comp *c : s->comps) if (c->noswitch) return false;
   return s->multistep > 0 && !first_step && s->mfirst[mdrft] == s->multistep;
 }
 
@@ -482,6 +484,9 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
     // (firstCall = this_step == 0 and mdrft == 0: begin_run's assignment; the first sub-step of the run examines every level
     // too -- first_step -- but is not the first call)
     const int first_k = (ck->freeze_levels && !(first_step && mdrft == 0)) ? ms + 1 : first;
+    // "noswitch" (src/multistep.cc:136-147): mstep = mdrft - 1 at do_step's call; begin_run's call is the firstCall
+    ck->ns_reset = ((ck->dtreset && mdrft == 1) || (first_step && mdrft == 0)) ? 1 : 0;
+    ck->ns_apply = (mdrft == s->Mstep || (first_step && mdrft == 0)) ? 1 : 0;
     const bool closing = kick && !first_step && mdrft == s->Mstep && first_k == 0 && !s->orients[k] && ck->nlevels == ms + 1 &&
                          ck->pending_kick == 0.0 && EXPAMD_EXPT("EXP_AMD_MS_PREKEY", 1) != 0;
     if (closing && !fk->prekey_launcher(ck, &kfn, &kself)) kfn = nullptr;

@@ -23,6 +23,28 @@ struct AdjustArgs {
   int multistep, shiftlevl, mfirst_mdrft;
 };
 
+// "noswitch" (Component::NoSwitch, src/multistep.cc:136-147): Particle::dtreq -- a float kept between sweeps, here one per
+// particle id -- holds the smallest time step asked for since its last reset, and a sweep only assigns levels when `apply`
+// (the end of a master step, or the first call).  dtreq == nullptr: the key is off, dtreq is this sweep's dt.
+struct NsArgs {
+  float *dtreq = nullptr;
+  const uint32_t *id = nullptr;
+  int reset = 0;               // (DTreset and mstep == 0) or firstCall: dtreq starts again from the largest float (:137-138)
+  int apply = 1;               // mdrft == Mstep or firstCall (:147)
+};
+// -> the float dtreq the level rule sees, and whether it is applied
+__device__ __forceinline__ float ns_dtreq(const NsArgs &N, size_t i, double dt, bool &apply)
+{
+  apply = true;
+  if (!N.dtreq) return (float)dt;
+  const uint32_t pid = N.id[i];
+  float q = N.reset ? __builtin_huge_valf() : N.dtreq[pid];
+  if (dt < (double)q) q = (float)dt;
+  N.dtreq[pid] = q;
+  apply = N.apply != 0;
+  return q;
+}
+
 // key output of k_kick_adjust (KeyFn::on): positions and the key array
 struct KaKeyArgs {
   const double *x = nullptr, *y = nullptr, *z = nullptr;
@@ -53,7 +75,7 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
               unsigned long long seq = 0ull,
               uint32_t *__restrict__ list = nullptr /* the movers' slots are compacted here as well (k_mover_list's job) */,
               uint32_t *__restrict__ lcnt = nullptr, uint32_t *__restrict__ lcnt_next = nullptr,
-              KeyFn kf = KeyFn(), KaKeyArgs K = KaKeyArgs())
+              KeyFn kf = KeyFn(), KaKeyArgs K = KaKeyArgs(), NsArgs N = NsArgs())
 {
   // two counter sets are used alternately: this launch leaves the other one clean for the next
   if (blockIdx.x == 0 && threadIdx.x < 32) out_next[threadIdx.x] = 0ull;
@@ -102,15 +124,18 @@ k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, do
         if (dta > 0.0 && dta < dmin) dmin = dta;
         if (dtA > 0.0 && dtA < dmin) dmin = dtA;
         const double dt = dmin > eps ? dmin : eps;
-        const float dtreq = (float)dt;
-        if ((double)dtreq > A.dtime) nlev = 0;
-        else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
-        if (A.shiftlevl) {
-          if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
-          else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+        bool apply;
+        const float dtreq = ns_dtreq(N, i, dt, apply);
+        if (apply) {
+          if ((double)dtreq > A.dtime) nlev = 0;
+          else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
+          if (A.shiftlevl) {
+            if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
+            else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+          }
+          if (nlev > (unsigned)A.multistep) nlev = A.multistep;
+          if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
         }
-        if (nlev > (unsigned)A.multistep) nlev = A.multistep;
-        if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
         newlev[i] = (uint8_t)nlev;
       }
       if constexpr (KeyFn::on) {
@@ -188,11 +213,12 @@ struct KaLaunch {
   unsigned long long *host_out, seq;
   uint32_t *list, *lcnt, *lcnt_next;
   KaKeyArgs K;
+  NsArgs N;
 };
 template <class KeyFn>
 static inline void ka_launch_with(const KaLaunch &L, const KeyFn &kf)
 {
   k_kick_adjust<KeyFn><<<L.grid, KA_TPB, 0, L.stream>>>(L.A, L.vx, L.vy, L.vz, L.ax, L.ay, L.az, L.pot, L.lev, L.newlev, L.lev_off,
                                                     L.kick_lo, L.first, L.last, L.dt_min, L.out, L.out_next, L.items, L.ticket,
-                                                    L.host_out, L.seq, L.list, L.lcnt, L.lcnt_next, kf, L.K);
+                                                    L.host_out, L.seq, L.list, L.lcnt, L.lcnt_next, kf, L.K, L.N);
 }

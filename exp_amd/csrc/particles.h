@@ -60,6 +60,12 @@ struct exp_amd_comp {
   // "noswitch" (:253, level changes at the end of a master step only, from the smallest time step seen during it) is not
   // built: exp_amd_comp_set_level_policy refuses it
   bool freeze_levels = false;
+  // "noswitch" / "dtreset" (Component::NoSwitch, DTreset; src/multistep.cc:136-147): d_dtreq is Particle::dtreq, one float per
+  // particle id; ns_reset / ns_apply are the two conditions of the sweep about to be launched, set by its caller (host.hip,
+  // force_api.hip) and read by expamd_comp_kick_adjust / expamd_comp_propose_levels (kick_adjust.h: NsArgs)
+  bool noswitch = false, dtreset = true;
+  DevBuf<float> d_dtreq;
+  int ns_reset = 0, ns_apply = 1;
   // Component::consp / tidal / rcom (src/Component.cc:214-216, :998-1000, :1024): the escape bookkeeping of fix_positions
   // (:3317-3334) -- a particle beyond rcom of com0 + center is flagged once and left out of the centre-of-mass sums from
   // then on.  d_escaped: iattrib[tidal] of every particle, indexed by its id (the caller's index; ids travel with the

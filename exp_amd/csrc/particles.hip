@@ -621,7 +621,7 @@ k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__res
                 const double *__restrict__ ay, const double *__restrict__ az,
                 const double *__restrict__ pot, const uint8_t *__restrict__ lev,
                 uint8_t *__restrict__ newlev, const uint32_t *__restrict__ lev_off, int first,
-                int last, size_t n, unsigned long long *__restrict__ nswitch)
+                int last, size_t n, unsigned long long *__restrict__ nswitch, NsArgs N)
 {
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
@@ -644,15 +644,18 @@ k_adjust_levels(AdjustArgs A, const double *__restrict__ vx, const double *__res
     if (dta > 0.0 && dta < dmin) dmin = dta;
     if (dtA > 0.0 && dtA < dmin) dmin = dtA;
     const double dt = dmin > eps ? dmin : eps;
-    const float dtreq = (float)dt;
-    if ((double)dtreq > A.dtime) nlev = 0;
-    else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
-    if (A.shiftlevl) {
-      if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
-      else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+    bool apply;
+    const float dtreq = ns_dtreq(N, i, dt, apply);       // ("noswitch": kick_adjust.h)
+    if (apply) {
+      if ((double)dtreq > A.dtime) nlev = 0;
+      else nlev = (unsigned)(int)floor(log(A.dtime / (double)dtreq) / log(2.0));
+      if (A.shiftlevl) {
+        if (nlev > plev) { if (nlev - plev > (unsigned)A.shiftlevl) nlev = plev + A.shiftlevl; }
+        else if (plev > nlev) { if (plev - nlev > (unsigned)A.shiftlevl) nlev = plev - A.shiftlevl; }
+      }
+      if (nlev > (unsigned)A.multistep) nlev = A.multistep;
+      if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
     }
-    if (nlev > (unsigned)A.multistep) nlev = A.multistep;
-    if ((int)nlev < A.mfirst_mdrft) nlev = A.mfirst_mdrft;
     if (nlev != plev) atomicAdd(nswitch, 1ull);
   }
   newlev[i] = (uint8_t)nlev;
@@ -663,6 +666,19 @@ k_commit_levels(uint8_t *__restrict__ lev, const uint8_t *__restrict__ newlev, s
 {
   const size_t i = beg + (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i < n) lev[i] = newlev[i];
+}
+
+// the "noswitch" arguments of the sweep about to be launched (exp_amd_comp::ns_reset / ns_apply: set by its caller)
+static NsArgs comp_ns_args(exp_amd_comp *c)
+{
+  NsArgs N;
+  if (c->noswitch && c->d_dtreq.p) {
+    N.dtreq = c->d_dtreq.p;
+    N.id = c->id[c->cur].p;
+    N.reset = c->ns_reset;
+    N.apply = c->ns_apply;
+  }
+  return N;
 }
 
 int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfrac[5], int shiftlevl,
@@ -677,7 +693,7 @@ int expamd_comp_propose_levels(exp_amd_comp *c, double dtime, const double dynfr
   ProfScope ps(ctx, "k_adjust_levels");
   k_adjust_levels<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(
       A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT),
-      c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, multistep, c->n, c->nswitch.p + 64);
+      c->level[c->cur].p, c->newlev.p, c->lev_off.p, first, multistep, c->n, c->nswitch.p + 64, comp_ns_args(c));
   HIP_TRY(ctx, hipGetLastError());
   return EXP_AMD_OK;
 }
@@ -817,7 +833,7 @@ int expamd_comp_kick_adjust(exp_amd_comp *c, double dtime, const double dynfrac[
   KaLaunch L{cdiv(tiles, (size_t)items), ctx->stream, A, c->a(A_VX), c->a(A_VY), c->a(A_VZ), c->a(A_AX), c->a(A_AY), c->a(A_AZ),
              c->a(A_POT), c->level[c->cur].p, c->newlev.p, c->lev_off.p, kick_lo, first, multistep, dt_min, out, nxt, items,
              (unsigned int *)(c->nswitch.p + 70), host_out, seq, lcnt ? c->mover_list.p : nullptr, lcnt, lnxt,
-             KaKeyArgs{c->a(A_X), c->a(A_Y), c->a(A_Z), c->key.p}};
+             KaKeyArgs{c->a(A_X), c->a(A_Y), c->a(A_Z), c->key.p}, comp_ns_args(c)};
   c->mprekey_valid = false;
   // (key_launch: the sweep that closes a master step, every slot examined: the force method's instantiation writes the
   // next sub-step's sort keys on the way -- host.hip, kick_adjust.h)
@@ -889,6 +905,7 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
   }
   c->d_frz.release();
   c->d_escaped.release();
+  c->d_dtreq.release();
   c->key.release();
   c->newlev.release();
   c->nswitch.release();
@@ -1450,11 +1467,15 @@ extern "C" int exp_amd_comp_log_sums(exp_amd_comp *c, double out[14])
 extern "C" int exp_amd_comp_set_level_policy(exp_amd_comp *c, int noswitch, int freeze_levels, int dtreset)
 {
   if (!c) return EXP_AMD_ERR_ARG;
-  (void)dtreset;               // (only read with noswitch on)
-  if (noswitch)
-    return expamd_fail(c->ctx, EXP_AMD_ERR_ARG, "comp_set_level_policy: 'noswitch: true' is not supported by this build -- level "
-                       "changes at the end of a master step only, from the smallest time step a particle asked for during it "
-                       "(Particle::dtreq kept between sweeps, src/multistep.cc:136-147), are not built");
+  exp_amd_ctx *ctx = c->ctx;
+  if (noswitch && !c->d_dtreq.p && c->n) {       // Particle::dtreq, one float per particle id (the first call resets it: firstCall)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->d_dtreq.alloc(c->n) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_set_level_policy: hipMalloc failed");
+    HIP_TRY(ctx, hipMemsetAsync(c->d_dtreq.p, 0, c->n * sizeof(float), ctx->stream));
+  }
+  c->noswitch = noswitch != 0;
+  c->dtreset = dtreset != 0;
   c->freeze_levels = freeze_levels != 0;
   return EXP_AMD_OK;
 }

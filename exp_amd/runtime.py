@@ -279,8 +279,8 @@ class Component:
     def set_level_policy(self, noswitch: bool = False, freeze_levels: bool = False, dtreset: bool = True) -> None:
         """The component keys ``noswitch``, ``freezeL``, ``dtreset`` (src/Component.cc:253-255, :1036-1038) that
         ``adjust_multistep_level`` reads (src/multistep.cc:136-158, :528-534).  ``freezeL``: levels are assigned on the first
-        call only.  ``noswitch: true`` is refused by name (the per-particle ``dtreq`` minimum over a master step is not
-        built); ``dtreset`` is only read with it."""
+        call only.  ``noswitch``: ``Particle::dtreq`` keeps the smallest time step asked for since its last reset (at mstep ==
+        0 with ``dtreset``, and on the first call) and levels are assigned at the end of a master step only."""
         check(self.lib.exp_amd_comp_set_level_policy(self.h, int(bool(noswitch)), int(bool(freeze_levels)), int(bool(dtreset))),
               self.ctx.h)
 

@@ -245,9 +245,10 @@ int  exp_amd_comp_fix_positions(exp_amd_comp *c, int mlevel, double out[10]);
 /* The component keys "noswitch", "freezeL", "dtreset" (src/Component.cc:253-255, :1036-1038), read by
  * adjust_multistep_level (src/multistep.cc:136-158, :528-534).  freeze_levels: levels are assigned on the first call only
  * (`if (not firstCall and c->FreezeLev()) apply = false;`) -- exp_amd_force_adjust_multistep_level and the step driver's
- * sweeps then move nothing of this component.  noswitch != 0 (level changes at the end of a master step only, from the
- * smallest time step a particle asked for during it: Particle::dtreq kept between sweeps) is NOT built and is refused
- * with EXP_AMD_ERR_ARG; dtreset is only read with it.                                                                  */
+ * sweeps then move nothing of this component.  noswitch: Particle::dtreq (a float per particle, kept on the device by particle
+ * id) holds the smallest time step asked for since its last reset -- at mstep == 0 when dtreset is set, and on the first call
+ * (:136-141) -- and levels are only assigned at the end of a master step (mdrft == Mstep) or on the first call (:147); the
+ * sweeps in between examine their levels for dtreq's sake and move nothing.  dtreset is only read with noswitch.          */
 int  exp_amd_comp_set_level_policy(exp_amd_comp *c, int noswitch, int freeze_levels, int dtreset);
 /* The escape bookkeeping of Component::fix_positions: the component keys "tidal" (which switches `consp` on and names the
  * integer attribute that holds the flag, src/Component.cc:998-1000) and "rcom" (:1024).  With it on, fix_positions flags a

@@ -71,8 +71,8 @@ struct ComponentView {
   virtual int tidal() const { return -1; }
   virtual double rcom() const { return 1.0e20; }
   // Component::NoSwitch / FreezeLev / DTreset (keys noswitch, freezeL, dtreset; src/Component.cc:253-255): read by
-  // adjust_multistep_level (src/multistep.cc:136-158).  FreezeLev is honoured; NoSwitch() == true is refused when the
-  // component is uploaded (exp_amd_comp_set_level_policy says why)
+  // adjust_multistep_level (src/multistep.cc:136-158); handed to the store when the component is uploaded
+  // (exp_amd_comp_set_level_policy)
   virtual bool NoSwitch() const { return false; }
   virtual bool FreezeLev() const { return false; }
   virtual bool DTreset() const { return true; }

@@ -635,10 +635,8 @@ void orc_mstep_combine(const orc_mstep_tables *t, int mdrft, long ncoef,
     for (long k = 0; k < ncoef; k++) coef[k] += coefN[(size_t)M * ncoef + k];
 }
 
-/* src/multistep.cc:94-196 (criteria + level rule; NoSwitch off; FreezeLev is the caller's: nbody_oracle.c adjust_levels) */
-int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
-                     int shiftlevl, const double *dynfrac, double scale,
-                     const double *v, const double *a, double pot, double *dtreq)
+/* src/multistep.cc:94-130: the five criteria and the smallest of them, dt = max(eps, .) */
+double orc_level_dt(const double *dynfrac, double scale, const double *v, const double *a, double pot)
 {
   const double eps = 1.0e-10;
   const double dynfracD = dynfrac[0], dynfracV = dynfrac[1], dynfracS = dynfrac[2],
@@ -665,12 +663,12 @@ int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_leve
   if (dta > 0.0 && dta < dmin) dmin = dta;
   if (dtA > 0.0 && dtA < dmin) dmin = dtA;
 
-  double dt = dmin > eps ? dmin : eps;
-  /* Particle::dtreq is a float (include/Particle.H:60-61): the level rule sees the
-   * float-rounded value */
-  float dtreq_f = (float)dt;
-  *dtreq = (double)dtreq_f;
+  return dmin > eps ? dmin : eps;
+}
 
+/* src/multistep.cc:160-196: the level rule on Particle::dtreq (a float, include/Particle.H:60-61) */
+int orc_level_rule(double dtime, int multistep, int mfirst_mdrft, int cur_level, int shiftlevl, float dtreq_f)
+{
   unsigned plev = (unsigned)cur_level;
   unsigned nlev = plev;
   if (dtreq_f > dtime) nlev = 0;
@@ -686,6 +684,18 @@ int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_leve
   if (nlev > (unsigned)multistep) nlev = multistep;
   if ((int)nlev < mfirst_mdrft) nlev = mfirst_mdrft;
   return (int)nlev;
+}
+
+/* src/multistep.cc:94-196 with NoSwitch off (`p->dtreq = dt`, :144); FreezeLev and NoSwitch are the caller's:
+ * nbody_oracle.c adjust_levels */
+int orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
+                     int shiftlevl, const double *dynfrac, double scale,
+                     const double *v, const double *a, double pot, double *dtreq)
+{
+  /* Particle::dtreq is a float: the level rule sees the float-rounded value */
+  float dtreq_f = (float)orc_level_dt(dynfrac, scale, v, a, pot);
+  *dtreq = (double)dtreq_f;
+  return orc_level_rule(dtime, multistep, mfirst_mdrft, cur_level, shiftlevl, dtreq_f);
 }
 
 /* ---- block-multistep master step for one self-gravitating spherical component ------------

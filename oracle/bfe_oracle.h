@@ -142,6 +142,9 @@ void   orc_mstep_combine(const orc_mstep_tables *t, int mdrft, long ncoef,
 
 /* time-step criterion + level choice (src/multistep.cc:52-236), one particle.
  * dynfrac = {D,V,S,A,P}; returns the new level; *dtreq receives dt.           */
+/* its two halves: the smallest criterion (src/multistep.cc:94-130) and the level rule on the float dtreq (:160-196) */
+double orc_level_dt(const double *dynfrac, double scale, const double *v, const double *a, double pot);
+int    orc_level_rule(double dtime, int multistep, int mfirst_mdrft, int cur_level, int shiftlevl, float dtreq_f);
 int    orc_level_select(double dtime, int multistep, int mfirst_mdrft, int cur_level,
                         int shiftlevl, const double *dynfrac, double scale,
                         const double *v, const double *a, double pot, double *dtreq);

@@ -230,14 +230,23 @@ static void adjust_levels(orc_nbody *S, const orc_mstep_tables *T, int mdrft, in
     long switched = 0;
     /* `if (not firstCall and c->FreezeLev()) apply = false;` (src/multistep.cc:158): no level is proposed, nothing moves */
     /* (firstCall = this_step == 0 and mdrft == 0: begin_run's call; the first sub-step of the run also does all levels, :453) */
-    const int frozen_levels = c->freeze_lev && !(all_levels && mdrft == 0);
+    const int first_call = all_levels && mdrft == 0;
+    const int mstep = mdrft - 1;                  /* do_step: mdrft = mstep + 1 at its call (src/step.cc:188, :221) */
+    const int frozen_levels = c->freeze_lev && !first_call;
     for (int lev = first; lev <= ms && !frozen_levels; lev++) {
       for (long i = 0; i < c->n; i++) {
         if (c->level[i] != lev) continue;
         double v[3] = {c->vx[i], c->vy[i], c->vz[i]}, a[3] = {c->ax[i], c->ay[i], c->az[i]};
-        double dtreq;
-        int nlev = orc_level_select(S->dtime, ms, mf, lev, S->shiftlevl, S->dynfrac, 0.0, v, a,
-                                    c->pot[i], &dtreq);
+        /* src/multistep.cc:132-158: Particle::dtreq (a float) and whether this sweep assigns levels */
+        const double dt = orc_level_dt(S->dynfrac, 0.0, v, a, c->pot[i]);
+        float dtreq;
+        if (c->noswitch) {
+          if ((!c->no_dtreset && mstep == 0) || first_call) c->dtreq[i] = HUGE_VALF;   /* (float)DBL_MAX */
+          if (dt < c->dtreq[i]) c->dtreq[i] = (float)dt;
+          dtreq = c->dtreq[i];
+          if (!(mdrft == (1 << ms) || first_call)) continue;                           /* apply (:147) */
+        } else dtreq = (float)dt;
+        int nlev = orc_level_rule(S->dtime, ms, mf, lev, S->shiftlevl, dtreq);
         if (nlev == lev) continue;
         double xx = c->x[i] - c->center[0], yy = c->y[i] - c->center[1], zz = c->z[i] - c->center[2];
         int inside;

@@ -49,6 +49,11 @@ typedef struct {
   int has_mlim;
   int freeze_lev;             /* "freezeL" (Component::FreezeLev, src/Component.cc:255, :1037): levels are assigned on the first
                                  call of adjust_multistep_level only (src/multistep.cc:158, :534)               */
+  int noswitch;               /* "noswitch" (Component::NoSwitch, src/Component.cc:253, :1036): Particle::dtreq keeps the smallest
+                                 time step asked for since its last reset and levels are only assigned at the end of a master
+                                 step (mdrft == Mstep) or on the first call (src/multistep.cc:136-147)            */
+  int no_dtreset;             /* "dtreset: false" (:254, :1038): dtreq is not reset at mstep == 0 (src/multistep.cc:137)      */
+  float *dtreq;               /* [n] Particle::dtreq when noswitch (caller's storage)                                         */
 } orc_nbody_comp;
 
 typedef struct {

@@ -87,7 +87,8 @@ class _NBodyComp(ctypes.Structure):
                 ("adiabatic", ctypes.c_int), ("ton", ctypes.c_double), ("toff", ctypes.c_double),
                 ("twid", ctypes.c_double), ("not_self_consistent", ctypes.c_int), ("coef_calls", ctypes.c_int),
                 ("fix_l0", ctypes.c_int), ("have_c0", ctypes.c_int), ("C0", c_double_p),
-                ("mlim", ctypes.c_int), ("has_mlim", ctypes.c_int), ("freeze_lev", ctypes.c_int)]
+                ("mlim", ctypes.c_int), ("has_mlim", ctypes.c_int), ("freeze_lev", ctypes.c_int),
+                ("noswitch", ctypes.c_int), ("no_dtreset", ctypes.c_int), ("dtreq", ctypes.POINTER(ctypes.c_float))]
 
 
 class _NBody(ctypes.Structure):
@@ -136,12 +137,13 @@ class NBodyOracle:
         self.inter.append((int(source), int(target)))
 
     def set_options(self, k, rtrunc=None, com0=(0.0, 0.0, 0.0), adiabatic=None, self_consistent=True, fix_l0=False,
-                    mlim=None, freeze_levels=False):
+                    mlim=None, freeze_levels=False, noswitch=False, dtreset=True):
         """The keys of component ``k`` that default to off (oracle/nbody_oracle.h): ``rtrunc`` (+ ``com0``),
-        ``adiabatic = (ton, toff, twid)``, ``self_consistent``, ``FIX_L0`` (sphere), ``mlim`` (cylinder), ``freezeL``."""
+        ``adiabatic = (ton, toff, twid)``, ``self_consistent``, ``FIX_L0`` (sphere), ``mlim`` (cylinder), ``freezeL``, ``noswitch`` /
+        ``dtreset``."""
         self.state[k]["options"] = dict(rtrunc=rtrunc, com0=tuple(com0), adiabatic=adiabatic,
                                         self_consistent=self_consistent, fix_l0=fix_l0, mlim=mlim,
-                                        freeze_levels=bool(freeze_levels))
+                                        freeze_levels=bool(freeze_levels), noswitch=bool(noswitch), dtreset=bool(dtreset))
 
     def _build(self):
         nc = len(self.state)
@@ -178,6 +180,10 @@ class NBodyOracle:
                 if o["mlim"] is not None:
                     c.has_mlim, c.mlim = 1, int(o["mlim"])
                 c.freeze_lev = 1 if o.get("freeze_levels") else 0
+                if o.get("noswitch"):
+                    st["dtreq"] = np.zeros(st["n"], np.float32)
+                    c.noswitch, c.no_dtreset = 1, 0 if o.get("dtreset", True) else 1
+                    c.dtreq = st["dtreq"].ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         self._inter = np.ascontiguousarray(np.array(self.inter, dtype=np.int32).reshape(-1))
         S = _NBody()
         S.ncomp, S.comp = nc, self._comps

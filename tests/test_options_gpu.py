@@ -275,8 +275,9 @@ def _driver_run(ctx, inp, opts_h, opts_d, ms, dtime, nsteps):
             c.set_rtrunc(o["rtrunc"], o.get("com0"))
         if o.get("adiabatic") is not None:
             sim.set_adiabatic(k, *o["adiabatic"])
-        if o.get("freeze_levels"):
-            c.set_level_policy(freeze_levels=True)
+        if o.get("freeze_levels") or o.get("noswitch"):
+            c.set_level_policy(noswitch=o.get("noswitch", False), freeze_levels=o.get("freeze_levels", False),
+                               dtreset=o.get("dtreset", True))
     sim.init()
     sim.step(nsteps)
     return sim, (fh, fd), (ch, cd)
@@ -289,6 +290,9 @@ SCENARIOS = [
     # "freezeL" (Component::FreezeLev, src/multistep.cc:158, :534): the disk keeps the levels of its first assignment, the halo moves on
     (dict(), dict(freeze_levels=True)),
     (dict(freeze_levels=True, rtrunc=0.6), dict(freeze_levels=True)),
+    # "noswitch" / "dtreset" (src/multistep.cc:136-147): dtreq keeps the smallest step asked for, levels move at the end of a master step
+    (dict(noswitch=True), dict()),
+    (dict(noswitch=True, dtreset=False), dict(noswitch=True)),
 ]
 
 
@@ -386,8 +390,8 @@ def test_self_consistent_false_and_fix_l0_at_the_call_level(ctx, oracle, plummer
 def test_level_policy_keys_through_the_c_abi(ctx):
     """The component keys noswitch / freezeL / dtreset (src/Component.cc:253-255): ``freezeL`` makes the per-call
     adjust_multistep_level (exp_amd_force_adjust_multistep_level, what the C++ adaptor calls) a no-op after the first call
-    (src/multistep.cc:158: firstCall = this_step == 0 and mdrft == 0) and leaves it alone on that call; ``noswitch: true`` is
-    refused by name."""
+    (src/multistep.cc:158: firstCall = this_step == 0 and mdrft == 0) and leaves it alone on that call; with ``noswitch`` the
+    calls inside a master step move nothing and the one at mdrft == Mstep does."""
     import ctypes
     from exp_amd.runtime import Component, SphereSL
     from tests.conftest import make_grid
@@ -399,8 +403,6 @@ def test_level_policy_keys_through_the_c_abi(ctx):
     vel = rng.standard_normal((n, 3)) * 0.3
     f = SphereSL(ctx, g, multistep=ms)
     c = Component.from_arrays(ctx, m, pos, vel)
-    with pytest.raises(RuntimeError, match="noswitch"):
-        c.set_level_policy(noswitch=True)
     c.set_level_policy(freeze_levels=True, dtreset=False)
     f.set_multistep_level(0)
     f.determine_coefficients(c)                  # (the store in this force's order, ms + 1 levels)
@@ -421,4 +423,11 @@ def test_level_policy_keys_through_the_c_abi(ctx):
     assert np.array_equal(c.download_levels(), lev)
     c.set_level_policy(freeze_levels=False)
     assert adjust(8, 0) > 0                      # ... and with the key off the same call moves particles
+    # noswitch: mdrft = 4 of Mstep = 8 examines levels >= 1 and moves nothing; mdrft = 8 assigns from the smallest dt seen
+    c.set_level_policy(noswitch=True)
+    assert adjust(0, 1) >= 0                     # (first call: dtreq reset, levels assigned)
+    lev = c.download_levels()
+    c.incr_velocity(-0.6)
+    assert adjust(4, 0) == 0 and np.array_equal(c.download_levels(), lev)
+    assert adjust(8, 0) > 0
     c.close(); f.close()
