@@ -1,4 +1,5 @@
-"""The YAML keys of EXP's n-body force methods, one by one.
+"""The YAML keys of EXP's n-body force methods -- and of the Component that owns one (``configure_component``, at the end) --
+one by one.
 
 ``SphereSL.from_config`` / ``Cylinder.from_config`` (exp_amd/runtime.py) take the ``parameters`` block a component's
 force has in an EXP configuration file.  Every key of ``SphericalBasis::valid_keys`` (src/SphericalBasis.cc:30-52) and
@@ -185,3 +186,77 @@ def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None):
     elif "coefCompute" in conf and _bool(conf["coefCompute"]):
         raise ValueError("Cylinder: coefCompute without playback (src/Cylinder.cc:560-618)")
     return f
+
+
+# ---- src/Component.cc:40-95: Component::valid_keys_parm -------------------------------------------------------------------
+COMPONENT_KEYS = ("name", "parameters", "bodyfile", "force", "EJ", "nEJkeep", "nEJwant", "nEJaccel", "EJkinE", "EJext", "EJdiag",
+                  "EJdryrun", "EJx0", "EJy0", "EJz0", "EJu0", "EJv0", "EJw0", "EJdT", "EJlinear", "EJdamp", "binary", "adiabatic",
+                  "ton", "toff", "twid", "rtrunc", "rcom", "consp", "tidal", "comlog", "bunch", "timers", "com", "indexing",
+                  "aindex", "magic", "nlevel", "keypos", "pbufsiz", "blocking", "ctr_name", "buffered", "noswitch", "freezeL",
+                  "dtreset", "H5compress", "H5shuffle", "H5chunk")
+
+
+def configure_component(sim, index: int, comp, conf: dict, com0=None, centerlevl: int = -1, logfile: Optional[str] = None):
+    """``Component::configure`` and the EJ block of ``Component::initialize`` (src/Component.cc:985-1075, :1323-1370) for the
+    ``parameters`` block of one component of an EXP configuration file: every key of ``Component::valid_keys_parm`` (:40-95)
+    is HONOURED -- it reaches the device store, the step driver or the orientation estimator -- or REFUSED by name with what is
+    missing; a key outside the set is refused as the reference refuses it.  ``sim`` is the ``Simulation`` the component was
+    added to as number ``index`` (``sim.add_component``), ``comp`` its ``Component``; call before ``sim.init()``.  ``com0``: the
+    centre ``rtrunc`` / ``rcom`` are measured from (zeros, as ``com_system`` is off here).  Returns the ``Orient`` it made
+    (EJ != 0) or None.  ``tests/test_config_keys_gpu.py`` walks the set."""
+    from .runtime import Orient
+    conf = dict(conf or {})
+    bad = sorted(set(conf) - set(COMPONENT_KEYS))
+    if bad:
+        raise ValueError(f"Component: unmatched parameter(s) {bad} (src/Component.cc:40-95)")
+    name = "Component"
+    g = conf.get
+    # ---- refused when they ask for something that is not built --------------------------------------------------------------
+    if "com" in conf and _bool(conf["com"]):
+        raise _refuse(name, "com", conf["com"], "the centre-of-mass coordinate system (com_system: positions local to a moving "
+                      "frame, incr_com_position / incr_com_velocity, src/Component.cc:3555-3590) is not built")
+    for key, why in (("comlog", "the centre-of-mass log file"), ("timers", "the per-component timing report"),
+                     ("aindex", "re-indexing the bodies from an attribute column"), ("EJdiag", "the estimator's diagnostic output")):
+        if key in conf and _bool(conf[key]):
+            raise _refuse(name, key, conf[key], why + " is not built")
+    if "keypos" in conf and int(conf["keypos"]) >= 0:
+        raise _refuse(name, "keypos", conf["keypos"], "species keys in an integer attribute belong to the collision modules")
+    if "ctr_name" in conf and str(conf["ctr_name"]) not in ("", "none", "None"):
+        raise _refuse(name, "ctr_name", conf["ctr_name"], "centring one component on another (Component::c0) is not built")
+    # (name, parameters, bodyfile, force: the structure of the file, read by whoever builds the components; binary, indexing,
+    # magic, pbufsiz, blocking, buffered, H5compress, H5shuffle, H5chunk: how phase-space files are read and written --
+    # exp_amd.reader / write_psp take them as arguments; bunch: the CUDA path's batch size; nlevel: how often the level
+    # populations are reported.  None of them reaches the path in the reference either.)
+    # ---- honoured: the store ---------------------------------------------------------------------------------------------------
+    if "rtrunc" in conf or com0 is not None:
+        comp.set_rtrunc(float(g("rtrunc", 1.0e20)), com0)
+    if "tidal" in conf or ("consp" in conf and _bool(conf["consp"])):
+        # (`tidal` is what switches consp on, src/Component.cc:998-1000; a bare `consp: true` leaves tidal at -1 and the thread
+        # body then tests nothing, :3317)
+        if "tidal" in conf and int(conf["tidal"]) >= 0:
+            comp.set_consp(float(g("rcom", 1.0e20)))
+    if any(k in conf for k in ("noswitch", "freezeL", "dtreset")):
+        comp.set_level_policy(noswitch=_bool(g("noswitch", False)), freeze_levels=_bool(g("freezeL", False)),
+                              dtreset=_bool(g("dtreset", True)))
+    # ---- honoured: the step driver ---------------------------------------------------------------------------------------------
+    if any(k in conf for k in ("ton", "toff", "twid")):      # each of the three switches `adiabatic` on (src/Component.cc:1040-1055)
+        sim.set_adiabatic(index, float(g("ton", -1.0e20)), float(g("toff", 1.0e20)), float(g("twid", 0.1)))
+    elif "adiabatic" in conf and _bool(conf["adiabatic"]):
+        raise ValueError("Component: 'adiabatic' is set by ton / toff / twid (src/Component.cc:1040-1055), not by itself")
+    # ---- honoured: the orientation estimator (src/Component.cc:1323-1370) -------------------------------------------------------
+    ej = int(g("EJ", 0))
+    if not ej:
+        return None
+    ctl = (Orient.KE if _bool(g("EJkinE", True)) else 0) | (Orient.EXTERNAL if _bool(g("EJext", False)) else 0)
+    o = Orient(comp.ctx, int(g("nEJkeep", 100)), int(g("nEJwant", 500)), ej, ctl, float(g("EJdT", 0.0)), float(g("EJdamp", 1.0)))
+    if int(g("nEJaccel", 0)) > 0:
+        o.set_naccel(int(conf["nEJaccel"]))
+    if _bool(g("EJlinear", False)):
+        o.set_linear()
+    o.set_center(float(g("EJx0", 0.0)), float(g("EJy0", 0.0)), float(g("EJz0", 0.0)))
+    o.set_cenvel(float(g("EJu0", 0.0)), float(g("EJv0", 0.0)), float(g("EJw0", 0.0)))
+    comp.set_center([float(g("EJx0", 0.0)), float(g("EJy0", 0.0)), float(g("EJz0", 0.0))])
+    if logfile:
+        o.openLog(logfile)
+    sim.set_orient(index, o, dryrun=_bool(g("EJdryrun", False)), centerlevl=centerlevl)
+    return o

@@ -200,3 +200,93 @@ def test_every_cylinder_key_is_honoured_or_refused(ctx, oracle):
                                        tnum=20, ncylodd=1, acyl=0.01, hcyl=0.001, mlim=1))
     assert (f.mmax, f.nmax, f.mlim) == (2, 4, 1) and f.grid.numx == 24
     f.close()
+
+
+# ---- Component::valid_keys_parm (src/Component.cc:40-95) through exp_amd.config.configure_component ------------------------------
+def _ref_component_keys():
+    txt = open(os.path.join(REF, "Component.cc")).read()
+    m = re.search(r"Component::valid_keys_parm =\s*\{(.*?)\};", txt, re.S)
+    seen, out = set(), []
+    for k in re.findall(r'"([^"]+)"', m.group(1)):          # ("ctr_name" stands twice in the reference's list)
+        if k not in seen:
+            seen.add(k); out.append(k)
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_component_key_tuple_is_the_references_list():
+    from exp_amd.config import COMPONENT_KEYS
+    assert list(COMPONENT_KEYS) == _ref_component_keys()
+
+
+# key -> (a value that ASKS for something, "honoured" | "refused")
+COMP_WALK = {
+    "name": ("halo", "honoured"), "parameters": ({}, "honoured"), "bodyfile": ("halo.bods", "honoured"), "force": ({}, "honoured"),
+    "EJ": (2, "honoured"), "nEJkeep": (50, "honoured"), "nEJwant": (300, "honoured"), "nEJaccel": (4, "honoured"),
+    "EJkinE": (False, "honoured"), "EJext": (True, "honoured"), "EJdiag": (True, "refused"), "EJdryrun": (True, "honoured"),
+    "EJx0": (0.01, "honoured"), "EJy0": (0.02, "honoured"), "EJz0": (-0.01, "honoured"), "EJu0": (0.1, "honoured"),
+    "EJv0": (0.1, "honoured"), "EJw0": (0.1, "honoured"), "EJdT": (0.05, "honoured"), "EJlinear": (True, "honoured"),
+    "EJdamp": (0.5, "honoured"), "binary": (True, "honoured"), "adiabatic": (True, "refused"), "ton": (0.1, "honoured"),
+    "toff": (5.0, "honoured"), "twid": (0.2, "honoured"), "rtrunc": (1.5, "honoured"), "rcom": (2.0, "honoured"),
+    "consp": (True, "honoured"), "tidal": (0, "honoured"), "comlog": (True, "refused"), "bunch": (1000, "honoured"),
+    "timers": (True, "refused"), "com": (True, "refused"), "indexing": (True, "honoured"), "aindex": (True, "refused"),
+    "magic": (True, "honoured"), "nlevel": (10, "honoured"), "keypos": (0, "refused"), "pbufsiz": (1000, "honoured"),
+    "blocking": (True, "honoured"), "ctr_name": ("disk", "refused"), "buffered": (False, "honoured"),
+    "noswitch": (True, "honoured"), "freezeL": (True, "honoured"), "dtreset": (False, "honoured"),
+    "H5compress": (5, "honoured"), "H5shuffle": (True, "honoured"), "H5chunk": (4096, "honoured"),
+}
+
+
+@pytest.mark.gpu
+def test_every_component_key_is_honoured_or_refused(ctx):
+    """``Component::configure`` + the EJ block of ``Component::initialize`` (src/Component.cc:985-1075, :1323-1370) through
+    ``exp_amd.config.configure_component``: each key alone, with a value that asks for something.  The keys that reach the
+    device are checked for having arrived (the store's switches, the estimator, the driver's adiabatic factor); what they then
+    DO is tests/test_options_gpu.py's (rtrunc, ton / toff / twid, noswitch / freezeL), test_multistep_gpu.py's (tidal / rcom) and
+    test_orient_gpu.py's (EJ*)."""
+    from exp_amd.config import COMPONENT_KEYS, configure_component
+    from exp_amd.runtime import Component, Simulation, SphereSL
+    from tests.conftest import make_grid
+    assert set(COMP_WALK) == set(COMPONENT_KEYS)
+    _, g = make_grid("plummer", 4, 8, 400)
+    rng = np.random.default_rng(1)
+    n = 3000
+    m, pos, vel = np.full(n, 1.0 / n), rng.standard_normal((n, 3)), 0.3 * rng.standard_normal((n, 3))
+
+    def fresh():
+        sim = Simulation(ctx, 0.01, multistep=2)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f = SphereSL(ctx, g, multistep=2)
+        return sim, c, f, sim.add_component(c, f)
+
+    for key, (val, kind) in COMP_WALK.items():
+        sim, c, f, k = fresh()
+        conf = {key: val}
+        if key.startswith("EJ") or key.startswith("nEJ"):
+            conf.setdefault("EJ", 2)                          # (the EJ keys are only read with EJ != 0)
+        if kind == "refused":
+            with pytest.raises(ValueError, match=key):
+                configure_component(sim, k, c, conf)
+        else:
+            o = configure_component(sim, k, c, conf)
+            if "EJ" in conf:
+                assert o is not None and np.allclose(o.currentCenter(), [conf.get("EJx0", 0.0), conf.get("EJy0", 0.0), conf.get("EJz0", 0.0)])
+            else:
+                assert o is None
+            if key == "tidal":
+                assert not c.escaped().any()                   # consp is on: the flags exist
+            if key == "rcom" or key == "consp":
+                with pytest.raises(RuntimeError):
+                    c.escaped()                                # (without `tidal` nothing is tested, src/Component.cc:3317)
+        sim.close(); c.close(); f.close()
+    with pytest.raises(ValueError, match="unmatched"):
+        sim, c, f, k = fresh()
+        configure_component(sim, k, c, {"rtrunk": 1.0})
+    # the keys together, as a configuration file has them: one master step runs
+    sim, c, f, k = fresh()
+    o = configure_component(sim, k, c, {"EJ": 2, "nEJkeep": 20, "nEJwant": 200, "EJdamp": 0.8, "rtrunc": 3.0, "tidal": 0, "rcom": 2.5,
+                                        "ton": -1.0, "twid": 0.5, "noswitch": True, "dtreset": True, "indexing": True})
+    sim.init()
+    sim.step(1)
+    assert o is not None and np.isfinite(c.fix_positions(0)["com"]).all() and c.escaped().sum() > 0
+    sim.close(); c.close(); f.close()
