@@ -30,6 +30,8 @@ struct exp_amd_sim {
   int centerlevl = -1;
   bool gottapot = false;
   bool restart = false;            // the global `restart` (src/global.cc): the estimators take in the first state too
+  bool eqmotion = true;            // the global `eqmotion` (src/global.cc:54): false = incr_position / incr_velocity return at once
+                                   // (src/incpos.cc:75, src/incvel.cc:93): fields, levels and the time go on, nothing moves
   unsigned long long *pinned = nullptr;   // page-locked landing area of the per-sub-step read-back
   size_t pinned_cap = 0;                  // (components it has room for)
   unsigned long long *pinned_dev = nullptr;   // the device's address of it (k_kick_adjust's last block writes there)
@@ -429,7 +431,7 @@ static int kick_adjust_levels(exp_amd_sim *s, int mdrft, int first_step, bool ki
   const int mf = s->mfirst[mdrft];
   const int first = first_step ? 0 : mf;            // src/multistep.cc:451-453
   const size_t nc = s->comps.size();
-  const double dt_min = s->dtime / s->Mstep;
+  const double dt_min = s->eqmotion ? s->dtime / s->Mstep : 0.0;      // (the kicks' step: zero moves nothing)
   if (s->pinned_cap < nc) {
     if (s->pinned) (void)hipHostFree(s->pinned);
     s->pinned = nullptr;
@@ -649,29 +651,39 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       const double dt = s->dtime / s->Mstep;
       for (int mstep = 0; mstep < s->Mstep; mstep++) {
         const int mdrft = mstep + 1;
-        if ((rc = substep_expansion(s, s->mfirst[mstep], dt, mdrft))) return rc;
+        if ((rc = substep_expansion(s, s->mfirst[mstep], s->eqmotion ? dt : 0.0, mdrft))) return rc;
         s->tnow += dt;
         const int first_step = (s->this_step == 0 && mstep == 0) ? 1 : 0;
         if ((rc = compute_potential_ms(s, s->mfirst[mstep], mdrft, mstep, !sweep_is_noop(s, mdrft, first_step)))) return rc;
         if ((rc = kick_adjust_levels(s, mdrft, first_step, true))) return rc;
       }
-    } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0]) {
+    } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0] && s->eqmotion) {
       s->tnow += s->dtime;
       if ((rc = exp_amd_step_kdk(s->forces[0], s->comps[0], s->dtime))) return rc;
     } else {
       s->tnow += s->dtime;
       for (auto c : s->comps) {
+        if (!s->eqmotion) break;
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
         if ((rc = exp_amd_comp_drift(c, s->dtime, -1))) return rc;
       }
       if ((rc = compute_expansion(s, 0))) return rc;
       if ((rc = compute_potential(s, 0, 1, 0))) return rc;
-      for (auto c : s->comps)
+      for (auto c : s->comps) {
+        if (!s->eqmotion) break;
         if ((rc = exp_amd_comp_kick(c, 0.5 * s->dtime, -1))) return rc;
+      }
     }
     s->this_step++;
   }
   return overlap_end(s);
+}
+
+extern "C" int exp_amd_sim_set_eqmotion(exp_amd_sim *s, int on)
+{
+  if (!s) return EXP_AMD_ERR_ARG;
+  s->eqmotion = on != 0;
+  return EXP_AMD_OK;
 }
 
 extern "C" double exp_amd_sim_time(const exp_amd_sim *s) { return s ? s->tnow : 0.0; }

@@ -1053,6 +1053,11 @@ class Simulation:
         """The global ``restart``: the estimators take in the first force evaluation's state too."""
         check(self.lib.exp_amd_sim_set_restart(self.h, int(bool(on))), self.ctx.h)
 
+    def set_eqmotion(self, on: bool = True) -> None:
+        """The global ``eqmotion`` (src/global.cc:54): ``False`` = ``incr_position`` / ``incr_velocity`` return at once
+        (src/incpos.cc:75, src/incvel.cc:93): the steps evaluate fields and levels as the time goes on and move nothing."""
+        check(self.lib.exp_amd_sim_set_eqmotion(self.h, int(bool(on))), self.ctx.h)
+
     def add_interaction(self, source: int, target: int) -> None:
         check(self.lib.exp_amd_sim_add_interaction(self.h, int(source), int(target)), self.ctx.h)
 

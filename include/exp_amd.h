@@ -556,6 +556,10 @@ int  exp_amd_sim_set_orient(exp_amd_sim *s, int index, exp_amd_orient *o, int dr
 /* The global `restart` (src/global.cc): the estimators take in the state of the first force
  * evaluation too, where a fresh run waits for potentials (src/ComponentContainer.cc:1386).   */
 int  exp_amd_sim_set_restart(exp_amd_sim *s, int on);
+/* The global "eqmotion" (src/global.cc:54): with 0, incr_position and incr_velocity return at once (src/incpos.cc:75,
+ * src/incvel.cc:93) -- the driver's steps then evaluate expansions, forces and level proposals as the time goes on, and move
+ * nothing (a fixed-particle run).  Default 1.                                                                          */
+int  exp_amd_sim_set_eqmotion(exp_amd_sim *s, int on);
 /* The adiabatic turn-on / turn-off of component `index` (its keys ton, toff, twid; src/Component.cc:1040-1055): the driver
  * evaluates Component::Adiabatic() at its tnow before every accumulation (the time at the START of the sub-step, as
  * do_step has it, src/step.cc:126-160) and before every level-change differencing (the time at its end) and hands it to

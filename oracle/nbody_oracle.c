@@ -340,14 +340,14 @@ void orc_nbody_step(orc_nbody *S, long *nswitch)
         /* incr_velocity(0.5*DT, M); incr_position(DT, M) over all components */
         for (int k = 0; k < S->ncomp; k++) {
           orc_nbody_comp *c = &S->comp[k];
-          for (long i = 0; i < c->n; i++)
+          for (long i = 0; i < c->n && !S->no_eqmotion; i++)
             if (c->level[i] == M) {
               c->vx[i] += c->ax[i] * (0.5 * DT); c->vy[i] += c->ay[i] * (0.5 * DT); c->vz[i] += c->az[i] * (0.5 * DT);
             }
         }
         for (int k = 0; k < S->ncomp; k++) {
           orc_nbody_comp *c = &S->comp[k];
-          for (long i = 0; i < c->n; i++)
+          for (long i = 0; i < c->n && !S->no_eqmotion; i++)
             if (c->level[i] == M) {
               c->x[i] += c->vx[i] * DT; c->y[i] += c->vy[i] * DT; c->z[i] += c->vz[i] * DT;
             }
@@ -361,7 +361,7 @@ void orc_nbody_step(orc_nbody *S, long *nswitch)
         double DT = dt * T->mintvl[M];
         for (int k = 0; k < S->ncomp; k++) {
           orc_nbody_comp *c = &S->comp[k];
-          for (long i = 0; i < c->n; i++)
+          for (long i = 0; i < c->n && !S->no_eqmotion; i++)
             if (c->level[i] == M) {
               c->vx[i] += c->ax[i] * (0.5 * DT); c->vy[i] += c->ay[i] * (0.5 * DT); c->vz[i] += c->az[i] * (0.5 * DT);
             }
@@ -374,17 +374,17 @@ void orc_nbody_step(orc_nbody *S, long *nswitch)
     S->tnow += S->dtime;
     for (int k = 0; k < S->ncomp; k++) {
       orc_nbody_comp *c = &S->comp[k];
-      orc_kick(c->n, 0.5 * S->dtime, c->vx, c->vy, c->vz, c->ax, c->ay, c->az);
+      if (!S->no_eqmotion) orc_kick(c->n, 0.5 * S->dtime, c->vx, c->vy, c->vz, c->ax, c->ay, c->az);
     }
     for (int k = 0; k < S->ncomp; k++) {
       orc_nbody_comp *c = &S->comp[k];
-      orc_drift(c->n, S->dtime, c->x, c->y, c->z, c->vx, c->vy, c->vz);
+      if (!S->no_eqmotion) orc_drift(c->n, S->dtime, c->x, c->y, c->z, c->vx, c->vy, c->vz);
     }
     compute_expansion(S, 0, &w);
     compute_potential(S, T, 0, 1);
     for (int k = 0; k < S->ncomp; k++) {
       orc_nbody_comp *c = &S->comp[k];
-      orc_kick(c->n, 0.5 * S->dtime, c->vx, c->vy, c->vz, c->ax, c->ay, c->az);
+      if (!S->no_eqmotion) orc_kick(c->n, 0.5 * S->dtime, c->vx, c->vy, c->vz, c->ax, c->ay, c->az);
     }
   }
   S->this_step++;

@@ -68,6 +68,8 @@ typedef struct {
   long this_step;
   double tnow;
   int initializing;           /* the global of src/begin.cc:80, :129 (set by orc_nbody_init itself)  */
+  int no_eqmotion;            /* the global "eqmotion: false" (src/global.cc:54): incr_position / incr_velocity return at once
+                                 (src/incpos.cc:75, src/incvel.cc:93) -- fields, levels and time go on, nothing moves     */
 } orc_nbody;
 
 /* begin_run's initial expansion, potential and level assignment (src/begin.cc:80-129) */

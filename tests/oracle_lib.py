@@ -96,7 +96,7 @@ class _NBody(ctypes.Structure):
     _fields_ = [("ncomp", ctypes.c_int), ("comp", ctypes.POINTER(_NBodyComp)), ("ninter", ctypes.c_int),
                 ("inter", c_int_p), ("multistep", ctypes.c_int), ("dtime", ctypes.c_double),
                 ("dynfrac", ctypes.c_double * 5), ("shiftlevl", ctypes.c_int), ("this_step", ctypes.c_long),
-                ("tnow", ctypes.c_double), ("initializing", ctypes.c_int)]
+                ("tnow", ctypes.c_double), ("initializing", ctypes.c_int), ("no_eqmotion", ctypes.c_int)]
 
 
 class NBodyOracle:
@@ -190,6 +190,7 @@ class NBodyOracle:
         S.ninter = len(self.inter)
         S.inter = self._inter.ctypes.data_as(c_int_p) if len(self.inter) else None
         S.multistep, S.dtime, S.shiftlevl = self.multistep, self.dtime, self.shiftlevl
+        S.no_eqmotion = 0 if getattr(self, "eqmotion", True) else 1        # (the global "eqmotion", src/global.cc:54)
         for j in range(5):
             S.dynfrac[j] = self.dyn[j]
         self.S = S

@@ -431,3 +431,52 @@ def test_level_policy_keys_through_the_c_abi(ctx):
     assert adjust(4, 0) == 0 and np.array_equal(c.download_levels(), lev)
     assert adjust(8, 0) > 0
     c.close(); f.close()
+
+
+@pytest.mark.parametrize("ms", [2, 0])
+def test_eqmotion_off_moves_nothing_and_matches_the_oracle(ctx, oracle, ms):
+    """The global ``eqmotion: false`` (src/global.cc:54; src/incpos.cc:75, src/incvel.cc:93): a step of the driver evaluates
+    expansions, forces and (block multistep) level proposals as the time goes on and moves nothing -- positions and velocities
+    bit for bit where they started, levels, accelerations and combined coefficient sets against the n-body oracle (the disk's
+    adiabatic factor makes the fields change with the time alone)."""
+    from exp_amd.runtime import Component, Cylinder, Simulation, SphereSL
+    dtime, nsteps = 1.5e-4, 2
+    inp = c4.config4_inputs(n_halo=400, n_disk=400)
+    g, cg = c4.grids()
+    sc = float(inp["scale"])
+    prm = oracle.params(**c4.sph_window(g, sc))
+    nb = NBodyOracle(oracle, ms, dtime, c4.DYN)
+    nb.eqmotion = False
+    i1 = nb.add_sphere(g, prm, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    i2 = nb.add_cylinder(cg, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    nb.add_interaction(i1, i2); nb.add_interaction(i2, i1)
+    nb.set_options(i2, adiabatic=(1.0e-4, 1.0e20, 1.0e-4))
+    nb.init()
+    for _ in range(nsteps):
+        nb.step()
+    ch = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    cd = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    fh = SphereSL(ctx, g, multistep=ms, **c4.sph_window(g, sc))
+    fd = Cylinder(ctx, cg, multistep=ms)
+    sim = Simulation(ctx, dtime, multistep=ms, dynfrac=c4.DYN)
+    ih, idk = sim.add_component(ch, fh), sim.add_component(cd, fd)
+    sim.add_interaction(ih, idk); sim.add_interaction(idk, ih)
+    sim.set_adiabatic(idk, 1.0e-4, 1.0e20, 1.0e-4)
+    sim.set_eqmotion(False)
+    sim.init()
+    a0 = cd.download()["acc"].copy()
+    sim.step(nsteps)
+    for k, (f, c, pos0, vel0) in enumerate(((fh, ch, inp["halo_pos"], inp["halo_vel"]), (fd, cd, inp["disk_pos"], inp["disk_vel"]))):
+        st, o = nb.state[k], c.download()
+        assert np.array_equal(o["pos"], pos0) and np.array_equal(o["vel"], vel0), k            # nothing moved
+        assert np.array_equal(np.stack([st[q] for q in "xyz"], 1), pos0), k
+        assert np.array_equal(c.download_levels(), st["level"]), k
+        a = np.stack([st["a" + q] for q in "xyz"], 1)
+        assert np.abs(o["acc"] - a).max() <= 1e-8 * np.linalg.norm(a, axis=1).max(), k
+        gc = f.get_coefs()
+        gc = np.concatenate([np.asarray(x).reshape(-1) for x in (gc if isinstance(gc, tuple) else (gc,))])
+        assert np.abs(gc - st["coef"]).max() <= 1e-10 * np.abs(st["coef"]).max(), k
+    assert np.abs(cd.download()["acc"] - a0).max() > 1e-3 * np.abs(a0).max()                   # ... while the fields did change
+    assert sim.time == pytest.approx(nsteps * dtime)
+    for x in (sim, ch, cd, fh, fd):
+        x.close()
