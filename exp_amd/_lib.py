@@ -108,6 +108,7 @@ SIGNATURES = {
     "exp_amd_orient_log_entry": (c_int, [c_void_p, c_double, c_void_p, c_void_p]),
     "exp_amd_sim_set_restart": (c_int, [c_void_p, c_int]),
     "exp_amd_sim_set_eqmotion": (c_int, [c_void_p, c_int]),
+    "exp_amd_sim_set_center_from": (c_int, [c_void_p, c_int, c_int]),
     "exp_amd_sim_set_orient": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int]),
     "exp_amd_orient_set_center": (c_int, [c_void_p, c_void_p]),
     "exp_amd_orient_set_cenvel": (c_int, [c_void_p, c_void_p]),

@@ -196,13 +196,15 @@ COMPONENT_KEYS = ("name", "parameters", "bodyfile", "force", "EJ", "nEJkeep", "n
                   "dtreset", "H5compress", "H5shuffle", "H5chunk")
 
 
-def configure_component(sim, index: int, comp, conf: dict, com0=None, centerlevl: int = -1, logfile: Optional[str] = None):
+def configure_component(sim, index: int, comp, conf: dict, com0=None, centerlevl: int = -1, logfile: Optional[str] = None,
+                        names: Optional[dict] = None):
     """``Component::configure`` and the EJ block of ``Component::initialize`` (src/Component.cc:985-1075, :1323-1370) for the
     ``parameters`` block of one component of an EXP configuration file: every key of ``Component::valid_keys_parm`` (:40-95)
     is HONOURED -- it reaches the device store, the step driver or the orientation estimator -- or REFUSED by name with what is
     missing; a key outside the set is refused as the reference refuses it.  ``sim`` is the ``Simulation`` the component was
     added to as number ``index`` (``sim.add_component``), ``comp`` its ``Component``; call before ``sim.init()``.  ``com0``: the
-    centre ``rtrunc`` / ``rcom`` are measured from (zeros, as ``com_system`` is off here).  Returns the ``Orient`` it made
+    centre ``rtrunc`` / ``rcom`` are measured from (zeros, as ``com_system`` is off here); ``names``: component name -> its number
+    in ``sim``, for ``ctr_name``.  Returns the ``Orient`` it made
     (EJ != 0) or None.  ``tests/test_config_keys_gpu.py`` walks the set."""
     from .runtime import Orient
     conf = dict(conf or {})
@@ -221,8 +223,12 @@ def configure_component(sim, index: int, comp, conf: dict, com0=None, centerlevl
             raise _refuse(name, key, conf[key], why + " is not built")
     if "keypos" in conf and int(conf["keypos"]) >= 0:
         raise _refuse(name, "keypos", conf["keypos"], "species keys in an integer attribute belong to the collision modules")
-    if "ctr_name" in conf and str(conf["ctr_name"]) not in ("", "none", "None"):
-        raise _refuse(name, "ctr_name", conf["ctr_name"], "centring one component on another (Component::c0) is not built")
+    if "ctr_name" in conf and str(conf["ctr_name"]) != "":
+        # Component::find_ctr_component (src/Component.cc:284-310): the centre follows the component of that name
+        if not names or str(conf["ctr_name"]) not in names:
+            raise _refuse(name, "ctr_name", conf["ctr_name"], "no component of that name among `names` (name -> its number in "
+                          "the Simulation); the reference stops as well when it finds none (src/Component.cc:312-320)")
+        sim.set_center_from(index, int(names[str(conf["ctr_name"])]))
     # (name, parameters, bodyfile, force: the structure of the file, read by whoever builds the components; binary, indexing,
     # magic, pbufsiz, blocking, buffered, H5compress, H5shuffle, H5chunk: how phase-space files are read and written --
     # exp_amd.reader / write_psp take them as arguments; bunch: the CUDA path's batch size; nlevel: how often the level

@@ -27,6 +27,8 @@ struct exp_amd_sim {
   // EJ centre (Component::orient, EJdryrun; global centerlevl, src/global.cc:68)
   std::vector<exp_amd_orient *> orients;
   std::vector<int> ej_dryrun;
+  std::vector<int> center_from;    // "ctr_name" (Component::c0, src/Component.cc:284-310, :3585-3587): the component whose centre
+                                   // this one takes at every fix_positions, or -1
   int centerlevl = -1;
   bool gottapot = false;
   bool restart = false;            // the global `restart` (src/global.cc): the estimators take in the first state too
@@ -171,6 +173,7 @@ extern "C" int exp_amd_sim_add_component(exp_amd_sim *s, exp_amd_comp *c, exp_am
   s->forces.push_back(f);
   s->orients.push_back(nullptr);
   s->ej_dryrun.push_back(0);
+  s->center_from.push_back(-1);
   s->adb.emplace_back();
   if (index) *index = (int)s->comps.size() - 1;
   return EXP_AMD_OK;
@@ -234,12 +237,22 @@ static int fix_centers(exp_amd_sim *s, int mstep)
 {
   bool any = false;
   for (auto o : s->orients) any = any || o;
+  for (int src : s->center_from) any = any || src >= 0;
   if (!any) return EXP_AMD_OK;
   const int cl = s->centerlevl < 0 ? s->multistep / 2 : s->centerlevl;
   const bool active = mstep == 0 || mstep % (1 << (s->multistep - cl)) == 0;     // mactive[mstep][centerlevl]
   if (!active) return EXP_AMD_OK;
   for (size_t k = 0; k < s->comps.size(); k++) {
     exp_amd_orient *o = s->orients[k];
+    // "Alternative center" (src/Component.cc:3584-3587): the centre of the component named by ctr_name, as it stands when this
+    // component's turn comes (components are visited in their order: a source further down the list still has last call's)
+    if (s->center_from[k] >= 0) {
+      if (!o) {
+        int rc = exp_amd_comp_set_center(s->comps[k], s->comps[(size_t)s->center_from[k]]->center);
+        if (rc) return rc;
+        continue;
+      }
+    }
     if (!o) continue;
     double ctr[3], center[3] = {0.0, 0.0, 0.0};
     int rc = exp_amd_orient_get(o, ctr, nullptr, nullptr, nullptr, nullptr);
@@ -247,6 +260,8 @@ static int fix_centers(exp_amd_sim *s, int mstep)
     if (!s->ej_dryrun[k] && (exp_amd_orient_flags(o) & 2u) &&            // EJ & Orient::CENTER
         !(std::isnan(ctr[0]) || std::isnan(ctr[1]) || std::isnan(ctr[2])))
       for (int i = 0; i < 3; i++) center[i] += ctr[i];
+    if (s->center_from[k] >= 0)                                            // (c0 overrides the estimator's centre, :3585)
+      for (int i = 0; i < 3; i++) center[i] = s->comps[(size_t)s->center_from[k]]->center[i];
     if ((rc = exp_amd_comp_set_center(s->comps[k], center))) return rc;
     if (!s->ej_dryrun[k] && (exp_amd_orient_flags(o) & 1u)) {            // EJ & Orient::AXIS
       double body[9];
@@ -677,6 +692,14 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
     s->this_step++;
   }
   return overlap_end(s);
+}
+
+extern "C" int exp_amd_sim_set_center_from(exp_amd_sim *s, int index, int source)
+{
+  if (!s || index < 0 || (size_t)index >= s->comps.size() || source >= (int)s->comps.size() || source == index)
+    return expamd_fail(s ? s->ctx : nullptr, EXP_AMD_ERR_ARG, "sim_set_center_from: component index out of range");
+  s->center_from[(size_t)index] = source < 0 ? -1 : source;
+  return EXP_AMD_OK;
 }
 
 extern "C" int exp_amd_sim_set_eqmotion(exp_amd_sim *s, int on)

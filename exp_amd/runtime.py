@@ -1053,6 +1053,11 @@ class Simulation:
         """The global ``restart``: the estimators take in the first force evaluation's state too."""
         check(self.lib.exp_amd_sim_set_restart(self.h, int(bool(on))), self.ctx.h)
 
+    def set_center_from(self, index: int, source: int) -> None:
+        """The component key ``ctr_name`` (``Component::c0``, src/Component.cc:284-310, :3584-3587): component ``index`` takes the
+        expansion centre of component ``source`` at every centre update (``source`` < 0: off)."""
+        check(self.lib.exp_amd_sim_set_center_from(self.h, int(index), int(source)), self.ctx.h)
+
     def set_eqmotion(self, on: bool = True) -> None:
         """The global ``eqmotion`` (src/global.cc:54): ``False`` = ``incr_position`` / ``incr_velocity`` return at once
         (src/incpos.cc:75, src/incvel.cc:93): the steps evaluate fields and levels as the time goes on and move nothing."""

@@ -560,6 +560,11 @@ int  exp_amd_sim_set_restart(exp_amd_sim *s, int on);
  * src/incvel.cc:93) -- the driver's steps then evaluate expansions, forces and level proposals as the time goes on, and move
  * nothing (a fixed-particle run).  Default 1.                                                                          */
 int  exp_amd_sim_set_eqmotion(exp_amd_sim *s, int on);
+/* The component key "ctr_name" (Component::c0: find_ctr_component src/Component.cc:284-310, fix_positions :3584-3587): component
+ * `index` takes the expansion centre of component `source` at every centre update of the driver (after its own estimator's,
+ * which it overrides); components are visited in the order they were added, as the reference visits its list.  source < 0
+ * switches it off.                                                                                                       */
+int  exp_amd_sim_set_center_from(exp_amd_sim *s, int index, int source);
 /* The adiabatic turn-on / turn-off of component `index` (its keys ton, toff, twid; src/Component.cc:1040-1055): the driver
  * evaluates Component::Adiabatic() at its tnow before every accumulation (the time at the START of the sub-step, as
  * do_step has it, src/step.cc:126-160) and before every level-change differencing (the time at its end) and hands it to

@@ -231,7 +231,8 @@ COMP_WALK = {
     "consp": (True, "honoured"), "tidal": (0, "honoured"), "comlog": (True, "refused"), "bunch": (1000, "honoured"),
     "timers": (True, "refused"), "com": (True, "refused"), "indexing": (True, "honoured"), "aindex": (True, "refused"),
     "magic": (True, "honoured"), "nlevel": (10, "honoured"), "keypos": (0, "refused"), "pbufsiz": (1000, "honoured"),
-    "blocking": (True, "honoured"), "ctr_name": ("disk", "refused"), "buffered": (False, "honoured"),
+    "blocking": (True, "honoured"), "ctr_name": ("disk", "refused"),            # (refused without `names`; honoured with: below)
+    "buffered": (False, "honoured"),
     "noswitch": (True, "honoured"), "freezeL": (True, "honoured"), "dtreset": (False, "honoured"),
     "H5compress": (5, "honoured"), "H5shuffle": (True, "honoured"), "H5chunk": (4096, "honoured"),
 }
@@ -264,6 +265,19 @@ def test_every_component_key_is_honoured_or_refused(ctx):
         conf = {key: val}
         if key.startswith("EJ") or key.startswith("nEJ"):
             conf.setdefault("EJ", 2)                          # (the EJ keys are only read with EJ != 0)
+        if key == "ctr_name":                                  # honoured when the name is known (below), refused otherwise
+            # (the source BEFORE the follower in the list: the follower then sees this call's centre -- one further down the list
+            # would hand on the centre of the call before, as in the reference's loop over its components)
+            sim2 = Simulation(ctx, 0.01, multistep=2)
+            c2, f2 = Component.from_arrays(ctx, m, pos + 0.25, vel), SphereSL(ctx, g, multistep=2)
+            c3, f3 = Component.from_arrays(ctx, m, pos, vel), SphereSL(ctx, g, multistep=2)
+            k2, k3 = sim2.add_component(c2, f2), sim2.add_component(c3, f3)
+            configure_component(sim2, k2, c2, {"EJ": 2, "nEJkeep": 10, "nEJwant": 200})
+            configure_component(sim2, k3, c3, conf, names={"disk": k2})
+            sim2.init(); sim2.step(3)
+            assert np.array_equal(c3.center, c2.center) and np.abs(c2.center).max() > 0.0     # (the estimator's, handed on)
+            for x in (sim2, c2, f2, c3, f3):
+                x.close()
         if kind == "refused":
             with pytest.raises(ValueError, match=key):
                 configure_component(sim, k, c, conf)
