@@ -1472,7 +1472,9 @@ extern "C" int exp_amd_comp_set_level_policy(exp_amd_comp *c, int noswitch, int 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (c->d_dtreq.alloc(c->n) != hipSuccess) return expamd_fail(ctx, EXP_AMD_ERR_HIP, "comp_set_level_policy: hipMalloc failed");
-    HIP_TRY(ctx, hipMemsetAsync(c->d_dtreq.p, 0, c->n * sizeof(float), ctx->stream));
+    // (+inf, what a reset leaves: a run that never makes the first call -- the per-call entry point in the middle of a run --
+    // then starts from "no step asked for yet" instead of a step of zero)
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)c->d_dtreq.p, 0x7f800000, c->n, ctx->stream));
   }
   c->noswitch = noswitch != 0;
   c->dtreset = dtreset != 0;
