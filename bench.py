@@ -465,6 +465,27 @@ def _timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def box_copy_rate(device, nbytes=1 << 30, reps=20):
+    """What a plain device-to-device copy reaches on THIS box (read + write bytes over the time, GB/s): the boxes of the pool
+    differ by 10-15 % in their HBM-bound passes (profiles/README.md), and this figure says which kind the line comes from.
+    torch's copy kernel on torch's stream, timed with its events; not part of any timed region."""
+    import torch
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
 def _kernel_fracs(prof, nsteps, n, basis, lmax):
     """per-kernel ms/step + the dominant kernel's algorithmic-byte and executed-fp64 fractions"""
     kern = {k: v["ms_total"] / nsteps for k, v in prof.items() if v["launches"] > 0}
@@ -846,6 +867,11 @@ def main():
         kern = {k: v for k, v in prof.items() if v["launches"] > 0}
         dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
         roof = None
+        box_copy = None
+        try:
+            box_copy = box_copy_rate(device)
+        except Exception:
+            box_copy = None
         if dom:
             # k_sph_accumulate is launched once per m-split per step: a "launch" here is the
             # whole split group (ProfScope brackets the group)
@@ -887,6 +913,7 @@ def main():
                     "step_frac": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     # the same two fractions against the rate a plain streaming kernel measures on MI355X
                     "measured_hbm_peak": HBM_MEASURED_GBS,
+                    "box_copy_gbs": box_copy,
                     "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
                     "step_frac_of_measured_peak": ALGO_BYTES["step"] * nloc / (ms_step * 1e-3) / 1e9 / HBM_MEASURED_GBS,
                     "kernels_ms_per_step": {k: v["ms_total"] / args.steps for k, v in kern.items()}}
