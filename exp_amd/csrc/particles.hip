@@ -567,12 +567,21 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
       else
         k_scatter_adv<false, SCAT_ITEMS_SHORT><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     } else {
-    const unsigned g = cdiv(nr, SCAT_TILE);
     const uint32_t win = (level < 0 && c->sort_win) ? c->sort_win : (uint32_t)SORT_WIN;
+    if (win == (uint32_t)SORT_WIN_DENSE) {
+      // (the dense one-level sort of the sphere's fused step: short window, short tiles -- sort_kernels.h)
+      const unsigned g = cdiv(nr, (size_t)SORT_TPB * SCAT_ITEMS_DENSE);
+      if (move_acc)
+        k_scatter_adv<true, SCAT_ITEMS_DENSE><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
+      else
+        k_scatter_adv<false, SCAT_ITEMS_DENSE><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
+    } else {
+    const unsigned g = cdiv(nr, SCAT_TILE);
     if (move_acc)
       k_scatter_adv<true><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
     else
       k_scatter_adv<false><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p, win);
+    }
     }
     c->sort_win = 0;
   }

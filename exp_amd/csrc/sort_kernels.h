@@ -33,6 +33,10 @@
 // (profiles/r05_sort_win_ab.txt).  Keys beyond the window take the global atomics either way.  Level ranges of a multistep store
 // keep the full window (their keys jump by ncell at a level boundary: config 4 +0.9 ms at 512 bins, +2 ms at 256).
 #define SORT_WIN_DENSE 256
+// ... and the scatter pass of such a sort takes two slots a thread instead of four: with 256 bins to zero and walk a block's
+// fixed cost is small, and the shorter tile keeps more independent blocks in flight (1e8: 2.42 -> 2.29 ms on a box whose plain
+// copy reaches 5.06 TB/s, one slot a thread the same, eight 2.55; profiles/r05_sort_win_ab.txt)
+#define SCAT_ITEMS_DENSE 2
 #define SORT_DENSE_MIN 64       // particles per cell from which a one-level store counts as dense
 
 // A/B switch of the scatter pass (tools/build_variant_tu.sh <suffix> particles "-DSCAT_NT=n"): bit 0 = non-temporal stores of
