@@ -213,8 +213,15 @@ int CylForce::sort(exp_amd_comp *c, bool move_acc, const AdvSpec &adv, int level
     // c->key was written by the previous fused step's force pass for exactly this advance
     ProfScope ps(ctx, "k_hist_keys");
     // (a block-multistep run: the closing sweep's full keys; those of the levels that are not cell-sorted collapse here)
+    // (a dense store: a tile's keys are a few neighbouring (x, y) cells, a row of numx apart at most -- the shorter LDS window
+    // and tiles of the sort passes, sort_kernels.h: SORT_WIN_DENSE2D)
+    // (one-level stores only, as the sphere's: sph.hip)
+    const long long dense_mode = EXPAMD_EXPT("EXP_AMD_SORT_DENSE", 1);
+    c->sort_win = (dense_mode != 0 && (c->nlevels == 1 || dense_mode >= 2) && c->n >= (size_t)SORT_DENSE_MIN * ncell &&
+                   4u * (uint32_t)cfg.numx <= SORT_WIN_DENSE2D) ? SORT_WIN_DENSE2D : 0;
     k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p,
-                                                                    f->multistep ? c->sparse_mask : 0u, ncell);
+                                                                    f->multistep ? c->sparse_mask : 0u, ncell,
+                                                                    c->sort_win ? c->sort_win : (uint32_t)SORT_WIN);
   } else {
     size_t nr = c->n;          // a level range is sized for its own population
     if (level >= 0 && (rc = expamd_comp_level_count(c, level, level_hi > level ? level_hi : level, &nr))) return rc;

@@ -568,7 +568,7 @@ int expamd_comp_finish_sort(exp_amd_comp *c, uint32_t nkeys, uint32_t ncell, boo
         k_scatter_adv<false, SCAT_ITEMS_SHORT><<<g, SORT_TPB, 0, ctx->stream>>>(A, S, D, R, c->key.p, c->hist.p);
     } else {
     const uint32_t win = (level < 0 && c->sort_win) ? c->sort_win : (uint32_t)SORT_WIN;
-    if (win == (uint32_t)SORT_WIN_DENSE) {
+    if (win < (uint32_t)SORT_WIN) {
       // (the dense one-level sort of the sphere's fused step: short window, short tiles -- sort_kernels.h)
       const unsigned g = cdiv(nr, (size_t)SORT_TPB * SCAT_ITEMS_DENSE);
       if (move_acc)

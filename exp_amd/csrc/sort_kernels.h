@@ -37,6 +37,9 @@
 // fixed cost is small, and the shorter tile keeps more independent blocks in flight (1e8: 2.42 -> 2.29 ms on a box whose plain
 // copy reaches 5.06 TB/s, one slot a thread the same, eight 2.55; profiles/r05_sort_win_ab.txt)
 #define SCAT_ITEMS_DENSE 2
+// the cylinder's cells are two-dimensional (key = iy * numx + ix): neighbouring rows are numx bins apart, so its dense window spans
+// four rows of a 256-column grid
+#define SORT_WIN_DENSE2D 1024
 #define SORT_DENSE_MIN 64       // particles per cell from which a one-level store counts as dense
 
 // A/B switch of the scatter pass (tools/build_variant_tu.sh <suffix> particles "-DSCAT_NT=n"): bit 0 = non-temporal stores of

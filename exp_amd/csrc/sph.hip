@@ -472,7 +472,10 @@ static int sph_sort(SphForce *f, exp_amd_comp *c, bool move_acc, const AdvSpec &
     // (a block-multistep run: the keys the closing sweep left are full (level, cell) keys, those of the levels that are
     // not cell-sorted collapse to the level's first bin here)
     // (a dense one-level store: a tile's keys are two or three neighbouring cells -- the short LDS window, sort_kernels.h)
-    c->sort_win = (c->nlevels == 1 && level < 0 && c->n >= (size_t)SORT_DENSE_MIN * ncell) ? SORT_WIN_DENSE : 0;
+    // (EXP_AMD_SORT_DENSE in an experimental build: 0 = the full window everywhere; 1 = one-level stores only, the default; 2 = the
+    // full sort of a block-multistep store as well: measured on config 4 at +0.25 ms per master step, profiles/r05_sort_win_ab.txt)
+    const long long dense_mode = EXPAMD_EXPT("EXP_AMD_SORT_DENSE", 1);
+    c->sort_win = (dense_mode != 0 && (c->nlevels == 1 || dense_mode >= 2) && level < 0 && c->n >= (size_t)SORT_DENSE_MIN * ncell) ? SORT_WIN_DENSE : 0;
     k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, ctx->stream>>>(c->key.p, c->n, c->hist.p,
                                                                     f->cfg.multistep ? c->sparse_mask : 0u, ncell,
                                                                     c->sort_win ? c->sort_win : (uint32_t)SORT_WIN);
