@@ -20,7 +20,8 @@
 #define HIST_ITEMS 16
 #endif
 #ifndef SCAT_ITEMS
-#define SCAT_ITEMS 4
+#define SCAT_ITEMS 2           // (4 until the end of round 5: config 4's full sorts 5.925 -> 5.868 ms per master step at 2, 5.93 at 8 --
+                               // three interleaved triples on one box; the dense one-level sorts take SCAT_ITEMS_DENSE below)
 #endif
 #define HIST_TILE (SORT_TPB * HIST_ITEMS)
 #define SCAT_TILE (SORT_TPB * SCAT_ITEMS)
