@@ -61,8 +61,10 @@ struct KaNoKey {
 // k_adjust_levels above.  out[0] += level changes; out[1 + L] += particles proposed for level L
 // among those examined (the host derives the new level offsets from them without a second
 // read-back).  kick_lo > last: no kick (begin_run's first assignment).
+#ifndef KA_ITEMS
 #define KA_ITEMS 8       // 256-slot tiles per block at most (the counters leave a block as one atomic per value); the
                          // short ranges of the upper levels take one tile per block: a block's tiles run one after the other
+#endif
 template <class KeyFn>
 __global__ void __launch_bounds__(KA_TPB)
 k_kick_adjust(AdjustArgs A, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,

@@ -382,7 +382,9 @@ struct LevChunks {
 // chunk, 67 us at 64; 1e6: 150 -> 87 us).
 #define ACC_CHUNK_MIN 64
 #ifndef ACC_CHUNK_MAX
-#define ACC_CHUNK_MAX 4096
+#define ACC_CHUNK_MAX 16384   // (4096 until the end of round 5; the launcher still keeps >= ACC_BLOCKS_TARGET blocks, so only components
+                              // above 1.3e7 particles see longer chunks: 1e8 / S10 2.99 -> 2.86 ms at 16384, 2.90 at 8192, 3.03 at 32768,
+                              // 3.21 at 2048 -- interleaved pairs on one box)
 #endif
 #ifndef ACC_P0_LDS
 #define ACC_P0_LDS 2048       // p0 table entries cached in LDS by the shared-input path (numr <= this)
