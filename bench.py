@@ -98,6 +98,10 @@ def parse_args():
                     help="time the K steps as ONE call of exp_amd_step_kdk_n (pairs of steady-state steps replayed from a "
                          "HIP graph, the RCCL all-reduce included) instead of K calls of exp_amd_step_kdk; per-kernel "
                          "events are off then (roofline.avg_launch_ms comes from a second, eager region)")
+    ap.add_argument("--split", action="store_true",
+                    help="the opt-in split fused step (exp_amd_ctx_set_split_min): the store as two independently sorted "
+                         "halves, the HBM-bound sort passes of one half on a second stream under the fp64-bound accumulate / "
+                         "force passes of the other (A/B: profiles/r06_overlap_ab.txt)")
     ap.add_argument("--no-sustained", action="store_true",
                     help="skip the extra >= 2 s timed region reported as `sustained`")
     ap.add_argument("--other-n", type=float, default=1e7, help="particles per component of those")
@@ -664,16 +668,74 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process becomes the launcher -- one
+    child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the layout `python -m torch.distributed.run
+    --nproc-per-node N` gives (one rank per GPU, /root/reference/src/begin.cc:146-210).  Nothing here imports torch or
+    touches HIP, the children are started with Popen (never exec), they inherit stdout (rank 0 alone prints the JSON line),
+    and the first child to fail takes the others down: the exit code is non-zero then."""
+    import socket
+    import subprocess
+    import time
+    n = int(args.gpus)
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   EXP_AMD_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            c = p_.poll()
+            if c is None:
+                continue
+            live.remove(p_)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {procs.index(p_)} exited with {c}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()         # (the exact children started above)
+                t_end = time.time() + 10.0
+                while any(q.poll() is None for q in live) and time.time() < t_end:
+                    time.sleep(0.1)
+                for q in live:
+                    if q.poll() is None:
+                        q.kill()
+    return rc
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # no launcher: be one (before torch / HIP are touched by this process)
+            raise SystemExit(self_launch(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a launcher's world that is not the one asked for: measuring it would put a wrong n_gpus next to the rate
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch "
+                         f"{args.gpus} ranks (or unset WORLD_SIZE and let bench.py start them)")
+    probe = os.environ.get("EXP_AMD_BENCH_LAUNCH_PROBE")
+    if probe is not None and os.environ.get("EXP_AMD_BENCH_SELF_LAUNCHED"):
+        # test hook of the launcher (tests/test_bench_launch_cpu.py): "<code>[:<rank>]" -- say who this child is and leave
+        code, _, who = probe.partition(":")
+        print("probe rank=%s local_rank=%s world=%s addr=%s" % (os.environ["RANK"], os.environ["LOCAL_RANK"],
+              os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"]), flush=True)
+        raise SystemExit(int(code) if (not who or who == os.environ["RANK"]) else 0)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rehearse = bool(args.rehearse_shared_gpu)
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
@@ -729,6 +791,8 @@ def main():
     tstream = torch.cuda.Stream(device)
     torch.cuda.set_stream(tstream)
     ctx = Context(dev_index, stream=tstream.cuda_stream)
+    if args.split:
+        ctx.set_split_min(1)
     comp = Component(ctx, nloc)
     comp.upload_device(mass, x, y, z, vx, vy, vz)
     del x, y, z, vx, vy, vz, mass
@@ -857,6 +921,7 @@ def main():
                  "mtot": com["mtot"], "coef_00_0": coef00}
 
     el = reduce_max(el)
+    comm_info = ctx.comm_info()          # (every rank: a query only -- no collective behind it)
 
     if rank == 0:
         if graph_region:                # --graph: the timed region is the replayed one
@@ -963,7 +1028,8 @@ def main():
             "step_times": step_times,
             "stepping": ("exp_amd_step_kdk_n: pairs of steps replayed from a HIP graph (eager region with per-kernel "
                          f"events: {1e3 * el_eager / args.steps:.4f} ms/step)") if graph_region else
-                        "exp_amd_step_kdk per step (eager launches, per-kernel events on)",
+                        ("exp_amd_step_kdk per step (eager launches, per-kernel events on)" +
+                         ("; SPLIT fused step: two half stores, sort passes on a second stream" if args.split else "")),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -977,7 +1043,7 @@ def main():
                        "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"
                                       if world > 1 else "single GPU",
                        # which all-reduce really ran, the rank count it saw and how often it was issued
-                       "comm": {"path": comm_used, "note": comm_note, **ctx.comm_info()},
+                       "comm": {"path": comm_used, "note": comm_note, **comm_info},
                        "rehearsal": ("ranks time-share ONE GPU (gloo process group, host-staged all-reduce): a dress "
                                      "rehearsal of the launch, not a scaling measurement") if rehearse else None},
             "roofline": roof,

@@ -159,7 +159,8 @@ struct ProfScope {
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
 // true when collectives may be issued on ctx->aux as well as on ctx->stream: a single rank, a host callback (it is
 // handed the stream), or an RCCL communicator that could be split into a second one
-bool expamd_comm_two_streams(exp_amd_ctx *ctx);
+bool expamd_comm_two_streams(exp_amd_ctx *ctx);          // query, no side effect
+bool expamd_comm_prepare_two_streams(exp_amd_ctx *ctx);  // collective: splits the RCCL communicator on first use
 bool expamd_orient_has_log(const exp_amd_orient *o);     // orient.hip: a log file is open
 
 // x + a*b rounded as a separate multiply and add (what the reference's scalar CPU code does).

@@ -142,7 +142,16 @@ int expamd_ctx_aux(exp_amd_ctx *ctx)
   if (ctx->aux) return EXP_AMD_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // (stream priorities were tried for the aux stream: no effect on the overlap, 12.12-12.33 ms)
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+  // (experimental builds: EXP_AMD_AUX_CUS = n > 0 confines the auxiliary stream to n compute units spread over the XCDs --
+  // does a bounded footprint of the HBM-bound passes leave the fp64-bound ones more of the part?  profiles/r06_overlap_ab.txt)
+  const long long aux_cus = EXPAMD_EXPT("EXP_AMD_AUX_CUS", 0);
+  if (aux_cus > 0 && aux_cus < 256) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // CU index = xcd + 8 * k in the mask's order on this part (round-robin over the XCDs): the first n bits spread evenly
+    for (long long k = 0; k < aux_cus; k++) mask[k / 32] |= 1u << (k % 32);
+    HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&ctx->aux, 8, mask));
+  } else
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_sorted[k], hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_forced[k], hipEventDisableTiming));
@@ -328,13 +337,31 @@ extern "C" int exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank)
 // communicator in the same order -- the driver's launch order does not depend on the data -- which is what NCCL asks of
 // concurrently used communicators.  No split available: one stream, as before.
 typedef int (*fn_comm_split)(void *, int, int, void **, void *);
+static fn_comm_split comm_split_fn(exp_amd_ctx *ctx)
+{
+  return ctx->rccl_lib ? (fn_comm_split)dlsym(ctx->rccl_lib, "ncclCommSplit") : nullptr;
+}
+
+// A QUERY, free of side effects (exp_amd_comm_streams / comm_info may be called on one rank alone): the answer the
+// collective below would give -- the twin exists, or it has not been asked for yet and the library can split.
 bool expamd_comm_two_streams(exp_amd_ctx *ctx)
 {
   if (ctx->ar_fn) return true;                       // (the callback is told the stream)
   if (!ctx->rccl_comm) return ctx->nranks <= 1;
+  if (ctx->rccl_comm2) return true;
+  return !ctx->rccl_comm2_tried && comm_split_fn(ctx) != nullptr;
+}
+
+// COLLECTIVE over the ranks of the RCCL communicator (ncclCommSplit is): makes the twin on first use.  Called by the
+// step driver where it decides its schedule (host.hip: overlap_begin), which every rank reaches with the same
+// components and settings.
+bool expamd_comm_prepare_two_streams(exp_amd_ctx *ctx)
+{
+  if (ctx->ar_fn) return true;
+  if (!ctx->rccl_comm) return ctx->nranks <= 1;
   if (!ctx->rccl_comm2 && !ctx->rccl_comm2_tried) {
     ctx->rccl_comm2_tried = true;
-    fn_comm_split f = ctx->rccl_lib ? (fn_comm_split)dlsym(ctx->rccl_lib, "ncclCommSplit") : nullptr;
+    fn_comm_split f = comm_split_fn(ctx);
     void *c2 = nullptr;
     if (f && f(ctx->rccl_comm, 0, ctx->rank, &c2, nullptr) == 0) ctx->rccl_comm2 = c2;
   }

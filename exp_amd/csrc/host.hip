@@ -65,7 +65,9 @@ static inline double host_now()
 static void set_mass_scale(exp_amd_sim *s, size_t k)
 {
   const exp_amd_sim::Adiabatic &a = s->adb[k];
-  s->forces[k]->mass_scale = !a.on ? 1.0 : 0.25 * (1.0 + erf((s->tnow - a.ton) / a.twid)) * (1.0 + erf((a.toff - s->tnow) / a.twid));
+  const double v = !a.on ? 1.0 : 0.25 * (1.0 + erf((s->tnow - a.ton) / a.twid)) * (1.0 + erf((a.toff - s->tnow) / a.twid));
+  if (v != s->forces[k]->mass_scale) expamd_mutated();       // (a captured graph of fused steps holds the old factor)
+  s->forces[k]->mass_scale = v;
 }
 
 // issue on component k's stream for the lifetime of the object
@@ -87,13 +89,13 @@ static int overlap_begin(exp_amd_sim *s)
   // EXP_AMD_SIM_OVERLAP=0 (include/exp_amd.h, environment): both components on the context's one stream
   const char *env = getenv("EXP_AMD_SIM_OVERLAP");
   // (several ranks: each stream needs a transport of its own -- a host callback is handed the stream; the library's RCCL
-  // communicator is split into a second one for the auxiliary stream, expamd_comm_two_streams -- and every rank issues
+  // communicator is split into a second one for the auxiliary stream, expamd_comm_prepare_two_streams, a collective -- and every rank issues
   // the collectives of each stream in the same order: the launch order below does not depend on the data)
   // (exactly two components: the stream of a launch is the parity of its TARGET, and a force method is
   // followed across the streams by ONE pair of events -- with a third component the cross forces of one
   // source on two targets would run on both streams at once and share the scratch of its force pass)
   s->overlap = s->multistep > 0 && s->comps.size() == 2 && !any_orient && !(env && atoi(env) == 0) &&
-               expamd_comm_two_streams(ctx);
+               expamd_comm_prepare_two_streams(ctx);
   if (!s->overlap) return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);
   if (rc) return rc;
@@ -674,6 +676,7 @@ extern "C" int exp_amd_sim_step(exp_amd_sim *s, int nsteps)
       }
     } else if (s->comps.size() == 1 && s->inter.empty() && !s->orients[0] && s->eqmotion) {
       s->tnow += s->dtime;
+      set_mass_scale(s, 0);            // (Component::Adiabatic at the time of this step's accumulation, as compute_expansion has it)
       if ((rc = exp_amd_step_kdk(s->forces[0], s->comps[0], s->dtime))) return rc;
     } else {
       s->tnow += s->dtime;

@@ -152,7 +152,9 @@ int  exp_amd_comm_set_world(exp_amd_ctx *ctx, int nranks, int rank);
 int  exp_amd_comm_info(exp_amd_ctx *ctx, int *kind, int *nranks, int *rank, long long *calls);
 /* 2 when the context can reduce on two streams at once -- a single rank, a host callback (it is handed the stream), or an
  * RCCL communicator that could be split into a second one for the auxiliary stream (ncclCommSplit) -- and the
- * two-component step driver therefore keeps its two-stream schedule with several ranks; 1 otherwise.            */
+ * two-component step driver therefore keeps its two-stream schedule with several ranks; 1 otherwise.  A QUERY: no
+ * collective is issued (one rank may ask alone); the split itself happens where the step driver decides its schedule
+ * (exp_amd_sim_begin_run / exp_amd_sim_step), which every rank reaches alike.                                    */
 int  exp_amd_comm_streams(exp_amd_ctx *ctx);
 /* MAX over the ranks of one HOST number through the same transport (a sum of one-hot slots): for host logic that must
  * agree on a count before it issues collectives (e.g. how many batches a reader is cut into, each ending in one

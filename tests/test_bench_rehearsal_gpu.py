@@ -133,3 +133,17 @@ def test_native_rccl_one_rank(one_rank):
     comm = line["config"]["comm"]
     assert comm["kind"] == "rccl" and comm["allreduce_calls"] > 0 and comm["note"] is None
     assert line["selfcheck"]["coef_00_0"] == pytest.approx(one_rank["selfcheck"]["coef_00_0"], rel=1e-12)
+
+
+def test_two_ranks_with_no_launcher(one_rank):
+    """`python bench.py --gpus 2` as the driver spells the N = 1 command -- no torchrun around it: bench.py starts its own
+    ranks (bench.py: self_launch) instead of measuring one GPU and printing n_gpus 1."""
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu"] + SMALL
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-3000:]
+    _check_two(lines[0], one_rank, graph=False)

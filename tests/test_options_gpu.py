@@ -480,3 +480,47 @@ def test_eqmotion_off_moves_nothing_and_matches_the_oracle(ctx, oracle, ms):
     assert sim.time == pytest.approx(nsteps * dtime)
     for x in (sim, ch, cd, fh, fd):
         x.close()
+
+
+def test_single_component_single_level_run_turns_on_adiabatically(ctx, oracle):
+    """One component, multistep 0: the step driver takes its fused step (exp_amd/csrc/host.hip: exp_amd_sim_step ->
+    exp_amd_step_kdk).  Component::Adiabatic is evaluated at EVERY determine_coefficients (src/SphericalBasis.cc:441,
+    src/step.cc:273-293), so a component whose turn-on lies ahead of begin_run must come on during the run -- against
+    the n-body oracle, and against the same run without the key."""
+    from exp_amd.runtime import Component, Simulation, SphereSL
+    dtime, nsteps = 1.5e-4, 4
+    adb = (3.0e-4, 1.0e20, 1.5e-4)                    # mass factor 2e-5 at t = 0, 0.98 at t = 6e-4
+    inp = c4.config4_inputs(n_halo=600, n_disk=10)
+    g, _ = c4.grids()
+    sc = float(inp["scale"])
+    prm = oracle.params(**c4.sph_window(g, sc))
+    nb = NBodyOracle(oracle, 0, dtime, c4.DYN)
+    i1 = nb.add_sphere(g, prm, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+    nb.set_options(i1, adiabatic=adb)
+    nb.init()
+    for _ in range(nsteps):
+        nb.step()
+    outs = []
+    for on in (True, False):
+        ch = Component.from_arrays(ctx, inp["halo_mass"], inp["halo_pos"], inp["halo_vel"])
+        fh = SphereSL(ctx, g, multistep=0, **c4.sph_window(g, sc))
+        sim = Simulation(ctx, dtime, multistep=0, dynfrac=c4.DYN)
+        ih = sim.add_component(ch, fh)
+        if on:
+            sim.set_adiabatic(ih, *adb)
+        sim.init()
+        sim.step(nsteps)
+        outs.append((ch.download(), np.asarray(fh.get_coefs()).reshape(-1).copy()))
+        for x in (sim, ch, fh):
+            x.close()
+    (o, gc), (o_off, gc_off) = outs
+    st = nb.state[0]
+    a = np.stack([st["a" + q] for q in "xyz"], 1)
+    p = np.stack([st[q] for q in "xyz"], 1)
+    assert np.abs(o["pos"] - p).max() <= 1e-12 * np.abs(p).max()
+    assert np.abs(o["acc"] - a).max() <= 1e-9 * np.linalg.norm(a, axis=1).max()
+    assert np.abs(gc - st["coef"]).max() <= 1e-10 * np.abs(st["coef"]).max()
+    # the factor at the last accumulation (t = 6e-4): the set is that fraction of the full-mass one, not the 2e-5 of begin_run
+    from math import erf
+    fac = 0.25 * (1.0 + erf((nsteps * dtime - adb[0]) / adb[2])) * 2.0
+    assert 0.9 < fac < 1.0 and abs(gc[0] / gc_off[0] - fac) < 0.02
