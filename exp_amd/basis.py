@@ -401,8 +401,13 @@ class BiorthBasis:
                         _dist.all_gather_object(box, nbatch)
                         nbatch = max(box)
                 else:
-                    raise RuntimeError("createFromReader: the context reduces through a callback but does not know its "
-                                       "world: Context.set_allreduce(fn, nranks, rank)")
+                    # a callback installed without its world and no process group to ask: a single-process host (e.g. a
+                    # pass-through callback) -- this rank's batch count stands.  A multi-rank host must declare the world,
+                    # or ranks whose shares straddle a multiple of 2^24 differently would issue unequal numbers of reductions
+                    import warnings
+                    warnings.warn("createFromReader: the context reduces through a callback but was not told its world "
+                                  "(Context.set_allreduce(fn, nranks, rank)); assuming a single rank", RuntimeWarning,
+                                  stacklevel=2)
             else:
                 nbatch = int(self.ctx.allreduce_max(nbatch))
         sampT = int(getattr(self, "sampT", 0) or 0)

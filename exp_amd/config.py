@@ -119,16 +119,23 @@ def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None):
             raise _refuse(name, key, conf[key], why + " is not built here")
     if int(g("nint", 0)) != 0:
         raise _refuse(name, "nint", conf["nint"], "the periodic sub-sample covariance of the step loop is not driven from here")
+    # npca / npca0: the reference acts on them only under pcavar / pcaeof (`compute`, src/Cylinder.cc:1025-1027; pca_hall
+    # does nothing without it, exputil/EmpCylSL.cc:4582; set_trimmed asks for pcavar, src/Cylinder.cc:1133) -- both refused
+    # above when switched on -- so any value is inert here, as there
     for key in ("npca", "npca0"):
-        if key in conf and int(conf[key]) < 2 ** 31 - 1:
-            raise _refuse(name, key, conf[key], "PCA / Hall smoothing (src/Cylinder.cc:1120-1131) is not built here")
+        if key in conf:
+            int(conf[key])
     if "ncylrecomp" in conf and int(conf["ncylrecomp"]) >= 0:
         raise _refuse(name, "ncylrecomp", conf["ncylrecomp"], "re-making the EOF basis from the particles during a run "
                       "(src/Cylinder.cc:1133-1190) is not built here")
-    for key in ("precond", "expcond"):
-        if key in conf and not _bool(conf[key]):
-            raise _refuse(name, key, conf[key], "conditioning the basis on the PARTICLES (determine_coefficients_eof, "
-                          "src/Cylinder.cc:1018-1080) is not built here: the tables are conditioned on the analytic disk")
+    # `expcond` is the deprecated spelling; a later `precond` overrides it (src/Cylinder.cc:492-493, :520-526)
+    precond, pkey = True, None
+    for key in ("expcond", "precond"):
+        if key in conf:
+            precond, pkey = _bool(conf[key]), key
+    if not precond:
+        raise _refuse(name, pkey, conf[pkey], "conditioning the basis on the PARTICLES (determine_coefficients_eof, "
+                      "src/Cylinder.cc:1018-1080) is not built here: the tables are conditioned on the analytic disk")
     if "pyname" in conf:
         raise _refuse(name, "pyname", conf["pyname"], "a Python target density: pass a callable to "
                       "exp_amd.empcyl.build_empcyl(dens=...) and hand the grid in")

@@ -77,23 +77,23 @@ struct exp_amd_ctx {
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
   bool prekick = true;               // the fused step stores velocities with the NEXT step's opening half-kick applied
-                                     // (exp_amd_ctx_set_prekick; EXP_AMD_PREKICK=0 sets the default off)
+                                     // (exp_amd_ctx_set_prekick)
   bool deterministic = false;        // order-independent (bit-reproducible) coefficient sums, exp_amd_ctx_set_deterministic
   long long mover_list_min = 8192;   // block multistep: from this many level changes in a sweep on, the differencing goes
                                      // through the accumulation kernel over a list of the movers instead of per-particle
-                                     // atomics (EXP_AMD_MOVER_LIST_MIN; < 0: never)
-  long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (EXP_AMD_MOVER_SLICES_MIN)
+                                     // atomics (exp_amd_ctx_set_mover_list_min; < 0: never)
+  long long mover_slices_min = 65536; // ... and from this many on with one adding pass per proposed level (experimental builds: EXP_AMD_MOVER_SLICES_MIN)
   long long stage_max = 1 << 20;     // particles up to which the per-particle atomic paths are staged (values by plain stores,
-                                     // one lane per value for the atomics): 8 (L+1)^2 bytes each (EXP_AMD_STAGE_MAX)
+                                     // one lane per value for the atomics): 8 (L+1)^2 bytes each (experimental builds: EXP_AMD_STAGE_MAX)
   long long thin_acc_scale = 4;      // ... times this for the accumulation side alone (the direct kernel replaces three launches
                                      // there; config 4, 13e3 particles in the halo's levels >= 2: 6.05 -> 5.93 ms per master step;
-                                     // EXP_AMD_THIN_ACC_SCALE)
+                                     // experimental builds: EXP_AMD_THIN_ACC_SCALE)
   long long thin_max = 8192;         // block multistep: an active slot range of at most this many particles, all of it in sparse
                                      // levels, is accumulated and evaluated straight from the basis tables (k_*_acc_thin,
                                      // k_*_force_thin: no moments, no contraction, no projected table); 0: never
-                                     // (exp_amd_ctx_set_thin_max; EXP_AMD_THIN_MAX sets the default)
+                                     // (exp_amd_ctx_set_thin_max)
   long long dense_min = -1;          // block multistep: levels with fewer particles are not cell-sorted (< 0: per force method)
-                                     // (exp_amd_ctx_set_dense_min; EXP_AMD_DENSE_MIN sets the default)
+                                     // (exp_amd_ctx_set_dense_min)
   hipStream_t aux = nullptr;
   struct ScanSums { uint32_t *p = nullptr; size_t n = 0; hipError_t alloc(size_t c) { expamd_mutated(); if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void **)&p, c * sizeof(uint32_t)); if (e == hipSuccess) n = c; return e; } } scan_sums[2];   // chunk totals of multi-chunk scans, one per stream (particles.hip)
   hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_forced[2] = {nullptr, nullptr};
@@ -159,6 +159,19 @@ struct ProfScope {
 int expamd_allreduce(exp_amd_ctx *ctx, double *dev, size_t count);
 // true when collectives may be issued on ctx->aux as well as on ctx->stream: a single rank, a host callback (it is
 // handed the stream), or an RCCL communicator that could be split into a second one
+// Opt one kernel in to more than 64 KB of dynamic LDS (once per kernel).  A refusal is KEPT, not discarded: it becomes the
+// library's global error text (exp_amd_last_global_error), and the launch that then asks for the LDS fails with an invalid-value
+// status which the caller's hipGetLastError check reports.
+inline bool expamd_big_lds(const void *fn, const char *name)
+{
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) {
+    (void)expamd_fail(nullptr, EXP_AMD_ERR_HIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 128 KB) -> %s", name,
+                      hipGetErrorString(e));
+    (void)hipGetLastError();
+  }
+  return e == hipSuccess;
+}
 bool expamd_comm_two_streams(exp_amd_ctx *ctx);          // query, no side effect
 bool expamd_comm_prepare_two_streams(exp_amd_ctx *ctx);  // collective: splits the RCCL communicator on first use
 bool expamd_orient_has_log(const exp_amd_orient *o);     // orient.hip: a log file is open

@@ -97,10 +97,7 @@ static void cyl_thin_force_launch(hipStream_t st, size_t n, const CylDev &C, con
   size_t grid = cdiv(n, (size_t)tp);
   if (grid > 16384) grid = 16384;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_force_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_cyl_force_thin<MM>), "k_cyl_force_thin<MM>");
   (void)big;
   const int nt0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_NT", 0);
   const int nt = nt0 ? nt0 : 256;
@@ -121,10 +118,7 @@ static void cyl_thin_acc_launch(hipStream_t st, size_t n, const CylDev &C, const
   size_t grid = cdiv(n, (size_t)tpa);
   if (grid > 4096) grid = 4096;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_acc_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_cyl_acc_thin<MM>), "k_cyl_acc_thin<MM>");
   (void)big;
   k_cyl_acc_thin<MM><<<(unsigned)grid, 256, (size_t)tpa * nset * half * sizeof(double), st>>>(C, X, Y, Z, M, lev_off, lo, hi, tabT,
                                                                                                  nk, part, tail, tpa, adv);
@@ -140,10 +134,7 @@ static void cyl_thin_diff_launch(hipStream_t st, size_t n, const CylDev &C, cons
   size_t grid = cdiv(n, (size_t)8);
   if (grid > 4096) grid = 4096;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_diff_thin<MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_cyl_diff_thin<MM>), "k_cyl_diff_thin<MM>");
   (void)big;
   k_cyl_diff_thin<MM><<<(unsigned)grid, 256, (size_t)8 * nset * half * sizeof(double), st>>>(C, X, Y, Z, M, list, cnt, lev, newlev,
                                                                                               mfirst, nl, tabT, nk, part);
@@ -175,10 +166,7 @@ static void cyl_tile_acc_launch(hipStream_t st, size_t n, const CylDev &C, const
   size_t grid = cdiv(n, (size_t)tile);
   if (grid > 4096) grid = 4096;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cyl_acc_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_cyl_acc_tile), "k_cyl_acc_tile");
   (void)big;
   k_cyl_acc_tile<<<(unsigned)grid, 256, need(tile), st>>>(C, X, Y, Z, M, lev_off, lo, hi, tabT, nk, part, tail, tile);
 }

@@ -323,7 +323,12 @@ k_cyl_accumulate(CylDev C, const double *__restrict__ X, const double *__restric
 #ifndef CSLOT_EXPT
 #define CSLOT_EXPT 0
 #endif
-#define CSLOT_TSTRIDE 65          // trig rows [m][65] pairs: 1040 B apart, i.e. 4 banks per row for the 16-byte reads
+// Trig rows [m][68] (cos, sin) pairs, 1088 B apart: the owner lanes' 16-byte reads (ds_read_b128: four groups of 16 lanes,
+// 16 slots of 16 B per 256-B bank row) then land on slot (4 m + sub) mod 16 -- the four sub-groups and the four azimuthal
+// orders of a lane group all on different slots.  With the former stride of 65 pairs the slot was (m + sub) mod 16: up to
+// three lanes of a group on one slot, a third of this kernel's LDS cycles (profiles/r05_cfg3_counters.txt:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32).
+#define CSLOT_TSTRIDE 68
 
 template <int MMAX, bool DET, bool LIST = false>
 __global__ void __launch_bounds__(CACC_WAVES * 64, CYL_SLOT_OCC)
@@ -341,8 +346,12 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
   const unsigned bx = blockIdx.x - LC.bstart[lj];
   const int lvl = multilevel ? lev_lo : 0;
   constexpr int NT = 2 * MMAX + 1;
-  // per wave: w[64][4] (2 KB), trig pairs [MMAX+1][65][2], flush scratch [64][4] (2 KB)
-  constexpr int WB = 64 * 4, TB = (MMAX + 1) * CSLOT_TSTRIDE * 2, SB = 64 * 4;
+  // per wave: w[64][4 (+2: rows 48 B apart)] (3 KB), trig pairs [MMAX+1][68][2], flush scratch [64][4] (2 KB).  The particle
+  // lanes store their w row with two 16-byte writes (eight contiguous lanes a group, banks mod 32): rows of 32 B put lanes
+  // l and l + 4 on the same banks, rows of 48 B none (12 l mod 32 is a permutation of the eight 4-bank slots); the owners'
+  // reads -- slot (3 p + k) mod 16 for the four particles p of a lane group -- stay conflict-free
+  constexpr int WS = 6;
+  constexpr int WB = 64 * WS, TB = (MMAX + 1) * CSLOT_TSTRIDE * 2, SB = 64 * 4;
   __shared__ __attribute__((aligned(16))) double lds_all[CACC_WAVES][WB + TB + SB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *wbuf = lds_all[wave], *tbuf = wbuf + WB, *sbuf = tbuf + TB;
@@ -354,7 +363,9 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
   const int nyp = C.numy + 1;
   const int sub = lane >> 3, om = lane & 7;            // owner role: sub-group, azimuthal order
   const bool owner = om <= MMAX && !(C.EVEN_M && (om & 1));
-  const int orow = om <= MMAX ? om : 0;                // (idle lanes read row 0 and accumulate nothing)
+  // (idle lanes accumulate nothing; they read the row whose slot their own row would have had -- m - 4 -- so that they do
+  // not add a second address to a slot another lane of their group reads)
+  const int orow = om <= MMAX ? om : (om - 4 <= MMAX ? om - 4 : 0);
   // trig row of m = 0: (1, 0) for every particle, once
   tbuf[(0 * CSLOT_TSTRIDE + lane) * 2 + 0] = 1.0;
   tbuf[(0 * CSLOT_TSTRIDE + lane) * 2 + 1] = 0.0;
@@ -450,7 +461,7 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
 #endif
     // this particle's row of the two LDS tables
     {
-      double *w = wbuf + lane * 4;
+      double *w = wbuf + lane * WS;
       w[0] = t0 * c00; w[1] = t0 * c10; w[2] = t0 * c01; w[3] = t0 * c11;
       double cm = 1.0, sm = 0.0;
       cstatic_for<1, MMAX + 1>([&](auto mc) {
@@ -483,7 +494,7 @@ k_cyl_accumulate_slot(CylDev C, const double *__restrict__ X, const double *__re
       const unsigned long long ms = mask >> sub;                       // bit 8 i: particle 8 i + sub
       for (int it = pa >> 3; it <= (pb >> 3); it++) {
         const int p = it * 8 + sub;
-        const double *w = wbuf + p * 4;
+        const double *w = wbuf + p * WS;
         const double w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         double tc = tbuf[(orow * CSLOT_TSTRIDE + p) * 2 + 0], tsn = tbuf[(orow * CSLOT_TSTRIDE + p) * 2 + 1];
         if (holes || it == (pa >> 3) || it == (pb >> 3)) {

@@ -1026,13 +1026,17 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
                         c->uniform_mass ? nullptr : c->b(A_M),
                         c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT), c->id[1 - c->cur].p,
                         c->levels_zero ? nullptr : c->level[1 - c->cur].p};
+  // (experimental builds: EXP_AMD_SPLIT_LDS = bytes of dynamic LDS asked for by the sort passes of this path on top of their
+  // 16 KB -- nothing uses it; it bounds how many of their blocks a CU takes (48 KB: two), so that the small-footprint
+  // HBM-bound blocks cannot crowd the fp64-bound kernel's waves out of the CU; profiles/r06_overlap_ab.txt)
+  const size_t pad_lds = (size_t)EXPAMD_EXPT("EXP_AMD_SPLIT_LDS", 0);
   for (int h = 0; h < 2; h++) {
     HIP_TRY(ctx, hipStreamWaitEvent(H, ctx->ev_forced[h], 0));
     const SortRange R{c->half_off.p, h, h, c->n};
     HIP_TRY(ctx, hipMemsetAsync(c->hist.p + (size_t)h * ncell, 0, ((size_t)ncell + (h ? 1 : 0)) * sizeof(uint32_t), H));
     if (have_keys) {
       ProfScope ps(ctx, "k_hist_keys", H);
-      k_hist_keys<<<cdiv(len[h], HIST_TILE), SORT_TPB, 0, H>>>(c->key.p + beg[h], len[h], c->hist.p);
+      k_hist_keys<<<cdiv(len[h], HIST_TILE), SORT_TPB, pad_lds, H>>>(c->key.p + beg[h], len[h], c->hist.p);
     } else {
       ProfScope ps(ctx, "k_key_hist", H);
       SphDev S = dev_for(f, c->center);
@@ -1045,7 +1049,7 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
     }
     {
       ProfScope ps(ctx, "k_scatter_adv", H);
-      k_scatter_adv<false><<<cdiv(len[h], SCAT_TILE), SORT_TPB, 0, H>>>(A, Ssrc, Sdst, R, c->key.p, c->hist.p);
+      k_scatter_adv<false><<<cdiv(len[h], SCAT_TILE), SORT_TPB, pad_lds, H>>>(A, Ssrc, Sdst, R, c->key.p, c->hist.p);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sorted[h], H));

@@ -601,11 +601,7 @@ void expamd_sph_thin_acc_gen(const SphThinAccArgs &a)
   // (ncoef <= SPH_TILE_KMAX * 256: the caller checks, sph.hip)
   size_t grid = cdiv(a.n, (size_t)tile);
   if (grid > 4096) grid = 4096;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_acc_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_sph_acc_tile), "k_sph_acc_tile");
   (void)big;
   k_sph_acc_tile<<<(unsigned)grid, 256, need(tile), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off, a.lo, a.hi, a.wscale, a.part,
                                                               a.used, tile);

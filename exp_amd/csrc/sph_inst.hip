@@ -161,11 +161,7 @@ void CAT(expamd_sph_thin_force_L, SPH_L)(const SphThinForceArgs &a)
   size_t grid = cdiv(a.n, (size_t)tp);
   if (grid > 16384) grid = 16384;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_force_thin<LMAX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_sph_force_thin<LMAX>), "k_sph_force_thin<LMAX>");
   (void)big;
   const int nt0 = (int)EXPAMD_EXPT("EXP_AMD_THIN_NT", 0);
   const int nt = nt0 ? nt0 : 256;       // (64-thread blocks -- four times as many resident -- measured SLOWER at 2e3 and 1.3e4 particles)
@@ -185,11 +181,7 @@ void CAT(expamd_sph_thin_acc_L, SPH_L)(const SphThinAccArgs &a)
   size_t grid = cdiv(a.n, (size_t)tpa);
   if (grid > 4096) grid = 4096;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_acc_thin<LMAX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_sph_acc_thin<LMAX>), "k_sph_acc_thin<LMAX>");
   (void)big;
   k_sph_acc_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.lev_off, a.lo, a.hi, a.wscale,
                                                                     a.part, a.used, tpa, a.adv);
@@ -205,11 +197,7 @@ void CAT(expamd_sph_thin_diff_L, SPH_L)(const SphThinDiffArgs &a)
   size_t grid = cdiv(a.n, (size_t)tpa);
   if (grid > 4096) grid = 4096;
   if (grid == 0) return;
-  static const bool big = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sph_diff_thin<LMAX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
+  static const bool big = expamd_big_lds(reinterpret_cast<const void *>(&k_sph_diff_thin<LMAX>), "k_sph_diff_thin<LMAX>");
   (void)big;
   k_sph_diff_thin<LMAX><<<(unsigned)grid, 256, need(tpa), a.stream>>>(a.S, a.X, a.Y, a.Z, a.M, a.list, a.cnt, a.lev, a.newlev,
                                                                      a.mfirst, a.nlev_out, a.wscale, a.part, tpa);

@@ -134,7 +134,7 @@ CYL_WALK = {
     "vflag": (3, "honoured"), "density": (True, "honoured"), "override": (True, "honoured"), "try_cache": (False, "honoured"),
     "sech2": (True, "honoured"), "expcond": (True, "honoured"), "precond": (True, "honoured"),
     "tk_type": ("Hall", "refused"), "bias": (2.0, "refused"), "hexp": (2.0, "refused"), "snr": (3.0, "refused"),
-    "evcut": (0.5, "refused"), "ncylrecomp": (10, "refused"), "npca": (50, "refused"), "npca0": (10, "refused"),
+    "evcut": (0.5, "refused"), "ncylrecomp": (10, "refused"), "npca": (50, "honoured"), "npca0": (10, "honoured"),
     "nvtk": (5, "refused"), "cachename": ("eof.cache", "refused"), "eof_file": ("eof.cache", "refused"),
     "samplesz": (4, "refused"), "logr": (True, "refused"), "pcavar": (True, "refused"), "pcaeof": (True, "refused"),
     "pcavtk": (True, "refused"), "pcadiag": (True, "refused"), "subsamp": (True, "refused"), "nint": (5, "refused"),
@@ -195,6 +195,12 @@ def test_every_cylinder_key_is_honoured_or_refused(ctx, oracle):
     f = Cylinder.from_config(ctx, dict(pcavar=False, logr=False, nint=0, ncylrecomp=-1, precond=True, mtype="Exponential",
                                        bias=1.0, tk_type="Null", samplesz=1, nvtk=1, evcut=-1.0), grid=cg)
     f.close()
+    # `expcond` is the deprecated spelling and a later `precond` overrides it (src/Cylinder.cc:492-493): this pair is valid ...
+    f = Cylinder.from_config(ctx, dict(expcond=False, precond=True, npca=50), grid=cg)
+    f.close()
+    for bad in (dict(precond=False), dict(expcond=False), dict(expcond=True, precond=False)):      # ... these ask for the EOF pass
+        with pytest.raises(ValueError, match="PARTICLES"):
+            Cylinder.from_config(ctx, bad, grid=cg)
     # grid=None: the tables are built from the keys (small orders so that it takes seconds)
     f = Cylinder.from_config(ctx, dict(mmax=2, nmax=4, ncylnx=24, ncylny=12, ncylr=400, lmaxfid=10, nmaxfid=8, rnum=40,
                                        tnum=20, ncylodd=1, acyl=0.01, hcyl=0.001, mlim=1))

@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of the split fused step on the headline workload: EXP_AMD_SPLIT_MIN=0 (off) vs default (on)
+# A/B of the split fused step on the headline workload: bench.py --split (exp_amd_ctx_set_split_min) against the plain step
+# (superseded by tools/dbg/overlap_r06.sh, which also traces the timeline)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
 for rep in 1 2; do
-for mode in 0 4000000; do
-  echo "== split_min $mode"
-  EXP_AMD_SPLIT_MIN=$mode timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $* 2>/dev/null | python -c "
+for mode in "" "--split"; do
+  echo "== ${mode:-plain}"
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $mode $* 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (needs make EXPERIMENTAL=1 for EXP_AMD_THIN_V / EXP_AMD_THIN_TILE; EXP_AMD_THIN_MAX is no longer read -- the thin path's
+# bound is exp_amd_ctx_set_thin_max, 8192 by default)
 # rocprofv3 kernel durations of the thin kernels by grid size, for the settings given as "V TILE" pairs
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
