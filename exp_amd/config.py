@@ -8,8 +8,7 @@ against the tables that were handed in -- or REFUSED with a ``ValueError`` that 
 two sets is refused as the reference refuses it (``unmatched()``, src/PotAccel.H:323).  Nothing is accepted and dropped:
 ``tests/test_config_keys_gpu.py`` walks both sets.
 
-A key whose value is the reference's default for a feature that is not built here (``NOISE: false``, ``pcavar: false``,
-``ssfrac: 0`` ...) asks for nothing and is honoured as such; only asking for the feature is refused.
+A key whose value is the reference's default for a feature that is not built here (``NOISE: false``, ``pcavar: false`` ...) asks for nothing and is honoured as such; only asking for the feature is refused.
 """
 from __future__ import annotations
 
@@ -44,7 +43,8 @@ def _refuse(cls_name: str, key: str, value, why: str):
     return ValueError(f"{cls_name}: key '{key}: {value}' is not supported by this build -- {why}")
 
 
-def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0):
+def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0, nthrds: int = 1):
+    """``nthrds``: the global thread count of the run (src/global.cc: nthrds) -- only ``ssfrac`` depends on it."""
     conf = dict(conf or {})
     bad = sorted(set(conf) - set(SPHERICALBASIS_KEYS))
     if bad:
@@ -56,11 +56,11 @@ def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0):
         raise _refuse(name, "NOISE", conf["NOISE"], "the noise-model coefficients (src/SphericalBasis.cc:907-1000) are not "
                       "on the device path")
     ss = float(g("ssfrac", 0.0))
-    if 0.0 < ss < 1.0:
-        # `subset`: the first floor(ssfrac * n) entries of every thread's slice of the level list (src/SphericalBasis.cc:
-        # 459-460) -- which particles those are follows the iteration order of the reference's hash map of particles
-        raise _refuse(name, "ssfrac", ss, "the sub-sample is whatever order EXP's particle map iterates in "
-                      "(src/SphericalBasis.cc:459-460); there is no such order to reproduce")
+    if 0.0 < ss < 1.0 and multistep > 0:
+        # `subset`: thread id walks [n id / nthrds, floor(ssfrac n (id + 1) / nthrds)) of every LEVEL list (src/SphericalBasis.cc:
+        # 435-460); with block multistep those lists are in the order of the run's level changes -- nothing to reproduce
+        raise _refuse(name, "ssfrac", ss, "with block multistep the sub-sample is a slice of level lists whose order is the "
+                      "history of the level changes (src/SphericalBasis.cc:435-460); single-level runs take it")
     for key in ("subsampleFloat", "totalCovar", "fullCovar"):
         if key in conf and _bool(conf[key]):
             raise _refuse(name, key, conf[key], "the n-body sub-sample covariance (nint, src/SphericalBasis.cc:700-720) is "
@@ -76,6 +76,10 @@ def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0):
     rmin = max(float(g("rmin", 0.0)), grid.rmin) if "rmin" in conf else grid.rmin
     rmax = min(float(g("rmax", grid.rmax)), grid.rmax) if "rmax" in conf else grid.rmax
     f = cls(ctx, grid, rmin=rmin, rmax=rmax, **kw)
+    if 0.0 < ss < 1.0:
+        # (the level list of a single-level run is the caller's particle order here; the reference's is the iteration order
+        # of its particle map -- exp_amd_sph_set_subset, include/exp_amd.h)
+        f.set_subset(ss, nthrds)
     if "orthocheck" in conf and _bool(conf["orthocheck"]):
         # SphericalBasis::orthoTest (src/SphericalBasis.cc:2109-2150): the worst deviation of the biorthogonality matrix
         from .slgrid import orthocheck_max

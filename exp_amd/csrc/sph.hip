@@ -426,6 +426,9 @@ void SphForce::release()
   expamd_sph_cov_release(this);
   d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release(); d_xwork.release();
   d_Wd.release(); d_differ.release();
+  for (auto &b : d_ss) b.release();
+  d_ss_prefix.release();
+  if (ss_comp) { exp_amd_comp_destroy(ss_comp); ss_comp = nullptr; }
 }
 
 static SphDev dev_for(const SphForce *f, const double center[3])
@@ -614,10 +617,104 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   return EXP_AMD_OK;
 }
 
+// ---- "ssfrac": coefficients from a sub-sample of the particles (sph_force.h) -------------------------------------------
+// One thread per slot: is the particle's place j in the level list (its caller index) inside its thread's shortened slice?
+// Then it goes to place prefix[thread] + (j - slice begin) of the compacted set -- no atomics, the same set every time.
+__global__ void __launch_bounds__(256)
+k_subset_gather(const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                const double *__restrict__ M, double umass, const uint32_t *__restrict__ id, size_t n, unsigned nthrds,
+                double ssfrac, const uint32_t *__restrict__ prefix, double *__restrict__ om, double *__restrict__ ox,
+                double *__restrict__ oy, double *__restrict__ oz)
+{
+  const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n) return;
+  const unsigned long long j = id[slot], T = nthrds;
+  const unsigned long long k = ((j + 1) * T + n - 1) / n - 1;        // nbeg(k) <= j < nbeg(k + 1), nbeg(k) = n k / T
+  const unsigned long long nbeg = n * k / T, nend = n * (k + 1) / T;
+  const long long lim = (long long)floor(ssfrac * (double)nend);     // `nend = (int)floor(ssfrac*nend)`, :460
+  if ((long long)j >= lim) return;
+  const size_t o = (size_t)prefix[k] + (size_t)(j - nbeg);
+  om[o] = umass != 0.0 ? umass : M[slot];
+  ox[o] = X[slot]; oy[o] = Y[slot]; oz[o] = Z[slot];
+}
+
+int SphForce::determine_coefficients_subset(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift)
+{
+  SphForce *f = this;
+  int rc;
+  if (f->cfg.multistep)
+    return expamd_fail(ctx, EXP_AMD_ERR_STATE, "ssfrac with block multistep: the sub-sample is a slice of every LEVEL list, "
+                       "whose order in the reference is the history of its level changes (src/SphericalBasis.cc:435-460)");
+  if (c->n >= 0x7fffffffu) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "ssfrac: more than 2^31 particles on one rank");
+  // the advance a fused step would have folded into the sort: on its own here (the store is not reordered)
+  if (advance && ((rc = exp_amd_comp_kick(c, dt_kick, -1)) || (rc = exp_amd_comp_drift(c, dt_drift, -1)))) return rc;
+  if ((rc = expamd_comp_touch(c))) return rc;
+  const size_t n = c->n;
+  const unsigned T = (unsigned)f->ss_nthrds;
+  std::vector<uint32_t> prefix(T, 0u);
+  size_t nsub = 0;
+  for (unsigned k = 0; k < T; k++) {
+    const long long nbeg = (long long)((unsigned long long)n * k / T), nend = (long long)((unsigned long long)n * (k + 1) / T);
+    const long long lim = (long long)floor(f->ssfrac * (double)nend);
+    prefix[k] = (uint32_t)nsub;
+    if (lim > nbeg) nsub += (size_t)(lim - nbeg);
+  }
+  if (!f->d_ss_prefix.p || f->d_ss_prefix.n < T) HIP_TRY(ctx, f->d_ss_prefix.alloc(T));
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_ss_prefix.p, prefix.data(), T * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // (`prefix` is a local)
+  if (f->ss_comp && f->ss_comp->n != nsub) { exp_amd_comp_destroy(f->ss_comp); f->ss_comp = nullptr; }
+  if (!f->ss_comp && (rc = exp_amd_comp_create(ctx, nsub, &f->ss_comp))) return rc;
+  exp_amd_comp *sub = f->ss_comp;
+  if (nsub) {
+    if (f->ss_cap < nsub) {
+      for (auto &b : f->d_ss) HIP_TRY(ctx, b.alloc(nsub));
+      f->ss_cap = nsub;
+    }
+    k_subset_gather<<<cdiv(n, 256), 256, 0, ctx->stream>>>(c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M),
+                                                          c->uniform_mass ? c->mass_value : 0.0, c->id[c->cur].p, n, T,
+                                                          f->ssfrac, f->d_ss_prefix.p, f->d_ss[0].p, f->d_ss[1].p,
+                                                          f->d_ss[2].p, f->d_ss[3].p);
+    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = exp_amd_comp_upload_device(sub, f->d_ss[0].p, f->d_ss[1].p, f->d_ss[2].p, f->d_ss[3].p, nullptr, nullptr,
+                                         nullptr)))
+      return rc;
+  }
+  // the sub-sample lives in the frame of the component it was drawn from, Component::freeze included (:468 sits inside the loop)
+  if ((rc = exp_amd_comp_set_center(sub, c->center))) return rc;
+  if ((rc = exp_amd_comp_set_rtrunc(sub, c->freeze_on ? c->rtrunc : 1.0e20, c->com0))) return rc;
+  const double ms_save = f->mass_scale;
+  f->mass_scale = ms_save / f->ssfrac;                       // `mass = Mass * adb; mass /= ssfrac` (:471-473)
+  f->subset_on = false;                                      // (the accumulation of the sub-sample itself is a plain one)
+  rc = determine_coefficients(sub, false, 0.0, 0.0, false);
+  f->subset_on = true;
+  f->mass_scale = ms_save;
+  f->home = c;                                               // the expansion belongs to the component, not to its sample
+  f->home_gone = false;
+  return rc;
+}
+
+// The "ssfrac" key (src/SphericalBasis.cc:149-152: taken when 0 < ssfrac < 1, ignored otherwise) with the thread count the
+// reference's partition of the level list depends on (`nthrds`, src/SphericalBasis.cc:438-439)
+extern "C" int exp_amd_sph_set_subset(exp_amd_force *fb, double ssfrac, int nthrds)
+{
+  expamd_mutated();
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_subset: not a spherical force");
+  if (nthrds < 1 || nthrds > 4096) return expamd_fail(f->ctx, EXP_AMD_ERR_ARG, "set_subset: nthrds must be in [1, 4096]");
+  if (ssfrac > 0.0 && ssfrac < 1.0 && f->cfg.multistep)
+    return expamd_fail(f->ctx, EXP_AMD_ERR_STATE, "set_subset: ssfrac with block multistep is not defined here (the order of "
+                       "the reference's level lists is the history of its level changes)");
+  f->subset_on = ssfrac > 0.0 && ssfrac < 1.0;               // "Check for sane value" (:151)
+  f->ssfrac = f->subset_on ? ssfrac : 1.0;
+  f->ss_nthrds = nthrds;
+  return EXP_AMD_OK;
+}
+
 int SphForce::determine_coefficients(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift,
                                      bool have_keys)
 {
   SphForce *f = this;
+  if (f->subset_on) return determine_coefficients_subset(c, advance, dt_kick, dt_drift);
   f->home = c;
   f->home_gone = false;
   // multistep: only level `mlevel` has moved since the store was last put in this basis' order,
@@ -985,7 +1082,8 @@ int SphForce::fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool 
 {
   SphForce *f = this;
   *handled = false;
-  if (f->cfg.multistep || ctx->split_min <= 0 || c->n < (size_t)ctx->split_min || c->n >= 0x7fffffffu || f->lit_on)
+  if (f->cfg.multistep || ctx->split_min <= 0 || c->n < (size_t)ctx->split_min || c->n >= 0x7fffffffu || f->lit_on ||
+      f->subset_on)
     return EXP_AMD_OK;
   int rc = expamd_ctx_aux(ctx);
   if (rc) return rc;

@@ -50,6 +50,19 @@ struct SphForce : exp_amd_force {
   double adv_dt_min = 0.0;
   bool part_clean = false;          // d_part is all zero (what the thin accumulation adds to; its summing kernels keep it so)
   bool w_clean = false;             // every per-level moment buffer of d_W is zero (substep_expansion keeps it so)
+  // "ssfrac" (src/SphericalBasis.cc:149-152, :437-440, :459-460, :472-473): the coefficients from a sub-sample of the level
+  // list.  Thread id of `nthrds` takes the entries [n id / nthrds, floor(ssfrac n (id + 1) / nthrds)) of the list -- the
+  // END INDEX is scaled, not the slice length, so with several threads the later slices come out short or empty, as in the
+  // reference -- and a particle's mass is divided by ssfrac.  The level list is the caller's particle order here (the
+  // reference's is the iteration order of its particle map).  exp_amd_sph_set_subset; single-level forces only.
+  bool subset_on = false;
+  double ssfrac = 1.0;
+  int ss_nthrds = 1;
+  exp_amd_comp *ss_comp = nullptr;  // the sub-sample as a component of its own (rebuilt at every accumulation)
+  DevBuf<double> d_ss[4];           // gathered m, x, y, z
+  DevBuf<uint32_t> d_ss_prefix;     // entries of the compacted set in front of each thread's slice
+  size_t ss_cap = 0;
+  int determine_coefficients_subset(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift);
   int step_parity() const override { return work_flip; }
   int multistep_reset() override
   {

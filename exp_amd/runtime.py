@@ -688,11 +688,18 @@ class SphereSL(_Force):
             self.set_fix_l0(True)
 
     @classmethod
-    def from_config(cls, ctx: Context, grid: SLGridSph, conf: dict, multistep: int = 0) -> "SphereSL":
+    def from_config(cls, ctx: Context, grid: SLGridSph, conf: dict, multistep: int = 0, nthrds: int = 1) -> "SphereSL":
         """From the reference's YAML keys (``SphericalBasis::valid_keys``, src/SphericalBasis.cc:30-52): every key is
-        honoured or refused, none dropped (exp_amd/config.py)."""
+        honoured or refused, none dropped (exp_amd/config.py).  ``nthrds``: the run's global thread count (``ssfrac``'s
+        partition of the level list depends on it)."""
         from .config import sphere_from_config
-        return sphere_from_config(cls, ctx, grid, conf, multistep)
+        return sphere_from_config(cls, ctx, grid, conf, multistep, nthrds)
+
+    def set_subset(self, ssfrac: float, nthrds: int = 1) -> None:
+        """``ssfrac`` (src/SphericalBasis.cc:149-152, :437-473): with 0 < ssfrac < 1 the coefficients come from a sub-sample
+        -- thread ``id`` of ``nthrds`` takes [n id / nthrds, floor(ssfrac n (id + 1) / nthrds)) of the level list (here: the
+        caller's particle order), every mass divided by ssfrac.  Any other value switches it off.  Single-level only."""
+        check(self.lib.exp_amd_sph_set_subset(self.h, float(ssfrac), int(nthrds)), self.ctx.h)
 
     def set_fix_l0(self, on: bool = True) -> None:
         """``FIX_L0`` (src/SphericalBasis.cc:1689-1694): the l = 0 row is saved at the next force evaluation and copied

@@ -346,6 +346,14 @@ int  exp_amd_sph_set_exterior(exp_amd_force *f, int continuation);
 /* FIX_L0 (src/SphericalBasis.cc:34, :119, :1689-1694): with on != 0 the next force evaluation saves the l = 0 row of the
  * coefficient set (nmax values) and every later one -- self or external -- copies it back into the active set first.  */
 int  exp_amd_sph_set_fix_l0(exp_amd_force *f, int on);
+/* The "ssfrac" key (src/SphericalBasis.cc:149-152, :437-440, :459-460, :472-473): with 0 < ssfrac < 1 the coefficients are
+ * accumulated from a sub-sample -- thread id of `nthrds` takes the entries [n id / nthrds, floor(ssfrac n (id + 1) / nthrds))
+ * of the level list (the END index is scaled, as in the reference: with several threads the later slices are short or empty)
+ * and every mass is divided by ssfrac.  The level list is the CALLER's particle order (the reference's is the iteration
+ * order of its particle map).  Any other ssfrac switches it off, as the reference's sanity check does.  Single-level forces
+ * only: with block multistep the level lists' order is the history of the level changes (EXP_AMD_ERR_STATE).  The fused
+ * step (exp_amd_step_kdk) then advances the particles in passes of their own.                                         */
+int  exp_amd_sph_set_subset(exp_amd_force *f, double ssfrac, int nthrds);
 /* M0_only in the accumulation: the n-body code skips the m > 0 sums altogether (src/SphericalBasis.cc:550), pyEXP's
  * Spherical::accumulate applies no flag at all (expui/BiorthBasis.cc:583-665: the coefficients it returns hold every m;
  * only the evaluation drops them, :851).  all_m = 1 selects the latter; the default is the former.                */

@@ -243,11 +243,19 @@ void orc_sl_orthocheck(const orc_slgrid *g, int num, const double *knots,
 }
 
 /* ---- per-call options (bfe_oracle.h) ---- */
-static _Thread_local orc_call_opts g_opts = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1};
+static _Thread_local orc_call_opts g_opts = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1, 1.0, 1};
 void orc_set_call_opts(const orc_call_opts *o)
 {
   if (o) g_opts = *o;
-  else { orc_call_opts d = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1}; g_opts = d; }
+  else { orc_call_opts d = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1, 1.0, 1}; g_opts = d; }
+}
+/* `if (ssfrac>0.0 && ssfrac<1.0) subset = true;` (src/SphericalBasis.cc:149-152) */
+int orc_opt_subset(double *ssfrac, int *nthrds)
+{
+  const int on = g_opts.ssfrac > 0.0 && g_opts.ssfrac < 1.0;
+  if (ssfrac) *ssfrac = on ? g_opts.ssfrac : 1.0;
+  if (nthrds) *nthrds = g_opts.nthrds < 1 ? 1 : g_opts.nthrds;
+  return on;
 }
 double orc_opt_adb(void) { return g_opts.adb; }
 int orc_opt_mlim(int mmax) { return (g_opts.mlim >= 0 && g_opts.mlim < mmax) ? g_opts.mlim : mmax; }
@@ -309,9 +317,19 @@ long orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodi
   } while (0)
 
   const double adb = orc_opt_adb();                                   /* :441 */
-  for (long i = 0; i < nbodies; i++) {
+  double ssfrac;
+  int nthrds;
+  const int subset = orc_opt_subset(&ssfrac, &nthrds);
+  /* the threads of the reference one after the other (their partial sums are added up afterwards, :873-887; here into one
+   * set: with the subset off the slices tile the list and the loop is the plain one) */
+  for (int id = 0; id < nthrds; id++) {
+  int nbeg = (int)((unsigned long)nbodies * (unsigned long)id / (unsigned long)nthrds);        /* :438 */
+  int nend = (int)((unsigned long)nbodies * (unsigned long)(id + 1) / (unsigned long)nthrds);  /* :439 */
+  if (subset) nend = (int)floor(ssfrac * nend);                       /* :460 */
+  for (long i = nbeg; i < nend; i++) {
     if (orc_opt_frozen(X[i], Y[i], Z[i])) continue;                   /* :468 */
     double mass = M[i] * adb;                                         /* :471 */
+    if (subset) mass /= ssfrac;                                       /* :473 */
     double xx = X[i] - center[0];
     double yy = Y[i] - center[1];
     double zz = Z[i] - center[2];
@@ -353,6 +371,7 @@ long orc_sph_accumulate(const orc_slgrid *g, const orc_sph_params *P, long nbodi
         }
       }
     }
+  }
   }
 #undef ACC
 

@@ -61,8 +61,14 @@ typedef struct {
   int    frz;
   double rtrunc, com0[3], fcenter[3];
   int    mlim;
+  /* "ssfrac" of SphericalBasis (src/SphericalBasis.cc:149-152): subset when 0 < ssfrac < 1 -- thread id of nthrds walks
+   * [n id / nthrds, floor(ssfrac * (n (id + 1) / nthrds))) of the level list (:438-439, :460) and every mass is divided by
+   * ssfrac (:473).  The level list is the order of the arrays handed in.  nthrds < 1 is read as 1.                     */
+  double ssfrac;
+  int    nthrds;
 } orc_call_opts;
-void   orc_set_call_opts(const orc_call_opts *o);      /* NULL: the defaults (adb 1, no freeze, no mlim) */
+void   orc_set_call_opts(const orc_call_opts *o);      /* NULL: the defaults (adb 1, no freeze, no mlim, no subset) */
+int    orc_opt_subset(double *ssfrac, int *nthrds);    /* 1 when the subset is on */
 double orc_opt_adb(void);
 int    orc_opt_mlim(int mmax);                         /* min(MLIM, MMAX) */
 int    orc_opt_frozen(double x, double y, double z);   /* Component::freeze of the position (component coordinates) */

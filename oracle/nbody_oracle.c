@@ -50,7 +50,11 @@ int orc_cyl_multistep_update(const orc_cylgrid *g, double xx, double yy, double 
  * adb = basis' component->Adiabatic() at tnow, freeze = walked->freeze(), mlim = the basis' */
 static void call_opts(const orc_nbody *S, const orc_nbody_comp *basis, const orc_nbody_comp *walked)
 {
-  orc_call_opts o = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1};
+  orc_call_opts o = {1.0, 0, 1.0e20, {0, 0, 0}, {0, 0, 0}, -1, 1.0, 1};
+  if (basis == walked && basis->ssfrac > 0.0 && basis->ssfrac < 1.0) {      /* (only the accumulation reads it) */
+    o.ssfrac = basis->ssfrac;
+    o.nthrds = basis->ss_nthrds < 1 ? 1 : basis->ss_nthrds;
+  }
   if (basis->adiabatic) o.adb = orc_adiabatic(S->tnow, basis->ton, basis->toff, basis->twid);
   if (walked->has_rtrunc) {
     o.frz = 1;

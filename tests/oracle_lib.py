@@ -88,7 +88,8 @@ class _NBodyComp(ctypes.Structure):
                 ("twid", ctypes.c_double), ("not_self_consistent", ctypes.c_int), ("coef_calls", ctypes.c_int),
                 ("fix_l0", ctypes.c_int), ("have_c0", ctypes.c_int), ("C0", c_double_p),
                 ("mlim", ctypes.c_int), ("has_mlim", ctypes.c_int), ("freeze_lev", ctypes.c_int),
-                ("noswitch", ctypes.c_int), ("no_dtreset", ctypes.c_int), ("dtreq", ctypes.POINTER(ctypes.c_float))]
+                ("noswitch", ctypes.c_int), ("no_dtreset", ctypes.c_int), ("dtreq", ctypes.POINTER(ctypes.c_float)),
+                ("ssfrac", ctypes.c_double), ("ss_nthrds", ctypes.c_int)]
 
 
 class _NBody(ctypes.Structure):
@@ -137,13 +138,14 @@ class NBodyOracle:
         self.inter.append((int(source), int(target)))
 
     def set_options(self, k, rtrunc=None, com0=(0.0, 0.0, 0.0), adiabatic=None, self_consistent=True, fix_l0=False,
-                    mlim=None, freeze_levels=False, noswitch=False, dtreset=True):
+                    mlim=None, freeze_levels=False, noswitch=False, dtreset=True, ssfrac=None, nthrds=1):
         """The keys of component ``k`` that default to off (oracle/nbody_oracle.h): ``rtrunc`` (+ ``com0``),
         ``adiabatic = (ton, toff, twid)``, ``self_consistent``, ``FIX_L0`` (sphere), ``mlim`` (cylinder), ``freezeL``, ``noswitch`` /
-        ``dtreset``."""
+        ``dtreset``, the sphere's ``ssfrac`` (with the thread count ``nthrds`` its partition of the level list depends on)."""
         self.state[k]["options"] = dict(rtrunc=rtrunc, com0=tuple(com0), adiabatic=adiabatic,
                                         self_consistent=self_consistent, fix_l0=fix_l0, mlim=mlim,
-                                        freeze_levels=bool(freeze_levels), noswitch=bool(noswitch), dtreset=bool(dtreset))
+                                        freeze_levels=bool(freeze_levels), noswitch=bool(noswitch), dtreset=bool(dtreset),
+                                        ssfrac=ssfrac, nthrds=int(nthrds))
 
     def _build(self):
         nc = len(self.state)
@@ -180,6 +182,8 @@ class NBodyOracle:
                 if o["mlim"] is not None:
                     c.has_mlim, c.mlim = 1, int(o["mlim"])
                 c.freeze_lev = 1 if o.get("freeze_levels") else 0
+                if o.get("ssfrac") is not None:
+                    c.ssfrac, c.ss_nthrds = float(o["ssfrac"]), int(o.get("nthrds", 1))
                 if o.get("noswitch"):
                     st["dtreq"] = np.zeros(st["n"], np.float32)
                     c.noswitch, c.no_dtreset = 1, 0 if o.get("dtreset", True) else 1
@@ -219,19 +223,22 @@ class NBodyOracle:
 class _CallOpts(ctypes.Structure):
     """orc_call_opts (oracle/bfe_oracle.h)"""
     _fields_ = [("adb", ctypes.c_double), ("frz", ctypes.c_int), ("rtrunc", ctypes.c_double),
-                ("com0", ctypes.c_double * 3), ("fcenter", ctypes.c_double * 3), ("mlim", ctypes.c_int)]
+                ("com0", ctypes.c_double * 3), ("fcenter", ctypes.c_double * 3), ("mlim", ctypes.c_int),
+                ("ssfrac", ctypes.c_double), ("nthrds", ctypes.c_int)]
 
 
 class Oracle:
-    def call_opts(self, adb=1.0, rtrunc=None, com0=(0.0, 0.0, 0.0), fcenter=(0.0, 0.0, 0.0), mlim=None):
+    def call_opts(self, adb=1.0, rtrunc=None, com0=(0.0, 0.0, 0.0), fcenter=(0.0, 0.0, 0.0), mlim=None, ssfrac=None, nthrds=1):
         """Context manager: the per-call options of the thread bodies (Adiabatic factor, Component::freeze of the
-        component walked, the cylinder's mlim) for the oracle calls made inside the ``with`` block."""
+        component walked, the cylinder's mlim, the sphere's ssfrac with its thread count) for the oracle calls made inside
+        the ``with`` block."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
             o = _CallOpts(float(adb), 0 if rtrunc is None else 1, 1e20 if rtrunc is None else float(rtrunc),
-                          (ctypes.c_double * 3)(*com0), (ctypes.c_double * 3)(*fcenter), -1 if mlim is None else int(mlim))
+                          (ctypes.c_double * 3)(*com0), (ctypes.c_double * 3)(*fcenter), -1 if mlim is None else int(mlim),
+                          1.0 if ssfrac is None else float(ssfrac), int(nthrds))
             self.lib.orc_set_call_opts(ctypes.byref(o))
             try:
                 yield

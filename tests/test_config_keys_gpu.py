@@ -50,7 +50,7 @@ SPH_WALK = {
     "NO_L1": (True, "honoured"), "EVEN_L": (True, "honoured"), "EVEN_M": (True, "honoured"), "M0_ONLY": (True, "honoured"),
     "NOISE": (True, "refused"), "noiseN": (1e-3, "honoured"),         # (read only with NOISE, which is refused)
     "noise_model_file": ("x.model", "honoured"), "seedN": (7, "honoured"),
-    "ssfrac": (0.5, "refused"), "playback": ("PLAYBACK_FILE", "honoured"), "coefCompute": (True, "refused"),   # (alone)
+    "ssfrac": (0.5, "honoured"), "playback": ("PLAYBACK_FILE", "honoured"), "coefCompute": (True, "refused"),   # (alone)
     "coefMaster": (False, "honoured"), "orthocheck": (True, "honoured"), "subsampleFloat": (True, "refused"),
     "totalCovar": (True, "refused"), "fullCovar": (True, "refused"),
 }
@@ -96,6 +96,12 @@ def test_every_sphericalbasis_key_is_honoured_or_refused(ctx, oracle, plummer_sm
             assert np.abs(acc - a_base).max() > 1e-6 * np.abs(a_base).max(), key          # ... and it matters
         elif key == "self_consistent":
             assert f.coefs_frozen
+        elif key == "ssfrac":                  # (one thread: the first half of the caller's order, masses doubled)
+            with oracle.call_opts(ssfrac=val, nthrds=1):
+                c_ref, used = oracle.sph_accumulate(g, oracle.params(rmin=g.rmin, rmax=g.rmax), pos, m)
+            assert f.Used() == used < len(m)
+            assert np.abs(coef - c_ref).max() <= 1e-10 * np.abs(c_ref).max()
+            assert np.abs(coef - c_base).max() > 1e-3 * np.abs(c_base).max()              # ... and it matters
         elif key == "FIX_L0":
             c.incr_position(0.1)
             f.determine_coefficients(c)
@@ -108,6 +114,9 @@ def test_every_sphericalbasis_key_is_honoured_or_refused(ctx, oracle, plummer_sm
             assert key in ("noiseN", "noise_model_file", "seedN", "coefMaster")
             assert np.abs(coef - c_base).max() <= 1e-12 * np.abs(c_base).max()      # (same sums, atomics in arrival order)
         c.close(); f.close()
+    with pytest.raises(ValueError, match="multistep"):              # the level lists of a multistep run have no order to reproduce
+        SphereSL.from_config(ctx, g, {"ssfrac": 0.5}, multistep=2)
+    SphereSL.from_config(ctx, g, {"ssfrac": 1.5}, multistep=2).close()      # (not a sane value: ignored, as the reference does)
     # playback: the key names a coefficient file; from_config takes it, start_playback opens it once dtime is known
     out = tmp_path / "outcoef.halo.test"
     with open(out, "wb") as fh:

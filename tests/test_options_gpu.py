@@ -524,3 +524,75 @@ def test_single_component_single_level_run_turns_on_adiabatically(ctx, oracle):
     from math import erf
     fac = 0.25 * (1.0 + erf((nsteps * dtime - adb[0]) / adb[2])) * 2.0
     assert 0.9 < fac < 1.0 and abs(gc[0] / gc_off[0] - fac) < 0.02
+
+
+@pytest.mark.parametrize("ssfrac,nthrds", [(0.5, 1), (0.37, 1), (0.8, 4), (0.3, 3)])
+def test_sphere_subset_against_the_oracle(ctx, oracle, ssfrac, nthrds):
+    """``ssfrac`` (src/SphericalBasis.cc:149-152, :437-440, :459-460, :472-473): thread id of nthrds walks
+    [n id / nthrds, floor(ssfrac * (n (id + 1) / nthrds))) of the level list -- the END index is scaled, so with several
+    threads the later slices come out short or empty -- with every mass divided by ssfrac; Component::freeze and the
+    adiabatic factor apply inside the loop.  The level list is the caller's order.  Coefficients, the in-window count and
+    the forces of ALL particles from the sub-sample's set against the oracle; then the fused step with the key on."""
+    from exp_amd.runtime import Component, SphereSL, do_step_single
+    inp = c4.config4_inputs(n_halo=3001, n_disk=10)
+    g, _ = c4.grids()
+    sc = float(inp["scale"])
+    win = c4.sph_window(g, sc)
+    prm = oracle.params(**win)
+    m, pos, vel = inp["halo_mass"], inp["halo_pos"], inp["halo_vel"]
+    n = len(m)
+    # which particles the reference's loops visit
+    sel = np.zeros(n, bool)
+    for i in range(nthrds):
+        nbeg, nend = n * i // nthrds, n * (i + 1) // nthrds
+        sel[nbeg:int(np.floor(ssfrac * nend))] = True
+    assert 0 < sel.sum() < n
+    rtr, com0, adb = 0.6 * np.abs(pos).max(), (0.002, -0.001, 0.0), 0.7
+    with oracle.call_opts(adb=adb, rtrunc=rtr, com0=com0, ssfrac=ssfrac, nthrds=nthrds):
+        c_ref, used = oracle.sph_accumulate(g, prm, pos, m)
+    with oracle.call_opts(adb=adb, rtrunc=rtr, com0=com0):           # the same set spelled out: the selected particles, m / ssfrac
+        c_sel, used_sel = oracle.sph_accumulate(g, prm, pos[sel], m[sel] / ssfrac)
+    assert used == used_sel and np.abs(c_ref - c_sel).max() <= 1e-13 * np.abs(c_ref).max()
+    f = SphereSL(ctx, g, **win)
+    f.set_subset(ssfrac, nthrds)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    c.set_rtrunc(rtr, com0)
+    f.set_mass_scale(adb)
+    f.determine_coefficients(c)
+    coef = f.get_coefs()
+    assert f.Used() == used
+    assert np.abs(coef - c_ref).max() <= 1e-10 * np.abs(c_ref).max()
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download()
+    assert np.array_equal(out["pos"], pos)                           # the store itself is left as it was
+    with oracle.call_opts(rtrunc=rtr, com0=com0):
+        a_ref, p_ref = oracle.sph_accel(g, prm, pos, coef)
+    own = np.linalg.norm(a_ref, axis=1)
+    ok = own > 0                                                     # (frozen particles are skipped by the force pass: zeros)
+    assert (np.linalg.norm(out["acc"] - a_ref, axis=1)[ok] <= 1e-9 * own[ok]).all()
+    # switched off again (not a sane value): the plain accumulation
+    f.set_subset(0.0, nthrds)
+    f.determine_coefficients(c)
+    with oracle.call_opts(adb=adb, rtrunc=rtr, com0=com0):
+        c_all, used_all = oracle.sph_accumulate(g, prm, pos, m)
+    assert f.Used() == used_all and np.abs(f.get_coefs() - c_all).max() <= 1e-10 * np.abs(c_all).max()
+    # the fused step with the key on == the call-for-call sequence (kick, drift, coefficients of the sub-sample, force, kick)
+    f.set_subset(ssfrac, nthrds)
+    f.set_mass_scale(1.0)
+    c2 = Component.from_arrays(ctx, m, pos, vel)
+    for cc in (c, c2):
+        cc.set_rtrunc(1e20)
+    c.upload(m, pos, vel)
+    for cc in (c, c2):
+        f.determine_coefficients(cc); cc.zero_acceleration(0); f.get_acceleration_and_potential(cc)
+    for _ in range(3):
+        f.step_kdk(c, 1.5e-4)
+        do_step_single(f, c2, 1.5e-4)
+    a, b = c.download(), c2.download()
+    for k in ("pos", "vel", "acc"):
+        assert np.abs(a[k] - b[k]).max() <= 1e-10 * np.abs(b[k]).max(), k
+    for x in (c, c2, f):
+        x.close()
+    with pytest.raises(RuntimeError, match="multistep"):
+        SphereSL(ctx, g, multistep=2, **win).set_subset(0.5, 1)
