@@ -730,6 +730,8 @@ def main():
         print("probe rank=%s local_rank=%s world=%s addr=%s" % (os.environ["RANK"], os.environ["LOCAL_RANK"],
               os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"]), flush=True)
         raise SystemExit(int(code) if (not who or who == os.environ["RANK"]) else 0)
+    # (multi-process GPU work on this pool needs dmabuf IPC: already exported where the driver runs; kept for any other shell)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

@@ -107,9 +107,17 @@ def trial_sph(t, rng):
     ctr = rng.normal(0, 0.3, 3) * scale if rng.random() < 0.5 else np.zeros(3)
     m, pos, lad = nasty_sphere(rng, model, g, scale, rmin, rmax, ctr)
     prm = orc.params(scale=scale, rmin=rmin, rmax=rmax, **flags)
-    c_ref, used_ref = orc.sph_accumulate(g, prm, pos, m, center=ctr)
+    # (round 6) one trial in five with the "ssfrac" key on: a sub-sample of the caller's order, 1-5 threads
+    # (src/SphericalBasis.cc:437-473; its own generator, so that the other trials of a seed stay what they were)
+    srng = np.random.default_rng([int(t), 6])
+    ssfrac, nthrds = (float(srng.uniform(0.05, 0.95)), int(srng.integers(1, 6))) if srng.random() < 0.2 else (None, 1)
+    with orc.call_opts(ssfrac=ssfrac, nthrds=nthrds):
+        c_ref, used_ref = orc.sph_accumulate(g, prm, pos, m, center=ctr)
     a_ref, p_ref = orc.sph_accel(g, prm, pos, c_ref, center=ctr)
     f = SphereSL(ctx, g, scale=scale, rmin=rmin, rmax=rmax, **flags)
+    if ssfrac is not None:
+        f.set_subset(ssfrac, nthrds)
+        key = key + (f"ssfrac {ssfrac:.3f}/{nthrds}",)
     c = Component.from_arrays(ctx, m, pos)
     c.set_center(ctr)
     f.determine_coefficients(c)
