@@ -147,3 +147,16 @@ def test_two_ranks_with_no_launcher(one_rank):
     lines = _json_lines(p.stdout)
     assert len(lines) == 1, p.stdout[-3000:]
     _check_two(lines[0], one_rank, graph=False)
+
+
+def test_split_step_flag_is_the_same_run(one_rank):
+    """`bench.py --split` (the opt-in two-half-shard fused step, sort passes on a second stream: profiles/r06_overlap_ab.txt)
+    is the same run: the coefficient set differs from the plain step's only in the order of its sums."""
+    line, _ = _bench(SMALL + ["--split"])
+    assert "SPLIT" in line["stepping"] and line["n_gpus"] == 1
+    sc, sc1 = line["selfcheck"], one_rank["selfcheck"]
+    assert sc["used_rank0"] == sc1["used_rank0"]
+    assert sc["coef_00_0"] == pytest.approx(sc1["coef_00_0"], rel=1e-12)
+    for a, b in zip(sc["center_of_mass"], sc1["center_of_mass"]):
+        assert abs(a - b) <= 1e-12
+    assert "k_scatter_adv" in line["roofline"]["kernels_ms_per_step"]
