@@ -61,6 +61,7 @@ SIGNATURES = {
     "exp_amd_force_coefs_frozen": (c_int, [c_void_p]),
     "exp_amd_sph_set_fix_l0": (c_int, [c_void_p, c_int]),
     "exp_amd_sph_set_subset": (c_int, [c_void_p, c_double, c_int]),
+    "exp_amd_sph_set_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_uint]),
     "exp_amd_cyl_set_mlim": (c_int, [c_void_p, c_int]),
     "exp_amd_sim_set_adiabatic": (c_int, [c_void_p, c_int, c_double, c_double, c_double]),
     "exp_amd_sim_set_time": (c_int, [c_void_p, c_double]),

@@ -52,9 +52,20 @@ def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0, nthrds: i
     name = "SphericalBasis"
     g = conf.get
     # ---- refused when they ask for something (defaults of src/SphericalBasis.cc:66-90) ------------------------------
+    noise = None
     if "NOISE" in conf and _bool(conf["NOISE"]):
-        raise _refuse(name, "NOISE", conf["NOISE"], "the noise-model coefficients (src/SphericalBasis.cc:907-1000) are not "
-                      "on the device path")
+        # update_noise (src/SphericalBasis.cc:2150-2210) with compute_rms_coefs (:2108-2147) of `noise_model_file`.  Two quirks of
+        # the reference, kept: `noiseN` is read `.as<bool>()` (:143) -- any true value is 1.0, a false one 0.0 (a division by
+        # zero there), the default 1e-6 only when the key is absent -- and `seedN` has no default at all (an uninitialised
+        # member, src/SphericalBasis.H:339): it must be given here
+        if "seedN" not in conf:
+            raise _refuse(name, "NOISE", conf["NOISE"], "NOISE needs `seedN`: the reference seeds its generator with an "
+                          "uninitialised member when the key is absent (src/SphericalBasis.H:339, src/SphericalBasis.cc:147)")
+        noise = (str(g("noise_model_file", "SLGridSph.model")),
+                 (1.0 if _bool(conf["noiseN"]) else 0.0) if "noiseN" in conf else 1.0e-6, int(conf["seedN"]))
+        if noise[1] == 0.0:
+            raise _refuse(name, "noiseN", conf["noiseN"], "read as a boolean by the reference (src/SphericalBasis.cc:143): "
+                          "false is a division by zero in update_noise (:2197)")
     ss = float(g("ssfrac", 0.0))
     if 0.0 < ss < 1.0 and multistep > 0:
         # `subset`: thread id walks [n id / nthrds, floor(ssfrac n (id + 1) / nthrds)) of every LEVEL list (src/SphericalBasis.cc:
@@ -66,7 +77,7 @@ def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0, nthrds: i
             raise _refuse(name, key, conf[key], "the n-body sub-sample covariance (nint, src/SphericalBasis.cc:700-720) is "
                           "not driven from here; SphereSL.cov_enable / cov_accumulate give the pyEXP form of it")
     # ---- honoured ------------------------------------------------------------------------------------------------------
-    # (noiseN, noise_model_file, seedN are only read when NOISE is on; coefMaster says which rank writes the coefficient
+    # (noiseN, noise_model_file, seedN are only read when NOISE is on: above; coefMaster says which rank writes the coefficient
     # file: the one process that calls dump_coefs here)
     kw = dict(scale=float(g("scale", 1.0)),
               NO_L0=_bool(g("NO_L0", False)), NO_L1=_bool(g("NO_L1", False)), EVEN_L=_bool(g("EVEN_L", False)),
@@ -76,6 +87,8 @@ def sphere_from_config(cls, ctx, grid, conf: dict, multistep: int = 0, nthrds: i
     rmin = max(float(g("rmin", 0.0)), grid.rmin) if "rmin" in conf else grid.rmin
     rmax = min(float(g("rmax", grid.rmax)), grid.rmax) if "rmax" in conf else grid.rmax
     f = cls(ctx, grid, rmin=rmin, rmax=rmax, **kw)
+    if noise is not None:
+        f.set_noise(noise[0], noiseN=noise[1], seedN=noise[2])
     if 0.0 < ss < 1.0:
         # (the level list of a single-level run is the caller's particle order here; the reference's is the iteration order
         # of its particle map -- exp_amd_sph_set_subset, include/exp_amd.h)

@@ -693,6 +693,73 @@ int SphForce::determine_coefficients_subset(exp_amd_comp *c, bool advance, doubl
   return rc;
 }
 
+// SphericalBasis::update_noise (src/SphericalBasis.cc:2150-2210): see sph_force.h
+int SphForce::update_noise(bool self_call)
+{
+  SphForce *f = this;
+  const int L = f->cfg.lmax, nmax = f->cfg.nmax;
+  if (f->noise_setup) {
+    f->noise_setup = false;                       // "Only do this initialization once"
+    f->rgen.seed(f->seedN);
+  }
+  f->noise_calls++;
+  f->n_host.assign(f->ncoef, 0.0);
+  for (int l = 0, loffset = 0; l <= L; loffset += (2 * l + 1), l++) {
+    for (int m = 0, moffset = 0; m <= l; m++) {
+      double fac = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * factrl(l - m) / factrl(l + m));     // factorial(l, m), :328-333
+      if (m) fac *= M_SQRT2;
+      if (m == 0) {
+        for (int n = 0; n < nmax; n++) {
+          double v = sqrt(fabs(f->n_rms[(size_t)l * nmax + n] - f->n_mean[n] * f->n_mean[n]) * fac / f->noiseN) * f->nrand(f->rgen);
+          if (l == 0) v += f->n_mean[n];
+          f->n_host[(size_t)(loffset + moffset) * nmax + n] = v;
+        }
+        moffset++;
+      } else {
+        for (int n = 0; n < nmax; n++) {
+          const double a = sqrt(fabs(f->n_rms[(size_t)l * nmax + n] - f->n_mean[n] * f->n_mean[n]) * fac / f->noiseN);
+          f->n_host[(size_t)(loffset + moffset + 0) * nmax + n] = a * f->nrand(f->rgen);
+          f->n_host[(size_t)(loffset + moffset + 1) * nmax + n] = a * f->nrand(f->rgen);
+        }
+        moffset += 2;
+      }
+    }
+  }
+  // a self call of a multistep force: compute_multistep_coefficients runs AFTER update_noise and rebuilds the set from the
+  // per-level ones (:395 then :1680-1685) -- the draws are consumed, the set is not touched
+  if (self_call && f->cfg.multistep && (f->self_consistent || f->initializing)) return EXP_AMD_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, f->n_host.data(), f->ncoef * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // (n_host is rewritten by the next call)
+  f->proj_dirty = true;
+  return EXP_AMD_OK;
+}
+
+// The NOISE keys: meanC[nmax], rmsC[(lmax+1)][nmax] of SphericalBasis::compute_rms_coefs (:2108-2147), noiseN, seedN.
+// meanC == NULL switches the mode off.  Setting it (re)starts the generator: the next evaluation seeds it.
+extern "C" int exp_amd_sph_set_noise(exp_amd_force *fb, const double *meanC, const double *rmsC, double noiseN, unsigned seedN)
+{
+  expamd_mutated();
+  SphForce *f = dynamic_cast<SphForce *>(fb);
+  if (!f) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "set_noise: not a spherical force");
+  if (!meanC) {
+    f->noise_on = false;
+    f->accel_writes_coef = f->fix_l0;
+    return EXP_AMD_OK;
+  }
+  if (!rmsC) return expamd_fail(f->ctx, EXP_AMD_ERR_ARG, "set_noise: rmsC is NULL");
+  const int L = f->cfg.lmax, nmax = f->cfg.nmax;
+  f->n_mean.assign(meanC, meanC + nmax);
+  f->n_rms.assign(rmsC, rmsC + (size_t)(L + 1) * nmax);
+  f->noiseN = noiseN;
+  f->seedN = seedN;
+  f->noise_setup = true;
+  f->nrand.reset();                               // (no deviate saved from an earlier run of the mode)
+  f->noise_calls = 0;
+  f->noise_on = true;
+  f->accel_writes_coef = true;                    // the evaluation itself writes the coefficient set (host.hip: ev_self ordering)
+  return EXP_AMD_OK;
+}
+
 // The "ssfrac" key (src/SphericalBasis.cc:149-152: taken when 0 < ssfrac < 1, ignored otherwise) with the thread count the
 // reference's partition of the level list depends on (`nthrds`, src/SphericalBasis.cc:438-439)
 extern "C" int exp_amd_sph_set_subset(exp_amd_force *fb, double ssfrac, int nthrds)
@@ -938,6 +1005,8 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
     if ((rc = expamd_comp_level_count(t, f->mlevel, t->nlevels - 1, &nthin))) return rc;
     thin = (long long)nthin <= ctx->thin_max;
   }
+  // `if (NOISE) update_noise();` opens get_acceleration_and_potential, for self and external calls alike (:395)
+  if (f->noise_on && (rc = f->update_noise(!external))) return rc;
   if (f->fix_l0) {
     // "Save the monopole coefficients on the first evaluation / Copy the saved coefficients to the active array"
     // (src/SphericalBasis.cc:1689-1694; outside the use_external test: self and external calls alike)
@@ -1374,7 +1443,7 @@ extern "C" int exp_amd_sph_set_fix_l0(exp_amd_force *fb, int on)
   if (on && !f->d_c0.p && f->d_c0.alloc((size_t)f->cfg.nmax) != hipSuccess)
     return expamd_fail(f->ctx, EXP_AMD_ERR_HIP, "set_fix_l0: hipMalloc failed");
   f->fix_l0 = on != 0;
-  f->accel_writes_coef = f->fix_l0;
+  f->accel_writes_coef = f->fix_l0 || f->noise_on;
   f->have_c0 = false;
   return EXP_AMD_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "sph_kernels.h"
 #include "force.h"
+#include <random>
 
 struct SphForce : exp_amd_force {
   exp_amd_sph_config cfg{};
@@ -63,6 +64,20 @@ struct SphForce : exp_amd_force {
   DevBuf<uint32_t> d_ss_prefix;     // entries of the compacted set in front of each thread's slice
   size_t ss_cap = 0;
   int determine_coefficients_subset(exp_amd_comp *c, bool advance, double dt_kick, double dt_drift);
+  // The NOISE keys (src/SphericalBasis.cc:79-81, :135-147, :355, :395, :2108-2210): every get_acceleration_and_potential call
+  // REPLACES the coefficient set by draws from a noise model -- sqrt(|rmsC(l,n) - meanC[n]^2| factorial(l,m) / noiseN) times a
+  // standard normal deviate, plus meanC[n] on the l = 0 row -- from one std::mt19937 / std::normal_distribution pair seeded
+  // once with seedN (the same standard-library objects the reference holds, :340-341 of its header).  A self call of a
+  // multistep force draws too and is then overwritten by compute_multistep_coefficients (:1680-1685), so nothing is uploaded
+  // for it.  exp_amd_sph_set_noise; meanC / rmsC come from the host (SphericalBasis::compute_rms_coefs, exp_amd/slgrid.py).
+  bool noise_on = false, noise_setup = true;
+  std::vector<double> n_mean, n_rms, n_host;
+  double noiseN = 1.0e-6;
+  unsigned seedN = 0;
+  std::mt19937 rgen;
+  std::normal_distribution<> nrand;
+  long long noise_calls = 0;
+  int update_noise(bool self_call);
   int step_parity() const override { return work_flip; }
   int multistep_reset() override
   {

@@ -695,6 +695,21 @@ class SphereSL(_Force):
         from .config import sphere_from_config
         return sphere_from_config(cls, ctx, grid, conf, multistep, nthrds)
 
+    def set_noise(self, model_file: Optional[str], noiseN: float = 1.0e-6, seedN: int = 0, scale: Optional[float] = None) -> None:
+        """The ``NOISE`` mode (src/SphericalBasis.cc:355, :395, :2108-2210): every force evaluation replaces the coefficient
+        set by draws from the noise model of ``noise_model_file`` -- ``compute_rms_coefs`` on the host
+        (exp_amd.slgrid.compute_rms_coefs), ``update_noise`` inside the library with the reference's own
+        std::mt19937 / std::normal_distribution pair.  ``model_file = None`` switches it off."""
+        from .slgrid import compute_rms_coefs
+        if model_file is None:
+            check(self.lib.exp_amd_sph_set_noise(self.h, None, None, 1.0, 0), self.ctx.h)
+            self.noise = None
+            return
+        meanC, rmsC = compute_rms_coefs(self.grid, model_file, float(self.cfg.scale) if scale is None else float(scale))
+        km, kr = as_f64(meanC), as_f64(rmsC)
+        check(self.lib.exp_amd_sph_set_noise(self.h, km[1], kr[1], float(noiseN), int(seedN) & 0xffffffff), self.ctx.h)
+        self.noise = (meanC, rmsC, float(noiseN), int(seedN) & 0xffffffff)
+
     def set_subset(self, ssfrac: float, nthrds: int = 1) -> None:
         """``ssfrac`` (src/SphericalBasis.cc:149-152, :437-473): with 0 < ssfrac < 1 the coefficients come from a sub-sample
         -- thread ``id`` of ``nthrds`` takes [n id / nthrds, floor(ssfrac n (id + 1) / nthrds)) of the level list (here: the

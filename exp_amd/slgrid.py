@@ -345,3 +345,64 @@ def orthocheck(g: "SLGridSph", num: int = 200):
 def orthocheck_max(g: "SLGridSph", num: int = 200) -> float:
     """worst deviation from the identity (what exputil/orthoTest.cc:19-87 holds against orthoTol = 1e-2)"""
     return float(max(np.abs(m - np.eye(g.nmax)).max() for m in orthocheck(g, num)))
+
+
+def read_model_table(path: str):
+    """The four columns (r, density, mass, potential) of a ``SphericalModelTable`` file (exputil/massmodel.cc:23-96): lines
+    with a '#' or '!' anywhere in them are skipped, the first other line holds the number of rows."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    k = 0
+    while k < len(lines) and ("#" in lines[k] or "!" in lines[k]):
+        k += 1
+    num = int(lines[k].split()[0])
+    rows = np.array([[float(v) for v in ln.split()[:4]] for ln in lines[k + 1:k + 1 + num]], dtype=np.float64)
+    return rows[:, 0].copy(), rows[:, 1].copy(), rows[:, 2].copy(), rows[:, 3].copy()
+
+
+def model_density(rtab: np.ndarray, dtab: np.ndarray, r: float) -> float:
+    """``SphericalModelTable::get_density`` with the class defaults ``linear = 1``, ``even = 0``, no divergence
+    (exputil/massmodel.cc:19-20, :266-291): the last table value beyond the table, else ``odd2`` -- linear interpolation on the
+    interval ``Vlocate`` finds (exputil/Vodd2.cc:49-70, Vlocate.cc:50-66)."""
+    if r > rtab[-1]:
+        return float(dtab[-1])
+    n = len(rtab)
+    jl, ju = -1, n
+    ascnd = rtab[-1] > rtab[0]
+    while ju - jl > 1:
+        jm = (ju + jl) >> 1
+        if (r > rtab[jm]) == ascnd:
+            jl = jm
+        else:
+            ju = jm
+    i = min(max(jl, 0), n - 2)
+    return float((dtab[i + 1] * (r - rtab[i]) - dtab[i] * (r - rtab[i + 1])) / (rtab[i + 1] - rtab[i]))
+
+
+def get_pot(g: "SLGridSph", r: float) -> np.ndarray:
+    """``SLGridSph::get_pot(mat, r)`` (exputil/SLGridMP2.cc:872-910): [lmax+1, nmax]"""
+    x = float(g.r_to_xi(r))
+    i = min(max(int((x - g.xmin) / g.dxi), 0), g.numr - 2)
+    x1, x2 = (g.xi[i + 1] - x) / g.dxi, (x - g.xi[i]) / g.dxi
+    return (x1 * g.ef[:, :, i] + x2 * g.ef[:, :, i + 1]) / np.sqrt(g.ev) * (x1 * g.p0[i] + x2 * g.p0[i + 1])
+
+
+def compute_rms_coefs(g: "SLGridSph", model_file: str, scale: float = 1.0, numg: int = 100):
+    """``SphericalBasis::compute_rms_coefs`` (src/SphericalBasis.cc:2108-2147): the mean of the l = 0 coefficients and the mean
+    square of every (l, n) coefficient of ONE particle drawn from the density of ``noise_model_file``, by a 100-point
+    Gauss-Legendre rule in radius over the table's range; ``sqnorm`` is 1 for the Sturm-Liouville basis (Sphere).  Returns
+    (meanC[nmax], rmsC[lmax+1, nmax]) -- what ``exp_amd_sph_set_noise`` takes."""
+    from numpy.polynomial import legendre as npleg
+    rt, dt, _, _ = read_model_table(model_file)
+    x, w = npleg.leggauss(int(numg))
+    knots, weights = 0.5 * (x + 1.0), 0.5 * w               # LegeQuad: on [0, 1] (tests/test_ref_util.py pins them)
+    rmin, rmax = float(rt[0]), float(rt[-1])
+    dl = rmax - rmin
+    meanC, rmsC = np.zeros(g.nmax), np.zeros((g.lmax + 1, g.nmax))
+    for i in range(int(numg)):
+        r = rmin + dl * knots[i]
+        pot = get_pot(g, r / scale) / 1.0 / scale
+        fac = dl * weights[i] * r * r * 4.0 * np.pi * model_density(rt, dt, r)
+        meanC += fac * pot[0]
+        rmsC += fac * pot * pot
+    return meanC, rmsC

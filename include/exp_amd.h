@@ -354,6 +354,15 @@ int  exp_amd_sph_set_fix_l0(exp_amd_force *f, int on);
  * only: with block multistep the level lists' order is the history of the level changes (EXP_AMD_ERR_STATE).  The fused
  * step (exp_amd_step_kdk) then advances the particles in passes of their own.                                         */
 int  exp_amd_sph_set_subset(exp_amd_force *f, double ssfrac, int nthrds);
+/* The NOISE keys of SphericalBasis (`NOISE`, `noiseN`, `noise_model_file`, `seedN`: src/SphericalBasis.cc:79-81, :135-147): every
+ * force evaluation -- self or external, `if (NOISE) update_noise();` opens get_acceleration_and_potential, :395 -- replaces the
+ * coefficient set by draws from the noise model (update_noise, :2150-2210): sqrt(|rmsC(l,n) - meanC[n]^2| factorial(l,m) / noiseN)
+ * times a standard normal deviate, plus meanC[n] on the l = 0 row; one std::mt19937 + std::normal_distribution per force,
+ * seeded with seedN at the first evaluation after this call.  A self call of a multistep force consumes its draws and leaves
+ * the set alone (compute_multistep_coefficients rebuilds it right after, :1680-1685).  meanC[nmax] and rmsC[lmax+1][nmax] are
+ * SphericalBasis::compute_rms_coefs (:2108-2147) of the noise model file, computed on the host (exp_amd/slgrid.py:
+ * compute_rms_coefs).  meanC == NULL switches the mode off.                                                             */
+int  exp_amd_sph_set_noise(exp_amd_force *f, const double *meanC, const double *rmsC, double noiseN, unsigned seedN);
 /* M0_only in the accumulation: the n-body code skips the m > 0 sums altogether (src/SphericalBasis.cc:550), pyEXP's
  * Spherical::accumulate applies no flag at all (expui/BiorthBasis.cc:583-665: the coefficients it returns hold every m;
  * only the evaluation drops them, :851).  all_m = 1 selects the latter; the default is the former.                */

@@ -69,6 +69,14 @@ typedef struct {
 } orc_call_opts;
 void   orc_set_call_opts(const orc_call_opts *o);      /* NULL: the defaults (adb 1, no freeze, no mlim, no subset) */
 int    orc_opt_subset(double *ssfrac, int *nthrds);    /* 1 when the subset is on */
+
+/* The NOISE mode (noise_oracle.cc, C++: the reference's std::mt19937 / std::normal_distribution): compute_rms_coefs
+ * (src/SphericalBasis.cc:2108-2147) and update_noise (:2150-2210)                                                    */
+void   orc_sph_compute_rms_coefs(const orc_slgrid *g, double scale, int num, const double *rtab, const double *dtab,
+                                 int numg, const double *knot, const double *weight, double *meanC, double *rmsC);
+void  *orc_noise_create(int lmax, int nmax, const double *meanC, const double *rmsC, double noiseN, unsigned seedN);
+void   orc_noise_update(void *h, double *expcoef);     /* [(lmax+1)^2][nmax] */
+void   orc_noise_destroy(void *h);
 double orc_opt_adb(void);
 int    orc_opt_mlim(int mmax);                         /* min(MLIM, MMAX) */
 int    orc_opt_frozen(double x, double y, double z);   /* Component::freeze of the position (component coordinates) */

@@ -177,6 +177,14 @@ static void combine(const orc_nbody *S, const orc_mstep_tables *T, orc_nbody_com
 /* one force method applied to the particles of `t` with level >= mlevel */
 static void apply_force(const orc_nbody *S, orc_nbody_comp *src, orc_nbody_comp *t, int mlevel)
 {
+  if (src->kind == 0 && src->noise) {
+    /* `if (NOISE) update_noise();` opens get_acceleration_and_potential (src/SphericalBasis.cc:395); the self call of a
+     * multistep force then rebuilds the set from the per-level ones (:1680-1685: combine() has run above), an external call
+     * and a single-level self call evaluate the draws */
+    orc_noise_update(src->noise, src->noise_buf);
+    const int rebuilt = src == t && S->multistep && (!src->not_self_consistent || S->initializing);
+    if (!rebuilt) memcpy(src->coef, src->noise_buf, sizeof(double) * src->ncoef);
+  }
   if (src->kind == 0 && src->fix_l0) {            /* src/SphericalBasis.cc:1689-1694 (self and external calls alike) */
     const int nmax = src->sg->nmax;
     if (!src->have_c0) { memcpy(src->C0, src->coef, sizeof(double) * nmax); src->have_c0 = 1; }

@@ -54,6 +54,8 @@ typedef struct {
                                  step (mdrft == Mstep) or on the first call (src/multistep.cc:136-147)            */
   int no_dtreset;             /* "dtreset: false" (:254, :1038): dtreq is not reset at mstep == 0 (src/multistep.cc:137)      */
   float *dtreq;               /* [n] Particle::dtreq when noswitch (caller's storage)                                         */
+  void *noise;                /* the sphere's NOISE mode: orc_noise_create's handle (NULL: off) and [ncoef] of scratch; every force  */
+  double *noise_buf;          /* evaluation, self or external, draws a set first (src/SphericalBasis.cc:395, :2150-2210)              */
   double ssfrac;              /* the sphere's "ssfrac" key (src/SphericalBasis.cc:149-152; subset when 0 < ssfrac < 1) ...      */
   int ss_nthrds;              /* ... and the thread count its partition of the level list depends on (0 is read as 1)         */
 } orc_nbody_comp;

@@ -89,6 +89,7 @@ class _NBodyComp(ctypes.Structure):
                 ("fix_l0", ctypes.c_int), ("have_c0", ctypes.c_int), ("C0", c_double_p),
                 ("mlim", ctypes.c_int), ("has_mlim", ctypes.c_int), ("freeze_lev", ctypes.c_int),
                 ("noswitch", ctypes.c_int), ("no_dtreset", ctypes.c_int), ("dtreq", ctypes.POINTER(ctypes.c_float)),
+                ("noise", ctypes.c_void_p), ("noise_buf", c_double_p),
                 ("ssfrac", ctypes.c_double), ("ss_nthrds", ctypes.c_int)]
 
 
@@ -138,14 +139,15 @@ class NBodyOracle:
         self.inter.append((int(source), int(target)))
 
     def set_options(self, k, rtrunc=None, com0=(0.0, 0.0, 0.0), adiabatic=None, self_consistent=True, fix_l0=False,
-                    mlim=None, freeze_levels=False, noswitch=False, dtreset=True, ssfrac=None, nthrds=1):
+                    mlim=None, freeze_levels=False, noswitch=False, dtreset=True, ssfrac=None, nthrds=1, noise=None):
         """The keys of component ``k`` that default to off (oracle/nbody_oracle.h): ``rtrunc`` (+ ``com0``),
         ``adiabatic = (ton, toff, twid)``, ``self_consistent``, ``FIX_L0`` (sphere), ``mlim`` (cylinder), ``freezeL``, ``noswitch`` /
-        ``dtreset``, the sphere's ``ssfrac`` (with the thread count ``nthrds`` its partition of the level list depends on)."""
+        ``dtreset``, the sphere's ``ssfrac`` (with the thread count ``nthrds`` its partition of the level list depends on) and
+        ``noise = (meanC, rmsC, noiseN, seedN)`` (the NOISE mode: ``Oracle.noise_create`` is called with it)."""
         self.state[k]["options"] = dict(rtrunc=rtrunc, com0=tuple(com0), adiabatic=adiabatic,
                                         self_consistent=self_consistent, fix_l0=fix_l0, mlim=mlim,
                                         freeze_levels=bool(freeze_levels), noswitch=bool(noswitch), dtreset=bool(dtreset),
-                                        ssfrac=ssfrac, nthrds=int(nthrds))
+                                        ssfrac=ssfrac, nthrds=int(nthrds), noise=noise)
 
     def _build(self):
         nc = len(self.state)
@@ -184,6 +186,10 @@ class NBodyOracle:
                 c.freeze_lev = 1 if o.get("freeze_levels") else 0
                 if o.get("ssfrac") is not None:
                     c.ssfrac, c.ss_nthrds = float(o["ssfrac"]), int(o.get("nthrds", 1))
+                if o.get("noise") is not None:
+                    st["noise_handle"] = self.orc.noise_create(G.lmax, G.nmax, *o["noise"])
+                    st["noise_buf"] = np.zeros(st["ncoef"])
+                    c.noise, c.noise_buf = st["noise_handle"], _dp(st["noise_buf"])
                 if o.get("noswitch"):
                     st["dtreq"] = np.zeros(st["n"], np.float32)
                     c.noswitch, c.no_dtreset = 1, 0 if o.get("dtreset", True) else 1
@@ -727,6 +733,31 @@ class Oracle:
                                _dp(cc), _dp(ss), ctypes.c_double(cylmass), _dp(ax), _dp(ay),
                                _dp(az), _dp(pot))
         return np.stack([ax, ay, az], axis=1), pot
+
+    # -- the NOISE mode (oracle/noise_oracle.cc) --------------------------------------------------
+    def sph_compute_rms_coefs(self, g, rtab, dtab, scale=1.0, numg=100):
+        """SphericalBasis::compute_rms_coefs (src/SphericalBasis.cc:2108-2147) -> (meanC[nmax], rmsC[lmax+1, nmax])"""
+        from numpy.polynomial import legendre as npleg
+        x, w = npleg.leggauss(int(numg))
+        kn, wt = np.ascontiguousarray(0.5 * (x + 1.0)), np.ascontiguousarray(0.5 * w)
+        G = self.grid(g)
+        rt, dt = np.ascontiguousarray(rtab, dtype=np.float64), np.ascontiguousarray(dtab, dtype=np.float64)
+        meanC, rmsC = np.zeros(g.nmax), np.zeros((g.lmax + 1, g.nmax))
+        self.lib.orc_sph_compute_rms_coefs(ctypes.byref(G), ctypes.c_double(scale), ctypes.c_int(len(rt)), _dp(rt), _dp(dt),
+                                           ctypes.c_int(int(numg)), _dp(kn), _dp(wt), _dp(meanC), _dp(rmsC))
+        return meanC, rmsC
+
+    def noise_create(self, lmax, nmax, meanC, rmsC, noiseN, seedN):
+        self.lib.orc_noise_create.restype = ctypes.c_void_p
+        m, r = np.ascontiguousarray(meanC, dtype=np.float64), np.ascontiguousarray(rmsC, dtype=np.float64)
+        return ctypes.c_void_p(self.lib.orc_noise_create(ctypes.c_int(lmax), ctypes.c_int(nmax), _dp(m), _dp(r),
+                                                         ctypes.c_double(noiseN), ctypes.c_uint(int(seedN) & 0xffffffff)))
+
+    def noise_update(self, handle, lmax, nmax):
+        """one SphericalBasis::update_noise (src/SphericalBasis.cc:2150-2210) -> [(lmax+1)^2, nmax]"""
+        out = np.zeros(((lmax + 1) ** 2, nmax))
+        self.lib.orc_noise_update(handle, _dp(out))
+        return out
 
     def cyl_fields(self, g, cosN, sinN, c1, c2, c3, coord="cartesian", **kw):
         """pyEXP Cylindrical::sph_eval / cyl_eval / crt_eval (expui/BiorthBasis.cc:1749-1849)."""

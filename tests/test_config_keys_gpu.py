@@ -48,7 +48,7 @@ SPH_WALK = {
     "scale": (2.0, "honoured"), "rmin": (0.4, "honoured"), "rmax": (10.0, "honoured"),
     "self_consistent": (False, "honoured"), "FIX_L0": (True, "honoured"), "NO_L0": (True, "honoured"),
     "NO_L1": (True, "honoured"), "EVEN_L": (True, "honoured"), "EVEN_M": (True, "honoured"), "M0_ONLY": (True, "honoured"),
-    "NOISE": (True, "refused"), "noiseN": (1e-3, "honoured"),         # (read only with NOISE, which is refused)
+    "NOISE": (True, "refused"), "noiseN": (1e-3, "honoured"),         # (NOISE alone: refused for want of seedN; the mode itself: below)
     "noise_model_file": ("x.model", "honoured"), "seedN": (7, "honoured"),
     "ssfrac": (0.5, "honoured"), "playback": ("PLAYBACK_FILE", "honoured"), "coefCompute": (True, "refused"),   # (alone)
     "coefMaster": (False, "honoured"), "orthocheck": (True, "honoured"), "subsampleFloat": (True, "refused"),
@@ -114,6 +114,13 @@ def test_every_sphericalbasis_key_is_honoured_or_refused(ctx, oracle, plummer_sm
             assert key in ("noiseN", "noise_model_file", "seedN", "coefMaster")
             assert np.abs(coef - c_base).max() <= 1e-12 * np.abs(c_base).max()      # (same sums, atomics in arrival order)
         c.close(); f.close()
+    # NOISE with its seed: every evaluation replaces the set by draws (tests/test_options_gpu.py holds them against the oracle)
+    f = SphereSL.from_config(ctx, g, {"NOISE": True, "seedN": 5, "noise_model_file": os.path.join(os.path.dirname(__file__),
+                                                                                                 "golden", "SLGridSph.model")})
+    c = Component.from_arrays(ctx, m, pos)
+    f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+    assert np.abs(f.get_coefs() - c_base).max() > 1e-3 * np.abs(c_base).max()
+    c.close(); f.close()
     with pytest.raises(ValueError, match="multistep"):              # the level lists of a multistep run have no order to reproduce
         SphereSL.from_config(ctx, g, {"ssfrac": 0.5}, multistep=2)
     SphereSL.from_config(ctx, g, {"ssfrac": 1.5}, multistep=2).close()      # (not a sane value: ignored, as the reference does)

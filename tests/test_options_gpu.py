@@ -9,6 +9,8 @@ a13 / a15 -- the option branches inside the cited line ranges):
 * ``mlim`` (src/Cylinder.cc:225; exputil/EmpCylSL.cc:5317, :5465, :5602).
 
 Bars as everywhere: coefficients 1e-10 of the largest, accelerations / potentials 1e-9.  GPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -275,6 +277,8 @@ def _driver_run(ctx, inp, opts_h, opts_d, ms, dtime, nsteps):
             c.set_rtrunc(o["rtrunc"], o.get("com0"))
         if o.get("adiabatic") is not None:
             sim.set_adiabatic(k, *o["adiabatic"])
+        if o.get("noise") is not None and k == ih:
+            fh.set_noise(NOISE_MODEL, noiseN=o["noise"][0], seedN=o["noise"][1])
         if o.get("freeze_levels") or o.get("noswitch"):
             c.set_level_policy(noswitch=o.get("noswitch", False), freeze_levels=o.get("freeze_levels", False),
                                dtreset=o.get("dtreset", True))
@@ -293,7 +297,22 @@ SCENARIOS = [
     # "noswitch" / "dtreset" (src/multistep.cc:136-147): dtreq keeps the smallest step asked for, levels move at the end of a master step
     (dict(noswitch=True), dict()),
     (dict(noswitch=True, dtreset=False), dict(noswitch=True)),
+    # NOISE (src/SphericalBasis.cc:395, :2150-2210): the halo's self calls consume their draws and keep the combined set
+    # (multistep: compute_multistep_coefficients follows), its force on the disk is evaluated from the draws
+    (dict(noise=(1.0, 77)), dict()),
 ]
+NOISE_MODEL = os.path.join(os.path.dirname(__file__), "golden", "SLGridSph.model")
+
+
+def _oracle_opts(oracle, g, scale, o):
+    """a scenario's option dict as NBodyOracle.set_options takes it (the NOISE entry needs compute_rms_coefs of the model)"""
+    o = dict(o)
+    if o.get("noise") is not None:
+        from exp_amd.slgrid import read_model_table
+        r, d, _, _ = read_model_table(NOISE_MODEL)
+        meanC, rmsC = oracle.sph_compute_rms_coefs(g, r, d, scale)
+        o["noise"] = (meanC, rmsC, o["noise"][0], o["noise"][1])
+    return o
 
 
 @pytest.mark.parametrize("scen", range(len(SCENARIOS)))
@@ -312,7 +331,7 @@ def test_step_driver_with_the_option_keys_against_the_nbody_oracle(ctx, oracle, 
     i2 = nb.add_cylinder(cg, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
     nb.add_interaction(i1, i2)
     nb.add_interaction(i2, i1)
-    nb.set_options(i1, **oh)
+    nb.set_options(i1, **_oracle_opts(oracle, g, float(inp["scale"]), oh))
     nb.set_options(i2, **od)
     nb.init()
     nsw = [0, 0]
@@ -596,3 +615,73 @@ def test_sphere_subset_against_the_oracle(ctx, oracle, ssfrac, nthrds):
         x.close()
     with pytest.raises(RuntimeError, match="multistep"):
         SphereSL(ctx, g, multistep=2, **win).set_subset(0.5, 1)
+
+
+def test_sphere_noise_mode_against_the_oracle(ctx, oracle):
+    """NOISE (src/SphericalBasis.cc:355, :395, :2108-2210) call by call: every force evaluation -- self, then external on another
+    component -- first REPLACES the coefficient set by the next draws of the noise model (one generator per force, seeded
+    once); the accumulation in between is the plain one.  Then the same through the step driver, single level (the self call
+    evaluates the draws) -- against oracle/noise_oracle.cc, whose deviates are the reference's std::mt19937 +
+    std::normal_distribution objects."""
+    from exp_amd.runtime import Component, Simulation, SphereSL
+    from exp_amd.slgrid import compute_rms_coefs
+    inp = c4.config4_inputs(n_halo=700, n_disk=300)
+    g, _ = c4.grids()
+    sc = float(inp["scale"])
+    win = c4.sph_window(g, sc)
+    prm = oracle.params(**win)
+    m, pos, vel = inp["halo_mass"], inp["halo_pos"], inp["halo_vel"]
+    meanC, rmsC = compute_rms_coefs(g, NOISE_MODEL, sc)
+    noiseN, seed = 1.0e-6, 4242
+    h = oracle.noise_create(g.lmax, g.nmax, meanC, rmsC, noiseN, seed)
+    f = SphereSL(ctx, g, **win)
+    f.set_noise(NOISE_MODEL, noiseN=noiseN, seedN=seed)
+    c = Component.from_arrays(ctx, m, pos, vel)
+    t = Component.from_arrays(ctx, inp["disk_mass"], inp["disk_pos"], inp["disk_vel"])
+    f.determine_coefficients(c)
+    c_acc, _ = oracle.sph_accumulate(g, prm, pos, m)
+    assert np.abs(f.get_coefs() - c_acc).max() <= 1e-10 * np.abs(c_acc).max()      # (the accumulation knows nothing of it)
+    for target, tpos, ext in ((c, pos, False), (t, inp["disk_pos"], True), (c, pos, False)):
+        target.zero_acceleration(0)
+        f.get_acceleration_and_potential(target, external=ext)
+        cn = oracle.noise_update(h, g.lmax, g.nmax)
+        assert np.abs(f.get_coefs() - cn).max() <= 1e-12 * np.abs(cn).max()
+        a_ref, p_ref = oracle.sph_accel(g, prm, tpos, cn)
+        o = target.download(("acc", "pot"))
+        own = np.linalg.norm(a_ref, axis=1)
+        assert (np.linalg.norm(o["acc"] - a_ref, axis=1) <= 1e-9 * own).all()
+        assert np.abs(o["pot"] - p_ref).max() <= 1e-9 * np.abs(p_ref).max()
+    oracle.lib.orc_noise_destroy(h)
+    # off again: the set an accumulation leaves is the one evaluated
+    f.set_noise(None)
+    f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+    assert np.abs(f.get_coefs() - c_acc).max() <= 1e-10 * np.abs(c_acc).max()
+    for x in (c, t, f):
+        x.close()
+    # the step driver, one component, single level: do_step's force evaluation is a self call that keeps its draws
+    dtime, nsteps = 1.0e-4, 3
+    nb = NBodyOracle(oracle, 0, dtime, c4.DYN)
+    i1 = nb.add_sphere(g, prm, m, pos, vel)
+    nb.set_options(i1, noise=(meanC, rmsC, 1.0, 9))
+    nb.init()
+    for _ in range(nsteps):
+        nb.step()
+    ch = Component.from_arrays(ctx, m, pos, vel)
+    fh = SphereSL.from_config(ctx, g, dict(NOISE=True, noiseN=True, seedN=9, noise_model_file=NOISE_MODEL, scale=sc,
+                                           rmin=win["rmin"], rmax=win["rmax"]))
+    sim = Simulation(ctx, dtime, multistep=0, dynfrac=c4.DYN)
+    sim.add_component(ch, fh)
+    sim.init()
+    sim.step(nsteps)
+    st, o = nb.state[0], ch.download()
+    a = np.stack([st["a" + q] for q in "xyz"], 1)
+    p = np.stack([st[q] for q in "xyz"], 1)
+    assert np.abs(o["pos"] - p).max() <= 1e-11 * np.abs(p).max()
+    assert (np.linalg.norm(o["acc"] - a, axis=1) <= 1e-9 * np.linalg.norm(a, axis=1)).all()
+    assert np.abs(np.asarray(fh.get_coefs()).reshape(-1) - st["coef"]).max() <= 1e-12 * np.abs(st["coef"]).max()
+    for x in (sim, ch, fh):
+        x.close()
+    with pytest.raises(ValueError, match="seedN"):
+        SphereSL.from_config(ctx, g, dict(NOISE=True))
+    with pytest.raises(ValueError, match="boolean"):
+        SphereSL.from_config(ctx, g, dict(NOISE=True, seedN=1, noiseN=0))
