@@ -128,6 +128,9 @@ struct exp_amd_force {
   // Host-side state of this force that alternates from one fused step to the next (the spherical method's two
   // work-list counters): part of the key under which exp_amd_step_kdk_n replays a captured pair of steps
   virtual int step_parity() const { return 0; }
+  // false: a fused step of this force has host-side effects that a replayed graph would not repeat (the NOISE mode draws
+  // its deviates on the host at every force evaluation) -- exp_amd_step_kdk_n then steps eagerly
+  virtual bool step_graph_ok() const { return true; }
   // the graph of TWO consecutive fused steps of (this, one component, one dt) and the host state it was captured in
   struct StepGraph {
     hipGraphExec_t exec = nullptr;

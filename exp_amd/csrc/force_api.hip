@@ -364,7 +364,7 @@ extern "C" int exp_amd_step_kdk_n(exp_amd_force *f, exp_amd_comp *c, double dt, 
   int rc, done = 0;
   while (done < nsteps) {
     const bool can = graphs_on && nsteps - done >= 2 && !ctx->profile && !ctx->ar_fn && ctx->split_min <= 0 &&
-                     !f->step_graph.refused && step_is_steady(f, c, dt);
+                     !f->step_graph.refused && f->step_graph_ok() && step_is_steady(f, c, dt);
     if (!can) {
       if ((rc = exp_amd_step_kdk(f, c, dt))) return rc;
       done++;

@@ -79,6 +79,7 @@ struct SphForce : exp_amd_force {
   long long noise_calls = 0;
   int update_noise(bool self_call);
   int step_parity() const override { return work_flip; }
+  bool step_graph_ok() const override { return !noise_on && !subset_on; }
   int multistep_reset() override
   {
     HIP_TRY(ctx, hipMemsetAsync(d_used.p, 0, sizeof(unsigned long long), ctx->stream));

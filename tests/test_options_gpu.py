@@ -681,6 +681,23 @@ def test_sphere_noise_mode_against_the_oracle(ctx, oracle):
     assert np.abs(np.asarray(fh.get_coefs()).reshape(-1) - st["coef"]).max() <= 1e-12 * np.abs(st["coef"]).max()
     for x in (sim, ch, fh):
         x.close()
+    # several fused steps in one call: the draws are host-side effects a replayed graph would not repeat -- stepped eagerly
+    outs = []
+    for many in (True, False):
+        cc = Component.from_arrays(ctx, m, pos, vel)
+        ff = SphereSL(ctx, g, **win)
+        ff.set_noise(NOISE_MODEL, noiseN=1.0, seedN=31)
+        ff.determine_coefficients(cc); cc.zero_acceleration(0); ff.get_acceleration_and_potential(cc)
+        if many:
+            ff.step_kdk_n(cc, dtime, 6)
+        else:
+            for _ in range(6):
+                ff.step_kdk(cc, dtime)
+        outs.append((cc.download(), ff.get_coefs().copy()))
+        cc.close(); ff.close()
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= 1e-13 * np.abs(outs[1][1]).max()
+    for k in ("pos", "vel", "acc"):
+        assert np.abs(outs[0][0][k] - outs[1][0][k]).max() <= 1e-10 * np.abs(outs[1][0][k]).max(), k
     with pytest.raises(ValueError, match="seedN"):
         SphereSL.from_config(ctx, g, dict(NOISE=True))
     with pytest.raises(ValueError, match="boolean"):
