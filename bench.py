@@ -98,6 +98,10 @@ def parse_args():
                     help="time the K steps as ONE call of exp_amd_step_kdk_n (pairs of steady-state steps replayed from a "
                          "HIP graph, the RCCL all-reduce included) instead of K calls of exp_amd_step_kdk; per-kernel "
                          "events are off then (roofline.avg_launch_ms comes from a second, eager region)")
+    ap.add_argument("--no-append", action="store_true",
+                    help="the ordinary fused step (key histogram, scan, scatter pass every step) instead of the APPEND form, in "
+                         "which the force pass places every particle in the next step's cell order itself "
+                         "(exp_amd_ctx_set_append_min; profiles/r06_append_ab.txt)")
     ap.add_argument("--split", action="store_true",
                     help="the opt-in split fused step (exp_amd_ctx_set_split_min): the store as two independently sorted "
                          "halves, the HBM-bound sort passes of one half on a second stream under the fp64-bound accumulate / "
@@ -795,6 +799,7 @@ def main():
     ctx = Context(dev_index, stream=tstream.cuda_stream)
     if args.split:
         ctx.set_split_min(1)
+    ctx.set_append_min(0 if (args.no_append or args.split or args.graph) else 1 << 20)
     comp = Component(ctx, nloc)
     comp.upload_device(mass, x, y, z, vx, vy, vz)
     del x, y, z, vx, vy, vz, mass

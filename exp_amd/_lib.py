@@ -95,6 +95,7 @@ SIGNATURES = {
     "exp_amd_orient_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_uint, c_double, c_double,
                                       POINTER(c_void_p)]),
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
+    "exp_amd_ctx_set_append_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_dense_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_thin_max": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_mover_list_min": (c_int, [c_void_p, c_longlong]),

@@ -46,6 +46,8 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   ctx->thin_acc_scale = EXPAMD_EXPT("EXP_AMD_THIN_ACC_SCALE", ctx->thin_acc_scale) > 0 ? EXPAMD_EXPT("EXP_AMD_THIN_ACC_SCALE", ctx->thin_acc_scale) : 1;
   ctx->mover_slices_min = EXPAMD_EXPT("EXP_AMD_MOVER_SLICES_MIN", ctx->mover_slices_min);
   ctx->stage_max = EXPAMD_EXPT("EXP_AMD_STAGE_MAX", ctx->stage_max);
+  // EXP_AMD_APPEND_MIN (include/exp_amd.h, "Environment"): the default of exp_amd_ctx_set_append_min
+  if (const char *e = getenv("EXP_AMD_APPEND_MIN")) ctx->append_min = atoll(e);
   HIP_TRY(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -126,6 +128,14 @@ extern "C" int exp_amd_ctx_set_mover_list_min(exp_amd_ctx *ctx, long long nmin)
   expamd_mutated();            // (drops a captured graph of fused steps: exp_amd_step_kdk_n)
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->mover_list_min = nmin;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_ctx_set_append_min(exp_amd_ctx *ctx, long long nmin)
+{
+  expamd_mutated();
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->append_min = nmin;
   return EXP_AMD_OK;
 }
 

@@ -322,6 +322,7 @@ extern "C" int exp_amd_cyl_cov_accumulate(exp_amd_force *fb, exp_amd_comp *c, co
 {
   CylForce *f = as_cyl(fb);
   if (!f || !c || !f->cov_T) return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cyl_cov_accumulate: covariance not enabled");
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }      // (an appended store: made an ordinary one first)
   exp_amd_ctx *ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // (positions and masses only: whatever half-kick the velocities are owed or ahead by does not matter here)

@@ -88,6 +88,13 @@ struct exp_amd_force {
     *handled = false;
     return EXP_AMD_OK;
   }
+  // ... or without sort passes at all: the force pass places every particle in the next step's cell order (the APPEND step,
+  // sph.hip).  *handled = false: not offered / not in its steady state yet.
+  virtual int fused_step_append(exp_amd_comp *, double, bool, bool *handled)
+  {
+    *handled = false;
+    return EXP_AMD_OK;
+  }
   virtual void release() = 0;
   // multistep_update for every particle whose proposed level (c->newlev) differs from its
   // level: subtract its contribution from expcoefN[from], add it to expcoefN[to]

@@ -299,11 +299,19 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
   c->prekey_valid = false;
   {
     bool handled = false;
+    if ((rc = f->fused_step_append(c, dt, have_keys && !c->prekey_split, &handled))) return rc;
+    if (handled) return EXP_AMD_OK;
+  }
+  {
+    bool handled = false;
     if ((rc = f->fused_step_split(c, dt, have_keys && c->prekey_split, &handled))) return rc;
     if (handled) return EXP_AMD_OK;
   }
-  const bool have_keys_whole = have_keys && !c->prekey_split;
-  if (c->n == 0) {
+  // (app_redo: an append step ran out of room and left an ordinary store that holds this step's advanced state)
+  const bool redo = c->app_redo;
+  c->app_redo = false;
+  const bool have_keys_whole = have_keys && !c->prekey_split && !redo && c->prekey_owner == (const void *)f && c->sorted_for == (const void *)f;
+  if (c->n == 0 || redo) {
     if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
   } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys_whole))) return rc;
   bool done = false;
@@ -363,7 +371,9 @@ extern "C" int exp_amd_step_kdk_n(exp_amd_force *f, exp_amd_comp *c, double dt, 
   static const bool graphs_on = !(getenv("EXP_AMD_STEP_GRAPH") && atoi(getenv("EXP_AMD_STEP_GRAPH")) == 0);
   int rc, done = 0;
   while (done < nsteps) {
-    const bool can = graphs_on && nsteps - done >= 2 && !ctx->profile && !ctx->ar_fn && ctx->split_min <= 0 &&
+    // (a component the append step takes is stepped eagerly: that step reads a flag back after every pass)
+    const bool app = ctx->append_min != 0 && c->n >= (size_t)(ctx->append_min < 0 ? -ctx->append_min : ctx->append_min);
+    const bool can = graphs_on && nsteps - done >= 2 && !ctx->profile && !ctx->ar_fn && ctx->split_min <= 0 && !app &&
                      !f->step_graph.refused && f->step_graph_ok() && step_is_steady(f, c, dt);
     if (!can) {
       if ((rc = exp_amd_step_kdk(f, c, dt))) return rc;

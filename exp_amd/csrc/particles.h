@@ -135,9 +135,45 @@ struct exp_amd_comp {
   size_t half = 0;
   DevBuf<uint32_t> half_off;
 
+  // The "append" fused step (sph_kernels.h: AppDev; sph.hip: SphForce::fused_step_append): the live buffer set is in the cell
+  // order of the NEXT step, every cell a region of app_base[cur] with empty slots (x = +inf) behind its particles -- `n`
+  // particles in up to app_ns slots.  X / Y / Z hold the positions the next accumulation reads (already drifted); the positions
+  // of the step that was completed are still in the OTHER set, at slot app_src[cur][slot]: what every other call sees, once expamd_comp_densify has made the store an
+  // ordinary one again (every entry point does that first: expamd_comp_apply_pending / _velocity_view / download).
+  bool appended = false;
+  const void *app_owner = nullptr;      // the force method whose cells the regions are
+  double app_dt = 0.0;                  // ... for steps of this length
+  double app_center[3] = {0, 0, 0};
+  size_t app_cap = 0;                   // slots every array of both sets has room for (0: never reserved)
+  size_t app_ns = 0;                    // host bound of the slots in use
+  uint32_t app_ncell = 0, app_tail = 0; // cells of the layout; slots of the tail region
+  DevBuf<double> xo[2][3];              // (scratch of expamd_comp_densify: the dense positions, then swapped in)
+  DevBuf<uint32_t> app_src[2];          // per slot: the slot of the other set the particle came from (its state position)
+  DevBuf<uint32_t> app_base[2];         // [ncell + 2] per buffer set
+  DevBuf<uint32_t> app_range[2];        // {0, end of the tail}: plays lev_off for the passes over an appended set
+  DevBuf<uint32_t> app_cursor;          // [ncell + 1] + flag word
+  bool app_redo = false;                // a step whose append pass ran out of room is being redone from its (advanced) source
   double *a(int k) { return arr[cur][k].p; }
   double *b(int k) { return arr[1 - cur][k].p; }
 };
+
+#ifndef APP_EMPTY
+#define APP_EMPTY __builtin_inf()        // x of a slot that holds no particle
+#endif
+// slots an appended store of n particles in ncell cells may use (regions: population + 1/64 of it + 192, rounded up to whole
+// waves; tail: max(65536, n / 128)), and the pieces of that rule the layout kernel applies
+inline uint32_t expamd_app_tail(size_t n) { const size_t t = n / 128; return (uint32_t)(t < 65536 ? 65536 : t); }
+inline size_t expamd_app_slots(size_t n, uint32_t ncell) { return n + n / 64 + (size_t)ncell * 256 + expamd_app_tail(n) + 64; }
+// make room: both buffer sets, ids and the state positions at `cap` slots (contents of the live set are kept)
+int expamd_comp_app_reserve(exp_amd_comp *c, size_t cap);
+// an appended store becomes an ordinary dense one (positions: those of the completed step; order: none)
+int expamd_comp_densify(exp_amd_comp *c, bool state_positions = true);
+// the layout of the NEXT buffer set from the populations in `counts` (ncell values), cursors cleared
+int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t ncell, int set, uint32_t *also_into);
+// after an append pass into buffer set `set`: empty slots marked, the next layout's populations are the cursors
+int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag);
+// ... after the ORDINARY scatter pass filled a set's regions (its running offsets `offs` are base + population)
+void k_app_mark_launch(exp_amd_comp *c, int set, const uint32_t *offs);
 
 // exclusive scan of the key histogram (range_lo >= 0: only the bins of that level / half, starting
 // at lev_off[range_lo]; lev_off is then left alone)

@@ -427,6 +427,211 @@ bool expamd_comp_mprekey_ok(const exp_amd_comp *c, const void *owner, double dt_
          c->mprekey_center[2] == c->center[2] && c->pending_kick == 0.0;
 }
 
+// ---- the appended store (particles.h; sph_kernels.h: AppDev) ---------------------------------------------------------------
+// layout of a buffer set from the cells' populations: region c = [base[c], base[c + 1]), population + 1/64 of it + 192 slots,
+// whole waves (a wave of the passes then never straddles two regions); the tail behind the last region; cursors and flag cleared
+__global__ void __launch_bounds__(1024)
+k_app_layout(const uint32_t *__restrict__ counts, uint32_t ncell, uint32_t tail, uint32_t *__restrict__ base,
+             uint32_t *__restrict__ range, uint32_t *__restrict__ cursor, uint32_t *__restrict__ also_into, int tight)
+{
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (ncell + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per < ncell ? threadIdx.x * per : ncell, hi = lo + per < ncell ? lo + per : ncell;
+  // (tight: no slack at all -- the test mode in which a pass runs out of room as soon as a population grows)
+  const auto room = [tight](uint32_t n) { return tight ? (n + 63u) & ~63u : (n + n / 64u + 192u + 63u) & ~63u; };
+  uint32_t sum = 0;
+  for (uint32_t k = lo; k < hi; k++) sum += room(counts[k]);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t n = counts[k];
+    base[k] = run;
+    if (also_into) also_into[k] = run;
+    run += room(n);
+  }
+  __syncthreads();            // (counts may alias cursor: every count has been read)
+  for (uint32_t k = lo; k < hi; k++) cursor[k] = 0u;
+  if (threadIdx.x == 1023) {
+    base[ncell] = part[1023];
+    base[ncell + 1] = part[1023] + tail;
+    range[0] = 0u;
+    range[1] = part[1023] + tail;
+    cursor[ncell] = 0u;          // tail
+    cursor[ncell + 1] = 0u;      // flag
+  }
+}
+
+// after the passes have placed their particles in a buffer set: x = +inf behind the filled part of every region and of the tail
+__global__ void __launch_bounds__(256)
+k_app_mark(const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill /* per cell: cursor, or the scatter's running
+           offsets (absolute != 0) */, int absolute, uint32_t ncell, double *__restrict__ X)
+{
+  const uint32_t c = blockIdx.x;        // ncell + 1 blocks: the last one is the tail
+  const uint32_t b = base[c], e = base[c + 1];
+  uint32_t f = absolute ? (c < ncell ? fill[c] - b : 0u) : fill[c];
+  if (f > e - b) f = e - b;
+  for (uint32_t s = b + f + threadIdx.x; s < e; s += 256) X[s] = APP_EMPTY;
+}
+
+__global__ void __launch_bounds__(256)
+k_app_fill(double *__restrict__ v, size_t n, double x)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) v[i] = x;
+}
+
+// an appended set -> a dense one: the slots that hold a particle, block by block to a place reserved with one atomic
+__global__ void __launch_bounds__(256)
+k_app_densify(const double *__restrict__ X, const uint32_t *__restrict__ range, uint32_t *__restrict__ counter,
+              const double *const *__restrict__ src, double *const *__restrict__ dst, int narr,
+              const uint32_t *__restrict__ id, uint32_t *__restrict__ id_out,
+              const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+              const uint32_t *__restrict__ pslot /* where the positions are: px[pslot[i]] (nullptr: px[i]) */,
+              double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz)
+{
+  __shared__ uint32_t s_cnt, s_base;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
+  const bool have = i < range[1] && X[i] != APP_EMPTY;
+  uint32_t my = 0;
+  if (have) my = atomicAdd(&s_cnt, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(counter, s_cnt);
+  __syncthreads();
+  if (!have) return;
+  const size_t o = (size_t)s_base + my;
+  for (int a = 0; a < narr; a++) dst[a][o] = src[a][i];
+  id_out[o] = id[i];
+  const size_t q = pslot ? (size_t)pslot[i] : i;
+  ox[o] = px[q]; oy[o] = py[q]; oz[o] = pz[q];
+}
+
+int expamd_comp_app_reserve(exp_amd_comp *c, size_t cap)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->app_cap >= cap) return EXP_AMD_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int w = 0; w < 2; w++) {
+    for (int a = 0; a < A_NARR; a++) {
+      DevBuf<double> nb;
+      HIP_TRY(ctx, nb.alloc(cap));
+      if (w == c->cur && c->n) HIP_TRY(ctx, hipMemcpy(nb.p, c->arr[w][a].p, c->n * sizeof(double), hipMemcpyDeviceToDevice));
+      c->arr[w][a].release();
+      c->arr[w][a] = nb;
+    }
+    DevBuf<uint32_t> ni;
+    HIP_TRY(ctx, ni.alloc(cap));
+    if (w == c->cur && c->n) HIP_TRY(ctx, hipMemcpy(ni.p, c->id[w].p, c->n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    c->id[w].release();
+    c->id[w] = ni;
+    for (int k = 0; k < 3; k++) HIP_TRY(ctx, c->xo[w][k].alloc(cap));
+    HIP_TRY(ctx, c->app_src[w].alloc(cap));
+  }
+  // a uniform mass lives as the constant in the mass arrays of both sets: in all of their slots now
+  if (c->uniform_mass)
+    for (int w = 0; w < 2; w++) k_app_fill<<<4096, 256, 0, ctx->stream>>>(c->arr[w][A_M].p, cap, c->mass_value);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  c->app_cap = cap;
+  return EXP_AMD_OK;
+}
+
+int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t ncell, int set, uint32_t *also_into)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  if (c->app_base[0].n < (size_t)ncell + 2) {
+    for (int w = 0; w < 2; w++) { HIP_TRY(ctx, c->app_base[w].alloc((size_t)ncell + 2)); HIP_TRY(ctx, c->app_range[w].alloc(2)); }
+    HIP_TRY(ctx, c->app_cursor.alloc((size_t)ncell + 2));
+  }
+  const bool tight = ctx->append_min < 0;
+  c->app_ncell = ncell;
+  c->app_tail = tight ? 64u : expamd_app_tail(c->n);
+  k_app_layout<<<1, 1024, 0, ctx->stream>>>(counts, ncell, c->app_tail, c->app_base[set].p, c->app_range[set].p,
+                                             c->app_cursor.p, also_into, tight ? 1 : 0);
+  HIP_TRY(ctx, hipGetLastError());
+  return EXP_AMD_OK;
+}
+
+int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag)
+{
+  exp_amd_ctx *ctx = c->ctx;
+  k_app_mark<<<c->app_ncell + 1, 256, 0, ctx->stream>>>(c->app_base[set].p, c->app_cursor.p, 0, c->app_ncell, c->arr[set][A_X].p);
+  HIP_TRY(ctx, hipGetLastError());
+  if (host_flag) {
+    HIP_TRY(ctx, hipMemcpyAsync(host_flag, c->app_cursor.p + c->app_ncell + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return EXP_AMD_OK;
+}
+
+void k_app_mark_launch(exp_amd_comp *c, int set, const uint32_t *offs)
+{
+  k_app_mark<<<c->app_ncell + 1, 256, 0, c->ctx->stream>>>(c->app_base[set].p, offs, 1, c->app_ncell, c->arr[set][A_X].p);
+}
+
+int expamd_comp_densify(exp_amd_comp *c, bool state_positions)
+{
+  if (!c->appended) return EXP_AMD_OK;
+  exp_amd_ctx *ctx = c->ctx;
+  expamd_mutated();
+  const int s = c->cur, d = 1 - c->cur;
+  // positions: those of the completed step (xo), or -- a step that is being redone from its source -- the advanced ones
+  const double *srcs[A_NARR];
+  double *dsts[A_NARR];
+  int na = 0;
+  for (int a = A_VX; a < A_NARR; a++) {
+    if (a == A_M && c->uniform_mass) continue;                   // (both sets hold the constant)
+    srcs[na] = c->arr[s][a].p;
+    dsts[na] = c->arr[d][a].p;
+    na++;
+  }
+  // positions: state_positions -- those of the completed step, which are still in the OTHER set (the set this call fills:
+  // they are gathered into scratch arrays that then take the other set's place); else the live set's own (a step being redone)
+  const double *px = state_positions ? c->arr[d][A_X].p : c->arr[s][A_X].p;
+  const double *py = state_positions ? c->arr[d][A_Y].p : c->arr[s][A_Y].p;
+  const double *pz = state_positions ? c->arr[d][A_Z].p : c->arr[s][A_Z].p;
+  // the pointer tables and the counter: scratch words behind the level sweeps' counters
+  DevBuf<unsigned char> tab;
+  HIP_TRY(ctx, tab.alloc(2 * A_NARR * sizeof(void *) + 16));
+  HIP_TRY(ctx, hipMemcpyAsync(tab.p, srcs, na * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(tab.p + A_NARR * sizeof(void *), dsts, na * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t *counter = (uint32_t *)(tab.p + 2 * A_NARR * sizeof(void *));
+  HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx->stream));
+  k_app_densify<<<cdiv(c->app_ns, 256), 256, 0, ctx->stream>>>(c->arr[s][A_X].p, c->app_range[s].p, counter,
+                                                               (const double *const *)tab.p,
+                                                               (double *const *)(tab.p + A_NARR * sizeof(void *)), na,
+                                                               c->id[s].p, c->id[d].p, px, py, pz,
+                                                               state_positions ? c->app_src[s].p : nullptr,
+                                                               c->xo[d][0].p, c->xo[d][1].p, c->xo[d][2].p);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t got = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&got, counter, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  tab.release();
+  if ((size_t)got != c->n)
+    return expamd_fail(ctx, EXP_AMD_ERR_STATE, "appended store: %u particles found, %zu expected", got, c->n);
+  for (int k = 0; k < 3; k++) std::swap(c->arr[d][A_X + k], c->xo[d][k]);
+  c->cur = d;
+  c->appended = false;
+  c->app_owner = nullptr;
+  c->sorted_for = nullptr;
+  c->prekey_valid = false;
+  c->split = false;
+  c->hist_clean = 0;
+  c->lev_host_valid = false;
+  const uint32_t lo1[2] = {0u, (uint32_t)c->n};
+  HIP_TRY(ctx, hipMemcpyAsync(c->lev_off.p, lo1, sizeof(lo1), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EXP_AMD_OK;
+}
+
 int expamd_comp_touch(exp_amd_comp *c)
 {
   expamd_mutated();
@@ -451,6 +656,7 @@ int expamd_comp_touch_keep_partition(exp_amd_comp *c)
 // move the trajectory by an ulp just because a diagnostic looked.  The keys recorded for the next step stay valid.
 int expamd_comp_velocity_view(exp_amd_comp *c, double *back)
 {
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }
   { int rc_ = expamd_comp_flush_commit(c); if (rc_) return rc_; }      // (these consumers read the level array too)
   *back = c->pending_kick < 0.0 ? c->pending_kick : 0.0;
   if (*back != 0.0) return EXP_AMD_OK;
@@ -459,6 +665,7 @@ int expamd_comp_velocity_view(exp_amd_comp *c, double *back)
 
 int expamd_comp_apply_pending(exp_amd_comp *c)
 {
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }     // (an appended store: every outside call sees an ordinary one)
   if (c->pending_kick != 0.0 && c->n) {
     const double dt = c->pending_kick;
     const int lo = c->pending_lo < c->nlevels ? c->pending_lo : 0;
@@ -912,6 +1119,13 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
     c->id[w].release();
     c->level[w].release();
   }
+  for (int w = 0; w < 2; w++) {
+    for (int k = 0; k < 3; k++) c->xo[w][k].release();
+    c->app_src[w].release();
+    c->app_base[w].release();
+    c->app_range[w].release();
+  }
+  c->app_cursor.release();
   c->d_frz.release();
   c->d_escaped.release();
   c->d_dtreq.release();
@@ -1156,6 +1370,7 @@ extern "C" int exp_amd_comp_download(exp_amd_comp *c, double *mass, double *x, d
                                      double *ay, double *az, double *pot)
 {
   if (!c) return EXP_AMD_ERR_ARG;
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }
   // A fused step leaves the velocities either short of their closing half-kick (pending_kick > 0: applied
   // now, exactly the operation the next step would have done first) or AHEAD by the next step's opening
   // half-kick (pending_kick < 0).  The second state is left as it is -- undoing and redoing a rounded
@@ -1186,6 +1401,7 @@ extern "C" int exp_amd_comp_download_levels(exp_amd_comp *c, int32_t *level)
   if (!c || !level) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }
   { int rc_ = expamd_comp_flush_commit(c); if (rc_) return rc_; }
   int32_t *tmp = (int32_t *)c->b(A_X);
   k_unpermute_lev<<<cdiv(c->n, TPB), TPB, 0, ctx->stream>>>(c->level[c->cur].p, c->id[c->cur].p,

@@ -581,7 +581,7 @@ static int sph_stage(SphForce *f, size_t np, SphUpdArgs &a)
 
 #define ACC_THICK_MIN 1000000u       // level population from which a multistep level is accumulated apart from thinner ones
 
-static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
+static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out, const uint32_t *range = nullptr, size_t nslots = 0)
 {
   exp_amd_ctx *ctx = f->ctx;
   const int lo = f->multistep ? f->mlevel : 0;
@@ -594,14 +594,15 @@ static int sph_accumulate(SphForce *f, exp_amd_comp *c, double *d_out)
   unsigned long long *used_p = f->d_used.p + ((f->multistep && !f->used_open) ? 1 : 0);
   if (!(f->multistep && f->used_open))
     HIP_TRY(ctx, hipMemsetAsync(used_p, 0, sizeof(unsigned long long), ctx->stream));
-  size_t nrange = c->n;      // particles of the level(s) accumulated: sizes the grid and the chunks
+  size_t nrange = range ? nslots : c->n;      // particles of the level(s) accumulated: sizes the grid and the chunks
   if (c->n && f->multistep) {
     int rc = expamd_comp_level_count(c, lo, hi, &nrange);
     if (rc) return rc;
   }
   if (nrange) {
     ProfScope ps(ctx, "k_sph_accumulate");
-    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), c->lev_off.p, lo, hi,
+    // (range: an appended store -- its slots [range[0], range[1]), empty ones among them: particles.h)
+    SphAccArgs a{S, c->a(A_X), c->a(A_Y), c->a(A_Z), c->a(A_M), range ? range : c->lev_off.p, lo, hi,
                  f->d_W.p, used_p, nrange, ctx->stream, f->multistep ? 1 : 0};
     sph_launch_acc(f, a);
   }
@@ -1135,6 +1136,134 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
   return EXP_AMD_OK;
 }
 
+
+// ---- append fused step ------------------------------------------------------------------------------------------
+// One KDK step (src/step.cc:271-323) of a large single-level component WITHOUT sort passes (sph_kernels.h: AppDev).  In the
+// fused step's steady state the force pass of step n already computes where every particle will be at step n + 1 (that step's
+// sort key); here it also stores the particle there -- position of step n + 1 (what the next accumulation reads), the slot
+// it came from (where the position of step n, what a download sees, stays until the next pass), the velocity with both half-kicks of the step boundary, acceleration, potential, id --
+// in the OTHER buffer set, whose cells are regions sized from the cells' present populations plus slack.  A step is then
+//   layout of the other set <- populations;  accumulate;  contract, all-reduce, project;  force + place;  mark empty slots
+// and the key histogram, the scan and the scatter pass (112 B per particle, 2.2 of 10.1 ms at 1e8) are gone.  The first such
+// step scatters the ordinary sorted store into a layout of this kind (the ordinary passes with the regions' offsets for
+// cursors).  A pass that runs out of room (a region AND the tail full: a flag, read back after every step) is redone the
+// ordinary way from its source set, which no pass writes.  Any other call on the component turns the store back into an
+// ordinary one first (expamd_comp_densify).  Trajectories: those of the ordinary fused step up to the order of the sums.
+int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool *handled)
+{
+  SphForce *f = this;
+  *handled = false;
+  int rc;
+  const double dt_kick = 0.5 * dt;
+  const bool cont = c->appended && c->app_owner == (const void *)f && c->app_dt == dt && c->pending_kick == -dt_kick &&
+                    c->app_center[0] == c->center[0] && c->app_center[1] == c->center[1] && c->app_center[2] == c->center[2];
+  const long long amin = ctx->append_min < 0 ? -ctx->append_min : ctx->append_min;
+  const bool offered = amin > 0 && c->n >= (size_t)amin && !f->cfg.multistep && !f->lit_on &&
+                       !f->subset_on && !f->noise_on && !f->generic && !ctx->deterministic && ctx->prekick && !c->freeze_on &&
+                       !(c->pseudo.center | c->pseudo.axis) && c->nlevels == 1 && c->levels_zero && !f->fix_l0 &&
+                       c->n < 0x70000000u && !(c->appended && !cont);
+  if (c->appended && !(cont && offered)) return expamd_comp_densify(c);     // (the ordinary step takes over)
+  if (!offered) return EXP_AMD_OK;
+  // entry: the ordinary fused step's steady state -- sorted for this force, velocities stored with this step's opening
+  // half-kick, this step's keys written by the last force pass
+  if (!cont && !(have_keys && c->sorted_for == (const void *)f && c->pending_kick == -dt_kick && !c->split)) return EXP_AMD_OK;
+  const uint32_t ncell = (uint32_t)(f->cfg.numr - 1);
+  const size_t cap = expamd_app_slots(c->n, ncell);
+  f->home = c;
+  f->home_gone = false;
+  hipStream_t st = ctx->stream;
+  if (!cont) {
+    if ((rc = expamd_comp_app_reserve(c, cap))) return rc;
+    c->app_ns = cap;
+    if ((rc = expamd_comp_prepare_hist(c, ncell))) return rc;
+    {
+      ProfScope ps(ctx, "k_hist_keys");
+      k_hist_keys<<<cdiv(c->n, HIST_TILE), SORT_TPB, 0, st>>>(c->key.p, c->n, c->hist.p, 0u, ncell, (uint32_t)SORT_WIN);
+    }
+    // both sets get a layout from these populations: the one the scatter fills now, the one the force pass fills below
+    if ((rc = expamd_comp_app_layout(c, c->hist.p, ncell, c->cur, nullptr))) return rc;
+    if ((rc = expamd_comp_app_layout(c, c->hist.p, ncell, 1 - c->cur, c->hist.p))) return rc;
+    const AdvanceArgs A = expamd_advance_args(c, AdvSpec::step(true, dt_kick, dt));
+    const ScatterSrc Ssrc{c->a(A_M), c->a(A_AX), c->a(A_AY), c->a(A_AZ), c->a(A_POT), c->id[c->cur].p};
+    const ScatterDst Sdst{c->b(A_X), c->b(A_Y), c->b(A_Z), c->b(A_VX), c->b(A_VY), c->b(A_VZ),
+                          c->uniform_mass ? nullptr : c->b(A_M), c->b(A_AX), c->b(A_AY), c->b(A_AZ), c->b(A_POT),
+                          c->id[1 - c->cur].p, nullptr};
+    {
+      ProfScope ps(ctx, "k_scatter_adv");
+      k_scatter_adv<false><<<cdiv(c->n, SCAT_TILE), SORT_TPB, 0, st>>>(A, Ssrc, Sdst, expamd_sort_range(c, -1), c->key.p,
+                                                                        c->hist.p, (uint32_t)SORT_WIN);
+    }
+    k_app_mark_launch(c, 1 - c->cur, c->hist.p);
+    HIP_TRY(ctx, hipGetLastError());
+    c->hist_clean = 0;
+    c->pending_kick = 0.0;
+    c->cur = 1 - c->cur;
+    c->appended = true;
+    c->app_owner = f;
+    c->app_dt = dt;
+    for (int k = 0; k < 3; k++) c->app_center[k] = c->center[k];
+    c->sorted_for = nullptr;          // (no ordinary pass may take this set for a sorted dense one)
+    c->acc_live = false;
+  } else {
+    // the other set's layout from the populations the last pass counted (its cursors; cleared on the way)
+    if ((rc = expamd_comp_app_layout(c, c->app_cursor.p, ncell, 1 - c->cur, nullptr))) return rc;
+    c->pending_kick = 0.0;            // (the store holds this step's positions and opening half-kick: nothing is owed)
+  }
+  const int src = c->cur, dst = 1 - c->cur;
+  // ---- accumulate, reduce, project
+  if ((rc = sph_accumulate(f, c, f->d_coef.p, c->app_range[src].p, c->app_ns))) return rc;
+  if ((rc = expamd_allreduce(ctx, f->d_coef.p, f->ncoef))) return rc;
+  f->proj_dirty = true;
+  if ((rc = sph_project(f))) return rc;
+  f->used_open = false;
+  // ---- force pass that places its results in the other set
+  {
+    const size_t need = c->app_ns / 64 + 8;
+    if (f->work_cap < need) {
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      HIP_TRY(ctx, f->d_work.alloc(SPH_WORK_STRIDE * need + 2));
+      HIP_TRY(ctx, hipMemsetAsync(f->d_work.p + SPH_WORK_STRIDE * need, 0, 2 * sizeof(uint32_t), st));
+      f->work_cap = need;
+      f->work_flip = 0;
+    }
+    SphDev S = dev_for(f, c->center);
+    S.ps = c->pseudo;
+    dev_freeze(S, c);
+    uint32_t *cnt = f->d_work.p + SPH_WORK_STRIDE * f->work_cap;
+    const AppDev app{c->arr[dst][A_X].p, c->arr[dst][A_Y].p, c->arr[dst][A_Z].p, c->app_src[dst].p,
+                     c->arr[dst][A_VX].p, c->arr[dst][A_VY].p, c->arr[dst][A_VZ].p,
+                     c->arr[dst][A_AX].p, c->arr[dst][A_AY].p, c->arr[dst][A_AZ].p, c->arr[dst][A_POT].p,
+                     c->uniform_mass ? nullptr : c->arr[dst][A_M].p, c->id[dst].p,
+                     c->arr[src][A_M].p, c->id[src].p, c->app_base[dst].p, c->app_cursor.p,
+                     c->app_cursor.p + ncell + 1, ncell};
+    SphForceArgs a{S, c->arr[src][A_X].p, c->arr[src][A_Y].p, c->arr[src][A_Z].p, c->app_range[src].p, 0, 0, f->d_T4.p,
+                   c->arr[src][A_AX].p, c->arr[src][A_AY].p, c->arr[src][A_AZ].p, c->arr[src][A_POT].p,
+                   c->arr[src][A_VX].p, c->arr[src][A_VY].p, c->arr[src][A_VZ].p, dt_kick, 1, c->app_ns,
+                   (unsigned)cdiv(c->app_ns, 256), st, f->d_work.p, cnt + f->work_flip, 0, ctx, nullptr, dt_kick, dt, 2,
+                   cnt + (1 - f->work_flip), 0};
+    a.app = &app;
+    sph_launch_force(f, a);
+    f->work_flip ^= 1;
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t lost = 0;
+  if ((rc = expamd_comp_app_finish(c, dst, &lost))) return rc;
+  if (lost) {
+    // no room (a region and the tail full): the source set is intact and holds this step's advanced positions and
+    // velocities -- an ordinary store again, and exp_amd_step_kdk finishes the step the ordinary way (no advance)
+    c->pending_kick = 0.0;
+    if ((rc = expamd_comp_densify(c, /*state_positions=*/false))) return rc;
+    c->app_redo = true;
+    return EXP_AMD_OK;
+  }
+  c->cur = dst;
+  c->acc_live = true;
+  c->pending_kick = -dt_kick;         // velocities stored with the next step's opening half-kick (as the ordinary step's prekick)
+  c->prekey_valid = false;
+  f->firstime_coef = false;
+  *handled = true;
+  return EXP_AMD_OK;
+}
 
 // ---- split fused step -------------------------------------------------------------------------------------------
 // One KDK step (src/step.cc:271-323) of a single-level component whose slots [0, half) and

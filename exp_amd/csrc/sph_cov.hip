@@ -212,6 +212,7 @@ extern "C" int exp_amd_sph_cov_accumulate(exp_amd_force *fb, exp_amd_comp *comp,
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f || !comp || !cov_of(f))
     return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_STATE, "cov_accumulate: covariance not enabled");
+  { int rc_ = expamd_comp_densify(comp); if (rc_) return rc_; }      // (an appended store: made an ordinary one first)
   SphCov *c = cov_of(f);
   exp_amd_ctx *ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

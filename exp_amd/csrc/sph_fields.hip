@@ -271,6 +271,7 @@ extern "C" int exp_amd_sph_window_mass(exp_amd_force *fb, exp_amd_comp *c, doubl
   SphForce *f = dynamic_cast<SphForce *>(fb);
   if (!f || !c || !mass)
     return expamd_fail(fb ? fb->ctx : nullptr, EXP_AMD_ERR_ARG, "sph_window_mass: not a spherical force / NULL");
+  { int rc_ = expamd_comp_densify(c); if (rc_) return rc_; }      // (an appended store: made an ordinary one first)
   exp_amd_ctx *ctx = f->ctx;
   if (c->ctx != ctx) return expamd_fail(ctx, EXP_AMD_ERR_ARG, "sph_window_mass: component of another context");
   HIP_TRY(ctx, hipSetDevice(ctx->device));

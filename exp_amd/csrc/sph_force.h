@@ -106,6 +106,7 @@ struct SphForce : exp_amd_force {
   }
   int resort(exp_amd_comp *c, int first = 0) override;
   int fused_step_split(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
+  int fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool *handled) override;
   void release() override;
 };
 

@@ -87,6 +87,21 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
           a.dt_kick, a.assign, nullptr, nullptr, a.key_out, a.nk_dtk, a.nk_dtd, a.store_v, nullptr);
     }
   } lit_pass(a);
+  if (a.app) {
+    // the append step: fast pass and general pass that place their results in the next step's order (sph_kernels.h: AppDev)
+    {
+      ProfScope ps(a.ctx, "k_sph_force");
+      k_sph_force<LMAX, 1, true><<<a.grid, 256, 0, a.stream>>>(
+          a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+          a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, nullptr, *a.app);
+    }
+    ProfScope ps(a.ctx, "k_sph_force_general");
+    const unsigned ggrid = a.grid < SPH_GENERAL_GRID ? a.grid : SPH_GENERAL_GRID;
+    k_sph_force<LMAX, 0, true><<<ggrid, 256, 0, a.stream>>>(
+        a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+        a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next, *a.app);
+    return;
+  }
   if (!a.all_slow) {
     // a.nwork[0..1]: two work-list counters used alternately; the general pass of launch k clears the
     // one launch k+1 will count into (no memset between the launches)

@@ -449,6 +449,7 @@ __device__ __forceinline__ AccIn sph_acc_input(const SphDev &S, ldp p0l, double 
 {
   AccIn in;
   double xx = 1, yy = 0, zz = 0;
+  valid = valid && px != __builtin_inf();      // (an empty slot of an appended store, particles.h: APP_EMPTY)
   if (valid) { xx = px - S.cx; yy = py - S.cy; zz = pz - S.cz; }
   // src/SphericalBasis.cc:486-494
   const double R2 = xx * xx + yy * yy;
@@ -1435,15 +1436,127 @@ sph_field_fast_call(cdp t4, double costh, double somx2, double cphi, double sphi
 // lanes (polar axis, exterior) go to the general pass, by lane mask.
 // Work-list entries are three words: first slot, lane mask low / high.
 #define SPH_WORK_STRIDE 3
+
+// ---- the "append" fused step (sph.hip: SphForce::fused_step_append) ---------------------------------------------------------
+// The force pass of a fused step knows where every particle will be at the NEXT step (it computes that step's sort key);
+// here it also puts the particle there: each cell of the next step's order owns a region [base[c], base[c + 1]) of the OTHER
+// buffer set, sized from the cell's current population plus slack, and a cursor; a block counts its particles per destination
+// cell in LDS, reserves with ONE atomic per (block, cell) -- one per (wave, cell) serialises on the few cells the resident
+// waves feed, one per (block, cell) is free: tools/dbg/append_cursor.hip -- and every lane stores its particle at its reserved
+// slot.  The sort passes of the next step (key histogram, scan, scatter: 2.2 of the 10.1 ms step at 1e8, 112 B per
+// particle) disappear.  Slots a region does not fill hold x = +inf (k_app_finish): the accumulation and force passes treat
+// such a slot as empty; a region that overflows spills into a tail region, the tail into `flag` (the step is then redone
+// the ordinary way from the source buffer, which is never written).
+#ifndef APP_EMPTY
+#define APP_EMPTY __builtin_inf()    // (particles.h) x of a slot that holds no particle
+#endif
+struct AppDev {
+  double *X, *Y, *Z;                 // destination: the position the NEXT accumulation and force pass read
+  uint32_t *SRC;                     // ... and the slot of the SOURCE set the particle came from: the position of THIS step (the
+                                     // state a download or any other call sees) stays there until the next pass -- 4 bytes
+                                     // instead of 24, and this pass is sensitive to what it stores (profiles/r06_append_ab.txt)
+  double *VX, *VY, *VZ, *AX, *AY, *AZ, *POT;
+  double *M;                         // nullptr: uniform mass (both buffer sets hold the constant)
+  uint32_t *ID;
+  const double *Msrc;
+  const uint32_t *IDsrc;
+  const uint32_t *base;              // [ncell + 2]: start of every cell's region, of the tail, end of the tail
+  uint32_t *cursor;                  // [ncell + 1]: arrivals per cell (all of them, spilled ones included) and in the tail
+  uint32_t *flag;                    // particles that found no room at all
+  uint32_t ncell;
+};
+struct AppOut {                      // one lane's particle, ready to be placed
+  double nx, ny, nz, vx, vy, vz, ax, ay, az, pot;
+  uint32_t cell;
+};
+#define APP_TAB 32
+struct AppShared { uint32_t cell[APP_TAB], cnt[APP_TAB], base[APP_TAB]; };
+
+__device__ __forceinline__ void app_store_at(const AppDev &A, size_t slot, const AppOut &o, size_t isrc);
+__device__ __forceinline__ void app_store(const AppDev &A, uint32_t cell, uint32_t r, const AppOut &o, size_t isrc)
+{
+  size_t slot;
+  const uint32_t cap = A.base[cell + 1] - A.base[cell];
+  if (r < cap) slot = (size_t)A.base[cell] + r;
+  else {
+    // the region is full: the tail (still a valid place: the passes recompute every particle's cell from its position)
+    const uint32_t t = atomicAdd(&A.cursor[A.ncell], 1u);
+    if (t >= A.base[A.ncell + 1] - A.base[A.ncell]) { atomicAdd(A.flag, 1u); return; }
+    slot = (size_t)A.base[A.ncell] + t;
+  }
+  app_store_at(A, slot, o, isrc);
+}
+__device__ __forceinline__ void app_store_at(const AppDev &A, size_t slot, const AppOut &o, size_t isrc)
+{
+  A.X[slot] = o.nx; A.Y[slot] = o.ny; A.Z[slot] = o.nz;
+  A.SRC[slot] = (uint32_t)isrc;
+  A.VX[slot] = o.vx; A.VY[slot] = o.vy; A.VZ[slot] = o.vz;
+  A.AX[slot] = o.ax; A.AY[slot] = o.ay; A.AZ[slot] = o.az;
+  A.POT[slot] = o.pot;
+  if (A.M) A.M[slot] = A.Msrc[isrc];
+  A.ID[slot] = A.IDsrc[isrc];
+}
+
+// a wave enters its particles in the block's table (one entry per destination cell): h = the entry (-1: the table is full:
+// the lane reserves for itself), rank = its place among the block's particles of that cell
+__device__ __forceinline__ void app_block_register(AppShared &sh, bool have, uint32_t cell, int &h, uint32_t &rank)
+{
+  const int lane = threadIdx.x & 63;
+  h = -1;
+  rank = 0;
+  unsigned long long todo = __ballot(have);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const uint32_t c = __shfl(cell, lead);
+    const unsigned long long m = __ballot(have && cell == c);
+    int hh = -1;
+    uint32_t woff = 0;
+    if (lane == lead) {
+      uint32_t k = c & (APP_TAB - 1);
+      for (int probe = 0; probe < APP_TAB; probe++, k = (k + 1) & (APP_TAB - 1)) {
+        const uint32_t old = atomicCAS(&sh.cell[k], 0xffffffffu, c);
+        if (old == 0xffffffffu || old == c) { hh = (int)k; break; }
+      }
+      if (hh >= 0) woff = atomicAdd(&sh.cnt[hh], (uint32_t)__popcll(m));
+    }
+    hh = __shfl(hh, lead);
+    woff = __shfl(woff, lead);
+    if (have && cell == c) { h = hh; rank = woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); }
+    todo &= ~m;
+  }
+}
+// ... after a barrier one thread per entry reserves in the cell's cursor; after another, the lanes store
+__device__ __forceinline__ void app_block_reserve(AppShared &sh, const AppDev &A)
+{
+  if (threadIdx.x < APP_TAB && sh.cell[threadIdx.x] != 0xffffffffu)
+    sh.base[threadIdx.x] = atomicAdd(&A.cursor[sh.cell[threadIdx.x]], sh.cnt[threadIdx.x]);
+}
+// the general pass' few waves: one atomic per (wave, cell)
+__device__ __forceinline__ void app_wave_store(const AppDev &A, bool have, const AppOut &o, size_t isrc)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(have);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const uint32_t c = __shfl(o.cell, lead);
+    const unsigned long long m = __ballot(have && o.cell == c);
+    uint32_t b = 0;
+    if (lane == lead) b = atomicAdd(&A.cursor[c], (uint32_t)__popcll(m));
+    b = __shfl(b, lead);
+    if (have && o.cell == c) app_store(A, c, b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), o, isrc);
+    todo &= ~m;
+  }
+}
+
 // The Cartesian projection and the stores of one particle's field (src/SphericalBasis.cc:1636-1652), with the fused
 // half-kick and the next step's sort key of the fused step: shared by every evaluation path.
-template <bool FAST>
+template <bool FAST, bool APP = false>
 __device__ __forceinline__ void
 sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double yy, double zz, double px, double py,
                  double pz, double fac, double ir, double iR2, double P0, double ffac, double dfac,
                  double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ, double *__restrict__ POT,
                  double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ, double dt_kick, int assign,
-                 uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v)
+                 uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v, AppOut *ao = nullptr)
 {
   // src/SphericalBasis.cc:1636-1652 (r is the clamped radius, as in the reference)
   const double potr = o.potr * ffac * (S.inv_scale * S.inv_scale);
@@ -1475,6 +1588,24 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
     if (fac > DSMALL) { ax -= qx; ay -= qy; }
   }
   double pt = potl;
+  if constexpr (APP) {
+    // the append step (fused, self force, assign, velocities stored with the next opening half-kick: store_v == 2): the
+    // arithmetic of the stores below, the results left in registers for the caller to place
+    const double vx = mul_then_add(VX[i], ax, dt_kick);
+    const double vy = mul_then_add(VY[i], ay, dt_kick);
+    const double vz = mul_then_add(VZ[i], az, dt_kick);
+    const double wx = mul_then_add(vx, ax, nk_dtk);
+    const double wy = mul_then_add(vy, ay, nk_dtk);
+    const double wz = mul_then_add(vz, az, nk_dtk);
+    ao->nx = mul_then_add(px, wx, nk_dtd);
+    ao->ny = mul_then_add(py, wy, nk_dtd);
+    ao->nz = mul_then_add(pz, wz, nk_dtd);
+    ao->vx = wx; ao->vy = wy; ao->vz = wz;
+    ao->ax = ax; ao->ay = ay; ao->az = az;
+    ao->pot = pt;
+    ao->cell = sph_key_cell_rcp(S, ao->nx, ao->ny, ao->nz);
+    return;
+  }
   // a frozen target particle is skipped by the thread body (src/SphericalBasis.cc:1521): nothing is added, the frame
   // term neither; the fused half-kick below still applies whatever other forces left in acc
   if (SPH_FRZ_ON(S) && sph_frozen(S, px, py, pz)) { ax = ay = az = 0.0; pt = 0.0; }
@@ -1513,15 +1644,17 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
   }
 }
 
-template <int LMAX, int MODE>
-__device__ __forceinline__ void
+// APP (the append step, MODE 0 and 1): the lane's results are left in *ao instead of being stored (the return value says
+// whether the lane has any); the store it reads may hold empty slots (x = +inf).
+template <int LMAX, int MODE, bool APP = false>
+__device__ __forceinline__ bool
 sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                 const double *__restrict__ Z, size_t base, size_t end, const double *__restrict__ T4,
                 double *__restrict__ AX, double *__restrict__ AY, double *__restrict__ AZ,
                 double *__restrict__ POT, double *__restrict__ VX, double *__restrict__ VY,
                 double *__restrict__ VZ, double dt_kick, int assign, uint32_t *__restrict__ work,
                 uint32_t *__restrict__ nwork, uint32_t *__restrict__ key_out, double nk_dtk,
-                double nk_dtd, int store_v, unsigned long long lanemask = ~0ull)
+                double nk_dtd, int store_v, unsigned long long lanemask = ~0ull, AppOut *ao = nullptr)
 {
   constexpr bool FAST = MODE != 0 && MODE != 3;
   const int lane = threadIdx.x & 63;
@@ -1533,6 +1666,10 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
   double px = 0, py = 0, pz = 0;          // kept for the next-step key (a reload at the end of the
   if (valid) {                            // wave would expose a full memory round trip)
     px = X[i]; py = Y[i]; pz = Z[i];
+    if constexpr (APP) valid = px != APP_EMPTY;
+  }
+  if constexpr (APP) { if (!__any(valid)) return false; }        // (a wave of empty slots: the end of a cell's region)
+  if (valid) {
     xx = px - S.cx;
     yy = py - S.cy;
     zz = pz - S.cz;
@@ -1580,7 +1717,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
           work[SPH_WORK_STRIDE * w + 1] = 0xffffffffu;
           work[SPH_WORK_STRIDE * w + 2] = 0xffffffffu;
         }
-        return;
+        return false;
       }
 #if SPH_T4_PREFETCH
       {
@@ -1690,16 +1827,20 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
     ir = 1.0 / r;
     iR2 = 1.0 / fac;
   }
-  if (!valid) return;
-  sph_force_finish<FAST>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
-                         dt_kick, assign, key_out, nk_dtk, nk_dtd, store_v);
+  if (valid)
+    sph_force_finish<FAST, APP>(S, o, i, xx, yy, zz, px, py, pz, fac, ir, iR2, P0, ffac, dfac, AX, AY, AZ, POT, VX, VY, VZ,
+                                dt_kick, assign, key_out, nk_dtk, nk_dtd, store_v, ao);
 #if SPH_T4_PREFETCH
   if constexpr (MODE != 0) asm volatile("" : : "v"(t4_sink));     // keeps the prefetch's registers out of circulation
 #endif
+  return valid;
 }
 
-template <int LMAX, int MODE>
-__global__ void __launch_bounds__(256, MODE == 1 ? SPH_FORCE_WAVES : MODE == 2 ? 2 : 1)
+#ifndef SPH_APP_WAVES
+#define SPH_APP_WAVES SPH_FORCE_WAVES
+#endif
+template <int LMAX, int MODE, bool APP = false>
+__global__ void __launch_bounds__(256, MODE == 1 ? (APP ? SPH_APP_WAVES : SPH_FORCE_WAVES) : MODE == 2 ? 2 : 1)
 k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
             int lev_hi, const double *__restrict__ T4, double *__restrict__ AX,
@@ -1707,9 +1848,49 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
             double *__restrict__ VX, double *__restrict__ VY, double *__restrict__ VZ,
             double dt_kick, int assign, uint32_t *__restrict__ work, uint32_t *__restrict__ nwork,
             uint32_t *__restrict__ key_out, double nk_dtk, double nk_dtd, int store_v,
-            uint32_t *__restrict__ nwork_clear /* counter of the NEXT launch pair: zeroed here */)
+            uint32_t *__restrict__ nwork_clear /* counter of the NEXT launch pair: zeroed here */,
+            AppDev app = AppDev{})
 {
   if (nwork_clear && blockIdx.x == 0 && threadIdx.x == 0) *nwork_clear = 0u;
+  if constexpr (APP && MODE == 1) {
+    // the append step's fast pass: every wave of the block reaches the two barriers (no early exit); a deferred wave has
+    // nothing to place here -- the general pass behind this launch places its particles
+    __shared__ AppShared sh;
+    if (threadIdx.x < APP_TAB) { sh.cell[threadIdx.x] = 0xffffffffu; sh.cnt[threadIdx.x] = 0u; }
+    __syncthreads();
+    const size_t beg = lev_off[lev_lo], end = lev_off[lev_hi + 1];
+    const size_t base = beg + ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63));
+    AppOut ao;
+    ao.cell = 0u;
+    bool have = false;
+    if (base < end)
+      have = sph_force_chunk<LMAX, 1, true>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, work,
+                                            nwork, nullptr, nk_dtk, nk_dtd, store_v, ~0ull, &ao);
+    // (reserving BEFORE the evaluation, by a next cell predicted from the last step's acceleration -- so that the atomics'
+    // round trip would pass under the evaluation -- was built and measured: 7.0 against 5.9 ms for this pass at 1e8; the
+    // early barrier and the registers held across the evaluation cost more than the round trip, profiles/r06_append_ab.txt)
+#if defined(APP_EXPT) && APP_EXPT == 1
+    // timing experiment: the wider stores alone -- own slot, no table, no barrier, no atomic (results are NOT usable)
+    if (have) { AppDev q = app; uint32_t zb[2] = {0u, 0xffffffffu}; (void)zb; app_store_at(q, base + (threadIdx.x & 63), ao, base + (threadIdx.x & 63)); }
+    return;
+#endif
+    int h;
+    uint32_t rank;
+    app_block_register(sh, have, ao.cell, h, rank);
+    __syncthreads();
+    app_block_reserve(sh, app);
+    __syncthreads();
+    if (have) {
+      const uint32_t r = h >= 0 ? sh.base[h] + rank : atomicAdd(&app.cursor[ao.cell], 1u);
+#if defined(APP_EXPT) && APP_EXPT == 2
+      // timing experiment: table, barriers and atomics as they are, the stores at the lane's own slot
+      (void)r; app_store_at(app, base + (threadIdx.x & 63), ao, base + (threadIdx.x & 63));
+#else
+      app_store(app, ao.cell, r, ao, base + (threadIdx.x & 63));
+#endif
+    }
+    return;
+  }
   if constexpr (MODE == 3) {
     // the literal pass: a fixed small grid walks the list (its length is only known on the device)
     const size_t n = S.lit_list[0] < S.lit_cap ? S.lit_list[0] : S.lit_cap;
@@ -1728,6 +1909,13 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
         const size_t base = work[SPH_WORK_STRIDE * w];
         const unsigned long long mask = (unsigned long long)work[SPH_WORK_STRIDE * w + 1] |
                                         ((unsigned long long)work[SPH_WORK_STRIDE * w + 2] << 32);
+        if constexpr (APP) {
+          AppOut ao;
+          ao.cell = 0u;
+          const bool have = sph_force_chunk<LMAX, 0, true>(S, X, Y, Z, base, end_, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+                                                           assign, work, nwork, nullptr, nk_dtk, nk_dtd, store_v, mask, &ao);
+          app_wave_store(app, have, ao, base + (threadIdx.x & 63));
+        } else
         sph_force_chunk<LMAX, 0>(S, X, Y, Z, base, end_, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, work, nwork,
                                  key_out, nk_dtk, nk_dtd, store_v, mask);
       }
@@ -2330,6 +2518,7 @@ struct SphForceArgs {
   uint32_t *nwork_next = nullptr;   // the counter the next launch will use (cleared by this one's general pass)
   int waterfall = 0;        // fast pass as a waterfall over each wave's radial cells (MODE 2)
   int stage_rows = 0;       // all_slow launches: cells whose table rows a block stages in LDS (0: global gathers)
+  const AppDev *app = nullptr;      // the append step (fused_step_append): place the results in the other buffer set
 };
 
 struct SphUpdArgs {

@@ -112,6 +112,11 @@ class Context:
         movers through the accumulation kernels instead of per-particle atomics (0: always, < 0: never)."""
         check(self.lib.exp_amd_ctx_set_mover_list_min(self.h, int(nmin)), self.h)
 
+    def set_append_min(self, nmin: int) -> None:
+        """Single-level components of at least ``nmin`` particles take the APPEND fused step (no sort passes: the force pass
+        places every particle in the next step's cell order; include/exp_amd.h).  ``nmin <= 0``: never."""
+        check(self.lib.exp_amd_ctx_set_append_min(self.h, int(nmin)), self.h)
+
     def set_split_min(self, nmin: int) -> None:
         """Smallest component the fused step handles as two overlapped halves (<= 0: never)."""
         check(self.lib.exp_amd_ctx_set_split_min(self.h, int(nmin)), self.h)

@@ -38,7 +38,7 @@ typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylin
 
 /* ---- library / context ------------------------------------------------------------ */
 
-/* Environment.  The library reads SEVEN environment variables, each once, where the object it concerns is created; none
+/* Environment.  The library reads EIGHT environment variables, each once, where the object it concerns is created; none
  * is needed for correct results, everything a host would want to set at run time has a setter below.
  *   EXP_AMD_SPH_GENERIC=1 / EXP_AMD_CYL_GENERIC=1   (exp_amd_sph_create / exp_amd_cyl_create) every per-particle pass of
  *       that force through the any-order (run-time loop) kernels, which orders above 12 always take
@@ -50,7 +50,8 @@ typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylin
  *   EXP_AMD_SIM_OVERLAP=0   (exp_amd_sim_init / exp_amd_sim_step) the two-component block-multistep driver keeps both
  *       components on the context's one stream (tests/test_config4_gpu.py);
  *   EXP_AMD_STEP_GRAPH=0    (exp_amd_step_kdk_n) never capture: every step eager (tests/test_rccl_gpu.py);
- *   EXP_AMD_POISON=1        (every device allocation) fresh device memory reads as NaN patterns (tests/test_poison_gpu.py).
+ *   EXP_AMD_POISON=1        (every device allocation) fresh device memory reads as NaN patterns (tests/test_poison_gpu.py);
+ *   EXP_AMD_APPEND_MIN=n    (exp_amd_ctx_create) the default of exp_amd_ctx_set_append_min (tests/test_sph_gpu.py).
  * The tuning and A/B switches of the development rounds (tile sizes, launch reductions that can be undone, ...) are
  * compile-time constants of the default build; `make EXPERIMENTAL=1` (-DEXP_AMD_EXPERIMENTAL) turns each
  * EXPAMD_EXPT("NAME", default) of exp_amd/csrc/ back into an environment variable for A/B runs.                       */
@@ -67,6 +68,12 @@ const char *exp_amd_last_global_error(void);
 int  exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out);
 void exp_amd_ctx_destroy(exp_amd_ctx *ctx);
 int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
+/* The APPEND form of the fused step (exp_amd_step_kdk, spherical force, single level, steady state: same dt, same centre):
+ * single-level components of at least `nmin` particles are stepped without sort passes -- the force pass, which knows where
+ * every particle will be at the next step, places it in that step's cell order itself (regions per cell in the other buffer
+ * set, one reservation per block and destination cell) -- and every other call first turns the store back into an ordinary
+ * one.  Same trajectories up to the order of the coefficient sums.  nmin <= 0 turns it off.                              */
+int  exp_amd_ctx_set_append_min(exp_amd_ctx *ctx, long long nmin);
 /* Tuning knob of exp_amd_step_kdk: single-level components of at least `nmin` particles are stepped
  * as two independently cell-sorted halves so that the HBM-bound sort passes of one half overlap the
  * VALU-bound accumulate / force passes of the other on a second HIP stream (same results up to the

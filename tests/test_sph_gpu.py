@@ -388,6 +388,54 @@ def test_fused_step_key_reuse_and_invalidation(ctx, oracle, plummer_s6):
         assert acc_err(out["acc"], ref["acc"]) <= 1e-8
 
 
+@pytest.mark.parametrize("violent", [False, True, "tight"])
+def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
+    """The APPEND form of the fused step (exp_amd_ctx_set_append_min; exp_amd/csrc/sph.hip: fused_step_append) -- no sort
+    passes: the force pass places every particle in the next step's cell order, in regions with empty slots behind their
+    particles -- against the ordinary fused step on the same particles, call for call: a download in the middle (the store
+    is turned into an ordinary one and the mode is entered again two steps later), a change of dt and of the centre, an
+    odd particle count, a non-uniform mass.  `violent`: velocities that empty half the cells within a step -- the regions
+    sized from the present populations and the tail overflow, and the step is redone the ordinary way from its source."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_s6
+    n = 300_007
+    m, pos, vel = _particles(model, n, seed=41)
+    m = m * np.random.default_rng(1).uniform(0.5, 1.5, n)
+    if violent is True:
+        vel = 8.0 * pos / np.linalg.norm(pos, axis=1)[:, None] + vel
+    # "tight": regions without slack (set_append_min(-n)): every pass runs out of room and the step is redone from its source
+    dts = [0.01] * 7 + [0.004] * 4 + [0.01] * 3
+
+    def run(app):
+        ctx.set_append_min((-1000 if violent == "tight" else 1000) if app else 0)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        snaps = []
+        for k, dt in enumerate(dts):
+            f.step_kdk(c, dt)
+            if k == 4:
+                snaps.append(c.download())                 # densify; the next steps are ordinary until the keys are back
+            if k == 11:
+                c.set_center([0.01, -0.02, 0.005])
+        out = c.download()
+        cf, used = f.get_coefs(), f.Used()
+        c.close(); f.close()
+        ctx.set_append_min(0)
+        return out, cf, used, snaps
+
+    ref, cref, uref, sref = run(False)
+    out, cf, used, snaps = run(True)
+    assert used == uref
+    assert coef_err(cf, cref) <= COEF_TOL
+    for a, b in ((out, ref), (snaps[0], sref[0])):
+        assert np.array_equal(a["mass"], b["mass"])                   # every particle is there, once, with its own mass
+        assert np.abs(a["pos"] - b["pos"]).max() <= 1e-11 * (1.0 + np.abs(b["pos"]).max())
+        assert np.abs(a["vel"] - b["vel"]).max() <= 1e-9 * np.abs(b["vel"]).max()
+        assert acc_err(a["acc"], b["acc"]) <= 1e-8
+        assert np.abs(a["pot"] - b["pot"]).max() <= 1e-9 * np.abs(b["pot"]).max()
+
+
 def test_split_fused_step_matches_the_unfused_sequence(ctx, oracle, plummer_s6):
     """The split fused step (two independently sorted halves, sort passes on a second stream
     overlapping accumulate / force) against the call-for-call step: same trajectory up to the order
