@@ -58,6 +58,11 @@ ALGO_BYTES = {
 # exp_amd_ctx_set_prekick, so that the reordering pass does not read the accelerations) and the 4-byte sort key of
 # the next step = 108 B, i.e. the contract's 104 + the key.
 OWN_BYTES = {"k_sph_force": 108.0, "k_cyl_force": 108.0}
+# ... and in the APPEND form of the fused step (exp_amd_ctx_set_append_min), where the force pass also
+# drifts the particle and places it in the next step's cell order: reads x,y,z,vx,vy,vz,id (52); writes the next position
+# (24), the velocities with both half-kicks (24), ax,ay,az,pot (32), id and the slot it came from (8) = 140 B.  The
+# contract figure quoted as `achieved` stays pass B's 104 B.
+OWN_BYTES_APPEND = {"k_sph_force": 140.0}
 # fp64 operations executed per particle (FMA = 2), static count of the unrolled fast paths
 # (tools/isa_count.py on the gfx950 assembly)
 # (k_cyl_force: its static count of 1427 holds both table paths -- scalar rows for a cell-uniform wave,
@@ -799,7 +804,8 @@ def main():
     ctx = Context(dev_index, stream=tstream.cuda_stream)
     if args.split:
         ctx.set_split_min(1)
-    ctx.set_append_min(0 if (args.no_append or args.split or args.graph) else 1 << 20)
+    ctx.set_append_min(0 if (args.no_append or args.split or args.graph) else 1 << 20)          # (2^20 is the library's default)
+    step_form = "ordinary" if (args.no_append or args.split or args.graph or nloc < (1 << 20)) else "append"
     comp = Component(ctx, nloc)
     comp.upload_device(mass, x, y, z, vx, vy, vz)
     del x, y, z, vx, vy, vz, mass
@@ -995,8 +1001,9 @@ def main():
             # what the kernel itself moves in the fused step (the contract's figure counts the v store
             # of the closing half-kick, which lives in the next scatter pass here)
             if dom in OWN_BYTES:
-                own = OWN_BYTES[dom] * nloc / (avg_ms * 1e-3) / 1e9
-                roof["kernel_own_bytes_per_particle"] = OWN_BYTES[dom]
+                ownb = OWN_BYTES_APPEND.get(dom, OWN_BYTES[dom]) if step_form == "append" else OWN_BYTES[dom]
+                own = ownb * nloc / (avg_ms * 1e-3) / 1e9
+                roof["kernel_own_bytes_per_particle"] = ownb
                 roof["kernel_own_achieved"] = own
                 roof["kernel_own_frac"] = own / HBM_PEAK_GBS
             # The binding limit of this kernel is the fp64 vector ALU: executed
@@ -1035,7 +1042,9 @@ def main():
             "step_times": step_times,
             "stepping": ("exp_amd_step_kdk_n: pairs of steps replayed from a HIP graph (eager region with per-kernel "
                          f"events: {1e3 * el_eager / args.steps:.4f} ms/step)") if graph_region else
-                        ("exp_amd_step_kdk per step (eager launches, per-kernel events on)" +
+                        ("exp_amd_step_kdk per step (eager launches, per-kernel events on" +
+                         ("; APPEND form: no sort passes, the force pass places every particle in the next step's cell order)"
+                          if step_form == "append" else ")") +
                          ("; SPLIT fused step: two half stores, sort passes on a second stream" if args.split else "")),
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -1045,6 +1054,9 @@ def main():
             "config": {"workload": f"{ntot:.0e}-particle truncated-NFW halo, SphericalSL "
                                    f"lmax={args.lmax} nmax={args.nmax} numr={args.numr}, "
                                    "multistep=0, KDK step (kick/2, drift, sort, coef, force, kick/2)",
+                       # "append": no sort passes -- the force pass drifts every particle and places it in the next step's cell
+                       # order (exp_amd_ctx_set_append_min); "ordinary": key histogram, scan and scatter pass every step
+                       "step_form": step_form,
                        "nbodies_total": ntot, "nbodies_per_gpu": nloc, "lmax": args.lmax,
                        "nmax": args.nmax, "numr": args.numr, "dt": args.dt,
                        "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"

@@ -74,7 +74,7 @@ struct exp_amd_ctx {
   unsigned long long force_epoch = 0;           // bumped when a force dies: sort keys recorded for "the force
                                                 // at this address" must not outlive it
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
-  long long append_min = 0;          // single-level components at least this large take the APPEND fused step: the force pass
+  long long append_min = 1 << 20;    // single-level components at least this large take the APPEND fused step: the force pass
                                      // places every particle in the next step's cell order itself, no sort passes
                                      // (sph.hip: fused_step_append; exp_amd_ctx_set_append_min; 0: never; < 0: as -nmin with
                                      // regions WITHOUT slack and a 64-slot tail, so that the run-out-of-room path is taken: tests)

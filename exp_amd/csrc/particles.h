@@ -153,6 +153,12 @@ struct exp_amd_comp {
   DevBuf<uint32_t> app_range[2];        // {0, end of the tail}: plays lev_off for the passes over an appended set
   DevBuf<uint32_t> app_cursor;          // [ncell + 1] + flag word
   bool app_redo = false;                // a step whose append pass ran out of room is being redone from its (advanced) source
+  // Hysteresis: turning an appended store back into an ordinary one costs a pass over everything (and the next step a full key
+  // pass), so a caller that looks at the particles every few steps must not bounce in and out of the mode -- after each such
+  // exit the mode stays off for app_wait more fused steps, twice as many as the time before (8, 16, ... 1024), back to 8 once
+  // it has run for 64 steps in a row
+  int app_wait = 0, app_backoff = 8, app_run = 0;
+  bool app_refused = false;             // no room on the device for the appended layout: the ordinary step from now on
   double *a(int k) { return arr[cur][k].p; }
   double *b(int k) { return arr[1 - cur][k].p; }
 };

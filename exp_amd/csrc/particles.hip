@@ -518,6 +518,15 @@ int expamd_comp_app_reserve(exp_amd_comp *c, size_t cap)
   exp_amd_ctx *ctx = c->ctx;
   if (c->app_cap >= cap) return EXP_AMD_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    // the larger arrays are made one at a time next to the ones they replace: is there room for the growth (and the new
+    // index / scratch arrays) plus one array in flight?  If not the component keeps the ordinary step (app_refused)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t grow = (cap - c->n) * (2 * (A_NARR * sizeof(double) + sizeof(uint32_t))) +
+                        cap * (2 * (3 * sizeof(double) + sizeof(uint32_t))) + cap * sizeof(double);
+    if (free_b < grow + (size_t)(1u << 30)) { c->app_refused = true; return EXP_AMD_OK; }
+  }
   for (int w = 0; w < 2; w++) {
     for (int a = 0; a < A_NARR; a++) {
       DevBuf<double> nb;
@@ -618,6 +627,9 @@ int expamd_comp_densify(exp_amd_comp *c, bool state_positions)
   if ((size_t)got != c->n)
     return expamd_fail(ctx, EXP_AMD_ERR_STATE, "appended store: %u particles found, %zu expected", got, c->n);
   for (int k = 0; k < 3; k++) std::swap(c->arr[d][A_X + k], c->xo[d][k]);
+  c->app_wait = c->app_backoff;
+  c->app_backoff = c->app_run >= 64 ? 8 : (c->app_backoff < 1024 ? 2 * c->app_backoff : 1024);
+  c->app_run = 0;
   c->cur = d;
   c->appended = false;
   c->app_owner = nullptr;
@@ -1223,6 +1235,7 @@ extern "C" int exp_amd_comp_upload(exp_amd_comp *c, const double *mass, const do
                                    const double *vy, const double *vz)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (c) { c->app_wait = 0; c->app_backoff = 8; }      // (new particle data: the append step's hysteresis starts over)
   if (!c) return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
   const double *h[7] = {x, y, z, vx, vy, vz, mass};
@@ -1288,6 +1301,7 @@ extern "C" int exp_amd_comp_upload_frame(exp_amd_comp *c, const double *mass, co
                                          int stride, const double center[3], const double rot[9])
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (c) { c->app_wait = 0; c->app_backoff = 8; }      // (new particle data: the append step's hysteresis starts over)
   if (!c || !x || (stride != 1 && stride != 3) || (stride == 1 && (!y || !z)) || (stride == 1 && vx && (!vy || !vz)))
     return EXP_AMD_ERR_ARG;
   if (c->n == 0) return EXP_AMD_OK;
@@ -1330,6 +1344,7 @@ extern "C" int exp_amd_comp_upload_device(exp_amd_comp *c, const double *mass, c
                                           const double *vy, const double *vz)
 {
   if (c) { int rc_ = expamd_comp_touch(c); if (rc_) return rc_; }
+  if (c) { c->app_wait = 0; c->app_backoff = 8; }      // (new particle data: the append step's hysteresis starts over)
   if (!c) return EXP_AMD_ERR_ARG;
   exp_amd_ctx *ctx = c->ctx;
   if (c->n == 0) return EXP_AMD_OK;

@@ -1161,9 +1161,10 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   const bool offered = amin > 0 && c->n >= (size_t)amin && !f->cfg.multistep && !f->lit_on &&
                        !f->subset_on && !f->noise_on && !f->generic && !ctx->deterministic && ctx->prekick && !c->freeze_on &&
                        !(c->pseudo.center | c->pseudo.axis) && c->nlevels == 1 && c->levels_zero && !f->fix_l0 &&
-                       c->n < 0x70000000u && !(c->appended && !cont);
+                       c->n < 0x70000000u && !c->app_refused && !(c->appended && !cont);
   if (c->appended && !(cont && offered)) return expamd_comp_densify(c);     // (the ordinary step takes over)
   if (!offered) return EXP_AMD_OK;
+  if (!cont && c->app_wait > 0) { c->app_wait--; return EXP_AMD_OK; }       // (hysteresis: particles.h)
   // entry: the ordinary fused step's steady state -- sorted for this force, velocities stored with this step's opening
   // half-kick, this step's keys written by the last force pass
   if (!cont && !(have_keys && c->sorted_for == (const void *)f && c->pending_kick == -dt_kick && !c->split)) return EXP_AMD_OK;
@@ -1174,6 +1175,7 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   hipStream_t st = ctx->stream;
   if (!cont) {
     if ((rc = expamd_comp_app_reserve(c, cap))) return rc;
+    if (c->app_refused) return EXP_AMD_OK;           // (no room for the layout: the ordinary step)
     c->app_ns = cap;
     if ((rc = expamd_comp_prepare_hist(c, ncell))) return rc;
     {
@@ -1257,6 +1259,7 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
     return EXP_AMD_OK;
   }
   c->cur = dst;
+  c->app_run++;
   c->acc_live = true;
   c->pending_kick = -dt_kick;         // velocities stored with the next step's opening half-kick (as the ordinary step's prekick)
   c->prekey_valid = false;

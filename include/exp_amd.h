@@ -72,7 +72,11 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
  * single-level components of at least `nmin` particles are stepped without sort passes -- the force pass, which knows where
  * every particle will be at the next step, places it in that step's cell order itself (regions per cell in the other buffer
  * set, one reservation per block and destination cell) -- and every other call first turns the store back into an ordinary
- * one.  Same trajectories up to the order of the coefficient sums.  nmin <= 0 turns it off.                              */
+ * one.  Same trajectories up to the order of the coefficient sums.  Default: 2^20; 0 turns it off; nmin < 0: as -nmin with
+ * regions that have no slack at all, so that a pass runs out of room and the step is redone from its source (the tests' way
+ * into that path).  The layout needs about a quarter more device memory than the ordinary store (the slack, the source-slot
+ * index, the scratch of the way back); a component for which that is not free keeps the ordinary step.  A caller that looks
+ * at the particles every few steps is recognised: each exit keeps the mode off for 8, 16, ... 1024 further steps.          */
 int  exp_amd_ctx_set_append_min(exp_amd_ctx *ctx, long long nmin);
 /* Tuning knob of exp_amd_step_kdk: single-level components of at least `nmin` particles are stepped
  * as two independently cell-sorted halves so that the HBM-bound sort passes of one half overlap the

@@ -404,7 +404,8 @@ def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
     if violent is True:
         vel = 8.0 * pos / np.linalg.norm(pos, axis=1)[:, None] + vel
     # "tight": regions without slack (set_append_min(-n)): every pass runs out of room and the step is redone from its source
-    dts = [0.01] * 7 + [0.004] * 4 + [0.01] * 3
+    # (after an exit the mode stays off for 8, then 16 ... fused steps -- particles.h: app_wait -- hence the long last stretch)
+    dts = [0.01] * 7 + [0.004] * 4 + [0.01] * 30
 
     def run(app):
         ctx.set_append_min((-1000 if violent == "tight" else 1000) if app else 0)
