@@ -469,15 +469,18 @@ k_app_layout(const uint32_t *__restrict__ counts, uint32_t ncell, uint32_t tail,
 }
 
 // after the passes have placed their particles in a buffer set: x = +inf behind the filled part of every region and of the tail
+#define APP_MARK_TAIL 256u
 __global__ void __launch_bounds__(256)
 k_app_mark(const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill /* per cell: cursor, or the scatter's running
            offsets (absolute != 0) */, int absolute, uint32_t ncell, double *__restrict__ X)
 {
-  const uint32_t c = blockIdx.x;        // ncell + 1 blocks: the last one is the tail
+  // ncell blocks for the regions, APP_MARK_TAIL more for the tail (one block alone would write its n / 128 slots in 0.1 ms)
+  const uint32_t c = blockIdx.x < ncell ? blockIdx.x : ncell;
   const uint32_t b = base[c], e = base[c + 1];
   uint32_t f = absolute ? (c < ncell ? fill[c] - b : 0u) : fill[c];
   if (f > e - b) f = e - b;
-  for (uint32_t s = b + f + threadIdx.x; s < e; s += 256) X[s] = APP_EMPTY;
+  const uint32_t part = c < ncell ? 0u : blockIdx.x - ncell, nparts = c < ncell ? 1u : APP_MARK_TAIL;
+  for (uint32_t s = b + f + part * 256u + threadIdx.x; s < e; s += 256u * nparts) X[s] = APP_EMPTY;
 }
 
 __global__ void __launch_bounds__(256)
@@ -571,7 +574,7 @@ int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t nce
 int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag)
 {
   exp_amd_ctx *ctx = c->ctx;
-  k_app_mark<<<c->app_ncell + 1, 256, 0, ctx->stream>>>(c->app_base[set].p, c->app_cursor.p, 0, c->app_ncell, c->arr[set][A_X].p);
+  k_app_mark<<<c->app_ncell + APP_MARK_TAIL, 256, 0, ctx->stream>>>(c->app_base[set].p, c->app_cursor.p, 0, c->app_ncell, c->arr[set][A_X].p);
   HIP_TRY(ctx, hipGetLastError());
   if (host_flag) {
     HIP_TRY(ctx, hipMemcpyAsync(host_flag, c->app_cursor.p + c->app_ncell + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -582,7 +585,7 @@ int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag)
 
 void k_app_mark_launch(exp_amd_comp *c, int set, const uint32_t *offs)
 {
-  k_app_mark<<<c->app_ncell + 1, 256, 0, c->ctx->stream>>>(c->app_base[set].p, offs, 1, c->app_ncell, c->arr[set][A_X].p);
+  k_app_mark<<<c->app_ncell + APP_MARK_TAIL, 256, 0, c->ctx->stream>>>(c->app_base[set].p, offs, 1, c->app_ncell, c->arr[set][A_X].p);
 }
 
 int expamd_comp_densify(exp_amd_comp *c, bool state_positions)
