@@ -63,6 +63,8 @@ OWN_BYTES = {"k_sph_force": 108.0, "k_cyl_force": 108.0}
 # (24), the velocities with both half-kicks (24), ax,ay,az,pot (32), id and the slot it came from (8) = 140 B.  The
 # contract figure quoted as `achieved` stays pass B's 104 B.
 OWN_BYTES_APPEND = {"k_sph_force": 140.0}
+# (--append-lean, exp_amd_ctx_set_append_lean: acceleration and potential are not placed but re-evaluated for whoever looks: 108 B)
+OWN_BYTES_APPEND_LEAN = {"k_sph_force": 108.0}
 # fp64 operations executed per particle (FMA = 2), static count of the unrolled fast paths
 # (tools/isa_count.py on the gfx950 assembly)
 # (k_cyl_force: its static count of 1427 holds both table paths -- scalar rows for a cell-uniform wave,
@@ -107,6 +109,11 @@ def parse_args():
                     help="the ordinary fused step (key histogram, scan, scatter pass every step) instead of the APPEND form, in "
                          "which the force pass places every particle in the next step's cell order itself "
                          "(exp_amd_ctx_set_append_min; profiles/r06_append_ab.txt)")
+    ap.add_argument("--append-lean", action="store_true",
+                    help="A/B: the append step with the LEAN payload (exp_amd_ctx_set_append_lean: the placing pass stores neither "
+                         "acceleration nor potential; they are re-evaluated for the first call that looks at the particles -- here the "
+                         "self-check after the timed region).  NOT the default line: the default leaves the complete state in the "
+                         "store after every step")
     ap.add_argument("--split", action="store_true",
                     help="the opt-in split fused step (exp_amd_ctx_set_split_min): the store as two independently sorted "
                          "halves, the HBM-bound sort passes of one half on a second stream under the fp64-bound accumulate / "
@@ -805,6 +812,7 @@ def main():
     if args.split:
         ctx.set_split_min(1)
     ctx.set_append_min(0 if (args.no_append or args.split or args.graph) else 1 << 20)          # (2^20 is the library's default)
+    ctx.set_append_lean(bool(args.append_lean))
     step_form = "ordinary" if (args.no_append or args.split or args.graph or nloc < (1 << 20)) else "append"
     comp = Component(ctx, nloc)
     comp.upload_device(mass, x, y, z, vx, vy, vz)
@@ -1001,7 +1009,8 @@ def main():
             # what the kernel itself moves in the fused step (the contract's figure counts the v store
             # of the closing half-kick, which lives in the next scatter pass here)
             if dom in OWN_BYTES:
-                ownb = OWN_BYTES_APPEND.get(dom, OWN_BYTES[dom]) if step_form == "append" else OWN_BYTES[dom]
+                ownb = ((OWN_BYTES_APPEND_LEAN if args.append_lean else OWN_BYTES_APPEND).get(dom, OWN_BYTES[dom])
+                        if step_form == "append" else OWN_BYTES[dom])
                 own = ownb * nloc / (avg_ms * 1e-3) / 1e9
                 roof["kernel_own_bytes_per_particle"] = ownb
                 roof["kernel_own_achieved"] = own
@@ -1057,6 +1066,9 @@ def main():
                        # "append": no sort passes -- the force pass drifts every particle and places it in the next step's cell
                        # order (exp_amd_ctx_set_append_min); "ordinary": key histogram, scan and scatter pass every step
                        "step_form": step_form,
+                       # "full": the placing pass stores the complete state (next position, velocities, acceleration, potential);
+                       # "lean" (--append-lean): acceleration and potential re-evaluated for whoever looks at the particles
+                       "append_payload": (None if step_form != "append" else "lean" if args.append_lean else "full"),
                        "nbodies_total": ntot, "nbodies_per_gpu": nloc, "lmax": args.lmax,
                        "nmax": args.nmax, "numr": args.numr, "dt": args.dt,
                        "parallelism": f"particle-shard x{world}, 1 coef all-reduce/step"

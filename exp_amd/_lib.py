@@ -96,6 +96,7 @@ SIGNATURES = {
                                       POINTER(c_void_p)]),
     "exp_amd_ctx_set_split_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_append_min": (c_int, [c_void_p, c_longlong]),
+    "exp_amd_ctx_set_append_lean": (c_int, [c_void_p, c_int]),
     "exp_amd_ctx_set_dense_min": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_thin_max": (c_int, [c_void_p, c_longlong]),
     "exp_amd_ctx_set_mover_list_min": (c_int, [c_void_p, c_longlong]),

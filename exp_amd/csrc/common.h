@@ -74,10 +74,17 @@ struct exp_amd_ctx {
   unsigned long long force_epoch = 0;           // bumped when a force dies: sort keys recorded for "the force
                                                 // at this address" must not outlive it
   std::vector<struct exp_amd_force *> forces;   // live force objects (so that a dying component can be forgotten)
+  std::vector<struct exp_amd_comp *> appended;  // components whose store is in the append step's layout (particles.h): a dying
+                                                // force turns those it owns back into ordinary stores first
   long long append_min = 1 << 20;    // single-level components at least this large take the APPEND fused step: the force pass
                                      // places every particle in the next step's cell order itself, no sort passes
                                      // (sph.hip: fused_step_append; exp_amd_ctx_set_append_min; 0: never; < 0: as -nmin with
                                      // regions WITHOUT slack and a 64-slot tail, so that the run-out-of-room path is taken: tests)
+  bool append_lean = false;          // ... and places neither acceleration nor potential (32 of the 88 bytes a particle, which no
+                                     // pass of the next step reads: 5.7 -> 5.2 ms for the pass at 1e8): the first call that looks
+                                     // at the component has them re-evaluated from the coefficient set kept at the completed step
+                                     // (exp_amd_ctx_set_append_lean; EXP_AMD_APPEND_LEAN; off by default: the state a step leaves
+                                     // in the store is then complete without a further pass)
   long long split_min = 0;           // components at least this large take the split step (<= 0: never;
                                      // off by default: +1.5 % at 1e8 on MI355X)
   bool prekick = true;               // the fused step stores velocities with the NEXT step's opening half-kick applied

@@ -48,6 +48,7 @@ extern "C" int exp_amd_ctx_create(int device, void *stream, exp_amd_ctx **out)
   ctx->stage_max = EXPAMD_EXPT("EXP_AMD_STAGE_MAX", ctx->stage_max);
   // EXP_AMD_APPEND_MIN (include/exp_amd.h, "Environment"): the default of exp_amd_ctx_set_append_min
   if (const char *e = getenv("EXP_AMD_APPEND_MIN")) ctx->append_min = atoll(e);
+  if (const char *e = getenv("EXP_AMD_APPEND_LEAN")) ctx->append_lean = atoll(e) != 0;
   HIP_TRY(ctx, hipSetDevice(device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -136,6 +137,14 @@ extern "C" int exp_amd_ctx_set_append_min(exp_amd_ctx *ctx, long long nmin)
   expamd_mutated();
   if (!ctx) return EXP_AMD_ERR_ARG;
   ctx->append_min = nmin;
+  return EXP_AMD_OK;
+}
+
+extern "C" int exp_amd_ctx_set_append_lean(exp_amd_ctx *ctx, int on)
+{
+  expamd_mutated();
+  if (!ctx) return EXP_AMD_ERR_ARG;
+  ctx->append_lean = on != 0;          // (read by every append step: a store placed the other way stays valid either way)
   return EXP_AMD_OK;
 }
 

@@ -58,6 +58,13 @@ extern "C" void exp_amd_force_destroy(exp_amd_force *f)
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->step_graph.exec) (void)hipGraphExecDestroy(f->step_graph.exec);
   f->step_graph.exec = nullptr;
+  {
+    // components whose store is in this force's append layout: ordinary stores again while the force can still
+    // evaluate the accelerations its placing passes did not store (particles.h: app_acc_stale)
+    std::vector<exp_amd_comp *> mine;
+    for (exp_amd_comp *c : f->ctx->appended) if (c->app_owner == (const void *)f) mine.push_back(c);
+    for (exp_amd_comp *c : mine) (void)expamd_comp_densify(c);
+  }
   f->ctx->force_epoch++;
   {
     auto &v = f->ctx->forces;

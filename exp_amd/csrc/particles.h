@@ -153,6 +153,12 @@ struct exp_amd_comp {
   DevBuf<uint32_t> app_range[2];        // {0, end of the tail}: plays lev_off for the passes over an appended set
   DevBuf<uint32_t> app_cursor;          // [ncell + 1] + flag word
   bool app_redo = false;                // a step whose append pass ran out of room is being redone from its (advanced) source
+  // The placing pass does not store the acceleration and the potential (32 of 88 bytes a particle that no pass of the next
+  // step reads): while app_acc_stale, AX / AY / AZ / POT of the live set are not the state's.  expamd_comp_densify has the
+  // owner re-evaluate them at the positions of the completed step, from the coefficient set of that step (sph.hip:
+  // sph_app_reeval); the component is on its context's `appended` list meanwhile, so that a dying force can do that first.
+  bool app_acc_stale = false;
+  int (*app_reeval)(void *owner, struct exp_amd_comp *c) = nullptr;
   // Hysteresis: turning an appended store back into an ordinary one costs a pass over everything (and the next step a full key
   // pass), so a caller that looks at the particles every few steps must not bounce in and out of the mode -- after each such
   // exit the mode stays off for app_wait more fused steps, twice as many as the time before (8, 16, ... 1024), back to 8 once
@@ -174,6 +180,7 @@ inline size_t expamd_app_slots(size_t n, uint32_t ncell) { return n + n / 64 + (
 int expamd_comp_app_reserve(exp_amd_comp *c, size_t cap);
 // an appended store becomes an ordinary dense one (positions: those of the completed step; order: none)
 int expamd_comp_densify(exp_amd_comp *c, bool state_positions = true);
+void expamd_app_unlist(exp_amd_comp *c);          // off its context's `appended` list
 // the layout of the NEXT buffer set from the populations in `counts` (ncell values), cursors cleared
 int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t ncell, int set, uint32_t *also_into);
 // after an append pass into buffer set `set`: empty slots marked, the next layout's populations are the cursors

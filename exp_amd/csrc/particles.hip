@@ -635,7 +635,11 @@ int expamd_comp_densify(exp_amd_comp *c, bool state_positions)
   c->app_run = 0;
   c->cur = d;
   c->appended = false;
+  void *const owner = const_cast<void *>(c->app_owner);
+  const bool reeval = state_positions && c->app_acc_stale && c->app_reeval && owner;
+  c->app_acc_stale = false;
   c->app_owner = nullptr;
+  expamd_app_unlist(c);
   c->sorted_for = nullptr;
   c->prekey_valid = false;
   c->split = false;
@@ -644,7 +648,16 @@ int expamd_comp_densify(exp_amd_comp *c, bool state_positions)
   const uint32_t lo1[2] = {0u, (uint32_t)c->n};
   HIP_TRY(ctx, hipMemcpyAsync(c->lev_off.p, lo1, sizeof(lo1), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the state's acceleration and potential, which the placing passes did not carry along (particles.h: app_acc_stale)
+  if (reeval) return c->app_reeval(owner, c);
   return EXP_AMD_OK;
+}
+
+void expamd_app_unlist(exp_amd_comp *c)
+{
+  auto &v = c->ctx->appended;
+  for (size_t k = 0; k < v.size(); k++)
+    if (v[k] == c) { v.erase(v.begin() + k); break; }
 }
 
 int expamd_comp_touch(exp_amd_comp *c)
@@ -1129,6 +1142,7 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
   if (c->ctx->aux) (void)hipStreamSynchronize(c->ctx->aux);
   (void)hipStreamSynchronize(c->ctx->stream);
   expamd_forget_component(c->ctx, c);
+  expamd_app_unlist(c);
   for (int w = 0; w < 2; w++) {
     for (int a = 0; a < A_NARR; a++) c->arr[w][a].release();
     c->id[w].release();

@@ -424,7 +424,7 @@ void SphForce::release()
   d_ev.release(); d_d0.release(); d_Gd.release();
   d_wscale.release();
   expamd_sph_cov_release(this);
-  d_W.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release(); d_xwork.release();
+  d_W.release(); d_coef_app.release(); d_part.release(); d_G.release(); d_T4.release(); d_work.release(); d_xwork.release();
   d_Wd.release(); d_differ.release();
   for (auto &b : d_ss) b.release();
   d_ss_prefix.release();
@@ -1149,6 +1149,44 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
 // cursors).  A pass that runs out of room (a region AND the tail full: a flag, read back after every step) is redone the
 // ordinary way from its source set, which no pass writes.  Any other call on the component turns the store back into an
 // ordinary one first (expamd_comp_densify).  Trajectories: those of the ordinary fused step up to the order of the sums.
+// The state's acceleration and potential after append steps.  The placing pass stores neither (AppDev): when the store has
+// been turned back into an ordinary one -- positions of the completed step n, velocities ahead by the next opening half-kick
+// -- they are evaluated here, once, with what step n's pass evaluated them with: the coefficient set kept at that step, the
+// centre of that step, none of the options under which the mode is not offered.  Bits: those of the staged evaluation
+// (k_sph_force_staged: the fast pass' arithmetic) -- a particle the in-step pass took through its general pass may differ
+// from the value its kick used in the last place or two, which is what the order of the coefficient sums does to it anyway.
+static int sph_app_reeval(void *owner, exp_amd_comp *c)
+{
+  SphForce *f = static_cast<SphForce *>(owner);
+  exp_amd_ctx *ctx = f->ctx;
+  if (!c->n) return EXP_AMD_OK;
+  if (f->d_coef_app.n < 2 * f->ncoef) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "appended store: no coefficient set kept");
+  hipStream_t st = ctx->stream;
+  const size_t nb = f->ncoef * sizeof(double);
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p + f->ncoef, f->d_coef.p, nb, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p, nb, hipMemcpyDeviceToDevice, st));
+  f->proj_dirty = true;
+  double ctr[3];
+  for (int k = 0; k < 3; k++) { ctr[k] = c->center[k]; c->center[k] = c->app_center[k]; }
+  const bool frz = c->freeze_on, noise = f->noise_on, fix0 = f->fix_l0, used_open = f->used_open;
+  const auto ps = c->pseudo;
+  c->freeze_on = false;
+  c->pseudo.center = c->pseudo.axis = 0;
+  f->noise_on = false;
+  f->fix_l0 = false;
+  int rc = f->accelerate(c, 0, /*assign=*/true, 0.0, 0.0, 0.0, nullptr, false);
+  c->freeze_on = frz;
+  c->pseudo = ps;
+  f->noise_on = noise;
+  f->fix_l0 = fix0;
+  f->used_open = used_open;
+  for (int k = 0; k < 3; k++) c->center[k] = ctr[k];
+  if (hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p + f->ncoef, nb, hipMemcpyDeviceToDevice, st) != hipSuccess && !rc)
+    rc = expamd_fail(ctx, EXP_AMD_ERR_HIP, "appended store: restoring the coefficient set failed");
+  f->proj_dirty = true;
+  return rc;
+}
+
 int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool *handled)
 {
   SphForce *f = this;
@@ -1202,6 +1240,8 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
     c->cur = 1 - c->cur;
     c->appended = true;
     c->app_owner = f;
+    c->app_reeval = sph_app_reeval;
+    ctx->appended.push_back(c);
     c->app_dt = dt;
     for (int k = 0; k < 3; k++) c->app_center[k] = c->center[k];
     c->sorted_for = nullptr;          // (no ordinary pass may take this set for a sorted dense one)
@@ -1215,6 +1255,13 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   // ---- accumulate, reduce, project
   if ((rc = sph_accumulate(f, c, f->d_coef.p, c->app_range[src].p, c->app_ns))) return rc;
   if ((rc = expamd_allreduce(ctx, f->d_coef.p, f->ncoef))) return rc;
+  // the lean payload (exp_amd_ctx_set_append_lean): the pass places neither acceleration nor potential, and the set they come
+  // from is kept -- whatever happens to d_coef before someone asks for them (sph_app_reeval)
+  const bool lean = ctx->append_lean;
+  if (lean) {
+    if (f->d_coef_app.n < 2 * f->ncoef) HIP_TRY(ctx, f->d_coef_app.alloc(2 * f->ncoef));
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p, f->d_coef.p, f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   f->proj_dirty = true;
   if ((rc = sph_project(f))) return rc;
   f->used_open = false;
@@ -1234,7 +1281,8 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
     uint32_t *cnt = f->d_work.p + SPH_WORK_STRIDE * f->work_cap;
     const AppDev app{c->arr[dst][A_X].p, c->arr[dst][A_Y].p, c->arr[dst][A_Z].p, c->app_src[dst].p,
                      c->arr[dst][A_VX].p, c->arr[dst][A_VY].p, c->arr[dst][A_VZ].p,
-                     c->arr[dst][A_AX].p, c->arr[dst][A_AY].p, c->arr[dst][A_AZ].p, c->arr[dst][A_POT].p,
+                     lean ? nullptr : c->arr[dst][A_AX].p, lean ? nullptr : c->arr[dst][A_AY].p,
+                     lean ? nullptr : c->arr[dst][A_AZ].p, lean ? nullptr : c->arr[dst][A_POT].p,
                      c->uniform_mass ? nullptr : c->arr[dst][A_M].p, c->id[dst].p,
                      c->arr[src][A_M].p, c->id[src].p, c->app_base[dst].p, c->app_cursor.p,
                      c->app_cursor.p + ncell + 1, ncell};
@@ -1261,6 +1309,7 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   c->cur = dst;
   c->app_run++;
   c->acc_live = true;
+  c->app_acc_stale = lean;            // (the pass placed neither acceleration nor potential: particles.h)
   c->pending_kick = -dt_kick;         // velocities stored with the next step's opening half-kick (as the ordinary step's prekick)
   c->prekey_valid = false;
   f->firstime_coef = false;

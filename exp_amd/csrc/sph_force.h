@@ -19,6 +19,8 @@ struct SphForce : exp_amd_force {
   DevBuf<double> d_gen_ac, d_gen_e; // run-time recurrence constants of the any-order kernels (SphDev::gen_ac, gen_e)
   bool generic = false;             // lmax > SPH_MAX_L (or EXP_AMD_SPH_GENERIC=1): every per-particle pass through sph_gen.hip
   DevBuf<double> d_W, d_part, d_G, d_T4;
+  DevBuf<double> d_coef_app;        // [2][ncoef]: the coefficient set of the last append step (whose accelerations the placing pass
+                                    // does not store: sph.hip, sph_app_reeval) and scratch for the set in force meanwhile
   DevBuf<int> d_rowmap;
   DevBuf<double> d_tscale, d_wscale;   // 1/s(l,m) per table slot / per coefficient row
   DevBuf<double> d_Wd, d_differ;    // multistep differencing: moments / coefficients per level

@@ -91,13 +91,18 @@ void CAT(expamd_sph_force_L, SPH_L)(const SphForceArgs &a)
     // the append step: fast pass and general pass that place their results in the next step's order (sph_kernels.h: AppDev)
     {
       ProfScope ps(a.ctx, "k_sph_force");
-      k_sph_force<LMAX, 1, true><<<a.grid, 256, 0, a.stream>>>(
-          a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
-          a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, nullptr, *a.app);
+      if (a.app->AX)
+        k_sph_force<LMAX, 1, 1><<<a.grid, 256, 0, a.stream>>>(
+            a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+            a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, nullptr, *a.app);
+      else        // the lean payload: neither acceleration nor potential placed (AppDev)
+        k_sph_force<LMAX, 1, 2><<<a.grid, 256, 0, a.stream>>>(
+            a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
+            a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, nullptr, *a.app);
     }
     ProfScope ps(a.ctx, "k_sph_force_general");
     const unsigned ggrid = a.grid < SPH_GENERAL_GRID ? a.grid : SPH_GENERAL_GRID;
-    k_sph_force<LMAX, 0, true><<<ggrid, 256, 0, a.stream>>>(
+    k_sph_force<LMAX, 0, 1><<<ggrid, 256, 0, a.stream>>>(
         a.S, a.X, a.Y, a.Z, a.lev_off, a.lo, a.hi, a.T4, a.AX, a.AY, a.AZ, a.POT, a.VX, a.VY, a.VZ,
         a.dt_kick, a.assign, a.work, a.nwork, nullptr, a.nk_dtk, a.nk_dtd, a.store_v, a.nwork_next, *a.app);
     return;

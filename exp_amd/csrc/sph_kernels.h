@@ -1455,7 +1455,10 @@ struct AppDev {
   uint32_t *SRC;                     // ... and the slot of the SOURCE set the particle came from: the position of THIS step (the
                                      // state a download or any other call sees) stays there until the next pass -- 4 bytes
                                      // instead of 24, and this pass is sensitive to what it stores (profiles/r06_append_ab.txt)
-  double *VX, *VY, *VZ, *AX, *AY, *AZ, *POT;
+  double *VX, *VY, *VZ;
+  double *AX, *AY, *AZ, *POT;        // nullptr (all four): the LEAN payload -- acceleration and potential are not placed, 32 of
+                                     // the 88 bytes, which no pass of the next step reads; whoever asks for the state of the
+                                     // completed step has them re-evaluated (sph.hip: sph_app_reeval; exp_amd_ctx_set_append_lean)
   double *M;                         // nullptr: uniform mass (both buffer sets hold the constant)
   uint32_t *ID;
   const double *Msrc;
@@ -1472,7 +1475,10 @@ struct AppOut {                      // one lane's particle, ready to be placed
 #define APP_TAB 32
 struct AppShared { uint32_t cell[APP_TAB], cnt[APP_TAB], base[APP_TAB]; };
 
+// LEAN: 1 -- the lean payload (compile time: the fast pass), 0 -- the full one, -1 -- whichever A says (the general pass)
+template <int LEAN = -1>
 __device__ __forceinline__ void app_store_at(const AppDev &A, size_t slot, const AppOut &o, size_t isrc);
+template <int LEAN = -1>
 __device__ __forceinline__ void app_store(const AppDev &A, uint32_t cell, uint32_t r, const AppOut &o, size_t isrc)
 {
   size_t slot;
@@ -1484,15 +1490,18 @@ __device__ __forceinline__ void app_store(const AppDev &A, uint32_t cell, uint32
     if (t >= A.base[A.ncell + 1] - A.base[A.ncell]) { atomicAdd(A.flag, 1u); return; }
     slot = (size_t)A.base[A.ncell] + t;
   }
-  app_store_at(A, slot, o, isrc);
+  app_store_at<LEAN>(A, slot, o, isrc);
 }
+template <int LEAN>
 __device__ __forceinline__ void app_store_at(const AppDev &A, size_t slot, const AppOut &o, size_t isrc)
 {
   A.X[slot] = o.nx; A.Y[slot] = o.ny; A.Z[slot] = o.nz;
   A.SRC[slot] = (uint32_t)isrc;
   A.VX[slot] = o.vx; A.VY[slot] = o.vy; A.VZ[slot] = o.vz;
-  A.AX[slot] = o.ax; A.AY[slot] = o.ay; A.AZ[slot] = o.az;
-  A.POT[slot] = o.pot;
+  if (LEAN == 0 || (LEAN < 0 && A.AX)) {
+    A.AX[slot] = o.ax; A.AY[slot] = o.ay; A.AZ[slot] = o.az;
+    A.POT[slot] = o.pot;
+  }
   if (A.M) A.M[slot] = A.Msrc[isrc];
   A.ID[slot] = A.IDsrc[isrc];
 }
@@ -1550,7 +1559,7 @@ __device__ __forceinline__ void app_wave_store(const AppDev &A, bool have, const
 
 // The Cartesian projection and the stores of one particle's field (src/SphericalBasis.cc:1636-1652), with the fused
 // half-kick and the next step's sort key of the fused step: shared by every evaluation path.
-template <bool FAST, bool APP = false>
+template <bool FAST, int APP = 0>
 __device__ __forceinline__ void
 sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double yy, double zz, double px, double py,
                  double pz, double fac, double ir, double iR2, double P0, double ffac, double dfac,
@@ -1601,8 +1610,7 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
     ao->ny = mul_then_add(py, wy, nk_dtd);
     ao->nz = mul_then_add(pz, wz, nk_dtd);
     ao->vx = wx; ao->vy = wy; ao->vz = wz;
-    ao->ax = ax; ao->ay = ay; ao->az = az;
-    ao->pot = pt;
+    if constexpr (APP != 2) { ao->ax = ax; ao->ay = ay; ao->az = az; ao->pot = pt; }
     ao->cell = sph_key_cell_rcp(S, ao->nx, ao->ny, ao->nz);
     return;
   }
@@ -1646,7 +1654,7 @@ sph_force_finish(const SphDev &S, const ForceOut &o, size_t i, double xx, double
 
 // APP (the append step, MODE 0 and 1): the lane's results are left in *ao instead of being stored (the return value says
 // whether the lane has any); the store it reads may hold empty slots (x = +inf).
-template <int LMAX, int MODE, bool APP = false>
+template <int LMAX, int MODE, int APP = 0 /* 1: the append step; 2: ... with the lean payload (fast pass) */>
 __device__ __forceinline__ bool
 sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__restrict__ Y,
                 const double *__restrict__ Z, size_t base, size_t end, const double *__restrict__ T4,
@@ -1839,7 +1847,7 @@ sph_force_chunk(const SphDev &S, const double *__restrict__ X, const double *__r
 #ifndef SPH_APP_WAVES
 #define SPH_APP_WAVES SPH_FORCE_WAVES
 #endif
-template <int LMAX, int MODE, bool APP = false>
+template <int LMAX, int MODE, int APP = 0>
 __global__ void __launch_bounds__(256, MODE == 1 ? (APP ? SPH_APP_WAVES : SPH_FORCE_WAVES) : MODE == 2 ? 2 : 1)
 k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y,
             const double *__restrict__ Z, const uint32_t *__restrict__ lev_off, int lev_lo,
@@ -1864,7 +1872,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
     ao.cell = 0u;
     bool have = false;
     if (base < end)
-      have = sph_force_chunk<LMAX, 1, true>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, work,
+      have = sph_force_chunk<LMAX, 1, APP>(S, X, Y, Z, base, end, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick, assign, work,
                                             nwork, nullptr, nk_dtk, nk_dtd, store_v, ~0ull, &ao);
     // (reserving BEFORE the evaluation, by a next cell predicted from the last step's acceleration -- so that the atomics'
     // round trip would pass under the evaluation -- was built and measured: 7.0 against 5.9 ms for this pass at 1e8; the
@@ -1886,7 +1894,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
       // timing experiment: table, barriers and atomics as they are, the stores at the lane's own slot
       (void)r; app_store_at(app, base + (threadIdx.x & 63), ao, base + (threadIdx.x & 63));
 #else
-      app_store(app, ao.cell, r, ao, base + (threadIdx.x & 63));
+      app_store<APP == 2 ? 1 : 0>(app, ao.cell, r, ao, base + (threadIdx.x & 63));
 #endif
     }
     return;
@@ -1912,7 +1920,7 @@ k_sph_force(SphDev S, const double *__restrict__ X, const double *__restrict__ Y
         if constexpr (APP) {
           AppOut ao;
           ao.cell = 0u;
-          const bool have = sph_force_chunk<LMAX, 0, true>(S, X, Y, Z, base, end_, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
+          const bool have = sph_force_chunk<LMAX, 0, 1>(S, X, Y, Z, base, end_, T4, AX, AY, AZ, POT, VX, VY, VZ, dt_kick,
                                                            assign, work, nwork, nullptr, nk_dtk, nk_dtd, store_v, mask, &ao);
           app_wave_store(app, have, ao, base + (threadIdx.x & 63));
         } else

@@ -117,6 +117,12 @@ class Context:
         places every particle in the next step's cell order; include/exp_amd.h).  ``nmin <= 0``: never."""
         check(self.lib.exp_amd_ctx_set_append_min(self.h, int(nmin)), self.h)
 
+    def set_append_lean(self, on: bool) -> None:
+        """The append step with the LEAN payload: the placing pass stores neither acceleration nor potential; the first call
+        that looks at the component has them re-evaluated from the coefficient set kept at the completed step
+        (include/exp_amd.h: exp_amd_ctx_set_append_lean).  Off by default."""
+        check(self.lib.exp_amd_ctx_set_append_lean(self.h, int(bool(on))), self.h)
+
     def set_split_min(self, nmin: int) -> None:
         """Smallest component the fused step handles as two overlapped halves (<= 0: never)."""
         check(self.lib.exp_amd_ctx_set_split_min(self.h, int(nmin)), self.h)

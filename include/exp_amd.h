@@ -52,6 +52,7 @@ typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylin
  *   EXP_AMD_STEP_GRAPH=0    (exp_amd_step_kdk_n) never capture: every step eager (tests/test_rccl_gpu.py);
  *   EXP_AMD_POISON=1        (every device allocation) fresh device memory reads as NaN patterns (tests/test_poison_gpu.py);
  *   EXP_AMD_APPEND_MIN=n    (exp_amd_ctx_create) the default of exp_amd_ctx_set_append_min (tests/test_sph_gpu.py).
+ *   EXP_AMD_APPEND_LEAN=1   (exp_amd_ctx_create) the default of exp_amd_ctx_set_append_lean.
  * The tuning and A/B switches of the development rounds (tile sizes, launch reductions that can be undone, ...) are
  * compile-time constants of the default build; `make EXPERIMENTAL=1` (-DEXP_AMD_EXPERIMENTAL) turns each
  * EXPAMD_EXPT("NAME", default) of exp_amd/csrc/ back into an environment variable for A/B runs.                       */
@@ -78,6 +79,17 @@ int  exp_amd_ctx_synchronize(exp_amd_ctx *ctx);
  * index, the scratch of the way back); a component for which that is not free keeps the ordinary step.  A caller that looks
  * at the particles every few steps is recognised: each exit keeps the mode off for 8, 16, ... 1024 further steps.          */
 int  exp_amd_ctx_set_append_min(exp_amd_ctx *ctx, long long nmin);
+/* ... with the LEAN payload (on != 0): the placing pass stores neither the acceleration nor the potential -- 32 of the 88
+ * bytes a particle, which no pass of the next step reads; that pass is sensitive to what it stores: 5.7 -> 5.2 ms at 1e8 --
+ * and the first call that looks at the component (which turns the store back into an ordinary one) has them evaluated at the
+ * positions of the completed step from the coefficient set KEPT at that step, with the centre of that step, whatever has
+ * been done to the force since; a force that is destroyed does so for its components first.  Values: those of an
+ * evaluation of that set at those positions -- the ones the in-step pass kicked with up to the last place or two for the
+ * few particles its general pass took.  Off by default (the state a step leaves in the store is then complete without a
+ * further pass): for runs that step many times between two looks at the particles.  Reference: the acceleration and the
+ * potential of a step are Particle::acc / ::pot after SphericalBasis::determine_acceleration_and_potential,
+ * src/SphericalBasis.cc:1476-1660.                                                                                        */
+int  exp_amd_ctx_set_append_lean(exp_amd_ctx *ctx, int on);
 /* Tuning knob of exp_amd_step_kdk: single-level components of at least `nmin` particles are stepped
  * as two independently cell-sorted halves so that the HBM-bound sort passes of one half overlap the
  * VALU-bound accumulate / force passes of the other on a second HIP stream (same results up to the

@@ -388,14 +388,16 @@ def test_fused_step_key_reuse_and_invalidation(ctx, oracle, plummer_s6):
         assert acc_err(out["acc"], ref["acc"]) <= 1e-8
 
 
-@pytest.mark.parametrize("violent", [False, True, "tight"])
+@pytest.mark.parametrize("violent", [False, True, "tight", "lean", "lean-tight"])
 def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
     """The APPEND form of the fused step (exp_amd_ctx_set_append_min; exp_amd/csrc/sph.hip: fused_step_append) -- no sort
     passes: the force pass places every particle in the next step's cell order, in regions with empty slots behind their
     particles -- against the ordinary fused step on the same particles, call for call: a download in the middle (the store
     is turned into an ordinary one and the mode is entered again two steps later), a change of dt and of the centre, an
     odd particle count, a non-uniform mass.  `violent`: velocities that empty half the cells within a step -- the regions
-    sized from the present populations and the tail overflow, and the step is redone the ordinary way from its source."""
+    sized from the present populations and the tail overflow, and the step is redone the ordinary way from its source.
+    "lean": the payload without acceleration and potential (exp_amd_ctx_set_append_lean): what the downloads see of them is
+    re-evaluated from the coefficient set kept at the completed step."""
     from exp_amd.runtime import Component, SphereSL
     model, g = plummer_s6
     n = 300_007
@@ -408,7 +410,8 @@ def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
     dts = [0.01] * 7 + [0.004] * 4 + [0.01] * 30
 
     def run(app):
-        ctx.set_append_min((-1000 if violent == "tight" else 1000) if app else 0)
+        ctx.set_append_min((-1000 if violent in ("tight", "lean-tight") else 1000) if app else 0)
+        ctx.set_append_lean(app and violent in ("lean", "lean-tight"))
         f = SphereSL(ctx, g)
         c = Component.from_arrays(ctx, m, pos, vel)
         f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
@@ -423,6 +426,7 @@ def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
         cf, used = f.get_coefs(), f.Used()
         c.close(); f.close()
         ctx.set_append_min(0)
+        ctx.set_append_lean(False)
         return out, cf, used, snaps
 
     ref, cref, uref, sref = run(False)
@@ -435,6 +439,66 @@ def test_append_fused_step_matches_the_ordinary_one(ctx, plummer_s6, violent):
         assert np.abs(a["vel"] - b["vel"]).max() <= 1e-9 * np.abs(b["vel"]).max()
         assert acc_err(a["acc"], b["acc"]) <= 1e-8
         assert np.abs(a["pot"] - b["pot"]).max() <= 1e-9 * np.abs(b["pot"]).max()
+
+
+@pytest.mark.parametrize("then", ["other_coefficients", "centre", "force_gone", "dt"])
+def test_append_state_acceleration_is_the_completed_steps(ctx, plummer_s6, then):
+    """With the LEAN payload (exp_amd_ctx_set_append_lean) the placing pass of the append step stores neither acceleration
+    nor potential (32 of 88 bytes no pass of the next step reads): the first call that looks at the component has them re-evaluated at the positions of the completed step from the
+    coefficient set KEPT at that step (exp_amd/csrc/sph.hip: sph_app_reeval) -- whatever has happened to the force since:
+    its set replaced by an accumulation of other particles (which must survive the re-evaluation), the component's centre
+    moved, the force destroyed, or a next step of another length (whose owed kick is formed from those accelerations)."""
+    from exp_amd.runtime import Component, SphereSL
+    model, g = plummer_s6
+    n = 200_003
+    m, pos, vel = _particles(model, n, seed=43)
+    m2, pos2, _ = _particles(model, 50_000, seed=44, squash=0.5)
+
+    def run(app):
+        ctx.set_append_min(1000 if app else 0)
+        ctx.set_append_lean(app)
+        f = SphereSL(ctx, g)
+        c = Component.from_arrays(ctx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        for _ in range(4):
+            f.step_kdk(c, 0.01)
+        ctx.profile(True); ctx.profile_reset()
+        f.step_kdk(c, 0.01)
+        rep = ctx.profile_report()
+        ctx.profile(False)
+        assert bool(rep.get("k_scatter_adv", {}).get("launches", 0)) == (not app)        # (the mode is on: no sort passes)
+        other = None
+        if then == "other_coefficients":
+            c2 = Component.from_arrays(ctx, m2, pos2)
+            f.determine_coefficients(c2)
+            out = c.download()
+            other = f.get_coefs()                      # still the other particles' set
+            c2.close()
+        elif then == "centre":
+            c.set_center([0.02, -0.01, 0.03])
+            out = c.download()
+        elif then == "force_gone":
+            f.close(); f = None
+            out = c.download()
+        else:
+            f.step_kdk(c, 0.004)                       # leaves the mode; the half-kick owed is a * 0.005, then -a * 0.002 ...
+            out = c.download()
+        c.close()
+        if f is not None:
+            f.close()
+        ctx.set_append_min(0)
+        ctx.set_append_lean(False)
+        return out, other
+
+    ref, oref = run(False)
+    out, other = run(True)
+    assert np.array_equal(out["mass"], ref["mass"])
+    assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-11 * (1.0 + np.abs(ref["pos"]).max())
+    assert np.abs(out["vel"] - ref["vel"]).max() <= 1e-10 * np.abs(ref["vel"]).max()
+    assert acc_err(out["acc"], ref["acc"]) <= 1e-9
+    assert np.abs(out["pot"] - ref["pot"]).max() <= 1e-10 * np.abs(ref["pot"]).max()
+    if oref is not None:
+        assert coef_err(other, oref) <= 1e-13
 
 
 def test_split_fused_step_matches_the_unfused_sequence(ctx, oracle, plummer_s6):
