@@ -116,7 +116,24 @@ _CYL_TABLE_KEYS = {
 }
 
 
-def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None):
+def _conditioning_particles(condition_on):
+    """(mass, pos in the basis' frame) of what ``precond: false`` conditions on: a ``Component`` -- every body whatever its
+    level, ``Pos(Local | Centered)``, frozen ones left out (src/Cylinder.cc:764-806) -- or a (mass, pos) pair already in
+    that frame."""
+    import numpy as np
+    if hasattr(condition_on, "download"):
+        d = condition_on.download(("mass", "pos"))
+        mass, pos = d["mass"], d["pos"] - condition_on.center[None, :]
+        rt = getattr(condition_on, "rtrunc", None)
+        if rt is not None and rt < 1.0e20:                  # Component::freeze (src/Component.cc:4194-4202; com0 = 0 here)
+            keep = np.linalg.norm(pos, axis=1) <= rt
+            mass, pos = mass[keep], pos[keep]
+        return mass, pos
+    mass, pos = condition_on
+    return np.asarray(mass, dtype=np.float64), np.asarray(pos, dtype=np.float64)
+
+
+def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None, condition_on=None):
     conf = dict(conf or {})
     bad = sorted(set(conf) - set(CYLINDER_KEYS))
     if bad:
@@ -150,9 +167,15 @@ def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None):
     for key in ("expcond", "precond"):
         if key in conf:
             precond, pkey = _bool(conf[key]), key
-    if not precond:
+    # precond: false -- the basis is conditioned on the PARTICLES at the first evaluation (`eof = 1`, src/Cylinder.cc:981-988,
+    # determine_coefficients_eof :1202-1249).  A force method is made before it sees a component here, so the component (or
+    # a (mass, pos) pair in the basis' frame) comes in as `condition_on`; without one there is nothing to condition on
+    if not precond and grid is None and condition_on is None:
         raise _refuse(name, pkey, conf[pkey], "conditioning the basis on the PARTICLES (determine_coefficients_eof, "
-                      "src/Cylinder.cc:1018-1080) is not built here: the tables are conditioned on the analytic disk")
+                      "src/Cylinder.cc:1202-1249) needs them: Cylinder.from_config(..., condition_on=component)")
+    if precond and condition_on is not None:
+        raise ValueError("Cylinder: condition_on is given but the keys ask for the analytic conditioning (precond: true, the "
+                         "default, src/Cylinder.cc:131): say precond: false")
     if "pyname" in conf:
         raise _refuse(name, "pyname", conf["pyname"], "a Python target density: pass a callable to "
                       "exp_amd.empcyl.build_empcyl(dens=...) and hand the grid in")
@@ -188,6 +211,8 @@ def cylinder_from_config(cls, ctx, conf: dict, multistep: int = 0, grid=None):
                 kw[arg] = dflt
         if "nodd" not in kw:
             kw["nodd"] = kw["norder"] // 4                 # `ncylodd = nmax/4` (src/Cylinder.cc:549-551)
+        if not precond:
+            kw["particles"] = _conditioning_particles(condition_on)
         grid = build_empcyl(**kw)
     else:
         for key, (_arg, attr, _dflt) in _CYL_TABLE_KEYS.items():

@@ -147,6 +147,7 @@ struct exp_amd_comp {
   size_t app_cap = 0;                   // slots every array of both sets has room for (0: never reserved)
   size_t app_ns = 0;                    // host bound of the slots in use
   uint32_t app_ncell = 0, app_tail = 0; // cells of the layout; slots of the tail region
+  uint32_t app_tail_used = 0;           // particles the last placing pass sent to the tail (their regions were full)
   DevBuf<double> xo[2][3];              // (scratch of expamd_comp_densify: the dense positions, then swapped in)
   DevBuf<uint32_t> app_src[2];          // per slot: the slot of the other set the particle came from (its state position)
   DevBuf<uint32_t> app_base[2];         // [ncell + 2] per buffer set

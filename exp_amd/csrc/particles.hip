@@ -577,8 +577,11 @@ int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag)
   k_app_mark<<<c->app_ncell + APP_MARK_TAIL, 256, 0, ctx->stream>>>(c->app_base[set].p, c->app_cursor.p, 0, c->app_ncell, c->arr[set][A_X].p);
   HIP_TRY(ctx, hipGetLastError());
   if (host_flag) {
-    HIP_TRY(ctx, hipMemcpyAsync(host_flag, c->app_cursor.p + c->app_ncell + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t two[2] = {0u, 0u};          // arrivals in the tail, particles that found no room at all
+    HIP_TRY(ctx, hipMemcpyAsync(two, c->app_cursor.p + c->app_ncell, sizeof(two), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *host_flag = two[1];
+    c->app_tail_used = two[0];
   }
   return EXP_AMD_OK;
 }

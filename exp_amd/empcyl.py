@@ -209,12 +209,51 @@ def default_disk_density(acyl: float, hcyl: float, sech2: bool = False) -> Calla
     return dens
 
 
+def eof_covariance_from_particles(sl: SLGridSph, m: int, ascale: float, rtable: float, rmax2: float, mass, pos,
+                                  chunk: int = 16384):
+    """The covariance of the helper functions over a set of particles -- ``EmpCylSL::accumulate_eof``
+    (exputil/EmpCylSL.cc:2686-2862) under its caller's cut (``Cylinder::determine_coefficients_thread``,
+    src/Cylinder.cc:806-820: x^2 + y^2 + z^2 < Rmax2) -- for ONE harmonic m: (SC, SS, used, cylmass) with SC, SS
+    [rank, rank], rank = NMAX (LMAX - m + 1), index nn = ir + NMAX (l - m); SS is None for m = 0.  ``pos`` [n, 3] in
+    the frame of the basis (centred, rotated).  The per-particle rank-one updates of the reference are one
+    matrix product a chunk here: V^T diag(mass cos^2 | sin^2) V -- init-time host work in the reference too (it runs
+    on the CPU there also when the step runs on a GPU)."""
+    mass = np.ascontiguousarray(mass, dtype=np.float64)
+    pos = np.asarray(pos, dtype=np.float64)
+    lmax, nmax = sl.lmax, sl.nmax
+    nl = lmax - m + 1
+    rank = nl * nmax
+    pfac = 1.0 / math.sqrt(ascale)
+    SC = np.zeros((rank, rank))
+    SS = np.zeros((rank, rank)) if m > 0 else None
+    r2 = pos[:, 0] ** 2 + pos[:, 1] ** 2
+    R2 = r2 + pos[:, 2] ** 2
+    inside = R2 < rmax2
+    used, cylmass = int(inside.sum()), float(mass[inside].sum())
+    rr = np.sqrt(np.sqrt(r2) ** 2 + pos[:, 2] ** 2)
+    sel = np.flatnonzero(inside & ~(rr / ascale > rtable))
+    for b in range(0, sel.size, chunk):
+        k = sel[b:b + chunk]
+        potd, _ = sl_eval(sl, rr[k] / ascale, want_force=False)          # [np, L+1, nmax]
+        costh = pos[k, 2] / (rr[k] + 1.0e-18)
+        P, _ = _legendre_all(lmax, m, costh)                              # [np, nl]
+        V = (pfac * P[:, :, None] * potd[:, m:, :]).reshape(k.size, rank)  # nn = ir + NMAX * (l - m)
+        if m == 0:
+            SC += (V * mass[k][:, None]).T @ V
+        else:
+            phi = np.arctan2(pos[k, 1], pos[k, 0])
+            c, s_ = np.cos(m * phi), np.sin(m * phi)
+            SC += (V * (mass[k] * c * c)[:, None]).T @ V
+            SS += (V * (mass[k] * s_ * s_)[:, None]).T @ V
+    return SC, SS, used, cylmass
+
+
 def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 64,
                  acyl: float = 0.01, hcyl: float = 0.002, rcylmin: float = 0.001,
                  rcylmax: float = 20.0, lmaxfid: int = 32, nmaxfid: int = 24, numr: int = 2000,
                  cmapr: int = 1, cmapz: int = 1, rnum: int = 200, tnum: int = 80,
                  dens: Optional[Callable] = None, nodd: Optional[int] = None, pnum: int = 1,
-                 ashift: float = 0.0) -> EmpCylGrid:
+                 ashift: float = 0.0, particles=None) -> EmpCylGrid:
     """``nodd`` (the reference's ``ncylodd``; EmpCylSL's constructor argument, exputil/EmpCylSL.cc:178-185): with
     0 <= nodd <= norder the functions are chosen by vertical parity -- the norder - nodd largest-variance combinations
     of the helper functions with l + m even (symmetric about the plane) first, then the nodd largest-variance ones with
@@ -225,7 +264,15 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
     one knot the covariance of the cosine and of the sine functions of an m >= 1 are integrated separately under a
     conditioning density folded into [-pi/m, pi/m] and shifted by ashift * acyl along x (``dcond``, src/Cylinder.cc:
     325-348, expui/BiorthBasis.cc:1345-1366; ``generate_eof``, exputil/EmpCylSL.cc:2455-2500) -- the sine tables then
-    differ from the cosine tables.  One knot: the azimuthal average, sine tables = cosine tables."""
+    differ from the cosine tables.  One knot: the azimuthal average, sine tables = cosine tables.
+
+    ``particles`` = (mass [n], pos [n, 3] in the basis' frame): the basis is conditioned on the PARTICLES instead of a
+    target density -- the reference's ``precond: false`` (``Cylinder::determine_coefficients_eof``, src/Cylinder.cc:
+    1202-1249: ``accumulate_eof`` of every particle inside rcylmax * acyl, then ``make_eof``, exputil/EmpCylSL.cc:
+    2866-3300): the covariance of the cosine and of the sine functions of each m are the particle sums
+    (``eof_covariance_from_particles``), each decomposed on its own (``eigen_problem`` with request_id 1 / 0), and
+    tabulated by the same ``compute_eof_grid``.  ``rnum`` / ``tnum`` / ``pnum`` / ``ashift`` / ``dens`` play no part then.
+    The grid records ``cylmass`` and ``used`` of the conditioning pass."""
     ASCALE, HSCALE, RMIN, RMAX = acyl, hcyl, rcylmin, rcylmax
     even_odd = nodd is not None and 0 <= nodd <= norder
     nump = max(1, int(pnum))
@@ -296,7 +343,10 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
         V = (pfac * Pq[None, :, :, None] * potd_q[:, None, m:, :])  # [rnum, tnum, nl, nmax]
         V = V.reshape(rnum * tnum, nl * nmaxfid)                # nn = ir + NMAX*(l-m)
         SS = None
-        if m == 0:
+        if particles is not None:
+            SC, SS, eof_used, eof_mass = eof_covariance_from_particles(sl, m, ASCALE, rtable, (RMAX * ASCALE) ** 2,
+                                                                       particles[0], particles[1])
+        elif m == 0:
             SC = (V * (wq * nump)[:, None]).T @ V               # (every knot adds the same)
         elif nump == 1:
             SC = 0.25 * ((V * wq[:, None]).T @ V)               # facC = facS = V / 2
@@ -355,7 +405,11 @@ def build_empcyl(mmax: int = 6, norder: int = 12, numx: int = 128, numy: int = 6
             # density (compute_eof_grid :1507, :1518, :1534): fac * P_lm * dend * dfac / (4 pi)
             dtab[off // 3, m] = (dnb @ vec).T.reshape(norder, numx + 1, numy + 1)
     _limit.__exit__(None, None, None)
-    return EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
-                      ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,
-                      xmin=XMIN, xmax=XMAX, dx=dX, ymin=YMIN, ymax=YMAX, dy=dY,
-                      tab=np.ascontiguousarray(tab), dens=np.ascontiguousarray(dtab))
+    out = EmpCylGrid(mmax=mmax, norder=norder, numx=numx, numy=numy, cmapr=cmapr, cmapz=cmapz,
+                     ascale=ASCALE, hscale=HSCALE, rmin=RMIN, rmax=RMAX, rtable=rtable,
+                     xmin=XMIN, xmax=XMAX, dx=dX, ymin=YMIN, ymax=YMAX, dy=dY,
+                     tab=np.ascontiguousarray(tab), dens=np.ascontiguousarray(dtab))
+    if particles is not None:
+        # "Cylinder: eof grid mass=..., number=..." (src/Cylinder.cc:1236-1237)
+        out.eof_used, out.eof_cylmass = eof_used, eof_mass
+    return out

@@ -875,11 +875,14 @@ class Cylinder(_Force):
             self.set_mlim(mlim)
 
     @classmethod
-    def from_config(cls, ctx: Context, conf: dict, multistep: int = 0, grid: Optional[EmpCylGrid] = None) -> "Cylinder":
+    def from_config(cls, ctx: Context, conf: dict, multistep: int = 0, grid: Optional[EmpCylGrid] = None,
+                    condition_on=None) -> "Cylinder":
         """From the reference's YAML keys (``Cylinder::valid_keys``, src/Cylinder.cc:24-80): every key is honoured or
-        refused, none dropped (exp_amd/config.py).  ``grid`` None: the EOF tables are built from the keys."""
+        refused, none dropped (exp_amd/config.py).  ``grid`` None: the EOF tables are built from the keys -- conditioned on
+        the analytic disk, or with ``precond: false`` on the particles of ``condition_on`` (a ``Component``, or a (mass, pos)
+        pair in the basis' frame): ``Cylinder::determine_coefficients_eof``, src/Cylinder.cc:1202-1249."""
         from .config import cylinder_from_config
-        return cylinder_from_config(cls, ctx, conf, multistep, grid)
+        return cylinder_from_config(cls, ctx, conf, multistep, grid, condition_on)
 
     def set_mlim(self, mlim: int) -> None:
         """The ``mlim`` key (src/Cylinder.cc:225 -> EmpCylSL::set_mlim): harmonics m > mlim take no part in accumulation or

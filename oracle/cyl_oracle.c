@@ -416,3 +416,111 @@ void orc_pyexp_cyl_accel(const orc_cylgrid *g, const double *accum_cos, const do
     acc[3 * i + 2] = tpotz;
   }
 }
+
+/* ---- conditioning the basis on the particles: the covariance of the helper functions ------------------------------------
+ * EmpCylSL::legendre_R (exputil/EmpCylSL.cc:6493-6569): Holmes & Featherstone forward column recursion, normalised,
+ * Condon-Shortley phase; p[l * (lmax + 1) + m]. */
+void orc_emp_legendre_R(int lmax, double x, double *p)
+{
+  const int s = lmax + 1;
+  for (int k = 0; k < s * s; k++) p[k] = 0.0;
+  double u = sqrt(1 - x * x), pll;
+  p[0] = 1.0;
+  if (lmax >= 1) p[1 * s + 1] = pll = -sqrt(3) * u;
+  if (lmax > 0) {
+    for (int m = 2; m <= lmax; m++) {
+      pll *= -u * sqrt((2. * m + 1) / (2. * m));
+      p[m * s + m] = pll;
+    }
+  }
+  for (int l = 1; l <= lmax; l++) {
+    for (int m = 0; m < l; m++) {
+      int l1 = l - 1 > 0 ? l - 1 : 0;
+      int l2 = l - 2 > 0 ? l - 2 : 0;
+      p[l * s + m] = sqrt((2. * l - 1) * (2 * l + 1) / (l - m) / (l + m)) * x * p[l1 * s + m]
+                   - sqrt((2. * l + 1) * (l + m - 1) * (l - m - 1) / (l - m) / (l + m) / (2 * l - 3)) * p[l2 * s + m];
+    }
+  }
+  for (int l = 0; l <= lmax; l++)
+    for (int m = 0; m <= l; m++) {
+      double norm = m > 0 ? sqrt(8. * M_PI) : sqrt(4. * M_PI);
+      p[l * s + m] = p[l * s + m] / norm;
+    }
+}
+
+/* EmpCylSL::sinecosine_R (exputil/EmpCylSL.cc:6624-6639) */
+static void emp_sinecosine_R(int mmax, double phi, double *c, double *s)
+{
+  c[0] = 1.0; s[0] = 0.0;
+  if (mmax >= 1) { c[1] = cos(phi); s[1] = sin(phi); }
+  for (int m = 2; m <= mmax; m++) {
+    c[m] = 2.0 * c[1] * c[m - 1] - c[m - 2];
+    s[m] = 2.0 * c[1] * s[m - 1] - s[m - 2];
+  }
+}
+
+/* EmpCylSL::accumulate_eof (exputil/EmpCylSL.cc:2686-2862, the branch without EvenOdd) of n particles for ONE harmonic
+ * M under its caller's cut (Cylinder::determine_coefficients_thread, src/Cylinder.cc:806-820: x^2 + y^2 + z^2 <
+ * Rmax2): SC, SS [rank][rank], rank = NMAX * (LMAX - M + 1), nn = ir + NMAX * (l - M).  sl: the helper SLGridSph
+ * (LMAX, NMAX).  Returns the particles used (`use`), *cylmass their mass. */
+long orc_cyl_accumulate_eof(const orc_slgrid *sl, int M, double ascale, double rtable, double rmax2, long n,
+                            const double *X, const double *Y, const double *Z, const double *mass,
+                            double *SC, double *SS, double *cylmass)
+{
+  const int LMAX = sl->lmax, NMAX = sl->nmax;
+  const int nl = LMAX - M + 1, rank = NMAX * nl;
+  const double pfac = 1.0 / sqrt(ascale);                /* exputil/EmpCylSL.cc:173 */
+  double *table = (double *)malloc(sizeof(double) * (LMAX + 1) * NMAX);
+  double *legs = (double *)malloc(sizeof(double) * (LMAX + 1) * (LMAX + 1));
+  double *cosm = (double *)malloc(sizeof(double) * (LMAX + 1));
+  double *sinm = (double *)malloc(sizeof(double) * (LMAX + 1));
+  double *facC = (double *)malloc(sizeof(double) * NMAX * nl);
+  double *facS = (double *)malloc(sizeof(double) * NMAX * nl);
+  for (long k = 0; k < (long)rank * rank; k++) SC[k] = SS[k] = 0.0;
+  long use = 0;
+  *cylmass = 0.0;
+  for (long i = 0; i < n; i++) {
+    double xx = X[i], yy = Y[i], zz = Z[i];
+    double r2 = xx * xx + yy * yy;
+    double r = sqrt(r2);
+    double R2 = r2 + zz * zz;
+    if (!(R2 < rmax2)) continue;
+    double mas = mass[i];
+    double phi = atan2(yy, xx);
+    use++;
+    *cylmass += mas;
+    /* accumulate_eof(r, zz, phi, mas, id, level) */
+    double rr = sqrt(r * r + zz * zz);
+    if (rr / ascale > rtable) continue;
+    orc_sl_get_pot(sl, rr / ascale, table);
+    double costh = zz / (rr + 1.0e-18);
+    orc_emp_legendre_R(LMAX, costh, legs);
+    emp_sinecosine_R(LMAX, phi, cosm, sinm);
+    for (int ir = 0; ir < NMAX; ir++) {
+      for (int l = M; l <= LMAX; l++) {
+        double ylm = pfac * legs[l * (LMAX + 1) + M];
+        if (M == 0) {
+          facC[ir * nl + (l - M)] = ylm * table[l * NMAX + ir];
+        } else {
+          facC[ir * nl + (l - M)] = ylm * table[l * NMAX + ir] * cosm[M];
+          facS[ir * nl + (l - M)] = ylm * table[l * NMAX + ir] * sinm[M];
+        }
+      }
+    }
+    for (int ir1 = 0; ir1 < NMAX; ir1++) {
+      for (int l1 = M; l1 <= LMAX; l1++) {
+        int nn1 = ir1 + NMAX * (l1 - M);
+        for (int ir2 = 0; ir2 < NMAX; ir2++) {
+          for (int l2 = M; l2 <= LMAX; l2++) {
+            int nn2 = ir2 + NMAX * (l2 - M);
+            SC[(long)nn1 * rank + nn2] += facC[ir1 * nl + (l1 - M)] * facC[ir2 * nl + (l2 - M)] * mas;
+            if (M > 0)
+              SS[(long)nn1 * rank + nn2] += facS[ir1 * nl + (l1 - M)] * facS[ir2 * nl + (l2 - M)] * mas;
+          }
+        }
+      }
+    }
+  }
+  free(table); free(legs); free(cosm); free(sinm); free(facC); free(facS);
+  return use;
+}

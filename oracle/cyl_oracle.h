@@ -2,6 +2,7 @@
  * (same scope statement as bfe_oracle.h: parity unpinned; never used by exp_amd/). */
 #ifndef CYL_ORACLE_H
 #define CYL_ORACLE_H
+#include "bfe_oracle.h"      /* orc_slgrid: the helper spherical basis of the conditioning */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -53,6 +54,12 @@ void   orc_pyexp_cyl_accel(const orc_cylgrid *g, const double *accum_cos, const 
 long   orc_cyl_covariance(const orc_cylgrid *g, long n, const double *x, const double *y,
                           const double *z, const double *mass, const long *seq, int sampT,
                           long *numbT, double *massT, double *VC, double *MV);
+/* conditioning the basis on the particles (precond: false): EmpCylSL::legendre_R (exputil/EmpCylSL.cc:6493-6569) and the
+ * covariance sums of EmpCylSL::accumulate_eof (:2686-2862) under Cylinder's cut (src/Cylinder.cc:806-820) */
+void   orc_emp_legendre_R(int lmax, double x, double *p);
+long   orc_cyl_accumulate_eof(const orc_slgrid *sl, int M, double ascale, double rtable, double rmax2, long n,
+                              const double *X, const double *Y, const double *Z, const double *mass,
+                              double *SC, double *SS, double *cylmass);
 #ifdef __cplusplus
 }
 #endif

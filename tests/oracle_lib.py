@@ -721,6 +721,27 @@ class Oracle:
         acc["covr"] = acc["mv2"][..., 0] + 1j * acc["mv2"][..., 1]
         return acc
 
+    def emp_legendre(self, lmax, x):
+        """EmpCylSL::legendre_R (exputil/EmpCylSL.cc:6493-6569) -> p[l, m]."""
+        p = np.zeros((lmax + 1, lmax + 1))
+        self.lib.orc_emp_legendre_R(ctypes.c_int(lmax), ctypes.c_double(x), _dp(p))
+        return p
+
+    def cyl_accumulate_eof(self, sl, m, ascale, rtable, rmax2, pos, mass):
+        """EmpCylSL::accumulate_eof (exputil/EmpCylSL.cc:2686-2862) of every particle under Cylinder's cut, harmonic m ->
+        (SC, SS [rank, rank], used, cylmass); sl: the helper SLGridSph."""
+        G = self.grid(sl)
+        rank = sl.nmax * (sl.lmax - m + 1)
+        SC, SS = np.zeros((rank, rank)), np.zeros((rank, rank))
+        x, y, z = [np.ascontiguousarray(pos[:, k], dtype=np.float64) for k in range(3)]
+        mm = np.ascontiguousarray(mass, dtype=np.float64)
+        cm = ctypes.c_double(0.0)
+        self.lib.orc_cyl_accumulate_eof.restype = ctypes.c_long
+        used = self.lib.orc_cyl_accumulate_eof(ctypes.byref(G), ctypes.c_int(m), ctypes.c_double(ascale), ctypes.c_double(rtable),
+                                               ctypes.c_double(rmax2), ctypes.c_long(len(mm)), _dp(x), _dp(y), _dp(z), _dp(mm),
+                                               _dp(SC), _dp(SS), ctypes.byref(cm))
+        return SC, SS, int(used), cm.value
+
     def cyl_accel(self, g, pos, cosN, sinN, cylmass, center=(0.0, 0.0, 0.0), **kw):
         G = self.cylgrid(g, **kw)
         n = pos.shape[0]

@@ -214,9 +214,16 @@ def test_every_cylinder_key_is_honoured_or_refused(ctx, oracle):
     # `expcond` is the deprecated spelling and a later `precond` overrides it (src/Cylinder.cc:492-493): this pair is valid ...
     f = Cylinder.from_config(ctx, dict(expcond=False, precond=True, npca=50), grid=cg)
     f.close()
-    for bad in (dict(precond=False), dict(expcond=False), dict(expcond=True, precond=False)):      # ... these ask for the EOF pass
+    # ... these ask for the EOF pass over the particles (src/Cylinder.cc:960-988): a cache that reads -- grid= here -- wins as
+    # it does there (`eof = cache_ok ? 0 : 1`); without one the particles must come along (condition_on=, tests/test_cyl_gpu.py)
+    small = dict(mmax=2, nmax=4, ncylnx=24, ncylny=12, ncylr=400, lmaxfid=10, nmaxfid=8, ncylodd=1, acyl=0.01, hcyl=0.001)
+    for eofp in (dict(precond=False), dict(expcond=False), dict(expcond=True, precond=False)):
+        f = Cylinder.from_config(ctx, eofp, grid=cg)
+        f.close()
         with pytest.raises(ValueError, match="PARTICLES"):
-            Cylinder.from_config(ctx, bad, grid=cg)
+            Cylinder.from_config(ctx, dict(small, **eofp))
+    with pytest.raises(ValueError, match="condition_on"):
+        Cylinder.from_config(ctx, dict(small), condition_on=(m, pos))
     # grid=None: the tables are built from the keys (small orders so that it takes seconds)
     f = Cylinder.from_config(ctx, dict(mmax=2, nmax=4, ncylnx=24, ncylny=12, ncylr=400, lmaxfid=10, nmaxfid=8, rnum=40,
                                        tnum=20, ncylodd=1, acyl=0.01, hcyl=0.001, mlim=1))

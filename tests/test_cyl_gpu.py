@@ -78,6 +78,44 @@ def test_cyl_coefficients_and_accel(ctx, oracle, mmax, norder, n):
     assert np.abs(out["pot"] - p_ref).max() <= ACC_TOL * np.abs(p_ref).max()
 
 
+def test_cyl_basis_conditioned_on_the_component(ctx, oracle):
+    """``precond: false`` (src/Cylinder.cc:960-988, determine_coefficients_eof :1202-1249): the EOF tables are made from the
+    covariance of the component's own particles -- downloaded from the device store, in the component's centred frame,
+    every body whatever its level -- and the device path then runs on those tables: coefficients and accelerations against
+    the oracle on the same tables; the conditioning pass itself against the oracle's accumulate_eof sums in
+    tests/test_oracle_kat.py."""
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    from exp_amd.runtime import Component, Cylinder
+    a, h = 0.01, 0.001
+    keys = dict(mmax=2, nmax=5, ncylnx=32, ncylny=16, ncylr=500, lmaxfid=12, nmaxfid=8, ncylodd=1, acyl=a, hcyl=h,
+                precond=False)
+    m, pos, _ = sample_disk(30000, 11, a=a, h=h)
+    pos[:, 0] *= 1.2
+    ctr = np.array([0.003, -0.002, 0.0005])
+    c = Component.from_arrays(ctx, m, pos + ctr)
+    c.set_center(ctr)
+    f = Cylinder.from_config(ctx, keys, condition_on=c)
+    g = f.grid
+    assert g.eof_used == len(m) and g.eof_cylmass == pytest.approx(m.sum(), rel=1e-12)
+    # the same tables from the same particles handed in as arrays in the basis' frame (to the rounding of pos + ctr - ctr)
+    g2 = build_empcyl(mmax=2, norder=5, numx=32, numy=16, numr=500, lmaxfid=12, nmaxfid=8, nodd=1, acyl=a, hcyl=h,
+                      particles=(m, pos))
+    assert np.abs(g.tab - g2.tab).max() <= 1e-7 * np.abs(g2.tab).max()
+    c_ref, s_ref, used_ref, mass_ref = oracle.cyl_accumulate(g, pos, m)
+    a_ref, p_ref = oracle.cyl_accel(g, pos, c_ref, s_ref, mass_ref)
+    f.determine_coefficients(c)
+    cc, ss = f.get_coefs()
+    assert f.Used() == used_ref
+    scale = np.abs(c_ref).max()
+    assert np.abs(cc - c_ref).max() <= 1e-9 * scale and np.abs(ss - s_ref).max() <= 1e-9 * scale
+    c.zero_acceleration(0)
+    f.get_acceleration_and_potential(c)
+    out = c.download(("acc", "pot"))
+    assert acc_err(out["acc"], a_ref, "conditioned_on_the_component") <= 1e-7
+    c.close(); f.close()
+
+
 def test_cyl_edges_offgrid_and_blend(ctx, oracle):
     """particles beyond the grid (monopole only), in the erf blend zone, on the plane, near the axis,
     inside RMIN (extrapolated weights), beyond rcylmax (not accumulated)."""

@@ -346,6 +346,69 @@ def test_cylinder_reconstructs_exponential_disk_force(oracle):
         assert pot[0] < 0
 
 
+def test_eof_covariance_of_the_particles_against_the_restatement(oracle):
+    """``precond: false``: the covariance sums of ``EmpCylSL::accumulate_eof`` (exputil/EmpCylSL.cc:2686-2862) under
+    Cylinder's cut (src/Cylinder.cc:806-820) -- the host's matrix products (exp_amd/empcyl.py) against the per-particle
+    triple loop of oracle/cyl_oracle.c, cosine and sine parts, particles outside the table and outside the cut among
+    them; and ``EmpCylSL::legendre_R`` (:6493-6569) against the builder's normalised functions."""
+    from exp_amd.empcyl import _legendre_all, eof_covariance_from_particles
+    from exp_amd.models import NumericModel
+    from exp_amd.slgrid import build_slgrid
+    for x in (-0.999, -0.3, 0.0, 0.42, 0.97):
+        p = oracle.emp_legendre(8, x)
+        for m in range(9):
+            P, _ = _legendre_all(8, m, np.array([x]))
+            assert np.abs(P[0] - p[m:, m]).max() <= 1e-13 * max(1.0, np.abs(p[m:, m]).max())
+    a, h, RMIN, RMAX = 0.01, 0.001, 0.001, 20.0
+    model = NumericModel(lambda R: np.exp(-R) / (4.0 * math.pi * R), RMIN, RMAX, total_mass=None)
+    sl = build_slgrid(model, 6, 5, numr=400, rmin=RMIN, rmax=RMAX * 0.99, cmap=1, rmap=1.0, nel=48, P=10)
+    rng = np.random.default_rng(3)
+    n = 3000
+    R, phi = a * rng.gamma(2.0, 1.0, n), rng.uniform(0, 2 * np.pi, n)
+    z = 2 * h * np.arctanh(rng.uniform(-1, 1, n) * 0.999)
+    pos = np.stack([R * np.cos(phi), R * np.sin(phi), z], 1)
+    pos[:5] *= 40.0                                   # beyond the table (Rtable) and beyond rcylmax * acyl
+    mass = rng.uniform(0.5, 1.5, n) / n
+    rtable, rmax2 = math.sqrt(0.5) * RMAX, (RMAX * a) ** 2
+    for m in (0, 1, 3):
+        SC0, SS0, u0, c0 = oracle.cyl_accumulate_eof(sl, m, a, rtable, rmax2, pos, mass)
+        SC, SS, u, c = eof_covariance_from_particles(sl, m, a, rtable, rmax2, mass, pos, chunk=700)
+        assert u == u0 and 0 < u < n and c == pytest.approx(c0, rel=1e-13)
+        assert np.abs(SC - SC0).max() <= 1e-13 * np.abs(SC0).max()
+        if m:
+            assert np.abs(SS - SS0).max() <= 1e-13 * np.abs(SS0).max()
+        else:
+            assert SS is None
+
+
+def test_basis_conditioned_on_the_particles(oracle):
+    """``precond: false`` (Cylinder::determine_coefficients_eof, src/Cylinder.cc:1202-1249): the empirical functions made
+    from the covariance of the PARTICLES.  Drawn from the analytic conditioning density, the particle covariance is the
+    Monte-Carlo estimate of the quadrature's (same leading function: the subspace overlap of the m = 0 tables is ~1), and
+    the basis reconstructs the exponential disk's in-plane force as the analytically conditioned one does."""
+    from scipy.special import i0, i1, k0, k1
+    from exp_amd.empcyl import build_empcyl
+    from exp_amd.models import sample_disk
+    a, h = 0.01, 0.001
+    kw = dict(mmax=2, norder=6, numx=48, numy=24, acyl=a, hcyl=h, lmaxfid=16, nmaxfid=12, numr=800, rnum=80, tnum=40)
+    m, pos, _ = sample_disk(60000, 5, a=a, h=h)
+    gp = build_empcyl(**kw, particles=(m, pos))
+    gq = build_empcyl(**kw, dens=None)
+    assert gp.eof_used == len(m) and gp.eof_cylmass == pytest.approx(1.0, rel=1e-9)
+    # the leading m = 0 potential function: same up to sign and the sampling noise
+    f0p, f0q = gp.tab[0, 0, 0].ravel(), gq.tab[0, 0, 0].ravel()
+    cosang = abs(f0p @ f0q) / (np.linalg.norm(f0p) * np.linalg.norm(f0q))
+    assert cosang > 0.995
+    cc, ss, used, mass = oracle.cyl_accumulate(gp, pos, m)
+    for R in (1.0 * a, 2.0 * a, 4.0 * a):
+        test = np.array([[R, 0.0, 0.0], [0.0, -R, 0.0]])
+        acc, pot = oracle.cyl_accel(gp, test, cc, ss, mass)
+        y = R / (2 * a)
+        vc2 = 4 * math.pi * (1.0 / (2 * math.pi * a * a)) * a * y * y * (i0(y) * k0(y) - i1(y) * k1(y))
+        assert -acc[0, 0] == pytest.approx(vc2 / R, rel=0.25) and acc[1, 1] == pytest.approx(vc2 / R, rel=0.25)
+        assert pot[0] < 0
+
+
 def test_cylinder_fields_known_answers(oracle):
     """pyEXP Cylindrical field evaluation (expui/BiorthBasis.cc:1749-1849) with the density tables
     of compute_eof_grid (exputil/EmpCylSL.cc:1507-1534) and accumulated_dens_eval (:5413-5502):
