@@ -125,8 +125,9 @@ def _conditioning_particles(condition_on):
         d = condition_on.download(("mass", "pos"))
         mass, pos = d["mass"], d["pos"] - condition_on.center[None, :]
         rt = getattr(condition_on, "rtrunc", None)
-        if rt is not None and rt < 1.0e20:                  # Component::freeze (src/Component.cc:4194-4202; com0 = 0 here)
-            keep = np.linalg.norm(pos, axis=1) <= rt
+        if rt is not None and rt < 1.0e20:                  # Component::freeze (src/Component.cc:4194-4202)
+            c0 = getattr(condition_on, "com0", None)
+            keep = np.linalg.norm(pos if c0 is None else pos - c0[None, :], axis=1) <= rt
             mass, pos = mass[keep], pos[keep]
         return mass, pos
     mass, pos = condition_on

@@ -286,6 +286,7 @@ class Component:
         c0 = None if com0 is None else as_f64(np.asarray(com0, dtype=np.float64).reshape(3))
         check(self.lib.exp_amd_comp_set_rtrunc(self.h, float(rtrunc), c0[1] if c0 else None), self.ctx.h)
         self.rtrunc = float(rtrunc)
+        self.com0 = None if com0 is None else np.asarray(com0, dtype=np.float64).reshape(3).copy()
 
     def set_level_policy(self, noswitch: bool = False, freeze_levels: bool = False, dtreset: bool = True) -> None:
         """The component keys ``noswitch``, ``freezeL``, ``dtreset`` (src/Component.cc:253-255, :1036-1038) that

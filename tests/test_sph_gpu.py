@@ -501,6 +501,49 @@ def test_append_state_acceleration_is_the_completed_steps(ctx, plummer_s6, then)
         assert coef_err(other, oref) <= 1e-13
 
 
+def test_append_step_is_the_default_from_2_to_the_20_particles(plummer_s6):
+    """A context as the library makes it -- no setter called, no environment variable: `exp_amd_step_kdk` of a single-level
+    spherical component of 3e6 particles leaves the sort passes out from its third step on (the APPEND form, on by default from
+    2^20 particles), and the run agrees with the same run under exp_amd_ctx_set_append_min(0): every particle there once,
+    coefficients to 1e-12, positions to 1e-11, with a download (the way back to an ordinary store) in the middle."""
+    if os.environ.get("EXP_AMD_APPEND_MIN") or os.environ.get("EXP_AMD_APPEND_LEAN"):
+        pytest.skip("the defaults are overridden by the environment")
+    from exp_amd.runtime import Component, Context, SphereSL
+    model, g = plummer_s6
+    n = 3_000_000
+    m, pos, vel = _particles(model, n, seed=47)
+
+    def run(off):
+        cx = Context(0)
+        if off:
+            cx.set_append_min(0)
+        f = SphereSL(cx, g)
+        c = Component.from_arrays(cx, m, pos, vel)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        sorts = []
+        for k in range(6):
+            cx.profile(True); cx.profile_reset()
+            f.step_kdk(c, 0.005)
+            sorts.append(bool(cx.profile_report().get("k_scatter_adv", {}).get("launches", 0)))
+            cx.profile(False)
+            if k == 3:
+                mid = c.download(("pos", "mass"))
+        out = c.download()
+        cf = f.get_coefs()
+        c.close(); f.close(); cx.close()
+        return out, cf, mid, sorts
+
+    ref, cref, mref, s0 = run(True)
+    out, cf, mid, s1 = run(False)
+    assert all(s0)                                         # the ordinary step sorts every step
+    assert s1[:2] == [True, True] and s1[2:4] == [False, False]      # entry at the second step; no sort passes afterwards
+    assert coef_err(cf, cref) <= 1e-12
+    assert np.array_equal(out["mass"], ref["mass"]) and np.array_equal(mid["mass"], mref["mass"])
+    assert np.abs(mid["pos"] - mref["pos"]).max() <= 1e-11 * (1.0 + np.abs(mref["pos"]).max())
+    assert np.abs(out["pos"] - ref["pos"]).max() <= 1e-11 * (1.0 + np.abs(ref["pos"]).max())
+    assert acc_err(out["acc"], ref["acc"]) <= 1e-8
+
+
 def test_split_fused_step_matches_the_unfused_sequence(ctx, oracle, plummer_s6):
     """The split fused step (two independently sorted halves, sort passes on a second stream
     overlapping accumulate / force) against the call-for-call step: same trajectory up to the order
