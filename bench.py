@@ -109,6 +109,8 @@ def parse_args():
                     help="the ordinary fused step (key histogram, scan, scatter pass every step) instead of the APPEND form, in "
                          "which the force pass places every particle in the next step's cell order itself "
                          "(exp_amd_ctx_set_append_min; profiles/r06_append_ab.txt)")
+    ap.add_argument("--no-lean-ab", action="store_true",
+                    help="skip the extra K-step region with the append step's lean payload reported as `append_lean_ab`")
     ap.add_argument("--append-lean", action="store_true",
                     help="A/B: the append step with the LEAN payload (exp_amd_ctx_set_append_lean: the placing pass stores neither "
                          "acceleration nor potential; they are re-evaluated for the first call that looks at the particles -- here the "
@@ -929,6 +931,30 @@ def main():
         es = reduce_max(time.perf_counter() - t1)
         sustained = {"steps": ns, "seconds": es, "ms_per_step": 1e3 * es / ns, "value": ntot * ns / es}
 
+    # The same K steps once more with the append step's LEAN payload (exp_amd_ctx_set_append_lean: acceleration and potential not
+    # placed, re-evaluated for the first call that looks) -- reported beside the line, never as `value`; then back to the full
+    # payload, so that the state checked below is the default step's.
+    lean_ab = None
+    # (skipped with --no-sustained as well: the profiling tools and the counter passes of this file measure the default step alone)
+    if step_form == "append" and not args.append_lean and not args.no_lean_ab and not args.no_sustained and not args.graph:
+        ctx.set_append_lean(True)
+        for _ in range(3):
+            force.step_kdk(comp, args.dt)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            force.step_kdk(comp, args.dt)
+        barrier()
+        e2 = reduce_max(time.perf_counter() - t2)
+        ctx.set_append_lean(False)
+        for _ in range(2):
+            force.step_kdk(comp, args.dt)
+        barrier()
+        lean_ab = {"steps": args.steps, "ms_per_step": 1e3 * e2 / args.steps, "value": ntot * args.steps / e2,
+                   "what": "the K steps again with exp_amd_ctx_set_append_lean(1): the placing pass stores neither acceleration "
+                           "nor potential (32 of 88 B a particle), which the first call that looks at the particles has "
+                           "re-evaluated from the coefficient set kept at the completed step; opt-in, not the default, not `value`"}
+
     # Full-size sanity of what was just timed (size-independent properties, no oracle): every
     # particle is inside the expansion window by construction, a self-gravitating system's
     # total force vanishes (sum m a: here up to the expansion's truncation), its centre of mass
@@ -1081,6 +1107,7 @@ def main():
             "cpu_baseline": cpu,
             "selfcheck": selfcheck,
             "sustained": sustained,
+            "append_lean_ab": lean_ab,
             "other_configs": others,
         }
         _flush_c_stdio()        # the JSON line is the last thing on stdout
