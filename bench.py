@@ -1041,6 +1041,17 @@ def main():
                 roof["kernel_own_bytes_per_particle"] = ownb
                 roof["kernel_own_achieved"] = own
                 roof["kernel_own_frac"] = own / HBM_PEAK_GBS
+                if traffic:
+                    # the counters against what THIS kernel has to move: the figure that says whether anything is re-read
+                    roof["traffic_over_own_bytes"] = traffic / (ownb * nloc)
+                    if step_form == "append":
+                        roof["traffic_note"] = (
+                            "append form: this kernel is the contract's pass B (104 B) AND pass A's advance and the reorder -- it "
+                            "reads x, v, id (52 B) and writes the next position, the velocities, acceleration, potential, id and the "
+                            f"source slot ({ownb - 52:.0f} B): {ownb:.0f} B of its own.  traffic / own = "
+                            f"{traffic / (ownb * nloc):.2f} (nothing is re-read); `traffic_over_algorithmic` holds the counters against "
+                            "pass B's 104 B alone, and `achieved` / `frac` stay on those 104 B although the kernel now does more per "
+                            "launch -- the step's fraction (`step_frac`, 232 B a particle-step) is the one that rose with this form")
             # The binding limit of this kernel is the fp64 vector ALU: executed
             # flops per particle from the ISA (tools/isa_count.py).
             fl = EXEC_FLOPS.get((dom, args.lmax))
