@@ -131,3 +131,37 @@ def test_sharded_two_component_run_reproduces_the_single_rank_run(tmp_path, over
     # (the sphere's used count is this rank's; the cylinder's rides the all-reduce with its in-cut mass)
     assert int(two[0]["used_h"]) + int(two[1]["used_h"]) == int(one["used_h"])
     assert int(two[0]["used_d"]) in (int(one["used_d"]), int(one["used_d"]) - int(two[1]["used_d"]))
+
+
+def test_append_step_over_two_ranks(tmp_path):
+    """The APPEND form of the fused step with the particles sharded over two ranks: every rank issues ONE
+    all-reduce per step whatever form its own step takes -- also a rank whose placing pass runs out of room and redoes the
+    force pass from its source (rank 0 of the "mixed" run: regions without slack; rank 1: append with slack and the lean
+    payload) -- and the sharded runs reproduce the single-rank ordinary run."""
+    port = 29900 + (os.getpid() % 90)
+
+    def run(world, mode):
+        outs = [str(tmp_path / f"app_{mode}_w{world}_r{r}.npz") for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_append_worker.py"), str(r), str(world),
+                                   str(port), outs[r], mode], cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=600)[0] for p in procs]
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-3000:]
+        return [np.load(o) for o in outs]
+
+    (one,) = run(1, "off")
+    assert not one["nosort"].any()
+    scale = np.abs(one["coef"]).max()
+    for mode in ("app", "mixed"):
+        two = run(2, mode)
+        assert two[0]["n1"] == two[1]["n0"] and two[1]["n1"] == one["n1"]
+        assert int(two[0]["used"]) + int(two[1]["used"]) == int(one["used"])
+        # the mode was on where it can hold (with slack); one all-reduce per accumulation on every rank: the first one + nine steps
+        assert two[1]["nosort"][3:].all() and (mode == "mixed" or two[0]["nosort"][3:].all())
+        assert int(two[0]["calls"]) == int(two[1]["calls"]) == 10
+        for r in two:
+            assert np.abs(r["coef"] - one["coef"]).max() <= 1e-10 * scale
+        for k, tol in (("pos", 1e-10), ("vel", 1e-9), ("acc", 1e-8), ("pot", 1e-9)):
+            both = np.concatenate([two[0][k], two[1][k]])
+            assert np.abs(both - one[k]).max() <= tol * np.abs(one[k]).max(), (mode, k)
