@@ -53,6 +53,8 @@ typedef struct exp_amd_force exp_amd_force;  /* one force method (sphereSL/cylin
  *   EXP_AMD_POISON=1        (every device allocation) fresh device memory reads as NaN patterns (tests/test_poison_gpu.py);
  *   EXP_AMD_APPEND_MIN=n    (exp_amd_ctx_create) the default of exp_amd_ctx_set_append_min (tests/test_sph_gpu.py).
  *   EXP_AMD_APPEND_LEAN=1   (exp_amd_ctx_create) the default of exp_amd_ctx_set_append_lean.
+ *   EXP_AMD_APP_DEBUG=1     (every append step) one line on stderr: particles the placing pass sent to the tail region, particles
+ *                           that found no room (the step is then redone from its source).
  * The tuning and A/B switches of the development rounds (tile sizes, launch reductions that can be undone, ...) are
  * compile-time constants of the default build; `make EXPERIMENTAL=1` (-DEXP_AMD_EXPERIMENTAL) turns each
  * EXPAMD_EXPT("NAME", default) of exp_amd/csrc/ back into an environment variable for A/B runs.                       */
