@@ -1298,7 +1298,8 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   HIP_TRY(ctx, hipGetLastError());
   uint32_t lost = 0;
   if ((rc = expamd_comp_app_finish(c, dst, &lost))) return rc;
-  if (getenv("EXP_AMD_APP_DEBUG")) fprintf(stderr, "append step: %u particles in the tail, %u without room\n", c->app_tail_used, lost);
+  static const bool app_debug = getenv("EXP_AMD_APP_DEBUG") != nullptr;
+  if (app_debug) fprintf(stderr, "append step: %u particles in the tail, %u without room\n", c->app_tail_used, lost);
   if (lost) {
     // no room (a region and the tail full): the source set is intact and holds this step's advanced positions and
     // velocities -- an ordinary store again, and exp_amd_step_kdk finishes the step the ordinary way (no advance)
