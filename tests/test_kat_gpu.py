@@ -11,6 +11,7 @@ to answers neither implementation produced:
 * at the HEADLINE size (1e8 particles, lmax 10, nmax 24, numr 2000: BASELINE config 5): linearity of the
   accumulation, invariance to particle order, the used count, and Newton's theorem."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -188,6 +189,67 @@ def test_headline_size_properties(ctx):
     assert np.abs(cf[0, 1:]).max() < 2e-3 * abs(cf[0, 0])
     c.close()
     f.close()
+
+
+def test_headline_step_forms_agree_at_full_size(ctx):
+    """BASELINE config 5 at its full size on one GPU, STEPPED: five `exp_amd_step_kdk` of 1e8 truncated-NFW particles
+    (SphericalSL lmax 10, nmax 24, numr 2000) in the three forms of the fused step -- ordinary (key histogram, scan, scatter
+    every step), APPEND (the default at this size: the force pass places every particle in the next step's cell order) and
+    append with the lean payload -- must leave the same system behind.  Size-independent properties, no oracle, nothing
+    but twenty numbers per run visits the host:
+      * every particle is still there, once: the used count of the last accumulation and the total mass (a particle lost or
+        placed twice moves the sum of 1e8 equal masses by 1e-8: bar 1e-12) agree with the ordinary run's;
+      * the coefficient sets agree to 1e-11 of their largest entry, the centres of mass and velocity to 1e-12;
+      * the sums of `OutLog` over the STATE the forms leave -- kinetic and potential energy, the Clausius virial, angular
+        momentum (positions, velocities, accelerations and potentials of every particle: for the lean payload the
+        re-evaluated ones) -- agree to 1e-10;
+      * the append runs really ran without sort passes (per-kernel launch counts)."""
+    import torch
+    from bench import make_halo
+    from exp_amd.models import NFWModel
+    from exp_amd.runtime import Component, SphereSL
+    from exp_amd.slgrid import build_slgrid
+    if os.environ.get("EXP_AMD_APPEND_MIN") or os.environ.get("EXP_AMD_APPEND_LEAN"):
+        pytest.skip("the forms are chosen by the environment")
+    model = NFWModel(1.0, 20.0, 6.0, 1e-3, 50.0)
+    g = build_slgrid(model, 10, 24, numr=2000, rmin=1e-3, rmax=49.5, cmap=1, rmap=1.0)
+    n = 100_000_000
+    dev = torch.device("cuda:0")
+    x, y, z, vx, vy, vz = make_halo(model, n, 23456, dev)
+    mass = torch.full((n,), 1.0 / n, device=dev, dtype=torch.float64)
+
+    def run(append_min, lean):
+        ctx.set_append_min(append_min)
+        ctx.set_append_lean(lean)
+        f = SphereSL(ctx, g)
+        c = Component(ctx, n)
+        c.upload_device(mass, x, y, z, vx, vy, vz)
+        f.determine_coefficients(c); c.zero_acceleration(0); f.get_acceleration_and_potential(c)
+        sorts = []
+        for _ in range(5):
+            ctx.profile(True); ctx.profile_reset()
+            f.step_kdk(c, 0.002)
+            sorts.append(bool(ctx.profile_report().get("k_scatter_adv", {}).get("launches", 0)))
+            ctx.profile(False)
+        out = {"coef": f.get_coefs(), "used": f.Used(), "fix": c.fix_positions(0), "log": c.log_sums(), "sorts": sorts}
+        c.close(); f.close()
+        ctx.set_append_min(0); ctx.set_append_lean(False)
+        return out
+
+    ref = run(0, False)
+    assert all(ref["sorts"]) and ref["log"]["nbodies"] == n
+    big = np.abs(ref["coef"]).max()
+    for form in (run(1 << 20, False), run(1 << 20, True)):
+        assert form["sorts"] == [True, True, False, False, False]       # entry at the second step, then no sort passes
+        assert form["used"] == ref["used"] and form["log"]["nbodies"] == n
+        assert form["fix"]["mtot"] == pytest.approx(ref["fix"]["mtot"], rel=1e-12)
+        assert np.abs(form["coef"] - ref["coef"]).max() <= 1e-11 * big
+        for k in ("com", "cov"):
+            assert np.abs(form["fix"][k] - ref["fix"][k]).max() <= 1e-12
+        assert np.abs(form["fix"]["coa"] - ref["fix"]["coa"]).max() <= 1e-10 * max(1.0, np.abs(ref["log"]["eptot"]))
+        for k in ("ektot", "eptot", "clausius"):
+            assert form["log"][k] == pytest.approx(ref["log"][k], rel=1e-10), k
+        assert np.abs(form["log"]["angm"] - ref["log"]["angm"]).max() <= 1e-10 * max(np.abs(ref["log"]["angm"]).max(), 1e-6)
 
 
 def test_cylinder_poisson_consistency_through_getbasis(ctx, tmp_path):
