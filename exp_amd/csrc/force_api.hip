@@ -314,16 +314,8 @@ extern "C" int exp_amd_step_kdk(exp_amd_force *f, exp_amd_comp *c, double dt)
     if ((rc = f->fused_step_split(c, dt, have_keys && c->prekey_split, &handled))) return rc;
     if (handled) return EXP_AMD_OK;
   }
-  // (app_redo: an append step ran out of room and left an ordinary store that holds this step's advanced state)
-  const bool redo = c->app_redo;
-  c->app_redo = false;
-  const bool have_keys_whole = have_keys && !c->prekey_split && !redo && c->prekey_owner == (const void *)f && c->sorted_for == (const void *)f;
-  if (redo) {
-    // the coefficient set of this step is in place, summed over the ranks and projected: the append pass accumulated the
-    // (complete) source set before it ran out of room placing.  Only the force pass is redone, on the store as the way back
-    // left it (any order: the evaluation of particles that are not in this basis' cell order).  Accumulating again would be
-    // one all-reduce more than the other ranks of a sharded run issue for this step.
-  } else if (c->n == 0) {
+  const bool have_keys_whole = have_keys && !c->prekey_split && c->prekey_owner == (const void *)f && c->sorted_for == (const void *)f;
+  if (c->n == 0) {
     if ((rc = f->determine_coefficients(c, false, 0.0, 0.0))) return rc;
   } else if ((rc = f->determine_coefficients(c, true, 0.5 * dt, dt, have_keys_whole))) return rc;
   bool done = false;

@@ -153,7 +153,12 @@ struct exp_amd_comp {
   DevBuf<uint32_t> app_base[2];         // [ncell + 2] per buffer set
   DevBuf<uint32_t> app_range[2];        // {0, end of the tail}: plays lev_off for the passes over an appended set
   DevBuf<uint32_t> app_cursor;          // [ncell + 1] + flag word
-  bool app_redo = false;                // a step whose append pass ran out of room is being redone from its (advanced) source
+  // A placing pass says at its end whether every particle found room (a flag word behind the cursors): copied to page-locked
+  // words behind an event the step waits for (a pageable copy and a stream-wide wait cost an eight-GPU share of 1.25e7
+  // particles 3 % of its step).  A pass that ran out of room is put right by its owner (sph.hip: sph_app_recover -- the source
+  // set, which no pass writes, made an ordinary store, the force pass redone on it).
+  uint32_t *app_hflag = nullptr;        // page-locked: {arrivals in the tail, particles without room} of the last placing pass
+  hipEvent_t app_ev = nullptr;
   // The placing pass does not store the acceleration and the potential (32 of 88 bytes a particle that no pass of the next
   // step reads): while app_acc_stale, AX / AY / AZ / POT of the live set are not the state's.  expamd_comp_densify has the
   // owner re-evaluate them at the positions of the completed step, from the coefficient set of that step (sph.hip:
@@ -185,7 +190,7 @@ void expamd_app_unlist(exp_amd_comp *c);          // off its context's `appended
 // the layout of the NEXT buffer set from the populations in `counts` (ncell values), cursors cleared
 int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t ncell, int set, uint32_t *also_into);
 // after an append pass into buffer set `set`: empty slots marked, the next layout's populations are the cursors
-int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag);
+int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *lost);
 // ... after the ORDINARY scatter pass filled a set's regions (its running offsets `offs` are base + population)
 void k_app_mark_launch(exp_amd_comp *c, int set, const uint32_t *offs);
 

@@ -519,6 +519,11 @@ k_app_densify(const double *__restrict__ X, const uint32_t *__restrict__ range, 
 int expamd_comp_app_reserve(exp_amd_comp *c, size_t cap)
 {
   exp_amd_ctx *ctx = c->ctx;
+  if (!c->app_hflag) {
+    HIP_TRY(ctx, hipHostMalloc((void **)&c->app_hflag, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    c->app_hflag[0] = c->app_hflag[1] = 0u;
+  }
+  if (!c->app_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&c->app_ev, hipEventDisableTiming));
   if (c->app_cap >= cap) return EXP_AMD_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   {
@@ -571,18 +576,19 @@ int expamd_comp_app_layout(exp_amd_comp *c, const uint32_t *counts, uint32_t nce
   return EXP_AMD_OK;
 }
 
-int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *host_flag)
+int expamd_comp_app_finish(exp_amd_comp *c, int set, uint32_t *lost)
 {
   exp_amd_ctx *ctx = c->ctx;
   k_app_mark<<<c->app_ncell + APP_MARK_TAIL, 256, 0, ctx->stream>>>(c->app_base[set].p, c->app_cursor.p, 0, c->app_ncell, c->arr[set][A_X].p);
   HIP_TRY(ctx, hipGetLastError());
-  if (host_flag) {
-    uint32_t two[2] = {0u, 0u};          // arrivals in the tail, particles that found no room at all
-    HIP_TRY(ctx, hipMemcpyAsync(two, c->app_cursor.p + c->app_ncell, sizeof(two), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *host_flag = two[1];
-    c->app_tail_used = two[0];
-  }
+  // {arrivals in the tail, particles that found no room at all}: to the page-locked words, behind an event (particles.h)
+  HIP_TRY(ctx, hipMemcpyAsync(c->app_hflag, c->app_cursor.p + c->app_ncell, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(c->app_ev, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(c->app_ev));
+  c->app_tail_used = c->app_hflag[0];
+  *lost = c->app_hflag[1];
+  static const bool app_debug = getenv("EXP_AMD_APP_DEBUG") != nullptr;
+  if (app_debug) fprintf(stderr, "append step: %u particles in the tail, %u without room\n", c->app_tail_used, *lost);
   return EXP_AMD_OK;
 }
 
@@ -1158,6 +1164,8 @@ extern "C" void exp_amd_comp_destroy(exp_amd_comp *c)
     c->app_range[w].release();
   }
   c->app_cursor.release();
+  if (c->app_ev) { (void)hipEventDestroy(c->app_ev); c->app_ev = nullptr; }
+  if (c->app_hflag) { (void)hipHostFree(c->app_hflag); c->app_hflag = nullptr; }
   c->d_frz.release();
   c->d_escaped.release();
   c->d_dtreq.release();

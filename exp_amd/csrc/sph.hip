@@ -1149,42 +1149,83 @@ int SphForce::accelerate(exp_amd_comp *t, int external, bool assign, double dt_k
 // cursors).  A pass that runs out of room (a region AND the tail full: a flag, read back after every step) is redone the
 // ordinary way from its source set, which no pass writes.  Any other call on the component turns the store back into an
 // ordinary one first (expamd_comp_densify).  Trajectories: those of the ordinary fused step up to the order of the sums.
-// The state's acceleration and potential after append steps.  The placing pass stores neither (AppDev): when the store has
-// been turned back into an ordinary one -- positions of the completed step n, velocities ahead by the next opening half-kick
-// -- they are evaluated here, once, with what step n's pass evaluated them with: the coefficient set kept at that step, the
-// centre of that step, none of the options under which the mode is not offered.  Bits: those of the staged evaluation
+// The frame of the last placing pass, put back for an evaluation on its behalf (the state's acceleration and potential the lean
+// payload leaves out; the redo of a pass that ran out of room): the coefficient set KEPT at that step (d_coef_app, a 23 KB copy
+// per step) in place of whatever the force holds by now, the centre of that step, none of the options under which the mode is
+// not offered.  sph_app_frame_end puts everything back.
+struct SphAppFrame {
+  double ctr[3];
+  bool frz, noise, fix0, used_open;
+  PseudoDev ps;
+};
+
+static int sph_app_frame_begin(SphForce *f, exp_amd_comp *c, SphAppFrame &F)
+{
+  exp_amd_ctx *ctx = f->ctx;
+  if (f->d_coef_app.n < 2 * f->ncoef) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "appended store: no coefficient set kept");
+  const size_t nb = f->ncoef * sizeof(double);
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p + f->ncoef, f->d_coef.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+  f->proj_dirty = true;
+  for (int k = 0; k < 3; k++) { F.ctr[k] = c->center[k]; c->center[k] = c->app_center[k]; }
+  F.frz = c->freeze_on; F.noise = f->noise_on; F.fix0 = f->fix_l0; F.used_open = f->used_open; F.ps = c->pseudo;
+  c->freeze_on = false;
+  c->pseudo.center = c->pseudo.axis = 0;
+  f->noise_on = false;
+  f->fix_l0 = false;
+  return EXP_AMD_OK;
+}
+
+static int sph_app_frame_end(SphForce *f, exp_amd_comp *c, const SphAppFrame &F, int rc)
+{
+  exp_amd_ctx *ctx = f->ctx;
+  c->freeze_on = F.frz;
+  c->pseudo = F.ps;
+  f->noise_on = F.noise;
+  f->fix_l0 = F.fix0;
+  f->used_open = F.used_open;
+  for (int k = 0; k < 3; k++) c->center[k] = F.ctr[k];
+  if (hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p + f->ncoef, f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess && !rc)
+    rc = expamd_fail(ctx, EXP_AMD_ERR_HIP, "appended store: restoring the coefficient set failed");
+  f->proj_dirty = true;
+  return rc;
+}
+
+// The state's acceleration and potential after append steps with the LEAN payload.  The placing pass stores neither (AppDev):
+// when the store has been turned back into an ordinary one -- positions of the completed step n, velocities ahead by the next
+// opening half-kick -- they are evaluated here, once, in the frame of that step.  Bits: those of the staged evaluation
 // (k_sph_force_staged: the fast pass' arithmetic) -- a particle the in-step pass took through its general pass may differ
 // from the value its kick used in the last place or two, which is what the order of the coefficient sums does to it anyway.
 static int sph_app_reeval(void *owner, exp_amd_comp *c)
 {
   SphForce *f = static_cast<SphForce *>(owner);
-  exp_amd_ctx *ctx = f->ctx;
   if (!c->n) return EXP_AMD_OK;
-  if (f->d_coef_app.n < 2 * f->ncoef) return expamd_fail(ctx, EXP_AMD_ERR_STATE, "appended store: no coefficient set kept");
-  hipStream_t st = ctx->stream;
-  const size_t nb = f->ncoef * sizeof(double);
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p + f->ncoef, f->d_coef.p, nb, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p, nb, hipMemcpyDeviceToDevice, st));
-  f->proj_dirty = true;
-  double ctr[3];
-  for (int k = 0; k < 3; k++) { ctr[k] = c->center[k]; c->center[k] = c->app_center[k]; }
-  const bool frz = c->freeze_on, noise = f->noise_on, fix0 = f->fix_l0, used_open = f->used_open;
-  const auto ps = c->pseudo;
-  c->freeze_on = false;
-  c->pseudo.center = c->pseudo.axis = 0;
-  f->noise_on = false;
-  f->fix_l0 = false;
-  int rc = f->accelerate(c, 0, /*assign=*/true, 0.0, 0.0, 0.0, nullptr, false);
-  c->freeze_on = frz;
-  c->pseudo = ps;
-  f->noise_on = noise;
-  f->fix_l0 = fix0;
-  f->used_open = used_open;
-  for (int k = 0; k < 3; k++) c->center[k] = ctr[k];
-  if (hipMemcpyAsync(f->d_coef.p, f->d_coef_app.p + f->ncoef, nb, hipMemcpyDeviceToDevice, st) != hipSuccess && !rc)
-    rc = expamd_fail(ctx, EXP_AMD_ERR_HIP, "appended store: restoring the coefficient set failed");
-  f->proj_dirty = true;
-  return rc;
+  SphAppFrame F;
+  int rc = sph_app_frame_begin(f, c, F);
+  if (rc) return rc;
+  rc = f->accelerate(c, 0, /*assign=*/true, 0.0, 0.0, 0.0, nullptr, false);
+  return sph_app_frame_end(f, c, F, rc);
+}
+
+// A placing pass ran out of room (a region AND the tail full: exp_amd_comp::app_hflag): its source set is intact and holds the step's advanced positions and the velocities with its opening
+// half-kick; the coefficient set of the step is in place, summed over the ranks and projected.  The source set is made an
+// ordinary store and the force pass -- that alone -- is redone on it, with the frame of that step: the state after it is the
+// completed step's, as the ordinary fused step leaves it (closing half-kick deferred).  No collective: the ranks that had room
+// issue none for this either.
+static int sph_app_recover(SphForce *f, exp_amd_comp *c)
+{
+  const double dt = c->app_dt;
+  int rc;
+  c->cur = 1 - c->cur;                 // (back on the source set of the pass)
+  c->pending_kick = 0.0;
+  c->app_acc_stale = false;
+  if ((rc = expamd_comp_densify(c, /*state_positions=*/false))) return rc;
+  SphAppFrame F;
+  if ((rc = sph_app_frame_begin(f, c, F))) return rc;
+  bool done = false;
+  rc = f->accelerate(c, 0, true, 0.5 * dt, 0.5 * dt, dt, &done, /*defer_kick=*/c->n > 0);
+  f->firstime_coef = false;
+  return sph_app_frame_end(f, c, F, rc);
 }
 
 int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool *handled)
@@ -1258,10 +1299,10 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   // the lean payload (exp_amd_ctx_set_append_lean): the pass places neither acceleration nor potential, and the set they come
   // from is kept -- whatever happens to d_coef before someone asks for them (sph_app_reeval)
   const bool lean = ctx->append_lean;
-  if (lean) {
-    if (f->d_coef_app.n < 2 * f->ncoef) HIP_TRY(ctx, f->d_coef_app.alloc(2 * f->ncoef));
-    HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p, f->d_coef.p, f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, st));
-  }
+  // (the set this step's pass evaluates with is kept, whatever happens to d_coef before someone acts on the pass' behalf:
+  // sph_app_frame_begin)
+  if (f->d_coef_app.n < 2 * f->ncoef) HIP_TRY(ctx, f->d_coef_app.alloc(2 * f->ncoef));
+  HIP_TRY(ctx, hipMemcpyAsync(f->d_coef_app.p, f->d_coef.p, f->ncoef * sizeof(double), hipMemcpyDeviceToDevice, st));
   f->proj_dirty = true;
   if ((rc = sph_project(f))) return rc;
   f->used_open = false;
@@ -1297,17 +1338,7 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   }
   HIP_TRY(ctx, hipGetLastError());
   uint32_t lost = 0;
-  if ((rc = expamd_comp_app_finish(c, dst, &lost))) return rc;
-  static const bool app_debug = getenv("EXP_AMD_APP_DEBUG") != nullptr;
-  if (app_debug) fprintf(stderr, "append step: %u particles in the tail, %u without room\n", c->app_tail_used, lost);
-  if (lost) {
-    // no room (a region and the tail full): the source set is intact and holds this step's advanced positions and
-    // velocities -- an ordinary store again, and exp_amd_step_kdk finishes the step the ordinary way (no advance)
-    c->pending_kick = 0.0;
-    if ((rc = expamd_comp_densify(c, /*state_positions=*/false))) return rc;
-    c->app_redo = true;
-    return EXP_AMD_OK;
-  }
+  if ((rc = expamd_comp_app_finish(c, dst, &lost))) return rc;  // (empty slots marked; did every particle find room?)
   c->cur = dst;
   c->app_run++;
   c->acc_live = true;
@@ -1316,6 +1347,8 @@ int SphForce::fused_step_append(exp_amd_comp *c, double dt, bool have_keys, bool
   c->prekey_valid = false;
   f->firstime_coef = false;
   *handled = true;
+  // no room (a region and the tail full): the step is put right from its source set (complete either way: handled)
+  if (lost) return sph_app_recover(f, c);
   return EXP_AMD_OK;
 }
 
