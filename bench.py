@@ -919,7 +919,9 @@ def main():
     # contract asks for; this shows that the rate holds when the region is not a quarter of a second.
     sustained = None
     if not args.no_sustained:
-        ns = max(args.steps, int(math.ceil(2.0 / max(el / args.steps, 1e-6))))
+        # (the step count from the SLOWEST rank's region: every rank must run the same number of steps -- each carries an
+        # all-reduce --, and a count formed from a rank's own clock differs between ranks by a step or two)
+        ns = max(args.steps, int(math.ceil(2.0 / max(reduce_max(el) / args.steps, 1e-6))))
         barrier()
         t1 = time.perf_counter()
         if args.graph:

@@ -107,6 +107,22 @@ def test_two_ranks_through_torchrun_graph(one_rank):
     _check_two(line, one_rank, graph=True)
 
 
+def test_two_ranks_the_driver_s_spelling_with_every_region():
+    """The scaling command as the driver spells it -- `--gpus N --steps K --warmup W` and nothing else that switches a region
+    off -- on two ranks with shards above 2^20 particles: the append form of the fused step over the all-reduce callback, the
+    `sustained` region (whose step count must be the SAME on every rank: each step carries an all-reduce -- formed from a
+    rank's own clock it differed between the ranks and the run never came back) and the lean A/B region."""
+    port = 31000 + (os.getpid() % 300)
+    line, _ = _bench(["--nbodies", "2.4e6", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-other-configs",
+                      "--rehearse-shared-gpu"], world=2, port=port, timeout=600)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["nbodies_per_gpu"] == 1200000 and cfg["comm"]["nranks"] == 2
+    assert cfg["step_form"] == "append" and cfg["append_payload"] == "full"
+    assert line["sustained"]["steps"] >= 3 and line["sustained"]["seconds"] > 0.5
+    assert line["append_lean_ab"]["steps"] == 3 and line["append_lean_ab"]["ms_per_step"] > 0
+    assert line["selfcheck"]["mtot"] == pytest.approx(1.0, rel=1e-12)
+
+
 def test_weak_scaling_flag_two_ranks():
     port = 30300 + (os.getpid() % 300)
     line, _ = _bench(["--nbodies", "2e5", "--scaling", "weak", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
