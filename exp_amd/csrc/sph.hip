@@ -1207,7 +1207,8 @@ static int sph_app_reeval(void *owner, exp_amd_comp *c)
   return sph_app_frame_end(f, c, F, rc);
 }
 
-// A placing pass ran out of room (a region AND the tail full: exp_amd_comp::app_hflag): its source set is intact and holds the step's advanced positions and the velocities with its opening
+// A placing pass ran out of room (a region AND the tail full: exp_amd_comp::app_hflag): its source set is intact and holds the
+// step's advanced positions and the velocities with its opening
 // half-kick; the coefficient set of the step is in place, summed over the ranks and projected.  The source set is made an
 // ordinary store and the force pass -- that alone -- is redone on it, with the frame of that step: the state after it is the
 // completed step's, as the ordinary fused step leaves it (closing half-kick deferred).  No collective: the ranks that had room
